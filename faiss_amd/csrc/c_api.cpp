@@ -1,0 +1,377 @@
+// faiss_amd/csrc/c_api.cpp -- extern "C" boundary (include/faiss_amd_c.h).
+// Error convention mirrors the reference C API (c_api/macros_impl.h:22-56, c_api/error_impl.cpp).
+#include "../../include/faiss_amd_c.h"
+#include <cstring>
+#include <exception>
+#include <memory>
+#include <string>
+#include "index.h"
+
+using namespace faiss_amd;
+
+static thread_local std::string g_last_error;
+
+#define FA_TRY try {
+#define FA_CATCH                                   \
+    }                                              \
+    catch (FaissAmdException & e) {                \
+        g_last_error = e.what();                   \
+        return -2;                                 \
+    }                                              \
+    catch (std::exception & e) {                   \
+        g_last_error = e.what();                   \
+        return -4;                                 \
+    }                                              \
+    catch (...) {                                  \
+        g_last_error = "Unknown error";            \
+        return -1;                                 \
+    }                                              \
+    return 0;
+
+struct FaissAmdGpuResources_H {
+    std::shared_ptr<GpuResources> res;
+};
+struct FaissAmdIndex_H {
+    Index* index;
+    std::shared_ptr<GpuResources> res; // keeps the resources alive as long as the index
+};
+
+static Index* I(FaissAmdIndex* h) {
+    if (!h || !h->index) FA_THROW_MSG("null index handle");
+    return h->index;
+}
+static const Index* I(const FaissAmdIndex* h) {
+    if (!h || !h->index) FA_THROW_MSG("null index handle");
+    return h->index;
+}
+template <typename T>
+static T* as(FaissAmdIndex* h, const char* what) {
+    T* t = dynamic_cast<T*>(I(h));
+    if (!t) FA_THROW_MSG(std::string("index is not a ") + what);
+    return t;
+}
+template <typename T>
+static const T* as(const FaissAmdIndex* h, const char* what) {
+    const T* t = dynamic_cast<const T*>(I(h));
+    if (!t) FA_THROW_MSG(std::string("index is not a ") + what);
+    return t;
+}
+static std::shared_ptr<GpuResources> R(FaissAmdGpuResources* r) {
+    if (!r || !r->res) FA_THROW_MSG("null resources handle");
+    return r->res;
+}
+
+extern "C" {
+
+const char* faiss_amd_get_last_error(void) {
+    return g_last_error.c_str();
+}
+
+int faiss_amd_get_num_gpus(int* p_output) {
+    FA_TRY
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    *p_output = n;
+    FA_CATCH
+}
+
+int faiss_amd_StandardGpuResources_new(FaissAmdGpuResources** p_res, int device) {
+    FA_TRY
+    auto* h = new FaissAmdGpuResources_H;
+    try {
+        h->res = std::make_shared<GpuResources>(device);
+    } catch (...) {
+        delete h;
+        throw;
+    }
+    *p_res = h;
+    FA_CATCH
+}
+void faiss_amd_StandardGpuResources_free(FaissAmdGpuResources* res) {
+    delete res;
+}
+int faiss_amd_StandardGpuResources_sync(FaissAmdGpuResources* res) {
+    FA_TRY
+    R(res)->set_device();
+    R(res)->sync();
+    FA_CATCH
+}
+int faiss_amd_StandardGpuResources_getDefaultStream(FaissAmdGpuResources* res, void** p_stream) {
+    FA_TRY
+    *p_stream = (void*)R(res)->stream;
+    FA_CATCH
+}
+int faiss_amd_StandardGpuResources_setTempMemory(FaissAmdGpuResources* res, size_t bytes) {
+    FA_TRY
+    FA_THROW_IF_NOT_MSG(bytes >= ((size_t)64 << 20), "temp memory must be at least 64 MiB");
+    R(res)->temp_budget_bytes = bytes;
+    FA_CATCH
+}
+
+int faiss_amd_GpuIndexFlat_new(FaissAmdIndex** p_index, FaissAmdGpuResources* res, int d,
+                               FaissAmdMetricType metric) {
+    FA_TRY
+    auto r = R(res);
+    auto* h = new FaissAmdIndex_H{nullptr, r};
+    try {
+        h->index = new GpuIndexFlat(r, d, (int)metric);
+    } catch (...) {
+        delete h;
+        throw;
+    }
+    *p_index = h;
+    FA_CATCH
+}
+int faiss_amd_GpuIndexIVFFlat_new(FaissAmdIndex** p_index, FaissAmdGpuResources* res, int d, int nlist,
+                                  FaissAmdMetricType metric) {
+    FA_TRY
+    auto r = R(res);
+    auto* h = new FaissAmdIndex_H{nullptr, r};
+    try {
+        h->index = new GpuIndexIVFFlat(r, d, nlist, (int)metric);
+    } catch (...) {
+        delete h;
+        throw;
+    }
+    *p_index = h;
+    FA_CATCH
+}
+int faiss_amd_GpuIndexIVFPQ_new(FaissAmdIndex** p_index, FaissAmdGpuResources* res, int d, int nlist, int M,
+                                int nbits, FaissAmdMetricType metric) {
+    FA_TRY
+    auto r = R(res);
+    auto* h = new FaissAmdIndex_H{nullptr, r};
+    try {
+        h->index = new GpuIndexIVFPQ(r, d, nlist, M, nbits, (int)metric);
+    } catch (...) {
+        delete h;
+        throw;
+    }
+    *p_index = h;
+    FA_CATCH
+}
+int faiss_amd_IndexShards_new(FaissAmdIndex** p_index, int d, int threaded, int successive_ids) {
+    FA_TRY
+    auto* h = new FaissAmdIndex_H{nullptr, nullptr};
+    h->index = new IndexShards(d, threaded != 0, successive_ids != 0);
+    *p_index = h;
+    FA_CATCH
+}
+int faiss_amd_IndexShards_add_shard(FaissAmdIndex* shards, FaissAmdIndex* shard) {
+    FA_TRY
+    as<IndexShards>(shards, "IndexShards")->add_shard(I(shard));
+    FA_CATCH
+}
+void faiss_amd_Index_free(FaissAmdIndex* index) {
+    if (!index) return;
+    delete index->index;
+    delete index;
+}
+
+int faiss_amd_Index_d(const FaissAmdIndex* index) {
+    return index && index->index ? index->index->d : -1;
+}
+int faiss_amd_Index_is_trained(const FaissAmdIndex* index) {
+    return index && index->index ? (int)index->index->is_trained : 0;
+}
+faiss_amd_idx_t faiss_amd_Index_ntotal(const FaissAmdIndex* index) {
+    return index && index->index ? index->index->ntotal : -1;
+}
+FaissAmdMetricType faiss_amd_Index_metric_type(const FaissAmdIndex* index) {
+    return (FaissAmdMetricType)(index && index->index ? index->index->metric_type : 1);
+}
+int faiss_amd_Index_train(FaissAmdIndex* index, faiss_amd_idx_t n, const float* x) {
+    FA_TRY
+    I(index)->train(n, x);
+    FA_CATCH
+}
+int faiss_amd_Index_add(FaissAmdIndex* index, faiss_amd_idx_t n, const float* x) {
+    FA_TRY
+    I(index)->add(n, x);
+    FA_CATCH
+}
+int faiss_amd_Index_add_with_ids(FaissAmdIndex* index, faiss_amd_idx_t n, const float* x,
+                                 const faiss_amd_idx_t* xids) {
+    FA_TRY
+    I(index)->add_with_ids(n, x, xids);
+    FA_CATCH
+}
+int faiss_amd_Index_search(const FaissAmdIndex* index, faiss_amd_idx_t n, const float* x, faiss_amd_idx_t k,
+                           float* distances, faiss_amd_idx_t* labels) {
+    FA_TRY
+    I(index)->search(n, x, k, distances, labels);
+    FA_CATCH
+}
+int faiss_amd_Index_assign(FaissAmdIndex* index, faiss_amd_idx_t n, const float* x, faiss_amd_idx_t* labels,
+                           faiss_amd_idx_t k) {
+    FA_TRY
+    I(index)->assign(n, x, labels, k);
+    FA_CATCH
+}
+int faiss_amd_Index_reset(FaissAmdIndex* index) {
+    FA_TRY
+    I(index)->reset();
+    FA_CATCH
+}
+int faiss_amd_Index_reconstruct(const FaissAmdIndex* index, faiss_amd_idx_t key, float* recons) {
+    FA_TRY
+    I(index)->reconstruct(key, recons);
+    FA_CATCH
+}
+int faiss_amd_Index_reconstruct_n(const FaissAmdIndex* index, faiss_amd_idx_t i0, faiss_amd_idx_t ni,
+                                  float* recons) {
+    FA_TRY
+    I(index)->reconstruct_n(i0, ni, recons);
+    FA_CATCH
+}
+
+int faiss_amd_IndexIVF_nlist(const FaissAmdIndex* index, int* p) {
+    FA_TRY
+    *p = as<GpuIndexIVF>(index, "GpuIndexIVF")->nlist;
+    FA_CATCH
+}
+int faiss_amd_IndexIVF_nprobe(const FaissAmdIndex* index, int* p) {
+    FA_TRY
+    *p = as<GpuIndexIVF>(index, "GpuIndexIVF")->nprobe;
+    FA_CATCH
+}
+int faiss_amd_IndexIVF_set_nprobe(FaissAmdIndex* index, int nprobe) {
+    FA_TRY
+    FA_THROW_IF_NOT_MSG(nprobe >= 1 && nprobe <= kMaxSelectionK, "nprobe must be in [1, 2048]");
+    as<GpuIndexIVF>(index, "GpuIndexIVF")->nprobe = nprobe;
+    FA_CATCH
+}
+int faiss_amd_IndexIVF_get_list_size(const FaissAmdIndex* index, faiss_amd_idx_t list_no, size_t* p_size) {
+    FA_TRY
+    auto* ivf = as<GpuIndexIVF>(index, "GpuIndexIVF");
+    FA_THROW_IF_NOT_MSG(list_no >= 0 && list_no < ivf->nlist, "list out of range");
+    *p_size = ivf->getListLength(list_no);
+    FA_CATCH
+}
+int faiss_amd_IndexIVF_get_list_ids(const FaissAmdIndex* index, faiss_amd_idx_t list_no,
+                                    faiss_amd_idx_t* ids_out) {
+    FA_TRY
+    auto v = as<GpuIndexIVF>(index, "GpuIndexIVF")->getListIndices(list_no);
+    if (!v.empty()) memcpy(ids_out, v.data(), v.size() * sizeof(idx_t));
+    FA_CATCH
+}
+int faiss_amd_IndexIVF_get_list_codes(const FaissAmdIndex* index, faiss_amd_idx_t list_no, uint8_t* out) {
+    FA_TRY
+    auto v = as<GpuIndexIVF>(index, "GpuIndexIVF")->getListVectorData(list_no);
+    if (!v.empty()) memcpy(out, v.data(), v.size());
+    FA_CATCH
+}
+int faiss_amd_IndexIVF_code_size(const FaissAmdIndex* index, size_t* p) {
+    FA_TRY
+    auto* ivf = as<GpuIndexIVF>(index, "GpuIndexIVF");
+    if (auto* pq = dynamic_cast<const GpuIndexIVFPQ*>(ivf)) *p = (size_t)pq->M;
+    else *p = (size_t)ivf->d * sizeof(float);
+    FA_CATCH
+}
+int faiss_amd_IndexIVF_get_centroids(const FaissAmdIndex* index, float* out) {
+    FA_TRY
+    auto* ivf = as<GpuIndexIVF>(index, "GpuIndexIVF");
+    FA_THROW_IF_NOT_MSG(ivf->quantizer->ntotal == ivf->nlist, "coarse quantizer not trained");
+    ivf->quantizer->reconstruct_n(0, ivf->nlist, out);
+    FA_CATCH
+}
+int faiss_amd_IndexIVF_set_clustering(FaissAmdIndex* index, int niter, int seed) {
+    FA_TRY
+    auto* ivf = as<GpuIndexIVF>(index, "GpuIndexIVF");
+    FA_THROW_IF_NOT_MSG(niter >= 1, "niter must be positive");
+    ivf->cp_niter = niter;
+    ivf->cp_seed = seed;
+    FA_CATCH
+}
+int faiss_amd_IndexIVF_copy_centroids(FaissAmdIndex* index, const float* centroids) {
+    FA_TRY
+    as<GpuIndexIVF>(index, "GpuIndexIVF")->set_centroids(centroids);
+    FA_CATCH
+}
+int faiss_amd_IndexIVFPQ_copy_pq_centroids(FaissAmdIndex* index, const float* pq) {
+    FA_TRY
+    as<GpuIndexIVFPQ>(index, "GpuIndexIVFPQ")->set_pq_centroids(pq);
+    FA_CATCH
+}
+int faiss_amd_IndexIVFPQ_get_pq_centroids(const FaissAmdIndex* index, float* pq_out) {
+    FA_TRY
+    auto v = as<GpuIndexIVFPQ>(index, "GpuIndexIVFPQ")->get_pq_centroids();
+    memcpy(pq_out, v.data(), v.size() * sizeof(float));
+    FA_CATCH
+}
+int faiss_amd_IndexIVF_copy_lists(FaissAmdIndex* index, const uint32_t* list_sizes, const uint8_t* codes,
+                                  const faiss_amd_idx_t* ids) {
+    FA_TRY
+    as<GpuIndexIVF>(index, "GpuIndexIVF")->set_lists(list_sizes, codes, ids);
+    FA_CATCH
+}
+
+int faiss_amd_kmeans_clustering(FaissAmdGpuResources* res, int d, faiss_amd_idx_t n, int k, const float* x,
+                                int niter, int seed, float* centroids_out, float* obj_out) {
+    FA_TRY
+    auto r = R(res);
+    GpuIndexFlat index(r, d, METRIC_L2);
+    Clustering clus(d, k);
+    clus.niter = niter;
+    clus.seed = seed;
+    clus.train(n, x, index);
+    memcpy(centroids_out, clus.centroids.data(), sizeof(float) * (size_t)k * d);
+    if (obj_out) memcpy(obj_out, clus.obj.data(), sizeof(float) * clus.obj.size());
+    FA_CATCH
+}
+
+int faiss_amd_merge_knn_results(FaissAmdMetricType metric, faiss_amd_idx_t n, faiss_amd_idx_t k, int nshard,
+                                const float* all_d, const faiss_amd_idx_t* all_i,
+                                const faiss_amd_idx_t* base, float* distances, faiss_amd_idx_t* labels) {
+    FA_TRY
+    FA_THROW_IF_NOT_MSG(nshard >= 1 && k >= 1 && n >= 0, "bad arguments");
+    merge_knn_results((int)metric, n, k, nshard, all_d, all_i, base, distances, labels);
+    FA_CATCH
+}
+
+int faiss_amd_profile_enable(FaissAmdGpuResources* res, int on) {
+    FA_TRY
+    R(res)->set_device();
+    R(res)->collect();
+    R(res)->profiling = on != 0;
+    FA_CATCH
+}
+int faiss_amd_profile_reset(FaissAmdGpuResources* res) {
+    FA_TRY
+    R(res)->set_device();
+    R(res)->reset_profile();
+    FA_CATCH
+}
+int faiss_amd_profile_get(FaissAmdGpuResources* res, const char* kernel_name, double* total_ms,
+                          long* launches) {
+    FA_TRY
+    auto r = R(res);
+    r->set_device();
+    r->collect();
+    auto it = r->totals.find(kernel_name);
+    if (it == r->totals.end()) {
+        *total_ms = 0.0;
+        *launches = 0;
+    } else {
+        *total_ms = it->second.first;
+        *launches = it->second.second;
+    }
+    FA_CATCH
+}
+
+int faiss_amd_GpuIndexFlat_pairwise_distances(const FaissAmdIndex* index, faiss_amd_idx_t n, const float* x,
+                                              float* out) {
+    FA_TRY
+    as<GpuIndexFlat>(index, "GpuIndexFlat")->pairwise_distances(n, x, out);
+    FA_CATCH
+}
+int faiss_amd_GpuIndexFlat_set_use_simple_kernel(FaissAmdIndex* index, int on) {
+    FA_TRY
+    as<GpuIndexFlat>(index, "GpuIndexFlat")->use_simple_kernel = on != 0;
+    FA_CATCH
+}
+
+} // extern "C"

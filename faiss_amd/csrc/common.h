@@ -1,0 +1,115 @@
+// faiss_amd/csrc/common.h -- shared host/device definitions for the MI355X (gfx950) backend.
+//
+// This backend re-implements the search path of the reference's GpuIndexFlat /
+// GpuIndexIVFFlat / GpuIndexIVFPQ (reference: faiss/gpu/GpuIndex.h:49-176,
+// faiss/Index.h:101-431) from scratch for CDNA4.  Nothing here is derived from
+// faiss/gpu sources; only the public contract (argument meaning, result layout,
+// error behaviour) is mirrored.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cfloat>
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+
+namespace faiss_amd {
+
+using idx_t = int64_t; // reference: faiss/MetricType.h:52
+
+// Same numeric values as the reference's faiss::MetricType (faiss/MetricType.h:23-28).
+enum MetricType : int {
+    METRIC_INNER_PRODUCT = 0,
+    METRIC_L2 = 1,
+};
+
+// Mirrors faiss::FaissException (faiss/impl/FaissException.h:20-43): thrown by host code,
+// translated to error code -2 at the C ABI (reference convention c_api/macros_impl.h:22-56).
+struct FaissAmdException : public std::runtime_error {
+    explicit FaissAmdException(const std::string& m) : std::runtime_error(m) {}
+};
+
+#define FA_STR2(x) #x
+#define FA_STR(x) FA_STR2(x)
+#define FA_THROW_MSG(msg)                                                          \
+    throw ::faiss_amd::FaissAmdException(                                          \
+            std::string("Error in ") + __func__ + " at " __FILE__ ":" FA_STR(      \
+                    __LINE__) ": " + (msg))
+#define FA_THROW_IF_NOT_MSG(cond, msg) \
+    do {                               \
+        if (!(cond)) {                 \
+            FA_THROW_MSG(std::string("'" #cond "' failed: ") + (msg)); \
+        }                              \
+    } while (0)
+#define FA_THROW_IF_NOT(cond) FA_THROW_IF_NOT_MSG(cond, "")
+
+#define HIP_CHECK(expr)                                                              \
+    do {                                                                             \
+        hipError_t _e = (expr);                                                      \
+        if (_e != hipSuccess) {                                                      \
+            FA_THROW_MSG(std::string("HIP error: ") + hipGetErrorString(_e) + " in " \
+                         #expr);                                                     \
+        }                                                                            \
+    } while (0)
+
+// Limits mirrored from the reference GPU path: k and nprobe are capped at 2048
+// (faiss/gpu/utils/DeviceDefs.cuh:39, faiss/gpu/impl/IndexUtils.cu:28-42).
+constexpr int kMaxSelectionK = 2048;
+
+static inline size_t round_up(size_t x, size_t m) {
+    return (x + m - 1) / m * m;
+}
+static inline size_t div_up(size_t x, size_t m) {
+    return (x + m - 1) / m;
+}
+
+// ---------------------------------------------------------------------------------
+// Sortable keys.  Every candidate that survives a scan is represented by one 64-bit
+// key = (ordkey(distance) << 32) | payload, compared as an unsigned integer.
+// ordkey() maps a float to a uint32 whose unsigned order is the search order:
+//   L2 (smaller is better): ascending float order
+//   IP (larger is better):  descending float order
+// so "k smallest keys" is always the answer, and ties on distance are resolved by the
+// payload (vector id for Flat => the total order (distance, id) of the reference CPU
+// heap, faiss/utils/ordered_key_value.h:74-76 + faiss/impl/ResultHandler.h:276-281).
+// -0.0f is canonicalised to +0.0f.
+// ---------------------------------------------------------------------------------
+__host__ __device__ static inline uint32_t float_flip(float f) {
+    union {
+        float f;
+        uint32_t u;
+    } v;
+    v.f = (f == 0.0f) ? 0.0f : f;
+    return (v.u & 0x80000000u) ? ~v.u : (v.u | 0x80000000u);
+}
+__host__ __device__ static inline float float_unflip(uint32_t u) {
+    union {
+        float f;
+        uint32_t u;
+    } v;
+    v.u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    return v.f;
+}
+template <int METRIC>
+__host__ __device__ static inline uint32_t ordkey(float dis) {
+    return METRIC == METRIC_L2 ? float_flip(dis) : ~float_flip(dis);
+}
+template <int METRIC>
+__host__ __device__ static inline float unordkey(uint32_t k) {
+    return METRIC == METRIC_L2 ? float_unflip(k) : float_unflip(~k);
+}
+__host__ __device__ static inline uint32_t ordkey_rt(int metric, float dis) {
+    return metric == METRIC_L2 ? float_flip(dis) : ~float_flip(dis);
+}
+__host__ __device__ static inline float unordkey_rt(int metric, uint32_t k) {
+    return metric == METRIC_L2 ? float_unflip(k) : float_unflip(~k);
+}
+
+// Value the reference pads missing results with: heap "neutral" element
+// (faiss/utils/ordered_key_value.h:57-59, 80-82; faiss/utils/Heap.h:427-457).
+__host__ __device__ static inline float neutral_distance(int metric) {
+    return metric == METRIC_L2 ? FLT_MAX : -FLT_MAX;
+}
+
+} // namespace faiss_amd

@@ -1,0 +1,491 @@
+// faiss_amd/csrc/flat_kernels.hip -- brute-force L2 / inner-product scan for gfx950 (MI355X).
+//
+// What it replaces in the reference: faiss/gpu/impl/Distance.cu:120-406 (runDistance: GEMM
+// into a 512 x 262144 fp32 tile, l2SelectMinK re-reads the tile, sumAlongRows) and
+// faiss/gpu/impl/L2Norm.cu.  Here the distance tile never exists in memory: every 32x32
+// block of distances is produced in MFMA accumulators, compared against the running k-th
+// best of its query in registers, and only the (rare) survivors are appended to a small
+// per-(query, split) reservoir.
+//
+// Arithmetic contract (restated by oracle/faiss_oracle.c: orc_ip_chain / orc_flat_search):
+//   ip(q, y)  = f32 fmaf chain over k in the order  for s: for e in 0..3: k = 8s+e, 8s+4+e
+//               (v_mfma_f32_32x32x2_f32 is bit-for-bit a k-ordered fmaf chain)
+//   L2: dis   = fmaf(-2, ip, |q|^2 + |y|^2);  if (dis < 0) dis = 0
+//               (same formula as the CPU reference, faiss/utils/distances.cpp:480-495)
+//   IP: dis   = ip
+//   selection = k best under the total order (dis, id)  (faiss/impl/ResultHandler.h:276-281
+//               strict admission + id-ascending scan; faiss/utils/ordered_key_value.h:74-76)
+#include "kernels.h"
+
+namespace faiss_amd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64;
+
+// ---------------------------------------------------------------------------------
+// small kernels
+// ---------------------------------------------------------------------------------
+__global__ void l2_norms_kernel(const float* __restrict__ x, int64_t ld, int64_t n, int d,
+                                float* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* r = x + i * ld;
+    float acc = 0.f;
+    for (int k = 0; k < d; ++k) {
+        float v = r[k];
+        acc = __fmaf_rn(v, v, acc);
+    }
+    out[i] = acc;
+}
+
+void launch_l2_norms(const float* x, int64_t ld, int64_t n, int d, float* out, hipStream_t stream) {
+    if (n == 0) return;
+    int bs = 256;
+    hipLaunchKernelGGL(l2_norms_kernel, dim3((unsigned)div_up(n, bs)), dim3(bs), 0, stream, x, ld, n, d,
+                       out);
+}
+
+__global__ void pad_rows_kernel(const float* __restrict__ src, int64_t ld_src, int64_t n, int d,
+                                float* __restrict__ dst, int64_t ld_dst, int dpad) {
+    int64_t total = n * dpad;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        int64_t i = t / dpad;
+        int c = (int)(t - i * dpad);
+        dst[i * ld_dst + c] = c < d ? src[i * ld_src + c] : 0.f;
+    }
+}
+
+void launch_pad_rows(const float* src, int64_t ld_src, int64_t n, int d, float* dst, int64_t ld_dst,
+                     int dpad, hipStream_t stream) {
+    if (n == 0) return;
+    int64_t total = n * dpad;
+    int bs = 256;
+    unsigned grid = (unsigned)std::min<int64_t>(div_up(total, bs), 65535 * 16);
+    hipLaunchKernelGGL(pad_rows_kernel, dim3(grid), dim3(bs), 0, stream, src, ld_src, n, d, dst, ld_dst,
+                       dpad);
+}
+
+// ---------------------------------------------------------------------------------
+// wave-level reservoir compaction (one 64-lane wavefront, no workgroup barriers)
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() {
+    return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+__device__ __forceinline__ void wave_mem_sync() {
+    // orders this wave's LDS/global accesses (s_waitcnt) and stops compiler reordering
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ u64 wave_max_u64(u64 v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        u64 o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// k-th smallest (1-based, 1 <= k <= n) of n unique 64-bit keys in global memory.
+// MSB-first radix select, 8 bits per pass, histogram in this wave's private LDS `hist[256]`.
+__device__ u64 wave_select_kth(const u64* __restrict__ keys, int n, int k, unsigned* hist) {
+    const int lane = lane_id();
+    u64 prefix = 0, mask = 0;
+    int need = k;
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        // zero histogram
+        *(uint4*)(hist + 4 * lane) = make_uint4(0, 0, 0, 0);
+        wave_mem_sync();
+        for (int i = lane; i < n; i += 64) {
+            u64 key = keys[i];
+            if ((key & mask) == prefix) {
+                atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
+            }
+        }
+        wave_mem_sync();
+        uint4 c;
+        {
+            volatile unsigned* hv = hist + 4 * lane;
+            c.x = hv[0]; c.y = hv[1]; c.z = hv[2]; c.w = hv[3];
+        }
+        unsigned s = c.x + c.y + c.z + c.w;
+        unsigned incl = s;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            unsigned o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        u64 ge = __ballot(incl >= (unsigned)need);
+        int src = __ffsll((long long)ge) - 1; // first lane whose inclusive count reaches need
+        unsigned excl_l = __shfl(incl - s, src, 64);
+        unsigned c0 = __shfl(c.x, src, 64), c1 = __shfl(c.y, src, 64), c2 = __shfl(c.z, src, 64),
+                 c3 = __shfl(c.w, src, 64);
+        unsigned rem = (unsigned)need - excl_l; // 1-based rank inside this lane's 4 bins
+        unsigned digit, cnt_b;
+        if (rem <= c0) {
+            digit = 0; cnt_b = c0;
+        } else if (rem <= c0 + c1) {
+            digit = 1; cnt_b = c1; rem -= c0;
+        } else if (rem <= c0 + c1 + c2) {
+            digit = 2; cnt_b = c2; rem -= c0 + c1;
+        } else {
+            digit = 3; cnt_b = c3; rem -= c0 + c1 + c2;
+        }
+        digit += 4u * (unsigned)src;
+        prefix |= (u64)digit << shift;
+        mask |= (u64)255u << shift;
+        need = (int)rem;
+        if ((unsigned)need == cnt_b) {
+            // the k-th key is the largest key of the selected bucket: one max pass
+            u64 best = 0;
+            for (int i = lane; i < n; i += 64) {
+                u64 key = keys[i];
+                if ((key & mask) == prefix && key > best) best = key;
+            }
+            return wave_max_u64(best);
+        }
+    }
+    return prefix;
+}
+
+// keep keys <= kth (in place, stable within chunks); returns the number kept
+__device__ int wave_compact(u64* keys, int n, u64 kth) {
+    const int lane = lane_id();
+    int out = 0;
+    for (int base = 0; base < n; base += 64) {
+        int i = base + lane;
+        u64 key = i < n ? keys[i] : ~0ull;
+        bool keep = (i < n) && key <= kth;
+        u64 m = __ballot(keep);
+        wave_mem_sync(); // every load of this chunk has returned before any store below
+        int pos = out + __popcll(m & ((1ull << lane) - 1ull));
+        if (keep) keys[pos] = key;
+        out += __popcll(m);
+    }
+    wave_mem_sync();
+    return out;
+}
+
+// ---------------------------------------------------------------------------------
+// fused MFMA scan
+//
+// Workgroup = 512 threads = 8 waves; wave w owns 32 queries for the whole kernel (their d
+// coordinates live in 64 VGPRs as MFMA B operands), the 8 waves share one stream of
+// 64-row database tiles staged through LDS (double buffered, 16-byte XOR swizzle so the
+// ds_read_b128 of 32 different rows at one column is bank-conflict free).
+// MFMA D[i][j]: i = database row of the 32-row block, j = query => each lane holds 16
+// distances of ONE query, so the threshold test needs no cross-lane traffic.
+// ---------------------------------------------------------------------------------
+constexpr int QPW = 32;
+constexpr int WAVES = 8;
+constexpr int QPB = QPW * WAVES; // kFlatQueriesPerBlock
+constexpr int TR = kFlatTileRows; // 64
+constexpr int KS = 128;           // k-slab staged per step
+constexpr int TILE_BYTES = TR * KS * 4; // 32768
+constexpr int LDS_TILES = 0;
+constexpr int LDS_BIAS = 2 * TILE_BYTES;           // 2 x 64 floats
+constexpr int LDS_HIST = LDS_BIAS + 2 * TR * 4;    // 8 waves x 256 uint
+constexpr int LDS_TOTAL = LDS_HIST + WAVES * 256 * 4;
+
+size_t flat_scan_lds_bytes() {
+    return LDS_TOTAL;
+}
+
+template <int METRIC, bool DUMP>
+__global__ void __launch_bounds__(512, 2) flat_scan_kernel(FlatScanParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    const int j = lane & 31;
+
+    // ---- block -> (split, query group); consecutive blocks on one XCD share a split
+    int split, grp;
+    {
+        int b = blockIdx.x;
+        if ((p.nsplit & 7) == 0) {
+            int xcd = b & 7;
+            int t = b >> 3;
+            grp = t % p.ngroups;
+            split = (t / p.ngroups) * 8 + xcd;
+        } else {
+            split = b % p.nsplit;
+            grp = b / p.nsplit;
+        }
+    }
+    const int r0 = split * p.rows_per_split;
+    const int r1 = min(p.nb, r0 + p.rows_per_split);
+    if (r0 >= r1) {
+        // empty split: publish zero counts
+        if (!DUMP) {
+            int q = grp * QPB + tid;
+            if (tid < QPB && q < p.nq) p.res_cnt[(int64_t)q * p.nsplit + split] = 0;
+        }
+        return;
+    }
+    const int ntiles = (r1 - r0 + TR - 1) / TR;
+    const int nslab = (p.dpad + KS - 1) / KS;
+    const int nsteps = ntiles * nslab;
+
+    // ---- this lane's query
+    const int qbase = grp * QPB + wave * QPW; // wave-uniform
+    const int q = qbase + j;
+    const bool qvalid = q < p.nq;
+    const int qc = qvalid ? q : p.nq - 1;
+    const float* qrow = p.xq + (int64_t)qc * p.ldq;
+    float xn = 0.f;
+    if (METRIC == METRIC_L2) xn = p.xqn[qc];
+    float tau;
+    if (METRIC == METRIC_L2)
+        tau = qvalid ? FLT_MAX : -INFINITY;
+    else
+        tau = qvalid ? -FLT_MAX : INFINITY;
+    int cnt = 0;
+    u64* resq = nullptr;       // this lane's query reservoir
+    u64* res_wave = nullptr;   // reservoir of query qbase (wave-uniform)
+    if (!DUMP) {
+        res_wave = p.res_keys + ((int64_t)qbase * p.nsplit + split) * p.cap;
+        resq = res_wave + (int64_t)j * p.nsplit * p.cap;
+    }
+    unsigned* hist = (unsigned*)(smem + LDS_HIST) + wave * 256;
+    const int cap_lim = p.cap - 32;
+
+    // ---- staging registers
+    f32x4 stg[4];
+    float stg_bias = 0.f;
+    auto stage_load = [&](int u) {
+        const int t = u / nslab, sl = u - t * nslab;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int g = tid + 512 * i;
+            int row = g >> 5, c = g & 31;
+            int col = sl * KS + c * 4;
+            int grow = min(r0 + t * TR + row, r1 - 1);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (col < p.dpad) v = *(const f32x4*)(p.xb + (int64_t)grow * p.ldb + col);
+            stg[i] = v;
+        }
+        if (sl == 0 && tid < TR) {
+            int grow = r0 + t * TR + tid;
+            float b;
+            if (METRIC == METRIC_L2)
+                b = grow < r1 ? p.xbn[grow] : INFINITY;
+            else
+                b = grow < r1 ? 0.f : -INFINITY;
+            stg_bias = b;
+        }
+    };
+    auto stage_store = [&](int u) {
+        const int t = u / nslab, sl = u - t * nslab;
+        char* tile = smem + LDS_TILES + (u & 1) * TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int g = tid + 512 * i;
+            int row = g >> 5, c = g & 31;
+            *(f32x4*)(tile + row * 512 + ((c ^ (row & 15)) << 4)) = stg[i];
+        }
+        if (sl == 0 && tid < TR) {
+            ((float*)(smem + LDS_BIAS))[(t & 1) * TR + tid] = stg_bias;
+        }
+    };
+
+    f32x4 bq[16];
+    f32x16 acc0, acc1;
+
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+
+    for (int u = 0; u < nsteps; ++u) {
+        const int t = u / nslab, sl = u - t * nslab;
+        if (u + 1 < nsteps) stage_load(u + 1);
+
+        // ---- B operands (queries) for this slab
+        const int ns = min(16, (p.dpad - sl * KS) >> 3); // 8-wide k steps in this slab
+        if (nslab > 1 || u == 0) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                if (s < ns) bq[s] = *(const f32x4*)(qrow + sl * KS + 8 * s + 4 * h);
+            }
+        }
+        if (sl == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc0[r] = 0.f;
+                acc1[r] = 0.f;
+            }
+        }
+        // ---- MFMA: 2 row blocks x ns x 4
+        {
+            const char* tile = smem + LDS_TILES + (u & 1) * TILE_BYTES;
+            const char* rowp0 = tile + j * 512;        // block 0: row j
+            const char* rowp1 = tile + (32 + j) * 512; // block 1: row 32 + j  ((32+j)&15 == j&15)
+            const int sw = j & 15;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                if (s < ns) {
+                    const int off = (((2 * s + h) ^ sw) << 4);
+                    f32x4 a0 = *(const f32x4*)(rowp0 + off);
+                    f32x4 a1 = *(const f32x4*)(rowp1 + off);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], bq[s][e], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], bq[s][e], acc1, 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // ---- epilogue after the last slab of the tile
+        if (sl == nslab - 1) {
+            const float* bias = (const float*)(smem + LDS_BIAS) + (t & 1) * TR;
+            const int tile_row0 = r0 + t * TR;
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 b4 = *(const f32x4*)(bias + blk * 32 + 8 * g + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * g + e;
+                        const float ip = blk == 0 ? acc0[r] : acc1[r];
+                        float dis;
+                        if (METRIC == METRIC_L2) {
+                            dis = __fmaf_rn(-2.f, ip, xn + b4[e]);
+                            dis = dis < 0.f ? 0.f : dis;
+                        } else {
+                            dis = ip + b4[e];
+                        }
+                        const int grow = tile_row0 + blk * 32 + 8 * g + 4 * h + e;
+                        if (DUMP) {
+                            if (qvalid && grow < r1) p.dump[(int64_t)q * p.nb + grow] = dis;
+                        } else {
+                            const bool pass = METRIC == METRIC_L2 ? dis < tau : dis > tau;
+                            const u64 m = __ballot(pass);
+                            if (m) {
+                                const int lo = (int)((m >> j) & 1ull);
+                                const int hi = (int)((m >> (j + 32)) & 1ull);
+                                if (pass) {
+                                    const int slot = cnt + (h ? lo : 0);
+                                    resq[slot] = ((u64)ordkey<METRIC>(dis) << 32) | (unsigned)grow;
+                                }
+                                cnt += lo + hi;
+                            }
+                        }
+                    }
+                }
+                if (!DUMP) {
+                    u64 flagged = __ballot(cnt > cap_lim) & 0xffffffffull;
+                    if (flagged) {
+                        wave_mem_sync();
+                        while (flagged) {
+                            const int jq = __ffsll((long long)flagged) - 1;
+                            flagged &= flagged - 1;
+                            const int n = __shfl(cnt, jq, 64);
+                            u64* base = res_wave + (int64_t)jq * p.nsplit * p.cap;
+                            const u64 kth = wave_select_kth(base, n, p.k, hist);
+                            const int kept = wave_compact(base, n, kth);
+                            if (j == jq) {
+                                cnt = kept;
+                                tau = unordkey<METRIC>((uint32_t)(kth >> 32));
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (u + 1 < nsteps) stage_store(u + 1);
+        __syncthreads();
+    }
+
+    if (!DUMP) {
+        // final compaction so the merge kernel sees at most k keys per (query, split)
+        u64 flagged = __ballot(cnt > p.k) & 0xffffffffull;
+        if (flagged) wave_mem_sync();
+        while (flagged) {
+            const int jq = __ffsll((long long)flagged) - 1;
+            flagged &= flagged - 1;
+            const int n = __shfl(cnt, jq, 64);
+            u64* base = res_wave + (int64_t)jq * p.nsplit * p.cap;
+            const u64 kth = wave_select_kth(base, n, p.k, hist);
+            const int kept = wave_compact(base, n, kth);
+            if (j == jq) cnt = kept;
+        }
+        if (qvalid && h == 0) p.res_cnt[(int64_t)q * p.nsplit + split] = (uint32_t)cnt;
+    }
+}
+
+void launch_flat_scan(const FlatScanParams& p, hipStream_t stream) {
+    if (p.nq == 0 || p.nb == 0) return;
+    FA_THROW_IF_NOT(p.dpad % 8 == 0 && p.ldq % 4 == 0 && p.ldb % 4 == 0);
+    FA_THROW_IF_NOT(p.rows_per_split % TR == 0);
+    FA_THROW_IF_NOT(p.dump || p.cap >= p.k + 32);
+    dim3 grid((unsigned)(p.nsplit * p.ngroups)), block(512);
+    size_t lds = LDS_TOTAL;
+#define FA_LAUNCH(M, D)                                                                           \
+    do {                                                                                          \
+        HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_kernel<M, D>,                        \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));     \
+        hipLaunchKernelGGL((flat_scan_kernel<M, D>), grid, block, lds, stream, p);                \
+    } while (0)
+    if (p.metric == METRIC_L2) {
+        if (p.dump) FA_LAUNCH(METRIC_L2, true);
+        else FA_LAUNCH(METRIC_L2, false);
+    } else {
+        if (p.dump) FA_LAUNCH(METRIC_INNER_PRODUCT, true);
+        else FA_LAUNCH(METRIC_INNER_PRODUCT, false);
+    }
+#undef FA_LAUNCH
+    HIP_CHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------
+// scalar cross-check kernel: identical arithmetic, no MFMA, no filtering
+// ---------------------------------------------------------------------------------
+template <int METRIC>
+__global__ void flat_simple_kernel(const float* __restrict__ xq, const float* __restrict__ xqn,
+                                   int64_t ldq, int nq, const float* __restrict__ xb,
+                                   const float* __restrict__ xbn, int64_t ldb, int nb, int dpad,
+                                   u64* __restrict__ keys) {
+    const int q = blockIdx.y;
+    const float* qr = xq + (int64_t)q * ldq;
+    const float xn = METRIC == METRIC_L2 ? xqn[q] : 0.f;
+    for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < nb; row += gridDim.x * blockDim.x) {
+        const float* yr = xb + (int64_t)row * ldb;
+        float acc = 0.f;
+        for (int s = 0; s < dpad; s += 8) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc = __fmaf_rn(yr[s + e], qr[s + e], acc);
+                acc = __fmaf_rn(yr[s + 4 + e], qr[s + 4 + e], acc);
+            }
+        }
+        float dis;
+        if (METRIC == METRIC_L2) {
+            dis = __fmaf_rn(-2.f, acc, xn + xbn[row]);
+            dis = dis < 0.f ? 0.f : dis;
+        } else {
+            dis = acc;
+        }
+        keys[(int64_t)q * nb + row] = ((u64)ordkey<METRIC>(dis) << 32) | (unsigned)row;
+    }
+}
+
+void launch_flat_simple(int metric, const float* xq, const float* xqn, int64_t ldq, int nq,
+                        const float* xb, const float* xbn, int64_t ldb, int nb, int dpad, u64* keys,
+                        hipStream_t stream) {
+    if (nq == 0 || nb == 0) return;
+    dim3 grid((unsigned)std::min<int64_t>(div_up(nb, 256), 1024), (unsigned)nq), block(256);
+    if (metric == METRIC_L2)
+        hipLaunchKernelGGL((flat_simple_kernel<METRIC_L2>), grid, block, 0, stream, xq, xqn, ldq, nq, xb,
+                           xbn, ldb, nb, dpad, keys);
+    else
+        hipLaunchKernelGGL((flat_simple_kernel<METRIC_INNER_PRODUCT>), grid, block, 0, stream, xq, xqn,
+                           ldq, nq, xb, xbn, ldb, nb, dpad, keys);
+    HIP_CHECK(hipGetLastError());
+}
+
+} // namespace faiss_amd

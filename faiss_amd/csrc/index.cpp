@@ -1,0 +1,1066 @@
+// faiss_amd/csrc/index.cpp -- host logic of the MI355X backend (see index.h for the reference
+// interfaces each class mirrors).  Every distance / selection / scan is a HIP kernel from
+// kernels.h; there is no CPU compute fallback anywhere in this file.
+#include "index.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <random>
+#include <thread>
+#include "kernels.h"
+
+namespace faiss_amd {
+
+// ====================================================================== memory helpers
+DevBuf::~DevBuf() {
+    release();
+}
+void DevBuf::release() {
+    if (p) {
+        (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+}
+void DevBuf::ensure(size_t bytes, size_t keep_bytes, hipStream_t stream) {
+    if (bytes <= cap) return;
+    size_t ncap = std::max(bytes, cap + cap / 2);
+    ncap = round_up(ncap, 256);
+    void* np = nullptr;
+    HIP_CHECK(hipMalloc(&np, ncap));
+    if (p && keep_bytes) {
+        HIP_CHECK(hipMemcpyAsync(np, p, keep_bytes, hipMemcpyDeviceToDevice, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    if (p) (void)hipFree(p);
+    p = np;
+    cap = ncap;
+}
+
+bool is_device_pointer(const void* p) {
+    if (!p) return false;
+    hipPointerAttribute_t a;
+    hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError(); // plain malloc'ed host memory: not an error for us
+        return false;
+    }
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+// ====================================================================== resources
+GpuResources::GpuResources(int device_) : device(device_) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) {
+        FA_THROW_MSG("no HIP device available: this backend has no CPU fallback");
+    }
+    FA_THROW_IF_NOT_MSG(device >= 0 && device < n, "invalid device");
+    HIP_CHECK(hipSetDevice(device));
+    HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+}
+GpuResources::~GpuResources() {
+    (void)hipSetDevice(device);
+    for (auto& s : spans) {
+        (void)hipEventDestroy(s.a);
+        (void)hipEventDestroy(s.b);
+    }
+    if (stream) (void)hipStreamDestroy(stream);
+}
+void GpuResources::set_device() const {
+    HIP_CHECK(hipSetDevice(device));
+}
+void GpuResources::sync() const {
+    HIP_CHECK(hipStreamSynchronize(stream));
+}
+void GpuResources::begin_span(const char* name) const {
+    Span s;
+    s.name = name;
+    HIP_CHECK(hipEventCreate(&s.a));
+    HIP_CHECK(hipEventCreate(&s.b));
+    HIP_CHECK(hipEventRecord(s.a, stream));
+    spans.push_back(s);
+}
+void GpuResources::end_span() const {
+    HIP_CHECK(hipEventRecord(spans.back().b, stream));
+}
+void GpuResources::collect() const {
+    sync();
+    for (auto& s : spans) {
+        float ms = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&ms, s.a, s.b));
+        auto& t = totals[s.name];
+        t.first += ms;
+        t.second += 1;
+        (void)hipEventDestroy(s.a);
+        (void)hipEventDestroy(s.b);
+    }
+    spans.clear();
+}
+void GpuResources::reset_profile() const {
+    collect();
+    totals.clear();
+}
+
+// ====================================================================== Index base
+void Index::add_with_ids(idx_t, const float*, const idx_t*) {
+    FA_THROW_MSG("add_with_ids not implemented for this type of index");
+}
+void Index::assign(idx_t n, const float* x, idx_t* labels, idx_t k) const {
+    std::vector<float> dis((size_t)n * k);
+    search(n, x, k, dis.data(), labels);
+}
+void Index::reconstruct(idx_t, float*) const {
+    FA_THROW_MSG("reconstruct not implemented for this type of index");
+}
+void Index::reconstruct_n(idx_t i0, idx_t ni, float* recons) const {
+    for (idx_t i = 0; i < ni; i++) reconstruct(i0 + i, recons + i * d);
+}
+void Index::compute_residual(const float* x, float* residual, idx_t key) const {
+    reconstruct(key, residual);
+    for (int i = 0; i < d; i++) residual[i] = x[i] - residual[i];
+}
+
+// stage n x d floats (host or device, dense rows) into a padded device buffer
+static void stage_padded(const GpuResources& res, const float* x, int64_t n, int d, int dpad, DevBuf& raw,
+                         float* dst) {
+    if (n == 0) return;
+    const float* src = x;
+    if (!is_device_pointer(x)) {
+        raw.ensure((size_t)n * d * sizeof(float));
+        HIP_CHECK(hipMemcpyAsync(raw.p, x, (size_t)n * d * sizeof(float), hipMemcpyHostToDevice,
+                                 res.stream));
+        src = raw.as<float>();
+    }
+    launch_pad_rows(src, d, n, d, dst, dpad, dpad, res.stream);
+}
+
+static void copy_out(const GpuResources& res, void* dst, const void* dsrc, size_t bytes) {
+    if (bytes == 0) return;
+    HIP_CHECK(hipMemcpyAsync(dst, dsrc, bytes,
+                             is_device_pointer(dst) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                             res.stream));
+}
+
+// ====================================================================== GpuIndexFlat
+GpuIndexFlat::GpuIndexFlat(std::shared_ptr<GpuResources> res, int dims, int metric)
+        : Index(dims, metric), res_(std::move(res)) {
+    FA_THROW_IF_NOT_MSG(dims > 0, "dimension must be positive");
+    FA_THROW_IF_NOT_MSG(metric == METRIC_L2 || metric == METRIC_INNER_PRODUCT,
+                        "only METRIC_L2 and METRIC_INNER_PRODUCT are supported");
+    dpad_ = (int)round_up(dims, 8);
+    is_trained = true;
+}
+GpuIndexFlat::~GpuIndexFlat() {
+    (void)hipSetDevice(res_->device);
+}
+
+void GpuIndexFlat::reset() {
+    std::lock_guard<std::mutex> g(mu_);
+    ntotal = 0;
+}
+
+void GpuIndexFlat::add(idx_t n, const float* x) {
+    if (n == 0) return;
+    FA_THROW_IF_NOT_MSG(x, "null input");
+    FA_THROW_IF_NOT_MSG(ntotal + n < ((idx_t)1 << 31), "at most 2^31-1 vectors per device index");
+    std::lock_guard<std::mutex> g(mu_);
+    res_->set_device();
+    const size_t row = (size_t)dpad_ * sizeof(float);
+    xb_.ensure((size_t)(ntotal + n) * row, (size_t)ntotal * row, res_->stream);
+    xbn_.ensure((size_t)(ntotal + n) * sizeof(float), (size_t)ntotal * sizeof(float), res_->stream);
+    // page the upload so the raw staging buffer stays bounded (reference: GpuIndex.cu:197-217)
+    const idx_t page = std::max<idx_t>(1, ((idx_t)256 << 20) / ((idx_t)d * 4));
+    for (idx_t i0 = 0; i0 < n; i0 += page) {
+        idx_t ni = std::min(page, n - i0);
+        float* dst = xb_.as<float>() + (size_t)(ntotal + i0) * dpad_;
+        stage_padded(*res_, x + (size_t)i0 * d, ni, d, dpad_, q_raw_, dst);
+        launch_l2_norms(dst, dpad_, ni, dpad_, xbn_.as<float>() + ntotal + i0, res_->stream);
+        res_->sync(); // q_raw_ is reused by the next page
+    }
+    ntotal += n;
+}
+
+void GpuIndexFlat::reconstruct_n(idx_t i0, idx_t ni, float* recons) const {
+    FA_THROW_IF_NOT_MSG(i0 >= 0 && ni >= 0 && i0 + ni <= ntotal, "index out of range");
+    if (ni == 0) return;
+    std::lock_guard<std::mutex> g(mu_);
+    res_->set_device();
+    HIP_CHECK(hipMemcpy2DAsync(recons, (size_t)d * 4, xb_.as<float>() + (size_t)i0 * dpad_,
+                               (size_t)dpad_ * 4, (size_t)d * 4, (size_t)ni,
+                               is_device_pointer(recons) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                               res_->stream));
+    res_->sync();
+}
+void GpuIndexFlat::reconstruct(idx_t key, float* recons) const {
+    reconstruct_n(key, 1, recons);
+}
+
+// choose the database split count: blocks = nsplit * ngroups should fill whole rounds of CUs
+static void choose_splits(int nb, int ngroups, int num_cus, int& nsplit, int& rows_per_split) {
+    const int TR = kFlatTileRows;
+    const int max_split = std::max(1, nb / 2048);
+    int best = 1;
+    if (max_split >= 8) {
+        double best_eff = -1.0;
+        for (int s = 8; s <= std::min(max_split, 64); s += 8) {
+            long total = (long)s * ngroups;
+            long rounds = (total + num_cus - 1) / num_cus;
+            double eff = (double)total / (double)(rounds * num_cus);
+            if (eff > best_eff + 1e-9) {
+                best_eff = eff;
+                best = s;
+            }
+        }
+    } else {
+        best = max_split;
+    }
+    nsplit = best;
+    rows_per_split = (int)round_up(div_up(nb, nsplit), TR);
+    // trailing splits that end up empty publish zero counts inside the kernel
+}
+
+static int reservoir_capacity(int k) {
+    int cap = 64;
+    while (cap < 4 * k) cap <<= 1;
+    cap = std::max(cap, 64);
+    if (cap < k + 32) cap = (int)round_up(k + 32, 64);
+    return cap;
+}
+
+void GpuIndexFlat::search_tile_(int n, const float* xq_pad, int k, float* dD, idx_t* dI) const {
+    const GpuResources& R = *res_;
+    const int nb = (int)ntotal;
+    if (metric_type == METRIC_L2) {
+        q_norm_.ensure((size_t)n * 4);
+        SpanGuard sg(&R, "l2_norms_query");
+        launch_l2_norms(xq_pad, dpad_, n, dpad_, q_norm_.as<float>(), R.stream);
+    }
+    SelectParams sp{};
+    sp.metric = metric_type;
+    sp.nq = n;
+    sp.k = k;
+    sp.mode = 0;
+    sp.id_base = 0;
+    sp.out_dis = dD;
+    sp.out_ids = dI;
+    if (nb == 0) {
+        one_cnt_.ensure((size_t)n * 4);
+        HIP_CHECK(hipMemsetAsync(one_cnt_.p, 0, (size_t)n * 4, R.stream));
+        sp.keys = nullptr;
+        sp.q_stride = 0;
+        sp.nseg = 1;
+        sp.seg_stride = 0;
+        sp.seg_cnt = one_cnt_.as<uint32_t>();
+        launch_select_k(sp, R.stream);
+        return;
+    }
+    if (use_simple_kernel) {
+        all_keys_.ensure((size_t)n * nb * 8);
+        one_cnt_.ensure((size_t)n * 4);
+        std::vector<uint32_t> cnt(n, (uint32_t)nb);
+        HIP_CHECK(hipMemcpyAsync(one_cnt_.p, cnt.data(), (size_t)n * 4, hipMemcpyHostToDevice, R.stream));
+        HIP_CHECK(hipStreamSynchronize(R.stream));
+        {
+            SpanGuard sg(&R, "flat_simple_kernel");
+            launch_flat_simple(metric_type, xq_pad, q_norm_.as<float>(), dpad_, n, xb_.as<float>(),
+                               xbn_.as<float>(), dpad_, nb, dpad_, all_keys_.as<unsigned long long>(),
+                               R.stream);
+        }
+        sp.keys = all_keys_.as<unsigned long long>();
+        sp.q_stride = nb;
+        sp.nseg = 1;
+        sp.seg_stride = 0;
+        sp.seg_cnt = one_cnt_.as<uint32_t>();
+        SpanGuard sg(&R, "select_k_kernel");
+        launch_select_k(sp, R.stream);
+        return;
+    }
+    FlatScanParams fp{};
+    fp.metric = metric_type;
+    fp.xq = xq_pad;
+    fp.xqn = q_norm_.as<float>();
+    fp.xb = xb_.as<float>();
+    fp.xbn = xbn_.as<float>();
+    fp.ldq = dpad_;
+    fp.ldb = dpad_;
+    fp.nq = n;
+    fp.nb = nb;
+    fp.dpad = dpad_;
+    fp.ngroups = (int)div_up(n, kFlatQueriesPerBlock);
+    choose_splits(nb, fp.ngroups, R.num_cus, fp.nsplit, fp.rows_per_split);
+    fp.k = k;
+    fp.cap = reservoir_capacity(k);
+    res_keys_.ensure((size_t)n * fp.nsplit * fp.cap * 8);
+    res_cnt_.ensure((size_t)n * fp.nsplit * 4);
+    fp.res_keys = res_keys_.as<unsigned long long>();
+    fp.res_cnt = res_cnt_.as<uint32_t>();
+    fp.dump = nullptr;
+    {
+        SpanGuard sg(&R, "flat_scan_kernel");
+        launch_flat_scan(fp, R.stream);
+    }
+    sp.keys = fp.res_keys;
+    sp.q_stride = (int64_t)fp.nsplit * fp.cap;
+    sp.nseg = fp.nsplit;
+    sp.seg_stride = fp.cap;
+    sp.seg_cnt = fp.res_cnt;
+    {
+        SpanGuard sg(&R, "select_k_kernel");
+        launch_select_k(sp, R.stream);
+    }
+}
+
+// queries per tile so that the reservoirs stay within the scratch budget
+static int flat_query_tile(const GpuResources& R, int k, bool simple, idx_t nb) {
+    size_t per_q;
+    if (simple) per_q = (size_t)std::max<idx_t>(nb, 1) * 8;
+    else per_q = (size_t)64 * reservoir_capacity(k) * 8;
+    size_t t = R.temp_budget_bytes / per_q;
+    t = std::max<size_t>(t, 256);
+    t = std::min<size_t>(t, (size_t)1 << 20);
+    return (int)(t / 256 * 256);
+}
+
+void GpuIndexFlat::search_device(int n, const float* xq_pad, int k, float* dD, idx_t* dI) const {
+    const int tile = flat_query_tile(*res_, k, use_simple_kernel, ntotal);
+    for (int i0 = 0; i0 < n; i0 += tile) {
+        int ni = std::min(tile, n - i0);
+        search_tile_(ni, xq_pad + (size_t)i0 * dpad_, k, dD + (size_t)i0 * k, dI + (size_t)i0 * k);
+    }
+}
+
+void GpuIndexFlat::search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels) const {
+    FA_THROW_IF_NOT_MSG(k >= 1 && k <= kMaxSelectionK, "k must be in [1, 2048]");
+    if (n == 0) return;
+    FA_THROW_IF_NOT_MSG(x && distances && labels, "null argument");
+    std::lock_guard<std::mutex> g(mu_);
+    res_->set_device();
+    const GpuResources& R = *res_;
+    const bool out_dev_d = is_device_pointer(distances), out_dev_i = is_device_pointer(labels);
+    const idx_t tile = flat_query_tile(R, (int)k, use_simple_kernel, ntotal);
+    for (idx_t i0 = 0; i0 < n; i0 += tile) {
+        const int ni = (int)std::min(tile, n - i0);
+        q_pad_.ensure((size_t)ni * dpad_ * 4);
+        stage_padded(R, x + (size_t)i0 * d, ni, d, dpad_, q_raw_, q_pad_.as<float>());
+        float* dD = out_dev_d ? distances + (size_t)i0 * k : nullptr;
+        idx_t* dI = out_dev_i ? labels + (size_t)i0 * k : nullptr;
+        if (!dD) {
+            out_d_.ensure((size_t)ni * k * 4);
+            dD = out_d_.as<float>();
+        }
+        if (!dI) {
+            out_i_.ensure((size_t)ni * k * 8);
+            dI = out_i_.as<idx_t>();
+        }
+        search_tile_(ni, q_pad_.as<float>(), (int)k, dD, dI);
+        if (!out_dev_d) copy_out(R, distances + (size_t)i0 * k, dD, (size_t)ni * k * 4);
+        if (!out_dev_i) copy_out(R, labels + (size_t)i0 * k, dI, (size_t)ni * k * 8);
+        R.sync();
+    }
+}
+
+void GpuIndexFlat::pairwise_distances(idx_t n, const float* x, float* out) const {
+    if (n == 0 || ntotal == 0) return;
+    std::lock_guard<std::mutex> g(mu_);
+    res_->set_device();
+    const GpuResources& R = *res_;
+    q_pad_.ensure((size_t)n * dpad_ * 4);
+    stage_padded(R, x, n, d, dpad_, q_raw_, q_pad_.as<float>());
+    q_norm_.ensure((size_t)n * 4);
+    launch_l2_norms(q_pad_.as<float>(), dpad_, n, dpad_, q_norm_.as<float>(), R.stream);
+    DevBuf dump;
+    float* dptr = out;
+    const bool dev_out = is_device_pointer(out);
+    if (!dev_out) {
+        dump.ensure((size_t)n * ntotal * 4);
+        dptr = dump.as<float>();
+    }
+    FlatScanParams fp{};
+    fp.metric = metric_type;
+    fp.xq = q_pad_.as<float>();
+    fp.xqn = q_norm_.as<float>();
+    fp.xb = xb_.as<float>();
+    fp.xbn = xbn_.as<float>();
+    fp.ldq = fp.ldb = dpad_;
+    fp.nq = (int)n;
+    fp.nb = (int)ntotal;
+    fp.dpad = dpad_;
+    fp.ngroups = (int)div_up(n, kFlatQueriesPerBlock);
+    choose_splits(fp.nb, fp.ngroups, R.num_cus, fp.nsplit, fp.rows_per_split);
+    fp.k = 1;
+    fp.cap = 64;
+    fp.dump = dptr;
+    launch_flat_scan(fp, R.stream);
+    if (!dev_out) copy_out(R, out, dptr, (size_t)n * ntotal * 4);
+    R.sync();
+}
+
+// ====================================================================== Clustering
+// Lloyd iterations exactly as the reference organises them (faiss/Clustering.cpp:255-357):
+// assignment through index.search(k=1), centroid update and empty-cluster splitting on the
+// host.  Random choices use our own generator, so centroids are not bit-identical to faiss
+// (its own GPU tests only compare the objective, faiss/gpu/test/test_gpu_basics.py:117-133).
+void Clustering::train(idx_t nx, const float* x_in, Index& index) {
+    FA_THROW_IF_NOT_MSG(nx >= k, "need at least as many training points as clusters");
+    std::mt19937_64 rng((uint64_t)seed);
+    // ---- subsample (faiss/Clustering.cpp subsample_training_set)
+    std::vector<float> sub;
+    const float* x = x_in;
+    if (nx > (idx_t)k * max_points_per_centroid) {
+        idx_t ns = (idx_t)k * max_points_per_centroid;
+        std::vector<idx_t> perm(nx);
+        std::iota(perm.begin(), perm.end(), 0);
+        for (idx_t i = 0; i < ns; i++) {
+            idx_t j = i + (idx_t)(rng() % (uint64_t)(nx - i));
+            std::swap(perm[i], perm[j]);
+        }
+        sub.resize((size_t)ns * d);
+        for (idx_t i = 0; i < ns; i++)
+            memcpy(&sub[(size_t)i * d], x_in + (size_t)perm[i] * d, sizeof(float) * d);
+        x = sub.data();
+        nx = ns;
+    }
+    // ---- init: k distinct random points
+    centroids.resize((size_t)k * d);
+    {
+        std::vector<idx_t> perm(nx);
+        std::iota(perm.begin(), perm.end(), 0);
+        for (int i = 0; i < k; i++) {
+            idx_t j = i + (idx_t)(rng() % (uint64_t)(nx - i));
+            std::swap(perm[i], perm[j]);
+            memcpy(&centroids[(size_t)i * d], x + (size_t)perm[i] * d, sizeof(float) * d);
+        }
+    }
+    std::vector<idx_t> assign(nx);
+    std::vector<float> dis(nx);
+    std::vector<double> sums((size_t)k * d);
+    std::vector<idx_t> hassign(k);
+    obj.clear();
+    for (int it = 0; it < niter; it++) {
+        index.reset();
+        index.add(k, centroids.data());
+        index.search(nx, x, 1, dis.data(), assign.data());
+        double o = 0;
+        for (idx_t i = 0; i < nx; i++) o += dis[i];
+        obj.push_back((float)o);
+        // ---- update (faiss/Clustering.cpp:307-324 compute_centroids)
+        std::fill(sums.begin(), sums.end(), 0.0);
+        std::fill(hassign.begin(), hassign.end(), 0);
+        for (idx_t i = 0; i < nx; i++) {
+            idx_t c = assign[i];
+            if (c < 0) continue;
+            hassign[c]++;
+            const float* xi = x + (size_t)i * d;
+            double* s = &sums[(size_t)c * d];
+            for (int j = 0; j < d; j++) s[j] += xi[j];
+        }
+        for (int c = 0; c < k; c++) {
+            if (hassign[c] == 0) continue;
+            for (int j = 0; j < d; j++)
+                centroids[(size_t)c * d + j] = (float)(sums[(size_t)c * d + j] / (double)hassign[c]);
+        }
+        // ---- split big clusters into empty ones (faiss/Clustering.cpp split_clusters)
+        const float EPS = 1.f / 1024.f;
+        for (int ci = 0; ci < k; ci++) {
+            if (hassign[ci] != 0) continue;
+            int cj = 0;
+            for (;;) {
+                double p = (hassign[cj] - 1.0) / (double)(nx - k);
+                double r = (double)(rng() >> 11) * (1.0 / 9007199254740992.0);
+                if (r < p) break;
+                cj = (cj + 1) % k;
+            }
+            memcpy(&centroids[(size_t)ci * d], &centroids[(size_t)cj * d], sizeof(float) * d);
+            for (int j = 0; j < d; j++) {
+                if (j % 2 == 0) {
+                    centroids[(size_t)ci * d + j] *= 1 + EPS;
+                    centroids[(size_t)cj * d + j] *= 1 - EPS;
+                } else {
+                    centroids[(size_t)ci * d + j] *= 1 - EPS;
+                    centroids[(size_t)cj * d + j] *= 1 + EPS;
+                }
+            }
+            hassign[ci] = hassign[cj] / 2;
+            hassign[cj] -= hassign[ci];
+        }
+        if (verbose) printf("  k-means iteration %d objective %g\n", it, o);
+    }
+    index.reset();
+    index.add(k, centroids.data());
+}
+
+// ====================================================================== GpuIndexIVF
+GpuIndexIVF::GpuIndexIVF(std::shared_ptr<GpuResources> res, int dims, int metric, int nlist_)
+        : Index(dims, metric), nlist(nlist_), res_(std::move(res)) {
+    FA_THROW_IF_NOT_MSG(nlist > 0, "nlist must be positive");
+    FA_THROW_IF_NOT_MSG(metric == METRIC_L2 || metric == METRIC_INNER_PRODUCT,
+                        "unsupported metric type (reference: faiss/gpu/GpuIndexIVF.cu:35-37)");
+    dpad_ = (int)round_up(dims, 8);
+    quantizer = new GpuIndexFlat(res_, dims, metric);
+    is_trained = false;
+    list_len_.assign(nlist, 0);
+    list_start_.assign(nlist, 0);
+}
+GpuIndexIVF::~GpuIndexIVF() {
+    (void)hipSetDevice(res_->device);
+    delete quantizer;
+}
+
+void GpuIndexIVF::upload_list_tables_() {
+    d_list_len_.ensure((size_t)nlist * 4);
+    d_list_start_.ensure((size_t)nlist * 8);
+    HIP_CHECK(hipMemcpyAsync(d_list_len_.p, list_len_.data(), (size_t)nlist * 4, hipMemcpyHostToDevice,
+                             res_->stream));
+    HIP_CHECK(hipMemcpyAsync(d_list_start_.p, list_start_.data(), (size_t)nlist * 8, hipMemcpyHostToDevice,
+                             res_->stream));
+    res_->sync();
+}
+
+void GpuIndexIVF::reset() {
+    std::lock_guard<std::mutex> g(mu_);
+    res_->set_device();
+    ntotal = 0;
+    std::fill(list_len_.begin(), list_len_.end(), 0);
+    std::fill(list_start_.begin(), list_start_.end(), 0);
+    upload_list_tables_();
+}
+
+void GpuIndexIVF::set_centroids(const float* centroids) {
+    res_->set_device();
+    quantizer->reset();
+    quantizer->add(nlist, centroids);
+    is_trained = true; // IVFPQ additionally needs set_pq_centroids (checked in add/search)
+    upload_list_tables_();
+}
+
+void GpuIndexIVF::train(idx_t n, const float* x) {
+    if (is_trained && quantizer->ntotal == nlist) return; // reference: GpuIndexIVF.cu trainQuantizer_
+    FA_THROW_IF_NOT_MSG(n > 0 && x, "empty training set");
+    res_->set_device();
+    std::vector<float> hx;
+    const float* xh = x;
+    if (is_device_pointer(x)) {
+        hx.resize((size_t)n * d);
+        HIP_CHECK(hipMemcpy(hx.data(), x, (size_t)n * d * 4, hipMemcpyDeviceToHost));
+        xh = hx.data();
+    }
+    Clustering clus(d, nlist);
+    clus.niter = cp_niter;
+    clus.seed = cp_seed;
+    clus.verbose = verbose;
+    // the quantizer itself is the assignment index, exactly like GpuIndexIVF::trainQuantizer_
+    // (faiss/gpu/GpuIndexIVF.cu:508-538)
+    clus.train(n, xh, *quantizer);
+    FA_THROW_IF_NOT(quantizer->ntotal == nlist);
+    {
+        // residual training (IVFPQ) works on padded device copies
+        std::lock_guard<std::mutex> g(mu_);
+        DevBuf xpad;
+        xpad.ensure((size_t)n * dpad_ * 4);
+        stage_padded(*res_, xh, n, d, dpad_, q_raw_, xpad.as<float>());
+        res_->sync();
+        train_residual_(n, xpad.as<float>());
+    }
+    is_trained = true;
+    upload_list_tables_();
+}
+
+void GpuIndexIVF::add(idx_t n, const float* x) {
+    // ids are generated sequentially when absent (reference: faiss/gpu/GpuIndex.cu:137-144)
+    std::vector<idx_t> ids((size_t)n);
+    for (idx_t i = 0; i < n; i++) ids[i] = ntotal + i;
+    add_with_ids(n, x, ids.data());
+}
+
+void GpuIndexIVF::add_with_ids(idx_t n, const float* x, const idx_t* xids) {
+    FA_THROW_IF_NOT_MSG(is_trained, "index must be trained before adding vectors");
+    if (n == 0) return;
+    FA_THROW_IF_NOT_MSG(x && xids, "null argument");
+    FA_THROW_IF_NOT_MSG(ntotal + n < ((idx_t)1 << 31), "at most 2^31-1 vectors per device index");
+    std::lock_guard<std::mutex> g(mu_);
+    res_->set_device();
+    const GpuResources& R = *res_;
+    const idx_t page = std::max<idx_t>(1, std::min<idx_t>(((idx_t)512 << 20) / ((idx_t)dpad_ * 4), 1 << 20));
+    // ---- pass 1: coarse assignment of every new vector (k = 1 search on the quantizer)
+    std::vector<idx_t> labels((size_t)n);
+    DevBuf xpad, dlab, ddis;
+    xpad.ensure((size_t)std::min(page, n) * dpad_ * 4);
+    dlab.ensure((size_t)std::min(page, n) * 8);
+    ddis.ensure((size_t)std::min(page, n) * 4);
+    for (idx_t i0 = 0; i0 < n; i0 += page) {
+        const int ni = (int)std::min(page, n - i0);
+        stage_padded(R, x + (size_t)i0 * d, ni, d, dpad_, q_raw_, xpad.as<float>());
+        quantizer->search_device(ni, xpad.as<float>(), 1, ddis.as<float>(), dlab.as<idx_t>());
+        HIP_CHECK(hipMemcpyAsync(labels.data() + i0, dlab.p, (size_t)ni * 8, hipMemcpyDeviceToHost, R.stream));
+        R.sync();
+    }
+    // ---- host bookkeeping: new layout (reference: IVFBase.cu:693-905 addVectorsToLists_)
+    std::vector<uint32_t> new_len(list_len_);
+    idx_t n_valid = 0;
+    for (idx_t i = 0; i < n; i++) {
+        if (labels[i] >= 0) { // NaN vectors get label -1 and are skipped, like the reference
+            new_len[labels[i]]++;
+            n_valid++;
+        }
+    }
+    std::vector<int64_t> new_start(nlist);
+    int64_t acc = 0;
+    for (int l = 0; l < nlist; l++) {
+        new_start[l] = acc;
+        acc += new_len[l];
+    }
+    std::vector<int64_t> dest((size_t)n);
+    {
+        std::vector<uint32_t> fill(list_len_);
+        for (idx_t i = 0; i < n; i++) {
+            idx_t l = labels[i];
+            dest[i] = l >= 0 ? new_start[l] + fill[l]++ : -1;
+        }
+    }
+    // ---- rebuild arenas: move old lists, then scatter the new entries
+    const size_t new_total = (size_t)acc;
+    DevBuf new_arena, new_ids, d_new_start;
+    new_arena.ensure(std::max<size_t>(new_total * code_bytes_, 256));
+    new_ids.ensure(std::max<size_t>(new_total * 8, 256));
+    d_new_start.ensure((size_t)nlist * 8);
+    HIP_CHECK(hipMemcpyAsync(d_new_start.p, new_start.data(), (size_t)nlist * 8, hipMemcpyHostToDevice,
+                             R.stream));
+    if (ntotal > 0) {
+        launch_move_lists(arena_.as<uint8_t>(), new_arena.as<uint8_t>(), d_list_start_.as<int64_t>(),
+                          d_new_start.as<int64_t>(), d_list_len_.as<uint32_t>(), nlist, (int)code_bytes_,
+                          R.stream);
+        launch_move_lists(arena_ids_.as<uint8_t>(), new_ids.as<uint8_t>(), d_list_start_.as<int64_t>(),
+                          d_new_start.as<int64_t>(), d_list_len_.as<uint32_t>(), nlist, 8, R.stream);
+    }
+    R.sync();
+    std::swap(arena_.p, new_arena.p);
+    std::swap(arena_.cap, new_arena.cap);
+    std::swap(arena_ids_.p, new_ids.p);
+    std::swap(arena_ids_.cap, new_ids.cap);
+    // ---- pass 2: encode + scatter
+    DevBuf ddest, dids;
+    ddest.ensure((size_t)std::min(page, n) * 8);
+    dids.ensure((size_t)std::min(page, n) * 8);
+    for (idx_t i0 = 0; i0 < n; i0 += page) {
+        const int ni = (int)std::min(page, n - i0);
+        stage_padded(R, x + (size_t)i0 * d, ni, d, dpad_, q_raw_, xpad.as<float>());
+        HIP_CHECK(hipMemcpyAsync(dlab.p, labels.data() + i0, (size_t)ni * 8, hipMemcpyHostToDevice, R.stream));
+        HIP_CHECK(hipMemcpyAsync(ddest.p, dest.data() + i0, (size_t)ni * 8, hipMemcpyHostToDevice, R.stream));
+        HIP_CHECK(hipMemcpyAsync(dids.p, xids + i0, (size_t)ni * 8,
+                                 is_device_pointer(xids) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                                 R.stream));
+        append_(ni, xpad.as<float>(), dlab.as<int64_t>(), ddest.as<int64_t>());
+        launch_scatter_i64(dids.as<int64_t>(), ddest.as<int64_t>(), ni, arena_ids_.as<int64_t>(), R.stream);
+        R.sync();
+    }
+    list_len_ = new_len;
+    list_start_ = new_start;
+    ntotal += n_valid;
+    upload_list_tables_();
+}
+
+void GpuIndexIVF::set_lists(const uint32_t* list_sizes, const uint8_t* codes, const idx_t* ids) {
+    std::lock_guard<std::mutex> g(mu_);
+    res_->set_device();
+    int64_t acc = 0;
+    for (int l = 0; l < nlist; l++) {
+        list_len_[l] = list_sizes[l];
+        list_start_[l] = acc;
+        acc += list_sizes[l];
+    }
+    FA_THROW_IF_NOT_MSG(acc < ((int64_t)1 << 31), "at most 2^31-1 vectors per device index");
+    ntotal = acc;
+    arena_.ensure(std::max<size_t>((size_t)acc * code_bytes_, 256));
+    arena_ids_.ensure(std::max<size_t>((size_t)acc * 8, 256));
+    if (acc > 0) {
+        HIP_CHECK(hipMemcpyAsync(arena_ids_.p, ids, (size_t)acc * 8, hipMemcpyHostToDevice, res_->stream));
+        // `codes` are the reference's list payloads: d floats (IVFFlat) or M bytes (IVFPQ) per entry
+        const size_t src_row = code_bytes_ == (size_t)dpad_ * 4 ? (size_t)d * 4 : code_bytes_;
+        HIP_CHECK(hipMemsetAsync(arena_.p, 0, (size_t)acc * code_bytes_, res_->stream));
+        HIP_CHECK(hipMemcpy2DAsync(arena_.p, code_bytes_, codes, src_row, src_row, (size_t)acc,
+                                   hipMemcpyHostToDevice, res_->stream));
+    }
+    upload_list_tables_();
+}
+
+std::vector<idx_t> GpuIndexIVF::getListIndices(idx_t list) const {
+    FA_THROW_IF_NOT(list >= 0 && list < nlist);
+    std::lock_guard<std::mutex> g(mu_);
+    res_->set_device();
+    std::vector<idx_t> out(list_len_[list]);
+    if (!out.empty())
+        HIP_CHECK(hipMemcpy(out.data(), arena_ids_.as<idx_t>() + list_start_[list], out.size() * 8,
+                            hipMemcpyDeviceToHost));
+    return out;
+}
+std::vector<uint8_t> GpuIndexIVF::getListVectorData(idx_t list) const {
+    FA_THROW_IF_NOT(list >= 0 && list < nlist);
+    std::lock_guard<std::mutex> g(mu_);
+    res_->set_device();
+    const size_t src_row = code_bytes_;
+    const size_t dst_row = code_bytes_ == (size_t)dpad_ * 4 ? (size_t)d * 4 : code_bytes_;
+    std::vector<uint8_t> out((size_t)list_len_[list] * dst_row);
+    if (!out.empty())
+        HIP_CHECK(hipMemcpy2D(out.data(), dst_row, arena_.as<uint8_t>() + list_start_[list] * src_row, src_row,
+                              dst_row, list_len_[list], hipMemcpyDeviceToHost));
+    return out;
+}
+
+void GpuIndexIVF::search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels) const {
+    FA_THROW_IF_NOT_MSG(is_trained, "index not trained");
+    FA_THROW_IF_NOT_MSG(k >= 1 && k <= kMaxSelectionK, "k must be in [1, 2048]");
+    FA_THROW_IF_NOT_MSG(nprobe >= 1 && nprobe <= kMaxSelectionK, "nprobe must be in [1, 2048]");
+    if (n == 0) return;
+    FA_THROW_IF_NOT_MSG(x && distances && labels, "null argument");
+    std::lock_guard<std::mutex> g(mu_);
+    res_->set_device();
+    const GpuResources& R = *res_;
+    const int np = std::min(nprobe, nlist);
+    const bool out_dev_d = is_device_pointer(distances), out_dev_i = is_device_pointer(labels);
+    // query tile bounded by the worst-case candidate volume (reference: IVFUtils.cu:46-127)
+    uint32_t max_len = 1;
+    for (auto l : list_len_) max_len = std::max(max_len, l);
+    size_t per_q = (size_t)np * max_len * 8;
+    idx_t tile = (idx_t)std::max<size_t>(1, R.temp_budget_bytes / per_q);
+    tile = std::min<idx_t>(tile, 16384);
+    for (idx_t i0 = 0; i0 < n; i0 += tile) {
+        const int ni = (int)std::min(tile, n - i0);
+        q_pad_.ensure((size_t)ni * dpad_ * 4);
+        stage_padded(R, x + (size_t)i0 * d, ni, d, dpad_, q_raw_, q_pad_.as<float>());
+        // ---- coarse quantizer: nprobe nearest centroids (reference: IVFBase.cu:509-593)
+        c_dis_.ensure((size_t)ni * np * 4);
+        c_ids_.ensure((size_t)ni * np * 8);
+        quantizer->search_device(ni, q_pad_.as<float>(), np, c_dis_.as<float>(), c_ids_.as<idx_t>());
+        // ---- per-(query, probe) offsets
+        prefix_.ensure((size_t)ni * (np + 1) * 4);
+        totals_.ensure((size_t)ni * 4);
+        launch_ivf_prefix(c_ids_.as<idx_t>(), ni, np, d_list_len_.as<uint32_t>(), prefix_.as<uint32_t>(),
+                          totals_.as<uint32_t>(), R.stream);
+        std::vector<uint32_t> tot(ni);
+        HIP_CHECK(hipMemcpyAsync(tot.data(), totals_.p, (size_t)ni * 4, hipMemcpyDeviceToHost, R.stream));
+        R.sync();
+        std::vector<int64_t> qoff(ni);
+        int64_t nkeys = 0;
+        for (int q = 0; q < ni; q++) {
+            qoff[q] = nkeys;
+            nkeys += tot[q];
+        }
+        q_off_.ensure((size_t)ni * 8);
+        HIP_CHECK(hipMemcpyAsync(q_off_.p, qoff.data(), (size_t)ni * 8, hipMemcpyHostToDevice, R.stream));
+        keys_.ensure(std::max<size_t>((size_t)nkeys * 8, 256));
+        // ---- list scan: every candidate distance as a 64-bit key
+        nprobe_eff_ = np;
+        scan_(ni, q_pad_.as<float>(), (int)k, nullptr);
+        // ---- k-selection + (probe, offset) -> user id
+        float* dD = out_dev_d ? distances + (size_t)i0 * k : nullptr;
+        idx_t* dI = out_dev_i ? labels + (size_t)i0 * k : nullptr;
+        if (!dD) {
+            out_d_.ensure((size_t)ni * k * 4);
+            dD = out_d_.as<float>();
+        }
+        if (!dI) {
+            out_i_.ensure((size_t)ni * k * 8);
+            dI = out_i_.as<idx_t>();
+        }
+        SelectParams sp{};
+        sp.metric = metric_type;
+        sp.nq = ni;
+        sp.k = (int)k;
+        sp.keys = keys_.as<unsigned long long>();
+        sp.q_off = q_off_.as<int64_t>();
+        sp.q_stride = 0;
+        sp.nseg = 1;
+        sp.seg_stride = 0;
+        sp.seg_cnt = totals_.as<uint32_t>();
+        sp.mode = 1;
+        sp.nprobe = np;
+        sp.ivf_prefix = prefix_.as<uint32_t>();
+        sp.coarse_ids = c_ids_.as<idx_t>();
+        sp.list_start = d_list_start_.as<int64_t>();
+        sp.arena_ids = arena_ids_.as<int64_t>();
+        sp.out_dis = dD;
+        sp.out_ids = dI;
+        {
+            SpanGuard sg(&R, "select_k_kernel");
+            launch_select_k(sp, R.stream);
+        }
+        if (!out_dev_d) copy_out(R, distances + (size_t)i0 * k, dD, (size_t)ni * k * 4);
+        if (!out_dev_i) copy_out(R, labels + (size_t)i0 * k, dI, (size_t)ni * k * 8);
+        R.sync();
+    }
+}
+
+// ---------------------------------------------------------------------- IVFFlat
+GpuIndexIVFFlat::GpuIndexIVFFlat(std::shared_ptr<GpuResources> res, int dims, int nlist, int metric)
+        : GpuIndexIVF(std::move(res), dims, metric, nlist) {
+    code_bytes_ = (size_t)dpad_ * 4;
+}
+void GpuIndexIVFFlat::append_(int n, const float* x_pad, const int64_t*, const int64_t* d_dest) {
+    launch_ivfflat_append(x_pad, dpad_, n, d, d_dest, arena_.as<float>(), dpad_, dpad_, res_->stream);
+}
+void GpuIndexIVFFlat::scan_(int nq, const float* xq_pad, int, const int64_t*) const {
+    IvfScanParams p{};
+    p.metric = metric_type;
+    p.nq = nq;
+    p.nprobe = nprobe_eff_;
+    p.d = d;
+    p.dpad = dpad_;
+    p.xq = xq_pad;
+    p.ldq = dpad_;
+    p.coarse_ids = c_ids_.as<idx_t>();
+    p.coarse_dis = c_dis_.as<float>();
+    p.list_len = d_list_len_.as<uint32_t>();
+    p.list_start = d_list_start_.as<int64_t>();
+    p.prefix = prefix_.as<uint32_t>();
+    p.q_off = q_off_.as<int64_t>();
+    p.keys = keys_.as<unsigned long long>();
+    p.arena_vecs = arena_.as<float>();
+    p.ldv = dpad_;
+    SpanGuard sg(res_.get(), "ivfflat_scan_kernel");
+    launch_ivfflat_scan(p, res_->stream);
+}
+
+// ---------------------------------------------------------------------- IVFPQ
+GpuIndexIVFPQ::GpuIndexIVFPQ(std::shared_ptr<GpuResources> res, int dims, int nlist, int M_, int nbits_,
+                             int metric)
+        : GpuIndexIVF(std::move(res), dims, metric, nlist), M(M_), nbits(nbits_) {
+    // same restrictions as the reference GPU index (faiss/gpu/GpuIndexIVFPQ.cu:574-617), minus its
+    // shared-memory limit on M: 160 KB of LDS holds an fp32 table up to M = 128.
+    FA_THROW_IF_NOT_MSG(nbits == 8, "only 8 bits per code are supported");
+    FA_THROW_IF_NOT_MSG(M > 0 && dims % M == 0, "d must be a multiple of M");
+    dsub = dims / M;
+    FA_THROW_IF_NOT_MSG(ivfpq_scan_lds_bytes(M, dpad_) <= 160 * 1024, "M too large for the LDS lookup table");
+    code_bytes_ = (size_t)M;
+    FA_THROW_IF_NOT_MSG(M % 4 == 0, "M must be a multiple of 4");
+}
+void GpuIndexIVFPQ::set_pq_centroids(const float* pq) {
+    res_->set_device();
+    pq_.ensure((size_t)M * 256 * dsub * 4);
+    HIP_CHECK(hipMemcpy(pq_.p, pq, (size_t)M * 256 * dsub * 4,
+                        is_device_pointer(pq) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+}
+std::vector<float> GpuIndexIVFPQ::get_pq_centroids() const {
+    res_->set_device();
+    std::vector<float> out((size_t)M * 256 * dsub);
+    FA_THROW_IF_NOT_MSG(pq_.p, "PQ not trained");
+    HIP_CHECK(hipMemcpy(out.data(), pq_.p, out.size() * 4, hipMemcpyDeviceToHost));
+    return out;
+}
+void GpuIndexIVFPQ::train_residual_(idx_t n, const float* x_dev_pad) {
+    // reference: GpuIndexIVFPQ::trainResidualQuantizer_ (faiss/gpu/GpuIndexIVFPQ.cu:287-340):
+    // residuals of the training set w.r.t. their nearest centroid, then one k-means (256
+    // centroids, dsub dims) per sub-quantizer with a GPU flat index as assignment engine
+    // (faiss/impl/ProductQuantizer.cpp:130-207).
+    const GpuResources& R = *res_;
+    idx_t nt = std::min<idx_t>(n, (idx_t)256 * 256); // max_points_per_centroid * ksub
+    DevBuf dlab, ddis, dres;
+    dlab.ensure((size_t)nt * 8);
+    ddis.ensure((size_t)nt * 4);
+    dres.ensure((size_t)nt * d * 4);
+    quantizer->search_device((int)nt, x_dev_pad, 1, ddis.as<float>(), dlab.as<idx_t>());
+    launch_residual(x_dev_pad, dpad_, nt, d, dlab.as<idx_t>(), quantizer->device_vectors(), dpad_,
+                    dres.as<float>(), d, R.stream);
+    std::vector<float> hres((size_t)nt * d);
+    HIP_CHECK(hipMemcpyAsync(hres.data(), dres.p, hres.size() * 4, hipMemcpyDeviceToHost, R.stream));
+    R.sync();
+    std::vector<float> pq((size_t)M * 256 * dsub);
+    std::vector<float> slice((size_t)nt * dsub);
+    GpuIndexFlat assign_index(res_, dsub, METRIC_L2);
+    for (int m = 0; m < M; m++) {
+        for (idx_t i = 0; i < nt; i++)
+            memcpy(&slice[(size_t)i * dsub], &hres[(size_t)i * d + (size_t)m * dsub], sizeof(float) * dsub);
+        Clustering clus(dsub, 256);
+        clus.niter = pq_niter;
+        clus.seed = cp_seed + m;
+        clus.train(nt, slice.data(), assign_index);
+        memcpy(&pq[(size_t)m * 256 * dsub], clus.centroids.data(), sizeof(float) * 256 * dsub);
+    }
+    pq_.ensure(pq.size() * 4);
+    HIP_CHECK(hipMemcpy(pq_.p, pq.data(), pq.size() * 4, hipMemcpyHostToDevice));
+}
+void GpuIndexIVFPQ::append_(int n, const float* x_pad, const int64_t* d_labels, const int64_t* d_dest) {
+    FA_THROW_IF_NOT_MSG(pq_.p, "PQ not trained");
+    launch_ivfpq_encode_append(x_pad, dpad_, n, d, d_labels, d_dest, quantizer->device_vectors(), dpad_, M,
+                               dsub, pq_.as<float>(), arena_.as<uint8_t>(), res_->stream);
+}
+void GpuIndexIVFPQ::scan_(int nq, const float* xq_pad, int, const int64_t*) const {
+    FA_THROW_IF_NOT_MSG(pq_.p, "PQ not trained");
+    IvfScanParams p{};
+    p.metric = metric_type;
+    p.nq = nq;
+    p.nprobe = nprobe_eff_;
+    p.d = d;
+    p.dpad = dpad_;
+    p.xq = xq_pad;
+    p.ldq = dpad_;
+    p.coarse_ids = c_ids_.as<idx_t>();
+    p.coarse_dis = c_dis_.as<float>();
+    p.list_len = d_list_len_.as<uint32_t>();
+    p.list_start = d_list_start_.as<int64_t>();
+    p.prefix = prefix_.as<uint32_t>();
+    p.q_off = q_off_.as<int64_t>();
+    p.keys = keys_.as<unsigned long long>();
+    p.centroids = quantizer->device_vectors();
+    p.ldc = dpad_;
+    p.M = M;
+    p.dsub = dsub;
+    p.pq_centroids = pq_.as<float>();
+    p.arena_codes = arena_.as<uint8_t>();
+    SpanGuard sg(res_.get(), "ivfpq_scan_kernel");
+    launch_ivfpq_scan(p, res_->stream);
+}
+
+// ====================================================================== shards
+void merge_knn_results(int metric, idx_t nq, idx_t k, int nshard, const float* all_d, const idx_t* all_i,
+                       const idx_t* base, float* D, idx_t* I) {
+    // k-way merge of sorted lists; ties on distance go to the smaller label, so the merged
+    // result equals an unsharded search (reference merge: faiss/utils/Heap.cpp:166-240)
+    const bool l2 = metric == METRIC_L2;
+    std::vector<idx_t> ptr(nshard);
+    for (idx_t q = 0; q < nq; q++) {
+        std::fill(ptr.begin(), ptr.end(), 0);
+        for (idx_t j = 0; j < k; j++) {
+            int best = -1;
+            float bd = 0;
+            idx_t bi = 0;
+            for (int s = 0; s < nshard; s++) {
+                if (ptr[s] >= k) continue;
+                size_t off = ((size_t)s * nq + q) * k + ptr[s];
+                idx_t id = all_i[off];
+                if (id < 0) continue; // exhausted shard (padding)
+                float dv = all_d[off];
+                idx_t gid = id + (base ? base[s] : 0);
+                bool better = best < 0 || (l2 ? dv < bd : dv > bd) || (dv == bd && gid < bi);
+                if (better) {
+                    best = s;
+                    bd = dv;
+                    bi = gid;
+                }
+            }
+            if (best < 0) {
+                D[q * k + j] = neutral_distance(metric);
+                I[q * k + j] = -1;
+            } else {
+                D[q * k + j] = bd;
+                I[q * k + j] = bi;
+                ptr[best]++;
+            }
+        }
+    }
+}
+
+IndexShards::IndexShards(int d_, bool threaded_, bool successive_ids_)
+        : Index(d_, METRIC_L2), threaded(threaded_), successive_ids(successive_ids_) {}
+IndexShards::~IndexShards() {
+    if (own_indices)
+        for (auto* s : shards_) delete s;
+}
+void IndexShards::sync_() {
+    // reference: IndexShardsTemplate::syncWithSubIndexes (faiss/IndexShards.cpp:87-110)
+    if (shards_.empty()) {
+        ntotal = 0;
+        is_trained = false;
+        return;
+    }
+    metric_type = shards_[0]->metric_type;
+    is_trained = shards_[0]->is_trained;
+    ntotal = 0;
+    for (auto* s : shards_) {
+        FA_THROW_IF_NOT_MSG(s->d == d, "shard dimension mismatch");
+        FA_THROW_IF_NOT_MSG(s->metric_type == metric_type, "shard metric mismatch");
+        FA_THROW_IF_NOT_MSG(s->is_trained == is_trained, "shard training state mismatch");
+        ntotal += s->ntotal;
+    }
+}
+void IndexShards::add_shard(Index* idx) {
+    shards_.push_back(idx);
+    sync_();
+}
+template <typename F>
+static void run_on_shards(const std::vector<Index*>& shards, bool threaded, F f) {
+    // one host thread per shard, exceptions gathered (reference: ThreadedIndex-inl.h:120-193)
+    std::vector<std::string> errors(shards.size());
+    auto body = [&](int s) {
+        try {
+            f(s, shards[s]);
+        } catch (std::exception& e) {
+            errors[s] = e.what();
+            if (errors[s].empty()) errors[s] = "unknown error";
+        }
+    };
+    if (threaded && shards.size() > 1) {
+        std::vector<std::thread> th;
+        for (int s = 0; s < (int)shards.size(); s++) th.emplace_back(body, s);
+        for (auto& t : th) t.join();
+    } else {
+        for (int s = 0; s < (int)shards.size(); s++) body(s);
+    }
+    std::string all;
+    for (size_t s = 0; s < errors.size(); s++)
+        if (!errors[s].empty()) all += "shard " + std::to_string(s) + ": " + errors[s] + "; ";
+    if (!all.empty()) FA_THROW_MSG(all);
+}
+void IndexShards::train(idx_t n, const float* x) {
+    run_on_shards(shards_, threaded, [&](int, Index* s) { s->train(n, x); });
+    sync_();
+}
+void IndexShards::add(idx_t n, const float* x) {
+    add_with_ids(n, x, nullptr);
+}
+void IndexShards::add_with_ids(idx_t n, const float* x, const idx_t* xids) {
+    // reference: faiss/IndexShards.cpp:135-194
+    FA_THROW_IF_NOT_MSG(!(successive_ids && xids), "It makes no sense to pass in ids and request them to be shifted");
+    FA_THROW_IF_NOT_MSG(!shards_.empty(), "no shards");
+    if (successive_ids && xids == nullptr) {
+        // ok
+    }
+    const idx_t nshard = (idx_t)shards_.size();
+    std::vector<idx_t> aids;
+    const idx_t* ids = xids;
+    if (!ids && !successive_ids) {
+        aids.resize(n);
+        for (idx_t i = 0; i < n; i++) aids[i] = ntotal + i;
+        ids = aids.data();
+    }
+    run_on_shards(shards_, threaded, [&](int no, Index* s) {
+        idx_t i0 = (idx_t)no * n / nshard;
+        idx_t i1 = ((idx_t)no + 1) * n / nshard;
+        const float* x0 = x + (size_t)i0 * d;
+        if (i1 == i0) return;
+        if (ids) s->add_with_ids(i1 - i0, x0, ids + i0);
+        else s->add(i1 - i0, x0);
+    });
+    sync_();
+}
+void IndexShards::reset() {
+    run_on_shards(shards_, threaded, [&](int, Index* s) { s->reset(); });
+    sync_();
+}
+void IndexShards::search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels) const {
+    // reference: faiss/IndexShards.cpp:196-265
+    FA_THROW_IF_NOT_MSG(k > 0, "k must be positive");
+    const int nshard = (int)shards_.size();
+    FA_THROW_IF_NOT_MSG(nshard > 0, "no shards");
+    std::vector<float> all_d((size_t)nshard * n * k);
+    std::vector<idx_t> all_i((size_t)nshard * n * k);
+    std::vector<idx_t> base(nshard, 0);
+    if (successive_ids) {
+        idx_t t = 0;
+        for (int s = 0; s < nshard; s++) {
+            base[s] = t;
+            t += shards_[s]->ntotal;
+        }
+    }
+    run_on_shards(shards_, threaded, [&](int no, Index* s) {
+        s->search(n, x, k, all_d.data() + (size_t)no * n * k, all_i.data() + (size_t)no * n * k);
+    });
+    merge_knn_results(metric_type, n, k, nshard, all_d.data(), all_i.data(),
+                      successive_ids ? base.data() : nullptr, distances, labels);
+}
+
+} // namespace faiss_amd

@@ -1,0 +1,259 @@
+// faiss_amd/csrc/index.h -- host-side C++ mirror of the reference interface for the hot path.
+//
+// Class and method names follow the reference so that its tests read the same here:
+//   faiss::Index                      faiss/Index.h:101-431
+//   faiss::gpu::StandardGpuResources  faiss/gpu/StandardGpuResources.h
+//   faiss::gpu::GpuIndexFlat          faiss/gpu/GpuIndexFlat.h:41-153
+//   faiss::gpu::GpuIndexIVF           faiss/gpu/GpuIndexIVF.h:37-153
+//   faiss::gpu::GpuIndexIVFFlat       faiss/gpu/GpuIndexIVFFlat.h:33-126
+//   faiss::gpu::GpuIndexIVFPQ         faiss/gpu/GpuIndexIVFPQ.h:53-176
+//   faiss::IndexShards                faiss/IndexShards.h:19-108
+//   faiss::Clustering                 faiss/Clustering.h:88-196
+// The implementation is new (HIP runtime + the kernels in kernels.h); no reference code.
+#pragma once
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+#include "common.h"
+
+namespace faiss_amd {
+
+// ------------------------------------------------------------------ device memory helpers
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf();
+    // grow (never shrinks); contents preserved up to keep_bytes
+    void ensure(size_t bytes, size_t keep_bytes = 0, hipStream_t stream = nullptr);
+    void release();
+    template <typename T>
+    T* as() const {
+        return (T*)p;
+    }
+};
+
+bool is_device_pointer(const void* p);
+
+// ------------------------------------------------------------------ resources
+// One per device (and per host thread driving it), like StandardGpuResources: owns the
+// stream all work of its indexes is ordered on, and per-kernel HIP-event timing.
+class GpuResources {
+   public:
+    explicit GpuResources(int device = 0);
+    ~GpuResources();
+    int device;
+    hipStream_t stream = nullptr;
+    int num_cus = 256;
+    size_t temp_budget_bytes = (size_t)4 << 30; // cap for per-search scratch (reservoirs, IVF keys)
+
+    void set_device() const;
+    void sync() const;
+
+    // ---- per-kernel timing with HIP events on `stream`
+    bool profiling = false;
+    struct Span {
+        hipEvent_t a, b;
+        std::string name;
+    };
+    mutable std::vector<Span> spans;
+    mutable std::map<std::string, std::pair<double, long>> totals; // name -> (ms, launches)
+    void begin_span(const char* name) const;
+    void end_span() const;
+    void collect() const; // sync + fold spans into totals
+    void reset_profile() const;
+};
+
+struct SpanGuard {
+    const GpuResources* r;
+    SpanGuard(const GpuResources* r_, const char* name) : r(r_) {
+        if (r->profiling) r->begin_span(name);
+    }
+    ~SpanGuard() {
+        if (r->profiling) r->end_span();
+    }
+};
+
+// ------------------------------------------------------------------ faiss::Index mirror
+struct Index {
+    int d = 0;
+    idx_t ntotal = 0;
+    bool verbose = false;
+    bool is_trained = true;
+    int metric_type = METRIC_L2;
+
+    explicit Index(int d_ = 0, int metric = METRIC_L2) : d(d_), metric_type(metric) {}
+    virtual ~Index() {}
+
+    virtual void train(idx_t n, const float* x) {}
+    virtual void add(idx_t n, const float* x) = 0;
+    virtual void add_with_ids(idx_t n, const float* x, const idx_t* xids);
+    virtual void search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels) const = 0;
+    virtual void assign(idx_t n, const float* x, idx_t* labels, idx_t k = 1) const;
+    virtual void reset() = 0;
+    virtual void reconstruct(idx_t key, float* recons) const;
+    virtual void reconstruct_n(idx_t i0, idx_t ni, float* recons) const;
+    virtual void compute_residual(const float* x, float* residual, idx_t key) const;
+    virtual int device() const { return -1; }
+};
+
+// ------------------------------------------------------------------ GpuIndexFlat
+class GpuIndexFlat : public Index {
+   public:
+    GpuIndexFlat(std::shared_ptr<GpuResources> res, int dims, int metric);
+    ~GpuIndexFlat() override;
+
+    void add(idx_t n, const float* x) override;
+    void search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels) const override;
+    void reset() override;
+    void reconstruct(idx_t key, float* recons) const override;
+    void reconstruct_n(idx_t i0, idx_t ni, float* recons) const override;
+    int device() const override { return res_->device; }
+    size_t getNumVecs() const { return (size_t)ntotal; }
+
+    // device-resident search used internally (IVF coarse quantizer): xq_pad is [n][dpad] on the
+    // device; results stay on the device.
+    void search_device(int n, const float* xq_pad, int k, float* dD, idx_t* dI) const;
+    // test hook: full distance matrix [n][ntotal] through the MFMA kernel (host or device out)
+    void pairwise_distances(idx_t n, const float* x, float* out) const;
+    // when true, search() uses the scalar cross-check kernel instead of the MFMA kernel
+    bool use_simple_kernel = false;
+
+    int dpad() const { return dpad_; }
+    const float* device_vectors() const { return xb_.as<float>(); }
+    std::shared_ptr<GpuResources> resources() const { return res_; }
+
+   private:
+    std::shared_ptr<GpuResources> res_;
+    int dpad_;
+    DevBuf xb_;  // [cap][dpad]
+    DevBuf xbn_; // [cap]
+    mutable std::mutex mu_;
+    // persistent scratch
+    mutable DevBuf q_raw_, q_pad_, q_norm_, res_keys_, res_cnt_, out_d_, out_i_, all_keys_, one_cnt_;
+    void search_tile_(int n, const float* xq_pad, int k, float* dD, idx_t* dI) const;
+};
+
+// ------------------------------------------------------------------ GpuIndexIVF
+class GpuIndexIVF : public Index {
+   public:
+    GpuIndexIVF(std::shared_ptr<GpuResources> res, int dims, int metric, int nlist);
+    ~GpuIndexIVF() override;
+
+    int nlist;
+    int nprobe = 1;
+    GpuIndexFlat* quantizer; // owned
+
+    void train(idx_t n, const float* x) override;
+    void add(idx_t n, const float* x) override;
+    void add_with_ids(idx_t n, const float* x, const idx_t* xids) override;
+    void search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels) const override;
+    void reset() override;
+    int device() const override { return res_->device; }
+
+    // mirrors GpuIndexIVF::getListLength / getListIndices (faiss/gpu/GpuIndexIVF.h:97-110)
+    size_t getListLength(idx_t list) const { return list_len_[list]; }
+    std::vector<idx_t> getListIndices(idx_t list) const;
+    std::vector<uint8_t> getListVectorData(idx_t list) const;
+    // copyFrom-style bulk load (train state + inverted lists), see include/faiss_amd_c.h
+    void set_centroids(const float* centroids);
+    void set_lists(const uint32_t* list_sizes, const uint8_t* codes, const idx_t* ids);
+    // Clustering parameters used by train() (reference default niter=10 for the GPU IVF
+    // quantizer, faiss/gpu/GpuIndexIVF.cu:80)
+    int cp_niter = 10;
+    int cp_seed = 1234;
+
+   protected:
+    std::shared_ptr<GpuResources> res_;
+    int dpad_;
+    size_t code_bytes_ = 0; // bytes per arena entry (ldv*4 for IVFFlat, M for IVFPQ)
+    std::vector<uint32_t> list_len_;
+    std::vector<int64_t> list_start_;
+    DevBuf d_list_len_, d_list_start_, arena_, arena_ids_;
+    mutable std::mutex mu_;
+    mutable DevBuf q_raw_, q_pad_, c_dis_, c_ids_, prefix_, totals_, q_off_, keys_, out_d_, out_i_, one_cnt_;
+    mutable int nprobe_eff_ = 1; // min(nprobe, nlist) of the search in flight
+
+    virtual void train_residual_(idx_t n, const float* x_dev_pad) {}
+    // encode/scatter n staged vectors (device, padded) with given labels into arena rows dest
+    virtual void append_(int n, const float* x_pad, const int64_t* d_labels, const int64_t* d_dest) = 0;
+    virtual void scan_(int nq, const float* xq_pad, int k, const int64_t* h_qoff) const = 0;
+    void upload_list_tables_();
+};
+
+class GpuIndexIVFFlat : public GpuIndexIVF {
+   public:
+    GpuIndexIVFFlat(std::shared_ptr<GpuResources> res, int dims, int nlist, int metric);
+
+   protected:
+    void append_(int n, const float* x_pad, const int64_t* d_labels, const int64_t* d_dest) override;
+    void scan_(int nq, const float* xq_pad, int k, const int64_t* h_qoff) const override;
+};
+
+class GpuIndexIVFPQ : public GpuIndexIVF {
+   public:
+    GpuIndexIVFPQ(std::shared_ptr<GpuResources> res, int dims, int nlist, int M, int nbits, int metric);
+    int M, nbits, dsub;
+    int pq_niter = 25; // faiss::ClusteringParameters default used by ProductQuantizer::train
+    void set_pq_centroids(const float* pq); // [M][256][dsub]
+    std::vector<float> get_pq_centroids() const;
+
+   protected:
+    DevBuf pq_; // [M][256][dsub]
+    void train_residual_(idx_t n, const float* x_dev_pad) override;
+    void append_(int n, const float* x_pad, const int64_t* d_labels, const int64_t* d_dest) override;
+    void scan_(int nq, const float* xq_pad, int k, const int64_t* h_qoff) const override;
+};
+
+// ------------------------------------------------------------------ IndexShards
+// Database-sharded meta index: add() splits rows evenly over the shards, search() runs every
+// shard on its own host thread and k-way merges the partial results on the host
+// (faiss/IndexShards.cpp:135-265, faiss/utils/Heap.cpp:166-240).
+class IndexShards : public Index {
+   public:
+    IndexShards(int d, bool threaded, bool successive_ids);
+    ~IndexShards() override;
+    bool threaded, successive_ids;
+    bool own_indices = false;
+    void add_shard(Index* idx);
+    int count() const { return (int)shards_.size(); }
+    Index* at(int i) { return shards_[i]; }
+    void train(idx_t n, const float* x) override;
+    void add(idx_t n, const float* x) override;
+    void add_with_ids(idx_t n, const float* x, const idx_t* xids) override;
+    void search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels) const override;
+    void reset() override;
+
+   private:
+    std::vector<Index*> shards_;
+    void sync_();
+};
+
+// merge nshard sorted partial results [s][nq][k] into [nq][k] under (distance, label) order;
+// base[s] is added to shard s's labels (successive_ids translation), may be null.
+void merge_knn_results(int metric, idx_t nq, idx_t k, int nshard, const float* all_d, const idx_t* all_i,
+                       const idx_t* base, float* D, idx_t* I);
+
+// ------------------------------------------------------------------ Clustering (k-means)
+struct ClusteringParameters {
+    int niter = 25;
+    int seed = 1234;
+    int max_points_per_centroid = 256;
+    int min_points_per_centroid = 39;
+    bool verbose = false;
+};
+struct Clustering : ClusteringParameters {
+    int d, k;
+    std::vector<float> centroids; // [k][d]
+    std::vector<float> obj;       // objective (sum of distances) per iteration
+    Clustering(int d_, int k_) : d(d_), k(k_) {}
+    // x on the host; `index` is the assignment engine (reset / add(k centroids) / search k=1),
+    // exactly how the reference drives a GPU flat index (faiss/Clustering.cpp:255-357).
+    void train(idx_t n, const float* x, Index& index);
+};
+
+} // namespace faiss_amd

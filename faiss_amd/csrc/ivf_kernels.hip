@@ -1,0 +1,313 @@
+// faiss_amd/csrc/ivf_kernels.hip -- inverted-file scans (IVFFlat, IVFPQ) and the add path, gfx950.
+//
+// Round-1 layout: every inverted list is a contiguous row range of one device arena
+// (list_start[l], list_len[l]); vectors row-major fp32 (IVFFlat) or M-byte PQ codes (IVFPQ),
+// user ids in a parallel int64 arena.  (The reference keeps one growable DeviceVector per
+// list, faiss/gpu/impl/IVFBase.cuh:220-299; a single arena costs one allocation and lets
+// 288 GB of HBM be sized once.)
+//
+// Arithmetic contract (restated by oracle/faiss_oracle.c):
+//   IVFFlat L2 : dis = chain_k fmaf(q[k]-y[k], q[k]-y[k], acc), k ascending
+//                (direct form as the CPU scanner, faiss/utils/simd_impl/IVFFlatScanner-inl.h:20-27)
+//   IVFFlat IP : dis = chain_k fmaf(q[k], y[k], acc)
+//   IVFPQ  L2  : r = q - centroid;  lut[m][c] = chain_j fmaf(r_mj - pq[m][c][j], same, acc);
+//                dis = ((0 + lut[0][c0]) + lut[1][c1]) + ...      (m ascending)
+//                (faiss/gpu/impl/PQCodeDistances-inl.cuh:29-285 semantics, by_residual,
+//                 no precomputed table; CPU counterpart faiss/IndexIVFPQ.cpp scan_list_with_table)
+//   IVFPQ  IP  : lut[m][c] = chain_j fmaf(q_mj, pq[m][c][j], acc);  dis = coarse_ip + sum_m lut
+//   PQ encode  : code[m] = first argmin_c of the L2 lut expression above
+//                (faiss/impl/ProductQuantizer.cpp compute_code)
+#include "kernels.h"
+
+namespace faiss_amd {
+
+typedef unsigned long long u64;
+
+// ---------------------------------------------------------------------------------
+__global__ void ivf_prefix_kernel(const int64_t* __restrict__ coarse_ids, int nq, int nprobe,
+                                  const uint32_t* __restrict__ list_len, uint32_t* __restrict__ prefix,
+                                  uint32_t* __restrict__ total) {
+    int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    uint32_t acc = 0;
+    uint32_t* pr = prefix + (int64_t)q * (nprobe + 1);
+    for (int p = 0; p < nprobe; ++p) {
+        pr[p] = acc;
+        int64_t l = coarse_ids[(int64_t)q * nprobe + p];
+        if (l >= 0) acc += list_len[l];
+    }
+    pr[nprobe] = acc;
+    total[q] = acc;
+}
+
+void launch_ivf_prefix(const int64_t* coarse_ids, int nq, int nprobe, const uint32_t* list_len,
+                       uint32_t* prefix, uint32_t* total, hipStream_t stream) {
+    if (nq == 0) return;
+    hipLaunchKernelGGL(ivf_prefix_kernel, dim3((unsigned)div_up(nq, 128)), dim3(128), 0, stream,
+                       coarse_ids, nq, nprobe, list_len, prefix, total);
+    HIP_CHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------
+// IVFFlat scan: one workgroup per (probe, query)
+// ---------------------------------------------------------------------------------
+template <int METRIC>
+__global__ void __launch_bounds__(256) ivfflat_scan_kernel(IvfScanParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* qs = (float*)smem; // [dpad]
+    const int pr = blockIdx.x, q = blockIdx.y;
+    const int64_t list = p.coarse_ids[(int64_t)q * p.nprobe + pr];
+    if (list < 0) return;
+    const unsigned len = p.list_len[list];
+    if (len == 0) return;
+    const int64_t start = p.list_start[list];
+    const uint32_t pos0 = p.prefix[(int64_t)q * (p.nprobe + 1) + pr];
+    u64* out = p.keys + p.q_off[q] + pos0;
+    for (int c = threadIdx.x; c < p.dpad; c += blockDim.x) qs[c] = p.xq[(int64_t)q * p.ldq + c];
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i < len; i += blockDim.x) {
+        const float* y = p.arena_vecs + (start + i) * p.ldv;
+        float acc = 0.f;
+        for (int k = 0; k < p.dpad; k += 4) {
+            const float4 yv = *(const float4*)(y + k);
+            const float4 qv = *(const float4*)(qs + k);
+            if (METRIC == METRIC_L2) {
+                float t;
+                t = qv.x - yv.x; acc = __fmaf_rn(t, t, acc);
+                t = qv.y - yv.y; acc = __fmaf_rn(t, t, acc);
+                t = qv.z - yv.z; acc = __fmaf_rn(t, t, acc);
+                t = qv.w - yv.w; acc = __fmaf_rn(t, t, acc);
+            } else {
+                acc = __fmaf_rn(qv.x, yv.x, acc);
+                acc = __fmaf_rn(qv.y, yv.y, acc);
+                acc = __fmaf_rn(qv.z, yv.z, acc);
+                acc = __fmaf_rn(qv.w, yv.w, acc);
+            }
+        }
+        out[i] = ((u64)ordkey<METRIC>(acc) << 32) | (u64)(pos0 + i);
+    }
+}
+
+void launch_ivfflat_scan(const IvfScanParams& p, hipStream_t stream) {
+    if (p.nq == 0 || p.nprobe == 0) return;
+    dim3 grid((unsigned)p.nprobe, (unsigned)p.nq), block(256);
+    size_t lds = (size_t)p.dpad * 4;
+    if (p.metric == METRIC_L2)
+        hipLaunchKernelGGL((ivfflat_scan_kernel<METRIC_L2>), grid, block, lds, stream, p);
+    else
+        hipLaunchKernelGGL((ivfflat_scan_kernel<METRIC_INNER_PRODUCT>), grid, block, lds, stream, p);
+    HIP_CHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------
+// IVFPQ scan: one workgroup per (probe, query); LUT [M][256] fp32 resident in LDS
+// ---------------------------------------------------------------------------------
+size_t ivfpq_scan_lds_bytes(int M, int dpad) {
+    return (size_t)M * 256 * 4 + (size_t)dpad * 4;
+}
+
+template <int METRIC>
+__global__ void __launch_bounds__(256) ivfpq_scan_kernel(IvfScanParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* lut = (float*)smem;          // [M][256]
+    float* rs = lut + (size_t)p.M * 256; // [dpad] residual (L2) or query (IP)
+    const int pr = blockIdx.x, q = blockIdx.y;
+    const int64_t list = p.coarse_ids[(int64_t)q * p.nprobe + pr];
+    if (list < 0) return;
+    const unsigned len = p.list_len[list];
+    if (len == 0) return;
+    const int64_t start = p.list_start[list];
+    const uint32_t pos0 = p.prefix[(int64_t)q * (p.nprobe + 1) + pr];
+    u64* out = p.keys + p.q_off[q] + pos0;
+    const int d = p.d;
+    for (int c = threadIdx.x; c < d; c += blockDim.x) {
+        float v = p.xq[(int64_t)q * p.ldq + c];
+        if (METRIC == METRIC_L2) v = v - p.centroids[list * p.ldc + c];
+        rs[c] = v;
+    }
+    __syncthreads();
+    // ---- lookup table
+    const int dsub = p.dsub;
+    for (int e = threadIdx.x; e < p.M * 256; e += blockDim.x) {
+        const int m = e >> 8;
+        const float* cen = p.pq_centroids + (size_t)e * dsub; // [m][c][dsub]
+        const float* r = rs + m * dsub;
+        float acc = 0.f;
+        for (int jd = 0; jd < dsub; ++jd) {
+            if (METRIC == METRIC_L2) {
+                float t = r[jd] - cen[jd];
+                acc = __fmaf_rn(t, t, acc);
+            } else {
+                acc = __fmaf_rn(r[jd], cen[jd], acc);
+            }
+        }
+        lut[e] = acc;
+    }
+    __syncthreads();
+    // ---- scan: one code per thread
+    const float dis0 = METRIC == METRIC_L2 ? 0.f : p.coarse_dis[(int64_t)q * p.nprobe + pr];
+    const int M = p.M;
+    for (unsigned i = threadIdx.x; i < len; i += blockDim.x) {
+        const uint8_t* code = p.arena_codes + (start + i) * M;
+        float acc = dis0;
+        int m = 0;
+        if ((M & 15) == 0) {
+            for (; m < M; m += 16) {
+                const uint4 cw = *(const uint4*)(code + m);
+                const unsigned w[4] = {cw.x, cw.y, cw.z, cw.w};
+#pragma unroll
+                for (int wi = 0; wi < 4; ++wi) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const unsigned c = (w[wi] >> (8 * b)) & 255u;
+                        acc = acc + lut[(m + wi * 4 + b) * 256 + c];
+                    }
+                }
+            }
+        } else {
+            for (; m < M; ++m) acc = acc + lut[m * 256 + code[m]];
+        }
+        out[i] = ((u64)ordkey<METRIC>(acc) << 32) | (u64)(pos0 + i);
+    }
+}
+
+void launch_ivfpq_scan(const IvfScanParams& p, hipStream_t stream) {
+    if (p.nq == 0 || p.nprobe == 0) return;
+    dim3 grid((unsigned)p.nprobe, (unsigned)p.nq), block(256);
+    size_t lds = ivfpq_scan_lds_bytes(p.M, p.dpad);
+    if (p.metric == METRIC_L2) {
+        HIP_CHECK(hipFuncSetAttribute((const void*)ivfpq_scan_kernel<METRIC_L2>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((ivfpq_scan_kernel<METRIC_L2>), grid, block, lds, stream, p);
+    } else {
+        HIP_CHECK(hipFuncSetAttribute((const void*)ivfpq_scan_kernel<METRIC_INNER_PRODUCT>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((ivfpq_scan_kernel<METRIC_INNER_PRODUCT>), grid, block, lds, stream, p);
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------
+// add path
+// ---------------------------------------------------------------------------------
+__global__ void ivfflat_append_kernel(const float* __restrict__ x, int64_t ldx, int n, int d,
+                                      const int64_t* __restrict__ dest, float* __restrict__ arena,
+                                      int64_t ldv, int dpad) {
+    const int i = blockIdx.x;
+    const int64_t dst = dest[i];
+    if (dst < 0) return;
+    for (int c = threadIdx.x; c < dpad; c += blockDim.x)
+        arena[dst * ldv + c] = c < d ? x[(int64_t)i * ldx + c] : 0.f;
+}
+
+void launch_ivfflat_append(const float* x, int64_t ldx, int n, int d, const int64_t* dest,
+                           float* arena_vecs, int64_t ldv, int dpad, hipStream_t stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(ivfflat_append_kernel, dim3((unsigned)n), dim3(64), 0, stream, x, ldx, n, d, dest,
+                       arena_vecs, ldv, dpad);
+    HIP_CHECK(hipGetLastError());
+}
+
+// one thread per (vector, sub-quantizer)
+__global__ void ivfpq_encode_append_kernel(const float* __restrict__ x, int64_t ldx, int n, int d,
+                                           const int64_t* __restrict__ labels,
+                                           const int64_t* __restrict__ dest,
+                                           const float* __restrict__ centroids, int64_t ldc, int M,
+                                           int dsub, const float* __restrict__ pq,
+                                           uint8_t* __restrict__ codes) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)n * M) return;
+    const int i = (int)(t / M), m = (int)(t % M);
+    const int64_t dst = dest[i];
+    if (dst < 0) return;
+    const int64_t list = labels[i];
+    const float* xr = x + (int64_t)i * ldx + m * dsub;
+    const float* cr = centroids + list * ldc + m * dsub;
+    const float* pm = pq + (size_t)m * 256 * dsub;
+    float best = INFINITY;
+    int bestc = 0;
+    for (int c = 0; c < 256; ++c) {
+        const float* cen = pm + c * dsub;
+        float acc = 0.f;
+        for (int jd = 0; jd < dsub; ++jd) {
+            float r = xr[jd] - cr[jd];
+            float tt = r - cen[jd];
+            acc = __fmaf_rn(tt, tt, acc);
+        }
+        if (acc < best) {
+            best = acc;
+            bestc = c;
+        }
+    }
+    codes[dst * M + m] = (uint8_t)bestc;
+}
+
+void launch_ivfpq_encode_append(const float* x, int64_t ldx, int n, int d, const int64_t* labels,
+                                const int64_t* dest, const float* centroids, int64_t ldc, int M,
+                                int dsub, const float* pq_centroids, uint8_t* arena_codes,
+                                hipStream_t stream) {
+    if (n == 0) return;
+    int64_t total = (int64_t)n * M;
+    hipLaunchKernelGGL(ivfpq_encode_append_kernel, dim3((unsigned)div_up(total, 256)), dim3(256), 0,
+                       stream, x, ldx, n, d, labels, dest, centroids, ldc, M, dsub, pq_centroids,
+                       arena_codes);
+    HIP_CHECK(hipGetLastError());
+}
+
+__global__ void move_lists_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                  const int64_t* __restrict__ old_start,
+                                  const int64_t* __restrict__ new_start,
+                                  const uint32_t* __restrict__ len, int bytes_per_row) {
+    const int l = blockIdx.x;
+    const int64_t words = (int64_t)len[l] * (bytes_per_row >> 2);
+    const uint32_t* s = (const uint32_t*)(src + old_start[l] * bytes_per_row);
+    uint32_t* t = (uint32_t*)(dst + new_start[l] * bytes_per_row);
+    for (int64_t w = threadIdx.x; w < words; w += blockDim.x) t[w] = s[w];
+}
+
+void launch_move_lists(const uint8_t* src, uint8_t* dst, const int64_t* old_start,
+                       const int64_t* new_start, const uint32_t* len, int nlist, int bytes_per_row,
+                       hipStream_t stream) {
+    if (nlist == 0) return;
+    FA_THROW_IF_NOT(bytes_per_row % 4 == 0);
+    hipLaunchKernelGGL(move_lists_kernel, dim3((unsigned)nlist), dim3(256), 0, stream, src, dst, old_start,
+                       new_start, len, bytes_per_row);
+    HIP_CHECK(hipGetLastError());
+}
+
+__global__ void scatter_i64_kernel(const int64_t* __restrict__ src, const int64_t* __restrict__ dest,
+                                   int64_t n, int64_t* __restrict__ dst) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t t = dest[i];
+    if (t >= 0) dst[t] = src[i];
+}
+
+void launch_scatter_i64(const int64_t* src, const int64_t* dest, int64_t n, int64_t* dst,
+                        hipStream_t stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(scatter_i64_kernel, dim3((unsigned)div_up(n, 256)), dim3(256), 0, stream, src, dest,
+                       n, dst);
+    HIP_CHECK(hipGetLastError());
+}
+
+__global__ void residual_kernel(const float* __restrict__ x, int64_t ldx, int64_t n, int d,
+                                const int64_t* __restrict__ labels, const float* __restrict__ centroids,
+                                int64_t ldc, float* __restrict__ out, int64_t ldo) {
+    const int64_t i = blockIdx.x;
+    const int64_t l = labels[i];
+    for (int c = threadIdx.x; c < d; c += blockDim.x) {
+        float v = x[i * ldx + c];
+        out[i * ldo + c] = l >= 0 ? v - centroids[l * ldc + c] : v;
+    }
+}
+
+void launch_residual(const float* x, int64_t ldx, int64_t n, int d, const int64_t* labels,
+                     const float* centroids, int64_t ldc, float* out, int64_t ldo, hipStream_t stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(residual_kernel, dim3((unsigned)n), dim3(64), 0, stream, x, ldx, n, d, labels,
+                       centroids, ldc, out, ldo);
+    HIP_CHECK(hipGetLastError());
+}
+
+} // namespace faiss_amd

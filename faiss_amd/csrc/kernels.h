@@ -1,0 +1,140 @@
+// faiss_amd/csrc/kernels.h -- host-callable launchers of the hand-written gfx950 kernels.
+// All pointers are DEVICE pointers; all launches are asynchronous on `stream`.
+#pragma once
+#include "common.h"
+
+namespace faiss_amd {
+
+// ------------------------------------------------------------------ utility kernels
+// out[i] = sum_k x[i][k]^2 as a sequential fmaf chain k = 0..d-1 (one rounding per term).
+// Replaces faiss/gpu/impl/L2Norm.cu:33-144 (l2NormRowMajor).
+void launch_l2_norms(const float* x, int64_t ld, int64_t n, int d, float* out, hipStream_t stream);
+
+// dst[i][0..dpad) = src[i][0..d) followed by zeros.  (Padded private copies let every
+// kernel use 16-byte loads and make fmaf(0,0,acc) the exact no-op tail of the dot chain.)
+void launch_pad_rows(const float* src, int64_t lds_src, int64_t n, int d, float* dst, int64_t ld_dst,
+                     int dpad, hipStream_t stream);
+
+// ------------------------------------------------------------------ Flat: fused distance + k-selection
+constexpr int kFlatQueriesPerBlock = 256; // 8 waves x 32 queries
+constexpr int kFlatTileRows = 64;
+
+struct FlatScanParams {
+    int metric;         // MetricType
+    const float* xq;    // [nq][ldq] padded queries
+    const float* xqn;   // [nq] query squared norms (L2 only; may be null for IP)
+    const float* xb;    // [nb][ldb] padded database
+    const float* xbn;   // [nb] database squared norms (L2 only)
+    int64_t ldq, ldb;
+    int nq;
+    int nb;             // < 2^31 per device index
+    int dpad;           // multiple of 8
+    int nsplit;         // database splits (each scanned by its own workgroups)
+    int rows_per_split; // multiple of kFlatTileRows
+    int ngroups;        // ceil(nq / 256)
+    int k;
+    int cap;            // reservoir capacity per (query, split); >= k + 32
+    unsigned long long* res_keys; // [nq][nsplit][cap]
+    uint32_t* res_cnt;            // [nq][nsplit]
+    float* dump;                  // optional [nq][nb] full distance matrix (tests), else null
+};
+// Fused MFMA (v_mfma_f32_32x32x2_f32) distance + threshold filter + reservoir append.
+// Replaces the GEMM -> l2SelectMinK -> sumAlongRows chain of
+// faiss/gpu/impl/Distance.cu:120-406 (runDistance) without materialising the distance tile.
+void launch_flat_scan(const FlatScanParams& p, hipStream_t stream);
+size_t flat_scan_lds_bytes();
+
+// Debug / cross-check path: scalar VALU distances with the identical fmaf chain, every
+// distance written as a 64-bit key.  keys: [nq][nb].
+void launch_flat_simple(int metric, const float* xq, const float* xqn, int64_t ldq, int nq,
+                        const float* xb, const float* xbn, int64_t ldb, int nb, int dpad,
+                        unsigned long long* keys, hipStream_t stream);
+
+// ------------------------------------------------------------------ k-selection
+struct SelectParams {
+    int metric;
+    int nq;
+    int k;
+    // candidates of query q: nseg segments; segment s holds seg_cnt[q*nseg+s] keys starting
+    // at keys + (q_off ? q_off[q] : q*q_stride) + s*seg_stride
+    const unsigned long long* keys;
+    const int64_t* q_off; // nullable
+    int64_t q_stride;
+    int nseg;
+    int64_t seg_stride;
+    const uint32_t* seg_cnt; // [nq][nseg]
+    // payload -> label translation
+    int mode; // 0: label = payload (+ id_base); 1: IVF position -> ids[list_start + off]
+    int64_t id_base;
+    // mode 1:
+    int nprobe;
+    const uint32_t* ivf_prefix;  // [nq][nprobe+1] exclusive prefix of probed list lengths
+    const int64_t* coarse_ids;   // [nq][nprobe]
+    const int64_t* list_start;   // [nlist] first entry of each list in the arena
+    const int64_t* arena_ids;    // [ntotal] user ids in arena order
+    // outputs, best first; padded with (-1, neutral distance)
+    float* out_dis;   // [nq][k]
+    int64_t* out_ids; // [nq][k]
+};
+// Exact k-selection: MSB radix select on 64-bit keys + bitonic sort of the k winners by
+// (distance, label).  Replaces faiss/gpu/utils/BlockSelectKernel.cuh:15-132 and the
+// pass1/pass2 kernels of faiss/gpu/impl/IVFUtilsSelect{1,2}.cu.
+void launch_select_k(const SelectParams& p, hipStream_t stream);
+
+// ------------------------------------------------------------------ IVF
+// prefix[q][0..nprobe] = exclusive prefix sum of list_len[coarse_ids[q][p]] (0 for id<0);
+// total[q] = prefix[q][nprobe].  (faiss/gpu/impl/IVFUtils.cu:131-186 runCalcListOffsets)
+void launch_ivf_prefix(const int64_t* coarse_ids, int nq, int nprobe, const uint32_t* list_len,
+                       uint32_t* prefix, uint32_t* total, hipStream_t stream);
+
+struct IvfScanParams {
+    int metric;
+    int nq, nprobe, d, dpad;
+    const float* xq; // [nq][ldq]
+    int64_t ldq;
+    const int64_t* coarse_ids;  // [nq][nprobe]
+    const float* coarse_dis;    // [nq][nprobe]
+    const uint32_t* list_len;   // [nlist]
+    const int64_t* list_start;  // [nlist]
+    const uint32_t* prefix;     // [nq][nprobe+1]
+    const int64_t* q_off;       // [nq] key offset of each query's candidate array
+    unsigned long long* keys;
+    // IVFFlat
+    const float* arena_vecs; // [ntotal][ldv]
+    int64_t ldv;
+    // IVFPQ
+    const float* centroids; // [nlist][ldc] coarse centroids (padded rows)
+    int64_t ldc;
+    int M, dsub;
+    const float* pq_centroids; // [M][256][dsub]
+    const uint8_t* arena_codes; // [ntotal][M]
+};
+// One workgroup per (query, probe): direct sum((q-y)^2) over the list (L2) or dot (IP).
+// Replaces faiss/gpu/impl/IVFFlatScan.cu:135-183 / IVFInterleaved.cuh:33-224.
+void launch_ivfflat_scan(const IvfScanParams& p, hipStream_t stream);
+// One workgroup per (query, probe): residual -> LDS lookup table [M][256] -> code scan.
+// Replaces PQCodeDistances-inl.cuh:29-285 + PQScanMultiPassNoPrecomputed-inl.cuh:173-270;
+// the table never leaves LDS.
+void launch_ivfpq_scan(const IvfScanParams& p, hipStream_t stream);
+size_t ivfpq_scan_lds_bytes(int M, int dpad);
+
+// add path (faiss/gpu/impl/IVFAppend.cu): scatter rows / encode PQ codes to arena slots
+void launch_ivfflat_append(const float* x, int64_t ldx, int n, int d, const int64_t* dest,
+                           float* arena_vecs, int64_t ldv, int dpad, hipStream_t stream);
+void launch_ivfpq_encode_append(const float* x, int64_t ldx, int n, int d, const int64_t* labels,
+                                const int64_t* dest, const float* centroids, int64_t ldc, int M,
+                                int dsub, const float* pq_centroids, uint8_t* arena_codes,
+                                hipStream_t stream);
+// list relocation when the arena is rebuilt: list l's `len[l]` rows move from row old_start[l]
+// of src to row new_start[l] of dst (row = bytes_per_row bytes, multiple of 4)
+void launch_move_lists(const uint8_t* src, uint8_t* dst, const int64_t* old_start,
+                       const int64_t* new_start, const uint32_t* len, int nlist, int bytes_per_row,
+                       hipStream_t stream);
+// dst[dest[i]] = src[i]  (dest < 0 skipped)
+void launch_scatter_i64(const int64_t* src, const int64_t* dest, int64_t n, int64_t* dst,
+                        hipStream_t stream);
+// out[i] = x[i] - centroids[labels[i]]  (faiss/gpu/impl/VectorResidual.cu:26)
+void launch_residual(const float* x, int64_t ldx, int64_t n, int d, const int64_t* labels,
+                     const float* centroids, int64_t ldc, float* out, int64_t ldo, hipStream_t stream);
+
+} // namespace faiss_amd

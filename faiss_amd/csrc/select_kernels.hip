@@ -1,0 +1,208 @@
+// faiss_amd/csrc/select_kernels.hip -- exact k-selection for gfx950, one workgroup per query.
+//
+// Replaces the reference's WarpSelect/BlockSelect family (faiss/gpu/utils/Select.cuh:139-335,
+// BlockSelectKernel.cuh:15-132, MergeNetwork*.cuh) and the IVF two-pass selection
+// (faiss/gpu/impl/IVFUtilsSelect1.cu:24-99, IVFUtilsSelect2.cu:49-155) for the merge stage.
+// Unlike the reference (which leaves ties unordered, MergeNetworkWarp.cuh:41-78) the result is
+// the k smallest 64-bit keys exactly, then ordered by (distance, label): the total order the
+// CPU reference produces for IndexFlat (faiss/impl/ResultHandler.h:276-281, 439-453).
+//
+// Algorithm: MSB-first 8-bit radix select over the candidate keys (histogram in LDS, early
+// exit when the k-th key is the maximum of its bucket), gather of the <= k winners into LDS,
+// payload -> label translation, bitonic sort of the winners, coalesced write-out.
+#include "kernels.h"
+
+namespace faiss_amd {
+
+typedef unsigned long long u64;
+
+constexpr int SEL_THREADS = 256;
+
+struct SelShared {
+    unsigned hist[256];
+    unsigned scan[256];
+    u64 prefix;
+    u64 mask;
+    u64 kth;
+    int need;
+    int done;
+    unsigned total;
+    unsigned nwin;
+};
+
+template <typename F>
+__device__ __forceinline__ void for_each_key(const SelectParams& p, int q, F f) {
+    const u64* base = p.keys + (p.q_off ? p.q_off[q] : (int64_t)q * p.q_stride);
+    for (int s = 0; s < p.nseg; ++s) {
+        const unsigned cnt = p.seg_cnt[(int64_t)q * p.nseg + s];
+        const u64* seg = base + (int64_t)s * p.seg_stride;
+        for (unsigned i = threadIdx.x; i < cnt; i += SEL_THREADS) f(seg[i]);
+    }
+}
+
+__global__ void __launch_bounds__(SEL_THREADS) select_k_kernel(SelectParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    SelShared* sh = (SelShared*)smem;
+    // winners: ordkey (u32) + label (i64); kp = pow2 >= k entries
+    int kp = 1;
+    while (kp < p.k) kp <<= 1;
+    int64_t* w_id = (int64_t*)(smem + ((sizeof(SelShared) + 15) & ~15));
+    unsigned* w_key = (unsigned*)(w_id + kp);
+
+    const int q = blockIdx.x;
+    const int tid = threadIdx.x;
+
+    // ---- total candidate count
+    if (tid == 0) {
+        sh->total = 0;
+        sh->nwin = 0;
+        sh->prefix = 0;
+        sh->mask = 0;
+        sh->need = p.k;
+        sh->done = 0;
+        sh->kth = ~0ull;
+    }
+    __syncthreads();
+    {
+        unsigned loc = 0;
+        for (int s = tid; s < p.nseg; s += SEL_THREADS) loc += p.seg_cnt[(int64_t)q * p.nseg + s];
+        if (loc) atomicAdd(&sh->total, loc);
+    }
+    __syncthreads();
+    const unsigned total = sh->total;
+
+    // ---- radix select of the k-th smallest key (only when there are more than k)
+    if (total > (unsigned)p.k) {
+        for (int shift = 56; shift >= 0; shift -= 8) {
+            sh->hist[tid] = 0;
+            __syncthreads();
+            const u64 prefix = sh->prefix, mask = sh->mask;
+            for_each_key(p, q, [&](u64 key) {
+                if ((key & mask) == prefix) atomicAdd(&sh->hist[(unsigned)(key >> shift) & 255u], 1u);
+            });
+            __syncthreads();
+            // inclusive scan of 256 bins (Hillis-Steele in LDS)
+            unsigned v = sh->hist[tid];
+            sh->scan[tid] = v;
+            __syncthreads();
+            for (int off = 1; off < 256; off <<= 1) {
+                unsigned o = tid >= off ? sh->scan[tid - off] : 0;
+                __syncthreads();
+                sh->scan[tid] += o;
+                __syncthreads();
+            }
+            const unsigned incl = sh->scan[tid];
+            const unsigned excl = incl - v;
+            const unsigned need = (unsigned)sh->need;
+            __syncthreads();
+            if (excl < need && need <= incl) {
+                // exactly one bin satisfies this
+                sh->prefix = prefix | ((u64)tid << shift);
+                sh->mask = mask | ((u64)255u << shift);
+                sh->need = (int)(need - excl);
+                sh->done = ((need - excl) == v) ? 1 : 0;
+            }
+            __syncthreads();
+            if (sh->done || shift == 0) break;
+        }
+        if (sh->done) {
+            // k-th key = max key of the selected bucket
+            if (tid == 0) sh->kth = 0;
+            __syncthreads();
+            const u64 prefix = sh->prefix, mask = sh->mask;
+            u64 best = 0;
+            for_each_key(p, q, [&](u64 key) {
+                if ((key & mask) == prefix && key > best) best = key;
+            });
+            if (best) atomicMax(&sh->kth, best);
+            __syncthreads();
+        } else {
+            if (tid == 0) sh->kth = sh->prefix;
+            __syncthreads();
+        }
+    }
+    const u64 kth = sh->kth;
+
+    // ---- gather winners (keys <= kth): exactly min(total, k) because keys are unique
+    for (int i = tid; i < kp; i += SEL_THREADS) {
+        w_key[i] = 0xffffffffu;
+        w_id[i] = INT64_MAX;
+    }
+    __syncthreads();
+    {
+        const uint32_t* pre = p.mode == 1 ? p.ivf_prefix + (int64_t)q * (p.nprobe + 1) : nullptr;
+        for_each_key(p, q, [&](u64 key) {
+            if (key <= kth) {
+                unsigned slot = atomicAdd(&sh->nwin, 1u);
+                if (slot < (unsigned)kp) {
+                    uint32_t payload = (uint32_t)key;
+                    int64_t label;
+                    if (p.mode == 0) {
+                        label = (int64_t)payload + p.id_base;
+                    } else {
+                        // binary search: largest pr with pre[pr] <= payload
+                        int lo = 0, hi = p.nprobe; // invariant pre[lo] <= payload < pre[hi]
+                        while (hi - lo > 1) {
+                            int mid = (lo + hi) >> 1;
+                            if (pre[mid] <= payload) lo = mid;
+                            else hi = mid;
+                        }
+                        const int64_t list = p.coarse_ids[(int64_t)q * p.nprobe + lo];
+                        label = p.arena_ids[p.list_start[list] + (payload - pre[lo])];
+                    }
+                    w_key[slot] = (uint32_t)(key >> 32);
+                    w_id[slot] = label;
+                }
+            }
+        });
+    }
+    __syncthreads();
+    const int nwin = min((int)sh->nwin, p.k);
+
+    // ---- bitonic sort of kp entries by (ordkey, label) ascending
+    for (int size = 2; size <= kp; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < (kp >> 1); t += SEL_THREADS) {
+                int lo = 2 * t - (t & (stride - 1));
+                int hi = lo + stride;
+                bool up = ((lo & size) == 0);
+                unsigned ka = w_key[lo], kb = w_key[hi];
+                int64_t ia = w_id[lo], ib = w_id[hi];
+                bool a_gt_b = (ka > kb) || (ka == kb && ia > ib);
+                if (a_gt_b == up) {
+                    w_key[lo] = kb; w_key[hi] = ka;
+                    w_id[lo] = ib; w_id[hi] = ia;
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- write-out
+    const float pad = neutral_distance(p.metric);
+    for (int i = tid; i < p.k; i += SEL_THREADS) {
+        float dis;
+        int64_t id;
+        if (i < nwin) {
+            dis = unordkey_rt(p.metric, w_key[i]);
+            id = w_id[i];
+        } else {
+            dis = pad;
+            id = -1;
+        }
+        p.out_dis[(int64_t)q * p.k + i] = dis;
+        p.out_ids[(int64_t)q * p.k + i] = id;
+    }
+}
+
+void launch_select_k(const SelectParams& p, hipStream_t stream) {
+    if (p.nq == 0) return;
+    FA_THROW_IF_NOT(p.k >= 1 && p.k <= kMaxSelectionK);
+    int kp = 1;
+    while (kp < p.k) kp <<= 1;
+    size_t lds = ((sizeof(SelShared) + 15) & ~(size_t)15) + (size_t)kp * (8 + 4);
+    hipLaunchKernelGGL(select_k_kernel, dim3((unsigned)p.nq), dim3(SEL_THREADS), lds, stream, p);
+    HIP_CHECK(hipGetLastError());
+}
+
+} // namespace faiss_amd

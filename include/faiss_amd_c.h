@@ -1,0 +1,150 @@
+/* include/faiss_amd_c.h -- C ABI of the MI355X (gfx950) similarity-search backend.
+ *
+ * Drop-in boundary for the search path of the reference's GpuIndexFlat / GpuIndexIVFFlat /
+ * GpuIndexIVFPQ behind faiss::Index's add()/search() surface.  Every entry point below names
+ * the reference interface it stands in for (paths relative to the faiss v1.15.0 tree).  The
+ * naming and the error convention follow the reference's own C API (c_api/Index_c.h,
+ * c_api/gpu/ *.h): functions return 0 on success, -2 for a library exception
+ * (faiss::FaissException there, FaissAmdException here), -4 for std::exception, -1 otherwise
+ * (c_api/macros_impl.h:22-56); the message is read with faiss_amd_get_last_error()
+ * (c_api/error_c.h:30 faiss_get_last_error).
+ *
+ * Pointers: `x`, `distances`, `labels` may be host OR device pointers, as in the reference
+ * GPU indexes (faiss/gpu/GpuIndex.h:76-105); plain pointers and sizes only, no C++ or torch
+ * types.  idx_t is int64 (faiss/MetricType.h:52).  L2 distances are squared; inner-product
+ * results are largest-first; missing results are label -1 and distance +/-FLT_MAX
+ * (faiss/utils/Heap.h:427-457).
+ */
+#ifndef FAISS_AMD_C_H
+#define FAISS_AMD_C_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int64_t faiss_amd_idx_t;
+
+/* same values as FaissMetricType (c_api/Index_c.h:32-44) */
+typedef enum FaissAmdMetricType {
+    FAISS_AMD_METRIC_INNER_PRODUCT = 0,
+    FAISS_AMD_METRIC_L2 = 1
+} FaissAmdMetricType;
+
+typedef struct FaissAmdIndex_H FaissAmdIndex;                 /* FaissIndex, c_api/Index_c.h:55 */
+typedef struct FaissAmdGpuResources_H FaissAmdGpuResources;   /* FaissStandardGpuResources */
+
+/* c_api/error_c.h:30 faiss_get_last_error */
+const char* faiss_amd_get_last_error(void);
+/* c_api/gpu/DeviceUtils_c.h:22 faiss_get_num_gpus */
+int faiss_amd_get_num_gpus(int* p_output);
+
+/* ---- resources: c_api/gpu/StandardGpuResources_c.h:24-33 (one stream + scratch per device) */
+int faiss_amd_StandardGpuResources_new(FaissAmdGpuResources** p_res, int device);
+void faiss_amd_StandardGpuResources_free(FaissAmdGpuResources* res);
+/* c_api/gpu/GpuResources_c.h:48 faiss_GpuResources_syncDefaultStreamCurrentDevice */
+int faiss_amd_StandardGpuResources_sync(FaissAmdGpuResources* res);
+/* c_api/gpu/GpuResources_c.h:33 faiss_GpuResources_getDefaultStream: *p_stream is a hipStream_t */
+int faiss_amd_StandardGpuResources_getDefaultStream(FaissAmdGpuResources* res, void** p_stream);
+/* c_api/gpu/StandardGpuResources_c.h:41 faiss_StandardGpuResources_setTempMemory */
+int faiss_amd_StandardGpuResources_setTempMemory(FaissAmdGpuResources* res, size_t bytes);
+
+/* ---- constructors
+ * faiss/gpu/GpuIndexFlat.h:62-72   GpuIndexFlat(resources, dims, metric, config)
+ * faiss/gpu/GpuIndexIVFFlat.h:49-57 GpuIndexIVFFlat(resources, dims, nlist, metric, config)
+ * faiss/gpu/GpuIndexIVFPQ.h:72-82  GpuIndexIVFPQ(resources, dims, nlist, subQuantizers,
+ *                                  bitsPerCode, metric, config)
+ * faiss/IndexShards.h:30-33        IndexShards(d, threaded, successive_ids) + add_shard */
+int faiss_amd_GpuIndexFlat_new(FaissAmdIndex** p_index, FaissAmdGpuResources* res, int d,
+                               FaissAmdMetricType metric);
+int faiss_amd_GpuIndexIVFFlat_new(FaissAmdIndex** p_index, FaissAmdGpuResources* res, int d, int nlist,
+                                  FaissAmdMetricType metric);
+int faiss_amd_GpuIndexIVFPQ_new(FaissAmdIndex** p_index, FaissAmdGpuResources* res, int d, int nlist,
+                                int M, int nbits, FaissAmdMetricType metric);
+int faiss_amd_IndexShards_new(FaissAmdIndex** p_index, int d, int threaded, int successive_ids);
+int faiss_amd_IndexShards_add_shard(FaissAmdIndex* shards, FaissAmdIndex* shard);
+/* c_api/Index_c.h:56 faiss_Index_free */
+void faiss_amd_Index_free(FaissAmdIndex* index);
+
+/* ---- faiss::Index surface: c_api/Index_c.h:58-176, faiss/Index.h:101-431 */
+int faiss_amd_Index_d(const FaissAmdIndex* index);
+int faiss_amd_Index_is_trained(const FaissAmdIndex* index);
+faiss_amd_idx_t faiss_amd_Index_ntotal(const FaissAmdIndex* index);
+FaissAmdMetricType faiss_amd_Index_metric_type(const FaissAmdIndex* index);
+int faiss_amd_Index_train(FaissAmdIndex* index, faiss_amd_idx_t n, const float* x);
+int faiss_amd_Index_add(FaissAmdIndex* index, faiss_amd_idx_t n, const float* x);
+int faiss_amd_Index_add_with_ids(FaissAmdIndex* index, faiss_amd_idx_t n, const float* x,
+                                 const faiss_amd_idx_t* xids);
+int faiss_amd_Index_search(const FaissAmdIndex* index, faiss_amd_idx_t n, const float* x,
+                           faiss_amd_idx_t k, float* distances, faiss_amd_idx_t* labels);
+int faiss_amd_Index_assign(FaissAmdIndex* index, faiss_amd_idx_t n, const float* x,
+                           faiss_amd_idx_t* labels, faiss_amd_idx_t k);
+int faiss_amd_Index_reset(FaissAmdIndex* index);
+int faiss_amd_Index_reconstruct(const FaissAmdIndex* index, faiss_amd_idx_t key, float* recons);
+int faiss_amd_Index_reconstruct_n(const FaissAmdIndex* index, faiss_amd_idx_t i0, faiss_amd_idx_t ni,
+                                  float* recons);
+
+/* ---- IVF surface: c_api/IndexIVF_c.h:31-62 (nlist, nprobe, quantizer, list sizes/ids),
+ *      faiss/gpu/GpuIndexIVF.h:97-110 (getListLength / getListVectorData / getListIndices) */
+int faiss_amd_IndexIVF_nlist(const FaissAmdIndex* index, int* p_nlist);
+int faiss_amd_IndexIVF_nprobe(const FaissAmdIndex* index, int* p_nprobe);
+int faiss_amd_IndexIVF_set_nprobe(FaissAmdIndex* index, int nprobe);
+int faiss_amd_IndexIVF_get_list_size(const FaissAmdIndex* index, faiss_amd_idx_t list_no, size_t* p_size);
+int faiss_amd_IndexIVF_get_list_ids(const FaissAmdIndex* index, faiss_amd_idx_t list_no,
+                                    faiss_amd_idx_t* ids_out);
+/* payload of one list in the reference's CPU layout: d floats (IVFFlat) or M bytes (IVFPQ)
+ * per entry; out must hold list_size * code_size bytes */
+int faiss_amd_IndexIVF_get_list_codes(const FaissAmdIndex* index, faiss_amd_idx_t list_no, uint8_t* out);
+int faiss_amd_IndexIVF_code_size(const FaissAmdIndex* index, size_t* p_code_size);
+/* coarse centroids out: nlist x d floats (quantizer->reconstruct_n) */
+int faiss_amd_IndexIVF_get_centroids(const FaissAmdIndex* index, float* centroids_out);
+/* k-means iterations / seed of train(): ClusteringParameters niter, seed (faiss/Clustering.h:24-63) */
+int faiss_amd_IndexIVF_set_clustering(FaissAmdIndex* index, int niter, int seed);
+
+/* copyFrom(IndexIVFFlat / IndexIVFPQ) decomposed into plain arrays
+ * (faiss/gpu/GpuIndexIVFFlat.cu copyFrom, faiss/gpu/GpuIndexIVFPQ.cu:98-168):
+ *   centroids   nlist x d floats                 (index->quantizer, an IndexFlat)
+ *   pq          M x 256 x (d/M) floats           (index->pq.centroids)
+ *   list_sizes  nlist counts, codes/ids = the lists' payloads concatenated in list order
+ *               (invlists->get_codes / get_ids) */
+int faiss_amd_IndexIVF_copy_centroids(FaissAmdIndex* index, const float* centroids);
+int faiss_amd_IndexIVFPQ_copy_pq_centroids(FaissAmdIndex* index, const float* pq);
+int faiss_amd_IndexIVFPQ_get_pq_centroids(const FaissAmdIndex* index, float* pq_out);
+int faiss_amd_IndexIVF_copy_lists(FaissAmdIndex* index, const uint32_t* list_sizes, const uint8_t* codes,
+                                  const faiss_amd_idx_t* ids);
+
+/* ---- k-means: faiss::Clustering::train with a GPU flat index as assignment engine
+ *      (c_api/Clustering_c.h:100-116 faiss_kmeans_clustering; faiss/Clustering.cpp:255-357).
+ *      centroids_out: k x d floats; obj_out (nullable): niter floats, objective per iteration */
+int faiss_amd_kmeans_clustering(FaissAmdGpuResources* res, int d, faiss_amd_idx_t n, int k, const float* x,
+                                int niter, int seed, float* centroids_out, float* obj_out);
+
+/* ---- shard merge: faiss::merge_knn_results (faiss/utils/Heap.h merge_knn_results,
+ *      faiss/utils/Heap.cpp:166-240); all_d/all_i are [nshard][n][k]; base (nullable) is added
+ *      to each shard's labels (IndexShards successive_ids, faiss/IndexShards.cpp:214-237) */
+int faiss_amd_merge_knn_results(FaissAmdMetricType metric, faiss_amd_idx_t n, faiss_amd_idx_t k, int nshard,
+                                const float* all_d, const faiss_amd_idx_t* all_i,
+                                const faiss_amd_idx_t* base, float* distances, faiss_amd_idx_t* labels);
+
+/* ---- measurement hooks (no reference equivalent; the reference brackets searches with
+ *      CpuTimer/KernelTimer, faiss/gpu/utils/Timer.h).  Per-kernel HIP-event timing on the
+ *      resources' stream: enable, run searches, then read total ms / launch count by kernel
+ *      name ("flat_scan_kernel", "select_k_kernel", "ivfflat_scan_kernel", "ivfpq_scan_kernel") */
+int faiss_amd_profile_enable(FaissAmdGpuResources* res, int on);
+int faiss_amd_profile_reset(FaissAmdGpuResources* res);
+int faiss_amd_profile_get(FaissAmdGpuResources* res, const char* kernel_name, double* total_ms, long* launches);
+
+/* ---- test hooks */
+/* full distance matrix [n][ntotal] produced by the fused MFMA kernel (bfKnn-style all-pairs,
+ * faiss/gpu/GpuDistance.h:32-152 with outDistances only) */
+int faiss_amd_GpuIndexFlat_pairwise_distances(const FaissAmdIndex* index, faiss_amd_idx_t n, const float* x,
+                                              float* out);
+/* route search() through the scalar cross-check kernel (identical arithmetic, no MFMA) */
+int faiss_amd_GpuIndexFlat_set_use_simple_kernel(FaissAmdIndex* index, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
