@@ -1,0 +1,395 @@
+"""faiss_amd -- thin ctypes mirror of the reference's Python surface for the hot path.
+
+The product is the C-ABI shared library ``faiss_amd/lib/libfaiss_amd.so`` (hand-written
+gfx950 kernels + C++ host code, see ``include/faiss_amd_c.h``).  This module only marshals
+numpy arrays / raw pointers into that ABI, using the reference's class and method names
+(faiss/python/class_wrappers.py: ``index.add(x)``, ``D, I = index.search(x, k)``,
+``index.train(x)``, ``index.nprobe``), so the reference's tests read the same here.
+
+There is NO CPU fallback: importing works anywhere, but constructing
+``StandardGpuResources`` raises if the library is missing or no HIP device is visible.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+METRIC_INNER_PRODUCT = 0
+METRIC_L2 = 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libfaiss_amd.so")
+
+_c_idx_p = ctypes.c_void_p
+_lib = None
+
+
+class FaissAmdError(RuntimeError):
+    """Raised for non-zero C-ABI return codes (reference: faiss.FaissException via SWIG)."""
+
+
+def load_library():
+    """Load libfaiss_amd.so (built in-tree by ``__graft_entry__.build()``) and declare prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FaissAmdError(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    i64, i32, vp, sz = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
+    P = ctypes.POINTER
+    protos = {
+        "faiss_amd_get_last_error": (ctypes.c_char_p, []),
+        "faiss_amd_get_num_gpus": (i32, [P(i32)]),
+        "faiss_amd_StandardGpuResources_new": (i32, [P(vp), i32]),
+        "faiss_amd_StandardGpuResources_free": (None, [vp]),
+        "faiss_amd_StandardGpuResources_sync": (i32, [vp]),
+        "faiss_amd_StandardGpuResources_getDefaultStream": (i32, [vp, P(vp)]),
+        "faiss_amd_StandardGpuResources_setTempMemory": (i32, [vp, sz]),
+        "faiss_amd_GpuIndexFlat_new": (i32, [P(vp), vp, i32, i32]),
+        "faiss_amd_GpuIndexIVFFlat_new": (i32, [P(vp), vp, i32, i32, i32]),
+        "faiss_amd_GpuIndexIVFPQ_new": (i32, [P(vp), vp, i32, i32, i32, i32, i32]),
+        "faiss_amd_IndexShards_new": (i32, [P(vp), i32, i32, i32]),
+        "faiss_amd_IndexShards_add_shard": (i32, [vp, vp]),
+        "faiss_amd_Index_free": (None, [vp]),
+        "faiss_amd_Index_d": (i32, [vp]),
+        "faiss_amd_Index_is_trained": (i32, [vp]),
+        "faiss_amd_Index_ntotal": (i64, [vp]),
+        "faiss_amd_Index_metric_type": (i32, [vp]),
+        "faiss_amd_Index_train": (i32, [vp, i64, vp]),
+        "faiss_amd_Index_add": (i32, [vp, i64, vp]),
+        "faiss_amd_Index_add_with_ids": (i32, [vp, i64, vp, vp]),
+        "faiss_amd_Index_search": (i32, [vp, i64, vp, i64, vp, vp]),
+        "faiss_amd_Index_assign": (i32, [vp, i64, vp, vp, i64]),
+        "faiss_amd_Index_reset": (i32, [vp]),
+        "faiss_amd_Index_reconstruct": (i32, [vp, i64, vp]),
+        "faiss_amd_Index_reconstruct_n": (i32, [vp, i64, i64, vp]),
+        "faiss_amd_IndexIVF_nlist": (i32, [vp, P(i32)]),
+        "faiss_amd_IndexIVF_nprobe": (i32, [vp, P(i32)]),
+        "faiss_amd_IndexIVF_set_nprobe": (i32, [vp, i32]),
+        "faiss_amd_IndexIVF_get_list_size": (i32, [vp, i64, P(sz)]),
+        "faiss_amd_IndexIVF_get_list_ids": (i32, [vp, i64, vp]),
+        "faiss_amd_IndexIVF_get_list_codes": (i32, [vp, i64, vp]),
+        "faiss_amd_IndexIVF_code_size": (i32, [vp, P(sz)]),
+        "faiss_amd_IndexIVF_get_centroids": (i32, [vp, vp]),
+        "faiss_amd_IndexIVF_set_clustering": (i32, [vp, i32, i32]),
+        "faiss_amd_IndexIVF_copy_centroids": (i32, [vp, vp]),
+        "faiss_amd_IndexIVFPQ_copy_pq_centroids": (i32, [vp, vp]),
+        "faiss_amd_IndexIVFPQ_get_pq_centroids": (i32, [vp, vp]),
+        "faiss_amd_IndexIVF_copy_lists": (i32, [vp, vp, vp, vp]),
+        "faiss_amd_kmeans_clustering": (i32, [vp, i32, i64, i32, vp, i32, i32, vp, vp]),
+        "faiss_amd_merge_knn_results": (i32, [i32, i64, i64, i32, vp, vp, vp, vp, vp]),
+        "faiss_amd_profile_enable": (i32, [vp, i32]),
+        "faiss_amd_profile_reset": (i32, [vp]),
+        "faiss_amd_profile_get": (i32, [vp, ctypes.c_char_p, P(ctypes.c_double), P(ctypes.c_long)]),
+        "faiss_amd_GpuIndexFlat_pairwise_distances": (i32, [vp, i64, vp, vp]),
+        "faiss_amd_GpuIndexFlat_set_use_simple_kernel": (i32, [vp, i32]),
+    }
+    for name, (res, args) in protos.items():
+        fn = getattr(lib, name)  # AttributeError => the library does not export the symbol
+        fn.restype = res
+        fn.argtypes = args
+    lib._protos = protos
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    """Names declared in include/faiss_amd_c.h that the loaded library must export."""
+    return sorted(load_library()._protos.keys())
+
+
+def _check(rc):
+    if rc != 0:
+        msg = load_library().faiss_amd_get_last_error()
+        raise FaissAmdError("faiss_amd error %d: %s" % (rc, msg.decode("utf-8", "replace") if msg else "?"))
+
+
+def get_num_gpus():
+    n = ctypes.c_int(0)
+    _check(load_library().faiss_amd_get_num_gpus(ctypes.byref(n)))
+    return n.value
+
+
+def _f32(x, d=None):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    if x.ndim != 2:
+        raise ValueError("expected a 2-D float32 array")
+    if d is not None and x.shape[1] != d:
+        raise ValueError("expected %d columns, got %d" % (d, x.shape[1]))
+    return x
+
+
+def _ptr(a):
+    return ctypes.c_void_p(a.ctypes.data) if a is not None else None
+
+
+class StandardGpuResources:
+    """faiss.StandardGpuResources (faiss/gpu/StandardGpuResources.h): one stream + scratch per device."""
+
+    def __init__(self, device=0):
+        self._lib = load_library()
+        h = ctypes.c_void_p()
+        _check(self._lib.faiss_amd_StandardGpuResources_new(ctypes.byref(h), int(device)))
+        self._h = h
+        self.device = int(device)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.faiss_amd_StandardGpuResources_free(h)
+
+    def syncDefaultStreamCurrentDevice(self):
+        _check(self._lib.faiss_amd_StandardGpuResources_sync(self._h))
+
+    def getDefaultStream(self):
+        s = ctypes.c_void_p()
+        _check(self._lib.faiss_amd_StandardGpuResources_getDefaultStream(self._h, ctypes.byref(s)))
+        return s.value
+
+    def setTempMemory(self, nbytes):
+        _check(self._lib.faiss_amd_StandardGpuResources_setTempMemory(self._h, int(nbytes)))
+
+    # measurement hooks ---------------------------------------------------------------
+    def profile_enable(self, on=True):
+        _check(self._lib.faiss_amd_profile_enable(self._h, 1 if on else 0))
+
+    def profile_reset(self):
+        _check(self._lib.faiss_amd_profile_reset(self._h))
+
+    def profile_get(self, kernel_name):
+        ms, n = ctypes.c_double(0), ctypes.c_long(0)
+        _check(self._lib.faiss_amd_profile_get(self._h, kernel_name.encode(), ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
+
+class Index:
+    """faiss.Index surface (faiss/Index.h:101-431) over an opaque C-ABI handle."""
+
+    def __init__(self):
+        self._lib = load_library()
+        self._h = ctypes.c_void_p()
+        self._keep = []
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.faiss_amd_Index_free(h)
+
+    d = property(lambda self: self._lib.faiss_amd_Index_d(self._h))
+    ntotal = property(lambda self: self._lib.faiss_amd_Index_ntotal(self._h))
+    is_trained = property(lambda self: bool(self._lib.faiss_amd_Index_is_trained(self._h)))
+    metric_type = property(lambda self: self._lib.faiss_amd_Index_metric_type(self._h))
+
+    def train(self, x):
+        x = _f32(x, self.d)
+        _check(self._lib.faiss_amd_Index_train(self._h, x.shape[0], _ptr(x)))
+
+    def add(self, x):
+        x = _f32(x, self.d)
+        _check(self._lib.faiss_amd_Index_add(self._h, x.shape[0], _ptr(x)))
+
+    def add_with_ids(self, x, ids):
+        x = _f32(x, self.d)
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        if ids.shape != (x.shape[0],):
+            raise ValueError("ids must have one entry per vector")
+        _check(self._lib.faiss_amd_Index_add_with_ids(self._h, x.shape[0], _ptr(x), _ptr(ids)))
+
+    def search(self, x, k):
+        x = _f32(x, self.d)
+        n = x.shape[0]
+        D = np.empty((n, k), dtype=np.float32)
+        I = np.empty((n, k), dtype=np.int64)
+        _check(self._lib.faiss_amd_Index_search(self._h, n, _ptr(x), int(k), _ptr(D), _ptr(I)))
+        return D, I
+
+    def search_ptr(self, n, x_ptr, k, d_ptr, i_ptr):
+        """Raw-pointer search (host or device addresses), e.g. torch tensors' ``data_ptr()``."""
+        _check(self._lib.faiss_amd_Index_search(self._h, int(n), ctypes.c_void_p(x_ptr), int(k),
+                                                ctypes.c_void_p(d_ptr), ctypes.c_void_p(i_ptr)))
+
+    def add_ptr(self, n, x_ptr):
+        _check(self._lib.faiss_amd_Index_add(self._h, int(n), ctypes.c_void_p(x_ptr)))
+
+    def assign(self, x, k=1):
+        x = _f32(x, self.d)
+        I = np.empty((x.shape[0], k), dtype=np.int64)
+        _check(self._lib.faiss_amd_Index_assign(self._h, x.shape[0], _ptr(x), _ptr(I), int(k)))
+        return I
+
+    def reset(self):
+        _check(self._lib.faiss_amd_Index_reset(self._h))
+
+    def reconstruct(self, key):
+        out = np.empty(self.d, dtype=np.float32)
+        _check(self._lib.faiss_amd_Index_reconstruct(self._h, int(key), _ptr(out)))
+        return out
+
+    def reconstruct_n(self, i0, ni):
+        out = np.empty((ni, self.d), dtype=np.float32)
+        _check(self._lib.faiss_amd_Index_reconstruct_n(self._h, int(i0), int(ni), _ptr(out)))
+        return out
+
+
+class GpuIndexFlat(Index):
+    """faiss.GpuIndexFlat (faiss/gpu/GpuIndexFlat.h:41-153)."""
+
+    def __init__(self, res, d, metric=METRIC_L2):
+        super().__init__()
+        self._keep.append(res)
+        _check(self._lib.faiss_amd_GpuIndexFlat_new(ctypes.byref(self._h), res._h, int(d), int(metric)))
+
+    def pairwise_distances(self, x):
+        x = _f32(x, self.d)
+        out = np.empty((x.shape[0], self.ntotal), dtype=np.float32)
+        _check(self._lib.faiss_amd_GpuIndexFlat_pairwise_distances(self._h, x.shape[0], _ptr(x), _ptr(out)))
+        return out
+
+    def set_use_simple_kernel(self, on):
+        _check(self._lib.faiss_amd_GpuIndexFlat_set_use_simple_kernel(self._h, 1 if on else 0))
+
+
+class GpuIndexFlatL2(GpuIndexFlat):
+    def __init__(self, res, d):
+        super().__init__(res, d, METRIC_L2)
+
+
+class GpuIndexFlatIP(GpuIndexFlat):
+    def __init__(self, res, d):
+        super().__init__(res, d, METRIC_INNER_PRODUCT)
+
+
+class _GpuIndexIVF(Index):
+    """faiss.GpuIndexIVF (faiss/gpu/GpuIndexIVF.h:37-153)."""
+
+    @property
+    def nlist(self):
+        v = ctypes.c_int(0)
+        _check(self._lib.faiss_amd_IndexIVF_nlist(self._h, ctypes.byref(v)))
+        return v.value
+
+    @property
+    def nprobe(self):
+        v = ctypes.c_int(0)
+        _check(self._lib.faiss_amd_IndexIVF_nprobe(self._h, ctypes.byref(v)))
+        return v.value
+
+    @nprobe.setter
+    def nprobe(self, v):
+        _check(self._lib.faiss_amd_IndexIVF_set_nprobe(self._h, int(v)))
+
+    @property
+    def code_size(self):
+        v = ctypes.c_size_t(0)
+        _check(self._lib.faiss_amd_IndexIVF_code_size(self._h, ctypes.byref(v)))
+        return v.value
+
+    def set_clustering(self, niter=10, seed=1234):
+        _check(self._lib.faiss_amd_IndexIVF_set_clustering(self._h, int(niter), int(seed)))
+
+    def get_list_size(self, l):
+        v = ctypes.c_size_t(0)
+        _check(self._lib.faiss_amd_IndexIVF_get_list_size(self._h, int(l), ctypes.byref(v)))
+        return v.value
+
+    def get_list_ids(self, l):
+        out = np.empty(self.get_list_size(l), dtype=np.int64)
+        _check(self._lib.faiss_amd_IndexIVF_get_list_ids(self._h, int(l), _ptr(out)))
+        return out
+
+    def get_list_codes(self, l):
+        out = np.empty((self.get_list_size(l), self.code_size), dtype=np.uint8)
+        _check(self._lib.faiss_amd_IndexIVF_get_list_codes(self._h, int(l), _ptr(out)))
+        return out
+
+    def get_centroids(self):
+        out = np.empty((self.nlist, self.d), dtype=np.float32)
+        _check(self._lib.faiss_amd_IndexIVF_get_centroids(self._h, _ptr(out)))
+        return out
+
+    # copyFrom decomposed into arrays (see include/faiss_amd_c.h)
+    def copy_centroids(self, centroids):
+        c = _f32(centroids, self.d)
+        assert c.shape[0] == self.nlist
+        _check(self._lib.faiss_amd_IndexIVF_copy_centroids(self._h, _ptr(c)))
+
+    def copy_lists(self, list_sizes, codes, ids):
+        ls = np.ascontiguousarray(list_sizes, dtype=np.uint32)
+        codes = np.ascontiguousarray(codes).view(np.uint8).reshape(-1)
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        assert ls.shape == (self.nlist,) and ids.shape == (int(ls.sum()),)
+        assert codes.size == ids.size * self.code_size
+        _check(self._lib.faiss_amd_IndexIVF_copy_lists(self._h, _ptr(ls), _ptr(codes), _ptr(ids)))
+
+
+class GpuIndexIVFFlat(_GpuIndexIVF):
+    """faiss.GpuIndexIVFFlat (faiss/gpu/GpuIndexIVFFlat.h:33-126)."""
+
+    def __init__(self, res, d, nlist, metric=METRIC_L2):
+        super().__init__()
+        self._keep.append(res)
+        _check(self._lib.faiss_amd_GpuIndexIVFFlat_new(ctypes.byref(self._h), res._h, int(d), int(nlist),
+                                                       int(metric)))
+
+
+class GpuIndexIVFPQ(_GpuIndexIVF):
+    """faiss.GpuIndexIVFPQ (faiss/gpu/GpuIndexIVFPQ.h:53-176)."""
+
+    def __init__(self, res, d, nlist, M, nbits=8, metric=METRIC_L2):
+        super().__init__()
+        self._keep.append(res)
+        self.M = int(M)
+        _check(self._lib.faiss_amd_GpuIndexIVFPQ_new(ctypes.byref(self._h), res._h, int(d), int(nlist), int(M),
+                                                     int(nbits), int(metric)))
+
+    def copy_pq_centroids(self, pq):
+        pq = np.ascontiguousarray(pq, dtype=np.float32).reshape(-1)
+        assert pq.size == self.M * 256 * (self.d // self.M)
+        _check(self._lib.faiss_amd_IndexIVFPQ_copy_pq_centroids(self._h, _ptr(pq)))
+
+    def get_pq_centroids(self):
+        out = np.empty((self.M, 256, self.d // self.M), dtype=np.float32)
+        _check(self._lib.faiss_amd_IndexIVFPQ_get_pq_centroids(self._h, _ptr(out)))
+        return out
+
+
+class IndexShards(Index):
+    """faiss.IndexShards (faiss/IndexShards.h:19-108): host threads + host merge."""
+
+    def __init__(self, d, threaded=True, successive_ids=True):
+        super().__init__()
+        _check(self._lib.faiss_amd_IndexShards_new(ctypes.byref(self._h), int(d), int(threaded),
+                                                   int(successive_ids)))
+
+    def add_shard(self, index):
+        self._keep.append(index)
+        _check(self._lib.faiss_amd_IndexShards_add_shard(self._h, index._h))
+
+
+def kmeans(res, x, k, niter=25, seed=1234):
+    """faiss.Kmeans-style helper: returns (centroids [k, d], objective per iteration)."""
+    lib = load_library()
+    x = _f32(x)
+    n, d = x.shape
+    cent = np.empty((k, d), dtype=np.float32)
+    obj = np.empty(niter, dtype=np.float32)
+    _check(lib.faiss_amd_kmeans_clustering(res._h, d, n, int(k), _ptr(x), int(niter), int(seed), _ptr(cent),
+                                           _ptr(obj)))
+    return cent, obj
+
+
+def merge_knn_results(metric, all_D, all_I, base=None):
+    """faiss.merge_knn_results: all_D/all_I are [nshard, n, k]; returns merged (D, I)."""
+    lib = load_library()
+    all_D = np.ascontiguousarray(all_D, dtype=np.float32)
+    all_I = np.ascontiguousarray(all_I, dtype=np.int64)
+    ns, n, k = all_D.shape
+    D = np.empty((n, k), dtype=np.float32)
+    I = np.empty((n, k), dtype=np.int64)
+    b = None if base is None else np.ascontiguousarray(base, dtype=np.int64)
+    _check(lib.faiss_amd_merge_knn_results(int(metric), n, k, ns, _ptr(all_D), _ptr(all_I), _ptr(b), _ptr(D),
+                                           _ptr(I)))
+    return D, I

@@ -83,6 +83,13 @@ __host__ __device__ static inline uint32_t float_flip(float f) {
     v.f = (f == 0.0f) ? 0.0f : f;
     return (v.u & 0x80000000u) ? ~v.u : (v.u | 0x80000000u);
 }
+// Keys at or above this value are "not better than the neutral element" for both metrics
+// (+/-FLT_MAX, infinities, NaN): the reference never admits them (strict compare against the
+// heap's neutral value), so they are reported as missing results.
+constexpr uint32_t kInvalidOrdKey = 0xff7fffffu;
+__host__ __device__ static inline bool float_isnan(float f) {
+    return f != f;
+}
 __host__ __device__ static inline float float_unflip(uint32_t u) {
     union {
         float f;
@@ -93,6 +100,7 @@ __host__ __device__ static inline float float_unflip(uint32_t u) {
 }
 template <int METRIC>
 __host__ __device__ static inline uint32_t ordkey(float dis) {
+    if (float_isnan(dis)) return 0xffffffffu;
     return METRIC == METRIC_L2 ? float_flip(dis) : ~float_flip(dis);
 }
 template <int METRIC>
@@ -100,6 +108,7 @@ __host__ __device__ static inline float unordkey(uint32_t k) {
     return METRIC == METRIC_L2 ? float_unflip(k) : float_unflip(~k);
 }
 __host__ __device__ static inline uint32_t ordkey_rt(int metric, float dis) {
+    if (float_isnan(dis)) return 0xffffffffu;
     return metric == METRIC_L2 ? float_flip(dis) : ~float_flip(dis);
 }
 __host__ __device__ static inline float unordkey_rt(int metric, uint32_t k) {

@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(SEL_THREADS) select_k_kernel(SelectParams p) {
     for (int i = tid; i < p.k; i += SEL_THREADS) {
         float dis;
         int64_t id;
-        if (i < nwin) {
+        if (i < nwin && w_key[i] < kInvalidOrdKey) {
             dis = unordkey_rt(p.metric, w_key[i]);
             id = w_id[i];
         } else {

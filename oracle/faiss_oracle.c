@@ -1,0 +1,435 @@
+/* oracle/faiss_oracle.c -- CPU restatement of the reference algorithms on the hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load this library; nothing under faiss_amd/ links, imports or executes it.
+ *
+ * What is restated (plain scalar C, one function per reference routine):
+ *   orc_flat_search      IndexFlat::search -> knn_L2sqr / knn_inner_product
+ *                        (faiss/IndexFlat.cpp:29-60, faiss/utils/distances.cpp:424-511, 834-875):
+ *                        dis = |x|^2 + |y|^2 - 2<x,y>, negative values clamped to 0, k best kept
+ *                        with strict admission and (distance, id) heap order
+ *                        (faiss/impl/ResultHandler.h:276-281, 354-360;
+ *                         faiss/utils/ordered_key_value.h:42-83)
+ *   orc_ivf_search       IndexIVF::search (faiss/IndexIVF.cpp:305-399): coarse quantizer search
+ *                        for nprobe lists, then search_preassigned (faiss/IndexIVF.cpp:401-768)
+ *                        scanning the lists in probe order
+ *        IVFFlat scanner faiss/utils/simd_impl/IVFFlatScanner-inl.h:20-34 (direct sum (x-y)^2 / dot)
+ *        IVFPQ scanner   faiss/IndexIVFPQ.cpp (IVFPQScanner, by_residual, table per (query,list)),
+ *                        faiss/impl/pq_code_distance/IVFPQScanner_impl.h:121-193,
+ *                        faiss/impl/ProductQuantizer.cpp compute_distance_table / compute_inner_prod_table
+ *   orc_pq_encode        ProductQuantizer::compute_code (faiss/impl/ProductQuantizer.cpp): per
+ *                        sub-vector nearest centroid, first minimum wins
+ *   orc_ivf_assign       IndexIVF::add_core coarse assignment (faiss/IndexIVF.cpp:194-260)
+ *   orc_merge_shards     merge_knn_results (faiss/utils/Heap.cpp:166-240)
+ *   orc_kmeans_objective Clustering objective (faiss/Clustering.cpp:268-357: sum of assignment distances)
+ *
+ * Floating point: the reference sums in whatever order BLAS / AVX2 picks, so its distances are
+ * reproducible only to rounding.  This restatement fixes ONE order -- the order the gfx950
+ * kernels use (documented at each function) -- so that the HIP path can be checked BIT-EXACTLY
+ * against it, while the restatement itself is pinned against the compiled reference
+ * (oracle/_ref, built by oracle/Makefile.ref) within the north-star tolerance (1e-4 relative)
+ * and bit-exactly on integer-valued data where every order gives the same result.
+ * Compile with -ffp-contract=off: every fused multiply-add below is an explicit fmaf().
+ */
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef int64_t idx_t;
+enum { ORC_METRIC_IP = 0, ORC_METRIC_L2 = 1 };
+
+/* pair order inside one MFMA step; 0 = (k, k+4), 1 = (k+4, k).  Exists so the first GPU run
+ * can tell which of the two the hardware implements; the committed value is the verified one. */
+static int g_pair_swapped = 0;
+void orc_set_pair_order(int swapped) {
+    g_pair_swapped = swapped;
+}
+
+/* <x, y> as the f32 fmaf chain of the fused MFMA kernel (faiss_amd/csrc/flat_kernels.hip):
+ * for s = 0, 8, 16, ...: for e in 0..3: k = s+e then k = s+4+e.  Coordinates >= d count as 0
+ * (fmaf(0,0,acc) == acc), which is how the kernel treats its zero padding. */
+float orc_ip_chain(const float* x, const float* y, int d) {
+    float acc = 0.f;
+    for (int s = 0; s < d; s += 8) {
+        for (int e = 0; e < 4; e++) {
+            int k0 = s + e, k1 = s + 4 + e;
+            if (g_pair_swapped) {
+                int t = k0;
+                k0 = k1;
+                k1 = t;
+            }
+            if (k0 < d) acc = fmaf(x[k0], y[k0], acc);
+            if (k1 < d) acc = fmaf(x[k1], y[k1], acc);
+        }
+    }
+    return acc;
+}
+
+/* |x|^2 as a sequential fmaf chain (fvec_norm_L2sqr, faiss/utils/distances.cpp; kernel
+ * l2_norms_kernel) */
+float orc_norm_l2sqr(const float* x, int d) {
+    float acc = 0.f;
+    for (int k = 0; k < d; k++) acc = fmaf(x[k], x[k], acc);
+    return acc;
+}
+void orc_norms_l2sqr(const float* x, idx_t n, int d, float* out) {
+    for (idx_t i = 0; i < n; i++) out[i] = orc_norm_l2sqr(x + (size_t)i * d, d);
+}
+
+/* flat distance: faiss/utils/distances.cpp:480-495 */
+static inline float flat_dis(int metric, float ip, float xn, float yn) {
+    if (metric == ORC_METRIC_L2) {
+        float dis = fmaf(-2.f, ip, xn + yn); /* == (xn + yn) - 2*ip: 2*ip is exact */
+        if (dis < 0) dis = 0;
+        return dis;
+    }
+    return ip;
+}
+
+/* all-pairs distances [nq][nb] */
+void orc_pairwise(int metric, int d, idx_t nb, const float* xb, idx_t nq, const float* xq, float* out) {
+    float* yn = (float*)malloc(sizeof(float) * (size_t)(nb ? nb : 1));
+    orc_norms_l2sqr(xb, nb, d, yn);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (idx_t q = 0; q < nq; q++) {
+        float xn = orc_norm_l2sqr(xq + (size_t)q * d, d);
+        for (idx_t j = 0; j < nb; j++) {
+            float ip = orc_ip_chain(xq + (size_t)q * d, xb + (size_t)j * d, d);
+            out[(size_t)q * nb + j] = flat_dis(metric, ip, xn, yn[j]);
+        }
+    }
+    free(yn);
+}
+
+/* ------------------------------------------------------------------ k-selection
+ * "a is better than b": smaller distance for L2, larger for IP; ties to the smaller label.
+ * For L2 this is exactly what the reference CPU heap keeps and how it orders the output
+ * (CMax::cmp2, strict admission, id-ascending scan).  For IP the reference's boundary ties
+ * depend on arrival order (CMin heap evicts the smallest (sim, id)); we define (sim desc,
+ * id asc) and the tests classify boundary ties separately. */
+typedef struct {
+    float dis;
+    idx_t id;
+} cand_t;
+
+static inline int better(int metric, float da, idx_t ia, float db, idx_t ib) {
+    if (metric == ORC_METRIC_L2) {
+        if (da < db) return 1;
+        if (da > db) return 0;
+    } else {
+        if (da > db) return 1;
+        if (da < db) return 0;
+    }
+    return ia < ib;
+}
+
+/* bounded "worst on top" binary heap */
+typedef struct {
+    cand_t* a;
+    int n, k, metric;
+} topk_t;
+
+static void topk_init(topk_t* t, cand_t* storage, int k, int metric) {
+    t->a = storage;
+    t->n = 0;
+    t->k = k;
+    t->metric = metric;
+}
+static void topk_sift_down(topk_t* t, int i) {
+    for (;;) {
+        int l = 2 * i + 1, r = l + 1, w = i;
+        if (l < t->n && better(t->metric, t->a[w].dis, t->a[w].id, t->a[l].dis, t->a[l].id)) w = l;
+        if (r < t->n && better(t->metric, t->a[w].dis, t->a[w].id, t->a[r].dis, t->a[r].id)) w = r;
+        if (w == i) break;
+        cand_t tmp = t->a[i];
+        t->a[i] = t->a[w];
+        t->a[w] = tmp;
+        i = w;
+    }
+}
+static void topk_push(topk_t* t, float dis, idx_t id) {
+    /* the reference never admits NaN, +/-FLT_MAX-or-worse values: strict compare against the
+     * neutral element (faiss/impl/ResultHandler.h:276-281) */
+    if (t->metric == ORC_METRIC_L2) {
+        if (!(dis < FLT_MAX)) return;
+    } else {
+        if (!(dis > -FLT_MAX)) return;
+    }
+    if (t->n < t->k) {
+        int i = t->n++;
+        t->a[i].dis = dis;
+        t->a[i].id = id;
+        while (i > 0) {
+            int p = (i - 1) / 2;
+            if (better(t->metric, t->a[p].dis, t->a[p].id, t->a[i].dis, t->a[i].id)) {
+                cand_t tmp = t->a[i];
+                t->a[i] = t->a[p];
+                t->a[p] = tmp;
+                i = p;
+            } else
+                break;
+        }
+    } else if (better(t->metric, dis, id, t->a[0].dis, t->a[0].id)) {
+        t->a[0].dis = dis;
+        t->a[0].id = id;
+        topk_sift_down(t, 0);
+    }
+}
+static void topk_finish(topk_t* t, float* D, idx_t* I) {
+    /* insertion sort, best first (k <= 2048); avoids qsort's global comparator state */
+    for (int i = 1; i < t->n; i++) {
+        cand_t c = t->a[i];
+        int j = i - 1;
+        while (j >= 0 && better(t->metric, c.dis, c.id, t->a[j].dis, t->a[j].id)) {
+            t->a[j + 1] = t->a[j];
+            j--;
+        }
+        t->a[j + 1] = c;
+    }
+    for (int i = 0; i < t->k; i++) {
+        if (i < t->n) {
+            D[i] = t->a[i].dis;
+            I[i] = t->a[i].id;
+        } else {
+            /* padding: heap neutral element and label -1 (faiss/utils/Heap.h:427-457) */
+            D[i] = t->metric == ORC_METRIC_L2 ? FLT_MAX : -FLT_MAX;
+            I[i] = -1;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ IndexFlat::search */
+int orc_flat_search(int metric, int d, idx_t nb, const float* xb, idx_t nq, const float* xq, int k, float* D,
+                    idx_t* I) {
+    if (k < 1) return -1;
+    float* yn = (float*)malloc(sizeof(float) * (size_t)(nb ? nb : 1));
+    orc_norms_l2sqr(xb, nb, d, yn);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (idx_t q = 0; q < nq; q++) {
+        cand_t* st = (cand_t*)malloc(sizeof(cand_t) * (size_t)k);
+        topk_t t;
+        topk_init(&t, st, k, metric);
+        const float* x = xq + (size_t)q * d;
+        float xn = orc_norm_l2sqr(x, d);
+        for (idx_t j = 0; j < nb; j++) {
+            float ip = orc_ip_chain(x, xb + (size_t)j * d, d);
+            topk_push(&t, flat_dis(metric, ip, xn, yn[j]), j);
+        }
+        topk_finish(&t, D + (size_t)q * k, I + (size_t)q * k);
+        free(st);
+    }
+    free(yn);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ IVF
+ * Inverted lists are given in the reference's ArrayInvertedLists terms
+ * (faiss/invlists/InvertedLists.h): list l holds list_sizes[l] entries; their codes and ids are
+ * concatenated in list order in `codes` / `ids` (code_size bytes per entry).
+ *
+ * Candidate order and ties: lists are scanned in probe-rank order and entries in list order
+ * (faiss/IndexIVF.cpp:642-655).  The k best are kept under (distance, scan position): the
+ * reference's strict admission makes the first-scanned of two equal distances win at the
+ * boundary.  The output is then ordered by (distance, label) like every faiss heap result.
+ * Entries of probes with label -1 (fewer than nprobe valid centroids) are skipped
+ * (faiss/IndexIVF.cpp:585-590). */
+static void ivf_finish(int metric, cand_t* a, int n, int k, const idx_t* pos2id, float* D, idx_t* I) {
+    /* a[].id holds the scan position; translate, then order by (distance, label) */
+    for (int i = 0; i < n; i++) a[i].id = pos2id[a[i].id];
+    for (int i = 1; i < n; i++) {
+        cand_t c = a[i];
+        int j = i - 1;
+        while (j >= 0 && better(metric, c.dis, c.id, a[j].dis, a[j].id)) {
+            a[j + 1] = a[j];
+            j--;
+        }
+        a[j + 1] = c;
+    }
+    for (int i = 0; i < k; i++) {
+        if (i < n) {
+            D[i] = a[i].dis;
+            I[i] = a[i].id;
+        } else {
+            D[i] = metric == ORC_METRIC_L2 ? FLT_MAX : -FLT_MAX;
+            I[i] = -1;
+        }
+    }
+}
+
+/* kind: 0 = IVFFlat (codes are d floats), 1 = IVFPQ (codes are M bytes, 8 bits each).
+ * coarse_D / coarse_I (nullable): receive the nprobe coarse results per query. */
+int orc_ivf_search(int kind, int metric, int d, int nlist, const float* centroids, const uint32_t* list_sizes,
+                   const uint8_t* codes, const idx_t* ids, int M, const float* pq_centroids, idx_t nq,
+                   const float* xq, int nprobe, int k, float* D, idx_t* I, float* coarse_D, idx_t* coarse_I) {
+    if (k < 1 || nprobe < 1) return -1;
+    if (nprobe > nlist) nprobe = nlist;
+    const int dsub = kind == 1 ? d / M : 0;
+    const size_t code_size = kind == 1 ? (size_t)M : (size_t)d * sizeof(float);
+    idx_t* list_start = (idx_t*)malloc(sizeof(idx_t) * (size_t)(nlist + 1));
+    list_start[0] = 0;
+    for (int l = 0; l < nlist; l++) list_start[l + 1] = list_start[l] + list_sizes[l];
+    /* coarse quantizer = IndexFlat over the centroids (faiss/IndexIVF.cpp:336-342) */
+    float* cD = (float*)malloc(sizeof(float) * (size_t)nq * nprobe);
+    idx_t* cI = (idx_t*)malloc(sizeof(idx_t) * (size_t)nq * nprobe);
+    orc_flat_search(metric, d, nlist, centroids, nq, xq, nprobe, cD, cI);
+    if (coarse_D) memcpy(coarse_D, cD, sizeof(float) * (size_t)nq * nprobe);
+    if (coarse_I) memcpy(coarse_I, cI, sizeof(idx_t) * (size_t)nq * nprobe);
+
+#pragma omp parallel for schedule(dynamic, 1)
+    for (idx_t q = 0; q < nq; q++) {
+        const float* x = xq + (size_t)q * d;
+        size_t ncand = 0;
+        for (int p = 0; p < nprobe; p++) {
+            idx_t l = cI[(size_t)q * nprobe + p];
+            if (l >= 0) ncand += list_sizes[l];
+        }
+        idx_t* pos2id = (idx_t*)malloc(sizeof(idx_t) * (ncand ? ncand : 1));
+        cand_t* st = (cand_t*)malloc(sizeof(cand_t) * (size_t)k);
+        float* lut = kind == 1 ? (float*)malloc(sizeof(float) * (size_t)M * 256) : NULL;
+        float* res = (float*)malloc(sizeof(float) * (size_t)d);
+        topk_t t;
+        topk_init(&t, st, k, metric);
+        idx_t pos = 0;
+        for (int p = 0; p < nprobe; p++) {
+            idx_t l = cI[(size_t)q * nprobe + p];
+            if (l < 0) continue;
+            const uint8_t* lc = codes + (size_t)list_start[l] * code_size;
+            const idx_t* lid = ids + list_start[l];
+            const uint32_t len = list_sizes[l];
+            float dis0 = 0.f;
+            if (kind == 1) {
+                /* lookup table for this (query, list); by_residual.
+                 * L2: tab[m][c] = |(x - centroid)_m - pq[m][c]|^2   IP: tab[m][c] = <x_m, pq[m][c]>,
+                 * dis0 = <x, centroid> = the coarse distance (faiss/IndexIVFPQ.cpp precompute_list_tables) */
+                const float* cen = centroids + (size_t)l * d;
+                for (int j = 0; j < d; j++) res[j] = metric == ORC_METRIC_L2 ? x[j] - cen[j] : x[j];
+                for (int m = 0; m < M; m++) {
+                    for (int c = 0; c < 256; c++) {
+                        const float* pc = pq_centroids + ((size_t)m * 256 + c) * dsub;
+                        float acc = 0.f;
+                        for (int j = 0; j < dsub; j++) {
+                            if (metric == ORC_METRIC_L2) {
+                                float tt = res[m * dsub + j] - pc[j];
+                                acc = fmaf(tt, tt, acc);
+                            } else {
+                                acc = fmaf(res[m * dsub + j], pc[j], acc);
+                            }
+                        }
+                        lut[m * 256 + c] = acc;
+                    }
+                }
+                if (metric == ORC_METRIC_IP) dis0 = cD[(size_t)q * nprobe + p];
+            }
+            for (uint32_t i = 0; i < len; i++) {
+                float dis;
+                if (kind == 0) {
+                    const float* y = (const float*)(lc + (size_t)i * code_size);
+                    float acc = 0.f;
+                    for (int j = 0; j < d; j++) {
+                        if (metric == ORC_METRIC_L2) {
+                            float tt = x[j] - y[j];
+                            acc = fmaf(tt, tt, acc);
+                        } else {
+                            acc = fmaf(x[j], y[j], acc);
+                        }
+                    }
+                    dis = acc;
+                } else {
+                    const uint8_t* code = lc + (size_t)i * code_size;
+                    float acc = dis0;
+                    for (int m = 0; m < M; m++) acc = acc + lut[m * 256 + code[m]];
+                    dis = acc;
+                }
+                pos2id[pos] = lid[i];
+                topk_push(&t, dis, pos); /* tie -> smaller scan position */
+                pos++;
+            }
+        }
+        ivf_finish(metric, t.a, t.n, k, pos2id, D + (size_t)q * k, I + (size_t)q * k);
+        free(pos2id);
+        free(st);
+        free(lut);
+        free(res);
+    }
+    free(cD);
+    free(cI);
+    free(list_start);
+    return 0;
+}
+
+/* coarse assignment of add(): nearest centroid under the flat distance, k = 1
+ * (faiss/IndexIVF.cpp:194-205 quantizer->assign) */
+int orc_ivf_assign(int metric, int d, int nlist, const float* centroids, idx_t n, const float* x, idx_t* labels) {
+    float* D = (float*)malloc(sizeof(float) * (size_t)(n ? n : 1));
+    int rc = orc_flat_search(metric, d, nlist, centroids, n, x, 1, D, labels);
+    free(D);
+    return rc;
+}
+
+/* PQ encoding of residuals x - centroid[label]: per sub-quantizer the first nearest centroid
+ * (ProductQuantizer::compute_code, faiss/impl/ProductQuantizer.cpp; residual by
+ * IndexIVFPQ::encode_vectors, faiss/IndexIVFPQ.cpp) */
+int orc_pq_encode(int d, int M, const float* pq_centroids, const float* centroids, idx_t n, const float* x,
+                  const idx_t* labels, uint8_t* codes) {
+    const int dsub = d / M;
+#pragma omp parallel for
+    for (idx_t i = 0; i < n; i++) {
+        const float* xi = x + (size_t)i * d;
+        const float* cen = centroids + (size_t)labels[i] * d;
+        for (int m = 0; m < M; m++) {
+            float best = INFINITY;
+            int bc = 0;
+            for (int c = 0; c < 256; c++) {
+                const float* pc = pq_centroids + ((size_t)m * 256 + c) * dsub;
+                float acc = 0.f;
+                for (int j = 0; j < dsub; j++) {
+                    float r = xi[m * dsub + j] - cen[m * dsub + j];
+                    float tt = r - pc[j];
+                    acc = fmaf(tt, tt, acc);
+                }
+                if (acc < best) {
+                    best = acc;
+                    bc = c;
+                }
+            }
+            codes[(size_t)i * M + m] = (uint8_t)bc;
+        }
+    }
+    return 0;
+}
+
+/* merge of per-shard sorted results, ties to the smaller label (faiss/utils/Heap.cpp:166-240;
+ * label translation faiss/IndexShards.cpp:214-237).  all_D/all_I: [nshard][nq][k] */
+int orc_merge_shards(int metric, idx_t nq, int k, int nshard, const float* all_D, const idx_t* all_I,
+                     const idx_t* base, float* D, idx_t* I) {
+    for (idx_t q = 0; q < nq; q++) {
+        cand_t* st = (cand_t*)malloc(sizeof(cand_t) * (size_t)k);
+        topk_t t;
+        topk_init(&t, st, k, metric);
+        for (int s = 0; s < nshard; s++) {
+            for (int j = 0; j < k; j++) {
+                size_t off = ((size_t)s * nq + q) * k + j;
+                if (all_I[off] < 0) continue;
+                topk_push(&t, all_D[off], all_I[off] + (base ? base[s] : 0));
+            }
+        }
+        topk_finish(&t, D + (size_t)q * k, I + (size_t)q * k);
+        free(st);
+    }
+    return 0;
+}
+
+/* k-means objective of a centroid set: sum over points of the flat L2 distance to the nearest
+ * centroid (faiss/Clustering.cpp:277-290 ClusteringIterationStats::obj) */
+double orc_kmeans_objective(int d, idx_t n, const float* x, int k, const float* centroids) {
+    float* D = (float*)malloc(sizeof(float) * (size_t)(n ? n : 1));
+    idx_t* I = (idx_t*)malloc(sizeof(idx_t) * (size_t)(n ? n : 1));
+    orc_flat_search(ORC_METRIC_L2, d, k, centroids, n, x, 1, D, I);
+    double o = 0;
+    for (idx_t i = 0; i < n; i++) o += D[i];
+    free(D);
+    free(I);
+    return o;
+}

@@ -1,0 +1,350 @@
+"""oracle/pyoracle.py -- ctypes access to the oracles.  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module;
+nothing under faiss_amd/ does.  Two oracles:
+
+* ``Oracle``  : oracle/libfaiss_oracle.so, the plain-C restatement (faiss_oracle.c) whose
+                summation order equals the gfx950 kernels' -> bit-exact comparisons.
+* ``Ref``     : oracle/_ref/libfaiss_ref.so, the UNMODIFIED reference (faiss v1.15.0 CPU
+                path) compiled from /root/reference by oracle/Makefile.ref.  It is built in
+                the dev container and travels to the GPU box as a prebuilt .so; when it is
+                absent, ``Ref.available()`` is False and the tests that need it skip.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(_HERE, "libfaiss_oracle.so")
+REF_SO = os.path.join(_HERE, "_ref", "libfaiss_ref.so")
+
+METRIC_INNER_PRODUCT = 0
+METRIC_L2 = 1
+
+
+def _p(a):
+    return ctypes.c_void_p(a.ctypes.data) if a is not None else None
+
+
+def _f32(x):
+    return np.ascontiguousarray(x, dtype=np.float32)
+
+
+class Oracle:
+    _lib = None
+
+    @classmethod
+    def lib(cls):
+        if cls._lib is None:
+            if not os.path.exists(ORACLE_SO):
+                raise RuntimeError("%s missing: run `make -C oracle`" % ORACLE_SO)
+            lib = ctypes.CDLL(ORACLE_SO)
+            lib.orc_ip_chain.restype = ctypes.c_float
+            lib.orc_kmeans_objective.restype = ctypes.c_double
+            cls._lib = lib
+        return cls._lib
+
+    @classmethod
+    def set_pair_order(cls, swapped):
+        cls.lib().orc_set_pair_order(ctypes.c_int(int(swapped)))
+
+    @classmethod
+    def pairwise(cls, metric, xb, xq):
+        xb, xq = _f32(xb), _f32(xq)
+        out = np.empty((xq.shape[0], xb.shape[0]), dtype=np.float32)
+        cls.lib().orc_pairwise(ctypes.c_int(metric), ctypes.c_int(xb.shape[1]), ctypes.c_int64(xb.shape[0]),
+                               _p(xb), ctypes.c_int64(xq.shape[0]), _p(xq), _p(out))
+        return out
+
+    @classmethod
+    def flat_search(cls, metric, xb, xq, k):
+        xb, xq = _f32(xb), _f32(xq)
+        d = xq.shape[1]
+        D = np.empty((xq.shape[0], k), dtype=np.float32)
+        I = np.empty((xq.shape[0], k), dtype=np.int64)
+        rc = cls.lib().orc_flat_search(ctypes.c_int(metric), ctypes.c_int(d), ctypes.c_int64(xb.shape[0]),
+                                       _p(xb) if xb.size else None, ctypes.c_int64(xq.shape[0]), _p(xq),
+                                       ctypes.c_int(k), _p(D), _p(I))
+        assert rc == 0
+        return D, I
+
+    @classmethod
+    def ivf_search(cls, kind, metric, centroids, list_sizes, codes, ids, xq, nprobe, k, M=0, pq=None):
+        centroids, xq = _f32(centroids), _f32(xq)
+        nlist, d = centroids.shape
+        ls = np.ascontiguousarray(list_sizes, dtype=np.uint32)
+        codes = np.ascontiguousarray(codes).view(np.uint8).reshape(-1)
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        pqc = _f32(pq).reshape(-1) if pq is not None else None
+        nq = xq.shape[0]
+        D = np.empty((nq, k), dtype=np.float32)
+        I = np.empty((nq, k), dtype=np.int64)
+        np_eff = min(nprobe, nlist)
+        cD = np.empty((nq, np_eff), dtype=np.float32)
+        cI = np.empty((nq, np_eff), dtype=np.int64)
+        rc = cls.lib().orc_ivf_search(ctypes.c_int(kind), ctypes.c_int(metric), ctypes.c_int(d),
+                                      ctypes.c_int(nlist), _p(centroids), _p(ls), _p(codes), _p(ids),
+                                      ctypes.c_int(M), _p(pqc), ctypes.c_int64(nq), _p(xq),
+                                      ctypes.c_int(nprobe), ctypes.c_int(k), _p(D), _p(I), _p(cD), _p(cI))
+        assert rc == 0
+        return D, I, cD, cI
+
+    @classmethod
+    def ivf_assign(cls, metric, centroids, x):
+        centroids, x = _f32(centroids), _f32(x)
+        lab = np.empty(x.shape[0], dtype=np.int64)
+        rc = cls.lib().orc_ivf_assign(ctypes.c_int(metric), ctypes.c_int(x.shape[1]),
+                                      ctypes.c_int(centroids.shape[0]), _p(centroids),
+                                      ctypes.c_int64(x.shape[0]), _p(x), _p(lab))
+        assert rc == 0
+        return lab
+
+    @classmethod
+    def pq_encode(cls, pq, centroids, x, labels):
+        pq, centroids, x = _f32(pq), _f32(centroids), _f32(x)
+        M = pq.shape[0]
+        labels = np.ascontiguousarray(labels, dtype=np.int64)
+        codes = np.empty((x.shape[0], M), dtype=np.uint8)
+        rc = cls.lib().orc_pq_encode(ctypes.c_int(x.shape[1]), ctypes.c_int(M), _p(pq.reshape(-1)), _p(centroids),
+                                     ctypes.c_int64(x.shape[0]), _p(x), _p(labels), _p(codes))
+        assert rc == 0
+        return codes
+
+    @classmethod
+    def merge_shards(cls, metric, all_D, all_I, base=None):
+        all_D = np.ascontiguousarray(all_D, dtype=np.float32)
+        all_I = np.ascontiguousarray(all_I, dtype=np.int64)
+        ns, nq, k = all_D.shape
+        D = np.empty((nq, k), dtype=np.float32)
+        I = np.empty((nq, k), dtype=np.int64)
+        b = None if base is None else np.ascontiguousarray(base, dtype=np.int64)
+        rc = cls.lib().orc_merge_shards(ctypes.c_int(metric), ctypes.c_int64(nq), ctypes.c_int(k),
+                                        ctypes.c_int(ns), _p(all_D), _p(all_I), _p(b), _p(D), _p(I))
+        assert rc == 0
+        return D, I
+
+    @classmethod
+    def kmeans_objective(cls, x, centroids):
+        x, centroids = _f32(x), _f32(centroids)
+        return cls.lib().orc_kmeans_objective(ctypes.c_int(x.shape[1]), ctypes.c_int64(x.shape[0]), _p(x),
+                                              ctypes.c_int(centroids.shape[0]), _p(centroids))
+
+    @classmethod
+    def build_ivf_lists(cls, kind, metric, centroids, x, ids=None, pq=None):
+        """IndexIVF::add on the restatement: returns (list_sizes, codes, ids) in list order,
+        entries in insertion order inside each list (faiss/IndexIVF.cpp:194-260)."""
+        x = _f32(x)
+        n = x.shape[0]
+        ids = np.arange(n, dtype=np.int64) if ids is None else np.asarray(ids, dtype=np.int64)
+        lab = cls.ivf_assign(metric, centroids, x)
+        nlist = centroids.shape[0]
+        order = np.argsort(lab, kind="stable")
+        order = order[lab[order] >= 0]
+        sizes = np.bincount(lab[lab >= 0], minlength=nlist).astype(np.uint32)
+        if kind == 0:
+            codes = x[order].view(np.uint8).reshape(len(order), -1)
+        else:
+            codes = cls.pq_encode(pq, centroids, x, np.maximum(lab, 0))[order]
+        return sizes, np.ascontiguousarray(codes), ids[order], lab
+
+
+class RefIndex:
+    def __init__(self, lib, h, d):
+        self.lib, self.h, self.d = lib, h, d
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.ref_index_free(ctypes.c_void_p(self.h))
+            self.h = None
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise RuntimeError("reference error: " + self.lib.ref_last_error().decode())
+
+    def train(self, x):
+        x = _f32(x)
+        self._ck(self.lib.ref_index_train(ctypes.c_void_p(self.h), ctypes.c_int64(x.shape[0]), _p(x)))
+
+    def add(self, x):
+        x = _f32(x)
+        self._ck(self.lib.ref_index_add(ctypes.c_void_p(self.h), ctypes.c_int64(x.shape[0]), _p(x)))
+
+    def add_with_ids(self, x, ids):
+        x = _f32(x)
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        self._ck(self.lib.ref_index_add_with_ids(ctypes.c_void_p(self.h), ctypes.c_int64(x.shape[0]), _p(x), _p(ids)))
+
+    def search(self, x, k):
+        x = _f32(x)
+        D = np.empty((x.shape[0], k), dtype=np.float32)
+        I = np.empty((x.shape[0], k), dtype=np.int64)
+        self._ck(self.lib.ref_index_search(ctypes.c_void_p(self.h), ctypes.c_int64(x.shape[0]), _p(x),
+                                           ctypes.c_int64(k), _p(D), _p(I)))
+        return D, I
+
+    def reset(self):
+        self._ck(self.lib.ref_index_reset(ctypes.c_void_p(self.h)))
+
+    @property
+    def ntotal(self):
+        return self.lib.ref_index_ntotal(ctypes.c_void_p(self.h))
+
+    # IVF -----------------------------------------------------------------------------
+    def set_nprobe(self, nprobe):
+        self._ck(self.lib.ref_ivf_set_nprobe(ctypes.c_void_p(self.h), ctypes.c_int(nprobe)))
+
+    @property
+    def nlist(self):
+        return self.lib.ref_ivf_nlist(ctypes.c_void_p(self.h))
+
+    @property
+    def code_size(self):
+        return self.lib.ref_ivf_code_size(ctypes.c_void_p(self.h))
+
+    def centroids(self):
+        out = np.empty((self.nlist, self.d), dtype=np.float32)
+        self._ck(self.lib.ref_ivf_get_centroids(ctypes.c_void_p(self.h), _p(out)))
+        return out
+
+    def lists(self):
+        sizes = np.empty(self.nlist, dtype=np.uint32)
+        self._ck(self.lib.ref_ivf_list_sizes(ctypes.c_void_p(self.h), _p(sizes)))
+        n = int(sizes.sum())
+        codes = np.empty((n, self.code_size), dtype=np.uint8)
+        ids = np.empty(n, dtype=np.int64)
+        self._ck(self.lib.ref_ivf_get_lists(ctypes.c_void_p(self.h), _p(codes), _p(ids)))
+        return sizes, codes, ids
+
+    def pq_info(self):
+        v = [ctypes.c_int(0) for _ in range(4)]
+        self._ck(self.lib.ref_ivfpq_info(ctypes.c_void_p(self.h), *[ctypes.byref(x) for x in v]))
+        return dict(M=v[0].value, dsub=v[1].value, nbits=v[2].value, use_precomputed_table=v[3].value)
+
+    def pq_centroids(self):
+        info = self.pq_info()
+        out = np.empty((info["M"], 1 << info["nbits"], info["dsub"]), dtype=np.float32)
+        self._ck(self.lib.ref_ivfpq_get_pq_centroids(ctypes.c_void_p(self.h), _p(out)))
+        return out
+
+    def set_precomputed_table(self, use):
+        self._ck(self.lib.ref_ivfpq_set_precomputed_table(ctypes.c_void_p(self.h), ctypes.c_int(use)))
+
+
+class Ref:
+    _lib = None
+
+    @classmethod
+    def available(cls):
+        return os.path.exists(REF_SO)
+
+    @classmethod
+    def lib(cls):
+        if cls._lib is None:
+            # MKL must use the GNU OpenMP runtime the reference objects were compiled against
+            os.environ.setdefault("MKL_THREADING_LAYER", "GNU")
+            lib = ctypes.CDLL(REF_SO)
+            lib.ref_index_factory.restype = ctypes.c_void_p
+            lib.ref_index_factory.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
+            lib.ref_last_error.restype = ctypes.c_char_p
+            lib.ref_index_ntotal.restype = ctypes.c_int64
+            lib.ref_amd_adapter_new.restype = ctypes.c_void_p
+            lib.ref_shards_new.restype = ctypes.c_void_p
+            cls._lib = lib
+        return cls._lib
+
+    @classmethod
+    def version(cls):
+        a, b, c = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        cls.lib().ref_version(ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
+        return (a.value, b.value, c.value)
+
+    @classmethod
+    def set_threads(cls, n):
+        cls.lib().ref_set_omp_threads(ctypes.c_int(n))
+
+    @classmethod
+    def max_threads(cls):
+        return cls.lib().ref_get_max_threads()
+
+    @classmethod
+    def index_factory(cls, d, desc, metric=METRIC_L2):
+        h = cls.lib().ref_index_factory(d, desc.encode(), metric)
+        if not h:
+            raise RuntimeError("reference error: " + cls.lib().ref_last_error().decode())
+        return RefIndex(cls.lib(), h, d)
+
+    @classmethod
+    def kmeans(cls, x, k, niter=25, seed=1234):
+        x = _f32(x)
+        cent = np.empty((k, x.shape[1]), dtype=np.float32)
+        obj = ctypes.c_float(0)
+        rc = cls.lib().ref_kmeans(ctypes.c_int(x.shape[1]), ctypes.c_int64(x.shape[0]), ctypes.c_int(k), _p(x),
+                                  ctypes.c_int(niter), ctypes.c_int(seed), _p(cent), ctypes.byref(obj))
+        if rc != 0:
+            raise RuntimeError("reference error: " + cls.lib().ref_last_error().decode())
+        return cent, obj.value
+
+    # ---- drop-in proof: the reference's own callers running on a faiss_amd handle
+    @classmethod
+    def adapter(cls, amd_index):
+        """Wrap a faiss_amd.Index handle into a faiss::Index subclass living in the reference
+        library (oracle/ref_shim.cpp AmdIndexAdapter)."""
+        import faiss_amd
+        L = faiss_amd.load_library()
+        fp = lambda name: ctypes.cast(getattr(L, name), ctypes.c_void_p)
+        h = cls.lib().ref_amd_adapter_new(
+            ctypes.c_int(amd_index.d), ctypes.c_int(amd_index.metric_type), amd_index._h,
+            fp("faiss_amd_Index_add"), fp("faiss_amd_Index_add_with_ids"), fp("faiss_amd_Index_search"),
+            fp("faiss_amd_Index_reset"), fp("faiss_amd_Index_train"), fp("faiss_amd_Index_ntotal"),
+            fp("faiss_amd_Index_is_trained"), fp("faiss_amd_get_last_error"))
+        r = RefIndex(cls.lib(), h, amd_index.d)
+        r._keep = amd_index
+        return r
+
+    @classmethod
+    def kmeans_with_index(cls, x, k, ref_index, niter=25, seed=1234):
+        x = _f32(x)
+        cent = np.empty((k, x.shape[1]), dtype=np.float32)
+        obj = ctypes.c_float(0)
+        rc = cls.lib().ref_kmeans_with_index(ctypes.c_int(x.shape[1]), ctypes.c_int64(x.shape[0]), ctypes.c_int(k),
+                                             _p(x), ctypes.c_int(niter), ctypes.c_int(seed),
+                                             ctypes.c_void_p(ref_index.h), _p(cent), ctypes.byref(obj))
+        if rc != 0:
+            raise RuntimeError("reference error: " + cls.lib().ref_last_error().decode())
+        return cent, obj.value
+
+    @classmethod
+    def shards(cls, d, subs, threaded=True, successive_ids=True):
+        h = cls.lib().ref_shards_new(ctypes.c_int(d), ctypes.c_int(int(threaded)), ctypes.c_int(int(successive_ids)))
+        r = RefIndex(cls.lib(), h, d)
+        r._keep = list(subs)
+        for s in subs:
+            rc = cls.lib().ref_shards_add(ctypes.c_void_p(h), ctypes.c_void_p(s.h))
+            if rc != 0:
+                raise RuntimeError("reference error: " + cls.lib().ref_last_error().decode())
+        return r
+
+
+# --------------------------------------------------------------------------- synthetic data
+def synthetic_dataset(d, nt, nb, nq, seed=1338):
+    """The reference's own SyntheticDataset recipe (contrib/datasets.py:89-105): a 10-dim
+    ellipsoid mapped to d dims and folded by sin(); clustered enough for IVF recall to mean
+    something.  Returns (xt, xb, xq) float32."""
+    d1 = 10
+    n = nb + nt + nq
+    rs = np.random.RandomState(seed)
+    x = rs.normal(size=(n, d1))
+    x = np.dot(x, rs.rand(d1, d))
+    x = x * (rs.rand(d) * 4 + 0.1)
+    x = np.sin(x).astype("float32")
+    return x[:nt], x[nt:nt + nb], x[nt + nb:]
+
+
+def integer_dataset(d, nb, nq, seed=7, hi=16):
+    """Small-integer coordinates: every partial sum is exact in fp32, so every summation
+    order gives identical bits and exact ties are frequent (tie-rule stress)."""
+    rs = np.random.RandomState(seed)
+    xb = rs.randint(0, hi, size=(nb, d)).astype("float32")
+    xq = rs.randint(0, hi, size=(nq, d)).astype("float32")
+    return xb, xq
