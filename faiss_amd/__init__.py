@@ -81,6 +81,7 @@ def load_library():
         "faiss_amd_IndexIVF_copy_lists": (i32, [vp, vp, vp, vp]),
         "faiss_amd_kmeans_clustering": (i32, [vp, i32, i64, i32, vp, i32, i32, vp, vp]),
         "faiss_amd_merge_knn_results": (i32, [i32, i64, i64, i32, vp, vp, vp, vp, vp]),
+        "faiss_amd_merge_knn_results_device": (i32, [vp, i32, i64, i64, i32, vp, vp, vp, vp, vp]),
         "faiss_amd_profile_enable": (i32, [vp, i32]),
         "faiss_amd_profile_reset": (i32, [vp]),
         "faiss_amd_profile_get": (i32, [vp, ctypes.c_char_p, P(ctypes.c_double), P(ctypes.c_long)]),
@@ -393,3 +394,12 @@ def merge_knn_results(metric, all_D, all_I, base=None):
     _check(lib.faiss_amd_merge_knn_results(int(metric), n, k, ns, _ptr(all_D), _ptr(all_I), _ptr(b), _ptr(D),
                                            _ptr(I)))
     return D, I
+
+
+def merge_knn_results_device(res, metric, n, k, nshard, all_d_ptr, all_i_ptr, base, d_ptr, i_ptr):
+    """Device-side shard merge; *_ptr are device addresses on res's device, base a host list/array."""
+    lib = load_library()
+    b = None if base is None else np.ascontiguousarray(base, dtype=np.int64)
+    _check(lib.faiss_amd_merge_knn_results_device(res._h, int(metric), int(n), int(k), int(nshard),
+                                                  ctypes.c_void_p(all_d_ptr), ctypes.c_void_p(all_i_ptr), _ptr(b),
+                                                  ctypes.c_void_p(d_ptr), ctypes.c_void_p(i_ptr)))

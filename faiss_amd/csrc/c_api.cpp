@@ -332,6 +332,16 @@ int faiss_amd_merge_knn_results(FaissAmdMetricType metric, faiss_amd_idx_t n, fa
     FA_CATCH
 }
 
+int faiss_amd_merge_knn_results_device(FaissAmdGpuResources* res, FaissAmdMetricType metric, faiss_amd_idx_t n,
+                                       faiss_amd_idx_t k, int nshard, const float* all_d,
+                                       const faiss_amd_idx_t* all_i, const faiss_amd_idx_t* base,
+                                       float* distances, faiss_amd_idx_t* labels) {
+    FA_TRY
+    merge_knn_results_device(*R(res), (int)metric, (int)n, (int)k, nshard, all_d, all_i, base, distances,
+                             labels);
+    FA_CATCH
+}
+
 int faiss_amd_profile_enable(FaissAmdGpuResources* res, int on) {
     FA_TRY
     R(res)->set_device();

@@ -954,6 +954,46 @@ void merge_knn_results(int metric, idx_t nq, idx_t k, int nshard, const float* a
     }
 }
 
+void merge_knn_results_device(GpuResources& R, int metric, int nq, int k, int nshard, const float* all_d,
+                              const idx_t* all_i, const idx_t* base_host, float* D, idx_t* I) {
+    FA_THROW_IF_NOT_MSG(k >= 1 && k <= kMaxSelectionK && nshard >= 1, "bad arguments");
+    FA_THROW_IF_NOT_MSG((int64_t)nshard * k < ((int64_t)1 << 31), "too many candidates");
+    if (nq == 0) return;
+    R.set_device();
+    static thread_local DevBuf keys, cnt, dbase; // per host thread == per device in our usage
+    keys.ensure((size_t)nq * nshard * k * 8);
+    cnt.ensure((size_t)nq * 4);
+    const idx_t* dbase_p = nullptr;
+    if (base_host) {
+        dbase.ensure((size_t)nshard * 8);
+        HIP_CHECK(hipMemcpyAsync(dbase.p, base_host, (size_t)nshard * 8, hipMemcpyHostToDevice, R.stream));
+        dbase_p = dbase.as<idx_t>();
+    }
+    {
+        SpanGuard sg(&R, "pack_merge_keys_kernel");
+        launch_pack_merge_keys(metric, all_d, all_i, nshard, nq, k, keys.as<unsigned long long>(),
+                               cnt.as<uint32_t>(), R.stream);
+    }
+    SelectParams sp{};
+    sp.metric = metric;
+    sp.nq = nq;
+    sp.k = k;
+    sp.keys = keys.as<unsigned long long>();
+    sp.q_stride = (int64_t)nshard * k;
+    sp.nseg = 1;
+    sp.seg_cnt = cnt.as<uint32_t>();
+    sp.mode = 2;
+    sp.merge_ids = all_i;
+    sp.merge_base = dbase_p;
+    sp.out_dis = D;
+    sp.out_ids = I;
+    {
+        SpanGuard sg(&R, "select_k_kernel");
+        launch_select_k(sp, R.stream);
+    }
+    R.sync();
+}
+
 IndexShards::IndexShards(int d_, bool threaded_, bool successive_ids_)
         : Index(d_, METRIC_L2), threaded(threaded_), successive_ids(successive_ids_) {}
 IndexShards::~IndexShards() {

@@ -238,6 +238,12 @@ class IndexShards : public Index {
 void merge_knn_results(int metric, idx_t nq, idx_t k, int nshard, const float* all_d, const idx_t* all_i,
                        const idx_t* base, float* D, idx_t* I);
 
+// device-side variant used by the one-process-per-GPU sharded search (faiss_amd/distributed.py):
+// all pointers are device pointers on res's device; work is ordered on res's stream and the
+// call returns after the stream has drained.
+void merge_knn_results_device(GpuResources& res, int metric, int nq, int k, int nshard, const float* all_d,
+                              const idx_t* all_i, const idx_t* base_host, float* D, idx_t* I);
+
 // ------------------------------------------------------------------ Clustering (k-means)
 struct ClusteringParameters {
     int niter = 25;

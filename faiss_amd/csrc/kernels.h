@@ -64,7 +64,8 @@ struct SelectParams {
     int64_t seg_stride;
     const uint32_t* seg_cnt; // [nq][nseg]
     // payload -> label translation
-    int mode; // 0: label = payload (+ id_base); 1: IVF position -> ids[list_start + off]
+    int mode; // 0: label = payload (+ id_base); 1: IVF position -> ids[list_start + off];
+              // 2: shard merge, payload = shard*k + rank -> merge_ids[shard][q][rank] + merge_base[shard]
     int64_t id_base;
     // mode 1:
     int nprobe;
@@ -72,6 +73,9 @@ struct SelectParams {
     const int64_t* coarse_ids;   // [nq][nprobe]
     const int64_t* list_start;   // [nlist] first entry of each list in the arena
     const int64_t* arena_ids;    // [ntotal] user ids in arena order
+    // mode 2:
+    const int64_t* merge_ids;    // [nshard][nq][k]
+    const int64_t* merge_base;   // [nshard] or null
     // outputs, best first; padded with (-1, neutral distance)
     float* out_dis;   // [nq][k]
     int64_t* out_ids; // [nq][k]
@@ -80,6 +84,13 @@ struct SelectParams {
 // (distance, label).  Replaces faiss/gpu/utils/BlockSelectKernel.cuh:15-132 and the
 // pass1/pass2 kernels of faiss/gpu/impl/IVFUtilsSelect{1,2}.cu.
 void launch_select_k(const SelectParams& p, hipStream_t stream);
+
+// Shard merge on the device: per-shard sorted results all_d/all_i [nshard][nq][k] are packed
+// into keys [nq][nshard*k] (payload = shard*k + rank, so equal distances resolve to the lower
+// shard / earlier rank = the smaller global id when shards hold successive id ranges); missing
+// entries (label < 0) become invalid keys.  cnt[q] = nshard*k.
+void launch_pack_merge_keys(int metric, const float* all_d, const int64_t* all_i, int nshard, int nq, int k,
+                            unsigned long long* keys, uint32_t* cnt, hipStream_t stream);
 
 // ------------------------------------------------------------------ IVF
 // prefix[q][0..nprobe] = exclusive prefix sum of list_len[coarse_ids[q][p]] (0 for id<0);

@@ -139,6 +139,10 @@ __global__ void __launch_bounds__(SEL_THREADS) select_k_kernel(SelectParams p) {
                     int64_t label;
                     if (p.mode == 0) {
                         label = (int64_t)payload + p.id_base;
+                    } else if (p.mode == 2) {
+                        const int s = (int)(payload / (uint32_t)p.k), r = (int)(payload % (uint32_t)p.k);
+                        label = p.merge_ids[((int64_t)s * p.nq + q) * p.k + r] +
+                                (p.merge_base ? p.merge_base[s] : 0);
                     } else {
                         // binary search: largest pr with pre[pr] <= payload
                         int lo = 0, hi = p.nprobe; // invariant pre[lo] <= payload < pre[hi]
@@ -193,6 +197,32 @@ __global__ void __launch_bounds__(SEL_THREADS) select_k_kernel(SelectParams p) {
         p.out_dis[(int64_t)q * p.k + i] = dis;
         p.out_ids[(int64_t)q * p.k + i] = id;
     }
+}
+
+__global__ void pack_merge_keys_kernel(int metric, const float* __restrict__ all_d,
+                                       const int64_t* __restrict__ all_i, int nshard, int nq, int k,
+                                       u64* __restrict__ keys, uint32_t* __restrict__ cnt) {
+    const int64_t total = (int64_t)nq * nshard * k;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int q = (int)(t / ((int64_t)nshard * k));
+        const int rem = (int)(t - (int64_t)q * nshard * k);
+        const int s = rem / k, r = rem - s * k;
+        const int64_t src = ((int64_t)s * nq + q) * k + r;
+        const uint32_t ok = all_i[src] >= 0 ? ordkey_rt(metric, all_d[src]) : 0xffffffffu;
+        keys[t] = ((u64)ok << 32) | (uint32_t)rem;
+        if (rem == 0) cnt[q] = (uint32_t)(nshard * k);
+    }
+}
+
+void launch_pack_merge_keys(int metric, const float* all_d, const int64_t* all_i, int nshard, int nq, int k,
+                            u64* keys, uint32_t* cnt, hipStream_t stream) {
+    if (nq == 0) return;
+    const int64_t total = (int64_t)nq * nshard * k;
+    unsigned grid = (unsigned)std::min<int64_t>(div_up(total, 256), 65535 * 8);
+    hipLaunchKernelGGL(pack_merge_keys_kernel, dim3(grid), dim3(256), 0, stream, metric, all_d, all_i, nshard,
+                       nq, k, keys, cnt);
+    HIP_CHECK(hipGetLastError());
 }
 
 void launch_select_k(const SelectParams& p, hipStream_t stream) {

@@ -128,6 +128,14 @@ int faiss_amd_merge_knn_results(FaissAmdMetricType metric, faiss_amd_idx_t n, fa
                                 const float* all_d, const faiss_amd_idx_t* all_i,
                                 const faiss_amd_idx_t* base, float* distances, faiss_amd_idx_t* labels);
 
+/* same merge on the device (all_d/all_i/distances/labels are device pointers on res's device,
+ * base is a host array): what the reference does only on the host; used by the
+ * one-process-per-GPU sharded search after the per-shard results were gathered over RCCL */
+int faiss_amd_merge_knn_results_device(FaissAmdGpuResources* res, FaissAmdMetricType metric, faiss_amd_idx_t n,
+                                       faiss_amd_idx_t k, int nshard, const float* all_d,
+                                       const faiss_amd_idx_t* all_i, const faiss_amd_idx_t* base,
+                                       float* distances, faiss_amd_idx_t* labels);
+
 /* ---- measurement hooks (no reference equivalent; the reference brackets searches with
  *      CpuTimer/KernelTimer, faiss/gpu/utils/Timer.h).  Per-kernel HIP-event timing on the
  *      resources' stream: enable, run searches, then read total ms / launch count by kernel
