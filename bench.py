@@ -1,0 +1,252 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the MI355X similarity-search backend.
+
+Metric (BASELINE.json): QPS at nq=10 000, k=100 on SIFT1M-shaped synthetic data (d=128,
+nb=1M; the reference's SyntheticDataset recipe, seed 1338).  A "step" is one search of all
+10 000 queries; queries and results are resident in HBM when the timed region starts.
+
+  N = 1 : GpuIndexFlatL2 (BASELINE.json configs[1]); `value` = Flat QPS.  The same line also
+          carries the IVF4096,PQ64 numbers (`ivfpq`), the roofline of the dominant kernel and
+          the reference CPU path timed on this node's host cores (`cpu_baseline`).
+  N > 1 : one process per GPU (torch.distributed, backend "nccl" = RCCL).  The 1M database is
+          sharded IndexShards-style (rank r holds rows [r*nb/N, (r+1)*nb/N)); every rank
+          searches all queries on its shard, the per-rank top-k are gathered point-to-point
+          onto rank 0 over xGMI and merged there by the device select kernel.  Total work is
+          fixed => "scaling": "strong".
+
+Run:  python bench.py [--gpus N --steps K --warmup W]
+      python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+D, NT, NB, NQ, K = 128, 100000, 1000000, 10000, 100
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+PEAK_HBM_GBS = 8000.0
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(xb, xq, k, gpu_D, gpu_I, budget_s=20.0):
+    """Reference CPU path (faiss IndexFlatL2, compiled unmodified into oracle/_ref) timed on this
+    node's host cores on a bounded sample of the same queries; falls back to the scalar C
+    restatement (kind "port") when oracle/_ref was not shipped."""
+    from oracle.pyoracle import METRIC_L2, Oracle, Ref
+    cores = os.cpu_count() or 1
+    if Ref.available():
+        Ref.set_threads(cores)
+        idx = Ref.index_factory(xb.shape[1], "Flat")
+        idx.add(xb)
+        idx.search(xq[:64], k)  # warm-up (MKL init)
+        ns = 250
+        t0 = time.time()
+        Dr, Ir = idx.search(xq[:ns], k)
+        dt = time.time() - t0
+        # scale the sample so the timed run takes ~budget_s/2, capped by the query set
+        ns2 = int(min(len(xq), max(ns, ns * (0.5 * budget_s) / max(dt, 1e-3))))
+        if ns2 > ns:
+            t0 = time.time()
+            Dr, Ir = idx.search(xq[:ns2], k)
+            dt = time.time() - t0
+            ns = ns2
+        kind, threads = "reference", Ref.max_threads()
+        sample = "faiss 1.15.0 IndexFlatL2.search of the first %d of the %d queries, nb=%d, k=%d" % (
+            ns, len(xq), len(xb), k)
+    else:
+        ns = 8
+        t0 = time.time()
+        Dr, Ir = Oracle.flat_search(METRIC_L2, xb, xq[:ns], k)
+        dt = time.time() - t0
+        kind, threads = "port", cores
+        sample = "oracle/faiss_oracle.c restatement (OpenMP over queries), first %d queries" % ns
+    out = {"value": round(ns / dt, 1), "unit": "QPS", "cores": int(threads), "kind": kind, "sample": sample}
+    if gpu_I is not None:
+        eq = float((gpu_I[:ns] == Ir).mean())
+        rel = float(np.max(np.abs(gpu_D[:ns] - Dr) / np.maximum(np.abs(Dr), 1e-30)))
+        out["parity_vs_gpu"] = {"labels_equal_frac": round(eq, 6), "max_rel_dist_err": float("%.3g" % rel),
+                                "recall_at_1": float((gpu_I[:ns, 0] == Ir[:, 0]).mean())}
+    return out
+
+
+def ivfpq_leg(res, xt, xb, xq_dev, gt_first, steps, warmup, torch):
+    """IVF4096,PQ64 (second half of the metric): native train + add on the GPU, nprobe=32."""
+    import faiss_amd
+    t0 = time.time()
+    idx = faiss_amd.GpuIndexIVFPQ(res, D, 4096, 64, 8, faiss_amd.METRIC_L2)
+    idx.train(xt)
+    t_train = time.time() - t0
+    t0 = time.time()
+    idx.add(xb)
+    t_add = time.time() - t0
+    idx.nprobe = 32
+    Dd = torch.empty((NQ, K), dtype=torch.float32, device=xq_dev.device)
+    Id = torch.empty((NQ, K), dtype=torch.int64, device=xq_dev.device)
+    for _ in range(max(1, warmup)):
+        idx.search_ptr(NQ, xq_dev.data_ptr(), K, Dd.data_ptr(), Id.data_ptr())
+    res.profile_enable(True)
+    res.profile_reset()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(steps):
+        idx.search_ptr(NQ, xq_dev.data_ptr(), K, Dd.data_ptr(), Id.data_ptr())
+    torch.cuda.synchronize()
+    dt = (time.time() - t0) / steps
+    I = Id.cpu().numpy()
+    scan_ms, scan_n = res.profile_get("ivfpq_scan_kernel")
+    sel_ms, sel_n = res.profile_get("select_k_kernel")
+    res.profile_enable(False)
+    codes_per_query = 32.0 * NB / 4096.0
+    out = {
+        "qps": round(NQ / dt, 1), "ms_per_step": round(dt * 1e3, 3), "nprobe": 32,
+        "recall_at_1": round(float((I[:, 0] == gt_first).mean()), 4),
+        "recall_at_100": round(float((I == gt_first[:, None]).any(axis=1).mean()), 4),
+        "train_s": round(t_train, 2), "add_s": round(t_add, 2),
+        "scan_kernel_ms": round(scan_ms / max(scan_n, 1), 3), "select_kernel_ms": round(sel_ms / max(sel_n, 1), 3),
+        # algorithmic HBM bytes of the code scan: nprobe * nb/nlist * M bytes per query
+        "scan_algorithmic_GBps": round(codes_per_query * 64 * NQ / (scan_ms / max(scan_n, 1) * 1e-3) / 1e9, 1)
+        if scan_n else None,
+    }
+    return out, idx
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ivfpq", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import faiss_amd  # after torch: both then share one HIP runtime in this process
+    from faiss_amd.datasets import synthetic_dataset
+    from faiss_amd.distributed import ShardedSearcher, shard_bounds
+
+    res = faiss_amd.StandardGpuResources(local_rank)
+    t0 = time.time()
+    xt, xb, xq = synthetic_dataset(D, NT, NB, NQ, seed=1338)
+    bounds = shard_bounds(NB, world)
+    lo, hi = bounds[rank]
+    index = faiss_amd.GpuIndexFlatL2(res, D)
+    index.add(xb[lo:hi])
+    if rank == 0:
+        log("data + add: %.1fs (shard rows %d..%d of %d)" % (time.time() - t0, lo, hi, NB))
+
+    xq_dev = torch.from_numpy(xq).to(dev)
+    D_loc = torch.empty((NQ, K), dtype=torch.float32, device=dev)
+    I_loc = torch.empty((NQ, K), dtype=torch.int64, device=dev)
+    D_out = torch.empty((NQ, K), dtype=torch.float32, device=dev)
+    I_out = torch.empty((NQ, K), dtype=torch.int64, device=dev)
+
+    def local_search(_xq, k):
+        index.search_ptr(NQ, xq_dev.data_ptr(), k, D_loc.data_ptr(), I_loc.data_ptr())
+        return D_loc, I_loc
+
+    def merge(all_D, all_I, base):
+        if all_D.shape[0] == 1:
+            return all_D[0], all_I[0]
+        torch.cuda.current_stream().synchronize()  # gathered tensors complete before our stream reads them
+        faiss_amd.merge_knn_results_device(res, faiss_amd.METRIC_L2, NQ, K, all_D.shape[0], all_D.data_ptr(),
+                                           all_I.data_ptr(), base, D_out.data_ptr(), I_out.data_ptr())
+        return D_out, I_out
+
+    searcher = ShardedSearcher(local_search, merge, [b - a for a, b in bounds], dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        searcher.search(xq_dev, K)
+    res.profile_enable(True)
+    res.profile_reset()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = searcher.search(xq_dev, K)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    scan_ms, scan_n = res.profile_get("flat_scan_kernel")
+    sel_ms, sel_n = res.profile_get("select_k_kernel")
+    res.profile_enable(False)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    qps = NQ * args.steps / elapsed
+    gD, gI = out[0].cpu().numpy(), out[1].cpu().numpy()
+    avg_scan_ms = scan_ms / max(scan_n, 1)
+    # dominant kernel: fused distance+select scan of this rank's shard.  Algorithmic work per
+    # launch = 2*nq*nb_shard*d flops (256 MFLOP/query at nb=1M, d=128).
+    flops = 2.0 * NQ * (hi - lo) * D
+    achieved = flops / (avg_scan_ms * 1e-3) / 1e12
+    # one sweep of the shard + queries + results is the algorithmic HBM traffic of the launch
+    hbm_bytes = (hi - lo) * D * 4.0 + NQ * D * 4.0 + NQ * K * 12.0
+    line = {
+        "metric": "QPS @ recall@1 (nq=10k, k=100) FlatL2, SIFT1M-shaped synthetic",
+        "value": round(qps, 1), "unit": "QPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "GpuIndexFlatL2 d=128 nb=1M nq=10k k=100 (BASELINE.json configs[1])",
+                   "generator": "SyntheticDataset(d=128, nt=100k, nb=1M, nq=10k, seed=1338)",
+                   "sharding": "IndexShards-style rows/%d per GPU, gather to rank 0 + device merge" % world
+                   if world > 1 else "single GPU", "inputs": "queries/results resident in HBM"},
+        "roofline": {"bound": "mfma", "kernel": "flat_scan_kernel", "achieved": round(achieved, 2),
+                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                     "traffic": None, "avg_kernel_ms": round(avg_scan_ms, 3), "launches": int(scan_n),
+                     "algorithmic_hbm_GBps": round(hbm_bytes / (avg_scan_ms * 1e-3) / 1e9, 1),
+                     "hbm_frac": round(hbm_bytes / (avg_scan_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 5)},
+        "select_kernel_ms": round(sel_ms / max(sel_n, 1), 3),
+    }
+    if world == 1:
+        if not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(xb, xq, K, gD, gI)
+                line["recall_at_1"] = line["cpu_baseline"].get("parity_vs_gpu", {}).get("recall_at_1")
+            except Exception as e:  # noqa: BLE001
+                line["cpu_baseline"] = {"error": repr(e)[:200]}
+        if not args.no_ivfpq:
+            try:
+                line["ivfpq"], _ = ivfpq_leg(res, xt, xb, xq_dev, gI[:, 0], max(1, args.steps // 2), 1, torch)
+            except Exception as e:  # noqa: BLE001
+                line["ivfpq"] = {"error": repr(e)[:300]}
+    print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -194,7 +194,11 @@ size_t flat_scan_lds_bytes() {
     return LDS_TOTAL;
 }
 
-template <int METRIC, bool DUMP>
+// FULL: dpad is a multiple of 128 (every k-slab is complete).  That variant has no data-dependent
+// branch in the MFMA loop, keeps the query operands of a single-slab problem (d <= 128) in
+// registers for the whole kernel, and contains no global load between the tile prefetch and
+// its consumer, so the compiler never has to drain the prefetch (s_waitcnt vmcnt(0)) early.
+template <int METRIC, bool DUMP, bool FULL, bool SINGLE>
 __global__ void __launch_bounds__(512, 2) flat_scan_kernel(FlatScanParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -228,7 +232,7 @@ __global__ void __launch_bounds__(512, 2) flat_scan_kernel(FlatScanParams p) {
         return;
     }
     const int ntiles = (r1 - r0 + TR - 1) / TR;
-    const int nslab = (p.dpad + KS - 1) / KS;
+    const int nslab = SINGLE ? 1 : (p.dpad + KS - 1) / KS; // SINGLE: d <= 128, one k-slab per tile
     const int nsteps = ntiles * nslab;
 
     // ---- this lane's query
@@ -254,9 +258,15 @@ __global__ void __launch_bounds__(512, 2) flat_scan_kernel(FlatScanParams p) {
     unsigned* hist = (unsigned*)(smem + LDS_HIST) + wave * 256;
     const int cap_lim = p.cap - 32;
 
+    // The two waves that share a SIMD would otherwise run their MFMA phases in lockstep and
+    // then both sit in the (VALU-only) epilogue with the matrix pipe idle; a static priority
+    // for one of them staggers the pair so one wave's epilogue overlaps the other's MFMAs.
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+
     // ---- staging registers
     f32x4 stg[4];
     float stg_bias = 0.f;
+    bool stg_ok = false;
     auto stage_load = [&](int u) {
         const int t = u / nslab, sl = u - t * nslab;
 #pragma unroll
@@ -265,18 +275,21 @@ __global__ void __launch_bounds__(512, 2) flat_scan_kernel(FlatScanParams p) {
             int row = g >> 5, c = g & 31;
             int col = sl * KS + c * 4;
             int grow = min(r0 + t * TR + row, r1 - 1);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (col < p.dpad) v = *(const f32x4*)(p.xb + (int64_t)grow * p.ldb + col);
-            stg[i] = v;
+            if (FULL) {
+                stg[i] = *(const f32x4*)(p.xb + (int64_t)grow * p.ldb + col);
+            } else {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (col < p.dpad) v = *(const f32x4*)(p.xb + (int64_t)grow * p.ldb + col);
+                stg[i] = v;
+            }
         }
-        if (sl == 0 && tid < TR) {
-            int grow = r0 + t * TR + tid;
-            float b;
-            if (METRIC == METRIC_L2)
-                b = grow < r1 ? p.xbn[grow] : INFINITY;
-            else
-                b = grow < r1 ? 0.f : -INFINITY;
-            stg_bias = b;
+        {
+            // every thread loads unconditionally (static vmcnt bookkeeping); rows >= r1 get a bias
+            // that can never pass the threshold
+            const int grow = r0 + t * TR + (tid & (TR - 1));
+            stg_ok = grow < r1;
+            // raw load only; the select happens in stage_store so that nothing waits on it here
+            if (METRIC == METRIC_L2) stg_bias = p.xbn[min(grow, r1 - 1)];
         }
     };
     auto stage_store = [&](int u) {
@@ -289,29 +302,46 @@ __global__ void __launch_bounds__(512, 2) flat_scan_kernel(FlatScanParams p) {
             *(f32x4*)(tile + row * 512 + ((c ^ (row & 15)) << 4)) = stg[i];
         }
         if (sl == 0 && tid < TR) {
-            ((float*)(smem + LDS_BIAS))[(t & 1) * TR + tid] = stg_bias;
+            float b;
+            if (METRIC == METRIC_L2) b = stg_ok ? stg_bias : INFINITY;
+            else b = stg_ok ? 0.f : -INFINITY;
+            ((float*)(smem + LDS_BIAS))[(t & 1) * TR + tid] = b;
         }
     };
 
     f32x4 bq[16];
     f32x16 acc0, acc1;
 
+    if (FULL) {
+        // slab 0 operands; for d <= 128 these are the only B loads of the kernel
+#pragma unroll
+        for (int s = 0; s < 16; ++s) bq[s] = *(const f32x4*)(qrow + 8 * s + 4 * h);
+    }
     stage_load(0);
     stage_store(0);
     __syncthreads();
 
     for (int u = 0; u < nsteps; ++u) {
         const int t = u / nslab, sl = u - t * nslab;
-        if (u + 1 < nsteps) stage_load(u + 1);
 
-        // ---- B operands (queries) for this slab
-        const int ns = min(16, (p.dpad - sl * KS) >> 3); // 8-wide k steps in this slab
-        if (nslab > 1 || u == 0) {
+        // ---- B operands (queries) for this slab, BEFORE the prefetch is issued: the counted
+        // wait for them then leaves the younger prefetch loads in flight
+        const int ns = FULL ? 16 : min(16, (p.dpad - sl * KS) >> 3); // 8-wide k steps in this slab
+        if (FULL) {
+            if (!SINGLE && u > 0) {
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                if (s < ns) bq[s] = *(const f32x4*)(qrow + sl * KS + 8 * s + 4 * h);
+                for (int s = 0; s < 16; ++s) bq[s] = *(const f32x4*)(qrow + sl * KS + 8 * s + 4 * h);
+            }
+        } else {
+            if (nslab > 1 || u == 0) {
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    if (s < ns) bq[s] = *(const f32x4*)(qrow + sl * KS + 8 * s + 4 * h);
+                }
             }
         }
+        if (u + 1 < nsteps) stage_load(u + 1);
+
         if (sl == 0) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -325,16 +355,49 @@ __global__ void __launch_bounds__(512, 2) flat_scan_kernel(FlatScanParams p) {
             const char* rowp0 = tile + j * 512;        // block 0: row j
             const char* rowp1 = tile + (32 + j) * 512; // block 1: row 32 + j  ((32+j)&15 == j&15)
             const int sw = j & 15;
+            if (FULL) {
+                // fragments of step s+1 are read (into the other register pair) before the MFMAs of
+                // step s are issued, so the LDS latency hides under 8 x 64 matrix-pipe cycles
+                f32x4 aA0 = *(const f32x4*)(rowp0 + (((0 + h) ^ sw) << 4));
+                f32x4 aA1 = *(const f32x4*)(rowp1 + (((0 + h) ^ sw) << 4));
+                f32x4 aB0, aB1;
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                if (s < ns) {
-                    const int off = (((2 * s + h) ^ sw) << 4);
-                    f32x4 a0 = *(const f32x4*)(rowp0 + off);
-                    f32x4 a1 = *(const f32x4*)(rowp1 + off);
+                for (int s = 0; s < 16; s += 2) {
+                    {
+                        const int off = (((2 * (s + 1) + h) ^ sw) << 4);
+                        aB0 = *(const f32x4*)(rowp0 + off);
+                        aB1 = *(const f32x4*)(rowp1 + off);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], bq[s][e], acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], bq[s][e], acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(aA0[e], bq[s][e], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(aA1[e], bq[s][e], acc1, 0, 0, 0);
+                    }
+                    if (s + 2 < 16) {
+                        const int off = (((2 * (s + 2) + h) ^ sw) << 4);
+                        aA0 = *(const f32x4*)(rowp0 + off);
+                        aA1 = *(const f32x4*)(rowp1 + off);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(aB0[e], bq[s + 1][e], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(aB1[e], bq[s + 1][e], acc1, 0, 0, 0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    if (s < ns) {
+                        const int off = (((2 * s + h) ^ sw) << 4);
+                        f32x4 a0 = *(const f32x4*)(rowp0 + off);
+                        f32x4 a1 = *(const f32x4*)(rowp1 + off);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], bq[s][e], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], bq[s][e], acc1, 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -425,19 +488,28 @@ void launch_flat_scan(const FlatScanParams& p, hipStream_t stream) {
     FA_THROW_IF_NOT(p.dump || p.cap >= p.k + 32);
     dim3 grid((unsigned)(p.nsplit * p.ngroups)), block(512);
     size_t lds = LDS_TOTAL;
-#define FA_LAUNCH(M, D)                                                                           \
+    const bool full = (p.dpad % KS) == 0;
+    const bool single = p.dpad == KS;
+#define FA_LAUNCH(M, D, F, S)                                                                     \
     do {                                                                                          \
-        HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_kernel<M, D>,                        \
+        HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_kernel<M, D, F, S>,                  \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));     \
-        hipLaunchKernelGGL((flat_scan_kernel<M, D>), grid, block, lds, stream, p);                \
+        hipLaunchKernelGGL((flat_scan_kernel<M, D, F, S>), grid, block, lds, stream, p);          \
+    } while (0)
+#define FA_LAUNCH_F(M, D)                          \
+    do {                                           \
+        if (single) FA_LAUNCH(M, D, true, true);   \
+        else if (full) FA_LAUNCH(M, D, true, false); \
+        else FA_LAUNCH(M, D, false, false);        \
     } while (0)
     if (p.metric == METRIC_L2) {
-        if (p.dump) FA_LAUNCH(METRIC_L2, true);
-        else FA_LAUNCH(METRIC_L2, false);
+        if (p.dump) FA_LAUNCH_F(METRIC_L2, true);
+        else FA_LAUNCH_F(METRIC_L2, false);
     } else {
-        if (p.dump) FA_LAUNCH(METRIC_INNER_PRODUCT, true);
-        else FA_LAUNCH(METRIC_INNER_PRODUCT, false);
+        if (p.dump) FA_LAUNCH_F(METRIC_INNER_PRODUCT, true);
+        else FA_LAUNCH_F(METRIC_INNER_PRODUCT, false);
     }
+#undef FA_LAUNCH_F
 #undef FA_LAUNCH
     HIP_CHECK(hipGetLastError());
 }

@@ -1,0 +1,30 @@
+"""faiss_amd/datasets.py -- synthetic inputs shaped like the reference's benchmarks.
+
+``synthetic_dataset`` restates the reference's own SyntheticDataset recipe
+(contrib/datasets.py:89-105): a 10-dimensional Gaussian pushed through a random linear map,
+per-dimension scaling and sin().  It is the generator SURVEY.md section 8(d) prescribes for the
+"SIFT1M-shaped" workload (d=128, nt=100k, nb=1M, nq=10k, seed 1338): clustered enough that IVF
+recall is meaningful, unlike uniform noise in 128 dimensions.
+"""
+import numpy as np
+
+
+def synthetic_dataset(d, nt, nb, nq, seed=1338):
+    """Returns (xt, xb, xq) float32, identical to SyntheticDataset(d, nt, nb, nq, seed=seed)."""
+    d1 = 10  # intrinsic dimension (more or less)
+    n = nb + nt + nq
+    rs = np.random.RandomState(seed)
+    x = rs.normal(size=(n, d1))
+    x = np.dot(x, rs.rand(d1, d))
+    x = x * (rs.rand(d) * 4 + 0.1)
+    x = np.sin(x).astype("float32")
+    return x[:nt], x[nt:nt + nb], x[nt + nb:]
+
+
+def integer_dataset(d, nb, nq, seed=7, hi=16):
+    """Small-integer coordinates: every partial sum is exact in fp32, so every summation order
+    gives identical bits and exact distance ties are frequent (tie-rule stress)."""
+    rs = np.random.RandomState(seed)
+    xb = rs.randint(0, hi, size=(nb, d)).astype("float32")
+    xq = rs.randint(0, hi, size=(nq, d)).astype("float32")
+    return xb, xq

@@ -13,9 +13,13 @@ nothing under faiss_amd/ does.  Two oracles:
 import ctypes
 import os
 
+import sys
+
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+if os.path.dirname(_HERE) not in sys.path:
+    sys.path.insert(0, os.path.dirname(_HERE))
 ORACLE_SO = os.path.join(_HERE, "libfaiss_oracle.so")
 REF_SO = os.path.join(_HERE, "_ref", "libfaiss_ref.so")
 
@@ -326,25 +330,5 @@ class Ref:
         return r
 
 
-# --------------------------------------------------------------------------- synthetic data
-def synthetic_dataset(d, nt, nb, nq, seed=1338):
-    """The reference's own SyntheticDataset recipe (contrib/datasets.py:89-105): a 10-dim
-    ellipsoid mapped to d dims and folded by sin(); clustered enough for IVF recall to mean
-    something.  Returns (xt, xb, xq) float32."""
-    d1 = 10
-    n = nb + nt + nq
-    rs = np.random.RandomState(seed)
-    x = rs.normal(size=(n, d1))
-    x = np.dot(x, rs.rand(d1, d))
-    x = x * (rs.rand(d) * 4 + 0.1)
-    x = np.sin(x).astype("float32")
-    return x[:nt], x[nt:nt + nb], x[nt + nb:]
-
-
-def integer_dataset(d, nb, nq, seed=7, hi=16):
-    """Small-integer coordinates: every partial sum is exact in fp32, so every summation
-    order gives identical bits and exact ties are frequent (tie-rule stress)."""
-    rs = np.random.RandomState(seed)
-    xb = rs.randint(0, hi, size=(nb, d)).astype("float32")
-    xq = rs.randint(0, hi, size=(nq, d)).astype("float32")
-    return xb, xq
+# synthetic inputs live in faiss_amd/datasets.py (no oracle code there); re-exported for the tests
+from faiss_amd.datasets import integer_dataset, synthetic_dataset  # noqa: E402,F401

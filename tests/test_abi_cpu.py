@@ -1,0 +1,72 @@
+"""CPU checks of the drop-in boundary: the library loads without a GPU, exports every symbol
+declared in include/faiss_amd_c.h, follows the reference's error convention, and its host-side
+logic (shard merge) agrees with the oracle."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import faiss_amd
+from compare import check_knn
+from oracle.pyoracle import METRIC_INNER_PRODUCT, METRIC_L2, Oracle, integer_dataset
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "faiss_amd_c.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(faiss_amd_\w+)\s*\(", hdr))
+    assert len(declared) >= 45
+    lib = ctypes.CDLL(faiss_amd.LIB_PATH)
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    # the python mirror declares prototypes for all of them
+    assert declared == set(faiss_amd.exported_symbols())
+
+
+def test_no_gpu_fails_loudly_not_silently():
+    n = faiss_amd.get_num_gpus()
+    if n > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(faiss_amd.FaissAmdError) as e:
+        faiss_amd.StandardGpuResources(0)
+    assert "no CPU fallback" in str(e.value)
+    # error convention: code -2 + message, as c_api/macros_impl.h:22-56
+    lib = faiss_amd.load_library()
+    h = ctypes.c_void_p()
+    assert lib.faiss_amd_StandardGpuResources_new(ctypes.byref(h), 0) == -2
+    assert b"no HIP device" in lib.faiss_amd_get_last_error()
+
+
+def test_null_handles_are_errors_not_crashes():
+    lib = faiss_amd.load_library()
+    assert lib.faiss_amd_Index_reset(None) == -2
+    assert lib.faiss_amd_Index_d(None) == -1
+    assert lib.faiss_amd_Index_ntotal(None) == -1
+
+
+@pytest.mark.parametrize("metric", [METRIC_L2, METRIC_INNER_PRODUCT])
+def test_host_merge_equals_oracle_and_unsharded(metric):
+    xb, xq = integer_dataset(12, 2000, 31, seed=3, hi=4)
+    parts = [(0, 700), (700, 701), (701, 2000)]
+    k = 40
+    aD = np.stack([Oracle.flat_search(metric, xb[a:b], xq, k)[0] for a, b in parts])
+    aI = np.stack([Oracle.flat_search(metric, xb[a:b], xq, k)[1] for a, b in parts])  # shard 1 has 1 row: padding
+    base = [a for a, _ in parts]
+    D, I = faiss_amd.merge_knn_results(metric, aD, aI, base)
+    check_knn(D, I, *Oracle.merge_shards(metric, aD, aI, base), exact=True, name="merge vs oracle")
+    check_knn(D, I, *Oracle.flat_search(metric, xb, xq, k), exact=True, name="merge vs unsharded")
+
+
+def test_product_does_not_import_the_oracle():
+    """Only tests/, smoke() and bench.py's cpu_baseline may touch oracle/."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "faiss_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")) or f == "Makefile":
+                src = open(os.path.join(dirpath, f), errors="replace").read()
+                code = "\n".join(l for l in src.splitlines()
+                                 if not l.strip().startswith(("//", "#", "*", "/*")))
+                assert "pyoracle" not in code and "libfaiss_oracle" not in code and "libfaiss_ref" not in code, f

@@ -1,0 +1,74 @@
+"""world_size-2 test of the one-process-per-GPU sharded search (faiss_amd/distributed.py) on CPU:
+gloo backend, per-rank "local search" played by the oracle on each rank's shard, host merge
+through the C ABI (faiss_amd_merge_knn_results, no GPU needed).  The sharded result must equal
+the unsharded one exactly, ties included (reference: faiss/gpu/test/test_multi_gpu.py:31-48)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, metric, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import faiss_amd
+    from faiss_amd.distributed import ShardedSearcher, shard_bounds
+    from oracle.pyoracle import Oracle, integer_dataset
+
+    xb, xq = integer_dataset(16, 3001, 37, seed=4, hi=5)  # uneven split, many exact ties
+    k = 25
+    bounds = shard_bounds(len(xb), world)
+    lo, hi = bounds[rank]
+
+    def local_search(xq_t, kk):
+        D, I = Oracle.flat_search(metric, xb[lo:hi], xq_t.numpy(), kk)
+        return torch.from_numpy(D), torch.from_numpy(I)
+
+    def merge(aD, aI, base):
+        D, I = faiss_amd.merge_knn_results(metric, aD.numpy(), aI.numpy(), base)
+        return torch.from_numpy(D), torch.from_numpy(I)
+
+    s = ShardedSearcher(local_search, merge, [b - a for a, b in bounds], torch.device("cpu"))
+    out = None
+    for _ in range(2):  # second call reuses the gather buffers
+        out = s.search(torch.from_numpy(xq), k)
+    if rank == 0:
+        Df, If = Oracle.flat_search(metric, xb, xq, k)
+        ok = np.array_equal(out[1].numpy(), If) and np.array_equal(out[0].numpy(), Df)
+        with open(out_path, "w") as f:
+            f.write("OK" if ok else "MISMATCH")
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("metric", [1, 0])
+def test_sharded_search_two_ranks_gloo(tmp_path, metric):
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_worker, args=(2, _free_port(), metric, out), nprocs=2, join=True)
+    assert open(out).read() == "OK"
+
+
+def test_shard_bounds_match_reference_split():
+    from faiss_amd.distributed import shard_bounds
+    # IndexShards::add: shard `no` gets rows [no*n/nshard, (no+1)*n/nshard) (faiss/IndexShards.cpp:172-175)
+    assert shard_bounds(10, 3) == [(0, 3), (3, 6), (6, 10)]
+    assert shard_bounds(1000000, 8)[7] == (875000, 1000000)

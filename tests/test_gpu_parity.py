@@ -1,0 +1,322 @@
+"""GPU parity tests (pytest -m gpu): every call goes through the C ABI (faiss_amd ctypes
+mirror) and is compared with the CPU oracle restatement -- BIT-EXACT distances and labels, the
+oracle using the same summation order as the kernels -- and with the golden outputs of the
+real reference within the north-star tolerance (1e-4 relative, labels exact outside near-tie
+groups).  Test matrix modelled on faiss/gpu/test/TestGpuIndexFlat.cpp:46-109 (L2/IP, k=1..2048,
+odd dims, tiny/empty inputs) and TestGpuIndexIVF{Flat,PQ}.cpp (copyFrom, add vs CPU lists)."""
+import numpy as np
+import pytest
+
+import faiss_amd
+from compare import check_knn
+from oracle.pyoracle import METRIC_INNER_PRODUCT, METRIC_L2, Oracle, Ref, integer_dataset, synthetic_dataset
+from test_oracle_cpu import load_flat_case, load_ivf_case
+
+pytestmark = pytest.mark.gpu
+FMAX = np.finfo(np.float32).max
+
+
+@pytest.mark.parametrize("metric", [METRIC_L2, METRIC_INNER_PRODUCT])
+@pytest.mark.parametrize("d,nb,nq", [(128, 300, 70), (40, 1000, 33), (264, 200, 10), (256, 500, 40)])
+def test_mfma_distance_matrix_bit_exact(res, metric, d, nb, nq):
+    _, xb, xq = synthetic_dataset(d, 0, nb, nq, seed=d)
+    idx = faiss_amd.GpuIndexFlat(res, d, metric)
+    idx.add(xb)
+    G = idx.pairwise_distances(xq)
+    assert np.array_equal(G, Oracle.pairwise(metric, xb, xq))
+
+
+FLAT_SHAPES = [(128, 5000, 300, 10), (128, 5000, 300, 1), (128, 20000, 64, 100), (40, 3000, 50, 7),
+               (64, 50, 5, 8), (128, 3000, 1, 16), (128, 40000, 513, 128), (32, 9000, 100, 2048),
+               (384, 4000, 30, 20), (100, 70000, 257, 50)]
+
+
+@pytest.mark.parametrize("simple", [False, True])
+@pytest.mark.parametrize("metric", [METRIC_L2, METRIC_INNER_PRODUCT])
+@pytest.mark.parametrize("d,nb,nq,k", FLAT_SHAPES)
+def test_flat_search_bit_exact(res, simple, metric, d, nb, nq, k):
+    if simple and nb * nq > 5_000_000:
+        pytest.skip("cross-check kernel only at small sizes")
+    _, xb, xq = synthetic_dataset(d, 0, nb, nq, seed=nb + k)
+    idx = faiss_amd.GpuIndexFlat(res, d, metric)
+    idx.set_use_simple_kernel(simple)
+    idx.add(xb)
+    D, I = idx.search(xq, k)
+    Do, Io = Oracle.flat_search(metric, xb, xq, k)
+    check_knn(D, I, Do, Io, exact=True, name="flat")
+
+
+def test_flat_integer_ties_exact_vs_reference_golden(res):
+    """Tie rule: lowest ids win and come first -- identical to the reference CPU output."""
+    z, xb, xq = load_flat_case("flat_l2_int_ties")
+    idx = faiss_amd.GpuIndexFlatL2(res, xb.shape[1])
+    idx.add(xb)
+    for k in z["ks"]:
+        D, I = idx.search(xq, int(k))
+        check_knn(D, I, z["D_%d" % k], z["I_%d" % k], exact=True, name="ties k=%d" % k)
+
+
+@pytest.mark.parametrize("name", ["flat_l2_small", "flat_ip_small", "flat_l2_blas"])
+def test_flat_vs_reference_golden(res, name):
+    z, xb, xq = load_flat_case(name)
+    idx = faiss_amd.GpuIndexFlat(res, xb.shape[1], int(z["metric"]))
+    idx.add(xb)
+    for k in z["ks"]:
+        D, I = idx.search(xq, int(k))
+        st = check_knn(D, I, z["D_%d" % k], z["I_%d" % k], rtol=1e-4, name="%s k=%d" % (name, k))
+        assert st["max_rel_err"] < 2e-5
+
+
+def test_flat_incremental_add_reset_reconstruct(res):
+    _, xb, xq = synthetic_dataset(72, 0, 5000, 20, seed=2)
+    idx = faiss_amd.GpuIndexFlatL2(res, 72)
+    idx.add(xb[:1234])
+    idx.add(xb[1234:1235])
+    idx.add(xb[1235:])
+    assert idx.ntotal == 5000
+    D, I = idx.search(xq, 9)
+    check_knn(D, I, *Oracle.flat_search(METRIC_L2, xb, xq, 9), exact=True, name="incremental")
+    assert np.array_equal(idx.reconstruct(777), xb[777])
+    assert np.array_equal(idx.reconstruct_n(100, 50), xb[100:150])
+    idx.reset()
+    assert idx.ntotal == 0
+    D, I = idx.search(xq, 3)
+    assert (I == -1).all() and (D == FMAX).all()
+
+
+def test_flat_k_larger_than_ntotal_pads(res):
+    xb, xq = integer_dataset(16, 5, 3, seed=1)
+    for metric, pad in ((METRIC_L2, FMAX), (METRIC_INNER_PRODUCT, -FMAX)):
+        idx = faiss_amd.GpuIndexFlat(res, 16, metric)
+        idx.add(xb)
+        D, I = idx.search(xq, 8)
+        Do, Io = Oracle.flat_search(metric, xb, xq, 8)
+        check_knn(D, I, Do, Io, exact=True, name="pad")
+        assert (I[:, 5:] == -1).all() and (D[:, 5:] == pad).all()
+
+
+def test_flat_empty_query_batch_and_errors(res):
+    idx = faiss_amd.GpuIndexFlatL2(res, 8)
+    idx.add(np.zeros((4, 8), "float32"))
+    D, I = idx.search(np.zeros((0, 8), "float32"), 3)
+    assert D.shape == (0, 3)
+    with pytest.raises(faiss_amd.FaissAmdError):
+        idx.search(np.zeros((1, 8), "float32"), 2049)  # k limit, faiss/gpu/utils/DeviceDefs.cuh:39
+    with pytest.raises(faiss_amd.FaissAmdError):
+        idx.search(np.zeros((1, 8), "float32"), 0)
+    with pytest.raises(ValueError):
+        idx.add(np.zeros((1, 9), "float32"))
+    with pytest.raises(faiss_amd.FaissAmdError):
+        faiss_amd.GpuIndexFlat(res, 8, 23)  # unsupported metric
+
+
+def test_flat_nan_query_returns_no_result(res):
+    """A NaN query admits nothing on the CPU reference (strict compare), TestGpuIndexFlat QueryNaN."""
+    _, xb, xq = synthetic_dataset(32, 0, 500, 4, seed=3)
+    xq = xq.copy()
+    xq[1, 5] = np.nan
+    idx = faiss_amd.GpuIndexFlatL2(res, 32)
+    idx.add(xb)
+    D, I = idx.search(xq, 5)
+    assert (I[1] == -1).all() and (I[0] >= 0).all()
+    check_knn(D, I, *Oracle.flat_search(METRIC_L2, xb, xq, 5), exact=True, name="nan")
+
+
+def test_flat_large_query_batch_tiles(res):
+    """More queries than one scratch tile (reference test LargeBatch, >= 65536 queries)."""
+    _, xb, xq = synthetic_dataset(16, 0, 300, 70000, seed=8)
+    idx = faiss_amd.GpuIndexFlatL2(res, 16)
+    idx.add(xb)
+    res.setTempMemory(64 << 20)
+    try:
+        D, I = idx.search(xq, 4)
+    finally:
+        res.setTempMemory(4 << 30)
+    sel = np.r_[0:50, 30000:30050, 69950:70000]
+    Do, Io = Oracle.flat_search(METRIC_L2, xb, xq[sel], 4)
+    check_knn(D[sel], I[sel], Do, Io, exact=True, name="large batch")
+
+
+# ------------------------------------------------------------------------------- IVF
+def _make_ivf(res, c):
+    z = c["z"]
+    d = c["xb"].shape[1]
+    nlist = z["centroids"].shape[0]
+    if c["kind"] == 0:
+        idx = faiss_amd.GpuIndexIVFFlat(res, d, nlist, c["metric"])
+    else:
+        idx = faiss_amd.GpuIndexIVFPQ(res, d, nlist, c["M"], 8, c["metric"])
+        idx.copy_pq_centroids(c["pq"])
+    idx.copy_centroids(z["centroids"])
+    return idx
+
+
+@pytest.mark.parametrize("name", ["ivfflat_l2", "ivfflat_ip", "ivfpq_l2", "ivfpq_ip"])
+def test_ivf_copy_from_reference_and_search(res, name):
+    """copyFrom a CPU-trained reference index (TestGpuIndexIVFPQ.cpp:149-168 pattern)."""
+    c = load_ivf_case(name)
+    z = c["z"]
+    idx = _make_ivf(res, c)
+    idx.copy_lists(z["list_sizes"], c["codes"], z["list_ids"])
+    assert idx.ntotal == len(z["list_ids"])
+    for nprobe in (1, c["nprobe"], 64):  # 64 > nlist: clamps like the reference
+        idx.nprobe = nprobe
+        D, I = idx.search(c["xq"], c["k"])
+        Do, Io, _, _ = Oracle.ivf_search(c["kind"], c["metric"], z["centroids"], z["list_sizes"], c["codes"],
+                                         z["list_ids"], c["xq"], nprobe, c["k"], M=c["M"], pq=c["pq"])
+        check_knn(D, I, Do, Io, exact=True, name=name + " vs oracle")
+        if nprobe == c["nprobe"]:
+            st = check_knn(D, I, z["D"], z["I"], rtol=1e-4, name=name + " vs golden")
+            assert st["max_rel_err"] < 2e-5
+
+
+@pytest.mark.parametrize("name", ["ivfflat_l2", "ivfpq_l2", "ivfpq_ip"])
+def test_ivf_add_builds_reference_lists(res, name):
+    """add_with_ids in several batches produces byte-identical lists (testIVFEquality,
+    faiss/gpu/test/TestUtils.h:111-142): sizes, ids and codes, in insertion order."""
+    c = load_ivf_case(name)
+    z = c["z"]
+    idx = _make_ivf(res, c)
+    n = len(c["xb"])
+    cuts = [0, n // 5, n // 5 + 1, n // 2, n]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        idx.add_with_ids(c["xb"][a:b], c["ids"][a:b])
+    nlist = z["centroids"].shape[0]
+    sizes, codes, lids, _ = Oracle.build_ivf_lists(c["kind"], c["metric"], z["centroids"], c["xb"], ids=c["ids"],
+                                                   pq=c["pq"])
+    assert np.array_equal(np.array([idx.get_list_size(l) for l in range(nlist)], dtype=np.uint32), sizes)
+    assert np.array_equal(np.concatenate([idx.get_list_ids(l) for l in range(nlist)]), lids)
+    got = np.concatenate([idx.get_list_codes(l) for l in range(nlist)])
+    assert np.array_equal(got.reshape(-1), codes.reshape(-1))
+    # and against the real reference's lists (golden): identical sizes / ids, codes up to argmin near-ties
+    assert np.array_equal(sizes, z["list_sizes"]) and np.array_equal(lids, z["list_ids"])
+    idx.nprobe = c["nprobe"]
+    D, I = idx.search(c["xq"], c["k"])
+    check_knn(D, I, z["D"], z["I"], rtol=1e-4, name=name + " add+search vs golden")
+
+
+def test_ivf_untrained_and_errors(res):
+    idx = faiss_amd.GpuIndexIVFFlat(res, 16, 8, METRIC_L2)
+    assert not idx.is_trained
+    with pytest.raises(faiss_amd.FaissAmdError):
+        idx.add(np.zeros((3, 16), "float32"))
+    with pytest.raises(faiss_amd.FaissAmdError):
+        idx.search(np.zeros((3, 16), "float32"), 2)
+    with pytest.raises(faiss_amd.FaissAmdError):
+        faiss_amd.GpuIndexIVFPQ(res, 30, 8, 8, 8, METRIC_L2)  # d % M != 0
+    with pytest.raises(faiss_amd.FaissAmdError):
+        faiss_amd.GpuIndexIVFPQ(res, 32, 8, 8, 6, METRIC_L2)  # only 8-bit codes (GpuIndexIVFPQ.cu:574-592)
+    with pytest.raises(faiss_amd.FaissAmdError):
+        idx.nprobe = 5000
+
+
+def test_ivf_native_train_recall(res):
+    """Train / add / search entirely on the GPU; recall threshold in the style of
+    tests/test_ivfpq_indexing.cpp and tests/test_index_accuracy.py."""
+    xt, xb, xq = synthetic_dataset(64, 20000, 100000, 500, seed=4)
+    flat = faiss_amd.GpuIndexFlatL2(res, 64)
+    flat.add(xb)
+    _, gt = flat.search(xq, 1)
+    ivf = faiss_amd.GpuIndexIVFFlat(res, 64, 256, METRIC_L2)
+    ivf.train(xt)
+    ivf.add(xb)
+    assert ivf.ntotal == 100000 and sum(ivf.get_list_size(l) for l in range(256)) == 100000
+    ivf.nprobe = 256  # probing every list == exhaustive search: same label sets as Flat
+    D, I = ivf.search(xq[:50], 10)
+    Df, If = flat.search(xq[:50], 10)
+    check_knn(D, I, Df, If, rtol=1e-4, tie_rtol=1e-4, name="ivfflat nprobe=nlist vs flat")
+    ivf.nprobe = 16
+    _, I = ivf.search(xq, 10)
+    assert (I[:, :1] == gt).mean() > 0.9
+    pq = faiss_amd.GpuIndexIVFPQ(res, 64, 256, 16, 8, METRIC_L2)
+    pq.train(xt)
+    pq.add(xb)
+    pq.nprobe = 16
+    _, I = pq.search(xq, 10)
+    assert (I == gt).any(axis=1).mean() > 0.8
+
+
+def test_kmeans_objective_matches_reference(res):
+    """faiss/gpu/test/test_gpu_basics.py:117-133: GPU k-means objective close to the CPU one."""
+    xt, _, _ = synthetic_dataset(32, 12000, 0, 0, seed=3)
+    cent, obj = faiss_amd.kmeans(res, xt, 40, niter=10, seed=1)
+    assert np.all(np.diff(obj) <= obj[:-1] * 1e-3)  # Lloyd objective is (almost) monotone
+    o = Oracle.kmeans_objective(xt, cent)
+    assert o <= obj[-1] * 1.001
+    if Ref.available():
+        _, robj = Ref.kmeans(xt, 40, niter=10, seed=1)
+        assert abs(obj[-1] / robj - 1) < 0.05
+
+
+# ------------------------------------------------------------------------------- shards / merge
+def test_index_shards_equals_single_index(res):
+    """faiss/gpu/test/test_multi_gpu.py:31-48: sharded flat must give I == I_ref exactly."""
+    xb, xq = integer_dataset(24, 9000, 64, seed=11, hi=6)  # ties on purpose
+    single = faiss_amd.GpuIndexFlatL2(res, 24)
+    single.add(xb)
+    Dr, Ir = single.search(xq, 40)
+    sh = faiss_amd.IndexShards(24, threaded=True, successive_ids=True)
+    for _ in range(3):
+        sh.add_shard(faiss_amd.GpuIndexFlatL2(res, 24))
+    sh.add(xb)
+    assert sh.ntotal == 9000
+    D, I = sh.search(xq, 40)
+    check_knn(D, I, Dr, Ir, exact=True, name="shards")
+
+
+def test_device_merge_matches_host_merge(res):
+    import torch
+    xb, xq = integer_dataset(16, 3000, 50, seed=2, hi=4)
+    parts = [(0, 1000), (1000, 2100), (2100, 3000)]
+    k = 33
+    aD = np.stack([Oracle.flat_search(METRIC_L2, xb[a:b], xq, k)[0] for a, b in parts])
+    aI = np.stack([Oracle.flat_search(METRIC_L2, xb[a:b], xq, k)[1] for a, b in parts])
+    base = [a for a, _ in parts]
+    Dh, Ih = faiss_amd.merge_knn_results(METRIC_L2, aD, aI, base)
+    Do, Io = Oracle.merge_shards(METRIC_L2, aD, aI, base)
+    check_knn(Dh, Ih, Do, Io, exact=True, name="host merge")
+    check_knn(Dh, Ih, *Oracle.flat_search(METRIC_L2, xb, xq, k), exact=True, name="merge == unsharded")
+    dD, dI = torch.from_numpy(aD).cuda(), torch.from_numpy(aI).cuda()
+    oD = torch.empty((50, k), dtype=torch.float32, device="cuda")
+    oI = torch.empty((50, k), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    faiss_amd.merge_knn_results_device(res, METRIC_L2, 50, k, 3, dD.data_ptr(), dI.data_ptr(), base,
+                                       oD.data_ptr(), oI.data_ptr())
+    check_knn(oD.cpu().numpy(), oI.cpu().numpy(), Do, Io, exact=True, name="device merge")
+
+
+def test_device_pointers_in_and_out(res):
+    import torch
+    _, xb, xq = synthetic_dataset(64, 0, 4000, 100, seed=6)
+    idx = faiss_amd.GpuIndexFlatL2(res, 64)
+    idx.add_ptr(4000, torch.from_numpy(xb).cuda().data_ptr())
+    q = torch.from_numpy(xq).cuda()
+    D = torch.empty((100, 10), dtype=torch.float32, device="cuda")
+    I = torch.empty((100, 10), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    idx.search_ptr(100, q.data_ptr(), 10, D.data_ptr(), I.data_ptr())
+    check_knn(D.cpu().numpy(), I.cpu().numpy(), *Oracle.flat_search(METRIC_L2, xb, xq, 10), exact=True, name="devptr")
+
+
+# ------------------------------------------------------------------------------- drop-in
+@pytest.mark.skipif(not Ref.available(), reason="oracle/_ref not shipped")
+def test_dropin_reference_clustering_and_shards_run_on_backend(res):
+    """The reference's own callers of the hot path run unchanged on the backend through a
+    faiss::Index subclass over the C ABI: faiss::Clustering::train (Clustering.cpp:255-357) and
+    faiss::IndexShards (IndexShards.cpp:135-265)."""
+    xt, xb, xq = synthetic_dataset(32, 6000, 5000, 40, seed=9)
+    amd = faiss_amd.GpuIndexFlatL2(res, 32)
+    ad = Ref.adapter(amd)
+    cent_gpu, obj_gpu = Ref.kmeans_with_index(xt, 24, ad, niter=8, seed=7)
+    cent_cpu, obj_cpu = Ref.kmeans(xt, 24, niter=8, seed=7)
+    # same RNG + same assignment results => same trajectory (up to fp noise in near-tie assignments)
+    assert abs(obj_gpu / obj_cpu - 1) < 1e-3
+    # faiss::IndexShards over two backend indexes == faiss CPU flat
+    subs = [Ref.adapter(faiss_amd.GpuIndexFlatL2(res, 32)) for _ in range(2)]
+    sh = Ref.shards(32, subs, threaded=True, successive_ids=True)
+    sh.add(xb)
+    D, I = sh.search(xq, 10)
+    ref = Ref.index_factory(32, "Flat")
+    ref.add(xb)
+    Dr, Ir = ref.search(xq, 10)
+    check_knn(D, I, Dr, Ir, rtol=1e-4, name="faiss::IndexShards over backend")
