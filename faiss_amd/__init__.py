@@ -87,6 +87,7 @@ def load_library():
         "faiss_amd_profile_get": (i32, [vp, ctypes.c_char_p, P(ctypes.c_double), P(ctypes.c_long)]),
         "faiss_amd_GpuIndexFlat_pairwise_distances": (i32, [vp, i64, vp, vp]),
         "faiss_amd_GpuIndexFlat_set_use_simple_kernel": (i32, [vp, i32]),
+        "faiss_amd_GpuIndexIVF_set_use_fused_scan": (i32, [vp, i32]),
     }
     for name, (res, args) in protos.items():
         fn = getattr(lib, name)  # AttributeError => the library does not export the symbol
@@ -265,6 +266,10 @@ class GpuIndexFlatIP(GpuIndexFlat):
 
 class _GpuIndexIVF(Index):
     """faiss.GpuIndexIVF (faiss/gpu/GpuIndexIVF.h:37-153)."""
+
+    def set_use_fused_scan(self, on):
+        """test hook: False routes search() through the unfused scan + select kernels"""
+        _check(self._lib.faiss_amd_GpuIndexIVF_set_use_fused_scan(self._h, 1 if on else 0))
 
     @property
     def nlist(self):

@@ -384,4 +384,10 @@ int faiss_amd_GpuIndexFlat_set_use_simple_kernel(FaissAmdIndex* index, int on) {
     FA_CATCH
 }
 
+int faiss_amd_GpuIndexIVF_set_use_fused_scan(FaissAmdIndex* index, int on) {
+    FA_TRY
+    as<GpuIndexIVF>(index, "GpuIndexIVF")->use_fused_scan = on != 0;
+    FA_CATCH
+}
+
 } // extern "C"

@@ -728,6 +728,10 @@ void GpuIndexIVF::search(idx_t n, const float* x, idx_t k, float* distances, idx
     size_t per_q = (size_t)np * max_len * 8;
     idx_t tile = (idx_t)std::max<size_t>(1, R.temp_budget_bytes / per_q);
     tile = std::min<idx_t>(tile, 16384);
+    int fused_cap = 0, fused_kp = 0;
+    const bool fused = use_fused_scan &&
+                       ivf_fused_supported(fused_kind_(), fused_M_(), dpad_, (int)k, np, &fused_cap, &fused_kp);
+    if (fused) tile = 65536; // no per-candidate scratch: the tile only bounds the staging buffers
     for (idx_t i0 = 0; i0 < n; i0 += tile) {
         const int ni = (int)std::min(tile, n - i0);
         q_pad_.ensure((size_t)ni * dpad_ * 4);
@@ -736,6 +740,81 @@ void GpuIndexIVF::search(idx_t n, const float* x, idx_t k, float* distances, idx
         c_dis_.ensure((size_t)ni * np * 4);
         c_ids_.ensure((size_t)ni * np * 8);
         quantizer->search_device(ni, q_pad_.as<float>(), np, c_dis_.as<float>(), c_ids_.as<idx_t>());
+        float* dD = out_dev_d ? distances + (size_t)i0 * k : nullptr;
+        idx_t* dI = out_dev_i ? labels + (size_t)i0 * k : nullptr;
+        if (!dD) {
+            out_d_.ensure((size_t)ni * k * 4);
+            dD = out_d_.as<float>();
+        }
+        if (!dI) {
+            out_i_.ensure((size_t)ni * k * 8);
+            dI = out_i_.as<idx_t>();
+        }
+        if (fused) {
+            // ---- table build + list scan + k-selection in one launch, nothing but results leaves LDS
+            IvfFusedParams fp{};
+            fp.metric = metric_type;
+            fp.kind = fused_kind_();
+            fp.nq = ni;
+            fp.nprobe = np;
+            fp.d = d;
+            fp.dpad = dpad_;
+            fp.xq = q_pad_.as<float>();
+            fp.ldq = dpad_;
+            fp.coarse_ids = c_ids_.as<idx_t>();
+            fp.coarse_dis = c_dis_.as<float>();
+            fp.list_len = d_list_len_.as<uint32_t>();
+            fp.list_start = d_list_start_.as<int64_t>();
+            fp.arena_ids = arena_ids_.as<int64_t>();
+            fp.k = (int)k;
+            fp.kp = fused_kp;
+            fp.cap = fused_cap;
+            // enough workgroups to fill the chip twice over; probes are split only for small batches
+            const int want = 4 * R.num_cus;
+            int G = ni >= want ? 1 : std::min<int>(np, (int)div_up(want, ni));
+            fp.npc = (int)div_up(np, G);
+            fp.G = (int)div_up(np, fp.npc);
+            fp.out_dis = dD;
+            fp.out_ids = dI;
+            if (fp.G > 1) {
+                part_keys_.ensure((size_t)ni * fp.G * k * 8);
+                part_cnt_.ensure((size_t)ni * fp.G * 4);
+                prefix_.ensure((size_t)ni * (np + 1) * 4);
+                fp.part_keys = part_keys_.as<unsigned long long>();
+                fp.part_cnt = part_cnt_.as<uint32_t>();
+                fp.prefix_out = prefix_.as<uint32_t>();
+            }
+            fill_fused_(fp);
+            {
+                SpanGuard sg(&R, fp.kind == 1 ? "ivfpq_fused_kernel" : "ivfflat_fused_kernel");
+                launch_ivf_fused(fp, R.stream);
+            }
+            if (fp.G > 1) {
+                SelectParams sp{};
+                sp.metric = metric_type;
+                sp.nq = ni;
+                sp.k = (int)k;
+                sp.keys = fp.part_keys;
+                sp.q_stride = (int64_t)fp.G * k;
+                sp.nseg = fp.G;
+                sp.seg_stride = k;
+                sp.seg_cnt = fp.part_cnt;
+                sp.mode = 1;
+                sp.nprobe = np;
+                sp.ivf_prefix = fp.prefix_out;
+                sp.coarse_ids = c_ids_.as<idx_t>();
+                sp.list_start = d_list_start_.as<int64_t>();
+                sp.arena_ids = arena_ids_.as<int64_t>();
+                sp.out_dis = dD;
+                sp.out_ids = dI;
+                SpanGuard sg(&R, "select_k_kernel");
+                launch_select_k(sp, R.stream);
+            }
+            if (!out_dev_d) copy_out(R, distances + (size_t)i0 * k, dD, (size_t)ni * k * 4);
+            if (!out_dev_i) copy_out(R, labels + (size_t)i0 * k, dI, (size_t)ni * k * 8);
+            R.sync();
+            continue;
+        }
         // ---- per-(query, probe) offsets
         prefix_.ensure((size_t)ni * (np + 1) * 4);
         totals_.ensure((size_t)ni * 4);
@@ -757,16 +836,6 @@ void GpuIndexIVF::search(idx_t n, const float* x, idx_t k, float* distances, idx
         nprobe_eff_ = np;
         scan_(ni, q_pad_.as<float>(), (int)k, nullptr);
         // ---- k-selection + (probe, offset) -> user id
-        float* dD = out_dev_d ? distances + (size_t)i0 * k : nullptr;
-        idx_t* dI = out_dev_i ? labels + (size_t)i0 * k : nullptr;
-        if (!dD) {
-            out_d_.ensure((size_t)ni * k * 4);
-            dD = out_d_.as<float>();
-        }
-        if (!dI) {
-            out_i_.ensure((size_t)ni * k * 8);
-            dI = out_i_.as<idx_t>();
-        }
         SelectParams sp{};
         sp.metric = metric_type;
         sp.nq = ni;
@@ -802,6 +871,10 @@ GpuIndexIVFFlat::GpuIndexIVFFlat(std::shared_ptr<GpuResources> res, int dims, in
 }
 void GpuIndexIVFFlat::append_(int n, const float* x_pad, const int64_t*, const int64_t* d_dest) {
     launch_ivfflat_append(x_pad, dpad_, n, d, d_dest, arena_.as<float>(), dpad_, dpad_, res_->stream);
+}
+void GpuIndexIVFFlat::fill_fused_(IvfFusedParams& p) const {
+    p.arena_vecs = arena_.as<float>();
+    p.ldv = dpad_;
 }
 void GpuIndexIVFFlat::scan_(int nq, const float* xq_pad, int, const int64_t*) const {
     IvfScanParams p{};
@@ -887,6 +960,15 @@ void GpuIndexIVFPQ::append_(int n, const float* x_pad, const int64_t* d_labels, 
     FA_THROW_IF_NOT_MSG(pq_.p, "PQ not trained");
     launch_ivfpq_encode_append(x_pad, dpad_, n, d, d_labels, d_dest, quantizer->device_vectors(), dpad_, M,
                                dsub, pq_.as<float>(), arena_.as<uint8_t>(), res_->stream);
+}
+void GpuIndexIVFPQ::fill_fused_(IvfFusedParams& p) const {
+    FA_THROW_IF_NOT_MSG(pq_.p, "PQ not trained");
+    p.centroids = quantizer->device_vectors();
+    p.ldc = dpad_;
+    p.M = M;
+    p.dsub = dsub;
+    p.pq_centroids = pq_.as<float>();
+    p.arena_codes = arena_.as<uint8_t>();
 }
 void GpuIndexIVFPQ::scan_(int nq, const float* xq_pad, int, const int64_t*) const {
     FA_THROW_IF_NOT_MSG(pq_.p, "PQ not trained");

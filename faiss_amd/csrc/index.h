@@ -182,7 +182,19 @@ class GpuIndexIVF : public Index {
     // encode/scatter n staged vectors (device, padded) with given labels into arena rows dest
     virtual void append_(int n, const float* x_pad, const int64_t* d_labels, const int64_t* d_dest) = 0;
     virtual void scan_(int nq, const float* xq_pad, int k, const int64_t* h_qoff) const = 0;
+    // fused search (ivf_fused.hip): kind/M and the type-specific pointers of IvfFusedParams
+    virtual void fill_fused_(struct IvfFusedParams& p) const = 0;
+    virtual int fused_kind_() const = 0;
+    virtual int fused_M_() const { return 0; }
+    mutable DevBuf part_keys_, part_cnt_;
     void upload_list_tables_();
+
+   public:
+    // when false, search() takes the unfused path (every distance as a key in HBM + select);
+    // kept for cross-checking the fused kernel and for shapes that do not fit its LDS budget
+    bool use_fused_scan = true;
+
+   protected:
 };
 
 class GpuIndexIVFFlat : public GpuIndexIVF {
@@ -190,6 +202,8 @@ class GpuIndexIVFFlat : public GpuIndexIVF {
     GpuIndexIVFFlat(std::shared_ptr<GpuResources> res, int dims, int nlist, int metric);
 
    protected:
+    void fill_fused_(struct IvfFusedParams& p) const override;
+    int fused_kind_() const override { return 0; }
     void append_(int n, const float* x_pad, const int64_t* d_labels, const int64_t* d_dest) override;
     void scan_(int nq, const float* xq_pad, int k, const int64_t* h_qoff) const override;
 };
@@ -203,6 +217,9 @@ class GpuIndexIVFPQ : public GpuIndexIVF {
     std::vector<float> get_pq_centroids() const;
 
    protected:
+    void fill_fused_(struct IvfFusedParams& p) const override;
+    int fused_kind_() const override { return 1; }
+    int fused_M_() const override { return M; }
     DevBuf pq_; // [M][256][dsub]
     void train_residual_(idx_t n, const float* x_dev_pad) override;
     void append_(int n, const float* x_pad, const int64_t* d_labels, const int64_t* d_dest) override;

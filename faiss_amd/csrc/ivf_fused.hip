@@ -1,0 +1,425 @@
+// faiss_amd/csrc/ivf_fused.hip -- fused inverted-list search for gfx950: one workgroup walks the
+// probed lists of one query, builds the PQ lookup table in LDS, scans the list codes against
+// it and keeps the running top-k in an LDS reservoir.  Neither the table (64 KB per (query,
+// probe) at M = 64) nor the per-code distances ever reach HBM; the only global traffic is
+// the code stream itself plus k results per query.
+//
+// Replaces, in one launch, the reference chain
+//   runPQCodeDistances        faiss/gpu/impl/PQCodeDistances-inl.cuh:29-285, 590-736  (table -> global)
+//   pqScanNoPrecomputedMultiPass  faiss/gpu/impl/PQScanMultiPassNoPrecomputed-inl.cuh:173-270 (distances -> global)
+//   runCalcListOffsets / runPass1SelectLists / runPass2SelectLists
+//                             faiss/gpu/impl/IVFUtils.cu:131-186, IVFUtilsSelect1.cu, IVFUtilsSelect2.cu
+// and, for IVFFlat, ivfInterleavedScan + ivfInterleavedScan2 (faiss/gpu/impl/IVFInterleaved.cuh:33-224,
+// IVFInterleaved.cu:18-177).
+//
+// Arithmetic contract: identical to ivf_kernels.hip (restated by oracle/faiss_oracle.c):
+//   IVFPQ L2: r = q - centroid; lut[m][c] = chain_j fmaf(r_mj - pq[m][c][j], same, acc);
+//             dis = ((0 + lut[0][c0]) + lut[1][c1]) + ...  (m ascending)
+//   IVFPQ IP: lut[m][c] = chain_j fmaf(q_mj, pq[m][c][j], acc); dis = coarse_ip + sum_m lut
+//   IVFFlat : dis = chain_k fmaf(q[k]-y[k], q[k]-y[k], acc) (L2) / fmaf(q[k], y[k], acc) (IP)
+//   selection: k smallest keys (ordkey(dis) << 32 | position in probe order) = "first scanned wins"
+//             among equal distances (faiss/IndexIVF.cpp:642-655 + strict heap admission); the k winners
+//             are then ordered by (distance, id) (faiss/impl/ResultHandler.h:439-453).
+#include "kernels.h"
+#include "wg_select.h"
+
+namespace faiss_amd {
+
+constexpr int FB = 512;   // threads per workgroup (8 wavefronts: ds_read_b32 needs >= 4 waves/SIMD to stream)
+constexpr int FMAXR = 8;  // reservoir capacity <= FMAXR * FB keys
+
+struct FusedLds {
+    char* lut;        // [M][256] fp32 | at the end: winners
+    float* rs;        // [dpad] residual (L2) or query (IP)
+    u64* res;         // [cap]
+    uint32_t* pre;    // [nprobe + 1]
+    int* lst;         // [nprobe]
+    unsigned* hist;   // [256]
+    WgSelCtl* ctl;
+};
+
+static size_t fused_region0_bytes(int kind, int M, int kp) {
+    size_t lut = kind == 1 ? (size_t)M * 1024 : 0;
+    return round_up(std::max<size_t>(std::max<size_t>(lut, (size_t)kp * 12), 16), 16);
+}
+size_t ivf_fused_lds_bytes(int kind, int M, int dpad, int kp, int cap, int nprobe) {
+    return fused_region0_bytes(kind, M, kp) + round_up((size_t)dpad * 4, 16) + (size_t)cap * 8 +
+           round_up((size_t)(nprobe + 1) * 4, 16) + round_up((size_t)nprobe * 4, 16) + 1024 + 64;
+}
+
+__device__ __forceinline__ FusedLds fused_carve(char* smem, const IvfFusedParams& p) {
+    FusedLds L;
+    size_t o = 0;
+    L.lut = smem;
+    {
+        size_t lut = p.kind == 1 ? (size_t)p.M * 1024 : 0;
+        size_t r0 = lut > (size_t)p.kp * 12 ? lut : (size_t)p.kp * 12;
+        if (r0 < 16) r0 = 16;
+        o = (r0 + 15) & ~(size_t)15;
+    }
+    L.rs = (float*)(smem + o);
+    o += ((size_t)p.dpad * 4 + 15) & ~(size_t)15;
+    L.res = (u64*)(smem + o);
+    o += (size_t)p.cap * 8;
+    L.pre = (uint32_t*)(smem + o);
+    o += ((size_t)(p.nprobe + 1) * 4 + 15) & ~(size_t)15;
+    L.lst = (int*)(smem + o);
+    o += ((size_t)p.nprobe * 4 + 15) & ~(size_t)15;
+    L.hist = (unsigned*)(smem + o);
+    o += 1024;
+    L.ctl = (WgSelCtl*)(smem + o);
+    return L;
+}
+
+// probed lists of query q -> LDS (list ids, exclusive prefix of their lengths)
+__device__ __forceinline__ void fused_load_probes(const IvfFusedParams& p, int q, const FusedLds& L) {
+    const int tid = threadIdx.x;
+    for (int t = tid; t < p.nprobe; t += FB) {
+        const int64_t l = p.coarse_ids[(int64_t)q * p.nprobe + t];
+        L.lst[t] = (int)l;
+        L.pre[t + 1] = l >= 0 ? p.list_len[l] : 0u;
+    }
+    if (tid == 0) {
+        L.pre[0] = 0;
+        L.ctl->cnt = 0;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        unsigned carry = 0;
+        for (int base = 0; base < p.nprobe; base += 64) {
+            const int t = base + tid;
+            unsigned v = t < p.nprobe ? L.pre[t + 1] : 0u;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned o = __shfl_up(v, off, 64);
+                if (tid >= off) v += o;
+            }
+            v += carry;
+            if (t < p.nprobe) L.pre[t + 1] = v;
+            carry = __shfl(v, 63, 64);
+        }
+    }
+    __syncthreads();
+}
+
+// Cut the reservoir back to its k smallest keys when the next chunk might not fit.  `bound` is
+// a wave-uniform upper bound of the live count kept in a register, so the shared counter is
+// only consulted (read by everybody, THEN a barrier, so that no early lane appends in between)
+// when the bound says the reservoir could be full.
+#define FUSED_MAKE_ROOM(chunk)                                                         \
+    do {                                                                               \
+        if (bound + FB > p.cap) {                                                      \
+            const int n_ = (int)L.ctl->cnt;                                            \
+            __syncthreads();                                                           \
+            bound = n_;                                                                \
+            if (n_ + FB > p.cap) {                                                     \
+                const u64 kth_ = wg_select_kth<FB>(L.res, n_, p.k, L.hist, L.ctl);     \
+                wg_compact<FB>(L.res, n_, kth_, L.ctl);                         \
+                tau = kth_;                                                            \
+                bound = p.k;                                                           \
+            }                                                                          \
+        }                                                                              \
+        bound += (int)(chunk);                                                         \
+    } while (0)
+
+// final k-selection, position -> user id, ordering, write-out (or partial keys when G > 1)
+__device__ __forceinline__ void fused_finish(const IvfFusedParams& p, int q, int g, const FusedLds& L) {
+    const int tid = threadIdx.x;
+    __syncthreads();
+    int n = (int)L.ctl->cnt;
+    if (n > p.k) {
+        const u64 kth = wg_select_kth<FB>(L.res, n, p.k, L.hist, L.ctl);
+        wg_compact<FB>(L.res, n, kth, L.ctl);
+        n = (int)L.ctl->cnt;
+    }
+    if (p.G > 1) {
+        u64* out = p.part_keys + ((int64_t)q * p.G + g) * p.k;
+        for (int i = tid; i < n; i += FB) out[i] = L.res[i];
+        if (tid == 0) p.part_cnt[(int64_t)q * p.G + g] = (uint32_t)n;
+        if (g == 0)
+            for (int t = tid; t <= p.nprobe; t += FB) p.prefix_out[(int64_t)q * (p.nprobe + 1) + t] = L.pre[t];
+        return;
+    }
+    int64_t* w_id = (int64_t*)L.lut;
+    unsigned* w_key = (unsigned*)(w_id + p.kp);
+    for (int i = tid; i < p.kp; i += FB) {
+        unsigned wk = 0xffffffffu;
+        int64_t wi = INT64_MAX;
+        if (i < n) {
+            const u64 key = L.res[i];
+            const uint32_t payload = (uint32_t)key;
+            int lo = 0, hi = p.nprobe; // invariant pre[lo] <= payload < pre[hi]
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (L.pre[mid] <= payload) lo = mid;
+                else hi = mid;
+            }
+            wi = p.arena_ids[p.list_start[L.lst[lo]] + (payload - L.pre[lo])];
+            wk = (uint32_t)(key >> 32);
+        }
+        w_key[i] = wk;
+        w_id[i] = wi;
+    }
+    __syncthreads();
+    wg_bitonic_sort<FB>(w_key, w_id, p.kp);
+    const float pad = neutral_distance(p.metric);
+    for (int i = tid; i < p.k; i += FB) {
+        float dis = pad;
+        int64_t id = -1;
+        if (i < n && w_key[i] < kInvalidOrdKey) {
+            dis = unordkey_rt(p.metric, w_key[i]);
+            id = w_id[i];
+        }
+        p.out_dis[(int64_t)q * p.k + i] = dis;
+        p.out_ids[(int64_t)q * p.k + i] = id;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// IVFPQ.  DSUB > 0: the PQ codebook lives in registers (thread t owns centroid t & 255 of the
+// sub-quantizers of its half of M; d <= 128, M even) and every table is built without touching
+// global memory; DSUB == 0: generic fallback that re-reads the codebook through L2.
+// ---------------------------------------------------------------------------------
+template <int METRIC, int DSUB>
+__global__ void __launch_bounds__(FB, 4) ivfpq_fused_kernel(IvfFusedParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const FusedLds L = fused_carve(smem, p);
+    const int tid = threadIdx.x;
+    const int q = blockIdx.x / p.G, g = blockIdx.x - q * p.G;
+    const int p0 = g * p.npc, p1 = min(p.nprobe, p0 + p.npc);
+    float* lut = (float*)L.lut;
+    const int M = p.M, d = p.d, dsub = p.dsub;
+
+    fused_load_probes(p, q, L);
+
+    constexpr int NREG = DSUB > 0 ? 64 : 1;
+    float pqr[NREG];
+    const int c = tid & 255;
+    const int half = __builtin_amdgcn_readfirstlane(tid >> 8);
+    const int mh = M >> 1; // sub-quantizers per half
+    if (DSUB > 0) {
+#pragma unroll
+        for (int mm = 0; mm < 64 / DSUB; ++mm) {
+#pragma unroll
+            for (int jd = 0; jd < DSUB; ++jd) {
+                float v = 0.f;
+                if (mm < mh) v = p.pq_centroids[((size_t)(half * mh + mm) * 256 + c) * DSUB + jd];
+                pqr[mm * DSUB + jd] = v;
+            }
+        }
+    }
+
+    auto build_lut = [&]() {
+        if (DSUB > 0) {
+#pragma unroll
+            for (int mm = 0; mm < 64 / DSUB; ++mm) {
+                if (mm < mh) {
+                    const int m = half * mh + mm;
+                    float acc = 0.f;
+#pragma unroll
+                    for (int jd = 0; jd < DSUB; ++jd) {
+                        const float r = L.rs[m * DSUB + jd];
+                        if (METRIC == METRIC_L2) {
+                            const float t = r - pqr[mm * DSUB + jd];
+                            acc = __fmaf_rn(t, t, acc);
+                        } else {
+                            acc = __fmaf_rn(r, pqr[mm * DSUB + jd], acc);
+                        }
+                    }
+                    lut[m * 256 + c] = acc;
+                }
+                // keep the LDS reads of the residual from being hoisted 64 deep (VGPR pressure)
+                if ((mm & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            for (int e = tid; e < M * 256; e += FB) {
+                const int m = e >> 8;
+                const float* cen = p.pq_centroids + (size_t)e * dsub;
+                const float* r = L.rs + m * dsub;
+                float acc = 0.f;
+                for (int jd = 0; jd < dsub; ++jd) {
+                    if (METRIC == METRIC_L2) {
+                        const float t = r[jd] - cen[jd];
+                        acc = __fmaf_rn(t, t, acc);
+                    } else {
+                        acc = __fmaf_rn(r[jd], cen[jd], acc);
+                    }
+                }
+                lut[e] = acc;
+            }
+        }
+    };
+
+    if (METRIC != METRIC_L2) {
+        // inner product: the table depends on the query only
+        for (int cc = tid; cc < d; cc += FB) L.rs[cc] = p.xq[(int64_t)q * p.ldq + cc];
+        __syncthreads();
+        build_lut();
+        __syncthreads();
+    }
+
+    u64 tau = ~0ull;
+    int bound = 0;
+    for (int pr = p0; pr < p1; ++pr) {
+        const int list = L.lst[pr];
+        const unsigned pos0 = L.pre[pr];
+        const unsigned len = L.pre[pr + 1] - pos0;
+        if (list < 0 || len == 0) continue;
+        const int64_t start = p.list_start[list];
+        float dis0 = 0.f;
+        if (METRIC == METRIC_L2) {
+            for (int cc = tid; cc < d; cc += FB)
+                L.rs[cc] = p.xq[(int64_t)q * p.ldq + cc] - p.centroids[(int64_t)list * p.ldc + cc];
+            __syncthreads();
+            build_lut();
+            __syncthreads();
+        } else {
+            dis0 = p.coarse_dis[(int64_t)q * p.nprobe + pr];
+        }
+        for (unsigned base = 0; base < len; base += FB) {
+            FUSED_MAKE_ROOM(min((unsigned)FB, len - base));
+            const unsigned i = base + tid;
+            bool pass = false;
+            u64 key = 0;
+            if (i < len) {
+                const uint8_t* code = p.arena_codes + (start + i) * M;
+                float acc = dis0;
+                if ((M & 15) == 0) {
+                    for (int m = 0; m < M; m += 16) {
+                        const uint4 cw = *(const uint4*)(code + m);
+                        const unsigned w[4] = {cw.x, cw.y, cw.z, cw.w};
+#pragma unroll
+                        for (int wi = 0; wi < 4; ++wi) {
+#pragma unroll
+                            for (int b = 0; b < 4; ++b) {
+                                const unsigned cc = (w[wi] >> (8 * b)) & 255u;
+                                acc = acc + lut[(m + wi * 4 + b) * 256 + cc];
+                            }
+                        }
+                    }
+                } else {
+                    for (int m = 0; m < M; m += 4) {
+                        const unsigned w = *(const unsigned*)(code + m);
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) acc = acc + lut[(m + b) * 256 + ((w >> (8 * b)) & 255u)];
+                    }
+                }
+                key = ((u64)ordkey<METRIC>(acc) << 32) | (u64)(pos0 + i);
+                pass = key < tau;
+            }
+            wg_append(L.res, L.ctl, pass, key);
+            __syncthreads();
+        }
+    }
+    fused_finish(p, q, g, L);
+}
+
+// ---------------------------------------------------------------------------------
+// IVFFlat: same reservoir machinery, distances straight from the fp32 rows of the list
+// ---------------------------------------------------------------------------------
+template <int METRIC>
+__global__ void __launch_bounds__(FB, 4) ivfflat_fused_kernel(IvfFusedParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const FusedLds L = fused_carve(smem, p);
+    const int tid = threadIdx.x;
+    const int q = blockIdx.x / p.G, g = blockIdx.x - q * p.G;
+    const int p0 = g * p.npc, p1 = min(p.nprobe, p0 + p.npc);
+
+    fused_load_probes(p, q, L);
+    for (int cc = tid; cc < p.dpad; cc += FB) L.rs[cc] = p.xq[(int64_t)q * p.ldq + cc];
+    __syncthreads();
+
+    u64 tau = ~0ull;
+    int bound = 0;
+    for (int pr = p0; pr < p1; ++pr) {
+        const int list = L.lst[pr];
+        const unsigned pos0 = L.pre[pr];
+        const unsigned len = L.pre[pr + 1] - pos0;
+        if (list < 0 || len == 0) continue;
+        const int64_t start = p.list_start[list];
+        for (unsigned base = 0; base < len; base += FB) {
+            FUSED_MAKE_ROOM(min((unsigned)FB, len - base));
+            const unsigned i = base + tid;
+            bool pass = false;
+            u64 key = 0;
+            if (i < len) {
+                const float* y = p.arena_vecs + (start + i) * p.ldv;
+                float acc = 0.f;
+                for (int k = 0; k < p.dpad; k += 4) {
+                    const float4 yv = *(const float4*)(y + k);
+                    const float4 qv = *(const float4*)(L.rs + k);
+                    if (METRIC == METRIC_L2) {
+                        float t;
+                        t = qv.x - yv.x; acc = __fmaf_rn(t, t, acc);
+                        t = qv.y - yv.y; acc = __fmaf_rn(t, t, acc);
+                        t = qv.z - yv.z; acc = __fmaf_rn(t, t, acc);
+                        t = qv.w - yv.w; acc = __fmaf_rn(t, t, acc);
+                    } else {
+                        acc = __fmaf_rn(qv.x, yv.x, acc);
+                        acc = __fmaf_rn(qv.y, yv.y, acc);
+                        acc = __fmaf_rn(qv.z, yv.z, acc);
+                        acc = __fmaf_rn(qv.w, yv.w, acc);
+                    }
+                }
+                key = ((u64)ordkey<METRIC>(acc) << 32) | (u64)(pos0 + i);
+                pass = key < tau;
+            }
+            wg_append(L.res, L.ctl, pass, key);
+            __syncthreads();
+        }
+    }
+    fused_finish(p, q, g, L);
+}
+
+// ---------------------------------------------------------------------------------
+bool ivf_fused_supported(int kind, int M, int dpad, int k, int nprobe, int* cap_out, int* kp_out) {
+    int kp = 1;
+    while (kp < k) kp <<= 1;
+    int cap = 1024;
+    while (cap < k + FB) cap <<= 1;
+    if (cap > FMAXR * FB) return false;
+    if (cap_out) *cap_out = cap;
+    if (kp_out) *kp_out = kp;
+    return ivf_fused_lds_bytes(kind, M, dpad, kp, cap, nprobe) <= 160 * 1024;
+}
+
+template <typename K>
+static void launch_one(K kern, const IvfFusedParams& p, size_t lds, hipStream_t stream) {
+    HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)(p.nq * p.G)), dim3(FB), lds, stream, p);
+}
+
+void launch_ivf_fused(const IvfFusedParams& p, hipStream_t stream) {
+    if (p.nq == 0) return;
+    FA_THROW_IF_NOT(p.G >= 1 && p.npc >= 1 && p.G * p.npc >= p.nprobe);
+    FA_THROW_IF_NOT(p.cap >= p.k + FB && p.cap <= FMAXR * FB);
+    const size_t lds = ivf_fused_lds_bytes(p.kind, p.M, p.dpad, p.kp, p.cap, p.nprobe);
+    FA_THROW_IF_NOT_MSG(lds <= 160 * 1024, "fused IVF scan does not fit the LDS");
+    const bool l2 = p.metric == METRIC_L2;
+    if (p.kind == 0) {
+        if (l2) launch_one(ivfflat_fused_kernel<METRIC_L2>, p, lds, stream);
+        else launch_one(ivfflat_fused_kernel<METRIC_INNER_PRODUCT>, p, lds, stream);
+    } else {
+        const bool regs = p.d <= 128 && (p.M % 2) == 0 && p.dsub * p.M == p.d;
+        int ds = regs ? p.dsub : 0;
+        if (!(ds == 1 || ds == 2 || ds == 4 || ds == 8 || ds == 16 || ds == 32)) ds = 0;
+#define FA_PQ(DS)                                                                        \
+    do {                                                                                 \
+        if (l2) launch_one(ivfpq_fused_kernel<METRIC_L2, DS>, p, lds, stream);            \
+        else launch_one(ivfpq_fused_kernel<METRIC_INNER_PRODUCT, DS>, p, lds, stream);    \
+    } while (0)
+        switch (ds) {
+            case 1: FA_PQ(1); break;
+            case 2: FA_PQ(2); break;
+            case 4: FA_PQ(4); break;
+            case 8: FA_PQ(8); break;
+            case 16: FA_PQ(16); break;
+            case 32: FA_PQ(32); break;
+            default: FA_PQ(0); break;
+        }
+#undef FA_PQ
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+} // namespace faiss_amd

@@ -129,6 +129,43 @@ void launch_ivfflat_scan(const IvfScanParams& p, hipStream_t stream);
 void launch_ivfpq_scan(const IvfScanParams& p, hipStream_t stream);
 size_t ivfpq_scan_lds_bytes(int M, int dpad);
 
+// ------------------------------------------------------------------ fused IVF search (ivf_fused.hip)
+struct IvfFusedParams {
+    int metric;
+    int kind; // 0 = IVFFlat, 1 = IVFPQ
+    int nq, nprobe, d, dpad;
+    const float* xq; // [nq][ldq]
+    int64_t ldq;
+    const int64_t* coarse_ids;  // [nq][nprobe]
+    const float* coarse_dis;    // [nq][nprobe]
+    const uint32_t* list_len;   // [nlist]
+    const int64_t* list_start;  // [nlist]
+    const int64_t* arena_ids;   // [ntotal]
+    int k, kp, cap;             // kp = pow2 >= k; cap = LDS reservoir capacity (>= k + 512)
+    int G, npc;                 // workgroups per query, probes per workgroup (G * npc >= nprobe)
+    float* out_dis;             // [nq][k]   (G == 1)
+    int64_t* out_ids;           // [nq][k]   (G == 1)
+    unsigned long long* part_keys; // [nq][G][k] partial winners (G > 1), merged by launch_select_k mode 1
+    uint32_t* part_cnt;            // [nq][G]
+    uint32_t* prefix_out;          // [nq][nprobe + 1] (G > 1)
+    // IVFFlat
+    const float* arena_vecs; // [ntotal][ldv]
+    int64_t ldv;
+    // IVFPQ
+    const float* centroids; // [nlist][ldc]
+    int64_t ldc;
+    int M, dsub;
+    const float* pq_centroids;  // [M][256][dsub]
+    const uint8_t* arena_codes; // [ntotal][M]
+};
+// One workgroup per (query, probe group): table build + code scan + running top-k all in LDS.
+// Replaces PQCodeDistances + PQScanMultiPassNoPrecomputed + IVFUtilsSelect{1,2} (IVFPQ) and
+// IVFInterleaved scan + scan2 (IVFFlat) of the reference in a single launch.
+void launch_ivf_fused(const IvfFusedParams& p, hipStream_t stream);
+// does the problem fit the fused kernel (LDS budget, reservoir size)?  Returns cap / kp to use.
+bool ivf_fused_supported(int kind, int M, int dpad, int k, int nprobe, int* cap_out, int* kp_out);
+size_t ivf_fused_lds_bytes(int kind, int M, int dpad, int kp, int cap, int nprobe);
+
 // add path (faiss/gpu/impl/IVFAppend.cu): scatter rows / encode PQ codes to arena slots
 void launch_ivfflat_append(const float* x, int64_t ldx, int n, int d, const int64_t* dest,
                            float* arena_vecs, int64_t ldv, int dpad, hipStream_t stream);

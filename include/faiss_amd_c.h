@@ -151,6 +151,9 @@ int faiss_amd_GpuIndexFlat_pairwise_distances(const FaissAmdIndex* index, faiss_
                                               float* out);
 /* route search() through the scalar cross-check kernel (identical arithmetic, no MFMA) */
 int faiss_amd_GpuIndexFlat_set_use_simple_kernel(FaissAmdIndex* index, int on);
+/* IVF search through the unfused path (every distance as a key in HBM + select kernel) instead
+ * of the fused LDS-resident scan; results are identical, the switch exists for cross-checks */
+int faiss_amd_GpuIndexIVF_set_use_fused_scan(FaissAmdIndex* index, int on);
 
 #ifdef __cplusplus
 }

@@ -322,3 +322,41 @@ def test_dropin_reference_clustering_and_shards_run_on_backend(res):
     ref.add(xb)
     Dr, Ir = ref.search(xq, 10)
     check_knn(D, I, Dr, Ir, rtol=1e-4, name="faiss::IndexShards over backend")
+
+
+# ------------------------------------------------------------------------------- fused IVF scan
+@pytest.mark.parametrize("kind,metric,d,M,nlist,nb,nq,nprobe,k", [
+    (1, METRIC_L2, 128, 64, 64, 40000, 1500, 8, 100),   # bench shape (dsub=2), one workgroup per query
+    (1, METRIC_INNER_PRODUCT, 128, 64, 64, 40000, 1100, 8, 10),
+    (1, METRIC_L2, 64, 16, 32, 30000, 40, 32, 600),      # dsub=4, probes split over workgroups, big k
+    (1, METRIC_L2, 96, 12, 16, 5000, 1200, 5, 2048),     # dsub=8, k at the limit, k > candidates for some
+    (1, METRIC_L2, 200, 20, 16, 6000, 50, 4, 20),        # d > 128: codebook re-read through L2
+    (1, METRIC_L2, 32, 32, 8, 3000, 1030, 3, 5),         # dsub=1
+    (0, METRIC_L2, 128, 0, 64, 40000, 1500, 8, 100),
+    (0, METRIC_INNER_PRODUCT, 40, 0, 16, 9000, 30, 16, 7),
+    (0, METRIC_L2, 72, 0, 8, 20000, 1100, 2, 1000),
+])
+def test_ivf_fused_scan_matches_unfused_and_oracle(res, kind, metric, d, M, nlist, nb, nq, nprobe, k):
+    """The LDS-resident fused scan (table build + scan + reservoir top-k in one launch) returns
+    bit-identical distances and labels to the unfused path (all keys in HBM + select kernel)
+    and to the CPU oracle restatement."""
+    xt, xb, xq = synthetic_dataset(d, 4000, nb, nq, seed=nb + k)
+    cent, _ = faiss_amd.kmeans(res, xt, nlist, niter=4, seed=3)
+    pq = None
+    if kind == 0:
+        idx = faiss_amd.GpuIndexIVFFlat(res, d, nlist, metric)
+    else:
+        idx = faiss_amd.GpuIndexIVFPQ(res, d, nlist, M, 8, metric)
+        pq = (np.random.RandomState(7).rand(M, 256, d // M).astype("float32") - 0.5) * 0.4
+        idx.copy_pq_centroids(pq)
+    idx.copy_centroids(cent)
+    idx.add(xb)
+    idx.nprobe = nprobe
+    D, I = idx.search(xq, k)
+    idx.set_use_fused_scan(False)
+    D0, I0 = idx.search(xq, k)
+    assert np.array_equal(D, D0) and np.array_equal(I, I0)
+    sel = np.r_[0:min(nq, 40)]
+    sizes, codes, ids, _ = Oracle.build_ivf_lists(kind, metric, cent, xb, pq=pq)
+    Do, Io, _, _ = Oracle.ivf_search(kind, metric, cent, sizes, codes, ids, xq[sel], nprobe, k, M=M, pq=pq)
+    check_knn(D[sel], I[sel], Do, Io, exact=True, name="fused vs oracle")
