@@ -31,6 +31,7 @@ if ROOT not in sys.path:
 
 D, NT, NB, NQ, K = 128, 100000, 1000000, 10000, 100
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+PEAK_F16_MFMA_TFLOPS = 2500.0  # same guide: dense f16/bf16 MFMA (v_mfma_f32_32x32x16_f16)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -158,6 +159,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ivfpq", action="store_true")
+    ap.add_argument("--flat-path", choices=["filter", "exact"], default="filter",
+                    help="filter: fp16 MFMA candidate filter + exact fp32 re-rank (default, bit-identical results); "
+                         "exact: fp32 MFMA scan only")
     args = ap.parse_args()
 
     import torch
@@ -183,6 +187,7 @@ def main():
     bounds = shard_bounds(NB, world)
     lo, hi = bounds[rank]
     index = faiss_amd.GpuIndexFlatL2(res, D)
+    index.set_use_filter_kernel(args.flat_path == "filter")
     index.add(xb[lo:hi])
     if rank == 0:
         log("data + add: %.1fs (shard rows %d..%d of %d)" % (time.time() - t0, lo, hi, NB))
@@ -227,7 +232,11 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    scan_ms, scan_n = res.profile_get("flat_scan_kernel")
+    used_filter, n_overflow = index.filter_stats()
+    dom = "flat_filter_kernel" if used_filter else "flat_scan_kernel"
+    scan_ms, scan_n = res.profile_get(dom)
+    rr_ms, rr_n = res.profile_get("flat_rerank_kernel")
+    cv_ms, cv_n = res.profile_get("convert_f16_query")
     sel_ms, sel_n = res.profile_get("select_k_kernel")
     res.profile_enable(False)
 
@@ -240,27 +249,36 @@ def main():
     qps = NQ * args.steps / elapsed
     gD, gI = out[0].cpu().numpy(), out[1].cpu().numpy()
     avg_scan_ms = scan_ms / max(scan_n, 1)
-    # dominant kernel: fused distance+select scan of this rank's shard.  Algorithmic work per
-    # launch = 2*nq*nb_shard*d flops (256 MFLOP/query at nb=1M, d=128).
+    # dominant kernel: the scan of this rank's shard.  Algorithmic work per launch =
+    # 2*nq*nb_shard*d flops (256 MFLOP/query at nb=1M, d=128), priced against the
+    # dense MFMA peak of the unit the kernel runs on (f16 for the filter, f32 for the exact scan).
     flops = 2.0 * NQ * (hi - lo) * D
     achieved = flops / (avg_scan_ms * 1e-3) / 1e12
+    peak = PEAK_F16_MFMA_TFLOPS if used_filter else PEAK_F32_MFMA_TFLOPS
     # one sweep of the shard + queries + results is the algorithmic HBM traffic of the launch
-    hbm_bytes = (hi - lo) * D * 4.0 + NQ * D * 4.0 + NQ * K * 12.0
+    row_bytes = D * (2.0 if used_filter else 4.0)
+    hbm_bytes = (hi - lo) * row_bytes + NQ * row_bytes + NQ * K * 12.0
     line = {
         "metric": "QPS @ recall@1 (nq=10k, k=100) FlatL2, SIFT1M-shaped synthetic",
         "value": round(qps, 1), "unit": "QPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None,
+        "dtype": "f32 in/out; f16 MFMA candidate filter + f32 exact re-rank, results bit-identical to the f32 scan"
+        if used_filter else "f32", "data": "synthetic",
         "config": {"workload": "GpuIndexFlatL2 d=128 nb=1M nq=10k k=100 (BASELINE.json configs[1])",
                    "generator": "SyntheticDataset(d=128, nt=100k, nb=1M, nq=10k, seed=1338)",
                    "sharding": "IndexShards-style rows/%d per GPU, gather to rank 0 + device merge" % world
-                   if world > 1 else "single GPU", "inputs": "queries/results resident in HBM"},
-        "roofline": {"bound": "mfma", "kernel": "flat_scan_kernel", "achieved": round(achieved, 2),
-                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                   if world > 1 else "single GPU", "inputs": "queries/results resident in HBM",
+                   "flat_path": "filter" if used_filter else "exact"},
+        "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2),
+                     "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                      "traffic": None, "avg_kernel_ms": round(avg_scan_ms, 3), "launches": int(scan_n),
                      "algorithmic_hbm_GBps": round(hbm_bytes / (avg_scan_ms * 1e-3) / 1e9, 1),
                      "hbm_frac": round(hbm_bytes / (avg_scan_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 5)},
-        "select_kernel_ms": round(sel_ms / max(sel_n, 1), 3),
+        "other_kernels_ms": {"flat_rerank_kernel": round(rr_ms / max(rr_n, 1), 3),
+                             "convert_f16_query+norms": round(cv_ms / max(cv_n, 1), 3),
+                             "select_k_kernel": round(sel_ms / max(sel_n, 1), 3)},
+        "filter_overflow_queries": int(n_overflow),
     }
     if world == 1:
         if not args.no_cpu_baseline:

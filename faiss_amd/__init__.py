@@ -88,6 +88,9 @@ def load_library():
         "faiss_amd_GpuIndexFlat_pairwise_distances": (i32, [vp, i64, vp, vp]),
         "faiss_amd_GpuIndexFlat_set_use_simple_kernel": (i32, [vp, i32]),
         "faiss_amd_GpuIndexIVF_set_use_fused_scan": (i32, [vp, i32]),
+        "faiss_amd_GpuIndexFlat_set_use_filter_kernel": (i32, [vp, i32, i64]),
+        "faiss_amd_GpuIndexFlat_filter_stats": (i32, [vp, P(i32), P(i32)]),
+        "faiss_amd_GpuIndexFlat_filter_scores": (i32, [vp, i64, vp, vp, vp]),
     }
     for name, (res, args) in protos.items():
         fn = getattr(lib, name)  # AttributeError => the library does not export the symbol
@@ -252,6 +255,25 @@ class GpuIndexFlat(Index):
 
     def set_use_simple_kernel(self, on):
         _check(self._lib.faiss_amd_GpuIndexFlat_set_use_simple_kernel(self._h, 1 if on else 0))
+
+    def set_use_filter_kernel(self, on, min_rows=-1):
+        """fp16 MFMA filter + exact fp32 re-rank (bit-identical results); min_rows: smallest database
+        that takes this path"""
+        _check(self._lib.faiss_amd_GpuIndexFlat_set_use_filter_kernel(self._h, 1 if on else 0, int(min_rows)))
+
+    def filter_stats(self):
+        """(used_filter, overflow_queries) of the last search tile"""
+        a, b = ctypes.c_int(0), ctypes.c_int(0)
+        _check(self._lib.faiss_amd_GpuIndexFlat_filter_stats(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return bool(a.value), b.value
+
+    def filter_scores(self, x):
+        """test hook: (approximate scores [n, ntotal], error bound [n]) of the filter kernel"""
+        x = _f32(x, self.d)
+        sc = np.empty((x.shape[0], self.ntotal), dtype=np.float32)
+        eb = np.empty(x.shape[0], dtype=np.float32)
+        _check(self._lib.faiss_amd_GpuIndexFlat_filter_scores(self._h, x.shape[0], _ptr(x), _ptr(sc), _ptr(eb)))
+        return sc, eb
 
 
 class GpuIndexFlatL2(GpuIndexFlat):

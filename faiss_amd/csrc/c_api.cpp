@@ -384,6 +384,26 @@ int faiss_amd_GpuIndexFlat_set_use_simple_kernel(FaissAmdIndex* index, int on) {
     FA_CATCH
 }
 
+int faiss_amd_GpuIndexFlat_set_use_filter_kernel(FaissAmdIndex* index, int on, faiss_amd_idx_t min_rows) {
+    FA_TRY
+    auto* f = as<GpuIndexFlat>(index, "GpuIndexFlat");
+    f->use_filter_kernel = on != 0;
+    if (min_rows >= 0) f->filter_min_rows = min_rows;
+    FA_CATCH
+}
+int faiss_amd_GpuIndexFlat_filter_stats(const FaissAmdIndex* index, int* used_filter, int* overflow_queries) {
+    FA_TRY
+    auto* f = as<GpuIndexFlat>(index, "GpuIndexFlat");
+    if (used_filter) *used_filter = f->last_used_filter ? 1 : 0;
+    if (overflow_queries) *overflow_queries = f->last_filter_overflow;
+    FA_CATCH
+}
+int faiss_amd_GpuIndexFlat_filter_scores(const FaissAmdIndex* index, faiss_amd_idx_t n, const float* x, float* scores,
+                                         float* err_bound) {
+    FA_TRY
+    as<GpuIndexFlat>(index, "GpuIndexFlat")->filter_scores(n, x, scores, err_bound);
+    FA_CATCH
+}
 int faiss_amd_GpuIndexIVF_set_use_fused_scan(FaissAmdIndex* index, int on) {
     FA_TRY
     as<GpuIndexIVF>(index, "GpuIndexIVF")->use_fused_scan = on != 0;

@@ -1,0 +1,670 @@
+// faiss_amd/csrc/flat_filter.hip -- brute-force search at the fp16 MFMA rate with fp32-exact
+// results: a candidate FILTER on v_mfma_f32_32x32x16_f16 followed by an exact fp32 RE-RANK.
+//
+// gfx950's fp32-input MFMA runs at the fp32 vector rate (157 TFLOP/s); its f16 MFMA is 16x
+// faster (2.5 PFLOP/s dense).  The reference's contract for this path is fp32 in / fp32 out
+// (faiss/gpu/impl/Distance.cu:120-406 runDistance<float>; faiss/utils/distances.cpp:424-511 on the
+// CPU), so the fast units may only be used where they cannot change the answer:
+//
+//   1. filter (flat_filter_kernel): approximate scores  t~(q,y) = <fp16(q), fp16(y)> - |y|^2/2
+//      (L2; plain inner product for IP; larger is better).  A rigorous bound
+//      e_q >= |t~(q,y) - s(q,y)| for every y (s = the exact score the fp32 path would produce) is
+//      computed per query from the fp16 rounding model (flat_filter_err_bound).  Every row whose
+//      approximate score is within 2*e_q of the running k-th best approximate score is kept in the
+//      (query, split) reservoir: if the k best by t~ all have exact score >= t~_k - e_q, then
+//      a row with t~ < t~_k - 2 e_q has exact score < t~_k - e_q and cannot be among the k best.
+//      The candidate set is therefore a SUPERSET of the exact top-k, whatever the data.
+//   2. re-rank (flat_rerank_kernel): exact fp32 distances of the surviving candidates (k plus
+//      the rows inside the error band, usually a handful) with the very same fmaf chain as the
+//      fp32 MFMA kernel (flat_kernels.hip / oracle orc_ip_chain), then k-selection under
+//      (distance, id).  Distances and labels are bit-identical to the fp32 path.
+//   3. overflow: a query whose band does not fit its reservoir (adversarial data: thousands of
+//      rows within fp16 rounding of the k-th neighbour, or fp16 range overflow) is flagged and
+//      re-run through the exact fp32 MFMA kernel by the host code.  Never a silent approximation.
+#include "kernels.h"
+#include "wave_select.h"
+#include "wg_select.h"
+
+namespace faiss_amd {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// score keys: larger score = better = smaller key (same mapping as the inner-product ordkey)
+__device__ __forceinline__ uint32_t score_key(float t) {
+    return ordkey<METRIC_INNER_PRODUCT>(t);
+}
+__device__ __forceinline__ float key_score(uint32_t k) {
+    return unordkey<METRIC_INNER_PRODUCT>(k);
+}
+
+// threshold strictly below (t_k - 2e): keeps exact ties of the k-th score inside the band even
+// when e underflows to 0
+__device__ __forceinline__ float band_threshold(float tk, float e) {
+    return tk - 2.f * e - 9.6e-7f * fabsf(tk) - 1e-37f;
+}
+
+// ---------------------------------------------------------------------------------
+// fp32 -> fp16 copies (database at add time, queries per search)
+// ---------------------------------------------------------------------------------
+// dst[i][0..dh) = fp16(src[i][0..d)) zero padded; absmax_bits = max over |x| (uint bits of a
+// non-negative float order like the float); flags[i] = 1 when row i leaves the fp16 range or
+// holds a NaN (flags may be null)
+__global__ void convert_f16_kernel(const float* __restrict__ src, int64_t ld_src, int64_t n, int d,
+                                   _Float16* __restrict__ dst, int dh, unsigned* __restrict__ absmax_bits,
+                                   uint32_t* __restrict__ flags) {
+    const int64_t i = blockIdx.x;
+    const float* r = src + i * ld_src;
+    _Float16* o = dst + i * dh;
+    float mx = 0.f;
+    bool bad = false;
+    for (int c = threadIdx.x; c < dh; c += blockDim.x) {
+        const float v = c < d ? r[c] : 0.f;
+        const float a = fabsf(v);
+        if (!(a <= 65000.f)) bad = true; // NaN, inf, or beyond the fp16 normal range
+        mx = fmaxf(mx, a);
+        o[c] = (_Float16)v;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    const bool anybad = __ballot(bad) != 0ull;
+    if (threadIdx.x == 0) {
+        if (absmax_bits) atomicMax(absmax_bits, anybad ? 0x7f800000u : __float_as_uint(mx));
+        if (flags) flags[i] = anybad ? 1u : 0u;
+    }
+}
+
+void launch_convert_f16(const float* src, int64_t ld_src, int64_t n, int d, void* dst, int dh,
+                        unsigned* absmax_bits, uint32_t* flags, hipStream_t stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(convert_f16_kernel, dim3((unsigned)n), dim3(64), 0, stream, src, ld_src, n, d,
+                       (_Float16*)dst, dh, absmax_bits, flags);
+    HIP_CHECK(hipGetLastError());
+}
+
+__global__ void half_norms_kernel(const float* __restrict__ xn, int64_t n, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = 0.5f * xn[i];
+}
+void launch_half_norms(const float* xn, int64_t n, float* out, hipStream_t stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(half_norms_kernel, dim3((unsigned)div_up(n, 256)), dim3(256), 0, stream, xn, n, out);
+    HIP_CHECK(hipGetLastError());
+}
+
+// max of n non-negative floats into *out_bits (as uint bits)
+__global__ void max_f32_kernel(const float* __restrict__ x, int64_t n, unsigned* __restrict__ out_bits) {
+    float mx = 0.f;
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        if (!(v <= FLT_MAX)) bad = true;
+        mx = fmaxf(mx, v);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    const bool anybad = __ballot(bad) != 0ull;
+    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, anybad ? 0x7f800000u : __float_as_uint(mx));
+}
+void launch_max_f32(const float* x, int64_t n, unsigned* out_bits, hipStream_t stream) {
+    if (n == 0) return;
+    unsigned grid = (unsigned)std::min<int64_t>(div_up(n, 256), 1024);
+    hipLaunchKernelGGL(max_f32_kernel, dim3(grid), dim3(256), 0, stream, x, n, out_bits);
+    HIP_CHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------
+// filter kernel
+//
+// Workgroup = 256 threads = 4 waves; wave w owns 64 queries (two 32-query MFMA column blocks whose
+// fp16 coordinates stay in 64 VGPRs as B operands); the 4 waves share one stream of 64-row
+// database tiles (64 x 128 halfs = 16 KB) brought in by global_load_lds_dwordx4 (no staging
+// registers), double buffered.  The 16-byte chunks of a row are XOR-swizzled with the row
+// number through the SOURCE address of the LDS-DMA (the LDS image is lane-linear), so the
+// ds_read_b128 of 16 different rows at one k offset hits 16 different 16-byte bank groups.
+// Per tile and wave: 2 x 2 blocks x 8 k-steps = 32 MFMAs (32 cycles each) against 128 VALU
+// compare/subtract instructions of epilogue.
+// ---------------------------------------------------------------------------------
+constexpr int FQ_THREADS = 256;
+constexpr int FQ_QPB = 256;          // queries per workgroup (kFilterQueriesPerBlock)
+constexpr int FQ_TR = 64;            // rows per tile
+constexpr int FQ_KS = 128;           // halfs per k-slab
+constexpr int FQ_TILE_BYTES = FQ_TR * FQ_KS * 2; // 16384
+constexpr int FQ_NBUF = 3;                       // LDS ring: tile u computes while u+1, u+2 are in flight
+constexpr int FQ_LDS_BIAS = FQ_NBUF * FQ_TILE_BYTES;
+constexpr int FQ_LDS_HIST = FQ_LDS_BIAS + FQ_NBUF * FQ_TR * 4;
+constexpr int FQ_LDS_TOTAL = FQ_LDS_HIST + 4 * 256 * 4;
+
+// LDS-DMA issued from inline asm: hipcc makes every ds_read that follows a
+// __builtin_amdgcn_global_load_lds wait for vmcnt(0) (it cannot tell the two LDS regions apart),
+// which would drain the prefetch before the tile in hand is even read.  Hidden in asm, the DMA
+// is invisible to the compiler's counters; completion is enforced by our own counted
+// s_waitcnt vmcnt(N) + barrier before the tile is consumed (cdna_hip_programming.md 5.7).
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+            "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(gsrc), "s"(lds_dst)
+            : "memory");
+}
+__device__ __forceinline__ void glds4(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+            "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(gsrc), "s"(lds_dst)
+            : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+
+// SINGLE: dh == 128, one k-slab per tile: the query operands never leave their registers and
+// the loop holds no compiler-visible global load, whose counted s_waitcnt would otherwise also
+// wait for the (younger, hidden) LDS-DMAs of the prefetch.
+template <int METRIC, bool DUMP, bool SINGLE>
+__global__ void __launch_bounds__(FQ_THREADS, 2) flat_filter_kernel(FlatFilterParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    const int j = lane & 31;
+
+    int split, grp;
+    {
+        const int b = blockIdx.x;
+        if ((p.nsplit & 7) == 0) {
+            // blocks b, b+8, b+16, ... run on one XCD: give them the same split (same rows, shared L2)
+            const int xcd = b & 7;
+            const int t = b >> 3;
+            grp = t % p.ngroups;
+            split = (t / p.ngroups) * 8 + xcd;
+        } else {
+            split = b % p.nsplit;
+            grp = b / p.nsplit;
+        }
+    }
+    const int r0 = split * p.rows_per_split;
+    const int r1 = min(p.nb, r0 + p.rows_per_split);
+    if (r0 >= r1) {
+        if (!DUMP) {
+            const int q = grp * FQ_QPB + tid;
+            if (q < p.nq) p.res_cnt[(int64_t)q * p.nsplit + split] = 0;
+        }
+        return;
+    }
+    const int ntiles = (r1 - r0 + FQ_TR - 1) / FQ_TR;
+    auto tile_row0_of = [&](int t) { return r0 + t * FQ_TR; };
+    const int nslab = SINGLE ? 1 : p.dh / FQ_KS;
+    const int nsteps = ntiles * nslab;
+
+    // ---- this lane's two queries
+    const int qbase = grp * FQ_QPB + wave * 64; // wave-uniform
+    const _Float16* qrow[2];
+    float thr[2], eb[2];
+    int cnt[2] = {0, 0};
+    bool qvalid[2];
+    u64* resq[2] = {nullptr, nullptr};
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int q = qbase + qb * 32 + j;
+        qvalid[qb] = q < p.nq;
+        const int qc = qvalid[qb] ? q : p.nq - 1;
+        qrow[qb] = p.xqh + (int64_t)qc * p.ldqh;
+        eb[qb] = flat_filter_err_bound(METRIC, p.d, p.xqn[qc], p.yn_max);
+        const bool usable = qvalid[qb] && eb[qb] < FLT_MAX && p.flags[qc] == 0; // NaN/inf bound or fp16 overflow
+        thr[qb] = usable ? -INFINITY : INFINITY;
+        if (qvalid[qb] && !usable && !DUMP && split == 0 && h == 0) p.flags[qc] = 1;
+        if (!DUMP) resq[qb] = p.res_keys + ((int64_t)qc * p.nsplit + split) * p.cap;
+    }
+    unsigned* hist = (unsigned*)(smem + FQ_LDS_HIST) + wave * 256;
+    const int cap_lim = p.cap - 32;
+
+    // ---- LDS-DMA staging of step u (tile u / nslab, slab u % nslab) into ring slot u % 3:
+    // 4 x 1 KB of row chunks + (every wave, redundantly, so that all waves count the same
+    // number of DMAs) the 64 per-row biases |y|^2 / 2
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+    constexpr int DMA_PER_STAGE = METRIC == METRIC_L2 ? 5 : 4;
+    auto stage = [&](int u, int slot) {
+        const int t = u / nslab, sl = u - t * nslab;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int g = (wave * 4 + i) * 64 + lane; // 16-byte chunk of the LDS image
+            const int row = g >> 4, cpos = g & 15;
+            const int c = cpos ^ (row & 15);          // chunk of the source row that lands there
+            const int grow = min(r0 + t * FQ_TR + row, r1 - 1);
+            const _Float16* src = p.xbh + (int64_t)grow * p.ldbh + sl * FQ_KS + c * 8;
+            glds16(src, lds_base + slot * FQ_TILE_BYTES + (wave * 4 + i) * 1024);
+        }
+        if (METRIC == METRIC_L2) {
+            // rows past the end of the split re-read row r1-1 (their scores are masked in the rare path)
+            const int grow = min(r0 + t * FQ_TR + lane, r1 - 1);
+            glds4(p.xbhn + grow, lds_base + FQ_LDS_BIAS + slot * FQ_TR * 4);
+        }
+    };
+
+    half8 bq[2][8];
+    f32x16 acc[2][2];
+
+    auto load_b = [&](int sl) {
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int s = 0; s < 8; ++s) bq[qb][s] = *(const half8*)(qrow[qb] + sl * FQ_KS + s * 16 + h * 8);
+    };
+
+    load_b(0);
+    // every compiler-visible load lands BEFORE the first hidden DMA is issued (vmcnt(0), the other
+    // counters untouched): from here on the compiler's own scoreboard holds no pending load and it
+    // inserts no counted vmcnt wait into the loop, which would also wait for the younger DMAs
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    stage(0, 0);
+    if (nsteps > 1) {
+        stage(1, 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_STAGE) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+
+    int slot = 0; // u % 3
+    for (int u = 0; u < nsteps; ++u) {
+        const int t = u / nslab, sl = u - t * nslab;
+        if (!SINGLE && u > 0) load_b(sl);
+        const int slot2 = slot >= 1 ? slot - 1 : 2; // (u + 2) % 3
+        if (u + 2 < nsteps) stage(u + 2, slot2);
+
+        if (sl == 0) {
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[rb][qb][r] = 0.f;
+        }
+        {
+            const char* tile = smem + slot * FQ_TILE_BYTES;
+            const char* rowp0 = tile + j * 256;
+            const char* rowp1 = tile + (32 + j) * 256;
+            const int sw = j & 15;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int off = ((2 * s + h) ^ sw) << 4;
+                const half8 a0 = *(const half8*)(rowp0 + off);
+                const half8 a1 = *(const half8*)(rowp1 + off);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bq[0][s], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bq[1][s], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bq[0][s], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bq[1][s], acc[1][1], 0, 0, 0);
+            }
+        }
+        if (sl == nslab - 1) {
+            const float* bias = (const float*)(smem + FQ_LDS_BIAS) + slot * FQ_TR;
+            const bool last_tile = tile_row0_of(t) + FQ_TR > r1;
+            const int tile_row0 = tile_row0_of(t);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                f32x4 b4[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (METRIC == METRIC_L2) b4[g] = *(const f32x4*)(bias + rb * 32 + 8 * g + 4 * h);
+                    else b4[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    float tv[16];
+                    bool anyp = false;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        tv[r] = acc[rb][qb][r] - b4[r >> 2][r & 3];
+                        anyp |= tv[r] > thr[qb];
+                    }
+                    if (DUMP) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int grow = tile_row0 + rb * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+                            const int q = qbase + qb * 32 + j;
+                            if (qvalid[qb] && grow < r1) p.dump[(int64_t)q * p.nb + grow] = tv[r];
+                        }
+                    } else if (__ballot(anyp)) {
+                        // ---- rare path: some lane has a row inside the band of its query
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int grow = tile_row0 + rb * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+                            const bool pass = tv[r] > thr[qb] && (!last_tile || grow < r1);
+                            const u64 m = __ballot(pass);
+                            if (m) {
+                                const int lo = (int)((m >> j) & 1ull);
+                                const int hi = (int)((m >> (j + 32)) & 1ull);
+                                if (pass) {
+                                    resq[qb][cnt[qb] + (h ? lo : 0)] = ((u64)score_key(tv[r]) << 32) | (unsigned)grow;
+                                }
+                                cnt[qb] += lo + hi;
+                            }
+                        }
+                        u64 flagged = __ballot(cnt[qb] > cap_lim) & 0xffffffffull;
+                        if (flagged) {
+                            wave_mem_sync();
+                            while (flagged) {
+                                const int jq = __ffsll((long long)flagged) - 1;
+                                flagged &= flagged - 1;
+                                const int n = __shfl(cnt[qb], jq, 64);
+                                const float ee = __shfl(eb[qb], jq, 64);
+                                const int qq = qbase + qb * 32 + jq;
+                                u64* base = p.res_keys + ((int64_t)qq * p.nsplit + split) * p.cap;
+                                const u64 kth = wave_select_kth(base, n, p.k, hist);
+                                const float thr_new = band_threshold(key_score((uint32_t)(kth >> 32)), ee);
+                                const u64 key_thr = ((u64)score_key(thr_new) << 32) | 0xffffffffull;
+                                const int kept = wave_compact(base, n, key_thr);
+                                const bool ovf = kept > (p.cap >> 1);
+                                if (ovf && lane == 0) p.flags[qq] = 1;
+                                if (j == jq) {
+                                    cnt[qb] = ovf ? 0 : kept;
+                                    thr[qb] = ovf ? INFINITY : thr_new;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        // tile u+1 must have landed (this wave's share) before anybody passes the barrier;
+        // the DMAs of tile u+2 stay in flight across it
+        if (u + 2 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_STAGE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        slot = slot == 2 ? 0 : slot + 1;
+    }
+
+    if (!DUMP) {
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            // final cut so that the re-rank kernel sees k + band keys per (query, split)
+            u64 flagged = __ballot(cnt[qb] > p.k) & 0xffffffffull;
+            if (flagged) wave_mem_sync();
+            while (flagged) {
+                const int jq = __ffsll((long long)flagged) - 1;
+                flagged &= flagged - 1;
+                const int n = __shfl(cnt[qb], jq, 64);
+                const float ee = __shfl(eb[qb], jq, 64);
+                const int qq = qbase + qb * 32 + jq;
+                u64* base = p.res_keys + ((int64_t)qq * p.nsplit + split) * p.cap;
+                const u64 kth = wave_select_kth(base, n, p.k, hist);
+                const float thr_new = band_threshold(key_score((uint32_t)(kth >> 32)), ee);
+                const u64 key_thr = ((u64)score_key(thr_new) << 32) | 0xffffffffull;
+                const int kept = wave_compact(base, n, key_thr);
+                if (j == jq) cnt[qb] = kept;
+            }
+            const int q = qbase + qb * 32 + j;
+            if (qvalid[qb] && h == 0) p.res_cnt[(int64_t)q * p.nsplit + split] = (uint32_t)cnt[qb];
+        }
+    }
+}
+
+size_t flat_filter_lds_bytes() {
+    return FQ_LDS_TOTAL;
+}
+
+void launch_flat_filter(const FlatFilterParams& p, hipStream_t stream) {
+    if (p.nq == 0 || p.nb == 0) return;
+    FA_THROW_IF_NOT(p.dh % FQ_KS == 0 && p.ldqh % 8 == 0 && p.ldbh % 8 == 0);
+    FA_THROW_IF_NOT(p.rows_per_split % FQ_TR == 0);
+    FA_THROW_IF_NOT(p.dump || p.cap >= 2 * (p.k + 32));
+    dim3 grid((unsigned)(p.nsplit * p.ngroups)), block(FQ_THREADS);
+    const size_t lds = FQ_LDS_TOTAL;
+    const bool single = p.dh == FQ_KS;
+#define FA_LAUNCH(M, D)                                                                              \
+    do {                                                                                             \
+        if (single) hipLaunchKernelGGL((flat_filter_kernel<M, D, true>), grid, block, lds, stream, p); \
+        else hipLaunchKernelGGL((flat_filter_kernel<M, D, false>), grid, block, lds, stream, p);     \
+    } while (0)
+    if (p.metric == METRIC_L2) {
+        if (p.dump) FA_LAUNCH(METRIC_L2, true);
+        else FA_LAUNCH(METRIC_L2, false);
+    } else {
+        if (p.dump) FA_LAUNCH(METRIC_INNER_PRODUCT, true);
+        else FA_LAUNCH(METRIC_INNER_PRODUCT, false);
+    }
+#undef FA_LAUNCH
+    HIP_CHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------
+// re-rank kernel: one workgroup per query
+// ---------------------------------------------------------------------------------
+constexpr int RR_THREADS = 256;
+constexpr int RR_CAND = 2048; // exact candidates per query held in LDS
+
+struct RrShared {
+    unsigned hist[256];
+    unsigned scan[256];
+    u64 prefix, mask, kth;
+    int need, done;
+    unsigned total, ncand;
+    WgSelCtl ctl;
+};
+
+template <typename F>
+__device__ __forceinline__ void rr_for_each_key(const FlatRerankParams& p, int q, F f) {
+    const u64* base = p.res_keys + (int64_t)q * p.nsplit * p.cap;
+    for (int s = 0; s < p.nsplit; ++s) {
+        const unsigned cnt = p.res_cnt[(int64_t)q * p.nsplit + s];
+        const u64* seg = base + (int64_t)s * p.cap;
+        for (unsigned i = threadIdx.x; i < cnt; i += RR_THREADS) f(seg[i]);
+    }
+}
+
+template <int METRIC>
+__global__ void __launch_bounds__(RR_THREADS) flat_rerank_kernel(FlatRerankParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    RrShared* sh = (RrShared*)smem;
+    u64* cand = (u64*)(smem + ((sizeof(RrShared) + 15) & ~(size_t)15)); // [RR_CAND]
+    float* qs = (float*)(cand + RR_CAND);                                 // [dpad]
+    int64_t* w_id = (int64_t*)(qs + p.dpad + (p.dpad & 1));               // [kp] (8-byte aligned)
+    unsigned* w_key = (unsigned*)(w_id + p.kp);                           // [kp]
+    const int q = blockIdx.x;
+    const int tid = threadIdx.x;
+
+    if (p.flags[q]) {
+        // the filter could not guarantee a superset for this query: hand it to the exact path
+        if (tid == 0) p.ovf_list[atomicAdd(p.ovf_cnt, 1u)] = (uint32_t)q;
+        return;
+    }
+    if (tid == 0) {
+        sh->total = 0;
+        sh->ncand = 0;
+        sh->prefix = 0;
+        sh->mask = 0;
+        sh->need = p.k;
+        sh->done = 0;
+        sh->kth = ~0ull;
+    }
+    for (int c = tid; c < p.dpad; c += RR_THREADS) qs[c] = p.xq[(int64_t)q * p.ldq + c];
+    __syncthreads();
+    {
+        unsigned loc = 0;
+        for (int s = tid; s < p.nsplit; s += RR_THREADS) loc += p.res_cnt[(int64_t)q * p.nsplit + s];
+        if (loc) atomicAdd(&sh->total, loc);
+    }
+    __syncthreads();
+    const unsigned total = sh->total;
+
+    // ---- k-th best approximate score over all splits (radix select over the global segments)
+    u64 key_thr = ~0ull;
+    if (total > (unsigned)p.k) {
+        for (int shift = 56; shift >= 0; shift -= 8) {
+            sh->hist[tid] = 0;
+            __syncthreads();
+            const u64 prefix = sh->prefix, mask = sh->mask;
+            rr_for_each_key(p, q, [&](u64 key) {
+                if ((key & mask) == prefix) atomicAdd(&sh->hist[(unsigned)(key >> shift) & 255u], 1u);
+            });
+            __syncthreads();
+            const unsigned v = sh->hist[tid];
+            sh->scan[tid] = v;
+            __syncthreads();
+            for (int off = 1; off < 256; off <<= 1) {
+                const unsigned o = tid >= off ? sh->scan[tid - off] : 0;
+                __syncthreads();
+                sh->scan[tid] += o;
+                __syncthreads();
+            }
+            const unsigned incl = sh->scan[tid];
+            const unsigned excl = incl - v;
+            const unsigned need = (unsigned)sh->need;
+            __syncthreads();
+            if (excl < need && need <= incl) {
+                sh->prefix = prefix | ((u64)tid << shift);
+                sh->mask = mask | ((u64)255u << shift);
+                sh->need = (int)(need - excl);
+                sh->done = ((need - excl) == v) ? 1 : 0;
+            }
+            __syncthreads();
+            if (sh->done || shift == 0) break;
+        }
+        if (sh->done) {
+            if (tid == 0) sh->kth = 0;
+            __syncthreads();
+            const u64 prefix = sh->prefix, mask = sh->mask;
+            u64 best = 0;
+            rr_for_each_key(p, q, [&](u64 key) {
+                if ((key & mask) == prefix && key > best) best = key;
+            });
+            if (best) atomicMax(&sh->kth, best);
+            __syncthreads();
+        } else {
+            if (tid == 0) sh->kth = sh->prefix;
+            __syncthreads();
+        }
+        const float e = flat_filter_err_bound(METRIC, p.d, p.xqn[q], p.yn_max);
+        const float thr = band_threshold(key_score((uint32_t)(sh->kth >> 32)), e);
+        key_thr = ((u64)score_key(thr) << 32) | 0xffffffffull;
+    }
+
+    // ---- gather the rows inside the band
+    rr_for_each_key(p, q, [&](u64 key) {
+        if (key <= key_thr) {
+            const unsigned slot = atomicAdd(&sh->ncand, 1u);
+            if (slot < (unsigned)RR_CAND) cand[slot] = key & 0xffffffffull;
+        }
+    });
+    __syncthreads();
+    int n = (int)sh->ncand;
+    if (n > RR_CAND) {
+        if (tid == 0) p.ovf_list[atomicAdd(p.ovf_cnt, 1u)] = (uint32_t)q;
+        return;
+    }
+
+    // ---- exact fp32 distances, same chain as flat_scan_kernel / oracle orc_ip_chain
+    const float xn = METRIC == METRIC_L2 ? p.xqn[q] : 0.f;
+    for (int c = tid; c < n; c += RR_THREADS) {
+        const unsigned row = (unsigned)cand[c];
+        const float* yr = p.xb + (int64_t)row * p.ldb;
+        float acc = 0.f;
+        for (int s = 0; s < p.dpad; s += 8) {
+            const f32x4 y0 = *(const f32x4*)(yr + s), y1 = *(const f32x4*)(yr + s + 4);
+            const f32x4 q0 = *(const f32x4*)(qs + s), q1 = *(const f32x4*)(qs + s + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc = __fmaf_rn(y0[e], q0[e], acc);
+                acc = __fmaf_rn(y1[e], q1[e], acc);
+            }
+        }
+        float dis;
+        if (METRIC == METRIC_L2) {
+            dis = __fmaf_rn(-2.f, acc, xn + p.xbn[row]);
+            dis = dis < 0.f ? 0.f : dis;
+        } else {
+            dis = acc;
+        }
+        cand[c] = ((u64)ordkey<METRIC>(dis) << 32) | row;
+    }
+    __syncthreads();
+
+    // ---- exact top-k under (distance, id)
+    if (n > p.k) {
+        const u64 kth = wg_select_kth<RR_THREADS>(cand, n, p.k, sh->hist, &sh->ctl);
+        wg_compact<RR_THREADS>(cand, n, kth, &sh->ctl);
+        n = (int)sh->ctl.cnt;
+    }
+    for (int i = tid; i < p.kp; i += RR_THREADS) {
+        unsigned wk = 0xffffffffu;
+        int64_t wi = INT64_MAX;
+        if (i < n) {
+            const u64 key = cand[i];
+            wk = (uint32_t)(key >> 32);
+            wi = (int64_t)(uint32_t)key + p.id_base;
+        }
+        w_key[i] = wk;
+        w_id[i] = wi;
+    }
+    __syncthreads();
+    wg_bitonic_sort<RR_THREADS>(w_key, w_id, p.kp);
+    const float pad = neutral_distance(METRIC);
+    for (int i = tid; i < p.k; i += RR_THREADS) {
+        float dis = pad;
+        int64_t id = -1;
+        if (i < n && w_key[i] < kInvalidOrdKey) {
+            dis = unordkey<METRIC>(w_key[i]);
+            id = w_id[i];
+        }
+        p.out_dis[(int64_t)q * p.k + i] = dis;
+        p.out_ids[(int64_t)q * p.k + i] = id;
+    }
+}
+
+void launch_flat_rerank(const FlatRerankParams& p, hipStream_t stream) {
+    if (p.nq == 0) return;
+    FA_THROW_IF_NOT(p.k >= 1 && p.k <= kMaxSelectionK && p.dpad % 8 == 0);
+    const size_t lds = ((sizeof(RrShared) + 15) & ~(size_t)15) + (size_t)RR_CAND * 8 +
+                       (size_t)(p.dpad + (p.dpad & 1)) * 4 + (size_t)p.kp * 12;
+    FA_THROW_IF_NOT_MSG(lds <= 160 * 1024, "re-rank workspace exceeds the LDS");
+    if (p.metric == METRIC_L2) {
+        HIP_CHECK(hipFuncSetAttribute((const void*)flat_rerank_kernel<METRIC_L2>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((flat_rerank_kernel<METRIC_L2>), dim3((unsigned)p.nq), dim3(RR_THREADS), lds, stream, p);
+    } else {
+        HIP_CHECK(hipFuncSetAttribute((const void*)flat_rerank_kernel<METRIC_INNER_PRODUCT>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((flat_rerank_kernel<METRIC_INNER_PRODUCT>), dim3((unsigned)p.nq), dim3(RR_THREADS), lds,
+                           stream, p);
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------
+// overflow fallback plumbing: gather flagged query rows, scatter their exact results back
+// ---------------------------------------------------------------------------------
+__global__ void gather_rows_kernel(const float* __restrict__ src, int64_t ld, int width,
+                                   const uint32_t* __restrict__ list, float* __restrict__ dst) {
+    const int64_t i = blockIdx.x;
+    const float* r = src + (int64_t)list[i] * ld;
+    for (int c = threadIdx.x; c < width; c += blockDim.x) dst[i * width + c] = r[c];
+}
+void launch_gather_rows(const float* src, int64_t ld, int width, const uint32_t* list, int n, float* dst,
+                        hipStream_t stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)n), dim3(64), 0, stream, src, ld, width, list, dst);
+    HIP_CHECK(hipGetLastError());
+}
+__global__ void scatter_results_kernel(const float* __restrict__ sd, const int64_t* __restrict__ si, int k,
+                                       const uint32_t* __restrict__ list, float* __restrict__ dd,
+                                       int64_t* __restrict__ di) {
+    const int64_t i = blockIdx.x;
+    const int64_t q = list[i];
+    for (int c = threadIdx.x; c < k; c += blockDim.x) {
+        dd[q * k + c] = sd[i * k + c];
+        di[q * k + c] = si[i * k + c];
+    }
+}
+void launch_scatter_results(const float* sd, const int64_t* si, int k, const uint32_t* list, int n, float* dd,
+                            int64_t* di, hipStream_t stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(scatter_results_kernel, dim3((unsigned)n), dim3(64), 0, stream, sd, si, k, list, dd, di);
+    HIP_CHECK(hipGetLastError());
+}
+
+} // namespace faiss_amd

@@ -153,7 +153,11 @@ GpuIndexFlat::GpuIndexFlat(std::shared_ptr<GpuResources> res, int dims, int metr
     FA_THROW_IF_NOT_MSG(metric == METRIC_L2 || metric == METRIC_INNER_PRODUCT,
                         "only METRIC_L2 and METRIC_INNER_PRODUCT are supported");
     dpad_ = (int)round_up(dims, 8);
+    dh_ = (int)round_up(dims, kFilterSlab);
     is_trained = true;
+    res_->set_device();
+    scal_.ensure(16);
+    HIP_CHECK(hipMemset(scal_.p, 0, 16));
 }
 GpuIndexFlat::~GpuIndexFlat() {
     (void)hipSetDevice(res_->device);
@@ -162,6 +166,10 @@ GpuIndexFlat::~GpuIndexFlat() {
 void GpuIndexFlat::reset() {
     std::lock_guard<std::mutex> g(mu_);
     ntotal = 0;
+    yn_max_ = 0.f;
+    db_f16_ok_ = true;
+    res_->set_device();
+    HIP_CHECK(hipMemsetAsync(scal_.p, 0, 16, res_->stream));
 }
 
 void GpuIndexFlat::add(idx_t n, const float* x) {
@@ -173,6 +181,8 @@ void GpuIndexFlat::add(idx_t n, const float* x) {
     const size_t row = (size_t)dpad_ * sizeof(float);
     xb_.ensure((size_t)(ntotal + n) * row, (size_t)ntotal * row, res_->stream);
     xbn_.ensure((size_t)(ntotal + n) * sizeof(float), (size_t)ntotal * sizeof(float), res_->stream);
+    xbh_.ensure((size_t)(ntotal + n) * dh_ * 2, (size_t)ntotal * dh_ * 2, res_->stream);
+    xbhn_.ensure((size_t)(ntotal + n) * sizeof(float), (size_t)ntotal * sizeof(float), res_->stream);
     // page the upload so the raw staging buffer stays bounded (reference: GpuIndex.cu:197-217)
     const idx_t page = std::max<idx_t>(1, ((idx_t)256 << 20) / ((idx_t)d * 4));
     for (idx_t i0 = 0; i0 < n; i0 += page) {
@@ -180,7 +190,21 @@ void GpuIndexFlat::add(idx_t n, const float* x) {
         float* dst = xb_.as<float>() + (size_t)(ntotal + i0) * dpad_;
         stage_padded(*res_, x + (size_t)i0 * d, ni, d, dpad_, q_raw_, dst);
         launch_l2_norms(dst, dpad_, ni, dpad_, xbn_.as<float>() + ntotal + i0, res_->stream);
+        // fp16 shadow copy + |y|^2/2 for the filter kernel, range / norm statistics
+        launch_convert_f16(dst, dpad_, ni, d, xbh_.as<char>() + (size_t)(ntotal + i0) * dh_ * 2, dh_,
+                           scal_.as<unsigned>(), nullptr, res_->stream);
+        launch_half_norms(xbn_.as<float>() + ntotal + i0, ni, xbhn_.as<float>() + ntotal + i0, res_->stream);
+        launch_max_f32(xbn_.as<float>() + ntotal + i0, ni, scal_.as<unsigned>() + 1, res_->stream);
         res_->sync(); // q_raw_ is reused by the next page
+    }
+    {
+        unsigned bits[2];
+        HIP_CHECK(hipMemcpy(bits, scal_.p, 8, hipMemcpyDeviceToHost));
+        float amax, ynm;
+        memcpy(&amax, &bits[0], 4);
+        memcpy(&ynm, &bits[1], 4);
+        db_f16_ok_ = amax <= 65000.f && ynm <= FLT_MAX; // NaN/inf are reported as +inf bits
+        yn_max_ = ynm;
     }
     ntotal += n;
 }
@@ -201,13 +225,13 @@ void GpuIndexFlat::reconstruct(idx_t key, float* recons) const {
 }
 
 // choose the database split count: blocks = nsplit * ngroups should fill whole rounds of CUs
-static void choose_splits(int nb, int ngroups, int num_cus, int& nsplit, int& rows_per_split) {
+static void choose_splits(int nb, int ngroups, int num_cus, int& nsplit, int& rows_per_split, int split_cap = 64) {
     const int TR = kFlatTileRows;
     const int max_split = std::max(1, nb / 2048);
     int best = 1;
     if (max_split >= 8) {
         double best_eff = -1.0;
-        for (int s = 8; s <= std::min(max_split, 64); s += 8) {
+        for (int s = 8; s <= std::min(max_split, split_cap); s += 8) {
             long total = (long)s * ngroups;
             long rounds = (total + num_cus - 1) / num_cus;
             double eff = (double)total / (double)(rounds * num_cus);
@@ -232,7 +256,165 @@ static int reservoir_capacity(int k) {
     return cap;
 }
 
+bool GpuIndexFlat::filter_applicable_(int k) const {
+    return use_filter_kernel && !use_simple_kernel && db_f16_ok_ && ntotal >= filter_min_rows && k <= 1024 &&
+           d >= 32 && dh_ <= 8 * kFilterSlab;
+}
+
+// split count, rows per split and reservoir capacity of the filter kernel for a tile of n queries
+void GpuIndexFlat::plan_filter_(int n, int k, int& nsplit, int& rows_per_split, int& cap) const {
+    const int ngroups = (int)div_up(n, kFilterQueriesPerBlock);
+    // two 4-wave workgroups are resident per CU; small batches may use up to 256 splits
+    cap = 64;
+    while (cap < 4 * k) cap <<= 1;
+    if (cap < 2 * (k + 32)) cap = (int)round_up(2 * (k + 32), 64);
+    // two 4-wave workgroups are resident per CU; small batches may use up to 256 splits as long
+    // as the reservoirs stay inside the scratch budget
+    int split_cap = ngroups >= 8 ? 64 : 256;
+    const size_t per_split = (size_t)n * cap * 8;
+    split_cap = (int)std::min<size_t>(split_cap, std::max<size_t>(8, res_->temp_budget_bytes / per_split / 8 * 8));
+    choose_splits((int)ntotal, ngroups, 2 * res_->num_cus, nsplit, rows_per_split, split_cap);
+}
+
+void GpuIndexFlat::filter_scores(idx_t n, const float* x, float* scores, float* err_bound) const {
+    FA_THROW_IF_NOT_MSG(db_f16_ok_ && ntotal > 0 && n > 0, "filter not applicable");
+    std::lock_guard<std::mutex> g(mu_);
+    res_->set_device();
+    const GpuResources& R = *res_;
+    q_pad_.ensure((size_t)n * dpad_ * 4);
+    stage_padded(R, x, n, d, dpad_, q_raw_, q_pad_.as<float>());
+    qh_.ensure((size_t)n * dh_ * 2);
+    flags_.ensure((size_t)n * 4);
+    q_norm_.ensure((size_t)n * 4);
+    launch_convert_f16(q_pad_.as<float>(), dpad_, n, d, qh_.p, dh_, nullptr, flags_.as<uint32_t>(), R.stream);
+    launch_l2_norms(q_pad_.as<float>(), dpad_, n, dpad_, q_norm_.as<float>(), R.stream);
+    DevBuf dump;
+    dump.ensure((size_t)n * ntotal * 4);
+    FlatFilterParams fp{};
+    fp.metric = metric_type;
+    fp.xqh = qh_.as<_Float16>();
+    fp.xqn = q_norm_.as<float>();
+    fp.xbh = xbh_.as<_Float16>();
+    fp.xbhn = xbhn_.as<float>();
+    fp.ldqh = fp.ldbh = dh_;
+    fp.nq = (int)n;
+    fp.nb = (int)ntotal;
+    fp.d = d;
+    fp.dh = dh_;
+    fp.ngroups = (int)div_up(n, kFilterQueriesPerBlock);
+    choose_splits(fp.nb, fp.ngroups, 2 * R.num_cus, fp.nsplit, fp.rows_per_split);
+    fp.k = 1;
+    fp.cap = 128;
+    fp.yn_max = yn_max_;
+    fp.flags = flags_.as<uint32_t>();
+    fp.dump = dump.as<float>();
+    launch_flat_filter(fp, R.stream);
+    copy_out(R, scores, dump.p, (size_t)n * ntotal * 4);
+    std::vector<float> xn(n);
+    HIP_CHECK(hipMemcpyAsync(xn.data(), q_norm_.p, (size_t)n * 4, hipMemcpyDeviceToHost, R.stream));
+    R.sync();
+    for (idx_t i = 0; i < n; i++) err_bound[i] = flat_filter_err_bound(metric_type, d, xn[i], yn_max_);
+}
+
 void GpuIndexFlat::search_tile_(int n, const float* xq_pad, int k, float* dD, idx_t* dI) const {
+    last_used_filter = false;
+    last_filter_overflow = 0;
+    if (!filter_applicable_(k)) {
+        search_tile_exact_(n, xq_pad, k, dD, dI);
+        return;
+    }
+    last_used_filter = true;
+    const GpuResources& R = *res_;
+    const int nb = (int)ntotal;
+    // ---- fp16 queries (+ per-query range flags), exact norms
+    qh_.ensure((size_t)n * dh_ * 2);
+    flags_.ensure((size_t)n * 4);
+    q_norm_.ensure((size_t)n * 4);
+    ovf_list_.ensure((size_t)n * 4);
+    {
+        SpanGuard sg(&R, "convert_f16_query");
+        launch_convert_f16(xq_pad, dpad_, n, d, qh_.p, dh_, nullptr, flags_.as<uint32_t>(), R.stream);
+        launch_l2_norms(xq_pad, dpad_, n, dpad_, q_norm_.as<float>(), R.stream);
+    }
+    HIP_CHECK(hipMemsetAsync(scal_.as<unsigned>() + 2, 0, 4, R.stream));
+    FlatFilterParams fp{};
+    fp.metric = metric_type;
+    fp.xqh = qh_.as<_Float16>();
+    fp.xqn = q_norm_.as<float>();
+    fp.xbh = xbh_.as<_Float16>();
+    fp.xbhn = xbhn_.as<float>();
+    fp.ldqh = dh_;
+    fp.ldbh = dh_;
+    fp.nq = n;
+    fp.nb = nb;
+    fp.d = d;
+    fp.dh = dh_;
+    fp.ngroups = (int)div_up(n, kFilterQueriesPerBlock);
+    plan_filter_(n, k, fp.nsplit, fp.rows_per_split, fp.cap);
+    fp.k = k;
+    fp.yn_max = yn_max_;
+    res_keys_.ensure((size_t)n * fp.nsplit * fp.cap * 8);
+    res_cnt_.ensure((size_t)n * fp.nsplit * 4);
+    fp.res_keys = res_keys_.as<unsigned long long>();
+    fp.res_cnt = res_cnt_.as<uint32_t>();
+    fp.flags = flags_.as<uint32_t>();
+    fp.dump = nullptr;
+    {
+        SpanGuard sg(&R, "flat_filter_kernel");
+        launch_flat_filter(fp, R.stream);
+    }
+    FlatRerankParams rp{};
+    rp.metric = metric_type;
+    rp.nq = n;
+    rp.k = k;
+    rp.kp = 1;
+    while (rp.kp < k) rp.kp <<= 1;
+    rp.d = d;
+    rp.dpad = dpad_;
+    rp.nsplit = fp.nsplit;
+    rp.cap = fp.cap;
+    rp.res_keys = fp.res_keys;
+    rp.res_cnt = fp.res_cnt;
+    rp.flags = fp.flags;
+    rp.xq = xq_pad;
+    rp.xqn = q_norm_.as<float>();
+    rp.xb = xb_.as<float>();
+    rp.xbn = xbn_.as<float>();
+    rp.ldq = dpad_;
+    rp.ldb = dpad_;
+    rp.yn_max = yn_max_;
+    rp.id_base = 0;
+    rp.out_dis = dD;
+    rp.out_ids = dI;
+    rp.ovf_list = ovf_list_.as<uint32_t>();
+    rp.ovf_cnt = scal_.as<unsigned>() + 2;
+    {
+        SpanGuard sg(&R, "flat_rerank_kernel");
+        launch_flat_rerank(rp, R.stream);
+    }
+    // ---- queries whose band overflowed (or left the fp16 range) go through the exact fp32 scan
+    unsigned novf = 0;
+    HIP_CHECK(hipMemcpyAsync(&novf, scal_.as<unsigned>() + 2, 4, hipMemcpyDeviceToHost, R.stream));
+    R.sync();
+    last_filter_overflow = (int)novf;
+    if (novf > 0) {
+        ovf_q_.ensure((size_t)novf * dpad_ * 4);
+        ovf_d_.ensure((size_t)novf * k * 4);
+        ovf_i_.ensure((size_t)novf * k * 8);
+        launch_gather_rows(xq_pad, dpad_, dpad_, ovf_list_.as<uint32_t>(), (int)novf, ovf_q_.as<float>(), R.stream);
+        // the exact scan tiles its own scratch; reuse of res_keys_ is ordered on the stream
+        const int tile = 16384;
+        for (int i0 = 0; i0 < (int)novf; i0 += tile) {
+            const int ni = std::min(tile, (int)novf - i0);
+            search_tile_exact_(ni, ovf_q_.as<float>() + (size_t)i0 * dpad_, k, ovf_d_.as<float>() + (size_t)i0 * k,
+                               ovf_i_.as<idx_t>() + (size_t)i0 * k);
+        }
+        launch_scatter_results(ovf_d_.as<float>(), ovf_i_.as<idx_t>(), k, ovf_list_.as<uint32_t>(), (int)novf, dD, dI,
+                               R.stream);
+    }
+}
+
+void GpuIndexFlat::search_tile_exact_(int n, const float* xq_pad, int k, float* dD, idx_t* dI) const {
     const GpuResources& R = *res_;
     const int nb = (int)ntotal;
     if (metric_type == METRIC_L2) {
@@ -319,7 +501,7 @@ void GpuIndexFlat::search_tile_(int n, const float* xq_pad, int k, float* dD, id
 static int flat_query_tile(const GpuResources& R, int k, bool simple, idx_t nb) {
     size_t per_q;
     if (simple) per_q = (size_t)std::max<idx_t>(nb, 1) * 8;
-    else per_q = (size_t)64 * reservoir_capacity(k) * 8;
+    else per_q = (size_t)64 * std::max(reservoir_capacity(k), 2 * (k + 32)) * 8;
     size_t t = R.temp_budget_bytes / per_q;
     t = std::max<size_t>(t, 256);
     t = std::min<size_t>(t, (size_t)1 << 20);

@@ -122,6 +122,16 @@ class GpuIndexFlat : public Index {
     void pairwise_distances(idx_t n, const float* x, float* out) const;
     // when true, search() uses the scalar cross-check kernel instead of the MFMA kernel
     bool use_simple_kernel = false;
+    // fp16 MFMA candidate filter + exact fp32 re-rank (flat_filter.hip); results are bit-identical
+    // to the fp32 MFMA scan, which remains the path for small databases, large k, data outside the
+    // fp16 range and any query whose error band overflows its reservoir
+    bool use_filter_kernel = true;
+    idx_t filter_min_rows = 16384;
+    // statistics of the last search() tile (tests / bench): queries re-run through the exact scan
+    mutable int last_filter_overflow = 0;
+    mutable bool last_used_filter = false;
+    // test hook: approximate scores [n][ntotal] of the filter kernel and its per-query error bound
+    void filter_scores(idx_t n, const float* x, float* scores, float* err_bound) const;
 
     int dpad() const { return dpad_; }
     const float* device_vectors() const { return xb_.as<float>(); }
@@ -132,6 +142,16 @@ class GpuIndexFlat : public Index {
     int dpad_;
     DevBuf xb_;  // [cap][dpad]
     DevBuf xbn_; // [cap]
+    // fp16 shadow copy for the filter kernel: rows padded to dh_ (multiple of 128) halfs, |y|^2/2
+    int dh_;
+    DevBuf xbh_, xbhn_;
+    DevBuf scal_;            // device scalars: [0] max |x| bits, [1] max |y|^2 bits, [2] overflow counter
+    float yn_max_ = 0.f;     // max squared norm over the database
+    bool db_f16_ok_ = true;  // every database value inside the fp16 range (no NaN/inf)
+    mutable DevBuf qh_, flags_, ovf_list_, ovf_q_, ovf_d_, ovf_i_;
+    void search_tile_exact_(int n, const float* xq_pad, int k, float* dD, idx_t* dI) const;
+    bool filter_applicable_(int k) const;
+    void plan_filter_(int n, int k, int& nsplit, int& rows_per_split, int& cap) const;
     mutable std::mutex mu_;
     // persistent scratch
     mutable DevBuf q_raw_, q_pad_, q_norm_, res_keys_, res_cnt_, out_d_, out_i_, all_keys_, one_cnt_;

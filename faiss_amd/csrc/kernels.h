@@ -1,6 +1,7 @@
 // faiss_amd/csrc/kernels.h -- host-callable launchers of the hand-written gfx950 kernels.
 // All pointers are DEVICE pointers; all launches are asynchronous on `stream`.
 #pragma once
+#include <cmath>
 #include "common.h"
 
 namespace faiss_amd {
@@ -49,6 +50,76 @@ size_t flat_scan_lds_bytes();
 void launch_flat_simple(int metric, const float* xq, const float* xqn, int64_t ldq, int nq,
                         const float* xb, const float* xbn, int64_t ldb, int nb, int dpad,
                         unsigned long long* keys, hipStream_t stream);
+
+// ------------------------------------------------------------------ Flat: fp16 MFMA filter + exact fp32 re-rank
+// (flat_filter.hip; see the header there for the superset argument)
+constexpr int kFilterQueriesPerBlock = 256; // 4 waves x 64 queries
+constexpr int kFilterTileRows = 64;
+constexpr int kFilterSlab = 128;            // fp16 rows are padded to a multiple of this many halfs
+
+struct FlatFilterParams {
+    int metric;
+    const _Float16* xqh; // [nq][ldqh] fp16 queries
+    const float* xqn;    // [nq] exact fp32 squared norms of the queries (both metrics: error bound)
+    const _Float16* xbh; // [nb][ldbh] fp16 database
+    const float* xbhn;   // [nb] |y|^2 / 2 (L2 bias of the approximate score; unused for IP)
+    int64_t ldqh, ldbh;
+    int nq, nb, d, dh;   // dh = padded fp16 row length, multiple of kFilterSlab
+    int nsplit, rows_per_split, ngroups;
+    int k, cap;          // reservoir capacity per (query, split), >= 2 * (k + 32)
+    float yn_max;        // max squared norm over the database
+    unsigned long long* res_keys; // [nq][nsplit][cap]  (score key << 32 | row)
+    uint32_t* res_cnt;            // [nq][nsplit]
+    uint32_t* flags;              // [nq] in: fp16 overflow of the query; out: |= band overflow
+    float* dump;                  // optional [nq][nb] approximate scores (tests)
+};
+// Bound on |t~ - s| for one query against any database row (see flat_filter.hip header).  fp16 round-to-nearest:
+// |dx| <= 2^-11 |x| in the normal range and <= 2^-25 below it, so
+//   |<q~,y~> - <q,y>| <= 2^-10 (1+2^-11) |q||y| + 2^-25 (1+2^-11) sqrt(d) (|q| + |y|) + d 2^-50;
+// MFMA fp32 accumulation and the exact path's own fmaf chain each contribute at most
+// d 2^-24 |q||y| (first-order, doubled below); the L2 epilogue rounds fl(|q|^2+|y|^2) and the
+// fmaf result once each: 2^-23 (|q|^2 + |y|^2) in distance units = 2^-24 (...) in score units.
+// A 1.25x safety factor covers the second-order terms and sqrtf.
+__host__ __device__ static inline float flat_filter_err_bound(int metric, int d, float xn, float yn_max) {
+    const float nq = sqrtf(xn), ny = sqrtf(yn_max);
+    float e = (9.775e-4f /*2^-10 * 1.001*/ + 2.4e-7f * (float)d /*4 d 2^-24*/) * nq * ny +
+              3.0e-8f /*2^-25 * 1.001*/ * sqrtf((float)d) * (nq + ny) + 1e-30f;
+    if (metric == METRIC_L2) e += 6.0e-8f /*2^-24*/ * (xn + yn_max);
+    return 1.25f * e;
+}
+void launch_flat_filter(const FlatFilterParams& p, hipStream_t stream);
+size_t flat_filter_lds_bytes();
+
+struct FlatRerankParams {
+    int metric;
+    int nq, k, kp, d, dpad, nsplit, cap;
+    const unsigned long long* res_keys;
+    const uint32_t* res_cnt;
+    const uint32_t* flags;
+    const float* xq;  // [nq][ldq] fp32 padded queries
+    const float* xqn; // [nq]
+    const float* xb;  // [nb][ldb] fp32 padded database
+    const float* xbn; // [nb]
+    int64_t ldq, ldb;
+    float yn_max;
+    int64_t id_base;
+    float* out_dis;     // [nq][k]
+    int64_t* out_ids;   // [nq][k]
+    uint32_t* ovf_list; // [nq] queries that must be re-run through the exact fp32 scan
+    uint32_t* ovf_cnt;  // [1] (zeroed by the caller)
+};
+void launch_flat_rerank(const FlatRerankParams& p, hipStream_t stream);
+
+// dst[i][0..dh) = fp16(src[i][0..d)), zero padded; *absmax_bits = max |x| (float bits, 0x7f800000 when
+// a value is NaN/inf/outside the fp16 range); flags[i] = that condition per row (nullable)
+void launch_convert_f16(const float* src, int64_t ld_src, int64_t n, int d, void* dst, int dh,
+                        unsigned* absmax_bits, uint32_t* flags, hipStream_t stream);
+void launch_max_f32(const float* x, int64_t n, unsigned* out_bits, hipStream_t stream);
+void launch_half_norms(const float* xn, int64_t n, float* out, hipStream_t stream); // out = xn / 2
+void launch_gather_rows(const float* src, int64_t ld, int width, const uint32_t* list, int n, float* dst,
+                        hipStream_t stream);
+void launch_scatter_results(const float* sd, const int64_t* si, int k, const uint32_t* list, int n, float* dd,
+                            int64_t* di, hipStream_t stream);
 
 // ------------------------------------------------------------------ k-selection
 struct SelectParams {

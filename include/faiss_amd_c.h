@@ -151,6 +151,15 @@ int faiss_amd_GpuIndexFlat_pairwise_distances(const FaissAmdIndex* index, faiss_
                                               float* out);
 /* route search() through the scalar cross-check kernel (identical arithmetic, no MFMA) */
 int faiss_amd_GpuIndexFlat_set_use_simple_kernel(FaissAmdIndex* index, int on);
+/* fp16 MFMA candidate filter + exact fp32 re-rank for GpuIndexFlat (results bit-identical to the fp32
+ * scan; on by default for databases of at least min_rows rows; min_rows < 0 keeps the current value) */
+int faiss_amd_GpuIndexFlat_set_use_filter_kernel(FaissAmdIndex* index, int on, faiss_amd_idx_t min_rows);
+/* did the last search tile go through the filter, and how many of its queries were re-run exactly */
+int faiss_amd_GpuIndexFlat_filter_stats(const FaissAmdIndex* index, int* used_filter, int* overflow_queries);
+/* approximate scores [n][ntotal] of the filter kernel (L2: <q,y> - |y|^2/2 on fp16 inputs; IP: <q,y>) and
+ * the per-query bound err_bound[n] on their deviation from the exact fp32 scores */
+int faiss_amd_GpuIndexFlat_filter_scores(const FaissAmdIndex* index, faiss_amd_idx_t n, const float* x, float* scores,
+                                         float* err_bound);
 /* IVF search through the unfused path (every distance as a key in HBM + select kernel) instead
  * of the fused LDS-resident scan; results are identical, the switch exists for cross-checks */
 int faiss_amd_GpuIndexIVF_set_use_fused_scan(FaissAmdIndex* index, int on);

@@ -360,3 +360,110 @@ def test_ivf_fused_scan_matches_unfused_and_oracle(res, kind, metric, d, M, nlis
     sizes, codes, ids, _ = Oracle.build_ivf_lists(kind, metric, cent, xb, pq=pq)
     Do, Io, _, _ = Oracle.ivf_search(kind, metric, cent, sizes, codes, ids, xq[sel], nprobe, k, M=M, pq=pq)
     check_knn(D[sel], I[sel], Do, Io, exact=True, name="fused vs oracle")
+
+
+# ------------------------------------------------------------------------------- fp16 filter + exact re-rank
+@pytest.mark.parametrize("metric", [METRIC_L2, METRIC_INNER_PRODUCT])
+@pytest.mark.parametrize("d,scale", [(128, 1.0), (96, 37.0), (200, 1e-3), (32, 300.0)])
+def test_filter_error_bound_holds(res, metric, d, scale):
+    """The per-query bound e_q used for the candidate band really bounds |approximate - exact| score
+    (fp16 rounding of both operands + fp32 accumulation), with margin, on data of several scales."""
+    _, xb, xq = synthetic_dataset(d, 0, 3000, 70, seed=d)
+    rs = np.random.RandomState(d)
+    xb = (xb * scale * (0.2 + rs.rand(len(xb), 1))).astype("float32")
+    xq = (xq * scale).astype("float32")
+    idx = faiss_amd.GpuIndexFlat(res, d, metric)
+    idx.add(xb)
+    sc, eb = idx.filter_scores(xq)
+    ip = xq.astype("float64") @ xb.astype("float64").T
+    exact = ip - (0.5 * (xb.astype("float64") ** 2).sum(1))[None, :] if metric == METRIC_L2 else ip
+    err = np.abs(sc - exact).max(axis=1)
+    assert (err <= eb).all(), (err / eb).max()
+    assert (err > 0).any() and (err / eb).max() < 0.8  # fp16 rounding is visible, the bound has slack
+
+
+FILTER_SHAPES = [(128, 30000, 300, 10), (128, 30000, 300, 100), (64, 20000, 513, 1), (100, 25000, 257, 50),
+                 (32, 18000, 100, 1000), (384, 17000, 30, 20), (200, 40000, 1100, 128)]
+
+
+@pytest.mark.parametrize("metric", [METRIC_L2, METRIC_INNER_PRODUCT])
+@pytest.mark.parametrize("d,nb,nq,k", FILTER_SHAPES)
+def test_flat_filter_path_bit_exact(res, metric, d, nb, nq, k):
+    """fp16 MFMA filter + exact fp32 re-rank returns the very same bits as the fp32 MFMA scan and
+    the CPU oracle restatement."""
+    _, xb, xq = synthetic_dataset(d, 0, nb, nq, seed=nb + k)
+    idx = faiss_amd.GpuIndexFlat(res, d, metric)
+    idx.add(xb)
+    D, I = idx.search(xq, k)
+    used, novf = idx.filter_stats()
+    assert used and novf == 0
+    idx.set_use_filter_kernel(False)
+    D0, I0 = idx.search(xq, k)
+    assert not idx.filter_stats()[0]
+    assert np.array_equal(D, D0) and np.array_equal(I, I0)
+    sel = np.r_[0:min(nq, 60)]
+    Do, Io = Oracle.flat_search(metric, xb, xq[sel], k)
+    check_knn(D[sel], I[sel], Do, Io, exact=True, name="filter vs oracle")
+
+
+def test_flat_filter_overflow_falls_back_to_exact(res):
+    """Adversarial data: 50 distinct vectors repeated 400 times (every neighbour tied 400-fold, so the
+    error band of a query holds thousands of rows) and integer data full of ties.  Such queries are
+    flagged and re-run through the exact scan; the (distance, id) tie order must survive."""
+    _, base, xq = synthetic_dataset(64, 0, 50, 40, seed=9)
+    xb = np.tile(base, (400, 1))
+    idx = faiss_amd.GpuIndexFlatL2(res, 64)
+    idx.add(xb)
+    for k in (10, 500):
+        D, I = idx.search(xq, k)
+        used, novf = idx.filter_stats()
+        assert used and novf > 0
+        check_knn(D, I, *Oracle.flat_search(METRIC_L2, xb, xq, k), exact=True, name="dup rows k=%d" % k)
+    z, xb, xq = load_flat_case("flat_l2_int_ties")
+    idx = faiss_amd.GpuIndexFlatL2(res, xb.shape[1])
+    idx.set_use_filter_kernel(True, 0)
+    idx.add(xb)
+    for k in z["ks"]:
+        D, I = idx.search(xq, int(k))
+        assert idx.filter_stats()[0]
+        check_knn(D, I, z["D_%d" % k], z["I_%d" % k], exact=True, name="ties k=%d (filter)" % k)
+
+
+def test_flat_filter_range_and_nan_handling(res):
+    """Values outside the fp16 range: a query is flagged and served by the exact scan; a database that
+    leaves the range (or holds a NaN) disables the filter for the index.  NaN queries behave as on the fp32 path."""
+    _, xb, xq = synthetic_dataset(48, 0, 20000, 12, seed=4)
+    xq = xq.copy()
+    xq[3] *= 1e6      # beyond 65504 after conversion
+    xq[5, 7] = np.nan  # admits nothing
+    idx = faiss_amd.GpuIndexFlatL2(res, 48)
+    idx.add(xb)
+    D, I = idx.search(xq, 8)
+    used, novf = idx.filter_stats()
+    assert used and novf >= 1
+    assert (I[5] == -1).all() and (I[3] >= 0).all()
+    idx.set_use_filter_kernel(False)
+    D0, I0 = idx.search(xq, 8)
+    assert np.array_equal(D, D0) and np.array_equal(I, I0)
+    big = faiss_amd.GpuIndexFlatL2(res, 48)
+    xb2 = xb.copy()
+    xb2[77] *= 1e5
+    big.add(xb2)
+    D, I = big.search(xq[:3], 8)
+    assert not big.filter_stats()[0]
+    check_knn(D, I, *Oracle.flat_search(METRIC_L2, xb2, xq[:3], 8), exact=True, name="out of range db")
+
+
+def test_flat_filter_full_size_matches_exact_scan(res):
+    """BASELINE.json configs[1] at full size (d=128, nb=1M, nq=10k, k=100): the two independent device
+    paths (fp16 filter + re-rank, fp32 MFMA scan) agree bit for bit on every query."""
+    _, xb, xq = synthetic_dataset(128, 0, 1000000, 10000, seed=1338)
+    idx = faiss_amd.GpuIndexFlatL2(res, 128)
+    idx.add(xb)
+    D, I = idx.search(xq, 100)
+    used, novf = idx.filter_stats()
+    assert used and novf < 100
+    idx.set_use_filter_kernel(False)
+    D0, I0 = idx.search(xq, 100)
+    assert np.array_equal(I, I0) and np.array_equal(D, D0)
+    assert (np.diff(D, axis=1) >= 0).all()
