@@ -236,6 +236,8 @@ def main():
     dom = "flat_filter_kernel" if used_filter else "flat_scan_kernel"
     scan_ms, scan_n = res.profile_get(dom)
     rr_ms, rr_n = res.profile_get("flat_rerank_kernel")
+    mxp_ms, mxp_n = res.profile_get("flat_filter_kernel_max")
+    tg_ms, tg_n = res.profile_get("flat_tighten_kernel")
     cv_ms, cv_n = res.profile_get("convert_f16_query")
     sel_ms, sel_n = res.profile_get("select_k_kernel")
     res.profile_enable(False)
@@ -275,7 +277,9 @@ def main():
                      "traffic": None, "avg_kernel_ms": round(avg_scan_ms, 3), "launches": int(scan_n),
                      "algorithmic_hbm_GBps": round(hbm_bytes / (avg_scan_ms * 1e-3) / 1e9, 1),
                      "hbm_frac": round(hbm_bytes / (avg_scan_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 5)},
-        "other_kernels_ms": {"flat_rerank_kernel": round(rr_ms / max(rr_n, 1), 3),
+        "other_kernels_ms": {"flat_filter_kernel<MODE_MAX> (chunk maxima on a 1/4 tile sample)": round(mxp_ms / max(mxp_n, 1), 3),
+                             "flat_tighten_kernel": round(tg_ms / max(tg_n, 1), 3),
+                             "flat_rerank_kernel": round(rr_ms / max(rr_n, 1), 3),
                              "convert_f16_query+norms": round(cv_ms / max(cv_n, 1), 3),
                              "select_k_kernel": round(sel_ms / max(sel_n, 1), 3)},
         "filter_overflow_queries": int(n_overflow),

@@ -22,7 +22,6 @@
 //      rows within fp16 rounding of the k-th neighbour, or fp16 range overflow) is flagged and
 //      re-run through the exact fp32 MFMA kernel by the host code.  Never a silent approximation.
 #include "kernels.h"
-#include "wave_select.h"
 #include "wg_select.h"
 
 namespace faiss_amd {
@@ -120,11 +119,25 @@ void launch_max_f32(const float* x, int64_t n, unsigned* out_bits, hipStream_t s
 // Workgroup = 256 threads = 4 waves; wave w owns 64 queries (two 32-query MFMA column blocks whose
 // fp16 coordinates stay in 64 VGPRs as B operands); the 4 waves share one stream of 64-row
 // database tiles (64 x 128 halfs = 16 KB) brought in by global_load_lds_dwordx4 (no staging
-// registers), double buffered.  The 16-byte chunks of a row are XOR-swizzled with the row
-// number through the SOURCE address of the LDS-DMA (the LDS image is lane-linear), so the
+// registers) through a 3-slot LDS ring.  The 16-byte chunks of a row are XOR-swizzled with the
+// row number through the SOURCE address of the LDS-DMA (the LDS image is lane-linear), so the
 // ds_read_b128 of 16 different rows at one k offset hits 16 different 16-byte bank groups.
-// Per tile and wave: 2 x 2 blocks x 8 k-steps = 32 MFMAs (32 cycles each) against 128 VALU
-// compare/subtract instructions of epilogue.
+// Per tile and wave: 2 x 2 blocks x 8 k-steps = 32 MFMAs (32 cycles each) against ~130 VALU
+// instructions of epilogue.
+//
+// Split s owns the tiles s, s + nsplit, s + 2 nsplit, ... (striped, so that a run of similar
+// consecutive rows is spread over every split), and the kernel runs in two modes that share the
+// MFMA loop:
+//   MODE_MAX      every lane keeps 8 running maxima per query (one per position class of the MFMA
+//                 output fragment) over a 1/tstride sample of its split's tiles: 16 * nsplit
+//                 "chunk maxima" per query.  The k-th largest of them is a lower bound of the k-th
+//                 best score of the whole database (each maximum is a distinct row), and because
+//                 rows are dealt to the chunks round-robin (period 64 * nsplit rows) only about
+//                 k + k^2/(2S) rows of the sample beat it.  No selection, no memory traffic.
+//   MODE_COLLECT  with the per-query threshold fixed (flat_tighten_kernel: k-th largest maximum
+//                 minus the error band), rows above it are appended to the (query, split)
+//                 segment: a few hundred per query in total.
+//   MODE_DUMP     test hook: every approximate score to memory.
 // ---------------------------------------------------------------------------------
 constexpr int FQ_THREADS = 256;
 constexpr int FQ_QPB = 256;          // queries per workgroup (kFilterQueriesPerBlock)
@@ -133,8 +146,9 @@ constexpr int FQ_KS = 128;           // halfs per k-slab
 constexpr int FQ_TILE_BYTES = FQ_TR * FQ_KS * 2; // 16384
 constexpr int FQ_NBUF = 3;                       // LDS ring: tile u computes while u+1, u+2 are in flight
 constexpr int FQ_LDS_BIAS = FQ_NBUF * FQ_TILE_BYTES;
-constexpr int FQ_LDS_HIST = FQ_LDS_BIAS + FQ_NBUF * FQ_TR * 4;
-constexpr int FQ_LDS_TOTAL = FQ_LDS_HIST + 4 * 256 * 4;
+constexpr int FQ_LDS_CNT = FQ_LDS_BIAS + FQ_NBUF * FQ_TR * 4; // [256] per-query append counters
+constexpr int FQ_LDS_TOTAL = FQ_LDS_CNT + FQ_QPB * 4;
+constexpr int MODE_MAX = 0, MODE_COLLECT = 1, MODE_DUMP = 2;
 
 // LDS-DMA issued from inline asm: hipcc makes every ds_read that follows a
 // __builtin_amdgcn_global_load_lds wait for vmcnt(0) (it cannot tell the two LDS regions apart),
@@ -164,7 +178,7 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 // SINGLE: dh == 128, one k-slab per tile: the query operands never leave their registers and
 // the loop holds no compiler-visible global load, whose counted s_waitcnt would otherwise also
 // wait for the (younger, hidden) LDS-DMAs of the prefetch.
-template <int METRIC, bool DUMP, bool SINGLE>
+template <int METRIC, int MODE, bool SINGLE>
 __global__ void __launch_bounds__(FQ_THREADS, 2) flat_filter_kernel(FlatFilterParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -187,25 +201,19 @@ __global__ void __launch_bounds__(FQ_THREADS, 2) flat_filter_kernel(FlatFilterPa
             grp = b / p.nsplit;
         }
     }
-    const int r0 = split * p.rows_per_split;
-    const int r1 = min(p.nb, r0 + p.rows_per_split);
-    if (r0 >= r1) {
-        if (!DUMP) {
-            const int q = grp * FQ_QPB + tid;
-            if (q < p.nq) p.res_cnt[(int64_t)q * p.nsplit + split] = 0;
-        }
-        return;
-    }
-    const int ntiles = (r1 - r0 + FQ_TR - 1) / FQ_TR;
-    auto tile_row0_of = [&](int t) { return r0 + t * FQ_TR; };
+    // tiles of this split: split, split + nsplit, ...; the maxima pass visits every tstride-th of them
+    const int total_tiles = (p.nb + FQ_TR - 1) / FQ_TR;
+    const int nt_split = split < total_tiles ? (total_tiles - split + p.nsplit - 1) / p.nsplit : 0;
+    const int tstep = MODE == MODE_MAX ? p.tstride : 1;
+    const int ntiles = (nt_split + tstep - 1) / tstep;
     const int nslab = SINGLE ? 1 : p.dh / FQ_KS;
     const int nsteps = ntiles * nslab;
+    auto tile_row0_of = [&](int tl) { return (split + tl * tstep * p.nsplit) * FQ_TR; };
 
     // ---- this lane's two queries
     const int qbase = grp * FQ_QPB + wave * 64; // wave-uniform
     const _Float16* qrow[2];
-    float thr[2], eb[2];
-    int cnt[2] = {0, 0};
+    float thr[2];
     bool qvalid[2];
     u64* resq[2] = {nullptr, nullptr};
 #pragma unroll
@@ -214,14 +222,39 @@ __global__ void __launch_bounds__(FQ_THREADS, 2) flat_filter_kernel(FlatFilterPa
         qvalid[qb] = q < p.nq;
         const int qc = qvalid[qb] ? q : p.nq - 1;
         qrow[qb] = p.xqh + (int64_t)qc * p.ldqh;
-        eb[qb] = flat_filter_err_bound(METRIC, p.d, p.xqn[qc], p.yn_max);
-        const bool usable = qvalid[qb] && eb[qb] < FLT_MAX && p.flags[qc] == 0; // NaN/inf bound or fp16 overflow
-        thr[qb] = usable ? -INFINITY : INFINITY;
-        if (qvalid[qb] && !usable && !DUMP && split == 0 && h == 0) p.flags[qc] = 1;
-        if (!DUMP) resq[qb] = p.res_keys + ((int64_t)qc * p.nsplit + split) * p.cap;
+        thr[qb] = INFINITY;
+        if (MODE == MODE_COLLECT) {
+            // +inf for queries the filter cannot serve (flagged by the tighten kernel)
+            if (qvalid[qb]) thr[qb] = p.thr[qc];
+            resq[qb] = p.res_keys + ((int64_t)qc * p.nsplit + split) * p.cap;
+        }
     }
-    unsigned* hist = (unsigned*)(smem + FQ_LDS_HIST) + wave * 256;
-    const int cap_lim = p.cap - 32;
+    unsigned* lcnt = (unsigned*)(smem + FQ_LDS_CNT);
+    if (MODE == MODE_COLLECT) lcnt[tid] = 0;
+
+    float mx[2][8];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) mx[qb][c] = -INFINITY;
+
+    if (nsteps == 0) {
+        if (MODE == MODE_MAX) {
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                const int q = qbase + qb * 32 + j;
+                if (qvalid[qb]) {
+                    float* o = p.maxes + (int64_t)q * p.nsplit * 16 + split * 16 + h * 8;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) o[c] = -INFINITY;
+                }
+            }
+        } else if (MODE == MODE_COLLECT) {
+            const int q = grp * FQ_QPB + tid;
+            if (q < p.nq) p.res_cnt[(int64_t)q * p.nsplit + split] = 0;
+        }
+        return;
+    }
 
     // ---- LDS-DMA staging of step u (tile u / nslab, slab u % nslab) into ring slot u % 3:
     // 4 x 1 KB of row chunks + (every wave, redundantly, so that all waves count the same
@@ -229,19 +262,20 @@ __global__ void __launch_bounds__(FQ_THREADS, 2) flat_filter_kernel(FlatFilterPa
     const unsigned lds_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
     constexpr int DMA_PER_STAGE = METRIC == METRIC_L2 ? 5 : 4;
     auto stage = [&](int u, int slot) {
-        const int t = u / nslab, sl = u - t * nslab;
+        const int tl = u / nslab, sl = u - tl * nslab;
+        const int row0 = tile_row0_of(tl);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int g = (wave * 4 + i) * 64 + lane; // 16-byte chunk of the LDS image
             const int row = g >> 4, cpos = g & 15;
             const int c = cpos ^ (row & 15);          // chunk of the source row that lands there
-            const int grow = min(r0 + t * FQ_TR + row, r1 - 1);
+            const int grow = min(row0 + row, p.nb - 1);
             const _Float16* src = p.xbh + (int64_t)grow * p.ldbh + sl * FQ_KS + c * 8;
             glds16(src, lds_base + slot * FQ_TILE_BYTES + (wave * 4 + i) * 1024);
         }
         if (METRIC == METRIC_L2) {
-            // rows past the end of the split re-read row r1-1 (their scores are masked in the rare path)
-            const int grow = min(r0 + t * FQ_TR + lane, r1 - 1);
+            // rows past the end of the database re-read the last row (masked in the epilogue)
+            const int grow = min(row0 + lane, p.nb - 1);
             glds4(p.xbhn + grow, lds_base + FQ_LDS_BIAS + slot * FQ_TR * 4);
         }
     };
@@ -272,7 +306,7 @@ __global__ void __launch_bounds__(FQ_THREADS, 2) flat_filter_kernel(FlatFilterPa
 
     int slot = 0; // u % 3
     for (int u = 0; u < nsteps; ++u) {
-        const int t = u / nslab, sl = u - t * nslab;
+        const int tl = u / nslab, sl = u - tl * nslab;
         if (!SINGLE && u > 0) load_b(sl);
         const int slot2 = slot >= 1 ? slot - 1 : 2; // (u + 2) % 3
         if (u + 2 < nsteps) stage(u + 2, slot2);
@@ -303,8 +337,8 @@ __global__ void __launch_bounds__(FQ_THREADS, 2) flat_filter_kernel(FlatFilterPa
         }
         if (sl == nslab - 1) {
             const float* bias = (const float*)(smem + FQ_LDS_BIAS) + slot * FQ_TR;
-            const bool last_tile = tile_row0_of(t) + FQ_TR > r1;
-            const int tile_row0 = tile_row0_of(t);
+            const int tile_row0 = tile_row0_of(tl);
+            const bool partial = tile_row0 + FQ_TR > p.nb; // wave-uniform
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) {
                 f32x4 b4[4];
@@ -316,54 +350,46 @@ __global__ void __launch_bounds__(FQ_THREADS, 2) flat_filter_kernel(FlatFilterPa
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb) {
                     float tv[16];
-                    bool anyp = false;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        tv[r] = acc[rb][qb][r] - b4[r >> 2][r & 3];
-                        anyp |= tv[r] > thr[qb];
+                    for (int r = 0; r < 16; ++r) tv[r] = acc[rb][qb][r] - b4[r >> 2][r & 3];
+                    if (partial) {
+                        // last tile of the database: the rows past the end re-read row nb-1; they must not
+                        // count (a duplicated row would appear in several chunk maxima and lift the threshold
+                        // above the true k-th best score)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int grow = tile_row0 + rb * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+                            if (grow >= p.nb) tv[r] = -INFINITY;
+                        }
                     }
-                    if (DUMP) {
+                    if (MODE == MODE_MAX) {
+                        // class (rb, r >> 2): 4 consecutive rows of the 64-row tile; fmaxf drops NaN scores
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const float m01 = fmaxf(tv[4 * g], tv[4 * g + 1]);
+                            const float m23 = fmaxf(tv[4 * g + 2], tv[4 * g + 3]);
+                            mx[qb][rb * 4 + g] = fmaxf(mx[qb][rb * 4 + g], fmaxf(m01, m23));
+                        }
+                    } else if (MODE == MODE_DUMP) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int grow = tile_row0 + rb * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
                             const int q = qbase + qb * 32 + j;
-                            if (qvalid[qb] && grow < r1) p.dump[(int64_t)q * p.nb + grow] = tv[r];
+                            if (qvalid[qb] && grow < p.nb) p.dump[(int64_t)q * p.nb + grow] = tv[r];
                         }
-                    } else if (__ballot(anyp)) {
-                        // ---- rare path: some lane has a row inside the band of its query
+                    } else {
+                        bool anyp = false;
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int grow = tile_row0 + rb * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-                            const bool pass = tv[r] > thr[qb] && (!last_tile || grow < r1);
-                            const u64 m = __ballot(pass);
-                            if (m) {
-                                const int lo = (int)((m >> j) & 1ull);
-                                const int hi = (int)((m >> (j + 32)) & 1ull);
-                                if (pass) {
-                                    resq[qb][cnt[qb] + (h ? lo : 0)] = ((u64)score_key(tv[r]) << 32) | (unsigned)grow;
-                                }
-                                cnt[qb] += lo + hi;
-                            }
-                        }
-                        u64 flagged = __ballot(cnt[qb] > cap_lim) & 0xffffffffull;
-                        if (flagged) {
-                            wave_mem_sync();
-                            while (flagged) {
-                                const int jq = __ffsll((long long)flagged) - 1;
-                                flagged &= flagged - 1;
-                                const int n = __shfl(cnt[qb], jq, 64);
-                                const float ee = __shfl(eb[qb], jq, 64);
-                                const int qq = qbase + qb * 32 + jq;
-                                u64* base = p.res_keys + ((int64_t)qq * p.nsplit + split) * p.cap;
-                                const u64 kth = wave_select_kth(base, n, p.k, hist);
-                                const float thr_new = band_threshold(key_score((uint32_t)(kth >> 32)), ee);
-                                const u64 key_thr = ((u64)score_key(thr_new) << 32) | 0xffffffffull;
-                                const int kept = wave_compact(base, n, key_thr);
-                                const bool ovf = kept > (p.cap >> 1);
-                                if (ovf && lane == 0) p.flags[qq] = 1;
-                                if (j == jq) {
-                                    cnt[qb] = ovf ? 0 : kept;
-                                    thr[qb] = ovf ? INFINITY : thr_new;
+                        for (int r = 0; r < 16; ++r) anyp |= tv[r] > thr[qb];
+                        if (anyp) {
+                            // rare, divergent: this lane's query has a row above its threshold
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int grow = tile_row0 + rb * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+                                if (tv[r] > thr[qb]) {
+                                    const unsigned slot_ = atomicAdd(&lcnt[wave * 64 + qb * 32 + j], 1u);
+                                    if (slot_ < (unsigned)p.cap)
+                                        resq[qb][slot_] = ((u64)score_key(tv[r]) << 32) | (unsigned)grow;
                                 }
                             }
                         }
@@ -379,27 +405,23 @@ __global__ void __launch_bounds__(FQ_THREADS, 2) flat_filter_kernel(FlatFilterPa
         slot = slot == 2 ? 0 : slot + 1;
     }
 
-    if (!DUMP) {
+    if (MODE == MODE_MAX) {
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
-            // final cut so that the re-rank kernel sees k + band keys per (query, split)
-            u64 flagged = __ballot(cnt[qb] > p.k) & 0xffffffffull;
-            if (flagged) wave_mem_sync();
-            while (flagged) {
-                const int jq = __ffsll((long long)flagged) - 1;
-                flagged &= flagged - 1;
-                const int n = __shfl(cnt[qb], jq, 64);
-                const float ee = __shfl(eb[qb], jq, 64);
-                const int qq = qbase + qb * 32 + jq;
-                u64* base = p.res_keys + ((int64_t)qq * p.nsplit + split) * p.cap;
-                const u64 kth = wave_select_kth(base, n, p.k, hist);
-                const float thr_new = band_threshold(key_score((uint32_t)(kth >> 32)), ee);
-                const u64 key_thr = ((u64)score_key(thr_new) << 32) | 0xffffffffull;
-                const int kept = wave_compact(base, n, key_thr);
-                if (j == jq) cnt[qb] = kept;
-            }
             const int q = qbase + qb * 32 + j;
-            if (qvalid[qb] && h == 0) p.res_cnt[(int64_t)q * p.nsplit + split] = (uint32_t)cnt[qb];
+            if (qvalid[qb]) {
+                float* o = p.maxes + (int64_t)q * p.nsplit * 16 + split * 16 + h * 8;
+                *(f32x4*)o = f32x4{mx[qb][0], mx[qb][1], mx[qb][2], mx[qb][3]};
+                *(f32x4*)(o + 4) = f32x4{mx[qb][4], mx[qb][5], mx[qb][6], mx[qb][7]};
+            }
+        }
+    } else if (MODE == MODE_COLLECT) {
+        // (the last loop iteration ended with a barrier: every append of the workgroup is counted)
+        const int q = grp * FQ_QPB + tid;
+        if (q < p.nq) {
+            const unsigned c = lcnt[tid];
+            if (c > (unsigned)p.cap) p.flags[q] = 1; // segment overflow: exact fallback for this query
+            p.res_cnt[(int64_t)q * p.nsplit + split] = c > (unsigned)p.cap ? (unsigned)p.cap : c;
         }
     }
 }
@@ -408,27 +430,77 @@ size_t flat_filter_lds_bytes() {
     return FQ_LDS_TOTAL;
 }
 
-void launch_flat_filter(const FlatFilterParams& p, hipStream_t stream) {
+void launch_flat_filter(const FlatFilterParams& p, int mode, hipStream_t stream) {
     if (p.nq == 0 || p.nb == 0) return;
     FA_THROW_IF_NOT(p.dh % FQ_KS == 0 && p.ldqh % 8 == 0 && p.ldbh % 8 == 0);
-    FA_THROW_IF_NOT(p.rows_per_split % FQ_TR == 0);
-    FA_THROW_IF_NOT(p.dump || p.cap >= 2 * (p.k + 32));
+    FA_THROW_IF_NOT(p.tstride >= 1 && p.nsplit >= 1);
     dim3 grid((unsigned)(p.nsplit * p.ngroups)), block(FQ_THREADS);
     const size_t lds = FQ_LDS_TOTAL;
     const bool single = p.dh == FQ_KS;
-#define FA_LAUNCH(M, D)                                                                              \
-    do {                                                                                             \
-        if (single) hipLaunchKernelGGL((flat_filter_kernel<M, D, true>), grid, block, lds, stream, p); \
-        else hipLaunchKernelGGL((flat_filter_kernel<M, D, false>), grid, block, lds, stream, p);     \
+#define FA_LAUNCH(M, MD)                                                                              \
+    do {                                                                                              \
+        if (single) hipLaunchKernelGGL((flat_filter_kernel<M, MD, true>), grid, block, lds, stream, p); \
+        else hipLaunchKernelGGL((flat_filter_kernel<M, MD, false>), grid, block, lds, stream, p);     \
     } while (0)
-    if (p.metric == METRIC_L2) {
-        if (p.dump) FA_LAUNCH(METRIC_L2, true);
-        else FA_LAUNCH(METRIC_L2, false);
-    } else {
-        if (p.dump) FA_LAUNCH(METRIC_INNER_PRODUCT, true);
-        else FA_LAUNCH(METRIC_INNER_PRODUCT, false);
-    }
+#define FA_LAUNCH_M(M)                                   \
+    do {                                                 \
+        if (mode == MODE_MAX) FA_LAUNCH(M, MODE_MAX);    \
+        else if (mode == MODE_COLLECT) FA_LAUNCH(M, MODE_COLLECT); \
+        else FA_LAUNCH(M, MODE_DUMP);                    \
+    } while (0)
+    if (p.metric == METRIC_L2) FA_LAUNCH_M(METRIC_L2);
+    else FA_LAUNCH_M(METRIC_INNER_PRODUCT);
+#undef FA_LAUNCH_M
 #undef FA_LAUNCH
+    HIP_CHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------
+// tighten kernel: one workgroup per query turns the S = 16 * nsplit chunk maxima into the
+// collect threshold  thr = (k-th largest maximum) - 2 e_q  (band_threshold)
+// ---------------------------------------------------------------------------------
+constexpr int TG_THREADS = 256;
+
+template <int METRIC>
+__global__ void __launch_bounds__(TG_THREADS) flat_tighten_kernel(FlatFilterParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int S = p.nsplit * 16;
+    u64* keys = (u64*)smem;                     // [S]
+    unsigned* hist = (unsigned*)(keys + S);     // [256]
+    WgSelCtl* ctl = (WgSelCtl*)(hist + 256);
+    const int q = blockIdx.x;
+    const int tid = threadIdx.x;
+    const float e = flat_filter_err_bound(METRIC, p.d, p.xqn[q], p.yn_max);
+    if (p.flags[q] || !(e < FLT_MAX)) {
+        // fp16 range overflow / NaN in the query: not served by the filter
+        if (tid == 0) {
+            p.flags[q] = 1;
+            p.thr[q] = INFINITY;
+        }
+        return;
+    }
+    const float* mxs = p.maxes + (int64_t)q * S;
+    for (int i = tid; i < S; i += TG_THREADS) keys[i] = ((u64)score_key(mxs[i]) << 32) | (unsigned)i;
+    __syncthreads();
+    float tk;
+    if (S > p.k) {
+        const u64 kth = wg_select_kth<TG_THREADS>(keys, S, p.k, hist, ctl);
+        tk = key_score((uint32_t)(kth >> 32));
+    } else {
+        tk = -INFINITY; // fewer chunks than k: no pruning possible
+    }
+    if (tid == 0) p.thr[q] = tk > -INFINITY ? band_threshold(tk, e) : -INFINITY;
+}
+
+void launch_flat_tighten(const FlatFilterParams& p, hipStream_t stream) {
+    if (p.nq == 0) return;
+    const size_t lds = (size_t)p.nsplit * 16 * 8 + 1024 + 64;
+    FA_THROW_IF_NOT(lds <= 64 * 1024);
+    if (p.metric == METRIC_L2)
+        hipLaunchKernelGGL((flat_tighten_kernel<METRIC_L2>), dim3((unsigned)p.nq), dim3(TG_THREADS), lds, stream, p);
+    else
+        hipLaunchKernelGGL((flat_tighten_kernel<METRIC_INNER_PRODUCT>), dim3((unsigned)p.nq), dim3(TG_THREADS), lds,
+                           stream, p);
     HIP_CHECK(hipGetLastError());
 }
 

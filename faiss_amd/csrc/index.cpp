@@ -261,59 +261,37 @@ bool GpuIndexFlat::filter_applicable_(int k) const {
            d >= 32 && dh_ <= 8 * kFilterSlab;
 }
 
-// split count, rows per split and reservoir capacity of the filter kernel for a tile of n queries
-void GpuIndexFlat::plan_filter_(int n, int k, int& nsplit, int& rows_per_split, int& cap) const {
+// split count, sampling stride of the maxima pass and segment capacity of the collect pass for a
+// tile of n queries
+void GpuIndexFlat::plan_filter_(int n, int k, int& nsplit, int& tstride, int& cap) const {
     const int ngroups = (int)div_up(n, kFilterQueriesPerBlock);
-    // two 4-wave workgroups are resident per CU; small batches may use up to 256 splits
-    cap = 64;
-    while (cap < 4 * k) cap <<= 1;
-    if (cap < 2 * (k + 32)) cap = (int)round_up(2 * (k + 32), 64);
-    // two 4-wave workgroups are resident per CU; small batches may use up to 256 splits as long
-    // as the reservoirs stay inside the scratch budget
-    int split_cap = ngroups >= 8 ? 64 : 256;
-    const size_t per_split = (size_t)n * cap * 8;
-    split_cap = (int)std::min<size_t>(split_cap, std::max<size_t>(8, res_->temp_budget_bytes / per_split / 8 * 8));
-    choose_splits((int)ntotal, ngroups, 2 * res_->num_cus, nsplit, rows_per_split, split_cap);
-}
-
-void GpuIndexFlat::filter_scores(idx_t n, const float* x, float* scores, float* err_bound) const {
-    FA_THROW_IF_NOT_MSG(db_f16_ok_ && ntotal > 0 && n > 0, "filter not applicable");
-    std::lock_guard<std::mutex> g(mu_);
-    res_->set_device();
-    const GpuResources& R = *res_;
-    q_pad_.ensure((size_t)n * dpad_ * 4);
-    stage_padded(R, x, n, d, dpad_, q_raw_, q_pad_.as<float>());
-    qh_.ensure((size_t)n * dh_ * 2);
-    flags_.ensure((size_t)n * 4);
-    q_norm_.ensure((size_t)n * 4);
-    launch_convert_f16(q_pad_.as<float>(), dpad_, n, d, qh_.p, dh_, nullptr, flags_.as<uint32_t>(), R.stream);
-    launch_l2_norms(q_pad_.as<float>(), dpad_, n, dpad_, q_norm_.as<float>(), R.stream);
-    DevBuf dump;
-    dump.ensure((size_t)n * ntotal * 4);
-    FlatFilterParams fp{};
-    fp.metric = metric_type;
-    fp.xqh = qh_.as<_Float16>();
-    fp.xqn = q_norm_.as<float>();
-    fp.xbh = xbh_.as<_Float16>();
-    fp.xbhn = xbhn_.as<float>();
-    fp.ldqh = fp.ldbh = dh_;
-    fp.nq = (int)n;
-    fp.nb = (int)ntotal;
-    fp.d = d;
-    fp.dh = dh_;
-    fp.ngroups = (int)div_up(n, kFilterQueriesPerBlock);
-    choose_splits(fp.nb, fp.ngroups, 2 * R.num_cus, fp.nsplit, fp.rows_per_split);
-    fp.k = 1;
-    fp.cap = 128;
-    fp.yn_max = yn_max_;
-    fp.flags = flags_.as<uint32_t>();
-    fp.dump = dump.as<float>();
-    launch_flat_filter(fp, R.stream);
-    copy_out(R, scores, dump.p, (size_t)n * ntotal * 4);
-    std::vector<float> xn(n);
-    HIP_CHECK(hipMemcpyAsync(xn.data(), q_norm_.p, (size_t)n * 4, hipMemcpyDeviceToHost, R.stream));
-    R.sync();
-    for (idx_t i = 0; i < n; i++) err_bound[i] = flat_filter_err_bound(metric_type, d, xn[i], yn_max_);
+    const int total_tiles = (int)div_up(ntotal, kFilterTileRows);
+    // S = 16 * nsplit chunk maxima per query must exceed k comfortably (S >= 2.5 k keeps the expected
+    // number of rows above the k-th largest maximum below ~1.3 k); two 4-wave workgroups are resident
+    // per CU, so nsplit * ngroups should fill whole rounds of 2 * num_cus slots
+    const int smin = (int)round_up(std::max<size_t>(8, div_up((size_t)(5 * k), 32)), 8);
+    const int smax = (int)std::max<size_t>(smin, std::min<size_t>(256, (size_t)total_tiles / 4 / 8 * 8));
+    const int slots = 2 * res_->num_cus;
+    int best = smin;
+    double best_eff = -1.0;
+    for (int s = smin; s <= smax; s += 8) {
+        const long total = (long)s * ngroups;
+        const long rounds = (total + slots - 1) / slots;
+        const double eff = (double)total / (double)(rounds * slots);
+        if (eff > best_eff + 1e-9) {
+            best_eff = eff;
+            best = s;
+        }
+        if (s >= 64 && best_eff > 0.9) break; // more splits only add chunk bookkeeping
+    }
+    nsplit = best;
+    const int tiles_per_split = total_tiles / nsplit;
+    tstride = tiles_per_split >= 32 ? 4 : tiles_per_split >= 16 ? 2 : 1;
+    // expected rows above the threshold: S * -ln(1 - k/S) in the sample, tstride times that overall
+    const double S = 16.0 * nsplit;
+    const double expect = S * -std::log(1.0 - std::min(0.95, (double)k / S)) * tstride / nsplit;
+    cap = 32;
+    while (cap < 4.0 * expect + 16.0) cap <<= 1;
 }
 
 void GpuIndexFlat::search_tile_(int n, const float* xq_pad, int k, float* dD, idx_t* dI) const {
@@ -326,19 +304,25 @@ void GpuIndexFlat::search_tile_(int n, const float* xq_pad, int k, float* dD, id
     last_used_filter = true;
     const GpuResources& R = *res_;
     const int nb = (int)ntotal;
+    FlatFilterParams fp{};
+    fp.metric = metric_type;
+    fp.ngroups = (int)div_up(n, kFilterQueriesPerBlock);
+    plan_filter_(n, k, fp.nsplit, fp.tstride, fp.cap);
     // ---- fp16 queries (+ per-query range flags), exact norms
     qh_.ensure((size_t)n * dh_ * 2);
     flags_.ensure((size_t)n * 4);
+    thr_.ensure((size_t)n * 4);
+    maxes_.ensure((size_t)n * fp.nsplit * 16 * 4);
     q_norm_.ensure((size_t)n * 4);
     ovf_list_.ensure((size_t)n * 4);
+    res_keys_.ensure((size_t)n * fp.nsplit * fp.cap * 8);
+    res_cnt_.ensure((size_t)n * fp.nsplit * 4);
     {
         SpanGuard sg(&R, "convert_f16_query");
         launch_convert_f16(xq_pad, dpad_, n, d, qh_.p, dh_, nullptr, flags_.as<uint32_t>(), R.stream);
         launch_l2_norms(xq_pad, dpad_, n, dpad_, q_norm_.as<float>(), R.stream);
     }
     HIP_CHECK(hipMemsetAsync(scal_.as<unsigned>() + 2, 0, 4, R.stream));
-    FlatFilterParams fp{};
-    fp.metric = metric_type;
     fp.xqh = qh_.as<_Float16>();
     fp.xqn = q_norm_.as<float>();
     fp.xbh = xbh_.as<_Float16>();
@@ -349,19 +333,27 @@ void GpuIndexFlat::search_tile_(int n, const float* xq_pad, int k, float* dD, id
     fp.nb = nb;
     fp.d = d;
     fp.dh = dh_;
-    fp.ngroups = (int)div_up(n, kFilterQueriesPerBlock);
-    plan_filter_(n, k, fp.nsplit, fp.rows_per_split, fp.cap);
     fp.k = k;
     fp.yn_max = yn_max_;
-    res_keys_.ensure((size_t)n * fp.nsplit * fp.cap * 8);
-    res_cnt_.ensure((size_t)n * fp.nsplit * 4);
+    fp.maxes = maxes_.as<float>();
+    fp.thr = thr_.as<float>();
     fp.res_keys = res_keys_.as<unsigned long long>();
     fp.res_cnt = res_cnt_.as<uint32_t>();
     fp.flags = flags_.as<uint32_t>();
     fp.dump = nullptr;
     {
+        // chunk maxima over a 1/tstride sample of the tiles -> per-query threshold
+        SpanGuard sg(&R, "flat_filter_kernel_max");
+        launch_flat_filter(fp, 0, R.stream);
+    }
+    {
+        SpanGuard sg(&R, "flat_tighten_kernel");
+        launch_flat_tighten(fp, R.stream);
+    }
+    {
+        // every row above the threshold -> (query, split) segments
         SpanGuard sg(&R, "flat_filter_kernel");
-        launch_flat_filter(fp, R.stream);
+        launch_flat_filter(fp, 1, R.stream);
     }
     FlatRerankParams rp{};
     rp.metric = metric_type;
@@ -392,7 +384,7 @@ void GpuIndexFlat::search_tile_(int n, const float* xq_pad, int k, float* dD, id
         SpanGuard sg(&R, "flat_rerank_kernel");
         launch_flat_rerank(rp, R.stream);
     }
-    // ---- queries whose band overflowed (or left the fp16 range) go through the exact fp32 scan
+    // ---- queries whose segments overflowed (or left the fp16 range) go through the exact fp32 scan
     unsigned novf = 0;
     HIP_CHECK(hipMemcpyAsync(&novf, scal_.as<unsigned>() + 2, 4, hipMemcpyDeviceToHost, R.stream));
     R.sync();
@@ -412,6 +404,47 @@ void GpuIndexFlat::search_tile_(int n, const float* xq_pad, int k, float* dD, id
         launch_scatter_results(ovf_d_.as<float>(), ovf_i_.as<idx_t>(), k, ovf_list_.as<uint32_t>(), (int)novf, dD, dI,
                                R.stream);
     }
+}
+
+void GpuIndexFlat::filter_scores(idx_t n, const float* x, float* scores, float* err_bound) const {
+    FA_THROW_IF_NOT_MSG(db_f16_ok_ && ntotal > 0 && n > 0, "filter not applicable");
+    std::lock_guard<std::mutex> g(mu_);
+    res_->set_device();
+    const GpuResources& R = *res_;
+    q_pad_.ensure((size_t)n * dpad_ * 4);
+    stage_padded(R, x, n, d, dpad_, q_raw_, q_pad_.as<float>());
+    qh_.ensure((size_t)n * dh_ * 2);
+    flags_.ensure((size_t)n * 4);
+    q_norm_.ensure((size_t)n * 4);
+    launch_convert_f16(q_pad_.as<float>(), dpad_, n, d, qh_.p, dh_, nullptr, flags_.as<uint32_t>(), R.stream);
+    launch_l2_norms(q_pad_.as<float>(), dpad_, n, dpad_, q_norm_.as<float>(), R.stream);
+    DevBuf dump;
+    dump.ensure((size_t)n * ntotal * 4);
+    FlatFilterParams fp{};
+    fp.metric = metric_type;
+    fp.xqh = qh_.as<_Float16>();
+    fp.xqn = q_norm_.as<float>();
+    fp.xbh = xbh_.as<_Float16>();
+    fp.xbhn = xbhn_.as<float>();
+    fp.ldqh = fp.ldbh = dh_;
+    fp.nq = (int)n;
+    fp.nb = (int)ntotal;
+    fp.d = d;
+    fp.dh = dh_;
+    fp.ngroups = (int)div_up(n, kFilterQueriesPerBlock);
+    fp.nsplit = 8;
+    fp.tstride = 1;
+    fp.k = 1;
+    fp.cap = 32;
+    fp.yn_max = yn_max_;
+    fp.flags = flags_.as<uint32_t>();
+    fp.dump = dump.as<float>();
+    launch_flat_filter(fp, 2, R.stream);
+    copy_out(R, scores, dump.p, (size_t)n * ntotal * 4);
+    std::vector<float> xn(n);
+    HIP_CHECK(hipMemcpyAsync(xn.data(), q_norm_.p, (size_t)n * 4, hipMemcpyDeviceToHost, R.stream));
+    R.sync();
+    for (idx_t i = 0; i < n; i++) err_bound[i] = flat_filter_err_bound(metric_type, d, xn[i], yn_max_);
 }
 
 void GpuIndexFlat::search_tile_exact_(int n, const float* xq_pad, int k, float* dD, idx_t* dI) const {

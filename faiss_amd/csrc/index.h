@@ -148,10 +148,10 @@ class GpuIndexFlat : public Index {
     DevBuf scal_;            // device scalars: [0] max |x| bits, [1] max |y|^2 bits, [2] overflow counter
     float yn_max_ = 0.f;     // max squared norm over the database
     bool db_f16_ok_ = true;  // every database value inside the fp16 range (no NaN/inf)
-    mutable DevBuf qh_, flags_, ovf_list_, ovf_q_, ovf_d_, ovf_i_;
+    mutable DevBuf qh_, flags_, thr_, maxes_, ovf_list_, ovf_q_, ovf_d_, ovf_i_;
     void search_tile_exact_(int n, const float* xq_pad, int k, float* dD, idx_t* dI) const;
     bool filter_applicable_(int k) const;
-    void plan_filter_(int n, int k, int& nsplit, int& rows_per_split, int& cap) const;
+    void plan_filter_(int n, int k, int& nsplit, int& tstride, int& cap) const;
     mutable std::mutex mu_;
     // persistent scratch
     mutable DevBuf q_raw_, q_pad_, q_norm_, res_keys_, res_cnt_, out_d_, out_i_, all_keys_, one_cnt_;

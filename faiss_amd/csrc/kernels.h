@@ -65,16 +65,19 @@ struct FlatFilterParams {
     const float* xbhn;   // [nb] |y|^2 / 2 (L2 bias of the approximate score; unused for IP)
     int64_t ldqh, ldbh;
     int nq, nb, d, dh;   // dh = padded fp16 row length, multiple of kFilterSlab
-    int nsplit, rows_per_split, ngroups;
-    int k, cap;          // reservoir capacity per (query, split), >= 2 * (k + 32)
+    int nsplit, ngroups; // split s owns tiles s, s + nsplit, ...; 16 * nsplit chunk maxima per query
+    int tstride;         // maxima pass: every tstride-th tile of a split
+    int k, cap;          // collect pass: segment capacity per (query, split)
     float yn_max;        // max squared norm over the database
+    float* maxes;        // [nq][nsplit * 16] chunk maxima (maxima pass out, tighten in)
+    float* thr;          // [nq] collect thresholds (tighten out; +inf = query not served by the filter)
     unsigned long long* res_keys; // [nq][nsplit][cap]  (score key << 32 | row)
     uint32_t* res_cnt;            // [nq][nsplit]
-    uint32_t* flags;              // [nq] in: fp16 overflow of the query; out: |= band overflow
+    uint32_t* flags;              // [nq] in: fp16 overflow of the query; out: |= segment overflow
     float* dump;                  // optional [nq][nb] approximate scores (tests)
 };
-// Bound on |t~ - s| for one query against any database row (see flat_filter.hip header).  fp16 round-to-nearest:
-// |dx| <= 2^-11 |x| in the normal range and <= 2^-25 below it, so
+// Bound on |t~ - s| for one query against any database row (see flat_filter.hip header).  fp16
+// round-to-nearest: |dx| <= 2^-11 |x| in the normal range and <= 2^-25 below it, so
 //   |<q~,y~> - <q,y>| <= 2^-10 (1+2^-11) |q||y| + 2^-25 (1+2^-11) sqrt(d) (|q| + |y|) + d 2^-50;
 // MFMA fp32 accumulation and the exact path's own fmaf chain each contribute at most
 // d 2^-24 |q||y| (first-order, doubled below); the L2 epilogue rounds fl(|q|^2+|y|^2) and the
@@ -87,7 +90,9 @@ __host__ __device__ static inline float flat_filter_err_bound(int metric, int d,
     if (metric == METRIC_L2) e += 6.0e-8f /*2^-24*/ * (xn + yn_max);
     return 1.25f * e;
 }
-void launch_flat_filter(const FlatFilterParams& p, hipStream_t stream);
+// mode: 0 = maxima pass, 1 = collect pass, 2 = dump every score (tests)
+void launch_flat_filter(const FlatFilterParams& p, int mode, hipStream_t stream);
+void launch_flat_tighten(const FlatFilterParams& p, hipStream_t stream);
 size_t flat_filter_lds_bytes();
 
 struct FlatRerankParams {

@@ -407,11 +407,11 @@ def test_flat_filter_path_bit_exact(res, metric, d, nb, nq, k):
 
 
 def test_flat_filter_overflow_falls_back_to_exact(res):
-    """Adversarial data: 50 distinct vectors repeated 400 times (every neighbour tied 400-fold, so the
-    error band of a query holds thousands of rows) and integer data full of ties.  Such queries are
-    flagged and re-run through the exact scan; the (distance, id) tie order must survive."""
-    _, base, xq = synthetic_dataset(64, 0, 50, 40, seed=9)
-    xb = np.tile(base, (400, 1))
+    """Adversarial data: 20 distinct vectors repeated 5000 times (every neighbour tied 5000-fold, so the
+    error band of a query holds thousands of rows) and integer data full of ties.  Queries whose band
+    does not fit are flagged and re-run through the exact scan; the (distance, id) tie order must survive."""
+    _, base, xq = synthetic_dataset(64, 0, 20, 40, seed=9)
+    xb = np.tile(base, (5000, 1))
     idx = faiss_amd.GpuIndexFlatL2(res, 64)
     idx.add(xb)
     for k in (10, 500):
@@ -419,6 +419,13 @@ def test_flat_filter_overflow_falls_back_to_exact(res):
         used, novf = idx.filter_stats()
         assert used and novf > 0
         check_knn(D, I, *Oracle.flat_search(METRIC_L2, xb, xq, k), exact=True, name="dup rows k=%d" % k)
+    # moderately tied data stays inside the band machinery (no fallback needed)
+    xb = np.tile(synthetic_dataset(64, 0, 2000, 0, seed=5)[1], (10, 1))
+    idx = faiss_amd.GpuIndexFlatL2(res, 64)
+    idx.add(xb)
+    D, I = idx.search(xq, 25)
+    assert idx.filter_stats()[0]
+    check_knn(D, I, *Oracle.flat_search(METRIC_L2, xb, xq, 25), exact=True, name="10-fold ties")
     z, xb, xq = load_flat_case("flat_l2_int_ties")
     idx = faiss_amd.GpuIndexFlatL2(res, xb.shape[1])
     idx.set_use_filter_kernel(True, 0)
