@@ -82,13 +82,17 @@ void launch_convert_f16(const float* src, int64_t ld_src, int64_t n, int d, void
     HIP_CHECK(hipGetLastError());
 }
 
-__global__ void half_norms_kernel(const float* __restrict__ xn, int64_t n, float* __restrict__ out) {
+// out[i] = |y_i|^2 / 2 (L2) or 0 (IP) for i < n, +inf for the npad entries that follow
+__global__ void half_norms_kernel(const float* __restrict__ xn, int64_t n, int npad, int metric,
+                                  float* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = 0.5f * xn[i];
+    if (i < n) out[i] = metric == METRIC_L2 ? 0.5f * xn[i] : 0.f;
+    else if (i < n + npad) out[i] = INFINITY;
 }
-void launch_half_norms(const float* xn, int64_t n, float* out, hipStream_t stream) {
-    if (n == 0) return;
-    hipLaunchKernelGGL(half_norms_kernel, dim3((unsigned)div_up(n, 256)), dim3(256), 0, stream, xn, n, out);
+void launch_half_norms(const float* xn, int64_t n, int npad, int metric, float* out, hipStream_t stream) {
+    if (n + npad == 0) return;
+    hipLaunchKernelGGL(half_norms_kernel, dim3((unsigned)div_up(n + npad, 256)), dim3(256), 0, stream, xn, n, npad,
+                       metric, out);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -139,16 +143,41 @@ void launch_max_f32(const float* x, int64_t n, unsigned* out_bits, hipStream_t s
 //                 segment: a few hundred per query in total.
 //   MODE_DUMP     test hook: every approximate score to memory.
 // ---------------------------------------------------------------------------------
-constexpr int FQ_THREADS = 256;
-constexpr int FQ_QPB = 256;          // queries per workgroup (kFilterQueriesPerBlock)
 constexpr int FQ_TR = 64;            // rows per tile
 constexpr int FQ_KS = 128;           // halfs per k-slab
 constexpr int FQ_TILE_BYTES = FQ_TR * FQ_KS * 2; // 16384
 constexpr int FQ_NBUF = 3;                       // LDS ring: tile u computes while u+1, u+2 are in flight
 constexpr int FQ_LDS_BIAS = FQ_NBUF * FQ_TILE_BYTES;
-constexpr int FQ_LDS_CNT = FQ_LDS_BIAS + FQ_NBUF * FQ_TR * 4; // [256] per-query append counters
-constexpr int FQ_LDS_TOTAL = FQ_LDS_CNT + FQ_QPB * 4;
+constexpr int FQ_LDS_CNT = FQ_LDS_BIAS + FQ_NBUF * FQ_TR * 4; // [queries per workgroup] append counters
 constexpr int MODE_MAX = 0, MODE_COLLECT = 1, MODE_DUMP = 2;
+
+// Two geometries share the code (QB = 32-query MFMA column blocks per wave):
+//   QB = 2: 4 waves x 64 queries, both 32-row blocks of a tile in flight (2 x 2 accumulators).
+//           256 queries per workgroup, 2 workgroups per CU.  For small query batches.
+//   QB = 4: 8 waves x 128 queries, the two 32-row blocks of a tile one after the other
+//           (1 x 4 accumulators).  1024 queries per workgroup, 1 workgroup per CU: one 16 KB tile
+//           feeds 8 x 64 MFMAs, i.e. 4 B/clk/CU of L2->LDS traffic at full MFMA rate, where the
+//           QB = 2 geometry needs 32 B/clk/CU and is bound by the CU's ~10 B/clk fill path.
+template <int QB>
+struct FqGeom {
+    static constexpr int WAVES = QB == 4 ? 8 : 4;
+    static constexpr int THREADS = WAVES * 64;
+    static constexpr int QPW = 32 * QB;          // queries per wave
+    static constexpr int QPB = WAVES * QPW;      // queries per workgroup
+    static constexpr int RBP = QB == 4 ? 1 : 2;  // 32-row blocks processed together
+    static constexpr int NCL = QB == 4 ? 4 : 8;  // running maxima (position classes) per lane and query
+    static constexpr int CPS = 2 * NCL;          // chunk maxima per (query, split)
+    static constexpr int DMA_ROWS = 16 / WAVES;  // 1 KB row-chunk DMAs per wave and tile
+    static constexpr int LDS_THR = FQ_LDS_CNT + QPB * 4; // [queries per workgroup] collect thresholds
+    // collect pass: candidates are parked in LDS and written to their (query, split) segments once,
+    // after the last tile -- a global store inside the loop would share the vmcnt counter with the
+    // LDS-DMA prefetch and every counted wait behind it would drain the ring
+    static constexpr int LBUF = QB == 4 ? 4096 : 1536;   // entries (expected: ~2 per query and split)
+    static constexpr int LDS_BUFK = (LDS_THR + QPB * 4 + 15) & ~15; // u64 keys
+    static constexpr int LDS_BUFQ = LDS_BUFK + LBUF * 8;           // u32 local query index
+    static constexpr int LDS_NBUF = LDS_BUFQ + LBUF * 4;           // u32 fill counter
+    static constexpr int LDS_TOTAL = LDS_NBUF + 16;
+};
 
 // LDS-DMA issued from inline asm: hipcc makes every ds_read that follows a
 // __builtin_amdgcn_global_load_lds wait for vmcnt(0) (it cannot tell the two LDS regions apart),
@@ -178,8 +207,9 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 // SINGLE: dh == 128, one k-slab per tile: the query operands never leave their registers and
 // the loop holds no compiler-visible global load, whose counted s_waitcnt would otherwise also
 // wait for the (younger, hidden) LDS-DMAs of the prefetch.
-template <int METRIC, int MODE, bool SINGLE>
-__global__ void __launch_bounds__(FQ_THREADS, 2) flat_filter_kernel(FlatFilterParams p) {
+template <int METRIC, int MODE, bool SINGLE, int QB>
+__global__ void __launch_bounds__(FqGeom<QB>::THREADS, 2) flat_filter_kernel(FlatFilterParams p) {
+    using G = FqGeom<QB>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -210,68 +240,76 @@ __global__ void __launch_bounds__(FQ_THREADS, 2) flat_filter_kernel(FlatFilterPa
     const int nsteps = ntiles * nslab;
     auto tile_row0_of = [&](int tl) { return (split + tl * tstep * p.nsplit) * FQ_TR; };
 
-    // ---- this lane's two queries
-    const int qbase = grp * FQ_QPB + wave * 64; // wave-uniform
-    const _Float16* qrow[2];
-    float thr[2];
-    bool qvalid[2];
-    u64* resq[2] = {nullptr, nullptr};
+    // ---- this lane's QB queries
+    const int qbase = grp * G::QPB + wave * G::QPW; // wave-uniform
+    const _Float16* qrow[QB];
+    bool qvalid[QB];
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
+    for (int qb = 0; qb < QB; ++qb) {
         const int q = qbase + qb * 32 + j;
         qvalid[qb] = q < p.nq;
         const int qc = qvalid[qb] ? q : p.nq - 1;
         qrow[qb] = p.xqh + (int64_t)qc * p.ldqh;
-        thr[qb] = INFINITY;
-        if (MODE == MODE_COLLECT) {
-            // +inf for queries the filter cannot serve (flagged by the tighten kernel)
-            if (qvalid[qb]) thr[qb] = p.thr[qc];
-            resq[qb] = p.res_keys + ((int64_t)qc * p.nsplit + split) * p.cap;
-        }
     }
     unsigned* lcnt = (unsigned*)(smem + FQ_LDS_CNT);
-    if (MODE == MODE_COLLECT) lcnt[tid] = 0;
+    // this wave's thresholds live in LDS (one ds_read per query block and 32-row block) rather than
+    // in registers: the 8-wave geometry has none to spare
+    const float* lthr = (const float*)(smem + G::LDS_THR) + wave * G::QPW + j;
+    u64* lbufk = (u64*)(smem + G::LDS_BUFK);
+    unsigned* lbufq = (unsigned*)(smem + G::LDS_BUFQ);
+    unsigned* lnbuf = (unsigned*)(smem + G::LDS_NBUF);
+    if (MODE == MODE_COLLECT) {
+        if (tid == 0) *lnbuf = 0;
+        for (int i = tid; i < G::QPB; i += G::THREADS) {
+            lcnt[i] = 0;
+            const int q = grp * G::QPB + i;
+            // +inf for queries the filter cannot serve (flagged by the tighten kernel) and for idle lanes
+            ((float*)(smem + G::LDS_THR))[i] = q < p.nq ? p.thr[q] : INFINITY;
+        }
+    }
 
-    float mx[2][8];
+    float mx[QB][G::NCL];
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb)
+    for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-        for (int c = 0; c < 8; ++c) mx[qb][c] = -INFINITY;
+        for (int c = 0; c < G::NCL; ++c) mx[qb][c] = -INFINITY;
 
     if (nsteps == 0) {
         if (MODE == MODE_MAX) {
 #pragma unroll
-            for (int qb = 0; qb < 2; ++qb) {
+            for (int qb = 0; qb < QB; ++qb) {
                 const int q = qbase + qb * 32 + j;
                 if (qvalid[qb]) {
-                    float* o = p.maxes + (int64_t)q * p.nsplit * 16 + split * 16 + h * 8;
+                    float* o = p.maxes + ((int64_t)q * p.nsplit + split) * G::CPS + h * G::NCL;
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) o[c] = -INFINITY;
+                    for (int c = 0; c < G::NCL; ++c) o[c] = -INFINITY;
                 }
             }
         } else if (MODE == MODE_COLLECT) {
-            const int q = grp * FQ_QPB + tid;
-            if (q < p.nq) p.res_cnt[(int64_t)q * p.nsplit + split] = 0;
+            for (int i = tid; i < G::QPB; i += G::THREADS) {
+                const int q = grp * G::QPB + i;
+                if (q < p.nq) p.res_cnt[(int64_t)q * p.nsplit + split] = 0;
+            }
         }
         return;
     }
 
     // ---- LDS-DMA staging of step u (tile u / nslab, slab u % nslab) into ring slot u % 3:
-    // 4 x 1 KB of row chunks + (every wave, redundantly, so that all waves count the same
-    // number of DMAs) the 64 per-row biases |y|^2 / 2
+    // 16 x 1 KB of row chunks over the waves + (every wave, redundantly, so that all waves count
+    // the same number of DMAs) the 64 per-row biases |y|^2 / 2
     const unsigned lds_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
-    constexpr int DMA_PER_STAGE = METRIC == METRIC_L2 ? 5 : 4;
+    constexpr int DMA_PER_STAGE = G::DMA_ROWS + (METRIC == METRIC_L2 ? 1 : 0);
     auto stage = [&](int u, int slot) {
         const int tl = u / nslab, sl = u - tl * nslab;
         const int row0 = tile_row0_of(tl);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int g = (wave * 4 + i) * 64 + lane; // 16-byte chunk of the LDS image
+        for (int i = 0; i < G::DMA_ROWS; ++i) {
+            const int g = (wave * G::DMA_ROWS + i) * 64 + lane; // 16-byte chunk of the LDS image
             const int row = g >> 4, cpos = g & 15;
-            const int c = cpos ^ (row & 15);          // chunk of the source row that lands there
+            const int c = cpos ^ (row & 15);                    // chunk of the source row that lands there
             const int grow = min(row0 + row, p.nb - 1);
             const _Float16* src = p.xbh + (int64_t)grow * p.ldbh + sl * FQ_KS + c * 8;
-            glds16(src, lds_base + slot * FQ_TILE_BYTES + (wave * 4 + i) * 1024);
+            glds16(src, lds_base + slot * FQ_TILE_BYTES + (wave * G::DMA_ROWS + i) * 1024);
         }
         if (METRIC == METRIC_L2) {
             // rows past the end of the database re-read the last row (masked in the epilogue)
@@ -280,15 +318,93 @@ __global__ void __launch_bounds__(FQ_THREADS, 2) flat_filter_kernel(FlatFilterPa
         }
     };
 
-    half8 bq[2][8];
-    f32x16 acc[2][2];
+    half8 bq[QB][8];
+    f32x16 acc[G::RBP][QB];
 
     auto load_b = [&](int sl) {
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
+        for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
             for (int s = 0; s < 8; ++s) bq[qb][s] = *(const half8*)(qrow[qb] + sl * FQ_KS + s * 16 + h * 8);
     };
+
+    // epilogue of the 32-row block(s) held in acc: rbase = first block index (0 or 1).  Loop order
+    // (4-row group outermost) keeps only one bias quad and four scores live at a time.
+    auto epilogue = [&](int tl, int slot, int rbase) {
+        const float* bias = (const float*)(smem + FQ_LDS_BIAS) + slot * FQ_TR;
+        const int tile_row0 = tile_row0_of(tl);
+        const bool partial = tile_row0 + FQ_TR > p.nb; // wave-uniform
+#pragma unroll
+        for (int rp = 0; rp < G::RBP; ++rp) {
+            const int rb = rbase + rp;
+            float thr[QB];
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) thr[qb] = MODE == MODE_COLLECT ? lthr[qb * 32] : INFINITY;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (METRIC == METRIC_L2) b4 = *(const f32x4*)(bias + rb * 32 + 8 * g + 4 * h);
+                if (partial) {
+                    // last tile of the database: the rows past the end re-read row nb-1; they must not
+                    // count (a duplicated row would appear in several chunk maxima and lift the threshold
+                    // above the true k-th best score): an infinite bias sends their score to -inf
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (tile_row0 + rb * 32 + 8 * g + 4 * h + e >= p.nb) b4[e] = INFINITY;
+                }
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) {
+                    float tv[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) tv[e] = acc[rp][qb][4 * g + e] - b4[e];
+                    if (MODE == MODE_MAX) {
+                        // class = 4 consecutive rows of the tile (QB = 2: per 32-row block, 8 classes;
+                        // QB = 4: the two blocks share 4 classes); fmaxf drops NaN scores
+                        const int cl = QB == 4 ? g : rp * 4 + g;
+                        mx[qb][cl] = fmaxf(mx[qb][cl], fmaxf(fmaxf(tv[0], tv[1]), fmaxf(tv[2], tv[3])));
+                        // opaque to the optimiser: otherwise it merges this block's maximum with the next
+                        // block's into one max3 chain, which keeps two accumulator sets alive (spills)
+                        if (QB == 4) asm volatile("" : "+v"(mx[qb][cl]));
+                    } else if (MODE == MODE_DUMP) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int grow = tile_row0 + rb * 32 + 8 * g + 4 * h + e;
+                            const int q = qbase + qb * 32 + j;
+                            if (qvalid[qb] && grow < p.nb) p.dump[(int64_t)q * p.nb + grow] = tv[e];
+                        }
+                    } else {
+                        const float th = thr[qb];
+                        if ((tv[0] > th) | (tv[1] > th) | (tv[2] > th) | (tv[3] > th)) {
+                            // rare, divergent: one of these 4 rows beats the threshold of this lane's query
+                            const unsigned ql = wave * G::QPW + qb * 32 + j;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                if (tv[e] > th) {
+                                    const int grow = tile_row0 + rb * 32 + 8 * g + 4 * h + e;
+                                    const u64 key = ((u64)score_key(tv[e]) << 32) | (unsigned)grow;
+                                    const unsigned pos = atomicAdd(lnbuf, 1u);
+                                    if (pos < (unsigned)G::LBUF) {
+                                        lbufk[pos] = key;
+                                        lbufq[pos] = ql;
+                                    } else {
+                                        // LDS buffer full (far more candidates than expected): straight to memory
+                                        const unsigned slot_ = atomicAdd(&lcnt[ql], 1u);
+                                        if (slot_ < (unsigned)p.cap)
+                                            p.res_keys[((int64_t)(grp * G::QPB + ql) * p.nsplit + split) * p.cap + slot_] = key;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    };
+
+    // The two waves that share a SIMD (8-wave geometry) run in lockstep behind the per-tile barrier and
+    // would both sit in the VALU epilogue with the matrix pipe idle; a static priority for one half
+    // staggers the pair (cdna_hip_programming.md T5, static form).
+    if (G::WAVES == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
 
     load_b(0);
     // every compiler-visible load lands BEFORE the first hidden DMA is issued (vmcnt(0), the other
@@ -311,90 +427,56 @@ __global__ void __launch_bounds__(FQ_THREADS, 2) flat_filter_kernel(FlatFilterPa
         const int slot2 = slot >= 1 ? slot - 1 : 2; // (u + 2) % 3
         if (u + 2 < nsteps) stage(u + 2, slot2);
 
-        if (sl == 0) {
+        const char* tile = smem + slot * FQ_TILE_BYTES;
+        const int sw = j & 15;
+        if (G::RBP == 2) {
+            if (sl == 0) {
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
+                for (int rp = 0; rp < G::RBP; ++rp)
 #pragma unroll
-                for (int qb = 0; qb < 2; ++qb)
+                    for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[rb][qb][r] = 0.f;
-        }
-        {
-            const char* tile = smem + slot * FQ_TILE_BYTES;
+                        for (int r = 0; r < 16; ++r) acc[rp][qb][r] = 0.f;
+            }
             const char* rowp0 = tile + j * 256;
             const char* rowp1 = tile + (32 + j) * 256;
-            const int sw = j & 15;
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 const int off = ((2 * s + h) ^ sw) << 4;
                 const half8 a0 = *(const half8*)(rowp0 + off);
                 const half8 a1 = *(const half8*)(rowp1 + off);
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bq[0][s], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bq[1][s], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bq[0][s], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bq[1][s], acc[1][1], 0, 0, 0);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) {
+                    acc[0][qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bq[qb][s], acc[0][qb], 0, 0, 0);
+                    acc[G::RBP - 1][qb] =
+                            __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bq[qb][s], acc[G::RBP - 1][qb], 0, 0, 0);
+                }
             }
-        }
-        if (sl == nslab - 1) {
-            const float* bias = (const float*)(smem + FQ_LDS_BIAS) + slot * FQ_TR;
-            const int tile_row0 = tile_row0_of(tl);
-            const bool partial = tile_row0 + FQ_TR > p.nb; // wave-uniform
+            if (sl == nslab - 1) epilogue(tl, slot, 0);
+        } else {
+            // one 32-row block at a time; with several k-slabs (d > 128) the two blocks of a tile
+            // need both accumulator sets, so that geometry is SINGLE only (launch_flat_filter)
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) {
-                f32x4 b4[4];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    if (METRIC == METRIC_L2) b4[g] = *(const f32x4*)(bias + rb * 32 + 8 * g + 4 * h);
-                    else b4[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[0][qb][r] = 0.f;
+                const char* rowp = tile + (rb * 32 + j) * 256;
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const int off = ((2 * s + h) ^ sw) << 4;
+                    const half8 a0 = *(const half8*)(rowp + off);
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb)
+                        acc[0][qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bq[qb][s], acc[0][qb], 0, 0, 0);
                 }
-#pragma unroll
-                for (int qb = 0; qb < 2; ++qb) {
-                    float tv[16];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) tv[r] = acc[rb][qb][r] - b4[r >> 2][r & 3];
-                    if (partial) {
-                        // last tile of the database: the rows past the end re-read row nb-1; they must not
-                        // count (a duplicated row would appear in several chunk maxima and lift the threshold
-                        // above the true k-th best score)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int grow = tile_row0 + rb * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-                            if (grow >= p.nb) tv[r] = -INFINITY;
-                        }
-                    }
-                    if (MODE == MODE_MAX) {
-                        // class (rb, r >> 2): 4 consecutive rows of the 64-row tile; fmaxf drops NaN scores
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const float m01 = fmaxf(tv[4 * g], tv[4 * g + 1]);
-                            const float m23 = fmaxf(tv[4 * g + 2], tv[4 * g + 3]);
-                            mx[qb][rb * 4 + g] = fmaxf(mx[qb][rb * 4 + g], fmaxf(m01, m23));
-                        }
-                    } else if (MODE == MODE_DUMP) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int grow = tile_row0 + rb * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-                            const int q = qbase + qb * 32 + j;
-                            if (qvalid[qb] && grow < p.nb) p.dump[(int64_t)q * p.nb + grow] = tv[r];
-                        }
-                    } else {
-                        bool anyp = false;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) anyp |= tv[r] > thr[qb];
-                        if (anyp) {
-                            // rare, divergent: this lane's query has a row above its threshold
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                const int grow = tile_row0 + rb * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-                                if (tv[r] > thr[qb]) {
-                                    const unsigned slot_ = atomicAdd(&lcnt[wave * 64 + qb * 32 + j], 1u);
-                                    if (slot_ < (unsigned)p.cap)
-                                        resq[qb][slot_] = ((u64)score_key(tv[r]) << 32) | (unsigned)grow;
-                                }
-                            }
-                        }
-                    }
-                }
+                // keep the epilogue of this block and the MFMAs of the next one apart: interleaved, the
+                // scheduler holds two accumulator sets (128 VGPRs) and spills the query operands; the
+                // other wave of the SIMD fills the matrix pipe meanwhile
+                __builtin_amdgcn_sched_barrier(0);
+                epilogue(tl, slot, rb);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         // tile u+1 must have landed (this wave's share) before anybody passes the barrier;
@@ -407,56 +489,79 @@ __global__ void __launch_bounds__(FQ_THREADS, 2) flat_filter_kernel(FlatFilterPa
 
     if (MODE == MODE_MAX) {
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
+        for (int qb = 0; qb < QB; ++qb) {
             const int q = qbase + qb * 32 + j;
             if (qvalid[qb]) {
-                float* o = p.maxes + (int64_t)q * p.nsplit * 16 + split * 16 + h * 8;
-                *(f32x4*)o = f32x4{mx[qb][0], mx[qb][1], mx[qb][2], mx[qb][3]};
-                *(f32x4*)(o + 4) = f32x4{mx[qb][4], mx[qb][5], mx[qb][6], mx[qb][7]};
+                float* o = p.maxes + ((int64_t)q * p.nsplit + split) * G::CPS + h * G::NCL;
+#pragma unroll
+                for (int c = 0; c < G::NCL; c += 4)
+                    *(f32x4*)(o + c) = f32x4{mx[qb][c], mx[qb][c + 1], mx[qb][c + 2], mx[qb][c + 3]};
             }
         }
     } else if (MODE == MODE_COLLECT) {
-        // (the last loop iteration ended with a barrier: every append of the workgroup is counted)
-        const int q = grp * FQ_QPB + tid;
-        if (q < p.nq) {
-            const unsigned c = lcnt[tid];
-            if (c > (unsigned)p.cap) p.flags[q] = 1; // segment overflow: exact fallback for this query
-            p.res_cnt[(int64_t)q * p.nsplit + split] = c > (unsigned)p.cap ? (unsigned)p.cap : c;
+        // (the last loop iteration ended with a barrier: every append of the workgroup is visible)
+        // flush the parked candidates to their (query, split) segments
+        const unsigned nbuf = min(*lnbuf, (unsigned)G::LBUF);
+        for (unsigned i = tid; i < nbuf; i += G::THREADS) {
+            const unsigned ql = lbufq[i];
+            const unsigned slot_ = atomicAdd(&lcnt[ql], 1u);
+            if (slot_ < (unsigned)p.cap)
+                p.res_keys[((int64_t)(grp * G::QPB + ql) * p.nsplit + split) * p.cap + slot_] = lbufk[i];
+        }
+        __syncthreads();
+        for (int i = tid; i < G::QPB; i += G::THREADS) {
+            const int q = grp * G::QPB + i;
+            if (q < p.nq) {
+                const unsigned c = lcnt[i];
+                if (c > (unsigned)p.cap) p.flags[q] = 1; // segment overflow: exact fallback for this query
+                p.res_cnt[(int64_t)q * p.nsplit + split] = c > (unsigned)p.cap ? (unsigned)p.cap : c;
+            }
         }
     }
 }
 
-size_t flat_filter_lds_bytes() {
-    return FQ_LDS_TOTAL;
+int flat_filter_queries_per_block(int geom) {
+    return geom == 2 ? FqGeom<4>::QPB : FqGeom<2>::QPB;
+}
+int flat_filter_chunks_per_split(int geom) {
+    return geom == 2 ? FqGeom<4>::CPS : FqGeom<2>::CPS;
+}
+
+template <int METRIC, int MODE>
+static void launch_filter_mode(const FlatFilterParams& p, hipStream_t stream) {
+    dim3 grid((unsigned)(p.nsplit * p.ngroups));
+    if (p.geom == 2) {
+        using G = FqGeom<4>;
+        hipLaunchKernelGGL((flat_filter_kernel<METRIC, MODE, true, 4>), grid, dim3(G::THREADS), G::LDS_TOTAL, stream, p);
+    } else {
+        using G = FqGeom<2>;
+        if (p.dh == FQ_KS)
+            hipLaunchKernelGGL((flat_filter_kernel<METRIC, MODE, true, 2>), grid, dim3(G::THREADS), G::LDS_TOTAL, stream, p);
+        else
+            hipLaunchKernelGGL((flat_filter_kernel<METRIC, MODE, false, 2>), grid, dim3(G::THREADS), G::LDS_TOTAL, stream, p);
+    }
 }
 
 void launch_flat_filter(const FlatFilterParams& p, int mode, hipStream_t stream) {
     if (p.nq == 0 || p.nb == 0) return;
     FA_THROW_IF_NOT(p.dh % FQ_KS == 0 && p.ldqh % 8 == 0 && p.ldbh % 8 == 0);
     FA_THROW_IF_NOT(p.tstride >= 1 && p.nsplit >= 1);
-    dim3 grid((unsigned)(p.nsplit * p.ngroups)), block(FQ_THREADS);
-    const size_t lds = FQ_LDS_TOTAL;
-    const bool single = p.dh == FQ_KS;
-#define FA_LAUNCH(M, MD)                                                                              \
-    do {                                                                                              \
-        if (single) hipLaunchKernelGGL((flat_filter_kernel<M, MD, true>), grid, block, lds, stream, p); \
-        else hipLaunchKernelGGL((flat_filter_kernel<M, MD, false>), grid, block, lds, stream, p);     \
-    } while (0)
-#define FA_LAUNCH_M(M)                                   \
-    do {                                                 \
-        if (mode == MODE_MAX) FA_LAUNCH(M, MODE_MAX);    \
-        else if (mode == MODE_COLLECT) FA_LAUNCH(M, MODE_COLLECT); \
-        else FA_LAUNCH(M, MODE_DUMP);                    \
+    FA_THROW_IF_NOT_MSG(p.geom == 0 || (p.geom == 2 && p.dh == FQ_KS), "the 8-wave geometry needs dh == 128");
+    FA_THROW_IF_NOT(p.cps == flat_filter_chunks_per_split(p.geom));
+#define FA_LAUNCH_M(M)                                                            \
+    do {                                                                          \
+        if (mode == MODE_MAX) launch_filter_mode<M, MODE_MAX>(p, stream);         \
+        else if (mode == MODE_COLLECT) launch_filter_mode<M, MODE_COLLECT>(p, stream); \
+        else launch_filter_mode<M, MODE_DUMP>(p, stream);                         \
     } while (0)
     if (p.metric == METRIC_L2) FA_LAUNCH_M(METRIC_L2);
     else FA_LAUNCH_M(METRIC_INNER_PRODUCT);
 #undef FA_LAUNCH_M
-#undef FA_LAUNCH
     HIP_CHECK(hipGetLastError());
 }
 
 // ---------------------------------------------------------------------------------
-// tighten kernel: one workgroup per query turns the S = 16 * nsplit chunk maxima into the
+// tighten kernel: one workgroup per query turns the S = cps * nsplit chunk maxima into the
 // collect threshold  thr = (k-th largest maximum) - 2 e_q  (band_threshold)
 // ---------------------------------------------------------------------------------
 constexpr int TG_THREADS = 256;
@@ -464,7 +569,7 @@ constexpr int TG_THREADS = 256;
 template <int METRIC>
 __global__ void __launch_bounds__(TG_THREADS) flat_tighten_kernel(FlatFilterParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int S = p.nsplit * 16;
+    const int S = p.nsplit * p.cps;
     u64* keys = (u64*)smem;                     // [S]
     unsigned* hist = (unsigned*)(keys + S);     // [256]
     WgSelCtl* ctl = (WgSelCtl*)(hist + 256);
@@ -494,7 +599,7 @@ __global__ void __launch_bounds__(TG_THREADS) flat_tighten_kernel(FlatFilterPara
 
 void launch_flat_tighten(const FlatFilterParams& p, hipStream_t stream) {
     if (p.nq == 0) return;
-    const size_t lds = (size_t)p.nsplit * 16 * 8 + 1024 + 64;
+    const size_t lds = (size_t)p.nsplit * p.cps * 8 + 1024 + 64;
     FA_THROW_IF_NOT(lds <= 64 * 1024);
     if (p.metric == METRIC_L2)
         hipLaunchKernelGGL((flat_tighten_kernel<METRIC_L2>), dim3((unsigned)p.nq), dim3(TG_THREADS), lds, stream, p);

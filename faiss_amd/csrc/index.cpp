@@ -182,7 +182,7 @@ void GpuIndexFlat::add(idx_t n, const float* x) {
     xb_.ensure((size_t)(ntotal + n) * row, (size_t)ntotal * row, res_->stream);
     xbn_.ensure((size_t)(ntotal + n) * sizeof(float), (size_t)ntotal * sizeof(float), res_->stream);
     xbh_.ensure((size_t)(ntotal + n) * dh_ * 2, (size_t)ntotal * dh_ * 2, res_->stream);
-    xbhn_.ensure((size_t)(ntotal + n) * sizeof(float), (size_t)ntotal * sizeof(float), res_->stream);
+    xbhn_.ensure((size_t)(ntotal + n + kFilterTileRows) * sizeof(float), (size_t)ntotal * sizeof(float), res_->stream);
     // page the upload so the raw staging buffer stays bounded (reference: GpuIndex.cu:197-217)
     const idx_t page = std::max<idx_t>(1, ((idx_t)256 << 20) / ((idx_t)d * 4));
     for (idx_t i0 = 0; i0 < n; i0 += page) {
@@ -193,7 +193,9 @@ void GpuIndexFlat::add(idx_t n, const float* x) {
         // fp16 shadow copy + |y|^2/2 for the filter kernel, range / norm statistics
         launch_convert_f16(dst, dpad_, ni, d, xbh_.as<char>() + (size_t)(ntotal + i0) * dh_ * 2, dh_,
                            scal_.as<unsigned>(), nullptr, res_->stream);
-        launch_half_norms(xbn_.as<float>() + ntotal + i0, ni, xbhn_.as<float>() + ntotal + i0, res_->stream);
+        // (the +inf padding after the last row is rewritten by every page; only the final one survives)
+        launch_half_norms(xbn_.as<float>() + ntotal + i0, ni, kFilterTileRows, metric_type,
+                          xbhn_.as<float>() + ntotal + i0, res_->stream);
         launch_max_f32(xbn_.as<float>() + ntotal + i0, ni, scal_.as<unsigned>() + 1, res_->stream);
         res_->sync(); // q_raw_ is reused by the next page
     }
@@ -263,15 +265,19 @@ bool GpuIndexFlat::filter_applicable_(int k) const {
 
 // split count, sampling stride of the maxima pass and segment capacity of the collect pass for a
 // tile of n queries
-void GpuIndexFlat::plan_filter_(int n, int k, int& nsplit, int& tstride, int& cap) const {
-    const int ngroups = (int)div_up(n, kFilterQueriesPerBlock);
+void GpuIndexFlat::plan_filter_(int n, int k, int& geom, int& nsplit, int& tstride, int& cap) const {
+    // large batches of d <= 128: 8 waves x 128 queries per workgroup, one workgroup per CU;
+    // otherwise 4 waves x 64 queries, two workgroups per CU
+    geom = (dh_ == kFilterSlab && n >= 2048) ? 2 : 0;
+    const int qpb = flat_filter_queries_per_block(geom), cps = flat_filter_chunks_per_split(geom);
+    const int ngroups = (int)div_up(n, qpb);
     const int total_tiles = (int)div_up(ntotal, kFilterTileRows);
-    // S = 16 * nsplit chunk maxima per query must exceed k comfortably (S >= 2.5 k keeps the expected
-    // number of rows above the k-th largest maximum below ~1.3 k); two 4-wave workgroups are resident
-    // per CU, so nsplit * ngroups should fill whole rounds of 2 * num_cus slots
-    const int smin = (int)round_up(std::max<size_t>(8, div_up((size_t)(5 * k), 32)), 8);
+    // S = cps * nsplit chunk maxima per query must exceed k comfortably (S >= 2.5 k keeps the expected
+    // number of rows above the k-th largest maximum below ~1.3 k); nsplit * ngroups should fill
+    // whole rounds of the resident workgroup slots
+    const int smin = (int)round_up(std::max<size_t>(8, div_up((size_t)(5 * k), 2 * cps)), 8);
     const int smax = (int)std::max<size_t>(smin, std::min<size_t>(256, (size_t)total_tiles / 4 / 8 * 8));
-    const int slots = 2 * res_->num_cus;
+    const int slots = (geom == 2 ? 1 : 2) * res_->num_cus;
     int best = smin;
     double best_eff = -1.0;
     for (int s = smin; s <= smax; s += 8) {
@@ -288,7 +294,7 @@ void GpuIndexFlat::plan_filter_(int n, int k, int& nsplit, int& tstride, int& ca
     const int tiles_per_split = total_tiles / nsplit;
     tstride = tiles_per_split >= 32 ? 4 : tiles_per_split >= 16 ? 2 : 1;
     // expected rows above the threshold: S * -ln(1 - k/S) in the sample, tstride times that overall
-    const double S = 16.0 * nsplit;
+    const double S = (double)cps * nsplit;
     const double expect = S * -std::log(1.0 - std::min(0.95, (double)k / S)) * tstride / nsplit;
     cap = 32;
     while (cap < 4.0 * expect + 16.0) cap <<= 1;
@@ -306,13 +312,14 @@ void GpuIndexFlat::search_tile_(int n, const float* xq_pad, int k, float* dD, id
     const int nb = (int)ntotal;
     FlatFilterParams fp{};
     fp.metric = metric_type;
-    fp.ngroups = (int)div_up(n, kFilterQueriesPerBlock);
-    plan_filter_(n, k, fp.nsplit, fp.tstride, fp.cap);
+    plan_filter_(n, k, fp.geom, fp.nsplit, fp.tstride, fp.cap);
+    fp.cps = flat_filter_chunks_per_split(fp.geom);
+    fp.ngroups = (int)div_up(n, flat_filter_queries_per_block(fp.geom));
     // ---- fp16 queries (+ per-query range flags), exact norms
     qh_.ensure((size_t)n * dh_ * 2);
     flags_.ensure((size_t)n * 4);
     thr_.ensure((size_t)n * 4);
-    maxes_.ensure((size_t)n * fp.nsplit * 16 * 4);
+    maxes_.ensure((size_t)n * fp.nsplit * fp.cps * 4);
     q_norm_.ensure((size_t)n * 4);
     ovf_list_.ensure((size_t)n * 4);
     res_keys_.ensure((size_t)n * fp.nsplit * fp.cap * 8);
@@ -431,7 +438,9 @@ void GpuIndexFlat::filter_scores(idx_t n, const float* x, float* scores, float* 
     fp.nb = (int)ntotal;
     fp.d = d;
     fp.dh = dh_;
-    fp.ngroups = (int)div_up(n, kFilterQueriesPerBlock);
+    fp.geom = 0;
+    fp.cps = flat_filter_chunks_per_split(fp.geom);
+    fp.ngroups = (int)div_up(n, flat_filter_queries_per_block(fp.geom));
     fp.nsplit = 8;
     fp.tstride = 1;
     fp.k = 1;

@@ -53,7 +53,10 @@ void launch_flat_simple(int metric, const float* xq, const float* xqn, int64_t l
 
 // ------------------------------------------------------------------ Flat: fp16 MFMA filter + exact fp32 re-rank
 // (flat_filter.hip; see the header there for the superset argument)
-constexpr int kFilterQueriesPerBlock = 256; // 4 waves x 64 queries
+// geometry of the filter kernel: 0 = 4 waves x 64 queries (any dh, two workgroups per CU),
+// 2 = 8 waves x 128 queries (dh == 128 only, one workgroup per CU)
+int flat_filter_queries_per_block(int geom); // 256 / 1024
+int flat_filter_chunks_per_split(int geom);  // chunk maxima per (query, split): 16 / 8
 constexpr int kFilterTileRows = 64;
 constexpr int kFilterSlab = 128;            // fp16 rows are padded to a multiple of this many halfs
 
@@ -62,14 +65,16 @@ struct FlatFilterParams {
     const _Float16* xqh; // [nq][ldqh] fp16 queries
     const float* xqn;    // [nq] exact fp32 squared norms of the queries (both metrics: error bound)
     const _Float16* xbh; // [nb][ldbh] fp16 database
-    const float* xbhn;   // [nb] |y|^2 / 2 (L2 bias of the approximate score; unused for IP)
+    const float* xbhn;   // [nb + 64] bias of the approximate score: |y|^2 / 2 (L2) or 0 (IP), then 64 x +inf
     int64_t ldqh, ldbh;
     int nq, nb, d, dh;   // dh = padded fp16 row length, multiple of kFilterSlab
-    int nsplit, ngroups; // split s owns tiles s, s + nsplit, ...; 16 * nsplit chunk maxima per query
+    int geom;            // kernel geometry, see flat_filter_queries_per_block
+    int cps;             // = flat_filter_chunks_per_split(geom)
+    int nsplit, ngroups; // split s owns tiles s, s + nsplit, ...; cps * nsplit chunk maxima per query
     int tstride;         // maxima pass: every tstride-th tile of a split
     int k, cap;          // collect pass: segment capacity per (query, split)
     float yn_max;        // max squared norm over the database
-    float* maxes;        // [nq][nsplit * 16] chunk maxima (maxima pass out, tighten in)
+    float* maxes;        // [nq][nsplit * cps] chunk maxima (maxima pass out, tighten in)
     float* thr;          // [nq] collect thresholds (tighten out; +inf = query not served by the filter)
     unsigned long long* res_keys; // [nq][nsplit][cap]  (score key << 32 | row)
     uint32_t* res_cnt;            // [nq][nsplit]
@@ -120,7 +125,7 @@ void launch_flat_rerank(const FlatRerankParams& p, hipStream_t stream);
 void launch_convert_f16(const float* src, int64_t ld_src, int64_t n, int d, void* dst, int dh,
                         unsigned* absmax_bits, uint32_t* flags, hipStream_t stream);
 void launch_max_f32(const float* x, int64_t n, unsigned* out_bits, hipStream_t stream);
-void launch_half_norms(const float* xn, int64_t n, float* out, hipStream_t stream); // out = xn / 2
+void launch_half_norms(const float* xn, int64_t n, int npad, int metric, float* out, hipStream_t stream);
 void launch_gather_rows(const float* src, int64_t ld, int width, const uint32_t* list, int n, float* dst,
                         hipStream_t stream);
 void launch_scatter_results(const float* sd, const int64_t* si, int k, const uint32_t* list, int n, float* dd,

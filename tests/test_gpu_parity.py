@@ -383,7 +383,8 @@ def test_filter_error_bound_holds(res, metric, d, scale):
 
 
 FILTER_SHAPES = [(128, 30000, 300, 10), (128, 30000, 300, 100), (64, 20000, 513, 1), (100, 25000, 257, 50),
-                 (32, 18000, 100, 1000), (384, 17000, 30, 20), (200, 40000, 1100, 128)]
+                 (32, 18000, 100, 1000), (384, 17000, 30, 20), (200, 40000, 1100, 128),
+                 (128, 50000, 2500, 100), (120, 33333, 3000, 7)]  # >= 2048 queries, d <= 128: 8-wave geometry
 
 
 @pytest.mark.parametrize("metric", [METRIC_L2, METRIC_INNER_PRODUCT])
