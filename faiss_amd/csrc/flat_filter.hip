@@ -613,33 +613,21 @@ void launch_flat_tighten(const FlatFilterParams& p, hipStream_t stream) {
 // re-rank kernel: one workgroup per query
 // ---------------------------------------------------------------------------------
 constexpr int RR_THREADS = 256;
-constexpr int RR_CAND = 2048; // exact candidates per query held in LDS
+constexpr int RR_GATHER = 4096; // approximate candidates per query gathered into LDS
+constexpr int RR_CAND = 2048;   // rows inside the error band that are re-ranked exactly
 
 struct RrShared {
     unsigned hist[256];
-    unsigned scan[256];
-    u64 prefix, mask, kth;
-    int need, done;
-    unsigned total, ncand;
     WgSelCtl ctl;
+    unsigned total;
 };
-
-template <typename F>
-__device__ __forceinline__ void rr_for_each_key(const FlatRerankParams& p, int q, F f) {
-    const u64* base = p.res_keys + (int64_t)q * p.nsplit * p.cap;
-    for (int s = 0; s < p.nsplit; ++s) {
-        const unsigned cnt = p.res_cnt[(int64_t)q * p.nsplit + s];
-        const u64* seg = base + (int64_t)s * p.cap;
-        for (unsigned i = threadIdx.x; i < cnt; i += RR_THREADS) f(seg[i]);
-    }
-}
 
 template <int METRIC>
 __global__ void __launch_bounds__(RR_THREADS) flat_rerank_kernel(FlatRerankParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     RrShared* sh = (RrShared*)smem;
-    u64* cand = (u64*)(smem + ((sizeof(RrShared) + 15) & ~(size_t)15)); // [RR_CAND]
-    float* qs = (float*)(cand + RR_CAND);                                 // [dpad]
+    u64* cand = (u64*)(smem + ((sizeof(RrShared) + 15) & ~(size_t)15)); // [RR_GATHER]
+    float* qs = (float*)(cand + RR_GATHER);                               // [dpad]
     int64_t* w_id = (int64_t*)(qs + p.dpad + (p.dpad & 1));               // [kp] (8-byte aligned)
     unsigned* w_key = (unsigned*)(w_id + p.kp);                           // [kp]
     const int q = blockIdx.x;
@@ -650,86 +638,36 @@ __global__ void __launch_bounds__(RR_THREADS) flat_rerank_kernel(FlatRerankParam
         if (tid == 0) p.ovf_list[atomicAdd(p.ovf_cnt, 1u)] = (uint32_t)q;
         return;
     }
-    if (tid == 0) {
-        sh->total = 0;
-        sh->ncand = 0;
-        sh->prefix = 0;
-        sh->mask = 0;
-        sh->need = p.k;
-        sh->done = 0;
-        sh->kth = ~0ull;
-    }
+    if (tid == 0) sh->total = 0;
     for (int c = tid; c < p.dpad; c += RR_THREADS) qs[c] = p.xq[(int64_t)q * p.ldq + c];
     __syncthreads();
-    {
-        unsigned loc = 0;
-        for (int s = tid; s < p.nsplit; s += RR_THREADS) loc += p.res_cnt[(int64_t)q * p.nsplit + s];
-        if (loc) atomicAdd(&sh->total, loc);
+    // ---- gather the (query, split) segments into LDS: one thread per segment, so the nsplit
+    // dependent (count -> keys) global loads run side by side instead of one after the other
+    for (int s = tid; s < p.nsplit; s += RR_THREADS) {
+        const unsigned cnt = p.res_cnt[(int64_t)q * p.nsplit + s];
+        if (cnt) {
+            const unsigned base = atomicAdd(&sh->total, cnt);
+            const u64* seg = p.res_keys + ((int64_t)q * p.nsplit + s) * p.cap;
+            for (unsigned i = 0; i < cnt; ++i)
+                if (base + i < (unsigned)RR_GATHER) cand[base + i] = seg[i];
+        }
     }
     __syncthreads();
-    const unsigned total = sh->total;
+    int n = (int)sh->total;
+    if (n > RR_GATHER) {
+        if (tid == 0) p.ovf_list[atomicAdd(p.ovf_cnt, 1u)] = (uint32_t)q;
+        return;
+    }
 
-    // ---- k-th best approximate score over all splits (radix select over the global segments)
-    u64 key_thr = ~0ull;
-    if (total > (unsigned)p.k) {
-        for (int shift = 56; shift >= 0; shift -= 8) {
-            sh->hist[tid] = 0;
-            __syncthreads();
-            const u64 prefix = sh->prefix, mask = sh->mask;
-            rr_for_each_key(p, q, [&](u64 key) {
-                if ((key & mask) == prefix) atomicAdd(&sh->hist[(unsigned)(key >> shift) & 255u], 1u);
-            });
-            __syncthreads();
-            const unsigned v = sh->hist[tid];
-            sh->scan[tid] = v;
-            __syncthreads();
-            for (int off = 1; off < 256; off <<= 1) {
-                const unsigned o = tid >= off ? sh->scan[tid - off] : 0;
-                __syncthreads();
-                sh->scan[tid] += o;
-                __syncthreads();
-            }
-            const unsigned incl = sh->scan[tid];
-            const unsigned excl = incl - v;
-            const unsigned need = (unsigned)sh->need;
-            __syncthreads();
-            if (excl < need && need <= incl) {
-                sh->prefix = prefix | ((u64)tid << shift);
-                sh->mask = mask | ((u64)255u << shift);
-                sh->need = (int)(need - excl);
-                sh->done = ((need - excl) == v) ? 1 : 0;
-            }
-            __syncthreads();
-            if (sh->done || shift == 0) break;
-        }
-        if (sh->done) {
-            if (tid == 0) sh->kth = 0;
-            __syncthreads();
-            const u64 prefix = sh->prefix, mask = sh->mask;
-            u64 best = 0;
-            rr_for_each_key(p, q, [&](u64 key) {
-                if ((key & mask) == prefix && key > best) best = key;
-            });
-            if (best) atomicMax(&sh->kth, best);
-            __syncthreads();
-        } else {
-            if (tid == 0) sh->kth = sh->prefix;
-            __syncthreads();
-        }
+    // ---- k-th best approximate score over all splits -> error band -> rows to re-rank
+    if (n > p.k) {
+        const u64 kth = wg_select_kth<RR_THREADS>(cand, n, p.k, sh->hist, &sh->ctl);
         const float e = flat_filter_err_bound(METRIC, p.d, p.xqn[q], p.yn_max);
-        const float thr = band_threshold(key_score((uint32_t)(sh->kth >> 32)), e);
-        key_thr = ((u64)score_key(thr) << 32) | 0xffffffffull;
+        const float thr = band_threshold(key_score((uint32_t)(kth >> 32)), e);
+        const u64 key_thr = ((u64)score_key(thr) << 32) | 0xffffffffull;
+        wg_compact<RR_THREADS>(cand, n, key_thr, &sh->ctl);
+        n = (int)sh->ctl.cnt;
     }
-
-    // ---- gather the rows inside the band
-    rr_for_each_key(p, q, [&](u64 key) {
-        if (key <= key_thr) {
-            const unsigned slot = atomicAdd(&sh->ncand, 1u);
-            if (slot < (unsigned)RR_CAND) cand[slot] = key & 0xffffffffull;
-        }
-    });
-    __syncthreads();
-    int n = (int)sh->ncand;
     if (n > RR_CAND) {
         if (tid == 0) p.ovf_list[atomicAdd(p.ovf_cnt, 1u)] = (uint32_t)q;
         return;
@@ -796,7 +734,7 @@ __global__ void __launch_bounds__(RR_THREADS) flat_rerank_kernel(FlatRerankParam
 void launch_flat_rerank(const FlatRerankParams& p, hipStream_t stream) {
     if (p.nq == 0) return;
     FA_THROW_IF_NOT(p.k >= 1 && p.k <= kMaxSelectionK && p.dpad % 8 == 0);
-    const size_t lds = ((sizeof(RrShared) + 15) & ~(size_t)15) + (size_t)RR_CAND * 8 +
+    const size_t lds = ((sizeof(RrShared) + 15) & ~(size_t)15) + (size_t)RR_GATHER * 8 +
                        (size_t)(p.dpad + (p.dpad & 1)) * 4 + (size_t)p.kp * 12;
     FA_THROW_IF_NOT_MSG(lds <= 160 * 1024, "re-rank workspace exceeds the LDS");
     if (p.metric == METRIC_L2) {

@@ -4,6 +4,7 @@
 #include "index.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <random>
@@ -952,9 +953,9 @@ void GpuIndexIVF::search(idx_t n, const float* x, idx_t k, float* distances, idx
     size_t per_q = (size_t)np * max_len * 8;
     idx_t tile = (idx_t)std::max<size_t>(1, R.temp_budget_bytes / per_q);
     tile = std::min<idx_t>(tile, 16384);
-    int fused_cap = 0, fused_kp = 0;
-    const bool fused = use_fused_scan &&
-                       ivf_fused_supported(fused_kind_(), fused_M_(), dpad_, (int)k, np, &fused_cap, &fused_kp);
+    int fused_cap = 0, fused_kp = 0, fused_nlut = 1;
+    const bool fused = use_fused_scan && ivf_fused_supported(fused_kind_(), fused_M_(), dpad_, (int)k, np, &fused_cap,
+                                                             &fused_kp, &fused_nlut);
     if (fused) tile = 65536; // no per-candidate scratch: the tile only bounds the staging buffers
     for (idx_t i0 = 0; i0 < n; i0 += tile) {
         const int ni = (int)std::min(tile, n - i0);
@@ -993,6 +994,7 @@ void GpuIndexIVF::search(idx_t n, const float* x, idx_t k, float* distances, idx
             fp.k = (int)k;
             fp.kp = fused_kp;
             fp.cap = fused_cap;
+            fp.nlut = fused_nlut;
             // enough workgroups to fill the chip twice over; probes are split only for small batches
             const int want = 4 * R.num_cus;
             int G = ni >= want ? 1 : std::min<int>(np, (int)div_up(want, ni));
@@ -1009,9 +1011,25 @@ void GpuIndexIVF::search(idx_t n, const float* x, idx_t k, float* distances, idx
                 fp.prefix_out = prefix_.as<uint32_t>();
             }
             fill_fused_(fp);
+            static const bool timing = getenv("FAISS_AMD_FUSED_TIMING") != nullptr;
+            DevBuf dbg;
+            if (timing) {
+                dbg.ensure(16 * 8);
+                HIP_CHECK(hipMemsetAsync(dbg.p, 0, 16 * 8, R.stream));
+                fp.dbg = dbg.as<unsigned long long>();
+            }
             {
                 SpanGuard sg(&R, fp.kind == 1 ? "ivfpq_fused_kernel" : "ivfflat_fused_kernel");
                 launch_ivf_fused(fp, R.stream);
+            }
+            if (timing) {
+                unsigned long long h[8];
+                HIP_CHECK(hipMemcpyAsync(h, dbg.p, sizeof(h), hipMemcpyDeviceToHost, R.stream));
+                R.sync();
+                const double nwg = (double)ni * fp.G;
+                fprintf(stderr, "[fused timing, cycles per workgroup] prologue %.0f | rs+bar %.0f | build %.0f | bar %.0f | "
+                                "room %.0f | scan %.0f | append+bar %.0f | finish %.0f\n",
+                        h[0] / nwg, h[1] / nwg, h[2] / nwg, h[3] / nwg, h[4] / nwg, h[5] / nwg, h[6] / nwg, h[7] / nwg);
             }
             if (fp.G > 1) {
                 SelectParams sp{};

@@ -11,7 +11,8 @@
 //                (direct form as the CPU scanner, faiss/utils/simd_impl/IVFFlatScanner-inl.h:20-27)
 //   IVFFlat IP : dis = chain_k fmaf(q[k], y[k], acc)
 //   IVFPQ  L2  : r = q - centroid;  lut[m][c] = chain_j fmaf(r_mj - pq[m][c][j], same, acc);
-//                dis = ((0 + lut[0][c0]) + lut[1][c1]) + ...      (m ascending)
+//                dis = dis0 + ((p0 + p1) + (p2 + p3)),  p_j = sequential sum of lut[m][c_m] over the
+//                j-th quarter of the sub-quantizers (the four lanes that share a code in the fused scan)
 //                (faiss/gpu/impl/PQCodeDistances-inl.cuh:29-285 semantics, by_residual,
 //                 no precomputed table; CPU counterpart faiss/IndexIVFPQ.cpp scan_list_with_table)
 //   IVFPQ  IP  : lut[m][c] = chain_j fmaf(q_mj, pq[m][c][j], acc);  dis = coarse_ip + sum_m lut
@@ -149,24 +150,17 @@ __global__ void __launch_bounds__(256) ivfpq_scan_kernel(IvfScanParams p) {
     const int M = p.M;
     for (unsigned i = threadIdx.x; i < len; i += blockDim.x) {
         const uint8_t* code = p.arena_codes + (start + i) * M;
-        float acc = dis0;
-        int m = 0;
-        if ((M & 15) == 0) {
-            for (; m < M; m += 16) {
-                const uint4 cw = *(const uint4*)(code + m);
-                const unsigned w[4] = {cw.x, cw.y, cw.z, cw.w};
+        // same order as the fused scan (ivf_fused.hip): four partial sums over M/4 consecutive
+        // sub-quantizers, combined pairwise, then added to dis0
+        const int mq = M >> 2;
+        float part[4];
 #pragma unroll
-                for (int wi = 0; wi < 4; ++wi) {
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        const unsigned c = (w[wi] >> (8 * b)) & 255u;
-                        acc = acc + lut[(m + wi * 4 + b) * 256 + c];
-                    }
-                }
-            }
-        } else {
-            for (; m < M; ++m) acc = acc + lut[m * 256 + code[m]];
+        for (int jq = 0; jq < 4; ++jq) {
+            float a = 0.f;
+            for (int m = jq * mq; m < (jq + 1) * mq; ++m) a = a + lut[m * 256 + code[m]];
+            part[jq] = a;
         }
+        const float acc = dis0 + ((part[0] + part[1]) + (part[2] + part[3]));
         out[i] = ((u64)ordkey<METRIC>(acc) << 32) | (u64)(pos0 + i);
     }
 }

@@ -224,6 +224,7 @@ struct IvfFusedParams {
     const int64_t* arena_ids;   // [ntotal]
     int k, kp, cap;             // kp = pow2 >= k; cap = LDS reservoir capacity (>= k + 512)
     int G, npc;                 // workgroups per query, probes per workgroup (G * npc >= nprobe)
+    int nlut;                   // lookup tables in LDS: 2 = build of probe p+1 overlaps the scan of probe p
     float* out_dis;             // [nq][k]   (G == 1)
     int64_t* out_ids;           // [nq][k]   (G == 1)
     unsigned long long* part_keys; // [nq][G][k] partial winners (G > 1), merged by launch_select_k mode 1
@@ -238,14 +239,17 @@ struct IvfFusedParams {
     int M, dsub;
     const float* pq_centroids;  // [M][256][dsub]
     const uint8_t* arena_codes; // [ntotal][M]
+    // optional phase timing (profiling hook, FAISS_AMD_FUSED_TIMING=1): 16 cycle counters summed over
+    // all workgroups by their thread 0
+    unsigned long long* dbg;
 };
 // One workgroup per (query, probe group): table build + code scan + running top-k all in LDS.
 // Replaces PQCodeDistances + PQScanMultiPassNoPrecomputed + IVFUtilsSelect{1,2} (IVFPQ) and
 // IVFInterleaved scan + scan2 (IVFFlat) of the reference in a single launch.
 void launch_ivf_fused(const IvfFusedParams& p, hipStream_t stream);
 // does the problem fit the fused kernel (LDS budget, reservoir size)?  Returns cap / kp to use.
-bool ivf_fused_supported(int kind, int M, int dpad, int k, int nprobe, int* cap_out, int* kp_out);
-size_t ivf_fused_lds_bytes(int kind, int M, int dpad, int kp, int cap, int nprobe);
+bool ivf_fused_supported(int kind, int M, int dpad, int k, int nprobe, int* cap_out, int* kp_out, int* nlut_out);
+size_t ivf_fused_lds_bytes(int kind, int M, int dpad, int kp, int cap, int nprobe, int nlut);
 
 // add path (faiss/gpu/impl/IVFAppend.cu): scatter rows / encode PQ codes to arena slots
 void launch_ivfflat_append(const float* x, int64_t ldx, int n, int d, const int64_t* dest,

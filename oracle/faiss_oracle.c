@@ -338,9 +338,25 @@ int orc_ivf_search(int kind, int metric, int d, int nlist, const float* centroid
                     dis = acc;
                 } else {
                     const uint8_t* code = lc + (size_t)i * code_size;
-                    float acc = dis0;
-                    for (int m = 0; m < M; m++) acc = acc + lut[m * 256 + code[m]];
-                    dis = acc;
+                    /* ADC sum in the order of the GPU scan: four lanes own M/4 consecutive
+                     * sub-quantizers each (sequential partial sums from 0), combined pairwise by a
+                     * lane butterfly, then added to dis0.  (The CPU reference sums sequentially,
+                     * faiss/impl/pq_code_distance/pq_code_distance-generic.cpp distance_single_code;
+                     * the two orders agree to fp32 rounding.) */
+                    float part[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (M % 4 == 0) {
+                        const int mq = M / 4;
+                        for (int jq = 0; jq < 4; jq++) {
+                            float acc = 0.f;
+                            for (int m = jq * mq; m < (jq + 1) * mq; m++) acc = acc + lut[m * 256 + code[m]];
+                            part[jq] = acc;
+                        }
+                    } else {
+                        float acc = 0.f;
+                        for (int m = 0; m < M; m++) acc = acc + lut[m * 256 + code[m]];
+                        part[0] = acc;
+                    }
+                    dis = dis0 + ((part[0] + part[1]) + (part[2] + part[3]));
                 }
                 pos2id[pos] = lid[i];
                 topk_push(&t, dis, pos); /* tie -> smaller scan position */

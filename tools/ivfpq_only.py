@@ -1,0 +1,29 @@
+#!/usr/bin/env python
+"""tools/ivfpq_only.py -- IVF4096,PQ64 search loop on the bench data, nothing else (profiling target)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import faiss_amd
+from faiss_amd.datasets import synthetic_dataset
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+nb = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000
+metric = faiss_amd.METRIC_INNER_PRODUCT if len(sys.argv) > 3 and sys.argv[3] == "ip" else faiss_amd.METRIC_L2
+res = faiss_amd.StandardGpuResources(0)
+xt, xb, xq = synthetic_dataset(128, 100000, nb, 10000, seed=1338)
+idx = faiss_amd.GpuIndexIVFPQ(res, 128, 4096, 64, 8, metric)
+idx.train(xt); idx.add(xb); idx.nprobe = 32
+dev = torch.device("cuda", 0)
+xq_dev = torch.from_numpy(xq).to(dev)
+Dd = torch.empty((10000, 100), dtype=torch.float32, device=dev)
+Id = torch.empty((10000, 100), dtype=torch.int64, device=dev)
+idx.search_ptr(10000, xq_dev.data_ptr(), 100, Dd.data_ptr(), Id.data_ptr())
+torch.cuda.synchronize(); t0 = time.time()
+for _ in range(steps):
+    idx.search_ptr(10000, xq_dev.data_ptr(), 100, Dd.data_ptr(), Id.data_ptr())
+torch.cuda.synchronize()
+print("ivfpq search (%s): %.3f ms/step" % ("ip" if metric == 0 else "l2", (time.time() - t0) / steps * 1e3))
+res.profile_enable(True); res.profile_reset()
+idx.search_ptr(10000, xq_dev.data_ptr(), 100, Dd.data_ptr(), Id.data_ptr())
+for kn in ("ivfpq_fused_kernel", "flat_scan_kernel", "select_k_kernel", "flat_filter_kernel", "flat_rerank_kernel"):
+    print(kn, res.profile_get(kn))
