@@ -230,7 +230,9 @@ void GpuIndexFlat::reconstruct(idx_t key, float* recons) const {
 // choose the database split count: blocks = nsplit * ngroups should fill whole rounds of CUs
 static void choose_splits(int nb, int ngroups, int num_cus, int& nsplit, int& rows_per_split, int split_cap = 64) {
     const int TR = kFlatTileRows;
-    const int max_split = std::max(1, nb / 2048);
+    // splits of at least 2048 rows for large databases; small ones (the IVF coarse quantizer: nlist
+    // centroids) go down to 4 tiles per split so that the grid still covers the chip
+    const int max_split = std::max(1, nb >= 65536 ? nb / 2048 : nb / (4 * TR));
     int best = 1;
     if (max_split >= 8) {
         double best_eff = -1.0;
@@ -727,6 +729,10 @@ GpuIndexIVF::GpuIndexIVF(std::shared_ptr<GpuResources> res, int dims, int metric
                         "unsupported metric type (reference: faiss/gpu/GpuIndexIVF.cu:35-37)");
     dpad_ = (int)round_up(dims, 8);
     quantizer = new GpuIndexFlat(res_, dims, metric);
+    // the coarse quantizer holds only nlist rows: let it take the fp16 filter + exact re-rank path from
+    // 2048 centroids on (bit-identical results; the fp32 scan's per-split reservoirs bootstrap poorly
+    // on a few thousand rows)
+    quantizer->filter_min_rows = 2048;
     is_trained = false;
     list_len_.assign(nlist, 0);
     list_start_.assign(nlist, 0);
@@ -761,6 +767,7 @@ void GpuIndexIVF::set_centroids(const float* centroids) {
     quantizer->add(nlist, centroids);
     is_trained = true; // IVFPQ additionally needs set_pq_centroids (checked in add/search)
     upload_list_tables_();
+    if (ntotal > 0) lists_changed_();
 }
 
 void GpuIndexIVF::train(idx_t n, const float* x) {
@@ -887,6 +894,7 @@ void GpuIndexIVF::add_with_ids(idx_t n, const float* x, const idx_t* xids) {
     list_start_ = new_start;
     ntotal += n_valid;
     upload_list_tables_();
+    lists_changed_();
 }
 
 void GpuIndexIVF::set_lists(const uint32_t* list_sizes, const uint8_t* codes, const idx_t* ids) {
@@ -911,6 +919,7 @@ void GpuIndexIVF::set_lists(const uint32_t* list_sizes, const uint8_t* codes, co
                                    hipMemcpyHostToDevice, res_->stream));
     }
     upload_list_tables_();
+    lists_changed_();
 }
 
 std::vector<idx_t> GpuIndexIVF::getListIndices(idx_t list) const {
@@ -1011,25 +1020,9 @@ void GpuIndexIVF::search(idx_t n, const float* x, idx_t k, float* distances, idx
                 fp.prefix_out = prefix_.as<uint32_t>();
             }
             fill_fused_(fp);
-            static const bool timing = getenv("FAISS_AMD_FUSED_TIMING") != nullptr;
-            DevBuf dbg;
-            if (timing) {
-                dbg.ensure(16 * 8);
-                HIP_CHECK(hipMemsetAsync(dbg.p, 0, 16 * 8, R.stream));
-                fp.dbg = dbg.as<unsigned long long>();
-            }
             {
                 SpanGuard sg(&R, fp.kind == 1 ? "ivfpq_fused_kernel" : "ivfflat_fused_kernel");
                 launch_ivf_fused(fp, R.stream);
-            }
-            if (timing) {
-                unsigned long long h[8];
-                HIP_CHECK(hipMemcpyAsync(h, dbg.p, sizeof(h), hipMemcpyDeviceToHost, R.stream));
-                R.sync();
-                const double nwg = (double)ni * fp.G;
-                fprintf(stderr, "[fused timing, cycles per workgroup] prologue %.0f | rs+bar %.0f | build %.0f | bar %.0f | "
-                                "room %.0f | scan %.0f | append+bar %.0f | finish %.0f\n",
-                        h[0] / nwg, h[1] / nwg, h[2] / nwg, h[3] / nwg, h[4] / nwg, h[5] / nwg, h[6] / nwg, h[7] / nwg);
             }
             if (fp.G > 1) {
                 SelectParams sp{};
@@ -1158,6 +1151,7 @@ void GpuIndexIVFPQ::set_pq_centroids(const float* pq) {
     pq_.ensure((size_t)M * 256 * dsub * 4);
     HIP_CHECK(hipMemcpy(pq_.p, pq, (size_t)M * 256 * dsub * 4,
                         is_device_pointer(pq) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    if (ntotal > 0) lists_changed_();
 }
 std::vector<float> GpuIndexIVFPQ::get_pq_centroids() const {
     res_->set_device();
@@ -1203,8 +1197,18 @@ void GpuIndexIVFPQ::append_(int n, const float* x_pad, const int64_t* d_labels, 
     launch_ivfpq_encode_append(x_pad, dpad_, n, d, d_labels, d_dest, quantizer->device_vectors(), dpad_, M,
                                dsub, pq_.as<float>(), arena_.as<uint8_t>(), res_->stream);
 }
+void GpuIndexIVFPQ::lists_changed_() {
+    // recompute the per-vector L2 term for the whole arena (one pass over the codes; add time only)
+    if (metric_type != METRIC_L2 || ntotal == 0) return;
+    FA_THROW_IF_NOT_MSG(pq_.p, "PQ not trained");
+    arena_t2_.ensure((size_t)ntotal * 4);
+    launch_ivfpq_t2(arena_.as<uint8_t>(), d_list_start_.as<int64_t>(), d_list_len_.as<uint32_t>(), nlist,
+                    quantizer->device_vectors(), dpad_, M, dsub, pq_.as<float>(), arena_t2_.as<float>(), res_->stream);
+    res_->sync();
+}
 void GpuIndexIVFPQ::fill_fused_(IvfFusedParams& p) const {
     FA_THROW_IF_NOT_MSG(pq_.p, "PQ not trained");
+    p.arena_t2 = arena_t2_.as<float>();
     p.centroids = quantizer->device_vectors();
     p.ldc = dpad_;
     p.M = M;
@@ -1235,6 +1239,7 @@ void GpuIndexIVFPQ::scan_(int nq, const float* xq_pad, int, const int64_t*) cons
     p.dsub = dsub;
     p.pq_centroids = pq_.as<float>();
     p.arena_codes = arena_.as<uint8_t>();
+    p.arena_t2 = arena_t2_.as<float>();
     SpanGuard sg(res_.get(), "ivfpq_scan_kernel");
     launch_ivfpq_scan(p, res_->stream);
 }

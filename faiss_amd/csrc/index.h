@@ -199,6 +199,8 @@ class GpuIndexIVF : public Index {
     mutable int nprobe_eff_ = 1; // min(nprobe, nlist) of the search in flight
 
     virtual void train_residual_(idx_t n, const float* x_dev_pad) {}
+    // called (under mu_) whenever the arena layout or contents changed: derived per-vector data
+    virtual void lists_changed_() {}
     // encode/scatter n staged vectors (device, padded) with given labels into arena rows dest
     virtual void append_(int n, const float* x_pad, const int64_t* d_labels, const int64_t* d_dest) = 0;
     virtual void scan_(int nq, const float* xq_pad, int k, const int64_t* h_qoff) const = 0;
@@ -241,6 +243,8 @@ class GpuIndexIVFPQ : public GpuIndexIVF {
     int fused_kind_() const override { return 1; }
     int fused_M_() const override { return M; }
     DevBuf pq_; // [M][256][dsub]
+    DevBuf arena_t2_; // [ntotal] L2: |r^|^2 + 2 <centroid, r^> per stored vector (see ivf_fused.hip)
+    void lists_changed_() override;
     void train_residual_(idx_t n, const float* x_dev_pad) override;
     void append_(int n, const float* x_pad, const int64_t* d_labels, const int64_t* d_dest) override;
     void scan_(int nq, const float* xq_pad, int k, const int64_t* h_qoff) const override;

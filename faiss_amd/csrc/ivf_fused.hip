@@ -181,14 +181,23 @@ __device__ __forceinline__ void fused_finish(const IvfFusedParams& p, int q, int
 }
 
 // ---------------------------------------------------------------------------------
-// IVFPQ.  DSUB > 0: the PQ codebook lives in registers (thread t owns centroid t & 255 of the
-// sub-quantizers of its part (t >> 8) of M; d <= 128) and every table is built without
-// touching global memory; DSUB == 0: generic fallback that re-reads the codebook through L2.
+// IVFPQ.  One lookup table per QUERY, resident in LDS for all of its probes:
+//   lut[m][c] = <q_m, pq[m][c]>                      (both metrics)
+//   IP :  dis = coarse_ip(q, list) + S               S = sum_m lut[m][code_m]
+//   L2 :  |q - c - r^|^2 = |q - c|^2 + (|r^|^2 + 2 <c, r^>) - 2 <q, r^>
+//         dis = fmaf(-2, S, coarse_l2(q, list) + t2(y))
+// with r^ the decoded residual of the stored vector and t2(y) = |r^|^2 + 2 <c, r^> a per-vector
+// constant computed once at add time (ivfpq_t2_kernel).  This is the decomposition the reference
+// CPU index uses by default (faiss/impl/pq_code_distance/IVFPQ_QueryTables.cpp:126-192 term 1-3,
+// use_precomputed_table) and the reference GPU index offers as usePrecomputedTables
+// (faiss/gpu/impl/IVFPQ.cu:362-489); keeping the list-dependent term per VECTOR instead of per
+// (list, m, code) costs 4 bytes per vector and removes the 256 MB term-2 table and, above all, the
+// rebuild of a 64 KB table for each of the 32 probes of a query.
+// The four 256-lane quarters of the workgroup scan FOUR probed lists side by side (one code per
+// lane, 64 gathers), so the global-load, LDS and barrier latencies of one list overlap the others'.
+// M64: the sub-quantizer count is the compile-time constant 64 (four 16-byte loads per code).
 // ---------------------------------------------------------------------------------
-// M64: the sub-quantizer count is the compile-time constant 64 (the headline PQ64 shape): every lane's
-// quarter of a code is exactly one 16-byte load and the byte-wise fallback paths (and their address
-// registers) disappear from the kernel.
-template <int METRIC, int DSUB, bool M64, bool TIMING = false>
+template <int METRIC, bool M64>
 __global__ void __launch_bounds__(FB) ivfpq_fused_kernel(IvfFusedParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const FusedLds L = fused_carve(smem, p);
@@ -197,255 +206,119 @@ __global__ void __launch_bounds__(FB) ivfpq_fused_kernel(IvfFusedParams p) {
     const int p0 = g * p.npc, p1 = min(p.nprobe, p0 + p.npc);
     float* lut = (float*)L.lut;
     const int M = M64 ? 64 : p.M, d = p.d, dsub = p.dsub;
+    constexpr int NG = FB / 256; // lists scanned side by side
+    const int grp = __builtin_amdgcn_readfirstlane(tid >> 8);
+    const int lg = tid & 255;
 
-    unsigned long long t_prev = TIMING ? clock64() : 0ull;
-    unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define FUSED_TICK(slot)                               \
-    do {                                               \
-        if (TIMING) {                                  \
-            const unsigned long long t_now = clock64(); \
-            t_acc[slot] += t_now - t_prev;             \
-            t_prev = t_now;                            \
-        }                                              \
-    } while (0)
     fused_load_probes(p, q, L);
-
-    // codebook slice of this thread: centroid c of the sub-quantizers of its quarter of M
-    constexpr int NREG = DSUB > 0 ? 128 / FPART : 1;
-    float pqr[NREG];
-    const int c = tid & 255;
-    const int quarter = __builtin_amdgcn_readfirstlane(tid >> 8);
-    const int mq = M / FPART; // sub-quantizers per part
-    if (DSUB > 0) {
-#pragma unroll
-        for (int mm = 0; mm < NREG / DSUB; ++mm) {
-#pragma unroll
-            for (int jd = 0; jd < DSUB; ++jd) {
-                float v = 0.f;
-                if (mm < mq) v = p.pq_centroids[((size_t)(quarter * mq + mm) * 256 + c) * DSUB + jd];
-                pqr[mm * DSUB + jd] = v;
-            }
-        }
+    for (int cc = tid; cc < d; cc += FB) L.rs[cc] = p.xq[(int64_t)q * p.ldq + cc];
+    __syncthreads();
+    // ---- the query's table (codebook read through L2 once per query)
+    for (int e = tid; e < M * 256; e += FB) {
+        const int m = e >> 8;
+        const float* cen = p.pq_centroids + (size_t)e * dsub;
+        const float* r = L.rs + m * dsub;
+        float acc = 0.f;
+        for (int jd = 0; jd < dsub; ++jd) acc = __fmaf_rn(r[jd], cen[jd], acc);
+        lut[e] = acc;
     }
+    __syncthreads();
 
-    const int rs_stride = (p.dpad + 3) & ~3;
-    auto build_lut = [&](float* lut, const float* rsb) {
-        if (DSUB > 0) {
+    const int mq = M >> 2; // sub-quantizers per partial sum
+    constexpr int NW = 4;  // 16-byte code words held in registers (wide path)
+    constexpr bool wide = M64; // code words prefetched into registers
+    uint4 cw[NW], cwn[NW];
+    float t2 = 0.f, t2n = 0.f;
+    // codes + t2 of this lane's entry `i` of the list probed at rank `pr` (nothing when out of range)
+    auto fetch = [&](int pr, unsigned i, uint4(&w)[NW], float& t) {
+        if (pr < p1) {
+            const int list = L.lst[pr];
+            const unsigned len = list < 0 ? 0u : L.pre[pr + 1] - L.pre[pr];
+            if (i < len) {
+                const int64_t row = L.lstart[pr] + i;
+                if (wide) {
+                    const uint8_t* code = p.arena_codes + row * M;
 #pragma unroll
-            for (int mm = 0; mm < NREG / DSUB; ++mm) {
-                if (mm < mq) {
-                    const int m = quarter * mq + mm;
-                    float acc = 0.f;
-#pragma unroll
-                    for (int jd = 0; jd < DSUB; ++jd) {
-                        const float r = rsb[m * DSUB + jd];
-                        if (METRIC == METRIC_L2) {
-                            const float t = r - pqr[mm * DSUB + jd];
-                            acc = __fmaf_rn(t, t, acc);
-                        } else {
-                            acc = __fmaf_rn(r, pqr[mm * DSUB + jd], acc);
-                        }
-                    }
-                    lut[m * 256 + c] = acc;
+                    for (int k = 0; k < NW; ++k) w[k] = *(const uint4*)(code + k * 16);
                 }
-                // keep the LDS reads of the residual from being hoisted 32 deep (VGPR pressure)
-                if ((mm & 7) == 7) __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
-            for (int e = tid; e < M * 256; e += FB) {
-                const int m = e >> 8;
-                const float* cen = p.pq_centroids + (size_t)e * dsub;
-                const float* r = rsb + m * dsub;
-                float acc = 0.f;
-                for (int jd = 0; jd < dsub; ++jd) {
-                    if (METRIC == METRIC_L2) {
-                        const float t = r[jd] - cen[jd];
-                        acc = __fmaf_rn(t, t, acc);
-                    } else {
-                        acc = __fmaf_rn(r[jd], cen[jd], acc);
-                    }
-                }
-                lut[e] = acc;
+                if (METRIC == METRIC_L2) t = p.arena_t2[row];
             }
         }
     };
-
-    // ---- scan geometry: four adjacent lanes share one code, each owns M/4 consecutive
-    // sub-quantizers (a 16-byte load per lane at M = 64, the wave reads 1 KB of contiguous codes per
-    // instruction); the four partial sums meet in a 2-step lane butterfly.  All 16 wavefronts
-    // gather from the table instead of the 4 that one-code-per-thread leaves busy at ~250-entry lists.
-    // ---- software pipeline across probes: the residual of probe pr+1 (one value per thread) and
-    // the first code chunk of probe pr are fetched from L2/HBM while the table of probe pr is
-    // being built, so that no global latency sits between two barriers.
-    constexpr int CPC = FB / 4;                 // codes per chunk
-    const int ml = M >> 2;                      // sub-quantizers per lane
-    const int jq = tid & 3;                     // this lane's quarter of the code
-    const bool wide = M64 || ((ml & 3) == 0 && ml <= 16); // quarter fetched as up to 4 dwords kept in registers
-    unsigned cw[4];
-    auto fetch_codes = [&](int64_t start, unsigned i, unsigned len) {
-        if (wide && i < len) {
-            const uint8_t* code = p.arena_codes + (start + i) * M + jq * ml;
-            if (M64 || ml == 16) {
-                const uint4 v = *(const uint4*)code;
-                cw[0] = v.x; cw[1] = v.y; cw[2] = v.z; cw[3] = v.w;
-            } else {
-#pragma unroll
-                for (int w = 0; w < 4; ++w)
-                    if (w * 4 < ml) cw[w] = *(const unsigned*)(code + w * 4);
-            }
-        }
-    };
-    auto residual_of = [&](int pr) -> float {
-        // threads tid < d only; list < 0 (fewer than nprobe lists exist) reads list 0, result unused
-        const int l = max(L.lst[pr], 0);
-        return p.xq[(int64_t)q * p.ldq + tid] - p.centroids[(int64_t)l * p.ldc + tid];
-    };
-
-    if (METRIC != METRIC_L2) {
-        // inner product: the table depends on the query only
-        for (int cc = tid; cc < d; cc += FB) L.rs[cc] = p.xq[(int64_t)q * p.ldq + cc];
-        __syncthreads();
-        build_lut(lut, L.rs);
-        __syncthreads();
-    }
-    const bool res_in_reg = METRIC == METRIC_L2 && d <= FB; // one residual coordinate per thread
-    float rres = 0.f;
-    if (res_in_reg && tid < d && p0 < p1) rres = residual_of(p0);
 
     u64 tau = ~0ull;
     int bound = 0;
-    FUSED_TICK(0); // prologue: probe table, codebook registers
-    // scan of one list against table `lt` (first chunk's codes already in cw)
-    auto scan_list = [&](const float* lt, int64_t start, unsigned pos0, unsigned len, float dis0) {
-        for (unsigned base = 0; base < len; base += CPC) {
-            FUSED_MAKE_ROOM(min((unsigned)CPC, len - base));
-            FUSED_TICK(4); // make room (reservoir compaction when needed)
-            const unsigned i = base + (tid >> 2);
-            float part = 0.f;
+    if (p0 < p1) fetch(p0 + grp, (unsigned)lg, cw, t2);
+    for (int r0 = p0; r0 < p1; r0 += NG) {
+        // lengths of the NG lists of this round (wave-uniform), longest first in `maxlen`
+        unsigned maxlen = 0;
+#pragma unroll
+        for (int gg = 0; gg < NG; ++gg) {
+            const int pr = r0 + gg;
+            if (pr < p1 && L.lst[pr] >= 0) maxlen = max(maxlen, L.pre[pr + 1] - L.pre[pr]);
+        }
+        const int pr = r0 + grp;
+        const bool pvalid = pr < p1 && L.lst[pr < p1 ? pr : p0] >= 0;
+        const unsigned pos0 = pvalid ? L.pre[pr] : 0u;
+        const unsigned len = pvalid ? L.pre[pr + 1] - pos0 : 0u;
+        const int64_t start = pvalid ? L.lstart[pr] : 0;
+        const float dis0 = pvalid ? p.coarse_dis[(int64_t)q * p.nprobe + pr] : 0.f;
+        for (unsigned base = 0; base < maxlen; base += 256) {
+            unsigned chunk = 0;
+#pragma unroll
+            for (int gg = 0; gg < NG; ++gg) {
+                const int pg = r0 + gg;
+                if (pg < p1 && L.lst[pg] >= 0) {
+                    const unsigned lgn = L.pre[pg + 1] - L.pre[pg];
+                    chunk += lgn > base ? min(256u, lgn - base) : 0u;
+                }
+            }
+            FUSED_MAKE_ROOM(chunk);
+            // next chunk of this round, or the first chunk of the next round: in flight while this one is scanned
+            if (base + 256 < maxlen) fetch(pr, base + 256 + lg, cwn, t2n);
+            else fetch(pr + NG, (unsigned)lg, cwn, t2n);
+            const unsigned i = base + lg;
+            bool pass = false;
+            u64 key = 0;
             if (i < len) {
-                const float* lq = lt + (size_t)jq * ml * 256;
-                if (wide) {
+                float part[4];
+                if (M64) {
+                    // quarter jq = sub-quantizers [16 jq, 16 jq + 16) = the 16 bytes of code word jq
 #pragma unroll
-                    for (int w = 0; w < 4; ++w) {
-                        if (w * 4 < ml) {
+                    for (int jq = 0; jq < 4; ++jq) {
+                        const unsigned wv[4] = {cw[jq].x, cw[jq].y, cw[jq].z, cw[jq].w};
+                        float a = 0.f;
 #pragma unroll
-                            for (int b = 0; b < 4; ++b)
-                                part = part + lq[(w * 4 + b) * 256 + ((cw[w] >> (8 * b)) & 255u)];
-                        }
+                        for (int bb = 0; bb < 16; ++bb)
+                            a = a + lut[(jq * 16 + bb) * 256 + ((wv[bb >> 2] >> (8 * (bb & 3))) & 255u)];
+                        part[jq] = a;
                     }
                 } else {
-                    const uint8_t* code = p.arena_codes + (start + i) * M + jq * ml;
-                    for (int m = 0; m < ml; ++m) part = part + lq[m * 256 + code[m]];
+                    const uint8_t* code = p.arena_codes + (start + i) * M;
+#pragma unroll
+                    for (int jq = 0; jq < 4; ++jq) {
+                        float a = 0.f;
+                        for (int m = jq * mq; m < (jq + 1) * mq; ++m) a = a + lut[m * 256 + code[m]];
+                        part[jq] = a;
+                    }
                 }
+                const float sum = (part[0] + part[1]) + (part[2] + part[3]);
+                const float dis = METRIC == METRIC_L2 ? __fmaf_rn(-2.f, sum, dis0 + t2) : dis0 + sum;
+                key = ((u64)ordkey<METRIC>(dis) << 32) | (u64)(pos0 + i);
+                pass = key < tau;
             }
-            // (p0 + p1) + (p2 + p3): xor-butterfly over the quad, identical bits in its four lanes
-            part = part + __shfl_xor(part, 1, 64);
-            part = part + __shfl_xor(part, 2, 64);
-            const float acc = dis0 + part;
-            const u64 key = ((u64)ordkey<METRIC>(acc) << 32) | (u64)(pos0 + i);
-            const bool pass = i < len && jq == 0 && key < tau;
-            // next chunk of this list (long lists): in flight behind the append and the barrier
-            if (base + CPC < len) fetch_codes(start, i + CPC, len);
-            FUSED_TICK(5); // gathers + butterfly (includes the wait for the codes)
             wg_append(L.res, L.ctl, pass, key);
-            if (base + CPC < len) __syncthreads(); // (the caller ends the list with its own barrier)
-            FUSED_TICK(6); // append (+ barrier)
-        }
-    };
-
-    if (METRIC == METRIC_L2 && p.nlut == 2 && res_in_reg) {
-        // ---- double-buffered tables: while the gathers of probe pr run against table b, the
-        // table of probe pr+1 is written into table b^1 by the same threads (LDS writes and reads
-        // of different buffers interleave in the LDS pipeline); ONE barrier per probe.
-        float* lutb[2] = {lut, lut + (size_t)M * 256};
-        float* rsb[2] = {L.rs, L.rs + rs_stride};
-        if (p0 < p1) {
-            if (tid < d) rsb[0][tid] = rres;
-            if (tid < d && p0 + 1 < p1) rres = residual_of(p0 + 1);
-            __syncthreads();
-            build_lut(lutb[0], rsb[0]);
-            if (tid < d) rsb[1][tid] = rres; // residual of probe p0+1 (garbage when there is none: unused)
-            {
-                const int l0 = L.lst[p0];
-                fetch_codes(L.lstart[p0], tid >> 2, l0 < 0 ? 0u : L.pre[p0 + 1] - L.pre[p0]);
-            }
-            __syncthreads();
-        }
-        FUSED_TICK(1);
-        for (int pr = p0; pr < p1; ++pr) {
-            const int b = (pr - p0) & 1;
-            const int list = L.lst[pr];
-            const unsigned pos0 = L.pre[pr];
-            const unsigned len = (list < 0) ? 0u : L.pre[pr + 1] - pos0;
-            const int64_t start = L.lstart[pr];
-            // in flight during this iteration: residual of probe pr+2, first codes of probe pr+1
-            if (tid < d && pr + 2 < p1) rres = residual_of(pr + 2);
-            unsigned cwn[4] = {0, 0, 0, 0};
-            if (pr + 1 < p1) {
-                const int l1 = L.lst[pr + 1];
-                const unsigned len1 = l1 < 0 ? 0u : L.pre[pr + 2] - L.pre[pr + 1];
-                const unsigned i1 = tid >> 2;
-                if (wide && i1 < len1) {
-                    const uint8_t* code = p.arena_codes + (L.lstart[pr + 1] + i1) * M + jq * ml;
-                    if (M64 || ml == 16) {
-                        const uint4 v = *(const uint4*)code;
-                        cwn[0] = v.x; cwn[1] = v.y; cwn[2] = v.z; cwn[3] = v.w;
-                    } else {
 #pragma unroll
-                        for (int w = 0; w < 4; ++w)
-                            if (w * 4 < ml) cwn[w] = *(const unsigned*)(code + w * 4);
-                    }
-                }
-                build_lut(lutb[b ^ 1], rsb[b ^ 1]);
-            }
-            FUSED_TICK(2);
-            scan_list(lutb[b], start, pos0, len, 0.f);
-            // rs[b] was consumed by the build of probe pr (previous iteration): refill for pr+2
-            if (tid < d && pr + 2 < p1) rsb[b][tid] = rres;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) cw[w] = cwn[w];
+            for (int k = 0; k < NW; ++k) cw[k] = cwn[k];
+            t2 = t2n;
             __syncthreads();
-            FUSED_TICK(3);
         }
-    } else {
-        for (int pr = p0; pr < p1; ++pr) {
-            const int list = L.lst[pr];
-            const unsigned pos0 = L.pre[pr];
-            const unsigned len = (list < 0) ? 0u : L.pre[pr + 1] - pos0;
-            const int64_t start = L.lstart[pr];
-            float dis0 = 0.f;
-            if (METRIC == METRIC_L2) {
-                if (res_in_reg) {
-                    if (tid < d) L.rs[tid] = rres;
-                } else {
-                    const int l = max(list, 0);
-                    for (int cc = tid; cc < d; cc += FB)
-                        L.rs[cc] = p.xq[(int64_t)q * p.ldq + cc] - p.centroids[(int64_t)l * p.ldc + cc];
-                }
-                __syncthreads();
-                FUSED_TICK(1); // residual -> LDS + barrier
-                // in flight during the table build: next probe's residual, this probe's first codes
-                if (res_in_reg && tid < d && pr + 1 < p1) rres = residual_of(pr + 1);
-                fetch_codes(start, tid >> 2, len);
-                build_lut(lut, L.rs);
-                FUSED_TICK(2); // table build (this wave)
-                __syncthreads();
-                FUSED_TICK(3); // barrier after the build
-            } else {
-                dis0 = p.coarse_dis[(int64_t)q * p.nprobe + pr];
-                fetch_codes(start, tid >> 2, len);
-            }
-            scan_list(lut, start, pos0, len, dis0);
-            __syncthreads();
+        if (maxlen == 0) {
+            // nothing scanned this round (empty lists): the prefetch for the next round is still pending
+            fetch(pr + NG, (unsigned)lg, cw, t2);
         }
     }
     fused_finish(p, q, g, L);
-    FUSED_TICK(7); // final selection, id translation, sort, write-out
-    if (TIMING && p.dbg && tid == 0) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) atomicAdd(p.dbg + i, t_acc[i]);
-    }
-#undef FUSED_TICK
 }
 
 // ---------------------------------------------------------------------------------
@@ -514,8 +387,7 @@ bool ivf_fused_supported(int kind, int M, int dpad, int k, int nprobe, int* cap_
     if (cap > FMAXR * FB) return false;
     if (cap_out) *cap_out = cap;
     if (kp_out) *kp_out = kp;
-    // two lookup tables (build of probe p+1 overlapped with the scan of probe p) when they fit
-    int nlut = (kind == 1 && ivf_fused_lds_bytes(kind, M, dpad, kp, cap, nprobe, 2) <= 160 * 1024) ? 2 : 1;
+    const int nlut = 1; // one lookup table per query (see ivfpq_fused_kernel)
     if (nlut_out) *nlut_out = nlut;
     return ivf_fused_lds_bytes(kind, M, dpad, kp, cap, nprobe, nlut) <= 160 * 1024;
 }
@@ -538,32 +410,14 @@ void launch_ivf_fused(const IvfFusedParams& p, hipStream_t stream) {
         if (l2) launch_one(ivfflat_fused_kernel<METRIC_L2>, p, lds, stream);
         else launch_one(ivfflat_fused_kernel<METRIC_INNER_PRODUCT>, p, lds, stream);
     } else {
-        const bool regs = p.d <= 128 && (p.M % FPART) == 0 && p.dsub * p.M == p.d;
-        int ds = regs ? p.dsub : 0;
-        if (!(ds == 1 || ds == 2 || ds == 4 || ds == 8 || ds == 16 || ds == 32)) ds = 0;
-#define FA_PQ(DS)                                                                               \
-    do {                                                                                        \
-        if (l2) launch_one(ivfpq_fused_kernel<METRIC_L2, DS, false>, p, lds, stream);            \
-        else launch_one(ivfpq_fused_kernel<METRIC_INNER_PRODUCT, DS, false>, p, lds, stream);    \
-    } while (0)
-        if (p.M == 64 && ds == 2) {
-            // PQ64 on d = 128: compile-time M
-            if (p.dbg && l2) launch_one(ivfpq_fused_kernel<METRIC_L2, 2, true, true>, p, lds, stream); // phase timing
-            else if (l2) launch_one(ivfpq_fused_kernel<METRIC_L2, 2, true>, p, lds, stream);
-            else launch_one(ivfpq_fused_kernel<METRIC_INNER_PRODUCT, 2, true>, p, lds, stream);
-            HIP_CHECK(hipGetLastError());
-            return;
+        FA_THROW_IF_NOT_MSG(p.metric != METRIC_L2 || p.arena_t2, "IVFPQ L2 needs the per-vector t2 terms");
+        if (p.M == 64) {
+            if (l2) launch_one(ivfpq_fused_kernel<METRIC_L2, true>, p, lds, stream);
+            else launch_one(ivfpq_fused_kernel<METRIC_INNER_PRODUCT, true>, p, lds, stream);
+        } else {
+            if (l2) launch_one(ivfpq_fused_kernel<METRIC_L2, false>, p, lds, stream);
+            else launch_one(ivfpq_fused_kernel<METRIC_INNER_PRODUCT, false>, p, lds, stream);
         }
-        switch (ds) {
-            case 1: FA_PQ(1); break;
-            case 2: FA_PQ(2); break;
-            case 4: FA_PQ(4); break;
-            case 8: FA_PQ(8); break;
-            case 16: FA_PQ(16); break;
-            case 32: FA_PQ(32); break;
-            default: FA_PQ(0); break;
-        }
-#undef FA_PQ
     }
     HIP_CHECK(hipGetLastError());
 }

@@ -10,12 +10,15 @@
 //   IVFFlat L2 : dis = chain_k fmaf(q[k]-y[k], q[k]-y[k], acc), k ascending
 //                (direct form as the CPU scanner, faiss/utils/simd_impl/IVFFlatScanner-inl.h:20-27)
 //   IVFFlat IP : dis = chain_k fmaf(q[k], y[k], acc)
-//   IVFPQ  L2  : r = q - centroid;  lut[m][c] = chain_j fmaf(r_mj - pq[m][c][j], same, acc);
-//                dis = dis0 + ((p0 + p1) + (p2 + p3)),  p_j = sequential sum of lut[m][c_m] over the
-//                j-th quarter of the sub-quantizers (the four lanes that share a code in the fused scan)
+//   IVFPQ      : lut[m][c] = chain_j fmaf(q_mj, pq[m][c][j], acc)   (one table per query, both metrics)
+//                S = (p0 + p1) + (p2 + p3),  p_j = sequential sum of lut[m][c_m] over the j-th quarter of
+//                the sub-quantizers
+//   IVFPQ  L2  : dis = fmaf(-2, S, coarse_l2 + t2),  t2 = chain_k fmaf(r^_k, fmaf(2, c_k, r^_k), acc)
+//                (r^ = decoded residual, c = list centroid; term decomposition of
+//                 faiss/impl/pq_code_distance/IVFPQ_QueryTables.cpp:126-192)
 //                (faiss/gpu/impl/PQCodeDistances-inl.cuh:29-285 semantics, by_residual,
 //                 no precomputed table; CPU counterpart faiss/IndexIVFPQ.cpp scan_list_with_table)
-//   IVFPQ  IP  : lut[m][c] = chain_j fmaf(q_mj, pq[m][c][j], acc);  dis = coarse_ip + sum_m lut
+//   IVFPQ  IP  : dis = coarse_ip + S
 //   PQ encode  : code[m] = first argmin_c of the L2 lut expression above
 //                (faiss/impl/ProductQuantizer.cpp compute_code)
 #include "kernels.h"
@@ -121,11 +124,7 @@ __global__ void __launch_bounds__(256) ivfpq_scan_kernel(IvfScanParams p) {
     const uint32_t pos0 = p.prefix[(int64_t)q * (p.nprobe + 1) + pr];
     u64* out = p.keys + p.q_off[q] + pos0;
     const int d = p.d;
-    for (int c = threadIdx.x; c < d; c += blockDim.x) {
-        float v = p.xq[(int64_t)q * p.ldq + c];
-        if (METRIC == METRIC_L2) v = v - p.centroids[list * p.ldc + c];
-        rs[c] = v;
-    }
+    for (int c = threadIdx.x; c < d; c += blockDim.x) rs[c] = p.xq[(int64_t)q * p.ldq + c];
     __syncthreads();
     // ---- lookup table
     const int dsub = p.dsub;
@@ -134,19 +133,12 @@ __global__ void __launch_bounds__(256) ivfpq_scan_kernel(IvfScanParams p) {
         const float* cen = p.pq_centroids + (size_t)e * dsub; // [m][c][dsub]
         const float* r = rs + m * dsub;
         float acc = 0.f;
-        for (int jd = 0; jd < dsub; ++jd) {
-            if (METRIC == METRIC_L2) {
-                float t = r[jd] - cen[jd];
-                acc = __fmaf_rn(t, t, acc);
-            } else {
-                acc = __fmaf_rn(r[jd], cen[jd], acc);
-            }
-        }
+        for (int jd = 0; jd < dsub; ++jd) acc = __fmaf_rn(r[jd], cen[jd], acc);
         lut[e] = acc;
     }
     __syncthreads();
     // ---- scan: one code per thread
-    const float dis0 = METRIC == METRIC_L2 ? 0.f : p.coarse_dis[(int64_t)q * p.nprobe + pr];
+    const float dis0 = p.coarse_dis[(int64_t)q * p.nprobe + pr];
     const int M = p.M;
     for (unsigned i = threadIdx.x; i < len; i += blockDim.x) {
         const uint8_t* code = p.arena_codes + (start + i) * M;
@@ -160,7 +152,8 @@ __global__ void __launch_bounds__(256) ivfpq_scan_kernel(IvfScanParams p) {
             for (int m = jq * mq; m < (jq + 1) * mq; ++m) a = a + lut[m * 256 + code[m]];
             part[jq] = a;
         }
-        const float acc = dis0 + ((part[0] + part[1]) + (part[2] + part[3]));
+        const float sum = (part[0] + part[1]) + (part[2] + part[3]);
+        const float acc = METRIC == METRIC_L2 ? __fmaf_rn(-2.f, sum, dis0 + p.arena_t2[start + i]) : dis0 + sum;
         out[i] = ((u64)ordkey<METRIC>(acc) << 32) | (u64)(pos0 + i);
     }
 }
@@ -245,6 +238,35 @@ void launch_ivfpq_encode_append(const float* x, int64_t ldx, int n, int d, const
     hipLaunchKernelGGL(ivfpq_encode_append_kernel, dim3((unsigned)div_up(total, 256)), dim3(256), 0,
                        stream, x, ldx, n, d, labels, dest, centroids, ldc, M, dsub, pq_centroids,
                        arena_codes);
+    HIP_CHECK(hipGetLastError());
+}
+
+__global__ void ivfpq_t2_kernel(const uint8_t* __restrict__ codes, const int64_t* __restrict__ list_start,
+                                const uint32_t* __restrict__ list_len, const float* __restrict__ centroids,
+                                int64_t ldc, int M, int dsub, const float* __restrict__ pq, float* __restrict__ t2) {
+    const int l = blockIdx.x;
+    const int64_t start = list_start[l];
+    const unsigned len = list_len[l];
+    const float* cen = centroids + (int64_t)l * ldc;
+    for (unsigned i = threadIdx.x; i < len; i += blockDim.x) {
+        const uint8_t* code = codes + (start + i) * M;
+        float acc = 0.f;
+        for (int m = 0; m < M; ++m) {
+            const float* pc = pq + ((size_t)m * 256 + code[m]) * dsub;
+            for (int jd = 0; jd < dsub; ++jd) {
+                const float rv = pc[jd];
+                acc = __fmaf_rn(rv, __fmaf_rn(2.f, cen[m * dsub + jd], rv), acc);
+            }
+        }
+        t2[start + i] = acc;
+    }
+}
+void launch_ivfpq_t2(const uint8_t* arena_codes, const int64_t* list_start, const uint32_t* list_len, int nlist,
+                     const float* centroids, int64_t ldc, int M, int dsub, const float* pq_centroids, float* t2,
+                     hipStream_t stream) {
+    if (nlist == 0) return;
+    hipLaunchKernelGGL(ivfpq_t2_kernel, dim3((unsigned)nlist), dim3(256), 0, stream, arena_codes, list_start,
+                       list_len, centroids, ldc, M, dsub, pq_centroids, t2);
     HIP_CHECK(hipGetLastError());
 }
 

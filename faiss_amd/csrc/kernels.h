@@ -200,6 +200,7 @@ struct IvfScanParams {
     int M, dsub;
     const float* pq_centroids; // [M][256][dsub]
     const uint8_t* arena_codes; // [ntotal][M]
+    const float* arena_t2;      // [ntotal] L2: |r^|^2 + 2 <centroid, r^> of every stored vector
 };
 // One workgroup per (query, probe): direct sum((q-y)^2) over the list (L2) or dot (IP).
 // Replaces faiss/gpu/impl/IVFFlatScan.cu:135-183 / IVFInterleaved.cuh:33-224.
@@ -239,9 +240,7 @@ struct IvfFusedParams {
     int M, dsub;
     const float* pq_centroids;  // [M][256][dsub]
     const uint8_t* arena_codes; // [ntotal][M]
-    // optional phase timing (profiling hook, FAISS_AMD_FUSED_TIMING=1): 16 cycle counters summed over
-    // all workgroups by their thread 0
-    unsigned long long* dbg;
+    const float* arena_t2;      // [ntotal] L2: |r^|^2 + 2 <centroid, r^> of every stored vector
 };
 // One workgroup per (query, probe group): table build + code scan + running top-k all in LDS.
 // Replaces PQCodeDistances + PQScanMultiPassNoPrecomputed + IVFUtilsSelect{1,2} (IVFPQ) and
@@ -258,6 +257,12 @@ void launch_ivfpq_encode_append(const float* x, int64_t ldx, int n, int d, const
                                 const int64_t* dest, const float* centroids, int64_t ldc, int M,
                                 int dsub, const float* pq_centroids, uint8_t* arena_codes,
                                 hipStream_t stream);
+// t2[row] = chain_k fmaf(r^_k, fmaf(2, c_k, r^_k), acc) over k = 0..d-1 for every arena row: r^ = decoded PQ
+// residual, c = centroid of the row's list (one block per list).  The list-dependent term of the IVFPQ L2
+// distance (faiss/impl/pq_code_distance/IVFPQ_QueryTables.cpp:126-192, term 2), kept per vector.
+void launch_ivfpq_t2(const uint8_t* arena_codes, const int64_t* list_start, const uint32_t* list_len, int nlist,
+                     const float* centroids, int64_t ldc, int M, int dsub, const float* pq_centroids, float* t2,
+                     hipStream_t stream);
 // list relocation when the arena is rebuilt: list l's `len[l]` rows move from row old_start[l]
 // of src to row new_start[l] of dst (row = bytes_per_row bytes, multiple of 4)
 void launch_move_lists(const uint8_t* src, uint8_t* dst, const int64_t* old_start,

@@ -300,27 +300,21 @@ int orc_ivf_search(int kind, int metric, int d, int nlist, const float* centroid
             const uint32_t len = list_sizes[l];
             float dis0 = 0.f;
             if (kind == 1) {
-                /* lookup table for this (query, list); by_residual.
-                 * L2: tab[m][c] = |(x - centroid)_m - pq[m][c]|^2   IP: tab[m][c] = <x_m, pq[m][c]>,
-                 * dis0 = <x, centroid> = the coarse distance (faiss/IndexIVFPQ.cpp precompute_list_tables) */
-                const float* cen = centroids + (size_t)l * d;
-                for (int j = 0; j < d; j++) res[j] = metric == ORC_METRIC_L2 ? x[j] - cen[j] : x[j];
+                /* lookup table of the QUERY (both metrics): tab[m][c] = <x_m, pq[m][c]>; dis0 = the coarse
+                 * distance of (query, list).  L2 uses the term decomposition of the reference CPU index
+                 * (faiss/impl/pq_code_distance/IVFPQ_QueryTables.cpp:126-192, use_precomputed_table):
+                 *   |x - c - r^|^2 = |x - c|^2 + (|r^|^2 + 2 <c, r^>) - 2 <x, r^>
+                 * with the middle term t2 computed per stored vector. */
+                for (int j = 0; j < d; j++) res[j] = x[j];
                 for (int m = 0; m < M; m++) {
                     for (int c = 0; c < 256; c++) {
                         const float* pc = pq_centroids + ((size_t)m * 256 + c) * dsub;
                         float acc = 0.f;
-                        for (int j = 0; j < dsub; j++) {
-                            if (metric == ORC_METRIC_L2) {
-                                float tt = res[m * dsub + j] - pc[j];
-                                acc = fmaf(tt, tt, acc);
-                            } else {
-                                acc = fmaf(res[m * dsub + j], pc[j], acc);
-                            }
-                        }
+                        for (int j = 0; j < dsub; j++) acc = fmaf(res[m * dsub + j], pc[j], acc);
                         lut[m * 256 + c] = acc;
                     }
                 }
-                if (metric == ORC_METRIC_IP) dis0 = cD[(size_t)q * nprobe + p];
+                dis0 = cD[(size_t)q * nprobe + p];
             }
             for (uint32_t i = 0; i < len; i++) {
                 float dis;
@@ -356,7 +350,22 @@ int orc_ivf_search(int kind, int metric, int d, int nlist, const float* centroid
                         for (int m = 0; m < M; m++) acc = acc + lut[m * 256 + code[m]];
                         part[0] = acc;
                     }
-                    dis = dis0 + ((part[0] + part[1]) + (part[2] + part[3]));
+                    {
+                        const float sum = (part[0] + part[1]) + (part[2] + part[3]);
+                        if (metric == ORC_METRIC_L2) {
+                            /* t2 = |r^|^2 + 2 <c, r^> as one fmaf chain over the d coordinates */
+                            const float* cen = centroids + (size_t)l * d;
+                            float t2 = 0.f;
+                            for (int m = 0; m < M; m++) {
+                                const float* pc = pq_centroids + ((size_t)m * 256 + code[m]) * dsub;
+                                for (int j = 0; j < dsub; j++)
+                                    t2 = fmaf(pc[j], fmaf(2.f, cen[m * dsub + j], pc[j]), t2);
+                            }
+                            dis = fmaf(-2.f, sum, dis0 + t2);
+                        } else {
+                            dis = dis0 + sum;
+                        }
+                    }
                 }
                 pos2id[pos] = lid[i];
                 topk_push(&t, dis, pos); /* tie -> smaller scan position */

@@ -198,6 +198,15 @@ class RefIndex:
     def set_nprobe(self, nprobe):
         self._ck(self.lib.ref_ivf_set_nprobe(ctypes.c_void_p(self.h), ctypes.c_int(nprobe)))
 
+    def set_trained(self, centroids, pq_centroids):
+        """install coarse centroids [nlist, d] and a PQ codebook [M, 256, dsub] into an untrained IVFPQ index"""
+        c, pq = _f32(centroids), np.ascontiguousarray(pq_centroids, dtype=np.float32)
+        self._ck(self.lib.ref_ivfpq_set_trained(ctypes.c_void_p(self.h), _p(c), _p(pq)))
+
+    def set_train_niter(self, niter_coarse, niter_pq=0):
+        self._ck(self.lib.ref_ivf_set_train_niter(ctypes.c_void_p(self.h), ctypes.c_int(niter_coarse),
+                                                  ctypes.c_int(niter_pq)))
+
     @property
     def nlist(self):
         return self.lib.ref_ivf_nlist(ctypes.c_void_p(self.h))

@@ -216,6 +216,35 @@ int ref_ivfpq_set_precomputed_table(void* p, int use) {
     SHIM_CATCH
 }
 
+// copyTo in the other direction: install a trained state (coarse centroids nlist x d, PQ codebook
+// M x 256 x dsub) into an untrained reference IndexIVFPQ, so that a CPU baseline can run on exactly the
+// quantizers the GPU index trained (faiss/gpu/GpuIndexIVFPQ.cu:170-217 copyTo does the same).
+int ref_ivfpq_set_trained(void* p, const float* centroids, const float* pq_centroids) {
+    SHIM_TRY auto* i = dynamic_cast<faiss::IndexIVFPQ*>((faiss::Index*)p);
+    FAISS_THROW_IF_NOT_MSG(i, "not an IndexIVFPQ");
+    i->quantizer->reset();
+    i->quantizer->add(i->nlist, centroids);
+    i->quantizer->is_trained = true;
+    FAISS_THROW_IF_NOT(i->pq.centroids.size() == (size_t)i->pq.M * i->pq.ksub * i->pq.dsub);
+    memcpy(i->pq.centroids.data(), pq_centroids, sizeof(float) * i->pq.centroids.size());
+    i->is_trained = true;
+    i->use_precomputed_table = 0; // automatic choice, as after train()
+    i->precompute_table();
+    SHIM_CATCH
+}
+
+// k-means iteration counts of an untrained IVF(PQ) index: coarse quantizer (IndexIVF::cp) and product
+// quantizer (ProductQuantizer::cp); <= 0 leaves a value unchanged.  Used to bound the training time of
+// the CPU baseline (search speed does not depend on it).
+int ref_ivf_set_train_niter(void* p, int niter_coarse, int niter_pq) {
+    SHIM_TRY auto* ivf = dynamic_cast<faiss::IndexIVF*>((faiss::Index*)p);
+    FAISS_THROW_IF_NOT_MSG(ivf, "not an IndexIVF");
+    if (niter_coarse > 0) ivf->cp.niter = niter_coarse;
+    auto* pq = dynamic_cast<faiss::IndexIVFPQ*>(ivf);
+    if (pq && niter_pq > 0) pq->pq.cp.niter = niter_pq;
+    SHIM_CATCH
+}
+
 // k-means with the reference's own CPU assignment index; returns the final objective
 int ref_kmeans(int d, idx_t n, int k, const float* x, int niter, int seed, float* centroids, float* obj_out) {
     SHIM_TRY faiss::ClusteringParameters cp;
