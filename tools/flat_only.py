@@ -1,0 +1,22 @@
+#!/usr/bin/env python
+"""tools/flat_only.py -- GpuIndexFlatL2 search loop on the bench data (profiling target for PMC passes)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import faiss_amd
+from faiss_amd.datasets import synthetic_dataset
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+res = faiss_amd.StandardGpuResources(0)
+_, xb, xq = synthetic_dataset(128, 0, 1000000, 10000, seed=1338)
+idx = faiss_amd.GpuIndexFlatL2(res, 128)
+idx.add(xb)
+dev = torch.device("cuda", 0)
+xq_dev = torch.from_numpy(xq).to(dev)
+Dd = torch.empty((10000, 100), dtype=torch.float32, device=dev)
+Id = torch.empty((10000, 100), dtype=torch.int64, device=dev)
+idx.search_ptr(10000, xq_dev.data_ptr(), 100, Dd.data_ptr(), Id.data_ptr())
+torch.cuda.synchronize(); t0 = time.time()
+for _ in range(steps):
+    idx.search_ptr(10000, xq_dev.data_ptr(), 100, Dd.data_ptr(), Id.data_ptr())
+torch.cuda.synchronize()
+print("flat search: %.3f ms/step" % ((time.time() - t0) / steps * 1e3))
