@@ -25,6 +25,8 @@
 
 namespace faiss_amd {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 constexpr int FB = 1024;  // threads per workgroup (16 wavefronts, one workgroup per CU)
 constexpr int FPART = FB / 256; // codebook split over the threads: thread t owns centroid t & 255 of part t >> 8
 constexpr int FMAXR = 8;  // reservoir capacity <= FMAXR * FB keys
@@ -322,8 +324,20 @@ __global__ void __launch_bounds__(FB) ivfpq_fused_kernel(IvfFusedParams p) {
 }
 
 // ---------------------------------------------------------------------------------
-// IVFFlat: same reservoir machinery, distances straight from the fp32 rows of the list
+// IVFFlat: same reservoir machinery, exact distances straight from the fp32 rows of the lists.
+// The probed lists of a query are treated as ONE array of rows addressed by scan position (the
+// payload of the keys): every iteration takes the next 512 positions whatever list they fall in
+// (position -> (probe, offset) by a 5-step search of the prefix table in LDS).  Eight adjacent
+// lanes share a row: lane j reads the 16-byte chunks j, j+8, ... (each load instruction covers
+// one full 128-byte segment per row), keeps a partial fmaf chain over them and the eight partial
+// sums meet in an xor butterfly (order restated by oracle/faiss_oracle.c).  With 4 rows per lane
+// group in flight a 1024-thread workgroup keeps 256 KB of loads outstanding per iteration.
+// HBM-bound: nprobe * (nb / nlist) * d * 4 bytes per query, no reuse across queries.
 // ---------------------------------------------------------------------------------
+constexpr int FF_ROWS = 4;                   // rows per 8-lane group and iteration
+constexpr int FF_POS = FF_ROWS * (FB / 8);   // positions per iteration (512)
+constexpr int FF_QCH = 4;                    // query chunks kept in registers per lane (dpad <= 128)
+
 template <int METRIC>
 __global__ void __launch_bounds__(FB) ivfflat_fused_kernel(IvfFusedParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -331,49 +345,108 @@ __global__ void __launch_bounds__(FB) ivfflat_fused_kernel(IvfFusedParams p) {
     const int tid = threadIdx.x;
     const int q = blockIdx.x / p.G, g = blockIdx.x - q * p.G;
     const int p0 = g * p.npc, p1 = min(p.nprobe, p0 + p.npc);
+    const int ln = tid & 7;   // lane inside the row group
+    const int rg = tid >> 3;  // row group 0..127
 
     fused_load_probes(p, q, L);
     for (int cc = tid; cc < p.dpad; cc += FB) L.rs[cc] = p.xq[(int64_t)q * p.ldq + cc];
     __syncthreads();
+    const int nch = p.dpad >> 2;               // 16-byte chunks per row
+    const bool qreg = nch <= 8 * FF_QCH;       // this lane's query chunks fit the register copy
+    f32x4 qv[FF_QCH];
+#pragma unroll
+    for (int t = 0; t < FF_QCH; ++t) {
+        const int c4 = ln + 8 * t;
+        qv[t] = c4 < nch ? *(const f32x4*)(L.rs + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
+    const unsigned pos_begin = L.pre[p0], pos_end = L.pre[p1];
     u64 tau = ~0ull;
     int bound = 0;
-    for (int pr = p0; pr < p1; ++pr) {
-        const int list = L.lst[pr];
-        const unsigned pos0 = L.pre[pr];
-        const unsigned len = L.pre[pr + 1] - pos0;
-        if (list < 0 || len == 0) continue;
-        const int64_t start = L.lstart[pr];
-        for (unsigned base = 0; base < len; base += FB) {
-            FUSED_MAKE_ROOM(min((unsigned)FB, len - base));
-            const unsigned i = base + tid;
-            bool pass = false;
-            u64 key = 0;
-            if (i < len) {
-                const float* y = p.arena_vecs + (start + i) * p.ldv;
-                float acc = 0.f;
-                for (int k = 0; k < p.dpad; k += 4) {
-                    const float4 yv = *(const float4*)(y + k);
-                    const float4 qv = *(const float4*)(L.rs + k);
-                    if (METRIC == METRIC_L2) {
-                        float t;
-                        t = qv.x - yv.x; acc = __fmaf_rn(t, t, acc);
-                        t = qv.y - yv.y; acc = __fmaf_rn(t, t, acc);
-                        t = qv.z - yv.z; acc = __fmaf_rn(t, t, acc);
-                        t = qv.w - yv.w; acc = __fmaf_rn(t, t, acc);
-                    } else {
-                        acc = __fmaf_rn(qv.x, yv.x, acc);
-                        acc = __fmaf_rn(qv.y, yv.y, acc);
-                        acc = __fmaf_rn(qv.z, yv.z, acc);
-                        acc = __fmaf_rn(qv.w, yv.w, acc);
+    for (unsigned base = pos_begin; base < pos_end; base += FF_POS) {
+        FUSED_MAKE_ROOM(min((unsigned)FF_POS, pos_end - base));
+        float part[FF_ROWS];
+        unsigned posv[FF_ROWS];
+        const float* rowp[FF_ROWS];
+        // ---- rows of this iteration: position -> arena row
+#pragma unroll
+        for (int u = 0; u < FF_ROWS; ++u) {
+            const unsigned pos = base + u * (FB / 8) + rg;
+            posv[u] = pos;
+            rowp[u] = nullptr;
+            if (pos < pos_end) {
+                int lo = p0, hi = p1; // invariant pre[lo] <= pos < pre[hi]
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (L.pre[mid] <= pos) lo = mid;
+                    else hi = mid;
+                }
+                rowp[u] = p.arena_vecs + (L.lstart[lo] + (pos - L.pre[lo])) * p.ldv;
+            }
+        }
+        // ---- partial chains
+        if (qreg) {
+            f32x4 yv[FF_ROWS][FF_QCH];
+#pragma unroll
+            for (int u = 0; u < FF_ROWS; ++u)
+#pragma unroll
+                for (int t = 0; t < FF_QCH; ++t) {
+                    const int c4 = ln + 8 * t;
+                    yv[u][t] = (rowp[u] && c4 < nch) ? *(const f32x4*)(rowp[u] + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+            for (int u = 0; u < FF_ROWS; ++u) {
+                float a = 0.f;
+#pragma unroll
+                for (int t = 0; t < FF_QCH; ++t) {
+                    if (ln + 8 * t < nch) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (METRIC == METRIC_L2) {
+                                const float tt = qv[t][e] - yv[u][t][e];
+                                a = __fmaf_rn(tt, tt, a);
+                            } else {
+                                a = __fmaf_rn(qv[t][e], yv[u][t][e], a);
+                            }
+                        }
                     }
                 }
-                key = ((u64)ordkey<METRIC>(acc) << 32) | (u64)(pos0 + i);
-                pass = key < tau;
+                part[u] = a;
             }
-            wg_append(L.res, L.ctl, pass, key);
-            __syncthreads();
+        } else {
+#pragma unroll
+            for (int u = 0; u < FF_ROWS; ++u) {
+                float a = 0.f;
+                if (rowp[u]) {
+                    for (int c4 = ln; c4 < nch; c4 += 8) {
+                        const f32x4 y4 = *(const f32x4*)(rowp[u] + 4 * c4);
+                        const f32x4 q4 = *(const f32x4*)(L.rs + 4 * c4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (METRIC == METRIC_L2) {
+                                const float tt = q4[e] - y4[e];
+                                a = __fmaf_rn(tt, tt, a);
+                            } else {
+                                a = __fmaf_rn(q4[e], y4[e], a);
+                            }
+                        }
+                    }
+                }
+                part[u] = a;
+            }
         }
+        // ---- ((p0+p1)+(p2+p3)) + ((p4+p5)+(p6+p7)) in every lane of the group, append from lane 0
+#pragma unroll
+        for (int u = 0; u < FF_ROWS; ++u) {
+            float a = part[u];
+            a = a + __shfl_xor(a, 1, 64);
+            a = a + __shfl_xor(a, 2, 64);
+            a = a + __shfl_xor(a, 4, 64);
+            const u64 key = ((u64)ordkey<METRIC>(a) << 32) | (u64)posv[u];
+            const bool pass = rowp[u] != nullptr && ln == 0 && key < tau;
+            wg_append(L.res, L.ctl, pass, key);
+        }
+        __syncthreads();
     }
     fused_finish(p, q, g, L);
 }

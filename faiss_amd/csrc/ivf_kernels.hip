@@ -7,9 +7,10 @@
 // 288 GB of HBM be sized once.)
 //
 // Arithmetic contract (restated by oracle/faiss_oracle.c):
-//   IVFFlat L2 : dis = chain_k fmaf(q[k]-y[k], q[k]-y[k], acc), k ascending
-//                (direct form as the CPU scanner, faiss/utils/simd_impl/IVFFlatScanner-inl.h:20-27)
-//   IVFFlat IP : dis = chain_k fmaf(q[k], y[k], acc)
+//   IVFFlat L2 : eight partial fmaf chains of (q[k]-y[k])^2: chain ln runs over the 4-float chunks ln, ln+8, ...
+//                (direct form as the CPU scanner, faiss/utils/simd_impl/IVFFlatScanner-inl.h:20-27, which also
+//                keeps 8 partial sums); dis = ((p0+p1)+(p2+p3)) + ((p4+p5)+(p6+p7))
+//   IVFFlat IP : the same with chains of fmaf(q[k], y[k], acc)
 //   IVFPQ      : lut[m][c] = chain_j fmaf(q_mj, pq[m][c][j], acc)   (one table per query, both metrics)
 //                S = (p0 + p1) + (p2 + p3),  p_j = sequential sum of lut[m][c_m] over the j-th quarter of
 //                the sub-quantizers
@@ -71,23 +72,31 @@ __global__ void __launch_bounds__(256) ivfflat_scan_kernel(IvfScanParams p) {
     __syncthreads();
     for (unsigned i = threadIdx.x; i < len; i += blockDim.x) {
         const float* y = p.arena_vecs + (start + i) * p.ldv;
-        float acc = 0.f;
-        for (int k = 0; k < p.dpad; k += 4) {
-            const float4 yv = *(const float4*)(y + k);
-            const float4 qv = *(const float4*)(qs + k);
-            if (METRIC == METRIC_L2) {
-                float t;
-                t = qv.x - yv.x; acc = __fmaf_rn(t, t, acc);
-                t = qv.y - yv.y; acc = __fmaf_rn(t, t, acc);
-                t = qv.z - yv.z; acc = __fmaf_rn(t, t, acc);
-                t = qv.w - yv.w; acc = __fmaf_rn(t, t, acc);
-            } else {
-                acc = __fmaf_rn(qv.x, yv.x, acc);
-                acc = __fmaf_rn(qv.y, yv.y, acc);
-                acc = __fmaf_rn(qv.z, yv.z, acc);
-                acc = __fmaf_rn(qv.w, yv.w, acc);
+        // same order as the fused scan (ivf_fused.hip): partial sum ln over the 4-float chunks
+        // ln, ln+8, ... and a pairwise combination of the eight partial sums
+        float part[8];
+#pragma unroll
+        for (int ln = 0; ln < 8; ++ln) {
+            float a = 0.f;
+            for (int k = ln * 4; k < p.dpad; k += 32) {
+                const float4 yv = *(const float4*)(y + k);
+                const float4 qv = *(const float4*)(qs + k);
+                if (METRIC == METRIC_L2) {
+                    float t;
+                    t = qv.x - yv.x; a = __fmaf_rn(t, t, a);
+                    t = qv.y - yv.y; a = __fmaf_rn(t, t, a);
+                    t = qv.z - yv.z; a = __fmaf_rn(t, t, a);
+                    t = qv.w - yv.w; a = __fmaf_rn(t, t, a);
+                } else {
+                    a = __fmaf_rn(qv.x, yv.x, a);
+                    a = __fmaf_rn(qv.y, yv.y, a);
+                    a = __fmaf_rn(qv.z, yv.z, a);
+                    a = __fmaf_rn(qv.w, yv.w, a);
+                }
             }
+            part[ln] = a;
         }
+        const float acc = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
         out[i] = ((u64)ordkey<METRIC>(acc) << 32) | (u64)(pos0 + i);
     }
 }

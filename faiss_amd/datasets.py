@@ -9,16 +9,31 @@ recall is meaningful, unlike uniform noise in 128 dimensions.
 import numpy as np
 
 
-def synthetic_dataset(d, nt, nb, nq, seed=1338):
-    """Returns (xt, xb, xq) float32, identical to SyntheticDataset(d, nt, nb, nq, seed=seed)."""
+def synthetic_dataset(d, nt, nb, nq, seed=1338, return_map=False):
+    """Returns (xt, xb, xq) float32, identical to SyntheticDataset(d, nt, nb, nq, seed=seed).
+    return_map=True also returns (proj, scale), the random map of this dataset, for synthetic_more()."""
     d1 = 10  # intrinsic dimension (more or less)
     n = nb + nt + nq
     rs = np.random.RandomState(seed)
     x = rs.normal(size=(n, d1))
-    x = np.dot(x, rs.rand(d1, d))
-    x = x * (rs.rand(d) * 4 + 0.1)
+    proj = rs.rand(d1, d)
+    x = np.dot(x, proj)
+    scale = rs.rand(d) * 4 + 0.1
+    x = x * scale
     x = np.sin(x).astype("float32")
+    if return_map:
+        return x[:nt], x[nt:nt + nb], x[nt + nb:], (proj, scale)
     return x[:nt], x[nt:nt + nb], x[nt + nb:]
+
+
+def synthetic_more(dmap, n, seed):
+    """n further vectors of the SAME distribution as a synthetic_dataset(..., return_map=True) call (same
+    low-dimensional map, fresh latent draws): databases of 10M-1B rows are produced chunk by chunk
+    with seed = base + chunk, never materialised on the host at once."""
+    proj, scale = dmap
+    rs = np.random.RandomState(seed)
+    x = rs.normal(size=(n, proj.shape[0]))
+    return np.sin(np.dot(x, proj) * scale).astype("float32")
 
 
 def integer_dataset(d, nb, nq, seed=7, hi=16):

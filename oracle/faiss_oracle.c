@@ -319,17 +319,30 @@ int orc_ivf_search(int kind, int metric, int d, int nlist, const float* centroid
             for (uint32_t i = 0; i < len; i++) {
                 float dis;
                 if (kind == 0) {
+                    /* summation order of the GPU scan: eight lanes share a row, lane j owns the 4-float chunks
+                     * j, j+8, j+16, ... (one coalesced 128-byte segment per load instruction) and keeps a
+                     * sequential fmaf chain over them; the eight partial sums meet in an xor butterfly.
+                     * (The CPU reference keeps 8 AVX2 partial sums too, faiss/utils/distances_simd.cpp
+                     * fvec_L2sqr; the orders agree to fp32 rounding.) */
                     const float* y = (const float*)(lc + (size_t)i * code_size);
-                    float acc = 0.f;
-                    for (int j = 0; j < d; j++) {
-                        if (metric == ORC_METRIC_L2) {
-                            float tt = x[j] - y[j];
-                            acc = fmaf(tt, tt, acc);
-                        } else {
-                            acc = fmaf(x[j], y[j], acc);
+                    float part[8];
+                    for (int ln = 0; ln < 8; ln++) {
+                        float acc = 0.f;
+                        for (int c4 = ln; c4 * 4 < d; c4 += 8) {
+                            for (int e = 0; e < 4; e++) {
+                                const int j = c4 * 4 + e;
+                                if (j >= d) break;
+                                if (metric == ORC_METRIC_L2) {
+                                    float tt = x[j] - y[j];
+                                    acc = fmaf(tt, tt, acc);
+                                } else {
+                                    acc = fmaf(x[j], y[j], acc);
+                                }
+                            }
                         }
+                        part[ln] = acc;
                     }
-                    dis = acc;
+                    dis = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
                 } else {
                     const uint8_t* code = lc + (size_t)i * code_size;
                     /* ADC sum in the order of the GPU scan: four lanes own M/4 consecutive
