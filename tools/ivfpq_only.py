@@ -5,14 +5,22 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 import faiss_amd
-from faiss_amd.datasets import synthetic_dataset
+from faiss_amd.datasets import synthetic_dataset, synthetic_more
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 nb = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000
 metric = faiss_amd.METRIC_INNER_PRODUCT if len(sys.argv) > 3 and sys.argv[3] == "ip" else faiss_amd.METRIC_L2
 res = faiss_amd.StandardGpuResources(0)
-xt, xb, xq = synthetic_dataset(128, 100000, nb, 10000, seed=1338)
+t0 = time.time()
+xt, xb, xq, dmap = synthetic_dataset(128, 100000, min(nb, 1000000), 10000, seed=1338, return_map=True)
 idx = faiss_amd.GpuIndexIVFPQ(res, 128, 4096, 64, 8, metric)
 idx.train(xt); idx.add(xb); idx.nprobe = 32
+done, chunk = len(xb), 0
+while done < nb:  # BASELINE.json configs[3]: nb = 100M, generated and added chunk by chunk
+    chunk += 1
+    xbc = synthetic_more(dmap, min(2000000, nb - done), seed=1338 + chunk)
+    idx.add(xbc)
+    done += len(xbc)
+print("train+add of %d vectors: %.1fs" % (nb, time.time() - t0), flush=True)
 dev = torch.device("cuda", 0)
 xq_dev = torch.from_numpy(xq).to(dev)
 Dd = torch.empty((10000, 100), dtype=torch.float32, device=dev)
@@ -22,8 +30,13 @@ torch.cuda.synchronize(); t0 = time.time()
 for _ in range(steps):
     idx.search_ptr(10000, xq_dev.data_ptr(), 100, Dd.data_ptr(), Id.data_ptr())
 torch.cuda.synchronize()
+dt_step = (time.time() - t0) / steps
 print("ivfpq search (%s): %.3f ms/step" % ("ip" if metric == 0 else "l2", (time.time() - t0) / steps * 1e3))
 res.profile_enable(True); res.profile_reset()
 idx.search_ptr(10000, xq_dev.data_ptr(), 100, Dd.data_ptr(), Id.data_ptr())
 for kn in ("ivfpq_fused_kernel", "flat_scan_kernel", "select_k_kernel", "flat_filter_kernel", "flat_rerank_kernel"):
     print(kn, res.profile_get(kn))
+ms, n = res.profile_get("ivfpq_fused_kernel")
+bpq = 32.0 * nb / 4096.0 * 64
+print("ivfpq nb=%d: %.0f QPS; fused kernel %.3f ms = %.0f GB/s algorithmic code bytes (%.1f%% of 8 TB/s)" % (
+    nb, 10000 / dt_step, ms, bpq * 10000 / (ms * 1e-3) / 1e9, bpq * 10000 / (ms * 1e-3) / 8e12 * 100))
