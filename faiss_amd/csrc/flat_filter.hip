@@ -175,8 +175,7 @@ struct FqGeom {
     static constexpr int LBUF = QB == 4 ? 4096 : 1536;   // entries (expected: ~2 per query and split)
     static constexpr int LDS_BUFK = (LDS_THR + QPB * 4 + 15) & ~15; // u64 keys
     static constexpr int LDS_BUFQ = LDS_BUFK + LBUF * 8;           // u32 local query index
-    static constexpr int LDS_NBUF = LDS_BUFQ + LBUF * 4;           // u32 fill counter
-    static constexpr int LDS_TOTAL = LDS_NBUF + 16;
+    static constexpr int LDS_TOTAL = LDS_BUFQ + LBUF * 4;
 };
 
 // LDS-DMA issued from inline asm: hipcc makes every ds_read that follows a
@@ -252,20 +251,24 @@ __global__ void __launch_bounds__(FqGeom<QB>::THREADS, 2) flat_filter_kernel(Fla
         qrow[qb] = p.xqh + (int64_t)qc * p.ldqh;
     }
     unsigned* lcnt = (unsigned*)(smem + FQ_LDS_CNT);
-    // this wave's thresholds live in LDS (one ds_read per query block and 32-row block) rather than
-    // in registers: the 8-wave geometry has none to spare
-    const float* lthr = (const float*)(smem + G::LDS_THR) + wave * G::QPW + j;
+    // collect thresholds of this lane's queries: +inf for queries the filter cannot serve (flagged by
+    // the tighten kernel) and for idle lanes
+    float thr[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int q = qbase + qb * 32 + j;
+        thr[qb] = (MODE == MODE_COLLECT && q < p.nq) ? p.thr[q] : INFINITY;
+    }
     u64* lbufk = (u64*)(smem + G::LDS_BUFK);
     unsigned* lbufq = (unsigned*)(smem + G::LDS_BUFQ);
-    unsigned* lnbuf = (unsigned*)(smem + G::LDS_NBUF);
+    // every wave parks its candidates in its own slice of the LDS buffer: the fill count is a
+    // wave-uniform register and slots come from ballot prefix counts -- no LDS atomic round trip
+    constexpr int WBUF = G::LBUF / G::WAVES;
+    lbufk += wave * WBUF;
+    lbufq += wave * WBUF;
+    int wcnt = 0;
     if (MODE == MODE_COLLECT) {
-        if (tid == 0) *lnbuf = 0;
-        for (int i = tid; i < G::QPB; i += G::THREADS) {
-            lcnt[i] = 0;
-            const int q = grp * G::QPB + i;
-            // +inf for queries the filter cannot serve (flagged by the tighten kernel) and for idle lanes
-            ((float*)(smem + G::LDS_THR))[i] = q < p.nq ? p.thr[q] : INFINITY;
-        }
+        for (int i = tid; i < G::QPB; i += G::THREADS) lcnt[i] = 0;
     }
 
     float mx[QB][G::NCL];
@@ -337,9 +340,6 @@ __global__ void __launch_bounds__(FqGeom<QB>::THREADS, 2) flat_filter_kernel(Fla
 #pragma unroll
         for (int rp = 0; rp < G::RBP; ++rp) {
             const int rb = rbase + rp;
-            float thr[QB];
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb) thr[qb] = MODE == MODE_COLLECT ? lthr[qb * 32] : INFINITY;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -374,24 +374,32 @@ __global__ void __launch_bounds__(FqGeom<QB>::THREADS, 2) flat_filter_kernel(Fla
                         }
                     } else {
                         const float th = thr[qb];
-                        if ((tv[0] > th) | (tv[1] > th) | (tv[2] > th) | (tv[3] > th)) {
-                            // rare, divergent: one of these 4 rows beats the threshold of this lane's query
+                        // wave-wide masks of the rows that beat their query's threshold (v_cmp -> SGPR pair)
+                        u64 pm[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pm[e] = __ballot(tv[e] > th);
+                        if (pm[0] | pm[1] | pm[2] | pm[3]) {
+                            // rare, wave-uniform: some lane's query has a candidate among these 4 rows
                             const unsigned ql = wave * G::QPW + qb * 32 + j;
+                            const u64 lt = (1ull << lane) - 1ull;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                if (tv[e] > th) {
-                                    const int grow = tile_row0 + rb * 32 + 8 * g + 4 * h + e;
-                                    const u64 key = ((u64)score_key(tv[e]) << 32) | (unsigned)grow;
-                                    const unsigned pos = atomicAdd(lnbuf, 1u);
-                                    if (pos < (unsigned)G::LBUF) {
-                                        lbufk[pos] = key;
-                                        lbufq[pos] = ql;
-                                    } else {
-                                        // LDS buffer full (far more candidates than expected): straight to memory
-                                        const unsigned slot_ = atomicAdd(&lcnt[ql], 1u);
-                                        if (slot_ < (unsigned)p.cap)
-                                            p.res_keys[((int64_t)(grp * G::QPB + ql) * p.nsplit + split) * p.cap + slot_] = key;
+                                if (pm[e]) {
+                                    if (tv[e] > th) {
+                                        const int grow = tile_row0 + rb * 32 + 8 * g + 4 * h + e;
+                                        const u64 key = ((u64)score_key(tv[e]) << 32) | (unsigned)grow;
+                                        const int pos = wcnt + __popcll(pm[e] & lt);
+                                        if (pos < WBUF) {
+                                            lbufk[pos] = key;
+                                            lbufq[pos] = ql;
+                                        } else {
+                                            // slice full (far more candidates than expected): straight to memory
+                                            const unsigned slot_ = atomicAdd(&lcnt[ql], 1u);
+                                            if (slot_ < (unsigned)p.cap)
+                                                p.res_keys[((int64_t)(grp * G::QPB + ql) * p.nsplit + split) * p.cap + slot_] = key;
+                                        }
                                     }
+                                    wcnt += __popcll(pm[e]);
                                 }
                             }
                         }
@@ -501,8 +509,8 @@ __global__ void __launch_bounds__(FqGeom<QB>::THREADS, 2) flat_filter_kernel(Fla
     } else if (MODE == MODE_COLLECT) {
         // (the last loop iteration ended with a barrier: every append of the workgroup is visible)
         // flush the parked candidates to their (query, split) segments
-        const unsigned nbuf = min(*lnbuf, (unsigned)G::LBUF);
-        for (unsigned i = tid; i < nbuf; i += G::THREADS) {
+        const int nmine = min(wcnt, WBUF); // this wave's slice
+        for (int i = lane; i < nmine; i += 64) {
             const unsigned ql = lbufq[i];
             const unsigned slot_ = atomicAdd(&lcnt[ql], 1u);
             if (slot_ < (unsigned)p.cap)
