@@ -146,9 +146,6 @@ void launch_max_f32(const float* x, int64_t n, unsigned* out_bits, hipStream_t s
 constexpr int FQ_TR = 64;            // rows per tile
 constexpr int FQ_KS = 128;           // halfs per k-slab
 constexpr int FQ_TILE_BYTES = FQ_TR * FQ_KS * 2; // 16384
-constexpr int FQ_NBUF = 3;                       // LDS ring: tile u computes while u+1, u+2 are in flight
-constexpr int FQ_LDS_BIAS = FQ_NBUF * FQ_TILE_BYTES;
-constexpr int FQ_LDS_CNT = FQ_LDS_BIAS + FQ_NBUF * FQ_TR * 4; // [queries per workgroup] append counters
 constexpr int MODE_MAX = 0, MODE_COLLECT = 1, MODE_DUMP = 2;
 
 // Two geometries share the code (QB = 32-query MFMA column blocks per wave):
@@ -168,12 +165,18 @@ struct FqGeom {
     static constexpr int NCL = QB == 4 ? 4 : 8;  // running maxima (position classes) per lane and query
     static constexpr int CPS = 2 * NCL;          // chunk maxima per (query, split)
     static constexpr int DMA_ROWS = 16 / WAVES;  // 1 KB row-chunk DMAs per wave and tile
-    static constexpr int LDS_THR = FQ_LDS_CNT + QPB * 4; // [queries per workgroup] collect thresholds
+    // steps (tiles) between two workgroup barriers.  Measured on the 8-wave geometry: 2 tiles per
+    // barrier (6-slot ring) = 1 tile per barrier within noise, and so is a static s_setprio for one
+    // half of the waves -- the barrier is not what holds the matrix pipe at ~30 % in the collect pass
+    static constexpr int TPB = 1;
+    static constexpr int RING = 3 * TPB;         // LDS ring slots: TPB computing, 2 * TPB in flight
+    static constexpr int LDS_BIAS = RING * FQ_TILE_BYTES;
+    static constexpr int LDS_CNT = LDS_BIAS + RING * FQ_TR * 4; // [queries per workgroup] append counters
     // collect pass: candidates are parked in LDS and written to their (query, split) segments once,
     // after the last tile -- a global store inside the loop would share the vmcnt counter with the
     // LDS-DMA prefetch and every counted wait behind it would drain the ring
     static constexpr int LBUF = QB == 4 ? 4096 : 1536;   // entries (expected: ~2 per query and split)
-    static constexpr int LDS_BUFK = (LDS_THR + QPB * 4 + 15) & ~15; // u64 keys
+    static constexpr int LDS_BUFK = (LDS_CNT + QPB * 4 + 15) & ~15; // u64 keys
     static constexpr int LDS_BUFQ = LDS_BUFK + LBUF * 8;           // u32 local query index
     static constexpr int LDS_TOTAL = LDS_BUFQ + LBUF * 4;
 };
@@ -250,7 +253,7 @@ __global__ void __launch_bounds__(FqGeom<QB>::THREADS, 2) flat_filter_kernel(Fla
         const int qc = qvalid[qb] ? q : p.nq - 1;
         qrow[qb] = p.xqh + (int64_t)qc * p.ldqh;
     }
-    unsigned* lcnt = (unsigned*)(smem + FQ_LDS_CNT);
+    unsigned* lcnt = (unsigned*)(smem + G::LDS_CNT);
     // collect thresholds of this lane's queries: +inf for queries the filter cannot serve (flagged by
     // the tighten kernel) and for idle lanes
     float thr[QB];
@@ -317,7 +320,7 @@ __global__ void __launch_bounds__(FqGeom<QB>::THREADS, 2) flat_filter_kernel(Fla
         if (METRIC == METRIC_L2) {
             // rows past the end of the database re-read the last row (masked in the epilogue)
             const int grow = min(row0 + lane, p.nb - 1);
-            glds4(p.xbhn + grow, lds_base + FQ_LDS_BIAS + slot * FQ_TR * 4);
+            glds4(p.xbhn + grow, lds_base + G::LDS_BIAS + slot * FQ_TR * 4);
         }
     };
 
@@ -334,7 +337,7 @@ __global__ void __launch_bounds__(FqGeom<QB>::THREADS, 2) flat_filter_kernel(Fla
     // epilogue of the 32-row block(s) held in acc: rbase = first block index (0 or 1).  Loop order
     // (4-row group outermost) keeps only one bias quad and four scores live at a time.
     auto epilogue = [&](int tl, int slot, int rbase) {
-        const float* bias = (const float*)(smem + FQ_LDS_BIAS) + slot * FQ_TR;
+        const float* bias = (const float*)(smem + G::LDS_BIAS) + slot * FQ_TR;
         const int tile_row0 = tile_row0_of(tl);
         const bool partial = tile_row0 + FQ_TR > p.nb; // wave-uniform
 #pragma unroll
@@ -409,32 +412,10 @@ __global__ void __launch_bounds__(FqGeom<QB>::THREADS, 2) flat_filter_kernel(Fla
         }
     };
 
-    // The two waves that share a SIMD (8-wave geometry) run in lockstep behind the per-tile barrier and
-    // would both sit in the VALU epilogue with the matrix pipe idle; a static priority for one half
-    // staggers the pair (cdna_hip_programming.md T5, static form).
-    if (G::WAVES == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
-
-    load_b(0);
-    // every compiler-visible load lands BEFORE the first hidden DMA is issued (vmcnt(0), the other
-    // counters untouched): from here on the compiler's own scoreboard holds no pending load and it
-    // inserts no counted vmcnt wait into the loop, which would also wait for the younger DMAs
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    stage(0, 0);
-    if (nsteps > 1) {
-        stage(1, 1);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_STAGE) : "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-
-    int slot = 0; // u % 3
-    for (int u = 0; u < nsteps; ++u) {
+    // one step: the MFMAs of tile/slab u out of ring slot `slot`, and the epilogue behind its last slab
+    auto compute = [&](int u, int slot) __attribute__((always_inline)) {
         const int tl = u / nslab, sl = u - tl * nslab;
         if (!SINGLE && u > 0) load_b(sl);
-        const int slot2 = slot >= 1 ? slot - 1 : 2; // (u + 2) % 3
-        if (u + 2 < nsteps) stage(u + 2, slot2);
-
         const char* tile = smem + slot * FQ_TILE_BYTES;
         const int sw = j & 15;
         if (G::RBP == 2) {
@@ -487,12 +468,37 @@ __global__ void __launch_bounds__(FqGeom<QB>::THREADS, 2) flat_filter_kernel(Fla
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // tile u+1 must have landed (this wave's share) before anybody passes the barrier;
-        // the DMAs of tile u+2 stay in flight across it
-        if (u + 2 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_STAGE) : "memory");
+    };
+
+    load_b(0);
+    // every compiler-visible load lands BEFORE the first hidden DMA is issued (vmcnt(0), the other
+    // counters untouched): from here on the compiler's own scoreboard holds no pending load and it
+    // inserts no counted vmcnt wait into the loop, which would also wait for the younger DMAs
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    // ring: group g (TPB steps) lives in slots (g % 3) * TPB ..; groups g+1 and g+2 are in flight while g computes
+    constexpr int TPB = G::TPB;
+#pragma unroll
+    for (int t = 0; t < 2 * TPB; ++t)
+        if (t < nsteps) stage(t, t);
+    if (nsteps >= 2 * TPB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_STAGE * TPB) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int gslot = 0; // (u / TPB) % 3
+    for (int u = 0; u < nsteps; u += TPB) {
+        const int gslot2 = gslot >= 1 ? gslot - 1 : 2; // ring position of the group two ahead
+#pragma unroll
+        for (int t = 0; t < TPB; ++t)
+            if (u + 2 * TPB + t < nsteps) stage(u + 2 * TPB + t, gslot2 * TPB + t);
+#pragma unroll
+        for (int t = 0; t < TPB; ++t)
+            if (u + t < nsteps) compute(u + t, gslot * TPB + t);
+        // the next group must have landed (this wave's share) before anybody passes the barrier; a
+        // complete group issued above stays in flight across it
+        if (u + 3 * TPB <= nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_STAGE * TPB) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        slot = slot == 2 ? 0 : slot + 1;
+        gslot = gslot == 2 ? 0 : gslot + 1;
     }
 
     if (MODE == MODE_MAX) {
