@@ -202,6 +202,32 @@ __device__ __forceinline__ void glds4(const void* gsrc, unsigned lds_dst) {
             : "v"(gsrc), "s"(lds_dst)
             : "memory");
 }
+// a wave-uniform pointer, forced into an SGPR pair (the register allocator may have computed it on the VALU)
+__device__ __forceinline__ const char* uniform_ptr(const char* ptr) {
+    const unsigned long long v = (unsigned long long)ptr;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const char*)(((unsigned long long)hi << 32) | lo);
+}
+// same, scalar 64-bit base + 32-bit per-lane byte offset (no address VGPR pair, no per-tile address math).
+// The leading s_nop 4 covers the SALU-write -> VMEM-read hazard on the base SGPRs, which hipcc cannot
+// see inside an asm statement (cdna_hip_programming.md 5.7, item 2).
+__device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+            "s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(voff), "s"(sbase), "s"(lds_dst)
+            : "memory");
+}
+__device__ __forceinline__ void glds4_s(const void* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+            "s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(voff), "s"(sbase), "s"(lds_dst)
+            : "memory");
+}
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
 }
@@ -300,28 +326,33 @@ __global__ void __launch_bounds__(FqGeom<QB>::THREADS, 2) flat_filter_kernel(Fla
         return;
     }
 
-    // ---- LDS-DMA staging of step u (tile u / nslab, slab u % nslab) into ring slot u % 3:
-    // 16 x 1 KB of row chunks over the waves + (every wave, redundantly, so that all waves count
-    // the same number of DMAs) the 64 per-row biases |y|^2 / 2
+    // ---- LDS-DMA staging of step u (tile u / nslab, slab u % nslab) into a ring slot: 16 x 1 KB of
+    // row chunks over the waves + (every wave, redundantly, so that all waves count the same number
+    // of DMAs) the 64 per-row biases.  Addressing: a wave-uniform 64-bit base per tile (SGPRs) plus a
+    // per-lane 32-bit offset that never changes (row-in-tile, swizzled chunk).  The fp16 rows and the
+    // bias array are padded by one tile past the last row (the bias padding is +inf, which sends the
+    // score of a row beyond the end to -inf), so no clamping and no masking anywhere.
     const unsigned lds_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
-    constexpr int DMA_PER_STAGE = G::DMA_ROWS + (METRIC == METRIC_L2 ? 1 : 0);
-    auto stage = [&](int u, int slot) {
-        const int tl = u / nslab, sl = u - tl * nslab;
-        const int row0 = tile_row0_of(tl);
+    constexpr int DMA_PER_STAGE = G::DMA_ROWS + 1;
+    unsigned voff[G::DMA_ROWS];
 #pragma unroll
-        for (int i = 0; i < G::DMA_ROWS; ++i) {
-            const int g = (wave * G::DMA_ROWS + i) * 64 + lane; // 16-byte chunk of the LDS image
-            const int row = g >> 4, cpos = g & 15;
-            const int c = cpos ^ (row & 15);                    // chunk of the source row that lands there
-            const int grow = min(row0 + row, p.nb - 1);
-            const _Float16* src = p.xbh + (int64_t)grow * p.ldbh + sl * FQ_KS + c * 8;
-            glds16(src, lds_base + slot * FQ_TILE_BYTES + (wave * G::DMA_ROWS + i) * 1024);
-        }
-        if (METRIC == METRIC_L2) {
-            // rows past the end of the database re-read the last row (masked in the epilogue)
-            const int grow = min(row0 + lane, p.nb - 1);
-            glds4(p.xbhn + grow, lds_base + G::LDS_BIAS + slot * FQ_TR * 4);
-        }
+    for (int i = 0; i < G::DMA_ROWS; ++i) {
+        const int g = (wave * G::DMA_ROWS + i) * 64 + lane; // 16-byte chunk of the LDS image
+        const int row = g >> 4, cpos = g & 15;
+        const int c = cpos ^ (row & 15);                    // chunk of the source row that lands there
+        voff[i] = (unsigned)(row * (int)p.ldbh * 2 + c * 16);
+    }
+    const unsigned voff_b = (unsigned)lane * 4u;
+    auto stage = [&](int u_, int slot_) __attribute__((always_inline)) {
+        // (wave-uniform by construction; spelled out because the asm operands below must be SGPRs)
+        const int u = __builtin_amdgcn_readfirstlane(u_), slot = __builtin_amdgcn_readfirstlane(slot_);
+        const int tl = u / nslab, sl = u - tl * nslab;
+        const int row0 = __builtin_amdgcn_readfirstlane(tile_row0_of(tl));
+        const char* sb = uniform_ptr((const char*)p.xbh + ((int64_t)row0 * p.ldbh + sl * FQ_KS) * 2);
+#pragma unroll
+        for (int i = 0; i < G::DMA_ROWS; ++i)
+            glds16_s(sb, voff[i], lds_base + slot * FQ_TILE_BYTES + (wave * G::DMA_ROWS + i) * 1024);
+        glds4_s(uniform_ptr((const char*)(p.xbhn + row0)), voff_b, lds_base + G::LDS_BIAS + slot * FQ_TR * 4);
     };
 
     half8 bq[QB][8];
@@ -339,22 +370,12 @@ __global__ void __launch_bounds__(FqGeom<QB>::THREADS, 2) flat_filter_kernel(Fla
     auto epilogue = [&](int tl, int slot, int rbase) {
         const float* bias = (const float*)(smem + G::LDS_BIAS) + slot * FQ_TR;
         const int tile_row0 = tile_row0_of(tl);
-        const bool partial = tile_row0 + FQ_TR > p.nb; // wave-uniform
 #pragma unroll
         for (int rp = 0; rp < G::RBP; ++rp) {
             const int rb = rbase + rp;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (METRIC == METRIC_L2) b4 = *(const f32x4*)(bias + rb * 32 + 8 * g + 4 * h);
-                if (partial) {
-                    // last tile of the database: the rows past the end re-read row nb-1; they must not
-                    // count (a duplicated row would appear in several chunk maxima and lift the threshold
-                    // above the true k-th best score): an infinite bias sends their score to -inf
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (tile_row0 + rb * 32 + 8 * g + 4 * h + e >= p.nb) b4[e] = INFINITY;
-                }
+                const f32x4 b4 = *(const f32x4*)(bias + rb * 32 + 8 * g + 4 * h);
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb) {
                     float tv[4];
@@ -396,10 +417,17 @@ __global__ void __launch_bounds__(FqGeom<QB>::THREADS, 2) flat_filter_kernel(Fla
                                             lbufk[pos] = key;
                                             lbufq[pos] = ql;
                                         } else {
-                                            // slice full (far more candidates than expected): straight to memory
-                                            const unsigned slot_ = atomicAdd(&lcnt[ql], 1u);
+                                            // slice full before the loop could be left for a flush (a tile
+                                            // with far more candidates than expected): straight to the
+                                            // segment in HBM.  The operands are made opaque so that no part
+                                            // of the address computation is hoisted out of this rare branch
+                                            // into registers that would live across the whole loop.
+                                            const u64* rk = p.res_keys;
+                                            unsigned qlo = ql;
+                                            asm volatile("" : "+s"(rk), "+v"(qlo));
+                                            const unsigned slot_ = atomicAdd(&lcnt[qlo], 1u);
                                             if (slot_ < (unsigned)p.cap)
-                                                p.res_keys[((int64_t)(grp * G::QPB + ql) * p.nsplit + split) * p.cap + slot_] = key;
+                                                const_cast<u64*>(rk)[((int64_t)(grp * G::QPB + qlo) * p.nsplit + split) * p.cap + slot_] = key;
                                         }
                                     }
                                     wcnt += __popcll(pm[e]);
@@ -484,21 +512,46 @@ __global__ void __launch_bounds__(FqGeom<QB>::THREADS, 2) flat_filter_kernel(Fla
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    // this wave's parked candidates -> their (query, split) segments in HBM.  Wave-private (own slice, own
+    // queries' counters), so it needs no barrier; it sits OUTSIDE the hot loop (the loop is left and
+    // re-entered around it) so that none of its addresses is kept in registers across the tiles.
+    auto flush = [&]() __attribute__((always_inline)) {
+        const int nmine = min(wcnt, WBUF);
+        for (int i = lane; i < nmine; i += 64) {
+            const unsigned ql = lbufq[i];
+            const unsigned slot_ = atomicAdd(&lcnt[ql], 1u);
+            if (slot_ < (unsigned)p.cap)
+                p.res_keys[((int64_t)(grp * G::QPB + ql) * p.nsplit + split) * p.cap + slot_] = lbufk[i];
+        }
+        wcnt = 0;
+    };
+    constexpr int WFLUSH = WBUF * 3 / 4;
+
     int gslot = 0; // (u / TPB) % 3
-    for (int u = 0; u < nsteps; u += TPB) {
-        const int gslot2 = gslot >= 1 ? gslot - 1 : 2; // ring position of the group two ahead
+    int u = 0;
+    while (u < nsteps) {
+        do {
+            const int gslot2 = gslot >= 1 ? gslot - 1 : 2; // ring position of the group two ahead
 #pragma unroll
-        for (int t = 0; t < TPB; ++t)
-            if (u + 2 * TPB + t < nsteps) stage(u + 2 * TPB + t, gslot2 * TPB + t);
+            for (int t = 0; t < TPB; ++t)
+                if (u + 2 * TPB + t < nsteps) stage(u + 2 * TPB + t, gslot2 * TPB + t);
 #pragma unroll
-        for (int t = 0; t < TPB; ++t)
-            if (u + t < nsteps) compute(u + t, gslot * TPB + t);
-        // the next group must have landed (this wave's share) before anybody passes the barrier; a
-        // complete group issued above stays in flight across it
-        if (u + 3 * TPB <= nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_STAGE * TPB) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        gslot = gslot == 2 ? 0 : gslot + 1;
+            for (int t = 0; t < TPB; ++t)
+                if (u + t < nsteps) compute(u + t, gslot * TPB + t);
+            // the next group must have landed (this wave's share) before anybody passes the barrier; a
+            // complete group issued above stays in flight across it
+            if (u + 3 * TPB <= nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_STAGE * TPB) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            gslot = gslot == 2 ? 0 : gslot + 1;
+            u += TPB;
+        } while (u < nsteps && (MODE != MODE_COLLECT || wcnt <= WFLUSH));
+        if (MODE == MODE_COLLECT) {
+            // slice three quarters full (wave-uniform) or scan finished
+            // (its stores share the vector-memory counter with the DMAs the loop counts; loads complete in
+            // order among themselves, so extra younger stores only make the counted waits conservative)
+            flush();
+        }
     }
 
     if (MODE == MODE_MAX) {
@@ -513,15 +566,7 @@ __global__ void __launch_bounds__(FqGeom<QB>::THREADS, 2) flat_filter_kernel(Fla
             }
         }
     } else if (MODE == MODE_COLLECT) {
-        // (the last loop iteration ended with a barrier: every append of the workgroup is visible)
-        // flush the parked candidates to their (query, split) segments
-        const int nmine = min(wcnt, WBUF); // this wave's slice
-        for (int i = lane; i < nmine; i += 64) {
-            const unsigned ql = lbufq[i];
-            const unsigned slot_ = atomicAdd(&lcnt[ql], 1u);
-            if (slot_ < (unsigned)p.cap)
-                p.res_keys[((int64_t)(grp * G::QPB + ql) * p.nsplit + split) * p.cap + slot_] = lbufk[i];
-        }
+        // every wave flushed its slice when it left the loop
         __syncthreads();
         for (int i = tid; i < G::QPB; i += G::THREADS) {
             const int q = grp * G::QPB + i;

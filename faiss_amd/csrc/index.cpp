@@ -182,7 +182,8 @@ void GpuIndexFlat::add(idx_t n, const float* x) {
     const size_t row = (size_t)dpad_ * sizeof(float);
     xb_.ensure((size_t)(ntotal + n) * row, (size_t)ntotal * row, res_->stream);
     xbn_.ensure((size_t)(ntotal + n) * sizeof(float), (size_t)ntotal * sizeof(float), res_->stream);
-    xbh_.ensure((size_t)(ntotal + n) * dh_ * 2, (size_t)ntotal * dh_ * 2, res_->stream);
+    // one tile of padding rows behind the last one: the filter kernel reads whole 64-row tiles
+    xbh_.ensure((size_t)(ntotal + n + kFilterTileRows) * dh_ * 2, (size_t)ntotal * dh_ * 2, res_->stream);
     xbhn_.ensure((size_t)(ntotal + n + kFilterTileRows) * sizeof(float), (size_t)ntotal * sizeof(float), res_->stream);
     // page the upload so the raw staging buffer stays bounded (reference: GpuIndex.cu:197-217)
     const idx_t page = std::max<idx_t>(1, ((idx_t)256 << 20) / ((idx_t)d * 4));
