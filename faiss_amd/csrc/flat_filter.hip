@@ -82,12 +82,13 @@ void launch_convert_f16(const float* src, int64_t ld_src, int64_t n, int d, void
     HIP_CHECK(hipGetLastError());
 }
 
-// out[i] = |y_i|^2 / 2 (L2) or 0 (IP) for i < n, +inf for the npad entries that follow
+// out[i] = -|y_i|^2 / 2 (L2) or 0 (IP) for i < n, -inf for the npad entries that follow: the value the
+// filter kernel's accumulators START from (score = <q,y> - |y|^2/2; rows past the end can never qualify)
 __global__ void half_norms_kernel(const float* __restrict__ xn, int64_t n, int npad, int metric,
                                   float* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = metric == METRIC_L2 ? 0.5f * xn[i] : 0.f;
-    else if (i < n + npad) out[i] = INFINITY;
+    if (i < n) out[i] = metric == METRIC_L2 ? -0.5f * xn[i] : 0.f;
+    else if (i < n + npad) out[i] = -INFINITY;
 }
 void launch_half_norms(const float* xn, int64_t n, int npad, int metric, float* out, hipStream_t stream) {
     if (n + npad == 0) return;
@@ -172,13 +173,16 @@ struct FqGeom {
     static constexpr int RING = 3 * TPB;         // LDS ring slots: TPB computing, 2 * TPB in flight
     static constexpr int LDS_BIAS = RING * FQ_TILE_BYTES;
     static constexpr int LDS_CNT = LDS_BIAS + RING * FQ_TR * 4; // [queries per workgroup] append counters
-    // collect pass: candidates are parked in LDS and written to their (query, split) segments once,
-    // after the last tile -- a global store inside the loop would share the vmcnt counter with the
-    // LDS-DMA prefetch and every counted wait behind it would drain the ring
-    static constexpr int LBUF = QB == 4 ? 4096 : 1536;   // entries (expected: ~2 per query and split)
-    static constexpr int LDS_BUFK = (LDS_CNT + QPB * 4 + 15) & ~15; // u64 keys
-    static constexpr int LDS_BUFQ = LDS_BUFK + LBUF * 8;           // u32 local query index
-    static constexpr int LDS_TOTAL = LDS_BUFQ + LBUF * 4;
+    static constexpr int LDS_THR = LDS_CNT + QPB * 4;           // [queries per workgroup] collect thresholds
+    // collect pass: a lane whose 16 scores of one (query, 32-row block) hold a candidate parks the
+    // whole 16-score fragment in its wave's LDS slice; the slices are sifted and written to the
+    // (query, split) segments outside the tile loop (a global store inside the loop would share
+    // the vmcnt counter with the LDS-DMA prefetch, and per-score work inside it costs more VALU
+    // time than the MFMAs take)
+    static constexpr int WBLK = QB == 4 ? 128 : 96;              // parked fragments per wave
+    static constexpr int LDS_BLKV = (LDS_THR + QPB * 4 + 15) & ~15; // [WAVES][WBLK][16] scores
+    static constexpr int LDS_BLKM = LDS_BLKV + WAVES * WBLK * 64;   // [WAVES][WBLK] {first row, local query}
+    static constexpr int LDS_TOTAL = LDS_BLKM + WAVES * WBLK * 8;
 };
 
 // LDS-DMA issued from inline asm: hipcc makes every ds_read that follows a
@@ -227,6 +231,22 @@ __device__ __forceinline__ void glds4_s(const void* sbase, unsigned voff, unsign
             : "=&s"(keep)
             : "v"(voff), "s"(sbase), "s"(lds_dst)
             : "memory");
+}
+// max(a, b, c) in one VALU instruction.  fmaxf() compiles to a canonicalising v_max_f32 x, x per operand
+// on top of the maximum itself; the scores here are MFMA outputs (never signalling NaNs), and a quiet NaN
+// operand is dropped by the hardware maximum like fmaxf drops it.
+// The compiler's hazard recogniser does not look into asm statements, and the hardware does not interlock
+// a VALU read of a register an MFMA is still writing: max3() consumers of accumulators sit behind
+// mfma_results_ready(), and all of them are volatile so that they stay behind it.
+__device__ __forceinline__ float max3(float a, float b, float c) {
+    float r;
+    asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// 20 wait states after the youngest MFMA that wrote one of the given accumulators (the ISA asks for 19
+// between a 16-pass XDL write and a VALU read, 11 for 8 passes)
+__device__ __forceinline__ void mfma_results_ready(const f32x16& a, const f32x16& b, const f32x16& c, const f32x16& d) {
+    asm volatile("s_nop 15\n\ts_nop 3" ::"v"(a), "v"(b), "v"(c), "v"(d));
 }
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
@@ -288,16 +308,19 @@ __global__ void __launch_bounds__(FqGeom<QB>::THREADS, 2) flat_filter_kernel(Fla
         const int q = qbase + qb * 32 + j;
         thr[qb] = (MODE == MODE_COLLECT && q < p.nq) ? p.thr[q] : INFINITY;
     }
-    u64* lbufk = (u64*)(smem + G::LDS_BUFK);
-    unsigned* lbufq = (unsigned*)(smem + G::LDS_BUFQ);
-    // every wave parks its candidates in its own slice of the LDS buffer: the fill count is a
-    // wave-uniform register and slots come from ballot prefix counts -- no LDS atomic round trip
-    constexpr int WBUF = G::LBUF / G::WAVES;
-    lbufk += wave * WBUF;
-    lbufq += wave * WBUF;
+    // every wave parks fragments in its own slice: the fill count is a wave-uniform register and
+    // slots come from ballot prefix counts -- no LDS atomic round trip
+    constexpr int WBLK = G::WBLK;
+    float* lthr = (float*)(smem + G::LDS_THR);
+    float* lblkv = (float*)(smem + G::LDS_BLKV) + wave * WBLK * 16;
+    int2* lblkm = (int2*)(smem + G::LDS_BLKM) + wave * WBLK;
     int wcnt = 0;
     if (MODE == MODE_COLLECT) {
         for (int i = tid; i < G::QPB; i += G::THREADS) lcnt[i] = 0;
+        if (h == 0) {
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) lthr[wave * G::QPW + qb * 32 + j] = thr[qb];
+        }
     }
 
     float mx[QB][G::NCL];
@@ -365,75 +388,79 @@ __global__ void __launch_bounds__(FqGeom<QB>::THREADS, 2) flat_filter_kernel(Fla
             for (int s = 0; s < 8; ++s) bq[qb][s] = *(const half8*)(qrow[qb] + sl * FQ_KS + s * 16 + h * 8);
     };
 
-    // epilogue of the 32-row block(s) held in acc: rbase = first block index (0 or 1).  Loop order
-    // (4-row group outermost) keeps only one bias quad and four scores live at a time.
-    auto epilogue = [&](int tl, int slot, int rbase) {
-        const float* bias = (const float*)(smem + G::LDS_BIAS) + slot * FQ_TR;
+    // epilogue of the 32-row block(s) held in acc (they started from -|y|^2/2, so they ARE the scores):
+    // rbase = first block index (0 or 1).  Lane (h, j) holds, for its query of column block qb, the
+    // rows rb*32 + 8g + 4h + e at acc[..][qb][4g + e].
+    auto epilogue = [&](int tl, int rbase) {
         const int tile_row0 = tile_row0_of(tl);
+        if (MODE != MODE_DUMP) {
+            if (QB == 4) mfma_results_ready(acc[0][0], acc[0][1], acc[0][QB - 2], acc[0][QB - 1]);
+            else mfma_results_ready(acc[0][0], acc[0][1], acc[G::RBP - 1][0], acc[G::RBP - 1][1]);
+        }
 #pragma unroll
         for (int rp = 0; rp < G::RBP; ++rp) {
             const int rb = rbase + rp;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 b4 = *(const f32x4*)(bias + rb * 32 + 8 * g + 4 * h);
+            for (int qb = 0; qb < QB; ++qb) {
+                const f32x16& a = acc[rp][qb];
+                if (MODE == MODE_MAX) {
+                    // class = 4 consecutive rows of the tile (QB = 2: per 32-row block, 8 classes;
+                    // QB = 4: the two blocks share 4 classes); fmaxf drops NaN scores
 #pragma unroll
-                for (int qb = 0; qb < QB; ++qb) {
-                    float tv[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) tv[e] = acc[rp][qb][4 * g + e] - b4[e];
-                    if (MODE == MODE_MAX) {
-                        // class = 4 consecutive rows of the tile (QB = 2: per 32-row block, 8 classes;
-                        // QB = 4: the two blocks share 4 classes); fmaxf drops NaN scores
+                    for (int g = 0; g < 4; ++g) {
                         const int cl = QB == 4 ? g : rp * 4 + g;
-                        mx[qb][cl] = fmaxf(mx[qb][cl], fmaxf(fmaxf(tv[0], tv[1]), fmaxf(tv[2], tv[3])));
+                        mx[qb][cl] = max3(max3(mx[qb][cl], a[4 * g], a[4 * g + 1]), a[4 * g + 2], a[4 * g + 3]);
                         // opaque to the optimiser: otherwise it merges this block's maximum with the next
                         // block's into one max3 chain, which keeps two accumulator sets alive (spills)
                         if (QB == 4) asm volatile("" : "+v"(mx[qb][cl]));
-                    } else if (MODE == MODE_DUMP) {
+                    }
+                } else if (MODE == MODE_DUMP) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int grow = tile_row0 + rb * 32 + 8 * g + 4 * h + e;
-                            const int q = qbase + qb * 32 + j;
-                            if (qvalid[qb] && grow < p.nb) p.dump[(int64_t)q * p.nb + grow] = tv[e];
-                        }
-                    } else {
-                        const float th = thr[qb];
-                        // wave-wide masks of the rows that beat their query's threshold (v_cmp -> SGPR pair)
-                        u64 pm[4];
+                    for (int i = 0; i < 16; ++i) {
+                        const int grow = tile_row0 + rb * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
+                        const int q = qbase + qb * 32 + j;
+                        if (qvalid[qb] && grow < p.nb) p.dump[(int64_t)q * p.nb + grow] = a[i];
+                    }
+                } else {
+                    // 8 max3 + one compare per 16 scores; a wave-wide hit (a candidate among 32 rows x 32
+                    // queries x 2) parks the lane's fragment as it is -- which of the 16 is sorted out later
+                    const float th = thr[qb];
+                    const float m = max3(max3(max3(a[0], a[1], a[2]), max3(a[3], a[4], a[5]), a[15]),
+                                         max3(a[6], a[7], a[8]), max3(max3(a[9], a[10], a[11]), max3(a[12], a[13], a[14]), a[12]));
+                    const u64 pm = __ballot(m > th);
+                    if (__builtin_expect(pm != 0ull, 0)) {
+                        // everything below hangs off operands made opaque here, so that none of the cold
+                        // path's address arithmetic is speculated into the tile loop
+                        int trow = tile_row0 + rb * 32 + 4 * h;
+                        unsigned qlo = wave * G::QPW + qb * 32 + j;
+                        asm volatile("" : "+v"(trow), "+v"(qlo));
+                        if (m > th) {
+                            const int pos = wcnt + __popcll(pm & ((1ull << lane) - 1ull));
+                            if (pos < WBLK) {
+                                f32x4* dst = (f32x4*)(lblkv + pos * 16);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) pm[e] = __ballot(tv[e] > th);
-                        if (pm[0] | pm[1] | pm[2] | pm[3]) {
-                            // rare, wave-uniform: some lane's query has a candidate among these 4 rows
-                            const unsigned ql = wave * G::QPW + qb * 32 + j;
-                            const u64 lt = (1ull << lane) - 1ull;
+                                for (int g = 0; g < 4; ++g)
+                                    dst[g] = f32x4{a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
+                                lblkm[pos] = int2{trow, (int)qlo};
+                            } else {
+                                // slice full before the loop could be left for a sift (tiles with far more
+                                // candidates than expected): straight to the segment in HBM
+                                const u64* rk = p.res_keys;
+                                asm volatile("" : "+s"(rk));
+                                u64* seg = const_cast<u64*>(rk) +
+                                           ((int64_t)(grp * G::QPB + qlo) * p.nsplit + split) * p.cap;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                if (pm[e]) {
-                                    if (tv[e] > th) {
-                                        const int grow = tile_row0 + rb * 32 + 8 * g + 4 * h + e;
-                                        const u64 key = ((u64)score_key(tv[e]) << 32) | (unsigned)grow;
-                                        const int pos = wcnt + __popcll(pm[e] & lt);
-                                        if (pos < WBUF) {
-                                            lbufk[pos] = key;
-                                            lbufq[pos] = ql;
-                                        } else {
-                                            // slice full before the loop could be left for a flush (a tile
-                                            // with far more candidates than expected): straight to the
-                                            // segment in HBM.  The operands are made opaque so that no part
-                                            // of the address computation is hoisted out of this rare branch
-                                            // into registers that would live across the whole loop.
-                                            const u64* rk = p.res_keys;
-                                            unsigned qlo = ql;
-                                            asm volatile("" : "+s"(rk), "+v"(qlo));
-                                            const unsigned slot_ = atomicAdd(&lcnt[qlo], 1u);
-                                            if (slot_ < (unsigned)p.cap)
-                                                const_cast<u64*>(rk)[((int64_t)(grp * G::QPB + qlo) * p.nsplit + split) * p.cap + slot_] = key;
-                                        }
+                                for (int i = 0; i < 16; ++i) {
+                                    if (a[i] > th) {
+                                        const int grow = trow + 8 * (i >> 2) + (i & 3);
+                                        const unsigned slot_ = atomicAdd(&lcnt[qlo], 1u);
+                                        if (slot_ < (unsigned)p.cap)
+                                            seg[slot_] = ((u64)score_key(a[i]) << 32) | (unsigned)grow;
                                     }
-                                    wcnt += __popcll(pm[e]);
                                 }
                             }
                         }
+                        wcnt += __popcll(pm);
                     }
                 }
             }
@@ -445,15 +472,23 @@ __global__ void __launch_bounds__(FqGeom<QB>::THREADS, 2) flat_filter_kernel(Fla
         const int tl = u / nslab, sl = u - tl * nslab;
         if (!SINGLE && u > 0) load_b(sl);
         const char* tile = smem + slot * FQ_TILE_BYTES;
+        const float* bias = (const float*)(smem + G::LDS_BIAS) + slot * FQ_TR;
         const int sw = j & 15;
         if (G::RBP == 2) {
             if (sl == 0) {
+                // accumulators start from -|y|^2/2 of their rows (the bias travels with every slab's DMA)
 #pragma unroll
-                for (int rp = 0; rp < G::RBP; ++rp)
+                for (int rp = 0; rp < G::RBP; ++rp) {
+                    f32x16 c0;
 #pragma unroll
-                    for (int qb = 0; qb < QB; ++qb)
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 b4 = *(const f32x4*)(bias + rp * 32 + 8 * g + 4 * h);
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[rp][qb][r] = 0.f;
+                        for (int e = 0; e < 4; ++e) c0[4 * g + e] = b4[e];
+                    }
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) acc[rp][qb] = c0;
+                }
             }
             const char* rowp0 = tile + j * 256;
             const char* rowp1 = tile + (32 + j) * 256;
@@ -469,16 +504,20 @@ __global__ void __launch_bounds__(FqGeom<QB>::THREADS, 2) flat_filter_kernel(Fla
                             __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bq[qb][s], acc[G::RBP - 1][qb], 0, 0, 0);
                 }
             }
-            if (sl == nslab - 1) epilogue(tl, slot, 0);
+            if (sl == nslab - 1) epilogue(tl, 0);
         } else {
             // one 32-row block at a time; with several k-slabs (d > 128) the two blocks of a tile
             // need both accumulator sets, so that geometry is SINGLE only (launch_flat_filter)
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) {
+                // the first k-step takes -|y|^2/2 of the block's rows as its C operand
+                f32x16 c0;
 #pragma unroll
-                for (int qb = 0; qb < QB; ++qb)
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 b4 = *(const f32x4*)(bias + rb * 32 + 8 * g + 4 * h);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[0][qb][r] = 0.f;
+                    for (int e = 0; e < 4; ++e) c0[4 * g + e] = b4[e];
+                }
                 const char* rowp = tile + (rb * 32 + j) * 256;
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
@@ -486,13 +525,14 @@ __global__ void __launch_bounds__(FqGeom<QB>::THREADS, 2) flat_filter_kernel(Fla
                     const half8 a0 = *(const half8*)(rowp + off);
 #pragma unroll
                     for (int qb = 0; qb < QB; ++qb)
-                        acc[0][qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bq[qb][s], acc[0][qb], 0, 0, 0);
+                        acc[0][qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bq[qb][s], s == 0 ? c0 : acc[0][qb],
+                                                                            0, 0, 0);
                 }
                 // keep the epilogue of this block and the MFMAs of the next one apart: interleaved, the
                 // scheduler holds two accumulator sets (128 VGPRs) and spills the query operands; the
                 // other wave of the SIMD fills the matrix pipe meanwhile
                 __builtin_amdgcn_sched_barrier(0);
-                epilogue(tl, slot, rb);
+                epilogue(tl, rb);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -516,16 +556,25 @@ __global__ void __launch_bounds__(FqGeom<QB>::THREADS, 2) flat_filter_kernel(Fla
     // queries' counters), so it needs no barrier; it sits OUTSIDE the hot loop (the loop is left and
     // re-entered around it) so that none of its addresses is kept in registers across the tiles.
     auto flush = [&]() __attribute__((always_inline)) {
-        const int nmine = min(wcnt, WBUF);
-        for (int i = lane; i < nmine; i += 64) {
-            const unsigned ql = lbufq[i];
-            const unsigned slot_ = atomicAdd(&lcnt[ql], 1u);
-            if (slot_ < (unsigned)p.cap)
-                p.res_keys[((int64_t)(grp * G::QPB + ql) * p.nsplit + split) * p.cap + slot_] = lbufk[i];
+        const int nmine = min(wcnt, WBLK);
+        // 4 fragments per pass: lane = (fragment, score); the sift repeats the kernel's own comparison
+        for (int b0 = 0; b0 < nmine; b0 += 4) {
+            const int b = b0 + (lane >> 4), vi = lane & 15;
+            if (b < nmine) {
+                const float v = lblkv[b * 16 + vi];
+                const int2 mt = lblkm[b];
+                if (v > lthr[mt.y]) {
+                    const int grow = mt.x + 8 * (vi >> 2) + (vi & 3);
+                    const unsigned slot_ = atomicAdd(&lcnt[mt.y], 1u);
+                    if (slot_ < (unsigned)p.cap)
+                        p.res_keys[((int64_t)(grp * G::QPB + mt.y) * p.nsplit + split) * p.cap + slot_] =
+                                ((u64)score_key(v) << 32) | (unsigned)grow;
+                }
+            }
         }
         wcnt = 0;
     };
-    constexpr int WFLUSH = WBUF * 3 / 4;
+    constexpr int WFLUSH = WBLK / 2;
 
     int gslot = 0; // (u / TPB) % 3
     int u = 0;
@@ -547,7 +596,7 @@ __global__ void __launch_bounds__(FqGeom<QB>::THREADS, 2) flat_filter_kernel(Fla
             u += TPB;
         } while (u < nsteps && (MODE != MODE_COLLECT || wcnt <= WFLUSH));
         if (MODE == MODE_COLLECT) {
-            // slice three quarters full (wave-uniform) or scan finished
+            // slice half full (wave-uniform) or scan finished
             // (its stores share the vector-memory counter with the DMAs the loop counts; loads complete in
             // order among themselves, so extra younger stores only make the counted waits conservative)
             flush();

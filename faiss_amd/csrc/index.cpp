@@ -195,12 +195,16 @@ void GpuIndexFlat::add(idx_t n, const float* x) {
         // fp16 shadow copy + |y|^2/2 for the filter kernel, range / norm statistics
         launch_convert_f16(dst, dpad_, ni, d, xbh_.as<char>() + (size_t)(ntotal + i0) * dh_ * 2, dh_,
                            scal_.as<unsigned>(), nullptr, res_->stream);
-        // (the +inf padding after the last row is rewritten by every page; only the final one survives)
+        // (the -inf padding after the last row is rewritten by every page; only the final one survives)
         launch_half_norms(xbn_.as<float>() + ntotal + i0, ni, kFilterTileRows, metric_type,
                           xbhn_.as<float>() + ntotal + i0, res_->stream);
         launch_max_f32(xbn_.as<float>() + ntotal + i0, ni, scal_.as<unsigned>() + 1, res_->stream);
         res_->sync(); // q_raw_ is reused by the next page
     }
+    // the tile of padding rows behind the last row: zeros (their bias is -inf, their coordinates must not
+    // turn that into a NaN next to real rows)
+    HIP_CHECK(hipMemsetAsync(xbh_.as<char>() + (size_t)(ntotal + n) * dh_ * 2, 0, (size_t)kFilterTileRows * dh_ * 2,
+                             res_->stream));
     {
         unsigned bits[2];
         HIP_CHECK(hipMemcpy(bits, scal_.p, 8, hipMemcpyDeviceToHost));

@@ -87,12 +87,14 @@ struct FlatFilterParams {
 // MFMA fp32 accumulation and the exact path's own fmaf chain each contribute at most
 // d 2^-24 |q||y| (first-order, doubled below); the L2 epilogue rounds fl(|q|^2+|y|^2) and the
 // fmaf result once each: 2^-23 (|q|^2 + |y|^2) in distance units = 2^-24 (...) in score units.
+// The L2 accumulators start from -|y|^2/2, so each of the (at most d) fp32 additions inside the MFMA
+// chain also rounds that magnitude: + d 2^-24 |y|^2/2, doubled.
 // A 1.25x safety factor covers the second-order terms and sqrtf.
 __host__ __device__ static inline float flat_filter_err_bound(int metric, int d, float xn, float yn_max) {
     const float nq = sqrtf(xn), ny = sqrtf(yn_max);
     float e = (9.775e-4f /*2^-10 * 1.001*/ + 2.4e-7f * (float)d /*4 d 2^-24*/) * nq * ny +
               3.0e-8f /*2^-25 * 1.001*/ * sqrtf((float)d) * (nq + ny) + 1e-30f;
-    if (metric == METRIC_L2) e += 6.0e-8f /*2^-24*/ * (xn + yn_max);
+    if (metric == METRIC_L2) e += 6.0e-8f /*2^-24*/ * (xn + yn_max) + 6.0e-8f * (float)d * yn_max;
     return 1.25f * e;
 }
 // mode: 0 = maxima pass, 1 = collect pass, 2 = dump every score (tests)
