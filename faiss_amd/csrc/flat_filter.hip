@@ -172,7 +172,8 @@ struct FqGeom {
     static constexpr int TPB = 1;
     static constexpr int RING = 3 * TPB;         // LDS ring slots: TPB computing, 2 * TPB in flight
     static constexpr int LDS_BIAS = RING * FQ_TILE_BYTES;
-    static constexpr int LDS_CNT = LDS_BIAS + RING * FQ_TR * 4; // [queries per workgroup] append counters
+    static constexpr int LDS_GEN = LDS_BIAS + RING * FQ_TR * 4; // step at which all waves sift their slices
+    static constexpr int LDS_CNT = LDS_GEN + 16;                // [queries per workgroup] append counters
     static constexpr int LDS_THR = LDS_CNT + QPB * 4;           // [queries per workgroup] collect thresholds
     // collect pass: a lane whose 16 scores of one (query, 32-row block) hold a candidate parks the
     // whole 16-score fragment in its wave's LDS slice; the slices are sifted and written to the
@@ -306,7 +307,7 @@ __global__ void __launch_bounds__(FqGeom<QB>::THREADS, 2) flat_filter_kernel(Fla
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         const int q = qbase + qb * 32 + j;
-        thr[qb] = (MODE == MODE_COLLECT && q < p.nq) ? p.thr[q] : INFINITY;
+        thr[qb] = (MODE == MODE_COLLECT && q < p.nq && !(p.dbg & 4)) ? p.thr[q] : INFINITY;
     }
     // every wave parks fragments in its own slice: the fill count is a wave-uniform register and
     // slots come from ballot prefix counts -- no LDS atomic round trip
@@ -317,6 +318,7 @@ __global__ void __launch_bounds__(FqGeom<QB>::THREADS, 2) flat_filter_kernel(Fla
     int wcnt = 0;
     if (MODE == MODE_COLLECT) {
         for (int i = tid; i < G::QPB; i += G::THREADS) lcnt[i] = 0;
+        if (tid == 0) *(unsigned*)(smem + G::LDS_GEN) = 0;
         if (h == 0) {
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) lthr[wave * G::QPW + qb * 32 + j] = thr[qb];
@@ -434,7 +436,7 @@ __global__ void __launch_bounds__(FqGeom<QB>::THREADS, 2) flat_filter_kernel(Fla
                         int trow = tile_row0 + rb * 32 + 4 * h;
                         unsigned qlo = wave * G::QPW + qb * 32 + j;
                         asm volatile("" : "+v"(trow), "+v"(qlo));
-                        if (m > th) {
+                        if (m > th && !(p.dbg & 1)) {
                             const int pos = wcnt + __popcll(pm & ((1ull << lane) - 1ull));
                             if (pos < WBLK) {
                                 f32x4* dst = (f32x4*)(lblkv + pos * 16);
@@ -460,7 +462,7 @@ __global__ void __launch_bounds__(FqGeom<QB>::THREADS, 2) flat_filter_kernel(Fla
                                 }
                             }
                         }
-                        wcnt += __popcll(pm);
+                        if (!(p.dbg & 1)) wcnt += __popcll(pm);
                     }
                 }
             }
@@ -552,33 +554,45 @@ __global__ void __launch_bounds__(FqGeom<QB>::THREADS, 2) flat_filter_kernel(Fla
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    // this wave's parked candidates -> their (query, split) segments in HBM.  Wave-private (own slice, own
-    // queries' counters), so it needs no barrier; it sits OUTSIDE the hot loop (the loop is left and
-    // re-entered around it) so that none of its addresses is kept in registers across the tiles.
+    // Sift: this wave's parked fragments -> candidates in their (query, split) segments in HBM.  One lane
+    // per fragment: repeat the kernel's own comparison on its 16 scores, take the segment slots with ONE
+    // LDS atomic, write the hits.  Wave-private (own slice, own queries' counters).  It sits OUTSIDE the
+    // tile loop (the loop is left and re-entered around it) so that none of its addresses is kept in
+    // registers across the tiles, and all waves of the workgroup do it at the same step: a wave sifting on
+    // its own would hold the other seven at the next barrier.
     auto flush = [&]() __attribute__((always_inline)) {
-        const int nmine = min(wcnt, WBLK);
-        // 4 fragments per pass: lane = (fragment, score); the sift repeats the kernel's own comparison
-        for (int b0 = 0; b0 < nmine; b0 += 4) {
-            const int b = b0 + (lane >> 4), vi = lane & 15;
-            if (b < nmine) {
-                const float v = lblkv[b * 16 + vi];
-                const int2 mt = lblkm[b];
-                if (v > lthr[mt.y]) {
-                    const int grow = mt.x + 8 * (vi >> 2) + (vi & 3);
-                    const unsigned slot_ = atomicAdd(&lcnt[mt.y], 1u);
-                    if (slot_ < (unsigned)p.cap)
-                        p.res_keys[((int64_t)(grp * G::QPB + mt.y) * p.nsplit + split) * p.cap + slot_] =
-                                ((u64)score_key(v) << 32) | (unsigned)grow;
-                }
+        const int nmine = (p.dbg & 2) ? 0 : min(wcnt, WBLK);
+        for (int b = lane; b < nmine; b += 64) {
+            const int2 mt = lblkm[b];
+            const float th = lthr[mt.y];
+            const f32x4* src = (const f32x4*)(lblkv + b * 16);
+            unsigned mask = 0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = src[g];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) mask |= v[e] > th ? 1u << (4 * g + e) : 0u;
+            }
+            unsigned slot_ = atomicAdd(&lcnt[mt.y], (unsigned)__popc(mask));
+            u64* seg = p.res_keys + ((int64_t)(grp * G::QPB + mt.y) * p.nsplit + split) * p.cap;
+            while (mask) {
+                const int i = __ffs(mask) - 1;
+                mask &= mask - 1;
+                const float v = lblkv[b * 16 + i];
+                if (slot_ < (unsigned)p.cap)
+                    seg[slot_] = ((u64)score_key(v) << 32) | (unsigned)(mt.x + 8 * (i >> 2) + (i & 3));
+                ++slot_;
             }
         }
         wcnt = 0;
     };
     constexpr int WFLUSH = WBLK / 2;
+    volatile unsigned* lgen = (volatile unsigned*)(smem + G::LDS_GEN);
 
     int gslot = 0; // (u / TPB) % 3
     int u = 0;
     while (u < nsteps) {
+        bool sift;
         do {
             const int gslot2 = gslot >= 1 ? gslot - 1 : 2; // ring position of the group two ahead
 #pragma unroll
@@ -587,20 +601,20 @@ __global__ void __launch_bounds__(FqGeom<QB>::THREADS, 2) flat_filter_kernel(Fla
 #pragma unroll
             for (int t = 0; t < TPB; ++t)
                 if (u + t < nsteps) compute(u + t, gslot * TPB + t);
+            u += TPB;
+            // a slice half full: every wave sifts after this step's barrier
+            if (MODE == MODE_COLLECT && wcnt > WFLUSH) *lgen = (unsigned)u;
             // the next group must have landed (this wave's share) before anybody passes the barrier; a
             // complete group issued above stays in flight across it
-            if (u + 3 * TPB <= nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_STAGE * TPB) : "memory");
+            if (u + 2 * TPB <= nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_STAGE * TPB) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             gslot = gslot == 2 ? 0 : gslot + 1;
-            u += TPB;
-        } while (u < nsteps && (MODE != MODE_COLLECT || wcnt <= WFLUSH));
-        if (MODE == MODE_COLLECT) {
-            // slice half full (wave-uniform) or scan finished
-            // (its stores share the vector-memory counter with the DMAs the loop counts; loads complete in
-            // order among themselves, so extra younger stores only make the counted waits conservative)
-            flush();
-        }
+            sift = MODE == MODE_COLLECT && __builtin_amdgcn_readfirstlane(*lgen) == (unsigned)u;
+        } while (u < nsteps && !sift);
+        // (the sift's stores share the vector-memory counter with the DMAs the loop counts; loads complete
+        // in order among themselves, so extra younger stores only make the counted waits conservative)
+        if (MODE == MODE_COLLECT) flush();
     }
 
     if (MODE == MODE_MAX) {
@@ -650,8 +664,10 @@ static void launch_filter_mode(const FlatFilterParams& p, hipStream_t stream) {
     }
 }
 
-void launch_flat_filter(const FlatFilterParams& p, int mode, hipStream_t stream) {
-    if (p.nq == 0 || p.nb == 0) return;
+void launch_flat_filter(const FlatFilterParams& p_, int mode, hipStream_t stream) {
+    if (p_.nq == 0 || p_.nb == 0) return;
+    FlatFilterParams p = p_;
+    if (const char* e = getenv("FAISS_AMD_FILTER_DBG")) p.dbg = atoi(e);
     FA_THROW_IF_NOT(p.dh % FQ_KS == 0 && p.ldqh % 8 == 0 && p.ldbh % 8 == 0);
     FA_THROW_IF_NOT(p.tstride >= 1 && p.nsplit >= 1);
     FA_THROW_IF_NOT_MSG(p.geom == 0 || (p.geom == 2 && p.dh == FQ_KS), "the 8-wave geometry needs dh == 128");

@@ -80,6 +80,7 @@ struct FlatFilterParams {
     uint32_t* res_cnt;            // [nq][nsplit]
     uint32_t* flags;              // [nq] in: fp16 overflow of the query; out: |= segment overflow
     float* dump;                  // optional [nq][nb] approximate scores (tests)
+    int dbg;                      // timing experiments only (env FAISS_AMD_FILTER_DBG): 1 no parking, 2 no sift, 4 no hits
 };
 // Bound on |t~ - s| for one query against any database row (see flat_filter.hip header).  fp16
 // round-to-nearest: |dx| <= 2^-11 |x| in the normal range and <= 2^-25 below it, so
