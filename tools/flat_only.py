@@ -15,10 +15,13 @@ xq_dev = torch.from_numpy(xq).to(dev)
 Dd = torch.empty((10000, 100), dtype=torch.float32, device=dev)
 Id = torch.empty((10000, 100), dtype=torch.int64, device=dev)
 for dbg in os.environ.get("DBG_LIST", "0").split(","):
+    if ":" in dbg:
+        dbg, ns = dbg.split(":")
+        os.environ["FAISS_AMD_FILTER_NSPLIT"] = ns
     os.environ["FAISS_AMD_FILTER_DBG"] = dbg
     idx.search_ptr(10000, xq_dev.data_ptr(), 100, Dd.data_ptr(), Id.data_ptr())
     torch.cuda.synchronize(); t0 = time.time()
     for _ in range(steps):
         idx.search_ptr(10000, xq_dev.data_ptr(), 100, Dd.data_ptr(), Id.data_ptr())
     torch.cuda.synchronize()
-    print("flat search (dbg %s): %.3f ms/step" % (dbg, (time.time() - t0) / steps * 1e3), flush=True)
+    print("flat search (dbg %s nsplit %s): %.3f ms/step" % (dbg, os.environ.get("FAISS_AMD_FILTER_NSPLIT"), (time.time() - t0) / steps * 1e3), flush=True)
