@@ -47,7 +47,7 @@ __device__ __forceinline__ const char* uniform_ptr(const char* ptr) {
 
 constexpr int TILE = 16384;
 
-template <int F, int WAVES>
+template <int F, int WAVES, int RING>
 __global__ void __launch_bounds__(WAVES * 64, 1)
 probe(const _Float16* __restrict__ xb, const _Float16* __restrict__ xq, float* out, int nsteps, int nsplit, float th) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -61,29 +61,31 @@ probe(const _Float16* __restrict__ xb, const _Float16* __restrict__ xq, float* o
         for (int s = 0; s < 8; ++s)
             bq[qb][s] = *(const half8*)(xq + ((size_t)(blockIdx.x * 64 + wave * 4 + qb) * 32 + j) % 4096 * 128 + s * 16 + h * 8);
     __builtin_amdgcn_s_waitcnt(0x0F70);
-    for (int i = tid; i < (3 * TILE + 1024) / 4; i += WAVES * 64) ((float*)smem)[i] = 0.001f * (i & 255);
+    for (int i = tid; i < (RING * TILE + 1024) / 4; i += WAVES * 64) ((float*)smem)[i] = 0.001f * (i & 255);
     __syncthreads();
     const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(const __attribute__((address_space(3))) char*)smem);
-    constexpr int DMA_ROWS = 16 / WAVES;
+    constexpr bool ONE = (F & 32) != 0;            // wave 0 issues the whole tile
+    constexpr int DMA_ROWS = ONE ? 16 : 16 / WAVES;
     unsigned voff[DMA_ROWS];
 #pragma unroll
     for (int i = 0; i < DMA_ROWS; ++i) {
-        const int g = (wave * DMA_ROWS + i) * 64 + lane;
+        const int g = ((ONE ? 0 : wave) * DMA_ROWS + i) * 64 + lane;
         const int row = g >> 4, cpos = g & 15, c = cpos ^ (row & 15);
         voff[i] = (unsigned)(row * 256 + c * 16);
     }
     auto stage = [&](int u, int slot) __attribute__((always_inline)) {
         const int row0 = __builtin_amdgcn_readfirstlane((split + u * nsplit) * 64);
         const char* sb = uniform_ptr((const char*)xb + (size_t)row0 * 256);
+        if (ONE && wave != 0) return;
 #pragma unroll
-        for (int i = 0; i < DMA_ROWS; ++i) glds16_s(sb, voff[i], lds_base + slot * TILE + (wave * DMA_ROWS + i) * 1024);
+        for (int i = 0; i < DMA_ROWS; ++i) glds16_s(sb, voff[i], lds_base + slot * TILE + ((ONE ? 0 : wave) * DMA_ROWS + i) * 1024);
     };
     float keep = 0.f;
     int hits = 0;
     if (F & 4) {
-        stage(0, 0);
-        stage(1, 1);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_ROWS) : "memory");
+#pragma unroll
+        for (int t = 0; t < RING - 1; ++t) stage(t, t);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 2) * DMA_ROWS) : "memory");
         __syncthreads();
     }
     half8 areg;
@@ -91,12 +93,12 @@ probe(const _Float16* __restrict__ xb, const _Float16* __restrict__ xq, float* o
     for (int i = 0; i < 8; ++i) areg[i] = (_Float16)(0.01f * (lane + i));
     int slot = 0;
     for (int u = 0; u < nsteps; ++u) {
-        const int slot2 = slot >= 1 ? slot - 1 : 2;
+        const int slot2 = slot >= 1 ? slot - 1 : RING - 1;
         if (F & 4) {
-            if (u + 2 < nsteps) stage(u + 2, slot2);
+            if (u + RING - 1 < nsteps) stage(u + RING - 1, slot2);
         }
         const char* tile = smem + slot * TILE;
-        const float* bias = (const float*)(smem + 3 * TILE);
+        const float* bias = (const float*)(smem + RING * TILE);
         const int sw = j & 15;
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
@@ -145,27 +147,27 @@ probe(const _Float16* __restrict__ xb, const _Float16* __restrict__ xq, float* o
             __builtin_amdgcn_sched_barrier(0);
         }
         if (F & 4) {
-            if (u + 3 <= nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_ROWS) : "memory");
+            if (u + RING <= nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 2) * DMA_ROWS) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         if (F & 2) __syncthreads();
-        slot = slot == 2 ? 0 : slot + 1;
+        slot = slot == RING - 1 ? 0 : slot + 1;
     }
     if (hits == 12345) out[blockIdx.x * WAVES * 64 + tid] = keep;
 }
 
-template <int F, int WAVES>
+template <int F, int WAVES, int RING = 3>
 static void run(const char* name, const _Float16* xb, const _Float16* xq, float* out, int nwg, int nsteps, int nsplit) {
-    const size_t lds = WAVES == 4 ? 100 * 1024 : 3 * TILE + 1024; // (4 waves: one workgroup per CU all the same)
-    CK(hipFuncSetAttribute((const void*)probe<F, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const size_t lds = WAVES == 4 ? 100 * 1024 : RING * TILE + 1024; // (4 waves: one workgroup per CU all the same)
+    CK(hipFuncSetAttribute((const void*)probe<F, WAVES, RING>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    for (int it = 0; it < 2; ++it) hipLaunchKernelGGL((probe<F, WAVES>), dim3(nwg), dim3(WAVES * 64), lds, 0, xb, xq, out, nsteps, nsplit, 1e30f);
+    for (int it = 0; it < 2; ++it) hipLaunchKernelGGL((probe<F, WAVES, RING>), dim3(nwg), dim3(WAVES * 64), lds, 0, xb, xq, out, nsteps, nsplit, 1e30f);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
     const int reps = 5;
-    for (int it = 0; it < reps; ++it) hipLaunchKernelGGL((probe<F, WAVES>), dim3(nwg), dim3(WAVES * 64), lds, 0, xb, xq, out, nsteps, nsplit, 1e30f);
+    for (int it = 0; it < reps; ++it) hipLaunchKernelGGL((probe<F, WAVES, RING>), dim3(nwg), dim3(WAVES * 64), lds, 0, xb, xq, out, nsteps, nsplit, 1e30f);
     CK(hipEventRecord(e1));
     CK(hipDeviceSynchronize());
     float ms;
@@ -201,5 +203,11 @@ int main(int argc, char** argv) {
     run<9, 8>("A from LDS + epilogue, no barrier, no DMA", xb, xq, out, nwg, nsteps, nsplit);
     run<8, 8>("mfma (A regs) + epilogue", xb, xq, out, nwg, nsteps, nsplit);
     run<5, 8>("A from LDS + DMA, no barrier (racy, timing only)", xb, xq, out, nwg, nsteps, nsplit);
+    run<7, 8, 4>("LDS + barrier + DMA, 4-slot ring", xb, xq, out, nwg, nsteps, nsplit);
+    run<7, 8, 6>("LDS + barrier + DMA, 6-slot ring", xb, xq, out, nwg, nsteps, nsplit);
+    run<7 | 32, 8, 3>("LDS + barrier + DMA issued by wave 0 only", xb, xq, out, nwg, nsteps, nsplit);
+    run<7 | 32, 8, 4>("LDS + barrier + DMA by wave 0, 4-slot ring", xb, xq, out, nwg, nsteps, nsplit);
+    run<31, 8, 4>("the kernel, 4-slot ring", xb, xq, out, nwg, nsteps, nsplit);
+    run<31 | 32, 8, 4>("the kernel, 4-slot ring, DMA by wave 0", xb, xq, out, nwg, nsteps, nsplit);
     return 0;
 }
