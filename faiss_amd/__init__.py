@@ -91,6 +91,12 @@ def load_library():
         "faiss_amd_GpuIndexFlat_set_use_filter_kernel": (i32, [vp, i32, i64]),
         "faiss_amd_GpuIndexFlat_filter_stats": (i32, [vp, P(i32), P(i32)]),
         "faiss_amd_GpuIndexFlat_filter_scores": (i32, [vp, i64, vp, vp, vp]),
+        "faiss_amd_Index_reconstruct_batch": (i32, [vp, i64, vp, vp]),
+        "faiss_amd_Index_compute_residual": (i32, [vp, vp, vp, i64]),
+        "faiss_amd_Index_compute_residual_n": (i32, [vp, i64, vp, vp, vp]),
+        "faiss_amd_GpuIndexIVF_search_preassigned": (i32, [vp, i64, vp, i64, vp, vp, vp, vp]),
+        "faiss_amd_IndexIVF_quantizer_search": (i32, [vp, i64, vp, i64, vp, vp]),
+        "faiss_amd_bfKnn": (i32, [vp, i32, vp, i64, vp, i64, i32, i64, vp, vp]),
     }
     for name, (res, args) in protos.items():
         fn = getattr(lib, name)  # AttributeError => the library does not export the symbol
@@ -233,6 +239,25 @@ class Index:
         _check(self._lib.faiss_amd_Index_reconstruct(self._h, int(key), _ptr(out)))
         return out
 
+    def reconstruct_batch(self, keys):
+        keys = np.ascontiguousarray(keys, dtype=np.int64)
+        out = np.empty((keys.shape[0], self.d), dtype=np.float32)
+        _check(self._lib.faiss_amd_Index_reconstruct_batch(self._h, keys.shape[0], _ptr(keys), _ptr(out)))
+        return out
+
+    def compute_residual(self, x, key):
+        x = _f32(np.asarray(x).reshape(1, -1), self.d)
+        out = np.empty(self.d, dtype=np.float32)
+        _check(self._lib.faiss_amd_Index_compute_residual(self._h, _ptr(x), _ptr(out), int(key)))
+        return out
+
+    def compute_residual_n(self, x, keys):
+        x = _f32(x, self.d)
+        keys = np.ascontiguousarray(keys, dtype=np.int64)
+        out = np.empty((x.shape[0], self.d), dtype=np.float32)
+        _check(self._lib.faiss_amd_Index_compute_residual_n(self._h, x.shape[0], _ptr(x), _ptr(out), _ptr(keys)))
+        return out
+
     def reconstruct_n(self, i0, ni):
         out = np.empty((ni, self.d), dtype=np.float32)
         _check(self._lib.faiss_amd_Index_reconstruct_n(self._h, int(i0), int(ni), _ptr(out)))
@@ -288,6 +313,29 @@ class GpuIndexFlatIP(GpuIndexFlat):
 
 class _GpuIndexIVF(Index):
     """faiss.GpuIndexIVF (faiss/gpu/GpuIndexIVF.h:37-153)."""
+
+    def quantizer_search(self, x, k):
+        """index.quantizer.search(x, k): the coarse centroids nearest to x (distances, list ids)"""
+        x = _f32(x, self.d)
+        D = np.empty((x.shape[0], k), dtype=np.float32)
+        I = np.empty((x.shape[0], k), dtype=np.int64)
+        _check(self._lib.faiss_amd_IndexIVF_quantizer_search(self._h, x.shape[0], _ptr(x), int(k), _ptr(D), _ptr(I)))
+        return D, I
+
+    def search_preassigned(self, x, k, Iq, Dq):
+        """faiss python `index.search_preassigned(x, k, Iq, Dq)` (class_wrappers.py replacement_search_preassigned):
+        Iq / Dq are the [n, nprobe] list ids / coarse distances of the queries."""
+        x = _f32(x, self.d)
+        n = x.shape[0]
+        Iq = np.ascontiguousarray(Iq, dtype=np.int64)
+        Dq = np.ascontiguousarray(Dq, dtype=np.float32)
+        if Iq.shape != (n, self.nprobe) or Dq.shape != (n, self.nprobe):
+            raise ValueError("Iq and Dq must be [n, nprobe]")
+        D = np.empty((n, k), dtype=np.float32)
+        I = np.empty((n, k), dtype=np.int64)
+        _check(self._lib.faiss_amd_GpuIndexIVF_search_preassigned(self._h, n, _ptr(x), int(k), _ptr(Iq), _ptr(Dq),
+                                                                  _ptr(D), _ptr(I)))
+        return D, I
 
     def set_use_fused_scan(self, on):
         """test hook: False routes search() through the unfused scan + select kernels"""
@@ -407,6 +455,18 @@ def kmeans(res, x, k, niter=25, seed=1234):
     _check(lib.faiss_amd_kmeans_clustering(res._h, d, n, int(k), _ptr(x), int(niter), int(seed), _ptr(cent),
                                            _ptr(obj)))
     return cent, obj
+
+
+def knn_gpu(res, xq, xb, k, metric=METRIC_L2):
+    """faiss.knn_gpu (faiss/python/gpu_wrappers.py:56-...) for float32 row-major numpy arrays -> (D, I)."""
+    lib = load_library()
+    xb = _f32(xb)
+    xq = _f32(xq, xb.shape[1])
+    D = np.empty((xq.shape[0], k), dtype=np.float32)
+    I = np.empty((xq.shape[0], k), dtype=np.int64)
+    _check(lib.faiss_amd_bfKnn(res._h, int(metric), _ptr(xb), xb.shape[0], _ptr(xq), xq.shape[0], xb.shape[1], int(k),
+                               _ptr(D), _ptr(I)))
+    return D, I
 
 
 def merge_knn_results(metric, all_D, all_I, base=None):

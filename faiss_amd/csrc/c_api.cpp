@@ -228,6 +228,24 @@ int faiss_amd_Index_reconstruct_n(const FaissAmdIndex* index, faiss_amd_idx_t i0
     FA_CATCH
 }
 
+int faiss_amd_Index_reconstruct_batch(const FaissAmdIndex* index, faiss_amd_idx_t n, const faiss_amd_idx_t* keys,
+                                      float* recons) {
+    FA_TRY
+    I(index)->reconstruct_batch(n, keys, recons);
+    FA_CATCH
+}
+int faiss_amd_Index_compute_residual(const FaissAmdIndex* index, const float* x, float* residual, faiss_amd_idx_t key) {
+    FA_TRY
+    I(index)->compute_residual(x, residual, key);
+    FA_CATCH
+}
+int faiss_amd_Index_compute_residual_n(const FaissAmdIndex* index, faiss_amd_idx_t n, const float* xs, float* residuals,
+                                       const faiss_amd_idx_t* keys) {
+    FA_TRY
+    I(index)->compute_residual_n(n, xs, residuals, keys);
+    FA_CATCH
+}
+
 int faiss_amd_IndexIVF_nlist(const FaissAmdIndex* index, int* p) {
     FA_TRY
     *p = as<GpuIndexIVF>(index, "GpuIndexIVF")->nlist;
@@ -402,6 +420,26 @@ int faiss_amd_GpuIndexFlat_filter_scores(const FaissAmdIndex* index, faiss_amd_i
                                          float* err_bound) {
     FA_TRY
     as<GpuIndexFlat>(index, "GpuIndexFlat")->filter_scores(n, x, scores, err_bound);
+    FA_CATCH
+}
+int faiss_amd_GpuIndexIVF_search_preassigned(const FaissAmdIndex* index, faiss_amd_idx_t n, const float* x,
+                                             faiss_amd_idx_t k, const faiss_amd_idx_t* assign, const float* centroid_dis,
+                                             float* distances, faiss_amd_idx_t* labels) {
+    FA_TRY
+    as<GpuIndexIVF>(index, "GpuIndexIVF")->search_preassigned(n, x, k, assign, centroid_dis, distances, labels);
+    FA_CATCH
+}
+int faiss_amd_IndexIVF_quantizer_search(const FaissAmdIndex* index, faiss_amd_idx_t n, const float* x, faiss_amd_idx_t k,
+                                        float* distances, faiss_amd_idx_t* labels) {
+    FA_TRY
+    as<GpuIndexIVF>(index, "GpuIndexIVF")->quantizer->search(n, x, k, distances, labels);
+    FA_CATCH
+}
+int faiss_amd_bfKnn(FaissAmdGpuResources* res, FaissAmdMetricType metric, const float* vectors,
+                    faiss_amd_idx_t num_vectors, const float* queries, faiss_amd_idx_t num_queries, int dims,
+                    faiss_amd_idx_t k, float* out_distances, faiss_amd_idx_t* out_indices) {
+    FA_TRY
+    bfKnn(R(res), (int)metric, vectors, num_vectors, queries, num_queries, dims, k, out_distances, out_indices);
     FA_CATCH
 }
 int faiss_amd_GpuIndexIVF_set_use_fused_scan(FaissAmdIndex* index, int on) {

@@ -67,6 +67,34 @@ void launch_pad_rows(const float* src, int64_t ld_src, int64_t n, int d, float* 
                        dpad);
 }
 
+// out[i][0..d) = (x ? x[i][0..d) : 0) -/= rows[key[i]][0..d): residuals (x given; faiss/gpu/impl/VectorResidual.cu:26-60,
+// a key of -1 yields a row of NaNs like there) or a gather of stored rows (x null; FlatIndex::reconstruct by ids)
+__global__ void rows_by_key_kernel(const float* __restrict__ x, int64_t ld_x, const int64_t* __restrict__ keys,
+                                   int64_t n, int d, const float* __restrict__ rows, int64_t ld_rows, int64_t nrows,
+                                   float* __restrict__ out, int64_t ld_out) {
+    const int64_t total = n * d;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = t / d;
+        const int c = (int)(t - i * d);
+        const int64_t key = keys[i];
+        float v;
+        if (key < 0 || key >= nrows) v = __builtin_nanf("");
+        else if (x) v = x[i * ld_x + c] - rows[key * ld_rows + c];
+        else v = rows[key * ld_rows + c];
+        out[i * ld_out + c] = v;
+    }
+}
+void launch_rows_by_key(const float* x, int64_t ld_x, const int64_t* keys, int64_t n, int d, const float* rows,
+                        int64_t ld_rows, int64_t nrows, float* out, int64_t ld_out, hipStream_t stream) {
+    if (n == 0) return;
+    const int64_t total = n * d;
+    unsigned grid = (unsigned)std::min<int64_t>(div_up(total, 256), 65535 * 16);
+    hipLaunchKernelGGL(rows_by_key_kernel, dim3(grid), dim3(256), 0, stream, x, ld_x, keys, n, d, rows, ld_rows, nrows,
+                       out, ld_out);
+    HIP_CHECK(hipGetLastError());
+}
+
 // ---------------------------------------------------------------------------------
 // fused MFMA scan
 //

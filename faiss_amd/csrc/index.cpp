@@ -126,6 +126,13 @@ void Index::compute_residual(const float* x, float* residual, idx_t key) const {
     for (int i = 0; i < d; i++) residual[i] = x[i] - residual[i];
 }
 
+void Index::compute_residual_n(idx_t n, const float* xs, float* residuals, const idx_t* keys) const {
+    for (idx_t i = 0; i < n; i++) compute_residual(xs + i * d, residuals + i * d, keys[i]);
+}
+void Index::reconstruct_batch(idx_t n, const idx_t* keys, float* recons) const {
+    for (idx_t i = 0; i < n; i++) reconstruct(keys[i], recons + i * d);
+}
+
 // stage n x d floats (host or device, dense rows) into a padded device buffer
 static void stage_padded(const GpuResources& res, const float* x, int64_t n, int d, int dpad, DevBuf& raw,
                          float* dst) {
@@ -230,6 +237,66 @@ void GpuIndexFlat::reconstruct_n(idx_t i0, idx_t ni, float* recons) const {
 }
 void GpuIndexFlat::reconstruct(idx_t key, float* recons) const {
     reconstruct_n(key, 1, recons);
+}
+
+// x (null: none), keys and out may each live on the host or on the device
+static void rows_by_key(const GpuResources& R, const float* x, const idx_t* keys, idx_t n, int d, const float* rows,
+                        int64_t ld_rows, idx_t nrows, float* out) {
+    if (n == 0) return;
+    DevBuf bx, bk, bo;
+    const float* dx = x;
+    if (x && !is_device_pointer(x)) {
+        bx.ensure((size_t)n * d * 4);
+        HIP_CHECK(hipMemcpyAsync(bx.p, x, (size_t)n * d * 4, hipMemcpyHostToDevice, R.stream));
+        dx = bx.as<float>();
+    }
+    const idx_t* dk = keys;
+    if (!is_device_pointer(keys)) {
+        bk.ensure((size_t)n * 8);
+        HIP_CHECK(hipMemcpyAsync(bk.p, keys, (size_t)n * 8, hipMemcpyHostToDevice, R.stream));
+        dk = bk.as<idx_t>();
+    }
+    float* dout = out;
+    if (!is_device_pointer(out)) {
+        bo.ensure((size_t)n * d * 4);
+        dout = bo.as<float>();
+    }
+    launch_rows_by_key(dx, d, dk, n, d, rows, ld_rows, nrows, dout, d, R.stream);
+    if (dout != out) HIP_CHECK(hipMemcpyAsync(out, dout, (size_t)n * d * 4, hipMemcpyDeviceToHost, R.stream));
+    R.sync();
+}
+void GpuIndexFlat::compute_residual_n(idx_t n, const float* xs, float* residuals, const idx_t* keys) const {
+    FA_THROW_IF_NOT_MSG(n >= 0, "negative count");
+    if (n == 0) return;
+    FA_THROW_IF_NOT_MSG(xs && residuals && keys, "null argument");
+    std::lock_guard<std::mutex> g(mu_);
+    res_->set_device();
+    rows_by_key(*res_, xs, keys, n, d, xb_.as<float>(), dpad_, ntotal, residuals);
+}
+void GpuIndexFlat::compute_residual(const float* x, float* residual, idx_t key) const {
+    compute_residual_n(1, x, residual, &key);
+}
+void GpuIndexFlat::reconstruct_batch(idx_t n, const idx_t* keys, float* recons) const {
+    FA_THROW_IF_NOT_MSG(n >= 0, "negative count");
+    if (n == 0) return;
+    FA_THROW_IF_NOT_MSG(keys && recons, "null argument");
+    std::lock_guard<std::mutex> g(mu_);
+    res_->set_device();
+    rows_by_key(*res_, nullptr, keys, n, d, xb_.as<float>(), dpad_, ntotal, recons);
+}
+
+void bfKnn(std::shared_ptr<GpuResources> res, int metric, const float* vectors, idx_t num_vectors, const float* queries,
+           idx_t num_queries, int dims, idx_t k, float* out_distances, idx_t* out_indices) {
+    FA_THROW_IF_NOT_MSG(res, "null resources");
+    FA_THROW_IF_NOT_MSG(dims >= 1 && num_vectors >= 0 && num_queries >= 0, "bad sizes");
+    FA_THROW_IF_NOT_MSG(metric == METRIC_L2 || metric == METRIC_INNER_PRODUCT, "bfKnn: metric must be L2 or inner product");
+    if (num_queries == 0) return;
+    FA_THROW_IF_NOT_MSG((vectors || num_vectors == 0) && queries && out_distances && out_indices, "null argument");
+    // the kernels read 16-byte aligned, zero-padded rows with their norms next to them: a private padded copy
+    // is the index add() path; the arrays the caller passed are never written
+    GpuIndexFlat tmp(res, dims, metric);
+    if (num_vectors) tmp.add(num_vectors, vectors);
+    tmp.search(num_queries, queries, k, out_distances, out_indices);
 }
 
 // choose the database split count: blocks = nsplit * ngroups should fill whole rounds of CUs
@@ -953,6 +1020,15 @@ std::vector<uint8_t> GpuIndexIVF::getListVectorData(idx_t list) const {
 }
 
 void GpuIndexIVF::search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels) const {
+    search_core_(n, x, k, distances, labels, nullptr, nullptr);
+}
+void GpuIndexIVF::search_preassigned(idx_t n, const float* x, idx_t k, const idx_t* assign, const float* centroid_dis,
+                                     float* distances, idx_t* labels) const {
+    FA_THROW_IF_NOT_MSG(n == 0 || (assign && centroid_dis), "search_preassigned: null assign / centroid_dis");
+    search_core_(n, x, k, distances, labels, assign, centroid_dis);
+}
+void GpuIndexIVF::search_core_(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels, const idx_t* assign,
+                               const float* centroid_dis) const {
     FA_THROW_IF_NOT_MSG(is_trained, "index not trained");
     FA_THROW_IF_NOT_MSG(k >= 1 && k <= kMaxSelectionK, "k must be in [1, 2048]");
     FA_THROW_IF_NOT_MSG(nprobe >= 1 && nprobe <= kMaxSelectionK, "nprobe must be in [1, 2048]");
@@ -961,7 +1037,8 @@ void GpuIndexIVF::search(idx_t n, const float* x, idx_t k, float* distances, idx
     std::lock_guard<std::mutex> g(mu_);
     res_->set_device();
     const GpuResources& R = *res_;
-    const int np = std::min(nprobe, nlist);
+    // preassigned arrays are [n][nprobe] whatever nlist is (surplus columns hold -1)
+    const int np = assign ? nprobe : std::min(nprobe, nlist);
     const bool out_dev_d = is_device_pointer(distances), out_dev_i = is_device_pointer(labels);
     // query tile bounded by the worst-case candidate volume (reference: IVFUtils.cu:46-127)
     uint32_t max_len = 1;
@@ -980,7 +1057,14 @@ void GpuIndexIVF::search(idx_t n, const float* x, idx_t k, float* distances, idx
         // ---- coarse quantizer: nprobe nearest centroids (reference: IVFBase.cu:509-593)
         c_dis_.ensure((size_t)ni * np * 4);
         c_ids_.ensure((size_t)ni * np * 8);
-        quantizer->search_device(ni, q_pad_.as<float>(), np, c_dis_.as<float>(), c_ids_.as<idx_t>());
+        if (assign) {
+            HIP_CHECK(hipMemcpyAsync(c_ids_.p, assign + (size_t)i0 * np, (size_t)ni * np * 8, hipMemcpyDefault, R.stream));
+            HIP_CHECK(hipMemcpyAsync(c_dis_.p, centroid_dis + (size_t)i0 * np, (size_t)ni * np * 4, hipMemcpyDefault,
+                                     R.stream));
+            launch_ivf_sanitize_assign(c_ids_.as<idx_t>(), (int64_t)ni * np, nlist, R.stream);
+        } else {
+            quantizer->search_device(ni, q_pad_.as<float>(), np, c_dis_.as<float>(), c_ids_.as<idx_t>());
+        }
         float* dD = out_dev_d ? distances + (size_t)i0 * k : nullptr;
         idx_t* dI = out_dev_i ? labels + (size_t)i0 * k : nullptr;
         if (!dD) {

@@ -98,6 +98,10 @@ struct Index {
     virtual void reconstruct(idx_t key, float* recons) const;
     virtual void reconstruct_n(idx_t i0, idx_t ni, float* recons) const;
     virtual void compute_residual(const float* x, float* residual, idx_t key) const;
+    // residuals[i] = xs[i] - reconstruct(keys[i])  (faiss/Index.h:375-383)
+    virtual void compute_residual_n(idx_t n, const float* xs, float* residuals, const idx_t* keys) const;
+    // recons[i] = reconstruct(keys[i])  (faiss/Index.h:297-307)
+    virtual void reconstruct_batch(idx_t n, const idx_t* keys, float* recons) const;
     virtual int device() const { return -1; }
 };
 
@@ -112,6 +116,11 @@ class GpuIndexFlat : public Index {
     void reset() override;
     void reconstruct(idx_t key, float* recons) const override;
     void reconstruct_n(idx_t i0, idx_t ni, float* recons) const override;
+    // on the device, any pointer host or device; a key of -1 gives a NaN row
+    // (faiss/gpu/GpuIndexFlat.cu:294-361, impl/VectorResidual.cu:26-60)
+    void compute_residual(const float* x, float* residual, idx_t key) const override;
+    void compute_residual_n(idx_t n, const float* xs, float* residuals, const idx_t* keys) const override;
+    void reconstruct_batch(idx_t n, const idx_t* keys, float* recons) const override;
     int device() const override { return res_->device; }
     size_t getNumVecs() const { return (size_t)ntotal; }
 
@@ -172,6 +181,12 @@ class GpuIndexIVF : public Index {
     void add(idx_t n, const float* x) override;
     void add_with_ids(idx_t n, const float* x, const idx_t* xids) override;
     void search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels) const override;
+    // search with the coarse quantization supplied by the caller: assign / centroid_dis are [n][nprobe]
+    // (host or device), -1 = no list (faiss/gpu/GpuIndexIVF.cu:408-488; IndexIVF::search_preassigned is what
+    // IndexShardsIVF and the hybrid CPU-quantizer benchmarks call).  centroid_dis must be the quantizer's
+    // distances for those lists (IVFPQ L2 adds them as the first term, as the reference does).
+    void search_preassigned(idx_t n, const float* x, idx_t k, const idx_t* assign, const float* centroid_dis,
+                            float* distances, idx_t* labels) const;
     void reset() override;
     int device() const override { return res_->device; }
 
@@ -210,6 +225,8 @@ class GpuIndexIVF : public Index {
     virtual int fused_M_() const { return 0; }
     mutable DevBuf part_keys_, part_cnt_;
     void upload_list_tables_();
+    void search_core_(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels, const idx_t* assign,
+                      const float* centroid_dis) const;
 
    public:
     // when false, search() takes the unfused path (every distance as a key in HBM + select);
@@ -278,6 +295,12 @@ class IndexShards : public Index {
 // base[s] is added to shard s's labels (successive_ids translation), may be null.
 void merge_knn_results(int metric, idx_t nq, idx_t k, int nshard, const float* all_d, const idx_t* all_i,
                        const idx_t* base, float* D, idx_t* I);
+
+// Brute-force k-nearest-neighbour on raw row-major fp32 arrays, host or device (the float32 / row-major subset
+// of faiss::gpu::bfKnn, faiss/gpu/GpuDistance.h:32-152 and GpuDistance.cu:bfKnn).  Same kernels, same tie rule and
+// the same bits as GpuIndexFlat::search on an index holding `vectors`.
+void bfKnn(std::shared_ptr<GpuResources> res, int metric, const float* vectors, idx_t num_vectors, const float* queries,
+           idx_t num_queries, int dims, idx_t k, float* out_distances, idx_t* out_indices);
 
 // device-side variant used by the one-process-per-GPU sharded search (faiss_amd/distributed.py):
 // all pointers are device pointers on res's device; work is ordered on res's stream and the

@@ -45,6 +45,20 @@ __global__ void ivf_prefix_kernel(const int64_t* __restrict__ coarse_ids, int nq
     total[q] = acc;
 }
 
+// caller-supplied probe lists (search_preassigned): anything outside [0, nlist) becomes -1 = "no list"
+__global__ void ivf_sanitize_assign_kernel(int64_t* __restrict__ ids, int64_t n, int nlist) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const int64_t l = ids[i];
+        if (l < 0 || l >= nlist) ids[i] = -1;
+    }
+}
+void launch_ivf_sanitize_assign(int64_t* ids, int64_t n, int nlist, hipStream_t stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(ivf_sanitize_assign_kernel, dim3((unsigned)div_up(n, 256)), dim3(256), 0, stream, ids, n, nlist);
+    HIP_CHECK(hipGetLastError());
+}
+
 void launch_ivf_prefix(const int64_t* coarse_ids, int nq, int nprobe, const uint32_t* list_len,
                        uint32_t* prefix, uint32_t* total, hipStream_t stream) {
     if (nq == 0) return;

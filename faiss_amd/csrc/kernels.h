@@ -16,6 +16,11 @@ void launch_l2_norms(const float* x, int64_t ld, int64_t n, int d, float* out, h
 void launch_pad_rows(const float* src, int64_t lds_src, int64_t n, int d, float* dst, int64_t ld_dst,
                      int dpad, hipStream_t stream);
 
+// out[i] = x[i] - rows[keys[i]] (x given) or rows[keys[i]] (x null); key outside [0, nrows) -> NaN row.
+// Replaces faiss/gpu/impl/VectorResidual.cu:26-97 (runCalcResidual) and the reconstruct-by-ids gather.
+void launch_rows_by_key(const float* x, int64_t ld_x, const int64_t* keys, int64_t n, int d, const float* rows,
+                        int64_t ld_rows, int64_t nrows, float* out, int64_t ld_out, hipStream_t stream);
+
 // ------------------------------------------------------------------ Flat: fused distance + k-selection
 constexpr int kFlatQueriesPerBlock = 256; // 8 waves x 32 queries
 constexpr int kFlatTileRows = 64;
@@ -65,7 +70,7 @@ struct FlatFilterParams {
     const _Float16* xqh; // [nq][ldqh] fp16 queries
     const float* xqn;    // [nq] exact fp32 squared norms of the queries (both metrics: error bound)
     const _Float16* xbh; // [nb][ldbh] fp16 database
-    const float* xbhn;   // [nb + 64] bias of the approximate score: |y|^2 / 2 (L2) or 0 (IP), then 64 x +inf
+    const float* xbhn;   // [nb + 64] start value of the approximate score: -|y|^2 / 2 (L2) or 0 (IP), then 64 x -inf
     int64_t ldqh, ldbh;
     int nq, nb, d, dh;   // dh = padded fp16 row length, multiple of kFilterSlab
     int geom;            // kernel geometry, see flat_filter_queries_per_block
@@ -177,6 +182,8 @@ void launch_pack_merge_keys(int metric, const float* all_d, const int64_t* all_i
                             unsigned long long* keys, uint32_t* cnt, hipStream_t stream);
 
 // ------------------------------------------------------------------ IVF
+// caller-supplied probe lists (search_preassigned): ids outside [0, nlist) become -1 = "no list"
+void launch_ivf_sanitize_assign(int64_t* ids, int64_t n, int nlist, hipStream_t stream);
 // prefix[q][0..nprobe] = exclusive prefix sum of list_len[coarse_ids[q][p]] (0 for id<0);
 // total[q] = prefix[q][nprobe].  (faiss/gpu/impl/IVFUtils.cu:131-186 runCalcListOffsets)
 void launch_ivf_prefix(const int64_t* coarse_ids, int nq, int nprobe, const uint32_t* list_len,

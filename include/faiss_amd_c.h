@@ -160,6 +160,33 @@ int faiss_amd_GpuIndexFlat_filter_stats(const FaissAmdIndex* index, int* used_fi
  * the per-query bound err_bound[n] on their deviation from the exact fp32 scores */
 int faiss_amd_GpuIndexFlat_filter_scores(const FaissAmdIndex* index, faiss_amd_idx_t n, const float* x, float* scores,
                                          float* err_bound);
+/* ---- the rest of the faiss::Index surface a coarse quantizer / shard wrapper uses
+ *      reconstruct_batch (faiss/Index.h:297-307; GpuIndexFlat.cu:294-320), compute_residual[_n]
+ *      (faiss/Index.h:363-383; GpuIndexFlat.cu:323-361, impl/VectorResidual.cu:26-97): residual = x - stored[key],
+ *      a key of -1 gives a row of NaNs.  Pointers host or device. */
+int faiss_amd_Index_reconstruct_batch(const FaissAmdIndex* index, faiss_amd_idx_t n, const faiss_amd_idx_t* keys,
+                                      float* recons);
+int faiss_amd_Index_compute_residual(const FaissAmdIndex* index, const float* x, float* residual, faiss_amd_idx_t key);
+int faiss_amd_Index_compute_residual_n(const FaissAmdIndex* index, faiss_amd_idx_t n, const float* xs, float* residuals,
+                                       const faiss_amd_idx_t* keys);
+
+/* ---- GpuIndexIVF::search_preassigned (faiss/gpu/GpuIndexIVF.h:112-122, GpuIndexIVF.cu:408-488; the entry
+ *      IndexShardsIVF and CPU-quantizer hybrids call): assign and centroid_dis are [n][nprobe] (nprobe = the
+ *      index's current value), host or device, -1 = no list.  With the arrays the index's own quantizer returns
+ *      (faiss_amd_IndexIVF_quantizer_search = index.quantizer->search) the result is bit-identical to search(). */
+int faiss_amd_GpuIndexIVF_search_preassigned(const FaissAmdIndex* index, faiss_amd_idx_t n, const float* x,
+                                             faiss_amd_idx_t k, const faiss_amd_idx_t* assign, const float* centroid_dis,
+                                             float* distances, faiss_amd_idx_t* labels);
+int faiss_amd_IndexIVF_quantizer_search(const FaissAmdIndex* index, faiss_amd_idx_t n, const float* x, faiss_amd_idx_t k,
+                                        float* distances, faiss_amd_idx_t* labels);
+
+/* ---- faiss::gpu::bfKnn (faiss/gpu/GpuDistance.h:32-152), float32 row-major subset: brute-force k-NN of
+ *      `queries` [num_queries][dims] in `vectors` [num_vectors][dims], both host or device, never written.
+ *      Same kernels, tie rule and bits as GpuIndexFlat::search.  L2 distances are squared. */
+int faiss_amd_bfKnn(FaissAmdGpuResources* res, FaissAmdMetricType metric, const float* vectors,
+                    faiss_amd_idx_t num_vectors, const float* queries, faiss_amd_idx_t num_queries, int dims,
+                    faiss_amd_idx_t k, float* out_distances, faiss_amd_idx_t* out_indices);
+
 /* IVF search through the unfused path (every distance as a key in HBM + select kernel) instead
  * of the fused LDS-resident scan; results are identical, the switch exists for cross-checks */
 int faiss_amd_GpuIndexIVF_set_use_fused_scan(FaissAmdIndex* index, int on);

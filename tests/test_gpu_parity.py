@@ -475,3 +475,77 @@ def test_flat_filter_full_size_matches_exact_scan(res):
     D0, I0 = idx.search(xq, 100)
     assert np.array_equal(I, I0) and np.array_equal(D, D0)
     assert (np.diff(D, axis=1) >= 0).all()
+
+
+# ------------------------------------------------------------------------------- rest of the Index surface
+@pytest.mark.parametrize("metric", [METRIC_L2, METRIC_INNER_PRODUCT])
+@pytest.mark.parametrize("kind", ["ivfflat", "ivfpq"])
+def test_search_preassigned_equals_search(res, kind, metric):
+    """faiss/gpu/test/test_gpu_index.py:124-194: search(x) and search_preassigned(x, quantizer.search(x)) return the
+    same bits; probes knocked out with -1 (or out-of-range ids) behave like a shorter probe list."""
+    d, nlist, nb, nq, k, nprobe = 64, 64, 20000, 300, 10, 8
+    xt, xb, xq = synthetic_dataset(d, 6000, nb, nq, seed=77)
+    if kind == "ivfflat":
+        idx = faiss_amd.GpuIndexIVFFlat(res, d, nlist, metric)
+    else:
+        idx = faiss_amd.GpuIndexIVFPQ(res, d, nlist, 8, 8, metric)
+    idx.train(xt)
+    idx.add(xb)
+    idx.nprobe = nprobe
+    D, I = idx.search(xq, k)
+    Dq, Iq = idx.quantizer_search(xq, nprobe)
+    D2, I2 = idx.search_preassigned(xq, k, Iq, Dq)
+    assert np.array_equal(I, I2) and np.array_equal(D, D2)
+    for fused in (True, False):
+        idx.set_use_fused_scan(fused)
+        Iq4 = Iq.copy()
+        Iq4[:, 4:] = -1
+        Iq4[::3, 5] = nlist + 7  # not a list: ignored
+        D3, I3 = idx.search_preassigned(xq, k, Iq4, Dq)
+        idx.nprobe = 4
+        D4, I4 = idx.search(xq, k)
+        idx.nprobe = nprobe
+        assert np.array_equal(I3, I4) and np.array_equal(D3, D4)
+    # all probes invalid: no result
+    Dn, In = idx.search_preassigned(xq[:5], k, np.full((5, nprobe), -1, dtype=np.int64), Dq[:5])
+    assert (In == -1).all()
+    with pytest.raises(ValueError):
+        idx.search_preassigned(xq, k, Iq[:, :4], Dq[:, :4])
+
+
+def test_flat_compute_residual_and_reconstruct_batch(res):
+    """GpuIndexFlat::compute_residual_n / reconstruct_batch (faiss/gpu/GpuIndexFlat.cu:294-361): one fp32
+    subtraction per element (bit-exact), key -1 -> NaN row (impl/VectorResidual.cu:35-47)."""
+    d, nb, n = 40, 3000, 257
+    _, xb, xq = synthetic_dataset(d, 0, nb, n, seed=9)
+    idx = faiss_amd.GpuIndexFlatL2(res, d)
+    idx.add(xb)
+    rs = np.random.RandomState(3)
+    keys = rs.randint(0, nb, size=n).astype(np.int64)
+    keys[5] = -1
+    keys[100] = -1
+    good = keys >= 0
+    R = idx.compute_residual_n(xq, keys)
+    assert np.array_equal(R[good], xq[good] - xb[keys[good]])
+    assert np.isnan(R[~good]).all()
+    B = idx.reconstruct_batch(keys)
+    assert np.array_equal(B[good], xb[keys[good]]) and np.isnan(B[~good]).all()
+    r1 = idx.compute_residual(xq[7], int(keys[7]))
+    assert np.array_equal(r1, xq[7] - xb[keys[7]])
+    assert idx.compute_residual_n(xq[:0], keys[:0]).shape == (0, d)
+
+
+@pytest.mark.parametrize("metric", [METRIC_L2, METRIC_INNER_PRODUCT])
+@pytest.mark.parametrize("d,nb,nq,k", [(128, 30000, 300, 10), (33, 2000, 17, 5), (64, 100, 4, 200)])
+def test_bfknn_equals_flat_index_and_oracle(res, metric, d, nb, nq, k):
+    """faiss::gpu::bfKnn on raw arrays (faiss/gpu/GpuDistance.h:32-152; test: faiss/gpu/test/test_gpu_basics.py
+    bfKnn cases): same answer as a flat index holding the vectors, and as the oracle."""
+    _, xb, xq = synthetic_dataset(d, 0, nb, nq, seed=d + k)
+    D, I = faiss_amd.knn_gpu(res, xq, xb, k, metric)
+    idx = faiss_amd.GpuIndexFlat(res, d, metric)
+    idx.add(xb)
+    D2, I2 = idx.search(xq, k)
+    assert np.array_equal(I, I2) and np.array_equal(D, D2)
+    Do, Io = Oracle.flat_search(metric, xb, xq, k)
+    check_knn(D, I, Do, Io, exact=True, name="bfKnn")
+    assert xb.flags.c_contiguous  # inputs untouched
