@@ -8,11 +8,16 @@ nb=1M; the reference's SyntheticDataset recipe, seed 1338).  A "step" is one sea
   N = 1 : GpuIndexFlatL2 (BASELINE.json configs[1]); `value` = Flat QPS.  The same line also
           carries the IVF4096,PQ64 numbers (`ivfpq`), the roofline of the dominant kernel and
           the reference CPU path timed on this node's host cores (`cpu_baseline`).
-  N > 1 : one process per GPU (torch.distributed, backend "nccl" = RCCL).  The 1M database is
-          sharded IndexShards-style (rank r holds rows [r*nb/N, (r+1)*nb/N)); every rank
-          searches all queries on its shard, the per-rank top-k are gathered point-to-point
-          onto rank 0 over xGMI and merged there by the device select kernel.  Total work is
-          fixed => "scaling": "strong".
+  N > 1 : one process per GPU (torch.distributed, backend "nccl" = RCCL), total work fixed =>
+          "scaling": "strong".  --multi-gpu replicas (default): what the reference builds for a
+          database that fits one GPU (index_cpu_to_gpu_multiple, GpuMultipleClonerOptions::shard =
+          false -> IndexReplicas): every rank holds the 1M vectors and searches its block of the
+          queries; the result blocks are gathered onto rank 0 (1.5 MB per rank at N = 8, no
+          merge).  --multi-gpu shards: IndexShards-style (rank r holds rows [r*nb/N, (r+1)*nb/N)),
+          every rank searches all queries on its shard, the per-rank top-k are gathered
+          point-to-point onto rank 0 over xGMI and merged there by the device select kernel --
+          the layout for databases beyond one GPU (BASELINE.json configs[4]); at nb = 1M its
+          replicated per-query work (re-rank, gather, merge) dominates.
 
 Run:  python bench.py [--gpus N --steps K --warmup W]
       python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -205,6 +210,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ivfpq", action="store_true")
+    ap.add_argument("--multi-gpu", choices=["replicas", "shards"], default="replicas",
+                    help="N > 1: replicas = every GPU holds the database, queries are split (IndexReplicas, the "
+                         "reference's default for databases that fit one GPU); shards = rows are split (IndexShards)")
     ap.add_argument("--flat-path", choices=["filter", "exact"], default="filter",
                     help="filter: fp16 MFMA candidate filter + exact fp32 re-rank (default, bit-identical results); "
                          "exact: fp32 MFMA scan only")
@@ -225,12 +233,13 @@ def main():
 
     import faiss_amd  # after torch: both then share one HIP runtime in this process
     from faiss_amd.datasets import synthetic_dataset
-    from faiss_amd.distributed import ShardedSearcher, shard_bounds
+    from faiss_amd.distributed import ReplicatedSearcher, ShardedSearcher, replica_bounds, shard_bounds
 
     res = faiss_amd.StandardGpuResources(local_rank)
     t0 = time.time()
     xt, xb, xq = synthetic_dataset(D, NT, NB, NQ, seed=1338)
-    bounds = shard_bounds(NB, world)
+    replicas = world > 1 and args.multi_gpu == "replicas"
+    bounds = [(0, NB)] * world if replicas else shard_bounds(NB, world)
     lo, hi = bounds[rank]
     index = faiss_amd.GpuIndexFlatL2(res, D)
     index.set_use_filter_kernel(args.flat_path == "filter")
@@ -239,8 +248,9 @@ def main():
         log("data + add: %.1fs (shard rows %d..%d of %d)" % (time.time() - t0, lo, hi, NB))
 
     xq_dev = torch.from_numpy(xq).to(dev)
-    D_loc = torch.empty((NQ, K), dtype=torch.float32, device=dev)
-    I_loc = torch.empty((NQ, K), dtype=torch.int64, device=dev)
+    nq_loc = replica_bounds(NQ, world)[1] if replicas else NQ
+    D_loc = torch.empty((nq_loc, K), dtype=torch.float32, device=dev)
+    I_loc = torch.empty((nq_loc, K), dtype=torch.int64, device=dev)
     D_out = torch.empty((NQ, K), dtype=torch.float32, device=dev)
     I_out = torch.empty((NQ, K), dtype=torch.int64, device=dev)
 
@@ -256,7 +266,21 @@ def main():
                                            all_I.data_ptr(), base, D_out.data_ptr(), I_out.data_ptr())
         return D_out, I_out
 
-    searcher = ShardedSearcher(local_search, merge, [b - a for a, b in bounds], dev)
+    def local_search_block(qlo, qhi, k):
+        if qhi > qlo:
+            index.search_ptr(qhi - qlo, xq_dev.data_ptr() + qlo * D * 4, k, D_loc.data_ptr(), I_loc.data_ptr())
+        return D_loc, I_loc
+
+    if replicas:
+        rep = ReplicatedSearcher(local_search_block, NQ, dev)
+
+        class _S:  # same call shape as ShardedSearcher.search
+            @staticmethod
+            def search(_xq, k):
+                return rep.search(k)
+        searcher = _S
+    else:
+        searcher = ShardedSearcher(local_search, merge, [b - a for a, b in bounds], dev)
 
     def barrier():
         if world > 1:
@@ -300,12 +324,13 @@ def main():
     # dominant kernel: the scan of this rank's shard.  Algorithmic work per launch =
     # 2*nq*nb_shard*d flops (256 MFLOP/query at nb=1M, d=128), priced against the
     # dense MFMA peak of the unit the kernel runs on (f16 for the filter, f32 for the exact scan).
-    flops = 2.0 * NQ * (hi - lo) * D
+    nq_rank0 = (replica_bounds(NQ, world)[0][0][1]) if replicas else NQ  # queries of the launches timed on rank 0
+    flops = 2.0 * nq_rank0 * (hi - lo) * D
     achieved = flops / (avg_scan_ms * 1e-3) / 1e12
     peak = PEAK_F16_MFMA_TFLOPS if used_filter else PEAK_F32_MFMA_TFLOPS
     # one sweep of the shard + queries + results is the algorithmic HBM traffic of the launch
     row_bytes = D * (2.0 if used_filter else 4.0)
-    hbm_bytes = (hi - lo) * row_bytes + NQ * row_bytes + NQ * K * 12.0
+    hbm_bytes = (hi - lo) * row_bytes + nq_rank0 * row_bytes + nq_rank0 * K * 12.0
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the
     # figure is the rocprofv3 --pmc FETCH_SIZE pass committed under profiles/ (same kernel, same
     # workload, corrected x2 as the MI355X guide prescribes for 16 B/lane reads on gfx950)
@@ -329,8 +354,11 @@ def main():
         if used_filter else "f32", "data": "synthetic",
         "config": {"workload": "GpuIndexFlatL2 d=128 nb=1M nq=10k k=100 (BASELINE.json configs[1])",
                    "generator": "SyntheticDataset(d=128, nt=100k, nb=1M, nq=10k, seed=1338)",
-                   "sharding": "IndexShards-style rows/%d per GPU, gather to rank 0 + device merge" % world
-                   if world > 1 else "single GPU", "inputs": "queries/results resident in HBM",
+                   "sharding": ("single GPU" if world == 1 else
+                                "IndexReplicas-style: database on every GPU, %d-query blocks, result blocks gathered to rank 0"
+                                % nq_loc if replicas else
+                                "IndexShards-style rows/%d per GPU, gather to rank 0 + device merge" % world),
+                   "inputs": "queries/results resident in HBM",
                    "flat_path": "filter" if used_filter else "exact"},
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2),
                      "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),

@@ -53,6 +53,8 @@ def load_library():
         "faiss_amd_GpuIndexIVFPQ_new": (i32, [P(vp), vp, i32, i32, i32, i32, i32]),
         "faiss_amd_IndexShards_new": (i32, [P(vp), i32, i32, i32]),
         "faiss_amd_IndexShards_add_shard": (i32, [vp, vp]),
+        "faiss_amd_IndexReplicas_new": (i32, [P(vp), i32, i32]),
+        "faiss_amd_IndexReplicas_add_replica": (i32, [vp, vp]),
         "faiss_amd_Index_free": (None, [vp]),
         "faiss_amd_Index_d": (i32, [vp]),
         "faiss_amd_Index_is_trained": (i32, [vp]),
@@ -443,6 +445,20 @@ class IndexShards(Index):
     def add_shard(self, index):
         self._keep.append(index)
         _check(self._lib.faiss_amd_IndexShards_add_shard(self._h, index._h))
+
+
+class IndexReplicas(Index):
+    """faiss.IndexReplicas (faiss/IndexReplicas.h:20-82): every replica holds the database, queries are split."""
+
+    def __init__(self, d, threaded=True):
+        super().__init__()
+        _check(self._lib.faiss_amd_IndexReplicas_new(ctypes.byref(self._h), int(d), int(threaded)))
+
+    def add_replica(self, index):
+        self._keep.append(index)
+        _check(self._lib.faiss_amd_IndexReplicas_add_replica(self._h, index._h))
+
+    addIndex = add_replica
 
 
 def kmeans(res, x, k, niter=25, seed=1234):

@@ -165,6 +165,18 @@ int faiss_amd_IndexShards_add_shard(FaissAmdIndex* shards, FaissAmdIndex* shard)
     as<IndexShards>(shards, "IndexShards")->add_shard(I(shard));
     FA_CATCH
 }
+int faiss_amd_IndexReplicas_new(FaissAmdIndex** p_index, int d, int threaded) {
+    FA_TRY
+    auto* h = new FaissAmdIndex_H{nullptr, nullptr};
+    h->index = new IndexReplicas(d, threaded != 0);
+    *p_index = h;
+    FA_CATCH
+}
+int faiss_amd_IndexReplicas_add_replica(FaissAmdIndex* replicas, FaissAmdIndex* replica) {
+    FA_TRY
+    as<IndexReplicas>(replicas, "IndexReplicas")->add_replica(I(replica));
+    FA_CATCH
+}
 void faiss_amd_Index_free(FaissAmdIndex* index) {
     if (!index) return;
     delete index->index;

@@ -470,7 +470,11 @@ __global__ void __launch_bounds__(FqGeom<QB>::THREADS, 2) flat_filter_kernel(Fla
     };
 
     // one step: the MFMAs of tile/slab u out of ring slot `slot`, and the epilogue behind its last slab
+    // a wave none of whose queries exists (last query group of a batch) only stages its share of the tiles and
+    // meets the barriers: the partner wave on its SIMD gets the matrix pipe to itself
+    const bool wave_idle = qbase >= p.nq; // wave-uniform
     auto compute = [&](int u, int slot) __attribute__((always_inline)) {
+        if (wave_idle) return;
         const int tl = u / nslab, sl = u - tl * nslab;
         if (!SINGLE && u > 0) load_b(sl);
         const char* tile = smem + slot * FQ_TILE_BYTES;

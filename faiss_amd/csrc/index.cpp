@@ -1523,4 +1523,67 @@ void IndexShards::search(idx_t n, const float* x, idx_t k, float* distances, idx
                       successive_ids ? base.data() : nullptr, distances, labels);
 }
 
+// ====================================================================== IndexReplicas
+IndexReplicas::IndexReplicas(int d_, bool threaded_) : Index(d_, METRIC_L2), threaded(threaded_) {}
+IndexReplicas::~IndexReplicas() {
+    if (own_indices)
+        for (auto* r : replicas_) delete r;
+}
+void IndexReplicas::sync_() {
+    // reference: IndexReplicasTemplate::syncWithSubIndexes (faiss/IndexReplicas.cpp:177-198)
+    if (replicas_.empty()) {
+        ntotal = 0;
+        is_trained = false;
+        return;
+    }
+    metric_type = replicas_[0]->metric_type;
+    is_trained = replicas_[0]->is_trained;
+    ntotal = replicas_[0]->ntotal;
+    for (auto* r : replicas_) {
+        FA_THROW_IF_NOT_MSG(r->d == d, "replica dimension mismatch");
+        FA_THROW_IF_NOT_MSG(r->metric_type == metric_type, "replica metric mismatch");
+        FA_THROW_IF_NOT_MSG(r->is_trained == is_trained, "replica training state mismatch");
+        FA_THROW_IF_NOT_MSG(r->ntotal == ntotal, "replicas hold different numbers of vectors");
+    }
+}
+void IndexReplicas::add_replica(Index* idx) {
+    replicas_.push_back(idx);
+    sync_();
+}
+void IndexReplicas::train(idx_t n, const float* x) {
+    run_on_shards(replicas_, threaded, [&](int, Index* r) { r->train(n, x); });
+    sync_();
+}
+void IndexReplicas::add(idx_t n, const float* x) {
+    run_on_shards(replicas_, threaded, [&](int, Index* r) { r->add(n, x); });
+    sync_();
+}
+void IndexReplicas::add_with_ids(idx_t n, const float* x, const idx_t* xids) {
+    run_on_shards(replicas_, threaded, [&](int, Index* r) { r->add_with_ids(n, x, xids); });
+    sync_();
+}
+void IndexReplicas::reset() {
+    run_on_shards(replicas_, threaded, [&](int, Index* r) { r->reset(); });
+    sync_();
+}
+void IndexReplicas::reconstruct(idx_t key, float* recons) const {
+    FA_THROW_IF_NOT_MSG(!replicas_.empty(), "no replicas in index");
+    replicas_[0]->reconstruct(key, recons); // faiss/IndexReplicas.cpp:83-89
+}
+void IndexReplicas::search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels) const {
+    // reference: faiss/IndexReplicas.cpp:123-175 (queries dealt out in ceil(n / count) blocks)
+    FA_THROW_IF_NOT_MSG(k > 0, "k must be positive");
+    const idx_t cnt = (idx_t)replicas_.size();
+    FA_THROW_IF_NOT_MSG(cnt > 0, "no replicas in index");
+    if (n == 0) return;
+    const idx_t per = (n + cnt - 1) / cnt;
+    run_on_shards(replicas_, threaded, [&](int i, Index* r) {
+        const idx_t base = (idx_t)i * per;
+        if (base < n) {
+            const idx_t ni = std::min(per, n - base);
+            r->search(ni, x + (size_t)base * d, k, distances + (size_t)base * k, labels + (size_t)base * k);
+        }
+    });
+}
+
 } // namespace faiss_amd

@@ -291,6 +291,30 @@ class IndexShards : public Index {
     void sync_();
 };
 
+// ------------------------------------------------------------------ IndexReplicas
+// Every replica holds the whole database; add() goes to all of them, search() splits the QUERIES evenly over
+// the replicas, one host thread each (faiss/IndexReplicas.cpp:91-175).  What index_cpu_to_gpu_multiple builds
+// by default (GpuMultipleClonerOptions::shard = false, faiss/gpu/GpuClonerOptions.h:57-59).
+class IndexReplicas : public Index {
+   public:
+    IndexReplicas(int d, bool threaded);
+    ~IndexReplicas() override;
+    bool threaded;
+    bool own_indices = false;
+    void add_replica(Index* idx);
+    int count() const { return (int)replicas_.size(); }
+    void train(idx_t n, const float* x) override;
+    void add(idx_t n, const float* x) override;
+    void add_with_ids(idx_t n, const float* x, const idx_t* xids) override;
+    void search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels) const override;
+    void reconstruct(idx_t key, float* recons) const override;
+    void reset() override;
+
+   private:
+    std::vector<Index*> replicas_;
+    void sync_();
+};
+
 // merge nshard sorted partial results [s][nq][k] into [nq][k] under (distance, label) order;
 // base[s] is added to shard s's labels (successive_ids translation), may be null.
 void merge_knn_results(int metric, idx_t nq, idx_t k, int nshard, const float* all_d, const idx_t* all_i,

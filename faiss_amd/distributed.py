@@ -13,6 +13,9 @@ The only exchange is that gather: nq*k*(4+8) bytes per rank (12 MB at nq=10k, k=
 point-to-point to rank 0 over xGMI by RCCL (``torch.distributed.gather`` on the "nccl" backend
 is a set of send/recv pairs, so each peer uses its own direct link).  No all-reduce / ring is
 involved.  On CPU the identical code path runs over gloo with a host merge (tests/).
+
+When the database fits one GPU the reference replicates instead (IndexReplicas: every GPU holds everything, the
+QUERIES are split) -- ReplicatedSearcher below; its only exchange is the gather of the result blocks.
 """
 import numpy as np
 import torch
@@ -55,6 +58,53 @@ class ShardedSearcher:
         dist.gather(D, None, dst=0, group=self.group)
         dist.gather(I, None, dst=0, group=self.group)
         return None
+
+
+class ReplicatedSearcher:
+    """IndexReplicas across the ranks of a torch.distributed group: every rank holds the WHOLE database and
+    searches its block of the queries (faiss/IndexReplicas.cpp:141-164; the default multi-GPU layout of the
+    reference, GpuMultipleClonerOptions::shard = false).  The only exchange is the gather of the result blocks
+    onto rank 0 -- nq/N * k * 12 bytes per rank, no merge.
+
+    local_search(lo, hi, k) -> (D, I) torch tensors [per, k] on `device` whose first hi-lo rows are the results of
+    queries [lo, hi); `per` = replica_bounds(nq, world)[1] (equal block size, so one gather moves everything).
+    """
+
+    def __init__(self, local_search, nq, device, group=None):
+        self.local_search = local_search
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.nq = nq
+        self.bounds, self.per = replica_bounds(nq, self.world)
+        self.device = device
+        self._gD = self._gI = None
+
+    def search(self, k):
+        lo, hi = self.bounds[self.rank]
+        D, I = self.local_search(lo, hi, k)
+        if self.world == 1:
+            return D[: self.nq], I[: self.nq]
+        assert D.shape == (self.per, k) and I.shape == (self.per, k)
+        if self.rank == 0:
+            if self._gD is None or self._gD.shape != (self.world, self.per, k):
+                self._gD = torch.empty((self.world, self.per, k), dtype=torch.float32, device=self.device)
+                self._gI = torch.empty((self.world, self.per, k), dtype=torch.int64, device=self.device)
+            dist.gather(D, list(self._gD.unbind(0)), dst=0, group=self.group)
+            dist.gather(I, list(self._gI.unbind(0)), dst=0, group=self.group)
+            # blocks are consecutive query ranges of equal size: the gathered buffer IS the result
+            return self._gD.view(-1, k)[: self.nq], self._gI.view(-1, k)[: self.nq]
+        dist.gather(D, None, dst=0, group=self.group)
+        dist.gather(I, None, dst=0, group=self.group)
+        return None
+
+
+def replica_bounds(nq, world, granule=128):
+    """Query block of every rank: equal blocks of ceil(nq / world) queries like IndexReplicas::search, rounded up
+    to the 128 queries one wavefront of the flat kernel holds.  Returns ([(lo, hi)], block size)."""
+    per = -(-nq // world)
+    per = -(-per // granule) * granule
+    return [(min(nq, r * per), min(nq, (r + 1) * per)) for r in range(world)], per
 
 
 def shard_bounds(nb, world):

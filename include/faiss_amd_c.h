@@ -65,6 +65,11 @@ int faiss_amd_GpuIndexIVFPQ_new(FaissAmdIndex** p_index, FaissAmdGpuResources* r
                                 int M, int nbits, FaissAmdMetricType metric);
 int faiss_amd_IndexShards_new(FaissAmdIndex** p_index, int d, int threaded, int successive_ids);
 int faiss_amd_IndexShards_add_shard(FaissAmdIndex* shards, FaissAmdIndex* shard);
+/* faiss/IndexReplicas.h:20-82: IndexReplicas(d, threaded) + addIndex.  Every replica holds the whole database;
+ * search() deals the queries out in ceil(n / count) blocks (IndexReplicas.cpp:123-175).  This is what
+ * index_cpu_to_gpu_multiple builds by default (GpuMultipleClonerOptions::shard = false, GpuClonerOptions.h:57-59) */
+int faiss_amd_IndexReplicas_new(FaissAmdIndex** p_index, int d, int threaded);
+int faiss_amd_IndexReplicas_add_replica(FaissAmdIndex* replicas, FaissAmdIndex* replica);
 /* c_api/Index_c.h:56 faiss_Index_free */
 void faiss_amd_Index_free(FaissAmdIndex* index);
 

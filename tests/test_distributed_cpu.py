@@ -72,3 +72,54 @@ def test_shard_bounds_match_reference_split():
     # IndexShards::add: shard `no` gets rows [no*n/nshard, (no+1)*n/nshard) (faiss/IndexShards.cpp:172-175)
     assert shard_bounds(10, 3) == [(0, 3), (3, 6), (6, 10)]
     assert shard_bounds(1000000, 8)[7] == (875000, 1000000)
+
+
+def _replica_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from faiss_amd.distributed import ReplicatedSearcher
+    from oracle.pyoracle import Oracle, integer_dataset
+
+    xb, xq = integer_dataset(16, 900, 301, seed=6, hi=5)  # 301 queries: blocks of 256 and 45
+    k = 7
+    s = ReplicatedSearcher(None, len(xq), torch.device("cpu"))
+    per = s.per
+
+    def local_search(lo, hi, kk):
+        D = np.full((per, kk), np.nan, dtype=np.float32)
+        I = np.full((per, kk), -7, dtype=np.int64)
+        if hi > lo:
+            D[: hi - lo], I[: hi - lo] = Oracle.flat_search(1, xb, xq[lo:hi], kk)
+        return torch.from_numpy(D), torch.from_numpy(I)
+
+    s.local_search = local_search
+    out = None
+    for _ in range(2):
+        out = s.search(k)
+    if rank == 0:
+        Df, If = Oracle.flat_search(1, xb, xq, k)
+        ok = out[0].shape == (len(xq), k) and np.array_equal(out[1].numpy(), If) and np.array_equal(out[0].numpy(), Df)
+        with open(out_path, "w") as f:
+            f.write("OK" if ok else "MISMATCH")
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_replicated_search_two_ranks_gloo(tmp_path):
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_replica_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert open(out).read() == "OK"
+
+
+def test_replica_bounds():
+    from faiss_amd.distributed import replica_bounds
+    # IndexReplicas::search deals out ceil(n / count) queries per replica (faiss/IndexReplicas.cpp:141-151),
+    # here rounded up to whole 128-query wavefronts
+    assert replica_bounds(10000, 8) == ([(0, 1280), (1280, 2560), (2560, 3840), (3840, 5120), (5120, 6400),
+                                         (6400, 7680), (7680, 8960), (8960, 10000)], 1280)
+    assert replica_bounds(10000, 1) == ([(0, 10000)], 10112)
+    assert replica_bounds(100, 4) == ([(0, 100), (100, 100), (100, 100), (100, 100)], 128)

@@ -549,3 +549,39 @@ def test_bfknn_equals_flat_index_and_oracle(res, metric, d, nb, nq, k):
     Do, Io = Oracle.flat_search(metric, xb, xq, k)
     check_knn(D, I, Do, Io, exact=True, name="bfKnn")
     assert xb.flags.c_contiguous  # inputs untouched
+
+
+def test_index_replicas_equals_single_index(res):
+    """faiss/tests/test_threaded_index.cpp:165-214 (replicas): add goes to every replica, queries are dealt out in
+    ceil(n / count) blocks, results equal the single index bit for bit."""
+    xb, xq = integer_dataset(24, 9000, 67, seed=12, hi=6)
+    single = faiss_amd.GpuIndexFlatL2(res, 24)
+    single.add(xb)
+    Dr, Ir = single.search(xq, 40)
+    rep = faiss_amd.IndexReplicas(24, threaded=True)
+    for _ in range(3):
+        rep.add_replica(faiss_amd.GpuIndexFlatL2(faiss_amd.StandardGpuResources(0), 24))
+    rep.add(xb)
+    assert rep.ntotal == 9000
+    D, I = rep.search(xq, 40)
+    assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+    D1, I1 = rep.search(xq[:2], 40)  # fewer queries than replicas
+    assert np.array_equal(I1, Ir[:2])
+    assert np.array_equal(rep.reconstruct(17), xb[17])
+    rep.reset()
+    assert rep.ntotal == 0
+
+
+def test_partial_query_groups_in_the_8_wave_geometry(res):
+    """query counts that leave whole wavefronts of the last workgroup without a query (they skip the MFMAs)"""
+    _, xb, xq = synthetic_dataset(128, 0, 40000, 2600, seed=21)
+    idx = faiss_amd.GpuIndexFlatL2(res, 128)
+    idx.add(xb)
+    idx.set_use_filter_kernel(False)
+    Dr, Ir = idx.search(xq, 20)
+    idx.set_use_filter_kernel(True)
+    for n in (2049, 2176, 2600):
+        D, I = idx.search(xq[:n], 20)
+        used, novf = idx.filter_stats()
+        assert used and novf == 0
+        assert np.array_equal(I, Ir[:n]) and np.array_equal(D, Dr[:n])
