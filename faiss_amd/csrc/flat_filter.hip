@@ -82,6 +82,42 @@ void launch_convert_f16(const float* src, int64_t ld_src, int64_t n, int d, void
     HIP_CHECK(hipGetLastError());
 }
 
+// Per-search query preparation in ONE launch (the searches of small batches are launch-latency bound): fp16 copy +
+// range flag of convert_f16_kernel, |q|^2 as the sequential fmaf chain of l2_norms_kernel (lane 0), and the reset
+// of the overflow counter the re-rank kernel appends to.  One wavefront per query.
+__global__ void __launch_bounds__(64) prep_queries_kernel(const float* __restrict__ xq_pad, int64_t ld, int64_t n, int d,
+                                                          int dpad, _Float16* __restrict__ qh, int dh,
+                                                          uint32_t* __restrict__ flags, float* __restrict__ qnorm,
+                                                          unsigned* __restrict__ counter) {
+    const int64_t i = blockIdx.x;
+    const float* r = xq_pad + i * ld;
+    _Float16* o = qh + i * dh;
+    bool bad = false;
+    for (int c = threadIdx.x; c < dh; c += 64) {
+        const float v = c < d ? r[c] : 0.f;
+        if (!(fabsf(v) <= 65000.f)) bad = true; // NaN, inf, or beyond the fp16 normal range
+        o[c] = (_Float16)v;
+    }
+    const bool anybad = __ballot(bad) != 0ull;
+    if (threadIdx.x == 0) {
+        flags[i] = anybad ? 1u : 0u;
+        float acc = 0.f;
+        for (int k = 0; k < dpad; ++k) {
+            const float v = r[k];
+            acc = __fmaf_rn(v, v, acc);
+        }
+        qnorm[i] = acc;
+        if (i == 0) *counter = 0u;
+    }
+}
+void launch_prep_queries(const float* xq_pad, int64_t ld, int64_t n, int d, int dpad, void* qh, int dh, uint32_t* flags,
+                         float* qnorm, unsigned* counter, hipStream_t stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(prep_queries_kernel, dim3((unsigned)n), dim3(64), 0, stream, xq_pad, ld, n, d, dpad,
+                       (_Float16*)qh, dh, flags, qnorm, counter);
+    HIP_CHECK(hipGetLastError());
+}
+
 // out[i] = -|y_i|^2 / 2 (L2) or 0 (IP) for i < n, -inf for the npad entries that follow: the value the
 // filter kernel's accumulators START from (score = <q,y> - |y|^2/2; rows past the end can never qualify)
 __global__ void half_norms_kernel(const float* __restrict__ xn, int64_t n, int npad, int metric,
@@ -741,7 +777,7 @@ void launch_flat_tighten(const FlatFilterParams& p, hipStream_t stream) {
 // re-rank kernel: one workgroup per query
 // ---------------------------------------------------------------------------------
 constexpr int RR_THREADS = 256;
-constexpr int RR_GATHER = 4096; // approximate candidates per query gathered into LDS
+constexpr int RR_GATHER = 4096; // upper limit of FlatRerankParams::gcap (approximate candidates gathered into LDS)
 constexpr int RR_CAND = 2048;   // rows inside the error band that are re-ranked exactly
 
 struct RrShared {
@@ -754,8 +790,8 @@ template <int METRIC>
 __global__ void __launch_bounds__(RR_THREADS) flat_rerank_kernel(FlatRerankParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     RrShared* sh = (RrShared*)smem;
-    u64* cand = (u64*)(smem + ((sizeof(RrShared) + 15) & ~(size_t)15)); // [RR_GATHER]
-    float* qs = (float*)(cand + RR_GATHER);                               // [dpad]
+    u64* cand = (u64*)(smem + ((sizeof(RrShared) + 15) & ~(size_t)15)); // [gcap]
+    float* qs = (float*)(cand + p.gcap);                                  // [dpad]
     int64_t* w_id = (int64_t*)(qs + p.dpad + (p.dpad & 1));               // [kp] (8-byte aligned)
     unsigned* w_key = (unsigned*)(w_id + p.kp);                           // [kp]
     const int q = blockIdx.x;
@@ -777,12 +813,12 @@ __global__ void __launch_bounds__(RR_THREADS) flat_rerank_kernel(FlatRerankParam
             const unsigned base = atomicAdd(&sh->total, cnt);
             const u64* seg = p.res_keys + ((int64_t)q * p.nsplit + s) * p.cap;
             for (unsigned i = 0; i < cnt; ++i)
-                if (base + i < (unsigned)RR_GATHER) cand[base + i] = seg[i];
+                if (base + i < (unsigned)p.gcap) cand[base + i] = seg[i];
         }
     }
     __syncthreads();
     int n = (int)sh->total;
-    if (n > RR_GATHER) {
+    if (n > p.gcap) {
         if (tid == 0) p.ovf_list[atomicAdd(p.ovf_cnt, 1u)] = (uint32_t)q;
         return;
     }
@@ -862,7 +898,8 @@ __global__ void __launch_bounds__(RR_THREADS) flat_rerank_kernel(FlatRerankParam
 void launch_flat_rerank(const FlatRerankParams& p, hipStream_t stream) {
     if (p.nq == 0) return;
     FA_THROW_IF_NOT(p.k >= 1 && p.k <= kMaxSelectionK && p.dpad % 8 == 0);
-    const size_t lds = ((sizeof(RrShared) + 15) & ~(size_t)15) + (size_t)RR_GATHER * 8 +
+    FA_THROW_IF_NOT(p.gcap >= p.kp && p.gcap <= RR_GATHER && p.gcap % 2 == 0);
+    const size_t lds = ((sizeof(RrShared) + 15) & ~(size_t)15) + (size_t)p.gcap * 8 +
                        (size_t)(p.dpad + (p.dpad & 1)) * 4 + (size_t)p.kp * 12;
     FA_THROW_IF_NOT_MSG(lds <= 160 * 1024, "re-rank workspace exceeds the LDS");
     if (p.metric == METRIC_L2) {

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <queue>
 #include <random>
 #include <thread>
 #include "kernels.h"
@@ -340,28 +341,58 @@ bool GpuIndexFlat::filter_applicable_(int k) const {
 
 // split count, sampling stride of the maxima pass and segment capacity of the collect pass for a
 // tile of n queries
-void GpuIndexFlat::plan_filter_(int n, int k, int& geom, int& nsplit, int& tstride, int& cap) const {
+void GpuIndexFlat::plan_filter_(int n, int k, int& geom, int& nsplit, int& tstride, int& cap, int& gcap) const {
+    std::string knobs;
+    for (const char* name : {"FAISS_AMD_FILTER_GEOM", "FAISS_AMD_FILTER_NSPLIT"}) {
+        const char* e = getenv(name);
+        knobs += e ? e : "-";
+        knobs += ';';
+    }
+    auto& pc = plan_cache_;
+    if (pc.n == n && pc.k == k && pc.ntotal == ntotal && pc.knobs == knobs) {
+        geom = pc.geom, nsplit = pc.nsplit, tstride = pc.tstride, cap = pc.cap, gcap = pc.gcap;
+        return;
+    }
     // large batches of d <= 128: 8 waves x 128 queries per workgroup, one workgroup per CU;
     // otherwise 4 waves x 64 queries, two workgroups per CU
     geom = (dh_ == kFilterSlab && n >= 2048) ? 2 : 0;
+    if (const char* e = getenv("FAISS_AMD_FILTER_GEOM")) { // timing experiments only
+        if (atoi(e) == 0 || dh_ == kFilterSlab) geom = atoi(e) ? 2 : 0;
+    }
     const int qpb = flat_filter_queries_per_block(geom), cps = flat_filter_chunks_per_split(geom);
     const int ngroups = (int)div_up(n, qpb);
     const int total_tiles = (int)div_up(ntotal, kFilterTileRows);
     // S = cps * nsplit chunk maxima per query must exceed k comfortably (S >= 2.5 k keeps the expected
-    // number of rows above the k-th largest maximum below ~1.3 k); nsplit * ngroups should fill
-    // whole rounds of the resident workgroup slots
+    // number of rows above the k-th largest maximum below ~1.3 k); nsplit * ngroups workgroups should keep
+    // every resident workgroup slot busy until the end
     const int smin = (int)round_up(std::max<size_t>(8, div_up((size_t)(5 * k), 2 * cps)), 8);
     const int smax = (int)std::max<size_t>(smin, std::min<size_t>(256, (size_t)total_tiles / 4 / 8 * 8));
     const int slots = (geom == 2 ? 1 : 2) * res_->num_cus;
+    // cost of a workgroup of the last query group relative to a full one: its wavefronts without a query
+    // skip the MFMAs, which leaves the matrix pipes to the others (measured: 2 of 8 waves ~ 0.4)
+    const int waves = geom == 2 ? 8 : 4, qpw = qpb / waves;
+    const int last_waves = (int)div_up(n - (ngroups - 1) * qpb, qpw);
+    const double last_cost = std::max(0.4, (double)last_waves / waves);
     int best = smin;
-    double best_score = -1.0;
+    double best_score = 1e30;
     for (int s = smin; s <= smax; s += 8) {
+        // makespan of the launch under the dispatcher's greedy placement (workgroup b: group (b >> 3) % ngroups
+        // when s is a multiple of 8, flat_filter_kernel), in units of one sweep of the database
+        std::priority_queue<double, std::vector<double>, std::greater<double>> free_at;
+        for (int i = 0; i < slots; ++i) free_at.push(0.0);
+        double makespan = 0.0;
         const long total = (long)s * ngroups;
-        const long rounds = (total + slots - 1) / slots;
-        // whole rounds of workgroups, with a slight preference for fewer splits (measured at nq = 10k,
-        // nb = 1M: 48 splits / 1.9 rounds 3.21 ms, 96 / 3.75 3.10 ms, 128 / 5.0 3.01 ms, 256 / 10.0 3.12 ms)
-        const double score = (double)total / (double)(rounds * slots) - 2e-4 * s;
-        if (score > best_score) {
+        for (long b = 0; b < total; ++b) {
+            const int grp = (int)((b >> 3) % ngroups);
+            const double t = free_at.top() + (grp == ngroups - 1 ? last_cost : 1.0) / s;
+            free_at.pop();
+            free_at.push(t);
+            makespan = std::max(makespan, t);
+        }
+        // slight preference for fewer splits (measured at nq = 10k, nb = 1M: 48 splits / 1.9 rounds 3.21 ms,
+        // 96 / 3.75 3.10 ms, 128 / 5.0 3.01 ms, 256 / 10.0 3.12 ms)
+        const double score = makespan * (1.0 + 2e-4 * s);
+        if (score < best_score) {
             best_score = score;
             best = s;
         }
@@ -370,11 +401,22 @@ void GpuIndexFlat::plan_filter_(int n, int k, int& geom, int& nsplit, int& tstri
     if (const char* e = getenv("FAISS_AMD_FILTER_NSPLIT")) nsplit = atoi(e); // timing experiments only
     const int tiles_per_split = total_tiles / nsplit;
     tstride = tiles_per_split >= 32 ? 4 : tiles_per_split >= 16 ? 2 : 1;
-    // expected rows above the threshold: S * -ln(1 - k/S) in the sample, tstride times that overall
+    // expected rows above the threshold: S * -ln(1 - k/S) in the sample, tstride times that overall; the
+    // re-rank kernel gathers at most 4096 of them per query, so large k samples more tiles
     const double S = (double)cps * nsplit;
-    const double expect = S * -std::log(1.0 - std::min(0.95, (double)k / S)) * tstride / nsplit;
+    const double in_sample = S * -std::log(1.0 - std::min(0.95, (double)k / S));
+    while (tstride > 1 && in_sample * tstride > 2800.0) tstride >>= 1;
+    const double expect = in_sample * tstride / nsplit;
     cap = 32;
     while (cap < 4.0 * expect + 16.0) cap <<= 1;
+    // LDS gather buffer of the re-rank kernel: twice the expectation + slack (more workgroups per CU than
+    // with the full 4096 entries); a query with more candidates than that takes the exact path
+    int kp = 1;
+    while (kp < k) kp <<= 1;
+    gcap = 1024;
+    while (gcap < 4096 && (gcap < 2.0 * in_sample * tstride + 512.0 || gcap < kp)) gcap <<= 1;
+    pc.n = n, pc.k = k, pc.ntotal = ntotal, pc.knobs = knobs;
+    pc.geom = geom, pc.nsplit = nsplit, pc.tstride = tstride, pc.cap = cap, pc.gcap = gcap;
 }
 
 void GpuIndexFlat::search_tile_(int n, const float* xq_pad, int k, float* dD, idx_t* dI) const {
@@ -389,7 +431,8 @@ void GpuIndexFlat::search_tile_(int n, const float* xq_pad, int k, float* dD, id
     const int nb = (int)ntotal;
     FlatFilterParams fp{};
     fp.metric = metric_type;
-    plan_filter_(n, k, fp.geom, fp.nsplit, fp.tstride, fp.cap);
+    int gcap = 4096;
+    plan_filter_(n, k, fp.geom, fp.nsplit, fp.tstride, fp.cap, gcap);
     fp.cps = flat_filter_chunks_per_split(fp.geom);
     fp.ngroups = (int)div_up(n, flat_filter_queries_per_block(fp.geom));
     // ---- fp16 queries (+ per-query range flags), exact norms
@@ -403,10 +446,9 @@ void GpuIndexFlat::search_tile_(int n, const float* xq_pad, int k, float* dD, id
     res_cnt_.ensure((size_t)n * fp.nsplit * 4);
     {
         SpanGuard sg(&R, "convert_f16_query");
-        launch_convert_f16(xq_pad, dpad_, n, d, qh_.p, dh_, nullptr, flags_.as<uint32_t>(), R.stream);
-        launch_l2_norms(xq_pad, dpad_, n, dpad_, q_norm_.as<float>(), R.stream);
+        launch_prep_queries(xq_pad, dpad_, n, d, dpad_, qh_.p, dh_, flags_.as<uint32_t>(), q_norm_.as<float>(),
+                            scal_.as<unsigned>() + 2, R.stream);
     }
-    HIP_CHECK(hipMemsetAsync(scal_.as<unsigned>() + 2, 0, 4, R.stream));
     fp.xqh = qh_.as<_Float16>();
     fp.xqn = q_norm_.as<float>();
     fp.xbh = xbh_.as<_Float16>();
@@ -449,6 +491,7 @@ void GpuIndexFlat::search_tile_(int n, const float* xq_pad, int k, float* dD, id
     rp.dpad = dpad_;
     rp.nsplit = fp.nsplit;
     rp.cap = fp.cap;
+    rp.gcap = gcap;
     rp.res_keys = fp.res_keys;
     rp.res_cnt = fp.res_cnt;
     rp.flags = fp.flags;

@@ -160,7 +160,13 @@ class GpuIndexFlat : public Index {
     mutable DevBuf qh_, flags_, thr_, maxes_, ovf_list_, ovf_q_, ovf_d_, ovf_i_;
     void search_tile_exact_(int n, const float* xq_pad, int k, float* dD, idx_t* dI) const;
     bool filter_applicable_(int k) const;
-    void plan_filter_(int n, int k, int& geom, int& nsplit, int& tstride, int& cap) const;
+    void plan_filter_(int n, int k, int& geom, int& nsplit, int& tstride, int& cap, int& gcap) const;
+    // last plan (searches come in runs of one batch size): key = (n, k, ntotal, knob string)
+    mutable struct {
+        int n = -1, k = -1, geom = 0, nsplit = 0, tstride = 0, cap = 0, gcap = 0;
+        idx_t ntotal = -1;
+        std::string knobs;
+    } plan_cache_;
     mutable std::mutex mu_;
     // persistent scratch
     mutable DevBuf q_raw_, q_pad_, q_norm_, res_keys_, res_cnt_, out_d_, out_i_, all_keys_, one_cnt_;

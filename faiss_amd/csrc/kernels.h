@@ -104,6 +104,9 @@ __host__ __device__ static inline float flat_filter_err_bound(int metric, int d,
     return 1.25f * e;
 }
 // mode: 0 = maxima pass, 1 = collect pass, 2 = dump every score (tests)
+// fp16 copy + range flags + |q|^2 (sequential fmaf chain) of n padded queries and *counter = 0, one launch
+void launch_prep_queries(const float* xq_pad, int64_t ld, int64_t n, int d, int dpad, void* qh, int dh, uint32_t* flags,
+                         float* qnorm, unsigned* counter, hipStream_t stream);
 void launch_flat_filter(const FlatFilterParams& p, int mode, hipStream_t stream);
 void launch_flat_tighten(const FlatFilterParams& p, hipStream_t stream);
 size_t flat_filter_lds_bytes();
@@ -111,6 +114,7 @@ size_t flat_filter_lds_bytes();
 struct FlatRerankParams {
     int metric;
     int nq, k, kp, d, dpad, nsplit, cap;
+    int gcap; // candidates per query the kernel can gather into LDS (<= 4096); more -> exact fallback for that query
     const unsigned long long* res_keys;
     const uint32_t* res_cnt;
     const uint32_t* flags;

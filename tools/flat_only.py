@@ -7,21 +7,23 @@ import faiss_amd
 from faiss_amd.datasets import synthetic_dataset
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 res = faiss_amd.StandardGpuResources(0)
+NQ = int(os.environ.get("NQ", "10000"))
 _, xb, xq = synthetic_dataset(128, 0, 1000000, 10000, seed=1338)
+xq = xq[:NQ]
 idx = faiss_amd.GpuIndexFlatL2(res, 128)
 idx.add(xb)
 dev = torch.device("cuda", 0)
 xq_dev = torch.from_numpy(xq).to(dev)
-Dd = torch.empty((10000, 100), dtype=torch.float32, device=dev)
-Id = torch.empty((10000, 100), dtype=torch.int64, device=dev)
+Dd = torch.empty((NQ, 100), dtype=torch.float32, device=dev)
+Id = torch.empty((NQ, 100), dtype=torch.int64, device=dev)
 for dbg in os.environ.get("DBG_LIST", "0").split(","):
     if ":" in dbg:
         dbg, ns = dbg.split(":")
         os.environ["FAISS_AMD_FILTER_NSPLIT"] = ns
     os.environ["FAISS_AMD_FILTER_DBG"] = dbg
-    idx.search_ptr(10000, xq_dev.data_ptr(), 100, Dd.data_ptr(), Id.data_ptr())
+    idx.search_ptr(NQ, xq_dev.data_ptr(), 100, Dd.data_ptr(), Id.data_ptr())
     torch.cuda.synchronize(); t0 = time.time()
     for _ in range(steps):
-        idx.search_ptr(10000, xq_dev.data_ptr(), 100, Dd.data_ptr(), Id.data_ptr())
+        idx.search_ptr(NQ, xq_dev.data_ptr(), 100, Dd.data_ptr(), Id.data_ptr())
     torch.cuda.synchronize()
-    print("flat search (dbg %s nsplit %s): %.3f ms/step" % (dbg, os.environ.get("FAISS_AMD_FILTER_NSPLIT"), (time.time() - t0) / steps * 1e3), flush=True)
+    print("flat search nq=%d (dbg %s nsplit %s geom %s): %.3f ms/step" % (NQ, dbg, os.environ.get("FAISS_AMD_FILTER_NSPLIT"), os.environ.get("FAISS_AMD_FILTER_GEOM"), (time.time() - t0) / steps * 1e3), flush=True)
