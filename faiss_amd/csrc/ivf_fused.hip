@@ -195,8 +195,9 @@ __device__ __forceinline__ void fused_finish(const IvfFusedParams& p, int q, int
 // (faiss/gpu/impl/IVFPQ.cu:362-489); keeping the list-dependent term per VECTOR instead of per
 // (list, m, code) costs 4 bytes per vector and removes the 256 MB term-2 table and, above all, the
 // rebuild of a 64 KB table for each of the 32 probes of a query.
-// The four 256-lane quarters of the workgroup scan FOUR probed lists side by side (one code per
-// lane, 64 gathers), so the global-load, LDS and barrier latencies of one list overlap the others'.
+// One code per lane (64 gathers); the probed lists are walked as one stream of scan positions so that every
+// lane carries a code whatever the list lengths (scanning the lists one or four at a time left half of the
+// lanes idle on lists of ~244 codes: measured 2.99 ms -> see DESIGN.md).
 // M64: the sub-quantizer count is the compile-time constant 64 (four 16-byte loads per code).
 // ---------------------------------------------------------------------------------
 template <int METRIC, bool M64>
@@ -208,9 +209,6 @@ __global__ void __launch_bounds__(FB) ivfpq_fused_kernel(IvfFusedParams p) {
     const int p0 = g * p.npc, p1 = min(p.nprobe, p0 + p.npc);
     float* lut = (float*)L.lut;
     const int M = M64 ? 64 : p.M, d = p.d, dsub = p.dsub;
-    constexpr int NG = FB / 256; // lists scanned side by side
-    const int grp = __builtin_amdgcn_readfirstlane(tid >> 8);
-    const int lg = tid & 255;
 
     fused_load_probes(p, q, L);
     for (int cc = tid; cc < d; cc += FB) L.rs[cc] = p.xq[(int64_t)q * p.ldq + cc];
@@ -229,96 +227,78 @@ __global__ void __launch_bounds__(FB) ivfpq_fused_kernel(IvfFusedParams p) {
     const int mq = M >> 2; // sub-quantizers per partial sum
     constexpr int NW = 4;  // 16-byte code words held in registers (wide path)
     constexpr bool wide = M64; // code words prefetched into registers
+    // The probed lists of this workgroup are ONE stream of scan positions [pre[p0], pre[p1]) (the payload of
+    // the keys): every iteration takes the next 1024 positions whatever list they fall in, so all lanes
+    // carry a code until the very last iteration (lists are ~nb/nlist long, far from a multiple of anything).
+    // position -> (probe, offset) is a 5-step search of the prefix table in LDS.
+    const unsigned pos_begin = L.pre[p0], pos_end = L.pre[p1];
     uint4 cw[NW], cwn[NW];
-    float t2 = 0.f, t2n = 0.f;
-    // codes + t2 of this lane's entry `i` of the list probed at rank `pr` (nothing when out of range)
-    auto fetch = [&](int pr, unsigned i, uint4(&w)[NW], float& t) {
-        if (pr < p1) {
-            const int list = L.lst[pr];
-            const unsigned len = list < 0 ? 0u : L.pre[pr + 1] - L.pre[pr];
-            if (i < len) {
-                const int64_t row = L.lstart[pr] + i;
-                if (wide) {
-                    const uint8_t* code = p.arena_codes + row * M;
-#pragma unroll
-                    for (int k = 0; k < NW; ++k) w[k] = *(const uint4*)(code + k * 16);
-                }
-                if (METRIC == METRIC_L2) t = p.arena_t2[row];
+    float t2 = 0.f, t2n = 0.f, dis0 = 0.f, dis0n = 0.f;
+    int64_t row = -1, rown = -1;
+    // arena row, coarse term, t2 and (wide path) the code words of scan position `pos`; row = -1 past the end
+    auto fetch = [&](unsigned pos, int64_t& r, float& c0, uint4(&w)[NW], float& t) {
+        r = -1;
+        if (pos < pos_end) {
+            int lo = p0, hi = p1; // invariant pre[lo] <= pos < pre[hi]
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (L.pre[mid] <= pos) lo = mid;
+                else hi = mid;
             }
+            r = L.lstart[lo] + (pos - L.pre[lo]);
+            c0 = p.coarse_dis[(int64_t)q * p.nprobe + lo];
+            if (wide) {
+                const uint8_t* code = p.arena_codes + r * M;
+#pragma unroll
+                for (int k = 0; k < NW; ++k) w[k] = *(const uint4*)(code + k * 16);
+            }
+            if (METRIC == METRIC_L2) t = p.arena_t2[r];
         }
     };
 
     u64 tau = ~0ull;
     int bound = 0;
-    if (p0 < p1) fetch(p0 + grp, (unsigned)lg, cw, t2);
-    for (int r0 = p0; r0 < p1; r0 += NG) {
-        // lengths of the NG lists of this round (wave-uniform), longest first in `maxlen`
-        unsigned maxlen = 0;
+    fetch(pos_begin + tid, row, dis0, cw, t2);
+    for (unsigned base = pos_begin; base < pos_end; base += FB) {
+        FUSED_MAKE_ROOM(min((unsigned)FB, pos_end - base));
+        // the next 1024 positions are in flight while these are scanned
+        fetch(base + FB + tid, rown, dis0n, cwn, t2n);
+        bool pass = false;
+        u64 key = 0;
+        if (row >= 0) {
+            float part[4];
+            if (M64) {
+                // quarter jq = sub-quantizers [16 jq, 16 jq + 16) = the 16 bytes of code word jq
 #pragma unroll
-        for (int gg = 0; gg < NG; ++gg) {
-            const int pr = r0 + gg;
-            if (pr < p1 && L.lst[pr] >= 0) maxlen = max(maxlen, L.pre[pr + 1] - L.pre[pr]);
-        }
-        const int pr = r0 + grp;
-        const bool pvalid = pr < p1 && L.lst[pr < p1 ? pr : p0] >= 0;
-        const unsigned pos0 = pvalid ? L.pre[pr] : 0u;
-        const unsigned len = pvalid ? L.pre[pr + 1] - pos0 : 0u;
-        const int64_t start = pvalid ? L.lstart[pr] : 0;
-        const float dis0 = pvalid ? p.coarse_dis[(int64_t)q * p.nprobe + pr] : 0.f;
-        for (unsigned base = 0; base < maxlen; base += 256) {
-            unsigned chunk = 0;
+                for (int jq = 0; jq < 4; ++jq) {
+                    const unsigned wv[4] = {cw[jq].x, cw[jq].y, cw[jq].z, cw[jq].w};
+                    float a = 0.f;
 #pragma unroll
-            for (int gg = 0; gg < NG; ++gg) {
-                const int pg = r0 + gg;
-                if (pg < p1 && L.lst[pg] >= 0) {
-                    const unsigned lgn = L.pre[pg + 1] - L.pre[pg];
-                    chunk += lgn > base ? min(256u, lgn - base) : 0u;
+                    for (int bb = 0; bb < 16; ++bb)
+                        a = a + lut[(jq * 16 + bb) * 256 + ((wv[bb >> 2] >> (8 * (bb & 3))) & 255u)];
+                    part[jq] = a;
+                }
+            } else {
+                const uint8_t* code = p.arena_codes + row * M;
+#pragma unroll
+                for (int jq = 0; jq < 4; ++jq) {
+                    float a = 0.f;
+                    for (int m = jq * mq; m < (jq + 1) * mq; ++m) a = a + lut[m * 256 + code[m]];
+                    part[jq] = a;
                 }
             }
-            FUSED_MAKE_ROOM(chunk);
-            // next chunk of this round, or the first chunk of the next round: in flight while this one is scanned
-            if (base + 256 < maxlen) fetch(pr, base + 256 + lg, cwn, t2n);
-            else fetch(pr + NG, (unsigned)lg, cwn, t2n);
-            const unsigned i = base + lg;
-            bool pass = false;
-            u64 key = 0;
-            if (i < len) {
-                float part[4];
-                if (M64) {
-                    // quarter jq = sub-quantizers [16 jq, 16 jq + 16) = the 16 bytes of code word jq
-#pragma unroll
-                    for (int jq = 0; jq < 4; ++jq) {
-                        const unsigned wv[4] = {cw[jq].x, cw[jq].y, cw[jq].z, cw[jq].w};
-                        float a = 0.f;
-#pragma unroll
-                        for (int bb = 0; bb < 16; ++bb)
-                            a = a + lut[(jq * 16 + bb) * 256 + ((wv[bb >> 2] >> (8 * (bb & 3))) & 255u)];
-                        part[jq] = a;
-                    }
-                } else {
-                    const uint8_t* code = p.arena_codes + (start + i) * M;
-#pragma unroll
-                    for (int jq = 0; jq < 4; ++jq) {
-                        float a = 0.f;
-                        for (int m = jq * mq; m < (jq + 1) * mq; ++m) a = a + lut[m * 256 + code[m]];
-                        part[jq] = a;
-                    }
-                }
-                const float sum = (part[0] + part[1]) + (part[2] + part[3]);
-                const float dis = METRIC == METRIC_L2 ? __fmaf_rn(-2.f, sum, dis0 + t2) : dis0 + sum;
-                key = ((u64)ordkey<METRIC>(dis) << 32) | (u64)(pos0 + i);
-                pass = key < tau;
-            }
-            wg_append(L.res, L.ctl, pass, key);
-#pragma unroll
-            for (int k = 0; k < NW; ++k) cw[k] = cwn[k];
-            t2 = t2n;
-            __syncthreads();
+            const float sum = (part[0] + part[1]) + (part[2] + part[3]);
+            const float dis = METRIC == METRIC_L2 ? __fmaf_rn(-2.f, sum, dis0 + t2) : dis0 + sum;
+            key = ((u64)ordkey<METRIC>(dis) << 32) | (u64)(base + tid);
+            pass = key < tau;
         }
-        if (maxlen == 0) {
-            // nothing scanned this round (empty lists): the prefetch for the next round is still pending
-            fetch(pr + NG, (unsigned)lg, cw, t2);
-        }
+        wg_append(L.res, L.ctl, pass, key);
+#pragma unroll
+        for (int k = 0; k < NW; ++k) cw[k] = cwn[k];
+        t2 = t2n;
+        dis0 = dis0n;
+        row = rown;
+        __syncthreads();
     }
     fused_finish(p, q, g, L);
 }
