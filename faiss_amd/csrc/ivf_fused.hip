@@ -27,8 +27,10 @@ namespace faiss_amd {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int FB = 1024;  // threads per workgroup (16 wavefronts, one workgroup per CU)
-constexpr int FPART = FB / 256; // codebook split over the threads: thread t owns centroid t & 255 of part t >> 8
+// threads per workgroup, a template parameter of the kernels (FB inside them): 1024 = 16 wavefronts, one workgroup per
+// CU (IVFFlat: 256 KB of row loads in flight per iteration); 512 for IVFPQ, whose 64 KB table then leaves room for
+// TWO workgroups per CU -- one query's table build / reservoir selects / final sort overlap the other's gathers
+constexpr int FB_MAX = 1024;
 constexpr int FMAXR = 8;  // reservoir capacity <= FMAXR * FB keys
 
 struct FusedLds {
@@ -78,6 +80,7 @@ __device__ __forceinline__ FusedLds fused_carve(char* smem, const IvfFusedParams
 }
 
 // probed lists of query q -> LDS (list ids, exclusive prefix of their lengths)
+template <int FB>
 __device__ __forceinline__ void fused_load_probes(const IvfFusedParams& p, int q, const FusedLds& L) {
     const int tid = threadIdx.x;
     for (int t = tid; t < p.nprobe; t += FB) {
@@ -130,6 +133,7 @@ __device__ __forceinline__ void fused_load_probes(const IvfFusedParams& p, int q
     } while (0)
 
 // final k-selection, position -> user id, ordering, write-out (or partial keys when G > 1)
+template <int FB>
 __device__ __forceinline__ void fused_finish(const IvfFusedParams& p, int q, int g, const FusedLds& L) {
     const int tid = threadIdx.x;
     __syncthreads();
@@ -200,7 +204,7 @@ __device__ __forceinline__ void fused_finish(const IvfFusedParams& p, int q, int
 // lanes idle on lists of ~244 codes: measured 2.99 ms -> see DESIGN.md).
 // M64: the sub-quantizer count is the compile-time constant 64 (four 16-byte loads per code).
 // ---------------------------------------------------------------------------------
-template <int METRIC, bool M64>
+template <int METRIC, bool M64, int FB>
 __global__ void __launch_bounds__(FB) ivfpq_fused_kernel(IvfFusedParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const FusedLds L = fused_carve(smem, p);
@@ -210,7 +214,7 @@ __global__ void __launch_bounds__(FB) ivfpq_fused_kernel(IvfFusedParams p) {
     float* lut = (float*)L.lut;
     const int M = M64 ? 64 : p.M, d = p.d, dsub = p.dsub;
 
-    fused_load_probes(p, q, L);
+    fused_load_probes<FB>(p, q, L);
     for (int cc = tid; cc < d; cc += FB) L.rs[cc] = p.xq[(int64_t)q * p.ldq + cc];
     __syncthreads();
     // ---- the query's table (codebook read through L2 once per query)
@@ -300,7 +304,7 @@ __global__ void __launch_bounds__(FB) ivfpq_fused_kernel(IvfFusedParams p) {
         row = rown;
         __syncthreads();
     }
-    fused_finish(p, q, g, L);
+    fused_finish<FB>(p, q, g, L);
 }
 
 // ---------------------------------------------------------------------------------
@@ -315,11 +319,12 @@ __global__ void __launch_bounds__(FB) ivfpq_fused_kernel(IvfFusedParams p) {
 // HBM-bound: nprobe * (nb / nlist) * d * 4 bytes per query, no reuse across queries.
 // ---------------------------------------------------------------------------------
 constexpr int FF_ROWS = 4;                   // rows per 8-lane group and iteration
-constexpr int FF_POS = FF_ROWS * (FB / 8);   // positions per iteration (512)
+constexpr int FF_POS = FF_ROWS * (FB_MAX / 8); // positions per iteration (512)
 constexpr int FF_QCH = 4;                    // query chunks kept in registers per lane (dpad <= 128)
 
 template <int METRIC>
-__global__ void __launch_bounds__(FB) ivfflat_fused_kernel(IvfFusedParams p) {
+__global__ void __launch_bounds__(FB_MAX) ivfflat_fused_kernel(IvfFusedParams p) {
+    constexpr int FB = FB_MAX;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const FusedLds L = fused_carve(smem, p);
     const int tid = threadIdx.x;
@@ -328,7 +333,7 @@ __global__ void __launch_bounds__(FB) ivfflat_fused_kernel(IvfFusedParams p) {
     const int ln = tid & 7;   // lane inside the row group
     const int rg = tid >> 3;  // row group 0..127
 
-    fused_load_probes(p, q, L);
+    fused_load_probes<FB>(p, q, L);
     for (int cc = tid; cc < p.dpad; cc += FB) L.rs[cc] = p.xq[(int64_t)q * p.ldq + cc];
     __syncthreads();
     const int nch = p.dpad >> 2;               // 16-byte chunks per row
@@ -428,16 +433,22 @@ __global__ void __launch_bounds__(FB) ivfflat_fused_kernel(IvfFusedParams p) {
         }
         __syncthreads();
     }
-    fused_finish(p, q, g, L);
+    fused_finish<FB>(p, q, g, L);
 }
 
 // ---------------------------------------------------------------------------------
+int ivf_fused_threads(int kind) {
+    if (kind != 1) return FB_MAX;
+    if (const char* e = getenv("FAISS_AMD_IVFPQ_FB")) return atoi(e) == 1024 ? 1024 : 512; // timing experiments only
+    return 512;
+}
 bool ivf_fused_supported(int kind, int M, int dpad, int k, int nprobe, int* cap_out, int* kp_out, int* nlut_out) {
+    const int fb = ivf_fused_threads(kind);
     int kp = 1;
     while (kp < k) kp <<= 1;
     int cap = 1024;
-    while (cap < k + FB) cap <<= 1;
-    if (cap > FMAXR * FB) return false;
+    while (cap < k + fb) cap <<= 1;
+    if (cap > FMAXR * fb) return false;
     if (cap_out) *cap_out = cap;
     if (kp_out) *kp_out = kp;
     const int nlut = 1; // one lookup table per query (see ivfpq_fused_kernel)
@@ -446,31 +457,38 @@ bool ivf_fused_supported(int kind, int M, int dpad, int k, int nprobe, int* cap_
 }
 
 template <typename K>
-static void launch_one(K kern, const IvfFusedParams& p, size_t lds, hipStream_t stream) {
+static void launch_one(K kern, const IvfFusedParams& p, size_t lds, int fb, hipStream_t stream) {
     HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)(p.nq * p.G)), dim3(FB), lds, stream, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(p.nq * p.G)), dim3(fb), lds, stream, p);
 }
 
 void launch_ivf_fused(const IvfFusedParams& p, hipStream_t stream) {
     if (p.nq == 0) return;
     FA_THROW_IF_NOT(p.G >= 1 && p.npc >= 1 && p.G * p.npc >= p.nprobe);
-    FA_THROW_IF_NOT(p.cap >= p.k + FB && p.cap <= FMAXR * FB);
+    const int fb = ivf_fused_threads(p.kind);
+    FA_THROW_IF_NOT(p.cap >= p.k + fb && p.cap <= FMAXR * fb);
     FA_THROW_IF_NOT(p.nlut == 1 || p.nlut == 2);
     const size_t lds = ivf_fused_lds_bytes(p.kind, p.M, p.dpad, p.kp, p.cap, p.nprobe, p.nlut);
     FA_THROW_IF_NOT_MSG(lds <= 160 * 1024, "fused IVF scan does not fit the LDS");
     const bool l2 = p.metric == METRIC_L2;
     if (p.kind == 0) {
-        if (l2) launch_one(ivfflat_fused_kernel<METRIC_L2>, p, lds, stream);
-        else launch_one(ivfflat_fused_kernel<METRIC_INNER_PRODUCT>, p, lds, stream);
+        if (l2) launch_one(ivfflat_fused_kernel<METRIC_L2>, p, lds, fb, stream);
+        else launch_one(ivfflat_fused_kernel<METRIC_INNER_PRODUCT>, p, lds, fb, stream);
     } else {
         FA_THROW_IF_NOT_MSG(p.metric != METRIC_L2 || p.arena_t2, "IVFPQ L2 needs the per-vector t2 terms");
+#define FA_PQ_LAUNCH(M64_, FB_)                                                                            \
+    do {                                                                                                   \
+        if (l2) launch_one(ivfpq_fused_kernel<METRIC_L2, M64_, FB_>, p, lds, fb, stream);                  \
+        else launch_one(ivfpq_fused_kernel<METRIC_INNER_PRODUCT, M64_, FB_>, p, lds, fb, stream);          \
+    } while (0)
         if (p.M == 64) {
-            if (l2) launch_one(ivfpq_fused_kernel<METRIC_L2, true>, p, lds, stream);
-            else launch_one(ivfpq_fused_kernel<METRIC_INNER_PRODUCT, true>, p, lds, stream);
+            if (fb == 512) FA_PQ_LAUNCH(true, 512);
+            else FA_PQ_LAUNCH(true, 1024);
         } else {
-            if (l2) launch_one(ivfpq_fused_kernel<METRIC_L2, false>, p, lds, stream);
-            else launch_one(ivfpq_fused_kernel<METRIC_INNER_PRODUCT, false>, p, lds, stream);
+            if (fb == 512) FA_PQ_LAUNCH(false, 512);
+            else FA_PQ_LAUNCH(false, 1024);
         }
+#undef FA_PQ_LAUNCH
     }
     HIP_CHECK(hipGetLastError());
 }

@@ -25,18 +25,21 @@ dev = torch.device("cuda", 0)
 xq_dev = torch.from_numpy(xq).to(dev)
 Dd = torch.empty((10000, 100), dtype=torch.float32, device=dev)
 Id = torch.empty((10000, 100), dtype=torch.int64, device=dev)
-idx.search_ptr(10000, xq_dev.data_ptr(), 100, Dd.data_ptr(), Id.data_ptr())
-torch.cuda.synchronize(); t0 = time.time()
-for _ in range(steps):
+for fb in os.environ.get("FB_LIST", "512").split(","):
+    os.environ["FAISS_AMD_IVFPQ_FB"] = fb
+    print("--- workgroup size", fb)
     idx.search_ptr(10000, xq_dev.data_ptr(), 100, Dd.data_ptr(), Id.data_ptr())
-torch.cuda.synchronize()
-dt_step = (time.time() - t0) / steps
-print("ivfpq search (%s): %.3f ms/step" % ("ip" if metric == 0 else "l2", (time.time() - t0) / steps * 1e3))
-res.profile_enable(True); res.profile_reset()
-idx.search_ptr(10000, xq_dev.data_ptr(), 100, Dd.data_ptr(), Id.data_ptr())
-for kn in ("ivfpq_fused_kernel", "flat_scan_kernel", "select_k_kernel", "flat_filter_kernel", "flat_rerank_kernel"):
-    print(kn, res.profile_get(kn))
-ms, n = res.profile_get("ivfpq_fused_kernel")
-bpq = 32.0 * nb / 4096.0 * 64
-print("ivfpq nb=%d: %.0f QPS; fused kernel %.3f ms = %.0f GB/s algorithmic code bytes (%.1f%% of 8 TB/s)" % (
-    nb, 10000 / dt_step, ms, bpq * 10000 / (ms * 1e-3) / 1e9, bpq * 10000 / (ms * 1e-3) / 8e12 * 100))
+    torch.cuda.synchronize(); t0 = time.time()
+    for _ in range(steps):
+        idx.search_ptr(10000, xq_dev.data_ptr(), 100, Dd.data_ptr(), Id.data_ptr())
+    torch.cuda.synchronize()
+    dt_step = (time.time() - t0) / steps
+    print("ivfpq search (%s): %.3f ms/step" % ("ip" if metric == 0 else "l2", (time.time() - t0) / steps * 1e3))
+    res.profile_enable(True); res.profile_reset()
+    idx.search_ptr(10000, xq_dev.data_ptr(), 100, Dd.data_ptr(), Id.data_ptr())
+    for kn in ("ivfpq_fused_kernel", "flat_scan_kernel", "select_k_kernel", "flat_filter_kernel", "flat_rerank_kernel"):
+        print(kn, res.profile_get(kn))
+    ms, n = res.profile_get("ivfpq_fused_kernel")
+    bpq = 32.0 * nb / 4096.0 * 64
+    print("ivfpq nb=%d: %.0f QPS; fused kernel %.3f ms = %.0f GB/s algorithmic code bytes (%.1f%% of 8 TB/s)" % (
+        nb, 10000 / dt_step, ms, bpq * 10000 / (ms * 1e-3) / 1e9, bpq * 10000 / (ms * 1e-3) / 8e12 * 100))
