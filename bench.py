@@ -191,7 +191,7 @@ def ivfpq_leg(res, xt, xb, xq_dev, gt_first, steps, warmup, torch, with_cpu=True
         "recall_at_1": round(float((I[:, 0] == gt_first).mean()), 4),
         "recall_at_100": round(float((I == gt_first[:, None]).any(axis=1).mean()), 4),
         "train_s": round(t_train, 2), "add_s": round(t_add, 2),
-        "scan_kernel": "ivfpq_fused_kernel (per-query LUT + code scan of 4 lists side by side + top-k, all in LDS)",
+        "scan_kernel": "ivfpq_fused_kernel (per-query LUT + code scan of the probed lists as one position stream + top-k, all in LDS; 2 workgroups per CU)",
         "scan_kernel_ms": round(scan_ms / max(scan_n, 1), 3), "select_kernel_ms": round(sel_ms / max(sel_n, 1), 3),
         # algorithmic HBM bytes of the code scan: nprobe * nb/nlist * M bytes per query
         "scan_algorithmic_GBps": round(codes_per_query * 64 * NQ / (scan_ms / max(scan_n, 1) * 1e-3) / 1e9, 1)
