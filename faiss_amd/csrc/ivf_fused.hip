@@ -218,13 +218,36 @@ __global__ void __launch_bounds__(FB) ivfpq_fused_kernel(IvfFusedParams p) {
     for (int cc = tid; cc < d; cc += FB) L.rs[cc] = p.xq[(int64_t)q * p.ldq + cc];
     __syncthreads();
     // ---- the query's table (codebook read through L2 once per query)
-    for (int e = tid; e < M * 256; e += FB) {
-        const int m = e >> 8;
-        const float* cen = p.pq_centroids + (size_t)e * dsub;
-        const float* r = L.rs + m * dsub;
-        float acc = 0.f;
-        for (int jd = 0; jd < dsub; ++jd) acc = __fmaf_rn(r[jd], cen[jd], acc);
-        lut[e] = acc;
+    if (dsub == 2) {
+        // eight independent 8-byte codebook loads in flight per lane (one dependent load per table entry made the
+        // build of a 16 K-entry table a chain of 32 L2 round trips per query)
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const int ne = M * 256;
+        for (int e0 = tid; e0 < ne; e0 += 8 * FB) {
+            f32x2 c[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * FB;
+                c[u] = e < ne ? *(const f32x2*)(p.pq_centroids + (size_t)e * 2) : f32x2{0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * FB;
+                if (e < ne) {
+                    const float* r = L.rs + (e >> 8) * 2;
+                    lut[e] = __fmaf_rn(r[1], c[u][1], __fmaf_rn(r[0], c[u][0], 0.f));
+                }
+            }
+        }
+    } else {
+        for (int e = tid; e < M * 256; e += FB) {
+            const int m = e >> 8;
+            const float* cen = p.pq_centroids + (size_t)e * dsub;
+            const float* r = L.rs + m * dsub;
+            float acc = 0.f;
+            for (int jd = 0; jd < dsub; ++jd) acc = __fmaf_rn(r[jd], cen[jd], acc);
+            lut[e] = acc;
+        }
     }
     __syncthreads();
 
