@@ -31,6 +31,31 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // CU (IVFFlat: 256 KB of row loads in flight per iteration); 512 for IVFPQ, whose 64 KB table then leaves room for
 // TWO workgroups per CU -- one query's table build / reservoir selects / final sort overlap the other's gathers
 constexpr int FB_MAX = 1024;
+
+// 4 * (byte B of w) in ONE VALU instruction (SDWA operand select; `two` is a register holding 2): the LDS byte offset
+// of a table entry.  hipcc emits v_bfe_u32 + v_lshl_add_u32 for the same thing, a third of the scan loop's VALU work.
+// fp32 at an absolute LDS byte address (the lookup table starts at LDS address 0: the kernels here have no static
+// LDS, checked once per workgroup) -- spares the "+ table base" VALU add per gather that pointer arithmetic costs
+__device__ __forceinline__ float lds_f32(unsigned byte_addr) {
+    return *(const __attribute__((address_space(3))) float*)(size_t)byte_addr;
+}
+template <int B>
+__device__ __forceinline__ unsigned byte_x4(unsigned w, unsigned two) {
+    unsigned r;
+    if (B == 0)
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0"
+            : "=v"(r) : "v"(two), "v"(w));
+    else if (B == 1)
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1"
+            : "=v"(r) : "v"(two), "v"(w));
+    else if (B == 2)
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2"
+            : "=v"(r) : "v"(two), "v"(w));
+    else
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3"
+            : "=v"(r) : "v"(two), "v"(w));
+    return r;
+}
 constexpr int FMAXR = 8;  // reservoir capacity <= FMAXR * FB keys
 
 struct FusedLds {
@@ -285,6 +310,9 @@ __global__ void __launch_bounds__(FB) ivfpq_fused_kernel(IvfFusedParams p) {
 
     u64 tau = ~0ull;
     int bound = 0;
+    unsigned two = 2u;
+    asm volatile("" : "+v"(two)); // a register operand for the SDWA shifts (no literal allowed there)
+    if ((unsigned)(size_t)(const __attribute__((address_space(3))) char*)lut != 0u) __builtin_trap(); // see lds_f32
     fetch(pos_begin + tid, row, dis0, cw, t2);
     for (unsigned base = pos_begin; base < pos_end; base += FB) {
         FUSED_MAKE_ROOM(min((unsigned)FB, pos_end - base));
@@ -295,15 +323,28 @@ __global__ void __launch_bounds__(FB) ivfpq_fused_kernel(IvfFusedParams p) {
         if (row >= 0) {
             float part[4];
             if (M64) {
-                // quarter jq = sub-quantizers [16 jq, 16 jq + 16) = the 16 bytes of code word jq
+                // quarter jq = sub-quantizers [16 jq, 16 jq + 16) = the 16 bytes of code word jq; the four
+                // sequential chains advance two at a time on v_pk_add_f32 (same additions, same order)
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-                for (int jq = 0; jq < 4; ++jq) {
-                    const unsigned wv[4] = {cw[jq].x, cw[jq].y, cw[jq].z, cw[jq].w};
-                    float a = 0.f;
+                for (int jp = 0; jp < 2; ++jp) {
+                    const unsigned w0[4] = {cw[2 * jp].x, cw[2 * jp].y, cw[2 * jp].z, cw[2 * jp].w};
+                    const unsigned w1[4] = {cw[2 * jp + 1].x, cw[2 * jp + 1].y, cw[2 * jp + 1].z, cw[2 * jp + 1].w};
+                    const unsigned t0 = (2 * jp) * 16 * 1024, t1 = t0 + 16 * 1024; // tables of the words' first sub-quantizers
+                    f32x2 a = {0.f, 0.f};
 #pragma unroll
-                    for (int bb = 0; bb < 16; ++bb)
-                        a = a + lut[(jq * 16 + bb) * 256 + ((wv[bb >> 2] >> (8 * (bb & 3))) & 255u)];
-                    part[jq] = a;
+                    for (int wd = 0; wd < 4; ++wd) {
+                        a += f32x2{lds_f32(t0 + (4 * wd + 0) * 1024 + byte_x4<0>(w0[wd], two)),
+                                   lds_f32(t1 + (4 * wd + 0) * 1024 + byte_x4<0>(w1[wd], two))};
+                        a += f32x2{lds_f32(t0 + (4 * wd + 1) * 1024 + byte_x4<1>(w0[wd], two)),
+                                   lds_f32(t1 + (4 * wd + 1) * 1024 + byte_x4<1>(w1[wd], two))};
+                        a += f32x2{lds_f32(t0 + (4 * wd + 2) * 1024 + byte_x4<2>(w0[wd], two)),
+                                   lds_f32(t1 + (4 * wd + 2) * 1024 + byte_x4<2>(w1[wd], two))};
+                        a += f32x2{lds_f32(t0 + (4 * wd + 3) * 1024 + byte_x4<3>(w0[wd], two)),
+                                   lds_f32(t1 + (4 * wd + 3) * 1024 + byte_x4<3>(w1[wd], two))};
+                    }
+                    part[2 * jp] = a[0];
+                    part[2 * jp + 1] = a[1];
                 }
             } else {
                 const uint8_t* code = p.arena_codes + row * M;
