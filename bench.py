@@ -336,12 +336,12 @@ def main():
     # workload, corrected x2 as the MI355X guide prescribes for 16 B/lane reads on gfx950)
     traffic = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_d_pmc_counters.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_e_pmc_counters.json")))
         if used_filter and world == 1:
             ent = [v for k, v in pmc.items() if "flat_filter_kernel<1, 1," in k and "FETCH_SIZE" in v][0]
             traffic = {"hbm_read_bytes_per_launch": round(ent["hbm_read_bytes_corrected"]),
                        "algorithmic_bytes_per_launch": round(hbm_bytes),
-                       "source": "profiles/r01_d_pmc_counters.txt (rocprofv3 --pmc FETCH_SIZE, separate pass, tools/flat_only.py; "
+                       "source": "profiles/r01_e_pmc_counters.txt (rocprofv3 --pmc FETCH_SIZE, separate pass, tools/flat_only.py; "
                                  "gfx950 2x correction for 16 B/lane reads applied)"}
     except (OSError, KeyError, ValueError, IndexError):
         pass

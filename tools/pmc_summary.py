@@ -1,8 +1,10 @@
 #!/usr/bin/env python
 """tools/pmc_summary.py -- per-kernel means of rocprofv3 --pmc counters (CSV output), as text + JSON.
 
-usage: python tools/pmc_summary.py OUT.txt OUT.json dir1 [dir2 ...]
-Each dir is one rocprofv3 pass (`--pmc ... --kernel-trace --output-format csv -d dir`).  Kernels that ran
+usage: python tools/pmc_summary.py OUT.txt OUT.json dir1[:substr] [dir2[:substr] ...]
+Each dir is one rocprofv3 pass (`--pmc ... --kernel-trace --output-format csv -d dir`); with `:substr` only the
+kernels whose name contains substr are taken from that pass (a pass of another workload launches small instances
+of the same kernel templates).  Kernels that ran
 for less than 20 us on average are left out.  FETCH_SIZE / WRITE_SIZE are reported in KiB as rocprofv3
 prints them; `hbm_read_bytes_corrected` applies the gfx950 correction for 16-byte-per-lane reads
 (x2, /opt/skills/guides/MI355X_MICROARCH.md, HBM section).
@@ -14,8 +16,11 @@ from collections import defaultdict
 def main(out_txt, out_json, dirs):
     acc = defaultdict(lambda: [0.0, 0, 0.0])  # (kernel, counter) -> sum value, launches, sum duration
     for d in dirs:
+        d, _, only = d.partition(":")
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
+                if only and only not in r["Kernel_Name"]:
+                    continue
                 k = (r["Kernel_Name"], r["Counter_Name"])
                 a = acc[k]
                 a[0] += float(r["Counter_Value"]); a[1] += 1

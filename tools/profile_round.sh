@@ -13,6 +13,8 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ
     i=$((i + 1))
     rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/${TAG}_pmc$i -o p -- python $R/tools/flat_only.py 3 > $O/${TAG}_pmc$i.log 2>&1
 done
-python $R/tools/pmc_summary.py $O/${TAG}_pmc_counters.txt $O/${TAG}_pmc_counters.json $O/${TAG}_pmc1 $O/${TAG}_pmc2 $O/${TAG}_pmc3 | grep -i "flat_filter\|rerank" | cut -c1-230
+# IVFPQ scan: HBM traffic of the fused kernel
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${TAG}_pmc4 -o p -- python $R/tools/ivfpq_only.py 3 > $O/${TAG}_pmc4.log 2>&1
+python $R/tools/pmc_summary.py $O/${TAG}_pmc_counters.txt $O/${TAG}_pmc_counters.json $O/${TAG}_pmc1 $O/${TAG}_pmc2 $O/${TAG}_pmc3 $O/${TAG}_pmc4:ivfpq_fused | grep -i "flat_filter\|rerank\|ivfpq_fused" | cut -c1-230
 find $O/${TAG}_kt -name "*kernel_stats.csv" -exec cp {} $O/${TAG}_bench_kernel_stats.csv \;
 head -12 $O/${TAG}_bench_kernel_stats.csv | cut -c1-200
