@@ -313,8 +313,9 @@ def main():
     res.profile_enable(False)
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        # leave together with rank 0 (which still assembles and prints the line)
+        dist.barrier()
+        dist.destroy_process_group()
         return
 
     ms_per_step = elapsed / args.steps * 1e3
@@ -387,6 +388,7 @@ def main():
                 line["ivfpq"] = {"error": repr(e)[:300]}
     print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 
