@@ -252,15 +252,72 @@ __global__ void ivfpq_encode_append_kernel(const float* __restrict__ x, int64_t 
     codes[dst * M + m] = (uint8_t)bestc;
 }
 
+// Same arithmetic, one workgroup per (256 vectors, sub-quantizer): the 256 x dsub codebook of the sub-quantizer
+// sits in LDS (every lane reads the same centroid: a broadcast) and the residual slice in registers, instead of
+// 256 dependent global loads per thread (82 ms per million vectors at M = 64).
+template <int DSUB_MAX>
+__global__ void __launch_bounds__(256) ivfpq_encode_append_lds_kernel(const float* __restrict__ x, int64_t ldx, int n,
+                                                                      const int64_t* __restrict__ labels,
+                                                                      const int64_t* __restrict__ dest,
+                                                                      const float* __restrict__ centroids, int64_t ldc,
+                                                                      int M, int dsub, const float* __restrict__ pq,
+                                                                      uint8_t* __restrict__ codes) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* cb = (float*)smem; // [256][dsub]
+    const int m = blockIdx.y;
+    const float* pm = pq + (size_t)m * 256 * dsub;
+    for (int e = threadIdx.x; e < 256 * dsub; e += 256) cb[e] = pm[e];
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t dst = dest[i];
+    if (dst < 0) return;
+    const int64_t list = labels[i];
+    const float* xr = x + (int64_t)i * ldx + m * dsub;
+    const float* cr = centroids + list * ldc + m * dsub;
+    float r[DSUB_MAX];
+#pragma unroll
+    for (int jd = 0; jd < DSUB_MAX; ++jd) r[jd] = jd < dsub ? xr[jd] - cr[jd] : 0.f;
+    float best = INFINITY;
+    int bestc = 0;
+    for (int c = 0; c < 256; ++c) {
+        const float* cen = cb + c * dsub;
+        float acc = 0.f;
+#pragma unroll
+        for (int jd = 0; jd < DSUB_MAX; ++jd) {
+            if (jd < dsub) {
+                const float tt = r[jd] - cen[jd];
+                acc = __fmaf_rn(tt, tt, acc);
+            }
+        }
+        if (acc < best) {
+            best = acc;
+            bestc = c;
+        }
+    }
+    codes[dst * M + m] = (uint8_t)bestc;
+}
+
 void launch_ivfpq_encode_append(const float* x, int64_t ldx, int n, int d, const int64_t* labels,
                                 const int64_t* dest, const float* centroids, int64_t ldc, int M,
                                 int dsub, const float* pq_centroids, uint8_t* arena_codes,
                                 hipStream_t stream) {
     if (n == 0) return;
-    int64_t total = (int64_t)n * M;
-    hipLaunchKernelGGL(ivfpq_encode_append_kernel, dim3((unsigned)div_up(total, 256)), dim3(256), 0,
-                       stream, x, ldx, n, d, labels, dest, centroids, ldc, M, dsub, pq_centroids,
-                       arena_codes);
+    if (dsub <= 16) {
+        const dim3 grid((unsigned)div_up(n, 256), (unsigned)M);
+        const size_t lds = (size_t)256 * dsub * 4;
+        if (dsub <= 4)
+            hipLaunchKernelGGL((ivfpq_encode_append_lds_kernel<4>), grid, dim3(256), lds, stream, x, ldx, n, labels, dest,
+                               centroids, ldc, M, dsub, pq_centroids, arena_codes);
+        else
+            hipLaunchKernelGGL((ivfpq_encode_append_lds_kernel<16>), grid, dim3(256), lds, stream, x, ldx, n, labels, dest,
+                               centroids, ldc, M, dsub, pq_centroids, arena_codes);
+    } else {
+        int64_t total = (int64_t)n * M;
+        hipLaunchKernelGGL(ivfpq_encode_append_kernel, dim3((unsigned)div_up(total, 256)), dim3(256), 0,
+                           stream, x, ldx, n, d, labels, dest, centroids, ldc, M, dsub, pq_centroids,
+                           arena_codes);
+    }
     HIP_CHECK(hipGetLastError());
 }
 
