@@ -6,6 +6,9 @@
 //   bit 2  LDS-DMA prefetch of the next-but-one tile (global_load_lds_dwordx4) + counted vmcnt wait
 //   bit 3  epilogue: max of the 16 scores of every accumulator + compare + (never taken) branch
 //   bit 4  accumulators start from an LDS bias quad instead of 0
+//   bit 5  the whole tile is staged by wave 0
+//   bit 6  software-pipelined epilogue: the max3/compare of block n sits between the first-k-step MFMAs of block n+1
+//          (per 32-query column block: epilogue(acc[qb]) then the MFMA that overwrites acc[qb]), across the barrier too
 // build:  hipcc --offload-arch=gfx950 -O3 tools/mfma_probe.hip -o tools/mfma_probe.bin   (run on the GPU box)
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -27,7 +30,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float max3(float a, float b, float c) {
     float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
 __device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsigned lds_dst) {
@@ -92,6 +95,11 @@ probe(const _Float16* __restrict__ xb, const _Float16* __restrict__ xq, float* o
 #pragma unroll
     for (int i = 0; i < 8; ++i) areg[i] = (_Float16)(0.01f * (lane + i));
     int slot = 0;
+    f32x16 acc[4];
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[qb][r] = 0.f;
     for (int u = 0; u < nsteps; ++u) {
         const int slot2 = slot >= 1 ? slot - 1 : RING - 1;
         if (F & 4) {
@@ -102,7 +110,6 @@ probe(const _Float16* __restrict__ xb, const _Float16* __restrict__ xq, float* o
         const int sw = j & 15;
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
-            f32x16 acc[4];
             f32x16 c0;
             if (F & 16) {
 #pragma unroll
@@ -116,6 +123,14 @@ probe(const _Float16* __restrict__ xb, const _Float16* __restrict__ xq, float* o
                 for (int r = 0; r < 16; ++r) c0[r] = 0.f;
             }
             const char* rowp = tile + (rb * 32 + j) * 256;
+            auto epi = [&](const f32x16& a) __attribute__((always_inline)) {
+                const float m = max3(max3(max3(a[0], a[1], a[2]), max3(a[3], a[4], a[5]), a[15]), max3(a[6], a[7], a[8]),
+                                     max3(max3(a[9], a[10], a[11]), max3(a[12], a[13], a[14]), a[12]));
+                if (__builtin_expect(__ballot(m > th) != 0ull, 0)) {
+                    hits++;
+                    keep += m;
+                }
+            };
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 half8 a0;
@@ -125,24 +140,30 @@ probe(const _Float16* __restrict__ xb, const _Float16* __restrict__ xq, float* o
                     asm volatile("" : "+v"(a0));
                 }
 #pragma unroll
-                for (int qb = 0; qb < 4; ++qb)
-                    acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bq[qb][s], s == 0 ? c0 : acc[qb], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (F & 8) {
-#pragma unroll
                 for (int qb = 0; qb < 4; ++qb) {
-                    const f32x16& a = acc[qb];
-                    const float m = max3(max3(max3(a[0], a[1], a[2]), max3(a[3], a[4], a[5]), a[15]), max3(a[6], a[7], a[8]),
-                                         max3(max3(a[9], a[10], a[11]), max3(a[12], a[13], a[14]), a[12]));
-                    if (__builtin_expect(__ballot(m > th) != 0ull, 0)) {
-                        hits++;
-                        keep += m;
+                    if ((F & 64) && s == 0) {
+                        // the previous block's scores of this column block, then the MFMA that overwrites them
+                        if (u > 0 || rb > 0) {
+                            asm volatile("s_nop 7" ::"v"(acc[qb]));
+                            epi(acc[qb]);
+                        }
+                        acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bq[qb][s], c0, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else {
+                        acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bq[qb][s], s == 0 ? c0 : acc[qb], 0, 0, 0);
                     }
                 }
-            } else {
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(F & 64)) {
+                if (F & 8) {
+                    asm volatile("s_nop 15\n\ts_nop 3" ::"v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]));
 #pragma unroll
-                for (int qb = 0; qb < 4; ++qb) asm volatile("" ::"v"(acc[qb]));
+                    for (int qb = 0; qb < 4; ++qb) epi(acc[qb]);
+                } else {
+#pragma unroll
+                    for (int qb = 0; qb < 4; ++qb) asm volatile("" ::"v"(acc[qb]));
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -152,6 +173,10 @@ probe(const _Float16* __restrict__ xb, const _Float16* __restrict__ xq, float* o
         }
         if (F & 2) __syncthreads();
         slot = slot == RING - 1 ? 0 : slot + 1;
+    }
+    if (F & 64) {
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) keep += acc[qb][0] > th ? 1.f : 0.f;
     }
     if (hits == 12345) out[blockIdx.x * WAVES * 64 + tid] = keep;
 }
@@ -209,5 +234,8 @@ int main(int argc, char** argv) {
     run<7 | 32, 8, 4>("LDS + barrier + DMA by wave 0, 4-slot ring", xb, xq, out, nwg, nsteps, nsplit);
     run<31, 8, 4>("the kernel, 4-slot ring", xb, xq, out, nwg, nsteps, nsplit);
     run<31 | 32, 8, 4>("the kernel, 4-slot ring, DMA by wave 0", xb, xq, out, nwg, nsteps, nsplit);
+    run<31, 8, 3>("the kernel (again)", xb, xq, out, nwg, nsteps, nsplit);
+    run<31 | 64, 8, 3>("the kernel, software-pipelined epilogue", xb, xq, out, nwg, nsteps, nsplit);
+    run<15 | 64, 8, 3>("same without the bias operand", xb, xq, out, nwg, nsteps, nsplit);
     return 0;
 }
