@@ -39,3 +39,15 @@ for c in cases:
     print("nq=%-6d geom=%-4s nsplit=%-4s %.3f ms/search  %.2f M QPS  (x%d ranks = %.1f M QPS)" % (
         nq, f[1] if len(f) > 1 else "auto", f[2] if len(f) > 2 else "auto", ms, nq / ms / 1e3, 10000 // nq if nq < 10000 else 1,
         (10000 // nq if nq < 10000 else 1) * nq / ms / 1e3), flush=True)
+
+# PCIe-inclusive rate: queries and results in (pageable) host memory, as benchs/bench_gpu_sift1m.py measures
+if "host" in os.environ.get("SWEEP_EXTRA", "host"):
+    for key in ("FAISS_AMD_FILTER_GEOM", "FAISS_AMD_FILTER_NSPLIT"):
+        os.environ.pop(key, None)
+    for _ in range(2):
+        idx.search(xq, 100)
+    t0 = time.time()
+    for _ in range(10):
+        D, I = idx.search(xq, 100)
+    ms = (time.time() - t0) / 10 * 1e3
+    print("host buffers in/out: nq=10000 %.3f ms/search  %.2f M QPS" % (ms, 10000 / ms / 1e3), flush=True)
