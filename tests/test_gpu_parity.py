@@ -626,3 +626,38 @@ def test_ivf_full_size_properties(res, kind):
         assert r1 > 0.93 and r100 >= r1
     else:
         assert r1 > 0.8 and r100 > 0.9  # PQ64: benchs/README.md:221 reports R@1 ~0.82 on SIFT1M
+
+
+@pytest.mark.parametrize("kind", ["ivfflat", "ivfpq"])
+def test_ivf_nan_queries_and_nan_adds(res, kind):
+    """faiss/gpu/test/TestGpuIndexIVFFlat.cpp:566-605 (QueryNaN: every result is -1 / FLT_MAX) and :633-675 (AddNaN:
+    NaN vectors are not stored, the valid one among them is, nothing crashes); same pair in TestGpuIndexIVFPQ.cpp."""
+    d, nlist, k = 32, 16, 5
+    xt, xb, xq = synthetic_dataset(d, 3000, 4000, 10, seed=31)
+    if kind == "ivfflat":
+        idx = faiss_amd.GpuIndexIVFFlat(res, d, nlist, METRIC_L2)
+    else:
+        idx = faiss_amd.GpuIndexIVFPQ(res, d, nlist, 4, 8, METRIC_L2)
+    idx.train(xt)
+    idx.nprobe = 4
+    # AddNaN on the empty index: one valid vector (not the first) among NaN rows
+    nans = np.full((10, d), np.nan, dtype=np.float32)
+    nans[1] = xb[123]
+    idx.add(nans)
+    assert sum(idx.get_list_size(l) for l in range(nlist)) == 1
+    idx.nprobe = nlist
+    D, I = idx.search(xq, k)
+    assert (I[:, 0] == 1).all() and (I[:, 1:] == -1).all()
+    # more data, then QueryNaN
+    idx.add(xb)
+    idx.nprobe = 4
+    qn = np.full((10, d), np.nan, dtype=np.float32)
+    D, I = idx.search(qn, k)
+    assert (I == -1).all() and (D == FMAX).all()
+    # a NaN query between valid ones leaves its neighbours' results untouched
+    mix = xq.copy()
+    mix[3] = np.nan
+    Dm, Im = idx.search(mix, k)
+    Dv, Iv = idx.search(xq, k)
+    keep = np.arange(10) != 3
+    assert np.array_equal(Im[keep], Iv[keep]) and np.array_equal(Dm[keep], Dv[keep]) and (Im[3] == -1).all()
