@@ -70,3 +70,32 @@ def test_product_does_not_import_the_oracle():
                 code = "\n".join(l for l in src.splitlines()
                                  if not l.strip().startswith(("//", "#", "*", "/*")))
                 assert "pyoracle" not in code and "libfaiss_oracle" not in code and "libfaiss_ref" not in code, f
+
+
+def test_meta_indexes_without_members_raise():
+    """IndexShards / IndexReplicas need no GPU themselves; their error behaviour mirrors the reference
+    (faiss/IndexReplicas.cpp:132 "no replicas in index", faiss/IndexShards.cpp FAISS_THROW_IF_NOT(count() > 0))."""
+    xq = np.zeros((3, 8), dtype=np.float32)
+    rep = faiss_amd.IndexReplicas(8)
+    assert rep.ntotal == 0 and rep.d == 8
+    with pytest.raises(faiss_amd.FaissAmdError) as e:
+        rep.search(xq, 2)
+    assert "no replicas" in str(e.value)
+    with pytest.raises(faiss_amd.FaissAmdError):
+        rep.reconstruct(0)
+    sh = faiss_amd.IndexShards(8)
+    with pytest.raises(faiss_amd.FaissAmdError) as e:
+        sh.search(xq, 2)
+    assert "no shards" in str(e.value)
+    with pytest.raises(faiss_amd.FaissAmdError):
+        sh.add(xq)
+
+
+def test_bfknn_without_resources_is_an_error():
+    lib = faiss_amd.load_library()
+    x = np.zeros((4, 8), dtype=np.float32)
+    D = np.zeros((4, 2), dtype=np.float32)
+    I = np.zeros((4, 2), dtype=np.int64)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    assert lib.faiss_amd_bfKnn(None, 1, p(x), 4, p(x), 4, 8, 2, p(D), p(I)) == -2
+    assert b"null resources" in lib.faiss_amd_get_last_error()
