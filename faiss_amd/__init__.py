@@ -99,6 +99,9 @@ def load_library():
         "faiss_amd_GpuIndexIVF_search_preassigned": (i32, [vp, i64, vp, i64, vp, vp, vp, vp]),
         "faiss_amd_IndexIVF_quantizer_search": (i32, [vp, i64, vp, i64, vp, vp]),
         "faiss_amd_bfKnn": (i32, [vp, i32, vp, i64, vp, i64, i32, i64, vp, vp]),
+        "faiss_amd_GpuIndexIVF_search_with_params": (i32, [vp, i64, vp, i64, vp, vp, vp]),
+        "faiss_amd_GpuIndexIVF_stored_vectors": (i32, [vp, P(i64)]),
+        "faiss_amd_GpuIndexIVF_arena_stats": (i32, [vp, P(i64), P(i64), P(i64)]),
     }
     for name, (res, args) in protos.items():
         fn = getattr(lib, name)  # AttributeError => the library does not export the symbol
@@ -339,6 +342,32 @@ class _GpuIndexIVF(Index):
                                                                   _ptr(D), _ptr(I)))
         return D, I
 
+    def search(self, x, k, params=None):
+        """index.search(x, k, params=SearchParametersIVF(nprobe=...)): per-call nprobe (faiss/IndexIVF.h:70-80)"""
+        if params is None:
+            return Index.search(self, x, k)
+        x = _f32(x, self.d)
+        n = x.shape[0]
+        D = np.empty((n, k), dtype=np.float32)
+        I = np.empty((n, k), dtype=np.int64)
+        c = ctypes.c_int(int(getattr(params, "nprobe", params)))
+        _check(self._lib.faiss_amd_GpuIndexIVF_search_with_params(self._h, n, _ptr(x), int(k), ctypes.byref(c), _ptr(D),
+                                                                  _ptr(I)))
+        return D, I
+
+    @property
+    def stored_vectors(self):
+        """vectors held by the lists (ntotal also counts NaN rows that add() skipped, like the reference)"""
+        v = ctypes.c_int64(0)
+        _check(self._lib.faiss_amd_GpuIndexIVF_stored_vectors(self._h, ctypes.byref(v)))
+        return v.value
+
+    def arena_stats(self):
+        """(used_rows, hole_rows, allocated_rows) of the list arena"""
+        a, b, c = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+        _check(self._lib.faiss_amd_GpuIndexIVF_arena_stats(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return a.value, b.value, c.value
+
     def set_use_fused_scan(self, on):
         """test hook: False routes search() through the unfused scan + select kernels"""
         _check(self._lib.faiss_amd_GpuIndexIVF_set_use_fused_scan(self._h, 1 if on else 0))
@@ -401,6 +430,13 @@ class _GpuIndexIVF(Index):
         assert ls.shape == (self.nlist,) and ids.shape == (int(ls.sum()),)
         assert codes.size == ids.size * self.code_size
         _check(self._lib.faiss_amd_IndexIVF_copy_lists(self._h, _ptr(ls), _ptr(codes), _ptr(ids)))
+
+
+class SearchParametersIVF:
+    """faiss.SearchParametersIVF (faiss/IndexIVF.h:70-80): nprobe override of one search call"""
+
+    def __init__(self, nprobe=0):
+        self.nprobe = int(nprobe)
 
 
 class GpuIndexIVFFlat(_GpuIndexIVF):

@@ -454,6 +454,29 @@ int faiss_amd_bfKnn(FaissAmdGpuResources* res, FaissAmdMetricType metric, const 
     bfKnn(R(res), (int)metric, vectors, num_vectors, queries, num_queries, dims, k, out_distances, out_indices);
     FA_CATCH
 }
+int faiss_amd_GpuIndexIVF_search_with_params(const FaissAmdIndex* index, faiss_amd_idx_t n, const float* x,
+                                             faiss_amd_idx_t k, const FaissAmdSearchParametersIVF* params,
+                                             float* distances, faiss_amd_idx_t* labels) {
+    FA_TRY
+    SearchParametersIVF sp;
+    if (params) {
+        FA_THROW_IF_NOT_MSG(params->nprobe <= kMaxSelectionK, "nprobe must be in [1, 2048]");
+        sp.nprobe = params->nprobe;
+    }
+    as<GpuIndexIVF>(index, "GpuIndexIVF")->search(n, x, k, distances, labels, &sp);
+    FA_CATCH
+}
+int faiss_amd_GpuIndexIVF_stored_vectors(const FaissAmdIndex* index, faiss_amd_idx_t* p_stored) {
+    FA_TRY
+    *p_stored = as<GpuIndexIVF>(index, "GpuIndexIVF")->stored_vectors();
+    FA_CATCH
+}
+int faiss_amd_GpuIndexIVF_arena_stats(const FaissAmdIndex* index, int64_t* used_rows, int64_t* hole_rows,
+                                      int64_t* allocated_rows) {
+    FA_TRY
+    as<GpuIndexIVF>(index, "GpuIndexIVF")->arena_stats(used_rows, hole_rows, allocated_rows);
+    FA_CATCH
+}
 int faiss_amd_GpuIndexIVF_set_use_fused_scan(FaissAmdIndex* index, int on) {
     FA_TRY
     as<GpuIndexIVF>(index, "GpuIndexIVF")->use_fused_scan = on != 0;

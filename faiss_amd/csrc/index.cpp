@@ -852,11 +852,16 @@ GpuIndexIVF::GpuIndexIVF(std::shared_ptr<GpuResources> res, int dims, int metric
     quantizer->filter_min_rows = 2048;
     is_trained = false;
     list_len_.assign(nlist, 0);
+    list_cap_.assign(nlist, 0);
     list_start_.assign(nlist, 0);
 }
 GpuIndexIVF::~GpuIndexIVF() {
     (void)hipSetDevice(res_->device);
     delete quantizer;
+}
+
+void GpuIndexIVF::update_is_trained_() {
+    is_trained = quantizer->ntotal == nlist && extra_trained_();
 }
 
 void GpuIndexIVF::upload_list_tables_() {
@@ -869,22 +874,51 @@ void GpuIndexIVF::upload_list_tables_() {
     res_->sync();
 }
 
+// the arena buffers hold at least `rows` rows (geometric growth; contents of the rows handed out so far kept)
+void GpuIndexIVF::ensure_arena_(int64_t rows) {
+    rows = std::max<int64_t>(rows, 64);
+    if (rows <= arena_cap_rows_ && arena_.p) return;
+    int64_t ncap = std::max<int64_t>(rows, arena_cap_rows_ + arena_cap_rows_ / 2);
+    ncap = (int64_t)round_up((size_t)ncap, 64);
+    const size_t keep = (size_t)arena_rows_;
+    // DevBuf::ensure grows to max(bytes, 1.5 cap): ask for exactly ncap rows of each array
+    arena_.ensure((size_t)ncap * code_bytes_, keep * code_bytes_, res_->stream);
+    arena_ids_.ensure((size_t)ncap * 8, keep * 8, res_->stream);
+    if (use_t2_) arena_t2_.ensure((size_t)ncap * 4, keep * 4, res_->stream);
+    arena_cap_rows_ = ncap;
+}
+
+void GpuIndexIVF::arena_stats(int64_t* used, int64_t* holes, int64_t* allocated) const {
+    std::lock_guard<std::mutex> g(mu_);
+    if (used) *used = arena_rows_;
+    if (holes) *holes = hole_rows_;
+    if (allocated) *allocated = arena_cap_rows_;
+}
+
 void GpuIndexIVF::reset() {
     std::lock_guard<std::mutex> g(mu_);
     res_->set_device();
     ntotal = 0;
+    nstored_ = 0;
+    arena_rows_ = 0;
+    hole_rows_ = 0;
     std::fill(list_len_.begin(), list_len_.end(), 0);
+    std::fill(list_cap_.begin(), list_cap_.end(), 0);
     std::fill(list_start_.begin(), list_start_.end(), 0);
+    ensure_arena_(64);
     upload_list_tables_();
 }
 
 void GpuIndexIVF::set_centroids(const float* centroids) {
+    FA_THROW_IF_NOT_MSG(centroids, "null centroids");
+    std::lock_guard<std::mutex> g(mu_);
     res_->set_device();
     quantizer->reset();
     quantizer->add(nlist, centroids);
-    is_trained = true; // IVFPQ additionally needs set_pq_centroids (checked in add/search)
+    update_is_trained_();
+    ensure_arena_(64);
     upload_list_tables_();
-    if (ntotal > 0) lists_changed_();
+    if (nstored_ > 0 && is_trained) lists_changed_();
 }
 
 void GpuIndexIVF::train(idx_t n, const float* x) {
@@ -898,143 +932,254 @@ void GpuIndexIVF::train(idx_t n, const float* x) {
         HIP_CHECK(hipMemcpy(hx.data(), x, (size_t)n * d * 4, hipMemcpyDeviceToHost));
         xh = hx.data();
     }
-    Clustering clus(d, nlist);
-    clus.niter = cp_niter;
-    clus.seed = cp_seed;
-    clus.verbose = verbose;
-    // the quantizer itself is the assignment index, exactly like GpuIndexIVF::trainQuantizer_
-    // (faiss/gpu/GpuIndexIVF.cu:508-538)
-    clus.train(n, xh, *quantizer);
-    FA_THROW_IF_NOT(quantizer->ntotal == nlist);
+    if (quantizer->ntotal != nlist) {
+        Clustering clus(d, nlist);
+        clus.niter = cp_niter;
+        clus.seed = cp_seed;
+        clus.verbose = verbose;
+        // the quantizer itself is the assignment index, exactly like GpuIndexIVF::trainQuantizer_
+        // (faiss/gpu/GpuIndexIVF.cu:508-538)
+        clus.train(n, xh, *quantizer);
+        FA_THROW_IF_NOT(quantizer->ntotal == nlist);
+    }
     {
         // residual training (IVFPQ) works on padded device copies
         std::lock_guard<std::mutex> g(mu_);
-        DevBuf xpad;
-        xpad.ensure((size_t)n * dpad_ * 4);
-        stage_padded(*res_, xh, n, d, dpad_, q_raw_, xpad.as<float>());
-        res_->sync();
-        train_residual_(n, xpad.as<float>());
+        if (!extra_trained_()) {
+            DevBuf xpad;
+            xpad.ensure((size_t)n * dpad_ * 4);
+            stage_padded(*res_, xh, n, d, dpad_, q_raw_, xpad.as<float>());
+            res_->sync();
+            train_residual_(n, xpad.as<float>());
+        }
+        update_is_trained_();
+        ensure_arena_(64);
+        upload_list_tables_();
     }
-    is_trained = true;
-    upload_list_tables_();
 }
 
 void GpuIndexIVF::add(idx_t n, const float* x) {
-    // ids are generated sequentially when absent (reference: faiss/gpu/GpuIndex.cu:137-144)
-    std::vector<idx_t> ids((size_t)n);
-    for (idx_t i = 0; i < n; i++) ids[i] = ntotal + i;
-    add_with_ids(n, x, ids.data());
+    // ids are generated sequentially when absent, from the number of vectors add() has been given so far
+    // (reference: faiss/gpu/GpuIndex.cu:137-144; ntotal counts attempted vectors, GpuIndexIVF.cu:293-298)
+    add_core_(n, x, nullptr);
+}
+void GpuIndexIVF::add_with_ids(idx_t n, const float* x, const idx_t* xids) {
+    FA_THROW_IF_NOT_MSG(n == 0 || xids, "null ids");
+    add_core_(n, x, xids);
 }
 
-void GpuIndexIVF::add_with_ids(idx_t n, const float* x, const idx_t* xids) {
+// Lists that outgrow their slack move to fresh rows at the end of the arena (geometric capacity); the abandoned
+// range becomes a hole that compact_() reclaims once holes make up half of the arena.  Per call O(nlist) host work
+// + the moved bytes (amortised O(1) per added vector), instead of round 1's rebuild of the whole arena.
+void GpuIndexIVF::grow_lists_(const std::vector<uint32_t>& new_len, const std::vector<double>* est) {
+    std::vector<IvfMoveJob> jobs;
+    int64_t extra = 0;
+    const int64_t G = granule_;
+    for (int l = 0; l < nlist; l++) {
+        if (new_len[l] <= list_cap_[l]) continue;
+        double want = (double)new_len[l];
+        if (list_cap_[l] > 0) want = std::max(want, 1.5 * (double)list_cap_[l]);
+        if (est) want = std::max(want, 1.03 * (*est)[l]);
+        const int64_t ncap = (int64_t)round_up((size_t)std::ceil(want), (size_t)G);
+        FA_THROW_IF_NOT_MSG(ncap < ((int64_t)1 << 32), "inverted list too long");
+        if (list_len_[l] > 0) jobs.push_back({list_start_[l], arena_rows_ + extra, (int64_t)round_up(list_len_[l], (size_t)G)});
+        hole_rows_ += list_cap_[l];
+        list_start_[l] = arena_rows_ + extra;
+        list_cap_[l] = (uint32_t)ncap;
+        extra += ncap;
+    }
+    if (extra == 0) return;
+    const GpuResources& R = *res_;
+    ensure_arena_(arena_rows_ + extra); // (keeps rows [0, arena_rows_): the jobs' sources)
+    arena_rows_ += extra;
+    if (!jobs.empty()) {
+        a_jobs_.ensure(jobs.size() * sizeof(IvfMoveJob));
+        HIP_CHECK(hipMemcpyAsync(a_jobs_.p, jobs.data(), jobs.size() * sizeof(IvfMoveJob), hipMemcpyHostToDevice,
+                                 R.stream));
+        const IvfMoveJob* dj = a_jobs_.as<IvfMoveJob>();
+        launch_ivf_move(arena_.as<uint8_t>(), arena_.as<uint8_t>(), dj, (int)jobs.size(), (int)code_bytes_, R.stream);
+        launch_ivf_move(arena_ids_.as<uint8_t>(), arena_ids_.as<uint8_t>(), dj, (int)jobs.size(), 8, R.stream);
+        if (use_t2_)
+            launch_ivf_move(arena_t2_.as<uint8_t>(), arena_t2_.as<uint8_t>(), dj, (int)jobs.size(), 4, R.stream);
+    }
+    HIP_CHECK(hipMemcpyAsync(d_list_start_.p, list_start_.data(), (size_t)nlist * 8, hipMemcpyHostToDevice, R.stream));
+    R.sync(); // jobs / list_start_ host vectors are read by the copies above
+}
+
+// rebuild the arena without holes (lists in id order, 1/8 slack each)
+void GpuIndexIVF::compact_() {
+    const GpuResources& R = *res_;
+    const int64_t G = granule_;
+    std::vector<IvfMoveJob> jobs;
+    std::vector<int64_t> nstart(nlist);
+    std::vector<uint32_t> ncap(nlist);
+    int64_t acc = 0;
+    for (int l = 0; l < nlist; l++) {
+        nstart[l] = acc;
+        ncap[l] = list_len_[l] ? (uint32_t)round_up((size_t)list_len_[l] + list_len_[l] / 8, (size_t)G) : 0u;
+        if (list_len_[l]) jobs.push_back({list_start_[l], acc, (int64_t)round_up(list_len_[l], (size_t)G)});
+        acc += ncap[l];
+    }
+    DevBuf na, ni, nt;
+    const int64_t rows = std::max<int64_t>(acc, 64);
+    na.ensure((size_t)rows * code_bytes_);
+    ni.ensure((size_t)rows * 8);
+    if (use_t2_) nt.ensure((size_t)rows * 4);
+    if (!jobs.empty()) {
+        a_jobs_.ensure(jobs.size() * sizeof(IvfMoveJob));
+        HIP_CHECK(hipMemcpyAsync(a_jobs_.p, jobs.data(), jobs.size() * sizeof(IvfMoveJob), hipMemcpyHostToDevice,
+                                 R.stream));
+        const IvfMoveJob* dj = a_jobs_.as<IvfMoveJob>();
+        launch_ivf_move(arena_.as<uint8_t>(), na.as<uint8_t>(), dj, (int)jobs.size(), (int)code_bytes_, R.stream);
+        launch_ivf_move(arena_ids_.as<uint8_t>(), ni.as<uint8_t>(), dj, (int)jobs.size(), 8, R.stream);
+        if (use_t2_) launch_ivf_move(arena_t2_.as<uint8_t>(), nt.as<uint8_t>(), dj, (int)jobs.size(), 4, R.stream);
+    }
+    R.sync();
+    std::swap(arena_.p, na.p);
+    std::swap(arena_.cap, na.cap);
+    std::swap(arena_ids_.p, ni.p);
+    std::swap(arena_ids_.cap, ni.cap);
+    if (use_t2_) {
+        std::swap(arena_t2_.p, nt.p);
+        std::swap(arena_t2_.cap, nt.cap);
+    }
+    list_start_ = nstart;
+    list_cap_ = ncap;
+    arena_rows_ = acc;
+    arena_cap_rows_ = rows;
+    hole_rows_ = 0;
+    upload_list_tables_();
+}
+
+// add path, page by page like the reference (faiss/gpu/GpuIndex.cu:197-254 addPaged_): per page the vectors are
+// staged once, assigned to their lists (k = 1 search on the quantizer), ranked inside their lists by a stable
+// counting sort on the device (ivf_kernels.hip) and encoded / scattered into the lists' slack.  The host sees
+// nlist list lengths per page, never a per-vector array.
+void GpuIndexIVF::add_core_(idx_t n, const float* x, const idx_t* xids) {
     FA_THROW_IF_NOT_MSG(is_trained, "index must be trained before adding vectors");
     if (n == 0) return;
-    FA_THROW_IF_NOT_MSG(x && xids, "null argument");
-    FA_THROW_IF_NOT_MSG(ntotal + n < ((idx_t)1 << 31), "at most 2^31-1 vectors per device index");
+    FA_THROW_IF_NOT_MSG(x, "null argument");
     std::lock_guard<std::mutex> g(mu_);
     res_->set_device();
     const GpuResources& R = *res_;
     const idx_t page = std::max<idx_t>(1, std::min<idx_t>(((idx_t)512 << 20) / ((idx_t)dpad_ * 4), 1 << 20));
-    // ---- pass 1: coarse assignment of every new vector (k = 1 search on the quantizer)
-    std::vector<idx_t> labels((size_t)n);
-    DevBuf xpad, dlab, ddis;
-    xpad.ensure((size_t)std::min(page, n) * dpad_ * 4);
-    dlab.ensure((size_t)std::min(page, n) * 8);
-    ddis.ensure((size_t)std::min(page, n) * 4);
+    const int chunk = 2048;
+    const idx_t pn = std::min(page, n);
+    a_xpad_.ensure((size_t)pn * dpad_ * 4);
+    a_lab_.ensure((size_t)pn * 8);
+    a_dis_.ensure((size_t)pn * 4);
+    a_dest_.ensure((size_t)pn * 8);
+    a_ids_.ensure((size_t)pn * 8);
+    a_newlen_.ensure((size_t)nlist * 4);
+    a_hist_.ensure(div_up(pn, chunk) * (size_t)nlist * 4);
+    const idx_t id_base = ntotal;
+    const std::vector<uint32_t> len0(list_len_);
+    std::vector<uint32_t> new_len(nlist);
+    std::vector<double> est(nlist);
     for (idx_t i0 = 0; i0 < n; i0 += page) {
         const int ni = (int)std::min(page, n - i0);
-        stage_padded(R, x + (size_t)i0 * d, ni, d, dpad_, q_raw_, xpad.as<float>());
-        quantizer->search_device(ni, xpad.as<float>(), 1, ddis.as<float>(), dlab.as<idx_t>());
-        HIP_CHECK(hipMemcpyAsync(labels.data() + i0, dlab.p, (size_t)ni * 8, hipMemcpyDeviceToHost, R.stream));
-        R.sync();
-    }
-    // ---- host bookkeeping: new layout (reference: IVFBase.cu:693-905 addVectorsToLists_)
-    std::vector<uint32_t> new_len(list_len_);
-    idx_t n_valid = 0;
-    for (idx_t i = 0; i < n; i++) {
-        if (labels[i] >= 0) { // NaN vectors get label -1 and are skipped, like the reference
-            new_len[labels[i]]++;
-            n_valid++;
+        const int nchunks = (int)div_up(ni, chunk);
+        stage_padded(R, x + (size_t)i0 * d, ni, d, dpad_, q_raw_, a_xpad_.as<float>());
+        // ---- coarse assignment (NaN vectors get label -1 and are skipped, like the reference)
+        quantizer->search_device(ni, a_xpad_.as<float>(), 1, a_dis_.as<float>(), a_lab_.as<idx_t>());
+        if (xids) {
+            HIP_CHECK(hipMemcpyAsync(a_ids_.p, xids + i0, (size_t)ni * 8, hipMemcpyDefault, R.stream));
+        } else {
+            launch_iota_i64(a_ids_.as<int64_t>(), ni, id_base + i0, R.stream);
         }
-    }
-    std::vector<int64_t> new_start(nlist);
-    int64_t acc = 0;
-    for (int l = 0; l < nlist; l++) {
-        new_start[l] = acc;
-        acc += new_len[l];
-    }
-    std::vector<int64_t> dest((size_t)n);
-    {
-        std::vector<uint32_t> fill(list_len_);
-        for (idx_t i = 0; i < n; i++) {
-            idx_t l = labels[i];
-            dest[i] = l >= 0 ? new_start[l] + fill[l]++ : -1;
-        }
-    }
-    // ---- rebuild arenas: move old lists, then scatter the new entries
-    const size_t new_total = (size_t)acc;
-    DevBuf new_arena, new_ids, d_new_start;
-    new_arena.ensure(std::max<size_t>(new_total * code_bytes_, 256));
-    new_ids.ensure(std::max<size_t>(new_total * 8, 256));
-    d_new_start.ensure((size_t)nlist * 8);
-    HIP_CHECK(hipMemcpyAsync(d_new_start.p, new_start.data(), (size_t)nlist * 8, hipMemcpyHostToDevice,
-                             R.stream));
-    if (ntotal > 0) {
-        launch_move_lists(arena_.as<uint8_t>(), new_arena.as<uint8_t>(), d_list_start_.as<int64_t>(),
-                          d_new_start.as<int64_t>(), d_list_len_.as<uint32_t>(), nlist, (int)code_bytes_,
-                          R.stream);
-        launch_move_lists(arena_ids_.as<uint8_t>(), new_ids.as<uint8_t>(), d_list_start_.as<int64_t>(),
-                          d_new_start.as<int64_t>(), d_list_len_.as<uint32_t>(), nlist, 8, R.stream);
-    }
-    R.sync();
-    std::swap(arena_.p, new_arena.p);
-    std::swap(arena_.cap, new_arena.cap);
-    std::swap(arena_ids_.p, new_ids.p);
-    std::swap(arena_ids_.cap, new_ids.cap);
-    // ---- pass 2: encode + scatter
-    DevBuf ddest, dids;
-    ddest.ensure((size_t)std::min(page, n) * 8);
-    dids.ensure((size_t)std::min(page, n) * 8);
-    for (idx_t i0 = 0; i0 < n; i0 += page) {
-        const int ni = (int)std::min(page, n - i0);
-        stage_padded(R, x + (size_t)i0 * d, ni, d, dpad_, q_raw_, xpad.as<float>());
-        HIP_CHECK(hipMemcpyAsync(dlab.p, labels.data() + i0, (size_t)ni * 8, hipMemcpyHostToDevice, R.stream));
-        HIP_CHECK(hipMemcpyAsync(ddest.p, dest.data() + i0, (size_t)ni * 8, hipMemcpyHostToDevice, R.stream));
-        HIP_CHECK(hipMemcpyAsync(dids.p, xids + i0, (size_t)ni * 8,
-                                 is_device_pointer(xids) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
-                                 R.stream));
-        append_(ni, xpad.as<float>(), dlab.as<int64_t>(), ddest.as<int64_t>());
-        launch_scatter_i64(dids.as<int64_t>(), ddest.as<int64_t>(), ni, arena_ids_.as<int64_t>(), R.stream);
+        // ---- list lengths after this page
+        HIP_CHECK(hipMemsetAsync(a_hist_.p, 0, (size_t)nchunks * nlist * 4, R.stream));
+        launch_ivf_histogram(a_lab_.as<int64_t>(), ni, nlist, chunk, a_hist_.as<uint32_t>(), R.stream);
+        launch_ivf_chunk_scan(a_hist_.as<uint32_t>(), nchunks, nlist, d_list_len_.as<uint32_t>(), a_newlen_.as<uint32_t>(),
+                              R.stream);
+        HIP_CHECK(hipMemcpyAsync(new_len.data(), a_newlen_.p, (size_t)nlist * 4, hipMemcpyDeviceToHost, R.stream));
         R.sync();
+        // ---- room: a list that has to move takes the length this call is expected to leave it with
+        const double scale = (double)n / (double)(i0 + ni);
+        idx_t added = 0;
+        for (int l = 0; l < nlist; l++) {
+            est[l] = (double)len0[l] + ((double)new_len[l] - (double)len0[l]) * scale;
+            added += (idx_t)new_len[l] - (idx_t)list_len_[l];
+        }
+        grow_lists_(new_len, &est);
+        // ---- destination rows (insertion order kept inside every list), then encode / scatter
+        launch_ivf_rank(a_lab_.as<int64_t>(), ni, nlist, chunk, a_hist_.as<uint32_t>(), d_list_start_.as<int64_t>(),
+                        a_dest_.as<int64_t>(), R.stream);
+        append_(ni, a_xpad_.as<float>(), a_lab_.as<int64_t>(), a_dest_.as<int64_t>());
+        launch_scatter_i64(a_ids_.as<int64_t>(), a_dest_.as<int64_t>(), ni, arena_ids_.as<int64_t>(), R.stream);
+        HIP_CHECK(hipMemcpyAsync(d_list_len_.p, a_newlen_.p, (size_t)nlist * 4, hipMemcpyDeviceToDevice, R.stream));
+        list_len_ = new_len;
+        nstored_ += added;
+        ntotal += ni;
+        R.sync(); // the staging buffers are reused by the next page
     }
-    list_len_ = new_len;
-    list_start_ = new_start;
-    ntotal += n_valid;
-    upload_list_tables_();
-    lists_changed_();
+    if (hole_rows_ > arena_rows_ / 2 && arena_rows_ > ((int64_t)1 << 16)) compact_();
 }
 
 void GpuIndexIVF::set_lists(const uint32_t* list_sizes, const uint8_t* codes, const idx_t* ids) {
+    FA_THROW_IF_NOT_MSG(is_trained, "copy the quantizers before the lists");
+    FA_THROW_IF_NOT_MSG(list_sizes, "null list sizes");
     std::lock_guard<std::mutex> g(mu_);
     res_->set_device();
-    int64_t acc = 0;
+    const GpuResources& R = *res_;
+    const int64_t G = granule_;
+    std::vector<int64_t> src_start(nlist), nstart(nlist);
+    std::vector<uint32_t> ncap(nlist);
+    int64_t acc = 0, rows = 0;
     for (int l = 0; l < nlist; l++) {
-        list_len_[l] = list_sizes[l];
-        list_start_[l] = acc;
+        src_start[l] = acc;
+        nstart[l] = rows;
+        ncap[l] = (uint32_t)round_up(list_sizes[l], (size_t)G);
         acc += list_sizes[l];
+        rows += ncap[l];
     }
-    FA_THROW_IF_NOT_MSG(acc < ((int64_t)1 << 31), "at most 2^31-1 vectors per device index");
-    ntotal = acc;
-    arena_.ensure(std::max<size_t>((size_t)acc * code_bytes_, 256));
-    arena_ids_.ensure(std::max<size_t>((size_t)acc * 8, 256));
+    FA_THROW_IF_NOT_MSG(acc == 0 || (codes && ids), "null codes / ids");
+    // nothing of the index changes before every device copy has been issued successfully
+    arena_rows_ = 0; // (old contents are dropped: nothing to keep when the buffers grow)
+    hole_rows_ = 0;
+    ensure_arena_(rows);
+    const size_t src_row = fused_kind_() == 0 ? (size_t)d * 4 : code_bytes_;
     if (acc > 0) {
-        HIP_CHECK(hipMemcpyAsync(arena_ids_.p, ids, (size_t)acc * 8, hipMemcpyHostToDevice, res_->stream));
+        // ids: list by list into the lists' row ranges
+        DevBuf tmp_ids, tmp_codes, dsrc;
+        tmp_ids.ensure((size_t)acc * 8);
+        HIP_CHECK(hipMemcpyAsync(tmp_ids.p, ids, (size_t)acc * 8, hipMemcpyDefault, R.stream));
+        std::vector<IvfMoveJob> jobs;
+        for (int l = 0; l < nlist; l++)
+            if (list_sizes[l]) jobs.push_back({src_start[l], nstart[l], (int64_t)list_sizes[l]});
+        a_jobs_.ensure(jobs.size() * sizeof(IvfMoveJob));
+        HIP_CHECK(hipMemcpyAsync(a_jobs_.p, jobs.data(), jobs.size() * sizeof(IvfMoveJob), hipMemcpyHostToDevice,
+                                 R.stream));
+        launch_ivf_move(tmp_ids.as<uint8_t>(), arena_ids_.as<uint8_t>(), a_jobs_.as<IvfMoveJob>(), (int)jobs.size(), 8,
+                        R.stream);
         // `codes` are the reference's list payloads: d floats (IVFFlat) or M bytes (IVFPQ) per entry
-        const size_t src_row = code_bytes_ == (size_t)dpad_ * 4 ? (size_t)d * 4 : code_bytes_;
-        HIP_CHECK(hipMemsetAsync(arena_.p, 0, (size_t)acc * code_bytes_, res_->stream));
-        HIP_CHECK(hipMemcpy2DAsync(arena_.p, code_bytes_, codes, src_row, src_row, (size_t)acc,
-                                   hipMemcpyHostToDevice, res_->stream));
+        tmp_codes.ensure((size_t)acc * code_bytes_);
+        if (fused_kind_() == 0) {
+            HIP_CHECK(hipMemsetAsync(tmp_codes.p, 0, (size_t)acc * code_bytes_, R.stream));
+            HIP_CHECK(hipMemcpy2DAsync(tmp_codes.p, code_bytes_, codes, src_row, src_row, (size_t)acc, hipMemcpyDefault,
+                                       R.stream));
+            launch_ivf_move(tmp_codes.as<uint8_t>(), arena_.as<uint8_t>(), a_jobs_.as<IvfMoveJob>(), (int)jobs.size(),
+                            (int)code_bytes_, R.stream);
+        } else {
+            HIP_CHECK(hipMemcpyAsync(tmp_codes.p, codes, (size_t)acc * code_bytes_, hipMemcpyDefault, R.stream));
+            dsrc.ensure((size_t)nlist * 8 * 2 + (size_t)nlist * 4);
+            int64_t* d_src = dsrc.as<int64_t>();
+            int64_t* d_dst = d_src + nlist;
+            uint32_t* d_len = (uint32_t*)(d_dst + nlist);
+            HIP_CHECK(hipMemcpyAsync(d_src, src_start.data(), (size_t)nlist * 8, hipMemcpyHostToDevice, R.stream));
+            HIP_CHECK(hipMemcpyAsync(d_dst, nstart.data(), (size_t)nlist * 8, hipMemcpyHostToDevice, R.stream));
+            HIP_CHECK(hipMemcpyAsync(d_len, list_sizes, (size_t)nlist * 4, hipMemcpyHostToDevice, R.stream));
+            launch_ivfpq_pack_lists(tmp_codes.as<uint8_t>(), d_src, d_dst, d_len, nlist, (int)code_bytes_, arena_.as<uint8_t>(),
+                                    R.stream);
+        }
+        R.sync();
     }
+    for (int l = 0; l < nlist; l++) list_len_[l] = list_sizes[l];
+    list_cap_ = ncap;
+    list_start_ = nstart;
+    arena_rows_ = rows;
+    ntotal = acc;
+    nstored_ = acc;
     upload_list_tables_();
     lists_changed_();
 }
@@ -1053,39 +1198,53 @@ std::vector<uint8_t> GpuIndexIVF::getListVectorData(idx_t list) const {
     FA_THROW_IF_NOT(list >= 0 && list < nlist);
     std::lock_guard<std::mutex> g(mu_);
     res_->set_device();
-    const size_t src_row = code_bytes_;
-    const size_t dst_row = code_bytes_ == (size_t)dpad_ * 4 ? (size_t)d * 4 : code_bytes_;
+    const size_t dst_row = fused_kind_() == 0 ? (size_t)d * 4 : code_bytes_;
     std::vector<uint8_t> out((size_t)list_len_[list] * dst_row);
-    if (!out.empty())
-        HIP_CHECK(hipMemcpy2D(out.data(), dst_row, arena_.as<uint8_t>() + list_start_[list] * src_row, src_row,
+    if (out.empty()) return out;
+    if (fused_kind_() == 0) {
+        HIP_CHECK(hipMemcpy2D(out.data(), dst_row, arena_.as<uint8_t>() + list_start_[list] * code_bytes_, code_bytes_,
                               dst_row, list_len_[list], hipMemcpyDeviceToHost));
+    } else {
+        // rotated block layout -> the reference's plain [entry][M] codes
+        DevBuf tmp;
+        tmp.ensure(out.size());
+        launch_ivfpq_unpack_list(arena_.as<uint8_t>(), list_start_[list], list_len_[list], (int)code_bytes_,
+                                 tmp.as<uint8_t>(), res_->stream);
+        HIP_CHECK(hipMemcpyAsync(out.data(), tmp.p, out.size(), hipMemcpyDeviceToHost, res_->stream));
+        res_->sync();
+    }
     return out;
 }
 
 void GpuIndexIVF::search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels) const {
-    search_core_(n, x, k, distances, labels, nullptr, nullptr);
+    search_core_(n, x, k, distances, labels, nullptr, nullptr, nprobe);
+}
+void GpuIndexIVF::search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels,
+                         const SearchParametersIVF* params) const {
+    search_core_(n, x, k, distances, labels, nullptr, nullptr, params && params->nprobe > 0 ? params->nprobe : nprobe);
 }
 void GpuIndexIVF::search_preassigned(idx_t n, const float* x, idx_t k, const idx_t* assign, const float* centroid_dis,
                                      float* distances, idx_t* labels) const {
     FA_THROW_IF_NOT_MSG(n == 0 || (assign && centroid_dis), "search_preassigned: null assign / centroid_dis");
-    search_core_(n, x, k, distances, labels, assign, centroid_dis);
+    search_core_(n, x, k, distances, labels, assign, centroid_dis, nprobe);
 }
 void GpuIndexIVF::search_core_(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels, const idx_t* assign,
-                               const float* centroid_dis) const {
+                               const float* centroid_dis, int nprobe_now) const {
     FA_THROW_IF_NOT_MSG(is_trained, "index not trained");
     FA_THROW_IF_NOT_MSG(k >= 1 && k <= kMaxSelectionK, "k must be in [1, 2048]");
-    FA_THROW_IF_NOT_MSG(nprobe >= 1 && nprobe <= kMaxSelectionK, "nprobe must be in [1, 2048]");
+    FA_THROW_IF_NOT_MSG(nprobe_now >= 1 && nprobe_now <= kMaxSelectionK, "nprobe must be in [1, 2048]");
     if (n == 0) return;
     FA_THROW_IF_NOT_MSG(x && distances && labels, "null argument");
     std::lock_guard<std::mutex> g(mu_);
     res_->set_device();
     const GpuResources& R = *res_;
     // preassigned arrays are [n][nprobe] whatever nlist is (surplus columns hold -1)
-    const int np = assign ? nprobe : std::min(nprobe, nlist);
+    const int np = assign ? nprobe_now : std::min(nprobe_now, nlist);
     const bool out_dev_d = is_device_pointer(distances), out_dev_i = is_device_pointer(labels);
     // query tile bounded by the worst-case candidate volume (reference: IVFUtils.cu:46-127)
     uint32_t max_len = 1;
     for (auto l : list_len_) max_len = std::max(max_len, l);
+    FA_THROW_IF_NOT_MSG((uint64_t)np * max_len < ((uint64_t)1 << 32), "nprobe * longest list exceeds 2^32 scan positions");
     size_t per_q = (size_t)np * max_len * 8;
     idx_t tile = (idx_t)std::max<size_t>(1, R.temp_budget_bytes / per_q);
     tile = std::min<idx_t>(tile, 16384);
@@ -1095,6 +1254,24 @@ void GpuIndexIVF::search_core_(idx_t n, const float* x, idx_t k, float* distance
     if (fused) tile = 65536; // no per-candidate scratch: the tile only bounds the staging buffers
     for (idx_t i0 = 0; i0 < n; i0 += tile) {
         const int ni = (int)std::min(tile, n - i0);
+        float* dD = out_dev_d ? distances + (size_t)i0 * k : nullptr;
+        idx_t* dI = out_dev_i ? labels + (size_t)i0 * k : nullptr;
+        if (!dD) {
+            out_d_.ensure((size_t)ni * k * 4);
+            dD = out_d_.as<float>();
+        }
+        if (!dI) {
+            out_i_.ensure((size_t)ni * k * 8);
+            dI = out_i_.as<idx_t>();
+        }
+        if (nstored_ == 0) {
+            // trained but empty (e.g. an IndexShards shard that received no rows): nothing to scan
+            launch_fill_knn(dD, dI, (int64_t)ni * k, metric_type, R.stream);
+            if (!out_dev_d) copy_out(R, distances + (size_t)i0 * k, dD, (size_t)ni * k * 4);
+            if (!out_dev_i) copy_out(R, labels + (size_t)i0 * k, dI, (size_t)ni * k * 8);
+            R.sync();
+            continue;
+        }
         q_pad_.ensure((size_t)ni * dpad_ * 4);
         stage_padded(R, x + (size_t)i0 * d, ni, d, dpad_, q_raw_, q_pad_.as<float>());
         // ---- coarse quantizer: nprobe nearest centroids (reference: IVFBase.cu:509-593)
@@ -1107,16 +1284,6 @@ void GpuIndexIVF::search_core_(idx_t n, const float* x, idx_t k, float* distance
             launch_ivf_sanitize_assign(c_ids_.as<idx_t>(), (int64_t)ni * np, nlist, R.stream);
         } else {
             quantizer->search_device(ni, q_pad_.as<float>(), np, c_dis_.as<float>(), c_ids_.as<idx_t>());
-        }
-        float* dD = out_dev_d ? distances + (size_t)i0 * k : nullptr;
-        idx_t* dI = out_dev_i ? labels + (size_t)i0 * k : nullptr;
-        if (!dD) {
-            out_d_.ensure((size_t)ni * k * 4);
-            dD = out_d_.as<float>();
-        }
-        if (!dI) {
-            out_i_.ensure((size_t)ni * k * 8);
-            dI = out_i_.as<idx_t>();
         }
         if (fused) {
             // ---- table build + list scan + k-selection in one launch, nothing but results leaves LDS
@@ -1237,6 +1404,7 @@ void GpuIndexIVF::search_core_(idx_t n, const float* x, idx_t k, float* distance
 GpuIndexIVFFlat::GpuIndexIVFFlat(std::shared_ptr<GpuResources> res, int dims, int nlist, int metric)
         : GpuIndexIVF(std::move(res), dims, metric, nlist) {
     code_bytes_ = (size_t)dpad_ * 4;
+    granule_ = 8;
 }
 void GpuIndexIVFFlat::append_(int n, const float* x_pad, const int64_t*, const int64_t* d_dest) {
     launch_ivfflat_append(x_pad, dpad_, n, d, d_dest, arena_.as<float>(), dpad_, dpad_, res_->stream);
@@ -1244,6 +1412,22 @@ void GpuIndexIVFFlat::append_(int n, const float* x_pad, const int64_t*, const i
 void GpuIndexIVFFlat::fill_fused_(IvfFusedParams& p) const {
     p.arena_vecs = arena_.as<float>();
     p.ldv = dpad_;
+}
+void GpuIndexIVFFlat::reconstruct_n(idx_t i0, idx_t ni, float* recons) const {
+    FA_THROW_IF_NOT_MSG(i0 >= 0 && ni >= 0, "negative range");
+    if (ni == 0) return;
+    FA_THROW_IF_NOT_MSG(recons, "null output");
+    std::lock_guard<std::mutex> g(mu_);
+    res_->set_device();
+    const GpuResources& R = *res_;
+    // rows of the ids in [i0, i0 + ni) wherever their lists hold them; ids that are not stored leave zeros
+    DevBuf out;
+    out.ensure((size_t)ni * d * 4);
+    HIP_CHECK(hipMemsetAsync(out.p, 0, (size_t)ni * d * 4, R.stream));
+    launch_ivfflat_rows_by_id(arena_.as<float>(), dpad_, arena_ids_.as<int64_t>(), d_list_start_.as<int64_t>(),
+                              d_list_len_.as<uint32_t>(), nlist, d, i0, ni, out.as<float>(), R.stream);
+    copy_out(R, recons, out.p, (size_t)ni * d * 4);
+    R.sync();
 }
 void GpuIndexIVFFlat::scan_(int nq, const float* xq_pad, int, const int64_t*) const {
     IvfScanParams p{};
@@ -1278,14 +1462,25 @@ GpuIndexIVFPQ::GpuIndexIVFPQ(std::shared_ptr<GpuResources> res, int dims, int nl
     dsub = dims / M;
     FA_THROW_IF_NOT_MSG(ivfpq_scan_lds_bytes(M, dpad_) <= 160 * 1024, "M too large for the LDS lookup table");
     code_bytes_ = (size_t)M;
+    granule_ = kPqBlockRows;
+    use_t2_ = metric == METRIC_L2;
     FA_THROW_IF_NOT_MSG(M % 4 == 0, "M must be a multiple of 4");
 }
 void GpuIndexIVFPQ::set_pq_centroids(const float* pq) {
+    FA_THROW_IF_NOT_MSG(pq, "null codebook");
+    std::lock_guard<std::mutex> g(mu_);
     res_->set_device();
-    pq_.ensure((size_t)M * 256 * dsub * 4);
-    HIP_CHECK(hipMemcpy(pq_.p, pq, (size_t)M * 256 * dsub * 4,
-                        is_device_pointer(pq) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
-    if (ntotal > 0) lists_changed_();
+    const size_t bytes = (size_t)M * 256 * dsub * 4;
+    DevBuf npq;
+    npq.ensure(bytes);
+    HIP_CHECK(hipMemcpy(npq.p, pq, bytes, hipMemcpyDefault));
+    pq_t_.ensure(bytes);
+    launch_pq_transpose(npq.as<float>(), M, dsub, pq_t_.as<float>(), res_->stream);
+    res_->sync();
+    std::swap(pq_.p, npq.p);
+    std::swap(pq_.cap, npq.cap);
+    update_is_trained_();
+    if (nstored_ > 0 && is_trained) lists_changed_();
 }
 std::vector<float> GpuIndexIVFPQ::get_pq_centroids() const {
     res_->set_device();
@@ -1301,12 +1496,30 @@ void GpuIndexIVFPQ::train_residual_(idx_t n, const float* x_dev_pad) {
     // (faiss/impl/ProductQuantizer.cpp:130-207).
     const GpuResources& R = *res_;
     idx_t nt = std::min<idx_t>(n, (idx_t)256 * 256); // max_points_per_centroid * ksub
-    DevBuf dlab, ddis, dres;
+    DevBuf dlab, ddis, dres, dsel, dsub_rows;
+    const float* xs = x_dev_pad;
+    if (nt < n) {
+        // a random subset of the training set (seeded), as ProductQuantizer::train / Clustering subsample
+        // (faiss/Clustering.cpp subsample_training_set): the first rows of an ordered training set would bias the codebook
+        std::mt19937_64 rng((uint64_t)cp_seed + 0x9e3779b97f4a7c15ull);
+        std::vector<uint32_t> perm((size_t)n);
+        std::iota(perm.begin(), perm.end(), 0u);
+        for (idx_t i = 0; i < nt; i++) {
+            const idx_t j = i + (idx_t)(rng() % (uint64_t)(n - i));
+            std::swap(perm[i], perm[j]);
+        }
+        dsel.ensure((size_t)nt * 4);
+        HIP_CHECK(hipMemcpyAsync(dsel.p, perm.data(), (size_t)nt * 4, hipMemcpyHostToDevice, R.stream));
+        dsub_rows.ensure((size_t)nt * dpad_ * 4);
+        launch_gather_rows(x_dev_pad, dpad_, dpad_, dsel.as<uint32_t>(), (int)nt, dsub_rows.as<float>(), R.stream);
+        R.sync();
+        xs = dsub_rows.as<float>();
+    }
     dlab.ensure((size_t)nt * 8);
     ddis.ensure((size_t)nt * 4);
     dres.ensure((size_t)nt * d * 4);
-    quantizer->search_device((int)nt, x_dev_pad, 1, ddis.as<float>(), dlab.as<idx_t>());
-    launch_residual(x_dev_pad, dpad_, nt, d, dlab.as<idx_t>(), quantizer->device_vectors(), dpad_,
+    quantizer->search_device((int)nt, xs, 1, ddis.as<float>(), dlab.as<idx_t>());
+    launch_residual(xs, dpad_, nt, d, dlab.as<idx_t>(), quantizer->device_vectors(), dpad_,
                     dres.as<float>(), d, R.stream);
     std::vector<float> hres((size_t)nt * d);
     HIP_CHECK(hipMemcpyAsync(hres.data(), dres.p, hres.size() * 4, hipMemcpyDeviceToHost, R.stream));
@@ -1325,33 +1538,35 @@ void GpuIndexIVFPQ::train_residual_(idx_t n, const float* x_dev_pad) {
     }
     pq_.ensure(pq.size() * 4);
     HIP_CHECK(hipMemcpy(pq_.p, pq.data(), pq.size() * 4, hipMemcpyHostToDevice));
+    pq_t_.ensure(pq.size() * 4);
+    launch_pq_transpose(pq_.as<float>(), M, dsub, pq_t_.as<float>(), R.stream);
+    R.sync();
 }
 void GpuIndexIVFPQ::append_(int n, const float* x_pad, const int64_t* d_labels, const int64_t* d_dest) {
-    FA_THROW_IF_NOT_MSG(pq_.p, "PQ not trained");
     launch_ivfpq_encode_append(x_pad, dpad_, n, d, d_labels, d_dest, quantizer->device_vectors(), dpad_, M,
                                dsub, pq_.as<float>(), arena_.as<uint8_t>(), res_->stream);
+    if (use_t2_)
+        launch_ivfpq_t2_rows(arena_.as<uint8_t>(), d_labels, d_dest, n, quantizer->device_vectors(), dpad_, M, dsub,
+                             pq_.as<float>(), arena_t2_.as<float>(), res_->stream);
 }
 void GpuIndexIVFPQ::lists_changed_() {
-    // recompute the per-vector L2 term for the whole arena (one pass over the codes; add time only)
-    if (metric_type != METRIC_L2 || ntotal == 0) return;
-    FA_THROW_IF_NOT_MSG(pq_.p, "PQ not trained");
-    arena_t2_.ensure((size_t)ntotal * 4);
-    launch_ivfpq_t2(arena_.as<uint8_t>(), d_list_start_.as<int64_t>(), d_list_len_.as<uint32_t>(), nlist,
-                    quantizer->device_vectors(), dpad_, M, dsub, pq_.as<float>(), arena_t2_.as<float>(), res_->stream);
+    // recompute the per-vector L2 term for every stored row (bulk load, or the quantizers were replaced)
+    if (!use_t2_ || nstored_ == 0) return;
+    launch_ivfpq_t2_lists(arena_.as<uint8_t>(), d_list_start_.as<int64_t>(), d_list_len_.as<uint32_t>(), nlist,
+                          quantizer->device_vectors(), dpad_, M, dsub, pq_.as<float>(), arena_t2_.as<float>(), res_->stream);
     res_->sync();
 }
 void GpuIndexIVFPQ::fill_fused_(IvfFusedParams& p) const {
-    FA_THROW_IF_NOT_MSG(pq_.p, "PQ not trained");
     p.arena_t2 = arena_t2_.as<float>();
     p.centroids = quantizer->device_vectors();
     p.ldc = dpad_;
     p.M = M;
     p.dsub = dsub;
     p.pq_centroids = pq_.as<float>();
+    p.pq_t = pq_t_.as<float>();
     p.arena_codes = arena_.as<uint8_t>();
 }
 void GpuIndexIVFPQ::scan_(int nq, const float* xq_pad, int, const int64_t*) const {
-    FA_THROW_IF_NOT_MSG(pq_.p, "PQ not trained");
     IvfScanParams p{};
     p.metric = metric_type;
     p.nq = nq;
@@ -1372,6 +1587,7 @@ void GpuIndexIVFPQ::scan_(int nq, const float* xq_pad, int, const int64_t*) cons
     p.M = M;
     p.dsub = dsub;
     p.pq_centroids = pq_.as<float>();
+    p.pq_t = pq_t_.as<float>();
     p.arena_codes = arena_.as<uint8_t>();
     p.arena_t2 = arena_t2_.as<float>();
     SpanGuard sg(res_.get(), "ivfpq_scan_kernel");

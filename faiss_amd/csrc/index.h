@@ -174,6 +174,12 @@ class GpuIndexFlat : public Index {
 };
 
 // ------------------------------------------------------------------ GpuIndexIVF
+// search-time overrides, mirror of faiss::SearchParametersIVF (faiss/IndexIVF.h:70-80; honoured by the reference
+// GPU index through getCurrentNProbe_, faiss/gpu/GpuIndexIVF.cu:358-381).  nprobe <= 0: the index's own value.
+struct SearchParametersIVF {
+    int nprobe = 0;
+};
+
 class GpuIndexIVF : public Index {
    public:
     GpuIndexIVF(std::shared_ptr<GpuResources> res, int dims, int metric, int nlist);
@@ -187,6 +193,7 @@ class GpuIndexIVF : public Index {
     void add(idx_t n, const float* x) override;
     void add_with_ids(idx_t n, const float* x, const idx_t* xids) override;
     void search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels) const override;
+    void search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels, const SearchParametersIVF* params) const;
     // search with the coarse quantization supplied by the caller: assign / centroid_dis are [n][nprobe]
     // (host or device), -1 = no list (faiss/gpu/GpuIndexIVF.cu:408-488; IndexIVF::search_preassigned is what
     // IndexShardsIVF and the hybrid CPU-quantizer benchmarks call).  centroid_dis must be the quantizer's
@@ -199,10 +206,16 @@ class GpuIndexIVF : public Index {
     // mirrors GpuIndexIVF::getListLength / getListIndices (faiss/gpu/GpuIndexIVF.h:97-110)
     size_t getListLength(idx_t list) const { return list_len_[list]; }
     std::vector<idx_t> getListIndices(idx_t list) const;
+    // list payload in the reference's CPU layout (d floats or M bytes per entry)
     std::vector<uint8_t> getListVectorData(idx_t list) const;
     // copyFrom-style bulk load (train state + inverted lists), see include/faiss_amd_c.h
-    void set_centroids(const float* centroids);
+    virtual void set_centroids(const float* centroids);
     void set_lists(const uint32_t* list_sizes, const uint8_t* codes, const idx_t* ids);
+    // vectors actually stored (ntotal counts the vectors add() was given, NaN rows included, like the reference:
+    // faiss/gpu/GpuIndexIVF.cu:293-298)
+    idx_t stored_vectors() const { return nstored_; }
+    // arena statistics (rows): used (lists + slack + holes), holes left behind by relocated lists, allocated
+    void arena_stats(int64_t* used, int64_t* holes, int64_t* allocated) const;
     // Clustering parameters used by train() (reference default niter=10 for the GPU IVF
     // quantizer, faiss/gpu/GpuIndexIVF.cu:80)
     int cp_niter = 10;
@@ -211,16 +224,27 @@ class GpuIndexIVF : public Index {
    protected:
     std::shared_ptr<GpuResources> res_;
     int dpad_;
-    size_t code_bytes_ = 0; // bytes per arena entry (ldv*4 for IVFFlat, M for IVFPQ)
-    std::vector<uint32_t> list_len_;
+    size_t code_bytes_ = 0; // bytes per arena row (dpad*4 for IVFFlat, M for IVFPQ)
+    int granule_ = 8;       // list capacities and starts are multiples of this many rows
+    bool use_t2_ = false;   // IVFPQ L2: per-row term in arena_t2_
+    std::vector<uint32_t> list_len_, list_cap_;
     std::vector<int64_t> list_start_;
-    DevBuf d_list_len_, d_list_start_, arena_, arena_ids_;
+    int64_t arena_rows_ = 0;     // rows handed out so far (next free row)
+    int64_t arena_cap_rows_ = 0; // rows allocated
+    int64_t hole_rows_ = 0;      // rows of abandoned ranges (relocated lists)
+    idx_t nstored_ = 0;
+    DevBuf d_list_len_, d_list_start_, arena_, arena_ids_, arena_t2_;
     mutable std::mutex mu_;
     mutable DevBuf q_raw_, q_pad_, c_dis_, c_ids_, prefix_, totals_, q_off_, keys_, out_d_, out_i_, one_cnt_;
     mutable int nprobe_eff_ = 1; // min(nprobe, nlist) of the search in flight
+    // add-path scratch
+    DevBuf a_xpad_, a_lab_, a_dis_, a_dest_, a_ids_, a_hist_, a_newlen_, a_jobs_;
 
     virtual void train_residual_(idx_t n, const float* x_dev_pad) {}
-    // called (under mu_) whenever the arena layout or contents changed: derived per-vector data
+    // everything add()/search() needs besides the coarse centroids is in place (IVFPQ: the codebook)
+    virtual bool extra_trained_() const { return true; }
+    void update_is_trained_();
+    // called (under mu_) when rows [lists] were bulk-loaded or the quantizers changed: derived per-row data
     virtual void lists_changed_() {}
     // encode/scatter n staged vectors (device, padded) with given labels into arena rows dest
     virtual void append_(int n, const float* x_pad, const int64_t* d_labels, const int64_t* d_dest) = 0;
@@ -231,20 +255,28 @@ class GpuIndexIVF : public Index {
     virtual int fused_M_() const { return 0; }
     mutable DevBuf part_keys_, part_cnt_;
     void upload_list_tables_();
+    void ensure_arena_(int64_t rows);
+    // make room for new_len[l] entries in every list (relocating the lists that outgrow their slack); est[l]
+    // (nullable) = expected final length, used as the new capacity of a list that has to move
+    void grow_lists_(const std::vector<uint32_t>& new_len, const std::vector<double>* est);
+    void compact_();
+    void add_core_(idx_t n, const float* x, const idx_t* xids);
     void search_core_(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels, const idx_t* assign,
-                      const float* centroid_dis) const;
+                      const float* centroid_dis, int nprobe_now) const;
 
    public:
     // when false, search() takes the unfused path (every distance as a key in HBM + select);
     // kept for cross-checking the fused kernel and for shapes that do not fit its LDS budget
     bool use_fused_scan = true;
-
-   protected:
 };
 
 class GpuIndexIVFFlat : public GpuIndexIVF {
    public:
     GpuIndexIVFFlat(std::shared_ptr<GpuResources> res, int dims, int nlist, int metric);
+    // stored vector of id `key` (ids as given to add_with_ids / generated by add); faiss/gpu/GpuIndexIVFFlat.cu:370-390
+    // offers reconstruct_n for contiguous ids, this is the same by-id lookup
+    void reconstruct_n(idx_t i0, idx_t ni, float* recons) const override;
+    void reconstruct(idx_t key, float* recons) const override { reconstruct_n(key, 1, recons); }
 
    protected:
     void fill_fused_(struct IvfFusedParams& p) const override;
@@ -265,8 +297,9 @@ class GpuIndexIVFPQ : public GpuIndexIVF {
     void fill_fused_(struct IvfFusedParams& p) const override;
     int fused_kind_() const override { return 1; }
     int fused_M_() const override { return M; }
-    DevBuf pq_; // [M][256][dsub]
-    DevBuf arena_t2_; // [ntotal] L2: |r^|^2 + 2 <centroid, r^> per stored vector (see ivf_fused.hip)
+    DevBuf pq_;   // [M][256][dsub]
+    DevBuf pq_t_; // [256][M][dsub]: the order the scan kernels build their lookup table in
+    bool extra_trained_() const override { return pq_.p != nullptr; }
     void lists_changed_() override;
     void train_residual_(idx_t n, const float* x_dev_pad) override;
     void append_(int n, const float* x_pad, const int64_t* d_labels, const int64_t* d_dest) override;

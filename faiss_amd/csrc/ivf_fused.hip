@@ -13,9 +13,9 @@
 // IVFInterleaved.cu:18-177).
 //
 // Arithmetic contract: identical to ivf_kernels.hip (restated by oracle/faiss_oracle.c):
-//   IVFPQ L2: r = q - centroid; lut[m][c] = chain_j fmaf(r_mj - pq[m][c][j], same, acc);
-//             dis = ((0 + lut[0][c0]) + lut[1][c1]) + ...  (m ascending)
-//   IVFPQ IP: lut[m][c] = chain_j fmaf(q_mj, pq[m][c][j], acc); dis = coarse_ip + sum_m lut
+//   IVFPQ   : lut[m][c] = chain_j fmaf(q_mj, pq[m][c][j], acc), rounded to the query's power-of-two grid
+//             (kernels.h pq_lut_grid); S = sum_m lut[m][code_m] is then exact in fp32 in ANY order
+//             L2: dis = fmaf(-2, S, coarse_l2 + t2(row));  IP: dis = coarse_ip + S
 //   IVFFlat : dis = chain_k fmaf(q[k]-y[k], q[k]-y[k], acc) (L2) / fmaf(q[k], y[k], acc) (IP)
 //   selection: k smallest keys (ordkey(dis) << 32 | position in probe order) = "first scanned wins"
 //             among equal distances (faiss/IndexIVF.cpp:642-655 + strict heap admission); the k winners
@@ -32,29 +32,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // TWO workgroups per CU -- one query's table build / reservoir selects / final sort overlap the other's gathers
 constexpr int FB_MAX = 1024;
 
-// 4 * (byte B of w) in ONE VALU instruction (SDWA operand select; `two` is a register holding 2): the LDS byte offset
-// of a table entry.  hipcc emits v_bfe_u32 + v_lshl_add_u32 for the same thing, a third of the scan loop's VALU work.
 // fp32 at an absolute LDS byte address (the lookup table starts at LDS address 0: the kernels here have no static
 // LDS, checked once per workgroup) -- spares the "+ table base" VALU add per gather that pointer arithmetic costs
 __device__ __forceinline__ float lds_f32(unsigned byte_addr) {
     return *(const __attribute__((address_space(3))) float*)(size_t)byte_addr;
 }
-template <int B>
-__device__ __forceinline__ unsigned byte_x4(unsigned w, unsigned two) {
-    unsigned r;
-    if (B == 0)
-        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0"
-            : "=v"(r) : "v"(two), "v"(w));
-    else if (B == 1)
-        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1"
-            : "=v"(r) : "v"(two), "v"(w));
-    else if (B == 2)
-        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2"
-            : "=v"(r) : "v"(two), "v"(w));
-    else
-        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3"
-            : "=v"(r) : "v"(two), "v"(w));
-    return r;
+// LDS byte address of table entry lut[c][m] (M = 64: c * 256 + 4 m) in ONE VALU instruction: v_perm_b32 puts code
+// byte I of `w` (= c) into byte 1 and byte I of `rot` (= 4 m for this lane and step, precomputed once) into byte 0.
+template <int I>
+__device__ __forceinline__ unsigned lut_addr64(unsigned w, unsigned rot) {
+    return __builtin_amdgcn_perm(w, rot, 0x0c0c0000u | ((4u + I) << 8) | (unsigned)I);
 }
 constexpr int FMAXR = 8;  // reservoir capacity <= FMAXR * FB keys
 
@@ -62,7 +49,9 @@ struct FusedLds {
     char* lut;        // [M][256] fp32 | at the end: winners
     float* rs;        // [dpad] residual (L2) or query (IP)
     u64* res;         // [cap]
-    uint32_t* pre;    // [nprobe + 1]
+    uint32_t* pre;    // [nprobe + 1] exclusive prefix of the probed lists' lengths (scan positions)
+    uint32_t* bpre;   // [nprobe + 1] exclusive prefix of their 64-row block counts (IVFPQ)
+    unsigned* colmax; // [M] + 4: bits of max_c |lut[m][c]|, then the table grid {delta, 1/delta, on}
     int* lst;         // [nprobe]
     int64_t* lstart;  // [nprobe] first arena row of each probed list
     unsigned* hist;   // [256]
@@ -75,7 +64,8 @@ static size_t fused_region0_bytes(int kind, int M, int kp, int nlut) {
 }
 size_t ivf_fused_lds_bytes(int kind, int M, int dpad, int kp, int cap, int nprobe, int nlut) {
     return fused_region0_bytes(kind, M, kp, nlut) + 2 * round_up((size_t)dpad * 4, 16) + (size_t)cap * 8 +
-           round_up((size_t)(nprobe + 1) * 4, 16) + round_up((size_t)nprobe * 4, 16) + (size_t)nprobe * 8 + 1024 + 64;
+           2 * round_up((size_t)(nprobe + 1) * 4, 16) + round_up((size_t)(M + 4) * 4, 16) +
+           round_up((size_t)nprobe * 4, 16) + (size_t)nprobe * 8 + 1024 + 64;
 }
 
 __device__ __forceinline__ FusedLds fused_carve(char* smem, const IvfFusedParams& p) {
@@ -94,6 +84,10 @@ __device__ __forceinline__ FusedLds fused_carve(char* smem, const IvfFusedParams
     o += (size_t)p.cap * 8;
     L.pre = (uint32_t*)(smem + o);
     o += ((size_t)(p.nprobe + 1) * 4 + 15) & ~(size_t)15;
+    L.bpre = (uint32_t*)(smem + o);
+    o += ((size_t)(p.nprobe + 1) * 4 + 15) & ~(size_t)15;
+    L.colmax = (unsigned*)(smem + o);
+    o += ((size_t)(p.M + 4) * 4 + 15) & ~(size_t)15;
     L.lst = (int*)(smem + o);
     o += ((size_t)p.nprobe * 4 + 15) & ~(size_t)15;
     L.lstart = (int64_t*)(smem + o);
@@ -114,24 +108,36 @@ __device__ __forceinline__ void fused_load_probes(const IvfFusedParams& p, int q
         L.pre[t + 1] = l >= 0 ? p.list_len[l] : 0u;
         L.lstart[t] = l >= 0 ? p.list_start[l] : 0;
     }
+    for (int m = tid; m < p.M; m += FB) L.colmax[m] = 0u;
     if (tid == 0) {
         L.pre[0] = 0;
+        L.bpre[0] = 0;
         L.ctl->cnt = 0;
     }
     __syncthreads();
     if (tid < 64) {
-        unsigned carry = 0;
+        unsigned carry = 0, bcarry = 0;
         for (int base = 0; base < p.nprobe; base += 64) {
             const int t = base + tid;
             unsigned v = t < p.nprobe ? L.pre[t + 1] : 0u;
+            unsigned bv = (v + 63u) >> 6;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
                 const unsigned o = __shfl_up(v, off, 64);
-                if (tid >= off) v += o;
+                const unsigned bo = __shfl_up(bv, off, 64);
+                if (tid >= off) {
+                    v += o;
+                    bv += bo;
+                }
             }
             v += carry;
-            if (t < p.nprobe) L.pre[t + 1] = v;
+            bv += bcarry;
+            if (t < p.nprobe) {
+                L.pre[t + 1] = v;
+                L.bpre[t + 1] = bv;
+            }
             carry = __shfl(v, 63, 64);
+            bcarry = __shfl(bv, 63, 64);
         }
     }
     __syncthreads();
@@ -213,151 +219,187 @@ __device__ __forceinline__ void fused_finish(const IvfFusedParams& p, int q, int
 
 // ---------------------------------------------------------------------------------
 // IVFPQ.  One lookup table per QUERY, resident in LDS for all of its probes:
-//   lut[m][c] = <q_m, pq[m][c]>                      (both metrics)
-//   IP :  dis = coarse_ip(q, list) + S               S = sum_m lut[m][code_m]
+//   lut[c][m] = <q_m, pq[m][c]> rounded to the query's grid (pq_lut_grid)        (both metrics)
+//   IP :  dis = coarse_ip(q, list) + S               S = sum_m lut[code_m][m]  (exact, order-free)
 //   L2 :  |q - c - r^|^2 = |q - c|^2 + (|r^|^2 + 2 <c, r^>) - 2 <q, r^>
 //         dis = fmaf(-2, S, coarse_l2(q, list) + t2(y))
 // with r^ the decoded residual of the stored vector and t2(y) = |r^|^2 + 2 <c, r^> a per-vector
-// constant computed once at add time (ivfpq_t2_kernel).  This is the decomposition the reference
+// constant computed once at add time (ivfpq_t2 kernels).  This is the decomposition the reference
 // CPU index uses by default (faiss/impl/pq_code_distance/IVFPQ_QueryTables.cpp:126-192 term 1-3,
 // use_precomputed_table) and the reference GPU index offers as usePrecomputedTables
 // (faiss/gpu/impl/IVFPQ.cu:362-489); keeping the list-dependent term per VECTOR instead of per
 // (list, m, code) costs 4 bytes per vector and removes the 256 MB term-2 table and, above all, the
 // rebuild of a 64 KB table for each of the 32 probes of a query.
-// One code per lane (64 gathers); the probed lists are walked as one stream of scan positions so that every
-// lane carries a code whatever the list lengths (scanning the lists one or four at a time left half of the
-// lanes idle on lists of ~244 codes: measured 2.99 ms -> see DESIGN.md).
-// M64: the sub-quantizer count is the compile-time constant 64 (four 16-byte loads per code).
+//
+// Scan: the probed lists are a stream of 64-row code BLOCKS (kernels.h pq_code_offset); every wavefront takes one
+// block per iteration, lane l = row l of the block.  The block layout hands lane l its code rotated by l, and the
+// table is laid out [256][M]: at step j the 32 lanes of an LDS access group read 32 different sub-quantizers =
+// 32 different banks, so the 64 gathers per code are conflict-free (round 1: [M][256] table, every lane the same
+// sub-quantizer, random codes -> 3.5-way conflicts, 60 % of all LDS cycles, profiles/r02_a_*).  The table grid
+// makes the sum exact, so the rotated order changes nothing.
+// M64: the sub-quantizer count is the compile-time constant 64 (four coalesced 1 KB loads per block; table address
+// of a gather = ONE v_perm_b32).
 // ---------------------------------------------------------------------------------
 template <int METRIC, bool M64, int FB>
 __global__ void __launch_bounds__(FB) ivfpq_fused_kernel(IvfFusedParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const FusedLds L = fused_carve(smem, p);
     const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int NWV = FB / 64;
     const int q = blockIdx.x / p.G, g = blockIdx.x - q * p.G;
     const int p0 = g * p.npc, p1 = min(p.nprobe, p0 + p.npc);
     float* lut = (float*)L.lut;
     const int M = M64 ? 64 : p.M, d = p.d, dsub = p.dsub;
+    float* grid = (float*)(L.colmax + M);
 
     fused_load_probes<FB>(p, q, L);
     for (int cc = tid; cc < d; cc += FB) L.rs[cc] = p.xq[(int64_t)q * p.ldq + cc];
     __syncthreads();
-    // ---- the query's table (codebook read through L2 once per query)
-    if (dsub == 2) {
-        // eight independent 8-byte codebook loads in flight per lane (one dependent load per table entry made the
-        // build of a 16 K-entry table a chain of 32 L2 round trips per query)
+    // ---- the query's table (transposed codebook read through L2 once per query), its grid, the rounding
+    const int ne = M * 256;
+    auto publish_grid = [&]() {
+        // B = sum_m max_c |lut[m][c]| in sub-quantizer order (the oracle's order), by one lane
+        if (tid == 0) {
+            float B = 0.f;
+            for (int m = 0; m < M; ++m) B = B + __uint_as_float(L.colmax[m]);
+            float delta = 0.f, inv = 0.f;
+            const bool on = pq_lut_grid(B, &delta, &inv);
+            grid[0] = delta;
+            grid[1] = inv;
+            grid[2] = on ? 1.f : 0.f;
+        }
+    };
+    if (M64 && dsub == 2) {
+        // entries e = tid + u * FB of the [256][64] table: sub-quantizer e & 63 = tid & 63 for all of them (FB is a
+        // multiple of 64), so the query slice and the running maximum stay in registers; eight independent 8-byte
+        // codebook loads in flight per lane
         typedef float f32x2 __attribute__((ext_vector_type(2)));
-        const int ne = M * 256;
-        for (int e0 = tid; e0 < ne; e0 += 8 * FB) {
+        constexpr int NE = 16384 / FB;
+        const float r0 = L.rs[2 * (tid & 63)], r1 = L.rs[2 * (tid & 63) + 1];
+        float v[NE];
+        float mx = 0.f;
+#pragma unroll
+        for (int u0 = 0; u0 < NE; u0 += 8) {
             f32x2 c[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = e0 + u * FB;
-                c[u] = e < ne ? *(const f32x2*)(p.pq_centroids + (size_t)e * 2) : f32x2{0.f, 0.f};
-            }
+            for (int u = 0; u < 8; ++u) c[u] = *(const f32x2*)(p.pq_t + (size_t)(tid + (u0 + u) * FB) * 2);
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int e = e0 + u * FB;
-                if (e < ne) {
-                    const float* r = L.rs + (e >> 8) * 2;
-                    lut[e] = __fmaf_rn(r[1], c[u][1], __fmaf_rn(r[0], c[u][0], 0.f));
-                }
+                v[u0 + u] = __fmaf_rn(r1, c[u][1], __fmaf_rn(r0, c[u][0], 0.f));
+                const float a = fabsf(v[u0 + u]);
+                mx = (a > mx || a != a) ? a : mx; // NaN sticks
             }
         }
+        atomicMax(&L.colmax[tid & 63], __float_as_uint(mx));
+        __syncthreads();
+        publish_grid();
+        __syncthreads();
+        const float delta = grid[0], inv = grid[1];
+        const bool on = grid[2] != 0.f;
+#pragma unroll
+        for (int u = 0; u < NE; ++u) lut[tid + u * FB] = on ? __builtin_rintf(v[u] * inv) * delta : v[u];
     } else {
-        for (int e = tid; e < M * 256; e += FB) {
-            const int m = e >> 8;
-            const float* cen = p.pq_centroids + (size_t)e * dsub;
+        for (int e = tid; e < ne; e += FB) {
+            const int m = e % M;
+            const float* cen = p.pq_t + (size_t)e * dsub;
             const float* r = L.rs + m * dsub;
             float acc = 0.f;
             for (int jd = 0; jd < dsub; ++jd) acc = __fmaf_rn(r[jd], cen[jd], acc);
             lut[e] = acc;
+            atomicMax(&L.colmax[m], __float_as_uint(fabsf(acc)));
+        }
+        __syncthreads();
+        publish_grid();
+        __syncthreads();
+        if (grid[2] != 0.f) {
+            const float delta = grid[0], inv = grid[1];
+            for (int e = tid; e < ne; e += FB) lut[e] = __builtin_rintf(lut[e] * inv) * delta;
         }
     }
     __syncthreads();
 
-    const int mq = M >> 2; // sub-quantizers per partial sum
-    constexpr int NW = 4;  // 16-byte code words held in registers (wide path)
-    constexpr bool wide = M64; // code words prefetched into registers
-    // The probed lists of this workgroup are ONE stream of scan positions [pre[p0], pre[p1]) (the payload of
-    // the keys): every iteration takes the next 1024 positions whatever list they fall in, so all lanes
-    // carry a code until the very last iteration (lists are ~nb/nlist long, far from a multiple of anything).
-    // position -> (probe, offset) is a 5-step search of the prefix table in LDS.
-    const unsigned pos_begin = L.pre[p0], pos_end = L.pre[p1];
+    // ---- block stream of this workgroup's probes [p0, p1): blocks [bpre[p0], bpre[p1])
+    const unsigned blk_begin = L.bpre[p0], blk_end = L.bpre[p1];
+    constexpr int NW = 4; // 16-byte code words per row (M64)
     uint4 cw[NW], cwn[NW];
     float t2 = 0.f, t2n = 0.f, dis0 = 0.f, dis0n = 0.f;
-    int64_t row = -1, rown = -1;
-    // arena row, coarse term, t2 and (wide path) the code words of scan position `pos`; row = -1 past the end
-    auto fetch = [&](unsigned pos, int64_t& r, float& c0, uint4(&w)[NW], float& t) {
-        r = -1;
-        if (pos < pos_end) {
-            int lo = p0, hi = p1; // invariant pre[lo] <= pos < pre[hi]
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (L.pre[mid] <= pos) lo = mid;
-                else hi = mid;
-            }
-            r = L.lstart[lo] + (pos - L.pre[lo]);
-            c0 = p.coarse_dis[(int64_t)q * p.nprobe + lo];
-            if (wide) {
-                const uint8_t* code = p.arena_codes + r * M;
+    unsigned pos = 0, posn = 0;
+    bool valid = false, validn = false;
+    const uint8_t* blkp = nullptr;
+    const uint8_t* blkpn = nullptr;
+    int tcur = p0; // probe of the block fetched last (blocks are visited in increasing order)
+    // row `lane` of block `blk`: validity, scan position, coarse term, t2 and (M64) the code words
+    auto fetch = [&](unsigned blk, bool& ok, unsigned& ps, float& c0, uint4(&w)[NW], float& t, const uint8_t*& bp) {
+        ok = false;
+        if (blk < blk_end) { // wave-uniform
+            while (L.bpre[tcur + 1] <= blk) ++tcur;
+            const unsigned b = blk - L.bpre[tcur];
+            const unsigned r = b * 64u + (unsigned)lane;
+            const int64_t row0 = L.lstart[tcur] + (int64_t)b * 64;
+            bp = p.arena_codes + row0 * M;
+            if (M64) {
 #pragma unroll
-                for (int k = 0; k < NW; ++k) w[k] = *(const uint4*)(code + k * 16);
+                for (int k = 0; k < NW; ++k) w[k] = *(const uint4*)(bp + k * 1024 + lane * 16);
             }
-            if (METRIC == METRIC_L2) t = p.arena_t2[r];
+            if (METRIC == METRIC_L2) t = p.arena_t2[row0 + lane];
+            c0 = p.coarse_dis[(int64_t)q * p.nprobe + tcur];
+            ok = r < L.pre[tcur + 1] - L.pre[tcur];
+            ps = L.pre[tcur] + r;
         }
     };
+    // per-lane table columns: rot[k] byte i = 4 * ((4 k + i + lane) mod 64)
+    unsigned rot[16];
+    if (M64) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            unsigned r = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r |= ((4u * (unsigned)(4 * k + i + lane)) & 255u) << (8 * i);
+            rot[k] = r;
+        }
+        if ((unsigned)(size_t)(const __attribute__((address_space(3))) char*)lut != 0u) __builtin_trap(); // see lds_f32
+    }
 
     u64 tau = ~0ull;
     int bound = 0;
-    unsigned two = 2u;
-    asm volatile("" : "+v"(two)); // a register operand for the SDWA shifts (no literal allowed there)
-    if ((unsigned)(size_t)(const __attribute__((address_space(3))) char*)lut != 0u) __builtin_trap(); // see lds_f32
-    fetch(pos_begin + tid, row, dis0, cw, t2);
-    for (unsigned base = pos_begin; base < pos_end; base += FB) {
-        FUSED_MAKE_ROOM(min((unsigned)FB, pos_end - base));
-        // the next 1024 positions are in flight while these are scanned
-        fetch(base + FB + tid, rown, dis0n, cwn, t2n);
+    fetch(blk_begin + wave, valid, pos, dis0, cw, t2, blkp);
+    for (unsigned base = blk_begin; base < blk_end; base += NWV) {
+        FUSED_MAKE_ROOM(FB);
+        // the next block of this wavefront is in flight while this one is scanned
+        fetch(base + NWV + wave, validn, posn, dis0n, cwn, t2n, blkpn);
         bool pass = false;
         u64 key = 0;
-        if (row >= 0) {
-            float part[4];
+        if (valid) {
+            float sum;
             if (M64) {
-                // quarter jq = sub-quantizers [16 jq, 16 jq + 16) = the 16 bytes of code word jq; the four
-                // sequential chains advance two at a time on v_pk_add_f32 (same additions, same order)
-                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
-                for (int jp = 0; jp < 2; ++jp) {
-                    const unsigned w0[4] = {cw[2 * jp].x, cw[2 * jp].y, cw[2 * jp].z, cw[2 * jp].w};
-                    const unsigned w1[4] = {cw[2 * jp + 1].x, cw[2 * jp + 1].y, cw[2 * jp + 1].z, cw[2 * jp + 1].w};
-                    const unsigned t0 = (2 * jp) * 16 * 1024, t1 = t0 + 16 * 1024; // tables of the words' first sub-quantizers
-                    f32x2 a = {0.f, 0.f};
+                for (int k = 0; k < NW; ++k) {
+                    const unsigned w4[4] = {cw[k].x, cw[k].y, cw[k].z, cw[k].w};
 #pragma unroll
                     for (int wd = 0; wd < 4; ++wd) {
-                        a += f32x2{lds_f32(t0 + (4 * wd + 0) * 1024 + byte_x4<0>(w0[wd], two)),
-                                   lds_f32(t1 + (4 * wd + 0) * 1024 + byte_x4<0>(w1[wd], two))};
-                        a += f32x2{lds_f32(t0 + (4 * wd + 1) * 1024 + byte_x4<1>(w0[wd], two)),
-                                   lds_f32(t1 + (4 * wd + 1) * 1024 + byte_x4<1>(w1[wd], two))};
-                        a += f32x2{lds_f32(t0 + (4 * wd + 2) * 1024 + byte_x4<2>(w0[wd], two)),
-                                   lds_f32(t1 + (4 * wd + 2) * 1024 + byte_x4<2>(w1[wd], two))};
-                        a += f32x2{lds_f32(t0 + (4 * wd + 3) * 1024 + byte_x4<3>(w0[wd], two)),
-                                   lds_f32(t1 + (4 * wd + 3) * 1024 + byte_x4<3>(w1[wd], two))};
+                        const unsigned ro = rot[4 * k + wd];
+                        a0 += lds_f32(lut_addr64<0>(w4[wd], ro));
+                        a1 += lds_f32(lut_addr64<1>(w4[wd], ro));
+                        a2 += lds_f32(lut_addr64<2>(w4[wd], ro));
+                        a3 += lds_f32(lut_addr64<3>(w4[wd], ro));
                     }
-                    part[2 * jp] = a[0];
-                    part[2 * jp + 1] = a[1];
                 }
+                sum = (a0 + a1) + (a2 + a3);
             } else {
-                const uint8_t* code = p.arena_codes + row * M;
-#pragma unroll
-                for (int jq = 0; jq < 4; ++jq) {
-                    float a = 0.f;
-                    for (int m = jq * mq; m < (jq + 1) * mq; ++m) a = a + lut[m * 256 + code[m]];
-                    part[jq] = a;
+                const int ch = pq_chunk_bytes(M);
+                sum = 0.f;
+                for (int j = 0; j < M; ++j) {
+                    const unsigned c = blkp[(j / ch) * 64 * ch + lane * ch + (j % ch)];
+                    int m = j + lane;
+                    m -= (m / M) * M;
+                    sum += lut[c * M + m];
                 }
             }
-            const float sum = (part[0] + part[1]) + (part[2] + part[3]);
             const float dis = METRIC == METRIC_L2 ? __fmaf_rn(-2.f, sum, dis0 + t2) : dis0 + sum;
-            key = ((u64)ordkey<METRIC>(dis) << 32) | (u64)(base + tid);
+            key = ((u64)ordkey<METRIC>(dis) << 32) | (u64)pos;
             pass = key < tau;
         }
         wg_append(L.res, L.ctl, pass, key);
@@ -365,7 +407,9 @@ __global__ void __launch_bounds__(FB) ivfpq_fused_kernel(IvfFusedParams p) {
         for (int k = 0; k < NW; ++k) cw[k] = cwn[k];
         t2 = t2n;
         dis0 = dis0n;
-        row = rown;
+        pos = posn;
+        valid = validn;
+        blkp = blkpn;
         __syncthreads();
     }
     fused_finish<FB>(p, q, g, L);

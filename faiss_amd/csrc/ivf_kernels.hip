@@ -1,19 +1,19 @@
 // faiss_amd/csrc/ivf_kernels.hip -- inverted-file scans (IVFFlat, IVFPQ) and the add path, gfx950.
 //
-// Round-1 layout: every inverted list is a contiguous row range of one device arena
-// (list_start[l], list_len[l]); vectors row-major fp32 (IVFFlat) or M-byte PQ codes (IVFPQ),
-// user ids in a parallel int64 arena.  (The reference keeps one growable DeviceVector per
-// list, faiss/gpu/impl/IVFBase.cuh:220-299; a single arena costs one allocation and lets
-// 288 GB of HBM be sized once.)
+// Layout (kernels.h, "IVF storage"): every inverted list owns a row range with slack of one device arena
+// (list_start[l], list_len[l], capacity a multiple of the granule); vectors row-major fp32 (IVFFlat) or PQ codes in
+// rotated 64-row blocks (IVFPQ, pq_code_offset), user ids (and the IVFPQ L2 term t2) in parallel per-row arenas.
+// (The reference keeps one growable DeviceVector per list, faiss/gpu/impl/IVFBase.cuh:220-299; a single arena
+// costs one allocation and lets 288 GB of HBM be sized once.)
 //
 // Arithmetic contract (restated by oracle/faiss_oracle.c):
 //   IVFFlat L2 : eight partial fmaf chains of (q[k]-y[k])^2: chain ln runs over the 4-float chunks ln, ln+8, ...
 //                (direct form as the CPU scanner, faiss/utils/simd_impl/IVFFlatScanner-inl.h:20-27, which also
 //                keeps 8 partial sums); dis = ((p0+p1)+(p2+p3)) + ((p4+p5)+(p6+p7))
 //   IVFFlat IP : the same with chains of fmaf(q[k], y[k], acc)
-//   IVFPQ      : lut[m][c] = chain_j fmaf(q_mj, pq[m][c][j], acc)   (one table per query, both metrics)
-//                S = (p0 + p1) + (p2 + p3),  p_j = sequential sum of lut[m][c_m] over the j-th quarter of
-//                the sub-quantizers
+//   IVFPQ      : lut[m][c] = chain_j fmaf(q_mj, pq[m][c][j], acc)   (one table per query, both metrics), rounded
+//                to the query's power-of-two grid (kernels.h pq_lut_grid); S = sum_m lut[m][c_m], exact in fp32
+//                in any order
 //   IVFPQ  L2  : dis = fmaf(-2, S, coarse_l2 + t2),  t2 = chain_k fmaf(r^_k, fmaf(2, c_k, r^_k), acc)
 //                (r^ = decoded residual, c = list centroid; term decomposition of
 //                 faiss/impl/pq_code_distance/IVFPQ_QueryTables.cpp:126-192)
@@ -127,17 +127,19 @@ void launch_ivfflat_scan(const IvfScanParams& p, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------
-// IVFPQ scan: one workgroup per (probe, query); LUT [M][256] fp32 resident in LDS
+// IVFPQ scan (unfused cross-check path): one workgroup per (probe, query); LUT [M][256] fp32 resident in LDS
 // ---------------------------------------------------------------------------------
 size_t ivfpq_scan_lds_bytes(int M, int dpad) {
-    return (size_t)M * 256 * 4 + (size_t)dpad * 4;
+    return (size_t)M * 256 * 4 + (size_t)dpad * 4 + (size_t)M * 4 + 16;
 }
 
 template <int METRIC>
 __global__ void __launch_bounds__(256) ivfpq_scan_kernel(IvfScanParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* lut = (float*)smem;          // [M][256]
-    float* rs = lut + (size_t)p.M * 256; // [dpad] residual (L2) or query (IP)
+    float* lut = (float*)smem;           // [M][256]
+    float* rs = lut + (size_t)p.M * 256; // [dpad] query
+    unsigned* colmax = (unsigned*)(rs + p.dpad); // [M] bits of max_c |lut[m][c]|
+    float* grid = (float*)(colmax + p.M);        // delta, 1/delta, flag
     const int pr = blockIdx.x, q = blockIdx.y;
     const int64_t list = p.coarse_ids[(int64_t)q * p.nprobe + pr];
     if (list < 0) return;
@@ -146,37 +148,44 @@ __global__ void __launch_bounds__(256) ivfpq_scan_kernel(IvfScanParams p) {
     const int64_t start = p.list_start[list];
     const uint32_t pos0 = p.prefix[(int64_t)q * (p.nprobe + 1) + pr];
     u64* out = p.keys + p.q_off[q] + pos0;
-    const int d = p.d;
+    const int d = p.d, M = p.M;
     for (int c = threadIdx.x; c < d; c += blockDim.x) rs[c] = p.xq[(int64_t)q * p.ldq + c];
+    for (int m = threadIdx.x; m < M; m += blockDim.x) colmax[m] = 0u;
     __syncthreads();
-    // ---- lookup table
+    // ---- lookup table of the query, then its grid (pq_lut_grid)
     const int dsub = p.dsub;
-    for (int e = threadIdx.x; e < p.M * 256; e += blockDim.x) {
+    for (int e = threadIdx.x; e < M * 256; e += blockDim.x) {
         const int m = e >> 8;
         const float* cen = p.pq_centroids + (size_t)e * dsub; // [m][c][dsub]
         const float* r = rs + m * dsub;
         float acc = 0.f;
         for (int jd = 0; jd < dsub; ++jd) acc = __fmaf_rn(r[jd], cen[jd], acc);
         lut[e] = acc;
+        atomicMax(&colmax[m], __float_as_uint(fabsf(acc)));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float B = 0.f;
+        for (int m = 0; m < M; ++m) B = B + __uint_as_float(colmax[m]);
+        float delta = 0.f, inv = 0.f;
+        const bool ok = pq_lut_grid(B, &delta, &inv);
+        grid[0] = delta;
+        grid[1] = inv;
+        grid[2] = ok ? 1.f : 0.f;
+    }
+    __syncthreads();
+    if (grid[2] != 0.f) {
+        const float delta = grid[0], inv = grid[1];
+        for (int e = threadIdx.x; e < M * 256; e += blockDim.x) lut[e] = __builtin_rintf(lut[e] * inv) * delta;
     }
     __syncthreads();
     // ---- scan: one code per thread
     const float dis0 = p.coarse_dis[(int64_t)q * p.nprobe + pr];
-    const int M = p.M;
     for (unsigned i = threadIdx.x; i < len; i += blockDim.x) {
-        const uint8_t* code = p.arena_codes + (start + i) * M;
-        // same order as the fused scan (ivf_fused.hip): four partial sums over M/4 consecutive
-        // sub-quantizers, combined pairwise, then added to dis0
-        const int mq = M >> 2;
-        float part[4];
-#pragma unroll
-        for (int jq = 0; jq < 4; ++jq) {
-            float a = 0.f;
-            for (int m = jq * mq; m < (jq + 1) * mq; ++m) a = a + lut[m * 256 + code[m]];
-            part[jq] = a;
-        }
-        const float sum = (part[0] + part[1]) + (part[2] + part[3]);
-        const float acc = METRIC == METRIC_L2 ? __fmaf_rn(-2.f, sum, dis0 + p.arena_t2[start + i]) : dis0 + sum;
+        const int64_t row = start + i;
+        float sum = 0.f;
+        for (int m = 0; m < M; ++m) sum = sum + lut[m * 256 + p.arena_codes[pq_code_offset(M, row, m)]];
+        const float acc = METRIC == METRIC_L2 ? __fmaf_rn(-2.f, sum, dis0 + p.arena_t2[row]) : dis0 + sum;
         out[i] = ((u64)ordkey<METRIC>(acc) << 32) | (u64)(pos0 + i);
     }
 }
@@ -198,8 +207,133 @@ void launch_ivfpq_scan(const IvfScanParams& p, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------
-// add path
+// add path: stable counting sort of the new vectors by coarse label, entirely on the device
 // ---------------------------------------------------------------------------------
+__global__ void ivf_histogram_kernel(const int64_t* __restrict__ labels, int64_t n, int nlist, int chunk,
+                                     uint32_t* __restrict__ hist) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t l = labels[i];
+    if (l >= 0 && l < nlist) atomicAdd(&hist[(i / chunk) * nlist + l], 1u);
+}
+void launch_ivf_histogram(const int64_t* labels, int64_t n, int nlist, int chunk, uint32_t* hist, hipStream_t stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(ivf_histogram_kernel, dim3((unsigned)div_up(n, 256)), dim3(256), 0, stream, labels, n, nlist,
+                       chunk, hist);
+    HIP_CHECK(hipGetLastError());
+}
+
+__global__ void ivf_chunk_scan_kernel(uint32_t* __restrict__ hist, int nchunks, int nlist,
+                                      const uint32_t* __restrict__ list_len, uint32_t* __restrict__ new_len) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= nlist) return;
+    uint32_t run = list_len[l];
+    for (int c = 0; c < nchunks; ++c) {
+        const uint32_t t = hist[(int64_t)c * nlist + l];
+        hist[(int64_t)c * nlist + l] = run;
+        run += t;
+    }
+    new_len[l] = run;
+}
+void launch_ivf_chunk_scan(uint32_t* hist, int nchunks, int nlist, const uint32_t* list_len, uint32_t* new_len,
+                           hipStream_t stream) {
+    hipLaunchKernelGGL(ivf_chunk_scan_kernel, dim3((unsigned)div_up(nlist, 256)), dim3(256), 0, stream, hist, nchunks,
+                       nlist, list_len, new_len);
+    HIP_CHECK(hipGetLastError());
+}
+
+// One wavefront per chunk walks its vectors 64 at a time, in order: the lanes that share a label take consecutive
+// slots behind the chunk's running offset for that list (ballot prefix), so entries keep their insertion order
+// (what testIVFEquality compares, faiss/gpu/test/TestUtils.h:111-142).  IN_LDS: the chunk's offset row lives in LDS.
+template <bool IN_LDS>
+__global__ void __launch_bounds__(64) ivf_rank_kernel(const int64_t* __restrict__ labels, int64_t n, int nlist,
+                                                      int chunk, uint32_t* __restrict__ hist,
+                                                      const int64_t* __restrict__ list_start,
+                                                      int64_t* __restrict__ dest) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int c = blockIdx.x, lane = threadIdx.x;
+    uint32_t* grow = hist + (int64_t)c * nlist;
+    uint32_t* row = IN_LDS ? (uint32_t*)smem : grow;
+    if (IN_LDS) {
+        for (int l = lane; l < nlist; l += 64) row[l] = grow[l];
+        __syncthreads();
+    }
+    const int64_t i0 = (int64_t)c * chunk, i1 = min(n, i0 + chunk);
+    for (int64_t g0 = i0; g0 < i1; g0 += 64) {
+        const int64_t i = g0 + lane;
+        int64_t lab = i < i1 ? labels[i] : -1;
+        if (lab >= nlist) lab = -1;
+        int64_t dst = -1;
+        u64 todo = __ballot(lab >= 0);
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            const int l0 = __shfl((int)lab, src, 64);
+            const u64 m = __ballot((int)lab == l0 && lab >= 0);
+            const uint32_t base = row[l0];
+            if (lab >= 0 && (int)lab == l0) dst = list_start[l0] + base + __popcll(m & ((1ull << lane) - 1ull));
+            if (lane == src) row[l0] = base + (uint32_t)__popcll(m);
+            todo &= ~m;
+        }
+        if (i < i1) dest[i] = dst;
+    }
+}
+void launch_ivf_rank(const int64_t* labels, int64_t n, int nlist, int chunk, uint32_t* hist,
+                     const int64_t* list_start, int64_t* dest, hipStream_t stream) {
+    if (n == 0) return;
+    const unsigned nchunks = (unsigned)div_up(n, chunk);
+    if ((size_t)nlist * 4 <= 64 * 1024) {
+        hipLaunchKernelGGL((ivf_rank_kernel<true>), dim3(nchunks), dim3(64), (size_t)nlist * 4, stream, labels, n, nlist,
+                           chunk, hist, list_start, dest);
+    } else {
+        hipLaunchKernelGGL((ivf_rank_kernel<false>), dim3(nchunks), dim3(64), 0, stream, labels, n, nlist, chunk, hist,
+                           list_start, dest);
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+__global__ void ivf_move_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                const IvfMoveJob* __restrict__ jobs, int bytes_per_row) {
+    const IvfMoveJob jb = jobs[blockIdx.x];
+    const int64_t words = jb.rows * (bytes_per_row >> 2);
+    const uint32_t* s = (const uint32_t*)(src + jb.src * bytes_per_row);
+    uint32_t* t = (uint32_t*)(dst + jb.dst * bytes_per_row);
+    for (int64_t w = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; w < words; w += (int64_t)gridDim.y * blockDim.x)
+        t[w] = s[w];
+}
+void launch_ivf_move(const uint8_t* arena_src, uint8_t* arena_dst, const IvfMoveJob* jobs, int njobs,
+                     int bytes_per_row, hipStream_t stream) {
+    if (njobs == 0) return;
+    FA_THROW_IF_NOT(bytes_per_row % 4 == 0);
+    // few long lists (IVF16 at 100M rows) as well as many short ones: spread each job over several workgroups
+    const unsigned gy = njobs >= 1024 ? 1u : njobs >= 64 ? 8u : 64u;
+    hipLaunchKernelGGL(ivf_move_kernel, dim3((unsigned)njobs, gy), dim3(256), 0, stream, arena_src, arena_dst, jobs,
+                       bytes_per_row);
+    HIP_CHECK(hipGetLastError());
+}
+
+__global__ void iota_i64_kernel(int64_t* __restrict__ out, int64_t n, int64_t base) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = base + i;
+}
+void launch_iota_i64(int64_t* out, int64_t n, int64_t base, hipStream_t stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(iota_i64_kernel, dim3((unsigned)div_up(n, 256)), dim3(256), 0, stream, out, n, base);
+    HIP_CHECK(hipGetLastError());
+}
+__global__ void fill_knn_kernel(float* __restrict__ D, int64_t* __restrict__ I, int64_t n, float pad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        D[i] = pad;
+        I[i] = -1;
+    }
+}
+void launch_fill_knn(float* D, int64_t* I, int64_t n, int metric, hipStream_t stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(fill_knn_kernel, dim3((unsigned)div_up(n, 256)), dim3(256), 0, stream, D, I, n,
+                       neutral_distance(metric));
+    HIP_CHECK(hipGetLastError());
+}
+
 __global__ void ivfflat_append_kernel(const float* __restrict__ x, int64_t ldx, int n, int d,
                                       const int64_t* __restrict__ dest, float* __restrict__ arena,
                                       int64_t ldv, int dpad) {
@@ -215,6 +349,30 @@ void launch_ivfflat_append(const float* x, int64_t ldx, int n, int d, const int6
     if (n == 0) return;
     hipLaunchKernelGGL(ivfflat_append_kernel, dim3((unsigned)n), dim3(64), 0, stream, x, ldx, n, d, dest,
                        arena_vecs, ldv, dpad);
+    HIP_CHECK(hipGetLastError());
+}
+
+__global__ void ivfflat_rows_by_id_kernel(const float* __restrict__ arena, int64_t ldv, const int64_t* __restrict__ ids,
+                                          const int64_t* __restrict__ list_start, const uint32_t* __restrict__ list_len,
+                                          int d, int64_t i0, int64_t ni, float* __restrict__ out) {
+    const int l = blockIdx.x;
+    const int64_t start = list_start[l];
+    const unsigned len = list_len[l];
+    // one wavefront per candidate row: the 64 lanes copy the row once its id is known to be wanted
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    for (unsigned i = blockIdx.y * nw + wave; i < len; i += gridDim.y * nw) {
+        const int64_t id = ids[start + i];
+        if (id < i0 || id >= i0 + ni) continue;
+        for (int c = lane; c < d; c += 64) out[(id - i0) * d + c] = arena[(start + i) * ldv + c];
+    }
+}
+void launch_ivfflat_rows_by_id(const float* arena_vecs, int64_t ldv, const int64_t* arena_ids, const int64_t* list_start,
+                               const uint32_t* list_len, int nlist, int d, int64_t i0, int64_t ni, float* out,
+                               hipStream_t stream) {
+    if (nlist == 0 || ni == 0) return;
+    const unsigned gy = nlist >= 1024 ? 1u : nlist >= 64 ? 8u : 64u;
+    hipLaunchKernelGGL(ivfflat_rows_by_id_kernel, dim3((unsigned)nlist, gy), dim3(256), 0, stream, arena_vecs, ldv,
+                       arena_ids, list_start, list_len, d, i0, ni, out);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -249,7 +407,7 @@ __global__ void ivfpq_encode_append_kernel(const float* __restrict__ x, int64_t 
             bestc = c;
         }
     }
-    codes[dst * M + m] = (uint8_t)bestc;
+    codes[pq_code_offset(M, dst, m)] = (uint8_t)bestc;
 }
 
 // Same arithmetic, one workgroup per (256 vectors, sub-quantizer): the 256 x dsub codebook of the sub-quantizer
@@ -295,7 +453,7 @@ __global__ void __launch_bounds__(256) ivfpq_encode_append_lds_kernel(const floa
             bestc = c;
         }
     }
-    codes[dst * M + m] = (uint8_t)bestc;
+    codes[pq_code_offset(M, dst, m)] = (uint8_t)bestc;
 }
 
 void launch_ivfpq_encode_append(const float* x, int64_t ldx, int n, int d, const int64_t* labels,
@@ -321,53 +479,102 @@ void launch_ivfpq_encode_append(const float* x, int64_t ldx, int n, int d, const
     HIP_CHECK(hipGetLastError());
 }
 
-__global__ void ivfpq_t2_kernel(const uint8_t* __restrict__ codes, const int64_t* __restrict__ list_start,
-                                const uint32_t* __restrict__ list_len, const float* __restrict__ centroids,
-                                int64_t ldc, int M, int dsub, const float* __restrict__ pq, float* __restrict__ t2) {
+__device__ __forceinline__ float ivfpq_t2_of_row(const uint8_t* __restrict__ codes, int64_t row, const float* cen, int M,
+                                                 int dsub, const float* __restrict__ pq) {
+    float acc = 0.f;
+    for (int m = 0; m < M; ++m) {
+        const float* pc = pq + ((size_t)m * 256 + codes[pq_code_offset(M, row, m)]) * dsub;
+        for (int jd = 0; jd < dsub; ++jd) {
+            const float rv = pc[jd];
+            acc = __fmaf_rn(rv, __fmaf_rn(2.f, cen[m * dsub + jd], rv), acc);
+        }
+    }
+    return acc;
+}
+__global__ void ivfpq_t2_lists_kernel(const uint8_t* __restrict__ codes, const int64_t* __restrict__ list_start,
+                                      const uint32_t* __restrict__ list_len, const float* __restrict__ centroids,
+                                      int64_t ldc, int M, int dsub, const float* __restrict__ pq,
+                                      float* __restrict__ t2) {
     const int l = blockIdx.x;
     const int64_t start = list_start[l];
     const unsigned len = list_len[l];
     const float* cen = centroids + (int64_t)l * ldc;
-    for (unsigned i = threadIdx.x; i < len; i += blockDim.x) {
-        const uint8_t* code = codes + (start + i) * M;
-        float acc = 0.f;
-        for (int m = 0; m < M; ++m) {
-            const float* pc = pq + ((size_t)m * 256 + code[m]) * dsub;
-            for (int jd = 0; jd < dsub; ++jd) {
-                const float rv = pc[jd];
-                acc = __fmaf_rn(rv, __fmaf_rn(2.f, cen[m * dsub + jd], rv), acc);
-            }
-        }
-        t2[start + i] = acc;
-    }
+    for (unsigned i = blockIdx.y * blockDim.x + threadIdx.x; i < len; i += gridDim.y * blockDim.x)
+        t2[start + i] = ivfpq_t2_of_row(codes, start + i, cen, M, dsub, pq);
 }
-void launch_ivfpq_t2(const uint8_t* arena_codes, const int64_t* list_start, const uint32_t* list_len, int nlist,
-                     const float* centroids, int64_t ldc, int M, int dsub, const float* pq_centroids, float* t2,
-                     hipStream_t stream) {
+void launch_ivfpq_t2_lists(const uint8_t* arena_codes, const int64_t* list_start, const uint32_t* list_len, int nlist,
+                           const float* centroids, int64_t ldc, int M, int dsub, const float* pq_centroids, float* t2,
+                           hipStream_t stream) {
     if (nlist == 0) return;
-    hipLaunchKernelGGL(ivfpq_t2_kernel, dim3((unsigned)nlist), dim3(256), 0, stream, arena_codes, list_start,
+    const unsigned gy = nlist >= 1024 ? 1u : nlist >= 64 ? 8u : 64u;
+    hipLaunchKernelGGL(ivfpq_t2_lists_kernel, dim3((unsigned)nlist, gy), dim3(256), 0, stream, arena_codes, list_start,
                        list_len, centroids, ldc, M, dsub, pq_centroids, t2);
     HIP_CHECK(hipGetLastError());
 }
-
-__global__ void move_lists_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
-                                  const int64_t* __restrict__ old_start,
-                                  const int64_t* __restrict__ new_start,
-                                  const uint32_t* __restrict__ len, int bytes_per_row) {
-    const int l = blockIdx.x;
-    const int64_t words = (int64_t)len[l] * (bytes_per_row >> 2);
-    const uint32_t* s = (const uint32_t*)(src + old_start[l] * bytes_per_row);
-    uint32_t* t = (uint32_t*)(dst + new_start[l] * bytes_per_row);
-    for (int64_t w = threadIdx.x; w < words; w += blockDim.x) t[w] = s[w];
+__global__ void ivfpq_t2_rows_kernel(const uint8_t* __restrict__ codes, const int64_t* __restrict__ labels,
+                                     const int64_t* __restrict__ dest, int n, const float* __restrict__ centroids,
+                                     int64_t ldc, int M, int dsub, const float* __restrict__ pq, float* __restrict__ t2) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t row = dest[i];
+    if (row < 0) return;
+    t2[row] = ivfpq_t2_of_row(codes, row, centroids + labels[i] * ldc, M, dsub, pq);
+}
+void launch_ivfpq_t2_rows(const uint8_t* arena_codes, const int64_t* labels, const int64_t* dest, int n,
+                          const float* centroids, int64_t ldc, int M, int dsub, const float* pq_centroids, float* t2,
+                          hipStream_t stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(ivfpq_t2_rows_kernel, dim3((unsigned)div_up(n, 256)), dim3(256), 0, stream, arena_codes, labels,
+                       dest, n, centroids, ldc, M, dsub, pq_centroids, t2);
+    HIP_CHECK(hipGetLastError());
 }
 
-void launch_move_lists(const uint8_t* src, uint8_t* dst, const int64_t* old_start,
-                       const int64_t* new_start, const uint32_t* len, int nlist, int bytes_per_row,
-                       hipStream_t stream) {
+// plain [row][M] <-> rotated block layout
+__global__ void ivfpq_pack_lists_kernel(const uint8_t* __restrict__ plain, const int64_t* __restrict__ src_start,
+                                        const int64_t* __restrict__ list_start, const uint32_t* __restrict__ list_len,
+                                        int M, uint8_t* __restrict__ codes) {
+    const int l = blockIdx.x;
+    const int64_t s0 = src_start[l], d0 = list_start[l];
+    const int64_t total = (int64_t)list_len[l] * M;
+    for (int64_t t = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.y * blockDim.x) {
+        const int64_t i = t / M;
+        const int m = (int)(t - i * M);
+        codes[pq_code_offset(M, d0 + i, m)] = plain[(s0 + i) * M + m];
+    }
+}
+void launch_ivfpq_pack_lists(const uint8_t* plain, const int64_t* src_start, const int64_t* list_start,
+                             const uint32_t* list_len, int nlist, int M, uint8_t* arena_codes, hipStream_t stream) {
     if (nlist == 0) return;
-    FA_THROW_IF_NOT(bytes_per_row % 4 == 0);
-    hipLaunchKernelGGL(move_lists_kernel, dim3((unsigned)nlist), dim3(256), 0, stream, src, dst, old_start,
-                       new_start, len, bytes_per_row);
+    const unsigned gy = nlist >= 1024 ? 1u : nlist >= 64 ? 8u : 64u;
+    hipLaunchKernelGGL(ivfpq_pack_lists_kernel, dim3((unsigned)nlist, gy), dim3(256), 0, stream, plain, src_start,
+                       list_start, list_len, M, arena_codes);
+    HIP_CHECK(hipGetLastError());
+}
+__global__ void ivfpq_unpack_list_kernel(const uint8_t* __restrict__ codes, int64_t first_row, uint32_t len, int M,
+                                         uint8_t* __restrict__ plain) {
+    const int64_t total = (int64_t)len * M;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = t / M;
+        const int m = (int)(t - i * M);
+        plain[t] = codes[pq_code_offset(M, first_row + i, m)];
+    }
+}
+void launch_ivfpq_unpack_list(const uint8_t* arena_codes, int64_t first_row, uint32_t len, int M, uint8_t* plain,
+                              hipStream_t stream) {
+    if (len == 0) return;
+    const unsigned grid = (unsigned)std::min<int64_t>(div_up((int64_t)len * M, 256), 4096);
+    hipLaunchKernelGGL(ivfpq_unpack_list_kernel, dim3(grid), dim3(256), 0, stream, arena_codes, first_row, len, M, plain);
+    HIP_CHECK(hipGetLastError());
+}
+__global__ void pq_transpose_kernel(const float* __restrict__ pq, int M, int dsub, float* __restrict__ pq_t) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x; // over [256][M][dsub]
+    if (t >= 256 * M * dsub) return;
+    const int jd = t % dsub, m = (t / dsub) % M, c = t / (dsub * M);
+    pq_t[t] = pq[((size_t)m * 256 + c) * dsub + jd];
+}
+void launch_pq_transpose(const float* pq, int M, int dsub, float* pq_t, hipStream_t stream) {
+    hipLaunchKernelGGL(pq_transpose_kernel, dim3((unsigned)div_up((size_t)256 * M * dsub, 256)), dim3(256), 0, stream, pq,
+                       M, dsub, pq_t);
     HIP_CHECK(hipGetLastError());
 }
 

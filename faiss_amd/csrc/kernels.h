@@ -213,8 +213,9 @@ struct IvfScanParams {
     int64_t ldc;
     int M, dsub;
     const float* pq_centroids; // [M][256][dsub]
-    const uint8_t* arena_codes; // [ntotal][M]
-    const float* arena_t2;      // [ntotal] L2: |r^|^2 + 2 <centroid, r^> of every stored vector
+    const float* pq_t;         // [256][M][dsub] transposed codebook
+    const uint8_t* arena_codes; // rotated 64-row block layout, see pq_code_offset
+    const float* arena_t2;      // [arena rows] L2: |r^|^2 + 2 <centroid, r^> of every stored vector
 };
 // One workgroup per (query, probe): direct sum((q-y)^2) over the list (L2) or dot (IP).
 // Replaces faiss/gpu/impl/IVFFlatScan.cu:135-183 / IVFInterleaved.cuh:33-224.
@@ -253,8 +254,9 @@ struct IvfFusedParams {
     int64_t ldc;
     int M, dsub;
     const float* pq_centroids;  // [M][256][dsub]
-    const uint8_t* arena_codes; // [ntotal][M]
-    const float* arena_t2;      // [ntotal] L2: |r^|^2 + 2 <centroid, r^> of every stored vector
+    const float* pq_t;          // [256][M][dsub] transposed codebook
+    const uint8_t* arena_codes; // rotated 64-row block layout, see pq_code_offset
+    const float* arena_t2;      // [arena rows] L2: |r^|^2 + 2 <centroid, r^> of every stored vector
 };
 // One workgroup per (query, probe group): table build + code scan + running top-k all in LDS.
 // Replaces PQCodeDistances + PQScanMultiPassNoPrecomputed + IVFUtilsSelect{1,2} (IVFPQ) and
@@ -264,24 +266,111 @@ void launch_ivf_fused(const IvfFusedParams& p, hipStream_t stream);
 bool ivf_fused_supported(int kind, int M, int dpad, int k, int nprobe, int* cap_out, int* kp_out, int* nlut_out);
 size_t ivf_fused_lds_bytes(int kind, int M, int dpad, int kp, int cap, int nprobe, int nlut);
 
-// add path (faiss/gpu/impl/IVFAppend.cu): scatter rows / encode PQ codes to arena slots
+// ------------------------------------------------------------------ IVF storage (round 2)
+// Every inverted list owns a row range [list_start, list_start + list_cap) of one arena, list_cap a multiple of
+// the granule (64 rows for IVFPQ, 8 for IVFFlat); lists grow in place inside their slack and move to the end of
+// the arena (geometric capacity) when it is used up -- the reference's one-growable-DeviceVector-per-list
+// (faiss/gpu/impl/IVFBase.cuh:220-299, DeviceVector.cuh) folded into one allocation.
+//
+// IVFPQ code layout: the arena is a sequence of 64-row BLOCKS (lists start on block boundaries).  A block holds
+// its rows' codes as [M / CH chunks][64 rows][CH bytes] (CH = 16 when M % 16 == 0, else 4, else 1: one coalesced
+// 1 KB load per chunk and wavefront), and row r stores its code ROTATED by r mod 64: stored byte j = code byte
+// (j + r) mod M.  Lane l of a wavefront scanning a block therefore looks up sub-quantizer (j + l) mod M at step j:
+// with the lookup table laid out [256][M] the 32 lanes of an LDS access group hit 32 different banks -- the scan's
+// 64 gathers per code run conflict-free instead of 3.5-way conflicted (profiles/r02_a_*: 60 % of the LDS cycles of
+// the round-1 kernel were bank conflicts).  (The reference has its own interleaved layouts for the same reason of
+// access shape, faiss/gpu/impl/InterleavedCodes.cpp; translation happens in copy_lists / get_list_codes.)
+constexpr int kPqBlockRows = 64;
+__host__ __device__ static inline int pq_chunk_bytes(int M) {
+    return (M & 15) == 0 ? 16 : (M & 3) == 0 ? 4 : 1;
+}
+// byte offset inside the code arena of code byte m of arena row `row`
+__host__ __device__ static inline size_t pq_code_offset(int M, int64_t row, int m) {
+    const int ch = pq_chunk_bytes(M);
+    const int l = (int)(row & 63);
+    int j = (m - l) % M;
+    if (j < 0) j += M;
+    return (size_t)(row >> 6) * 64 * M + (size_t)(j / ch) * 64 * ch + (size_t)l * ch + (size_t)(j % ch);
+}
+
+// ---- IVFPQ lookup tables on a power-of-two grid (round 2).
+// A query's table lut[m][c] = <q_m, pq[m][c]> (fmaf chain over the dsub coordinates) is rounded to multiples of
+// delta = 2^ed, ed chosen per query such that 2^24 * delta > 1.0001 * B with B = sum_m max_c |lut[m][c]| (sequential
+// fp32 sum over m).  Every partial sum of table entries is then a multiple of delta below 2^24 * delta, i.e. EXACT in
+// fp32: the ADC sum S = sum_m lut[m][code_m] no longer depends on the summation order, which is what lets each lane
+// walk the sub-quantizers in its own rotated order (pq_code_offset) and lets the result be independent of where a
+// vector is stored.  Rounding error per entry <= delta / 2 <= 2^-24 * 1.0001 * B: the same order as the rounding
+// of a plain fp32 sum of M terms of that magnitude (the reference GPU index offers an fp16 table,
+// GpuIndexIVFPQConfig::useFloat16LookupTables -- 2^-11 per entry).  oracle/faiss_oracle.c restates this bit for bit.
+// Returns false (no rounding: NaN / inf / all-zero tables) or true with delta and 1 / delta.
+__host__ __device__ static inline bool pq_lut_grid(float B, float* delta, float* inv) {
+    if (!(B > 0.f)) return false;
+    const float Bs = B * 1.0001f;
+    if (!(Bs <= FLT_MAX)) return false;
+    union {
+        float f;
+        uint32_t u;
+    } v;
+    v.f = Bs;
+    int ed = (int)((v.u >> 23) & 255u) - 126 - 24; // Bs < 2^(ed + 24)
+    if (ed < -126) ed = -126;
+    v.u = (uint32_t)(ed + 127) << 23;
+    *delta = v.f;
+    v.u = (uint32_t)(127 - ed) << 23;
+    *inv = v.f;
+    return true;
+}
+
+// ---- add path (faiss/gpu/impl/IVFBase.cu:595-905 addVectors / IVFAppend.cu), all on the device:
+// histogram of the coarse labels per chunk of `chunk` consecutive vectors: hist[c][l] (zeroed by the caller)
+void launch_ivf_histogram(const int64_t* labels, int64_t n, int nlist, int chunk, uint32_t* hist, hipStream_t stream);
+// per list: hist[c][l] <- list_len[l] + sum_{c' < c} hist[c'][l] (offset of the chunk's first entry inside the
+// list); new_len[l] = list_len[l] + total
+void launch_ivf_chunk_scan(uint32_t* hist, int nchunks, int nlist, const uint32_t* list_len, uint32_t* new_len,
+                           hipStream_t stream);
+// dest[i] = list_start[label] + (offset of vector i inside its list), insertion order kept (a stable counting
+// sort: one wavefront per chunk walks its vectors in order); label < 0 (NaN vectors) -> -1
+void launch_ivf_rank(const int64_t* labels, int64_t n, int nlist, int chunk, uint32_t* hist,
+                     const int64_t* list_start, int64_t* dest, hipStream_t stream);
+// list relocation: job j moves rows[j] rows of bytes_per_row bytes from row src[j] to row dst[j] (regions never
+// overlap: destinations are fresh space at the end of the arena)
+struct IvfMoveJob {
+    int64_t src, dst, rows;
+};
+void launch_ivf_move(const uint8_t* arena_src, uint8_t* arena_dst, const IvfMoveJob* jobs, int njobs,
+                     int bytes_per_row, hipStream_t stream);
+void launch_iota_i64(int64_t* out, int64_t n, int64_t base, hipStream_t stream);
+void launch_fill_knn(float* D, int64_t* I, int64_t n, int metric, hipStream_t stream);
 void launch_ivfflat_append(const float* x, int64_t ldx, int n, int d, const int64_t* dest,
                            float* arena_vecs, int64_t ldv, int dpad, hipStream_t stream);
+// out[id - i0][0..d) = the stored row whose user id is `id`, for every stored id in [i0, i0 + ni)
+// (GpuIndexIVFFlat::reconstruct_n, faiss/gpu/impl/IVFFlat.cu:289-335, as one pass over the id arena)
+void launch_ivfflat_rows_by_id(const float* arena_vecs, int64_t ldv, const int64_t* arena_ids, const int64_t* list_start,
+                               const uint32_t* list_len, int nlist, int d, int64_t i0, int64_t ni, float* out,
+                               hipStream_t stream);
+// PQ-encode the residuals and write the code bytes into the rotated block layout
 void launch_ivfpq_encode_append(const float* x, int64_t ldx, int n, int d, const int64_t* labels,
                                 const int64_t* dest, const float* centroids, int64_t ldc, int M,
                                 int dsub, const float* pq_centroids, uint8_t* arena_codes,
                                 hipStream_t stream);
-// t2[row] = chain_k fmaf(r^_k, fmaf(2, c_k, r^_k), acc) over k = 0..d-1 for every arena row: r^ = decoded PQ
-// residual, c = centroid of the row's list (one block per list).  The list-dependent term of the IVFPQ L2
-// distance (faiss/impl/pq_code_distance/IVFPQ_QueryTables.cpp:126-192, term 2), kept per vector.
-void launch_ivfpq_t2(const uint8_t* arena_codes, const int64_t* list_start, const uint32_t* list_len, int nlist,
-                     const float* centroids, int64_t ldc, int M, int dsub, const float* pq_centroids, float* t2,
-                     hipStream_t stream);
-// list relocation when the arena is rebuilt: list l's `len[l]` rows move from row old_start[l]
-// of src to row new_start[l] of dst (row = bytes_per_row bytes, multiple of 4)
-void launch_move_lists(const uint8_t* src, uint8_t* dst, const int64_t* old_start,
-                       const int64_t* new_start, const uint32_t* len, int nlist, int bytes_per_row,
-                       hipStream_t stream);
+// t2[row] = chain_k fmaf(r^_k, fmaf(2, c_k, r^_k), acc) over k = 0..d-1: r^ = decoded PQ residual of the row,
+// c = centroid of its list.  The list-dependent term of the IVFPQ L2 distance
+// (faiss/impl/pq_code_distance/IVFPQ_QueryTables.cpp:126-192, term 2), kept per vector.
+// rows variant: the n freshly appended rows dest[i] (list labels[i]); lists variant: every row of every list.
+void launch_ivfpq_t2_rows(const uint8_t* arena_codes, const int64_t* labels, const int64_t* dest, int n,
+                          const float* centroids, int64_t ldc, int M, int dsub, const float* pq_centroids, float* t2,
+                          hipStream_t stream);
+void launch_ivfpq_t2_lists(const uint8_t* arena_codes, const int64_t* list_start, const uint32_t* list_len, int nlist,
+                           const float* centroids, int64_t ldc, int M, int dsub, const float* pq_centroids, float* t2,
+                           hipStream_t stream);
+// layout translation (copy_lists / get_list_codes): plain [row][M] codes <-> rotated block layout.
+// pack: list l's len[l] codes start at plain row src_start[l]; unpack: one list
+void launch_ivfpq_pack_lists(const uint8_t* plain, const int64_t* src_start, const int64_t* list_start,
+                             const uint32_t* list_len, int nlist, int M, uint8_t* arena_codes, hipStream_t stream);
+void launch_ivfpq_unpack_list(const uint8_t* arena_codes, int64_t first_row, uint32_t len, int M, uint8_t* plain,
+                              hipStream_t stream);
+// pq [M][256][dsub] -> pq_t [256][M][dsub] (the order the scan kernels build their [256][M] lookup table in)
+void launch_pq_transpose(const float* pq, int M, int dsub, float* pq_t, hipStream_t stream);
 // dst[dest[i]] = src[i]  (dest < 0 skipped)
 void launch_scatter_i64(const int64_t* src, const int64_t* dest, int64_t n, int64_t* dst,
                         hipStream_t stream);

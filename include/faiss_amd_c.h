@@ -192,6 +192,21 @@ int faiss_amd_bfKnn(FaissAmdGpuResources* res, FaissAmdMetricType metric, const 
                     faiss_amd_idx_t num_vectors, const float* queries, faiss_amd_idx_t num_queries, int dims,
                     faiss_amd_idx_t k, float* out_distances, faiss_amd_idx_t* out_indices);
 
+/* ---- SearchParametersIVF (faiss/IndexIVF.h:70-80): per-call override of nprobe, as GpuIndexIVF::search honours it
+ *      through getCurrentNProbe_ (faiss/gpu/GpuIndexIVF.cu:358-381).  nprobe <= 0 keeps the index's own value. */
+typedef struct FaissAmdSearchParametersIVF {
+    int nprobe;
+} FaissAmdSearchParametersIVF;
+int faiss_amd_GpuIndexIVF_search_with_params(const FaissAmdIndex* index, faiss_amd_idx_t n, const float* x,
+                                             faiss_amd_idx_t k, const FaissAmdSearchParametersIVF* params,
+                                             float* distances, faiss_amd_idx_t* labels);
+/* vectors actually stored in the inverted lists: ntotal counts every vector add() was given (NaN rows are not
+ * stored but counted, faiss/gpu/GpuIndexIVF.cu:293-298) */
+int faiss_amd_GpuIndexIVF_stored_vectors(const FaissAmdIndex* index, faiss_amd_idx_t* p_stored);
+/* list arena in rows: handed out (lists + slack + holes), holes left by relocated lists, allocated */
+int faiss_amd_GpuIndexIVF_arena_stats(const FaissAmdIndex* index, int64_t* used_rows, int64_t* hole_rows,
+                                      int64_t* allocated_rows);
+
 /* IVF search through the unfused path (every distance as a key in HBM + select kernel) instead
  * of the fused LDS-resident scan; results are identical, the switch exists for cross-checks */
 int faiss_amd_GpuIndexIVF_set_use_fused_scan(FaissAmdIndex* index, int on);

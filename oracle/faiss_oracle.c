@@ -258,6 +258,27 @@ static void ivf_finish(int metric, cand_t* a, int n, int k, const idx_t* pos2id,
     }
 }
 
+/* Grid of an IVFPQ lookup table (faiss_amd/csrc/kernels.h pq_lut_grid restated): delta = 2^ed with
+ * 2^(ed + 24) > 1.0001 * B, B = sum over sub-quantizers of max_c |tab[m][c]|.  Entries rounded to multiples of delta
+ * add up exactly in fp32 in any order.  Returns 0 when the table is left as it is (B zero, NaN or infinite). */
+static int orc_pq_lut_grid(float B, float* delta, float* inv) {
+    if (!(B > 0.f)) return 0;
+    const float Bs = B * 1.0001f;
+    if (!(Bs <= FLT_MAX)) return 0;
+    union {
+        float f;
+        uint32_t u;
+    } v;
+    v.f = Bs;
+    int ed = (int)((v.u >> 23) & 255u) - 126 - 24;
+    if (ed < -126) ed = -126;
+    v.u = (uint32_t)(ed + 127) << 23;
+    *delta = v.f;
+    v.u = (uint32_t)(127 - ed) << 23;
+    *inv = v.f;
+    return 1;
+}
+
 /* kind: 0 = IVFFlat (codes are d floats), 1 = IVFPQ (codes are M bytes, 8 bits each).
  * coarse_D / coarse_I (nullable): receive the nprobe coarse results per query. */
 int orc_ivf_search(int kind, int metric, int d, int nlist, const float* centroids, const uint32_t* list_sizes,
@@ -288,7 +309,7 @@ int orc_ivf_search(int kind, int metric, int d, int nlist, const float* centroid
         idx_t* pos2id = (idx_t*)malloc(sizeof(idx_t) * (ncand ? ncand : 1));
         cand_t* st = (cand_t*)malloc(sizeof(cand_t) * (size_t)k);
         float* lut = kind == 1 ? (float*)malloc(sizeof(float) * (size_t)M * 256) : NULL;
-        float* res = (float*)malloc(sizeof(float) * (size_t)d);
+        int lut_ready = 0;
         topk_t t;
         topk_init(&t, st, k, metric);
         idx_t pos = 0;
@@ -300,19 +321,39 @@ int orc_ivf_search(int kind, int metric, int d, int nlist, const float* centroid
             const uint32_t len = list_sizes[l];
             float dis0 = 0.f;
             if (kind == 1) {
-                /* lookup table of the QUERY (both metrics): tab[m][c] = <x_m, pq[m][c]>; dis0 = the coarse
-                 * distance of (query, list).  L2 uses the term decomposition of the reference CPU index
+                /* lookup table of the QUERY (both metrics): tab[m][c] = <x_m, pq[m][c]> as an fmaf chain, rounded to
+                 * the query's power-of-two grid (orc_pq_lut_grid = faiss_amd/csrc/kernels.h pq_lut_grid); dis0 = the
+                 * coarse distance of (query, list).  L2 uses the term decomposition of the reference CPU index
                  * (faiss/impl/pq_code_distance/IVFPQ_QueryTables.cpp:126-192, use_precomputed_table):
                  *   |x - c - r^|^2 = |x - c|^2 + (|r^|^2 + 2 <c, r^>) - 2 <x, r^>
                  * with the middle term t2 computed per stored vector. */
-                for (int j = 0; j < d; j++) res[j] = x[j];
-                for (int m = 0; m < M; m++) {
-                    for (int c = 0; c < 256; c++) {
-                        const float* pc = pq_centroids + ((size_t)m * 256 + c) * dsub;
-                        float acc = 0.f;
-                        for (int j = 0; j < dsub; j++) acc = fmaf(res[m * dsub + j], pc[j], acc);
-                        lut[m * 256 + c] = acc;
+                if (!lut_ready) {
+                    float B = 0.f;
+                    for (int m = 0; m < M; m++) {
+                        uint32_t mxbits = 0; /* max over bit patterns of |v|: NaN (0x7fc00000) beats every number */
+                        for (int c = 0; c < 256; c++) {
+                            const float* pc = pq_centroids + ((size_t)m * 256 + c) * dsub;
+                            float acc = 0.f;
+                            for (int j = 0; j < dsub; j++) acc = fmaf(x[m * dsub + j], pc[j], acc);
+                            lut[m * 256 + c] = acc;
+                            union {
+                                float f;
+                                uint32_t u;
+                            } a;
+                            a.f = fabsf(acc);
+                            if (a.u > mxbits) mxbits = a.u;
+                        }
+                        union {
+                            float f;
+                            uint32_t u;
+                        } mx;
+                        mx.u = mxbits;
+                        B = B + mx.f;
                     }
+                    float delta, inv;
+                    if (orc_pq_lut_grid(B, &delta, &inv))
+                        for (int e = 0; e < M * 256; e++) lut[e] = rintf(lut[e] * inv) * delta;
+                    lut_ready = 1;
                 }
                 dis0 = cD[(size_t)q * nprobe + p];
             }
@@ -345,26 +386,13 @@ int orc_ivf_search(int kind, int metric, int d, int nlist, const float* centroid
                     dis = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
                 } else {
                     const uint8_t* code = lc + (size_t)i * code_size;
-                    /* ADC sum in the order of the GPU scan: four lanes own M/4 consecutive
-                     * sub-quantizers each (sequential partial sums from 0), combined pairwise by a
-                     * lane butterfly, then added to dis0.  (The CPU reference sums sequentially,
-                     * faiss/impl/pq_code_distance/pq_code_distance-generic.cpp distance_single_code;
-                     * the two orders agree to fp32 rounding.) */
-                    float part[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (M % 4 == 0) {
-                        const int mq = M / 4;
-                        for (int jq = 0; jq < 4; jq++) {
-                            float acc = 0.f;
-                            for (int m = jq * mq; m < (jq + 1) * mq; m++) acc = acc + lut[m * 256 + code[m]];
-                            part[jq] = acc;
-                        }
-                    } else {
-                        float acc = 0.f;
-                        for (int m = 0; m < M; m++) acc = acc + lut[m * 256 + code[m]];
-                        part[0] = acc;
-                    }
+                    /* ADC sum: the table entries sit on a grid on which every partial sum is exact in fp32
+                     * (orc_pq_lut_grid), so any summation order gives these bits; the GPU scan walks the
+                     * sub-quantizers in a per-row rotated order, the CPU reference sequentially
+                     * (faiss/impl/pq_code_distance/pq_code_distance-generic.cpp distance_single_code). */
+                    float sum = 0.f;
+                    for (int m = 0; m < M; m++) sum = sum + lut[m * 256 + code[m]];
                     {
-                        const float sum = (part[0] + part[1]) + (part[2] + part[3]);
                         if (metric == ORC_METRIC_L2) {
                             /* t2 = |r^|^2 + 2 <c, r^> as one fmaf chain over the d coordinates */
                             const float* cen = centroids + (size_t)l * d;
@@ -389,7 +417,6 @@ int orc_ivf_search(int kind, int metric, int d, int nlist, const float* centroid
         free(pos2id);
         free(st);
         free(lut);
-        free(res);
     }
     free(cD);
     free(cI);

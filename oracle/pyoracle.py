@@ -203,6 +203,11 @@ class RefIndex:
         c, pq = _f32(centroids), np.ascontiguousarray(pq_centroids, dtype=np.float32)
         self._ck(self.lib.ref_ivfpq_set_trained(ctypes.c_void_p(self.h), _p(c), _p(pq)))
 
+    def set_centroids(self, centroids):
+        """install coarse centroids [nlist, d] into an untrained IVFFlat index"""
+        c = _f32(centroids)
+        self._ck(self.lib.ref_ivf_set_centroids(ctypes.c_void_p(self.h), _p(c)))
+
     def set_train_niter(self, niter_coarse, niter_pq=0):
         self._ck(self.lib.ref_ivf_set_train_niter(ctypes.c_void_p(self.h), ctypes.c_int(niter_coarse),
                                                   ctypes.c_int(niter_pq)))

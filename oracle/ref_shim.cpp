@@ -233,6 +233,16 @@ int ref_ivfpq_set_trained(void* p, const float* centroids, const float* pq_centr
     SHIM_CATCH
 }
 
+// same for any IndexIVF whose only trained state is the coarse quantizer (IndexIVFFlat)
+int ref_ivf_set_centroids(void* p, const float* centroids) {
+    SHIM_TRY auto* i = ivf(p);
+    i->quantizer->reset();
+    i->quantizer->add(i->nlist, centroids);
+    i->quantizer->is_trained = true;
+    i->is_trained = true;
+    SHIM_CATCH
+}
+
 // k-means iteration counts of an untrained IVF(PQ) index: coarse quantizer (IndexIVF::cp) and product
 // quantizer (ProductQuantizer::cp); <= 0 leaves a value unchanged.  Used to bound the training time of
 // the CPU baseline (search speed does not depend on it).

@@ -462,21 +462,6 @@ def test_flat_filter_range_and_nan_handling(res):
     check_knn(D, I, *Oracle.flat_search(METRIC_L2, xb2, xq[:3], 8), exact=True, name="out of range db")
 
 
-def test_flat_filter_full_size_matches_exact_scan(res):
-    """BASELINE.json configs[1] at full size (d=128, nb=1M, nq=10k, k=100): the two independent device
-    paths (fp16 filter + re-rank, fp32 MFMA scan) agree bit for bit on every query."""
-    _, xb, xq = synthetic_dataset(128, 0, 1000000, 10000, seed=1338)
-    idx = faiss_amd.GpuIndexFlatL2(res, 128)
-    idx.add(xb)
-    D, I = idx.search(xq, 100)
-    used, novf = idx.filter_stats()
-    assert used and novf < 100
-    idx.set_use_filter_kernel(False)
-    D0, I0 = idx.search(xq, 100)
-    assert np.array_equal(I, I0) and np.array_equal(D, D0)
-    assert (np.diff(D, axis=1) >= 0).all()
-
-
 # ------------------------------------------------------------------------------- rest of the Index surface
 @pytest.mark.parametrize("metric", [METRIC_L2, METRIC_INNER_PRODUCT])
 @pytest.mark.parametrize("kind", ["ivfflat", "ivfpq"])
@@ -588,47 +573,6 @@ def test_partial_query_groups_in_the_8_wave_geometry(res):
 
 
 @pytest.mark.parametrize("kind", ["ivfflat", "ivfpq"])
-def test_ivf_full_size_properties(res, kind):
-    """BASELINE.json shapes at nb = 1M (IVF4096, nprobe 32, k = 100; PQ64x8): properties that do not need an oracle
-    run -- the fused LDS-resident scan and the unfused path (every distance as a key in HBM + select) are independent
-    device implementations and agree bit for bit; search_preassigned on the quantizer's own output reproduces
-    search(); results are sorted, labels unique and valid; IVFFlat distances are exact distances to the labelled
-    rows; recall against the flat index is in the range the reference reports for this configuration."""
-    d, nlist, nprobe, k, nq = 128, 4096, 32, 100, 400
-    xt, xb, xq = synthetic_dataset(d, 100000, 1000000, nq, seed=1338)
-    if kind == "ivfflat":
-        idx = faiss_amd.GpuIndexIVFFlat(res, d, nlist, METRIC_L2)
-    else:
-        idx = faiss_amd.GpuIndexIVFPQ(res, d, nlist, 64, 8, METRIC_L2)
-    idx.train(xt)
-    idx.add(xb)
-    assert idx.ntotal == 1000000
-    idx.nprobe = nprobe
-    D, I = idx.search(xq, k)
-    idx.set_use_fused_scan(False)
-    D0, I0 = idx.search(xq, k)
-    idx.set_use_fused_scan(True)
-    assert np.array_equal(I, I0) and np.array_equal(D, D0)
-    Dq, Iq = idx.quantizer_search(xq, nprobe)
-    D1, I1 = idx.search_preassigned(xq, k, Iq, Dq)
-    assert np.array_equal(I, I1) and np.array_equal(D, D1)
-    assert (np.diff(D, axis=1) >= 0).all() and (I >= 0).all() and (I < 1000000).all()
-    assert all(len(set(row)) == k for row in I[:50])
-    flat = faiss_amd.GpuIndexFlatL2(res, d)
-    flat.add(xb)
-    _, gt = flat.search(xq, 1)
-    r1 = float((I[:, :1] == gt).mean())
-    r100 = float((I == gt).any(axis=1).mean())
-    if kind == "ivfflat":
-        # exact distances of the rows it returns (same fmaf chain up to the summation order: 1e-5 relative)
-        ex = ((xq[:20, None, :].astype(np.float64) - xb[I[:20]].astype(np.float64)) ** 2).sum(-1)
-        assert np.allclose(D[:20], ex, rtol=1e-5, atol=1e-4)
-        assert r1 > 0.93 and r100 >= r1
-    else:
-        assert r1 > 0.8 and r100 > 0.9  # PQ64: benchs/README.md:221 reports R@1 ~0.82 on SIFT1M
-
-
-@pytest.mark.parametrize("kind", ["ivfflat", "ivfpq"])
 def test_ivf_nan_queries_and_nan_adds(res, kind):
     """faiss/gpu/test/TestGpuIndexIVFFlat.cpp:566-605 (QueryNaN: every result is -1 / FLT_MAX) and :633-675 (AddNaN:
     NaN vectors are not stored, the valid one among them is, nothing crashes); same pair in TestGpuIndexIVFPQ.cpp."""
@@ -645,11 +589,18 @@ def test_ivf_nan_queries_and_nan_adds(res, kind):
     nans[1] = xb[123]
     idx.add(nans)
     assert sum(idx.get_list_size(l) for l in range(nlist)) == 1
+    # ntotal counts the vectors add() was given, stored or not (faiss/gpu/GpuIndexIVF.cu:293-298) ...
+    assert idx.ntotal == 10 and idx.stored_vectors == 1
     idx.nprobe = nlist
     D, I = idx.search(xq, k)
     assert (I[:, 0] == 1).all() and (I[:, 1:] == -1).all()
     # more data, then QueryNaN
     idx.add(xb)
+    # ... so the ids generated for the next add() start behind them and never collide (GpuIndex.cu:137-144)
+    assert idx.ntotal == 10 + len(xb) and idx.stored_vectors == 1 + len(xb)
+    all_ids = np.concatenate([idx.get_list_ids(l) for l in range(nlist)])
+    assert len(np.unique(all_ids)) == len(all_ids) == 1 + len(xb)
+    assert set(all_ids.tolist()) == {1} | set(range(10, 10 + len(xb)))
     idx.nprobe = 4
     qn = np.full((10, d), np.nan, dtype=np.float32)
     D, I = idx.search(qn, k)
@@ -661,3 +612,143 @@ def test_ivf_nan_queries_and_nan_adds(res, kind):
     Dv, Iv = idx.search(xq, k)
     keep = np.arange(10) != 3
     assert np.array_equal(Im[keep], Iv[keep]) and np.array_equal(Dm[keep], Dv[keep]) and (Im[3] == -1).all()
+
+
+# ------------------------------------------------------------------------------- round 2: storage, add path, parameters
+@pytest.mark.parametrize("metric", [METRIC_L2, METRIC_INNER_PRODUCT])
+@pytest.mark.parametrize("kind", ["ivfflat", "ivfpq"])
+def test_ivf_trained_but_empty_returns_padding(res, kind, metric):
+    """A trained index without vectors (a fresh index, an IndexShards shard that received no rows) answers with
+    -1 / +-FLT_MAX like the reference (faiss/utils/Heap.h:427-457), on every path."""
+    d, nlist = 32, 8
+    xt, _, xq = synthetic_dataset(d, 3000, 0, 9, seed=5)
+    idx = (faiss_amd.GpuIndexIVFFlat(res, d, nlist, metric) if kind == "ivfflat"
+           else faiss_amd.GpuIndexIVFPQ(res, d, nlist, 4, 8, metric))
+    idx.train(xt)
+    assert idx.is_trained and idx.ntotal == 0
+    idx.nprobe = 3
+    pad = FMAX if metric == METRIC_L2 else -FMAX
+    for fused in (True, False):
+        idx.set_use_fused_scan(fused)
+        D, I = idx.search(xq, 4)
+        assert (I == -1).all() and (D == pad).all()
+    # one shard of three stays empty: the sharded search still answers
+    if kind == "ivfpq" and metric == METRIC_L2:
+        sh = faiss_amd.IndexShards(d, threaded=True, successive_ids=False)
+        subs = []
+        for _ in range(3):
+            s = faiss_amd.GpuIndexIVFPQ(res, d, nlist, 4, 8, metric)
+            s.copy_centroids(idx.get_centroids())
+            s.copy_pq_centroids(idx.get_pq_centroids())
+            s.nprobe = nlist
+            subs.append(s)
+            sh.add_shard(s)
+        sh.add_with_ids(synthetic_dataset(d, 0, 2, 0, seed=6)[1], np.array([5, 9]))  # rows go to shards 0 and 1... or 1 and 2
+        D, I = sh.search(xq, 3)
+        assert (np.sort(I[:, :2], axis=1) == np.array([5, 9])).all() and (I[:, 2] == -1).all()
+
+
+def test_ivfpq_is_trained_needs_both_quantizers(res):
+    d, nlist, M = 32, 8, 4
+    xt, xb, _ = synthetic_dataset(d, 3000, 100, 0, seed=5)
+    cent, _ = faiss_amd.kmeans(res, xt, nlist, niter=3, seed=1)
+    idx = faiss_amd.GpuIndexIVFPQ(res, d, nlist, M, 8, METRIC_L2)
+    idx.copy_centroids(cent)
+    assert not idx.is_trained  # no codebook yet
+    with pytest.raises(faiss_amd.FaissAmdError):
+        idx.add(xb)
+    with pytest.raises(faiss_amd.FaissAmdError):
+        idx.copy_lists(np.zeros(nlist, np.uint32), np.zeros((0, M), np.uint8), np.zeros(0, np.int64))
+    assert idx.ntotal == 0
+    idx.train(xt)  # trains only what is missing: the centroids stay
+    assert idx.is_trained and np.array_equal(idx.get_centroids(), cent)
+    idx.add(xb)
+    assert idx.ntotal == 100
+
+
+@pytest.mark.parametrize("name", ["ivfflat_l2", "ivfpq_l2"])
+def test_ivf_many_incremental_adds_equal_one_add(res, name):
+    """20 add_with_ids calls of uneven size leave byte-identical lists (sizes, ids, codes, insertion order) to one big
+    add and to the reference's own lists (testIVFEquality, faiss/gpu/test/TestUtils.h:111-142;
+    reference add path faiss/gpu/impl/IVFBase.cu:595-905), and identical search results."""
+    c = load_ivf_case(name)
+    z = c["z"]
+    n = len(c["xb"])
+    nlist = z["centroids"].shape[0]
+    one = _make_ivf(res, c)
+    one.add_with_ids(c["xb"], c["ids"])
+    many = _make_ivf(res, c)
+    cuts = np.unique(np.r_[0, np.sort(np.random.RandomState(4).randint(1, n, size=19)), n])
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        many.add_with_ids(c["xb"][a:b], c["ids"][a:b])
+    assert many.ntotal == one.ntotal == n
+    for l in range(nlist):
+        assert np.array_equal(many.get_list_ids(l), one.get_list_ids(l))
+        assert np.array_equal(many.get_list_codes(l), one.get_list_codes(l))
+    assert np.array_equal(np.array([many.get_list_size(l) for l in range(nlist)], dtype=np.uint32), z["list_sizes"])
+    assert np.array_equal(np.concatenate([many.get_list_ids(l) for l in range(nlist)]), z["list_ids"])
+    used, holes, alloc = many.arena_stats()
+    assert holes < used <= alloc and used < 8 * n + 64 * nlist  # geometric growth, bounded waste
+    for idx in (one, many):
+        idx.nprobe = c["nprobe"]
+    D1, I1 = one.search(c["xq"], c["k"])
+    D2, I2 = many.search(c["xq"], c["k"])
+    assert np.array_equal(I1, I2) and np.array_equal(D1, D2)  # distances do not depend on where a vector is stored
+    check_knn(D2, I2, z["D"], z["I"], rtol=1e-4, name=name + " incremental vs golden")
+
+
+def test_ivf_search_parameters_nprobe_override(res):
+    """SearchParametersIVF.nprobe (faiss/IndexIVF.h:70-80, GpuIndexIVF.cu:358-381) overrides index.nprobe for one call"""
+    c = load_ivf_case("ivfpq_l2")
+    idx = _make_ivf(res, c)
+    idx.copy_lists(c["z"]["list_sizes"], c["codes"], c["z"]["list_ids"])
+    idx.nprobe = 1
+    D1, I1 = idx.search(c["xq"], c["k"])
+    Dp, Ip = idx.search(c["xq"], c["k"], params=faiss_amd.SearchParametersIVF(nprobe=c["nprobe"]))
+    assert idx.nprobe == 1
+    idx.nprobe = c["nprobe"]
+    D2, I2 = idx.search(c["xq"], c["k"])
+    assert np.array_equal(Ip, I2) and np.array_equal(Dp, D2) and not np.array_equal(I1, I2)
+    with pytest.raises(faiss_amd.FaissAmdError):
+        idx.search(c["xq"], c["k"], params=faiss_amd.SearchParametersIVF(nprobe=5000))
+
+
+def test_ivfflat_reconstruct_n(res):
+    """GpuIndexIVFFlat::reconstruct_n (faiss/gpu/GpuIndexIVFFlat.cu:370-390): rows of a contiguous id range"""
+    c = load_ivf_case("ivfflat_l2")
+    idx = _make_ivf(res, c)
+    idx.add(c["xb"])  # ids 0..n-1
+    assert np.array_equal(idx.reconstruct_n(100, 300), c["xb"][100:400])
+    assert np.array_equal(idx.reconstruct(7), c["xb"][7])
+
+
+@pytest.mark.parametrize("M,d", [(4, 32), (8, 64), (12, 96), (20, 200), (32, 32), (48, 96), (64, 128), (96, 192)])
+def test_ivfpq_code_layout_round_trip(res, M, d):
+    """copy_lists -> rotated 64-row block layout -> get_list_codes is the identity for every chunk width (M % 16 == 0:
+    16-byte chunks, else 4), on lists that are empty, shorter than a block, and several blocks long; the scan over that
+    layout matches the oracle bit for bit."""
+    nlist, nq, k = 5, 30, 10
+    rs = np.random.RandomState(M)
+    xt, _, xq = synthetic_dataset(d, 2000, 0, nq, seed=M)
+    cent, _ = faiss_amd.kmeans(res, xt, nlist, niter=3, seed=2)
+    pq = (rs.rand(M, 256, d // M).astype("float32") - 0.5) * 0.5
+    sizes = np.array([0, 1, 63, 64, 200], dtype=np.uint32)
+    n = int(sizes.sum())
+    codes = rs.randint(0, 256, size=(n, M)).astype(np.uint8)
+    ids = rs.permutation(10 * n)[:n].astype(np.int64)
+    for metric in (METRIC_L2, METRIC_INNER_PRODUCT):
+        idx = faiss_amd.GpuIndexIVFPQ(res, d, nlist, M, 8, metric)
+        idx.copy_centroids(cent)
+        idx.copy_pq_centroids(pq)
+        idx.copy_lists(sizes, codes, ids)
+        off = 0
+        for l in range(nlist):
+            assert np.array_equal(idx.get_list_codes(l), codes[off:off + sizes[l]])
+            assert np.array_equal(idx.get_list_ids(l), ids[off:off + sizes[l]])
+            off += int(sizes[l])
+        idx.nprobe = nlist
+        Do, Io, _, _ = Oracle.ivf_search(1, metric, cent, sizes, codes, ids, xq, nlist, k, M=M, pq=pq)
+        for fused in (True, False):
+            idx.set_use_fused_scan(fused)
+            D, I = idx.search(xq, k)
+            check_knn(D, I, Do, Io, exact=True, name="layout M=%d fused=%s" % (M, fused))
