@@ -1,23 +1,25 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark of the MI355X similarity-search backend.
 
-Metric (BASELINE.json): QPS at nq=10 000, k=100 on SIFT1M-shaped synthetic data (d=128,
-nb=1M; the reference's SyntheticDataset recipe, seed 1338).  A "step" is one search of all
-10 000 queries; queries and results are resident in HBM when the timed region starts.
+Metric (BASELINE.json): QPS at nq=10 000, k=100 on SIFT1M-shaped synthetic data (d=128, nb=1M; the reference's
+SyntheticDataset recipe, seed 1338).  A "step" is one search of all 10 000 queries.
 
-  N = 1 : GpuIndexFlatL2 (BASELINE.json configs[1]); `value` = Flat QPS.  The same line also
-          carries the IVF4096,PQ64 numbers (`ivfpq`), the roofline of the dominant kernel and
-          the reference CPU path timed on this node's host cores (`cpu_baseline`).
-  N > 1 : one process per GPU (torch.distributed, backend "nccl" = RCCL), total work fixed =>
-          "scaling": "strong".  --multi-gpu replicas (default): what the reference builds for a
-          database that fits one GPU (index_cpu_to_gpu_multiple, GpuMultipleClonerOptions::shard =
-          false -> IndexReplicas): every rank holds the 1M vectors and searches its block of the
-          queries; the result blocks are gathered onto rank 0 (1.5 MB per rank at N = 8, no
-          merge).  --multi-gpu shards: IndexShards-style (rank r holds rows [r*nb/N, (r+1)*nb/N)),
-          every rank searches all queries on its shard, the per-rank top-k are gathered
-          point-to-point onto rank 0 over xGMI and merged there by the device select kernel --
-          the layout for databases beyond one GPU (BASELINE.json configs[4]); at nb = 1M its
-          replicated per-query work (re-rank, gather, merge) dominates.
+  N = 1 : `value` = GpuIndexFlatL2 QPS (BASELINE.json configs[1]) with queries and results resident in HBM when the
+          timed region starts; `value_host_buffers` beside it is the same search handed pageable HOST buffers (how
+          benchs/bench_gpu_sift1m.py times the reference; PCIe copies inside the timed region).  The same JSON line
+          carries the IVF4096,PQ64 and IVF4096,Flat legs at nb=1M (`ivfpq`, `ivfflat`), each with its own `roofline`
+          block (HBM-bound scans: algorithmic bytes of SURVEY.md 8d over the HIP-event kernel time), the parity of
+          every leg against the reference CPU index on ALL queries (every label mismatch classified as near-tie or
+          counted as real) and the reference CPU path timed on this node's host cores (`cpu_baseline`).
+  N > 1 : one process per GPU (torch.distributed, backend "nccl" = RCCL), total work fixed => "scaling": "strong".
+          Flat leg (`value`): --multi-gpu replicas (default; what the reference builds for a database that fits one
+          GPU, GpuMultipleClonerOptions::shard = false -> IndexReplicas: every rank holds the 1M vectors and searches
+          its block of the queries, the result blocks are gathered onto rank 0) or shards (IndexShards: rows split).
+          IVFPQ leg (`ivfpq`): ALWAYS IndexShards-style, the layout the north star names for databases beyond one
+          GPU (BASELINE.json configs[4]): rank 0 trains the coarse quantizer and the PQ codebook and broadcasts them
+          (the only collective), rank r adds rows [r*nb/N, (r+1)*nb/N) with their global ids, every rank searches all
+          queries on its shard (its own coarse quantization: identical on every rank, cheaper than shipping it), the
+          per-rank top-k are gathered point-to-point onto rank 0 over xGMI and merged by the device select kernel.
 
 Run:  python bench.py [--gpus N --steps K --warmup W]
       python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -35,9 +37,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 D, NT, NB, NQ, K = 128, 100000, 1000000, 10000, 100
+NLIST, NPROBE, PQ_M = 4096, 32, 64
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 PEAK_F16_MFMA_TFLOPS = 2500.0  # same guide: dense f16/bf16 MFMA (v_mfma_f32_32x32x16_f16)
 PEAK_HBM_GBS = 8000.0
+PROFILE_JSON = os.path.join(ROOT, "profiles", "r02_pmc_counters.json")  # committed rocprofv3 --pmc summary
 
 
 def log(*a):
@@ -61,14 +65,31 @@ def effective_cores():
     return n
 
 
-def cpu_baseline(xb, xq, k, gpu_D, gpu_I, budget_s=25.0):
-    """Reference CPU path (faiss IndexFlatL2, compiled unmodified into oracle/_ref) timed on this
-    node's host cores on a bounded sample of the same queries; falls back to the scalar C
-    restatement (kind "port") when oracle/_ref was not shipped.
+def classify_parity(D, I, Dr, Ir, rtol=1e-4):
+    """Every label that differs from the reference's is either a near-tie permutation / a tie at the k-th boundary
+    (reference distances within 2e-5 relative, tests/compare.py check_knn -- the north star's "ties broken
+    consistently") or REAL.  Returns the counts; a real mismatch or a distance off by more than rtol is reported as
+    such, never hidden in an average."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from compare import check_knn
+    out = {"queries": int(I.shape[0]), "k": int(I.shape[1]), "labels_equal_frac": round(float((I == Ir).mean()), 6),
+           "max_rel_dist_err": float("%.3g" % np.max(np.abs(D - Dr) / np.maximum(np.abs(Dr), 1e-30))),
+           "top1_label_equal_frac": round(float((I[:, 0] == Ir[:, 0]).mean()), 6)}
+    try:
+        st = check_knn(D, I, Dr, Ir, rtol=rtol, max_tie_frac=1.0, name="bench")
+        out.update({"near_tie_mismatches": int(st["tie_swaps"] + st["boundary_ties"]), "real_mismatches": 0,
+                    "distances_within_1e-4": True})
+    except AssertionError as e:  # a real mismatch: say so
+        out.update({"near_tie_mismatches": None, "real_mismatches": "FAILED: " + str(e)[:160],
+                    "distances_within_1e-4": False})
+    return out
 
-    The reference blocks the search into 4096-query x 1024-row sgemm tiles
-    (faiss/utils/distances.cpp:424-511), so the sample is ONE large query batch (as
-    benchs/bench_gpu_sift1m.py does), never many small ones."""
+
+def cpu_baseline_flat(xb, xq, k, gpu_D, gpu_I, budget_s=25.0):
+    """Reference CPU path (faiss IndexFlatL2, compiled unmodified into oracle/_ref) timed on this node's host cores
+    on a bounded sample of the same queries; falls back to the scalar C restatement (kind "port") when oracle/_ref was
+    not shipped.  The reference blocks the search into 4096-query x 1024-row sgemm tiles
+    (faiss/utils/distances.cpp:424-511), so the sample is ONE large query batch (as benchs/bench_gpu_sift1m.py does)."""
     from oracle.pyoracle import METRIC_L2, Oracle, Ref
     cores = effective_cores()
     if Ref.available():
@@ -78,9 +99,8 @@ def cpu_baseline(xb, xq, k, gpu_D, gpu_I, budget_s=25.0):
         idx.add(xb)
         ns = min(len(xq), 2048)
         idx.search(xq[:ns], k)  # warm-up (MKL init, page faults)
-        # probe the full core allowance and half of it (SMT siblings rarely help sgemm), keep the faster
         best = None
-        for nthr in sorted({cores, max(1, cores // 2)}, reverse=True):
+        for nthr in sorted({cores, max(1, cores // 2)}, reverse=True):  # SMT siblings rarely help sgemm
             Ref.set_threads(nthr)
             t0 = time.time()
             Dr, Ir = idx.search(xq[:ns], k)
@@ -90,8 +110,7 @@ def cpu_baseline(xb, xq, k, gpu_D, gpu_I, budget_s=25.0):
                 best = (dt, nthr, Dr, Ir)
         dt, nthr, Dr, Ir = best
         Ref.set_threads(nthr)
-        # grow the sample towards the full query set while it stays inside the budget
-        if dt * (len(xq) / ns) < 0.5 * budget_s and ns < len(xq):
+        if dt * (len(xq) / ns) < 0.5 * budget_s and ns < len(xq):  # the full query set fits the budget
             ns = len(xq)
             t0 = time.time()
             Dr, Ir = idx.search(xq[:ns], k)
@@ -108,99 +127,198 @@ def cpu_baseline(xb, xq, k, gpu_D, gpu_I, budget_s=25.0):
         sample = "oracle/faiss_oracle.c restatement (OpenMP over queries), first %d queries" % ns
     out = {"value": round(ns / dt, 1), "unit": "QPS", "cores": int(threads), "kind": kind, "sample": sample}
     if gpu_I is not None:
-        eq = float((gpu_I[:ns] == Ir).mean())
-        rel = float(np.max(np.abs(gpu_D[:ns] - Dr) / np.maximum(np.abs(Dr), 1e-30)))
-        out["parity_vs_gpu"] = {"labels_equal_frac": round(eq, 6), "max_rel_dist_err": float("%.3g" % rel),
-                                "recall_at_1": float((gpu_I[:ns, 0] == Ir[:, 0]).mean())}
+        out["parity_vs_gpu"] = classify_parity(gpu_D[:ns], gpu_I[:ns], Dr, Ir)
+        out["parity_vs_gpu"]["recall_at_1"] = float((gpu_I[:ns, 0] == Ir[:, 0]).mean())
     return out
 
 
-def cpu_baseline_ivfpq(gpu_index, xb, xq, gt_first):
-    """Reference CPU IndexIVFPQ (index_factory "IVF4096,PQ64", default search parameters, nprobe=32) holding
-    the SAME coarse centroids and PQ codebook as the GPU index (installed through the shim, the reverse of
-    GpuIndexIVFPQ::copyTo), filled with the same vectors by the reference's own add(), timed on the node's
-    core allowance.  About 10-20 s of CPU work (add 1M vectors + search)."""
-    from oracle.pyoracle import Ref
-    if not Ref.available():
-        return None
-    cores = effective_cores()
-    Ref.set_threads(cores)
-    idx = Ref.index_factory(xb.shape[1], "IVF4096,PQ64")
-    idx.set_trained(gpu_index.get_centroids(), gpu_index.get_pq_centroids())
-    t0 = time.time()
-    idx.add(xb)
-    t_add = time.time() - t0
-    idx.set_nprobe(32)
-    idx.search(xq[:256], K)
-    t0 = time.time()
-    Dr, Ir = idx.search(xq, K)
-    dt = time.time() - t0
-    return {"value": round(len(xq) / dt, 1), "unit": "QPS", "cores": int(cores), "kind": "reference",
-            "sample": "faiss 1.15.0 index_factory('IVF4096,PQ64') with the GPU-trained quantizers, nprobe=32, all %d "
-                      "queries, nb=%d, k=%d, use_precomputed_table=%d" % (len(xq), len(xb), K,
-                                                                          idx.pq_info()["use_precomputed_table"]),
-            "add_s": round(t_add, 1),
-            "recall_at_1": round(float((Ir[:, 0] == gt_first).mean()), 4),
-            "recall_at_100": round(float((Ir == gt_first[:, None]).any(axis=1).mean()), 4)}, (Dr, Ir)
+def time_search(index, torch, n, xq_ptr, d_ptr, i_ptr, steps, warmup):
+    for _ in range(warmup):
+        index.search_ptr(n, xq_ptr, K, d_ptr, i_ptr)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        index.search_ptr(n, xq_ptr, K, d_ptr, i_ptr)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
 
 
-def ivfpq_leg(res, xt, xb, xq_dev, gt_first, steps, warmup, torch, with_cpu=True):
-    """IVF4096,PQ64 (second half of the metric): native train + add on the GPU, nprobe=32."""
+def ivf_leg(kind, res, xt, xb, xq, xq_dev, gt_first, steps, torch, with_cpu=True):
+    """IVF4096,PQ64 / IVF4096,Flat at nb = 1M (BASELINE.json configs[3] / configs[2] at the metric's database size):
+    native train + add on the GPU, nprobe = 32, the reference CPU index with the SAME quantizers as baseline and as
+    parity reference (it is filled by its own add(); its lists are then also loaded into a second GPU index, so the
+    parity comparison scans identical lists on both sides)."""
     import faiss_amd
+    from oracle.pyoracle import Ref
+    pq = kind == "ivfpq"
     t0 = time.time()
-    idx = faiss_amd.GpuIndexIVFPQ(res, D, 4096, 64, 8, faiss_amd.METRIC_L2)
+    idx = (faiss_amd.GpuIndexIVFPQ(res, D, NLIST, PQ_M, 8, faiss_amd.METRIC_L2) if pq
+           else faiss_amd.GpuIndexIVFFlat(res, D, NLIST, faiss_amd.METRIC_L2))
     idx.train(xt)
     t_train = time.time() - t0
     t0 = time.time()
     idx.add(xb)
     t_add = time.time() - t0
-    idx.nprobe = 32
+    idx.nprobe = NPROBE
     Dd = torch.empty((NQ, K), dtype=torch.float32, device=xq_dev.device)
     Id = torch.empty((NQ, K), dtype=torch.int64, device=xq_dev.device)
-    for _ in range(max(1, warmup)):
-        idx.search_ptr(NQ, xq_dev.data_ptr(), K, Dd.data_ptr(), Id.data_ptr())
+    kname = "ivfpq_fused_kernel" if pq else "ivfflat_fused_kernel"
+    time_search(idx, torch, NQ, xq_dev.data_ptr(), Dd.data_ptr(), Id.data_ptr(), 1, 1)
     res.profile_enable(True)
     res.profile_reset()
-    torch.cuda.synchronize()
-    t0 = time.time()
-    for _ in range(steps):
-        idx.search_ptr(NQ, xq_dev.data_ptr(), K, Dd.data_ptr(), Id.data_ptr())
-    torch.cuda.synchronize()
-    dt = (time.time() - t0) / steps
-    I = Id.cpu().numpy()
-    scan_ms, scan_n = res.profile_get("ivfpq_fused_kernel")
-    sel_ms, sel_n = res.profile_get("select_k_kernel")  # coarse quantizer's selection
+    dt = time_search(idx, torch, NQ, xq_dev.data_ptr(), Dd.data_ptr(), Id.data_ptr(), steps, 0)
+    scan_ms, scan_n = res.profile_get(kname)
     res.profile_enable(False)
-    cpu = None
-    if with_cpu:
-        try:
-            cpu, (Dr, Ir) = cpu_baseline_ivfpq(idx, xb, xq_dev.cpu().numpy(), gt_first)
-            # same quantizers, same codes (up to encode near-ties): how close are the two result sets
-            Dg = Dd.cpu().numpy()
-            cpu["parity_vs_gpu"] = {
-                "top1_label_equal_frac": round(float((I[:, 0] == Ir[:, 0]).mean()), 4),
-                "top100_set_overlap": round(float(np.mean([len(np.intersect1d(a, b)) / float(K) for a, b in
-                                                           zip(I[:200], Ir[:200])])), 4),
-                "median_rel_dist_err_top1": float("%.3g" % np.median(np.abs(Dg[:, 0] - Dr[:, 0]) /
-                                                                      np.maximum(np.abs(Dr[:, 0]), 1e-30)))}
-        except Exception as e:  # noqa: BLE001
-            cpu = {"error": repr(e)[:200]}
-    codes_per_query = 32.0 * NB / 4096.0
+    Dh = np.empty((NQ, K), dtype=np.float32)
+    Ih = np.empty((NQ, K), dtype=np.int64)
+    dt_host = time_search(idx, torch, NQ, xq.ctypes.data, Dh.ctypes.data, Ih.ctypes.data, max(2, steps // 2), 1)
+    I = Id.cpu().numpy()
+    avg_ms = scan_ms / max(scan_n, 1)
+    # algorithmic HBM bytes of the list scan (SURVEY.md 8d): nprobe * nb/nlist * bytes-per-entry per query
+    row_bytes = PQ_M if pq else D * 4
+    alg_bytes = float(NPROBE) * NB / NLIST * row_bytes * NQ
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if scan_n else None
     out = {
-        "qps": round(NQ / dt, 1), "ms_per_step": round(dt * 1e3, 3), "nprobe": 32,
+        "workload": "%s nlist=%d nprobe=%d d=%d nb=%d nq=%d k=%d" % ("GpuIndexIVFPQ PQ%dx8" % PQ_M if pq else "GpuIndexIVFFlat",
+                                                                       NLIST, NPROBE, D, NB, NQ, K),
+        "qps": round(NQ / dt, 1), "ms_per_step": round(dt * 1e3, 3),
+        "qps_host_buffers": round(NQ / dt_host, 1),
         "recall_at_1": round(float((I[:, 0] == gt_first).mean()), 4),
         "recall_at_100": round(float((I == gt_first[:, None]).any(axis=1).mean()), 4),
+        "recall_gate": ("R@100 >= 0.95 (PQ64 saturates R@1 near 0.9 on this data; SURVEY.md 8d)" if pq
+                        else "R@1 >= 0.95"),
         "train_s": round(t_train, 2), "add_s": round(t_add, 2),
-        "scan_kernel": "ivfpq_fused_kernel (per-query LUT + code scan of the probed lists as one position stream + top-k, all in LDS; 2 workgroups per CU)",
-        "scan_kernel_ms": round(scan_ms / max(scan_n, 1), 3), "select_kernel_ms": round(sel_ms / max(sel_n, 1), 3),
-        # algorithmic HBM bytes of the code scan (SURVEY.md 8d): nprobe * nb/nlist * M bytes per query
-        "scan_algorithmic_GBps": round(codes_per_query * 64 * NQ / (scan_ms / max(scan_n, 1) * 1e-3) / 1e9, 1)
-        if scan_n else None,
-        "cpu_baseline": cpu,
+        "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1) if achieved else None,
+                     "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4) if achieved else None,
+                     "avg_kernel_ms": round(avg_ms, 3), "launches": int(scan_n),
+                     "algorithmic_bytes_per_launch": int(alg_bytes),
+                     "traffic": committed_traffic(kname, alg_bytes)},
     }
-    if cpu and cpu.get("value"):
-        out["speedup_vs_cpu"] = round(out["qps"] / cpu["value"], 1)
+    if with_cpu and Ref.available():
+        try:
+            cores = effective_cores()
+            Ref.set_threads(cores)
+            ref = Ref.index_factory(D, "IVF4096,PQ64" if pq else "IVF4096,Flat")
+            if pq:
+                ref.set_trained(idx.get_centroids(), idx.get_pq_centroids())
+            else:
+                ref.set_centroids(idx.get_centroids())
+            t0 = time.time()
+            ref.add(xb)
+            t_cadd = time.time() - t0
+            ref.set_nprobe(NPROBE)
+            ref.search(xq[:256], K)
+            t0 = time.time()
+            Dr, Ir = ref.search(xq, K)
+            dtc = time.time() - t0
+            cpu = {"value": round(NQ / dtc, 1), "unit": "QPS", "cores": int(cores), "kind": "reference",
+                   "sample": "faiss 1.15.0 index_factory('%s') with the GPU-trained quantizers, nprobe=%d, all %d queries, "
+                             "nb=%d, k=%d" % ("IVF4096,PQ64" if pq else "IVF4096,Flat", NPROBE, NQ, NB, K),
+                   "add_s": round(t_cadd, 1),
+                   "recall_at_1": round(float((Ir[:, 0] == gt_first).mean()), 4),
+                   "recall_at_100": round(float((Ir == gt_first[:, None]).any(axis=1).mean()), 4)}
+            # parity on identical lists: the reference's own lists copied to a GPU index (copyFrom)
+            g2 = (faiss_amd.GpuIndexIVFPQ(res, D, NLIST, PQ_M, 8, faiss_amd.METRIC_L2) if pq
+                  else faiss_amd.GpuIndexIVFFlat(res, D, NLIST, faiss_amd.METRIC_L2))
+            g2.copy_centroids(idx.get_centroids())
+            if pq:
+                g2.copy_pq_centroids(idx.get_pq_centroids())
+            sizes, codes, lids = ref.lists()
+            g2.copy_lists(sizes, codes, lids)
+            g2.nprobe = NPROBE
+            D2, I2 = g2.search(xq, K)
+            cpu["parity_vs_gpu"] = classify_parity(D2, I2, Dr, Ir)
+            cpu["parity_vs_gpu"]["native_add_top1_equal_frac"] = round(float((I[:, 0] == Ir[:, 0]).mean()), 4)
+            out["cpu_baseline"] = cpu
+            out["speedup_vs_cpu"] = round(out["qps"] / cpu["value"], 1)
+        except Exception as e:  # noqa: BLE001
+            out["cpu_baseline"] = {"error": repr(e)[:300]}
     return out, idx
+
+
+def committed_traffic(kernel_substr, alg_bytes):
+    """HBM bytes per launch of a kernel from the rocprofv3 --pmc FETCH_SIZE pass committed under profiles/ (PMC
+    counters cannot be read from inside this process; same kernel, same workload, corrected x2 as the MI355X guide
+    prescribes for 16 B/lane reads on gfx950).  None when the summary holds no entry."""
+    try:
+        pmc = json.load(open(PROFILE_JSON))
+        ent = [v for k, v in pmc.items() if kernel_substr in k and "FETCH_SIZE" in v]
+        if not ent:
+            return None
+        e = max(ent, key=lambda v: v.get("avg_duration_ns", 0))
+        return {"hbm_read_bytes_per_launch_from_committed_profile": round(e["hbm_read_bytes_corrected"]),
+                "algorithmic_bytes_per_launch": round(alg_bytes),
+                "source": os.path.relpath(PROFILE_JSON, ROOT) + " (rocprofv3 --pmc FETCH_SIZE, separate pass; gfx950 2x "
+                          "correction for 16 B/lane reads applied)"}
+    except (OSError, KeyError, ValueError, IndexError):
+        return None
+
+
+def committed_mfma_busy(kernel_substr):
+    """MFMA-busy share of the dominant flat kernel from the committed SQ pass: SQ_VALU_MFMA_BUSY_CYCLES /
+    (GRBM_GUI_ACTIVE x 1024 SIMDs)."""
+    try:
+        pmc = json.load(open(PROFILE_JSON))
+        ent = [v for k, v in pmc.items() if kernel_substr in k and "SQ_VALU_MFMA_BUSY_CYCLES" in v and "GRBM_GUI_ACTIVE" in v]
+        e = max(ent, key=lambda v: v.get("avg_duration_ns", 0))
+        return round(e["SQ_VALU_MFMA_BUSY_CYCLES"] / (e["GRBM_GUI_ACTIVE"] * 1024.0), 4)
+    except (OSError, KeyError, ValueError, IndexError):
+        return None
+
+
+def sharded_ivfpq_leg(res, rank, world, dev, xt, xb, xq_dev, steps, torch, dist):
+    """IndexShards over the ranks for IVF4096,PQ64 (docstring of this file, N > 1)."""
+    import faiss_amd
+    from faiss_amd.distributed import ShardedSearcher, shard_bounds
+    idx = faiss_amd.GpuIndexIVFPQ(res, D, NLIST, PQ_M, 8, faiss_amd.METRIC_L2)
+    cent = torch.empty((NLIST, D), dtype=torch.float32, device=dev)
+    pqc = torch.empty((PQ_M, 256, D // PQ_M), dtype=torch.float32, device=dev)
+    t0 = time.time()
+    if rank == 0:
+        idx.train(xt)
+        cent.copy_(torch.from_numpy(idx.get_centroids()))
+        pqc.copy_(torch.from_numpy(idx.get_pq_centroids()))
+    dist.broadcast(cent, 0)
+    dist.broadcast(pqc, 0)
+    if rank != 0:
+        idx.copy_centroids(cent.cpu().numpy())
+        idx.copy_pq_centroids(pqc.cpu().numpy())
+    t_train = time.time() - t0
+    lo, hi = shard_bounds(NB, world)[rank]
+    idx.add_with_ids(xb[lo:hi], np.arange(lo, hi, dtype=np.int64))  # global ids: no translation at the merge
+    idx.nprobe = NPROBE
+    D_loc = torch.empty((NQ, K), dtype=torch.float32, device=dev)
+    I_loc = torch.empty((NQ, K), dtype=torch.int64, device=dev)
+    D_out = torch.empty((NQ, K), dtype=torch.float32, device=dev)
+    I_out = torch.empty((NQ, K), dtype=torch.int64, device=dev)
+
+    def local_search(_xq, k):
+        idx.search_ptr(NQ, xq_dev.data_ptr(), k, D_loc.data_ptr(), I_loc.data_ptr())
+        return D_loc, I_loc
+
+    def merge(all_D, all_I, _base):
+        torch.cuda.current_stream().synchronize()  # gathered tensors complete before the library's stream reads them
+        faiss_amd.merge_knn_results_device(res, faiss_amd.METRIC_L2, NQ, K, all_D.shape[0], all_D.data_ptr(),
+                                           all_I.data_ptr(), None, D_out.data_ptr(), I_out.data_ptr())
+        return D_out, I_out
+
+    s = ShardedSearcher(local_search, merge, [0] * world, dev)
+    s.search(xq_dev, K)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = s.search(xq_dev, K)
+    torch.cuda.synchronize()
+    dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    dt = float(el.item()) / steps
+    info = {"qps": round(NQ / dt, 1), "ms_per_step": round(dt * 1e3, 3), "train_broadcast_s": round(t_train, 2),
+            "sharding": "IndexShards-style: rows [r*nb/N, (r+1)*nb/N) per rank with global ids, quantizers trained on "
+                        "rank 0 and broadcast, per-rank top-k gathered to rank 0 + device merge",
+            "rows_per_rank": hi - lo}
+    return info, (out if rank == 0 else None)
 
 
 def main():
@@ -209,10 +327,11 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-ivfpq", action="store_true")
+    ap.add_argument("--no-ivf", action="store_true", help="skip the IVF4096,PQ64 / IVF4096,Flat legs")
     ap.add_argument("--multi-gpu", choices=["replicas", "shards"], default="replicas",
-                    help="N > 1: replicas = every GPU holds the database, queries are split (IndexReplicas, the "
-                         "reference's default for databases that fit one GPU); shards = rows are split (IndexShards)")
+                    help="layout of the FLAT leg at N > 1: replicas = every GPU holds the database, queries are split "
+                         "(IndexReplicas, the reference's default for databases that fit one GPU); shards = rows are split "
+                         "(IndexShards).  The IVFPQ leg is always sharded.")
     ap.add_argument("--flat-path", choices=["filter", "exact"], default="filter",
                     help="filter: fp16 MFMA candidate filter + exact fp32 re-rank (default, bit-identical results); "
                          "exact: fp32 MFMA scan only")
@@ -305,12 +424,20 @@ def main():
     used_filter, n_overflow = index.filter_stats()
     dom = "flat_filter_kernel" if used_filter else "flat_scan_kernel"
     scan_ms, scan_n = res.profile_get(dom)
-    rr_ms, rr_n = res.profile_get("flat_rerank_kernel")
-    mxp_ms, mxp_n = res.profile_get("flat_filter_kernel_max")
-    tg_ms, tg_n = res.profile_get("flat_tighten_kernel")
-    cv_ms, cv_n = res.profile_get("convert_f16_query")
-    sel_ms, sel_n = res.profile_get("select_k_kernel")
+    others = {}
+    for label, key in (("flat_filter_kernel<MODE_MAX> (chunk maxima on a 1/4 tile sample)", "flat_filter_kernel_max"),
+                       ("flat_tighten_kernel", "flat_tighten_kernel"), ("flat_rerank_kernel", "flat_rerank_kernel"),
+                       ("convert_f16_query+norms", "convert_f16_query"), ("select_k_kernel", "select_k_kernel")):
+        ms, n = res.profile_get(key)
+        others[label] = round(ms / max(n, 1), 3)
     res.profile_enable(False)
+
+    ivfpq_multi = None
+    if world > 1 and not args.no_ivf:
+        try:
+            ivfpq_multi, ivf_out = sharded_ivfpq_leg(res, rank, world, dev, xt, xb, xq_dev, max(2, args.steps // 2), torch, dist)
+        except Exception as e:  # noqa: BLE001
+            ivfpq_multi, ivf_out = {"error": repr(e)[:300]}, None
 
     if rank != 0:
         # leave together with rank 0 (which still assembles and prints the line)
@@ -322,9 +449,9 @@ def main():
     qps = NQ * args.steps / elapsed
     gD, gI = out[0].cpu().numpy(), out[1].cpu().numpy()
     avg_scan_ms = scan_ms / max(scan_n, 1)
-    # dominant kernel: the scan of this rank's shard.  Algorithmic work per launch =
-    # 2*nq*nb_shard*d flops (256 MFLOP/query at nb=1M, d=128), priced against the
-    # dense MFMA peak of the unit the kernel runs on (f16 for the filter, f32 for the exact scan).
+    # dominant kernel: the scan of this rank's shard.  Algorithmic work per launch = 2*nq*nb_shard*d flops
+    # (256 MFLOP/query at nb=1M, d=128), priced against the dense MFMA peak of the unit the kernel
+    # runs on (f16 for the filter, f32 for the exact scan).
     nq_rank0 = (replica_bounds(NQ, world)[0][0][1]) if replicas else NQ  # queries of the launches timed on rank 0
     flops = 2.0 * nq_rank0 * (hi - lo) * D
     achieved = flops / (avg_scan_ms * 1e-3) / 1e12
@@ -332,20 +459,6 @@ def main():
     # one sweep of the shard + queries + results is the algorithmic HBM traffic of the launch
     row_bytes = D * (2.0 if used_filter else 4.0)
     hbm_bytes = (hi - lo) * row_bytes + nq_rank0 * row_bytes + nq_rank0 * K * 12.0
-    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the
-    # figure is the rocprofv3 --pmc FETCH_SIZE pass committed under profiles/ (same kernel, same
-    # workload, corrected x2 as the MI355X guide prescribes for 16 B/lane reads on gfx950)
-    traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_e_pmc_counters.json")))
-        if used_filter and world == 1:
-            ent = [v for k, v in pmc.items() if "flat_filter_kernel<1, 1," in k and "FETCH_SIZE" in v][0]
-            traffic = {"hbm_read_bytes_per_launch": round(ent["hbm_read_bytes_corrected"]),
-                       "algorithmic_bytes_per_launch": round(hbm_bytes),
-                       "source": "profiles/r01_e_pmc_counters.txt (rocprofv3 --pmc FETCH_SIZE, separate pass, tools/flat_only.py; "
-                                 "gfx950 2x correction for 16 B/lane reads applied)"}
-    except (OSError, KeyError, ValueError, IndexError):
-        pass
     line = {
         "metric": "QPS @ recall@1 (nq=10k, k=100) FlatL2, SIFT1M-shaped synthetic",
         "value": round(qps, 1), "unit": "QPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -359,33 +472,47 @@ def main():
                                 "IndexReplicas-style: database on every GPU, %d-query blocks, result blocks gathered to rank 0"
                                 % nq_loc if replicas else
                                 "IndexShards-style rows/%d per GPU, gather to rank 0 + device merge" % world),
-                   "inputs": "queries/results resident in HBM",
+                   "inputs": "`value`: queries/results resident in HBM; `value_host_buffers`: pageable host buffers, "
+                             "PCIe copies inside the timed region (SURVEY.md 8d / benchs/bench_gpu_sift1m.py)",
                    "flat_path": "filter" if used_filter else "exact"},
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2),
                      "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                     "traffic": traffic, "avg_kernel_ms": round(avg_scan_ms, 3), "launches": int(scan_n),
+                     "whole_search_frac": round(2.0 * NQ * NB * D / (ms_per_step * 1e-3) / 1e12 / peak, 4) if world == 1 else None,
+                     "mfma_busy_frac_from_committed_profile": committed_mfma_busy("flat_filter_kernel<1, 1,") if used_filter else None,
+                     "traffic": committed_traffic("flat_filter_kernel<1, 1,", hbm_bytes) if used_filter and world == 1 else None,
+                     "avg_kernel_ms": round(avg_scan_ms, 3), "launches": int(scan_n),
                      "algorithmic_hbm_GBps": round(hbm_bytes / (avg_scan_ms * 1e-3) / 1e9, 1),
                      "hbm_frac": round(hbm_bytes / (avg_scan_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 5)},
-        "other_kernels_ms": {"flat_filter_kernel<MODE_MAX> (chunk maxima on a 1/4 tile sample)": round(mxp_ms / max(mxp_n, 1), 3),
-                             "flat_tighten_kernel": round(tg_ms / max(tg_n, 1), 3),
-                             "flat_rerank_kernel": round(rr_ms / max(rr_n, 1), 3),
-                             "convert_f16_query+norms": round(cv_ms / max(cv_n, 1), 3),
-                             "select_k_kernel": round(sel_ms / max(sel_n, 1), 3)},
+        "other_kernels_ms": others,
         "filter_overflow_queries": int(n_overflow),
     }
     if world == 1:
+        # the same search handed pageable host buffers (queries H2D, results D2H inside the timed region)
+        Dh = np.empty((NQ, K), dtype=np.float32)
+        Ih = np.empty((NQ, K), dtype=np.int64)
+        dt_host = time_search(index, torch, NQ, xq.ctypes.data, Dh.ctypes.data, Ih.ctypes.data, max(3, args.steps // 2), 1)
+        line["value_host_buffers"] = round(NQ / dt_host, 1)
+        line["ms_per_step_host_buffers"] = round(dt_host * 1e3, 3)
+        assert np.array_equal(Ih, gI) and np.array_equal(Dh, gD)
         if not args.no_cpu_baseline:
             try:
-                line["cpu_baseline"] = cpu_baseline(xb, xq, K, gD, gI)
+                line["cpu_baseline"] = cpu_baseline_flat(xb, xq, K, gD, gI)
                 line["recall_at_1"] = line["cpu_baseline"].get("parity_vs_gpu", {}).get("recall_at_1")
             except Exception as e:  # noqa: BLE001
                 line["cpu_baseline"] = {"error": repr(e)[:200]}
-        if not args.no_ivfpq:
-            try:
-                line["ivfpq"], _ = ivfpq_leg(res, xt, xb, xq_dev, gI[:, 0], max(1, args.steps // 2), 1, torch,
-                                             with_cpu=not args.no_cpu_baseline)
-            except Exception as e:  # noqa: BLE001
-                line["ivfpq"] = {"error": repr(e)[:300]}
+        if not args.no_ivf:
+            for kind in ("ivfpq", "ivfflat"):
+                try:
+                    line[kind], _ = ivf_leg(kind, res, xt, xb, xq, xq_dev, gI[:, 0], max(2, args.steps // 2), torch,
+                                            with_cpu=not args.no_cpu_baseline)
+                except Exception as e:  # noqa: BLE001
+                    line[kind] = {"error": repr(e)[:300]}
+    elif ivfpq_multi is not None:
+        if ivf_out is not None:
+            I2 = ivf_out[1].cpu().numpy()
+            ivfpq_multi["recall_at_1"] = round(float((I2[:, 0] == gI[:, 0]).mean()), 4)
+            ivfpq_multi["recall_at_100"] = round(float((I2 == gI[:, :1]).any(axis=1).mean()), 4)
+        line["ivfpq"] = ivfpq_multi
     print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

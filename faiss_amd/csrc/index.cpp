@@ -878,7 +878,7 @@ void GpuIndexIVF::upload_list_tables_() {
 void GpuIndexIVF::ensure_arena_(int64_t rows) {
     rows = std::max<int64_t>(rows, 64);
     if (rows <= arena_cap_rows_ && arena_.p) return;
-    int64_t ncap = std::max<int64_t>(rows, arena_cap_rows_ + arena_cap_rows_ / 2);
+    int64_t ncap = std::max<int64_t>(rows, arena_cap_rows_ + arena_cap_rows_ / 4);
     ncap = (int64_t)round_up((size_t)ncap, 64);
     const size_t keep = (size_t)arena_rows_;
     // DevBuf::ensure grows to max(bytes, 1.5 cap): ask for exactly ncap rows of each array
@@ -969,7 +969,7 @@ void GpuIndexIVF::add_with_ids(idx_t n, const float* x, const idx_t* xids) {
 }
 
 // Lists that outgrow their slack move to fresh rows at the end of the arena (geometric capacity); the abandoned
-// range becomes a hole that compact_() reclaims once holes make up half of the arena.  Per call O(nlist) host work
+// range becomes a hole that compact_() reclaims once holes and slack exceed 60 % of the stored rows.  Per call O(nlist) host work
 // + the moved bytes (amortised O(1) per added vector), instead of round 1's rebuild of the whole arena.
 void GpuIndexIVF::grow_lists_(const std::vector<uint32_t>& new_len, const std::vector<double>* est) {
     std::vector<IvfMoveJob> jobs;
@@ -1113,7 +1113,9 @@ void GpuIndexIVF::add_core_(idx_t n, const float* x, const idx_t* xids) {
         ntotal += ni;
         R.sync(); // the staging buffers are reused by the next page
     }
-    if (hole_rows_ > arena_rows_ / 2 && arena_rows_ > ((int64_t)1 << 16)) compact_();
+    // holes + slack beyond 60 % of the stored rows: rebuild without holes (amortised: the stored rows grew by a
+    // constant factor since the last rebuild)
+    if (arena_rows_ > ((int64_t)1 << 16) && (double)arena_rows_ > 1.6 * (double)nstored_ + 2.0 * granule_ * nlist) compact_();
 }
 
 void GpuIndexIVF::set_lists(const uint32_t* list_sizes, const uint8_t* codes, const idx_t* ids) {

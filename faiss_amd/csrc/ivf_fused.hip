@@ -203,8 +203,32 @@ __device__ __forceinline__ void fused_finish(const IvfFusedParams& p, int q, int
         w_id[i] = wi;
     }
     __syncthreads();
-    wg_bitonic_sort<FB>(w_key, w_id, p.kp);
     const float pad = neutral_distance(p.metric);
+    if (p.kp <= 256) {
+        // n <= 256 winners: every thread ranks one of them against all others (broadcast LDS reads) and writes it
+        // straight to its place -- no barrier ladder of a sorting network
+        for (int i = tid; i < p.k; i += FB) {
+            if (i < n) {
+                const unsigned ki = w_key[i];
+                const int64_t ii = w_id[i];
+                int rank = 0;
+                for (int j2 = 0; j2 < n; ++j2) {
+                    const unsigned kj = w_key[j2];
+                    const int64_t ij = w_id[j2];
+                    // (duplicate user ids are legal: the slot index breaks the last tie)
+                    rank += (kj < ki || (kj == ki && (ij < ii || (ij == ii && j2 < i)))) ? 1 : 0;
+                }
+                const bool ok = ki < kInvalidOrdKey;
+                p.out_dis[(int64_t)q * p.k + rank] = ok ? unordkey_rt(p.metric, ki) : pad;
+                p.out_ids[(int64_t)q * p.k + rank] = ok ? ii : -1;
+            } else {
+                p.out_dis[(int64_t)q * p.k + i] = pad;
+                p.out_ids[(int64_t)q * p.k + i] = -1;
+            }
+        }
+        return;
+    }
+    wg_bitonic_sort<FB>(w_key, w_id, p.kp);
     for (int i = tid; i < p.k; i += FB) {
         float dis = pad;
         int64_t id = -1;
@@ -273,22 +297,21 @@ __global__ void __launch_bounds__(FB) ivfpq_fused_kernel(IvfFusedParams p) {
     };
     if (M64 && dsub == 2) {
         // entries e = tid + u * FB of the [256][64] table: sub-quantizer e & 63 = tid & 63 for all of them (FB is a
-        // multiple of 64), so the query slice and the running maximum stay in registers; eight independent 8-byte
-        // codebook loads in flight per lane
+        // multiple of 64), so the query slice and the running maximum stay in registers
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         constexpr int NE = 16384 / FB;
         const float r0 = L.rs[2 * (tid & 63)], r1 = L.rs[2 * (tid & 63) + 1];
         float v[NE];
         float mx = 0.f;
+        {
+            // every codebook load of this lane in flight before the first is consumed: one L2 round trip per query
+            f32x2 c[NE];
 #pragma unroll
-        for (int u0 = 0; u0 < NE; u0 += 8) {
-            f32x2 c[8];
+            for (int u = 0; u < NE; ++u) c[u] = *(const f32x2*)(p.pq_t + (size_t)(tid + u * FB) * 2);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) c[u] = *(const f32x2*)(p.pq_t + (size_t)(tid + (u0 + u) * FB) * 2);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                v[u0 + u] = __fmaf_rn(r1, c[u][1], __fmaf_rn(r0, c[u][0], 0.f));
-                const float a = fabsf(v[u0 + u]);
+            for (int u = 0; u < NE; ++u) {
+                v[u] = __fmaf_rn(r1, c[u][1], __fmaf_rn(r0, c[u][0], 0.f));
+                const float a = fabsf(v[u]);
                 mx = (a > mx || a != a) ? a : mx; // NaN sticks
             }
         }

@@ -190,6 +190,44 @@ class RefIndex:
     def reset(self):
         self._ck(self.lib.ref_index_reset(ctypes.c_void_p(self.h)))
 
+    def search_nprobe(self, x, k, nprobe):
+        """index.search(x, k, params=SearchParametersIVF(nprobe=nprobe))"""
+        x = _f32(x)
+        D = np.empty((x.shape[0], k), dtype=np.float32)
+        I = np.empty((x.shape[0], k), dtype=np.int64)
+        self._ck(self.lib.ref_index_search_nprobe(ctypes.c_void_p(self.h), ctypes.c_int64(x.shape[0]), _p(x),
+                                                  ctypes.c_int64(k), ctypes.c_int(nprobe), _p(D), _p(I)))
+        return D, I
+
+    def assign(self, x, k=1):
+        x = _f32(x)
+        I = np.empty((x.shape[0], k), dtype=np.int64)
+        self._ck(self.lib.ref_index_assign(ctypes.c_void_p(self.h), ctypes.c_int64(x.shape[0]), _p(x), _p(I),
+                                           ctypes.c_int64(k)))
+        return I
+
+    def reconstruct_n(self, i0, ni):
+        out = np.empty((ni, self.d), dtype=np.float32)
+        self._ck(self.lib.ref_index_reconstruct_n(ctypes.c_void_p(self.h), ctypes.c_int64(i0), ctypes.c_int64(ni), _p(out)))
+        return out
+
+    def compute_residual_n(self, x, keys):
+        x = _f32(x)
+        keys = np.ascontiguousarray(keys, dtype=np.int64)
+        out = np.empty_like(x)
+        self._ck(self.lib.ref_index_compute_residual_n(ctypes.c_void_p(self.h), ctypes.c_int64(x.shape[0]), _p(x), _p(out),
+                                                       _p(keys)))
+        return out
+
+    def type_name(self):
+        buf = ctypes.create_string_buffer(256)
+        self._ck(self.lib.ref_index_type(ctypes.c_void_p(self.h), buf, ctypes.c_int(256)))
+        return buf.value.decode()
+
+    @property
+    def is_trained(self):
+        return bool(self.lib.ref_index_is_trained(ctypes.c_void_p(self.h)))
+
     @property
     def ntotal(self):
         return self.lib.ref_index_ntotal(ctypes.c_void_p(self.h))
@@ -266,7 +304,6 @@ class Ref:
             lib.ref_index_factory.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
             lib.ref_last_error.restype = ctypes.c_char_p
             lib.ref_index_ntotal.restype = ctypes.c_int64
-            lib.ref_amd_adapter_new.restype = ctypes.c_void_p
             lib.ref_shards_new.restype = ctypes.c_void_p
             cls._lib = lib
         return cls._lib
@@ -305,20 +342,61 @@ class Ref:
 
     # ---- drop-in proof: the reference's own callers running on a faiss_amd handle
     @classmethod
-    def adapter(cls, amd_index):
-        """Wrap a faiss_amd.Index handle into a faiss::Index subclass living in the reference
-        library (oracle/ref_shim.cpp AmdIndexAdapter)."""
-        import faiss_amd
-        L = faiss_amd.load_library()
-        fp = lambda name: ctypes.cast(getattr(L, name), ctypes.c_void_p)
-        h = cls.lib().ref_amd_adapter_new(
-            ctypes.c_int(amd_index.d), ctypes.c_int(amd_index.metric_type), amd_index._h,
-            fp("faiss_amd_Index_add"), fp("faiss_amd_Index_add_with_ids"), fp("faiss_amd_Index_search"),
-            fp("faiss_amd_Index_reset"), fp("faiss_amd_Index_train"), fp("faiss_amd_Index_ntotal"),
-            fp("faiss_amd_Index_is_trained"), fp("faiss_amd_get_last_error"))
-        r = RefIndex(cls.lib(), h, amd_index.d)
-        r._keep = amd_index
+    def _wrap_ptr(cls, h, d, keep=None):
+        if not h:
+            raise RuntimeError("reference error: " + cls.lib().ref_last_error().decode())
+        r = RefIndex(cls.lib(), h, d)
+        r._keep = keep
         return r
+
+    @classmethod
+    def adapter(cls, amd_index):
+        """Wrap a faiss_amd.Index handle into the bridge's faiss::Index subclass living in the reference library
+        (integration/faiss_amd_bridge.h AmdIndex / AmdIndexIVF; the handle stays owned by `amd_index`)."""
+        cls.lib().ref_amd_wrap.restype = ctypes.c_void_p
+        return cls._wrap_ptr(cls.lib().ref_amd_wrap(amd_index._h), amd_index.d, amd_index)
+
+    @classmethod
+    def amd_resources(cls, device=0):
+        """faiss::amd::AmdGpuResources of the bridge (an opaque pointer; freed with amd_resources_free)"""
+        cls.lib().ref_amd_resources_new.restype = ctypes.c_void_p
+        r = cls.lib().ref_amd_resources_new(ctypes.c_int(device))
+        if not r:
+            raise RuntimeError("reference error: " + cls.lib().ref_last_error().decode())
+        return r
+
+    @classmethod
+    def amd_resources_free(cls, r):
+        cls.lib().ref_amd_resources_free(ctypes.c_void_p(r))
+
+    @classmethod
+    def index_cpu_to_gpu(cls, res, cpu_index):
+        """faiss::amd::index_cpu_to_gpu(res, index) of the bridge -> RefIndex over the new backend index"""
+        cls.lib().ref_amd_index_cpu_to_gpu.restype = ctypes.c_void_p
+        return cls._wrap_ptr(cls.lib().ref_amd_index_cpu_to_gpu(ctypes.c_void_p(res), ctypes.c_void_p(cpu_index.h)),
+                             cpu_index.d, [cpu_index])
+
+    @classmethod
+    def index_cpu_to_gpu_multiple(cls, res_list, cpu_index, shard=False, shard_type=1, common_ivf_quantizer=False):
+        cls.lib().ref_amd_index_cpu_to_gpu_multiple.restype = ctypes.c_void_p
+        arr = (ctypes.c_void_p * len(res_list))(*res_list)
+        h = cls.lib().ref_amd_index_cpu_to_gpu_multiple(arr, ctypes.c_int(len(res_list)), ctypes.c_void_p(cpu_index.h),
+                                                        ctypes.c_int(int(shard)), ctypes.c_int(shard_type),
+                                                        ctypes.c_int(int(common_ivf_quantizer)))
+        return cls._wrap_ptr(h, cpu_index.d, [cpu_index])
+
+    @classmethod
+    def index_gpu_to_cpu(cls, gpu_index):
+        cls.lib().ref_amd_index_gpu_to_cpu.restype = ctypes.c_void_p
+        return cls._wrap_ptr(cls.lib().ref_amd_index_gpu_to_cpu(ctypes.c_void_p(gpu_index.h)), gpu_index.d, [gpu_index])
+
+    @classmethod
+    def ivfflat_with_quantizer(cls, quantizer, d, nlist, metric=METRIC_L2):
+        """a reference faiss::IndexIVFFlat whose coarse quantizer is `quantizer` (any RefIndex, e.g. Ref.adapter(...))"""
+        cls.lib().ref_ivfflat_with_quantizer.restype = ctypes.c_void_p
+        h = cls.lib().ref_ivfflat_with_quantizer(ctypes.c_void_p(quantizer.h), ctypes.c_int(d), ctypes.c_int(nlist),
+                                                 ctypes.c_int(metric))
+        return cls._wrap_ptr(h, d, [quantizer])
 
     @classmethod
     def kmeans_with_index(cls, x, k, ref_index, niter=25, seed=1234):

@@ -4,11 +4,12 @@
 // TEST INFRASTRUCTURE ONLY: loaded by tests/ and by bench.py's cpu_baseline leg.  This file
 // is our own code; it includes the reference's public headers and calls its public API.
 //
-// Besides the oracle calls it contains the drop-in proof: `AmdIndexAdapter`, a faiss::Index
-// subclass that forwards add/search/reset to a faiss_amd C-ABI handle (function pointers are
-// handed in by the caller, so this library does not link against HIP).  With it the reference's
-// own callers of the hot path -- faiss::Clustering::train (faiss/Clustering.cpp:255-357) and
-// faiss::IndexShards (faiss/IndexShards.cpp:135-265) -- run unchanged on the MI355X backend.
+// Besides the oracle calls it compiles the drop-in proof: integration/faiss_amd_bridge.h, the reference-side
+// binding of the backend (faiss::Index / IndexIVFInterface subclasses over the C ABI + the cloner functions), against
+// the unmodified reference headers, and exposes it to the tests.  With it the reference's own callers of the hot
+// path -- faiss::Clustering::train (faiss/Clustering.cpp:255-357), faiss::IndexShards (faiss/IndexShards.cpp:135-265),
+// faiss::IndexShardsIVF, faiss::IndexReplicas, faiss::IndexIVF with the backend as coarse quantizer
+// (faiss/IndexIVF.cpp:194,336-342) -- run unchanged on the MI355X backend.  (This library links libfaiss_amd.so.)
 #include <faiss/Clustering.h>
 #include <faiss/Index.h>
 #include <faiss/IndexFlat.h>
@@ -20,6 +21,7 @@
 #include <faiss/impl/FaissException.h>
 #include <faiss/utils/distances.h>
 #include <omp.h>
+#include "../integration/faiss_amd_bridge.h"
 #include <cstring>
 #include <string>
 
@@ -34,58 +36,6 @@ static thread_local std::string g_err;
         return -1;            \
     }                         \
     return 0;
-
-// ---------------------------------------------------------------- adapter (drop-in boundary)
-typedef int (*amd_add_fn)(void*, int64_t, const float*);
-typedef int (*amd_add_ids_fn)(void*, int64_t, const float*, const int64_t*);
-typedef int (*amd_search_fn)(const void*, int64_t, const float*, int64_t, float*, int64_t*);
-typedef int (*amd_reset_fn)(void*);
-typedef int (*amd_train_fn)(void*, int64_t, const float*);
-typedef int64_t (*amd_ntotal_fn)(const void*);
-typedef int (*amd_trained_fn)(const void*);
-typedef const char* (*amd_err_fn)(void);
-
-struct AmdIndexAdapter : faiss::Index {
-    void* h;
-    amd_add_fn f_add;
-    amd_add_ids_fn f_add_ids;
-    amd_search_fn f_search;
-    amd_reset_fn f_reset;
-    amd_train_fn f_train;
-    amd_ntotal_fn f_ntotal;
-    amd_trained_fn f_trained;
-    amd_err_fn f_err;
-
-    AmdIndexAdapter(int d_, faiss::MetricType m) : faiss::Index(d_, m) {}
-    void check(int rc) const {
-        if (rc != 0) FAISS_THROW_MSG(f_err ? f_err() : "faiss_amd error");
-    }
-    void sync() {
-        ntotal = f_ntotal(h);
-        is_trained = f_trained(h) != 0;
-    }
-    void train(idx_t n, const float* x) override {
-        check(f_train(h, n, x));
-        sync();
-    }
-    void add(idx_t n, const float* x) override {
-        check(f_add(h, n, x));
-        sync();
-    }
-    void add_with_ids(idx_t n, const float* x, const idx_t* xids) override {
-        check(f_add_ids(h, n, x, xids));
-        sync();
-    }
-    void search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels,
-                const faiss::SearchParameters* params = nullptr) const override {
-        FAISS_THROW_IF_NOT_MSG(!params, "search params not supported");
-        check(f_search(h, n, x, k, distances, labels));
-    }
-    void reset() override {
-        check(f_reset(h));
-        sync();
-    }
-};
 
 extern "C" {
 
@@ -268,21 +218,102 @@ int ref_kmeans(int d, idx_t n, int k, const float* x, int niter, int seed, float
     SHIM_CATCH
 }
 
-// ------------------------------------------------------------ drop-in: adapter over the C ABI
-void* ref_amd_adapter_new(int d, int metric, void* handle, void* f_add, void* f_add_ids, void* f_search,
-                          void* f_reset, void* f_train, void* f_ntotal, void* f_trained, void* f_err) {
-    auto* a = new AmdIndexAdapter(d, (faiss::MetricType)metric);
-    a->h = handle;
-    a->f_add = (amd_add_fn)f_add;
-    a->f_add_ids = (amd_add_ids_fn)f_add_ids;
-    a->f_search = (amd_search_fn)f_search;
-    a->f_reset = (amd_reset_fn)f_reset;
-    a->f_train = (amd_train_fn)f_train;
-    a->f_ntotal = (amd_ntotal_fn)f_ntotal;
-    a->f_trained = (amd_trained_fn)f_trained;
-    a->f_err = (amd_err_fn)f_err;
-    a->sync();
-    return (faiss::Index*)a;
+// ------------------------------------------------------------ drop-in: the bridge over the C ABI
+// a faiss::Index view of a backend handle the caller keeps owning
+void* ref_amd_wrap(void* handle) {
+    try {
+        auto* h = (FaissAmdIndex*)handle;
+        int nlist = 0;
+        if (faiss_amd_IndexIVF_nlist(h, &nlist) == 0) {
+            auto* a = new faiss::amd::AmdIndexIVF(h, (size_t)nlist);
+            a->own_handle = false;
+            int np = 1;
+            faiss_amd_IndexIVF_nprobe(h, &np);
+            a->nprobe = np;
+            return (faiss::Index*)a;
+        }
+        return (faiss::Index*)new faiss::amd::AmdIndex(h, false);
+    } catch (std::exception& e) {
+        g_err = e.what();
+        return nullptr;
+    }
+}
+void* ref_amd_resources_new(int device) {
+    try {
+        return new faiss::amd::AmdGpuResources(device);
+    } catch (std::exception& e) {
+        g_err = e.what();
+        return nullptr;
+    }
+}
+void ref_amd_resources_free(void* r) {
+    delete (faiss::amd::AmdGpuResources*)r;
+}
+// index_cpu_to_gpu / index_cpu_to_gpu_multiple / index_gpu_to_cpu of the bridge
+void* ref_amd_index_cpu_to_gpu(void* res, void* cpu_index) {
+    try {
+        return faiss::amd::index_cpu_to_gpu((faiss::amd::AmdGpuResources*)res, (const faiss::Index*)cpu_index);
+    } catch (std::exception& e) {
+        g_err = e.what();
+        return nullptr;
+    }
+}
+void* ref_amd_index_cpu_to_gpu_multiple(void** res, int nres, void* cpu_index, int shard, int shard_type,
+                                        int common_ivf_quantizer) {
+    try {
+        std::vector<faiss::amd::AmdGpuResources*> v;
+        for (int i = 0; i < nres; i++) v.push_back((faiss::amd::AmdGpuResources*)res[i]);
+        faiss::amd::AmdClonerOptions opt;
+        opt.shard = shard != 0;
+        opt.shard_type = shard_type;
+        opt.common_ivf_quantizer = common_ivf_quantizer != 0;
+        return faiss::amd::index_cpu_to_gpu_multiple(v, (const faiss::Index*)cpu_index, &opt);
+    } catch (std::exception& e) {
+        g_err = e.what();
+        return nullptr;
+    }
+}
+void* ref_amd_index_gpu_to_cpu(void* gpu_index) {
+    try {
+        return faiss::amd::index_gpu_to_cpu((const faiss::Index*)gpu_index);
+    } catch (std::exception& e) {
+        g_err = e.what();
+        return nullptr;
+    }
+}
+// a reference IndexIVFFlat whose coarse quantizer is ANY faiss::Index* (e.g. a backend flat index): the caller of
+// quantizer->search / assign (faiss/IndexIVF.cpp:194, 336-342)
+void* ref_ivfflat_with_quantizer(void* quantizer, int d, int nlist, int metric) {
+    try {
+        return (faiss::Index*)new faiss::IndexIVFFlat((faiss::Index*)quantizer, d, nlist, (faiss::MetricType)metric);
+    } catch (std::exception& e) {
+        g_err = e.what();
+        return nullptr;
+    }
+}
+int ref_index_search_nprobe(void* p, idx_t n, const float* x, idx_t k, int nprobe, float* D, idx_t* I) {
+    SHIM_TRY faiss::SearchParametersIVF sp;
+    sp.nprobe = nprobe;
+    ((faiss::Index*)p)->search(n, x, k, D, I, &sp);
+    SHIM_CATCH
+}
+int ref_index_assign(void* p, idx_t n, const float* x, idx_t* labels, idx_t k) {
+    SHIM_TRY((faiss::Index*)p)->assign(n, x, labels, k);
+    SHIM_CATCH
+}
+int ref_index_reconstruct_n(void* p, idx_t i0, idx_t ni, float* out) {
+    SHIM_TRY((faiss::Index*)p)->reconstruct_n(i0, ni, out);
+    SHIM_CATCH
+}
+int ref_index_compute_residual_n(void* p, idx_t n, const float* x, float* res, const idx_t* keys) {
+    SHIM_TRY((faiss::Index*)p)->compute_residual_n(n, x, res, keys);
+    SHIM_CATCH
+}
+int ref_index_type(void* p, char* out, int cap) {
+    SHIM_TRY const char* name = typeid(*(faiss::Index*)p).name();
+    strncpy(out, name, cap - 1);
+    out[cap - 1] = 0;
+    SHIM_CATCH
 }
 // faiss::Clustering::train driving ANY faiss::Index* (e.g. an adapter) as assignment engine
 int ref_kmeans_with_index(int d, idx_t n, int k, const float* x, int niter, int seed, void* index,

@@ -67,6 +67,63 @@ def test_sharded_search_two_ranks_gloo(tmp_path, metric):
     assert open(out).read() == "OK"
 
 
+def _ivf_shard_worker(rank, world, port, kind, out_path):
+    """IndexShards over IVF indexes that share one trained coarse quantizer (+ PQ codebook): what
+    index_cpu_to_gpu_multiple(shard=True) builds (faiss/gpu/GpuCloner.cpp:325-439) and bench.py's multi-GPU IVFPQ leg
+    runs, one process per shard.  Rank 0 'trains' and broadcasts the quantizers (the only collective), every rank
+    adds its row range with GLOBAL ids, searches all queries on its shard (oracle restatement in the role of the
+    device), the per-rank top-k are gathered and merged on rank 0 without label translation."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import faiss_amd
+    from faiss_amd.distributed import ShardedSearcher, shard_bounds
+    from oracle.pyoracle import METRIC_L2, Oracle, synthetic_dataset
+
+    d, nlist, M, nb, nq, k, nprobe = 32, 16, 8, 6001, 41, 20, 5
+    xt, xb, xq = synthetic_dataset(d, 500, nb, nq, seed=9)
+    cent = torch.zeros((nlist, d), dtype=torch.float32)
+    pq = torch.zeros((M, 256, d // M), dtype=torch.float32)
+    if rank == 0:
+        rs = np.random.RandomState(1)
+        cent.copy_(torch.from_numpy(xt[rs.choice(len(xt), nlist, replace=False)]))
+        pq.copy_(torch.from_numpy(((rs.rand(M, 256, d // M) - 0.5) * 0.6).astype(np.float32)))
+    dist.broadcast(cent, 0)
+    dist.broadcast(pq, 0)
+    cent_np, pq_np = cent.numpy(), (pq.numpy() if kind == 1 else None)
+    lo, hi = shard_bounds(nb, world)[rank]
+    sizes, codes, ids, _ = Oracle.build_ivf_lists(kind, METRIC_L2, cent_np, xb[lo:hi], ids=np.arange(lo, hi), pq=pq_np)
+
+    def local_search(xq_t, kk):
+        D, I, _, _ = Oracle.ivf_search(kind, METRIC_L2, cent_np, sizes, codes, ids, xq_t.numpy(), nprobe, kk,
+                                       M=M if kind else 0, pq=pq_np)
+        return torch.from_numpy(D), torch.from_numpy(I)
+
+    def merge(aD, aI, _base):
+        D, I = faiss_amd.merge_knn_results(METRIC_L2, aD.numpy(), aI.numpy(), None)  # ids are global already
+        return torch.from_numpy(D), torch.from_numpy(I)
+
+    s = ShardedSearcher(local_search, merge, [0] * world, torch.device("cpu"))
+    out = s.search(torch.from_numpy(xq), k)
+    if rank == 0:
+        fs, fc, fi, _ = Oracle.build_ivf_lists(kind, METRIC_L2, cent_np, xb, pq=pq_np)
+        Df, If, _, _ = Oracle.ivf_search(kind, METRIC_L2, cent_np, fs, fc, fi, xq, nprobe, k, M=M if kind else 0, pq=pq_np)
+        # faiss/gpu/test/test_multi_gpu.py:74-90: np.testing.assert_array_equal(Iref, Inew)
+        ok = np.array_equal(out[1].numpy(), If) and np.array_equal(out[0].numpy(), Df)
+        with open(out_path, "w") as f:
+            f.write("OK" if ok else "MISMATCH")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_sharded_ivf_two_ranks_gloo(tmp_path, kind):
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_ivf_shard_worker, args=(2, _free_port(), kind, out), nprocs=2, join=True)
+    assert open(out).read() == "OK"
+
+
 def test_shard_bounds_match_reference_split():
     from faiss_amd.distributed import shard_bounds
     # IndexShards::add: shard `no` gets rows [no*n/nshard, (no+1)*n/nshard) (faiss/IndexShards.cpp:172-175)

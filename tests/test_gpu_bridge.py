@@ -1,0 +1,129 @@
+"""GPU tests of the reference-side binding (integration/faiss_amd_bridge.h, compiled against the unmodified reference in
+oracle/_ref): faiss::Index / IndexIVFInterface subclasses over the C ABI and the cloner functions
+index_cpu_to_gpu / index_cpu_to_gpu_multiple / index_gpu_to_cpu (faiss/gpu/GpuCloner.cpp:43-522).  Everything here is
+driven from the REFERENCE side: reference CPU indexes are built by the reference, cloned onto the backend by the bridge,
+searched through faiss::Index::search, and cloned back.  Test pattern: faiss/gpu/test/TestGpuIndexIVFPQ.cpp:149-330
+(copyFrom / copyTo), faiss/gpu/test/test_multi_gpu.py:15-98 (sharded == unsharded ids)."""
+import numpy as np
+import pytest
+
+import faiss_amd
+from compare import check_knn
+from oracle.pyoracle import METRIC_INNER_PRODUCT, METRIC_L2, Ref, synthetic_dataset
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not Ref.available(), reason="oracle/_ref not shipped")]
+
+
+@pytest.fixture(scope="module")
+def bres():
+    rs = [Ref.amd_resources(0) for _ in range(3)]
+    yield rs
+    for r in rs:
+        Ref.amd_resources_free(r)
+
+
+def _cpu_index(desc, d, xt, xb, metric=METRIC_L2, nprobe=8):
+    r = Ref.index_factory(d, desc, metric)
+    if "IVF" in desc:
+        r.set_train_niter(5, 6)
+        r.train(xt)
+        r.set_nprobe(nprobe)
+    r.add(xb)
+    return r
+
+
+@pytest.mark.parametrize("desc,metric", [("Flat", METRIC_L2), ("Flat", METRIC_INNER_PRODUCT), ("IVF64,Flat", METRIC_L2),
+                                         ("IVF64,PQ16", METRIC_L2), ("IVF64,PQ16", METRIC_INNER_PRODUCT)])
+def test_index_cpu_to_gpu_and_back(bres, desc, metric):
+    d, k = 64, 20
+    xt, xb, xq = synthetic_dataset(d, 4000, 20000, 300, seed=41)
+    cpu = _cpu_index(desc, d, xt, xb, metric)
+    Dr, Ir = cpu.search(xq, k)
+    gpu = Ref.index_cpu_to_gpu(bres[0], cpu)
+    assert "Amd" in gpu.type_name() and gpu.ntotal == len(xb) and gpu.is_trained
+    D, I = gpu.search(xq, k)
+    check_knn(D, I, Dr, Ir, rtol=1e-4, name=desc + " cloned to the backend")
+    # and back: the CPU copy holds the same lists, so the reference's own search reproduces its first answer exactly
+    back = Ref.index_gpu_to_cpu(gpu)
+    assert back.ntotal == len(xb)
+    if "IVF" in desc:
+        back.set_nprobe(8)
+        s0, c0, i0 = cpu.lists()
+        s1, c1, i1 = back.lists()
+        assert np.array_equal(s0, s1) and np.array_equal(i0, i1) and np.array_equal(c0, c1)
+        assert np.array_equal(back.centroids(), cpu.centroids())
+    Db, Ib = back.search(xq, k)
+    assert np.array_equal(Ib, Ir) and np.array_equal(Db, Dr)
+    # incremental use of the clone through faiss::Index::add
+    gpu.add(xb[:100])
+    assert gpu.ntotal == len(xb) + 100
+
+
+def test_search_parameters_and_ivf_surface_through_the_bridge(bres):
+    d, k = 64, 10
+    xt, xb, xq = synthetic_dataset(d, 4000, 20000, 100, seed=42)
+    cpu = _cpu_index("IVF64,Flat", d, xt, xb, nprobe=2)
+    gpu = Ref.index_cpu_to_gpu(bres[0], cpu)
+    D2, I2 = gpu.search(xq, k)  # nprobe = 2 copied from the CPU index
+    check_knn(D2, I2, *cpu.search(xq, k), rtol=1e-4, name="nprobe 2")
+    D16, I16 = gpu.search_nprobe(xq, k, 16)  # SearchParametersIVF.nprobe
+    cpu.set_nprobe(16)
+    check_knn(D16, I16, *cpu.search(xq, k), rtol=1e-4, name="params nprobe 16")
+    assert not np.array_equal(I2, I16)
+
+
+def test_reference_ivfflat_on_backend_coarse_quantizer(res):
+    """faiss::IndexIVFFlat with an AmdIndex as its quantizer: IndexIVF::add (quantizer->assign, IndexIVF.cpp:194) and
+    IndexIVF::search (quantizer->search, :336-342) run on the backend; lists and results equal the all-CPU index built
+    on the same centroids (up to coarse near-ties)."""
+    d, nlist, k = 48, 64, 10
+    xt, xb, xq = synthetic_dataset(d, 4000, 15000, 200, seed=43)
+    cpu = _cpu_index("IVF64,Flat", d, xt, xb, nprobe=6)
+    cent = cpu.centroids()
+    amd_q = faiss_amd.GpuIndexFlatL2(res, d)
+    q = Ref.adapter(amd_q)
+    q.add(cent)  # a trained quantizer: IndexIVF::train leaves it alone (quantizer->ntotal == nlist)
+    assert amd_q.ntotal == nlist
+    hybrid = Ref.ivfflat_with_quantizer(q, d, nlist)
+    assert hybrid.is_trained
+    hybrid.add(xb)
+    hybrid.set_nprobe(6)
+    s0, c0, i0 = cpu.lists()
+    s1, c1, i1 = hybrid.lists()
+    assert np.abs(s0.astype(np.int64) - s1.astype(np.int64)).sum() <= 4
+    D, I = hybrid.search(xq, k)
+    check_knn(D, I, *cpu.search(xq, k), rtol=1e-4, tie_rtol=1e-4, name="IVFFlat over a backend quantizer")
+    # the rest of the surface a quantizer is used through (faiss/Index.h:268, 297-307, 363-383)
+    lab = q.assign(xq)
+    assert np.array_equal(lab, amd_q.assign(xq))
+    assert np.array_equal(q.reconstruct_n(3, 5), cent[3:8])
+    keys = lab[:, 0]
+    assert np.array_equal(q.compute_residual_n(xq, keys), xq - cent[keys])
+
+
+@pytest.mark.parametrize("desc", ["Flat", "IVF64,Flat", "IVF64,PQ16"])
+@pytest.mark.parametrize("mode", ["replicas", "shards1", "shards2", "shards4", "shards_ivf"])
+def test_index_cpu_to_gpu_multiple(bres, desc, mode):
+    """faiss/gpu/test/test_multi_gpu.py:15-98: the multi-device clone answers like the CPU index (ids exactly, up to
+    distance near-ties), whatever the layout: replicas, shards by id modulo / id range / list range, and one common
+    coarse quantizer (IndexShardsIVF -> search_preassigned on every shard)."""
+    if desc == "Flat" and mode in ("shards1", "shards4", "shards_ivf"):
+        pytest.skip("IVF-only shard types")
+    d, k = 64, 15
+    xt, xb, xq = synthetic_dataset(d, 4000, 20000, 150, seed=44)
+    cpu = _cpu_index(desc, d, xt, xb)
+    Dr, Ir = cpu.search(xq, k)
+    kw = dict(replicas=dict(shard=False), shards1=dict(shard=True, shard_type=1), shards2=dict(shard=True, shard_type=2),
+              shards4=dict(shard=True, shard_type=4), shards_ivf=dict(shard=True, shard_type=1, common_ivf_quantizer=True))[mode]
+    multi = Ref.index_cpu_to_gpu_multiple(bres, cpu, **kw)
+    assert multi.ntotal == len(xb)
+    name = multi.type_name()
+    assert ("Replicas" in name) == (mode == "replicas") and ("ShardsIVF" in name) == (mode == "shards_ivf")
+    D, I = multi.search(xq, k)
+    check_knn(D, I, Dr, Ir, rtol=1e-4, name="%s %s" % (desc, mode))
+    back = Ref.index_gpu_to_cpu(multi)
+    assert back.ntotal == len(xb)
+    if "IVF" in desc:
+        back.set_nprobe(8)
+    Db, Ib = back.search(xq, k)
+    check_knn(Db, Ib, Dr, Ir, rtol=1e-6, name="%s %s back on the CPU" % (desc, mode))
