@@ -99,6 +99,11 @@ def load_library():
         "faiss_amd_GpuIndexIVF_search_preassigned": (i32, [vp, i64, vp, i64, vp, vp, vp, vp]),
         "faiss_amd_IndexIVF_quantizer_search": (i32, [vp, i64, vp, i64, vp, vp]),
         "faiss_amd_bfKnn": (i32, [vp, i32, vp, i64, vp, i64, i32, i64, vp, vp]),
+        "faiss_amd_GpuIndexFlat_new_with_config": (i32, [P(vp), vp, i32, i32, vp]),
+        "faiss_amd_GpuIndexIVFFlat_new_with_config": (i32, [P(vp), vp, i32, i32, i32, vp]),
+        "faiss_amd_GpuIndexIVFPQ_new_with_config": (i32, [P(vp), vp, i32, i32, i32, i32, i32, vp]),
+        "faiss_amd_GpuIndexFlat_resident_bytes": (i32, [vp, P(sz)]),
+        "faiss_amd_test_select": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp]),
         "faiss_amd_GpuIndexIVF_search_with_params": (i32, [vp, i64, vp, i64, vp, vp, vp]),
         "faiss_amd_GpuIndexIVF_stored_vectors": (i32, [vp, P(i64)]),
         "faiss_amd_GpuIndexIVF_arena_stats": (i32, [vp, P(i64), P(i64), P(i64)]),
@@ -269,13 +274,54 @@ class Index:
         return out
 
 
+class GpuIndexFlatConfig(ctypes.Structure):
+    """faiss.GpuIndexFlatConfig (faiss/gpu/GpuIndexFlat.h:24-40 + GpuIndexConfig): device, memorySpace, useFloat16,
+    storeTransposed -- see include/faiss_amd_c.h for what each means on this backend"""
+    _fields_ = [("device", ctypes.c_int), ("memorySpace", ctypes.c_int), ("useFloat16", ctypes.c_int),
+                ("storeTransposed", ctypes.c_int)]
+
+    def __init__(self, device=-1, memorySpace=0, useFloat16=False, storeTransposed=False):
+        super().__init__(int(device), int(memorySpace), int(useFloat16), int(storeTransposed))
+
+
+class GpuIndexIVFConfig(ctypes.Structure):
+    """faiss.GpuIndexIVFConfig / GpuIndexIVFFlatConfig (faiss/gpu/GpuIndexIVF.h:24-38)"""
+    _fields_ = [("device", ctypes.c_int), ("memorySpace", ctypes.c_int), ("indicesOptions", ctypes.c_int),
+                ("flat_useFloat16", ctypes.c_int), ("allowCpuCoarseQuantizer", ctypes.c_int)]
+
+    def __init__(self, device=-1, memorySpace=0, indicesOptions=3, flat_useFloat16=False, allowCpuCoarseQuantizer=False):
+        super().__init__(int(device), int(memorySpace), int(indicesOptions), int(flat_useFloat16),
+                         int(allowCpuCoarseQuantizer))
+
+
+class GpuIndexIVFPQConfig(ctypes.Structure):
+    """faiss.GpuIndexIVFPQConfig (faiss/gpu/GpuIndexIVFPQ.h:25-49)"""
+    _fields_ = [("ivf", GpuIndexIVFConfig), ("useFloat16LookupTables", ctypes.c_int), ("usePrecomputedTables", ctypes.c_int),
+                ("interleavedLayout", ctypes.c_int), ("useMMCodeDistance", ctypes.c_int)]
+
+    def __init__(self, useFloat16LookupTables=False, usePrecomputedTables=False, interleavedLayout=False,
+                 useMMCodeDistance=False, **ivf):
+        super().__init__(GpuIndexIVFConfig(**ivf), int(useFloat16LookupTables), int(usePrecomputedTables),
+                         int(interleavedLayout), int(useMMCodeDistance))
+
+
 class GpuIndexFlat(Index):
     """faiss.GpuIndexFlat (faiss/gpu/GpuIndexFlat.h:41-153)."""
 
-    def __init__(self, res, d, metric=METRIC_L2):
+    def __init__(self, res, d, metric=METRIC_L2, config=None):
         super().__init__()
         self._keep.append(res)
-        _check(self._lib.faiss_amd_GpuIndexFlat_new(ctypes.byref(self._h), res._h, int(d), int(metric)))
+        if config is None:
+            _check(self._lib.faiss_amd_GpuIndexFlat_new(ctypes.byref(self._h), res._h, int(d), int(metric)))
+        else:
+            _check(self._lib.faiss_amd_GpuIndexFlat_new_with_config(ctypes.byref(self._h), res._h, int(d), int(metric),
+                                                                   ctypes.byref(config)))
+
+    @property
+    def resident_bytes(self):
+        v = ctypes.c_size_t(0)
+        _check(self._lib.faiss_amd_GpuIndexFlat_resident_bytes(self._h, ctypes.byref(v)))
+        return v.value
 
     def pairwise_distances(self, x):
         x = _f32(x, self.d)
@@ -307,13 +353,13 @@ class GpuIndexFlat(Index):
 
 
 class GpuIndexFlatL2(GpuIndexFlat):
-    def __init__(self, res, d):
-        super().__init__(res, d, METRIC_L2)
+    def __init__(self, res, d, config=None):
+        super().__init__(res, d, METRIC_L2, config)
 
 
 class GpuIndexFlatIP(GpuIndexFlat):
-    def __init__(self, res, d):
-        super().__init__(res, d, METRIC_INNER_PRODUCT)
+    def __init__(self, res, d, config=None):
+        super().__init__(res, d, METRIC_INNER_PRODUCT, config)
 
 
 class _GpuIndexIVF(Index):
@@ -442,22 +488,23 @@ class SearchParametersIVF:
 class GpuIndexIVFFlat(_GpuIndexIVF):
     """faiss.GpuIndexIVFFlat (faiss/gpu/GpuIndexIVFFlat.h:33-126)."""
 
-    def __init__(self, res, d, nlist, metric=METRIC_L2):
+    def __init__(self, res, d, nlist, metric=METRIC_L2, config=None):
         super().__init__()
         self._keep.append(res)
-        _check(self._lib.faiss_amd_GpuIndexIVFFlat_new(ctypes.byref(self._h), res._h, int(d), int(nlist),
-                                                       int(metric)))
+        _check(self._lib.faiss_amd_GpuIndexIVFFlat_new_with_config(ctypes.byref(self._h), res._h, int(d), int(nlist),
+                                                                   int(metric), ctypes.byref(config) if config else None))
 
 
 class GpuIndexIVFPQ(_GpuIndexIVF):
     """faiss.GpuIndexIVFPQ (faiss/gpu/GpuIndexIVFPQ.h:53-176)."""
 
-    def __init__(self, res, d, nlist, M, nbits=8, metric=METRIC_L2):
+    def __init__(self, res, d, nlist, M, nbits=8, metric=METRIC_L2, config=None):
         super().__init__()
         self._keep.append(res)
         self.M = int(M)
-        _check(self._lib.faiss_amd_GpuIndexIVFPQ_new(ctypes.byref(self._h), res._h, int(d), int(nlist), int(M),
-                                                     int(nbits), int(metric)))
+        _check(self._lib.faiss_amd_GpuIndexIVFPQ_new_with_config(ctypes.byref(self._h), res._h, int(d), int(nlist), int(M),
+                                                                 int(nbits), int(metric),
+                                                                 ctypes.byref(config) if config else None))
 
     def copy_pq_centroids(self, pq):
         pq = np.ascontiguousarray(pq, dtype=np.float32).reshape(-1)
@@ -519,6 +566,20 @@ def knn_gpu(res, xq, xb, k, metric=METRIC_L2):
     _check(lib.faiss_amd_bfKnn(res._h, int(metric), _ptr(xb), xb.shape[0], _ptr(xq), xq.shape[0], xb.shape[1], int(k),
                                _ptr(D), _ptr(I)))
     return D, I
+
+
+def test_select(res, which, vals, k, metric=METRIC_L2):
+    """test hook: k best per row of `vals` through one selection primitive (include/faiss_amd_c.h faiss_amd_test_select)"""
+    lib = load_library()
+    vals = _f32(vals)
+    rows, cols = vals.shape
+    D = np.empty((rows, k), dtype=np.float32)
+    I = np.empty((rows, k), dtype=np.int64)
+    _check(lib.faiss_amd_test_select(res._h, int(which), int(metric), rows, cols, int(k), _ptr(vals), _ptr(D), _ptr(I)))
+    return D, I
+
+
+test_select.__test__ = False  # (not a pytest test)
 
 
 def merge_knn_results(metric, all_D, all_I, base=None):

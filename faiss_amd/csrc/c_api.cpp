@@ -6,6 +6,7 @@
 #include <memory>
 #include <string>
 #include "index.h"
+#include "kernels.h"
 
 using namespace faiss_amd;
 
@@ -27,6 +28,22 @@ static thread_local std::string g_last_error;
         return -1;                                 \
     }                                              \
     return 0;
+
+// same, falling through to the code behind it on success
+#define FA_CATCH_RC                                \
+    }                                              \
+    catch (FaissAmdException & e) {                \
+        g_last_error = e.what();                   \
+        return -2;                                 \
+    }                                              \
+    catch (std::exception & e) {                   \
+        g_last_error = e.what();                   \
+        return -4;                                 \
+    }                                              \
+    catch (...) {                                  \
+        g_last_error = "Unknown error";            \
+        return -1;                                 \
+    }
 
 struct FaissAmdGpuResources_H {
     std::shared_ptr<GpuResources> res;
@@ -151,6 +168,55 @@ int faiss_amd_GpuIndexIVFPQ_new(FaissAmdIndex** p_index, FaissAmdGpuResources* r
         throw;
     }
     *p_index = h;
+    FA_CATCH
+}
+static void check_common_config(const std::shared_ptr<GpuResources>& r, int device, int memorySpace) {
+    FA_THROW_IF_NOT_MSG(device == -1 || device == r->device, "config.device differs from the device of the resources");
+    FA_THROW_IF_NOT_MSG(memorySpace == 0, "only MemorySpace::Device is supported");
+}
+static void check_ivf_config(const std::shared_ptr<GpuResources>& r, const FaissAmdGpuIndexIVFConfig& c) {
+    check_common_config(r, c.device, c.memorySpace);
+    FA_THROW_IF_NOT_MSG(c.indicesOptions == 3 || c.indicesOptions == 2,
+                        "indicesOptions must be INDICES_64_BIT or INDICES_32_BIT (ids live on the device)");
+    FA_THROW_IF_NOT_MSG(!c.flat_useFloat16, "an fp16 coarse quantizer is not supported");
+}
+int faiss_amd_GpuIndexFlat_new_with_config(FaissAmdIndex** p_index, FaissAmdGpuResources* res, int d,
+                                           FaissAmdMetricType metric, const FaissAmdGpuIndexFlatConfig* config) {
+    FA_TRY
+    auto r = R(res);
+    bool f16 = false;
+    if (config) {
+        check_common_config(r, config->device, config->memorySpace);
+        f16 = config->useFloat16 != 0;
+    }
+    auto* h = new FaissAmdIndex_H{nullptr, r};
+    try {
+        h->index = new GpuIndexFlat(r, d, (int)metric, f16);
+    } catch (...) {
+        delete h;
+        throw;
+    }
+    *p_index = h;
+    FA_CATCH
+}
+int faiss_amd_GpuIndexIVFFlat_new_with_config(FaissAmdIndex** p_index, FaissAmdGpuResources* res, int d, int nlist,
+                                              FaissAmdMetricType metric, const FaissAmdGpuIndexIVFConfig* config) {
+    FA_TRY
+    if (config) check_ivf_config(R(res), *config);
+    FA_CATCH_RC
+    return faiss_amd_GpuIndexIVFFlat_new(p_index, res, d, nlist, metric);
+}
+int faiss_amd_GpuIndexIVFPQ_new_with_config(FaissAmdIndex** p_index, FaissAmdGpuResources* res, int d, int nlist, int M,
+                                            int nbits, FaissAmdMetricType metric,
+                                            const FaissAmdGpuIndexIVFPQConfig* config) {
+    FA_TRY
+    if (config) check_ivf_config(R(res), config->ivf);
+    FA_CATCH_RC
+    return faiss_amd_GpuIndexIVFPQ_new(p_index, res, d, nlist, M, nbits, metric);
+}
+int faiss_amd_GpuIndexFlat_resident_bytes(const FaissAmdIndex* index, size_t* p_bytes) {
+    FA_TRY
+    *p_bytes = as<GpuIndexFlat>(index, "GpuIndexFlat")->resident_bytes();
     FA_CATCH
 }
 int faiss_amd_IndexShards_new(FaissAmdIndex** p_index, int d, int threaded, int successive_ids) {
@@ -452,6 +518,27 @@ int faiss_amd_bfKnn(FaissAmdGpuResources* res, FaissAmdMetricType metric, const 
                     faiss_amd_idx_t k, float* out_distances, faiss_amd_idx_t* out_indices) {
     FA_TRY
     bfKnn(R(res), (int)metric, vectors, num_vectors, queries, num_queries, dims, k, out_distances, out_indices);
+    FA_CATCH
+}
+int faiss_amd_test_select(FaissAmdGpuResources* res, int which, FaissAmdMetricType metric, int rows, int cols, int k,
+                          const float* vals, float* out_distances, faiss_amd_idx_t* out_indices) {
+    FA_TRY
+    auto r = R(res);
+    r->set_device();
+    FA_THROW_IF_NOT_MSG(which >= 0 && which <= 2 && rows >= 0 && cols >= 1, "bad arguments");
+    DevBuf dv, dk, dc, dd, di;
+    const size_t n = (size_t)rows * cols;
+    dv.ensure(std::max<size_t>(n * 4, 16));
+    dk.ensure(std::max<size_t>(n * 8, 16));
+    dc.ensure(std::max<size_t>((size_t)rows * 4, 16));
+    dd.ensure(std::max<size_t>((size_t)rows * k * 4, 16));
+    di.ensure(std::max<size_t>((size_t)rows * k * 8, 16));
+    HIP_CHECK(hipMemcpyAsync(dv.p, vals, n * 4, hipMemcpyHostToDevice, r->stream));
+    launch_select_test(which, (int)metric, dv.as<float>(), rows, cols, k, dd.as<float>(), di.as<idx_t>(),
+                       dk.as<unsigned long long>(), dc.as<uint32_t>(), r->stream);
+    HIP_CHECK(hipMemcpyAsync(out_distances, dd.p, (size_t)rows * k * 4, hipMemcpyDeviceToHost, r->stream));
+    HIP_CHECK(hipMemcpyAsync(out_indices, di.p, (size_t)rows * k * 8, hipMemcpyDeviceToHost, r->stream));
+    r->sync();
     FA_CATCH
 }
 int faiss_amd_GpuIndexIVF_search_with_params(const FaissAmdIndex* index, faiss_amd_idx_t n, const float* x,

@@ -739,7 +739,7 @@ __global__ void __launch_bounds__(TG_THREADS) flat_tighten_kernel(FlatFilterPara
     WgSelCtl* ctl = (WgSelCtl*)(hist + 256);
     const int q = blockIdx.x;
     const int tid = threadIdx.x;
-    const float e = flat_filter_err_bound(METRIC, p.d, p.xqn[q], p.yn_max);
+    const float e = flat_filter_err_bound(METRIC, p.d, p.xqn[q], p.yn_max, p.exact_inputs != 0);
     if (p.flags[q] || !(e < FLT_MAX)) {
         // fp16 range overflow / NaN in the query: not served by the filter
         if (tid == 0) {
@@ -826,7 +826,7 @@ __global__ void __launch_bounds__(RR_THREADS) flat_rerank_kernel(FlatRerankParam
     // ---- k-th best approximate score over all splits -> error band -> rows to re-rank
     if (n > p.k) {
         const u64 kth = wg_select_kth<RR_THREADS>(cand, n, p.k, sh->hist, &sh->ctl);
-        const float e = flat_filter_err_bound(METRIC, p.d, p.xqn[q], p.yn_max);
+        const float e = flat_filter_err_bound(METRIC, p.d, p.xqn[q], p.yn_max, p.exact_inputs != 0);
         const float thr = band_threshold(key_score((uint32_t)(kth >> 32)), e);
         const u64 key_thr = ((u64)score_key(thr) << 32) | 0xffffffffull;
         wg_compact<RR_THREADS>(cand, n, key_thr, &sh->ctl);
@@ -841,10 +841,20 @@ __global__ void __launch_bounds__(RR_THREADS) flat_rerank_kernel(FlatRerankParam
     const float xn = METRIC == METRIC_L2 ? p.xqn[q] : 0.f;
     for (int c = tid; c < n; c += RR_THREADS) {
         const unsigned row = (unsigned)cand[c];
-        const float* yr = p.xb + (int64_t)row * p.ldb;
+        const float* yr = p.xb ? p.xb + (int64_t)row * p.ldb : nullptr;
+        const _Float16* yh = p.xb16 + (int64_t)row * p.ldb16;
         float acc = 0.f;
         for (int s = 0; s < p.dpad; s += 8) {
-            const f32x4 y0 = *(const f32x4*)(yr + s), y1 = *(const f32x4*)(yr + s + 4);
+            f32x4 y0, y1;
+            if (yr) {
+                y0 = *(const f32x4*)(yr + s);
+                y1 = *(const f32x4*)(yr + s + 4);
+            } else {
+                // fp16 storage: the stored values, widened (exact), through the same chain
+                const half8 hv = *(const half8*)(yh + s);
+                y0 = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+                y1 = f32x4{(float)hv[4], (float)hv[5], (float)hv[6], (float)hv[7]};
+            }
             const f32x4 q0 = *(const f32x4*)(qs + s), q1 = *(const f32x4*)(qs + s + 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {

@@ -71,7 +71,8 @@ void launch_pad_rows(const float* src, int64_t ld_src, int64_t n, int d, float* 
 // a key of -1 yields a row of NaNs like there) or a gather of stored rows (x null; FlatIndex::reconstruct by ids)
 __global__ void rows_by_key_kernel(const float* __restrict__ x, int64_t ld_x, const int64_t* __restrict__ keys,
                                    int64_t n, int d, const float* __restrict__ rows, int64_t ld_rows, int64_t nrows,
-                                   float* __restrict__ out, int64_t ld_out) {
+                                   float* __restrict__ out, int64_t ld_out, const _Float16* __restrict__ rows16,
+                                   int64_t ld_rows16) {
     const int64_t total = n * d;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
          t += (int64_t)gridDim.x * blockDim.x) {
@@ -79,19 +80,49 @@ __global__ void rows_by_key_kernel(const float* __restrict__ x, int64_t ld_x, co
         const int c = (int)(t - i * d);
         const int64_t key = keys[i];
         float v;
-        if (key < 0 || key >= nrows) v = __builtin_nanf("");
-        else if (x) v = x[i * ld_x + c] - rows[key * ld_rows + c];
-        else v = rows[key * ld_rows + c];
+        if (key < 0 || key >= nrows) {
+            v = __builtin_nanf("");
+        } else {
+            const float r = rows ? rows[key * ld_rows + c] : (float)rows16[key * ld_rows16 + c];
+            v = x ? x[i * ld_x + c] - r : r;
+        }
         out[i * ld_out + c] = v;
     }
 }
 void launch_rows_by_key(const float* x, int64_t ld_x, const int64_t* keys, int64_t n, int d, const float* rows,
-                        int64_t ld_rows, int64_t nrows, float* out, int64_t ld_out, hipStream_t stream) {
+                        int64_t ld_rows, int64_t nrows, float* out, int64_t ld_out, hipStream_t stream,
+                        const _Float16* rows16, int64_t ld_rows16) {
     if (n == 0) return;
     const int64_t total = n * d;
     unsigned grid = (unsigned)std::min<int64_t>(div_up(total, 256), 65535 * 16);
     hipLaunchKernelGGL(rows_by_key_kernel, dim3(grid), dim3(256), 0, stream, x, ld_x, keys, n, d, rows, ld_rows, nrows,
-                       out, ld_out);
+                       out, ld_out, rows16, ld_rows16);
+    HIP_CHECK(hipGetLastError());
+}
+
+__global__ void round_f16_inplace_kernel(float* __restrict__ x, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        x[i] = (float)(_Float16)x[i];
+}
+void launch_round_f16_inplace(float* x, int64_t n, hipStream_t stream) {
+    if (n == 0) return;
+    unsigned grid = (unsigned)std::min<int64_t>(div_up(n, 256), 65535 * 16);
+    hipLaunchKernelGGL(round_f16_inplace_kernel, dim3(grid), dim3(256), 0, stream, x, n);
+    HIP_CHECK(hipGetLastError());
+}
+__global__ void f16_rows_to_f32_kernel(const _Float16* __restrict__ src, int64_t ld_src, int64_t n, int dpad,
+                                       float* __restrict__ dst) {
+    const int64_t total = n * dpad;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = t / dpad;
+        const int c = (int)(t - i * dpad);
+        dst[t] = (float)src[i * ld_src + c];
+    }
+}
+void launch_f16_rows_to_f32(const _Float16* src, int64_t ld_src, int64_t n, int dpad, float* dst, hipStream_t stream) {
+    if (n == 0) return;
+    unsigned grid = (unsigned)std::min<int64_t>(div_up(n * dpad, 256), 65535 * 16);
+    hipLaunchKernelGGL(f16_rows_to_f32_kernel, dim3(grid), dim3(256), 0, stream, src, ld_src, n, dpad, dst);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -156,8 +156,8 @@ static void copy_out(const GpuResources& res, void* dst, const void* dsrc, size_
 }
 
 // ====================================================================== GpuIndexFlat
-GpuIndexFlat::GpuIndexFlat(std::shared_ptr<GpuResources> res, int dims, int metric)
-        : Index(dims, metric), res_(std::move(res)) {
+GpuIndexFlat::GpuIndexFlat(std::shared_ptr<GpuResources> res, int dims, int metric, bool use_float16)
+        : Index(dims, metric), res_(std::move(res)), use_float16_(use_float16) {
     FA_THROW_IF_NOT_MSG(dims > 0, "dimension must be positive");
     FA_THROW_IF_NOT_MSG(metric == METRIC_L2 || metric == METRIC_INNER_PRODUCT,
                         "only METRIC_L2 and METRIC_INNER_PRODUCT are supported");
@@ -170,6 +170,21 @@ GpuIndexFlat::GpuIndexFlat(std::shared_ptr<GpuResources> res, int dims, int metr
 }
 GpuIndexFlat::~GpuIndexFlat() {
     (void)hipSetDevice(res_->device);
+}
+
+const float* GpuIndexFlat::device_vectors() const {
+    FA_THROW_IF_NOT_MSG(!use_float16_, "fp32 rows are not resident with fp16 storage");
+    return xb_.as<float>();
+}
+size_t GpuIndexFlat::resident_bytes() const {
+    const size_t n = (size_t)ntotal;
+    return (use_float16_ ? 0 : n * dpad_ * 4) + n * 4 + (n + kFilterTileRows) * ((size_t)dh_ * 2 + 4);
+}
+const float* GpuIndexFlat::rows_f32_(DevBuf& tmp) const {
+    if (!use_float16_) return xb_.as<float>();
+    tmp.ensure(std::max<size_t>((size_t)ntotal * dpad_ * 4, 256));
+    launch_f16_rows_to_f32(xbh_.as<_Float16>(), dh_, ntotal, dpad_, tmp.as<float>(), res_->stream);
+    return tmp.as<float>();
 }
 
 void GpuIndexFlat::reset() {
@@ -188,17 +203,21 @@ void GpuIndexFlat::add(idx_t n, const float* x) {
     std::lock_guard<std::mutex> g(mu_);
     res_->set_device();
     const size_t row = (size_t)dpad_ * sizeof(float);
-    xb_.ensure((size_t)(ntotal + n) * row, (size_t)ntotal * row, res_->stream);
+    if (!use_float16_) xb_.ensure((size_t)(ntotal + n) * row, (size_t)ntotal * row, res_->stream);
     xbn_.ensure((size_t)(ntotal + n) * sizeof(float), (size_t)ntotal * sizeof(float), res_->stream);
     // one tile of padding rows behind the last one: the filter kernel reads whole 64-row tiles
     xbh_.ensure((size_t)(ntotal + n + kFilterTileRows) * dh_ * 2, (size_t)ntotal * dh_ * 2, res_->stream);
     xbhn_.ensure((size_t)(ntotal + n + kFilterTileRows) * sizeof(float), (size_t)ntotal * sizeof(float), res_->stream);
     // page the upload so the raw staging buffer stays bounded (reference: GpuIndex.cu:197-217)
     const idx_t page = std::max<idx_t>(1, ((idx_t)256 << 20) / ((idx_t)d * 4));
+    DevBuf f16_stage; // fp16 storage: the padded fp32 page lives only until its fp16 copy and norms exist
+    if (use_float16_) f16_stage.ensure((size_t)std::min(page, n) * row);
     for (idx_t i0 = 0; i0 < n; i0 += page) {
         idx_t ni = std::min(page, n - i0);
-        float* dst = xb_.as<float>() + (size_t)(ntotal + i0) * dpad_;
+        float* dst = use_float16_ ? f16_stage.as<float>() : xb_.as<float>() + (size_t)(ntotal + i0) * dpad_;
         stage_padded(*res_, x + (size_t)i0 * d, ni, d, dpad_, q_raw_, dst);
+        // (the index holds fp16 VALUES: norms, range statistics and the filter's bias are those of the rounded rows)
+        if (use_float16_) launch_round_f16_inplace(dst, (int64_t)ni * dpad_, res_->stream);
         launch_l2_norms(dst, dpad_, ni, dpad_, xbn_.as<float>() + ntotal + i0, res_->stream);
         // fp16 shadow copy + |y|^2/2 for the filter kernel, range / norm statistics
         launch_convert_f16(dst, dpad_, ni, d, xbh_.as<char>() + (size_t)(ntotal + i0) * dh_ * 2, dh_,
@@ -230,8 +249,14 @@ void GpuIndexFlat::reconstruct_n(idx_t i0, idx_t ni, float* recons) const {
     if (ni == 0) return;
     std::lock_guard<std::mutex> g(mu_);
     res_->set_device();
-    HIP_CHECK(hipMemcpy2DAsync(recons, (size_t)d * 4, xb_.as<float>() + (size_t)i0 * dpad_,
-                               (size_t)dpad_ * 4, (size_t)d * 4, (size_t)ni,
+    DevBuf tmp;
+    const float* src = xb_.as<float>() + (size_t)i0 * dpad_;
+    if (use_float16_) {
+        tmp.ensure((size_t)ni * dpad_ * 4);
+        launch_f16_rows_to_f32(xbh_.as<_Float16>() + (size_t)i0 * dh_, dh_, ni, dpad_, tmp.as<float>(), res_->stream);
+        src = tmp.as<float>();
+    }
+    HIP_CHECK(hipMemcpy2DAsync(recons, (size_t)d * 4, src, (size_t)dpad_ * 4, (size_t)d * 4, (size_t)ni,
                                is_device_pointer(recons) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
                                res_->stream));
     res_->sync();
@@ -242,7 +267,7 @@ void GpuIndexFlat::reconstruct(idx_t key, float* recons) const {
 
 // x (null: none), keys and out may each live on the host or on the device
 static void rows_by_key(const GpuResources& R, const float* x, const idx_t* keys, idx_t n, int d, const float* rows,
-                        int64_t ld_rows, idx_t nrows, float* out) {
+                        int64_t ld_rows, idx_t nrows, float* out, const _Float16* rows16 = nullptr, int64_t ld_rows16 = 0) {
     if (n == 0) return;
     DevBuf bx, bk, bo;
     const float* dx = x;
@@ -262,7 +287,7 @@ static void rows_by_key(const GpuResources& R, const float* x, const idx_t* keys
         bo.ensure((size_t)n * d * 4);
         dout = bo.as<float>();
     }
-    launch_rows_by_key(dx, d, dk, n, d, rows, ld_rows, nrows, dout, d, R.stream);
+    launch_rows_by_key(dx, d, dk, n, d, rows, ld_rows, nrows, dout, d, R.stream, rows16, ld_rows16);
     if (dout != out) HIP_CHECK(hipMemcpyAsync(out, dout, (size_t)n * d * 4, hipMemcpyDeviceToHost, R.stream));
     R.sync();
 }
@@ -272,7 +297,8 @@ void GpuIndexFlat::compute_residual_n(idx_t n, const float* xs, float* residuals
     FA_THROW_IF_NOT_MSG(xs && residuals && keys, "null argument");
     std::lock_guard<std::mutex> g(mu_);
     res_->set_device();
-    rows_by_key(*res_, xs, keys, n, d, xb_.as<float>(), dpad_, ntotal, residuals);
+    rows_by_key(*res_, xs, keys, n, d, use_float16_ ? nullptr : xb_.as<float>(), dpad_, ntotal, residuals,
+                xbh_.as<_Float16>(), dh_);
 }
 void GpuIndexFlat::compute_residual(const float* x, float* residual, idx_t key) const {
     compute_residual_n(1, x, residual, &key);
@@ -283,7 +309,8 @@ void GpuIndexFlat::reconstruct_batch(idx_t n, const idx_t* keys, float* recons) 
     FA_THROW_IF_NOT_MSG(keys && recons, "null argument");
     std::lock_guard<std::mutex> g(mu_);
     res_->set_device();
-    rows_by_key(*res_, nullptr, keys, n, d, xb_.as<float>(), dpad_, ntotal, recons);
+    rows_by_key(*res_, nullptr, keys, n, d, use_float16_ ? nullptr : xb_.as<float>(), dpad_, ntotal, recons,
+                xbh_.as<_Float16>(), dh_);
 }
 
 void bfKnn(std::shared_ptr<GpuResources> res, int metric, const float* vectors, idx_t num_vectors, const float* queries,
@@ -467,6 +494,7 @@ void GpuIndexFlat::search_tile_(int n, const float* xq_pad, int k, float* dD, id
     fp.res_cnt = res_cnt_.as<uint32_t>();
     fp.flags = flags_.as<uint32_t>();
     fp.dump = nullptr;
+    fp.exact_inputs = use_float16_ ? 1 : 0;
     {
         // chunk maxima over a 1/tstride sample of the tiles -> per-query threshold
         SpanGuard sg(&R, "flat_filter_kernel_max");
@@ -497,10 +525,13 @@ void GpuIndexFlat::search_tile_(int n, const float* xq_pad, int k, float* dD, id
     rp.flags = fp.flags;
     rp.xq = xq_pad;
     rp.xqn = q_norm_.as<float>();
-    rp.xb = xb_.as<float>();
+    rp.xb = use_float16_ ? nullptr : xb_.as<float>();
+    rp.xb16 = xbh_.as<_Float16>();
     rp.xbn = xbn_.as<float>();
     rp.ldq = dpad_;
     rp.ldb = dpad_;
+    rp.ldb16 = dh_;
+    rp.exact_inputs = use_float16_ ? 1 : 0;
     rp.yn_max = yn_max_;
     rp.id_base = 0;
     rp.out_dis = dD;
@@ -540,6 +571,7 @@ void GpuIndexFlat::filter_scores(idx_t n, const float* x, float* scores, float* 
     const GpuResources& R = *res_;
     q_pad_.ensure((size_t)n * dpad_ * 4);
     stage_padded(R, x, n, d, dpad_, q_raw_, q_pad_.as<float>());
+    if (use_float16_) launch_round_f16_inplace(q_pad_.as<float>(), (int64_t)n * dpad_, R.stream);
     qh_.ensure((size_t)n * dh_ * 2);
     flags_.ensure((size_t)n * 4);
     q_norm_.ensure((size_t)n * 4);
@@ -568,17 +600,21 @@ void GpuIndexFlat::filter_scores(idx_t n, const float* x, float* scores, float* 
     fp.yn_max = yn_max_;
     fp.flags = flags_.as<uint32_t>();
     fp.dump = dump.as<float>();
+    fp.exact_inputs = use_float16_ ? 1 : 0;
     launch_flat_filter(fp, 2, R.stream);
     copy_out(R, scores, dump.p, (size_t)n * ntotal * 4);
     std::vector<float> xn(n);
     HIP_CHECK(hipMemcpyAsync(xn.data(), q_norm_.p, (size_t)n * 4, hipMemcpyDeviceToHost, R.stream));
     R.sync();
-    for (idx_t i = 0; i < n; i++) err_bound[i] = flat_filter_err_bound(metric_type, d, xn[i], yn_max_);
+    for (idx_t i = 0; i < n; i++) err_bound[i] = flat_filter_err_bound(metric_type, d, xn[i], yn_max_, use_float16_);
 }
 
 void GpuIndexFlat::search_tile_exact_(int n, const float* xq_pad, int k, float* dD, idx_t* dI) const {
     const GpuResources& R = *res_;
     const int nb = (int)ntotal;
+    // fp16 storage: this path (small databases, k > 1024, overflow fallback) runs on a widened temporary copy
+    DevBuf widened;
+    const float* xb_rows = nb > 0 ? rows_f32_(widened) : nullptr;
     if (metric_type == METRIC_L2) {
         q_norm_.ensure((size_t)n * 4);
         SpanGuard sg(&R, "l2_norms_query");
@@ -611,7 +647,7 @@ void GpuIndexFlat::search_tile_exact_(int n, const float* xq_pad, int k, float* 
         HIP_CHECK(hipStreamSynchronize(R.stream));
         {
             SpanGuard sg(&R, "flat_simple_kernel");
-            launch_flat_simple(metric_type, xq_pad, q_norm_.as<float>(), dpad_, n, xb_.as<float>(),
+            launch_flat_simple(metric_type, xq_pad, q_norm_.as<float>(), dpad_, n, xb_rows,
                                xbn_.as<float>(), dpad_, nb, dpad_, all_keys_.as<unsigned long long>(),
                                R.stream);
         }
@@ -620,15 +656,18 @@ void GpuIndexFlat::search_tile_exact_(int n, const float* xq_pad, int k, float* 
         sp.nseg = 1;
         sp.seg_stride = 0;
         sp.seg_cnt = one_cnt_.as<uint32_t>();
-        SpanGuard sg(&R, "select_k_kernel");
-        launch_select_k(sp, R.stream);
+        {
+            SpanGuard sg(&R, "select_k_kernel");
+            launch_select_k(sp, R.stream);
+        }
+        if (use_float16_) R.sync(); // `widened` is released on return
         return;
     }
     FlatScanParams fp{};
     fp.metric = metric_type;
     fp.xq = xq_pad;
     fp.xqn = q_norm_.as<float>();
-    fp.xb = xb_.as<float>();
+    fp.xb = xb_rows;
     fp.xbn = xbn_.as<float>();
     fp.ldq = dpad_;
     fp.ldb = dpad_;
@@ -657,6 +696,7 @@ void GpuIndexFlat::search_tile_exact_(int n, const float* xq_pad, int k, float* 
         SpanGuard sg(&R, "select_k_kernel");
         launch_select_k(sp, R.stream);
     }
+    if (use_float16_) R.sync(); // `widened` is released on return
 }
 
 // queries per tile so that the reservoirs stay within the scratch budget
@@ -691,6 +731,8 @@ void GpuIndexFlat::search(idx_t n, const float* x, idx_t k, float* distances, id
         const int ni = (int)std::min(tile, n - i0);
         q_pad_.ensure((size_t)ni * dpad_ * 4);
         stage_padded(R, x + (size_t)i0 * d, ni, d, dpad_, q_raw_, q_pad_.as<float>());
+        // fp16 storage: the queries are converted too (FlatIndex::query, faiss/gpu/impl/FlatIndex.cu:112-135)
+        if (use_float16_) launch_round_f16_inplace(q_pad_.as<float>(), (int64_t)ni * dpad_, R.stream);
         float* dD = out_dev_d ? distances + (size_t)i0 * k : nullptr;
         idx_t* dI = out_dev_i ? labels + (size_t)i0 * k : nullptr;
         if (!dD) {
@@ -715,6 +757,7 @@ void GpuIndexFlat::pairwise_distances(idx_t n, const float* x, float* out) const
     const GpuResources& R = *res_;
     q_pad_.ensure((size_t)n * dpad_ * 4);
     stage_padded(R, x, n, d, dpad_, q_raw_, q_pad_.as<float>());
+    if (use_float16_) launch_round_f16_inplace(q_pad_.as<float>(), (int64_t)n * dpad_, R.stream);
     q_norm_.ensure((size_t)n * 4);
     launch_l2_norms(q_pad_.as<float>(), dpad_, n, dpad_, q_norm_.as<float>(), R.stream);
     DevBuf dump;
@@ -724,11 +767,12 @@ void GpuIndexFlat::pairwise_distances(idx_t n, const float* x, float* out) const
         dump.ensure((size_t)n * ntotal * 4);
         dptr = dump.as<float>();
     }
+    DevBuf widened;
     FlatScanParams fp{};
     fp.metric = metric_type;
     fp.xq = q_pad_.as<float>();
     fp.xqn = q_norm_.as<float>();
-    fp.xb = xb_.as<float>();
+    fp.xb = rows_f32_(widened);
     fp.xbn = xbn_.as<float>();
     fp.ldq = fp.ldb = dpad_;
     fp.nq = (int)n;

@@ -108,8 +108,12 @@ struct Index {
 // ------------------------------------------------------------------ GpuIndexFlat
 class GpuIndexFlat : public Index {
    public:
-    GpuIndexFlat(std::shared_ptr<GpuResources> res, int dims, int metric);
+    // use_float16: GpuIndexFlatConfig::useFloat16 (faiss/gpu/GpuIndexFlat.h:24-40, impl/FlatIndex.cu:39-135): vectors
+    // are stored as fp16 only (half the resident bytes), queries are converted to fp16 as well, and distances are the
+    // fp32 distances between those fp16 values
+    GpuIndexFlat(std::shared_ptr<GpuResources> res, int dims, int metric, bool use_float16 = false);
     ~GpuIndexFlat() override;
+    bool getUseFloat16() const { return use_float16_; }
 
     void add(idx_t n, const float* x) override;
     void search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels) const override;
@@ -143,14 +147,19 @@ class GpuIndexFlat : public Index {
     void filter_scores(idx_t n, const float* x, float* scores, float* err_bound) const;
 
     int dpad() const { return dpad_; }
-    const float* device_vectors() const { return xb_.as<float>(); }
+    const float* device_vectors() const; // fp32 rows [ntotal][dpad] (not available with fp16 storage)
+    size_t resident_bytes() const;       // device bytes held for the database (rows, shadow copy, norms)
     std::shared_ptr<GpuResources> resources() const { return res_; }
 
    private:
     std::shared_ptr<GpuResources> res_;
     int dpad_;
-    DevBuf xb_;  // [cap][dpad]
+    bool use_float16_ = false;
+    DevBuf xb_;  // [cap][dpad] fp32 rows (absent with fp16 storage)
     DevBuf xbn_; // [cap]
+    // fp32 view of the rows for the paths that need one (exact scan, test hooks): xb_ itself, or -- fp16 storage -- a
+    // temporary widened copy in `tmp`
+    const float* rows_f32_(DevBuf& tmp) const;
     // fp16 shadow copy for the filter kernel: rows padded to dh_ (multiple of 128) halfs, |y|^2/2
     int dh_;
     DevBuf xbh_, xbhn_;

@@ -265,7 +265,7 @@ __device__ __forceinline__ void fused_finish(const IvfFusedParams& p, int q, int
 // of a gather = ONE v_perm_b32).
 // ---------------------------------------------------------------------------------
 template <int METRIC, bool M64, int FB>
-__global__ void __launch_bounds__(FB) ivfpq_fused_kernel(IvfFusedParams p) {
+__global__ void __launch_bounds__(FB, 4) ivfpq_fused_kernel(IvfFusedParams p) { // 4 waves per SIMD: two 512-thread workgroups per CU
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const FusedLds L = fused_carve(smem, p);
     const int tid = threadIdx.x;
@@ -303,15 +303,17 @@ __global__ void __launch_bounds__(FB) ivfpq_fused_kernel(IvfFusedParams p) {
         const float r0 = L.rs[2 * (tid & 63)], r1 = L.rs[2 * (tid & 63) + 1];
         float v[NE];
         float mx = 0.f;
-        {
-            // every codebook load of this lane in flight before the first is consumed: one L2 round trip per query
-            f32x2 c[NE];
+        // the codebook loads of this lane go out in two waves of NE / 2 (two L2 round trips per query, 32 + 32 live
+        // registers instead of 96)
 #pragma unroll
-            for (int u = 0; u < NE; ++u) c[u] = *(const f32x2*)(p.pq_t + (size_t)(tid + u * FB) * 2);
+        for (int u0 = 0; u0 < NE; u0 += NE / 2) {
+            f32x2 c[NE / 2];
 #pragma unroll
-            for (int u = 0; u < NE; ++u) {
-                v[u] = __fmaf_rn(r1, c[u][1], __fmaf_rn(r0, c[u][0], 0.f));
-                const float a = fabsf(v[u]);
+            for (int u = 0; u < NE / 2; ++u) c[u] = *(const f32x2*)(p.pq_t + (size_t)(tid + (u0 + u) * FB) * 2);
+#pragma unroll
+            for (int u = 0; u < NE / 2; ++u) {
+                v[u0 + u] = __fmaf_rn(r1, c[u][1], __fmaf_rn(r0, c[u][0], 0.f));
+                const float a = fabsf(v[u0 + u]);
                 mx = (a > mx || a != a) ? a : mx; // NaN sticks
             }
         }
@@ -346,37 +348,43 @@ __global__ void __launch_bounds__(FB) ivfpq_fused_kernel(IvfFusedParams p) {
     // ---- block stream of this workgroup's probes [p0, p1): blocks [bpre[p0], bpre[p1])
     const unsigned blk_begin = L.bpre[p0], blk_end = L.bpre[p1];
     constexpr int NW = 4; // 16-byte code words per row (M64)
-    uint4 cw[NW], cwn[NW];
-    float t2 = 0.f, t2n = 0.f, dis0 = 0.f, dis0n = 0.f;
-    unsigned pos = 0, posn = 0;
-    bool valid = false, validn = false;
-    const uint8_t* blkp = nullptr;
-    const uint8_t* blkpn = nullptr;
+    // one block of one wavefront on its way from HBM to the gathers: row `lane` of the block
+    struct Stage {
+        uint4 w[NW];        // code words (M64)
+        float t2;           // per-row L2 term
+        // wave-uniform (kept in scalar registers): coarse term of the block's list, scan position of the block's
+        // first row, rows of the list from that row on (0 = no block)
+        float dis0;
+        unsigned pos0, rem;
+        const uint8_t* bp;  // block base (generic M: codes are read in the gather loop)
+    };
     int tcur = p0; // probe of the block fetched last (blocks are visited in increasing order)
-    // row `lane` of block `blk`: validity, scan position, coarse term, t2 and (M64) the code words
-    auto fetch = [&](unsigned blk, bool& ok, unsigned& ps, float& c0, uint4(&w)[NW], float& t, const uint8_t*& bp) {
-        ok = false;
+    auto fetch = [&](unsigned blk, Stage& st) {
+        st.rem = 0;
         if (blk < blk_end) { // wave-uniform
             while (L.bpre[tcur + 1] <= blk) ++tcur;
             const unsigned b = blk - L.bpre[tcur];
-            const unsigned r = b * 64u + (unsigned)lane;
             const int64_t row0 = L.lstart[tcur] + (int64_t)b * 64;
-            bp = p.arena_codes + row0 * M;
+            st.bp = p.arena_codes + row0 * M;
             if (M64) {
 #pragma unroll
-                for (int k = 0; k < NW; ++k) w[k] = *(const uint4*)(bp + k * 1024 + lane * 16);
+                for (int k = 0; k < NW; ++k) st.w[k] = *(const uint4*)(st.bp + k * 1024 + lane * 16);
             }
-            if (METRIC == METRIC_L2) t = p.arena_t2[row0 + lane];
-            c0 = p.coarse_dis[(int64_t)q * p.nprobe + tcur];
-            ok = r < L.pre[tcur + 1] - L.pre[tcur];
-            ps = L.pre[tcur] + r;
+            if (METRIC == METRIC_L2) st.t2 = p.arena_t2[row0 + lane];
+            st.dis0 = __uint_as_float(__builtin_amdgcn_readfirstlane(
+                    __float_as_uint(p.coarse_dis[(int64_t)q * p.nprobe + tcur])));
+            st.pos0 = __builtin_amdgcn_readfirstlane(L.pre[tcur] + b * 64u);
+            st.rem = __builtin_amdgcn_readfirstlane(L.pre[tcur + 1] - L.pre[tcur] - b * 64u);
         }
     };
-    // per-lane table columns: rot[k] byte i = 4 * ((4 k + i + lane) mod 64)
-    unsigned rot[16];
+    // per-lane table columns: dword kk = 4 k + wd of the code, byte i -> column byte offset 4 * ((4 kk + i + lane) mod 64).
+    // Kept in registers for k = 0 (rot[wd]); for k = 1..3 it is (rot[wd] + k * 0x40404040) & 0xfcfcfcfc: the bytes are
+    // multiples of 4, a carry out of a byte can only set bit 0 of its neighbour, which the mask clears (two VALU
+    // instructions per four gathers instead of twelve more registers -- the three-stage prefetch needs them).
+    unsigned rot[4];
     if (M64) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
+        for (int k = 0; k < 4; ++k) {
             unsigned r = 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) r |= ((4u * (unsigned)(4 * k + i + lane)) & 255u) << (8 * i);
@@ -387,23 +395,24 @@ __global__ void __launch_bounds__(FB) ivfpq_fused_kernel(IvfFusedParams p) {
 
     u64 tau = ~0ull;
     int bound = 0;
-    fetch(blk_begin + wave, valid, pos, dis0, cw, t2, blkp);
-    for (unsigned base = blk_begin; base < blk_end; base += NWV) {
-        FUSED_MAKE_ROOM(FB);
-        // the next block of this wavefront is in flight while this one is scanned
-        fetch(base + NWV + wave, validn, posn, dis0n, cwn, t2n, blkpn);
+    // gathers + key + append of one staged block
+    auto scan = [&](const Stage& st) {
         bool pass = false;
         u64 key = 0;
-        if (valid) {
+        if ((unsigned)lane < st.rem) {
             float sum;
             if (M64) {
                 float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
                 for (int k = 0; k < NW; ++k) {
-                    const unsigned w4[4] = {cw[k].x, cw[k].y, cw[k].z, cw[k].w};
+                    const unsigned w4[4] = {st.w[k].x, st.w[k].y, st.w[k].z, st.w[k].w};
+                    // (a scalar register written HERE: keeps the twelve derived values from being hoisted out of the
+                    // block loop as loop invariants, which would bring the register pressure back)
+                    unsigned kadd = 0x40404040u * (unsigned)k;
+                    asm volatile("" : "+s"(kadd));
 #pragma unroll
                     for (int wd = 0; wd < 4; ++wd) {
-                        const unsigned ro = rot[4 * k + wd];
+                        const unsigned ro = k == 0 ? rot[wd] : ((rot[wd] + kadd) & 0xfcfcfcfcu);
                         a0 += lds_f32(lut_addr64<0>(w4[wd], ro));
                         a1 += lds_f32(lut_addr64<1>(w4[wd], ro));
                         a2 += lds_f32(lut_addr64<2>(w4[wd], ro));
@@ -415,25 +424,45 @@ __global__ void __launch_bounds__(FB) ivfpq_fused_kernel(IvfFusedParams p) {
                 const int ch = pq_chunk_bytes(M);
                 sum = 0.f;
                 for (int j = 0; j < M; ++j) {
-                    const unsigned c = blkp[(j / ch) * 64 * ch + lane * ch + (j % ch)];
+                    const unsigned c = st.bp[(j / ch) * 64 * ch + lane * ch + (j % ch)];
                     int m = j + lane;
                     m -= (m / M) * M;
                     sum += lut[c * M + m];
                 }
             }
-            const float dis = METRIC == METRIC_L2 ? __fmaf_rn(-2.f, sum, dis0 + t2) : dis0 + sum;
-            key = ((u64)ordkey<METRIC>(dis) << 32) | (u64)pos;
+            const float dis = METRIC == METRIC_L2 ? __fmaf_rn(-2.f, sum, st.dis0 + st.t2) : st.dis0 + sum;
+            key = ((u64)ordkey<METRIC>(dis) << 32) | (u64)(st.pos0 + (unsigned)lane);
             pass = key < tau;
         }
         wg_append(L.res, L.ctl, pass, key);
-#pragma unroll
-        for (int k = 0; k < NW; ++k) cw[k] = cwn[k];
-        t2 = t2n;
-        dis0 = dis0n;
-        pos = posn;
-        valid = validn;
-        blkp = blkpn;
+    };
+    // Three stages per wavefront: while block i is gathered, blocks i + 1 and i + 2 are in flight (8 KB per wavefront).
+    // With one block ahead a workgroup on its own drew ~2/3 of the CU's fill bandwidth (load latency > gather time), so
+    // the per-query fixed work of the OTHER workgroup of the CU (probe tables, table build, final selection) was not
+    // hidden: 1.24 ms at nb = 1M against 0.44 ms of it being fixed cost (tools/ivfpq_sweep.py, nprobe 1 vs 32).
+    Stage s0, s1, s2;
+    fetch(blk_begin + wave, s0);
+    fetch(blk_begin + NWV + wave, s1);
+    unsigned base = blk_begin;
+    for (;;) {
+        if (base >= blk_end) break;
+        FUSED_MAKE_ROOM(FB);
+        fetch(base + 2 * NWV + wave, s2);
+        scan(s0);
         __syncthreads();
+        base += NWV;
+        if (base >= blk_end) break;
+        FUSED_MAKE_ROOM(FB);
+        fetch(base + 2 * NWV + wave, s0);
+        scan(s1);
+        __syncthreads();
+        base += NWV;
+        if (base >= blk_end) break;
+        FUSED_MAKE_ROOM(FB);
+        fetch(base + 2 * NWV + wave, s1);
+        scan(s2);
+        __syncthreads();
+        base += NWV;
     }
     fused_finish<FB>(p, q, g, L);
 }

@@ -18,8 +18,15 @@ void launch_pad_rows(const float* src, int64_t lds_src, int64_t n, int d, float*
 
 // out[i] = x[i] - rows[keys[i]] (x given) or rows[keys[i]] (x null); key outside [0, nrows) -> NaN row.
 // Replaces faiss/gpu/impl/VectorResidual.cu:26-97 (runCalcResidual) and the reconstruct-by-ids gather.
+// rows16 (fp16 storage) is used when rows is null.
 void launch_rows_by_key(const float* x, int64_t ld_x, const int64_t* keys, int64_t n, int d, const float* rows,
-                        int64_t ld_rows, int64_t nrows, float* out, int64_t ld_out, hipStream_t stream);
+                        int64_t ld_rows, int64_t nrows, float* out, int64_t ld_out, hipStream_t stream,
+                        const _Float16* rows16 = nullptr, int64_t ld_rows16 = 0);
+// x[i] = float(half(x[i])): the values an fp16-storage index holds (queries are rounded the same way, as
+// FlatIndex::query converts them, faiss/gpu/impl/FlatIndex.cu:112-135)
+void launch_round_f16_inplace(float* x, int64_t n, hipStream_t stream);
+// dst[i][0..dpad) = float(src[i][0..dpad)) for fp16 rows of stride ld_src (dpad <= ld_src)
+void launch_f16_rows_to_f32(const _Float16* src, int64_t ld_src, int64_t n, int dpad, float* dst, hipStream_t stream);
 
 // ------------------------------------------------------------------ Flat: fused distance + k-selection
 constexpr int kFlatQueriesPerBlock = 256; // 8 waves x 32 queries
@@ -85,6 +92,7 @@ struct FlatFilterParams {
     uint32_t* res_cnt;            // [nq][nsplit]
     uint32_t* flags;              // [nq] in: fp16 overflow of the query; out: |= segment overflow
     float* dump;                  // optional [nq][nb] approximate scores (tests)
+    int exact_inputs;             // fp16 storage: q and y are fp16 values, the error band shrinks to the accumulation terms
     int dbg;                      // timing experiments only (env FAISS_AMD_FILTER_DBG): 1 no parking, 2 no sift, 4 no hits
 };
 // Bound on |t~ - s| for one query against any database row (see flat_filter.hip header).  fp16
@@ -96,10 +104,13 @@ struct FlatFilterParams {
 // The L2 accumulators start from -|y|^2/2, so each of the (at most d) fp32 additions inside the MFMA
 // chain also rounds that magnitude: + d 2^-24 |y|^2/2, doubled.
 // A 1.25x safety factor covers the second-order terms and sqrtf.
-__host__ __device__ static inline float flat_filter_err_bound(int metric, int d, float xn, float yn_max) {
+// exact_inputs: queries and database ARE fp16 values (GpuIndexFlatConfig::useFloat16 storage): no conversion error,
+// only the accumulation terms remain.
+__host__ __device__ static inline float flat_filter_err_bound(int metric, int d, float xn, float yn_max,
+                                                               bool exact_inputs = false) {
     const float nq = sqrtf(xn), ny = sqrtf(yn_max);
-    float e = (9.775e-4f /*2^-10 * 1.001*/ + 2.4e-7f * (float)d /*4 d 2^-24*/) * nq * ny +
-              3.0e-8f /*2^-25 * 1.001*/ * sqrtf((float)d) * (nq + ny) + 1e-30f;
+    float e = ((exact_inputs ? 0.f : 9.775e-4f /*2^-10 * 1.001*/) + 2.4e-7f * (float)d /*4 d 2^-24*/) * nq * ny +
+              (exact_inputs ? 0.f : 3.0e-8f /*2^-25 * 1.001*/ * sqrtf((float)d) * (nq + ny)) + 1e-30f;
     if (metric == METRIC_L2) e += 6.0e-8f /*2^-24*/ * (xn + yn_max) + 6.0e-8f * (float)d * yn_max;
     return 1.25f * e;
 }
@@ -120,9 +131,11 @@ struct FlatRerankParams {
     const uint32_t* flags;
     const float* xq;  // [nq][ldq] fp32 padded queries
     const float* xqn; // [nq]
-    const float* xb;  // [nb][ldb] fp32 padded database
+    const float* xb;  // [nb][ldb] fp32 padded database (null with fp16 storage)
+    const _Float16* xb16; // [nb][ldb16] fp16 rows, zero padded to a multiple of 8 (fp16 storage: the exact chain runs on them)
     const float* xbn; // [nb]
-    int64_t ldq, ldb;
+    int64_t ldq, ldb, ldb16;
+    int exact_inputs; // see FlatFilterParams
     float yn_max;
     int64_t id_base;
     float* out_dis;     // [nq][k]
@@ -177,6 +190,12 @@ struct SelectParams {
 // (distance, label).  Replaces faiss/gpu/utils/BlockSelectKernel.cuh:15-132 and the
 // pass1/pass2 kernels of faiss/gpu/impl/IVFUtilsSelect{1,2}.cu.
 void launch_select_k(const SelectParams& p, hipStream_t stream);
+
+// test hook: the k best entries of every row of vals [rows][cols] through one of the selection primitives
+// (which = 0: select_k_kernel, 1: the LDS reservoir of wg_select.h streamed like the fused IVF scans, 2: the wavefront
+// select of wave_select.h -- winners unordered); keys [rows * cols] and cnt [rows] are scratch
+void launch_select_test(int which, int metric, const float* vals, int rows, int cols, int k, float* out_dis,
+                        int64_t* out_ids, unsigned long long* keys, uint32_t* cnt, hipStream_t stream);
 
 // Shard merge on the device: per-shard sorted results all_d/all_i [nshard][nq][k] are packed
 // into keys [nq][nshard*k] (payload = shard*k + rank, so equal distances resolve to the lower

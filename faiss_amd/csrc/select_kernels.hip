@@ -11,10 +11,10 @@
 // exit when the k-th key is the maximum of its bucket), gather of the <= k winners into LDS,
 // payload -> label translation, bitonic sort of the winners, coalesced write-out.
 #include "kernels.h"
+#include "wave_select.h"
+#include "wg_select.h"
 
 namespace faiss_amd {
-
-typedef unsigned long long u64;
 
 constexpr int SEL_THREADS = 256;
 
@@ -222,6 +222,124 @@ void launch_pack_merge_keys(int metric, const float* all_d, const int64_t* all_i
     unsigned grid = (unsigned)std::min<int64_t>(div_up(total, 256), 65535 * 8);
     hipLaunchKernelGGL(pack_merge_keys_kernel, dim3(grid), dim3(256), 0, stream, metric, all_d, all_i, nshard,
                        nq, k, keys, cnt);
+    HIP_CHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------
+// stand-alone exercise of the three selection primitives (test hook, faiss/gpu/test/TestGpuSelect.cu:23-198 style):
+// k best of every row of a [rows][cols] matrix
+// ---------------------------------------------------------------------------------
+__global__ void pack_row_keys_kernel(int metric, const float* __restrict__ vals, int rows, int cols, u64* __restrict__ keys,
+                                     uint32_t* __restrict__ cnt) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)rows * cols) return;
+    const int c = (int)(t % cols);
+    keys[t] = ((u64)ordkey_rt(metric, vals[t]) << 32) | (uint32_t)c;
+    if (c == 0) cnt[t / cols] = (uint32_t)cols;
+}
+
+// wg_select.h: the row streamed through an LDS reservoir exactly as the fused IVF scans do (threshold, append, cut back
+// to k when full, final cut + sort)
+template <int FB>
+__global__ void __launch_bounds__(FB) wg_reservoir_test_kernel(int metric, const u64* __restrict__ keys, int cols, int k,
+                                                                int kp, int cap, float* __restrict__ out_dis,
+                                                                int64_t* __restrict__ out_ids) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u64* res = (u64*)smem;                          // [cap]
+    int64_t* w_id = (int64_t*)(res + cap);          // [kp]
+    unsigned* w_key = (unsigned*)(w_id + kp);       // [kp]
+    unsigned* hist = w_key + kp;                    // [256]
+    WgSelCtl* ctl = (WgSelCtl*)(hist + 256);
+    const int tid = threadIdx.x, r = blockIdx.x;
+    const u64* row = keys + (int64_t)r * cols;
+    if (tid == 0) ctl->cnt = 0;
+    __syncthreads();
+    u64 tau = ~0ull;
+    for (int base = 0; base < cols; base += FB) {
+        const int n_ = (int)ctl->cnt;
+        __syncthreads();
+        if (n_ + FB > cap) {
+            const u64 kth = wg_select_kth<FB>(res, n_, k, hist, ctl);
+            wg_compact<FB>(res, n_, kth, ctl);
+            tau = kth;
+        }
+        const int i = base + tid;
+        const u64 key = i < cols ? row[i] : ~0ull;
+        wg_append(res, ctl, i < cols && key < tau, key);
+        __syncthreads();
+    }
+    int n = (int)ctl->cnt;
+    if (n > k) {
+        const u64 kth = wg_select_kth<FB>(res, n, k, hist, ctl);
+        wg_compact<FB>(res, n, kth, ctl);
+        n = (int)ctl->cnt;
+    }
+    for (int i = tid; i < kp; i += FB) {
+        w_key[i] = i < n ? (uint32_t)(res[i] >> 32) : 0xffffffffu;
+        w_id[i] = i < n ? (int64_t)(uint32_t)res[i] : INT64_MAX;
+    }
+    __syncthreads();
+    wg_bitonic_sort<FB>(w_key, w_id, kp);
+    for (int i = tid; i < k; i += FB) {
+        const bool ok = i < n && w_key[i] < kInvalidOrdKey;
+        out_dis[(int64_t)r * k + i] = ok ? unordkey_rt(metric, w_key[i]) : neutral_distance(metric);
+        out_ids[(int64_t)r * k + i] = ok ? w_id[i] : -1;
+    }
+}
+
+// wave_select.h: one wavefront per row, keys in global memory (the per-(query, split) reservoirs of the flat scan);
+// the winners are written in whatever order the compaction leaves them
+__global__ void __launch_bounds__(64) wave_select_test_kernel(int metric, u64* __restrict__ keys, int cols, int k,
+                                                              float* __restrict__ out_dis, int64_t* __restrict__ out_ids) {
+    __shared__ unsigned hist[256];
+    const int r = blockIdx.x, lane = threadIdx.x;
+    u64* row = keys + (int64_t)r * cols;
+    int n = cols;
+    if (n > k) {
+        const u64 kth = wave_select_kth(row, n, k, hist);
+        n = wave_compact(row, n, kth);
+    }
+    for (int i = lane; i < k; i += 64) {
+        const bool ok = i < n && (uint32_t)(row[i] >> 32) < kInvalidOrdKey;
+        out_dis[(int64_t)r * k + i] = ok ? unordkey_rt(metric, (uint32_t)(row[i] >> 32)) : neutral_distance(metric);
+        out_ids[(int64_t)r * k + i] = ok ? (int64_t)(uint32_t)row[i] : -1;
+    }
+}
+
+void launch_select_test(int which, int metric, const float* vals, int rows, int cols, int k, float* out_dis,
+                        int64_t* out_ids, unsigned long long* keys, uint32_t* cnt, hipStream_t stream) {
+    if (rows == 0) return;
+    FA_THROW_IF_NOT(k >= 1 && k <= kMaxSelectionK && cols >= 1);
+    hipLaunchKernelGGL(pack_row_keys_kernel, dim3((unsigned)div_up((size_t)rows * cols, 256)), dim3(256), 0, stream, metric,
+                       vals, rows, cols, keys, cnt);
+    if (which == 0) {
+        SelectParams sp{};
+        sp.metric = metric;
+        sp.nq = rows;
+        sp.k = k;
+        sp.keys = keys;
+        sp.q_stride = cols;
+        sp.nseg = 1;
+        sp.seg_cnt = cnt;
+        sp.mode = 0;
+        sp.out_dis = out_dis;
+        sp.out_ids = out_ids;
+        launch_select_k(sp, stream);
+    } else if (which == 1) {
+        constexpr int FB = 512;
+        int kp = 1;
+        while (kp < k) kp <<= 1;
+        int cap = 1024;
+        while (cap < k + FB) cap <<= 1;
+        const size_t lds = (size_t)cap * 8 + (size_t)kp * 12 + 1024 + 64;
+        HIP_CHECK(hipFuncSetAttribute((const void*)wg_reservoir_test_kernel<FB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds));
+        hipLaunchKernelGGL((wg_reservoir_test_kernel<FB>), dim3((unsigned)rows), dim3(FB), lds, stream, metric, keys, cols, k,
+                           kp, cap, out_dis, out_ids);
+    } else {
+        hipLaunchKernelGGL(wave_select_test_kernel, dim3((unsigned)rows), dim3(64), 0, stream, metric, keys, cols, k, out_dis,
+                           out_ids);
+    }
     HIP_CHECK(hipGetLastError());
 }
 

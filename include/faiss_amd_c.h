@@ -63,6 +63,40 @@ int faiss_amd_GpuIndexIVFFlat_new(FaissAmdIndex** p_index, FaissAmdGpuResources*
                                   FaissAmdMetricType metric);
 int faiss_amd_GpuIndexIVFPQ_new(FaissAmdIndex** p_index, FaissAmdGpuResources* res, int d, int nlist,
                                 int M, int nbits, FaissAmdMetricType metric);
+/* ---- the same constructors with the reference's config structs (faiss/gpu/GpuIndex.h:30-47 GpuIndexConfig,
+ *      GpuIndexFlat.h:24-40 GpuIndexFlatConfig, GpuIndexIVF.h:24-38 GpuIndexIVFConfig, GpuIndexIVFPQ.h:25-49
+ *      GpuIndexIVFPQConfig), field for field as plain ints.  What each field means here:
+ *   device            must be -1 or the device of `res` (an index lives on its resources' device)
+ *   memorySpace       0 = Device.  Unified (1) is refused: 288 GB of HBM is the design point
+ *   useFloat16        GpuIndexFlat: vectors stored as fp16 only, queries converted to fp16, distances = the fp32
+ *                     distances of those fp16 values (impl/FlatIndex.cu:39-135).  Halves the resident bytes.
+ *   storeTransposed   accepted, ignored (the device layout is private to the kernels)
+ *   indicesOptions    INDICES_64_BIT (3) or INDICES_32_BIT (2; ids are held as 64-bit anyway); INDICES_CPU / INDICES_IVF
+ *                     (ids not on the device) are refused
+ *   flat_useFloat16   coarse quantizer in fp16: refused (the residual / table kernels read fp32 centroids)
+ *   allowCpuCoarseQuantizer  accepted, ignored (the coarse quantizer is always a device flat index)
+ *   useFloat16LookupTables   accepted, ignored: the tables are fp32 on a per-query power-of-two grid (>= fp16 accuracy)
+ *   usePrecomputedTables     accepted, ignored: the list-dependent L2 term is always kept per stored vector (4 B each),
+ *                            which is what precomputed tables buy, without the nlist x M x 256 table
+ *   interleavedLayout, useMMCodeDistance  accepted, ignored (layout and table construction are fixed) */
+typedef struct FaissAmdGpuIndexFlatConfig {
+    int device, memorySpace, useFloat16, storeTransposed;
+} FaissAmdGpuIndexFlatConfig;
+typedef struct FaissAmdGpuIndexIVFConfig {
+    int device, memorySpace, indicesOptions, flat_useFloat16, allowCpuCoarseQuantizer;
+} FaissAmdGpuIndexIVFConfig;
+typedef struct FaissAmdGpuIndexIVFPQConfig {
+    FaissAmdGpuIndexIVFConfig ivf;
+    int useFloat16LookupTables, usePrecomputedTables, interleavedLayout, useMMCodeDistance;
+} FaissAmdGpuIndexIVFPQConfig;
+int faiss_amd_GpuIndexFlat_new_with_config(FaissAmdIndex** p_index, FaissAmdGpuResources* res, int d,
+                                           FaissAmdMetricType metric, const FaissAmdGpuIndexFlatConfig* config);
+int faiss_amd_GpuIndexIVFFlat_new_with_config(FaissAmdIndex** p_index, FaissAmdGpuResources* res, int d, int nlist,
+                                              FaissAmdMetricType metric, const FaissAmdGpuIndexIVFConfig* config);
+int faiss_amd_GpuIndexIVFPQ_new_with_config(FaissAmdIndex** p_index, FaissAmdGpuResources* res, int d, int nlist, int M,
+                                            int nbits, FaissAmdMetricType metric, const FaissAmdGpuIndexIVFPQConfig* config);
+/* device bytes held for the database of a flat index (rows, fp16 shadow / storage, norms) */
+int faiss_amd_GpuIndexFlat_resident_bytes(const FaissAmdIndex* index, size_t* p_bytes);
 int faiss_amd_IndexShards_new(FaissAmdIndex** p_index, int d, int threaded, int successive_ids);
 int faiss_amd_IndexShards_add_shard(FaissAmdIndex* shards, FaissAmdIndex* shard);
 /* faiss/IndexReplicas.h:20-82: IndexReplicas(d, threaded) + addIndex.  Every replica holds the whole database;
@@ -165,6 +199,12 @@ int faiss_amd_GpuIndexFlat_filter_stats(const FaissAmdIndex* index, int* used_fi
  * the per-query bound err_bound[n] on their deviation from the exact fp32 scores */
 int faiss_amd_GpuIndexFlat_filter_scores(const FaissAmdIndex* index, faiss_amd_idx_t n, const float* x, float* scores,
                                          float* err_bound);
+/* the k best entries (smallest for L2, largest for inner product; ties to the lower column) of every row of the host
+ * matrix vals [rows][cols] through one selection primitive in isolation -- the stand-alone select test of the reference
+ * (faiss/gpu/test/TestGpuSelect.cu:23-198, runBlockSelect / runWarpSelect).  which: 0 = select_k_kernel (BlockSelect's
+ * role), 1 = workgroup LDS reservoir (fused IVF scans), 2 = wavefront select (flat scan reservoirs; winners unordered) */
+int faiss_amd_test_select(FaissAmdGpuResources* res, int which, FaissAmdMetricType metric, int rows, int cols, int k,
+                          const float* vals, float* out_distances, faiss_amd_idx_t* out_indices);
 /* ---- the rest of the faiss::Index surface a coarse quantizer / shard wrapper uses
  *      reconstruct_batch (faiss/Index.h:297-307; GpuIndexFlat.cu:294-320), compute_residual[_n]
  *      (faiss/Index.h:363-383; GpuIndexFlat.cu:323-361, impl/VectorResidual.cu:26-97): residual = x - stored[key],

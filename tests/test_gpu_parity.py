@@ -752,3 +752,138 @@ def test_ivfpq_code_layout_round_trip(res, M, d):
             idx.set_use_fused_scan(fused)
             D, I = idx.search(xq, k)
             check_knn(D, I, Do, Io, exact=True, name="layout M=%d fused=%s" % (M, fused))
+
+
+# ------------------------------------------------------------------------------- selection primitives in isolation
+@pytest.mark.parametrize("which", [0, 1, 2])
+@pytest.mark.parametrize("k", [1, 64, 100, 1024, 2048])
+def test_select_primitives_standalone(res, which, k):
+    """faiss/gpu/test/TestGpuSelect.cu:23-198 (testForSize): for every row the k selected VALUES are exactly the k best of
+    a CPU sort, every returned index gathers to the returned value, indices are unique; here additionally ties go to the
+    lower column (the backend's total order), so indices are compared exactly too.  which = 0: select_k_kernel (the
+    BlockSelect role), 1: workgroup LDS reservoir (wg_select.h), 2: wavefront select (wave_select.h, unordered winners).
+    Inputs: random, heavily tied (16 distinct values), all-equal, and fewer columns than k."""
+    rs = np.random.RandomState(k + which)
+    cases = [rs.rand(7, 5000).astype(np.float32), rs.randint(0, 16, size=(5, 4097)).astype(np.float32),
+             np.full((3, 3000), 2.5, dtype=np.float32), rs.rand(4, max(1, k // 2)).astype(np.float32),
+             rs.rand(2, k).astype(np.float32)]
+    for metric in (METRIC_L2, METRIC_INNER_PRODUCT):
+        for vals in cases:
+            rows, cols = vals.shape
+            D, I = faiss_amd.test_select(res, which, vals, k, metric)
+            kk = min(k, cols)
+            order = np.lexsort((np.broadcast_to(np.arange(cols), vals.shape), vals if metric == METRIC_L2 else -vals), axis=1)
+            Iref = order[:, :kk]
+            Dref = np.take_along_axis(vals, Iref, axis=1)
+            if which == 2:  # unordered winners: bring them into (value, index) order first
+                o = np.lexsort((I, D if metric == METRIC_L2 else -D), axis=1)
+                pad = I == -1
+                o = np.lexsort((I, np.where(pad, np.inf, D if metric == METRIC_L2 else -D)), axis=1)
+                D, I = np.take_along_axis(D, o, axis=1), np.take_along_axis(I, o, axis=1)
+            assert np.array_equal(D[:, :kk], Dref), (which, k, metric, vals.shape)
+            assert np.array_equal(I[:, :kk], Iref), (which, k, metric, vals.shape)
+            assert np.array_equal(np.take_along_axis(vals, I[:, :kk], axis=1), D[:, :kk])  # indices gather to the values
+            assert all(len(set(r)) == kk for r in I[:, :kk])
+            pad = FMAX if metric == METRIC_L2 else -FMAX
+            assert (I[:, kk:] == -1).all() and (D[:, kk:] == pad).all()
+
+
+def test_flat_l2_clamp_of_negative_distances(res):
+    """runSumAlongRows(zeroClamp = true), faiss/gpu/impl/BroadcastSum.cu:201-354 / faiss/utils/distances.cpp:480-495: a
+    query equal to a database row can come out of |x|^2 + |y|^2 - 2<x,y> slightly negative; the result is clamped to 0.
+    Large-norm rows make the cancellation error visible; every path (fp32 scan, fp16 filter + re-rank, scalar
+    cross-check) returns exactly what the oracle returns, never a negative distance."""
+    rs = np.random.RandomState(3)
+    xb = (rs.rand(20000, 96).astype(np.float32) + 0.5) * 37.0
+    xq = xb[rs.choice(len(xb), 200, replace=False)].copy()
+    Do, Io = Oracle.flat_search(METRIC_L2, xb, xq, 5)
+    assert (Do >= 0).all()
+    # the clamp really fires on this data: the unclamped expression fmaf(-2, <x,x>, |x|^2 + |x|^2) of the restatement is
+    # negative for some (query, own row) pairs -- they must come out as exactly 0
+    import ctypes
+    lib = Oracle.lib()
+    lib.orc_norm_l2sqr.restype = ctypes.c_float
+    neg = 0
+    for i in range(len(xq)):
+        x = np.ascontiguousarray(xq[i])
+        xp = ctypes.c_void_p(x.ctypes.data)
+        ip = lib.orc_ip_chain(xp, xp, ctypes.c_int(96))
+        xn = lib.orc_norm_l2sqr(xp, ctypes.c_int(96))
+        raw = np.float32(np.float64(np.float32(xn + xn)) - 2.0 * np.float64(ip))
+        if raw < 0:
+            neg += 1
+            assert Do[i, 0] == 0.0 and Io[i, 0] >= 0
+    assert neg >= 10, neg
+    for simple, filt in ((False, True), (False, False), (True, False)):
+        idx = faiss_amd.GpuIndexFlatL2(res, 96)
+        idx.set_use_simple_kernel(simple)
+        idx.set_use_filter_kernel(filt)
+        idx.add(xb)
+        D, I = idx.search(xq, 5)
+        check_knn(D, I, Do, Io, exact=True, name="clamp simple=%s filter=%s" % (simple, filt))
+        assert (D >= 0).all()
+
+
+# ------------------------------------------------------------------------------- config structs, fp16 storage
+@pytest.mark.parametrize("metric", [METRIC_L2, METRIC_INNER_PRODUCT])
+@pytest.mark.parametrize("d,nb,nq,k", [(128, 30000, 300, 10), (96, 20000, 257, 100), (40, 3000, 50, 7), (64, 50, 5, 8),
+                                        (128, 40000, 64, 2048)])
+def test_flat_use_float16_storage(res, metric, d, nb, nq, k):
+    """GpuIndexFlatConfig::useFloat16 (faiss/gpu/GpuIndexFlat.h:24-40, impl/FlatIndex.cu:39-135): vectors stored as fp16
+    only, queries converted to fp16, distances = fp32 arithmetic on those fp16 values.  Parity contract: bit-identical to
+    the fp32 path (and to the oracle) run on the fp16-rounded inputs -- on the filter path, the exact scan (small
+    database, k > 1024) and the scalar cross-check; half the resident bytes; reconstruct returns the stored values."""
+    _, xb, xq = synthetic_dataset(d, 0, nb, nq, seed=nb + k)
+    xb16, xq16 = xb.astype(np.float16).astype(np.float32), xq.astype(np.float16).astype(np.float32)
+    idx = faiss_amd.GpuIndexFlat(res, d, metric, faiss_amd.GpuIndexFlatConfig(useFloat16=True))
+    idx.add(xb[: nb // 3])
+    idx.add(xb[nb // 3:])
+    assert idx.ntotal == nb
+    D, I = idx.search(xq, k)
+    Do, Io = Oracle.flat_search(metric, xb16, xq16[:64], k)
+    check_knn(D[:64], I[:64], Do, Io, exact=True, name="fp16 storage vs oracle on rounded inputs")
+    ref = faiss_amd.GpuIndexFlat(res, d, metric)
+    ref.add(xb16)
+    D32, I32 = ref.search(xq16, k)
+    assert np.array_equal(I, I32) and np.array_equal(D, D32)
+    if nb >= 16384 and k <= 1024:
+        assert idx.filter_stats() == (True, 0)
+    idx.set_use_filter_kernel(False)
+    D2, I2 = idx.search(xq, k)
+    assert np.array_equal(I, I2) and np.array_equal(D, D2)
+    assert idx.resident_bytes < 0.45 * ref.resident_bytes + 65536
+    assert np.array_equal(idx.reconstruct_n(5, 40), xb16[5:45])
+    keys = np.array([0, nb - 1, 7, -1], dtype=np.int64)
+    rb = idx.reconstruct_batch(keys)
+    assert np.array_equal(rb[:3], xb16[keys[:3]]) and np.isnan(rb[3]).all()
+    assert np.array_equal(idx.compute_residual_n(xq[:3], keys[:3]), xq[:3] - xb16[keys[:3]])
+    # and against the original fp32 data: the fp16 rounding of the inputs is all that separates the two
+    Df, If = Oracle.flat_search(metric, xb, xq[:64], min(k, 10))
+    assert (I[:64, 0] == If[:, 0]).mean() > 0.9
+    assert np.allclose(D[:64, :1], Df[:, :1], rtol=5e-3, atol=5e-3 * float(np.abs(Df).max()))
+
+
+def test_config_structs_on_the_constructors(res):
+    """GpuIndexConfig / GpuIndexIVFConfig / GpuIndexIVFPQConfig fields (faiss/gpu/GpuIndex.h:30-47, GpuIndexIVF.h:24-38,
+    GpuIndexIVFPQ.h:25-49): accepted where they are meaningful or harmless here, refused loudly where not."""
+    d = 32
+    faiss_amd.GpuIndexFlat(res, d, METRIC_L2, faiss_amd.GpuIndexFlatConfig(device=0, storeTransposed=True))
+    with pytest.raises(faiss_amd.FaissAmdError):
+        faiss_amd.GpuIndexFlat(res, d, METRIC_L2, faiss_amd.GpuIndexFlatConfig(device=3))
+    with pytest.raises(faiss_amd.FaissAmdError):
+        faiss_amd.GpuIndexFlat(res, d, METRIC_L2, faiss_amd.GpuIndexFlatConfig(memorySpace=1))
+    faiss_amd.GpuIndexIVFFlat(res, d, 8, METRIC_L2, faiss_amd.GpuIndexIVFConfig(indicesOptions=2))  # INDICES_32_BIT
+    for bad in (dict(indicesOptions=0), dict(indicesOptions=1), dict(flat_useFloat16=True)):
+        with pytest.raises(faiss_amd.FaissAmdError):
+            faiss_amd.GpuIndexIVFFlat(res, d, 8, METRIC_L2, faiss_amd.GpuIndexIVFConfig(**bad))
+    xt, xb, xq = synthetic_dataset(d, 2000, 3000, 20, seed=3)
+    a = faiss_amd.GpuIndexIVFPQ(res, d, 8, 4, 8, METRIC_L2,
+                                faiss_amd.GpuIndexIVFPQConfig(useFloat16LookupTables=True, usePrecomputedTables=True))
+    b = faiss_amd.GpuIndexIVFPQ(res, d, 8, 4, 8, METRIC_L2)
+    for i in (a, b):
+        i.train(xt)
+        i.add(xb)
+        i.nprobe = 4
+    Da, Ia = a.search(xq, 5)
+    Db, Ib = b.search(xq, 5)
+    assert np.array_equal(Ia, Ib) and np.array_equal(Da, Db)  # the options do not change the arithmetic here

@@ -1,20 +1,26 @@
 #!/bin/bash
 # tools/profile_round.sh TAG -- the rocprofv3 passes behind profiles/<TAG>_* (run on the GPU box through gpurun):
-#   kernel trace + stats of the default bench.py command, and one --pmc pass per counter group on the
-#   flat search loop (never combined with runtime/sys tracing).
-TAG=${1:-r01_d}
+#   kernel trace + stats of the default bench.py command, and one --pmc pass per counter group on the flat / IVFPQ /
+#   IVFFlat search loops (counter passes carry --kernel-trace only, never runtime / sys tracing).
+TAG=${1:-r02_b}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_kt -o kt -- python $R/bench.py --steps 10 --warmup 3 > $O/${TAG}_bench.log 2>&1
-tail -1 $O/${TAG}_bench.log | grep '^{' > $O/${TAG}_bench_line.json
-i=0
-for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_ANY"; do
-    i=$((i + 1))
-    rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/${TAG}_pmc$i -o p -- python $R/tools/flat_only.py 3 > $O/${TAG}_pmc$i.log 2>&1
-done
-# IVFPQ scan: HBM traffic of the fused kernel
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${TAG}_pmc4 -o p -- python $R/tools/ivfpq_only.py 3 > $O/${TAG}_pmc4.log 2>&1
-python $R/tools/pmc_summary.py $O/${TAG}_pmc_counters.txt $O/${TAG}_pmc_counters.json $O/${TAG}_pmc1 $O/${TAG}_pmc2 $O/${TAG}_pmc3 $O/${TAG}_pmc4:ivfpq_fused | grep -i "flat_filter\|rerank\|ivfpq_fused" | cut -c1-230
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_kt -o kt -- python $R/bench.py --steps 10 --warmup 2 > $O/${TAG}_bench.log 2>&1
+grep '^{' $O/${TAG}_bench.log | tail -1 > $O/${TAG}_bench_line.json
 find $O/${TAG}_kt -name "*kernel_stats.csv" -exec cp {} $O/${TAG}_bench_kernel_stats.csv \;
-head -12 $O/${TAG}_bench_kernel_stats.csv | cut -c1-200
+python $R/tools/dispatch_summary.py $O/${TAG}_kt $O/${TAG}_dominant_kernel_dispatches.csv flat_filter_kernel ivfpq_fused_kernel ivfflat_fused_kernel
+dirs=""
+for w in flat ivfpq ivfflat; do
+  i=0
+  for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAVES"; do
+    i=$((i + 1))
+    rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/${TAG}_${w}_pmc$i -o p -- python $R/tools/${w}_only.py 3 > $O/${TAG}_${w}_pmc$i.log 2>&1
+    sub=$w; [ $w = flat ] && sub=flat_; [ $w != flat ] && sub=${w}_fused
+    dirs="$dirs $O/${TAG}_${w}_pmc$i:$sub"
+  done
+done
+python $R/tools/pmc_summary.py $O/${TAG}_pmc_counters.txt $O/${TAG}_pmc_counters.json $dirs | grep -i "filter_kernel\|rerank\|fused" | cut -c1-220
+head -14 $O/${TAG}_bench_kernel_stats.csv | cut -c1-200
+# keep the merged-back directory small: the raw traces stay on the box
+rm -rf $O/${TAG}_kt $O/${TAG}_*_pmc[0-9]
