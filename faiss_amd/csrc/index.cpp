@@ -1367,9 +1367,30 @@ void GpuIndexIVF::search_core_(idx_t n, const float* x, idx_t k, float* distance
                 fp.prefix_out = prefix_.as<uint32_t>();
             }
             fill_fused_(fp);
+            probe_len_.ensure((size_t)ni * np * 4);
+            probe_start_.ensure((size_t)ni * np * 8);
+            launch_ivf_probe_info(c_ids_.as<idx_t>(), (int64_t)ni * np, d_list_len_.as<uint32_t>(),
+                                  d_list_start_.as<int64_t>(), probe_len_.as<uint32_t>(), probe_start_.as<int64_t>(), R.stream);
+            fp.probe_len = probe_len_.as<uint32_t>();
+            fp.probe_start = probe_start_.as<int64_t>();
+            static const bool phases = getenv("FAISS_AMD_IVF_PHASES") != nullptr; // diagnostics only
+            DevBuf ticks;
+            if (phases && fp.kind == 1) {
+                ticks.ensure(64);
+                HIP_CHECK(hipMemsetAsync(ticks.p, 0, 64, R.stream));
+                fp.phase_ticks = ticks.as<unsigned long long>();
+            }
             {
                 SpanGuard sg(&R, fp.kind == 1 ? "ivfpq_fused_kernel" : "ivfflat_fused_kernel");
                 launch_ivf_fused(fp, R.stream);
+            }
+            if (fp.phase_ticks) {
+                unsigned long long h[5];
+                HIP_CHECK(hipMemcpyAsync(h, ticks.p, sizeof(h), hipMemcpyDeviceToHost, R.stream));
+                R.sync();
+                const double w = (double)std::max<unsigned long long>(h[4], 1);
+                fprintf(stderr, "ivfpq_fused_kernel phases, mean shader-clock ticks per workgroup (%llu workgroups): probes+query "
+                        "%.0f, table %.0f, scan %.0f, finish %.0f\n", h[4], h[0] / w, h[1] / w, h[2] / w, h[3] / w);
             }
             if (fp.G > 1) {
                 SelectParams sp{};

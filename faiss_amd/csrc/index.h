@@ -262,7 +262,7 @@ class GpuIndexIVF : public Index {
     virtual void fill_fused_(struct IvfFusedParams& p) const = 0;
     virtual int fused_kind_() const = 0;
     virtual int fused_M_() const { return 0; }
-    mutable DevBuf part_keys_, part_cnt_;
+    mutable DevBuf part_keys_, part_cnt_, probe_len_, probe_start_;
     void upload_list_tables_();
     void ensure_arena_(int64_t rows);
     // make room for new_len[l] entries in every list (relocating the lists that outgrow their slack); est[l]

@@ -105,8 +105,13 @@ __device__ __forceinline__ void fused_load_probes(const IvfFusedParams& p, int q
     for (int t = tid; t < p.nprobe; t += FB) {
         const int64_t l = p.coarse_ids[(int64_t)q * p.nprobe + t];
         L.lst[t] = (int)l;
-        L.pre[t + 1] = l >= 0 ? p.list_len[l] : 0u;
-        L.lstart[t] = l >= 0 ? p.list_start[l] : 0;
+        if (p.probe_len) {
+            L.pre[t + 1] = p.probe_len[(int64_t)q * p.nprobe + t];
+            L.lstart[t] = p.probe_start[(int64_t)q * p.nprobe + t];
+        } else {
+            L.pre[t + 1] = l >= 0 ? p.list_len[l] : 0u;
+            L.lstart[t] = l >= 0 ? p.list_start[l] : 0;
+        }
     }
     for (int m = tid; m < p.M; m += FB) L.colmax[m] = 0u;
     if (tid == 0) {
@@ -278,9 +283,58 @@ __global__ void __launch_bounds__(FB, 4) ivfpq_fused_kernel(IvfFusedParams p) { 
     const int M = M64 ? 64 : p.M, d = p.d, dsub = p.dsub;
     float* grid = (float*)(L.colmax + M);
 
+    long long t_ph = p.phase_ticks ? (long long)__builtin_readcyclecounter() : 0;
+    auto phase_mark = [&](int ph) {
+        if (p.phase_ticks && tid == 0) {
+            const long long now = (long long)__builtin_readcyclecounter();
+            atomicAdd(&p.phase_ticks[ph], (unsigned long long)(now - t_ph));
+            t_ph = now;
+        }
+    };
+    // (the query row is requested before the probe tables: its latency overlaps theirs)
+    const float q_first = tid < d ? p.xq[(int64_t)q * p.ldq + tid] : 0.f;
     fused_load_probes<FB>(p, q, L);
-    for (int cc = tid; cc < d; cc += FB) L.rs[cc] = p.xq[(int64_t)q * p.ldq + cc];
+    if (tid < d) L.rs[tid] = q_first;
+    for (int cc = tid + FB; cc < d; cc += FB) L.rs[cc] = p.xq[(int64_t)q * p.ldq + cc];
     __syncthreads();
+    // ---- block stream of this workgroup's probes [p0, p1): blocks [bpre[p0], bpre[p1])
+    const unsigned blk_begin = L.bpre[p0], blk_end = L.bpre[p1];
+    constexpr int NW = 4; // 16-byte code words per row (M64)
+    // one block of one wavefront on its way from HBM to the gathers: row `lane` of the block
+    struct Stage {
+        uint4 w[NW];        // code words (M64)
+        float t2;           // per-row L2 term
+        // wave-uniform (kept in scalar registers): coarse term of the block's list, scan position of the block's
+        // first row, rows of the list from that row on (0 = no block)
+        float dis0;
+        unsigned pos0, rem;
+        const uint8_t* bp;  // block base (generic M: codes are read in the gather loop)
+    };
+    int tcur = p0; // probe of the block fetched last (blocks are visited in increasing order)
+    auto fetch = [&](unsigned blk, Stage& st) {
+        st.rem = 0;
+        if (blk < blk_end) { // wave-uniform
+            while (L.bpre[tcur + 1] <= blk) ++tcur;
+            const unsigned b = blk - L.bpre[tcur];
+            const int64_t row0 = L.lstart[tcur] + (int64_t)b * 64;
+            st.bp = p.arena_codes + row0 * M;
+            if (M64) {
+#pragma unroll
+                for (int k = 0; k < NW; ++k) st.w[k] = *(const uint4*)(st.bp + k * 1024 + lane * 16);
+            }
+            if (METRIC == METRIC_L2) st.t2 = p.arena_t2[row0 + lane];
+            st.dis0 = __uint_as_float(__builtin_amdgcn_readfirstlane(
+                    __float_as_uint(p.coarse_dis[(int64_t)q * p.nprobe + tcur])));
+            st.pos0 = __builtin_amdgcn_readfirstlane(L.pre[tcur] + b * 64u);
+            st.rem = __builtin_amdgcn_readfirstlane(L.pre[tcur + 1] - L.pre[tcur] - b * 64u);
+        }
+    };
+    // the first two blocks of every wavefront are requested BEFORE the table is built: their HBM latency hides behind
+    // the codebook reads and the rounding
+    Stage s0, s1, s2;
+    fetch(blk_begin + wave, s0);
+    fetch(blk_begin + NWV + wave, s1);
+    phase_mark(0);
     // ---- the query's table (transposed codebook read through L2 once per query), its grid, the rounding
     const int ne = M * 256;
     auto publish_grid = [&]() {
@@ -345,38 +399,6 @@ __global__ void __launch_bounds__(FB, 4) ivfpq_fused_kernel(IvfFusedParams p) { 
     }
     __syncthreads();
 
-    // ---- block stream of this workgroup's probes [p0, p1): blocks [bpre[p0], bpre[p1])
-    const unsigned blk_begin = L.bpre[p0], blk_end = L.bpre[p1];
-    constexpr int NW = 4; // 16-byte code words per row (M64)
-    // one block of one wavefront on its way from HBM to the gathers: row `lane` of the block
-    struct Stage {
-        uint4 w[NW];        // code words (M64)
-        float t2;           // per-row L2 term
-        // wave-uniform (kept in scalar registers): coarse term of the block's list, scan position of the block's
-        // first row, rows of the list from that row on (0 = no block)
-        float dis0;
-        unsigned pos0, rem;
-        const uint8_t* bp;  // block base (generic M: codes are read in the gather loop)
-    };
-    int tcur = p0; // probe of the block fetched last (blocks are visited in increasing order)
-    auto fetch = [&](unsigned blk, Stage& st) {
-        st.rem = 0;
-        if (blk < blk_end) { // wave-uniform
-            while (L.bpre[tcur + 1] <= blk) ++tcur;
-            const unsigned b = blk - L.bpre[tcur];
-            const int64_t row0 = L.lstart[tcur] + (int64_t)b * 64;
-            st.bp = p.arena_codes + row0 * M;
-            if (M64) {
-#pragma unroll
-                for (int k = 0; k < NW; ++k) st.w[k] = *(const uint4*)(st.bp + k * 1024 + lane * 16);
-            }
-            if (METRIC == METRIC_L2) st.t2 = p.arena_t2[row0 + lane];
-            st.dis0 = __uint_as_float(__builtin_amdgcn_readfirstlane(
-                    __float_as_uint(p.coarse_dis[(int64_t)q * p.nprobe + tcur])));
-            st.pos0 = __builtin_amdgcn_readfirstlane(L.pre[tcur] + b * 64u);
-            st.rem = __builtin_amdgcn_readfirstlane(L.pre[tcur + 1] - L.pre[tcur] - b * 64u);
-        }
-    };
     // per-lane table columns: dword kk = 4 k + wd of the code, byte i -> column byte offset 4 * ((4 kk + i + lane) mod 64).
     // Kept in registers for k = 0 (rot[wd]); for k = 1..3 it is (rot[wd] + k * 0x40404040) & 0xfcfcfcfc: the bytes are
     // multiples of 4, a carry out of a byte can only set bit 0 of its neighbour, which the mask clears (two VALU
@@ -393,6 +415,7 @@ __global__ void __launch_bounds__(FB, 4) ivfpq_fused_kernel(IvfFusedParams p) { 
         if ((unsigned)(size_t)(const __attribute__((address_space(3))) char*)lut != 0u) __builtin_trap(); // see lds_f32
     }
 
+    phase_mark(1);
     u64 tau = ~0ull;
     int bound = 0;
     // gathers + key + append of one staged block
@@ -440,9 +463,6 @@ __global__ void __launch_bounds__(FB, 4) ivfpq_fused_kernel(IvfFusedParams p) { 
     // With one block ahead a workgroup on its own drew ~2/3 of the CU's fill bandwidth (load latency > gather time), so
     // the per-query fixed work of the OTHER workgroup of the CU (probe tables, table build, final selection) was not
     // hidden: 1.24 ms at nb = 1M against 0.44 ms of it being fixed cost (tools/ivfpq_sweep.py, nprobe 1 vs 32).
-    Stage s0, s1, s2;
-    fetch(blk_begin + wave, s0);
-    fetch(blk_begin + NWV + wave, s1);
     unsigned base = blk_begin;
     for (;;) {
         if (base >= blk_end) break;
@@ -464,7 +484,10 @@ __global__ void __launch_bounds__(FB, 4) ivfpq_fused_kernel(IvfFusedParams p) { 
         __syncthreads();
         base += NWV;
     }
+    phase_mark(2);
     fused_finish<FB>(p, q, g, L);
+    phase_mark(3);
+    if (p.phase_ticks && tid == 0) atomicAdd(&p.phase_ticks[4], 1ull);
 }
 
 // ---------------------------------------------------------------------------------

@@ -59,6 +59,23 @@ void launch_ivf_sanitize_assign(int64_t* ids, int64_t n, int nlist, hipStream_t 
     HIP_CHECK(hipGetLastError());
 }
 
+__global__ void ivf_probe_info_kernel(const int64_t* __restrict__ coarse_ids, int64_t n,
+                                      const uint32_t* __restrict__ list_len, const int64_t* __restrict__ list_start,
+                                      uint32_t* __restrict__ probe_len, int64_t* __restrict__ probe_start) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t l = coarse_ids[i];
+    probe_len[i] = l >= 0 ? list_len[l] : 0u;
+    probe_start[i] = l >= 0 ? list_start[l] : 0;
+}
+void launch_ivf_probe_info(const int64_t* coarse_ids, int64_t n, const uint32_t* list_len, const int64_t* list_start,
+                           uint32_t* probe_len, int64_t* probe_start, hipStream_t stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(ivf_probe_info_kernel, dim3((unsigned)div_up(n, 256)), dim3(256), 0, stream, coarse_ids, n, list_len,
+                       list_start, probe_len, probe_start);
+    HIP_CHECK(hipGetLastError());
+}
+
 void launch_ivf_prefix(const int64_t* coarse_ids, int nq, int nprobe, const uint32_t* list_len,
                        uint32_t* prefix, uint32_t* total, hipStream_t stream) {
     if (nq == 0) return;

@@ -212,6 +212,10 @@ void launch_ivf_sanitize_assign(int64_t* ids, int64_t n, int nlist, hipStream_t 
 void launch_ivf_prefix(const int64_t* coarse_ids, int nq, int nprobe, const uint32_t* list_len,
                        uint32_t* prefix, uint32_t* total, hipStream_t stream);
 
+// probe_len[i] / probe_start[i] = list_len / list_start of coarse_ids[i] (0 for "no list"), i < n = nq * nprobe
+void launch_ivf_probe_info(const int64_t* coarse_ids, int64_t n, const uint32_t* list_len, const int64_t* list_start,
+                           uint32_t* probe_len, int64_t* probe_start, hipStream_t stream);
+
 struct IvfScanParams {
     int metric;
     int nq, nprobe, d, dpad;
@@ -257,6 +261,13 @@ struct IvfFusedParams {
     const uint32_t* list_len;   // [nlist]
     const int64_t* list_start;  // [nlist]
     const int64_t* arena_ids;   // [ntotal]
+    // optional (both or neither): length and first arena row of every probed list, [nq][nprobe], gathered by
+    // launch_ivf_probe_info -- one load round trip per workgroup instead of two dependent ones
+    const uint32_t* probe_len;
+    const int64_t* probe_start;
+    // diagnostics (env FAISS_AMD_IVF_PHASES=1): shader clock ticks of workgroup phases summed over the launch,
+    // [0] probe tables + query, [1] table build, [2] scan, [3] final selection + write-out, [4] workgroups; else null
+    unsigned long long* phase_ticks;
     int k, kp, cap;             // kp = pow2 >= k; cap = LDS reservoir capacity (>= k + 512)
     int G, npc;                 // workgroups per query, probes per workgroup (G * npc >= nprobe)
     int nlut;                   // lookup tables in LDS: 2 = build of probe p+1 overlaps the scan of probe p

@@ -248,7 +248,7 @@ __global__ void __launch_bounds__(FB) wg_reservoir_test_kernel(int metric, const
     u64* res = (u64*)smem;                          // [cap]
     int64_t* w_id = (int64_t*)(res + cap);          // [kp]
     unsigned* w_key = (unsigned*)(w_id + kp);       // [kp]
-    unsigned* hist = w_key + kp;                    // [256]
+    unsigned* hist = w_key + ((kp + 1) & ~1);       // [256] (8-byte aligned: WgSelCtl holds a 64-bit atomic)
     WgSelCtl* ctl = (WgSelCtl*)(hist + 256);
     const int tid = threadIdx.x, r = blockIdx.x;
     const u64* row = keys + (int64_t)r * cols;
@@ -331,7 +331,7 @@ void launch_select_test(int which, int metric, const float* vals, int rows, int 
         while (kp < k) kp <<= 1;
         int cap = 1024;
         while (cap < k + FB) cap <<= 1;
-        const size_t lds = (size_t)cap * 8 + (size_t)kp * 12 + 1024 + 64;
+        const size_t lds = (size_t)cap * 8 + (size_t)kp * 8 + (size_t)((kp + 1) & ~1) * 4 + 1024 + 64;
         HIP_CHECK(hipFuncSetAttribute((const void*)wg_reservoir_test_kernel<FB>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds));
         hipLaunchKernelGGL((wg_reservoir_test_kernel<FB>), dim3((unsigned)rows), dim3(FB), lds, stream, metric, keys, cols, k,
