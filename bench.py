@@ -255,13 +255,13 @@ def committed_traffic(kernel_substr, alg_bytes):
 
 
 def committed_mfma_busy(kernel_substr):
-    """MFMA-busy share of the dominant flat kernel from the committed SQ pass: SQ_VALU_MFMA_BUSY_CYCLES /
-    (GRBM_GUI_ACTIVE x 1024 SIMDs)."""
+    """MFMA-busy share of the dominant flat kernel from the committed SQ pass: SQ_VALU_MFMA_BUSY_CYCLES (cycles, summed
+    over the 1024 SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs = active cycles of the launch) / 1024."""
     try:
         pmc = json.load(open(PROFILE_JSON))
         ent = [v for k, v in pmc.items() if kernel_substr in k and "SQ_VALU_MFMA_BUSY_CYCLES" in v and "GRBM_GUI_ACTIVE" in v]
         e = max(ent, key=lambda v: v.get("avg_duration_ns", 0))
-        return round(e["SQ_VALU_MFMA_BUSY_CYCLES"] / (e["GRBM_GUI_ACTIVE"] * 1024.0), 4)
+        return round(e["SQ_VALU_MFMA_BUSY_CYCLES"] / (e["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), 4)
     except (OSError, KeyError, ValueError, IndexError):
         return None
 

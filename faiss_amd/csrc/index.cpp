@@ -1358,8 +1358,13 @@ void GpuIndexIVF::search_core_(idx_t n, const float* x, idx_t k, float* distance
             fp.G = (int)div_up(np, fp.npc);
             fp.out_dis = dD;
             fp.out_ids = dI;
-            if (fp.G > 1) {
-                part_keys_.ensure((size_t)ni * fp.G * k * 8);
+            // large batches of IVFPQ: the final selection of a query runs in its own launch (select_k_kernel)
+            static const char* defer_env = getenv("FAISS_AMD_IVF_DEFER"); // timing experiments only: 0 / 1
+            fp.defer_finish = fp.G == 1 && fp.kind == 1 && ni >= want && (!defer_env || atoi(defer_env) != 0) ? 1 : 0;
+            if (defer_env && atoi(defer_env) == 1 && fp.G == 1) fp.defer_finish = 1;
+            if (fp.G > 1 || fp.defer_finish) {
+                const size_t per_q = fp.defer_finish ? (size_t)fp.cap : (size_t)fp.G * k;
+                part_keys_.ensure((size_t)ni * per_q * 8);
                 part_cnt_.ensure((size_t)ni * fp.G * 4);
                 prefix_.ensure((size_t)ni * (np + 1) * 4);
                 fp.part_keys = part_keys_.as<unsigned long long>();
@@ -1392,13 +1397,13 @@ void GpuIndexIVF::search_core_(idx_t n, const float* x, idx_t k, float* distance
                 fprintf(stderr, "ivfpq_fused_kernel phases, mean shader-clock ticks per workgroup (%llu workgroups): probes+query "
                         "%.0f, table %.0f, scan %.0f, finish %.0f\n", h[4], h[0] / w, h[1] / w, h[2] / w, h[3] / w);
             }
-            if (fp.G > 1) {
+            if (fp.G > 1 || fp.defer_finish) {
                 SelectParams sp{};
                 sp.metric = metric_type;
                 sp.nq = ni;
                 sp.k = (int)k;
                 sp.keys = fp.part_keys;
-                sp.q_stride = (int64_t)fp.G * k;
+                sp.q_stride = fp.defer_finish ? (int64_t)fp.cap : (int64_t)fp.G * k;
                 sp.nseg = fp.G;
                 sp.seg_stride = k;
                 sp.seg_cnt = fp.part_cnt;

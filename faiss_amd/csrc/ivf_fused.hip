@@ -174,6 +174,15 @@ __device__ __forceinline__ void fused_finish(const IvfFusedParams& p, int q, int
     const int tid = threadIdx.x;
     __syncthreads();
     int n = (int)L.ctl->cnt;
+    if (p.defer_finish) {
+        // the reservoir as it is: the selection runs in its own launch at many workgroups per CU instead of on the
+        // critical path of this one (33 k of 146 k cycles per workgroup at nb = 1M, tools/ivfpq_phases.py)
+        u64* out = p.part_keys + (int64_t)q * p.cap;
+        for (int i = tid; i < n; i += FB) out[i] = L.res[i];
+        if (tid == 0) p.part_cnt[q] = (uint32_t)n;
+        for (int t = tid; t <= p.nprobe; t += FB) p.prefix_out[(int64_t)q * (p.nprobe + 1) + t] = L.pre[t];
+        return;
+    }
     if (n > p.k) {
         const u64 kth = wg_select_kth<FB>(L.res, n, p.k, L.hist, L.ctl);
         wg_compact<FB>(L.res, n, kth, L.ctl);

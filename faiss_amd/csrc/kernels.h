@@ -270,6 +270,8 @@ struct IvfFusedParams {
     unsigned long long* phase_ticks;
     int k, kp, cap;             // kp = pow2 >= k; cap = LDS reservoir capacity (>= k + 512)
     int G, npc;                 // workgroups per query, probes per workgroup (G * npc >= nprobe)
+    int defer_finish;           // G == 1: leave the final k-selection / id translation / ordering to launch_select_k
+                                // (mode 1): the workgroup writes its reservoir (<= cap keys) to part_keys[q][cap]
     int nlut;                   // lookup tables in LDS: 2 = build of probe p+1 overlaps the scan of probe p
     float* out_dis;             // [nq][k]   (G == 1)
     int64_t* out_ids;           // [nq][k]   (G == 1)

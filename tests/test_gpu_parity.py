@@ -851,7 +851,11 @@ def test_flat_use_float16_storage(res, metric, d, nb, nq, k):
     idx.set_use_filter_kernel(False)
     D2, I2 = idx.search(xq, k)
     assert np.array_equal(I, I2) and np.array_equal(D, D2)
-    assert idx.resident_bytes < 0.45 * ref.resident_bytes + 65536
+    # the fp32 rows are gone (the fp16 rows are what the filter kernel reads anyway): 264 instead of 776 bytes per
+    # vector at d = 128
+    assert idx.resident_bytes == ref.resident_bytes - nb * ((d + 7) // 8 * 8) * 4
+    if d >= 96:
+        assert idx.resident_bytes < 0.45 * ref.resident_bytes
     assert np.array_equal(idx.reconstruct_n(5, 40), xb16[5:45])
     keys = np.array([0, nb - 1, 7, -1], dtype=np.int64)
     rb = idx.reconstruct_batch(keys)
