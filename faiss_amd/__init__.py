@@ -48,6 +48,9 @@ def load_library():
         "faiss_amd_StandardGpuResources_sync": (i32, [vp]),
         "faiss_amd_StandardGpuResources_getDefaultStream": (i32, [vp, P(vp)]),
         "faiss_amd_StandardGpuResources_setTempMemory": (i32, [vp, sz]),
+        "faiss_amd_StandardGpuResources_setPagedSearch": (i32, [vp, sz, i64]),
+        "faiss_amd_StandardGpuResources_getPagedSearchCount": (i32, [vp, P(i64)]),
+        "faiss_amd_StandardGpuResources_setDefaultStream": (i32, [vp, vp]),
         "faiss_amd_GpuIndexFlat_new": (i32, [P(vp), vp, i32, i32]),
         "faiss_amd_GpuIndexIVFFlat_new": (i32, [P(vp), vp, i32, i32, i32]),
         "faiss_amd_GpuIndexIVFPQ_new": (i32, [P(vp), vp, i32, i32, i32, i32, i32]),
@@ -172,6 +175,21 @@ class StandardGpuResources:
 
     def setTempMemory(self, nbytes):
         _check(self._lib.faiss_amd_StandardGpuResources_setTempMemory(self._h, int(nbytes)))
+
+    def setDefaultStream(self, stream):
+        """order all work of this resources object on `stream` (a hipStream_t value, e.g.
+        torch.cuda.current_stream().cuda_stream); None / 0 = back to the private stream"""
+        _check(self._lib.faiss_amd_StandardGpuResources_setDefaultStream(self._h, ctypes.c_void_p(stream or 0)))
+
+    def setPagedSearch(self, min_bytes=64 << 20, page_queries=0):
+        """host-resident query batches of at least min_bytes take the pinned double-buffered path"""
+        _check(self._lib.faiss_amd_StandardGpuResources_setPagedSearch(self._h, int(min_bytes), int(page_queries)))
+
+    @property
+    def paged_search_count(self):
+        v = ctypes.c_int64(0)
+        _check(self._lib.faiss_amd_StandardGpuResources_getPagedSearchCount(self._h, ctypes.byref(v)))
+        return v.value
 
     # measurement hooks ---------------------------------------------------------------
     def profile_enable(self, on=True):

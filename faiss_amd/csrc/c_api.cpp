@@ -121,6 +121,23 @@ int faiss_amd_StandardGpuResources_getDefaultStream(FaissAmdGpuResources* res, v
     *p_stream = (void*)R(res)->stream;
     FA_CATCH
 }
+int faiss_amd_StandardGpuResources_setPagedSearch(FaissAmdGpuResources* res, size_t min_bytes, int64_t page_queries) {
+    FA_TRY
+    FA_THROW_IF_NOT_MSG(page_queries >= 0, "negative page size");
+    R(res)->paged_min_bytes = min_bytes;
+    R(res)->paged_page_queries = page_queries;
+    FA_CATCH
+}
+int faiss_amd_StandardGpuResources_getPagedSearchCount(FaissAmdGpuResources* res, int64_t* p_count) {
+    FA_TRY
+    *p_count = R(res)->paged_searches;
+    FA_CATCH
+}
+int faiss_amd_StandardGpuResources_setDefaultStream(FaissAmdGpuResources* res, void* stream) {
+    FA_TRY
+    R(res)->set_default_stream((hipStream_t)stream);
+    FA_CATCH
+}
 int faiss_amd_StandardGpuResources_setTempMemory(FaissAmdGpuResources* res, size_t bytes) {
     FA_TRY
     FA_THROW_IF_NOT_MSG(bytes >= ((size_t)64 << 20), "temp memory must be at least 64 MiB");

@@ -60,7 +60,8 @@ GpuResources::GpuResources(int device_) : device(device_) {
     }
     FA_THROW_IF_NOT_MSG(device >= 0 && device < n, "invalid device");
     HIP_CHECK(hipSetDevice(device));
-    HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    HIP_CHECK(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
+    stream = own_stream_;
     hipDeviceProp_t prop;
     HIP_CHECK(hipGetDeviceProperties(&prop, device));
     num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -71,7 +72,26 @@ GpuResources::~GpuResources() {
         (void)hipEventDestroy(s.a);
         (void)hipEventDestroy(s.b);
     }
-    if (stream) (void)hipStreamDestroy(stream);
+    if (pager.events) {
+        for (int s = 0; s < 2; s++) {
+            (void)hipEventDestroy(pager.q_ready[s]);
+            (void)hipEventDestroy(pager.r_ready[s]);
+            (void)hipEventDestroy(pager.r_copied[s]);
+        }
+    }
+    for (int s = 0; s < 2; s++) {
+        if (pager.pin_q[s]) (void)hipHostFree(pager.pin_q[s]);
+        if (pager.pin_d[s]) (void)hipHostFree(pager.pin_d[s]);
+        if (pager.pin_i[s]) (void)hipHostFree(pager.pin_i[s]);
+    }
+    if (pager.copy_stream) (void)hipStreamDestroy(pager.copy_stream);
+    if (own_stream_) (void)hipStreamDestroy(own_stream_);
+}
+void GpuResources::set_default_stream(hipStream_t s) {
+    set_device();
+    collect(); // (timing events were recorded on the old stream)
+    sync();
+    stream = s ? s : own_stream_;
 }
 void GpuResources::set_device() const {
     HIP_CHECK(hipSetDevice(device));
@@ -153,6 +173,94 @@ static void copy_out(const GpuResources& res, void* dst, const void* dsrc, size_
     HIP_CHECK(hipMemcpyAsync(dst, dsrc, bytes,
                              is_device_pointer(dst) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
                              res.stream));
+}
+
+// ====================================================================== paged host search
+// Pages of a host-resident query batch through pinned double buffers: while the kernels of page p run on the
+// resources' stream, the copy stream moves page p+1 to the device and the results of page p-1 back, and the host
+// thread does the pageable <-> pinned memcpys of both.  `compute(ni, dq, dD, dI)` searches one page whose queries
+// (dense [ni][d]), distances and labels are DEVICE buffers; it enqueues on R.stream (it may synchronise).
+// Reference: GpuIndex::searchFromCpuPaged_ (faiss/gpu/GpuIndex.cu:554-774).
+template <typename Compute>
+static void paged_host_search(const GpuResources& R, idx_t n, const float* x, int d, idx_t k, float* distances,
+                              idx_t* labels, idx_t page, Compute compute) {
+    GpuResources::Pager& P = R.pager;
+    if (!P.copy_stream) HIP_CHECK(hipStreamCreateWithFlags(&P.copy_stream, hipStreamNonBlocking));
+    if (!P.events) {
+        for (int s = 0; s < 2; s++) {
+            HIP_CHECK(hipEventCreateWithFlags(&P.q_ready[s], hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&P.r_ready[s], hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&P.r_copied[s], hipEventDisableTiming));
+        }
+        P.events = true;
+    }
+    const size_t qbytes = (size_t)page * d * 4, rbytes = (size_t)page * k * 8;
+    if (qbytes > P.pin_q_cap) {
+        for (int s = 0; s < 2; s++) {
+            if (P.pin_q[s]) (void)hipHostFree(P.pin_q[s]);
+            HIP_CHECK(hipHostMalloc(&P.pin_q[s], qbytes, hipHostMallocDefault));
+        }
+        P.pin_q_cap = qbytes;
+    }
+    if (rbytes > P.pin_r_cap) {
+        for (int s = 0; s < 2; s++) {
+            if (P.pin_d[s]) (void)hipHostFree(P.pin_d[s]);
+            if (P.pin_i[s]) (void)hipHostFree(P.pin_i[s]);
+            HIP_CHECK(hipHostMalloc(&P.pin_d[s], rbytes / 2, hipHostMallocDefault));
+            HIP_CHECK(hipHostMalloc(&P.pin_i[s], rbytes, hipHostMallocDefault));
+        }
+        P.pin_r_cap = rbytes;
+    }
+    DevBuf dq[2], dD[2], dI[2];
+    for (int s = 0; s < 2; s++) {
+        dq[s].ensure(qbytes);
+        dD[s].ensure((size_t)page * k * 4);
+        dI[s].ensure((size_t)page * k * 8);
+    }
+    const idx_t npages = (n + page - 1) / page;
+    auto rows = [&](idx_t p) { return std::min(page, n - p * page); };
+    auto issue_h2d = [&](idx_t p) {
+        const int s = (int)(p & 1);
+        // (slot s was last read by the H2D of page p-2, which the kernels of page p-2 waited for: long complete)
+        memcpy(P.pin_q[s], x + (size_t)p * page * d, (size_t)rows(p) * d * 4);
+        HIP_CHECK(hipMemcpyAsync(dq[s].p, P.pin_q[s], (size_t)rows(p) * d * 4, hipMemcpyHostToDevice, P.copy_stream));
+        HIP_CHECK(hipEventRecord(P.q_ready[s], P.copy_stream));
+    };
+    auto drain = [&](idx_t p) {
+        const int s = (int)(p & 1);
+        HIP_CHECK(hipEventSynchronize(P.r_copied[s]));
+        memcpy(distances + (size_t)p * page * k, P.pin_d[s], (size_t)rows(p) * k * 4);
+        memcpy(labels + (size_t)p * page * k, P.pin_i[s], (size_t)rows(p) * k * 8);
+    };
+    issue_h2d(0);
+    for (idx_t p = 0; p < npages; p++) {
+        const int s = (int)(p & 1);
+        const idx_t ni = rows(p);
+        if (p + 1 < npages) issue_h2d(p + 1);
+        HIP_CHECK(hipStreamWaitEvent(R.stream, P.q_ready[s], 0));
+        if (p >= 2) HIP_CHECK(hipStreamWaitEvent(R.stream, P.r_copied[s], 0)); // result slot s free again
+        compute(ni, dq[s].as<float>(), dD[s].as<float>(), dI[s].as<idx_t>());
+        HIP_CHECK(hipEventRecord(P.r_ready[s], R.stream));
+        HIP_CHECK(hipStreamWaitEvent(P.copy_stream, P.r_ready[s], 0));
+        HIP_CHECK(hipMemcpyAsync(P.pin_d[s], dD[s].p, (size_t)ni * k * 4, hipMemcpyDeviceToHost, P.copy_stream));
+        HIP_CHECK(hipMemcpyAsync(P.pin_i[s], dI[s].p, (size_t)ni * k * 8, hipMemcpyDeviceToHost, P.copy_stream));
+        HIP_CHECK(hipEventRecord(P.r_copied[s], P.copy_stream));
+        if (p >= 1) drain(p - 1); // its D2H had the kernels of page p to complete under
+    }
+    drain(npages - 1);
+    R.sync();
+    R.paged_searches++;
+}
+// page size of a paged search: at least four pages, whole thousands of queries, never more than `tile`
+static idx_t paged_page_size(const GpuResources& R, idx_t n, idx_t tile) {
+    if (R.paged_page_queries > 0) return std::min<idx_t>(R.paged_page_queries, tile);
+    idx_t page = std::max<idx_t>(4096, (n / 4 + 1023) / 1024 * 1024);
+    return std::min<idx_t>(std::min<idx_t>(page, 65536), tile);
+}
+static bool use_paged_path(const GpuResources& R, idx_t n, int d, const float* x, const float* distances,
+                           const idx_t* labels) {
+    return (size_t)n * d * 4 >= R.paged_min_bytes && !is_device_pointer(x) && !is_device_pointer(distances) &&
+           !is_device_pointer(labels);
 }
 
 // ====================================================================== GpuIndexFlat
@@ -725,6 +833,17 @@ void GpuIndexFlat::search(idx_t n, const float* x, idx_t k, float* distances, id
     std::lock_guard<std::mutex> g(mu_);
     res_->set_device();
     const GpuResources& R = *res_;
+    if (use_paged_path(R, n, d, x, distances, labels)) {
+        const idx_t page = paged_page_size(R, n, flat_query_tile(R, (int)k, use_simple_kernel, ntotal));
+        paged_host_search(R, n, x, d, k, distances, labels, page, [&](idx_t ni, const float* dq, float* dD, idx_t* dI) {
+            search_body_(ni, dq, k, dD, dI);
+        });
+        return;
+    }
+    search_body_(n, x, k, distances, labels);
+}
+void GpuIndexFlat::search_body_(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels) const {
+    const GpuResources& R = *res_;
     const bool out_dev_d = is_device_pointer(distances), out_dev_i = is_device_pointer(labels);
     const idx_t tile = flat_query_tile(R, (int)k, use_simple_kernel, ntotal);
     for (idx_t i0 = 0; i0 < n; i0 += tile) {
@@ -1283,6 +1402,21 @@ void GpuIndexIVF::search_core_(idx_t n, const float* x, idx_t k, float* distance
     FA_THROW_IF_NOT_MSG(x && distances && labels, "null argument");
     std::lock_guard<std::mutex> g(mu_);
     res_->set_device();
+    const GpuResources& R = *res_;
+    if (use_paged_path(R, n, d, x, distances, labels)) {
+        const idx_t page = paged_page_size(R, n, 65536);
+        idx_t done = 0; // pages come in order
+        paged_host_search(R, n, x, d, k, distances, labels, page, [&](idx_t ni, const float* dq, float* dD, idx_t* dI) {
+            search_core_body_(ni, dq, k, dD, dI, assign ? assign + (size_t)done * nprobe_now : nullptr,
+                              centroid_dis ? centroid_dis + (size_t)done * nprobe_now : nullptr, nprobe_now);
+            done += ni;
+        });
+        return;
+    }
+    search_core_body_(n, x, k, distances, labels, assign, centroid_dis, nprobe_now);
+}
+void GpuIndexIVF::search_core_body_(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels, const idx_t* assign,
+                                    const float* centroid_dis, int nprobe_now) const {
     const GpuResources& R = *res_;
     // preassigned arrays are [n][nprobe] whatever nlist is (surplus columns hold -1)
     const int np = assign ? nprobe_now : std::min(nprobe_now, nlist);

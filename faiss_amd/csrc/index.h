@@ -47,12 +47,33 @@ class GpuResources {
     explicit GpuResources(int device = 0);
     ~GpuResources();
     int device;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr; // the stream all work is ordered on: own_stream_ or the caller's (set_default_stream)
+    hipStream_t own_stream_ = nullptr;
+    // StandardGpuResources::setDefaultStream: order all further work on the caller's stream (null: back to our own).
+    // Pending work on the old stream is drained first.
+    void set_default_stream(hipStream_t s);
     int num_cus = 256;
     size_t temp_budget_bytes = (size_t)4 << 30; // cap for per-search scratch (reservoirs, IVF keys)
 
     void set_device() const;
     void sync() const;
+
+    // ---- paged search of host-resident query batches (reference: GpuIndex::searchFromCpuPaged_, faiss/gpu/GpuIndex.cu:
+    // 554-774): pinned double buffers + a copy stream, so that the H2D of page p+1 and the D2H of page p-1 run under the
+    // kernels of page p.  Batches below paged_min_bytes take the direct path (one pageable copy each way).
+    size_t paged_min_bytes = (size_t)64 << 20; // reference: 256 MiB (GpuIndex.cu:29); ours pipelines earlier
+    idx_t paged_page_queries = 0;              // 0 = automatic; tests set small pages
+    struct Pager {
+        hipStream_t copy_stream = nullptr;
+        void* pin_q[2] = {nullptr, nullptr};
+        void* pin_d[2] = {nullptr, nullptr};
+        void* pin_i[2] = {nullptr, nullptr};
+        size_t pin_q_cap = 0, pin_r_cap = 0;
+        hipEvent_t q_ready[2], r_ready[2], r_copied[2];
+        bool events = false;
+    };
+    mutable Pager pager;
+    mutable long paged_searches = 0; // statistics: calls that took the paged path
 
     // ---- per-kernel timing with HIP events on `stream`
     bool profiling = false;
@@ -131,6 +152,8 @@ class GpuIndexFlat : public Index {
     // device-resident search used internally (IVF coarse quantizer): xq_pad is [n][dpad] on the
     // device; results stay on the device.
     void search_device(int n, const float* xq_pad, int k, float* dD, idx_t* dI) const;
+    // search() without taking the lock / choosing the host path (x, distances, labels each host or device)
+    void search_body_(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels) const;
     // test hook: full distance matrix [n][ntotal] through the MFMA kernel (host or device out)
     void pairwise_distances(idx_t n, const float* x, float* out) const;
     // when true, search() uses the scalar cross-check kernel instead of the MFMA kernel
@@ -272,6 +295,8 @@ class GpuIndexIVF : public Index {
     void add_core_(idx_t n, const float* x, const idx_t* xids);
     void search_core_(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels, const idx_t* assign,
                       const float* centroid_dis, int nprobe_now) const;
+    void search_core_body_(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels, const idx_t* assign,
+                           const float* centroid_dis, int nprobe_now) const;
 
    public:
     // when false, search() takes the unfused path (every distance as a key in HBM + select);

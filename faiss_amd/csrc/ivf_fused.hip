@@ -327,22 +327,25 @@ __global__ void __launch_bounds__(FB, 4) ivfpq_fused_kernel(IvfFusedParams p) { 
             const unsigned b = blk - L.bpre[tcur];
             const int64_t row0 = L.lstart[tcur] + (int64_t)b * 64;
             st.bp = p.arena_codes + row0 * M;
-            if (M64) {
+            st.rem = __builtin_amdgcn_readfirstlane(L.pre[tcur + 1] - L.pre[tcur] - b * 64u);
+            // only the rows the list really holds are requested: the last block of a list is on average half empty,
+            // 13 % of the code traffic at nb / nlist = 244 rows per list
+            if ((unsigned)lane < st.rem) {
+                if (M64) {
 #pragma unroll
-                for (int k = 0; k < NW; ++k) st.w[k] = *(const uint4*)(st.bp + k * 1024 + lane * 16);
+                    for (int k = 0; k < NW; ++k) st.w[k] = *(const uint4*)(st.bp + k * 1024 + lane * 16);
+                }
+                if (METRIC == METRIC_L2) st.t2 = p.arena_t2[row0 + lane];
             }
-            if (METRIC == METRIC_L2) st.t2 = p.arena_t2[row0 + lane];
             st.dis0 = __uint_as_float(__builtin_amdgcn_readfirstlane(
                     __float_as_uint(p.coarse_dis[(int64_t)q * p.nprobe + tcur])));
             st.pos0 = __builtin_amdgcn_readfirstlane(L.pre[tcur] + b * 64u);
-            st.rem = __builtin_amdgcn_readfirstlane(L.pre[tcur + 1] - L.pre[tcur] - b * 64u);
         }
     };
-    // the first two blocks of every wavefront are requested BEFORE the table is built: their HBM latency hides behind
-    // the codebook reads and the rounding
-    Stage s0, s1, s2;
+    // the first block of every wavefront is requested BEFORE the table is built: its HBM latency hides behind the
+    // codebook reads and the rounding
+    Stage s0, s1;
     fetch(blk_begin + wave, s0);
-    fetch(blk_begin + NWV + wave, s1);
     phase_mark(0);
     // ---- the query's table (transposed codebook read through L2 once per query), its grid, the rounding
     const int ne = M * 256;
@@ -408,14 +411,11 @@ __global__ void __launch_bounds__(FB, 4) ivfpq_fused_kernel(IvfFusedParams p) { 
     }
     __syncthreads();
 
-    // per-lane table columns: dword kk = 4 k + wd of the code, byte i -> column byte offset 4 * ((4 kk + i + lane) mod 64).
-    // Kept in registers for k = 0 (rot[wd]); for k = 1..3 it is (rot[wd] + k * 0x40404040) & 0xfcfcfcfc: the bytes are
-    // multiples of 4, a carry out of a byte can only set bit 0 of its neighbour, which the mask clears (two VALU
-    // instructions per four gathers instead of twelve more registers -- the three-stage prefetch needs them).
-    unsigned rot[4];
+    // per-lane table columns: rot[kk] byte i = 4 * ((4 kk + i + lane) mod 64) for dword kk of the code
+    unsigned rot[16];
     if (M64) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 16; ++k) {
             unsigned r = 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) r |= ((4u * (unsigned)(4 * k + i + lane)) & 255u) << (8 * i);
@@ -438,13 +438,9 @@ __global__ void __launch_bounds__(FB, 4) ivfpq_fused_kernel(IvfFusedParams p) { 
 #pragma unroll
                 for (int k = 0; k < NW; ++k) {
                     const unsigned w4[4] = {st.w[k].x, st.w[k].y, st.w[k].z, st.w[k].w};
-                    // (a scalar register written HERE: keeps the twelve derived values from being hoisted out of the
-                    // block loop as loop invariants, which would bring the register pressure back)
-                    unsigned kadd = 0x40404040u * (unsigned)k;
-                    asm volatile("" : "+s"(kadd));
 #pragma unroll
                     for (int wd = 0; wd < 4; ++wd) {
-                        const unsigned ro = k == 0 ? rot[wd] : ((rot[wd] + kadd) & 0xfcfcfcfcu);
+                        const unsigned ro = rot[4 * k + wd];
                         a0 += lds_f32(lut_addr64<0>(w4[wd], ro));
                         a1 += lds_f32(lut_addr64<1>(w4[wd], ro));
                         a2 += lds_f32(lut_addr64<2>(w4[wd], ro));
@@ -468,28 +464,21 @@ __global__ void __launch_bounds__(FB, 4) ivfpq_fused_kernel(IvfFusedParams p) { 
         }
         wg_append(L.res, L.ctl, pass, key);
     };
-    // Three stages per wavefront: while block i is gathered, blocks i + 1 and i + 2 are in flight (8 KB per wavefront).
-    // With one block ahead a workgroup on its own drew ~2/3 of the CU's fill bandwidth (load latency > gather time), so
-    // the per-query fixed work of the OTHER workgroup of the CU (probe tables, table build, final selection) was not
-    // hidden: 1.24 ms at nb = 1M against 0.44 ms of it being fixed cost (tools/ivfpq_sweep.py, nprobe 1 vs 32).
+    // Two stages per wavefront: while block i is gathered, block i + 1 is in flight.  (A third stage was measured
+    // and dropped: no gain -- with both workgroups of a CU scanning the kernel already moves ~5.2 TB/s of actual traffic,
+    // the fabric's limit -- and it needed the table columns recomputed per gather to fit 128 registers.)
     unsigned base = blk_begin;
     for (;;) {
         if (base >= blk_end) break;
         FUSED_MAKE_ROOM(FB);
-        fetch(base + 2 * NWV + wave, s2);
+        fetch(base + NWV + wave, s1);
         scan(s0);
         __syncthreads();
         base += NWV;
         if (base >= blk_end) break;
         FUSED_MAKE_ROOM(FB);
-        fetch(base + 2 * NWV + wave, s0);
+        fetch(base + NWV + wave, s0);
         scan(s1);
-        __syncthreads();
-        base += NWV;
-        if (base >= blk_end) break;
-        FUSED_MAKE_ROOM(FB);
-        fetch(base + 2 * NWV + wave, s1);
-        scan(s2);
         __syncthreads();
         base += NWV;
     }

@@ -51,6 +51,18 @@ int faiss_amd_StandardGpuResources_getDefaultStream(FaissAmdGpuResources* res, v
 /* c_api/gpu/StandardGpuResources_c.h:41 faiss_StandardGpuResources_setTempMemory */
 int faiss_amd_StandardGpuResources_setTempMemory(FaissAmdGpuResources* res, size_t bytes);
 
+/* paged search of host-resident query batches (GpuIndex::searchFromCpuPaged_, faiss/gpu/GpuIndex.cu:554-774): batches of
+ * at least min_bytes of queries (reference: 256 MiB; default here 64 MiB) go through pinned double buffers and a copy
+ * stream, page_queries queries at a time (0 = automatic).  *p_count (nullable) receives the number of searches that
+ * took this path so far. */
+int faiss_amd_StandardGpuResources_setPagedSearch(FaissAmdGpuResources* res, size_t min_bytes, int64_t page_queries);
+int faiss_amd_StandardGpuResources_getPagedSearchCount(FaissAmdGpuResources* res, int64_t* p_count);
+/* faiss::gpu::StandardGpuResources::setDefaultStream (faiss/gpu/StandardGpuResources.h): all work of the indexes of `res`
+ * is ordered on `stream` (a hipStream_t) from now on -- hand in the stream that produced device-resident inputs (e.g.
+ * torch.cuda.current_stream().cuda_stream) and no cross-stream synchronisation is needed; NULL restores the private
+ * stream.  The caller keeps owning the stream. */
+int faiss_amd_StandardGpuResources_setDefaultStream(FaissAmdGpuResources* res, void* stream);
+
 /* ---- constructors
  * faiss/gpu/GpuIndexFlat.h:62-72   GpuIndexFlat(resources, dims, metric, config)
  * faiss/gpu/GpuIndexIVFFlat.h:49-57 GpuIndexIVFFlat(resources, dims, nlist, metric, config)

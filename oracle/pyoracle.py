@@ -31,8 +31,27 @@ def _p(a):
     return ctypes.c_void_p(a.ctypes.data) if a is not None else None
 
 
+def effective_cores():
+    """CPUs this process may really use: scheduler affinity capped by the cgroup CPU quota"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def _f32(x):
     return np.ascontiguousarray(x, dtype=np.float32)
+
+
+# both libraries size their OpenMP pools when they are loaded: keep them inside the CPU quota (see effective_cores)
+os.environ.setdefault("OMP_NUM_THREADS", str(effective_cores()))
 
 
 class Oracle:
@@ -306,6 +325,9 @@ class Ref:
             lib.ref_index_ntotal.restype = ctypes.c_int64
             lib.ref_shards_new.restype = ctypes.c_void_p
             cls._lib = lib
+            # OpenMP sizes its pool by the visible CPUs; under a cgroup quota (GPU boxes: 256 visible, 16 allowed) that
+            # many threads are throttled to a crawl -- use what the process may really run on
+            lib.ref_set_omp_threads(ctypes.c_int(effective_cores()))
         return cls._lib
 
     @classmethod

@@ -891,3 +891,61 @@ def test_config_structs_on_the_constructors(res):
     Da, Ia = a.search(xq, 5)
     Db, Ib = b.search(xq, 5)
     assert np.array_equal(Ia, Ib) and np.array_equal(Da, Db)  # the options do not change the arithmetic here
+
+
+# ------------------------------------------------------------------------------- host-query pipeline, caller streams
+@pytest.mark.parametrize("kind", ["flat", "ivfflat", "ivfpq"])
+def test_paged_host_search_equals_direct(kind):
+    """GpuIndex::searchFromCpuPaged_ (faiss/gpu/GpuIndex.cu:554-774): host-resident batches above the paging threshold go
+    page by page through pinned double buffers with the copies on a second stream -- same bits as the direct path, for
+    uneven last pages, one page, and with preassigned coarse quantization."""
+    res = faiss_amd.StandardGpuResources(0)
+    d, k = 48, 12
+    xt, xb, xq = synthetic_dataset(d, 3000, 30000, 5003, seed=13)
+    if kind == "flat":
+        idx = faiss_amd.GpuIndexFlatL2(res, d)
+    elif kind == "ivfflat":
+        idx = faiss_amd.GpuIndexIVFFlat(res, d, 32, METRIC_L2)
+    else:
+        idx = faiss_amd.GpuIndexIVFPQ(res, d, 32, 8, 8, METRIC_L2)
+    idx.train(xt)
+    idx.add(xb)
+    if kind != "flat":
+        idx.nprobe = 6
+    D0, I0 = idx.search(xq, k)
+    assert res.paged_search_count == 0
+    for page in (1024, 5003, 7000):
+        res.setPagedSearch(min_bytes=1, page_queries=page)
+        D, I = idx.search(xq, k)
+        assert np.array_equal(I, I0) and np.array_equal(D, D0), page
+    assert res.paged_search_count == 3
+    if kind != "flat":
+        res.setPagedSearch(min_bytes=1 << 40)
+        Dq, Iq = idx.quantizer_search(xq, 6)
+        res.setPagedSearch(min_bytes=1, page_queries=999)
+        D, I = idx.search_preassigned(xq, k, Iq, Dq)
+        assert np.array_equal(I, I0) and np.array_equal(D, D0)
+    res.setPagedSearch()  # defaults
+
+
+def test_set_default_stream_orders_work_on_the_callers_stream():
+    """StandardGpuResources::setDefaultStream: inputs produced on a torch stream and results consumed on it need no
+    synchronisation once the index works on that stream."""
+    import torch
+    res = faiss_amd.StandardGpuResources(0)
+    _, xb, xq = synthetic_dataset(64, 0, 20000, 500, seed=3)
+    idx = faiss_amd.GpuIndexFlatL2(res, 64)
+    idx.add(xb)
+    D0, I0 = idx.search(xq, 10)
+    st = torch.cuda.Stream()
+    res.setDefaultStream(st.cuda_stream)
+    with torch.cuda.stream(st):
+        q = torch.from_numpy(xq).cuda(non_blocking=True) * 1.0  # produced on st
+        D = torch.empty((500, 10), dtype=torch.float32, device="cuda")
+        I = torch.empty((500, 10), dtype=torch.int64, device="cuda")
+        idx.search_ptr(500, q.data_ptr(), 10, D.data_ptr(), I.data_ptr())
+        Dh, Ih = D.cpu(), I.cpu()  # consumed on st
+    assert np.array_equal(Ih.numpy(), I0) and np.array_equal(Dh.numpy(), D0)
+    res.setDefaultStream(None)
+    D1, I1 = idx.search(xq, 10)
+    assert np.array_equal(I1, I0)
