@@ -106,6 +106,8 @@ def load_library():
         "faiss_amd_GpuIndexIVFFlat_new_with_config": (i32, [P(vp), vp, i32, i32, i32, vp]),
         "faiss_amd_GpuIndexIVFPQ_new_with_config": (i32, [P(vp), vp, i32, i32, i32, i32, i32, vp]),
         "faiss_amd_GpuIndexFlat_resident_bytes": (i32, [vp, P(sz)]),
+        "faiss_amd_bfKnn_params": (i32, [vp, vp]),
+        "faiss_amd_bfKnn_tiling": (i32, [vp, vp, sz, sz]),
         "faiss_amd_test_select": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp]),
         "faiss_amd_GpuIndexIVF_search_with_params": (i32, [vp, i64, vp, i64, vp, vp, vp]),
         "faiss_amd_GpuIndexIVF_stored_vectors": (i32, [vp, P(i64)]),
@@ -574,15 +576,57 @@ def kmeans(res, x, k, niter=25, seed=1234):
     return cent, obj
 
 
-def knn_gpu(res, xq, xb, k, metric=METRIC_L2):
-    """faiss.knn_gpu (faiss/python/gpu_wrappers.py:56-...) for float32 row-major numpy arrays -> (D, I)."""
+class GpuDistanceParams(ctypes.Structure):
+    """faiss.GpuDistanceParams (faiss/gpu/GpuDistance.h:32-152) as the C ABI takes it"""
+    _fields_ = [("metric", ctypes.c_int), ("metricArg", ctypes.c_float), ("k", ctypes.c_int), ("dims", ctypes.c_int),
+                ("vectors", ctypes.c_void_p), ("vectorType", ctypes.c_int), ("vectorsRowMajor", ctypes.c_int),
+                ("numVectors", ctypes.c_int64), ("vectorNorms", ctypes.c_void_p), ("queries", ctypes.c_void_p),
+                ("queryType", ctypes.c_int), ("queriesRowMajor", ctypes.c_int), ("numQueries", ctypes.c_int64),
+                ("outDistances", ctypes.c_void_p), ("ignoreOutDistances", ctypes.c_int), ("outIndicesType", ctypes.c_int),
+                ("outIndices", ctypes.c_void_p), ("device", ctypes.c_int)]
+
+
+def _matrix_arg(x, name):
+    """(pointer, DistanceDataType, row_major, n, d) of a float32 / float16 matrix in C or Fortran order"""
+    x = np.asarray(x)
+    if x.dtype not in (np.float32, np.float16) or x.ndim != 2:
+        raise TypeError("%s must be a 2-D float32 or float16 array" % name)
+    if x.flags.c_contiguous:
+        row_major = True
+    elif x.flags.f_contiguous:
+        row_major = False
+    else:
+        x, row_major = np.ascontiguousarray(x), True
+    return x, (1 if x.dtype == np.float32 else 2), row_major
+
+
+def knn_gpu(res, xq, xb, k, D=None, I=None, metric=METRIC_L2, vectorsMemoryLimit=0, queriesMemoryLimit=0):
+    """faiss.knn_gpu (faiss/python/gpu_wrappers.py:56-206): brute-force k-NN of xq in xb -> (D, I).  float32 or float16
+    inputs in row- or column-major order, int64 or int32 labels (dtype of a supplied I); k = -1 returns the full
+    distance matrix as D (I is None); the memory limits select bfKnn_tiling."""
     lib = load_library()
-    xb = _f32(xb)
-    xq = _f32(xq, xb.shape[1])
-    D = np.empty((xq.shape[0], k), dtype=np.float32)
-    I = np.empty((xq.shape[0], k), dtype=np.int64)
-    _check(lib.faiss_amd_bfKnn(res._h, int(metric), _ptr(xb), xb.shape[0], _ptr(xq), xq.shape[0], xb.shape[1], int(k),
-                               _ptr(D), _ptr(I)))
+    xb, vt, vrm = _matrix_arg(xb, "xb")
+    xq, qt, qrm = _matrix_arg(xq, "xq")
+    if xb.shape[1] != xq.shape[1]:
+        raise ValueError("dimension mismatch")
+    nq, d = xq.shape
+    if k == -1:
+        D = np.empty((nq, xb.shape[0]), dtype=np.float32)
+        I = None
+    else:
+        if D is None:
+            D = np.empty((nq, k), dtype=np.float32)
+        if I is None:
+            I = np.empty((nq, k), dtype=np.int64)
+        if D.shape != (nq, k) or I.shape != (nq, k) or D.dtype != np.float32 or I.dtype not in (np.int64, np.int32):
+            raise ValueError("D / I have the wrong shape or dtype")
+    a = GpuDistanceParams(int(metric), 0.0, int(k), int(d), xb.ctypes.data, vt, int(vrm), xb.shape[0], None,
+                          xq.ctypes.data, qt, int(qrm), nq, D.ctypes.data, 0,
+                          2 if (I is not None and I.dtype == np.int32) else 1, I.ctypes.data if I is not None else None, -1)
+    if vectorsMemoryLimit or queriesMemoryLimit:
+        _check(lib.faiss_amd_bfKnn_tiling(res._h, ctypes.byref(a), int(vectorsMemoryLimit), int(queriesMemoryLimit)))
+    else:
+        _check(lib.faiss_amd_bfKnn_params(res._h, ctypes.byref(a)))
     return D, I
 
 

@@ -581,6 +581,40 @@ int faiss_amd_GpuIndexIVF_arena_stats(const FaissAmdIndex* index, int64_t* used_
     as<GpuIndexIVF>(index, "GpuIndexIVF")->arena_stats(used_rows, hole_rows, allocated_rows);
     FA_CATCH
 }
+static DistanceParams to_params(const FaissAmdGpuDistanceParams* a) {
+    FA_THROW_IF_NOT_MSG(a, "null args");
+    DistanceParams p;
+    p.metric = a->metric;
+    p.metricArg = a->metricArg;
+    p.k = a->k;
+    p.dims = a->dims;
+    p.vectors = a->vectors;
+    p.vectorType = a->vectorType;
+    p.vectorsRowMajor = a->vectorsRowMajor != 0;
+    p.numVectors = a->numVectors;
+    p.vectorNorms = a->vectorNorms;
+    p.queries = a->queries;
+    p.queryType = a->queryType;
+    p.queriesRowMajor = a->queriesRowMajor != 0;
+    p.numQueries = a->numQueries;
+    p.outDistances = a->outDistances;
+    p.ignoreOutDistances = a->ignoreOutDistances != 0;
+    p.outIndicesType = a->outIndicesType;
+    p.outIndices = a->outIndices;
+    p.device = a->device;
+    return p;
+}
+int faiss_amd_bfKnn_params(FaissAmdGpuResources* res, const FaissAmdGpuDistanceParams* args) {
+    FA_TRY
+    bfKnn(R(res), to_params(args));
+    FA_CATCH
+}
+int faiss_amd_bfKnn_tiling(FaissAmdGpuResources* res, const FaissAmdGpuDistanceParams* args, size_t vectorsMemoryLimit,
+                           size_t queriesMemoryLimit) {
+    FA_TRY
+    bfKnn_tiling(R(res), to_params(args), vectorsMemoryLimit, queriesMemoryLimit);
+    FA_CATCH
+}
 int faiss_amd_GpuIndexIVF_set_use_fused_scan(FaissAmdIndex* index, int on) {
     FA_TRY
     as<GpuIndexIVF>(index, "GpuIndexIVF")->use_fused_scan = on != 0;

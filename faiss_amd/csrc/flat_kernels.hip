@@ -100,6 +100,40 @@ void launch_rows_by_key(const float* x, int64_t ld_x, const int64_t* keys, int64
     HIP_CHECK(hipGetLastError());
 }
 
+__global__ void convert_matrix_kernel(const void* __restrict__ src, int type, bool row_major, int64_t n, int d,
+                                      float* __restrict__ dst) {
+    const int64_t total = n * d;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = t / d;
+        const int c = (int)(t - i * d);
+        const int64_t s = row_major ? t : (int64_t)c * n + i;
+        float v;
+        if (type == 1) {
+            v = ((const float*)src)[s];
+        } else if (type == 2) {
+            v = (float)((const _Float16*)src)[s];
+        } else {
+            v = __uint_as_float((unsigned)((const unsigned short*)src)[s] << 16); // bf16 = upper half of an fp32
+        }
+        dst[t] = v;
+    }
+}
+void launch_convert_matrix(const void* src, int type, bool row_major, int64_t n, int d, float* dst, hipStream_t stream) {
+    if (n == 0) return;
+    unsigned grid = (unsigned)std::min<int64_t>(div_up(n * d, 256), 65535 * 16);
+    hipLaunchKernelGGL(convert_matrix_kernel, dim3(grid), dim3(256), 0, stream, src, type, row_major, n, d, dst);
+    HIP_CHECK(hipGetLastError());
+}
+__global__ void i64_to_i32_kernel(const int64_t* __restrict__ src, int64_t n, int32_t* __restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (int32_t)src[i];
+}
+void launch_i64_to_i32(const int64_t* src, int64_t n, int32_t* dst, hipStream_t stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(i64_to_i32_kernel, dim3((unsigned)div_up(n, 256)), dim3(256), 0, stream, src, n, dst);
+    HIP_CHECK(hipGetLastError());
+}
+
 __global__ void round_f16_inplace_kernel(float* __restrict__ x, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         x[i] = (float)(_Float16)x[i];

@@ -435,6 +435,141 @@ void bfKnn(std::shared_ptr<GpuResources> res, int metric, const float* vectors, 
     tmp.search(num_queries, queries, k, out_distances, out_indices);
 }
 
+static size_t dtype_size(int type) {
+    FA_THROW_IF_NOT_MSG(type >= 1 && type <= 3, "unknown DistanceDataType");
+    return type == 1 ? 4 : 2;
+}
+// fp32 row-major device copy [n][d] of a matrix of any supported type / layout (host or device source); when the
+// source already is that (device, f32, row major) it is returned as it is
+static const float* as_f32_rows(const GpuResources& R, const void* src, int type, bool row_major, idx_t n, int d,
+                                DevBuf& raw, DevBuf& out) {
+    const size_t bytes = (size_t)n * d * dtype_size(type);
+    const void* dsrc = src;
+    if (!is_device_pointer(src)) {
+        raw.ensure(std::max<size_t>(bytes, 16));
+        HIP_CHECK(hipMemcpyAsync(raw.p, src, bytes, hipMemcpyHostToDevice, R.stream));
+        dsrc = raw.p;
+    }
+    if (type == 1 && row_major) return (const float*)dsrc;
+    out.ensure(std::max<size_t>((size_t)n * d * 4, 16));
+    launch_convert_matrix(dsrc, type, row_major, n, d, out.as<float>(), R.stream);
+    return out.as<float>();
+}
+
+void bfKnn(std::shared_ptr<GpuResources> res, const DistanceParams& a) {
+    FA_THROW_IF_NOT_MSG(res, "null resources");
+    FA_THROW_IF_NOT_MSG(a.device == -1 || a.device == res->device, "args.device differs from the device of the resources");
+    FA_THROW_IF_NOT_MSG(a.metric == METRIC_L2 || a.metric == METRIC_INNER_PRODUCT, "bfKnn: metric must be L2 or inner product");
+    FA_THROW_IF_NOT_MSG(a.dims >= 1 && a.numVectors >= 0 && a.numQueries >= 0, "bad sizes");
+    FA_THROW_IF_NOT_MSG(a.k == -1 || (a.k >= 1 && a.k <= kMaxSelectionK), "k must be in [1, 2048], or -1 for all pairwise distances");
+    if (a.numQueries == 0) return;
+    FA_THROW_IF_NOT_MSG((a.vectors || a.numVectors == 0) && a.queries, "bfKnn: vectors / queries must be provided (passed null)");
+    res->set_device();
+    const GpuResources& R = *res;
+    DevBuf vraw, vf32, qraw, qf32;
+    const float* v = a.numVectors ? as_f32_rows(R, a.vectors, a.vectorType, a.vectorsRowMajor, a.numVectors, a.dims, vraw, vf32) : nullptr;
+    const float* q = as_f32_rows(R, a.queries, a.queryType, a.queriesRowMajor, a.numQueries, a.dims, qraw, qf32);
+    // fp16 vectors AND queries: an fp16-storage index holds exactly those values at half the bytes
+    GpuIndexFlat tmp(res, a.dims, a.metric, a.vectorType == 2 && a.queryType == 2);
+    if (a.numVectors) tmp.add(a.numVectors, v);
+    if (a.k == -1) {
+        FA_THROW_IF_NOT_MSG(a.outDistances, "bfKnn: outDistances must be provided for k = -1");
+        tmp.pairwise_distances(a.numQueries, q, a.outDistances);
+        return;
+    }
+    FA_THROW_IF_NOT_MSG(a.outIndices, "bfKnn: outIndices must be provided (passed null)");
+    FA_THROW_IF_NOT_MSG(a.ignoreOutDistances || a.outDistances, "bfKnn: outDistances must be provided (passed null)");
+    FA_THROW_IF_NOT_MSG(a.outIndicesType == 1 || a.outIndicesType == 2, "unknown IndicesDataType");
+    DevBuf dd, di;
+    float* D = a.outDistances;
+    if (a.ignoreOutDistances || !D) {
+        dd.ensure((size_t)a.numQueries * a.k * 4);
+        D = dd.as<float>();
+    }
+    if (a.outIndicesType == 1) {
+        tmp.search(a.numQueries, q, a.k, D, (idx_t*)a.outIndices);
+        return;
+    }
+    di.ensure((size_t)a.numQueries * a.k * 8);
+    tmp.search(a.numQueries, q, a.k, D, di.as<idx_t>());
+    DevBuf d32;
+    int32_t* out32 = (int32_t*)a.outIndices;
+    const bool out_dev = is_device_pointer(a.outIndices);
+    if (!out_dev) {
+        d32.ensure((size_t)a.numQueries * a.k * 4);
+        out32 = d32.as<int32_t>();
+    }
+    launch_i64_to_i32(di.as<idx_t>(), a.numQueries * a.k, out32, R.stream);
+    if (!out_dev)
+        HIP_CHECK(hipMemcpyAsync(a.outIndices, out32, (size_t)a.numQueries * a.k * 4, hipMemcpyDeviceToHost, R.stream));
+    R.sync();
+}
+
+void bfKnn_tiling(std::shared_ptr<GpuResources> res, const DistanceParams& a, size_t vectorsMemoryLimit,
+                  size_t queriesMemoryLimit) {
+    if (vectorsMemoryLimit == 0 && queriesMemoryLimit == 0) {
+        bfKnn(res, a);
+        return;
+    }
+    // reference: faiss/gpu/GpuDistance.cu:430-570 (same argument checks)
+    FA_THROW_IF_NOT_MSG(a.k > 0, "bfKnn_tiling: tiling is only supported for k > 0");
+    FA_THROW_IF_NOT_MSG(a.numQueries > 0 && a.queries && a.vectors, "bfKnn_tiling: vectors and queries must be provided");
+    FA_THROW_IF_NOT_MSG(a.outIndices, "bfKnn: outIndices must be provided (passed null)");
+    const size_t qsz = dtype_size(a.queryType), vsz = dtype_size(a.vectorType);
+    const size_t lsz = a.outIndicesType == 1 ? 8 : 4;
+    idx_t qshard = a.numQueries, vshard = a.numVectors;
+    if (queriesMemoryLimit > 0) {
+        FA_THROW_IF_NOT_MSG(!is_device_pointer(a.queries), "bfKnn_tiling: queries should be in CPU memory when queriesMemoryLimit > 0");
+        FA_THROW_IF_NOT_MSG(a.queriesRowMajor, "bfKnn_tiling: tiling queries is only supported in row major mode");
+        qshard = (idx_t)(queriesMemoryLimit / ((size_t)a.k * (qsz + lsz) + (size_t)a.dims * qsz));
+        FA_THROW_IF_NOT_MSG(qshard > 0, "bfKnn_tiling: queriesMemoryLimit is too low");
+    }
+    if (vectorsMemoryLimit > 0) {
+        FA_THROW_IF_NOT_MSG(!is_device_pointer(a.vectors), "bfKnn_tiling: vectors should be in CPU memory when vectorsMemoryLimit > 0");
+        FA_THROW_IF_NOT_MSG(a.vectorsRowMajor, "bfKnn_tiling: tiling vectors is only supported in row major mode");
+        vshard = (idx_t)(vectorsMemoryLimit / ((size_t)a.dims * vsz));
+        FA_THROW_IF_NOT_MSG(vshard > 0, "bfKnn_tiling: vectorsMemoryLimit is too low");
+    }
+    const int nvs = (int)std::max<idx_t>(1, (a.numVectors + vshard - 1) / std::max<idx_t>(vshard, 1));
+    for (idx_t q0 = 0; q0 < a.numQueries; q0 += qshard) {
+        const idx_t nq = std::min(qshard, a.numQueries - q0);
+        std::vector<float> pd((size_t)nvs * nq * a.k);
+        std::vector<idx_t> pi((size_t)nvs * nq * a.k);
+        std::vector<idx_t> base(nvs);
+        for (int s = 0; s < nvs; s++) {
+            const idx_t v0 = (idx_t)s * vshard, nv = std::min(vshard, a.numVectors - v0);
+            DistanceParams t = a;
+            t.queries = (const char*)a.queries + (a.queriesRowMajor ? (size_t)q0 * a.dims * qsz : (size_t)q0 * qsz);
+            t.numQueries = nq;
+            t.vectors = (const char*)a.vectors + (size_t)v0 * a.dims * vsz;
+            t.numVectors = nv;
+            t.vectorNorms = nullptr;
+            t.outDistances = pd.data() + (size_t)s * nq * a.k;
+            t.ignoreOutDistances = false;
+            t.outIndicesType = 1;
+            t.outIndices = pi.data() + (size_t)s * nq * a.k;
+            FA_THROW_IF_NOT_MSG(a.queriesRowMajor || qshard == a.numQueries, "column-major queries cannot be tiled");
+            bfKnn(res, t);
+            base[s] = v0;
+        }
+        // partial top-k of the vector chunks -> top-k (ties to the lower id: equal to one untiled search)
+        std::vector<float> D((size_t)nq * a.k);
+        std::vector<idx_t> I((size_t)nq * a.k);
+        merge_knn_results(a.metric, nq, a.k, nvs, pd.data(), pi.data(), base.data(), D.data(), I.data());
+        if (!a.ignoreOutDistances && a.outDistances) {
+            FA_THROW_IF_NOT_MSG(!is_device_pointer(a.outDistances), "bfKnn_tiling: outputs of a tiled search live in CPU memory");
+            memcpy(a.outDistances + (size_t)q0 * a.k, D.data(), D.size() * 4);
+        }
+        FA_THROW_IF_NOT_MSG(!is_device_pointer(a.outIndices), "bfKnn_tiling: outputs of a tiled search live in CPU memory");
+        if (a.outIndicesType == 1) {
+            memcpy((idx_t*)a.outIndices + (size_t)q0 * a.k, I.data(), I.size() * 8);
+        } else {
+            int32_t* o = (int32_t*)a.outIndices + (size_t)q0 * a.k;
+            for (size_t i = 0; i < I.size(); i++) o[i] = (int32_t)I[i];
+        }
+    }
+}
+
 // choose the database split count: blocks = nsplit * ngroups should fill whole rounds of CUs
 static void choose_splits(int nb, int ngroups, int num_cus, int& nsplit, int& rows_per_split, int split_cap = 64) {
     const int TR = kFlatTileRows;

@@ -399,6 +399,33 @@ void merge_knn_results(int metric, idx_t nq, idx_t k, int nshard, const float* a
 void bfKnn(std::shared_ptr<GpuResources> res, int metric, const float* vectors, idx_t num_vectors, const float* queries,
            idx_t num_queries, int dims, idx_t k, float* out_distances, idx_t* out_indices);
 
+// The whole operator surface of faiss::gpu::bfKnn (GpuDistanceParams, faiss/gpu/GpuDistance.h:32-152): f32 / f16 / bf16
+// inputs, row or column major, int64 or int32 indices, optional distances, k = -1 for all pairwise distances; and
+// bfKnn_tiling (GpuDistance.cu:430-570): inputs beyond the given device-memory limits are processed in (query chunk) x
+// (vector chunk) tiles whose partial results are merged.  All-fp16 vectors run as an fp16-storage index.
+struct DistanceParams {
+    int metric = METRIC_L2;
+    float metricArg = 0.f;
+    int k = 0, dims = 0;
+    const void* vectors = nullptr;
+    int vectorType = 1; // 1 = f32, 2 = f16, 3 = bf16
+    bool vectorsRowMajor = true;
+    idx_t numVectors = 0;
+    const float* vectorNorms = nullptr; // accepted, unused (norms are recomputed in the kernels' own summation order)
+    const void* queries = nullptr;
+    int queryType = 1;
+    bool queriesRowMajor = true;
+    idx_t numQueries = 0;
+    float* outDistances = nullptr;
+    bool ignoreOutDistances = false;
+    int outIndicesType = 1; // 1 = int64, 2 = int32
+    void* outIndices = nullptr;
+    int device = -1;
+};
+void bfKnn(std::shared_ptr<GpuResources> res, const DistanceParams& args);
+void bfKnn_tiling(std::shared_ptr<GpuResources> res, const DistanceParams& args, size_t vectorsMemoryLimit,
+                  size_t queriesMemoryLimit);
+
 // device-side variant used by the one-process-per-GPU sharded search (faiss_amd/distributed.py):
 // all pointers are device pointers on res's device; work is ordered on res's stream and the
 // call returns after the stream has drained.

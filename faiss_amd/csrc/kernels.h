@@ -22,6 +22,10 @@ void launch_pad_rows(const float* src, int64_t lds_src, int64_t n, int d, float*
 void launch_rows_by_key(const float* x, int64_t ld_x, const int64_t* keys, int64_t n, int d, const float* rows,
                         int64_t ld_rows, int64_t nrows, float* out, int64_t ld_out, hipStream_t stream,
                         const _Float16* rows16 = nullptr, int64_t ld_rows16 = 0);
+// dst [n][d] fp32 row-major <- src [n][d] (row_major) or [d][n] (column major) of type 1 = f32, 2 = f16, 3 = bf16
+// (faiss::gpu::DistanceDataType, faiss/gpu/GpuDistance.h:19-23); widening is exact
+void launch_convert_matrix(const void* src, int type, bool row_major, int64_t n, int d, float* dst, hipStream_t stream);
+void launch_i64_to_i32(const int64_t* src, int64_t n, int32_t* dst, hipStream_t stream);
 // x[i] = float(half(x[i])): the values an fp16-storage index holds (queries are rounded the same way, as
 // FlatIndex::query converts them, faiss/gpu/impl/FlatIndex.cu:112-135)
 void launch_round_f16_inplace(float* x, int64_t n, hipStream_t stream);

@@ -244,6 +244,33 @@ int faiss_amd_bfKnn(FaissAmdGpuResources* res, FaissAmdMetricType metric, const 
                     faiss_amd_idx_t num_vectors, const float* queries, faiss_amd_idx_t num_queries, int dims,
                     faiss_amd_idx_t k, float* out_distances, faiss_amd_idx_t* out_indices);
 
+/* ---- the full operator surface of faiss::gpu::bfKnn: GpuDistanceParams field for field (faiss/gpu/GpuDistance.h:32-152).
+ *      vectorType / queryType: 1 = F32, 2 = F16, 3 = BF16 (DistanceDataType); row or column major; outIndicesType:
+ *      1 = int64, 2 = int32; k = -1 returns all pairwise distances [numQueries][numVectors] in outDistances; vectorNorms
+ *      is accepted and unused; pointers host or device.  With F16 vectors AND queries the search runs on an
+ *      fp16-storage index (those exact values, half the bytes).  faiss_amd_bfKnn_tiling = faiss::gpu::bfKnn_tiling
+ *      (GpuDistance.cu:430-570): 0 = "must fit", else at most that many bytes of vectors / of queries + results on the
+ *      device at a time (row-major CPU inputs, k > 0); the tiles' partial results are merged under (distance, id). */
+typedef struct FaissAmdGpuDistanceParams {
+    int metric;
+    float metricArg;
+    int k, dims;
+    const void* vectors;
+    int vectorType, vectorsRowMajor;
+    faiss_amd_idx_t numVectors;
+    const float* vectorNorms;
+    const void* queries;
+    int queryType, queriesRowMajor;
+    faiss_amd_idx_t numQueries;
+    float* outDistances;
+    int ignoreOutDistances, outIndicesType;
+    void* outIndices;
+    int device;
+} FaissAmdGpuDistanceParams;
+int faiss_amd_bfKnn_params(FaissAmdGpuResources* res, const FaissAmdGpuDistanceParams* args);
+int faiss_amd_bfKnn_tiling(FaissAmdGpuResources* res, const FaissAmdGpuDistanceParams* args, size_t vectorsMemoryLimit,
+                           size_t queriesMemoryLimit);
+
 /* ---- SearchParametersIVF (faiss/IndexIVF.h:70-80): per-call override of nprobe, as GpuIndexIVF::search honours it
  *      through getCurrentNProbe_ (faiss/gpu/GpuIndexIVF.cu:358-381).  nprobe <= 0 keeps the index's own value. */
 typedef struct FaissAmdSearchParametersIVF {

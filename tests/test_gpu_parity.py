@@ -526,7 +526,7 @@ def test_bfknn_equals_flat_index_and_oracle(res, metric, d, nb, nq, k):
     """faiss::gpu::bfKnn on raw arrays (faiss/gpu/GpuDistance.h:32-152; test: faiss/gpu/test/test_gpu_basics.py
     bfKnn cases): same answer as a flat index holding the vectors, and as the oracle."""
     _, xb, xq = synthetic_dataset(d, 0, nb, nq, seed=d + k)
-    D, I = faiss_amd.knn_gpu(res, xq, xb, k, metric)
+    D, I = faiss_amd.knn_gpu(res, xq, xb, k, metric=metric)
     idx = faiss_amd.GpuIndexFlat(res, d, metric)
     idx.add(xb)
     D2, I2 = idx.search(xq, k)
@@ -949,3 +949,45 @@ def test_set_default_stream_orders_work_on_the_callers_stream():
     res.setDefaultStream(None)
     D1, I1 = idx.search(xq, 10)
     assert np.array_equal(I1, I0)
+
+
+# ------------------------------------------------------------------------------- bfKnn: the full GpuDistanceParams surface
+def test_bfknn_dtypes_layouts_indices_and_pairwise(res):
+    """faiss::gpu::bfKnn with GpuDistanceParams (faiss/gpu/GpuDistance.h:32-152; tests: faiss/gpu/test/test_gpu_basics.py
+    TestKnn / bfKnn cases): float16 inputs, column-major inputs, int32 labels, k = -1 (all pairwise distances)."""
+    d, nb, nq, k = 64, 20000, 200, 10
+    _, xb, xq = synthetic_dataset(d, 0, nb, nq, seed=17)
+    D0, I0 = faiss_amd.knn_gpu(res, xq, xb, k)
+    Do, Io = Oracle.flat_search(METRIC_L2, xb, xq, k)
+    check_knn(D0, I0, Do, Io, exact=True, name="bfKnn f32 row major")
+    # column-major vectors and queries: the same values, the same answer
+    D1, I1 = faiss_amd.knn_gpu(res, np.asfortranarray(xq), np.asfortranarray(xb), k)
+    assert np.array_equal(I1, I0) and np.array_equal(D1, D0)
+    # int32 labels
+    I32 = np.empty((nq, k), dtype=np.int32)
+    D2, _ = faiss_amd.knn_gpu(res, xq, xb, k, I=I32)
+    assert np.array_equal(I32, I0.astype(np.int32)) and np.array_equal(D2, D0)
+    # float16 vectors and queries: fp32 arithmetic on those fp16 values (the useFloat16 contract)
+    xb16, xq16 = xb.astype(np.float16), xq.astype(np.float16)
+    D3, I3 = faiss_amd.knn_gpu(res, xq16, xb16, k)
+    check_knn(D3, I3, *Oracle.flat_search(METRIC_L2, xb16.astype(np.float32), xq16.astype(np.float32), k), exact=True,
+              name="bfKnn f16")
+    # mixed: fp16 vectors, fp32 queries
+    D4, I4 = faiss_amd.knn_gpu(res, xq, xb16, k)
+    check_knn(D4, I4, *Oracle.flat_search(METRIC_L2, xb16.astype(np.float32), xq, k), exact=True, name="bfKnn mixed")
+    # inner product, k = -1: the whole matrix
+    G, none = faiss_amd.knn_gpu(res, xq[:40], xb[:3000], -1, metric=METRIC_INNER_PRODUCT)
+    assert none is None and np.array_equal(G, Oracle.pairwise(METRIC_INNER_PRODUCT, xb[:3000], xq[:40]))
+
+
+@pytest.mark.parametrize("vlim,qlim", [(300000, 0), (0, 40000), (700001, 123457)])
+def test_bfknn_tiling_equals_untiled(res, vlim, qlim):
+    """faiss::gpu::bfKnn_tiling (GpuDistance.cu:430-570): vectors / queries beyond the given device-memory limits are
+    processed tile by tile; the merged result equals the untiled search (ids exactly, ties to the lower id)."""
+    xb, xq = integer_dataset(32, 9001, 301, seed=21, hi=6)  # many exact ties across the chunk borders
+    k = 25
+    D0, I0 = faiss_amd.knn_gpu(res, xq, xb, k)
+    D, I = faiss_amd.knn_gpu(res, xq, xb, k, vectorsMemoryLimit=vlim, queriesMemoryLimit=qlim)
+    assert np.array_equal(I, I0) and np.array_equal(D, D0)
+    with pytest.raises(faiss_amd.FaissAmdError):
+        faiss_amd.knn_gpu(res, xq, xb, k, vectorsMemoryLimit=16)  # below one vector
