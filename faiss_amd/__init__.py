@@ -106,6 +106,8 @@ def load_library():
         "faiss_amd_GpuIndexIVFFlat_new_with_config": (i32, [P(vp), vp, i32, i32, i32, vp]),
         "faiss_amd_GpuIndexIVFPQ_new_with_config": (i32, [P(vp), vp, i32, i32, i32, i32, i32, vp]),
         "faiss_amd_GpuIndexFlat_resident_bytes": (i32, [vp, P(sz)]),
+        "faiss_amd_set_interrupt_callback": (i32, [vp, vp]),
+        "faiss_amd_GpuParameterSpace_set_index_parameter": (i32, [vp, ctypes.c_char_p, ctypes.c_double]),
         "faiss_amd_bfKnn_params": (i32, [vp, vp]),
         "faiss_amd_bfKnn_tiling": (i32, [vp, vp, sz, sz]),
         "faiss_amd_test_select": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp]),
@@ -574,6 +576,47 @@ def kmeans(res, x, k, niter=25, seed=1234):
     _check(lib.faiss_amd_kmeans_clustering(res._h, d, n, int(k), _ptr(x), int(niter), int(seed), _ptr(cent),
                                            _ptr(obj)))
     return cent, obj
+
+
+class GpuParameterSpace:
+    """faiss.GpuParameterSpace (faiss/gpu/GpuAutoTune.h / .cpp:40-114): the tunable parameters of a backend index"""
+
+    def initialize(self, index):
+        """parameter ranges like ParameterSpace::initialize: nprobe in powers of two up to min(nlist, 2048)"""
+        self.parameter_ranges = {}
+        nl = getattr(index, "nlist", None)
+        if nl:
+            vals, v = [], 1
+            while v <= min(nl, 2048):
+                vals.append(v)
+                v *= 2
+            self.parameter_ranges["nprobe"] = vals
+        return self.parameter_ranges
+
+    def set_index_parameter(self, index, name, val):
+        _check(load_library().faiss_amd_GpuParameterSpace_set_index_parameter(index._h, name.encode(), float(val)))
+
+    def set_index_parameters(self, index, description):
+        """'nprobe=32,use_precomputed_table=1'"""
+        for item in description.split(","):
+            if item.strip():
+                name, val = item.split("=")
+                self.set_index_parameter(index, name.strip(), float(val))
+
+
+_INTERRUPT_KEEP = []
+
+
+def set_interrupt_callback(fn):
+    """faiss.InterruptCallback: fn() -> truthy aborts the running call with FaissAmdError; None removes the hook"""
+    lib = load_library()
+    if fn is None:
+        _check(lib.faiss_amd_set_interrupt_callback(None, None))
+        _INTERRUPT_KEEP.clear()
+        return
+    cb = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p)(lambda _u: 1 if fn() else 0)
+    _INTERRUPT_KEEP[:] = [cb]
+    _check(lib.faiss_amd_set_interrupt_callback(ctypes.cast(cb, ctypes.c_void_p), None))
 
 
 class GpuDistanceParams(ctypes.Structure):

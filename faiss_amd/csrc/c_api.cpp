@@ -581,6 +581,17 @@ int faiss_amd_GpuIndexIVF_arena_stats(const FaissAmdIndex* index, int64_t* used_
     as<GpuIndexIVF>(index, "GpuIndexIVF")->arena_stats(used_rows, hole_rows, allocated_rows);
     FA_CATCH
 }
+int faiss_amd_set_interrupt_callback(faiss_amd_interrupt_fn fn, void* user) {
+    FA_TRY
+    set_interrupt_callback(fn, user);
+    FA_CATCH
+}
+int faiss_amd_GpuParameterSpace_set_index_parameter(FaissAmdIndex* index, const char* name, double value) {
+    FA_TRY
+    FA_THROW_IF_NOT_MSG(name, "null parameter name");
+    set_index_parameter(I(index), name, value);
+    FA_CATCH
+}
 static DistanceParams to_params(const FaissAmdGpuDistanceParams* a) {
     FA_THROW_IF_NOT_MSG(a, "null args");
     DistanceParams p;

@@ -128,6 +128,47 @@ void GpuResources::reset_profile() const {
     totals.clear();
 }
 
+// ====================================================================== interruption
+static std::mutex g_interrupt_mu;
+static InterruptFn g_interrupt_fn = nullptr;
+static void* g_interrupt_user = nullptr;
+void set_interrupt_callback(InterruptFn fn, void* user) {
+    std::lock_guard<std::mutex> g(g_interrupt_mu);
+    g_interrupt_fn = fn;
+    g_interrupt_user = user;
+}
+void check_interrupt() {
+    InterruptFn fn;
+    void* user;
+    {
+        std::lock_guard<std::mutex> g(g_interrupt_mu);
+        fn = g_interrupt_fn;
+        user = g_interrupt_user;
+    }
+    if (fn && fn(user)) FA_THROW_MSG("computation interrupted");
+}
+
+void set_index_parameter(Index* index, const std::string& name, double val) {
+    FA_THROW_IF_NOT_MSG(index, "null index");
+    if (auto* rep = dynamic_cast<IndexReplicas*>(index)) {
+        for (int i = 0; i < rep->count(); i++) set_index_parameter(rep->at(i), name, val);
+        return;
+    }
+    if (auto* sh = dynamic_cast<IndexShards*>(index)) {
+        for (int i = 0; i < sh->count(); i++) set_index_parameter(sh->at(i), name, val);
+        return;
+    }
+    if (name == "nprobe") {
+        if (auto* ivf = dynamic_cast<GpuIndexIVF*>(index)) {
+            FA_THROW_IF_NOT_MSG(val >= 1 && val <= kMaxSelectionK, "nprobe must be in [1, 2048]");
+            ivf->nprobe = (int)val;
+            return;
+        }
+    }
+    if (name == "use_precomputed_table" && dynamic_cast<GpuIndexIVFPQ*>(index)) return;
+    FA_THROW_MSG("ParameterSpace: parameter '" + name + "' does not apply to this index");
+}
+
 // ====================================================================== Index base
 void Index::add_with_ids(idx_t, const float*, const idx_t*) {
     FA_THROW_MSG("add_with_ids not implemented for this type of index");
@@ -982,6 +1023,7 @@ void GpuIndexFlat::search_body_(idx_t n, const float* x, idx_t k, float* distanc
     const bool out_dev_d = is_device_pointer(distances), out_dev_i = is_device_pointer(labels);
     const idx_t tile = flat_query_tile(R, (int)k, use_simple_kernel, ntotal);
     for (idx_t i0 = 0; i0 < n; i0 += tile) {
+        check_interrupt();
         const int ni = (int)std::min(tile, n - i0);
         q_pad_.ensure((size_t)ni * dpad_ * 4);
         stage_padded(R, x + (size_t)i0 * d, ni, d, dpad_, q_raw_, q_pad_.as<float>());
@@ -1084,6 +1126,7 @@ void Clustering::train(idx_t nx, const float* x_in, Index& index) {
     std::vector<idx_t> hassign(k);
     obj.clear();
     for (int it = 0; it < niter; it++) {
+        check_interrupt();
         index.reset();
         index.add(k, centroids.data());
         index.search(nx, x, 1, dis.data(), assign.data());
@@ -1375,6 +1418,7 @@ void GpuIndexIVF::add_core_(idx_t n, const float* x, const idx_t* xids) {
     std::vector<uint32_t> new_len(nlist);
     std::vector<double> est(nlist);
     for (idx_t i0 = 0; i0 < n; i0 += page) {
+        check_interrupt();
         const int ni = (int)std::min(page, n - i0);
         const int nchunks = (int)div_up(ni, chunk);
         stage_padded(R, x + (size_t)i0 * d, ni, d, dpad_, q_raw_, a_xpad_.as<float>());
@@ -1568,6 +1612,7 @@ void GpuIndexIVF::search_core_body_(idx_t n, const float* x, idx_t k, float* dis
                                                              &fused_kp, &fused_nlut);
     if (fused) tile = 65536; // no per-candidate scratch: the tile only bounds the staging buffers
     for (idx_t i0 = 0; i0 < n; i0 += tile) {
+        check_interrupt();
         const int ni = (int)std::min(tile, n - i0);
         float* dD = out_dev_d ? distances + (size_t)i0 * k : nullptr;
         idx_t* dI = out_dev_i ? labels + (size_t)i0 * k : nullptr;

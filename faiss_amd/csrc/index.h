@@ -99,6 +99,14 @@ struct SpanGuard {
     }
 };
 
+// ------------------------------------------------------------------ interruption
+// faiss::InterruptCallback (faiss/impl/AuxIndexStructures.h:138-165): a process-wide hook polled between the tiles of
+// long-running calls (search tiles, add pages, k-means iterations -- where faiss/gpu/impl/Distance.cu:245,266 polls);
+// when it returns non-zero the call throws "computation interrupted".  null = none.
+typedef int (*InterruptFn)(void*);
+void set_interrupt_callback(InterruptFn fn, void* user);
+void check_interrupt(); // throws FaissAmdException when the callback says so
+
 // ------------------------------------------------------------------ faiss::Index mirror
 struct Index {
     int d = 0;
@@ -376,6 +384,7 @@ class IndexReplicas : public Index {
     bool own_indices = false;
     void add_replica(Index* idx);
     int count() const { return (int)replicas_.size(); }
+    Index* at(int i) { return replicas_[i]; }
     void train(idx_t n, const float* x) override;
     void add(idx_t n, const float* x) override;
     void add_with_ids(idx_t n, const float* x, const idx_t* xids) override;
@@ -387,6 +396,11 @@ class IndexReplicas : public Index {
     std::vector<Index*> replicas_;
     void sync_();
 };
+
+// faiss::gpu::GpuParameterSpace::set_index_parameter (faiss/gpu/GpuAutoTune.cpp:81-114): "nprobe" on IVF indexes,
+// recursively through IndexReplicas / IndexShards; "use_precomputed_table" is accepted on IVFPQ (the per-vector term is
+// always on here).  Throws on a parameter the index does not have.
+void set_index_parameter(Index* index, const std::string& name, double val);
 
 // merge nshard sorted partial results [s][nq][k] into [nq][k] under (distance, label) order;
 // base[s] is added to shard s's labels (successive_ids translation), may be null.

@@ -271,6 +271,15 @@ int faiss_amd_bfKnn_params(FaissAmdGpuResources* res, const FaissAmdGpuDistanceP
 int faiss_amd_bfKnn_tiling(FaissAmdGpuResources* res, const FaissAmdGpuDistanceParams* args, size_t vectorsMemoryLimit,
                            size_t queriesMemoryLimit);
 
+/* ---- faiss::InterruptCallback (faiss/impl/AuxIndexStructures.h:138-165): a process-wide hook polled between the tiles of
+ *      long-running calls (as faiss/gpu/impl/Distance.cu:245,266 does); a non-zero return makes the call fail with
+ *      "computation interrupted".  NULL removes it. */
+typedef int (*faiss_amd_interrupt_fn)(void* user);
+int faiss_amd_set_interrupt_callback(faiss_amd_interrupt_fn fn, void* user);
+/* ---- faiss::gpu::GpuParameterSpace::set_index_parameter (faiss/gpu/GpuAutoTune.cpp:81-114): "nprobe" on IVF indexes,
+ *      recursively through IndexReplicas / IndexShards ("use_precomputed_table" is accepted on IVFPQ: always on here) */
+int faiss_amd_GpuParameterSpace_set_index_parameter(FaissAmdIndex* index, const char* name, double value);
+
 /* ---- SearchParametersIVF (faiss/IndexIVF.h:70-80): per-call override of nprobe, as GpuIndexIVF::search honours it
  *      through getCurrentNProbe_ (faiss/gpu/GpuIndexIVF.cu:358-381).  nprobe <= 0 keeps the index's own value. */
 typedef struct FaissAmdSearchParametersIVF {

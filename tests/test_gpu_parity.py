@@ -991,3 +991,37 @@ def test_bfknn_tiling_equals_untiled(res, vlim, qlim):
     assert np.array_equal(I, I0) and np.array_equal(D, D0)
     with pytest.raises(faiss_amd.FaissAmdError):
         faiss_amd.knn_gpu(res, xq, xb, k, vectorsMemoryLimit=16)  # below one vector
+
+
+# ------------------------------------------------------------------------------- ParameterSpace, InterruptCallback
+def test_gpu_parameter_space_and_interrupt(res):
+    """GpuParameterSpace::set_index_parameter (faiss/gpu/GpuAutoTune.cpp:81-114): nprobe on IVF indexes, through
+    IndexReplicas / IndexShards; InterruptCallback polled between tiles (faiss/gpu/impl/Distance.cu:245,266)."""
+    d = 32
+    xt, xb, xq = synthetic_dataset(d, 2000, 6000, 30, seed=8)
+    ivf = faiss_amd.GpuIndexIVFFlat(res, d, 16, METRIC_L2)
+    ivf.train(xt)
+    ivf.add(xb)
+    ps = faiss_amd.GpuParameterSpace()
+    assert ps.initialize(ivf)["nprobe"] == [1, 2, 4, 8, 16]
+    ps.set_index_parameters(ivf, "nprobe=8")
+    assert ivf.nprobe == 8
+    sh = faiss_amd.IndexShards(d, threaded=False, successive_ids=False)
+    subs = [faiss_amd.GpuIndexIVFFlat(res, d, 16, METRIC_L2) for _ in range(2)]
+    for s in subs:
+        s.copy_centroids(ivf.get_centroids())
+        sh.add_shard(s)
+    ps.set_index_parameter(sh, "nprobe", 4)
+    assert [s.nprobe for s in subs] == [4, 4]
+    with pytest.raises(faiss_amd.FaissAmdError):
+        ps.set_index_parameter(faiss_amd.GpuIndexFlatL2(res, d), "nprobe", 4)
+    calls = []
+    faiss_amd.set_interrupt_callback(lambda: calls.append(1) or len(calls) > 1)
+    try:
+        ivf.search(xq, 3)  # first poll passes
+        with pytest.raises(faiss_amd.FaissAmdError, match="interrupted"):
+            ivf.search(xq, 3)
+    finally:
+        faiss_amd.set_interrupt_callback(None)
+    D, I = ivf.search(xq, 3)
+    assert (I >= 0).all()
