@@ -1711,13 +1711,16 @@ void GpuIndexIVF::search_core_body_(idx_t n, const float* x, idx_t k, float* dis
                 fprintf(stderr, "ivfpq_fused_kernel phases, mean shader-clock ticks per workgroup (%llu workgroups): probes+query "
                         "%.0f, table %.0f, scan %.0f, finish %.0f\n", h[4], h[0] / w, h[1] / w, h[2] / w, h[3] / w);
             }
-            if (fp.G > 1 || fp.defer_finish) {
+            if (fp.defer_finish) {
+                SpanGuard sg(&R, "ivf_finish_kernel");
+                launch_ivf_finish(fp, R.stream);
+            } else if (fp.G > 1) {
                 SelectParams sp{};
                 sp.metric = metric_type;
                 sp.nq = ni;
                 sp.k = (int)k;
                 sp.keys = fp.part_keys;
-                sp.q_stride = fp.defer_finish ? (int64_t)fp.cap : (int64_t)fp.G * k;
+                sp.q_stride = (int64_t)fp.G * k;
                 sp.nseg = fp.G;
                 sp.seg_stride = k;
                 sp.seg_cnt = fp.part_cnt;

@@ -300,8 +300,17 @@ __global__ void __launch_bounds__(FB, 4) ivfpq_fused_kernel(IvfFusedParams p) { 
             t_ph = now;
         }
     };
-    // (the query row is requested before the probe tables: its latency overlaps theirs)
+    // (the query row is requested before the probe tables: its latency overlaps theirs; so is the first half of this
+    // lane's codebook entries, which depend on nothing)
     const float q_first = tid < d ? p.xq[(int64_t)q * p.ldq + tid] : 0.f;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    constexpr int NE = 16384 / FB; // table entries per lane (M64, dsub == 2)
+    const bool fast_build = M64 && dsub == 2;
+    f32x2 cb0[NE / 2];
+    if (fast_build) {
+#pragma unroll
+        for (int u = 0; u < NE / 2; ++u) cb0[u] = *(const f32x2*)(p.pq_t + (size_t)(tid + u * FB) * 2);
+    }
     fused_load_probes<FB>(p, q, L);
     if (tid < d) L.rs[tid] = q_first;
     for (int cc = tid + FB; cc < d; cc += FB) L.rs[cc] = p.xq[(int64_t)q * p.ldq + cc];
@@ -361,27 +370,23 @@ __global__ void __launch_bounds__(FB, 4) ivfpq_fused_kernel(IvfFusedParams p) { 
             grid[2] = on ? 1.f : 0.f;
         }
     };
-    if (M64 && dsub == 2) {
+    if (fast_build) {
         // entries e = tid + u * FB of the [256][64] table: sub-quantizer e & 63 = tid & 63 for all of them (FB is a
         // multiple of 64), so the query slice and the running maximum stay in registers
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        constexpr int NE = 16384 / FB;
         const float r0 = L.rs[2 * (tid & 63)], r1 = L.rs[2 * (tid & 63) + 1];
         float v[NE];
         float mx = 0.f;
-        // the codebook loads of this lane go out in two waves of NE / 2 (two L2 round trips per query, 32 + 32 live
-        // registers instead of 96)
+        // the codebook entries of this lane arrive in two waves of NE / 2 loads (32 + 32 live registers instead of
+        // 96): the first went out at kernel entry, the second goes out now and lands while the first is consumed
+        f32x2 cb1[NE / 2];
 #pragma unroll
-        for (int u0 = 0; u0 < NE; u0 += NE / 2) {
-            f32x2 c[NE / 2];
+        for (int u = 0; u < NE / 2; ++u) cb1[u] = *(const f32x2*)(p.pq_t + (size_t)(tid + (NE / 2 + u) * FB) * 2);
 #pragma unroll
-            for (int u = 0; u < NE / 2; ++u) c[u] = *(const f32x2*)(p.pq_t + (size_t)(tid + (u0 + u) * FB) * 2);
-#pragma unroll
-            for (int u = 0; u < NE / 2; ++u) {
-                v[u0 + u] = __fmaf_rn(r1, c[u][1], __fmaf_rn(r0, c[u][0], 0.f));
-                const float a = fabsf(v[u0 + u]);
-                mx = (a > mx || a != a) ? a : mx; // NaN sticks
-            }
+        for (int u = 0; u < NE; ++u) {
+            const f32x2 c = u < NE / 2 ? cb0[u] : cb1[u - NE / 2];
+            v[u] = __fmaf_rn(r1, c[1], __fmaf_rn(r0, c[0], 0.f));
+            const float a = fabsf(v[u]);
+            mx = (a > mx || a != a) ? a : mx; // NaN sticks
         }
         atomicMax(&L.colmax[tid & 63], __float_as_uint(mx));
         __syncthreads();
@@ -615,6 +620,50 @@ __global__ void __launch_bounds__(FB_MAX) ivfflat_fused_kernel(IvfFusedParams p)
         __syncthreads();
     }
     fused_finish<FB>(p, q, g, L);
+}
+
+// ---------------------------------------------------------------------------------
+// Deferred finish (IvfFusedParams::defer_finish): the reservoir a scan workgroup left in part_keys[q][0..n) is cut to
+// the k best, translated to user ids and ordered by a small workgroup of its own -- 256 threads, ~11 KB of LDS, many
+// per CU -- instead of on the critical path of a 75 KB scan workgroup.  Same code as the in-kernel finish.
+// ---------------------------------------------------------------------------------
+constexpr int FIN_THREADS = 256;
+static size_t ivf_finish_lds_bytes(int kp, int cap, int nprobe) {
+    return round_up((size_t)kp * 12, 16) + (size_t)cap * 8 + round_up((size_t)(nprobe + 1) * 4, 16) + (size_t)nprobe * 8 + 1024 +
+           64;
+}
+__global__ void __launch_bounds__(FIN_THREADS) ivf_finish_kernel(IvfFusedParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    FusedLds L{};
+    size_t o = 0;
+    L.lut = smem; // winners (kp x 12 bytes)
+    o += ((size_t)p.kp * 12 + 15) & ~(size_t)15;
+    L.res = (u64*)(smem + o);
+    o += (size_t)p.cap * 8;
+    L.pre = (uint32_t*)(smem + o);
+    o += ((size_t)(p.nprobe + 1) * 4 + 15) & ~(size_t)15;
+    L.lstart = (int64_t*)(smem + o);
+    o += (size_t)p.nprobe * 8;
+    L.hist = (unsigned*)(smem + o);
+    o += 1024;
+    L.ctl = (WgSelCtl*)(smem + o);
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const int n = (int)p.part_cnt[q];
+    const u64* src = p.part_keys + (int64_t)q * p.cap;
+    for (int i = tid; i < n; i += FIN_THREADS) L.res[i] = src[i];
+    for (int t = tid; t <= p.nprobe; t += FIN_THREADS) L.pre[t] = p.prefix_out[(int64_t)q * (p.nprobe + 1) + t];
+    for (int t = tid; t < p.nprobe; t += FIN_THREADS) L.lstart[t] = p.probe_start[(int64_t)q * p.nprobe + t];
+    if (tid == 0) L.ctl->cnt = (unsigned)n;
+    p.defer_finish = 0;
+    fused_finish<FIN_THREADS>(p, q, 0, L); // (starts with a barrier)
+}
+void launch_ivf_finish(const IvfFusedParams& p, hipStream_t stream) {
+    if (p.nq == 0) return;
+    FA_THROW_IF_NOT(p.G == 1 && p.part_keys && p.part_cnt && p.prefix_out && p.probe_start);
+    const size_t lds = ivf_finish_lds_bytes(p.kp, p.cap, p.nprobe);
+    FA_THROW_IF_NOT(lds <= 64 * 1024);
+    hipLaunchKernelGGL(ivf_finish_kernel, dim3((unsigned)p.nq), dim3(FIN_THREADS), lds, stream, p);
+    HIP_CHECK(hipGetLastError());
 }
 
 // ---------------------------------------------------------------------------------

@@ -298,6 +298,9 @@ struct IvfFusedParams {
 // Replaces PQCodeDistances + PQScanMultiPassNoPrecomputed + IVFUtilsSelect{1,2} (IVFPQ) and
 // IVFInterleaved scan + scan2 (IVFFlat) of the reference in a single launch.
 void launch_ivf_fused(const IvfFusedParams& p, hipStream_t stream);
+// second launch of a search with IvfFusedParams::defer_finish: k-selection, id translation and ordering of every
+// query's reservoir (needs probe_len / probe_start, part_keys, part_cnt, prefix_out of the scan launch)
+void launch_ivf_finish(const IvfFusedParams& p, hipStream_t stream);
 // does the problem fit the fused kernel (LDS budget, reservoir size)?  Returns cap / kp to use.
 bool ivf_fused_supported(int kind, int M, int dpad, int k, int nprobe, int* cap_out, int* kp_out, int* nlut_out);
 size_t ivf_fused_lds_bytes(int kind, int M, int dpad, int kp, int cap, int nprobe, int nlut);
