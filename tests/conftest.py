@@ -21,6 +21,16 @@ def _built():
     src = os.path.join(ROOT, "oracle", "faiss_oracle.c")
     if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    # torch wheels bundle their own HIP runtime: when torch is to share the process with libfaiss_amd.so (the tests use
+    # it for device pointers and streams), it has to initialise first so that both end up on one runtime -- initialising
+    # it after the library has created and destroyed streams / pinned buffers fails with hipErrorNoDevice.  bench.py
+    # imports in the same order.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     yield
 
 
