@@ -537,6 +537,83 @@ __global__ void flat_simple_kernel(const float* __restrict__ xq, const float* __
     }
 }
 
+// ---------------------------------------------------------------------------------
+// k = 1 over a small database (k-means assignment of a product-quantizer sub-space: 256 centroids of 2-8 dims, tens of
+// thousands of points, thousands of times per training): the whole database and its norms sit in LDS, one thread per
+// query walks it with the very chain / formula / tie rule of the scan kernels (first minimum = lowest id), one launch
+// instead of scan + select (146 + 71 us per call in round 1 -- 0.35 s of a 0.85 s IVFPQ training).
+// ---------------------------------------------------------------------------------
+template <int METRIC>
+__global__ void __launch_bounds__(256) flat_assign_small_kernel(const float* __restrict__ xq, int64_t ldq, int nq,
+                                                                const float* __restrict__ xb,
+                                                                const float* __restrict__ xbn, int64_t ldb, int nb,
+                                                                int dpad, float* __restrict__ out_dis,
+                                                                int64_t* __restrict__ out_ids) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* yb = (float*)smem;          // [nb][dpad]
+    float* yn = yb + (size_t)nb * dpad; // [nb]
+    for (int t = threadIdx.x; t < nb * dpad; t += 256) yb[t] = xb[(int64_t)(t / dpad) * ldb + (t % dpad)];
+    for (int t = threadIdx.x; t < nb; t += 256) yn[t] = METRIC == METRIC_L2 ? xbn[t] : 0.f;
+    __syncthreads();
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    const float* qr = xq + (int64_t)q * ldq;
+    float qv[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) qv[c] = c < dpad ? qr[c] : 0.f;
+    float xn = 0.f;
+    if (METRIC == METRIC_L2)
+        for (int c = 0; c < dpad; ++c) xn = __fmaf_rn(qv[c], qv[c], xn); // (sequential chain = l2_norms_kernel)
+    unsigned best_key = 0xffffffffu;
+    int best = -1;
+    for (int row = 0; row < nb; ++row) {
+        const float* yr = yb + row * dpad; // every lane the same address: LDS broadcast
+        float acc = 0.f;
+#pragma unroll
+        for (int s = 0; s < 32; s += 8) {
+            if (s < dpad) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc = __fmaf_rn(yr[s + e], qv[s + e], acc);
+                    acc = __fmaf_rn(yr[s + 4 + e], qv[s + 4 + e], acc);
+                }
+            }
+        }
+        float dis;
+        if (METRIC == METRIC_L2) {
+            dis = __fmaf_rn(-2.f, acc, xn + yn[row]);
+            dis = dis < 0.f ? 0.f : dis;
+        } else {
+            dis = acc;
+        }
+        const unsigned key = ordkey<METRIC>(dis);
+        if (key < best_key) { // strict: the first (lowest id) of equal distances stays
+            best_key = key;
+            best = row;
+        }
+    }
+    const bool ok = best >= 0 && best_key < kInvalidOrdKey;
+    out_dis[q] = ok ? unordkey<METRIC>(best_key) : neutral_distance(METRIC);
+    out_ids[q] = ok ? best : -1;
+}
+bool flat_assign_small_supported(int nb, int dpad) {
+    return nb >= 1 && dpad <= 32 && (size_t)nb * (dpad + 1) * 4 <= 48 * 1024;
+}
+void launch_flat_assign_small(int metric, const float* xq, int64_t ldq, int nq, const float* xb, const float* xbn, int64_t ldb,
+                              int nb, int dpad, float* out_dis, int64_t* out_ids, hipStream_t stream) {
+    if (nq == 0) return;
+    FA_THROW_IF_NOT(flat_assign_small_supported(nb, dpad));
+    const size_t lds = (size_t)nb * (dpad + 1) * 4;
+    const dim3 grid((unsigned)div_up(nq, 256));
+    if (metric == METRIC_L2)
+        hipLaunchKernelGGL((flat_assign_small_kernel<METRIC_L2>), grid, dim3(256), lds, stream, xq, ldq, nq, xb, xbn, ldb, nb,
+                           dpad, out_dis, out_ids);
+    else
+        hipLaunchKernelGGL((flat_assign_small_kernel<METRIC_INNER_PRODUCT>), grid, dim3(256), lds, stream, xq, ldq, nq, xb, xbn,
+                           ldb, nb, dpad, out_dis, out_ids);
+    HIP_CHECK(hipGetLastError());
+}
+
 void launch_flat_simple(int metric, const float* xq, const float* xqn, int64_t ldq, int nq,
                         const float* xb, const float* xbn, int64_t ldb, int nb, int dpad, u64* keys,
                         hipStream_t stream) {

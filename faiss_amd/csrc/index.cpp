@@ -923,6 +923,12 @@ void GpuIndexFlat::search_tile_exact_(int n, const float* xq_pad, int k, float* 
         launch_select_k(sp, R.stream);
         return;
     }
+    if (k == 1 && !use_simple_kernel && flat_assign_small_supported(nb, dpad_)) {
+        SpanGuard sg(&R, "flat_assign_small_kernel");
+        launch_flat_assign_small(metric_type, xq_pad, dpad_, n, xb_rows, xbn_.as<float>(), dpad_, nb, dpad_, dD, dI, R.stream);
+        if (use_float16_) R.sync(); // `widened` is released on return
+        return;
+    }
     if (use_simple_kernel) {
         all_keys_.ensure((size_t)n * nb * 8);
         one_cnt_.ensure((size_t)n * 4);

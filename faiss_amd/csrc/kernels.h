@@ -61,6 +61,12 @@ struct FlatScanParams {
 void launch_flat_scan(const FlatScanParams& p, hipStream_t stream);
 size_t flat_scan_lds_bytes();
 
+// k = 1 over a database small enough for LDS (dpad <= 32, nb * (dpad + 1) * 4 <= 48 KB): distance + argmin in one launch,
+// same arithmetic and tie rule as the scan + select pair (k-means assignment of PQ sub-spaces)
+bool flat_assign_small_supported(int nb, int dpad);
+void launch_flat_assign_small(int metric, const float* xq, int64_t ldq, int nq, const float* xb, const float* xbn, int64_t ldb,
+                              int nb, int dpad, float* out_dis, int64_t* out_ids, hipStream_t stream);
+
 // Debug / cross-check path: scalar VALU distances with the identical fmaf chain, every
 // distance written as a 64-bit key.  keys: [nq][nb].
 void launch_flat_simple(int metric, const float* xq, const float* xqn, int64_t ldq, int nq,

@@ -1025,3 +1025,28 @@ def test_gpu_parameter_space_and_interrupt(res):
         faiss_amd.set_interrupt_callback(None)
     D, I = ivf.search(xq, 3)
     assert (I >= 0).all()
+
+
+@pytest.mark.parametrize("metric", [METRIC_L2, METRIC_INNER_PRODUCT])
+@pytest.mark.parametrize("d,nb,nq", [(2, 256, 70000), (8, 256, 5000), (30, 300, 1000), (4, 1, 10), (16, 700, 333)])
+def test_flat_k1_small_database_assign_kernel(res, metric, d, nb, nq):
+    """k = 1 on a database that fits LDS (the k-means assignment of a PQ sub-space, ProductQuantizer::train ->
+    Clustering::train -> index.search(k = 1), faiss/Clustering.cpp:351-356): the one-launch assign kernel returns the
+    bits of the scan + select pair and of the oracle; ties go to the lower id; NaN queries get -1."""
+    _, xb, xq = synthetic_dataset(d, 0, nb, nq, seed=d + nb)
+    xq = xq.copy()
+    xq[min(7, nq - 1)] = np.nan
+    idx = faiss_amd.GpuIndexFlat(res, d, metric)
+    idx.add(xb)
+    D, I = idx.search(xq, 1)
+    Do, Io = Oracle.flat_search(metric, xb, xq[:2000], 1)
+    check_knn(D[:2000], I[:2000], Do, Io, exact=True, name="k=1 small db")
+    idx.set_use_simple_kernel(True)  # the generic path: every distance as a key + select
+    D2, I2 = idx.search(xq, 1)
+    assert np.array_equal(I, I2) and np.array_equal(D, D2)
+    assert I[min(7, nq - 1), 0] == -1
+    xbi, xqi = integer_dataset(4, 200, 500, seed=1, hi=3)  # exact ties everywhere
+    idx = faiss_amd.GpuIndexFlat(res, 4, metric)
+    idx.add(xbi)
+    D, I = idx.search(xqi, 1)
+    check_knn(D, I, *Oracle.flat_search(metric, xbi, xqi, 1), exact=True, name="k=1 ties")
