@@ -1050,3 +1050,65 @@ def test_flat_k1_small_database_assign_kernel(res, metric, d, nb, nq):
     idx.add(xbi)
     D, I = idx.search(xqi, 1)
     check_knn(D, I, *Oracle.flat_search(metric, xbi, xqi, 1), exact=True, name="k=1 ties")
+
+
+# ------------------------------------------------------------------------------- storage corner cases (round 2 arena)
+def test_ivf_arena_corner_cases(res):
+    """The list arena through its less travelled paths: add after copy_lists (no slack: every touched list relocates),
+    compaction once holes pile up, reset + reuse, many lists (nlist > 16384: the rank kernel's global-memory variant),
+    an add that touches a single list only.  Lists stay byte-identical to the restatement's, searches to the oracle's."""
+    d, nlist, M = 32, 24, 8
+    xt, xb, xq = synthetic_dataset(d, 2000, 12000, 25, seed=71)
+    cent, _ = faiss_amd.kmeans(res, xt, nlist, niter=3, seed=5)
+    pq = (np.random.RandomState(2).rand(M, 256, d // M).astype("float32") - 0.5) * 0.5
+
+    def fresh():
+        i = faiss_amd.GpuIndexIVFPQ(res, d, nlist, M, 8, METRIC_L2)
+        i.copy_centroids(cent)
+        i.copy_pq_centroids(pq)
+        i.nprobe = 6
+        return i
+
+    def check(idx, rows, ids):
+        sizes, codes, lids, _ = Oracle.build_ivf_lists(1, METRIC_L2, cent, rows, ids=ids, pq=pq)
+        assert np.array_equal(np.array([idx.get_list_size(l) for l in range(nlist)], dtype=np.uint32), sizes)
+        assert np.array_equal(np.concatenate([idx.get_list_ids(l) for l in range(nlist)]), lids)
+        assert np.array_equal(np.concatenate([idx.get_list_codes(l) for l in range(nlist)]), codes)
+        D, I = idx.search(xq, 10)
+        Do, Io, _, _ = Oracle.ivf_search(1, METRIC_L2, cent, sizes, codes, lids, xq, 6, 10, M=M, pq=pq)
+        check_knn(D, I, Do, Io, exact=True, name="arena")
+
+    ids = np.arange(len(xb), dtype=np.int64) * 3 + 1
+    # copy_lists (capacity = length rounded to the granule) followed by adds
+    s0, c0, l0, _ = Oracle.build_ivf_lists(1, METRIC_L2, cent, xb[:5000], ids=ids[:5000], pq=pq)
+    idx = fresh()
+    idx.copy_lists(s0, c0, l0)
+    idx.add_with_ids(xb[5000:5001], ids[5000:5001])  # one vector: one list grows
+    idx.add_with_ids(xb[5001:9000], ids[5001:9000])
+    check(idx, xb[:9000], ids[:9000])
+    # many small adds: relocations leave holes, compaction keeps the arena bounded
+    for a in range(9000, 12000, 250):
+        idx.add_with_ids(xb[a:a + 250], ids[a:a + 250])
+    check(idx, xb, ids)
+    used, holes, alloc = idx.arena_stats()
+    assert used <= 4 * (12000 + 64 * nlist) and holes <= used and used <= alloc  # (small arenas are not compacted)
+    # reset and reuse
+    idx.reset()
+    assert idx.ntotal == 0 and idx.stored_vectors == 0 and (idx.search(xq, 3)[1] == -1).all()
+    idx.add_with_ids(xb[:3000], ids[:3000])
+    check(idx, xb[:3000], ids[:3000])
+    # nlist beyond the LDS variant of the rank kernel
+    big = 20000
+    rs = np.random.RandomState(9)
+    cb = rs.rand(big, 8).astype(np.float32)
+    iv = faiss_amd.GpuIndexIVFFlat(res, 8, big, METRIC_L2)
+    iv.copy_centroids(cb)
+    x8 = rs.rand(30000, 8).astype(np.float32)
+    iv.add(x8[:17000])
+    iv.add(x8[17000:])
+    lab = Oracle.ivf_assign(METRIC_L2, cb, x8)
+    sizes = np.bincount(lab, minlength=big)
+    probe = np.nonzero(sizes > 1)[0][:50]
+    for l in probe:
+        assert np.array_equal(iv.get_list_ids(int(l)), np.nonzero(lab == l)[0])  # insertion order = id order here
+    assert iv.stored_vectors == 30000
