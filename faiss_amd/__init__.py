@@ -85,6 +85,7 @@ def load_library():
         "faiss_amd_IndexIVFPQ_get_pq_centroids": (i32, [vp, vp]),
         "faiss_amd_IndexIVF_copy_lists": (i32, [vp, vp, vp, vp]),
         "faiss_amd_kmeans_clustering": (i32, [vp, i32, i64, i32, vp, i32, i32, vp, vp]),
+        "faiss_amd_Clustering_train": (i32, [vp, i64, vp, i32, i32, i32, vp, vp, vp]),
         "faiss_amd_merge_knn_results": (i32, [i32, i64, i64, i32, vp, vp, vp, vp, vp]),
         "faiss_amd_merge_knn_results_device": (i32, [vp, i32, i64, i64, i32, vp, vp, vp, vp, vp]),
         "faiss_amd_profile_enable": (i32, [vp, i32]),
@@ -256,6 +257,9 @@ class Index:
 
     def add_ptr(self, n, x_ptr):
         _check(self._lib.faiss_amd_Index_add(self._h, int(n), ctypes.c_void_p(x_ptr)))
+
+    def train_ptr(self, x_ptr, n):
+        _check(self._lib.faiss_amd_Index_train(self._h, int(n), ctypes.c_void_p(x_ptr)))
 
     def assign(self, x, k=1):
         x = _f32(x, self.d)
@@ -576,6 +580,30 @@ def kmeans(res, x, k, niter=25, seed=1234):
     _check(lib.faiss_amd_kmeans_clustering(res._h, d, n, int(k), _ptr(x), int(niter), int(seed), _ptr(cent),
                                            _ptr(obj)))
     return cent, obj
+
+
+class Clustering:
+    """faiss.Clustering (faiss/Clustering.h:88-196): k-means with an index as the assignment engine.
+
+    c = Clustering(d, k, niter=..., seed=...); c.train(x, index); c.centroids, c.obj (objective per iteration).
+    With a GpuIndexFlat the loop runs on the device (c.on_device is True)."""
+
+    def __init__(self, d, k, niter=25, seed=1234):
+        self.d, self.k, self.niter, self.seed = int(d), int(k), int(niter), int(seed)
+        self.centroids = None
+        self.obj = None
+        self.on_device = None
+
+    def train(self, x, index):
+        x = _f32(x)
+        n, d = x.shape
+        assert d == self.d
+        cent = np.empty((self.k, d), dtype=np.float32)
+        obj = np.empty(self.niter, dtype=np.float32)
+        dev = ctypes.c_int(0)
+        _check(load_library().faiss_amd_Clustering_train(index._h, n, _ptr(x), self.k, self.niter, self.seed,
+                                                         _ptr(cent), _ptr(obj), ctypes.byref(dev)))
+        self.centroids, self.obj, self.on_device = cent, obj, bool(dev.value)
 
 
 class GpuParameterSpace:

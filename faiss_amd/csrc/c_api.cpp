@@ -436,6 +436,20 @@ int faiss_amd_kmeans_clustering(FaissAmdGpuResources* res, int d, faiss_amd_idx_
     FA_CATCH
 }
 
+int faiss_amd_Clustering_train(FaissAmdIndex* index, faiss_amd_idx_t n, const float* x, int k, int niter, int seed,
+                               float* centroids_out, float* obj_out, int* on_device_out) {
+    FA_TRY
+    Index* ix = as<Index>(index, "Index");
+    Clustering clus(ix->d, k);
+    clus.niter = niter;
+    clus.seed = seed;
+    clus.train(n, x, *ix);
+    memcpy(centroids_out, clus.centroids.data(), sizeof(float) * (size_t)k * ix->d);
+    if (obj_out) memcpy(obj_out, clus.obj.data(), sizeof(float) * clus.obj.size());
+    if (on_device_out) *on_device_out = clus.last_train_on_device ? 1 : 0;
+    FA_CATCH
+}
+
 int faiss_amd_merge_knn_results(FaissAmdMetricType metric, faiss_amd_idx_t n, faiss_amd_idx_t k, int nshard,
                                 const float* all_d, const faiss_amd_idx_t* all_i,
                                 const faiss_amd_idx_t* base, float* distances, faiss_amd_idx_t* labels) {

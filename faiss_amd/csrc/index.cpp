@@ -1095,8 +1095,45 @@ void GpuIndexFlat::pairwise_distances(idx_t n, const float* x, float* out) const
 // assignment through index.search(k=1), centroid update and empty-cluster splitting on the
 // host.  Random choices use our own generator, so centroids are not bit-identical to faiss
 // (its own GPU tests only compare the objective, faiss/gpu/test/test_gpu_basics.py:117-133).
-void Clustering::train(idx_t nx, const float* x_in, Index& index) {
+// split big clusters into empty ones (faiss/Clustering.cpp split_clusters); centroids on the host
+void Clustering::split_clusters_(std::mt19937_64& rng, idx_t nx, std::vector<idx_t>& hassign) {
+    const float EPS = 1.f / 1024.f;
+    for (int ci = 0; ci < k; ci++) {
+        if (hassign[ci] != 0) continue;
+        int cj = 0;
+        for (;;) {
+            double p = (hassign[cj] - 1.0) / (double)(nx - k);
+            double r = (double)(rng() >> 11) * (1.0 / 9007199254740992.0);
+            if (r < p) break;
+            cj = (cj + 1) % k;
+        }
+        memcpy(&centroids[(size_t)ci * d], &centroids[(size_t)cj * d], sizeof(float) * d);
+        for (int j = 0; j < d; j++) {
+            if (j % 2 == 0) {
+                centroids[(size_t)ci * d + j] *= 1 + EPS;
+                centroids[(size_t)cj * d + j] *= 1 - EPS;
+            } else {
+                centroids[(size_t)ci * d + j] *= 1 - EPS;
+                centroids[(size_t)cj * d + j] *= 1 + EPS;
+            }
+        }
+        hassign[ci] = hassign[cj] / 2;
+        hassign[cj] -= hassign[ci];
+    }
+}
+
+void Clustering::train(idx_t nx, const float* x_in, Index& index, int64_t ldx) {
     FA_THROW_IF_NOT_MSG(nx >= k, "need at least as many training points as clusters");
+    last_train_on_device = false;
+    if (ldx == 0) ldx = d;
+    if (auto* flat = dynamic_cast<GpuIndexFlat*>(&index)) {
+        if (!flat->getUseFloat16() && flat->d == d && nx < ((idx_t)1 << 31)) {
+            train_device_(nx, x_in, ldx, *flat);
+            return;
+        }
+    }
+    FA_THROW_IF_NOT_MSG(!is_device_pointer(x_in) && ldx == d,
+                        "k-means through a generic assignment index takes dense host training data");
     std::mt19937_64 rng((uint64_t)seed);
     // ---- subsample (faiss/Clustering.cpp subsample_training_set)
     std::vector<float> sub;
@@ -1155,34 +1192,128 @@ void Clustering::train(idx_t nx, const float* x_in, Index& index) {
             for (int j = 0; j < d; j++)
                 centroids[(size_t)c * d + j] = (float)(sums[(size_t)c * d + j] / (double)hassign[c]);
         }
-        // ---- split big clusters into empty ones (faiss/Clustering.cpp split_clusters)
-        const float EPS = 1.f / 1024.f;
-        for (int ci = 0; ci < k; ci++) {
-            if (hassign[ci] != 0) continue;
-            int cj = 0;
-            for (;;) {
-                double p = (hassign[cj] - 1.0) / (double)(nx - k);
-                double r = (double)(rng() >> 11) * (1.0 / 9007199254740992.0);
-                if (r < p) break;
-                cj = (cj + 1) % k;
-            }
-            memcpy(&centroids[(size_t)ci * d], &centroids[(size_t)cj * d], sizeof(float) * d);
-            for (int j = 0; j < d; j++) {
-                if (j % 2 == 0) {
-                    centroids[(size_t)ci * d + j] *= 1 + EPS;
-                    centroids[(size_t)cj * d + j] *= 1 - EPS;
-                } else {
-                    centroids[(size_t)ci * d + j] *= 1 - EPS;
-                    centroids[(size_t)cj * d + j] *= 1 + EPS;
-                }
-            }
-            hassign[ci] = hassign[cj] / 2;
-            hassign[cj] -= hassign[ci];
-        }
+        split_clusters_(rng, nx, hassign);
         if (verbose) printf("  k-means iteration %d objective %g\n", it, o);
     }
     index.reset();
     index.add(k, centroids.data());
+}
+
+// The same loop with everything but the random choices on the device.  The generator is drawn from in the same
+// order as above (subsample, initial points, splits) and the update adds in the same order, so both paths give
+// the same centroids bit for bit (tests/test_gpu_parity.py::test_kmeans_device_matches_host_loop).
+void Clustering::train_device_(idx_t nx, const float* x_in, int64_t ldx, GpuIndexFlat& flat) {
+    last_train_on_device = true;
+    auto res = flat.resources();
+    const GpuResources& R = *res;
+    R.set_device();
+    const int dp = flat.dpad();
+    const bool x_dev = is_device_pointer(x_in);
+    FA_THROW_IF_NOT_MSG(x_dev || ldx == d, "strided training rows must live on the device");
+    std::mt19937_64 rng((uint64_t)seed);
+    DevBuf xd, raw, sel, tmp;
+    // ---- subsample (faiss/Clustering.cpp subsample_training_set)
+    if (nx > (idx_t)k * max_points_per_centroid) {
+        const idx_t ns = (idx_t)k * max_points_per_centroid;
+        std::vector<uint32_t> perm((size_t)nx);
+        std::iota(perm.begin(), perm.end(), 0u);
+        for (idx_t i = 0; i < ns; i++) {
+            idx_t j = i + (idx_t)(rng() % (uint64_t)(nx - i));
+            std::swap(perm[i], perm[j]);
+        }
+        xd.ensure((size_t)ns * dp * 4);
+        if (x_dev) {
+            sel.ensure((size_t)ns * 4);
+            HIP_CHECK(hipMemcpyAsync(sel.p, perm.data(), (size_t)ns * 4, hipMemcpyHostToDevice, R.stream));
+            tmp.ensure((size_t)ns * d * 4);
+            launch_gather_rows(x_in, ldx, d, sel.as<uint32_t>(), (int)ns, tmp.as<float>(), R.stream);
+            launch_pad_rows(tmp.as<float>(), d, ns, d, xd.as<float>(), dp, dp, R.stream);
+            R.sync();
+        } else {
+            std::vector<float> sub((size_t)ns * d);
+            for (idx_t i = 0; i < ns; i++) memcpy(&sub[(size_t)i * d], x_in + (size_t)perm[i] * d, sizeof(float) * d);
+            stage_padded(R, sub.data(), ns, d, dp, raw, xd.as<float>());
+            R.sync();
+        }
+        nx = ns;
+    } else {
+        xd.ensure((size_t)nx * dp * 4);
+        if (x_dev) launch_pad_rows(x_in, ldx, nx, d, xd.as<float>(), dp, dp, R.stream);
+        else stage_padded(R, x_in, nx, d, dp, raw, xd.as<float>());
+        R.sync();
+    }
+    raw.release();
+    tmp.release();
+    // ---- init: k distinct random points
+    DevBuf cen; // [k][d] dense
+    cen.ensure((size_t)k * d * 4);
+    {
+        std::vector<uint32_t> perm((size_t)nx);
+        std::iota(perm.begin(), perm.end(), 0u);
+        for (int i = 0; i < k; i++) {
+            idx_t j = i + (idx_t)(rng() % (uint64_t)(nx - i));
+            std::swap(perm[i], perm[j]);
+        }
+        sel.ensure((size_t)k * 4);
+        HIP_CHECK(hipMemcpyAsync(sel.p, perm.data(), (size_t)k * 4, hipMemcpyHostToDevice, R.stream));
+        launch_gather_rows(xd.as<float>(), dp, d, sel.as<uint32_t>(), k, cen.as<float>(), R.stream);
+        R.sync();
+    }
+    // a chunk per wavefront of the rank kernel; at most ~1024 chunks so that the per-chunk histograms stay small
+    int chunk = 2048;
+    while (div_up(nx, chunk) > 1024) chunk *= 2;
+    const int nchunks = (int)div_up(nx, chunk);
+    DevBuf dis, lab, hist, cnt, zero, start, dest, order;
+    dis.ensure((size_t)nx * 4);
+    lab.ensure((size_t)nx * 8);
+    dest.ensure((size_t)nx * 8);
+    order.ensure((size_t)nx * 4);
+    hist.ensure((size_t)nchunks * k * 4);
+    cnt.ensure((size_t)k * 4);
+    zero.ensure((size_t)k * 4);
+    start.ensure((size_t)(k + 1) * 8);
+    HIP_CHECK(hipMemsetAsync(zero.p, 0, (size_t)k * 4, R.stream));
+    std::vector<float> hdis((size_t)nx);
+    std::vector<uint32_t> hcnt((size_t)k);
+    std::vector<idx_t> hassign(k);
+    centroids.resize((size_t)k * d);
+    obj.clear();
+    for (int it = 0; it < niter; it++) {
+        check_interrupt();
+        flat.reset();
+        flat.add(k, cen.as<float>());
+        flat.search_device((int)nx, xd.as<float>(), 1, dis.as<float>(), lab.as<idx_t>());
+        HIP_CHECK(hipMemcpyAsync(hdis.data(), dis.p, (size_t)nx * 4, hipMemcpyDeviceToHost, R.stream));
+        // ---- update (faiss/Clustering.cpp:307-324 compute_centroids)
+        HIP_CHECK(hipMemsetAsync(hist.p, 0, (size_t)nchunks * k * 4, R.stream));
+        launch_ivf_histogram(lab.as<int64_t>(), nx, k, chunk, hist.as<uint32_t>(), R.stream);
+        launch_ivf_chunk_scan(hist.as<uint32_t>(), nchunks, k, zero.as<uint32_t>(), cnt.as<uint32_t>(), R.stream);
+        HIP_CHECK(hipMemcpyAsync(hcnt.data(), cnt.p, (size_t)k * 4, hipMemcpyDeviceToHost, R.stream));
+        launch_exclusive_scan(cnt.as<uint32_t>(), k, start.as<int64_t>(), R.stream);
+        launch_ivf_rank(lab.as<int64_t>(), nx, k, chunk, hist.as<uint32_t>(), start.as<int64_t>(), dest.as<int64_t>(),
+                        R.stream);
+        launch_invert_dest(dest.as<int64_t>(), nx, order.as<uint32_t>(), R.stream);
+        launch_kmeans_update(xd.as<float>(), dp, d, order.as<uint32_t>(), start.as<int64_t>(), cnt.as<uint32_t>(), k,
+                             cen.as<float>(), R.stream);
+        R.sync();
+        double o = 0;
+        for (idx_t i = 0; i < nx; i++) o += hdis[i];
+        obj.push_back((float)o);
+        bool any_empty = false;
+        for (int c = 0; c < k; c++) {
+            hassign[c] = hcnt[c];
+            any_empty |= hcnt[c] == 0;
+        }
+        if (any_empty) {
+            HIP_CHECK(hipMemcpy(centroids.data(), cen.p, (size_t)k * d * 4, hipMemcpyDeviceToHost));
+            split_clusters_(rng, nx, hassign);
+            HIP_CHECK(hipMemcpy(cen.p, centroids.data(), (size_t)k * d * 4, hipMemcpyHostToDevice));
+        }
+        if (verbose) printf("  k-means iteration %d objective %g\n", it, o);
+    }
+    HIP_CHECK(hipMemcpy(centroids.data(), cen.p, (size_t)k * d * 4, hipMemcpyDeviceToHost));
+    flat.reset();
+    flat.add(k, cen.as<float>());
 }
 
 // ====================================================================== GpuIndexIVF
@@ -1272,13 +1403,6 @@ void GpuIndexIVF::train(idx_t n, const float* x) {
     if (is_trained && quantizer->ntotal == nlist) return; // reference: GpuIndexIVF.cu trainQuantizer_
     FA_THROW_IF_NOT_MSG(n > 0 && x, "empty training set");
     res_->set_device();
-    std::vector<float> hx;
-    const float* xh = x;
-    if (is_device_pointer(x)) {
-        hx.resize((size_t)n * d);
-        HIP_CHECK(hipMemcpy(hx.data(), x, (size_t)n * d * 4, hipMemcpyDeviceToHost));
-        xh = hx.data();
-    }
     if (quantizer->ntotal != nlist) {
         Clustering clus(d, nlist);
         clus.niter = cp_niter;
@@ -1286,7 +1410,7 @@ void GpuIndexIVF::train(idx_t n, const float* x) {
         clus.verbose = verbose;
         // the quantizer itself is the assignment index, exactly like GpuIndexIVF::trainQuantizer_
         // (faiss/gpu/GpuIndexIVF.cu:508-538)
-        clus.train(n, xh, *quantizer);
+        clus.train(n, x, *quantizer);
         FA_THROW_IF_NOT(quantizer->ntotal == nlist);
     }
     {
@@ -1295,7 +1419,7 @@ void GpuIndexIVF::train(idx_t n, const float* x) {
         if (!extra_trained_()) {
             DevBuf xpad;
             xpad.ensure((size_t)n * dpad_ * 4);
-            stage_padded(*res_, xh, n, d, dpad_, q_raw_, xpad.as<float>());
+            stage_padded(*res_, x, n, d, dpad_, q_raw_, xpad.as<float>());
             res_->sync();
             train_residual_(n, xpad.as<float>());
         }
@@ -1916,19 +2040,15 @@ void GpuIndexIVFPQ::train_residual_(idx_t n, const float* x_dev_pad) {
     quantizer->search_device((int)nt, xs, 1, ddis.as<float>(), dlab.as<idx_t>());
     launch_residual(xs, dpad_, nt, d, dlab.as<idx_t>(), quantizer->device_vectors(), dpad_,
                     dres.as<float>(), d, R.stream);
-    std::vector<float> hres((size_t)nt * d);
-    HIP_CHECK(hipMemcpyAsync(hres.data(), dres.p, hres.size() * 4, hipMemcpyDeviceToHost, R.stream));
     R.sync();
+    // one k-means per sub-quantizer on its dsub columns of the device-resident residuals (row stride d)
     std::vector<float> pq((size_t)M * 256 * dsub);
-    std::vector<float> slice((size_t)nt * dsub);
     GpuIndexFlat assign_index(res_, dsub, METRIC_L2);
     for (int m = 0; m < M; m++) {
-        for (idx_t i = 0; i < nt; i++)
-            memcpy(&slice[(size_t)i * dsub], &hres[(size_t)i * d + (size_t)m * dsub], sizeof(float) * dsub);
         Clustering clus(dsub, 256);
         clus.niter = pq_niter;
         clus.seed = cp_seed + m;
-        clus.train(nt, slice.data(), assign_index);
+        clus.train(nt, dres.as<float>() + (size_t)m * dsub, assign_index, d);
         memcpy(&pq[(size_t)m * 256 * dsub], clus.centroids.data(), sizeof(float) * 256 * dsub);
     }
     pq_.ensure(pq.size() * 4);

@@ -15,6 +15,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <random>
 #include <vector>
 #include "common.h"
 
@@ -459,9 +460,18 @@ struct Clustering : ClusteringParameters {
     std::vector<float> centroids; // [k][d]
     std::vector<float> obj;       // objective (sum of distances) per iteration
     Clustering(int d_, int k_) : d(d_), k(k_) {}
-    // x on the host; `index` is the assignment engine (reset / add(k centroids) / search k=1),
+    // `index` is the assignment engine (reset / add(k centroids) / search k=1),
     // exactly how the reference drives a GPU flat index (faiss/Clustering.cpp:255-357).
-    void train(idx_t n, const float* x, Index& index);
+    // With a GpuIndexFlat as the engine the whole loop runs on the device (training set uploaded once, assignment,
+    // counting sort by cluster and centroid update as kernels; only the objective and the cluster sizes come back
+    // per iteration) and x may be a host or a device pointer; results are bit-identical to the host loop.
+    // ldx: row stride of x in floats (0 = d; other strides for device data only)
+    void train(idx_t n, const float* x, Index& index, int64_t ldx = 0);
+    bool last_train_on_device = false;
+
+   private:
+    void train_device_(idx_t n, const float* x, int64_t ldx, class GpuIndexFlat& flat);
+    void split_clusters_(std::mt19937_64& rng, idx_t nx, std::vector<idx_t>& hassign);
 };
 
 } // namespace faiss_amd

@@ -308,6 +308,73 @@ void launch_ivf_rank(const int64_t* labels, int64_t n, int nlist, int chunk, uin
     HIP_CHECK(hipGetLastError());
 }
 
+// ---------------------------------------------------------------------------------
+// k-means centroid update on the device (faiss/Clustering.cpp:307-324 compute_centroids): the points are
+// counting-sorted by their assignment with the kernels above (stable: a cluster's members stay in index order), then
+// one thread per (centroid, dimension) adds its members in that order in double precision -- the same additions in
+// the same order as a sequential host loop, whatever the launch geometry.
+// ---------------------------------------------------------------------------------
+// start[l] = sum_{l' < l} cnt[l'] for l in [0, n]: one workgroup, segments of ceil(n / 1024) per thread
+__global__ void __launch_bounds__(1024) exclusive_scan_kernel(const uint32_t* __restrict__ cnt, int n,
+                                                             int64_t* __restrict__ start) {
+    __shared__ int64_t part[1024];
+    const int t = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    const int a = min(n, t * per), b = min(n, a + per);
+    int64_t s = 0;
+    for (int i = a; i < b; ++i) s += cnt[i];
+    part[t] = s;
+    __syncthreads();
+    if (t == 0) {
+        int64_t run = 0;
+        for (int i = 0; i < 1024; ++i) {
+            const int64_t v = part[i];
+            part[i] = run;
+            run += v;
+        }
+        start[n] = run;
+    }
+    __syncthreads();
+    int64_t run = part[t];
+    for (int i = a; i < b; ++i) {
+        start[i] = run;
+        run += cnt[i];
+    }
+}
+void launch_exclusive_scan(const uint32_t* cnt, int n, int64_t* start, hipStream_t stream) {
+    hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, stream, cnt, n, start);
+    HIP_CHECK(hipGetLastError());
+}
+__global__ void invert_dest_kernel(const int64_t* __restrict__ dest, int64_t n, uint32_t* __restrict__ order) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && dest[i] >= 0) order[dest[i]] = (uint32_t)i;
+}
+void launch_invert_dest(const int64_t* dest, int64_t n, uint32_t* order, hipStream_t stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(invert_dest_kernel, dim3((unsigned)div_up(n, 256)), dim3(256), 0, stream, dest, n, order);
+    HIP_CHECK(hipGetLastError());
+}
+__global__ void kmeans_update_kernel(const float* __restrict__ x, int64_t ldx, int d, const uint32_t* __restrict__ order,
+                                     const int64_t* __restrict__ start, const uint32_t* __restrict__ cnt,
+                                     float* __restrict__ cen) {
+    const int c = blockIdx.x;
+    const uint32_t n = cnt[c];
+    if (n == 0) return; // an empty cluster keeps its centroid (split on the host)
+    const uint32_t* mem = order + start[c];
+    for (int j = threadIdx.x; j < d; j += blockDim.x) {
+        double s = 0.0;
+        for (uint32_t t = 0; t < n; ++t) s += (double)x[(int64_t)mem[t] * ldx + j];
+        cen[(int64_t)c * d + j] = (float)(s / (double)n);
+    }
+}
+void launch_kmeans_update(const float* x, int64_t ldx, int d, const uint32_t* order, const int64_t* start,
+                          const uint32_t* cnt, int k, float* centroids, hipStream_t stream) {
+    const int threads = d >= 128 ? 128 : 64;
+    hipLaunchKernelGGL(kmeans_update_kernel, dim3((unsigned)k), dim3(threads), 0, stream, x, ldx, d, order, start, cnt,
+                       centroids);
+    HIP_CHECK(hipGetLastError());
+}
+
 __global__ void ivf_move_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                 const IvfMoveJob* __restrict__ jobs, int bytes_per_row) {
     const IvfMoveJob jb = jobs[blockIdx.x];

@@ -377,6 +377,12 @@ void launch_ivf_chunk_scan(uint32_t* hist, int nchunks, int nlist, const uint32_
 // sort: one wavefront per chunk walks its vectors in order); label < 0 (NaN vectors) -> -1
 void launch_ivf_rank(const int64_t* labels, int64_t n, int nlist, int chunk, uint32_t* hist,
                      const int64_t* list_start, int64_t* dest, hipStream_t stream);
+// k-means centroid update (faiss/Clustering.cpp:307-324): start[0..n] = exclusive prefix of cnt; order[dest[i]] = i;
+// centroids[c][j] = float(sum over the members of c, in index order, of double(x[i][j]) / count) for count > 0
+void launch_exclusive_scan(const uint32_t* cnt, int n, int64_t* start, hipStream_t stream);
+void launch_invert_dest(const int64_t* dest, int64_t n, uint32_t* order, hipStream_t stream);
+void launch_kmeans_update(const float* x, int64_t ldx, int d, const uint32_t* order, const int64_t* start,
+                          const uint32_t* cnt, int k, float* centroids, hipStream_t stream);
 // list relocation: job j moves rows[j] rows of bytes_per_row bytes from row src[j] to row dst[j] (regions never
 // overlap: destinations are fresh space at the end of the arena)
 struct IvfMoveJob {

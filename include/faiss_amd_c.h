@@ -172,6 +172,13 @@ int faiss_amd_IndexIVF_copy_lists(FaissAmdIndex* index, const uint32_t* list_siz
 int faiss_amd_kmeans_clustering(FaissAmdGpuResources* res, int d, faiss_amd_idx_t n, int k, const float* x,
                                 int niter, int seed, float* centroids_out, float* obj_out);
 
+/* faiss::Clustering::train(n, x, index) (faiss/Clustering.h:147-160; c_api/Clustering_c.h:118-122 faiss_Clustering_train):
+ * k-means with `index` (dimension d, empty or not -- it is reset) as the assignment engine; on return the index holds
+ * the k centroids.  With a GpuIndexFlat the whole loop runs on the device (x host or device); any other index of this
+ * library is driven through add / search with host data.  on_device_out (nullable): which of the two ran. */
+int faiss_amd_Clustering_train(FaissAmdIndex* index, faiss_amd_idx_t n, const float* x, int k, int niter, int seed,
+                               float* centroids_out, float* obj_out, int* on_device_out);
+
 /* ---- shard merge: faiss::merge_knn_results (faiss/utils/Heap.h merge_knn_results,
  *      faiss/utils/Heap.cpp:166-240); all_d/all_i are [nshard][n][k]; base (nullable) is added
  *      to each shard's labels (IndexShards successive_ids, faiss/IndexShards.cpp:214-237) */

@@ -250,6 +250,74 @@ def test_kmeans_objective_matches_reference(res):
         assert abs(obj[-1] / robj - 1) < 0.05
 
 
+@pytest.mark.parametrize("d,n,k,niter", [(32, 10000, 40, 6), (2, 65536, 256, 5), (16, 30000, 100, 4), (128, 5000, 512, 3)])
+def test_kmeans_device_matches_host_loop(res, d, n, k, niter):
+    """The device-resident Lloyd loop (training set uploaded once; assignment, counting sort by cluster and centroid
+    update as kernels) against the same loop driven through add()/search() with the update on the host, which is how
+    the reference organises it (faiss/Clustering.cpp:255-357): identical centroids and objectives, bit for bit.
+    (16, 30000, 100): 30000 > 100 * 256 exercises the subsample; (128, 5000, 512): < 39 points per centroid and
+    clustered data leave empty clusters, which exercises the split."""
+    if d == 128:
+        rs = np.random.RandomState(5)
+        xt = (rs.randint(0, 8, size=(n, 1)) * 10 + rs.rand(n, d) * 0.01).astype(np.float32)  # 8 tight blobs, 512 centroids
+    else:
+        xt, _, _ = synthetic_dataset(d, n, 0, 0, seed=d + k)
+    dev_ix = faiss_amd.GpuIndexFlatL2(res, d)
+    c_dev = faiss_amd.Clustering(d, k, niter=niter, seed=11)
+    c_dev.train(xt, dev_ix)
+    assert c_dev.on_device and dev_ix.ntotal == k
+    rep = faiss_amd.IndexReplicas(d, threaded=False)  # not a GpuIndexFlat: the generic host loop
+    rep.add_replica(faiss_amd.GpuIndexFlatL2(res, d))
+    c_host = faiss_amd.Clustering(d, k, niter=niter, seed=11)
+    c_host.train(xt, rep)
+    assert not c_host.on_device and rep.ntotal == k
+    assert np.array_equal(c_dev.obj, c_host.obj)
+    assert np.array_equal(c_dev.centroids, c_host.centroids)
+    assert np.array_equal(dev_ix.reconstruct_n(0, k), c_dev.centroids)
+    cent, obj = faiss_amd.kmeans(res, xt, k, niter=niter, seed=11)
+    assert np.array_equal(cent, c_dev.centroids) and np.array_equal(obj, c_dev.obj)
+
+
+def test_kmeans_device_update_equals_numpy_sums(res):
+    """One Lloyd iteration from known centroids: new centroid = float(double sum of the members in index order / count)
+    (faiss/Clustering.cpp:307-324), checked against numpy on the assignment the index itself reports."""
+    xt, _, _ = synthetic_dataset(24, 6000, 0, 0, seed=9)
+    k = 50
+    c1 = faiss_amd.Clustering(24, k, niter=1, seed=3)
+    ix = faiss_amd.GpuIndexFlatL2(res, 24)
+    c1.train(xt, ix)
+    c0 = faiss_amd.Clustering(24, k, niter=0, seed=3)  # just the initial points
+    ix0 = faiss_amd.GpuIndexFlatL2(res, 24)
+    c0.train(xt, ix0)
+    _, a = ix0.search(xt, 1)
+    a = a.ravel()
+    want = c0.centroids.copy()
+    for c in range(k):
+        m = xt[a == c].astype(np.float64)
+        if len(m):
+            acc = np.zeros(24, dtype=np.float64)
+            for row in m:
+                acc += row
+            want[c] = (acc / len(m)).astype(np.float32)
+    assert (np.bincount(a, minlength=k) > 0).all()  # no split in this configuration
+    assert np.array_equal(c1.centroids, want)
+
+
+def test_ivf_train_from_device_pointers(res):
+    """GpuIndexIVF::train with the training set resident on the device (no host round trip) gives the quantizers the
+    host-pointer call gives."""
+    import torch
+    xt, xb, xq = synthetic_dataset(32, 20000, 5000, 50, seed=21)
+    a = faiss_amd.GpuIndexIVFPQ(res, 32, 64, 8, 8, METRIC_L2)
+    a.train(xt)
+    b = faiss_amd.GpuIndexIVFPQ(res, 32, 64, 8, 8, METRIC_L2)
+    t = torch.from_numpy(xt).cuda()
+    torch.cuda.synchronize()
+    b.train_ptr(t.data_ptr(), t.shape[0])
+    assert np.array_equal(a.get_centroids(), b.get_centroids())
+    assert np.array_equal(a.get_pq_centroids(), b.get_pq_centroids())
+
+
 # ------------------------------------------------------------------------------- shards / merge
 def test_index_shards_equals_single_index(res):
     """faiss/gpu/test/test_multi_gpu.py:31-48: sharded flat must give I == I_ref exactly."""
