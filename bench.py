@@ -151,9 +151,19 @@ def ivf_leg(kind, res, xt, xb, xq, xq_dev, gt_first, steps, torch, with_cpu=True
     import faiss_amd
     from oracle.pyoracle import Ref
     pq = kind == "ivfpq"
+    sq = kind == "ivfsq"
+
+    def make():
+        if pq:
+            return faiss_amd.GpuIndexIVFPQ(res, D, NLIST, PQ_M, 8, faiss_amd.METRIC_L2)
+        if sq:
+            return faiss_amd.GpuIndexIVFScalarQuantizer(res, D, NLIST, faiss_amd.ScalarQuantizer.QT_8bit, faiss_amd.METRIC_L2, True)
+        return faiss_amd.GpuIndexIVFFlat(res, D, NLIST, faiss_amd.METRIC_L2)
+
+    factory = "IVF4096,PQ64" if pq else "IVF4096,SQ8" if sq else "IVF4096,Flat"
+    title = "GpuIndexIVFPQ PQ%dx8" % PQ_M if pq else "GpuIndexIVFScalarQuantizer QT_8bit" if sq else "GpuIndexIVFFlat"
     t0 = time.time()
-    idx = (faiss_amd.GpuIndexIVFPQ(res, D, NLIST, PQ_M, 8, faiss_amd.METRIC_L2) if pq
-           else faiss_amd.GpuIndexIVFFlat(res, D, NLIST, faiss_amd.METRIC_L2))
+    idx = make()
     idx.train(xt)
     t_train = time.time() - t0
     t0 = time.time()
@@ -162,7 +172,7 @@ def ivf_leg(kind, res, xt, xb, xq, xq_dev, gt_first, steps, torch, with_cpu=True
     idx.nprobe = NPROBE
     Dd = torch.empty((NQ, K), dtype=torch.float32, device=xq_dev.device)
     Id = torch.empty((NQ, K), dtype=torch.int64, device=xq_dev.device)
-    kname = "ivfpq_fused_kernel" if pq else "ivfflat_fused_kernel"
+    kname = "ivfpq_fused_kernel" if pq else "ivfsq_fused_kernel" if sq else "ivfflat_fused_kernel"
     time_search(idx, torch, NQ, xq_dev.data_ptr(), Dd.data_ptr(), Id.data_ptr(), 1, 1)
     res.profile_enable(True)
     res.profile_reset()
@@ -175,12 +185,11 @@ def ivf_leg(kind, res, xt, xb, xq, xq_dev, gt_first, steps, torch, with_cpu=True
     I = Id.cpu().numpy()
     avg_ms = scan_ms / max(scan_n, 1)
     # algorithmic HBM bytes of the list scan: nprobe * nb/nlist * bytes-per-entry per query
-    row_bytes = PQ_M if pq else D * 4
+    row_bytes = PQ_M if pq else D if sq else D * 4
     alg_bytes = float(NPROBE) * NB / NLIST * row_bytes * NQ
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if scan_n else None
     out = {
-        "workload": "%s nlist=%d nprobe=%d d=%d nb=%d nq=%d k=%d" % ("GpuIndexIVFPQ PQ%dx8" % PQ_M if pq else "GpuIndexIVFFlat",
-                                                                       NLIST, NPROBE, D, NB, NQ, K),
+        "workload": "%s nlist=%d nprobe=%d d=%d nb=%d nq=%d k=%d" % (title, NLIST, NPROBE, D, NB, NQ, K),
         "qps": round(NQ / dt, 1), "ms_per_step": round(dt * 1e3, 3),
         "qps_host_buffers": round(NQ / dt_host, 1),
         "recall_at_1": round(float((I[:, 0] == gt_first).mean()), 4),
@@ -198,9 +207,11 @@ def ivf_leg(kind, res, xt, xb, xq, xq_dev, gt_first, steps, torch, with_cpu=True
         try:
             cores = effective_cores()
             Ref.set_threads(cores)
-            ref = Ref.index_factory(D, "IVF4096,PQ64" if pq else "IVF4096,Flat")
+            ref = Ref.index_factory(D, factory)
             if pq:
                 ref.set_trained(idx.get_centroids(), idx.get_pq_centroids())
+            elif sq:
+                ref.set_sq_trained(idx.get_centroids(), idx.get_trained())
             else:
                 ref.set_centroids(idx.get_centroids())
             t0 = time.time()
@@ -213,16 +224,17 @@ def ivf_leg(kind, res, xt, xb, xq, xq_dev, gt_first, steps, torch, with_cpu=True
             dtc = time.time() - t0
             cpu = {"value": round(NQ / dtc, 1), "unit": "QPS", "cores": int(cores), "kind": "reference",
                    "sample": "faiss 1.15.0 index_factory('%s') with the GPU-trained quantizers, nprobe=%d, all %d queries, "
-                             "nb=%d, k=%d" % ("IVF4096,PQ64" if pq else "IVF4096,Flat", NPROBE, NQ, NB, K),
+                             "nb=%d, k=%d" % (factory, NPROBE, NQ, NB, K),
                    "add_s": round(t_cadd, 1),
                    "recall_at_1": round(float((Ir[:, 0] == gt_first).mean()), 4),
                    "recall_at_100": round(float((Ir == gt_first[:, None]).any(axis=1).mean()), 4)}
             # parity on identical lists: the reference's own lists copied to a GPU index (copyFrom)
-            g2 = (faiss_amd.GpuIndexIVFPQ(res, D, NLIST, PQ_M, 8, faiss_amd.METRIC_L2) if pq
-                  else faiss_amd.GpuIndexIVFFlat(res, D, NLIST, faiss_amd.METRIC_L2))
+            g2 = make()
             g2.copy_centroids(idx.get_centroids())
             if pq:
                 g2.copy_pq_centroids(idx.get_pq_centroids())
+            if sq:
+                g2.copy_trained(idx.get_trained())
             sizes, codes, lids = ref.lists()
             g2.copy_lists(sizes, codes, lids)
             g2.nprobe = NPROBE
@@ -327,7 +339,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-ivf", action="store_true", help="skip the IVF4096,PQ64 / IVF4096,Flat legs")
+    ap.add_argument("--no-ivf", action="store_true", help="skip the IVF4096,PQ64 / IVF4096,Flat / IVF4096,SQ8 legs")
     ap.add_argument("--multi-gpu", choices=["replicas", "shards"], default="replicas",
                     help="layout of the FLAT leg at N > 1: replicas = every GPU holds the database, queries are split "
                          "(IndexReplicas, the reference's default for databases that fit one GPU); shards = rows are split "
@@ -501,7 +513,7 @@ def main():
             except Exception as e:  # noqa: BLE001
                 line["cpu_baseline"] = {"error": repr(e)[:200]}
         if not args.no_ivf:
-            for kind in ("ivfpq", "ivfflat"):
+            for kind in ("ivfpq", "ivfflat", "ivfsq"):
                 try:
                     line[kind], _ = ivf_leg(kind, res, xt, xb, xq, xq_dev, gI[:, 0], max(2, args.steps // 2), torch,
                                             with_cpu=not args.no_cpu_baseline)

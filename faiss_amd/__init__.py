@@ -54,6 +54,11 @@ def load_library():
         "faiss_amd_GpuIndexFlat_new": (i32, [P(vp), vp, i32, i32]),
         "faiss_amd_GpuIndexIVFFlat_new": (i32, [P(vp), vp, i32, i32, i32]),
         "faiss_amd_GpuIndexIVFPQ_new": (i32, [P(vp), vp, i32, i32, i32, i32, i32]),
+        "faiss_amd_GpuIndexIVFScalarQuantizer_new": (i32, [P(vp), vp, i32, i32, i32, i32, i32]),
+        "faiss_amd_IndexIVFSQ_info": (i32, [vp, P(i32), P(i32), P(sz), P(sz)]),
+        "faiss_amd_IndexIVFSQ_get_trained": (i32, [vp, vp]),
+        "faiss_amd_IndexIVFSQ_copy_trained": (i32, [vp, vp, sz]),
+        "faiss_amd_IndexIVFSQ_set_rangestat": (i32, [vp, i32, ctypes.c_float]),
         "faiss_amd_IndexShards_new": (i32, [P(vp), i32, i32, i32]),
         "faiss_amd_IndexShards_add_shard": (i32, [vp, vp]),
         "faiss_amd_IndexReplicas_new": (i32, [P(vp), i32, i32]),
@@ -541,6 +546,46 @@ class GpuIndexIVFPQ(_GpuIndexIVF):
         out = np.empty((self.M, 256, self.d // self.M), dtype=np.float32)
         _check(self._lib.faiss_amd_IndexIVFPQ_get_pq_centroids(self._h, _ptr(out)))
         return out
+
+
+class ScalarQuantizer:
+    """faiss.ScalarQuantizer.QuantizerType values (faiss/impl/ScalarQuantizer.h:27-34) of the types the GPU index stores"""
+    QT_8bit, QT_4bit, QT_8bit_uniform, QT_4bit_uniform, QT_fp16, QT_8bit_direct, QT_6bit = range(7)
+    RS_minmax, RS_meanstd, RS_quantiles, RS_optim = range(4)
+
+
+class GpuIndexIVFScalarQuantizer(_GpuIndexIVF):
+    """faiss.GpuIndexIVFScalarQuantizer (faiss/gpu/GpuIndexIVFScalarQuantizer.h:27-131)."""
+
+    def __init__(self, res, d, nlist, qtype, metric=METRIC_L2, encodeResidual=True):
+        super().__init__()
+        self._keep.append(res)
+        _check(self._lib.faiss_amd_GpuIndexIVFScalarQuantizer_new(ctypes.byref(self._h), res._h, int(d), int(nlist),
+                                                                  int(qtype), int(metric), int(bool(encodeResidual))))
+
+    def _info(self):
+        qt, br = ctypes.c_int(0), ctypes.c_int(0)
+        cs, ts = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        _check(self._lib.faiss_amd_IndexIVFSQ_info(self._h, ctypes.byref(qt), ctypes.byref(br), ctypes.byref(cs),
+                                                   ctypes.byref(ts)))
+        return qt.value, bool(br.value), cs.value, ts.value
+
+    qtype = property(lambda self: self._info()[0])
+    by_residual = property(lambda self: self._info()[1])
+
+    def get_trained(self):
+        """index.sq.trained: {vmin, vdiff} (uniform types) or vmin[d] then vdiff[d]"""
+        out = np.empty(self._info()[3], dtype=np.float32)
+        if out.size:
+            _check(self._lib.faiss_amd_IndexIVFSQ_get_trained(self._h, _ptr(out)))
+        return out
+
+    def copy_trained(self, trained):
+        t = np.ascontiguousarray(trained, dtype=np.float32).reshape(-1)
+        _check(self._lib.faiss_amd_IndexIVFSQ_copy_trained(self._h, _ptr(t), t.size))
+
+    def set_rangestat(self, rangestat, rangestat_arg=0.0):
+        _check(self._lib.faiss_amd_IndexIVFSQ_set_rangestat(self._h, int(rangestat), float(rangestat_arg)))
 
 
 class IndexShards(Index):

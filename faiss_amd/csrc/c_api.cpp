@@ -231,6 +231,48 @@ int faiss_amd_GpuIndexIVFPQ_new_with_config(FaissAmdIndex** p_index, FaissAmdGpu
     FA_CATCH_RC
     return faiss_amd_GpuIndexIVFPQ_new(p_index, res, d, nlist, M, nbits, metric);
 }
+int faiss_amd_GpuIndexIVFScalarQuantizer_new(FaissAmdIndex** p_index, FaissAmdGpuResources* res, int d, int nlist,
+                                             int qtype, FaissAmdMetricType metric, int encode_residual) {
+    FA_TRY
+    auto r = R(res);
+    auto* h = new FaissAmdIndex_H{nullptr, r};
+    try {
+        h->index = new GpuIndexIVFScalarQuantizer(r, d, nlist, qtype, (int)metric, encode_residual != 0);
+    } catch (...) {
+        delete h;
+        throw;
+    }
+    *p_index = h;
+    FA_CATCH
+}
+int faiss_amd_IndexIVFSQ_info(const FaissAmdIndex* index, int* qtype, int* by_residual, size_t* code_size,
+                              size_t* trained_size) {
+    FA_TRY
+    auto* sq = as<GpuIndexIVFScalarQuantizer>(index, "GpuIndexIVFScalarQuantizer");
+    if (qtype) *qtype = sq->qtype;
+    if (by_residual) *by_residual = sq->by_residual ? 1 : 0;
+    if (code_size) *code_size = sq->code_size;
+    if (trained_size) *trained_size = sq->trained.size();
+    FA_CATCH
+}
+int faiss_amd_IndexIVFSQ_get_trained(const FaissAmdIndex* index, float* out) {
+    FA_TRY
+    auto* sq = as<GpuIndexIVFScalarQuantizer>(index, "GpuIndexIVFScalarQuantizer");
+    memcpy(out, sq->trained.data(), sq->trained.size() * sizeof(float));
+    FA_CATCH
+}
+int faiss_amd_IndexIVFSQ_copy_trained(FaissAmdIndex* index, const float* trained, size_t n) {
+    FA_TRY
+    as<GpuIndexIVFScalarQuantizer>(index, "GpuIndexIVFScalarQuantizer")->set_trained(trained, n);
+    FA_CATCH
+}
+int faiss_amd_IndexIVFSQ_set_rangestat(FaissAmdIndex* index, int rangestat, float rangestat_arg) {
+    FA_TRY
+    auto* sq = as<GpuIndexIVFScalarQuantizer>(index, "GpuIndexIVFScalarQuantizer");
+    sq->rangestat = rangestat;
+    sq->rangestat_arg = rangestat_arg;
+    FA_CATCH
+}
 int faiss_amd_GpuIndexFlat_resident_bytes(const FaissAmdIndex* index, size_t* p_bytes) {
     FA_TRY
     *p_bytes = as<GpuIndexFlat>(index, "GpuIndexFlat")->resident_bytes();
@@ -379,9 +421,7 @@ int faiss_amd_IndexIVF_get_list_codes(const FaissAmdIndex* index, faiss_amd_idx_
 }
 int faiss_amd_IndexIVF_code_size(const FaissAmdIndex* index, size_t* p) {
     FA_TRY
-    auto* ivf = as<GpuIndexIVF>(index, "GpuIndexIVF");
-    if (auto* pq = dynamic_cast<const GpuIndexIVFPQ*>(ivf)) *p = (size_t)pq->M;
-    else *p = (size_t)ivf->d * sizeof(float);
+    *p = as<GpuIndexIVF>(index, "GpuIndexIVF")->ref_code_size();
     FA_CATCH
 }
 int faiss_amd_IndexIVF_get_centroids(const FaissAmdIndex* index, float* out) {

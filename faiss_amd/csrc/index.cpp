@@ -1259,9 +1259,10 @@ void Clustering::train_device_(idx_t nx, const float* x_in, int64_t ldx, GpuInde
         launch_gather_rows(xd.as<float>(), dp, d, sel.as<uint32_t>(), k, cen.as<float>(), R.stream);
         R.sync();
     }
-    // a chunk per wavefront of the rank kernel; at most ~1024 chunks so that the per-chunk histograms stay small
-    int chunk = 2048;
-    while (div_up(nx, chunk) > 1024) chunk *= 2;
+    // a chunk per wavefront of the rank kernel (which walks its chunk 64 points at a time): about 512 of them
+    int chunk = 256;
+    while (div_up(nx, chunk) > 512) chunk *= 2;
+    if (const char* e = getenv("FAISS_AMD_KMEANS_CHUNK")) chunk = std::max(64, atoi(e)); // timing experiments only
     const int nchunks = (int)div_up(nx, chunk);
     DevBuf dis, lab, hist, cnt, zero, start, dest, order;
     dis.ensure((size_t)nx * 4);
@@ -1612,7 +1613,7 @@ void GpuIndexIVF::set_lists(const uint32_t* list_sizes, const uint8_t* codes, co
     arena_rows_ = 0; // (old contents are dropped: nothing to keep when the buffers grow)
     hole_rows_ = 0;
     ensure_arena_(rows);
-    const size_t src_row = fused_kind_() == 0 ? (size_t)d * 4 : code_bytes_;
+    const size_t src_row = ref_row_bytes_();
     if (acc > 0) {
         // ids: list by list into the lists' row ranges
         DevBuf tmp_ids, tmp_codes, dsrc;
@@ -1628,7 +1629,7 @@ void GpuIndexIVF::set_lists(const uint32_t* list_sizes, const uint8_t* codes, co
                         R.stream);
         // `codes` are the reference's list payloads: d floats (IVFFlat) or M bytes (IVFPQ) per entry
         tmp_codes.ensure((size_t)acc * code_bytes_);
-        if (fused_kind_() == 0) {
+        if (fused_kind_() != 1) {
             HIP_CHECK(hipMemsetAsync(tmp_codes.p, 0, (size_t)acc * code_bytes_, R.stream));
             HIP_CHECK(hipMemcpy2DAsync(tmp_codes.p, code_bytes_, codes, src_row, src_row, (size_t)acc, hipMemcpyDefault,
                                        R.stream));
@@ -1672,10 +1673,10 @@ std::vector<uint8_t> GpuIndexIVF::getListVectorData(idx_t list) const {
     FA_THROW_IF_NOT(list >= 0 && list < nlist);
     std::lock_guard<std::mutex> g(mu_);
     res_->set_device();
-    const size_t dst_row = fused_kind_() == 0 ? (size_t)d * 4 : code_bytes_;
+    const size_t dst_row = ref_row_bytes_();
     std::vector<uint8_t> out((size_t)list_len_[list] * dst_row);
     if (out.empty()) return out;
-    if (fused_kind_() == 0) {
+    if (fused_kind_() != 1) {
         HIP_CHECK(hipMemcpy2D(out.data(), dst_row, arena_.as<uint8_t>() + list_start_[list] * code_bytes_, code_bytes_,
                               dst_row, list_len_[list], hipMemcpyDeviceToHost));
     } else {
@@ -1738,8 +1739,30 @@ void GpuIndexIVF::search_core_body_(idx_t n, const float* x, idx_t k, float* dis
     idx_t tile = (idx_t)std::max<size_t>(1, R.temp_budget_bytes / per_q);
     tile = std::min<idx_t>(tile, 16384);
     int fused_cap = 0, fused_kp = 0, fused_nlut = 1;
-    const bool fused = use_fused_scan && ivf_fused_supported(fused_kind_(), fused_M_(), dpad_, (int)k, np, &fused_cap,
-                                                             &fused_kp, &fused_nlut);
+    bool fused;
+    int sq_npc = np; // scalar quantizer: probes per workgroup the LDS table rows allow
+    if (fused_kind_() == 2) {
+        // the scan exists only as the fused kernel; with residual encoding (L2) every probe of a workgroup needs its
+        // own table row, so a large nprobe x d is split over several workgroups per query
+        const int dsq = (int)round_up(d, 16);
+        IvfFusedParams probe{};
+        fill_fused_(probe);
+        fused = false;
+        for (;;) {
+            const int rows = sq_table_rows(metric_type, probe.sq_by_residual != 0, sq_npc);
+            if (ivf_fused_supported(2, rows, dsq, (int)k, np, &fused_cap, &fused_kp, &fused_nlut) &&
+                (size_t)rows * dsq * 4 <= 64 * 1024) {
+                fused = true;
+                break;
+            }
+            if (sq_npc == 1) break;
+            sq_npc = (sq_npc + 1) / 2;
+        }
+        FA_THROW_IF_NOT_MSG(fused, "scalar-quantizer search: k / d outside the range of the scan kernel");
+    } else {
+        fused = use_fused_scan && ivf_fused_supported(fused_kind_(), fused_M_(), dpad_, (int)k, np, &fused_cap, &fused_kp,
+                                                     &fused_nlut);
+    }
     if (fused) tile = 65536; // no per-candidate scratch: the tile only bounds the staging buffers
     for (idx_t i0 = 0; i0 < n; i0 += tile) {
         check_interrupt();
@@ -1799,6 +1822,7 @@ void GpuIndexIVF::search_core_body_(idx_t n, const float* x, idx_t k, float* dis
             const int want = 4 * R.num_cus;
             int G = ni >= want ? 1 : std::min<int>(np, (int)div_up(want, ni));
             fp.npc = (int)div_up(np, G);
+            if (fp.kind == 2) fp.npc = std::min(fp.npc, sq_npc);
             fp.G = (int)div_up(np, fp.npc);
             fp.out_dis = dD;
             fp.out_ids = dI;
@@ -1816,6 +1840,7 @@ void GpuIndexIVF::search_core_body_(idx_t n, const float* x, idx_t k, float* dis
                 fp.prefix_out = prefix_.as<uint32_t>();
             }
             fill_fused_(fp);
+            if (fp.kind == 2) fp.M = sq_table_rows(metric_type, fp.sq_by_residual != 0, fp.npc);
             probe_len_.ensure((size_t)ni * np * 4);
             probe_start_.ensure((size_t)ni * np * 8);
             launch_ivf_probe_info(c_ids_.as<idx_t>(), (int64_t)ni * np, d_list_len_.as<uint32_t>(),
@@ -1830,7 +1855,7 @@ void GpuIndexIVF::search_core_body_(idx_t n, const float* x, idx_t k, float* dis
                 fp.phase_ticks = ticks.as<unsigned long long>();
             }
             {
-                SpanGuard sg(&R, fp.kind == 1 ? "ivfpq_fused_kernel" : "ivfflat_fused_kernel");
+                SpanGuard sg(&R, fp.kind == 1 ? "ivfpq_fused_kernel" : fp.kind == 2 ? "ivfsq_fused_kernel" : "ivfflat_fused_kernel");
                 launch_ivf_fused(fp, R.stream);
             }
             if (fp.phase_ticks) {
@@ -1917,6 +1942,166 @@ void GpuIndexIVF::search_core_body_(idx_t n, const float* x, idx_t k, float* dis
         if (!out_dev_i) copy_out(R, labels + (size_t)i0 * k, dI, (size_t)ni * k * 8);
         R.sync();
     }
+}
+
+// ---------------------------------------------------------------------- IVF scalar quantizer
+GpuIndexIVFScalarQuantizer::GpuIndexIVFScalarQuantizer(std::shared_ptr<GpuResources> res, int dims, int nlist, int qtype_,
+                                                       int metric, bool encode_residual)
+        : GpuIndexIVF(std::move(res), dims, metric, nlist), qtype(qtype_), by_residual(encode_residual) {
+    // the types GpuIndexIVFScalarQuantizer accepts (faiss/gpu/impl/GpuScalarQuantizer.cuh:20-33 isSQSupported)
+    dsq_ = (int)round_up(dims, 16);
+    switch (qtype) {
+        case QT_8bit:
+        case QT_8bit_uniform:
+            ct_ = SQ_U8, levels_ = 255.f, code_size = (size_t)dims;
+            break;
+        case QT_8bit_direct:
+            ct_ = SQ_U8, levels_ = 0.f, code_size = (size_t)dims;
+            break;
+        case QT_4bit:
+        case QT_4bit_uniform:
+            ct_ = SQ_U4, levels_ = 15.f, code_size = ((size_t)dims + 1) / 2;
+            break;
+        case QT_6bit:
+            ct_ = SQ_U6, levels_ = 63.f, code_size = ((size_t)dims * 6 + 7) / 8;
+            break;
+        case QT_fp16:
+            ct_ = SQ_F16, levels_ = 0.f, code_size = (size_t)dims * 2;
+            break;
+        default:
+            FA_THROW_MSG("unsupported scalar quantizer type (reference: GpuScalarQuantizer.cuh isSQSupported)");
+    }
+    FA_THROW_IF_NOT_MSG(dims <= 1024, "scalar-quantizer index: d <= 1024");
+    code_bytes_ = (size_t)(dsq_ / 16) * sq_chunk_bytes(ct_); // arena row: whole 16-component chunks, zero padded
+    granule_ = 8;
+    upload_tables_();
+}
+
+// decoder tables: x^_i = fmaf(code_i, s_i, b_i) with s = vdiff / levels, b = vmin + s / 2 -- the reconstruction
+// vmin + (code + 0.5) / levels * vdiff of faiss/impl/scalar_quantizer/quantizers.h:92-150, codecs.h:36-58
+void GpuIndexIVFScalarQuantizer::upload_tables_() {
+    res_->set_device();
+    std::vector<float> vmin(d, 0.f), vdiff(d, 0.f), s(dsq_, 0.f), b(dsq_, 0.f);
+    if (needs_training_()) {
+        if (trained.empty()) return;
+        const bool uniform = qtype == QT_8bit_uniform || qtype == QT_4bit_uniform;
+        FA_THROW_IF_NOT_MSG(trained.size() == (uniform ? 2u : 2u * (size_t)d), "scalar quantizer: wrong size of `trained`");
+        for (int i = 0; i < d; i++) {
+            vmin[i] = uniform ? trained[0] : trained[i];
+            vdiff[i] = uniform ? trained[1] : trained[(size_t)d + i];
+            s[i] = vdiff[i] / levels_;
+            b[i] = vmin[i] + 0.5f * s[i];
+        }
+    } else if (qtype == QT_8bit_direct) {
+        for (int i = 0; i < d; i++) s[i] = 1.f; // the code is the value
+    }
+    vmin_.ensure((size_t)d * 4);
+    vdiff_.ensure((size_t)d * 4);
+    sq_s_.ensure((size_t)dsq_ * 4);
+    sq_b_.ensure((size_t)dsq_ * 4);
+    HIP_CHECK(hipMemcpy(vmin_.p, vmin.data(), (size_t)d * 4, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(vdiff_.p, vdiff.data(), (size_t)d * 4, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(sq_s_.p, s.data(), (size_t)dsq_ * 4, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(sq_b_.p, b.data(), (size_t)dsq_ * 4, hipMemcpyHostToDevice));
+}
+void GpuIndexIVFScalarQuantizer::set_trained(const float* t, size_t n) {
+    FA_THROW_IF_NOT_MSG(needs_training_(), "this scalar quantizer type has no trained range");
+    FA_THROW_IF_NOT_MSG(t && n > 0, "null `trained`");
+    const bool uniform = qtype == QT_8bit_uniform || qtype == QT_4bit_uniform;
+    FA_THROW_IF_NOT_MSG(n == (uniform ? 2u : 2u * (size_t)d), "scalar quantizer: wrong size of `trained`");
+    std::lock_guard<std::mutex> g(mu_);
+    trained.assign(t, t + n);
+    upload_tables_();
+    update_is_trained_();
+}
+void GpuIndexIVFScalarQuantizer::train_residual_(idx_t n, const float* x_dev_pad) {
+    // IndexIVF::train_encoder on at most 100000 vectors (IndexScalarQuantizer.cpp:152-161), residuals when
+    // by_residual (IndexIVF.cpp train_encoder path), then ScalarQuantizer::train = per-dimension (or global) range
+    // (impl/scalar_quantizer/training.cpp:209-232, 333-365)
+    if (!needs_training_()) return;
+    FA_THROW_IF_NOT_MSG(rangestat == 0, "only RS_minmax ranges are trained on the device; train the CPU index and copy it");
+    const GpuResources& R = *res_;
+    idx_t nt = std::min<idx_t>(n, 100000);
+    DevBuf dsel, dsub_rows, dlab, ddis, dres, dmm;
+    const float* xs = x_dev_pad;
+    if (nt < n) {
+        std::mt19937_64 rng((uint64_t)cp_seed + 0x51ed270b7c3f9a1dull);
+        std::vector<uint32_t> perm((size_t)n);
+        std::iota(perm.begin(), perm.end(), 0u);
+        for (idx_t i = 0; i < nt; i++) {
+            const idx_t j = i + (idx_t)(rng() % (uint64_t)(n - i));
+            std::swap(perm[i], perm[j]);
+        }
+        dsel.ensure((size_t)nt * 4);
+        HIP_CHECK(hipMemcpyAsync(dsel.p, perm.data(), (size_t)nt * 4, hipMemcpyHostToDevice, R.stream));
+        dsub_rows.ensure((size_t)nt * dpad_ * 4);
+        launch_gather_rows(x_dev_pad, dpad_, dpad_, dsel.as<uint32_t>(), (int)nt, dsub_rows.as<float>(), R.stream);
+        R.sync();
+        xs = dsub_rows.as<float>();
+    }
+    int64_t ldr = dpad_;
+    if (by_residual) {
+        dlab.ensure((size_t)nt * 8);
+        ddis.ensure((size_t)nt * 4);
+        dres.ensure((size_t)nt * d * 4);
+        quantizer->search_device((int)nt, xs, 1, ddis.as<float>(), dlab.as<idx_t>());
+        launch_residual(xs, dpad_, nt, d, dlab.as<idx_t>(), quantizer->device_vectors(), dpad_, dres.as<float>(), d, R.stream);
+        xs = dres.as<float>();
+        ldr = d;
+    }
+    const int nb = ivfsq_minmax_blocks(nt);
+    dmm.ensure((size_t)nb * 2 * d * 4);
+    launch_ivfsq_minmax(xs, ldr, nt, d, dmm.as<float>(), R.stream);
+    std::vector<float> mm((size_t)nb * 2 * d);
+    HIP_CHECK(hipMemcpyAsync(mm.data(), dmm.p, mm.size() * 4, hipMemcpyDeviceToHost, R.stream));
+    R.sync();
+    std::vector<float> lo(d, INFINITY), hi(d, -INFINITY);
+    for (int b = 0; b < nb; b++)
+        for (int j = 0; j < d; j++) {
+            lo[j] = std::min(lo[j], mm[((size_t)b * 2 + 0) * d + j]);
+            hi[j] = std::max(hi[j], mm[((size_t)b * 2 + 1) * d + j]);
+        }
+    const bool uniform = qtype == QT_8bit_uniform || qtype == QT_4bit_uniform;
+    if (uniform) {
+        float vmin = INFINITY, vmax = -INFINITY;
+        for (int j = 0; j < d; j++) {
+            vmin = std::min(vmin, lo[j]);
+            vmax = std::max(vmax, hi[j]);
+        }
+        const float vexp = (vmax - vmin) * rangestat_arg;
+        vmin -= vexp;
+        vmax += vexp;
+        trained = {vmin, vmax - vmin};
+    } else {
+        trained.assign((size_t)2 * d, 0.f);
+        for (int j = 0; j < d; j++) {
+            float vmin = lo[j], vmax = hi[j];
+            const float vexp = (vmax - vmin) * rangestat_arg;
+            vmin -= vexp;
+            vmax += vexp;
+            trained[j] = vmin;
+            trained[(size_t)d + j] = vmax - vmin;
+        }
+    }
+    upload_tables_();
+}
+void GpuIndexIVFScalarQuantizer::append_(int n, const float* x_pad, const int64_t* d_labels, const int64_t* d_dest) {
+    launch_ivfsq_encode_append(qtype, x_pad, dpad_, n, d, d_labels, d_dest, quantizer->device_vectors(), dpad_, by_residual,
+                               vmin_.as<float>(), vdiff_.as<float>(), arena_.as<uint8_t>(), (int)code_bytes_, res_->stream);
+}
+void GpuIndexIVFScalarQuantizer::fill_fused_(IvfFusedParams& p) const {
+    p.arena_codes = arena_.as<uint8_t>();
+    p.sq_ct = ct_;
+    p.sq_dsq = dsq_;
+    p.sq_ld = (int)code_bytes_;
+    p.sq_by_residual = by_residual ? 1 : 0;
+    p.sq_s = sq_s_.as<float>();
+    p.sq_b = sq_b_.as<float>();
+    p.centroids = quantizer->device_vectors();
+    p.ldc = dpad_;
+}
+void GpuIndexIVFScalarQuantizer::scan_(int, const float*, int, const int64_t*) const {
+    FA_THROW_MSG("the scalar-quantizer scan exists only as the fused kernel");
 }
 
 // ---------------------------------------------------------------------- IVFFlat

@@ -255,6 +255,8 @@ class GpuIndexIVF : public Index {
     // vectors actually stored (ntotal counts the vectors add() was given, NaN rows included, like the reference:
     // faiss/gpu/GpuIndexIVF.cu:293-298)
     idx_t stored_vectors() const { return nstored_; }
+    // bytes per list entry as the reference counts them (IndexIVF::code_size)
+    size_t ref_code_size() const { return ref_row_bytes_(); }
     // arena statistics (rows): used (lists + slack + holes), holes left behind by relocated lists, allocated
     void arena_stats(int64_t* used, int64_t* holes, int64_t* allocated) const;
     // Clustering parameters used by train() (reference default niter=10 for the GPU IVF
@@ -294,6 +296,9 @@ class GpuIndexIVF : public Index {
     virtual void fill_fused_(struct IvfFusedParams& p) const = 0;
     virtual int fused_kind_() const = 0;
     virtual int fused_M_() const { return 0; }
+    // bytes per entry of the reference's inverted-list payload (invlists->code_size): what copy_lists takes and
+    // getListVectorData returns
+    virtual size_t ref_row_bytes_() const { return code_bytes_; }
     mutable DevBuf part_keys_, part_cnt_, probe_len_, probe_start_;
     void upload_list_tables_();
     void ensure_arena_(int64_t rows);
@@ -324,6 +329,7 @@ class GpuIndexIVFFlat : public GpuIndexIVF {
    protected:
     void fill_fused_(struct IvfFusedParams& p) const override;
     int fused_kind_() const override { return 0; }
+    size_t ref_row_bytes_() const override { return (size_t)d * 4; }
     void append_(int n, const float* x_pad, const int64_t* d_labels, const int64_t* d_dest) override;
     void scan_(int nq, const float* xq_pad, int k, const int64_t* h_qoff) const override;
 };
@@ -347,6 +353,44 @@ class GpuIndexIVFPQ : public GpuIndexIVF {
     void train_residual_(idx_t n, const float* x_dev_pad) override;
     void append_(int n, const float* x_pad, const int64_t* d_labels, const int64_t* d_dest) override;
     void scan_(int nq, const float* xq_pad, int k, const int64_t* h_qoff) const override;
+};
+
+// faiss::gpu::GpuIndexIVFScalarQuantizer (faiss/gpu/GpuIndexIVFScalarQuantizer.h:27-131) over
+// faiss::ScalarQuantizer (faiss/impl/ScalarQuantizer.h:25-120): every vector (or its residual to the list centroid)
+// is stored as one small code per dimension.  qtype takes the reference's enum values for the types its GPU index
+// supports (GpuScalarQuantizer.cuh:20-33): QT_8bit 0, QT_4bit 1, QT_8bit_uniform 2, QT_4bit_uniform 3, QT_fp16 4,
+// QT_8bit_direct 5, QT_6bit 6.
+class GpuIndexIVFScalarQuantizer : public GpuIndexIVF {
+   public:
+    GpuIndexIVFScalarQuantizer(std::shared_ptr<GpuResources> res, int dims, int nlist, int qtype, int metric,
+                               bool encode_residual = true);
+    int qtype;
+    bool by_residual;
+    size_t code_size; // bytes per vector as the reference counts them (sq.code_size)
+    // ScalarQuantizer::rangestat / rangestat_arg (ScalarQuantizer.h:60-70); only RS_minmax (0) is trained here
+    int rangestat = 0;
+    float rangestat_arg = 0.f;
+    // ScalarQuantizer::trained (ScalarQuantizer.h:72-73): {vmin, vdiff} (uniform types) or vmin[d] then vdiff[d]
+    std::vector<float> trained;
+    void set_trained(const float* t, size_t n);
+
+   protected:
+    void fill_fused_(struct IvfFusedParams& p) const override;
+    int fused_kind_() const override { return 2; }
+    size_t ref_row_bytes_() const override { return code_size; }
+    bool extra_trained_() const override { return !needs_training_() || !trained.empty(); }
+    void train_residual_(idx_t n, const float* x_dev_pad) override;
+    void append_(int n, const float* x_pad, const int64_t* d_labels, const int64_t* d_dest) override;
+    void scan_(int nq, const float* xq_pad, int k, const int64_t* h_qoff) const override;
+
+   private:
+    int dsq_;      // d rounded up to 16
+    int ct_;       // SqCodeType of the scan kernel
+    float levels_; // 255 / 15 / 63 (code range of the type), 0 for the types without a trained range
+    bool needs_training_() const { return levels_ > 0.f; }
+    DevBuf vmin_, vdiff_; // [d] (uniform types: replicated) -- the encoder's view of `trained`
+    DevBuf sq_s_, sq_b_;  // [dsq_] scale / offset per dimension of the decoder: x^ = fmaf(code, s, b)
+    void upload_tables_();
 };
 
 // ------------------------------------------------------------------ IndexShards

@@ -58,12 +58,15 @@ struct FusedLds {
     WgSelCtl* ctl;
 };
 
-static size_t fused_region0_bytes(int kind, int M, int kp, int nlut) {
-    size_t lut = kind == 1 ? (size_t)M * 1024 * nlut : 0;
+// region 0: the PQ lookup table(s) / the scalar quantizer's M table rows of dpad (= dsq) floats + one coarse distance
+// per probe; reused for the winners once the scan is over
+static size_t fused_region0_bytes(int kind, int M, int kp, int nlut, int dpad, int nprobe) {
+    size_t lut = kind == 1 ? (size_t)M * 1024 * nlut : kind == 2 ? (size_t)M * dpad * 4 + (size_t)nprobe * 4 : 0;
     return round_up(std::max<size_t>(std::max<size_t>(lut, (size_t)kp * 12), 16), 16);
 }
+// (kind 2: dpad = the quantizer's padded dimension sq_dsq, M = table rows)
 size_t ivf_fused_lds_bytes(int kind, int M, int dpad, int kp, int cap, int nprobe, int nlut) {
-    return fused_region0_bytes(kind, M, kp, nlut) + 2 * round_up((size_t)dpad * 4, 16) + (size_t)cap * 8 +
+    return fused_region0_bytes(kind, M, kp, nlut, dpad, nprobe) + 2 * round_up((size_t)dpad * 4, 16) + (size_t)cap * 8 +
            2 * round_up((size_t)(nprobe + 1) * 4, 16) + round_up((size_t)(M + 4) * 4, 16) +
            round_up((size_t)nprobe * 4, 16) + (size_t)nprobe * 8 + 1024 + 64;
 }
@@ -72,14 +75,16 @@ __device__ __forceinline__ FusedLds fused_carve(char* smem, const IvfFusedParams
     FusedLds L;
     size_t o = 0;
     L.lut = smem;
+    const int dq = p.kind == 2 ? p.sq_dsq : p.dpad;
     {
-        size_t lut = p.kind == 1 ? (size_t)p.M * 1024 * p.nlut : 0;
+        size_t lut = p.kind == 1 ? (size_t)p.M * 1024 * p.nlut
+                   : p.kind == 2 ? (size_t)p.M * dq * 4 + (size_t)p.nprobe * 4 : 0;
         size_t r0 = lut > (size_t)p.kp * 12 ? lut : (size_t)p.kp * 12;
         if (r0 < 16) r0 = 16;
         o = (r0 + 15) & ~(size_t)15;
     }
     L.rs = (float*)(smem + o); // two buffers of rs_stride floats
-    o += 2 * (((size_t)p.dpad * 4 + 15) & ~(size_t)15);
+    o += 2 * (((size_t)dq * 4 + 15) & ~(size_t)15);
     L.res = (u64*)(smem + o);
     o += (size_t)p.cap * 8;
     L.pre = (uint32_t*)(smem + o);
@@ -623,6 +628,223 @@ __global__ void __launch_bounds__(FB_MAX) ivfflat_fused_kernel(IvfFusedParams p)
 }
 
 // ---------------------------------------------------------------------------------
+// IVF scalar quantizer (kind 2).  The IVFFlat walk (eight lanes per row, position stream over the probed lists) over
+// rows of CODES: a lane owns the 16-component chunks c = ln, ln + 8, ... of its row (16 bytes of 8-bit codes, 8 of
+// 4-bit, 12 of 6-bit, 32 of fp16), decodes them in registers and folds them into the distance with the per-dimension
+// scale s and a query-side table row a kept in LDS:
+//   L2: tt = fmaf(-code, s_i, a_i), a_i = (q_i [- centroid_i]) - b_i   (fp16: tt = a_i - half)   acc = fmaf(tt, tt, acc)
+//   IP: acc = fmaf(w_i, code, acc), w_i = q_i * s_i                     (fp16: w_i = q_i);  + <q, b> (+ coarse term)
+// i.e. the distance to the reconstruction b_i + s_i * code_i of faiss::ScalarQuantizer (quantizers.h:92-150: vmin +
+// (code + 0.5) / 255 * vdiff) without materialising it.  With residual encoding the L2 row a changes with the list:
+// one row per probe of the workgroup (built once, nprobe x d x 4 bytes); otherwise the row sits in registers.
+// The code stream is the only HBM traffic: d bytes per scanned vector for 8-bit codes.
+// Reference: IVFSQScannerL2 / IVFSQScannerIP (faiss/impl/scalar_quantizer/scanners.h:34-140), on the GPU
+// IVFFlatScan with a Codec (faiss/gpu/impl/IVFFlatScan.cu, GpuScalarQuantizer.cuh).
+// ---------------------------------------------------------------------------------
+constexpr int SQ_FB = 512;
+template <int CT>
+struct SqChunk {
+    static constexpr int WORDS = CT == SQ_U8 ? 4 : CT == SQ_U4 ? 2 : CT == SQ_U6 ? 3 : 8;
+};
+// component E (0..15) of a chunk, as a float
+template <int CT, int E>
+__device__ __forceinline__ float sq_comp(const unsigned (&w)[SqChunk<CT>::WORDS]) {
+    if constexpr (CT == SQ_U8) {
+        return (float)((w[E >> 2] >> (8 * (E & 3))) & 255u);
+    } else if constexpr (CT == SQ_U4) {
+        return (float)((w[E >> 3] >> (4 * (E & 7))) & 15u);
+    } else if constexpr (CT == SQ_U6) {
+        constexpr int off = 6 * E, wi = off >> 5, sh = off & 31;
+        if constexpr (sh <= 26) return (float)((w[wi] >> sh) & 63u);
+        else return (float)(((w[wi] >> sh) | (w[wi + 1] << (32 - sh))) & 63u);
+    } else {
+        const unsigned short hw = (unsigned short)(w[E >> 1] >> (16 * (E & 1)));
+        return (float)__builtin_bit_cast(_Float16, hw);
+    }
+}
+template <int METRIC, int CT, int E>
+__device__ __forceinline__ void sq_fold(const unsigned (&w)[SqChunk<CT>::WORDS], const float* sv, const float* av, float& acc) {
+    if constexpr (E < 16) {
+        const float cf = sq_comp<CT, E>(w);
+        if (METRIC == METRIC_L2) {
+            const float tt = CT == SQ_F16 ? av[E] - cf : __fmaf_rn(-cf, sv[E], av[E]);
+            acc = __fmaf_rn(tt, tt, acc);
+        } else {
+            acc = __fmaf_rn(av[E], cf, acc);
+        }
+        sq_fold<METRIC, CT, E + 1>(w, sv, av, acc);
+    }
+}
+
+template <int METRIC, int CT, int NT>
+__global__ void __launch_bounds__(SQ_FB, 4) ivfsq_fused_kernel(IvfFusedParams p) {
+    constexpr int FB = SQ_FB;
+    constexpr int W = SqChunk<CT>::WORDS;
+    constexpr int SR0 = 32 / (NT * W);
+    constexpr int SR = SR0 > 8 ? 8 : SR0 < 1 ? 1 : SR0; // rows per 8-lane group and iteration
+    constexpr int NPOS = SR * (FB / 8);
+    constexpr int CHB = W * 4;                           // bytes per chunk
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const FusedLds L = fused_carve(smem, p);
+    const int tid = threadIdx.x;
+    const int q = blockIdx.x / p.G, g = blockIdx.x - q * p.G;
+    const int p0 = g * p.npc, p1 = min(p.nprobe, p0 + p.npc);
+    const int ln = tid & 7, rg = tid >> 3;
+    const int dsq = p.sq_dsq, nch = dsq >> 4;
+    const bool per_probe = METRIC == METRIC_L2 && p.sq_by_residual;
+    float* tab_s = (float*)L.lut;
+    float* tab_a = tab_s + dsq;
+    float* tab_c = tab_a + (size_t)(p.M - 1) * dsq; // [npc] coarse distances (IP with residual encoding)
+
+    fused_load_probes<FB>(p, q, L);
+    const float* xq = p.xq + (int64_t)q * p.ldq;
+    for (int i = tid; i < dsq; i += FB) tab_s[i] = CT == SQ_F16 ? 0.f : p.sq_s[i];
+    if (per_probe) {
+        const int cnt = (p1 - p0) * dsq;
+        for (int idx = tid; idx < cnt; idx += FB) {
+            const int t = idx / dsq, i = idx - t * dsq;
+            const int l = L.lst[p0 + t];
+            float a = 0.f;
+            if (i < p.d && l >= 0) {
+                a = xq[i] - p.centroids[(int64_t)l * p.ldc + i];
+                if (CT != SQ_F16) a = a - p.sq_b[i];
+            }
+            tab_a[idx] = a;
+        }
+    } else {
+        for (int i = tid; i < dsq; i += FB) {
+            float a = 0.f;
+            if (i < p.d) {
+                if (METRIC == METRIC_L2) a = CT == SQ_F16 ? xq[i] : xq[i] - p.sq_b[i];
+                else a = CT == SQ_F16 ? xq[i] : xq[i] * p.sq_s[i];
+            }
+            tab_a[i] = a;
+        }
+    }
+    if (METRIC != METRIC_L2) {
+        for (int t = tid; t < p1 - p0; t += FB) tab_c[t] = p.sq_by_residual ? p.coarse_dis[(int64_t)q * p.nprobe + p0 + t] : 0.f;
+        // <q, b>: summed like a row (lane chunks, then the 8-lane tree)
+        if (tid < 8) {
+            float acc = 0.f;
+            if (CT != SQ_F16)
+                for (int c = tid; c < nch; c += 8)
+                    for (int e = 0; e < 16; ++e) {
+                        const int i = 16 * c + e;
+                        if (i < p.d) acc = __fmaf_rn(xq[i], p.sq_b[i], acc);
+                    }
+            acc = acc + __shfl_xor(acc, 1, 64);
+            acc = acc + __shfl_xor(acc, 2, 64);
+            acc = acc + __shfl_xor(acc, 4, 64);
+            if (tid == 0) L.rs[0] = acc;
+        }
+    }
+    __syncthreads();
+    const float qb = METRIC != METRIC_L2 ? L.rs[0] : 0.f;
+    // one chunk per lane: its scale (and, without per-probe rows, its table row) stay in registers
+    float sreg[16], areg[16];
+    if (NT == 1) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            sreg[e] = ln < nch ? tab_s[16 * ln + e] : 0.f;
+            areg[e] = (!per_probe && ln < nch) ? tab_a[16 * ln + e] : 0.f;
+        }
+    }
+
+    const unsigned pos_begin = L.pre[p0], pos_end = L.pre[p1];
+    u64 tau = ~0ull;
+    int bound = 0;
+    for (unsigned base = pos_begin; base < pos_end; base += NPOS) {
+        FUSED_MAKE_ROOM(min((unsigned)NPOS, pos_end - base));
+        unsigned rowi[SR]; // arena row (rows are counted in 32 bits: at most 2^31 per index), ~0u = none
+        int tq[SR];
+#pragma unroll
+        for (int u = 0; u < SR; ++u) {
+            const unsigned pos = base + u * (FB / 8) + rg;
+            rowi[u] = ~0u;
+            tq[u] = 0;
+            if (pos < pos_end) {
+                int lo = p0, hi = p1; // invariant pre[lo] <= pos < pre[hi]
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (L.pre[mid] <= pos) lo = mid;
+                    else hi = mid;
+                }
+                rowi[u] = (unsigned)(L.lstart[lo] + (pos - L.pre[lo]));
+                tq[u] = lo - p0;
+            }
+        }
+        unsigned w[SR][NT][W];
+#pragma unroll
+        for (int u = 0; u < SR; ++u)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int c = ln + 8 * t;
+                const bool ok = rowi[u] != ~0u && c < nch;
+                const unsigned* src = (const unsigned*)(p.arena_codes + (int64_t)rowi[u] * p.sq_ld + c * CHB);
+                if constexpr (W == 4) {
+                    const uint4 v = ok ? *(const uint4*)src : uint4{0u, 0u, 0u, 0u};
+                    w[u][t][0] = v.x, w[u][t][1] = v.y, w[u][t][2] = v.z, w[u][t][3] = v.w;
+                } else if constexpr (W == 2) {
+                    const uint2 v = ok ? *(const uint2*)src : uint2{0u, 0u};
+                    w[u][t][0] = v.x, w[u][t][1] = v.y;
+                } else if constexpr (W == 3) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) w[u][t][i] = ok ? src[i] : 0u;
+                } else {
+                    const uint4 v0 = ok ? *(const uint4*)src : uint4{0u, 0u, 0u, 0u};
+                    const uint4 v1 = ok ? *(const uint4*)(src + 4) : uint4{0u, 0u, 0u, 0u};
+                    w[u][t][0] = v0.x, w[u][t][1] = v0.y, w[u][t][2] = v0.z, w[u][t][3] = v0.w;
+                    w[u][t][4] = v1.x, w[u][t][5] = v1.y, w[u][t][6] = v1.z, w[u][t][7] = v1.w;
+                }
+            }
+#pragma unroll
+        for (int u = 0; u < SR; ++u) {
+            float acc = 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int c = ln + 8 * t;
+                if (NT == 1) {
+                    if (per_probe) {
+                        float av[16];
+                        const f32x4* ap = (const f32x4*)(tab_a + tq[u] * dsq + 16 * (ln < nch ? ln : 0));
+#pragma unroll
+                        for (int v4 = 0; v4 < 4; ++v4) {
+                            const f32x4 x4 = ap[v4];
+                            av[4 * v4] = x4[0], av[4 * v4 + 1] = x4[1], av[4 * v4 + 2] = x4[2], av[4 * v4 + 3] = x4[3];
+                        }
+                        if (ln < nch) sq_fold<METRIC, CT, 0>(w[u][t], sreg, av, acc);
+                    } else {
+                        sq_fold<METRIC, CT, 0>(w[u][t], sreg, areg, acc);
+                    }
+                } else if (c < nch) {
+                    float sv[16], av[16];
+                    const f32x4* sp = (const f32x4*)(tab_s + 16 * c);
+                    const f32x4* ap = (const f32x4*)(tab_a + (per_probe ? tq[u] * dsq : 0) + 16 * c);
+#pragma unroll
+                    for (int v4 = 0; v4 < 4; ++v4) {
+                        const f32x4 s4 = sp[v4], x4 = ap[v4];
+                        sv[4 * v4] = s4[0], sv[4 * v4 + 1] = s4[1], sv[4 * v4 + 2] = s4[2], sv[4 * v4 + 3] = s4[3];
+                        av[4 * v4] = x4[0], av[4 * v4 + 1] = x4[1], av[4 * v4 + 2] = x4[2], av[4 * v4 + 3] = x4[3];
+                    }
+                    sq_fold<METRIC, CT, 0>(w[u][t], sv, av, acc);
+                }
+            }
+            // ((p0+p1)+(p2+p3)) + ((p4+p5)+(p6+p7)) in every lane of the group, append from lane 0
+            float a = acc;
+            a = a + __shfl_xor(a, 1, 64);
+            a = a + __shfl_xor(a, 2, 64);
+            a = a + __shfl_xor(a, 4, 64);
+            if (METRIC != METRIC_L2) a = (a + qb) + tab_c[tq[u]];
+            const u64 key = ((u64)ordkey<METRIC>(a) << 32) | (u64)(base + u * (FB / 8) + rg);
+            const bool pass = rowi[u] != ~0u && ln == 0 && key < tau;
+            wg_append(L.res, L.ctl, pass, key);
+        }
+        __syncthreads();
+    }
+    fused_finish<FB>(p, q, g, L);
+}
+
+// ---------------------------------------------------------------------------------
 // Deferred finish (IvfFusedParams::defer_finish): the reservoir a scan workgroup left in part_keys[q][0..n) is cut to
 // the k best, translated to user ids and ordered by a small workgroup of its own -- 256 threads, ~11 KB of LDS, many
 // per CU -- instead of on the critical path of a 75 KB scan workgroup.  Same code as the in-kernel finish.
@@ -668,6 +890,7 @@ void launch_ivf_finish(const IvfFusedParams& p, hipStream_t stream) {
 
 // ---------------------------------------------------------------------------------
 int ivf_fused_threads(int kind) {
+    if (kind == 2) return SQ_FB;
     if (kind != 1) return FB_MAX;
     if (const char* e = getenv("FAISS_AMD_IVFPQ_FB")) return atoi(e) == 1024 ? 1024 : 512; // timing experiments only
     return 512;
@@ -698,12 +921,37 @@ void launch_ivf_fused(const IvfFusedParams& p, hipStream_t stream) {
     const int fb = ivf_fused_threads(p.kind);
     FA_THROW_IF_NOT(p.cap >= p.k + fb && p.cap <= FMAXR * fb);
     FA_THROW_IF_NOT(p.nlut == 1 || p.nlut == 2);
-    const size_t lds = ivf_fused_lds_bytes(p.kind, p.M, p.dpad, p.kp, p.cap, p.nprobe, p.nlut);
+    const size_t lds = ivf_fused_lds_bytes(p.kind, p.M, p.kind == 2 ? p.sq_dsq : p.dpad, p.kp, p.cap, p.nprobe, p.nlut);
     FA_THROW_IF_NOT_MSG(lds <= 160 * 1024, "fused IVF scan does not fit the LDS");
     const bool l2 = p.metric == METRIC_L2;
     if (p.kind == 0) {
         if (l2) launch_one(ivfflat_fused_kernel<METRIC_L2>, p, lds, fb, stream);
         else launch_one(ivfflat_fused_kernel<METRIC_INNER_PRODUCT>, p, lds, fb, stream);
+    } else if (p.kind == 2) {
+        const int nch = p.sq_dsq / 16;
+        FA_THROW_IF_NOT_MSG(p.sq_dsq % 16 == 0 && nch >= 1 && nch <= 64, "scalar-quantizer scan: d <= 1024");
+        FA_THROW_IF_NOT(p.M == sq_table_rows(p.metric, p.sq_by_residual != 0, p.npc) && p.arena_codes && p.sq_s && p.sq_b);
+        FA_THROW_IF_NOT(p.sq_ld % 4 == 0 && p.sq_ld >= nch * sq_chunk_bytes(p.sq_ct));
+#define FA_SQ_LAUNCH_NT(CT_, NT_)                                                                          \
+    do {                                                                                                   \
+        if (l2) launch_one(ivfsq_fused_kernel<METRIC_L2, CT_, NT_>, p, lds, fb, stream);                   \
+        else launch_one(ivfsq_fused_kernel<METRIC_INNER_PRODUCT, CT_, NT_>, p, lds, fb, stream);           \
+    } while (0)
+#define FA_SQ_LAUNCH(CT_)                                                                                  \
+    do {                                                                                                   \
+        if (nch <= 8) FA_SQ_LAUNCH_NT(CT_, 1);                                                             \
+        else if (nch <= 16) FA_SQ_LAUNCH_NT(CT_, 2);                                                       \
+        else if (nch <= 32) FA_SQ_LAUNCH_NT(CT_, 4);                                                       \
+        else FA_SQ_LAUNCH_NT(CT_, 8);                                                                      \
+    } while (0)
+        switch (p.sq_ct) {
+            case SQ_U8: FA_SQ_LAUNCH(SQ_U8); break;
+            case SQ_U4: FA_SQ_LAUNCH(SQ_U4); break;
+            case SQ_U6: FA_SQ_LAUNCH(SQ_U6); break;
+            default: FA_SQ_LAUNCH(SQ_F16); break;
+        }
+#undef FA_SQ_LAUNCH
+#undef FA_SQ_LAUNCH_NT
     } else {
         FA_THROW_IF_NOT_MSG(p.metric != METRIC_L2 || p.arena_t2, "IVFPQ L2 needs the per-vector t2 terms");
 #define FA_PQ_LAUNCH(M64_, FB_)                                                                            \

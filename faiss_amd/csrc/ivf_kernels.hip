@@ -436,6 +436,135 @@ void launch_ivfflat_append(const float* x, int64_t ldx, int n, int d, const int6
     HIP_CHECK(hipGetLastError());
 }
 
+// ---------------------------------------------------------------------------------
+// IVF scalar quantizer: encoder (bit-identical to faiss::ScalarQuantizer::compute_codes) and range training
+// ---------------------------------------------------------------------------------
+// impl/scalar_quantizer/quantizers.h:76-90 / 118-132: x -> [0, 1] with the trained range, clamped
+__device__ __forceinline__ float sq_unit(float x, float vmin, float vdiff) {
+    float xi = 0.f;
+    if (vdiff != 0.f) {
+        xi = __fdiv_rn(x - vmin, vdiff);
+        if (xi < 0.f) xi = 0.f;
+        if (xi > 1.f) xi = 1.f;
+    }
+    return xi;
+}
+// one thread per (vector, chunk of 16 components): the chunk's 16 / 8 / 12 / 32 code bytes
+__global__ void ivfsq_encode_kernel(int qtype, const float* __restrict__ x, int64_t ldx, int n, int d,
+                                    const int64_t* __restrict__ labels, const int64_t* __restrict__ dest,
+                                    const float* __restrict__ centroids, int64_t ldc, int by_residual,
+                                    const float* __restrict__ vmin, const float* __restrict__ vdiff,
+                                    uint8_t* __restrict__ arena, int ld, int nch) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = idx / nch;
+    const int c = (int)(idx - i * nch);
+    if (i >= n) return;
+    const int64_t dst = dest[i];
+    if (dst < 0) return;
+    const int64_t l = labels[i];
+    unsigned code[16]; // component codes (fp16: the half's bits)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int dim = 16 * c + e;
+        unsigned cv = 0;
+        if (dim < d) {
+            float v = x[i * ldx + dim];
+            if (by_residual) v = v - centroids[l * ldc + dim]; // Index::compute_residual
+            switch (qtype) {
+                case QT_8bit:
+                case QT_8bit_uniform:
+                    cv = (unsigned)(int)(255.f * sq_unit(v, vmin[dim], vdiff[dim])); // codecs.h:29-34
+                    break;
+                case QT_4bit:
+                case QT_4bit_uniform:
+                    cv = (unsigned)(int)((double)sq_unit(v, vmin[dim], vdiff[dim]) * 15.0); // codecs.h:48-53
+                    break;
+                case QT_6bit:
+                    cv = (unsigned)(int)((double)sq_unit(v, vmin[dim], vdiff[dim]) * 63.0); // codecs.h:67-72
+                    break;
+                case QT_fp16:
+                    cv = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)v); // encode_fp16: round to nearest even
+                    break;
+                default: // QT_8bit_direct (quantizers.h Quantizer8bitDirect): the value itself as a byte
+                    cv = (unsigned)(uint8_t)(int)v;
+                    break;
+            }
+        }
+        code[e] = cv;
+    }
+    uint8_t* row = arena + dst * (int64_t)ld;
+    if (qtype == QT_fp16) {
+        uint32_t* o = (uint32_t*)(row + 32 * c);
+#pragma unroll
+        for (int w = 0; w < 8; ++w) o[w] = code[2 * w] | (code[2 * w + 1] << 16);
+    } else if (qtype == QT_4bit || qtype == QT_4bit_uniform) {
+        // component i in byte i / 2, low nibble first (codecs.h:48-53)
+        uint32_t* o = (uint32_t*)(row + 8 * c);
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v |= (code[8 * w + e] & 15u) << (4 * e);
+            o[w] = v;
+        }
+    } else if (qtype == QT_6bit) {
+        // a little-endian stream of 6-bit fields: 4 components per 3 bytes (codecs.h:67-92)
+        uint32_t* o = (uint32_t*)(row + 12 * c);
+        unsigned long long lo = 0, hi = 0; // 96 bits
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int off = 6 * e;
+            const unsigned long long v = code[e] & 63u;
+            if (off < 64) {
+                lo |= v << off;
+                if (off > 58) hi |= v >> (64 - off);
+            } else {
+                hi |= v << (off - 64);
+            }
+        }
+        o[0] = (uint32_t)lo;
+        o[1] = (uint32_t)(lo >> 32);
+        o[2] = (uint32_t)hi;
+    } else {
+        uint32_t* o = (uint32_t*)(row + 16 * c);
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+            o[w] = (code[4 * w] & 255u) | ((code[4 * w + 1] & 255u) << 8) | ((code[4 * w + 2] & 255u) << 16) |
+                   ((code[4 * w + 3] & 255u) << 24);
+    }
+}
+void launch_ivfsq_encode_append(int qtype, const float* x, int64_t ldx, int n, int d, const int64_t* labels,
+                                const int64_t* dest, const float* centroids, int64_t ldc, bool by_residual,
+                                const float* vmin, const float* vdiff, uint8_t* arena, int ld, hipStream_t stream) {
+    if (n == 0) return;
+    const int nch = (int)div_up(d, 16);
+    hipLaunchKernelGGL(ivfsq_encode_kernel, dim3((unsigned)div_up((int64_t)n * nch, 256)), dim3(256), 0, stream, qtype, x,
+                       ldx, n, d, labels, dest, centroids, ldc, by_residual ? 1 : 0, vmin, vdiff, arena, ld, nch);
+    HIP_CHECK(hipGetLastError());
+}
+
+constexpr int SQ_MM_BLOCKS = 256;
+int ivfsq_minmax_blocks(int64_t n) {
+    return (int)std::min<int64_t>(SQ_MM_BLOCKS, std::max<int64_t>(n, 1));
+}
+__global__ void ivfsq_minmax_kernel(const float* __restrict__ x, int64_t ldx, int64_t n, int d, float* __restrict__ out) {
+    const int b = blockIdx.x, nb = gridDim.x;
+    for (int j = threadIdx.x; j < d; j += blockDim.x) {
+        float lo = INFINITY, hi = -INFINITY;
+        for (int64_t r = b; r < n; r += nb) {
+            const float v = x[r * ldx + j];
+            if (v < lo) lo = v; // (train_NonUniform's comparisons, impl/scalar_quantizer/training.cpp:345-356)
+            if (v > hi) hi = v;
+        }
+        out[((int64_t)b * 2 + 0) * d + j] = lo;
+        out[((int64_t)b * 2 + 1) * d + j] = hi;
+    }
+}
+void launch_ivfsq_minmax(const float* x, int64_t ldx, int64_t n, int d, float* out, hipStream_t stream) {
+    hipLaunchKernelGGL(ivfsq_minmax_kernel, dim3((unsigned)ivfsq_minmax_blocks(n)), dim3(256), 0, stream, x, ldx, n, d, out);
+    HIP_CHECK(hipGetLastError());
+}
+
 __global__ void ivfflat_rows_by_id_kernel(const float* __restrict__ arena, int64_t ldv, const int64_t* __restrict__ ids,
                                           const int64_t* __restrict__ list_start, const uint32_t* __restrict__ list_len,
                                           int d, int64_t i0, int64_t ni, float* __restrict__ out) {

@@ -262,7 +262,7 @@ size_t ivfpq_scan_lds_bytes(int M, int dpad);
 // ------------------------------------------------------------------ fused IVF search (ivf_fused.hip)
 struct IvfFusedParams {
     int metric;
-    int kind; // 0 = IVFFlat, 1 = IVFPQ
+    int kind; // 0 = IVFFlat, 1 = IVFPQ, 2 = IVF scalar quantizer
     int nq, nprobe, d, dpad;
     const float* xq; // [nq][ldq]
     int64_t ldq;
@@ -299,7 +299,21 @@ struct IvfFusedParams {
     const float* pq_t;          // [256][M][dsub] transposed codebook
     const uint8_t* arena_codes; // rotated 64-row block layout, see pq_code_offset
     const float* arena_t2;      // [arena rows] L2: |r^|^2 + 2 <centroid, r^> of every stored vector
+    // IVF scalar quantizer (kind 2): rows of sq_ld bytes in arena_codes; component i of a row decodes to
+    // fmaf(code_i, sq_s[i], sq_b[i]) (fp16 codes: the half itself); centroids / ldc as for IVFPQ
+    int sq_ct;             // SqCodeType
+    int sq_dsq;            // d rounded up to 16 (components per row as stored)
+    int sq_ld;             // bytes per arena row
+    int sq_by_residual;
+    const float* sq_s;     // [sq_dsq] scale per dimension (0 beyond d)
+    const float* sq_b;     // [sq_dsq] offset per dimension
 };
+// code types of the scalar quantizer as the scan kernel sees them (16 components per lane chunk)
+enum SqCodeType { SQ_U8 = 0, SQ_U4 = 1, SQ_U6 = 2, SQ_F16 = 3 };
+inline int sq_chunk_bytes(int ct) { return ct == SQ_U8 ? 16 : ct == SQ_U4 ? 8 : ct == SQ_U6 ? 12 : 32; }
+// table rows the fused scalar-quantizer scan keeps in LDS: the scale row, then one row per probe of a workgroup (L2
+// with residual encoding: the query residual changes with the list) or a single one
+inline int sq_table_rows(int metric, bool by_residual, int npc) { return 1 + ((metric == METRIC_L2 && by_residual) ? npc : 1); }
 // One workgroup per (query, probe group): table build + code scan + running top-k all in LDS.
 // Replaces PQCodeDistances + PQScanMultiPassNoPrecomputed + IVFUtilsSelect{1,2} (IVFPQ) and
 // IVFInterleaved scan + scan2 (IVFFlat) of the reference in a single launch.
@@ -399,6 +413,18 @@ void launch_ivfflat_append(const float* x, int64_t ldx, int n, int d, const int6
 void launch_ivfflat_rows_by_id(const float* arena_vecs, int64_t ldv, const int64_t* arena_ids, const int64_t* list_start,
                                const uint32_t* list_len, int nlist, int d, int64_t i0, int64_t ni, float* out,
                                hipStream_t stream);
+// ---- IVF scalar quantizer (faiss/impl/ScalarQuantizer.h, faiss/gpu/impl/GpuScalarQuantizer.cuh)
+// qtype values of faiss::ScalarQuantizer::QuantizerType that this backend stores (ScalarQuantizer.h:27-34)
+enum SqQuantizerType { QT_8bit = 0, QT_4bit = 1, QT_8bit_uniform = 2, QT_4bit_uniform = 3, QT_fp16 = 4, QT_8bit_direct = 5, QT_6bit = 6 };
+// encode n staged vectors (x: [n][ldx] fp32, residual w.r.t. centroids[labels[i]] when by_residual) exactly as
+// ScalarQuantizer::compute_codes does (impl/scalar_quantizer/quantizers.h:60-150, codecs.h:24-110) and write them to
+// arena rows dest[i] (row stride ld bytes, zero padded).  vmin / vdiff: [d] (uniform types: replicated).
+void launch_ivfsq_encode_append(int qtype, const float* x, int64_t ldx, int n, int d, const int64_t* labels,
+                                const int64_t* dest, const float* centroids, int64_t ldc, bool by_residual,
+                                const float* vmin, const float* vdiff, uint8_t* arena, int ld, hipStream_t stream);
+// per-dimension minimum and maximum of x [n][ldx] over column blocks: out [nblocks][2][d] (min row, max row)
+int ivfsq_minmax_blocks(int64_t n);
+void launch_ivfsq_minmax(const float* x, int64_t ldx, int64_t n, int d, float* out, hipStream_t stream);
 // PQ-encode the residuals and write the code bytes into the rotated block layout
 void launch_ivfpq_encode_append(const float* x, int64_t ldx, int n, int d, const int64_t* labels,
                                 const int64_t* dest, const float* centroids, int64_t ldc, int M,

@@ -75,6 +75,24 @@ int faiss_amd_GpuIndexIVFFlat_new(FaissAmdIndex** p_index, FaissAmdGpuResources*
                                   FaissAmdMetricType metric);
 int faiss_amd_GpuIndexIVFPQ_new(FaissAmdIndex** p_index, FaissAmdGpuResources* res, int d, int nlist,
                                 int M, int nbits, FaissAmdMetricType metric);
+/* faiss/gpu/GpuIndexIVFScalarQuantizer.h:44-52  GpuIndexIVFScalarQuantizer(resources, dims, nlist, qtype, metric,
+ * encodeResidual, config).  qtype: faiss::ScalarQuantizer::QuantizerType values (faiss/impl/ScalarQuantizer.h:27-34) of
+ * the types the reference GPU index supports (gpu/impl/GpuScalarQuantizer.cuh:20-33): QT_8bit 0, QT_4bit 1,
+ * QT_8bit_uniform 2, QT_4bit_uniform 3, QT_fp16 4, QT_8bit_direct 5, QT_6bit 6.  train() learns the coarse centroids and
+ * (RS_minmax, the reference default) the value range of the residuals; codes are byte-identical to
+ * faiss::ScalarQuantizer::compute_codes with the same `trained`. */
+int faiss_amd_GpuIndexIVFScalarQuantizer_new(FaissAmdIndex** p_index, FaissAmdGpuResources* res, int d, int nlist,
+                                             int qtype, FaissAmdMetricType metric, int encode_residual);
+/* index->sq.qtype, index->by_residual, index->code_size, index->sq.trained.size() (each pointer nullable) */
+int faiss_amd_IndexIVFSQ_info(const FaissAmdIndex* index, int* qtype, int* by_residual, size_t* code_size,
+                              size_t* trained_size);
+/* index->sq.trained (faiss/impl/ScalarQuantizer.h:72-73): {vmin, vdiff} for the uniform types, vmin[d] then vdiff[d]
+ * otherwise -- the array copyFrom / copyTo move (gpu/GpuIndexIVFScalarQuantizer.cu copyFrom: sq = index->sq) */
+int faiss_amd_IndexIVFSQ_get_trained(const FaissAmdIndex* index, float* out);
+int faiss_amd_IndexIVFSQ_copy_trained(FaissAmdIndex* index, const float* trained, size_t n);
+/* index->sq.rangestat / rangestat_arg (ScalarQuantizer.h:60-70) used by train(); only RS_minmax (0) trains on the
+ * device -- other statistics: train the CPU index and copy `trained` */
+int faiss_amd_IndexIVFSQ_set_rangestat(FaissAmdIndex* index, int rangestat, float rangestat_arg);
 /* ---- the same constructors with the reference's config structs (faiss/gpu/GpuIndex.h:30-47 GpuIndexConfig,
  *      GpuIndexFlat.h:24-40 GpuIndexFlatConfig, GpuIndexIVF.h:24-38 GpuIndexIVFConfig, GpuIndexIVFPQ.h:25-49
  *      GpuIndexIVFPQConfig), field for field as plain ints.  What each field means here:

@@ -26,6 +26,7 @@
 #include <faiss/IndexIVFFlat.h>
 #include <faiss/IndexIVFPQ.h>
 #include <faiss/IndexReplicas.h>
+#include <faiss/IndexScalarQuantizer.h>
 #include <faiss/IndexShards.h>
 #include <faiss/IndexShardsIVF.h>
 #include <faiss/impl/FaissAssert.h>
@@ -383,6 +384,64 @@ struct AmdIndexIVFPQ : AmdIndexIVF {
     }
 };
 
+/// faiss::gpu::GpuIndexIVFScalarQuantizer counterpart (faiss/gpu/GpuIndexIVFScalarQuantizer.h:27-131)
+struct AmdIndexIVFScalarQuantizer : AmdIndexIVF {
+    faiss::ScalarQuantizer sq; ///< like the reference: the quantizer parameters, mirrored on this side
+    bool by_residual;
+    static FaissAmdIndex* make(AmdGpuResources* res, int d, size_t nlist, int qtype, MetricType metric, bool by_residual) {
+        FaissAmdIndex* handle = nullptr;
+        amd_check(faiss_amd_GpuIndexIVFScalarQuantizer_new(&handle, res->h, d, (int)nlist, qtype, (FaissAmdMetricType)metric,
+                                                           by_residual ? 1 : 0));
+        return handle;
+    }
+    AmdIndexIVFScalarQuantizer(AmdGpuResources* res, int d, size_t nlist, faiss::ScalarQuantizer::QuantizerType qtype,
+                               MetricType metric = METRIC_L2, bool encodeResidual = true)
+            : AmdIndexIVF(make(res, d, nlist, (int)qtype, metric, encodeResidual), nlist),
+              sq(d, qtype),
+              by_residual(encodeResidual) {}
+    /// GpuIndexIVFScalarQuantizer(resources, const IndexIVFScalarQuantizer*) (GpuIndexIVFScalarQuantizer.cu:27-43)
+    AmdIndexIVFScalarQuantizer(AmdGpuResources* res, const faiss::IndexIVFScalarQuantizer* index)
+            : AmdIndexIVF(make(res, index->d, index->nlist, (int)index->sq.qtype, index->metric_type, index->by_residual),
+                          index->nlist),
+              sq(index->sq),
+              by_residual(index->by_residual) {
+        copyFrom(index);
+    }
+    /// GpuIndexIVFScalarQuantizer.cu:96-140
+    void copyFrom(const faiss::IndexIVFScalarQuantizer* index) {
+        FAISS_THROW_IF_NOT(index->sq.qtype == sq.qtype && index->by_residual == by_residual);
+        reset();
+        nprobe = index->nprobe;
+        sq = index->sq;
+        if (!index->is_trained) return;
+        copy_quantizer_from(index);
+        if (!sq.trained.empty()) amd_check(faiss_amd_IndexIVFSQ_copy_trained(h, sq.trained.data(), sq.trained.size()));
+        is_trained = faiss_amd_Index_is_trained(h) != 0;
+        copy_lists_from(index);
+    }
+    /// GpuIndexIVFScalarQuantizer.cu:142-160
+    void copyTo(faiss::IndexIVFScalarQuantizer* index) const {
+        size_t nt = 0;
+        amd_check(faiss_amd_IndexIVFSQ_info(h, nullptr, nullptr, nullptr, &nt));
+        faiss::ScalarQuantizer q(d, sq.qtype);
+        q.rangestat = sq.rangestat;
+        q.rangestat_arg = sq.rangestat_arg;
+        q.trained.resize(nt);
+        if (nt) amd_check(faiss_amd_IndexIVFSQ_get_trained(h, q.trained.data()));
+        index->sq = q;
+        index->code_size = q.code_size;
+        index->by_residual = by_residual;
+        copy_to_ivf(index);
+    }
+    void train(idx_t n, const float* x) override {
+        AmdIndexIVF::train(n, x);
+        size_t nt = 0;
+        amd_check(faiss_amd_IndexIVFSQ_info(h, nullptr, nullptr, nullptr, &nt));
+        sq.trained.resize(nt);
+        if (nt) amd_check(faiss_amd_IndexIVFSQ_get_trained(h, sq.trained.data()));
+    }
+};
+
 // ------------------------------------------------------------------ cloners (faiss/gpu/GpuCloner.cpp)
 struct AmdClonerOptions {
     bool shard = false;               ///< GpuMultipleClonerOptions::shard: shards instead of replicas
@@ -398,6 +457,8 @@ inline faiss::Index* index_cpu_to_gpu(AmdGpuResources* res, const faiss::Index* 
         return new AmdIndexIVFFlat(res, ivf);
     } else if (auto ipq = dynamic_cast<const faiss::IndexIVFPQ*>(index)) {
         return new AmdIndexIVFPQ(res, ipq);
+    } else if (auto isq = dynamic_cast<const faiss::IndexIVFScalarQuantizer*>(index)) {
+        return new AmdIndexIVFScalarQuantizer(res, isq);
     }
     FAISS_THROW_MSG("This index type is not implemented on the MI355X backend.");
 }
@@ -419,6 +480,12 @@ inline faiss::Index* index_gpu_to_cpu(const faiss::Index* index) {
                                           ipq->nbits, ipq->metric_type);
         res->own_fields = true;
         ipq->copyTo(res);
+        return res;
+    } else if (auto isq = dynamic_cast<const AmdIndexIVFScalarQuantizer*>(index)) {
+        auto* res = new faiss::IndexIVFScalarQuantizer(new faiss::IndexFlat(isq->d, isq->metric_type), isq->d, isq->nlist,
+                                                       isq->sq.qtype, isq->metric_type, isq->by_residual);
+        res->own_fields = true;
+        isq->copyTo(res);
         return res;
     } else if (auto ipr = dynamic_cast<const faiss::IndexReplicas*>(index)) {
         FAISS_THROW_IF_NOT(ipr->count() > 0);
@@ -457,8 +524,10 @@ inline faiss::Index* index_cpu_to_gpu_multiple(const std::vector<AmdGpuResources
     auto index_ivfpq = dynamic_cast<const faiss::IndexIVFPQ*>(index);
     auto index_ivfflat = dynamic_cast<const faiss::IndexIVFFlat*>(index);
     auto index_flat = dynamic_cast<const faiss::IndexFlat*>(index);
-    FAISS_THROW_IF_NOT_MSG(index_ivfpq || index_ivfflat || index_flat,
-                           "multi-device cloning is implemented for IndexFlat, IndexIVFFlat and IndexIVFPQ");
+    auto index_ivfsq = dynamic_cast<const faiss::IndexIVFScalarQuantizer*>(index);
+    FAISS_THROW_IF_NOT_MSG(index_ivfpq || index_ivfflat || index_flat || index_ivfsq,
+                           "multi-device cloning is implemented for IndexFlat, IndexIVFFlat, IndexIVFPQ and "
+                           "IndexIVFScalarQuantizer");
     if (!opt.shard) {
         auto* rep = new faiss::IndexReplicas();
         for (auto* r : res) rep->addIndex(index_cpu_to_gpu(r, index));
@@ -477,6 +546,12 @@ inline faiss::Index* index_cpu_to_gpu_multiple(const std::vector<AmdGpuResources
                 p->metric_type = index->metric_type;
                 p->pq = index_ivfpq->pq;
                 p->use_precomputed_table = 0;
+                idx2.reset(p);
+            } else if (index_ivfsq) {
+                auto* p = new faiss::IndexIVFScalarQuantizer(const_cast<faiss::Index*>(index_ivf->quantizer), index->d,
+                                                             index_ivf->nlist, index_ivfsq->sq.qtype, index->metric_type,
+                                                             index_ivfsq->by_residual);
+                p->sq = index_ivfsq->sq;
                 idx2.reset(p);
             } else {
                 idx2.reset(new faiss::IndexIVFFlat(const_cast<faiss::Index*>(index_ivf->quantizer), index->d,

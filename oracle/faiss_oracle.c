@@ -20,6 +20,8 @@
  *   orc_pq_encode        ProductQuantizer::compute_code (faiss/impl/ProductQuantizer.cpp): per
  *                        sub-vector nearest centroid, first minimum wins
  *   orc_ivf_assign       IndexIVF::add_core coarse assignment (faiss/IndexIVF.cpp:194-260)
+ *   orc_sq_encode / orc_ivfsq_search  ScalarQuantizer::compute_codes and the IVFSQ scanners
+ *                        (faiss/impl/scalar_quantizer/quantizers.h, codecs.h, scanners.h:34-140)
  *   orc_merge_shards     merge_knn_results (faiss/utils/Heap.cpp:166-240)
  *   orc_kmeans_objective Clustering objective (faiss/Clustering.cpp:268-357: sum of assignment distances)
  *
@@ -421,6 +423,283 @@ int orc_ivf_search(int kind, int metric, int d, int nlist, const float* centroid
     free(cD);
     free(cI);
     free(list_start);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ IVF scalar quantizer
+ * faiss::IndexIVFScalarQuantizer (faiss/IndexScalarQuantizer.cpp:122-330) over faiss::ScalarQuantizer
+ * (faiss/impl/ScalarQuantizer.h:25-120).  qtype = ScalarQuantizer::QuantizerType: QT_8bit 0, QT_4bit 1,
+ * QT_8bit_uniform 2, QT_4bit_uniform 3, QT_fp16 4, QT_8bit_direct 5, QT_6bit 6.
+ * vmin / vdiff: [d] (the uniform types replicate their pair), i.e. ScalarQuantizer::trained unpacked. */
+static float orc_half_to_float(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h >> 15) << 31;
+    const int e = (h >> 10) & 31;
+    const uint32_t m = h & 1023u;
+    union {
+        float f;
+        uint32_t u;
+    } v;
+    if (e == 0) {
+        v.f = (float)m * (1.0f / 16777216.0f); /* subnormal: m * 2^-24, exact */
+        v.u |= sign;
+    } else if (e == 31) {
+        v.u = sign | 0x7f800000u | (m << 13);
+    } else {
+        v.u = sign | ((uint32_t)(e + 112) << 23) | (m << 13);
+    }
+    return v.f;
+}
+/* round to nearest even, like _cvtss_sh(x, 0) behind faiss::encode_fp16 (faiss/utils/fp16-fp16c.h) */
+static uint16_t orc_float_to_half(float f) {
+    union {
+        float f;
+        uint32_t u;
+    } v;
+    v.f = f;
+    const uint32_t sign = (v.u >> 16) & 0x8000u;
+    const uint32_t a = v.u & 0x7fffffffu;
+    if (a > 0x7f800000u) return (uint16_t)(sign | 0x7e00u | ((a >> 13) & 0x3ffu)); /* NaN */
+    if (a >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u); /* >= 65520 rounds to infinity (and infinity) */
+    if (a < 0x33000001u) return (uint16_t)sign;             /* <= 2^-25: rounds to zero */
+    const int e = (int)(a >> 23) - 127;
+    uint32_t m = (a & 0x7fffffu) | 0x800000u; /* 24-bit significand */
+    int shift = e < -14 ? 13 + (-14 - e) : 13; /* bits dropped */
+    uint32_t keep = m >> shift;
+    const uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (keep & 1u))) keep++;
+    if (e < -14) return (uint16_t)(sign | keep); /* subnormal (a carry into the exponent field is the right answer) */
+    return (uint16_t)(sign | (((uint32_t)(e + 15) << 10) + (keep - 0x400u)));
+}
+static size_t orc_sq_code_size(int qtype, int d) {
+    switch (qtype) {
+        case 1:
+        case 3:
+            return ((size_t)d + 1) / 2;
+        case 4:
+            return (size_t)d * 2;
+        case 6:
+            return ((size_t)d * 6 + 7) / 8;
+        default:
+            return (size_t)d;
+    }
+}
+/* impl/scalar_quantizer/quantizers.h:76-90 / 118-132 */
+static float orc_sq_unit(float x, float vmin, float vdiff) {
+    float xi = 0.f;
+    if (vdiff != 0.f) {
+        xi = (x - vmin) / vdiff;
+        if (xi < 0.f) xi = 0.f;
+        if (xi > 1.f) xi = 1.f;
+    }
+    return xi;
+}
+/* ScalarQuantizer::compute_codes on x (or, by_residual, on x - centroids[labels[i]]: IndexIVFScalarQuantizer::
+ * encode_vectors, IndexScalarQuantizer.cpp:163-206); codes: [n][code_size], zeroed first like the reference */
+int orc_sq_encode(int qtype, int d, idx_t n, const float* x, const idx_t* labels, const float* centroids, int by_residual,
+                  const float* vmin, const float* vdiff, uint8_t* codes) {
+    const size_t cs = orc_sq_code_size(qtype, d);
+    memset(codes, 0, cs * (size_t)n);
+    for (idx_t i = 0; i < n; i++) {
+        uint8_t* code = codes + (size_t)i * cs;
+        for (int j = 0; j < d; j++) {
+            float v = x[(size_t)i * d + j];
+            if (by_residual) v = v - centroids[(size_t)labels[i] * d + j];
+            switch (qtype) {
+                case 0:
+                case 2: /* codecs.h:29-34 */
+                    code[j] = (uint8_t)(int)(255 * orc_sq_unit(v, vmin[j], vdiff[j]));
+                    break;
+                case 1:
+                case 3: /* codecs.h:48-53 */
+                    code[j / 2] |= (uint8_t)((int)(orc_sq_unit(v, vmin[j], vdiff[j]) * 15.0) << ((j & 1) << 2));
+                    break;
+                case 6: { /* codecs.h:67-92 */
+                    const int bits = (int)(orc_sq_unit(v, vmin[j], vdiff[j]) * 63.0);
+                    uint8_t* c3 = code + (j >> 2) * 3;
+                    switch (j & 3) {
+                        case 0:
+                            c3[0] |= (uint8_t)bits;
+                            break;
+                        case 1:
+                            c3[0] |= (uint8_t)(bits << 6);
+                            c3[1] |= (uint8_t)(bits >> 2);
+                            break;
+                        case 2:
+                            c3[1] |= (uint8_t)(bits << 4);
+                            c3[2] |= (uint8_t)(bits >> 4);
+                            break;
+                        default:
+                            c3[2] |= (uint8_t)(bits << 2);
+                            break;
+                    }
+                    break;
+                }
+                case 4: {
+                    const uint16_t h = orc_float_to_half(v);
+                    code[2 * j] = (uint8_t)(h & 255u);
+                    code[2 * j + 1] = (uint8_t)(h >> 8);
+                    break;
+                }
+                default: /* QT_8bit_direct */
+                    code[j] = (uint8_t)(int)v;
+                    break;
+            }
+        }
+    }
+    return 0;
+}
+/* component j of a code, as the integer (or half) it stores */
+static float orc_sq_component(int qtype, const uint8_t* code, int j) {
+    switch (qtype) {
+        case 1:
+        case 3:
+            return (float)((code[j / 2] >> ((j & 1) << 2)) & 0xf);
+        case 6: {
+            const uint8_t* c3 = code + (j >> 2) * 3;
+            const uint32_t v = (uint32_t)c3[0] | ((uint32_t)c3[1] << 8) | ((uint32_t)c3[2] << 16);
+            return (float)((v >> (6 * (j & 3))) & 63u);
+        }
+        case 4:
+            return orc_half_to_float((uint16_t)(code[2 * j] | ((uint16_t)code[2 * j + 1] << 8)));
+        default:
+            return (float)code[j];
+    }
+}
+/* decoder tables shared with the GPU scan (faiss_amd/csrc/index.cpp GpuIndexIVFScalarQuantizer::upload_tables_):
+ * x^_j = fmaf(code_j, s_j, b_j), s = vdiff / levels, b = vmin + s / 2, which is the reference's reconstruction
+ * vmin + (code + 0.5) / levels * vdiff (quantizers.h:92-150, codecs.h:36-58) up to the rounding of s and b */
+static void orc_sq_tables(int qtype, int d, const float* vmin, const float* vdiff, float* s, float* b) {
+    const float levels = (qtype == 0 || qtype == 2) ? 255.f : (qtype == 1 || qtype == 3) ? 15.f : qtype == 6 ? 63.f : 0.f;
+    for (int j = 0; j < d; j++) {
+        if (levels > 0.f) {
+            s[j] = vdiff[j] / levels;
+            b[j] = vmin[j] + 0.5f * s[j];
+        } else {
+            s[j] = qtype == 5 ? 1.f : 0.f;
+            b[j] = 0.f;
+        }
+    }
+}
+/* ScalarQuantizer::decode (reconstruction of the stored value, without the centroid) in the GPU's arithmetic */
+int orc_sq_decode(int qtype, int d, idx_t n, const uint8_t* codes, const float* vmin, const float* vdiff, float* out) {
+    const size_t cs = orc_sq_code_size(qtype, d);
+    float* s = (float*)malloc(sizeof(float) * (size_t)d * 2);
+    float* b = s + d;
+    orc_sq_tables(qtype, d, vmin, vdiff, s, b);
+    for (idx_t i = 0; i < n; i++)
+        for (int j = 0; j < d; j++) {
+            const float c = orc_sq_component(qtype, codes + (size_t)i * cs, j);
+            out[(size_t)i * d + j] = qtype == 4 ? c : fmaf(c, s[j], b[j]);
+        }
+    free(s);
+    return 0;
+}
+/* Search: IVFSQScannerL2 / IVFSQScannerIP (faiss/impl/scalar_quantizer/scanners.h:34-140).  L2: distance between the
+ * query (by_residual: minus the list centroid) and the reconstruction; IP: <q, reconstruction> (+ the coarse inner
+ * product with by_residual).  Arithmetic and summation order of the gfx950 scan (ivf_fused.hip ivfsq_fused_kernel):
+ * eight lanes share a row, lane ln owns the 16-component chunks ln, ln + 8, ...:
+ *   L2: a_j = (q_j [- centroid_j]) - b_j;  tt = fmaf(-code_j, s_j, a_j)  (fp16: a_j - half_j);  acc = fmaf(tt, tt, acc)
+ *   IP: w_j = q_j * s_j;  acc = fmaf(w_j, code_j, acc)  (fp16: w_j = q_j);  dis = (sum + <q, b>) + coarse
+ * with <q, b> summed in the same lane / tree order. */
+static float orc_sq_tree(const float* part) {
+    return ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
+}
+int orc_ivfsq_search(int qtype, int by_residual, int metric, int d, int nlist, const float* centroids,
+                     const uint32_t* list_sizes, const uint8_t* codes, const idx_t* ids, const float* vmin,
+                     const float* vdiff, idx_t nq, const float* xq, int nprobe, int k, float* D, idx_t* I) {
+    if (k < 1 || nprobe < 1) return -1;
+    if (nprobe > nlist) nprobe = nlist;
+    const size_t cs = orc_sq_code_size(qtype, d);
+    const int nch = (d + 15) / 16;
+    idx_t* list_start = (idx_t*)malloc(sizeof(idx_t) * (size_t)(nlist + 1));
+    list_start[0] = 0;
+    for (int l = 0; l < nlist; l++) list_start[l + 1] = list_start[l] + list_sizes[l];
+    float* cD = (float*)malloc(sizeof(float) * (size_t)nq * nprobe);
+    idx_t* cI = (idx_t*)malloc(sizeof(idx_t) * (size_t)nq * nprobe);
+    orc_flat_search(metric, d, nlist, centroids, nq, xq, nprobe, cD, cI);
+    float* s = (float*)malloc(sizeof(float) * (size_t)d * 2);
+    float* b = s + d;
+    orc_sq_tables(qtype, d, vmin, vdiff, s, b);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (idx_t q = 0; q < nq; q++) {
+        const float* x = xq + (size_t)q * d;
+        size_t ncand = 0;
+        for (int p = 0; p < nprobe; p++) {
+            idx_t l = cI[(size_t)q * nprobe + p];
+            if (l >= 0) ncand += list_sizes[l];
+        }
+        idx_t* pos2id = (idx_t*)malloc(sizeof(idx_t) * (ncand ? ncand : 1));
+        cand_t* st = (cand_t*)malloc(sizeof(cand_t) * (size_t)k);
+        float* a = (float*)malloc(sizeof(float) * (size_t)d);
+        topk_t t;
+        topk_init(&t, st, k, metric);
+        float qb = 0.f;
+        if (metric != ORC_METRIC_L2) {
+            float part[8];
+            for (int ln = 0; ln < 8; ln++) {
+                float acc = 0.f;
+                if (qtype != 4)
+                    for (int c = ln; c < nch; c += 8)
+                        for (int e = 0; e < 16; e++) {
+                            const int j = 16 * c + e;
+                            if (j < d) acc = fmaf(x[j], b[j], acc);
+                        }
+                part[ln] = acc;
+            }
+            qb = orc_sq_tree(part);
+        }
+        idx_t pos = 0;
+        for (int p = 0; p < nprobe; p++) {
+            idx_t l = cI[(size_t)q * nprobe + p];
+            if (l < 0) continue;
+            const uint8_t* lc = codes + (size_t)list_start[l] * cs;
+            const idx_t* lid = ids + list_start[l];
+            const uint32_t len = list_sizes[l];
+            const float* cen = centroids + (size_t)l * d;
+            for (int j = 0; j < d; j++) {
+                if (metric == ORC_METRIC_L2) {
+                    float r = by_residual ? x[j] - cen[j] : x[j];
+                    a[j] = qtype == 4 ? r : r - b[j];
+                } else {
+                    a[j] = qtype == 4 ? x[j] : x[j] * s[j];
+                }
+            }
+            const float coarse = (metric != ORC_METRIC_L2 && by_residual) ? cD[(size_t)q * nprobe + p] : 0.f;
+            for (uint32_t i = 0; i < len; i++) {
+                const uint8_t* code = lc + (size_t)i * cs;
+                float part[8];
+                for (int ln = 0; ln < 8; ln++) {
+                    float acc = 0.f;
+                    for (int c = ln; c < nch; c += 8)
+                        for (int e = 0; e < 16; e++) {
+                            const int j = 16 * c + e;
+                            if (j >= d) break;
+                            const float cf = orc_sq_component(qtype, code, j);
+                            if (metric == ORC_METRIC_L2) {
+                                const float tt = qtype == 4 ? a[j] - cf : fmaf(-cf, s[j], a[j]);
+                                acc = fmaf(tt, tt, acc);
+                            } else {
+                                acc = fmaf(a[j], cf, acc);
+                            }
+                        }
+                    part[ln] = acc;
+                }
+                float dis = orc_sq_tree(part);
+                if (metric != ORC_METRIC_L2) dis = (dis + qb) + coarse;
+                pos2id[pos] = lid[i];
+                topk_push(&t, dis, pos);
+                pos++;
+            }
+        }
+        ivf_finish(metric, t.a, t.n, k, pos2id, D + (size_t)q * k, I + (size_t)q * k);
+        free(pos2id);
+        free(st);
+        free(a);
+    }
+    free(cD);
+    free(cI);
+    free(list_start);
+    free(s);
     return 0;
 }
 

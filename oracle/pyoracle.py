@@ -134,6 +134,60 @@ class Oracle:
         assert rc == 0
         return codes
 
+    # ---- IVF scalar quantizer (faiss/impl/ScalarQuantizer.h qtype values; vmin / vdiff are [d], see sq_unpack)
+    @staticmethod
+    def sq_code_size(qtype, d):
+        return {1: (d + 1) // 2, 3: (d + 1) // 2, 4: 2 * d, 6: (6 * d + 7) // 8}.get(qtype, d)
+
+    @staticmethod
+    def sq_unpack(qtype, d, trained):
+        """ScalarQuantizer::trained -> (vmin[d], vdiff[d]); the types without a trained range give zeros"""
+        t = np.asarray(trained, dtype=np.float32).reshape(-1)
+        if qtype in (2, 3):
+            return np.full(d, t[0], np.float32), np.full(d, t[1], np.float32)
+        if qtype in (0, 1, 6):
+            return t[:d].copy(), t[d:2 * d].copy()
+        return np.zeros(d, np.float32), np.zeros(d, np.float32)
+
+    @classmethod
+    def sq_encode(cls, qtype, x, vmin, vdiff, labels=None, centroids=None):
+        x = _f32(x)
+        n, d = x.shape
+        by_res = centroids is not None
+        lab = np.ascontiguousarray(labels, dtype=np.int64) if by_res else None
+        cen = _f32(centroids) if by_res else None
+        codes = np.empty((n, cls.sq_code_size(qtype, d)), dtype=np.uint8)
+        rc = cls.lib().orc_sq_encode(ctypes.c_int(qtype), ctypes.c_int(d), ctypes.c_int64(n), _p(x), _p(lab), _p(cen),
+                                     ctypes.c_int(int(by_res)), _p(_f32(vmin)), _p(_f32(vdiff)), _p(codes))
+        assert rc == 0
+        return codes
+
+    @classmethod
+    def sq_decode(cls, qtype, d, codes, vmin, vdiff):
+        codes = np.ascontiguousarray(codes, dtype=np.uint8).reshape(-1, cls.sq_code_size(qtype, d))
+        out = np.empty((codes.shape[0], d), dtype=np.float32)
+        rc = cls.lib().orc_sq_decode(ctypes.c_int(qtype), ctypes.c_int(d), ctypes.c_int64(codes.shape[0]), _p(codes),
+                                     _p(_f32(vmin)), _p(_f32(vdiff)), _p(out))
+        assert rc == 0
+        return out
+
+    @classmethod
+    def ivfsq_search(cls, qtype, by_residual, metric, centroids, list_sizes, codes, ids, vmin, vdiff, xq, nprobe, k):
+        centroids, xq = _f32(centroids), _f32(xq)
+        nlist, d = centroids.shape
+        ls = np.ascontiguousarray(list_sizes, dtype=np.uint32)
+        codes = np.ascontiguousarray(codes).view(np.uint8).reshape(-1)
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        nq = xq.shape[0]
+        D = np.empty((nq, k), dtype=np.float32)
+        I = np.empty((nq, k), dtype=np.int64)
+        rc = cls.lib().orc_ivfsq_search(ctypes.c_int(qtype), ctypes.c_int(int(by_residual)), ctypes.c_int(metric),
+                                        ctypes.c_int(d), ctypes.c_int(nlist), _p(centroids), _p(ls), _p(codes), _p(ids),
+                                        _p(_f32(vmin)), _p(_f32(vdiff)), ctypes.c_int64(nq), _p(xq), ctypes.c_int(nprobe),
+                                        ctypes.c_int(k), _p(D), _p(I))
+        assert rc == 0
+        return D, I
+
     @classmethod
     def merge_shards(cls, metric, all_D, all_I, base=None):
         all_D = np.ascontiguousarray(all_D, dtype=np.float32)
@@ -302,6 +356,31 @@ class RefIndex:
         self._ck(self.lib.ref_ivfpq_get_pq_centroids(ctypes.c_void_p(self.h), _p(out)))
         return out
 
+    def sq_info(self):
+        qt, br = ctypes.c_int(0), ctypes.c_int(0)
+        cs, ts = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        self._ck(self.lib.ref_ivfsq_info(ctypes.c_void_p(self.h), ctypes.byref(qt), ctypes.byref(br), ctypes.byref(cs),
+                                         ctypes.byref(ts)))
+        return dict(qtype=qt.value, by_residual=bool(br.value), code_size=cs.value, trained_size=ts.value)
+
+    def sq_trained(self):
+        out = np.empty(self.sq_info()["trained_size"], dtype=np.float32)
+        if out.size:
+            self._ck(self.lib.ref_ivfsq_get_trained(ctypes.c_void_p(self.h), _p(out)))
+        return out
+
+    def set_sq_trained(self, centroids, trained):
+        """install coarse centroids [nlist, d] and ScalarQuantizer::trained into an untrained IndexIVFScalarQuantizer"""
+        c = _f32(centroids)
+        t = np.ascontiguousarray(trained, dtype=np.float32).reshape(-1)
+        self._ck(self.lib.ref_ivfsq_set_trained(ctypes.c_void_p(self.h), _p(c), _p(t), ctypes.c_size_t(t.size)))
+
+    def sq_decode(self, codes):
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        out = np.empty((codes.shape[0], self.d), dtype=np.float32)
+        self._ck(self.lib.ref_ivfsq_decode(ctypes.c_void_p(self.h), ctypes.c_int64(codes.shape[0]), _p(codes), _p(out)))
+        return out
+
     def set_precomputed_table(self, use):
         self._ck(self.lib.ref_ivfpq_set_precomputed_table(ctypes.c_void_p(self.h), ctypes.c_int(use)))
 
@@ -347,6 +426,16 @@ class Ref:
     @classmethod
     def index_factory(cls, d, desc, metric=METRIC_L2):
         h = cls.lib().ref_index_factory(d, desc.encode(), metric)
+        if not h:
+            raise RuntimeError("reference error: " + cls.lib().ref_last_error().decode())
+        return RefIndex(cls.lib(), h, d)
+
+    @classmethod
+    def ivfsq(cls, d, nlist, qtype, metric=METRIC_L2, by_residual=True):
+        """faiss::IndexIVFScalarQuantizer(new IndexFlat(d, metric), d, nlist, qtype, metric, by_residual)"""
+        cls.lib().ref_ivfsq_new.restype = ctypes.c_void_p
+        h = cls.lib().ref_ivfsq_new(ctypes.c_int(d), ctypes.c_int(nlist), ctypes.c_int(qtype), ctypes.c_int(metric),
+                                    ctypes.c_int(int(by_residual)))
         if not h:
             raise RuntimeError("reference error: " + cls.lib().ref_last_error().decode())
         return RefIndex(cls.lib(), h, d)

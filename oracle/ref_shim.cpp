@@ -16,6 +16,7 @@
 #include <faiss/IndexIVF.h>
 #include <faiss/IndexIVFFlat.h>
 #include <faiss/IndexIVFPQ.h>
+#include <faiss/IndexScalarQuantizer.h>
 #include <faiss/IndexShards.h>
 #include <faiss/index_factory.h>
 #include <faiss/impl/FaissException.h>
@@ -180,6 +181,53 @@ int ref_ivfpq_set_trained(void* p, const float* centroids, const float* pq_centr
     i->is_trained = true;
     i->use_precomputed_table = 0; // automatic choice, as after train()
     i->precompute_table();
+    SHIM_CATCH
+}
+
+// ---- IndexIVFScalarQuantizer
+void* ref_ivfsq_new(int d, int nlist, int qtype, int metric, int by_residual) {
+    try {
+        auto* q = new faiss::IndexFlat(d, (faiss::MetricType)metric);
+        auto* i = new faiss::IndexIVFScalarQuantizer(q, d, nlist, (faiss::ScalarQuantizer::QuantizerType)qtype,
+                                                     (faiss::MetricType)metric, by_residual != 0);
+        i->own_fields = true;
+        return i;
+    } catch (std::exception& e) {
+        g_err = e.what();
+        return nullptr;
+    }
+}
+int ref_ivfsq_info(void* p, int* qtype, int* by_residual, size_t* code_size, size_t* trained_size) {
+    SHIM_TRY auto* i = dynamic_cast<faiss::IndexIVFScalarQuantizer*>((faiss::Index*)p);
+    FAISS_THROW_IF_NOT_MSG(i, "not an IndexIVFScalarQuantizer");
+    *qtype = (int)i->sq.qtype;
+    *by_residual = i->by_residual ? 1 : 0;
+    *code_size = i->code_size;
+    *trained_size = i->sq.trained.size();
+    SHIM_CATCH
+}
+int ref_ivfsq_get_trained(void* p, float* out) {
+    SHIM_TRY auto* i = dynamic_cast<faiss::IndexIVFScalarQuantizer*>((faiss::Index*)p);
+    FAISS_THROW_IF_NOT_MSG(i, "not an IndexIVFScalarQuantizer");
+    memcpy(out, i->sq.trained.data(), sizeof(float) * i->sq.trained.size());
+    SHIM_CATCH
+}
+// install a trained state (coarse centroids nlist x d + ScalarQuantizer::trained), like copyTo of the GPU index
+int ref_ivfsq_set_trained(void* p, const float* centroids, const float* trained, size_t n) {
+    SHIM_TRY auto* i = dynamic_cast<faiss::IndexIVFScalarQuantizer*>((faiss::Index*)p);
+    FAISS_THROW_IF_NOT_MSG(i, "not an IndexIVFScalarQuantizer");
+    i->quantizer->reset();
+    i->quantizer->add(i->nlist, centroids);
+    i->quantizer->is_trained = true;
+    i->sq.trained.assign(trained, trained + n);
+    i->is_trained = true;
+    SHIM_CATCH
+}
+// ScalarQuantizer::decode of n codes (the stored values, without the list centroid)
+int ref_ivfsq_decode(void* p, idx_t n, const uint8_t* codes, float* out) {
+    SHIM_TRY auto* i = dynamic_cast<faiss::IndexIVFScalarQuantizer*>((faiss::Index*)p);
+    FAISS_THROW_IF_NOT_MSG(i, "not an IndexIVFScalarQuantizer");
+    i->sq.decode(codes, out, n);
     SHIM_CATCH
 }
 

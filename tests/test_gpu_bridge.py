@@ -33,7 +33,9 @@ def _cpu_index(desc, d, xt, xb, metric=METRIC_L2, nprobe=8):
 
 
 @pytest.mark.parametrize("desc,metric", [("Flat", METRIC_L2), ("Flat", METRIC_INNER_PRODUCT), ("IVF64,Flat", METRIC_L2),
-                                         ("IVF64,PQ16", METRIC_L2), ("IVF64,PQ16", METRIC_INNER_PRODUCT)])
+                                         ("IVF64,PQ16", METRIC_L2), ("IVF64,PQ16", METRIC_INNER_PRODUCT),
+                                         ("IVF64,SQ8", METRIC_L2), ("IVF64,SQ8", METRIC_INNER_PRODUCT), ("IVF64,SQ4", METRIC_L2),
+                                         ("IVF64,SQ6", METRIC_L2), ("IVF64,SQfp16", METRIC_L2)])
 def test_index_cpu_to_gpu_and_back(bres, desc, metric):
     d, k = 64, 20
     xt, xb, xq = synthetic_dataset(d, 4000, 20000, 300, seed=41)
@@ -52,6 +54,8 @@ def test_index_cpu_to_gpu_and_back(bres, desc, metric):
         s1, c1, i1 = back.lists()
         assert np.array_equal(s0, s1) and np.array_equal(i0, i1) and np.array_equal(c0, c1)
         assert np.array_equal(back.centroids(), cpu.centroids())
+        if "SQ" in desc:
+            assert back.sq_info() == cpu.sq_info() and np.array_equal(back.sq_trained(), cpu.sq_trained())
     Db, Ib = back.search(xq, k)
     assert np.array_equal(Ib, Ir) and np.array_equal(Db, Dr)
     # incremental use of the clone through faiss::Index::add
@@ -101,7 +105,7 @@ def test_reference_ivfflat_on_backend_coarse_quantizer(res):
     assert np.array_equal(q.compute_residual_n(xq, keys), xq - cent[keys])
 
 
-@pytest.mark.parametrize("desc", ["Flat", "IVF64,Flat", "IVF64,PQ16"])
+@pytest.mark.parametrize("desc", ["Flat", "IVF64,Flat", "IVF64,PQ16", "IVF64,SQ8"])
 @pytest.mark.parametrize("mode", ["replicas", "shards1", "shards2", "shards4", "shards_ivf"])
 def test_index_cpu_to_gpu_multiple(bres, desc, mode):
     """faiss/gpu/test/test_multi_gpu.py:15-98: the multi-device clone answers like the CPU index (ids exactly, up to

@@ -1,0 +1,204 @@
+"""GPU parity tests of GpuIndexIVFScalarQuantizer (pytest -m gpu), through the C ABI:
+codes byte-identical to faiss::ScalarQuantizer::compute_codes (oracle restatement, pinned on the real reference by
+tests/test_oracle_cpu.py::test_ivfsq_* and the committed golden fixture), search results BIT-EXACT against the oracle's
+restatement of the IVFSQ scanners in the kernel's summation order, and within 1e-4 relative of the live reference
+(faiss/gpu/test/TestGpuIndexIVFScalarQuantizer.cpp runs the same matrix: every supported qtype, L2 / IP, copyFrom /
+copyTo)."""
+import numpy as np
+import pytest
+
+import faiss_amd
+from compare import check_knn
+from faiss_amd import ScalarQuantizer as SQ
+from oracle.pyoracle import METRIC_INNER_PRODUCT, METRIC_L2, Oracle, Ref, synthetic_dataset
+
+pytestmark = pytest.mark.gpu
+
+QTYPES = [SQ.QT_8bit, SQ.QT_4bit, SQ.QT_8bit_uniform, SQ.QT_4bit_uniform, SQ.QT_fp16, SQ.QT_8bit_direct, SQ.QT_6bit]
+QNAMES = {SQ.QT_8bit: "8bit", SQ.QT_4bit: "4bit", SQ.QT_8bit_uniform: "8bit_uniform", SQ.QT_4bit_uniform: "4bit_uniform",
+          SQ.QT_fp16: "fp16", SQ.QT_8bit_direct: "8bit_direct", SQ.QT_6bit: "6bit"}
+
+
+def _data(qtype, d, nt, nb, nq, seed):
+    xt, xb, xq = synthetic_dataset(d, nt, nb, nq, seed=seed)
+    if qtype == SQ.QT_8bit_direct:
+        # "fast indexing of uint8s": byte-valued data
+        sc = 255.0 / max(xt.max(), xb.max(), xq.max())
+        xt, xb, xq = (np.floor(np.abs(v) * sc).astype(np.float32) for v in (xt, xb, xq))
+    return xt, xb, xq
+
+
+def _gpu_lists(idx):
+    sizes = np.array([idx.get_list_size(l) for l in range(idx.nlist)], dtype=np.uint32)
+    codes = np.concatenate([idx.get_list_codes(l) for l in range(idx.nlist)], axis=0)
+    ids = np.concatenate([idx.get_list_ids(l) for l in range(idx.nlist)])
+    return sizes, codes, ids
+
+
+@pytest.mark.parametrize("by_residual", [True, False])
+@pytest.mark.parametrize("metric", [METRIC_L2, METRIC_INNER_PRODUCT])
+@pytest.mark.parametrize("qtype", QTYPES, ids=[QNAMES[q] for q in QTYPES])
+def test_ivfsq_codes_and_search_match_oracle(res, qtype, metric, by_residual):
+    d, nlist, nb, nq, nprobe, k = 40, 32, 20000, 700, 6, 50  # d = 40: partly filled chunks, padded rows
+    xt, xb, xq = _data(qtype, d, 6000, nb, nq, seed=31 + qtype)
+    idx = faiss_amd.GpuIndexIVFScalarQuantizer(res, d, nlist, qtype, metric, by_residual)
+    assert not idx.is_trained
+    idx.train(xt)
+    assert idx.is_trained and idx.qtype == qtype and idx.by_residual == by_residual
+    assert idx.code_size == Oracle.sq_code_size(qtype, d)
+    idx.add(xb)
+    idx.nprobe = nprobe
+    cent = idx.get_centroids()
+    vmin, vdiff = Oracle.sq_unpack(qtype, d, idx.get_trained())
+    # ---- codes: ScalarQuantizer::compute_codes on the (residual) vectors, byte for byte
+    sizes, codes, ids = _gpu_lists(idx)
+    lab = Oracle.ivf_assign(metric, cent, xb)
+    want = Oracle.sq_encode(qtype, xb, vmin, vdiff, lab if by_residual else None, cent if by_residual else None)
+    got = np.empty_like(want)
+    got[ids] = codes
+    assert np.array_equal(got, want)
+    assert np.array_equal(np.bincount(lab, minlength=nlist).astype(np.uint32), sizes)
+    # ---- search: bit-exact against the oracle's restatement of the scanner
+    D, I = idx.search(xq, k)
+    sel = np.r_[0:60]
+    Do, Io = Oracle.ivfsq_search(qtype, by_residual, metric, cent, sizes, codes, ids, vmin, vdiff, xq[sel], nprobe, k)
+    check_knn(D[sel], I[sel], Do, Io, exact=True, name="ivfsq vs oracle")
+    # small batch: the probes of a query are split over several workgroups and merged by the select kernel
+    D2, I2 = idx.search(xq[:7], k)
+    assert np.array_equal(D2, D[:7]) and np.array_equal(I2, I[:7])
+
+
+@pytest.mark.parametrize("qtype,metric,by_residual,d,nlist,nb,nq,nprobe,k", [
+    (SQ.QT_8bit, METRIC_L2, True, 128, 64, 40000, 1500, 8, 100),        # bench shape: one chunk per lane
+    (SQ.QT_8bit, METRIC_INNER_PRODUCT, True, 128, 64, 40000, 1100, 8, 10),
+    (SQ.QT_8bit, METRIC_L2, True, 200, 16, 8000, 1100, 4, 20),           # two chunks per lane
+    (SQ.QT_4bit, METRIC_L2, True, 300, 16, 6000, 40, 16, 600),           # four chunks, probes split, big k
+    (SQ.QT_fp16, METRIC_L2, False, 600, 8, 3000, 1030, 3, 5),            # eight chunks
+    (SQ.QT_6bit, METRIC_INNER_PRODUCT, False, 1024, 8, 2000, 20, 8, 7),  # d at the limit
+    (SQ.QT_8bit_uniform, METRIC_L2, True, 16, 8, 5000, 1200, 5, 2048),   # k at the limit, one chunk in all
+    (SQ.QT_8bit, METRIC_L2, True, 128, 512, 60000, 1100, 300, 10),       # nprobe x d beyond the table rows: groups
+])
+def test_ivfsq_shapes_match_oracle(res, qtype, metric, by_residual, d, nlist, nb, nq, nprobe, k):
+    xt, xb, xq = _data(qtype, d, max(4000, 40 * nlist), nb, nq, seed=nb + k)
+    idx = faiss_amd.GpuIndexIVFScalarQuantizer(res, d, nlist, qtype, metric, by_residual)
+    idx.train(xt)
+    idx.add(xb)
+    idx.nprobe = nprobe
+    D, I = idx.search(xq, k)
+    cent = idx.get_centroids()
+    vmin, vdiff = Oracle.sq_unpack(qtype, d, idx.get_trained())
+    sizes, codes, ids = _gpu_lists(idx)
+    sel = np.r_[0:min(nq, 24)]
+    Do, Io = Oracle.ivfsq_search(qtype, by_residual, metric, cent, sizes, codes, ids, vmin, vdiff, xq[sel], nprobe, k)
+    check_knn(D[sel], I[sel], Do, Io, exact=True, name="ivfsq vs oracle")
+
+
+def test_ivfsq_trained_range_is_minmax_of_the_residuals(res):
+    """ScalarQuantizer::train with RS_minmax (training.cpp:209-232, 333-365): per-dimension (or global) minimum and
+    range of the training residuals, widened by rangestat_arg."""
+    d, nlist = 24, 16
+    xt, _, _ = synthetic_dataset(d, 5000, 0, 0, seed=4)
+    for qtype, arg in [(SQ.QT_8bit, 0.0), (SQ.QT_4bit, 0.1), (SQ.QT_8bit_uniform, 0.0), (SQ.QT_6bit, 0.25)]:
+        idx = faiss_amd.GpuIndexIVFScalarQuantizer(res, d, nlist, qtype, METRIC_L2, True)
+        idx.set_rangestat(SQ.RS_minmax, arg)
+        idx.train(xt)
+        cent = idx.get_centroids()
+        r = xt - cent[Oracle.ivf_assign(METRIC_L2, cent, xt)]
+        t = idx.get_trained()
+        if qtype == SQ.QT_8bit_uniform:
+            vmin, vmax = np.float32(r.min()), np.float32(r.max())
+            vexp = np.float32(vmax - vmin) * np.float32(arg)
+            assert t.shape == (2,) and t[0] == vmin - vexp and t[1] == (vmax + vexp) - (vmin - vexp)
+        else:
+            vmin, vmax = r.min(axis=0), r.max(axis=0)
+            vexp = (vmax - vmin) * np.float32(arg)
+            assert np.array_equal(t[:d], vmin - vexp) and np.array_equal(t[d:], (vmax + vexp) - (vmin - vexp))
+    idx = faiss_amd.GpuIndexIVFScalarQuantizer(res, d, nlist, SQ.QT_8bit, METRIC_L2, True)
+    idx.set_rangestat(SQ.RS_meanstd, 2.0)
+    with pytest.raises(RuntimeError):
+        idx.train(xt)
+    # the types without a range are trained as soon as the coarse quantizer is
+    f = faiss_amd.GpuIndexIVFScalarQuantizer(res, d, nlist, SQ.QT_fp16, METRIC_L2, True)
+    f.train(xt)
+    assert f.is_trained and f.get_trained().size == 0
+    with pytest.raises(RuntimeError):
+        faiss_amd.GpuIndexIVFScalarQuantizer(res, d, nlist, 7, METRIC_L2, True)  # QT_bf16: not a GPU type
+
+
+@pytest.mark.skipif(not Ref.available(), reason="oracle/_ref not shipped")
+@pytest.mark.parametrize("by_residual", [True, False])
+@pytest.mark.parametrize("metric", [METRIC_L2, METRIC_INNER_PRODUCT])
+@pytest.mark.parametrize("qtype", QTYPES, ids=[QNAMES[q] for q in QTYPES])
+def test_ivfsq_vs_live_reference(res, qtype, metric, by_residual):
+    """The same quantizers in faiss::IndexIVFScalarQuantizer (CPU): identical lists (codes and ids, byte for byte),
+    distances within 1e-4 relative, labels equal outside near-tie groups; then the other direction: the reference's
+    lists loaded into the backend (copyFrom) give the same results as its own add()."""
+    d, nlist, nb, nq, nprobe, k = 64, 32, 15000, 200, 8, 20
+    xt, xb, xq = _data(qtype, d, 5000, nb, nq, seed=77 + qtype)
+    idx = faiss_amd.GpuIndexIVFScalarQuantizer(res, d, nlist, qtype, metric, by_residual)
+    idx.train(xt)
+    idx.add(xb)
+    idx.nprobe = nprobe
+    D, I = idx.search(xq, k)
+    ref = Ref.ivfsq(d, nlist, qtype, metric, by_residual)
+    ref.set_sq_trained(idx.get_centroids(), idx.get_trained())
+    ref.add(xb)
+    ref.set_nprobe(nprobe)
+    rs, rc, ri = ref.lists()
+    gs, gc, gi = _gpu_lists(idx)
+    # a vector at (near-)equal distance from two centroids may land in either list (the reference's coarse quantizer
+    # sums in BLAS order); everywhere else the lists agree entry for entry
+    same_lists = np.array_equal(rs, gs) and np.array_equal(ri, gi)
+    gcode, rcode = np.empty_like(gc), np.empty_like(rc)
+    gcode[gi], rcode[ri] = gc, rc
+    glist, rlist = np.empty(nb, np.int64), np.empty(nb, np.int64)
+    glist[gi], rlist[ri] = np.repeat(np.arange(nlist), gs), np.repeat(np.arange(nlist), rs)
+    agree = glist == rlist
+    assert agree.mean() > 0.999
+    assert np.array_equal(gcode[agree], rcode[agree])
+    if same_lists:
+        assert np.array_equal(rc, gc)
+    Dr, Ir = ref.search(xq, k)
+    other = faiss_amd.GpuIndexIVFScalarQuantizer(res, d, nlist, qtype, metric, by_residual)
+    other.copy_centroids(ref.centroids())
+    if ref.sq_trained().size:
+        other.copy_trained(ref.sq_trained())
+    assert other.is_trained
+    other.copy_lists(rs, rc, ri)
+    other.nprobe = nprobe
+    D2, I2 = other.search(xq, k)
+    check_knn(D2, I2, Dr, Ir, rtol=1e-4, tie_rtol=1e-4, name="ivfsq vs reference")
+    if same_lists:
+        assert np.array_equal(D2, D) and np.array_equal(I2, I)
+
+
+def test_ivfsq_incremental_adds_nan_rows_reset(res):
+    d, nlist = 32, 16
+    xt, xb, xq = synthetic_dataset(d, 4000, 9000, 64, seed=12)
+    a = faiss_amd.GpuIndexIVFScalarQuantizer(res, d, nlist, SQ.QT_8bit, METRIC_L2, True)
+    a.train(xt)
+    b = faiss_amd.GpuIndexIVFScalarQuantizer(res, d, nlist, SQ.QT_8bit, METRIC_L2, True)
+    b.copy_centroids(a.get_centroids())
+    b.copy_trained(a.get_trained())
+    a.add(xb)
+    for i0 in range(0, 9000, 777):
+        b.add(xb[i0:i0 + 777])
+    a.nprobe = b.nprobe = 5
+    Da, Ia = a.search(xq, 10)
+    Db, Ib = b.search(xq, 10)
+    assert np.array_equal(Da, Db) and np.array_equal(Ia, Ib)
+    # NaN rows are counted by ntotal but not stored (faiss/gpu/GpuIndexIVF.cu:293-298); NaN queries find nothing
+    bad = xb[:5].copy()
+    bad[2, 3] = np.nan
+    a.add(bad)
+    assert a.ntotal == 9005 and a.stored_vectors() == 9004
+    q = xq[:3].copy()
+    q[1, 0] = np.nan
+    D, I = a.search(q, 4)
+    assert (I[1] == -1).all() and (I[0] >= 0).all()
+    a.reset()
+    assert a.ntotal == 0 and a.is_trained
+    D, I = a.search(xq[:2], 3)
+    assert (I == -1).all()
+    with pytest.raises(RuntimeError):
+        faiss_amd.GpuIndexIVFScalarQuantizer(res, d, nlist, SQ.QT_8bit, METRIC_L2, True).add(xb[:10])  # untrained
