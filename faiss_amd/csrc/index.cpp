@@ -1633,8 +1633,21 @@ void GpuIndexIVF::set_lists(const uint32_t* list_sizes, const uint8_t* codes, co
             HIP_CHECK(hipMemsetAsync(tmp_codes.p, 0, (size_t)acc * code_bytes_, R.stream));
             HIP_CHECK(hipMemcpy2DAsync(tmp_codes.p, code_bytes_, codes, src_row, src_row, (size_t)acc, hipMemcpyDefault,
                                        R.stream));
-            launch_ivf_move(tmp_codes.as<uint8_t>(), arena_.as<uint8_t>(), a_jobs_.as<IvfMoveJob>(), (int)jobs.size(),
-                            (int)code_bytes_, R.stream);
+            if (fused_kind_() == 2) {
+                // plain rows -> 64-row chunk-major blocks (kernels.h sq_code_offset)
+                dsrc.ensure((size_t)nlist * 8 * 2 + (size_t)nlist * 4);
+                int64_t* d_src = dsrc.as<int64_t>();
+                int64_t* d_dst = d_src + nlist;
+                uint32_t* d_len = (uint32_t*)(d_dst + nlist);
+                HIP_CHECK(hipMemcpyAsync(d_src, src_start.data(), (size_t)nlist * 8, hipMemcpyHostToDevice, R.stream));
+                HIP_CHECK(hipMemcpyAsync(d_dst, nstart.data(), (size_t)nlist * 8, hipMemcpyHostToDevice, R.stream));
+                HIP_CHECK(hipMemcpyAsync(d_len, list_sizes, (size_t)nlist * 4, hipMemcpyHostToDevice, R.stream));
+                launch_ivfsq_pack_lists(tmp_codes.as<uint8_t>(), d_src, d_dst, d_len, nlist, (int)code_bytes_, sq_chunk_bytes_(),
+                                        arena_.as<uint8_t>(), R.stream);
+            } else {
+                launch_ivf_move(tmp_codes.as<uint8_t>(), arena_.as<uint8_t>(), a_jobs_.as<IvfMoveJob>(), (int)jobs.size(),
+                                (int)code_bytes_, R.stream);
+            }
         } else {
             HIP_CHECK(hipMemcpyAsync(tmp_codes.p, codes, (size_t)acc * code_bytes_, hipMemcpyDefault, R.stream));
             dsrc.ensure((size_t)nlist * 8 * 2 + (size_t)nlist * 4);
@@ -1676,7 +1689,16 @@ std::vector<uint8_t> GpuIndexIVF::getListVectorData(idx_t list) const {
     const size_t dst_row = ref_row_bytes_();
     std::vector<uint8_t> out((size_t)list_len_[list] * dst_row);
     if (out.empty()) return out;
-    if (fused_kind_() != 1) {
+    if (fused_kind_() == 2) {
+        // chunk-major blocks -> plain rows -> the reference's code_size-byte entries
+        DevBuf tmp;
+        tmp.ensure((size_t)list_len_[list] * code_bytes_);
+        launch_ivfsq_unpack_rows(arena_.as<uint8_t>(), list_start_[list], list_len_[list], (int)code_bytes_, sq_chunk_bytes_(),
+                                 tmp.as<uint8_t>(), res_->stream);
+        HIP_CHECK(hipMemcpy2DAsync(out.data(), dst_row, tmp.p, code_bytes_, dst_row, list_len_[list], hipMemcpyDeviceToHost,
+                                   res_->stream));
+        res_->sync();
+    } else if (fused_kind_() != 1) {
         HIP_CHECK(hipMemcpy2D(out.data(), dst_row, arena_.as<uint8_t>() + list_start_[list] * code_bytes_, code_bytes_,
                               dst_row, list_len_[list], hipMemcpyDeviceToHost));
     } else {
@@ -1973,7 +1995,7 @@ GpuIndexIVFScalarQuantizer::GpuIndexIVFScalarQuantizer(std::shared_ptr<GpuResour
     }
     FA_THROW_IF_NOT_MSG(dims <= 1024, "scalar-quantizer index: d <= 1024");
     code_bytes_ = (size_t)(dsq_ / 16) * sq_chunk_bytes(ct_); // arena row: whole 16-component chunks, zero padded
-    granule_ = 8;
+    granule_ = 64;                                           // 64-row chunk-major blocks (kernels.h sq_code_offset)
     upload_tables_();
 }
 
@@ -2099,6 +2121,9 @@ void GpuIndexIVFScalarQuantizer::fill_fused_(IvfFusedParams& p) const {
     p.sq_b = sq_b_.as<float>();
     p.centroids = quantizer->device_vectors();
     p.ldc = dpad_;
+}
+int GpuIndexIVFScalarQuantizer::sq_chunk_bytes_() const {
+    return sq_chunk_bytes(ct_);
 }
 void GpuIndexIVFScalarQuantizer::scan_(int, const float*, int, const int64_t*) const {
     FA_THROW_MSG("the scalar-quantizer scan exists only as the fused kernel");

@@ -299,6 +299,7 @@ class GpuIndexIVF : public Index {
     // bytes per entry of the reference's inverted-list payload (invlists->code_size): what copy_lists takes and
     // getListVectorData returns
     virtual size_t ref_row_bytes_() const { return code_bytes_; }
+    virtual int sq_chunk_bytes_() const { return 0; } // scalar quantizer: bytes per 16-component chunk
     mutable DevBuf part_keys_, part_cnt_, probe_len_, probe_start_;
     void upload_list_tables_();
     void ensure_arena_(int64_t rows);
@@ -378,6 +379,7 @@ class GpuIndexIVFScalarQuantizer : public GpuIndexIVF {
     void fill_fused_(struct IvfFusedParams& p) const override;
     int fused_kind_() const override { return 2; }
     size_t ref_row_bytes_() const override { return code_size; }
+    int sq_chunk_bytes_() const override;
     bool extra_trained_() const override { return !needs_training_() || !trained.empty(); }
     void train_residual_(idx_t n, const float* x_dev_pad) override;
     void append_(int n, const float* x_pad, const int64_t* d_labels, const int64_t* d_dest) override;

@@ -628,15 +628,20 @@ __global__ void __launch_bounds__(FB_MAX) ivfflat_fused_kernel(IvfFusedParams p)
 }
 
 // ---------------------------------------------------------------------------------
-// IVF scalar quantizer (kind 2).  The IVFFlat walk (eight lanes per row, position stream over the probed lists) over
-// rows of CODES: a lane owns the 16-component chunks c = ln, ln + 8, ... of its row (16 bytes of 8-bit codes, 8 of
-// 4-bit, 12 of 6-bit, 32 of fp16), decodes them in registers and folds them into the distance with the per-dimension
-// scale s and a query-side table row a kept in LDS:
+// IVF scalar quantizer (kind 2).  The block stream of the IVFPQ scan over rows of CODES: the arena is a sequence of
+// 64-row blocks (lists start on block boundaries), a block holds its rows chunk-major -- [chunk][64 rows][chunk bytes],
+// a chunk = 16 components = 16 bytes of 8-bit codes / 8 of 4-bit / 12 of 6-bit / 32 of fp16 (kernels.h sq_code_offset)
+// -- so that a wavefront reads one chunk of all 64 rows with ONE coalesced load instruction and lane l owns row l:
+// no cross-lane reduction, no per-row address search (one prefix lookup per block and wavefront).  A lane decodes its
+// chunk in registers and folds it into the distance with the per-dimension scale s and a query-side table row a,
+// both read from LDS as wave-wide broadcasts (every row of a block belongs to the same list):
 //   L2: tt = fmaf(-code, s_i, a_i), a_i = (q_i [- centroid_i]) - b_i   (fp16: tt = a_i - half)   acc = fmaf(tt, tt, acc)
 //   IP: acc = fmaf(w_i, code, acc), w_i = q_i * s_i                     (fp16: w_i = q_i);  + <q, b> (+ coarse term)
-// i.e. the distance to the reconstruction b_i + s_i * code_i of faiss::ScalarQuantizer (quantizers.h:92-150: vmin +
-// (code + 0.5) / 255 * vdiff) without materialising it.  With residual encoding the L2 row a changes with the list:
-// one row per probe of the workgroup (built once, nprobe x d x 4 bytes); otherwise the row sits in registers.
+// as ONE sequential chain over the dimensions, i.e. the distance to the reconstruction b_i + s_i * code_i of
+// faiss::ScalarQuantizer (quantizers.h:92-150: vmin + (code + 0.5) / 255 * vdiff) without materialising it.  With
+// residual encoding the L2 row a changes with the list: one row per probe of the workgroup (built once per query,
+// nprobe x d x 4 bytes).  Two stages per wavefront: the next (block, chunk group) is in flight while the current one is
+// folded; rows longer than a stage (32 registers: 128 8-bit components) take several chunk groups per block.
 // The code stream is the only HBM traffic: d bytes per scanned vector for 8-bit codes.
 // Reference: IVFSQScannerL2 / IVFSQScannerIP (faiss/impl/scalar_quantizer/scanners.h:34-140), on the GPU
 // IVFFlatScan with a Codec (faiss/gpu/impl/IVFFlatScan.cu, GpuScalarQuantizer.cuh).
@@ -645,6 +650,7 @@ constexpr int SQ_FB = 512;
 template <int CT>
 struct SqChunk {
     static constexpr int WORDS = CT == SQ_U8 ? 4 : CT == SQ_U4 ? 2 : CT == SQ_U6 ? 3 : 8;
+    static constexpr int CG = 32 / WORDS > 8 ? 8 : 32 / WORDS; // chunks per stage (<= 32 registers)
 };
 // component E (0..15) of a chunk, as a float
 template <int CT, int E>
@@ -676,27 +682,79 @@ __device__ __forceinline__ void sq_fold(const unsigned (&w)[SqChunk<CT>::WORDS],
     }
 }
 
-template <int METRIC, int CT, int NT>
-__global__ void __launch_bounds__(SQ_FB, 4) ivfsq_fused_kernel(IvfFusedParams p) {
+template <int METRIC, int CT>
+__global__ void __launch_bounds__(SQ_FB, 4) ivfsq_fused_kernel(IvfFusedParams p) { // two 512-thread workgroups per CU
     constexpr int FB = SQ_FB;
+    constexpr int NWV = FB / 64;
     constexpr int W = SqChunk<CT>::WORDS;
-    constexpr int SR0 = 32 / (NT * W);
-    constexpr int SR = SR0 > 8 ? 8 : SR0 < 1 ? 1 : SR0; // rows per 8-lane group and iteration
-    constexpr int NPOS = SR * (FB / 8);
-    constexpr int CHB = W * 4;                           // bytes per chunk
+    constexpr int CG = SqChunk<CT>::CG;
+    constexpr int CHB = W * 4; // bytes per chunk
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const FusedLds L = fused_carve(smem, p);
     const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = blockIdx.x / p.G, g = blockIdx.x - q * p.G;
     const int p0 = g * p.npc, p1 = min(p.nprobe, p0 + p.npc);
-    const int ln = tid & 7, rg = tid >> 3;
     const int dsq = p.sq_dsq, nch = dsq >> 4;
+    const int ngrp = (nch + CG - 1) / CG;
     const bool per_probe = METRIC == METRIC_L2 && p.sq_by_residual;
     float* tab_s = (float*)L.lut;
     float* tab_a = tab_s + dsq;
     float* tab_c = tab_a + (size_t)(p.M - 1) * dsq; // [npc] coarse distances (IP with residual encoding)
 
     fused_load_probes<FB>(p, q, L);
+    // ---- block stream of this workgroup's probes [p0, p1): blocks [bpre[p0], bpre[p1])
+    const unsigned blk_begin = L.bpre[p0], blk_end = L.bpre[p1];
+    struct Stage {
+        unsigned w[CG][W];  // code words of this lane's row, chunks grp * CG ..
+        // wave-uniform: probe (relative to p0) of the block's list, scan position of the block's first row, rows of the
+        // list from that row on (0 = no block)
+        int t;
+        unsigned pos0, rem;
+    };
+    int tcur = p0; // probe of the block fetched last (blocks are visited in non-decreasing order)
+    auto fetch = [&](unsigned blk, int grp, Stage& st) {
+        st.rem = 0;
+        if (blk < blk_end) { // wave-uniform
+            while (L.bpre[tcur + 1] <= blk) ++tcur;
+            const unsigned b = blk - L.bpre[tcur];
+            const int64_t row0 = L.lstart[tcur] + (int64_t)b * 64;
+            const uint8_t* bp = p.arena_codes + row0 * (int64_t)p.sq_ld + lane * CHB;
+            st.rem = __builtin_amdgcn_readfirstlane(L.pre[tcur + 1] - L.pre[tcur] - b * 64u);
+            st.t = __builtin_amdgcn_readfirstlane(tcur - p0);
+            st.pos0 = __builtin_amdgcn_readfirstlane(L.pre[tcur] + b * 64u);
+            // only the rows the list really holds are requested
+            if ((unsigned)lane < st.rem) {
+#pragma unroll
+                for (int j = 0; j < CG; ++j) {
+                    const int c = grp * CG + j;
+                    if (c < nch) { // wave-uniform
+                        const unsigned* src = (const unsigned*)(bp + (int64_t)c * 64 * CHB);
+                        if constexpr (W == 4) {
+                            const uint4 v = *(const uint4*)src;
+                            st.w[j][0] = v.x, st.w[j][1] = v.y, st.w[j][2] = v.z, st.w[j][3] = v.w;
+                        } else if constexpr (W == 2) {
+                            const uint2 v = *(const uint2*)src;
+                            st.w[j][0] = v.x, st.w[j][1] = v.y;
+                        } else if constexpr (W == 3) {
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) st.w[j][i] = src[i];
+                        } else {
+                            const uint4 v0 = *(const uint4*)src, v1 = *(const uint4*)(src + 4);
+                            st.w[j][0] = v0.x, st.w[j][1] = v0.y, st.w[j][2] = v0.z, st.w[j][3] = v0.w;
+                            st.w[j][4] = v1.x, st.w[j][5] = v1.y, st.w[j][6] = v1.z, st.w[j][7] = v1.w;
+                        }
+                    }
+                }
+            }
+        }
+    };
+    // the first stage of every wavefront is requested BEFORE the tables are built: its HBM latency hides behind them
+    Stage s0, s1;
+    fetch(blk_begin + wave, 0, s0);
+
+    // ---- tables
     const float* xq = p.xq + (int64_t)q * p.ldq;
     for (int i = tid; i < dsq; i += FB) tab_s[i] = CT == SQ_F16 ? 0.f : p.sq_s[i];
     if (per_probe) {
@@ -723,123 +781,90 @@ __global__ void __launch_bounds__(SQ_FB, 4) ivfsq_fused_kernel(IvfFusedParams p)
     }
     if (METRIC != METRIC_L2) {
         for (int t = tid; t < p1 - p0; t += FB) tab_c[t] = p.sq_by_residual ? p.coarse_dis[(int64_t)q * p.nprobe + p0 + t] : 0.f;
-        // <q, b>: summed like a row (lane chunks, then the 8-lane tree)
-        if (tid < 8) {
+        if (tid == 0) { // <q, b>: one sequential chain
             float acc = 0.f;
             if (CT != SQ_F16)
-                for (int c = tid; c < nch; c += 8)
-                    for (int e = 0; e < 16; ++e) {
-                        const int i = 16 * c + e;
-                        if (i < p.d) acc = __fmaf_rn(xq[i], p.sq_b[i], acc);
-                    }
-            acc = acc + __shfl_xor(acc, 1, 64);
-            acc = acc + __shfl_xor(acc, 2, 64);
-            acc = acc + __shfl_xor(acc, 4, 64);
-            if (tid == 0) L.rs[0] = acc;
+                for (int i = 0; i < p.d; ++i) acc = __fmaf_rn(xq[i], p.sq_b[i], acc);
+            L.rs[0] = acc;
         }
     }
     __syncthreads();
     const float qb = METRIC != METRIC_L2 ? L.rs[0] : 0.f;
-    // one chunk per lane: its scale (and, without per-probe rows, its table row) stay in registers
-    float sreg[16], areg[16];
-    if (NT == 1) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            sreg[e] = ln < nch ? tab_s[16 * ln + e] : 0.f;
-            areg[e] = (!per_probe && ln < nch) ? tab_a[16 * ln + e] : 0.f;
-        }
-    }
 
-    const unsigned pos_begin = L.pre[p0], pos_end = L.pre[p1];
     u64 tau = ~0ull;
     int bound = 0;
-    for (unsigned base = pos_begin; base < pos_end; base += NPOS) {
-        FUSED_MAKE_ROOM(min((unsigned)NPOS, pos_end - base));
-        unsigned rowi[SR]; // arena row (rows are counted in 32 bits: at most 2^31 per index), ~0u = none
-        int tq[SR];
+    float acc = 0.f; // this lane's row, carried over the chunk groups of a block
+    // fold one staged chunk group; behind the last group of a block: key + append
+    auto scan = [&](const Stage& st, int grp) {
+        if (grp == 0) acc = 0.f;
+        if ((unsigned)lane < st.rem) {
+            const float* arow = tab_a + (per_probe ? st.t * dsq : 0);
 #pragma unroll
-        for (int u = 0; u < SR; ++u) {
-            const unsigned pos = base + u * (FB / 8) + rg;
-            rowi[u] = ~0u;
-            tq[u] = 0;
-            if (pos < pos_end) {
-                int lo = p0, hi = p1; // invariant pre[lo] <= pos < pre[hi]
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if (L.pre[mid] <= pos) lo = mid;
-                    else hi = mid;
-                }
-                rowi[u] = (unsigned)(L.lstart[lo] + (pos - L.pre[lo]));
-                tq[u] = lo - p0;
-            }
-        }
-        unsigned w[SR][NT][W];
-#pragma unroll
-        for (int u = 0; u < SR; ++u)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int c = ln + 8 * t;
-                const bool ok = rowi[u] != ~0u && c < nch;
-                const unsigned* src = (const unsigned*)(p.arena_codes + (int64_t)rowi[u] * p.sq_ld + c * CHB);
-                if constexpr (W == 4) {
-                    const uint4 v = ok ? *(const uint4*)src : uint4{0u, 0u, 0u, 0u};
-                    w[u][t][0] = v.x, w[u][t][1] = v.y, w[u][t][2] = v.z, w[u][t][3] = v.w;
-                } else if constexpr (W == 2) {
-                    const uint2 v = ok ? *(const uint2*)src : uint2{0u, 0u};
-                    w[u][t][0] = v.x, w[u][t][1] = v.y;
-                } else if constexpr (W == 3) {
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) w[u][t][i] = ok ? src[i] : 0u;
-                } else {
-                    const uint4 v0 = ok ? *(const uint4*)src : uint4{0u, 0u, 0u, 0u};
-                    const uint4 v1 = ok ? *(const uint4*)(src + 4) : uint4{0u, 0u, 0u, 0u};
-                    w[u][t][0] = v0.x, w[u][t][1] = v0.y, w[u][t][2] = v0.z, w[u][t][3] = v0.w;
-                    w[u][t][4] = v1.x, w[u][t][5] = v1.y, w[u][t][6] = v1.z, w[u][t][7] = v1.w;
-                }
-            }
-#pragma unroll
-        for (int u = 0; u < SR; ++u) {
-            float acc = 0.f;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int c = ln + 8 * t;
-                if (NT == 1) {
-                    if (per_probe) {
-                        float av[16];
-                        const f32x4* ap = (const f32x4*)(tab_a + tq[u] * dsq + 16 * (ln < nch ? ln : 0));
-#pragma unroll
-                        for (int v4 = 0; v4 < 4; ++v4) {
-                            const f32x4 x4 = ap[v4];
-                            av[4 * v4] = x4[0], av[4 * v4 + 1] = x4[1], av[4 * v4 + 2] = x4[2], av[4 * v4 + 3] = x4[3];
-                        }
-                        if (ln < nch) sq_fold<METRIC, CT, 0>(w[u][t], sreg, av, acc);
-                    } else {
-                        sq_fold<METRIC, CT, 0>(w[u][t], sreg, areg, acc);
-                    }
-                } else if (c < nch) {
+            for (int j = 0; j < CG; ++j) {
+                const int c = grp * CG + j;
+                if (c < nch) { // wave-uniform
                     float sv[16], av[16];
                     const f32x4* sp = (const f32x4*)(tab_s + 16 * c);
-                    const f32x4* ap = (const f32x4*)(tab_a + (per_probe ? tq[u] * dsq : 0) + 16 * c);
+                    const f32x4* ap = (const f32x4*)(arow + 16 * c);
 #pragma unroll
-                    for (int v4 = 0; v4 < 4; ++v4) {
-                        const f32x4 s4 = sp[v4], x4 = ap[v4];
-                        sv[4 * v4] = s4[0], sv[4 * v4 + 1] = s4[1], sv[4 * v4 + 2] = s4[2], sv[4 * v4 + 3] = s4[3];
+                    for (int v4 = 0; v4 < 4; ++v4) { // (wave-wide broadcast reads)
+                        const f32x4 x4 = ap[v4];
                         av[4 * v4] = x4[0], av[4 * v4 + 1] = x4[1], av[4 * v4 + 2] = x4[2], av[4 * v4 + 3] = x4[3];
+                        if (METRIC == METRIC_L2 && CT != SQ_F16) {
+                            const f32x4 s4 = sp[v4];
+                            sv[4 * v4] = s4[0], sv[4 * v4 + 1] = s4[1], sv[4 * v4 + 2] = s4[2], sv[4 * v4 + 3] = s4[3];
+                        }
                     }
-                    sq_fold<METRIC, CT, 0>(w[u][t], sv, av, acc);
+                    sq_fold<METRIC, CT, 0>(st.w[j], sv, av, acc);
                 }
             }
-            // ((p0+p1)+(p2+p3)) + ((p4+p5)+(p6+p7)) in every lane of the group, append from lane 0
-            float a = acc;
-            a = a + __shfl_xor(a, 1, 64);
-            a = a + __shfl_xor(a, 2, 64);
-            a = a + __shfl_xor(a, 4, 64);
-            if (METRIC != METRIC_L2) a = (a + qb) + tab_c[tq[u]];
-            const u64 key = ((u64)ordkey<METRIC>(a) << 32) | (u64)(base + u * (FB / 8) + rg);
-            const bool pass = rowi[u] != ~0u && ln == 0 && key < tau;
-            wg_append(L.res, L.ctl, pass, key);
         }
-        __syncthreads();
+        if (grp == ngrp - 1) {
+            bool pass = false;
+            u64 key = 0;
+            if ((unsigned)lane < st.rem) {
+                float dis = acc;
+                if (METRIC != METRIC_L2) dis = (dis + qb) + tab_c[st.t];
+                key = ((u64)ordkey<METRIC>(dis) << 32) | (u64)(st.pos0 + (unsigned)lane);
+                pass = key < tau;
+            }
+            wg_append(L.res, L.ctl, pass, key);
+            __syncthreads();
+        }
+    };
+    // work item k of a wavefront: block blk_begin + wave + NWV * (k / ngrp), chunk group k % ngrp; all wavefronts of the
+    // workgroup walk the items in lockstep (the reservoir bookkeeping needs workgroup-uniform barriers)
+    unsigned base = blk_begin;
+    int grp = 0;
+    auto next_item = [&](unsigned& nb, int& ng) {
+        ng = grp + 1;
+        nb = base;
+        if (ng == ngrp) {
+            ng = 0;
+            nb = base + NWV;
+        }
+    };
+    for (;;) {
+        if (base >= blk_end) break;
+        {
+            if (grp == 0) FUSED_MAKE_ROOM(FB);
+            unsigned nb;
+            int ng;
+            next_item(nb, ng);
+            fetch(nb + wave, ng, s1);
+            scan(s0, grp);
+            base = nb, grp = ng;
+        }
+        if (base >= blk_end) break;
+        {
+            if (grp == 0) FUSED_MAKE_ROOM(FB);
+            unsigned nb;
+            int ng;
+            next_item(nb, ng);
+            fetch(nb + wave, ng, s0);
+            scan(s1, grp);
+            base = nb, grp = ng;
+        }
     }
     fused_finish<FB>(p, q, g, L);
 }
@@ -932,17 +957,10 @@ void launch_ivf_fused(const IvfFusedParams& p, hipStream_t stream) {
         FA_THROW_IF_NOT_MSG(p.sq_dsq % 16 == 0 && nch >= 1 && nch <= 64, "scalar-quantizer scan: d <= 1024");
         FA_THROW_IF_NOT(p.M == sq_table_rows(p.metric, p.sq_by_residual != 0, p.npc) && p.arena_codes && p.sq_s && p.sq_b);
         FA_THROW_IF_NOT(p.sq_ld % 4 == 0 && p.sq_ld >= nch * sq_chunk_bytes(p.sq_ct));
-#define FA_SQ_LAUNCH_NT(CT_, NT_)                                                                          \
-    do {                                                                                                   \
-        if (l2) launch_one(ivfsq_fused_kernel<METRIC_L2, CT_, NT_>, p, lds, fb, stream);                   \
-        else launch_one(ivfsq_fused_kernel<METRIC_INNER_PRODUCT, CT_, NT_>, p, lds, fb, stream);           \
-    } while (0)
 #define FA_SQ_LAUNCH(CT_)                                                                                  \
     do {                                                                                                   \
-        if (nch <= 8) FA_SQ_LAUNCH_NT(CT_, 1);                                                             \
-        else if (nch <= 16) FA_SQ_LAUNCH_NT(CT_, 2);                                                       \
-        else if (nch <= 32) FA_SQ_LAUNCH_NT(CT_, 4);                                                       \
-        else FA_SQ_LAUNCH_NT(CT_, 8);                                                                      \
+        if (l2) launch_one(ivfsq_fused_kernel<METRIC_L2, CT_>, p, lds, fb, stream);                        \
+        else launch_one(ivfsq_fused_kernel<METRIC_INNER_PRODUCT, CT_>, p, lds, fb, stream);                \
     } while (0)
         switch (p.sq_ct) {
             case SQ_U8: FA_SQ_LAUNCH(SQ_U8); break;
@@ -951,7 +969,6 @@ void launch_ivf_fused(const IvfFusedParams& p, hipStream_t stream) {
             default: FA_SQ_LAUNCH(SQ_F16); break;
         }
 #undef FA_SQ_LAUNCH
-#undef FA_SQ_LAUNCH_NT
     } else {
         FA_THROW_IF_NOT_MSG(p.metric != METRIC_L2 || p.arena_t2, "IVFPQ L2 needs the per-vector t2 terms");
 #define FA_PQ_LAUNCH(M64_, FB_)                                                                            \

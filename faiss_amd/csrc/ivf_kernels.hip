@@ -492,14 +492,16 @@ __global__ void ivfsq_encode_kernel(int qtype, const float* __restrict__ x, int6
         }
         code[e] = cv;
     }
-    uint8_t* row = arena + dst * (int64_t)ld;
+    // chunk c of arena row dst in the block layout (kernels.h sq_code_offset)
+    const int chb = (qtype == QT_fp16) ? 32 : (qtype == QT_4bit || qtype == QT_4bit_uniform) ? 8 : qtype == QT_6bit ? 12 : 16;
+    uint8_t* chunk = arena + sq_code_offset(dst, c * chb, ld, chb);
     if (qtype == QT_fp16) {
-        uint32_t* o = (uint32_t*)(row + 32 * c);
+        uint32_t* o = (uint32_t*)chunk;
 #pragma unroll
         for (int w = 0; w < 8; ++w) o[w] = code[2 * w] | (code[2 * w + 1] << 16);
     } else if (qtype == QT_4bit || qtype == QT_4bit_uniform) {
         // component i in byte i / 2, low nibble first (codecs.h:48-53)
-        uint32_t* o = (uint32_t*)(row + 8 * c);
+        uint32_t* o = (uint32_t*)chunk;
 #pragma unroll
         for (int w = 0; w < 2; ++w) {
             uint32_t v = 0;
@@ -509,7 +511,7 @@ __global__ void ivfsq_encode_kernel(int qtype, const float* __restrict__ x, int6
         }
     } else if (qtype == QT_6bit) {
         // a little-endian stream of 6-bit fields: 4 components per 3 bytes (codecs.h:67-92)
-        uint32_t* o = (uint32_t*)(row + 12 * c);
+        uint32_t* o = (uint32_t*)chunk;
         unsigned long long lo = 0, hi = 0; // 96 bits
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -526,7 +528,7 @@ __global__ void ivfsq_encode_kernel(int qtype, const float* __restrict__ x, int6
         o[1] = (uint32_t)(lo >> 32);
         o[2] = (uint32_t)hi;
     } else {
-        uint32_t* o = (uint32_t*)(row + 16 * c);
+        uint32_t* o = (uint32_t*)chunk;
 #pragma unroll
         for (int w = 0; w < 4; ++w)
             o[w] = (code[4 * w] & 255u) | ((code[4 * w + 1] & 255u) << 8) | ((code[4 * w + 2] & 255u) << 16) |
@@ -540,6 +542,46 @@ void launch_ivfsq_encode_append(int qtype, const float* x, int64_t ldx, int n, i
     const int nch = (int)div_up(d, 16);
     hipLaunchKernelGGL(ivfsq_encode_kernel, dim3((unsigned)div_up((int64_t)n * nch, 256)), dim3(256), 0, stream, qtype, x,
                        ldx, n, d, labels, dest, centroids, ldc, by_residual ? 1 : 0, vmin, vdiff, arena, ld, nch);
+    HIP_CHECK(hipGetLastError());
+}
+
+__global__ void ivfsq_pack_lists_kernel(const uint8_t* __restrict__ rows, const int64_t* __restrict__ src_start,
+                                        const int64_t* __restrict__ dst_start, const uint32_t* __restrict__ len, int ld,
+                                        int chb, uint8_t* __restrict__ arena) {
+    const int l = blockIdx.x;
+    const int wpr = ld >> 2; // 4-byte words per row
+    const int64_t words = (int64_t)len[l] * wpr;
+    const int64_t s0 = src_start[l], d0 = dst_start[l];
+    for (int64_t w = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; w < words; w += (int64_t)gridDim.y * blockDim.x) {
+        const int64_t i = w / wpr;
+        const int byte = (int)(w - i * wpr) * 4;
+        *(uint32_t*)(arena + sq_code_offset(d0 + i, byte, ld, chb)) = *(const uint32_t*)(rows + (s0 + i) * ld + byte);
+    }
+}
+void launch_ivfsq_pack_lists(const uint8_t* rows, const int64_t* src_start, const int64_t* dst_start, const uint32_t* len,
+                             int nlist, int ld, int chb, uint8_t* arena, hipStream_t stream) {
+    if (nlist == 0) return;
+    FA_THROW_IF_NOT(ld % 4 == 0 && chb % 4 == 0);
+    const unsigned gy = nlist >= 1024 ? 1u : nlist >= 64 ? 8u : 64u;
+    hipLaunchKernelGGL(ivfsq_pack_lists_kernel, dim3((unsigned)nlist, gy), dim3(256), 0, stream, rows, src_start, dst_start,
+                       len, ld, chb, arena);
+    HIP_CHECK(hipGetLastError());
+}
+__global__ void ivfsq_unpack_rows_kernel(const uint8_t* __restrict__ arena, int64_t row0, int64_t n, int ld, int chb,
+                                         uint8_t* __restrict__ rows) {
+    const int wpr = ld >> 2;
+    const int64_t words = n * wpr;
+    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < words; w += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = w / wpr;
+        const int byte = (int)(w - i * wpr) * 4;
+        *(uint32_t*)(rows + i * ld + byte) = *(const uint32_t*)(arena + sq_code_offset(row0 + i, byte, ld, chb));
+    }
+}
+void launch_ivfsq_unpack_rows(const uint8_t* arena, int64_t row0, int64_t n, int ld, int chb, uint8_t* rows,
+                              hipStream_t stream) {
+    if (n == 0) return;
+    const unsigned grid = (unsigned)std::min<int64_t>(div_up(n * (ld >> 2), 256), 4096);
+    hipLaunchKernelGGL(ivfsq_unpack_rows_kernel, dim3(grid), dim3(256), 0, stream, arena, row0, n, ld, chb, rows);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -311,6 +311,14 @@ struct IvfFusedParams {
 // code types of the scalar quantizer as the scan kernel sees them (16 components per lane chunk)
 enum SqCodeType { SQ_U8 = 0, SQ_U4 = 1, SQ_U6 = 2, SQ_F16 = 3 };
 inline int sq_chunk_bytes(int ct) { return ct == SQ_U8 ? 16 : ct == SQ_U4 ? 8 : ct == SQ_U6 ? 12 : 32; }
+// Scalar-quantizer code layout: the arena is a sequence of 64-row blocks (lists start on block boundaries); a block
+// holds its rows chunk-major, [chunk][64 rows][chunk bytes] with a chunk = 16 components, so that a wavefront reads
+// one chunk of all 64 rows with one coalesced load and lane l owns row l.  ld = bytes per row = chunks * chunk bytes.
+// Byte offset of byte `byte` (0 .. ld) of arena row `row`:
+__host__ __device__ inline int64_t sq_code_offset(int64_t row, int byte, int ld, int chb) {
+    const int c = byte / chb;
+    return (row >> 6) * 64 * (int64_t)ld + (int64_t)c * 64 * chb + (row & 63) * chb + (byte - c * chb);
+}
 // table rows the fused scalar-quantizer scan keeps in LDS: the scale row, then one row per probe of a workgroup (L2
 // with residual encoding: the query residual changes with the list) or a single one
 inline int sq_table_rows(int metric, bool by_residual, int npc) { return 1 + ((metric == METRIC_L2 && by_residual) ? npc : 1); }
@@ -422,6 +430,13 @@ enum SqQuantizerType { QT_8bit = 0, QT_4bit = 1, QT_8bit_uniform = 2, QT_4bit_un
 void launch_ivfsq_encode_append(int qtype, const float* x, int64_t ldx, int n, int d, const int64_t* labels,
                                 const int64_t* dest, const float* centroids, int64_t ldc, bool by_residual,
                                 const float* vmin, const float* vdiff, uint8_t* arena, int ld, hipStream_t stream);
+// plain rows [n][ld] (the reference's entries, zero padded to whole chunks) <-> the block layout: list l's rows
+// src_start[l] .. of `rows` go to arena rows dst_start[l] .. (pack); rows [row0, row0 + n) of the arena come back as
+// plain rows (unpack)
+void launch_ivfsq_pack_lists(const uint8_t* rows, const int64_t* src_start, const int64_t* dst_start, const uint32_t* len,
+                             int nlist, int ld, int chb, uint8_t* arena, hipStream_t stream);
+void launch_ivfsq_unpack_rows(const uint8_t* arena, int64_t row0, int64_t n, int ld, int chb, uint8_t* rows,
+                              hipStream_t stream);
 // per-dimension minimum and maximum of x [n][ldx] over column blocks: out [nblocks][2][d] (min row, max row)
 int ivfsq_minmax_blocks(int64_t n);
 void launch_ivfsq_minmax(const float* x, int64_t ldx, int64_t n, int d, float* out, hipStream_t stream);

