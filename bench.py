@@ -339,6 +339,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ivf-legs", default="ivfpq,ivfflat,ivfsq", help="comma-separated subset of the IVF legs to run")
     ap.add_argument("--no-ivf", action="store_true", help="skip the IVF4096,PQ64 / IVF4096,Flat / IVF4096,SQ8 legs")
     ap.add_argument("--multi-gpu", choices=["replicas", "shards"], default="replicas",
                     help="layout of the FLAT leg at N > 1: replicas = every GPU holds the database, queries are split "
@@ -513,7 +514,7 @@ def main():
             except Exception as e:  # noqa: BLE001
                 line["cpu_baseline"] = {"error": repr(e)[:200]}
         if not args.no_ivf:
-            for kind in ("ivfpq", "ivfflat", "ivfsq"):
+            for kind in [v for v in args.ivf_legs.split(",") if v in ("ivfpq", "ivfflat", "ivfsq")]:
                 try:
                     line[kind], _ = ivf_leg(kind, res, xt, xb, xq, xq_dev, gI[:, 0], max(2, args.steps // 2), torch,
                                             with_cpu=not args.no_cpu_baseline)

@@ -1848,9 +1848,9 @@ void GpuIndexIVF::search_core_body_(idx_t n, const float* x, idx_t k, float* dis
             fp.G = (int)div_up(np, fp.npc);
             fp.out_dis = dD;
             fp.out_ids = dI;
-            // large batches of IVFPQ: the final selection of a query runs in its own launch (select_k_kernel)
+            // large batches: the final selection of a query runs in its own launch (ivf_finish_kernel)
             static const char* defer_env = getenv("FAISS_AMD_IVF_DEFER"); // timing experiments only: 0 / 1
-            fp.defer_finish = fp.G == 1 && fp.kind == 1 && ni >= want && (!defer_env || atoi(defer_env) != 0) ? 1 : 0;
+            fp.defer_finish = fp.G == 1 && ni >= want && (!defer_env || atoi(defer_env) != 0) ? 1 : 0;
             if (defer_env && atoi(defer_env) == 1 && fp.G == 1) fp.defer_finish = 1;
             if (fp.G > 1 || fp.defer_finish) {
                 const size_t per_q = fp.defer_finish ? (size_t)fp.cap : (size_t)fp.G * k;

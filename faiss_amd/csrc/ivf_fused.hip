@@ -173,6 +173,25 @@ __device__ __forceinline__ void fused_load_probes(const IvfFusedParams& p, int q
         bound += (int)(chunk);                                                         \
     } while (0)
 
+// The same for a loop WITHOUT a barrier per iteration (the wavefronts of the workgroup drift apart between two cuts):
+// everybody's appends are complete before the counter is read, and nobody appends again before everybody has read it.
+#define FUSED_MAKE_ROOM_DRIFT(chunk)                                                   \
+    do {                                                                               \
+        if (bound + FB > p.cap) {                                                      \
+            __syncthreads();                                                           \
+            const int n_ = (int)L.ctl->cnt;                                            \
+            __syncthreads();                                                           \
+            bound = n_;                                                                \
+            if (n_ + FB > p.cap) {                                                     \
+                const u64 kth_ = wg_select_kth<FB>(L.res, n_, p.k, L.hist, L.ctl);     \
+                wg_compact<FB>(L.res, n_, kth_, L.ctl);                                \
+                tau = kth_;                                                            \
+                bound = p.k;                                                           \
+            }                                                                          \
+        }                                                                              \
+        bound += (int)(chunk);                                                         \
+    } while (0)
+
 // final k-selection, position -> user id, ordering, write-out (or partial keys when G > 1)
 template <int FB>
 __device__ __forceinline__ void fused_finish(const IvfFusedParams& p, int q, int g, const FusedLds& L) {
@@ -829,11 +848,10 @@ __global__ void __launch_bounds__(SQ_FB, 4) ivfsq_fused_kernel(IvfFusedParams p)
                 pass = key < tau;
             }
             wg_append(L.res, L.ctl, pass, key);
-            __syncthreads();
         }
     };
     // work item k of a wavefront: block blk_begin + wave + NWV * (k / ngrp), chunk group k % ngrp; all wavefronts of the
-    // workgroup walk the items in lockstep (the reservoir bookkeeping needs workgroup-uniform barriers)
+    // workgroup walk the same item sequence (the reservoir cuts are workgroup-wide), without a barrier per item
     unsigned base = blk_begin;
     int grp = 0;
     auto next_item = [&](unsigned& nb, int& ng) {
@@ -847,7 +865,7 @@ __global__ void __launch_bounds__(SQ_FB, 4) ivfsq_fused_kernel(IvfFusedParams p)
     for (;;) {
         if (base >= blk_end) break;
         {
-            if (grp == 0) FUSED_MAKE_ROOM(FB);
+            if (grp == 0) FUSED_MAKE_ROOM_DRIFT(FB);
             unsigned nb;
             int ng;
             next_item(nb, ng);
@@ -857,7 +875,7 @@ __global__ void __launch_bounds__(SQ_FB, 4) ivfsq_fused_kernel(IvfFusedParams p)
         }
         if (base >= blk_end) break;
         {
-            if (grp == 0) FUSED_MAKE_ROOM(FB);
+            if (grp == 0) FUSED_MAKE_ROOM_DRIFT(FB);
             unsigned nb;
             int ng;
             next_item(nb, ng);
