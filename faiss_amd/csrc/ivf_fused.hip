@@ -656,7 +656,8 @@ __global__ void __launch_bounds__(FB_MAX) ivfflat_fused_kernel(IvfFusedParams p)
 // both read from LDS as wave-wide broadcasts (every row of a block belongs to the same list):
 //   L2: tt = fmaf(-code, s_i, a_i), a_i = (q_i [- centroid_i]) - b_i   (fp16: tt = a_i - half)   acc = fmaf(tt, tt, acc)
 //   IP: acc = fmaf(w_i, code, acc), w_i = q_i * s_i                     (fp16: w_i = q_i);  + <q, b> (+ coarse term)
-// as ONE sequential chain over the dimensions, i.e. the distance to the reconstruction b_i + s_i * code_i of
+// as two sequential chains, one over the even and one over the odd dimensions (packed fp32 math), added at the end:
+// the distance to the reconstruction b_i + s_i * code_i of
 // faiss::ScalarQuantizer (quantizers.h:92-150: vmin + (code + 0.5) / 255 * vdiff) without materialising it.  With
 // residual encoding the L2 row a changes with the list: one row per probe of the workgroup (built once per query,
 // nprobe x d x 4 bytes).  Two stages per wavefront: the next (block, chunk group) is in flight while the current one is
@@ -687,17 +688,27 @@ __device__ __forceinline__ float sq_comp(const unsigned (&w)[SqChunk<CT>::WORDS]
         return (float)__builtin_bit_cast(_Float16, hw);
     }
 }
+// components E, E + 1 of a chunk folded into the (even, odd) pair of chains with packed fp32 math (v_pk_fma_f32: two
+// IEEE fmas per instruction): acc[0] runs over the even dimensions, acc[1] over the odd ones
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int METRIC, int CT, int E>
-__device__ __forceinline__ void sq_fold(const unsigned (&w)[SqChunk<CT>::WORDS], const float* sv, const float* av, float& acc) {
+__device__ __forceinline__ void sq_fold(const unsigned (&w)[SqChunk<CT>::WORDS], const float* sv, const float* av, f32x2& acc) {
     if constexpr (E < 16) {
-        const float cf = sq_comp<CT, E>(w);
+        const f32x2 cf = {sq_comp<CT, E>(w), sq_comp<CT, E + 1>(w)};
+        const f32x2 a2 = {av[E], av[E + 1]};
         if (METRIC == METRIC_L2) {
-            const float tt = CT == SQ_F16 ? av[E] - cf : __fmaf_rn(-cf, sv[E], av[E]);
-            acc = __fmaf_rn(tt, tt, acc);
+            f32x2 tt;
+            if (CT == SQ_F16) {
+                tt = a2 - cf;
+            } else {
+                const f32x2 s2 = {sv[E], sv[E + 1]};
+                tt = __builtin_elementwise_fma(-cf, s2, a2);
+            }
+            acc = __builtin_elementwise_fma(tt, tt, acc);
         } else {
-            acc = __fmaf_rn(av[E], cf, acc);
+            acc = __builtin_elementwise_fma(a2, cf, acc);
         }
-        sq_fold<METRIC, CT, E + 1>(w, sv, av, acc);
+        sq_fold<METRIC, CT, E + 2>(w, sv, av, acc);
     }
 }
 
@@ -812,10 +823,10 @@ __global__ void __launch_bounds__(SQ_FB, 4) ivfsq_fused_kernel(IvfFusedParams p)
 
     u64 tau = ~0ull;
     int bound = 0;
-    float acc = 0.f; // this lane's row, carried over the chunk groups of a block
+    f32x2 acc = {0.f, 0.f}; // this lane's row (even / odd dimensions), carried over the chunk groups of a block
     // fold one staged chunk group; behind the last group of a block: key + append
     auto scan = [&](const Stage& st, int grp) {
-        if (grp == 0) acc = 0.f;
+        if (grp == 0) acc = f32x2{0.f, 0.f};
         if ((unsigned)lane < st.rem) {
             const float* arow = tab_a + (per_probe ? st.t * dsq : 0);
 #pragma unroll
@@ -842,7 +853,7 @@ __global__ void __launch_bounds__(SQ_FB, 4) ivfsq_fused_kernel(IvfFusedParams p)
             bool pass = false;
             u64 key = 0;
             if ((unsigned)lane < st.rem) {
-                float dis = acc;
+                float dis = acc[0] + acc[1];
                 if (METRIC != METRIC_L2) dis = (dis + qb) + tab_c[st.t];
                 key = ((u64)ordkey<METRIC>(dis) << 32) | (u64)(st.pos0 + (unsigned)lane);
                 pass = key < tau;

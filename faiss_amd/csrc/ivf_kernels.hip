@@ -245,7 +245,19 @@ __global__ void ivf_chunk_scan_kernel(uint32_t* __restrict__ hist, int nchunks, 
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= nlist) return;
     uint32_t run = list_len[l];
-    for (int c = 0; c < nchunks; ++c) {
+    // eight chunks per round trip: the loads of a group are independent of the running offset
+    int c = 0;
+    for (; c + 8 <= nchunks; c += 8) {
+        uint32_t t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = hist[(int64_t)(c + u) * nlist + l];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            hist[(int64_t)(c + u) * nlist + l] = run;
+            run += t[u];
+        }
+    }
+    for (; c < nchunks; ++c) {
         const uint32_t t = hist[(int64_t)c * nlist + l];
         hist[(int64_t)c * nlist + l] = run;
         run += t;

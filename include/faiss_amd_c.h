@@ -163,8 +163,8 @@ int faiss_amd_IndexIVF_set_nprobe(FaissAmdIndex* index, int nprobe);
 int faiss_amd_IndexIVF_get_list_size(const FaissAmdIndex* index, faiss_amd_idx_t list_no, size_t* p_size);
 int faiss_amd_IndexIVF_get_list_ids(const FaissAmdIndex* index, faiss_amd_idx_t list_no,
                                     faiss_amd_idx_t* ids_out);
-/* payload of one list in the reference's CPU layout: d floats (IVFFlat) or M bytes (IVFPQ)
- * per entry; out must hold list_size * code_size bytes */
+/* payload of one list in the reference's CPU layout: d floats (IVFFlat), M bytes (IVFPQ) or sq.code_size bytes
+ * (IVF scalar quantizer) per entry; out must hold list_size * code_size bytes */
 int faiss_amd_IndexIVF_get_list_codes(const FaissAmdIndex* index, faiss_amd_idx_t list_no, uint8_t* out);
 int faiss_amd_IndexIVF_code_size(const FaissAmdIndex* index, size_t* p_code_size);
 /* coarse centroids out: nlist x d floats (quantizer->reconstruct_n) */
@@ -172,8 +172,8 @@ int faiss_amd_IndexIVF_get_centroids(const FaissAmdIndex* index, float* centroid
 /* k-means iterations / seed of train(): ClusteringParameters niter, seed (faiss/Clustering.h:24-63) */
 int faiss_amd_IndexIVF_set_clustering(FaissAmdIndex* index, int niter, int seed);
 
-/* copyFrom(IndexIVFFlat / IndexIVFPQ) decomposed into plain arrays
- * (faiss/gpu/GpuIndexIVFFlat.cu copyFrom, faiss/gpu/GpuIndexIVFPQ.cu:98-168):
+/* copyFrom(IndexIVFFlat / IndexIVFPQ / IndexIVFScalarQuantizer) decomposed into plain arrays
+ * (faiss/gpu/GpuIndexIVFFlat.cu copyFrom, faiss/gpu/GpuIndexIVFPQ.cu:98-168, GpuIndexIVFScalarQuantizer.cu:96-140):
  *   centroids   nlist x d floats                 (index->quantizer, an IndexFlat)
  *   pq          M x 256 x (d/M) floats           (index->pq.centroids)
  *   list_sizes  nlist counts, codes/ids = the lists' payloads concatenated in list order

@@ -597,7 +597,7 @@ int orc_sq_decode(int qtype, int d, idx_t n, const uint8_t* codes, const float* 
 /* Search: IVFSQScannerL2 / IVFSQScannerIP (faiss/impl/scalar_quantizer/scanners.h:34-140).  L2: distance between the
  * query (by_residual: minus the list centroid) and the reconstruction; IP: <q, reconstruction> (+ the coarse inner
  * product with by_residual).  Arithmetic and summation order of the gfx950 scan (ivf_fused.hip ivfsq_fused_kernel: one
- * lane per stored row, ONE chain over the dimensions in order):
+ * lane per stored row, two chains -- even and odd dimensions, the two halves of its packed fp32 math -- added at the end):
  *   L2: a_j = (q_j [- centroid_j]) - b_j;  tt = fmaf(-code_j, s_j, a_j)  (fp16: a_j - half_j);  acc = fmaf(tt, tt, acc)
  *   IP: w_j = q_j * s_j;  acc = fmaf(w_j, code_j, acc)  (fp16: w_j = q_j);  dis = (acc + <q, b>) + coarse
  * with <q, b> one fmaf chain as well. */
@@ -651,16 +651,17 @@ int orc_ivfsq_search(int qtype, int by_residual, int metric, int d, int nlist, c
             const float coarse = (metric != ORC_METRIC_L2 && by_residual) ? cD[(size_t)q * nprobe + p] : 0.f;
             for (uint32_t i = 0; i < len; i++) {
                 const uint8_t* code = lc + (size_t)i * cs;
-                float dis = 0.f;
+                float ch[2] = {0.f, 0.f}; /* the chain of the even and of the odd dimensions */
                 for (int j = 0; j < d; j++) {
                     const float cf = orc_sq_component(qtype, code, j);
                     if (metric == ORC_METRIC_L2) {
                         const float tt = qtype == 4 ? a[j] - cf : fmaf(-cf, s[j], a[j]);
-                        dis = fmaf(tt, tt, dis);
+                        ch[j & 1] = fmaf(tt, tt, ch[j & 1]);
                     } else {
-                        dis = fmaf(a[j], cf, dis);
+                        ch[j & 1] = fmaf(a[j], cf, ch[j & 1]);
                     }
                 }
+                float dis = ch[0] + ch[1];
                 if (metric != ORC_METRIC_L2) dis = (dis + qb) + coarse;
                 pos2id[pos] = lid[i];
                 topk_push(&t, dis, pos);

