@@ -118,6 +118,22 @@ def load_library():
         "faiss_amd_bfKnn_tiling": (i32, [vp, vp, sz, sz]),
         "faiss_amd_test_select": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp]),
         "faiss_amd_GpuIndexIVF_search_with_params": (i32, [vp, i64, vp, i64, vp, vp, vp]),
+        "faiss_amd_IDSelectorAll_new": (i32, [P(vp)]),
+        "faiss_amd_IDSelectorRange_new": (i32, [P(vp), i64, i64]),
+        "faiss_amd_IDSelectorBatch_new": (i32, [P(vp), sz, vp]),
+        "faiss_amd_IDSelectorArray_new": (i32, [P(vp), sz, vp]),
+        "faiss_amd_IDSelectorBitmap_new": (i32, [P(vp), sz, vp]),
+        "faiss_amd_IDSelectorNot_new": (i32, [P(vp), vp]),
+        "faiss_amd_IDSelectorAnd_new": (i32, [P(vp), vp, vp]),
+        "faiss_amd_IDSelectorOr_new": (i32, [P(vp), vp, vp]),
+        "faiss_amd_IDSelectorXOr_new": (i32, [P(vp), vp, vp]),
+        "faiss_amd_IDSelector_is_member": (i32, [vp, i64]),
+        "faiss_amd_IDSelector_free": (None, [vp]),
+        "faiss_amd_SearchParameters_new": (i32, [P(vp), vp]),
+        "faiss_amd_SearchParametersIVF_new_with": (i32, [P(vp), vp, sz, sz]),
+        "faiss_amd_SearchParameters_free": (None, [vp]),
+        "faiss_amd_Index_search_with_params": (i32, [vp, i64, vp, i64, vp, vp, vp]),
+        "faiss_amd_GpuIndexIVF_search_preassigned_with_params": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, vp]),
         "faiss_amd_GpuIndexIVF_stored_vectors": (i32, [vp, P(i64)]),
         "faiss_amd_GpuIndexIVF_arena_stats": (i32, [vp, P(i64), P(i64), P(i64)]),
     }
@@ -247,18 +263,29 @@ class Index:
             raise ValueError("ids must have one entry per vector")
         _check(self._lib.faiss_amd_Index_add_with_ids(self._h, x.shape[0], _ptr(x), _ptr(ids)))
 
-    def search(self, x, k):
+    def search(self, x, k, params=None):
+        """D, I = index.search(x, k, params=None) (faiss/python/class_wrappers.py replacement_search); params:
+        SearchParameters(sel=...) / SearchParametersIVF(sel=..., nprobe=...)"""
         x = _f32(x, self.d)
         n = x.shape[0]
         D = np.empty((n, k), dtype=np.float32)
         I = np.empty((n, k), dtype=np.int64)
-        _check(self._lib.faiss_amd_Index_search(self._h, n, _ptr(x), int(k), _ptr(D), _ptr(I)))
+        if params is None:
+            _check(self._lib.faiss_amd_Index_search(self._h, n, _ptr(x), int(k), _ptr(D), _ptr(I)))
+        else:
+            with _params_handle(self._lib, params) as h:
+                _check(self._lib.faiss_amd_Index_search_with_params(self._h, n, _ptr(x), int(k), h, _ptr(D), _ptr(I)))
         return D, I
 
-    def search_ptr(self, n, x_ptr, k, d_ptr, i_ptr):
+    def search_ptr(self, n, x_ptr, k, d_ptr, i_ptr, params=None):
         """Raw-pointer search (host or device addresses), e.g. torch tensors' ``data_ptr()``."""
-        _check(self._lib.faiss_amd_Index_search(self._h, int(n), ctypes.c_void_p(x_ptr), int(k),
-                                                ctypes.c_void_p(d_ptr), ctypes.c_void_p(i_ptr)))
+        if params is None:
+            _check(self._lib.faiss_amd_Index_search(self._h, int(n), ctypes.c_void_p(x_ptr), int(k),
+                                                    ctypes.c_void_p(d_ptr), ctypes.c_void_p(i_ptr)))
+        else:
+            with _params_handle(self._lib, params) as h:
+                _check(self._lib.faiss_amd_Index_search_with_params(self._h, int(n), ctypes.c_void_p(x_ptr), int(k), h,
+                                                                    ctypes.c_void_p(d_ptr), ctypes.c_void_p(i_ptr)))
 
     def add_ptr(self, n, x_ptr):
         _check(self._lib.faiss_amd_Index_add(self._h, int(n), ctypes.c_void_p(x_ptr)))
@@ -404,9 +431,9 @@ class _GpuIndexIVF(Index):
         _check(self._lib.faiss_amd_IndexIVF_quantizer_search(self._h, x.shape[0], _ptr(x), int(k), _ptr(D), _ptr(I)))
         return D, I
 
-    def search_preassigned(self, x, k, Iq, Dq):
-        """faiss python `index.search_preassigned(x, k, Iq, Dq)` (class_wrappers.py replacement_search_preassigned):
-        Iq / Dq are the [n, nprobe] list ids / coarse distances of the queries."""
+    def search_preassigned(self, x, k, Iq, Dq, params=None):
+        """faiss python `index.search_preassigned(x, k, Iq, Dq, params=None)` (class_wrappers.py
+        replacement_search_preassigned): Iq / Dq are the [n, nprobe] list ids / coarse distances of the queries."""
         x = _f32(x, self.d)
         n = x.shape[0]
         Iq = np.ascontiguousarray(Iq, dtype=np.int64)
@@ -415,22 +442,21 @@ class _GpuIndexIVF(Index):
             raise ValueError("Iq and Dq must be [n, nprobe]")
         D = np.empty((n, k), dtype=np.float32)
         I = np.empty((n, k), dtype=np.int64)
-        _check(self._lib.faiss_amd_GpuIndexIVF_search_preassigned(self._h, n, _ptr(x), int(k), _ptr(Iq), _ptr(Dq),
-                                                                  _ptr(D), _ptr(I)))
+        if params is None:
+            _check(self._lib.faiss_amd_GpuIndexIVF_search_preassigned(self._h, n, _ptr(x), int(k), _ptr(Iq), _ptr(Dq),
+                                                                      _ptr(D), _ptr(I)))
+        else:
+            with _params_handle(self._lib, params) as h:
+                _check(self._lib.faiss_amd_GpuIndexIVF_search_preassigned_with_params(
+                    self._h, n, _ptr(x), int(k), _ptr(Iq), _ptr(Dq), h, _ptr(D), _ptr(I)))
         return D, I
 
     def search(self, x, k, params=None):
-        """index.search(x, k, params=SearchParametersIVF(nprobe=...)): per-call nprobe (faiss/IndexIVF.h:70-80)"""
-        if params is None:
-            return Index.search(self, x, k)
-        x = _f32(x, self.d)
-        n = x.shape[0]
-        D = np.empty((n, k), dtype=np.float32)
-        I = np.empty((n, k), dtype=np.int64)
-        c = ctypes.c_int(int(getattr(params, "nprobe", params)))
-        _check(self._lib.faiss_amd_GpuIndexIVF_search_with_params(self._h, n, _ptr(x), int(k), ctypes.byref(c), _ptr(D),
-                                                                  _ptr(I)))
-        return D, I
+        """index.search(x, k, params=SearchParametersIVF(nprobe=..., sel=...)): per-call nprobe (faiss/IndexIVF.h:70-80)
+        and / or an IDSelector on the stored ids; a bare integer is taken as nprobe"""
+        if params is not None and not isinstance(params, SearchParameters):
+            params = SearchParametersIVF(nprobe=int(params))
+        return Index.search(self, x, k, params)
 
     @property
     def stored_vectors(self):
@@ -509,11 +535,135 @@ class _GpuIndexIVF(Index):
         _check(self._lib.faiss_amd_IndexIVF_copy_lists(self._h, _ptr(ls), _ptr(codes), _ptr(ids)))
 
 
-class SearchParametersIVF:
-    """faiss.SearchParametersIVF (faiss/IndexIVF.h:70-80): nprobe override of one search call"""
+class IDSelector:
+    """faiss.IDSelector (faiss/impl/IDSelector.h:21-24): a predicate on the labels a search may return (row numbers for
+    GpuIndexFlat, stored ids for the IVF indexes).  Evaluated on the device by the search kernels."""
 
-    def __init__(self, nprobe=0):
+    def __init__(self):
+        self._lib = load_library()
+        self._h = ctypes.c_void_p()
+        self._keep = []  # operands / arrays that must outlive this selector
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.faiss_amd_IDSelector_free(h)
+
+    def is_member(self, i):
+        return bool(self._lib.faiss_amd_IDSelector_is_member(self._h, int(i)))
+
+    def __invert__(self):
+        return IDSelectorNot(self)
+
+    def __and__(self, other):
+        return IDSelectorAnd(self, other)
+
+    def __or__(self, other):
+        return IDSelectorOr(self, other)
+
+    def __xor__(self, other):
+        return IDSelectorXOr(self, other)
+
+
+class IDSelectorAll(IDSelector):
+    def __init__(self):
+        super().__init__()
+        _check(self._lib.faiss_amd_IDSelectorAll_new(ctypes.byref(self._h)))
+
+
+class IDSelectorRange(IDSelector):
+    """imin <= id < imax (faiss/impl/IDSelector.h:71-92)"""
+
+    def __init__(self, imin, imax, assume_sorted=False):
+        super().__init__()
+        self.imin, self.imax = int(imin), int(imax)
+        _check(self._lib.faiss_amd_IDSelectorRange_new(ctypes.byref(self._h), self.imin, self.imax))
+
+
+class IDSelectorBatch(IDSelector):
+    """the listed ids (faiss/impl/IDSelector.h:98-141: IDSelectorArray / IDSelectorBatch); the ids are copied"""
+
+    def __init__(self, ids):
+        super().__init__()
+        ids = np.ascontiguousarray(ids, dtype=np.int64).reshape(-1)
+        _check(self._lib.faiss_amd_IDSelectorBatch_new(ctypes.byref(self._h), ids.size, _ptr(ids)))
+
+
+IDSelectorArray = IDSelectorBatch
+
+
+class IDSelectorBitmap(IDSelector):
+    """id selected iff id // 8 < len(bitmap) and bit id % 8 of bitmap[id // 8] is set (IDSelector.h:145-158); copied"""
+
+    def __init__(self, bitmap):
+        super().__init__()
+        bitmap = np.ascontiguousarray(bitmap, dtype=np.uint8).reshape(-1)
+        _check(self._lib.faiss_amd_IDSelectorBitmap_new(ctypes.byref(self._h), bitmap.size, _ptr(bitmap)))
+
+
+class IDSelectorNot(IDSelector):
+    def __init__(self, sel):
+        super().__init__()
+        self._keep.append(sel)
+        _check(self._lib.faiss_amd_IDSelectorNot_new(ctypes.byref(self._h), sel._h))
+
+
+class _IDSelectorBinary(IDSelector):
+    _ctor = None
+
+    def __init__(self, lhs, rhs):
+        super().__init__()
+        self._keep += [lhs, rhs]
+        _check(getattr(self._lib, self._ctor)(ctypes.byref(self._h), lhs._h, rhs._h))
+
+
+class IDSelectorAnd(_IDSelectorBinary):
+    _ctor = "faiss_amd_IDSelectorAnd_new"
+
+
+class IDSelectorOr(_IDSelectorBinary):
+    _ctor = "faiss_amd_IDSelectorOr_new"
+
+
+class IDSelectorXOr(_IDSelectorBinary):
+    _ctor = "faiss_amd_IDSelectorXOr_new"
+
+
+class SearchParameters:
+    """faiss.SearchParameters (faiss/Index.h:86-93): sel = IDSelector or None"""
+
+    def __init__(self, sel=None):
+        self.sel = sel
+
+
+class SearchParametersIVF(SearchParameters):
+    """faiss.SearchParametersIVF (faiss/IndexIVF.h:70-80): nprobe override of one search call (0 = the index's own),
+    sel = IDSelector on the stored ids"""
+
+    def __init__(self, nprobe=0, sel=None, max_codes=0):
+        super().__init__(sel)
         self.nprobe = int(nprobe)
+        self.max_codes = int(max_codes)
+
+
+class _params_handle:
+    """context manager: the C handle of a SearchParameters object for the duration of one call"""
+
+    def __init__(self, lib, params):
+        self._lib, self._h = lib, ctypes.c_void_p()
+        sel = params.sel._h if params.sel is not None else None
+        if isinstance(params, SearchParametersIVF):
+            _check(lib.faiss_amd_SearchParametersIVF_new_with(ctypes.byref(self._h), sel, max(params.nprobe, 0),
+                                                              params.max_codes))
+        else:
+            _check(lib.faiss_amd_SearchParameters_new(ctypes.byref(self._h), sel))
+
+    def __enter__(self):
+        return self._h
+
+    def __exit__(self, *exc):
+        self._lib.faiss_amd_SearchParameters_free(self._h)
+        return False
 
 
 class GpuIndexIVFFlat(_GpuIndexIVF):

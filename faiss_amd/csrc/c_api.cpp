@@ -624,6 +624,114 @@ int faiss_amd_GpuIndexIVF_search_with_params(const FaissAmdIndex* index, faiss_a
     as<GpuIndexIVF>(index, "GpuIndexIVF")->search(n, x, k, distances, labels, &sp);
     FA_CATCH
 }
+// ---- IDSelector / SearchParameters
+struct FaissAmdIDSelector_H {
+    std::unique_ptr<IDSelector> sel;
+};
+struct FaissAmdSearchParameters_H {
+    std::unique_ptr<SearchParameters> sp;
+};
+static const IDSelector* S(const FaissAmdIDSelector* h) {
+    if (!h || !h->sel) FA_THROW_MSG("null IDSelector handle");
+    return h->sel.get();
+}
+static int new_selector(FaissAmdIDSelector** p_sel, IDSelector* sel) {
+    std::unique_ptr<IDSelector> guard(sel);
+    if (!p_sel) FA_THROW_MSG("null output handle");
+    *p_sel = new FaissAmdIDSelector_H{std::move(guard)};
+    return 0;
+}
+int faiss_amd_IDSelectorAll_new(FaissAmdIDSelector** p_sel) {
+    FA_TRY
+    new_selector(p_sel, new IDSelectorAll());
+    FA_CATCH
+}
+int faiss_amd_IDSelectorRange_new(FaissAmdIDSelector** p_sel, faiss_amd_idx_t imin, faiss_amd_idx_t imax) {
+    FA_TRY
+    new_selector(p_sel, new IDSelectorRange(imin, imax));
+    FA_CATCH
+}
+int faiss_amd_IDSelectorBatch_new(FaissAmdIDSelector** p_sel, size_t n, const faiss_amd_idx_t* ids) {
+    FA_TRY
+    FA_THROW_IF_NOT_MSG(n == 0 || ids, "null id array");
+    new_selector(p_sel, new IDSelectorBatch(n, ids));
+    FA_CATCH
+}
+int faiss_amd_IDSelectorArray_new(FaissAmdIDSelector** p_sel, size_t n, const faiss_amd_idx_t* ids) {
+    return faiss_amd_IDSelectorBatch_new(p_sel, n, ids);
+}
+int faiss_amd_IDSelectorBitmap_new(FaissAmdIDSelector** p_sel, size_t n, const uint8_t* bitmap) {
+    FA_TRY
+    FA_THROW_IF_NOT_MSG(n == 0 || bitmap, "null bitmap");
+    new_selector(p_sel, new IDSelectorBitmap(n, bitmap));
+    FA_CATCH
+}
+int faiss_amd_IDSelectorNot_new(FaissAmdIDSelector** p_sel, const FaissAmdIDSelector* sel) {
+    FA_TRY
+    new_selector(p_sel, new IDSelectorNot(S(sel)));
+    FA_CATCH
+}
+int faiss_amd_IDSelectorAnd_new(FaissAmdIDSelector** p_sel, const FaissAmdIDSelector* lhs, const FaissAmdIDSelector* rhs) {
+    FA_TRY
+    new_selector(p_sel, new IDSelectorBinary(SEL_AND, S(lhs), S(rhs)));
+    FA_CATCH
+}
+int faiss_amd_IDSelectorOr_new(FaissAmdIDSelector** p_sel, const FaissAmdIDSelector* lhs, const FaissAmdIDSelector* rhs) {
+    FA_TRY
+    new_selector(p_sel, new IDSelectorBinary(SEL_OR, S(lhs), S(rhs)));
+    FA_CATCH
+}
+int faiss_amd_IDSelectorXOr_new(FaissAmdIDSelector** p_sel, const FaissAmdIDSelector* lhs, const FaissAmdIDSelector* rhs) {
+    FA_TRY
+    new_selector(p_sel, new IDSelectorBinary(SEL_XOR, S(lhs), S(rhs)));
+    FA_CATCH
+}
+int faiss_amd_IDSelector_is_member(const FaissAmdIDSelector* sel, faiss_amd_idx_t id) {
+    FA_TRY
+    return S(sel)->is_member(id) ? 1 : 0;
+    FA_CATCH
+}
+void faiss_amd_IDSelector_free(FaissAmdIDSelector* sel) {
+    delete sel;
+}
+int faiss_amd_SearchParameters_new(FaissAmdSearchParameters** p_sp, const FaissAmdIDSelector* sel) {
+    FA_TRY
+    if (!p_sp) FA_THROW_MSG("null output handle");
+    std::unique_ptr<SearchParameters> sp(new SearchParameters());
+    sp->sel = sel ? S(sel) : nullptr;
+    *p_sp = new FaissAmdSearchParameters_H{std::move(sp)};
+    FA_CATCH
+}
+int faiss_amd_SearchParametersIVF_new_with(FaissAmdSearchParameters** p_sp, const FaissAmdIDSelector* sel, size_t nprobe,
+                                           size_t max_codes) {
+    FA_TRY
+    if (!p_sp) FA_THROW_MSG("null output handle");
+    FA_THROW_IF_NOT_MSG(max_codes == 0, "max_codes is not supported (faiss/gpu/GpuIndexIVF.cu:372-375)");
+    FA_THROW_IF_NOT_MSG(nprobe <= (size_t)kMaxSelectionK, "nprobe must be in [1, 2048]");
+    std::unique_ptr<SearchParametersIVF> sp(new SearchParametersIVF());
+    sp->sel = sel ? S(sel) : nullptr;
+    sp->nprobe = (int)nprobe;
+    *p_sp = new FaissAmdSearchParameters_H{std::move(sp)};
+    FA_CATCH
+}
+void faiss_amd_SearchParameters_free(FaissAmdSearchParameters* sp) {
+    delete sp;
+}
+int faiss_amd_Index_search_with_params(const FaissAmdIndex* index, faiss_amd_idx_t n, const float* x, faiss_amd_idx_t k,
+                                       const FaissAmdSearchParameters* params, float* distances, faiss_amd_idx_t* labels) {
+    FA_TRY
+    I(index)->search(n, x, k, distances, labels, params ? params->sp.get() : nullptr);
+    FA_CATCH
+}
+int faiss_amd_GpuIndexIVF_search_preassigned_with_params(const FaissAmdIndex* index, faiss_amd_idx_t n, const float* x,
+                                                         faiss_amd_idx_t k, const faiss_amd_idx_t* assign,
+                                                         const float* centroid_dis, const FaissAmdSearchParameters* params,
+                                                         float* distances, faiss_amd_idx_t* labels) {
+    FA_TRY
+    as<GpuIndexIVF>(index, "GpuIndexIVF")
+            ->search_preassigned(n, x, k, assign, centroid_dis, distances, labels, params ? params->sp.get() : nullptr);
+    FA_CATCH
+}
 int faiss_amd_GpuIndexIVF_stored_vectors(const FaissAmdIndex* index, faiss_amd_idx_t* p_stored) {
     FA_TRY
     *p_stored = as<GpuIndexIVF>(index, "GpuIndexIVF")->stored_vectors();

@@ -281,6 +281,7 @@ __global__ void __launch_bounds__(512, 2) flat_scan_kernel(FlatScanParams p) {
             stg_ok = grow < r1;
             // raw load only; the select happens in stage_store so that nothing waits on it here
             if (METRIC == METRIC_L2) stg_bias = p.xbn[min(grow, r1 - 1)];
+            else if (p.ip_bias) stg_bias = p.ip_bias[min(grow, r1 - 1)]; // IDSelector: -inf for excluded rows
         }
     };
     auto stage_store = [&](int u) {
@@ -295,7 +296,7 @@ __global__ void __launch_bounds__(512, 2) flat_scan_kernel(FlatScanParams p) {
         if (sl == 0 && tid < TR) {
             float b;
             if (METRIC == METRIC_L2) b = stg_ok ? stg_bias : INFINITY;
-            else b = stg_ok ? 0.f : -INFINITY;
+            else b = stg_ok ? stg_bias : -INFINITY; // (stg_bias stays 0 without p.ip_bias)
             ((float*)(smem + LDS_BIAS))[(t & 1) * TR + tid] = b;
         }
     };

@@ -763,7 +763,7 @@ void GpuIndexFlat::search_tile_(int n, const float* xq_pad, int k, float* dD, id
     fp.xqh = qh_.as<_Float16>();
     fp.xqn = q_norm_.as<float>();
     fp.xbh = xbh_.as<_Float16>();
-    fp.xbhn = xbhn_.as<float>();
+    fp.xbhn = sel_active_ ? sel_xbhn_.as<float>() : xbhn_.as<float>();
     fp.ldqh = dh_;
     fp.ldbh = dh_;
     fp.nq = n;
@@ -923,7 +923,7 @@ void GpuIndexFlat::search_tile_exact_(int n, const float* xq_pad, int k, float* 
         launch_select_k(sp, R.stream);
         return;
     }
-    if (k == 1 && !use_simple_kernel && flat_assign_small_supported(nb, dpad_)) {
+    if (k == 1 && !use_simple_kernel && !sel_active_ && flat_assign_small_supported(nb, dpad_)) {
         SpanGuard sg(&R, "flat_assign_small_kernel");
         launch_flat_assign_small(metric_type, xq_pad, dpad_, n, xb_rows, xbn_.as<float>(), dpad_, nb, dpad_, dD, dI, R.stream);
         if (use_float16_) R.sync(); // `widened` is released on return
@@ -959,6 +959,11 @@ void GpuIndexFlat::search_tile_exact_(int n, const float* xq_pad, int k, float* 
     fp.xqn = q_norm_.as<float>();
     fp.xb = xb_rows;
     fp.xbn = xbn_.as<float>();
+    if (sel_active_) { // IDSelector: excluded rows carry +inf (L2 norms) / -inf (IP start value)
+        FA_THROW_IF_NOT_MSG(!use_simple_kernel, "IDSelector: not available on the scalar cross-check kernel");
+        if (metric_type == METRIC_L2) fp.xbn = sel_xbn_.as<float>();
+        else fp.ip_bias = sel_xbhn_.as<float>();
+    }
     fp.ldq = dpad_;
     fp.ldb = dpad_;
     fp.nq = n;
@@ -1008,13 +1013,50 @@ void GpuIndexFlat::search_device(int n, const float* xq_pad, int k, float* dD, i
     }
 }
 
-void GpuIndexFlat::search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels) const {
+// IDSelector of a flat search: labels are row numbers, so the selector becomes one bit per row, and the bit becomes a
+// start value no threshold admits: the filter kernel's accumulators start from xbhn (-|y|^2/2 or 0), -inf there keeps an
+// excluded row out of the chunk maxima and out of the candidates; the exact scan adds xbn (L2: +inf) / ip_bias (IP: -inf).
+// Every kernel then computes, for the rows that remain, exactly what it computes without a selector.
+void GpuIndexFlat::prepare_selector_(const IDSelector& sel) const {
+    const GpuResources& R = *res_;
+    FA_THROW_IF_NOT_MSG(!use_simple_kernel, "IDSelector: not available on the scalar cross-check kernel");
+    SelProgram prog{};
+    sel.compile(prog, R.device, R.stream);
+    const size_t words = div_up((size_t)std::max<idx_t>(ntotal, 1), 64);
+    sel_mask_.ensure(words * 8);
+    sel_cnt_.ensure(8);
+    HIP_CHECK(hipMemsetAsync(sel_cnt_.p, 0, 8, R.stream));
+    launch_selector_mask(nullptr, ntotal, 0, prog, sel_mask_.as<uint64_t>(), sel_cnt_.as<unsigned long long>(), R.stream);
+    sel_xbhn_.ensure((size_t)(ntotal + kFilterTileRows) * 4);
+    launch_mask_bias(xbhn_.as<float>(), sel_mask_.as<uint32_t>(), ntotal, kFilterTileRows, -INFINITY, -INFINITY,
+                     sel_xbhn_.as<float>(), R.stream);
+    if (metric_type == METRIC_L2) {
+        sel_xbn_.ensure((size_t)std::max<idx_t>(ntotal, 1) * 4);
+        launch_mask_bias(xbn_.as<float>(), sel_mask_.as<uint32_t>(), ntotal, 0, INFINITY, INFINITY, sel_xbn_.as<float>(),
+                         R.stream);
+    }
+    unsigned long long cnt = 0;
+    HIP_CHECK(hipMemcpyAsync(&cnt, sel_cnt_.p, 8, hipMemcpyDeviceToHost, R.stream));
+    R.sync();
+    last_sel_count_ = (idx_t)cnt;
+}
+
+void GpuIndexFlat::search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels,
+                          const SearchParameters* params) const {
     FA_THROW_IF_NOT_MSG(k >= 1 && k <= kMaxSelectionK, "k must be in [1, 2048]");
     if (n == 0) return;
     FA_THROW_IF_NOT_MSG(x && distances && labels, "null argument");
     std::lock_guard<std::mutex> g(mu_);
     res_->set_device();
     const GpuResources& R = *res_;
+    struct SelScope { // the masked arrays serve this call only
+        bool& on;
+        ~SelScope() { on = false; }
+    } sel_scope{sel_active_};
+    if (params && params->sel && ntotal > 0) {
+        prepare_selector_(*params->sel);
+        sel_active_ = true;
+    }
     if (use_paged_path(R, n, d, x, distances, labels)) {
         const idx_t page = paged_page_size(R, n, flat_query_tile(R, (int)k, use_simple_kernel, ntotal));
         paged_host_search(R, n, x, d, k, distances, labels, page, [&](idx_t ni, const float* dq, float* dD, idx_t* dI) {
@@ -1713,20 +1755,22 @@ std::vector<uint8_t> GpuIndexIVF::getListVectorData(idx_t list) const {
     return out;
 }
 
-void GpuIndexIVF::search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels) const {
-    search_core_(n, x, k, distances, labels, nullptr, nullptr, nprobe);
-}
 void GpuIndexIVF::search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels,
-                         const SearchParametersIVF* params) const {
-    search_core_(n, x, k, distances, labels, nullptr, nullptr, params && params->nprobe > 0 ? params->nprobe : nprobe);
+                         const SearchParameters* params) const {
+    // (faiss/gpu/GpuIndexIVF.cu:358-402: nprobe of SearchParametersIVF when that is what the caller passed)
+    const SearchParametersIVF* ivf = dynamic_cast<const SearchParametersIVF*>(params);
+    search_core_(n, x, k, distances, labels, nullptr, nullptr, ivf && ivf->nprobe > 0 ? ivf->nprobe : nprobe,
+                 params ? params->sel : nullptr);
 }
 void GpuIndexIVF::search_preassigned(idx_t n, const float* x, idx_t k, const idx_t* assign, const float* centroid_dis,
-                                     float* distances, idx_t* labels) const {
+                                     float* distances, idx_t* labels, const SearchParameters* params) const {
     FA_THROW_IF_NOT_MSG(n == 0 || (assign && centroid_dis), "search_preassigned: null assign / centroid_dis");
-    search_core_(n, x, k, distances, labels, assign, centroid_dis, nprobe);
+    const SearchParametersIVF* ivf = dynamic_cast<const SearchParametersIVF*>(params);
+    search_core_(n, x, k, distances, labels, assign, centroid_dis, ivf && ivf->nprobe > 0 ? ivf->nprobe : nprobe,
+                 params ? params->sel : nullptr);
 }
 void GpuIndexIVF::search_core_(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels, const idx_t* assign,
-                               const float* centroid_dis, int nprobe_now) const {
+                               const float* centroid_dis, int nprobe_now, const IDSelector* sel) const {
     FA_THROW_IF_NOT_MSG(is_trained, "index not trained");
     FA_THROW_IF_NOT_MSG(k >= 1 && k <= kMaxSelectionK, "k must be in [1, 2048]");
     FA_THROW_IF_NOT_MSG(nprobe_now >= 1 && nprobe_now <= kMaxSelectionK, "nprobe must be in [1, 2048]");
@@ -1735,6 +1779,19 @@ void GpuIndexIVF::search_core_(idx_t n, const float* x, idx_t k, float* distance
     std::lock_guard<std::mutex> g(mu_);
     res_->set_device();
     const GpuResources& R = *res_;
+    // IDSelector: one bit per arena row from the stored ids (one pass over 8 bytes per row, once per call); the scan
+    // kernels consult it for the rows that would otherwise become candidates
+    struct SelScope {
+        const uint32_t*& m;
+        ~SelScope() { m = nullptr; }
+    } sel_scope{cur_sel_mask_};
+    if (sel && arena_rows_ > 0) {
+        SelProgram prog{};
+        sel->compile(prog, R.device, R.stream);
+        sel_mask_.ensure(div_up((size_t)arena_rows_, 64) * 8);
+        launch_selector_mask(arena_ids_.as<int64_t>(), arena_rows_, 0, prog, sel_mask_.as<uint64_t>(), nullptr, R.stream);
+        cur_sel_mask_ = sel_mask_.as<uint32_t>();
+    }
     if (use_paged_path(R, n, d, x, distances, labels)) {
         const idx_t page = paged_page_size(R, n, 65536);
         idx_t done = 0; // pages come in order
@@ -1836,6 +1893,7 @@ void GpuIndexIVF::search_core_body_(idx_t n, const float* x, idx_t k, float* dis
             fp.list_len = d_list_len_.as<uint32_t>();
             fp.list_start = d_list_start_.as<int64_t>();
             fp.arena_ids = arena_ids_.as<int64_t>();
+            fp.sel_mask = cur_sel_mask_;
             fp.k = (int)k;
             fp.kp = fused_kp;
             fp.cap = fused_cap;
@@ -2176,6 +2234,7 @@ void GpuIndexIVFFlat::scan_(int nq, const float* xq_pad, int, const int64_t*) co
     p.keys = keys_.as<unsigned long long>();
     p.arena_vecs = arena_.as<float>();
     p.ldv = dpad_;
+    p.sel_mask = cur_sel_mask_;
     SpanGuard sg(res_.get(), "ivfflat_scan_kernel");
     launch_ivfflat_scan(p, res_->stream);
 }
@@ -2315,6 +2374,7 @@ void GpuIndexIVFPQ::scan_(int nq, const float* xq_pad, int, const int64_t*) cons
     p.pq_t = pq_t_.as<float>();
     p.arena_codes = arena_.as<uint8_t>();
     p.arena_t2 = arena_t2_.as<float>();
+    p.sel_mask = cur_sel_mask_;
     SpanGuard sg(res_.get(), "ivfpq_scan_kernel");
     launch_ivfpq_scan(p, res_->stream);
 }
@@ -2485,7 +2545,8 @@ void IndexShards::reset() {
     run_on_shards(shards_, threaded, [&](int, Index* s) { s->reset(); });
     sync_();
 }
-void IndexShards::search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels) const {
+void IndexShards::search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels,
+                         const SearchParameters* params) const {
     // reference: faiss/IndexShards.cpp:196-265
     FA_THROW_IF_NOT_MSG(k > 0, "k must be positive");
     const int nshard = (int)shards_.size();
@@ -2501,7 +2562,7 @@ void IndexShards::search(idx_t n, const float* x, idx_t k, float* distances, idx
         }
     }
     run_on_shards(shards_, threaded, [&](int no, Index* s) {
-        s->search(n, x, k, all_d.data() + (size_t)no * n * k, all_i.data() + (size_t)no * n * k);
+        s->search(n, x, k, all_d.data() + (size_t)no * n * k, all_i.data() + (size_t)no * n * k, params);
     });
     merge_knn_results(metric_type, n, k, nshard, all_d.data(), all_i.data(),
                       successive_ids ? base.data() : nullptr, distances, labels);
@@ -2554,8 +2615,10 @@ void IndexReplicas::reconstruct(idx_t key, float* recons) const {
     FA_THROW_IF_NOT_MSG(!replicas_.empty(), "no replicas in index");
     replicas_[0]->reconstruct(key, recons); // faiss/IndexReplicas.cpp:83-89
 }
-void IndexReplicas::search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels) const {
+void IndexReplicas::search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels,
+                           const SearchParameters* params) const {
     // reference: faiss/IndexReplicas.cpp:123-175 (queries dealt out in ceil(n / count) blocks)
+    FA_THROW_IF_NOT_MSG(!params, "search params not supported for this index");
     FA_THROW_IF_NOT_MSG(k > 0, "k must be positive");
     const idx_t cnt = (idx_t)replicas_.size();
     FA_THROW_IF_NOT_MSG(cnt > 0, "no replicas in index");

@@ -108,6 +108,85 @@ typedef int (*InterruptFn)(void*);
 void set_interrupt_callback(InterruptFn fn, void* user);
 void check_interrupt(); // throws FaissAmdException when the callback says so
 
+// ------------------------------------------------------------------ IDSelector / SearchParameters
+// faiss::IDSelector and its concrete selectors (faiss/impl/IDSelector.h:21-215): a predicate on the LABELS a search may
+// return (row numbers for GpuIndexFlat, the stored user ids for the IVF indexes).  A search with a selector returns the
+// k best among the selected vectors -- bit for bit what a search of an index holding only those vectors returns.
+// The reference's GPU indexes take the parameter and ignore it outside the cuVS back-end (faiss/gpu/GpuIndexFlat.cu:232,
+// GpuIndexIVF.cu:402); the CPU indexes honour it (IndexFlat.cpp:36-58, IndexIVF.cpp scan_codes), and so do the
+// indexes here: the selector is compiled to a small device program (kernels.h SelProgram), evaluated once per stored
+// row and search call into a bit mask that the scan kernels consult.
+struct SelProgram;
+struct IDSelector {
+    virtual bool is_member(idx_t id) const = 0;
+    virtual ~IDSelector() {}
+    // append this selector's postfix instructions; device copies of id arrays / bitmaps are made (once per device) on
+    // `stream` and owned by the selector
+    virtual void compile(SelProgram& prog, int device, hipStream_t stream) const = 0;
+};
+struct IDSelectorAll : IDSelector {
+    bool is_member(idx_t) const override { return true; }
+    void compile(SelProgram& prog, int device, hipStream_t stream) const override;
+};
+struct IDSelectorRange : IDSelector {
+    idx_t imin, imax; // imin <= id < imax
+    bool assume_sorted;
+    IDSelectorRange(idx_t imin_, idx_t imax_, bool assume_sorted_ = false)
+            : imin(imin_), imax(imax_), assume_sorted(assume_sorted_) {}
+    bool is_member(idx_t id) const override { return id >= imin && id < imax; }
+    void compile(SelProgram& prog, int device, hipStream_t stream) const override;
+};
+// IDSelectorArray and IDSelectorBatch of the reference (a list of ids; linear search / hash set + Bloom filter there):
+// one class here, a sorted array of the distinct ids, binary search on host and device.  The ids are copied.
+struct IDSelectorBatch : IDSelector {
+    std::vector<idx_t> ids; // sorted, distinct
+    IDSelectorBatch(size_t n, const idx_t* indices);
+    bool is_member(idx_t id) const override;
+    void compile(SelProgram& prog, int device, hipStream_t stream) const override;
+
+   private:
+    mutable DevBuf dev_;
+    mutable int dev_id_ = -1;
+};
+typedef IDSelectorBatch IDSelectorArray;
+// id selected iff id / 8 < n and bit id % 8 of bitmap[id / 8] is set (IDSelector.cpp:123-129); the bitmap is copied
+struct IDSelectorBitmap : IDSelector {
+    std::vector<uint8_t> bitmap;
+    IDSelectorBitmap(size_t n, const uint8_t* bits) : bitmap(bits, bits + n) {}
+    bool is_member(idx_t id) const override {
+        const uint64_t u = (uint64_t)id;
+        return (u >> 3) < bitmap.size() && ((bitmap[u >> 3] >> (u & 7)) & 1);
+    }
+    void compile(SelProgram& prog, int device, hipStream_t stream) const override;
+
+   private:
+    mutable DevBuf dev_;
+    mutable int dev_id_ = -1;
+};
+// the operands are not owned (as in the reference)
+struct IDSelectorNot : IDSelector {
+    const IDSelector* sel;
+    explicit IDSelectorNot(const IDSelector* s) : sel(s) {}
+    bool is_member(idx_t id) const override { return !sel->is_member(id); }
+    void compile(SelProgram& prog, int device, hipStream_t stream) const override;
+};
+struct IDSelectorBinary : IDSelector {
+    const IDSelector *lhs, *rhs;
+    int op; // SelOp: SEL_AND / SEL_OR / SEL_XOR
+    IDSelectorBinary(int op_, const IDSelector* l, const IDSelector* r) : lhs(l), rhs(r), op(op_) {}
+    bool is_member(idx_t id) const override;
+    void compile(SelProgram& prog, int device, hipStream_t stream) const override;
+};
+// faiss::SearchParameters (faiss/Index.h:86-93) / faiss::SearchParametersIVF (faiss/IndexIVF.h:70-80; nprobe is honoured
+// by the reference GPU index through getCurrentNProbe_, faiss/gpu/GpuIndexIVF.cu:358-381).  nprobe <= 0: the index's own.
+struct SearchParameters {
+    const IDSelector* sel = nullptr; // not owned
+    virtual ~SearchParameters() {}
+};
+struct SearchParametersIVF : SearchParameters {
+    int nprobe = 0;
+};
+
 // ------------------------------------------------------------------ faiss::Index mirror
 struct Index {
     int d = 0;
@@ -122,7 +201,8 @@ struct Index {
     virtual void train(idx_t n, const float* x) {}
     virtual void add(idx_t n, const float* x) = 0;
     virtual void add_with_ids(idx_t n, const float* x, const idx_t* xids);
-    virtual void search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels) const = 0;
+    virtual void search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels,
+                        const SearchParameters* params = nullptr) const = 0;
     virtual void assign(idx_t n, const float* x, idx_t* labels, idx_t k = 1) const;
     virtual void reset() = 0;
     virtual void reconstruct(idx_t key, float* recons) const;
@@ -146,7 +226,9 @@ class GpuIndexFlat : public Index {
     bool getUseFloat16() const { return use_float16_; }
 
     void add(idx_t n, const float* x) override;
-    void search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels) const override;
+    // params->sel: only rows the selector admits are returned (labels = row numbers)
+    void search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels,
+                const SearchParameters* params = nullptr) const override;
     void reset() override;
     void reconstruct(idx_t key, float* recons) const override;
     void reconstruct_n(idx_t i0, idx_t ni, float* recons) const override;
@@ -209,18 +291,18 @@ class GpuIndexFlat : public Index {
         std::string knobs;
     } plan_cache_;
     mutable std::mutex mu_;
+    // IDSelector of the search in flight (under mu_): row mask, and the start values / norms with the excluded rows
+    // set to -inf / +inf -- the filter and scan kernels then skip those rows without knowing about selectors
+    mutable bool sel_active_ = false;
+    mutable DevBuf sel_mask_, sel_xbhn_, sel_xbn_, sel_cnt_;
+    mutable idx_t last_sel_count_ = -1; // rows the last selector admitted (tests)
+    void prepare_selector_(const IDSelector& sel) const;
     // persistent scratch
     mutable DevBuf q_raw_, q_pad_, q_norm_, res_keys_, res_cnt_, out_d_, out_i_, all_keys_, one_cnt_;
     void search_tile_(int n, const float* xq_pad, int k, float* dD, idx_t* dI) const;
 };
 
 // ------------------------------------------------------------------ GpuIndexIVF
-// search-time overrides, mirror of faiss::SearchParametersIVF (faiss/IndexIVF.h:70-80; honoured by the reference
-// GPU index through getCurrentNProbe_, faiss/gpu/GpuIndexIVF.cu:358-381).  nprobe <= 0: the index's own value.
-struct SearchParametersIVF {
-    int nprobe = 0;
-};
-
 class GpuIndexIVF : public Index {
    public:
     GpuIndexIVF(std::shared_ptr<GpuResources> res, int dims, int metric, int nlist);
@@ -233,14 +315,15 @@ class GpuIndexIVF : public Index {
     void train(idx_t n, const float* x) override;
     void add(idx_t n, const float* x) override;
     void add_with_ids(idx_t n, const float* x, const idx_t* xids) override;
-    void search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels) const override;
-    void search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels, const SearchParametersIVF* params) const;
+    // params: SearchParameters (sel) or SearchParametersIVF (sel, nprobe); the selector applies to the stored ids
+    void search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels,
+                const SearchParameters* params = nullptr) const override;
     // search with the coarse quantization supplied by the caller: assign / centroid_dis are [n][nprobe]
     // (host or device), -1 = no list (faiss/gpu/GpuIndexIVF.cu:408-488; IndexIVF::search_preassigned is what
     // IndexShardsIVF and the hybrid CPU-quantizer benchmarks call).  centroid_dis must be the quantizer's
     // distances for those lists (IVFPQ L2 adds them as the first term, as the reference does).
     void search_preassigned(idx_t n, const float* x, idx_t k, const idx_t* assign, const float* centroid_dis,
-                            float* distances, idx_t* labels) const;
+                            float* distances, idx_t* labels, const SearchParameters* params = nullptr) const;
     void reset() override;
     int device() const override { return res_->device; }
 
@@ -280,6 +363,9 @@ class GpuIndexIVF : public Index {
     mutable std::mutex mu_;
     mutable DevBuf q_raw_, q_pad_, c_dis_, c_ids_, prefix_, totals_, q_off_, keys_, out_d_, out_i_, one_cnt_;
     mutable int nprobe_eff_ = 1; // min(nprobe, nlist) of the search in flight
+    // IDSelector of the search in flight (under mu_): one bit per arena row, null = none
+    mutable DevBuf sel_mask_;
+    mutable const uint32_t* cur_sel_mask_ = nullptr;
     // add-path scratch
     DevBuf a_xpad_, a_lab_, a_dis_, a_dest_, a_ids_, a_hist_, a_newlen_, a_jobs_;
 
@@ -309,7 +395,7 @@ class GpuIndexIVF : public Index {
     void compact_();
     void add_core_(idx_t n, const float* x, const idx_t* xids);
     void search_core_(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels, const idx_t* assign,
-                      const float* centroid_dis, int nprobe_now) const;
+                      const float* centroid_dis, int nprobe_now, const IDSelector* sel) const;
     void search_core_body_(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels, const idx_t* assign,
                            const float* centroid_dis, int nprobe_now) const;
 
@@ -411,7 +497,9 @@ class IndexShards : public Index {
     void train(idx_t n, const float* x) override;
     void add(idx_t n, const float* x) override;
     void add_with_ids(idx_t n, const float* x, const idx_t* xids) override;
-    void search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels) const override;
+    // params are handed to every shard (faiss/IndexShards.cpp:196-265); a selector sees the shard-local labels
+    void search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels,
+                const SearchParameters* params = nullptr) const override;
     void reset() override;
 
    private:
@@ -435,7 +523,9 @@ class IndexReplicas : public Index {
     void train(idx_t n, const float* x) override;
     void add(idx_t n, const float* x) override;
     void add_with_ids(idx_t n, const float* x, const idx_t* xids) override;
-    void search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels) const override;
+    // search parameters are refused, like the reference (faiss/IndexReplicas.cpp:129-130)
+    void search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels,
+                const SearchParameters* params = nullptr) const override;
     void reconstruct(idx_t key, float* recons) const override;
     void reset() override;
 

@@ -44,6 +44,11 @@ __device__ __forceinline__ unsigned lut_addr64(unsigned w, unsigned rot) {
     return __builtin_amdgcn_perm(w, rot, 0x0c0c0000u | ((4u + I) << 8) | (unsigned)I);
 }
 constexpr int FMAXR = 8;  // reservoir capacity <= FMAXR * FB keys
+// IDSelector: bit `row` of the per-arena-row mask (launch_selector_mask).  Tested only for rows whose key beats the
+// running threshold, i.e. after the distance is known: the mask (1 bit per row) stays in L2, the code stream is untouched.
+__device__ __forceinline__ bool sel_bit(const uint32_t* __restrict__ mask, int64_t row) {
+    return ((mask[row >> 5] >> (row & 31)) & 1u) != 0u;
+}
 
 struct FusedLds {
     char* lut;        // [M][256] fp32 | at the end: winners
@@ -302,7 +307,7 @@ __device__ __forceinline__ void fused_finish(const IvfFusedParams& p, int q, int
 // M64: the sub-quantizer count is the compile-time constant 64 (four coalesced 1 KB loads per block; table address
 // of a gather = ONE v_perm_b32).
 // ---------------------------------------------------------------------------------
-template <int METRIC, bool M64, int FB>
+template <int METRIC, bool M64, int FB, bool SEL>
 __global__ void __launch_bounds__(FB, 4) ivfpq_fused_kernel(IvfFusedParams p) { // 4 waves per SIMD: two 512-thread workgroups per CU
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const FusedLds L = fused_carve(smem, p);
@@ -351,6 +356,7 @@ __global__ void __launch_bounds__(FB, 4) ivfpq_fused_kernel(IvfFusedParams p) { 
         float dis0;
         unsigned pos0, rem;
         const uint8_t* bp;  // block base (generic M: codes are read in the gather loop)
+        int64_t row0;       // SEL: arena row of the block's first row
     };
     int tcur = p0; // probe of the block fetched last (blocks are visited in increasing order)
     auto fetch = [&](unsigned blk, Stage& st) {
@@ -360,6 +366,7 @@ __global__ void __launch_bounds__(FB, 4) ivfpq_fused_kernel(IvfFusedParams p) { 
             const unsigned b = blk - L.bpre[tcur];
             const int64_t row0 = L.lstart[tcur] + (int64_t)b * 64;
             st.bp = p.arena_codes + row0 * M;
+            if (SEL) st.row0 = row0;
             st.rem = __builtin_amdgcn_readfirstlane(L.pre[tcur + 1] - L.pre[tcur] - b * 64u);
             // only the rows the list really holds are requested: the last block of a list is on average half empty,
             // 13 % of the code traffic at nb / nlist = 244 rows per list
@@ -490,6 +497,9 @@ __global__ void __launch_bounds__(FB, 4) ivfpq_fused_kernel(IvfFusedParams p) { 
             const float dis = METRIC == METRIC_L2 ? __fmaf_rn(-2.f, sum, st.dis0 + st.t2) : st.dis0 + sum;
             key = ((u64)ordkey<METRIC>(dis) << 32) | (u64)(st.pos0 + (unsigned)lane);
             pass = key < tau;
+            if (SEL) {
+                if (pass) pass = sel_bit(p.sel_mask, st.row0 + lane);
+            }
         }
         wg_append(L.res, L.ctl, pass, key);
     };
@@ -532,7 +542,7 @@ constexpr int FF_ROWS = 4;                   // rows per 8-lane group and iterat
 constexpr int FF_POS = FF_ROWS * (FB_MAX / 8); // positions per iteration (512)
 constexpr int FF_QCH = 4;                    // query chunks kept in registers per lane (dpad <= 128)
 
-template <int METRIC>
+template <int METRIC, bool SEL>
 __global__ void __launch_bounds__(FB_MAX) ivfflat_fused_kernel(IvfFusedParams p) {
     constexpr int FB = FB_MAX;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -563,6 +573,7 @@ __global__ void __launch_bounds__(FB_MAX) ivfflat_fused_kernel(IvfFusedParams p)
         float part[FF_ROWS];
         unsigned posv[FF_ROWS];
         const float* rowp[FF_ROWS];
+        int64_t rowi[FF_ROWS]; // SEL: arena row index
         // ---- rows of this iteration: position -> arena row
 #pragma unroll
         for (int u = 0; u < FF_ROWS; ++u) {
@@ -576,7 +587,9 @@ __global__ void __launch_bounds__(FB_MAX) ivfflat_fused_kernel(IvfFusedParams p)
                     if (L.pre[mid] <= pos) lo = mid;
                     else hi = mid;
                 }
-                rowp[u] = p.arena_vecs + (L.lstart[lo] + (pos - L.pre[lo])) * p.ldv;
+                const int64_t row = L.lstart[lo] + (pos - L.pre[lo]);
+                rowp[u] = p.arena_vecs + row * p.ldv;
+                if (SEL) rowi[u] = row;
             }
         }
         // ---- partial chains
@@ -638,7 +651,10 @@ __global__ void __launch_bounds__(FB_MAX) ivfflat_fused_kernel(IvfFusedParams p)
             a = a + __shfl_xor(a, 2, 64);
             a = a + __shfl_xor(a, 4, 64);
             const u64 key = ((u64)ordkey<METRIC>(a) << 32) | (u64)posv[u];
-            const bool pass = rowp[u] != nullptr && ln == 0 && key < tau;
+            bool pass = rowp[u] != nullptr && ln == 0 && key < tau;
+            if (SEL) {
+                if (pass) pass = sel_bit(p.sel_mask, rowi[u]);
+            }
             wg_append(L.res, L.ctl, pass, key);
         }
         __syncthreads();
@@ -712,7 +728,7 @@ __device__ __forceinline__ void sq_fold(const unsigned (&w)[SqChunk<CT>::WORDS],
     }
 }
 
-template <int METRIC, int CT>
+template <int METRIC, int CT, bool SEL>
 __global__ void __launch_bounds__(SQ_FB, 4) ivfsq_fused_kernel(IvfFusedParams p) { // two 512-thread workgroups per CU
     constexpr int FB = SQ_FB;
     constexpr int NWV = FB / 64;
@@ -742,6 +758,7 @@ __global__ void __launch_bounds__(SQ_FB, 4) ivfsq_fused_kernel(IvfFusedParams p)
         // list from that row on (0 = no block)
         int t;
         unsigned pos0, rem;
+        int64_t row0; // SEL: arena row of the block's first row
     };
     int tcur = p0; // probe of the block fetched last (blocks are visited in non-decreasing order)
     auto fetch = [&](unsigned blk, int grp, Stage& st) {
@@ -751,6 +768,7 @@ __global__ void __launch_bounds__(SQ_FB, 4) ivfsq_fused_kernel(IvfFusedParams p)
             const unsigned b = blk - L.bpre[tcur];
             const int64_t row0 = L.lstart[tcur] + (int64_t)b * 64;
             const uint8_t* bp = p.arena_codes + row0 * (int64_t)p.sq_ld + lane * CHB;
+            if (SEL) st.row0 = row0;
             st.rem = __builtin_amdgcn_readfirstlane(L.pre[tcur + 1] - L.pre[tcur] - b * 64u);
             st.t = __builtin_amdgcn_readfirstlane(tcur - p0);
             st.pos0 = __builtin_amdgcn_readfirstlane(L.pre[tcur] + b * 64u);
@@ -857,6 +875,9 @@ __global__ void __launch_bounds__(SQ_FB, 4) ivfsq_fused_kernel(IvfFusedParams p)
                 if (METRIC != METRIC_L2) dis = (dis + qb) + tab_c[st.t];
                 key = ((u64)ordkey<METRIC>(dis) << 32) | (u64)(st.pos0 + (unsigned)lane);
                 pass = key < tau;
+                if (SEL) {
+                    if (pass) pass = sel_bit(p.sel_mask, st.row0 + lane);
+                }
             }
             wg_append(L.res, L.ctl, pass, key);
         }
@@ -978,9 +999,15 @@ void launch_ivf_fused(const IvfFusedParams& p, hipStream_t stream) {
     const size_t lds = ivf_fused_lds_bytes(p.kind, p.M, p.kind == 2 ? p.sq_dsq : p.dpad, p.kp, p.cap, p.nprobe, p.nlut);
     FA_THROW_IF_NOT_MSG(lds <= 160 * 1024, "fused IVF scan does not fit the LDS");
     const bool l2 = p.metric == METRIC_L2;
+    const bool sel = p.sel_mask != nullptr; // IDSelector: the instantiations that test the row mask
     if (p.kind == 0) {
-        if (l2) launch_one(ivfflat_fused_kernel<METRIC_L2>, p, lds, fb, stream);
-        else launch_one(ivfflat_fused_kernel<METRIC_INNER_PRODUCT>, p, lds, fb, stream);
+        if (sel) {
+            if (l2) launch_one(ivfflat_fused_kernel<METRIC_L2, true>, p, lds, fb, stream);
+            else launch_one(ivfflat_fused_kernel<METRIC_INNER_PRODUCT, true>, p, lds, fb, stream);
+        } else {
+            if (l2) launch_one(ivfflat_fused_kernel<METRIC_L2, false>, p, lds, fb, stream);
+            else launch_one(ivfflat_fused_kernel<METRIC_INNER_PRODUCT, false>, p, lds, fb, stream);
+        }
     } else if (p.kind == 2) {
         const int nch = p.sq_dsq / 16;
         FA_THROW_IF_NOT_MSG(p.sq_dsq % 16 == 0 && nch >= 1 && nch <= 64, "scalar-quantizer scan: d <= 1024");
@@ -988,8 +1015,13 @@ void launch_ivf_fused(const IvfFusedParams& p, hipStream_t stream) {
         FA_THROW_IF_NOT(p.sq_ld % 4 == 0 && p.sq_ld >= nch * sq_chunk_bytes(p.sq_ct));
 #define FA_SQ_LAUNCH(CT_)                                                                                  \
     do {                                                                                                   \
-        if (l2) launch_one(ivfsq_fused_kernel<METRIC_L2, CT_>, p, lds, fb, stream);                        \
-        else launch_one(ivfsq_fused_kernel<METRIC_INNER_PRODUCT, CT_>, p, lds, fb, stream);                \
+        if (sel) {                                                                                         \
+            if (l2) launch_one(ivfsq_fused_kernel<METRIC_L2, CT_, true>, p, lds, fb, stream);              \
+            else launch_one(ivfsq_fused_kernel<METRIC_INNER_PRODUCT, CT_, true>, p, lds, fb, stream);      \
+        } else {                                                                                           \
+            if (l2) launch_one(ivfsq_fused_kernel<METRIC_L2, CT_, false>, p, lds, fb, stream);             \
+            else launch_one(ivfsq_fused_kernel<METRIC_INNER_PRODUCT, CT_, false>, p, lds, fb, stream);     \
+        }                                                                                                  \
     } while (0)
         switch (p.sq_ct) {
             case SQ_U8: FA_SQ_LAUNCH(SQ_U8); break;
@@ -1002,8 +1034,13 @@ void launch_ivf_fused(const IvfFusedParams& p, hipStream_t stream) {
         FA_THROW_IF_NOT_MSG(p.metric != METRIC_L2 || p.arena_t2, "IVFPQ L2 needs the per-vector t2 terms");
 #define FA_PQ_LAUNCH(M64_, FB_)                                                                            \
     do {                                                                                                   \
-        if (l2) launch_one(ivfpq_fused_kernel<METRIC_L2, M64_, FB_>, p, lds, fb, stream);                  \
-        else launch_one(ivfpq_fused_kernel<METRIC_INNER_PRODUCT, M64_, FB_>, p, lds, fb, stream);          \
+        if (sel) {                                                                                         \
+            if (l2) launch_one(ivfpq_fused_kernel<METRIC_L2, M64_, FB_, true>, p, lds, fb, stream);        \
+            else launch_one(ivfpq_fused_kernel<METRIC_INNER_PRODUCT, M64_, FB_, true>, p, lds, fb, stream); \
+        } else {                                                                                           \
+            if (l2) launch_one(ivfpq_fused_kernel<METRIC_L2, M64_, FB_, false>, p, lds, fb, stream);       \
+            else launch_one(ivfpq_fused_kernel<METRIC_INNER_PRODUCT, M64_, FB_, false>, p, lds, fb, stream); \
+        }                                                                                                  \
     } while (0)
         if (p.M == 64) {
             if (fb == 512) FA_PQ_LAUNCH(true, 512);

@@ -128,7 +128,9 @@ __global__ void __launch_bounds__(256) ivfflat_scan_kernel(IvfScanParams p) {
             part[ln] = a;
         }
         const float acc = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
-        out[i] = ((u64)ordkey<METRIC>(acc) << 32) | (u64)(pos0 + i);
+        // (a row an IDSelector excludes keeps its slot with a key no result can have)
+        const bool keep = !p.sel_mask || ((p.sel_mask[(start + i) >> 5] >> ((start + i) & 31)) & 1u);
+        out[i] = ((u64)(keep ? ordkey<METRIC>(acc) : 0xffffffffu) << 32) | (u64)(pos0 + i);
     }
 }
 
@@ -203,7 +205,8 @@ __global__ void __launch_bounds__(256) ivfpq_scan_kernel(IvfScanParams p) {
         float sum = 0.f;
         for (int m = 0; m < M; ++m) sum = sum + lut[m * 256 + p.arena_codes[pq_code_offset(M, row, m)]];
         const float acc = METRIC == METRIC_L2 ? __fmaf_rn(-2.f, sum, dis0 + p.arena_t2[row]) : dis0 + sum;
-        out[i] = ((u64)ordkey<METRIC>(acc) << 32) | (u64)(pos0 + i);
+        const bool keep = !p.sel_mask || ((p.sel_mask[row >> 5] >> (row & 31)) & 1u);
+        out[i] = ((u64)(keep ? ordkey<METRIC>(acc) : 0xffffffffu) << 32) | (u64)(pos0 + i);
     }
 }
 

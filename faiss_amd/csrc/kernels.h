@@ -42,6 +42,9 @@ struct FlatScanParams {
     const float* xqn;   // [nq] query squared norms (L2 only; may be null for IP)
     const float* xb;    // [nb][ldb] padded database
     const float* xbn;   // [nb] database squared norms (L2 only)
+    // IP, optional: additive start value per row, 0 for rows that take part and -inf for rows an IDSelector excludes
+    // (the L2 kernels get the same effect from +inf entries in xbn); null = every row takes part
+    const float* ip_bias;
     int64_t ldq, ldb;
     int nq;
     int nb;             // < 2^31 per device index
@@ -166,6 +169,31 @@ void launch_gather_rows(const float* src, int64_t ld, int width, const uint32_t*
 void launch_scatter_results(const float* sd, const int64_t* si, int k, const uint32_t* list, int n, float* dd,
                             int64_t* di, hipStream_t stream);
 
+// ------------------------------------------------------------------ IDSelector on the device
+// faiss::IDSelector (faiss/impl/IDSelector.h:21-215) compiled to a postfix program that a kernel evaluates per id:
+// leaves push one truth value (ALL, RANGE imin <= id < imax, SET = id in a sorted array of distinct ids -- what
+// IDSelectorArray / IDSelectorBatch mean --, BITMAP = bit id of an n-byte bitmap, ids >= 8 n excluded), NOT / AND / OR /
+// XOR combine the top of the stack.  All pointers are device pointers owned by the host-side selector object.
+enum SelOp : int { SEL_ALL = 0, SEL_RANGE = 1, SEL_SET = 2, SEL_BITMAP = 3, SEL_NOT = 4, SEL_AND = 5, SEL_OR = 6, SEL_XOR = 7 };
+constexpr int kSelMaxInstr = 24; // instructions per program (a tree of up to 12 leaves)
+struct SelInstr {
+    int op;
+    int64_t a, b;    // RANGE: imin, imax; SET: a = number of ids; BITMAP: a = bytes
+    const void* ptr; // SET: sorted int64 ids; BITMAP: the bytes
+};
+struct SelProgram {
+    int n;
+    SelInstr ins[kSelMaxInstr];
+};
+// mask bit i (bit i & 63 of word i >> 6, equally bit i & 31 of 32-bit word i >> 5) = selector(ids ? ids[i] : id_base + i)
+// for i < n; bits n .. of the last word are 0.  *count (nullable, zeroed by the caller) += number of set bits.
+void launch_selector_mask(const int64_t* ids, int64_t n, int64_t id_base, const SelProgram& prog, uint64_t* mask,
+                          unsigned long long* count, hipStream_t stream);
+// dst[i] = bit i of mask ? src[i] : excluded for i < n, dst[n .. n + npad) = pad: the start values / norms of a flat
+// search restricted by a selector (FlatFilterParams::xbhn, FlatScanParams::xbn / ip_bias)
+void launch_mask_bias(const float* src, const uint32_t* mask, int64_t n, int npad, float excluded, float pad, float* dst,
+                      hipStream_t stream);
+
 // ------------------------------------------------------------------ k-selection
 struct SelectParams {
     int metric;
@@ -249,6 +277,7 @@ struct IvfScanParams {
     const float* pq_t;         // [256][M][dsub] transposed codebook
     const uint8_t* arena_codes; // rotated 64-row block layout, see pq_code_offset
     const float* arena_t2;      // [arena rows] L2: |r^|^2 + 2 <centroid, r^> of every stored vector
+    const uint32_t* sel_mask;   // optional: one bit per arena row (launch_selector_mask), rows with a 0 bit are skipped
 };
 // One workgroup per (query, probe): direct sum((q-y)^2) over the list (L2) or dot (IP).
 // Replaces faiss/gpu/impl/IVFFlatScan.cu:135-183 / IVFInterleaved.cuh:33-224.
@@ -307,6 +336,10 @@ struct IvfFusedParams {
     int sq_by_residual;
     const float* sq_s;     // [sq_dsq] scale per dimension (0 beyond d)
     const float* sq_b;     // [sq_dsq] offset per dimension
+    // IDSelector (faiss/impl/IDSelector.h): one bit per arena row, built by launch_selector_mask from the stored ids for
+    // the search in flight; a row whose bit is 0 never becomes a candidate.  null = no selector (the kernels are
+    // instantiated separately for the two cases, the unfiltered scan carries no test)
+    const uint32_t* sel_mask;
 };
 // code types of the scalar quantizer as the scan kernel sees them (16 components per lane chunk)
 enum SqCodeType { SQ_U8 = 0, SQ_U4 = 1, SQ_U6 = 2, SQ_F16 = 3 };

@@ -313,6 +313,44 @@ typedef struct FaissAmdSearchParametersIVF {
 int faiss_amd_GpuIndexIVF_search_with_params(const FaissAmdIndex* index, faiss_amd_idx_t n, const float* x,
                                              faiss_amd_idx_t k, const FaissAmdSearchParametersIVF* params,
                                              float* distances, faiss_amd_idx_t* labels);
+/* ---- faiss::IDSelector (faiss/impl/IDSelector.h:21-215; C API of the reference: c_api/impl/AuxIndexStructures_c.h:51-116)
+ *      and faiss::SearchParameters / SearchParametersIVF (c_api/Index_c.h:41-46, c_api/IndexIVF_c.h:22-37).
+ *      A selector restricts a search to the vectors whose LABEL it admits: row numbers for GpuIndexFlat, the stored user
+ *      ids for the IVF indexes; the result is bit for bit what an index holding only those vectors returns, -1 / the
+ *      neutral distance fill up when fewer than k qualify.  The reference's CPU indexes honour `sel`, its GPU indexes
+ *      accept and ignore it outside cuVS (faiss/gpu/GpuIndexFlat.cu:232, GpuIndexIVF.cu:402); here it runs on the device.
+ *      Range: imin <= id < imax.  Batch / Array: the listed ids (copied).  Bitmap: id / 8 < n and bit id % 8 of
+ *      bitmap[id / 8] (copied).  Not / And / Or / XOr combine selectors that must outlive the combination (not owned). */
+typedef struct FaissAmdIDSelector_H FaissAmdIDSelector;
+int faiss_amd_IDSelectorAll_new(FaissAmdIDSelector** p_sel);
+int faiss_amd_IDSelectorRange_new(FaissAmdIDSelector** p_sel, faiss_amd_idx_t imin, faiss_amd_idx_t imax);
+int faiss_amd_IDSelectorBatch_new(FaissAmdIDSelector** p_sel, size_t n, const faiss_amd_idx_t* ids);
+int faiss_amd_IDSelectorArray_new(FaissAmdIDSelector** p_sel, size_t n, const faiss_amd_idx_t* ids);
+int faiss_amd_IDSelectorBitmap_new(FaissAmdIDSelector** p_sel, size_t n, const uint8_t* bitmap);
+int faiss_amd_IDSelectorNot_new(FaissAmdIDSelector** p_sel, const FaissAmdIDSelector* sel);
+int faiss_amd_IDSelectorAnd_new(FaissAmdIDSelector** p_sel, const FaissAmdIDSelector* lhs, const FaissAmdIDSelector* rhs);
+int faiss_amd_IDSelectorOr_new(FaissAmdIDSelector** p_sel, const FaissAmdIDSelector* lhs, const FaissAmdIDSelector* rhs);
+int faiss_amd_IDSelectorXOr_new(FaissAmdIDSelector** p_sel, const FaissAmdIDSelector* lhs, const FaissAmdIDSelector* rhs);
+/* 1 / 0 (host-side evaluation; the reference's faiss_IDSelector_is_member) */
+int faiss_amd_IDSelector_is_member(const FaissAmdIDSelector* sel, faiss_amd_idx_t id);
+void faiss_amd_IDSelector_free(FaissAmdIDSelector* sel);
+
+typedef struct FaissAmdSearchParameters_H FaissAmdSearchParameters;
+/* sel may be NULL (no restriction); it is not owned and must outlive the parameters */
+int faiss_amd_SearchParameters_new(FaissAmdSearchParameters** p_sp, const FaissAmdIDSelector* sel);
+/* nprobe 0 keeps the index's own value; max_codes must be 0 (the GPU indexes of the reference refuse it too) */
+int faiss_amd_SearchParametersIVF_new_with(FaissAmdSearchParameters** p_sp, const FaissAmdIDSelector* sel, size_t nprobe,
+                                           size_t max_codes);
+void faiss_amd_SearchParameters_free(FaissAmdSearchParameters* sp);
+/* faiss_Index_search_with_params (c_api/Index_c.h:127-135): any index behind this ABI; params may be NULL */
+int faiss_amd_Index_search_with_params(const FaissAmdIndex* index, faiss_amd_idx_t n, const float* x, faiss_amd_idx_t k,
+                                       const FaissAmdSearchParameters* params, float* distances, faiss_amd_idx_t* labels);
+/* search_preassigned with search parameters (IndexIVF::search_preassigned takes them as its `params` argument) */
+int faiss_amd_GpuIndexIVF_search_preassigned_with_params(const FaissAmdIndex* index, faiss_amd_idx_t n, const float* x,
+                                                         faiss_amd_idx_t k, const faiss_amd_idx_t* assign,
+                                                         const float* centroid_dis, const FaissAmdSearchParameters* params,
+                                                         float* distances, faiss_amd_idx_t* labels);
+
 /* vectors actually stored in the inverted lists: ntotal counts every vector add() was given (NaN rows are not
  * stored but counted, faiss/gpu/GpuIndexIVF.cu:293-298) */
 int faiss_amd_GpuIndexIVF_stored_vectors(const FaissAmdIndex* index, faiss_amd_idx_t* p_stored);

@@ -5,7 +5,8 @@
 // torch, no access to the backend's internals.  It provides
 //   * faiss::amd::AmdIndex / AmdIndexFlat / AmdIndexIVFFlat / AmdIndexIVFPQ: faiss::Index subclasses (the IVF ones also
 //     faiss::IndexIVFInterface, like faiss::gpu::GpuIndexIVF, faiss/gpu/GpuIndexIVF.h:37-40) that forward the whole
-//     add/search surface the reference's callers use -- train, add, add_with_ids, search (+ SearchParametersIVF.nprobe),
+//     add/search surface the reference's callers use -- train, add, add_with_ids, search (+ SearchParameters: nprobe and
+//     IDSelector, translated to the backend's device-side selectors),
 //     assign, reset, reconstruct, reconstruct_n, reconstruct_batch, compute_residual[_n], search_preassigned -- so
 //     faiss::IndexShards / IndexReplicas / IndexShardsIVF / Clustering / IndexIVF (as coarse quantizer) / IndexIDMap /
 //     IndexPreTransform run on them unchanged;
@@ -30,6 +31,7 @@
 #include <faiss/IndexShards.h>
 #include <faiss/IndexShardsIVF.h>
 #include <faiss/impl/FaissAssert.h>
+#include <faiss/impl/IDSelector.h>
 #include <faiss/invlists/InvertedLists.h>
 
 #include <cstring>
@@ -56,6 +58,88 @@ struct AmdGpuResources {
     AmdGpuResources(const AmdGpuResources&) = delete;
     ~AmdGpuResources() {
         faiss_amd_StandardGpuResources_free(h);
+    }
+};
+
+/// faiss::IDSelector -> the backend's selector objects.  The reference's concrete selectors (Range, Array, Batch,
+/// Bitmap, All, Not, And, Or, XOr; faiss/impl/IDSelector.h:71-215) are translated structurally; any other subclass is
+/// tabulated through is_member() over the labels [0, domain) when the index has such a domain (flat: row numbers) and
+/// refused otherwise.  Owns the translated objects; `root` is what SearchParameters point at.
+struct AmdSelector {
+    std::vector<FaissAmdIDSelector*> owned;
+    const FaissAmdIDSelector* root = nullptr;
+    AmdSelector(const faiss::IDSelector* sel, idx_t domain) {
+        root = build(sel, domain);
+    }
+    AmdSelector(const AmdSelector&) = delete;
+    ~AmdSelector() {
+        for (auto it = owned.rbegin(); it != owned.rend(); ++it) {
+            faiss_amd_IDSelector_free(*it);
+        }
+    }
+    const FaissAmdIDSelector* keep(FaissAmdIDSelector* s) {
+        owned.push_back(s);
+        return s;
+    }
+    const FaissAmdIDSelector* build(const faiss::IDSelector* sel, idx_t domain) {
+        FAISS_THROW_IF_NOT_MSG(sel, "null IDSelector");
+        FaissAmdIDSelector* out = nullptr;
+        if (auto r = dynamic_cast<const faiss::IDSelectorRange*>(sel)) {
+            amd_check(faiss_amd_IDSelectorRange_new(&out, r->imin, r->imax));
+        } else if (auto a = dynamic_cast<const faiss::IDSelectorArray*>(sel)) {
+            amd_check(faiss_amd_IDSelectorArray_new(&out, a->n, a->ids));
+        } else if (auto b = dynamic_cast<const faiss::IDSelectorBatch*>(sel)) {
+            std::vector<idx_t> ids(b->set.begin(), b->set.end());
+            amd_check(faiss_amd_IDSelectorBatch_new(&out, ids.size(), ids.data()));
+        } else if (auto m = dynamic_cast<const faiss::IDSelectorBitmap*>(sel)) {
+            amd_check(faiss_amd_IDSelectorBitmap_new(&out, m->n, m->bitmap));
+        } else if (dynamic_cast<const faiss::IDSelectorAll*>(sel)) {
+            amd_check(faiss_amd_IDSelectorAll_new(&out));
+        } else if (auto nt = dynamic_cast<const faiss::IDSelectorNot*>(sel)) {
+            const FaissAmdIDSelector* inner = build(nt->sel, domain);
+            amd_check(faiss_amd_IDSelectorNot_new(&out, inner));
+        } else if (auto x = dynamic_cast<const faiss::IDSelectorAnd*>(sel)) {
+            const FaissAmdIDSelector *l = build(x->lhs, domain), *r2 = build(x->rhs, domain);
+            amd_check(faiss_amd_IDSelectorAnd_new(&out, l, r2));
+        } else if (auto x = dynamic_cast<const faiss::IDSelectorOr*>(sel)) {
+            const FaissAmdIDSelector *l = build(x->lhs, domain), *r2 = build(x->rhs, domain);
+            amd_check(faiss_amd_IDSelectorOr_new(&out, l, r2));
+        } else if (auto x = dynamic_cast<const faiss::IDSelectorXOr*>(sel)) {
+            const FaissAmdIDSelector *l = build(x->lhs, domain), *r2 = build(x->rhs, domain);
+            amd_check(faiss_amd_IDSelectorXOr_new(&out, l, r2));
+        } else {
+            FAISS_THROW_IF_NOT_MSG(
+                    domain >= 0, "this IDSelector type cannot be evaluated on the device for arbitrary stored ids");
+            std::vector<uint8_t> bits((size_t)(domain + 7) / 8, 0);
+            for (idx_t i = 0; i < domain; i++) {
+                if (sel->is_member(i)) {
+                    bits[i >> 3] |= (uint8_t)(1u << (i & 7));
+                }
+            }
+            amd_check(faiss_amd_IDSelectorBitmap_new(&out, bits.size(), bits.data()));
+        }
+        return keep(out);
+    }
+};
+
+/// SearchParameters of one call on the backend side (sel translated, nprobe when the caller passed IVF parameters)
+struct AmdSearchParams {
+    std::unique_ptr<AmdSelector> sel;
+    FaissAmdSearchParameters* h = nullptr;
+    /// ivf: create SearchParametersIVF with this nprobe; domain: see AmdSelector
+    AmdSearchParams(const faiss::IDSelector* s, idx_t domain, bool ivf, size_t nprobe) {
+        if (s) {
+            sel.reset(new AmdSelector(s, domain));
+        }
+        if (ivf) {
+            amd_check(faiss_amd_SearchParametersIVF_new_with(&h, sel ? sel->root : nullptr, nprobe, 0));
+        } else {
+            amd_check(faiss_amd_SearchParameters_new(&h, sel ? sel->root : nullptr));
+        }
+    }
+    AmdSearchParams(const AmdSearchParams&) = delete;
+    ~AmdSearchParams() {
+        faiss_amd_SearchParameters_free(h);
     }
 };
 
@@ -92,9 +176,18 @@ struct AmdIndex : faiss::Index {
         amd_check(faiss_amd_Index_add_with_ids(h, n, x, xids));
         sync();
     }
+    /// labels an IDSelector of unknown type can be tabulated over: [0, result), -1 = arbitrary ids (IVF)
+    virtual idx_t selector_domain() const {
+        return -1;
+    }
+    /// params->sel is honoured (IndexFlat::search does, faiss/IndexFlat.cpp:36-58)
     void search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels,
                 const SearchParameters* params = nullptr) const override {
-        FAISS_THROW_IF_NOT_MSG(!params, "search params not supported for this index");
+        if (params && params->sel) {
+            AmdSearchParams sp(params->sel, selector_domain(), false, 0);
+            amd_check(faiss_amd_Index_search_with_params(h, n, x, k, sp.h, distances, labels));
+            return;
+        }
         amd_check(faiss_amd_Index_search(h, n, x, k, distances, labels));
     }
     void assign(idx_t n, const float* x, idx_t* labels, idx_t k = 1) const override {
@@ -131,6 +224,9 @@ struct AmdIndexFlat : AmdIndex {
         return handle;
     }
     AmdIndexFlat(AmdGpuResources* res, int d, MetricType metric = METRIC_L2) : AmdIndex(make(res, d, metric)) {}
+    idx_t selector_domain() const override {
+        return ntotal; // labels are row numbers
+    }
     /// GpuIndexFlat(resources, const IndexFlat*) / copyFrom (faiss/gpu/GpuIndexFlat.cu:125-148)
     AmdIndexFlat(AmdGpuResources* res, const faiss::IndexFlat* index) : AmdIndex(make(res, index->d, index->metric_type)) {
         copyFrom(index);
@@ -214,24 +310,27 @@ struct AmdIndexIVF : AmdIndex, faiss::IndexIVFInterface {
     /// nprobe is a public data member callers assign to (index.nprobe = 32): it travels with every call
     void search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels,
                 const SearchParameters* params = nullptr) const override {
-        FaissAmdSearchParametersIVF sp;
-        sp.nprobe = (int)nprobe;
+        size_t np = nprobe;
+        const faiss::IDSelector* sel = nullptr;
         if (params) {
             auto ivf_params = dynamic_cast<const SearchParametersIVF*>(params);
             FAISS_THROW_IF_NOT_MSG(ivf_params, "IndexIVF params have incorrect type");
-            FAISS_THROW_IF_NOT_MSG(!ivf_params->sel, "IDSelector is not supported (as in faiss/gpu without cuVS)");
-            sp.nprobe = (int)ivf_params->nprobe;
+            FAISS_THROW_IF_NOT_MSG(ivf_params->max_codes == 0, "max_codes is not supported (faiss/gpu/GpuIndexIVF.cu:372)");
+            np = ivf_params->nprobe;
+            sel = ivf_params->sel; // on the stored ids, as IndexIVF::search applies it (faiss/IndexIVF.cpp scan_codes)
         }
-        amd_check(faiss_amd_GpuIndexIVF_search_with_params(h, n, x, k, &sp, distances, labels));
+        AmdSearchParams sp(sel, -1, true, np);
+        amd_check(faiss_amd_Index_search_with_params(h, n, x, k, sp.h, distances, labels));
     }
     void search_preassigned(idx_t n, const float* x, idx_t k, const idx_t* assign, const float* centroid_dis,
                             float* distances, idx_t* labels, bool store_pairs,
                             const IVFSearchParameters* params = nullptr, IndexIVFStats* stats = nullptr) const override {
         FAISS_THROW_IF_NOT_MSG(!store_pairs, "store_pairs is not supported (faiss/gpu/GpuIndexIVF.cu:424-426)");
         FAISS_THROW_IF_NOT_MSG(!stats, "IndexIVFStats are not supported");
-        const size_t np = params ? params->nprobe : nprobe;
-        amd_check(faiss_amd_IndexIVF_set_nprobe(h, (int)np)); // assign / centroid_dis are [n][np]
-        amd_check(faiss_amd_GpuIndexIVF_search_preassigned(h, n, x, k, assign, centroid_dis, distances, labels));
+        const size_t np = params ? params->nprobe : nprobe; // assign / centroid_dis are [n][np]
+        AmdSearchParams sp(params ? params->sel : nullptr, -1, true, np);
+        amd_check(faiss_amd_GpuIndexIVF_search_preassigned_with_params(h, n, x, k, assign, centroid_dis, sp.h, distances,
+                                                                       labels));
     }
     void range_search_preassigned(idx_t, const float*, float, const idx_t*, const float*, RangeSearchResult*, bool,
                                   const IVFSearchParameters*, IndexIVFStats*) const override {

@@ -272,6 +272,21 @@ class RefIndex:
                                                   ctypes.c_int64(k), ctypes.c_int(nprobe), _p(D), _p(I)))
         return D, I
 
+    def search_sel(self, x, k, kind, a=0, b=0, data=None, negate=False, nprobe=0):
+        """index.search(x, k, params=SearchParameters[IVF](sel=...)) with a faiss::IDSelector described by scalars
+        (oracle/ref_shim.cpp ref_index_search_sel): kind 0 Range [a, b), 1 Batch(ids), 2 Array(ids), 3 Bitmap(bytes),
+        4 And(Range [a, b), Not(Batch(ids))), 5 a custom selector id % a == b, 6 XOr(Range [a, b), Or(Bitmap, All))"""
+        x = _f32(x)
+        D = np.empty((x.shape[0], k), dtype=np.float32)
+        I = np.empty((x.shape[0], k), dtype=np.int64)
+        if data is None:
+            data = np.zeros(0, dtype=np.int64)
+        data = np.ascontiguousarray(data, dtype=np.uint8 if kind in (3, 6) else np.int64).reshape(-1)
+        self._ck(self.lib.ref_index_search_sel(ctypes.c_void_p(self.h), ctypes.c_int64(x.shape[0]), _p(x), ctypes.c_int64(k),
+                                               ctypes.c_int(nprobe), ctypes.c_int(kind), ctypes.c_int64(a), ctypes.c_int64(b),
+                                               ctypes.c_size_t(data.size), _p(data), ctypes.c_int(int(negate)), _p(D), _p(I)))
+        return D, I
+
     def assign(self, x, k=1):
         x = _f32(x)
         I = np.empty((x.shape[0], k), dtype=np.int64)

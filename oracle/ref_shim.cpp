@@ -345,6 +345,64 @@ int ref_index_search_nprobe(void* p, idx_t n, const float* x, idx_t k, int nprob
     ((faiss::Index*)p)->search(n, x, k, D, I, &sp);
     SHIM_CATCH
 }
+// search restricted by a faiss::IDSelector (SearchParameters::sel) described by a few scalars, so that the CPU indexes of
+// the reference and the bridge indexes can be driven with the SAME selector objects from the tests:
+//   kind 0 IDSelectorRange [a, b)   1 IDSelectorBatch(nsel ids)   2 IDSelectorArray(nsel ids)   3 IDSelectorBitmap(nsel bytes)
+//   4 IDSelectorAnd(IDSelectorRange [a, b), IDSelectorNot(IDSelectorBatch(nsel ids)))
+//   5 a selector type the bridge does not know (id % a == b): exercises its tabulating fallback
+//   6 IDSelectorXOr(IDSelectorRange [a, b), IDSelectorOr(IDSelectorBitmap(nsel bytes), IDSelectorAll)) = not in [a, b)
+// negate wraps the result in IDSelectorNot.  nprobe > 0: SearchParametersIVF, else SearchParameters.
+struct ModuloSelector : faiss::IDSelector {
+    idx_t m, r;
+    ModuloSelector(idx_t m_, idx_t r_) : m(m_), r(r_) {}
+    bool is_member(idx_t id) const override {
+        return id % m == r;
+    }
+};
+int ref_index_search_sel(void* p, idx_t n, const float* x, idx_t k, int nprobe, int kind, idx_t a, idx_t b, size_t nsel,
+                         const void* data, int negate, float* D, idx_t* I) {
+    SHIM_TRY std::vector<std::unique_ptr<faiss::IDSelector>> own;
+    auto mk = [&](faiss::IDSelector* s) {
+        own.emplace_back(s);
+        return s;
+    };
+    faiss::IDSelector* sel = nullptr;
+    switch (kind) {
+        case 0: sel = mk(new faiss::IDSelectorRange(a, b)); break;
+        case 1: sel = mk(new faiss::IDSelectorBatch(nsel, (const idx_t*)data)); break;
+        case 2: sel = mk(new faiss::IDSelectorArray(nsel, (const idx_t*)data)); break;
+        case 3: sel = mk(new faiss::IDSelectorBitmap(nsel, (const uint8_t*)data)); break;
+        case 4: {
+            auto* r = mk(new faiss::IDSelectorRange(a, b));
+            auto* bt = mk(new faiss::IDSelectorBatch(nsel, (const idx_t*)data));
+            auto* nb = mk(new faiss::IDSelectorNot(bt));
+            sel = mk(new faiss::IDSelectorAnd(r, nb));
+            break;
+        }
+        case 5: sel = mk(new ModuloSelector(a, b)); break;
+        case 6: {
+            auto* r = mk(new faiss::IDSelectorRange(a, b));
+            auto* bm = mk(new faiss::IDSelectorBitmap(nsel, (const uint8_t*)data));
+            auto* all = mk(new faiss::IDSelectorAll());
+            auto* o = mk(new faiss::IDSelectorOr(bm, all));
+            sel = mk(new faiss::IDSelectorXOr(r, o));
+            break;
+        }
+        default: FAISS_THROW_MSG("unknown selector kind");
+    }
+    if (negate) sel = mk(new faiss::IDSelectorNot(sel));
+    if (nprobe > 0) {
+        faiss::SearchParametersIVF sp;
+        sp.nprobe = nprobe;
+        sp.sel = sel;
+        ((faiss::Index*)p)->search(n, x, k, D, I, &sp);
+    } else {
+        faiss::SearchParameters sp;
+        sp.sel = sel;
+        ((faiss::Index*)p)->search(n, x, k, D, I, &sp);
+    }
+    SHIM_CATCH
+}
 int ref_index_assign(void* p, idx_t n, const float* x, idx_t* labels, idx_t k) {
     SHIM_TRY((faiss::Index*)p)->assign(n, x, labels, k);
     SHIM_CATCH
