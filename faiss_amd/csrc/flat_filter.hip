@@ -99,13 +99,22 @@ __global__ void __launch_bounds__(64) prep_queries_kernel(const float* __restric
         o[c] = (_Float16)v;
     }
     const bool anybad = __ballot(bad) != 0ull;
+    // |q|^2: ONE sequential chain over k = 0 .. dpad-1 (the order of l2_norms_kernel / the oracle).  The coordinates are
+    // loaded by all lanes, 64 at a time, and handed to the chain through v_readlane (a scalar operand of the fma)
+    // instead of 128 dependent single-lane loads (40 us per 10k queries, round 2 profile); the zeros behind dpad are
+    // fmaf(0, 0, acc) = acc, exact no-ops.
+    float acc = 0.f;
+    for (int base = 0; base < dpad; base += 64) {
+        const int c = base + (int)threadIdx.x;
+        const float v = c < dpad ? r[c] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 64; ++k) {
+            const float vk = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), k));
+            acc = __fmaf_rn(vk, vk, acc);
+        }
+    }
     if (threadIdx.x == 0) {
         flags[i] = anybad ? 1u : 0u;
-        float acc = 0.f;
-        for (int k = 0; k < dpad; ++k) {
-            const float v = r[k];
-            acc = __fmaf_rn(v, v, acc);
-        }
         qnorm[i] = acc;
         if (i == 0) *counter = 0u;
     }
@@ -812,8 +821,16 @@ __global__ void __launch_bounds__(RR_THREADS) flat_rerank_kernel(FlatRerankParam
         if (cnt) {
             const unsigned base = atomicAdd(&sh->total, cnt);
             const u64* seg = p.res_keys + ((int64_t)q * p.nsplit + s) * p.cap;
-            for (unsigned i = 0; i < cnt; ++i)
-                if (base + i < (unsigned)p.gcap) cand[base + i] = seg[i];
+            // four keys per round trip (a segment holds ~3 on average; one load per iteration would serialise
+            // their latencies).  The slots behind cnt belong to the segment (cap >= 32, a multiple of 4).
+            for (unsigned i = 0; i < cnt; i += 4) {
+                u64 kv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) kv[u] = seg[i + u];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (i + u < cnt && base + i + u < (unsigned)p.gcap) cand[base + i + u] = kv[u];
+            }
         }
     }
     __syncthreads();
@@ -844,22 +861,49 @@ __global__ void __launch_bounds__(RR_THREADS) flat_rerank_kernel(FlatRerankParam
         const float* yr = p.xb ? p.xb + (int64_t)row * p.ldb : nullptr;
         const _Float16* yh = p.xb16 + (int64_t)row * p.ldb16;
         float acc = 0.f;
-        for (int s = 0; s < p.dpad; s += 8) {
-            f32x4 y0, y1;
-            if (yr) {
-                y0 = *(const f32x4*)(yr + s);
-                y1 = *(const f32x4*)(yr + s + 4);
-            } else {
-                // fp16 storage: the stored values, widened (exact), through the same chain
-                const half8 hv = *(const half8*)(yh + s);
-                y0 = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
-                y1 = f32x4{(float)hv[4], (float)hv[5], (float)hv[6], (float)hv[7]};
-            }
+        // one 8-float step of the chain (the order of flat_scan_kernel's MFMA k-steps: e, 4 + e interleaved)
+        auto step = [&](const f32x4& y0, const f32x4& y1, int s) {
             const f32x4 q0 = *(const f32x4*)(qs + s), q1 = *(const f32x4*)(qs + s + 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 acc = __fmaf_rn(y0[e], q0[e], acc);
                 acc = __fmaf_rn(y1[e], q1[e], acc);
+            }
+        };
+        // The row is a random 512-byte (fp16 storage: 256-byte) read: all loads of a 32-float stretch are issued
+        // before the chain consumes the first of them -- one memory round trip per stretch instead of one per step
+        // (the chain itself stays the sequential one).
+        int s = 0;
+        if (yr) {
+            for (; s + 32 <= p.dpad; s += 32) {
+                f32x4 y[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) y[u] = *(const f32x4*)(yr + s + 4 * u);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) step(y[2 * u], y[2 * u + 1], s + 8 * u);
+            }
+            for (; s < p.dpad; s += 8) step(*(const f32x4*)(yr + s), *(const f32x4*)(yr + s + 4), s);
+        } else {
+            // fp16 storage: the stored values, widened (exact), through the same chain
+            auto widen = [](const half8& hv, f32x4& y0, f32x4& y1) {
+                y0 = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+                y1 = f32x4{(float)hv[4], (float)hv[5], (float)hv[6], (float)hv[7]};
+            };
+            for (; s + 32 <= p.dpad; s += 32) {
+                half8 hv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) hv[u] = *(const half8*)(yh + s + 8 * u);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    f32x4 y0, y1;
+                    widen(hv[u], y0, y1);
+                    step(y0, y1, s + 8 * u);
+                }
+            }
+            for (; s < p.dpad; s += 8) {
+                f32x4 y0, y1;
+                widen(*(const half8*)(yh + s), y0, y1);
+                step(y0, y1, s);
             }
         }
         float dis;

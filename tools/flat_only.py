@@ -27,3 +27,9 @@ for dbg in os.environ.get("DBG_LIST", "0").split(","):
         idx.search_ptr(NQ, xq_dev.data_ptr(), 100, Dd.data_ptr(), Id.data_ptr())
     torch.cuda.synchronize()
     print("flat search nq=%d (dbg %s nsplit %s geom %s): %.3f ms/step" % (NQ, dbg, os.environ.get("FAISS_AMD_FILTER_NSPLIT"), os.environ.get("FAISS_AMD_FILTER_GEOM"), (time.time() - t0) / steps * 1e3), flush=True)
+    res.profile_enable(True); res.profile_reset()
+    idx.search_ptr(NQ, xq_dev.data_ptr(), 100, Dd.data_ptr(), Id.data_ptr())
+    print("   per kernel (ms, launches):", {kn: tuple(round(v, 4) for v in res.profile_get(kn)) for kn in (
+        "convert_f16_query", "flat_filter_kernel_max", "flat_tighten_kernel", "flat_filter_kernel", "flat_rerank_kernel")})
+    res.profile_enable(False)
+
