@@ -788,6 +788,7 @@ void launch_flat_tighten(const FlatFilterParams& p, hipStream_t stream) {
 constexpr int RR_THREADS = 256;
 constexpr int RR_GATHER = 4096; // upper limit of FlatRerankParams::gcap (approximate candidates gathered into LDS)
 constexpr int RR_CAND = 2048;   // rows inside the error band that are re-ranked exactly
+constexpr int RR_RANK_MAX = 512; // final stage: up to this many keys go straight to their rank (rank_of) instead of select + sort
 
 struct RrShared {
     unsigned hist[256];
@@ -840,9 +841,34 @@ __global__ void __launch_bounds__(RR_THREADS) flat_rerank_kernel(FlatRerankParam
         return;
     }
 
+    // rank of key x among cand[0, n) = number of smaller keys (keys are unique); two keys per LDS read, every lane the
+    // same address (broadcast).  For the few hundred keys a query has here this beats the radix select (up to eight
+    // histogram passes with three barriers each, most of them over a digit all keys share) and, at the end, replaces
+    // select + sorting network: the rank IS the output position.
+    auto rank_of = [&](u64 x, int n_) {
+        int r = 0;
+        const ulonglong2* c2 = (const ulonglong2*)cand;
+        for (int i = 0; i < n_; i += 2) {
+            const ulonglong2 kk = c2[i >> 1];
+            r += (kk.x < x ? 1 : 0) + ((i + 1 < n_ && kk.y < x) ? 1 : 0);
+        }
+        return r;
+    };
+
     // ---- k-th best approximate score over all splits -> error band -> rows to re-rank
     if (n > p.k) {
-        const u64 kth = wg_select_kth<RR_THREADS>(cand, n, p.k, sh->hist, &sh->ctl);
+        u64 kth;
+        if (n <= RR_THREADS) { // (one key per thread; beyond that the radix select is the faster one)
+            if (tid < n) {
+                const u64 x = cand[tid];
+                if (rank_of(x, n) == p.k - 1) sh->ctl.kth = x;
+            }
+            __syncthreads();
+            kth = sh->ctl.kth;
+            // (wg_compact below starts with a barrier before anything is rewritten)
+        } else {
+            kth = wg_select_kth<RR_THREADS>(cand, n, p.k, sh->hist, &sh->ctl);
+        }
         const float e = flat_filter_err_bound(METRIC, p.d, p.xqn[q], p.yn_max, p.exact_inputs != 0);
         const float thr = band_threshold(key_score((uint32_t)(kth >> 32)), e);
         const u64 key_thr = ((u64)score_key(thr) << 32) | 0xffffffffull;
@@ -918,6 +944,25 @@ __global__ void __launch_bounds__(RR_THREADS) flat_rerank_kernel(FlatRerankParam
     __syncthreads();
 
     // ---- exact top-k under (distance, id)
+    if (n <= RR_RANK_MAX) {
+        // the usual case (k plus the few rows inside the error band): every key straight to its rank
+        const float pad = neutral_distance(METRIC);
+        for (int c = tid; c < n; c += RR_THREADS) {
+            const u64 key = cand[c];
+            const int r = rank_of(key, n);
+            if (r < p.k) {
+                const uint32_t wk = (uint32_t)(key >> 32);
+                const bool ok = wk < kInvalidOrdKey;
+                p.out_dis[(int64_t)q * p.k + r] = ok ? unordkey<METRIC>(wk) : pad;
+                p.out_ids[(int64_t)q * p.k + r] = ok ? (int64_t)(uint32_t)key + p.id_base : -1;
+            }
+        }
+        for (int i = n + tid; i < p.k; i += RR_THREADS) {
+            p.out_dis[(int64_t)q * p.k + i] = pad;
+            p.out_ids[(int64_t)q * p.k + i] = -1;
+        }
+        return;
+    }
     if (n > p.k) {
         const u64 kth = wg_select_kth<RR_THREADS>(cand, n, p.k, sh->hist, &sh->ctl);
         wg_compact<RR_THREADS>(cand, n, kth, &sh->ctl);
