@@ -666,8 +666,8 @@ void GpuIndexFlat::plan_filter_(int n, int k, int& geom, int& nsplit, int& tstri
     }
     // large batches of d <= 128: 8 waves x 128 queries per workgroup, one workgroup per CU;
     // otherwise 4 waves x 64 queries, two workgroups per CU.  The 1024-query workgroups pay off only when they are
-    // (nearly) full: measured nq = 2560 (2.5 groups) 1.10 ms against 0.94 ms with the small geometry, nq = 5120 (5 full
-    // groups) 1.60 against 1.71, nq = 10000 (9.8) 3.1 against 3.4 (profiles/r02_g_flat_batch_sizes.txt)
+    // (nearly) full: measured nq = 2560 (2.5 groups) 1.10 ms against 0.94 ms with the small geometry, nq = 1280 0.77
+    // against 0.53, nq = 5120 (5 full groups) 1.60 against 1.71 (profiles/r02_g_flat_batch_sizes.txt)
     const double fill2 = (double)n / ((double)div_up((size_t)n, 1024) * 1024.0);
     geom = (dh_ == kFilterSlab && n >= 2048 && fill2 >= 0.92) ? 2 : 0;
     if (const char* e = getenv("FAISS_AMD_FILTER_GEOM")) { // timing experiments only
