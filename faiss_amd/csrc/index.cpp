@@ -319,6 +319,7 @@ GpuIndexFlat::GpuIndexFlat(std::shared_ptr<GpuResources> res, int dims, int metr
 }
 GpuIndexFlat::~GpuIndexFlat() {
     (void)hipSetDevice(res_->device);
+    if (h_novf_) (void)hipHostFree(h_novf_);
 }
 
 const float* GpuIndexFlat::device_vectors() const {
@@ -830,9 +831,10 @@ void GpuIndexFlat::search_tile_(int n, const float* xq_pad, int k, float* dD, id
         launch_flat_rerank(rp, R.stream);
     }
     // ---- queries whose segments overflowed (or left the fp16 range) go through the exact fp32 scan
-    unsigned novf = 0;
-    HIP_CHECK(hipMemcpyAsync(&novf, scal_.as<unsigned>() + 2, 4, hipMemcpyDeviceToHost, R.stream));
+    if (!h_novf_) HIP_CHECK(hipHostMalloc((void**)&h_novf_, 64, hipHostMallocDefault));
+    HIP_CHECK(hipMemcpyAsync(h_novf_, scal_.as<unsigned>() + 2, 4, hipMemcpyDeviceToHost, R.stream));
     R.sync();
+    const unsigned novf = *h_novf_;
     last_filter_overflow = (int)novf;
     if (novf > 0) {
         ovf_q_.ensure((size_t)novf * dpad_ * 4);
@@ -1027,9 +1029,7 @@ void GpuIndexFlat::prepare_selector_(const IDSelector& sel) const {
     sel.compile(prog, R.device, R.stream);
     const size_t words = div_up((size_t)std::max<idx_t>(ntotal, 1), 64);
     sel_mask_.ensure(words * 8);
-    sel_cnt_.ensure(8);
-    HIP_CHECK(hipMemsetAsync(sel_cnt_.p, 0, 8, R.stream));
-    launch_selector_mask(nullptr, ntotal, 0, prog, sel_mask_.as<uint64_t>(), sel_cnt_.as<unsigned long long>(), R.stream);
+    launch_selector_mask(nullptr, ntotal, 0, prog, sel_mask_.as<uint64_t>(), nullptr, R.stream);
     sel_xbhn_.ensure((size_t)(ntotal + kFilterTileRows) * 4);
     launch_mask_bias(xbhn_.as<float>(), sel_mask_.as<uint32_t>(), ntotal, kFilterTileRows, -INFINITY, -INFINITY,
                      sel_xbhn_.as<float>(), R.stream);
@@ -1038,10 +1038,7 @@ void GpuIndexFlat::prepare_selector_(const IDSelector& sel) const {
         launch_mask_bias(xbn_.as<float>(), sel_mask_.as<uint32_t>(), ntotal, 0, INFINITY, INFINITY, sel_xbn_.as<float>(),
                          R.stream);
     }
-    unsigned long long cnt = 0;
-    HIP_CHECK(hipMemcpyAsync(&cnt, sel_cnt_.p, 8, hipMemcpyDeviceToHost, R.stream));
-    R.sync();
-    last_sel_count_ = (idx_t)cnt;
+    // (everything stays on the stream: no read-back, the searches that follow are ordered behind the mask)
 }
 
 void GpuIndexFlat::search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels,

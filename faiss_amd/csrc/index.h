@@ -278,6 +278,9 @@ class GpuIndexFlat : public Index {
     int dh_;
     DevBuf xbh_, xbhn_;
     DevBuf scal_;            // device scalars: [0] max |x| bits, [1] max |y|^2 bits, [2] overflow counter
+    // pinned host word the overflow count of a filter search is copied to (a pageable destination would make the 4-byte
+    // read-back a staged, blocking copy: tens of microseconds on every search)
+    mutable unsigned* h_novf_ = nullptr;
     float yn_max_ = 0.f;     // max squared norm over the database
     bool db_f16_ok_ = true;  // every database value inside the fp16 range (no NaN/inf)
     mutable DevBuf qh_, flags_, thr_, maxes_, ovf_list_, ovf_q_, ovf_d_, ovf_i_;
@@ -294,8 +297,7 @@ class GpuIndexFlat : public Index {
     // IDSelector of the search in flight (under mu_): row mask, and the start values / norms with the excluded rows
     // set to -inf / +inf -- the filter and scan kernels then skip those rows without knowing about selectors
     mutable bool sel_active_ = false;
-    mutable DevBuf sel_mask_, sel_xbhn_, sel_xbn_, sel_cnt_;
-    mutable idx_t last_sel_count_ = -1; // rows the last selector admitted (tests)
+    mutable DevBuf sel_mask_, sel_xbhn_, sel_xbn_;
     void prepare_selector_(const IDSelector& sel) const;
     // persistent scratch
     mutable DevBuf q_raw_, q_pad_, q_norm_, res_keys_, res_cnt_, out_d_, out_i_, all_keys_, one_cnt_;
