@@ -145,8 +145,10 @@ struct IDSelectorBatch : IDSelector {
     void compile(SelProgram& prog, int device, hipStream_t stream) const override;
 
    private:
-    mutable DevBuf dev_;
-    mutable int dev_id_ = -1;
+    // one device copy per device, made on first use under the lock: the shards of a threaded IndexShards search with
+    // the same selector object concurrently, possibly on different devices
+    mutable std::mutex mu_;
+    mutable std::map<int, DevBuf> dev_;
 };
 typedef IDSelectorBatch IDSelectorArray;
 // id selected iff id / 8 < n and bit id % 8 of bitmap[id / 8] is set (IDSelector.cpp:123-129); the bitmap is copied
@@ -160,8 +162,8 @@ struct IDSelectorBitmap : IDSelector {
     void compile(SelProgram& prog, int device, hipStream_t stream) const override;
 
    private:
-    mutable DevBuf dev_;
-    mutable int dev_id_ = -1;
+    mutable std::mutex mu_;
+    mutable std::map<int, DevBuf> dev_; // per device, see IDSelectorBatch
 };
 // the operands are not owned (as in the reference)
 struct IDSelectorNot : IDSelector {

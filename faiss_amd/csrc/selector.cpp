@@ -16,14 +16,16 @@ static SelInstr& sel_push(SelProgram& prog, int op) {
     return in;
 }
 
-// device copy of a host array, made once per device (selectors are immutable after construction)
-static const void* sel_upload(DevBuf& dev, int& dev_id, const void* src, size_t bytes, int device, hipStream_t stream) {
-    if (dev_id != device) {
-        dev.release();
+// device copy of a host array, made once per device (selectors are immutable after construction; the current device is
+// `device`, set by the search that compiles the selector)
+static const void* sel_upload(std::mutex& mu, std::map<int, DevBuf>& copies, const void* src, size_t bytes, int device,
+                              hipStream_t stream) {
+    std::lock_guard<std::mutex> g(mu);
+    DevBuf& dev = copies[device];
+    if (!dev.p) {
         dev.ensure(std::max<size_t>(bytes, 16));
         if (bytes) HIP_CHECK(hipMemcpyAsync(dev.p, src, bytes, hipMemcpyHostToDevice, stream));
         HIP_CHECK(hipStreamSynchronize(stream)); // the host array may be pageable
-        dev_id = device;
     }
     return dev.p;
 }
@@ -48,13 +50,13 @@ bool IDSelectorBatch::is_member(idx_t id) const {
 void IDSelectorBatch::compile(SelProgram& prog, int device, hipStream_t stream) const {
     SelInstr& in = sel_push(prog, SEL_SET);
     in.a = (int64_t)ids.size();
-    in.ptr = sel_upload(dev_, dev_id_, ids.data(), ids.size() * sizeof(idx_t), device, stream);
+    in.ptr = sel_upload(mu_, dev_, ids.data(), ids.size() * sizeof(idx_t), device, stream);
 }
 
 void IDSelectorBitmap::compile(SelProgram& prog, int device, hipStream_t stream) const {
     SelInstr& in = sel_push(prog, SEL_BITMAP);
     in.a = (int64_t)bitmap.size();
-    in.ptr = sel_upload(dev_, dev_id_, bitmap.data(), bitmap.size(), device, stream);
+    in.ptr = sel_upload(mu_, dev_, bitmap.data(), bitmap.size(), device, stream);
 }
 
 void IDSelectorNot::compile(SelProgram& prog, int device, hipStream_t stream) const {

@@ -22,6 +22,14 @@ import torch
 import torch.distributed as dist
 
 
+def _fence(t):
+    """The collective that read or wrote `t` has completed.  A blocking NCCL (RCCL) collective only orders itself against
+    torch's CURRENT stream; the library searches on its own stream, so without this the next local search could rewrite
+    the per-rank result buffers while the previous gather is still sending them.  (gloo / CPU tensors: nothing to do.)"""
+    if t.is_cuda:
+        torch.cuda.current_stream(t.device).synchronize()
+
+
 class ShardedSearcher:
     """IndexShards(successive_ids=True) across the ranks of a torch.distributed group.
 
@@ -54,9 +62,11 @@ class ShardedSearcher:
                 self._gI = torch.empty((self.world, nq, k), dtype=torch.int64, device=self.device)
             dist.gather(D, list(self._gD.unbind(0)), dst=0, group=self.group)
             dist.gather(I, list(self._gI.unbind(0)), dst=0, group=self.group)
+            _fence(self._gI)
             return self.merge(self._gD, self._gI, self.base)
         dist.gather(D, None, dst=0, group=self.group)
         dist.gather(I, None, dst=0, group=self.group)
+        _fence(I)
         return None
 
 
@@ -92,10 +102,12 @@ class ReplicatedSearcher:
                 self._gI = torch.empty((self.world, self.per, k), dtype=torch.int64, device=self.device)
             dist.gather(D, list(self._gD.unbind(0)), dst=0, group=self.group)
             dist.gather(I, list(self._gI.unbind(0)), dst=0, group=self.group)
+            _fence(self._gI)
             # blocks are consecutive query ranges of equal size: the gathered buffer IS the result
             return self._gD.view(-1, k)[: self.nq], self._gI.view(-1, k)[: self.nq]
         dist.gather(D, None, dst=0, group=self.group)
         dist.gather(I, None, dst=0, group=self.group)
+        _fence(I)
         return None
 
 

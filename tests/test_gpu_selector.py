@@ -181,22 +181,26 @@ def test_shards_forward_search_parameters(res):
     ids = np.random.RandomState(2).permutation(nb).astype(np.int64) + 100
     cent, _ = faiss_amd.kmeans(res, xt, nlist, niter=4, seed=3)
 
-    def make():
-        i = faiss_amd.GpuIndexIVFFlat(res, d, nlist, METRIC_L2)
+    def make(r=res):
+        i = faiss_amd.GpuIndexIVFFlat(r, d, nlist, METRIC_L2)
         i.copy_centroids(cent)
         i.nprobe = 4
         return i
 
     whole = make()
     whole.add_with_ids(xb, ids)
-    shards = faiss_amd.IndexShards(d, threaded=False, successive_ids=False)
+    # one resources object (stream) per shard, one host thread per shard: the shards compile and upload the SAME selector
+    # objects concurrently
+    shards = faiss_amd.IndexShards(d, threaded=True, successive_ids=False)
     for _ in range(3):
-        shards.add_shard(make())
+        shards.add_shard(make(faiss_amd.StandardGpuResources(0)))
     shards.add_with_ids(xb, ids)
     sel = faiss_amd.IDSelectorRange(2000, 9000) & ~faiss_amd.IDSelectorBatch(ids[::3])
     Dw, Iw = whole.search(xq, k, params=SPI(sel=sel))
-    Ds, Is = shards.search(xq, k, params=SPI(sel=sel))
-    assert np.array_equal(Iw, Is) and np.array_equal(Dw, Ds)
+    for _ in range(3):
+        fresh = faiss_amd.IDSelectorRange(2000, 9000) & ~faiss_amd.IDSelectorBatch(ids[::3])  # (first use: upload race)
+        Ds, Is = shards.search(xq, k, params=SPI(sel=fresh))
+        assert np.array_equal(Iw, Is) and np.array_equal(Dw, Ds)
     rep = faiss_amd.IndexReplicas(d, threaded=False)
     rep.add_replica(make())
     with pytest.raises(faiss_amd.FaissAmdError, match="search params not supported"):
