@@ -106,6 +106,7 @@ def load_library():
         "faiss_amd_Index_compute_residual": (i32, [vp, vp, vp, i64]),
         "faiss_amd_Index_compute_residual_n": (i32, [vp, i64, vp, vp, vp]),
         "faiss_amd_GpuIndexIVF_search_preassigned": (i32, [vp, i64, vp, i64, vp, vp, vp, vp]),
+        "faiss_amd_GpuIndexIVF_add_core": (i32, [vp, i64, vp, vp, vp]),
         "faiss_amd_IndexIVF_quantizer_search": (i32, [vp, i64, vp, i64, vp, vp]),
         "faiss_amd_bfKnn": (i32, [vp, i32, vp, i64, vp, i64, i32, i64, vp, vp]),
         "faiss_amd_GpuIndexFlat_new_with_config": (i32, [P(vp), vp, i32, i32, vp]),
@@ -430,6 +431,20 @@ class _GpuIndexIVF(Index):
         I = np.empty((x.shape[0], k), dtype=np.int64)
         _check(self._lib.faiss_amd_IndexIVF_quantizer_search(self._h, x.shape[0], _ptr(x), int(k), _ptr(D), _ptr(I)))
         return D, I
+
+    def add_core(self, x, assign, ids=None):
+        """index.add_core(n, x, ids, assign) of the reference (GpuIndexIVF::add_core; contrib/ivf_tools.py
+        add_preassigned): add with the inverted list of every vector given by the caller"""
+        x = _f32(x, self.d)
+        assign = np.ascontiguousarray(assign, dtype=np.int64)
+        if assign.shape != (x.shape[0],):
+            raise ValueError("one list number per vector")
+        if ids is not None:
+            ids = np.ascontiguousarray(ids, dtype=np.int64)
+            if ids.shape != (x.shape[0],):
+                raise ValueError("ids must have one entry per vector")
+        _check(self._lib.faiss_amd_GpuIndexIVF_add_core(self._h, x.shape[0], _ptr(x), _ptr(ids) if ids is not None else None,
+                                                        _ptr(assign)))
 
     def search_preassigned(self, x, k, Iq, Dq, params=None):
         """faiss python `index.search_preassigned(x, k, Iq, Dq, params=None)` (class_wrappers.py
@@ -763,6 +778,11 @@ class IndexReplicas(Index):
         _check(self._lib.faiss_amd_IndexReplicas_add_replica(self._h, index._h))
 
     addIndex = add_replica
+
+
+def add_preassigned(index_ivf, x, a, ids=None):
+    """faiss.contrib.ivf_tools.add_preassigned (contrib/ivf_tools.py:12-24)"""
+    index_ivf.add_core(x, a, ids)
 
 
 def kmeans(res, x, k, niter=25, seed=1234):

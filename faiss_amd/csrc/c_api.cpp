@@ -571,6 +571,12 @@ int faiss_amd_GpuIndexFlat_filter_scores(const FaissAmdIndex* index, faiss_amd_i
     as<GpuIndexFlat>(index, "GpuIndexFlat")->filter_scores(n, x, scores, err_bound);
     FA_CATCH
 }
+int faiss_amd_GpuIndexIVF_add_core(FaissAmdIndex* index, faiss_amd_idx_t n, const float* x, const faiss_amd_idx_t* xids,
+                                   const faiss_amd_idx_t* precomputed_idx) {
+    FA_TRY
+    as<GpuIndexIVF>(index, "GpuIndexIVF")->add_core(n, x, xids, precomputed_idx);
+    FA_CATCH
+}
 int faiss_amd_GpuIndexIVF_search_preassigned(const FaissAmdIndex* index, faiss_amd_idx_t n, const float* x,
                                              faiss_amd_idx_t k, const faiss_amd_idx_t* assign, const float* centroid_dis,
                                              float* distances, faiss_amd_idx_t* labels) {

@@ -1569,7 +1569,11 @@ void GpuIndexIVF::compact_() {
 // staged once, assigned to their lists (k = 1 search on the quantizer), ranked inside their lists by a stable
 // counting sort on the device (ivf_kernels.hip) and encoded / scattered into the lists' slack.  The host sees
 // nlist list lengths per page, never a per-vector array.
-void GpuIndexIVF::add_core_(idx_t n, const float* x, const idx_t* xids) {
+void GpuIndexIVF::add_core(idx_t n, const float* x, const idx_t* xids, const idx_t* precomputed_idx) {
+    FA_THROW_IF_NOT_MSG(n == 0 || precomputed_idx, "precomputed IVF assignments must not be null");
+    add_core_(n, x, xids, precomputed_idx);
+}
+void GpuIndexIVF::add_core_(idx_t n, const float* x, const idx_t* xids, const idx_t* assign) {
     FA_THROW_IF_NOT_MSG(is_trained, "index must be trained before adding vectors");
     if (n == 0) return;
     FA_THROW_IF_NOT_MSG(x, "null argument");
@@ -1595,8 +1599,13 @@ void GpuIndexIVF::add_core_(idx_t n, const float* x, const idx_t* xids) {
         const int ni = (int)std::min(page, n - i0);
         const int nchunks = (int)div_up(ni, chunk);
         stage_padded(R, x + (size_t)i0 * d, ni, d, dpad_, q_raw_, a_xpad_.as<float>());
-        // ---- coarse assignment (NaN vectors get label -1 and are skipped, like the reference)
-        quantizer->search_device(ni, a_xpad_.as<float>(), 1, a_dis_.as<float>(), a_lab_.as<idx_t>());
+        // ---- coarse assignment (NaN vectors get label -1 and are skipped, like the reference), or the caller's
+        if (assign) {
+            HIP_CHECK(hipMemcpyAsync(a_lab_.p, assign + i0, (size_t)ni * 8, hipMemcpyDefault, R.stream));
+            launch_ivf_sanitize_assign(a_lab_.as<idx_t>(), ni, nlist, R.stream);
+        } else {
+            quantizer->search_device(ni, a_xpad_.as<float>(), 1, a_dis_.as<float>(), a_lab_.as<idx_t>());
+        }
         if (xids) {
             HIP_CHECK(hipMemcpyAsync(a_ids_.p, xids + i0, (size_t)ni * 8, hipMemcpyDefault, R.stream));
         } else {

@@ -319,6 +319,11 @@ class GpuIndexIVF : public Index {
     void train(idx_t n, const float* x) override;
     void add(idx_t n, const float* x) override;
     void add_with_ids(idx_t n, const float* x, const idx_t* xids) override;
+    // GpuIndexIVF::add_core (faiss/gpu/GpuIndexIVF.cu:321-356; what contrib/ivf_tools.py add_preassigned calls): add
+    // with the inverted-list assignment supplied by the caller instead of the coarse quantizer's.  precomputed_idx: [n],
+    // host or device; an entry outside [0, nlist) leaves its vector out (it still counts in ntotal, like a NaN vector).
+    // xids may be null (ids ntotal, ntotal + 1, ...).  Residuals (IVFPQ, IVFSQ) are taken against the GIVEN list's centroid.
+    void add_core(idx_t n, const float* x, const idx_t* xids, const idx_t* precomputed_idx);
     // params: SearchParameters (sel) or SearchParametersIVF (sel, nprobe); the selector applies to the stored ids
     void search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels,
                 const SearchParameters* params = nullptr) const override;
@@ -397,7 +402,7 @@ class GpuIndexIVF : public Index {
     // (nullable) = expected final length, used as the new capacity of a list that has to move
     void grow_lists_(const std::vector<uint32_t>& new_len, const std::vector<double>* est);
     void compact_();
-    void add_core_(idx_t n, const float* x, const idx_t* xids);
+    void add_core_(idx_t n, const float* x, const idx_t* xids, const idx_t* assign = nullptr);
     void search_core_(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels, const idx_t* assign,
                       const float* centroid_dis, int nprobe_now, const IDSelector* sel) const;
     void search_core_body_(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels, const idx_t* assign,

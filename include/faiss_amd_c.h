@@ -252,6 +252,12 @@ int faiss_amd_Index_compute_residual(const FaissAmdIndex* index, const float* x,
 int faiss_amd_Index_compute_residual_n(const FaissAmdIndex* index, faiss_amd_idx_t n, const float* xs, float* residuals,
                                        const faiss_amd_idx_t* keys);
 
+/* ---- GpuIndexIVF::add_core (faiss/gpu/GpuIndexIVF.h:84-95, GpuIndexIVF.cu:321-356; what contrib/ivf_tools.py
+ *      add_preassigned drives): add n vectors whose inverted list is given by the caller (precomputed_idx [n], host or
+ *      device; entries outside [0, nlist) leave their vector out).  xids may be NULL (sequential ids from ntotal). */
+int faiss_amd_GpuIndexIVF_add_core(FaissAmdIndex* index, faiss_amd_idx_t n, const float* x, const faiss_amd_idx_t* xids,
+                                   const faiss_amd_idx_t* precomputed_idx);
+
 /* ---- GpuIndexIVF::search_preassigned (faiss/gpu/GpuIndexIVF.h:112-122, GpuIndexIVF.cu:408-488; the entry
  *      IndexShardsIVF and CPU-quantizer hybrids call): assign and centroid_dis are [n][nprobe] (nprobe = the
  *      index's current value), host or device, -1 = no list.  With the arrays the index's own quantizer returns

@@ -307,6 +307,14 @@ struct AmdIndexIVF : AmdIndex, faiss::IndexIVFInterface {
         AmdIndex::train(n, x);
         refresh_quantizer_();
     }
+    /// GpuIndexIVF::add_core (faiss/gpu/GpuIndexIVF.h:84-95): the inverted list of every vector comes from the caller
+    /// (contrib/ivf_tools.py add_preassigned; IndexIVF::add_core has the same signature, faiss/IndexIVF.h:261-266)
+    void add_core(idx_t n, const float* x, const idx_t* xids, const idx_t* precomputed_idx,
+                  void* inverted_list_context = nullptr) {
+        FAISS_THROW_IF_NOT_MSG(inverted_list_context == nullptr, "add_core does not support inverted_list_context");
+        amd_check(faiss_amd_GpuIndexIVF_add_core(h, n, x, xids, precomputed_idx));
+        sync();
+    }
     /// nprobe is a public data member callers assign to (index.nprobe = 32): it travels with every call
     void search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels,
                 const SearchParameters* params = nullptr) const override {

@@ -272,6 +272,13 @@ class RefIndex:
                                                   ctypes.c_int64(k), ctypes.c_int(nprobe), _p(D), _p(I)))
         return D, I
 
+    def add_core(self, x, assign, ids=None):
+        """contrib.ivf_tools.add_preassigned: IndexIVF::add_core (or the bridge's) with the list of every vector given"""
+        x = _f32(x)
+        assign = np.ascontiguousarray(assign, dtype=np.int64)
+        ids = None if ids is None else np.ascontiguousarray(ids, dtype=np.int64)
+        self._ck(self.lib.ref_ivf_add_core(ctypes.c_void_p(self.h), ctypes.c_int64(x.shape[0]), _p(x), _p(ids), _p(assign)))
+
     def search_sel(self, x, k, kind, a=0, b=0, data=None, negate=False, nprobe=0):
         """index.search(x, k, params=SearchParameters[IVF](sel=...)) with a faiss::IDSelector described by scalars
         (oracle/ref_shim.cpp ref_index_search_sel): kind 0 Range [a, b), 1 Batch(ids), 2 Array(ids), 3 Bitmap(bytes),

@@ -403,6 +403,15 @@ int ref_index_search_sel(void* p, idx_t n, const float* x, idx_t k, int nprobe, 
     }
     SHIM_CATCH
 }
+// IndexIVF::add_core / GpuIndexIVF::add_core with a caller-supplied list assignment (contrib/ivf_tools.py add_preassigned)
+int ref_ivf_add_core(void* p, idx_t n, const float* x, const idx_t* xids, const idx_t* assign) {
+    SHIM_TRY if (auto* a = dynamic_cast<faiss::amd::AmdIndexIVF*>((faiss::Index*)p)) {
+        a->add_core(n, x, xids, assign);
+    } else {
+        ivf(p)->add_core(n, x, xids, assign);
+    }
+    SHIM_CATCH
+}
 int ref_index_assign(void* p, idx_t n, const float* x, idx_t* labels, idx_t k) {
     SHIM_TRY((faiss::Index*)p)->assign(n, x, labels, k);
     SHIM_CATCH
