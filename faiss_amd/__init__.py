@@ -16,6 +16,14 @@ import numpy as np
 
 METRIC_INNER_PRODUCT = 0
 METRIC_L2 = 1
+# the extra metrics of the flat index / knn_gpu (faiss.METRIC_*, faiss/MetricType.h:31-52)
+METRIC_L1 = 2
+METRIC_Linf = 3
+METRIC_Lp = 4
+METRIC_Canberra = 20
+METRIC_BrayCurtis = 21
+METRIC_JensenShannon = 22
+METRIC_Jaccard = 23
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libfaiss_amd.so")
@@ -68,6 +76,8 @@ def load_library():
         "faiss_amd_Index_is_trained": (i32, [vp]),
         "faiss_amd_Index_ntotal": (i64, [vp]),
         "faiss_amd_Index_metric_type": (i32, [vp]),
+        "faiss_amd_Index_metric_arg": (ctypes.c_float, [vp]),
+        "faiss_amd_Index_set_metric_arg": (i32, [vp, ctypes.c_float]),
         "faiss_amd_Index_train": (i32, [vp, i64, vp]),
         "faiss_amd_Index_add": (i32, [vp, i64, vp]),
         "faiss_amd_Index_add_with_ids": (i32, [vp, i64, vp, vp]),
@@ -248,6 +258,15 @@ class Index:
     ntotal = property(lambda self: self._lib.faiss_amd_Index_ntotal(self._h))
     is_trained = property(lambda self: bool(self._lib.faiss_amd_Index_is_trained(self._h)))
     metric_type = property(lambda self: self._lib.faiss_amd_Index_metric_type(self._h))
+
+    @property
+    def metric_arg(self):
+        """faiss.Index.metric_arg: the p of METRIC_Lp"""
+        return float(self._lib.faiss_amd_Index_metric_arg(self._h))
+
+    @metric_arg.setter
+    def metric_arg(self, v):
+        _check(self._lib.faiss_amd_Index_set_metric_arg(self._h, float(v)))
 
     def train(self, x):
         x = _f32(x, self.d)
@@ -886,7 +905,7 @@ def _matrix_arg(x, name):
     return x, (1 if x.dtype == np.float32 else 2), row_major
 
 
-def knn_gpu(res, xq, xb, k, D=None, I=None, metric=METRIC_L2, vectorsMemoryLimit=0, queriesMemoryLimit=0):
+def knn_gpu(res, xq, xb, k, D=None, I=None, metric=METRIC_L2, vectorsMemoryLimit=0, queriesMemoryLimit=0, metric_arg=0.0):
     """faiss.knn_gpu (faiss/python/gpu_wrappers.py:56-206): brute-force k-NN of xq in xb -> (D, I).  float32 or float16
     inputs in row- or column-major order, int64 or int32 labels (dtype of a supplied I); k = -1 returns the full
     distance matrix as D (I is None); the memory limits select bfKnn_tiling."""
@@ -906,7 +925,7 @@ def knn_gpu(res, xq, xb, k, D=None, I=None, metric=METRIC_L2, vectorsMemoryLimit
             I = np.empty((nq, k), dtype=np.int64)
         if D.shape != (nq, k) or I.shape != (nq, k) or D.dtype != np.float32 or I.dtype not in (np.int64, np.int32):
             raise ValueError("D / I have the wrong shape or dtype")
-    a = GpuDistanceParams(int(metric), 0.0, int(k), int(d), xb.ctypes.data, vt, int(vrm), xb.shape[0], None,
+    a = GpuDistanceParams(int(metric), float(metric_arg), int(k), int(d), xb.ctypes.data, vt, int(vrm), xb.shape[0], None,
                           xq.ctypes.data, qt, int(qrm), nq, D.ctypes.data, 0,
                           2 if (I is not None and I.dtype == np.int32) else 1, I.ctypes.data if I is not None else None, -1)
     if vectorsMemoryLimit or queriesMemoryLimit:

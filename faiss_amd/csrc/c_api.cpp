@@ -320,6 +320,14 @@ faiss_amd_idx_t faiss_amd_Index_ntotal(const FaissAmdIndex* index) {
 FaissAmdMetricType faiss_amd_Index_metric_type(const FaissAmdIndex* index) {
     return (FaissAmdMetricType)(index && index->index ? index->index->metric_type : 1);
 }
+float faiss_amd_Index_metric_arg(const FaissAmdIndex* index) {
+    return index && index->index ? index->index->metric_arg : 0.f;
+}
+int faiss_amd_Index_set_metric_arg(FaissAmdIndex* index, float metric_arg) {
+    FA_TRY
+    I(index)->metric_arg = metric_arg;
+    FA_CATCH
+}
 int faiss_amd_Index_train(FaissAmdIndex* index, faiss_amd_idx_t n, const float* x) {
     FA_TRY
     I(index)->train(n, x);

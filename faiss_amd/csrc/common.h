@@ -22,7 +22,25 @@ using idx_t = int64_t; // reference: faiss/MetricType.h:52
 enum MetricType : int {
     METRIC_INNER_PRODUCT = 0,
     METRIC_L2 = 1,
+    // the "extra" metrics of the flat index / bfKnn (faiss/gpu/impl/GeneralDistance.cuh over the functors of
+    // faiss/gpu/impl/DistanceUtils.cuh:47-281): no GEMM form, one pass over the dimensions per (query, vector) pair
+    METRIC_L1 = 2,
+    METRIC_Linf = 3,
+    METRIC_Lp = 4, // p = Index::metric_arg
+    METRIC_Canberra = 20,
+    METRIC_BrayCurtis = 21,
+    METRIC_JensenShannon = 22,
+    METRIC_Jaccard = 23, // a similarity: larger is better (faiss::is_similarity_metric, faiss/MetricType.h:59-62)
 };
+static inline bool is_general_metric(int m) {
+    return m == METRIC_L1 || m == METRIC_Linf || m == METRIC_Lp || m == METRIC_Canberra || m == METRIC_BrayCurtis ||
+           m == METRIC_JensenShannon || m == METRIC_Jaccard;
+}
+// the order results are kept in: a similarity is searched like the inner product (descending, padded with -FLT_MAX),
+// a distance like L2
+static inline int order_metric(int m) {
+    return (m == METRIC_INNER_PRODUCT || m == METRIC_Jaccard) ? METRIC_INNER_PRODUCT : METRIC_L2;
+}
 
 // Mirrors faiss::FaissException (faiss/impl/FaissException.h:20-43): thrown by host code,
 // translated to error code -2 at the C ABI (reference convention c_api/macros_impl.h:22-56).

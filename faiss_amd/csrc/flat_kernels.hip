@@ -629,4 +629,80 @@ void launch_flat_simple(int metric, const float* xq, const float* xqn, int64_t l
     HIP_CHECK(hipGetLastError());
 }
 
+// ---------------------------------------------------------------------------------
+// "extra" metrics (faiss/gpu/impl/DistanceUtils.cuh:47-281 functors, faiss/utils/simd_impl/distances_autovec-inl.h:177-262
+// on the CPU): no inner-product form, so no matrix pipe -- one thread per (query, row), the query in LDS, ONE sequential
+// fp32 pass over the dimensions with every operation rounded once (IEEE division spelled out), which is what
+// oracle/faiss_oracle.c general_distance restates.  All distances go to memory as keys and the select kernel picks
+// the k best: the brute-force layout of the reference's general-distance path, good for the few GFLOP these metrics
+// are used at.
+// ---------------------------------------------------------------------------------
+template <int GM>
+__global__ void __launch_bounds__(256) flat_general_kernel(const float* __restrict__ xq, int64_t ldq, int nq,
+                                                           const float* __restrict__ xb, int64_t ldb, int nb, int d,
+                                                           float arg, u64* __restrict__ keys) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* qs = (float*)smem; // [d]
+    const int q = blockIdx.y;
+    for (int c = threadIdx.x; c < d; c += blockDim.x) qs[c] = xq[(int64_t)q * ldq + c];
+    __syncthreads();
+    for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < nb; row += gridDim.x * blockDim.x) {
+        const float* yr = xb + (int64_t)row * ldb;
+        float a = 0.f, b = 0.f;
+        for (int i = 0; i < d; ++i) {
+            const float xi = qs[i], yi = yr[i];
+            if (GM == METRIC_L1) {
+                a = a + fabsf(xi - yi);
+            } else if (GM == METRIC_Linf) {
+                a = fmaxf(a, fabsf(xi - yi));
+            } else if (GM == METRIC_Lp) {
+                a = a + powf(fabsf(xi - yi), arg);
+            } else if (GM == METRIC_Canberra) {
+                a = a + __fdiv_rn(fabsf(xi - yi), fabsf(xi) + fabsf(yi));
+            } else if (GM == METRIC_BrayCurtis) {
+                a = a + fabsf(xi - yi);
+                b = b + fabsf(xi + yi);
+            } else if (GM == METRIC_JensenShannon) {
+                const float m = 0.5f * (xi + yi);
+                const float kl1 = -xi * logf(__fdiv_rn(m, xi));
+                const float kl2 = -yi * logf(__fdiv_rn(m, yi));
+                a = a + (kl1 + kl2);
+            } else { // METRIC_Jaccard
+                a = a + fminf(xi, yi);
+                b = b + fmaxf(xi, yi);
+            }
+        }
+        float dis = a;
+        if (GM == METRIC_BrayCurtis || GM == METRIC_Jaccard) dis = __fdiv_rn(a, b);
+        if (GM == METRIC_JensenShannon) dis = 0.5f * a;
+        const uint32_t ok = GM == METRIC_Jaccard ? ordkey<METRIC_INNER_PRODUCT>(dis) : ordkey<METRIC_L2>(dis);
+        keys[(int64_t)q * nb + row] = ((u64)ok << 32) | (unsigned)row;
+    }
+}
+
+void launch_flat_general(int metric, float metric_arg, const float* xq, int64_t ldq, int nq, const float* xb, int64_t ldb,
+                         int nb, int d, u64* keys, hipStream_t stream) {
+    if (nq == 0 || nb == 0) return;
+    FA_THROW_IF_NOT_MSG(is_general_metric(metric), "not one of the extra metrics");
+    FA_THROW_IF_NOT_MSG(nq <= 65535, "query tile too large for the general-distance kernel");
+    dim3 grid((unsigned)std::min<int64_t>(div_up(nb, 256), 1024), (unsigned)nq), block(256);
+    const size_t lds = (size_t)d * 4;
+#define FA_GEN(M_)                                                                                                   \
+    case M_:                                                                                                         \
+        hipLaunchKernelGGL((flat_general_kernel<M_>), grid, block, lds, stream, xq, ldq, nq, xb, ldb, nb, d, metric_arg, \
+                           keys);                                                                                    \
+        break
+    switch (metric) {
+        FA_GEN(METRIC_L1);
+        FA_GEN(METRIC_Linf);
+        FA_GEN(METRIC_Lp);
+        FA_GEN(METRIC_Canberra);
+        FA_GEN(METRIC_BrayCurtis);
+        FA_GEN(METRIC_JensenShannon);
+        default: FA_GEN(METRIC_Jaccard);
+    }
+#undef FA_GEN
+    HIP_CHECK(hipGetLastError());
+}
+
 } // namespace faiss_amd

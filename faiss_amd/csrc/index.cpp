@@ -308,8 +308,10 @@ static bool use_paged_path(const GpuResources& R, idx_t n, int d, const float* x
 GpuIndexFlat::GpuIndexFlat(std::shared_ptr<GpuResources> res, int dims, int metric, bool use_float16)
         : Index(dims, metric), res_(std::move(res)), use_float16_(use_float16) {
     FA_THROW_IF_NOT_MSG(dims > 0, "dimension must be positive");
-    FA_THROW_IF_NOT_MSG(metric == METRIC_L2 || metric == METRIC_INNER_PRODUCT,
-                        "only METRIC_L2 and METRIC_INNER_PRODUCT are supported");
+    // L2 / inner product on the matrix pipes; the extra metrics of the reference's flat index (faiss/gpu/impl/
+    // GeneralDistance.cuh: L1, Linf, Lp, Canberra, BrayCurtis, JensenShannon, Jaccard) on a plain brute-force pass
+    FA_THROW_IF_NOT_MSG(metric == METRIC_L2 || metric == METRIC_INNER_PRODUCT || is_general_metric(metric),
+                        "unsupported metric type");
     dpad_ = (int)round_up(dims, 8);
     dh_ = (int)round_up(dims, kFilterSlab);
     is_trained = true;
@@ -501,7 +503,9 @@ static const float* as_f32_rows(const GpuResources& R, const void* src, int type
 void bfKnn(std::shared_ptr<GpuResources> res, const DistanceParams& a) {
     FA_THROW_IF_NOT_MSG(res, "null resources");
     FA_THROW_IF_NOT_MSG(a.device == -1 || a.device == res->device, "args.device differs from the device of the resources");
-    FA_THROW_IF_NOT_MSG(a.metric == METRIC_L2 || a.metric == METRIC_INNER_PRODUCT, "bfKnn: metric must be L2 or inner product");
+    FA_THROW_IF_NOT_MSG(a.metric == METRIC_L2 || a.metric == METRIC_INNER_PRODUCT || is_general_metric(a.metric),
+                        "bfKnn: unsupported metric");
+    FA_THROW_IF_NOT_MSG(a.k != -1 || !is_general_metric(a.metric), "bfKnn: k = -1 (all pairwise distances) is L2 / inner product only");
     FA_THROW_IF_NOT_MSG(a.dims >= 1 && a.numVectors >= 0 && a.numQueries >= 0, "bad sizes");
     FA_THROW_IF_NOT_MSG(a.k == -1 || (a.k >= 1 && a.k <= kMaxSelectionK), "k must be in [1, 2048], or -1 for all pairwise distances");
     if (a.numQueries == 0) return;
@@ -513,6 +517,7 @@ void bfKnn(std::shared_ptr<GpuResources> res, const DistanceParams& a) {
     const float* q = as_f32_rows(R, a.queries, a.queryType, a.queriesRowMajor, a.numQueries, a.dims, qraw, qf32);
     // fp16 vectors AND queries: an fp16-storage index holds exactly those values at half the bytes
     GpuIndexFlat tmp(res, a.dims, a.metric, a.vectorType == 2 && a.queryType == 2);
+    tmp.metric_arg = a.metricArg;
     if (a.numVectors) tmp.add(a.numVectors, v);
     if (a.k == -1) {
         FA_THROW_IF_NOT_MSG(a.outDistances, "bfKnn: outDistances must be provided for k = -1");
@@ -597,7 +602,7 @@ void bfKnn_tiling(std::shared_ptr<GpuResources> res, const DistanceParams& a, si
         // partial top-k of the vector chunks -> top-k (ties to the lower id: equal to one untiled search)
         std::vector<float> D((size_t)nq * a.k);
         std::vector<idx_t> I((size_t)nq * a.k);
-        merge_knn_results(a.metric, nq, a.k, nvs, pd.data(), pi.data(), base.data(), D.data(), I.data());
+        merge_knn_results(order_metric(a.metric), nq, a.k, nvs, pd.data(), pi.data(), base.data(), D.data(), I.data());
         if (!a.ignoreOutDistances && a.outDistances) {
             FA_THROW_IF_NOT_MSG(!is_device_pointer(a.outDistances), "bfKnn_tiling: outputs of a tiled search live in CPU memory");
             memcpy(a.outDistances + (size_t)q0 * a.k, D.data(), D.size() * 4);
@@ -734,9 +739,53 @@ void GpuIndexFlat::plan_filter_(int n, int k, int& geom, int& nsplit, int& tstri
     pc.geom = geom, pc.nsplit = nsplit, pc.tstride = tstride, pc.cap = cap, pc.gcap = gcap;
 }
 
+void GpuIndexFlat::search_tile_general_(int n, const float* xq_pad, int k, float* dD, idx_t* dI) const {
+    const GpuResources& R = *res_;
+    const int nb = (int)ntotal;
+    SelectParams sp{};
+    sp.metric = order_metric(metric_type);
+    sp.nq = n;
+    sp.k = k;
+    sp.mode = 0;
+    sp.id_base = 0;
+    sp.out_dis = dD;
+    sp.out_ids = dI;
+    sp.nseg = 1;
+    sp.seg_stride = 0;
+    one_cnt_.ensure((size_t)n * 4);
+    sp.seg_cnt = one_cnt_.as<uint32_t>();
+    if (nb == 0) {
+        HIP_CHECK(hipMemsetAsync(one_cnt_.p, 0, (size_t)n * 4, R.stream));
+        launch_select_k(sp, R.stream);
+        return;
+    }
+    DevBuf widened; // fp16 storage: a widened temporary copy of the rows
+    const float* xb_rows = rows_f32_(widened);
+    all_keys_.ensure((size_t)n * nb * 8);
+    std::vector<uint32_t> cnt(n, (uint32_t)nb);
+    HIP_CHECK(hipMemcpyAsync(one_cnt_.p, cnt.data(), (size_t)n * 4, hipMemcpyHostToDevice, R.stream));
+    HIP_CHECK(hipStreamSynchronize(R.stream));
+    {
+        SpanGuard sg(&R, "flat_general_kernel");
+        launch_flat_general(metric_type, metric_arg, xq_pad, dpad_, n, xb_rows, dpad_, nb, d,
+                            all_keys_.as<unsigned long long>(), R.stream);
+    }
+    sp.keys = all_keys_.as<unsigned long long>();
+    sp.q_stride = nb;
+    {
+        SpanGuard sg(&R, "select_k_kernel");
+        launch_select_k(sp, R.stream);
+    }
+    if (use_float16_) R.sync(); // `widened` is released on return
+}
+
 void GpuIndexFlat::search_tile_(int n, const float* xq_pad, int k, float* dD, idx_t* dI) const {
     last_used_filter = false;
     last_filter_overflow = 0;
+    if (is_general_metric(metric_type)) {
+        search_tile_general_(n, xq_pad, k, dD, dI);
+        return;
+    }
     if (!filter_applicable_(k)) {
         search_tile_exact_(n, xq_pad, k, dD, dI);
         return;
@@ -854,7 +903,7 @@ void GpuIndexFlat::search_tile_(int n, const float* xq_pad, int k, float* dD, id
 }
 
 void GpuIndexFlat::filter_scores(idx_t n, const float* x, float* scores, float* err_bound) const {
-    FA_THROW_IF_NOT_MSG(db_f16_ok_ && ntotal > 0 && n > 0, "filter not applicable");
+    FA_THROW_IF_NOT_MSG(db_f16_ok_ && ntotal > 0 && n > 0 && !is_general_metric(metric_type), "filter not applicable");
     std::lock_guard<std::mutex> g(mu_);
     res_->set_device();
     const GpuResources& R = *res_;
@@ -1002,16 +1051,17 @@ void GpuIndexFlat::search_tile_exact_(int n, const float* xq_pad, int k, float* 
 // queries per tile so that the reservoirs stay within the scratch budget
 static int flat_query_tile(const GpuResources& R, int k, bool simple, idx_t nb) {
     size_t per_q;
+    // (simple: every distance of a query as a key in memory -- the scalar cross-check kernel and the extra metrics)
     if (simple) per_q = (size_t)std::max<idx_t>(nb, 1) * 8;
     else per_q = (size_t)64 * std::max(reservoir_capacity(k), 2 * (k + 32)) * 8;
     size_t t = R.temp_budget_bytes / per_q;
     t = std::max<size_t>(t, 256);
-    t = std::min<size_t>(t, (size_t)1 << 20);
+    t = std::min<size_t>(t, simple ? (size_t)65280 : (size_t)1 << 20); // (simple: one grid row per query)
     return (int)(t / 256 * 256);
 }
 
 void GpuIndexFlat::search_device(int n, const float* xq_pad, int k, float* dD, idx_t* dI) const {
-    const int tile = flat_query_tile(*res_, k, use_simple_kernel, ntotal);
+    const int tile = flat_query_tile(*res_, k, use_simple_kernel || is_general_metric(metric_type), ntotal);
     for (int i0 = 0; i0 < n; i0 += tile) {
         int ni = std::min(tile, n - i0);
         search_tile_(ni, xq_pad + (size_t)i0 * dpad_, k, dD + (size_t)i0 * k, dI + (size_t)i0 * k);
@@ -1025,6 +1075,7 @@ void GpuIndexFlat::search_device(int n, const float* xq_pad, int k, float* dD, i
 void GpuIndexFlat::prepare_selector_(const IDSelector& sel) const {
     const GpuResources& R = *res_;
     FA_THROW_IF_NOT_MSG(!use_simple_kernel, "IDSelector: not available on the scalar cross-check kernel");
+    FA_THROW_IF_NOT_MSG(!is_general_metric(metric_type), "IDSelector: not available with the extra metrics");
     SelProgram prog{};
     sel.compile(prog, R.device, R.stream);
     const size_t words = div_up((size_t)std::max<idx_t>(ntotal, 1), 64);
@@ -1058,7 +1109,7 @@ void GpuIndexFlat::search(idx_t n, const float* x, idx_t k, float* distances, id
         sel_active_ = true;
     }
     if (use_paged_path(R, n, d, x, distances, labels)) {
-        const idx_t page = paged_page_size(R, n, flat_query_tile(R, (int)k, use_simple_kernel, ntotal));
+        const idx_t page = paged_page_size(R, n, flat_query_tile(R, (int)k, use_simple_kernel || is_general_metric(metric_type), ntotal));
         paged_host_search(R, n, x, d, k, distances, labels, page, [&](idx_t ni, const float* dq, float* dD, idx_t* dI) {
             search_body_(ni, dq, k, dD, dI);
         });
@@ -1069,7 +1120,7 @@ void GpuIndexFlat::search(idx_t n, const float* x, idx_t k, float* distances, id
 void GpuIndexFlat::search_body_(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels) const {
     const GpuResources& R = *res_;
     const bool out_dev_d = is_device_pointer(distances), out_dev_i = is_device_pointer(labels);
-    const idx_t tile = flat_query_tile(R, (int)k, use_simple_kernel, ntotal);
+    const idx_t tile = flat_query_tile(R, (int)k, use_simple_kernel || is_general_metric(metric_type), ntotal);
     for (idx_t i0 = 0; i0 < n; i0 += tile) {
         check_interrupt();
         const int ni = (int)std::min(tile, n - i0);
@@ -1096,6 +1147,7 @@ void GpuIndexFlat::search_body_(idx_t n, const float* x, idx_t k, float* distanc
 
 void GpuIndexFlat::pairwise_distances(idx_t n, const float* x, float* out) const {
     if (n == 0 || ntotal == 0) return;
+    FA_THROW_IF_NOT_MSG(!is_general_metric(metric_type), "pairwise distances: L2 / inner product only");
     std::lock_guard<std::mutex> g(mu_);
     res_->set_device();
     const GpuResources& R = *res_;
@@ -2573,7 +2625,7 @@ void IndexShards::search(idx_t n, const float* x, idx_t k, float* distances, idx
     run_on_shards(shards_, threaded, [&](int no, Index* s) {
         s->search(n, x, k, all_d.data() + (size_t)no * n * k, all_i.data() + (size_t)no * n * k, params);
     });
-    merge_knn_results(metric_type, n, k, nshard, all_d.data(), all_i.data(),
+    merge_knn_results(order_metric(metric_type), n, k, nshard, all_d.data(), all_i.data(),
                       successive_ids ? base.data() : nullptr, distances, labels);
 }
 

@@ -196,6 +196,7 @@ struct Index {
     bool verbose = false;
     bool is_trained = true;
     int metric_type = METRIC_L2;
+    float metric_arg = 0.f; // faiss::Index::metric_arg (faiss/Index.h:114): the p of METRIC_Lp
 
     explicit Index(int d_ = 0, int metric = METRIC_L2) : d(d_), metric_type(metric) {}
     virtual ~Index() {}
@@ -287,6 +288,8 @@ class GpuIndexFlat : public Index {
     bool db_f16_ok_ = true;  // every database value inside the fp16 range (no NaN/inf)
     mutable DevBuf qh_, flags_, thr_, maxes_, ovf_list_, ovf_q_, ovf_d_, ovf_i_;
     void search_tile_exact_(int n, const float* xq_pad, int k, float* dD, idx_t* dI) const;
+    // the "extra" metrics (L1, Linf, Lp, Canberra, BrayCurtis, JensenShannon, Jaccard): every distance as a key + select
+    void search_tile_general_(int n, const float* xq_pad, int k, float* dD, idx_t* dI) const;
     bool filter_applicable_(int k) const;
     void plan_filter_(int n, int k, int& geom, int& nsplit, int& tstride, int& cap, int& gcap) const;
     // last plan (searches come in runs of one batch size): key = (n, k, ntotal, knob string)

@@ -76,6 +76,13 @@ void launch_flat_simple(int metric, const float* xq, const float* xqn, int64_t l
                         const float* xb, const float* xbn, int64_t ldb, int nb, int dpad,
                         unsigned long long* keys, hipStream_t stream);
 
+// The "extra" metrics of the flat index (L1, Linf, Lp, Canberra, BrayCurtis, JensenShannon, Jaccard): one sequential
+// fp32 pass over the d dimensions per (query, row), every distance written as a 64-bit key (ordered by order_metric).
+// keys: [nq][nb].  Replaces faiss/gpu/impl/GeneralDistance.cuh:runGeneralDistance for these functors; restated by
+// oracle/faiss_oracle.c orc_flat_search_general.
+void launch_flat_general(int metric, float metric_arg, const float* xq, int64_t ldq, int nq, const float* xb, int64_t ldb,
+                         int nb, int d, unsigned long long* keys, hipStream_t stream);
+
 // ------------------------------------------------------------------ Flat: fp16 MFMA filter + exact fp32 re-rank
 // (flat_filter.hip; see the header there for the superset argument)
 // geometry of the filter kernel: 0 = 4 waves x 64 queries (any dh, two workgroups per CU),

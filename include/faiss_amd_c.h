@@ -28,9 +28,19 @@ extern "C" {
 typedef int64_t faiss_amd_idx_t;
 
 /* same values as FaissMetricType (c_api/Index_c.h:32-44) */
+/* values of faiss::MetricType (faiss/MetricType.h:31-52).  L2 and inner product: every index type.  The "extra" metrics:
+ * GpuIndexFlat and bfKnn only, like the reference (faiss/gpu/impl/GeneralDistance.cuh; GpuIndexIVF refuses them,
+ * faiss/gpu/GpuIndexIVF.cu:35-37); Jaccard is a similarity (results best = largest first, padded with -FLT_MAX). */
 typedef enum FaissAmdMetricType {
     FAISS_AMD_METRIC_INNER_PRODUCT = 0,
-    FAISS_AMD_METRIC_L2 = 1
+    FAISS_AMD_METRIC_L2 = 1,
+    FAISS_AMD_METRIC_L1 = 2,
+    FAISS_AMD_METRIC_Linf = 3,
+    FAISS_AMD_METRIC_Lp = 4, /* p = metric_arg */
+    FAISS_AMD_METRIC_Canberra = 20,
+    FAISS_AMD_METRIC_BrayCurtis = 21,
+    FAISS_AMD_METRIC_JensenShannon = 22,
+    FAISS_AMD_METRIC_Jaccard = 23
 } FaissAmdMetricType;
 
 typedef struct FaissAmdIndex_H FaissAmdIndex;                 /* FaissIndex, c_api/Index_c.h:55 */
@@ -142,6 +152,9 @@ int faiss_amd_Index_d(const FaissAmdIndex* index);
 int faiss_amd_Index_is_trained(const FaissAmdIndex* index);
 faiss_amd_idx_t faiss_amd_Index_ntotal(const FaissAmdIndex* index);
 FaissAmdMetricType faiss_amd_Index_metric_type(const FaissAmdIndex* index);
+/* faiss::Index::metric_arg (faiss/Index.h:114; c_api/Index_c.h faiss_Index_metric_arg): the p of METRIC_Lp */
+float faiss_amd_Index_metric_arg(const FaissAmdIndex* index);
+int faiss_amd_Index_set_metric_arg(FaissAmdIndex* index, float metric_arg);
 int faiss_amd_Index_train(FaissAmdIndex* index, faiss_amd_idx_t n, const float* x);
 int faiss_amd_Index_add(FaissAmdIndex* index, faiss_amd_idx_t n, const float* x);
 int faiss_amd_Index_add_with_ids(FaissAmdIndex* index, faiss_amd_idx_t n, const float* x,

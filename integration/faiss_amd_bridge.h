@@ -218,7 +218,10 @@ struct AmdIndex : faiss::Index {
 struct AmdIndexFlat : AmdIndex {
     static FaissAmdIndex* make(AmdGpuResources* res, int d, MetricType metric) {
         FAISS_THROW_IF_NOT_MSG(
-                metric == METRIC_L2 || metric == METRIC_INNER_PRODUCT, "AmdIndexFlat: metric must be L2 or inner product");
+                metric == METRIC_L2 || metric == METRIC_INNER_PRODUCT || metric == METRIC_L1 || metric == METRIC_Linf ||
+                        metric == METRIC_Lp || metric == METRIC_Canberra || metric == METRIC_BrayCurtis ||
+                        metric == METRIC_JensenShannon || metric == METRIC_Jaccard,
+                "AmdIndexFlat: unsupported metric");
         FaissAmdIndex* handle = nullptr;
         amd_check(faiss_amd_GpuIndexFlat_new(&handle, res->h, d, (FaissAmdMetricType)metric));
         return handle;
@@ -227,12 +230,21 @@ struct AmdIndexFlat : AmdIndex {
     idx_t selector_domain() const override {
         return ntotal; // labels are row numbers
     }
+    /// metric_arg is a public data member callers assign to (index.metric_arg = 3 for METRIC_Lp): it travels with the call
+    void search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels,
+                const SearchParameters* params = nullptr) const override {
+        if (metric_type == METRIC_Lp) {
+            amd_check(faiss_amd_Index_set_metric_arg(h, metric_arg));
+        }
+        AmdIndex::search(n, x, k, distances, labels, params);
+    }
     /// GpuIndexFlat(resources, const IndexFlat*) / copyFrom (faiss/gpu/GpuIndexFlat.cu:125-148)
     AmdIndexFlat(AmdGpuResources* res, const faiss::IndexFlat* index) : AmdIndex(make(res, index->d, index->metric_type)) {
         copyFrom(index);
     }
     void copyFrom(const faiss::IndexFlat* index) {
         FAISS_THROW_IF_NOT(index->d == d && index->metric_type == metric_type);
+        metric_arg = index->metric_arg;
         reset();
         if (index->ntotal > 0) {
             add(index->ntotal, index->get_xb());
@@ -242,6 +254,7 @@ struct AmdIndexFlat : AmdIndex {
     void copyTo(faiss::IndexFlat* index) const {
         FAISS_THROW_IF_NOT(index->d == d);
         index->metric_type = metric_type;
+        index->metric_arg = metric_arg;
         index->reset();
         const idx_t bs = 1 << 18;
         std::vector<float> buf((size_t)std::min<idx_t>(bs, std::max<idx_t>(ntotal, 1)) * d);

@@ -10,6 +10,8 @@
  *                        with strict admission and (distance, id) heap order
  *                        (faiss/impl/ResultHandler.h:276-281, 354-360;
  *                         faiss/utils/ordered_key_value.h:42-83)
+ *   orc_flat_search_general  IndexFlat::search with the "extra" metrics (L1, Linf, Lp, Canberra, BrayCurtis,
+ *                        JensenShannon, Jaccard; faiss/utils/extra_distances.cpp, distances_autovec-inl.h:177-262)
  *   orc_ivf_search       IndexIVF::search (faiss/IndexIVF.cpp:305-399): coarse quantizer search
  *                        for nprobe lists, then search_preassigned (faiss/IndexIVF.cpp:401-768)
  *                        scanning the lists in probe order
@@ -223,6 +225,72 @@ int orc_flat_search(int metric, int d, idx_t nb, const float* xb, idx_t nq, cons
         free(st);
     }
     free(yn);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ IndexFlat::search, the "extra" metrics
+ * faiss/utils/extra_distances.cpp knn_extra_metrics over VectorDistance<metric>
+ * (faiss/utils/simd_impl/distances_autovec-inl.h:177-262); on the GPU faiss/gpu/impl/GeneralDistance.cuh over the
+ * functors of faiss/gpu/impl/DistanceUtils.cuh:47-281 (L1, Lp, Linf, Canberra, BrayCurtis, JensenShannon, Jaccard).
+ * One sequential pass over the dimensions in fp32, every operation rounded once (the order and the operations of
+ * flat_general_kernel); metric numbers are faiss::MetricType's (faiss/MetricType.h:31-52).  Jaccard is a similarity
+ * (larger is better, is_similarity_metric), the others are distances.  Lp and JensenShannon go through powf / logf,
+ * whose device and libm versions differ in the last bits: compared with a tolerance, not bit for bit. */
+enum { ORC_METRIC_L1 = 2, ORC_METRIC_Linf = 3, ORC_METRIC_Lp = 4, ORC_METRIC_Canberra = 20, ORC_METRIC_BrayCurtis = 21,
+       ORC_METRIC_JensenShannon = 22, ORC_METRIC_Jaccard = 23 };
+
+static float general_distance(int metric, float arg, const float* x, const float* y, int d) {
+    float a = 0.f, b = 0.f;
+    for (int i = 0; i < d; i++) {
+        const float xi = x[i], yi = y[i];
+        switch (metric) {
+            case ORC_METRIC_L1: a = a + fabsf(xi - yi); break;
+            case ORC_METRIC_Linf: a = fmaxf(a, fabsf(xi - yi)); break;
+            case ORC_METRIC_Lp: a = a + powf(fabsf(xi - yi), arg); break;
+            case ORC_METRIC_Canberra: a = a + fabsf(xi - yi) / (fabsf(xi) + fabsf(yi)); break;
+            case ORC_METRIC_BrayCurtis:
+                a = a + fabsf(xi - yi);
+                b = b + fabsf(xi + yi);
+                break;
+            case ORC_METRIC_JensenShannon: {
+                const float m = 0.5f * (xi + yi);
+                const float kl1 = -xi * logf(m / xi);
+                const float kl2 = -yi * logf(m / yi);
+                a = a + (kl1 + kl2);
+                break;
+            }
+            case ORC_METRIC_Jaccard:
+                a = a + fminf(xi, yi);
+                b = b + fmaxf(xi, yi);
+                break;
+            default: return NAN;
+        }
+    }
+    if (metric == ORC_METRIC_BrayCurtis || metric == ORC_METRIC_Jaccard) return a / b;
+    if (metric == ORC_METRIC_JensenShannon) return 0.5f * a;
+    return a;
+}
+
+int orc_general_supported(int metric) {
+    return metric == ORC_METRIC_L1 || metric == ORC_METRIC_Linf || metric == ORC_METRIC_Lp || metric == ORC_METRIC_Canberra ||
+           metric == ORC_METRIC_BrayCurtis || metric == ORC_METRIC_JensenShannon || metric == ORC_METRIC_Jaccard;
+}
+
+int orc_flat_search_general(int metric, float metric_arg, int d, idx_t nb, const float* xb, idx_t nq, const float* xq, int k,
+                            float* D, idx_t* I) {
+    if (k < 1 || !orc_general_supported(metric)) return -1;
+    /* order of the results: a similarity is searched like the inner product, a distance like L2 */
+    const int order = metric == ORC_METRIC_Jaccard ? ORC_METRIC_IP : ORC_METRIC_L2;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (idx_t q = 0; q < nq; q++) {
+        cand_t* st = (cand_t*)malloc(sizeof(cand_t) * (size_t)k);
+        topk_t t;
+        topk_init(&t, st, k, order);
+        const float* x = xq + (size_t)q * d;
+        for (idx_t j = 0; j < nb; j++) topk_push(&t, general_distance(metric, metric_arg, x, xb + (size_t)j * d, d), j);
+        topk_finish(&t, D + (size_t)q * k, I + (size_t)q * k);
+        free(st);
+    }
     return 0;
 }
 

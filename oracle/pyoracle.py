@@ -93,6 +93,19 @@ class Oracle:
         return D, I
 
     @classmethod
+    def flat_search_general(cls, metric, xb, xq, k, metric_arg=0.0):
+        """IndexFlat(d, metric).search for the extra metrics (faiss.METRIC_L1 = 2, Linf 3, Lp 4, Canberra 20,
+        BrayCurtis 21, JensenShannon 22, Jaccard 23)"""
+        xb, xq = _f32(xb), _f32(xq)
+        D = np.empty((xq.shape[0], k), dtype=np.float32)
+        I = np.empty((xq.shape[0], k), dtype=np.int64)
+        rc = cls.lib().orc_flat_search_general(ctypes.c_int(metric), ctypes.c_float(metric_arg), ctypes.c_int(xq.shape[1]),
+                                               ctypes.c_int64(xb.shape[0]), _p(xb) if xb.size else None,
+                                               ctypes.c_int64(xq.shape[0]), _p(xq), ctypes.c_int(k), _p(D), _p(I))
+        assert rc == 0
+        return D, I
+
+    @classmethod
     def ivf_search(cls, kind, metric, centroids, list_sizes, codes, ids, xq, nprobe, k, M=0, pq=None):
         centroids, xq = _f32(centroids), _f32(xq)
         nlist, d = centroids.shape
@@ -262,6 +275,10 @@ class RefIndex:
 
     def reset(self):
         self._ck(self.lib.ref_index_reset(ctypes.c_void_p(self.h)))
+
+    def set_metric_arg(self, arg):
+        """index.metric_arg (the p of METRIC_Lp)"""
+        self._ck(self.lib.ref_index_set_metric_arg(ctypes.c_void_p(self.h), ctypes.c_float(arg)))
 
     def search_nprobe(self, x, k, nprobe):
         """index.search(x, k, params=SearchParametersIVF(nprobe=nprobe))"""

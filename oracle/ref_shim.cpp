@@ -84,6 +84,10 @@ int ref_index_search(void* p, idx_t n, const float* x, idx_t k, float* D, idx_t*
     SHIM_TRY((faiss::Index*)p)->search(n, x, k, D, I);
     SHIM_CATCH
 }
+int ref_index_set_metric_arg(void* p, float arg) {
+    SHIM_TRY((faiss::Index*)p)->metric_arg = arg;
+    SHIM_CATCH
+}
 int ref_index_reset(void* p) {
     SHIM_TRY((faiss::Index*)p)->reset();
     SHIM_CATCH
