@@ -21,6 +21,7 @@
 //   3. overflow: a query whose band does not fit its reservoir (adversarial data: thousands of
 //      rows within fp16 rounding of the k-th neighbour, or fp16 range overflow) is flagged and
 //      re-run through the exact fp32 MFMA kernel by the host code.  Never a silent approximation.
+#include <type_traits>
 #include "kernels.h"
 #include "wg_select.h"
 
@@ -301,7 +302,18 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 // SINGLE: dh == 128, one k-slab per tile: the query operands never leave their registers and
 // the loop holds no compiler-visible global load, whose counted s_waitcnt would otherwise also
 // wait for the (younger, hidden) LDS-DMAs of the prefetch.
-template <int METRIC, int MODE, bool SINGLE, int QB>
+// STAGGER (8-wave geometry only; an experiment that has not run on hardware yet, off unless FAISS_AMD_FILTER_STAGGER=1):
+// the two wavefronts that share a SIMD (w and w + 4) meet at the workgroup barrier of every tile and therefore run IN
+// PHASE: both issue the MFMAs of a 32-row block at the same time (sharing the matrix pipe), then both sit in the VALU
+// epilogue with the pipe idle -- per tile and SIMD 4 x 1024 cycles of MFMA and 2 x 2 epilogues back to back, which is
+// what the 52 % MFMA-busy figure of the profiles says.  With STAGGER the second wave of every SIMD runs half a tile out
+// of phase: it DEFERS the epilogue of a tile's second block to the start of the next tile,
+//     waves 0..3:  M(b0) E(b0) M(b1) E(b1) | barrier
+//     waves 4..7:  E(previous b1) M(b0) E(b0) M(b1) | barrier
+// so that one wave's epilogue always falls under the other's MFMAs.  Same scores, same candidates, another order.  The
+// two schedules are two copies of the tile loop (a wave-uniform branch picks one): with a single copy and a flag the
+// register allocator spills the query operands.
+template <int METRIC, int MODE, bool SINGLE, int QB, bool STAGGER = false>
 __global__ void __launch_bounds__(FqGeom<QB>::THREADS, 2) flat_filter_kernel(FlatFilterParams p) {
     using G = FqGeom<QB>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -438,7 +450,7 @@ __global__ void __launch_bounds__(FqGeom<QB>::THREADS, 2) flat_filter_kernel(Fla
     // epilogue of the 32-row block(s) held in acc (they started from -|y|^2/2, so they ARE the scores):
     // rbase = first block index (0 or 1).  Lane (h, j) holds, for its query of column block qb, the
     // rows rb*32 + 8g + 4h + e at acc[..][qb][4g + e].
-    auto epilogue = [&](int tl, int rbase) {
+    auto epilogue = [&](int tl, int rbase) __attribute__((always_inline)) {
         const int tile_row0 = tile_row0_of(tl);
         if (MODE != MODE_DUMP) {
             if (QB == 4) mfma_results_ready(acc[0][0], acc[0][1], acc[0][QB - 2], acc[0][QB - 1]);
@@ -638,6 +650,82 @@ __global__ void __launch_bounds__(FqGeom<QB>::THREADS, 2) flat_filter_kernel(Fla
     constexpr int WFLUSH = WBLK / 2;
     volatile unsigned* lgen = (volatile unsigned*)(smem + G::LDS_GEN);
 
+    if constexpr (STAGGER) {
+        static_assert(QB == 4 && SINGLE && G::TPB == 1, "the staggered schedule exists for the 8-wave geometry only");
+        // the MFMAs of one 32-row block of the tile in ring slot `slot` (the code of compute() above)
+        auto block_mfma = [&](int slot, int rb) __attribute__((always_inline)) {
+            const char* tile = smem + slot * FQ_TILE_BYTES;
+            const float* bias = (const float*)(smem + G::LDS_BIAS) + slot * FQ_TR;
+            const int sw = j & 15;
+            f32x16 c0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 b4 = *(const f32x4*)(bias + rb * 32 + 8 * g + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) c0[4 * g + e] = b4[e];
+            }
+            const char* rowp = tile + (rb * 32 + j) * 256;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int off = ((2 * s + h) ^ sw) << 4;
+                const half8 a0 = *(const half8*)(rowp + off);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb)
+                    acc[0][qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bq[qb][s], s == 0 ? c0 : acc[0][qb], 0, 0, 0);
+            }
+        };
+        // the tile loop; LATE = this wavefront is the out-of-phase one of its SIMD: the epilogue of a tile's second
+        // block is owed (`pend`, scores in acc) until the next tile begins, a sift is due or the tiles are exhausted
+        auto run = [&](auto late_c) __attribute__((always_inline)) {
+            constexpr bool LATE = decltype(late_c)::value;
+            int gslot = 0, u = 0, pend_tl = 0;
+            bool pend = false;
+            while (u < nsteps) {
+                bool sift;
+                do {
+                    if (LATE && pend) {
+                        epilogue(pend_tl, 1);
+                        pend = false;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    const int gslot2 = gslot >= 1 ? gslot - 1 : 2; // ring position of the tile two ahead
+                    if (u + 2 < nsteps) stage(u + 2, gslot2);
+                    if (!wave_idle) {
+                        block_mfma(gslot, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        epilogue(u, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        block_mfma(gslot, 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (LATE) {
+                            pend = true;
+                            pend_tl = u;
+                        } else {
+                            epilogue(u, 1);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    u += 1;
+                    if (MODE == MODE_COLLECT && wcnt > WFLUSH) *lgen = (unsigned)u;
+                    if (u + 2 <= nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_STAGE) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    gslot = gslot == 2 ? 0 : gslot + 1;
+                    sift = MODE == MODE_COLLECT && __builtin_amdgcn_readfirstlane(*lgen) == (unsigned)u;
+                } while (u < nsteps && !sift);
+                if (LATE && pend) {
+                    epilogue(pend_tl, 1);
+                    pend = false;
+                }
+                if (MODE == MODE_COLLECT) flush();
+            }
+        };
+        // which wavefronts share a SIMD is the dispatcher's business: stagger = 1 assumes w and w + 4 (round-robin over
+        // the four SIMDs), stagger = 2 assumes 2 i and 2 i + 1
+        const bool late = p.stagger == 2 ? (wave & 1) != 0 : wave >= G::WAVES / 2;
+        if (late) run(std::true_type{});
+        else run(std::false_type{});
+    } else {
     int gslot = 0; // (u / TPB) % 3
     int u = 0;
     while (u < nsteps) {
@@ -665,6 +753,7 @@ __global__ void __launch_bounds__(FqGeom<QB>::THREADS, 2) flat_filter_kernel(Fla
         // in order among themselves, so extra younger stores only make the counted waits conservative)
         if (MODE == MODE_COLLECT) flush();
     }
+    } // (!STAGGER)
 
     if (MODE == MODE_MAX) {
 #pragma unroll
@@ -703,6 +792,13 @@ static void launch_filter_mode(const FlatFilterParams& p, hipStream_t stream) {
     dim3 grid((unsigned)(p.nsplit * p.ngroups));
     if (p.geom == 2) {
         using G = FqGeom<4>;
+        if constexpr (MODE != MODE_DUMP) {
+            if (p.stagger) {
+                hipLaunchKernelGGL((flat_filter_kernel<METRIC, MODE, true, 4, true>), grid, dim3(G::THREADS), G::LDS_TOTAL,
+                                   stream, p);
+                return;
+            }
+        }
         hipLaunchKernelGGL((flat_filter_kernel<METRIC, MODE, true, 4>), grid, dim3(G::THREADS), G::LDS_TOTAL, stream, p);
     } else {
         using G = FqGeom<2>;
@@ -717,6 +813,8 @@ void launch_flat_filter(const FlatFilterParams& p_, int mode, hipStream_t stream
     if (p_.nq == 0 || p_.nb == 0) return;
     FlatFilterParams p = p_;
     if (const char* e = getenv("FAISS_AMD_FILTER_DBG")) p.dbg = atoi(e);
+    // experiment, not yet measured on hardware (hence off unless asked for): second wave of every SIMD out of phase
+    if (const char* e = getenv("FAISS_AMD_FILTER_STAGGER")) p.stagger = atoi(e);
     FA_THROW_IF_NOT(p.dh % FQ_KS == 0 && p.ldqh % 8 == 0 && p.ldbh % 8 == 0);
     FA_THROW_IF_NOT(p.tstride >= 1 && p.nsplit >= 1);
     FA_THROW_IF_NOT_MSG(p.geom == 0 || (p.geom == 2 && p.dh == FQ_KS), "the 8-wave geometry needs dh == 128");

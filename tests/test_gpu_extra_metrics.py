@@ -83,3 +83,24 @@ def test_extra_metric_through_the_bridge(tag, metric, arg):
         del gpu
     finally:
         Ref.amd_resources_free(bres)
+
+
+@pytest.mark.parametrize("stagger", ["1", "2"])
+@pytest.mark.parametrize("metric", [faiss_amd.METRIC_L2, faiss_amd.METRIC_INNER_PRODUCT])
+def test_flat_filter_staggered_schedule_is_bit_identical(res, monkeypatch, stagger, metric):
+    """FAISS_AMD_FILTER_STAGGER (flat_filter.hip: the second wave of every SIMD half a tile out of phase) computes the
+    same scores and collects the same candidates in another order: results bit-identical to the default schedule, on
+    the 8-wave geometry (d = 128, batches that fill 1024-query workgroups), incl. a ragged last tile and last group."""
+    from oracle.pyoracle import synthetic_dataset
+    d, nb, nq, k = 128, 50021, 3000, 100
+    _, xb, xq = synthetic_dataset(d, 0, nb, nq, seed=3)
+    idx = faiss_amd.GpuIndexFlat(res, d, metric)
+    idx.add(xb)
+    D0, I0 = idx.search(xq, k)
+    assert idx.filter_stats()[0]
+    monkeypatch.setenv("FAISS_AMD_FILTER_STAGGER", stagger)
+    D1, I1 = idx.search(xq, k)
+    assert idx.filter_stats() == (True, 0)
+    assert np.array_equal(I0, I1) and np.array_equal(D0, D1)
+    Do, Io = Oracle.flat_search(metric, xb, xq[:24], k)
+    check_knn(D1[:24], I1[:24], Do, Io, exact=True, name="staggered schedule vs oracle")

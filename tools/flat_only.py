@@ -16,7 +16,13 @@ dev = torch.device("cuda", 0)
 xq_dev = torch.from_numpy(xq).to(dev)
 Dd = torch.empty((NQ, 100), dtype=torch.float32, device=dev)
 Id = torch.empty((NQ, 100), dtype=torch.int64, device=dev)
+# DBG_LIST: comma-separated FAISS_AMD_FILTER_DBG values, each optionally "dbg:nsplit" and / or "dbg/stagger"
+# (FAISS_AMD_FILTER_STAGGER: 0 default schedule, 1 / 2 the out-of-phase second wave per SIMD, flat_filter.hip)
 for dbg in os.environ.get("DBG_LIST", "0").split(","):
+    stag = "0"
+    if "/" in dbg:
+        dbg, stag = dbg.split("/")
+    os.environ["FAISS_AMD_FILTER_STAGGER"] = stag
     if ":" in dbg:
         dbg, ns = dbg.split(":")
         os.environ["FAISS_AMD_FILTER_NSPLIT"] = ns
@@ -26,7 +32,7 @@ for dbg in os.environ.get("DBG_LIST", "0").split(","):
     for _ in range(steps):
         idx.search_ptr(NQ, xq_dev.data_ptr(), 100, Dd.data_ptr(), Id.data_ptr())
     torch.cuda.synchronize()
-    print("flat search nq=%d (dbg %s nsplit %s geom %s): %.3f ms/step" % (NQ, dbg, os.environ.get("FAISS_AMD_FILTER_NSPLIT"), os.environ.get("FAISS_AMD_FILTER_GEOM"), (time.time() - t0) / steps * 1e3), flush=True)
+    print("flat search nq=%d (dbg %s stagger %s nsplit %s geom %s): %.3f ms/step" % (NQ, dbg, stag, os.environ.get("FAISS_AMD_FILTER_NSPLIT"), os.environ.get("FAISS_AMD_FILTER_GEOM"), (time.time() - t0) / steps * 1e3), flush=True)
     res.profile_enable(True); res.profile_reset()
     idx.search_ptr(NQ, xq_dev.data_ptr(), 100, Dd.data_ptr(), Id.data_ptr())
     print("   per kernel (ms, launches):", {kn: tuple(round(v, 4) for v in res.profile_get(kn)) for kn in (
