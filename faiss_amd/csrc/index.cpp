@@ -660,7 +660,7 @@ bool GpuIndexFlat::filter_applicable_(int k) const {
 // tile of n queries
 void GpuIndexFlat::plan_filter_(int n, int k, int& geom, int& nsplit, int& tstride, int& cap, int& gcap) const {
     std::string knobs;
-    for (const char* name : {"FAISS_AMD_FILTER_GEOM", "FAISS_AMD_FILTER_NSPLIT"}) {
+    for (const char* name : {"FAISS_AMD_FILTER_GEOM", "FAISS_AMD_FILTER_NSPLIT", "FAISS_AMD_FILTER_TSTRIDE"}) {
         const char* e = getenv(name);
         knobs += e ? e : "-";
         knobs += ';';
@@ -721,6 +721,7 @@ void GpuIndexFlat::plan_filter_(int n, int k, int& geom, int& nsplit, int& tstri
     if (const char* e = getenv("FAISS_AMD_FILTER_NSPLIT")) nsplit = atoi(e); // timing experiments only
     const int tiles_per_split = total_tiles / nsplit;
     tstride = tiles_per_split >= 32 ? 4 : tiles_per_split >= 16 ? 2 : 1;
+    if (const char* e = getenv("FAISS_AMD_FILTER_TSTRIDE")) tstride = std::max(1, atoi(e)); // timing experiments only
     // expected rows above the threshold: S * -ln(1 - k/S) in the sample, tstride times that overall; the
     // re-rank kernel gathers at most 4096 of them per query, so large k samples more tiles
     const double S = (double)cps * nsplit;
