@@ -833,6 +833,25 @@ void GpuIndexFlat::search_tile_(int n, const float* xq_pad, int k, float* dD, id
     fp.flags = flags_.as<uint32_t>();
     fp.dump = nullptr;
     fp.exact_inputs = use_float16_ ? 1 : 0;
+    // experiment, not yet run on hardware (FAISS_AMD_FLAT_SMALL=1): small databases -- the coarse quantizer of the IVF
+    // searches -- in ONE launch instead of the four below (flat_small.hip)
+    const char* small_env = getenv("FAISS_AMD_FLAT_SMALL");
+    if (small_env && atoi(small_env) == 1 && !use_float16_ && !sel_active_ && flat_small_supported(nb, dh_, dpad_, k)) {
+        FlatSmallParams sp{};
+        sp.metric = metric_type;
+        sp.nq = n, sp.nb = nb, sp.d = d, sp.dh = dh_, sp.dpad = dpad_, sp.k = k;
+        sp.xqh = fp.xqh, sp.xq = xq_pad, sp.xqn = fp.xqn;
+        sp.xbh = fp.xbh, sp.xbhn = fp.xbhn, sp.xb = xb_.as<float>(), sp.xbn = xbn_.as<float>();
+        sp.ldqh = dh_, sp.ldq = dpad_, sp.ldbh = dh_, sp.ldb = dpad_;
+        sp.yn_max = yn_max_;
+        sp.flags = fp.flags;
+        sp.id_base = 0;
+        sp.out_dis = dD, sp.out_ids = dI;
+        sp.ovf_list = ovf_list_.as<uint32_t>();
+        sp.ovf_cnt = scal_.as<unsigned>() + 2;
+        SpanGuard sg(&R, "flat_small_kernel");
+        launch_flat_small(sp, R.stream);
+    } else {
     {
         // chunk maxima over a 1/tstride sample of the tiles -> per-query threshold
         SpanGuard sg(&R, "flat_filter_kernel_max");
@@ -880,6 +899,7 @@ void GpuIndexFlat::search_tile_(int n, const float* xq_pad, int k, float* dD, id
         SpanGuard sg(&R, "flat_rerank_kernel");
         launch_flat_rerank(rp, R.stream);
     }
+    } // (general filter path)
     // ---- queries whose segments overflowed (or left the fp16 range) go through the exact fp32 scan
     if (!h_novf_) HIP_CHECK(hipHostMalloc((void**)&h_novf_, 64, hipHostMallocDefault));
     HIP_CHECK(hipMemcpyAsync(h_novf_, scal_.as<unsigned>() + 2, 4, hipMemcpyDeviceToHost, R.stream));

@@ -104,3 +104,44 @@ def test_flat_filter_staggered_schedule_is_bit_identical(res, monkeypatch, stagg
     assert np.array_equal(I0, I1) and np.array_equal(D0, D1)
     Do, Io = Oracle.flat_search(metric, xb, xq[:24], k)
     check_knn(D1[:24], I1[:24], Do, Io, exact=True, name="staggered schedule vs oracle")
+
+
+@pytest.mark.parametrize("metric", [faiss_amd.METRIC_L2, faiss_amd.METRIC_INNER_PRODUCT])
+@pytest.mark.parametrize("d,nb,nq,k", [(128, 4096, 1100, 32), (128, 8192, 37, 10), (128, 2048 + 17, 300, 1), (100, 5000, 64, 32)])
+def test_flat_small_one_launch_kernel_is_bit_identical(res, monkeypatch, metric, d, nb, nq, k):
+    """FAISS_AMD_FLAT_SMALL=1 (flat_small.hip: bound, candidates, exact distances and ranking of a small database in one
+    launch -- the coarse quantizer of the IVF searches): bit-identical to the default filter path and to the oracle."""
+    from oracle.pyoracle import synthetic_dataset
+    _, xb, xq = synthetic_dataset(d, 0, nb, nq, seed=nb + k)
+    idx = faiss_amd.GpuIndexFlat(res, d, metric)
+    idx.set_use_filter_kernel(True, 2048)  # (what GpuIndexIVF sets on its coarse quantizer)
+    idx.add(xb)
+    D0, I0 = idx.search(xq, k)
+    monkeypatch.setenv("FAISS_AMD_FLAT_SMALL", "1")
+    res.profile_enable(True)
+    res.profile_reset()
+    D1, I1 = idx.search(xq, k)
+    assert res.profile_get("flat_small_kernel")[1] == 1, "the one-launch kernel did not serve the search"
+    res.profile_enable(False)
+    assert idx.filter_stats()[1] == 0
+    assert np.array_equal(I0, I1) and np.array_equal(D0, D1)
+    Do, Io = Oracle.flat_search(metric, xb, xq[:40], k)
+    check_knn(D1[:40], I1[:40], Do, Io, exact=True, name="one-launch small-database kernel vs oracle")
+
+
+def test_ivf_search_with_one_launch_coarse_quantizer(res, monkeypatch):
+    from oracle.pyoracle import synthetic_dataset
+    d, nlist, nb, nq, k = 128, 4096, 100000, 1500, 20
+    xt, xb, xq = synthetic_dataset(d, 20000, nb, nq, seed=4)
+    cent, _ = faiss_amd.kmeans(res, xt, nlist, niter=2, seed=3)
+    idx = faiss_amd.GpuIndexIVFFlat(res, d, nlist, faiss_amd.METRIC_L2)
+    idx.copy_centroids(cent)
+    idx.add(xb)
+    idx.nprobe = 32
+    D0, I0 = idx.search(xq, k)
+    Dq0, Iq0 = idx.quantizer_search(xq, 32)
+    monkeypatch.setenv("FAISS_AMD_FLAT_SMALL", "1")
+    D1, I1 = idx.search(xq, k)
+    Dq1, Iq1 = idx.quantizer_search(xq, 32)
+    assert np.array_equal(Iq0, Iq1) and np.array_equal(Dq0, Dq1)
+    assert np.array_equal(I0, I1) and np.array_equal(D0, D1)
