@@ -117,6 +117,11 @@ def load_library():
         "faiss_amd_Index_compute_residual_n": (i32, [vp, i64, vp, vp, vp]),
         "faiss_amd_GpuIndexIVF_search_preassigned": (i32, [vp, i64, vp, i64, vp, vp, vp, vp]),
         "faiss_amd_GpuIndexIVF_add_core": (i32, [vp, i64, vp, vp, vp]),
+        "faiss_amd_GpuIndexIVF_reserveMemory": (i32, [vp, sz]),
+        "faiss_amd_GpuIndexIVF_reclaimMemory": (i32, [vp, P(sz)]),
+        "faiss_amd_GpuIndexIVF_updateQuantizer": (i32, [vp]),
+        "faiss_amd_GpuIndexIVFPQ_setPrecomputedCodes": (i32, [vp, i32]),
+        "faiss_amd_GpuIndexIVFPQ_getInfo": (i32, [vp, P(i32), P(i32), P(i32), P(i32)]),
         "faiss_amd_IndexIVF_quantizer_search": (i32, [vp, i64, vp, i64, vp, vp]),
         "faiss_amd_bfKnn": (i32, [vp, i32, vp, i64, vp, i64, i32, i64, vp, vp]),
         "faiss_amd_GpuIndexFlat_new_with_config": (i32, [P(vp), vp, i32, i32, vp]),
@@ -451,6 +456,19 @@ class _GpuIndexIVF(Index):
         _check(self._lib.faiss_amd_IndexIVF_quantizer_search(self._h, x.shape[0], _ptr(x), int(k), _ptr(D), _ptr(I)))
         return D, I
 
+    def reserveMemory(self, num_vecs):
+        """GpuIndexIVF*.reserveMemory: room for num_vecs vectors up front"""
+        _check(self._lib.faiss_amd_GpuIndexIVF_reserveMemory(self._h, int(num_vecs)))
+
+    def reclaimMemory(self):
+        """GpuIndexIVF*.reclaimMemory: release slack, holes and add scratch; returns the device bytes given back"""
+        b = ctypes.c_size_t(0)
+        _check(self._lib.faiss_amd_GpuIndexIVF_reclaimMemory(self._h, ctypes.byref(b)))
+        return b.value
+
+    def updateQuantizer(self):
+        _check(self._lib.faiss_amd_GpuIndexIVF_updateQuantizer(self._h))
+
     def add_core(self, x, assign, ids=None):
         """index.add_core(n, x, ids, assign) of the reference (GpuIndexIVF::add_core; contrib/ivf_tools.py
         add_preassigned): add with the inverted list of every vector given by the caller"""
@@ -720,6 +738,27 @@ class GpuIndexIVFPQ(_GpuIndexIVF):
         _check(self._lib.faiss_amd_GpuIndexIVFPQ_new_with_config(ctypes.byref(self._h), res._h, int(d), int(nlist), int(M),
                                                                  int(nbits), int(metric),
                                                                  ctypes.byref(config) if config else None))
+
+    def _info(self):
+        v = [ctypes.c_int(0) for _ in range(4)]
+        _check(self._lib.faiss_amd_GpuIndexIVFPQ_getInfo(self._h, *[ctypes.byref(x) for x in v]))
+        return [x.value for x in v]
+
+    def setPrecomputedCodes(self, enable):
+        """GpuIndexIVFPQ.setPrecomputedCodes: kept and reported; the per-vector term it stands for is always on here"""
+        _check(self._lib.faiss_amd_GpuIndexIVFPQ_setPrecomputedCodes(self._h, int(bool(enable))))
+
+    def getPrecomputedCodes(self):
+        return bool(self._info()[0])
+
+    def getNumSubQuantizers(self):
+        return self._info()[1]
+
+    def getBitsPerCode(self):
+        return self._info()[2]
+
+    def getCentroidsPerSubQuantizer(self):
+        return self._info()[3]
 
     def copy_pq_centroids(self, pq):
         pq = np.ascontiguousarray(pq, dtype=np.float32).reshape(-1)

@@ -579,6 +579,37 @@ int faiss_amd_GpuIndexFlat_filter_scores(const FaissAmdIndex* index, faiss_amd_i
     as<GpuIndexFlat>(index, "GpuIndexFlat")->filter_scores(n, x, scores, err_bound);
     FA_CATCH
 }
+int faiss_amd_GpuIndexIVF_reserveMemory(FaissAmdIndex* index, size_t num_vecs) {
+    FA_TRY
+    as<GpuIndexIVF>(index, "GpuIndexIVF")->reserveMemory(num_vecs);
+    FA_CATCH
+}
+int faiss_amd_GpuIndexIVF_reclaimMemory(FaissAmdIndex* index, size_t* p_bytes) {
+    FA_TRY
+    const size_t b = as<GpuIndexIVF>(index, "GpuIndexIVF")->reclaimMemory();
+    if (p_bytes) *p_bytes = b;
+    FA_CATCH
+}
+int faiss_amd_GpuIndexIVF_updateQuantizer(FaissAmdIndex* index) {
+    FA_TRY
+    as<GpuIndexIVF>(index, "GpuIndexIVF")->updateQuantizer();
+    FA_CATCH
+}
+int faiss_amd_GpuIndexIVFPQ_setPrecomputedCodes(FaissAmdIndex* index, int enable) {
+    FA_TRY
+    as<GpuIndexIVFPQ>(index, "GpuIndexIVFPQ")->setPrecomputedCodes(enable != 0);
+    FA_CATCH
+}
+int faiss_amd_GpuIndexIVFPQ_getInfo(const FaissAmdIndex* index, int* precomputed_codes, int* num_sub_quantizers,
+                                    int* bits_per_code, int* centroids_per_sub_quantizer) {
+    FA_TRY
+    const GpuIndexIVFPQ* pq = as<GpuIndexIVFPQ>(index, "GpuIndexIVFPQ");
+    if (precomputed_codes) *precomputed_codes = pq->getPrecomputedCodes() ? 1 : 0;
+    if (num_sub_quantizers) *num_sub_quantizers = pq->getNumSubQuantizers();
+    if (bits_per_code) *bits_per_code = pq->getBitsPerCode();
+    if (centroids_per_sub_quantizer) *centroids_per_sub_quantizer = pq->getCentroidsPerSubQuantizer();
+    FA_CATCH
+}
 int faiss_amd_GpuIndexIVF_add_core(FaissAmdIndex* index, faiss_amd_idx_t n, const float* x, const faiss_amd_idx_t* xids,
                                    const faiss_amd_idx_t* precomputed_idx) {
     FA_TRY

@@ -1593,8 +1593,41 @@ void GpuIndexIVF::grow_lists_(const std::vector<uint32_t>& new_len, const std::v
     R.sync(); // jobs / list_start_ host vectors are read by the copies above
 }
 
+void GpuIndexIVF::reserveMemory(size_t numVecs) {
+    std::lock_guard<std::mutex> g(mu_);
+    res_->set_device();
+    // the vectors + one granule of rounding per list + the growth margin a relocated list takes (1.5 x)
+    const int64_t want = (int64_t)((double)numVecs * 1.25) + (int64_t)nlist * granule_ + 64;
+    ensure_arena_(std::max<int64_t>(want, arena_rows_));
+    res_->sync();
+}
+size_t GpuIndexIVF::reclaimMemory() {
+    std::lock_guard<std::mutex> g(mu_);
+    res_->set_device();
+    const size_t row_bytes = code_bytes_ + 8 + (use_t2_ ? 4 : 0);
+    size_t before = (size_t)arena_cap_rows_ * row_bytes;
+    for (DevBuf* b : {&a_xpad_, &a_lab_, &a_dis_, &a_dest_, &a_ids_, &a_hist_, &a_newlen_, &a_jobs_}) {
+        before += b->cap;
+        b->release();
+    }
+    if (arena_.p) compact_(true);
+    const size_t after = (size_t)arena_cap_rows_ * row_bytes;
+    return before > after ? before - after : 0;
+}
+void GpuIndexIVF::updateQuantizer() {
+    std::lock_guard<std::mutex> g(mu_);
+    res_->set_device();
+    FA_THROW_IF_NOT_MSG(quantizer->ntotal == 0 || quantizer->ntotal == nlist, "the coarse quantizer must hold nlist centroids");
+    update_is_trained_();
+    if (quantizer->ntotal == nlist) {
+        ensure_arena_(64);
+        upload_list_tables_();
+        if (nstored_ > 0 && is_trained) lists_changed_();
+    }
+}
+
 // rebuild the arena without holes (lists in id order, 1/8 slack each)
-void GpuIndexIVF::compact_() {
+void GpuIndexIVF::compact_(bool tight) {
     const GpuResources& R = *res_;
     const int64_t G = granule_;
     std::vector<IvfMoveJob> jobs;
@@ -1603,7 +1636,7 @@ void GpuIndexIVF::compact_() {
     int64_t acc = 0;
     for (int l = 0; l < nlist; l++) {
         nstart[l] = acc;
-        ncap[l] = list_len_[l] ? (uint32_t)round_up((size_t)list_len_[l] + list_len_[l] / 8, (size_t)G) : 0u;
+        ncap[l] = list_len_[l] ? (uint32_t)round_up((size_t)list_len_[l] + (tight ? 0 : list_len_[l] / 8), (size_t)G) : 0u;
         if (list_len_[l]) jobs.push_back({list_start_[l], acc, (int64_t)round_up(list_len_[l], (size_t)G)});
         acc += ncap[l];
     }

@@ -347,6 +347,16 @@ class GpuIndexIVF : public Index {
     // copyFrom-style bulk load (train state + inverted lists), see include/faiss_amd_c.h
     virtual void set_centroids(const float* centroids);
     void set_lists(const uint32_t* list_sizes, const uint8_t* codes, const idx_t* ids);
+    // GpuIndexIVFFlat / IVFPQ / IVFScalarQuantizer::reserveMemory (faiss/gpu/GpuIndexIVFFlat.h:64): room for numVecs
+    // vectors up front, so that the adds that follow do not re-allocate the list arena
+    void reserveMemory(size_t numVecs);
+    // ...::reclaimMemory (GpuIndexIVFFlat.h:76): give back what the lists do not need (slack, holes of relocated lists,
+    // add-path scratch); returns the bytes released.  The lists keep their order and contents.
+    size_t reclaimMemory();
+    // GpuIndexIVF::updateQuantizer (faiss/gpu/GpuIndexIVF.h:79): the coarse centroids were changed from outside
+    // (quantizer->reset() / add()): re-derive what depends on them (training state, the per-vector IVFPQ term)
+    void updateQuantizer();
+    idx_t getNumLists() const { return nlist; }
     // vectors actually stored (ntotal counts the vectors add() was given, NaN rows included, like the reference:
     // faiss/gpu/GpuIndexIVF.cu:293-298)
     idx_t stored_vectors() const { return nstored_; }
@@ -404,7 +414,7 @@ class GpuIndexIVF : public Index {
     // make room for new_len[l] entries in every list (relocating the lists that outgrow their slack); est[l]
     // (nullable) = expected final length, used as the new capacity of a list that has to move
     void grow_lists_(const std::vector<uint32_t>& new_len, const std::vector<double>* est);
-    void compact_();
+    void compact_(bool tight = false); // tight: no per-list slack beyond the granule (reclaimMemory)
     void add_core_(idx_t n, const float* x, const idx_t* xids, const idx_t* assign = nullptr);
     void search_core_(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels, const idx_t* assign,
                       const float* centroid_dis, int nprobe_now, const IDSelector* sel) const;
@@ -440,11 +450,19 @@ class GpuIndexIVFPQ : public GpuIndexIVF {
     int pq_niter = 25; // faiss::ClusteringParameters default used by ProductQuantizer::train
     void set_pq_centroids(const float* pq); // [M][256][dsub]
     std::vector<float> get_pq_centroids() const;
+    // GpuIndexIVFPQ.h:98-113.  The term decomposition behind "precomputed codes" is always on here (one table per
+    // query + a per-vector term): the flag is recorded and reported, results do not depend on it.
+    void setPrecomputedCodes(bool enable) { precomputed_codes_ = enable; }
+    bool getPrecomputedCodes() const { return precomputed_codes_; }
+    int getNumSubQuantizers() const { return M; }
+    int getBitsPerCode() const { return nbits; }
+    int getCentroidsPerSubQuantizer() const { return 1 << nbits; }
 
    protected:
     void fill_fused_(struct IvfFusedParams& p) const override;
     int fused_kind_() const override { return 1; }
     int fused_M_() const override { return M; }
+    bool precomputed_codes_ = false;
     DevBuf pq_;   // [M][256][dsub]
     DevBuf pq_t_; // [256][M][dsub]: the order the scan kernels build their lookup table in
     bool extra_trained_() const override { return pq_.p != nullptr; }

@@ -265,6 +265,20 @@ int faiss_amd_Index_compute_residual(const FaissAmdIndex* index, const float* x,
 int faiss_amd_Index_compute_residual_n(const FaissAmdIndex* index, faiss_amd_idx_t n, const float* xs, float* residuals,
                                        const faiss_amd_idx_t* keys);
 
+/* ---- memory management and quantizer refresh of the reference's IVF classes (faiss/gpu/GpuIndexIVFFlat.h:64-85,
+ *      GpuIndexIVFPQ.h:98-126, GpuIndexIVFScalarQuantizer.h:66-87, GpuIndexIVF.h:79):
+ *      reserveMemory: room for numVecs vectors up front (no re-allocation of the list arena by the adds that follow);
+ *      reclaimMemory: give back slack, holes and add-path scratch, *p_bytes = device bytes released (may be NULL);
+ *      updateQuantizer: call after changing the coarse centroids from outside.
+ *      IVFPQ: precomputed codes are the per-vector term that is always on here -- the flag is kept and reported only. */
+int faiss_amd_GpuIndexIVF_reserveMemory(FaissAmdIndex* index, size_t num_vecs);
+int faiss_amd_GpuIndexIVF_reclaimMemory(FaissAmdIndex* index, size_t* p_bytes);
+int faiss_amd_GpuIndexIVF_updateQuantizer(FaissAmdIndex* index);
+int faiss_amd_GpuIndexIVFPQ_setPrecomputedCodes(FaissAmdIndex* index, int enable);
+/* getters of GpuIndexIVFPQ.h:104-113: any of the outputs may be NULL */
+int faiss_amd_GpuIndexIVFPQ_getInfo(const FaissAmdIndex* index, int* precomputed_codes, int* num_sub_quantizers,
+                                    int* bits_per_code, int* centroids_per_sub_quantizer);
+
 /* ---- GpuIndexIVF::add_core (faiss/gpu/GpuIndexIVF.h:84-95, GpuIndexIVF.cu:321-356; what contrib/ivf_tools.py
  *      add_preassigned drives): add n vectors whose inverted list is given by the caller (precomputed_idx [n], host or
  *      device; entries outside [0, nlist) leave their vector out).  xids may be NULL (sequential ids from ntotal). */

@@ -320,6 +320,20 @@ struct AmdIndexIVF : AmdIndex, faiss::IndexIVFInterface {
         AmdIndex::train(n, x);
         refresh_quantizer_();
     }
+    /// GpuIndexIVFFlat / IVFPQ / IVFScalarQuantizer::reserveMemory, reclaimMemory; GpuIndexIVF::updateQuantizer
+    void reserveMemory(size_t numVecs) {
+        amd_check(faiss_amd_GpuIndexIVF_reserveMemory(h, numVecs));
+    }
+    size_t reclaimMemory() {
+        size_t bytes = 0;
+        amd_check(faiss_amd_GpuIndexIVF_reclaimMemory(h, &bytes));
+        return bytes;
+    }
+    void updateQuantizer() {
+        amd_check(faiss_amd_GpuIndexIVF_updateQuantizer(h));
+        sync();
+        refresh_quantizer_();
+    }
     /// GpuIndexIVF::add_core (faiss/gpu/GpuIndexIVF.h:84-95): the inverted list of every vector comes from the caller
     /// (contrib/ivf_tools.py add_preassigned; IndexIVF::add_core has the same signature, faiss/IndexIVF.h:261-266)
     void add_core(idx_t n, const float* x, const idx_t* xids, const idx_t* precomputed_idx,

@@ -1,10 +1,13 @@
-"""GPU tests of the "extra" metrics of GpuIndexFlat / bfKnn (L1, Linf, Lp, Canberra, BrayCurtis, JensenShannon, Jaccard:
-faiss/gpu/impl/GeneralDistance.cuh over the functors of faiss/gpu/impl/DistanceUtils.cuh:47-281; reference tests
-faiss/gpu/test/TestGpuIndexFlat.cpp L1_Float32 / Lp_Float32, TestGpuDistance.cu L1 .. Jaccard).
-
-STATUS: written after this round's GPU budget was spent -- the kernel (flat_general_kernel) compiles for gfx950 but has
-not run on hardware yet, so these tests only run when FAISS_AMD_RUN_UNVALIDATED=1 is set (first GPU call of the next
-round).  The oracle they compare with is pinned on the real reference by tests/test_golden_extra_cpu.py."""
+"""GPU tests of everything written after round 2's GPU budget was spent -- code that compiles for gfx950 but has NOT run on
+hardware yet, so these tests only run when FAISS_AMD_RUN_UNVALIDATED=1 is set (tools/validate_unvalidated.sh, first GPU
+call of the next round):
+  * the "extra" metrics of GpuIndexFlat / bfKnn (L1, Linf, Lp, Canberra, BrayCurtis, JensenShannon, Jaccard:
+    faiss/gpu/impl/GeneralDistance.cuh over the functors of faiss/gpu/impl/DistanceUtils.cuh:47-281; reference tests
+    faiss/gpu/test/TestGpuIndexFlat.cpp L1_Float32 / Lp_Float32, TestGpuDistance.cu L1 .. Jaccard); the oracle they are
+    compared with is pinned on the real reference by tests/test_golden_extra_cpu.py;
+  * the staggered schedule of the filter kernel (FAISS_AMD_FILTER_STAGGER) and the one-launch small-database kernel
+    (FAISS_AMD_FLAT_SMALL): both must be bit-identical to the default path;
+  * reserveMemory / reclaimMemory / updateQuantizer and the IVFPQ getters of the reference's GPU index classes."""
 import os
 
 import numpy as np
@@ -145,3 +148,43 @@ def test_ivf_search_with_one_launch_coarse_quantizer(res, monkeypatch):
     Dq1, Iq1 = idx.quantizer_search(xq, 32)
     assert np.array_equal(Iq0, Iq1) and np.array_equal(Dq0, Dq1)
     assert np.array_equal(I0, I1) and np.array_equal(D0, D1)
+
+
+def test_ivf_reserve_and_reclaim_memory(res):
+    """GpuIndexIVFFlat::reserveMemory / reclaimMemory (faiss/gpu/GpuIndexIVFFlat.h:64-76), GpuIndexIVFPQ getters: the arena
+    does not grow during the add a reservation covers, reclaiming shrinks it and changes no result."""
+    from oracle.pyoracle import synthetic_dataset
+    d, nlist, nb, nq, k = 32, 64, 30000, 200, 10
+    xt, xb, xq = synthetic_dataset(d, 4000, nb, nq, seed=6)
+    cent, _ = faiss_amd.kmeans(res, xt, nlist, niter=4, seed=3)
+    for kind in (0, 1):
+        if kind == 0:
+            idx = faiss_amd.GpuIndexIVFFlat(res, d, nlist, faiss_amd.METRIC_L2)
+        else:
+            idx = faiss_amd.GpuIndexIVFPQ(res, d, nlist, 8, 8, faiss_amd.METRIC_L2)
+            idx.copy_pq_centroids((np.random.RandomState(7).rand(8, 256, 4).astype("float32") - 0.5) * 0.4)
+            assert idx.getNumSubQuantizers() == 8 and idx.getBitsPerCode() == 8 and idx.getCentroidsPerSubQuantizer() == 256
+            assert not idx.getPrecomputedCodes()
+            idx.setPrecomputedCodes(True)
+            assert idx.getPrecomputedCodes()
+        idx.copy_centroids(cent)
+        idx.nprobe = 8
+        idx.reserveMemory(nb)
+        alloc0 = idx.arena_stats()[2]
+        assert alloc0 >= nb
+        idx.add(xb)  # one call: every list gets its final capacity at once, inside the reservation
+        assert idx.arena_stats()[2] == alloc0, "the reservation did not cover the add"
+        D0, I0 = idx.search(xq, k)
+        lists0 = [(idx.get_list_ids(l).copy(), idx.get_list_codes(l).copy()) for l in range(nlist)]
+        freed = idx.reclaimMemory()
+        used, holes, alloc1 = idx.arena_stats()
+        assert freed > 0 and alloc1 < alloc0 and holes == 0 and alloc1 <= nb + nlist * 64 + 64
+        D1, I1 = idx.search(xq, k)
+        assert np.array_equal(D0, D1) and np.array_equal(I0, I1)
+        for l in range(nlist):
+            assert np.array_equal(idx.get_list_ids(l), lists0[l][0]) and np.array_equal(idx.get_list_codes(l), lists0[l][1])
+        idx.add(xb[:3000])  # the index keeps working after a reclaim
+        assert idx.ntotal == nb + 3000
+        idx.updateQuantizer()
+        D2, I2 = idx.search(xq, k)
+        assert (I2[:, 0] >= 0).all()

@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
-FAISS_AMD_RUN_UNVALIDATED=1 timeout 600 python -m pytest tests/test_gpu_extra_metrics.py -q --tb=short --maxfail=10 -p no:cacheprovider > $O/unvalidated_tests.log 2>&1
+FAISS_AMD_RUN_UNVALIDATED=1 timeout 600 python -m pytest tests/test_gpu_unvalidated.py -q --tb=short --maxfail=10 -p no:cacheprovider > $O/unvalidated_tests.log 2>&1
 tail -25 $O/unvalidated_tests.log
 DBG_LIST=0,0/1,0/2,0,0/1 timeout 200 python tools/flat_only.py 20 > $O/unvalidated_flat_stagger.log 2>&1
 grep -v amdgpu.ids $O/unvalidated_flat_stagger.log | tail -12
