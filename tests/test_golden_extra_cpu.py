@@ -75,3 +75,21 @@ def test_selector_subset_rule_vs_reference_golden():
                       name="ivf selector " + case["name"])
             n += 1
     assert n >= 7
+
+
+def test_add_core_lists_vs_reference_golden():
+    """IndexIVF::add_core with a caller-supplied assignment (tests/golden/add_core.npz): entries in insertion order in the
+    GIVEN lists, -1 left out but counted, PQ codes of the residual against the given list's centroid -- byte for byte what
+    the oracle's encoder produces (the GPU test tests/test_gpu_add_core.py holds the device lists against the same oracle)."""
+    z = np.load(os.path.join(GOLD, "add_core.npz"))
+    d, nt, nb, nq, seed = (int(v) for v in z["gen"])
+    _, xb, _ = synthetic_dataset(d, nt, nb, nq, seed=seed)
+    assign, ids = z["assign"], z["ids"]
+    ok = assign >= 0
+    order = np.argsort(np.where(ok, assign, 1 << 30), kind="stable")[: int(ok.sum())]
+    want_sizes = np.bincount(assign[ok], minlength=64).astype(np.uint32)
+    for tag in ("flat", "pq"):
+        assert int(z[tag + "_ntotal"]) == nb
+        assert np.array_equal(z[tag + "_sizes"], want_sizes) and np.array_equal(z[tag + "_ids"], ids[order])
+    codes = Oracle.pq_encode(z["pq_codebook"], z["pq_coarse"], xb, np.where(ok, assign, 0))
+    assert np.array_equal(codes[order], z["pq_codes"])
