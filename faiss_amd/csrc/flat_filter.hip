@@ -652,6 +652,7 @@ __global__ void __launch_bounds__(FqGeom<QB>::THREADS, 2) flat_filter_kernel(Fla
 
     if constexpr (STAGGER) {
         static_assert(QB == 4 && SINGLE && G::TPB == 1, "the staggered schedule exists for the 8-wave geometry only");
+        const bool mfma_prio = (p.stagger & 4) != 0; // (a kernel argument: wave-uniform, a scalar branch around s_setprio)
         // the MFMAs of one 32-row block of the tile in ring slot `slot` (the code of compute() above)
         auto block_mfma = [&](int slot, int rb) __attribute__((always_inline)) {
             const char* tile = smem + slot * FQ_TILE_BYTES;
@@ -665,6 +666,9 @@ __global__ void __launch_bounds__(FqGeom<QB>::THREADS, 2) flat_filter_kernel(Fla
                 for (int e = 0; e < 4; ++e) c0[4 * g + e] = b4[e];
             }
             const char* rowp = tile + (rb * 32 + j) * 256;
+            // (stagger & 4: the wave in its MFMA cluster outranks its partner's epilogue at the issue port -- with the two
+            // waves of a SIMD in different roles the priority has something to arbitrate, cdna_hip_programming.md T5)
+            if (mfma_prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 const int off = ((2 * s + h) ^ sw) << 4;
@@ -673,6 +677,7 @@ __global__ void __launch_bounds__(FqGeom<QB>::THREADS, 2) flat_filter_kernel(Fla
                 for (int qb = 0; qb < QB; ++qb)
                     acc[0][qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bq[qb][s], s == 0 ? c0 : acc[0][qb], 0, 0, 0);
             }
+            if (mfma_prio) __builtin_amdgcn_s_setprio(0);
         };
         // the tile loop; LATE = this wavefront is the out-of-phase one of its SIMD: the epilogue of a tile's second
         // block is owed (`pend`, scores in acc) until the next tile begins, a sift is due or the tiles are exhausted
@@ -722,7 +727,7 @@ __global__ void __launch_bounds__(FqGeom<QB>::THREADS, 2) flat_filter_kernel(Fla
         };
         // which wavefronts share a SIMD is the dispatcher's business: stagger = 1 assumes w and w + 4 (round-robin over
         // the four SIMDs), stagger = 2 assumes 2 i and 2 i + 1
-        const bool late = p.stagger == 2 ? (wave & 1) != 0 : wave >= G::WAVES / 2;
+        const bool late = (p.stagger & 3) == 2 ? (wave & 1) != 0 : wave >= G::WAVES / 2;
         if (late) run(std::true_type{});
         else run(std::false_type{});
     } else {
