@@ -727,9 +727,16 @@ __global__ void __launch_bounds__(FqGeom<QB>::THREADS, 2) flat_filter_kernel(Fla
         };
         // which wavefronts share a SIMD is the dispatcher's business: stagger = 1 assumes w and w + 4 (round-robin over
         // the four SIMDs), stagger = 2 assumes 2 i and 2 i + 1
-        const bool late = (p.stagger & 3) == 2 ? (wave & 1) != 0 : wave >= G::WAVES / 2;
-        if (late) run(std::true_type{});
-        else run(std::false_type{});
+        // (+ 3: waves 0..3 -- the OLDER half, whose VALU work right behind a barrier release is the unimpeded one,
+        // MI355X_MICROARCH.md "Two waves per SIMD" items 2 and 6; + 8: one static s_setprio 1 for the out-of-phase half)
+        const int who = p.stagger & 3;
+        const bool late = who == 2 ? (wave & 1) != 0 : who == 3 ? wave < G::WAVES / 2 : wave >= G::WAVES / 2;
+        if (late) {
+            if ((p.stagger & 8) != 0) __builtin_amdgcn_s_setprio(1);
+            run(std::true_type{});
+        } else {
+            run(std::false_type{});
+        }
     } else {
     int gslot = 0; // (u / TPB) % 3
     int u = 0;

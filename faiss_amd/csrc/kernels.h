@@ -115,7 +115,8 @@ struct FlatFilterParams {
     int exact_inputs;             // fp16 storage: q and y are fp16 values, the error band shrinks to the accumulation terms
     int dbg;                      // timing experiments only (env FAISS_AMD_FILTER_DBG): 1 no parking, 2 no sift, 4 no hits
     int stagger;                  // 8-wave geometry: second wave of every SIMD half a tile out of phase (flat_filter.hip);
-                                  // 1: waves 4..7, 2: odd waves, + 4: s_setprio 1 around the MFMA clusters
+                                  // 1: waves 4..7, 2: odd waves, 3: waves 0..3; + 4: s_setprio 1 around the MFMA
+                                  // clusters; + 8: static s_setprio 1 for the out-of-phase half
                                   // (env FAISS_AMD_FILTER_STAGGER; experiment, default 0)
 };
 // Bound on |t~ - s| for one query against any database row (see flat_filter.hip header).  fp16

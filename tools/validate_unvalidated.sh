@@ -9,7 +9,7 @@ mkdir -p $O
 cd $R
 FAISS_AMD_RUN_UNVALIDATED=1 timeout 600 python -m pytest tests/test_gpu_unvalidated.py -q --tb=short --maxfail=10 -p no:cacheprovider > $O/unvalidated_tests.log 2>&1
 tail -25 $O/unvalidated_tests.log
-DBG_LIST=0,0/1,0/2,0/5,0/6,0,0/1,0/5 timeout 300 python tools/flat_only.py 20 > $O/unvalidated_flat_stagger.log 2>&1
+DBG_LIST=0,0/1,0/2,0/3,0/5,0/9,0/11,0,0/1,0/3 timeout 300 python tools/flat_only.py 20 > $O/unvalidated_flat_stagger.log 2>&1
 grep -v amdgpu.ids $O/unvalidated_flat_stagger.log | tail -18
 for s in 0 1; do
   FAISS_AMD_FLAT_SMALL=$s timeout 200 python tools/ivfpq_only.py 20 2>&1 | grep -v amdgpu.ids | sed "s/^/[FLAT_SMALL=$s] /" >> $O/unvalidated_ivfpq_small.log
