@@ -1451,6 +1451,7 @@ GpuIndexIVF::GpuIndexIVF(std::shared_ptr<GpuResources> res, int dims, int metric
 }
 GpuIndexIVF::~GpuIndexIVF() {
     (void)hipSetDevice(res_->device);
+    if (h_sort_total_) (void)hipHostFree(h_sort_total_);
     delete quantizer;
 }
 
@@ -2036,9 +2037,61 @@ void GpuIndexIVF::search_core_body_(idx_t n, const float* x, idx_t k, float* dis
             }
             fill_fused_(fp);
             if (fp.kind == 2) fp.M = sq_table_rows(metric_type, fp.sq_by_residual != 0, fp.npc);
+            // ---- experiment, not yet run on hardware (FAISS_AMD_IVF_SORT=1): scan the queries of a large batch in the
+            // order of their nearest list.  Workgroups that run at the same time then probe (nearly) the same lists, so a
+            // list read from HBM by one of them is an L2 / MALL hit for the others -- SURVEY H4's list-major batching
+            // without a new scan kernel: the queries, their probe lists and coarse distances are gathered into sorted order
+            // (stable counting sort by the first probe: the add path's kernels), the unchanged kernels run on the
+            // permuted batch, the results are scattered back.  Per-query work and results are exactly the same.
+            bool sorted_batch = false;
+            float *dD_final = dD;
+            idx_t* dI_final = dI;
+            const char* sort_env = getenv("FAISS_AMD_IVF_SORT");
+            if (sort_env && atoi(sort_env) == 1 && !assign && fp.G == 1 && ni >= want) {
+                const int chunk = 2048, nchunks = (int)div_up(ni, chunk);
+                s_lab_.ensure((size_t)ni * 8);
+                s_hist_.ensure((size_t)nchunks * nlist * 4);
+                s_cnt_.ensure((size_t)nlist * 4);
+                s_zero_.ensure((size_t)nlist * 4);
+                s_start_.ensure((size_t)(nlist + 1) * 8);
+                s_dest_.ensure((size_t)ni * 8);
+                s_order_.ensure((size_t)ni * 4);
+                if (!h_sort_total_) HIP_CHECK(hipHostMalloc((void**)&h_sort_total_, 64, hipHostMallocDefault));
+                // first probe of every query (column 0 of the [ni][np] id matrix)
+                HIP_CHECK(hipMemcpy2DAsync(s_lab_.p, 8, c_ids_.p, (size_t)np * 8, 8, (size_t)ni, hipMemcpyDeviceToDevice, R.stream));
+                HIP_CHECK(hipMemsetAsync(s_hist_.p, 0, (size_t)nchunks * nlist * 4, R.stream));
+                HIP_CHECK(hipMemsetAsync(s_zero_.p, 0, (size_t)nlist * 4, R.stream));
+                launch_ivf_histogram(s_lab_.as<int64_t>(), ni, nlist, chunk, s_hist_.as<uint32_t>(), R.stream);
+                launch_ivf_chunk_scan(s_hist_.as<uint32_t>(), nchunks, nlist, s_zero_.as<uint32_t>(), s_cnt_.as<uint32_t>(), R.stream);
+                launch_exclusive_scan(s_cnt_.as<uint32_t>(), nlist, s_start_.as<int64_t>(), R.stream);
+                launch_ivf_rank(s_lab_.as<int64_t>(), ni, nlist, chunk, s_hist_.as<uint32_t>(), s_start_.as<int64_t>(),
+                                s_dest_.as<int64_t>(), R.stream);
+                launch_invert_dest(s_dest_.as<int64_t>(), ni, s_order_.as<uint32_t>(), R.stream);
+                HIP_CHECK(hipMemcpyAsync(h_sort_total_, s_start_.as<int64_t>() + nlist, 8, hipMemcpyDeviceToHost, R.stream));
+                R.sync();
+                // (a query without a nearest list -- NaN -- is in no bin: such a batch stays in its own order)
+                if (*h_sort_total_ == (int64_t)ni) {
+                    sorted_batch = true;
+                    s_q_.ensure((size_t)ni * dpad_ * 4);
+                    s_ids_.ensure((size_t)ni * np * 8);
+                    s_dis_.ensure((size_t)ni * np * 4);
+                    s_outd_.ensure((size_t)ni * k * 4);
+                    s_outi_.ensure((size_t)ni * k * 8);
+                    const uint32_t* ord = s_order_.as<uint32_t>();
+                    launch_gather_rows(q_pad_.as<float>(), dpad_, dpad_, ord, ni, s_q_.as<float>(), R.stream);
+                    // (rows of 64-bit ids move as pairs of 32-bit words: a copy, no arithmetic)
+                    launch_gather_rows((const float*)c_ids_.p, 2 * np, 2 * np, ord, ni, (float*)s_ids_.p, R.stream);
+                    launch_gather_rows(c_dis_.as<float>(), np, np, ord, ni, s_dis_.as<float>(), R.stream);
+                    fp.xq = s_q_.as<float>();
+                    fp.coarse_ids = s_ids_.as<idx_t>();
+                    fp.coarse_dis = s_dis_.as<float>();
+                    fp.out_dis = dD = s_outd_.as<float>();
+                    fp.out_ids = dI = s_outi_.as<idx_t>();
+                }
+            }
             probe_len_.ensure((size_t)ni * np * 4);
             probe_start_.ensure((size_t)ni * np * 8);
-            launch_ivf_probe_info(c_ids_.as<idx_t>(), (int64_t)ni * np, d_list_len_.as<uint32_t>(),
+            launch_ivf_probe_info(fp.coarse_ids, (int64_t)ni * np, d_list_len_.as<uint32_t>(),
                                   d_list_start_.as<int64_t>(), probe_len_.as<uint32_t>(), probe_start_.as<int64_t>(), R.stream);
             fp.probe_len = probe_len_.as<uint32_t>();
             fp.probe_start = probe_start_.as<int64_t>();
@@ -2084,6 +2137,12 @@ void GpuIndexIVF::search_core_body_(idx_t n, const float* x, idx_t k, float* dis
                 sp.out_ids = dI;
                 SpanGuard sg(&R, "select_k_kernel");
                 launch_select_k(sp, R.stream);
+            }
+            if (sorted_batch) {
+                // results of sorted position i belong to query order[i]
+                launch_scatter_results(dD, dI, (int)k, s_order_.as<uint32_t>(), ni, dD_final, dI_final, R.stream);
+                dD = dD_final;
+                dI = dI_final;
             }
             if (!out_dev_d) copy_out(R, distances + (size_t)i0 * k, dD, (size_t)ni * k * 4);
             if (!out_dev_i) copy_out(R, labels + (size_t)i0 * k, dI, (size_t)ni * k * 8);

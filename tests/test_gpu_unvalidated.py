@@ -188,3 +188,37 @@ def test_ivf_reserve_and_reclaim_memory(res):
         idx.updateQuantizer()
         D2, I2 = idx.search(xq, k)
         assert (I2[:, 0] >= 0).all()
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_ivf_sorted_batch_is_bit_identical(res, monkeypatch, kind):
+    """FAISS_AMD_IVF_SORT=1: the queries of a large batch are scanned in the order of their nearest list (gathered into
+    sorted order, searched by the unchanged kernels, results scattered back): every result as without it; a batch with a
+    NaN query (no nearest list) keeps its own order."""
+    from oracle.pyoracle import synthetic_dataset
+    d, nlist, nb, nq, k = 64, 256, 60000, 2500, 20
+    xt, xb, xq = synthetic_dataset(d, 8000, nb, nq, seed=17 + kind)
+    cent, _ = faiss_amd.kmeans(res, xt, nlist, niter=4, seed=3)
+    if kind == 0:
+        idx = faiss_amd.GpuIndexIVFFlat(res, d, nlist, faiss_amd.METRIC_L2)
+        idx.copy_centroids(cent)
+    elif kind == 1:
+        idx = faiss_amd.GpuIndexIVFPQ(res, d, nlist, 8, 8, faiss_amd.METRIC_L2)
+        idx.copy_pq_centroids((np.random.RandomState(7).rand(8, 256, 8).astype("float32") - 0.5) * 0.4)
+        idx.copy_centroids(cent)
+    else:
+        idx = faiss_amd.GpuIndexIVFScalarQuantizer(res, d, nlist, faiss_amd.ScalarQuantizer.QT_8bit, faiss_amd.METRIC_L2, True)
+        idx.train(xt)
+    idx.add(xb)
+    idx.nprobe = 16
+    D0, I0 = idx.search(xq, k)
+    xq_nan = xq.copy()
+    xq_nan[77, 3] = np.nan
+    Dn0, In0 = idx.search(xq_nan, k)
+    monkeypatch.setenv("FAISS_AMD_IVF_SORT", "1")
+    D1, I1 = idx.search(xq, k)
+    assert np.array_equal(I0, I1) and np.array_equal(D0, D1)
+    Dn1, In1 = idx.search(xq_nan, k)
+    assert np.array_equal(In0, In1) and np.array_equal(Dn0, Dn1, equal_nan=True)
+    D2, I2 = idx.search(xq[:700], k)  # below the batch size the sorting is used from: untouched path
+    assert np.array_equal(I2, I0[:700]) and np.array_equal(D2, D0[:700])

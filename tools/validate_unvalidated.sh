@@ -15,3 +15,10 @@ for s in 0 1; do
   FAISS_AMD_FLAT_SMALL=$s timeout 200 python tools/ivfpq_only.py 20 2>&1 | grep -v amdgpu.ids | sed "s/^/[FLAT_SMALL=$s] /" >> $O/unvalidated_ivfpq_small.log
 done
 grep -i "ms/step\|rerank\|flat_small\|QPS" $O/unvalidated_ivfpq_small.log | tail -12
+for s in 0 1; do
+  for t in ivfpq ivfflat ivfsq; do
+    FAISS_AMD_IVF_SORT=$s timeout 200 python tools/${t}_only.py 10 2>&1 | grep -i "ms/step\|fused_kernel\|QPS" | sed "s/^/[IVF_SORT=$s $t] /" >> $O/unvalidated_ivf_sort.log
+  done
+done
+cat $O/unvalidated_ivf_sort.log | tail -24
+
