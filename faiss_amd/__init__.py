@@ -406,6 +406,13 @@ class GpuIndexFlat(Index):
         _check(self._lib.faiss_amd_GpuIndexFlat_resident_bytes(self._h, ctypes.byref(v)))
         return v.value
 
+    def search_and_reconstruct(self, x, k):
+        """D, I, R = index.search_and_reconstruct(x, k) (faiss::Index::search_and_reconstruct, faiss/Index.h:322-335; reference
+        test TestGpuIndexFlat.cpp SearchAndReconstruct): R[i, j] = the stored vector I[i, j], NaN rows for missing results"""
+        D, I = self.search(x, k)
+        R = self.reconstruct_batch(I.reshape(-1)).reshape(I.shape[0], int(k), self.d)
+        return D, I, R
+
     def pairwise_distances(self, x):
         x = _f32(x, self.d)
         out = np.empty((x.shape[0], self.ntotal), dtype=np.float32)

@@ -222,3 +222,16 @@ def test_ivf_sorted_batch_is_bit_identical(res, monkeypatch, kind):
     assert np.array_equal(In0, In1) and np.array_equal(Dn0, Dn1, equal_nan=True)
     D2, I2 = idx.search(xq[:700], k)  # below the batch size the sorting is used from: untouched path
     assert np.array_equal(I2, I0[:700]) and np.array_equal(D2, D0[:700])
+
+
+def test_flat_search_and_reconstruct(res):
+    """faiss::Index::search_and_reconstruct on the flat index (TestGpuIndexFlat.cpp SearchAndReconstruct): composed of
+    search + reconstruct_batch, both validated; the test waits for its first GPU run with the rest of this file."""
+    from oracle.pyoracle import synthetic_dataset
+    d, nb, nq, k = 32, 50, 6, 60  # k > nb: the tail of every row is missing
+    _, xb, xq = synthetic_dataset(d, 0, nb, nq, seed=2)
+    idx = faiss_amd.GpuIndexFlatL2(res, d)
+    idx.add(xb)
+    D, I, R = idx.search_and_reconstruct(xq, k)
+    assert R.shape == (nq, k, d) and (I[:, nb:] == -1).all()
+    assert np.array_equal(R[:, :nb], xb[I[:, :nb]]) and np.isnan(R[:, nb:]).all()
