@@ -51,6 +51,7 @@ def load_library():
     protos = {
         "faiss_amd_get_last_error": (ctypes.c_char_p, []),
         "faiss_amd_get_num_gpus": (i32, [P(i32)]),
+        "faiss_amd_metric_supported": (i32, [i32, i32, P(i32)]),
         "faiss_amd_StandardGpuResources_new": (i32, [P(vp), i32]),
         "faiss_amd_StandardGpuResources_free": (None, [vp]),
         "faiss_amd_StandardGpuResources_sync": (i32, [vp]),
@@ -171,6 +172,13 @@ def _check(rc):
     if rc != 0:
         msg = load_library().faiss_amd_get_last_error()
         raise FaissAmdError("faiss_amd error %d: %s" % (rc, msg.decode("utf-8", "replace") if msg else "?"))
+
+
+def metric_supported(index_kind, metric):
+    """does an index of the kind (0 = GpuIndexFlat / bfKnn, 1 = IVF) accept the metric?  (no device needed)"""
+    out = ctypes.c_int(0)
+    _check(load_library().faiss_amd_metric_supported(int(index_kind), int(metric), ctypes.byref(out)))
+    return bool(out.value)
 
 
 def get_num_gpus():
@@ -609,7 +617,10 @@ class IDSelector:
             self._lib.faiss_amd_IDSelector_free(h)
 
     def is_member(self, i):
-        return bool(self._lib.faiss_amd_IDSelector_is_member(self._h, int(i)))
+        rc = self._lib.faiss_amd_IDSelector_is_member(self._h, int(i))
+        if rc < 0:  # error codes (null / freed handle ...) are negative and must not read as True
+            _check(rc)
+        return rc == 1
 
     def __invert__(self):
         return IDSelectorNot(self)
@@ -923,8 +934,11 @@ def set_interrupt_callback(fn):
         _INTERRUPT_KEEP.clear()
         return
     cb = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p)(lambda _u: 1 if fn() else 0)
-    _INTERRUPT_KEEP[:] = [cb]
+    old = list(_INTERRUPT_KEEP)
+    _INTERRUPT_KEEP.append(cb)  # alive before the C side can call it ...
     _check(lib.faiss_amd_set_interrupt_callback(ctypes.cast(cb, ctypes.c_void_p), None))
+    for o in old:  # ... and the previous thunk is dropped only after the C side has swapped the pointer
+        _INTERRUPT_KEEP.remove(o)
 
 
 class GpuDistanceParams(ctypes.Structure):

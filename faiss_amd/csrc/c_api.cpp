@@ -84,6 +84,13 @@ const char* faiss_amd_get_last_error(void) {
     return g_last_error.c_str();
 }
 
+int faiss_amd_metric_supported(int index_kind, int metric, int* p_output) {
+    FA_TRY
+    FA_THROW_IF_NOT_MSG(p_output && (index_kind == 0 || index_kind == 1), "bad argument");
+    *p_output = metric_supported(index_kind, metric) ? 1 : 0;
+    FA_CATCH
+}
+
 int faiss_amd_get_num_gpus(int* p_output) {
     FA_TRY
     int n = 0;

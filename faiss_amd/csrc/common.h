@@ -36,6 +36,14 @@ static inline bool is_general_metric(int m) {
     return m == METRIC_L1 || m == METRIC_Linf || m == METRIC_Lp || m == METRIC_Canberra || m == METRIC_BrayCurtis ||
            m == METRIC_JensenShannon || m == METRIC_Jaccard;
 }
+// The one predicate every constructor / bfKnn validates its metric with (also exported as faiss_amd_metric_supported, so
+// that the argument-validation expectations of the GPU tests can be checked without a device: tests/test_abi_cpu.py).
+// index_kind: 0 = GpuIndexFlat / bfKnn (faiss/gpu/GpuIndexFlat.cu, GpuDistance.cu), 1 = the IVF indexes
+// (faiss/gpu/GpuIndexIVF.cu:35-37: L2 and inner product only).
+static inline bool metric_supported(int index_kind, int m) {
+    if (m == METRIC_L2 || m == METRIC_INNER_PRODUCT) return true;
+    return index_kind == 0 && is_general_metric(m);
+}
 // the order results are kept in: a similarity is searched like the inner product (descending, padded with -FLT_MAX),
 // a distance like L2
 static inline int order_metric(int m) {

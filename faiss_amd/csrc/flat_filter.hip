@@ -302,18 +302,7 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 // SINGLE: dh == 128, one k-slab per tile: the query operands never leave their registers and
 // the loop holds no compiler-visible global load, whose counted s_waitcnt would otherwise also
 // wait for the (younger, hidden) LDS-DMAs of the prefetch.
-// STAGGER (8-wave geometry only; an experiment that has not run on hardware yet, off unless FAISS_AMD_FILTER_STAGGER=1):
-// the two wavefronts that share a SIMD (w and w + 4) meet at the workgroup barrier of every tile and therefore run IN
-// PHASE: both issue the MFMAs of a 32-row block at the same time (sharing the matrix pipe), then both sit in the VALU
-// epilogue with the pipe idle -- per tile and SIMD 4 x 1024 cycles of MFMA and 2 x 2 epilogues back to back, which is
-// what the 52 % MFMA-busy figure of the profiles says.  With STAGGER the second wave of every SIMD runs half a tile out
-// of phase: it DEFERS the epilogue of a tile's second block to the start of the next tile,
-//     waves 0..3:  M(b0) E(b0) M(b1) E(b1) | barrier
-//     waves 4..7:  E(previous b1) M(b0) E(b0) M(b1) | barrier
-// so that one wave's epilogue always falls under the other's MFMAs.  Same scores, same candidates, another order.  The
-// two schedules are two copies of the tile loop (a wave-uniform branch picks one): with a single copy and a flag the
-// register allocator spills the query operands.
-template <int METRIC, int MODE, bool SINGLE, int QB, bool STAGGER = false>
+template <int METRIC, int MODE, bool SINGLE, int QB>
 __global__ void __launch_bounds__(FqGeom<QB>::THREADS, 2) flat_filter_kernel(FlatFilterParams p) {
     using G = FqGeom<QB>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -650,94 +639,6 @@ __global__ void __launch_bounds__(FqGeom<QB>::THREADS, 2) flat_filter_kernel(Fla
     constexpr int WFLUSH = WBLK / 2;
     volatile unsigned* lgen = (volatile unsigned*)(smem + G::LDS_GEN);
 
-    if constexpr (STAGGER) {
-        static_assert(QB == 4 && SINGLE && G::TPB == 1, "the staggered schedule exists for the 8-wave geometry only");
-        const bool mfma_prio = (p.stagger & 4) != 0; // (a kernel argument: wave-uniform, a scalar branch around s_setprio)
-        // the MFMAs of one 32-row block of the tile in ring slot `slot` (the code of compute() above)
-        auto block_mfma = [&](int slot, int rb) __attribute__((always_inline)) {
-            const char* tile = smem + slot * FQ_TILE_BYTES;
-            const float* bias = (const float*)(smem + G::LDS_BIAS) + slot * FQ_TR;
-            const int sw = j & 15;
-            f32x16 c0;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 b4 = *(const f32x4*)(bias + rb * 32 + 8 * g + 4 * h);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) c0[4 * g + e] = b4[e];
-            }
-            const char* rowp = tile + (rb * 32 + j) * 256;
-            // (stagger & 4: the wave in its MFMA cluster outranks its partner's epilogue at the issue port -- with the two
-            // waves of a SIMD in different roles the priority has something to arbitrate, cdna_hip_programming.md T5)
-            if (mfma_prio) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const int off = ((2 * s + h) ^ sw) << 4;
-                const half8 a0 = *(const half8*)(rowp + off);
-#pragma unroll
-                for (int qb = 0; qb < QB; ++qb)
-                    acc[0][qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bq[qb][s], s == 0 ? c0 : acc[0][qb], 0, 0, 0);
-            }
-            if (mfma_prio) __builtin_amdgcn_s_setprio(0);
-        };
-        // the tile loop; LATE = this wavefront is the out-of-phase one of its SIMD: the epilogue of a tile's second
-        // block is owed (`pend`, scores in acc) until the next tile begins, a sift is due or the tiles are exhausted
-        auto run = [&](auto late_c) __attribute__((always_inline)) {
-            constexpr bool LATE = decltype(late_c)::value;
-            int gslot = 0, u = 0, pend_tl = 0;
-            bool pend = false;
-            while (u < nsteps) {
-                bool sift;
-                do {
-                    if (LATE && pend) {
-                        epilogue(pend_tl, 1);
-                        pend = false;
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    const int gslot2 = gslot >= 1 ? gslot - 1 : 2; // ring position of the tile two ahead
-                    if (u + 2 < nsteps) stage(u + 2, gslot2);
-                    if (!wave_idle) {
-                        block_mfma(gslot, 0);
-                        __builtin_amdgcn_sched_barrier(0);
-                        epilogue(u, 0);
-                        __builtin_amdgcn_sched_barrier(0);
-                        block_mfma(gslot, 1);
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (LATE) {
-                            pend = true;
-                            pend_tl = u;
-                        } else {
-                            epilogue(u, 1);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    u += 1;
-                    if (MODE == MODE_COLLECT && wcnt > WFLUSH) *lgen = (unsigned)u;
-                    if (u + 2 <= nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_STAGE) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __syncthreads();
-                    gslot = gslot == 2 ? 0 : gslot + 1;
-                    sift = MODE == MODE_COLLECT && __builtin_amdgcn_readfirstlane(*lgen) == (unsigned)u;
-                } while (u < nsteps && !sift);
-                if (LATE && pend) {
-                    epilogue(pend_tl, 1);
-                    pend = false;
-                }
-                if (MODE == MODE_COLLECT) flush();
-            }
-        };
-        // which wavefronts share a SIMD is the dispatcher's business: stagger = 1 assumes w and w + 4 (round-robin over
-        // the four SIMDs), stagger = 2 assumes 2 i and 2 i + 1
-        // (+ 3: waves 0..3 -- the OLDER half, whose VALU work right behind a barrier release is the unimpeded one,
-        // MI355X_MICROARCH.md "Two waves per SIMD" items 2 and 6; + 8: one static s_setprio 1 for the out-of-phase half)
-        const int who = p.stagger & 3;
-        const bool late = who == 2 ? (wave & 1) != 0 : who == 3 ? wave < G::WAVES / 2 : wave >= G::WAVES / 2;
-        if (late) {
-            if ((p.stagger & 8) != 0) __builtin_amdgcn_s_setprio(1);
-            run(std::true_type{});
-        } else {
-            run(std::false_type{});
-        }
-    } else {
     int gslot = 0; // (u / TPB) % 3
     int u = 0;
     while (u < nsteps) {
@@ -765,7 +666,6 @@ __global__ void __launch_bounds__(FqGeom<QB>::THREADS, 2) flat_filter_kernel(Fla
         // in order among themselves, so extra younger stores only make the counted waits conservative)
         if (MODE == MODE_COLLECT) flush();
     }
-    } // (!STAGGER)
 
     if (MODE == MODE_MAX) {
 #pragma unroll
@@ -804,13 +704,6 @@ static void launch_filter_mode(const FlatFilterParams& p, hipStream_t stream) {
     dim3 grid((unsigned)(p.nsplit * p.ngroups));
     if (p.geom == 2) {
         using G = FqGeom<4>;
-        if constexpr (MODE != MODE_DUMP) {
-            if (p.stagger) {
-                hipLaunchKernelGGL((flat_filter_kernel<METRIC, MODE, true, 4, true>), grid, dim3(G::THREADS), G::LDS_TOTAL,
-                                   stream, p);
-                return;
-            }
-        }
         hipLaunchKernelGGL((flat_filter_kernel<METRIC, MODE, true, 4>), grid, dim3(G::THREADS), G::LDS_TOTAL, stream, p);
     } else {
         using G = FqGeom<2>;
@@ -825,8 +718,6 @@ void launch_flat_filter(const FlatFilterParams& p_, int mode, hipStream_t stream
     if (p_.nq == 0 || p_.nb == 0) return;
     FlatFilterParams p = p_;
     if (const char* e = getenv("FAISS_AMD_FILTER_DBG")) p.dbg = atoi(e);
-    // experiment, not yet measured on hardware (hence off unless asked for): second wave of every SIMD out of phase
-    if (const char* e = getenv("FAISS_AMD_FILTER_STAGGER")) p.stagger = atoi(e);
     FA_THROW_IF_NOT(p.dh % FQ_KS == 0 && p.ldqh % 8 == 0 && p.ldbh % 8 == 0);
     FA_THROW_IF_NOT(p.tstride >= 1 && p.nsplit >= 1);
     FA_THROW_IF_NOT_MSG(p.geom == 0 || (p.geom == 2 && p.dh == FQ_KS), "the 8-wave geometry needs dh == 128");

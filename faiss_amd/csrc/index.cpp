@@ -226,6 +226,7 @@ template <typename Compute>
 static void paged_host_search(const GpuResources& R, idx_t n, const float* x, int d, idx_t k, float* distances,
                               idx_t* labels, idx_t page, Compute compute) {
     GpuResources::Pager& P = R.pager;
+    std::lock_guard<std::mutex> pager_lock(P.mu);
     if (!P.copy_stream) HIP_CHECK(hipStreamCreateWithFlags(&P.copy_stream, hipStreamNonBlocking));
     if (!P.events) {
         for (int s = 0; s < 2; s++) {
@@ -262,7 +263,8 @@ static void paged_host_search(const GpuResources& R, idx_t n, const float* x, in
     auto rows = [&](idx_t p) { return std::min(page, n - p * page); };
     auto issue_h2d = [&](idx_t p) {
         const int s = (int)(p & 1);
-        // (slot s was last read by the H2D of page p-2, which the kernels of page p-2 waited for: long complete)
+        // slot s was last read by the H2D of page p-2: wait for that copy itself, not for the kernels that consumed it
+        if (p >= 2) HIP_CHECK(hipEventSynchronize(P.q_ready[s]));
         memcpy(P.pin_q[s], x + (size_t)p * page * d, (size_t)rows(p) * d * 4);
         HIP_CHECK(hipMemcpyAsync(dq[s].p, P.pin_q[s], (size_t)rows(p) * d * 4, hipMemcpyHostToDevice, P.copy_stream));
         HIP_CHECK(hipEventRecord(P.q_ready[s], P.copy_stream));
@@ -310,8 +312,7 @@ GpuIndexFlat::GpuIndexFlat(std::shared_ptr<GpuResources> res, int dims, int metr
     FA_THROW_IF_NOT_MSG(dims > 0, "dimension must be positive");
     // L2 / inner product on the matrix pipes; the extra metrics of the reference's flat index (faiss/gpu/impl/
     // GeneralDistance.cuh: L1, Linf, Lp, Canberra, BrayCurtis, JensenShannon, Jaccard) on a plain brute-force pass
-    FA_THROW_IF_NOT_MSG(metric == METRIC_L2 || metric == METRIC_INNER_PRODUCT || is_general_metric(metric),
-                        "unsupported metric type");
+    FA_THROW_IF_NOT_MSG(metric_supported(0, metric), "unsupported metric type");
     dpad_ = (int)round_up(dims, 8);
     dh_ = (int)round_up(dims, kFilterSlab);
     is_trained = true;
@@ -503,8 +504,7 @@ static const float* as_f32_rows(const GpuResources& R, const void* src, int type
 void bfKnn(std::shared_ptr<GpuResources> res, const DistanceParams& a) {
     FA_THROW_IF_NOT_MSG(res, "null resources");
     FA_THROW_IF_NOT_MSG(a.device == -1 || a.device == res->device, "args.device differs from the device of the resources");
-    FA_THROW_IF_NOT_MSG(a.metric == METRIC_L2 || a.metric == METRIC_INNER_PRODUCT || is_general_metric(a.metric),
-                        "bfKnn: unsupported metric");
+    FA_THROW_IF_NOT_MSG(metric_supported(0, a.metric), "bfKnn: unsupported metric");
     FA_THROW_IF_NOT_MSG(a.k != -1 || !is_general_metric(a.metric), "bfKnn: k = -1 (all pairwise distances) is L2 / inner product only");
     FA_THROW_IF_NOT_MSG(a.dims >= 1 && a.numVectors >= 0 && a.numQueries >= 0, "bad sizes");
     FA_THROW_IF_NOT_MSG(a.k == -1 || (a.k >= 1 && a.k <= kMaxSelectionK), "k must be in [1, 2048], or -1 for all pairwise distances");
@@ -833,25 +833,6 @@ void GpuIndexFlat::search_tile_(int n, const float* xq_pad, int k, float* dD, id
     fp.flags = flags_.as<uint32_t>();
     fp.dump = nullptr;
     fp.exact_inputs = use_float16_ ? 1 : 0;
-    // experiment, not yet run on hardware (FAISS_AMD_FLAT_SMALL=1): small databases -- the coarse quantizer of the IVF
-    // searches -- in ONE launch instead of the four below (flat_small.hip)
-    const char* small_env = getenv("FAISS_AMD_FLAT_SMALL");
-    if (small_env && atoi(small_env) == 1 && !use_float16_ && !sel_active_ && flat_small_supported(nb, dh_, dpad_, k)) {
-        FlatSmallParams sp{};
-        sp.metric = metric_type;
-        sp.nq = n, sp.nb = nb, sp.d = d, sp.dh = dh_, sp.dpad = dpad_, sp.k = k;
-        sp.xqh = fp.xqh, sp.xq = xq_pad, sp.xqn = fp.xqn;
-        sp.xbh = fp.xbh, sp.xbhn = fp.xbhn, sp.xb = xb_.as<float>(), sp.xbn = xbn_.as<float>();
-        sp.ldqh = dh_, sp.ldq = dpad_, sp.ldbh = dh_, sp.ldb = dpad_;
-        sp.yn_max = yn_max_;
-        sp.flags = fp.flags;
-        sp.id_base = 0;
-        sp.out_dis = dD, sp.out_ids = dI;
-        sp.ovf_list = ovf_list_.as<uint32_t>();
-        sp.ovf_cnt = scal_.as<unsigned>() + 2;
-        SpanGuard sg(&R, "flat_small_kernel");
-        launch_flat_small(sp, R.stream);
-    } else {
     {
         // chunk maxima over a 1/tstride sample of the tiles -> per-query threshold
         SpanGuard sg(&R, "flat_filter_kernel_max");
@@ -899,7 +880,6 @@ void GpuIndexFlat::search_tile_(int n, const float* xq_pad, int k, float* dD, id
         SpanGuard sg(&R, "flat_rerank_kernel");
         launch_flat_rerank(rp, R.stream);
     }
-    } // (general filter path)
     // ---- queries whose segments overflowed (or left the fp16 range) go through the exact fp32 scan
     if (!h_novf_) HIP_CHECK(hipHostMalloc((void**)&h_novf_, 64, hipHostMallocDefault));
     HIP_CHECK(hipMemcpyAsync(h_novf_, scal_.as<unsigned>() + 2, 4, hipMemcpyDeviceToHost, R.stream));
@@ -1436,8 +1416,7 @@ void Clustering::train_device_(idx_t nx, const float* x_in, int64_t ldx, GpuInde
 GpuIndexIVF::GpuIndexIVF(std::shared_ptr<GpuResources> res, int dims, int metric, int nlist_)
         : Index(dims, metric), nlist(nlist_), res_(std::move(res)) {
     FA_THROW_IF_NOT_MSG(nlist > 0, "nlist must be positive");
-    FA_THROW_IF_NOT_MSG(metric == METRIC_L2 || metric == METRIC_INNER_PRODUCT,
-                        "unsupported metric type (reference: faiss/gpu/GpuIndexIVF.cu:35-37)");
+    FA_THROW_IF_NOT_MSG(metric_supported(1, metric), "unsupported metric type (reference: faiss/gpu/GpuIndexIVF.cu:35-37)");
     dpad_ = (int)round_up(dims, 8);
     quantizer = new GpuIndexFlat(res_, dims, metric);
     // the coarse quantizer holds only nlist rows: let it take the fp16 filter + exact re-rank path from
@@ -1451,7 +1430,6 @@ GpuIndexIVF::GpuIndexIVF(std::shared_ptr<GpuResources> res, int dims, int metric
 }
 GpuIndexIVF::~GpuIndexIVF() {
     (void)hipSetDevice(res_->device);
-    if (h_sort_total_) (void)hipHostFree(h_sort_total_);
     delete quantizer;
 }
 
@@ -2037,58 +2015,6 @@ void GpuIndexIVF::search_core_body_(idx_t n, const float* x, idx_t k, float* dis
             }
             fill_fused_(fp);
             if (fp.kind == 2) fp.M = sq_table_rows(metric_type, fp.sq_by_residual != 0, fp.npc);
-            // ---- experiment, not yet run on hardware (FAISS_AMD_IVF_SORT=1): scan the queries of a large batch in the
-            // order of their nearest list.  Workgroups that run at the same time then probe (nearly) the same lists, so a
-            // list read from HBM by one of them is an L2 / MALL hit for the others -- SURVEY H4's list-major batching
-            // without a new scan kernel: the queries, their probe lists and coarse distances are gathered into sorted order
-            // (stable counting sort by the first probe: the add path's kernels), the unchanged kernels run on the
-            // permuted batch, the results are scattered back.  Per-query work and results are exactly the same.
-            bool sorted_batch = false;
-            float *dD_final = dD;
-            idx_t* dI_final = dI;
-            const char* sort_env = getenv("FAISS_AMD_IVF_SORT");
-            if (sort_env && atoi(sort_env) == 1 && !assign && fp.G == 1 && ni >= want) {
-                const int chunk = 2048, nchunks = (int)div_up(ni, chunk);
-                s_lab_.ensure((size_t)ni * 8);
-                s_hist_.ensure((size_t)nchunks * nlist * 4);
-                s_cnt_.ensure((size_t)nlist * 4);
-                s_zero_.ensure((size_t)nlist * 4);
-                s_start_.ensure((size_t)(nlist + 1) * 8);
-                s_dest_.ensure((size_t)ni * 8);
-                s_order_.ensure((size_t)ni * 4);
-                if (!h_sort_total_) HIP_CHECK(hipHostMalloc((void**)&h_sort_total_, 64, hipHostMallocDefault));
-                // first probe of every query (column 0 of the [ni][np] id matrix)
-                HIP_CHECK(hipMemcpy2DAsync(s_lab_.p, 8, c_ids_.p, (size_t)np * 8, 8, (size_t)ni, hipMemcpyDeviceToDevice, R.stream));
-                HIP_CHECK(hipMemsetAsync(s_hist_.p, 0, (size_t)nchunks * nlist * 4, R.stream));
-                HIP_CHECK(hipMemsetAsync(s_zero_.p, 0, (size_t)nlist * 4, R.stream));
-                launch_ivf_histogram(s_lab_.as<int64_t>(), ni, nlist, chunk, s_hist_.as<uint32_t>(), R.stream);
-                launch_ivf_chunk_scan(s_hist_.as<uint32_t>(), nchunks, nlist, s_zero_.as<uint32_t>(), s_cnt_.as<uint32_t>(), R.stream);
-                launch_exclusive_scan(s_cnt_.as<uint32_t>(), nlist, s_start_.as<int64_t>(), R.stream);
-                launch_ivf_rank(s_lab_.as<int64_t>(), ni, nlist, chunk, s_hist_.as<uint32_t>(), s_start_.as<int64_t>(),
-                                s_dest_.as<int64_t>(), R.stream);
-                launch_invert_dest(s_dest_.as<int64_t>(), ni, s_order_.as<uint32_t>(), R.stream);
-                HIP_CHECK(hipMemcpyAsync(h_sort_total_, s_start_.as<int64_t>() + nlist, 8, hipMemcpyDeviceToHost, R.stream));
-                R.sync();
-                // (a query without a nearest list -- NaN -- is in no bin: such a batch stays in its own order)
-                if (*h_sort_total_ == (int64_t)ni) {
-                    sorted_batch = true;
-                    s_q_.ensure((size_t)ni * dpad_ * 4);
-                    s_ids_.ensure((size_t)ni * np * 8);
-                    s_dis_.ensure((size_t)ni * np * 4);
-                    s_outd_.ensure((size_t)ni * k * 4);
-                    s_outi_.ensure((size_t)ni * k * 8);
-                    const uint32_t* ord = s_order_.as<uint32_t>();
-                    launch_gather_rows(q_pad_.as<float>(), dpad_, dpad_, ord, ni, s_q_.as<float>(), R.stream);
-                    // (rows of 64-bit ids move as pairs of 32-bit words: a copy, no arithmetic)
-                    launch_gather_rows((const float*)c_ids_.p, 2 * np, 2 * np, ord, ni, (float*)s_ids_.p, R.stream);
-                    launch_gather_rows(c_dis_.as<float>(), np, np, ord, ni, s_dis_.as<float>(), R.stream);
-                    fp.xq = s_q_.as<float>();
-                    fp.coarse_ids = s_ids_.as<idx_t>();
-                    fp.coarse_dis = s_dis_.as<float>();
-                    fp.out_dis = dD = s_outd_.as<float>();
-                    fp.out_ids = dI = s_outi_.as<idx_t>();
-                }
-            }
             probe_len_.ensure((size_t)ni * np * 4);
             probe_start_.ensure((size_t)ni * np * 8);
             launch_ivf_probe_info(fp.coarse_ids, (int64_t)ni * np, d_list_len_.as<uint32_t>(),
@@ -2137,12 +2063,6 @@ void GpuIndexIVF::search_core_body_(idx_t n, const float* x, idx_t k, float* dis
                 sp.out_ids = dI;
                 SpanGuard sg(&R, "select_k_kernel");
                 launch_select_k(sp, R.stream);
-            }
-            if (sorted_batch) {
-                // results of sorted position i belong to query order[i]
-                launch_scatter_results(dD, dI, (int)k, s_order_.as<uint32_t>(), ni, dD_final, dI_final, R.stream);
-                dD = dD_final;
-                dI = dI_final;
             }
             if (!out_dev_d) copy_out(R, distances + (size_t)i0 * k, dD, (size_t)ni * k * 4);
             if (!out_dev_i) copy_out(R, labels + (size_t)i0 * k, dI, (size_t)ni * k * 8);
@@ -2378,13 +2298,17 @@ void GpuIndexIVFFlat::reconstruct_n(idx_t i0, idx_t ni, float* recons) const {
     FA_THROW_IF_NOT_MSG(i0 >= 0 && ni >= 0, "negative range");
     if (ni == 0) return;
     FA_THROW_IF_NOT_MSG(recons, "null output");
+    // range check of the reference (faiss/gpu/GpuIndexIVFFlat.cu:378-387)
+    FA_THROW_IF_NOT_MSG(i0 < ntotal && i0 + ni - 1 < ntotal, "reconstruct_n: id range out of bounds (ntotal)");
     std::lock_guard<std::mutex> g(mu_);
     res_->set_device();
     const GpuResources& R = *res_;
-    // rows of the ids in [i0, i0 + ni) wherever their lists hold them; ids that are not stored leave zeros
+    // rows of the ids in [i0, i0 + ni) wherever their lists hold them; an id of the range that no list holds (a NaN
+    // vector that add() counted but skipped, a user id never added) comes back as a NaN row -- like the -1 keys of
+    // GpuIndexFlat::reconstruct_batch -- so that a caller can tell it from a stored zero vector
     DevBuf out;
     out.ensure((size_t)ni * d * 4);
-    HIP_CHECK(hipMemsetAsync(out.p, 0, (size_t)ni * d * 4, R.stream));
+    HIP_CHECK(hipMemsetAsync(out.p, 0xff, (size_t)ni * d * 4, R.stream)); // 0xffffffff = a quiet NaN
     launch_ivfflat_rows_by_id(arena_.as<float>(), dpad_, arena_ids_.as<int64_t>(), d_list_start_.as<int64_t>(),
                               d_list_len_.as<uint32_t>(), nlist, d, i0, ni, out.as<float>(), R.stream);
     copy_out(R, recons, out.p, (size_t)ni * d * 4);

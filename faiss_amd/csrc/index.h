@@ -72,6 +72,7 @@ class GpuResources {
         size_t pin_q_cap = 0, pin_r_cap = 0;
         hipEvent_t q_ready[2], r_ready[2], r_copied[2];
         bool events = false;
+        std::mutex mu; // one paged search at a time per resources object (indexes sharing it may be searched from several threads)
     };
     mutable Pager pager;
     mutable long paged_searches = 0; // statistics: calls that took the paged path
@@ -409,9 +410,6 @@ class GpuIndexIVF : public Index {
     virtual size_t ref_row_bytes_() const { return code_bytes_; }
     virtual int sq_chunk_bytes_() const { return 0; } // scalar quantizer: bytes per 16-component chunk
     mutable DevBuf part_keys_, part_cnt_, probe_len_, probe_start_;
-    // experiment (FAISS_AMD_IVF_SORT=1): the queries of a batch scanned in the order of their nearest list
-    mutable DevBuf s_lab_, s_hist_, s_cnt_, s_zero_, s_start_, s_dest_, s_order_, s_q_, s_ids_, s_dis_, s_outd_, s_outi_;
-    mutable int64_t* h_sort_total_ = nullptr; // pinned
     void upload_list_tables_();
     void ensure_arena_(int64_t rows);
     // make room for new_len[l] entries in every list (relocating the lists that outgrow their slack); est[l]

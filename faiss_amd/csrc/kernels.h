@@ -114,10 +114,6 @@ struct FlatFilterParams {
     float* dump;                  // optional [nq][nb] approximate scores (tests)
     int exact_inputs;             // fp16 storage: q and y are fp16 values, the error band shrinks to the accumulation terms
     int dbg;                      // timing experiments only (env FAISS_AMD_FILTER_DBG): 1 no parking, 2 no sift, 4 no hits
-    int stagger;                  // 8-wave geometry: second wave of every SIMD half a tile out of phase (flat_filter.hip);
-                                  // 1: waves 4..7, 2: odd waves, 3: waves 0..3; + 4: s_setprio 1 around the MFMA
-                                  // clusters; + 8: static s_setprio 1 for the out-of-phase half
-                                  // (env FAISS_AMD_FILTER_STAGGER; experiment, default 0)
 };
 // Bound on |t~ - s| for one query against any database row (see flat_filter.hip header).  fp16
 // round-to-nearest: |dx| <= 2^-11 |x| in the normal range and <= 2^-25 below it, so
@@ -168,31 +164,6 @@ struct FlatRerankParams {
     uint32_t* ovf_cnt;  // [1] (zeroed by the caller)
 };
 void launch_flat_rerank(const FlatRerankParams& p, hipStream_t stream);
-
-// One-launch exact k-nearest rows of a small database (2048 .. 8192 rows, dh == 128, k <= 32): fp16 MFMA scores twice
-// (bound, candidates), exact fp32 distances of the candidates, rank -- flat_small.hip.  Experiment, not yet run on
-// hardware: used only with FAISS_AMD_FLAT_SMALL=1 (the coarse quantizer of the IVF searches).
-struct FlatSmallParams {
-    int metric;
-    int nq, nb, d, dh, dpad, k;
-    const _Float16* xqh; // [nq][ldqh] fp16 queries
-    const float* xq;     // [nq][ldq] fp32 padded queries
-    const float* xqn;    // [nq] |q|^2
-    const _Float16* xbh; // [nb + 64][ldbh] fp16 rows (one tile of zero rows behind the last)
-    const float* xbhn;   // [nb + 64] start values: -|y|^2/2 (L2) / 0 (IP), -inf behind the last row
-    const float* xb;     // [nb][ldb] fp32 padded rows
-    const float* xbn;    // [nb] |y|^2
-    int64_t ldqh, ldq, ldbh, ldb;
-    float yn_max;
-    const uint32_t* flags; // [nq] query left the fp16 range (prep_queries_kernel)
-    int64_t id_base;
-    float* out_dis;      // [nq][k]
-    int64_t* out_ids;    // [nq][k]
-    uint32_t* ovf_list;  // [nq] queries handed to the exact scan
-    uint32_t* ovf_cnt;   // [1] (zeroed by prep_queries_kernel)
-};
-bool flat_small_supported(int nb, int dh, int dpad, int k);
-void launch_flat_small(const FlatSmallParams& p, hipStream_t stream);
 
 // dst[i][0..dh) = fp16(src[i][0..d)), zero padded; *absmax_bits = max |x| (float bits, 0x7f800000 when
 // a value is NaN/inf/outside the fp16 range); flags[i] = that condition per row (nullable)

@@ -50,6 +50,10 @@ typedef struct FaissAmdGpuResources_H FaissAmdGpuResources;   /* FaissStandardGp
 const char* faiss_amd_get_last_error(void);
 /* c_api/gpu/DeviceUtils_c.h:22 faiss_get_num_gpus */
 int faiss_amd_get_num_gpus(int* p_output);
+/* *p_output = 1 when an index of the kind (0 = GpuIndexFlat / bfKnn, 1 = the IVF indexes) accepts the metric, else 0 --
+ * the predicate the constructors apply (faiss/gpu/GpuIndexFlat.cu, faiss/gpu/GpuIndexIVF.cu:35-37 "unsupported metric
+ * type"; values of faiss/MetricType.h:31-52).  Needs no device. */
+int faiss_amd_metric_supported(int index_kind, int metric, int* p_output);
 
 /* ---- resources: c_api/gpu/StandardGpuResources_c.h:24-33 (one stream + scratch per device) */
 int faiss_amd_StandardGpuResources_new(FaissAmdGpuResources** p_res, int device);

@@ -99,3 +99,56 @@ def test_bfknn_without_resources_is_an_error():
     p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
     assert lib.faiss_amd_bfKnn(None, 1, p(x), 4, p(x), 4, 8, 2, p(D), p(I)) == -2
     assert b"null resources" in lib.faiss_amd_get_last_error()
+
+
+def test_metric_predicate_matches_metrictype_h():
+    """faiss_amd_metric_supported (the predicate the constructors apply) over every value of faiss/MetricType.h:31-52."""
+    flat_ok = {0, 1, 2, 3, 4, 20, 21, 22, 23}
+    for m in list(range(-2, 30)) + [99, 1 << 20]:
+        assert faiss_amd.metric_supported(0, m) == (m in flat_ok), m
+        assert faiss_amd.metric_supported(1, m) == (m in (0, 1)), m
+
+
+def test_gpu_tests_expect_refusal_only_of_metrics_the_library_refuses():
+    """Round 2's driver run stopped on `pytest.raises(...): GpuIndexFlat(res, 8, 23)` after 23 (Jaccard) had become a
+    valid metric.  Walk every `with pytest.raises` block of the GPU tests: a constructor call in it whose metric argument
+    is a literal (or a faiss_amd.METRIC_* name) and whose other arguments are plainly valid must name a metric the
+    library's own predicate refuses -- checked here without a device."""
+    import ast
+    import glob
+    metric_pos = {"GpuIndexFlat": (2, 0), "GpuIndexIVFFlat": (3, 1), "GpuIndexIVFPQ": (5, 1),
+                  "GpuIndexIVFScalarQuantizer": (4, 1)}
+
+    def value(node):
+        if isinstance(node, ast.Constant) and isinstance(node.value, int):
+            return node.value
+        if isinstance(node, ast.Attribute) and node.attr.startswith("METRIC_"):
+            return getattr(faiss_amd, node.attr)
+        return None
+
+    checked = 0
+    for path in sorted(glob.glob(os.path.join(ROOT, "tests", "test_gpu_*.py"))):
+        tree = ast.parse(open(path).read())
+        for w in ast.walk(tree):
+            if not isinstance(w, ast.With):
+                continue
+            ctx = w.items[0].context_expr
+            if not (isinstance(ctx, ast.Call) and getattr(ctx.func, "attr", "") == "raises"):
+                continue
+            match = next((kw.value.value for kw in ctx.keywords if kw.arg == "match" and isinstance(kw.value, ast.Constant)),
+                         None)
+            for c in ast.walk(w):
+                if isinstance(c, ast.Call) and getattr(c.func, "attr", "") in metric_pos:
+                    pos, kind = metric_pos[c.func.attr]
+                    if len(c.args) != pos + 1:
+                        continue
+                    m = value(c.args[pos])
+                    if m is None:
+                        continue
+                    # the block expects a refusal; when it is about the metric (the only non-trivial argument, or the
+                    # message says so) the library must indeed refuse that value
+                    about_metric = match is None and c.func.attr == "GpuIndexFlat" or (match and "metric" in match)
+                    if about_metric:
+                        assert not faiss_amd.metric_supported(kind, m), (os.path.basename(path), c.lineno, m)
+                        checked += 1
+    assert checked >= 2

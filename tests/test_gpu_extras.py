@@ -1,13 +1,11 @@
-"""GPU tests of everything written after round 2's GPU budget was spent -- code that compiles for gfx950 but has NOT run on
-hardware yet, so these tests only run when FAISS_AMD_RUN_UNVALIDATED=1 is set (tools/validate_unvalidated.sh, first GPU
-call of the next round):
+"""GPU tests of the interface corners added at the end of round 2 and first run on hardware in round 3 (all green on
+the first run, gpurun_out/r3a_validate.log):
   * the "extra" metrics of GpuIndexFlat / bfKnn (L1, Linf, Lp, Canberra, BrayCurtis, JensenShannon, Jaccard:
     faiss/gpu/impl/GeneralDistance.cuh over the functors of faiss/gpu/impl/DistanceUtils.cuh:47-281; reference tests
     faiss/gpu/test/TestGpuIndexFlat.cpp L1_Float32 / Lp_Float32, TestGpuDistance.cu L1 .. Jaccard); the oracle they are
     compared with is pinned on the real reference by tests/test_golden_extra_cpu.py;
-  * the staggered schedule of the filter kernel (FAISS_AMD_FILTER_STAGGER) and the one-launch small-database kernel
-    (FAISS_AMD_FLAT_SMALL): both must be bit-identical to the default path;
-  * reserveMemory / reclaimMemory / updateQuantizer and the IVFPQ getters of the reference's GPU index classes."""
+  * reserveMemory / reclaimMemory / updateQuantizer and the IVFPQ getters of the reference's GPU index classes;
+  * Index::search_and_reconstruct."""
 import os
 
 import numpy as np
@@ -18,9 +16,7 @@ from compare import check_knn
 from oracle.pyoracle import Oracle, Ref
 from test_golden_extra_cpu import EXTRA_METRICS, GOLD, positive_dataset
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("FAISS_AMD_RUN_UNVALIDATED") != "1",
-                                 reason="extra-metric kernel not yet run on hardware (set FAISS_AMD_RUN_UNVALIDATED=1)")]
+pytestmark = pytest.mark.gpu
 EXACT = {2, 3, 20, 21, 23}  # no transcendental function: bit-exact against the oracle
 
 
@@ -88,68 +84,6 @@ def test_extra_metric_through_the_bridge(tag, metric, arg):
         Ref.amd_resources_free(bres)
 
 
-@pytest.mark.parametrize("stagger", ["1", "2", "3", "5", "9", "11"])
-@pytest.mark.parametrize("metric", [faiss_amd.METRIC_L2, faiss_amd.METRIC_INNER_PRODUCT])
-def test_flat_filter_staggered_schedule_is_bit_identical(res, monkeypatch, stagger, metric):
-    """FAISS_AMD_FILTER_STAGGER (flat_filter.hip: the second wave of every SIMD half a tile out of phase) computes the
-    same scores and collects the same candidates in another order: results bit-identical to the default schedule, on
-    the 8-wave geometry (d = 128, batches that fill 1024-query workgroups), incl. a ragged last tile and last group."""
-    from oracle.pyoracle import synthetic_dataset
-    d, nb, nq, k = 128, 50021, 3000, 100
-    _, xb, xq = synthetic_dataset(d, 0, nb, nq, seed=3)
-    idx = faiss_amd.GpuIndexFlat(res, d, metric)
-    idx.add(xb)
-    D0, I0 = idx.search(xq, k)
-    assert idx.filter_stats()[0]
-    monkeypatch.setenv("FAISS_AMD_FILTER_STAGGER", stagger)
-    D1, I1 = idx.search(xq, k)
-    assert idx.filter_stats() == (True, 0)
-    assert np.array_equal(I0, I1) and np.array_equal(D0, D1)
-    Do, Io = Oracle.flat_search(metric, xb, xq[:24], k)
-    check_knn(D1[:24], I1[:24], Do, Io, exact=True, name="staggered schedule vs oracle")
-
-
-@pytest.mark.parametrize("metric", [faiss_amd.METRIC_L2, faiss_amd.METRIC_INNER_PRODUCT])
-@pytest.mark.parametrize("d,nb,nq,k", [(128, 4096, 1100, 32), (128, 8192, 37, 10), (128, 2048 + 17, 300, 1), (100, 5000, 64, 32)])
-def test_flat_small_one_launch_kernel_is_bit_identical(res, monkeypatch, metric, d, nb, nq, k):
-    """FAISS_AMD_FLAT_SMALL=1 (flat_small.hip: bound, candidates, exact distances and ranking of a small database in one
-    launch -- the coarse quantizer of the IVF searches): bit-identical to the default filter path and to the oracle."""
-    from oracle.pyoracle import synthetic_dataset
-    _, xb, xq = synthetic_dataset(d, 0, nb, nq, seed=nb + k)
-    idx = faiss_amd.GpuIndexFlat(res, d, metric)
-    idx.set_use_filter_kernel(True, 2048)  # (what GpuIndexIVF sets on its coarse quantizer)
-    idx.add(xb)
-    D0, I0 = idx.search(xq, k)
-    monkeypatch.setenv("FAISS_AMD_FLAT_SMALL", "1")
-    res.profile_enable(True)
-    res.profile_reset()
-    D1, I1 = idx.search(xq, k)
-    assert res.profile_get("flat_small_kernel")[1] == 1, "the one-launch kernel did not serve the search"
-    res.profile_enable(False)
-    assert idx.filter_stats()[1] == 0
-    assert np.array_equal(I0, I1) and np.array_equal(D0, D1)
-    Do, Io = Oracle.flat_search(metric, xb, xq[:40], k)
-    check_knn(D1[:40], I1[:40], Do, Io, exact=True, name="one-launch small-database kernel vs oracle")
-
-
-def test_ivf_search_with_one_launch_coarse_quantizer(res, monkeypatch):
-    from oracle.pyoracle import synthetic_dataset
-    d, nlist, nb, nq, k = 128, 4096, 100000, 1500, 20
-    xt, xb, xq = synthetic_dataset(d, 20000, nb, nq, seed=4)
-    cent, _ = faiss_amd.kmeans(res, xt, nlist, niter=2, seed=3)
-    idx = faiss_amd.GpuIndexIVFFlat(res, d, nlist, faiss_amd.METRIC_L2)
-    idx.copy_centroids(cent)
-    idx.add(xb)
-    idx.nprobe = 32
-    D0, I0 = idx.search(xq, k)
-    Dq0, Iq0 = idx.quantizer_search(xq, 32)
-    monkeypatch.setenv("FAISS_AMD_FLAT_SMALL", "1")
-    D1, I1 = idx.search(xq, k)
-    Dq1, Iq1 = idx.quantizer_search(xq, 32)
-    assert np.array_equal(Iq0, Iq1) and np.array_equal(Dq0, Dq1)
-    assert np.array_equal(I0, I1) and np.array_equal(D0, D1)
-
-
 def test_ivf_reserve_and_reclaim_memory(res):
     """GpuIndexIVFFlat::reserveMemory / reclaimMemory (faiss/gpu/GpuIndexIVFFlat.h:64-76), GpuIndexIVFPQ getters: the arena
     does not grow during the add a reservation covers, reclaiming shrinks it and changes no result."""
@@ -190,43 +124,9 @@ def test_ivf_reserve_and_reclaim_memory(res):
         assert (I2[:, 0] >= 0).all()
 
 
-@pytest.mark.parametrize("kind", [0, 1, 2])
-def test_ivf_sorted_batch_is_bit_identical(res, monkeypatch, kind):
-    """FAISS_AMD_IVF_SORT=1: the queries of a large batch are scanned in the order of their nearest list (gathered into
-    sorted order, searched by the unchanged kernels, results scattered back): every result as without it; a batch with a
-    NaN query (no nearest list) keeps its own order."""
-    from oracle.pyoracle import synthetic_dataset
-    d, nlist, nb, nq, k = 64, 256, 60000, 2500, 20
-    xt, xb, xq = synthetic_dataset(d, 8000, nb, nq, seed=17 + kind)
-    cent, _ = faiss_amd.kmeans(res, xt, nlist, niter=4, seed=3)
-    if kind == 0:
-        idx = faiss_amd.GpuIndexIVFFlat(res, d, nlist, faiss_amd.METRIC_L2)
-        idx.copy_centroids(cent)
-    elif kind == 1:
-        idx = faiss_amd.GpuIndexIVFPQ(res, d, nlist, 8, 8, faiss_amd.METRIC_L2)
-        idx.copy_pq_centroids((np.random.RandomState(7).rand(8, 256, 8).astype("float32") - 0.5) * 0.4)
-        idx.copy_centroids(cent)
-    else:
-        idx = faiss_amd.GpuIndexIVFScalarQuantizer(res, d, nlist, faiss_amd.ScalarQuantizer.QT_8bit, faiss_amd.METRIC_L2, True)
-        idx.train(xt)
-    idx.add(xb)
-    idx.nprobe = 16
-    D0, I0 = idx.search(xq, k)
-    xq_nan = xq.copy()
-    xq_nan[77, 3] = np.nan
-    Dn0, In0 = idx.search(xq_nan, k)
-    monkeypatch.setenv("FAISS_AMD_IVF_SORT", "1")
-    D1, I1 = idx.search(xq, k)
-    assert np.array_equal(I0, I1) and np.array_equal(D0, D1)
-    Dn1, In1 = idx.search(xq_nan, k)
-    assert np.array_equal(In0, In1) and np.array_equal(Dn0, Dn1, equal_nan=True)
-    D2, I2 = idx.search(xq[:700], k)  # below the batch size the sorting is used from: untouched path
-    assert np.array_equal(I2, I0[:700]) and np.array_equal(D2, D0[:700])
-
-
 def test_flat_search_and_reconstruct(res):
     """faiss::Index::search_and_reconstruct on the flat index (TestGpuIndexFlat.cpp SearchAndReconstruct): composed of
-    search + reconstruct_batch, both validated; the test waits for its first GPU run with the rest of this file."""
+    search + reconstruct_batch."""
     from oracle.pyoracle import synthetic_dataset
     d, nb, nq, k = 32, 50, 6, 60  # k > nb: the tail of every row is missing
     _, xb, xq = synthetic_dataset(d, 0, nb, nq, seed=2)

@@ -107,7 +107,7 @@ def test_flat_empty_query_batch_and_errors(res):
     with pytest.raises(ValueError):
         idx.add(np.zeros((1, 9), "float32"))
     with pytest.raises(faiss_amd.FaissAmdError):
-        faiss_amd.GpuIndexFlat(res, 8, 23)  # unsupported metric
+        faiss_amd.GpuIndexFlat(res, 8, 99)  # not a value of faiss/MetricType.h:31-52
 
 
 def test_flat_nan_query_returns_no_result(res):

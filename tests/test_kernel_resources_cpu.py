@@ -14,7 +14,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "faiss_amd", "csrc")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-FILES = ["flat_filter.hip", "flat_kernels.hip", "flat_small.hip", "ivf_fused.hip", "ivf_kernels.hip", "select_kernels.hip",
+FILES = ["flat_filter.hip", "flat_kernels.hip", "ivf_fused.hip", "ivf_kernels.hip", "select_kernels.hip",
          "selector_kernels.hip"]
 
 
@@ -90,7 +90,7 @@ def test_ivf_scan_kernels_keep_their_occupancy(usage):
 def test_exact_scan_and_helpers(usage):
     for name, u in _pick(usage, "flat_scan_kernel").items():
         assert u["scratch"] == 0 and u["occupancy"] >= 2, (name, u)
-    for sub in ("flat_rerank_kernel", "flat_tighten_kernel", "select_k_kernel", "selector_mask_kernel", "flat_small_kernel",
+    for sub in ("flat_rerank_kernel", "flat_tighten_kernel", "select_k_kernel", "selector_mask_kernel",
                 "flat_general_kernel"):
         for name, u in _pick(usage, sub).items():
             assert u["scratch"] == 0, (name, u)

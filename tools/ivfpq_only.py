@@ -37,7 +37,7 @@ for fb in os.environ.get("FB_LIST", "512").split(","):
     print("ivfpq search (%s): %.3f ms/step" % ("ip" if metric == 0 else "l2", (time.time() - t0) / steps * 1e3))
     res.profile_enable(True); res.profile_reset()
     idx.search_ptr(10000, xq_dev.data_ptr(), 100, Dd.data_ptr(), Id.data_ptr())
-    for kn in ("ivfpq_fused_kernel", "ivf_finish_kernel", "flat_scan_kernel", "select_k_kernel", "flat_filter_kernel", "flat_filter_kernel_max", "flat_tighten_kernel", "flat_rerank_kernel", "flat_small_kernel", "convert_f16_query"):
+    for kn in ("ivfpq_fused_kernel", "ivf_finish_kernel", "flat_scan_kernel", "select_k_kernel", "flat_filter_kernel", "flat_filter_kernel_max", "flat_tighten_kernel", "flat_rerank_kernel", "convert_f16_query"):
         print(kn, res.profile_get(kn))
     ms, n = res.profile_get("ivfpq_fused_kernel")
     bpq = 32.0 * nb / 4096.0 * 64
