@@ -110,6 +110,9 @@ def load_library():
         "faiss_amd_GpuIndexFlat_pairwise_distances": (i32, [vp, i64, vp, vp]),
         "faiss_amd_GpuIndexFlat_set_use_simple_kernel": (i32, [vp, i32]),
         "faiss_amd_GpuIndexIVF_set_use_fused_scan": (i32, [vp, i32]),
+        "faiss_amd_GpuIndexIVF_set_scan_mode": (i32, [vp, i32]),
+        "faiss_amd_GpuIndexIVF_scan_info": (i32, [vp, P(i32), P(i32), P(i64)]),
+        "faiss_amd_GpuIndexIVF_list_major_rule": (i32, [vp, i64, i32, i64, P(i32)]),
         "faiss_amd_GpuIndexFlat_set_use_filter_kernel": (i32, [vp, i32, i64]),
         "faiss_amd_GpuIndexFlat_filter_stats": (i32, [vp, P(i32), P(i32)]),
         "faiss_amd_GpuIndexFlat_filter_scores": (i32, [vp, i64, vp, vp, vp]),
@@ -537,6 +540,27 @@ class _GpuIndexIVF(Index):
         a, b, c = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
         _check(self._lib.faiss_amd_GpuIndexIVF_arena_stats(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
         return a.value, b.value, c.value
+
+    SCAN_AUTO, SCAN_QUERY_MAJOR, SCAN_LIST_MAJOR = 0, 1, 2
+
+    def set_scan_mode(self, mode):
+        """0 = automatic (large batches list-major), 1 = query-major always, 2 = list-major always"""
+        _check(self._lib.faiss_amd_GpuIndexIVF_set_scan_mode(self._h, int(mode)))
+
+    def scan_info(self):
+        """(mode set, mode of the last search: 1 query-major / 2 list-major, queries redone after a segment overflow)"""
+        a, b, c = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int64(0)
+        _check(self._lib.faiss_amd_GpuIndexIVF_scan_info(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return a.value, b.value, c.value
+
+    def last_scan_arith(self):
+        """the `arith` argument under which Oracle.ivf_search restates the last search (0 query-major, 1 list-major)"""
+        return self.scan_info()[1] - 1
+
+    def list_major_rule(self, n, nprobe=None, k=1):
+        v = ctypes.c_int(0)
+        _check(self._lib.faiss_amd_GpuIndexIVF_list_major_rule(self._h, int(n), int(nprobe or self.nprobe), int(k), ctypes.byref(v)))
+        return bool(v.value)
 
     def set_use_fused_scan(self, on):
         """test hook: False routes search() through the unfused scan + select kernels"""

@@ -845,5 +845,25 @@ int faiss_amd_GpuIndexIVF_set_use_fused_scan(FaissAmdIndex* index, int on) {
     as<GpuIndexIVF>(index, "GpuIndexIVF")->use_fused_scan = on != 0;
     FA_CATCH
 }
+int faiss_amd_GpuIndexIVF_set_scan_mode(FaissAmdIndex* index, int mode) {
+    FA_TRY
+    FA_THROW_IF_NOT_MSG(mode >= 0 && mode <= 2, "scan mode: 0 = automatic, 1 = query-major, 2 = list-major");
+    as<GpuIndexIVF>(index, "GpuIndexIVF")->scan_mode = mode;
+    FA_CATCH
+}
+int faiss_amd_GpuIndexIVF_scan_info(const FaissAmdIndex* index, int* mode, int* last_mode, int64_t* overflow_queries) {
+    FA_TRY
+    auto* ix = as<GpuIndexIVF>(const_cast<FaissAmdIndex*>(index), "GpuIndexIVF");
+    if (mode) *mode = ix->scan_mode;
+    if (last_mode) *last_mode = ix->last_scan_mode();
+    if (overflow_queries) *overflow_queries = ix->list_major_overflows();
+    FA_CATCH
+}
+int faiss_amd_GpuIndexIVF_list_major_rule(const FaissAmdIndex* index, int64_t n, int nprobe, int64_t k, int* p_output) {
+    FA_TRY
+    FA_THROW_IF_NOT_MSG(p_output, "null output");
+    *p_output = as<GpuIndexIVF>(const_cast<FaissAmdIndex*>(index), "GpuIndexIVF")->list_major_rule(n, nprobe, k, false) ? 1 : 0;
+    FA_CATCH
+}
 
 } // extern "C"

@@ -1430,6 +1430,7 @@ GpuIndexIVF::GpuIndexIVF(std::shared_ptr<GpuResources> res, int dims, int metric
 }
 GpuIndexIVF::~GpuIndexIVF() {
     (void)hipSetDevice(res_->device);
+    if (h_lm_) (void)hipHostFree(h_lm_);
     delete quantizer;
 }
 
@@ -1458,6 +1459,7 @@ void GpuIndexIVF::ensure_arena_(int64_t rows) {
     arena_.ensure((size_t)ncap * code_bytes_, keep * code_bytes_, res_->stream);
     arena_ids_.ensure((size_t)ncap * 8, keep * 8, res_->stream);
     if (use_t2_) arena_t2_.ensure((size_t)ncap * 4, keep * 4, res_->stream);
+    if (use_rn_) arena_rn_.ensure((size_t)ncap * 4, keep * 4, res_->stream);
     arena_cap_rows_ = ncap;
 }
 
@@ -1567,6 +1569,8 @@ void GpuIndexIVF::grow_lists_(const std::vector<uint32_t>& new_len, const std::v
         launch_ivf_move(arena_ids_.as<uint8_t>(), arena_ids_.as<uint8_t>(), dj, (int)jobs.size(), 8, R.stream);
         if (use_t2_)
             launch_ivf_move(arena_t2_.as<uint8_t>(), arena_t2_.as<uint8_t>(), dj, (int)jobs.size(), 4, R.stream);
+        if (use_rn_)
+            launch_ivf_move(arena_rn_.as<uint8_t>(), arena_rn_.as<uint8_t>(), dj, (int)jobs.size(), 4, R.stream);
     }
     HIP_CHECK(hipMemcpyAsync(d_list_start_.p, list_start_.data(), (size_t)nlist * 8, hipMemcpyHostToDevice, R.stream));
     R.sync(); // jobs / list_start_ host vectors are read by the copies above
@@ -1583,7 +1587,7 @@ void GpuIndexIVF::reserveMemory(size_t numVecs) {
 size_t GpuIndexIVF::reclaimMemory() {
     std::lock_guard<std::mutex> g(mu_);
     res_->set_device();
-    const size_t row_bytes = code_bytes_ + 8 + (use_t2_ ? 4 : 0);
+    const size_t row_bytes = code_bytes_ + 8 + (use_t2_ ? 4 : 0) + (use_rn_ ? 4 : 0);
     size_t before = (size_t)arena_cap_rows_ * row_bytes;
     for (DevBuf* b : {&a_xpad_, &a_lab_, &a_dis_, &a_dest_, &a_ids_, &a_hist_, &a_newlen_, &a_jobs_}) {
         before += b->cap;
@@ -1619,11 +1623,12 @@ void GpuIndexIVF::compact_(bool tight) {
         if (list_len_[l]) jobs.push_back({list_start_[l], acc, (int64_t)round_up(list_len_[l], (size_t)G)});
         acc += ncap[l];
     }
-    DevBuf na, ni, nt;
+    DevBuf na, ni, nt, nr;
     const int64_t rows = std::max<int64_t>(acc, 64);
     na.ensure((size_t)rows * code_bytes_);
     ni.ensure((size_t)rows * 8);
     if (use_t2_) nt.ensure((size_t)rows * 4);
+    if (use_rn_) nr.ensure((size_t)rows * 4);
     if (!jobs.empty()) {
         a_jobs_.ensure(jobs.size() * sizeof(IvfMoveJob));
         HIP_CHECK(hipMemcpyAsync(a_jobs_.p, jobs.data(), jobs.size() * sizeof(IvfMoveJob), hipMemcpyHostToDevice,
@@ -1632,6 +1637,7 @@ void GpuIndexIVF::compact_(bool tight) {
         launch_ivf_move(arena_.as<uint8_t>(), na.as<uint8_t>(), dj, (int)jobs.size(), (int)code_bytes_, R.stream);
         launch_ivf_move(arena_ids_.as<uint8_t>(), ni.as<uint8_t>(), dj, (int)jobs.size(), 8, R.stream);
         if (use_t2_) launch_ivf_move(arena_t2_.as<uint8_t>(), nt.as<uint8_t>(), dj, (int)jobs.size(), 4, R.stream);
+        if (use_rn_) launch_ivf_move(arena_rn_.as<uint8_t>(), nr.as<uint8_t>(), dj, (int)jobs.size(), 4, R.stream);
     }
     R.sync();
     std::swap(arena_.p, na.p);
@@ -1641,6 +1647,10 @@ void GpuIndexIVF::compact_(bool tight) {
     if (use_t2_) {
         std::swap(arena_t2_.p, nt.p);
         std::swap(arena_t2_.cap, nt.cap);
+    }
+    if (use_rn_) {
+        std::swap(arena_rn_.p, nr.p);
+        std::swap(arena_rn_.cap, nr.cap);
     }
     list_start_ = nstart;
     list_cap_ = ncap;
@@ -1886,6 +1896,16 @@ void GpuIndexIVF::search_core_(idx_t n, const float* x, idx_t k, float* distance
         launch_selector_mask(arena_ids_.as<int64_t>(), arena_rows_, 0, prog, sel_mask_.as<uint64_t>(), nullptr, R.stream);
         cur_sel_mask_ = sel_mask_.as<uint32_t>();
     }
+    // which scan serves this call: decided once, on the whole batch, so that the pages / tiles of one call agree
+    FA_THROW_IF_NOT_MSG(scan_mode >= 0 && scan_mode <= 2, "scan_mode must be 0 (auto), 1 (query-major) or 2 (list-major)");
+    if (scan_mode == 2) {
+        FA_THROW_IF_NOT_MSG(lm_capable_(), "list-major scan: index type / dimension not supported (IVFFlat, IVFPQ; d <= 128)");
+        FA_THROW_IF_NOT_MSG(!sel, "list-major scan: IDSelector searches take the query-major scan");
+        cur_lm_ = true;
+    } else {
+        cur_lm_ = scan_mode == 0 && list_major_rule(n, nprobe_now, k, sel != nullptr);
+    }
+    last_scan_mode_ = cur_lm_ ? 2 : 1;
     if (use_paged_path(R, n, d, x, distances, labels)) {
         const idx_t page = paged_page_size(R, n, 65536);
         idx_t done = 0; // pages come in order
@@ -1936,7 +1956,7 @@ void GpuIndexIVF::search_core_body_(idx_t n, const float* x, idx_t k, float* dis
         fused = use_fused_scan && ivf_fused_supported(fused_kind_(), fused_M_(), dpad_, (int)k, np, &fused_cap, &fused_kp,
                                                      &fused_nlut);
     }
-    if (fused) tile = 65536; // no per-candidate scratch: the tile only bounds the staging buffers
+    if (fused || cur_lm_) tile = 65536; // no per-candidate scratch here: the tile only bounds the staging buffers
     for (idx_t i0 = 0; i0 < n; i0 += tile) {
         check_interrupt();
         const int ni = (int)std::min(tile, n - i0);
@@ -1970,6 +1990,14 @@ void GpuIndexIVF::search_core_body_(idx_t n, const float* x, idx_t k, float* dis
             launch_ivf_sanitize_assign(c_ids_.as<idx_t>(), (int64_t)ni * np, nlist, R.stream);
         } else {
             quantizer->search_device(ni, q_pad_.as<float>(), np, c_dis_.as<float>(), c_ids_.as<idx_t>());
+        }
+        if (cur_lm_) {
+            // ---- large batch: list-major (ivf_listmajor.hip)
+            search_listmajor_(ni, q_pad_.as<float>(), c_ids_.as<idx_t>(), c_dis_.as<float>(), np, (int)k, dD, dI, false);
+            if (!out_dev_d) copy_out(R, distances + (size_t)i0 * k, dD, (size_t)ni * k * 4);
+            if (!out_dev_i) copy_out(R, labels + (size_t)i0 * k, dI, (size_t)ni * k * 8);
+            R.sync();
+            continue;
         }
         if (fused) {
             // ---- table build + list scan + k-selection in one launch, nothing but results leaves LDS
@@ -2115,6 +2143,169 @@ void GpuIndexIVF::search_core_body_(idx_t n, const float* x, idx_t k, float* dis
         if (!out_dev_d) copy_out(R, distances + (size_t)i0 * k, dD, (size_t)ni * k * 4);
         if (!out_dev_i) copy_out(R, labels + (size_t)i0 * k, dI, (size_t)ni * k * 8);
         R.sync();
+    }
+}
+
+// ---------------------------------------------------------------------- list-major search (ivf_listmajor.hip)
+bool GpuIndexIVF::list_major_rule(idx_t n, int nprobe_now, idx_t k, bool has_selector) const {
+    if (has_selector || !lm_capable_()) return false;
+    const int64_t np = std::min<int64_t>(nprobe_now, nlist);
+    return n >= 2048 && (int64_t)n * np >= (int64_t)8 * nlist && k <= kMaxSelectionK;
+}
+
+// Queries [0, ni) with their coarse results on the device -> k best per query in dD / dI (device).  Splits the batch
+// so that the key segments fit the scratch budget.
+void GpuIndexIVF::search_listmajor_(int ni, const float* xq_pad, const idx_t* c_ids, const float* c_dis, int np, int k,
+                                    float* dD, idx_t* dI, bool force_all) const {
+    const GpuResources& R = *res_;
+    uint32_t max_len = 1;
+    for (auto l : list_len_) max_len = std::max(max_len, l);
+    // segment of a query: the rows of pass 1 (fewer than k + the longest list) + room for the candidates of pass 2;
+    // with every probe in pass 1 (overflow rerun): all probed rows
+    const int64_t cap2 = std::max<int64_t>(1024, 4 * (int64_t)k);
+    const int64_t stride = force_all ? std::max<int64_t>((int64_t)np * max_len, k) : (int64_t)k + max_len + cap2;
+    const int64_t fit = std::max<int64_t>(1, (int64_t)(R.temp_budget_bytes / ((size_t)stride * 8)));
+    for (int c0 = 0; c0 < ni; c0 += (int)std::min<int64_t>(fit, ni)) {
+        const int cn = (int)std::min<int64_t>(fit, ni - c0);
+        search_listmajor_chunk_(cn, xq_pad + (size_t)c0 * dpad_, c_ids + (size_t)c0 * np, c_dis + (size_t)c0 * np, np, k,
+                                dD + (size_t)c0 * k, dI + (size_t)c0 * k, force_all, stride, max_len);
+    }
+}
+
+void GpuIndexIVF::search_listmajor_chunk_(int ni, const float* xq_pad, const idx_t* c_ids, const float* c_dis, int np, int k,
+                                          float* dD, idx_t* dI, bool force_all, int64_t stride, uint32_t max_len) const {
+    const GpuResources& R = *res_;
+    const int RT = 1024; // rows of a list per work item (16 tiles)
+    // upper bound of the work items: sum over (pass, list) of ceil(pairs / 128) * ceil(len / RT)
+    int64_t sum_nrt = 0, nrt_max = 1;
+    for (auto l : list_len_) {
+        const int64_t nrt = (int64_t)div_up(l, (size_t)RT);
+        sum_nrt += nrt;
+        nrt_max = std::max(nrt_max, nrt);
+    }
+    const int64_t npairs = (int64_t)ni * np;
+    const int64_t max_items = nrt_max * (int64_t)div_up((size_t)npairs, (size_t)kLmQueriesPerItem) + 2 * sum_nrt + 16;
+    FA_THROW_IF_NOT_MSG(max_items < ((int64_t)1 << 30), "list-major scan: too many work items");
+
+    IvfLmParams P{};
+    P.metric = metric_type;
+    P.nq = ni;
+    P.nprobe = np;
+    P.d = d;
+    P.dpad = dpad_;
+    P.nlist = nlist;
+    P.k = k;
+    P.xq = xq_pad;
+    P.ldq = dpad_;
+    P.coarse_ids = c_ids;
+    P.coarse_dis = c_dis;
+    P.list_len = d_list_len_.as<uint32_t>();
+    P.list_start = d_list_start_.as<int64_t>();
+    fill_lm_(P);
+    lm_prefix_.ensure((size_t)ni * (np + 1) * 4);
+    lm_p0_.ensure((size_t)ni * 4);
+    lm_cnt_.ensure((size_t)ni * 4);
+    lm_bucket_.ensure((size_t)4 * nlist * 4);
+    lm_bstart_.ensure((size_t)(2 * nlist + 1) * 4);
+    lm_pairs_.ensure((size_t)npairs * 4);
+    lm_items_.ensure((size_t)max_items * sizeof(IvfLmItem));
+    lm_bounds_.ensure(16);
+    lm_thr_.ensure((size_t)ni * 4);
+    lm_keys_.ensure((size_t)ni * stride * 8);
+    lm_ovf_.ensure((size_t)(ni + 1) * 4);
+    if (!h_lm_) HIP_CHECK(hipHostMalloc((void**)&h_lm_, 64, hipHostMallocDefault));
+    P.prefix = lm_prefix_.as<uint32_t>();
+    P.p0 = lm_p0_.as<uint32_t>();
+    P.cnt = lm_cnt_.as<uint32_t>();
+    P.bucket_cnt = lm_bucket_.as<uint32_t>();
+    P.bucket_fill = P.bucket_cnt + 2 * nlist;
+    P.bucket_start = lm_bstart_.as<uint32_t>();
+    P.pairs = lm_pairs_.as<uint32_t>();
+    P.items = lm_items_.as<IvfLmItem>();
+    P.item_bounds = lm_bounds_.as<uint32_t>();
+    P.max_items = (int)max_items;
+    P.rows_per_item = RT;
+    P.force_all = force_all ? 1 : 0;
+    P.keys = lm_keys_.as<unsigned long long>();
+    P.stride = stride;
+    P.thr = lm_thr_.as<uint32_t>();
+    P.ovf = lm_ovf_.as<uint32_t>();
+    if (P.kind == 0 && metric_type == METRIC_L2) {
+        lm_qn_.ensure((size_t)ni * 4);
+        launch_l2_norms(xq_pad, dpad_, ni, d, lm_qn_.as<float>(), R.stream);
+        P.xqn = lm_qn_.as<float>();
+    }
+    {
+        SpanGuard sg(&R, "ivf_lm_plan");
+        launch_ivf_lm_plan(P, R.stream);
+    }
+    const int grid = 3 * R.num_cus / 8 * 8; // three 256-thread workgroups per CU are resident (registers): one wave of persistent blocks
+    {
+        SpanGuard sg(&R, "ivf_lm_scan_pass1");
+        launch_ivf_lm_scan(P, 1, grid, R.stream);
+    }
+    SelectParams sp{};
+    sp.metric = metric_type;
+    sp.nq = ni;
+    sp.k = k;
+    sp.keys = P.keys;
+    sp.q_stride = stride;
+    sp.nseg = 1;
+    sp.seg_stride = 0;
+    sp.seg_cnt = P.cnt;
+    if (!force_all) {
+        {
+            // bound of every query: the k-th smallest key among its pass-1 rows
+            SpanGuard sg(&R, "ivf_lm_threshold");
+            sp.mode = 0;
+            sp.kth_out = P.thr;
+            launch_select_k(sp, R.stream);
+            sp.kth_out = nullptr;
+        }
+        HIP_CHECK(hipMemsetAsync(P.ovf, 0, 4, R.stream));
+        {
+            SpanGuard sg(&R, "ivf_lm_scan_pass2");
+            launch_ivf_lm_scan(P, 2, grid, R.stream);
+        }
+        launch_ivf_lm_clamp(P, R.stream);
+    }
+    sp.mode = 1;
+    sp.nprobe = np;
+    sp.ivf_prefix = P.prefix;
+    sp.coarse_ids = c_ids;
+    sp.list_start = d_list_start_.as<int64_t>();
+    sp.arena_ids = arena_ids_.as<int64_t>();
+    sp.out_dis = dD;
+    sp.out_ids = dI;
+    {
+        SpanGuard sg(&R, "select_k_kernel");
+        launch_select_k(sp, R.stream);
+    }
+    // one read-back: queries whose segment overflowed in pass 2 (+ the item-table check)
+    h_lm_[0] = 0;
+    if (!force_all) HIP_CHECK(hipMemcpyAsync(&h_lm_[0], P.ovf, 4, hipMemcpyDeviceToHost, R.stream));
+    HIP_CHECK(hipMemcpyAsync(&h_lm_[1], P.item_bounds + 3, 4, hipMemcpyDeviceToHost, R.stream));
+    R.sync();
+    FA_THROW_IF_NOT_MSG(h_lm_[1] == 0, "list-major scan: work-item table too small (internal error)");
+    const int novf = (int)h_lm_[0];
+    lm_overflows_ += novf;
+    if (novf > 0) {
+        // redo those queries with every probe in pass 1 (all their rows written, exact capacity): same arithmetic, same
+        // answer as an unbounded segment would have given
+        DevBuf olist, gq, gids, gdis, gD, gI;
+        olist.ensure((size_t)novf * 4);
+        HIP_CHECK(hipMemcpyAsync(olist.p, P.ovf + 1, (size_t)novf * 4, hipMemcpyDeviceToDevice, R.stream));
+        gq.ensure((size_t)novf * dpad_ * 4);
+        gids.ensure((size_t)novf * np * 8);
+        gdis.ensure((size_t)novf * np * 4);
+        gD.ensure((size_t)novf * k * 4);
+        gI.ensure((size_t)novf * k * 8);
+        launch_gather_rows(xq_pad, dpad_, dpad_, olist.as<uint32_t>(), novf, gq.as<float>(), R.stream);
+        launch_gather_rows((const float*)c_ids, 2 * np, 2 * np, olist.as<uint32_t>(), novf, (float*)gids.p, R.stream);
+        launch_gather_rows(c_dis, np, np, olist.as<uint32_t>(), novf, gdis.as<float>(), R.stream);
+        search_listmajor_(novf, gq.as<float>(), gids.as<idx_t>(), gdis.as<float>(), np, k, gD.as<float>(), gI.as<idx_t>(), true);
+        launch_scatter_results(gD.as<float>(), gI.as<idx_t>(), k, olist.as<uint32_t>(), novf, dD, dI, R.stream);
+        R.sync(); // the gathered buffers die with this scope
     }
 }
 
@@ -2286,9 +2477,27 @@ GpuIndexIVFFlat::GpuIndexIVFFlat(std::shared_ptr<GpuResources> res, int dims, in
         : GpuIndexIVF(std::move(res), dims, metric, nlist) {
     code_bytes_ = (size_t)dpad_ * 4;
     granule_ = 8;
+    use_rn_ = metric == METRIC_L2;
 }
 void GpuIndexIVFFlat::append_(int n, const float* x_pad, const int64_t*, const int64_t* d_dest) {
     launch_ivfflat_append(x_pad, dpad_, n, d, d_dest, arena_.as<float>(), dpad_, dpad_, res_->stream);
+    // |y|^2 of the new rows (the sequential chain of the flat index's norms): the list-major scan's second term
+    if (use_rn_) launch_l2_norms_scatter(x_pad, dpad_, n, d, d_dest, arena_rn_.as<float>(), res_->stream);
+}
+void GpuIndexIVFFlat::lists_changed_() {
+    // bulk load: norms of every arena row (rows of the slack hold whatever they hold; no scan reads them)
+    if (!use_rn_ || arena_rows_ == 0) return;
+    launch_l2_norms(arena_.as<float>(), dpad_, arena_rows_, d, arena_rn_.as<float>(), res_->stream);
+    res_->sync();
+}
+bool GpuIndexIVFFlat::lm_capable_() const {
+    return ivf_lm_supported(0, dpad_, 0, d);
+}
+void GpuIndexIVFFlat::fill_lm_(IvfLmParams& p) const {
+    p.kind = 0;
+    p.arena_vecs = arena_.as<float>();
+    p.ldv = dpad_;
+    p.arena_rn = arena_rn_.as<float>();
 }
 void GpuIndexIVFFlat::fill_fused_(IvfFusedParams& p) const {
     p.arena_vecs = arena_.as<float>();
@@ -2350,7 +2559,11 @@ GpuIndexIVFPQ::GpuIndexIVFPQ(std::shared_ptr<GpuResources> res, int dims, int nl
     code_bytes_ = (size_t)M;
     granule_ = kPqBlockRows;
     use_t2_ = metric == METRIC_L2;
+    use_rn_ = metric == METRIC_L2;
     FA_THROW_IF_NOT_MSG(M % 4 == 0, "M must be a multiple of 4");
+    res_->set_device();
+    zero_row_.ensure((size_t)dpad_ * 4);
+    HIP_CHECK(hipMemset(zero_row_.p, 0, (size_t)dpad_ * 4));
 }
 void GpuIndexIVFPQ::set_pq_centroids(const float* pq) {
     FA_THROW_IF_NOT_MSG(pq, "null codebook");
@@ -2430,13 +2643,34 @@ void GpuIndexIVFPQ::append_(int n, const float* x_pad, const int64_t* d_labels, 
     if (use_t2_)
         launch_ivfpq_t2_rows(arena_.as<uint8_t>(), d_labels, d_dest, n, quantizer->device_vectors(), dpad_, M, dsub,
                              pq_.as<float>(), arena_t2_.as<float>(), res_->stream);
+    // |r^|^2 of the new rows = the same chain against a zero centroid (fmaf(2, 0, r) == r): the list-major scan's term
+    if (use_rn_)
+        launch_ivfpq_t2_rows(arena_.as<uint8_t>(), d_labels, d_dest, n, zero_row_.as<float>(), 0, M, dsub, pq_.as<float>(),
+                             arena_rn_.as<float>(), res_->stream);
 }
 void GpuIndexIVFPQ::lists_changed_() {
-    // recompute the per-vector L2 term for every stored row (bulk load, or the quantizers were replaced)
-    if (!use_t2_ || nstored_ == 0) return;
-    launch_ivfpq_t2_lists(arena_.as<uint8_t>(), d_list_start_.as<int64_t>(), d_list_len_.as<uint32_t>(), nlist,
-                          quantizer->device_vectors(), dpad_, M, dsub, pq_.as<float>(), arena_t2_.as<float>(), res_->stream);
+    // recompute the per-vector L2 terms for every stored row (bulk load, or the quantizers were replaced)
+    if (nstored_ == 0) return;
+    if (use_t2_)
+        launch_ivfpq_t2_lists(arena_.as<uint8_t>(), d_list_start_.as<int64_t>(), d_list_len_.as<uint32_t>(), nlist,
+                              quantizer->device_vectors(), dpad_, M, dsub, pq_.as<float>(), arena_t2_.as<float>(), res_->stream);
+    if (use_rn_)
+        launch_ivfpq_t2_lists(arena_.as<uint8_t>(), d_list_start_.as<int64_t>(), d_list_len_.as<uint32_t>(), nlist,
+                              zero_row_.as<float>(), 0, M, dsub, pq_.as<float>(), arena_rn_.as<float>(), res_->stream);
     res_->sync();
+}
+bool GpuIndexIVFPQ::lm_capable_() const {
+    return ivf_lm_supported(1, dpad_, M, d);
+}
+void GpuIndexIVFPQ::fill_lm_(IvfLmParams& p) const {
+    p.kind = 1;
+    p.arena_codes = arena_.as<uint8_t>();
+    p.arena_rn = arena_rn_.as<float>();
+    p.M = M;
+    p.dsub = dsub;
+    p.pq_centroids = pq_.as<float>();
+    p.centroids = quantizer->device_vectors();
+    p.ldc = dpad_;
 }
 void GpuIndexIVFPQ::fill_fused_(IvfFusedParams& p) const {
     p.arena_t2 = arena_t2_.as<float>();

@@ -376,13 +376,14 @@ class GpuIndexIVF : public Index {
     size_t code_bytes_ = 0; // bytes per arena row (dpad*4 for IVFFlat, M for IVFPQ)
     int granule_ = 8;       // list capacities and starts are multiples of this many rows
     bool use_t2_ = false;   // IVFPQ L2: per-row term in arena_t2_
+    bool use_rn_ = false;   // L2: squared norm of every stored (decoded) row in arena_rn_ (list-major scan)
     std::vector<uint32_t> list_len_, list_cap_;
     std::vector<int64_t> list_start_;
     int64_t arena_rows_ = 0;     // rows handed out so far (next free row)
     int64_t arena_cap_rows_ = 0; // rows allocated
     int64_t hole_rows_ = 0;      // rows of abandoned ranges (relocated lists)
     idx_t nstored_ = 0;
-    DevBuf d_list_len_, d_list_start_, arena_, arena_ids_, arena_t2_;
+    DevBuf d_list_len_, d_list_start_, arena_, arena_ids_, arena_t2_, arena_rn_;
     mutable std::mutex mu_;
     mutable DevBuf q_raw_, q_pad_, c_dis_, c_ids_, prefix_, totals_, q_off_, keys_, out_d_, out_i_, one_cnt_;
     mutable int nprobe_eff_ = 1; // min(nprobe, nlist) of the search in flight
@@ -410,6 +411,19 @@ class GpuIndexIVF : public Index {
     virtual size_t ref_row_bytes_() const { return code_bytes_; }
     virtual int sq_chunk_bytes_() const { return 0; } // scalar quantizer: bytes per 16-component chunk
     mutable DevBuf part_keys_, part_cnt_, probe_len_, probe_start_;
+    // ---- list-major search of large batches (ivf_listmajor.hip, kernels.h IvfLmParams)
+    virtual bool lm_capable_() const { return false; }
+    virtual void fill_lm_(struct IvfLmParams& p) const {}
+    mutable DevBuf lm_prefix_, lm_p0_, lm_cnt_, lm_bucket_, lm_bstart_, lm_pairs_, lm_items_, lm_bounds_, lm_thr_, lm_keys_,
+            lm_ovf_, lm_qn_;
+    mutable uint32_t* h_lm_ = nullptr; // pinned: overflow count + item-table check of the search in flight
+    mutable bool cur_lm_ = false;      // the search call in flight takes the list-major path (decided once per call)
+    mutable int last_scan_mode_ = 0;
+    mutable long lm_overflows_ = 0; // statistics: queries redone because their candidate segment overflowed
+    void search_listmajor_(int ni, const float* xq_pad, const idx_t* c_ids, const float* c_dis, int np, int k, float* dD,
+                           idx_t* dI, bool force_all) const;
+    void search_listmajor_chunk_(int ni, const float* xq_pad, const idx_t* c_ids, const float* c_dis, int np, int k,
+                                 float* dD, idx_t* dI, bool force_all, int64_t stride, uint32_t max_len) const;
     void upload_list_tables_();
     void ensure_arena_(int64_t rows);
     // make room for new_len[l] entries in every list (relocating the lists that outgrow their slack); est[l]
@@ -426,6 +440,16 @@ class GpuIndexIVF : public Index {
     // when false, search() takes the unfused path (every distance as a key in HBM + select);
     // kept for cross-checking the fused kernel and for shapes that do not fit its LDS budget
     bool use_fused_scan = true;
+    // which scan serves search(): 0 = automatic (list-major for batches of >= 2048 queries that probe every list
+    // >= 8 times on average, without IDSelector, when the index type / dimension support it), 1 = query-major always
+    // (ivf_fused.hip), 2 = list-major always (throws when unsupported).  The two differ in arithmetic,
+    // each bit-exact against its own restatement in the oracle.
+    int scan_mode = 0;
+    // what the last search() call used: 1 = query-major, 2 = list-major
+    int last_scan_mode() const { return last_scan_mode_; }
+    long list_major_overflows() const { return lm_overflows_; }
+    // the rule of scan_mode 0
+    bool list_major_rule(idx_t n, int nprobe_now, idx_t k, bool has_selector) const;
 };
 
 class GpuIndexIVFFlat : public GpuIndexIVF {
@@ -442,6 +466,9 @@ class GpuIndexIVFFlat : public GpuIndexIVF {
     size_t ref_row_bytes_() const override { return (size_t)d * 4; }
     void append_(int n, const float* x_pad, const int64_t* d_labels, const int64_t* d_dest) override;
     void scan_(int nq, const float* xq_pad, int k, const int64_t* h_qoff) const override;
+    void lists_changed_() override;
+    bool lm_capable_() const override;
+    void fill_lm_(struct IvfLmParams& p) const override;
 };
 
 class GpuIndexIVFPQ : public GpuIndexIVF {
@@ -466,6 +493,9 @@ class GpuIndexIVFPQ : public GpuIndexIVF {
     bool precomputed_codes_ = false;
     DevBuf pq_;   // [M][256][dsub]
     DevBuf pq_t_; // [256][M][dsub]: the order the scan kernels build their lookup table in
+    DevBuf zero_row_; // dpad zeros: the "centroid" with which the per-row term kernels yield |r^|^2 (arena_rn_)
+    bool lm_capable_() const override;
+    void fill_lm_(struct IvfLmParams& p) const override;
     bool extra_trained_() const override { return pq_.p != nullptr; }
     void lists_changed_() override;
     void train_residual_(idx_t n, const float* x_dev_pad) override;

@@ -1,0 +1,412 @@
+// faiss_amd/csrc/ivf_listmajor.hip -- list-major inverted-list search for gfx950 (round 3).
+//
+// The query-major scans (ivf_fused.hip; the reference's IVFInterleaved.cuh:33-224 and
+// PQScanMultiPassNoPrecomputed-inl.cuh:173-270 are query-major too) stream every probed list once per query: a batch
+// of 10 000 queries x 32 probes over 4096 lists reads each list ~78 times.  Here a workgroup takes one list and up to
+// 128 of the queries that probe it: the queries sit in registers as MFMA B operands, the list's rows pass through LDS
+// in 64-row tiles ONCE (IVFPQ: decoded from the codes on the way in), and the 64 x 128 distance block is computed on
+// the f32 matrix pipe (v_mfma_f32_32x32x2_f32 = a k-ordered fmaf chain, bit for bit that of flat_scan_kernel).
+// The bound moves from the code / vector stream (HBM, fabric) to the f32 MFMA rate: 2 * nq * nprobe * (nb / nlist) * d
+// flop per batch (20 GFLOP at nb = 1M, 2 TFLOP at nb = 100M) against 157 TFLOP/s.
+//
+// Per-query state cannot live in a workgroup any more (a query's probes are spread over many of them), so selection is
+// two passes over a per-query key segment in HBM (kernels.h IvfLmParams): pass 1 writes every distance of the query's
+// leading probes (>= k rows) at its scan position; the k-th smallest of those is a bound no better result can exceed;
+// pass 2 appends the rows of the remaining probes that are at or below the bound.  The result is the k smallest keys
+// of the segment under (distance, scan position) -- the same rule as every other scan here -- whatever order the
+// workgroups ran in.
+#include "kernels.h"
+
+namespace faiss_amd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned long long u64;
+
+constexpr int LM_THREADS = 256;
+constexpr int LM_TR = 64;                       // rows per tile
+constexpr int LM_ROWB = 512;                    // LDS bytes per tile row (128 floats, whatever dpad is)
+constexpr int LM_TILE_BYTES = LM_TR * LM_ROWB;  // 32768
+constexpr int LM_LDS_RN = LM_TILE_BYTES;        // 64 row norms
+constexpr int LM_LDS_TOTAL = LM_TILE_BYTES + LM_TR * 4;
+
+bool ivf_lm_supported(int kind, int dpad, int M, int d) {
+    if (dpad > 128 || (dpad & 7)) return false;
+    if (kind == 0) return true;
+    if (kind == 1) return M >= 1 && d % M == 0;
+    return false;
+}
+
+// ------------------------------------------------------------------ plan
+// one thread per query: scan positions of its probes, the probes of pass 1, pairs per (pass, list)
+__global__ void lm_plan_kernel(IvfLmParams p) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= p.nq) return;
+    const int np = p.nprobe;
+    const int64_t* ids = p.coarse_ids + (int64_t)q * np;
+    uint32_t* pre = p.prefix + (int64_t)q * (np + 1);
+    uint32_t cum = 0;
+    int p0 = np;
+    for (int pr = 0; pr < np; ++pr) {
+        const int64_t l = ids[pr];
+        const uint32_t len = l >= 0 ? p.list_len[l] : 0u;
+        pre[pr] = cum;
+        cum += len;
+        if (p0 == np && cum >= (uint32_t)p.k) p0 = pr + 1;
+    }
+    pre[np] = cum;
+    if (p.force_all) p0 = np;
+    p.p0[q] = (uint32_t)p0;
+    p.cnt[q] = pre[p0];
+    for (int pr = 0; pr < np; ++pr) {
+        const int64_t l = ids[pr];
+        if (l >= 0 && p.list_len[l] > 0) atomicAdd(&p.bucket_cnt[(int)l + (pr >= p0 ? p.nlist : 0)], 1u);
+    }
+}
+
+// one workgroup: bucket_start = exclusive scan of bucket_cnt; items of bucket b = query groups x row chunks, listed
+// bucket by bucket (pass 1 = buckets [0, nlist) first), row chunk by row chunk, query group innermost (consecutive
+// items share their rows)
+__global__ void __launch_bounds__(1024) lm_items_kernel(IvfLmParams p) {
+    __shared__ uint32_t part_pairs[1024];
+    __shared__ uint32_t part_items[1024];
+    __shared__ uint32_t bounds[2];
+    const int t = threadIdx.x;
+    const int n = 2 * p.nlist;
+    const int per = (n + 1023) / 1024;
+    const int a = min(n, t * per), b = min(n, a + per);
+    auto items_of = [&](int bk) -> uint32_t {
+        const uint32_t c = p.bucket_cnt[bk];
+        if (c == 0) return 0u;
+        const uint32_t len = p.list_len[bk >= p.nlist ? bk - p.nlist : bk];
+        return ((c + kLmQueriesPerItem - 1) / kLmQueriesPerItem) * ((len + p.rows_per_item - 1) / p.rows_per_item);
+    };
+    uint32_t sp = 0, si = 0;
+    for (int i = a; i < b; ++i) {
+        sp += p.bucket_cnt[i];
+        si += items_of(i);
+    }
+    part_pairs[t] = sp;
+    part_items[t] = si;
+    __syncthreads();
+    if (t == 0) {
+        uint32_t rp = 0, ri = 0;
+        for (int i = 0; i < 1024; ++i) {
+            const uint32_t vp = part_pairs[i], vi = part_items[i];
+            part_pairs[i] = rp;
+            part_items[i] = ri;
+            rp += vp;
+            ri += vi;
+        }
+        p.bucket_start[n] = rp;
+        bounds[1] = ri;
+    }
+    __syncthreads();
+    uint32_t rp = part_pairs[t], ri = part_items[t];
+    for (int i = a; i < b; ++i) {
+        p.bucket_start[i] = rp;
+        if (i == p.nlist) bounds[0] = ri; // (nlist < n: exactly one thread owns bucket nlist)
+        const uint32_t c = p.bucket_cnt[i];
+        if (c) {
+            const uint32_t len = p.list_len[i >= p.nlist ? i - p.nlist : i];
+            const int nqt = (int)((c + kLmQueriesPerItem - 1) / kLmQueriesPerItem);
+            const int nrt = (int)((len + p.rows_per_item - 1) / p.rows_per_item);
+            for (int rt = 0; rt < nrt; ++rt)
+                for (int qt = 0; qt < nqt; ++qt) {
+                    if (ri < (uint32_t)p.max_items) p.items[ri] = IvfLmItem{i, qt, rt, 0};
+                    ++ri;
+                }
+        }
+        rp += c;
+    }
+    __syncthreads();
+    if (t == 0) {
+        p.item_bounds[0] = 0;
+        p.item_bounds[1] = min(bounds[0], (uint32_t)p.max_items);
+        p.item_bounds[2] = min(bounds[1], (uint32_t)p.max_items);
+        // (max_items is an upper bound computed on the host from the list lengths; exceeding it would lose work, so the
+        // host checks item_bounds[3] == 0 whenever it reads the overflow word)
+        p.item_bounds[3] = bounds[1] > (uint32_t)p.max_items ? 1u : 0u;
+    }
+}
+
+// one thread per (query, probe): its place among the pairs of its bucket (any order inside a bucket)
+__global__ void lm_fill_kernel(IvfLmParams p) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)p.nq * p.nprobe) return;
+    const int64_t l = p.coarse_ids[i];
+    if (l < 0 || p.list_len[l] == 0) return;
+    const int q = (int)(i / p.nprobe), pr = (int)(i - (int64_t)q * p.nprobe);
+    const int bk = (int)l + (pr >= (int)p.p0[q] ? p.nlist : 0);
+    const uint32_t slot = p.bucket_start[bk] + atomicAdd(&p.bucket_fill[bk], 1u);
+    p.pairs[slot] = (uint32_t)i;
+}
+
+void launch_ivf_lm_plan(const IvfLmParams& p, hipStream_t stream) {
+    if (p.nq == 0) return;
+    FA_THROW_IF_NOT(p.rows_per_item % LM_TR == 0 && p.rows_per_item > 0);
+    // bucket_cnt and bucket_fill are one allocation [2][2 nlist]
+    FA_THROW_IF_NOT(p.bucket_fill == p.bucket_cnt + 2 * p.nlist);
+    HIP_CHECK(hipMemsetAsync(p.bucket_cnt, 0, (size_t)4 * p.nlist * 4, stream));
+    hipLaunchKernelGGL(lm_plan_kernel, dim3((unsigned)div_up(p.nq, 128)), dim3(128), 0, stream, p);
+    hipLaunchKernelGGL(lm_items_kernel, dim3(1), dim3(1024), 0, stream, p);
+    hipLaunchKernelGGL(lm_fill_kernel, dim3((unsigned)div_up((size_t)p.nq * p.nprobe, 256)), dim3(256), 0, stream, p);
+    HIP_CHECK(hipGetLastError());
+}
+
+__global__ void lm_clamp_kernel(IvfLmParams p) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= p.nq) return;
+    if ((int64_t)p.cnt[q] > p.stride) {
+        p.cnt[q] = (uint32_t)p.stride;
+        const uint32_t s = atomicAdd(&p.ovf[0], 1u);
+        p.ovf[1 + s] = (uint32_t)q;
+    }
+}
+void launch_ivf_lm_clamp(const IvfLmParams& p, hipStream_t stream) {
+    if (p.nq == 0) return;
+    hipLaunchKernelGGL(lm_clamp_kernel, dim3((unsigned)div_up(p.nq, 256)), dim3(256), 0, stream, p);
+    HIP_CHECK(hipGetLastError());
+}
+
+__global__ void l2_norms_scatter_kernel(const float* __restrict__ x, int64_t ld, int64_t n, int d,
+                                        const int64_t* __restrict__ dest, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t row = dest[i];
+    if (row < 0) return;
+    const float* r = x + i * ld;
+    float acc = 0.f;
+    for (int k = 0; k < d; ++k) {
+        const float v = r[k];
+        acc = __fmaf_rn(v, v, acc);
+    }
+    out[row] = acc;
+}
+void launch_l2_norms_scatter(const float* x, int64_t ld, int64_t n, int d, const int64_t* dest, float* out,
+                             hipStream_t stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(l2_norms_scatter_kernel, dim3((unsigned)div_up(n, 256)), dim3(256), 0, stream, x, ld, n, d, dest, out);
+    HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ scan
+// Workgroup = 4 waves; wave w owns 32 of the item's queries (B operands: their dpad coordinates in 16 x 4 VGPRs, lane
+// (h, j): query j, coordinates 8 s + 4 h + e), all waves share the tile.  MFMA D[i][j]: i = row of a 32-row block,
+// j = query: lane (h, j) holds the distances of rows 8 g + 4 h + e (acc[4 g + e]) to ITS query -- threshold, scan
+// position and segment are per-lane registers, nothing crosses lanes.
+// FULL: dpad == 128 (no bound checks in the k loop).
+template <int METRIC, int KIND, int PASS, bool FULL>
+__global__ void __launch_bounds__(LM_THREADS, 3) ivf_lm_scan_kernel(IvfLmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    const int j = lane & 31;
+    const int np = p.nprobe;
+    const int ns = FULL ? 16 : (p.dpad >> 3);
+    float* rnl = (float*)(smem + LM_LDS_RN);
+
+    const uint32_t it0 = p.item_bounds[PASS - 1], it1 = p.item_bounds[PASS];
+    // blocks b, b + 8, ... share an XCD (and its L2): give them consecutive items
+    const int nblk = (int)gridDim.x;
+    int vb = (int)blockIdx.x;
+    if ((nblk & 7) == 0) vb = ((int)blockIdx.x & 7) * (nblk >> 3) + ((int)blockIdx.x >> 3);
+
+    for (uint32_t it = it0 + (uint32_t)vb; it < it1; it += (uint32_t)nblk) {
+        const IvfLmItem item = p.items[it];
+        const int bk = __builtin_amdgcn_readfirstlane(item.bucket);
+        const int qt = __builtin_amdgcn_readfirstlane(item.qt);
+        const int rt = __builtin_amdgcn_readfirstlane(item.rt);
+        const int list = PASS == 2 ? bk - p.nlist : bk;
+        const int len = (int)p.list_len[list];
+        const int64_t start = p.list_start[list];
+        const uint32_t pb = p.bucket_start[bk];
+        const int npair = min(kLmQueriesPerItem, (int)(p.bucket_start[bk + 1] - pb) - qt * kLmQueriesPerItem);
+        const int r0 = rt * p.rows_per_item;
+        const int r1 = min(len, r0 + p.rows_per_item);
+
+        // ---- this lane's query
+        const int my = wave * 32 + j;
+        const bool qv = my < npair;
+        const uint32_t pi = p.pairs[pb + (uint32_t)(qt * kLmQueriesPerItem) + (uint32_t)(qv ? my : 0)];
+        const int q = (int)(pi / (uint32_t)np);
+        const int pr = (int)(pi - (uint32_t)q * (uint32_t)np);
+        const bool wave_active = wave * 32 < npair; // wave-uniform
+        const float* qrow = p.xq + (int64_t)q * p.ldq;
+        f32x4 bq[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            if (FULL || s < ns) bq[s] = *(const f32x4*)(qrow + 8 * s + 4 * h);
+            else bq[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        float xn = 0.f;
+        if (KIND == 1 && METRIC == METRIC_L2) {
+            // residual against the list's centroid; |q - c|^2 = the two interleaved half chains of the lane pair
+            const float* cen = p.centroids + (int64_t)list * p.ldc;
+            float acc = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                if (FULL || s < ns) {
+                    const f32x4 c4 = *(const f32x4*)(cen + 8 * s + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = bq[s][e] - c4[e];
+                        bq[s][e] = v;
+                        acc = __fmaf_rn(v, v, acc);
+                    }
+                }
+            }
+            xn = acc + __shfl_xor(acc, 32, 64);
+        } else if (METRIC == METRIC_L2) {
+            xn = p.xqn[q];
+        } else if (KIND == 1) {
+            xn = p.coarse_dis[pi];
+        }
+        const uint32_t base_pos = p.prefix[(int64_t)q * (np + 1) + pr];
+        u64* kq = p.keys + (int64_t)q * p.stride;
+        float thr_f = 0.f;
+        if (PASS == 2) {
+            const uint32_t tk = p.thr[q];
+            if (tk >= kInvalidOrdKey) thr_f = METRIC == METRIC_L2 ? INFINITY : -INFINITY;
+            else thr_f = unordkey<METRIC>(tk);
+        }
+
+        for (int t = r0; t < r1; t += LM_TR) {
+            __syncthreads(); // everybody is done with the previous tile
+            // ---- tile [t, t + 64) of the list -> LDS: row r at r * 512, 16-byte chunk c at (c ^ (r & 15)) * 16
+            if (KIND == 0) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int g = tid + LM_THREADS * i;
+                    const int row = g >> 5, c = g & 31;
+                    if (FULL || c * 4 < p.dpad) {
+                        const int grow = min(t + row, r1 - 1);
+                        const f32x4 v = *(const f32x4*)(p.arena_vecs + (start + grow) * p.ldv + c * 4);
+                        *(f32x4*)(smem + row * LM_ROWB + ((c ^ (row & 15)) << 4)) = v;
+                    }
+                }
+            } else {
+                // IVFPQ: thread (row l, quarter) decodes sub-quantizers quarter, quarter + 4, ...: stored byte
+                // (m - l) mod M of row l (rotated block layout, kernels.h pq_code_offset) -> dsub floats of the codebook
+                const int l = tid & 63, qd = tid >> 6;
+                const int M = p.M, dsub = p.dsub, ch = pq_chunk_bytes(M);
+                const uint8_t* blk = p.arena_codes + (size_t)((start + t) >> 6) * 64 * M;
+                char* rowp = smem + l * LM_ROWB;
+                const int sw = l & 15;
+                for (int m = qd; m < M; m += 4) {
+                    int jb = (m - l) % M;
+                    if (jb < 0) jb += M;
+                    const unsigned code = blk[(size_t)(jb / ch) * 64 * ch + (size_t)l * ch + (jb % ch)];
+                    const float* src = p.pq_centroids + ((size_t)m * 256 + code) * dsub;
+                    for (int jd = 0; jd < dsub; ++jd) {
+                        const int col = m * dsub + jd;
+                        *(float*)(rowp + ((((col >> 2) ^ sw)) << 4) + ((col & 3) << 2)) = src[jd];
+                    }
+                }
+                // zero padding d .. dpad
+                for (int col = p.d + qd; col < p.dpad; col += 4)
+                    *(float*)(rowp + ((((col >> 2) ^ sw)) << 4) + ((col & 3) << 2)) = 0.f;
+            }
+            if (tid < LM_TR) {
+                float v = 0.f;
+                if (METRIC == METRIC_L2 && t + tid < r1) v = p.arena_rn[start + t + tid];
+                rnl[tid] = v;
+            }
+            __syncthreads();
+            if (!wave_active) continue;
+
+#pragma unroll
+            for (int blk2 = 0; blk2 < 2; ++blk2) {
+                if (t + blk2 * 32 >= r1) break; // (wave-uniform) the second block of the last tile may be empty
+                const char* rowp = smem + (blk2 * 32 + j) * LM_ROWB;
+                const int sw = j & 15; // ((32 + j) & 15 == j & 15)
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                if (FULL) {
+                    f32x4 aA = *(const f32x4*)(rowp + (((0 + h) ^ sw) << 4));
+                    f32x4 aB;
+#pragma unroll
+                    for (int s = 0; s < 16; s += 2) {
+                        aB = *(const f32x4*)(rowp + (((2 * (s + 1) + h) ^ sw) << 4));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aA[e], bq[s][e], acc, 0, 0, 0);
+                        if (s + 2 < 16) aA = *(const f32x4*)(rowp + (((2 * (s + 2) + h) ^ sw) << 4));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aB[e], bq[s + 1][e], acc, 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) {
+                        if (s < ns) {
+                            const f32x4 a = *(const f32x4*)(rowp + (((2 * s + h) ^ sw) << 4));
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], bq[s][e], acc, 0, 0, 0);
+                        }
+                    }
+                }
+                // ---- epilogue: 16 distances of this lane's query
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 b4 = *(const f32x4*)(rnl + blk2 * 32 + 8 * g + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float ip = acc[4 * g + e];
+                        float dis;
+                        if (METRIC == METRIC_L2) {
+                            dis = __fmaf_rn(-2.f, ip, xn + b4[e]);
+                            dis = dis < 0.f ? 0.f : dis;
+                        } else {
+                            dis = xn + ip;
+                        }
+                        const int rowl = t + blk2 * 32 + 8 * g + 4 * h + e; // row of the list
+                        const bool ok = qv && rowl < r1;
+                        const uint32_t pos = base_pos + (uint32_t)rowl;
+                        if (PASS == 1) {
+                            if (ok) kq[pos] = ((u64)ordkey<METRIC>(dis) << 32) | pos;
+                        } else {
+                            const bool pass = ok && (METRIC == METRIC_L2 ? dis <= thr_f : dis >= thr_f);
+                            if (pass) {
+                                const uint32_t slot = atomicAdd(&p.cnt[q], 1u);
+                                if ((int64_t)slot < p.stride) kq[slot] = ((u64)ordkey<METRIC>(dis) << 32) | pos;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int METRIC, int KIND, int PASS>
+static void lm_launch3(const IvfLmParams& p, int grid_blocks, hipStream_t stream) {
+    if (p.dpad == 128)
+        hipLaunchKernelGGL((ivf_lm_scan_kernel<METRIC, KIND, PASS, true>), dim3((unsigned)grid_blocks), dim3(LM_THREADS),
+                           LM_LDS_TOTAL, stream, p);
+    else
+        hipLaunchKernelGGL((ivf_lm_scan_kernel<METRIC, KIND, PASS, false>), dim3((unsigned)grid_blocks), dim3(LM_THREADS),
+                           LM_LDS_TOTAL, stream, p);
+}
+template <int METRIC, int KIND>
+static void lm_launch2(const IvfLmParams& p, int pass, int grid_blocks, hipStream_t stream) {
+    if (pass == 1) lm_launch3<METRIC, KIND, 1>(p, grid_blocks, stream);
+    else lm_launch3<METRIC, KIND, 2>(p, grid_blocks, stream);
+}
+void launch_ivf_lm_scan(const IvfLmParams& p, int pass, int grid_blocks, hipStream_t stream) {
+    if (p.nq == 0) return;
+    FA_THROW_IF_NOT(ivf_lm_supported(p.kind, p.dpad, p.M, p.d) && (pass == 1 || pass == 2) && grid_blocks > 0);
+    FA_THROW_IF_NOT(p.ldq % 4 == 0 && (p.kind != 0 || p.ldv % 4 == 0) && (p.kind != 1 || p.ldc % 4 == 0));
+    if (p.metric == METRIC_L2) {
+        if (p.kind == 0) lm_launch2<METRIC_L2, 0>(p, pass, grid_blocks, stream);
+        else lm_launch2<METRIC_L2, 1>(p, pass, grid_blocks, stream);
+    } else {
+        if (p.kind == 0) lm_launch2<METRIC_INNER_PRODUCT, 0>(p, pass, grid_blocks, stream);
+        else lm_launch2<METRIC_INNER_PRODUCT, 1>(p, pass, grid_blocks, stream);
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+} // namespace faiss_amd

@@ -230,6 +230,9 @@ struct SelectParams {
     // outputs, best first; padded with (-1, neutral distance)
     float* out_dis;   // [nq][k]
     int64_t* out_ids; // [nq][k]
+    // when set: only kth_out[q] = the ordkey (upper 32 bits) of the k-th smallest key is written (0xffffffff when the
+    // query has no more than k keys... then every key qualifies); nothing else is produced
+    uint32_t* kth_out; // [nq] or null
 };
 // Exact k-selection: MSB radix select on 64-bit keys + bitonic sort of the k winners by
 // (distance, label).  Replaces faiss/gpu/utils/BlockSelectKernel.cuh:15-132 and the
@@ -372,6 +375,77 @@ void launch_ivf_finish(const IvfFusedParams& p, hipStream_t stream);
 // does the problem fit the fused kernel (LDS budget, reservoir size)?  Returns cap / kp to use.
 bool ivf_fused_supported(int kind, int M, int dpad, int k, int nprobe, int* cap_out, int* kp_out, int* nlut_out);
 size_t ivf_fused_lds_bytes(int kind, int M, int dpad, int kp, int cap, int nprobe, int nlut);
+
+// ------------------------------------------------------------------ list-major IVF search (ivf_listmajor.hip, round 3)
+// Large batches: every inverted list is visited once per GROUP of the queries that probe it instead of once per
+// query.  A workgroup takes (list, up to 128 of its queries, up to rows_per_item of its rows), keeps the queries as
+// MFMA B operands in registers, streams the list's rows through LDS in 64-row tiles (IVFPQ: decoded there from the
+// codes, once per workgroup) and computes the 64 x 128 distance block on v_mfma_f32_32x32x2_f32 -- bit for bit the
+// k-ordered fmaf chain of the exact flat scan.  Two passes share the kernel:
+//   pass 1  the leading probes of every query (as many as it takes to see >= k rows): EVERY distance is written to the
+//           query's key segment at its scan position (no atomics); the k-th smallest key of the segment is an upper
+//           bound of the query's k-th best distance over all its probes (select_k_kernel with kth_out);
+//   pass 2  the remaining probes: rows at or below the bound are appended to the segment (one atomic per candidate).
+// The k best keys of the segment are the answer (select_k_kernel mode 1).  A segment that overflows is redone with
+// all probes in pass 1 (exact capacity).  SURVEY 7 H4; the reference scans query-major (IVFInterleaved.cuh:33-224,
+// PQScanMultiPassNoPrecomputed-inl.cuh:173-270).
+// Arithmetic (restated by oracle/faiss_oracle.c orc_ivf_search, arith = 1):
+//   IVFFlat  L2: max(0, fmaf(-2, <q, y>, |q|^2 + |y|^2)),  IP: <q, y>             (= the flat index's distances)
+//   IVFPQ    L2: max(0, fmaf(-2, <q - c, r^>, |q - c|^2 + |r^|^2)),  IP: <q, c> + <q, r^>   (r^ = decoded residual)
+//   <.,.> = the MFMA chain of flat_scan_kernel (orc_ip_chain); |y|^2, |r^|^2 sequential chains kept per stored row
+//   (arena_rn); |q - c|^2 = the sum of the two interleaved half chains a lane pair holds (orc_lm_residual_norm).
+struct IvfLmItem {
+    int bucket, qt, rt, pad;
+};
+constexpr int kLmQueriesPerItem = 128; // 4 waves x 32 queries
+struct IvfLmParams {
+    int metric;
+    int kind; // 0 = IVFFlat, 1 = IVFPQ
+    int nq, nprobe, d, dpad, nlist, k;
+    const float* xq; // [nq][ldq] padded queries
+    int64_t ldq;
+    const float* xqn;           // [nq] |q|^2, sequential chain (IVFFlat L2)
+    const int64_t* coarse_ids;  // [nq][nprobe]
+    const float* coarse_dis;    // [nq][nprobe] (IVFPQ IP: first term)
+    const uint32_t* list_len;   // [nlist]
+    const int64_t* list_start;  // [nlist]
+    // ---- plan, built on the device by launch_ivf_lm_plan
+    uint32_t* prefix;        // [nq][nprobe + 1] exclusive prefix of the probed lists' lengths = scan positions
+    uint32_t* p0;            // [nq] probes of pass 1
+    uint32_t* cnt;           // [nq] keys in the segment (after the plan: the pass-1 rows)
+    uint32_t* bucket_cnt;    // [2 nlist] pairs per (pass, list); zeroed by the plan launcher
+    uint32_t* bucket_fill;   // [2 nlist] cursors; zeroed by the plan launcher
+    uint32_t* bucket_start;  // [2 nlist + 1]
+    uint32_t* pairs;         // [nq * nprobe] pair = q * nprobe + p, grouped by bucket
+    IvfLmItem* items;        // [max_items], pass 1 first
+    uint32_t* item_bounds;   // [4] = 0, items of pass 1, all items, 1 if max_items was too small (a bug: the host checks)
+    int max_items;
+    int rows_per_item;       // multiple of 64
+    int force_all;           // every probe in pass 1
+    // ---- candidates
+    unsigned long long* keys; // [nq][stride]
+    int64_t stride;
+    uint32_t* thr;            // [nq] pass 2 admits ordkey(distance) <= thr
+    uint32_t* ovf;            // [1 + nq]: number of queries whose segment overflowed, then their numbers
+    // ---- storage
+    const float* arena_vecs; // IVFFlat rows [arena rows][ldv]
+    int64_t ldv;
+    const float* arena_rn;   // [arena rows] L2: squared norm of the stored (decoded) row, sequential chain
+    const uint8_t* arena_codes; // IVFPQ: rotated 64-row blocks (pq_code_offset)
+    int M, dsub;
+    const float* pq_centroids;  // [M][256][dsub]
+    const float* centroids;     // [nlist][ldc] coarse centroids
+    int64_t ldc;
+};
+bool ivf_lm_supported(int kind, int dpad, int M, int d);
+// prefix / p0 / cnt, the pairs grouped by (pass, list), the work items.  (4 launches + 1 memset)
+void launch_ivf_lm_plan(const IvfLmParams& p, hipStream_t stream);
+// pass = 1 or 2; grid_blocks workgroups walk the pass's items (a multiple of 8: consecutive items on one XCD)
+void launch_ivf_lm_scan(const IvfLmParams& p, int pass, int grid_blocks, hipStream_t stream);
+// cnt[q] > stride -> cnt[q] = stride, the query is listed in ovf
+void launch_ivf_lm_clamp(const IvfLmParams& p, hipStream_t stream);
+// out[dest[i]] = |x_i|^2 as the sequential fmaf chain of l2_norms_kernel, for dest[i] >= 0
+void launch_l2_norms_scatter(const float* x, int64_t ld, int64_t n, int d, const int64_t* dest, float* out, hipStream_t stream);
 
 // ------------------------------------------------------------------ IVF storage (round 2)
 // Every inverted list owns a row range [list_start, list_start + list_cap) of one arena, list_cap a multiple of

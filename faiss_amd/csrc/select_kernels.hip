@@ -122,6 +122,12 @@ __global__ void __launch_bounds__(SEL_THREADS) select_k_kernel(SelectParams p) {
         }
     }
     const u64 kth = sh->kth;
+    if (p.kth_out) {
+        // threshold-only use (list-major IVF scan): with fewer than k keys every distance qualifies
+        // (with exactly k keys the radix select did not run either: kth = ~0, a valid if loose bound)
+        if (tid == 0) p.kth_out[q] = (uint32_t)(kth >> 32);
+        return;
+    }
 
     // ---- gather winners (keys <= kth): exactly min(total, k) because keys are unique
     for (int i = tid; i < kp; i += SEL_THREADS) {

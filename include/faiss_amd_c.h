@@ -399,6 +399,20 @@ int faiss_amd_GpuIndexIVF_arena_stats(const FaissAmdIndex* index, int64_t* used_
  * of the fused LDS-resident scan; results are identical, the switch exists for cross-checks */
 int faiss_amd_GpuIndexIVF_set_use_fused_scan(FaissAmdIndex* index, int on);
 
+/* Which scan serves search() / search_preassigned() of an IVF index (no reference counterpart: the reference has one
+ * scan per index type, faiss/gpu/impl/IVFInterleaved.cuh:33-224, PQScanMultiPassNoPrecomputed-inl.cuh:173-270, both
+ * query-major).  0 = automatic: batches of >= 2048 queries that probe every list >= 8 times on average, without
+ * IDSelector, on IVFFlat / IVFPQ with d <= 128 take the list-major scan (faiss_amd/csrc/ivf_listmajor.hip: every list is
+ * read once per group of up to 128 of the queries probing it, distances on the f32 matrix pipe); 1 = query-major always;
+ * 2 = list-major always (an error where unsupported).  The two scans sum in different orders: each is bit-exact against
+ * its own restatement in oracle/faiss_oracle.c (orc_ivf_search_ex, arith 0 / 1), both within the 1e-4 relative tolerance
+ * of the reference.  scan_info: the mode set, the one the last search used (1 / 2), and how many queries so far had to
+ * be redone with an unbounded candidate segment. */
+int faiss_amd_GpuIndexIVF_set_scan_mode(FaissAmdIndex* index, int mode);
+int faiss_amd_GpuIndexIVF_scan_info(const FaissAmdIndex* index, int* mode, int* last_mode, int64_t* overflow_queries);
+/* *p_output = 1 when mode 0 sends a batch of n queries with this nprobe and k through the list-major scan */
+int faiss_amd_GpuIndexIVF_list_major_rule(const FaissAmdIndex* index, int64_t n, int nprobe, int64_t k, int* p_output);
+
 #ifdef __cplusplus
 }
 #endif

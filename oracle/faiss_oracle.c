@@ -349,11 +349,43 @@ static int orc_pq_lut_grid(float B, float* delta, float* inv) {
     return 1;
 }
 
+/* |x - c|^2 as the list-major scan holds it (faiss_amd/csrc/ivf_listmajor.hip): the two lanes that share a query own
+ * the coordinates 8 s + 4 h + e (h = 0 / 1), each keeps a sequential fmaf chain over its own, the two sums are added. */
+float orc_lm_residual_norm(const float* x, const float* c, int d) {
+    float acc[2] = {0.f, 0.f};
+    for (int h = 0; h < 2; h++)
+        for (int s = 0; s < d; s += 8)
+            for (int e = 0; e < 4; e++) {
+                const int k = s + 4 * h + e;
+                if (k < d) {
+                    const float v = x[k] - c[k];
+                    acc[h] = fmaf(v, v, acc[h]);
+                }
+            }
+    return acc[0] + acc[1];
+}
+
 /* kind: 0 = IVFFlat (codes are d floats), 1 = IVFPQ (codes are M bytes, 8 bits each).
- * coarse_D / coarse_I (nullable): receive the nprobe coarse results per query. */
+ * coarse_D / coarse_I (nullable): receive the nprobe coarse results per query.
+ * arith: which of the backend's two scans is restated -- 0 = the query-major kernels (ivf_fused.hip / ivf_kernels.hip),
+ * 1 = the list-major kernel of large batches (ivf_listmajor.hip), whose distances are MFMA dot products:
+ *   IVFFlat  L2 max(0, fmaf(-2, <x, y>, |x|^2 + |y|^2)), IP <x, y>      (exactly the flat index's distances)
+ *   IVFPQ    L2 max(0, fmaf(-2, <x - c, r^>, |x - c|^2 + |r^|^2)), IP <x, c> + <x, r^>   (r^ = decoded residual)
+ * with <.,.> = orc_ip_chain, |x|^2 |y|^2 |r^|^2 sequential chains, |x - c|^2 = orc_lm_residual_norm.  Both are
+ * restatements of the same reference computation (faiss/IndexIVFFlat.cpp, faiss/IndexIVFPQ.cpp) in another summation
+ * order; selection and tie rules are identical. */
+int orc_ivf_search_ex(int kind, int metric, int d, int nlist, const float* centroids, const uint32_t* list_sizes,
+                      const uint8_t* codes, const idx_t* ids, int M, const float* pq_centroids, idx_t nq,
+                      const float* xq, int nprobe, int k, float* D, idx_t* I, float* coarse_D, idx_t* coarse_I, int arith);
 int orc_ivf_search(int kind, int metric, int d, int nlist, const float* centroids, const uint32_t* list_sizes,
                    const uint8_t* codes, const idx_t* ids, int M, const float* pq_centroids, idx_t nq,
                    const float* xq, int nprobe, int k, float* D, idx_t* I, float* coarse_D, idx_t* coarse_I) {
+    return orc_ivf_search_ex(kind, metric, d, nlist, centroids, list_sizes, codes, ids, M, pq_centroids, nq, xq, nprobe, k, D,
+                             I, coarse_D, coarse_I, 0);
+}
+int orc_ivf_search_ex(int kind, int metric, int d, int nlist, const float* centroids, const uint32_t* list_sizes,
+                      const uint8_t* codes, const idx_t* ids, int M, const float* pq_centroids, idx_t nq,
+                      const float* xq, int nprobe, int k, float* D, idx_t* I, float* coarse_D, idx_t* coarse_I, int arith) {
     if (k < 1 || nprobe < 1) return -1;
     if (nprobe > nlist) nprobe = nlist;
     const int dsub = kind == 1 ? d / M : 0;
@@ -379,6 +411,9 @@ int orc_ivf_search(int kind, int metric, int d, int nlist, const float* centroid
         idx_t* pos2id = (idx_t*)malloc(sizeof(idx_t) * (ncand ? ncand : 1));
         cand_t* st = (cand_t*)malloc(sizeof(cand_t) * (size_t)k);
         float* lut = kind == 1 ? (float*)malloc(sizeof(float) * (size_t)M * 256) : NULL;
+        float* rhat = (kind == 1 && arith == 1) ? (float*)malloc(sizeof(float) * (size_t)d) : NULL;
+        float* xres = (kind == 1 && arith == 1) ? (float*)malloc(sizeof(float) * (size_t)d) : NULL;
+        const float xnorm = arith == 1 ? orc_norm_l2sqr(x, d) : 0.f;
         int lut_ready = 0;
         topk_t t;
         topk_init(&t, st, k, metric);
@@ -389,8 +424,16 @@ int orc_ivf_search(int kind, int metric, int d, int nlist, const float* centroid
             const uint8_t* lc = codes + (size_t)list_start[l] * code_size;
             const idx_t* lid = ids + list_start[l];
             const uint32_t len = list_sizes[l];
-            float dis0 = 0.f;
-            if (kind == 1) {
+            float dis0 = 0.f, rqn = 0.f;
+            if (kind == 1 && arith == 1) {
+                /* list-major: residual query against this list's centroid (L2), coarse term (IP) */
+                const float* cen = centroids + (size_t)l * d;
+                if (metric == ORC_METRIC_L2) {
+                    for (int j = 0; j < d; j++) xres[j] = x[j] - cen[j];
+                    rqn = orc_lm_residual_norm(x, cen, d);
+                }
+                dis0 = cD[(size_t)q * nprobe + p];
+            } else if (kind == 1) {
                 /* lookup table of the QUERY (both metrics): tab[m][c] = <x_m, pq[m][c]> as an fmaf chain, rounded to
                  * the query's power-of-two grid (orc_pq_lut_grid = faiss_amd/csrc/kernels.h pq_lut_grid); dis0 = the
                  * coarse distance of (query, list).  L2 uses the term decomposition of the reference CPU index
@@ -429,7 +472,16 @@ int orc_ivf_search(int kind, int metric, int d, int nlist, const float* centroid
             }
             for (uint32_t i = 0; i < len; i++) {
                 float dis;
-                if (kind == 0) {
+                if (arith == 1 && kind == 0) {
+                    const float* y = (const float*)(lc + (size_t)i * code_size);
+                    dis = flat_dis(metric, orc_ip_chain(x, y, d), xnorm, orc_norm_l2sqr(y, d));
+                } else if (arith == 1) {
+                    const uint8_t* code = lc + (size_t)i * code_size;
+                    for (int m = 0; m < M; m++)
+                        memcpy(rhat + (size_t)m * dsub, pq_centroids + ((size_t)m * 256 + code[m]) * dsub, sizeof(float) * dsub);
+                    if (metric == ORC_METRIC_L2) dis = flat_dis(ORC_METRIC_L2, orc_ip_chain(xres, rhat, d), rqn, orc_norm_l2sqr(rhat, d));
+                    else dis = dis0 + orc_ip_chain(x, rhat, d);
+                } else if (kind == 0) {
                     /* summation order of the GPU scan: eight lanes share a row, lane j owns the 4-float chunks
                      * j, j+8, j+16, ... (one coalesced 128-byte segment per load instruction) and keeps a
                      * sequential fmaf chain over them; the eight partial sums meet in an xor butterfly.
@@ -487,6 +539,8 @@ int orc_ivf_search(int kind, int metric, int d, int nlist, const float* centroid
         free(pos2id);
         free(st);
         free(lut);
+        free(rhat);
+        free(xres);
     }
     free(cD);
     free(cI);

@@ -106,7 +106,9 @@ class Oracle:
         return D, I
 
     @classmethod
-    def ivf_search(cls, kind, metric, centroids, list_sizes, codes, ids, xq, nprobe, k, M=0, pq=None):
+    def ivf_search(cls, kind, metric, centroids, list_sizes, codes, ids, xq, nprobe, k, M=0, pq=None, arith=0):
+        """arith: 0 = the query-major scans, 1 = the list-major scan of large batches (faiss_oracle.c orc_ivf_search_ex;
+        GpuIndexIVF.last_scan_mode() - 1 says which one served a search)"""
         centroids, xq = _f32(centroids), _f32(xq)
         nlist, d = centroids.shape
         ls = np.ascontiguousarray(list_sizes, dtype=np.uint32)
@@ -119,10 +121,11 @@ class Oracle:
         np_eff = min(nprobe, nlist)
         cD = np.empty((nq, np_eff), dtype=np.float32)
         cI = np.empty((nq, np_eff), dtype=np.int64)
-        rc = cls.lib().orc_ivf_search(ctypes.c_int(kind), ctypes.c_int(metric), ctypes.c_int(d),
-                                      ctypes.c_int(nlist), _p(centroids), _p(ls), _p(codes), _p(ids),
-                                      ctypes.c_int(M), _p(pqc), ctypes.c_int64(nq), _p(xq),
-                                      ctypes.c_int(nprobe), ctypes.c_int(k), _p(D), _p(I), _p(cD), _p(cI))
+        rc = cls.lib().orc_ivf_search_ex(ctypes.c_int(kind), ctypes.c_int(metric), ctypes.c_int(d),
+                                         ctypes.c_int(nlist), _p(centroids), _p(ls), _p(codes), _p(ids),
+                                         ctypes.c_int(M), _p(pqc), ctypes.c_int64(nq), _p(xq),
+                                         ctypes.c_int(nprobe), ctypes.c_int(k), _p(D), _p(I), _p(cD), _p(cI),
+                                         ctypes.c_int(arith))
         assert rc == 0
         return D, I, cD, cI
 

@@ -1,0 +1,210 @@
+"""GPU parity tests of the list-major IVF scan (faiss_amd/csrc/ivf_listmajor.hip, round 3): large batches visit every
+inverted list once per group of the queries probing it and compute the distances on the f32 matrix pipe.
+
+Contract (the same as for every other scan): distances and labels BIT-IDENTICAL to the CPU restatement of the kernel's
+arithmetic (oracle/faiss_oracle.c orc_ivf_search_ex, arith = 1 -- itself pinned on the reference's golden outputs by
+tests/test_oracle_cpu.py::test_ivf_list_major_restatement_vs_golden*), and within the north-star tolerance of the
+query-major scan / the reference (labels identical outside near-tie groups, distances <= 1e-4 relative).
+Reference being replaced: faiss/gpu/impl/IVFInterleaved.cuh:33-224, PQScanMultiPassNoPrecomputed-inl.cuh:173-270."""
+import numpy as np
+import pytest
+
+import faiss_amd
+from compare import check_knn
+from oracle.pyoracle import METRIC_INNER_PRODUCT, METRIC_L2, Oracle, synthetic_dataset
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(res, kind, metric, d, M, nlist, xt, xb, seed=7):
+    cent, _ = faiss_amd.kmeans(res, xt, nlist, niter=4, seed=3)
+    pq = None
+    if kind == 0:
+        idx = faiss_amd.GpuIndexIVFFlat(res, d, nlist, metric)
+    else:
+        idx = faiss_amd.GpuIndexIVFPQ(res, d, nlist, M, 8, metric)
+        pq = (np.random.RandomState(seed).rand(M, 256, d // M).astype("float32") - 0.5) * 0.4
+        idx.copy_pq_centroids(pq)
+    idx.copy_centroids(cent)
+    idx.add(xb)
+    return idx, cent, pq
+
+
+@pytest.mark.parametrize("kind,metric,d,M,nlist,nb,nq,nprobe,k", [
+    (0, METRIC_L2, 128, 0, 64, 40000, 1500, 8, 100),            # dpad = 128: the fully unrolled instantiation
+    (0, METRIC_INNER_PRODUCT, 128, 0, 64, 40000, 700, 8, 10),
+    (0, METRIC_L2, 40, 0, 16, 9000, 300, 16, 7),                # dpad < 128, every list probed, ragged tiles
+    (0, METRIC_L2, 72, 0, 8, 20000, 1100, 2, 1000),             # lists of ~2500 rows: several row chunks per list, big k
+    (0, METRIC_INNER_PRODUCT, 64, 0, 32, 5000, 130, 5, 2048),   # k above the rows many queries see
+    (1, METRIC_L2, 128, 64, 64, 40000, 1500, 8, 100),           # bench shape: M = 64, dsub = 2
+    (1, METRIC_INNER_PRODUCT, 128, 64, 64, 40000, 1100, 8, 10),
+    (1, METRIC_L2, 64, 16, 32, 30000, 400, 32, 600),            # dsub = 4, every list probed
+    (1, METRIC_L2, 96, 12, 16, 5000, 1200, 5, 2048),            # dsub = 8, code chunks of 4 bytes
+    (1, METRIC_L2, 32, 32, 8, 3000, 1030, 3, 5),                # dsub = 1
+    (1, METRIC_INNER_PRODUCT, 36, 4, 16, 6000, 257, 4, 20),     # d = 36 -> dpad = 40: zero padding of the decoded tile, dsub = 9
+])
+def test_list_major_scan_matches_oracle_and_query_major(res, kind, metric, d, M, nlist, nb, nq, nprobe, k):
+    xt, xb, xq = synthetic_dataset(d, 4000, nb, nq, seed=nb + k)
+    idx, cent, pq = _build(res, kind, metric, d, M, nlist, xt, xb)
+    idx.nprobe = nprobe
+    idx.set_scan_mode(idx.SCAN_QUERY_MAJOR)
+    D0, I0 = idx.search(xq, k)
+    assert idx.scan_info()[1] == 1
+    idx.set_scan_mode(idx.SCAN_LIST_MAJOR)
+    D, I = idx.search(xq, k)
+    assert idx.scan_info()[1] == 2 and idx.last_scan_arith() == 1
+    # the two scans agree to rounding
+    check_knn(D, I, D0, I0, rtol=1e-4, name="list-major vs query-major")
+    sel = np.r_[0:min(nq, 48)]
+    sizes, codes, ids, _ = Oracle.build_ivf_lists(kind, metric, cent, xb, pq=pq)
+    Do, Io, _, _ = Oracle.ivf_search(kind, metric, cent, sizes, codes, ids, xq[sel], nprobe, k, M=M, pq=pq, arith=1)
+    check_knn(D[sel], I[sel], Do, Io, exact=True, name="list-major vs oracle")
+    # run to run: the order in which workgroups append candidates never shows
+    D2, I2 = idx.search(xq, k)
+    assert np.array_equal(D, D2) and np.array_equal(I, I2)
+
+
+def test_list_major_independent_of_batch_composition(res):
+    """A query's result does not depend on which other queries share its batch (tiles, item order, pass-1 / pass-2 split
+    of the lists all change with the batch)."""
+    d, nlist, nb, k = 64, 32, 20000, 30
+    xt, xb, xq = synthetic_dataset(d, 4000, nb, 900, seed=11)
+    idx, _, _ = _build(res, 0, METRIC_L2, d, 0, nlist, xt, xb)
+    idx.nprobe = 6
+    idx.set_scan_mode(idx.SCAN_LIST_MAJOR)
+    D, I = idx.search(xq, k)
+    D1, I1 = idx.search(xq[100:137], k)
+    assert np.array_equal(D1, D[100:137]) and np.array_equal(I1, I[100:137])
+    perm = np.random.RandomState(0).permutation(len(xq))
+    D2, I2 = idx.search(xq[perm], k)
+    assert np.array_equal(D2, D[perm]) and np.array_equal(I2, I[perm])
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_list_major_overflow_rerun_is_exact(res, kind):
+    """Adversarial layout for the pass-1 bound: the nearest list of every query holds exactly k rows that are FAR away,
+    the next two lists hold 6000 rows each that are all closer -- more candidates than a segment has room for
+    (k + longest list + 1024).  Those queries are redone with every probe in pass 1; the answer is still the oracle's
+    bit for bit."""
+    d, k, nlist = 32, 4, 4
+    rs = np.random.RandomState(3)
+    cent = np.zeros((nlist, d), "float32")
+    cent[:, 0] = [0.0, 10.0, 20.0, 30.0]
+    xq = np.zeros((40, d), "float32")       # queries sit on centroid 0
+    xq[:, 1] = rs.rand(40) * 0.01
+    far = np.zeros((k, d), "float32")       # list 0: |far - q|^2 ~ 900
+    far[:, 2] = 30.0 + rs.rand(k)
+    near1 = np.zeros((6000, d), "float32")  # list 1 (4.95 from centroid 1, 5.05 from centroid 0): |near1 - q|^2 ~ 25.5
+    near1[:, 0] = 5.05 + rs.rand(6000) * 0.01
+    near2 = np.zeros((6000, d), "float32")  # list 2: |near2 - q|^2 ~ 226
+    near2[:, 0] = 15.05 + rs.rand(6000) * 0.01
+    xb = np.concatenate([far, near1, near2]).astype("float32")
+    M = 8
+    if kind == 0:
+        idx = faiss_amd.GpuIndexIVFFlat(res, d, nlist, METRIC_L2)
+        pq = None
+    else:
+        idx = faiss_amd.GpuIndexIVFPQ(res, d, nlist, M, 8, METRIC_L2)
+        pq = (np.random.RandomState(7).rand(M, 256, d // M).astype("float32") - 0.5) * 0.02
+        idx.copy_pq_centroids(pq)
+    idx.copy_centroids(cent)
+    idx.add(xb)
+    sizes = [idx.get_list_size(l) for l in range(nlist)]
+    assert sizes[0] == k and sizes[1] == 6000 and sizes[2] == 6000
+    idx.nprobe = 3
+    idx.set_scan_mode(idx.SCAN_LIST_MAJOR)
+    before = idx.scan_info()[2]
+    D, I = idx.search(xq, k)
+    if kind == 0:
+        assert idx.scan_info()[2] - before == len(xq), "the overflow path was not exercised"
+    sz, codes, ids, _ = Oracle.build_ivf_lists(kind, METRIC_L2, cent, xb, pq=pq)
+    Do, Io, _, _ = Oracle.ivf_search(kind, METRIC_L2, cent, sz, codes, ids, xq, 3, k, M=M if kind else 0, pq=pq, arith=1)
+    check_knn(D, I, Do, Io, exact=True, name="overflow rerun vs oracle")
+
+
+def test_list_major_edge_cases(res):
+    """empty lists, probes without a list (-1), a NaN query, fewer than k rows in all probed lists, search_preassigned"""
+    d, nlist, k = 24, 16, 12
+    xt, xb, xq = synthetic_dataset(d, 2000, 3000, 64, seed=2)
+    idx, cent, _ = _build(res, 0, METRIC_L2, d, 0, nlist, xt, xb[:1])  # one stored row: 15 of 16 lists empty
+    idx.nprobe = 4
+    idx.set_scan_mode(idx.SCAN_LIST_MAJOR)
+    D, I = idx.search(xq, k)
+    sizes, codes, ids, _ = Oracle.build_ivf_lists(0, METRIC_L2, cent, xb[:1])
+    Do, Io, _, _ = Oracle.ivf_search(0, METRIC_L2, cent, sizes, codes, ids, xq, 4, k, arith=1)
+    check_knn(D, I, Do, Io, exact=True, name="nearly empty index")
+    idx.add(xb[1:])
+    xqn = xq.copy()
+    xqn[5, 3] = np.nan
+    D, I = idx.search(xqn, k)
+    sizes, codes, ids, _ = Oracle.build_ivf_lists(0, METRIC_L2, cent, xb)
+    Do, Io, cD, cI = Oracle.ivf_search(0, METRIC_L2, cent, sizes, codes, ids, xqn, 4, k, arith=1)
+    keep = np.r_[0:5, 6:len(xq)]
+    check_knn(D[keep], I[keep], Do[keep], Io[keep], exact=True, name="batch with a NaN query")
+    assert (I[5] == -1).all()
+    # preassigned: the caller's lists, some of them -1
+    assign = cI.copy()
+    assign[5] = 0
+    assign[::3, 1] = -1
+    cdis = cD.copy()
+    cdis[5] = 0
+    Dp, Ip = idx.search_preassigned(xq, k, assign, cdis)
+    idx.set_scan_mode(idx.SCAN_QUERY_MAJOR)
+    Dq, Iq = idx.search_preassigned(xq, k, assign, cdis)
+    check_knn(Dp, Ip, Dq, Iq, rtol=1e-4, name="preassigned, list-major vs query-major")
+
+
+def test_scan_mode_rule_and_refusals(res):
+    d, nlist = 32, 64
+    xt, xb, xq = synthetic_dataset(d, 3000, 8000, 2100, seed=4)
+    idx, _, _ = _build(res, 0, METRIC_L2, d, 0, nlist, xt, xb)
+    idx.nprobe = 8
+    assert idx.scan_info()[0] == 0
+    assert idx.list_major_rule(2100, 8, 10) and not idx.list_major_rule(2047, 8, 10) and not idx.list_major_rule(100, 64, 10)
+    D, I = idx.search(xq, 10)
+    assert idx.scan_info()[1] == 2  # 2100 queries x 8 probes over 64 lists: automatic list-major
+    D1, I1 = idx.search(xq[:500], 10)
+    assert idx.scan_info()[1] == 1
+    check_knn(D[:500], I[:500], D1, I1, rtol=1e-4, name="automatic list-major vs query-major")
+    with pytest.raises(faiss_amd.FaissAmdError):
+        idx.set_scan_mode(3)
+    idx.set_scan_mode(idx.SCAN_LIST_MAJOR)
+    with pytest.raises(faiss_amd.FaissAmdError, match="IDSelector"):
+        idx.search(xq[:10], 5, params=faiss_amd.SearchParameters(sel=faiss_amd.IDSelectorRange(0, 100)))
+    big = faiss_amd.GpuIndexIVFFlat(res, 136, 8, METRIC_L2)  # d > 128: not served by the list-major kernel
+    big.set_scan_mode(big.SCAN_LIST_MAJOR)
+    big.copy_centroids(np.random.RandomState(0).rand(8, 136).astype("float32"))
+    big.add(np.random.RandomState(1).rand(100, 136).astype("float32"))
+    with pytest.raises(faiss_amd.FaissAmdError, match="not supported"):
+        big.search(np.zeros((3, 136), "float32"), 2)
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_list_major_after_incremental_adds_and_copied_lists(res, kind):
+    """the per-row norms the scan needs follow the rows through list growth / relocation / compaction and bulk loads"""
+    d, nlist, nb, nq, k, M = 64, 32, 30000, 300, 20, 16
+    xt, xb, xq = synthetic_dataset(d, 4000, nb, nq, seed=9)
+    idx, cent, pq = _build(res, kind, METRIC_L2, d, M, nlist, xt, xb[:100])
+    for a, b in ((100, 150), (150, 4000), (4000, 4100), (4100, 30000)):
+        idx.add(xb[a:b])
+    idx.nprobe = 7
+    idx.set_scan_mode(idx.SCAN_LIST_MAJOR)
+    D, I = idx.search(xq, k)
+    sizes, codes, ids, _ = Oracle.build_ivf_lists(kind, METRIC_L2, cent, xb, pq=pq)
+    Do, Io, _, _ = Oracle.ivf_search(kind, METRIC_L2, cent, sizes, codes, ids, xq, 7, k, M=M if kind else 0, pq=pq, arith=1)
+    check_knn(D, I, Do, Io, exact=True, name="after incremental adds")
+    # bulk load of the same lists into a fresh index (copyFrom path)
+    if kind == 0:
+        idx2 = faiss_amd.GpuIndexIVFFlat(res, d, nlist, METRIC_L2)
+    else:
+        idx2 = faiss_amd.GpuIndexIVFPQ(res, d, nlist, M, 8, METRIC_L2)
+        idx2.copy_pq_centroids(pq)
+    idx2.copy_centroids(cent)
+    idx2.copy_lists(sizes, codes, ids)
+    idx2.nprobe = 7
+    idx2.set_scan_mode(idx2.SCAN_LIST_MAJOR)
+    D2, I2 = idx2.search(xq, k)
+    assert np.array_equal(D, D2) and np.array_equal(I, I2)
+    freed = idx.reclaimMemory()  # compaction moves every list
+    D3, I3 = idx.search(xq, k)
+    assert freed >= 0 and np.array_equal(D, D3) and np.array_equal(I, I3)

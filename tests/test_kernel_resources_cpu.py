@@ -14,7 +14,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "faiss_amd", "csrc")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-FILES = ["flat_filter.hip", "flat_kernels.hip", "ivf_fused.hip", "ivf_kernels.hip", "select_kernels.hip",
+FILES = ["flat_filter.hip", "flat_kernels.hip", "ivf_fused.hip", "ivf_kernels.hip", "ivf_listmajor.hip", "select_kernels.hip",
          "selector_kernels.hip"]
 
 
@@ -94,3 +94,11 @@ def test_exact_scan_and_helpers(usage):
                 "flat_general_kernel"):
         for name, u in _pick(usage, sub).items():
             assert u["scratch"] == 0, (name, u)
+
+
+def test_list_major_scan(usage):
+    """three 4-wave workgroups per CU (168 registers), nothing in scratch"""
+    picked = _pick(usage, "ivf_lm_scan_kernel")
+    assert len(picked) == 16
+    for name, u in picked.items():
+        assert u["scratch"] == 0 and u["occupancy"] >= 3, (name, u)
