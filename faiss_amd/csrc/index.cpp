@@ -2149,6 +2149,9 @@ void GpuIndexIVF::search_core_body_(idx_t n, const float* x, idx_t k, float* dis
 // ---------------------------------------------------------------------- list-major search (ivf_listmajor.hip)
 bool GpuIndexIVF::list_major_rule(idx_t n, int nprobe_now, idx_t k, bool has_selector) const {
     if (has_selector || !lm_capable_()) return false;
+    // IVFPQ: the list-major kernel decodes the codes through gathers from the codebook in L2, which costs more than the
+    // matrix work it feeds (profiles/r03_b_*): opt-in (scan_mode 2) until the decode runs from LDS
+    if (fused_kind_() != 0) return false;
     const int64_t np = std::min<int64_t>(nprobe_now, nlist);
     return n >= 2048 && (int64_t)n * np >= (int64_t)8 * nlist && k <= kMaxSelectionK;
 }
@@ -2160,22 +2163,31 @@ void GpuIndexIVF::search_listmajor_(int ni, const float* xq_pad, const idx_t* c_
     const GpuResources& R = *res_;
     uint32_t max_len = 1;
     for (auto l : list_len_) max_len = std::max(max_len, l);
-    // segment of a query: the rows of pass 1 (fewer than k + the longest list) + room for the candidates of pass 2;
-    // with every probe in pass 1 (overflow rerun): all probed rows
-    const int64_t cap2 = std::max<int64_t>(1024, 4 * (int64_t)k);
-    const int64_t stride = force_all ? std::max<int64_t>((int64_t)np * max_len, k) : (int64_t)k + max_len + cap2;
+    // Probes of pass 1: enough to see k rows, and at least min_p1 -- chosen so that a list meets ~16 of them (half a
+    // 32-query MFMA block: pass 1 then costs one sweep of the lists' first row chunks whatever min_p1 is), at most 8 and
+    // at most half of the probes.
+    const char* p1_env = getenv("FAISS_AMD_LM_P1"); // tuning experiments
+    int min_p1 = (int)std::min<int64_t>(8, std::max<int64_t>(1, (16 * (int64_t)nlist + ni / 2) / std::max(ni, 1)));
+    min_p1 = std::max(1, std::min(min_p1, np / 2));
+    if (p1_env) min_p1 = std::max(1, std::min(np, atoi(p1_env)));
+    // segment of a query: the rows of pass 1 (first row chunk of its lists: fewer than k + one chunk, or min_p1 chunks) +
+    // room for the candidates of pass 2; with every probe in pass 1 (overflow rerun): all probed rows
+    const int64_t chunk_rows = std::min<int64_t>(max_len, kLmRowsPerItem);
+    const int64_t cap2 = std::max<int64_t>(2048, 4 * (int64_t)k);
+    const int64_t stride = force_all ? std::max<int64_t>((int64_t)np * max_len, k)
+                                     : std::max<int64_t>((int64_t)k + chunk_rows, (int64_t)min_p1 * chunk_rows) + cap2;
     const int64_t fit = std::max<int64_t>(1, (int64_t)(R.temp_budget_bytes / ((size_t)stride * 8)));
     for (int c0 = 0; c0 < ni; c0 += (int)std::min<int64_t>(fit, ni)) {
         const int cn = (int)std::min<int64_t>(fit, ni - c0);
         search_listmajor_chunk_(cn, xq_pad + (size_t)c0 * dpad_, c_ids + (size_t)c0 * np, c_dis + (size_t)c0 * np, np, k,
-                                dD + (size_t)c0 * k, dI + (size_t)c0 * k, force_all, stride, max_len);
+                                dD + (size_t)c0 * k, dI + (size_t)c0 * k, force_all, stride, min_p1);
     }
 }
 
 void GpuIndexIVF::search_listmajor_chunk_(int ni, const float* xq_pad, const idx_t* c_ids, const float* c_dis, int np, int k,
-                                          float* dD, idx_t* dI, bool force_all, int64_t stride, uint32_t max_len) const {
+                                          float* dD, idx_t* dI, bool force_all, int64_t stride, int min_p1) const {
     const GpuResources& R = *res_;
-    const int RT = 1024; // rows of a list per work item (16 tiles)
+    const int RT = kLmRowsPerItem; // rows of a list per work item (16 tiles)
     // upper bound of the work items: sum over (pass, list) of ceil(pairs / 128) * ceil(len / RT)
     int64_t sum_nrt = 0, nrt_max = 1;
     for (auto l : list_len_) {
@@ -2202,7 +2214,7 @@ void GpuIndexIVF::search_listmajor_chunk_(int ni, const float* xq_pad, const idx
     P.list_len = d_list_len_.as<uint32_t>();
     P.list_start = d_list_start_.as<int64_t>();
     fill_lm_(P);
-    lm_prefix_.ensure((size_t)ni * (np + 1) * 4);
+    lm_prefix_.ensure((size_t)ni * (np + 1) * 4 * 2);
     lm_p0_.ensure((size_t)ni * 4);
     lm_cnt_.ensure((size_t)ni * 4);
     lm_bucket_.ensure((size_t)4 * nlist * 4);
@@ -2215,6 +2227,7 @@ void GpuIndexIVF::search_listmajor_chunk_(int ni, const float* xq_pad, const idx
     lm_ovf_.ensure((size_t)(ni + 1) * 4);
     if (!h_lm_) HIP_CHECK(hipHostMalloc((void**)&h_lm_, 64, hipHostMallocDefault));
     P.prefix = lm_prefix_.as<uint32_t>();
+    P.prefix1 = P.prefix + (size_t)ni * (np + 1);
     P.p0 = lm_p0_.as<uint32_t>();
     P.cnt = lm_cnt_.as<uint32_t>();
     P.bucket_cnt = lm_bucket_.as<uint32_t>();
@@ -2226,6 +2239,9 @@ void GpuIndexIVF::search_listmajor_chunk_(int ni, const float* xq_pad, const idx
     P.max_items = (int)max_items;
     P.rows_per_item = RT;
     P.force_all = force_all ? 1 : 0;
+    const char* dbg_env = getenv("FAISS_AMD_LM_DBG"); // timing experiments only (results are wrong)
+    P.min_p1 = min_p1;
+    P.dbg = dbg_env ? atoi(dbg_env) : 0;
     P.keys = lm_keys_.as<unsigned long long>();
     P.stride = stride;
     P.thr = lm_thr_.as<uint32_t>();
@@ -2259,8 +2275,10 @@ void GpuIndexIVF::search_listmajor_chunk_(int ni, const float* xq_pad, const idx
             SpanGuard sg(&R, "ivf_lm_threshold");
             sp.mode = 0;
             sp.kth_out = P.thr;
+            sp.cnt_out = P.cnt; // the segment keeps only what can still win: pass 2 appends behind k keys
             launch_select_k(sp, R.stream);
             sp.kth_out = nullptr;
+            sp.cnt_out = nullptr;
         }
         HIP_CHECK(hipMemsetAsync(P.ovf, 0, 4, R.stream));
         {

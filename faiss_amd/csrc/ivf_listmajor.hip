@@ -45,88 +45,112 @@ __global__ void lm_plan_kernel(IvfLmParams p) {
     const int np = p.nprobe;
     const int64_t* ids = p.coarse_ids + (int64_t)q * np;
     uint32_t* pre = p.prefix + (int64_t)q * (np + 1);
-    uint32_t cum = 0;
+    uint32_t* pre1 = p.prefix1 + (int64_t)q * (np + 1);
+    // pass 1 sees the first rows_per_item rows of a list (its first row chunk); the rest of a longer list waits for
+    // pass 2 like the lists of the later probes
+    const uint32_t r1max = p.force_all ? 0xffffffffu : (uint32_t)p.rows_per_item;
+    uint32_t cum = 0, cum1 = 0;
     int p0 = np;
     for (int pr = 0; pr < np; ++pr) {
         const int64_t l = ids[pr];
         const uint32_t len = l >= 0 ? p.list_len[l] : 0u;
         pre[pr] = cum;
+        pre1[pr] = cum1;
         cum += len;
-        if (p0 == np && cum >= (uint32_t)p.k) p0 = pr + 1;
+        cum1 += min(len, r1max);
+        if (p0 == np && cum1 >= (uint32_t)p.k) p0 = pr + 1;
     }
     pre[np] = cum;
+    pre1[np] = cum1;
+    // at least min_p1 probes in pass 1: the k-th best of the nearest FEW lists is a far tighter bound than that of the
+    // nearest one alone (a query near a cell border finds most of its neighbours next door)
+    if (p0 < p.min_p1) p0 = min(np, p.min_p1);
     if (p.force_all) p0 = np;
     p.p0[q] = (uint32_t)p0;
-    p.cnt[q] = pre[p0];
+    p.cnt[q] = pre1[p0];
     for (int pr = 0; pr < np; ++pr) {
         const int64_t l = ids[pr];
         if (l >= 0 && p.list_len[l] > 0) atomicAdd(&p.bucket_cnt[(int)l + (pr >= p0 ? p.nlist : 0)], 1u);
     }
 }
 
-// one workgroup: bucket_start = exclusive scan of bucket_cnt; items of bucket b = query groups x row chunks, listed
-// bucket by bucket (pass 1 = buckets [0, nlist) first), row chunk by row chunk, query group innermost (consecutive
-// items share their rows)
+// one workgroup: bucket_start = exclusive scan of bucket_cnt; work items.  Bucket b < nlist holds the pass-1 pairs of
+// list b, bucket nlist + l the other pairs of list l.  Pass 1 runs (pass-1 bucket, row chunk 0); pass 2 runs every row
+// chunk of the other buckets and the row chunks 1.. of the pass-1 buckets (lists longer than a chunk).  Items are listed
+// pass 1 first, bucket by bucket, row chunk by row chunk, query group innermost (consecutive items share their rows).
 __global__ void __launch_bounds__(1024) lm_items_kernel(IvfLmParams p) {
     __shared__ uint32_t part_pairs[1024];
-    __shared__ uint32_t part_items[1024];
-    __shared__ uint32_t bounds[2];
+    __shared__ uint32_t part_i1[1024];
+    __shared__ uint32_t part_i2[1024];
+    __shared__ uint32_t tot[2];
     const int t = threadIdx.x;
     const int n = 2 * p.nlist;
     const int per = (n + 1023) / 1024;
     const int a = min(n, t * per), b = min(n, a + per);
-    auto items_of = [&](int bk) -> uint32_t {
+    auto shape = [&](int bk, int& nqt, int& nrt) {
         const uint32_t c = p.bucket_cnt[bk];
-        if (c == 0) return 0u;
         const uint32_t len = p.list_len[bk >= p.nlist ? bk - p.nlist : bk];
-        return ((c + kLmQueriesPerItem - 1) / kLmQueriesPerItem) * ((len + p.rows_per_item - 1) / p.rows_per_item);
+        nqt = (int)((c + kLmQueriesPerItem - 1) / kLmQueriesPerItem);
+        nrt = p.force_all ? 1 : (int)((len + p.rows_per_item - 1) / p.rows_per_item);
     };
-    uint32_t sp = 0, si = 0;
+    // (force_all: one item takes all rows of its list: the redo of a few queries is not worth balancing)
+    uint32_t sp = 0, s1 = 0, s2 = 0;
     for (int i = a; i < b; ++i) {
+        int nqt, nrt;
+        shape(i, nqt, nrt);
         sp += p.bucket_cnt[i];
-        si += items_of(i);
+        if (i < p.nlist) {
+            s1 += nqt;
+            s2 += nqt * (nrt - (nqt ? 1 : 0));
+        } else {
+            s2 += nqt * nrt;
+        }
     }
     part_pairs[t] = sp;
-    part_items[t] = si;
+    part_i1[t] = s1;
+    part_i2[t] = s2;
     __syncthreads();
     if (t == 0) {
-        uint32_t rp = 0, ri = 0;
+        uint32_t rp = 0, r1 = 0, r2 = 0;
         for (int i = 0; i < 1024; ++i) {
-            const uint32_t vp = part_pairs[i], vi = part_items[i];
+            const uint32_t vp = part_pairs[i], v1 = part_i1[i], v2 = part_i2[i];
             part_pairs[i] = rp;
-            part_items[i] = ri;
+            part_i1[i] = r1;
+            part_i2[i] = r2;
             rp += vp;
-            ri += vi;
+            r1 += v1;
+            r2 += v2;
         }
         p.bucket_start[n] = rp;
-        bounds[1] = ri;
+        tot[0] = r1;
+        tot[1] = r2;
     }
     __syncthreads();
-    uint32_t rp = part_pairs[t], ri = part_items[t];
+    uint32_t rp = part_pairs[t], i1 = part_i1[t], i2 = tot[0] + part_i2[t];
+    auto put = [&](uint32_t at, int bk, int qt, int rt) {
+        if (at < (uint32_t)p.max_items) p.items[at] = IvfLmItem{bk, qt, rt, 0};
+    };
     for (int i = a; i < b; ++i) {
         p.bucket_start[i] = rp;
-        if (i == p.nlist) bounds[0] = ri; // (nlist < n: exactly one thread owns bucket nlist)
-        const uint32_t c = p.bucket_cnt[i];
-        if (c) {
-            const uint32_t len = p.list_len[i >= p.nlist ? i - p.nlist : i];
-            const int nqt = (int)((c + kLmQueriesPerItem - 1) / kLmQueriesPerItem);
-            const int nrt = (int)((len + p.rows_per_item - 1) / p.rows_per_item);
+        int nqt, nrt;
+        shape(i, nqt, nrt);
+        if (nqt) {
             for (int rt = 0; rt < nrt; ++rt)
                 for (int qt = 0; qt < nqt; ++qt) {
-                    if (ri < (uint32_t)p.max_items) p.items[ri] = IvfLmItem{i, qt, rt, 0};
-                    ++ri;
+                    if (i < p.nlist && rt == 0) put(i1++, i, qt, rt);
+                    else put(i2++, i, qt, rt);
                 }
         }
-        rp += c;
+        rp += p.bucket_cnt[i];
     }
-    __syncthreads();
     if (t == 0) {
+        const uint32_t all = tot[0] + tot[1];
         p.item_bounds[0] = 0;
-        p.item_bounds[1] = min(bounds[0], (uint32_t)p.max_items);
-        p.item_bounds[2] = min(bounds[1], (uint32_t)p.max_items);
+        p.item_bounds[1] = min(tot[0], (uint32_t)p.max_items);
+        p.item_bounds[2] = min(all, (uint32_t)p.max_items);
         // (max_items is an upper bound computed on the host from the list lengths; exceeding it would lose work, so the
         // host checks item_bounds[3] == 0 whenever it reads the overflow word)
-        p.item_bounds[3] = bounds[1] > (uint32_t)p.max_items ? 1u : 0u;
+        p.item_bounds[3] = all > (uint32_t)p.max_items ? 1u : 0u;
     }
 }
 
@@ -191,10 +215,13 @@ void launch_l2_norms_scatter(const float* x, int64_t ld, int64_t n, int d, const
 }
 
 // ------------------------------------------------------------------ scan
-// Workgroup = 4 waves; wave w owns 32 of the item's queries (B operands: their dpad coordinates in 16 x 4 VGPRs, lane
-// (h, j): query j, coordinates 8 s + 4 h + e), all waves share the tile.  MFMA D[i][j]: i = row of a 32-row block,
-// j = query: lane (h, j) holds the distances of rows 8 g + 4 h + e (acc[4 g + e]) to ITS query -- threshold, scan
-// position and segment are per-lane registers, nothing crosses lanes.
+// Workgroup = 4 waves over one 64-row tile and up to 64 of the item's queries: wave w owns the 32 queries of query block
+// w & 1 (B operands: their dpad coordinates in 16 x 4 VGPRs, lane (h, j): query j, coordinates 8 s + 4 h + e) and the 32-row
+// block w >> 1 of every tile -- so a list probed by few queries (pass 1) still keeps two waves busy, a full item four.
+// (Measured against 128-query items with one query block per wave, and against roles chosen per item by its query
+// count: both slower -- profiles/r03_b_listmajor_experiments.txt.)
+// MFMA D[i][j]: i = row of the block, j = query: lane (h, j) holds the distances of rows 8 g + 4 h + e (acc[4 g + e]) to
+// ITS query -- threshold, scan position and segment are per-lane registers, nothing crosses lanes.
 // FULL: dpad == 128 (no bound checks in the k loop).
 template <int METRIC, int KIND, int PASS, bool FULL>
 __global__ void __launch_bounds__(LM_THREADS, 3) ivf_lm_scan_kernel(IvfLmParams p) {
@@ -219,21 +246,22 @@ __global__ void __launch_bounds__(LM_THREADS, 3) ivf_lm_scan_kernel(IvfLmParams 
         const int bk = __builtin_amdgcn_readfirstlane(item.bucket);
         const int qt = __builtin_amdgcn_readfirstlane(item.qt);
         const int rt = __builtin_amdgcn_readfirstlane(item.rt);
-        const int list = PASS == 2 ? bk - p.nlist : bk;
+        const int list = bk >= p.nlist ? bk - p.nlist : bk;
         const int len = (int)p.list_len[list];
         const int64_t start = p.list_start[list];
         const uint32_t pb = p.bucket_start[bk];
         const int npair = min(kLmQueriesPerItem, (int)(p.bucket_start[bk + 1] - pb) - qt * kLmQueriesPerItem);
         const int r0 = rt * p.rows_per_item;
-        const int r1 = min(len, r0 + p.rows_per_item);
+        const int r1 = p.force_all ? len : min(len, r0 + p.rows_per_item);
 
         // ---- this lane's query
-        const int my = wave * 32 + j;
+        const int wq = wave & 1, wr = wave >> 1; // query block, row block of this wave
+        const int my = wq * 32 + j;
         const bool qv = my < npair;
         const uint32_t pi = p.pairs[pb + (uint32_t)(qt * kLmQueriesPerItem) + (uint32_t)(qv ? my : 0)];
         const int q = (int)(pi / (uint32_t)np);
         const int pr = (int)(pi - (uint32_t)q * (uint32_t)np);
-        const bool wave_active = wave * 32 < npair; // wave-uniform
+        const bool wave_active = wq * 32 < npair; // wave-uniform
         const float* qrow = p.xq + (int64_t)q * p.ldq;
         f32x4 bq[16];
 #pragma unroll
@@ -265,6 +293,8 @@ __global__ void __launch_bounds__(LM_THREADS, 3) ivf_lm_scan_kernel(IvfLmParams 
             xn = p.coarse_dis[pi];
         }
         const uint32_t base_pos = p.prefix[(int64_t)q * (np + 1) + pr];
+        // pass 1: the segment slot of row 0 of this list (the pass-1 rows of a query are dense in its segment)
+        const uint32_t base_slot = PASS == 1 ? p.prefix1[(int64_t)q * (np + 1) + pr] : 0u;
         u64* kq = p.keys + (int64_t)q * p.stride;
         float thr_f = 0.f;
         if (PASS == 2) {
@@ -276,7 +306,9 @@ __global__ void __launch_bounds__(LM_THREADS, 3) ivf_lm_scan_kernel(IvfLmParams 
         for (int t = r0; t < r1; t += LM_TR) {
             __syncthreads(); // everybody is done with the previous tile
             // ---- tile [t, t + 64) of the list -> LDS: row r at r * 512, 16-byte chunk c at (c ^ (r & 15)) * 16
-            if (KIND == 0) {
+            if (p.dbg & 4) {
+                // (timing experiments: the tile is not loaded)
+            } else if (KIND == 0) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int g = tid + LM_THREADS * i;
@@ -317,15 +349,17 @@ __global__ void __launch_bounds__(LM_THREADS, 3) ivf_lm_scan_kernel(IvfLmParams 
             __syncthreads();
             if (!wave_active) continue;
 
-#pragma unroll
-            for (int blk2 = 0; blk2 < 2; ++blk2) {
-                if (t + blk2 * 32 >= r1) break; // (wave-uniform) the second block of the last tile may be empty
+            {
+                const int blk2 = wr;
+                if (t + blk2 * 32 >= r1) continue; // (wave-uniform) the second block of the last tile may be empty
                 const char* rowp = smem + (blk2 * 32 + j) * LM_ROWB;
                 const int sw = j & 15; // ((32 + j) & 15 == j & 15)
                 f32x16 acc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-                if (FULL) {
+                if (p.dbg & 2) {
+                    // (timing experiments: no matrix work)
+                } else if (FULL) {
                     f32x4 aA = *(const f32x4*)(rowp + (((0 + h) ^ sw) << 4));
                     f32x4 aB;
 #pragma unroll
@@ -349,29 +383,54 @@ __global__ void __launch_bounds__(LM_THREADS, 3) ivf_lm_scan_kernel(IvfLmParams 
                     }
                 }
                 // ---- epilogue: 16 distances of this lane's query
+                auto dist_of = [&](float ip, float rn) -> float {
+                    if (METRIC == METRIC_L2) {
+                        const float dd = __fmaf_rn(-2.f, ip, xn + rn);
+                        return dd < 0.f ? 0.f : dd;
+                    }
+                    return xn + ip;
+                };
+                const int row_b = t + blk2 * 32 + 4 * h; // row of the list of acc[4 g + e]: row_b + 8 g + e
+                if (PASS == 1) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 b4 = *(const f32x4*)(rnl + blk2 * 32 + 8 * g + 4 * h);
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 b4 = *(const f32x4*)(rnl + blk2 * 32 + 8 * g + 4 * h);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float ip = acc[4 * g + e];
-                        float dis;
-                        if (METRIC == METRIC_L2) {
-                            dis = __fmaf_rn(-2.f, ip, xn + b4[e]);
-                            dis = dis < 0.f ? 0.f : dis;
-                        } else {
-                            dis = xn + ip;
+                        for (int e = 0; e < 4; ++e) {
+                            const int rowl = row_b + 8 * g + e;
+                            const uint32_t pos = base_pos + (uint32_t)rowl;
+                            if (qv && rowl < r1 && !(p.dbg & 1))
+                                kq[base_slot + (uint32_t)rowl] = ((u64)ordkey<METRIC>(dist_of(acc[4 * g + e], b4[e])) << 32) | pos;
                         }
-                        const int rowl = t + blk2 * 32 + 8 * g + 4 * h + e; // row of the list
-                        const bool ok = qv && rowl < r1;
-                        const uint32_t pos = base_pos + (uint32_t)rowl;
-                        if (PASS == 1) {
-                            if (ok) kq[pos] = ((u64)ordkey<METRIC>(dis) << 32) | pos;
-                        } else {
-                            const bool pass = ok && (METRIC == METRIC_L2 ? dis <= thr_f : dis >= thr_f);
-                            if (pass) {
-                                const uint32_t slot = atomicAdd(&p.cnt[q], 1u);
-                                if ((int64_t)slot < p.stride) kq[slot] = ((u64)ordkey<METRIC>(dis) << 32) | pos;
+                    }
+                } else {
+                    // which of the 16 pass the bound; ONE atomic per lane and block takes their slots (a returning
+                    // atomic per candidate would put a memory round trip behind each of them)
+                    unsigned mask = 0;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 b4 = *(const f32x4*)(rnl + blk2 * 32 + 8 * g + 4 * h);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float dis = dist_of(acc[4 * g + e], b4[e]);
+                            const bool pass = (METRIC == METRIC_L2 ? dis <= thr_f : dis >= thr_f) && row_b + 8 * g + e < r1;
+                            mask |= pass ? 1u << (4 * g + e) : 0u;
+                        }
+                    }
+                    if (!qv || (p.dbg & 1)) mask = 0;
+                    if (mask) {
+                        uint32_t slot = atomicAdd(&p.cnt[q], (uint32_t)__popc(mask));
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x4 b4 = *(const f32x4*)(rnl + blk2 * 32 + 8 * g + 4 * h);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                if (mask & (1u << (4 * g + e))) {
+                                    const uint32_t pos = base_pos + (uint32_t)(row_b + 8 * g + e);
+                                    if ((int64_t)slot < p.stride)
+                                        kq[slot] = ((u64)ordkey<METRIC>(dist_of(acc[4 * g + e], b4[e])) << 32) | pos;
+                                    ++slot;
+                                }
                             }
                         }
                     }

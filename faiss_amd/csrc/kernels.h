@@ -233,6 +233,9 @@ struct SelectParams {
     // when set: only kth_out[q] = the ordkey (upper 32 bits) of the k-th smallest key is written (0xffffffff when the
     // query has no more than k keys... then every key qualifies); nothing else is produced
     uint32_t* kth_out; // [nq] or null
+    // with kth_out (nseg == 1): the segment is also cut back to its keys <= the k-th (they move to its front) and
+    // cnt_out[q] = their number
+    uint32_t* cnt_out; // [nq] or null
 };
 // Exact k-selection: MSB radix select on 64-bit keys + bitonic sort of the k winners by
 // (distance, label).  Replaces faiss/gpu/utils/BlockSelectKernel.cuh:15-132 and the
@@ -382,13 +385,15 @@ size_t ivf_fused_lds_bytes(int kind, int M, int dpad, int kp, int cap, int nprob
 // MFMA B operands in registers, streams the list's rows through LDS in 64-row tiles (IVFPQ: decoded there from the
 // codes, once per workgroup) and computes the 64 x 128 distance block on v_mfma_f32_32x32x2_f32 -- bit for bit the
 // k-ordered fmaf chain of the exact flat scan.  Two passes share the kernel:
-//   pass 1  the leading probes of every query (as many as it takes to see >= k rows): EVERY distance is written to the
-//           query's key segment at its scan position (no atomics); the k-th smallest key of the segment is an upper
-//           bound of the query's k-th best distance over all its probes (select_k_kernel with kth_out);
-//   pass 2  the remaining probes: rows at or below the bound are appended to the segment (one atomic per candidate).
+//   pass 1  the first row chunk (rows_per_item rows) of the lists of every query's leading probes -- min_p1 of them, more if
+//           it takes more to see k rows: EVERY distance is written to the query's key segment (dense slots, no atomics);
+//           the k-th smallest key of the segment is an upper bound of the query's k-th best distance over all its
+//           probes; the segment is cut back to those k keys (select_k_kernel with kth_out / cnt_out);
+//   pass 2  everything else (the lists of the remaining probes, the further row chunks of the pass-1 lists): rows at or
+//           below the bound are appended to the segment (one atomic per lane and 32-row block that holds any).
 // The k best keys of the segment are the answer (select_k_kernel mode 1).  A segment that overflows is redone with
-// all probes in pass 1 (exact capacity).  SURVEY 7 H4; the reference scans query-major (IVFInterleaved.cuh:33-224,
-// PQScanMultiPassNoPrecomputed-inl.cuh:173-270).
+// all probes and rows in pass 1 (exact capacity).  SURVEY 7 H4; the reference scans query-major (IVFInterleaved.cuh:
+// 33-224, PQScanMultiPassNoPrecomputed-inl.cuh:173-270).
 // Arithmetic (restated by oracle/faiss_oracle.c orc_ivf_search, arith = 1):
 //   IVFFlat  L2: max(0, fmaf(-2, <q, y>, |q|^2 + |y|^2)),  IP: <q, y>             (= the flat index's distances)
 //   IVFPQ    L2: max(0, fmaf(-2, <q - c, r^>, |q - c|^2 + |r^|^2)),  IP: <q, c> + <q, r^>   (r^ = decoded residual)
@@ -397,7 +402,8 @@ size_t ivf_fused_lds_bytes(int kind, int M, int dpad, int kp, int cap, int nprob
 struct IvfLmItem {
     int bucket, qt, rt, pad;
 };
-constexpr int kLmQueriesPerItem = 128; // 4 waves x 32 queries
+constexpr int kLmRowsPerItem = 1024; // rows of a list per work item (16 tiles); pass 1 sees the first chunk of a list
+constexpr int kLmQueriesPerItem = 64; // two 32-query blocks (x the two 32-row blocks of a tile = 4 waves)
 struct IvfLmParams {
     int metric;
     int kind; // 0 = IVFFlat, 1 = IVFPQ
@@ -411,6 +417,7 @@ struct IvfLmParams {
     const int64_t* list_start;  // [nlist]
     // ---- plan, built on the device by launch_ivf_lm_plan
     uint32_t* prefix;        // [nq][nprobe + 1] exclusive prefix of the probed lists' lengths = scan positions
+    uint32_t* prefix1;       // [nq][nprobe + 1] the same over min(length, rows_per_item): segment slots of pass 1
     uint32_t* p0;            // [nq] probes of pass 1
     uint32_t* cnt;           // [nq] keys in the segment (after the plan: the pass-1 rows)
     uint32_t* bucket_cnt;    // [2 nlist] pairs per (pass, list); zeroed by the plan launcher
@@ -422,6 +429,8 @@ struct IvfLmParams {
     int max_items;
     int rows_per_item;       // multiple of 64
     int force_all;           // every probe in pass 1
+    int min_p1;              // at least this many probes of every query in pass 1
+    int dbg;                 // timing experiments (env FAISS_AMD_LM_DBG): 1 no key writes, 2 no MFMAs, 4 no tile loads
     // ---- candidates
     unsigned long long* keys; // [nq][stride]
     int64_t stride;

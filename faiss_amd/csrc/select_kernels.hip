@@ -123,9 +123,25 @@ __global__ void __launch_bounds__(SEL_THREADS) select_k_kernel(SelectParams p) {
     }
     const u64 kth = sh->kth;
     if (p.kth_out) {
-        // threshold-only use (list-major IVF scan): with fewer than k keys every distance qualifies
-        // (with exactly k keys the radix select did not run either: kth = ~0, a valid if loose bound)
+        // threshold-only use (list-major IVF scan): kth_out = the bound (with no more than k keys every distance
+        // qualifies: kth = ~0), and -- cnt_out given -- the segment (one per query) is cut back to its keys <= kth, which
+        // is all of it that can still be part of the answer
         if (tid == 0) p.kth_out[q] = (uint32_t)(kth >> 32);
+        if (p.cnt_out && total > (unsigned)p.k) {
+            u64* keep = (u64*)w_id; // [kp]
+            u64* seg = const_cast<u64*>(p.keys) + (p.q_off ? p.q_off[q] : (int64_t)q * p.q_stride);
+            for (unsigned i = tid; i < total; i += SEL_THREADS) {
+                const u64 key = seg[i];
+                if (key <= kth) {
+                    const unsigned slot = atomicAdd(&sh->nwin, 1u);
+                    if (slot < (unsigned)kp) keep[slot] = key;
+                }
+            }
+            __syncthreads(); // every read of the segment precedes the writes below
+            const unsigned nw = min(sh->nwin, (unsigned)p.k);
+            for (unsigned i = tid; i < nw; i += SEL_THREADS) seg[i] = keep[i];
+            if (tid == 0) p.cnt_out[q] = nw;
+        }
         return;
     }
 
