@@ -7,10 +7,14 @@ SyntheticDataset recipe, seed 1338).  A "step" is one search of all 10 000 queri
   N = 1 : `value` = GpuIndexFlatL2 QPS (BASELINE.json configs[1]) with queries and results resident in HBM when the
           timed region starts; `value_host_buffers` beside it is the same search handed pageable HOST buffers (how
           benchs/bench_gpu_sift1m.py times the reference; PCIe copies inside the timed region).  The same JSON line
-          carries the IVF4096,PQ64 and IVF4096,Flat legs at nb=1M (`ivfpq`, `ivfflat`), each with its own `roofline`
-          block (HBM-bound scans: algorithmic bytes of SURVEY.md 8d over the HIP-event kernel time), the parity of
-          every leg against the reference CPU index on ALL queries (every label mismatch classified as near-tie or
-          counted as real) and the reference CPU path timed on this node's host cores (`cpu_baseline`).
+          carries the IVF4096,PQ64 / IVF4096,Flat / IVF4096,SQ8 legs at nb=1M (`ivfpq`, `ivfflat`, `ivfsq`), each with its
+          own `roofline` block (query-major scans: HBM-bound, algorithmic bytes of SURVEY.md 8d over the HIP-event kernel
+          time; the list-major scan that serves large IVFFlat batches since round 3: f32-MFMA-bound, 2*nq*nprobe*(nb/nlist)*d
+          flop over the time of its two scan launches, with the SURVEY 8d byte figure beside it), the parity of every leg
+          against the reference CPU index on ALL queries (every label mismatch classified as near-tie or counted as
+          real) and the reference CPU path timed on this node's host cores (`cpu_baseline`).  `ivfflat_10m` and
+          `ivfpq_100m` are BASELINE.json configs[2] and configs[3] (built chunk by chunk; a query sample bit-exact
+          against the oracle run on the probed lists read back from the device; --budget-s bounds the run).
   N > 1 : one process per GPU (torch.distributed, backend "nccl" = RCCL), total work fixed => "scaling": "strong".
           Flat leg (`value`): --multi-gpu replicas (default; what the reference builds for a database that fits one
           GPU, GpuMultipleClonerOptions::shard = false -> IndexReplicas: every rank holds the 1M vectors and searches
@@ -172,24 +176,21 @@ def ivf_leg(kind, res, xt, xb, xq, xq_dev, gt_first, steps, torch, with_cpu=True
     idx.nprobe = NPROBE
     Dd = torch.empty((NQ, K), dtype=torch.float32, device=xq_dev.device)
     Id = torch.empty((NQ, K), dtype=torch.int64, device=xq_dev.device)
-    kname = "ivfpq_fused_kernel" if pq else "ivfsq_fused_kernel" if sq else "ivfflat_fused_kernel"
     time_search(idx, torch, NQ, xq_dev.data_ptr(), Dd.data_ptr(), Id.data_ptr(), 1, 1)
     res.profile_enable(True)
     res.profile_reset()
     dt = time_search(idx, torch, NQ, xq_dev.data_ptr(), Dd.data_ptr(), Id.data_ptr(), steps, 0)
-    scan_ms, scan_n = res.profile_get(kname)
+    spans = collect_spans(res)
     res.profile_enable(False)
+    list_major = idx.scan_info()[1] == 2
     Dh = np.empty((NQ, K), dtype=np.float32)
     Ih = np.empty((NQ, K), dtype=np.int64)
     dt_host = time_search(idx, torch, NQ, xq.ctypes.data, Dh.ctypes.data, Ih.ctypes.data, max(2, steps // 2), 1)
     I = Id.cpu().numpy()
-    avg_ms = scan_ms / max(scan_n, 1)
-    # algorithmic HBM bytes of the list scan: nprobe * nb/nlist * bytes-per-entry per query
     row_bytes = PQ_M if pq else D if sq else D * 4
-    alg_bytes = float(NPROBE) * NB / NLIST * row_bytes * NQ
-    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if scan_n else None
     out = {
         "workload": "%s nlist=%d nprobe=%d d=%d nb=%d nq=%d k=%d" % (title, NLIST, NPROBE, D, NB, NQ, K),
+        "scan": "list-major (ivf_listmajor.hip)" if list_major else "query-major (ivf_fused.hip)",
         "qps": round(NQ / dt, 1), "ms_per_step": round(dt * 1e3, 3),
         "qps_host_buffers": round(NQ / dt_host, 1),
         "recall_at_1": round(float((I[:, 0] == gt_first).mean()), 4),
@@ -197,11 +198,8 @@ def ivf_leg(kind, res, xt, xb, xq, xq_dev, gt_first, steps, torch, with_cpu=True
         "recall_gate": ("R@100 >= 0.95 (PQ64 saturates R@1 near 0.9 on this data; SURVEY.md 8d)" if pq
                         else "R@1 >= 0.95"),
         "train_s": round(t_train, 2), "add_s": round(t_add, 2),
-        "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1) if achieved else None,
-                     "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4) if achieved else None,
-                     "avg_kernel_ms": round(avg_ms, 3), "launches": int(scan_n),
-                     "algorithmic_bytes_per_launch": int(alg_bytes),
-                     "traffic": committed_traffic(kname, alg_bytes)},
+        "roofline": ivf_roofline(spans, list_major, "ivfpq" if pq else "ivfsq" if sq else "ivfflat", NB, row_bytes),
+        "kernels_ms": {k: round(v[0] / max(v[1], 1), 3) for k, v in spans.items() if v[1]},
     }
     if with_cpu and Ref.available():
         try:
@@ -246,6 +244,133 @@ def ivf_leg(kind, res, xt, xb, xq, xq_dev, gt_first, steps, torch, with_cpu=True
         except Exception as e:  # noqa: BLE001
             out["cpu_baseline"] = {"error": repr(e)[:300]}
     return out, idx
+
+
+SPAN_NAMES = ("ivf_lm_plan", "ivf_lm_scan_pass1", "ivf_lm_threshold", "ivf_lm_scan_pass2", "select_k_kernel",
+              "ivfflat_fused_kernel", "ivfpq_fused_kernel", "ivfsq_fused_kernel", "ivf_finish_kernel", "flat_filter_kernel",
+              "flat_filter_kernel_max", "flat_tighten_kernel", "flat_rerank_kernel", "convert_f16_query")
+
+
+def collect_spans(res):
+    """(total ms, launches) per kernel span of the library's HIP-event profile (events on the library's own stream)"""
+    return {k: res.profile_get(k) for k in SPAN_NAMES}
+
+
+def ivf_roofline(spans, list_major, kind, nb, row_bytes):
+    """roofline block of an IVF leg.  Query-major scan: HBM-bound, SURVEY.md 8d's algorithmic bytes (nprobe * nb/nlist *
+    bytes per entry per query) over the scan launch.  List-major scan: every list is read once per group of up to 64 of
+    the queries probing it and the distances are f32 MFMA dot products, so the bound is the f32 matrix pipe: 2 * nq *
+    nprobe * (nb/nlist) * d flop over the two scan launches; the 8d byte figure is reported beside it (it may exceed the
+    HBM peak: those bytes are no longer moved once per query) together with the bytes a batch really has to read."""
+    alg_bytes = float(NPROBE) * nb / NLIST * row_bytes * NQ
+    if not list_major:
+        kname = {"ivfpq": "ivfpq_fused_kernel", "ivfsq": "ivfsq_fused_kernel", "ivfflat": "ivfflat_fused_kernel"}[kind]
+        ms, n = spans[kname]
+        avg = ms / max(n, 1)
+        ach = alg_bytes / (avg * 1e-3) / 1e9 if n else None
+        return {"bound": "hbm", "kernel": kname, "achieved": round(ach, 1) if ach else None, "peak": PEAK_HBM_GBS,
+                "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4) if ach else None, "avg_kernel_ms": round(avg, 3),
+                "launches": int(n), "algorithmic_bytes_per_launch": int(alg_bytes),
+                "traffic": committed_traffic(kname, alg_bytes)}
+    (m1, n1), (m2, n2) = spans["ivf_lm_scan_pass1"], spans["ivf_lm_scan_pass2"]
+    searches = max(n2, 1)
+    scan_ms = (m1 + m2) / searches  # both scan launches of one search (pass 1 may run twice when queries are redone)
+    flops = 2.0 * NQ * NPROBE * (nb / float(NLIST)) * D
+    ach = flops / (scan_ms * 1e-3) / 1e12
+    unique = nb * float(row_bytes) + NQ * D * 4.0
+    return {"bound": "mfma", "kernel": "ivf_lm_scan_kernel (pass 1 + pass 2 launches of one search)",
+            "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+            "avg_kernel_ms": round(scan_ms, 3), "launches": int(n1 + n2),
+            "algorithmic_flop_per_search": int(flops),
+            "survey_8d_bytes": {"algorithmic_bytes_per_search": int(alg_bytes),
+                                "GBps_over_the_scan_launches": round(alg_bytes / (scan_ms * 1e-3) / 1e9, 1),
+                                "frac_of_hbm_peak": round(alg_bytes / (scan_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 3),
+                                "note": "bytes the query-major formulation moves per search; the list-major scan reads a "
+                                        "list once per group of <= 64 queries, so this figure is not bound by the HBM peak"},
+            "unique_bytes_per_batch": int(unique),
+            "traffic": None}
+
+
+def scale_leg(kind, nb, res, xt, xb, xq, xq_dev, dmap, torch, leg_1m, nsample=16):
+    """BASELINE.json configs[2] (GpuIndexIVFFlat nb = 10M) / configs[3] (GpuIndexIVFPQ PQ64 nb = 100M) on one MI355X:
+    the index is built chunk by chunk from the generator (never more than 1M rows on the host), all 10 000 queries are
+    searched (k = 100, nprobe = 32, queries / results in HBM), `nsample` of them are checked BIT-EXACTLY against the
+    oracle restatement run on the lists they probe, read back from the device; all results are checked for order and
+    label validity.  The reference CPU index is not built at this size: `cpu_baseline` is the figure
+    measured at nb = 1M with the same quantizers and nprobe, scaled by the list length, and says so."""
+    import faiss_amd
+    from faiss_amd.datasets import synthetic_more
+    from oracle.pyoracle import METRIC_L2, Oracle
+    pq = kind == "ivfpq"
+    idx = (faiss_amd.GpuIndexIVFPQ(res, D, NLIST, PQ_M, 8, faiss_amd.METRIC_L2) if pq
+           else faiss_amd.GpuIndexIVFFlat(res, D, NLIST, faiss_amd.METRIC_L2))
+    t0 = time.time()
+    idx.train(xt)
+    t_add = t_gen = 0.0
+    done = chunk = 0
+    while done < nb:
+        t1 = time.time()
+        xbc = xb if chunk == 0 else synthetic_more(dmap, min(1000000, nb - done), seed=1338 + chunk)
+        t_gen += time.time() - t1
+        t1 = time.time()
+        idx.add(xbc)
+        t_add += time.time() - t1
+        done += len(xbc)
+        chunk += 1
+    t_build = time.time() - t0
+    idx.nprobe = NPROBE
+    Dd = torch.empty((NQ, K), dtype=torch.float32, device=xq_dev.device)
+    Id = torch.empty((NQ, K), dtype=torch.int64, device=xq_dev.device)
+    time_search(idx, torch, NQ, xq_dev.data_ptr(), Dd.data_ptr(), Id.data_ptr(), 1, 1)
+    steps = 3 if nb <= 20000000 else 2
+    res.profile_enable(True)
+    res.profile_reset()
+    dt = time_search(idx, torch, NQ, xq_dev.data_ptr(), Dd.data_ptr(), Id.data_ptr(), steps, 0)
+    spans = collect_spans(res)
+    res.profile_enable(False)
+    list_major = idx.scan_info()[1] == 2
+    Dg, Ig = Dd.cpu().numpy(), Id.cpu().numpy()
+    ok_order = bool((np.diff(Dg, axis=1) >= 0).all() and (Ig >= 0).all() and (Ig < nb).all())
+    # ---- sample parity: oracle on the probed lists read back from the device
+    sel = np.random.RandomState(3).choice(NQ, nsample, replace=False)
+    cent = idx.get_centroids()
+    pqc = idx.get_pq_centroids() if pq else None
+    Dq, Iq = idx.quantizer_search(xq[sel], NPROBE)
+    sizes = np.zeros(NLIST, dtype=np.uint32)
+    codes, ids = [], []
+    for l in np.unique(Iq):
+        sizes[l] = idx.get_list_size(int(l))
+        codes.append(idx.get_list_codes(int(l)))
+        ids.append(idx.get_list_ids(int(l)))
+    codes, ids = np.concatenate(codes), np.concatenate(ids)
+    Do, Io, cD, cI = Oracle.ivf_search(1 if pq else 0, METRIC_L2, cent, sizes, codes, ids, xq[sel], NPROBE, K,
+                                       M=PQ_M if pq else 0, pq=pqc, arith=1 if list_major else 0)
+    exact = bool(np.array_equal(cI, Iq) and np.array_equal(cD, Dq) and np.array_equal(Io, Ig[sel]) and np.array_equal(Do, Dg[sel]))
+    row_bytes = PQ_M if pq else D * 4
+    used, holes, alloc = idx.arena_stats()
+    out = {
+        "workload": "%s nlist=%d nprobe=%d d=%d nb=%d nq=%d k=%d (BASELINE.json configs[%d])" % (
+            "GpuIndexIVFPQ PQ%dx8" % PQ_M if pq else "GpuIndexIVFFlat", NLIST, NPROBE, D, nb, NQ, K, 3 if pq else 2),
+        "scan": "list-major (ivf_listmajor.hip)" if list_major else "query-major (ivf_fused.hip)",
+        "qps": round(NQ / dt, 1), "ms_per_step": round(dt * 1e3, 3), "steps": steps,
+        "build_s": round(t_build, 1), "add_s": round(t_add, 1), "data_generation_s": round(t_gen, 1),
+        "add_M_vectors_per_s": round(nb / t_add / 1e6, 2),
+        "arena_rows_over_vectors": round(alloc / float(nb), 3), "overflow_queries": int(idx.scan_info()[2]),
+        "roofline": ivf_roofline(spans, list_major, kind, nb, row_bytes),
+        "kernels_ms": {k: round(v[0] / max(v[1], 1), 3) for k, v in spans.items() if v[1]},
+        "parity": {"sampled_queries_bit_exact_vs_oracle_on_probed_lists": exact, "sampled_queries": int(nsample),
+                   "probed_list_entries_read_back": int(len(ids)), "all_results_ordered_and_labels_valid": ok_order},
+    }
+    base = (leg_1m or {}).get("cpu_baseline", {})
+    if isinstance(base.get("value"), (int, float)):
+        out["cpu_baseline"] = {"value": round(base["value"] * NB / nb, 1), "unit": "QPS", "cores": base.get("cores"),
+                               "kind": "reference, SCALED (not measured at this size)",
+                               "sample": "the nb=1M figure of this run (%s) x %g: the scan cost of an IVF search is linear in "
+                                         "the list length; the reference index is not built at nb=%d (BASELINE.md 3.6)"
+                                         % (base.get("sample", "")[:80], NB / float(nb), nb)}
+        out["speedup_vs_cpu"] = round(out["qps"] / out["cpu_baseline"]["value"], 1)
+    del idx
+    return out
 
 
 def committed_traffic(kernel_substr, alg_bytes):
@@ -341,6 +466,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ivf-legs", default="ivfpq,ivfflat,ivfsq", help="comma-separated subset of the IVF legs to run")
     ap.add_argument("--no-ivf", action="store_true", help="skip the IVF4096,PQ64 / IVF4096,Flat / IVF4096,SQ8 legs")
+    ap.add_argument("--scale-legs", default="ivfflat_10m,ivfpq_100m",
+                    help="BASELINE.json configs[2] / configs[3] on one GPU (comma-separated subset, empty = none)")
+    ap.add_argument("--budget-s", type=float, default=900.0,
+                    help="a scale leg is started only while the run is expected to stay inside this many seconds "
+                         "(ivfflat_10m needs ~40 s, ivfpq_100m ~300 s)")
     ap.add_argument("--multi-gpu", choices=["replicas", "shards"], default="replicas",
                     help="layout of the FLAT leg at N > 1: replicas = every GPU holds the database, queries are split "
                          "(IndexReplicas, the reference's default for databases that fit one GPU); shards = rows are split "
@@ -369,7 +499,8 @@ def main():
 
     res = faiss_amd.StandardGpuResources(local_rank)
     t0 = time.time()
-    xt, xb, xq = synthetic_dataset(D, NT, NB, NQ, seed=1338)
+    t_start = time.time()
+    xt, xb, xq, dmap = synthetic_dataset(D, NT, NB, NQ, seed=1338, return_map=True)
     replicas = world > 1 and args.multi_gpu == "replicas"
     bounds = [(0, NB)] * world if replicas else shard_bounds(NB, world)
     lo, hi = bounds[rank]
@@ -520,6 +651,22 @@ def main():
                                             with_cpu=not args.no_cpu_baseline)
                 except Exception as e:  # noqa: BLE001
                     line[kind] = {"error": repr(e)[:300]}
+            need = {"ivfflat_10m": 60.0, "ivfpq_100m": 330.0}
+            for name in [v for v in args.scale_legs.split(",") if v in need]:
+                if time.time() - t_start + need[name] > args.budget_s:
+                    line[name] = {"skipped": "--budget-s %.0f would be exceeded (%.0f s used, ~%.0f s needed)"
+                                             % (args.budget_s, time.time() - t_start, need[name])}
+                    continue
+                kind, nbig = name.split("_")
+                try:
+                    del index  # the flat index (0.8 GB) is not needed any more
+                except NameError:
+                    pass
+                try:
+                    line[name] = scale_leg(kind, 10000000 if nbig == "10m" else 100000000, res, xt, xb, xq, xq_dev, dmap,
+                                           torch, line.get(kind))
+                except Exception as e:  # noqa: BLE001
+                    line[name] = {"error": repr(e)[:300]}
     elif ivfpq_multi is not None:
         if ivf_out is not None:
             I2 = ivf_out[1].cpu().numpy()

@@ -157,25 +157,48 @@ def test_ivf4096_1m_vs_oracle_and_live_reference(res, sift_shaped, kind):
         g2.copy_pq_centroids(pq)
     g2.copy_lists(sizes, codes, lids)
     g2.nprobe = NPROBE
-    D, I = g2.search(xq, K)
-    st = check_knn(D, I, Dr, Ir, rtol=1e-4, max_tie_frac=2e-3, name="%s 1M vs live reference" % kind)
-    _report("%s 1M x 10k" % kind, st)
-    assert (np.diff(D, axis=1) >= 0).all()
+    kd = 0 if kind == "ivfflat" else 1
+    M = 64 if pq is not None else 0
     sel = np.random.RandomState(2).choice(NQ, 64, replace=False)
-    Do, Io, _, _ = Oracle.ivf_search(0 if kind == "ivfflat" else 1, METRIC_L2, cent, sizes, codes, lids, xq[sel], NPROBE, K,
-                                     M=64 if pq is not None else 0, pq=pq)
+    # ---- the scan the library picks for this batch (10 000 queries x 32 probes over 4096 lists: list-major for IVFFlat)
+    D, I = g2.search(xq, K)
+    arith = g2.last_scan_arith()
+    assert arith == (1 if kind == "ivfflat" else 0)
+    st = check_knn(D, I, Dr, Ir, rtol=1e-4, max_tie_frac=2e-3, name="%s 1M vs live reference" % kind)
+    _report("%s 1M x 10k (automatic scan, arith %d)" % (kind, arith), st)
+    assert (np.diff(D, axis=1) >= 0).all()
+    Do, Io, _, _ = Oracle.ivf_search(kd, METRIC_L2, cent, sizes, codes, lids, xq[sel], NPROBE, K, M=M, pq=pq, arith=arith)
     check_knn(D[sel], I[sel], Do, Io, exact=True, name="%s 1M vs oracle" % kind)
+    # ---- both scans explicitly, each against the reference on all queries and against its own restatement on the sample
+    res_by_mode = {}
+    for mode in (g2.SCAN_QUERY_MAJOR, g2.SCAN_LIST_MAJOR):
+        g2.set_scan_mode(mode)
+        Dm, Im = g2.search(xq, K)
+        assert g2.scan_info()[1] == mode
+        st = check_knn(Dm, Im, Dr, Ir, rtol=1e-4, max_tie_frac=2e-3, name="%s 1M scan mode %d vs live reference" % (kind, mode))
+        _report("%s 1M x 10k (scan mode %d)" % (kind, mode), st)
+        Do, Io, _, _ = Oracle.ivf_search(kd, METRIC_L2, cent, sizes, codes, lids, xq[sel], NPROBE, K, M=M, pq=pq, arith=mode - 1)
+        check_knn(Dm[sel], Im[sel], Do, Io, exact=True, name="%s 1M scan mode %d vs oracle" % (kind, mode))
+        res_by_mode[mode] = (Dm, Im)
+    assert g2.scan_info()[2] == 0, "no query of this batch should overflow its candidate segment"
+    Dq_, Iq_ = res_by_mode[g2.SCAN_QUERY_MAJOR]
     # native lists: same results wherever the lists agree (PQ codes may differ in argmin near-ties)
-    agree = (In[:, 0] == I[:512, 0]).mean()
+    agree = (In[:, 0] == Iq_[:512, 0]).mean()
     assert agree > 0.99, agree
-    # unfused cross-check path and search_preassigned reproduce the fused scan bit for bit
+    # unfused cross-check path and search_preassigned reproduce the fused query-major scan bit for bit
+    g2.set_scan_mode(g2.SCAN_QUERY_MAJOR)
     g2.set_use_fused_scan(False)
     D0, I0 = g2.search(xq[:400], K)
     g2.set_use_fused_scan(True)
-    assert np.array_equal(I0, I[:400]) and np.array_equal(D0, D[:400])
-    Dq, Iq = g2.quantizer_search(xq[:400], NPROBE)
-    D1, I1 = g2.search_preassigned(xq[:400], K, Iq, Dq)
-    assert np.array_equal(I1, I[:400]) and np.array_equal(D1, D[:400])
+    assert np.array_equal(I0, Iq_[:400]) and np.array_equal(D0, Dq_[:400])
+    Dc, Ic = g2.quantizer_search(xq[:400], NPROBE)
+    D1, I1 = g2.search_preassigned(xq[:400], K, Ic, Dc)
+    assert np.array_equal(I1, Iq_[:400]) and np.array_equal(D1, Dq_[:400])
+    # ... and the list-major one (IVFPQ L2 derives |q - c|^2 itself there: the caller's centroid distances are not used)
+    g2.set_scan_mode(g2.SCAN_LIST_MAJOR)
+    Dc, Ic = g2.quantizer_search(xq, NPROBE)
+    D2, I2 = g2.search_preassigned(xq, K, Ic, Dc)
+    assert np.array_equal(I2, res_by_mode[g2.SCAN_LIST_MAJOR][1]) and np.array_equal(D2, res_by_mode[g2.SCAN_LIST_MAJOR][0])
 
 
 # ------------------------------------------------------------------------------- BASELINE.json configs[2]: nb = 10M
@@ -218,6 +241,14 @@ def test_ivfflat_10m_sample_vs_oracle(res):
     Do, Io, cD, cI = Oracle.ivf_search(0, METRIC_L2, cent, sizes, codes, ids, xq, NPROBE, K)
     assert np.array_equal(cI, Iq) and np.array_equal(cD, Dq)
     check_knn(D, I, Do, Io, exact=True, name="ivfflat 10M vs oracle")
+    # the list-major scan on the same queries: lists of ~2400 rows = three row chunks each (pass 1 sees the first chunk of
+    # the leading lists, the rest goes through pass 2)
+    idx.set_scan_mode(idx.SCAN_LIST_MAJOR)
+    D2, I2 = idx.search(xq, K)
+    Do2, Io2, _, _ = Oracle.ivf_search(0, METRIC_L2, cent, sizes, codes, ids, xq, NPROBE, K, arith=1)
+    check_knn(D2, I2, Do2, Io2, exact=True, name="ivfflat 10M list-major vs oracle")
+    check_knn(D2, I2, D, I, rtol=1e-4, name="ivfflat 10M list-major vs query-major")
+    idx.set_scan_mode(idx.SCAN_AUTO)
     # exact distances of returned rows that live in the kept chunks
     for chunk, xbc in keep.items():
         lo = chunk * 500000
