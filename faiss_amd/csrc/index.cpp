@@ -1455,11 +1455,13 @@ void GpuIndexIVF::ensure_arena_(int64_t rows) {
     int64_t ncap = std::max<int64_t>(rows, arena_cap_rows_ + arena_cap_rows_ / 4);
     ncap = (int64_t)round_up((size_t)ncap, 64);
     const size_t keep = (size_t)arena_rows_;
-    // DevBuf::ensure grows to max(bytes, 1.5 cap): ask for exactly ncap rows of each array
-    arena_.ensure((size_t)ncap * code_bytes_, keep * code_bytes_, res_->stream);
+    // DevBuf::ensure grows to max(bytes, 1.5 cap): ask for exactly ncap rows of each array (+ one tile of rows nobody
+    // owns behind the last: the list-major scan fetches whole 64-row tiles without clamping at the end of a list)
+    const size_t pad = 64;
+    arena_.ensure(((size_t)ncap + pad) * code_bytes_, keep * code_bytes_, res_->stream);
     arena_ids_.ensure((size_t)ncap * 8, keep * 8, res_->stream);
     if (use_t2_) arena_t2_.ensure((size_t)ncap * 4, keep * 4, res_->stream);
-    if (use_rn_) arena_rn_.ensure((size_t)ncap * 4, keep * 4, res_->stream);
+    if (use_rn_) arena_rn_.ensure(((size_t)ncap + pad) * 4, keep * 4, res_->stream);
     arena_cap_rows_ = ncap;
 }
 
@@ -1625,10 +1627,10 @@ void GpuIndexIVF::compact_(bool tight) {
     }
     DevBuf na, ni, nt, nr;
     const int64_t rows = std::max<int64_t>(acc, 64);
-    na.ensure((size_t)rows * code_bytes_);
+    na.ensure(((size_t)rows + 64) * code_bytes_); // (+ one tile: see ensure_arena_)
     ni.ensure((size_t)rows * 8);
     if (use_t2_) nt.ensure((size_t)rows * 4);
-    if (use_rn_) nr.ensure((size_t)rows * 4);
+    if (use_rn_) nr.ensure(((size_t)rows + 64) * 4);
     if (!jobs.empty()) {
         a_jobs_.ensure(jobs.size() * sizeof(IvfMoveJob));
         HIP_CHECK(hipMemcpyAsync(a_jobs_.p, jobs.data(), jobs.size() * sizeof(IvfMoveJob), hipMemcpyHostToDevice,
@@ -2174,18 +2176,18 @@ void GpuIndexIVF::search_listmajor_(int ni, const float* xq_pad, const idx_t* c_
     // room for the candidates of pass 2; with every probe in pass 1 (overflow rerun): all probed rows
     const int64_t chunk_rows = std::min<int64_t>(max_len, kLmRowsPerItem);
     const int64_t cap2 = std::max<int64_t>(2048, 4 * (int64_t)k);
-    const int64_t stride = force_all ? std::max<int64_t>((int64_t)np * max_len, k)
-                                     : std::max<int64_t>((int64_t)k + chunk_rows, (int64_t)min_p1 * chunk_rows) + cap2;
+    const int64_t c1max = std::max<int64_t>((int64_t)k + chunk_rows, (int64_t)min_p1 * chunk_rows); // rows of pass 1
+    const int64_t stride = force_all ? std::max<int64_t>((int64_t)np * max_len, k) : c1max + cap2;
     const int64_t fit = std::max<int64_t>(1, (int64_t)(R.temp_budget_bytes / ((size_t)stride * 8)));
     for (int c0 = 0; c0 < ni; c0 += (int)std::min<int64_t>(fit, ni)) {
         const int cn = (int)std::min<int64_t>(fit, ni - c0);
         search_listmajor_chunk_(cn, xq_pad + (size_t)c0 * dpad_, c_ids + (size_t)c0 * np, c_dis + (size_t)c0 * np, np, k,
-                                dD + (size_t)c0 * k, dI + (size_t)c0 * k, force_all, stride, min_p1);
+                                dD + (size_t)c0 * k, dI + (size_t)c0 * k, force_all, stride, min_p1, (int)c1max);
     }
 }
 
 void GpuIndexIVF::search_listmajor_chunk_(int ni, const float* xq_pad, const idx_t* c_ids, const float* c_dis, int np, int k,
-                                          float* dD, idx_t* dI, bool force_all, int64_t stride, int min_p1) const {
+                                          float* dD, idx_t* dI, bool force_all, int64_t stride, int min_p1, int c1max) const {
     const GpuResources& R = *res_;
     const int RT = kLmRowsPerItem; // rows of a list per work item (16 tiles)
     // upper bound of the work items: sum over (pass, list) of ceil(pairs / 128) * ceil(len / RT)
@@ -2255,7 +2257,7 @@ void GpuIndexIVF::search_listmajor_chunk_(int ni, const float* xq_pad, const idx
         SpanGuard sg(&R, "ivf_lm_plan");
         launch_ivf_lm_plan(P, R.stream);
     }
-    const int grid = 3 * R.num_cus / 8 * 8; // three 256-thread workgroups per CU are resident (registers): one wave of persistent blocks
+    const int grid = ivf_lm_blocks_per_cu(P.kind) * R.num_cus / 8 * 8; // one wave of persistent workgroups
     {
         SpanGuard sg(&R, "ivf_lm_scan_pass1");
         launch_ivf_lm_scan(P, 1, grid, R.stream);
@@ -2271,11 +2273,14 @@ void GpuIndexIVF::search_listmajor_chunk_(int ni, const float* xq_pad, const idx
     sp.seg_cnt = P.cnt;
     if (!force_all) {
         {
-            // bound of every query: the k-th smallest key among its pass-1 rows
+            // bound of every query: the k-th smallest key among its pass-1 rows; the segment keeps only those k keys
+            // (all of pass 1 that can still win): pass 2 appends behind them.  (A variant that holds the keys in LDS --
+            // one read of the segment instead of one per radix pass -- measured slower: 64 KB of LDS per workgroup
+            // leaves two of them per CU, profiles/r03_b_listmajor_experiments.txt.)
             SpanGuard sg(&R, "ivf_lm_threshold");
             sp.mode = 0;
             sp.kth_out = P.thr;
-            sp.cnt_out = P.cnt; // the segment keeps only what can still win: pass 2 appends behind k keys
+            sp.cnt_out = P.cnt;
             launch_select_k(sp, R.stream);
             sp.kth_out = nullptr;
             sp.cnt_out = nullptr;

@@ -423,7 +423,7 @@ class GpuIndexIVF : public Index {
     void search_listmajor_(int ni, const float* xq_pad, const idx_t* c_ids, const float* c_dis, int np, int k, float* dD,
                            idx_t* dI, bool force_all) const;
     void search_listmajor_chunk_(int ni, const float* xq_pad, const idx_t* c_ids, const float* c_dis, int np, int k,
-                                 float* dD, idx_t* dI, bool force_all, int64_t stride, int min_p1) const;
+                                 float* dD, idx_t* dI, bool force_all, int64_t stride, int min_p1, int c1max) const;
     void upload_list_tables_();
     void ensure_arena_(int64_t rows);
     // make room for new_len[l] entries in every list (relocating the lists that outgrow their slack); est[l]

@@ -16,6 +16,7 @@
 // of the segment under (distance, scan position) -- the same rule as every other scan here -- whatever order the
 // workgroups ran in.
 #include "kernels.h"
+#include "wg_select.h"
 
 namespace faiss_amd {
 
@@ -27,8 +28,79 @@ constexpr int LM_THREADS = 256;
 constexpr int LM_TR = 64;                       // rows per tile
 constexpr int LM_ROWB = 512;                    // LDS bytes per tile row (128 floats, whatever dpad is)
 constexpr int LM_TILE_BYTES = LM_TR * LM_ROWB;  // 32768
-constexpr int LM_LDS_RN = LM_TILE_BYTES;        // 64 row norms
-constexpr int LM_LDS_TOTAL = LM_TILE_BYTES + LM_TR * 4;
+// IVFPQ (tile decoded by the threads): one tile + 64 row norms.  IVFFlat: TWO tiles + 2 x 64 row norms -- the rows of
+// tile t + 1 arrive by LDS-DMA (global_load_lds_dwordx4: no staging registers) while tile t is multiplied.
+constexpr int LM_LDS_RN = LM_TILE_BYTES;        // 64 row norms (single-tile layout)
+constexpr int LM2_LDS_RN = 2 * LM_TILE_BYTES;   // 2 x 64 row norms (two-tile layout)
+// pass 2: every wave parks its candidates (key + query) in an LDS slice of its own and hands them to the segments in
+// HBM only when the slice fills up (and when the kernel ends): one atomic round trip per ~hundred candidates instead of
+// one per 32-row block -- a returning atomic inside the tile loop stalls its wave for a memory round trip per tile,
+// as long as the tile's MFMAs take, and drains the prefetch with it
+constexpr int LM_PARK = 192;                                   // parked candidates per wave
+constexpr int LM_PARK_BYTES = 4 * LM_PARK * (8 + 4);           // 4 waves x (u64 key + u32 query)
+constexpr int LM_LDS_PARK = LM_TILE_BYTES + LM_TR * 4;         // single-tile layout
+constexpr int LM2_LDS_PARK = 2 * LM_TILE_BYTES + 2 * LM_TR * 4; // two-tile layout
+constexpr int LM_LDS_TOTAL_P = LM_LDS_PARK + LM_PARK_BYTES;
+constexpr int LM2_LDS_TOTAL = LM2_LDS_PARK + LM_PARK_BYTES;
+
+// LDS-DMA issued from inline asm (the helpers of flat_filter.hip): hipcc would make every ds_read that follows a
+// __builtin_amdgcn_global_load_lds wait for vmcnt(0), draining the prefetch before the tile in hand is even read.
+// Hidden in asm the DMA is invisible to the compiler's counters; completion is enforced by our own counted
+// s_waitcnt vmcnt(N) + barrier before a tile is consumed (cdna_hip_programming.md 5.7).  Extra vector-memory operations
+// of the compiler's (the epilogue's key stores, the query loads of the next item) only make both sides' counted waits
+// conservative: loads complete in order, so "at most N outstanding" always covers everything older than the last N.
+__device__ __forceinline__ void lm_glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+            "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(gsrc), "s"(lds_dst)
+            : "memory");
+}
+__device__ __forceinline__ void lm_glds4(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+            "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(gsrc), "s"(lds_dst)
+            : "memory");
+}
+// Workgroup barrier WITHOUT the fences of __syncthreads(): with key stores / atomics of the epilogue pending, the
+// workgroup-scope release / acquire around s_barrier makes hipcc wait for vmcnt(0), which also drains the prefetch DMAs.
+// In the DMA pipeline no thread writes LDS (the tile arrives by DMA, covered by the counted vmcnt wait before this
+// barrier) and a wave that arrives has consumed every LDS read it issued; the "memory" clobber keeps the compiler from
+// moving LDS reads across it.
+__device__ __forceinline__ void lm_barrier() {
+    asm volatile("s_barrier" ::: "memory");
+}
+// same, scalar 64-bit base + 32-bit per-lane byte offset: the per-tile address arithmetic is one scalar add.  The leading
+// s_nop covers the SALU-write -> VMEM-read hazard on the base SGPRs, which hipcc cannot see inside an asm statement
+// (cdna_hip_programming.md 5.7)
+__device__ __forceinline__ void lm_glds16_s(const void* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+            "s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(voff), "s"(sbase), "s"(lds_dst)
+            : "memory");
+}
+__device__ __forceinline__ void lm_glds4_s(const void* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+            "s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(voff), "s"(sbase), "s"(lds_dst)
+            : "memory");
+}
+__device__ __forceinline__ const char* lm_uniform_ptr(const char* ptr) {
+    const unsigned long long v = (unsigned long long)ptr;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const char*)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ unsigned lm_lds_addr(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
 
 bool ivf_lm_supported(int kind, int dpad, int M, int d) {
     if (dpad > 128 || (dpad & 7)) return false;
@@ -38,9 +110,11 @@ bool ivf_lm_supported(int kind, int dpad, int M, int d) {
 }
 
 // ------------------------------------------------------------------ plan
-// one thread per query: scan positions of its probes, the probes of pass 1, pairs per (pass, list)
-__global__ void lm_plan_kernel(IvfLmParams p) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+// one wavefront per query: scan positions of its probes (exclusive prefix sums over the probe list, 64 probes per round),
+// the probes of pass 1, pairs per (pass, list)
+__global__ void __launch_bounds__(256) lm_plan_kernel(IvfLmParams p) {
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (q >= p.nq) return;
     const int np = p.nprobe;
     const int64_t* ids = p.coarse_ids + (int64_t)q * np;
@@ -49,26 +123,58 @@ __global__ void lm_plan_kernel(IvfLmParams p) {
     // pass 1 sees the first rows_per_item rows of a list (its first row chunk); the rest of a longer list waits for
     // pass 2 like the lists of the later probes
     const uint32_t r1max = p.force_all ? 0xffffffffu : (uint32_t)p.rows_per_item;
-    uint32_t cum = 0, cum1 = 0;
+    uint32_t cum = 0, cum1 = 0; // (wave-uniform) totals of the probes before this round
     int p0 = np;
-    for (int pr = 0; pr < np; ++pr) {
-        const int64_t l = ids[pr];
+    for (int base = 0; base < np; base += 64) {
+        const int pr = base + lane;
+        const int64_t l = pr < np ? ids[pr] : -1;
         const uint32_t len = l >= 0 ? p.list_len[l] : 0u;
-        pre[pr] = cum;
-        pre1[pr] = cum1;
-        cum += len;
-        cum1 += min(len, r1max);
-        if (p0 == np && cum1 >= (uint32_t)p.k) p0 = pr + 1;
+        const uint32_t len1 = min(len, r1max);
+        uint32_t inc = len, inc1 = len1; // inclusive scans over the lanes
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(inc, off, 64), o1 = __shfl_up(inc1, off, 64);
+            if (lane >= off) {
+                inc += o;
+                inc1 += o1;
+            }
+        }
+        if (pr < np) {
+            pre[pr] = cum + inc - len;
+            pre1[pr] = cum1 + inc1 - len1;
+        }
+        // first probe after which pass 1 has seen k rows
+        const unsigned long long reach = __ballot(pr < np && cum1 + inc1 >= (uint32_t)p.k);
+        if (p0 == np && reach) p0 = base + __ffsll((long long)reach);
+        cum += __shfl(inc, 63, 64);
+        cum1 += __shfl(inc1, 63, 64);
     }
-    pre[np] = cum;
-    pre1[np] = cum1;
     // at least min_p1 probes in pass 1: the k-th best of the nearest FEW lists is a far tighter bound than that of the
     // nearest one alone (a query near a cell border finds most of its neighbours next door)
     if (p0 < p.min_p1) p0 = min(np, p.min_p1);
     if (p.force_all) p0 = np;
-    p.p0[q] = (uint32_t)p0;
-    p.cnt[q] = pre1[p0];
-    for (int pr = 0; pr < np; ++pr) {
+    if (lane == 0) {
+        pre[np] = cum;
+        pre1[np] = cum1;
+        p.p0[q] = (uint32_t)p0;
+    }
+    // rows of pass 1 = pre1[p0] (p0 == np: the total)
+    uint32_t c1 = cum1;
+    if (p0 < np) {
+        // recompute from the lens of the probes before p0 (a second sweep is cheaper than a round trip through memory)
+        uint32_t s1 = 0;
+        for (int base = 0; base < p0; base += 64) {
+            const int pr = base + lane;
+            const int64_t l = pr < p0 ? ids[pr] : -1;
+            uint32_t v = l >= 0 ? min(p.list_len[l], r1max) : 0u;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+            s1 += v;
+        }
+        c1 = s1;
+    }
+    if (lane == 0) p.cnt[q] = c1;
+    for (int pr = lane; pr < np; pr += 64) {
         const int64_t l = ids[pr];
         if (l >= 0 && p.list_len[l] > 0) atomicAdd(&p.bucket_cnt[(int)l + (pr >= p0 ? p.nlist : 0)], 1u);
     }
@@ -106,27 +212,55 @@ __global__ void __launch_bounds__(1024) lm_items_kernel(IvfLmParams p) {
             s2 += nqt * nrt;
         }
     }
-    part_pairs[t] = sp;
-    part_i1[t] = s1;
-    part_i2[t] = s2;
-    __syncthreads();
-    if (t == 0) {
-        uint32_t rp = 0, r1 = 0, r2 = 0;
-        for (int i = 0; i < 1024; ++i) {
-            const uint32_t vp = part_pairs[i], v1 = part_i1[i], v2 = part_i2[i];
-            part_pairs[i] = rp;
-            part_i1[i] = r1;
-            part_i2[i] = r2;
-            rp += vp;
-            r1 += v1;
-            r2 += v2;
+    // exclusive scans of the three per-thread sums over the 1024 threads: inclusive scan inside every wavefront
+    // (shuffles), then the 16 wavefront totals by the first wavefront
+    {
+        const int ln = t & 63, wv = t >> 6;
+        uint32_t ip = sp, i1s = s1, i2s = s2;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t op = __shfl_up(ip, off, 64), o1 = __shfl_up(i1s, off, 64), o2 = __shfl_up(i2s, off, 64);
+            if (ln >= off) {
+                ip += op;
+                i1s += o1;
+                i2s += o2;
+            }
         }
-        p.bucket_start[n] = rp;
-        tot[0] = r1;
-        tot[1] = r2;
+        if (ln == 63) {
+            part_pairs[wv] = ip;
+            part_i1[wv] = i1s;
+            part_i2[wv] = i2s;
+        }
+        __syncthreads();
+        if (t < 64) {
+            uint32_t vp = t < 16 ? part_pairs[t] : 0u, v1 = t < 16 ? part_i1[t] : 0u, v2 = t < 16 ? part_i2[t] : 0u;
+            const uint32_t wp = vp, w1 = v1, w2 = v2;
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                const uint32_t op = __shfl_up(vp, off, 64), o1 = __shfl_up(v1, off, 64), o2 = __shfl_up(v2, off, 64);
+                if (t >= off) {
+                    vp += op;
+                    v1 += o1;
+                    v2 += o2;
+                }
+            }
+            if (t < 16) { // exclusive offsets of the wavefronts (written behind the totals read above)
+                part_pairs[64 + t] = vp - wp;
+                part_i1[64 + t] = v1 - w1;
+                part_i2[64 + t] = v2 - w2;
+            }
+            if (t == 15) {
+                p.bucket_start[n] = vp;
+                tot[0] = v1;
+                tot[1] = v2;
+            }
+        }
+        __syncthreads();
+        sp = part_pairs[64 + wv] + ip - sp; // exclusive prefix of this thread
+        s1 = part_i1[64 + wv] + i1s - s1;
+        s2 = part_i2[64 + wv] + i2s - s2;
     }
-    __syncthreads();
-    uint32_t rp = part_pairs[t], i1 = part_i1[t], i2 = tot[0] + part_i2[t];
+    uint32_t rp = sp, i1 = s1, i2 = tot[0] + s2;
     auto put = [&](uint32_t at, int bk, int qt, int rt) {
         if (at < (uint32_t)p.max_items) p.items[at] = IvfLmItem{bk, qt, rt, 0};
     };
@@ -172,7 +306,7 @@ void launch_ivf_lm_plan(const IvfLmParams& p, hipStream_t stream) {
     // bucket_cnt and bucket_fill are one allocation [2][2 nlist]
     FA_THROW_IF_NOT(p.bucket_fill == p.bucket_cnt + 2 * p.nlist);
     HIP_CHECK(hipMemsetAsync(p.bucket_cnt, 0, (size_t)4 * p.nlist * 4, stream));
-    hipLaunchKernelGGL(lm_plan_kernel, dim3((unsigned)div_up(p.nq, 128)), dim3(128), 0, stream, p);
+    hipLaunchKernelGGL(lm_plan_kernel, dim3((unsigned)div_up(p.nq, 4)), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(lm_items_kernel, dim3(1), dim3(1024), 0, stream, p);
     hipLaunchKernelGGL(lm_fill_kernel, dim3((unsigned)div_up((size_t)p.nq * p.nprobe, 256)), dim3(256), 0, stream, p);
     HIP_CHECK(hipGetLastError());
@@ -224,7 +358,7 @@ void launch_l2_norms_scatter(const float* x, int64_t ld, int64_t n, int d, const
 // ITS query -- threshold, scan position and segment are per-lane registers, nothing crosses lanes.
 // FULL: dpad == 128 (no bound checks in the k loop).
 template <int METRIC, int KIND, int PASS, bool FULL>
-__global__ void __launch_bounds__(LM_THREADS, 3) ivf_lm_scan_kernel(IvfLmParams p) {
+__global__ void __launch_bounds__(LM_THREADS, KIND == 0 ? 2 : 3) ivf_lm_scan_kernel(IvfLmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -233,7 +367,39 @@ __global__ void __launch_bounds__(LM_THREADS, 3) ivf_lm_scan_kernel(IvfLmParams 
     const int j = lane & 31;
     const int np = p.nprobe;
     const int ns = FULL ? 16 : (p.dpad >> 3);
-    float* rnl = (float*)(smem + LM_LDS_RN);
+    float* rnl = (float*)(smem + (KIND == 0 ? LM2_LDS_RN : LM_LDS_RN));
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane(lm_lds_addr(smem));
+    // IVFFlat: DMAs per wave and tile -- 8 x 1 KB of rows (+ the 64 row norms, by every wave, so that all count alike)
+    constexpr int NDMA = 8 + (METRIC == METRIC_L2 ? 1 : 0);
+
+    // pass 2: this wave's slice of parked candidates
+    u64* pk_keys = (u64*)(smem + (KIND == 0 ? LM2_LDS_PARK : LM_LDS_PARK)) + wave * LM_PARK;
+    uint32_t* pk_q = (uint32_t*)(smem + (KIND == 0 ? LM2_LDS_PARK : LM_LDS_PARK) + 4 * LM_PARK * 8) + wave * LM_PARK;
+    int wcnt = 0; // (wave-uniform) parked candidates
+    auto flush = [&]() __attribute__((always_inline)) {
+        for (int e = lane; e < wcnt; e += 64) {
+            const u64 key = pk_keys[e];
+            const uint32_t qq = pk_q[e];
+            uint32_t slot;
+            uint32_t* cp = p.cnt + qq;
+            const uint32_t one = 1u;
+            // (asm, with its own wait: a returning atomic the compiler can see, waited for only inside branches, makes
+            // it guard the top of the tile loop with s_waitcnt vmcnt(0) -- draining the prefetch DMAs on EVERY tile)
+            asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(slot) : "v"(cp), "v"(one) : "memory");
+            if ((int64_t)slot < p.stride) p.keys[(int64_t)qq * p.stride + slot] = key;
+        }
+        wcnt = 0;
+    };
+
+    // IVFFlat: byte offsets of this lane's 8 DMA pieces relative to the first row of a tile
+    unsigned voff_row[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = wave * 16 + 2 * i + (lane >> 5);
+        int c = (lane & 31) ^ (row & 15);
+        if (!FULL && c * 4 >= p.dpad) c = 0; // (columns the k loop never reads)
+        voff_row[i] = (unsigned)(row * (int)p.ldv * 4 + c * 16);
+    }
 
     const uint32_t it0 = p.item_bounds[PASS - 1], it1 = p.item_bounds[PASS];
     // blocks b, b + 8, ... share an XCD (and its L2): give them consecutive items
@@ -253,6 +419,26 @@ __global__ void __launch_bounds__(LM_THREADS, 3) ivf_lm_scan_kernel(IvfLmParams 
         const int npair = min(kLmQueriesPerItem, (int)(p.bucket_start[bk + 1] - pb) - qt * kLmQueriesPerItem);
         const int r0 = rt * p.rows_per_item;
         const int r1 = p.force_all ? len : min(len, r0 + p.rows_per_item);
+
+        // IVFFlat: the 8 DMAs of this wave cover rows 16 w .. 16 w + 15 of a tile; lane l of DMA i lands at chunk position
+        // l & 31 of row 16 w + 2 i + (l >> 5) and therefore fetches source chunk (l & 31) ^ (row & 15) (the swizzle of the
+        // LDS image, applied through the source address).  Addressing: a wave-uniform 64-bit base per tile (SGPRs) plus
+        // per-lane 32-bit offsets that never change (voff_*, set up once per kernel).  Tiles are fetched whole: the rows
+        // behind the end of a list belong to the next list or to the arena's padding (index.cpp ensure_arena_) and their
+        // distances are never looked at.
+        auto issue_tile = [&](int t, int buf_) __attribute__((always_inline)) {
+            if (p.dbg & 4) return;
+            const int bf = __builtin_amdgcn_readfirstlane(buf_);
+            const char* sb = lm_uniform_ptr((const char*)(p.arena_vecs + (start + t) * p.ldv));
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                lm_glds16_s(sb, voff_row[i], lds_base + (unsigned)(bf * LM_TILE_BYTES + (wave * 8 + i) * 1024));
+            if (METRIC == METRIC_L2)
+                lm_glds4_s(lm_uniform_ptr((const char*)(p.arena_rn + start + t)), (unsigned)lane * 4u,
+                           lds_base + (unsigned)(LM2_LDS_RN + bf * LM_TR * 4));
+        };
+        // (first tile on its way before the query operands are gathered)
+        if (KIND == 0) issue_tile(r0, 0);
 
         // ---- this lane's query
         const int wq = wave & 1, wr = wave >> 1; // query block, row block of this wave
@@ -292,9 +478,9 @@ __global__ void __launch_bounds__(LM_THREADS, 3) ivf_lm_scan_kernel(IvfLmParams 
         } else if (KIND == 1) {
             xn = p.coarse_dis[pi];
         }
-        const uint32_t base_pos = p.prefix[(int64_t)q * (np + 1) + pr];
+        uint32_t base_pos = p.prefix[(int64_t)q * (np + 1) + pr];
         // pass 1: the segment slot of row 0 of this list (the pass-1 rows of a query are dense in its segment)
-        const uint32_t base_slot = PASS == 1 ? p.prefix1[(int64_t)q * (np + 1) + pr] : 0u;
+        uint32_t base_slot = PASS == 1 ? p.prefix1[(int64_t)q * (np + 1) + pr] : 0u;
         u64* kq = p.keys + (int64_t)q * p.stride;
         float thr_f = 0.f;
         if (PASS == 2) {
@@ -303,22 +489,34 @@ __global__ void __launch_bounds__(LM_THREADS, 3) ivf_lm_scan_kernel(IvfLmParams 
             else thr_f = unordkey<METRIC>(tk);
         }
 
-        for (int t = r0; t < r1; t += LM_TR) {
+        int buf = 0;
+        if (KIND == 0) {
+            // every load of the item set-up has landed HERE, as far as the compiler's scoreboard goes (the values pass
+            // through an opaque asm): otherwise its wait for them would sit at their first use inside the tile loop and,
+            // counting only its own loads, would also drain the prefetch of the next tile
+#pragma unroll
+            for (int s = 0; s < 16; ++s) asm volatile("" : "+v"(bq[s]));
+            asm volatile("" : "+v"(xn), "+v"(thr_f));
+            asm volatile("" : "+v"(kq), "+v"(base_pos), "+v"(base_slot));
+        }
+        for (int t = r0; t < r1; t += LM_TR, buf ^= 1) {
+            const char* tile = smem + (KIND == 0 ? buf * LM_TILE_BYTES : 0);
+            const float* rnt = rnl + (KIND == 0 ? buf * LM_TR : 0);
+            if (KIND == 0) {
+                // tile t + 1 into the other buffer (its readers passed the barrier that ended the previous iteration);
+                // then everything older than those DMAs -- tile t -- must have landed
+                if (t + LM_TR < r1) {
+                    issue_tile(t + LM_TR, buf ^ 1);
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                lm_barrier();
+            } else {
             __syncthreads(); // everybody is done with the previous tile
             // ---- tile [t, t + 64) of the list -> LDS: row r at r * 512, 16-byte chunk c at (c ^ (r & 15)) * 16
             if (p.dbg & 4) {
                 // (timing experiments: the tile is not loaded)
-            } else if (KIND == 0) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int g = tid + LM_THREADS * i;
-                    const int row = g >> 5, c = g & 31;
-                    if (FULL || c * 4 < p.dpad) {
-                        const int grow = min(t + row, r1 - 1);
-                        const f32x4 v = *(const f32x4*)(p.arena_vecs + (start + grow) * p.ldv + c * 4);
-                        *(f32x4*)(smem + row * LM_ROWB + ((c ^ (row & 15)) << 4)) = v;
-                    }
-                }
             } else {
                 // IVFPQ: thread (row l, quarter) decodes sub-quantizers quarter, quarter + 4, ...: stored byte
                 // (m - l) mod M of row l (rotated block layout, kernels.h pq_code_offset) -> dsub floats of the codebook
@@ -347,12 +545,13 @@ __global__ void __launch_bounds__(LM_THREADS, 3) ivf_lm_scan_kernel(IvfLmParams 
                 rnl[tid] = v;
             }
             __syncthreads();
-            if (!wave_active) continue;
+            }
 
-            {
+            // (wave-uniform condition: a wave without queries, or whose block of the list's last tile is empty, only
+            // takes part in the loads and barriers)
+            if (wave_active && t + wr * 32 < r1) {
                 const int blk2 = wr;
-                if (t + blk2 * 32 >= r1) continue; // (wave-uniform) the second block of the last tile may be empty
-                const char* rowp = smem + (blk2 * 32 + j) * LM_ROWB;
+                const char* rowp = tile + (blk2 * 32 + j) * LM_ROWB;
                 const int sw = j & 15; // ((32 + j) & 15 == j & 15)
                 f32x16 acc;
 #pragma unroll
@@ -394,7 +593,7 @@ __global__ void __launch_bounds__(LM_THREADS, 3) ivf_lm_scan_kernel(IvfLmParams 
                 if (PASS == 1) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const f32x4 b4 = *(const f32x4*)(rnl + blk2 * 32 + 8 * g + 4 * h);
+                        const f32x4 b4 = *(const f32x4*)(rnt + blk2 * 32 + 8 * g + 4 * h);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int rowl = row_b + 8 * g + e;
@@ -409,7 +608,7 @@ __global__ void __launch_bounds__(LM_THREADS, 3) ivf_lm_scan_kernel(IvfLmParams 
                     unsigned mask = 0;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const f32x4 b4 = *(const f32x4*)(rnl + blk2 * 32 + 8 * g + 4 * h);
+                        const f32x4 b4 = *(const f32x4*)(rnt + blk2 * 32 + 8 * g + 4 * h);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const float dis = dist_of(acc[4 * g + e], b4[e]);
@@ -418,41 +617,90 @@ __global__ void __launch_bounds__(LM_THREADS, 3) ivf_lm_scan_kernel(IvfLmParams 
                         }
                     }
                     if (!qv || (p.dbg & 1)) mask = 0;
-                    if (mask) {
-                        uint32_t slot = atomicAdd(&p.cnt[q], (uint32_t)__popc(mask));
+                    if (__ballot(mask != 0u)) {
+                        // (wave-uniform branch) park the candidates: this lane's go behind those of the lanes before it
+                        const int c = __popc(mask);
+                        int inc = c; // inclusive scan over the lanes
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const f32x4 b4 = *(const f32x4*)(rnl + blk2 * 32 + 8 * g + 4 * h);
+                        for (int off = 1; off < 64; off <<= 1) {
+                            const int o = __shfl_up(inc, off, 64);
+                            if (lane >= off) inc += o;
+                        }
+                        const int total = __builtin_amdgcn_readlane(inc, 63);
+                        if (total > LM_PARK) {
+                            // more candidates in one 32-row block than a slice holds (a bound that admits everything):
+                            // straight to the segment, one atomic per lane
+                            if (mask) {
+                                uint32_t slot;
+                                uint32_t* cp = p.cnt + q;
+                                const uint32_t nc = (uint32_t)c;
+                                asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)"
+                                             : "=&v"(slot)
+                                             : "v"(cp), "v"(nc)
+                                             : "memory");
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                if (mask & (1u << (4 * g + e))) {
-                                    const uint32_t pos = base_pos + (uint32_t)(row_b + 8 * g + e);
-                                    if ((int64_t)slot < p.stride)
-                                        kq[slot] = ((u64)ordkey<METRIC>(dist_of(acc[4 * g + e], b4[e])) << 32) | pos;
-                                    ++slot;
+                                for (int g = 0; g < 4; ++g) {
+                                    const f32x4 b4 = *(const f32x4*)(rnt + blk2 * 32 + 8 * g + 4 * h);
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        if (mask & (1u << (4 * g + e))) {
+                                            const uint32_t pos = base_pos + (uint32_t)(row_b + 8 * g + e);
+                                            if ((int64_t)slot < p.stride)
+                                                kq[slot] = ((u64)ordkey<METRIC>(dist_of(acc[4 * g + e], b4[e])) << 32) | pos;
+                                            ++slot;
+                                        }
+                                    }
                                 }
                             }
+                        } else {
+                            if (wcnt + total > LM_PARK) flush();
+                            int at = wcnt + inc - c;
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const f32x4 b4 = *(const f32x4*)(rnt + blk2 * 32 + 8 * g + 4 * h);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    if (mask & (1u << (4 * g + e))) {
+                                        const uint32_t pos = base_pos + (uint32_t)(row_b + 8 * g + e);
+                                        pk_keys[at] = ((u64)ordkey<METRIC>(dist_of(acc[4 * g + e], b4[e])) << 32) | pos;
+                                        pk_q[at] = (uint32_t)q;
+                                        ++at;
+                                    }
+                                }
+                            }
+                            wcnt += total;
                         }
                     }
                 }
             }
+            if (KIND == 0) lm_barrier(); // everybody is done with this buffer before the next iteration's DMAs target it
         }
     }
+    if (PASS == 2 && wcnt > 0) flush();
 }
 
 template <int METRIC, int KIND, int PASS>
 static void lm_launch3(const IvfLmParams& p, int grid_blocks, hipStream_t stream) {
-    if (p.dpad == 128)
-        hipLaunchKernelGGL((ivf_lm_scan_kernel<METRIC, KIND, PASS, true>), dim3((unsigned)grid_blocks), dim3(LM_THREADS),
-                           LM_LDS_TOTAL, stream, p);
-    else
-        hipLaunchKernelGGL((ivf_lm_scan_kernel<METRIC, KIND, PASS, false>), dim3((unsigned)grid_blocks), dim3(LM_THREADS),
-                           LM_LDS_TOTAL, stream, p);
+    const int lds = KIND == 0 ? LM2_LDS_TOTAL : LM_LDS_TOTAL_P;
+    if (p.dpad == 128) {
+        HIP_CHECK(hipFuncSetAttribute((const void*)ivf_lm_scan_kernel<METRIC, KIND, PASS, true>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL((ivf_lm_scan_kernel<METRIC, KIND, PASS, true>), dim3((unsigned)grid_blocks), dim3(LM_THREADS), lds,
+                           stream, p);
+    } else {
+        HIP_CHECK(hipFuncSetAttribute((const void*)ivf_lm_scan_kernel<METRIC, KIND, PASS, false>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL((ivf_lm_scan_kernel<METRIC, KIND, PASS, false>), dim3((unsigned)grid_blocks), dim3(LM_THREADS), lds,
+                           stream, p);
+    }
 }
 template <int METRIC, int KIND>
 static void lm_launch2(const IvfLmParams& p, int pass, int grid_blocks, hipStream_t stream) {
     if (pass == 1) lm_launch3<METRIC, KIND, 1>(p, grid_blocks, stream);
     else lm_launch3<METRIC, KIND, 2>(p, grid_blocks, stream);
+}
+int ivf_lm_blocks_per_cu(int kind) {
+    return kind == 0 ? 2 : 3;
 }
 void launch_ivf_lm_scan(const IvfLmParams& p, int pass, int grid_blocks, hipStream_t stream) {
     if (p.nq == 0) return;

@@ -451,6 +451,8 @@ bool ivf_lm_supported(int kind, int dpad, int M, int d);
 void launch_ivf_lm_plan(const IvfLmParams& p, hipStream_t stream);
 // pass = 1 or 2; grid_blocks workgroups walk the pass's items (a multiple of 8: consecutive items on one XCD)
 void launch_ivf_lm_scan(const IvfLmParams& p, int pass, int grid_blocks, hipStream_t stream);
+// workgroups of the scan kernel that are resident per CU (IVFFlat: two, with two tiles in LDS each; IVFPQ: three)
+int ivf_lm_blocks_per_cu(int kind);
 // cnt[q] > stride -> cnt[q] = stride, the query is listed in ovf
 void launch_ivf_lm_clamp(const IvfLmParams& p, hipStream_t stream);
 // out[dest[i]] = |x_i|^2 as the sequential fmaf chain of l2_norms_kernel, for dest[i] >= 0
