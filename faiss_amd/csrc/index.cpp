@@ -1457,7 +1457,7 @@ void GpuIndexIVF::ensure_arena_(int64_t rows) {
     const size_t keep = (size_t)arena_rows_;
     // DevBuf::ensure grows to max(bytes, 1.5 cap): ask for exactly ncap rows of each array (+ one tile of rows nobody
     // owns behind the last: the list-major scan fetches whole 64-row tiles without clamping at the end of a list)
-    const size_t pad = 64;
+    const size_t pad = 128;
     arena_.ensure(((size_t)ncap + pad) * code_bytes_, keep * code_bytes_, res_->stream);
     arena_ids_.ensure((size_t)ncap * 8, keep * 8, res_->stream);
     if (use_t2_) arena_t2_.ensure((size_t)ncap * 4, keep * 4, res_->stream);
@@ -1627,10 +1627,10 @@ void GpuIndexIVF::compact_(bool tight) {
     }
     DevBuf na, ni, nt, nr;
     const int64_t rows = std::max<int64_t>(acc, 64);
-    na.ensure(((size_t)rows + 64) * code_bytes_); // (+ one tile: see ensure_arena_)
+    na.ensure(((size_t)rows + 128) * code_bytes_); // (+ one tile: see ensure_arena_)
     ni.ensure((size_t)rows * 8);
     if (use_t2_) nt.ensure((size_t)rows * 4);
-    if (use_rn_) nr.ensure(((size_t)rows + 64) * 4);
+    if (use_rn_) nr.ensure(((size_t)rows + 128) * 4);
     if (!jobs.empty()) {
         a_jobs_.ensure(jobs.size() * sizeof(IvfMoveJob));
         HIP_CHECK(hipMemcpyAsync(a_jobs_.p, jobs.data(), jobs.size() * sizeof(IvfMoveJob), hipMemcpyHostToDevice,
@@ -2151,9 +2151,11 @@ void GpuIndexIVF::search_core_body_(idx_t n, const float* x, idx_t k, float* dis
 // ---------------------------------------------------------------------- list-major search (ivf_listmajor.hip)
 bool GpuIndexIVF::list_major_rule(idx_t n, int nprobe_now, idx_t k, bool has_selector) const {
     if (has_selector || !lm_capable_()) return false;
-    // IVFPQ: the list-major kernel decodes the codes through gathers from the codebook in L2, which costs more than the
-    // matrix work it feeds (profiles/r03_b_*): opt-in (scan_mode 2) until the decode runs from LDS
-    if (fused_kind_() != 0) return false;
+    // IVFPQ: 64 bytes per row make the query-major scan cheap per query; the list-major kernel (codebook in LDS, one
+    // workgroup per CU) pays a fixed cost per work item that only lists of >= ~1000 rows amortise (measured, profiles/
+    // r03_b_listmajor_experiments.txt: nb = 1M 1.68 vs 1.35 ms query-major, nb = 10M 8.1 vs 9.7 ms)
+    if (fused_kind_() == 1 && !(lm_pq_lds_capable_() && nstored_ >= (idx_t)1024 * nlist)) return false;
+    if (fused_kind_() > 1) return false;
     const int64_t np = std::min<int64_t>(nprobe_now, nlist);
     return n >= 2048 && (int64_t)n * np >= (int64_t)8 * nlist && k <= kMaxSelectionK;
 }
@@ -2257,7 +2259,7 @@ void GpuIndexIVF::search_listmajor_chunk_(int ni, const float* xq_pad, const idx
         SpanGuard sg(&R, "ivf_lm_plan");
         launch_ivf_lm_plan(P, R.stream);
     }
-    const int grid = ivf_lm_blocks_per_cu(P.kind) * R.num_cus / 8 * 8; // one wave of persistent workgroups
+    const int grid = ivf_lm_grid_blocks(P, R.num_cus); // one wave of persistent workgroups
     {
         SpanGuard sg(&R, "ivf_lm_scan_pass1");
         launch_ivf_lm_scan(P, 1, grid, R.stream);
@@ -2681,6 +2683,9 @@ void GpuIndexIVFPQ::lists_changed_() {
         launch_ivfpq_t2_lists(arena_.as<uint8_t>(), d_list_start_.as<int64_t>(), d_list_len_.as<uint32_t>(), nlist,
                               zero_row_.as<float>(), 0, M, dsub, pq_.as<float>(), arena_rn_.as<float>(), res_->stream);
     res_->sync();
+}
+bool GpuIndexIVFPQ::ivf_lm_pq_lds_supported_() const {
+    return ivf_lm_pq_lds_supported(d, dpad_, M);
 }
 bool GpuIndexIVFPQ::lm_capable_() const {
     return ivf_lm_supported(1, dpad_, M, d);

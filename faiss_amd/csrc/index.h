@@ -413,6 +413,7 @@ class GpuIndexIVF : public Index {
     mutable DevBuf part_keys_, part_cnt_, probe_len_, probe_start_;
     // ---- list-major search of large batches (ivf_listmajor.hip, kernels.h IvfLmParams)
     virtual bool lm_capable_() const { return false; }
+    virtual bool lm_pq_lds_capable_() const { return false; } // IVFPQ: the codebook-in-LDS kernel serves this shape
     virtual void fill_lm_(struct IvfLmParams& p) const {}
     mutable DevBuf lm_prefix_, lm_p0_, lm_cnt_, lm_bucket_, lm_bstart_, lm_pairs_, lm_items_, lm_bounds_, lm_thr_, lm_keys_,
             lm_ovf_, lm_qn_;
@@ -495,6 +496,8 @@ class GpuIndexIVFPQ : public GpuIndexIVF {
     DevBuf pq_t_; // [256][M][dsub]: the order the scan kernels build their lookup table in
     DevBuf zero_row_; // dpad zeros: the "centroid" with which the per-row term kernels yield |r^|^2 (arena_rn_)
     bool lm_capable_() const override;
+    bool lm_pq_lds_capable_() const override { return ivf_lm_pq_lds_supported_(); }
+    bool ivf_lm_pq_lds_supported_() const;
     void fill_lm_(struct IvfLmParams& p) const override;
     bool extra_trained_() const override { return pq_.p != nullptr; }
     void lists_changed_() override;

@@ -679,6 +679,340 @@ __global__ void __launch_bounds__(LM_THREADS, KIND == 0 ? 2 : 3) ivf_lm_scan_ker
     if (PASS == 2 && wcnt > 0) flush();
 }
 
+// ------------------------------------------------------------------ IVFPQ, codebook in LDS (round 3, second kernel)
+// The generic kernel above decodes an IVFPQ tile through 64 codebook gathers per row from L2 -- more expensive than the
+// matrix work the tile feeds (profiles/r03_b_listmajor_experiments.txt: 0.44 of 0.92 ms).  Here the whole codebook
+// [M][256][dsub] (d KB of fp32: 128 KB at d = 128) lives in LDS for the life of a persistent workgroup, and a lane builds
+// its MFMA A operand -- 4 consecutive coordinates of ITS row -- straight from it: code byte(s) of the row from an LDS copy
+// of the tile's codes (un-rotated on the way in), then one to four LDS gathers.  No decoded tile, no codebook traffic
+// outside the CU.  Same operands, same MFMA chain as the generic kernel: bit-identical results.
+// Workgroup = 8 waves over a 128-row tile and up to 64 of the item's queries: wave w owns query block w & 1 and the
+// 32-row block w >> 1.  One workgroup per CU (LDS); the two waves of a SIMD cover each other's epilogues.
+// DS: 1 / 2 = dsub itself, 4 = any multiple of 4 (the 4 coordinates of an operand then lie inside one sub-vector).
+constexpr int LQ_THREADS = 512;
+constexpr int LQ_TR = 128;   // rows per tile
+constexpr int LQ_PARK = 96;  // parked candidates per wave
+struct LqLayout {
+    int cb_bytes, rs, off_codes, off_rn, off_park, total;
+};
+__host__ __device__ static inline LqLayout lq_layout(int d, int M) {
+    LqLayout L;
+    L.cb_bytes = d * 256 * 4;
+    L.rs = M + 4;                                   // bytes per row of the code tile (odd multiple of 4: conflict-free)
+    L.off_codes = (L.cb_bytes + 15) & ~15;
+    L.off_rn = (L.off_codes + 2 * LQ_TR * L.rs + 15) & ~15;
+    L.off_park = L.off_rn + 2 * LQ_TR * 4;
+    L.total = L.off_park + 8 * LQ_PARK * (8 + 4);
+    return L;
+}
+bool ivf_lm_pq_lds_supported(int d, int dpad, int M) {
+    if (dpad > 128 || M < 4 || (M & 3) || d % M) return false;
+    const int dsub = d / M;
+    if (!(dsub == 1 || dsub == 2 || (dsub & 3) == 0)) return false;
+    return lq_layout(d, M).total <= 160 * 1024;
+}
+
+template <int METRIC, int PASS, int DS, bool FULL>
+__global__ void __launch_bounds__(LQ_THREADS, 2) ivf_lm_pq_kernel(IvfLmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    const int j = lane & 31;
+    const int np = p.nprobe;
+    const int M = p.M, dsub = p.dsub;
+    const int ns = FULL ? 16 : (p.dpad >> 3);
+    const LqLayout L = lq_layout(p.d, M);
+    const float* cb = (const float*)smem;
+    const int wq = wave & 1, wr = wave >> 1; // query block, row block of this wave
+
+    // ---- the codebook, once per workgroup
+    {
+        const f32x4* src = (const f32x4*)p.pq_centroids;
+        f32x4* dst = (f32x4*)smem;
+        for (int i = tid; i < p.d * 64; i += LQ_THREADS) dst[i] = src[i];
+    }
+    u64* pk_keys = (u64*)(smem + L.off_park) + wave * LQ_PARK;
+    uint32_t* pk_q = (uint32_t*)(smem + L.off_park + 8 * LQ_PARK * 8) + wave * LQ_PARK;
+    int wcnt = 0; // (wave-uniform) parked candidates of pass 2
+    auto flush = [&]() __attribute__((always_inline)) {
+        for (int e = lane; e < wcnt; e += 64) {
+            const u64 key = pk_keys[e];
+            const uint32_t qq = pk_q[e];
+            uint32_t slot;
+            uint32_t* cp = p.cnt + qq;
+            const uint32_t one = 1u;
+            asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(slot) : "v"(cp), "v"(one) : "memory");
+            if ((int64_t)slot < p.stride) p.keys[(int64_t)qq * p.stride + slot] = key;
+        }
+        wcnt = 0;
+    };
+    // barrier of the tile loop: this thread's LDS writes have completed, no fence (a fenced __syncthreads() would also wait
+    // for the key stores of the epilogue, every tile)
+    auto tile_barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    __syncthreads();
+
+    const uint32_t it0 = p.item_bounds[PASS - 1], it1 = p.item_bounds[PASS];
+    for (uint32_t it = it0 + blockIdx.x; it < it1; it += gridDim.x) {
+        const IvfLmItem item = p.items[it];
+        const int bk = __builtin_amdgcn_readfirstlane(item.bucket);
+        const int qt = __builtin_amdgcn_readfirstlane(item.qt);
+        const int rt = __builtin_amdgcn_readfirstlane(item.rt);
+        const int list = bk >= p.nlist ? bk - p.nlist : bk;
+        const int len = (int)p.list_len[list];
+        const int64_t start = p.list_start[list];
+        const uint32_t pb = p.bucket_start[bk];
+        const int npair = min(kLmQueriesPerItem, (int)(p.bucket_start[bk + 1] - pb) - qt * kLmQueriesPerItem);
+        const int r0 = rt * p.rows_per_item;
+        const int r1 = p.force_all ? len : min(len, r0 + p.rows_per_item);
+
+        // ---- staging of a tile: thread -> 16 stored code bytes of one row (ch = 16) in registers, rn of one row
+        const int ch = pq_chunk_bytes(M);
+        const int npieces = LQ_TR * (M >> 4); // ch == 16 only
+        uint4 creg[2];
+        float rnreg = 0.f;
+        auto prefetch = [&](int t) __attribute__((always_inline)) {
+            if (ch == 16) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int piece = tid + LQ_THREADS * i;
+                    if (piece < npieces) {
+                        const int r = piece & (LQ_TR - 1), c = piece >> 7;
+                        const int64_t row = start + t + r; // arena row (lists start on 64-row block boundaries)
+                        creg[i] = *(const uint4*)(p.arena_codes + (size_t)(row >> 6) * 64 * M + (size_t)c * 1024 + (size_t)(row & 63) * 16);
+                    }
+                }
+            }
+            if (METRIC == METRIC_L2 && tid < LQ_TR) rnreg = t + tid < r1 ? p.arena_rn[start + t + tid] : 0.f;
+        };
+        auto stage = [&](int t, int buf) __attribute__((always_inline)) {
+            unsigned char* ct = (unsigned char*)(smem + L.off_codes + buf * LQ_TR * L.rs);
+            if (ch == 16) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int piece = tid + LQ_THREADS * i;
+                    if (piece < npieces) {
+                        const int r = piece & (LQ_TR - 1), c = piece >> 7;
+                        const int l = (int)((start + t + r) & 63);
+                        const unsigned w[4] = {creg[i].x, creg[i].y, creg[i].z, creg[i].w};
+#pragma unroll
+                        for (int b = 0; b < 16; ++b) {
+                            int m = (16 * c + b + l) % M; // stored byte j of row l is sub-quantizer (j + l) mod M
+                            ct[r * L.rs + m] = (unsigned char)(w[b >> 2] >> (8 * (b & 3)));
+                        }
+                    }
+                }
+            } else {
+                // (code chunks of 4 bytes: M not a multiple of 16) byte by byte
+                for (int idx = tid; idx < LQ_TR * M; idx += LQ_THREADS) {
+                    const int r = idx & (LQ_TR - 1), m = idx >> 7;
+                    ct[r * L.rs + m] = p.arena_codes[pq_code_offset(M, start + t + r, m)];
+                }
+            }
+            if (METRIC == METRIC_L2 && tid < LQ_TR) ((float*)(smem + L.off_rn))[buf * LQ_TR + tid] = rnreg;
+        };
+        prefetch(r0);
+
+        // ---- this lane's query
+        const int my = wq * 32 + j;
+        const bool qv = my < npair;
+        const uint32_t pi = p.pairs[pb + (uint32_t)(qt * kLmQueriesPerItem) + (uint32_t)(qv ? my : 0)];
+        const int q = (int)(pi / (uint32_t)np);
+        const int pr = (int)(pi - (uint32_t)q * (uint32_t)np);
+        const bool wave_active = wq * 32 < npair; // wave-uniform
+        const float* qrow = p.xq + (int64_t)q * p.ldq;
+        f32x4 bq[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            if (FULL || s < ns) bq[s] = *(const f32x4*)(qrow + 8 * s + 4 * h);
+            else bq[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        float xn = 0.f;
+        if (METRIC == METRIC_L2) {
+            const float* cen = p.centroids + (int64_t)list * p.ldc;
+            float acc = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                if (FULL || s < ns) {
+                    const f32x4 c4 = *(const f32x4*)(cen + 8 * s + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = bq[s][e] - c4[e];
+                        bq[s][e] = v;
+                        acc = __fmaf_rn(v, v, acc);
+                    }
+                }
+            }
+            xn = acc + __shfl_xor(acc, 32, 64);
+        } else {
+            xn = p.coarse_dis[pi];
+        }
+        const uint32_t base_pos = p.prefix[(int64_t)q * (np + 1) + pr];
+        const uint32_t base_slot = PASS == 1 ? p.prefix1[(int64_t)q * (np + 1) + pr] : 0u;
+        u64* kq = p.keys + (int64_t)q * p.stride;
+        float thr_f = 0.f;
+        if (PASS == 2) {
+            const uint32_t tk = p.thr[q];
+            if (tk >= kInvalidOrdKey) thr_f = METRIC == METRIC_L2 ? INFINITY : -INFINITY;
+            else thr_f = unordkey<METRIC>(tk);
+        }
+        auto dist_of = [&](float ip, float rn) -> float {
+            if (METRIC == METRIC_L2) {
+                const float dd = __fmaf_rn(-2.f, ip, xn + rn);
+                return dd < 0.f ? 0.f : dd;
+            }
+            return xn + ip;
+        };
+
+        stage(r0, 0);
+        tile_barrier();
+        int buf = 0;
+        for (int t = r0; t < r1; t += LQ_TR, buf ^= 1) {
+            const bool more = t + LQ_TR < r1;
+            if (more) prefetch(t + LQ_TR);
+            if (wave_active && t + wr * 32 < r1) {
+                const unsigned char* crow = (const unsigned char*)(smem + L.off_codes + buf * LQ_TR * L.rs) + (wr * 32 + j) * L.rs;
+                const float* rnt = (const float*)(smem + L.off_rn) + buf * LQ_TR + wr * 32;
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    if (FULL || s < ns) {
+                        const int kb = 8 * s + 4 * h; // first coordinate of this operand
+                        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                        if (kb < p.d) {
+                            if (DS == 2) {
+                                const int m0 = kb >> 1;
+                                const unsigned c0 = crow[m0], c1 = crow[m0 + 1];
+                                const float2 lo = *(const float2*)(cb + ((m0 << 8) + c0) * 2);
+                                const float2 hi = *(const float2*)(cb + (((m0 + 1) << 8) + c1) * 2);
+                                a = f32x4{lo.x, lo.y, hi.x, hi.y};
+                            } else if (DS == 1) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) a[e] = cb[((kb + e) << 8) + crow[kb + e]];
+                            } else {
+                                const int m = kb / dsub, off = kb - m * dsub;
+                                a = *(const f32x4*)(cb + ((m << 8) + crow[m]) * dsub + off);
+                            }
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], bq[s][e], acc, 0, 0, 0);
+                    }
+                }
+                // ---- epilogue: 16 distances of this lane's query (as in the generic kernel)
+                const int row_b = t + wr * 32 + 4 * h; // row of the list of acc[4 g + e]: row_b + 8 g + e
+                if (PASS == 1) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 b4 = *(const f32x4*)(rnt + 8 * g + 4 * h);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int rowl = row_b + 8 * g + e;
+                            const uint32_t pos = base_pos + (uint32_t)rowl;
+                            if (qv && rowl < r1 && !(p.dbg & 1))
+                                kq[base_slot + (uint32_t)rowl] = ((u64)ordkey<METRIC>(dist_of(acc[4 * g + e], b4[e])) << 32) | pos;
+                        }
+                    }
+                } else {
+                    unsigned mask = 0;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 b4 = *(const f32x4*)(rnt + 8 * g + 4 * h);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float dis = dist_of(acc[4 * g + e], b4[e]);
+                            const bool pass = (METRIC == METRIC_L2 ? dis <= thr_f : dis >= thr_f) && row_b + 8 * g + e < r1;
+                            mask |= pass ? 1u << (4 * g + e) : 0u;
+                        }
+                    }
+                    if (!qv || (p.dbg & 1)) mask = 0;
+                    if (__ballot(mask != 0u)) {
+                        const int c = __popc(mask);
+                        int inc = c;
+#pragma unroll
+                        for (int off = 1; off < 64; off <<= 1) {
+                            const int o = __shfl_up(inc, off, 64);
+                            if (lane >= off) inc += o;
+                        }
+                        const int total = __builtin_amdgcn_readlane(inc, 63);
+                        if (total > LQ_PARK) {
+                            if (mask) {
+                                uint32_t slot;
+                                uint32_t* cp = p.cnt + q;
+                                const uint32_t nc = (uint32_t)c;
+                                asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)"
+                                             : "=&v"(slot)
+                                             : "v"(cp), "v"(nc)
+                                             : "memory");
+#pragma unroll
+                                for (int g = 0; g < 4; ++g) {
+                                    const f32x4 b4 = *(const f32x4*)(rnt + 8 * g + 4 * h);
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        if (mask & (1u << (4 * g + e))) {
+                                            const uint32_t pos = base_pos + (uint32_t)(row_b + 8 * g + e);
+                                            if ((int64_t)slot < p.stride)
+                                                kq[slot] = ((u64)ordkey<METRIC>(dist_of(acc[4 * g + e], b4[e])) << 32) | pos;
+                                            ++slot;
+                                        }
+                                    }
+                                }
+                            }
+                        } else {
+                            if (wcnt + total > LQ_PARK) flush();
+                            int at = wcnt + inc - c;
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const f32x4 b4 = *(const f32x4*)(rnt + 8 * g + 4 * h);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    if (mask & (1u << (4 * g + e))) {
+                                        const uint32_t pos = base_pos + (uint32_t)(row_b + 8 * g + e);
+                                        pk_keys[at] = ((u64)ordkey<METRIC>(dist_of(acc[4 * g + e], b4[e])) << 32) | pos;
+                                        pk_q[at] = (uint32_t)q;
+                                        ++at;
+                                    }
+                                }
+                            }
+                            wcnt += total;
+                        }
+                    }
+                }
+            }
+            if (more) stage(t + LQ_TR, buf ^ 1);
+            tile_barrier(); // next tile staged, this one no longer read
+        }
+    }
+    if (PASS == 2 && wcnt > 0) flush();
+}
+
+template <int METRIC, int PASS>
+static void lq_launch(const IvfLmParams& p, int grid_blocks, hipStream_t stream) {
+    const int lds = lq_layout(p.d, p.M).total;
+    const int ds = p.dsub == 1 ? 1 : p.dsub == 2 ? 2 : 4;
+    const bool full = p.dpad == 128;
+#define FA_LQ(DS_, F_)                                                                                                  \
+    do {                                                                                                                \
+        HIP_CHECK(hipFuncSetAttribute((const void*)ivf_lm_pq_kernel<METRIC, PASS, DS_, F_>,                             \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));                                \
+        hipLaunchKernelGGL((ivf_lm_pq_kernel<METRIC, PASS, DS_, F_>), dim3((unsigned)grid_blocks), dim3(LQ_THREADS), lds, \
+                           stream, p);                                                                                  \
+    } while (0)
+    if (ds == 1) {
+        if (full) FA_LQ(1, true);
+        else FA_LQ(1, false);
+    } else if (ds == 2) {
+        if (full) FA_LQ(2, true);
+        else FA_LQ(2, false);
+    } else {
+        if (full) FA_LQ(4, true);
+        else FA_LQ(4, false);
+    }
+#undef FA_LQ
+}
+
 template <int METRIC, int KIND, int PASS>
 static void lm_launch3(const IvfLmParams& p, int grid_blocks, hipStream_t stream) {
     const int lds = KIND == 0 ? LM2_LDS_TOTAL : LM_LDS_TOTAL_P;
@@ -702,10 +1036,29 @@ static void lm_launch2(const IvfLmParams& p, int pass, int grid_blocks, hipStrea
 int ivf_lm_blocks_per_cu(int kind) {
     return kind == 0 ? 2 : 3;
 }
+static bool lm_use_pq_lds(const IvfLmParams& p) {
+    static const char* e = getenv("FAISS_AMD_LM_PQ_GENERIC"); // timing experiments: 1 = the generic (L2-gather) kernel
+    return p.kind == 1 && ivf_lm_pq_lds_supported(p.d, p.dpad, p.M) && !(e && atoi(e) == 1);
+}
+int ivf_lm_grid_blocks(const IvfLmParams& p, int num_cus) {
+    if (lm_use_pq_lds(p)) return num_cus; // one 8-wave workgroup per CU (the codebook fills its LDS)
+    return ivf_lm_blocks_per_cu(p.kind) * num_cus / 8 * 8;
+}
 void launch_ivf_lm_scan(const IvfLmParams& p, int pass, int grid_blocks, hipStream_t stream) {
     if (p.nq == 0) return;
     FA_THROW_IF_NOT(ivf_lm_supported(p.kind, p.dpad, p.M, p.d) && (pass == 1 || pass == 2) && grid_blocks > 0);
     FA_THROW_IF_NOT(p.ldq % 4 == 0 && (p.kind != 0 || p.ldv % 4 == 0) && (p.kind != 1 || p.ldc % 4 == 0));
+    if (lm_use_pq_lds(p)) {
+        if (p.metric == METRIC_L2) {
+            if (pass == 1) lq_launch<METRIC_L2, 1>(p, grid_blocks, stream);
+            else lq_launch<METRIC_L2, 2>(p, grid_blocks, stream);
+        } else {
+            if (pass == 1) lq_launch<METRIC_INNER_PRODUCT, 1>(p, grid_blocks, stream);
+            else lq_launch<METRIC_INNER_PRODUCT, 2>(p, grid_blocks, stream);
+        }
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     if (p.metric == METRIC_L2) {
         if (p.kind == 0) lm_launch2<METRIC_L2, 0>(p, pass, grid_blocks, stream);
         else lm_launch2<METRIC_L2, 1>(p, pass, grid_blocks, stream);

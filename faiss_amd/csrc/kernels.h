@@ -453,6 +453,9 @@ void launch_ivf_lm_plan(const IvfLmParams& p, hipStream_t stream);
 void launch_ivf_lm_scan(const IvfLmParams& p, int pass, int grid_blocks, hipStream_t stream);
 // workgroups of the scan kernel that are resident per CU (IVFFlat: two, with two tiles in LDS each; IVFPQ: three)
 int ivf_lm_blocks_per_cu(int kind);
+// persistent workgroups to launch for this problem (IVFPQ with the codebook in LDS: one 8-wave workgroup per CU)
+int ivf_lm_grid_blocks(const IvfLmParams& p, int num_cus);
+bool ivf_lm_pq_lds_supported(int d, int dpad, int M);
 // cnt[q] > stride -> cnt[q] = stride, the query is listed in ovf
 void launch_ivf_lm_clamp(const IvfLmParams& p, hipStream_t stream);
 // out[dest[i]] = |x_i|^2 as the sequential fmaf chain of l2_norms_kernel, for dest[i] >= 0
