@@ -102,6 +102,9 @@ def load_library():
         "faiss_amd_IndexIVF_copy_lists": (i32, [vp, vp, vp, vp]),
         "faiss_amd_kmeans_clustering": (i32, [vp, i32, i64, i32, vp, i32, i32, vp, vp]),
         "faiss_amd_Clustering_train": (i32, [vp, i64, vp, i32, i32, i32, vp, vp, vp]),
+        "faiss_amd_ClusteringParameters_init": (None, [vp]),
+        "faiss_amd_Clustering_train_ex": (i32, [vp, i64, vp, i32, vp, vp, i32, vp, vp, vp]),
+        "faiss_amd_IndexIVF_set_clustering_params": (i32, [vp, vp]),
         "faiss_amd_merge_knn_results": (i32, [i32, i64, i64, i32, vp, vp, vp, vp, vp]),
         "faiss_amd_merge_knn_results_device": (i32, [vp, i32, i64, i64, i32, vp, vp, vp, vp, vp]),
         "faiss_amd_profile_enable": (i32, [vp, i32]),
@@ -125,6 +128,7 @@ def load_library():
         "faiss_amd_GpuIndexIVF_reclaimMemory": (i32, [vp, P(sz)]),
         "faiss_amd_GpuIndexIVF_updateQuantizer": (i32, [vp]),
         "faiss_amd_GpuIndexIVFPQ_setPrecomputedCodes": (i32, [vp, i32]),
+        "faiss_amd_GpuIndexIVFPQ_getTableInfo": (i32, [vp, P(i32), P(i32), P(i32)]),
         "faiss_amd_GpuIndexIVFPQ_getInfo": (i32, [vp, P(i32), P(i32), P(i32), P(i32)]),
         "faiss_amd_IndexIVF_quantizer_search": (i32, [vp, i64, vp, i64, vp, vp]),
         "faiss_amd_bfKnn": (i32, [vp, i32, vp, i64, vp, i64, i32, i64, vp, vp]),
@@ -591,6 +595,11 @@ class _GpuIndexIVF(Index):
     def set_clustering(self, niter=10, seed=1234):
         _check(self._lib.faiss_amd_IndexIVF_set_clustering(self._h, int(niter), int(seed)))
 
+    def set_clustering_params(self, **params):
+        """GpuIndexIVF.cp: ClusteringParameters of the coarse quantizer's training (niter, nredo, spherical, seed, ...)"""
+        cp = ClusteringParameters(**params)
+        _check(self._lib.faiss_amd_IndexIVF_set_clustering_params(self._h, ctypes.byref(cp)))
+
     def get_list_size(self, l):
         v = ctypes.c_size_t(0)
         _check(self._lib.faiss_amd_IndexIVF_get_list_size(self._h, int(l), ctypes.byref(v)))
@@ -791,7 +800,14 @@ class GpuIndexIVFPQ(_GpuIndexIVF):
         _check(self._lib.faiss_amd_GpuIndexIVFPQ_setPrecomputedCodes(self._h, int(bool(enable))))
 
     def getPrecomputedCodes(self):
+        """what is IN FORCE: True for L2 (the per-vector term is always used), False for inner product"""
         return bool(self._info()[0])
+
+    def getTableInfo(self):
+        """(precomputed codes in force, precomputed codes requested, fp16 lookup tables in force -- always False)"""
+        a, b, c = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        _check(self._lib.faiss_amd_GpuIndexIVFPQ_getTableInfo(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return bool(a.value), bool(b.value), bool(c.value)
 
     def getNumSubQuantizers(self):
         return self._info()[1]
@@ -897,14 +913,30 @@ def kmeans(res, x, k, niter=25, seed=1234):
     return cent, obj
 
 
+class ClusteringParameters(ctypes.Structure):
+    """faiss.ClusteringParameters (faiss/Clustering.h:27-60) as the C ABI takes it"""
+    _fields_ = [(n, ctypes.c_int) for n in ("niter", "nredo", "verbose", "spherical", "int_centroids", "update_index",
+                                            "frozen_centroids", "min_points_per_centroid", "max_points_per_centroid", "seed")]
+
+    def __init__(self, **kw):
+        super().__init__()
+        load_library().faiss_amd_ClusteringParameters_init(ctypes.byref(self))
+        for k_, v in kw.items():
+            if k_ not in dict(self._fields_):
+                raise TypeError("unknown clustering parameter " + k_)
+            setattr(self, k_, int(v))
+
+
 class Clustering:
     """faiss.Clustering (faiss/Clustering.h:88-196): k-means with an index as the assignment engine.
 
-    c = Clustering(d, k, niter=..., seed=...); c.train(x, index); c.centroids, c.obj (objective per iteration).
-    With a GpuIndexFlat the loop runs on the device (c.on_device is True)."""
+    c = Clustering(d, k, niter=..., seed=..., nredo=..., spherical=..., int_centroids=..., frozen_centroids=...);
+    c.centroids = initial centroids (optional); c.train(x, index); c.centroids, c.obj (objective per iteration of the
+    winning run).  With a GpuIndexFlat the loop runs on the device (c.on_device is True)."""
 
-    def __init__(self, d, k, niter=25, seed=1234):
+    def __init__(self, d, k, niter=25, seed=1234, **params):
         self.d, self.k, self.niter, self.seed = int(d), int(k), int(niter), int(seed)
+        self.params = params
         self.centroids = None
         self.obj = None
         self.on_device = None
@@ -916,8 +948,12 @@ class Clustering:
         cent = np.empty((self.k, d), dtype=np.float32)
         obj = np.empty(self.niter, dtype=np.float32)
         dev = ctypes.c_int(0)
-        _check(load_library().faiss_amd_Clustering_train(index._h, n, _ptr(x), self.k, self.niter, self.seed,
-                                                         _ptr(cent), _ptr(obj), ctypes.byref(dev)))
+        cp = ClusteringParameters(niter=self.niter, seed=self.seed, **self.params)
+        init = None if self.centroids is None else _f32(self.centroids, self.d)
+        _check(load_library().faiss_amd_Clustering_train_ex(index._h, n, _ptr(x), self.k, ctypes.byref(cp),
+                                                            _ptr(init) if init is not None and len(init) else None,
+                                                            0 if init is None else len(init), _ptr(cent), _ptr(obj),
+                                                            ctypes.byref(dev)))
         self.centroids, self.obj, self.on_device = cent, obj, bool(dev.value)
 
 

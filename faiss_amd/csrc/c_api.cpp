@@ -505,6 +505,52 @@ int faiss_amd_Clustering_train(FaissAmdIndex* index, faiss_amd_idx_t n, const fl
     FA_CATCH
 }
 
+static void to_cp(const FaissAmdClusteringParameters& a, ClusteringParameters& c) {
+    FA_THROW_IF_NOT_MSG(a.niter >= 0 && a.nredo >= 1, "clustering parameters: niter >= 0, nredo >= 1");
+    FA_THROW_IF_NOT_MSG(a.max_points_per_centroid >= 1, "clustering parameters: max_points_per_centroid >= 1");
+    c.niter = a.niter;
+    c.nredo = a.nredo;
+    c.verbose = a.verbose != 0;
+    c.spherical = a.spherical != 0;
+    c.int_centroids = a.int_centroids != 0;
+    c.update_index = a.update_index != 0;
+    c.frozen_centroids = a.frozen_centroids != 0;
+    c.min_points_per_centroid = a.min_points_per_centroid;
+    c.max_points_per_centroid = a.max_points_per_centroid;
+    c.seed = a.seed;
+}
+void faiss_amd_ClusteringParameters_init(FaissAmdClusteringParameters* p) {
+    if (!p) return;
+    const ClusteringParameters d;
+    *p = FaissAmdClusteringParameters{d.niter, d.nredo, 0, 0, 0, 0, 0, d.min_points_per_centroid, d.max_points_per_centroid, d.seed};
+}
+int faiss_amd_Clustering_train_ex(FaissAmdIndex* index, faiss_amd_idx_t n, const float* x, int k,
+                                  const FaissAmdClusteringParameters* params, const float* init_centroids, int n_init,
+                                  float* centroids_out, float* obj_out, int* on_device_out) {
+    FA_TRY
+    Index* ix = as<Index>(index, "Index");
+    FA_THROW_IF_NOT_MSG(params && centroids_out, "null argument");
+    FA_THROW_IF_NOT_MSG(n_init >= 0 && n_init <= k && (n_init == 0 || init_centroids), "bad initial centroids");
+    Clustering clus(ix->d, k);
+    to_cp(*params, clus);
+    if (n_init) clus.centroids.assign(init_centroids, init_centroids + (size_t)n_init * ix->d);
+    clus.train(n, x, *ix);
+    memcpy(centroids_out, clus.centroids.data(), sizeof(float) * (size_t)k * ix->d);
+    if (obj_out) memcpy(obj_out, clus.obj.data(), sizeof(float) * clus.obj.size());
+    if (on_device_out) *on_device_out = clus.last_train_on_device ? 1 : 0;
+    FA_CATCH
+}
+int faiss_amd_IndexIVF_set_clustering_params(FaissAmdIndex* index, const FaissAmdClusteringParameters* params) {
+    FA_TRY
+    auto* ivf = as<GpuIndexIVF>(index, "GpuIndexIVF");
+    FA_THROW_IF_NOT_MSG(params, "null parameters");
+    to_cp(*params, ivf->cp);
+    FA_THROW_IF_NOT_MSG(params->niter >= 1, "niter must be positive");
+    ivf->cp_niter = params->niter;
+    ivf->cp_seed = params->seed;
+    FA_CATCH
+}
+
 int faiss_amd_merge_knn_results(FaissAmdMetricType metric, faiss_amd_idx_t n, faiss_amd_idx_t k, int nshard,
                                 const float* all_d, const faiss_amd_idx_t* all_i,
                                 const faiss_amd_idx_t* base, float* distances, faiss_amd_idx_t* labels) {
@@ -615,6 +661,15 @@ int faiss_amd_GpuIndexIVFPQ_getInfo(const FaissAmdIndex* index, int* precomputed
     if (num_sub_quantizers) *num_sub_quantizers = pq->getNumSubQuantizers();
     if (bits_per_code) *bits_per_code = pq->getBitsPerCode();
     if (centroids_per_sub_quantizer) *centroids_per_sub_quantizer = pq->getCentroidsPerSubQuantizer();
+    FA_CATCH
+}
+int faiss_amd_GpuIndexIVFPQ_getTableInfo(const FaissAmdIndex* index, int* precomputed_in_force, int* precomputed_requested,
+                                         int* float16_tables_in_force) {
+    FA_TRY
+    const GpuIndexIVFPQ* pq = as<GpuIndexIVFPQ>(index, "GpuIndexIVFPQ");
+    if (precomputed_in_force) *precomputed_in_force = pq->getPrecomputedCodes() ? 1 : 0;
+    if (precomputed_requested) *precomputed_requested = pq->getPrecomputedCodesRequested() ? 1 : 0;
+    if (float16_tables_in_force) *float16_tables_in_force = pq->getFloat16LookupTables() ? 1 : 0;
     FA_CATCH
 }
 int faiss_amd_GpuIndexIVF_add_core(FaissAmdIndex* index, faiss_amd_idx_t n, const float* x, const faiss_amd_idx_t* xids,

@@ -1191,16 +1191,23 @@ void GpuIndexFlat::pairwise_distances(idx_t n, const float* x, float* out) const
 // host.  Random choices use our own generator, so centroids are not bit-identical to faiss
 // (its own GPU tests only compare the objective, faiss/gpu/test/test_gpu_basics.py:117-133).
 // split big clusters into empty ones (faiss/Clustering.cpp split_clusters); centroids on the host
-void Clustering::split_clusters_(std::mt19937_64& rng, idx_t nx, std::vector<idx_t>& hassign) {
+void Clustering::split_clusters_(std::mt19937_64& rng, idx_t nx, std::vector<idx_t>& hassign, int first_free) {
     const float EPS = 1.f / 1024.f;
-    for (int ci = 0; ci < k; ci++) {
+    // (frozen centroids are neither refilled nor split: faiss/Clustering.cpp:180-232 starts at k_frozen)
+    for (int ci = first_free; ci < k; ci++) {
         if (hassign[ci] != 0) continue;
-        int cj = 0;
-        for (;;) {
+        int cj = first_free;
+        for (long tries = 0;; ++tries) {
             double p = (hassign[cj] - 1.0) / (double)(nx - k);
             double r = (double)(rng() >> 11) * (1.0 / 9007199254740992.0);
             if (r < p) break;
-            cj = (cj + 1) % k;
+            if (tries > 64L * k) {
+                // (only reachable with frozen centroids owning nearly all points: take the largest free cluster)
+                for (int c = first_free; c < k; c++)
+                    if (hassign[c] > hassign[cj]) cj = c;
+                break;
+            }
+            cj = cj + 1 < k ? cj + 1 : first_free;
         }
         memcpy(&centroids[(size_t)ci * d], &centroids[(size_t)cj * d], sizeof(float) * d);
         for (int j = 0; j < d; j++) {
@@ -1217,19 +1224,71 @@ void Clustering::split_clusters_(std::mt19937_64& rng, idx_t nx, std::vector<idx
     }
 }
 
+void Clustering::post_process_(int first_free) {
+    if (spherical) {
+        // fvec_renorm_L2 (faiss/utils/distances.cpp): x /= sqrt(|x|^2), zero vectors stay
+        for (int c = first_free; c < k; c++) {
+            float* v = &centroids[(size_t)c * d];
+            float n2 = 0.f;
+            for (int j = 0; j < d; j++) n2 += v[j] * v[j];
+            if (n2 > 0.f) {
+                const float inv = 1.f / sqrtf(n2);
+                for (int j = 0; j < d; j++) v[j] *= inv;
+            }
+        }
+    }
+    if (int_centroids)
+        for (size_t i = (size_t)first_free * d; i < (size_t)k * d; i++) centroids[i] = roundf(centroids[i]);
+}
+
+// faiss::Clustering::train_encoded's outer structure (faiss/Clustering.cpp:255-420): nredo runs from different random
+// starts, the centroids of the run with the best final objective are kept and end up in the index
 void Clustering::train(idx_t nx, const float* x_in, Index& index, int64_t ldx) {
     FA_THROW_IF_NOT_MSG(nx >= k, "need at least as many training points as clusters");
+    FA_THROW_IF_NOT_MSG(nredo >= 1 && niter >= 0, "nredo must be positive");
+    FA_THROW_IF_NOT_MSG(centroids.size() % (size_t)d == 0 && centroids.size() <= (size_t)k * d,
+                        "initial centroids: a multiple of d floats, at most k vectors");
+    const std::vector<float> init = centroids;
+    if (nredo == 1) {
+        train_once_(nx, x_in, index, ldx, (uint64_t)seed, init);
+        return;
+    }
+    const bool similarity = order_metric(index.metric_type) == METRIC_INNER_PRODUCT;
+    std::vector<float> best_c, best_obj;
+    float best = 0.f;
+    for (int redo = 0; redo < nredo; redo++) {
+        train_once_(nx, x_in, index, ldx, (uint64_t)seed + 1 + (uint64_t)redo, init);
+        const float o = obj.empty() ? 0.f : obj.back();
+        if (verbose) printf("k-means run %d of %d: objective %g\n", redo + 1, nredo, o);
+        if (redo == 0 || (similarity ? o > best : o < best)) {
+            best = o;
+            best_c = centroids;
+            best_obj = obj;
+        }
+    }
+    centroids = best_c;
+    obj = best_obj;
+    index.reset();
+    index.add(k, centroids.data());
+}
+
+void Clustering::train_once_(idx_t nx, const float* x_in, Index& index, int64_t ldx, uint64_t run_seed,
+                             const std::vector<float>& init) {
     last_train_on_device = false;
     if (ldx == 0) ldx = d;
     if (auto* flat = dynamic_cast<GpuIndexFlat*>(&index)) {
         if (!flat->getUseFloat16() && flat->d == d && nx < ((idx_t)1 << 31)) {
-            train_device_(nx, x_in, ldx, *flat);
+            train_device_(nx, x_in, ldx, *flat, run_seed, init);
             return;
         }
     }
     FA_THROW_IF_NOT_MSG(!is_device_pointer(x_in) && ldx == d,
                         "k-means through a generic assignment index takes dense host training data");
-    std::mt19937_64 rng((uint64_t)seed);
+    train_host_(nx, x_in, index, run_seed, init);
+}
+
+void Clustering::train_host_(idx_t nx, const float* x_in, Index& index, uint64_t run_seed, const std::vector<float>& init) {
+    std::mt19937_64 rng(run_seed);
     // ---- subsample (faiss/Clustering.cpp subsample_training_set)
     std::vector<float> sub;
     const float* x = x_in;
@@ -1247,17 +1306,21 @@ void Clustering::train(idx_t nx, const float* x_in, Index& index, int64_t ldx) {
         x = sub.data();
         nx = ns;
     }
-    // ---- init: k distinct random points
-    centroids.resize((size_t)k * d);
+    // ---- init: the given centroids, then distinct random points for the rest
+    const int n_init = (int)(init.size() / (size_t)d);
+    const int first_free = frozen_centroids ? n_init : 0;
+    centroids.assign((size_t)k * d, 0.f);
+    if (n_init) memcpy(centroids.data(), init.data(), init.size() * sizeof(float));
     {
         std::vector<idx_t> perm(nx);
         std::iota(perm.begin(), perm.end(), 0);
-        for (int i = 0; i < k; i++) {
+        for (int i = 0; i < k - n_init; i++) {
             idx_t j = i + (idx_t)(rng() % (uint64_t)(nx - i));
             std::swap(perm[i], perm[j]);
-            memcpy(&centroids[(size_t)i * d], x + (size_t)perm[i] * d, sizeof(float) * d);
+            memcpy(&centroids[(size_t)(n_init + i) * d], x + (size_t)perm[i] * d, sizeof(float) * d);
         }
     }
+    post_process_(first_free);
     std::vector<idx_t> assign(nx);
     std::vector<float> dis(nx);
     std::vector<double> sums((size_t)k * d);
@@ -1282,12 +1345,13 @@ void Clustering::train(idx_t nx, const float* x_in, Index& index, int64_t ldx) {
             double* s = &sums[(size_t)c * d];
             for (int j = 0; j < d; j++) s[j] += xi[j];
         }
-        for (int c = 0; c < k; c++) {
+        for (int c = first_free; c < k; c++) {
             if (hassign[c] == 0) continue;
             for (int j = 0; j < d; j++)
                 centroids[(size_t)c * d + j] = (float)(sums[(size_t)c * d + j] / (double)hassign[c]);
         }
-        split_clusters_(rng, nx, hassign);
+        split_clusters_(rng, nx, hassign, first_free);
+        post_process_(first_free);
         if (verbose) printf("  k-means iteration %d objective %g\n", it, o);
     }
     index.reset();
@@ -1297,7 +1361,8 @@ void Clustering::train(idx_t nx, const float* x_in, Index& index, int64_t ldx) {
 // The same loop with everything but the random choices on the device.  The generator is drawn from in the same
 // order as above (subsample, initial points, splits) and the update adds in the same order, so both paths give
 // the same centroids bit for bit (tests/test_gpu_parity.py::test_kmeans_device_matches_host_loop).
-void Clustering::train_device_(idx_t nx, const float* x_in, int64_t ldx, GpuIndexFlat& flat) {
+void Clustering::train_device_(idx_t nx, const float* x_in, int64_t ldx, GpuIndexFlat& flat, uint64_t run_seed,
+                               const std::vector<float>& init) {
     last_train_on_device = true;
     auto res = flat.resources();
     const GpuResources& R = *res;
@@ -1305,7 +1370,10 @@ void Clustering::train_device_(idx_t nx, const float* x_in, int64_t ldx, GpuInde
     const int dp = flat.dpad();
     const bool x_dev = is_device_pointer(x_in);
     FA_THROW_IF_NOT_MSG(x_dev || ldx == d, "strided training rows must live on the device");
-    std::mt19937_64 rng((uint64_t)seed);
+    std::mt19937_64 rng(run_seed);
+    const int n_init = (int)(init.size() / (size_t)d);
+    const int first_free = frozen_centroids ? n_init : 0;
+    const bool post = spherical || int_centroids;
     DevBuf xd, raw, sel, tmp;
     // ---- subsample (faiss/Clustering.cpp subsample_training_set)
     if (nx > (idx_t)k * max_points_per_centroid) {
@@ -1339,20 +1407,34 @@ void Clustering::train_device_(idx_t nx, const float* x_in, int64_t ldx, GpuInde
     }
     raw.release();
     tmp.release();
-    // ---- init: k distinct random points
-    DevBuf cen; // [k][d] dense
+    // ---- init: the given centroids, then distinct random points for the rest
+    DevBuf cen, frozen; // [k][d] dense
     cen.ensure((size_t)k * d * 4);
+    centroids.resize((size_t)k * d);
     {
         std::vector<uint32_t> perm((size_t)nx);
         std::iota(perm.begin(), perm.end(), 0u);
-        for (int i = 0; i < k; i++) {
+        for (int i = 0; i < k - n_init; i++) {
             idx_t j = i + (idx_t)(rng() % (uint64_t)(nx - i));
             std::swap(perm[i], perm[j]);
         }
-        sel.ensure((size_t)k * 4);
-        HIP_CHECK(hipMemcpyAsync(sel.p, perm.data(), (size_t)k * 4, hipMemcpyHostToDevice, R.stream));
-        launch_gather_rows(xd.as<float>(), dp, d, sel.as<uint32_t>(), k, cen.as<float>(), R.stream);
+        if (n_init) HIP_CHECK(hipMemcpyAsync(cen.p, init.data(), init.size() * 4, hipMemcpyHostToDevice, R.stream));
+        if (k > n_init) {
+            sel.ensure((size_t)(k - n_init) * 4);
+            HIP_CHECK(hipMemcpyAsync(sel.p, perm.data(), (size_t)(k - n_init) * 4, hipMemcpyHostToDevice, R.stream));
+            launch_gather_rows(xd.as<float>(), dp, d, sel.as<uint32_t>(), k - n_init, cen.as<float>() + (size_t)n_init * d,
+                               R.stream);
+        }
         R.sync();
+        if (post) {
+            HIP_CHECK(hipMemcpy(centroids.data(), cen.p, (size_t)k * d * 4, hipMemcpyDeviceToHost));
+            post_process_(first_free);
+            HIP_CHECK(hipMemcpy(cen.p, centroids.data(), (size_t)k * d * 4, hipMemcpyHostToDevice));
+        }
+        if (first_free) {
+            frozen.ensure((size_t)first_free * d * 4);
+            HIP_CHECK(hipMemcpy(frozen.p, cen.p, (size_t)first_free * d * 4, hipMemcpyDeviceToDevice));
+        }
     }
     // a chunk per wavefront of the rank kernel (which walks its chunk 64 points at a time): about 512 of them
     int chunk = 256;
@@ -1372,7 +1454,6 @@ void Clustering::train_device_(idx_t nx, const float* x_in, int64_t ldx, GpuInde
     std::vector<float> hdis((size_t)nx);
     std::vector<uint32_t> hcnt((size_t)k);
     std::vector<idx_t> hassign(k);
-    centroids.resize((size_t)k * d);
     obj.clear();
     for (int it = 0; it < niter; it++) {
         check_interrupt();
@@ -1391,6 +1472,9 @@ void Clustering::train_device_(idx_t nx, const float* x_in, int64_t ldx, GpuInde
         launch_invert_dest(dest.as<int64_t>(), nx, order.as<uint32_t>(), R.stream);
         launch_kmeans_update(xd.as<float>(), dp, d, order.as<uint32_t>(), start.as<int64_t>(), cnt.as<uint32_t>(), k,
                              cen.as<float>(), R.stream);
+        // frozen centroids: what the update wrote over them is undone
+        if (first_free)
+            HIP_CHECK(hipMemcpyAsync(cen.p, frozen.p, (size_t)first_free * d * 4, hipMemcpyDeviceToDevice, R.stream));
         R.sync();
         double o = 0;
         for (idx_t i = 0; i < nx; i++) o += hdis[i];
@@ -1398,11 +1482,12 @@ void Clustering::train_device_(idx_t nx, const float* x_in, int64_t ldx, GpuInde
         bool any_empty = false;
         for (int c = 0; c < k; c++) {
             hassign[c] = hcnt[c];
-            any_empty |= hcnt[c] == 0;
+            any_empty |= c >= first_free && hcnt[c] == 0;
         }
-        if (any_empty) {
+        if (any_empty || post) {
             HIP_CHECK(hipMemcpy(centroids.data(), cen.p, (size_t)k * d * 4, hipMemcpyDeviceToHost));
-            split_clusters_(rng, nx, hassign);
+            if (any_empty) split_clusters_(rng, nx, hassign, first_free);
+            post_process_(first_free);
             HIP_CHECK(hipMemcpy(cen.p, centroids.data(), (size_t)k * d * 4, hipMemcpyHostToDevice));
         }
         if (verbose) printf("  k-means iteration %d objective %g\n", it, o);
@@ -1504,9 +1589,10 @@ void GpuIndexIVF::train(idx_t n, const float* x) {
     res_->set_device();
     if (quantizer->ntotal != nlist) {
         Clustering clus(d, nlist);
+        static_cast<ClusteringParameters&>(clus) = cp;
         clus.niter = cp_niter;
         clus.seed = cp_seed;
-        clus.verbose = verbose;
+        clus.verbose = verbose || cp.verbose;
         // the quantizer itself is the assignment index, exactly like GpuIndexIVF::trainQuantizer_
         // (faiss/gpu/GpuIndexIVF.cu:508-538)
         clus.train(n, x, *quantizer);

@@ -310,6 +310,20 @@ class GpuIndexFlat : public Index {
     void search_tile_(int n, const float* xq_pad, int k, float* dD, idx_t* dI) const;
 };
 
+// faiss::ClusteringParameters (faiss/Clustering.h:27-60), the fields of the k-means loop proper
+struct ClusteringParameters {
+    int niter = 25;
+    int nredo = 1;                 // runs from different random starts; the best objective wins
+    int seed = 1234;
+    int max_points_per_centroid = 256;
+    int min_points_per_centroid = 39;
+    bool verbose = false;
+    bool spherical = false;        // L2-normalise the centroids after every update (inner-product clustering)
+    bool int_centroids = false;    // round the centroid coordinates to integers after every update
+    bool update_index = false;     // re-train the assignment index after every update (flat engines: nothing to train)
+    bool frozen_centroids = false; // centroids given as input (Clustering::centroids before train) are never updated
+};
+
 // ------------------------------------------------------------------ GpuIndexIVF
 class GpuIndexIVF : public Index {
    public:
@@ -369,6 +383,8 @@ class GpuIndexIVF : public Index {
     // quantizer, faiss/gpu/GpuIndexIVF.cu:80)
     int cp_niter = 10;
     int cp_seed = 1234;
+    // the rest of GpuIndexIVF::cp (faiss/gpu/GpuIndexIVF.h, faiss/Clustering.h:27-60); niter / seed above win
+    ClusteringParameters cp;
 
    protected:
     std::shared_ptr<GpuResources> res_;
@@ -479,10 +495,15 @@ class GpuIndexIVFPQ : public GpuIndexIVF {
     int pq_niter = 25; // faiss::ClusteringParameters default used by ProductQuantizer::train
     void set_pq_centroids(const float* pq); // [M][256][dsub]
     std::vector<float> get_pq_centroids() const;
-    // GpuIndexIVFPQ.h:98-113.  The term decomposition behind "precomputed codes" is always on here (one table per
-    // query + a per-vector term): the flag is recorded and reported, results do not depend on it.
+    // GpuIndexIVFPQ.h:98-113.  The term decomposition behind "precomputed codes" is always on here for L2 (one table per
+    // query + a per-vector term) and has no meaning for inner product (the reference forces it off there,
+    // GpuIndexIVFPQ.cu:228-241): the setter records the request, the getter reports what is IN FORCE -- true for L2,
+    // false for inner product, whatever was asked for.  Likewise the lookup tables are always fp32 (on a power-of-two
+    // grid): useFloat16LookupTables is accepted, getFloat16LookupTables() says false.
     void setPrecomputedCodes(bool enable) { precomputed_codes_ = enable; }
-    bool getPrecomputedCodes() const { return precomputed_codes_; }
+    bool getPrecomputedCodes() const { return metric_type == METRIC_L2; }
+    bool getPrecomputedCodesRequested() const { return precomputed_codes_; }
+    bool getFloat16LookupTables() const { return false; }
     int getNumSubQuantizers() const { return M; }
     int getBitsPerCode() const { return nbits; }
     int getCentroidsPerSubQuantizer() const { return 1 << nbits; }
@@ -648,13 +669,6 @@ void merge_knn_results_device(GpuResources& res, int metric, int nq, int k, int 
                               const idx_t* all_i, const idx_t* base_host, float* D, idx_t* I);
 
 // ------------------------------------------------------------------ Clustering (k-means)
-struct ClusteringParameters {
-    int niter = 25;
-    int seed = 1234;
-    int max_points_per_centroid = 256;
-    int min_points_per_centroid = 39;
-    bool verbose = false;
-};
 struct Clustering : ClusteringParameters {
     int d, k;
     std::vector<float> centroids; // [k][d]
@@ -666,12 +680,19 @@ struct Clustering : ClusteringParameters {
     // counting sort by cluster and centroid update as kernels; only the objective and the cluster sizes come back
     // per iteration) and x may be a host or a device pointer; results are bit-identical to the host loop.
     // ldx: row stride of x in floats (0 = d; other strides for device data only)
+    // `centroids` non-empty on entry = initial centroids (a multiple of d floats, at most k of them: the rest is drawn
+    // from the training set), faiss/Clustering.cpp:330-345; with frozen_centroids they stay as given.
     void train(idx_t n, const float* x, Index& index, int64_t ldx = 0);
     bool last_train_on_device = false;
 
    private:
-    void train_device_(idx_t n, const float* x, int64_t ldx, class GpuIndexFlat& flat);
-    void split_clusters_(std::mt19937_64& rng, idx_t nx, std::vector<idx_t>& hassign);
+    void train_once_(idx_t n, const float* x, Index& index, int64_t ldx, uint64_t run_seed, const std::vector<float>& init);
+    void train_host_(idx_t n, const float* x, Index& index, uint64_t run_seed, const std::vector<float>& init);
+    void train_device_(idx_t n, const float* x, int64_t ldx, class GpuIndexFlat& flat, uint64_t run_seed,
+                       const std::vector<float>& init);
+    // post_process_centroids (faiss/Clustering.cpp:236-253) on the host copy; first_free: centroids [0, first_free) frozen
+    void post_process_(int first_free);
+    void split_clusters_(std::mt19937_64& rng, idx_t nx, std::vector<idx_t>& hassign, int first_free = 0);
 };
 
 } // namespace faiss_amd

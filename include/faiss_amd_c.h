@@ -207,6 +207,25 @@ int faiss_amd_IndexIVF_copy_lists(FaissAmdIndex* index, const uint32_t* list_siz
 int faiss_amd_kmeans_clustering(FaissAmdGpuResources* res, int d, faiss_amd_idx_t n, int k, const float* x,
                                 int niter, int seed, float* centroids_out, float* obj_out);
 
+/* faiss::ClusteringParameters (faiss/Clustering.h:27-60; c_api/Clustering_c.h:22-58 FaissClusteringParameters), the
+ * fields the k-means loop here honours.  nredo: runs from different random starts, best final objective wins;
+ * spherical: centroids L2-normalised after every update (inner-product clustering); int_centroids: rounded to integers;
+ * frozen_centroids: the initial centroids handed to train_ex are never updated; update_index is accepted (flat
+ * assignment engines have nothing to re-train). */
+typedef struct FaissAmdClusteringParameters {
+    int niter, nredo, verbose, spherical, int_centroids, update_index, frozen_centroids;
+    int min_points_per_centroid, max_points_per_centroid, seed;
+} FaissAmdClusteringParameters;
+/* c_api/Clustering_c.h:61 faiss_ClusteringParameters_init: the reference's defaults (niter 25, nredo 1, 39 / 256, seed 1234) */
+void faiss_amd_ClusteringParameters_init(FaissAmdClusteringParameters* params);
+/* Clustering::train with all parameters; init_centroids (nullable): n_init x d floats placed first (Clustering::centroids
+ * set before train, faiss/Clustering.cpp:330-345).  obj_out (nullable): niter floats of the winning run. */
+int faiss_amd_Clustering_train_ex(FaissAmdIndex* index, faiss_amd_idx_t n, const float* x, int k,
+                                  const FaissAmdClusteringParameters* params, const float* init_centroids, int n_init,
+                                  float* centroids_out, float* obj_out, int* on_device_out);
+/* GpuIndexIVF::cp (faiss/gpu/GpuIndexIVF.h): the clustering parameters train() uses for the coarse quantizer */
+int faiss_amd_IndexIVF_set_clustering_params(FaissAmdIndex* index, const FaissAmdClusteringParameters* params);
+
 /* faiss::Clustering::train(n, x, index) (faiss/Clustering.h:147-160; c_api/Clustering_c.h:118-122 faiss_Clustering_train):
  * k-means with `index` (dimension d, empty or not -- it is reset) as the assignment engine; on return the index holds
  * the k centroids.  With a GpuIndexFlat the whole loop runs on the device (x host or device); any other index of this
@@ -274,7 +293,9 @@ int faiss_amd_Index_compute_residual_n(const FaissAmdIndex* index, faiss_amd_idx
  *      reserveMemory: room for numVecs vectors up front (no re-allocation of the list arena by the adds that follow);
  *      reclaimMemory: give back slack, holes and add-path scratch, *p_bytes = device bytes released (may be NULL);
  *      updateQuantizer: call after changing the coarse centroids from outside.
- *      IVFPQ: precomputed codes are the per-vector term that is always on here -- the flag is kept and reported only. */
+ *      IVFPQ: precomputed codes are the per-vector term that is always on here for L2 -- the setter records the request,
+ *      the getter reports what is in force (1 for L2, 0 for inner product: GpuIndexIVFPQ.cu:228-241 forces it off there);
+ *      getTableInfo adds the request itself and the lookup-table precision in force (always fp32: 0). */
 int faiss_amd_GpuIndexIVF_reserveMemory(FaissAmdIndex* index, size_t num_vecs);
 int faiss_amd_GpuIndexIVF_reclaimMemory(FaissAmdIndex* index, size_t* p_bytes);
 int faiss_amd_GpuIndexIVF_updateQuantizer(FaissAmdIndex* index);
@@ -282,6 +303,8 @@ int faiss_amd_GpuIndexIVFPQ_setPrecomputedCodes(FaissAmdIndex* index, int enable
 /* getters of GpuIndexIVFPQ.h:104-113: any of the outputs may be NULL */
 int faiss_amd_GpuIndexIVFPQ_getInfo(const FaissAmdIndex* index, int* precomputed_codes, int* num_sub_quantizers,
                                     int* bits_per_code, int* centroids_per_sub_quantizer);
+int faiss_amd_GpuIndexIVFPQ_getTableInfo(const FaissAmdIndex* index, int* precomputed_in_force, int* precomputed_requested,
+                                         int* float16_tables_in_force);
 
 /* ---- GpuIndexIVF::add_core (faiss/gpu/GpuIndexIVF.h:84-95, GpuIndexIVF.cu:321-356; what contrib/ivf_tools.py
  *      add_preassigned drives): add n vectors whose inverted list is given by the caller (precomputed_idx [n], host or

@@ -317,6 +317,20 @@ struct AmdIndexIVF : AmdIndex, faiss::IndexIVFInterface {
         quantizer_view.ntotal = faiss_amd_IndexIVF_get_centroids(h, c.data()) == 0 ? (idx_t)nlist : 0;
     }
     void train(idx_t n, const float* x) override {
+        // GpuIndexIVF::cp (Level1Quantizer::cp, faiss/IndexIVF.h:60): the clustering parameters of the coarse quantizer
+        FaissAmdClusteringParameters p;
+        faiss_amd_ClusteringParameters_init(&p);
+        p.niter = cp.niter;
+        p.nredo = cp.nredo;
+        p.verbose = cp.verbose ? 1 : 0;
+        p.spherical = cp.spherical ? 1 : 0;
+        p.int_centroids = cp.int_centroids ? 1 : 0;
+        p.update_index = cp.update_index ? 1 : 0;
+        p.frozen_centroids = cp.frozen_centroids ? 1 : 0;
+        p.min_points_per_centroid = cp.min_points_per_centroid;
+        p.max_points_per_centroid = cp.max_points_per_centroid;
+        p.seed = cp.seed;
+        amd_check(faiss_amd_IndexIVF_set_clustering_params(h, &p));
         AmdIndex::train(n, x);
         refresh_quantizer_();
     }

@@ -43,7 +43,7 @@ def test_flat_100k_vs_reference_golden(res):
         check_knn(D[:32], I[:32], Do, Io, exact=True, name="flat 100k vs oracle")
 
 
-@pytest.mark.parametrize("name", ["ivfflat_l2_4096", "ivfpq_l2_4096"])
+@pytest.mark.parametrize("name", ["ivfflat_l2_4096", "ivfpq_l2_4096", "ivfflat_ip_4096", "ivfpq_ip_4096"])
 def test_ivf4096_vs_reference_golden(res, name):
     """copy_lists of the reference's IVF4096 lists, search vs the reference's results; native add reproduces the
     reference's list sizes and ids exactly (codes up to argmin near-ties)."""
@@ -71,6 +71,14 @@ def test_ivf4096_vs_reference_golden(res, name):
     Do, Io, _, _ = Oracle.ivf_search(c["kind"], c["metric"], z["centroids"], z["list_sizes"], c["codes"], z["list_ids"],
                                      c["xq"][sel], c["nprobe"], c["k"], M=c["M"], pq=c["pq"])
     check_knn(D[sel], I[sel], Do, Io, exact=True, name=name + " vs oracle")
+    # the list-major scan on the same lists: vs the reference, and bit-exact vs its own restatement
+    idx.set_scan_mode(idx.SCAN_LIST_MAJOR)
+    D2, I2 = idx.search(c["xq"], c["k"])
+    st = check_knn(D2, I2, z["D"], z["I"], rtol=1e-4, name=name + " list-major vs golden")
+    assert st["max_rel_err"] < 2e-5
+    Do, Io, _, _ = Oracle.ivf_search(c["kind"], c["metric"], z["centroids"], z["list_sizes"], c["codes"], z["list_ids"],
+                                     c["xq"][sel], c["nprobe"], c["k"], M=c["M"], pq=c["pq"], arith=1)
+    check_knn(D2[sel], I2[sel], Do, Io, exact=True, name=name + " list-major vs oracle")
     nat = make()
     nat.add(c["xb"])
     sizes = np.array([nat.get_list_size(l) for l in range(nlist)], dtype=np.uint32)

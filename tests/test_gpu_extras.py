@@ -98,9 +98,13 @@ def test_ivf_reserve_and_reclaim_memory(res):
             idx = faiss_amd.GpuIndexIVFPQ(res, d, nlist, 8, 8, faiss_amd.METRIC_L2)
             idx.copy_pq_centroids((np.random.RandomState(7).rand(8, 256, 4).astype("float32") - 0.5) * 0.4)
             assert idx.getNumSubQuantizers() == 8 and idx.getBitsPerCode() == 8 and idx.getCentroidsPerSubQuantizer() == 256
-            assert not idx.getPrecomputedCodes()
+            # the getters report what is in force: L2 always uses the per-vector term, tables are always fp32
+            assert idx.getPrecomputedCodes() and idx.getTableInfo() == (True, False, False)
             idx.setPrecomputedCodes(True)
-            assert idx.getPrecomputedCodes()
+            assert idx.getTableInfo() == (True, True, False)
+            ip = faiss_amd.GpuIndexIVFPQ(res, d, nlist, 8, 8, faiss_amd.METRIC_INNER_PRODUCT)
+            ip.setPrecomputedCodes(True)
+            assert not ip.getPrecomputedCodes() and ip.getTableInfo() == (False, True, False)
         idx.copy_centroids(cent)
         idx.nprobe = 8
         idx.reserveMemory(nb)
@@ -135,3 +139,71 @@ def test_flat_search_and_reconstruct(res):
     D, I, R = idx.search_and_reconstruct(xq, k)
     assert R.shape == (nq, k, d) and (I[:, nb:] == -1).all()
     assert np.array_equal(R[:, :nb], xb[I[:, :nb]]) and np.isnan(R[:, nb:]).all()
+
+
+# ------------------------------------------------------------------------------- ClusteringParameters (faiss/Clustering.h:27-60)
+@pytest.mark.parametrize("flags", [dict(spherical=1), dict(int_centroids=1), dict(nredo=3), dict(frozen_centroids=1),
+                                   dict(spherical=1, nredo=2, frozen_centroids=1)])
+def test_clustering_parameters_device_loop_equals_host_loop(res, flags):
+    """nredo / spherical / int_centroids / frozen_centroids: the device-resident loop and the loop driven through
+    add() / search() (the reference's organisation, faiss/Clustering.cpp:255-420) give the same centroids bit for bit,
+    and each flag does what faiss::ClusteringParameters says."""
+    from oracle.pyoracle import synthetic_dataset
+    d, n, k, niter = 24, 12000, 30, 5
+    xt, _, _ = synthetic_dataset(d, n, 0, 0, seed=77)
+    if flags.get("int_centroids"):
+        xt = (xt * 20).astype(np.float32)
+    metric = faiss_amd.METRIC_INNER_PRODUCT if flags.get("spherical") else faiss_amd.METRIC_L2
+    init = None
+    if flags.get("frozen_centroids"):
+        init = xt[:7].copy() * (1.0 if not flags.get("spherical") else 1.0 / np.linalg.norm(xt[:7], axis=1, keepdims=True))
+        init = init.astype(np.float32)
+    runs = []
+    for engine in ("device", "host"):
+        if engine == "device":
+            ix = faiss_amd.GpuIndexFlat(res, d, metric)
+        else:
+            ix = faiss_amd.IndexReplicas(d, threaded=False)
+            ix.add_replica(faiss_amd.GpuIndexFlat(res, d, metric))
+        c = faiss_amd.Clustering(d, k, niter=niter, seed=5, **flags)
+        c.centroids = init
+        c.train(xt, ix)
+        assert c.on_device == (engine == "device") and ix.ntotal == k
+        runs.append(c)
+    a, b = runs
+    assert np.array_equal(a.centroids, b.centroids) and np.array_equal(a.obj, b.obj)
+    if flags.get("spherical"):
+        free = a.centroids[7:] if init is not None else a.centroids
+        assert np.allclose(np.linalg.norm(free, axis=1), 1.0, atol=1e-5)
+    if flags.get("int_centroids"):
+        assert np.array_equal(a.centroids, np.round(a.centroids))
+    if flags.get("frozen_centroids"):
+        assert np.array_equal(a.centroids[:7], init)
+    if flags.get("nredo", 1) > 1 and not flags.get("frozen_centroids"):
+        # the winner is at least as good as every single run with the seeds the redo loop uses (seed + 1 + redo)
+        finals = []
+        for redo in range(flags["nredo"]):
+            one = faiss_amd.Clustering(d, k, niter=niter, seed=5 + 1 + redo, **{f: v for f, v in flags.items() if f != "nredo"})
+            one.train(xt, faiss_amd.GpuIndexFlat(res, d, metric))
+            finals.append(float(one.obj[-1]))
+        best = max(finals) if metric == faiss_amd.METRIC_INNER_PRODUCT else min(finals)
+        assert float(a.obj[-1]) == best
+
+
+def test_ivf_training_honours_clustering_parameters(res):
+    """GpuIndexIVF::cp: spherical k-means for an inner-product IVF index (unit-norm coarse centroids), through the ABI"""
+    from oracle.pyoracle import synthetic_dataset
+    d, nlist = 32, 24
+    xt, xb, xq = synthetic_dataset(d, 6000, 4000, 20, seed=3)
+    idx = faiss_amd.GpuIndexIVFFlat(res, d, nlist, faiss_amd.METRIC_INNER_PRODUCT)
+    idx.set_clustering_params(niter=6, spherical=1, nredo=2, seed=9)
+    idx.train(xt)
+    cent = idx.get_centroids()
+    assert np.allclose(np.linalg.norm(cent, axis=1), 1.0, atol=1e-5)
+    idx.add(xb)
+    idx.nprobe = nlist
+    D, I = idx.search(xq, 5)
+    Do, Io = Oracle.flat_search(faiss_amd.METRIC_INNER_PRODUCT, xb, xq, 5)
+    check_knn(D, I, Do, Io, rtol=1e-4, name="IP IVF with spherical coarse quantizer, all lists probed")
+    with pytest.raises(faiss_amd.FaissAmdError):
+        idx.set_clustering_params(nredo=0)
