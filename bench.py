@@ -373,6 +373,38 @@ def scale_leg(kind, nb, res, xt, xb, xq, xq_dev, dmap, torch, leg_1m, nsample=16
     return out
 
 
+def predicted_per_rank(res, flat_index, ivfpq_index, xb, xq_dev, torch):
+    """What ONE rank of an N-GPU run of this bench would execute, timed on this single GPU: the Flat leg replicates the
+    database and splits the queries (rank block = nq / N queries, rounded up to 128), the IVFPQ leg shards the rows
+    (nb / N rows per rank, shared quantizers, all queries).  A PREDICTION of the per-rank compute step, not a scaling
+    measurement: no gather, no merge, no second GPU (no multi-GPU node was available to the builder in rounds 1-3)."""
+    import faiss_amd
+    from faiss_amd.distributed import replica_bounds
+    out = {"what": "per-rank compute step of an N-GPU run, timed on ONE GPU: a prediction, not a scaling measurement "
+                   "(no gather / merge / second GPU involved)", "flat_replicas_query_block": {}, "ivfpq_row_shard": {}}
+    Dd = torch.empty((NQ, K), dtype=torch.float32, device=xq_dev.device)
+    Id = torch.empty((NQ, K), dtype=torch.int64, device=xq_dev.device)
+    for n in (2, 4, 8):
+        per = replica_bounds(NQ, n)[1]
+        dt = time_search(flat_index, torch, per, xq_dev.data_ptr(), Dd.data_ptr(), Id.data_ptr(), 5, 2)
+        out["flat_replicas_query_block"][str(n)] = {"queries": per, "ms": round(dt * 1e3, 3),
+                                                    "implied_aggregate_qps_before_gather": round(NQ / dt, 0)}
+    if ivfpq_index is not None:
+        cent, pqc = ivfpq_index.get_centroids(), ivfpq_index.get_pq_centroids()
+        for n in (2, 4, 8):
+            rows = NB // n
+            sh = faiss_amd.GpuIndexIVFPQ(res, D, NLIST, PQ_M, 8, faiss_amd.METRIC_L2)
+            sh.copy_centroids(cent)
+            sh.copy_pq_centroids(pqc)
+            sh.add_with_ids(xb[:rows], np.arange(rows, dtype=np.int64))
+            sh.nprobe = NPROBE
+            dt = time_search(sh, torch, NQ, xq_dev.data_ptr(), Dd.data_ptr(), Id.data_ptr(), 5, 2)
+            out["ivfpq_row_shard"][str(n)] = {"rows": rows, "ms": round(dt * 1e3, 3),
+                                              "implied_aggregate_qps_before_merge": round(NQ / dt, 0)}
+            del sh
+    return out
+
+
 def committed_traffic(kernel_substr, alg_bytes):
     """HBM bytes per launch of a kernel from the rocprofv3 --pmc FETCH_SIZE pass committed under profiles/ (PMC
     counters cannot be read from inside this process; same kernel, same workload, corrected x2 as the MI355X guide
@@ -645,12 +677,18 @@ def main():
             except Exception as e:  # noqa: BLE001
                 line["cpu_baseline"] = {"error": repr(e)[:200]}
         if not args.no_ivf:
+            ivf_idx = {}
             for kind in [v for v in args.ivf_legs.split(",") if v in ("ivfpq", "ivfflat", "ivfsq")]:
                 try:
-                    line[kind], _ = ivf_leg(kind, res, xt, xb, xq, xq_dev, gI[:, 0], max(2, args.steps // 2), torch,
-                                            with_cpu=not args.no_cpu_baseline)
+                    line[kind], ivf_idx[kind] = ivf_leg(kind, res, xt, xb, xq, xq_dev, gI[:, 0], max(2, args.steps // 2), torch,
+                                                        with_cpu=not args.no_cpu_baseline)
                 except Exception as e:  # noqa: BLE001
                     line[kind] = {"error": repr(e)[:300]}
+            try:
+                line["predicted_per_rank_ms"] = predicted_per_rank(res, index, ivf_idx.get("ivfpq"), xb, xq_dev, torch)
+            except Exception as e:  # noqa: BLE001
+                line["predicted_per_rank_ms"] = {"error": repr(e)[:300]}
+            ivf_idx.clear()
             need = {"ivfflat_10m": 60.0, "ivfpq_100m": 330.0}
             for name in [v for v in args.scale_legs.split(",") if v in need]:
                 if time.time() - t_start + need[name] > args.budget_s:

@@ -207,3 +207,42 @@ def test_ivf_training_honours_clustering_parameters(res):
     check_knn(D, I, Do, Io, rtol=1e-4, name="IP IVF with spherical coarse quantizer, all lists probed")
     with pytest.raises(faiss_amd.FaissAmdError):
         idx.set_clustering_params(nredo=0)
+
+
+@pytest.mark.parametrize("kind", ["flat", "ivfpq", "ivfflat_listmajor"])
+def test_concurrent_searches_on_one_index_equal_serial(res, kind):
+    """Four host threads searching ONE index at the same time (ctypes drops the GIL): the entry points serialise on the
+    index's lock, every thread gets exactly the serial answer (faiss/impl/ThreadedIndex-inl.h:80-133 is what drives
+    replicas from threads; an index object of the reference's GPU classes is not re-entrant at all)."""
+    import threading
+    from oracle.pyoracle import synthetic_dataset
+    d, nb = 64, 30000
+    xt, xb, xq = synthetic_dataset(d, 4000, nb, 2400, seed=21)
+    if kind == "flat":
+        idx = faiss_amd.GpuIndexFlatL2(res, d)
+    elif kind == "ivfpq":
+        idx = faiss_amd.GpuIndexIVFPQ(res, d, 32, 16, 8, faiss_amd.METRIC_L2)
+        idx.train(xt)
+    else:
+        idx = faiss_amd.GpuIndexIVFFlat(res, d, 32, faiss_amd.METRIC_L2)
+        idx.train(xt)
+    idx.add(xb)
+    if kind != "flat":
+        idx.nprobe = 8
+    blocks = [xq[i * 600:(i + 1) * 600] for i in range(4)]
+    if kind == "ivfflat_listmajor":
+        idx.set_scan_mode(idx.SCAN_LIST_MAJOR)
+    want = [idx.search(b, 10) for b in blocks]
+    got = [None] * 4
+
+    def run(i):
+        for _ in range(3):
+            got[i] = idx.search(blocks[i], 10)
+
+    th = [threading.Thread(target=run, args=(i,)) for i in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for i in range(4):
+        assert np.array_equal(got[i][0], want[i][0]) and np.array_equal(got[i][1], want[i][1])
