@@ -2253,16 +2253,18 @@ void GpuIndexIVF::search_listmajor_(int ni, const float* xq_pad, const idx_t* c_
     const GpuResources& R = *res_;
     uint32_t max_len = 1;
     for (auto l : list_len_) max_len = std::max(max_len, l);
-    // Probes of pass 1: enough to see k rows, and at least min_p1 -- chosen so that a list meets ~16 of them (half a
-    // 32-query MFMA block: pass 1 then costs one sweep of the lists' first row chunks whatever min_p1 is), at most 8 and
-    // at most half of the probes.
+    // Probes of pass 1: enough to see k rows, and at least min_p1 -- chosen so that a list meets ~14 of them (half a
+    // 32-query MFMA block: pass 1 then costs one sweep of the lists' first row chunks whatever min_p1 is), at most 8, at
+    // most half of the probes, and no more than ~4096 pass-1 rows per query (the bound kernel selects among them: 0.5 ms for
+    // 7 x 1024 rows at nb = 10M against 0.29 for 4 x 1024, more than the tighter bound saves in pass 2).
     const char* p1_env = getenv("FAISS_AMD_LM_P1"); // tuning experiments
-    int min_p1 = (int)std::min<int64_t>(8, std::max<int64_t>(1, (16 * (int64_t)nlist + ni / 2) / std::max(ni, 1)));
+    const int64_t chunk_rows = std::min<int64_t>(max_len, kLmRowsPerItem);
+    int min_p1 = (int)std::min<int64_t>(8, std::max<int64_t>(1, (14 * (int64_t)nlist + ni / 2) / std::max(ni, 1)));
+    min_p1 = std::min<int>(min_p1, (int)std::max<int64_t>(1, 4096 / chunk_rows));
     min_p1 = std::max(1, std::min(min_p1, np / 2));
     if (p1_env) min_p1 = std::max(1, std::min(np, atoi(p1_env)));
     // segment of a query: the rows of pass 1 (first row chunk of its lists: fewer than k + one chunk, or min_p1 chunks) +
     // room for the candidates of pass 2; with every probe in pass 1 (overflow rerun): all probed rows
-    const int64_t chunk_rows = std::min<int64_t>(max_len, kLmRowsPerItem);
     const int64_t cap2 = std::max<int64_t>(2048, 4 * (int64_t)k);
     const int64_t c1max = std::max<int64_t>((int64_t)k + chunk_rows, (int64_t)min_p1 * chunk_rows); // rows of pass 1
     const int64_t stride = force_all ? std::max<int64_t>((int64_t)np * max_len, k) : c1max + cap2;
@@ -2286,7 +2288,8 @@ void GpuIndexIVF::search_listmajor_chunk_(int ni, const float* xq_pad, const idx
         nrt_max = std::max(nrt_max, nrt);
     }
     const int64_t npairs = (int64_t)ni * np;
-    const int64_t max_items = nrt_max * (int64_t)div_up((size_t)npairs, (size_t)kLmQueriesPerItem) + 2 * sum_nrt + 16;
+    const int qpi = ivf_lm_queries_per_item(fused_kind_());
+    const int64_t max_items = nrt_max * (int64_t)div_up((size_t)npairs, (size_t)qpi) + 2 * sum_nrt + 16;
     FA_THROW_IF_NOT_MSG(max_items < ((int64_t)1 << 30), "list-major scan: too many work items");
 
     IvfLmParams P{};
@@ -2311,7 +2314,7 @@ void GpuIndexIVF::search_listmajor_chunk_(int ni, const float* xq_pad, const idx
     lm_bstart_.ensure((size_t)(2 * nlist + 1) * 4);
     lm_pairs_.ensure((size_t)npairs * 4);
     lm_items_.ensure((size_t)max_items * sizeof(IvfLmItem));
-    lm_bounds_.ensure(16);
+    lm_bounds_.ensure(32);
     lm_thr_.ensure((size_t)ni * 4);
     lm_keys_.ensure((size_t)ni * stride * 8);
     lm_ovf_.ensure((size_t)(ni + 1) * 4);
@@ -2328,6 +2331,7 @@ void GpuIndexIVF::search_listmajor_chunk_(int ni, const float* xq_pad, const idx
     P.item_bounds = lm_bounds_.as<uint32_t>();
     P.max_items = (int)max_items;
     P.rows_per_item = RT;
+    P.qpi = qpi;
     P.force_all = force_all ? 1 : 0;
     const char* dbg_env = getenv("FAISS_AMD_LM_DBG"); // timing experiments only (results are wrong)
     P.min_p1 = min_p1;

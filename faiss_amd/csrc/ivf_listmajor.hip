@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(1024) lm_items_kernel(IvfLmParams p) {
     auto shape = [&](int bk, int& nqt, int& nrt) {
         const uint32_t c = p.bucket_cnt[bk];
         const uint32_t len = p.list_len[bk >= p.nlist ? bk - p.nlist : bk];
-        nqt = (int)((c + kLmQueriesPerItem - 1) / kLmQueriesPerItem);
+        nqt = (int)((c + p.qpi - 1) / p.qpi);
         nrt = p.force_all ? 1 : (int)((len + p.rows_per_item - 1) / p.rows_per_item);
     };
     // (force_all: one item takes all rows of its list: the redo of a few queries is not worth balancing)
@@ -285,6 +285,7 @@ __global__ void __launch_bounds__(1024) lm_items_kernel(IvfLmParams p) {
         // (max_items is an upper bound computed on the host from the list lengths; exceeding it would lose work, so the
         // host checks item_bounds[3] == 0 whenever it reads the overflow word)
         p.item_bounds[3] = all > (uint32_t)p.max_items ? 1u : 0u;
+        p.item_bounds[4] = 0; // item counter of the register-fed pass-2 kernel
     }
 }
 
@@ -416,7 +417,7 @@ __global__ void __launch_bounds__(LM_THREADS, KIND == 0 ? 2 : 3) ivf_lm_scan_ker
         const int len = (int)p.list_len[list];
         const int64_t start = p.list_start[list];
         const uint32_t pb = p.bucket_start[bk];
-        const int npair = min(kLmQueriesPerItem, (int)(p.bucket_start[bk + 1] - pb) - qt * kLmQueriesPerItem);
+        const int npair = min(p.qpi, (int)(p.bucket_start[bk + 1] - pb) - qt * p.qpi);
         const int r0 = rt * p.rows_per_item;
         const int r1 = p.force_all ? len : min(len, r0 + p.rows_per_item);
 
@@ -444,7 +445,7 @@ __global__ void __launch_bounds__(LM_THREADS, KIND == 0 ? 2 : 3) ivf_lm_scan_ker
         const int wq = wave & 1, wr = wave >> 1; // query block, row block of this wave
         const int my = wq * 32 + j;
         const bool qv = my < npair;
-        const uint32_t pi = p.pairs[pb + (uint32_t)(qt * kLmQueriesPerItem) + (uint32_t)(qv ? my : 0)];
+        const uint32_t pi = p.pairs[pb + (uint32_t)(qt * p.qpi) + (uint32_t)(qv ? my : 0)];
         const int q = (int)(pi / (uint32_t)np);
         const int pr = (int)(pi - (uint32_t)q * (uint32_t)np);
         const bool wave_active = wq * 32 < npair; // wave-uniform
@@ -677,6 +678,221 @@ __global__ void __launch_bounds__(LM_THREADS, KIND == 0 ? 2 : 3) ivf_lm_scan_ker
         }
     }
     if (PASS == 2 && wcnt > 0) flush();
+}
+
+// ------------------------------------------------------------------ IVFFlat pass 2, register-fed (round 3, third kernel)
+// A row of a list is only ever needed by the few wavefronts whose queries probe it, so pass 2 -- where the work is --
+// shares nothing through LDS: a work item is (list, ONE 32-query block, up to 1024 rows) and belongs to ONE wavefront;
+// lane (h, j) loads the 16-byte pieces 8 s + 4 h of row j of the current 32-row block straight into the registers it feeds
+// the MFMAs from, and refills a[s] for the NEXT block right behind the four MFMAs that read it -- sixteen loads in flight
+// per lane, each with ~3800 cycles to land.  No barrier, no DMA bookkeeping, and no load imbalance between the waves of a
+// workgroup: every wavefront DRAWS its next item from a counter (items differ 3 : 1 in length, a static deal leaves the
+// pipe idle behind the longest hand).  Same operands, same chain: bit-identical to the LDS kernel.
+// The block loop holds no vector-memory STORE (candidates go to the wave's LDS slice; when it is full the loop is left, the
+// slice flushed, the loop re-entered): with loads and stores in one loop hipcc stops counting the loads in flight and
+// waits vmcnt(0) before every use.
+constexpr int LR_THREADS = 256;
+constexpr int LR_PARK = 1280; // parked candidates per wave: a whole block (32 rows x 32 queries) always fits an empty slice
+constexpr int LR_LDS_TOTAL = 4 * LR_PARK * (8 + 4);
+
+template <int METRIC, bool FULL>
+__global__ void __launch_bounds__(LR_THREADS, 2) ivf_lm_flat_reg_kernel(IvfLmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    const int j = lane & 31;
+    const int np = p.nprobe;
+    const int ns = FULL ? 16 : (p.dpad >> 3);
+    u64* pk_keys = (u64*)smem + wave * LR_PARK;
+    uint32_t* pk_q = (uint32_t*)(smem + 4 * LR_PARK * 8) + wave * LR_PARK;
+    int wcnt = 0; // (wave-uniform) parked candidates
+    auto flush = [&]() __attribute__((always_inline)) {
+        for (int e = lane; e < wcnt; e += 64) {
+            const u64 key = pk_keys[e];
+            const uint32_t qq = pk_q[e];
+            const uint32_t slot = atomicAdd(p.cnt + qq, 1u);
+            if ((int64_t)slot < p.stride) p.keys[(int64_t)qq * p.stride + slot] = key;
+        }
+        wcnt = 0;
+        // every store above has completed, AS FAR AS THE COMPILER KNOWS TOO (vmcnt(0) through the builtin): with a store
+        // possibly in flight on some path into the block loop it would not count the loop's loads (mixed loads and
+        // stores on one counter) and wait vmcnt(0) at the head of every block
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+    };
+
+    const uint32_t it0 = p.item_bounds[1], it1 = p.item_bounds[2];
+    uint32_t* ctr = p.item_bounds + 4; // next item of pass 2 (zeroed by the plan)
+    for (;;) {
+        uint32_t it = 0;
+        if (lane == 0) it = atomicAdd(ctr, 1u);
+        it = it0 + (uint32_t)__builtin_amdgcn_readfirstlane((int)it);
+        if (it >= it1) break;
+        const IvfLmItem item = p.items[it];
+        const int bk = __builtin_amdgcn_readfirstlane(item.bucket);
+        const int qt = __builtin_amdgcn_readfirstlane(item.qt);
+        const int rt = __builtin_amdgcn_readfirstlane(item.rt);
+        const int list = bk >= p.nlist ? bk - p.nlist : bk;
+        const int len = (int)p.list_len[list];
+        const int64_t start = p.list_start[list];
+        const uint32_t pb = p.bucket_start[bk];
+        const int npair = min(32, (int)(p.bucket_start[bk + 1] - pb) - qt * 32);
+        const int r0 = rt * p.rows_per_item;
+        const int r1 = p.force_all ? len : min(len, r0 + p.rows_per_item);
+
+        // ---- this lane's query
+        const bool qv = j < npair;
+        const uint32_t pi = p.pairs[pb + (uint32_t)(qt * 32) + (uint32_t)(qv ? j : 0)];
+        const int q = (int)(pi / (uint32_t)np);
+        const int pr = (int)(pi - (uint32_t)q * (uint32_t)np);
+        const float* qrow = p.xq + (int64_t)q * p.ldq;
+        f32x4 bq[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            if (FULL || s < ns) bq[s] = *(const f32x4*)(qrow + 8 * s + 4 * h);
+            else bq[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const float xn = METRIC == METRIC_L2 ? p.xqn[q] : 0.f;
+        const uint32_t base_pos = p.prefix[(int64_t)q * (np + 1) + pr];
+        float thr_f;
+        {
+            const uint32_t tk = p.thr[q];
+            if (tk >= kInvalidOrdKey) thr_f = METRIC == METRIC_L2 ? INFINITY : -INFINITY;
+            else thr_f = unordkey<METRIC>(tk);
+        }
+        auto dist_of = [&](float ip, float rnv) -> float {
+            if (METRIC == METRIC_L2) {
+                const float dd = __fmaf_rn(-2.f, ip, xn + rnv);
+                return dd < 0.f ? 0.f : dd;
+            }
+            return xn + ip;
+        };
+
+        int t = r0;
+        while (t < r1) {
+            // ---- (re-)entry: the rows of block t (row j of the block; rows behind the end of the list belong to the next
+            // list or the arena's padding, index.cpp ensure_arena_: loaded, never looked at).  Always 16 pieces per row
+            // (rows shorter than 128 floats: the surplus reads the following rows and is ignored).
+            // The loads are issued in the order the block loop re-issues them (a[0] .. a[15]; the empty asm statements keep
+            // hipcc from reordering them): its wait for a[0] at the head of a block is then "all but the 15 youngest" on
+            // every path into the loop -- with a[0] loaded last here it was vmcnt(0) for every block.
+            const float* arow = p.arena_vecs + (start + t + j) * p.ldv + 4 * h;
+            f32x4 a[16];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                a[s] = *(const f32x4*)(arow + 8 * s);
+                asm volatile("" ::: "memory");
+            }
+            const float* rnp = p.arena_rn + start + t + 4 * h; // rn of rows 8 g + 4 h + e of the block: rnp[8 g + e]
+            bool full = false; // the slice cannot take the candidates of the block in hand: leave, flush, come back
+            for (; t < r1; t += 32) {
+                arow += 32 * p.ldv;
+                rnp += 32;
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                f32x4 rn[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) rn[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+                // (the refills are UNCONDITIONAL -- behind the last block they read the rows that follow the list: a branch
+                // around them would stop the compiler from counting the loads in flight)
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    if (FULL || s < ns) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][e], bq[s][e], acc, 0, 0, 0);
+                    }
+                    // refill for the next block right behind the MFMAs that consumed a[s]
+                    a[s] = *(const f32x4*)(arow + 8 * s);
+                    // the row norms of THIS block, half a block ahead of the epilogue that needs them (not carried from
+                    // block to block: the register allocator would shuffle them at the head of the block, waiting for
+                    // the youngest loads there)
+                    if (s == 7 && METRIC == METRIC_L2) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) rn[g] = *(const f32x4*)(rnp - 32 + 8 * g);
+                    }
+                }
+                // the instruction order above IS the schedule: four MFMAs, one load (five behind group 7), sixteen times
+                // (left to itself the scheduler gathers the loads behind the last MFMA, where they have only the epilogue to
+                // land in)
+#pragma unroll
+                for (int s = 0; s < 7; ++s) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); // VMEM read
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                if constexpr (METRIC == METRIC_L2) __builtin_amdgcn_sched_group_barrier(0x020, 5, 0);
+                else __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+#pragma unroll
+                for (int s = 8; s < 16; ++s) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+                // (nothing of the epilogue may be scheduled above this line)
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- epilogue: which of this lane's 16 distances pass its query's bound
+                const int row_b = t + 4 * h; // row of the list of acc[4 g + e]: row_b + 8 g + e
+                unsigned mask = 0;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float dis = dist_of(acc[4 * g + e], rn[g][e]);
+                        const bool pass = (METRIC == METRIC_L2 ? dis <= thr_f : dis >= thr_f) && row_b + 8 * g + e < r1;
+                        mask |= pass ? 1u << (4 * g + e) : 0u;
+                    }
+                }
+                if (!qv || (p.dbg & 1)) mask = 0;
+                if (__ballot(mask != 0u)) {
+                    // (wave-uniform branch) park the candidates: this lane's go behind those of the lanes before it
+                    const int c = __popc(mask);
+                    int inc = c; // inclusive scan over the lanes
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const int o = __shfl_up(inc, off, 64);
+                        if (lane >= off) inc += o;
+                    }
+                    const int total = __builtin_amdgcn_readlane(inc, 63);
+                    if (wcnt + total > LR_PARK) {
+                        full = true; // (block t is redone after the flush: its candidates were not parked)
+                        break;
+                    }
+                    int at = wcnt + inc - c;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (mask & (1u << (4 * g + e))) {
+                                const uint32_t pos = base_pos + (uint32_t)(row_b + 8 * g + e);
+                                pk_keys[at] = ((u64)ordkey<METRIC>(dist_of(acc[4 * g + e], rn[g][e])) << 32) | pos;
+                                pk_q[at] = (uint32_t)q;
+                                ++at;
+                            }
+                        }
+                    }
+                    wcnt += total;
+                }
+            }
+            if (full) flush();
+        }
+    }
+    if (wcnt > 0) flush();
+}
+
+template <int METRIC>
+static void lr_launch(const IvfLmParams& p, int grid_blocks, hipStream_t stream) {
+    if (p.dpad == 128) {
+        HIP_CHECK(hipFuncSetAttribute((const void*)ivf_lm_flat_reg_kernel<METRIC, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      LR_LDS_TOTAL));
+        hipLaunchKernelGGL((ivf_lm_flat_reg_kernel<METRIC, true>), dim3((unsigned)grid_blocks), dim3(LR_THREADS), LR_LDS_TOTAL, stream,
+                           p);
+    } else {
+        HIP_CHECK(hipFuncSetAttribute((const void*)ivf_lm_flat_reg_kernel<METRIC, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      LR_LDS_TOTAL));
+        hipLaunchKernelGGL((ivf_lm_flat_reg_kernel<METRIC, false>), dim3((unsigned)grid_blocks), dim3(LR_THREADS), LR_LDS_TOTAL, stream,
+                           p);
+    }
 }
 
 // ------------------------------------------------------------------ IVFPQ, codebook in LDS (round 3, second kernel)
@@ -1036,18 +1252,33 @@ static void lm_launch2(const IvfLmParams& p, int pass, int grid_blocks, hipStrea
 int ivf_lm_blocks_per_cu(int kind) {
     return kind == 0 ? 2 : 3;
 }
+static bool lm_flat_lds_env() {
+    static const char* e = getenv("FAISS_AMD_LM_FLAT_LDS"); // timing experiments: 1 = the LDS-tile kernel for IVFFlat
+    return e && atoi(e) == 1;
+}
+int ivf_lm_queries_per_item(int kind) {
+    return kind == 0 && !lm_flat_lds_env() ? 32 : kLmQueriesPerItem;
+}
 static bool lm_use_pq_lds(const IvfLmParams& p) {
     static const char* e = getenv("FAISS_AMD_LM_PQ_GENERIC"); // timing experiments: 1 = the generic (L2-gather) kernel
     return p.kind == 1 && ivf_lm_pq_lds_supported(p.d, p.dpad, p.M) && !(e && atoi(e) == 1);
 }
 int ivf_lm_grid_blocks(const IvfLmParams& p, int num_cus) {
     if (lm_use_pq_lds(p)) return num_cus; // one 8-wave workgroup per CU (the codebook fills its LDS)
+    // IVFFlat: two 4-wave workgroups per CU for both kernels (pass 1: LDS tiles, 2 x 75 KB; pass 2: registers)
     return ivf_lm_blocks_per_cu(p.kind) * num_cus / 8 * 8;
 }
 void launch_ivf_lm_scan(const IvfLmParams& p, int pass, int grid_blocks, hipStream_t stream) {
     if (p.nq == 0) return;
     FA_THROW_IF_NOT(ivf_lm_supported(p.kind, p.dpad, p.M, p.d) && (pass == 1 || pass == 2) && grid_blocks > 0);
     FA_THROW_IF_NOT(p.ldq % 4 == 0 && (p.kind != 0 || p.ldv % 4 == 0) && (p.kind != 1 || p.ldc % 4 == 0));
+    if (p.kind == 0 && p.qpi == 32 && pass == 2) {
+        if (p.metric == METRIC_L2) lr_launch<METRIC_L2>(p, grid_blocks, stream);
+        else lr_launch<METRIC_INNER_PRODUCT>(p, grid_blocks, stream);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
+    FA_THROW_IF_NOT(p.qpi == kLmQueriesPerItem || p.kind == 0);
     if (lm_use_pq_lds(p)) {
         if (p.metric == METRIC_L2) {
             if (pass == 1) lq_launch<METRIC_L2, 1>(p, grid_blocks, stream);

@@ -425,8 +425,9 @@ struct IvfLmParams {
     uint32_t* bucket_start;  // [2 nlist + 1]
     uint32_t* pairs;         // [nq * nprobe] pair = q * nprobe + p, grouped by bucket
     IvfLmItem* items;        // [max_items], pass 1 first
-    uint32_t* item_bounds;   // [4] = 0, items of pass 1, all items, 1 if max_items was too small (a bug: the host checks)
+    uint32_t* item_bounds;   // [8] = 0, items of pass 1, all items, 1 if max_items was too small (a bug: the host checks), [4] work counter of pass 2
     int max_items;
+    int qpi;                 // queries per work item: 32 (register-fed IVFFlat kernel: one wavefront per item) or 64
     int rows_per_item;       // multiple of 64
     int force_all;           // every probe in pass 1
     int min_p1;              // at least this many probes of every query in pass 1
@@ -453,6 +454,7 @@ void launch_ivf_lm_plan(const IvfLmParams& p, hipStream_t stream);
 void launch_ivf_lm_scan(const IvfLmParams& p, int pass, int grid_blocks, hipStream_t stream);
 // workgroups of the scan kernel that are resident per CU (IVFFlat: two, with two tiles in LDS each; IVFPQ: three)
 int ivf_lm_blocks_per_cu(int kind);
+int ivf_lm_queries_per_item(int kind); // IvfLmParams::qpi the scan kernel of this index type works with
 // persistent workgroups to launch for this problem (IVFPQ with the codebook in LDS: one 8-wave workgroup per CU)
 int ivf_lm_grid_blocks(const IvfLmParams& p, int num_cus);
 bool ivf_lm_pq_lds_supported(int d, int dpad, int M);

@@ -61,7 +61,9 @@ def test_no_kernel_spills_beyond_the_known_cold_paths(usage):
     # the reservoir cut of the IVFFlat scan and one scalar-quantizer variant spill a few registers in their (rare)
     # selection path; nothing else may touch scratch at all
     # (list-major scan: a few per-item invariants are reloaded once per work item, outside the tile loop)
-    allowed = {"ivfflat_fused_kernel": 64, "ivfsq_fused_kernel": 48, "ivf_lm_scan_kernel": 48}
+    # (ivf_lm_pq_kernel: the compiler hoists every LDS gather it can and runs into the 256-register ceiling of its
+    # two-waves-per-SIMD budget: a handful of per-item values live in scratch, none inside the tile loop)
+    allowed = {"ivfflat_fused_kernel": 64, "ivfsq_fused_kernel": 48, "ivf_lm_scan_kernel": 48, "ivf_lm_pq_kernel": 32}
     for name, u in usage.items():
         limit = max([v for k, v in allowed.items() if k in name] or [0])
         assert u["scratch"] <= limit, (name, u)
@@ -102,4 +104,9 @@ def test_list_major_scan(usage):
     picked = _pick(usage, "ivf_lm_scan_kernel")
     assert len(picked) == 16
     for name, u in picked.items():
-        assert u["scratch"] <= 48 and u["occupancy"] >= 3, (name, u)
+        assert u["scratch"] <= 48 and u["occupancy"] >= 2, (name, u)
+    # the register-fed pass-2 kernel of IVFFlat: 64 + 64 registers of operands per lane, two waves per SIMD, no scratch
+    for name, u in _pick(usage, "ivf_lm_flat_reg_kernel").items():
+        assert u["scratch"] == 0 and u["occupancy"] >= 2, (name, u)
+    for name, u in _pick(usage, "ivf_lm_pq_kernel").items():
+        assert u["scratch"] <= 32 and u["occupancy"] >= 2, (name, u)
