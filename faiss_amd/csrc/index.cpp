@@ -2081,7 +2081,7 @@ void GpuIndexIVF::search_core_body_(idx_t n, const float* x, idx_t k, float* dis
         }
         if (cur_lm_) {
             // ---- large batch: list-major (ivf_listmajor.hip)
-            search_listmajor_(ni, q_pad_.as<float>(), c_ids_.as<idx_t>(), c_dis_.as<float>(), np, (int)k, dD, dI, false);
+            search_listmajor_(ni, q_pad_.as<float>(), c_ids_.as<idx_t>(), c_dis_.as<float>(), np, (int)k, dD, dI, 0);
             if (!out_dev_d) copy_out(R, distances + (size_t)i0 * k, dD, (size_t)ni * k * 4);
             if (!out_dev_i) copy_out(R, labels + (size_t)i0 * k, dI, (size_t)ni * k * 8);
             R.sync();
@@ -2237,10 +2237,10 @@ void GpuIndexIVF::search_core_body_(idx_t n, const float* x, idx_t k, float* dis
 // ---------------------------------------------------------------------- list-major search (ivf_listmajor.hip)
 bool GpuIndexIVF::list_major_rule(idx_t n, int nprobe_now, idx_t k, bool has_selector) const {
     if (has_selector || !lm_capable_()) return false;
-    // IVFPQ: 64 bytes per row make the query-major scan cheap per query; the list-major kernel (codebook in LDS, one
-    // workgroup per CU) pays a fixed cost per work item that only lists of >= ~1000 rows amortise (measured, profiles/
-    // r03_b_listmajor_experiments.txt: nb = 1M 1.68 vs 1.35 ms query-major, nb = 10M 8.1 vs 9.7 ms)
-    if (fused_kind_() == 1 && !(lm_pq_lds_capable_() && nstored_ >= (idx_t)1024 * nlist)) return false;
+    // IVFPQ: 64 bytes per row make the query-major scan cheap per query; the list-major kernel (codebook in LDS) runs its
+    // matrix pipe at ~20 % and only wins where lists are long (profiles/r03_b_*: nb = 1M 1.68 vs 1.35 ms, nb = 10M 8.1 vs
+    // 9.7 ms, nb = 100M 63.9 vs 95.7 ms): lists of 2048 rows on average and a shape the LDS kernel serves.
+    if (fused_kind_() == 1 && !(lm_pq_lds_capable_() && nstored_ >= (int64_t)2048 * nlist)) return false;
     if (fused_kind_() > 1) return false;
     const int64_t np = std::min<int64_t>(nprobe_now, nlist);
     return n >= 2048 && (int64_t)n * np >= (int64_t)8 * nlist && k <= kMaxSelectionK;
@@ -2249,37 +2249,46 @@ bool GpuIndexIVF::list_major_rule(idx_t n, int nprobe_now, idx_t k, bool has_sel
 // Queries [0, ni) with their coarse results on the device -> k best per query in dD / dI (device).  Splits the batch
 // so that the key segments fit the scratch budget.
 void GpuIndexIVF::search_listmajor_(int ni, const float* xq_pad, const idx_t* c_ids, const float* c_dis, int np, int k,
-                                    float* dD, idx_t* dI, bool force_all) const {
+                                    float* dD, idx_t* dI, int level) const {
     const GpuResources& R = *res_;
     uint32_t max_len = 1;
     for (auto l : list_len_) max_len = std::max(max_len, l);
+    // level 0: the regular search; level 1: queries whose candidate segment overflowed, with 16 x the room; level 2: every
+    // probe and row in pass 1 (no bound, exact capacity) -- the last resort, its segments hold ALL probed rows
+    const bool force_all = level >= 2;
+    // Rows of a list per work item = the rows of a list pass 1 looks at (its first chunk): a quarter of an average
+    // list, between 1024 and 8192.  The bound of pass 2 is the k-th best of a SAMPLE (the first chunk of the min_p1 nearest
+    // lists); what it admits grows like k / (sampled fraction): with 1024-row chunks of 24 000-row lists (nb = 100M) 4 %
+    // were sampled, ~6000 candidates per query overflowed every segment and the redo cost 7 x the search.
+    const int64_t avg_len = std::max<int64_t>(1, nstored_ / std::max(nlist, 1));
+    const int RT = (int)std::min<int64_t>(8192, std::max<int64_t>(kLmRowsPerItem, (int64_t)round_up((size_t)(avg_len / 4), 128)));
     // Probes of pass 1: enough to see k rows, and at least min_p1 -- chosen so that a list meets ~14 of them (half a
     // 32-query MFMA block: pass 1 then costs one sweep of the lists' first row chunks whatever min_p1 is), at most 8, at
-    // most half of the probes, and no more than ~4096 pass-1 rows per query (the bound kernel selects among them: 0.5 ms for
-    // 7 x 1024 rows at nb = 10M against 0.29 for 4 x 1024, more than the tighter bound saves in pass 2).
+    // most half of the probes, at most 4 when the lists are longer than a chunk (the bound kernel selects among min_p1
+    // chunks of keys: 0.5 ms for 7 x 1024 at nb = 10M against 0.29 for 4 x 1024, more than the tighter bound saves).
     const char* p1_env = getenv("FAISS_AMD_LM_P1"); // tuning experiments
-    const int64_t chunk_rows = std::min<int64_t>(max_len, kLmRowsPerItem);
+    const int64_t chunk_rows = std::min<int64_t>(max_len, RT);
     int min_p1 = (int)std::min<int64_t>(8, std::max<int64_t>(1, (14 * (int64_t)nlist + ni / 2) / std::max(ni, 1)));
-    min_p1 = std::min<int>(min_p1, (int)std::max<int64_t>(1, 4096 / chunk_rows));
+    if (avg_len >= kLmRowsPerItem) min_p1 = std::min(min_p1, 4);
     min_p1 = std::max(1, std::min(min_p1, np / 2));
     if (p1_env) min_p1 = std::max(1, std::min(np, atoi(p1_env)));
     // segment of a query: the rows of pass 1 (first row chunk of its lists: fewer than k + one chunk, or min_p1 chunks) +
-    // room for the candidates of pass 2; with every probe in pass 1 (overflow rerun): all probed rows
-    const int64_t cap2 = std::max<int64_t>(2048, 4 * (int64_t)k);
+    // room for the candidates of pass 2
+    const int64_t cap2 = std::max<int64_t>(avg_len >= kLmRowsPerItem ? 4096 : 2048, 4 * (int64_t)k) * (level == 1 ? 16 : 1);
     const int64_t c1max = std::max<int64_t>((int64_t)k + chunk_rows, (int64_t)min_p1 * chunk_rows); // rows of pass 1
     const int64_t stride = force_all ? std::max<int64_t>((int64_t)np * max_len, k) : c1max + cap2;
     const int64_t fit = std::max<int64_t>(1, (int64_t)(R.temp_budget_bytes / ((size_t)stride * 8)));
     for (int c0 = 0; c0 < ni; c0 += (int)std::min<int64_t>(fit, ni)) {
         const int cn = (int)std::min<int64_t>(fit, ni - c0);
         search_listmajor_chunk_(cn, xq_pad + (size_t)c0 * dpad_, c_ids + (size_t)c0 * np, c_dis + (size_t)c0 * np, np, k,
-                                dD + (size_t)c0 * k, dI + (size_t)c0 * k, force_all, stride, min_p1, (int)c1max);
+                                dD + (size_t)c0 * k, dI + (size_t)c0 * k, level, stride, min_p1, RT);
     }
 }
 
 void GpuIndexIVF::search_listmajor_chunk_(int ni, const float* xq_pad, const idx_t* c_ids, const float* c_dis, int np, int k,
-                                          float* dD, idx_t* dI, bool force_all, int64_t stride, int min_p1, int c1max) const {
+                                          float* dD, idx_t* dI, int level, int64_t stride, int min_p1, int RT) const {
     const GpuResources& R = *res_;
-    const int RT = kLmRowsPerItem; // rows of a list per work item (16 tiles)
+    const bool force_all = level >= 2;
     // upper bound of the work items: sum over (pass, list) of ceil(pairs / 128) * ceil(len / RT)
     int64_t sum_nrt = 0, nrt_max = 1;
     for (auto l : list_len_) {
@@ -2405,8 +2414,8 @@ void GpuIndexIVF::search_listmajor_chunk_(int ni, const float* xq_pad, const idx
     const int novf = (int)h_lm_[0];
     lm_overflows_ += novf;
     if (novf > 0) {
-        // redo those queries with every probe in pass 1 (all their rows written, exact capacity): same arithmetic, same
-        // answer as an unbounded segment would have given
+        // redo those queries with 16 x the room, and what still overflows with every probe in pass 1 (all their rows
+        // written, exact capacity): same arithmetic, same answer as an unbounded segment would have given
         DevBuf olist, gq, gids, gdis, gD, gI;
         olist.ensure((size_t)novf * 4);
         HIP_CHECK(hipMemcpyAsync(olist.p, P.ovf + 1, (size_t)novf * 4, hipMemcpyDeviceToDevice, R.stream));
@@ -2418,7 +2427,7 @@ void GpuIndexIVF::search_listmajor_chunk_(int ni, const float* xq_pad, const idx
         launch_gather_rows(xq_pad, dpad_, dpad_, olist.as<uint32_t>(), novf, gq.as<float>(), R.stream);
         launch_gather_rows((const float*)c_ids, 2 * np, 2 * np, olist.as<uint32_t>(), novf, (float*)gids.p, R.stream);
         launch_gather_rows(c_dis, np, np, olist.as<uint32_t>(), novf, gdis.as<float>(), R.stream);
-        search_listmajor_(novf, gq.as<float>(), gids.as<idx_t>(), gdis.as<float>(), np, k, gD.as<float>(), gI.as<idx_t>(), true);
+        search_listmajor_(novf, gq.as<float>(), gids.as<idx_t>(), gdis.as<float>(), np, k, gD.as<float>(), gI.as<idx_t>(), level + 1);
         launch_scatter_results(gD.as<float>(), gI.as<idx_t>(), k, olist.as<uint32_t>(), novf, dD, dI, R.stream);
         R.sync(); // the gathered buffers die with this scope
     }

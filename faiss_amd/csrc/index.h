@@ -438,9 +438,9 @@ class GpuIndexIVF : public Index {
     mutable int last_scan_mode_ = 0;
     mutable long lm_overflows_ = 0; // statistics: queries redone because their candidate segment overflowed
     void search_listmajor_(int ni, const float* xq_pad, const idx_t* c_ids, const float* c_dis, int np, int k, float* dD,
-                           idx_t* dI, bool force_all) const;
+                           idx_t* dI, int level) const;
     void search_listmajor_chunk_(int ni, const float* xq_pad, const idx_t* c_ids, const float* c_dis, int np, int k,
-                                 float* dD, idx_t* dI, bool force_all, int64_t stride, int min_p1, int c1max) const;
+                                 float* dD, idx_t* dI, int level, int64_t stride, int min_p1, int RT) const;
     void upload_list_tables_();
     void ensure_arena_(int64_t rows);
     // make room for new_len[l] entries in every list (relocating the lists that outgrow their slack); est[l]
