@@ -723,6 +723,8 @@ __global__ void __launch_bounds__(LR_THREADS, 2) ivf_lm_flat_reg_kernel(IvfLmPar
     };
 
     const uint32_t it0 = p.item_bounds[1], it1 = p.item_bounds[2];
+    // (Eight per-XCD item queues -- neighbouring items read the same rows, workgroups b, b + 8, ... share an L2 -- were
+    // measured: L2 misses 19.4 -> 14.2 GB per launch at nb = 10M, same time; slower at nb = 1M.  profiles/r03_b_*)
     uint32_t* ctr = p.item_bounds + 4; // next item of pass 2 (zeroed by the plan)
     for (;;) {
         uint32_t it = 0;
@@ -735,7 +737,8 @@ __global__ void __launch_bounds__(LR_THREADS, 2) ivf_lm_flat_reg_kernel(IvfLmPar
         const int rt = __builtin_amdgcn_readfirstlane(item.rt);
         const int list = bk >= p.nlist ? bk - p.nlist : bk;
         const int len = (int)p.list_len[list];
-        const int64_t start = p.list_start[list];
+        // (dbg 8, timing experiments: every item reads the rows of one of four lists -- a working set the L2 holds)
+        const int64_t start = p.list_start[(p.dbg & 8) ? (list & 3) : list];
         const uint32_t pb = p.bucket_start[bk];
         const int npair = min(32, (int)(p.bucket_start[bk + 1] - pb) - qt * 32);
         const int r0 = rt * p.rows_per_item;

@@ -36,6 +36,8 @@ def _build(res, kind, metric, d, M, nlist, xt, xb, seed=7):
     (0, METRIC_L2, 40, 0, 16, 9000, 300, 16, 7),                # dpad < 128, every list probed, ragged tiles
     (0, METRIC_L2, 72, 0, 8, 20000, 1100, 2, 1000),             # lists of ~2500 rows: several row chunks per list, big k
     (0, METRIC_INNER_PRODUCT, 64, 0, 32, 5000, 130, 5, 2048),   # k above the rows many queries see
+    (0, METRIC_L2, 64, 0, 8, 90000, 600, 3, 50),                # lists of ~11 000 rows: row chunks of 2816 rows
+    (1, METRIC_L2, 64, 32, 8, 90000, 600, 3, 50),               # the same for codes
     (1, METRIC_L2, 128, 64, 64, 40000, 1500, 8, 100),           # bench shape: M = 64, dsub = 2
     (1, METRIC_INNER_PRODUCT, 128, 64, 64, 40000, 1100, 8, 10),
     (1, METRIC_L2, 64, 16, 32, 30000, 400, 32, 600),            # dsub = 4, every list probed
@@ -80,12 +82,12 @@ def test_list_major_independent_of_batch_composition(res):
     assert np.array_equal(D2, D[perm]) and np.array_equal(I2, I[perm])
 
 
-@pytest.mark.parametrize("kind", [0, 1])
-def test_list_major_overflow_rerun_is_exact(res, kind):
+@pytest.mark.parametrize("kind,nnear,levels", [(0, 6000, 1), (1, 6000, 1), (0, 40000, 2), (1, 40000, 2)])
+def test_list_major_overflow_rerun_is_exact(res, kind, nnear, levels):
     """Adversarial layout for the pass-1 bound: the nearest list of every query holds exactly k rows that are FAR away,
-    the next two lists hold 6000 rows each that are all closer -- more candidates than a segment has room for
-    (k + longest list + 1024).  Those queries are redone with every probe in pass 1; the answer is still the oracle's
-    bit for bit."""
+    the next two lists hold `nnear` rows each that are all closer -- more candidates than a segment has room for (4096).
+    Those queries are redone with 16 x the room (enough for 2 x 6000 rows), and where that overflows too (2 x 40 000
+    rows) with every probe in pass 1; the answer is still the oracle's bit for bit."""
     d, k, nlist = 32, 4, 4
     rs = np.random.RandomState(3)
     cent = np.zeros((nlist, d), "float32")
@@ -94,10 +96,10 @@ def test_list_major_overflow_rerun_is_exact(res, kind):
     xq[:, 1] = rs.rand(40) * 0.01
     far = np.zeros((k, d), "float32")       # list 0: |far - q|^2 ~ 900
     far[:, 2] = 30.0 + rs.rand(k)
-    near1 = np.zeros((6000, d), "float32")  # list 1 (4.95 from centroid 1, 5.05 from centroid 0): |near1 - q|^2 ~ 25.5
-    near1[:, 0] = 5.05 + rs.rand(6000) * 0.01
-    near2 = np.zeros((6000, d), "float32")  # list 2: |near2 - q|^2 ~ 226
-    near2[:, 0] = 15.05 + rs.rand(6000) * 0.01
+    near1 = np.zeros((nnear, d), "float32")  # list 1 (4.95 from centroid 1, 5.05 from centroid 0): |near1 - q|^2 ~ 25.5
+    near1[:, 0] = 5.05 + rs.rand(nnear) * 0.01
+    near2 = np.zeros((nnear, d), "float32")  # list 2: |near2 - q|^2 ~ 226
+    near2[:, 0] = 15.05 + rs.rand(nnear) * 0.01
     xb = np.concatenate([far, near1, near2]).astype("float32")
     M = 8
     if kind == 0:
@@ -110,13 +112,13 @@ def test_list_major_overflow_rerun_is_exact(res, kind):
     idx.copy_centroids(cent)
     idx.add(xb)
     sizes = [idx.get_list_size(l) for l in range(nlist)]
-    assert sizes[0] == k and sizes[1] == 6000 and sizes[2] == 6000
+    assert sizes[0] == k and sizes[1] == nnear and sizes[2] == nnear
     idx.nprobe = 3
     idx.set_scan_mode(idx.SCAN_LIST_MAJOR)
     before = idx.scan_info()[2]
     D, I = idx.search(xq, k)
     if kind == 0:
-        assert idx.scan_info()[2] - before == len(xq), "the overflow path was not exercised"
+        assert idx.scan_info()[2] - before == levels * len(xq), "the overflow path was not exercised"
     sz, codes, ids, _ = Oracle.build_ivf_lists(kind, METRIC_L2, cent, xb, pq=pq)
     Do, Io, _, _ = Oracle.ivf_search(kind, METRIC_L2, cent, sz, codes, ids, xq, 3, k, M=M if kind else 0, pq=pq, arith=1)
     check_knn(D, I, Do, Io, exact=True, name="overflow rerun vs oracle")
