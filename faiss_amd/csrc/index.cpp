@@ -2237,12 +2237,16 @@ void GpuIndexIVF::search_core_body_(idx_t n, const float* x, idx_t k, float* dis
 // ---------------------------------------------------------------------- list-major search (ivf_listmajor.hip)
 bool GpuIndexIVF::list_major_rule(idx_t n, int nprobe_now, idx_t k, bool has_selector) const {
     if (has_selector || !lm_capable_()) return false;
-    // IVFPQ: 64 bytes per row make the query-major scan cheap per query; the list-major kernel (codebook in LDS) runs its
-    // matrix pipe at ~20 % and only wins where lists are long (profiles/r03_b_*: nb = 1M 1.68 vs 1.35 ms, nb = 10M 8.1 vs
-    // 9.7 ms, nb = 100M 63.9 vs 95.7 ms): lists of 2048 rows on average and a shape the LDS kernel serves.
-    if (fused_kind_() == 1 && !(lm_pq_lds_capable_() && nstored_ >= (int64_t)2048 * nlist)) return false;
-    if (fused_kind_() > 1) return false;
+    // IVFPQ: 64 bytes per row make the query-major scan cheap per query (its cost: rows x queries of a list, HBM-bound);
+    // the list-major kernel (codebook in LDS) costs rows x 32-query blocks of matrix work plus the fixed plan / bound /
+    // select launches.  Measured at nlist 4096, nprobe 32 (profiles/r03_b_*), list-major vs query-major, ms: nb = 1M 1.38 vs
+    // 1.31 (0.77 vs 0.41 with 2500 queries), 2M 1.96 vs 2.07, 4M 2.83 vs 3.63, 10M 5.0 vs 9.7 -- break-even near
+    // (rows per list) x (queries per list) = 415 x 78; the rule asks for 50 000, and a shape the LDS kernel serves.
     const int64_t np = std::min<int64_t>(nprobe_now, nlist);
+    if (fused_kind_() == 1 &&
+        !(lm_pq_lds_capable_() && (double)n * (double)np * (double)nstored_ >= 50000.0 * (double)nlist * (double)nlist))
+        return false;
+    if (fused_kind_() > 1) return false;
     return n >= 2048 && (int64_t)n * np >= (int64_t)8 * nlist && k <= kMaxSelectionK;
 }
 

@@ -16,6 +16,7 @@
 // of the segment under (distance, scan position) -- the same rule as every other scan here -- whatever order the
 // workgroups ran in.
 #include "kernels.h"
+#include <type_traits>
 #include "wg_select.h"
 
 namespace faiss_amd {
@@ -285,7 +286,8 @@ __global__ void __launch_bounds__(1024) lm_items_kernel(IvfLmParams p) {
         // (max_items is an upper bound computed on the host from the list lengths; exceeding it would lose work, so the
         // host checks item_bounds[3] == 0 whenever it reads the overflow word)
         p.item_bounds[3] = all > (uint32_t)p.max_items ? 1u : 0u;
-        p.item_bounds[4] = 0; // item counter of the register-fed pass-2 kernel
+        p.item_bounds[4] = 0; // item counter of pass 2 (the kernels whose waves draw their items: IVFFlat pass 2, IVFPQ)
+        p.item_bounds[5] = 0; // ... of pass 1 (IVFPQ)
     }
 }
 
@@ -898,29 +900,35 @@ static void lr_launch(const IvfLmParams& p, int grid_blocks, hipStream_t stream)
     }
 }
 
-// ------------------------------------------------------------------ IVFPQ, codebook in LDS (round 3, second kernel)
+// ------------------------------------------------------------------ IVFPQ, codebook in LDS (round 3, third kernel)
 // The generic kernel above decodes an IVFPQ tile through 64 codebook gathers per row from L2 -- more expensive than the
 // matrix work the tile feeds (profiles/r03_b_listmajor_experiments.txt: 0.44 of 0.92 ms).  Here the whole codebook
 // [M][256][dsub] (d KB of fp32: 128 KB at d = 128) lives in LDS for the life of a persistent workgroup, and a lane builds
-// its MFMA A operand -- 4 consecutive coordinates of ITS row -- straight from it: code byte(s) of the row from an LDS copy
-// of the tile's codes (un-rotated on the way in), then one to four LDS gathers.  No decoded tile, no codebook traffic
-// outside the CU.  Same operands, same MFMA chain as the generic kernel: bit-identical results.
-// Workgroup = 8 waves over a 128-row tile and up to 64 of the item's queries: wave w owns query block w & 1 and the
-// 32-row block w >> 1.  One workgroup per CU (LDS); the two waves of a SIMD cover each other's epilogues.
+// its MFMA A operand -- 4 consecutive coordinates of ITS row -- straight from it: code byte(s) of the row, then one to
+// four LDS gathers.  No decoded tile, no codebook traffic outside the CU.  Same operands, same MFMA chain as the generic
+// kernel: bit-identical results.
+// A wavefront works alone (the second kernel of this round ran 8 waves in lock step over a 128-row tile, two barriers a
+// tile, every operand decoded twice -- by the waves of the two query blocks: the LDS side, not the matrix pipe, was its
+// bound, dbg = 3 in profiles/r03_b_*): it draws an item (list, up to 64 queries, row chunk) from a counter, keeps the
+// B operands of both 32-query blocks in 128 registers, and walks the rows in blocks of 32: the block's code bytes go
+// global -> registers (one block ahead) -> a private 32-row LDS slice, un-rotated on the way in (pq_code_offset), so that
+// the code bytes of an operand are one aligned LDS read.  Code reads run two operand pairs ahead of the MFMAs, codebook
+// gathers one pair ahead (explicit software pipeline: left alone hipcc hoists all 64 LDS reads of a block to its top and
+// spills).  One decoded operand feeds the MFMAs of both query blocks; an item with <= 32 queries skips the second
+// block's.  No barrier after the codebook load.
 // DS: 1 / 2 = dsub itself, 4 = any multiple of 4 (the 4 coordinates of an operand then lie inside one sub-vector).
 constexpr int LQ_THREADS = 512;
-constexpr int LQ_TR = 128;   // rows per tile
+constexpr int LQ_BR = 32;    // rows per block
 constexpr int LQ_PARK = 96;  // parked candidates per wave
 struct LqLayout {
-    int cb_bytes, rs, off_codes, off_rn, off_park, total;
+    int cb_bytes, rs, off_codes, off_park, total;
 };
 __host__ __device__ static inline LqLayout lq_layout(int d, int M) {
     LqLayout L;
     L.cb_bytes = d * 256 * 4;
-    L.rs = M + 4;                                   // bytes per row of the code tile (odd multiple of 4: conflict-free)
+    L.rs = ((M + 15) & ~15) + 16;                   // bytes per row of a code slice (16-byte pieces; + 16: rows on different banks)
     L.off_codes = (L.cb_bytes + 15) & ~15;
-    L.off_rn = (L.off_codes + 2 * LQ_TR * L.rs + 15) & ~15;
-    L.off_park = L.off_rn + 2 * LQ_TR * 4;
+    L.off_park = L.off_codes + 8 * LQ_BR * L.rs;
     L.total = L.off_park + 8 * LQ_PARK * (8 + 4);
     return L;
 }
@@ -944,7 +952,6 @@ __global__ void __launch_bounds__(LQ_THREADS, 2) ivf_lm_pq_kernel(IvfLmParams p)
     const int ns = FULL ? 16 : (p.dpad >> 3);
     const LqLayout L = lq_layout(p.d, M);
     const float* cb = (const float*)smem;
-    const int wq = wave & 1, wr = wave >> 1; // query block, row block of this wave
 
     // ---- the codebook, once per workgroup
     {
@@ -952,6 +959,7 @@ __global__ void __launch_bounds__(LQ_THREADS, 2) ivf_lm_pq_kernel(IvfLmParams p)
         f32x4* dst = (f32x4*)smem;
         for (int i = tid; i < p.d * 64; i += LQ_THREADS) dst[i] = src[i];
     }
+    unsigned char* crow = (unsigned char*)(smem + L.off_codes) + (wave * LQ_BR + j) * L.rs; // this lane's row of the slice
     u64* pk_keys = (u64*)(smem + L.off_park) + wave * LQ_PARK;
     uint32_t* pk_q = (uint32_t*)(smem + L.off_park + 8 * LQ_PARK * 8) + wave * LQ_PARK;
     int wcnt = 0; // (wave-uniform) parked candidates of pass 2
@@ -967,13 +975,18 @@ __global__ void __launch_bounds__(LQ_THREADS, 2) ivf_lm_pq_kernel(IvfLmParams p)
         }
         wcnt = 0;
     };
-    // barrier of the tile loop: this thread's LDS writes have completed, no fence (a fenced __syncthreads() would also wait
-    // for the key stores of the epilogue, every tile)
-    auto tile_barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     __syncthreads();
 
+    const int ch = pq_chunk_bytes(M);
+    const int nch = M >> 4;            // 16-byte pieces of a stored row (ch == 16)
+    const int cpl = (nch + 1) >> 1;    // ... per lane: lane (j, h) moves pieces h * cpl .. of row j (at most 4: M <= 112)
     const uint32_t it0 = p.item_bounds[PASS - 1], it1 = p.item_bounds[PASS];
-    for (uint32_t it = it0 + blockIdx.x; it < it1; it += gridDim.x) {
+    uint32_t* ctr = p.item_bounds + (PASS == 1 ? 5 : 4); // next item of this pass (zeroed by the plan)
+    for (;;) {
+        uint32_t it = 0;
+        if (lane == 0) it = atomicAdd(ctr, 1u);
+        it = it0 + (uint32_t)__builtin_amdgcn_readfirstlane((int)it);
+        if (it >= it1) break;
         const IvfLmItem item = p.items[it];
         const int bk = __builtin_amdgcn_readfirstlane(item.bucket);
         const int qt = __builtin_amdgcn_readfirstlane(item.qt);
@@ -983,170 +996,219 @@ __global__ void __launch_bounds__(LQ_THREADS, 2) ivf_lm_pq_kernel(IvfLmParams p)
         const int64_t start = p.list_start[list];
         const uint32_t pb = p.bucket_start[bk];
         const int npair = min(kLmQueriesPerItem, (int)(p.bucket_start[bk + 1] - pb) - qt * kLmQueriesPerItem);
+        const bool two = npair > 32; // (wave-uniform) the second query block holds queries
         const int r0 = rt * p.rows_per_item;
         const int r1 = p.force_all ? len : min(len, r0 + p.rows_per_item);
 
-        // ---- staging of a tile: thread -> 16 stored code bytes of one row (ch = 16) in registers, rn of one row
-        const int ch = pq_chunk_bytes(M);
-        const int npieces = LQ_TR * (M >> 4); // ch == 16 only
+        // ---- the code bytes of a block: global -> registers -> this wave's slice
+        const bool fast = ch == 16 && nch <= 4; // lane (j, h) moves the 16-byte pieces h * cpl .. (at most two) of row j
         uint4 creg[2];
-        float rnreg = 0.f;
-        auto prefetch = [&](int t) __attribute__((always_inline)) {
-            if (ch == 16) {
+        auto fetch = [&](int t) __attribute__((always_inline)) {
+            if (fast) {
+                const int64_t row = start + t + j; // arena row (inside the list's capacity: a multiple of 64 rows)
+                const unsigned char* src = p.arena_codes + (size_t)(row >> 6) * 64 * M + (size_t)(row & 63) * 16;
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const int piece = tid + LQ_THREADS * i;
-                    if (piece < npieces) {
-                        const int r = piece & (LQ_TR - 1), c = piece >> 7;
-                        const int64_t row = start + t + r; // arena row (lists start on 64-row block boundaries)
-                        creg[i] = *(const uint4*)(p.arena_codes + (size_t)(row >> 6) * 64 * M + (size_t)c * 1024 + (size_t)(row & 63) * 16);
-                    }
+                    const int c = h * cpl + i;
+                    if (i < cpl && c < nch) creg[i] = *(const uint4*)(src + (size_t)c * 1024);
                 }
             }
-            if (METRIC == METRIC_L2 && tid < LQ_TR) rnreg = t + tid < r1 ? p.arena_rn[start + t + tid] : 0.f;
         };
-        auto stage = [&](int t, int buf) __attribute__((always_inline)) {
-            unsigned char* ct = (unsigned char*)(smem + L.off_codes + buf * LQ_TR * L.rs);
-            if (ch == 16) {
+        auto stage = [&](int t) __attribute__((always_inline)) {
+            const int64_t row = start + t + j;
+            if (fast) {
+                const int lrot = (int)(row & 63) % M; // stored byte x of the row is sub-quantizer (x + row) mod M
+                // (the registers are opaque up to here: hipcc otherwise takes the bytes apart right behind the loads of
+                // fetch() -- a wait for the loads a block early, 32 live registers instead of 8)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(creg[i].x), "+v"(creg[i].y), "+v"(creg[i].z), "+v"(creg[i].w));
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const int piece = tid + LQ_THREADS * i;
-                    if (piece < npieces) {
-                        const int r = piece & (LQ_TR - 1), c = piece >> 7;
-                        const int l = (int)((start + t + r) & 63);
+                    const int c = h * cpl + i;
+                    if (i < cpl && c < nch) {
                         const unsigned w[4] = {creg[i].x, creg[i].y, creg[i].z, creg[i].w};
 #pragma unroll
                         for (int b = 0; b < 16; ++b) {
-                            int m = (16 * c + b + l) % M; // stored byte j of row l is sub-quantizer (j + l) mod M
-                            ct[r * L.rs + m] = (unsigned char)(w[b >> 2] >> (8 * (b & 3)));
+                            int m = 16 * c + b + lrot;
+                            m -= m >= M ? M : 0;
+                            crow[m] = (unsigned char)(w[b >> 2] >> (8 * (b & 3)));
                         }
                     }
                 }
             } else {
-                // (code chunks of 4 bytes: M not a multiple of 16) byte by byte
-                for (int idx = tid; idx < LQ_TR * M; idx += LQ_THREADS) {
-                    const int r = idx & (LQ_TR - 1), m = idx >> 7;
-                    ct[r * L.rs + m] = p.arena_codes[pq_code_offset(M, start + t + r, m)];
-                }
+                for (int m = h; m < M; m += 2) crow[m] = p.arena_codes[pq_code_offset(M, row, m)];
             }
-            if (METRIC == METRIC_L2 && tid < LQ_TR) ((float*)(smem + L.off_rn))[buf * LQ_TR + tid] = rnreg;
+            // the slice is written and read by this wavefront only: LDS executes a wave's accesses in order, the compiler
+            // must not move the reads of other lanes' bytes above the writes
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
         };
-        prefetch(r0);
+        fetch(r0);
 
-        // ---- this lane's query
-        const int my = wq * 32 + j;
-        const bool qv = my < npair;
-        const uint32_t pi = p.pairs[pb + (uint32_t)(qt * kLmQueriesPerItem) + (uint32_t)(qv ? my : 0)];
-        const int q = (int)(pi / (uint32_t)np);
-        const int pr = (int)(pi - (uint32_t)q * (uint32_t)np);
-        const bool wave_active = wq * 32 < npair; // wave-uniform
-        const float* qrow = p.xq + (int64_t)q * p.ldq;
-        f32x4 bq[16];
+        // ---- this lane's queries: one per 32-query block
+        bool qv[2];
+        int q[2];
+        uint32_t base_pos[2], base_slot[2];
+        float xn[2], thr_f[2];
+        f32x4 bq[2][16];
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            if (FULL || s < ns) bq[s] = *(const f32x4*)(qrow + 8 * s + 4 * h);
-            else bq[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        float xn = 0.f;
-        if (METRIC == METRIC_L2) {
-            const float* cen = p.centroids + (int64_t)list * p.ldc;
-            float acc = 0.f;
+        for (int b = 0; b < 2; ++b) {
+            const int my = b * 32 + j;
+            qv[b] = my < npair;
+            const uint32_t pi = p.pairs[pb + (uint32_t)(qt * kLmQueriesPerItem) + (uint32_t)(qv[b] ? my : 0)];
+            q[b] = (int)(pi / (uint32_t)np);
+            const int pr = (int)(pi - (uint32_t)q[b] * (uint32_t)np);
+            const float* qrow = p.xq + (int64_t)q[b] * p.ldq;
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
-                if (FULL || s < ns) {
-                    const f32x4 c4 = *(const f32x4*)(cen + 8 * s + 4 * h);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float v = bq[s][e] - c4[e];
-                        bq[s][e] = v;
-                        acc = __fmaf_rn(v, v, acc);
-                    }
-                }
+                if ((FULL || s < ns) && (b == 0 || two)) bq[b][s] = *(const f32x4*)(qrow + 8 * s + 4 * h);
+                else bq[b][s] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            xn = acc + __shfl_xor(acc, 32, 64);
-        } else {
-            xn = p.coarse_dis[pi];
-        }
-        const uint32_t base_pos = p.prefix[(int64_t)q * (np + 1) + pr];
-        const uint32_t base_slot = PASS == 1 ? p.prefix1[(int64_t)q * (np + 1) + pr] : 0u;
-        u64* kq = p.keys + (int64_t)q * p.stride;
-        float thr_f = 0.f;
-        if (PASS == 2) {
-            const uint32_t tk = p.thr[q];
-            if (tk >= kInvalidOrdKey) thr_f = METRIC == METRIC_L2 ? INFINITY : -INFINITY;
-            else thr_f = unordkey<METRIC>(tk);
-        }
-        auto dist_of = [&](float ip, float rn) -> float {
+            xn[b] = 0.f;
             if (METRIC == METRIC_L2) {
-                const float dd = __fmaf_rn(-2.f, ip, xn + rn);
-                return dd < 0.f ? 0.f : dd;
-            }
-            return xn + ip;
-        };
-
-        stage(r0, 0);
-        tile_barrier();
-        int buf = 0;
-        for (int t = r0; t < r1; t += LQ_TR, buf ^= 1) {
-            const bool more = t + LQ_TR < r1;
-            if (more) prefetch(t + LQ_TR);
-            if (wave_active && t + wr * 32 < r1) {
-                const unsigned char* crow = (const unsigned char*)(smem + L.off_codes + buf * LQ_TR * L.rs) + (wr * 32 + j) * L.rs;
-                const float* rnt = (const float*)(smem + L.off_rn) + buf * LQ_TR + wr * 32;
-                f32x16 acc;
+                if (b == 0 || two) {
+                    const float* cen = p.centroids + (int64_t)list * p.ldc;
+                    float acc = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                    for (int s = 0; s < 16; ++s) {
+                        if (FULL || s < ns) {
+                            const f32x4 c4 = *(const f32x4*)(cen + 8 * s + 4 * h);
 #pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    if (FULL || s < ns) {
-                        const int kb = 8 * s + 4 * h; // first coordinate of this operand
-                        f32x4 a = {0.f, 0.f, 0.f, 0.f};
-                        if (kb < p.d) {
-                            if (DS == 2) {
-                                const int m0 = kb >> 1;
-                                const unsigned c0 = crow[m0], c1 = crow[m0 + 1];
-                                const float2 lo = *(const float2*)(cb + ((m0 << 8) + c0) * 2);
-                                const float2 hi = *(const float2*)(cb + (((m0 + 1) << 8) + c1) * 2);
-                                a = f32x4{lo.x, lo.y, hi.x, hi.y};
-                            } else if (DS == 1) {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) a[e] = cb[((kb + e) << 8) + crow[kb + e]];
-                            } else {
-                                const int m = kb / dsub, off = kb - m * dsub;
-                                a = *(const f32x4*)(cb + ((m << 8) + crow[m]) * dsub + off);
+                            for (int e = 0; e < 4; ++e) {
+                                const float v = bq[b][s][e] - c4[e];
+                                bq[b][s][e] = v;
+                                acc = __fmaf_rn(v, v, acc);
                             }
                         }
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], bq[s][e], acc, 0, 0, 0);
                     }
+                    xn[b] = acc + __shfl_xor(acc, 32, 64);
                 }
-                // ---- epilogue: 16 distances of this lane's query (as in the generic kernel)
-                const int row_b = t + wr * 32 + 4 * h; // row of the list of acc[4 g + e]: row_b + 8 g + e
+            } else {
+                xn[b] = p.coarse_dis[pi];
+            }
+            base_pos[b] = p.prefix[(int64_t)q[b] * (np + 1) + pr];
+            base_slot[b] = PASS == 1 ? p.prefix1[(int64_t)q[b] * (np + 1) + pr] : 0u;
+            thr_f[b] = 0.f;
+            if (PASS == 2) {
+                const uint32_t tk = p.thr[q[b]];
+                if (tk >= kInvalidOrdKey) thr_f[b] = METRIC == METRIC_L2 ? INFINITY : -INFINITY;
+                else thr_f[b] = unordkey<METRIC>(tk);
+            }
+        }
+        auto dist_of = [&](float ip, float rn, float xnb) -> float {
+            if (METRIC == METRIC_L2) {
+                const float dd = __fmaf_rn(-2.f, ip, xnb + rn);
+                return dd < 0.f ? 0.f : dd;
+            }
+            return xnb + ip;
+        };
+
+        for (int t = r0; t < r1; t += LQ_BR) {
+            stage(t);
+            const bool more = t + LQ_BR < r1;
+            // code byte(s) of operand s of this lane's row: one aligned read of the un-rotated slice
+            // (FULL means d == 128 for every shape this kernel serves.  Otherwise the last operand may start at a
+            // coordinate >= d (dpad > d): it is built from whatever LDS holds there and replaced by zeros with a select,
+            // no divergent branch in the operand stream)
+            auto codes_of = [&](int s_) __attribute__((always_inline)) -> unsigned {
+                if (!(FULL || s_ < ns)) return 0u;
+                const int kb = 8 * s_ + 4 * h; // first coordinate of the operand
+                if (DS == 2) return *(const unsigned short*)(crow + (kb >> 1));
+                if (DS == 1) return *(const unsigned*)(crow + kb);
+                return crow[kb / dsub];
+            };
+            auto operand_of = [&](int s_, unsigned cw) __attribute__((always_inline)) -> f32x4 {
+                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                if (!(FULL || s_ < ns)) return a;
+                const int kb = 8 * s_ + 4 * h;
+                if (DS == 2) {
+                    const int m0 = kb >> 1;
+                    const float2 lo = *(const float2*)(cb + ((m0 << 8) + (cw & 255u)) * 2);
+                    const float2 hi = *(const float2*)(cb + (((m0 + 1) << 8) + (cw >> 8)) * 2);
+                    a = f32x4{lo.x, lo.y, hi.x, hi.y};
+                } else if (DS == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a[e] = cb[((kb + e) << 8) + ((cw >> (8 * e)) & 255u)];
+                } else {
+                    const int m = kb / dsub, off = kb - m * dsub;
+                    a = *(const f32x4*)(cb + ((m << 8) + (cw & 255u)) * dsub + off);
+                }
+                if (!FULL && kb >= p.d) a = f32x4{0.f, 0.f, 0.f, 0.f};
+                return a;
+            };
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc0[r] = 0.f;
+                acc1[r] = 0.f;
+            }
+            f32x4 rn4[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) rn4[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            auto operands_and_mfmas = [&](auto two_c) __attribute__((always_inline)) {
+                constexpr bool TWO = decltype(two_c)::value;
+                // pairs of operands: codes of pair g + 2 | gathers of pair g + 1 | MFMAs of pair g
+                unsigned cw[3][2];
+                f32x4 av[2][2];
+                cw[0][0] = codes_of(0), cw[0][1] = codes_of(1);
+                cw[1][0] = codes_of(2), cw[1][1] = codes_of(3);
+                av[0][0] = operand_of(0, cw[0][0]), av[0][1] = operand_of(1, cw[0][1]);
+    #pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    if (g + 2 < 8) cw[(g + 2) % 3][0] = codes_of(2 * g + 4), cw[(g + 2) % 3][1] = codes_of(2 * g + 5);
+                    if (g + 1 < 8)
+                        av[(g + 1) & 1][0] = operand_of(2 * g + 2, cw[(g + 1) % 3][0]), av[(g + 1) & 1][1] = operand_of(2 * g + 3, cw[(g + 1) % 3][1]);
+                    if (g == 1 && more) fetch(t + LQ_BR);
+                    if (g == 4 && METRIC == METRIC_L2) {
+                        // |r^|^2 of the block's rows (lane: rows 4 h + 8 g + e), consumed by the epilogue
+    #pragma unroll
+                        for (int gg = 0; gg < 4; ++gg) rn4[gg] = *(const f32x4*)(p.arena_rn + start + t + 8 * gg + 4 * h);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (FULL || 2 * g < ns) {
+    #pragma unroll
+                        for (int u = 0; u < 2; ++u)
+    #pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g & 1][u][e], bq[0][2 * g + u][e], acc0, 0, 0, 0);
+                                if (TWO) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g & 1][u][e], bq[1][2 * g + u][e], acc1, 0, 0, 0);
+                            }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            if (two) operands_and_mfmas(std::true_type{});
+            else operands_and_mfmas(std::false_type{});
+            // ---- epilogue: 16 distances of each of this lane's queries (as in the generic kernel)
+            const int row_b = t + 4 * h; // row of the list of acc[4 g + e]: row_b + 8 g + e
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                if (b == 1 && !two) break;
+                const f32x16& acc = b == 0 ? acc0 : acc1;
                 if (PASS == 1) {
+                    u64* kq = p.keys + (int64_t)q[b] * p.stride;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const f32x4 b4 = *(const f32x4*)(rnt + 8 * g + 4 * h);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int rowl = row_b + 8 * g + e;
-                            const uint32_t pos = base_pos + (uint32_t)rowl;
-                            if (qv && rowl < r1 && !(p.dbg & 1))
-                                kq[base_slot + (uint32_t)rowl] = ((u64)ordkey<METRIC>(dist_of(acc[4 * g + e], b4[e])) << 32) | pos;
+                            const uint32_t pos = base_pos[b] + (uint32_t)rowl;
+                            if (qv[b] && rowl < r1 && !(p.dbg & 1))
+                                kq[base_slot[b] + (uint32_t)rowl] = ((u64)ordkey<METRIC>(dist_of(acc[4 * g + e], rn4[g][e], xn[b])) << 32) | pos;
                         }
                     }
                 } else {
                     unsigned mask = 0;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const f32x4 b4 = *(const f32x4*)(rnt + 8 * g + 4 * h);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float dis = dist_of(acc[4 * g + e], b4[e]);
-                            const bool pass = (METRIC == METRIC_L2 ? dis <= thr_f : dis >= thr_f) && row_b + 8 * g + e < r1;
+                            const float dis = dist_of(acc[4 * g + e], rn4[g][e], xn[b]);
+                            const bool pass = (METRIC == METRIC_L2 ? dis <= thr_f[b] : dis >= thr_f[b]) && row_b + 8 * g + e < r1;
                             mask |= pass ? 1u << (4 * g + e) : 0u;
                         }
                     }
-                    if (!qv || (p.dbg & 1)) mask = 0;
+                    if (!qv[b] || (p.dbg & 1)) mask = 0;
                     if (__ballot(mask != 0u)) {
                         const int c = __popc(mask);
                         int inc = c;
@@ -1158,8 +1220,9 @@ __global__ void __launch_bounds__(LQ_THREADS, 2) ivf_lm_pq_kernel(IvfLmParams p)
                         const int total = __builtin_amdgcn_readlane(inc, 63);
                         if (total > LQ_PARK) {
                             if (mask) {
+                                u64* kq = p.keys + (int64_t)q[b] * p.stride;
                                 uint32_t slot;
-                                uint32_t* cp = p.cnt + q;
+                                uint32_t* cp = p.cnt + q[b];
                                 const uint32_t nc = (uint32_t)c;
                                 asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)"
                                              : "=&v"(slot)
@@ -1167,13 +1230,12 @@ __global__ void __launch_bounds__(LQ_THREADS, 2) ivf_lm_pq_kernel(IvfLmParams p)
                                              : "memory");
 #pragma unroll
                                 for (int g = 0; g < 4; ++g) {
-                                    const f32x4 b4 = *(const f32x4*)(rnt + 8 * g + 4 * h);
 #pragma unroll
                                     for (int e = 0; e < 4; ++e) {
                                         if (mask & (1u << (4 * g + e))) {
-                                            const uint32_t pos = base_pos + (uint32_t)(row_b + 8 * g + e);
+                                            const uint32_t pos = base_pos[b] + (uint32_t)(row_b + 8 * g + e);
                                             if ((int64_t)slot < p.stride)
-                                                kq[slot] = ((u64)ordkey<METRIC>(dist_of(acc[4 * g + e], b4[e])) << 32) | pos;
+                                                kq[slot] = ((u64)ordkey<METRIC>(dist_of(acc[4 * g + e], rn4[g][e], xn[b])) << 32) | pos;
                                             ++slot;
                                         }
                                     }
@@ -1184,13 +1246,12 @@ __global__ void __launch_bounds__(LQ_THREADS, 2) ivf_lm_pq_kernel(IvfLmParams p)
                             int at = wcnt + inc - c;
 #pragma unroll
                             for (int g = 0; g < 4; ++g) {
-                                const f32x4 b4 = *(const f32x4*)(rnt + 8 * g + 4 * h);
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) {
                                     if (mask & (1u << (4 * g + e))) {
-                                        const uint32_t pos = base_pos + (uint32_t)(row_b + 8 * g + e);
-                                        pk_keys[at] = ((u64)ordkey<METRIC>(dist_of(acc[4 * g + e], b4[e])) << 32) | pos;
-                                        pk_q[at] = (uint32_t)q;
+                                        const uint32_t pos = base_pos[b] + (uint32_t)(row_b + 8 * g + e);
+                                        pk_keys[at] = ((u64)ordkey<METRIC>(dist_of(acc[4 * g + e], rn4[g][e], xn[b])) << 32) | pos;
+                                        pk_q[at] = (uint32_t)q[b];
                                         ++at;
                                     }
                                 }
@@ -1200,8 +1261,9 @@ __global__ void __launch_bounds__(LQ_THREADS, 2) ivf_lm_pq_kernel(IvfLmParams p)
                     }
                 }
             }
-            if (more) stage(t + LQ_TR, buf ^ 1);
-            tile_barrier(); // next tile staged, this one no longer read
+            // (the next block's stage() writes the slice: every read above was issued before it, LDS keeps a wave's order)
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
         }
     }
     if (PASS == 2 && wcnt > 0) flush();

@@ -168,6 +168,15 @@ def test_scan_mode_rule_and_refusals(res):
     D1, I1 = idx.search(xq[:500], 10)
     assert idx.scan_info()[1] == 1
     check_knn(D[:500], I[:500], D1, I1, rtol=1e-4, name="automatic list-major vs query-major")
+    # IVFPQ: (rows per list) x (queries per list) >= 50 000 -- 125 rows per list here
+    pq, _, _ = _build(res, 1, METRIC_L2, d, 8, nlist, xt, xb)
+    pq.nprobe = 8
+    assert not pq.list_major_rule(2100, 8, 10) and pq.list_major_rule(3300, 8, 10) and not pq.list_major_rule(3100, 8, 10)
+    Dp, Ip = pq.search(np.tile(xq, (2, 1))[:3300], 10)
+    assert pq.scan_info()[1] == 2
+    pq.set_scan_mode(pq.SCAN_QUERY_MAJOR)
+    Dq, Iq = pq.search(np.tile(xq, (2, 1))[:3300], 10)
+    check_knn(Dp, Ip, Dq, Iq, rtol=1e-4, name="IVFPQ automatic list-major vs query-major")
     with pytest.raises(faiss_amd.FaissAmdError):
         idx.set_scan_mode(3)
     idx.set_scan_mode(idx.SCAN_LIST_MAJOR)
