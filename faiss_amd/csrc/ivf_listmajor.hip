@@ -177,41 +177,40 @@ __global__ void __launch_bounds__(256) lm_plan_kernel(IvfLmParams p) {
     if (lane == 0) p.cnt[q] = c1;
     for (int pr = lane; pr < np; pr += 64) {
         const int64_t l = ids[pr];
-        if (l >= 0 && p.list_len[l] > 0) atomicAdd(&p.bucket_cnt[(int)l + (pr >= p0 ? p.nlist : 0)], 1u);
+        if (l >= 0 && p.list_len[l] > 0) atomicAdd(&p.bucket_cnt[2 * (int)l + (pr >= p0 ? 1 : 0)], 1u);
     }
 }
 
-// one workgroup: bucket_start = exclusive scan of bucket_cnt; work items.  Bucket b < nlist holds the pass-1 pairs of
-// list b, bucket nlist + l the other pairs of list l.  Pass 1 runs (pass-1 bucket, row chunk 0); pass 2 runs every row
-// chunk of the other buckets and the row chunks 1.. of the pass-1 buckets (lists longer than a chunk).  Items are listed
-// pass 1 first, bucket by bucket, row chunk by row chunk, query group innermost (consecutive items share their rows).
+// one workgroup: bucket_start = exclusive scan of bucket_cnt; work items.  Bucket 2 l holds the pass-1 pairs of list l,
+// bucket 2 l + 1 its other pairs (next to each other in `pairs`).  Pass 1 runs (pass-1 bucket, row chunk 0); pass 2 runs row
+// chunk 0 for the other bucket, and the row chunks 1.. of a list (lists longer than a chunk) for BOTH buckets as one range
+// of pairs (item.both): past the first chunk all queries of a list are candidates against the bound alike, and
+// grouping them together fills the 32-query blocks (10 + 68 queries: 3 blocks instead of 1 + 3).  Items are listed pass 1
+// first, list by list, row chunk by row chunk, query group innermost (consecutive items share their rows).
 __global__ void __launch_bounds__(1024) lm_items_kernel(IvfLmParams p) {
     __shared__ uint32_t part_pairs[1024];
     __shared__ uint32_t part_i1[1024];
     __shared__ uint32_t part_i2[1024];
     __shared__ uint32_t tot[2];
     const int t = threadIdx.x;
-    const int n = 2 * p.nlist;
+    const int n = p.nlist;
     const int per = (n + 1023) / 1024;
     const int a = min(n, t * per), b = min(n, a + per);
-    auto shape = [&](int bk, int& nqt, int& nrt) {
-        const uint32_t c = p.bucket_cnt[bk];
-        const uint32_t len = p.list_len[bk >= p.nlist ? bk - p.nlist : bk];
-        nqt = (int)((c + p.qpi - 1) / p.qpi);
-        nrt = p.force_all ? 1 : (int)((len + p.rows_per_item - 1) / p.rows_per_item);
+    auto shape = [&](int l, uint32_t& c1, uint32_t& c2, int& nrt) {
+        c1 = p.bucket_cnt[2 * l];
+        c2 = p.bucket_cnt[2 * l + 1];
+        nrt = p.force_all ? 1 : (int)((p.list_len[l] + p.rows_per_item - 1) / p.rows_per_item);
     };
+    auto groups = [&](uint32_t c) { return (c + p.qpi - 1) / p.qpi; };
     // (force_all: one item takes all rows of its list: the redo of a few queries is not worth balancing)
     uint32_t sp = 0, s1 = 0, s2 = 0;
     for (int i = a; i < b; ++i) {
-        int nqt, nrt;
-        shape(i, nqt, nrt);
-        sp += p.bucket_cnt[i];
-        if (i < p.nlist) {
-            s1 += nqt;
-            s2 += nqt * (nrt - (nqt ? 1 : 0));
-        } else {
-            s2 += nqt * nrt;
-        }
+        uint32_t c1, c2;
+        int nrt;
+        shape(i, c1, c2, nrt);
+        sp += c1 + c2;
+        s1 += groups(c1);
+        s2 += groups(c2) + groups(c1 + c2) * (uint32_t)max(nrt - 1, 0);
     }
     // exclusive scans of the three per-thread sums over the 1024 threads: inclusive scan inside every wavefront
     // (shuffles), then the 16 wavefront totals by the first wavefront
@@ -251,7 +250,7 @@ __global__ void __launch_bounds__(1024) lm_items_kernel(IvfLmParams p) {
                 part_i2[64 + t] = v2 - w2;
             }
             if (t == 15) {
-                p.bucket_start[n] = vp;
+                p.bucket_start[2 * n] = vp;
                 tot[0] = v1;
                 tot[1] = v2;
             }
@@ -262,21 +261,20 @@ __global__ void __launch_bounds__(1024) lm_items_kernel(IvfLmParams p) {
         s2 = part_i2[64 + wv] + i2s - s2;
     }
     uint32_t rp = sp, i1 = s1, i2 = tot[0] + s2;
-    auto put = [&](uint32_t at, int bk, int qt, int rt) {
-        if (at < (uint32_t)p.max_items) p.items[at] = IvfLmItem{bk, qt, rt, 0};
+    auto put = [&](uint32_t at, int bk, int qt, int rt, int both) {
+        if (at < (uint32_t)p.max_items) p.items[at] = IvfLmItem{bk, qt, rt, both};
     };
     for (int i = a; i < b; ++i) {
-        p.bucket_start[i] = rp;
-        int nqt, nrt;
-        shape(i, nqt, nrt);
-        if (nqt) {
-            for (int rt = 0; rt < nrt; ++rt)
-                for (int qt = 0; qt < nqt; ++qt) {
-                    if (i < p.nlist && rt == 0) put(i1++, i, qt, rt);
-                    else put(i2++, i, qt, rt);
-                }
-        }
-        rp += p.bucket_cnt[i];
+        uint32_t c1, c2;
+        int nrt;
+        shape(i, c1, c2, nrt);
+        p.bucket_start[2 * i] = rp;
+        p.bucket_start[2 * i + 1] = rp + c1;
+        for (uint32_t qt = 0; qt < groups(c1); ++qt) put(i1++, 2 * i, (int)qt, 0, 0);
+        for (uint32_t qt = 0; qt < groups(c2); ++qt) put(i2++, 2 * i + 1, (int)qt, 0, 0);
+        for (int rt = 1; rt < nrt; ++rt)
+            for (uint32_t qt = 0; qt < groups(c1 + c2); ++qt) put(i2++, 2 * i, (int)qt, rt, 1);
+        rp += c1 + c2;
     }
     if (t == 0) {
         const uint32_t all = tot[0] + tot[1];
@@ -298,7 +296,7 @@ __global__ void lm_fill_kernel(IvfLmParams p) {
     const int64_t l = p.coarse_ids[i];
     if (l < 0 || p.list_len[l] == 0) return;
     const int q = (int)(i / p.nprobe), pr = (int)(i - (int64_t)q * p.nprobe);
-    const int bk = (int)l + (pr >= (int)p.p0[q] ? p.nlist : 0);
+    const int bk = 2 * (int)l + (pr >= (int)p.p0[q] ? 1 : 0);
     const uint32_t slot = p.bucket_start[bk] + atomicAdd(&p.bucket_fill[bk], 1u);
     p.pairs[slot] = (uint32_t)i;
 }
@@ -415,11 +413,11 @@ __global__ void __launch_bounds__(LM_THREADS, KIND == 0 ? 2 : 3) ivf_lm_scan_ker
         const int bk = __builtin_amdgcn_readfirstlane(item.bucket);
         const int qt = __builtin_amdgcn_readfirstlane(item.qt);
         const int rt = __builtin_amdgcn_readfirstlane(item.rt);
-        const int list = bk >= p.nlist ? bk - p.nlist : bk;
+        const int list = bk >> 1;
         const int len = (int)p.list_len[list];
         const int64_t start = p.list_start[list];
         const uint32_t pb = p.bucket_start[bk];
-        const int npair = min(p.qpi, (int)(p.bucket_start[bk + 1] - pb) - qt * p.qpi);
+        const int npair = min(p.qpi, (int)(p.bucket_start[bk + 1 + item.both] - pb) - qt * p.qpi);
         const int r0 = rt * p.rows_per_item;
         const int r1 = p.force_all ? len : min(len, r0 + p.rows_per_item);
 
@@ -737,12 +735,12 @@ __global__ void __launch_bounds__(LR_THREADS, 2) ivf_lm_flat_reg_kernel(IvfLmPar
         const int bk = __builtin_amdgcn_readfirstlane(item.bucket);
         const int qt = __builtin_amdgcn_readfirstlane(item.qt);
         const int rt = __builtin_amdgcn_readfirstlane(item.rt);
-        const int list = bk >= p.nlist ? bk - p.nlist : bk;
+        const int list = bk >> 1;
         const int len = (int)p.list_len[list];
         // (dbg 8, timing experiments: every item reads the rows of one of four lists -- a working set the L2 holds)
         const int64_t start = p.list_start[(p.dbg & 8) ? (list & 3) : list];
         const uint32_t pb = p.bucket_start[bk];
-        const int npair = min(32, (int)(p.bucket_start[bk + 1] - pb) - qt * 32);
+        const int npair = min(32, (int)(p.bucket_start[bk + 1 + item.both] - pb) - qt * 32);
         const int r0 = rt * p.rows_per_item;
         const int r1 = p.force_all ? len : min(len, r0 + p.rows_per_item);
 
@@ -991,11 +989,11 @@ __global__ void __launch_bounds__(LQ_THREADS, 2) ivf_lm_pq_kernel(IvfLmParams p)
         const int bk = __builtin_amdgcn_readfirstlane(item.bucket);
         const int qt = __builtin_amdgcn_readfirstlane(item.qt);
         const int rt = __builtin_amdgcn_readfirstlane(item.rt);
-        const int list = bk >= p.nlist ? bk - p.nlist : bk;
+        const int list = bk >> 1;
         const int len = (int)p.list_len[list];
         const int64_t start = p.list_start[list];
         const uint32_t pb = p.bucket_start[bk];
-        const int npair = min(kLmQueriesPerItem, (int)(p.bucket_start[bk + 1] - pb) - qt * kLmQueriesPerItem);
+        const int npair = min(kLmQueriesPerItem, (int)(p.bucket_start[bk + 1 + item.both] - pb) - qt * kLmQueriesPerItem);
         const bool two = npair > 32; // (wave-uniform) the second query block holds queries
         const int r0 = rt * p.rows_per_item;
         const int r1 = p.force_all ? len : min(len, r0 + p.rows_per_item);

@@ -400,7 +400,8 @@ size_t ivf_fused_lds_bytes(int kind, int M, int dpad, int kp, int cap, int nprob
 //   <.,.> = the MFMA chain of flat_scan_kernel (orc_ip_chain); |y|^2, |r^|^2 sequential chains kept per stored row
 //   (arena_rn); |q - c|^2 = the sum of the two interleaved half chains a lane pair holds (orc_lm_residual_norm).
 struct IvfLmItem {
-    int bucket, qt, rt, pad;
+    int bucket, qt, rt; // bucket = 2 * list + (0: pairs of pass 1, 1: the other pairs), group of qpi pairs, row chunk
+    int both;           // 1: the item's pairs are those of bucket and bucket + 1 (all pairs of the list)
 };
 constexpr int kLmRowsPerItem = 1024; // rows of a list per work item (16 tiles); pass 1 sees the first chunk of a list
 constexpr int kLmQueriesPerItem = 64; // two 32-query blocks (x the two 32-row blocks of a tile = 4 waves)
@@ -420,7 +421,7 @@ struct IvfLmParams {
     uint32_t* prefix1;       // [nq][nprobe + 1] the same over min(length, rows_per_item): segment slots of pass 1
     uint32_t* p0;            // [nq] probes of pass 1
     uint32_t* cnt;           // [nq] keys in the segment (after the plan: the pass-1 rows)
-    uint32_t* bucket_cnt;    // [2 nlist] pairs per (pass, list); zeroed by the plan launcher
+    uint32_t* bucket_cnt;    // [2 nlist] pairs per (list, pass); zeroed by the plan launcher
     uint32_t* bucket_fill;   // [2 nlist] cursors; zeroed by the plan launcher
     uint32_t* bucket_start;  // [2 nlist + 1]
     uint32_t* pairs;         // [nq * nprobe] pair = q * nprobe + p, grouped by bucket
