@@ -45,7 +45,11 @@ NLIST, NPROBE, PQ_M = 4096, 32, 64
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 PEAK_F16_MFMA_TFLOPS = 2500.0  # same guide: dense f16/bf16 MFMA (v_mfma_f32_32x32x16_f16)
 PEAK_HBM_GBS = 8000.0
-PROFILE_JSON = os.path.join(ROOT, "profiles", "r02_pmc_counters.json")  # committed rocprofv3 --pmc summary
+# committed rocprofv3 --pmc summaries (tools/profile_round.sh; one file per profiled search loop)
+PROFILE_DIR = os.path.join(ROOT, "profiles")
+PROFILE_JSON = {"flat": "r03_d_pmc_flat.json", "ivfpq": "r03_d_pmc_ivfpq_1m.json", "ivfsq": "r02_pmc_counters.json",
+                "ivfflat": "r03_d_pmc_ivfflat_1m.json", "ivfflat_10m": "r03_d_pmc_ivfflat_10m.json",
+                "ivfpq_10m": "r03_d_pmc_ivfpq_10m.json"}
 
 
 def log(*a):
@@ -256,7 +260,7 @@ def collect_spans(res):
     return {k: res.profile_get(k) for k in SPAN_NAMES}
 
 
-def ivf_roofline(spans, list_major, kind, nb, row_bytes):
+def ivf_roofline(spans, list_major, kind, nb, row_bytes, profile=None):
     """roofline block of an IVF leg.  Query-major scan: HBM-bound, SURVEY.md 8d's algorithmic bytes (nprobe * nb/nlist *
     bytes per entry per query) over the scan launch.  List-major scan: every list is read once per group of up to 64 of
     the queries probing it and the distances are f32 MFMA dot products, so the bound is the f32 matrix pipe: 2 * nq *
@@ -271,14 +275,15 @@ def ivf_roofline(spans, list_major, kind, nb, row_bytes):
         return {"bound": "hbm", "kernel": kname, "achieved": round(ach, 1) if ach else None, "peak": PEAK_HBM_GBS,
                 "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4) if ach else None, "avg_kernel_ms": round(avg, 3),
                 "launches": int(n), "algorithmic_bytes_per_launch": int(alg_bytes),
-                "traffic": committed_traffic(kname, alg_bytes)}
+                "traffic": committed_traffic(kname, alg_bytes, profile or kind)}
     (m1, n1), (m2, n2) = spans["ivf_lm_scan_pass1"], spans["ivf_lm_scan_pass2"]
     searches = max(n2, 1)
     scan_ms = (m1 + m2) / searches  # both scan launches of one search (pass 1 may run twice when queries are redone)
     flops = 2.0 * NQ * NPROBE * (nb / float(NLIST)) * D
     ach = flops / (scan_ms * 1e-3) / 1e12
     unique = nb * float(row_bytes) + NQ * D * 4.0
-    return {"bound": "mfma", "kernel": "ivf_lm_scan_kernel (pass 1 + pass 2 launches of one search)",
+    kernels = ("ivf_lm_scan_kernel (pass 1) + ivf_lm_flat_reg_kernel (pass 2)" if kind == "ivfflat" else "ivf_lm_pq_kernel (pass 1 + pass 2)")
+    return {"bound": "mfma", "kernel": kernels + ": the scan launches of one search",
             "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
             "avg_kernel_ms": round(scan_ms, 3), "launches": int(n1 + n2),
             "algorithmic_flop_per_search": int(flops),
@@ -288,7 +293,7 @@ def ivf_roofline(spans, list_major, kind, nb, row_bytes):
                                 "note": "bytes the query-major formulation moves per search; the list-major scan reads a "
                                         "list once per group of <= 64 queries, so this figure is not bound by the HBM peak"},
             "unique_bytes_per_batch": int(unique),
-            "traffic": None}
+            "traffic": committed_lm_traffic(profile or kind, unique)}
 
 
 def scale_leg(kind, nb, res, xt, xb, xq, xq_dev, dmap, torch, leg_1m, nsample=16):
@@ -356,7 +361,7 @@ def scale_leg(kind, nb, res, xt, xb, xq, xq_dev, dmap, torch, leg_1m, nsample=16
         "build_s": round(t_build, 1), "add_s": round(t_add, 1), "data_generation_s": round(t_gen, 1),
         "add_M_vectors_per_s": round(nb / t_add / 1e6, 2),
         "arena_rows_over_vectors": round(alloc / float(nb), 3), "overflow_queries": int(idx.scan_info()[2]),
-        "roofline": ivf_roofline(spans, list_major, kind, nb, row_bytes),
+        "roofline": ivf_roofline(spans, list_major, kind, nb, row_bytes, profile="%s_%dm" % (kind, nb // 1000000)),
         "kernels_ms": {k: round(v[0] / max(v[1], 1), 3) for k, v in spans.items() if v[1]},
         "parity": {"sampled_queries_bit_exact_vs_oracle_on_probed_lists": exact, "sampled_queries": int(nsample),
                    "probed_list_entries_read_back": int(len(ids)), "all_results_ordered_and_labels_valid": ok_order},
@@ -405,29 +410,52 @@ def predicted_per_rank(res, flat_index, ivfpq_index, xb, xq_dev, torch):
     return out
 
 
-def committed_traffic(kernel_substr, alg_bytes):
+def _pmc(profile):
+    path = os.path.join(PROFILE_DIR, PROFILE_JSON.get(profile, ""))
+    return json.load(open(path)), os.path.relpath(path, ROOT)
+
+
+def committed_traffic(kernel_substr, alg_bytes, profile):
     """HBM bytes per launch of a kernel from the rocprofv3 --pmc FETCH_SIZE pass committed under profiles/ (PMC
     counters cannot be read from inside this process; same kernel, same workload, corrected x2 as the MI355X guide
     prescribes for 16 B/lane reads on gfx950).  None when the summary holds no entry."""
     try:
-        pmc = json.load(open(PROFILE_JSON))
+        pmc, rel = _pmc(profile)
         ent = [v for k, v in pmc.items() if kernel_substr in k and "FETCH_SIZE" in v]
         if not ent:
             return None
         e = max(ent, key=lambda v: v.get("avg_duration_ns", 0))
         return {"hbm_read_bytes_per_launch_from_committed_profile": round(e["hbm_read_bytes_corrected"]),
                 "algorithmic_bytes_per_launch": round(alg_bytes),
-                "source": os.path.relpath(PROFILE_JSON, ROOT) + " (rocprofv3 --pmc FETCH_SIZE, separate pass; gfx950 2x "
-                          "correction for 16 B/lane reads applied)"}
+                "source": rel + " (rocprofv3 --pmc FETCH_SIZE, separate pass; gfx950 2x correction for 16 B/lane reads applied)"}
     except (OSError, KeyError, ValueError, IndexError):
         return None
 
 
-def committed_mfma_busy(kernel_substr):
+def committed_lm_traffic(profile, unique_bytes):
+    """L2-miss bytes of the list-major scan launches of ONE search (pass 1 + pass 2 kernels) from the committed FETCH_SIZE
+    pass of the same workload, next to the bytes a batch has to read at least once."""
+    try:
+        pmc, rel = _pmc(profile)
+        ent = {k: v for k, v in pmc.items() if "ivf_lm_" in k and "_kernel<" in k and "FETCH_SIZE" in v
+               and ("scan_kernel" in k or "reg_kernel" in k or "pq_kernel" in k)}
+        if not ent:
+            return None
+        return {"hbm_read_bytes_per_search_from_committed_profile": round(sum(v["hbm_read_bytes_corrected"] for v in ent.values())),
+                "unique_bytes_per_batch": round(unique_bytes),
+                "kernels": {k.split("(")[0].replace("void faiss_amd::", ""): {"bytes": round(v["hbm_read_bytes_corrected"]),
+                                                                              "avg_ms": round(v["avg_duration_ns"] / 1e6, 3)}
+                            for k, v in ent.items()},
+                "source": rel + " (rocprofv3 --pmc FETCH_SIZE = L2 misses, separate pass; gfx950 2x correction for 16 B/lane reads applied)"}
+    except (OSError, KeyError, ValueError, IndexError):
+        return None
+
+
+def committed_mfma_busy(kernel_substr, profile="flat"):
     """MFMA-busy share of the dominant flat kernel from the committed SQ pass: SQ_VALU_MFMA_BUSY_CYCLES (cycles, summed
     over the 1024 SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs = active cycles of the launch) / 1024."""
     try:
-        pmc = json.load(open(PROFILE_JSON))
+        pmc, _ = _pmc(profile)
         ent = [v for k, v in pmc.items() if kernel_substr in k and "SQ_VALU_MFMA_BUSY_CYCLES" in v and "GRBM_GUI_ACTIVE" in v]
         e = max(ent, key=lambda v: v.get("avg_duration_ns", 0))
         return round(e["SQ_VALU_MFMA_BUSY_CYCLES"] / (e["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), 4)
@@ -655,7 +683,7 @@ def main():
                      "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                      "whole_search_frac": round(2.0 * NQ * NB * D / (ms_per_step * 1e-3) / 1e12 / peak, 4) if world == 1 else None,
                      "mfma_busy_frac_from_committed_profile": committed_mfma_busy("flat_filter_kernel<1, 1,") if used_filter else None,
-                     "traffic": committed_traffic("flat_filter_kernel<1, 1,", hbm_bytes) if used_filter and world == 1 else None,
+                     "traffic": committed_traffic("flat_filter_kernel<1, 1,", hbm_bytes, "flat") if used_filter and world == 1 else None,
                      "avg_kernel_ms": round(avg_scan_ms, 3), "launches": int(scan_n),
                      "algorithmic_hbm_GBps": round(hbm_bytes / (avg_scan_ms * 1e-3) / 1e9, 1),
                      "hbm_frac": round(hbm_bytes / (avg_scan_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 5)},

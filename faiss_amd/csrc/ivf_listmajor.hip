@@ -1102,7 +1102,7 @@ __global__ void __launch_bounds__(LQ_THREADS, 2) ivf_lm_pq_kernel(IvfLmParams p)
         };
 
         for (int t = r0; t < r1; t += LQ_BR) {
-            stage(t);
+            if (!(p.dbg & 16)) stage(t); // (dbg: timing experiments, results wrong)
             const bool more = t + LQ_BR < r1;
             // code byte(s) of operand s of this lane's row: one aligned read of the un-rotated slice
             // (FULL means d == 128 for every shape this kernel serves.  Otherwise the last operand may start at a
@@ -1175,8 +1175,10 @@ __global__ void __launch_bounds__(LQ_THREADS, 2) ivf_lm_pq_kernel(IvfLmParams p)
                     __builtin_amdgcn_sched_barrier(0);
                 }
             };
-            if (two) operands_and_mfmas(std::true_type{});
+            if (p.dbg & 2) {
+            } else if (two) operands_and_mfmas(std::true_type{});
             else operands_and_mfmas(std::false_type{});
+            if (p.dbg & 32) continue;
             // ---- epilogue: 16 distances of each of this lane's queries (as in the generic kernel)
             const int row_b = t + 4 * h; // row of the list of acc[4 g + e]: row_b + 8 g + e
 #pragma unroll

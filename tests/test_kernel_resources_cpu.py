@@ -112,4 +112,4 @@ def test_list_major_scan(usage):
     for name, u in _pick(usage, "ivf_lm_pq_kernel").items():
         assert u["occupancy"] >= 2, (name, u)
     for name, u in _pick(usage, "ivf_lm_pq_kernel", "ELi2ELb1E").items():  # dsub = 2, d = 128: PQ64 of the bench
-        assert u["scratch"] <= 128, (name, u)
+        assert u["scratch"] <= 192, (name, u)

@@ -36,7 +36,8 @@ torch.cuda.synchronize()
 dt = (time.time() - t0) / steps
 res.profile_enable(True); res.profile_reset()
 idx.search_ptr(10000, xq_dev.data_ptr(), 100, Dd.data_ptr(), Id.data_ptr())
-ms, n = res.profile_get("ivfflat_fused_kernel")
-bytes_per_query = 32.0 * nb / 4096.0 * 128 * 4
-print("ivfflat nb=%d: %.3f ms/step = %.0f QPS; fused kernel %.3f ms = %.0f GB/s algorithmic (%.1f%% of 8 TB/s)" % (
-    nb, dt * 1e3, 10000 / dt, ms, bytes_per_query * 10000 / (ms * 1e-3) / 1e9, bytes_per_query * 10000 / (ms * 1e-3) / 8e12 * 100))
+print("ivfflat nb=%d: %.3f ms/step = %.0f QPS; scan_info %s" % (nb, dt * 1e3, 10000 / dt, idx.scan_info()))
+for kn in ("ivfflat_fused_kernel", "ivf_finish_kernel", "ivf_lm_plan", "ivf_lm_scan_pass1", "ivf_lm_threshold", "ivf_lm_scan_pass2", "select_k_kernel"):
+    ms, n = res.profile_get(kn)
+    if n:
+        print("  %s %.3f ms (%d)" % (kn, ms, n))

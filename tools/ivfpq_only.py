@@ -37,9 +37,8 @@ for fb in os.environ.get("FB_LIST", "512").split(","):
     print("ivfpq search (%s): %.3f ms/step" % ("ip" if metric == 0 else "l2", (time.time() - t0) / steps * 1e3))
     res.profile_enable(True); res.profile_reset()
     idx.search_ptr(10000, xq_dev.data_ptr(), 100, Dd.data_ptr(), Id.data_ptr())
-    for kn in ("ivfpq_fused_kernel", "ivf_finish_kernel", "flat_scan_kernel", "select_k_kernel", "flat_filter_kernel", "flat_filter_kernel_max", "flat_tighten_kernel", "flat_rerank_kernel", "convert_f16_query"):
-        print(kn, res.profile_get(kn))
-    ms, n = res.profile_get("ivfpq_fused_kernel")
-    bpq = 32.0 * nb / 4096.0 * 64
-    print("ivfpq nb=%d: %.0f QPS; fused kernel %.3f ms = %.0f GB/s algorithmic code bytes (%.1f%% of 8 TB/s)" % (
-        nb, 10000 / dt_step, ms, bpq * 10000 / (ms * 1e-3) / 1e9, bpq * 10000 / (ms * 1e-3) / 8e12 * 100))
+    print("scan_info", idx.scan_info())
+    for kn in ("ivfpq_fused_kernel", "ivf_finish_kernel", "ivf_lm_plan", "ivf_lm_scan_pass1", "ivf_lm_threshold", "ivf_lm_scan_pass2", "flat_scan_kernel", "select_k_kernel", "flat_filter_kernel", "flat_filter_kernel_max", "flat_tighten_kernel", "flat_rerank_kernel", "convert_f16_query"):
+        ms, n = res.profile_get(kn)
+        if n:
+            print("  %s %.3f ms (%d)" % (kn, ms, n))
