@@ -44,6 +44,9 @@ def _build(res, kind, metric, d, M, nlist, xt, xb, seed=7):
     (1, METRIC_L2, 96, 12, 16, 5000, 1200, 5, 2048),            # dsub = 8, code chunks of 4 bytes
     (1, METRIC_L2, 32, 32, 8, 3000, 1030, 3, 5),                # dsub = 1
     (1, METRIC_INNER_PRODUCT, 36, 4, 16, 6000, 257, 4, 20),     # d = 36 -> dpad = 40: zero padding of the decoded tile, dsub = 9
+    (1, METRIC_L2, 96, 48, 16, 12000, 700, 6, 30),              # three 16-byte pieces per stored row (lane pairs 2 + 1)
+    (1, METRIC_INNER_PRODUCT, 80, 80, 8, 9000, 300, 4, 40),     # five pieces: staged byte by byte; dsub = 1
+    (1, METRIC_L2, 120, 60, 16, 8000, 520, 5, 64),              # dpad = 120 < 128, M % 16 != 0 (4-byte pieces), dsub = 2
 ])
 def test_list_major_scan_matches_oracle_and_query_major(res, kind, metric, d, M, nlist, nb, nq, nprobe, k):
     xt, xb, xq = synthetic_dataset(d, 4000, nb, nq, seed=nb + k)
