@@ -2749,21 +2749,99 @@ void GpuIndexIVFPQ::train_residual_(idx_t n, const float* x_dev_pad) {
     launch_residual(xs, dpad_, nt, d, dlab.as<idx_t>(), quantizer->device_vectors(), dpad_,
                     dres.as<float>(), d, R.stream);
     R.sync();
-    // one k-means per sub-quantizer on its dsub columns of the device-resident residuals (row stride d)
     std::vector<float> pq((size_t)M * 256 * dsub);
-    GpuIndexFlat assign_index(res_, dsub, METRIC_L2);
-    for (int m = 0; m < M; m++) {
-        Clustering clus(dsub, 256);
-        clus.niter = pq_niter;
-        clus.seed = cp_seed + m;
-        clus.train(nt, dres.as<float>() + (size_t)m * dsub, assign_index, d);
-        memcpy(&pq[(size_t)m * 256 * dsub], clus.centroids.data(), sizeof(float) * 256 * dsub);
+    const char* loop_env = getenv("FAISS_AMD_PQ_TRAIN_LOOP");
+    if (pq_train_batched && !(loop_env && atoi(loop_env) == 1) && pq_train_batched_supported(dsub) && nt >= 256) {
+        train_pq_batched_(nt, dres.as<float>(), pq);
+    } else {
+        // one k-means per sub-quantizer on its dsub columns of the device-resident residuals (row stride d)
+        GpuIndexFlat assign_index(res_, dsub, METRIC_L2);
+        for (int m = 0; m < M; m++) {
+            Clustering clus(dsub, 256);
+            clus.niter = pq_niter;
+            clus.seed = cp_seed + m;
+            clus.train(nt, dres.as<float>() + (size_t)m * dsub, assign_index, d);
+            memcpy(&pq[(size_t)m * 256 * dsub], clus.centroids.data(), sizeof(float) * 256 * dsub);
+        }
     }
     pq_.ensure(pq.size() * 4);
     HIP_CHECK(hipMemcpy(pq_.p, pq.data(), pq.size() * 4, hipMemcpyHostToDevice));
     pq_t_.ensure(pq.size() * 4);
     launch_pq_transpose(pq_.as<float>(), M, dsub, pq_t_.as<float>(), R.stream);
     R.sync();
+}
+// All M sub-quantizers as ONE k-means over M * nt points and M * 256 clusters (kernels: ivf_kernels.hip pq_train_*): what
+// Clustering::train_device_ does per sub-space -- same initial draw per sub-space (seed cp_seed + m), same assignment and
+// update arithmetic, same refill of empty clusters with the sub-space's own generator -- with one set of launches and one
+// host synchronisation per iteration instead of M.  res: [nt][d] residuals on the device.
+void GpuIndexIVFPQ::train_pq_batched_(idx_t nt, const float* res, std::vector<float>& pq) {
+    const GpuResources& R = *res_;
+    const int K = 256, KT = M * K;
+    const int64_t N = (int64_t)M * nt;
+    FA_THROW_IF_NOT_MSG(N < ((int64_t)1 << 32), "product quantizer training: too many points");
+    // ---- init: k distinct random points per sub-space (Clustering::train_device_: the first k of a partial shuffle)
+    std::vector<std::mt19937_64> rng;
+    std::vector<uint32_t> hsel((size_t)KT);
+    {
+        std::vector<uint32_t> perm((size_t)nt);
+        for (int m = 0; m < M; m++) {
+            rng.emplace_back((uint64_t)(cp_seed + m));
+            std::iota(perm.begin(), perm.end(), 0u);
+            for (int i = 0; i < K; i++) {
+                const idx_t j = i + (idx_t)(rng[m]() % (uint64_t)(nt - i));
+                std::swap(perm[i], perm[j]);
+            }
+            memcpy(&hsel[(size_t)m * K], perm.data(), sizeof(uint32_t) * K);
+        }
+    }
+    DevBuf sel, cen, lab, dest, order, hist, cnt, zero, start;
+    sel.ensure((size_t)KT * 4);
+    cen.ensure((size_t)KT * dsub * 4);
+    HIP_CHECK(hipMemcpyAsync(sel.p, hsel.data(), (size_t)KT * 4, hipMemcpyHostToDevice, R.stream));
+    launch_pq_train_init(res, d, M, dsub, sel.as<uint32_t>(), cen.as<float>(), R.stream);
+    int chunk = 256;
+    while (div_up((size_t)N, (size_t)chunk) > 512) chunk *= 2;
+    const int nchunks = (int)div_up((size_t)N, (size_t)chunk);
+    lab.ensure((size_t)N * 8);
+    dest.ensure((size_t)N * 8);
+    order.ensure((size_t)N * 4);
+    hist.ensure((size_t)nchunks * KT * 4);
+    cnt.ensure((size_t)KT * 4);
+    zero.ensure((size_t)KT * 4);
+    start.ensure((size_t)(KT + 1) * 8);
+    HIP_CHECK(hipMemsetAsync(zero.p, 0, (size_t)KT * 4, R.stream));
+    std::vector<uint32_t> hcnt((size_t)KT);
+    std::vector<idx_t> hassign(K);
+    Clustering split(dsub, K);
+    for (int it = 0; it < pq_niter; it++) {
+        check_interrupt();
+        launch_pq_train_assign(res, d, nt, M, dsub, cen.as<float>(), lab.as<int64_t>(), R.stream);
+        HIP_CHECK(hipMemsetAsync(hist.p, 0, (size_t)nchunks * KT * 4, R.stream));
+        launch_ivf_histogram(lab.as<int64_t>(), N, KT, chunk, hist.as<uint32_t>(), R.stream);
+        launch_ivf_chunk_scan(hist.as<uint32_t>(), nchunks, KT, zero.as<uint32_t>(), cnt.as<uint32_t>(), R.stream);
+        HIP_CHECK(hipMemcpyAsync(hcnt.data(), cnt.p, (size_t)KT * 4, hipMemcpyDeviceToHost, R.stream));
+        launch_exclusive_scan(cnt.as<uint32_t>(), KT, start.as<int64_t>(), R.stream);
+        launch_ivf_rank(lab.as<int64_t>(), N, KT, chunk, hist.as<uint32_t>(), start.as<int64_t>(), dest.as<int64_t>(), R.stream);
+        launch_invert_dest(dest.as<int64_t>(), N, order.as<uint32_t>(), R.stream);
+        launch_pq_train_update(res, d, nt, M, dsub, order.as<uint32_t>(), start.as<int64_t>(), cnt.as<uint32_t>(), cen.as<float>(),
+                               R.stream);
+        R.sync();
+        // empty clusters (rare): the sub-space's centroids come to the host, are refilled as Clustering does, go back
+        for (int m = 0; m < M; m++) {
+            bool any_empty = false;
+            for (int c = 0; c < K; c++) {
+                hassign[c] = hcnt[(size_t)m * K + c];
+                any_empty |= hassign[c] == 0;
+            }
+            if (!any_empty) continue;
+            split.centroids.resize((size_t)K * dsub);
+            float* dm = cen.as<float>() + (size_t)m * K * dsub;
+            HIP_CHECK(hipMemcpy(split.centroids.data(), dm, (size_t)K * dsub * 4, hipMemcpyDeviceToHost));
+            split.split_empty_clusters(rng[m], nt, hassign);
+            HIP_CHECK(hipMemcpy(dm, split.centroids.data(), (size_t)K * dsub * 4, hipMemcpyHostToDevice));
+        }
+    }
+    HIP_CHECK(hipMemcpy(pq.data(), cen.p, (size_t)KT * dsub * 4, hipMemcpyDeviceToHost));
 }
 void GpuIndexIVFPQ::append_(int n, const float* x_pad, const int64_t* d_labels, const int64_t* d_dest) {
     launch_ivfpq_encode_append(x_pad, dpad_, n, d, d_labels, d_dest, quantizer->device_vectors(), dpad_, M,

@@ -493,6 +493,9 @@ class GpuIndexIVFPQ : public GpuIndexIVF {
     GpuIndexIVFPQ(std::shared_ptr<GpuResources> res, int dims, int nlist, int M, int nbits, int metric);
     int M, nbits, dsub;
     int pq_niter = 25; // faiss::ClusteringParameters default used by ProductQuantizer::train
+    // the M sub-quantizers are trained as one k-means (ivf_kernels.hip pq_train_*); false, or FAISS_AMD_PQ_TRAIN_LOOP=1 in
+    // the environment: one Clustering per sub-space, the round-2 loop (same codebook bit for bit)
+    bool pq_train_batched = true;
     void set_pq_centroids(const float* pq); // [M][256][dsub]
     std::vector<float> get_pq_centroids() const;
     // GpuIndexIVFPQ.h:98-113.  The term decomposition behind "precomputed codes" is always on here for L2 (one table per
@@ -519,6 +522,7 @@ class GpuIndexIVFPQ : public GpuIndexIVF {
     bool lm_capable_() const override;
     bool lm_pq_lds_capable_() const override { return ivf_lm_pq_lds_supported_(); }
     bool ivf_lm_pq_lds_supported_() const;
+    void train_pq_batched_(idx_t nt, const float* res, std::vector<float>& pq);
     void fill_lm_(struct IvfLmParams& p) const override;
     bool extra_trained_() const override { return pq_.p != nullptr; }
     void lists_changed_() override;
@@ -684,6 +688,9 @@ struct Clustering : ClusteringParameters {
     // from the training set), faiss/Clustering.cpp:330-345; with frozen_centroids they stay as given.
     void train(idx_t n, const float* x, Index& index, int64_t ldx = 0);
     bool last_train_on_device = false;
+    // the refill of empty clusters (faiss/Clustering.cpp:180-232 split_clusters) on `centroids`, for callers that run the
+    // iterations themselves (the product quantizer trains its M sub-spaces as one k-means): hassign = cluster sizes
+    void split_empty_clusters(std::mt19937_64& rng, idx_t nx, std::vector<idx_t>& hassign) { split_clusters_(rng, nx, hassign, 0); }
 
    private:
     void train_once_(idx_t n, const float* x, Index& index, int64_t ldx, uint64_t run_seed, const std::vector<float>& init);

@@ -390,6 +390,117 @@ void launch_kmeans_update(const float* x, int64_t ldx, int d, const uint32_t* or
     HIP_CHECK(hipGetLastError());
 }
 
+// ---------------------------------------------------------------------------------
+// Product-quantizer training as ONE k-means over all M sub-spaces (round 3): point (m, i) is the dsub columns
+// [m dsub, (m+1) dsub) of residual row i, its label m * 256 + (nearest of the 256 centroids of sub-space m); the counting
+// sort and the update above then run once per iteration over M * nt points and M * 256 clusters instead of M times.
+// Every point sees the arithmetic of the per-sub-space loop (flat_assign_small_kernel: chains over the sub-vector padded
+// to a multiple of 8 with zeros, norms as sequential chains, first minimum wins; kmeans_update_kernel: members added in
+// index order in double precision): the codebook is bit-identical (tests/test_gpu_extras.py).
+// Reference: faiss/impl/ProductQuantizer.cpp:140-190 (one Clustering per sub-quantizer), faiss/gpu/GpuIndexIVFPQ.cu:287-340.
+// ---------------------------------------------------------------------------------
+__global__ void pq_train_init_kernel(const float* __restrict__ res, int64_t ld, int M, int dsub,
+                                     const uint32_t* __restrict__ sel, float* __restrict__ cen) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x; // (m, c, j)
+    if (i >= M * 256 * dsub) return;
+    const int j = i % dsub, mc = i / dsub, m = mc >> 8;
+    cen[i] = res[(int64_t)sel[mc] * ld + (int64_t)m * dsub + j];
+}
+void launch_pq_train_init(const float* res, int64_t ld, int M, int dsub, const uint32_t* sel, float* cen, hipStream_t stream) {
+    hipLaunchKernelGGL(pq_train_init_kernel, dim3((unsigned)div_up((size_t)M * 256 * dsub, 256)), dim3(256), 0, stream, res, ld,
+                       M, dsub, sel, cen);
+    HIP_CHECK(hipGetLastError());
+}
+// grid (point tiles of 256, M); the 256 centroids of the sub-space and their norms in LDS, one thread per point
+__global__ void __launch_bounds__(256) pq_train_assign_kernel(const float* __restrict__ res, int64_t ld, int64_t nt, int dsub,
+                                                              int dpad, const float* __restrict__ cen,
+                                                              int64_t* __restrict__ labels) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* yb = (float*)smem;              // [256][dpad], zero padded
+    float* yn = yb + (size_t)256 * dpad;   // [256]
+    const int m = blockIdx.y;
+    const float* cm = cen + (size_t)m * 256 * dsub;
+    for (int t = threadIdx.x; t < 256 * dpad; t += 256) {
+        const int c = t % dpad;
+        yb[t] = c < dsub ? cm[(size_t)(t / dpad) * dsub + c] : 0.f;
+    }
+    __syncthreads();
+    {
+        // |y|^2 as l2_norms_kernel computes it for the rows of a flat index: one sequential chain
+        float acc = 0.f;
+        for (int c = 0; c < dpad; ++c) acc = __fmaf_rn(yb[threadIdx.x * dpad + c], yb[threadIdx.x * dpad + c], acc);
+        yn[threadIdx.x] = acc;
+    }
+    __syncthreads();
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= nt) return;
+    const float* qr = res + q * ld + (int64_t)m * dsub;
+    float qv[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) qv[c] = c < dsub ? qr[c] : 0.f;
+    float xn = 0.f;
+    for (int c = 0; c < dpad; ++c) xn = __fmaf_rn(qv[c], qv[c], xn);
+    unsigned best_key = 0xffffffffu;
+    int best = -1;
+    for (int row = 0; row < 256; ++row) {
+        const float* yr = yb + row * dpad; // every lane the same address: LDS broadcast
+        float acc = 0.f;
+#pragma unroll
+        for (int s = 0; s < 32; s += 8) {
+            if (s < dpad) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc = __fmaf_rn(yr[s + e], qv[s + e], acc);
+                    acc = __fmaf_rn(yr[s + 4 + e], qv[s + 4 + e], acc);
+                }
+            }
+        }
+        float dis = __fmaf_rn(-2.f, acc, xn + yn[row]);
+        dis = dis < 0.f ? 0.f : dis;
+        const unsigned key = ordkey<METRIC_L2>(dis);
+        if (key < best_key) { // strict: the first (lowest id) of equal distances stays
+            best_key = key;
+            best = row;
+        }
+    }
+    const bool ok = best >= 0 && best_key < kInvalidOrdKey;
+    labels[(int64_t)m * nt + q] = ok ? (int64_t)m * 256 + best : -1;
+}
+bool pq_train_batched_supported(int dsub) {
+    return dsub >= 1 && dsub <= 32;
+}
+void launch_pq_train_assign(const float* res, int64_t ld, int64_t nt, int M, int dsub, const float* cen, int64_t* labels,
+                            hipStream_t stream) {
+    FA_THROW_IF_NOT(pq_train_batched_supported(dsub));
+    const int dpad = (int)round_up(dsub, 8);
+    const size_t lds = (size_t)256 * (dpad + 1) * 4;
+    hipLaunchKernelGGL(pq_train_assign_kernel, dim3((unsigned)div_up((size_t)nt, 256), (unsigned)M), dim3(256), lds, stream, res,
+                       ld, nt, dsub, dpad, cen, labels);
+    HIP_CHECK(hipGetLastError());
+}
+// one workgroup per cluster (m, c): thread j adds coordinate j of the members in index order, in double precision
+__global__ void pq_train_update_kernel(const float* __restrict__ res, int64_t ld, int64_t nt, int dsub,
+                                       const uint32_t* __restrict__ order, const int64_t* __restrict__ start,
+                                       const uint32_t* __restrict__ cnt, float* __restrict__ cen) {
+    const int c = blockIdx.x;
+    const uint32_t n = cnt[c];
+    if (n == 0) return; // an empty cluster keeps its centroid (split on the host)
+    const int m = c >> 8;
+    const uint32_t* mem = order + start[c];
+    const float* base = res + (int64_t)m * dsub - (int64_t)m * nt * ld; // point p of sub-space m = row p - m nt
+    for (int j = threadIdx.x; j < dsub; j += blockDim.x) {
+        double s = 0.0;
+        for (uint32_t t = 0; t < n; ++t) s += (double)base[(int64_t)mem[t] * ld + j];
+        cen[(int64_t)c * dsub + j] = (float)(s / (double)n);
+    }
+}
+void launch_pq_train_update(const float* res, int64_t ld, int64_t nt, int M, int dsub, const uint32_t* order,
+                            const int64_t* start, const uint32_t* cnt, float* cen, hipStream_t stream) {
+    hipLaunchKernelGGL(pq_train_update_kernel, dim3((unsigned)(M * 256)), dim3(64), 0, stream, res, ld, nt, dsub, order, start,
+                       cnt, cen);
+    HIP_CHECK(hipGetLastError());
+}
+
 __global__ void ivf_move_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                 const IvfMoveJob* __restrict__ jobs, int bytes_per_row) {
     const IvfMoveJob jb = jobs[blockIdx.x];

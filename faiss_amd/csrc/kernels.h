@@ -534,6 +534,13 @@ void launch_ivf_rank(const int64_t* labels, int64_t n, int nlist, int chunk, uin
 // centroids[c][j] = float(sum over the members of c, in index order, of double(x[i][j]) / count) for count > 0
 void launch_exclusive_scan(const uint32_t* cnt, int n, int64_t* start, hipStream_t stream);
 void launch_invert_dest(const int64_t* dest, int64_t n, uint32_t* order, hipStream_t stream);
+// product-quantizer training, all sub-spaces in one k-means (ivf_kernels.hip): labels m * 256 + c over M * nt points
+bool pq_train_batched_supported(int dsub);
+void launch_pq_train_init(const float* res, int64_t ld, int M, int dsub, const uint32_t* sel, float* cen, hipStream_t stream);
+void launch_pq_train_assign(const float* res, int64_t ld, int64_t nt, int M, int dsub, const float* cen, int64_t* labels,
+                            hipStream_t stream);
+void launch_pq_train_update(const float* res, int64_t ld, int64_t nt, int M, int dsub, const uint32_t* order,
+                            const int64_t* start, const uint32_t* cnt, float* cen, hipStream_t stream);
 void launch_kmeans_update(const float* x, int64_t ldx, int d, const uint32_t* order, const int64_t* start,
                           const uint32_t* cnt, int k, float* centroids, hipStream_t stream);
 // list relocation: job j moves rows[j] rows of bytes_per_row bytes from row src[j] to row dst[j] (regions never

@@ -246,3 +246,30 @@ def test_concurrent_searches_on_one_index_equal_serial(res, kind):
         t.join()
     for i in range(4):
         assert np.array_equal(got[i][0], want[i][0]) and np.array_equal(got[i][1], want[i][1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,M,nt,tight", [(128, 64, 70000, False), (32, 8, 3000, False), (64, 4, 2500, True), (24, 24, 1200, False)])
+def test_pq_training_as_one_kmeans_equals_the_per_subspace_loop(res, d, M, nt, tight, monkeypatch):
+    """The M sub-quantizers trained as ONE k-means over M * nt points (labels m * 256 + c, one counting sort and one
+    update launch per iteration) against one Clustering per sub-space (faiss/impl/ProductQuantizer.cpp:140-190, the
+    round-2 loop): the same codebook bit for bit.  (128, 64, 70000): the bench shape, training set sub-sampled to 65536;
+    (64, 4, 2500, tight): 2500 points in a few tight blobs for 256 centroids leave empty clusters -- the refill of the
+    sub-space's own generator; (24, 24): dsub = 1."""
+    from faiss_amd.datasets import synthetic_dataset
+    if tight:
+        rs = np.random.RandomState(3)
+        xt = (rs.randint(0, 6, size=(nt, 1)) * 5 + rs.rand(nt, d) * 0.01).astype(np.float32)
+    else:
+        xt, _, _ = synthetic_dataset(d, nt, 0, 0, seed=d + M)
+    nlist = 16
+    cent = xt[:: nt // nlist][:nlist].copy()
+    books = []
+    for loop in ("1", "0"):
+        monkeypatch.setenv("FAISS_AMD_PQ_TRAIN_LOOP", loop)
+        idx = faiss_amd.GpuIndexIVFPQ(res, d, nlist, M, 8, faiss_amd.METRIC_L2)
+        idx.train(xt)
+        books.append((idx.get_centroids(), idx.get_pq_centroids()))
+    assert np.array_equal(books[0][0], books[1][0])
+    assert np.array_equal(books[0][1], books[1][1]), "batched product-quantizer training differs from the per-sub-space loop"
+    assert np.isfinite(books[1][1]).all()
