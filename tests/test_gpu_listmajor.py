@@ -38,6 +38,8 @@ def _build(res, kind, metric, d, M, nlist, xt, xb, seed=7):
     (0, METRIC_INNER_PRODUCT, 64, 0, 32, 5000, 130, 5, 2048),   # k above the rows many queries see
     (0, METRIC_L2, 64, 0, 8, 90000, 600, 3, 50),                # lists of ~11 000 rows: row chunks of 2816 rows
     (1, METRIC_L2, 64, 32, 8, 90000, 600, 3, 50),               # the same for codes
+    (0, METRIC_L2, 32, 0, 128, 20000, 600, 100, 10),            # more than 64 probes: two rounds of the plan's scans
+    (1, METRIC_INNER_PRODUCT, 32, 16, 128, 20000, 600, 100, 10),
     (1, METRIC_L2, 128, 64, 64, 40000, 1500, 8, 100),           # bench shape: M = 64, dsub = 2
     (1, METRIC_INNER_PRODUCT, 128, 64, 64, 40000, 1100, 8, 10),
     (1, METRIC_L2, 64, 16, 32, 30000, 400, 32, 600),            # dsub = 4, every list probed
