@@ -2285,12 +2285,12 @@ void GpuIndexIVF::search_listmajor_(int ni, const float* xq_pad, const idx_t* c_
     for (int c0 = 0; c0 < ni; c0 += (int)std::min<int64_t>(fit, ni)) {
         const int cn = (int)std::min<int64_t>(fit, ni - c0);
         search_listmajor_chunk_(cn, xq_pad + (size_t)c0 * dpad_, c_ids + (size_t)c0 * np, c_dis + (size_t)c0 * np, np, k,
-                                dD + (size_t)c0 * k, dI + (size_t)c0 * k, level, stride, min_p1, RT);
+                                dD + (size_t)c0 * k, dI + (size_t)c0 * k, level, stride, min_p1, RT, c1max);
     }
 }
 
 void GpuIndexIVF::search_listmajor_chunk_(int ni, const float* xq_pad, const idx_t* c_ids, const float* c_dis, int np, int k,
-                                          float* dD, idx_t* dI, int level, int64_t stride, int min_p1, int RT) const {
+                                          float* dD, idx_t* dI, int level, int64_t stride, int min_p1, int RT, int64_t c1max) const {
     const GpuResources& R = *res_;
     const bool force_all = level >= 2;
     // upper bound of the work items: sum over (pass, list) of ceil(pairs / 128) * ceil(len / RT)
@@ -2386,6 +2386,7 @@ void GpuIndexIVF::search_listmajor_chunk_(int ni, const float* xq_pad, const idx
             sp.mode = 0;
             sp.kth_out = P.thr;
             sp.cnt_out = P.cnt;
+            sp.max_cnt = c1max; // rows of pass 1: few enough for the wavefront-per-query kernel unless lists are long
             launch_select_k(sp, R.stream);
             sp.kth_out = nullptr;
             sp.cnt_out = nullptr;
@@ -2398,6 +2399,7 @@ void GpuIndexIVF::search_listmajor_chunk_(int ni, const float* xq_pad, const idx
         launch_ivf_lm_clamp(P, R.stream);
     }
     sp.mode = 1;
+    sp.max_cnt = stride;
     sp.nprobe = np;
     sp.ivf_prefix = P.prefix;
     sp.coarse_ids = c_ids;

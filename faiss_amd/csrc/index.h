@@ -440,7 +440,7 @@ class GpuIndexIVF : public Index {
     void search_listmajor_(int ni, const float* xq_pad, const idx_t* c_ids, const float* c_dis, int np, int k, float* dD,
                            idx_t* dI, int level) const;
     void search_listmajor_chunk_(int ni, const float* xq_pad, const idx_t* c_ids, const float* c_dis, int np, int k,
-                                 float* dD, idx_t* dI, int level, int64_t stride, int min_p1, int RT) const;
+                                 float* dD, idx_t* dI, int level, int64_t stride, int min_p1, int RT, int64_t c1max) const;
     void upload_list_tables_();
     void ensure_arena_(int64_t rows);
     // make room for new_len[l] entries in every list (relocating the lists that outgrow their slack); est[l]

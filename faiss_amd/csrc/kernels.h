@@ -236,6 +236,9 @@ struct SelectParams {
     // with kth_out (nseg == 1): the segment is also cut back to its keys <= the k-th (they move to its front) and
     // cnt_out[q] = their number
     uint32_t* cnt_out; // [nq] or null
+    // upper bound of seg_cnt known to the caller (0 = unknown).  nseg == 1, k <= 256 and max_cnt <= 4096 (bound) /
+    // 8192 (selection) take the wavefront-per-query kernel (select_kernels.hip: keys in registers, bisection)
+    int64_t max_cnt;
 };
 // Exact k-selection: MSB radix select on 64-bit keys + bitonic sort of the k winners by
 // (distance, label).  Replaces faiss/gpu/utils/BlockSelectKernel.cuh:15-132 and the

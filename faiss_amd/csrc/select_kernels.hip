@@ -21,6 +21,7 @@ constexpr int SEL_THREADS = 256;
 struct SelShared {
     unsigned hist[256];
     unsigned scan[256];
+    unsigned wsum[4];
     u64 prefix;
     u64 mask;
     u64 kth;
@@ -81,15 +82,22 @@ __global__ void __launch_bounds__(SEL_THREADS) select_k_kernel(SelectParams p) {
                 if ((key & mask) == prefix) atomicAdd(&sh->hist[(unsigned)(key >> shift) & 255u], 1u);
             });
             __syncthreads();
-            // inclusive scan of 256 bins (Hillis-Steele in LDS)
-            unsigned v = sh->hist[tid];
-            sh->scan[tid] = v;
-            __syncthreads();
-            for (int off = 1; off < 256; off <<= 1) {
-                unsigned o = tid >= off ? sh->scan[tid - off] : 0;
+            // inclusive scan of the 256 bins: inside each wavefront by shuffles, then the three wavefront totals before
+            // it (one barrier; the Hillis-Steele ladder in LDS it replaces took 16 per radix pass -- most of the kernel's
+            // time on the ~2000-key segments of the list-major IVF scan)
+            const unsigned v = sh->hist[tid];
+            {
+                unsigned inc = v;
+                const int ln = tid & 63;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const unsigned o = __shfl_up(inc, off, 64);
+                    if (ln >= off) inc += o;
+                }
+                if (ln == 63) sh->wsum[tid >> 6] = inc;
                 __syncthreads();
-                sh->scan[tid] += o;
-                __syncthreads();
+                for (int w = 0; w < (tid >> 6); ++w) inc += sh->wsum[w];
+                sh->scan[tid] = inc;
             }
             const unsigned incl = sh->scan[tid];
             const unsigned excl = incl - v;
@@ -219,6 +227,268 @@ __global__ void __launch_bounds__(SEL_THREADS) select_k_kernel(SelectParams p) {
         p.out_dis[(int64_t)q * p.k + i] = dis;
         p.out_ids[(int64_t)q * p.k + i] = id;
     }
+}
+
+// ---------------------------------------------------------------------------------
+// One WAVEFRONT per query (round 3): the bound and the final selection of the list-major IVF scan choose k of a few
+// thousand keys per query, 10 000 times per search; the workgroup-per-query radix select above spends its time in
+// barriers and in LDS atomics that pile onto one histogram bin (the keys of a query share their leading bytes).  Here
+// a query's keys sit in the registers of one wavefront (64 per lane); the k-th smallest distance is found by bisection
+// on the 32-bit ordkey between the segment's minimum and maximum -- a compare-and-count sweep over the registers and a
+// wave reduction per step, no barrier, no atomic -- ties at that distance are resolved by a second bisection on the
+// scan position (the key's lower half; positions are unique), which yields EXACTLY the k smallest 64-bit keys, the set
+// select_k_kernel selects.  Bound mode (kth_out / cnt_out): the segment is cut back to those k keys.  Selection mode
+// (mode 1): winners -> labels -> bitonic sort by (distance, label) in a per-wave LDS slice -> best first.
+// A query with more keys than the registers hold streams them from memory in every step (rare by construction).
+// ---------------------------------------------------------------------------------
+constexpr int WS_KPL = 64; // keys per lane held in registers
+__device__ __forceinline__ unsigned ws_sum(unsigned v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ unsigned ws_min(unsigned v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = min(v, (unsigned)__shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ unsigned ws_max(unsigned v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = max(v, (unsigned)__shfl_xor(v, off, 64));
+    return v;
+}
+
+template <bool BOUND>
+__global__ void __launch_bounds__(256) wave_select_kernel(SelectParams p, int kp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + wave;
+    if (q >= p.nq) return; // (no barrier below: wavefronts are independent)
+    const unsigned n = p.seg_cnt[q];
+    u64* seg = const_cast<u64*>(p.keys) + (p.q_off ? p.q_off[q] : (int64_t)q * p.q_stride);
+    const unsigned k = (unsigned)p.k;
+    const bool resident = n <= 64u * WS_KPL;
+    const int nrow8 = (int)((n + 511u) >> 9); // groups of 8 register slots (512 keys) that hold keys
+    // slot i of lane l = key l + 64 i; slots past the end hold ~0 (hi = lo = 0xffffffff: no real key, positions stay below)
+    unsigned hi[WS_KPL], lo[WS_KPL];
+    if (resident) {
+#pragma unroll
+        for (int i = 0; i < WS_KPL; ++i) {
+            const unsigned idx = (unsigned)lane + 64u * i;
+            const u64 key = idx < n ? seg[idx] : ~0ull;
+            hi[i] = (unsigned)(key >> 32);
+            lo[i] = (unsigned)key;
+        }
+    }
+    // f(hi, lo) over this lane's keys (exact: slots past the end are skipped)
+    auto for_keys = [&](auto f) __attribute__((always_inline)) {
+        if (resident) {
+#pragma unroll
+            for (int i = 0; i < WS_KPL; ++i)
+                if ((unsigned)lane + 64u * i < n) f(hi[i], lo[i]);
+        } else {
+            for (unsigned idx = lane; idx < n; idx += 64) {
+                const u64 key = seg[idx];
+                f((unsigned)(key >> 32), (unsigned)key);
+            }
+        }
+    };
+    // wave-wide count of the keys with pred(hi, lo), for predicates that are false on the ~0 filler: one compare per
+    // slot into a lane mask, counted on the scalar unit -- no cross-lane traffic
+    auto count = [&](auto pred) __attribute__((always_inline)) -> unsigned {
+        unsigned c = 0;
+        if (resident) {
+#pragma unroll
+            for (int g = 0; g < WS_KPL / 8; ++g) {
+                if (g < nrow8) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) c += (unsigned)__builtin_popcountll(__ballot(pred(hi[8 * g + e], lo[8 * g + e])));
+                }
+            }
+        } else {
+            for (unsigned base = 0; base < n; base += 64) {
+                const unsigned idx = base + lane;
+                const u64 key = idx < n ? seg[idx] : ~0ull;
+                c += (unsigned)__builtin_popcountll(__ballot(pred((unsigned)(key >> 32), (unsigned)key)));
+            }
+        }
+        return c;
+    };
+    unsigned T = 0xffffffffu, P = 0xffffffffu; // winners: hi < T, or hi == T and lo <= P
+    if (n > k) {
+        unsigned mn = 0xffffffffu, mx = 0u;
+        for_keys([&](unsigned h, unsigned) {
+            mn = min(mn, h);
+            mx = max(mx, h);
+        });
+        unsigned lo_b = ws_min(mn), hi_b = ws_max(mx);
+        while (lo_b < hi_b) { // smallest T with #(hi <= T) >= k; mid < hi_b <= 0xffffffff: the filler never counts
+            const unsigned mid = lo_b + ((hi_b - lo_b) >> 1);
+            if (count([&](unsigned h, unsigned) { return h <= mid; }) >= k) hi_b = mid;
+            else lo_b = mid + 1;
+        }
+        T = lo_b;
+        unsigned cl = 0, ct = 0;
+        for_keys([&](unsigned h, unsigned) {
+            cl += h < T ? 1u : 0u;
+            ct += h == T ? 1u : 0u;
+        });
+        cl = ws_sum(cl);
+        ct = ws_sum(ct);
+        const unsigned need = k - cl; // 1 <= need <= ct
+        if (need < ct) {
+            unsigned pl = 0u, ph = 0xffffffffu; // smallest P with #(hi == T, lo <= P) >= need (mid < 0xffffffff)
+            while (pl < ph) {
+                const unsigned mid = pl + ((ph - pl) >> 1);
+                if (count([&](unsigned h, unsigned l) { return h == T && l <= mid; }) >= need) ph = mid;
+                else pl = mid + 1;
+            }
+            P = pl;
+        }
+    }
+    auto wins = [&](unsigned h, unsigned l) { return h < T || (h == T && l <= P); };
+    // slots of this lane's winners: exclusive scan of the per-lane counts
+    unsigned mine = 0;
+    for_keys([&](unsigned h, unsigned l) { mine += wins(h, l) ? 1u : 0u; });
+    unsigned inc = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned o = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += o;
+    }
+    unsigned at = inc - mine;
+    const unsigned nwin = (unsigned)__shfl(inc, 63, 64); // = min(n, k)
+
+    if (BOUND) {
+        // kth_out = the bound (with no more than k keys every distance qualifies: 0xffffffff); the segment keeps the k keys.
+        // They pass through this wave's LDS slice: every key has been read before the first one is overwritten, also
+        // when the keys are streamed from memory.
+        if (lane == 0) p.kth_out[q] = n > k ? T : 0xffffffffu;
+        if (p.cnt_out && n > k) {
+            u64* keep = (u64*)smem + (size_t)wave * kp;
+            for_keys([&](unsigned h, unsigned l) {
+                if (wins(h, l)) keep[at++] = ((u64)h << 32) | l;
+            });
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            for (unsigned t = lane; t < nwin; t += 64) seg[t] = keep[t];
+            if (lane == 0) p.cnt_out[q] = nwin;
+        }
+        return;
+    }
+
+    // ---- winners -> this wave's LDS slice (ordkey, payload), then payload -> label one winner per lane
+    int64_t* w_id = (int64_t*)smem + (size_t)wave * kp;
+    unsigned* w_key = (unsigned*)(smem + (size_t)4 * kp * 8) + (size_t)wave * kp;
+    for (int i = lane; i < kp; i += 64) {
+        w_key[i] = 0xffffffffu;
+        w_id[i] = INT64_MAX;
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    for_keys([&](unsigned h, unsigned l) {
+        if (wins(h, l)) {
+            w_key[at] = h;
+            w_id[at] = (int64_t)l;
+            ++at;
+        }
+    });
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    {
+        const uint32_t* pre = p.mode == 1 ? p.ivf_prefix + (int64_t)q * (p.nprobe + 1) : nullptr;
+        // up to 63 probes: lane pr keeps pre[pr] and the arena row of the first entry of probe pr's list; the binary search
+        // of a winner then reads other lanes' registers instead of walking memory (five dependent loads per winner)
+        const bool in_regs = p.mode == 1 && p.nprobe < 64;
+        uint32_t pre_l = 0xffffffffu;
+        int64_t base_l = 0;
+        if (in_regs) {
+            if (lane <= p.nprobe) pre_l = pre[lane];
+            if (lane < p.nprobe) {
+                const int64_t list = p.coarse_ids[(int64_t)q * p.nprobe + lane];
+                base_l = list >= 0 ? p.list_start[list] : 0;
+            }
+        }
+        for (unsigned t0 = 0; t0 < nwin; t0 += 64) { // (uniform trip count: the shuffles below need every lane)
+            const unsigned t = t0 + lane;
+            const bool live = t < nwin;
+            const uint32_t l = live ? (uint32_t)w_id[t] : 0u;
+            int64_t label = -1;
+            if (p.mode == 0) {
+                label = (int64_t)l + p.id_base;
+            } else if (in_regs) {
+                int a = 0, b = p.nprobe; // invariant pre[a] <= payload < pre[b]
+                for (int step = 0; step < 6; ++step) { // 2^6 >= 64 probes
+                    const int mid = (a + b) >> 1;
+                    const uint32_t pm = (uint32_t)__shfl((int)pre_l, mid, 64);
+                    if (b - a > 1) {
+                        if (pm <= l) a = mid;
+                        else b = mid;
+                    }
+                }
+                const uint32_t pa = (uint32_t)__shfl((int)pre_l, a, 64);
+                const int64_t base = ((int64_t)__shfl((int)(base_l >> 32), a, 64) << 32) | (uint32_t)__shfl((int)base_l, a, 64);
+                if (live) label = p.arena_ids[base + (l - pa)];
+            } else if (live) {
+                // binary search: largest pr with pre[pr] <= payload
+                int a = 0, b = p.nprobe; // invariant pre[a] <= payload < pre[b]
+                while (b - a > 1) {
+                    const int mid = (a + b) >> 1;
+                    if (pre[mid] <= l) a = mid;
+                    else b = mid;
+                }
+                const int64_t list = p.coarse_ids[(int64_t)q * p.nprobe + a];
+                label = p.arena_ids[p.list_start[list] + (l - pre[a])];
+            }
+            if (live) w_id[t] = label;
+        }
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    // ---- bitonic sort of kp entries by (ordkey, label) ascending, inside the wavefront
+    for (int size = 2; size <= kp; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = lane; t < (kp >> 1); t += 64) {
+                const int a = 2 * t - (t & (stride - 1));
+                const int b = a + stride;
+                const bool up = ((a & size) == 0);
+                const unsigned ka = w_key[a], kb = w_key[b];
+                const int64_t ia = w_id[a], ib = w_id[b];
+                const bool a_gt_b = (ka > kb) || (ka == kb && ia > ib);
+                if (a_gt_b == up) {
+                    w_key[a] = kb;
+                    w_key[b] = ka;
+                    w_id[a] = ib;
+                    w_id[b] = ia;
+                }
+            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    const float pad = neutral_distance(p.metric);
+    for (int i = lane; i < p.k; i += 64) {
+        float dis;
+        int64_t id;
+        if (i < (int)nwin && w_key[i] < kInvalidOrdKey) {
+            dis = unordkey_rt(p.metric, w_key[i]);
+            id = w_id[i];
+        } else {
+            dis = pad;
+            id = -1;
+        }
+        p.out_dis[(int64_t)q * p.k + i] = dis;
+        p.out_ids[(int64_t)q * p.k + i] = id;
+    }
+}
+static bool wave_select_serves(const SelectParams& p) {
+    static const char* e = getenv("FAISS_AMD_WAVE_SELECT"); // timing experiments: 0 = the radix kernel everywhere
+    if (e && atoi(e) == 0) return false;
+    if (p.nseg != 1 || p.k > 256 || p.max_cnt <= 0) return false;
+    // (segments longer than the 4096 keys the registers hold are streamed from memory in every bisection step: fine for
+    // the odd query, not for a launch made of them)
+    return (p.kth_out || p.mode == 0 || p.mode == 1) && p.max_cnt <= 2 * 64 * WS_KPL;
 }
 
 __global__ void pack_merge_keys_kernel(int metric, const float* __restrict__ all_d,
@@ -370,6 +640,13 @@ void launch_select_k(const SelectParams& p, hipStream_t stream) {
     FA_THROW_IF_NOT(p.k >= 1 && p.k <= kMaxSelectionK);
     int kp = 1;
     while (kp < p.k) kp <<= 1;
+    if (wave_select_serves(p)) {
+        const dim3 grid((unsigned)div_up(p.nq, 4));
+        if (p.kth_out) hipLaunchKernelGGL((wave_select_kernel<true>), grid, dim3(256), (size_t)4 * kp * 8, stream, p, kp);
+        else hipLaunchKernelGGL((wave_select_kernel<false>), grid, dim3(256), (size_t)4 * kp * 12, stream, p, kp);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     size_t lds = ((sizeof(SelShared) + 15) & ~(size_t)15) + (size_t)kp * (8 + 4);
     hipLaunchKernelGGL(select_k_kernel, dim3((unsigned)p.nq), dim3(SEL_THREADS), lds, stream, p);
     HIP_CHECK(hipGetLastError());

@@ -224,3 +224,28 @@ def test_list_major_after_incremental_adds_and_copied_lists(res, kind):
     freed = idx.reclaimMemory()  # compaction moves every list
     D3, I3 = idx.search(xq, k)
     assert freed >= 0 and np.array_equal(D, D3) and np.array_equal(I, I3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [1, 50, 256, 300])
+def test_list_major_many_equal_distances(res, k):
+    """Integer-valued vectors: thousands of rows at exactly the same distance from a query.  The bound and the final
+    selection must pick the k smallest (distance, scan position) keys and order them by (distance, label) -- the
+    wavefront-per-query kernel resolves the ties at the k-th distance by a second bisection on the position (k <= 256), the
+    radix kernel serves k = 300; both against the oracle bit for bit."""
+    d, nlist, nb, nq, nprobe = 16, 16, 30000, 500, 5
+    rs = np.random.RandomState(k)
+    xb = rs.randint(0, 3, size=(nb, d)).astype("float32")
+    xq = rs.randint(0, 3, size=(nq, d)).astype("float32")
+    cent = rs.rand(nlist, d).astype("float32") * 2
+    idx = faiss_amd.GpuIndexIVFFlat(res, d, nlist, METRIC_L2)
+    idx.copy_centroids(cent)
+    idx.add(xb)
+    idx.nprobe = nprobe
+    idx.set_scan_mode(idx.SCAN_LIST_MAJOR)
+    D, I = idx.search(xq, k)
+    assert idx.scan_info()[1] == 2
+    sizes, codes, ids, _ = Oracle.build_ivf_lists(0, METRIC_L2, cent, xb)
+    Do, Io, _, _ = Oracle.ivf_search(0, METRIC_L2, cent, sizes, codes, ids, xq, nprobe, k, arith=1)
+    check_knn(D, I, Do, Io, exact=True, name="tie-heavy list-major")
+    assert len(np.unique(D[0])) < max(2, k // 2) or k == 1  # the data really ties
