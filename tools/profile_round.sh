@@ -3,7 +3,7 @@
 #   kernel trace + stats of the default bench.py command (scale leg ivfflat_10m included), and one --pmc pass per counter
 #   group on the search loops of the bench legs (counter passes carry --kernel-trace only, never runtime / sys tracing):
 #   flat, IVFPQ nb=1M (query-major), IVFFlat nb=1M (list-major), IVFFlat nb=10M and IVFPQ nb=10M (list-major).
-TAG=${1:-r03_d}
+TAG=${1:-r03_f}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
