@@ -282,7 +282,9 @@ def ivf_roofline(spans, list_major, kind, nb, row_bytes, profile=None):
     flops = 2.0 * NQ * NPROBE * (nb / float(NLIST)) * D
     ach = flops / (scan_ms * 1e-3) / 1e12
     unique = nb * float(row_bytes) + NQ * D * 4.0
-    kernels = ("ivf_lm_scan_kernel (pass 1) + ivf_lm_flat_reg_kernel (pass 2)" if kind == "ivfflat" else "ivf_lm_pq_kernel (pass 1 + pass 2)")
+    kernels = ("ivf_lm_scan_kernel (pass 1) + ivf_lm_flat_reg_kernel (pass 2)" if kind == "ivfflat"
+               else "ivf_lm_scan_kernel<kind 2> (pass 1) + ivf_lm_flat_reg_kernel<8-bit codes> (pass 2)" if kind == "ivfsq"
+               else "ivf_lm_pq_kernel (pass 1 + pass 2)")
     return {"bound": "mfma", "kernel": kernels + ": the scan launches of one search",
             "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
             "avg_kernel_ms": round(scan_ms, 3), "launches": int(n1 + n2),

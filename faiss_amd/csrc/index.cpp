@@ -1987,7 +1987,8 @@ void GpuIndexIVF::search_core_(idx_t n, const float* x, idx_t k, float* distance
     // which scan serves this call: decided once, on the whole batch, so that the pages / tiles of one call agree
     FA_THROW_IF_NOT_MSG(scan_mode >= 0 && scan_mode <= 2, "scan_mode must be 0 (auto), 1 (query-major) or 2 (list-major)");
     if (scan_mode == 2) {
-        FA_THROW_IF_NOT_MSG(lm_capable_(), "list-major scan: index type / dimension not supported (IVFFlat, IVFPQ; d <= 128)");
+        FA_THROW_IF_NOT_MSG(lm_capable_(), "list-major scan: index type / dimension not supported (IVFFlat, IVFPQ, scalar "
+                            "quantizer with 8-bit / 4-bit / fp16 codes; d <= 128)");
         FA_THROW_IF_NOT_MSG(!sel, "list-major scan: IDSelector searches take the query-major scan");
         cur_lm_ = true;
     } else {
@@ -2246,7 +2247,6 @@ bool GpuIndexIVF::list_major_rule(idx_t n, int nprobe_now, idx_t k, bool has_sel
     if (fused_kind_() == 1 &&
         !(lm_pq_lds_capable_() && (double)n * (double)np * (double)nstored_ >= 50000.0 * (double)nlist * (double)nlist))
         return false;
-    if (fused_kind_() > 1) return false;
     return n >= 2048 && (int64_t)n * np >= (int64_t)8 * nlist && k <= kMaxSelectionK;
 }
 
@@ -2469,6 +2469,11 @@ GpuIndexIVFScalarQuantizer::GpuIndexIVFScalarQuantizer(std::shared_ptr<GpuResour
     FA_THROW_IF_NOT_MSG(dims <= 1024, "scalar-quantizer index: d <= 1024");
     code_bytes_ = (size_t)(dsq_ / 16) * sq_chunk_bytes(ct_); // arena row: whole 16-component chunks, zero padded
     granule_ = 64;                                           // 64-row chunk-major blocks (kernels.h sq_code_offset)
+    // |s o code|^2 per stored row: the second L2 term of the list-major scan
+    use_rn_ = metric == METRIC_L2 && ivf_lm_supported(2, dpad_, ct_, dims);
+    res_->set_device();
+    sq_zero_.ensure((size_t)dsq_ * 4);
+    HIP_CHECK(hipMemset(sq_zero_.p, 0, (size_t)dsq_ * 4));
     upload_tables_();
 }
 
@@ -2487,8 +2492,10 @@ void GpuIndexIVFScalarQuantizer::upload_tables_() {
             s[i] = vdiff[i] / levels_;
             b[i] = vmin[i] + 0.5f * s[i];
         }
-    } else if (qtype == QT_8bit_direct) {
-        for (int i = 0; i < d; i++) s[i] = 1.f; // the code is the value
+    } else if (qtype == QT_8bit_direct || qtype == QT_fp16) {
+        // the code is the value (the query-major kernel never reads the tables of fp16 codes; the list-major one folds
+        // s and b into its query operands whatever the type: a * 1 == a, fmaf(q, 0, acc) == acc)
+        for (int i = 0; i < d; i++) s[i] = 1.f;
     }
     vmin_.ensure((size_t)d * 4);
     vdiff_.ensure((size_t)d * 4);
@@ -2498,6 +2505,43 @@ void GpuIndexIVFScalarQuantizer::upload_tables_() {
     HIP_CHECK(hipMemcpy(vdiff_.p, vdiff.data(), (size_t)d * 4, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(sq_s_.p, s.data(), (size_t)dsq_ * 4, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(sq_b_.p, b.data(), (size_t)dsq_ * 4, hipMemcpyHostToDevice));
+    // list-major scan: offsets of the CENTRED codes, b' = fmaf(mid, s, b) (kernels.h IvfLmParams)
+    {
+        const float mid = ct_ == SQ_U8 ? 127.5f : ct_ == SQ_U4 ? 7.5f : 0.f;
+        std::vector<float> bm(dsq_, 0.f);
+        for (int i = 0; i < d; i++) bm[i] = std::fmaf(mid, s[i], b[i]);
+        sq_bm_.ensure((size_t)dsq_ * 4);
+        HIP_CHECK(hipMemcpy(sq_bm_.p, bm.data(), (size_t)dsq_ * 4, hipMemcpyHostToDevice));
+    }
+    // the scale changed under rows that are already stored (set_trained after copy_lists): their norms follow
+    if (use_rn_ && nstored_ > 0 && arena_.p) row_norms_all_();
+}
+void GpuIndexIVFScalarQuantizer::row_norms_all_() {
+    if (!use_rn_ || arena_rows_ == 0) return;
+    launch_ivfsq_row_norms(arena_.as<uint8_t>(), ct_, (int)code_bytes_, d, sq_s_.as<float>(), nullptr, 0, arena_rows_,
+                           arena_rn_.as<float>(), res_->stream);
+    res_->sync();
+}
+void GpuIndexIVFScalarQuantizer::lists_changed_() {
+    // bulk load (copy_lists / compaction into a new arena): norms of every arena row (the slack holds whatever it holds)
+    row_norms_all_();
+}
+bool GpuIndexIVFScalarQuantizer::lm_capable_() const {
+    return ivf_lm_supported(2, dpad_, ct_, d);
+}
+void GpuIndexIVFScalarQuantizer::fill_lm_(IvfLmParams& p) const {
+    p.kind = 2;
+    p.arena_codes = arena_.as<uint8_t>();
+    p.arena_rn = arena_rn_.as<float>();
+    p.M = ct_; // (ivf_lm_supported's third argument for this kind)
+    p.centroids = quantizer->device_vectors();
+    p.ldc = dpad_;
+    p.sq_ct = ct_;
+    p.sq_ld = (int)code_bytes_;
+    p.sq_by_residual = by_residual ? 1 : 0;
+    p.sq_s = sq_s_.as<float>();
+    p.sq_b = sq_bm_.as<float>();
+    p.sq_zero = sq_zero_.as<float>();
 }
 void GpuIndexIVFScalarQuantizer::set_trained(const float* t, size_t n) {
     FA_THROW_IF_NOT_MSG(needs_training_(), "this scalar quantizer type has no trained range");
@@ -2583,6 +2627,9 @@ void GpuIndexIVFScalarQuantizer::train_residual_(idx_t n, const float* x_dev_pad
 void GpuIndexIVFScalarQuantizer::append_(int n, const float* x_pad, const int64_t* d_labels, const int64_t* d_dest) {
     launch_ivfsq_encode_append(qtype, x_pad, dpad_, n, d, d_labels, d_dest, quantizer->device_vectors(), dpad_, by_residual,
                                vmin_.as<float>(), vdiff_.as<float>(), arena_.as<uint8_t>(), (int)code_bytes_, res_->stream);
+    if (use_rn_)
+        launch_ivfsq_row_norms(arena_.as<uint8_t>(), ct_, (int)code_bytes_, d, sq_s_.as<float>(), d_dest, 0, n,
+                               arena_rn_.as<float>(), res_->stream);
 }
 void GpuIndexIVFScalarQuantizer::fill_fused_(IvfFusedParams& p) const {
     p.arena_codes = arena_.as<uint8_t>();

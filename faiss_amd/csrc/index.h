@@ -559,6 +559,10 @@ class GpuIndexIVFScalarQuantizer : public GpuIndexIVF {
     void train_residual_(idx_t n, const float* x_dev_pad) override;
     void append_(int n, const float* x_pad, const int64_t* d_labels, const int64_t* d_dest) override;
     void scan_(int nq, const float* xq_pad, int k, const int64_t* h_qoff) const override;
+    // list-major scan (ivf_listmajor.hip, kind 2): 8-bit, 4-bit and fp16 codes, d <= 128
+    void lists_changed_() override;
+    bool lm_capable_() const override;
+    void fill_lm_(struct IvfLmParams& p) const override;
 
    private:
     int dsq_;      // d rounded up to 16
@@ -567,7 +571,10 @@ class GpuIndexIVFScalarQuantizer : public GpuIndexIVF {
     bool needs_training_() const { return levels_ > 0.f; }
     DevBuf vmin_, vdiff_; // [d] (uniform types: replicated) -- the encoder's view of `trained`
     DevBuf sq_s_, sq_b_;  // [dsq_] scale / offset per dimension of the decoder: x^ = fmaf(code, s, b)
+    DevBuf sq_bm_;        // [dsq_] list-major scan: offset of the centred codes, fmaf(mid, s, b)
+    DevBuf sq_zero_;      // [dsq_] zeros (list-major scan: the centroid of a search without residual encoding)
     void upload_tables_();
+    void row_norms_all_(); // arena_rn_ = |s o code|^2 of every arena row (list-major scan, L2)
 };
 
 // ------------------------------------------------------------------ IndexShards

@@ -107,7 +107,127 @@ bool ivf_lm_supported(int kind, int dpad, int M, int d) {
     if (dpad > 128 || (dpad & 7)) return false;
     if (kind == 0) return true;
     if (kind == 1) return M >= 1 && d % M == 0;
+    // scalar quantizer: the codes a lane's MFMA operand takes are whole bytes for 8-bit, 4-bit and fp16 codes (6-bit
+    // fields straddle them: that type keeps the query-major scan)
+    if (kind == 2) return M == SQ_U8 || M == SQ_U4 || M == SQ_F16;
     return false;
+}
+
+// ------------------------------------------------------------------ IVF scalar quantizer: decode helpers
+// bytes of one 16-component chunk
+template <int CT>
+struct LmSq {
+    static constexpr int CHB = CT == SQ_U8 ? 16 : CT == SQ_U4 ? 8 : 32;
+    static constexpr int PIECE = CHB / 4; // bytes of the 4 components 8 s + 4 h + e of a lane's MFMA operand group
+};
+// component e (0..3) of a 4-component piece (8-bit: a dword; 4-bit: 16 bits; fp16: two dwords) as the matrix pipe sees it:
+// integer codes CENTRED on the middle of their range (code - 127.5 / code - 7.5, exact in fp32; the offset b the query
+// operand carries is moved by the same amount, kernels.h IvfLmParams::sq_b).  Uncentred, |a|^2 and |s o code|^2 are
+// ~10 x the distance they cancel to (both vectors sit half a range away from the origin) and the rounding of the three
+// terms shows at 4e-5 of the distances at the bench shape; centred it is the rounding of the distance itself.
+template <int CT>
+__device__ __forceinline__ float lm_sq_comp(const uint2 w, int e) {
+    if constexpr (CT == SQ_U8) {
+        return __fsub_rn((float)((w.x >> (8 * e)) & 255u), 127.5f);
+    } else if constexpr (CT == SQ_U4) {
+        return __fsub_rn((float)((w.x >> (4 * e)) & 15u), 7.5f);
+    } else {
+        const unsigned v = e < 2 ? w.x : w.y;
+        return (float)__builtin_bit_cast(_Float16, (unsigned short)(v >> (16 * (e & 1))));
+    }
+}
+template <int CT>
+__device__ __forceinline__ uint2 lm_sq_load_piece(const uint8_t* ptr) {
+    if constexpr (CT == SQ_U8) {
+        return uint2{*(const unsigned*)ptr, 0u};
+    } else if constexpr (CT == SQ_U4) {
+        return uint2{(unsigned)*(const unsigned short*)ptr, 0u};
+    } else {
+        return *(const uint2*)ptr;
+    }
+}
+// The B operands of a (query, list) pair and the scalar that goes with them (kernels.h IvfLmParams, kind 2).  Lane (h, j)
+// owns the coordinates 8 s + 4 h + e of query j.  L2: bq = a o s with a = (q [- centroid]) - b, xn = |a|^2; inner product:
+// bq = q o s, xn = <q, b> + coarse.  |a|^2 and <q, b>: each lane of the pair (h = 0 / 1) runs a sequential fmaf chain over
+// its own coordinates, the two sums are added (oracle: orc_ivfsq_search, arith 1).
+template <int METRIC, bool FULL>
+__device__ __forceinline__ void lm_sq_query(const IvfLmParams& p, int ns, int h, const float* qrow, const float* cen,
+                                            float coarse, f32x4 (&bq)[16], float& xn) {
+    // branch-free: `cen` is the list's centroid or a row of zeros (no residual encoding: x - 0 == x), fp16 codes come
+    // with s = 1, b = 0 (a * 1 == a, fmaf(q, 0, acc) == acc)
+    float acc = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        // (four coordinate groups at a time: left alone hipcc hoists all 64 loads -- query, centroid, scale, offset --
+        // above the arithmetic and spills)
+        if ((s & 3) == 0 && s > 0) __builtin_amdgcn_sched_barrier(0);
+        if (FULL || s < ns) {
+            const f32x4 v = *(const f32x4*)(qrow + 8 * s + 4 * h);
+            const f32x4 s4 = *(const f32x4*)(p.sq_s + 8 * s + 4 * h);
+            const f32x4 b4 = *(const f32x4*)(p.sq_b + 8 * s + 4 * h);
+            if (METRIC == METRIC_L2) {
+                const f32x4 c4 = *(const f32x4*)(cen + 8 * s + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a = __fsub_rn(__fsub_rn(v[e], c4[e]), b4[e]);
+                    acc = __fmaf_rn(a, a, acc);
+                    bq[s][e] = __fmul_rn(a, s4[e]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc = __fmaf_rn(v[e], b4[e], acc);
+                    bq[s][e] = __fmul_rn(v[e], s4[e]);
+                }
+            }
+        } else {
+            bq[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const float both = acc + __shfl_xor(acc, 32, 64);
+    xn = METRIC == METRIC_L2 ? both : both + coarse;
+}
+
+// |s o code|^2 of arena rows (the list-major scan's second L2 term for the scalar quantizer)
+template <int CT>
+__global__ void ivfsq_row_norms_kernel(const uint8_t* __restrict__ arena, int ld, int d, const float* __restrict__ sq_s,
+                                       const int64_t* __restrict__ dest, int64_t row0, int64_t n, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t row = dest ? dest[i] : row0 + i;
+    if (row < 0) return;
+    constexpr int CHB = LmSq<CT>::CHB;
+    const uint8_t* rp = arena + (row >> 6) * 64 * (int64_t)ld + (row & 63) * CHB;
+    float acc = 0.f;
+    for (int c = 0; 16 * c < d; ++c) {
+        const uint8_t* ch = rp + (size_t)c * 64 * CHB;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const uint2 w = lm_sq_load_piece<CT>(ch + g * LmSq<CT>::PIECE);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = 16 * c + 4 * g + e;
+                if (j < d) {
+                    const float cf = lm_sq_comp<CT>(w, e);
+                    const float v = CT == SQ_F16 ? cf : __fmul_rn(sq_s[j], cf);
+                    acc = __fmaf_rn(v, v, acc);
+                }
+            }
+        }
+    }
+    out[row] = acc;
+}
+void launch_ivfsq_row_norms(const uint8_t* arena, int ct, int ld, int d, const float* sq_s, const int64_t* dest, int64_t row0,
+                            int64_t n, float* out, hipStream_t stream) {
+    if (n == 0) return;
+    const dim3 grid((unsigned)div_up(n, 256)), block(256);
+    switch (ct) {
+        case SQ_U8: hipLaunchKernelGGL(ivfsq_row_norms_kernel<SQ_U8>, grid, block, 0, stream, arena, ld, d, sq_s, dest, row0, n, out); break;
+        case SQ_U4: hipLaunchKernelGGL(ivfsq_row_norms_kernel<SQ_U4>, grid, block, 0, stream, arena, ld, d, sq_s, dest, row0, n, out); break;
+        case SQ_F16: hipLaunchKernelGGL(ivfsq_row_norms_kernel<SQ_F16>, grid, block, 0, stream, arena, ld, d, sq_s, dest, row0, n, out); break;
+        default: FA_THROW_MSG("list-major scan: scalar-quantizer code type without row norms");
+    }
+    HIP_CHECK(hipGetLastError());
 }
 
 // ------------------------------------------------------------------ plan
@@ -359,7 +479,7 @@ void launch_l2_norms_scatter(const float* x, int64_t ld, int64_t n, int d, const
 // ITS query -- threshold, scan position and segment are per-lane registers, nothing crosses lanes.
 // FULL: dpad == 128 (no bound checks in the k loop).
 template <int METRIC, int KIND, int PASS, bool FULL>
-__global__ void __launch_bounds__(LM_THREADS, KIND == 0 ? 2 : 3) ivf_lm_scan_kernel(IvfLmParams p) {
+__global__ void __launch_bounds__(LM_THREADS, KIND == 1 ? 3 : 2) ivf_lm_scan_kernel(IvfLmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -457,7 +577,12 @@ __global__ void __launch_bounds__(LM_THREADS, KIND == 0 ? 2 : 3) ivf_lm_scan_ker
             else bq[s] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         float xn = 0.f;
-        if (KIND == 1 && METRIC == METRIC_L2) {
+        if (KIND == 2) {
+            // scalar quantizer: B = a o s, xn = |a|^2 (L2) or <q, b> + coarse (inner product); see lm_sq_query
+            const float* cen = (METRIC == METRIC_L2 && p.sq_by_residual) ? p.centroids + (int64_t)list * p.ldc : p.sq_zero;
+            const float coarse = (METRIC != METRIC_L2 && p.sq_by_residual) ? p.coarse_dis[pi] : 0.f;
+            lm_sq_query<METRIC, FULL>(p, ns, h, qrow, cen, coarse, bq, xn);
+        } else if (KIND == 1 && METRIC == METRIC_L2) {
             // residual against the list's centroid; |q - c|^2 = the two interleaved half chains of the lane pair
             const float* cen = p.centroids + (int64_t)list * p.ldc;
             float acc = 0.f;
@@ -490,6 +615,33 @@ __global__ void __launch_bounds__(LM_THREADS, KIND == 0 ? 2 : 3) ivf_lm_scan_ker
             else thr_f = unordkey<METRIC>(tk);
         }
 
+        // scalar quantizer: this thread's share of a tile (two chunks of its row as 4-component pieces, and the row norm)
+        // is fetched into registers a tile ahead of its decode into LDS
+        uint2 sq_pf[2][4];
+        float sq_rn = 0.f;
+        auto sq_fetch = [&](int tt) __attribute__((always_inline)) {
+            if (p.dbg & 4) return;
+            const int l = tid & 63, qd = tid >> 6;
+            const int ct = p.sq_ct;
+            const int chb = sq_chunk_bytes(ct);
+            const uint8_t* blk = p.arena_codes + (size_t)((start + tt) >> 6) * 64 * p.sq_ld + (size_t)l * chb;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int c = qd + 4 * i;
+                if (16 * c < p.dpad) {
+                    const uint8_t* ch = blk + (size_t)c * 64 * chb;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        if (ct == SQ_U8) sq_pf[i][g] = lm_sq_load_piece<SQ_U8>(ch + 4 * g);
+                        else if (ct == SQ_U4) sq_pf[i][g] = lm_sq_load_piece<SQ_U4>(ch + 2 * g);
+                        else sq_pf[i][g] = lm_sq_load_piece<SQ_F16>(ch + 8 * g);
+                    }
+                }
+            }
+            sq_rn = 0.f;
+            if (METRIC == METRIC_L2 && tid < LM_TR && tt + tid < r1) sq_rn = p.arena_rn[start + tt + tid];
+        };
+        if (KIND == 2) sq_fetch(r0);
         int buf = 0;
         if (KIND == 0) {
             // every load of the item set-up has landed HERE, as far as the compiler's scoreboard goes (the values pass
@@ -518,6 +670,36 @@ __global__ void __launch_bounds__(LM_THREADS, KIND == 0 ? 2 : 3) ivf_lm_scan_ker
             // ---- tile [t, t + 64) of the list -> LDS: row r at r * 512, 16-byte chunk c at (c ^ (r & 15)) * 16
             if (p.dbg & 4) {
                 // (timing experiments: the tile is not loaded)
+            } else if (KIND == 2) {
+                // scalar quantizer: thread (row l, quarter) turns the 16-component chunks quarter, quarter + 4 of row l into
+                // floats -- the CODE values; scale and offset live in the query operands.  The chunk bytes were fetched
+                // into registers one tile ahead (sq_fetch below: the 64 threads of a quarter read one chunk of all rows of
+                // the chunk-major 64-row block in one coalesced sweep, kernels.h sq_code_offset)
+                const int l = tid & 63, qd = tid >> 6;
+                const int ct = p.sq_ct;
+                char* rowp = smem + l * LM_ROWB;
+                const int sw = l & 15;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int c = qd + 4 * i;
+                    if (16 * c < p.dpad) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            f32x4 v;
+                            if (ct == SQ_U8) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = lm_sq_comp<SQ_U8>(sq_pf[i][g], e);
+                            } else if (ct == SQ_U4) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = lm_sq_comp<SQ_U4>(sq_pf[i][g], e);
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = lm_sq_comp<SQ_F16>(sq_pf[i][g], e);
+                            }
+                            *(f32x4*)(rowp + (((4 * c + g) ^ sw) << 4)) = v;
+                        }
+                    }
+                }
             } else {
                 // IVFPQ: thread (row l, quarter) decodes sub-quantizers quarter, quarter + 4, ...: stored byte
                 // (m - l) mod M of row l (rotated block layout, kernels.h pq_code_offset) -> dsub floats of the codebook
@@ -540,12 +722,16 @@ __global__ void __launch_bounds__(LM_THREADS, KIND == 0 ? 2 : 3) ivf_lm_scan_ker
                 for (int col = p.d + qd; col < p.dpad; col += 4)
                     *(float*)(rowp + ((((col >> 2) ^ sw)) << 4) + ((col & 3) << 2)) = 0.f;
             }
-            if (tid < LM_TR) {
+            if (KIND == 2) {
+                if (tid < LM_TR) rnl[tid] = sq_rn;
+            } else if (tid < LM_TR) {
                 float v = 0.f;
                 if (METRIC == METRIC_L2 && t + tid < r1) v = p.arena_rn[start + t + tid];
                 rnl[tid] = v;
             }
             __syncthreads();
+            // scalar quantizer: the next tile's bytes on their way while this one is multiplied
+            if (KIND == 2 && t + LM_TR < r1) sq_fetch(t + LM_TR);
             }
 
             // (wave-uniform condition: a wave without queries, or whose block of the list's last tile is empty, only
@@ -695,7 +881,11 @@ constexpr int LR_THREADS = 256;
 constexpr int LR_PARK = 1280; // parked candidates per wave: a whole block (32 rows x 32 queries) always fits an empty slice
 constexpr int LR_LDS_TOTAL = 4 * LR_PARK * (8 + 4);
 
-template <int METRIC, bool FULL>
+// CT: -1 = IVFFlat (fp32 rows); a SqCodeType = IVF scalar quantizer: the register a[s] holds the 4 CODES of the lane's
+// operand group (a dword of 8-bit codes, 16 bits of 4-bit codes, two dwords of fp16), converted to floats right in front
+// of the MFMAs that read them; scale / offset / centroid are folded into the query operands (lm_sq_query).  Same item
+// walk, same refill schedule: the loads are 4 to 16 times narrower.
+template <int METRIC, bool FULL, int CT>
 __global__ void __launch_bounds__(LR_THREADS, 2) ivf_lm_flat_reg_kernel(IvfLmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -751,12 +941,19 @@ __global__ void __launch_bounds__(LR_THREADS, 2) ivf_lm_flat_reg_kernel(IvfLmPar
         const int pr = (int)(pi - (uint32_t)q * (uint32_t)np);
         const float* qrow = p.xq + (int64_t)q * p.ldq;
         f32x4 bq[16];
+        float xn = 0.f;
+        if constexpr (CT >= 0) {
+            const float* cen = (METRIC == METRIC_L2 && p.sq_by_residual) ? p.centroids + (int64_t)list * p.ldc : p.sq_zero;
+            const float coarse = (METRIC != METRIC_L2 && p.sq_by_residual) ? p.coarse_dis[pi] : 0.f;
+            lm_sq_query<METRIC, FULL>(p, ns, h, qrow, cen, coarse, bq, xn);
+        } else {
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            if (FULL || s < ns) bq[s] = *(const f32x4*)(qrow + 8 * s + 4 * h);
-            else bq[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < 16; ++s) {
+                if (FULL || s < ns) bq[s] = *(const f32x4*)(qrow + 8 * s + 4 * h);
+                else bq[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            xn = METRIC == METRIC_L2 ? p.xqn[q] : 0.f;
         }
-        const float xn = METRIC == METRIC_L2 ? p.xqn[q] : 0.f;
         const uint32_t base_pos = p.prefix[(int64_t)q * (np + 1) + pr];
         float thr_f;
         {
@@ -780,17 +977,48 @@ __global__ void __launch_bounds__(LR_THREADS, 2) ivf_lm_flat_reg_kernel(IvfLmPar
             // The loads are issued in the order the block loop re-issues them (a[0] .. a[15]; the empty asm statements keep
             // hipcc from reordering them): its wait for a[0] at the head of a block is then "all but the 15 youngest" on
             // every path into the loop -- with a[0] loaded last here it was vmcnt(0) for every block.
-            const float* arow = p.arena_vecs + (start + t + j) * p.ldv + 4 * h;
-            f32x4 a[16];
+            // (scalar quantizer: row j of block t is row ((start + t) & 63) + j of the 64-row code block (start + t) >> 6 --
+            // lists start on block boundaries, t is a multiple of 32 --; the piece of operand group s sits in chunk
+            // s >> 1 at byte ((s & 1) * 2 + h) * PIECE of the row's chunk bytes)
+            typedef typename std::conditional<CT >= 0, uint2, f32x4>::type areg_t;
+            const float* arow = nullptr;
+            const uint8_t* crow = nullptr;
+            int64_t cstep0 = 0, cstep1 = 0; // byte steps to the next 32-row block from an even / odd half of a code block
+            int nch1 = 7;                   // last chunk of a row (rows shorter than 8 chunks: the surplus pieces re-read it)
+            if constexpr (CT >= 0) {
+                constexpr int CHB = LmSq<CT < 0 ? 0 : CT>::CHB, PIECE = LmSq<CT < 0 ? 0 : CT>::PIECE;
+                const int64_t R = start + t;
+                crow = p.arena_codes + (R >> 6) * 64 * (int64_t)p.sq_ld + (int64_t)(((int)R & 63) + j) * CHB + h * PIECE;
+                cstep0 = 32 * CHB;
+                cstep1 = 64 * (int64_t)p.sq_ld - 32 * CHB;
+                nch1 = p.sq_ld / CHB - 1;
+            } else {
+                arow = p.arena_vecs + (start + t + j) * p.ldv + 4 * h;
+            }
+            auto load_a = [&](int s) __attribute__((always_inline)) -> areg_t {
+                if constexpr (CT >= 0) {
+                    constexpr int CHB = LmSq<CT < 0 ? 0 : CT>::CHB, PIECE = LmSq<CT < 0 ? 0 : CT>::PIECE;
+                    const int c = FULL ? (s >> 1) : min(s >> 1, nch1);
+                    return lm_sq_load_piece<CT < 0 ? 0 : CT>(crow + c * 64 * CHB + (s & 1) * 2 * PIECE);
+                } else {
+                    return *(const f32x4*)(arow + 8 * s);
+                }
+            };
+            auto comp_a = [&](const areg_t& v, int e) __attribute__((always_inline)) -> float {
+                if constexpr (CT >= 0) return lm_sq_comp<CT < 0 ? 0 : CT>(v, e);
+                else return v[e];
+            };
+            areg_t a[16];
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
-                a[s] = *(const f32x4*)(arow + 8 * s);
+                a[s] = load_a(s);
                 asm volatile("" ::: "memory");
             }
             const float* rnp = p.arena_rn + start + t + 4 * h; // rn of rows 8 g + 4 h + e of the block: rnp[8 g + e]
             bool full = false; // the slice cannot take the candidates of the block in hand: leave, flush, come back
             for (; t < r1; t += 32) {
-                arow += 32 * p.ldv;
+                if constexpr (CT >= 0) crow += (((int)(start & 63) + t) & 32) ? cstep1 : cstep0;
+                else arow += 32 * p.ldv;
                 rnp += 32;
                 f32x16 acc;
 #pragma unroll
@@ -804,10 +1032,11 @@ __global__ void __launch_bounds__(LR_THREADS, 2) ivf_lm_flat_reg_kernel(IvfLmPar
                 for (int s = 0; s < 16; ++s) {
                     if (FULL || s < ns) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][e], bq[s][e], acc, 0, 0, 0);
+                        for (int e = 0; e < 4; ++e)
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(comp_a(a[s], e), bq[s][e], acc, 0, 0, 0);
                     }
                     // refill for the next block right behind the MFMAs that consumed a[s]
-                    a[s] = *(const f32x4*)(arow + 8 * s);
+                    a[s] = load_a(s);
                     // the row norms of THIS block, half a block ahead of the epilogue that needs them (not carried from
                     // block to block: the register allocator would shuffle them at the head of the block, waiting for
                     // the youngest loads there)
@@ -883,18 +1112,27 @@ __global__ void __launch_bounds__(LR_THREADS, 2) ivf_lm_flat_reg_kernel(IvfLmPar
     if (wcnt > 0) flush();
 }
 
-template <int METRIC>
+template <int METRIC, int CT>
 static void lr_launch(const IvfLmParams& p, int grid_blocks, hipStream_t stream) {
     if (p.dpad == 128) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)ivf_lm_flat_reg_kernel<METRIC, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      LR_LDS_TOTAL));
-        hipLaunchKernelGGL((ivf_lm_flat_reg_kernel<METRIC, true>), dim3((unsigned)grid_blocks), dim3(LR_THREADS), LR_LDS_TOTAL, stream,
-                           p);
+        HIP_CHECK(hipFuncSetAttribute((const void*)ivf_lm_flat_reg_kernel<METRIC, true, CT>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, LR_LDS_TOTAL));
+        hipLaunchKernelGGL((ivf_lm_flat_reg_kernel<METRIC, true, CT>), dim3((unsigned)grid_blocks), dim3(LR_THREADS), LR_LDS_TOTAL,
+                           stream, p);
     } else {
-        HIP_CHECK(hipFuncSetAttribute((const void*)ivf_lm_flat_reg_kernel<METRIC, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      LR_LDS_TOTAL));
-        hipLaunchKernelGGL((ivf_lm_flat_reg_kernel<METRIC, false>), dim3((unsigned)grid_blocks), dim3(LR_THREADS), LR_LDS_TOTAL, stream,
-                           p);
+        HIP_CHECK(hipFuncSetAttribute((const void*)ivf_lm_flat_reg_kernel<METRIC, false, CT>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, LR_LDS_TOTAL));
+        hipLaunchKernelGGL((ivf_lm_flat_reg_kernel<METRIC, false, CT>), dim3((unsigned)grid_blocks), dim3(LR_THREADS), LR_LDS_TOTAL,
+                           stream, p);
+    }
+}
+template <int METRIC>
+static void lr_launch_sq(const IvfLmParams& p, int grid_blocks, hipStream_t stream) {
+    switch (p.sq_ct) {
+        case SQ_U8: lr_launch<METRIC, SQ_U8>(p, grid_blocks, stream); break;
+        case SQ_U4: lr_launch<METRIC, SQ_U4>(p, grid_blocks, stream); break;
+        case SQ_F16: lr_launch<METRIC, SQ_F16>(p, grid_blocks, stream); break;
+        default: FA_THROW_MSG("list-major scan: scalar-quantizer code type not supported");
     }
 }
 
@@ -1315,14 +1553,16 @@ static void lm_launch2(const IvfLmParams& p, int pass, int grid_blocks, hipStrea
     else lm_launch3<METRIC, KIND, 2>(p, grid_blocks, stream);
 }
 int ivf_lm_blocks_per_cu(int kind) {
-    return kind == 0 ? 2 : 3;
+    return kind == 1 ? 3 : 2;
 }
 static bool lm_flat_lds_env() {
     static const char* e = getenv("FAISS_AMD_LM_FLAT_LDS"); // timing experiments: 1 = the LDS-tile kernel for IVFFlat
     return e && atoi(e) == 1;
 }
 int ivf_lm_queries_per_item(int kind) {
-    return kind == 0 && !lm_flat_lds_env() ? 32 : kLmQueriesPerItem;
+    // IVFFlat and the scalar quantizer: pass 2 by the register-fed kernel (one wavefront and 32 queries per item);
+    // pass 1 walks the same 32-query items with the LDS-tile kernel
+    return (kind == 0 || kind == 2) && !lm_flat_lds_env() ? 32 : kLmQueriesPerItem;
 }
 static bool lm_use_pq_lds(const IvfLmParams& p) {
     static const char* e = getenv("FAISS_AMD_LM_PQ_GENERIC"); // timing experiments: 1 = the generic (L2-gather) kernel
@@ -1336,10 +1576,22 @@ int ivf_lm_grid_blocks(const IvfLmParams& p, int num_cus) {
 void launch_ivf_lm_scan(const IvfLmParams& p, int pass, int grid_blocks, hipStream_t stream) {
     if (p.nq == 0) return;
     FA_THROW_IF_NOT(ivf_lm_supported(p.kind, p.dpad, p.M, p.d) && (pass == 1 || pass == 2) && grid_blocks > 0);
-    FA_THROW_IF_NOT(p.ldq % 4 == 0 && (p.kind != 0 || p.ldv % 4 == 0) && (p.kind != 1 || p.ldc % 4 == 0));
+    FA_THROW_IF_NOT(p.ldq % 4 == 0 && (p.kind != 0 || p.ldv % 4 == 0) && (p.kind == 0 || p.ldc % 4 == 0));
     if (p.kind == 0 && p.qpi == 32 && pass == 2) {
-        if (p.metric == METRIC_L2) lr_launch<METRIC_L2>(p, grid_blocks, stream);
-        else lr_launch<METRIC_INNER_PRODUCT>(p, grid_blocks, stream);
+        if (p.metric == METRIC_L2) lr_launch<METRIC_L2, -1>(p, grid_blocks, stream);
+        else lr_launch<METRIC_INNER_PRODUCT, -1>(p, grid_blocks, stream);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
+    if (p.kind == 2) {
+        FA_THROW_IF_NOT(p.sq_s && p.sq_b && p.sq_zero && p.arena_codes && p.sq_ld > 0 && (p.metric != METRIC_L2 || p.arena_rn));
+        if (p.qpi == 32 && pass == 2) {
+            if (p.metric == METRIC_L2) lr_launch_sq<METRIC_L2>(p, grid_blocks, stream);
+            else lr_launch_sq<METRIC_INNER_PRODUCT>(p, grid_blocks, stream);
+        } else {
+            if (p.metric == METRIC_L2) lm_launch2<METRIC_L2, 2>(p, pass, grid_blocks, stream);
+            else lm_launch2<METRIC_INNER_PRODUCT, 2>(p, pass, grid_blocks, stream);
+        }
         HIP_CHECK(hipGetLastError());
         return;
     }

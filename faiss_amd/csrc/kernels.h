@@ -359,7 +359,7 @@ struct IvfFusedParams {
 };
 // code types of the scalar quantizer as the scan kernel sees them (16 components per lane chunk)
 enum SqCodeType { SQ_U8 = 0, SQ_U4 = 1, SQ_U6 = 2, SQ_F16 = 3 };
-inline int sq_chunk_bytes(int ct) { return ct == SQ_U8 ? 16 : ct == SQ_U4 ? 8 : ct == SQ_U6 ? 12 : 32; }
+__host__ __device__ inline int sq_chunk_bytes(int ct) { return ct == SQ_U8 ? 16 : ct == SQ_U4 ? 8 : ct == SQ_U6 ? 12 : 32; }
 // Scalar-quantizer code layout: the arena is a sequence of 64-row blocks (lists start on block boundaries); a block
 // holds its rows chunk-major, [chunk][64 rows][chunk bytes] with a chunk = 16 components, so that a wavefront reads
 // one chunk of all 64 rows with one coalesced load and lane l owns row l.  ld = bytes per row = chunks * chunk bytes.
@@ -410,7 +410,7 @@ constexpr int kLmRowsPerItem = 1024; // rows of a list per work item (16 tiles);
 constexpr int kLmQueriesPerItem = 64; // two 32-query blocks (x the two 32-row blocks of a tile = 4 waves)
 struct IvfLmParams {
     int metric;
-    int kind; // 0 = IVFFlat, 1 = IVFPQ
+    int kind; // 0 = IVFFlat, 1 = IVFPQ, 2 = IVF scalar quantizer (round 3, late: 8-bit / 4-bit / fp16 codes)
     int nq, nprobe, d, dpad, nlist, k;
     const float* xq; // [nq][ldq] padded queries
     int64_t ldq;
@@ -450,7 +450,21 @@ struct IvfLmParams {
     const float* pq_centroids;  // [M][256][dsub]
     const float* centroids;     // [nlist][ldc] coarse centroids
     int64_t ldc;
+    // IVF scalar quantizer (kind 2): arena_codes in the chunk-major 64-row blocks of sq_code_offset; component j of a row
+    // decodes to b_j + s_j * code_j (fp16 codes: the half itself).  The scan never materialises it.  With the codes
+    // centred on the middle of their range, code' = code - mid (mid = 127.5 for 8-bit, 7.5 for 4-bit codes, 0 for fp16),
+    // b' = fmaf(mid, s, b) and a = (q [- centroid]) - b', the B operand is a o s and the A operand code' as a float:
+    //   L2  max(0, fmaf(-2, <a o s, code'>, |a|^2 + |s o code'|^2)),   IP  (<q, b'> + coarse) + <q o s, code'>
+    // (|s o code'|^2 per stored row in arena_rn, launch_ivfsq_row_norms; |a|^2 and <q, b'> as the two interleaved half
+    // chains of a lane pair, like IVFPQ's |q - c|^2)
+    int sq_ct;             // SqCodeType
+    int sq_ld;             // bytes per arena row
+    int sq_by_residual;
+    const float* sq_s;     // [>= dpad] scale per dimension (0 beyond d)
+    const float* sq_b;     // [>= dpad] b': offset per dimension moved to the middle of the code range (fp16: s = 1, b' = 0)
+    const float* sq_zero;  // [>= dpad] zeros: the "centroid" of a search without residual encoding
 };
+// kind 0: M unused; kind 1: M = sub-quantizers; kind 2: M = SqCodeType
 bool ivf_lm_supported(int kind, int dpad, int M, int d);
 // prefix / p0 / cnt, the pairs grouped by (pass, list), the work items.  (4 launches + 1 memset)
 void launch_ivf_lm_plan(const IvfLmParams& p, hipStream_t stream);
@@ -464,6 +478,10 @@ int ivf_lm_grid_blocks(const IvfLmParams& p, int num_cus);
 bool ivf_lm_pq_lds_supported(int d, int dpad, int M);
 // cnt[q] > stride -> cnt[q] = stride, the query is listed in ovf
 void launch_ivf_lm_clamp(const IvfLmParams& p, hipStream_t stream);
+// IVF scalar quantizer: out[row] = sum_j (s_j * code'_j)^2 (centred codes; fp16: the half itself), sequential fmaf chain over
+// j = 0 .. d - 1, for the n arena rows dest[i] (dest != null; negative entries skipped) or row0 .. row0 + n - 1
+void launch_ivfsq_row_norms(const uint8_t* arena, int ct, int ld, int d, const float* sq_s, const int64_t* dest, int64_t row0,
+                            int64_t n, float* out, hipStream_t stream);
 // out[dest[i]] = |x_i|^2 as the sequential fmaf chain of l2_norms_kernel, for dest[i] >= 0
 void launch_l2_norms_scatter(const float* x, int64_t ld, int64_t n, int d, const int64_t* dest, float* out, hipStream_t stream);
 

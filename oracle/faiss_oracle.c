@@ -723,10 +723,28 @@ int orc_sq_decode(int qtype, int d, idx_t n, const uint8_t* codes, const float* 
  *   L2: a_j = (q_j [- centroid_j]) - b_j;  tt = fmaf(-code_j, s_j, a_j)  (fp16: a_j - half_j);  acc = fmaf(tt, tt, acc)
  *   IP: w_j = q_j * s_j;  acc = fmaf(w_j, code_j, acc)  (fp16: w_j = q_j);  dis = (acc + <q, b>) + coarse
  * with <q, b> one fmaf chain as well. */
+int orc_ivfsq_search_ex(int qtype, int by_residual, int metric, int d, int nlist, const float* centroids,
+                        const uint32_t* list_sizes, const uint8_t* codes, const idx_t* ids, const float* vmin,
+                        const float* vdiff, idx_t nq, const float* xq, int nprobe, int k, float* D, idx_t* I, int arith);
 int orc_ivfsq_search(int qtype, int by_residual, int metric, int d, int nlist, const float* centroids,
                      const uint32_t* list_sizes, const uint8_t* codes, const idx_t* ids, const float* vmin,
                      const float* vdiff, idx_t nq, const float* xq, int nprobe, int k, float* D, idx_t* I) {
+    return orc_ivfsq_search_ex(qtype, by_residual, metric, d, nlist, centroids, list_sizes, codes, ids, vmin, vdiff, nq, xq,
+                               nprobe, k, D, I, 0);
+}
+/* arith 1: the list-major scan of large batches (faiss_amd/csrc/ivf_listmajor.hip, kind 2; 8-bit, 4-bit and fp16 codes).
+ * The reconstruction is never formed.  The codes are centred on the middle of their range, code' = code - mid (127.5 /
+ * 7.5 / 0 for 8-bit / 4-bit / fp16 codes; exact), the offset moves with them, b' = fmaf(mid, s, b) (fp16: s = 1, b' = 0);
+ * with a_j = ((q_j - centroid_j) - b'_j) (no residual encoding: centroid = 0) the matrix pipe multiplies w = a o s with
+ * the centred codes,
+ *   L2: max(0, fmaf(-2, <w, code'>, |a|^2 + |s o code'|^2)),   IP: (<q, b'> + coarse) + <q o s, code'>
+ * <.,.> = orc_ip_chain (the MFMA chain); |a|^2 and <q, b'> as the two interleaved half chains of a lane pair (coordinates
+ * 8 s + 4 h + e, h = 0 / 1), summed; |s o code'|^2 one sequential chain per stored row over v_j = s_j * code'_j. */
+int orc_ivfsq_search_ex(int qtype, int by_residual, int metric, int d, int nlist, const float* centroids,
+                        const uint32_t* list_sizes, const uint8_t* codes, const idx_t* ids, const float* vmin,
+                        const float* vdiff, idx_t nq, const float* xq, int nprobe, int k, float* D, idx_t* I, int arith) {
     if (k < 1 || nprobe < 1) return -1;
+    if (arith == 1 && qtype == 6) return -2; /* 6-bit codes keep the query-major scan */
     if (nprobe > nlist) nprobe = nlist;
     const size_t cs = orc_sq_code_size(qtype, d);
     idx_t* list_start = (idx_t*)malloc(sizeof(idx_t) * (size_t)(nlist + 1));
@@ -738,6 +756,12 @@ int orc_ivfsq_search(int qtype, int by_residual, int metric, int d, int nlist, c
     float* s = (float*)malloc(sizeof(float) * (size_t)d * 2);
     float* b = s + d;
     orc_sq_tables(qtype, d, vmin, vdiff, s, b);
+    const float mid = (qtype == 0 || qtype == 2 || qtype == 5) ? 127.5f : (qtype == 1 || qtype == 3) ? 7.5f : 0.f;
+    if (arith == 1)
+        for (int j = 0; j < d; j++) {
+            if (qtype == 4) s[j] = 1.f;
+            b[j] = fmaf(mid, s[j], b[j]);
+        }
 #pragma omp parallel for schedule(dynamic, 1)
     for (idx_t q = 0; q < nq; q++) {
         const float* x = xq + (size_t)q * d;
@@ -754,6 +778,8 @@ int orc_ivfsq_search(int qtype, int by_residual, int metric, int d, int nlist, c
         float qb = 0.f;
         if (metric != ORC_METRIC_L2 && qtype != 4)
             for (int j = 0; j < d; j++) qb = fmaf(x[j], b[j], qb);
+        float* w = (float*)malloc(sizeof(float) * (size_t)d * 2); /* arith 1: the B operand, a row's codes as floats */
+        float* cfv = w + d;
         idx_t pos = 0;
         for (int p = 0; p < nprobe; p++) {
             idx_t l = cI[(size_t)q * nprobe + p];
@@ -771,6 +797,41 @@ int orc_ivfsq_search(int qtype, int by_residual, int metric, int d, int nlist, c
                 }
             }
             const float coarse = (metric != ORC_METRIC_L2 && by_residual) ? cD[(size_t)q * nprobe + p] : 0.f;
+            if (arith == 1) {
+                float hc[2] = {0.f, 0.f}; /* half chains of the lane pair: |a|^2 (L2) or <q, b> (IP) */
+                for (int h = 0; h < 2; h++)
+                    for (int s0 = 0; s0 < d; s0 += 8)
+                        for (int e = 0; e < 4; e++) {
+                            const int j = s0 + 4 * h + e;
+                            if (j >= d) continue;
+                            if (metric == ORC_METRIC_L2) {
+                                const float aj = (x[j] - (by_residual ? cen[j] : 0.f)) - b[j];
+                                hc[h] = fmaf(aj, aj, hc[h]);
+                                w[j] = aj * s[j];
+                            } else {
+                                hc[h] = fmaf(x[j], b[j], hc[h]);
+                                w[j] = x[j] * s[j];
+                            }
+                        }
+                const float xn = metric == ORC_METRIC_L2 ? hc[0] + hc[1] : (hc[0] + hc[1]) + coarse;
+                for (uint32_t i = 0; i < len; i++) {
+                    const uint8_t* code = lc + (size_t)i * cs;
+                    float rn = 0.f;
+                    for (int j = 0; j < d; j++) {
+                        cfv[j] = orc_sq_component(qtype, code, j) - mid;
+                        const float v = qtype == 4 ? cfv[j] : s[j] * cfv[j];
+                        rn = fmaf(v, v, rn);
+                    }
+                    const float ip = orc_ip_chain(w, cfv, d);
+                    float dis;
+                    if (metric == ORC_METRIC_L2) dis = flat_dis(ORC_METRIC_L2, ip, xn, rn);
+                    else dis = xn + ip;
+                    pos2id[pos] = lid[i];
+                    topk_push(&t, dis, pos);
+                    pos++;
+                }
+                continue;
+            }
             for (uint32_t i = 0; i < len; i++) {
                 const uint8_t* code = lc + (size_t)i * cs;
                 float ch[2] = {0.f, 0.f}; /* the chain of the even and of the odd dimensions */
@@ -794,6 +855,7 @@ int orc_ivfsq_search(int qtype, int by_residual, int metric, int d, int nlist, c
         free(pos2id);
         free(st);
         free(a);
+        free(w);
     }
     free(cD);
     free(cI);

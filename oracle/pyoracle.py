@@ -188,7 +188,9 @@ class Oracle:
         return out
 
     @classmethod
-    def ivfsq_search(cls, qtype, by_residual, metric, centroids, list_sizes, codes, ids, vmin, vdiff, xq, nprobe, k):
+    def ivfsq_search(cls, qtype, by_residual, metric, centroids, list_sizes, codes, ids, vmin, vdiff, xq, nprobe, k, arith=0):
+        """arith: 0 = the query-major scan (ivfsq_fused_kernel), 1 = the list-major scan of large batches
+        (faiss_oracle.c orc_ivfsq_search_ex)"""
         centroids, xq = _f32(centroids), _f32(xq)
         nlist, d = centroids.shape
         ls = np.ascontiguousarray(list_sizes, dtype=np.uint32)
@@ -197,10 +199,10 @@ class Oracle:
         nq = xq.shape[0]
         D = np.empty((nq, k), dtype=np.float32)
         I = np.empty((nq, k), dtype=np.int64)
-        rc = cls.lib().orc_ivfsq_search(ctypes.c_int(qtype), ctypes.c_int(int(by_residual)), ctypes.c_int(metric),
-                                        ctypes.c_int(d), ctypes.c_int(nlist), _p(centroids), _p(ls), _p(codes), _p(ids),
-                                        _p(_f32(vmin)), _p(_f32(vdiff)), ctypes.c_int64(nq), _p(xq), ctypes.c_int(nprobe),
-                                        ctypes.c_int(k), _p(D), _p(I))
+        rc = cls.lib().orc_ivfsq_search_ex(ctypes.c_int(qtype), ctypes.c_int(int(by_residual)), ctypes.c_int(metric),
+                                           ctypes.c_int(d), ctypes.c_int(nlist), _p(centroids), _p(ls), _p(codes), _p(ids),
+                                           _p(_f32(vmin)), _p(_f32(vdiff)), ctypes.c_int64(nq), _p(xq), ctypes.c_int(nprobe),
+                                           ctypes.c_int(k), _p(D), _p(I), ctypes.c_int(arith))
         assert rc == 0
         return D, I
 

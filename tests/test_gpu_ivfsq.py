@@ -219,3 +219,124 @@ def test_ivfsq_incremental_adds_nan_rows_reset(res):
     assert (I == -1).all()
     with pytest.raises(RuntimeError):
         faiss_amd.GpuIndexIVFScalarQuantizer(res, d, nlist, SQ.QT_8bit, METRIC_L2, True).add(xb[:10])  # untrained
+
+
+# ---------------------------------------------------------------------- list-major scan (ivf_listmajor.hip, kind 2)
+LM_QTYPES = [SQ.QT_8bit, SQ.QT_4bit, SQ.QT_8bit_uniform, SQ.QT_4bit_uniform, SQ.QT_fp16, SQ.QT_8bit_direct]
+
+
+def _lm_check(idx, qtype, metric, by_residual, xq, nprobe, k, nsel=48):
+    """query-major vs list-major vs the oracle's restatement of the list-major arithmetic (orc_ivfsq_search_ex, arith 1)"""
+    d = xq.shape[1]
+    idx.nprobe = nprobe
+    idx.set_scan_mode(idx.SCAN_QUERY_MAJOR)
+    D0, I0 = idx.search(xq, k)
+    assert idx.scan_info()[1] == 1
+    idx.set_scan_mode(idx.SCAN_LIST_MAJOR)
+    D, I = idx.search(xq, k)
+    assert idx.scan_info()[1] == 2 and idx.last_scan_arith() == 1
+    # (two roundings of the same sums: where offset and code terms cancel -- inner products near zero at deep ranks --
+    # neighbours a few 1e-6 of the row's scale apart may swap; each scan is bit-exact against its own restatement below)
+    check_knn(D, I, D0, I0, rtol=1e-4, tie_rtol=2e-3, name="ivfsq list-major vs query-major")
+    cent = idx.get_centroids()
+    vmin, vdiff = Oracle.sq_unpack(qtype, d, idx.get_trained())
+    sizes, codes, ids = _gpu_lists(idx)
+    sel = np.r_[0:min(len(xq), nsel)]
+    Do, Io = Oracle.ivfsq_search(qtype, by_residual, metric, cent, sizes, codes, ids, vmin, vdiff, xq[sel], nprobe, k, arith=1)
+    check_knn(D[sel], I[sel], Do, Io, exact=True, name="ivfsq list-major vs oracle")
+    D2, I2 = idx.search(xq, k)  # run to run: the order in which wavefronts append candidates never shows
+    assert np.array_equal(D, D2) and np.array_equal(I, I2)
+    idx.set_scan_mode(idx.SCAN_AUTO)
+    return D, I
+
+
+@pytest.mark.parametrize("by_residual", [True, False])
+@pytest.mark.parametrize("metric", [METRIC_L2, METRIC_INNER_PRODUCT])
+@pytest.mark.parametrize("qtype", LM_QTYPES, ids=[QNAMES[q] for q in LM_QTYPES])
+def test_ivfsq_list_major_matches_oracle_and_query_major(res, qtype, metric, by_residual):
+    """Every code type the list-major kernels decode x metric x residual flag, d = 40 (dpad 40, rows of three 16-component
+    chunks, the last one half filled; 32-row blocks in both halves of the 64-row code blocks, ragged list ends)."""
+    d, nlist, nb, nq, nprobe, k = 40, 32, 20000, 700, 6, 50
+    xt, xb, xq = _data(qtype, d, 6000, nb, nq, seed=31 + qtype)
+    idx = faiss_amd.GpuIndexIVFScalarQuantizer(res, d, nlist, qtype, metric, by_residual)
+    idx.train(xt)
+    idx.add(xb)
+    _lm_check(idx, qtype, metric, by_residual, xq, nprobe, k)
+
+
+@pytest.mark.parametrize("qtype,metric,by_residual,d,nlist,nb,nq,nprobe,k", [
+    (SQ.QT_8bit, METRIC_L2, True, 128, 64, 40000, 1500, 8, 100),            # bench shape: the fully unrolled kernels
+    (SQ.QT_8bit, METRIC_INNER_PRODUCT, True, 128, 64, 40000, 1100, 8, 10),
+    (SQ.QT_fp16, METRIC_L2, True, 128, 64, 30000, 900, 8, 100),
+    (SQ.QT_4bit, METRIC_L2, False, 128, 64, 30000, 900, 8, 100),            # 16 levels: many equal distances (ties by position)
+    (SQ.QT_8bit, METRIC_L2, True, 72, 8, 20000, 1100, 2, 1000),             # dpad 72 < dsq 80; lists of ~2500 rows: row chunks, big k
+    (SQ.QT_8bit_uniform, METRIC_L2, True, 64, 8, 90000, 600, 3, 50),        # lists of ~11 000 rows: row chunks of 2816 rows
+    (SQ.QT_fp16, METRIC_INNER_PRODUCT, False, 32, 128, 20000, 600, 100, 10),  # more than 64 probes
+    (SQ.QT_4bit_uniform, METRIC_INNER_PRODUCT, True, 64, 32, 5000, 130, 5, 2048),  # k above the rows many queries see
+    (SQ.QT_8bit_direct, METRIC_L2, False, 16, 8, 5000, 1200, 5, 2048),      # one chunk per row, k at the limit
+    (SQ.QT_8bit, METRIC_L2, True, 8, 16, 9000, 300, 16, 7),                 # d = 8: half a chunk, every list probed
+])
+def test_ivfsq_list_major_shapes(res, qtype, metric, by_residual, d, nlist, nb, nq, nprobe, k):
+    xt, xb, xq = _data(qtype, d, max(4000, 40 * nlist), nb, nq, seed=nb + k)
+    idx = faiss_amd.GpuIndexIVFScalarQuantizer(res, d, nlist, qtype, metric, by_residual)
+    idx.train(xt)
+    idx.add(xb)
+    _lm_check(idx, qtype, metric, by_residual, xq, nprobe, k, nsel=24)
+
+
+def test_ivfsq_list_major_rule_and_refusals(res):
+    d, nlist = 32, 16
+    xt, xb, xq = synthetic_dataset(d, 4000, 6000, 2500, seed=3)
+    idx = faiss_amd.GpuIndexIVFScalarQuantizer(res, d, nlist, SQ.QT_8bit, METRIC_L2, True)
+    idx.train(xt)
+    idx.add(xb)
+    idx.nprobe = 4
+    # large batches take the list-major scan on their own, small ones and IDSelector searches the query-major one
+    assert idx.list_major_rule(2500) and not idx.list_major_rule(500)
+    D, I = idx.search(xq, 10)
+    assert idx.scan_info()[1] == 2
+    D1, I1 = idx.search(xq[:100], 10)
+    assert idx.scan_info()[1] == 1
+    check_knn(D[:100], I[:100], D1, I1, rtol=1e-4, tie_rtol=1e-4, name="auto: list-major vs query-major")
+    # 6-bit fields straddle the operand groups: that type keeps the query-major scan; so does d > 128
+    six = faiss_amd.GpuIndexIVFScalarQuantizer(res, d, nlist, SQ.QT_6bit, METRIC_L2, True)
+    six.train(xt)
+    six.add(xb)
+    assert not six.list_major_rule(2500)
+    six.search(xq, 10)
+    assert six.scan_info()[1] == 1
+    six.set_scan_mode(six.SCAN_LIST_MAJOR)
+    with pytest.raises(RuntimeError):
+        six.search(xq, 10)
+    wide = faiss_amd.GpuIndexIVFScalarQuantizer(res, 136, nlist, SQ.QT_8bit, METRIC_L2, True)
+    assert not wide.list_major_rule(2500)
+
+
+def test_ivfsq_list_major_row_norms_follow_the_rows(res):
+    """The per-row term |s o code|^2 (arena_rn) through list growth and relocation (many small adds), a bulk load
+    (copy_lists) and a later copy_trained: the list-major results are those of one big add."""
+    d, nlist, k = 32, 16, 10
+    xt, xb, xq = synthetic_dataset(d, 4000, 9000, 400, seed=12)
+    a = faiss_amd.GpuIndexIVFScalarQuantizer(res, d, nlist, SQ.QT_8bit, METRIC_L2, True)
+    a.train(xt)
+    b = faiss_amd.GpuIndexIVFScalarQuantizer(res, d, nlist, SQ.QT_8bit, METRIC_L2, True)
+    b.copy_centroids(a.get_centroids())
+    b.copy_trained(a.get_trained())
+    a.add(xb)
+    for i0 in range(0, 9000, 777):
+        b.add(xb[i0:i0 + 777])
+    for idx in (a, b):
+        idx.nprobe = 5
+        idx.set_scan_mode(idx.SCAN_LIST_MAJOR)
+    Da, Ia = a.search(xq, k)
+    Db, Ib = b.search(xq, k)
+    assert np.array_equal(Da, Db) and np.array_equal(Ia, Ib)
+    c = faiss_amd.GpuIndexIVFScalarQuantizer(res, d, nlist, SQ.QT_8bit, METRIC_L2, True)
+    c.copy_centroids(a.get_centroids())
+    c.copy_trained(a.get_trained())
+    c.copy_lists(*_gpu_lists(a))
+    c.copy_trained(a.get_trained())  # the same ranges again, now under stored rows: the norms are recomputed
+    c.nprobe = 5
+    c.set_scan_mode(c.SCAN_LIST_MAJOR)
+    Dc, Ic = c.search(xq, k)
+    assert np.array_equal(Da, Dc) and np.array_equal(Ia, Ic)

@@ -105,13 +105,16 @@ def test_exact_scan_and_helpers(usage):
 
 
 def test_list_major_scan(usage):
-    """three 4-wave workgroups per CU (168 registers)"""
+    """IVFPQ: three 4-wave workgroups per CU (168 registers); IVFFlat and the scalar quantizer: two"""
     picked = _pick(usage, "ivf_lm_scan_kernel")
-    assert len(picked) == 16
+    assert len(picked) == 24  # metric x kind (IVFFlat, IVFPQ, scalar quantizer) x pass x (dpad == 128)
     for name, u in picked.items():
         assert u["scratch"] <= 48 and u["occupancy"] >= 2, (name, u)
-    # the register-fed pass-2 kernel of IVFFlat: 64 + 64 registers of operands per lane, two waves per SIMD, no scratch
-    for name, u in _pick(usage, "ivf_lm_flat_reg_kernel").items():
+    # the register-fed pass-2 kernel of IVFFlat: 64 + 64 registers of operands per lane, two waves per SIMD, no scratch;
+    # the scalar quantizer's instantiations (8-bit, 4-bit, fp16 codes: 16 / 16 / 32 registers of codes) likewise
+    picked = _pick(usage, "ivf_lm_flat_reg_kernel")
+    assert len(picked) == 16  # metric x (dpad == 128) x (fp32 rows, three code types)
+    for name, u in picked.items():
         assert u["scratch"] == 0 and u["occupancy"] >= 2, (name, u)
     for name, u in _pick(usage, "ivf_lm_pq_kernel").items():
         assert u["occupancy"] >= 2, (name, u)

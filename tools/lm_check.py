@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """tools/lm_check.py -- list-major vs query-major IVF scan on the bench data (IVF4096, nprobe 32, 10k queries, k 100):
 per-kernel times of both, agreement of the results, a sample against the oracle's list-major restatement.
-usage: lm_check.py [kinds=ivfflat,ivfpq] [steps=5] [nb=1000000] [nq=10000]"""
+usage: lm_check.py [kinds=ivfflat,ivfpq] [steps=5] [nb=1000000] [nq=10000]      (kinds: ivfflat, ivfpq, ivfsq = QT_8bit)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -22,12 +22,14 @@ xq = xq[:nq]
 dev = torch.device("cuda", 0)
 xq_dev = torch.from_numpy(xq).to(dev)
 SPANS = ("ivf_lm_plan", "ivf_lm_scan_pass1", "ivf_lm_threshold", "ivf_lm_scan_pass2", "select_k_kernel", "ivfflat_fused_kernel",
-         "ivfpq_fused_kernel", "ivf_finish_kernel", "flat_filter_kernel", "flat_filter_kernel_max", "flat_tighten_kernel",
+         "ivfpq_fused_kernel", "ivfsq_fused_kernel", "ivf_finish_kernel", "flat_filter_kernel", "flat_filter_kernel_max", "flat_tighten_kernel",
          "flat_rerank_kernel", "convert_f16_query")
 for kind in kinds:
     t0 = time.time()
     if kind == "ivfpq":
         idx = faiss_amd.GpuIndexIVFPQ(res, 128, NLIST, 64, 8, faiss_amd.METRIC_L2)
+    elif kind == "ivfsq":
+        idx = faiss_amd.GpuIndexIVFScalarQuantizer(res, 128, NLIST, faiss_amd.ScalarQuantizer.QT_8bit, faiss_amd.METRIC_L2, True)
     else:
         idx = faiss_amd.GpuIndexIVFFlat(res, 128, NLIST, faiss_amd.METRIC_L2)
     idx.train(xt)
@@ -69,8 +71,13 @@ for kind in kinds:
         ids = np.concatenate([idx.get_list_ids(l) for l in range(NLIST) if sizes[l]])
         sel = np.r_[0:8, nq // 2: nq // 2 + 8]
         pq = idx.get_pq_centroids() if kind == "ivfpq" else None
-        Do, Io, _, _ = Oracle.ivf_search(1 if kind == "ivfpq" else 0, METRIC_L2, idx.get_centroids(), sizes, codes, ids, xq[sel],
-                                         NPROBE, K, M=64 if kind == "ivfpq" else 0, pq=pq, arith=1)
+        if kind == "ivfsq":
+            vmin, vdiff = Oracle.sq_unpack(0, 128, idx.get_trained())
+            Do, Io = Oracle.ivfsq_search(0, True, METRIC_L2, idx.get_centroids(), sizes, codes, ids, vmin, vdiff, xq[sel], NPROBE, K,
+                                         arith=1)
+        else:
+            Do, Io, _, _ = Oracle.ivf_search(1 if kind == "ivfpq" else 0, METRIC_L2, idx.get_centroids(), sizes, codes, ids, xq[sel],
+                                             NPROBE, K, M=64 if kind == "ivfpq" else 0, pq=pq, arith=1)
         check_knn(out[2][0][sel], out[2][1][sel], Do, Io, exact=True, name="list-major vs oracle")
         print("    list-major == oracle (arith 1) bit for bit on %d sampled queries" % len(sel), flush=True)
     del idx
