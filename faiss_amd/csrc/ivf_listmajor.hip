@@ -885,7 +885,12 @@ constexpr int LR_LDS_TOTAL = 4 * LR_PARK * (8 + 4);
 // operand group (a dword of 8-bit codes, 16 bits of 4-bit codes, two dwords of fp16), converted to floats right in front
 // of the MFMAs that read them; scale / offset / centroid are folded into the query operands (lm_sq_query).  Same item
 // walk, same refill schedule: the loads are 4 to 16 times narrower.
-template <int METRIC, bool FULL, int CT>
+// PASS 1 (round 3, late): the same walk over the items of pass 1 -- every distance goes to its dense slot of the query's
+// segment.  The key stores are issued from inline asm: hipcc does not see them, so it keeps COUNTING the loads in flight
+// (with a store of its own in the loop it waits vmcnt(0) before every use); its counted waits stay correct -- loads
+// return in order, "at most N operations outstanding" still covers every load older than the N youngest -- and merely
+// become conservative by the stores in between.
+template <int METRIC, bool FULL, int CT, int PASS>
 __global__ void __launch_bounds__(LR_THREADS, 2) ivf_lm_flat_reg_kernel(IvfLmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -912,10 +917,10 @@ __global__ void __launch_bounds__(LR_THREADS, 2) ivf_lm_flat_reg_kernel(IvfLmPar
         __builtin_amdgcn_s_waitcnt(0x0F70);
     };
 
-    const uint32_t it0 = p.item_bounds[1], it1 = p.item_bounds[2];
+    const uint32_t it0 = p.item_bounds[PASS - 1], it1 = p.item_bounds[PASS];
     // (Eight per-XCD item queues -- neighbouring items read the same rows, workgroups b, b + 8, ... share an L2 -- were
     // measured: L2 misses 19.4 -> 14.2 GB per launch at nb = 10M, same time; slower at nb = 1M.  profiles/r03_b_*)
-    uint32_t* ctr = p.item_bounds + 4; // next item of pass 2 (zeroed by the plan)
+    uint32_t* ctr = p.item_bounds + (PASS == 2 ? 4 : 5); // next item of this pass (zeroed by the plan)
     for (;;) {
         uint32_t it = 0;
         if (lane == 0) it = atomicAdd(ctr, 1u);
@@ -955,11 +960,14 @@ __global__ void __launch_bounds__(LR_THREADS, 2) ivf_lm_flat_reg_kernel(IvfLmPar
             xn = METRIC == METRIC_L2 ? p.xqn[q] : 0.f;
         }
         const uint32_t base_pos = p.prefix[(int64_t)q * (np + 1) + pr];
-        float thr_f;
-        {
+        float thr_f = 0.f;
+        u64* kslot = nullptr; // pass 1: the segment slot of row 0 of this list (dense: one slot per pass-1 row)
+        if constexpr (PASS == 2) {
             const uint32_t tk = p.thr[q];
             if (tk >= kInvalidOrdKey) thr_f = METRIC == METRIC_L2 ? INFINITY : -INFINITY;
             else thr_f = unordkey<METRIC>(tk);
+        } else {
+            kslot = p.keys + (int64_t)q * p.stride + p.prefix1[(int64_t)q * (np + 1) + pr];
         }
         auto dist_of = [&](float ip, float rnv) -> float {
             if (METRIC == METRIC_L2) {
@@ -1063,8 +1071,27 @@ __global__ void __launch_bounds__(LR_THREADS, 2) ivf_lm_flat_reg_kernel(IvfLmPar
                 }
                 // (nothing of the epilogue may be scheduled above this line)
                 __builtin_amdgcn_sched_barrier(0);
-                // ---- epilogue: which of this lane's 16 distances pass its query's bound
                 const int row_b = t + 4 * h; // row of the list of acc[4 g + e]: row_b + 8 g + e
+                if constexpr (PASS == 1) {
+                    // ---- epilogue of pass 1: every distance to its slot (stores the compiler does not see, see above)
+                    if (!(p.dbg & 1)) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int rowl = row_b + 8 * g + e;
+                                if (qv && rowl < r1) {
+                                    const u64 key = ((u64)ordkey<METRIC>(dist_of(acc[4 * g + e], rn[g][e])) << 32) |
+                                                    (u64)(base_pos + (uint32_t)rowl);
+                                    const u64* at = kslot + rowl;
+                                    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(at), "v"(key));
+                                }
+                            }
+                        }
+                    }
+                    continue;
+                }
+                // ---- epilogue: which of this lane's 16 distances pass its query's bound
                 unsigned mask = 0;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -1112,28 +1139,43 @@ __global__ void __launch_bounds__(LR_THREADS, 2) ivf_lm_flat_reg_kernel(IvfLmPar
     if (wcnt > 0) flush();
 }
 
-template <int METRIC, int CT>
-static void lr_launch(const IvfLmParams& p, int grid_blocks, hipStream_t stream) {
+template <int METRIC, int CT, int PASS>
+static void lr_launch2(const IvfLmParams& p, int grid_blocks, hipStream_t stream) {
+    const int lds = PASS == 2 ? LR_LDS_TOTAL : 0; // (pass 1 parks nothing)
     if (p.dpad == 128) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)ivf_lm_flat_reg_kernel<METRIC, true, CT>,
+        HIP_CHECK(hipFuncSetAttribute((const void*)ivf_lm_flat_reg_kernel<METRIC, true, CT, PASS>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, LR_LDS_TOTAL));
-        hipLaunchKernelGGL((ivf_lm_flat_reg_kernel<METRIC, true, CT>), dim3((unsigned)grid_blocks), dim3(LR_THREADS), LR_LDS_TOTAL,
+        hipLaunchKernelGGL((ivf_lm_flat_reg_kernel<METRIC, true, CT, PASS>), dim3((unsigned)grid_blocks), dim3(LR_THREADS), lds,
                            stream, p);
     } else {
-        HIP_CHECK(hipFuncSetAttribute((const void*)ivf_lm_flat_reg_kernel<METRIC, false, CT>,
+        HIP_CHECK(hipFuncSetAttribute((const void*)ivf_lm_flat_reg_kernel<METRIC, false, CT, PASS>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, LR_LDS_TOTAL));
-        hipLaunchKernelGGL((ivf_lm_flat_reg_kernel<METRIC, false, CT>), dim3((unsigned)grid_blocks), dim3(LR_THREADS), LR_LDS_TOTAL,
+        hipLaunchKernelGGL((ivf_lm_flat_reg_kernel<METRIC, false, CT, PASS>), dim3((unsigned)grid_blocks), dim3(LR_THREADS), lds,
                            stream, p);
     }
 }
+template <int METRIC, int CT>
+static void lr_launch(const IvfLmParams& p, int pass, int grid_blocks, hipStream_t stream) {
+    if (pass == 1) lr_launch2<METRIC, CT, 1>(p, grid_blocks, stream);
+    else lr_launch2<METRIC, CT, 2>(p, grid_blocks, stream);
+}
 template <int METRIC>
-static void lr_launch_sq(const IvfLmParams& p, int grid_blocks, hipStream_t stream) {
+static void lr_launch_sq(const IvfLmParams& p, int pass, int grid_blocks, hipStream_t stream) {
     switch (p.sq_ct) {
-        case SQ_U8: lr_launch<METRIC, SQ_U8>(p, grid_blocks, stream); break;
-        case SQ_U4: lr_launch<METRIC, SQ_U4>(p, grid_blocks, stream); break;
-        case SQ_F16: lr_launch<METRIC, SQ_F16>(p, grid_blocks, stream); break;
+        case SQ_U8: lr_launch<METRIC, SQ_U8>(p, pass, grid_blocks, stream); break;
+        case SQ_U4: lr_launch<METRIC, SQ_U4>(p, pass, grid_blocks, stream); break;
+        case SQ_F16: lr_launch<METRIC, SQ_F16>(p, pass, grid_blocks, stream); break;
         default: FA_THROW_MSG("list-major scan: scalar-quantizer code type not supported");
     }
+}
+// pass 1 by the register-fed kernel?  Measured at nb = 1M (profiles/r03_g_ivfsq_listmajor.txt): scalar quantizer 0.353 ms
+// with the LDS-tile kernel (its threads decode the tile between two barriers) against 0.225 register-fed; IVFFlat 0.229
+// with the LDS-DMA tiles against 0.276 register-fed (pass-1 items hold 10-17 queries: a DMA tile feeds two half-idle
+// waves for free, a register-fed wave pays every row's load latency alone).  FAISS_AMD_LM_P1_REG = 0 / 1 overrides.
+static bool lm_p1_reg(int kind) {
+    static const char* e = getenv("FAISS_AMD_LM_P1_REG");
+    if (e) return atoi(e) != 0;
+    return kind == 2;
 }
 
 // ------------------------------------------------------------------ IVFPQ, codebook in LDS (round 3, third kernel)
@@ -1577,17 +1619,17 @@ void launch_ivf_lm_scan(const IvfLmParams& p, int pass, int grid_blocks, hipStre
     if (p.nq == 0) return;
     FA_THROW_IF_NOT(ivf_lm_supported(p.kind, p.dpad, p.M, p.d) && (pass == 1 || pass == 2) && grid_blocks > 0);
     FA_THROW_IF_NOT(p.ldq % 4 == 0 && (p.kind != 0 || p.ldv % 4 == 0) && (p.kind == 0 || p.ldc % 4 == 0));
-    if (p.kind == 0 && p.qpi == 32 && pass == 2) {
-        if (p.metric == METRIC_L2) lr_launch<METRIC_L2, -1>(p, grid_blocks, stream);
-        else lr_launch<METRIC_INNER_PRODUCT, -1>(p, grid_blocks, stream);
+    if (p.kind == 0 && p.qpi == 32 && (pass == 2 || lm_p1_reg(0))) {
+        if (p.metric == METRIC_L2) lr_launch<METRIC_L2, -1>(p, pass, grid_blocks, stream);
+        else lr_launch<METRIC_INNER_PRODUCT, -1>(p, pass, grid_blocks, stream);
         HIP_CHECK(hipGetLastError());
         return;
     }
     if (p.kind == 2) {
         FA_THROW_IF_NOT(p.sq_s && p.sq_b && p.sq_zero && p.arena_codes && p.sq_ld > 0 && (p.metric != METRIC_L2 || p.arena_rn));
-        if (p.qpi == 32 && pass == 2) {
-            if (p.metric == METRIC_L2) lr_launch_sq<METRIC_L2>(p, grid_blocks, stream);
-            else lr_launch_sq<METRIC_INNER_PRODUCT>(p, grid_blocks, stream);
+        if (p.qpi == 32 && (pass == 2 || lm_p1_reg(2))) {
+            if (p.metric == METRIC_L2) lr_launch_sq<METRIC_L2>(p, pass, grid_blocks, stream);
+            else lr_launch_sq<METRIC_INNER_PRODUCT>(p, pass, grid_blocks, stream);
         } else {
             if (p.metric == METRIC_L2) lm_launch2<METRIC_L2, 2>(p, pass, grid_blocks, stream);
             else lm_launch2<METRIC_INNER_PRODUCT, 2>(p, pass, grid_blocks, stream);
