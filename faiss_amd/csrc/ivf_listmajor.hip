@@ -878,8 +878,15 @@ __global__ void __launch_bounds__(LM_THREADS, KIND == 1 ? 3 : 2) ivf_lm_scan_ker
 // slice flushed, the loop re-entered): with loads and stores in one loop hipcc stops counting the loads in flight and
 // waits vmcnt(0) before every use.
 constexpr int LR_THREADS = 256;
-constexpr int LR_PARK = 1280; // parked candidates per wave: a whole block (32 rows x 32 queries) always fits an empty slice
-constexpr int LR_LDS_TOTAL = 4 * LR_PARK * (8 + 4);
+// parked candidates per wave: a whole block (32 rows x 32 queries) always fits an empty slice.  IVFFlat: 1280 (two 60 KB
+// workgroups per CU; 128 registers of operands leave two waves per SIMD anyway); scalar quantizer: 1024, three 48 KB
+// workgroups per CU (16-32 registers of codes: 168 registers, three waves per SIMD)
+template <int CT>
+struct LrCfg {
+    static constexpr int PARK = CT >= 0 ? 1024 : 1280;
+    static constexpr int LDS = 4 * PARK * (8 + 4);
+    static constexpr int WG_PER_CU = CT >= 0 ? 3 : 2;
+};
 
 // CT: -1 = IVFFlat (fp32 rows); a SqCodeType = IVF scalar quantizer: the register a[s] holds the 4 CODES of the lane's
 // operand group (a dword of 8-bit codes, 16 bits of 4-bit codes, two dwords of fp16), converted to floats right in front
@@ -891,7 +898,8 @@ constexpr int LR_LDS_TOTAL = 4 * LR_PARK * (8 + 4);
 // return in order, "at most N operations outstanding" still covers every load older than the N youngest -- and merely
 // become conservative by the stores in between.
 template <int METRIC, bool FULL, int CT, int PASS>
-__global__ void __launch_bounds__(LR_THREADS, 2) ivf_lm_flat_reg_kernel(IvfLmParams p) {
+__global__ void __launch_bounds__(LR_THREADS, LrCfg<CT>::WG_PER_CU) ivf_lm_flat_reg_kernel(IvfLmParams p) {
+    constexpr int LR_PARK = LrCfg<CT>::PARK;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -921,9 +929,15 @@ __global__ void __launch_bounds__(LR_THREADS, 2) ivf_lm_flat_reg_kernel(IvfLmPar
     // (Eight per-XCD item queues -- neighbouring items read the same rows, workgroups b, b + 8, ... share an L2 -- were
     // measured: L2 misses 19.4 -> 14.2 GB per launch at nb = 10M, same time; slower at nb = 1M.  profiles/r03_b_*)
     uint32_t* ctr = p.item_bounds + (PASS == 2 ? 4 : 5); // next item of this pass (zeroed by the plan)
+    uint32_t static_it = (uint32_t)(blockIdx.x * 4 + wave); // (dbg 64, timing experiments: a static deal, no counter)
     for (;;) {
         uint32_t it = 0;
-        if (lane == 0) it = atomicAdd(ctr, 1u);
+        if (p.dbg & 64) {
+            it = static_it;
+            static_it += gridDim.x * 4;
+        } else if (lane == 0) {
+            it = atomicAdd(ctr, 1u);
+        }
         it = it0 + (uint32_t)__builtin_amdgcn_readfirstlane((int)it);
         if (it >= it1) break;
         const IvfLmItem item = p.items[it];
@@ -1141,6 +1155,7 @@ __global__ void __launch_bounds__(LR_THREADS, 2) ivf_lm_flat_reg_kernel(IvfLmPar
 
 template <int METRIC, int CT, int PASS>
 static void lr_launch2(const IvfLmParams& p, int grid_blocks, hipStream_t stream) {
+    constexpr int LR_LDS_TOTAL = LrCfg<CT>::LDS;
     const int lds = PASS == 2 ? LR_LDS_TOTAL : 0; // (pass 1 parks nothing)
     if (p.dpad == 128) {
         HIP_CHECK(hipFuncSetAttribute((const void*)ivf_lm_flat_reg_kernel<METRIC, true, CT, PASS>,
@@ -1612,6 +1627,11 @@ static bool lm_use_pq_lds(const IvfLmParams& p) {
 }
 int ivf_lm_grid_blocks(const IvfLmParams& p, int num_cus) {
     if (lm_use_pq_lds(p)) return num_cus; // one 8-wave workgroup per CU (the codebook fills its LDS)
+    if (p.kind == 2) { // register-fed kernels in both passes: three workgroups per CU (FAISS_AMD_LM_SQ_WG: experiments)
+        static const char* e = getenv("FAISS_AMD_LM_SQ_WG");
+        const int per = e ? std::max(1, atoi(e)) : LrCfg<0>::WG_PER_CU;
+        return per * num_cus / 8 * 8;
+    }
     // IVFFlat: two 4-wave workgroups per CU for both kernels (pass 1: LDS tiles, 2 x 75 KB; pass 2: registers)
     return ivf_lm_blocks_per_cu(p.kind) * num_cus / 8 * 8;
 }

@@ -18,7 +18,9 @@ xt, xb, xq, dmap = synthetic_dataset(128, 100000, min(nb, 1000000), 10000, seed=
 xq = xq[:nq]
 dev = torch.device("cuda", 0)
 xq_dev = torch.from_numpy(xq).to(dev)
-idx = faiss_amd.GpuIndexIVFPQ(res, 128, NLIST, 64, 8, faiss_amd.METRIC_L2) if kind == "ivfpq" else faiss_amd.GpuIndexIVFFlat(res, 128, NLIST, faiss_amd.METRIC_L2)
+idx = (faiss_amd.GpuIndexIVFPQ(res, 128, NLIST, 64, 8, faiss_amd.METRIC_L2) if kind == "ivfpq"
+       else faiss_amd.GpuIndexIVFScalarQuantizer(res, 128, NLIST, faiss_amd.ScalarQuantizer.QT_8bit, faiss_amd.METRIC_L2, True) if kind == "ivfsq"
+       else faiss_amd.GpuIndexIVFFlat(res, 128, NLIST, faiss_amd.METRIC_L2))
 idx.train(xt); idx.add(xb)
 done, chunk = len(xb), 0
 while done < nb:
