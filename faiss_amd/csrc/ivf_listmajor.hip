@@ -878,14 +878,15 @@ __global__ void __launch_bounds__(LM_THREADS, KIND == 1 ? 3 : 2) ivf_lm_scan_ker
 // slice flushed, the loop re-entered): with loads and stores in one loop hipcc stops counting the loads in flight and
 // waits vmcnt(0) before every use.
 constexpr int LR_THREADS = 256;
-// parked candidates per wave: a whole block (32 rows x 32 queries) always fits an empty slice.  IVFFlat: 1280 (two 60 KB
-// workgroups per CU; 128 registers of operands leave two waves per SIMD anyway); scalar quantizer: 1024, three 48 KB
-// workgroups per CU (16-32 registers of codes: 168 registers, three waves per SIMD)
+// parked candidates per wave: a whole block (32 rows x 32 queries) always fits an empty slice; two 60 KB workgroups per
+// CU.  (The scalar quantizer's instantiations need 16-32 instead of 64 registers of A operands and were measured with
+// 1024-entry slices and three workgroups per CU -- 168 registers, a few of them spilled: 0.364 / 0.359 / 0.368 ms for
+// 2 / 3 / 4 workgroups per CU at nb = 1M, profiles/r03_g_ivfsq_listmajor.txt.  Occupancy is not what the loop lacks.)
 template <int CT>
 struct LrCfg {
-    static constexpr int PARK = CT >= 0 ? 1024 : 1280;
+    static constexpr int PARK = 1280;
     static constexpr int LDS = 4 * PARK * (8 + 4);
-    static constexpr int WG_PER_CU = CT >= 0 ? 3 : 2;
+    static constexpr int WG_PER_CU = 2;
 };
 
 // CT: -1 = IVFFlat (fp32 rows); a SqCodeType = IVF scalar quantizer: the register a[s] holds the 4 CODES of the lane's
@@ -1627,7 +1628,7 @@ static bool lm_use_pq_lds(const IvfLmParams& p) {
 }
 int ivf_lm_grid_blocks(const IvfLmParams& p, int num_cus) {
     if (lm_use_pq_lds(p)) return num_cus; // one 8-wave workgroup per CU (the codebook fills its LDS)
-    if (p.kind == 2) { // register-fed kernels in both passes: three workgroups per CU (FAISS_AMD_LM_SQ_WG: experiments)
+    if (p.kind == 2) { // register-fed kernels in both passes (FAISS_AMD_LM_SQ_WG: occupancy experiments)
         static const char* e = getenv("FAISS_AMD_LM_SQ_WG");
         const int per = e ? std::max(1, atoi(e)) : LrCfg<0>::WG_PER_CU;
         return per * num_cus / 8 * 8;
