@@ -47,7 +47,7 @@ PEAK_F16_MFMA_TFLOPS = 2500.0  # same guide: dense f16/bf16 MFMA (v_mfma_f32_32x
 PEAK_HBM_GBS = 8000.0
 # committed rocprofv3 --pmc summaries (tools/profile_round.sh; one file per profiled search loop)
 PROFILE_DIR = os.path.join(ROOT, "profiles")
-PROFILE_JSON = {"flat": "r03_f_pmc_flat.json", "ivfpq": "r03_f_pmc_ivfpq_1m.json", "ivfsq": "r02_pmc_counters.json",
+PROFILE_JSON = {"flat": "r03_f_pmc_flat.json", "ivfpq": "r03_f_pmc_ivfpq_1m.json", "ivfsq": "r03_g_pmc_ivfsq_1m_listmajor.json",
                 "ivfflat": "r03_f_pmc_ivfflat_1m.json", "ivfflat_10m": "r03_f_pmc_ivfflat_10m.json",
                 "ivfpq_10m": "r03_f_pmc_ivfpq_10m.json"}
 
@@ -295,7 +295,7 @@ def ivf_roofline(spans, list_major, kind, nb, row_bytes, profile=None):
                                 "note": "bytes the query-major formulation moves per search; the list-major scan reads a "
                                         "list once per group of <= 64 queries, so this figure is not bound by the HBM peak"},
             "unique_bytes_per_batch": int(unique),
-            "traffic": committed_lm_traffic(profile or kind, unique)}
+            "traffic": lm_traffic_note(committed_lm_traffic(profile or kind, unique), kind)}
 
 
 def scale_leg(kind, nb, res, xt, xb, xq, xq_dev, dmap, torch, leg_1m, nsample=16):
@@ -451,6 +451,13 @@ def committed_lm_traffic(profile, unique_bytes):
                 "source": rel + " (rocprofv3 --pmc FETCH_SIZE = L2 misses, separate pass; gfx950 2x correction for 16 B/lane reads applied)"}
     except (OSError, KeyError, ValueError, IndexError):
         return None
+
+
+def lm_traffic_note(t, kind):
+    if t and kind == "ivfsq":
+        t["note"] = ("the scalar quantizer's kernels read 4 bytes per lane and load: the x2 correction (prescribed for 16 B/lane "
+                     "reads) makes these figures an upper bound, the raw FETCH_SIZE is half of them")
+    return t
 
 
 def committed_mfma_busy(kernel_substr, profile="flat"):

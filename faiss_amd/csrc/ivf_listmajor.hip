@@ -931,16 +931,34 @@ __global__ void __launch_bounds__(LR_THREADS, LrCfg<CT>::WG_PER_CU) ivf_lm_flat_
     // measured: L2 misses 19.4 -> 14.2 GB per launch at nb = 10M, same time; slower at nb = 1M.  profiles/r03_b_*)
     uint32_t* ctr = p.item_bounds + (PASS == 2 ? 4 : 5); // next item of this pass (zeroed by the plan)
     uint32_t static_it = (uint32_t)(blockIdx.x * 4 + wave); // (dbg 64, timing experiments: a static deal, no counter)
+    __shared__ uint32_t wg_it_s; // (dbg 128, timing experiments: the four waves of a workgroup draw four CONSECUTIVE items)
     for (;;) {
         uint32_t it = 0;
-        if (p.dbg & 64) {
+        bool wg_done = false;
+        if (p.dbg & 128) {
+            // consecutive items are the query groups of one (list, row chunk): drawn together they read the same rows at
+            // the same time (one L2 miss instead of one per group); items of a chunk take the same time whatever their
+            // query count, so the waves meet again at the next draw.  Measured (profiles/r03_g_ivfsq_listmajor.txt): pass 2
+            // at nb = 10M 2.97 / 2.88 -> 3.05 / 3.07 ms, nb = 1M unchanged -- the re-reads are not what the loop waits for.
+            __syncthreads();
+            if (tid == 0) wg_it_s = atomicAdd(ctr, 4u);
+            __syncthreads();
+            const uint32_t base = wg_it_s;
+            wg_done = it0 + base >= it1;
+            it = base + (uint32_t)wave;
+        } else if (p.dbg & 64) {
             it = static_it;
             static_it += gridDim.x * 4;
         } else if (lane == 0) {
             it = atomicAdd(ctr, 1u);
         }
         it = it0 + (uint32_t)__builtin_amdgcn_readfirstlane((int)it);
-        if (it >= it1) break;
+        if (p.dbg & 128) {
+            if (wg_done) break;
+            if (it >= it1) continue;
+        } else if (it >= it1) {
+            break;
+        }
         const IvfLmItem item = p.items[it];
         const int bk = __builtin_amdgcn_readfirstlane(item.bucket);
         const int qt = __builtin_amdgcn_readfirstlane(item.qt);

@@ -2,7 +2,7 @@
 # tools/profile_round.sh TAG -- the rocprofv3 passes behind profiles/<TAG>_* (run on the GPU box through gpurun):
 #   kernel trace + stats of the default bench.py command (scale leg ivfflat_10m included), and one --pmc pass per counter
 #   group on the search loops of the bench legs (counter passes carry --kernel-trace only, never runtime / sys tracing):
-#   flat, IVFPQ nb=1M (query-major), IVFFlat nb=1M (list-major), IVFFlat nb=10M and IVFPQ nb=10M (list-major).
+#   flat, IVFPQ nb=1M (query-major), IVFFlat nb=1M and IVF-SQ8 nb=1M (list-major), IVFFlat nb=10M and IVFPQ nb=10M (list-major).
 TAG=${1:-r03_f}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
@@ -29,6 +29,7 @@ pass() { # name script nb filter groups...
 pass flat flat_only.py 1000000 flat_ "$G_FETCH" "$G_WRITE" "$G_SQ" "$G_WAIT"
 pass ivfpq_1m ivfpq_only.py 1000000 ivf "$G_FETCH" "$G_SQ"
 pass ivfflat_1m ivfflat_only.py 1000000 ivf_lm "$G_FETCH" "$G_SQ"
+pass ivfsq_1m ivfsq_only.py 1000000 ivf_lm "$G_FETCH" "$G_SQ"
 pass ivfflat_10m ivfflat_only.py 10000000 ivf_lm "$G_FETCH" "$G_SQ"
 pass ivfpq_10m ivfpq_only.py 10000000 ivf_lm "$G_FETCH" "$G_SQ"
 head -16 $O/${TAG}_bench_kernel_stats.csv | cut -c1-200
