@@ -209,6 +209,54 @@ def test_ivf4096_1m_vs_oracle_and_live_reference(res, sift_shaped, kind):
     assert np.array_equal(I2, res_by_mode[g2.SCAN_LIST_MAJOR][1]) and np.array_equal(D2, res_by_mode[g2.SCAN_LIST_MAJOR][0])
 
 
+def test_ivfsq8_4096_1m_vs_oracle_and_live_reference(res, sift_shaped):
+    """IVF4096,SQ8 (QT_8bit, residual encoding) at the metric's database size: the reference index with the GPU-trained
+    quantizers is filled by its own add(), its lists are loaded into a second GPU index (copyFrom); nprobe 32, k 100.
+    The automatic choice for 10 000 queries is the list-major scan (ivf_listmajor.hip, kind 2); both scans are compared
+    with the reference on ALL queries and bit-exactly with their own restatement on 48 of them."""
+    if not Ref.available():
+        pytest.skip("oracle/_ref not shipped")
+    from faiss_amd import ScalarQuantizer as SQ
+    xt, xb, xq = sift_shaped
+    g = faiss_amd.GpuIndexIVFScalarQuantizer(res, D_, NLIST, SQ.QT_8bit, METRIC_L2, True)
+    g.train(xt)
+    cent, trained = g.get_centroids(), g.get_trained()
+    ref = Ref.index_factory(D_, "IVF4096,SQ8")
+    ref.set_sq_trained(cent, trained)
+    ref.add(xb)
+    ref.set_nprobe(NPROBE)
+    Dr, Ir = ref.search(xq, K)
+    sizes, codes, lids = ref.lists()
+    g2 = faiss_amd.GpuIndexIVFScalarQuantizer(res, D_, NLIST, SQ.QT_8bit, METRIC_L2, True)
+    g2.copy_centroids(cent)
+    g2.copy_trained(trained)
+    g2.copy_lists(sizes, codes, lids)
+    g2.nprobe = NPROBE
+    vmin, vdiff = Oracle.sq_unpack(SQ.QT_8bit, D_, trained)
+    sel = np.random.RandomState(4).choice(NQ, 48, replace=False)
+    D, I = g2.search(xq, K)
+    assert g2.last_scan_arith() == 1, "10 000 queries x 32 probes over 4096 lists: the list-major scan"
+    for mode in (g2.SCAN_QUERY_MAJOR, g2.SCAN_LIST_MAJOR):
+        g2.set_scan_mode(mode)
+        Dm, Im = g2.search(xq, K)
+        assert g2.scan_info()[1] == mode
+        st = check_knn(Dm, Im, Dr, Ir, rtol=1e-4, max_tie_frac=2e-3, name="ivfsq8 1M scan mode %d vs live reference" % mode)
+        _report("ivfsq8 1M x 10k (scan mode %d)" % mode, st)
+        assert st["max_rel_err"] < 2e-5
+        assert (np.diff(Dm, axis=1) >= 0).all()
+        Do, Io = Oracle.ivfsq_search(SQ.QT_8bit, True, METRIC_L2, cent, sizes, codes, lids, vmin, vdiff, xq[sel], NPROBE, K,
+                                     arith=mode - 1)
+        check_knn(Dm[sel], Im[sel], Do, Io, exact=True, name="ivfsq8 1M scan mode %d vs oracle" % mode)
+        if mode == g2.SCAN_LIST_MAJOR:
+            assert np.array_equal(Dm, D) and np.array_equal(Im, I)
+    assert g2.scan_info()[2] == 0, "no query of this batch should overflow its candidate segment"
+    # native add: the lists the reference builds (up to coarse near-ties), same nearest neighbour
+    g.add(xb)
+    g.nprobe = NPROBE
+    Dn, In = g.search(xq[:2048], K)
+    assert (In[:, 0] == Ir[:2048, 0]).mean() > 0.99
+
+
 # ------------------------------------------------------------------------------- BASELINE.json configs[2]: nb = 10M
 def test_ivfflat_10m_sample_vs_oracle(res):
     """GpuIndexIVFFlat nlist=4096 nprobe=32 at nb = 10M (added in 1M-row chunks, 20 calls of add), a 32-query sample:
