@@ -435,7 +435,9 @@ struct IvfLmParams {
     int rows_per_item;       // multiple of 64
     int force_all;           // every probe in pass 1
     int min_p1;              // at least this many probes of every query in pass 1
-    int dbg;                 // timing experiments (env FAISS_AMD_LM_DBG): 1 no key writes, 2 no MFMAs, 4 no tile loads
+    int dbg;                 // timing experiments (env FAISS_AMD_LM_DBG): 1 no key writes, 2 no MFMAs, 4 no tile loads (LDS-tile
+                             // kernel), 8 rows of four lists only (L2-resident), 64 static deal of the items instead of the
+                             // work counter, 128 workgroup-level draws of four consecutive items (register-fed kernels)
     // ---- candidates
     unsigned long long* keys; // [nq][stride]
     int64_t stride;
