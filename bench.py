@@ -13,7 +13,7 @@ SyntheticDataset recipe, seed 1338).  A "step" is one search of all 10 000 queri
           flop over the time of its two scan launches, with the SURVEY 8d byte figure beside it), the parity of every leg
           against the reference CPU index on ALL queries (every label mismatch classified as near-tie or counted as
           real) and the reference CPU path timed on this node's host cores (`cpu_baseline`).  `ivfflat_10m` and
-          `ivfpq_100m` are BASELINE.json configs[2] and configs[3] (built chunk by chunk; a query sample bit-exact
+          `ivfpq_100m` are BASELINE.json configs[2] and configs[3] (built chunk by chunk, chunks drawn on the device; a query sample bit-exact
           against the oracle run on the probed lists read back from the device; --budget-s bounds the run).
   N > 1 : one process per GPU (torch.distributed, backend "nccl" = RCCL), total work fixed => "scaling": "strong".
           Flat leg (`value`): --multi-gpu replicas (default; what the reference builds for a database that fits one
@@ -315,15 +315,37 @@ def scale_leg(kind, nb, res, xt, xb, xq, xq_dev, dmap, torch, leg_1m, nsample=16
     idx.train(xt)
     t_add = t_gen = 0.0
     done = chunk = 0
+    # Chunks 1.. are drawn ON THE DEVICE (the recipe of faiss_amd/datasets.py synthetic_more in torch: same low-dimensional
+    # map, fresh latent draws from a CUDA generator seeded 1338 + chunk, fp64 like the numpy recipe) and handed to add() as
+    # device pointers: the host recipe costs 2 s per million rows (205 s of a 100M build; nothing of it is measured work).
+    # FAISS_AMD_BENCH_HOST_GEN=1 restores the host generator.
+    host_gen = os.environ.get("FAISS_AMD_BENCH_HOST_GEN") == "1"
+    dev = xq_dev.device
+    proj_d = torch.from_numpy(np.ascontiguousarray(dmap[0], dtype=np.float64)).to(dev)
+    scale_d = torch.from_numpy(np.ascontiguousarray(dmap[1], dtype=np.float64)).to(dev)
     while done < nb:
+        n_c = len(xb) if chunk == 0 else min(1000000, nb - done)
         t1 = time.time()
-        xbc = xb if chunk == 0 else synthetic_more(dmap, min(1000000, nb - done), seed=1338 + chunk)
+        if chunk == 0:
+            xbc = xb
+        elif host_gen:
+            xbc = synthetic_more(dmap, n_c, seed=1338 + chunk)
+        else:
+            g = torch.Generator(device=dev)
+            g.manual_seed(1338 + chunk)
+            lat = torch.randn((n_c, proj_d.shape[0]), generator=g, device=dev, dtype=torch.float64)
+            xbc = torch.sin(torch.matmul(lat, proj_d) * scale_d).to(torch.float32).contiguous()
+            torch.cuda.synchronize()
         t_gen += time.time() - t1
         t1 = time.time()
-        idx.add(xbc)
+        if isinstance(xbc, np.ndarray):
+            idx.add(xbc)
+        else:
+            idx.add_ptr(n_c, xbc.data_ptr())
         t_add += time.time() - t1
-        done += len(xbc)
+        done += n_c
         chunk += 1
+        del xbc
     t_build = time.time() - t0
     idx.nprobe = NPROBE
     Dd = torch.empty((NQ, K), dtype=torch.float32, device=xq_dev.device)
@@ -360,6 +382,10 @@ def scale_leg(kind, nb, res, xt, xb, xq, xq_dev, dmap, torch, leg_1m, nsample=16
             "GpuIndexIVFPQ PQ%dx8" % PQ_M if pq else "GpuIndexIVFFlat", NLIST, NPROBE, D, nb, NQ, K, 3 if pq else 2),
         "scan": "list-major (ivf_listmajor.hip)" if list_major else "query-major (ivf_fused.hip)",
         "qps": round(NQ / dt, 1), "ms_per_step": round(dt * 1e3, 3), "steps": steps,
+        "generator": ("chunk 0 = the flat leg's 1M database; chunks 1.. " +
+                      ("synthetic_more(seed 1338 + chunk) on the host" if host_gen else
+                       "drawn on the device (torch CUDA generator seeded 1338 + chunk through the SyntheticDataset map in fp64) "
+                       "and added from device buffers")),
         "build_s": round(t_build, 1), "add_s": round(t_add, 1), "data_generation_s": round(t_gen, 1),
         "add_M_vectors_per_s": round(nb / t_add / 1e6, 2),
         "arena_rows_over_vectors": round(alloc / float(nb), 3), "overflow_queries": int(idx.scan_info()[2]),
@@ -726,7 +752,7 @@ def main():
             except Exception as e:  # noqa: BLE001
                 line["predicted_per_rank_ms"] = {"error": repr(e)[:300]}
             ivf_idx.clear()
-            need = {"ivfflat_10m": 60.0, "ivfpq_100m": 330.0}
+            need = {"ivfflat_10m": 45.0, "ivfpq_100m": 90.0}  # device-side generation (scale_leg)
             for name in [v for v in args.scale_legs.split(",") if v in need]:
                 if time.time() - t_start + need[name] > args.budget_s:
                     line[name] = {"skipped": "--budget-s %.0f would be exceeded (%.0f s used, ~%.0f s needed)"
