@@ -181,9 +181,12 @@ def ivf_leg(kind, res, xt, xb, xq, xq_dev, gt_first, steps, torch, with_cpu=True
     Dd = torch.empty((NQ, K), dtype=torch.float32, device=xq_dev.device)
     Id = torch.empty((NQ, K), dtype=torch.int64, device=xq_dev.device)
     time_search(idx, torch, NQ, xq_dev.data_ptr(), Dd.data_ptr(), Id.data_ptr(), 1, 1)
+    # throughput from a loop without instrumentation; kernel times from a second loop with a HIP-event span around every
+    # launch (an event record is a barrier packet: the ~20 of an IVF search cost these 1 ms searches ~0.1 ms each)
+    dt = time_search(idx, torch, NQ, xq_dev.data_ptr(), Dd.data_ptr(), Id.data_ptr(), steps, 0)
     res.profile_enable(True)
     res.profile_reset()
-    dt = time_search(idx, torch, NQ, xq_dev.data_ptr(), Dd.data_ptr(), Id.data_ptr(), steps, 0)
+    dt_spans = time_search(idx, torch, NQ, xq_dev.data_ptr(), Dd.data_ptr(), Id.data_ptr(), max(3, steps // 2), 0)
     spans = collect_spans(res)
     res.profile_enable(False)
     list_major = idx.scan_info()[1] == 2
@@ -196,6 +199,9 @@ def ivf_leg(kind, res, xt, xb, xq, xq_dev, gt_first, steps, torch, with_cpu=True
         "workload": "%s nlist=%d nprobe=%d d=%d nb=%d nq=%d k=%d" % (title, NLIST, NPROBE, D, NB, NQ, K),
         "scan": "list-major (ivf_listmajor.hip)" if list_major else "query-major (ivf_fused.hip)",
         "qps": round(NQ / dt, 1), "ms_per_step": round(dt * 1e3, 3),
+        "ms_per_step_with_event_spans": round(dt_spans * 1e3, 3),
+        "timing": "qps / ms_per_step: loop of searches without instrumentation; kernels_ms and roofline: a second loop with a "
+                  "HIP-event span around every launch",
         "qps_host_buffers": round(NQ / dt_host, 1),
         "recall_at_1": round(float((I[:, 0] == gt_first).mean()), 4),
         "recall_at_100": round(float((I == gt_first[:, None]).any(axis=1).mean()), 4),
@@ -351,10 +357,11 @@ def scale_leg(kind, nb, res, xt, xb, xq, xq_dev, dmap, torch, leg_1m, nsample=16
     Dd = torch.empty((NQ, K), dtype=torch.float32, device=xq_dev.device)
     Id = torch.empty((NQ, K), dtype=torch.int64, device=xq_dev.device)
     time_search(idx, torch, NQ, xq_dev.data_ptr(), Dd.data_ptr(), Id.data_ptr(), 1, 1)
-    steps = 3 if nb <= 20000000 else 2
+    steps = 5 if nb <= 20000000 else 3
+    dt = time_search(idx, torch, NQ, xq_dev.data_ptr(), Dd.data_ptr(), Id.data_ptr(), steps, 0)  # no instrumentation
     res.profile_enable(True)
     res.profile_reset()
-    dt = time_search(idx, torch, NQ, xq_dev.data_ptr(), Dd.data_ptr(), Id.data_ptr(), steps, 0)
+    dt_spans = time_search(idx, torch, NQ, xq_dev.data_ptr(), Dd.data_ptr(), Id.data_ptr(), 2, 0)
     spans = collect_spans(res)
     res.profile_enable(False)
     list_major = idx.scan_info()[1] == 2
@@ -382,6 +389,7 @@ def scale_leg(kind, nb, res, xt, xb, xq, xq_dev, dmap, torch, leg_1m, nsample=16
             "GpuIndexIVFPQ PQ%dx8" % PQ_M if pq else "GpuIndexIVFFlat", NLIST, NPROBE, D, nb, NQ, K, 3 if pq else 2),
         "scan": "list-major (ivf_listmajor.hip)" if list_major else "query-major (ivf_fused.hip)",
         "qps": round(NQ / dt, 1), "ms_per_step": round(dt * 1e3, 3), "steps": steps,
+        "ms_per_step_with_event_spans": round(dt_spans * 1e3, 3),
         "generator": ("chunk 0 = the flat leg's 1M database; chunks 1.. " +
                       ("synthetic_more(seed 1338 + chunk) on the host" if host_gen else
                        "drawn on the device (torch CUDA generator seeded 1338 + chunk through the SyntheticDataset map in fp64) "
