@@ -1988,7 +1988,7 @@ void GpuIndexIVF::search_core_(idx_t n, const float* x, idx_t k, float* distance
     FA_THROW_IF_NOT_MSG(scan_mode >= 0 && scan_mode <= 2, "scan_mode must be 0 (auto), 1 (query-major) or 2 (list-major)");
     if (scan_mode == 2) {
         FA_THROW_IF_NOT_MSG(lm_capable_(), "list-major scan: index type / dimension not supported (IVFFlat, IVFPQ, scalar "
-                            "quantizer with 8-bit / 4-bit / fp16 codes; d <= 128)");
+                            "quantizer; d <= 128)");
         FA_THROW_IF_NOT_MSG(!sel, "list-major scan: IDSelector searches take the query-major scan");
         cur_lm_ = true;
     } else {
@@ -2507,7 +2507,7 @@ void GpuIndexIVFScalarQuantizer::upload_tables_() {
     HIP_CHECK(hipMemcpy(sq_b_.p, b.data(), (size_t)dsq_ * 4, hipMemcpyHostToDevice));
     // list-major scan: offsets of the CENTRED codes, b' = fmaf(mid, s, b) (kernels.h IvfLmParams)
     {
-        const float mid = ct_ == SQ_U8 ? 127.5f : ct_ == SQ_U4 ? 7.5f : 0.f;
+        const float mid = ct_ == SQ_U8 ? 127.5f : ct_ == SQ_U4 ? 7.5f : ct_ == SQ_U6 ? 31.5f : 0.f;
         std::vector<float> bm(dsq_, 0.f);
         for (int i = 0; i < d; i++) bm[i] = std::fmaf(mid, s[i], b[i]);
         sq_bm_.ensure((size_t)dsq_ * 4);

@@ -559,7 +559,7 @@ class GpuIndexIVFScalarQuantizer : public GpuIndexIVF {
     void train_residual_(idx_t n, const float* x_dev_pad) override;
     void append_(int n, const float* x_pad, const int64_t* d_labels, const int64_t* d_dest) override;
     void scan_(int nq, const float* xq_pad, int k, const int64_t* h_qoff) const override;
-    // list-major scan (ivf_listmajor.hip, kind 2): 8-bit, 4-bit and fp16 codes, d <= 128
+    // list-major scan (ivf_listmajor.hip, kind 2): every code type, d <= 128
     void lists_changed_() override;
     bool lm_capable_() const override;
     void fill_lm_(struct IvfLmParams& p) const override;

@@ -107,9 +107,9 @@ bool ivf_lm_supported(int kind, int dpad, int M, int d) {
     if (dpad > 128 || (dpad & 7)) return false;
     if (kind == 0) return true;
     if (kind == 1) return M >= 1 && d % M == 0;
-    // scalar quantizer: the codes a lane's MFMA operand takes are whole bytes for 8-bit, 4-bit and fp16 codes (6-bit
-    // fields straddle them: that type keeps the query-major scan)
-    if (kind == 2) return M == SQ_U8 || M == SQ_U4 || M == SQ_F16;
+    // scalar quantizer: every code type (6-bit fields: the 24 bits of an operand group straddle dwords and are cut out of
+    // a dword pair with one v_alignbit)
+    if (kind == 2) return M == SQ_U8 || M == SQ_U4 || M == SQ_U6 || M == SQ_F16;
     return false;
 }
 
@@ -117,31 +117,57 @@ bool ivf_lm_supported(int kind, int dpad, int M, int d) {
 // bytes of one 16-component chunk
 template <int CT>
 struct LmSq {
-    static constexpr int CHB = CT == SQ_U8 ? 16 : CT == SQ_U4 ? 8 : 32;
-    static constexpr int PIECE = CHB / 4; // bytes of the 4 components 8 s + 4 h + e of a lane's MFMA operand group
+    static constexpr int CHB = CT == SQ_U8 ? 16 : CT == SQ_U4 ? 8 : CT == SQ_U6 ? 12 : 32;
+    // bytes of the 4 components 8 s + 4 h + e of a lane's MFMA operand group (6-bit codes: 3 bytes, not addressable as
+    // such -- see lm_sq_piece_off / lm_sq_piece_shift)
+    static constexpr int PIECE = CHB / 4;
+    static constexpr float MID = CT == SQ_U8 ? 127.5f : CT == SQ_U4 ? 7.5f : CT == SQ_U6 ? 31.5f : 0.f;
 };
-// component e (0..3) of a 4-component piece (8-bit: a dword; 4-bit: 16 bits; fp16: two dwords) as the matrix pipe sees it:
-// integer codes CENTRED on the middle of their range (code - 127.5 / code - 7.5, exact in fp32; the offset b the query
-// operand carries is moved by the same amount, kernels.h IvfLmParams::sq_b).  Uncentred, |a|^2 and |s o code|^2 are
-// ~10 x the distance they cancel to (both vectors sit half a range away from the origin) and the rounding of the three
-// terms shows at 4e-5 of the distances at the bench shape; centred it is the rounding of the distance itself.
+// piece g (0..3) of a row's chunk = its components 4 g .. 4 g + 3.  Byte offset of the load that fetches it and, for 6-bit
+// codes, the bit position of the piece inside the loaded dword pair: pieces start at bytes 0, 3, 6, 9 of the 12-byte
+// chunk, i.e. in dwords 0, 0, 1, 2 at bits 0, 24, 16, 8.  (The pair of piece 3 ends one dword behind the chunk: the next
+// row's bytes, the next chunk of the block or the arena's padding -- loaded, shifted out.)
 template <int CT>
-__device__ __forceinline__ float lm_sq_comp(const uint2 w, int e) {
+__device__ __forceinline__ int lm_sq_piece_off(int g) {
+    if constexpr (CT == SQ_U6) return g < 2 ? 0 : 4 * (g - 1);
+    else return g * LmSq<CT>::PIECE;
+}
+__device__ __forceinline__ int lm_sq_piece_shift(int g) { // 6-bit codes only
+    return (32 - 8 * g) & 31;
+}
+// component e (0..3) of a 4-component piece (8-bit: a dword; 4-bit: 16 bits; 6-bit: 24 bits at bit `sh` of a dword pair;
+// fp16: two dwords) as the matrix pipe sees it: integer codes CENTRED on the middle of their range (code - 127.5 / 7.5 /
+// 31.5, exact in fp32; the offset b the query operand carries is moved by the same amount, kernels.h
+// IvfLmParams::sq_b).  Uncentred, |a|^2 and |s o code|^2 are ~10 x the distance they cancel to (both vectors sit half a
+// range away from the origin) and the rounding of the three terms shows at 4e-5 of the distances at the bench shape;
+// centred it is the rounding of the distance itself.
+template <int CT>
+__device__ __forceinline__ float lm_sq_comp(const uint2 w, int e, int sh = 0) {
     if constexpr (CT == SQ_U8) {
         return __fsub_rn((float)((w.x >> (8 * e)) & 255u), 127.5f);
     } else if constexpr (CT == SQ_U4) {
         return __fsub_rn((float)((w.x >> (4 * e)) & 15u), 7.5f);
+    } else if constexpr (CT == SQ_U6) {
+        const unsigned v = __builtin_amdgcn_alignbit(w.y, w.x, (unsigned)sh); // ({w.y, w.x} >> sh)[31:0]
+        return __fsub_rn((float)((v >> (6 * e)) & 63u), 31.5f);
     } else {
         const unsigned v = e < 2 ? w.x : w.y;
         return (float)__builtin_bit_cast(_Float16, (unsigned short)(v >> (16 * (e & 1))));
     }
 }
+// the load of a piece: `ptr` = the row's chunk bytes + lm_sq_piece_off(g)
+struct __attribute__((packed, aligned(4))) LmDwordPair {
+    unsigned x, y;
+};
 template <int CT>
 __device__ __forceinline__ uint2 lm_sq_load_piece(const uint8_t* ptr) {
     if constexpr (CT == SQ_U8) {
         return uint2{*(const unsigned*)ptr, 0u};
     } else if constexpr (CT == SQ_U4) {
         return uint2{(unsigned)*(const unsigned short*)ptr, 0u};
+    } else if constexpr (CT == SQ_U6) {
+        const LmDwordPair v = *(const LmDwordPair*)ptr; // (dword-aligned, not 8-byte-aligned)
+        return uint2{v.x, v.y};
     } else {
         return *(const uint2*)ptr;
     }
@@ -203,12 +229,12 @@ __global__ void ivfsq_row_norms_kernel(const uint8_t* __restrict__ arena, int ld
         const uint8_t* ch = rp + (size_t)c * 64 * CHB;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const uint2 w = lm_sq_load_piece<CT>(ch + g * LmSq<CT>::PIECE);
+            const uint2 w = lm_sq_load_piece<CT>(ch + lm_sq_piece_off<CT>(g));
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int j = 16 * c + 4 * g + e;
                 if (j < d) {
-                    const float cf = lm_sq_comp<CT>(w, e);
+                    const float cf = lm_sq_comp<CT>(w, e, lm_sq_piece_shift(g));
                     const float v = CT == SQ_F16 ? cf : __fmul_rn(sq_s[j], cf);
                     acc = __fmaf_rn(v, v, acc);
                 }
@@ -224,6 +250,7 @@ void launch_ivfsq_row_norms(const uint8_t* arena, int ct, int ld, int d, const f
     switch (ct) {
         case SQ_U8: hipLaunchKernelGGL(ivfsq_row_norms_kernel<SQ_U8>, grid, block, 0, stream, arena, ld, d, sq_s, dest, row0, n, out); break;
         case SQ_U4: hipLaunchKernelGGL(ivfsq_row_norms_kernel<SQ_U4>, grid, block, 0, stream, arena, ld, d, sq_s, dest, row0, n, out); break;
+        case SQ_U6: hipLaunchKernelGGL(ivfsq_row_norms_kernel<SQ_U6>, grid, block, 0, stream, arena, ld, d, sq_s, dest, row0, n, out); break;
         case SQ_F16: hipLaunchKernelGGL(ivfsq_row_norms_kernel<SQ_F16>, grid, block, 0, stream, arena, ld, d, sq_s, dest, row0, n, out); break;
         default: FA_THROW_MSG("list-major scan: scalar-quantizer code type without row norms");
     }
@@ -632,9 +659,10 @@ __global__ void __launch_bounds__(LM_THREADS, KIND == 1 ? 3 : 2) ivf_lm_scan_ker
                     const uint8_t* ch = blk + (size_t)c * 64 * chb;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        if (ct == SQ_U8) sq_pf[i][g] = lm_sq_load_piece<SQ_U8>(ch + 4 * g);
-                        else if (ct == SQ_U4) sq_pf[i][g] = lm_sq_load_piece<SQ_U4>(ch + 2 * g);
-                        else sq_pf[i][g] = lm_sq_load_piece<SQ_F16>(ch + 8 * g);
+                        if (ct == SQ_U8) sq_pf[i][g] = lm_sq_load_piece<SQ_U8>(ch + lm_sq_piece_off<SQ_U8>(g));
+                        else if (ct == SQ_U4) sq_pf[i][g] = lm_sq_load_piece<SQ_U4>(ch + lm_sq_piece_off<SQ_U4>(g));
+                        else if (ct == SQ_U6) sq_pf[i][g] = lm_sq_load_piece<SQ_U6>(ch + lm_sq_piece_off<SQ_U6>(g));
+                        else sq_pf[i][g] = lm_sq_load_piece<SQ_F16>(ch + lm_sq_piece_off<SQ_F16>(g));
                     }
                 }
             }
@@ -692,6 +720,9 @@ __global__ void __launch_bounds__(LM_THREADS, KIND == 1 ? 3 : 2) ivf_lm_scan_ker
                             } else if (ct == SQ_U4) {
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) v[e] = lm_sq_comp<SQ_U4>(sq_pf[i][g], e);
+                            } else if (ct == SQ_U6) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = lm_sq_comp<SQ_U6>(sq_pf[i][g], e, lm_sq_piece_shift(g));
                             } else {
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) v[e] = lm_sq_comp<SQ_F16>(sq_pf[i][g], e);
@@ -1023,13 +1054,20 @@ __global__ void __launch_bounds__(LR_THREADS, LrCfg<CT>::WG_PER_CU) ivf_lm_flat_
             // s >> 1 at byte ((s & 1) * 2 + h) * PIECE of the row's chunk bytes)
             typedef typename std::conditional<CT >= 0, uint2, f32x4>::type areg_t;
             const float* arow = nullptr;
-            const uint8_t* crow = nullptr;
+            const uint8_t* crow = nullptr;     // piece of the EVEN operand groups of this lane (g = h) in chunk 0 of its row
+            const uint8_t* crow_odd = nullptr; // ... of the odd ones (g = 2 + h)
+            int sh_even = 0, sh_odd = 0;       // 6-bit codes: bit position of those pieces in the loaded dword pair
             int64_t cstep0 = 0, cstep1 = 0; // byte steps to the next 32-row block from an even / odd half of a code block
             int nch1 = 7;                   // last chunk of a row (rows shorter than 8 chunks: the surplus pieces re-read it)
             if constexpr (CT >= 0) {
-                constexpr int CHB = LmSq<CT < 0 ? 0 : CT>::CHB, PIECE = LmSq<CT < 0 ? 0 : CT>::PIECE;
+                constexpr int CTT = CT < 0 ? 0 : CT;
+                constexpr int CHB = LmSq<CTT>::CHB;
                 const int64_t R = start + t;
-                crow = p.arena_codes + (R >> 6) * 64 * (int64_t)p.sq_ld + (int64_t)(((int)R & 63) + j) * CHB + h * PIECE;
+                const uint8_t* rowc = p.arena_codes + (R >> 6) * 64 * (int64_t)p.sq_ld + (int64_t)(((int)R & 63) + j) * CHB;
+                crow = rowc + lm_sq_piece_off<CTT>(h);
+                crow_odd = rowc + lm_sq_piece_off<CTT>(2 + h);
+                sh_even = lm_sq_piece_shift(h);
+                sh_odd = lm_sq_piece_shift(2 + h);
                 cstep0 = 32 * CHB;
                 cstep1 = 64 * (int64_t)p.sq_ld - 32 * CHB;
                 nch1 = p.sq_ld / CHB - 1;
@@ -1038,15 +1076,15 @@ __global__ void __launch_bounds__(LR_THREADS, LrCfg<CT>::WG_PER_CU) ivf_lm_flat_
             }
             auto load_a = [&](int s) __attribute__((always_inline)) -> areg_t {
                 if constexpr (CT >= 0) {
-                    constexpr int CHB = LmSq<CT < 0 ? 0 : CT>::CHB, PIECE = LmSq<CT < 0 ? 0 : CT>::PIECE;
+                    constexpr int CHB = LmSq<CT < 0 ? 0 : CT>::CHB;
                     const int c = FULL ? (s >> 1) : min(s >> 1, nch1);
-                    return lm_sq_load_piece<CT < 0 ? 0 : CT>(crow + c * 64 * CHB + (s & 1) * 2 * PIECE);
+                    return lm_sq_load_piece<CT < 0 ? 0 : CT>(((s & 1) ? crow_odd : crow) + c * 64 * CHB);
                 } else {
                     return *(const f32x4*)(arow + 8 * s);
                 }
             };
-            auto comp_a = [&](const areg_t& v, int e) __attribute__((always_inline)) -> float {
-                if constexpr (CT >= 0) return lm_sq_comp<CT < 0 ? 0 : CT>(v, e);
+            auto comp_a = [&](const areg_t& v, int e, int s) __attribute__((always_inline)) -> float {
+                if constexpr (CT >= 0) return lm_sq_comp<CT < 0 ? 0 : CT>(v, e, (s & 1) ? sh_odd : sh_even);
                 else return v[e];
             };
             areg_t a[16];
@@ -1058,7 +1096,11 @@ __global__ void __launch_bounds__(LR_THREADS, LrCfg<CT>::WG_PER_CU) ivf_lm_flat_
             const float* rnp = p.arena_rn + start + t + 4 * h; // rn of rows 8 g + 4 h + e of the block: rnp[8 g + e]
             bool full = false; // the slice cannot take the candidates of the block in hand: leave, flush, come back
             for (; t < r1; t += 32) {
-                if constexpr (CT >= 0) crow += (((int)(start & 63) + t) & 32) ? cstep1 : cstep0;
+                if constexpr (CT >= 0) {
+                    const int64_t step = (((int)(start & 63) + t) & 32) ? cstep1 : cstep0;
+                    crow += step;
+                    crow_odd += step;
+                }
                 else arow += 32 * p.ldv;
                 rnp += 32;
                 f32x16 acc;
@@ -1074,7 +1116,7 @@ __global__ void __launch_bounds__(LR_THREADS, LrCfg<CT>::WG_PER_CU) ivf_lm_flat_
                     if (FULL || s < ns) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(comp_a(a[s], e), bq[s][e], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(comp_a(a[s], e, s), bq[s][e], acc, 0, 0, 0);
                     }
                     // refill for the next block right behind the MFMAs that consumed a[s]
                     a[s] = load_a(s);
@@ -1198,6 +1240,7 @@ static void lr_launch_sq(const IvfLmParams& p, int pass, int grid_blocks, hipStr
     switch (p.sq_ct) {
         case SQ_U8: lr_launch<METRIC, SQ_U8>(p, pass, grid_blocks, stream); break;
         case SQ_U4: lr_launch<METRIC, SQ_U4>(p, pass, grid_blocks, stream); break;
+        case SQ_U6: lr_launch<METRIC, SQ_U6>(p, pass, grid_blocks, stream); break;
         case SQ_F16: lr_launch<METRIC, SQ_F16>(p, pass, grid_blocks, stream); break;
         default: FA_THROW_MSG("list-major scan: scalar-quantizer code type not supported");
     }

@@ -410,7 +410,7 @@ constexpr int kLmRowsPerItem = 1024; // rows of a list per work item (16 tiles);
 constexpr int kLmQueriesPerItem = 64; // two 32-query blocks (x the two 32-row blocks of a tile = 4 waves)
 struct IvfLmParams {
     int metric;
-    int kind; // 0 = IVFFlat, 1 = IVFPQ, 2 = IVF scalar quantizer (round 3, late: 8-bit / 4-bit / fp16 codes)
+    int kind; // 0 = IVFFlat, 1 = IVFPQ, 2 = IVF scalar quantizer (round 3, second session)
     int nq, nprobe, d, dpad, nlist, k;
     const float* xq; // [nq][ldq] padded queries
     int64_t ldq;
@@ -454,7 +454,7 @@ struct IvfLmParams {
     int64_t ldc;
     // IVF scalar quantizer (kind 2): arena_codes in the chunk-major 64-row blocks of sq_code_offset; component j of a row
     // decodes to b_j + s_j * code_j (fp16 codes: the half itself).  The scan never materialises it.  With the codes
-    // centred on the middle of their range, code' = code - mid (mid = 127.5 for 8-bit, 7.5 for 4-bit codes, 0 for fp16),
+    // centred on the middle of their range, code' = code - mid (mid = 127.5 / 31.5 / 7.5 for 8- / 6- / 4-bit codes, 0 for fp16),
     // b' = fmaf(mid, s, b) and a = (q [- centroid]) - b', the B operand is a o s and the A operand code' as a float:
     //   L2  max(0, fmaf(-2, <a o s, code'>, |a|^2 + |s o code'|^2)),   IP  (<q, b'> + coarse) + <q o s, code'>
     // (|s o code'|^2 per stored row in arena_rn, launch_ivfsq_row_norms; |a|^2 and <q, b'> as the two interleaved half

@@ -425,7 +425,7 @@ int faiss_amd_GpuIndexIVF_set_use_fused_scan(FaissAmdIndex* index, int on);
 /* Which scan serves search() / search_preassigned() of an IVF index (no reference counterpart: the reference has one
  * scan per index type, faiss/gpu/impl/IVFInterleaved.cuh:33-224, PQScanMultiPassNoPrecomputed-inl.cuh:173-270, both
  * query-major).  0 = automatic: batches of >= 2048 queries that probe every list >= 8 times on average, without
- * IDSelector, on IVFFlat / IVFPQ / the scalar quantizer's 8-bit, 4-bit and fp16 codes with d <= 128 take the list-major
+ * IDSelector, on IVFFlat / IVFPQ / IVF scalar-quantizer indexes with d <= 128 take the list-major
  * scan (faiss_amd/csrc/ivf_listmajor.hip: every list is read once per group of up to 64 of the queries probing it,
  * distances on the f32 matrix pipe); 1 = query-major always; 2 = list-major always (an error where unsupported).  The
  * two scans sum in different orders: each is bit-exact against its own restatement in oracle/faiss_oracle.c

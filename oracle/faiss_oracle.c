@@ -732,9 +732,9 @@ int orc_ivfsq_search(int qtype, int by_residual, int metric, int d, int nlist, c
     return orc_ivfsq_search_ex(qtype, by_residual, metric, d, nlist, centroids, list_sizes, codes, ids, vmin, vdiff, nq, xq,
                                nprobe, k, D, I, 0);
 }
-/* arith 1: the list-major scan of large batches (faiss_amd/csrc/ivf_listmajor.hip, kind 2; 8-bit, 4-bit and fp16 codes).
+/* arith 1: the list-major scan of large batches (faiss_amd/csrc/ivf_listmajor.hip, kind 2).
  * The reconstruction is never formed.  The codes are centred on the middle of their range, code' = code - mid (127.5 /
- * 7.5 / 0 for 8-bit / 4-bit / fp16 codes; exact), the offset moves with them, b' = fmaf(mid, s, b) (fp16: s = 1, b' = 0);
+ * 31.5 / 7.5 / 0 for 8-bit / 6-bit / 4-bit / fp16 codes; exact), the offset moves with them, b' = fmaf(mid, s, b) (fp16: s = 1, b' = 0);
  * with a_j = ((q_j - centroid_j) - b'_j) (no residual encoding: centroid = 0) the matrix pipe multiplies w = a o s with
  * the centred codes,
  *   L2: max(0, fmaf(-2, <w, code'>, |a|^2 + |s o code'|^2)),   IP: (<q, b'> + coarse) + <q o s, code'>
@@ -744,7 +744,6 @@ int orc_ivfsq_search_ex(int qtype, int by_residual, int metric, int d, int nlist
                         const uint32_t* list_sizes, const uint8_t* codes, const idx_t* ids, const float* vmin,
                         const float* vdiff, idx_t nq, const float* xq, int nprobe, int k, float* D, idx_t* I, int arith) {
     if (k < 1 || nprobe < 1) return -1;
-    if (arith == 1 && qtype == 6) return -2; /* 6-bit codes keep the query-major scan */
     if (nprobe > nlist) nprobe = nlist;
     const size_t cs = orc_sq_code_size(qtype, d);
     idx_t* list_start = (idx_t*)malloc(sizeof(idx_t) * (size_t)(nlist + 1));
@@ -756,7 +755,7 @@ int orc_ivfsq_search_ex(int qtype, int by_residual, int metric, int d, int nlist
     float* s = (float*)malloc(sizeof(float) * (size_t)d * 2);
     float* b = s + d;
     orc_sq_tables(qtype, d, vmin, vdiff, s, b);
-    const float mid = (qtype == 0 || qtype == 2 || qtype == 5) ? 127.5f : (qtype == 1 || qtype == 3) ? 7.5f : 0.f;
+    const float mid = (qtype == 0 || qtype == 2 || qtype == 5) ? 127.5f : (qtype == 1 || qtype == 3) ? 7.5f : qtype == 6 ? 31.5f : 0.f;
     if (arith == 1)
         for (int j = 0; j < d; j++) {
             if (qtype == 4) s[j] = 1.f;

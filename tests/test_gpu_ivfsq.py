@@ -222,7 +222,7 @@ def test_ivfsq_incremental_adds_nan_rows_reset(res):
 
 
 # ---------------------------------------------------------------------- list-major scan (ivf_listmajor.hip, kind 2)
-LM_QTYPES = [SQ.QT_8bit, SQ.QT_4bit, SQ.QT_8bit_uniform, SQ.QT_4bit_uniform, SQ.QT_fp16, SQ.QT_8bit_direct]
+LM_QTYPES = QTYPES
 
 
 def _lm_check(idx, qtype, metric, by_residual, xq, nprobe, k, nsel=48):
@@ -254,7 +254,7 @@ def _lm_check(idx, qtype, metric, by_residual, xq, nprobe, k, nsel=48):
 @pytest.mark.parametrize("metric", [METRIC_L2, METRIC_INNER_PRODUCT])
 @pytest.mark.parametrize("qtype", LM_QTYPES, ids=[QNAMES[q] for q in LM_QTYPES])
 def test_ivfsq_list_major_matches_oracle_and_query_major(res, qtype, metric, by_residual):
-    """Every code type the list-major kernels decode x metric x residual flag, d = 40 (dpad 40, rows of three 16-component
+    """Every code type x metric x residual flag, d = 40 (dpad 40, rows of three 16-component
     chunks, the last one half filled; 32-row blocks in both halves of the 64-row code blocks, ragged list ends)."""
     d, nlist, nb, nq, nprobe, k = 40, 32, 20000, 700, 6, 50
     xt, xb, xq = _data(qtype, d, 6000, nb, nq, seed=31 + qtype)
@@ -275,6 +275,8 @@ def test_ivfsq_list_major_matches_oracle_and_query_major(res, qtype, metric, by_
     (SQ.QT_4bit_uniform, METRIC_INNER_PRODUCT, True, 64, 32, 5000, 130, 5, 2048),  # k above the rows many queries see
     (SQ.QT_8bit_direct, METRIC_L2, False, 16, 8, 5000, 1200, 5, 2048),      # one chunk per row, k at the limit
     (SQ.QT_8bit, METRIC_L2, True, 8, 16, 9000, 300, 16, 7),                 # d = 8: half a chunk, every list probed
+    (SQ.QT_6bit, METRIC_L2, True, 128, 64, 30000, 900, 8, 100),             # 6-bit fields cut out of dword pairs, unrolled kernels
+    (SQ.QT_6bit, METRIC_INNER_PRODUCT, False, 72, 8, 20000, 700, 2, 300),   # ... dpad 72, row chunks
 ])
 def test_ivfsq_list_major_shapes(res, qtype, metric, by_residual, d, nlist, nb, nq, nprobe, k):
     xt, xb, xq = _data(qtype, d, max(4000, 40 * nlist), nb, nq, seed=nb + k)
@@ -298,18 +300,17 @@ def test_ivfsq_list_major_rule_and_refusals(res):
     D1, I1 = idx.search(xq[:100], 10)
     assert idx.scan_info()[1] == 1
     check_knn(D[:100], I[:100], D1, I1, rtol=1e-4, tie_rtol=1e-4, name="auto: list-major vs query-major")
-    # 6-bit fields straddle the operand groups: that type keeps the query-major scan; so does d > 128
-    six = faiss_amd.GpuIndexIVFScalarQuantizer(res, d, nlist, SQ.QT_6bit, METRIC_L2, True)
-    six.train(xt)
-    six.add(xb)
-    assert not six.list_major_rule(2500)
-    six.search(xq, 10)
-    assert six.scan_info()[1] == 1
-    six.set_scan_mode(six.SCAN_LIST_MAJOR)
-    with pytest.raises(RuntimeError):
-        six.search(xq, 10)
+    # d > 128 keeps the query-major scan
+    xt2, xb2, xq2 = synthetic_dataset(136, 3000, 4000, 2100, seed=5)
     wide = faiss_amd.GpuIndexIVFScalarQuantizer(res, 136, nlist, SQ.QT_8bit, METRIC_L2, True)
+    wide.train(xt2)
+    wide.add(xb2)
     assert not wide.list_major_rule(2500)
+    wide.search(xq2, 10)
+    assert wide.scan_info()[1] == 1
+    wide.set_scan_mode(wide.SCAN_LIST_MAJOR)
+    with pytest.raises(RuntimeError):
+        wide.search(xq2, 10)
 
 
 def test_ivfsq_list_major_row_norms_follow_the_rows(res):

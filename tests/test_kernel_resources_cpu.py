@@ -111,9 +111,9 @@ def test_list_major_scan(usage):
     for name, u in picked.items():
         assert u["scratch"] <= 48 and u["occupancy"] >= 2, (name, u)
     # the register-fed pass-2 kernel of IVFFlat: 64 + 64 registers of operands per lane, two waves per SIMD, no scratch;
-    # the scalar quantizer's instantiations (8-bit, 4-bit, fp16 codes: 16 / 16 / 32 registers of codes) likewise
+    # the scalar quantizer's instantiations (8-bit, 4-bit, 6-bit, fp16 codes: 16 / 16 / 32 / 32 registers of codes) likewise
     picked = _pick(usage, "ivf_lm_flat_reg_kernel")
-    assert len(picked) == 32  # metric x (dpad == 128) x (fp32 rows, three code types) x pass
+    assert len(picked) == 40  # metric x (dpad == 128) x (fp32 rows, four code types) x pass
     for name, u in picked.items():
         assert u["scratch"] == 0 and u["occupancy"] >= 2, (name, u)
     for name, u in _pick(usage, "ivf_lm_pq_kernel").items():
