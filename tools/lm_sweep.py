@@ -23,10 +23,17 @@ idx = (faiss_amd.GpuIndexIVFPQ(res, 128, NLIST, 64, 8, faiss_amd.METRIC_L2) if k
        else faiss_amd.GpuIndexIVFFlat(res, 128, NLIST, faiss_amd.METRIC_L2))
 idx.train(xt); idx.add(xb)
 done, chunk = len(xb), 0
-while done < nb:
+proj_d = torch.from_numpy(np.ascontiguousarray(dmap[0], dtype=np.float64)).to(dev)
+scale_d = torch.from_numpy(np.ascontiguousarray(dmap[1], dtype=np.float64)).to(dev)
+while done < nb:  # further chunks drawn on the device (bench.py scale_leg): the host recipe costs 2 s per million rows
     chunk += 1
-    xbc = synthetic_more(dmap, min(1000000, nb - done), seed=1338 + chunk)
-    idx.add(xbc); done += len(xbc)
+    n_c = min(1000000, nb - done)
+    g = torch.Generator(device=dev); g.manual_seed(1338 + chunk)
+    lat = torch.randn((n_c, proj_d.shape[0]), generator=g, device=dev, dtype=torch.float64)
+    xbc = torch.sin(torch.matmul(lat, proj_d) * scale_d).to(torch.float32).contiguous()
+    torch.cuda.synchronize()
+    idx.add_ptr(n_c, xbc.data_ptr()); done += n_c
+    del xbc, lat
 idx.nprobe = NPROBE
 idx.set_scan_mode(2)
 Dd = torch.empty((nq, K), dtype=torch.float32, device=dev)
