@@ -573,7 +573,7 @@ def main():
                     help="BASELINE.json configs[2] / configs[3] on one GPU (comma-separated subset, empty = none)")
     ap.add_argument("--budget-s", type=float, default=900.0,
                     help="a scale leg is started only while the run is expected to stay inside this many seconds "
-                         "(ivfflat_10m needs ~40 s, ivfpq_100m ~300 s)")
+                         "(ivfflat_10m needs ~10 s, ivfpq_100m ~20 s since the chunks are drawn on the device)")
     ap.add_argument("--multi-gpu", choices=["replicas", "shards"], default="replicas",
                     help="layout of the FLAT leg at N > 1: replicas = every GPU holds the database, queries are split "
                          "(IndexReplicas, the reference's default for databases that fit one GPU); shards = rows are split "

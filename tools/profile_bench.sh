@@ -1,16 +1,13 @@
 #!/bin/bash
-# tools/profile_bench.sh TAG -- kernel trace + stats of the default bench.py command only (the first step of
-# tools/profile_round.sh, without the PMC passes): profiles/<TAG>_bench_line.json, _bench_kernel_stats.csv,
-# _dominant_kernel_dispatches.csv.  Run on the GPU box through gpurun.
-TAG=${1:-r02_g}
+# tools/profile_bench.sh TAG -- rocprofv3 kernel trace + stats of the DEFAULT bench command (all legs, the driver's
+# --steps 20 --warmup 5), run on the GPU box through gpurun; outputs under gpurun_out/<TAG>_*.
+TAG=${1:-r03_j}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
-mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_kt -o kt -- python $R/bench.py --steps 10 --warmup 2 > $O/${TAG}_bench.log 2>&1
-grep '^{' $O/${TAG}_bench.log | tail -1 > $O/${TAG}_bench_line.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_kt -o kt -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 > $O/${TAG}_profiled_bench.log 2>&1
+grep '^{' $O/${TAG}_profiled_bench.log | tail -1 > $O/${TAG}_profiled_bench_line.json
 find $O/${TAG}_kt -name "*kernel_stats.csv" -exec cp {} $O/${TAG}_bench_kernel_stats.csv \;
-python $R/tools/dispatch_summary.py $O/${TAG}_kt $O/${TAG}_dominant_kernel_dispatches.csv flat_filter_kernel flat_rerank_kernel ivfpq_fused_kernel ivfflat_fused_kernel ivfsq_fused_kernel ivf_finish_kernel
-head -16 $O/${TAG}_bench_kernel_stats.csv | cut -c1-180
-tail -3 $O/${TAG}_bench.log | cut -c1-600
+python $R/tools/dispatch_summary.py $O/${TAG}_kt $O/${TAG}_dominant_kernel_dispatches.csv flat_filter_kernel ivfpq_fused_kernel ivf_lm_flat_reg_kernel ivf_lm_scan_kernel ivf_lm_pq_kernel select_k_kernel wave_select_kernel
+head -14 $O/${TAG}_bench_kernel_stats.csv | cut -c1-180
 rm -rf $O/${TAG}_kt
