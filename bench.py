@@ -151,7 +151,7 @@ def time_search(index, torch, n, xq_ptr, d_ptr, i_ptr, steps, warmup):
     return (time.perf_counter() - t0) / steps
 
 
-def ivf_leg(kind, res, xt, xb, xq, xq_dev, gt_first, steps, torch, with_cpu=True):
+def ivf_leg(kind, res, xt, xb, xq, xq_dev, gt_first, steps, torch, with_cpu=True, sweep=False):
     """IVF4096,PQ64 / IVF4096,Flat at nb = 1M (BASELINE.json configs[3] / configs[2] at the metric's database size):
     native train + add on the GPU, nprobe = 32, the reference CPU index with the SAME quantizers as baseline and as
     parity reference (it is filled by its own add(); its lists are then also loaded into a second GPU index, so the
@@ -253,7 +253,66 @@ def ivf_leg(kind, res, xt, xb, xq, xq_dev, gt_first, steps, torch, with_cpu=True
             out["speedup_vs_cpu"] = round(out["qps"] / cpu["value"], 1)
         except Exception as e:  # noqa: BLE001
             out["cpu_baseline"] = {"error": repr(e)[:300]}
+            ref = None
+    else:
+        ref = None
+    if sweep:
+        try:
+            out["nprobe_sweep"] = nprobe_sweep(idx, ref, xq, xq_dev, gt_first, torch, pq)
+        except Exception as e:  # noqa: BLE001
+            out["nprobe_sweep"] = {"error": repr(e)[:300]}
+        idx.nprobe = NPROBE
     return out, idx
+
+
+SWEEP_NPROBES = (1, 2, 4, 8, 16, 32, 64, 128, 256, 512)
+
+
+def nprobe_sweep(idx, ref, xq, xq_dev, gt_first, torch, pq):
+    """QPS @ recall over nprobe = 1 ... 512 (the operating-point sweep of benchs/bench_gpu_sift1m.py:81-89) at nb = 1M,
+    k = 100, all 10 000 queries: the GPU index (queries / results in HBM, 3 timed searches per point after one warm-up)
+    and -- when the compiled reference is there -- the reference CPU index holding the same quantizers (`ref`, filled by its
+    own add()), one timed search of all queries per point on the effective host cores.  R@1 / R@100 against the exact
+    ground truth (the Flat leg's labels)."""
+    Dd = torch.empty((NQ, K), dtype=torch.float32, device=xq_dev.device)
+    Id = torch.empty((NQ, K), dtype=torch.int64, device=xq_dev.device)
+    rows = []
+    for npb in SWEEP_NPROBES:
+        idx.nprobe = npb
+        dt = time_search(idx, torch, NQ, xq_dev.data_ptr(), Dd.data_ptr(), Id.data_ptr(), 3, 1)
+        I = Id.cpu().numpy()
+        row = {"nprobe": npb, "qps": round(NQ / dt, 1), "ms": round(dt * 1e3, 3),
+               "scan": "list-major" if idx.scan_info()[1] == 2 else "query-major",
+               "recall_at_1": round(float((I[:, 0] == gt_first).mean()), 4),
+               "recall_at_100": round(float((I == gt_first[:, None]).any(axis=1).mean()), 4)}
+        if ref is not None:
+            ref.set_nprobe(npb)
+            t0 = time.time()
+            _, Ir = ref.search(xq, K)
+            dtc = time.time() - t0
+            row.update({"cpu_qps": round(NQ / dtc, 1), "cpu_recall_at_1": round(float((Ir[:, 0] == gt_first).mean()), 4),
+                        "cpu_recall_at_100": round(float((Ir == gt_first[:, None]).any(axis=1).mean()), 4),
+                        "speedup_vs_cpu": round(dtc / dt, 1)})
+        rows.append(row)
+    if ref is not None:
+        ref.set_nprobe(NPROBE)
+    best = max(rows, key=lambda r: r["recall_at_1"])
+    first95 = next((r for r in rows if r["recall_at_1"] >= 0.95), None)
+    first95_100 = next((r for r in rows if r["recall_at_100"] >= 0.95), None)
+    return {"points": rows,
+            "what": "nb=1M, nq=10k, k=100; GPU: queries / results in HBM; cpu_*: faiss 1.15.0 CPU index with the same quantizers, "
+                    "%d OpenMP threads" % effective_cores(),
+            "best_recall_at_1": {"nprobe": best["nprobe"], "recall_at_1": best["recall_at_1"], "qps": best["qps"]},
+            "smallest_nprobe_with_recall_at_1_ge_0.95": ({"nprobe": first95["nprobe"], "qps": first95["qps"],
+                                                           "cpu_qps": first95.get("cpu_qps"),
+                                                           "speedup_vs_cpu": first95.get("speedup_vs_cpu")} if first95 else None),
+            "smallest_nprobe_with_recall_at_100_ge_0.95": ({"nprobe": first95_100["nprobe"], "qps": first95_100["qps"],
+                                                             "cpu_qps": first95_100.get("cpu_qps"),
+                                                             "speedup_vs_cpu": first95_100.get("speedup_vs_cpu")}
+                                                            if first95_100 else None),
+            "note": ("PQ64 quantisation error caps R@1 (the exact nearest neighbour is not always the nearest code): the "
+                     "curve above is that cap measured; R@100 is the gate this leg claims" if pq else
+                     "IVFFlat distances are exact: R@1 = the fraction of queries whose nearest neighbour lies in a probed list")}
 
 
 SPAN_NAMES = ("ivf_lm_plan", "ivf_lm_scan_pass1", "ivf_lm_threshold", "ivf_lm_scan_pass2", "select_k_kernel",
@@ -304,15 +363,36 @@ def ivf_roofline(spans, list_major, kind, nb, row_bytes, profile=None):
             "traffic": lm_traffic_note(committed_lm_traffic(profile or kind, unique), kind)}
 
 
-def scale_leg(kind, nb, res, xt, xb, xq, xq_dev, dmap, torch, leg_1m, nsample=16):
+def sample_vs_oracle(idx, pq, xq, sel, Dg, Ig, list_major):
+    """The queries `sel` of a search of an IVF index, BIT-EXACT against the oracle restatement (arith = the scan that
+    served the search) run on the lists they probe, read back from the device; the coarse assignment is compared too.
+    Returns (exact, entries read back, (Do, Io) = the oracle's results for the sample)."""
+    from oracle.pyoracle import METRIC_L2, Oracle
+    cent = idx.get_centroids()
+    pqc = idx.get_pq_centroids() if pq else None
+    Dq, Iq = idx.quantizer_search(xq[sel], NPROBE)
+    sizes = np.zeros(NLIST, dtype=np.uint32)
+    codes, ids = [], []
+    for l in np.unique(Iq):
+        sizes[l] = idx.get_list_size(int(l))
+        codes.append(idx.get_list_codes(int(l)))
+        ids.append(idx.get_list_ids(int(l)))
+    codes, ids = np.concatenate(codes), np.concatenate(ids)
+    Do, Io, cD, cI = Oracle.ivf_search(1 if pq else 0, METRIC_L2, cent, sizes, codes, ids, xq[sel], NPROBE, K,
+                                       M=PQ_M if pq else 0, pq=pqc, arith=1 if list_major else 0)
+    exact = bool(np.array_equal(cI, Iq) and np.array_equal(cD, Dq) and np.array_equal(Io, Ig[sel]) and np.array_equal(Do, Dg[sel]))
+    return exact, len(ids), (Do, Io)
+
+
+def scale_leg(kind, nb, res, xt, xb, xq, xq_dev, dmap, torch, leg_1m, nsample=16, with_cpu=True, cpu_budget_s=20.0):
     """BASELINE.json configs[2] (GpuIndexIVFFlat nb = 10M) / configs[3] (GpuIndexIVFPQ PQ64 nb = 100M) on one MI355X:
     the index is built chunk by chunk from the generator (never more than 1M rows on the host), all 10 000 queries are
     searched (k = 100, nprobe = 32, queries / results in HBM), `nsample` of them are checked BIT-EXACTLY against the
     oracle restatement run on the lists they probe, read back from the device; all results are checked for order and
-    label validity.  The reference CPU index is not built at this size: `cpu_baseline` is the figure
-    measured at nb = 1M with the same quantizers and nprobe, scaled by the list length, and says so."""
+    label validity.  `cpu_baseline` is MEASURED at this size (cpu_baseline_on_gpu_lists): a reference CPU index with the
+    same quantizers is filled with the very lists the GPU index holds and searched on the node's host cores."""
     import faiss_amd
-    from faiss_amd.datasets import synthetic_more
+    from faiss_amd.datasets import synthetic_more, synthetic_more_device
     from oracle.pyoracle import METRIC_L2, Oracle
     pq = kind == "ivfpq"
     idx = (faiss_amd.GpuIndexIVFPQ(res, D, NLIST, PQ_M, 8, faiss_amd.METRIC_L2) if pq
@@ -321,14 +401,12 @@ def scale_leg(kind, nb, res, xt, xb, xq, xq_dev, dmap, torch, leg_1m, nsample=16
     idx.train(xt)
     t_add = t_gen = 0.0
     done = chunk = 0
-    # Chunks 1.. are drawn ON THE DEVICE (the recipe of faiss_amd/datasets.py synthetic_more in torch: same low-dimensional
-    # map, fresh latent draws from a CUDA generator seeded 1338 + chunk, fp64 like the numpy recipe) and handed to add() as
-    # device pointers: the host recipe costs 2 s per million rows (205 s of a 100M build; nothing of it is measured work).
-    # FAISS_AMD_BENCH_HOST_GEN=1 restores the host generator.
+    # Chunks 1.. are drawn ON THE DEVICE (faiss_amd.datasets.synthetic_more_device: the SyntheticDataset map in fp64 on fresh
+    # latent draws of a CUDA generator seeded 1338 + chunk) and handed to add() as device pointers: the host recipe costs
+    # 2 s per million rows (205 s of a 100M build; nothing of it is measured work).  FAISS_AMD_BENCH_HOST_GEN=1 restores
+    # the host generator.
     host_gen = os.environ.get("FAISS_AMD_BENCH_HOST_GEN") == "1"
     dev = xq_dev.device
-    proj_d = torch.from_numpy(np.ascontiguousarray(dmap[0], dtype=np.float64)).to(dev)
-    scale_d = torch.from_numpy(np.ascontiguousarray(dmap[1], dtype=np.float64)).to(dev)
     while done < nb:
         n_c = len(xb) if chunk == 0 else min(1000000, nb - done)
         t1 = time.time()
@@ -337,11 +415,7 @@ def scale_leg(kind, nb, res, xt, xb, xq, xq_dev, dmap, torch, leg_1m, nsample=16
         elif host_gen:
             xbc = synthetic_more(dmap, n_c, seed=1338 + chunk)
         else:
-            g = torch.Generator(device=dev)
-            g.manual_seed(1338 + chunk)
-            lat = torch.randn((n_c, proj_d.shape[0]), generator=g, device=dev, dtype=torch.float64)
-            xbc = torch.sin(torch.matmul(lat, proj_d) * scale_d).to(torch.float32).contiguous()
-            torch.cuda.synchronize()
+            xbc = synthetic_more_device(dmap, n_c, 1338 + chunk, dev)
         t_gen += time.time() - t1
         t1 = time.time()
         if isinstance(xbc, np.ndarray):
@@ -369,19 +443,7 @@ def scale_leg(kind, nb, res, xt, xb, xq, xq_dev, dmap, torch, leg_1m, nsample=16
     ok_order = bool((np.diff(Dg, axis=1) >= 0).all() and (Ig >= 0).all() and (Ig < nb).all())
     # ---- sample parity: oracle on the probed lists read back from the device
     sel = np.random.RandomState(3).choice(NQ, nsample, replace=False)
-    cent = idx.get_centroids()
-    pqc = idx.get_pq_centroids() if pq else None
-    Dq, Iq = idx.quantizer_search(xq[sel], NPROBE)
-    sizes = np.zeros(NLIST, dtype=np.uint32)
-    codes, ids = [], []
-    for l in np.unique(Iq):
-        sizes[l] = idx.get_list_size(int(l))
-        codes.append(idx.get_list_codes(int(l)))
-        ids.append(idx.get_list_ids(int(l)))
-    codes, ids = np.concatenate(codes), np.concatenate(ids)
-    Do, Io, cD, cI = Oracle.ivf_search(1 if pq else 0, METRIC_L2, cent, sizes, codes, ids, xq[sel], NPROBE, K,
-                                       M=PQ_M if pq else 0, pq=pqc, arith=1 if list_major else 0)
-    exact = bool(np.array_equal(cI, Iq) and np.array_equal(cD, Dq) and np.array_equal(Io, Ig[sel]) and np.array_equal(Do, Dg[sel]))
+    exact, nread, _ = sample_vs_oracle(idx, pq, xq, sel, Dg, Ig, list_major)
     row_bytes = PQ_M if pq else D * 4
     used, holes, alloc = idx.arena_stats()
     out = {
@@ -400,17 +462,60 @@ def scale_leg(kind, nb, res, xt, xb, xq, xq_dev, dmap, torch, leg_1m, nsample=16
         "roofline": ivf_roofline(spans, list_major, kind, nb, row_bytes, profile="%s_%dm" % (kind, nb // 1000000)),
         "kernels_ms": {k: round(v[0] / max(v[1], 1), 3) for k, v in spans.items() if v[1]},
         "parity": {"sampled_queries_bit_exact_vs_oracle_on_probed_lists": exact, "sampled_queries": int(nsample),
-                   "probed_list_entries_read_back": int(len(ids)), "all_results_ordered_and_labels_valid": ok_order},
+                   "probed_list_entries_read_back": int(nread), "all_results_ordered_and_labels_valid": ok_order},
     }
-    base = (leg_1m or {}).get("cpu_baseline", {})
-    if isinstance(base.get("value"), (int, float)):
-        out["cpu_baseline"] = {"value": round(base["value"] * NB / nb, 1), "unit": "QPS", "cores": base.get("cores"),
-                               "kind": "reference, SCALED (not measured at this size)",
-                               "sample": "the nb=1M figure of this run (%s) x %g: the scan cost of an IVF search is linear in "
-                                         "the list length; the reference index is not built at nb=%d (BASELINE.md 3.6)"
-                                         % (base.get("sample", "")[:80], NB / float(nb), nb)}
-        out["speedup_vs_cpu"] = round(out["qps"] / out["cpu_baseline"]["value"], 1)
+    if with_cpu:
+        try:
+            out["cpu_baseline"] = cpu_baseline_on_gpu_lists(kind, idx, nb, xq, Dg, Ig, leg_1m, cpu_budget_s)
+            if isinstance(out["cpu_baseline"].get("value"), (int, float)):
+                out["speedup_vs_cpu"] = round(out["qps"] / out["cpu_baseline"]["value"], 1)
+        except Exception as e:  # noqa: BLE001
+            out["cpu_baseline"] = {"error": repr(e)[:300]}
+    else:
+        out["cpu_baseline"] = {"not_measured": "--no-cpu-baseline"}
     del idx
+    return out
+
+
+def cpu_baseline_on_gpu_lists(kind, idx, nb, xq, Dg, Ig, leg_1m, budget_s):
+    """The reference CPU index (faiss 1.15.0 IndexIVFFlat / IndexIVFPQ, compiled unmodified into oracle/_ref) AT THE SCALE
+    of the leg: it gets the GPU index's quantizers and the GPU index's inverted lists (read back list by list and appended
+    with InvertedLists::add_entries -- what GpuIndexIVF::copyTo does, faiss/gpu/impl/IVFBase.cu:328-344), so both sides
+    scan identical lists; no CPU add() of 10M-100M vectors is paid.  Timed: IndexIVF::search of a bounded query sample
+    (sized from the nb = 1M figure of this run so that it takes ~budget_s; the figure printed is measured, never
+    scaled), on the effective host cores.  The sample's results are compared with the GPU's (classify_parity)."""
+    from oracle.pyoracle import Ref
+    if not Ref.available():
+        return {"not_measured": "oracle/_ref (the compiled reference) was not shipped"}
+    pq = kind == "ivfpq"
+    cores = effective_cores()
+    Ref.set_threads(cores)
+    t0 = time.time()
+    ref = Ref.index_factory(D, "IVF%d,PQ%d" % (NLIST, PQ_M) if pq else "IVF%d,Flat" % NLIST)
+    if pq:
+        ref.set_trained(idx.get_centroids(), idx.get_pq_centroids())
+    else:
+        ref.set_centroids(idx.get_centroids())
+    for l in range(NLIST):
+        ref.add_list_entries(l, idx.get_list_ids(l), idx.get_list_codes(l))
+    t_fill = time.time() - t0
+    assert ref.ntotal == nb, (ref.ntotal, nb)
+    ref.set_nprobe(NPROBE)
+    qps_1m = ((leg_1m or {}).get("cpu_baseline") or {}).get("value")
+    est_qps = qps_1m * NB / float(nb) if isinstance(qps_1m, (int, float)) else 200.0  # only sizes the sample
+    ns = int(max(64, min(NQ, budget_s * est_qps)))
+    ref.search(xq[:min(ns, 64)], K)  # warm-up
+    t0 = time.time()
+    Dr, Ir = ref.search(xq[:ns], K)
+    dt = time.time() - t0
+    out = {"value": round(ns / dt, 1), "unit": "QPS", "cores": int(cores), "kind": "reference",
+           "sample": "faiss 1.15.0 %s.search MEASURED at nb=%d: the first %d of the %d queries in one batch (%.1f s), nprobe=%d, "
+                     "k=%d, %d OpenMP threads; the index holds the GPU index's quantizers and its inverted lists (read back "
+                     "and appended with add_entries in %.1f s: no CPU add at this size)"
+                     % ("IndexIVFPQ" if pq else "IndexIVFFlat", nb, ns, NQ, dt, NPROBE, K, cores, t_fill),
+           "search_s": round(dt, 2), "queries": int(ns), "fill_s": round(t_fill, 1),
+           "parity_vs_gpu": classify_parity(Dg[:ns], Ig[:ns], Dr, Ir)}
+    del ref
     return out
 
 
@@ -561,6 +666,137 @@ def sharded_ivfpq_leg(res, rank, world, dev, xt, xb, xq_dev, steps, torch, dist)
     return info, (out if rank == 0 else None)
 
 
+def sharded_sample_check(local_exact, Do, Io, merged_D, merged_I, metric, dist_mod, rank, world):
+    """Parity of a sharded search on a query sample, without moving the shards: every rank has compared ITS local top-k
+    bit-exactly with the oracle restatement run on ITS lists (`local_exact`, oracle results Do / Io with global ids);
+    top-k of a union = top-k of the per-part top-k's, so the oracle's answer for the union of the shards is the k-way
+    merge of the per-rank oracle results under (distance, id) (Oracle.merge_shards, the rule of the device merge kernel
+    and of faiss/utils/Heap.cpp:166-240 merge_knn_results).  Rank 0 compares the merged GPU result with it.
+    Returns on rank 0: {"per_shard_bit_exact": [...], "merged_bit_exact": bool}; None elsewhere."""
+    from oracle.pyoracle import Oracle
+    if world > 1:
+        box = [None] * world
+        dist_mod.all_gather_object(box, (bool(local_exact), Do, Io))
+    else:
+        box = [(bool(local_exact), Do, Io)]
+    if rank != 0:
+        return None
+    aD = np.stack([b[1] for b in box])
+    aI = np.stack([b[2] for b in box])
+    Dm, Im = Oracle.merge_shards(metric, aD, aI)
+    return {"per_shard_bit_exact": [b[0] for b in box],
+            "merged_bit_exact": bool(np.array_equal(Dm, merged_D) and np.array_equal(Im, merged_I))}
+
+
+def sharded_scale_leg(res, rank, world, dev, xt, xb, xq, xq_dev, dmap, rows_per_rank, steps, torch, dist, nsample):
+    """BASELINE.json configs[4]: IndexShards over the ranks for IVF4096,PQ64 at nb = world x rows_per_rank (8 x 125M = 1B).
+    Rank 0 trains the coarse quantizer and the PQ codebook, one broadcast ships them (the only collective); rank r draws
+    ITS rows on ITS device (chunk seeds = 1338 + global chunk number: the union of the shards is one database whatever
+    the world size) and adds them with their GLOBAL ids; every rank searches all 10 000 queries on its shard (nprobe 32,
+    k 100); the per-rank top-k are gathered point-to-point onto rank 0 and merged by the device select kernel -- gather
+    and merge INSIDE the timed region (faiss/IndexShards.cpp:196-265, gpu/GpuCloner.cpp:368-391).  Per-GPU work is fixed
+    as N grows: weak scaling.  Parity: sharded_sample_check on `nsample` queries."""
+    import faiss_amd
+    from faiss_amd.datasets import synthetic_more_device
+    from faiss_amd.distributed import ShardedSearcher, broadcast_arrays, shard_chunks
+    idx = faiss_amd.GpuIndexIVFPQ(res, D, NLIST, PQ_M, 8, faiss_amd.METRIC_L2)
+    t0 = time.time()
+    if rank == 0:
+        idx.train(xt)
+        cent, pqc = idx.get_centroids(), idx.get_pq_centroids()
+    else:
+        cent = np.empty((NLIST, D), dtype=np.float32)
+        pqc = np.empty((PQ_M, 256, D // PQ_M), dtype=np.float32)
+    cent, pqc = broadcast_arrays([cent, pqc], dev)
+    if rank != 0:
+        idx.copy_centroids(cent)
+        idx.copy_pq_centroids(pqc)
+    t_train = time.time() - t0
+    t0 = time.time()
+    for gchunk, id0, n_c in shard_chunks(rows_per_rank, rank):
+        if gchunk == 0:
+            x0 = np.ascontiguousarray(xb[:n_c])  # global chunk 0 = the flat leg's database, like the single-GPU scale legs
+            idx.add_with_ids(x0, np.arange(id0, id0 + n_c, dtype=np.int64))
+        else:
+            xbc = synthetic_more_device(dmap, n_c, 1338 + gchunk, dev)
+            idx.add_with_ids_ptr(n_c, xbc.data_ptr(), np.arange(id0, id0 + n_c, dtype=np.int64))
+            del xbc
+    t_build = time.time() - t0
+    idx.nprobe = NPROBE
+    D_loc = torch.empty((NQ, K), dtype=torch.float32, device=dev)
+    I_loc = torch.empty((NQ, K), dtype=torch.int64, device=dev)
+    D_out = torch.empty((NQ, K), dtype=torch.float32, device=dev)
+    I_out = torch.empty((NQ, K), dtype=torch.int64, device=dev)
+
+    def local_search(_xq, k):
+        idx.search_ptr(NQ, xq_dev.data_ptr(), k, D_loc.data_ptr(), I_loc.data_ptr())
+        return D_loc, I_loc
+
+    def merge(all_D, all_I, _base):
+        if all_D.shape[0] == 1:
+            return all_D[0], all_I[0]
+        torch.cuda.current_stream().synchronize()  # gathered tensors complete before the library's stream reads them
+        faiss_amd.merge_knn_results_device(res, faiss_amd.METRIC_L2, NQ, K, all_D.shape[0], all_D.data_ptr(),
+                                           all_I.data_ptr(), None, D_out.data_ptr(), I_out.data_ptr())
+        return D_out, I_out
+
+    s = ShardedSearcher(local_search, merge, [0] * world, dev)
+    s.search(xq_dev, K)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = s.search(xq_dev, K)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    dt = float(el.item()) / steps
+    # kernel spans of this rank's local search (a second, instrumented loop)
+    res.profile_enable(True)
+    res.profile_reset()
+    for _ in range(2):
+        local_search(None, K)
+    torch.cuda.synchronize()
+    spans = collect_spans(res)
+    res.profile_enable(False)
+    list_major = idx.scan_info()[1] == 2
+    # ---- parity on a query sample (every rank: its shard vs the oracle; rank 0: the merge)
+    sel = np.random.RandomState(5).choice(NQ, nsample, replace=False)
+    Dl, Il = D_loc.cpu().numpy(), I_loc.cpu().numpy()
+    local_exact, nread, (Do, Io) = sample_vs_oracle(idx, True, xq, sel, Dl, Il, list_major)
+    merged = (out[0].cpu().numpy()[sel], out[1].cpu().numpy()[sel]) if rank == 0 else (None, None)
+    par = sharded_sample_check(local_exact, Do, Io, merged[0], merged[1], faiss_amd.METRIC_L2, dist, rank, world)
+    ovf = int(idx.scan_info()[2])
+    del idx
+    if rank != 0:
+        return None
+    nb_total = rows_per_rank * world
+    Ig = out[1].cpu().numpy()
+    Dg = out[0].cpu().numpy()
+    par.update({"sampled_queries": int(nsample), "probed_list_entries_read_back_on_rank0": int(nread),
+                "all_results_ordered_and_labels_valid": bool((np.diff(Dg, axis=1) >= 0).all() and (Ig >= 0).all()
+                                                             and (Ig < nb_total).all())})
+    return {
+        "workload": "IndexShards over %d x MI355X: GpuIndexIVFPQ PQ%dx8 nlist=%d nprobe=%d d=%d nb=%d (%d rows per GPU) nq=%d "
+                    "k=%d (BASELINE.json configs[4] at %d of its 8 shards)" % (world, PQ_M, NLIST, NPROBE, D, nb_total,
+                                                                              rows_per_rank, NQ, K, world),
+        "scaling": "weak (rows per GPU fixed; all queries to every shard)",
+        "qps": round(NQ / dt, 1), "ms_per_step": round(dt * 1e3, 3), "steps": int(steps),
+        "timed_region": "local search of all queries on every rank + point-to-point gather of the per-rank top-k onto rank 0 "
+                        "+ device merge; barrier + synchronize on both sides, max over ranks",
+        "scan": "list-major (ivf_listmajor.hip)" if list_major else "query-major (ivf_fused.hip)",
+        "train_broadcast_s": round(t_train, 2), "build_s": round(t_build, 1),
+        "add_M_vectors_per_s_per_gpu": round(rows_per_rank / t_build / 1e6, 2), "overflow_queries": ovf,
+        "roofline": ivf_roofline(spans, list_major, "ivfpq", rows_per_rank, PQ_M, profile="ivfpq_100m"),
+        "kernels_ms_rank0": {k: round(v[0] / max(v[1], 1), 3) for k, v in spans.items() if v[1]},
+        "parity": par,
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -569,8 +805,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ivf-legs", default="ivfpq,ivfflat,ivfsq", help="comma-separated subset of the IVF legs to run")
     ap.add_argument("--no-ivf", action="store_true", help="skip the IVF4096,PQ64 / IVF4096,Flat / IVF4096,SQ8 legs")
-    ap.add_argument("--scale-legs", default="ivfflat_10m,ivfpq_100m",
-                    help="BASELINE.json configs[2] / configs[3] on one GPU (comma-separated subset, empty = none)")
+    ap.add_argument("--scale-legs", default="ivfflat_10m,ivfpq_100m,ivfpq_shards",
+                    help="BASELINE.json configs[2] / configs[3] on one GPU and the configs[4] shard (--shard-rows rows per "
+                         "GPU through the sharded code path); comma-separated subset, empty = none")
+    ap.add_argument("--shard-rows", type=int, default=125000000,
+                    help="rows per GPU of the sharded IVF4096,PQ64 leg `ivfpq_shards` (BASELINE.json configs[4]: 8 x 125M = 1B)")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the nprobe sweeps (QPS @ recall curves) of the nb=1M IVF legs")
+    ap.add_argument("--cpu-budget-s", type=float, default=15.0,
+                    help="seconds of reference-CPU search per scale leg (sizes the query sample of its measured cpu_baseline)")
     ap.add_argument("--budget-s", type=float, default=900.0,
                     help="a scale leg is started only while the run is expected to stay inside this many seconds "
                          "(ivfflat_10m needs ~10 s, ivfpq_100m ~20 s since the chunks are drawn on the device)")
@@ -686,6 +928,14 @@ def main():
         except Exception as e:  # noqa: BLE001
             ivfpq_multi, ivf_out = {"error": repr(e)[:300]}, None
 
+    shards_multi = None
+    if world > 1 and not args.no_ivf and "ivfpq_shards" in args.scale_legs.split(","):
+        try:
+            del index
+            shards_multi = sharded_scale_leg(res, rank, world, dev, xt, xb, xq, xq_dev, dmap, args.shard_rows, 3, torch, dist, 8)
+        except Exception as e:  # noqa: BLE001
+            shards_multi = {"error": repr(e)[:300]}
+
     if rank != 0:
         # leave together with rank 0 (which still assembles and prints the line)
         dist.barrier()
@@ -752,7 +1002,8 @@ def main():
             for kind in [v for v in args.ivf_legs.split(",") if v in ("ivfpq", "ivfflat", "ivfsq")]:
                 try:
                     line[kind], ivf_idx[kind] = ivf_leg(kind, res, xt, xb, xq, xq_dev, gI[:, 0], max(2, args.steps // 2), torch,
-                                                        with_cpu=not args.no_cpu_baseline)
+                                                        with_cpu=not args.no_cpu_baseline,
+                                                        sweep=not args.no_sweep and kind in ("ivfpq", "ivfflat"))
                 except Exception as e:  # noqa: BLE001
                     line[kind] = {"error": repr(e)[:300]}
             try:
@@ -760,20 +1011,25 @@ def main():
             except Exception as e:  # noqa: BLE001
                 line["predicted_per_rank_ms"] = {"error": repr(e)[:300]}
             ivf_idx.clear()
-            need = {"ivfflat_10m": 45.0, "ivfpq_100m": 90.0}  # device-side generation (scale_leg)
+            # seconds a leg needs (build + search + oracle sample + measured CPU baseline on the GPU's lists)
+            need = {"ivfflat_10m": 60.0, "ivfpq_100m": 150.0, "ivfpq_shards": 90.0}
             for name in [v for v in args.scale_legs.split(",") if v in need]:
                 if time.time() - t_start + need[name] > args.budget_s:
                     line[name] = {"skipped": "--budget-s %.0f would be exceeded (%.0f s used, ~%.0f s needed)"
                                              % (args.budget_s, time.time() - t_start, need[name])}
                     continue
-                kind, nbig = name.split("_")
                 try:
                     del index  # the flat index (0.8 GB) is not needed any more
                 except NameError:
                     pass
                 try:
-                    line[name] = scale_leg(kind, 10000000 if nbig == "10m" else 100000000, res, xt, xb, xq, xq_dev, dmap,
-                                           torch, line.get(kind))
+                    if name == "ivfpq_shards":
+                        line[name] = sharded_scale_leg(res, 0, 1, dev, xt, xb, xq, xq_dev, dmap, args.shard_rows, 3, torch, dist, 16)
+                    else:
+                        kind, nbig = name.split("_")
+                        line[name] = scale_leg(kind, 10000000 if nbig == "10m" else 100000000, res, xt, xb, xq, xq_dev, dmap,
+                                               torch, line.get(kind), with_cpu=not args.no_cpu_baseline,
+                                               cpu_budget_s=args.cpu_budget_s)
                 except Exception as e:  # noqa: BLE001
                     line[name] = {"error": repr(e)[:300]}
     elif ivfpq_multi is not None:
@@ -782,6 +1038,8 @@ def main():
             ivfpq_multi["recall_at_1"] = round(float((I2[:, 0] == gI[:, 0]).mean()), 4)
             ivfpq_multi["recall_at_100"] = round(float((I2 == gI[:, :1]).any(axis=1).mean()), 4)
         line["ivfpq"] = ivfpq_multi
+    if world > 1 and shards_multi is not None:
+        line["ivfpq_shards"] = shards_multi
     print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

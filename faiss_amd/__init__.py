@@ -330,6 +330,17 @@ class Index:
     def add_ptr(self, n, x_ptr):
         _check(self._lib.faiss_amd_Index_add(self._h, int(n), ctypes.c_void_p(x_ptr)))
 
+    def add_with_ids_ptr(self, n, x_ptr, ids):
+        """add_with_ids with the vectors behind a raw (host or device) address; `ids`: numpy int64 [n] or an address"""
+        if isinstance(ids, np.ndarray):
+            ids = np.ascontiguousarray(ids, dtype=np.int64)
+            if ids.shape != (int(n),):
+                raise ValueError("ids must have one entry per vector")
+            ip = _ptr(ids)
+        else:
+            ip = ctypes.c_void_p(ids)
+        _check(self._lib.faiss_amd_Index_add_with_ids(self._h, int(n), ctypes.c_void_p(x_ptr), ip))
+
     def train_ptr(self, x_ptr, n):
         _check(self._lib.faiss_amd_Index_train(self._h, int(n), ctypes.c_void_p(x_ptr)))
 

@@ -36,6 +36,23 @@ def synthetic_more(dmap, n, seed):
     return np.sin(np.dot(x, proj) * scale).astype("float32")
 
 
+def synthetic_more_device(dmap, n, seed, device):
+    """synthetic_more() drawn ON THE DEVICE: the same low-dimensional map (proj, scale) applied in fp64 to fresh latent
+    draws of a torch generator seeded `seed` on `device`; returns a contiguous float32 torch tensor [n][d] that add()
+    takes as a device pointer.  The host recipe costs ~2 s per million rows (numpy normal + a 10 x d matmul in fp64),
+    which is all of the build time of a 100M-1B row database; the rows differ from synthetic_more()'s (another
+    generator), their distribution does not."""
+    import torch
+    proj = torch.from_numpy(np.ascontiguousarray(dmap[0], dtype=np.float64)).to(device)
+    scale = torch.from_numpy(np.ascontiguousarray(dmap[1], dtype=np.float64)).to(device)
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    lat = torch.randn((n, proj.shape[0]), generator=g, device=device, dtype=torch.float64)
+    x = torch.sin(torch.matmul(lat, proj) * scale).to(torch.float32).contiguous()
+    torch.cuda.synchronize(device)
+    return x
+
+
 def integer_dataset(d, nb, nq, seed=7, hi=16):
     """Small-integer coordinates: every partial sum is exact in fp32, so every summation order
     gives identical bits and exact distance ties are frequent (tie-rule stress)."""

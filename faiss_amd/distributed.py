@@ -122,3 +122,33 @@ def replica_bounds(nq, world, granule=128):
 def shard_bounds(nb, world):
     """Row range of every rank, as IndexShards::add splits them (faiss/IndexShards.cpp:172-175)."""
     return [(r * nb // world, (r + 1) * nb // world) for r in range(world)]
+
+
+def shard_chunks(rows_per_rank, rank, chunk_rows=1000000):
+    """Row chunks of rank `rank` of a database of world x rows_per_rank rows split IndexShards-style (rank r owns the
+    global rows [r * rows_per_rank, (r + 1) * rows_per_rank), faiss/IndexShards.cpp:172-175): a list of
+    (global chunk number, first global id, rows).  The global chunk number seeds the generator of the chunk, so the union
+    of the ranks' rows is ONE well-defined database of world x rows_per_rank rows; the global ids are what add_with_ids
+    gets, so the merge needs no label translation (IndexShards with successive_ids = false)."""
+    per = -(-rows_per_rank // chunk_rows)
+    out, done, c = [], 0, 0
+    while done < rows_per_rank:
+        n = min(chunk_rows, rows_per_rank - done)
+        out.append((rank * per + c, rank * rows_per_rank + done, n))
+        done += n
+        c += 1
+    return out
+
+
+def broadcast_arrays(arrays, device, src=0, group=None):
+    """float32 numpy arrays of rank `src` -> every rank (shapes known on every rank; the values of the other ranks are
+    ignored): the trained coarse quantizer and product-quantizer codebook of a sharded IVF index -- the only collective of
+    the layout, once per build (the reference clones one trained CPU index to every device, gpu/GpuCloner.cpp:368-391)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return [np.ascontiguousarray(a, dtype=np.float32) for a in arrays]
+    out = []
+    for a in arrays:
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
+        dist.broadcast(t, src, group=group)
+        out.append(t.cpu().numpy())
+    return out

@@ -389,6 +389,14 @@ class RefIndex:
         self._ck(self.lib.ref_ivf_get_lists(ctypes.c_void_p(self.h), _p(codes), _p(ids)))
         return sizes, codes, ids
 
+    def add_list_entries(self, list_no, ids, codes):
+        """append entries (ids int64 [n], codes uint8 [n][code_size] / float32 rows for IVFFlat) to one inverted list"""
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        codes = np.ascontiguousarray(codes)
+        assert codes.nbytes == len(ids) * self.code_size, (codes.nbytes, len(ids), self.code_size)
+        self._ck(self.lib.ref_ivf_add_list_entries(ctypes.c_void_p(self.h), ctypes.c_int64(int(list_no)),
+                                                   ctypes.c_int64(len(ids)), _p(ids), _p(codes)))
+
     def pq_info(self):
         v = [ctypes.c_int(0) for _ in range(4)]
         self._ck(self.lib.ref_ivfpq_info(ctypes.c_void_p(self.h), *[ctypes.byref(x) for x in v]))

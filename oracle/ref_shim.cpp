@@ -147,6 +147,19 @@ int ref_ivf_get_lists(void* p, uint8_t* codes, idx_t* ids) {
     }
     SHIM_CATCH
 }
+// n entries (ids + code_size-byte codes, the reference's plain [entry][code_size] payload) appended to list `list_no` of
+// a trained IndexIVF: how a CPU index of nb = 10M-100M rows is filled with exactly the lists the GPU index holds (read
+// back list by list) for the measured CPU baselines of bench.py -- invlists->add_entries is what IndexIVF::add_core and
+// GpuIndexIVF::copyTo (faiss/gpu/impl/IVFBase.cu:328-344 copyInvertedListsTo) end in
+int ref_ivf_add_list_entries(void* p, idx_t list_no, idx_t n, const idx_t* ids, const uint8_t* codes) {
+    SHIM_TRY auto* i = ivf(p);
+    FAISS_THROW_IF_NOT(i->is_trained && list_no >= 0 && (size_t)list_no < i->nlist);
+    if (n > 0) {
+        i->invlists->add_entries((size_t)list_no, (size_t)n, ids, codes);
+        i->ntotal += n;
+    }
+    SHIM_CATCH
+}
 int ref_ivfpq_info(void* p, int* M, int* dsub, int* nbits, int* use_precomputed_table) {
     SHIM_TRY auto* i = dynamic_cast<faiss::IndexIVFPQ*>((faiss::Index*)p);
     FAISS_THROW_IF_NOT_MSG(i, "not an IndexIVFPQ");

@@ -180,3 +180,88 @@ def test_replica_bounds():
                                          (6400, 7680), (7680, 8960), (8960, 10000)], 1280)
     assert replica_bounds(10000, 1) == ([(0, 10000)], 10112)
     assert replica_bounds(100, 4) == ([(0, 100), (100, 100), (100, 100), (100, 100)], 128)
+
+
+def _scale_shard_worker(rank, world, port, out_path):
+    """The id / chunk / merge / parity logic of bench.py's configs[4] leg (sharded_scale_leg: N x rows_per_rank rows,
+    chunks seeded by their GLOBAL chunk number, global ids, quantizers broadcast once, per-rank top-k gathered + merged,
+    sharded_sample_check) with the oracle restatement in the role of the device and a numpy generator in the role of
+    synthetic_more_device.  The merged result must equal the search of ONE index over the union of the shards, and
+    sharded_sample_check must say so (and must notice a corrupted shard result)."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    import faiss_amd
+    from faiss_amd.distributed import ShardedSearcher, broadcast_arrays, shard_chunks
+    from oracle.pyoracle import METRIC_L2, Oracle, synthetic_dataset
+
+    d, nlist, M, nq, k, nprobe = 32, 16, 8, 33, 20, 5
+    rows_per_rank, chunk_rows = 2500, 1000  # chunks of 1000, 1000, 500 rows per rank
+    xt, _, xq, dmap = synthetic_dataset(d, 500, 10, nq, seed=9, return_map=True)
+
+    def gen(gchunk, n):  # stand-in for synthetic_more_device: rows depend on the GLOBAL chunk number only
+        from faiss_amd.datasets import synthetic_more
+        return synthetic_more(dmap, n, seed=1338 + gchunk)
+
+    if rank == 0:
+        rs = np.random.RandomState(1)
+        cent = xt[rs.choice(len(xt), nlist, replace=False)]
+        pq = ((rs.rand(M, 256, d // M) - 0.5) * 0.6).astype(np.float32)
+    else:
+        cent, pq = np.zeros((nlist, d), np.float32), np.zeros((M, 256, d // M), np.float32)
+    cent, pq = broadcast_arrays([cent, pq], torch.device("cpu"))
+    plan = shard_chunks(rows_per_rank, rank, chunk_rows)
+    assert [p[2] for p in plan] == [1000, 1000, 500] and plan[0][0] == rank * 3 and plan[0][1] == rank * rows_per_rank
+    rows = np.concatenate([gen(g, n) for g, _, n in plan])
+    gids = np.concatenate([np.arange(i0, i0 + n) for _, i0, n in plan])
+    sizes, codes, ids, _ = Oracle.build_ivf_lists(1, METRIC_L2, cent, rows, ids=gids, pq=pq)
+
+    def local_search(xq_t, kk):
+        D, I, _, _ = Oracle.ivf_search(1, METRIC_L2, cent, sizes, codes, ids, xq_t.numpy(), nprobe, kk, M=M, pq=pq)
+        return torch.from_numpy(D), torch.from_numpy(I)
+
+    def merge(aD, aI, _base):
+        D, I = faiss_amd.merge_knn_results(METRIC_L2, aD.numpy(), aI.numpy(), None)
+        return torch.from_numpy(D), torch.from_numpy(I)
+
+    s = ShardedSearcher(local_search, merge, [0] * world, torch.device("cpu"))
+    out = s.search(torch.from_numpy(xq), k)
+    sel = np.array([0, 7, 32])
+    Dl, Il = local_search(torch.from_numpy(xq), k)
+    Do, Io = Dl.numpy()[sel], Il.numpy()[sel]  # "the oracle on this rank's lists" (here the local search IS the oracle)
+    mD, mI = (out[0].numpy()[sel], out[1].numpy()[sel]) if rank == 0 else (None, None)
+    par = bench.sharded_sample_check(True, Do, Io, mD, mI, METRIC_L2, dist, rank, world)
+    bad = Do.copy()
+    if rank == 1:
+        bad[1, 0] = np.float32(0.0)  # a shard whose restated result differs: the merged comparison must fail
+    par_bad = bench.sharded_sample_check(rank != 1, bad, Io, mD, mI, METRIC_L2, dist, rank, world)
+    if rank == 0:
+        # one index over the union (rows in global-id order)
+        allrows = np.concatenate([gen(g, n) for r in range(world) for g, _, n in shard_chunks(rows_per_rank, r, chunk_rows)])
+        fs, fc, fi, _ = Oracle.build_ivf_lists(1, METRIC_L2, cent, allrows, pq=pq)
+        Df, If, _, _ = Oracle.ivf_search(1, METRIC_L2, cent, fs, fc, fi, xq, nprobe, k, M=M, pq=pq)
+        ok = (np.array_equal(out[1].numpy(), If) and np.array_equal(out[0].numpy(), Df)
+              and par == {"per_shard_bit_exact": [True, True], "merged_bit_exact": True}
+              and par_bad["per_shard_bit_exact"] == [True, False] and not par_bad["merged_bit_exact"])
+        with open(out_path, "w") as f:
+            f.write("OK" if ok else "MISMATCH %r %r" % (par, par_bad))
+    else:
+        assert par is None and par_bad is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_scale_leg_logic_two_ranks_gloo(tmp_path):
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_scale_shard_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert open(out).read() == "OK"
+
+
+def test_shard_chunks():
+    from faiss_amd.distributed import shard_chunks
+    # 8 x 125M rows in 1M-row chunks: rank 7's first chunk is global chunk 875 with ids from 875M
+    c = shard_chunks(125000000, 7)
+    assert len(c) == 125 and c[0] == (875, 875000000, 1000000) and c[-1] == (999, 999000000, 1000000)
+    assert shard_chunks(10, 0, 4) == [(0, 0, 4), (1, 4, 4), (2, 8, 2)] and shard_chunks(10, 1, 4)[0] == (3, 10, 4)
