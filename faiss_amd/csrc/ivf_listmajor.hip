@@ -272,6 +272,10 @@ __global__ void __launch_bounds__(256) lm_plan_kernel(IvfLmParams p) {
     // pass 2 like the lists of the later probes
     const uint32_t r1max = p.force_all ? 0xffffffffu : (uint32_t)p.rows_per_item;
     uint32_t cum = 0, cum1 = 0; // (wave-uniform) totals of the probes before this round
+    // f16 filter scan (ivf_lm_filter.hip): granule slots of the probes, 2 per 32 * gran_blocks rows of a list
+    uint32_t* preg = p.filter ? p.prefixg + (int64_t)q * (np + 1) : nullptr;
+    const uint32_t grows = 32u * (uint32_t)max(p.gran_blocks, 1);
+    uint32_t cumg = 0;
     int p0 = np;
     for (int base = 0; base < np; base += 64) {
         const int pr = base + lane;
@@ -291,6 +295,17 @@ __global__ void __launch_bounds__(256) lm_plan_kernel(IvfLmParams p) {
             pre[pr] = cum + inc - len;
             pre1[pr] = cum1 + inc1 - len1;
         }
+        if (p.filter) {
+            const uint32_t lg = 2u * ((len + grows - 1) / grows);
+            uint32_t incg = lg;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t o = __shfl_up(incg, off, 64);
+                if (lane >= off) incg += o;
+            }
+            if (pr < np) preg[pr] = cumg + incg - lg;
+            cumg += __shfl(incg, 63, 64);
+        }
         // first probe after which pass 1 has seen k rows
         const unsigned long long reach = __ballot(pr < np && cum1 + inc1 >= (uint32_t)p.k);
         if (p0 == np && reach) p0 = base + __ffsll((long long)reach);
@@ -301,10 +316,12 @@ __global__ void __launch_bounds__(256) lm_plan_kernel(IvfLmParams p) {
     // nearest one alone (a query near a cell border finds most of its neighbours next door)
     if (p0 < p.min_p1) p0 = min(np, p.min_p1);
     if (p.force_all) p0 = np;
+    if (p.filter) p0 = 0; // no exact sample: every pair belongs to the sweeps' one class of items
     if (lane == 0) {
         pre[np] = cum;
         pre1[np] = cum1;
         p.p0[q] = (uint32_t)p0;
+        if (p.filter) preg[np] = cumg;
     }
     // rows of pass 1 = pre1[p0] (p0 == np: the total)
     uint32_t c1 = cum1;
@@ -451,6 +468,7 @@ __global__ void lm_fill_kernel(IvfLmParams p) {
 void launch_ivf_lm_plan(const IvfLmParams& p, hipStream_t stream) {
     if (p.nq == 0) return;
     FA_THROW_IF_NOT(p.rows_per_item % LM_TR == 0 && p.rows_per_item > 0);
+    FA_THROW_IF_NOT(!p.filter || (p.prefixg && p.gran_blocks >= 1 && p.rows_per_item % (32 * p.gran_blocks) == 0 && !p.force_all));
     // bucket_cnt and bucket_fill are one allocation [2][2 nlist]
     FA_THROW_IF_NOT(p.bucket_fill == p.bucket_cnt + 2 * p.nlist);
     HIP_CHECK(hipMemsetAsync(p.bucket_cnt, 0, (size_t)4 * p.nlist * 4, stream));

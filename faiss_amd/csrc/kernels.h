@@ -465,7 +465,62 @@ struct IvfLmParams {
     const float* sq_s;     // [>= dpad] scale per dimension (0 beyond d)
     const float* sq_b;     // [>= dpad] b': offset per dimension moved to the middle of the code range (fp16: s = 1, b' = 0)
     const float* sq_zero;  // [>= dpad] zeros: the "centroid" of a search without residual encoding
+    // ---- f16 filter scan (round 4, ivf_lm_filter.hip; kinds 0 and 1).  Every (query, probe) pair is a "pass 2" pair
+    // (filter = 1: the plan puts p0 = 0); two sweeps over the same work items -- granule minima of the ESTIMATED
+    // distances, then the collection of every row whose estimate is at or below the query's threshold -- and the
+    // exact arithmetic of the query-major scan on the few survivors (launch_ivf_lmf_rerank).
+    int filter;
+    int gran_blocks;            // G: 32-row blocks per granule; a granule of a list = 32 G rows = two slots (lane halves)
+    uint32_t* prefixg;          // [nq][nprobe + 1] exclusive prefix of 2 * ceil(len / (32 G)): granule slots of the probes
+    uint32_t* gmin;             // [nq][gstride] ordkey of the best estimate in every granule slot
+    int64_t gstride;
+    float* thr_f;               // [nq] collect threshold on the estimate (bound + 2 x error band; +/-inf = everything / nothing)
+    const void* xq16;           // [nq][ldq16] fp16 queries, zero padded (kind 0)
+    int64_t ldq16;
+    const void* arena_h;        // [arena rows][ldh] fp16 shadow of the IVFFlat rows, zero padded to a multiple of 16
+    int64_t ldh;
+    const void* pq16;           // [M][256][dsub] fp16 codebook (kind 1)
+    const uint32_t* qflags;     // [nq] nonzero: the query leaves the fp16 range / holds NaN -> not filtered (fallback)
+    uint16_t* cand_pr;          // [nq][stride] probe number of every collected candidate (beside keys)
+    const float* arena_t2;      // kind 1, L2: the per-row term of the query-major scan (rerank)
+    const float* xn_full;       // [nq] |q|^2 (kind 0: == xqn)
+    float yn_max;               // max |y|^2 over the stored rows (kind 0) / upper bound of |r^|^2 from the codebook (kind 1)
+    float cn_max;               // kind 1: max |centroid|^2
+    float* pq_grid;             // kind 1: [nq][2] delta, 1 / delta of the query's table grid (pq_lut_grid; 0, 0 = no rounding)
 };
+// |estimate - exact| <= this for every stored row, whatever the data: `estimate` = what the f16 MFMA sweeps of
+// ivf_lm_filter.hip compute (L2: fmaf(-2, <f16 q', f16 y'>, |q'|^2 + |y'|^2) with the two norms as fp32 chains; IP:
+// <f16 q', f16 y'> [+ coarse term]), `exact` = the distance the query-major scan returns for the same row (and the rerank
+// kernel recomputes).  q' / y' = query / stored row (kind 0) or residual query / decoded residual (kind 1); xn >= |q'|^2,
+// yn_max >= |y'|^2.  Terms: both operands rounded to fp16 (2^-11 relative each, Cauchy-Schwarz), products exact in fp32,
+// d fp32 accumulations (4 d 2^-24: margin for the pipe's internal order), fp16 denormals; the fp32 chains of the norms,
+// the final fmaf and the exact path's own rounding ((d + 8) 2^-23 of the magnitudes involved).  extra: kind 1's table
+// grid and per-row terms, see lmf_bound_kernel.  Verified on hardware by test_list_filter_error_bound_holds.
+__host__ __device__ static inline float ivf_filter_err_bound(int metric, int d, float xn, float yn_max, float extra = 0.f) {
+    const float nq = sqrtf(xn), ny = sqrtf(yn_max);
+    float e = (9.775e-4f /*2^-10 * 1.001*/ + 2.4e-7f * (float)d) * nq * ny + 3.0e-8f * sqrtf((float)d) * (nq + ny);
+    if (metric == METRIC_L2) e = 2.f * e + 1.2e-7f * (float)(d + 8) * (xn + yn_max);
+    else e += 1.2e-7f * (float)(d + 8) * nq * ny;
+    return 1.25f * (e + extra) + 1e-30f;
+}
+constexpr int kLmfQueryBlocks = 3;  // 32-query MFMA blocks per work item of the filter sweeps (B operands: 32 VGPRs each)
+bool ivf_lmf_supported(int kind, int d, int dpad, int M);
+int ivf_lmf_queries_per_item(int kind);
+int ivf_lmf_grid_blocks(const IvfLmParams& p, int num_cus);
+// mode 1: granule minima -> gmin; mode 2: collect (keys / cand_pr / cnt); mode 3 (tests): every estimate as a key at its
+// scan position (keys [nq][stride], stride >= rows probed)
+void launch_ivf_lmf_sweep(const IvfLmParams& p, int mode, int grid_blocks, hipStream_t stream);
+// thr_f[q] from gmin (k-th best granule estimate + 2 x ivf_filter_err_bound); queries with qflags set get "nothing" and are
+// appended to ovf (zeroed here).  xn_bound: [nq] upper bound of |q'|^2 over the query's probes (kind 0: |q|^2).
+void launch_ivf_lmf_bound(const IvfLmParams& p, const float* xn_bound, hipStream_t stream);
+// kind 1: xn_bound[q] = max over the probes of |q - c|^2 (sequential chains), pq_grid[q] = the query's table grid
+void launch_ivf_lmf_pq_prepare(const IvfLmParams& p, float* xn_bound, hipStream_t stream);
+// keys[q][0 .. cnt[q]) <- the exact distance of the query-major scan (ivf_fused.hip) for the same row, bit for bit
+void launch_ivf_lmf_rerank(const IvfLmParams& p, hipStream_t stream);
+// fp16 shadow of the rows of every list (rows [0, len) of each; dh halfs per row, zero padded) + max |y|^2 over them
+// (float bits by atomicMax; 0x7f800000 when a stored value is NaN / inf / beyond the fp16 range)
+void launch_ivf_lmf_shadow(const float* arena, int64_t ldv, const float* arena_rn, int d, int nlist, const uint32_t* list_len,
+                           const int64_t* list_start, void* arena_h, int dh, unsigned* yn_max_bits, hipStream_t stream);
 // kind 0: M unused; kind 1: M = sub-quantizers; kind 2: M = SqCodeType
 bool ivf_lm_supported(int kind, int dpad, int M, int d);
 // prefix / p0 / cnt, the pairs grouped by (pass, list), the work items.  (4 launches + 1 memset)
