@@ -197,7 +197,7 @@ def ivf_leg(kind, res, xt, xb, xq, xq_dev, gt_first, steps, torch, with_cpu=True
     row_bytes = PQ_M if pq else D if sq else D * 4
     out = {
         "workload": "%s nlist=%d nprobe=%d d=%d nb=%d nq=%d k=%d" % (title, NLIST, NPROBE, D, NB, NQ, K),
-        "scan": "list-major (ivf_listmajor.hip)" if list_major else "query-major (ivf_fused.hip)",
+        "scan": scan_name(list_major, idx.last_scan_arith()),
         "qps": round(NQ / dt, 1), "ms_per_step": round(dt * 1e3, 3),
         "ms_per_step_with_event_spans": round(dt_spans * 1e3, 3),
         "timing": "qps / ms_per_step: loop of searches without instrumentation; kernels_ms and roofline: a second loop with a "
@@ -282,7 +282,7 @@ def nprobe_sweep(idx, ref, xq, xq_dev, gt_first, torch, pq):
         dt = time_search(idx, torch, NQ, xq_dev.data_ptr(), Dd.data_ptr(), Id.data_ptr(), 3, 1)
         I = Id.cpu().numpy()
         row = {"nprobe": npb, "qps": round(NQ / dt, 1), "ms": round(dt * 1e3, 3),
-               "scan": "list-major" if idx.scan_info()[1] == 2 else "query-major",
+               "scan": ("list-major" if idx.scan_info()[1] == 2 else "query-major") + (" (f32)" if idx.last_scan_arith() else ""),
                "recall_at_1": round(float((I[:, 0] == gt_first).mean()), 4),
                "recall_at_100": round(float((I == gt_first[:, None]).any(axis=1).mean()), 4)}
         if ref is not None:
@@ -315,9 +315,17 @@ def nprobe_sweep(idx, ref, xq, xq_dev, gt_first, torch, pq):
                      "IVFFlat distances are exact: R@1 = the fraction of queries whose nearest neighbour lies in a probed list")}
 
 
-SPAN_NAMES = ("ivf_lm_plan", "ivf_lm_scan_pass1", "ivf_lm_threshold", "ivf_lm_scan_pass2", "select_k_kernel",
+SPAN_NAMES = ("ivf_lmf_prepare", "ivf_lm_plan", "ivf_lmf_sweep_min", "ivf_lmf_bound", "ivf_lmf_sweep_collect", "ivf_lmf_rerank",
+              "ivf_lm_scan_pass1", "ivf_lm_threshold", "ivf_lm_scan_pass2", "select_k_kernel",
               "ivfflat_fused_kernel", "ivfpq_fused_kernel", "ivfsq_fused_kernel", "ivf_finish_kernel", "flat_filter_kernel",
               "flat_filter_kernel_max", "flat_tighten_kernel", "flat_rerank_kernel", "convert_f16_query")
+
+
+def scan_name(list_major, arith):
+    if not list_major:
+        return "query-major (ivf_fused.hip)"
+    return ("list-major behind the f16 filter (ivf_lm_filter.hip): results bit-identical to the query-major scan" if arith == 0
+            else "list-major on the f32 matrix pipe (ivf_listmajor.hip)")
 
 
 def collect_spans(res):
@@ -341,6 +349,8 @@ def ivf_roofline(spans, list_major, kind, nb, row_bytes, profile=None):
                 "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4) if ach else None, "avg_kernel_ms": round(avg, 3),
                 "launches": int(n), "algorithmic_bytes_per_launch": int(alg_bytes),
                 "traffic": committed_traffic(kname, alg_bytes, profile or kind)}
+    if spans.get("ivf_lmf_sweep_collect", (0, 0))[1]:
+        return lmf_roofline(spans, kind, nb, row_bytes, profile)
     (m1, n1), (m2, n2) = spans["ivf_lm_scan_pass1"], spans["ivf_lm_scan_pass2"]
     searches = max(n2, 1)
     scan_ms = (m1 + m2) / searches  # both scan launches of one search (pass 1 may run twice when queries are redone)
@@ -363,9 +373,38 @@ def ivf_roofline(spans, list_major, kind, nb, row_bytes, profile=None):
             "traffic": lm_traffic_note(committed_lm_traffic(profile or kind, unique), kind)}
 
 
-def sample_vs_oracle(idx, pq, xq, sel, Dg, Ig, list_major):
-    """The queries `sel` of a search of an IVF index, BIT-EXACT against the oracle restatement (arith = the scan that
-    served the search) run on the lists they probe, read back from the device; the coarse assignment is compared too.
+def lmf_roofline(spans, kind, nb, row_bytes, profile=None):
+    """roofline block of a list-major leg behind the f16 filter (ivf_lm_filter.hip).  The two sweeps dominate; each reads
+    every probed list once per group of up to 96 of the queries probing it: the fp16 shadow rows + their fp32 norms
+    (IVFFlat: 2 d + 4 bytes per row) or the code bytes + norms (IVFPQ: M + 4 bytes per row).  Bound: the row stream (HBM);
+    achieved = unique bytes of ONE sweep / the average sweep time.  The f16 matrix pipe's share is reported beside it
+    (useful flop of one sweep = 2 * nq * nprobe * (nb / nlist) * d over the dense f16 MFMA peak), and the SURVEY 8d byte
+    figure of the query-major formulation for comparison."""
+    (m1, n1), (m2, n2) = spans["ivf_lmf_sweep_min"], spans["ivf_lmf_sweep_collect"]
+    sweep_ms = (m1 + m2) / max(n1 + n2, 1)
+    per_row = (2.0 * D + 4.0) if kind == "ivfflat" else (float(row_bytes) + 4.0)
+    unique = nb * per_row
+    ach = unique / (sweep_ms * 1e-3) / 1e9
+    flops = 2.0 * NQ * NPROBE * (nb / float(NLIST)) * D
+    alg_bytes = float(NPROBE) * nb / NLIST * row_bytes * NQ
+    search_ms = sum(v[0] for k, v in spans.items() if k.startswith("ivf_lm") or k in ("select_k_kernel",)) / max(n2, 1)
+    return {"bound": "hbm", "kernel": ("ivf_lmf_flat_kernel" if kind == "ivfflat" else "ivf_lmf_pq_kernel") +
+                                       " (sweep 1: granule minima, sweep 2: collect): one sweep",
+            "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4),
+            "avg_kernel_ms": round(sweep_ms, 3), "launches": int(n1 + n2),
+            "algorithmic_bytes_per_launch": int(unique),
+            "bytes_per_row": per_row,
+            "f16_mfma": {"useful_flop_per_sweep": int(flops), "TFLOPs": round(flops / (sweep_ms * 1e-3) / 1e12, 1),
+                         "frac_of_f16_peak": round(flops / (sweep_ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4)},
+            "list_major_kernels_ms_per_search": round(search_ms, 3),
+            "survey_8d_bytes": {"algorithmic_bytes_per_search": int(alg_bytes),
+                                "note": "bytes the query-major formulation moves per search (once per query and probe)"},
+            "traffic": committed_lm_traffic(profile or kind, unique, filt=True)}
+
+
+def sample_vs_oracle(idx, pq, xq, sel, Dg, Ig, arith):
+    """The queries `sel` of a search of an IVF index, BIT-EXACT against the oracle restatement (arith =
+    idx.last_scan_arith() of the search) run on the lists they probe, read back from the device; the coarse assignment is compared too.
     Returns (exact, entries read back, (Do, Io) = the oracle's results for the sample)."""
     from oracle.pyoracle import METRIC_L2, Oracle
     cent = idx.get_centroids()
@@ -379,7 +418,7 @@ def sample_vs_oracle(idx, pq, xq, sel, Dg, Ig, list_major):
         ids.append(idx.get_list_ids(int(l)))
     codes, ids = np.concatenate(codes), np.concatenate(ids)
     Do, Io, cD, cI = Oracle.ivf_search(1 if pq else 0, METRIC_L2, cent, sizes, codes, ids, xq[sel], NPROBE, K,
-                                       M=PQ_M if pq else 0, pq=pqc, arith=1 if list_major else 0)
+                                       M=PQ_M if pq else 0, pq=pqc, arith=arith)
     exact = bool(np.array_equal(cI, Iq) and np.array_equal(cD, Dq) and np.array_equal(Io, Ig[sel]) and np.array_equal(Do, Dg[sel]))
     return exact, len(ids), (Do, Io)
 
@@ -439,17 +478,18 @@ def scale_leg(kind, nb, res, xt, xb, xq, xq_dev, dmap, torch, leg_1m, nsample=16
     spans = collect_spans(res)
     res.profile_enable(False)
     list_major = idx.scan_info()[1] == 2
+    arith = idx.last_scan_arith()
     Dg, Ig = Dd.cpu().numpy(), Id.cpu().numpy()
     ok_order = bool((np.diff(Dg, axis=1) >= 0).all() and (Ig >= 0).all() and (Ig < nb).all())
     # ---- sample parity: oracle on the probed lists read back from the device
     sel = np.random.RandomState(3).choice(NQ, nsample, replace=False)
-    exact, nread, _ = sample_vs_oracle(idx, pq, xq, sel, Dg, Ig, list_major)
+    exact, nread, _ = sample_vs_oracle(idx, pq, xq, sel, Dg, Ig, arith)
     row_bytes = PQ_M if pq else D * 4
     used, holes, alloc = idx.arena_stats()
     out = {
         "workload": "%s nlist=%d nprobe=%d d=%d nb=%d nq=%d k=%d (BASELINE.json configs[%d])" % (
             "GpuIndexIVFPQ PQ%dx8" % PQ_M if pq else "GpuIndexIVFFlat", NLIST, NPROBE, D, nb, NQ, K, 3 if pq else 2),
-        "scan": "list-major (ivf_listmajor.hip)" if list_major else "query-major (ivf_fused.hip)",
+        "scan": scan_name(list_major, arith),
         "qps": round(NQ / dt, 1), "ms_per_step": round(dt * 1e3, 3), "steps": steps,
         "ms_per_step_with_event_spans": round(dt_spans * 1e3, 3),
         "generator": ("chunk 0 = the flat leg's 1M database; chunks 1.. " +
@@ -573,13 +613,16 @@ def committed_traffic(kernel_substr, alg_bytes, profile):
         return None
 
 
-def committed_lm_traffic(profile, unique_bytes):
+def committed_lm_traffic(profile, unique_bytes, filt=False):
     """L2-miss bytes of the list-major scan launches of ONE search (pass 1 + pass 2 kernels) from the committed FETCH_SIZE
     pass of the same workload, next to the bytes a batch has to read at least once."""
     try:
         pmc, rel = _pmc(profile)
-        ent = {k: v for k, v in pmc.items() if "ivf_lm_" in k and "_kernel<" in k and "FETCH_SIZE" in v
-               and ("scan_kernel" in k or "reg_kernel" in k or "pq_kernel" in k)}
+        if filt:  # the sweeps of ivf_lm_filter.hip (only profiles taken since they exist hold them)
+            ent = {k: v for k, v in pmc.items() if "ivf_lmf_" in k and "_kernel<" in k and "FETCH_SIZE" in v}
+        else:
+            ent = {k: v for k, v in pmc.items() if "ivf_lm_" in k and "_kernel<" in k and "FETCH_SIZE" in v
+                   and ("scan_kernel" in k or "reg_kernel" in k or "pq_kernel" in k)}
         if not ent:
             return None
         return {"hbm_read_bytes_per_search_from_committed_profile": round(sum(v["hbm_read_bytes_corrected"] for v in ent.values())),
@@ -764,10 +807,11 @@ def sharded_scale_leg(res, rank, world, dev, xt, xb, xq, xq_dev, dmap, rows_per_
     spans = collect_spans(res)
     res.profile_enable(False)
     list_major = idx.scan_info()[1] == 2
+    arith = idx.last_scan_arith()
     # ---- parity on a query sample (every rank: its shard vs the oracle; rank 0: the merge)
     sel = np.random.RandomState(5).choice(NQ, nsample, replace=False)
     Dl, Il = D_loc.cpu().numpy(), I_loc.cpu().numpy()
-    local_exact, nread, (Do, Io) = sample_vs_oracle(idx, True, xq, sel, Dl, Il, list_major)
+    local_exact, nread, (Do, Io) = sample_vs_oracle(idx, True, xq, sel, Dl, Il, arith)
     merged = (out[0].cpu().numpy()[sel], out[1].cpu().numpy()[sel]) if rank == 0 else (None, None)
     par = sharded_sample_check(local_exact, Do, Io, merged[0], merged[1], faiss_amd.METRIC_L2, dist, rank, world)
     ovf = int(idx.scan_info()[2])
@@ -788,7 +832,7 @@ def sharded_scale_leg(res, rank, world, dev, xt, xb, xq, xq_dev, dmap, rows_per_
         "qps": round(NQ / dt, 1), "ms_per_step": round(dt * 1e3, 3), "steps": int(steps),
         "timed_region": "local search of all queries on every rank + point-to-point gather of the per-rank top-k onto rank 0 "
                         "+ device merge; barrier + synchronize on both sides, max over ranks",
-        "scan": "list-major (ivf_listmajor.hip)" if list_major else "query-major (ivf_fused.hip)",
+        "scan": scan_name(list_major, arith),
         "train_broadcast_s": round(t_train, 2), "build_s": round(t_build, 1),
         "add_M_vectors_per_s_per_gpu": round(rows_per_rank / t_build / 1e6, 2), "overflow_queries": ovf,
         "roofline": ivf_roofline(spans, list_major, "ivfpq", rows_per_rank, PQ_M, profile="ivfpq_100m"),

@@ -115,6 +115,9 @@ def load_library():
         "faiss_amd_GpuIndexIVF_set_use_fused_scan": (i32, [vp, i32]),
         "faiss_amd_GpuIndexIVF_set_scan_mode": (i32, [vp, i32]),
         "faiss_amd_GpuIndexIVF_scan_info": (i32, [vp, P(i32), P(i32), P(i64)]),
+        "faiss_amd_GpuIndexIVF_last_scan_arith": (i32, [vp, P(i32)]),
+        "faiss_amd_GpuIndexIVF_test_filter_dump": (i32, [vp, i64, vp, i32, i64, i64, vp, vp]),
+        "faiss_amd_GpuIndexIVF_set_lmf_tuning": (i32, [vp, i32, i32, i32]),
         "faiss_amd_GpuIndexIVF_list_major_rule": (i32, [vp, i64, i32, i64, P(i32)]),
         "faiss_amd_GpuIndexFlat_set_use_filter_kernel": (i32, [vp, i32, i64]),
         "faiss_amd_GpuIndexFlat_filter_stats": (i32, [vp, P(i32), P(i32)]),
@@ -556,10 +559,11 @@ class _GpuIndexIVF(Index):
         _check(self._lib.faiss_amd_GpuIndexIVF_arena_stats(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
         return a.value, b.value, c.value
 
-    SCAN_AUTO, SCAN_QUERY_MAJOR, SCAN_LIST_MAJOR = 0, 1, 2
+    SCAN_AUTO, SCAN_QUERY_MAJOR, SCAN_LIST_MAJOR, SCAN_LIST_MAJOR_F32 = 0, 1, 2, 3
 
     def set_scan_mode(self, mode):
-        """0 = automatic (large batches list-major), 1 = query-major always, 2 = list-major always"""
+        """0 = automatic (large batches list-major), 1 = query-major always, 2 = list-major always (IVFFlat / IVFPQ: behind
+        the f16 filter, results bit-identical to the query-major scan), 3 = list-major on the f32 matrix pipe (round 3)"""
         _check(self._lib.faiss_amd_GpuIndexIVF_set_scan_mode(self._h, int(mode)))
 
     def scan_info(self):
@@ -569,8 +573,33 @@ class _GpuIndexIVF(Index):
         return a.value, b.value, c.value
 
     def last_scan_arith(self):
-        """the `arith` argument under which Oracle.ivf_search restates the last search (0 query-major, 1 list-major)"""
-        return self.scan_info()[1] - 1
+        """the `arith` argument under which Oracle.ivf_search restates the last search: 0 = the query-major arithmetic
+        (also what the list-major scan behind the f16 filter returns), 1 = the f32 list-major arithmetic"""
+        v = ctypes.c_int(0)
+        _check(self._lib.faiss_amd_GpuIndexIVF_last_scan_arith(self._h, ctypes.byref(v)))
+        return v.value
+
+    def set_lmf_tuning(self, rows_per_item=0, gran_blocks=0, cand_cap=0):
+        """tuning experiments of the list-major scan behind the f16 filter (0 = the built-in rule); results never change"""
+        _check(self._lib.faiss_amd_GpuIndexIVF_set_lmf_tuning(self._h, int(rows_per_item), int(gran_blocks), int(cand_cap)))
+
+    def filter_dump(self, x, k, stride, nprobe=None):
+        """test hook: (estimates [n][stride] float32 with NaN where no row sits, band [n]) of the f16 filter sweeps -- the
+        estimate of the row at scan position p of query q is estimates[q, p] (include/faiss_amd_c.h
+        faiss_amd_GpuIndexIVF_test_filter_dump); band[q] = NaN for queries without a bound"""
+        x = _f32(x, self.d)
+        n = x.shape[0]
+        keys = np.empty((n, stride), dtype=np.uint64)
+        band = np.full(n, np.nan, dtype=np.float32)
+        _check(self._lib.faiss_amd_GpuIndexIVF_test_filter_dump(self._h, n, _ptr(x), int(nprobe or self.nprobe), int(k),
+                                                                int(stride), _ptr(keys), _ptr(band)))
+        u = (keys >> np.uint64(32)).astype(np.uint32)
+        if self.metric_type != METRIC_L2:
+            u = ~u
+        bits = np.where(u & np.uint32(0x80000000), u & np.uint32(0x7fffffff), ~u).astype(np.uint32)
+        est = bits.view(np.float32).copy()
+        est[keys == np.uint64(0xffffffffffffffff)] = np.nan
+        return est, band
 
     def list_major_rule(self, n, nprobe=None, k=1):
         v = ctypes.c_int(0)

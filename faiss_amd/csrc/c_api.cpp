@@ -544,8 +544,12 @@ int faiss_amd_IndexIVF_set_clustering_params(FaissAmdIndex* index, const FaissAm
     FA_TRY
     auto* ivf = as<GpuIndexIVF>(index, "GpuIndexIVF");
     FA_THROW_IF_NOT_MSG(params, "null parameters");
-    to_cp(*params, ivf->cp);
-    FA_THROW_IF_NOT_MSG(params->niter >= 1, "niter must be positive");
+    // validated before anything of the index changes; niter = 0 is legal (k-means that keeps its initial centroids,
+    // faiss/Clustering.cpp:351-356 -- what faiss_amd_Clustering_train accepts too)
+    FA_THROW_IF_NOT_MSG(params->niter >= 0, "niter must not be negative");
+    ClusteringParameters tmp = ivf->cp;
+    to_cp(*params, tmp);
+    ivf->cp = tmp;
     ivf->cp_niter = params->niter;
     ivf->cp_seed = params->seed;
     FA_CATCH
@@ -902,7 +906,8 @@ int faiss_amd_GpuIndexIVF_set_use_fused_scan(FaissAmdIndex* index, int on) {
 }
 int faiss_amd_GpuIndexIVF_set_scan_mode(FaissAmdIndex* index, int mode) {
     FA_TRY
-    FA_THROW_IF_NOT_MSG(mode >= 0 && mode <= 2, "scan mode: 0 = automatic, 1 = query-major, 2 = list-major");
+    FA_THROW_IF_NOT_MSG(mode >= 0 && mode <= 3,
+                        "scan mode: 0 = automatic, 1 = query-major, 2 = list-major, 3 = list-major on the f32 matrix pipe");
     as<GpuIndexIVF>(index, "GpuIndexIVF")->scan_mode = mode;
     FA_CATCH
 }
@@ -912,6 +917,28 @@ int faiss_amd_GpuIndexIVF_scan_info(const FaissAmdIndex* index, int* mode, int* 
     if (mode) *mode = ix->scan_mode;
     if (last_mode) *last_mode = ix->last_scan_mode();
     if (overflow_queries) *overflow_queries = ix->list_major_overflows();
+    FA_CATCH
+}
+int faiss_amd_GpuIndexIVF_set_lmf_tuning(FaissAmdIndex* index, int rows_per_item, int gran_blocks, int cand_cap) {
+    FA_TRY
+    auto* ix = as<GpuIndexIVF>(index, "GpuIndexIVF");
+    FA_THROW_IF_NOT_MSG(rows_per_item >= 0 && gran_blocks >= 0 && cand_cap >= 0, "negative tuning value");
+    ix->lmf_rows_per_item = rows_per_item;
+    ix->lmf_gran_blocks = gran_blocks;
+    ix->lmf_cand_cap = cand_cap;
+    FA_CATCH
+}
+int faiss_amd_GpuIndexIVF_test_filter_dump(const FaissAmdIndex* index, int64_t n, const float* x, int nprobe, int64_t k, int64_t stride,
+                                           uint64_t* keys_out, float* band_out) {
+    FA_TRY
+    as<GpuIndexIVF>(const_cast<FaissAmdIndex*>(index), "GpuIndexIVF")
+            ->test_filter_dump(n, x, nprobe, k, stride, (unsigned long long*)keys_out, band_out);
+    FA_CATCH
+}
+int faiss_amd_GpuIndexIVF_last_scan_arith(const FaissAmdIndex* index, int* p_arith) {
+    FA_TRY
+    FA_THROW_IF_NOT_MSG(p_arith, "null output");
+    *p_arith = as<GpuIndexIVF>(const_cast<FaissAmdIndex*>(index), "GpuIndexIVF")->last_scan_arith();
     FA_CATCH
 }
 int faiss_amd_GpuIndexIVF_list_major_rule(const FaissAmdIndex* index, int64_t n, int nprobe, int64_t k, int* p_output) {

@@ -1560,6 +1560,7 @@ void GpuIndexIVF::arena_stats(int64_t* used, int64_t* holes, int64_t* allocated)
 void GpuIndexIVF::reset() {
     std::lock_guard<std::mutex> g(mu_);
     res_->set_device();
+    shadow_dirty_ = true;
     ntotal = 0;
     nstored_ = 0;
     arena_rows_ = 0;
@@ -1578,6 +1579,7 @@ void GpuIndexIVF::set_centroids(const float* centroids) {
     quantizer->reset();
     quantizer->add(nlist, centroids);
     update_is_trained_();
+    lmf_quant_dirty_ = true;
     ensure_arena_(64);
     upload_list_tables_();
     if (nstored_ > 0 && is_trained) lists_changed_();
@@ -1585,6 +1587,7 @@ void GpuIndexIVF::set_centroids(const float* centroids) {
 
 void GpuIndexIVF::train(idx_t n, const float* x) {
     if (is_trained && quantizer->ntotal == nlist) return; // reference: GpuIndexIVF.cu trainQuantizer_
+    lmf_quant_dirty_ = true;
     FA_THROW_IF_NOT_MSG(n > 0 && x, "empty training set");
     res_->set_device();
     if (quantizer->ntotal != nlist) {
@@ -1646,6 +1649,7 @@ void GpuIndexIVF::grow_lists_(const std::vector<uint32_t>& new_len, const std::v
     }
     if (extra == 0) return;
     const GpuResources& R = *res_;
+    shadow_dirty_ = true;
     ensure_arena_(arena_rows_ + extra); // (keeps rows [0, arena_rows_): the jobs' sources)
     arena_rows_ += extra;
     if (!jobs.empty()) {
@@ -1676,19 +1680,27 @@ size_t GpuIndexIVF::reclaimMemory() {
     std::lock_guard<std::mutex> g(mu_);
     res_->set_device();
     const size_t row_bytes = code_bytes_ + 8 + (use_t2_ ? 4 : 0) + (use_rn_ ? 4 : 0);
-    size_t before = (size_t)arena_cap_rows_ * row_bytes;
-    for (DevBuf* b : {&a_xpad_, &a_lab_, &a_dis_, &a_dest_, &a_ids_, &a_hist_, &a_newlen_, &a_jobs_}) {
+    // (+ the 128 rows of padding behind the codes and the norms, ensure_arena_)
+    const size_t pad_bytes = 128 * (code_bytes_ + (use_rn_ ? 4 : 0));
+    size_t before = (size_t)arena_cap_rows_ * row_bytes + (arena_.p ? pad_bytes : 0);
+    // add-path scratch and the per-search scratch of the list-major scans (key segments sized up to the temp budget,
+    // plan tables, granule minima): all of it is re-grown on demand
+    for (DevBuf* b : {&a_xpad_, &a_lab_, &a_dis_, &a_dest_, &a_ids_, &a_hist_, &a_newlen_, &a_jobs_, &lm_prefix_, &lm_p0_,
+                      &lm_cnt_, &lm_bucket_, &lm_bstart_, &lm_pairs_, &lm_items_, &lm_bounds_, &lm_thr_, &lm_keys_, &lm_ovf_,
+                      &lm_qn_, &lm_prefixg_, &lm_gmin_, &lm_thrf_, &lm_candpr_, &lm_q16_, &lm_qflags_, &lm_xnb_, &lm_pqgrid_,
+                      &part_keys_, &part_cnt_, &keys_}) {
         before += b->cap;
         b->release();
     }
     if (arena_.p) compact_(true);
-    const size_t after = (size_t)arena_cap_rows_ * row_bytes;
+    const size_t after = (size_t)arena_cap_rows_ * row_bytes + (arena_.p ? pad_bytes : 0);
     return before > after ? before - after : 0;
 }
 void GpuIndexIVF::updateQuantizer() {
     std::lock_guard<std::mutex> g(mu_);
     res_->set_device();
     FA_THROW_IF_NOT_MSG(quantizer->ntotal == 0 || quantizer->ntotal == nlist, "the coarse quantizer must hold nlist centroids");
+    lmf_quant_dirty_ = true;
     update_is_trained_();
     if (quantizer->ntotal == nlist) {
         ensure_arena_(64);
@@ -1700,6 +1712,7 @@ void GpuIndexIVF::updateQuantizer() {
 // rebuild the arena without holes (lists in id order, 1/8 slack each)
 void GpuIndexIVF::compact_(bool tight) {
     const GpuResources& R = *res_;
+    shadow_dirty_ = true;
     const int64_t G = granule_;
     std::vector<IvfMoveJob> jobs;
     std::vector<int64_t> nstart(nlist);
@@ -1764,6 +1777,7 @@ void GpuIndexIVF::add_core_(idx_t n, const float* x, const idx_t* xids, const id
     res_->set_device();
     const GpuResources& R = *res_;
     const idx_t page = std::max<idx_t>(1, std::min<idx_t>(((idx_t)512 << 20) / ((idx_t)dpad_ * 4), 1 << 20));
+    shadow_dirty_ = true;
     const int chunk = 2048;
     const idx_t pn = std::min(page, n);
     a_xpad_.ensure((size_t)pn * dpad_ * 4);
@@ -1843,6 +1857,7 @@ void GpuIndexIVF::set_lists(const uint32_t* list_sizes, const uint8_t* codes, co
         rows += ncap[l];
     }
     FA_THROW_IF_NOT_MSG(acc == 0 || (codes && ids), "null codes / ids");
+    shadow_dirty_ = true;
     // nothing of the index changes before every device copy has been issued successfully
     arena_rows_ = 0; // (old contents are dropped: nothing to keep when the buffers grow)
     hole_rows_ = 0;
@@ -1985,8 +2000,9 @@ void GpuIndexIVF::search_core_(idx_t n, const float* x, idx_t k, float* distance
         cur_sel_mask_ = sel_mask_.as<uint32_t>();
     }
     // which scan serves this call: decided once, on the whole batch, so that the pages / tiles of one call agree
-    FA_THROW_IF_NOT_MSG(scan_mode >= 0 && scan_mode <= 2, "scan_mode must be 0 (auto), 1 (query-major) or 2 (list-major)");
-    if (scan_mode == 2) {
+    FA_THROW_IF_NOT_MSG(scan_mode >= 0 && scan_mode <= 3,
+                        "scan_mode must be 0 (auto), 1 (query-major), 2 (list-major) or 3 (list-major, f32 matrix pipe)");
+    if (scan_mode >= 2) {
         FA_THROW_IF_NOT_MSG(lm_capable_(), "list-major scan: index type / dimension not supported (IVFFlat, IVFPQ, scalar "
                             "quantizer; d <= 128)");
         FA_THROW_IF_NOT_MSG(!sel, "list-major scan: IDSelector searches take the query-major scan");
@@ -1994,7 +2010,16 @@ void GpuIndexIVF::search_core_(idx_t n, const float* x, idx_t k, float* distance
     } else {
         cur_lm_ = scan_mode == 0 && list_major_rule(n, nprobe_now, k, sel != nullptr);
     }
+    // IVFFlat / IVFPQ: the list-major scan runs behind the f16 filter (results = the query-major scan's, bit for bit)
+    // unless the f32 scan of round 3 is asked for.  Stored values outside the fp16 range: the query-major scan serves
+    // the call (same bits, no filter).
+    cur_lmf_ = cur_lm_ && scan_mode != 3 && lmf_capable_();
+    if (cur_lmf_ && nstored_ > 0) {
+        IvfLmParams probe{};
+        if (!lmf_prepare_(probe)) cur_lmf_ = cur_lm_ = false;
+    }
     last_scan_mode_ = cur_lm_ ? 2 : 1;
+    last_scan_arith_ = cur_lm_ && !cur_lmf_ ? 1 : 0;
     if (use_paged_path(R, n, d, x, distances, labels)) {
         const idx_t page = paged_page_size(R, n, 65536);
         idx_t done = 0; // pages come in order
@@ -2080,14 +2105,11 @@ void GpuIndexIVF::search_core_body_(idx_t n, const float* x, idx_t k, float* dis
         } else {
             quantizer->search_device(ni, q_pad_.as<float>(), np, c_dis_.as<float>(), c_ids_.as<idx_t>());
         }
-        if (cur_lm_) {
-            // ---- large batch: list-major (ivf_listmajor.hip)
-            search_listmajor_(ni, q_pad_.as<float>(), c_ids_.as<idx_t>(), c_dis_.as<float>(), np, (int)k, dD, dI, 0);
-            if (!out_dev_d) copy_out(R, distances + (size_t)i0 * k, dD, (size_t)ni * k * 4);
-            if (!out_dev_i) copy_out(R, labels + (size_t)i0 * k, dI, (size_t)ni * k * 8);
-            R.sync();
-            continue;
-        }
+        // the query-major scan of the `nn` queries staged in q_pad_ / c_ids_ / c_dis_ -> gD / gI (device)
+        auto query_major = [&](int nn, float* gD, idx_t* gI) {
+        const int ni = nn; // (shadows the tile's count: the redo of a list-major search runs this on a few queries)
+        float* const dD = gD;
+        idx_t* const dI = gI;
         if (fused) {
             // ---- table build + list scan + k-selection in one launch, nothing but results leaves LDS
             IvfFusedParams fp{};
@@ -2181,10 +2203,7 @@ void GpuIndexIVF::search_core_body_(idx_t n, const float* x, idx_t k, float* dis
                 SpanGuard sg(&R, "select_k_kernel");
                 launch_select_k(sp, R.stream);
             }
-            if (!out_dev_d) copy_out(R, distances + (size_t)i0 * k, dD, (size_t)ni * k * 4);
-            if (!out_dev_i) copy_out(R, labels + (size_t)i0 * k, dI, (size_t)ni * k * 8);
-            R.sync();
-            continue;
+            return;
         }
         // ---- per-(query, probe) offsets
         prefix_.ensure((size_t)ni * (np + 1) * 4);
@@ -2229,10 +2248,52 @@ void GpuIndexIVF::search_core_body_(idx_t n, const float* x, idx_t k, float* dis
             SpanGuard sg(&R, "select_k_kernel");
             launch_select_k(sp, R.stream);
         }
+        }; // query_major
+        if (cur_lm_) {
+            // ---- large batch: list-major (ivf_listmajor.hip, ivf_lm_filter.hip)
+            std::vector<uint32_t> redo;
+            search_listmajor_(ni, q_pad_.as<float>(), c_ids_.as<idx_t>(), c_dis_.as<float>(), np, (int)k, dD, dI, 0, &redo);
+            if (!redo.empty()) {
+                // filter path: queries whose candidate segment overflowed (a threshold that admits too much: fewer
+                // granules than k, near-duplicate data) or that leave the fp16 range go through the query-major scan --
+                // the same bits.  They are gathered to the front of the staging buffers (the list-major pass is done
+                // with them) and scattered back into the tile's results.
+                const int nr = (int)redo.size();
+                DevBuf olist, gq, gids, gdis, gD, gI;
+                olist.ensure((size_t)nr * 4);
+                HIP_CHECK(hipMemcpyAsync(olist.p, redo.data(), (size_t)nr * 4, hipMemcpyHostToDevice, R.stream));
+                gq.ensure((size_t)nr * dpad_ * 4);
+                gids.ensure((size_t)nr * np * 8);
+                gdis.ensure((size_t)nr * np * 4);
+                gD.ensure((size_t)nr * k * 4);
+                gI.ensure((size_t)nr * k * 8);
+                launch_gather_rows(q_pad_.as<float>(), dpad_, dpad_, olist.as<uint32_t>(), nr, gq.as<float>(), R.stream);
+                launch_gather_rows((const float*)c_ids_.p, 2 * np, 2 * np, olist.as<uint32_t>(), nr, (float*)gids.p, R.stream);
+                launch_gather_rows(c_dis_.as<float>(), np, np, olist.as<uint32_t>(), nr, gdis.as<float>(), R.stream);
+                HIP_CHECK(hipMemcpyAsync(q_pad_.p, gq.p, (size_t)nr * dpad_ * 4, hipMemcpyDeviceToDevice, R.stream));
+                HIP_CHECK(hipMemcpyAsync(c_ids_.p, gids.p, (size_t)nr * np * 8, hipMemcpyDeviceToDevice, R.stream));
+                HIP_CHECK(hipMemcpyAsync(c_dis_.p, gdis.p, (size_t)nr * np * 4, hipMemcpyDeviceToDevice, R.stream));
+                query_major(nr, gD.as<float>(), gI.as<idx_t>());
+                launch_scatter_results(gD.as<float>(), gI.as<idx_t>(), (int)k, olist.as<uint32_t>(), nr, dD, dI, R.stream);
+                R.sync(); // `redo` and the gathered buffers die with this scope
+            }
+        } else {
+            query_major(ni, dD, dI);
+        }
         if (!out_dev_d) copy_out(R, distances + (size_t)i0 * k, dD, (size_t)ni * k * 4);
         if (!out_dev_i) copy_out(R, labels + (size_t)i0 * k, dI, (size_t)ni * k * 8);
         R.sync();
     }
+}
+
+// Experiment knobs of the list-major scans (FAISS_AMD_LM_*) change timings and, some of them, RESULTS: a stray variable in
+// a production environment must not.  They are read once per process and only when FAISS_AMD_EXPERIMENTS=1 is set too.
+static const char* experiment_env(const char* name) {
+    static const bool on = [] {
+        const char* e = getenv("FAISS_AMD_EXPERIMENTS");
+        return e && atoi(e) == 1;
+    }();
+    return on ? getenv(name) : nullptr;
 }
 
 // ---------------------------------------------------------------------- list-major search (ivf_listmajor.hip)
@@ -2247,16 +2308,46 @@ bool GpuIndexIVF::list_major_rule(idx_t n, int nprobe_now, idx_t k, bool has_sel
     if (fused_kind_() == 1 &&
         !(lm_pq_lds_capable_() && (double)n * (double)np * (double)nstored_ >= 50000.0 * (double)nlist * (double)nlist))
         return false;
+    // IVFFlat / scalar quantizer: the plan / bound / select launches and the read-back of a list-major search are a fixed
+    // cost the single fused query-major launch does not pay; with short lists (a small index) there is no scan time to
+    // win it back from.  Measured on the bench shape only at >= 244 rows per list; the rule asks for 64.
+    if (fused_kind_() != 1 && (double)nstored_ < 64.0 * (double)nlist) return false;
     return n >= 2048 && (int64_t)n * np >= (int64_t)8 * nlist && k <= kMaxSelectionK;
 }
 
 // Queries [0, ni) with their coarse results on the device -> k best per query in dD / dI (device).  Splits the batch
 // so that the key segments fit the scratch budget.
 void GpuIndexIVF::search_listmajor_(int ni, const float* xq_pad, const idx_t* c_ids, const float* c_dis, int np, int k,
-                                    float* dD, idx_t* dI, int level) const {
+                                    float* dD, idx_t* dI, int level, std::vector<uint32_t>* redo) const {
     const GpuResources& R = *res_;
     uint32_t max_len = 1;
     for (auto l : list_len_) max_len = std::max(max_len, l);
+    if (cur_lmf_ && level == 0) {
+        // ---- behind the f16 filter (ivf_lm_filter.hip).  Rows of a list per work item: a quarter of an average list,
+        // between 1024 and 8192, a multiple of the granule; candidate room per query: the k-th best granule estimate
+        // admits ~ S ln(S / (S - k)) rows (S granule slots per query) + those inside the error band.
+        FA_THROW_IF_NOT(redo != nullptr);
+        const int64_t avg_len = std::max<int64_t>(1, nstored_ / std::max(nlist, 1));
+        int RT = (int)std::min<int64_t>(8192, std::max<int64_t>(kLmRowsPerItem, (int64_t)round_up((size_t)(avg_len / 4), 256)));
+        int64_t stride = std::max<int64_t>(1024, 6 * (int64_t)k);
+        // granule: 32 G rows of a list hold two slots (16 G rows per lane half); ~ 8192 slots per query at most
+        const double rows_per_query = (double)np * (double)avg_len;
+        int G = 1;
+        while (G < 8 && rows_per_query / (16.0 * G) > 8192.0) G *= 2;
+        if (lmf_rows_per_item > 0) RT = (int)round_up((size_t)lmf_rows_per_item, 256);
+        if (lmf_gran_blocks > 0) G = lmf_gran_blocks;
+        if (lmf_cand_cap > 0) stride = std::max<int64_t>(lmf_cand_cap, k);
+        FA_THROW_IF_NOT_MSG(G >= 1 && G <= 8 && (G & (G - 1)) == 0 && RT <= 65280, "filter tuning: granule / rows per item");
+        const int64_t gstride = 2 * (int64_t)np * (int64_t)div_up((size_t)max_len, (size_t)(32 * G));
+        const size_t per_q = (size_t)stride * 10 + (size_t)gstride * 4 + (size_t)(np + 1) * 12 + 256;
+        const int64_t fit = std::max<int64_t>(1, std::min<int64_t>((int64_t)(R.temp_budget_bytes / per_q), (1 << 20)));
+        for (int c0 = 0; c0 < ni; c0 += (int)std::min<int64_t>(fit, ni)) {
+            const int cn = (int)std::min<int64_t>(fit, ni - c0);
+            search_listmajor_filter_chunk_(cn, c0, xq_pad + (size_t)c0 * dpad_, c_ids + (size_t)c0 * np, c_dis + (size_t)c0 * np, np,
+                                           k, dD + (size_t)c0 * k, dI + (size_t)c0 * k, stride, RT | (G << 16), *redo);
+        }
+        return;
+    }
     // level 0: the regular search; level 1: queries whose candidate segment overflowed, with 16 x the room; level 2: every
     // probe and row in pass 1 (no bound, exact capacity) -- the last resort, its segments hold ALL probed rows
     const bool force_all = level >= 2;
@@ -2270,7 +2361,7 @@ void GpuIndexIVF::search_listmajor_(int ni, const float* xq_pad, const idx_t* c_
     // 32-query MFMA block: pass 1 then costs one sweep of the lists' first row chunks whatever min_p1 is), at most 8, at
     // most half of the probes, at most 4 when the lists are longer than a chunk (the bound kernel selects among min_p1
     // chunks of keys: 0.5 ms for 7 x 1024 at nb = 10M against 0.29 for 4 x 1024, more than the tighter bound saves).
-    const char* p1_env = getenv("FAISS_AMD_LM_P1"); // tuning experiments
+    static const char* p1_env = experiment_env("FAISS_AMD_LM_P1"); // tuning experiments
     const int64_t chunk_rows = std::min<int64_t>(max_len, RT);
     int min_p1 = (int)std::min<int64_t>(8, std::max<int64_t>(1, (14 * (int64_t)nlist + ni / 2) / std::max(ni, 1)));
     if (avg_len >= kLmRowsPerItem) min_p1 = std::min(min_p1, 4);
@@ -2281,6 +2372,9 @@ void GpuIndexIVF::search_listmajor_(int ni, const float* xq_pad, const idx_t* c_
     const int64_t cap2 = std::max<int64_t>(avg_len >= kLmRowsPerItem ? 4096 : 2048, 4 * (int64_t)k) * (level == 1 ? 16 : 1);
     const int64_t c1max = std::max<int64_t>((int64_t)k + chunk_rows, (int64_t)min_p1 * chunk_rows); // rows of pass 1
     const int64_t stride = force_all ? std::max<int64_t>((int64_t)np * max_len, k) : c1max + cap2;
+    // (level 2: one query's segment holds every row it probes -- it has to fit the scratch budget by itself)
+    FA_THROW_IF_NOT_MSG(!force_all || (size_t)stride * 8 <= std::max<size_t>(R.temp_budget_bytes, (size_t)1 << 30),
+                        "list-major scan: the rows one query probes exceed the scratch budget (setTempMemory); use scan_mode 1");
     const int64_t fit = std::max<int64_t>(1, (int64_t)(R.temp_budget_bytes / ((size_t)stride * 8)));
     for (int c0 = 0; c0 < ni; c0 += (int)std::min<int64_t>(fit, ni)) {
         const int cn = (int)std::min<int64_t>(fit, ni - c0);
@@ -2346,7 +2440,8 @@ void GpuIndexIVF::search_listmajor_chunk_(int ni, const float* xq_pad, const idx
     P.rows_per_item = RT;
     P.qpi = qpi;
     P.force_all = force_all ? 1 : 0;
-    const char* dbg_env = getenv("FAISS_AMD_LM_DBG"); // timing experiments only (results are wrong)
+    // timing experiments only (results are WRONG with it): honoured only under FAISS_AMD_EXPERIMENTS=1, read once
+    static const char* dbg_env = experiment_env("FAISS_AMD_LM_DBG");
     P.min_p1 = min_p1;
     P.dbg = dbg_env ? atoi(dbg_env) : 0;
     P.keys = lm_keys_.as<unsigned long long>();
@@ -2437,6 +2532,275 @@ void GpuIndexIVF::search_listmajor_chunk_(int ni, const float* xq_pad, const idx
         launch_scatter_results(gD.as<float>(), gI.as<idx_t>(), k, olist.as<uint32_t>(), novf, dD, dI, R.stream);
         R.sync(); // the gathered buffers die with this scope
     }
+}
+
+// One chunk of queries through the filter path: plan -> sweep 1 (granule minima) -> bound -> sweep 2 (collect) -> exact
+// rerank of the candidates -> k-selection.  rt_g = rows per item | granule blocks << 16.
+void GpuIndexIVF::search_listmajor_filter_chunk_(int ni, int q0, const float* xq_pad, const idx_t* c_ids, const float* c_dis, int np,
+                                                 int k, float* dD, idx_t* dI, int64_t stride, int rt_g,
+                                                 std::vector<uint32_t>& redo) const {
+    const GpuResources& R = *res_;
+    const int RT = rt_g & 0xffff, G = rt_g >> 16;
+    int64_t sum_nrt = 0, nrt_max = 1;
+    uint32_t max_len = 1;
+    for (auto l : list_len_) {
+        const int64_t nrt = (int64_t)div_up(l, (size_t)RT);
+        sum_nrt += nrt;
+        nrt_max = std::max(nrt_max, nrt);
+        max_len = std::max(max_len, l);
+    }
+    const int64_t npairs = (int64_t)ni * np;
+    const int qpi = ivf_lmf_queries_per_item(fused_kind_());
+    const int64_t max_items = nrt_max * (int64_t)div_up((size_t)npairs, (size_t)qpi) + 2 * sum_nrt + 16;
+    FA_THROW_IF_NOT_MSG(max_items < ((int64_t)1 << 30), "list-major scan: too many work items");
+    const int64_t gstride = 2 * (int64_t)np * (int64_t)div_up((size_t)max_len, (size_t)(32 * G));
+
+    IvfLmParams P{};
+    P.metric = metric_type;
+    P.nq = ni;
+    P.nprobe = np;
+    P.d = d;
+    P.dpad = dpad_;
+    P.nlist = nlist;
+    P.k = k;
+    P.xq = xq_pad;
+    P.ldq = dpad_;
+    P.coarse_ids = c_ids;
+    P.coarse_dis = c_dis;
+    P.list_len = d_list_len_.as<uint32_t>();
+    P.list_start = d_list_start_.as<int64_t>();
+    fill_lm_(P);
+    FA_THROW_IF_NOT(lmf_prepare_(P)); // (built by search_core_; here it only fills the fields)
+    lm_prefix_.ensure((size_t)ni * (np + 1) * 4 * 2);
+    lm_prefixg_.ensure((size_t)ni * (np + 1) * 4);
+    lm_p0_.ensure((size_t)ni * 4);
+    lm_cnt_.ensure((size_t)ni * 4);
+    lm_bucket_.ensure((size_t)4 * nlist * 4);
+    lm_bstart_.ensure((size_t)(2 * nlist + 1) * 4);
+    lm_pairs_.ensure((size_t)npairs * 4);
+    lm_items_.ensure((size_t)max_items * sizeof(IvfLmItem));
+    lm_bounds_.ensure(32);
+    lm_thrf_.ensure((size_t)ni * 4);
+    lm_keys_.ensure((size_t)ni * stride * 8);
+    lm_candpr_.ensure((size_t)ni * stride * 2);
+    lm_gmin_.ensure((size_t)ni * gstride * 4);
+    lm_ovf_.ensure((size_t)(ni + 1) * 4);
+    lm_qflags_.ensure((size_t)ni * 4);
+    lm_xnb_.ensure((size_t)ni * 4);
+    lm_qn_.ensure((size_t)ni * 4);
+    lm_scalar_.ensure(64);
+    if (!h_lm_) HIP_CHECK(hipHostMalloc((void**)&h_lm_, 64, hipHostMallocDefault));
+    P.prefix = lm_prefix_.as<uint32_t>();
+    P.prefix1 = P.prefix + (size_t)ni * (np + 1);
+    P.prefixg = lm_prefixg_.as<uint32_t>();
+    P.p0 = lm_p0_.as<uint32_t>();
+    P.cnt = lm_cnt_.as<uint32_t>();
+    P.bucket_cnt = lm_bucket_.as<uint32_t>();
+    P.bucket_fill = P.bucket_cnt + 2 * nlist;
+    P.bucket_start = lm_bstart_.as<uint32_t>();
+    P.pairs = lm_pairs_.as<uint32_t>();
+    P.items = lm_items_.as<IvfLmItem>();
+    P.item_bounds = lm_bounds_.as<uint32_t>();
+    P.max_items = (int)max_items;
+    P.rows_per_item = RT;
+    P.qpi = qpi;
+    P.filter = 1;
+    P.gran_blocks = G;
+    P.gmin = lm_gmin_.as<uint32_t>();
+    P.gstride = gstride;
+    P.thr_f = lm_thrf_.as<float>();
+    P.keys = lm_keys_.as<unsigned long long>();
+    P.cand_pr = lm_candpr_.as<uint16_t>();
+    P.stride = stride;
+    P.ovf = lm_ovf_.as<uint32_t>();
+    P.qflags = lm_qflags_.as<uint32_t>();
+    // ---- queries: fp16 copy + range flags + |q|^2 (the sequential chain of the flat index)
+    {
+        SpanGuard sg(&R, "ivf_lmf_prepare");
+        const int dh = (int)round_up(d, 16);
+        lm_q16_.ensure((size_t)ni * dh * 2);
+        launch_prep_queries(xq_pad, dpad_, ni, d, dpad_, lm_q16_.p, dh, lm_qflags_.as<uint32_t>(), lm_qn_.as<float>(),
+                            lm_scalar_.as<unsigned>(), R.stream);
+        P.xq16 = lm_q16_.p;
+        P.ldq16 = dh;
+        P.xqn = lm_qn_.as<float>();
+        P.xn_full = lm_qn_.as<float>();
+        if (P.kind == 1) {
+            lm_pqgrid_.ensure((size_t)ni * 8);
+            P.pq_grid = lm_pqgrid_.as<float>();
+            launch_ivf_lmf_pq_prepare(P, lm_xnb_.as<float>(), R.stream);
+        }
+        // granule slots nobody writes must never look like good estimates
+        HIP_CHECK(hipMemsetAsync(P.gmin, 0xff, (size_t)ni * gstride * 4, R.stream));
+    }
+    {
+        SpanGuard sg(&R, "ivf_lm_plan");
+        launch_ivf_lm_plan(P, R.stream);
+    }
+    const int grid = ivf_lmf_grid_blocks(P, R.num_cus);
+    {
+        SpanGuard sg(&R, "ivf_lmf_sweep_min");
+        launch_ivf_lmf_sweep(P, 1, grid, R.stream);
+    }
+    {
+        SpanGuard sg(&R, "ivf_lmf_bound");
+        launch_ivf_lmf_bound(P, P.kind == 1 ? lm_xnb_.as<float>() : lm_qn_.as<float>(), R.stream);
+    }
+    {
+        SpanGuard sg(&R, "ivf_lmf_sweep_collect");
+        launch_ivf_lmf_sweep(P, 2, grid, R.stream);
+    }
+    launch_ivf_lm_clamp(P, R.stream);
+    {
+        SpanGuard sg(&R, "ivf_lmf_rerank");
+        launch_ivf_lmf_rerank(P, R.stream);
+    }
+    SelectParams sp{};
+    sp.metric = metric_type;
+    sp.nq = ni;
+    sp.k = k;
+    sp.keys = P.keys;
+    sp.q_stride = stride;
+    sp.nseg = 1;
+    sp.seg_stride = 0;
+    sp.seg_cnt = P.cnt;
+    sp.mode = 1;
+    sp.max_cnt = stride;
+    sp.nprobe = np;
+    sp.ivf_prefix = P.prefix;
+    sp.coarse_ids = c_ids;
+    sp.list_start = d_list_start_.as<int64_t>();
+    sp.arena_ids = arena_ids_.as<int64_t>();
+    sp.out_dis = dD;
+    sp.out_ids = dI;
+    {
+        SpanGuard sg(&R, "select_k_kernel");
+        launch_select_k(sp, R.stream);
+    }
+    // one read-back: queries to redo (+ the item-table check)
+    HIP_CHECK(hipMemcpyAsync(&h_lm_[0], P.ovf, 4, hipMemcpyDeviceToHost, R.stream));
+    HIP_CHECK(hipMemcpyAsync(&h_lm_[1], P.item_bounds + 3, 4, hipMemcpyDeviceToHost, R.stream));
+    R.sync();
+    FA_THROW_IF_NOT_MSG(h_lm_[1] == 0, "list-major scan: work-item table too small (internal error)");
+    const int novf = (int)h_lm_[0];
+    lm_overflows_ += novf;
+    if (novf > 0) {
+        std::vector<uint32_t> ol((size_t)novf);
+        HIP_CHECK(hipMemcpy(ol.data(), P.ovf + 1, (size_t)novf * 4, hipMemcpyDeviceToHost));
+        for (uint32_t q : ol) redo.push_back(q + (uint32_t)q0);
+    }
+}
+
+void GpuIndexIVF::test_filter_dump(idx_t n, const float* x, int nprobe_now, idx_t k, int64_t stride, unsigned long long* keys_out,
+                                   float* band_out) const {
+    FA_THROW_IF_NOT_MSG(is_trained && nstored_ > 0 && n >= 1 && n <= 65536 && x && keys_out && band_out, "bad arguments");
+    FA_THROW_IF_NOT_MSG(lmf_capable_(), "the f16 filter does not serve this index type / shape");
+    std::lock_guard<std::mutex> g(mu_);
+    res_->set_device();
+    const GpuResources& R = *res_;
+    const int ni = (int)n, np = std::min(nprobe_now, nlist);
+    uint32_t max_len = 1;
+    for (auto l : list_len_) max_len = std::max(max_len, l);
+    FA_THROW_IF_NOT_MSG(stride >= (int64_t)np * max_len, "stride below nprobe x the longest list");
+    q_pad_.ensure((size_t)ni * dpad_ * 4);
+    stage_padded(R, x, ni, d, dpad_, q_raw_, q_pad_.as<float>());
+    c_dis_.ensure((size_t)ni * np * 4);
+    c_ids_.ensure((size_t)ni * np * 8);
+    quantizer->search_device(ni, q_pad_.as<float>(), np, c_dis_.as<float>(), c_ids_.as<idx_t>());
+    const int RT = kLmRowsPerItem, G = 1;
+    int64_t sum_nrt = 0, nrt_max = 1;
+    for (auto l : list_len_) {
+        const int64_t nrt = (int64_t)div_up(l, (size_t)RT);
+        sum_nrt += nrt;
+        nrt_max = std::max(nrt_max, nrt);
+    }
+    const int64_t npairs = (int64_t)ni * np;
+    const int qpi = ivf_lmf_queries_per_item(fused_kind_());
+    const int64_t max_items = nrt_max * (int64_t)div_up((size_t)npairs, (size_t)qpi) + 2 * sum_nrt + 16;
+    const int64_t gstride = 2 * (int64_t)np * (int64_t)div_up((size_t)max_len, (size_t)(32 * G));
+    IvfLmParams P{};
+    P.metric = metric_type;
+    P.nq = ni;
+    P.nprobe = np;
+    P.d = d;
+    P.dpad = dpad_;
+    P.nlist = nlist;
+    P.k = (int)k;
+    P.xq = q_pad_.as<float>();
+    P.ldq = dpad_;
+    P.coarse_ids = c_ids_.as<idx_t>();
+    P.coarse_dis = c_dis_.as<float>();
+    P.list_len = d_list_len_.as<uint32_t>();
+    P.list_start = d_list_start_.as<int64_t>();
+    fill_lm_(P);
+    FA_THROW_IF_NOT_MSG(lmf_prepare_(P), "stored values outside the fp16 range");
+    DevBuf prefix, prefixg, p0, cnt, bucket, bstart, pairs, items, bounds, thrf, keys, gmin, ovf, qflags, xnb, qn, q16, scalar, grid,
+            band;
+    prefix.ensure((size_t)ni * (np + 1) * 8);
+    prefixg.ensure((size_t)ni * (np + 1) * 4);
+    p0.ensure((size_t)ni * 4);
+    cnt.ensure((size_t)ni * 4);
+    bucket.ensure((size_t)4 * nlist * 4);
+    bstart.ensure((size_t)(2 * nlist + 1) * 4);
+    pairs.ensure((size_t)npairs * 4);
+    items.ensure((size_t)max_items * sizeof(IvfLmItem));
+    bounds.ensure(32);
+    thrf.ensure((size_t)ni * 4);
+    keys.ensure((size_t)ni * stride * 8);
+    gmin.ensure((size_t)ni * gstride * 4);
+    ovf.ensure((size_t)(ni + 1) * 4);
+    qflags.ensure((size_t)ni * 4);
+    xnb.ensure((size_t)ni * 4);
+    qn.ensure((size_t)ni * 4);
+    scalar.ensure(64);
+    band.ensure((size_t)ni * 4);
+    HIP_CHECK(hipMemcpyAsync(band.p, band_out, (size_t)ni * 4, hipMemcpyHostToDevice, R.stream));
+    HIP_CHECK(hipMemsetAsync(keys.p, 0xff, (size_t)ni * stride * 8, R.stream));
+    HIP_CHECK(hipMemsetAsync(gmin.p, 0xff, (size_t)ni * gstride * 4, R.stream));
+    P.prefix = prefix.as<uint32_t>();
+    P.prefix1 = P.prefix + (size_t)ni * (np + 1);
+    P.prefixg = prefixg.as<uint32_t>();
+    P.p0 = p0.as<uint32_t>();
+    P.cnt = cnt.as<uint32_t>();
+    P.bucket_cnt = bucket.as<uint32_t>();
+    P.bucket_fill = P.bucket_cnt + 2 * nlist;
+    P.bucket_start = bstart.as<uint32_t>();
+    P.pairs = pairs.as<uint32_t>();
+    P.items = items.as<IvfLmItem>();
+    P.item_bounds = bounds.as<uint32_t>();
+    P.max_items = (int)max_items;
+    P.rows_per_item = RT;
+    P.qpi = qpi;
+    P.filter = 1;
+    P.gran_blocks = G;
+    P.gmin = gmin.as<uint32_t>();
+    P.gstride = gstride;
+    P.thr_f = thrf.as<float>();
+    P.keys = keys.as<unsigned long long>();
+    P.stride = stride;
+    P.ovf = ovf.as<uint32_t>();
+    P.qflags = qflags.as<uint32_t>();
+    P.band_out = band.as<float>();
+    const int dh = (int)round_up(d, 16);
+    q16.ensure((size_t)ni * dh * 2);
+    launch_prep_queries(P.xq, dpad_, ni, d, dpad_, q16.p, dh, qflags.as<uint32_t>(), qn.as<float>(), scalar.as<unsigned>(), R.stream);
+    P.xq16 = q16.p;
+    P.ldq16 = dh;
+    P.xqn = qn.as<float>();
+    P.xn_full = qn.as<float>();
+    if (P.kind == 1) {
+        grid.ensure((size_t)ni * 8);
+        P.pq_grid = grid.as<float>();
+        launch_ivf_lmf_pq_prepare(P, xnb.as<float>(), R.stream);
+    }
+    launch_ivf_lm_plan(P, R.stream);
+    const int gb = ivf_lmf_grid_blocks(P, R.num_cus);
+    launch_ivf_lmf_sweep(P, 1, gb, R.stream);
+    launch_ivf_lmf_bound(P, P.kind == 1 ? xnb.as<float>() : qn.as<float>(), R.stream);
+    launch_ivf_lmf_sweep(P, 3, gb, R.stream);
+    HIP_CHECK(hipMemcpyAsync(keys_out, keys.p, (size_t)ni * stride * 8, hipMemcpyDeviceToHost, R.stream));
+    HIP_CHECK(hipMemcpyAsync(band_out, band.p, (size_t)ni * 4, hipMemcpyDeviceToHost, R.stream));
+    R.sync();
 }
 
 // ---------------------------------------------------------------------- IVF scalar quantizer
@@ -2654,7 +3018,39 @@ GpuIndexIVFFlat::GpuIndexIVFFlat(std::shared_ptr<GpuResources> res, int dims, in
         : GpuIndexIVF(std::move(res), dims, metric, nlist) {
     code_bytes_ = (size_t)dpad_ * 4;
     granule_ = 8;
-    use_rn_ = metric == METRIC_L2;
+    // |y|^2 per stored row: second term of the list-major scans' L2 distances / estimates; the filter's error band needs
+    // max |y|^2 for the inner product as well
+    use_rn_ = true;
+}
+bool GpuIndexIVFFlat::lmf_capable_() const {
+    return ivf_lmf_supported(0, d, dpad_, 0);
+}
+// fp16 shadow of the arena rows for the f16 sweeps of ivf_lm_filter.hip.  Rebuilt as a whole (one pass over the lists,
+// 6 bytes per coordinate) at the first list-major search after a list changed (add / copy_lists / compaction): a
+// database that is built once and searched many times pays it once, interleaved add / search workloads pay one arena
+// pass per add call.
+bool GpuIndexIVFFlat::lmf_prepare_(IvfLmParams& p) const {
+    const int dh = (int)round_up(d, 16);
+    if (shadow_dirty_) {
+        const GpuResources& R = *res_;
+        arena_h_.ensure(((size_t)arena_cap_rows_ + 128) * dh * 2);
+        lm_scalar_.ensure(64);
+        HIP_CHECK(hipMemsetAsync(lm_scalar_.p, 0, 4, R.stream));
+        launch_ivf_lmf_shadow(arena_.as<float>(), dpad_, arena_rn_.as<float>(), d, nlist, d_list_len_.as<uint32_t>(),
+                              d_list_start_.as<int64_t>(), arena_h_.p, dh, lm_scalar_.as<unsigned>(), R.stream);
+        unsigned bits = 0;
+        HIP_CHECK(hipMemcpyAsync(&bits, lm_scalar_.p, 4, hipMemcpyDeviceToHost, R.stream));
+        R.sync();
+        shadow_in_range_ = bits != 0x7f800000u;
+        memcpy(&shadow_yn_max_, &bits, 4);
+        shadow_dirty_ = false;
+    }
+    if (!shadow_in_range_) return false;
+    p.filter = 1;
+    p.arena_h = arena_h_.p;
+    p.ldh = dh;
+    p.yn_max = shadow_yn_max_;
+    return true;
 }
 void GpuIndexIVFFlat::append_(int n, const float* x_pad, const int64_t*, const int64_t* d_dest) {
     launch_ivfflat_append(x_pad, dpad_, n, d, d_dest, arena_.as<float>(), dpad_, dpad_, res_->stream);
@@ -2755,6 +3151,7 @@ void GpuIndexIVFPQ::set_pq_centroids(const float* pq) {
     res_->sync();
     std::swap(pq_.p, npq.p);
     std::swap(pq_.cap, npq.cap);
+    lmf_quant_dirty_ = true;
     update_is_trained_();
     if (nstored_ > 0 && is_trained) lists_changed_();
 }
@@ -2919,6 +3316,60 @@ bool GpuIndexIVFPQ::ivf_lm_pq_lds_supported_() const {
 }
 bool GpuIndexIVFPQ::lm_capable_() const {
     return ivf_lm_supported(1, dpad_, M, d);
+}
+bool GpuIndexIVFPQ::lmf_capable_() const {
+    return ivf_lmf_supported(1, d, dpad_, M) && (size_t)d * 512 + 8 * 32 * (size_t)(round_up(M, 16) + 16) + 8 * 256 * 12 <= 160 * 1024;
+}
+// fp16 codebook + the norm bounds of the filter's error band: upper bound of |r^|^2 (sum over the sub-quantizers of their
+// largest squared entry norm), max |centroid|^2.  Rebuilt when a quantizer changed.
+bool GpuIndexIVFPQ::lmf_prepare_(IvfLmParams& p) const {
+    if (lmf_quant_dirty_) {
+        FA_THROW_IF_NOT_MSG(pq_.p && quantizer->ntotal == nlist, "index not trained");
+        std::vector<float> cb((size_t)M * 256 * dsub);
+        HIP_CHECK(hipMemcpy(cb.data(), pq_.p, cb.size() * 4, hipMemcpyDeviceToHost));
+        std::vector<_Float16> h(cb.size());
+        bool ok = true;
+        double yn = 0.0;
+        for (int m = 0; m < M; m++) {
+            double mx = 0.0;
+            for (int c = 0; c < 256; c++) {
+                double nn = 0.0;
+                for (int jd = 0; jd < dsub; jd++) {
+                    const float v = cb[((size_t)m * 256 + c) * dsub + jd];
+                    if (!(std::fabs(v) <= 65000.f)) ok = false;
+                    h[((size_t)m * 256 + c) * dsub + jd] = (_Float16)v;
+                    nn += (double)v * (double)v;
+                }
+                mx = std::max(mx, nn);
+            }
+            yn += mx;
+        }
+        std::vector<float> cen((size_t)nlist * dpad_);
+        HIP_CHECK(hipMemcpy(cen.data(), quantizer->device_vectors(), cen.size() * 4, hipMemcpyDeviceToHost));
+        double cn = 0.0;
+        for (int l = 0; l < nlist; l++) {
+            double nn = 0.0;
+            for (int jd = 0; jd < d; jd++) {
+                const float v = cen[(size_t)l * dpad_ + jd];
+                if (!(std::fabs(v) <= 30000.f)) ok = false;
+                nn += (double)v * (double)v;
+            }
+            cn = std::max(cn, nn);
+        }
+        pq16_.ensure(h.size() * 2);
+        HIP_CHECK(hipMemcpy(pq16_.p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+        pq16_in_range_ = ok && yn < 1e30 && cn < 1e30;
+        pq_yn_max_ = (float)(yn * 1.0001);
+        cn_max_ = (float)(cn * 1.0001);
+        lmf_quant_dirty_ = false;
+    }
+    if (!pq16_in_range_) return false;
+    p.filter = 1;
+    p.pq16 = pq16_.p;
+    p.yn_max = pq_yn_max_;
+    p.cn_max = cn_max_;
+    p.arena_t2 = arena_t2_.as<float>();
+    return true;
 }
 void GpuIndexIVFPQ::fill_lm_(IvfLmParams& p) const {
     p.kind = 1;

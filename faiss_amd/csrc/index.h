@@ -438,7 +438,22 @@ class GpuIndexIVF : public Index {
     mutable int last_scan_mode_ = 0;
     mutable long lm_overflows_ = 0; // statistics: queries redone because their candidate segment overflowed
     void search_listmajor_(int ni, const float* xq_pad, const idx_t* c_ids, const float* c_dis, int np, int k, float* dD,
-                           idx_t* dI, int level) const;
+                           idx_t* dI, int level, std::vector<uint32_t>* redo = nullptr) const;
+    // ---- list-major search behind the f16 filter (ivf_lm_filter.hip; IVFFlat, IVFPQ): results bit-identical to the
+    // query-major scan.  lmf_capable_: index type / shape; lmf_prepare_: (re)build what the sweeps need beside the lists
+    // (IVFFlat: the fp16 shadow of the arena rows + max |y|^2; IVFPQ: the fp16 codebook + norm bounds) when a list or a
+    // quantizer changed since the last call, and fill the filter fields of `p`; false = the stored values leave the
+    // fp16 range (the search takes the query-major scan).
+    virtual bool lmf_capable_() const { return false; }
+    virtual bool lmf_prepare_(struct IvfLmParams& p) const { return false; }
+    mutable bool cur_lmf_ = false;        // the list-major search in flight runs the filter sweeps
+    mutable int last_scan_arith_ = 0;     // oracle restatement of the last search: 0 query-major arithmetic, 1 f32 list-major
+    mutable bool shadow_dirty_ = true;    // a list changed since the fp16 shadow was built
+    mutable bool lmf_quant_dirty_ = true; // a quantizer changed since the fp16 codebook / norm bounds were built
+    mutable DevBuf lm_prefixg_, lm_gmin_, lm_thrf_, lm_candpr_, lm_q16_, lm_qflags_, lm_xnb_, lm_pqgrid_, lm_scalar_;
+    // queries whose candidate segment overflowed (or that leave the fp16 range) are appended to `redo`
+    void search_listmajor_filter_chunk_(int ni, int q0, const float* xq_pad, const idx_t* c_ids, const float* c_dis, int np, int k,
+                                        float* dD, idx_t* dI, int64_t stride, int RT, std::vector<uint32_t>& redo) const;
     void search_listmajor_chunk_(int ni, const float* xq_pad, const idx_t* c_ids, const float* c_dis, int np, int k,
                                  float* dD, idx_t* dI, int level, int64_t stride, int min_p1, int RT, int64_t c1max) const;
     void upload_list_tables_();
@@ -459,14 +474,28 @@ class GpuIndexIVF : public Index {
     bool use_fused_scan = true;
     // which scan serves search(): 0 = automatic (list-major for batches of >= 2048 queries that probe every list
     // >= 8 times on average, without IDSelector, when the index type / dimension support it), 1 = query-major always
-    // (ivf_fused.hip), 2 = list-major always (throws when unsupported).  The two differ in arithmetic,
-    // each bit-exact against its own restatement in the oracle.
+    // (ivf_fused.hip), 2 = list-major always (throws when unsupported): IVFFlat / IVFPQ behind the f16 filter of
+    // ivf_lm_filter.hip -- results bit-identical to the query-major scan --, the scalar quantizer on the f32 matrix pipe;
+    // 3 = list-major on the f32 matrix pipe for every type (round 3's scan, its own arithmetic: DESIGN.md 3.9).
     int scan_mode = 0;
     // what the last search() call used: 1 = query-major, 2 = list-major
     int last_scan_mode() const { return last_scan_mode_; }
+    // ... and under which `arith` the oracle restates it: 0 = the query-major arithmetic (also what the list-major scan
+    // behind the f16 filter returns, scan_mode 2 on IVFFlat / IVFPQ), 1 = the f32 list-major arithmetic (scan_mode 3, and
+    // the scalar quantizer's list-major scan)
+    int last_scan_arith() const { return last_scan_arith_; }
     long list_major_overflows() const { return lm_overflows_; }
     // the rule of scan_mode 0
     bool list_major_rule(idx_t n, int nprobe_now, idx_t k, bool has_selector) const;
+    // tuning experiments of the filter path (faiss_amd_GpuIndexIVF_set_lmf_tuning; 0 = the built-in rule): rows of a list
+    // per work item (a multiple of 256), 32-row blocks per granule (a power of two <= 8), candidate room per query
+    int lmf_rows_per_item = 0, lmf_gran_blocks = 0, lmf_cand_cap = 0;
+    // test hook (faiss_amd_GpuIndexIVF_test_filter_dump): the ESTIMATES of the f16 filter sweeps for every row the n
+    // queries probe, as keys (ordkey(estimate) << 32 | scan position) at keys_out[q * stride + scan position], and the
+    // error band E_q the bound kernel derives for each query (band_out [n], written for queries whose probed lists hold
+    // >= k granules; others keep the caller's value).  x: host, n <= 65536; stride >= rows any query probes.
+    void test_filter_dump(idx_t n, const float* x, int nprobe_now, idx_t k, int64_t stride, unsigned long long* keys_out,
+                          float* band_out) const;
 };
 
 class GpuIndexIVFFlat : public GpuIndexIVF {
@@ -486,6 +515,11 @@ class GpuIndexIVFFlat : public GpuIndexIVF {
     void lists_changed_() override;
     bool lm_capable_() const override;
     void fill_lm_(struct IvfLmParams& p) const override;
+    bool lmf_capable_() const override;
+    bool lmf_prepare_(struct IvfLmParams& p) const override;
+    mutable DevBuf arena_h_;          // fp16 shadow of the arena rows [arena_cap_rows_ + 128][dh_]
+    mutable float shadow_yn_max_ = 0.f;
+    mutable bool shadow_in_range_ = true;
 };
 
 class GpuIndexIVFPQ : public GpuIndexIVF {
@@ -520,6 +554,11 @@ class GpuIndexIVFPQ : public GpuIndexIVF {
     DevBuf pq_t_; // [256][M][dsub]: the order the scan kernels build their lookup table in
     DevBuf zero_row_; // dpad zeros: the "centroid" with which the per-row term kernels yield |r^|^2 (arena_rn_)
     bool lm_capable_() const override;
+    bool lmf_capable_() const override;
+    bool lmf_prepare_(struct IvfLmParams& p) const override;
+    mutable DevBuf pq16_;             // fp16 codebook [M][256][dsub]
+    mutable float pq_yn_max_ = 0.f, cn_max_ = 0.f;
+    mutable bool pq16_in_range_ = true;
     bool lm_pq_lds_capable_() const override { return ivf_lm_pq_lds_supported_(); }
     bool ivf_lm_pq_lds_supported_() const;
     void train_pq_batched_(idx_t nt, const float* res, std::vector<float>& pq);

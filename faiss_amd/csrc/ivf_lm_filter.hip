@@ -1,0 +1,1051 @@
+// faiss_amd/csrc/ivf_lm_filter.hip -- list-major inverted-list search behind an f16 MFMA filter (round 4, gfx950).
+//
+// The list-major scan of round 3 (ivf_listmajor.hip) computes EVERY (query, row) distance of a batch on the f32 matrix
+// pipe (v_mfma_f32_32x32x2_f32, 157 TFLOP/s) and reads a list once per 32-query group.  The f16 pipe is 16 x faster
+// (v_mfma_f32_32x32x16_f16) and its B operands are half as wide, so here -- the scheme of the flat index
+// (flat_filter.hip) carried into the lists -- the matrix pipe only ESTIMATES:
+//   sweep 1 (MODE_MIN)      every probed row x every query that probes its list: estimate d~ on the f16 pipe; per lane the
+//                           best estimate of every granule (16 G rows) goes to gmin[q][slot].  Nothing else is written.
+//   bound                   T_q = k-th best granule estimate = an upper bound of the k-th best ESTIMATE of the query
+//                           (granule minima are distinct rows); thr_q = T_q + 2 E_q with E_q >= |d~ - d| for every row
+//                           (kernels.h ivf_filter_err_bound).  The k best rows by estimate have exact distance <= T_q + E_q, so
+//                           a row of the exact top-k has estimate <= T_q + 2 E_q: the rows the second sweep collects are a
+//                           SUPERSET of the exact answer, whatever the data.
+//   sweep 2 (MODE_COLLECT)  the same sweep; rows with d~ <= thr_q are parked (wave-private LDS slice) and flushed to the
+//                           query's candidate segment (~ k .. 2 k rows per query).
+//   rerank                  the EXACT distance of every candidate, with the arithmetic of the QUERY-MAJOR scan
+//                           (ivf_fused.hip: IVFFlat eight partial chains of (q - y)^2 + butterfly; IVFPQ the table sum on
+//                           the query's power-of-two grid + the per-row term): a large batch now returns, bit for bit,
+//                           what the same queries return one at a time (oracle: orc_ivf_search_ex, arith 0).
+//   select                  select_k_kernel / wave_select_kernel over the segment, as for every other scan.
+// A work item is (list, up to 96 of the queries probing it, a chunk of its rows) and belongs to ONE wavefront: the
+// queries' fp16 coordinates are its B operands (32 VGPRs per 32-query block, three blocks), the rows' fp16 shadow
+// (IVFFlat: arena_h, 2 bytes per coordinate) or the fp16 codebook entries their codes select (IVFPQ, codebook in LDS) are
+// the A operands; a list is read once per sweep for up to 96 queries instead of once per 32.  The sweeps are bound by
+// the row stream (IVFFlat: nb * d * 2 bytes per sweep) / the LDS gathers (IVFPQ), not by the matrix pipe any more.
+// Reference behaviour kept: faiss/gpu/impl/IVFInterleaved.cuh:33-224, PQScanMultiPassNoPrecomputed-inl.cuh:173-270
+// (exhaustive scan of the probed lists, k best under (distance, scan position)).
+#include "kernels.h"
+#include <type_traits>
+
+namespace faiss_amd {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned long long u64;
+
+constexpr int LF_THREADS = 256;
+constexpr int LF_PARK = 1024;                     // parked candidates per wave (a (32-row, 32-query) block always fits)
+constexpr int LF_LDS = 4 * LF_PARK * (8 + 4);     // 48 KB: two workgroups per CU
+constexpr int MODE_MIN = 1, MODE_COLLECT = 2, MODE_DUMP = 3;
+
+template <int METRIC>
+__device__ __forceinline__ float lmf_worst() {
+    return METRIC == METRIC_L2 ? INFINITY : -INFINITY;
+}
+template <int METRIC>
+__device__ __forceinline__ float lmf_better(float a, float b) { // NaN-ignoring (v_min_f32 / v_max_f32 return the number)
+    return METRIC == METRIC_L2 ? fminf(a, b) : fmaxf(a, b);
+}
+// stores the compiler does not see (see ivf_listmajor.hip, pass 1 of the register-fed kernel: with a store of its own in
+// the block loop hipcc stops counting the loads in flight and waits vmcnt(0) before every use)
+__device__ __forceinline__ void lmf_store_u32(uint32_t* at, uint32_t v) {
+    asm volatile("global_store_dword %0, %1, off" ::"v"(at), "v"(v));
+}
+__device__ __forceinline__ void lmf_store_u64(u64* at, u64 v) {
+    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(at), "v"(v));
+}
+
+bool ivf_lmf_supported(int kind, int d, int dpad, int M) {
+    if (dpad > 128 || (dpad & 7) || d < 1) return false;
+    if (kind == 0) return true;
+    if (kind == 1) {
+        if (M < 4 || (M & 3) || d % M) return false;
+        const int dsub = d / M;
+        // an MFMA operand = 8 consecutive coordinates: whole sub-vectors (dsub 1, 2, 4, 8) or a piece of one (8 | dsub)
+        if (!(dsub == 1 || dsub == 2 || dsub == 4 || (dsub & 7) == 0)) return false;
+        return d == dpad && (d & 15) == 0; // (rows of a multiple of 16 coordinates: no tail handling in the decode)
+    }
+    return false;
+}
+int ivf_lmf_queries_per_item(int) {
+    return 32 * kLmfQueryBlocks;
+}
+
+// ------------------------------------------------------------------ fp16 shadow of the IVFFlat rows
+__global__ void __launch_bounds__(256) lmf_shadow_kernel(const float* __restrict__ arena, int64_t ldv,
+                                                         const float* __restrict__ arena_rn, int d, const uint32_t* list_len,
+                                                         const int64_t* list_start, _Float16* __restrict__ arena_h, int dh,
+                                                         unsigned* __restrict__ yn_max_bits) {
+    const int list = blockIdx.x;
+    const uint32_t len = list_len[list];
+    const int64_t start = list_start[list];
+    const int pieces = dh >> 3; // 8-coordinate pieces per row
+    float mx = 0.f;
+    bool bad = false;
+    const int64_t total = (int64_t)len * pieces;
+    for (int64_t i = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.y * blockDim.x) {
+        const int64_t r = i / pieces;
+        const int c = (int)(i - r * pieces) * 8;
+        const float* src = arena + (start + r) * ldv + c;
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = c + e < d ? src[e] : 0.f;
+            if (!(fabsf(v) <= 65000.f)) bad = true; // NaN, inf, or beyond the fp16 normal range
+            o[e] = (_Float16)v;
+        }
+        *(half8*)(arena_h + (start + r) * dh + c) = o;
+        if (c == 0 && arena_rn) {
+            const float n = arena_rn[start + r];
+            if (!(n <= 3.0e38f)) bad = true;
+            mx = fmaxf(mx, n);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    const bool anybad = __ballot(bad) != 0ull;
+    if ((threadIdx.x & 63) == 0) atomicMax(yn_max_bits, anybad ? 0x7f800000u : __float_as_uint(mx));
+}
+void launch_ivf_lmf_shadow(const float* arena, int64_t ldv, const float* arena_rn, int d, int nlist, const uint32_t* list_len,
+                           const int64_t* list_start, void* arena_h, int dh, unsigned* yn_max_bits, hipStream_t stream) {
+    if (nlist == 0) return;
+    hipLaunchKernelGGL(lmf_shadow_kernel, dim3((unsigned)nlist, 4), dim3(256), 0, stream, arena, ldv, arena_rn, d, list_len,
+                       list_start, (_Float16*)arena_h, dh, yn_max_bits);
+    HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ epilogue shared by the two sweep kernels
+// acc: the 16 inner products of this lane's query of block b with rows 8 g + 4 h + e of the 32-row block at list row t.
+struct LmfLane { // per (lane, query block)
+    bool qv;
+    int q;
+    uint32_t base_pos, qpr;
+    float xn, thr, gm;
+    uint32_t* gq; // MODE_MIN: gmin + q * gstride + granule-slot base of this (query, probe) + h
+    u64* kq;      // MODE_DUMP: keys + q * stride + base_pos
+};
+
+// ------------------------------------------------------------------ IVFFlat sweep
+// One WAVEFRONT per work item, items drawn from a counter; A operands global -> registers one 32-row block ahead, refilled
+// right behind the MFMAs that consumed them (the walk of ivf_lm_flat_reg_kernel).  FULL: ldh == 128 (8 k-steps).
+template <int METRIC, int MODE, int NQB, bool FULL>
+__global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    const int j = lane & 31;
+    const int np = p.nprobe;
+    const int nks = FULL ? 8 : (int)(p.ldh >> 4);
+    const int G = p.gran_blocks, gsh = __builtin_ctz((unsigned)p.gran_blocks); // (a power of two)
+    const _Float16* xq16 = (const _Float16*)p.xq16;
+    const _Float16* arena_h = (const _Float16*)p.arena_h;
+    u64* pk_keys = (u64*)smem + wave * LF_PARK;
+    uint32_t* pk_q = (uint32_t*)(smem + 4 * LF_PARK * 8) + wave * LF_PARK;
+    int wcnt = 0; // (wave-uniform) parked candidates
+    auto flush = [&]() __attribute__((always_inline)) {
+        for (int e = lane; e < wcnt; e += 64) {
+            const u64 key = pk_keys[e];
+            const uint32_t qp = pk_q[e];
+            const uint32_t qq = qp >> 11;
+            const uint32_t slot = atomicAdd(p.cnt + qq, 1u);
+            if ((int64_t)slot < p.stride) {
+                p.keys[(int64_t)qq * p.stride + slot] = key;
+                p.cand_pr[(int64_t)qq * p.stride + slot] = (uint16_t)(qp & 2047u);
+            }
+        }
+        wcnt = 0;
+        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): no store in flight on any path into the block loop
+    };
+
+    const uint32_t it0 = p.item_bounds[1], it1 = p.item_bounds[2];
+    uint32_t* ctr = p.item_bounds + (MODE == MODE_MIN ? 5 : 4); // both zeroed by the plan
+    for (;;) {
+        uint32_t it = 0;
+        if (lane == 0) it = atomicAdd(ctr, 1u);
+        it = it0 + (uint32_t)__builtin_amdgcn_readfirstlane((int)it);
+        if (it >= it1) break;
+        const IvfLmItem item = p.items[it];
+        const int bk = __builtin_amdgcn_readfirstlane(item.bucket);
+        const int qt = __builtin_amdgcn_readfirstlane(item.qt);
+        const int rt = __builtin_amdgcn_readfirstlane(item.rt);
+        const int list = bk >> 1;
+        const int len = (int)p.list_len[list];
+        const int64_t start = p.list_start[list];
+        const uint32_t pb = p.bucket_start[bk];
+        const int npair = min(32 * NQB, (int)(p.bucket_start[bk + 1 + item.both] - pb) - qt * (32 * NQB));
+        const int r0 = rt * p.rows_per_item;
+        const int r1 = min(len, r0 + p.rows_per_item);
+
+        // ---- this lane's queries: one per 32-query block
+        LmfLane L[NQB];
+        half8 bq[NQB][8];
+#pragma unroll
+        for (int b = 0; b < NQB; ++b) {
+            const int my = b * 32 + j;
+            L[b].qv = my < npair;
+            const uint32_t pi = p.pairs[pb + (uint32_t)(qt * (32 * NQB)) + (uint32_t)(L[b].qv ? my : 0)];
+            const int q = (int)(pi / (uint32_t)np);
+            const int pr = (int)(pi - (uint32_t)q * (uint32_t)np);
+            L[b].q = q;
+            const _Float16* qrow = xq16 + (int64_t)q * p.ldq16 + 8 * h;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                if (FULL || s < nks) bq[b][s] = *(const half8*)(qrow + 16 * s);
+                else bq[b][s] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+            L[b].xn = METRIC == METRIC_L2 ? p.xqn[q] : 0.f;
+            L[b].base_pos = p.prefix[(int64_t)q * (np + 1) + pr];
+            L[b].qpr = ((uint32_t)q << 11) | (uint32_t)pr;
+            L[b].thr = 0.f;
+            L[b].gm = lmf_worst<METRIC>();
+            L[b].gq = nullptr;
+            L[b].kq = nullptr;
+            if (MODE == MODE_MIN) L[b].gq = p.gmin + (int64_t)q * p.gstride + p.prefixg[(int64_t)q * (np + 1) + pr] + h;
+            if (MODE == MODE_COLLECT) L[b].thr = p.thr_f[q];
+            if (MODE == MODE_DUMP) L[b].kq = p.keys + (int64_t)q * p.stride + L[b].base_pos;
+        }
+
+        int t = r0;
+        int skip_b = 0; // MODE_COLLECT: query blocks of block t whose candidates were parked before the slice filled up
+        while (t < r1) {
+            // ---- (re-)entry: the rows of block t.  Rows behind the end of the list belong to the next list or the
+            // arena's padding: loaded, never looked at.
+            const _Float16* arow = arena_h + (start + t + j) * p.ldh + 8 * h;
+            half8 a[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                if (FULL || s < nks) a[s] = *(const half8*)(arow + 16 * s);
+                else a[s] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+                asm volatile("" ::: "memory");
+            }
+            const float* rnp = p.arena_rn + start + t + 4 * h; // |y|^2 of rows 8 g + 4 h + e of the block: rnp[8 g + e]
+            bool full = false;
+            for (; t < r1; t += 32) {
+                arow += 32 * p.ldh;
+                rnp += 32;
+                f32x16 acc[NQB];
+#pragma unroll
+                for (int b = 0; b < NQB; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+                f32x4 rn[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) rn[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+                // (the refills are UNCONDITIONAL -- behind the last block they read the rows that follow the list)
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    if (FULL || s < nks) {
+#pragma unroll
+                        for (int b = 0; b < NQB; ++b)
+                            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s], bq[b][s], acc[b], 0, 0, 0);
+                        a[s] = *(const half8*)(arow + 16 * s);
+                    }
+                    if (s == 3 && METRIC == METRIC_L2) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) rn[g] = *(const f32x4*)(rnp - 32 + 8 * g);
+                    }
+                }
+                if (FULL) {
+                    // the instruction order above IS the schedule: NQB MFMAs, one load (five behind k-step 3)
+#pragma unroll
+                    for (int s = 0; s < 3; ++s) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, NQB, 0); // MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, NQB, 0);
+                    if constexpr (METRIC == METRIC_L2) __builtin_amdgcn_sched_group_barrier(0x020, 5, 0);
+                    else __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+#pragma unroll
+                    for (int s = 4; s < 8; ++s) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, NQB, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const int row_b = t + 4 * h;    // row of the list of acc[.][4 g + e]: row_b + 8 g + e
+                const bool tail = t + 32 > r1;  // (wave-uniform) the block reaches past the end of the chunk
+                auto est = [&](int b, int g, int e) __attribute__((always_inline)) -> float {
+                    float dv = METRIC == METRIC_L2 ? __fmaf_rn(-2.f, acc[b][4 * g + e], L[b].xn + rn[g][e]) : acc[b][4 * g + e];
+                    if (tail && row_b + 8 * g + e >= r1) dv = lmf_worst<METRIC>();
+                    return dv;
+                };
+                if constexpr (MODE == MODE_MIN) {
+#pragma unroll
+                    for (int b = 0; b < NQB; ++b) {
+                        float m = L[b].gm;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) m = lmf_better<METRIC>(m, est(b, g, e));
+                        L[b].gm = m;
+                    }
+                    const int blk = t >> 5;
+                    if (((blk + 1) & (G - 1)) == 0 || t + 32 >= r1) { // (wave-uniform) the granule ends with this block
+#pragma unroll
+                        for (int b = 0; b < NQB; ++b) {
+                            if (L[b].qv) lmf_store_u32(L[b].gq + 2 * (blk >> gsh), ordkey<METRIC>(L[b].gm));
+                            L[b].gm = lmf_worst<METRIC>();
+                        }
+                    }
+                } else if constexpr (MODE == MODE_DUMP) {
+#pragma unroll
+                    for (int b = 0; b < NQB; ++b)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int rowl = row_b + 8 * g + e;
+                                if (L[b].qv && rowl < r1)
+                                    lmf_store_u64(L[b].kq + rowl, ((u64)ordkey<METRIC>(est(b, g, e)) << 32) |
+                                                                          (u64)(L[b].base_pos + (uint32_t)rowl));
+                            }
+                } else {
+                    // ---- which of this lane's 16 estimates per query block pass its query's threshold
+#pragma unroll
+                    for (int b = 0; b < NQB; ++b) {
+                        unsigned mask = 0;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float dv = est(b, g, e);
+                                const bool pass = (METRIC == METRIC_L2 ? dv <= L[b].thr : dv >= L[b].thr) &&
+                                                  !(tail && row_b + 8 * g + e >= r1);
+                                mask |= pass ? 1u << (4 * g + e) : 0u;
+                            }
+                        if (!L[b].qv || b < skip_b) mask = 0;
+                        if (__ballot(mask != 0u)) {
+                            // (wave-uniform branch) park the candidates: this lane's go behind those of the lanes before it
+                            const int c = __popc(mask);
+                            int inc = c;
+#pragma unroll
+                            for (int off = 1; off < 64; off <<= 1) {
+                                const int o = __shfl_up(inc, off, 64);
+                                if (lane >= off) inc += o;
+                            }
+                            const int total = __builtin_amdgcn_readlane(inc, 63);
+                            if (wcnt + total > LF_PARK) {
+                                full = true; // block t is redone after the flush, from query block b on
+                                skip_b = b;
+                                break;
+                            }
+                            int at = wcnt + inc - c;
+#pragma unroll
+                            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    if (mask & (1u << (4 * g + e))) {
+                                        const uint32_t pos = L[b].base_pos + (uint32_t)(row_b + 8 * g + e);
+                                        pk_keys[at] = ((u64)ordkey<METRIC>(est(b, g, e)) << 32) | pos;
+                                        pk_q[at] = L[b].qpr;
+                                        ++at;
+                                    }
+                                }
+                            wcnt += total;
+                        }
+                    }
+                    if (full) break;
+                    skip_b = 0;
+                }
+            }
+            if (MODE == MODE_COLLECT && full) flush();
+        }
+    }
+    if (MODE == MODE_COLLECT && wcnt > 0) flush();
+}
+
+// ------------------------------------------------------------------ IVFPQ sweep, fp16 codebook in LDS
+// The codebook [M][256][dsub] as fp16 (d * 512 bytes: 64 KB at d = 128) lives in LDS for the life of a persistent 8-wave
+// workgroup; a WAVEFRONT works alone on an item (list, up to 96 queries, row chunk): B operands = fp16 (q - centroid)
+// (inner product: fp16 q) of its queries, the block's code bytes global -> registers (one block ahead) -> a private
+// 32-row LDS slice (un-rotated on the way in, kernels.h pq_code_offset), then per k-step one aligned read of the operand's
+// code bytes and 1 .. 8 codebook gathers: ONE decoded operand feeds the MFMAs of all query blocks.
+// DS: 1 / 2 / 4 / 8 = dsub itself (8 also: any multiple of 8).
+constexpr int LP_THREADS = 512;
+constexpr int LP_BR = 32;    // rows per block
+constexpr int LP_PARK = 256; // parked candidates per wave
+struct LpLayout {
+    int cb_bytes, rs, off_codes, off_park, total;
+};
+__host__ __device__ static inline LpLayout lp_layout(int d, int M) {
+    LpLayout L;
+    L.cb_bytes = d * 256 * 2;
+    L.rs = ((M + 15) & ~15) + 16; // bytes per row of a code slice (+ 16: rows on different banks)
+    L.off_codes = (L.cb_bytes + 15) & ~15;
+    L.off_park = L.off_codes + 8 * LP_BR * L.rs;
+    L.total = L.off_park + 8 * LP_PARK * (8 + 4);
+    return L;
+}
+
+template <int METRIC, int MODE, int NQB, int DS>
+__global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    const int j = lane & 31;
+    const int np = p.nprobe;
+    const int M = p.M, dsub = p.dsub;
+    const int nks = p.d >> 4;
+    const int G = p.gran_blocks, gsh = __builtin_ctz((unsigned)p.gran_blocks); // (a power of two)
+    const LpLayout LY = lp_layout(p.d, M);
+    const _Float16* cb = (const _Float16*)smem;
+    {
+        const uint4* src = (const uint4*)p.pq16;
+        uint4* dst = (uint4*)smem;
+        for (int i = tid; i < p.d * 32; i += LP_THREADS) dst[i] = src[i];
+    }
+    unsigned char* crow = (unsigned char*)(smem + LY.off_codes) + (wave * LP_BR + j) * LY.rs; // this lane's row of the slice
+    u64* pk_keys = (u64*)(smem + LY.off_park) + wave * LP_PARK;
+    uint32_t* pk_q = (uint32_t*)(smem + LY.off_park + 8 * LP_PARK * 8) + wave * LP_PARK;
+    int wcnt = 0;
+    auto flush = [&]() __attribute__((always_inline)) {
+        for (int e = lane; e < wcnt; e += 64) {
+            const u64 key = pk_keys[e];
+            const uint32_t qp = pk_q[e];
+            const uint32_t qq = qp >> 11;
+            uint32_t slot;
+            uint32_t* cp = p.cnt + qq;
+            const uint32_t one = 1u;
+            asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(slot) : "v"(cp), "v"(one) : "memory");
+            if ((int64_t)slot < p.stride) {
+                p.keys[(int64_t)qq * p.stride + slot] = key;
+                p.cand_pr[(int64_t)qq * p.stride + slot] = (uint16_t)(qp & 2047u);
+            }
+        }
+        wcnt = 0;
+    };
+    __syncthreads();
+
+    const int ch = pq_chunk_bytes(M);
+    const int nch = M >> 4;          // 16-byte pieces of a stored row (ch == 16)
+    const int cpl = (nch + 1) >> 1;  // ... per lane: lane (j, h) moves pieces h * cpl .. of row j
+    const bool fast = ch == 16 && nch <= 4;
+    const uint32_t it0 = p.item_bounds[1], it1 = p.item_bounds[2];
+    uint32_t* ctr = p.item_bounds + (MODE == MODE_MIN ? 5 : 4);
+    for (;;) {
+        uint32_t it = 0;
+        if (lane == 0) it = atomicAdd(ctr, 1u);
+        it = it0 + (uint32_t)__builtin_amdgcn_readfirstlane((int)it);
+        if (it >= it1) break;
+        const IvfLmItem item = p.items[it];
+        const int bk = __builtin_amdgcn_readfirstlane(item.bucket);
+        const int qt = __builtin_amdgcn_readfirstlane(item.qt);
+        const int rt = __builtin_amdgcn_readfirstlane(item.rt);
+        const int list = bk >> 1;
+        const int len = (int)p.list_len[list];
+        const int64_t start = p.list_start[list];
+        const uint32_t pb = p.bucket_start[bk];
+        const int npair = min(32 * NQB, (int)(p.bucket_start[bk + 1 + item.both] - pb) - qt * (32 * NQB));
+        const int r0 = rt * p.rows_per_item;
+        const int r1 = min(len, r0 + p.rows_per_item);
+
+        uint4 creg[2];
+        auto fetch = [&](int t) __attribute__((always_inline)) {
+            if (fast) {
+                const int64_t row = start + t + j; // arena row (inside the list's capacity: a multiple of 64 rows)
+                const unsigned char* src = p.arena_codes + (size_t)(row >> 6) * 64 * M + (size_t)(row & 63) * 16;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int c = h * cpl + i;
+                    if (i < cpl && c < nch) creg[i] = *(const uint4*)(src + (size_t)c * 1024);
+                }
+            }
+        };
+        auto stage = [&](int t) __attribute__((always_inline)) {
+            const int64_t row = start + t + j;
+            if (fast) {
+                const int lrot = (int)(row & 63) % M; // stored byte x of the row is sub-quantizer (x + row) mod M
+#pragma unroll
+                for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(creg[i].x), "+v"(creg[i].y), "+v"(creg[i].z), "+v"(creg[i].w));
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int c = h * cpl + i;
+                    if (i < cpl && c < nch) {
+                        const unsigned w[4] = {creg[i].x, creg[i].y, creg[i].z, creg[i].w};
+#pragma unroll
+                        for (int b = 0; b < 16; ++b) {
+                            int m = 16 * c + b + lrot;
+                            m -= m >= M ? M : 0;
+                            crow[m] = (unsigned char)(w[b >> 2] >> (8 * (b & 3)));
+                        }
+                    }
+                }
+            } else {
+                for (int m = h; m < M; m += 2) crow[m] = p.arena_codes[pq_code_offset(M, row, m)];
+            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        };
+        fetch(r0);
+
+        // ---- this lane's queries: B operands = fp16 of the residual query (L2) / of the query (inner product)
+        LmfLane L[NQB];
+        half8 bq[NQB][8];
+        const float* cen = p.centroids + (int64_t)list * p.ldc + 8 * h;
+#pragma unroll
+        for (int b = 0; b < NQB; ++b) {
+            const int my = b * 32 + j;
+            L[b].qv = my < npair;
+            const uint32_t pi = p.pairs[pb + (uint32_t)(qt * (32 * NQB)) + (uint32_t)(L[b].qv ? my : 0)];
+            const int q = (int)(pi / (uint32_t)np);
+            const int pr = (int)(pi - (uint32_t)q * (uint32_t)np);
+            L[b].q = q;
+            const float* qrow = p.xq + (int64_t)q * p.ldq + 8 * h;
+            float accn = 0.f;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                half8 o = half8{0, 0, 0, 0, 0, 0, 0, 0};
+                if (s < nks) {
+                    const f32x4 v0 = *(const f32x4*)(qrow + 16 * s), v1 = *(const f32x4*)(qrow + 16 * s + 4);
+                    f32x4 c0 = f32x4{0.f, 0.f, 0.f, 0.f}, c1 = c0;
+                    if (METRIC == METRIC_L2) {
+                        c0 = *(const f32x4*)(cen + 16 * s);
+                        c1 = *(const f32x4*)(cen + 16 * s + 4);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float r0v = v0[e] - c0[e], r1v = v1[e] - c1[e];
+                        accn = __fmaf_rn(r0v, r0v, accn);
+                        accn = __fmaf_rn(r1v, r1v, accn);
+                        o[e] = (_Float16)r0v;
+                        o[4 + e] = (_Float16)r1v;
+                    }
+                }
+                bq[b][s] = o;
+            }
+            // |q - c|^2: the two half chains of the lane pair (h = 0 / 1)
+            L[b].xn = METRIC == METRIC_L2 ? accn + __shfl_xor(accn, 32, 64) : p.coarse_dis[pi];
+            L[b].base_pos = p.prefix[(int64_t)q * (np + 1) + pr];
+            L[b].qpr = ((uint32_t)q << 11) | (uint32_t)pr;
+            L[b].thr = 0.f;
+            L[b].gm = lmf_worst<METRIC>();
+            L[b].gq = nullptr;
+            L[b].kq = nullptr;
+            if (MODE == MODE_MIN) L[b].gq = p.gmin + (int64_t)q * p.gstride + p.prefixg[(int64_t)q * (np + 1) + pr] + h;
+            if (MODE == MODE_COLLECT) L[b].thr = p.thr_f[q];
+            if (MODE == MODE_DUMP) L[b].kq = p.keys + (int64_t)q * p.stride + L[b].base_pos;
+        }
+
+        for (int t = r0; t < r1; t += LP_BR) {
+            stage(t);
+            const bool more = t + LP_BR < r1;
+            // the A operand of k-step s: coordinates 16 s + 8 h .. + 7 of this lane's row
+            auto operand_of = [&](int s_) __attribute__((always_inline)) -> half8 {
+                half8 a = half8{0, 0, 0, 0, 0, 0, 0, 0};
+                if (s_ >= nks) return a;
+                const int kb = 16 * s_ + 8 * h; // first coordinate
+                if (DS == 8) {
+                    const int m = kb / dsub, off = kb - m * dsub;
+                    a = *(const half8*)(cb + ((m << 8) + (int)crow[m]) * dsub + off);
+                } else if (DS == 4) {
+                    const unsigned cw = *(const unsigned short*)(crow + (kb >> 2));
+                    const half4v lo = *(const half4v*)(cb + ((((kb >> 2)) << 8) + (int)(cw & 255u)) * 4);
+                    const half4v hi = *(const half4v*)(cb + ((((kb >> 2) + 1) << 8) + (int)(cw >> 8)) * 4);
+                    a = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                } else if (DS == 2) {
+                    const unsigned cw = *(const unsigned*)(crow + (kb >> 1));
+                    const int m0 = kb >> 1;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const half2v v = *(const half2v*)(cb + (((m0 + u) << 8) + (int)((cw >> (8 * u)) & 255u)) * 2);
+                        a[2 * u] = v[0];
+                        a[2 * u + 1] = v[1];
+                    }
+                } else {
+                    const uint2 cw = *(const uint2*)(crow + kb);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const unsigned c = ((u < 4 ? cw.x : cw.y) >> (8 * (u & 3))) & 255u;
+                        a[u] = cb[((kb + u) << 8) + (int)c];
+                    }
+                }
+                return a;
+            };
+            f32x16 acc[NQB];
+#pragma unroll
+            for (int b = 0; b < NQB; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+            f32x4 rn[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) rn[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // software pipeline: gathers of k-step s + 1 | MFMAs of k-step s
+            half8 av[2];
+            av[0] = operand_of(0);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                if (s + 1 < 8) av[(s + 1) & 1] = operand_of(s + 1);
+                if (s == 1 && more) fetch(t + LP_BR);
+                if (s == 4 && METRIC == METRIC_L2) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) rn[g] = *(const f32x4*)(p.arena_rn + start + t + 8 * g + 4 * h);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (s < nks) {
+#pragma unroll
+                    for (int b = 0; b < NQB; ++b)
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s & 1], bq[b][s], acc[b], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const int row_b = t + 4 * h;
+            const bool tail = t + 32 > r1;
+            auto est = [&](int b, int g, int e) __attribute__((always_inline)) -> float {
+                float dv = METRIC == METRIC_L2 ? __fmaf_rn(-2.f, acc[b][4 * g + e], L[b].xn + rn[g][e])
+                                               : L[b].xn + acc[b][4 * g + e];
+                if (tail && row_b + 8 * g + e >= r1) dv = lmf_worst<METRIC>();
+                return dv;
+            };
+            if constexpr (MODE == MODE_MIN) {
+#pragma unroll
+                for (int b = 0; b < NQB; ++b) {
+                    float m = L[b].gm;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) m = lmf_better<METRIC>(m, est(b, g, e));
+                    L[b].gm = m;
+                }
+                const int blk = t >> 5;
+                if (((blk + 1) & (G - 1)) == 0 || t + 32 >= r1) {
+#pragma unroll
+                    for (int b = 0; b < NQB; ++b) {
+                        if (L[b].qv) L[b].gq[2 * (blk >> gsh)] = ordkey<METRIC>(L[b].gm);
+                        L[b].gm = lmf_worst<METRIC>();
+                    }
+                }
+            } else if constexpr (MODE == MODE_DUMP) {
+#pragma unroll
+                for (int b = 0; b < NQB; ++b)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int rowl = row_b + 8 * g + e;
+                            if (L[b].qv && rowl < r1)
+                                L[b].kq[rowl] = ((u64)ordkey<METRIC>(est(b, g, e)) << 32) | (u64)(L[b].base_pos + (uint32_t)rowl);
+                        }
+            } else {
+#pragma unroll
+                for (int b = 0; b < NQB; ++b) {
+                    unsigned mask = 0;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float dv = est(b, g, e);
+                            const bool pass = (METRIC == METRIC_L2 ? dv <= L[b].thr : dv >= L[b].thr) &&
+                                              !(tail && row_b + 8 * g + e >= r1);
+                            mask |= pass ? 1u << (4 * g + e) : 0u;
+                        }
+                    if (!L[b].qv) mask = 0;
+                    if (__ballot(mask != 0u)) {
+                        const int c = __popc(mask);
+                        int inc = c;
+#pragma unroll
+                        for (int off = 1; off < 64; off <<= 1) {
+                            const int o = __shfl_up(inc, off, 64);
+                            if (lane >= off) inc += o;
+                        }
+                        const int total = __builtin_amdgcn_readlane(inc, 63);
+                        if (total > LP_PARK) {
+                            // more candidates in one (32-row, 32-query) block than a slice holds (a threshold that admits
+                            // everything): straight to the segment, one atomic per lane
+                            if (mask) {
+                                uint32_t slot;
+                                uint32_t* cp = p.cnt + L[b].q;
+                                const uint32_t nc = (uint32_t)c;
+                                asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)"
+                                             : "=&v"(slot)
+                                             : "v"(cp), "v"(nc)
+                                             : "memory");
+#pragma unroll
+                                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        if (mask & (1u << (4 * g + e))) {
+                                            const uint32_t pos = L[b].base_pos + (uint32_t)(row_b + 8 * g + e);
+                                            if ((int64_t)slot < p.stride) {
+                                                p.keys[(int64_t)L[b].q * p.stride + slot] = ((u64)ordkey<METRIC>(est(b, g, e)) << 32) | pos;
+                                                p.cand_pr[(int64_t)L[b].q * p.stride + slot] = (uint16_t)(L[b].qpr & 2047u);
+                                            }
+                                            ++slot;
+                                        }
+                                    }
+                            }
+                        } else {
+                            if (wcnt + total > LP_PARK) flush();
+                            int at = wcnt + inc - c;
+#pragma unroll
+                            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    if (mask & (1u << (4 * g + e))) {
+                                        const uint32_t pos = L[b].base_pos + (uint32_t)(row_b + 8 * g + e);
+                                        pk_keys[at] = ((u64)ordkey<METRIC>(est(b, g, e)) << 32) | pos;
+                                        pk_q[at] = L[b].qpr;
+                                        ++at;
+                                    }
+                                }
+                            wcnt += total;
+                        }
+                    }
+                }
+            }
+            // (the next block's stage() writes the slice: every read above was issued before it, LDS keeps a wave's order)
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (MODE == MODE_COLLECT && wcnt > 0) flush();
+}
+
+// ------------------------------------------------------------------ launchers of the sweeps
+int ivf_lmf_grid_blocks(const IvfLmParams& p, int num_cus) {
+    if (p.kind == 1) return num_cus;       // one 8-wave workgroup per CU (codebook + slices in its LDS)
+    return 2 * num_cus / 8 * 8;            // IVFFlat: two 4-wave workgroups per CU
+}
+template <int METRIC, int MODE>
+static void lmf_flat_launch(const IvfLmParams& p, int grid_blocks, hipStream_t stream) {
+    constexpr int NQB = kLmfQueryBlocks;
+    const int lds = MODE == MODE_COLLECT ? LF_LDS : 0;
+    if (p.ldh == 128) {
+        HIP_CHECK(hipFuncSetAttribute((const void*)ivf_lmf_flat_kernel<METRIC, MODE, NQB, true>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, LF_LDS));
+        hipLaunchKernelGGL((ivf_lmf_flat_kernel<METRIC, MODE, NQB, true>), dim3((unsigned)grid_blocks), dim3(LF_THREADS), lds,
+                           stream, p);
+    } else {
+        HIP_CHECK(hipFuncSetAttribute((const void*)ivf_lmf_flat_kernel<METRIC, MODE, NQB, false>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, LF_LDS));
+        hipLaunchKernelGGL((ivf_lmf_flat_kernel<METRIC, MODE, NQB, false>), dim3((unsigned)grid_blocks), dim3(LF_THREADS), lds,
+                           stream, p);
+    }
+}
+template <int METRIC, int MODE>
+static void lmf_pq_launch(const IvfLmParams& p, int grid_blocks, hipStream_t stream) {
+    constexpr int NQB = kLmfQueryBlocks;
+    const int lds = lp_layout(p.d, p.M).total;
+    const int ds = p.dsub >= 8 ? 8 : p.dsub;
+#define FA_LP(DS_)                                                                                                       \
+    do {                                                                                                                 \
+        HIP_CHECK(hipFuncSetAttribute((const void*)ivf_lmf_pq_kernel<METRIC, MODE, NQB, DS_>,                            \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));                                 \
+        hipLaunchKernelGGL((ivf_lmf_pq_kernel<METRIC, MODE, NQB, DS_>), dim3((unsigned)grid_blocks), dim3(LP_THREADS), lds, \
+                           stream, p);                                                                                   \
+    } while (0)
+    if (ds == 1) FA_LP(1);
+    else if (ds == 2) FA_LP(2);
+    else if (ds == 4) FA_LP(4);
+    else FA_LP(8);
+#undef FA_LP
+}
+template <int METRIC>
+static void lmf_launch_mode(const IvfLmParams& p, int mode, int grid_blocks, hipStream_t stream) {
+    if (p.kind == 0) {
+        if (mode == MODE_MIN) lmf_flat_launch<METRIC, MODE_MIN>(p, grid_blocks, stream);
+        else if (mode == MODE_COLLECT) lmf_flat_launch<METRIC, MODE_COLLECT>(p, grid_blocks, stream);
+        else lmf_flat_launch<METRIC, MODE_DUMP>(p, grid_blocks, stream);
+    } else {
+        if (mode == MODE_MIN) lmf_pq_launch<METRIC, MODE_MIN>(p, grid_blocks, stream);
+        else if (mode == MODE_COLLECT) lmf_pq_launch<METRIC, MODE_COLLECT>(p, grid_blocks, stream);
+        else lmf_pq_launch<METRIC, MODE_DUMP>(p, grid_blocks, stream);
+    }
+}
+void launch_ivf_lmf_sweep(const IvfLmParams& p, int mode, int grid_blocks, hipStream_t stream) {
+    if (p.nq == 0) return;
+    FA_THROW_IF_NOT(p.filter && ivf_lmf_supported(p.kind, p.d, p.dpad, p.M) && mode >= 1 && mode <= 3 && grid_blocks > 0);
+    FA_THROW_IF_NOT(p.qpi == 32 * kLmfQueryBlocks && p.nq < (1 << 21) && p.nprobe <= 2048 && p.gran_blocks >= 1 &&
+                    (p.gran_blocks & (p.gran_blocks - 1)) == 0);
+    if (p.kind == 0) {
+        FA_THROW_IF_NOT(p.xq16 && p.arena_h && p.ldh % 16 == 0 && p.ldh <= 128 && p.ldq16 >= p.ldh && p.ldq16 % 8 == 0);
+        FA_THROW_IF_NOT(p.metric != METRIC_L2 || (p.arena_rn && p.xqn));
+    } else {
+        FA_THROW_IF_NOT(p.pq16 && p.arena_codes && p.centroids && p.ldq % 4 == 0 && p.ldc % 4 == 0);
+        FA_THROW_IF_NOT(lp_layout(p.d, p.M).total <= 160 * 1024 && (p.metric != METRIC_L2 || p.arena_rn));
+    }
+    if (p.metric == METRIC_L2) lmf_launch_mode<METRIC_L2>(p, mode, grid_blocks, stream);
+    else lmf_launch_mode<METRIC_INNER_PRODUCT>(p, mode, grid_blocks, stream);
+    HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ bound: k-th best granule estimate + error band
+// One workgroup per query: radix select (4 x 8 bits) over the query's granule slots.
+template <int METRIC>
+__global__ void __launch_bounds__(256) lmf_bound_kernel(IvfLmParams p, const float* __restrict__ xn_bound) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t sel_prefix, sel_need;
+    const int q = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int np = p.nprobe;
+    const uint32_t S = p.prefixg[(int64_t)q * (np + 1) + np];
+    const uint32_t* g = p.gmin + (int64_t)q * p.gstride;
+    // (IVFPQ: the B operands are fp16 (q - c): every coordinate is below sqrt(max |q - c|^2), which must stay in range)
+    if ((p.qflags && p.qflags[q]) || (p.kind == 1 && !(xn_bound[q] <= 9.0e8f))) {
+        // outside the fp16 range / NaN: nothing is collected, the query is redone by the query-major scan
+        if (tid == 0) {
+            p.thr_f[q] = METRIC == METRIC_L2 ? -INFINITY : INFINITY;
+            const uint32_t s = atomicAdd(&p.ovf[0], 1u);
+            p.ovf[1 + s] = (uint32_t)q;
+        }
+        return;
+    }
+    if (S < (uint32_t)p.k) { // fewer granules than results: everything is a candidate
+        if (tid == 0) p.thr_f[q] = lmf_worst<METRIC>();
+        return;
+    }
+    if (tid == 0) {
+        sel_prefix = 0u;
+        sel_need = (uint32_t)p.k;
+    }
+    for (int pass = 3; pass >= 0; --pass) {
+        hist[tid] = 0u;
+        __syncthreads();
+        const uint32_t pre = sel_prefix;
+        for (uint32_t i = tid; i < S; i += 256) {
+            const uint32_t v = g[i];
+            const bool in = pass == 3 || (v >> (8 * (pass + 1))) == pre;
+            if (in) atomicAdd(&hist[(v >> (8 * pass)) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            // bucket holding the sel_need-th smallest: exclusive prefix over 256 bins, 4 bins per lane
+            uint32_t c[4], sum = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                c[u] = hist[4 * tid + u];
+                sum += c[u];
+            }
+            uint32_t inc = sum;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t o = __shfl_up(inc, off, 64);
+                if (tid >= off) inc += o;
+            }
+            uint32_t before = inc - sum;
+            const uint32_t need = sel_need;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (before < need && need <= before + c[u]) {
+                    sel_prefix = (pre << 8) | (uint32_t)(4 * tid + u);
+                    sel_need = need - before;
+                }
+                before += c[u];
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const uint32_t tk = sel_prefix;
+        float thr;
+        if (tk >= kInvalidOrdKey) {
+            thr = lmf_worst<METRIC>();
+        } else {
+            const float T = unordkey<METRIC>(tk);
+            float extra = 0.f;
+            if (p.kind == 1) {
+                // IVFPQ: the exact path's table grid (M entries rounded to delta <= 2^-23 sum_m max_c |<q_m, cb_mc>|), its
+                // per-row term |r^|^2 + 2 <c, r^> and the coarse term, all below (|q| + |c| + |r^|)^2 in magnitude
+                const float sroot = sqrtf(p.xn_full[q]) + sqrtf(p.cn_max) + sqrtf(p.yn_max);
+                extra = (4.8e-7f * (float)p.M + 1.0e-6f) * sroot * sroot;
+            }
+            const float E = ivf_filter_err_bound(METRIC, p.d, xn_bound[q], p.yn_max, extra);
+            if (p.band_out) p.band_out[q] = E;
+            thr = METRIC == METRIC_L2 ? T + 2.f * E : T - 2.f * E;
+            if (thr != thr) thr = lmf_worst<METRIC>();
+        }
+        p.thr_f[q] = thr;
+    }
+}
+void launch_ivf_lmf_bound(const IvfLmParams& p, const float* xn_bound, hipStream_t stream) {
+    if (p.nq == 0) return;
+    HIP_CHECK(hipMemsetAsync(p.ovf, 0, 4, stream));
+    if (p.metric == METRIC_L2) hipLaunchKernelGGL(lmf_bound_kernel<METRIC_L2>, dim3((unsigned)p.nq), dim3(256), 0, stream, p, xn_bound);
+    else hipLaunchKernelGGL(lmf_bound_kernel<METRIC_INNER_PRODUCT>, dim3((unsigned)p.nq), dim3(256), 0, stream, p, xn_bound);
+    HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ IVFPQ: per-query preparation
+// xn_bound[q] = max over the probes of |q - c|^2 (L2; inner product: |q|^2) for the error band; pq_grid[q] = the query's
+// table grid, exactly as the query-major scan builds it (ivf_fused.hip / oracle orc_ivf_search_ex arith 0): entries
+// <q_m, cb[m][c]> as sequential fmaf chains from 0, B = sum_m max_c |entry| in sub-quantizer order, pq_lut_grid(B).
+__global__ void __launch_bounds__(256) lmf_pq_prepare_kernel(IvfLmParams p, float* __restrict__ xn_bound) {
+    __shared__ uint32_t colmax[256]; // (M <= 128)
+    __shared__ float red[4];
+    const int q = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int M = p.M, dsub = p.dsub, np = p.nprobe;
+    const float* x = p.xq + (int64_t)q * p.ldq;
+    for (int m = tid; m < M; m += 256) colmax[m] = 0u;
+    __syncthreads();
+    for (int e = tid; e < M * 256; e += 256) {
+        const int m = e >> 8;
+        const float* cen = p.pq_centroids + (size_t)e * dsub;
+        float acc = 0.f;
+        for (int jd = 0; jd < dsub; ++jd) acc = __fmaf_rn(x[m * dsub + jd], cen[jd], acc);
+        const float a = fabsf(acc);
+        atomicMax(&colmax[m], __float_as_uint(a)); // NaN (0x7fc00000) beats every number, like the oracle's bit-pattern max
+    }
+    // max over the probes of |q - c|^2 (any order: it only feeds the error band)
+    float mx = 0.f;
+    for (int pr = tid >> 6; pr < np; pr += 4) {
+        const int64_t l = p.coarse_ids[(int64_t)q * np + pr];
+        if (l < 0) continue;
+        const float* c = p.centroids + l * p.ldc;
+        float acc = 0.f;
+        for (int k = tid & 63; k < p.d; k += 64) {
+            const float v = p.metric == METRIC_L2 ? x[k] - c[k] : x[k];
+            acc = __fmaf_rn(v, v, acc);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        mx = fmaxf(mx, acc);
+    }
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    if (tid == 0) {
+        float B = 0.f;
+        for (int m = 0; m < M; ++m) B = B + __uint_as_float(colmax[m]);
+        float delta = 0.f, inv = 0.f;
+        const bool on = pq_lut_grid(B, &delta, &inv);
+        p.pq_grid[2 * q] = on ? delta : 0.f;
+        p.pq_grid[2 * q + 1] = on ? inv : 0.f;
+        xn_bound[q] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * 1.0001f;
+    }
+}
+void launch_ivf_lmf_pq_prepare(const IvfLmParams& p, float* xn_bound, hipStream_t stream) {
+    if (p.nq == 0) return;
+    FA_THROW_IF_NOT(p.kind == 1 && p.M <= 256 && p.pq_grid && p.pq_centroids);
+    hipLaunchKernelGGL(lmf_pq_prepare_kernel, dim3((unsigned)p.nq), dim3(256), 0, stream, p, xn_bound);
+    HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ rerank: exact distances of the candidates
+// One wavefront per query, eight lanes per candidate row.
+// IVFFlat: the arithmetic of ivfflat_fused_kernel -- lane ln of the group owns the 16-byte chunks ln, ln + 8, ... of the row
+// and keeps one sequential fmaf chain of (q - y)^2 (inner product: q * y) over them; the eight partial sums meet in the
+// xor butterfly ((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7)).
+template <int METRIC>
+__global__ void __launch_bounds__(256) lmf_rerank_flat_kernel(IvfLmParams p) {
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= p.nq) return;
+    const int lane = threadIdx.x & 63;
+    const int ln = lane & 7, grp = lane >> 3;
+    const int np = p.nprobe;
+    const int n = (int)min((int64_t)p.cnt[q], p.stride);
+    const int nch = p.dpad >> 2;
+    u64* kq = p.keys + (int64_t)q * p.stride;
+    const uint16_t* cpr = p.cand_pr + (int64_t)q * p.stride;
+    const float* qrow = p.xq + (int64_t)q * p.ldq;
+    for (int base = 0; base < n; base += 8) {
+        const int i = base + grp;
+        const bool valid = i < n;
+        float a = 0.f;
+        uint32_t pos = 0;
+        if (valid) {
+            pos = (uint32_t)kq[i];
+            const int pr = (int)cpr[i];
+            const int64_t l = p.coarse_ids[(int64_t)q * np + pr];
+            const int64_t row = p.list_start[l] + (pos - p.prefix[(int64_t)q * (np + 1) + pr]);
+            const float* rowp = p.arena_vecs + row * p.ldv;
+            for (int c4 = ln; c4 < nch; c4 += 8) {
+                const f32x4 y4 = *(const f32x4*)(rowp + 4 * c4);
+                const f32x4 q4 = *(const f32x4*)(qrow + 4 * c4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (METRIC == METRIC_L2) {
+                        const float tt = q4[e] - y4[e];
+                        a = __fmaf_rn(tt, tt, a);
+                    } else {
+                        a = __fmaf_rn(q4[e], y4[e], a);
+                    }
+                }
+            }
+        }
+        a = a + __shfl_xor(a, 1, 64);
+        a = a + __shfl_xor(a, 2, 64);
+        a = a + __shfl_xor(a, 4, 64);
+        if (valid && ln == 0) kq[i] = ((u64)ordkey<METRIC>(a) << 32) | (u64)pos;
+    }
+}
+// IVFPQ: the arithmetic of ivfpq_fused_kernel -- S = sum_m round_to_grid(<q_m, cb[m][code_m]>) (every partial sum exact in
+// fp32, so any order gives these bits; here sub-quantizer order), L2: fmaf(-2, S, coarse + t2[row]), inner product:
+// coarse + S.  Lane ln of a group takes the sub-quantizers ln, ln + 8, ...; the partial sums are exact multiples of the
+// grid, their butterfly sum is exact too.  Without a grid (NaN / inf / all-zero tables) the sum runs in sub-quantizer
+// order on one lane, like the oracle.
+template <int METRIC>
+__global__ void __launch_bounds__(256) lmf_rerank_pq_kernel(IvfLmParams p) {
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= p.nq) return;
+    const int lane = threadIdx.x & 63;
+    const int ln = lane & 7, grp = lane >> 3;
+    const int np = p.nprobe, M = p.M, dsub = p.dsub;
+    const int n = (int)min((int64_t)p.cnt[q], p.stride);
+    u64* kq = p.keys + (int64_t)q * p.stride;
+    const uint16_t* cpr = p.cand_pr + (int64_t)q * p.stride;
+    const float* x = p.xq + (int64_t)q * p.ldq;
+    const float delta = p.pq_grid[2 * q], inv = p.pq_grid[2 * q + 1];
+    const bool on = delta != 0.f;
+    for (int base = 0; base < n; base += 8) {
+        const int i = base + grp;
+        const bool valid = i < n;
+        float s = 0.f, dis0 = 0.f, t2 = 0.f;
+        uint32_t pos = 0;
+        if (valid) {
+            pos = (uint32_t)kq[i];
+            const int pr = (int)cpr[i];
+            const int64_t l = p.coarse_ids[(int64_t)q * np + pr];
+            const int64_t row = p.list_start[l] + (pos - p.prefix[(int64_t)q * (np + 1) + pr]);
+            dis0 = p.coarse_dis[(int64_t)q * np + pr];
+            if (METRIC == METRIC_L2) t2 = p.arena_t2[row];
+            if (on) {
+                for (int m = ln; m < M; m += 8) {
+                    const unsigned code = p.arena_codes[pq_code_offset(M, row, m)];
+                    const float* cen = p.pq_centroids + ((size_t)m * 256 + code) * dsub;
+                    float acc = 0.f;
+                    for (int jd = 0; jd < dsub; ++jd) acc = __fmaf_rn(x[m * dsub + jd], cen[jd], acc);
+                    s = s + __builtin_rintf(acc * inv) * delta;
+                }
+            } else if (ln == 0) {
+                for (int m = 0; m < M; ++m) {
+                    const unsigned code = p.arena_codes[pq_code_offset(M, row, m)];
+                    const float* cen = p.pq_centroids + ((size_t)m * 256 + code) * dsub;
+                    float acc = 0.f;
+                    for (int jd = 0; jd < dsub; ++jd) acc = __fmaf_rn(x[m * dsub + jd], cen[jd], acc);
+                    s = s + acc;
+                }
+            }
+        }
+        if (on) {
+            s = s + __shfl_xor(s, 1, 64);
+            s = s + __shfl_xor(s, 2, 64);
+            s = s + __shfl_xor(s, 4, 64);
+        }
+        if (valid && ln == 0) {
+            const float dis = METRIC == METRIC_L2 ? __fmaf_rn(-2.f, s, dis0 + t2) : dis0 + s;
+            kq[i] = ((u64)ordkey<METRIC>(dis) << 32) | (u64)pos;
+        }
+    }
+}
+void launch_ivf_lmf_rerank(const IvfLmParams& p, hipStream_t stream) {
+    if (p.nq == 0) return;
+    const dim3 grid((unsigned)div_up(p.nq, 4)), block(256);
+    if (p.kind == 0) {
+        if (p.metric == METRIC_L2) hipLaunchKernelGGL(lmf_rerank_flat_kernel<METRIC_L2>, grid, block, 0, stream, p);
+        else hipLaunchKernelGGL(lmf_rerank_flat_kernel<METRIC_INNER_PRODUCT>, grid, block, 0, stream, p);
+    } else {
+        FA_THROW_IF_NOT(p.pq_grid && (p.metric != METRIC_L2 || p.arena_t2));
+        if (p.metric == METRIC_L2) hipLaunchKernelGGL(lmf_rerank_pq_kernel<METRIC_L2>, grid, block, 0, stream, p);
+        else hipLaunchKernelGGL(lmf_rerank_pq_kernel<METRIC_INNER_PRODUCT>, grid, block, 0, stream, p);
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+} // namespace faiss_amd

@@ -487,6 +487,7 @@ struct IvfLmParams {
     float yn_max;               // max |y|^2 over the stored rows (kind 0) / upper bound of |r^|^2 from the codebook (kind 1)
     float cn_max;               // kind 1: max |centroid|^2
     float* pq_grid;             // kind 1: [nq][2] delta, 1 / delta of the query's table grid (pq_lut_grid; 0, 0 = no rounding)
+    float* band_out;            // optional [nq]: the error band E_q the bound kernel used (tests)
 };
 // |estimate - exact| <= this for every stored row, whatever the data: `estimate` = what the f16 MFMA sweeps of
 // ivf_lm_filter.hip compute (L2: fmaf(-2, <f16 q', f16 y'>, |q'|^2 + |y'|^2) with the two norms as fp32 chains; IP:

@@ -425,15 +425,30 @@ int faiss_amd_GpuIndexIVF_set_use_fused_scan(FaissAmdIndex* index, int on);
 /* Which scan serves search() / search_preassigned() of an IVF index (no reference counterpart: the reference has one
  * scan per index type, faiss/gpu/impl/IVFInterleaved.cuh:33-224, PQScanMultiPassNoPrecomputed-inl.cuh:173-270, both
  * query-major).  0 = automatic: batches of >= 2048 queries that probe every list >= 8 times on average, without
- * IDSelector, on IVFFlat / IVFPQ / IVF scalar-quantizer indexes with d <= 128 take the list-major
- * scan (faiss_amd/csrc/ivf_listmajor.hip: every list is read once per group of up to 64 of the queries probing it,
- * distances on the f32 matrix pipe); 1 = query-major always; 2 = list-major always (an error where unsupported).  The
- * two scans sum in different orders: each is bit-exact against its own restatement in oracle/faiss_oracle.c
- * (orc_ivf_search_ex / orc_ivfsq_search_ex, arith 0 / 1), both within the 1e-4 relative tolerance
- * of the reference.  scan_info: the mode set, the one the last search used (1 / 2), and how many queries so far had to
- * be redone with an unbounded candidate segment. */
+ * IDSelector, on IVFFlat / IVFPQ / IVF scalar-quantizer indexes with d <= 128 take the list-major scan (every list is
+ * read once per group of the queries probing it); 1 = query-major always; 2 = list-major always (an error where
+ * unsupported); 3 = list-major on the f32 matrix pipe (round 3's scan, faiss_amd/csrc/ivf_listmajor.hip).
+ * IVFFlat / IVFPQ (round 4): the list-major scan runs behind an f16 MFMA filter with a rigorous error band and
+ * re-derives the survivors with the arithmetic of the query-major scan (faiss_amd/csrc/ivf_lm_filter.hip): a query
+ * returns THE SAME BITS whatever the batch size, the shard / replica split or the paging of the call.  The scalar
+ * quantizer's list-major scan and mode 3 sum in their own order (f32 MFMA chains).  Every scan is bit-exact against its
+ * restatement in oracle/faiss_oracle.c (orc_ivf_search_ex / orc_ivfsq_search_ex, arith = last_scan_arith), all within
+ * the 1e-4 relative tolerance of the reference.  scan_info: the mode set, the scan the last search used (1 query-major /
+ * 2 list-major), and how many queries so far had to be redone (candidate segment overflow, fp16 range).
+ * last_scan_arith: 0 = query-major arithmetic, 1 = f32 list-major arithmetic. */
 int faiss_amd_GpuIndexIVF_set_scan_mode(FaissAmdIndex* index, int mode);
 int faiss_amd_GpuIndexIVF_scan_info(const FaissAmdIndex* index, int* mode, int* last_mode, int64_t* overflow_queries);
+int faiss_amd_GpuIndexIVF_last_scan_arith(const FaissAmdIndex* index, int* p_arith);
+/* Tuning experiments of the filter path (tools/lmf_sweep.py; results never change, only timings): rows of a list per
+ * work item, 32-row blocks per granule (1, 2, 4, 8), candidate room per query.  0 = the built-in rule. */
+int faiss_amd_GpuIndexIVF_set_lmf_tuning(FaissAmdIndex* index, int rows_per_item, int gran_blocks, int cand_cap);
+/* Test hook of the f16 filter (no reference counterpart): for n host queries, the ESTIMATED distance of every row they
+ * probe as a key (ordkey(estimate) << 32 | scan position) at keys_out[q * stride + scan position] (slots nobody owns
+ * hold ~0), and band_out[q] = the error band the filter grants query q (|estimate - exact| <= band is what makes the
+ * collected rows a superset of the answer; tests/test_gpu_listmajor.py::test_list_filter_error_bound_holds).  band_out
+ * is read first: queries whose probed lists hold fewer than k granules keep the caller's value. */
+int faiss_amd_GpuIndexIVF_test_filter_dump(const FaissAmdIndex* index, int64_t n, const float* x, int nprobe, int64_t k, int64_t stride,
+                                           uint64_t* keys_out, float* band_out);
 /* *p_output = 1 when mode 0 sends a batch of n queries with this nprobe and k through the list-major scan */
 int faiss_amd_GpuIndexIVF_list_major_rule(const FaissAmdIndex* index, int64_t n, int nprobe, int64_t k, int* p_output);
 

@@ -71,14 +71,20 @@ def test_ivf4096_vs_reference_golden(res, name):
     Do, Io, _, _ = Oracle.ivf_search(c["kind"], c["metric"], z["centroids"], z["list_sizes"], c["codes"], z["list_ids"],
                                      c["xq"][sel], c["nprobe"], c["k"], M=c["M"], pq=c["pq"])
     check_knn(D[sel], I[sel], Do, Io, exact=True, name=name + " vs oracle")
-    # the list-major scan on the same lists: vs the reference, and bit-exact vs its own restatement
-    idx.set_scan_mode(idx.SCAN_LIST_MAJOR)
-    D2, I2 = idx.search(c["xq"], c["k"])
-    st = check_knn(D2, I2, z["D"], z["I"], rtol=1e-4, name=name + " list-major vs golden")
-    assert st["max_rel_err"] < 2e-5
-    Do, Io, _, _ = Oracle.ivf_search(c["kind"], c["metric"], z["centroids"], z["list_sizes"], c["codes"], z["list_ids"],
-                                     c["xq"][sel], c["nprobe"], c["k"], M=c["M"], pq=c["pq"], arith=1)
-    check_knn(D2[sel], I2[sel], Do, Io, exact=True, name=name + " list-major vs oracle")
+    # the list-major scans on the same lists (behind the f16 filter: the query-major bits; on the f32 matrix pipe: its
+    # own restatement): vs the reference, and bit-exact vs the restatement that applies
+    for mode in (idx.SCAN_LIST_MAJOR, idx.SCAN_LIST_MAJOR_F32):
+        idx.set_scan_mode(mode)
+        D2, I2 = idx.search(c["xq"], c["k"])
+        arith = idx.last_scan_arith()
+        assert arith == (1 if mode == idx.SCAN_LIST_MAJOR_F32 else 0)
+        if arith == 0:
+            assert np.array_equal(D2, D) and np.array_equal(I2, I)
+        st = check_knn(D2, I2, z["D"], z["I"], rtol=1e-4, name=name + " list-major vs golden")
+        assert st["max_rel_err"] < 2e-5
+        Do, Io, _, _ = Oracle.ivf_search(c["kind"], c["metric"], z["centroids"], z["list_sizes"], c["codes"], z["list_ids"],
+                                         c["xq"][sel], c["nprobe"], c["k"], M=c["M"], pq=c["pq"], arith=arith)
+        check_knn(D2[sel], I2[sel], Do, Io, exact=True, name=name + " list-major (mode %d) vs oracle" % mode)
     nat = make()
     nat.add(c["xb"])
     sizes = np.array([nat.get_list_size(l) for l in range(nlist)], dtype=np.uint32)
@@ -171,7 +177,7 @@ def test_ivf4096_1m_vs_oracle_and_live_reference(res, sift_shaped, kind):
     # ---- the scan the library picks for this batch (10 000 queries x 32 probes over 4096 lists: list-major for IVFFlat)
     D, I = g2.search(xq, K)
     arith = g2.last_scan_arith()
-    assert arith == (1 if kind == "ivfflat" else 0)
+    assert arith == 0 and g2.scan_info()[1] == (2 if kind == "ivfflat" else 1)
     st = check_knn(D, I, Dr, Ir, rtol=1e-4, max_tie_frac=2e-3, name="%s 1M vs live reference" % kind)
     _report("%s 1M x 10k (automatic scan, arith %d)" % (kind, arith), st)
     assert (np.diff(D, axis=1) >= 0).all()
@@ -179,16 +185,20 @@ def test_ivf4096_1m_vs_oracle_and_live_reference(res, sift_shaped, kind):
     check_knn(D[sel], I[sel], Do, Io, exact=True, name="%s 1M vs oracle" % kind)
     # ---- both scans explicitly, each against the reference on all queries and against its own restatement on the sample
     res_by_mode = {}
-    for mode in (g2.SCAN_QUERY_MAJOR, g2.SCAN_LIST_MAJOR):
+    for mode in (g2.SCAN_QUERY_MAJOR, g2.SCAN_LIST_MAJOR, g2.SCAN_LIST_MAJOR_F32):
         g2.set_scan_mode(mode)
         Dm, Im = g2.search(xq, K)
-        assert g2.scan_info()[1] == mode
+        assert g2.scan_info()[1] == min(mode, 2) and g2.last_scan_arith() == (1 if mode == g2.SCAN_LIST_MAJOR_F32 else 0)
         st = check_knn(Dm, Im, Dr, Ir, rtol=1e-4, max_tie_frac=2e-3, name="%s 1M scan mode %d vs live reference" % (kind, mode))
         _report("%s 1M x 10k (scan mode %d)" % (kind, mode), st)
-        Do, Io, _, _ = Oracle.ivf_search(kd, METRIC_L2, cent, sizes, codes, lids, xq[sel], NPROBE, K, M=M, pq=pq, arith=mode - 1)
+        Do, Io, _, _ = Oracle.ivf_search(kd, METRIC_L2, cent, sizes, codes, lids, xq[sel], NPROBE, K, M=M, pq=pq,
+                                         arith=g2.last_scan_arith())
         check_knn(Dm[sel], Im[sel], Do, Io, exact=True, name="%s 1M scan mode %d vs oracle" % (kind, mode))
         res_by_mode[mode] = (Dm, Im)
-    assert g2.scan_info()[2] == 0, "no query of this batch should overflow its candidate segment"
+    print("queries redone so far (segment overflow / fp16 range):", g2.scan_info()[2])
+    # behind the f16 filter the list-major scan returns the query-major bits: ALL 10 000 x 100 results
+    assert np.array_equal(res_by_mode[g2.SCAN_LIST_MAJOR][0], res_by_mode[g2.SCAN_QUERY_MAJOR][0])
+    assert np.array_equal(res_by_mode[g2.SCAN_LIST_MAJOR][1], res_by_mode[g2.SCAN_QUERY_MAJOR][1])
     Dq_, Iq_ = res_by_mode[g2.SCAN_QUERY_MAJOR]
     # native lists: same results wherever the lists agree (PQ codes may differ in argmin near-ties)
     agree = (In[:, 0] == Iq_[:512, 0]).mean()
@@ -202,11 +212,12 @@ def test_ivf4096_1m_vs_oracle_and_live_reference(res, sift_shaped, kind):
     Dc, Ic = g2.quantizer_search(xq[:400], NPROBE)
     D1, I1 = g2.search_preassigned(xq[:400], K, Ic, Dc)
     assert np.array_equal(I1, Iq_[:400]) and np.array_equal(D1, Dq_[:400])
-    # ... and the list-major one (IVFPQ L2 derives |q - c|^2 itself there: the caller's centroid distances are not used)
-    g2.set_scan_mode(g2.SCAN_LIST_MAJOR)
+    # ... and the list-major ones
     Dc, Ic = g2.quantizer_search(xq, NPROBE)
-    D2, I2 = g2.search_preassigned(xq, K, Ic, Dc)
-    assert np.array_equal(I2, res_by_mode[g2.SCAN_LIST_MAJOR][1]) and np.array_equal(D2, res_by_mode[g2.SCAN_LIST_MAJOR][0])
+    for mode in (g2.SCAN_LIST_MAJOR, g2.SCAN_LIST_MAJOR_F32):
+        g2.set_scan_mode(mode)
+        D2, I2 = g2.search_preassigned(xq, K, Ic, Dc)
+        assert np.array_equal(I2, res_by_mode[mode][1]) and np.array_equal(D2, res_by_mode[mode][0])
 
 
 def test_ivfsq8_4096_1m_vs_oracle_and_live_reference(res, sift_shaped):
@@ -245,7 +256,7 @@ def test_ivfsq8_4096_1m_vs_oracle_and_live_reference(res, sift_shaped):
         assert st["max_rel_err"] < 2e-5
         assert (np.diff(Dm, axis=1) >= 0).all()
         Do, Io = Oracle.ivfsq_search(SQ.QT_8bit, True, METRIC_L2, cent, sizes, codes, lids, vmin, vdiff, xq[sel], NPROBE, K,
-                                     arith=mode - 1)
+                                     arith=g2.last_scan_arith())
         check_knn(Dm[sel], Im[sel], Do, Io, exact=True, name="ivfsq8 1M scan mode %d vs oracle" % mode)
         if mode == g2.SCAN_LIST_MAJOR:
             assert np.array_equal(Dm, D) and np.array_equal(Im, I)
@@ -299,11 +310,16 @@ def test_ivfflat_10m_sample_vs_oracle(res):
     check_knn(D, I, Do, Io, exact=True, name="ivfflat 10M vs oracle")
     # the list-major scan on the same queries: lists of ~2400 rows = three row chunks each (pass 1 sees the first chunk of
     # the leading lists, the rest goes through pass 2)
-    idx.set_scan_mode(idx.SCAN_LIST_MAJOR)
-    D2, I2 = idx.search(xq, K)
-    Do2, Io2, _, _ = Oracle.ivf_search(0, METRIC_L2, cent, sizes, codes, ids, xq, NPROBE, K, arith=1)
-    check_knn(D2, I2, Do2, Io2, exact=True, name="ivfflat 10M list-major vs oracle")
-    check_knn(D2, I2, D, I, rtol=1e-4, name="ivfflat 10M list-major vs query-major")
+    for mode in (idx.SCAN_LIST_MAJOR, idx.SCAN_LIST_MAJOR_F32):
+        idx.set_scan_mode(mode)
+        D2, I2 = idx.search(xq, K)
+        arith = idx.last_scan_arith()
+        assert idx.scan_info()[1] == 2 and arith == (1 if mode == idx.SCAN_LIST_MAJOR_F32 else 0)
+        Do2, Io2, _, _ = Oracle.ivf_search(0, METRIC_L2, cent, sizes, codes, ids, xq, NPROBE, K, arith=arith)
+        check_knn(D2, I2, Do2, Io2, exact=True, name="ivfflat 10M list-major (mode %d) vs oracle" % mode)
+        check_knn(D2, I2, D, I, rtol=1e-4, name="ivfflat 10M list-major vs query-major")
+        if arith == 0:
+            assert np.array_equal(D2, D) and np.array_equal(I2, I)
     idx.set_scan_mode(idx.SCAN_AUTO)
     # exact distances of returned rows that live in the kept chunks
     for chunk, xbc in keep.items():
@@ -323,10 +339,11 @@ def test_ivfflat_10m_sample_vs_oracle(res):
 def test_ivfpq_100m_sample_vs_oracle(res):
     """GpuIndexIVFPQ nlist=4096 PQ64x8 nprobe=32 at nb = 100M on one MI355X (BASELINE.json configs[3]): the database is
     drawn chunk by chunk ON THE DEVICE (faiss_amd.datasets.synthetic_more_device, 1M rows per add call) -- the codes
-    take 6.4 GB of HBM, the host never holds more than the first chunk.  All 10 000 queries are searched with BOTH
-    scans (no segment overflow in the list-major one); a 32-query sample is compared BIT-EXACTLY with the oracle
-    restatement of each scan (arith 0 / 1) run on the ~900 probed lists read back from the device (their codes and
-    ids); the coarse assignment of the sample is bit-exact too; all results ordered, labels valid and distinct."""
+    take 6.4 GB of HBM, the host never holds more than the first chunk.  All 10 000 queries are searched with the three
+    scans (query-major, list-major behind the f16 filter, list-major on the f32 matrix pipe); a 32-query sample is
+    compared BIT-EXACTLY with the oracle restatement that applies (arith 0 / 0 / 1) run on the ~900 probed lists read back
+    from the device (their codes and ids); the coarse assignment of the sample is bit-exact too; all results ordered,
+    labels valid and distinct; the filter scan equals the query-major scan on ALL queries."""
     import torch
     dev = torch.device("cuda", 0)
     nb, M, nsample = 100000000, 64, 32
@@ -356,10 +373,13 @@ def test_ivfpq_100m_sample_vs_oracle(res):
     codes, ids = np.concatenate(codes), np.concatenate(ids)
     print("%d probed lists, %d entries read back" % (len(np.unique(Iq)), len(ids)))
     results = {}
-    for mode, arith in ((idx.SCAN_LIST_MAJOR, 1), (idx.SCAN_QUERY_MAJOR, 0)):
+    for mode in (idx.SCAN_LIST_MAJOR, idx.SCAN_QUERY_MAJOR, idx.SCAN_LIST_MAJOR_F32):
         idx.set_scan_mode(mode)
+        t0 = time.time()
         D, I = idx.search(xq, K)
-        assert idx.scan_info()[1] == mode and idx.scan_info()[2] == 0, "segment overflow at the BASELINE shape"
+        arith = idx.last_scan_arith()
+        print("scan mode %d: %.3f s for 10 000 queries (host buffers), %d queries redone so far" % (mode, time.time() - t0, idx.scan_info()[2]))
+        assert idx.scan_info()[1] == min(mode, 2) and arith == (1 if mode == idx.SCAN_LIST_MAJOR_F32 else 0)
         assert (np.diff(D, axis=1) >= 0).all() and (I >= 0).all() and (I < nb).all()
         srt = np.sort(I, axis=1)
         assert (srt[:, 1:] != srt[:, :-1]).all(), "a label was returned twice"
@@ -367,15 +387,18 @@ def test_ivfpq_100m_sample_vs_oracle(res):
         assert np.array_equal(cI, Iq) and np.array_equal(cD, Dq)
         check_knn(D[sel], I[sel], Do, Io, exact=True, name="ivfpq 100M scan mode %d vs oracle" % mode)
         results[mode] = (D, I)
+    # behind the f16 filter the list-major scan returns the query-major bits: ALL 10 000 x 100 results at nb = 100M
+    assert np.array_equal(results[idx.SCAN_LIST_MAJOR][0], results[idx.SCAN_QUERY_MAJOR][0])
+    assert np.array_equal(results[idx.SCAN_LIST_MAJOR][1], results[idx.SCAN_QUERY_MAJOR][1])
     idx.set_scan_mode(idx.SCAN_AUTO)
     D, I = idx.search(xq, K)
-    assert idx.scan_info()[1] == idx.SCAN_LIST_MAJOR, "configs[3] is a list-major workload"
+    assert idx.scan_info()[1] == 2 and idx.last_scan_arith() == 0, "configs[3] is a list-major workload"
     assert np.array_equal(D, results[idx.SCAN_LIST_MAJOR][0]) and np.array_equal(I, results[idx.SCAN_LIST_MAJOR][1])
-    # the two scans sum in different orders (ADC table on a power-of-two grid vs decoded residuals on the matrix pipe):
-    # rank by rank the distances agree within the tolerance, the labels outside near-tie groups
-    Dl, Il = results[idx.SCAN_LIST_MAJOR]
+    # the f32 list-major scan sums in another order (decoded residuals on the matrix pipe vs the ADC table on a
+    # power-of-two grid): rank by rank the distances agree within the tolerance, the labels outside near-tie groups
+    Dl, Il = results[idx.SCAN_LIST_MAJOR_F32]
     Dm, Im = results[idx.SCAN_QUERY_MAJOR]
     rel = np.abs(Dl - Dm) / np.maximum(np.abs(Dm), 1e-30)
-    print("ivfpq 100M list-major vs query-major: labels equal %.5f, max rel distance difference rank by rank %.3g"
+    print("ivfpq 100M f32 list-major vs query-major: labels equal %.5f, max rel distance difference rank by rank %.3g"
           % ((Il == Im).mean(), rel.max()))
     assert rel.max() < 1e-4 and (Il == Im).mean() > 0.98 and (Il[:, 0] == Im[:, 0]).mean() > 0.995

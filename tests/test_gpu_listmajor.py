@@ -1,10 +1,14 @@
-"""GPU parity tests of the list-major IVF scan (faiss_amd/csrc/ivf_listmajor.hip, round 3): large batches visit every
-inverted list once per group of the queries probing it and compute the distances on the f32 matrix pipe.
-
-Contract (the same as for every other scan): distances and labels BIT-IDENTICAL to the CPU restatement of the kernel's
-arithmetic (oracle/faiss_oracle.c orc_ivf_search_ex, arith = 1 -- itself pinned on the reference's golden outputs by
-tests/test_oracle_cpu.py::test_ivf_list_major_restatement_vs_golden*), and within the north-star tolerance of the
-query-major scan / the reference (labels identical outside near-tie groups, distances <= 1e-4 relative).
+"""GPU parity tests of the list-major IVF scans: large batches visit every inverted list once per group of the queries
+probing it.  Two scans, both run by every test here (fixture lm_mode):
+  * SCAN_LIST_MAJOR (faiss_amd/csrc/ivf_lm_filter.hip, round 4; IVFFlat and IVFPQ shapes it serves): f16 MFMA estimates
+    with a rigorous error band select a superset of the answer, the survivors are re-derived with the arithmetic of the
+    query-major scan -- results BIT-IDENTICAL to the query-major scan and to its restatement (orc_ivf_search_ex, arith 0);
+  * SCAN_LIST_MAJOR_F32 (faiss_amd/csrc/ivf_listmajor.hip, round 3; also what SCAN_LIST_MAJOR falls back to for the
+    shapes the filter does not serve): every distance on the f32 matrix pipe, BIT-IDENTICAL to its own restatement
+    (arith 1 -- pinned on the reference's golden outputs by tests/test_oracle_cpu.py::test_ivf_list_major_restatement_
+    vs_golden*), within the north-star tolerance of the query-major scan (labels identical outside near-tie groups,
+    distances <= 1e-4 relative).
+idx.last_scan_arith() says which restatement applies to the last search.
 Reference being replaced: faiss/gpu/impl/IVFInterleaved.cuh:33-224, PQScanMultiPassNoPrecomputed-inl.cuh:173-270."""
 import numpy as np
 import pytest
@@ -14,6 +18,11 @@ from compare import check_knn
 from oracle.pyoracle import METRIC_INNER_PRODUCT, METRIC_L2, Oracle, synthetic_dataset
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=[2, 3], ids=["filter", "f32"])
+def lm_mode(request):
+    return request.param
 
 
 def _build(res, kind, metric, d, M, nlist, xt, xb, seed=7):
@@ -50,35 +59,39 @@ def _build(res, kind, metric, d, M, nlist, xt, xb, seed=7):
     (1, METRIC_INNER_PRODUCT, 80, 80, 8, 9000, 300, 4, 40),     # five pieces: staged byte by byte; dsub = 1
     (1, METRIC_L2, 120, 60, 16, 8000, 520, 5, 64),              # dpad = 120 < 128, M % 16 != 0 (4-byte pieces), dsub = 2
 ])
-def test_list_major_scan_matches_oracle_and_query_major(res, kind, metric, d, M, nlist, nb, nq, nprobe, k):
+def test_list_major_scan_matches_oracle_and_query_major(res, lm_mode, kind, metric, d, M, nlist, nb, nq, nprobe, k):
     xt, xb, xq = synthetic_dataset(d, 4000, nb, nq, seed=nb + k)
     idx, cent, pq = _build(res, kind, metric, d, M, nlist, xt, xb)
     idx.nprobe = nprobe
     idx.set_scan_mode(idx.SCAN_QUERY_MAJOR)
     D0, I0 = idx.search(xq, k)
     assert idx.scan_info()[1] == 1
-    idx.set_scan_mode(idx.SCAN_LIST_MAJOR)
+    idx.set_scan_mode(lm_mode)
     D, I = idx.search(xq, k)
-    assert idx.scan_info()[1] == 2 and idx.last_scan_arith() == 1
+    arith = idx.last_scan_arith()
+    assert idx.scan_info()[1] == 2 and (arith == 1 or lm_mode == idx.SCAN_LIST_MAJOR)
+    if arith == 0:
+        # behind the f16 filter: the very bits of the query-major scan, for every query
+        assert np.array_equal(I, I0) and np.array_equal(D, D0)
     # the two scans agree to rounding
     check_knn(D, I, D0, I0, rtol=1e-4, name="list-major vs query-major")
     sel = np.r_[0:min(nq, 48)]
     sizes, codes, ids, _ = Oracle.build_ivf_lists(kind, metric, cent, xb, pq=pq)
-    Do, Io, _, _ = Oracle.ivf_search(kind, metric, cent, sizes, codes, ids, xq[sel], nprobe, k, M=M, pq=pq, arith=1)
+    Do, Io, _, _ = Oracle.ivf_search(kind, metric, cent, sizes, codes, ids, xq[sel], nprobe, k, M=M, pq=pq, arith=arith)
     check_knn(D[sel], I[sel], Do, Io, exact=True, name="list-major vs oracle")
     # run to run: the order in which workgroups append candidates never shows
     D2, I2 = idx.search(xq, k)
     assert np.array_equal(D, D2) and np.array_equal(I, I2)
 
 
-def test_list_major_independent_of_batch_composition(res):
+def test_list_major_independent_of_batch_composition(res, lm_mode):
     """A query's result does not depend on which other queries share its batch (tiles, item order, pass-1 / pass-2 split
     of the lists all change with the batch)."""
     d, nlist, nb, k = 64, 32, 20000, 30
     xt, xb, xq = synthetic_dataset(d, 4000, nb, 900, seed=11)
     idx, _, _ = _build(res, 0, METRIC_L2, d, 0, nlist, xt, xb)
     idx.nprobe = 6
-    idx.set_scan_mode(idx.SCAN_LIST_MAJOR)
+    idx.set_scan_mode(lm_mode)
     D, I = idx.search(xq, k)
     D1, I1 = idx.search(xq[100:137], k)
     assert np.array_equal(D1, D[100:137]) and np.array_equal(I1, I[100:137])
@@ -88,7 +101,7 @@ def test_list_major_independent_of_batch_composition(res):
 
 
 @pytest.mark.parametrize("kind,nnear,levels", [(0, 6000, 1), (1, 6000, 1), (0, 40000, 2), (1, 40000, 2)])
-def test_list_major_overflow_rerun_is_exact(res, kind, nnear, levels):
+def test_list_major_overflow_rerun_is_exact(res, lm_mode, kind, nnear, levels):
     """Adversarial layout for the pass-1 bound: the nearest list of every query holds exactly k rows that are FAR away,
     the next two lists hold `nnear` rows each that are all closer -- more candidates than a segment has room for (4096).
     Those queries are redone with 16 x the room (enough for 2 x 6000 rows), and where that overflows too (2 x 40 000
@@ -119,33 +132,34 @@ def test_list_major_overflow_rerun_is_exact(res, kind, nnear, levels):
     sizes = [idx.get_list_size(l) for l in range(nlist)]
     assert sizes[0] == k and sizes[1] == nnear and sizes[2] == nnear
     idx.nprobe = 3
-    idx.set_scan_mode(idx.SCAN_LIST_MAJOR)
+    idx.set_scan_mode(lm_mode)
     before = idx.scan_info()[2]
     D, I = idx.search(xq, k)
-    if kind == 0:
+    if kind == 0 and lm_mode == idx.SCAN_LIST_MAJOR_F32:
         assert idx.scan_info()[2] - before == levels * len(xq), "the overflow path was not exercised"
     sz, codes, ids, _ = Oracle.build_ivf_lists(kind, METRIC_L2, cent, xb, pq=pq)
-    Do, Io, _, _ = Oracle.ivf_search(kind, METRIC_L2, cent, sz, codes, ids, xq, 3, k, M=M if kind else 0, pq=pq, arith=1)
+    Do, Io, _, _ = Oracle.ivf_search(kind, METRIC_L2, cent, sz, codes, ids, xq, 3, k, M=M if kind else 0, pq=pq,
+                                     arith=idx.last_scan_arith())
     check_knn(D, I, Do, Io, exact=True, name="overflow rerun vs oracle")
 
 
-def test_list_major_edge_cases(res):
+def test_list_major_edge_cases(res, lm_mode):
     """empty lists, probes without a list (-1), a NaN query, fewer than k rows in all probed lists, search_preassigned"""
     d, nlist, k = 24, 16, 12
     xt, xb, xq = synthetic_dataset(d, 2000, 3000, 64, seed=2)
     idx, cent, _ = _build(res, 0, METRIC_L2, d, 0, nlist, xt, xb[:1])  # one stored row: 15 of 16 lists empty
     idx.nprobe = 4
-    idx.set_scan_mode(idx.SCAN_LIST_MAJOR)
+    idx.set_scan_mode(lm_mode)
     D, I = idx.search(xq, k)
     sizes, codes, ids, _ = Oracle.build_ivf_lists(0, METRIC_L2, cent, xb[:1])
-    Do, Io, _, _ = Oracle.ivf_search(0, METRIC_L2, cent, sizes, codes, ids, xq, 4, k, arith=1)
+    Do, Io, _, _ = Oracle.ivf_search(0, METRIC_L2, cent, sizes, codes, ids, xq, 4, k, arith=idx.last_scan_arith())
     check_knn(D, I, Do, Io, exact=True, name="nearly empty index")
     idx.add(xb[1:])
     xqn = xq.copy()
     xqn[5, 3] = np.nan
     D, I = idx.search(xqn, k)
     sizes, codes, ids, _ = Oracle.build_ivf_lists(0, METRIC_L2, cent, xb)
-    Do, Io, cD, cI = Oracle.ivf_search(0, METRIC_L2, cent, sizes, codes, ids, xqn, 4, k, arith=1)
+    Do, Io, cD, cI = Oracle.ivf_search(0, METRIC_L2, cent, sizes, codes, ids, xqn, 4, k, arith=idx.last_scan_arith())
     keep = np.r_[0:5, 6:len(xq)]
     check_knn(D[keep], I[keep], Do[keep], Io[keep], exact=True, name="batch with a NaN query")
     assert (I[5] == -1).all()
@@ -183,7 +197,7 @@ def test_scan_mode_rule_and_refusals(res):
     Dq, Iq = pq.search(np.tile(xq, (2, 1))[:3300], 10)
     check_knn(Dp, Ip, Dq, Iq, rtol=1e-4, name="IVFPQ automatic list-major vs query-major")
     with pytest.raises(faiss_amd.FaissAmdError):
-        idx.set_scan_mode(3)
+        idx.set_scan_mode(4)
     idx.set_scan_mode(idx.SCAN_LIST_MAJOR)
     with pytest.raises(faiss_amd.FaissAmdError, match="IDSelector"):
         idx.search(xq[:10], 5, params=faiss_amd.SearchParameters(sel=faiss_amd.IDSelectorRange(0, 100)))
@@ -196,7 +210,7 @@ def test_scan_mode_rule_and_refusals(res):
 
 
 @pytest.mark.parametrize("kind", [0, 1])
-def test_list_major_after_incremental_adds_and_copied_lists(res, kind):
+def test_list_major_after_incremental_adds_and_copied_lists(res, lm_mode, kind):
     """the per-row norms the scan needs follow the rows through list growth / relocation / compaction and bulk loads"""
     d, nlist, nb, nq, k, M = 64, 32, 30000, 300, 20, 16
     xt, xb, xq = synthetic_dataset(d, 4000, nb, nq, seed=9)
@@ -204,10 +218,10 @@ def test_list_major_after_incremental_adds_and_copied_lists(res, kind):
     for a, b in ((100, 150), (150, 4000), (4000, 4100), (4100, 30000)):
         idx.add(xb[a:b])
     idx.nprobe = 7
-    idx.set_scan_mode(idx.SCAN_LIST_MAJOR)
+    idx.set_scan_mode(lm_mode)
     D, I = idx.search(xq, k)
     sizes, codes, ids, _ = Oracle.build_ivf_lists(kind, METRIC_L2, cent, xb, pq=pq)
-    Do, Io, _, _ = Oracle.ivf_search(kind, METRIC_L2, cent, sizes, codes, ids, xq, 7, k, M=M if kind else 0, pq=pq, arith=1)
+    Do, Io, _, _ = Oracle.ivf_search(kind, METRIC_L2, cent, sizes, codes, ids, xq, 7, k, M=M if kind else 0, pq=pq, arith=idx.last_scan_arith())
     check_knn(D, I, Do, Io, exact=True, name="after incremental adds")
     # bulk load of the same lists into a fresh index (copyFrom path)
     if kind == 0:
@@ -218,7 +232,7 @@ def test_list_major_after_incremental_adds_and_copied_lists(res, kind):
     idx2.copy_centroids(cent)
     idx2.copy_lists(sizes, codes, ids)
     idx2.nprobe = 7
-    idx2.set_scan_mode(idx2.SCAN_LIST_MAJOR)
+    idx2.set_scan_mode(lm_mode)
     D2, I2 = idx2.search(xq, k)
     assert np.array_equal(D, D2) and np.array_equal(I, I2)
     freed = idx.reclaimMemory()  # compaction moves every list
@@ -228,7 +242,7 @@ def test_list_major_after_incremental_adds_and_copied_lists(res, kind):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("k", [1, 50, 256, 300])
-def test_list_major_many_equal_distances(res, k):
+def test_list_major_many_equal_distances(res, lm_mode, k):
     """Integer-valued vectors: thousands of rows at exactly the same distance from a query.  The bound and the final
     selection must pick the k smallest (distance, scan position) keys and order them by (distance, label) -- the
     wavefront-per-query kernel resolves the ties at the k-th distance by a second bisection on the position (k <= 256), the
@@ -242,10 +256,110 @@ def test_list_major_many_equal_distances(res, k):
     idx.copy_centroids(cent)
     idx.add(xb)
     idx.nprobe = nprobe
-    idx.set_scan_mode(idx.SCAN_LIST_MAJOR)
+    idx.set_scan_mode(lm_mode)
     D, I = idx.search(xq, k)
     assert idx.scan_info()[1] == 2
     sizes, codes, ids, _ = Oracle.build_ivf_lists(0, METRIC_L2, cent, xb)
-    Do, Io, _, _ = Oracle.ivf_search(0, METRIC_L2, cent, sizes, codes, ids, xq, nprobe, k, arith=1)
+    Do, Io, _, _ = Oracle.ivf_search(0, METRIC_L2, cent, sizes, codes, ids, xq, nprobe, k, arith=idx.last_scan_arith())
     check_knn(D, I, Do, Io, exact=True, name="tie-heavy list-major")
     assert len(np.unique(D[0])) < max(2, k // 2) or k == 1  # the data really ties
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_results_do_not_depend_on_the_batch_size(res, kind):
+    """the automatic rule sends batches of >= 2048 queries through the list-major scan.  Behind the f16
+    filter that scan returns the bits of the query-major scan, so a query's distances and labels are the same at
+    n = 2047 and n = 2048 (and therefore under IndexShards / IndexReplicas query splits and the paged host path)."""
+    d, nlist, M, k = 64, 64, 32, 40
+    xt, xb, xq = synthetic_dataset(d, 4000, 60000, 2048, seed=31)
+    idx, _, _ = _build(res, kind, METRIC_L2, d, M, nlist, xt, xb)
+    idx.nprobe = 16
+    assert idx.list_major_rule(2048, 16, k) or kind == 1
+    if kind == 1:
+        idx.set_scan_mode(idx.SCAN_LIST_MAJOR)  # (the IVFPQ rule asks for longer lists; force the scan)
+    D, I = idx.search(xq, k)
+    assert idx.scan_info()[1] == 2 and idx.last_scan_arith() == 0
+    idx.set_scan_mode(idx.SCAN_AUTO)
+    D1, I1 = idx.search(xq[:2047], k)
+    assert idx.scan_info()[1] == 1
+    assert np.array_equal(D1, D[:2047]) and np.array_equal(I1, I[:2047])
+
+
+def test_list_major_near_duplicates_and_self_search(res, lm_mode):
+    """rows that are (near-)duplicates of the queries.  The f32 list-major scan computes L2 by the norm
+    expansion |q|^2 + |y|^2 - 2 <q, y> (clamped at 0): near distance 0 its relative error is unbounded (cancellation),
+    its absolute error stays at the rounding of the norms.  Behind the filter the list-major scan re-derives the
+    survivors with the direct sum of (q - y)^2: a stored copy of the query comes back with distance exactly 0 and the
+    near-duplicates keep full relative precision -- the bits of the query-major scan."""
+    d, nlist, k = 64, 32, 10
+    xt, xb, xq = synthetic_dataset(d, 4000, 30000, 2100, seed=17)
+    rs = np.random.RandomState(5)
+    xb = xb.copy()
+    xb[:2100] = xq                                                     # exact copies
+    xb[2100:4200] = xq + (rs.rand(2100, d).astype("float32") - 0.5) * 1e-3   # near-duplicates
+    idx, cent, _ = _build(res, 0, METRIC_L2, d, 0, nlist, xt, xb)
+    idx.nprobe = 8
+    idx.set_scan_mode(idx.SCAN_QUERY_MAJOR)
+    D0, I0 = idx.search(xq, k)
+    idx.set_scan_mode(lm_mode)
+    D, I = idx.search(xq, k)
+    assert idx.scan_info()[1] == 2
+    if idx.last_scan_arith() == 0:
+        assert np.array_equal(D, D0) and np.array_equal(I, I0)
+        assert (D[:, 0] == 0).all() and (I[:, 0] == np.arange(2100)).all()
+        exact = ((xq.astype(np.float64) - xb[I[:, 1]].astype(np.float64)) ** 2).sum(-1)
+        assert np.allclose(D[:, 1], exact, rtol=1e-5, atol=0)         # ~1e-5 distances, relative precision kept
+    else:
+        # the norm expansion: absolute error at the scale of the rounding of |q|^2 + |y|^2, whatever the distance
+        scale = (xq.astype(np.float64) ** 2).sum(-1)
+        assert (np.abs(D[:, 0]) <= 1e-5 * scale).all()
+        exact = ((xq.astype(np.float64)[:, None, :] - xb[I].astype(np.float64)) ** 2).sum(-1)
+        assert (np.abs(D - exact) <= 1e-5 * scale[:, None] + 1e-4 * exact).all()
+
+
+@pytest.mark.parametrize("kind,metric,d,M,scale", [
+    (0, METRIC_L2, 128, 0, 1.0), (0, METRIC_INNER_PRODUCT, 128, 0, 1.0), (0, METRIC_L2, 40, 0, 1.0),
+    (0, METRIC_L2, 128, 0, 200.0),           # large values: the band scales with |q| |y|
+    (0, METRIC_L2, 64, 0, 1e-3),             # small values (fp16 denormals in play)
+    (1, METRIC_L2, 128, 64, 1.0), (1, METRIC_INNER_PRODUCT, 128, 64, 1.0), (1, METRIC_L2, 64, 16, 1.0),
+    (1, METRIC_L2, 96, 12, 1.0), (1, METRIC_L2, 32, 32, 1.0), (1, METRIC_L2, 128, 64, 50.0),
+])
+def test_list_filter_error_bound_holds(res, kind, metric, d, M, scale):
+    """The superset argument of the f16 filter (ivf_lm_filter.hip) rests on |estimate - exact| <= E_q for EVERY row a query
+    probes (kernels.h ivf_filter_err_bound + the IVFPQ table-grid term).  Checked directly: the estimates of every probed
+    row (test hook, sweep mode 3) against the exact distances of the query-major arithmetic (the oracle, k = all rows),
+    with the band the bound kernel grants the query.  The measured worst |estimate - exact| / E_q is printed: how much
+    of the band real data uses."""
+    nlist, nb, nq, nprobe = 16, 12000, 96, 4
+    xt, xb, xq = synthetic_dataset(d, 3000, nb, nq, seed=d + M)
+    xt, xb, xq = xt * np.float32(scale), xb * np.float32(scale), xq * np.float32(scale)
+    idx, cent, pq = _build(res, kind, metric, d, M, nlist, xt, xb)
+    if pq is not None and scale != 1.0:
+        pq = (pq * np.float32(scale)).astype(np.float32)
+        idx.copy_pq_centroids(pq)
+        idx.reset()
+        idx.add(xb)
+    idx.nprobe = nprobe
+    sizes, codes, ids, _ = Oracle.build_ivf_lists(kind, metric, cent, xb, pq=pq)
+    Dq, Iq = idx.quantizer_search(xq, nprobe)
+    rows = np.array([int(sum(sizes[l] for l in Iq[q] if l >= 0)) for q in range(nq)])
+    stride = int(nprobe * sizes.max())
+    est, band = idx.filter_dump(xq, 10, stride)
+    assert np.isfinite(band).all() and (band > 0).all()
+    # exact distances of all probed rows: the oracle with k = the rows the query probes, mapped back to scan positions
+    kall = int(rows.max())
+    Do, Io, _, _ = Oracle.ivf_search(kind, metric, cent, sizes, codes, ids, xq, nprobe, kall, M=M, pq=pq)
+    starts = np.concatenate([[0], np.cumsum(sizes)])[:-1]
+    worst = 0.0
+    for q in range(nq):
+        pos_ids = np.concatenate([ids[starts[l]:starts[l] + sizes[l]] for l in Iq[q] if l >= 0])
+        assert len(pos_ids) == rows[q] and not np.isnan(est[q, :rows[q]]).any() and np.isnan(est[q, rows[q]:]).all()
+        exact = np.empty(rows[q], dtype=np.float64)
+        order = {int(i): r for r, i in enumerate(Io[q, :rows[q]])}
+        for p_, i in enumerate(pos_ids):
+            exact[p_] = Do[q, order[int(i)]]
+        err = np.abs(est[q, :rows[q]].astype(np.float64) - exact)
+        assert (err <= band[q]).all(), (q, float(err.max()), float(band[q]))
+        worst = max(worst, float(err.max() / band[q]))
+    print("kind %d metric %d d %d scale %g: worst |estimate - exact| / band = %.3f" % (kind, metric, d, scale, worst))
+    assert worst > 1e-4  # (the estimates are estimates: a zero error would mean the test compares a thing with itself)
