@@ -2013,6 +2013,7 @@ void GpuIndexIVF::search_core_(idx_t n, const float* x, idx_t k, float* distance
     // IVFFlat / IVFPQ: the list-major scan runs behind the f16 filter (results = the query-major scan's, bit for bit)
     // unless the f32 scan of round 3 is asked for.  Stored values outside the fp16 range: the query-major scan serves
     // the call (same bits, no filter).
+    cur_preassigned_ = assign != nullptr;
     cur_lmf_ = cur_lm_ && scan_mode != 3 && lmf_capable_();
     if (cur_lmf_ && nstored_ > 0) {
         IvfLmParams probe{};
@@ -2338,13 +2339,23 @@ void GpuIndexIVF::search_listmajor_(int ni, const float* xq_pad, const idx_t* c_
         if (lmf_gran_blocks > 0) G = lmf_gran_blocks;
         if (lmf_cand_cap > 0) stride = std::max<int64_t>(lmf_cand_cap, k);
         FA_THROW_IF_NOT_MSG(G >= 1 && G <= 8 && (G & (G - 1)) == 0 && RT <= 65280, "filter tuning: granule / rows per item");
-        const int64_t gstride = 2 * (int64_t)np * (int64_t)div_up((size_t)max_len, (size_t)(32 * G));
+        // granule slots a query can own: those of the np longest lists
+        int64_t gstride = 0;
+        {
+            std::vector<uint32_t> len(list_len_);
+            const size_t top = (size_t)std::min<int64_t>(np, nlist);
+            std::nth_element(len.begin(), len.begin() + (top - 1), len.end(), std::greater<uint32_t>());
+            for (size_t i = 0; i < top; i++) gstride += 2 * (int64_t)div_up((size_t)len[i], (size_t)(32 * G));
+            // (a caller's own assignment may name a list more than once: the longest list np times)
+            if (cur_preassigned_) gstride = 2 * (int64_t)np * (int64_t)div_up((size_t)max_len, (size_t)(32 * G));
+            gstride = std::max<int64_t>(gstride, 2);
+        }
         const size_t per_q = (size_t)stride * 10 + (size_t)gstride * 4 + (size_t)(np + 1) * 12 + 256;
         const int64_t fit = std::max<int64_t>(1, std::min<int64_t>((int64_t)(R.temp_budget_bytes / per_q), (1 << 20)));
         for (int c0 = 0; c0 < ni; c0 += (int)std::min<int64_t>(fit, ni)) {
             const int cn = (int)std::min<int64_t>(fit, ni - c0);
             search_listmajor_filter_chunk_(cn, c0, xq_pad + (size_t)c0 * dpad_, c_ids + (size_t)c0 * np, c_dis + (size_t)c0 * np, np,
-                                           k, dD + (size_t)c0 * k, dI + (size_t)c0 * k, stride, RT | (G << 16), *redo);
+                                           k, dD + (size_t)c0 * k, dI + (size_t)c0 * k, stride, RT | (G << 16), gstride, *redo);
         }
         return;
     }
@@ -2537,7 +2548,7 @@ void GpuIndexIVF::search_listmajor_chunk_(int ni, const float* xq_pad, const idx
 // One chunk of queries through the filter path: plan -> sweep 1 (granule minima) -> bound -> sweep 2 (collect) -> exact
 // rerank of the candidates -> k-selection.  rt_g = rows per item | granule blocks << 16.
 void GpuIndexIVF::search_listmajor_filter_chunk_(int ni, int q0, const float* xq_pad, const idx_t* c_ids, const float* c_dis, int np,
-                                                 int k, float* dD, idx_t* dI, int64_t stride, int rt_g,
+                                                 int k, float* dD, idx_t* dI, int64_t stride, int rt_g, int64_t gstride,
                                                  std::vector<uint32_t>& redo) const {
     const GpuResources& R = *res_;
     const int RT = rt_g & 0xffff, G = rt_g >> 16;
@@ -2553,7 +2564,6 @@ void GpuIndexIVF::search_listmajor_filter_chunk_(int ni, int q0, const float* xq
     const int qpi = ivf_lmf_queries_per_item(fused_kind_());
     const int64_t max_items = nrt_max * (int64_t)div_up((size_t)npairs, (size_t)qpi) + 2 * sum_nrt + 16;
     FA_THROW_IF_NOT_MSG(max_items < ((int64_t)1 << 30), "list-major scan: too many work items");
-    const int64_t gstride = 2 * (int64_t)np * (int64_t)div_up((size_t)max_len, (size_t)(32 * G));
 
     IvfLmParams P{};
     P.metric = metric_type;
@@ -3017,7 +3027,8 @@ void GpuIndexIVFScalarQuantizer::scan_(int, const float*, int, const int64_t*) c
 GpuIndexIVFFlat::GpuIndexIVFFlat(std::shared_ptr<GpuResources> res, int dims, int nlist, int metric)
         : GpuIndexIVF(std::move(res), dims, metric, nlist) {
     code_bytes_ = (size_t)dpad_ * 4;
-    granule_ = 8;
+    // lists start on multiples of 32 rows: the fp16 shadow of the filter sweeps is kept in 32-row operand-major blocks
+    granule_ = 32;
     // |y|^2 per stored row: second term of the list-major scans' L2 distances / estimates; the filter's error band needs
     // max |y|^2 for the inner product as well
     use_rn_ = true;
@@ -3033,7 +3044,7 @@ bool GpuIndexIVFFlat::lmf_prepare_(IvfLmParams& p) const {
     const int dh = (int)round_up(d, 16);
     if (shadow_dirty_) {
         const GpuResources& R = *res_;
-        arena_h_.ensure(((size_t)arena_cap_rows_ + 128) * dh * 2);
+        arena_h_.ensure(((size_t)arena_cap_rows_ / 32 + 4) * (size_t)(dh / 16) * 1024); // whole 32-row blocks + padding
         lm_scalar_.ensure(64);
         HIP_CHECK(hipMemsetAsync(lm_scalar_.p, 0, 4, R.stream));
         launch_ivf_lmf_shadow(arena_.as<float>(), dpad_, arena_rn_.as<float>(), d, nlist, d_list_len_.as<uint32_t>(),
@@ -3318,7 +3329,7 @@ bool GpuIndexIVFPQ::lm_capable_() const {
     return ivf_lm_supported(1, dpad_, M, d);
 }
 bool GpuIndexIVFPQ::lmf_capable_() const {
-    return ivf_lmf_supported(1, d, dpad_, M) && (size_t)d * 512 + 8 * 32 * (size_t)(round_up(M, 16) + 16) + 8 * 256 * 12 <= 160 * 1024;
+    return ivf_lmf_supported(1, d, dpad_, M) && (size_t)d * 512 + 8 * 256 * 12 <= 160 * 1024;
 }
 // fp16 codebook + the norm bounds of the filter's error band: upper bound of |r^|^2 (sum over the sub-quantizers of their
 // largest squared entry norm), max |centroid|^2.  Rebuilt when a quantizer changed.
@@ -3364,6 +3375,21 @@ bool GpuIndexIVFPQ::lmf_prepare_(IvfLmParams& p) const {
         lmf_quant_dirty_ = false;
     }
     if (!pq16_in_range_) return false;
+    int bpl = 0, piece = 0;
+    ivf_lmf_code_shadow_shape(d, M, &bpl, &piece);
+    if (shadow_dirty_) {
+        // operand-major copy of the codes (kernels.h IvfLmParams::arena_cs): rebuilt as a whole at the first list-major
+        // search after a list changed, like the fp16 shadow of IVFFlat
+        const size_t blk = (size_t)64 * ((bpl + piece - 1) / piece) * piece;
+        arena_cs_.ensure(((size_t)arena_cap_rows_ / 32 + 4) * blk);
+        launch_ivf_lmf_code_shadow(arena_.as<uint8_t>(), d, M, nlist, d_list_len_.as<uint32_t>(), d_list_start_.as<int64_t>(),
+                                   arena_cs_.as<uint8_t>(), res_->stream);
+        res_->sync();
+        shadow_dirty_ = false;
+    }
+    p.arena_cs = arena_cs_.as<uint8_t>();
+    p.cs_bpl = bpl;
+    p.cs_piece = piece;
     p.filter = 1;
     p.pq16 = pq16_.p;
     p.yn_max = pq_yn_max_;

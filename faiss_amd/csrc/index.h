@@ -447,13 +447,15 @@ class GpuIndexIVF : public Index {
     virtual bool lmf_capable_() const { return false; }
     virtual bool lmf_prepare_(struct IvfLmParams& p) const { return false; }
     mutable bool cur_lmf_ = false;        // the list-major search in flight runs the filter sweeps
+    mutable bool cur_preassigned_ = false; // ... with the caller's coarse assignment (search_preassigned)
     mutable int last_scan_arith_ = 0;     // oracle restatement of the last search: 0 query-major arithmetic, 1 f32 list-major
     mutable bool shadow_dirty_ = true;    // a list changed since the fp16 shadow was built
     mutable bool lmf_quant_dirty_ = true; // a quantizer changed since the fp16 codebook / norm bounds were built
     mutable DevBuf lm_prefixg_, lm_gmin_, lm_thrf_, lm_candpr_, lm_q16_, lm_qflags_, lm_xnb_, lm_pqgrid_, lm_scalar_;
     // queries whose candidate segment overflowed (or that leave the fp16 range) are appended to `redo`
     void search_listmajor_filter_chunk_(int ni, int q0, const float* xq_pad, const idx_t* c_ids, const float* c_dis, int np, int k,
-                                        float* dD, idx_t* dI, int64_t stride, int RT, std::vector<uint32_t>& redo) const;
+                                        float* dD, idx_t* dI, int64_t stride, int rt_g, int64_t gstride,
+                                        std::vector<uint32_t>& redo) const;
     void search_listmajor_chunk_(int ni, const float* xq_pad, const idx_t* c_ids, const float* c_dis, int np, int k,
                                  float* dD, idx_t* dI, int level, int64_t stride, int min_p1, int RT, int64_t c1max) const;
     void upload_list_tables_();
@@ -557,6 +559,7 @@ class GpuIndexIVFPQ : public GpuIndexIVF {
     bool lmf_capable_() const override;
     bool lmf_prepare_(struct IvfLmParams& p) const override;
     mutable DevBuf pq16_;             // fp16 codebook [M][256][dsub]
+    mutable DevBuf arena_cs_;         // operand-major copy of the codes for the filter sweeps (kernels.h IvfLmParams::arena_cs)
     mutable float pq_yn_max_ = 0.f, cn_max_ = 0.f;
     mutable bool pq16_in_range_ = true;
     bool lm_pq_lds_capable_() const override { return ivf_lm_pq_lds_supported_(); }

@@ -75,35 +75,45 @@ int ivf_lmf_queries_per_item(int) {
     return 32 * kLmfQueryBlocks;
 }
 
-// ------------------------------------------------------------------ fp16 shadow of the IVFFlat rows
+// ------------------------------------------------------------------ fp16 shadow of the IVFFlat rows (operand-major blocks)
 __global__ void __launch_bounds__(256) lmf_shadow_kernel(const float* __restrict__ arena, int64_t ldv,
                                                          const float* __restrict__ arena_rn, int d, const uint32_t* list_len,
                                                          const int64_t* list_start, _Float16* __restrict__ arena_h, int dh,
                                                          unsigned* __restrict__ yn_max_bits) {
     const int list = blockIdx.x;
     const uint32_t len = list_len[list];
-    const int64_t start = list_start[list];
-    const int pieces = dh >> 3; // 8-coordinate pieces per row
+    const int64_t start = list_start[list]; // (a multiple of 32)
+    const int nks = dh >> 4;
     float mx = 0.f;
     bool bad = false;
-    const int64_t total = (int64_t)len * pieces;
+    // piece i of the list's shadow: (block, k-step, lane) with the lane fastest -- consecutive threads write consecutive
+    // 16-byte pieces; rows behind the end of the list are written as zeros
+    const int64_t nblk = (len + 31) / 32;
+    const int64_t total = nblk * nks * 64;
     for (int64_t i = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.y * blockDim.x) {
-        const int64_t r = i / pieces;
-        const int c = (int)(i - r * pieces) * 8;
-        const float* src = arena + (start + r) * ldv + c;
-        half8 o;
+        const int ln = (int)(i & 63);
+        const int64_t bs = i >> 6;
+        const int s = (int)(bs % nks);
+        const int64_t b = bs / nks;
+        const int h = ln >> 5, j = ln & 31;
+        const int64_t r = b * 32 + j;
+        const int c = 16 * s + 8 * h;
+        half8 o = half8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (r < (int64_t)len) {
+            const float* src = arena + (start + r) * ldv + c;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float v = c + e < d ? src[e] : 0.f;
-            if (!(fabsf(v) <= 65000.f)) bad = true; // NaN, inf, or beyond the fp16 normal range
-            o[e] = (_Float16)v;
+            for (int e = 0; e < 8; ++e) {
+                const float v = c + e < d ? src[e] : 0.f;
+                if (!(fabsf(v) <= 65000.f)) bad = true; // NaN, inf, or beyond the fp16 normal range
+                o[e] = (_Float16)v;
+            }
+            if (c == 0 && arena_rn) {
+                const float n = arena_rn[start + r];
+                if (!(n <= 3.0e38f)) bad = true;
+                mx = fmaxf(mx, n);
+            }
         }
-        *(half8*)(arena_h + (start + r) * dh + c) = o;
-        if (c == 0 && arena_rn) {
-            const float n = arena_rn[start + r];
-            if (!(n <= 3.0e38f)) bad = true;
-            mx = fmaxf(mx, n);
-        }
+        *(half8*)(arena_h + (((start >> 5) + b) * nks + s) * 512 + ln * 8) = o;
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
@@ -115,6 +125,54 @@ void launch_ivf_lmf_shadow(const float* arena, int64_t ldv, const float* arena_r
     if (nlist == 0) return;
     hipLaunchKernelGGL(lmf_shadow_kernel, dim3((unsigned)nlist, 4), dim3(256), 0, stream, arena, ldv, arena_rn, d, list_len,
                        list_start, (_Float16*)arena_h, dh, yn_max_bits);
+    HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ IVFPQ: operand-major copy of the codes
+void ivf_lmf_code_shadow_shape(int d, int M, int* bpl, int* piece) {
+    const int dsub = d / M;
+    const int ncode = dsub >= 8 ? 1 : 8 / dsub;
+    *bpl = (d >> 4) * ncode;
+    *piece = (*bpl % 16 == 0) ? 16 : 4;
+}
+__global__ void __launch_bounds__(256) lmf_code_shadow_kernel(const uint8_t* __restrict__ arena_codes, int d, int M,
+                                                              const uint32_t* list_len, const int64_t* list_start,
+                                                              uint8_t* __restrict__ arena_cs, int bpl, int piece) {
+    const int list = blockIdx.x;
+    const uint32_t len = list_len[list];
+    const int64_t start = list_start[list]; // (a multiple of 64)
+    const int dsub = d / M;
+    const int ncode = dsub >= 8 ? 1 : 8 / dsub;
+    const int npiece = (bpl + piece - 1) / piece;
+    const int64_t nblk = (len + 31) / 32;
+    const int64_t total = nblk * npiece * 64; // pieces of the list's shadow, lane fastest
+    for (int64_t i = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.y * blockDim.x) {
+        const int ln = (int)(i & 63);
+        const int64_t bp = i >> 6;
+        const int pc = (int)(bp % npiece);
+        const int64_t b = bp / npiece;
+        const int h = ln >> 5, j = ln & 31;
+        const int64_t r = b * 32 + j;
+        uint8_t* dst = arena_cs + ((start >> 5) + b) * (int64_t)(64 * npiece * piece) + ((int64_t)pc * 64 + ln) * piece;
+        for (int u = 0; u < piece; ++u) {
+            const int bb = pc * piece + u; // byte of the lane's share
+            uint8_t v = 0;
+            if (bb < bpl && r < (int64_t)len) {
+                const int s = bb / ncode;
+                const int m = (16 * s + 8 * h) / dsub + bb % ncode;
+                v = arena_codes[pq_code_offset(M, start + r, m)];
+            }
+            dst[u] = v;
+        }
+    }
+}
+void launch_ivf_lmf_code_shadow(const uint8_t* arena_codes, int d, int M, int nlist, const uint32_t* list_len,
+                                const int64_t* list_start, uint8_t* arena_cs, hipStream_t stream) {
+    if (nlist == 0) return;
+    int bpl, piece;
+    ivf_lmf_code_shadow_shape(d, M, &bpl, &piece);
+    hipLaunchKernelGGL(lmf_code_shadow_kernel, dim3((unsigned)nlist, 8), dim3(256), 0, stream, arena_codes, d, M, list_len,
+                       list_start, arena_cs, bpl, piece);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -216,18 +274,19 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
         while (t < r1) {
             // ---- (re-)entry: the rows of block t.  Rows behind the end of the list belong to the next list or the
             // arena's padding: loaded, never looked at.
-            const _Float16* arow = arena_h + (start + t + j) * p.ldh + 8 * h;
+            // (operand-major shadow: k-step s of block b is the KB at (b * nks + s) * 1024, lane l its 16-byte piece l)
+            const _Float16* arow = arena_h + ((start + t) >> 5) * (int64_t)(nks * 512) + lane * 8;
             half8 a[8];
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
-                if (FULL || s < nks) a[s] = *(const half8*)(arow + 16 * s);
+                if (FULL || s < nks) a[s] = *(const half8*)(arow + 512 * s);
                 else a[s] = half8{0, 0, 0, 0, 0, 0, 0, 0};
                 asm volatile("" ::: "memory");
             }
             const float* rnp = p.arena_rn + start + t + 4 * h; // |y|^2 of rows 8 g + 4 h + e of the block: rnp[8 g + e]
             bool full = false;
             for (; t < r1; t += 32) {
-                arow += 32 * p.ldh;
+                arow += nks * 512;
                 rnp += 32;
                 f32x16 acc[NQB];
 #pragma unroll
@@ -244,7 +303,7 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
 #pragma unroll
                         for (int b = 0; b < NQB; ++b)
                             acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s], bq[b][s], acc[b], 0, 0, 0);
-                        a[s] = *(const half8*)(arow + 16 * s);
+                        a[s] = *(const half8*)(arow + 512 * s);
                     }
                     if (s == 3 && METRIC == METRIC_L2) {
 #pragma unroll
@@ -371,17 +430,20 @@ constexpr int LP_THREADS = 512;
 constexpr int LP_BR = 32;    // rows per block
 constexpr int LP_PARK = 256; // parked candidates per wave
 struct LpLayout {
-    int cb_bytes, rs, off_codes, off_park, total;
+    int cb_bytes, off_park, total;
 };
 __host__ __device__ static inline LpLayout lp_layout(int d, int M) {
     LpLayout L;
     L.cb_bytes = d * 256 * 2;
-    L.rs = ((M + 15) & ~15) + 16; // bytes per row of a code slice (+ 16: rows on different banks)
-    L.off_codes = (L.cb_bytes + 15) & ~15;
-    L.off_park = L.off_codes + 8 * LP_BR * L.rs;
+    L.off_park = (L.cb_bytes + 15) & ~15;
     L.total = L.off_park + 8 * LP_PARK * (8 + 4);
     return L;
 }
+// code dwords a lane holds per 32-row block (IvfLmParams::cs_bpl / 4, at most): 8 k-steps x (8 / dsub) codes
+template <int DS>
+struct LpCodes {
+    static constexpr int ND = DS == 1 ? 16 : DS == 2 ? 8 : DS == 4 ? 4 : 2;
+};
 
 template <int METRIC, int MODE, int NQB, int DS>
 __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p) {
@@ -402,7 +464,6 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
         uint4* dst = (uint4*)smem;
         for (int i = tid; i < p.d * 32; i += LP_THREADS) dst[i] = src[i];
     }
-    unsigned char* crow = (unsigned char*)(smem + LY.off_codes) + (wave * LP_BR + j) * LY.rs; // this lane's row of the slice
     u64* pk_keys = (u64*)(smem + LY.off_park) + wave * LP_PARK;
     uint32_t* pk_q = (uint32_t*)(smem + LY.off_park + 8 * LP_PARK * 8) + wave * LP_PARK;
     int wcnt = 0;
@@ -424,10 +485,11 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
     };
     __syncthreads();
 
-    const int ch = pq_chunk_bytes(M);
-    const int nch = M >> 4;          // 16-byte pieces of a stored row (ch == 16)
-    const int cpl = (nch + 1) >> 1;  // ... per lane: lane (j, h) moves pieces h * cpl .. of row j
-    const bool fast = ch == 16 && nch <= 4;
+    // operand-major code shadow (IvfLmParams::arena_cs): a block = npiece pieces of 64 lanes x cs_piece bytes
+    constexpr int ND = LpCodes<DS>::ND;
+    const bool x4 = p.cs_piece == 16;
+    const int npiece = (p.cs_bpl + p.cs_piece - 1) / p.cs_piece;
+    const int64_t blk_bytes = (int64_t)64 * npiece * p.cs_piece;
     const uint32_t it0 = p.item_bounds[1], it1 = p.item_bounds[2];
     uint32_t* ctr = p.item_bounds + (MODE == MODE_MIN ? 5 : 4);
     for (;;) {
@@ -447,44 +509,27 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
         const int r0 = rt * p.rows_per_item;
         const int r1 = min(len, r0 + p.rows_per_item);
 
-        uint4 creg[2];
-        auto fetch = [&](int t) __attribute__((always_inline)) {
-            if (fast) {
-                const int64_t row = start + t + j; // arena row (inside the list's capacity: a multiple of 64 rows)
-                const unsigned char* src = p.arena_codes + (size_t)(row >> 6) * 64 * M + (size_t)(row & 63) * 16;
+        // the code bytes of this lane's operands for block t: global -> registers, one block ahead
+        unsigned cw[ND], cn[ND];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int c = h * cpl + i;
-                    if (i < cpl && c < nch) creg[i] = *(const uint4*)(src + (size_t)c * 1024);
-                }
-            }
-        };
-        auto stage = [&](int t) __attribute__((always_inline)) {
-            const int64_t row = start + t + j;
-            if (fast) {
-                const int lrot = (int)(row & 63) % M; // stored byte x of the row is sub-quantizer (x + row) mod M
+        for (int i = 0; i < ND; ++i) cw[i] = cn[i] = 0u;
+        auto fetch = [&](int t, unsigned (&dst)[ND]) __attribute__((always_inline)) {
+            const uint8_t* bp = p.arena_cs + ((start + t) >> 5) * blk_bytes;
+            if (x4) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(creg[i].x), "+v"(creg[i].y), "+v"(creg[i].z), "+v"(creg[i].w));
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int c = h * cpl + i;
-                    if (i < cpl && c < nch) {
-                        const unsigned w[4] = {creg[i].x, creg[i].y, creg[i].z, creg[i].w};
-#pragma unroll
-                        for (int b = 0; b < 16; ++b) {
-                            int m = 16 * c + b + lrot;
-                            m -= m >= M ? M : 0;
-                            crow[m] = (unsigned char)(w[b >> 2] >> (8 * (b & 3)));
-                        }
+                for (int c = 0; c < ND / 4; ++c) {
+                    if (c < npiece) {
+                        const uint4 v = *(const uint4*)(bp + ((int64_t)c * 64 + lane) * 16);
+                        dst[4 * c] = v.x, dst[4 * c + 1] = v.y, dst[4 * c + 2] = v.z, dst[4 * c + 3] = v.w;
                     }
                 }
             } else {
-                for (int m = h; m < M; m += 2) crow[m] = p.arena_codes[pq_code_offset(M, row, m)];
+#pragma unroll
+                for (int c = 0; c < ND; ++c)
+                    if (c < npiece) dst[c] = *(const unsigned*)(bp + ((int64_t)c * 64 + lane) * 4);
             }
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
         };
-        fetch(r0);
+        fetch(r0, cw);
 
         // ---- this lane's queries: B operands = fp16 of the residual query (L2) / of the query (inner product)
         LmfLane L[NQB];
@@ -535,35 +580,36 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
         }
 
         for (int t = r0; t < r1; t += LP_BR) {
-            stage(t);
             const bool more = t + LP_BR < r1;
-            // the A operand of k-step s: coordinates 16 s + 8 h .. + 7 of this lane's row
+            // the A operand of k-step s: coordinates 16 s + 8 h .. + 7 of this lane's row, gathered from the codebook by
+            // the code bytes in cw
             auto operand_of = [&](int s_) __attribute__((always_inline)) -> half8 {
                 half8 a = half8{0, 0, 0, 0, 0, 0, 0, 0};
                 if (s_ >= nks) return a;
                 const int kb = 16 * s_ + 8 * h; // first coordinate
                 if (DS == 8) {
                     const int m = kb / dsub, off = kb - m * dsub;
-                    a = *(const half8*)(cb + ((m << 8) + (int)crow[m]) * dsub + off);
+                    const unsigned c = (cw[s_ >> 2] >> (8 * (s_ & 3))) & 255u;
+                    a = *(const half8*)(cb + ((m << 8) + (int)c) * dsub + off);
                 } else if (DS == 4) {
-                    const unsigned cw = *(const unsigned short*)(crow + (kb >> 2));
-                    const half4v lo = *(const half4v*)(cb + ((((kb >> 2)) << 8) + (int)(cw & 255u)) * 4);
-                    const half4v hi = *(const half4v*)(cb + ((((kb >> 2) + 1) << 8) + (int)(cw >> 8)) * 4);
+                    const unsigned c2 = (cw[s_ >> 1] >> (16 * (s_ & 1))) & 0xffffu;
+                    const int m0 = kb >> 2;
+                    const half4v lo = *(const half4v*)(cb + ((m0 << 8) + (int)(c2 & 255u)) * 4);
+                    const half4v hi = *(const half4v*)(cb + (((m0 + 1) << 8) + (int)(c2 >> 8)) * 4);
                     a = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 } else if (DS == 2) {
-                    const unsigned cw = *(const unsigned*)(crow + (kb >> 1));
+                    const unsigned c4 = cw[s_];
                     const int m0 = kb >> 1;
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        const half2v v = *(const half2v*)(cb + (((m0 + u) << 8) + (int)((cw >> (8 * u)) & 255u)) * 2);
+                        const half2v v = *(const half2v*)(cb + (((m0 + u) << 8) + (int)((c4 >> (8 * u)) & 255u)) * 2);
                         a[2 * u] = v[0];
                         a[2 * u + 1] = v[1];
                     }
                 } else {
-                    const uint2 cw = *(const uint2*)(crow + kb);
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
-                        const unsigned c = ((u < 4 ? cw.x : cw.y) >> (8 * (u & 3))) & 255u;
+                        const unsigned c = (cw[2 * s_ + (u >> 2)] >> (8 * (u & 3))) & 255u;
                         a[u] = cb[((kb + u) << 8) + (int)c];
                     }
                 }
@@ -583,7 +629,7 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 if (s + 1 < 8) av[(s + 1) & 1] = operand_of(s + 1);
-                if (s == 1 && more) fetch(t + LP_BR);
+                if (s == 1 && more) fetch(t + LP_BR, cn);
                 if (s == 4 && METRIC == METRIC_L2) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) rn[g] = *(const f32x4*)(p.arena_rn + start + t + 8 * g + 4 * h);
@@ -700,9 +746,8 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
                     }
                 }
             }
-            // (the next block's stage() writes the slice: every read above was issued before it, LDS keeps a wave's order)
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < ND; ++i) cw[i] = cn[i];
         }
     }
     if (MODE == MODE_COLLECT && wcnt > 0) flush();
@@ -768,7 +813,8 @@ void launch_ivf_lmf_sweep(const IvfLmParams& p, int mode, int grid_blocks, hipSt
         FA_THROW_IF_NOT(p.xq16 && p.arena_h && p.ldh % 16 == 0 && p.ldh <= 128 && p.ldq16 >= p.ldh && p.ldq16 % 8 == 0);
         FA_THROW_IF_NOT(p.metric != METRIC_L2 || (p.arena_rn && p.xqn));
     } else {
-        FA_THROW_IF_NOT(p.pq16 && p.arena_codes && p.centroids && p.ldq % 4 == 0 && p.ldc % 4 == 0);
+        FA_THROW_IF_NOT(p.pq16 && p.arena_cs && p.cs_bpl > 0 && (p.cs_piece == 4 || p.cs_piece == 16) && p.centroids &&
+                        p.ldq % 4 == 0 && p.ldc % 4 == 0);
         FA_THROW_IF_NOT(lp_layout(p.d, p.M).total <= 160 * 1024 && (p.metric != METRIC_L2 || p.arena_rn));
     }
     if (p.metric == METRIC_L2) lmf_launch_mode<METRIC_L2>(p, mode, grid_blocks, stream);
@@ -928,23 +974,22 @@ void launch_ivf_lmf_pq_prepare(const IvfLmParams& p, float* xn_bound, hipStream_
 }
 
 // ------------------------------------------------------------------ rerank: exact distances of the candidates
-// One wavefront per query, eight lanes per candidate row.
+// One workgroup per query, eight lanes per candidate row (the first version ran a wavefront per query: ~19 rounds of
+// dependent loads each, 0.18 ms at nb = 1M and 10M alike -- latency, not bytes).
 // IVFFlat: the arithmetic of ivfflat_fused_kernel -- lane ln of the group owns the 16-byte chunks ln, ln + 8, ... of the row
 // and keeps one sequential fmaf chain of (q - y)^2 (inner product: q * y) over them; the eight partial sums meet in the
 // xor butterfly ((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7)).
 template <int METRIC>
 __global__ void __launch_bounds__(256) lmf_rerank_flat_kernel(IvfLmParams p) {
-    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (q >= p.nq) return;
-    const int lane = threadIdx.x & 63;
-    const int ln = lane & 7, grp = lane >> 3;
+    const int q = blockIdx.x;
+    const int ln = threadIdx.x & 7, grp = threadIdx.x >> 3; // 32 groups: 32 candidates per round, their loads in flight together
     const int np = p.nprobe;
     const int n = (int)min((int64_t)p.cnt[q], p.stride);
     const int nch = p.dpad >> 2;
     u64* kq = p.keys + (int64_t)q * p.stride;
     const uint16_t* cpr = p.cand_pr + (int64_t)q * p.stride;
     const float* qrow = p.xq + (int64_t)q * p.ldq;
-    for (int base = 0; base < n; base += 8) {
+    for (int base = 0; base < n; base += 32) {
         const int i = base + grp;
         const bool valid = i < n;
         float a = 0.f;
@@ -982,10 +1027,8 @@ __global__ void __launch_bounds__(256) lmf_rerank_flat_kernel(IvfLmParams p) {
 // order on one lane, like the oracle.
 template <int METRIC>
 __global__ void __launch_bounds__(256) lmf_rerank_pq_kernel(IvfLmParams p) {
-    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (q >= p.nq) return;
-    const int lane = threadIdx.x & 63;
-    const int ln = lane & 7, grp = lane >> 3;
+    const int q = blockIdx.x;
+    const int ln = threadIdx.x & 7, grp = threadIdx.x >> 3;
     const int np = p.nprobe, M = p.M, dsub = p.dsub;
     const int n = (int)min((int64_t)p.cnt[q], p.stride);
     u64* kq = p.keys + (int64_t)q * p.stride;
@@ -993,7 +1036,7 @@ __global__ void __launch_bounds__(256) lmf_rerank_pq_kernel(IvfLmParams p) {
     const float* x = p.xq + (int64_t)q * p.ldq;
     const float delta = p.pq_grid[2 * q], inv = p.pq_grid[2 * q + 1];
     const bool on = delta != 0.f;
-    for (int base = 0; base < n; base += 8) {
+    for (int base = 0; base < n; base += 32) {
         const int i = base + grp;
         const bool valid = i < n;
         float s = 0.f, dis0 = 0.f, t2 = 0.f;
@@ -1036,7 +1079,7 @@ __global__ void __launch_bounds__(256) lmf_rerank_pq_kernel(IvfLmParams p) {
 }
 void launch_ivf_lmf_rerank(const IvfLmParams& p, hipStream_t stream) {
     if (p.nq == 0) return;
-    const dim3 grid((unsigned)div_up(p.nq, 4)), block(256);
+    const dim3 grid((unsigned)p.nq), block(256);
     if (p.kind == 0) {
         if (p.metric == METRIC_L2) hipLaunchKernelGGL(lmf_rerank_flat_kernel<METRIC_L2>, grid, block, 0, stream, p);
         else hipLaunchKernelGGL(lmf_rerank_flat_kernel<METRIC_INNER_PRODUCT>, grid, block, 0, stream, p);

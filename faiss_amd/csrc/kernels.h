@@ -477,8 +477,18 @@ struct IvfLmParams {
     float* thr_f;               // [nq] collect threshold on the estimate (bound + 2 x error band; +/-inf = everything / nothing)
     const void* xq16;           // [nq][ldq16] fp16 queries, zero padded (kind 0)
     int64_t ldq16;
-    const void* arena_h;        // [arena rows][ldh] fp16 shadow of the IVFFlat rows, zero padded to a multiple of 16
-    int64_t ldh;
+    // fp16 shadow of the IVFFlat rows in OPERAND-MAJOR 32-row blocks (lists start on multiples of 32 rows): block b = arena
+    // rows 32 b .. 32 b + 31 holds ldh / 16 k-steps of 1 KB each, k-step s = the 16-byte pieces [lane h * 32 + j] = coordinates
+    // 16 s + 8 h .. + 7 of row j -- exactly what lane (h, j) feeds the MFMA, so every load instruction of a wavefront reads
+    // one contiguous KB (the row-major shadow of the first version moved 32-byte segments: 3.2 TB/s at best)
+    const void* arena_h;
+    int64_t ldh;                // fp16 coordinates per row, zero padded to a multiple of 16
+    // IVFPQ: the code bytes again, operand-major (kind 1): per 32-row block and lane (h, j) the cs_bpl bytes the lane's
+    // operands need -- byte b belongs to k-step b / ncode (ncode = max(1, 8 / dsub) codes per 8-coordinate operand), code
+    // (16 s + 8 h) / dsub + b % ncode of row j -- stored [piece][lane][cs_piece bytes] (cs_piece = 16 when 16 | cs_bpl, else 4):
+    // the sweeps load their codes straight into registers, no LDS staging, no un-rotation
+    const uint8_t* arena_cs;
+    int cs_bpl, cs_piece;
     const void* pq16;           // [M][256][dsub] fp16 codebook (kind 1)
     const uint32_t* qflags;     // [nq] nonzero: the query leaves the fp16 range / holds NaN -> not filtered (fallback)
     uint16_t* cand_pr;          // [nq][stride] probe number of every collected candidate (beside keys)
@@ -522,6 +532,10 @@ void launch_ivf_lmf_rerank(const IvfLmParams& p, hipStream_t stream);
 // (float bits by atomicMax; 0x7f800000 when a stored value is NaN / inf / beyond the fp16 range)
 void launch_ivf_lmf_shadow(const float* arena, int64_t ldv, const float* arena_rn, int d, int nlist, const uint32_t* list_len,
                            const int64_t* list_start, void* arena_h, int dh, unsigned* yn_max_bits, hipStream_t stream);
+// IVFPQ: operand-major copy of the codes of every list (see IvfLmParams::arena_cs); bytes per lane and block / piece size
+void ivf_lmf_code_shadow_shape(int d, int M, int* bpl, int* piece);
+void launch_ivf_lmf_code_shadow(const uint8_t* arena_codes, int d, int M, int nlist, const uint32_t* list_len,
+                                const int64_t* list_start, uint8_t* arena_cs, hipStream_t stream);
 // kind 0: M unused; kind 1: M = sub-quantizers; kind 2: M = SqCodeType
 bool ivf_lm_supported(int kind, int dpad, int M, int d);
 // prefix / p0 / cnt, the pairs grouped by (pass, list), the work items.  (4 launches + 1 memset)

@@ -352,7 +352,7 @@ def test_list_filter_error_bound_holds(res, kind, metric, d, M, scale):
     starts = np.concatenate([[0], np.cumsum(sizes)])[:-1]
     worst = 0.0
     for q in range(nq):
-        pos_ids = np.concatenate([ids[starts[l]:starts[l] + sizes[l]] for l in Iq[q] if l >= 0])
+        pos_ids = np.concatenate([ids[int(starts[l]):int(starts[l]) + int(sizes[l])] for l in Iq[q] if l >= 0])
         assert len(pos_ids) == rows[q] and not np.isnan(est[q, :rows[q]]).any() and np.isnan(est[q, rows[q]:]).all()
         exact = np.empty(rows[q], dtype=np.float64)
         order = {int(i): r for r, i in enumerate(Io[q, :rows[q]])}
