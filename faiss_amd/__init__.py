@@ -117,7 +117,7 @@ def load_library():
         "faiss_amd_GpuIndexIVF_scan_info": (i32, [vp, P(i32), P(i32), P(i64)]),
         "faiss_amd_GpuIndexIVF_last_scan_arith": (i32, [vp, P(i32)]),
         "faiss_amd_GpuIndexIVF_test_filter_dump": (i32, [vp, i64, vp, i32, i64, i64, vp, vp]),
-        "faiss_amd_GpuIndexIVF_set_lmf_tuning": (i32, [vp, i32, i32, i32]),
+        "faiss_amd_GpuIndexIVF_set_lmf_tuning": (i32, [vp, i32, i32, i32, i32]),
         "faiss_amd_GpuIndexIVF_list_major_rule": (i32, [vp, i64, i32, i64, P(i32)]),
         "faiss_amd_GpuIndexFlat_set_use_filter_kernel": (i32, [vp, i32, i64]),
         "faiss_amd_GpuIndexFlat_filter_stats": (i32, [vp, P(i32), P(i32)]),
@@ -579,9 +579,10 @@ class _GpuIndexIVF(Index):
         _check(self._lib.faiss_amd_GpuIndexIVF_last_scan_arith(self._h, ctypes.byref(v)))
         return v.value
 
-    def set_lmf_tuning(self, rows_per_item=0, gran_blocks=0, cand_cap=0):
+    def set_lmf_tuning(self, rows_per_item=0, gran_blocks=0, cand_cap=0, min_stride=0):
         """tuning experiments of the list-major scan behind the f16 filter (0 = the built-in rule); results never change"""
-        _check(self._lib.faiss_amd_GpuIndexIVF_set_lmf_tuning(self._h, int(rows_per_item), int(gran_blocks), int(cand_cap)))
+        _check(self._lib.faiss_amd_GpuIndexIVF_set_lmf_tuning(self._h, int(rows_per_item), int(gran_blocks), int(cand_cap),
+                                                              int(min_stride)))
 
     def filter_dump(self, x, k, stride, nprobe=None):
         """test hook: (estimates [n][stride] float32 with NaN where no row sits, band [n]) of the f16 filter sweeps -- the

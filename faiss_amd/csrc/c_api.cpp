@@ -919,13 +919,14 @@ int faiss_amd_GpuIndexIVF_scan_info(const FaissAmdIndex* index, int* mode, int* 
     if (overflow_queries) *overflow_queries = ix->list_major_overflows();
     FA_CATCH
 }
-int faiss_amd_GpuIndexIVF_set_lmf_tuning(FaissAmdIndex* index, int rows_per_item, int gran_blocks, int cand_cap) {
+int faiss_amd_GpuIndexIVF_set_lmf_tuning(FaissAmdIndex* index, int rows_per_item, int gran_blocks, int cand_cap, int min_stride) {
     FA_TRY
     auto* ix = as<GpuIndexIVF>(index, "GpuIndexIVF");
-    FA_THROW_IF_NOT_MSG(rows_per_item >= 0 && gran_blocks >= 0 && cand_cap >= 0, "negative tuning value");
+    FA_THROW_IF_NOT_MSG(rows_per_item >= 0 && gran_blocks >= 0 && cand_cap >= 0 && min_stride >= 0, "negative tuning value");
     ix->lmf_rows_per_item = rows_per_item;
     ix->lmf_gran_blocks = gran_blocks;
     ix->lmf_cand_cap = cand_cap;
+    ix->lmf_min_stride = min_stride;
     FA_CATCH
 }
 int faiss_amd_GpuIndexIVF_test_filter_dump(const FaissAmdIndex* index, int64_t n, const float* x, int nprobe, int64_t k, int64_t stride,

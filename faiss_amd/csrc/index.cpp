@@ -2331,13 +2331,17 @@ void GpuIndexIVF::search_listmajor_(int ni, const float* xq_pad, const idx_t* c_
         const int64_t avg_len = std::max<int64_t>(1, nstored_ / std::max(nlist, 1));
         int RT = (int)std::min<int64_t>(8192, std::max<int64_t>(kLmRowsPerItem, (int64_t)round_up((size_t)(avg_len / 4), 256)));
         int64_t stride = std::max<int64_t>(1024, 6 * (int64_t)k);
-        // granule: 32 G rows of a list hold two slots (16 G rows per lane half); ~ 8192 slots per query at most
+        // granule: 32 G rows of a list hold two slots (16 G rows per lane half).  ~ 2048 slots per query at most: every
+        // slot costs a scattered 4-byte store in sweep 1 and a read in the bound kernel, and S >> k slots already bound
+        // the k-th best estimate tightly (S ln(S / (S - k)) candidates).  Measured (profiles/r04_c_filter_tuning_sweep.txt):
+        // IVFFlat nb = 10M G = 1 / 2 / 4 / 8: 2.83 / 2.31 / 2.16 / 2.16 ms; nb = 1M G = 1 / 2 / 4: 1.00 / 1.04 / 1.19 ms
         const double rows_per_query = (double)np * (double)avg_len;
         int G = 1;
-        while (G < 8 && rows_per_query / (16.0 * G) > 8192.0) G *= 2;
+        while (G < 8 && rows_per_query / (16.0 * G) > 2048.0) G *= 2;
         if (lmf_rows_per_item > 0) RT = (int)round_up((size_t)lmf_rows_per_item, 256);
         if (lmf_gran_blocks > 0) G = lmf_gran_blocks;
         if (lmf_cand_cap > 0) stride = std::max<int64_t>(lmf_cand_cap, k);
+        const int min_stride = lmf_min_stride > 0 ? std::min(lmf_min_stride, 8) : 1;
         FA_THROW_IF_NOT_MSG(G >= 1 && G <= 8 && (G & (G - 1)) == 0 && RT <= 65280, "filter tuning: granule / rows per item");
         // granule slots a query can own: those of the np longest lists
         int64_t gstride = 0;
@@ -2355,7 +2359,7 @@ void GpuIndexIVF::search_listmajor_(int ni, const float* xq_pad, const idx_t* c_
         for (int c0 = 0; c0 < ni; c0 += (int)std::min<int64_t>(fit, ni)) {
             const int cn = (int)std::min<int64_t>(fit, ni - c0);
             search_listmajor_filter_chunk_(cn, c0, xq_pad + (size_t)c0 * dpad_, c_ids + (size_t)c0 * np, c_dis + (size_t)c0 * np, np,
-                                           k, dD + (size_t)c0 * k, dI + (size_t)c0 * k, stride, RT | (G << 16), gstride, *redo);
+                                           k, dD + (size_t)c0 * k, dI + (size_t)c0 * k, stride, RT | (G << 16), gstride, min_stride, *redo);
         }
         return;
     }
@@ -2549,7 +2553,7 @@ void GpuIndexIVF::search_listmajor_chunk_(int ni, const float* xq_pad, const idx
 // rerank of the candidates -> k-selection.  rt_g = rows per item | granule blocks << 16.
 void GpuIndexIVF::search_listmajor_filter_chunk_(int ni, int q0, const float* xq_pad, const idx_t* c_ids, const float* c_dis, int np,
                                                  int k, float* dD, idx_t* dI, int64_t stride, int rt_g, int64_t gstride,
-                                                 std::vector<uint32_t>& redo) const {
+                                                 int min_stride, std::vector<uint32_t>& redo) const {
     const GpuResources& R = *res_;
     const int RT = rt_g & 0xffff, G = rt_g >> 16;
     int64_t sum_nrt = 0, nrt_max = 1;
@@ -2616,6 +2620,7 @@ void GpuIndexIVF::search_listmajor_filter_chunk_(int ni, int q0, const float* xq
     P.qpi = qpi;
     P.filter = 1;
     P.gran_blocks = G;
+    P.min_stride = min_stride;
     P.gmin = lm_gmin_.as<uint32_t>();
     P.gstride = gstride;
     P.thr_f = lm_thrf_.as<float>();
@@ -2636,8 +2641,6 @@ void GpuIndexIVF::search_listmajor_filter_chunk_(int ni, int q0, const float* xq
         P.xqn = lm_qn_.as<float>();
         P.xn_full = lm_qn_.as<float>();
         if (P.kind == 1) {
-            lm_pqgrid_.ensure((size_t)ni * 8);
-            P.pq_grid = lm_pqgrid_.as<float>();
             launch_ivf_lmf_pq_prepare(P, lm_xnb_.as<float>(), R.stream);
         }
         // granule slots nobody writes must never look like good estimates
@@ -2783,6 +2786,7 @@ void GpuIndexIVF::test_filter_dump(idx_t n, const float* x, int nprobe_now, idx_
     P.qpi = qpi;
     P.filter = 1;
     P.gran_blocks = G;
+    P.min_stride = 1;
     P.gmin = gmin.as<uint32_t>();
     P.gstride = gstride;
     P.thr_f = thrf.as<float>();
@@ -2799,8 +2803,6 @@ void GpuIndexIVF::test_filter_dump(idx_t n, const float* x, int nprobe_now, idx_
     P.xqn = qn.as<float>();
     P.xn_full = qn.as<float>();
     if (P.kind == 1) {
-        grid.ensure((size_t)ni * 8);
-        P.pq_grid = grid.as<float>();
         launch_ivf_lmf_pq_prepare(P, xnb.as<float>(), R.stream);
     }
     launch_ivf_lm_plan(P, R.stream);

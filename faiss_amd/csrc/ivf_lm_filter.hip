@@ -180,8 +180,7 @@ void launch_ivf_lmf_code_shadow(const uint8_t* arena_codes, int d, int M, int nl
 // acc: the 16 inner products of this lane's query of block b with rows 8 g + 4 h + e of the 32-row block at list row t.
 struct LmfLane { // per (lane, query block)
     bool qv;
-    int q;
-    uint32_t base_pos, qpr;
+    uint32_t base_pos, qpr; // qpr = query << 11 | probe
     float xn, thr, gm;
     uint32_t* gq; // MODE_MIN: gmin + q * gstride + granule-slot base of this (query, probe) + h
     u64* kq;      // MODE_DUMP: keys + q * stride + base_pos
@@ -250,7 +249,6 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
             const uint32_t pi = p.pairs[pb + (uint32_t)(qt * (32 * NQB)) + (uint32_t)(L[b].qv ? my : 0)];
             const int q = (int)(pi / (uint32_t)np);
             const int pr = (int)(pi - (uint32_t)q * (uint32_t)np);
-            L[b].q = q;
             const _Float16* qrow = xq16 + (int64_t)q * p.ldq16 + 8 * h;
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
@@ -265,7 +263,7 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
             L[b].gq = nullptr;
             L[b].kq = nullptr;
             if (MODE == MODE_MIN) L[b].gq = p.gmin + (int64_t)q * p.gstride + p.prefixg[(int64_t)q * (np + 1) + pr] + h;
-            if (MODE == MODE_COLLECT) L[b].thr = p.thr_f[q];
+            if (MODE == MODE_COLLECT) L[b].thr = L[b].qv ? p.thr_f[q] : (METRIC == METRIC_L2 ? -INFINITY : INFINITY);
             if (MODE == MODE_DUMP) L[b].kq = p.keys + (int64_t)q * p.stride + L[b].base_pos;
         }
 
@@ -285,9 +283,12 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
             }
             const float* rnp = p.arena_rn + start + t + 4 * h; // |y|^2 of rows 8 g + 4 h + e of the block: rnp[8 g + e]
             bool full = false;
-            for (; t < r1; t += 32) {
-                arow += nks * 512;
-                rnp += 32;
+            // sweep 1 may look at every min_stride-th block only (a SAMPLE of the rows still bounds the k-th best estimate
+            // from above; fewer rows -> a looser bound -> more candidates in sweep 2)
+            const int bstep = MODE == MODE_MIN ? 32 * p.min_stride : 32;
+            for (; t < r1; t += bstep) {
+                arow += (bstep >> 5) * nks * 512;
+                rnp += bstep;
                 f32x16 acc[NQB];
 #pragma unroll
                 for (int b = 0; b < NQB; ++b)
@@ -307,7 +308,7 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
                     }
                     if (s == 3 && METRIC == METRIC_L2) {
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) rn[g] = *(const f32x4*)(rnp - 32 + 8 * g);
+                        for (int g = 0; g < 4; ++g) rn[g] = *(const f32x4*)(rnp - bstep + 8 * g);
                     }
                 }
                 if (FULL) {
@@ -345,7 +346,8 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
                         L[b].gm = m;
                     }
                     const int blk = t >> 5;
-                    if (((blk + 1) & (G - 1)) == 0 || t + 32 >= r1) { // (wave-uniform) the granule ends with this block
+                    // (wave-uniform) the granule ends with this block: the next block looked at lies in another one
+                    if ((((t + bstep) >> 5) >> gsh) != (blk >> gsh) || t + bstep >= r1) {
 #pragma unroll
                         for (int b = 0; b < NQB; ++b) {
                             if (L[b].qv) lmf_store_u32(L[b].gq + 2 * (blk >> gsh), ordkey<METRIC>(L[b].gm));
@@ -378,7 +380,7 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
                                                   !(tail && row_b + 8 * g + e >= r1);
                                 mask |= pass ? 1u << (4 * g + e) : 0u;
                             }
-                        if (!L[b].qv || b < skip_b) mask = 0;
+                        if (b < skip_b) mask = 0;
                         if (__ballot(mask != 0u)) {
                             // (wave-uniform branch) park the candidates: this lane's go behind those of the lanes before it
                             const int c = __popc(mask);
@@ -542,7 +544,6 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
             const uint32_t pi = p.pairs[pb + (uint32_t)(qt * (32 * NQB)) + (uint32_t)(L[b].qv ? my : 0)];
             const int q = (int)(pi / (uint32_t)np);
             const int pr = (int)(pi - (uint32_t)q * (uint32_t)np);
-            L[b].q = q;
             const float* qrow = p.xq + (int64_t)q * p.ldq + 8 * h;
             float accn = 0.f;
 #pragma unroll
@@ -575,12 +576,13 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
             L[b].gq = nullptr;
             L[b].kq = nullptr;
             if (MODE == MODE_MIN) L[b].gq = p.gmin + (int64_t)q * p.gstride + p.prefixg[(int64_t)q * (np + 1) + pr] + h;
-            if (MODE == MODE_COLLECT) L[b].thr = p.thr_f[q];
+            if (MODE == MODE_COLLECT) L[b].thr = L[b].qv ? p.thr_f[q] : (METRIC == METRIC_L2 ? -INFINITY : INFINITY);
             if (MODE == MODE_DUMP) L[b].kq = p.keys + (int64_t)q * p.stride + L[b].base_pos;
         }
 
-        for (int t = r0; t < r1; t += LP_BR) {
-            const bool more = t + LP_BR < r1;
+        const int bstep = MODE == MODE_MIN ? LP_BR * p.min_stride : LP_BR; // (sweep 1 may sample the blocks, see the flat kernel)
+        for (int t = r0; t < r1; t += bstep) {
+            const bool more = t + bstep < r1;
             // the A operand of k-step s: coordinates 16 s + 8 h .. + 7 of this lane's row, gathered from the codebook by
             // the code bytes in cw
             auto operand_of = [&](int s_) __attribute__((always_inline)) -> half8 {
@@ -623,13 +625,15 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
             f32x4 rn[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) rn[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-            // software pipeline: gathers of k-step s + 1 | MFMAs of k-step s
-            half8 av[2];
+            // software pipeline: gathers of k-step s + 2 | MFMAs of k-step s (one k-step ahead the gathers of a step had only
+            // the 3 MFMAs of the step before -- ~100 cycles -- to come back from an LDS all eight wavefronts gather from)
+            half8 av[3];
             av[0] = operand_of(0);
+            av[1] = operand_of(1);
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
-                if (s + 1 < 8) av[(s + 1) & 1] = operand_of(s + 1);
-                if (s == 1 && more) fetch(t + LP_BR, cn);
+                if (s + 2 < 8) av[(s + 2) % 3] = operand_of(s + 2);
+                if (s == 1 && more) fetch(t + bstep, cn);
                 if (s == 4 && METRIC == METRIC_L2) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) rn[g] = *(const f32x4*)(p.arena_rn + start + t + 8 * g + 4 * h);
@@ -638,7 +642,7 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
                 if (s < nks) {
 #pragma unroll
                     for (int b = 0; b < NQB; ++b)
-                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s & 1], bq[b][s], acc[b], 0, 0, 0);
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s % 3], bq[b][s], acc[b], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -661,7 +665,7 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
                     L[b].gm = m;
                 }
                 const int blk = t >> 5;
-                if (((blk + 1) & (G - 1)) == 0 || t + 32 >= r1) {
+                if ((((t + bstep) >> 5) >> gsh) != (blk >> gsh) || t + bstep >= r1) {
 #pragma unroll
                     for (int b = 0; b < NQB; ++b) {
                         if (L[b].qv) L[b].gq[2 * (blk >> gsh)] = ordkey<METRIC>(L[b].gm);
@@ -682,6 +686,8 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
             } else {
 #pragma unroll
                 for (int b = 0; b < NQB; ++b) {
+                    // (one query block after the other: left alone hipcc interleaves the three epilogues and spills)
+                    __builtin_amdgcn_sched_barrier(0);
                     unsigned mask = 0;
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
@@ -692,55 +698,32 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
                                               !(tail && row_b + 8 * g + e >= r1);
                             mask |= pass ? 1u << (4 * g + e) : 0u;
                         }
-                    if (!L[b].qv) mask = 0;
                     if (__ballot(mask != 0u)) {
-                        const int c = __popc(mask);
-                        int inc = c;
+                        // (wave-uniform branch) park the candidates row group by row group (8 g + 4 h + e, g = 0 .. 3): a
+                        // group holds at most 4 x 64 = LP_PARK candidates, so it always fits an empty slice
 #pragma unroll
-                        for (int off = 1; off < 64; off <<= 1) {
-                            const int o = __shfl_up(inc, off, 64);
-                            if (lane >= off) inc += o;
-                        }
-                        const int total = __builtin_amdgcn_readlane(inc, 63);
-                        if (total > LP_PARK) {
-                            // more candidates in one (32-row, 32-query) block than a slice holds (a threshold that admits
-                            // everything): straight to the segment, one atomic per lane
-                            if (mask) {
-                                uint32_t slot;
-                                uint32_t* cp = p.cnt + L[b].q;
-                                const uint32_t nc = (uint32_t)c;
-                                asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)"
-                                             : "=&v"(slot)
-                                             : "v"(cp), "v"(nc)
-                                             : "memory");
+                        for (int g = 0; g < 4; ++g) {
+                            const unsigned mg = (mask >> (4 * g)) & 15u;
+                            if (!__ballot(mg != 0u)) continue;
+                            const int c = __popc(mg);
+                            int inc = c;
 #pragma unroll
-                                for (int g = 0; g < 4; ++g)
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) {
-                                        if (mask & (1u << (4 * g + e))) {
-                                            const uint32_t pos = L[b].base_pos + (uint32_t)(row_b + 8 * g + e);
-                                            if ((int64_t)slot < p.stride) {
-                                                p.keys[(int64_t)L[b].q * p.stride + slot] = ((u64)ordkey<METRIC>(est(b, g, e)) << 32) | pos;
-                                                p.cand_pr[(int64_t)L[b].q * p.stride + slot] = (uint16_t)(L[b].qpr & 2047u);
-                                            }
-                                            ++slot;
-                                        }
-                                    }
+                            for (int off = 1; off < 64; off <<= 1) {
+                                const int o = __shfl_up(inc, off, 64);
+                                if (lane >= off) inc += o;
                             }
-                        } else {
+                            const int total = __builtin_amdgcn_readlane(inc, 63);
                             if (wcnt + total > LP_PARK) flush();
                             int at = wcnt + inc - c;
 #pragma unroll
-                            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    if (mask & (1u << (4 * g + e))) {
-                                        const uint32_t pos = L[b].base_pos + (uint32_t)(row_b + 8 * g + e);
-                                        pk_keys[at] = ((u64)ordkey<METRIC>(est(b, g, e)) << 32) | pos;
-                                        pk_q[at] = L[b].qpr;
-                                        ++at;
-                                    }
+                            for (int e = 0; e < 4; ++e) {
+                                if (mg & (1u << e)) {
+                                    const uint32_t pos = L[b].base_pos + (uint32_t)(row_b + 8 * g + e);
+                                    pk_keys[at] = ((u64)ordkey<METRIC>(est(b, g, e)) << 32) | pos;
+                                    pk_q[at] = L[b].qpr;
+                                    ++at;
                                 }
+                            }
                             wcnt += total;
                         }
                     }
@@ -807,6 +790,7 @@ static void lmf_launch_mode(const IvfLmParams& p, int mode, int grid_blocks, hip
 void launch_ivf_lmf_sweep(const IvfLmParams& p, int mode, int grid_blocks, hipStream_t stream) {
     if (p.nq == 0) return;
     FA_THROW_IF_NOT(p.filter && ivf_lmf_supported(p.kind, p.d, p.dpad, p.M) && mode >= 1 && mode <= 3 && grid_blocks > 0);
+    FA_THROW_IF_NOT(p.min_stride >= 1 && p.min_stride <= 8);
     FA_THROW_IF_NOT(p.qpi == 32 * kLmfQueryBlocks && p.nq < (1 << 21) && p.nprobe <= 2048 && p.gran_blocks >= 1 &&
                     (p.gran_blocks & (p.gran_blocks - 1)) == 0);
     if (p.kind == 0) {
@@ -919,57 +903,35 @@ void launch_ivf_lmf_bound(const IvfLmParams& p, const float* xn_bound, hipStream
 }
 
 // ------------------------------------------------------------------ IVFPQ: per-query preparation
-// xn_bound[q] = max over the probes of |q - c|^2 (L2; inner product: |q|^2) for the error band; pq_grid[q] = the query's
-// table grid, exactly as the query-major scan builds it (ivf_fused.hip / oracle orc_ivf_search_ex arith 0): entries
-// <q_m, cb[m][c]> as sequential fmaf chains from 0, B = sum_m max_c |entry| in sub-quantizer order, pq_lut_grid(B).
+// xn_bound[q] = max over the probes of |q - c|^2 (L2; inner product: |q|^2): the |q'|^2 of the error band.  One wavefront per
+// query (any summation order: it only feeds the band; 1.0001 x covers the difference to the sweeps' own chains).
 __global__ void __launch_bounds__(256) lmf_pq_prepare_kernel(IvfLmParams p, float* __restrict__ xn_bound) {
-    __shared__ uint32_t colmax[256]; // (M <= 128)
-    __shared__ float red[4];
-    const int q = blockIdx.x;
-    const int tid = threadIdx.x;
-    const int M = p.M, dsub = p.dsub, np = p.nprobe;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= p.nq) return;
+    const int lane = threadIdx.x & 63;
+    const int np = p.nprobe;
     const float* x = p.xq + (int64_t)q * p.ldq;
-    for (int m = tid; m < M; m += 256) colmax[m] = 0u;
-    __syncthreads();
-    for (int e = tid; e < M * 256; e += 256) {
-        const int m = e >> 8;
-        const float* cen = p.pq_centroids + (size_t)e * dsub;
-        float acc = 0.f;
-        for (int jd = 0; jd < dsub; ++jd) acc = __fmaf_rn(x[m * dsub + jd], cen[jd], acc);
-        const float a = fabsf(acc);
-        atomicMax(&colmax[m], __float_as_uint(a)); // NaN (0x7fc00000) beats every number, like the oracle's bit-pattern max
-    }
-    // max over the probes of |q - c|^2 (any order: it only feeds the error band)
     float mx = 0.f;
-    for (int pr = tid >> 6; pr < np; pr += 4) {
+    for (int pr = 0; pr < np; ++pr) {
         const int64_t l = p.coarse_ids[(int64_t)q * np + pr];
         if (l < 0) continue;
         const float* c = p.centroids + l * p.ldc;
         float acc = 0.f;
-        for (int k = tid & 63; k < p.d; k += 64) {
+        for (int k = lane; k < p.d; k += 64) {
             const float v = p.metric == METRIC_L2 ? x[k] - c[k] : x[k];
             acc = __fmaf_rn(v, v, acc);
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
         mx = fmaxf(mx, acc);
+        if (p.metric != METRIC_L2) break; // (|q|^2 does not depend on the probe)
     }
-    if ((tid & 63) == 0) red[tid >> 6] = mx;
-    __syncthreads();
-    if (tid == 0) {
-        float B = 0.f;
-        for (int m = 0; m < M; ++m) B = B + __uint_as_float(colmax[m]);
-        float delta = 0.f, inv = 0.f;
-        const bool on = pq_lut_grid(B, &delta, &inv);
-        p.pq_grid[2 * q] = on ? delta : 0.f;
-        p.pq_grid[2 * q + 1] = on ? inv : 0.f;
-        xn_bound[q] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * 1.0001f;
-    }
+    if (lane == 0) xn_bound[q] = mx * 1.0001f;
 }
 void launch_ivf_lmf_pq_prepare(const IvfLmParams& p, float* xn_bound, hipStream_t stream) {
     if (p.nq == 0) return;
-    FA_THROW_IF_NOT(p.kind == 1 && p.M <= 256 && p.pq_grid && p.pq_centroids);
-    hipLaunchKernelGGL(lmf_pq_prepare_kernel, dim3((unsigned)p.nq), dim3(256), 0, stream, p, xn_bound);
+    FA_THROW_IF_NOT(p.kind == 1 && p.centroids);
+    hipLaunchKernelGGL(lmf_pq_prepare_kernel, dim3((unsigned)div_up(p.nq, 4)), dim3(256), 0, stream, p, xn_bound);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -1020,22 +982,59 @@ __global__ void __launch_bounds__(256) lmf_rerank_flat_kernel(IvfLmParams p) {
         if (valid && ln == 0) kq[i] = ((u64)ordkey<METRIC>(a) << 32) | (u64)pos;
     }
 }
-// IVFPQ: the arithmetic of ivfpq_fused_kernel -- S = sum_m round_to_grid(<q_m, cb[m][code_m]>) (every partial sum exact in
-// fp32, so any order gives these bits; here sub-quantizer order), L2: fmaf(-2, S, coarse + t2[row]), inner product:
-// coarse + S.  Lane ln of a group takes the sub-quantizers ln, ln + 8, ...; the partial sums are exact multiples of the
-// grid, their butterfly sum is exact too.  Without a grid (NaN / inf / all-zero tables) the sum runs in sub-quantizer
-// order on one lane, like the oracle.
+// IVFPQ: the arithmetic of ivfpq_fused_kernel.  The workgroup first builds the query's table exactly as the query-major
+// scan does (oracle orc_ivf_search_ex arith 0): entries <q_m, cb[m][c]> as sequential fmaf chains from 0, B = sum_m max_c
+// |entry| in sub-quantizer order, the power-of-two grid pq_lut_grid(B), every entry rounded to it -- M x 256 floats in LDS
+// (the first version recomputed the entries per candidate from the L2-resident codebook: 0.7 ms at nb = 10M / 100M).  Then
+// S = sum_m table[m][code_m] (every partial sum exact in fp32, so any order gives these bits; lane ln of a candidate's
+// group takes the sub-quantizers ln, ln + 8, ..., the partial sums meet in a butterfly), L2: fmaf(-2, S, coarse + t2[row]),
+// inner product: coarse + S.  Without a grid (NaN / inf / all-zero tables) the sum runs in sub-quantizer order on one
+// lane, like the oracle.
 template <int METRIC>
 __global__ void __launch_bounds__(256) lmf_rerank_pq_kernel(IvfLmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int q = blockIdx.x;
-    const int ln = threadIdx.x & 7, grp = threadIdx.x >> 3;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int ln = tid & 7, grp = tid >> 3;
     const int np = p.nprobe, M = p.M, dsub = p.dsub;
     const int n = (int)min((int64_t)p.cnt[q], p.stride);
+    if (n == 0) return; // (workgroup-uniform)
+    float* lut = (float*)smem;                      // [M][256]
+    uint32_t* colmax = (uint32_t*)(lut + M * 256);  // [M]
+    float* grid = (float*)(colmax + M);             // delta, 1 / delta, on
     u64* kq = p.keys + (int64_t)q * p.stride;
     const uint16_t* cpr = p.cand_pr + (int64_t)q * p.stride;
     const float* x = p.xq + (int64_t)q * p.ldq;
-    const float delta = p.pq_grid[2 * q], inv = p.pq_grid[2 * q + 1];
-    const bool on = delta != 0.f;
+    for (int m = tid; m < M; m += 256) colmax[m] = 0u;
+    __syncthreads();
+    for (int m = 0; m < M; ++m) {
+        const float* cen = p.pq_centroids + ((size_t)m * 256 + tid) * dsub;
+        float acc = 0.f;
+        for (int jd = 0; jd < dsub; ++jd) acc = __fmaf_rn(x[m * dsub + jd], cen[jd], acc);
+        lut[m * 256 + tid] = acc;
+        uint32_t u = __float_as_uint(fabsf(acc)); // (bit patterns: NaN beats every number, like the oracle's maximum)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) u = max(u, (uint32_t)__shfl_xor((int)u, off, 64));
+        if (lane == 0) atomicMax(&colmax[m], u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float B = 0.f;
+        for (int m = 0; m < M; ++m) B = B + __uint_as_float(colmax[m]);
+        float delta = 0.f, inv = 0.f;
+        const bool on = pq_lut_grid(B, &delta, &inv);
+        grid[0] = delta;
+        grid[1] = inv;
+        grid[2] = on ? 1.f : 0.f;
+    }
+    __syncthreads();
+    const bool on = grid[2] != 0.f;
+    if (on) {
+        const float delta = grid[0], inv = grid[1];
+        for (int e = tid; e < M * 256; e += 256) lut[e] = __builtin_rintf(lut[e] * inv) * delta;
+    }
+    __syncthreads();
     for (int base = 0; base < n; base += 32) {
         const int i = base + grp;
         const bool valid = i < n;
@@ -1049,21 +1048,9 @@ __global__ void __launch_bounds__(256) lmf_rerank_pq_kernel(IvfLmParams p) {
             dis0 = p.coarse_dis[(int64_t)q * np + pr];
             if (METRIC == METRIC_L2) t2 = p.arena_t2[row];
             if (on) {
-                for (int m = ln; m < M; m += 8) {
-                    const unsigned code = p.arena_codes[pq_code_offset(M, row, m)];
-                    const float* cen = p.pq_centroids + ((size_t)m * 256 + code) * dsub;
-                    float acc = 0.f;
-                    for (int jd = 0; jd < dsub; ++jd) acc = __fmaf_rn(x[m * dsub + jd], cen[jd], acc);
-                    s = s + __builtin_rintf(acc * inv) * delta;
-                }
+                for (int m = ln; m < M; m += 8) s = s + lut[m * 256 + (int)p.arena_codes[pq_code_offset(M, row, m)]];
             } else if (ln == 0) {
-                for (int m = 0; m < M; ++m) {
-                    const unsigned code = p.arena_codes[pq_code_offset(M, row, m)];
-                    const float* cen = p.pq_centroids + ((size_t)m * 256 + code) * dsub;
-                    float acc = 0.f;
-                    for (int jd = 0; jd < dsub; ++jd) acc = __fmaf_rn(x[m * dsub + jd], cen[jd], acc);
-                    s = s + acc;
-                }
+                for (int m = 0; m < M; ++m) s = s + lut[m * 256 + (int)p.arena_codes[pq_code_offset(M, row, m)]];
             }
         }
         if (on) {
@@ -1084,9 +1071,17 @@ void launch_ivf_lmf_rerank(const IvfLmParams& p, hipStream_t stream) {
         if (p.metric == METRIC_L2) hipLaunchKernelGGL(lmf_rerank_flat_kernel<METRIC_L2>, grid, block, 0, stream, p);
         else hipLaunchKernelGGL(lmf_rerank_flat_kernel<METRIC_INNER_PRODUCT>, grid, block, 0, stream, p);
     } else {
-        FA_THROW_IF_NOT(p.pq_grid && (p.metric != METRIC_L2 || p.arena_t2));
-        if (p.metric == METRIC_L2) hipLaunchKernelGGL(lmf_rerank_pq_kernel<METRIC_L2>, grid, block, 0, stream, p);
-        else hipLaunchKernelGGL(lmf_rerank_pq_kernel<METRIC_INNER_PRODUCT>, grid, block, 0, stream, p);
+        FA_THROW_IF_NOT(p.metric != METRIC_L2 || p.arena_t2);
+        const int lds = p.M * 1024 + p.M * 4 + 16;
+        FA_THROW_IF_NOT(lds <= 160 * 1024);
+        if (p.metric == METRIC_L2) {
+            HIP_CHECK(hipFuncSetAttribute((const void*)lmf_rerank_pq_kernel<METRIC_L2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            hipLaunchKernelGGL(lmf_rerank_pq_kernel<METRIC_L2>, grid, block, lds, stream, p);
+        } else {
+            HIP_CHECK(hipFuncSetAttribute((const void*)lmf_rerank_pq_kernel<METRIC_INNER_PRODUCT>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            hipLaunchKernelGGL(lmf_rerank_pq_kernel<METRIC_INNER_PRODUCT>, grid, block, lds, stream, p);
+        }
     }
     HIP_CHECK(hipGetLastError());
 }

@@ -471,6 +471,7 @@ struct IvfLmParams {
     // exact arithmetic of the query-major scan on the few survivors (launch_ivf_lmf_rerank).
     int filter;
     int gran_blocks;            // G: 32-row blocks per granule; a granule of a list = 32 G rows = two slots (lane halves)
+    int min_stride;             // sweep 1 looks at every min_stride-th 32-row block of a row chunk (1 = all rows)
     uint32_t* prefixg;          // [nq][nprobe + 1] exclusive prefix of 2 * ceil(len / (32 G)): granule slots of the probes
     uint32_t* gmin;             // [nq][gstride] ordkey of the best estimate in every granule slot
     int64_t gstride;
@@ -496,7 +497,6 @@ struct IvfLmParams {
     const float* xn_full;       // [nq] |q|^2 (kind 0: == xqn)
     float yn_max;               // max |y|^2 over the stored rows (kind 0) / upper bound of |r^|^2 from the codebook (kind 1)
     float cn_max;               // kind 1: max |centroid|^2
-    float* pq_grid;             // kind 1: [nq][2] delta, 1 / delta of the query's table grid (pq_lut_grid; 0, 0 = no rounding)
     float* band_out;            // optional [nq]: the error band E_q the bound kernel used (tests)
 };
 // |estimate - exact| <= this for every stored row, whatever the data: `estimate` = what the f16 MFMA sweeps of
@@ -524,7 +524,7 @@ void launch_ivf_lmf_sweep(const IvfLmParams& p, int mode, int grid_blocks, hipSt
 // thr_f[q] from gmin (k-th best granule estimate + 2 x ivf_filter_err_bound); queries with qflags set get "nothing" and are
 // appended to ovf (zeroed here).  xn_bound: [nq] upper bound of |q'|^2 over the query's probes (kind 0: |q|^2).
 void launch_ivf_lmf_bound(const IvfLmParams& p, const float* xn_bound, hipStream_t stream);
-// kind 1: xn_bound[q] = max over the probes of |q - c|^2 (sequential chains), pq_grid[q] = the query's table grid
+// kind 1: xn_bound[q] = max over the probes of |q - c|^2
 void launch_ivf_lmf_pq_prepare(const IvfLmParams& p, float* xn_bound, hipStream_t stream);
 // keys[q][0 .. cnt[q]) <- the exact distance of the query-major scan (ivf_fused.hip) for the same row, bit for bit
 void launch_ivf_lmf_rerank(const IvfLmParams& p, hipStream_t stream);

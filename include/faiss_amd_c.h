@@ -440,8 +440,9 @@ int faiss_amd_GpuIndexIVF_set_scan_mode(FaissAmdIndex* index, int mode);
 int faiss_amd_GpuIndexIVF_scan_info(const FaissAmdIndex* index, int* mode, int* last_mode, int64_t* overflow_queries);
 int faiss_amd_GpuIndexIVF_last_scan_arith(const FaissAmdIndex* index, int* p_arith);
 /* Tuning experiments of the filter path (tools/lmf_sweep.py; results never change, only timings): rows of a list per
- * work item, 32-row blocks per granule (1, 2, 4, 8), candidate room per query.  0 = the built-in rule. */
-int faiss_amd_GpuIndexIVF_set_lmf_tuning(FaissAmdIndex* index, int rows_per_item, int gran_blocks, int cand_cap);
+ * work item, 32-row blocks per granule (1, 2, 4, 8), candidate room per query, and the block sampling stride of the
+ * first sweep (it may bound the k-th best estimate from every min_stride-th 32-row block).  0 = the built-in rule. */
+int faiss_amd_GpuIndexIVF_set_lmf_tuning(FaissAmdIndex* index, int rows_per_item, int gran_blocks, int cand_cap, int min_stride);
 /* Test hook of the f16 filter (no reference counterpart): for n host queries, the ESTIMATED distance of every row they
  * probe as a key (ordkey(estimate) << 32 | scan position) at keys_out[q * stride + scan position] (slots nobody owns
  * hold ~0), and band_out[q] = the error band the filter grants query q (|estimate - exact| <= band is what makes the

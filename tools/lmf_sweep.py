@@ -77,19 +77,16 @@ def main():
                 ok = np.array_equal(ref[0], Dd.cpu().numpy()) and np.array_equal(ref[1], Id.cpu().numpy())
                 print("    filter == query-major on all queries: %s" % ok, flush=True)
         base = (Dd.cpu().numpy().copy(), Id.cpu().numpy().copy())
-        avg = nb // NLIST
-        rts = sorted({1024, 2048, 4096} if avg < 8192 else {2048, 4096, 8192})
-        for rt in rts:
-            for g in (1, 2, 4, 8):
-                for cap in (1024, 2048):
-                    if g > 1 and cap != 1024:
-                        continue
-                    idx.set_lmf_tuning(rt, g, cap)
-                    ms, sp = timed(idx, res, xq_dev, Dd, Id, steps=3)
-                    same = np.array_equal(base[0], Dd.cpu().numpy()) and np.array_equal(base[1], Id.cpu().numpy())
-                    print("rt %5d g %d cap %5d: %8.3f ms redo %6d same %s  min %.3f bound %.3f collect %.3f rerank %.3f select %.3f"
-                          % (rt, g, cap, ms, idx.scan_info()[2], same, sp.get("ivf_lmf_sweep_min", 0), sp.get("ivf_lmf_bound", 0),
-                             sp.get("ivf_lmf_sweep_collect", 0), sp.get("ivf_lmf_rerank", 0), sp.get("select_k_kernel", 0)), flush=True)
+        gs = (1, 2) if nb <= 1000000 else (2, 4, 8) if nb <= 10000000 else (4, 8)
+        for g in gs:
+            for ms, cap in ((1, 1024), (2, 1024), (2, 2048), (4, 2048), (4, 4096)):
+                idx.set_lmf_tuning(0, g, cap, ms)
+                ms_t, sp = timed(idx, res, xq_dev, Dd, Id, steps=3)
+                same = np.array_equal(base[0], Dd.cpu().numpy()) and np.array_equal(base[1], Id.cpu().numpy())
+                print("g %d min_stride %d cap %5d: %8.3f ms redo %6d same %s  prep %.3f plan %.3f min %.3f bound %.3f collect %.3f rerank %.3f select %.3f"
+                      % (g, ms, cap, ms_t, idx.scan_info()[2], same, sp.get("ivf_lmf_prepare", 0), sp.get("ivf_lm_plan", 0),
+                         sp.get("ivf_lmf_sweep_min", 0), sp.get("ivf_lmf_bound", 0), sp.get("ivf_lmf_sweep_collect", 0),
+                         sp.get("ivf_lmf_rerank", 0), sp.get("select_k_kernel", 0)), flush=True)
         del idx
 
 
