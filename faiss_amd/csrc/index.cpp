@@ -2005,7 +2005,9 @@ void GpuIndexIVF::search_core_(idx_t n, const float* x, idx_t k, float* distance
     if (scan_mode >= 2) {
         FA_THROW_IF_NOT_MSG(lm_capable_(), "list-major scan: index type / dimension not supported (IVFFlat, IVFPQ, scalar "
                             "quantizer; d <= 128)");
-        FA_THROW_IF_NOT_MSG(!sel, "list-major scan: IDSelector searches take the query-major scan");
+        // (the filter sweeps test the selector's row bits themselves; the f32 scans do not)
+        FA_THROW_IF_NOT_MSG(!sel || (scan_mode == 2 && lmf_capable_()),
+                            "list-major scan: IDSelector searches take the query-major scan (or the filter path of IVFFlat / IVFPQ)");
         cur_lm_ = true;
     } else {
         cur_lm_ = scan_mode == 0 && list_major_rule(n, nprobe_now, k, sel != nullptr);
@@ -2299,7 +2301,7 @@ static const char* experiment_env(const char* name) {
 
 // ---------------------------------------------------------------------- list-major search (ivf_listmajor.hip)
 bool GpuIndexIVF::list_major_rule(idx_t n, int nprobe_now, idx_t k, bool has_selector) const {
-    if (has_selector || !lm_capable_()) return false;
+    if (!lm_capable_() || (has_selector && !lmf_capable_())) return false;
     // IVFPQ: 64 bytes per row make the query-major scan cheap per query (its cost: rows x queries of a list, HBM-bound);
     // the list-major kernel (codebook in LDS) costs rows x 32-query blocks of matrix work plus the fixed plan / bound /
     // select launches.  Measured at nlist 4096, nprobe 32 (profiles/r03_b_*), list-major vs query-major, ms: nb = 1M 1.38 vs
@@ -2341,7 +2343,9 @@ void GpuIndexIVF::search_listmajor_(int ni, const float* xq_pad, const idx_t* c_
         if (lmf_rows_per_item > 0) RT = (int)round_up((size_t)lmf_rows_per_item, 256);
         if (lmf_gran_blocks > 0) G = lmf_gran_blocks;
         if (lmf_cand_cap > 0) stride = std::max<int64_t>(lmf_cand_cap, k);
-        const int min_stride = lmf_min_stride > 0 ? std::min(lmf_min_stride, 8) : 1;
+        // sweep 1 over every 2nd block when lists are long (profiles/r04_d_filter_sampling_sweep.txt: IVFPQ nb = 100M 14.9 ->
+        // 12.8 ms, IVFFlat nb = 10M 2.26 -> 2.17 ms, nb = 1M slower: the looser bound doubles the candidates)
+        const int min_stride = lmf_min_stride > 0 ? std::min(lmf_min_stride, 8) : (avg_len >= 8192 ? 2 : 1);
         FA_THROW_IF_NOT_MSG(G >= 1 && G <= 8 && (G & (G - 1)) == 0 && RT <= 65280, "filter tuning: granule / rows per item");
         // granule slots a query can own: those of the np longest lists
         int64_t gstride = 0;
@@ -2629,6 +2633,7 @@ void GpuIndexIVF::search_listmajor_filter_chunk_(int ni, int q0, const float* xq
     P.stride = stride;
     P.ovf = lm_ovf_.as<uint32_t>();
     P.qflags = lm_qflags_.as<uint32_t>();
+    P.sel_mask = cur_sel_mask_;
     // ---- queries: fp16 copy + range flags + |q|^2 (the sequential chain of the flat index)
     {
         SpanGuard sg(&R, "ivf_lmf_prepare");
@@ -3393,6 +3398,7 @@ bool GpuIndexIVFPQ::lmf_prepare_(IvfLmParams& p) const {
     p.cs_bpl = bpl;
     p.cs_piece = piece;
     p.filter = 1;
+    p.pq_t = pq_t_.as<float>();
     p.pq16 = pq16_.p;
     p.yn_max = pq_yn_max_;
     p.cn_max = cn_max_;

@@ -189,7 +189,7 @@ struct LmfLane { // per (lane, query block)
 // ------------------------------------------------------------------ IVFFlat sweep
 // One WAVEFRONT per work item, items drawn from a counter; A operands global -> registers one 32-row block ahead, refilled
 // right behind the MFMAs that consumed them (the walk of ivf_lm_flat_reg_kernel).  FULL: ldh == 128 (8 k-steps).
-template <int METRIC, int MODE, int NQB, bool FULL>
+template <int METRIC, int MODE, int NQB, bool FULL, bool SEL>
 __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -330,9 +330,13 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
                 __builtin_amdgcn_sched_barrier(0);
                 const int row_b = t + 4 * h;    // row of the list of acc[.][4 g + e]: row_b + 8 g + e
                 const bool tail = t + 32 > r1;  // (wave-uniform) the block reaches past the end of the chunk
+                // IDSelector: one bit per arena row (launch_selector_mask); a block = one aligned word of the mask (lists
+                // start on multiples of 32 rows).  Rows the selector excludes take no part in the bound nor in the collection.
+                const uint32_t mw = SEL ? p.sel_mask[(start + t) >> 5] >> (4 * h) : 0u;
                 auto est = [&](int b, int g, int e) __attribute__((always_inline)) -> float {
                     float dv = METRIC == METRIC_L2 ? __fmaf_rn(-2.f, acc[b][4 * g + e], L[b].xn + rn[g][e]) : acc[b][4 * g + e];
                     if (tail && row_b + 8 * g + e >= r1) dv = lmf_worst<METRIC>();
+                    if (SEL && !((mw >> (8 * g + e)) & 1u)) dv = lmf_worst<METRIC>();
                     return dv;
                 };
                 if constexpr (MODE == MODE_MIN) {
@@ -377,7 +381,7 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
                             for (int e = 0; e < 4; ++e) {
                                 const float dv = est(b, g, e);
                                 const bool pass = (METRIC == METRIC_L2 ? dv <= L[b].thr : dv >= L[b].thr) &&
-                                                  !(tail && row_b + 8 * g + e >= r1);
+                                                  !(tail && row_b + 8 * g + e >= r1) && (!SEL || ((mw >> (8 * g + e)) & 1u));
                                 mask |= pass ? 1u << (4 * g + e) : 0u;
                             }
                         if (b < skip_b) mask = 0;
@@ -447,7 +451,7 @@ struct LpCodes {
     static constexpr int ND = DS == 1 ? 16 : DS == 2 ? 8 : DS == 4 ? 4 : 2;
 };
 
-template <int METRIC, int MODE, int NQB, int DS>
+template <int METRIC, int MODE, int NQB, int DS, bool SEL>
 __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -648,10 +652,12 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
             }
             const int row_b = t + 4 * h;
             const bool tail = t + 32 > r1;
+            const uint32_t mw = SEL ? p.sel_mask[(start + t) >> 5] >> (4 * h) : 0u; // IDSelector bits of the block's rows
             auto est = [&](int b, int g, int e) __attribute__((always_inline)) -> float {
                 float dv = METRIC == METRIC_L2 ? __fmaf_rn(-2.f, acc[b][4 * g + e], L[b].xn + rn[g][e])
                                                : L[b].xn + acc[b][4 * g + e];
                 if (tail && row_b + 8 * g + e >= r1) dv = lmf_worst<METRIC>();
+                if (SEL && !((mw >> (8 * g + e)) & 1u)) dv = lmf_worst<METRIC>();
                 return dv;
             };
             if constexpr (MODE == MODE_MIN) {
@@ -695,7 +701,7 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
                         for (int e = 0; e < 4; ++e) {
                             const float dv = est(b, g, e);
                             const bool pass = (METRIC == METRIC_L2 ? dv <= L[b].thr : dv >= L[b].thr) &&
-                                              !(tail && row_b + 8 * g + e >= r1);
+                                              !(tail && row_b + 8 * g + e >= r1) && (!SEL || ((mw >> (8 * g + e)) & 1u));
                             mask |= pass ? 1u << (4 * g + e) : 0u;
                         }
                     if (__ballot(mask != 0u)) {
@@ -741,33 +747,33 @@ int ivf_lmf_grid_blocks(const IvfLmParams& p, int num_cus) {
     if (p.kind == 1) return num_cus;       // one 8-wave workgroup per CU (codebook + slices in its LDS)
     return 2 * num_cus / 8 * 8;            // IVFFlat: two 4-wave workgroups per CU
 }
-template <int METRIC, int MODE>
+template <int METRIC, int MODE, bool SEL>
 static void lmf_flat_launch(const IvfLmParams& p, int grid_blocks, hipStream_t stream) {
     constexpr int NQB = kLmfQueryBlocks;
     const int lds = MODE == MODE_COLLECT ? LF_LDS : 0;
     if (p.ldh == 128) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)ivf_lmf_flat_kernel<METRIC, MODE, NQB, true>,
+        HIP_CHECK(hipFuncSetAttribute((const void*)ivf_lmf_flat_kernel<METRIC, MODE, NQB, true, SEL>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, LF_LDS));
-        hipLaunchKernelGGL((ivf_lmf_flat_kernel<METRIC, MODE, NQB, true>), dim3((unsigned)grid_blocks), dim3(LF_THREADS), lds,
+        hipLaunchKernelGGL((ivf_lmf_flat_kernel<METRIC, MODE, NQB, true, SEL>), dim3((unsigned)grid_blocks), dim3(LF_THREADS), lds,
                            stream, p);
     } else {
-        HIP_CHECK(hipFuncSetAttribute((const void*)ivf_lmf_flat_kernel<METRIC, MODE, NQB, false>,
+        HIP_CHECK(hipFuncSetAttribute((const void*)ivf_lmf_flat_kernel<METRIC, MODE, NQB, false, SEL>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, LF_LDS));
-        hipLaunchKernelGGL((ivf_lmf_flat_kernel<METRIC, MODE, NQB, false>), dim3((unsigned)grid_blocks), dim3(LF_THREADS), lds,
+        hipLaunchKernelGGL((ivf_lmf_flat_kernel<METRIC, MODE, NQB, false, SEL>), dim3((unsigned)grid_blocks), dim3(LF_THREADS), lds,
                            stream, p);
     }
 }
-template <int METRIC, int MODE>
+template <int METRIC, int MODE, bool SEL>
 static void lmf_pq_launch(const IvfLmParams& p, int grid_blocks, hipStream_t stream) {
     constexpr int NQB = kLmfQueryBlocks;
     const int lds = lp_layout(p.d, p.M).total;
     const int ds = p.dsub >= 8 ? 8 : p.dsub;
-#define FA_LP(DS_)                                                                                                       \
-    do {                                                                                                                 \
-        HIP_CHECK(hipFuncSetAttribute((const void*)ivf_lmf_pq_kernel<METRIC, MODE, NQB, DS_>,                            \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));                                 \
-        hipLaunchKernelGGL((ivf_lmf_pq_kernel<METRIC, MODE, NQB, DS_>), dim3((unsigned)grid_blocks), dim3(LP_THREADS), lds, \
-                           stream, p);                                                                                   \
+#define FA_LP(DS_)                                                                                                            \
+    do {                                                                                                                      \
+        HIP_CHECK(hipFuncSetAttribute((const void*)ivf_lmf_pq_kernel<METRIC, MODE, NQB, DS_, SEL>,                            \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));                                      \
+        hipLaunchKernelGGL((ivf_lmf_pq_kernel<METRIC, MODE, NQB, DS_, SEL>), dim3((unsigned)grid_blocks), dim3(LP_THREADS), lds, \
+                           stream, p);                                                                                        \
     } while (0)
     if (ds == 1) FA_LP(1);
     else if (ds == 2) FA_LP(2);
@@ -775,17 +781,23 @@ static void lmf_pq_launch(const IvfLmParams& p, int grid_blocks, hipStream_t str
     else FA_LP(8);
 #undef FA_LP
 }
+template <int METRIC, bool SEL>
+static void lmf_launch_sel(const IvfLmParams& p, int mode, int grid_blocks, hipStream_t stream) {
+    if (p.kind == 0) {
+        if (mode == MODE_MIN) lmf_flat_launch<METRIC, MODE_MIN, SEL>(p, grid_blocks, stream);
+        else if (mode == MODE_COLLECT) lmf_flat_launch<METRIC, MODE_COLLECT, SEL>(p, grid_blocks, stream);
+        else lmf_flat_launch<METRIC, MODE_DUMP, SEL>(p, grid_blocks, stream);
+    } else {
+        if (mode == MODE_MIN) lmf_pq_launch<METRIC, MODE_MIN, SEL>(p, grid_blocks, stream);
+        else if (mode == MODE_COLLECT) lmf_pq_launch<METRIC, MODE_COLLECT, SEL>(p, grid_blocks, stream);
+        else lmf_pq_launch<METRIC, MODE_DUMP, SEL>(p, grid_blocks, stream);
+    }
+}
 template <int METRIC>
 static void lmf_launch_mode(const IvfLmParams& p, int mode, int grid_blocks, hipStream_t stream) {
-    if (p.kind == 0) {
-        if (mode == MODE_MIN) lmf_flat_launch<METRIC, MODE_MIN>(p, grid_blocks, stream);
-        else if (mode == MODE_COLLECT) lmf_flat_launch<METRIC, MODE_COLLECT>(p, grid_blocks, stream);
-        else lmf_flat_launch<METRIC, MODE_DUMP>(p, grid_blocks, stream);
-    } else {
-        if (mode == MODE_MIN) lmf_pq_launch<METRIC, MODE_MIN>(p, grid_blocks, stream);
-        else if (mode == MODE_COLLECT) lmf_pq_launch<METRIC, MODE_COLLECT>(p, grid_blocks, stream);
-        else lmf_pq_launch<METRIC, MODE_DUMP>(p, grid_blocks, stream);
-    }
+    // (the test dump never runs with a selector: one instantiation less)
+    if (p.sel_mask && mode != MODE_DUMP) lmf_launch_sel<METRIC, true>(p, mode, grid_blocks, stream);
+    else lmf_launch_sel<METRIC, false>(p, mode, grid_blocks, stream);
 }
 void launch_ivf_lmf_sweep(const IvfLmParams& p, int mode, int grid_blocks, hipStream_t stream) {
     if (p.nq == 0) return;
@@ -1000,7 +1012,7 @@ __global__ void __launch_bounds__(256) lmf_rerank_pq_kernel(IvfLmParams p) {
     const int np = p.nprobe, M = p.M, dsub = p.dsub;
     const int n = (int)min((int64_t)p.cnt[q], p.stride);
     if (n == 0) return; // (workgroup-uniform)
-    float* lut = (float*)smem;                      // [M][256]
+    float* lut = (float*)smem;                      // [256][M]
     uint32_t* colmax = (uint32_t*)(lut + M * 256);  // [M]
     float* grid = (float*)(colmax + M);             // delta, 1 / delta, on
     u64* kq = p.keys + (int64_t)q * p.stride;
@@ -1008,15 +1020,28 @@ __global__ void __launch_bounds__(256) lmf_rerank_pq_kernel(IvfLmParams p) {
     const float* x = p.xq + (int64_t)q * p.ldq;
     for (int m = tid; m < M; m += 256) colmax[m] = 0u;
     __syncthreads();
-    for (int m = 0; m < M; ++m) {
-        const float* cen = p.pq_centroids + ((size_t)m * 256 + tid) * dsub;
-        float acc = 0.f;
-        for (int jd = 0; jd < dsub; ++jd) acc = __fmaf_rn(x[m * dsub + jd], cen[jd], acc);
-        lut[m * 256 + tid] = acc;
-        uint32_t u = __float_as_uint(fabsf(acc)); // (bit patterns: NaN beats every number, like the oracle's maximum)
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) u = max(u, (uint32_t)__shfl_xor((int)u, off, 64));
-        if (lane == 0) atomicMax(&colmax[m], u);
+    // table entries e = c * M + m in the order of the transposed codebook pq_t [256][M][dsub] (coalesced reads, conflict-free
+    // LDS writes).  When M divides 256 a thread meets one sub-quantizer only: its maximum stays in a register.
+    if (256 % M == 0) {
+        const int m = tid % M;
+        uint32_t mx = 0u;
+        for (int e = tid; e < M * 256; e += 256) {
+            const float* cen = p.pq_t + (size_t)e * dsub;
+            float acc = 0.f;
+            for (int jd = 0; jd < dsub; ++jd) acc = __fmaf_rn(x[m * dsub + jd], cen[jd], acc);
+            lut[e] = acc;
+            mx = max(mx, __float_as_uint(fabsf(acc))); // (bit patterns: NaN beats every number, like the oracle's maximum)
+        }
+        atomicMax(&colmax[m], mx);
+    } else {
+        for (int e = tid; e < M * 256; e += 256) {
+            const int m = e % M;
+            const float* cen = p.pq_t + (size_t)e * dsub;
+            float acc = 0.f;
+            for (int jd = 0; jd < dsub; ++jd) acc = __fmaf_rn(x[m * dsub + jd], cen[jd], acc);
+            lut[e] = acc;
+            atomicMax(&colmax[m], __float_as_uint(fabsf(acc)));
+        }
     }
     __syncthreads();
     if (tid == 0) {
@@ -1035,6 +1060,9 @@ __global__ void __launch_bounds__(256) lmf_rerank_pq_kernel(IvfLmParams p) {
         for (int e = tid; e < M * 256; e += 256) lut[e] = __builtin_rintf(lut[e] * inv) * delta;
     }
     __syncthreads();
+    // candidates: lane ln of a group takes the sub-quantizers ln, ln + 8, ...; the groups of a wavefront start at different
+    // ones (rotation by the group number), so that their gathers fall on different LDS banks (bank = m mod 32 in [c][m])
+    const int nm8 = (M + 7) >> 3;
     for (int base = 0; base < n; base += 32) {
         const int i = base + grp;
         const bool valid = i < n;
@@ -1048,9 +1076,12 @@ __global__ void __launch_bounds__(256) lmf_rerank_pq_kernel(IvfLmParams p) {
             dis0 = p.coarse_dis[(int64_t)q * np + pr];
             if (METRIC == METRIC_L2) t2 = p.arena_t2[row];
             if (on) {
-                for (int m = ln; m < M; m += 8) s = s + lut[m * 256 + (int)p.arena_codes[pq_code_offset(M, row, m)]];
+                for (int i8 = 0; i8 < nm8; ++i8) {
+                    const int m = ln + 8 * ((i8 + grp) % nm8);
+                    if (m < M) s = s + lut[(int)p.arena_codes[pq_code_offset(M, row, m)] * M + m];
+                }
             } else if (ln == 0) {
-                for (int m = 0; m < M; ++m) s = s + lut[m * 256 + (int)p.arena_codes[pq_code_offset(M, row, m)]];
+                for (int m = 0; m < M; ++m) s = s + lut[(int)p.arena_codes[pq_code_offset(M, row, m)] * M + m];
             }
         }
         if (on) {
@@ -1071,7 +1102,7 @@ void launch_ivf_lmf_rerank(const IvfLmParams& p, hipStream_t stream) {
         if (p.metric == METRIC_L2) hipLaunchKernelGGL(lmf_rerank_flat_kernel<METRIC_L2>, grid, block, 0, stream, p);
         else hipLaunchKernelGGL(lmf_rerank_flat_kernel<METRIC_INNER_PRODUCT>, grid, block, 0, stream, p);
     } else {
-        FA_THROW_IF_NOT(p.metric != METRIC_L2 || p.arena_t2);
+        FA_THROW_IF_NOT((p.metric != METRIC_L2 || p.arena_t2) && p.pq_t);
         const int lds = p.M * 1024 + p.M * 4 + 16;
         FA_THROW_IF_NOT(lds <= 160 * 1024);
         if (p.metric == METRIC_L2) {

@@ -491,6 +491,7 @@ struct IvfLmParams {
     const uint8_t* arena_cs;
     int cs_bpl, cs_piece;
     const void* pq16;           // [M][256][dsub] fp16 codebook (kind 1)
+    const float* pq_t;          // [256][M][dsub] fp32 codebook, transposed: the order the exact path builds its table in
     const uint32_t* qflags;     // [nq] nonzero: the query leaves the fp16 range / holds NaN -> not filtered (fallback)
     uint16_t* cand_pr;          // [nq][stride] probe number of every collected candidate (beside keys)
     const float* arena_t2;      // kind 1, L2: the per-row term of the query-major scan (rerank)
@@ -498,6 +499,9 @@ struct IvfLmParams {
     float yn_max;               // max |y|^2 over the stored rows (kind 0) / upper bound of |r^|^2 from the codebook (kind 1)
     float cn_max;               // kind 1: max |centroid|^2
     float* band_out;            // optional [nq]: the error band E_q the bound kernel used (tests)
+    // IDSelector of the search in flight (filter path only): one bit per arena row (launch_selector_mask), null = none.
+    // Excluded rows take no part in the bound nor in the collection: the result is that of the selected subset.
+    const uint32_t* sel_mask;
 };
 // |estimate - exact| <= this for every stored row, whatever the data: `estimate` = what the f16 MFMA sweeps of
 // ivf_lm_filter.hip compute (L2: fmaf(-2, <f16 q', f16 y'>, |q'|^2 + |y'|^2) with the two norms as fp32 chains; IP:

@@ -198,9 +198,12 @@ def test_scan_mode_rule_and_refusals(res):
     check_knn(Dp, Ip, Dq, Iq, rtol=1e-4, name="IVFPQ automatic list-major vs query-major")
     with pytest.raises(faiss_amd.FaissAmdError):
         idx.set_scan_mode(4)
-    idx.set_scan_mode(idx.SCAN_LIST_MAJOR)
+    idx.set_scan_mode(idx.SCAN_LIST_MAJOR_F32)
     with pytest.raises(faiss_amd.FaissAmdError, match="IDSelector"):
         idx.search(xq[:10], 5, params=faiss_amd.SearchParameters(sel=faiss_amd.IDSelectorRange(0, 100)))
+    idx.set_scan_mode(idx.SCAN_LIST_MAJOR)  # (behind the filter the list-major scan serves selector searches)
+    idx.search(xq[:10], 5, params=faiss_amd.SearchParameters(sel=faiss_amd.IDSelectorRange(0, 100)))
+    assert idx.scan_info()[1] == 2
     big = faiss_amd.GpuIndexIVFFlat(res, 136, 8, METRIC_L2)  # d > 128: not served by the list-major kernel
     big.set_scan_mode(big.SCAN_LIST_MAJOR)
     big.copy_centroids(np.random.RandomState(0).rand(8, 136).astype("float32"))

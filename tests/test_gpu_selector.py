@@ -157,6 +157,46 @@ def test_ivf_selector_equals_filtered_lists(res, kind, metric, d, nq, k):
     assert np.array_equal(D1, D0) and np.array_equal(I1, I0)
 
 
+@pytest.mark.parametrize("kind,metric,d,M", [(0, METRIC_L2, 128, 0), (0, METRIC_INNER_PRODUCT, 40, 0), (1, METRIC_L2, 128, 64),
+                                             (1, METRIC_INNER_PRODUCT, 64, 16)])
+def test_list_major_filter_scan_honours_the_selector(res, kind, metric, d, M):
+    """Round 4: the list-major scan behind the f16 filter (ivf_lm_filter.hip) tests the selector's row bits in both sweeps
+    (rows it excludes take no part in the bound nor in the collection), so IDSelector searches of large batches no longer
+    fall back to the query-major scan.  Every selector: bit-identical to the query-major search with the same selector
+    (all queries) and to the oracle on the lists restricted to the selected entries (a sample); sparse selections that
+    leave fewer than k granules admit everything and still come out exact."""
+    nlist, nb, nq, nprobe, k = 32, 40000, 2100, 8, 50
+    xt, xb, xq = synthetic_dataset(d, 4000, nb, nq, seed=nb + d)
+    ids = np.random.RandomState(5).permutation(nb).astype(np.int64) * 7 + 3
+    idx, cent, pq = _ivf_index(res, kind, metric, d, nlist, xt, M)
+    idx.add_with_ids(xb, ids)
+    idx.nprobe = nprobe
+    sizes, codes, lids = _gpu_lists(idx)
+    sub = np.r_[0:32]
+    for case in selector_cases(3, 3 + 7 * nb, seed=kind):
+        idx.set_scan_mode(idx.SCAN_QUERY_MAJOR)
+        D0, I0 = idx.search(xq, k, params=SPI(sel=case["sel"]))
+        idx.set_scan_mode(idx.SCAN_LIST_MAJOR)
+        D, I = idx.search(xq, k, params=SPI(sel=case["sel"]))
+        assert idx.scan_info()[1] == 2 and idx.last_scan_arith() == 0, case["name"]
+        assert np.array_equal(D, D0) and np.array_equal(I, I0), case["name"]
+        keep = case["member"](lids)
+        s2, c2, i2 = filter_lists(sizes, codes, lids, keep)
+        Do, Io = _ivf_oracle(kind, metric, idx, cent, pq, M, SQ.QT_8bit, s2, c2, i2, xq[sub], nprobe, k)
+        check_knn(D[sub], I[sub], Do, Io, exact=True, name="list-major filter, selector %s" % case["name"])
+        assert case["member"](I[I >= 0]).all(), case["name"]
+    # automatic mode: the batch is large enough for the list-major scan, with or without a selector
+    idx.set_scan_mode(idx.SCAN_AUTO)
+    case = selector_cases(3, 3 + 7 * nb, seed=kind)[2]
+    if idx.list_major_rule(nq, nprobe, k):
+        idx.search(xq, k, params=SPI(sel=case["sel"]))
+        assert idx.scan_info()[1] == 2
+    # the f32 list-major scan still refuses selectors
+    idx.set_scan_mode(idx.SCAN_LIST_MAJOR_F32)
+    with pytest.raises(faiss_amd.FaissAmdError, match="IDSelector"):
+        idx.search(xq[:10], 5, params=SPI(sel=case["sel"]))
+
+
 def test_ivfpq64_selector_bench_shape_kernel(res):
     """the M = 64 instantiation of the fused IVFPQ scan (the bench kernel: one v_perm per gather, rotated blocks)"""
     d, nlist, nb, nq, nprobe, k, M = 128, 64, 40000, 1100, 8, 100, 64
