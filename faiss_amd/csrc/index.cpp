@@ -720,7 +720,10 @@ void GpuIndexFlat::plan_filter_(int n, int k, int& geom, int& nsplit, int& tstri
     nsplit = best;
     if (const char* e = getenv("FAISS_AMD_FILTER_NSPLIT")) nsplit = atoi(e); // timing experiments only
     const int tiles_per_split = total_tiles / nsplit;
-    tstride = tiles_per_split >= 32 ? 4 : tiles_per_split >= 16 ? 2 : 1;
+    // sample of the maxima pass: every 8th tile when a split holds >= 96 of them (same-box A/B at the bench shape, round 4,
+    // profiles/r04_d_flat_tstride_ab.txt + r04_e: stride 2 / 4 / 8 / 16 = 3.29 / 2.92 / 2.85 / 3.05 ms and 2.98 / 2.90 / 3.05 ms
+    // for 4 / 8 / 16 on a second box: the halved maxima pass outweighs the doubled candidates, a quarter of it does not)
+    tstride = tiles_per_split >= 96 ? 8 : tiles_per_split >= 32 ? 4 : tiles_per_split >= 16 ? 2 : 1;
     if (const char* e = getenv("FAISS_AMD_FILTER_TSTRIDE")) tstride = std::max(1, atoi(e)); // timing experiments only
     // expected rows above the threshold: S * -ln(1 - k/S) in the sample, tstride times that overall; the
     // re-rank kernel gathers at most 4096 of them per query, so large k samples more tiles

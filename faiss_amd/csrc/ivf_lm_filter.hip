@@ -176,15 +176,58 @@ void launch_ivf_lmf_code_shadow(const uint8_t* arena_codes, int d, int M, int nl
     HIP_CHECK(hipGetLastError());
 }
 
-// ------------------------------------------------------------------ epilogue shared by the two sweep kernels
-// acc: the 16 inner products of this lane's query of block b with rows 8 g + 4 h + e of the 32-row block at list row t.
+// ------------------------------------------------------------------ scores, shared by the two sweep kernels
+// The epilogue of a 32-row x 32-query block works on SCORES, larger = better, whose order is the order of the estimates:
+//   L2   score = <q', y'> - |y'|^2 / 2 - |q'|^2 / 2,   estimate = -2 score          IP   score = <q', y'> [+ coarse term] = estimate
+// one fma per accumulator (the row term; -inf for rows that take no part: behind the end of the list, excluded by the
+// IDSelector), then a maximum (8 x v_max3 per query block); the query's own term xh is added to that maximum only (sweep 1)
+// or folded into the threshold (sweep 2, where the 16 scores are looked at one by one only when a lane has a hit).  The
+// first version computed fmaf(-2, acc, |q'|^2 + |y'|^2), a bound check and a comparison per accumulator: 446 VALU
+// instructions per 32-row block against 24 MFMAs (PMC, profiles/r04_e_pmc_ivfpq_10m.txt: SQ_INSTS_VALU) -- the sweeps were
+// bound by the vector ALU.
 struct LmfLane { // per (lane, query block)
     bool qv;
     uint32_t base_pos, qpr; // qpr = query << 11 | probe
-    float xn, thr, gm;
-    uint32_t* gq; // MODE_MIN: gmin + q * gstride + granule-slot base of this (query, probe) + h
-    u64* kq;      // MODE_DUMP: keys + q * stride + base_pos
+    float xh;               // L2: -|q'|^2 / 2; IP: the coarse term (IVFPQ) or 0
+    float tq;               // sweep 2: row scores (without xh) >= tq are collected (L2: -thr / 2 - xh; IP: thr - xh; +inf = nothing)
+    float gm;               // sweep 1: best row score (without xh) of the granule so far
+    uint32_t* gq;           // sweep 1: gmin + q * gstride + granule-slot base of this (query, probe) + h
+    u64* kq;                // MODE_DUMP: keys + q * stride + base_pos
 };
+template <int METRIC>
+__device__ __forceinline__ float lmf_to_est(float sc) {
+    return METRIC == METRIC_L2 ? -2.f * sc : sc;
+}
+__device__ __forceinline__ float lmf_max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float lmf_lane_max(const f32x16& a) { // 8 instructions
+    const float m0 = lmf_max3(a[0], a[1], a[2]), m1 = lmf_max3(a[3], a[4], a[5]), m2 = lmf_max3(a[6], a[7], a[8]);
+    const float m3 = lmf_max3(a[9], a[10], a[11]), m4 = lmf_max3(a[12], a[13], a[14]);
+    return lmf_max3(lmf_max3(m0, m1, m2), lmf_max3(m3, m4, a[15]), a[15]);
+}
+// the accumulators of a block -> scores without the query's own term, in place: L2 acc - |y'|^2 / 2, IP acc; -inf for rows
+// that take no part.  rn: |y'|^2 of the lane's rows 8 g + 4 h + e; tail: the block reaches past row r1 of the list; mw:
+// IDSelector bits of the lane's rows (bit 8 g + e), SEL only.
+template <int METRIC, bool SEL>
+__device__ __forceinline__ void lmf_scores(f32x16& a, const f32x4 (&rn)[4], bool tail, int row_b, int r1, uint32_t mw) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (METRIC == METRIC_L2) a[4 * g + e] = __fmaf_rn(-0.5f, rn[g][e], a[4 * g + e]);
+    if (tail || SEL) { // (wave-uniform)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool ok = !(tail && row_b + 8 * g + e >= r1) && (!SEL || ((mw >> (8 * g + e)) & 1u));
+                a[4 * g + e] = ok ? a[4 * g + e] : -INFINITY;
+            }
+    }
+}
 
 // ------------------------------------------------------------------ IVFFlat sweep
 // One WAVEFRONT per work item, items drawn from a counter; A operands global -> registers one 32-row block ahead, refilled
@@ -255,15 +298,15 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
                 if (FULL || s < nks) bq[b][s] = *(const half8*)(qrow + 16 * s);
                 else bq[b][s] = half8{0, 0, 0, 0, 0, 0, 0, 0};
             }
-            L[b].xn = METRIC == METRIC_L2 ? p.xqn[q] : 0.f;
+            L[b].xh = METRIC == METRIC_L2 ? -0.5f * p.xqn[q] : 0.f;
             L[b].base_pos = p.prefix[(int64_t)q * (np + 1) + pr];
             L[b].qpr = ((uint32_t)q << 11) | (uint32_t)pr;
-            L[b].thr = 0.f;
-            L[b].gm = lmf_worst<METRIC>();
+            L[b].tq = INFINITY;
+            L[b].gm = -INFINITY;
             L[b].gq = nullptr;
             L[b].kq = nullptr;
             if (MODE == MODE_MIN) L[b].gq = p.gmin + (int64_t)q * p.gstride + p.prefixg[(int64_t)q * (np + 1) + pr] + h;
-            if (MODE == MODE_COLLECT) L[b].thr = L[b].qv ? p.thr_f[q] : (METRIC == METRIC_L2 ? -INFINITY : INFINITY);
+            if (MODE == MODE_COLLECT && L[b].qv) L[b].tq = (METRIC == METRIC_L2 ? -0.5f * p.thr_f[q] : p.thr_f[q]) - L[b].xh;
             if (MODE == MODE_DUMP) L[b].kq = p.keys + (int64_t)q * p.stride + L[b].base_pos;
         }
 
@@ -289,6 +332,11 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
             for (; t < r1; t += bstep) {
                 arow += (bstep >> 5) * nks * 512;
                 rnp += bstep;
+                const int row_b = t + 4 * h;    // row of the list of acc[.][4 g + e]: row_b + 8 g + e
+                const bool tail = t + 32 > r1;  // (wave-uniform) the block reaches past the end of the chunk
+                // IDSelector: one bit per arena row (launch_selector_mask); a block = one aligned word of the mask (lists
+                // start on multiples of 32 rows).  Rows the selector excludes take no part in the bound nor in the collection.
+                const uint32_t mw = SEL ? p.sel_mask[(start + t) >> 5] >> (4 * h) : 0u;
                 f32x16 acc[NQB];
 #pragma unroll
                 for (int b = 0; b < NQB; ++b)
@@ -328,92 +376,76 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                const int row_b = t + 4 * h;    // row of the list of acc[.][4 g + e]: row_b + 8 g + e
-                const bool tail = t + 32 > r1;  // (wave-uniform) the block reaches past the end of the chunk
-                // IDSelector: one bit per arena row (launch_selector_mask); a block = one aligned word of the mask (lists
-                // start on multiples of 32 rows).  Rows the selector excludes take no part in the bound nor in the collection.
-                const uint32_t mw = SEL ? p.sel_mask[(start + t) >> 5] >> (4 * h) : 0u;
-                auto est = [&](int b, int g, int e) __attribute__((always_inline)) -> float {
-                    float dv = METRIC == METRIC_L2 ? __fmaf_rn(-2.f, acc[b][4 * g + e], L[b].xn + rn[g][e]) : acc[b][4 * g + e];
-                    if (tail && row_b + 8 * g + e >= r1) dv = lmf_worst<METRIC>();
-                    if (SEL && !((mw >> (8 * g + e)) & 1u)) dv = lmf_worst<METRIC>();
-                    return dv;
-                };
                 if constexpr (MODE == MODE_MIN) {
 #pragma unroll
                     for (int b = 0; b < NQB; ++b) {
-                        float m = L[b].gm;
-#pragma unroll
-                        for (int g = 0; g < 4; ++g)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) m = lmf_better<METRIC>(m, est(b, g, e));
-                        L[b].gm = m;
+                        lmf_scores<METRIC, SEL>(acc[b], rn, tail, row_b, r1, mw);
+                        L[b].gm = fmaxf(L[b].gm, lmf_lane_max(acc[b]));
                     }
                     const int blk = t >> 5;
                     // (wave-uniform) the granule ends with this block: the next block looked at lies in another one
                     if ((((t + bstep) >> 5) >> gsh) != (blk >> gsh) || t + bstep >= r1) {
 #pragma unroll
                         for (int b = 0; b < NQB; ++b) {
-                            if (L[b].qv) lmf_store_u32(L[b].gq + 2 * (blk >> gsh), ordkey<METRIC>(L[b].gm));
-                            L[b].gm = lmf_worst<METRIC>();
+                            if (L[b].qv)
+                                lmf_store_u32(L[b].gq + 2 * (blk >> gsh), ordkey<METRIC>(lmf_to_est<METRIC>(L[b].gm + L[b].xh)));
+                            L[b].gm = -INFINITY;
                         }
                     }
                 } else if constexpr (MODE == MODE_DUMP) {
 #pragma unroll
-                    for (int b = 0; b < NQB; ++b)
+                    for (int b = 0; b < NQB; ++b) {
+                        lmf_scores<METRIC, SEL>(acc[b], rn, tail, row_b, r1, mw);
 #pragma unroll
                         for (int g = 0; g < 4; ++g)
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const int rowl = row_b + 8 * g + e;
                                 if (L[b].qv && rowl < r1)
-                                    lmf_store_u64(L[b].kq + rowl, ((u64)ordkey<METRIC>(est(b, g, e)) << 32) |
-                                                                          (u64)(L[b].base_pos + (uint32_t)rowl));
+                                    lmf_store_u64(L[b].kq + rowl,
+                                                  ((u64)ordkey<METRIC>(lmf_to_est<METRIC>(acc[b][4 * g + e] + L[b].xh)) << 32) |
+                                                          (u64)(L[b].base_pos + (uint32_t)rowl));
                             }
+                    }
                 } else {
-                    // ---- which of this lane's 16 estimates per query block pass its query's threshold
 #pragma unroll
                     for (int b = 0; b < NQB; ++b) {
+                        // ---- does any of this lane's 16 scores of query block b reach its query's threshold?
+                        if (b < skip_b) continue;
+                        lmf_scores<METRIC, SEL>(acc[b], rn, tail, row_b, r1, mw);
+                        if (!__ballot(lmf_lane_max(acc[b]) >= L[b].tq)) continue; // (wave-uniform)
                         unsigned mask = 0;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            mask |= (acc[b][r] >= L[b].tq && acc[b][r] > -INFINITY) ? 1u << r : 0u;
+                        if (!__ballot(mask != 0u)) continue;
+                        // park the candidates: this lane's go behind those of the lanes before it
+                        const int c = __popc(mask);
+                        int inc = c;
+#pragma unroll
+                        for (int off = 1; off < 64; off <<= 1) {
+                            const int o = __shfl_up(inc, off, 64);
+                            if (lane >= off) inc += o;
+                        }
+                        const int total = __builtin_amdgcn_readlane(inc, 63);
+                        if (wcnt + total > LF_PARK) {
+                            full = true; // block t is redone after the flush, from query block b on
+                            skip_b = b;
+                            break;
+                        }
+                        int at = wcnt + inc - c;
 #pragma unroll
                         for (int g = 0; g < 4; ++g)
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                const float dv = est(b, g, e);
-                                const bool pass = (METRIC == METRIC_L2 ? dv <= L[b].thr : dv >= L[b].thr) &&
-                                                  !(tail && row_b + 8 * g + e >= r1) && (!SEL || ((mw >> (8 * g + e)) & 1u));
-                                mask |= pass ? 1u << (4 * g + e) : 0u;
-                            }
-                        if (b < skip_b) mask = 0;
-                        if (__ballot(mask != 0u)) {
-                            // (wave-uniform branch) park the candidates: this lane's go behind those of the lanes before it
-                            const int c = __popc(mask);
-                            int inc = c;
-#pragma unroll
-                            for (int off = 1; off < 64; off <<= 1) {
-                                const int o = __shfl_up(inc, off, 64);
-                                if (lane >= off) inc += o;
-                            }
-                            const int total = __builtin_amdgcn_readlane(inc, 63);
-                            if (wcnt + total > LF_PARK) {
-                                full = true; // block t is redone after the flush, from query block b on
-                                skip_b = b;
-                                break;
-                            }
-                            int at = wcnt + inc - c;
-#pragma unroll
-                            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    if (mask & (1u << (4 * g + e))) {
-                                        const uint32_t pos = L[b].base_pos + (uint32_t)(row_b + 8 * g + e);
-                                        pk_keys[at] = ((u64)ordkey<METRIC>(est(b, g, e)) << 32) | pos;
-                                        pk_q[at] = L[b].qpr;
-                                        ++at;
-                                    }
+                                if (mask & (1u << (4 * g + e))) {
+                                    const uint32_t pos = L[b].base_pos + (uint32_t)(row_b + 8 * g + e);
+                                    pk_keys[at] = ((u64)ordkey<METRIC>(lmf_to_est<METRIC>(acc[b][4 * g + e] + L[b].xh)) << 32) | pos;
+                                    pk_q[at] = L[b].qpr;
+                                    ++at;
                                 }
-                            wcnt += total;
-                        }
+                            }
+                        wcnt += total;
                     }
                     if (full) break;
                     skip_b = 0;
@@ -572,15 +604,15 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
                 bq[b][s] = o;
             }
             // |q - c|^2: the two half chains of the lane pair (h = 0 / 1)
-            L[b].xn = METRIC == METRIC_L2 ? accn + __shfl_xor(accn, 32, 64) : p.coarse_dis[pi];
+            L[b].xh = METRIC == METRIC_L2 ? -0.5f * (accn + __shfl_xor(accn, 32, 64)) : p.coarse_dis[pi];
             L[b].base_pos = p.prefix[(int64_t)q * (np + 1) + pr];
             L[b].qpr = ((uint32_t)q << 11) | (uint32_t)pr;
-            L[b].thr = 0.f;
-            L[b].gm = lmf_worst<METRIC>();
+            L[b].tq = INFINITY;
+            L[b].gm = -INFINITY;
             L[b].gq = nullptr;
             L[b].kq = nullptr;
             if (MODE == MODE_MIN) L[b].gq = p.gmin + (int64_t)q * p.gstride + p.prefixg[(int64_t)q * (np + 1) + pr] + h;
-            if (MODE == MODE_COLLECT) L[b].thr = L[b].qv ? p.thr_f[q] : (METRIC == METRIC_L2 ? -INFINITY : INFINITY);
+            if (MODE == MODE_COLLECT && L[b].qv) L[b].tq = (METRIC == METRIC_L2 ? -0.5f * p.thr_f[q] : p.thr_f[q]) - L[b].xh;
             if (MODE == MODE_DUMP) L[b].kq = p.keys + (int64_t)q * p.stride + L[b].base_pos;
         }
 
@@ -621,6 +653,9 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
                 }
                 return a;
             };
+            const int row_b = t + 4 * h;
+            const bool tail = t + 32 > r1;
+            const uint32_t mw = SEL ? p.sel_mask[(start + t) >> 5] >> (4 * h) : 0u; // IDSelector bits of the block's rows
             f32x16 acc[NQB];
 #pragma unroll
             for (int b = 0; b < NQB; ++b)
@@ -638,7 +673,7 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
             for (int s = 0; s < 8; ++s) {
                 if (s + 2 < 8) av[(s + 2) % 3] = operand_of(s + 2);
                 if (s == 1 && more) fetch(t + bstep, cn);
-                if (s == 4 && METRIC == METRIC_L2) {
+                if (s == 4 && METRIC == METRIC_L2) { // |r^|^2 of the block's rows (lane: rows 8 g + 4 h + e), for the epilogue
 #pragma unroll
                     for (int g = 0; g < 4; ++g) rn[g] = *(const f32x4*)(p.arena_rn + start + t + 8 * g + 4 * h);
                 }
@@ -650,88 +685,70 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            const int row_b = t + 4 * h;
-            const bool tail = t + 32 > r1;
-            const uint32_t mw = SEL ? p.sel_mask[(start + t) >> 5] >> (4 * h) : 0u; // IDSelector bits of the block's rows
-            auto est = [&](int b, int g, int e) __attribute__((always_inline)) -> float {
-                float dv = METRIC == METRIC_L2 ? __fmaf_rn(-2.f, acc[b][4 * g + e], L[b].xn + rn[g][e])
-                                               : L[b].xn + acc[b][4 * g + e];
-                if (tail && row_b + 8 * g + e >= r1) dv = lmf_worst<METRIC>();
-                if (SEL && !((mw >> (8 * g + e)) & 1u)) dv = lmf_worst<METRIC>();
-                return dv;
-            };
             if constexpr (MODE == MODE_MIN) {
 #pragma unroll
                 for (int b = 0; b < NQB; ++b) {
-                    float m = L[b].gm;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) m = lmf_better<METRIC>(m, est(b, g, e));
-                    L[b].gm = m;
+                    lmf_scores<METRIC, SEL>(acc[b], rn, tail, row_b, r1, mw);
+                    L[b].gm = fmaxf(L[b].gm, lmf_lane_max(acc[b]));
                 }
                 const int blk = t >> 5;
                 if ((((t + bstep) >> 5) >> gsh) != (blk >> gsh) || t + bstep >= r1) {
 #pragma unroll
                     for (int b = 0; b < NQB; ++b) {
-                        if (L[b].qv) L[b].gq[2 * (blk >> gsh)] = ordkey<METRIC>(L[b].gm);
-                        L[b].gm = lmf_worst<METRIC>();
+                        if (L[b].qv) L[b].gq[2 * (blk >> gsh)] = ordkey<METRIC>(lmf_to_est<METRIC>(L[b].gm + L[b].xh));
+                        L[b].gm = -INFINITY;
                     }
                 }
             } else if constexpr (MODE == MODE_DUMP) {
 #pragma unroll
-                for (int b = 0; b < NQB; ++b)
+                for (int b = 0; b < NQB; ++b) {
+                    lmf_scores<METRIC, SEL>(acc[b], rn, tail, row_b, r1, mw);
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int rowl = row_b + 8 * g + e;
                             if (L[b].qv && rowl < r1)
-                                L[b].kq[rowl] = ((u64)ordkey<METRIC>(est(b, g, e)) << 32) | (u64)(L[b].base_pos + (uint32_t)rowl);
+                                L[b].kq[rowl] = ((u64)ordkey<METRIC>(lmf_to_est<METRIC>(acc[b][4 * g + e] + L[b].xh)) << 32) |
+                                                (u64)(L[b].base_pos + (uint32_t)rowl);
                         }
+                }
             } else {
 #pragma unroll
                 for (int b = 0; b < NQB; ++b) {
-                    // (one query block after the other: left alone hipcc interleaves the three epilogues and spills)
-                    __builtin_amdgcn_sched_barrier(0);
+                    // ---- does any of this lane's 16 scores of query block b reach its query's threshold?
+                    lmf_scores<METRIC, SEL>(acc[b], rn, tail, row_b, r1, mw);
+                    if (!__ballot(lmf_lane_max(acc[b]) >= L[b].tq)) continue; // (wave-uniform)
                     unsigned mask = 0;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g)
+                    for (int r = 0; r < 16; ++r) mask |= (acc[b][r] >= L[b].tq && acc[b][r] > -INFINITY) ? 1u << r : 0u;
+                    if (!__ballot(mask != 0u)) continue;
+                    // park the candidates row group by row group (8 g + 4 h + e, g = 0 .. 3): a group holds at most
+                    // 4 x 64 = LP_PARK candidates, so it always fits an empty slice
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const unsigned mg = (mask >> (4 * g)) & 15u;
+                        if (!__ballot(mg != 0u)) continue;
+                        const int c = __popc(mg);
+                        int inc = c;
+#pragma unroll
+                        for (int off = 1; off < 64; off <<= 1) {
+                            const int o = __shfl_up(inc, off, 64);
+                            if (lane >= off) inc += o;
+                        }
+                        const int total = __builtin_amdgcn_readlane(inc, 63);
+                        if (wcnt + total > LP_PARK) flush();
+                        int at = wcnt + inc - c;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float dv = est(b, g, e);
-                            const bool pass = (METRIC == METRIC_L2 ? dv <= L[b].thr : dv >= L[b].thr) &&
-                                              !(tail && row_b + 8 * g + e >= r1) && (!SEL || ((mw >> (8 * g + e)) & 1u));
-                            mask |= pass ? 1u << (4 * g + e) : 0u;
-                        }
-                    if (__ballot(mask != 0u)) {
-                        // (wave-uniform branch) park the candidates row group by row group (8 g + 4 h + e, g = 0 .. 3): a
-                        // group holds at most 4 x 64 = LP_PARK candidates, so it always fits an empty slice
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const unsigned mg = (mask >> (4 * g)) & 15u;
-                            if (!__ballot(mg != 0u)) continue;
-                            const int c = __popc(mg);
-                            int inc = c;
-#pragma unroll
-                            for (int off = 1; off < 64; off <<= 1) {
-                                const int o = __shfl_up(inc, off, 64);
-                                if (lane >= off) inc += o;
+                            if (mg & (1u << e)) {
+                                const uint32_t pos = L[b].base_pos + (uint32_t)(row_b + 8 * g + e);
+                                pk_keys[at] = ((u64)ordkey<METRIC>(lmf_to_est<METRIC>(acc[b][4 * g + e] + L[b].xh)) << 32) | pos;
+                                pk_q[at] = L[b].qpr;
+                                ++at;
                             }
-                            const int total = __builtin_amdgcn_readlane(inc, 63);
-                            if (wcnt + total > LP_PARK) flush();
-                            int at = wcnt + inc - c;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                if (mg & (1u << e)) {
-                                    const uint32_t pos = L[b].base_pos + (uint32_t)(row_b + 8 * g + e);
-                                    pk_keys[at] = ((u64)ordkey<METRIC>(est(b, g, e)) << 32) | pos;
-                                    pk_q[at] = L[b].qpr;
-                                    ++at;
-                                }
-                            }
-                            wcnt += total;
                         }
+                        wcnt += total;
                     }
                 }
             }
@@ -1063,6 +1080,8 @@ __global__ void __launch_bounds__(256) lmf_rerank_pq_kernel(IvfLmParams p) {
     // candidates: lane ln of a group takes the sub-quantizers ln, ln + 8, ...; the groups of a wavefront start at different
     // ones (rotation by the group number), so that their gathers fall on different LDS banks (bank = m mod 32 in [c][m])
     const int nm8 = (M + 7) >> 3;
+    const bool fastc = pq_chunk_bytes(M) == 16 && (M == 32 || M == 64 || M == 128);
+    const int B8 = M >> 3; // fastc: stored bytes per lane of a candidate's group
     for (int base = 0; base < n; base += 32) {
         const int i = base + grp;
         const bool valid = i < n;
@@ -1075,7 +1094,33 @@ __global__ void __launch_bounds__(256) lmf_rerank_pq_kernel(IvfLmParams p) {
             const int64_t row = p.list_start[l] + (pos - p.prefix[(int64_t)q * (np + 1) + pr]);
             dis0 = p.coarse_dis[(int64_t)q * np + pr];
             if (METRIC == METRIC_L2) t2 = p.arena_t2[row];
-            if (on) {
+            if (on && fastc) {
+                // the row's M stored bytes in ONE load per lane: lane ln takes the stored bytes ln * M / 8 .. (a piece of a
+                // 16-byte chunk of the rotated block layout, kernels.h pq_code_offset); stored byte x is sub-quantizer
+                // (x + row) mod M.  (Byte by byte through pq_code_offset the 64 dependent loads per candidate made this
+                // kernel cost 1.2 ms at nb = 10M.)
+                const int x0 = ln * B8;
+                const uint8_t* src = p.arena_codes + (size_t)(row >> 6) * 64 * M + (size_t)(x0 >> 4) * 1024 + (size_t)(row & 63) * 16 + (x0 & 15);
+                unsigned w[4] = {0u, 0u, 0u, 0u};
+                if (B8 == 16) {
+                    const uint4 v = *(const uint4*)src;
+                    w[0] = v.x, w[1] = v.y, w[2] = v.z, w[3] = v.w;
+                } else if (B8 == 8) {
+                    const uint2 v = *(const uint2*)src;
+                    w[0] = v.x, w[1] = v.y;
+                } else {
+                    w[0] = *(const unsigned*)src;
+                }
+                const int lrot = (int)(row & 63);
+#pragma unroll
+                for (int b = 0; b < 16; ++b) {
+                    if (b < B8) {
+                        const int m = (x0 + b + lrot) & (M - 1);
+                        const unsigned code = (w[b >> 2] >> (8 * (b & 3))) & 255u;
+                        s = s + lut[(int)code * M + m];
+                    }
+                }
+            } else if (on) {
                 for (int i8 = 0; i8 < nm8; ++i8) {
                     const int m = ln + 8 * ((i8 + grp) % nm8);
                     if (m < M) s = s + lut[(int)p.arena_codes[pq_code_offset(M, row, m)] * M + m];
