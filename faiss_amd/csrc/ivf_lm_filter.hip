@@ -247,6 +247,9 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
     const _Float16* arena_h = (const _Float16*)p.arena_h;
     u64* pk_keys = (u64*)smem + wave * LF_PARK;
     uint32_t* pk_q = (uint32_t*)(smem + 4 * LF_PARK * 8) + wave * LF_PARK;
+    // |y|^2 of the rows of TWO consecutive blocks of this wave (see the block loop)
+    __shared__ float rn_lds_all[4][64];
+    float* rn_lds = rn_lds_all[wave];
     int wcnt = 0; // (wave-uniform) parked candidates
     auto flush = [&]() __attribute__((always_inline)) {
         for (int e = lane; e < wcnt; e += 64) {
@@ -324,14 +327,34 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
                 else a[s] = half8{0, 0, 0, 0, 0, 0, 0, 0};
                 asm volatile("" ::: "memory");
             }
-            const float* rnp = p.arena_rn + start + t + 4 * h; // |y|^2 of rows 8 g + 4 h + e of the block: rnp[8 g + e]
             bool full = false;
             // sweep 1 may look at every min_stride-th block only (a SAMPLE of the rows still bounds the k-th best estimate
             // from above; fewer rows -> a looser bound -> more candidates in sweep 2)
             const int bstep = MODE == MODE_MIN ? 32 * p.min_stride : 32;
-            for (; t < r1; t += bstep) {
+            // |y|^2 of the rows, for the epilogue.  Every lane of a half needs the same 16 of a block's 32 values, and it needs
+            // them a memory latency EARLIER than the epilogue of a 24-MFMA block can wait (loaded inside the block, as the f32
+            // kernels do, each block stalled ~3000 cycles on them: the sweeps ran at a fifth of the matrix pipe with every
+            // unit idle, profiles/r04_f_pmc_*).  So: lane l fetches ONE value of a block PAIR (rows of the pair's first block
+            // for l < 32, of its second for l >= 32), three pairs ahead, through a register ring; at the start of a pair the
+            // values go to the wave's 64-float LDS slice, the epilogues read theirs back as four broadcast ds_read_b128.
+            const int tb = t; // first block of this run (runs restart behind a flush)
+            auto rn_fetch = [&](int pair) __attribute__((always_inline)) -> float {
+                const int row = min(tb + (2 * pair + (lane >> 5)) * bstep + (lane & 31), r1 - 1); // (rows >= r1 are never used)
+                return METRIC == METRIC_L2 ? p.arena_rn[start + row] : 0.f;
+            };
+            float pf0 = rn_fetch(0), pf1 = rn_fetch(1), pf2 = rn_fetch(2);
+            int bi = 0; // blocks of this run so far
+            for (; t < r1; t += bstep, ++bi) {
                 arow += (bstep >> 5) * nks * 512;
-                rnp += bstep;
+                if (METRIC == METRIC_L2 && (bi & 1) == 0) { // (wave-uniform) a pair begins
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_wave_barrier(); // (the reads of the previous pair were issued: LDS keeps a wave's order)
+                    rn_lds[lane] = pf0;
+                    pf0 = pf1, pf1 = pf2;
+                    pf2 = rn_fetch((bi >> 1) + 3);
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_wave_barrier();
+                }
                 const int row_b = t + 4 * h;    // row of the list of acc[.][4 g + e]: row_b + 8 g + e
                 const bool tail = t + 32 > r1;  // (wave-uniform) the block reaches past the end of the chunk
                 // IDSelector: one bit per arena row (launch_selector_mask); a block = one aligned word of the mask (lists
@@ -354,25 +377,17 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
                             acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s], bq[b][s], acc[b], 0, 0, 0);
                         a[s] = *(const half8*)(arow + 512 * s);
                     }
-                    if (s == 3 && METRIC == METRIC_L2) {
+                    if (s == 5 && METRIC == METRIC_L2) { // the block's norms from the wave's slice (rows 8 g + 4 h + e)
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) rn[g] = *(const f32x4*)(rnp - bstep + 8 * g);
+                        for (int g = 0; g < 4; ++g) rn[g] = *(const f32x4*)(rn_lds + (bi & 1) * 32 + 8 * g + 4 * h);
                     }
                 }
                 if (FULL) {
-                    // the instruction order above IS the schedule: NQB MFMAs, one load (five behind k-step 3)
+                    // the instruction order above IS the schedule: NQB MFMAs, one load, 8 times
 #pragma unroll
-                    for (int s = 0; s < 3; ++s) {
+                    for (int s = 0; s < 8; ++s) {
                         __builtin_amdgcn_sched_group_barrier(0x008, NQB, 0); // MFMA
                         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
-                    }
-                    __builtin_amdgcn_sched_group_barrier(0x008, NQB, 0);
-                    if constexpr (METRIC == METRIC_L2) __builtin_amdgcn_sched_group_barrier(0x020, 5, 0);
-                    else __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-#pragma unroll
-                    for (int s = 4; s < 8; ++s) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, NQB, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -504,6 +519,8 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
     }
     u64* pk_keys = (u64*)(smem + LY.off_park) + wave * LP_PARK;
     uint32_t* pk_q = (uint32_t*)(smem + LY.off_park + 8 * LP_PARK * 8) + wave * LP_PARK;
+    __shared__ float rn_lds_all[8][64]; // |r^|^2 of the rows of two consecutive blocks of every wave (see the flat kernel)
+    float* rn_lds = rn_lds_all[wave];
     int wcnt = 0;
     auto flush = [&]() __attribute__((always_inline)) {
         for (int e = lane; e < wcnt; e += 64) {
@@ -547,10 +564,11 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
         const int r0 = rt * p.rows_per_item;
         const int r1 = min(len, r0 + p.rows_per_item);
 
-        // the code bytes of this lane's operands for block t: global -> registers, one block ahead
-        unsigned cw[ND], cn[ND];
+        // the code bytes of this lane's operands for block t: global -> registers, TWO blocks ahead (a 24-MFMA block is
+        // shorter than a memory latency)
+        unsigned cw[ND], cn[ND], cn2[ND];
 #pragma unroll
-        for (int i = 0; i < ND; ++i) cw[i] = cn[i] = 0u;
+        for (int i = 0; i < ND; ++i) cw[i] = cn[i] = cn2[i] = 0u;
         auto fetch = [&](int t, unsigned (&dst)[ND]) __attribute__((always_inline)) {
             const uint8_t* bp = p.arena_cs + ((start + t) >> 5) * blk_bytes;
             if (x4) {
@@ -567,7 +585,15 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
                     if (c < npiece) dst[c] = *(const unsigned*)(bp + ((int64_t)c * 64 + lane) * 4);
             }
         };
+        const int bstep = MODE == MODE_MIN ? LP_BR * p.min_stride : LP_BR; // (sweep 1 may sample the blocks, see the flat kernel)
         fetch(r0, cw);
+        if (r0 + bstep < r1) fetch(r0 + bstep, cn);
+        // row norms: register ring -> LDS slice -> broadcast reads, as in the flat kernel
+        auto rn_fetch = [&](int pair) __attribute__((always_inline)) -> float {
+            const int row = min(r0 + (2 * pair + (lane >> 5)) * bstep + (lane & 31), r1 - 1);
+            return METRIC == METRIC_L2 ? p.arena_rn[start + row] : 0.f;
+        };
+        float pf0 = rn_fetch(0), pf1 = rn_fetch(1), pf2 = rn_fetch(2);
 
         // ---- this lane's queries: B operands = fp16 of the residual query (L2) / of the query (inner product)
         LmfLane L[NQB];
@@ -616,9 +642,18 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
             if (MODE == MODE_DUMP) L[b].kq = p.keys + (int64_t)q * p.stride + L[b].base_pos;
         }
 
-        const int bstep = MODE == MODE_MIN ? LP_BR * p.min_stride : LP_BR; // (sweep 1 may sample the blocks, see the flat kernel)
-        for (int t = r0; t < r1; t += bstep) {
-            const bool more = t + bstep < r1;
+        int bi = 0;
+        for (int t = r0; t < r1; t += bstep, ++bi) {
+            const bool more2 = t + 2 * bstep < r1;
+            if (METRIC == METRIC_L2 && (bi & 1) == 0) { // (wave-uniform) a block pair begins
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                rn_lds[lane] = pf0;
+                pf0 = pf1, pf1 = pf2;
+                pf2 = rn_fetch((bi >> 1) + 3);
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            }
             // the A operand of k-step s: coordinates 16 s + 8 h .. + 7 of this lane's row, gathered from the codebook by
             // the code bytes in cw
             auto operand_of = [&](int s_) __attribute__((always_inline)) -> half8 {
@@ -672,10 +707,10 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 if (s + 2 < 8) av[(s + 2) % 3] = operand_of(s + 2);
-                if (s == 1 && more) fetch(t + bstep, cn);
-                if (s == 4 && METRIC == METRIC_L2) { // |r^|^2 of the block's rows (lane: rows 8 g + 4 h + e), for the epilogue
+                if (s == 1 && more2) fetch(t + 2 * bstep, cn2);
+                if (s == 5 && METRIC == METRIC_L2) { // |r^|^2 of the block's rows (lane: rows 8 g + 4 h + e) from the wave's slice
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) rn[g] = *(const f32x4*)(p.arena_rn + start + t + 8 * g + 4 * h);
+                    for (int g = 0; g < 4; ++g) rn[g] = *(const f32x4*)(rn_lds + (bi & 1) * 32 + 8 * g + 4 * h);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (s < nks) {
@@ -753,7 +788,7 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
                 }
             }
 #pragma unroll
-            for (int i = 0; i < ND; ++i) cw[i] = cn[i];
+            for (int i = 0; i < ND; ++i) cw[i] = cn[i], cn[i] = cn2[i];
         }
     }
     if (MODE == MODE_COLLECT && wcnt > 0) flush();

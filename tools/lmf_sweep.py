@@ -77,9 +77,9 @@ def main():
                 ok = np.array_equal(ref[0], Dd.cpu().numpy()) and np.array_equal(ref[1], Id.cpu().numpy())
                 print("    filter == query-major on all queries: %s" % ok, flush=True)
         base = (Dd.cpu().numpy().copy(), Id.cpu().numpy().copy())
-        gs = (1, 2) if nb <= 1000000 else (2, 4, 8) if nb <= 10000000 else (4, 8)
+        gs = (1, 2) if nb <= 1000000 else (4, 8) if nb <= 10000000 else (8,)
         for g in gs:
-            for ms, cap in ((1, 1024), (2, 1024), (2, 2048), (4, 2048), (4, 4096)):
+            for ms, cap in ((1, 1024), (2, 1024)):
                 idx.set_lmf_tuning(0, g, cap, ms)
                 ms_t, sp = timed(idx, res, xq_dev, Dd, Id, steps=3)
                 same = np.array_equal(base[0], Dd.cpu().numpy()) and np.array_equal(base[1], Id.cpu().numpy())
