@@ -334,24 +334,24 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
             // |y|^2 of the rows, for the epilogue.  Every lane of a half needs the same 16 of a block's 32 values, and it needs
             // them a memory latency EARLIER than the epilogue of a 24-MFMA block can wait (loaded inside the block, as the f32
             // kernels do, each block stalled ~3000 cycles on them: the sweeps ran at a fifth of the matrix pipe with every
-            // unit idle, profiles/r04_f_pmc_*).  So: lane l fetches ONE value of a block PAIR (rows of the pair's first block
-            // for l < 32, of its second for l >= 32), three pairs ahead, through a register ring; at the start of a pair the
-            // values go to the wave's 64-float LDS slice, the epilogues read theirs back as four broadcast ds_read_b128.
+            // unit idle, profiles/r04_f_pmc_*).  So: lane l fetches ONE value per block (row l & 31), four blocks ahead, through a
+            // register ring; at the start of a block the values go to the wave's LDS slice and the epilogue reads its 16 back
+            // as four broadcast ds_read_b128.
             const int tb = t; // first block of this run (runs restart behind a flush)
-            auto rn_fetch = [&](int pair) __attribute__((always_inline)) -> float {
-                const int row = min(tb + (2 * pair + (lane >> 5)) * bstep + (lane & 31), r1 - 1); // (rows >= r1 are never used)
+            auto rn_fetch = [&](int blk) __attribute__((always_inline)) -> float {
+                const int row = min(tb + blk * bstep + (lane & 31), r1 - 1); // (rows >= r1 are never used)
                 return METRIC == METRIC_L2 ? p.arena_rn[start + row] : 0.f;
             };
-            float pf0 = rn_fetch(0), pf1 = rn_fetch(1), pf2 = rn_fetch(2);
+            float pf0 = rn_fetch(0), pf1 = rn_fetch(1), pf2 = rn_fetch(2), pf3 = rn_fetch(3);
             int bi = 0; // blocks of this run so far
             for (; t < r1; t += bstep, ++bi) {
                 arow += (bstep >> 5) * nks * 512;
-                if (METRIC == METRIC_L2 && (bi & 1) == 0) { // (wave-uniform) a pair begins
+                if (METRIC == METRIC_L2) { // (no branch: unconditional loads keep the compiler counting them)
                     asm volatile("" ::: "memory");
-                    __builtin_amdgcn_wave_barrier(); // (the reads of the previous pair were issued: LDS keeps a wave's order)
-                    rn_lds[lane] = pf0;
-                    pf0 = pf1, pf1 = pf2;
-                    pf2 = rn_fetch((bi >> 1) + 3);
+                    __builtin_amdgcn_wave_barrier(); // (the reads of the previous block were issued: LDS keeps a wave's order)
+                    rn_lds[lane] = pf0;              // (both halves write the block's 32 values)
+                    pf0 = pf1, pf1 = pf2, pf2 = pf3;
+                    pf3 = rn_fetch(bi + 4);
                     asm volatile("" ::: "memory");
                     __builtin_amdgcn_wave_barrier();
                 }
@@ -379,7 +379,7 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
                     }
                     if (s == 5 && METRIC == METRIC_L2) { // the block's norms from the wave's slice (rows 8 g + 4 h + e)
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) rn[g] = *(const f32x4*)(rn_lds + (bi & 1) * 32 + 8 * g + 4 * h);
+                        for (int g = 0; g < 4; ++g) rn[g] = *(const f32x4*)(rn_lds + 8 * g + 4 * h);
                     }
                 }
                 if (FULL) {
@@ -498,7 +498,11 @@ struct LpCodes {
     static constexpr int ND = DS == 1 ? 16 : DS == 2 ? 8 : DS == 4 ? 4 : 2;
 };
 
-template <int METRIC, int MODE, int NQB, int DS, bool SEL>
+// FULLK: d == 128 (8 k-steps, no runtime bound in the operand pipeline) and, for DS == 2, M == 64 (two 16-byte code pieces
+// per lane and block): the block loop then holds no conditional code around its loads and LDS reads -- with runtime bounds
+// hipcc closed every k-step with lgkmcnt(0) / vmcnt(0) (the gathers of step s + 2 were waited for before the MFMAs of step
+// s, the code prefetch before the next instruction): 8400 cycles per 24-MFMA block, every unit idle (profiles/r04_g_pmc_*).
+template <int METRIC, int MODE, int NQB, int DS, bool SEL, bool FULLK>
 __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -508,7 +512,7 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
     const int j = lane & 31;
     const int np = p.nprobe;
     const int M = p.M, dsub = p.dsub;
-    const int nks = p.d >> 4;
+    const int nks = FULLK ? 8 : (p.d >> 4);
     const int G = p.gran_blocks, gsh = __builtin_ctz((unsigned)p.gran_blocks); // (a power of two)
     const LpLayout LY = lp_layout(p.d, M);
     const _Float16* cb = (const _Float16*)smem;
@@ -519,7 +523,7 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
     }
     u64* pk_keys = (u64*)(smem + LY.off_park) + wave * LP_PARK;
     uint32_t* pk_q = (uint32_t*)(smem + LY.off_park + 8 * LP_PARK * 8) + wave * LP_PARK;
-    __shared__ float rn_lds_all[8][64]; // |r^|^2 of the rows of two consecutive blocks of every wave (see the flat kernel)
+    __shared__ float rn_lds_all[8][64]; // |r^|^2 of the rows of the block in hand, per wave (see the flat kernel)
     float* rn_lds = rn_lds_all[wave];
     int wcnt = 0;
     auto flush = [&]() __attribute__((always_inline)) {
@@ -571,7 +575,11 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
         for (int i = 0; i < ND; ++i) cw[i] = cn[i] = cn2[i] = 0u;
         auto fetch = [&](int t, unsigned (&dst)[ND]) __attribute__((always_inline)) {
             const uint8_t* bp = p.arena_cs + ((start + t) >> 5) * blk_bytes;
-            if (x4) {
+            if (FULLK && DS == 2) { // two 16-byte pieces, unconditionally
+                const uint4 v0 = *(const uint4*)(bp + (int64_t)lane * 16), v1 = *(const uint4*)(bp + ((int64_t)64 + lane) * 16);
+                dst[0] = v0.x, dst[1] = v0.y, dst[2] = v0.z, dst[3] = v0.w;
+                dst[4] = v1.x, dst[5] = v1.y, dst[6] = v1.z, dst[7] = v1.w;
+            } else if (x4) {
 #pragma unroll
                 for (int c = 0; c < ND / 4; ++c) {
                     if (c < npiece) {
@@ -586,14 +594,16 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
             }
         };
         const int bstep = MODE == MODE_MIN ? LP_BR * p.min_stride : LP_BR; // (sweep 1 may sample the blocks, see the flat kernel)
+        const int tlast = (r1 - 1) & ~31; // (prefetches behind the last block re-read it: loads stay unconditional)
         fetch(r0, cw);
-        if (r0 + bstep < r1) fetch(r0 + bstep, cn);
+        fetch(min(r0 + bstep, tlast), cn);
         // row norms: register ring -> LDS slice -> broadcast reads, as in the flat kernel
-        auto rn_fetch = [&](int pair) __attribute__((always_inline)) -> float {
-            const int row = min(r0 + (2 * pair + (lane >> 5)) * bstep + (lane & 31), r1 - 1);
+        // (one value per lane and block: lane l fetches row l & 31 of the block four blocks ahead -- both halves the same)
+        auto rn_fetch = [&](int blk) __attribute__((always_inline)) -> float {
+            const int row = min(r0 + blk * bstep + (lane & 31), r1 - 1);
             return METRIC == METRIC_L2 ? p.arena_rn[start + row] : 0.f;
         };
-        float pf0 = rn_fetch(0), pf1 = rn_fetch(1), pf2 = rn_fetch(2);
+        float pf0 = rn_fetch(0), pf1 = rn_fetch(1), pf2 = rn_fetch(2), pf3 = rn_fetch(3);
 
         // ---- this lane's queries: B operands = fp16 of the residual query (L2) / of the query (inner product)
         LmfLane L[NQB];
@@ -611,7 +621,7 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 half8 o = half8{0, 0, 0, 0, 0, 0, 0, 0};
-                if (s < nks) {
+                if (FULLK || s < nks) {
                     const f32x4 v0 = *(const f32x4*)(qrow + 16 * s), v1 = *(const f32x4*)(qrow + 16 * s + 4);
                     f32x4 c0 = f32x4{0.f, 0.f, 0.f, 0.f}, c1 = c0;
                     if (METRIC == METRIC_L2) {
@@ -644,13 +654,12 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
 
         int bi = 0;
         for (int t = r0; t < r1; t += bstep, ++bi) {
-            const bool more2 = t + 2 * bstep < r1;
-            if (METRIC == METRIC_L2 && (bi & 1) == 0) { // (wave-uniform) a block pair begins
+            if (METRIC == METRIC_L2) {
                 asm volatile("" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-                rn_lds[lane] = pf0;
-                pf0 = pf1, pf1 = pf2;
-                pf2 = rn_fetch((bi >> 1) + 3);
+                __builtin_amdgcn_wave_barrier(); // (the epilogue reads of the previous block were issued: LDS keeps a wave's order)
+                rn_lds[lane] = pf0;              // (both halves write the block's 32 values: rn_lds[l] == rn_lds[32 + l])
+                pf0 = pf1, pf1 = pf2, pf2 = pf3;
+                pf3 = rn_fetch(bi + 4);
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
             }
@@ -658,7 +667,7 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
             // the code bytes in cw
             auto operand_of = [&](int s_) __attribute__((always_inline)) -> half8 {
                 half8 a = half8{0, 0, 0, 0, 0, 0, 0, 0};
-                if (s_ >= nks) return a;
+                if (!FULLK && s_ >= nks) return a;
                 const int kb = 16 * s_ + 8 * h; // first coordinate
                 if (DS == 8) {
                     const int m = kb / dsub, off = kb - m * dsub;
@@ -707,13 +716,13 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 if (s + 2 < 8) av[(s + 2) % 3] = operand_of(s + 2);
-                if (s == 1 && more2) fetch(t + 2 * bstep, cn2);
+                if (s == 1) fetch(min(t + 2 * bstep, tlast), cn2);
                 if (s == 5 && METRIC == METRIC_L2) { // |r^|^2 of the block's rows (lane: rows 8 g + 4 h + e) from the wave's slice
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) rn[g] = *(const f32x4*)(rn_lds + (bi & 1) * 32 + 8 * g + 4 * h);
+                    for (int g = 0; g < 4; ++g) rn[g] = *(const f32x4*)(rn_lds + 8 * g + 4 * h);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (s < nks) {
+                if (FULLK || s < nks) {
 #pragma unroll
                     for (int b = 0; b < NQB; ++b)
                         acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s % 3], bq[b][s], acc[b], 0, 0, 0);
@@ -820,17 +829,18 @@ static void lmf_pq_launch(const IvfLmParams& p, int grid_blocks, hipStream_t str
     constexpr int NQB = kLmfQueryBlocks;
     const int lds = lp_layout(p.d, p.M).total;
     const int ds = p.dsub >= 8 ? 8 : p.dsub;
-#define FA_LP(DS_)                                                                                                            \
-    do {                                                                                                                      \
-        HIP_CHECK(hipFuncSetAttribute((const void*)ivf_lmf_pq_kernel<METRIC, MODE, NQB, DS_, SEL>,                            \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));                                      \
-        hipLaunchKernelGGL((ivf_lmf_pq_kernel<METRIC, MODE, NQB, DS_, SEL>), dim3((unsigned)grid_blocks), dim3(LP_THREADS), lds, \
-                           stream, p);                                                                                        \
+#define FA_LP(DS_, FK_)                                                                                                        \
+    do {                                                                                                                       \
+        HIP_CHECK(hipFuncSetAttribute((const void*)ivf_lmf_pq_kernel<METRIC, MODE, NQB, DS_, SEL, FK_>,                        \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));                                       \
+        hipLaunchKernelGGL((ivf_lmf_pq_kernel<METRIC, MODE, NQB, DS_, SEL, FK_>), dim3((unsigned)grid_blocks), dim3(LP_THREADS), \
+                           lds, stream, p);                                                                                    \
     } while (0)
-    if (ds == 1) FA_LP(1);
-    else if (ds == 2) FA_LP(2);
-    else if (ds == 4) FA_LP(4);
-    else FA_LP(8);
+    if (ds == 2 && p.d == 128 && p.M == 64 && p.cs_piece == 16) FA_LP(2, true); // the bench shape: PQ64 over d = 128
+    else if (ds == 1) FA_LP(1, false);
+    else if (ds == 2) FA_LP(2, false);
+    else if (ds == 4) FA_LP(4, false);
+    else FA_LP(8, false);
 #undef FA_LP
 }
 template <int METRIC, bool SEL>
