@@ -1116,12 +1116,10 @@ __global__ void __launch_bounds__(256) lmf_rerank_pq_kernel(IvfLmParams p) {
         grid[2] = on ? 1.f : 0.f;
     }
     __syncthreads();
+    // (the entries are rounded to the grid where they are looked up: ~10 000 lookups per query against 16 384 entries, and no
+    // second pass over the table)
     const bool on = grid[2] != 0.f;
-    if (on) {
-        const float delta = grid[0], inv = grid[1];
-        for (int e = tid; e < M * 256; e += 256) lut[e] = __builtin_rintf(lut[e] * inv) * delta;
-    }
-    __syncthreads();
+    const float delta = grid[0], inv = grid[1];
     // candidates: lane ln of a group takes the sub-quantizers ln, ln + 8, ...; the groups of a wavefront start at different
     // ones (rotation by the group number), so that their gathers fall on different LDS banks (bank = m mod 32 in [c][m])
     const int nm8 = (M + 7) >> 3;
@@ -1162,13 +1160,13 @@ __global__ void __launch_bounds__(256) lmf_rerank_pq_kernel(IvfLmParams p) {
                     if (b < B8) {
                         const int m = (x0 + b + lrot) & (M - 1);
                         const unsigned code = (w[b >> 2] >> (8 * (b & 3))) & 255u;
-                        s = s + lut[(int)code * M + m];
+                        s = s + __builtin_rintf(lut[(int)code * M + m] * inv) * delta;
                     }
                 }
             } else if (on) {
                 for (int i8 = 0; i8 < nm8; ++i8) {
                     const int m = ln + 8 * ((i8 + grp) % nm8);
-                    if (m < M) s = s + lut[(int)p.arena_codes[pq_code_offset(M, row, m)] * M + m];
+                    if (m < M) s = s + __builtin_rintf(lut[(int)p.arena_codes[pq_code_offset(M, row, m)] * M + m] * inv) * delta;
                 }
             } else if (ln == 0) {
                 for (int m = 0; m < M; ++m) s = s + lut[(int)p.arena_codes[pq_code_offset(M, row, m)] * M + m];

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 import faiss_amd
-from faiss_amd.datasets import synthetic_dataset, synthetic_more
+from faiss_amd.datasets import synthetic_dataset, synthetic_more_device
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 nb = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000
 res = faiss_amd.StandardGpuResources(0)
@@ -19,9 +19,11 @@ done = len(xb0)
 chunk = 0
 while done < nb:  # further chunks of the same distribution (never 5 GB on the host at once)
     chunk += 1
-    xbc = synthetic_more(dmap, min(1000000, nb - done), seed=1338 + chunk)
-    idx.add(xbc)
-    done += len(xbc)
+    n_c = min(1000000, nb - done)
+    xbc = synthetic_more_device(dmap, n_c, 1338 + chunk, torch.device("cuda", 0))
+    idx.add_ptr(n_c, xbc.data_ptr())
+    done += n_c
+    del xbc
 print("train+add of %d vectors: %.1fs" % (nb, time.time() - t0), flush=True)
 idx.nprobe = 32
 dev = torch.device("cuda", 0)

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 import faiss_amd
-from faiss_amd.datasets import synthetic_dataset, synthetic_more
+from faiss_amd.datasets import synthetic_dataset, synthetic_more_device
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 nb = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000
 metric = faiss_amd.METRIC_INNER_PRODUCT if len(sys.argv) > 3 and sys.argv[3] == "ip" else faiss_amd.METRIC_L2
@@ -17,9 +17,11 @@ idx.train(xt); idx.add(xb); idx.nprobe = 32
 done, chunk = len(xb), 0
 while done < nb:  # BASELINE.json configs[3]: nb = 100M, generated and added chunk by chunk
     chunk += 1
-    xbc = synthetic_more(dmap, min(2000000, nb - done), seed=1338 + chunk)
-    idx.add(xbc)
-    done += len(xbc)
+    n_c = min(1000000, nb - done)
+    xbc = synthetic_more_device(dmap, n_c, 1338 + chunk, torch.device("cuda", 0))
+    idx.add_ptr(n_c, xbc.data_ptr())
+    done += n_c
+    del xbc
 print("train+add of %d vectors: %.1fs" % (nb, time.time() - t0), flush=True)
 dev = torch.device("cuda", 0)
 xq_dev = torch.from_numpy(xq).to(dev)
