@@ -605,12 +605,17 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
         };
         float pf0 = rn_fetch(0), pf1 = rn_fetch(1), pf2 = rn_fetch(2), pf3 = rn_fetch(3);
 
+        // The item's query blocks that hold queries (1 .. NQB): the block loop is instantiated per count, so that a list probed
+        // by <= 32 / <= 64 of the batch's queries costs 8 / 16 MFMAs and one / two epilogues per 32-row block instead of 24 and
+        // three -- chosen per ITEM, outside the loop (a bound inside it costs the compiler its count of the loads in flight).
+        auto run_item = [&](auto nb_c) __attribute__((always_inline)) {
+        constexpr int NB = decltype(nb_c)::value;
         // ---- this lane's queries: B operands = fp16 of the residual query (L2) / of the query (inner product)
-        LmfLane L[NQB];
-        half8 bq[NQB][8];
+        LmfLane L[NB];
+        half8 bq[NB][8];
         const float* cen = p.centroids + (int64_t)list * p.ldc + 8 * h;
 #pragma unroll
-        for (int b = 0; b < NQB; ++b) {
+        for (int b = 0; b < NB; ++b) {
             const int my = b * 32 + j;
             L[b].qv = my < npair;
             const uint32_t pi = p.pairs[pb + (uint32_t)(qt * (32 * NQB)) + (uint32_t)(L[b].qv ? my : 0)];
@@ -700,9 +705,9 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
             const int row_b = t + 4 * h;
             const bool tail = t + 32 > r1;
             const uint32_t mw = SEL ? p.sel_mask[(start + t) >> 5] >> (4 * h) : 0u; // IDSelector bits of the block's rows
-            f32x16 acc[NQB];
+            f32x16 acc[NB];
 #pragma unroll
-            for (int b = 0; b < NQB; ++b)
+            for (int b = 0; b < NB; ++b)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
             f32x4 rn[4];
@@ -724,28 +729,28 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
                 __builtin_amdgcn_sched_barrier(0);
                 if (FULLK || s < nks) {
 #pragma unroll
-                    for (int b = 0; b < NQB; ++b)
+                    for (int b = 0; b < NB; ++b)
                         acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s % 3], bq[b][s], acc[b], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr (MODE == MODE_MIN) {
 #pragma unroll
-                for (int b = 0; b < NQB; ++b) {
+                for (int b = 0; b < NB; ++b) {
                     lmf_scores<METRIC, SEL>(acc[b], rn, tail, row_b, r1, mw);
                     L[b].gm = fmaxf(L[b].gm, lmf_lane_max(acc[b]));
                 }
                 const int blk = t >> 5;
                 if ((((t + bstep) >> 5) >> gsh) != (blk >> gsh) || t + bstep >= r1) {
 #pragma unroll
-                    for (int b = 0; b < NQB; ++b) {
+                    for (int b = 0; b < NB; ++b) {
                         if (L[b].qv) L[b].gq[2 * (blk >> gsh)] = ordkey<METRIC>(lmf_to_est<METRIC>(L[b].gm + L[b].xh));
                         L[b].gm = -INFINITY;
                     }
                 }
             } else if constexpr (MODE == MODE_DUMP) {
 #pragma unroll
-                for (int b = 0; b < NQB; ++b) {
+                for (int b = 0; b < NB; ++b) {
                     lmf_scores<METRIC, SEL>(acc[b], rn, tail, row_b, r1, mw);
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
@@ -759,7 +764,7 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
                 }
             } else {
 #pragma unroll
-                for (int b = 0; b < NQB; ++b) {
+                for (int b = 0; b < NB; ++b) {
                     // ---- does any of this lane's 16 scores of query block b reach its query's threshold?
                     lmf_scores<METRIC, SEL>(acc[b], rn, tail, row_b, r1, mw);
                     if (!__ballot(lmf_lane_max(acc[b]) >= L[b].tq)) continue; // (wave-uniform)
@@ -799,6 +804,10 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
 #pragma unroll
             for (int i = 0; i < ND; ++i) cw[i] = cn[i], cn[i] = cn2[i];
         }
+        };
+        if (npair > 64) run_item(std::integral_constant<int, 3>{});
+        else if (npair > 32) run_item(std::integral_constant<int, 2>{});
+        else run_item(std::integral_constant<int, 1>{});
     }
     if (MODE == MODE_COLLECT && wcnt > 0) flush();
 }
