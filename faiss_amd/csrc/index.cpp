@@ -2304,21 +2304,30 @@ static const char* experiment_env(const char* name) {
 
 // ---------------------------------------------------------------------- list-major search (ivf_listmajor.hip)
 bool GpuIndexIVF::list_major_rule(idx_t n, int nprobe_now, idx_t k, bool has_selector) const {
-    if (!lm_capable_() || (has_selector && !lmf_capable_())) return false;
-    // IVFPQ: 64 bytes per row make the query-major scan cheap per query (its cost: rows x queries of a list, HBM-bound);
-    // the list-major kernel (codebook in LDS) costs rows x 32-query blocks of matrix work plus the fixed plan / bound /
-    // select launches.  Measured at nlist 4096, nprobe 32 (profiles/r03_b_*), list-major vs query-major, ms: nb = 1M 1.38 vs
-    // 1.31 (0.77 vs 0.41 with 2500 queries), 2M 1.96 vs 2.07, 4M 2.83 vs 3.63, 10M 5.0 vs 9.7 -- break-even near
-    // (rows per list) x (queries per list) = 415 x 78; the rule asks for 50 000, and a shape the LDS kernel serves.
+    if (!lm_capable_() || (has_selector && !lmf_capable_()) || k > kMaxSelectionK || nstored_ == 0) return false;
     const int64_t np = std::min<int64_t>(nprobe_now, nlist);
-    if (fused_kind_() == 1 &&
-        !(lm_pq_lds_capable_() && (double)n * (double)np * (double)nstored_ >= 50000.0 * (double)nlist * (double)nlist))
-        return false;
-    // IVFFlat / scalar quantizer: the plan / bound / select launches and the read-back of a list-major search are a fixed
-    // cost the single fused query-major launch does not pay; with short lists (a small index) there is no scan time to
-    // win it back from.  Measured on the bench shape only at >= 244 rows per list; the rule asks for 64.
-    if (fused_kind_() != 1 && (double)nstored_ < 64.0 * (double)nlist) return false;
-    return n >= 2048 && (int64_t)n * np >= (int64_t)8 * nlist && k <= kMaxSelectionK;
+    // every list has to meet >= 8 of the batch's queries on average: below that the 32-query MFMA blocks run mostly empty
+    // (nlist 16384, nprobe 8, 10 000 queries: 4.9 queries per list, list-major 2.6 ms against 1.0 ms)
+    if ((int64_t)n * np < (int64_t)8 * nlist) return false;
+    const double avg_len = (double)nstored_ / (double)nlist;
+    if (fused_kind_() == 2 || (fused_kind_() == 1 && !lmf_capable_())) {
+        // scalar quantizer / IVFPQ shapes the filter does not serve: round 3's f32 list-major scan and its rule (measured at
+        // nlist 4096 / nprobe 32 only: IVFPQ break-even near (rows per list) x (queries per list) = 415 x 78)
+        if (fused_kind_() == 1 &&
+            !(lm_pq_lds_capable_() && (double)n * (double)np * (double)nstored_ >= 50000.0 * (double)nlist * (double)nlist))
+            return false;
+        return n >= 2048 && (double)nstored_ >= 64.0 * (double)nlist;
+    }
+    // Behind the f16 filter (round 4; profiles/r04_i_scan_rule_sweep.txt: nlist 1024 / 4096 / 16384 x nprobe 8 / 32 / 128 x 512
+    // ... 10 000 queries at nb = 1M, both index types).  The query-major scan is bound by the bytes it streams -- queries x
+    // probes x rows per list x bytes per row at ~6 TB/s (IVFFlat) / ~5 TB/s (IVFPQ) on top of 0.1-0.2 ms --, the list-major
+    // scan costs 0.4-0.6 ms whatever the batch (plan, two sweeps, bound, rerank, select) and grows slowly from there: it
+    // wins once the query-major stream exceeds ~3 GB (IVFFlat: 512 queries x 128 probes already, 6.4 x faster) / ~6 GB
+    // (IVFPQ, whose lists must also be long enough to amortise an item's set-up: nlist 16384 at nb = 1M -- 61 rows per list --
+    // never wins).
+    const double stream = (double)n * (double)np * avg_len * (double)ref_row_bytes_();
+    if (fused_kind_() == 0) return (double)nstored_ >= 64.0 * (double)nlist && stream >= 3.0e9;
+    return avg_len >= 128.0 && stream >= 6.0e9;
 }
 
 // Queries [0, ni) with their coarse results on the device -> k best per query in dD / dI (device).  Splits the batch

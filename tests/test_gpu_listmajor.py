@@ -181,21 +181,35 @@ def test_scan_mode_rule_and_refusals(res):
     idx, _, _ = _build(res, 0, METRIC_L2, d, 0, nlist, xt, xb)
     idx.nprobe = 8
     assert idx.scan_info()[0] == 0
-    assert idx.list_major_rule(2100, 8, 10) and not idx.list_major_rule(2047, 8, 10) and not idx.list_major_rule(100, 64, 10)
+    # the rule (profiles/r04_i_scan_rule_sweep.txt): every list meets >= 8 queries of the batch, and the bytes the
+    # query-major scan would stream (queries x probes x rows per list x bytes per row) exceed ~3 GB (IVFFlat) / ~6 GB
+    # (IVFPQ): a small index like this one (8000 rows of 128 bytes) stays query-major whatever the batch
+    assert not idx.list_major_rule(2100, 8, 10) and not idx.list_major_rule(100000, 64, 10)
     D, I = idx.search(xq, 10)
-    assert idx.scan_info()[1] == 2  # 2100 queries x 8 probes over 64 lists: automatic list-major
-    D1, I1 = idx.search(xq[:500], 10)
     assert idx.scan_info()[1] == 1
-    check_knn(D[:500], I[:500], D1, I1, rtol=1e-4, name="automatic list-major vs query-major")
-    # IVFPQ: (rows per list) x (queries per list) >= 50 000 -- 125 rows per list here
-    pq, _, _ = _build(res, 1, METRIC_L2, d, 8, nlist, xt, xb)
-    pq.nprobe = 8
-    assert not pq.list_major_rule(2100, 8, 10) and pq.list_major_rule(3300, 8, 10) and not pq.list_major_rule(3100, 8, 10)
-    Dp, Ip = pq.search(np.tile(xq, (2, 1))[:3300], 10)
-    assert pq.scan_info()[1] == 2
+    idx.set_scan_mode(idx.SCAN_LIST_MAJOR)
+    D1, I1 = idx.search(xq, 10)
+    assert idx.scan_info()[1] == 2 and np.array_equal(D, D1) and np.array_equal(I, I1)
+    idx.set_scan_mode(idx.SCAN_AUTO)
+    # a larger one: 64 lists of 3125 rows of 256 bytes; 2100 queries x 16 probes stream 27 GB
+    d2 = 64
+    xt2, xb2, xq2 = synthetic_dataset(d2, 3000, 200000, 2100, seed=5)
+    big, _, _ = _build(res, 0, METRIC_L2, d2, 0, nlist, xt2, xb2)
+    big.nprobe = 16
+    assert big.list_major_rule(2100, 16, 10) and big.list_major_rule(300, 16, 10) and not big.list_major_rule(20, 16, 10)
+    Db, Ib = big.search(xq2, 10)
+    assert big.scan_info()[1] == 2 and big.last_scan_arith() == 0
+    Ds, Is = big.search(xq2[:20], 10)
+    assert big.scan_info()[1] == 1 and np.array_equal(Ds, Db[:20]) and np.array_equal(Is, Ib[:20])
+    # IVFPQ: lists of >= 128 rows and ~6 GB of code bytes
+    pq, _, _ = _build(res, 1, METRIC_L2, d2, 16, nlist, xt2, xb2)
+    pq.nprobe = 16
+    assert not pq.list_major_rule(2100, 16, 10) and pq.list_major_rule(2100, 64, 10)
+    Dp, Ip = pq.search(xq2, 10, params=faiss_amd.SearchParametersIVF(nprobe=64))
+    assert pq.scan_info()[1] == 2 and pq.last_scan_arith() == 0
     pq.set_scan_mode(pq.SCAN_QUERY_MAJOR)
-    Dq, Iq = pq.search(np.tile(xq, (2, 1))[:3300], 10)
-    check_knn(Dp, Ip, Dq, Iq, rtol=1e-4, name="IVFPQ automatic list-major vs query-major")
+    Dq, Iq = pq.search(xq2, 10, params=faiss_amd.SearchParametersIVF(nprobe=64))
+    assert np.array_equal(Dp, Dq) and np.array_equal(Ip, Iq)
     with pytest.raises(faiss_amd.FaissAmdError):
         idx.set_scan_mode(4)
     idx.set_scan_mode(idx.SCAN_LIST_MAJOR_F32)
@@ -270,22 +284,25 @@ def test_list_major_many_equal_distances(res, lm_mode, k):
 
 @pytest.mark.parametrize("kind", [0, 1])
 def test_results_do_not_depend_on_the_batch_size(res, kind):
-    """the automatic rule sends batches of >= 2048 queries through the list-major scan.  Behind the f16
-    filter that scan returns the bits of the query-major scan, so a query's distances and labels are the same at
-    n = 2047 and n = 2048 (and therefore under IndexShards / IndexReplicas query splits and the paged host path)."""
+    """the automatic rule sends large batches through the list-major scan.  Behind the f16 filter that
+    scan returns the bits of the query-major scan, so a query's distances and labels are the same whatever batch it
+    arrives in (and therefore under IndexShards / IndexReplicas query splits and the paged host path)."""
     d, nlist, M, k = 64, 64, 32, 40
     xt, xb, xq = synthetic_dataset(d, 4000, 60000, 2048, seed=31)
     idx, _, _ = _build(res, kind, METRIC_L2, d, M, nlist, xt, xb)
     idx.nprobe = 16
-    assert idx.list_major_rule(2048, 16, k) or kind == 1
     if kind == 1:
-        idx.set_scan_mode(idx.SCAN_LIST_MAJOR)  # (the IVFPQ rule asks for longer lists; force the scan)
+        idx.set_scan_mode(idx.SCAN_LIST_MAJOR)  # (the IVFPQ rule asks for more code bytes; force the scan)
+    else:
+        assert idx.list_major_rule(2048, 16, k) and not idx.list_major_rule(30, 16, k)
     D, I = idx.search(xq, k)
     assert idx.scan_info()[1] == 2 and idx.last_scan_arith() == 0
+    D2, I2 = idx.search(xq[:2047], k)
+    assert idx.scan_info()[1] == 2 and np.array_equal(D2, D[:2047]) and np.array_equal(I2, I[:2047])
     idx.set_scan_mode(idx.SCAN_AUTO)
-    D1, I1 = idx.search(xq[:2047], k)
+    D1, I1 = idx.search(xq[:30], k)
     assert idx.scan_info()[1] == 1
-    assert np.array_equal(D1, D[:2047]) and np.array_equal(I1, I[:2047])
+    assert np.array_equal(D1, D[:30]) and np.array_equal(I1, I[:30])
 
 
 def test_list_major_near_duplicates_and_self_search(res, lm_mode):
