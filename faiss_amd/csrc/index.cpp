@@ -2326,6 +2326,9 @@ bool GpuIndexIVF::list_major_rule(idx_t n, int nprobe_now, idx_t k, bool has_sel
     // (IVFPQ, whose lists must also be long enough to amortise an item's set-up: nlist 16384 at nb = 1M -- 61 rows per list --
     // never wins).
     const double stream = (double)n * (double)np * avg_len * (double)ref_row_bytes_();
+    // the bound is the k-th best of the query's granule minima (16 rows each): a query that probes fewer than ~1.1 k granules
+    // gets no bound and is redone query-major (bench sweep, nprobe 4 at nb = 1M: 61 granules for k = 100 -- 3.5 ms, all redone)
+    if ((double)np * avg_len < 18.0 * (double)k) return false;
     if (fused_kind_() == 0) return (double)nstored_ >= 64.0 * (double)nlist && stream >= 3.0e9;
     return avg_len >= 128.0 && stream >= 6.0e9;
 }

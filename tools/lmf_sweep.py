@@ -79,7 +79,7 @@ def main():
         base = (Dd.cpu().numpy().copy(), Id.cpu().numpy().copy())
         gs = (1, 2) if nb <= 1000000 else (4, 8) if nb <= 10000000 else (8,)
         for g in gs:
-            for ms, cap in ((1, 1024), (2, 1024)):
+            for ms, cap in ((1, 1024), (2, 1024)) + (((4, 1024), (4, 2048)) if nb >= 100000000 else ()):
                 idx.set_lmf_tuning(0, g, cap, ms)
                 ms_t, sp = timed(idx, res, xq_dev, Dd, Id, steps=3)
                 same = np.array_equal(base[0], Dd.cpu().numpy()) and np.array_equal(base[1], Id.cpu().numpy())

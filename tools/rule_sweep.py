@@ -3,7 +3,7 @@
 list-major search time of IVFFlat and IVFPQ (PQ64) over nlist in {1024, 4096, 16384}, nprobe in {8, 32, 128} and batches of
 512 ... 10 000 queries at nb = 1M (d = 128, k = 100), with what the rule picks beside the faster one.
 
-usage: python tools/rule_sweep.py > gpurun_out/rule_sweep.txt"""
+usage: python tools/rule_sweep.py [ivfflat,ivfpq] > gpurun_out/rule_sweep.txt"""
 import os
 import sys
 import time
@@ -40,7 +40,7 @@ def main():
     Id = torch.empty((10000, K), dtype=torch.int64, device=dev)
     wrong = total = 0
     for nlist in (1024, 4096, 16384):
-        for kind in ("ivfflat", "ivfpq"):
+        for kind in (sys.argv[1].split(",") if len(sys.argv) > 1 else ("ivfflat", "ivfpq")):
             idx = (faiss_amd.GpuIndexIVFPQ(res, D, nlist, 64, 8, faiss_amd.METRIC_L2) if kind == "ivfpq"
                    else faiss_amd.GpuIndexIVFFlat(res, D, nlist, faiss_amd.METRIC_L2))
             idx.train(xt)
