@@ -2006,8 +2006,9 @@ void GpuIndexIVF::search_core_(idx_t n, const float* x, idx_t k, float* distance
     FA_THROW_IF_NOT_MSG(scan_mode >= 0 && scan_mode <= 3,
                         "scan_mode must be 0 (auto), 1 (query-major), 2 (list-major) or 3 (list-major, f32 matrix pipe)");
     if (scan_mode >= 2) {
-        FA_THROW_IF_NOT_MSG(lm_capable_(), "list-major scan: index type / dimension not supported (IVFFlat, IVFPQ, scalar "
-                            "quantizer; d <= 128)");
+        FA_THROW_IF_NOT_MSG(lm_capable_() || (scan_mode == 2 && lmf_capable_()),
+                            "list-major scan: index type / dimension not supported (IVFFlat behind the f16 filter: d <= 512; "
+                            "IVFPQ, scalar quantizer, the f32 scan: d <= 128)");
         // (the filter sweeps test the selector's row bits themselves; the f32 scans do not)
         FA_THROW_IF_NOT_MSG(!sel || (scan_mode == 2 && lmf_capable_()),
                             "list-major scan: IDSelector searches take the query-major scan (or the filter path of IVFFlat / IVFPQ)");
@@ -2304,7 +2305,7 @@ static const char* experiment_env(const char* name) {
 
 // ---------------------------------------------------------------------- list-major search (ivf_listmajor.hip)
 bool GpuIndexIVF::list_major_rule(idx_t n, int nprobe_now, idx_t k, bool has_selector) const {
-    if (!lm_capable_() || (has_selector && !lmf_capable_()) || k > kMaxSelectionK || nstored_ == 0) return false;
+    if (!(lm_capable_() || lmf_capable_()) || (has_selector && !lmf_capable_()) || k > kMaxSelectionK || nstored_ == 0) return false;
     const int64_t np = std::min<int64_t>(nprobe_now, nlist);
     // every list has to meet >= 8 of the batch's queries on average: below that the 32-query MFMA blocks run mostly empty
     // (nlist 16384, nprobe 8, 10 000 queries: 4.9 queries per list, list-major 2.6 ms against 1.0 ms)
@@ -2322,15 +2323,16 @@ bool GpuIndexIVF::list_major_rule(idx_t n, int nprobe_now, idx_t k, bool has_sel
     // ... 10 000 queries at nb = 1M, both index types).  The query-major scan is bound by the bytes it streams -- queries x
     // probes x rows per list x bytes per row at ~6 TB/s (IVFFlat) / ~5 TB/s (IVFPQ) on top of 0.1-0.2 ms --, the list-major
     // scan costs 0.4-0.6 ms whatever the batch (plan, two sweeps, bound, rerank, select) and grows slowly from there: it
-    // wins once the query-major stream exceeds ~3 GB (IVFFlat: 512 queries x 128 probes already, 6.4 x faster) / ~6 GB
-    // (IVFPQ, whose lists must also be long enough to amortise an item's set-up: nlist 16384 at nb = 1M -- 61 rows per list --
+    // wins once the query-major stream exceeds ~3 GB (IVFFlat: 512 queries x 128 probes already, 6.4 x faster) / ~3.5 GB of
+    // code bytes (IVFPQ, profiles/r04_k_ivfpq_rule_sweep.txt: at 4.1 GB list-major is 1.14-1.20 x faster, at 2.05 GB 4-16 %
+    // slower; its lists must also be long enough to amortise an item's set-up: nlist 16384 at nb = 1M -- 61 rows per list --
     // never wins).
     const double stream = (double)n * (double)np * avg_len * (double)ref_row_bytes_();
     // the bound is the k-th best of the query's granule minima (16 rows each): a query that probes fewer than ~1.1 k granules
     // gets no bound and is redone query-major (bench sweep, nprobe 4 at nb = 1M: 61 granules for k = 100 -- 3.5 ms, all redone)
     if ((double)np * avg_len < 18.0 * (double)k) return false;
     if (fused_kind_() == 0) return (double)nstored_ >= 64.0 * (double)nlist && stream >= 3.0e9;
-    return avg_len >= 128.0 && stream >= 6.0e9;
+    return avg_len >= 128.0 && stream >= 3.5e9;
 }
 
 // Queries [0, ni) with their coarse results on the device -> k best per query in dD / dI (device).  Splits the batch
@@ -2584,7 +2586,7 @@ void GpuIndexIVF::search_listmajor_filter_chunk_(int ni, int q0, const float* xq
         max_len = std::max(max_len, l);
     }
     const int64_t npairs = (int64_t)ni * np;
-    const int qpi = ivf_lmf_queries_per_item(fused_kind_());
+    const int qpi = ivf_lmf_queries_per_item(fused_kind_(), d);
     const int64_t max_items = nrt_max * (int64_t)div_up((size_t)npairs, (size_t)qpi) + 2 * sum_nrt + 16;
     FA_THROW_IF_NOT_MSG(max_items < ((int64_t)1 << 30), "list-major scan: too many work items");
 
@@ -2652,7 +2654,7 @@ void GpuIndexIVF::search_listmajor_filter_chunk_(int ni, int q0, const float* xq
     // ---- queries: fp16 copy + range flags + |q|^2 (the sequential chain of the flat index)
     {
         SpanGuard sg(&R, "ivf_lmf_prepare");
-        const int dh = (int)round_up(d, 16);
+        const int dh = P.kind == 0 ? ivf_lmf_row_halfs(d) : (int)round_up(d, 16);
         lm_q16_.ensure((size_t)ni * dh * 2);
         launch_prep_queries(xq_pad, dpad_, ni, d, dpad_, lm_q16_.p, dh, lm_qflags_.as<uint32_t>(), lm_qn_.as<float>(),
                             lm_scalar_.as<unsigned>(), R.stream);
@@ -2748,7 +2750,7 @@ void GpuIndexIVF::test_filter_dump(idx_t n, const float* x, int nprobe_now, idx_
         nrt_max = std::max(nrt_max, nrt);
     }
     const int64_t npairs = (int64_t)ni * np;
-    const int qpi = ivf_lmf_queries_per_item(fused_kind_());
+    const int qpi = ivf_lmf_queries_per_item(fused_kind_(), d);
     const int64_t max_items = nrt_max * (int64_t)div_up((size_t)npairs, (size_t)qpi) + 2 * sum_nrt + 16;
     const int64_t gstride = 2 * (int64_t)np * (int64_t)div_up((size_t)max_len, (size_t)(32 * G));
     IvfLmParams P{};
@@ -2815,7 +2817,7 @@ void GpuIndexIVF::test_filter_dump(idx_t n, const float* x, int nprobe_now, idx_
     P.ovf = ovf.as<uint32_t>();
     P.qflags = qflags.as<uint32_t>();
     P.band_out = band.as<float>();
-    const int dh = (int)round_up(d, 16);
+    const int dh = P.kind == 0 ? ivf_lmf_row_halfs(d) : (int)round_up(d, 16);
     q16.ensure((size_t)ni * dh * 2);
     launch_prep_queries(P.xq, dpad_, ni, d, dpad_, q16.p, dh, qflags.as<uint32_t>(), qn.as<float>(), scalar.as<unsigned>(), R.stream);
     P.xq16 = q16.p;
@@ -3063,10 +3065,11 @@ bool GpuIndexIVFFlat::lmf_capable_() const {
 // database that is built once and searched many times pays it once, interleaved add / search workloads pay one arena
 // pass per add call.
 bool GpuIndexIVFFlat::lmf_prepare_(IvfLmParams& p) const {
-    const int dh = (int)round_up(d, 16);
+    const int dh = ivf_lmf_row_halfs(d);
     if (shadow_dirty_) {
         const GpuResources& R = *res_;
-        arena_h_.ensure(((size_t)arena_cap_rows_ / 32 + 4) * (size_t)(dh / 16) * 1024); // whole 32-row blocks + padding
+        // whole 32-row blocks + padding (the sweeps prefetch the next block they look at: up to 8 blocks behind the last list)
+        arena_h_.ensure(((size_t)arena_cap_rows_ / 32 + 10) * (size_t)(dh / 16) * 1024);
         lm_scalar_.ensure(64);
         HIP_CHECK(hipMemsetAsync(lm_scalar_.p, 0, 4, R.stream));
         launch_ivf_lmf_shadow(arena_.as<float>(), dpad_, arena_rn_.as<float>(), d, nlist, d_list_len_.as<uint32_t>(),

@@ -60,8 +60,9 @@ __device__ __forceinline__ void lmf_store_u64(u64* at, u64 v) {
 }
 
 bool ivf_lmf_supported(int kind, int d, int dpad, int M) {
-    if (dpad > 128 || (dpad & 7) || d < 1) return false;
-    if (kind == 0) return true;
+    if ((dpad & 7) || d < 1) return false;
+    if (kind == 0) return dpad <= 512; // (d > 128: one or two query blocks per item, see ivf_lmf_queries_per_item)
+    if (dpad > 128) return false;
     if (kind == 1) {
         if (M < 4 || (M & 3) || d % M) return false;
         const int dsub = d / M;
@@ -71,8 +72,17 @@ bool ivf_lmf_supported(int kind, int d, int dpad, int M) {
     }
     return false;
 }
-int ivf_lmf_queries_per_item(int) {
-    return 32 * kLmfQueryBlocks;
+// halfs per row of the fp16 shadow / the fp16 queries: d <= 128 whole 16-coordinate k-steps, beyond that whole groups of
+// 8 k-steps (zeros behind d): the sweeps' block loops then have compile-time bounds (8 / 16 / 24 / 32 k-steps)
+int ivf_lmf_row_halfs(int d) {
+    return d <= 128 ? (d + 15) / 16 * 16 : (d + 127) / 128 * 128;
+}
+// B operands of a 32-query block: d / 4 VGPRs.  Three blocks at d <= 128 (96 VGPRs), two at d <= 256, one beyond.
+static int lmf_query_blocks(int kind, int d) {
+    return kind == 1 || d <= 128 ? kLmfQueryBlocks : d <= 256 ? 2 : 1;
+}
+int ivf_lmf_queries_per_item(int kind, int d) {
+    return 32 * lmf_query_blocks(kind, d);
 }
 
 // ------------------------------------------------------------------ fp16 shadow of the IVFFlat rows (operand-major blocks)
@@ -231,9 +241,15 @@ __device__ __forceinline__ void lmf_scores(f32x16& a, const f32x4 (&rn)[4], bool
 
 // ------------------------------------------------------------------ IVFFlat sweep
 // One WAVEFRONT per work item, items drawn from a counter; A operands global -> registers one 32-row block ahead, refilled
-// right behind the MFMAs that consumed them (the walk of ivf_lm_flat_reg_kernel).  FULL: ldh == 128 (8 k-steps).
-template <int METRIC, int MODE, int NQB, bool FULL, bool SEL>
+// right behind the MFMAs that consumed them (the walk of ivf_lm_flat_reg_kernel).  KS: k-steps of a row the loops are
+// unrolled for (8: d <= 128, 16 / 24 / 32: d <= 256 / 384 / 512 with fewer query blocks per item); FULL: ldh == 16 KS.
+// The A operands wait in a ring of R pieces (a whole block at d <= 128, half a block beyond: the registers go to the B
+// operands): the shadow is operand-major, so the ring simply runs R KB ahead of the MFMAs through the k-steps of this block
+// and the next one looked at.
+template <int METRIC, int MODE, int NQB, int KS, bool FULL, bool SEL>
 __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams p) {
+    static_assert(KS == 8 || (FULL && (KS == 16 || KS == 24 || KS == 32)), "k-steps");
+    constexpr int R = KS == 8 ? 8 : KS / 2; // (KS % R == 0: slot s % R holds k-step s of the block at its start)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -241,7 +257,7 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
     const int h = lane >> 5;
     const int j = lane & 31;
     const int np = p.nprobe;
-    const int nks = FULL ? 8 : (int)(p.ldh >> 4);
+    const int nks = FULL ? KS : (int)(p.ldh >> 4);
     const int G = p.gran_blocks, gsh = __builtin_ctz((unsigned)p.gran_blocks); // (a power of two)
     const _Float16* xq16 = (const _Float16*)p.xq16;
     const _Float16* arena_h = (const _Float16*)p.arena_h;
@@ -287,7 +303,7 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
 
         // ---- this lane's queries: one per 32-query block
         LmfLane L[NQB];
-        half8 bq[NQB][8];
+        half8 bq[NQB][KS];
 #pragma unroll
         for (int b = 0; b < NQB; ++b) {
             const int my = b * 32 + j;
@@ -297,7 +313,7 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
             const int pr = (int)(pi - (uint32_t)q * (uint32_t)np);
             const _Float16* qrow = xq16 + (int64_t)q * p.ldq16 + 8 * h;
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
+            for (int s = 0; s < KS; ++s) {
                 if (FULL || s < nks) bq[b][s] = *(const half8*)(qrow + 16 * s);
                 else bq[b][s] = half8{0, 0, 0, 0, 0, 0, 0, 0};
             }
@@ -320,9 +336,9 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
             // arena's padding: loaded, never looked at.
             // (operand-major shadow: k-step s of block b is the KB at (b * nks + s) * 1024, lane l its 16-byte piece l)
             const _Float16* arow = arena_h + ((start + t) >> 5) * (int64_t)(nks * 512) + lane * 8;
-            half8 a[8];
+            half8 a[R];
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
+            for (int s = 0; s < R; ++s) {
                 if (FULL || s < nks) a[s] = *(const half8*)(arow + 512 * s);
                 else a[s] = half8{0, 0, 0, 0, 0, 0, 0, 0};
                 asm volatile("" ::: "memory");
@@ -345,6 +361,7 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
             float pf0 = rn_fetch(0), pf1 = rn_fetch(1), pf2 = rn_fetch(2), pf3 = rn_fetch(3);
             int bi = 0; // blocks of this run so far
             for (; t < r1; t += bstep, ++bi) {
+                const _Float16* acur = arow; // (KS > R: the ring refills from this block first)
                 arow += (bstep >> 5) * nks * 512;
                 if (METRIC == METRIC_L2) { // (no branch: unconditional loads keep the compiler counting them)
                     asm volatile("" ::: "memory");
@@ -370,12 +387,12 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
                 for (int g = 0; g < 4; ++g) rn[g] = f32x4{0.f, 0.f, 0.f, 0.f};
                 // (the refills are UNCONDITIONAL -- behind the last block they read the rows that follow the list)
 #pragma unroll
-                for (int s = 0; s < 8; ++s) {
+                for (int s = 0; s < KS; ++s) {
                     if (FULL || s < nks) {
 #pragma unroll
                         for (int b = 0; b < NQB; ++b)
-                            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s], bq[b][s], acc[b], 0, 0, 0);
-                        a[s] = *(const half8*)(arow + 512 * s);
+                            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s % R], bq[b][s], acc[b], 0, 0, 0);
+                        a[s % R] = s + R < KS ? *(const half8*)(acur + 512 * (s + R)) : *(const half8*)(arow + 512 * (s + R - KS));
                     }
                     if (s == 5 && METRIC == METRIC_L2) { // the block's norms from the wave's slice (rows 8 g + 4 h + e)
 #pragma unroll
@@ -383,9 +400,9 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
                     }
                 }
                 if (FULL) {
-                    // the instruction order above IS the schedule: NQB MFMAs, one load, 8 times
+                    // the instruction order above IS the schedule: NQB MFMAs, one load, KS times
 #pragma unroll
-                    for (int s = 0; s < 8; ++s) {
+                    for (int s = 0; s < KS; ++s) {
                         __builtin_amdgcn_sched_group_barrier(0x008, NQB, 0); // MFMA
                         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
                     }
@@ -819,19 +836,20 @@ int ivf_lmf_grid_blocks(const IvfLmParams& p, int num_cus) {
 }
 template <int METRIC, int MODE, bool SEL>
 static void lmf_flat_launch(const IvfLmParams& p, int grid_blocks, hipStream_t stream) {
-    constexpr int NQB = kLmfQueryBlocks;
     const int lds = MODE == MODE_COLLECT ? LF_LDS : 0;
-    if (p.ldh == 128) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)ivf_lmf_flat_kernel<METRIC, MODE, NQB, true, SEL>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, LF_LDS));
-        hipLaunchKernelGGL((ivf_lmf_flat_kernel<METRIC, MODE, NQB, true, SEL>), dim3((unsigned)grid_blocks), dim3(LF_THREADS), lds,
-                           stream, p);
-    } else {
-        HIP_CHECK(hipFuncSetAttribute((const void*)ivf_lmf_flat_kernel<METRIC, MODE, NQB, false, SEL>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, LF_LDS));
-        hipLaunchKernelGGL((ivf_lmf_flat_kernel<METRIC, MODE, NQB, false, SEL>), dim3((unsigned)grid_blocks), dim3(LF_THREADS), lds,
-                           stream, p);
-    }
+#define FA_LF(NQB_, KS_, FULL_)                                                                                                \
+    do {                                                                                                                       \
+        HIP_CHECK(hipFuncSetAttribute((const void*)ivf_lmf_flat_kernel<METRIC, MODE, NQB_, KS_, FULL_, SEL>,                   \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, LF_LDS));                                    \
+        hipLaunchKernelGGL((ivf_lmf_flat_kernel<METRIC, MODE, NQB_, KS_, FULL_, SEL>), dim3((unsigned)grid_blocks),            \
+                           dim3(LF_THREADS), lds, stream, p);                                                                  \
+    } while (0)
+    if (p.ldh == 128) FA_LF(kLmfQueryBlocks, 8, true);
+    else if (p.ldh < 128) FA_LF(kLmfQueryBlocks, 8, false);
+    else if (p.ldh == 256) FA_LF(2, 16, true);
+    else if (p.ldh == 384) FA_LF(1, 24, true);
+    else FA_LF(1, 32, true);
+#undef FA_LF
 }
 template <int METRIC, int MODE, bool SEL>
 static void lmf_pq_launch(const IvfLmParams& p, int grid_blocks, hipStream_t stream) {
@@ -874,10 +892,11 @@ void launch_ivf_lmf_sweep(const IvfLmParams& p, int mode, int grid_blocks, hipSt
     if (p.nq == 0) return;
     FA_THROW_IF_NOT(p.filter && ivf_lmf_supported(p.kind, p.d, p.dpad, p.M) && mode >= 1 && mode <= 3 && grid_blocks > 0);
     FA_THROW_IF_NOT(p.min_stride >= 1 && p.min_stride <= 8);
-    FA_THROW_IF_NOT(p.qpi == 32 * kLmfQueryBlocks && p.nq < (1 << 21) && p.nprobe <= 2048 && p.gran_blocks >= 1 &&
-                    (p.gran_blocks & (p.gran_blocks - 1)) == 0);
+    FA_THROW_IF_NOT(p.qpi == ivf_lmf_queries_per_item(p.kind, p.d) && p.nq < (1 << 21) && p.nprobe <= 2048 &&
+                    p.gran_blocks >= 1 && (p.gran_blocks & (p.gran_blocks - 1)) == 0);
     if (p.kind == 0) {
-        FA_THROW_IF_NOT(p.xq16 && p.arena_h && p.ldh % 16 == 0 && p.ldh <= 128 && p.ldq16 >= p.ldh && p.ldq16 % 8 == 0);
+        FA_THROW_IF_NOT(p.xq16 && p.arena_h && p.ldh == ivf_lmf_row_halfs(p.d) && p.ldh <= 512 && p.ldq16 >= p.ldh &&
+                        p.ldq16 % 8 == 0);
         FA_THROW_IF_NOT(p.metric != METRIC_L2 || (p.arena_rn && p.xqn));
     } else {
         FA_THROW_IF_NOT(p.pq16 && p.arena_cs && p.cs_bpl > 0 && (p.cs_piece == 4 || p.cs_piece == 16) && p.centroids &&

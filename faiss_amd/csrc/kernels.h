@@ -520,7 +520,8 @@ __host__ __device__ static inline float ivf_filter_err_bound(int metric, int d, 
 }
 constexpr int kLmfQueryBlocks = 3;  // 32-query MFMA blocks per work item of the filter sweeps (B operands: 32 VGPRs each)
 bool ivf_lmf_supported(int kind, int d, int dpad, int M);
-int ivf_lmf_queries_per_item(int kind);
+int ivf_lmf_queries_per_item(int kind, int d);
+int ivf_lmf_row_halfs(int d); // halfs per row of the IVFFlat fp16 shadow and of the fp16 queries
 int ivf_lmf_grid_blocks(const IvfLmParams& p, int num_cus);
 // mode 1: granule minima -> gmin; mode 2: collect (keys / cand_pr / cnt); mode 3 (tests): every estimate as a key at its
 // scan position (keys [nq][stride], stride >= rows probed)

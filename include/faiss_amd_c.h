@@ -424,10 +424,12 @@ int faiss_amd_GpuIndexIVF_set_use_fused_scan(FaissAmdIndex* index, int on);
 
 /* Which scan serves search() / search_preassigned() of an IVF index (no reference counterpart: the reference has one
  * scan per index type, faiss/gpu/impl/IVFInterleaved.cuh:33-224, PQScanMultiPassNoPrecomputed-inl.cuh:173-270, both
- * query-major).  0 = automatic: batches of >= 2048 queries that probe every list >= 8 times on average, without
- * IDSelector, on IVFFlat / IVFPQ / IVF scalar-quantizer indexes with d <= 128 take the list-major scan (every list is
- * read once per group of the queries probing it); 1 = query-major always; 2 = list-major always (an error where
- * unsupported); 3 = list-major on the f32 matrix pipe (round 3's scan, faiss_amd/csrc/ivf_listmajor.hip).
+ * query-major).  0 = automatic: the measured rule of GpuIndexIVF::list_major_rule -- batches that
+ * probe every list >= 8 times on average and whose query-major scan would stream more than ~3 GB (IVFFlat, d <= 512) /
+ * ~3.5 GB of codes (IVFPQ, d <= 128), the scalar quantizer (d <= 128) from 2048 queries on, take the list-major scan
+ * (every list is read once per group of the queries probing it); 1 = query-major always; 2 = list-major always (an
+ * error where unsupported); 3 = list-major on the f32 matrix pipe (round 3's scan, faiss_amd/csrc/ivf_listmajor.hip,
+ * d <= 128, no IDSelector).
  * IVFFlat / IVFPQ (round 4): the list-major scan runs behind an f16 MFMA filter with a rigorous error band and
  * re-derives the survivors with the arithmetic of the query-major scan (faiss_amd/csrc/ivf_lm_filter.hip): a query
  * returns THE SAME BITS whatever the batch size, the shard / replica split or the paging of the call.  The scalar

@@ -58,8 +58,18 @@ def _build(res, kind, metric, d, M, nlist, xt, xb, seed=7):
     (1, METRIC_L2, 96, 48, 16, 12000, 700, 6, 30),              # three 16-byte pieces per stored row (lane pairs 2 + 1)
     (1, METRIC_INNER_PRODUCT, 80, 80, 8, 9000, 300, 4, 40),     # five pieces: staged byte by byte; dsub = 1
     (1, METRIC_L2, 120, 60, 16, 8000, 520, 5, 64),              # dpad = 120 < 128, M % 16 != 0 (4-byte pieces), dsub = 2
+    # d > 128 (round 4, filter scan only): 16 / 24 / 32 k-steps per row, two or one query block per work item
+    (0, METRIC_L2, 256, 0, 32, 20000, 900, 8, 50),
+    (0, METRIC_INNER_PRODUCT, 200, 0, 16, 8000, 300, 4, 20),    # shadow rows padded to 256 halfs
+    (0, METRIC_L2, 136, 0, 16, 9000, 700, 5, 100),
+    (0, METRIC_L2, 384, 0, 16, 8000, 500, 6, 100),
+    (0, METRIC_INNER_PRODUCT, 300, 0, 8, 6000, 200, 3, 1000),   # padded to 384
+    (0, METRIC_L2, 512, 0, 16, 6000, 300, 4, 10),
+    (0, METRIC_L2, 420, 0, 8, 12000, 640, 2, 30),               # padded to 512, lists of ~1500 rows
 ])
 def test_list_major_scan_matches_oracle_and_query_major(res, lm_mode, kind, metric, d, M, nlist, nb, nq, nprobe, k):
+    if d > 128 and lm_mode == 3:
+        pytest.skip("the f32 list-major scan serves d <= 128")
     xt, xb, xq = synthetic_dataset(d, 4000, nb, nq, seed=nb + k)
     idx, cent, pq = _build(res, kind, metric, d, M, nlist, xt, xb)
     idx.nprobe = nprobe
@@ -182,7 +192,7 @@ def test_scan_mode_rule_and_refusals(res):
     idx.nprobe = 8
     assert idx.scan_info()[0] == 0
     # the rule (profiles/r04_i_scan_rule_sweep.txt): every list meets >= 8 queries of the batch, and the bytes the
-    # query-major scan would stream (queries x probes x rows per list x bytes per row) exceed ~3 GB (IVFFlat) / ~6 GB
+    # query-major scan would stream (queries x probes x rows per list x bytes per row) exceed ~3 GB (IVFFlat) / ~3.5 GB
     # (IVFPQ): a small index like this one (8000 rows of 128 bytes) stays query-major for any batch but a huge one.  A query
     # must also probe >= ~1.1 k granules of 16 rows, or the k-th best granule estimate bounds nothing (k = 100 of 1000 rows)
     assert not idx.list_major_rule(2100, 8, 10) and idx.list_major_rule(100000, 64, 10)
@@ -203,7 +213,7 @@ def test_scan_mode_rule_and_refusals(res):
     assert big.scan_info()[1] == 2 and big.last_scan_arith() == 0
     Ds, Is = big.search(xq2[:20], 10)
     assert big.scan_info()[1] == 1 and np.array_equal(Ds, Db[:20]) and np.array_equal(Is, Ib[:20])
-    # IVFPQ: lists of >= 128 rows and ~6 GB of code bytes
+    # IVFPQ: lists of >= 128 rows and ~3.5 GB of code bytes
     pq, _, _ = _build(res, 1, METRIC_L2, d2, 16, nlist, xt2, xb2)
     pq.nprobe = 16
     assert not pq.list_major_rule(2100, 16, 10) and pq.list_major_rule(2100, 64, 10)
@@ -220,12 +230,23 @@ def test_scan_mode_rule_and_refusals(res):
     idx.set_scan_mode(idx.SCAN_LIST_MAJOR)  # (behind the filter the list-major scan serves selector searches)
     idx.search(xq[:10], 5, params=faiss_amd.SearchParameters(sel=faiss_amd.IDSelectorRange(0, 100)))
     assert idx.scan_info()[1] == 2
-    big = faiss_amd.GpuIndexIVFFlat(res, 136, 8, METRIC_L2)  # d > 128: not served by the list-major kernel
-    big.set_scan_mode(big.SCAN_LIST_MAJOR)
-    big.copy_centroids(np.random.RandomState(0).rand(8, 136).astype("float32"))
-    big.add(np.random.RandomState(1).rand(100, 136).astype("float32"))
+    # d > 128: IVFFlat behind the filter up to d = 512, the f32 scan not at all
+    for dbig, modes_refused in ((136, (idx.SCAN_LIST_MAJOR_F32,)), (520, (idx.SCAN_LIST_MAJOR, idx.SCAN_LIST_MAJOR_F32))):
+        big = faiss_amd.GpuIndexIVFFlat(res, dbig, 8, METRIC_L2)
+        big.copy_centroids(np.random.RandomState(0).rand(8, dbig).astype("float32"))
+        big.add(np.random.RandomState(1).rand(100, dbig).astype("float32"))
+        assert not big.list_major_rule(10, 8, 2)
+        for m in modes_refused:
+            big.set_scan_mode(m)
+            with pytest.raises(faiss_amd.FaissAmdError, match="not supported"):
+                big.search(np.zeros((3, dbig), "float32"), 2)
+    pq_big = faiss_amd.GpuIndexIVFPQ(res, 256, 8, 32, 8, METRIC_L2)  # IVFPQ: d <= 128
+    pq_big.set_scan_mode(pq_big.SCAN_LIST_MAJOR)
+    xs = np.random.RandomState(2).rand(3000, 256).astype("float32")
+    pq_big.train(xs)
+    pq_big.add(xs[:500])
     with pytest.raises(faiss_amd.FaissAmdError, match="not supported"):
-        big.search(np.zeros((3, 136), "float32"), 2)
+        pq_big.search(xs[:3], 2)
 
 
 @pytest.mark.parametrize("kind", [0, 1])
@@ -284,12 +305,12 @@ def test_list_major_many_equal_distances(res, lm_mode, k):
     assert len(np.unique(D[0])) < max(2, k // 2) or k == 1  # the data really ties
 
 
-@pytest.mark.parametrize("kind", [0, 1])
-def test_results_do_not_depend_on_the_batch_size(res, kind):
+@pytest.mark.parametrize("kind,d", [(0, 64), (1, 64), (0, 256)])
+def test_results_do_not_depend_on_the_batch_size(res, kind, d):
     """the automatic rule sends large batches through the list-major scan.  Behind the f16 filter that
     scan returns the bits of the query-major scan, so a query's distances and labels are the same whatever batch it
     arrives in (and therefore under IndexShards / IndexReplicas query splits and the paged host path)."""
-    d, nlist, M, k = 64, 64, 32, 40
+    nlist, M, k = 64, 32, 40
     xt, xb, xq = synthetic_dataset(d, 4000, 60000, 2048, seed=31)
     idx, _, _ = _build(res, kind, METRIC_L2, d, M, nlist, xt, xb)
     idx.nprobe = 16
@@ -343,6 +364,7 @@ def test_list_major_near_duplicates_and_self_search(res, lm_mode):
     (0, METRIC_L2, 128, 0, 1.0), (0, METRIC_INNER_PRODUCT, 128, 0, 1.0), (0, METRIC_L2, 40, 0, 1.0),
     (0, METRIC_L2, 128, 0, 200.0),           # large values: the band scales with |q| |y|
     (0, METRIC_L2, 64, 0, 1e-3),             # small values (fp16 denormals in play)
+    (0, METRIC_L2, 256, 0, 1.0), (0, METRIC_INNER_PRODUCT, 300, 0, 1.0), (0, METRIC_L2, 512, 0, 1.0),  # d > 128
     (1, METRIC_L2, 128, 64, 1.0), (1, METRIC_INNER_PRODUCT, 128, 64, 1.0), (1, METRIC_L2, 64, 16, 1.0),
     (1, METRIC_L2, 96, 12, 1.0), (1, METRIC_L2, 32, 32, 1.0), (1, METRIC_L2, 128, 64, 50.0),
 ])
