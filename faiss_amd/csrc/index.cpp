@@ -2323,7 +2323,9 @@ bool GpuIndexIVF::list_major_rule(idx_t n, int nprobe_now, idx_t k, bool has_sel
     // ... 10 000 queries at nb = 1M, both index types).  The query-major scan is bound by the bytes it streams -- queries x
     // probes x rows per list x bytes per row at ~6 TB/s (IVFFlat) / ~5 TB/s (IVFPQ) on top of 0.1-0.2 ms --, the list-major
     // scan costs 0.4-0.6 ms whatever the batch (plan, two sweeps, bound, rerank, select) and grows slowly from there: it
-    // wins once the query-major stream exceeds ~3 GB (IVFFlat: 512 queries x 128 probes already, 6.4 x faster) / ~3.5 GB of
+    // wins once the query-major stream exceeds ~2 GB (IVFFlat: 512 queries x 128 probes already, 6.4 x faster; short lists too
+    // -- nlist 16384 at nb = 1M, 61 rows per list: 5.4 x at 10 000 queries x 128 probes; against the sweep the rule is off by
+    // more than 10 % in 2 of 45 cases, both at 512 queries where condition (a) keeps a 14-23 % faster list-major out) / ~3.5 GB of
     // code bytes (IVFPQ, profiles/r04_k_ivfpq_rule_sweep.txt: at 4.1 GB list-major is 1.14-1.20 x faster, at 2.05 GB 4-16 %
     // slower; its lists must also be long enough to amortise an item's set-up: nlist 16384 at nb = 1M -- 61 rows per list --
     // never wins).
@@ -2331,7 +2333,7 @@ bool GpuIndexIVF::list_major_rule(idx_t n, int nprobe_now, idx_t k, bool has_sel
     // the bound is the k-th best of the query's granule minima (16 rows each): a query that probes fewer than ~1.1 k granules
     // gets no bound and is redone query-major (bench sweep, nprobe 4 at nb = 1M: 61 granules for k = 100 -- 3.5 ms, all redone)
     if ((double)np * avg_len < 18.0 * (double)k) return false;
-    if (fused_kind_() == 0) return (double)nstored_ >= 64.0 * (double)nlist && stream >= 3.0e9;
+    if (fused_kind_() == 0) return stream >= 2.0e9;
     return avg_len >= 128.0 && stream >= 3.5e9;
 }
 

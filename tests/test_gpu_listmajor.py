@@ -192,7 +192,7 @@ def test_scan_mode_rule_and_refusals(res):
     idx.nprobe = 8
     assert idx.scan_info()[0] == 0
     # the rule (profiles/r04_i_scan_rule_sweep.txt): every list meets >= 8 queries of the batch, and the bytes the
-    # query-major scan would stream (queries x probes x rows per list x bytes per row) exceed ~3 GB (IVFFlat) / ~3.5 GB
+    # query-major scan would stream (queries x probes x rows per list x bytes per row) exceed ~2 GB (IVFFlat) / ~3.5 GB
     # (IVFPQ): a small index like this one (8000 rows of 128 bytes) stays query-major for any batch but a huge one.  A query
     # must also probe >= ~1.1 k granules of 16 rows, or the k-th best granule estimate bounds nothing (k = 100 of 1000 rows)
     assert not idx.list_major_rule(2100, 8, 10) and idx.list_major_rule(100000, 64, 10)
