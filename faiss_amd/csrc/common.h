@@ -101,6 +101,25 @@ static inline size_t div_up(size_t x, size_t m) {
 // heap, faiss/utils/ordered_key_value.h:74-76 + faiss/impl/ResultHandler.h:276-281).
 // -0.0f is canonicalised to +0.0f.
 // ---------------------------------------------------------------------------------
+#if defined(__HIPCC__)
+// Inclusive prefix sum over the 64 lanes of a wavefront -- ALL lanes active (call it from wave-uniform control flow).  Six
+// DPP adds: row_shr 1 / 2 / 4 / 8 inside the 16-lane rows (lanes the shift leaves without a source read 0), then row_bcast 15
+// into rows 1 and 3 and row_bcast 31 into rows 2 and 3.  The __shfl_up ladder it replaces is six ds_bpermute round trips
+// through the LDS crossbar (~100 cycles each, serialised by lgkmcnt(0)): the candidate parking of the list-major sweeps
+// runs one scan per (32-row block, 32-query block) that holds a candidate -- nearly all of them at nb <= 10M.
+// tools/dpp_scan_probe.hip checks it against the shuffle ladder on the device.
+__device__ __forceinline__ unsigned wave_incl_scan(unsigned v) {
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true); // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true); // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true); // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true); // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false); // row_bcast:15 -> rows 1, 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false); // row_bcast:31 -> rows 2, 3
+    return (unsigned)x;
+}
+#endif
+
 __host__ __device__ static inline uint32_t float_flip(float f) {
     union {
         float f;

@@ -856,12 +856,7 @@ __global__ void __launch_bounds__(LM_THREADS, KIND == 1 ? 3 : 2) ivf_lm_scan_ker
                     if (__ballot(mask != 0u)) {
                         // (wave-uniform branch) park the candidates: this lane's go behind those of the lanes before it
                         const int c = __popc(mask);
-                        int inc = c; // inclusive scan over the lanes
-#pragma unroll
-                        for (int off = 1; off < 64; off <<= 1) {
-                            const int o = __shfl_up(inc, off, 64);
-                            if (lane >= off) inc += o;
-                        }
+                        const int inc = (int)wave_incl_scan((unsigned)c); // inclusive scan over the lanes (DPP, common.h)
                         const int total = __builtin_amdgcn_readlane(inc, 63);
                         if (total > LM_PARK) {
                             // more candidates in one 32-row block than a slice holds (a bound that admits everything):
@@ -1199,12 +1194,7 @@ __global__ void __launch_bounds__(LR_THREADS, LrCfg<CT>::WG_PER_CU) ivf_lm_flat_
                 if (__ballot(mask != 0u)) {
                     // (wave-uniform branch) park the candidates: this lane's go behind those of the lanes before it
                     const int c = __popc(mask);
-                    int inc = c; // inclusive scan over the lanes
-#pragma unroll
-                    for (int off = 1; off < 64; off <<= 1) {
-                        const int o = __shfl_up(inc, off, 64);
-                        if (lane >= off) inc += o;
-                    }
+                    const int inc = (int)wave_incl_scan((unsigned)c); // inclusive scan over the lanes (DPP, common.h)
                     const int total = __builtin_amdgcn_readlane(inc, 63);
                     if (wcnt + total > LR_PARK) {
                         full = true; // (block t is redone after the flush: its candidates were not parked)
@@ -1586,12 +1576,7 @@ __global__ void __launch_bounds__(LQ_THREADS, 2) ivf_lm_pq_kernel(IvfLmParams p)
                     if (!qv[b] || (p.dbg & 1)) mask = 0;
                     if (__ballot(mask != 0u)) {
                         const int c = __popc(mask);
-                        int inc = c;
-#pragma unroll
-                        for (int off = 1; off < 64; off <<= 1) {
-                            const int o = __shfl_up(inc, off, 64);
-                            if (lane >= off) inc += o;
-                        }
+                        const int inc = (int)wave_incl_scan((unsigned)c); // inclusive scan over the lanes (DPP, common.h)
                         const int total = __builtin_amdgcn_readlane(inc, 63);
                         if (total > LQ_PARK) {
                             if (mask) {

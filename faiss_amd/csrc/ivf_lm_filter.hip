@@ -33,6 +33,7 @@ namespace faiss_amd {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned long long u64;
@@ -223,17 +224,29 @@ __device__ __forceinline__ float lmf_lane_max(const f32x16& a) { // 8 instructio
 // IDSelector bits of the lane's rows (bit 8 g + e), SEL only.
 template <int METRIC, bool SEL>
 __device__ __forceinline__ void lmf_scores(f32x16& a, const f32x4 (&rn)[4], bool tail, int row_b, int r1, uint32_t mw) {
+    if (METRIC == METRIC_L2) {
+        // two accumulators per v_pk_fma_f32 (asked for explicitly: left to itself hipcc emits 16 v_fma_f32 in some
+        // instantiations and 8 packed ones in others)
+        const f32x2 mh = f32x2{-0.5f, -0.5f};
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (METRIC == METRIC_L2) a[4 * g + e] = __fmaf_rn(-0.5f, rn[g][e], a[4 * g + e]);
-    if (tail || SEL) { // (wave-uniform)
+            for (int e = 0; e < 4; e += 2) {
+                const f32x2 r2 = f32x2{rn[g][e], rn[g][e + 1]};
+                f32x2 a2 = f32x2{a[4 * g + e], a[4 * g + e + 1]};
+                a2 = __builtin_elementwise_fma(mh, r2, a2);
+                a[4 * g + e] = a2[0];
+                a[4 * g + e + 1] = a2[1];
+            }
+    }
+    // L2: rows behind the end of the chunk arrive with |y'|^2 = +inf (rn_fetch of the sweeps), so they are -inf already --
+    // the 16 row tests hipcc hoisted out of the `tail` branch cost every block 32 VALU instructions.
+    if ((tail && METRIC != METRIC_L2) || SEL) { // (wave-uniform)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const bool ok = !(tail && row_b + 8 * g + e >= r1) && (!SEL || ((mw >> (8 * g + e)) & 1u));
+                const bool ok = !(METRIC != METRIC_L2 && tail && row_b + 8 * g + e >= r1) && (!SEL || ((mw >> (8 * g + e)) & 1u));
                 a[4 * g + e] = ok ? a[4 * g + e] : -INFINITY;
             }
     }
@@ -355,8 +368,11 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
             // as four broadcast ds_read_b128.
             const int tb = t; // first block of this run (runs restart behind a flush)
             auto rn_fetch = [&](int blk) __attribute__((always_inline)) -> float {
-                const int row = min(tb + blk * bstep + (lane & 31), r1 - 1); // (rows >= r1 are never used)
-                return METRIC == METRIC_L2 ? p.arena_rn[start + row] : 0.f;
+                // (the load stays unconditional; rows behind the chunk get |y|^2 = +inf: their scores become -inf by themselves)
+                const int row = tb + blk * bstep + (lane & 31);
+                if (METRIC != METRIC_L2) return 0.f;
+                const float v = p.arena_rn[start + min(row, r1 - 1)];
+                return row < r1 ? v : INFINITY;
             };
             float pf0 = rn_fetch(0), pf1 = rn_fetch(1), pf2 = rn_fetch(2), pf3 = rn_fetch(3);
             int bi = 0; // blocks of this run so far
@@ -412,7 +428,10 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
 #pragma unroll
                     for (int b = 0; b < NQB; ++b) {
                         lmf_scores<METRIC, SEL>(acc[b], rn, tail, row_b, r1, mw);
-                        L[b].gm = fmaxf(L[b].gm, lmf_lane_max(acc[b]));
+                        {
+                        const float lm = lmf_lane_max(acc[b]);
+                        L[b].gm = lmf_max3(L[b].gm, lm, lm); // (no canonicalising v_max x, x around it)
+                    }
                     }
                     const int blk = t >> 5;
                     // (wave-uniform) the granule ends with this block: the next block looked at lies in another one
@@ -446,19 +465,18 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
                         if (b < skip_b) continue;
                         lmf_scores<METRIC, SEL>(acc[b], rn, tail, row_b, r1, mw);
                         if (!__ballot(lmf_lane_max(acc[b]) >= L[b].tq)) continue; // (wave-uniform)
+                        // (opaque copy: hipcc otherwise computes the 16 row tests of the first query block ABOVE the branch,
+                        // ~55 VALU instructions for every block of every item)
+                        float tqv = L[b].tq;
+                        asm volatile("" : "+v"(tqv));
                         unsigned mask = 0;
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
-                            mask |= (acc[b][r] >= L[b].tq && acc[b][r] > -INFINITY) ? 1u << r : 0u;
+                            mask |= (acc[b][r] >= tqv && acc[b][r] > -INFINITY) ? 1u << r : 0u;
                         if (!__ballot(mask != 0u)) continue;
                         // park the candidates: this lane's go behind those of the lanes before it
                         const int c = __popc(mask);
-                        int inc = c;
-#pragma unroll
-                        for (int off = 1; off < 64; off <<= 1) {
-                            const int o = __shfl_up(inc, off, 64);
-                            if (lane >= off) inc += o;
-                        }
+                        const int inc = (int)wave_incl_scan((unsigned)c);
                         const int total = __builtin_amdgcn_readlane(inc, 63);
                         if (wcnt + total > LF_PARK) {
                             full = true; // block t is redone after the flush, from query block b on
@@ -499,6 +517,7 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
 constexpr int LP_THREADS = 512;
 constexpr int LP_BR = 32;    // rows per block
 constexpr int LP_PARK = 256; // parked candidates per wave
+constexpr int LP_AHEAD = 3;  // k-steps the codebook gathers run ahead of the MFMAs (ring of 4 operands)
 struct LpLayout {
     int cb_bytes, off_park, total;
 };
@@ -617,8 +636,10 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
         // row norms: register ring -> LDS slice -> broadcast reads, as in the flat kernel
         // (one value per lane and block: lane l fetches row l & 31 of the block four blocks ahead -- both halves the same)
         auto rn_fetch = [&](int blk) __attribute__((always_inline)) -> float {
-            const int row = min(r0 + blk * bstep + (lane & 31), r1 - 1);
-            return METRIC == METRIC_L2 ? p.arena_rn[start + row] : 0.f;
+            const int row = r0 + blk * bstep + (lane & 31);
+            if (METRIC != METRIC_L2) return 0.f;
+            const float v = p.arena_rn[start + min(row, r1 - 1)];
+            return row < r1 ? v : INFINITY; // (rows behind the chunk: scores of -inf without a test in the epilogue)
         };
         float pf0 = rn_fetch(0), pf1 = rn_fetch(1), pf2 = rn_fetch(2), pf3 = rn_fetch(3);
 
@@ -674,7 +695,44 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
             if (MODE == MODE_DUMP) L[b].kq = p.keys + (int64_t)q * p.stride + L[b].base_pos;
         }
 
+        // the A operand of k-step s: coordinates 16 s + 8 h .. + 7 of this lane's row, gathered from the codebook by
+        // the code bytes in cw
+        auto operand_of = [&](const unsigned (&cw)[ND], int s_) __attribute__((always_inline)) -> half8 {
+            half8 a = half8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (!FULLK && s_ >= nks) return a;
+            const int kb = 16 * s_ + 8 * h; // first coordinate
+            if (DS == 8) {
+                const int m = kb / dsub, off = kb - m * dsub;
+                const unsigned c = (cw[s_ >> 2] >> (8 * (s_ & 3))) & 255u;
+                a = *(const half8*)(cb + ((m << 8) + (int)c) * dsub + off);
+            } else if (DS == 4) {
+                const unsigned c2 = (cw[s_ >> 1] >> (16 * (s_ & 1))) & 0xffffu;
+                const int m0 = kb >> 2;
+                const half4v lo = *(const half4v*)(cb + ((m0 << 8) + (int)(c2 & 255u)) * 4);
+                const half4v hi = *(const half4v*)(cb + (((m0 + 1) << 8) + (int)(c2 >> 8)) * 4);
+                a = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            } else if (DS == 2) {
+                const unsigned c4 = cw[s_];
+                const int m0 = kb >> 1;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const half2v v = *(const half2v*)(cb + (((m0 + u) << 8) + (int)((c4 >> (8 * u)) & 255u)) * 2);
+                    a[2 * u] = v[0];
+                    a[2 * u + 1] = v[1];
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const unsigned c = (cw[2 * s_ + (u >> 2)] >> (8 * (u & 3))) & 255u;
+                    a[u] = cb[((kb + u) << 8) + (int)c];
+                }
+            }
+            return a;
+        };
         int bi = 0;
+        half8 av[4]; // ring of decoded A operands (k-step s in slot s % 4)
+#pragma unroll
+        for (int s = 0; s < LP_AHEAD; ++s) av[s] = operand_of(cw, s);
         for (int t = r0; t < r1; t += bstep, ++bi) {
             if (METRIC == METRIC_L2) {
                 asm volatile("" ::: "memory");
@@ -685,40 +743,6 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
             }
-            // the A operand of k-step s: coordinates 16 s + 8 h .. + 7 of this lane's row, gathered from the codebook by
-            // the code bytes in cw
-            auto operand_of = [&](int s_) __attribute__((always_inline)) -> half8 {
-                half8 a = half8{0, 0, 0, 0, 0, 0, 0, 0};
-                if (!FULLK && s_ >= nks) return a;
-                const int kb = 16 * s_ + 8 * h; // first coordinate
-                if (DS == 8) {
-                    const int m = kb / dsub, off = kb - m * dsub;
-                    const unsigned c = (cw[s_ >> 2] >> (8 * (s_ & 3))) & 255u;
-                    a = *(const half8*)(cb + ((m << 8) + (int)c) * dsub + off);
-                } else if (DS == 4) {
-                    const unsigned c2 = (cw[s_ >> 1] >> (16 * (s_ & 1))) & 0xffffu;
-                    const int m0 = kb >> 2;
-                    const half4v lo = *(const half4v*)(cb + ((m0 << 8) + (int)(c2 & 255u)) * 4);
-                    const half4v hi = *(const half4v*)(cb + (((m0 + 1) << 8) + (int)(c2 >> 8)) * 4);
-                    a = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                } else if (DS == 2) {
-                    const unsigned c4 = cw[s_];
-                    const int m0 = kb >> 1;
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const half2v v = *(const half2v*)(cb + (((m0 + u) << 8) + (int)((c4 >> (8 * u)) & 255u)) * 2);
-                        a[2 * u] = v[0];
-                        a[2 * u + 1] = v[1];
-                    }
-                } else {
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const unsigned c = (cw[2 * s_ + (u >> 2)] >> (8 * (u & 3))) & 255u;
-                        a[u] = cb[((kb + u) << 8) + (int)c];
-                    }
-                }
-                return a;
-            };
             const int row_b = t + 4 * h;
             const bool tail = t + 32 > r1;
             const uint32_t mw = SEL ? p.sel_mask[(start + t) >> 5] >> (4 * h) : 0u; // IDSelector bits of the block's rows
@@ -730,14 +754,15 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
             f32x4 rn[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) rn[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-            // software pipeline: gathers of k-step s + 2 | MFMAs of k-step s (one k-step ahead the gathers of a step had only
-            // the 3 MFMAs of the step before -- ~100 cycles -- to come back from an LDS all eight wavefronts gather from)
-            half8 av[3];
-            av[0] = operand_of(0);
-            av[1] = operand_of(1);
+            // software pipeline: gathers of k-step s + LP_AHEAD | MFMAs of k-step s (one k-step ahead the gathers of a step
+            // had only the 3 MFMAs of the step before -- ~100 cycles -- to come back from an LDS all eight wavefronts gather
+            // from).  The pipeline runs ACROSS blocks: the last k-steps of a block gather the first operands of the next
+            // block looked at (its code bytes wait in cn), so that a block does not open with LP_AHEAD exposed LDS latencies
+            // and the epilogue runs with gathers in flight.
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
-                if (s + 2 < 8) av[(s + 2) % 3] = operand_of(s + 2);
+                if (s + LP_AHEAD < 8) av[(s + LP_AHEAD) % 4] = operand_of(cw, s + LP_AHEAD);
+                else av[(s + LP_AHEAD) % 4] = operand_of(cn, s + LP_AHEAD - 8);
                 if (s == 1) fetch(min(t + 2 * bstep, tlast), cn2);
                 if (s == 5 && METRIC == METRIC_L2) { // |r^|^2 of the block's rows (lane: rows 8 g + 4 h + e) from the wave's slice
 #pragma unroll
@@ -747,7 +772,7 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
                 if (FULLK || s < nks) {
 #pragma unroll
                     for (int b = 0; b < NB; ++b)
-                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s % 3], bq[b][s], acc[b], 0, 0, 0);
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s % 4], bq[b][s], acc[b], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -755,7 +780,10 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
                     lmf_scores<METRIC, SEL>(acc[b], rn, tail, row_b, r1, mw);
-                    L[b].gm = fmaxf(L[b].gm, lmf_lane_max(acc[b]));
+                    {
+                        const float lm = lmf_lane_max(acc[b]);
+                        L[b].gm = lmf_max3(L[b].gm, lm, lm); // (no canonicalising v_max x, x around it)
+                    }
                 }
                 const int blk = t >> 5;
                 if ((((t + bstep) >> 5) >> gsh) != (blk >> gsh) || t + bstep >= r1) {
@@ -785,9 +813,11 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
                     // ---- does any of this lane's 16 scores of query block b reach its query's threshold?
                     lmf_scores<METRIC, SEL>(acc[b], rn, tail, row_b, r1, mw);
                     if (!__ballot(lmf_lane_max(acc[b]) >= L[b].tq)) continue; // (wave-uniform)
+                    float tqv = L[b].tq; // (opaque copy: keeps the 16 row tests below the branch, see the flat kernel)
+                    asm volatile("" : "+v"(tqv));
                     unsigned mask = 0;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) mask |= (acc[b][r] >= L[b].tq && acc[b][r] > -INFINITY) ? 1u << r : 0u;
+                    for (int r = 0; r < 16; ++r) mask |= (acc[b][r] >= tqv && acc[b][r] > -INFINITY) ? 1u << r : 0u;
                     if (!__ballot(mask != 0u)) continue;
                     // park the candidates row group by row group (8 g + 4 h + e, g = 0 .. 3): a group holds at most
                     // 4 x 64 = LP_PARK candidates, so it always fits an empty slice
@@ -796,12 +826,7 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
                         const unsigned mg = (mask >> (4 * g)) & 15u;
                         if (!__ballot(mg != 0u)) continue;
                         const int c = __popc(mg);
-                        int inc = c;
-#pragma unroll
-                        for (int off = 1; off < 64; off <<= 1) {
-                            const int o = __shfl_up(inc, off, 64);
-                            if (lane >= off) inc += o;
-                        }
+                        const int inc = (int)wave_incl_scan((unsigned)c);
                         const int total = __builtin_amdgcn_readlane(inc, 63);
                         if (wcnt + total > LP_PARK) flush();
                         int at = wcnt + inc - c;
@@ -955,12 +980,7 @@ __global__ void __launch_bounds__(256) lmf_bound_kernel(IvfLmParams p, const flo
                 c[u] = hist[4 * tid + u];
                 sum += c[u];
             }
-            uint32_t inc = sum;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t o = __shfl_up(inc, off, 64);
-                if (tid >= off) inc += o;
-            }
+            const uint32_t inc = wave_incl_scan(sum);
             uint32_t before = inc - sum;
             const uint32_t need = sel_need;
 #pragma unroll

@@ -87,13 +87,8 @@ __global__ void __launch_bounds__(SEL_THREADS) select_k_kernel(SelectParams p) {
             // time on the ~2000-key segments of the list-major IVF scan)
             const unsigned v = sh->hist[tid];
             {
-                unsigned inc = v;
+                unsigned inc = wave_incl_scan(v);
                 const int ln = tid & 63;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const unsigned o = __shfl_up(inc, off, 64);
-                    if (ln >= off) inc += o;
-                }
                 if (ln == 63) sh->wsum[tid >> 6] = inc;
                 __syncthreads();
                 for (int w = 0; w < (tid >> 6); ++w) inc += sh->wsum[w];
@@ -351,12 +346,7 @@ __global__ void __launch_bounds__(256) wave_select_kernel(SelectParams p, int kp
     // slots of this lane's winners: exclusive scan of the per-lane counts
     unsigned mine = 0;
     for_keys([&](unsigned h, unsigned l) { mine += wins(h, l) ? 1u : 0u; });
-    unsigned inc = mine;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const unsigned o = __shfl_up(inc, off, 64);
-        if (lane >= off) inc += o;
-    }
+    const unsigned inc = wave_incl_scan(mine);
     unsigned at = inc - mine;
     const unsigned nwin = (unsigned)__shfl(inc, 63, 64); // = min(n, k)
 

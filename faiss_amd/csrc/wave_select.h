@@ -53,12 +53,7 @@ __device__ inline u64 wave_select_kth(const u64* __restrict__ keys, int n, int k
             c.x = hv[0]; c.y = hv[1]; c.z = hv[2]; c.w = hv[3];
         }
         unsigned s = c.x + c.y + c.z + c.w;
-        unsigned incl = s;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            unsigned o = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += o;
-        }
+        const unsigned incl = wave_incl_scan(s);
         u64 ge = __ballot(incl >= (unsigned)need);
         int src = __ffsll((long long)ge) - 1; // first lane whose inclusive count reaches need
         unsigned excl_l = __shfl(incl - s, src, 64);

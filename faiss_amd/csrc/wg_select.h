@@ -43,12 +43,7 @@ __device__ u64 wg_select_kth(const u64* keys, int n, int k, unsigned* hist, WgSe
             const int lane = tid;
             const uint4 c = *(const uint4*)(hist + 4 * lane);
             const unsigned s = c.x + c.y + c.z + c.w;
-            unsigned incl = s;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const unsigned o = __shfl_up(incl, off, 64);
-                if (lane >= off) incl += o;
-            }
+            const unsigned incl = wave_incl_scan(s);
             const u64 ge = __ballot(incl >= (unsigned)need);
             const int src = __ffsll((long long)ge) - 1;
             if (lane == src) {

@@ -177,7 +177,8 @@ def test_ivf4096_1m_vs_oracle_and_live_reference(res, sift_shaped, kind):
     # ---- the scan the library picks for this batch (10 000 queries x 32 probes over 4096 lists: list-major for IVFFlat)
     D, I = g2.search(xq, K)
     arith = g2.last_scan_arith()
-    assert arith == 0 and g2.scan_info()[1] == (2 if kind == "ivfflat" else 1)
+    # (both index types take the list-major scan behind the f16 filter at this shape: 5 GB of code bytes / 40 GB of vectors)
+    assert arith == 0 and g2.scan_info()[1] == 2
     st = check_knn(D, I, Dr, Ir, rtol=1e-4, max_tie_frac=2e-3, name="%s 1M vs live reference" % kind)
     _report("%s 1M x 10k (automatic scan, arith %d)" % (kind, arith), st)
     assert (np.diff(D, axis=1) >= 0).all()
