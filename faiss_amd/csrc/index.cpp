@@ -2459,7 +2459,7 @@ void GpuIndexIVF::search_listmajor_chunk_(int ni, const float* xq_pad, const idx
     lm_bstart_.ensure((size_t)(2 * nlist + 1) * 4);
     lm_pairs_.ensure((size_t)npairs * 4);
     lm_items_.ensure((size_t)max_items * sizeof(IvfLmItem));
-    lm_bounds_.ensure(32);
+    lm_bounds_.ensure(kLmBoundsBytes);
     lm_thr_.ensure((size_t)ni * 4);
     lm_keys_.ensure((size_t)ni * stride * 8);
     lm_ovf_.ensure((size_t)(ni + 1) * 4);
@@ -2616,7 +2616,7 @@ void GpuIndexIVF::search_listmajor_filter_chunk_(int ni, int q0, const float* xq
     lm_bstart_.ensure((size_t)(2 * nlist + 1) * 4);
     lm_pairs_.ensure((size_t)npairs * 4);
     lm_items_.ensure((size_t)max_items * sizeof(IvfLmItem));
-    lm_bounds_.ensure(32);
+    lm_bounds_.ensure(kLmBoundsBytes);
     lm_thrf_.ensure((size_t)ni * 4);
     lm_keys_.ensure((size_t)ni * stride * 8);
     lm_candpr_.ensure((size_t)ni * stride * 2);
@@ -2781,7 +2781,7 @@ void GpuIndexIVF::test_filter_dump(idx_t n, const float* x, int nprobe_now, idx_
     bstart.ensure((size_t)(2 * nlist + 1) * 4);
     pairs.ensure((size_t)npairs * 4);
     items.ensure((size_t)max_items * sizeof(IvfLmItem));
-    bounds.ensure(32);
+    bounds.ensure(kLmBoundsBytes);
     thrf.ensure((size_t)ni * 4);
     keys.ensure((size_t)ni * stride * 8);
     gmin.ensure((size_t)ni * gstride * 4);

@@ -451,6 +451,8 @@ __global__ void __launch_bounds__(1024) lm_items_kernel(IvfLmParams p) {
         p.item_bounds[4] = 0; // item counter of pass 2 (the kernels whose waves draw their items: IVFFlat pass 2, IVFPQ)
         p.item_bounds[5] = 0; // ... of pass 1 (IVFPQ)
     }
+    // the filter sweeps draw their items from one counter per XCD (ivf_lm_filter.hip)
+    if (p.filter && t < 16) p.item_bounds[kLmXcdCtr + t * 32] = 0;
 }
 
 // one thread per (query, probe): its place among the pairs of its bucket (any order inside a bucket)

@@ -430,6 +430,7 @@ struct IvfLmParams {
     uint32_t* pairs;         // [nq * nprobe] pair = q * nprobe + p, grouped by bucket
     IvfLmItem* items;        // [max_items], pass 1 first
     uint32_t* item_bounds;   // [8] = 0, items of pass 1, all items, 1 if max_items was too small (a bug: the host checks), [4] work counter of pass 2
+                             // filter sweeps: + per-XCD work counters at [kLmXcdCtr + (sweep * 8 + xcd) * 32] (kLmBoundsBytes in all)
     int max_items;
     int qpi;                 // queries per work item: 32 (register-fed IVFFlat kernel: one wavefront per item) or 64
     int rows_per_item;       // multiple of 64
@@ -518,6 +519,8 @@ __host__ __device__ static inline float ivf_filter_err_bound(int metric, int d, 
     else e += 1.2e-7f * (float)(d + 8) * nq * ny;
     return 1.25f * (e + extra) + 1e-30f;
 }
+constexpr int kLmXcdCtr = 64;                                  // first per-XCD counter (u32 index into item_bounds), 128 bytes apart
+constexpr size_t kLmBoundsBytes = (kLmXcdCtr + 2 * 8 * 32) * 4; // bytes behind IvfLmParams::item_bounds
 constexpr int kLmfQueryBlocks = 3;  // 32-query MFMA blocks per work item of the filter sweeps (B operands: 32 VGPRs each)
 bool ivf_lmf_supported(int kind, int d, int dpad, int M);
 int ivf_lmf_queries_per_item(int kind, int d);
