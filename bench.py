@@ -47,9 +47,9 @@ PEAK_F16_MFMA_TFLOPS = 2500.0  # same guide: dense f16/bf16 MFMA (v_mfma_f32_32x
 PEAK_HBM_GBS = 8000.0
 # committed rocprofv3 --pmc summaries (tools/profile_round.sh; one file per profiled search loop)
 PROFILE_DIR = os.path.join(ROOT, "profiles")
-PROFILE_JSON = {"flat": "r04_p_pmc_flat.json", "ivfpq": "r04_p_pmc_ivfpq_1m.json", "ivfsq": "r04_p_pmc_ivfsq_1m.json",
-                "ivfflat": "r04_p_pmc_ivfflat_1m.json", "ivfflat_10m": "r04_p_pmc_ivfflat_10m.json",
-                "ivfpq_10m": "r04_p_pmc_ivfpq_10m.json", "ivfpq_100m": "r04_p_pmc_ivfpq_100m.json"}
+PROFILE_JSON = {"flat": "r04_q_pmc_flat.json", "ivfpq": "r04_q_pmc_ivfpq_1m.json", "ivfsq": "r04_q_pmc_ivfsq_1m.json",
+                "ivfflat": "r04_q_pmc_ivfflat_1m.json", "ivfflat_10m": "r04_q_pmc_ivfflat_10m.json",
+                "ivfpq_10m": "r04_q_pmc_ivfpq_10m.json", "ivfpq_100m": "r04_q_pmc_ivfpq_100m.json"}
 
 
 def log(*a):
@@ -836,10 +836,21 @@ def sharded_scale_leg(res, rank, world, dev, xt, xb, xq, xq_dev, dmap, rows_per_
         "scan": scan_name(list_major, arith),
         "train_broadcast_s": round(t_train, 2), "build_s": round(t_build, 1),
         "add_M_vectors_per_s_per_gpu": round(rows_per_rank / t_build / 1e6, 2), "overflow_queries": ovf,
-        "roofline": ivf_roofline(spans, list_major, "ivfpq", rows_per_rank, PQ_M, profile="ivfpq_100m"),
+        "roofline": _shard_roofline(ivf_roofline(spans, list_major, "ivfpq", rows_per_rank, PQ_M, profile="ivfpq_100m"),
+                                    rows_per_rank),
         "kernels_ms_rank0": {k: round(v[0] / max(v[1], 1), 3) for k, v in spans.items() if v[1]},
         "parity": par,
     }
+
+
+def _shard_roofline(r, rows_per_rank):
+    """the shard leg has no PMC pass of its own: its traffic block is the committed nb = 100M pass of the same kernels, and
+    says so (the bytes scale with the rows)"""
+    t = r.get("traffic") if isinstance(r, dict) else None
+    if t:
+        t["note"] = ("counters of the nb = 100 000 000 pass of the same kernels (profiles/*_pmc_ivfpq_100m); this leg holds "
+                     "%d rows per rank: scale the byte figures by %.2f" % (rows_per_rank, rows_per_rank / 1e8))
+    return r
 
 
 def main():
