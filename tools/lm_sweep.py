@@ -1,6 +1,11 @@
 #!/usr/bin/env python
-"""tools/lm_sweep.py -- list-major scan, timing experiments on the bench data: FAISS_AMD_LM_P1 x FAISS_AMD_LM_DBG
-usage: lm_sweep.py kind "p1/dbg,p1/dbg,..." [nb] [nq]"""
+"""tools/lm_sweep.py -- round 3's f32 list-major scan (scan_mode 3), timing experiments on the bench data: FAISS_AMD_LM_P1 x
+FAISS_AMD_LM_DBG.  The library reads these knobs ONCE per process and only under FAISS_AMD_EXPERIMENTS=1 (round 4): run one
+combination per process, e.g.
+    FAISS_AMD_EXPERIMENTS=1 FAISS_AMD_LM_P1=4 FAISS_AMD_LM_DBG=0 python tools/lm_sweep.py ivfflat 4/0 10000000
+(the combination argument only labels the output; the filter path of round 4 is swept by tools/lmf_sweep.py, whose knobs
+are API calls).
+usage: lm_sweep.py kind "p1/dbg" [nb] [nq]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -35,7 +40,7 @@ while done < nb:  # further chunks drawn on the device (bench.py scale_leg): the
     idx.add_ptr(n_c, xbc.data_ptr()); done += n_c
     del xbc, lat
 idx.nprobe = NPROBE
-idx.set_scan_mode(2)
+idx.set_scan_mode(3)  # the f32 list-major scan these knobs belong to
 Dd = torch.empty((nq, K), dtype=torch.float32, device=dev)
 Id = torch.empty((nq, K), dtype=torch.int64, device=dev)
 SPANS = ("ivf_lm_plan", "ivf_lm_scan_pass1", "ivf_lm_threshold", "ivf_lm_scan_pass2", "select_k_kernel")
