@@ -87,6 +87,13 @@ def main():
                       % (g, ms, cap, ms_t, idx.scan_info()[2], same, sp.get("ivf_lmf_prepare", 0), sp.get("ivf_lm_plan", 0),
                          sp.get("ivf_lmf_sweep_min", 0), sp.get("ivf_lmf_bound", 0), sp.get("ivf_lmf_sweep_collect", 0),
                          sp.get("ivf_lmf_rerank", 0), sp.get("select_k_kernel", 0)), flush=True)
+        # rows of a list per work item (0 = the rule: a quarter of an average list, 1024 ... 8192)
+        for rt in (256, 512, 1024, 2048, 4096):
+            idx.set_lmf_tuning(rt, 0, 0, 0)
+            ms_t, sp = timed(idx, res, xq_dev, Dd, Id, steps=3)
+            same = np.array_equal(base[0], Dd.cpu().numpy()) and np.array_equal(base[1], Id.cpu().numpy())
+            print("rows per item %5d: %8.3f ms same %s  min %.3f collect %.3f" % (rt, ms_t, same, sp.get("ivf_lmf_sweep_min", 0),
+                                                                              sp.get("ivf_lmf_sweep_collect", 0)), flush=True)
         del idx
 
 
