@@ -4,7 +4,7 @@ BASELINE shapes: IVFFlat nb = 1M / 10M and IVFPQ nb = 1M / 10M / 100M (10 000 qu
 tuning knobs of faiss_amd_GpuIndexIVF_set_lmf_tuning (rows of a list per work item, blocks per granule, candidate room)
 and against the query-major and f32 list-major scans.  Results never change with the knobs (asserted here).
 
-usage: python tools/lmf_sweep.py [ivfflat_1m,ivfflat_10m,ivfpq_10m,ivfpq_100m] > gpurun_out/lmf_sweep.txt"""
+usage: python tools/lmf_sweep.py [ivfflat_1m,ivfflat_10m,ivfpq_10m,ivfpq_100m] [rows-per-item values] > gpurun_out/lmf_sweep.txt"""
 import os
 import sys
 import time
@@ -88,7 +88,7 @@ def main():
                          sp.get("ivf_lmf_sweep_min", 0), sp.get("ivf_lmf_bound", 0), sp.get("ivf_lmf_sweep_collect", 0),
                          sp.get("ivf_lmf_rerank", 0), sp.get("select_k_kernel", 0)), flush=True)
         # rows of a list per work item (0 = the rule: a quarter of an average list, 1024 ... 8192)
-        for rt in (256, 512, 1024, 2048, 4096):
+        for rt in ([int(v) for v in sys.argv[2].split(',')] if len(sys.argv) > 2 else (256, 512, 1024, 2048, 4096)):
             idx.set_lmf_tuning(rt, 0, 0, 0)
             ms_t, sp = timed(idx, res, xq_dev, Dd, Id, steps=3)
             same = np.array_equal(base[0], Dd.cpu().numpy()) and np.array_equal(base[1], Id.cpu().numpy())
