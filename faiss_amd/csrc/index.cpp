@@ -1695,6 +1695,9 @@ size_t GpuIndexIVF::reclaimMemory() {
         before += b->cap;
         b->release();
     }
+    // the filter sweeps' copies of the lists (fp16 shadow / operand-major codes): derived data, rebuilt on demand
+    const size_t shadow = lmf_release_();
+    before += shadow;
     if (arena_.p) compact_(true);
     const size_t after = (size_t)arena_cap_rows_ * row_bytes + (arena_.p ? pad_bytes : 0);
     return before > after ? before - after : 0;

@@ -446,6 +446,8 @@ class GpuIndexIVF : public Index {
     // fp16 range (the search takes the query-major scan).
     virtual bool lmf_capable_() const { return false; }
     virtual bool lmf_prepare_(struct IvfLmParams& p) const { return false; }
+    // bytes freed by dropping the sweeps' own copies of the lists (rebuilt at the next list-major search)
+    virtual size_t lmf_release_() { return 0; }
     mutable bool cur_lmf_ = false;        // the list-major search in flight runs the filter sweeps
     mutable bool cur_preassigned_ = false; // ... with the caller's coarse assignment (search_preassigned)
     mutable int last_scan_arith_ = 0;     // oracle restatement of the last search: 0 query-major arithmetic, 1 f32 list-major
@@ -520,6 +522,12 @@ class GpuIndexIVFFlat : public GpuIndexIVF {
     bool lmf_capable_() const override;
     bool lmf_prepare_(struct IvfLmParams& p) const override;
     mutable DevBuf arena_h_;          // fp16 shadow of the arena rows [arena_cap_rows_ + 128][dh_]
+    size_t lmf_release_() override {
+        const size_t b = arena_h_.cap;
+        arena_h_.release();
+        shadow_dirty_ = true;
+        return b;
+    }
     mutable float shadow_yn_max_ = 0.f;
     mutable bool shadow_in_range_ = true;
 };
@@ -560,6 +568,12 @@ class GpuIndexIVFPQ : public GpuIndexIVF {
     bool lmf_prepare_(struct IvfLmParams& p) const override;
     mutable DevBuf pq16_;             // fp16 codebook [M][256][dsub]
     mutable DevBuf arena_cs_;         // operand-major copy of the codes for the filter sweeps (kernels.h IvfLmParams::arena_cs)
+    size_t lmf_release_() override {
+        const size_t b = arena_cs_.cap;
+        arena_cs_.release();
+        shadow_dirty_ = true;
+        return b;
+    }
     mutable float pq_yn_max_ = 0.f, cn_max_ = 0.f;
     mutable bool pq16_in_range_ = true;
     bool lm_pq_lds_capable_() const override { return ivf_lm_pq_lds_supported_(); }
