@@ -23,6 +23,9 @@
 // (IVFFlat: arena_h, 2 bytes per coordinate) or the fp16 codebook entries their codes select (IVFPQ, codebook in LDS) are
 // the A operands; a list is read once per sweep for up to 96 queries instead of once per 32.  The sweeps are bound by
 // the row stream (IVFFlat: nb * d * 2 bytes per sweep) / the LDS gathers (IVFPQ), not by the matrix pipe any more.
+// Shapes: IVFFlat d <= 512 (beyond 128: 16 / 24 / 32 k-steps per row, two or one query block per item); IVFPQ d <= 128,
+// d % 16 == 0, dsub 1 / 2 / 4 / 8 k.  Work items are drawn from one counter per XCD (LmfDraw): the query groups of a list
+// run behind the same L2.  DESIGN.md 3.10 holds the measurements every choice here rests on.
 // Reference behaviour kept: faiss/gpu/impl/IVFInterleaved.cuh:33-224, PQScanMultiPassNoPrecomputed-inl.cuh:173-270
 // (exhaustive scan of the probed lists, k best under (distance, scan position)).
 #include "kernels.h"
