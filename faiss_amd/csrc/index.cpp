@@ -2364,11 +2364,12 @@ void GpuIndexIVF::search_listmajor_(int ni, const float* xq_pad, const idx_t* c_
         while (G < 8 && rows_per_query / (16.0 * G) > 2048.0) G *= 2;
         if (lmf_rows_per_item > 0) RT = (int)round_up((size_t)lmf_rows_per_item, 256);
         if (lmf_gran_blocks > 0) G = lmf_gran_blocks;
+        if (G > 8 && G <= 32) RT = (int)round_up((size_t)RT, (size_t)32 * G); // (an item holds whole granules)
         if (lmf_cand_cap > 0) stride = std::max<int64_t>(lmf_cand_cap, k);
         // sweep 1 over every 2nd block when lists are long (profiles/r04_d_filter_sampling_sweep.txt: IVFPQ nb = 100M 14.9 ->
         // 12.8 ms, IVFFlat nb = 10M 2.26 -> 2.17 ms, nb = 1M slower: the looser bound doubles the candidates)
         const int min_stride = lmf_min_stride > 0 ? std::min(lmf_min_stride, 8) : (avg_len >= 8192 ? 2 : 1);
-        FA_THROW_IF_NOT_MSG(G >= 1 && G <= 8 && (G & (G - 1)) == 0 && RT <= 65280, "filter tuning: granule / rows per item");
+        FA_THROW_IF_NOT_MSG(G >= 1 && G <= 32 && (G & (G - 1)) == 0 && RT <= 65280, "filter tuning: granule / rows per item");
         // granule slots a query can own: those of the np longest lists
         int64_t gstride = 0;
         {

@@ -77,7 +77,7 @@ def main():
                 ok = np.array_equal(ref[0], Dd.cpu().numpy()) and np.array_equal(ref[1], Id.cpu().numpy())
                 print("    filter == query-major on all queries: %s" % ok, flush=True)
         base = (Dd.cpu().numpy().copy(), Id.cpu().numpy().copy())
-        gs = (1, 2) if nb <= 1000000 else (4, 8) if nb <= 10000000 else (8,)
+        gs = (1, 2) if nb <= 1000000 else (4, 8, 16) if nb <= 10000000 else (8, 16, 32)
         for g in gs:
             for ms, cap in ((1, 1024), (2, 1024)) + (((4, 1024), (4, 2048)) if nb >= 100000000 else ()):
                 idx.set_lmf_tuning(0, g, cap, ms)
