@@ -128,6 +128,41 @@ def test_flat_1m_x_10k_vs_oracle_and_live_reference(res, sift_shaped):
     assert (I[:, 0] == Ir[:, 0]).mean() > 0.9999
 
 
+# ------------------------------------------------------------------------------- IVFFlat beyond d = 128 (round 4)
+@pytest.mark.parametrize("d", [256, 384])
+def test_ivfflat_wide_rows_vs_live_reference(res, d):
+    """d > 128 takes the 16 / 24 k-step instantiations of the list-major filter sweeps (two / one query block per work item):
+    IVF1024,Flat over 200 000 rows of d coordinates, 4000 queries, nprobe 16, k 100 -- ALL queries against the live
+    reference index holding the same quantizer (north-star tolerance), list-major == query-major on all of them, a sample
+    bit-exact against the oracle."""
+    if not Ref.available():
+        pytest.skip("oracle/_ref not shipped")
+    nlist, nb, nq, nprobe, k = 1024, 200000, 4000, 16, 100
+    xt, xb, xq = synthetic_dataset(d, 40000, nb, nq, seed=77 + d)
+    g = faiss_amd.GpuIndexIVFFlat(res, d, nlist, METRIC_L2)
+    g.train(xt)
+    cent = g.get_centroids()
+    ref = Ref.index_factory(d, "IVF%d,Flat" % nlist)
+    ref.set_centroids(cent)
+    ref.add(xb)
+    ref.set_nprobe(nprobe)
+    Dr, Ir = ref.search(xq, k)
+    sizes, codes, lids = ref.lists()
+    g.copy_lists(sizes, codes, lids)
+    g.nprobe = nprobe
+    assert g.list_major_rule(nq, nprobe, k)
+    D, I = g.search(xq, k)
+    assert g.scan_info()[1] == 2 and g.last_scan_arith() == 0
+    st = check_knn(D, I, Dr, Ir, rtol=1e-4, max_tie_frac=2e-3, name="ivfflat d=%d vs live reference" % d)
+    _report("ivfflat d=%d 200k x 4000 (list-major behind the f16 filter)" % d, st)
+    g.set_scan_mode(g.SCAN_QUERY_MAJOR)
+    D0, I0 = g.search(xq, k)
+    assert g.scan_info()[1] == 1 and np.array_equal(D, D0) and np.array_equal(I, I0)
+    sel = np.random.RandomState(3).choice(nq, 24, replace=False)
+    Do, Io, _, _ = Oracle.ivf_search(0, METRIC_L2, cent, sizes, codes, lids, xq[sel], nprobe, k, arith=0)
+    check_knn(D[sel], I[sel], Do, Io, exact=True, name="ivfflat d=%d sample vs oracle" % d)
+
+
 # ------------------------------------------------------------------------------- IVF4096 at nb = 1M (configs[2]/[3] shape)
 @pytest.mark.parametrize("kind", ["ivfflat", "ivfpq"])
 def test_ivf4096_1m_vs_oracle_and_live_reference(res, sift_shaped, kind):
