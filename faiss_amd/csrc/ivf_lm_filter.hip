@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
     const int j = lane & 31;
     const int np = p.nprobe;
     const int nks = FULL ? KS : (int)(p.ldh >> 4);
-    const int G = p.gran_blocks, gsh = __builtin_ctz((unsigned)p.gran_blocks); // (a power of two)
+    const int gsh = __builtin_ctz((unsigned)p.gran_blocks); // blocks per granule: a power of two
     const _Float16* xq16 = (const _Float16*)p.xq16;
     const _Float16* arena_h = (const _Float16*)p.arena_h;
     u64* pk_keys = (u64*)smem + wave * LF_PARK;
@@ -579,7 +579,7 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
     const int np = p.nprobe;
     const int M = p.M, dsub = p.dsub;
     const int nks = FULLK ? 8 : (p.d >> 4);
-    const int G = p.gran_blocks, gsh = __builtin_ctz((unsigned)p.gran_blocks); // (a power of two)
+    const int gsh = __builtin_ctz((unsigned)p.gran_blocks); // blocks per granule: a power of two
     const LpLayout LY = lp_layout(p.d, M);
     const _Float16* cb = (const _Float16*)smem;
     {
