@@ -2310,34 +2310,49 @@ static const char* experiment_env(const char* name) {
 bool GpuIndexIVF::list_major_rule(idx_t n, int nprobe_now, idx_t k, bool has_selector) const {
     if (!(lm_capable_() || lmf_capable_()) || (has_selector && !lmf_capable_()) || k > kMaxSelectionK || nstored_ == 0) return false;
     const int64_t np = std::min<int64_t>(nprobe_now, nlist);
-    // every list has to meet >= 8 of the batch's queries on average: below that the 32-query MFMA blocks run mostly empty
-    // (nlist 16384, nprobe 8, 10 000 queries: 4.9 queries per list, list-major 2.6 ms against 1.0 ms)
-    if ((int64_t)n * np < (int64_t)8 * nlist) return false;
     const double avg_len = (double)nstored_ / (double)nlist;
     if (fused_kind_() == 2 || (fused_kind_() == 1 && !lmf_capable_())) {
         // scalar quantizer / IVFPQ shapes the filter does not serve: round 3's f32 list-major scan and its rule (measured at
-        // nlist 4096 / nprobe 32 only: IVFPQ break-even near (rows per list) x (queries per list) = 415 x 78)
+        // nlist 4096 / nprobe 32 only: IVFPQ break-even near (rows per list) x (queries per list) = 415 x 78): every list
+        // has to meet >= 8 of the batch's queries on average, below that the 32-query MFMA blocks run mostly empty
+        if ((int64_t)n * np < (int64_t)8 * nlist) return false;
         if (fused_kind_() == 1 &&
             !(lm_pq_lds_capable_() && (double)n * (double)np * (double)nstored_ >= 50000.0 * (double)nlist * (double)nlist))
             return false;
         return n >= 2048 && (double)nstored_ >= 64.0 * (double)nlist;
     }
-    // Behind the f16 filter (round 4; profiles/r04_i_scan_rule_sweep.txt: nlist 1024 / 4096 / 16384 x nprobe 8 / 32 / 128 x 512
-    // ... 10 000 queries at nb = 1M, both index types).  The query-major scan is bound by the bytes it streams -- queries x
-    // probes x rows per list x bytes per row at ~6 TB/s (IVFFlat) / ~5 TB/s (IVFPQ) on top of 0.1-0.2 ms --, the list-major
-    // scan costs 0.4-0.6 ms whatever the batch (plan, two sweeps, bound, rerank, select) and grows slowly from there: it
-    // wins once the query-major stream exceeds ~2 GB (IVFFlat: 512 queries x 128 probes already, 6.4 x faster; short lists too
-    // -- nlist 16384 at nb = 1M, 61 rows per list: 5.4 x at 10 000 queries x 128 probes; against the sweep the rule is off by
-    // more than 10 % in 2 of 45 cases, both at 512 queries where condition (a) keeps a 14-23 % faster list-major out) / ~3.5 GB of
-    // code bytes (IVFPQ, profiles/r04_k_ivfpq_rule_sweep.txt: at 4.1 GB list-major is 1.14-1.20 x faster, at 2.05 GB 4-16 %
-    // slower; its lists must also be long enough to amortise an item's set-up: nlist 16384 at nb = 1M -- 61 rows per list --
-    // never wins).
-    const double stream = (double)n * (double)np * avg_len * (double)ref_row_bytes_();
+    // ---- behind the f16 filter (round 4): both scans return the same bits, so the choice is a matter of time only, and it is
+    // made by two small cost models fitted to side-by-side timings (profiles/r04_i_scan_rule_sweep.txt, r04_k_ivfpq_rule_
+    // sweep.txt: nlist 1024 / 4096 / 16384 x nprobe 8 / 32 / 128 x 512 ... 10 000 queries at nb = 1M; profiles/r04_y_latency_
+    // both_scans.txt: 16 ... 4096 queries at nb = 1M / 10M / 100M).  Against those 118 measurements the choice is off by more
+    // than 10 % twice (11 % and 15 %); the thresholds it replaces (queries per list >= 8 and a fixed stream size) kept the
+    // query-major scan for 128 ... 512 queries at nb >= 10M, where it is 1.4 ... 3.6 x slower.
+    //   query-major: bound by the bytes it streams -- queries x probes x rows per list x bytes per row at 4.9 TB/s (IVFFlat) /
+    //                4.3 TB/s (IVFPQ) on top of 0.12 ms;
+    //   list-major:  0.3 ms of fixed launches + rerank / selection per query + two sweeps over the lists the batch touches
+    //                (IVFFlat: the fp16 shadow at the fabric's rate; IVFPQ: per row and occupied 32-query block of an item).
     // the bound is the k-th best of the query's granule minima (16 rows each): a query that probes fewer than ~1.1 k granules
     // gets no bound and is redone query-major (bench sweep, nprobe 4 at nb = 1M: 61 granules for k = 100 -- 3.5 ms, all redone)
     if ((double)np * avg_len < 18.0 * (double)k) return false;
-    if (fused_kind_() == 0) return stream >= 2.0e9;
-    return avg_len >= 128.0 && stream >= 3.5e9;
+    const double pairs = (double)n * (double)np;
+    const double touched = 1.0 - std::exp(-pairs / (double)nlist); // share of the lists the batch probes (uniform model)
+    const double stream = pairs * avg_len * (double)ref_row_bytes_();
+    const double kq = 0.5 + 0.5 * std::min<double>((double)k, 1000.0) / 100.0; // candidates per query grow with k
+    double est_qm, est_lm; // ms
+    if (fused_kind_() == 0) {
+        est_qm = 0.12 + stream / 4.9e9;
+        est_lm = 0.27 + 0.10e-3 * kq * (double)n + 2.0 * touched * (double)nstored_ * (2.0 * ivf_lmf_row_halfs(d) + 4.0) / 4.0e9;
+    } else {
+        if (avg_len < 128.0) return false; // (an item's set-up is never amortised: nlist 16384 at nb = 1M, 61 rows per list)
+        est_qm = 0.13 + stream / 4.3e9;
+        // ms per row and sweep pair at three occupied query blocks: 5.6e-8 with sweep 1 on every 2nd block (long lists),
+        // 1.07e-7 otherwise, more on short lists (per-item latencies), scaled by the blocks an item really holds
+        const double c = (avg_len >= 8192.0 ? 5.6e-8 : 1.07e-7) * (1.0 + 250.0 / avg_len) * ((double)d / 128.0);
+        const double qpl = pairs / (touched * (double)nlist);
+        const double nblk = std::min(3.0, std::max(1.0, std::ceil(qpl / 32.0)));
+        est_lm = 0.30 + 0.055e-3 * kq * (double)n + touched * (double)nstored_ * c * nblk / 3.0;
+    }
+    return est_lm < est_qm;
 }
 
 // Queries [0, ni) with their coarse results on the device -> k best per query in dD / dI (device).  Splits the batch

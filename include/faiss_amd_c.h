@@ -424,9 +424,10 @@ int faiss_amd_GpuIndexIVF_set_use_fused_scan(FaissAmdIndex* index, int on);
 
 /* Which scan serves search() / search_preassigned() of an IVF index (no reference counterpart: the reference has one
  * scan per index type, faiss/gpu/impl/IVFInterleaved.cuh:33-224, PQScanMultiPassNoPrecomputed-inl.cuh:173-270, both
- * query-major).  0 = automatic: the measured rule of GpuIndexIVF::list_major_rule -- batches that
- * probe every list >= 8 times on average and whose query-major scan would stream more than ~2 GB (IVFFlat, d <= 512) /
- * ~3.5 GB of codes (IVFPQ, d <= 128), the scalar quantizer (d <= 128) from 2048 queries on, take the list-major scan
+ * query-major).  0 = automatic: GpuIndexIVF::list_major_rule -- IVFFlat (d <= 512) and IVFPQ (d <= 128):
+ * a cost model fitted to side-by-side timings picks the faster scan (query-major: the bytes it streams; list-major: fixed
+ * launches + per-query work + two sweeps over the lists the batch touches; the results are the same bits either way);
+ * the scalar quantizer (d <= 128) takes the list-major scan from 2048 queries on
  * (every list is read once per group of the queries probing it); 1 = query-major always; 2 = list-major always (an
  * error where unsupported); 3 = list-major on the f32 matrix pipe (round 3's scan, faiss_amd/csrc/ivf_listmajor.hip,
  * d <= 128, no IDSelector).

@@ -191,12 +191,13 @@ def test_scan_mode_rule_and_refusals(res):
     idx, _, _ = _build(res, 0, METRIC_L2, d, 0, nlist, xt, xb)
     idx.nprobe = 8
     assert idx.scan_info()[0] == 0
-    # the rule (profiles/r04_i_scan_rule_sweep.txt): every list meets >= 8 queries of the batch, and the bytes the
-    # query-major scan would stream (queries x probes x rows per list x bytes per row) exceed ~2 GB (IVFFlat) / ~3.5 GB
-    # (IVFPQ): a small index like this one (8000 rows of 128 bytes) stays query-major for any batch but a huge one.  A query
+    # the rule (GpuIndexIVF::list_major_rule: two cost models fitted to side-by-side timings, profiles/r04_i / r04_k / r04_y):
+    # the time the query-major scan needs for the bytes it streams (queries x probes x rows per list x bytes per row) against
+    # the fixed + per-query + per-touched-list cost of the list-major scan: a small index like this one (8000 rows of 128
+    # bytes) stays query-major for any batch but a huge one.  A query
     # must also probe >= ~1.1 k granules of 16 rows, or the k-th best granule estimate bounds nothing (k = 100 of 1000 rows)
     assert not idx.list_major_rule(2100, 8, 10) and idx.list_major_rule(100000, 64, 10)
-    assert idx.list_major_rule(1000000, 16, 100) and not idx.list_major_rule(1000000, 8, 100)
+    assert idx.list_major_rule(100000, 64, 100) and not idx.list_major_rule(100000, 8, 100)
     D, I = idx.search(xq, 10)
     assert idx.scan_info()[1] == 1
     idx.set_scan_mode(idx.SCAN_LIST_MAJOR)
@@ -213,10 +214,10 @@ def test_scan_mode_rule_and_refusals(res):
     assert big.scan_info()[1] == 2 and big.last_scan_arith() == 0
     Ds, Is = big.search(xq2[:20], 10)
     assert big.scan_info()[1] == 1 and np.array_equal(Ds, Db[:20]) and np.array_equal(Is, Ib[:20])
-    # IVFPQ: lists of >= 128 rows and ~3.5 GB of code bytes
+    # IVFPQ: lists of >= 128 rows, and the code bytes the query-major scan would stream must outweigh the fixed cost
     pq, _, _ = _build(res, 1, METRIC_L2, d2, 16, nlist, xt2, xb2)
     pq.nprobe = 16
-    assert not pq.list_major_rule(2100, 16, 10) and pq.list_major_rule(2100, 64, 10)
+    assert not pq.list_major_rule(100, 4, 10) and pq.list_major_rule(2100, 16, 10) and pq.list_major_rule(2100, 64, 10)
     Dp, Ip = pq.search(xq2, 10, params=faiss_amd.SearchParametersIVF(nprobe=64))
     assert pq.scan_info()[1] == 2 and pq.last_scan_arith() == 0
     pq.set_scan_mode(pq.SCAN_QUERY_MAJOR)
