@@ -151,6 +151,20 @@ def time_search(index, torch, n, xq_ptr, d_ptr, i_ptr, steps, warmup):
     return (time.perf_counter() - t0) / steps
 
 
+def time_search_each(index, torch, n, xq_ptr, d_ptr, i_ptr, steps):
+    """every search between two synchronisations: (median seconds, [ms per step]).  For the legs that run a handful of
+    10 ms searches: one stalled step would otherwise be the figure (seen once in the shard leg: 3 steps averaging 70 ms
+    between runs of 8.4 and 8.6 ms)."""
+    each = []
+    for _ in range(steps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        index.search_ptr(n, xq_ptr, K, d_ptr, i_ptr)
+        torch.cuda.synchronize()
+        each.append(time.perf_counter() - t0)
+    return float(np.median(each)), [round(v * 1e3, 3) for v in each]
+
+
 def ivf_leg(kind, res, xt, xb, xq, xq_dev, gt_first, steps, torch, with_cpu=True, sweep=False):
     """IVF4096,PQ64 / IVF4096,Flat at nb = 1M (BASELINE.json configs[3] / configs[2] at the metric's database size):
     native train + add on the GPU, nprobe = 32, the reference CPU index with the SAME quantizers as baseline and as
@@ -471,8 +485,8 @@ def scale_leg(kind, nb, res, xt, xb, xq, xq_dev, dmap, torch, leg_1m, nsample=16
     Dd = torch.empty((NQ, K), dtype=torch.float32, device=xq_dev.device)
     Id = torch.empty((NQ, K), dtype=torch.int64, device=xq_dev.device)
     time_search(idx, torch, NQ, xq_dev.data_ptr(), Dd.data_ptr(), Id.data_ptr(), 1, 1)
-    steps = 5 if nb <= 20000000 else 3
-    dt = time_search(idx, torch, NQ, xq_dev.data_ptr(), Dd.data_ptr(), Id.data_ptr(), steps, 0)  # no instrumentation
+    steps = 9 if nb <= 20000000 else 7
+    dt, step_ms = time_search_each(idx, torch, NQ, xq_dev.data_ptr(), Dd.data_ptr(), Id.data_ptr(), steps)  # no instrumentation
     res.profile_enable(True)
     res.profile_reset()
     dt_spans = time_search(idx, torch, NQ, xq_dev.data_ptr(), Dd.data_ptr(), Id.data_ptr(), 2, 0)
@@ -492,6 +506,7 @@ def scale_leg(kind, nb, res, xt, xb, xq, xq_dev, dmap, torch, leg_1m, nsample=16
             "GpuIndexIVFPQ PQ%dx8" % PQ_M if pq else "GpuIndexIVFFlat", NLIST, NPROBE, D, nb, NQ, K, 3 if pq else 2),
         "scan": scan_name(list_major, arith),
         "qps": round(NQ / dt, 1), "ms_per_step": round(dt * 1e3, 3), "steps": steps,
+        "step_ms": step_ms, "timing": "every step between two synchronisations; ms_per_step / qps = the MEDIAN step",
         "ms_per_step_with_event_spans": round(dt_spans * 1e3, 3),
         "generator": ("chunk 0 = the flat leg's 1M database; chunks 1.. " +
                       ("synthetic_more(seed 1338 + chunk) on the host" if host_gen else
@@ -785,20 +800,26 @@ def sharded_scale_leg(res, rank, world, dev, xt, xb, xq, xq_dev, dmap, rows_per_
         return D_out, I_out
 
     s = ShardedSearcher(local_search, merge, [0] * world, dev)
-    s.search(xq_dev, K)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    for _ in range(2):
+        s.search(xq_dev, K)
+    # every step timed on its own (barrier + synchronize on both sides, max over ranks): with a handful of steps of ~10 ms
+    # one stalled step (seen once: 3 steps averaging 70 ms between runs of 8.4 and 8.6 ms) would otherwise be the figure
+    step_s = []
     for _ in range(steps):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
         out = s.search(xq_dev, K)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        step_s.append(time.perf_counter() - t0)
+    el = torch.tensor(step_s, dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    dt = float(el.item()) / steps
+    step_ms = [round(float(v) * 1e3, 3) for v in el.tolist()]
+    dt = float(np.median(el.cpu().numpy()))
     # kernel spans of this rank's local search (a second, instrumented loop)
     res.profile_enable(True)
     res.profile_reset()
@@ -831,8 +852,10 @@ def sharded_scale_leg(res, rank, world, dev, xt, xb, xq, xq_dev, dmap, rows_per_
                                                                               rows_per_rank, NQ, K, world),
         "scaling": "weak (rows per GPU fixed; all queries to every shard)",
         "qps": round(NQ / dt, 1), "ms_per_step": round(dt * 1e3, 3), "steps": int(steps),
+        "step_ms": step_ms, "ms_per_step_mean": round(float(np.mean(step_ms)), 3),
         "timed_region": "local search of all queries on every rank + point-to-point gather of the per-rank top-k onto rank 0 "
-                        "+ device merge; barrier + synchronize on both sides, max over ranks",
+                        "+ device merge; every step between barrier + synchronize, max over ranks; ms_per_step / qps = the "
+                        "MEDIAN step (step_ms lists all of them)",
         "scan": scan_name(list_major, arith),
         "train_broadcast_s": round(t_train, 2), "build_s": round(t_build, 1),
         "add_M_vectors_per_s_per_gpu": round(rows_per_rank / t_build / 1e6, 2), "overflow_queries": ovf,
@@ -988,7 +1011,7 @@ def main():
     if world > 1 and not args.no_ivf and "ivfpq_shards" in args.scale_legs.split(","):
         try:
             del index
-            shards_multi = sharded_scale_leg(res, rank, world, dev, xt, xb, xq, xq_dev, dmap, args.shard_rows, 3, torch, dist, 8)
+            shards_multi = sharded_scale_leg(res, rank, world, dev, xt, xb, xq, xq_dev, dmap, args.shard_rows, 7, torch, dist, 8)
         except Exception as e:  # noqa: BLE001
             shards_multi = {"error": repr(e)[:300]}
 
@@ -1080,7 +1103,7 @@ def main():
                     pass
                 try:
                     if name == "ivfpq_shards":
-                        line[name] = sharded_scale_leg(res, 0, 1, dev, xt, xb, xq, xq_dev, dmap, args.shard_rows, 3, torch, dist, 16)
+                        line[name] = sharded_scale_leg(res, 0, 1, dev, xt, xb, xq, xq_dev, dmap, args.shard_rows, 7, torch, dist, 16)
                     else:
                         kind, nbig = name.split("_")
                         line[name] = scale_leg(kind, 10000000 if nbig == "10m" else 100000000, res, xt, xb, xq, xq_dev, dmap,
