@@ -1690,7 +1690,7 @@ size_t GpuIndexIVF::reclaimMemory() {
     // plan tables, granule minima): all of it is re-grown on demand
     for (DevBuf* b : {&a_xpad_, &a_lab_, &a_dis_, &a_dest_, &a_ids_, &a_hist_, &a_newlen_, &a_jobs_, &lm_prefix_, &lm_p0_,
                       &lm_cnt_, &lm_bucket_, &lm_bstart_, &lm_pairs_, &lm_items_, &lm_bounds_, &lm_thr_, &lm_keys_, &lm_ovf_,
-                      &lm_qn_, &lm_prefixg_, &lm_gmin_, &lm_thrf_, &lm_candpr_, &lm_q16_, &lm_qflags_, &lm_xnb_, &lm_pqgrid_,
+                      &lm_qn_, &lm_prefixg_, &lm_gmin_, &lm_thrf_, &lm_candpr_, &lm_q16_, &lm_qflags_, &lm_xnb_, &lm_pqgrid_, &lm_pair16_, &lm_pairxh_,
                       &part_keys_, &part_cnt_, &keys_}) {
         before += b->cap;
         b->release();
@@ -2396,7 +2396,8 @@ void GpuIndexIVF::search_listmajor_(int ni, const float* xq_pad, const idx_t* c_
             if (cur_preassigned_) gstride = 2 * (int64_t)np * (int64_t)div_up((size_t)max_len, (size_t)(32 * G));
             gstride = std::max<int64_t>(gstride, 2);
         }
-        const size_t per_q = (size_t)stride * 10 + (size_t)gstride * 4 + (size_t)(np + 1) * 12 + 256;
+        const size_t per_q = (size_t)stride * 10 + (size_t)gstride * 4 + (size_t)(np + 1) * 12 + 256 +
+                             (fused_kind_() == 1 ? (size_t)np * ((size_t)d * 2 + 4) : 0); // (IVFPQ: fp16 residual query per probe)
         const int64_t fit = std::max<int64_t>(1, std::min<int64_t>((int64_t)(R.temp_budget_bytes / per_q), (1 << 20)));
         for (int c0 = 0; c0 < ni; c0 += (int)std::min<int64_t>(fit, ni)) {
             const int cn = (int)std::min<int64_t>(fit, ni - c0);
@@ -2684,6 +2685,10 @@ void GpuIndexIVF::search_listmajor_filter_chunk_(int ni, int q0, const float* xq
         P.xqn = lm_qn_.as<float>();
         P.xn_full = lm_qn_.as<float>();
         if (P.kind == 1) {
+            lm_pair16_.ensure((size_t)ni * (metric_type == METRIC_L2 ? np : 1) * d * 2);
+            lm_pairxh_.ensure((size_t)ni * np * 4);
+            P.pair16 = lm_pair16_.p;
+            P.pair_xh = lm_pairxh_.as<float>();
             launch_ivf_lmf_pq_prepare(P, lm_xnb_.as<float>(), R.stream);
         }
         // granule slots nobody writes must never look like good estimates
@@ -2845,7 +2850,12 @@ void GpuIndexIVF::test_filter_dump(idx_t n, const float* x, int nprobe_now, idx_
     P.ldq16 = dh;
     P.xqn = qn.as<float>();
     P.xn_full = qn.as<float>();
+    DevBuf pair16, pairxh;
     if (P.kind == 1) {
+        pair16.ensure((size_t)ni * (metric_type == METRIC_L2 ? np : 1) * d * 2);
+        pairxh.ensure((size_t)ni * np * 4);
+        P.pair16 = pair16.p;
+        P.pair_xh = pairxh.as<float>();
         launch_ivf_lmf_pq_prepare(P, xnb.as<float>(), R.stream);
     }
     launch_ivf_lm_plan(P, R.stream);

@@ -676,10 +676,10 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
         // three -- chosen per ITEM, outside the loop (a bound inside it costs the compiler its count of the loads in flight).
         auto run_item = [&](auto nb_c) __attribute__((always_inline)) {
         constexpr int NB = decltype(nb_c)::value;
-        // ---- this lane's queries: B operands = fp16 of the residual query (L2) / of the query (inner product)
+        // ---- this lane's queries: B operands = fp16 of the residual query (L2) / of the query (inner product), prepared
+        // once per search (lmf_pq_prepare_kernel)
         LmfLane L[NB];
         half8 bq[NB][8];
-        const float* cen = p.centroids + (int64_t)list * p.ldc + 8 * h;
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const int my = b * 32 + j;
@@ -687,31 +687,13 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
             const uint32_t pi = p.pairs[pb + (uint32_t)(qt * (32 * NQB)) + (uint32_t)(L[b].qv ? my : 0)];
             const int q = (int)(pi / (uint32_t)np);
             const int pr = (int)(pi - (uint32_t)q * (uint32_t)np);
-            const float* qrow = p.xq + (int64_t)q * p.ldq + 8 * h;
-            float accn = 0.f;
+            const _Float16* qrow = (const _Float16*)p.pair16 + (int64_t)(METRIC == METRIC_L2 ? pi : (uint32_t)q) * p.d + 8 * h;
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
-                half8 o = half8{0, 0, 0, 0, 0, 0, 0, 0};
-                if (FULLK || s < nks) {
-                    const f32x4 v0 = *(const f32x4*)(qrow + 16 * s), v1 = *(const f32x4*)(qrow + 16 * s + 4);
-                    f32x4 c0 = f32x4{0.f, 0.f, 0.f, 0.f}, c1 = c0;
-                    if (METRIC == METRIC_L2) {
-                        c0 = *(const f32x4*)(cen + 16 * s);
-                        c1 = *(const f32x4*)(cen + 16 * s + 4);
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float r0v = v0[e] - c0[e], r1v = v1[e] - c1[e];
-                        accn = __fmaf_rn(r0v, r0v, accn);
-                        accn = __fmaf_rn(r1v, r1v, accn);
-                        o[e] = (_Float16)r0v;
-                        o[4 + e] = (_Float16)r1v;
-                    }
-                }
-                bq[b][s] = o;
+                if (FULLK || s < nks) bq[b][s] = *(const half8*)(qrow + 16 * s);
+                else bq[b][s] = half8{0, 0, 0, 0, 0, 0, 0, 0};
             }
-            // |q - c|^2: the two half chains of the lane pair (h = 0 / 1)
-            L[b].xh = METRIC == METRIC_L2 ? -0.5f * (accn + __shfl_xor(accn, 32, 64)) : p.coarse_dis[pi];
+            L[b].xh = METRIC == METRIC_L2 ? p.pair_xh[pi] : p.coarse_dis[pi];
             L[b].base_pos = p.prefix[(int64_t)q * (np + 1) + pr];
             L[b].qpr = ((uint32_t)q << 11) | (uint32_t)pr;
             L[b].tq = INFINITY;
@@ -1052,36 +1034,61 @@ void launch_ivf_lmf_bound(const IvfLmParams& p, const float* xn_bound, hipStream
     HIP_CHECK(hipGetLastError());
 }
 
-// ------------------------------------------------------------------ IVFPQ: per-query preparation
-// xn_bound[q] = max over the probes of |q - c|^2 (L2; inner product: |q|^2): the |q'|^2 of the error band.  One wavefront per
-// query (any summation order: it only feeds the band; 1.0001 x covers the difference to the sweeps' own chains).
+// ------------------------------------------------------------------ IVFPQ: per-search preparation
+// The sweeps' B operands and query terms, once per search instead of at every work item (a list of 24 000 rows is cut into
+// four items, each of which loaded 96 fp32 queries + the centroid and rounded the differences: 48 loads and ~200 VALU
+// instructions per query block and item -- half of an item's life at nb = 1M):
+//   L2: pair16[(q, probe)][d] = fp16 of (q - centroid), pair_xh[(q, probe)] = -|q - c|^2 / 2;
+//   inner product: pair16[q][d] = fp16 of q (the coarse term of a pair is read from coarse_dis).
+// xn_bound[q] = max over the probes of |q - c|^2 (inner product: |q|^2): the |q'|^2 of the error band.
+// Sixteen lanes per (query, probe): lane (s, h) owns the coordinates 16 s + 8 h .. + 7 -- one operand piece of the sweeps --
+// so a pair reads its query and centroid rows and writes its fp16 row as contiguous 512 / 256 bytes.  |q - c|^2 is the
+// tree sum of the sixteen 8-term chains (any order serves: the value only enters estimates, and the error band covers the
+// fp32 chains of the norms with (d + 8) 2^-23 of their magnitude).
 __global__ void __launch_bounds__(256) lmf_pq_prepare_kernel(IvfLmParams p, float* __restrict__ xn_bound) {
-    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (q >= p.nq) return;
-    const int lane = threadIdx.x & 63;
     const int np = p.nprobe;
-    const float* x = p.xq + (int64_t)q * p.ldq;
-    float mx = 0.f;
-    for (int pr = 0; pr < np; ++pr) {
-        const int64_t l = p.coarse_ids[(int64_t)q * np + pr];
-        if (l < 0) continue;
-        const float* c = p.centroids + l * p.ldc;
-        float acc = 0.f;
-        for (int k = lane; k < p.d; k += 64) {
-            const float v = p.metric == METRIC_L2 ? x[k] - c[k] : x[k];
-            acc = __fmaf_rn(v, v, acc);
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t pair = t >> 4;
+    const int sub = (int)(t & 15);
+    if (pair >= (int64_t)p.nq * np) return; // (whole groups of 16 lanes leave together)
+    const int q = (int)(pair / np), pr = (int)(pair - (int64_t)q * np);
+    const bool l2 = p.metric == METRIC_L2;
+    if (!l2 && pr != 0) return; // (inner product: one row per query)
+    const int64_t l = p.coarse_ids[pair];
+    float acc = 0.f;
+    if (8 * sub < p.d) {
+        const float* x = p.xq + (int64_t)q * p.ldq + 8 * sub;
+        const f32x4 v0 = *(const f32x4*)x, v1 = *(const f32x4*)(x + 4);
+        f32x4 c0 = f32x4{0.f, 0.f, 0.f, 0.f}, c1 = c0;
+        if (l2 && l >= 0) {
+            const float* c = p.centroids + l * p.ldc + 8 * sub;
+            c0 = *(const f32x4*)c;
+            c1 = *(const f32x4*)(c + 4);
         }
+        half8 o;
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
-        mx = fmaxf(mx, acc);
-        if (p.metric != METRIC_L2) break; // (|q|^2 does not depend on the probe)
+        for (int e = 0; e < 4; ++e) {
+            const float r0 = v0[e] - c0[e], r1 = v1[e] - c1[e];
+            acc = __fmaf_rn(r0, r0, acc);
+            acc = __fmaf_rn(r1, r1, acc);
+            o[e] = (_Float16)r0;
+            o[4 + e] = (_Float16)r1;
+        }
+        *(half8*)((_Float16*)p.pair16 + (l2 ? pair : (int64_t)q) * p.d + 8 * sub) = o;
     }
-    if (lane == 0) xn_bound[q] = mx * 1.0001f;
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) acc += __shfl_xor(acc, off, 64);
+    if (sub == 0) {
+        if (l2) p.pair_xh[pair] = -0.5f * acc;
+        if (l >= 0 || !l2) atomicMax((unsigned*)xn_bound + q, __float_as_uint(acc * 1.0001f)); // (non-negative floats order as integers)
+    }
 }
 void launch_ivf_lmf_pq_prepare(const IvfLmParams& p, float* xn_bound, hipStream_t stream) {
     if (p.nq == 0) return;
-    FA_THROW_IF_NOT(p.kind == 1 && p.centroids);
-    hipLaunchKernelGGL(lmf_pq_prepare_kernel, dim3((unsigned)div_up(p.nq, 4)), dim3(256), 0, stream, p, xn_bound);
+    FA_THROW_IF_NOT(p.kind == 1 && p.centroids && p.pair16 && p.pair_xh && p.d % 16 == 0 && p.d <= 128 && p.ldq % 4 == 0 && p.ldc % 4 == 0);
+    HIP_CHECK(hipMemsetAsync(xn_bound, 0, (size_t)p.nq * 4, stream));
+    hipLaunchKernelGGL(lmf_pq_prepare_kernel, dim3((unsigned)div_up((size_t)p.nq * p.nprobe * 16, 256)), dim3(256), 0, stream, p,
+                       xn_bound);
     HIP_CHECK(hipGetLastError());
 }
 

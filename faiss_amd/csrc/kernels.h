@@ -494,6 +494,11 @@ struct IvfLmParams {
     const void* pq16;           // [M][256][dsub] fp16 codebook (kind 1)
     const float* pq_t;          // [256][M][dsub] fp32 codebook, transposed: the order the exact path builds its table in
     const uint32_t* qflags;     // [nq] nonzero: the query leaves the fp16 range / holds NaN -> not filtered (fallback)
+    // kind 1: the sweeps' B operands, prepared once per search (launch_ivf_lmf_pq_prepare) instead of at every work item:
+    // L2 [nq * nprobe][d] fp16 of (q - centroid of the probe), pair_xh [nq * nprobe] = -|q - c|^2 / 2; inner product
+    // [nq][d] fp16 of q (the coarse term of a pair comes from coarse_dis)
+    void* pair16;
+    float* pair_xh;
     uint16_t* cand_pr;          // [nq][stride] probe number of every collected candidate (beside keys)
     const float* arena_t2;      // kind 1, L2: the per-row term of the query-major scan (rerank)
     const float* xn_full;       // [nq] |q|^2 (kind 0: == xqn)
@@ -532,7 +537,7 @@ void launch_ivf_lmf_sweep(const IvfLmParams& p, int mode, int grid_blocks, hipSt
 // thr_f[q] from gmin (k-th best granule estimate + 2 x ivf_filter_err_bound); queries with qflags set get "nothing" and are
 // appended to ovf (zeroed here).  xn_bound: [nq] upper bound of |q'|^2 over the query's probes (kind 0: |q|^2).
 void launch_ivf_lmf_bound(const IvfLmParams& p, const float* xn_bound, hipStream_t stream);
-// kind 1: xn_bound[q] = max over the probes of |q - c|^2
+// kind 1: xn_bound[q] = max over the probes of |q - c|^2; pair16 / pair_xh = the sweeps' B operands and query terms
 void launch_ivf_lmf_pq_prepare(const IvfLmParams& p, float* xn_bound, hipStream_t stream);
 // keys[q][0 .. cnt[q]) <- the exact distance of the query-major scan (ivf_fused.hip) for the same row, bit for bit
 void launch_ivf_lmf_rerank(const IvfLmParams& p, hipStream_t stream);
