@@ -5,7 +5,7 @@
 #   2. one --pmc pass per counter group (never combined with runtime / sys tracing) on the search loop of every bench leg:
 #      flat, IVFPQ nb=1M (query-major), IVFFlat nb=1M / 10M and IVFPQ nb=10M / 100M (list-major behind the f16 filter),
 #      IVF-SQ8 nb=1M (list-major, f32 pipe).  bench.py reads its roofline.traffic blocks from the JSON summaries.
-TAG=${1:-r04_q}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
