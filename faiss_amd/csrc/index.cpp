@@ -2712,6 +2712,15 @@ void GpuIndexIVF::search_listmajor_filter_chunk_(int ni, int q0, const float* xq
         launch_ivf_lmf_sweep(P, 2, grid, R.stream);
     }
     launch_ivf_lm_clamp(P, R.stream);
+    // the workgroup that re-derives a query's candidates also selects its k best when both fit its LDS (no selection launch)
+    // (IVFFlat: rerank 0.135 -> 0.19 ms for 0.105 ms of selection launch at nb = 1M; IVFPQ keeps the separate launch: its rerank
+    // workgroups -- two per CU, the 64 KB table -- serialise the tail: 0.25 -> 0.52 ms)
+    const bool fused_select = P.kind == 0 && k <= kLmfFusedSelectK && stride <= kLmfFusedSelectN;
+    if (fused_select) {
+        P.fin_dis = dD;
+        P.fin_ids = dI;
+        P.arena_ids = arena_ids_.as<int64_t>();
+    }
     {
         SpanGuard sg(&R, "ivf_lmf_rerank");
         launch_ivf_lmf_rerank(P, R.stream);
@@ -2734,7 +2743,7 @@ void GpuIndexIVF::search_listmajor_filter_chunk_(int ni, int q0, const float* xq
     sp.arena_ids = arena_ids_.as<int64_t>();
     sp.out_dis = dD;
     sp.out_ids = dI;
-    {
+    if (!fused_select) {
         SpanGuard sg(&R, "select_k_kernel");
         launch_select_k(sp, R.stream);
     }

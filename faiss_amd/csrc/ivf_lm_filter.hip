@@ -1098,8 +1098,59 @@ void launch_ivf_lmf_pq_prepare(const IvfLmParams& p, float* xn_bound, hipStream_
 // IVFFlat: the arithmetic of ivfflat_fused_kernel -- lane ln of the group owns the 16-byte chunks ln, ln + 8, ... of the row
 // and keeps one sequential fmaf chain of (q - y)^2 (inner product: q * y) over them; the eight partial sums meet in the
 // xor butterfly ((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7)).
+// The k best of a query's re-derived candidates, by the workgroup that holds them (IvfLmParams::fin_dis): keys kl[0 .. n) in
+// LDS (ordkey << 32 | scan position, all distinct), their probe numbers in cpr.  Winners = the k smallest keys (rank by
+// counting: every thread reads the same kl[j], an LDS broadcast); labels from the stored ids; output order by (distance,
+// label) among the winners, ties of both by their winner slot -- what select_k_kernel / wave_select_kernel produce.
+// wk / wl: LDS room for kLmfFusedSelectK winners.  Called by all threads of the workgroup.
+template <int THREADS>
+__device__ __forceinline__ void lmf_select_tail(const IvfLmParams& p, int q, int n, const u64* kl, const uint16_t* cpr, uint32_t* wk,
+                                                int64_t* wl) {
+    const int tid = threadIdx.x, np = p.nprobe, k = p.k;
+    __syncthreads();
+    for (int i = tid; i < n; i += THREADS) {
+        const u64 ki = kl[i];
+        int r = 0;
+        for (int j = 0; j < n; ++j) r += kl[j] < ki ? 1 : 0;
+        if (r < k) {
+            const uint32_t pos = (uint32_t)ki;
+            const int pr = (int)cpr[i];
+            const int64_t l = p.coarse_ids[(int64_t)q * np + pr];
+            wk[r] = (uint32_t)(ki >> 32);
+            wl[r] = p.arena_ids[p.list_start[l] + (pos - p.prefix[(int64_t)q * (np + 1) + pr])];
+        }
+    }
+    __syncthreads();
+    const int nwin = min(n, k);
+    const float pad = neutral_distance(p.metric);
+    float* od = p.fin_dis + (int64_t)q * k;
+    int64_t* oi = p.fin_ids + (int64_t)q * k;
+    for (int i = tid; i < k; i += THREADS) {
+        if (i >= nwin) { // fewer candidates than k: the tail is padding
+            od[i] = pad;
+            oi[i] = -1;
+            continue;
+        }
+        const uint32_t a = wk[i];
+        const int64_t ia = wl[i];
+        int r = 0;
+        for (int j = 0; j < nwin; ++j) {
+            const uint32_t b = wk[j];
+            const int64_t ib = wl[j];
+            r += (b < a || (b == a && (ib < ia || (ib == ia && j < i)))) ? 1 : 0;
+        }
+        const bool real = a < kInvalidOrdKey;
+        od[r] = real ? unordkey_rt(p.metric, a) : pad;
+        oi[r] = real ? ia : -1;
+    }
+}
+
 template <int METRIC>
 __global__ void __launch_bounds__(256) lmf_rerank_flat_kernel(IvfLmParams p) {
+    __shared__ u64 sel_k[kLmfFusedSelectN];
+    __shared__ uint32_t sel_wk[kLmfFusedSelectK];
+    __shared__ int64_t sel_wl[kLmfFusedSelectK];
+    const bool fin = p.fin_dis != nullptr; // (launch_ivf_lmf_rerank checked k and stride)
     const int q = blockIdx.x;
     const int ln = threadIdx.x & 7, grp = threadIdx.x >> 3; // 32 groups: 32 candidates per round, their loads in flight together
     const int np = p.nprobe;
@@ -1136,8 +1187,13 @@ __global__ void __launch_bounds__(256) lmf_rerank_flat_kernel(IvfLmParams p) {
         a = a + __shfl_xor(a, 1, 64);
         a = a + __shfl_xor(a, 2, 64);
         a = a + __shfl_xor(a, 4, 64);
-        if (valid && ln == 0) kq[i] = ((u64)ordkey<METRIC>(a) << 32) | (u64)pos;
+        if (valid && ln == 0) {
+            const u64 key = ((u64)ordkey<METRIC>(a) << 32) | (u64)pos;
+            if (fin) sel_k[i] = key;
+            else kq[i] = key;
+        }
     }
+    if (fin) lmf_select_tail<256>(p, q, n, sel_k, cpr, sel_wk, sel_wl);
 }
 // IVFPQ: the arithmetic of ivfpq_fused_kernel.  The workgroup first builds the query's table exactly as the query-major
 // scan does (oracle orc_ivf_search_ex arith 0): entries <q_m, cb[m][c]> as sequential fmaf chains from 0, B = sum_m max_c
@@ -1156,10 +1212,18 @@ __global__ void __launch_bounds__(RRQ_THREADS) lmf_rerank_pq_kernel(IvfLmParams 
     const int ln = tid & 7, grp = tid >> 3;
     const int np = p.nprobe, M = p.M, dsub = p.dsub;
     const int n = (int)min((int64_t)p.cnt[q], p.stride);
-    if (n == 0) return; // (workgroup-uniform)
     float* lut = (float*)smem;                      // [256][M]
     uint32_t* colmax = (uint32_t*)(lut + M * 256);  // [M]
     float* grid = (float*)(colmax + M);             // delta, 1 / delta, on
+    // fused selection (IvfLmParams::fin_dis): keys + winners behind the table
+    const bool fin = p.fin_dis != nullptr;
+    u64* sel_k = (u64*)(smem + ((M * 1024 + M * 4 + 16 + 15) & ~15));
+    int64_t* sel_wl = (int64_t*)(sel_k + kLmfFusedSelectN);
+    uint32_t* sel_wk = (uint32_t*)(sel_wl + kLmfFusedSelectK);
+    if (n == 0) { // (workgroup-uniform)
+        if (fin) lmf_select_tail<RRQ_THREADS>(p, q, 0, sel_k, nullptr, sel_wk, sel_wl);
+        return;
+    }
     u64* kq = p.keys + (int64_t)q * p.stride;
     const uint16_t* cpr = p.cand_pr + (int64_t)q * p.stride;
     const float* x = p.xq + (int64_t)q * p.ldq;
@@ -1286,19 +1350,23 @@ __global__ void __launch_bounds__(RRQ_THREADS) lmf_rerank_pq_kernel(IvfLmParams 
         }
         if (valid && ln == 0) {
             const float dis = METRIC == METRIC_L2 ? __fmaf_rn(-2.f, s, dis0 + t2) : dis0 + s;
-            kq[i] = ((u64)ordkey<METRIC>(dis) << 32) | (u64)pos;
+            const u64 key = ((u64)ordkey<METRIC>(dis) << 32) | (u64)pos;
+            if (fin) sel_k[i] = key;
+            else kq[i] = key;
         }
     }
+    if (fin) lmf_select_tail<RRQ_THREADS>(p, q, n, sel_k, cpr, sel_wk, sel_wl);
 }
 void launch_ivf_lmf_rerank(const IvfLmParams& p, hipStream_t stream) {
     if (p.nq == 0) return;
+    FA_THROW_IF_NOT(!p.fin_dis || (p.fin_ids && p.arena_ids && p.k <= kLmfFusedSelectK && p.stride <= kLmfFusedSelectN));
     const dim3 grid((unsigned)p.nq), block(256);
     if (p.kind == 0) {
         if (p.metric == METRIC_L2) hipLaunchKernelGGL(lmf_rerank_flat_kernel<METRIC_L2>, grid, block, 0, stream, p);
         else hipLaunchKernelGGL(lmf_rerank_flat_kernel<METRIC_INNER_PRODUCT>, grid, block, 0, stream, p);
     } else {
         FA_THROW_IF_NOT((p.metric != METRIC_L2 || p.arena_t2) && p.pq_t);
-        const int lds = p.M * 1024 + p.M * 4 + 16;
+        const int lds = ((p.M * 1024 + p.M * 4 + 16 + 15) & ~15) + (p.fin_dis ? kLmfFusedSelectN * 8 + kLmfFusedSelectK * 12 : 0);
         FA_THROW_IF_NOT(lds <= 160 * 1024);
         if (p.metric == METRIC_L2) {
             HIP_CHECK(hipFuncSetAttribute((const void*)lmf_rerank_pq_kernel<METRIC_L2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));

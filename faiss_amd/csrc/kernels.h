@@ -508,7 +508,14 @@ struct IvfLmParams {
     // IDSelector of the search in flight (filter path only): one bit per arena row (launch_selector_mask), null = none.
     // Excluded rows take no part in the bound nor in the collection: the result is that of the selected subset.
     const uint32_t* sel_mask;
+    // rerank kernels: when fin_dis is set (k <= kLmfFusedSelectK, stride <= kLmfFusedSelectN) the workgroup that re-derived a
+    // query's candidates also selects its k best -- (distance, scan position) picks them, (distance, label) orders them,
+    // the rule of select_k_kernel / wave_select_kernel -- and writes the result rows; no selection launch follows
+    float* fin_dis;
+    int64_t* fin_ids;
+    const int64_t* arena_ids;
 };
+constexpr int kLmfFusedSelectK = 256, kLmfFusedSelectN = 1024;
 // |estimate - exact| <= this for every stored row, whatever the data: `estimate` = what the f16 MFMA sweeps of
 // ivf_lm_filter.hip compute (L2: fmaf(-2, <f16 q', f16 y'>, |q'|^2 + |y'|^2) with the two norms as fp32 chains; IP:
 // <f16 q', f16 y'> [+ coarse term]), `exact` = the distance the query-major scan returns for the same row (and the rerank
