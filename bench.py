@@ -133,7 +133,7 @@ def cpu_baseline_flat(xb, xq, k, gpu_D, gpu_I, budget_s=25.0):
         dt = time.time() - t0
         kind, threads = "port", cores
         sample = "oracle/faiss_oracle.c restatement (OpenMP over queries), first %d queries" % ns
-    out = {"value": round(ns / dt, 1), "unit": "QPS", "cores": int(threads), "kind": kind, "sample": sample}
+    out = {"value": round(ns / dt, 1), "unit": "QPS", "cores": int(threads), "cpu_model": cpu_model(), "kind": kind, "sample": sample}
     if gpu_I is not None:
         out["parity_vs_gpu"] = classify_parity(gpu_D[:ns], gpu_I[:ns], Dr, Ir)
         out["parity_vs_gpu"]["recall_at_1"] = float((gpu_I[:ns, 0] == Ir[:, 0]).mean())
@@ -212,7 +212,7 @@ def ivf_leg(kind, res, xt, xb, xq, xq_dev, gt_first, steps, torch, with_cpu=True
     out = {
         "workload": "%s nlist=%d nprobe=%d d=%d nb=%d nq=%d k=%d" % (title, NLIST, NPROBE, D, NB, NQ, K),
         "scan": scan_name(list_major, idx.last_scan_arith()),
-        "qps": round(NQ / dt, 1), "ms_per_step": round(dt * 1e3, 3),
+        "qps": round(NQ / dt, 1), "ms_per_step": round(dt * 1e3, 3), "steps": int(steps),
         "ms_per_step_with_event_spans": round(dt_spans * 1e3, 3),
         "timing": "qps / ms_per_step: loop of searches without instrumentation; kernels_ms and roofline: a second loop with a "
                   "HIP-event span around every launch",
@@ -244,7 +244,7 @@ def ivf_leg(kind, res, xt, xb, xq, xq_dev, gt_first, steps, torch, with_cpu=True
             t0 = time.time()
             Dr, Ir = ref.search(xq, K)
             dtc = time.time() - t0
-            cpu = {"value": round(NQ / dtc, 1), "unit": "QPS", "cores": int(cores), "kind": "reference",
+            cpu = {"value": round(NQ / dtc, 1), "unit": "QPS", "cores": int(cores), "cpu_model": cpu_model(), "kind": "reference",
                    "sample": "faiss 1.15.0 index_factory('%s') with the GPU-trained quantizers, nprobe=%d, all %d queries, "
                              "nb=%d, k=%d" % (factory, NPROBE, NQ, NB, K),
                    "add_s": round(t_cadd, 1),
@@ -564,7 +564,7 @@ def cpu_baseline_on_gpu_lists(kind, idx, nb, xq, Dg, Ig, leg_1m, budget_s):
     t0 = time.time()
     Dr, Ir = ref.search(xq[:ns], K)
     dt = time.time() - t0
-    out = {"value": round(ns / dt, 1), "unit": "QPS", "cores": int(cores), "kind": "reference",
+    out = {"value": round(ns / dt, 1), "unit": "QPS", "cores": int(cores), "cpu_model": cpu_model(), "kind": "reference",
            "sample": "faiss 1.15.0 %s.search MEASURED at nb=%d: the first %d of the %d queries in one batch (%.1f s), nprobe=%d, "
                      "k=%d, %d OpenMP threads; the index holds the GPU index's quantizers and its inverted lists (read back "
                      "and appended with add_entries in %.1f s: no CPU add at this size)"
@@ -876,6 +876,167 @@ def _shard_roofline(r, rows_per_rank):
     return r
 
 
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The ONE line the driver parses.  Everything measured lands in the `detail` dict (bench_detail.json, written next to this
+# file and under gpurun_out/ when that exists); the printed line is the compact view of it: the contract's top-level keys
+# for the headline Flat leg + one short record per BASELINE.json config.  Bounded: tests/test_bench_line_cpu.py asserts
+# < 4096 bytes on a canned full record (round 4's 25 KB line could not be parsed by the driver).
+MAX_LINE_BYTES = 4096
+DETAIL_NAME = "bench_detail.json"
+
+
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return " ".join(ln.split(":", 1)[1].split())[:48]
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _num(v, nd=4):
+    return round(v, nd) if isinstance(v, float) else v
+
+
+def _traffic_bytes(t):
+    """HBM bytes of the dominant launch from a detail traffic block (per launch for the query-major / flat kernels; for the
+    list-major legs the block lists the sweeps: the largest entry is sweep 2 = the kernel the roofline prices)"""
+    if not isinstance(t, dict):
+        return None, None
+    if "hbm_read_bytes_per_launch_from_committed_profile" in t:
+        return t["hbm_read_bytes_per_launch_from_committed_profile"], None
+    ks = t.get("kernels") or {}
+    per_launch = max((v.get("bytes", 0) for v in ks.values()), default=None)
+    return per_launch, t.get("hbm_read_bytes_per_search_from_committed_profile")
+
+
+def compact_roofline(r):
+    if not isinstance(r, dict) or "bound" not in r:
+        return None
+    per_launch, per_search = _traffic_bytes(r.get("traffic"))
+    out = {"bound": r["bound"], "kernel": str(r.get("kernel", "")).split(" in sweep")[0].split(":")[0][:60],
+           "achieved": r.get("achieved"), "peak": r.get("peak"), "unit": r.get("unit"), "frac": r.get("frac"),
+           "avg_kernel_ms": r.get("avg_kernel_ms"), "traffic": per_launch}
+    alg = r.get("algorithmic_bytes_per_launch")
+    if per_launch and alg:
+        out["traffic_ratio"] = round(per_launch / float(alg), 2)
+    if per_search and alg:
+        out["search_traffic_ratio"] = round(per_search / float(alg), 2)
+    return out
+
+
+def compact_leg(name, leg):
+    """one short record per BASELINE config: throughput, the dominant kernel's roofline fraction, parity, CPU baseline"""
+    if not isinstance(leg, dict):
+        return None
+    if "error" in leg or "skipped" in leg:
+        return {k: str(leg[k])[:120] for k in ("error", "skipped") if k in leg}
+    wl = str(leg.get("workload", name)).split(" (BASELINE")[0].split(" (1250")[0]
+    for a, b in ((" nq=%d k=%d" % (NQ, K), ""), (" d=%d" % D, ""), ("000000000", "B"), ("000000", "M"), ("GpuIndex", "")):
+        wl = wl.replace(a, b)
+    out = {"workload": wl[:80], "qps": leg.get("qps"), "ms_per_step": leg.get("ms_per_step"),
+           "steps": leg.get("steps"),
+           "scan": "lm-f16" if "f16 filter" in str(leg.get("scan")) else
+                   "lm-f32" if "list-major" in str(leg.get("scan")) else "qm"}
+    r = compact_roofline(leg.get("roofline"))
+    if r:
+        out.update({"bound": r["bound"], "frac": r["frac"], "kernel_ms": r["avg_kernel_ms"]})
+        for k in ("traffic_ratio", "search_traffic_ratio"):
+            if k in r and name != "ivfpq_shards":  # the shard leg borrows the nb = 100M counters: not its own ratio
+                out[k] = r[k]
+    for k in ("recall_at_1", "recall_at_100", "speedup_vs_cpu", "ranks_seen", "devices"):
+        if leg.get(k) is not None:
+            out[k] = leg[k]
+    c = leg.get("cpu_baseline")
+    if isinstance(c, dict) and "value" in c:
+        out["cpu_qps"] = c["value"]
+        out["cpu_queries"] = c.get("queries", NQ)
+        pv = c.get("parity_vs_gpu") or {}
+        if "real_mismatches" in pv:
+            out["real_mismatches"] = pv["real_mismatches"] if isinstance(pv["real_mismatches"], int) else "FAILED"
+            out["max_rel_dist_err"] = pv.get("max_rel_dist_err")
+    par = leg.get("parity")
+    if isinstance(par, dict):
+        out["oracle_sample_bit_exact"] = bool(par.get("sampled_queries_bit_exact_vs_oracle_on_probed_lists",
+                                                      par.get("merged_bit_exact") and all(par.get("per_shard_bit_exact", [False]))))
+        out["oracle_sample_queries"] = par.get("sampled_queries")
+    return {k: v for k, v in out.items() if v is not None}
+
+
+LEG_NAMES = ("ivfpq", "ivfflat", "ivfsq", "ivfflat_10m", "ivfpq_100m", "ivfpq_shards")
+
+
+def compact_line(detail, detail_path=DETAIL_NAME):
+    """the printed line: contract keys of the headline leg + `legs` (compact_leg of every leg present) + the path of the
+    full record.  Always < MAX_LINE_BYTES: optional fields are dropped in a fixed order if a value ever pushes it over."""
+    top = {k: detail.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                      "scaling", "vs_baseline", "dtype", "data")}
+    cfg = detail.get("config") or {}
+    top["config"] = {k: str(cfg[k])[:110] for k in ("workload", "generator", "sharding", "flat_path") if k in cfg}
+    r = detail.get("roofline") or {}
+    rc = compact_roofline(r) or {}
+    for k in ("launches", "whole_search_frac", "hbm_frac"):
+        if r.get(k) is not None:
+            rc[k] = r[k]
+    if r.get("mfma_busy_frac_from_committed_profile") is not None:
+        rc["mfma_busy"] = r["mfma_busy_frac_from_committed_profile"]
+    if r.get("bound") == "mfma":
+        rc["note"] = "MFMA-bound: north star's HBM gate does not bind (hbm_frac)"
+    top["roofline"] = rc
+    c = detail.get("cpu_baseline")
+    if isinstance(c, dict):
+        top["cpu_baseline"] = {k: (str(c[k])[:100] if k in ("sample", "error", "cpu_model") else c[k])
+                               for k in ("value", "unit", "cores", "cpu_model", "kind", "sample", "error") if k in c}
+        pv = c.get("parity_vs_gpu") or {}
+        if "real_mismatches" in pv:
+            top["parity_vs_cpu_reference"] = {"queries": pv.get("queries"),
+                                              "real_mismatches": pv["real_mismatches"] if isinstance(pv["real_mismatches"], int) else "FAILED",
+                                              "near_tie_mismatches": pv.get("near_tie_mismatches"),
+                                              "max_rel_dist_err": pv.get("max_rel_dist_err")}
+    for k in ("recall_at_1", "value_host_buffers", "filter_overflow_queries", "ranks_seen", "devices"):
+        if detail.get(k) is not None:
+            top[k] = detail[k]
+    legs = {}
+    for name in LEG_NAMES:
+        if name in detail:
+            legs[name] = compact_leg(name, detail[name])
+    if legs:
+        top["legs"] = legs
+    top["detail"] = detail_path
+    drop_order = ("oracle_sample_queries", "cpu_queries", "max_rel_dist_err", "steps", "kernel_ms", "recall_at_100", "scan",
+                  "workload")
+    s = json.dumps(top, separators=(",", ":"))
+    for key in drop_order:
+        if len(s) < MAX_LINE_BYTES:
+            break
+        for leg in legs.values():
+            if isinstance(leg, dict):
+                leg.pop(key, None)
+        s = json.dumps(top, separators=(",", ":"))
+    if len(s) >= MAX_LINE_BYTES:  # last resort: the headline leg alone
+        top.pop("legs", None)
+        s = json.dumps(top, separators=(",", ":"))
+    assert len(s) < MAX_LINE_BYTES, len(s)
+    return s
+
+
+def write_detail(detail):
+    """the full record (nprobe sweeps, per-kernel spans, prose) next to this file, and under gpurun_out/ when run through
+    gpurun (that directory is what travels back).  Returns the repo-relative path named in the printed line."""
+    txt = json.dumps(detail, indent=1)
+    rel = DETAIL_NAME
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, DETAIL_NAME), "w") as f:
+                    f.write(txt + "\n")
+            except OSError:
+                rel = None if d == ROOT else rel
+    return rel or "not written"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -916,6 +1077,18 @@ def main():
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
+
+    ranks_seen, devices = 1, [local_rank]
+    if world > 1:
+        # self-validation of an N-GPU record: the ranks the RCCL backend really connected (all-reduce of ones) and the HIP
+        # device each of them runs on (all-gather of hipGetDevice), printed in the line
+        ones = torch.ones(1, dtype=torch.int32, device=dev)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+        mine = torch.tensor([torch.cuda.current_device()], dtype=torch.int32, device=dev)
+        box = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(box, mine)
+        devices = [int(b.item()) for b in box]
 
     import faiss_amd  # after torch: both then share one HIP runtime in this process
     from faiss_amd.datasets import synthetic_dataset
@@ -1040,8 +1213,7 @@ def main():
         "value": round(qps, 1), "unit": "QPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "f32 in/out; f16 MFMA candidate filter + f32 exact re-rank, results bit-identical to the f32 scan"
-        if used_filter else "f32", "data": "synthetic",
+        "dtype": "f32 (f16 MFMA candidate filter + exact f32 re-rank: bit-identical to the f32 scan)" if used_filter else "f32", "data": "synthetic",
         "config": {"workload": "GpuIndexFlatL2 d=128 nb=1M nq=10k k=100 (BASELINE.json configs[1])",
                    "generator": "SyntheticDataset(d=128, nt=100k, nb=1M, nq=10k, seed=1338)",
                    "sharding": ("single GPU" if world == 1 else
@@ -1061,6 +1233,7 @@ def main():
                      "hbm_frac": round(hbm_bytes / (avg_scan_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 5)},
         "other_kernels_ms": others,
         "filter_overflow_queries": int(n_overflow),
+        "ranks_seen": ranks_seen, "devices": devices,
     }
     if world == 1:
         # the same search handed pageable host buffers (queries H2D, results D2H inside the timed region)
@@ -1119,7 +1292,7 @@ def main():
         line["ivfpq"] = ivfpq_multi
     if world > 1 and shards_multi is not None:
         line["ivfpq_shards"] = shards_multi
-    print(json.dumps(line), flush=True)
+    print(compact_line(line, write_detail(line)), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
