@@ -31,6 +31,7 @@ Run:  python bench.py [--gpus N --steps K --warmup W]
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -934,8 +935,9 @@ def compact_leg(name, leg):
     if "error" in leg or "skipped" in leg:
         return {k: str(leg[k])[:120] for k in ("error", "skipped") if k in leg}
     wl = str(leg.get("workload", name)).split(" (BASELINE")[0].split(" (1250")[0]
-    for a, b in ((" nq=%d k=%d" % (NQ, K), ""), (" d=%d" % D, ""), ("000000000", "B"), ("000000", "M"), ("GpuIndex", "")):
+    for a, b in ((" nq=%d k=%d" % (NQ, K), ""), (" d=%d" % D, ""), ("GpuIndex", "")):
         wl = wl.replace(a, b)
+    wl = re.sub(r"nb=(\d+)000000\b", r"nb=\1M", wl)
     out = {"workload": wl[:80], "qps": leg.get("qps"), "ms_per_step": leg.get("ms_per_step"),
            "steps": leg.get("steps"),
            "scan": "lm-f16" if "f16 filter" in str(leg.get("scan")) else

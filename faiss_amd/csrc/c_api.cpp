@@ -1,6 +1,7 @@
 // faiss_amd/csrc/c_api.cpp -- extern "C" boundary (include/faiss_amd_c.h).
 // Error convention mirrors the reference C API (c_api/macros_impl.h:22-56, c_api/error_impl.cpp).
 #include "../../include/faiss_amd_c.h"
+#include "faiss_amd_internal.h"
 #include <cstring>
 #include <exception>
 #include <memory>
@@ -923,6 +924,12 @@ int faiss_amd_GpuIndexIVF_set_lmf_tuning(FaissAmdIndex* index, int rows_per_item
     FA_TRY
     auto* ix = as<GpuIndexIVF>(index, "GpuIndexIVF");
     FA_THROW_IF_NOT_MSG(rows_per_item >= 0 && gran_blocks >= 0 && cand_cap >= 0 && min_stride >= 0, "negative tuning value");
+    // the ranges the sweeps are built for: a bad value must fail HERE, not as an internal assertion of the next search
+    FA_THROW_IF_NOT_MSG(rows_per_item <= 65280, "rows_per_item: at most 65280 rows of a list per work item");
+    FA_THROW_IF_NOT_MSG(gran_blocks <= 32 && (gran_blocks & (gran_blocks - 1)) == 0,
+                        "gran_blocks: 0 (rule) or a power of two up to 32");
+    FA_THROW_IF_NOT_MSG(min_stride <= 8, "min_stride: 0 (rule) ... 8");
+    FA_THROW_IF_NOT_MSG(cand_cap == 0 || (cand_cap >= 256 && cand_cap <= 16384), "cand_cap: 0 (rule) or 256 ... 16384 per query");
     ix->lmf_rows_per_item = rows_per_item;
     ix->lmf_gran_blocks = gran_blocks;
     ix->lmf_cand_cap = cand_cap;

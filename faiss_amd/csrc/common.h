@@ -11,6 +11,7 @@
 #include <cfloat>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 
@@ -55,6 +56,14 @@ static inline int order_metric(int m) {
 struct FaissAmdException : public std::runtime_error {
     explicit FaissAmdException(const std::string& m) : std::runtime_error(m) {}
 };
+
+// Experiment / diagnostic knobs (FAISS_AMD_* environment variables) change timings and, some of them, RESULTS: a stray
+// variable in a production environment must not.  EVERY knob of the library is read through this gate: it answers only
+// when FAISS_AMD_EXPERIMENTS=1 is set too (tools/ and the two tests that drive a knob set it).
+static inline const char* experiment_env(const char* name) {
+    const char* e = getenv("FAISS_AMD_EXPERIMENTS");
+    return (e && e[0] == '1' && e[1] == 0) ? getenv(name) : nullptr;
+}
 
 #define FA_STR2(x) #x
 #define FA_STR(x) FA_STR2(x)

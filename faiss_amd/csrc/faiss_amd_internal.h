@@ -1,0 +1,40 @@
+/* faiss_amd/csrc/faiss_amd_internal.h -- test and tuning hooks of libfaiss_amd.so that have NO counterpart in the
+ * reference's interface.  They are exported (the Python test-suite and tools/ bind them through ctypes) but they are not
+ * part of the drop-in boundary: include/faiss_amd_c.h declares only what a reference-side binding would use.  Same error
+ * convention as the public header (0 ok, -2 FaissAmdException, -4 std::exception, -1 unknown; faiss_amd_get_last_error). */
+#ifndef FAISS_AMD_INTERNAL_H
+#define FAISS_AMD_INTERNAL_H
+#include "../../include/faiss_amd_c.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* approximate scores [n][ntotal] of the filter kernel (L2: <q,y> - |y|^2/2 on fp16 inputs; IP: <q,y>) and
+ * the per-query bound err_bound[n] on their deviation from the exact fp32 scores */
+int faiss_amd_GpuIndexFlat_filter_scores(const FaissAmdIndex* index, faiss_amd_idx_t n, const float* x, float* scores,
+                                         float* err_bound);
+
+/* the k best entries (smallest for L2, largest for inner product; ties to the lower column) of every row of the host
+ * matrix vals [rows][cols] through one selection primitive in isolation -- the stand-alone select test of the reference
+ * (faiss/gpu/test/TestGpuSelect.cu:23-198, runBlockSelect / runWarpSelect).  which: 0 = select_k_kernel (BlockSelect's
+ * role), 1 = workgroup LDS reservoir (fused IVF scans), 2 = wavefront select (flat scan reservoirs; winners unordered) */
+int faiss_amd_test_select(FaissAmdGpuResources* res, int which, FaissAmdMetricType metric, int rows, int cols, int k,
+                          const float* vals, float* out_distances, faiss_amd_idx_t* out_indices);
+
+/* Tuning experiments of the filter path (tools/lmf_sweep.py; results never change, only timings): rows of a list per
+ * work item, 32-row blocks per granule (1, 2, 4, 8), candidate room per query, and the block sampling stride of the
+ * first sweep (it may bound the k-th best estimate from every min_stride-th 32-row block).  0 = the built-in rule. */
+int faiss_amd_GpuIndexIVF_set_lmf_tuning(FaissAmdIndex* index, int rows_per_item, int gran_blocks, int cand_cap, int min_stride);
+
+/* Test hook of the f16 filter (no reference counterpart): for n host queries, the ESTIMATED distance of every row they
+ * probe as a key (ordkey(estimate) << 32 | scan position) at keys_out[q * stride + scan position] (slots nobody owns
+ * hold ~0), and band_out[q] = the error band the filter grants query q (|estimate - exact| <= band is what makes the
+ * collected rows a superset of the answer; tests/test_gpu_listmajor.py::test_list_filter_error_bound_holds).  band_out
+ * is read first: queries whose probed lists hold fewer than k granules keep the caller's value. */
+int faiss_amd_GpuIndexIVF_test_filter_dump(const FaissAmdIndex* index, int64_t n, const float* x, int nprobe, int64_t k, int64_t stride,
+                                           uint64_t* keys_out, float* band_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -717,7 +717,7 @@ static void launch_filter_mode(const FlatFilterParams& p, hipStream_t stream) {
 void launch_flat_filter(const FlatFilterParams& p_, int mode, hipStream_t stream) {
     if (p_.nq == 0 || p_.nb == 0) return;
     FlatFilterParams p = p_;
-    if (const char* e = getenv("FAISS_AMD_FILTER_DBG")) p.dbg = atoi(e);
+    if (const char* e = experiment_env("FAISS_AMD_FILTER_DBG")) p.dbg = atoi(e);
     FA_THROW_IF_NOT(p.dh % FQ_KS == 0 && p.ldqh % 8 == 0 && p.ldbh % 8 == 0);
     FA_THROW_IF_NOT(p.tstride >= 1 && p.nsplit >= 1);
     FA_THROW_IF_NOT_MSG(p.geom == 0 || (p.geom == 2 && p.dh == FQ_KS), "the 8-wave geometry needs dh == 128");

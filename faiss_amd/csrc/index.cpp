@@ -661,7 +661,7 @@ bool GpuIndexFlat::filter_applicable_(int k) const {
 void GpuIndexFlat::plan_filter_(int n, int k, int& geom, int& nsplit, int& tstride, int& cap, int& gcap) const {
     std::string knobs;
     for (const char* name : {"FAISS_AMD_FILTER_GEOM", "FAISS_AMD_FILTER_NSPLIT", "FAISS_AMD_FILTER_TSTRIDE"}) {
-        const char* e = getenv(name);
+        const char* e = experiment_env(name);
         knobs += e ? e : "-";
         knobs += ';';
     }
@@ -676,7 +676,7 @@ void GpuIndexFlat::plan_filter_(int n, int k, int& geom, int& nsplit, int& tstri
     // against 0.53, nq = 5120 (5 full groups) 1.60 against 1.71 (profiles/r02_g_flat_batch_sizes.txt)
     const double fill2 = (double)n / ((double)div_up((size_t)n, 1024) * 1024.0);
     geom = (dh_ == kFilterSlab && n >= 2048 && fill2 >= 0.92) ? 2 : 0;
-    if (const char* e = getenv("FAISS_AMD_FILTER_GEOM")) { // timing experiments only
+    if (const char* e = experiment_env("FAISS_AMD_FILTER_GEOM")) { // timing experiments only
         if (atoi(e) == 0 || dh_ == kFilterSlab) geom = atoi(e) ? 2 : 0;
     }
     const int qpb = flat_filter_queries_per_block(geom), cps = flat_filter_chunks_per_split(geom);
@@ -718,13 +718,13 @@ void GpuIndexFlat::plan_filter_(int n, int k, int& geom, int& nsplit, int& tstri
         }
     }
     nsplit = best;
-    if (const char* e = getenv("FAISS_AMD_FILTER_NSPLIT")) nsplit = atoi(e); // timing experiments only
+    if (const char* e = experiment_env("FAISS_AMD_FILTER_NSPLIT")) nsplit = atoi(e); // timing experiments only
     const int tiles_per_split = total_tiles / nsplit;
     // sample of the maxima pass: every 8th tile when a split holds >= 96 of them (same-box A/B at the bench shape, round 4,
     // profiles/r04_d_flat_tstride_ab.txt + r04_e: stride 2 / 4 / 8 / 16 = 3.29 / 2.92 / 2.85 / 3.05 ms and 2.98 / 2.90 / 3.05 ms
     // for 4 / 8 / 16 on a second box: the halved maxima pass outweighs the doubled candidates, a quarter of it does not)
     tstride = tiles_per_split >= 96 ? 8 : tiles_per_split >= 32 ? 4 : tiles_per_split >= 16 ? 2 : 1;
-    if (const char* e = getenv("FAISS_AMD_FILTER_TSTRIDE")) tstride = std::max(1, atoi(e)); // timing experiments only
+    if (const char* e = experiment_env("FAISS_AMD_FILTER_TSTRIDE")) tstride = std::max(1, atoi(e)); // timing experiments only
     // expected rows above the threshold: S * -ln(1 - k/S) in the sample, tstride times that overall; the
     // re-rank kernel gathers at most 4096 of them per query, so large k samples more tiles
     const double S = (double)cps * nsplit;
@@ -1442,7 +1442,7 @@ void Clustering::train_device_(idx_t nx, const float* x_in, int64_t ldx, GpuInde
     // a chunk per wavefront of the rank kernel (which walks its chunk 64 points at a time): about 512 of them
     int chunk = 256;
     while (div_up(nx, chunk) > 512) chunk *= 2;
-    if (const char* e = getenv("FAISS_AMD_KMEANS_CHUNK")) chunk = std::max(64, atoi(e)); // timing experiments only
+    if (const char* e = experiment_env("FAISS_AMD_KMEANS_CHUNK")) chunk = std::max(64, atoi(e)); // timing experiments only
     const int nchunks = (int)div_up(nx, chunk);
     DevBuf dis, lab, hist, cnt, zero, start, dest, order;
     dis.ensure((size_t)nx * 4);
@@ -2150,7 +2150,7 @@ void GpuIndexIVF::search_core_body_(idx_t n, const float* x, idx_t k, float* dis
             fp.out_dis = dD;
             fp.out_ids = dI;
             // large batches: the final selection of a query runs in its own launch (ivf_finish_kernel)
-            static const char* defer_env = getenv("FAISS_AMD_IVF_DEFER"); // timing experiments only: 0 / 1
+            static const char* defer_env = experiment_env("FAISS_AMD_IVF_DEFER"); // timing experiments only: 0 / 1
             fp.defer_finish = fp.G == 1 && ni >= want && (!defer_env || atoi(defer_env) != 0) ? 1 : 0;
             if (defer_env && atoi(defer_env) == 1 && fp.G == 1) fp.defer_finish = 1;
             if (fp.G > 1 || fp.defer_finish) {
@@ -2170,7 +2170,7 @@ void GpuIndexIVF::search_core_body_(idx_t n, const float* x, idx_t k, float* dis
                                   d_list_start_.as<int64_t>(), probe_len_.as<uint32_t>(), probe_start_.as<int64_t>(), R.stream);
             fp.probe_len = probe_len_.as<uint32_t>();
             fp.probe_start = probe_start_.as<int64_t>();
-            static const bool phases = getenv("FAISS_AMD_IVF_PHASES") != nullptr; // diagnostics only
+            static const bool phases = experiment_env("FAISS_AMD_IVF_PHASES") != nullptr; // diagnostics only
             DevBuf ticks;
             if (phases && fp.kind == 1) {
                 ticks.ensure(64);
@@ -2294,16 +2294,6 @@ void GpuIndexIVF::search_core_body_(idx_t n, const float* x, idx_t k, float* dis
         if (!out_dev_i) copy_out(R, labels + (size_t)i0 * k, dI, (size_t)ni * k * 8);
         R.sync();
     }
-}
-
-// Experiment knobs of the list-major scans (FAISS_AMD_LM_*) change timings and, some of them, RESULTS: a stray variable in
-// a production environment must not.  They are read once per process and only when FAISS_AMD_EXPERIMENTS=1 is set too.
-static const char* experiment_env(const char* name) {
-    static const bool on = [] {
-        const char* e = getenv("FAISS_AMD_EXPERIMENTS");
-        return e && atoi(e) == 1;
-    }();
-    return on ? getenv(name) : nullptr;
 }
 
 // ---------------------------------------------------------------------- list-major search (ivf_listmajor.hip)
@@ -3272,7 +3262,7 @@ void GpuIndexIVFPQ::train_residual_(idx_t n, const float* x_dev_pad) {
                     dres.as<float>(), d, R.stream);
     R.sync();
     std::vector<float> pq((size_t)M * 256 * dsub);
-    const char* loop_env = getenv("FAISS_AMD_PQ_TRAIN_LOOP");
+    const char* loop_env = experiment_env("FAISS_AMD_PQ_TRAIN_LOOP");
     if (pq_train_batched && !(loop_env && atoi(loop_env) == 1) && pq_train_batched_supported(dsub) && nt >= 256) {
         train_pq_batched_(nt, dres.as<float>(), pq);
     } else {

@@ -967,7 +967,7 @@ void launch_ivf_finish(const IvfFusedParams& p, hipStream_t stream) {
 int ivf_fused_threads(int kind) {
     if (kind == 2) return SQ_FB;
     if (kind != 1) return FB_MAX;
-    if (const char* e = getenv("FAISS_AMD_IVFPQ_FB")) return atoi(e) == 1024 ? 1024 : 512; // timing experiments only
+    if (const char* e = experiment_env("FAISS_AMD_IVFPQ_FB")) return atoi(e) == 1024 ? 1024 : 512; // timing experiments only
     return 512;
 }
 bool ivf_fused_supported(int kind, int M, int dpad, int k, int nprobe, int* cap_out, int* kp_out, int* nlut_out) {

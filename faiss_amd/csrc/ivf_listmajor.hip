@@ -1260,7 +1260,7 @@ static void lr_launch_sq(const IvfLmParams& p, int pass, int grid_blocks, hipStr
 // with the LDS-DMA tiles against 0.276 register-fed (pass-1 items hold 10-17 queries: a DMA tile feeds two half-idle
 // waves for free, a register-fed wave pays every row's load latency alone).  FAISS_AMD_LM_P1_REG = 0 / 1 overrides.
 static bool lm_p1_reg(int kind) {
-    static const char* e = getenv("FAISS_AMD_LM_P1_REG");
+    static const char* e = experiment_env("FAISS_AMD_LM_P1_REG");
     if (e) return atoi(e) != 0;
     return kind == 2;
 }
@@ -1680,7 +1680,7 @@ int ivf_lm_blocks_per_cu(int kind) {
     return kind == 1 ? 3 : 2;
 }
 static bool lm_flat_lds_env() {
-    static const char* e = getenv("FAISS_AMD_LM_FLAT_LDS"); // timing experiments: 1 = the LDS-tile kernel for IVFFlat
+    static const char* e = experiment_env("FAISS_AMD_LM_FLAT_LDS"); // timing experiments: 1 = the LDS-tile kernel for IVFFlat
     return e && atoi(e) == 1;
 }
 int ivf_lm_queries_per_item(int kind) {
@@ -1689,13 +1689,13 @@ int ivf_lm_queries_per_item(int kind) {
     return (kind == 0 || kind == 2) && !lm_flat_lds_env() ? 32 : kLmQueriesPerItem;
 }
 static bool lm_use_pq_lds(const IvfLmParams& p) {
-    static const char* e = getenv("FAISS_AMD_LM_PQ_GENERIC"); // timing experiments: 1 = the generic (L2-gather) kernel
+    static const char* e = experiment_env("FAISS_AMD_LM_PQ_GENERIC"); // timing experiments: 1 = the generic (L2-gather) kernel
     return p.kind == 1 && ivf_lm_pq_lds_supported(p.d, p.dpad, p.M) && !(e && atoi(e) == 1);
 }
 int ivf_lm_grid_blocks(const IvfLmParams& p, int num_cus) {
     if (lm_use_pq_lds(p)) return num_cus; // one 8-wave workgroup per CU (the codebook fills its LDS)
     if (p.kind == 2) { // register-fed kernels in both passes (FAISS_AMD_LM_SQ_WG: occupancy experiments)
-        static const char* e = getenv("FAISS_AMD_LM_SQ_WG");
+        static const char* e = experiment_env("FAISS_AMD_LM_SQ_WG");
         const int per = e ? std::max(1, atoi(e)) : LrCfg<0>::WG_PER_CU;
         return per * num_cus / 8 * 8;
     }

@@ -473,7 +473,7 @@ __global__ void __launch_bounds__(256) wave_select_kernel(SelectParams p, int kp
     }
 }
 static bool wave_select_serves(const SelectParams& p) {
-    static const char* e = getenv("FAISS_AMD_WAVE_SELECT"); // timing experiments: 0 = the radix kernel everywhere
+    static const char* e = experiment_env("FAISS_AMD_WAVE_SELECT"); // timing experiments: 0 = the radix kernel everywhere
     if (e && atoi(e) == 0) return false;
     if (p.nseg != 1 || p.k > 256 || p.max_cnt <= 0) return false;
     // (segments longer than the 4096 keys the registers hold are streamed from memory in every bisection step: fine for

@@ -268,16 +268,6 @@ int faiss_amd_GpuIndexFlat_set_use_simple_kernel(FaissAmdIndex* index, int on);
 int faiss_amd_GpuIndexFlat_set_use_filter_kernel(FaissAmdIndex* index, int on, faiss_amd_idx_t min_rows);
 /* did the last search tile go through the filter, and how many of its queries were re-run exactly */
 int faiss_amd_GpuIndexFlat_filter_stats(const FaissAmdIndex* index, int* used_filter, int* overflow_queries);
-/* approximate scores [n][ntotal] of the filter kernel (L2: <q,y> - |y|^2/2 on fp16 inputs; IP: <q,y>) and
- * the per-query bound err_bound[n] on their deviation from the exact fp32 scores */
-int faiss_amd_GpuIndexFlat_filter_scores(const FaissAmdIndex* index, faiss_amd_idx_t n, const float* x, float* scores,
-                                         float* err_bound);
-/* the k best entries (smallest for L2, largest for inner product; ties to the lower column) of every row of the host
- * matrix vals [rows][cols] through one selection primitive in isolation -- the stand-alone select test of the reference
- * (faiss/gpu/test/TestGpuSelect.cu:23-198, runBlockSelect / runWarpSelect).  which: 0 = select_k_kernel (BlockSelect's
- * role), 1 = workgroup LDS reservoir (fused IVF scans), 2 = wavefront select (flat scan reservoirs; winners unordered) */
-int faiss_amd_test_select(FaissAmdGpuResources* res, int which, FaissAmdMetricType metric, int rows, int cols, int k,
-                          const float* vals, float* out_distances, faiss_amd_idx_t* out_indices);
 /* ---- the rest of the faiss::Index surface a coarse quantizer / shard wrapper uses
  *      reconstruct_batch (faiss/Index.h:297-307; GpuIndexFlat.cu:294-320), compute_residual[_n]
  *      (faiss/Index.h:363-383; GpuIndexFlat.cu:323-361, impl/VectorResidual.cu:26-97): residual = x - stored[key],
@@ -442,17 +432,6 @@ int faiss_amd_GpuIndexIVF_set_use_fused_scan(FaissAmdIndex* index, int on);
 int faiss_amd_GpuIndexIVF_set_scan_mode(FaissAmdIndex* index, int mode);
 int faiss_amd_GpuIndexIVF_scan_info(const FaissAmdIndex* index, int* mode, int* last_mode, int64_t* overflow_queries);
 int faiss_amd_GpuIndexIVF_last_scan_arith(const FaissAmdIndex* index, int* p_arith);
-/* Tuning experiments of the filter path (tools/lmf_sweep.py; results never change, only timings): rows of a list per
- * work item, 32-row blocks per granule (1, 2, 4, 8), candidate room per query, and the block sampling stride of the
- * first sweep (it may bound the k-th best estimate from every min_stride-th 32-row block).  0 = the built-in rule. */
-int faiss_amd_GpuIndexIVF_set_lmf_tuning(FaissAmdIndex* index, int rows_per_item, int gran_blocks, int cand_cap, int min_stride);
-/* Test hook of the f16 filter (no reference counterpart): for n host queries, the ESTIMATED distance of every row they
- * probe as a key (ordkey(estimate) << 32 | scan position) at keys_out[q * stride + scan position] (slots nobody owns
- * hold ~0), and band_out[q] = the error band the filter grants query q (|estimate - exact| <= band is what makes the
- * collected rows a superset of the answer; tests/test_gpu_listmajor.py::test_list_filter_error_bound_holds).  band_out
- * is read first: queries whose probed lists hold fewer than k granules keep the caller's value. */
-int faiss_amd_GpuIndexIVF_test_filter_dump(const FaissAmdIndex* index, int64_t n, const float* x, int nprobe, int64_t k, int64_t stride,
-                                           uint64_t* keys_out, float* band_out);
 /* *p_output = 1 when mode 0 sends a batch of n queries with this nprobe and k through the list-major scan */
 int faiss_amd_GpuIndexIVF_list_major_rule(const FaissAmdIndex* index, int64_t n, int nprobe, int64_t k, int* p_output);
 

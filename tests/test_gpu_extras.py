@@ -265,6 +265,7 @@ def test_pq_training_as_one_kmeans_equals_the_per_subspace_loop(res, d, M, nt, t
     nlist = 16
     cent = xt[:: nt // nlist][:nlist].copy()
     books = []
+    monkeypatch.setenv("FAISS_AMD_EXPERIMENTS", "1")  # the library reads its knobs only behind this gate
     for loop in ("1", "0"):
         monkeypatch.setenv("FAISS_AMD_PQ_TRAIN_LOOP", loop)
         idx = faiss_amd.GpuIndexIVFPQ(res, d, nlist, M, 8, faiss_amd.METRIC_L2)

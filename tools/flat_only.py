@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """tools/flat_only.py -- GpuIndexFlatL2 search loop on the bench data (profiling target for PMC passes)."""
 import os, sys, time
+os.environ["FAISS_AMD_EXPERIMENTS"] = "1"  # the library reads its FAISS_AMD_* knobs only behind this gate
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import faiss_amd

@@ -2,6 +2,7 @@
 """tools/flat_sweep.py -- GpuIndexFlatL2 search time vs query batch size on the bench database (1M x 128), with the
 planner's geometry / split count overridden through the timing knobs (FAISS_AMD_FILTER_GEOM / _NSPLIT)."""
 import os, sys, time
+os.environ["FAISS_AMD_EXPERIMENTS"] = "1"  # the library reads its FAISS_AMD_* knobs only behind this gate
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import faiss_amd

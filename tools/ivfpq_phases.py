@@ -2,6 +2,7 @@
 """tools/ivfpq_phases.py -- per-phase shader-clock ticks of the fused IVFPQ kernel (FAISS_AMD_IVF_PHASES diagnostics) and
 kernel time for the workgroup sizes 512 / 1024, nb = 1M, nprobe = 32."""
 import os, sys, time
+os.environ["FAISS_AMD_EXPERIMENTS"] = "1"  # the library reads its FAISS_AMD_* knobs only behind this gate
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch

@@ -7,6 +7,7 @@ combination per process, e.g.
 are API calls).
 usage: lm_sweep.py kind "p1/dbg" [nb] [nq]"""
 import os, sys, time
+os.environ["FAISS_AMD_EXPERIMENTS"] = "1"  # the library reads its FAISS_AMD_* knobs only behind this gate
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
