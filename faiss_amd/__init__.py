@@ -115,6 +115,8 @@ def load_library():
         "faiss_amd_GpuIndexIVF_set_use_fused_scan": (i32, [vp, i32]),
         "faiss_amd_GpuIndexIVF_set_scan_mode": (i32, [vp, i32]),
         "faiss_amd_GpuIndexIVF_scan_info": (i32, [vp, P(i32), P(i32), P(i64)]),
+        "faiss_amd_GpuIndexIVF_set_use_filter_shadow": (i32, [vp, i32]),
+        "faiss_amd_GpuIndexIVF_resident_bytes": (i32, [vp, P(ctypes.c_size_t), P(ctypes.c_size_t)]),
         "faiss_amd_GpuIndexIVF_last_scan_arith": (i32, [vp, P(i32)]),
         "faiss_amd_GpuIndexIVF_test_filter_dump": (i32, [vp, i64, vp, i32, i64, i64, vp, vp]),
         "faiss_amd_GpuIndexIVF_set_lmf_tuning": (i32, [vp, i32, i32, i32, i32]),
@@ -565,6 +567,16 @@ class _GpuIndexIVF(Index):
         """0 = automatic (large batches list-major), 1 = query-major always, 2 = list-major always (IVFFlat / IVFPQ: behind
         the f16 filter, results bit-identical to the query-major scan), 3 = list-major on the f32 matrix pipe (round 3)"""
         _check(self._lib.faiss_amd_GpuIndexIVF_set_scan_mode(self._h, int(mode)))
+
+    def set_use_filter_shadow(self, on):
+        """False: the automatic mode never builds the filter sweeps' copy of the lists (query-major serves, same bits)"""
+        _check(self._lib.faiss_amd_GpuIndexIVF_set_use_filter_shadow(self._h, 1 if on else 0))
+
+    def resident_bytes(self):
+        """(device bytes of the lists, device bytes of the filter sweeps' copies of them)"""
+        a, b = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        _check(self._lib.faiss_amd_GpuIndexIVF_resident_bytes(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
 
     def scan_info(self):
         """(mode set, mode of the last search: 1 query-major / 2 list-major, queries redone after a segment overflow)"""

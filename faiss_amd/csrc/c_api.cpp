@@ -912,6 +912,16 @@ int faiss_amd_GpuIndexIVF_set_scan_mode(FaissAmdIndex* index, int mode) {
     as<GpuIndexIVF>(index, "GpuIndexIVF")->scan_mode = mode;
     FA_CATCH
 }
+int faiss_amd_GpuIndexIVF_set_use_filter_shadow(FaissAmdIndex* index, int on) {
+    FA_TRY
+    as<GpuIndexIVF>(index, "GpuIndexIVF")->use_filter_shadow = on != 0;
+    FA_CATCH
+}
+int faiss_amd_GpuIndexIVF_resident_bytes(const FaissAmdIndex* index, size_t* p_lists, size_t* p_shadow) {
+    FA_TRY
+    as<GpuIndexIVF>(const_cast<FaissAmdIndex*>(index), "GpuIndexIVF")->resident_bytes(p_lists, p_shadow);
+    FA_CATCH
+}
 int faiss_amd_GpuIndexIVF_scan_info(const FaissAmdIndex* index, int* mode, int* last_mode, int64_t* overflow_queries) {
     FA_TRY
     auto* ix = as<GpuIndexIVF>(const_cast<FaissAmdIndex*>(index), "GpuIndexIVF");

@@ -65,6 +65,18 @@ static inline const char* experiment_env(const char* name) {
     return (e && e[0] == '1' && e[1] == 0) ? getenv(name) : nullptr;
 }
 
+// device allocation failure: lets a caller with an alternative (the query-major scan instead of the filter sweeps' shadow
+// copies) take it; everything else sees a FaissAmdException
+struct DeviceOutOfMemory : public FaissAmdException {
+    explicit DeviceOutOfMemory(const std::string& m) : FaissAmdException(m) {}
+};
+
+// This code base is written for gfx950 (CDNA4) and nothing else: inline assembly with gfx942+ cache-policy bits (`sc0`),
+// DPP row broadcasts, the 160 KB LDS, v_mfma_f32_32x32x16_f16.  Refuse any other device target at compile time.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "faiss_amd is written for gfx950 (MI355X); build with --offload-arch=gfx950"
+#endif
+
 #define FA_STR2(x) #x
 #define FA_STR(x) FA_STR2(x)
 #define FA_THROW_MSG(msg)                                                          \

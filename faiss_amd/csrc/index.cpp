@@ -30,7 +30,12 @@ void DevBuf::ensure(size_t bytes, size_t keep_bytes, hipStream_t stream) {
     size_t ncap = std::max(bytes, cap + cap / 2);
     ncap = round_up(ncap, 256);
     void* np = nullptr;
-    HIP_CHECK(hipMalloc(&np, ncap));
+    const hipError_t me = hipMalloc(&np, ncap);
+    if (me == hipErrorOutOfMemory) {
+        (void)hipGetLastError(); // (not sticky: the next call must not see it)
+        throw DeviceOutOfMemory("out of device memory allocating " + std::to_string(ncap) + " bytes");
+    }
+    HIP_CHECK(me);
     if (p && keep_bytes) {
         HIP_CHECK(hipMemcpyAsync(np, p, keep_bytes, hipMemcpyDeviceToDevice, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
@@ -1553,6 +1558,11 @@ void GpuIndexIVF::ensure_arena_(int64_t rows) {
     arena_cap_rows_ = ncap;
 }
 
+void GpuIndexIVF::resident_bytes(size_t* lists, size_t* shadow) const {
+    std::lock_guard<std::mutex> g(mu_);
+    if (lists) *lists = arena_.cap + arena_ids_.cap + arena_t2_.cap + arena_rn_.cap;
+    if (shadow) *shadow = lmf_shadow_bytes_();
+}
 void GpuIndexIVF::arena_stats(int64_t* used, int64_t* holes, int64_t* allocated) const {
     std::lock_guard<std::mutex> g(mu_);
     if (used) *used = arena_rows_;
@@ -2024,9 +2034,18 @@ void GpuIndexIVF::search_core_(idx_t n, const float* x, idx_t k, float* distance
     // the call (same bits, no filter).
     cur_preassigned_ = assign != nullptr;
     cur_lmf_ = cur_lm_ && scan_mode != 3 && lmf_capable_();
+    if (cur_lmf_ && scan_mode == 0 && !use_filter_shadow) cur_lmf_ = cur_lm_ = false; // (the caller opted out of the copies)
     if (cur_lmf_ && nstored_ > 0) {
         IvfLmParams probe{};
-        if (!lmf_prepare_(probe)) cur_lmf_ = cur_lm_ = false;
+        try {
+            if (!lmf_prepare_(probe)) cur_lmf_ = cur_lm_ = false;
+        } catch (const DeviceOutOfMemory&) {
+            // the sweeps' copy of the lists (IVFFlat: + 50 % of the rows, IVFPQ: the codes again) does not fit: the
+            // query-major scan returns the same bits without it.  Only an explicit scan_mode 2 reports the failure.
+            if (scan_mode == 2) throw;
+            (void)const_cast<GpuIndexIVF*>(this)->lmf_release_();
+            cur_lmf_ = cur_lm_ = false;
+        }
     }
     last_scan_mode_ = cur_lm_ ? 2 : 1;
     last_scan_arith_ = cur_lm_ && !cur_lmf_ ? 1 : 0;
@@ -2283,7 +2302,22 @@ void GpuIndexIVF::search_core_body_(idx_t n, const float* x, idx_t k, float* dis
                 HIP_CHECK(hipMemcpyAsync(q_pad_.p, gq.p, (size_t)nr * dpad_ * 4, hipMemcpyDeviceToDevice, R.stream));
                 HIP_CHECK(hipMemcpyAsync(c_ids_.p, gids.p, (size_t)nr * np * 8, hipMemcpyDeviceToDevice, R.stream));
                 HIP_CHECK(hipMemcpyAsync(c_dis_.p, gdis.p, (size_t)nr * np * 4, hipMemcpyDeviceToDevice, R.stream));
-                query_major(nr, gD.as<float>(), gI.as<idx_t>());
+                // the fused scan keeps no per-candidate scratch; the key-segment scan holds nprobe x longest list keys per
+                // query: the redo set then goes through it in sub-tiles of the scratch budget (a forced scan_mode 2 on tie-heavy
+                // data can redo every query of the tile)
+                const int sub = fused ? nr : (int)std::max<size_t>(1, std::min<size_t>((size_t)nr, R.temp_budget_bytes / per_q));
+                for (int s0 = 0; s0 < nr; s0 += sub) {
+                    const int ns = std::min(sub, nr - s0);
+                    if (s0 > 0) {
+                        HIP_CHECK(hipMemcpyAsync(q_pad_.p, gq.as<float>() + (size_t)s0 * dpad_, (size_t)ns * dpad_ * 4,
+                                                 hipMemcpyDeviceToDevice, R.stream));
+                        HIP_CHECK(hipMemcpyAsync(c_ids_.p, gids.as<idx_t>() + (size_t)s0 * np, (size_t)ns * np * 8,
+                                                 hipMemcpyDeviceToDevice, R.stream));
+                        HIP_CHECK(hipMemcpyAsync(c_dis_.p, gdis.as<float>() + (size_t)s0 * np, (size_t)ns * np * 4,
+                                                 hipMemcpyDeviceToDevice, R.stream));
+                    }
+                    query_major(ns, gD.as<float>() + (size_t)s0 * k, gI.as<idx_t>() + (size_t)s0 * k);
+                }
                 launch_scatter_results(gD.as<float>(), gI.as<idx_t>(), (int)k, olist.as<uint32_t>(), nr, dD, dI, R.stream);
                 R.sync(); // `redo` and the gathered buffers die with this scope
             }

@@ -448,6 +448,7 @@ class GpuIndexIVF : public Index {
     virtual bool lmf_prepare_(struct IvfLmParams& p) const { return false; }
     // bytes freed by dropping the sweeps' own copies of the lists (rebuilt at the next list-major search)
     virtual size_t lmf_release_() { return 0; }
+    virtual size_t lmf_shadow_bytes_() const { return 0; }
     mutable bool cur_lmf_ = false;        // the list-major search in flight runs the filter sweeps
     mutable bool cur_preassigned_ = false; // ... with the caller's coarse assignment (search_preassigned)
     mutable int last_scan_arith_ = 0;     // oracle restatement of the last search: 0 query-major arithmetic, 1 f32 list-major
@@ -482,6 +483,13 @@ class GpuIndexIVF : public Index {
     // ivf_lm_filter.hip -- results bit-identical to the query-major scan --, the scalar quantizer on the f32 matrix pipe;
     // 3 = list-major on the f32 matrix pipe for every type (round 3's scan, its own arithmetic: DESIGN.md 3.9).
     int scan_mode = 0;
+    // The filter sweeps of the automatic mode keep their own copy of the lists (IVFFlat: an fp16 shadow, + 2 d bytes per
+    // row on top of 4 d + 12; IVFPQ: the codes again in operand order, + M bytes per row): built at the first list-major
+    // search, kept up to date by add().  false = never build it in mode 0 (query-major / f32 list-major serve the
+    // calls, same results); a build that fails for lack of memory falls back the same way by itself.
+    bool use_filter_shadow = true;
+    // device bytes held for the database: the lists (rows / codes, ids, per-row terms) and the sweeps' copies
+    void resident_bytes(size_t* lists, size_t* shadow) const;
     // what the last search() call used: 1 = query-major, 2 = list-major
     int last_scan_mode() const { return last_scan_mode_; }
     // ... and under which `arith` the oracle restates it: 0 = the query-major arithmetic (also what the list-major scan
@@ -522,6 +530,7 @@ class GpuIndexIVFFlat : public GpuIndexIVF {
     bool lmf_capable_() const override;
     bool lmf_prepare_(struct IvfLmParams& p) const override;
     mutable DevBuf arena_h_;          // fp16 shadow of the arena rows [arena_cap_rows_ + 128][dh_]
+    size_t lmf_shadow_bytes_() const override { return arena_h_.cap; }
     size_t lmf_release_() override {
         const size_t b = arena_h_.cap;
         arena_h_.release();
@@ -568,6 +577,7 @@ class GpuIndexIVFPQ : public GpuIndexIVF {
     bool lmf_prepare_(struct IvfLmParams& p) const override;
     mutable DevBuf pq16_;             // fp16 codebook [M][256][dsub]
     mutable DevBuf arena_cs_;         // operand-major copy of the codes for the filter sweeps (kernels.h IvfLmParams::arena_cs)
+    size_t lmf_shadow_bytes_() const override { return arena_cs_.cap + pq16_.cap; }
     size_t lmf_release_() override {
         const size_t b = arena_cs_.cap;
         arena_cs_.release();

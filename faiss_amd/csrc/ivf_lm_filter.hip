@@ -1016,7 +1016,8 @@ __global__ void __launch_bounds__(256) lmf_bound_kernel(IvfLmParams p, const flo
                 // IVFPQ: the exact path's table grid (M entries rounded to delta <= 2^-23 sum_m max_c |<q_m, cb_mc>|), its
                 // per-row term |r^|^2 + 2 <c, r^> and the coarse term, all below (|q| + |c| + |r^|)^2 in magnitude
                 const float sroot = sqrtf(p.xn_full[q]) + sqrtf(p.cn_max) + sqrtf(p.yn_max);
-                extra = (4.8e-7f * (float)p.M + 1.0e-6f) * sroot * sroot;
+                // + the fp32 chains of those terms themselves (d products each: d 2^-24 |c| |r^| and the like), ADVICE r4
+                extra = (4.8e-7f * (float)p.M + 1.2e-7f * (float)(p.d + 8)) * sroot * sroot;
             }
             const float E = ivf_filter_err_bound(METRIC, p.d, xn_bound[q], p.yn_max, extra);
             if (p.band_out) p.band_out[q] = E;

@@ -430,6 +430,14 @@ int faiss_amd_GpuIndexIVF_set_use_fused_scan(FaissAmdIndex* index, int on);
  * 2 list-major), and how many queries so far had to be redone (candidate segment overflow, fp16 range).
  * last_scan_arith: 0 = query-major arithmetic, 1 = f32 list-major arithmetic. */
 int faiss_amd_GpuIndexIVF_set_scan_mode(FaissAmdIndex* index, int mode);
+/* Memory of the filter path (the reference's GpuIndexIVFConfig / GpuIndexConfig::memorySpace are where a caller states its
+ * memory policy, faiss/gpu/GpuIndex.h:31-47): the sweeps of the automatic mode keep their own copy of the lists -- IVFFlat an
+ * fp16 shadow (+ 2 d bytes per row), IVFPQ the codes again in operand order (+ M bytes per row) -- built at the first
+ * list-major search and kept up to date by add().  set_use_filter_shadow(0): never build it under mode 0 (the query-major
+ * scan serves every call, same bits).  A build that runs out of device memory falls back the same way by itself; only an
+ * explicit mode 2 reports the failure.  resident_bytes: device bytes of the lists and of the copies (either may be NULL). */
+int faiss_amd_GpuIndexIVF_set_use_filter_shadow(FaissAmdIndex* index, int on);
+int faiss_amd_GpuIndexIVF_resident_bytes(const FaissAmdIndex* index, size_t* p_lists, size_t* p_shadow);
 int faiss_amd_GpuIndexIVF_scan_info(const FaissAmdIndex* index, int* mode, int* last_mode, int64_t* overflow_queries);
 int faiss_amd_GpuIndexIVF_last_scan_arith(const FaissAmdIndex* index, int* p_arith);
 /* *p_output = 1 when mode 0 sends a batch of n queries with this nprobe and k through the list-major scan */

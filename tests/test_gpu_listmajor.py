@@ -368,6 +368,10 @@ def test_list_major_near_duplicates_and_self_search(res, lm_mode):
     (0, METRIC_L2, 256, 0, 1.0), (0, METRIC_INNER_PRODUCT, 300, 0, 1.0), (0, METRIC_L2, 512, 0, 1.0),  # d > 128
     (1, METRIC_L2, 128, 64, 1.0), (1, METRIC_INNER_PRODUCT, 128, 64, 1.0), (1, METRIC_L2, 64, 16, 1.0),
     (1, METRIC_L2, 96, 12, 1.0), (1, METRIC_L2, 32, 32, 1.0), (1, METRIC_L2, 128, 64, 50.0),
+    # few sub-quantizers of many coordinates (dsub = 32) with the data far from the origin -- the fp32 chains of the
+    # exact path's per-row term |r^|^2 + 2 <c, r^> then carry an error of ~ d 2^-24 |c| |r^| that the M-proportional term of
+    # the band does not cover (scale < 0 marks the shifted case: every coordinate + 20)
+    (1, METRIC_L2, 128, 4, -1.0), (1, METRIC_INNER_PRODUCT, 128, 4, -1.0), (1, METRIC_L2, 64, 4, -1.0),
 ])
 def test_list_filter_error_bound_holds(res, kind, metric, d, M, scale):
     """The superset argument of the f16 filter (ivf_lm_filter.hip) rests on |estimate - exact| <= E_q for EVERY row a query
@@ -377,6 +381,9 @@ def test_list_filter_error_bound_holds(res, kind, metric, d, M, scale):
     of the band real data uses."""
     nlist, nb, nq, nprobe = 16, 12000, 96, 4
     xt, xb, xq = synthetic_dataset(d, 3000, nb, nq, seed=d + M)
+    if scale < 0:
+        xt, xb, xq = xt + np.float32(20.0), xb + np.float32(20.0), xq + np.float32(20.0)
+        scale = 1.0
     xt, xb, xq = xt * np.float32(scale), xb * np.float32(scale), xq * np.float32(scale)
     idx, cent, pq = _build(res, kind, metric, d, M, nlist, xt, xb)
     if pq is not None and scale != 1.0:
