@@ -330,7 +330,7 @@ def nprobe_sweep(idx, ref, xq, xq_dev, gt_first, torch, pq):
                      "IVFFlat distances are exact: R@1 = the fraction of queries whose nearest neighbour lies in a probed list")}
 
 
-SPAN_NAMES = ("ivf_lmf_prepare", "ivf_lm_plan", "ivf_lmf_sweep_min", "ivf_lmf_bound", "ivf_lmf_sweep_collect", "ivf_lmf_rerank",
+SPAN_NAMES = ("ivf_lmf_prepare", "ivf_lm_plan", "ivf_lmf_sweep_min", "ivf_lmf_bound", "ivf_lmf_sweep_collect", "ivf_lmf_tighten", "ivf_lmf_rerank",
               "ivf_lm_scan_pass1", "ivf_lm_threshold", "ivf_lm_scan_pass2", "select_k_kernel",
               "ivfflat_fused_kernel", "ivfpq_fused_kernel", "ivfsq_fused_kernel", "ivf_finish_kernel", "flat_filter_kernel",
               "flat_filter_kernel_max", "flat_tighten_kernel", "flat_rerank_kernel", "convert_f16_query")

@@ -946,6 +946,12 @@ int faiss_amd_GpuIndexIVF_set_lmf_tuning(FaissAmdIndex* index, int rows_per_item
     ix->lmf_min_stride = min_stride;
     FA_CATCH
 }
+int faiss_amd_GpuIndexIVF_set_lmf_sampling(FaissAmdIndex* index, int sample_shift) {
+    FA_TRY
+    FA_THROW_IF_NOT_MSG(sample_shift >= -1 && sample_shift <= 4, "sample_shift: -1 (all rows), 0 (rule), 1 ... 4");
+    as<GpuIndexIVF>(index, "GpuIndexIVF")->lmf_sample_shift = sample_shift;
+    FA_CATCH
+}
 int faiss_amd_GpuIndexIVF_test_filter_dump(const FaissAmdIndex* index, int64_t n, const float* x, int nprobe, int64_t k, int64_t stride,
                                            uint64_t* keys_out, float* band_out) {
     FA_TRY

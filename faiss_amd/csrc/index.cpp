@@ -1700,7 +1700,7 @@ size_t GpuIndexIVF::reclaimMemory() {
     // plan tables, granule minima): all of it is re-grown on demand
     for (DevBuf* b : {&a_xpad_, &a_lab_, &a_dis_, &a_dest_, &a_ids_, &a_hist_, &a_newlen_, &a_jobs_, &lm_prefix_, &lm_p0_,
                       &lm_cnt_, &lm_bucket_, &lm_bstart_, &lm_pairs_, &lm_items_, &lm_bounds_, &lm_thr_, &lm_keys_, &lm_ovf_,
-                      &lm_qn_, &lm_prefixg_, &lm_gmin_, &lm_thrf_, &lm_candpr_, &lm_q16_, &lm_qflags_, &lm_xnb_, &lm_pqgrid_, &lm_pair16_, &lm_pairxh_,
+                      &lm_qn_, &lm_prefixg_, &lm_gmin_, &lm_thrf_, &lm_candpr_, &lm_q16_, &lm_qflags_, &lm_xnb_, &lm_pqgrid_, &lm_pair16_, &lm_pairxh_, &lm_errf_,
                       &part_keys_, &part_cnt_, &keys_}) {
         before += b->cap;
         b->release();
@@ -2398,16 +2398,33 @@ void GpuIndexIVF::search_listmajor_(int ni, const float* xq_pad, const idx_t* c_
         // slot costs a scattered 4-byte store in sweep 1 and a read in the bound kernel, and S >> k slots already bound
         // the k-th best estimate tightly (S ln(S / (S - k)) candidates).  Measured (profiles/r04_c_filter_tuning_sweep.txt):
         // IVFFlat nb = 10M G = 1 / 2 / 4 / 8: 2.83 / 2.31 / 2.16 / 2.16 ms; nb = 1M G = 1 / 2 / 4: 1.00 / 1.04 / 1.19 ms
-        const double rows_per_query = (double)np * (double)avg_len;
+        if (lmf_rows_per_item > 0) RT = (int)round_up((size_t)lmf_rows_per_item, 256);
+        // Sweep 1 on a SAMPLE of the rows (round 5): the first quarter of every work item's row chunk.  Any subset of the rows
+        // bounds the k-th best estimate from above; the looser bound admits ~ 1 / share as many candidates into sweep 2's
+        // segments, and the tightening launch behind it cuts them back to the rows inside the band of the k-th best
+        // collected estimate, so the rerank sees no more than without sampling.  Lists of >= 1024 rows on average (shorter: an
+        // item's set-up is not amortised over a quarter of it), and the sample must still hold >> k granules per query.
+        // lmf_sample_shift: 0 = this rule, 1 .. 4 = prefix of RT >> shift rows, -1 = no sampling.
+        int sample_rows = 0;
+        {
+            int shift = lmf_sample_shift > 0 ? lmf_sample_shift : (lmf_sample_shift == 0 && avg_len >= 1024 ? 2 : 0);
+            while (shift > 0 && (double)np * (double)avg_len / (double)(1 << shift) < 64.0 * (double)k) --shift;
+            if (shift > 0) sample_rows = (int)round_up((size_t)(RT >> shift), 256);
+            if (sample_rows >= RT) sample_rows = 0;
+        }
+        const double share = sample_rows ? (double)sample_rows / (double)std::min<int64_t>(RT, std::max<int64_t>(avg_len, 1)) : 1.0;
+        const double rows_per_query = (double)np * (double)avg_len * std::min(1.0, share);
         int G = 1;
         while (G < 8 && rows_per_query / (16.0 * G) > 2048.0) G *= 2;
-        if (lmf_rows_per_item > 0) RT = (int)round_up((size_t)lmf_rows_per_item, 256);
         if (lmf_gran_blocks > 0) G = lmf_gran_blocks;
         if (G > 8 && G <= 32) RT = (int)round_up((size_t)RT, (size_t)32 * G); // (an item holds whole granules)
+        if (sample_rows) sample_rows = (int)round_up((size_t)sample_rows, (size_t)32 * G);
+        if (sample_rows >= RT) sample_rows = 0;
+        // candidate room: ~ k / share rows at or below the sampled bound + those inside the band
+        if (sample_rows) stride = std::max<int64_t>(stride, (int64_t)std::min(16384.0, 2048.0 + 3.0 * (double)k / std::min(1.0, share)));
         if (lmf_cand_cap > 0) stride = std::max<int64_t>(lmf_cand_cap, k);
-        // sweep 1 over every 2nd block when lists are long (profiles/r04_d_filter_sampling_sweep.txt: IVFPQ nb = 100M 14.9 ->
-        // 12.8 ms, IVFFlat nb = 10M 2.26 -> 2.17 ms, nb = 1M slower: the looser bound doubles the candidates)
-        const int min_stride = lmf_min_stride > 0 ? std::min(lmf_min_stride, 8) : (avg_len >= 8192 ? 2 : 1);
+        // (round 4's sampling of every 2nd 32-row block for long lists remains behind the tuning call: min_stride)
+        const int min_stride = lmf_min_stride > 0 ? std::min(lmf_min_stride, 8) : 1;
         FA_THROW_IF_NOT_MSG(G >= 1 && G <= 32 && (G & (G - 1)) == 0 && RT <= 65280, "filter tuning: granule / rows per item");
         // granule slots a query can own: those of the np longest lists
         int64_t gstride = 0;
@@ -2415,9 +2432,11 @@ void GpuIndexIVF::search_listmajor_(int ni, const float* xq_pad, const idx_t* c_
             std::vector<uint32_t> len(list_len_);
             const size_t top = (size_t)std::min<int64_t>(np, nlist);
             std::nth_element(len.begin(), len.begin() + (top - 1), len.end(), std::greater<uint32_t>());
-            for (size_t i = 0; i < top; i++) gstride += 2 * (int64_t)div_up((size_t)len[i], (size_t)(32 * G));
+            for (size_t i = 0; i < top; i++)
+                gstride += 2 * (int64_t)ivf_lmf_list_granules(len[i], (uint32_t)RT, (uint32_t)(32 * G), (uint32_t)sample_rows);
             // (a caller's own assignment may name a list more than once: the longest list np times)
-            if (cur_preassigned_) gstride = 2 * (int64_t)np * (int64_t)div_up((size_t)max_len, (size_t)(32 * G));
+            if (cur_preassigned_)
+                gstride = 2 * (int64_t)np * (int64_t)ivf_lmf_list_granules(max_len, (uint32_t)RT, (uint32_t)(32 * G), (uint32_t)sample_rows);
             gstride = std::max<int64_t>(gstride, 2);
         }
         const size_t per_q = (size_t)stride * 10 + (size_t)gstride * 4 + (size_t)(np + 1) * 12 + 256 +
@@ -2426,7 +2445,8 @@ void GpuIndexIVF::search_listmajor_(int ni, const float* xq_pad, const idx_t* c_
         for (int c0 = 0; c0 < ni; c0 += (int)std::min<int64_t>(fit, ni)) {
             const int cn = (int)std::min<int64_t>(fit, ni - c0);
             search_listmajor_filter_chunk_(cn, c0, xq_pad + (size_t)c0 * dpad_, c_ids + (size_t)c0 * np, c_dis + (size_t)c0 * np, np,
-                                           k, dD + (size_t)c0 * k, dI + (size_t)c0 * k, stride, RT | (G << 16), gstride, min_stride, *redo);
+                                           k, dD + (size_t)c0 * k, dI + (size_t)c0 * k, stride, RT | (G << 16), gstride,
+                                           min_stride | (sample_rows << 4), *redo);
         }
         return;
     }
@@ -2623,6 +2643,8 @@ void GpuIndexIVF::search_listmajor_filter_chunk_(int ni, int q0, const float* xq
                                                  int min_stride, std::vector<uint32_t>& redo) const {
     const GpuResources& R = *res_;
     const int RT = rt_g & 0xffff, G = rt_g >> 16;
+    const int sample_rows = min_stride >> 4; // (packed by search_listmajor_)
+    min_stride &= 15;
     int64_t sum_nrt = 0, nrt_max = 1;
     uint32_t max_len = 1;
     for (auto l : list_len_) {
@@ -2688,6 +2710,9 @@ void GpuIndexIVF::search_listmajor_filter_chunk_(int ni, int q0, const float* xq
     P.filter = 1;
     P.gran_blocks = G;
     P.min_stride = min_stride;
+    P.sample_rows = sample_rows;
+    lm_errf_.ensure((size_t)ni * 4);
+    P.err_f = lm_errf_.as<float>();
     P.gmin = lm_gmin_.as<uint32_t>();
     P.gstride = gstride;
     P.thr_f = lm_thrf_.as<float>();
@@ -2735,11 +2760,16 @@ void GpuIndexIVF::search_listmajor_filter_chunk_(int ni, int q0, const float* xq
         SpanGuard sg(&R, "ivf_lmf_sweep_collect");
         launch_ivf_lmf_sweep(P, 2, grid, R.stream);
     }
-    launch_ivf_lm_clamp(P, R.stream);
     // the workgroup that re-derives a query's candidates also selects its k best when both fit its LDS (no selection launch)
     // (IVFFlat: rerank 0.135 -> 0.19 ms for 0.105 ms of selection launch at nb = 1M; IVFPQ keeps the separate launch: its rerank
-    // workgroups -- two per CU, the 64 KB table -- serialise the tail: 0.25 -> 0.52 ms)
-    const bool fused_select = P.kind == 0 && k <= kLmfFusedSelectK && stride <= kLmfFusedSelectN;
+    // workgroups -- two per CU, the 64 KB table -- serialise the tail: 0.25 -> 0.52 ms).  The tightening launch leaves a query
+    // with more than kLmfFusedSelectN candidates (that many rows inside the band of its k-th best) to the redo path.
+    const bool fused_select = P.kind == 0 && k <= kLmfFusedSelectK;
+    {
+        // clamp of overflowed segments + the smallest superset the band allows (launch_ivf_lmf_tighten)
+        SpanGuard sg(&R, "ivf_lmf_tighten");
+        launch_ivf_lmf_tighten(P, fused_select ? kLmfFusedSelectN : 0, R.stream);
+    }
     if (fused_select) {
         P.fin_dis = dD;
         P.fin_ids = dI;

@@ -454,7 +454,7 @@ class GpuIndexIVF : public Index {
     mutable int last_scan_arith_ = 0;     // oracle restatement of the last search: 0 query-major arithmetic, 1 f32 list-major
     mutable bool shadow_dirty_ = true;    // a list changed since the fp16 shadow was built
     mutable bool lmf_quant_dirty_ = true; // a quantizer changed since the fp16 codebook / norm bounds were built
-    mutable DevBuf lm_prefixg_, lm_gmin_, lm_thrf_, lm_candpr_, lm_q16_, lm_qflags_, lm_xnb_, lm_pqgrid_, lm_scalar_, lm_pair16_, lm_pairxh_;
+    mutable DevBuf lm_prefixg_, lm_gmin_, lm_thrf_, lm_candpr_, lm_q16_, lm_qflags_, lm_xnb_, lm_pqgrid_, lm_scalar_, lm_pair16_, lm_pairxh_, lm_errf_;
     // queries whose candidate segment overflowed (or that leave the fp16 range) are appended to `redo`
     void search_listmajor_filter_chunk_(int ni, int q0, const float* xq_pad, const idx_t* c_ids, const float* c_dis, int np, int k,
                                         float* dD, idx_t* dI, int64_t stride, int rt_g, int64_t gstride, int min_stride,
@@ -502,6 +502,7 @@ class GpuIndexIVF : public Index {
     // tuning experiments of the filter path (faiss_amd_GpuIndexIVF_set_lmf_tuning; 0 = the built-in rule): rows of a list
     // per work item (a multiple of 256), 32-row blocks per granule (a power of two <= 8), candidate room per query
     int lmf_rows_per_item = 0, lmf_gran_blocks = 0, lmf_cand_cap = 0, lmf_min_stride = 0;
+    int lmf_sample_shift = 0; // sweep 1 on the first rows_per_item >> shift rows of every item: 0 = the rule, -1 = all rows
     // test hook (faiss_amd_GpuIndexIVF_test_filter_dump): the ESTIMATES of the f16 filter sweeps for every row the n
     // queries probe, as keys (ordkey(estimate) << 32 | scan position) at keys_out[q * stride + scan position], and the
     // error band E_q the bound kernel derives for each query (band_out [n], written for queries whose probed lists hold

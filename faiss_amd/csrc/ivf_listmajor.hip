@@ -296,7 +296,7 @@ __global__ void __launch_bounds__(256) lm_plan_kernel(IvfLmParams p) {
             pre1[pr] = cum1 + inc1 - len1;
         }
         if (p.filter) {
-            const uint32_t lg = 2u * ((len + grows - 1) / grows);
+            const uint32_t lg = 2u * ivf_lmf_list_granules(len, (uint32_t)p.rows_per_item, grows, (uint32_t)p.sample_rows);
             uint32_t incg = lg;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
@@ -471,6 +471,7 @@ void launch_ivf_lm_plan(const IvfLmParams& p, hipStream_t stream) {
     if (p.nq == 0) return;
     FA_THROW_IF_NOT(p.rows_per_item % LM_TR == 0 && p.rows_per_item > 0);
     FA_THROW_IF_NOT(!p.filter || (p.prefixg && p.gran_blocks >= 1 && p.rows_per_item % (32 * p.gran_blocks) == 0 && !p.force_all));
+    FA_THROW_IF_NOT(!p.filter || (p.sample_rows >= 0 && p.sample_rows % (32 * p.gran_blocks) == 0));
     // bucket_cnt and bucket_fill are one allocation [2][2 nlist]
     FA_THROW_IF_NOT(p.bucket_fill == p.bucket_cnt + 2 * p.nlist);
     HIP_CHECK(hipMemsetAsync(p.bucket_cnt, 0, (size_t)4 * p.nlist * 4, stream));

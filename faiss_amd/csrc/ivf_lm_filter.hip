@@ -343,6 +343,11 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
         const int npair = min(32 * NQB, (int)(p.bucket_start[bk + 1 + item.both] - pb) - qt * (32 * NQB));
         const int r0 = rt * p.rows_per_item;
         const int r1 = min(len, r0 + p.rows_per_item);
+        // sweep 1 may look at a prefix of the chunk only (IvfLmParams::sample_rows): rows [r0, rend); its granule slots are
+        // then numbered over the sampled granules of the list (ivf_lmf_list_granules)
+        const bool smp = MODE == MODE_MIN && p.sample_rows > 0 && p.sample_rows < p.rows_per_item;
+        const int rend = smp ? min(r1, r0 + p.sample_rows) : r1;
+        const int gbase = smp ? rt * (p.sample_rows >> (5 + gsh)) - ((r0 >> 5) >> gsh) : 0;
 
         // ---- this lane's queries: one per 32-query block
         LmfLane L[NQB];
@@ -374,7 +379,7 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
 
         int t = r0;
         int skip_b = 0; // MODE_COLLECT: query blocks of block t whose candidates were parked before the slice filled up
-        while (t < r1) {
+        while (t < rend) {
             // ---- (re-)entry: the rows of block t.  Rows behind the end of the list belong to the next list or the
             // arena's padding: loaded, never looked at.
             // (operand-major shadow: k-step s of block b is the KB at (b * nks + s) * 1024, lane l its 16-byte piece l)
@@ -406,7 +411,7 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
             };
             float pf0 = rn_fetch(0), pf1 = rn_fetch(1), pf2 = rn_fetch(2), pf3 = rn_fetch(3);
             int bi = 0; // blocks of this run so far
-            for (; t < r1; t += bstep, ++bi) {
+            for (; t < rend; t += bstep, ++bi) {
                 const _Float16* acur = arow; // (KS > R: the ring refills from this block first)
                 arow += (bstep >> 5) * nks * 512;
                 if (METRIC == METRIC_L2) { // (no branch: unconditional loads keep the compiler counting them)
@@ -465,11 +470,11 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
                     }
                     const int blk = t >> 5;
                     // (wave-uniform) the granule ends with this block: the next block looked at lies in another one
-                    if ((((t + bstep) >> 5) >> gsh) != (blk >> gsh) || t + bstep >= r1) {
+                    if ((((t + bstep) >> 5) >> gsh) != (blk >> gsh) || t + bstep >= rend) {
 #pragma unroll
                         for (int b = 0; b < NQB; ++b) {
                             if (L[b].qv)
-                                lmf_store_u32(L[b].gq + 2 * (blk >> gsh), ordkey<METRIC>(lmf_to_est<METRIC>(L[b].gm + L[b].xh)));
+                                lmf_store_u32(L[b].gq + 2 * ((blk >> gsh) + gbase), ordkey<METRIC>(lmf_to_est<METRIC>(L[b].gm + L[b].xh)));
                             L[b].gm = -INFINITY;
                         }
                     }
@@ -631,6 +636,10 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
         const int npair = min(32 * NQB, (int)(p.bucket_start[bk + 1 + item.both] - pb) - qt * (32 * NQB));
         const int r0 = rt * p.rows_per_item;
         const int r1 = min(len, r0 + p.rows_per_item);
+        // sweep 1 may look at a prefix of the chunk only (see the flat kernel)
+        const bool smp = MODE == MODE_MIN && p.sample_rows > 0 && p.sample_rows < p.rows_per_item;
+        const int rend = smp ? min(r1, r0 + p.sample_rows) : r1;
+        const int gbase = smp ? rt * (p.sample_rows >> (5 + gsh)) - ((r0 >> 5) >> gsh) : 0;
 
         // the code bytes of this lane's operands for block t: global -> registers, TWO blocks ahead (a 24-MFMA block is
         // shorter than a memory latency)
@@ -743,7 +752,7 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
         half8 av[4]; // ring of decoded A operands (k-step s in slot s % 4)
 #pragma unroll
         for (int s = 0; s < LP_AHEAD; ++s) av[s] = operand_of(cw, s);
-        for (int t = r0; t < r1; t += bstep, ++bi) {
+        for (int t = r0; t < rend; t += bstep, ++bi) {
             if (METRIC == METRIC_L2) {
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_wave_barrier(); // (the epilogue reads of the previous block were issued: LDS keeps a wave's order)
@@ -796,10 +805,10 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
                     }
                 }
                 const int blk = t >> 5;
-                if ((((t + bstep) >> 5) >> gsh) != (blk >> gsh) || t + bstep >= r1) {
+                if ((((t + bstep) >> 5) >> gsh) != (blk >> gsh) || t + bstep >= rend) {
 #pragma unroll
                     for (int b = 0; b < NB; ++b) {
-                        if (L[b].qv) L[b].gq[2 * (blk >> gsh)] = ordkey<METRIC>(lmf_to_est<METRIC>(L[b].gm + L[b].xh));
+                        if (L[b].qv) L[b].gq[2 * ((blk >> gsh) + gbase)] = ordkey<METRIC>(lmf_to_est<METRIC>(L[b].gm + L[b].xh));
                         L[b].gm = -INFINITY;
                     }
                 }
@@ -964,6 +973,7 @@ __global__ void __launch_bounds__(256) lmf_bound_kernel(IvfLmParams p, const flo
         }
         return;
     }
+    if (tid == 0 && p.err_f) p.err_f[q] = INFINITY; // (no band known yet: the tightening keeps every candidate)
     if (S < (uint32_t)p.k) { // fewer granules than results: everything is a candidate
         if (tid == 0) p.thr_f[q] = lmf_worst<METRIC>();
         return;
@@ -1021,6 +1031,7 @@ __global__ void __launch_bounds__(256) lmf_bound_kernel(IvfLmParams p, const flo
             }
             const float E = ivf_filter_err_bound(METRIC, p.d, xn_bound[q], p.yn_max, extra);
             if (p.band_out) p.band_out[q] = E;
+            if (p.err_f) p.err_f[q] = E;
             thr = METRIC == METRIC_L2 ? T + 2.f * E : T - 2.f * E;
             if (thr != thr) thr = lmf_worst<METRIC>();
         }
@@ -1032,6 +1043,114 @@ void launch_ivf_lmf_bound(const IvfLmParams& p, const float* xn_bound, hipStream
     HIP_CHECK(hipMemsetAsync(p.ovf, 0, 4, stream));
     if (p.metric == METRIC_L2) hipLaunchKernelGGL(lmf_bound_kernel<METRIC_L2>, dim3((unsigned)p.nq), dim3(256), 0, stream, p, xn_bound);
     else hipLaunchKernelGGL(lmf_bound_kernel<METRIC_INNER_PRODUCT>, dim3((unsigned)p.nq), dim3(256), 0, stream, p, xn_bound);
+    HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ tighten: the smallest superset the band allows
+// One workgroup per query, behind sweep 2.  The collected candidates of a query are ALL its rows with estimate <= thr_f, and
+// thr_f >= (k-th best estimate of the query) by construction, so the k-th best estimate among them, T2, is the k-th best
+// estimate of all the query's rows; a row of the exact top-k has estimate <= T2 + 2 E_q (the superset
+// argument with the sharpest T).  Candidates above that leave the segment (compacted in place through LDS) before
+// anything exact is computed: the rerank then works on ~ k + (rows inside the band) candidates whatever sample of the rows
+// the first sweep's bound came from.  Also does what lm_clamp_kernel does for the other scans (cnt > stride: clamp + ovf).
+constexpr int LT_CAP = 2048; // kept candidates a workgroup can stage (24 KB of LDS); more: the segment stays as it is
+template <int METRIC>
+__global__ void __launch_bounds__(256) lmf_tighten_kernel(IvfLmParams p, int fin_cap) {
+    __shared__ u64 keep_k[LT_CAP];
+    __shared__ uint16_t keep_p[LT_CAP];
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t sel_prefix, sel_need, nkeep;
+    const int q = blockIdx.x;
+    const int tid = threadIdx.x;
+    const uint32_t raw = p.cnt[q];
+    auto overflow = [&]() {
+        const uint32_t s = atomicAdd(&p.ovf[0], 1u);
+        p.ovf[1 + s] = (uint32_t)q;
+    };
+    if ((int64_t)raw > p.stride) { // (workgroup-uniform) the segment overflowed: redone by the caller
+        if (tid == 0) {
+            p.cnt[q] = (uint32_t)p.stride;
+            overflow();
+        }
+        return;
+    }
+    const uint32_t n = raw;
+    u64* kq = p.keys + (int64_t)q * p.stride;
+    uint16_t* cpr = p.cand_pr + (int64_t)q * p.stride;
+    const float E = p.err_f[q];
+    if (n > (uint32_t)p.k && E < INFINITY) {
+        if (tid == 0) {
+            sel_prefix = 0u;
+            sel_need = (uint32_t)p.k;
+            nkeep = 0u;
+        }
+        for (int pass = 3; pass >= 0; --pass) { // radix select of the k-th smallest estimate key (lmf_bound_kernel's loop)
+            hist[tid] = 0u;
+            __syncthreads();
+            const uint32_t pre = sel_prefix;
+            for (uint32_t i = tid; i < n; i += 256) {
+                const uint32_t v = (uint32_t)(kq[i] >> 32);
+                if (pass == 3 || (v >> (8 * (pass + 1))) == pre) atomicAdd(&hist[(v >> (8 * pass)) & 255u], 1u);
+            }
+            __syncthreads();
+            if (tid < 64) {
+                uint32_t c[4], sum = 0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    c[u] = hist[4 * tid + u];
+                    sum += c[u];
+                }
+                const uint32_t inc = wave_incl_scan(sum);
+                uint32_t before = inc - sum;
+                const uint32_t need = sel_need;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (before < need && need <= before + c[u]) {
+                        sel_prefix = (pre << 8) | (uint32_t)(4 * tid + u);
+                        sel_need = need - before;
+                    }
+                    before += c[u];
+                }
+            }
+            __syncthreads();
+        }
+        const float T2 = unordkey<METRIC>(sel_prefix);
+        float thr = METRIC == METRIC_L2 ? T2 + 2.f * E : T2 - 2.f * E;
+        if (thr != thr) thr = lmf_worst<METRIC>();
+        const uint32_t tkey = ordkey<METRIC>(thr);
+        // (an estimate key of a collected row is never the invalid key; tkey >= the k-th key, so at least k rows stay)
+        for (uint32_t i0 = 0; i0 < n; i0 += 256) {
+            const uint32_t i = i0 + tid;
+            if (i < n) {
+                const u64 key = kq[i];
+                if ((uint32_t)(key >> 32) <= tkey) {
+                    const uint32_t s = atomicAdd(&nkeep, 1u);
+                    if (s < (uint32_t)LT_CAP) {
+                        keep_k[s] = key;
+                        keep_p[s] = cpr[i];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t kept = nkeep;
+        if (kept <= (uint32_t)LT_CAP) { // (workgroup-uniform; every read of the segment happened before the barrier)
+            for (uint32_t i = tid; i < kept; i += 256) {
+                kq[i] = keep_k[i];
+                cpr[i] = keep_p[i];
+            }
+            if (tid == 0) p.cnt[q] = kept;
+            if (tid == 0 && fin_cap > 0 && kept > (uint32_t)fin_cap) overflow();
+            return;
+        }
+    }
+    if (tid == 0 && fin_cap > 0 && n > (uint32_t)fin_cap) overflow();
+}
+void launch_ivf_lmf_tighten(const IvfLmParams& p, int fin_cap, hipStream_t stream) {
+    if (p.nq == 0) return;
+    FA_THROW_IF_NOT(p.err_f && p.cand_pr && p.keys && p.cnt && p.ovf);
+    if (p.metric == METRIC_L2) hipLaunchKernelGGL(lmf_tighten_kernel<METRIC_L2>, dim3((unsigned)p.nq), dim3(256), 0, stream, p, fin_cap);
+    else hipLaunchKernelGGL(lmf_tighten_kernel<METRIC_INNER_PRODUCT>, dim3((unsigned)p.nq), dim3(256), 0, stream, p, fin_cap);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -1155,7 +1274,8 @@ __global__ void __launch_bounds__(256) lmf_rerank_flat_kernel(IvfLmParams p) {
     const int q = blockIdx.x;
     const int ln = threadIdx.x & 7, grp = threadIdx.x >> 3; // 32 groups: 32 candidates per round, their loads in flight together
     const int np = p.nprobe;
-    const int n = (int)min((int64_t)p.cnt[q], p.stride);
+    int n = (int)min((int64_t)p.cnt[q], p.stride);
+    if (fin) n = min(n, kLmfFusedSelectN); // (more: the tightening launch listed the query for the redo; its rows here are dropped)
     const int nch = p.dpad >> 2;
     u64* kq = p.keys + (int64_t)q * p.stride;
     const uint16_t* cpr = p.cand_pr + (int64_t)q * p.stride;
@@ -1212,7 +1332,8 @@ __global__ void __launch_bounds__(RRQ_THREADS) lmf_rerank_pq_kernel(IvfLmParams 
     const int tid = threadIdx.x;
     const int ln = tid & 7, grp = tid >> 3;
     const int np = p.nprobe, M = p.M, dsub = p.dsub;
-    const int n = (int)min((int64_t)p.cnt[q], p.stride);
+    int n = (int)min((int64_t)p.cnt[q], p.stride);
+    if (p.fin_dis) n = min(n, kLmfFusedSelectN);
     float* lut = (float*)smem;                      // [256][M]
     uint32_t* colmax = (uint32_t*)(lut + M * 256);  // [M]
     float* grid = (float*)(colmax + M);             // delta, 1 / delta, on
@@ -1360,7 +1481,8 @@ __global__ void __launch_bounds__(RRQ_THREADS) lmf_rerank_pq_kernel(IvfLmParams 
 }
 void launch_ivf_lmf_rerank(const IvfLmParams& p, hipStream_t stream) {
     if (p.nq == 0) return;
-    FA_THROW_IF_NOT(!p.fin_dis || (p.fin_ids && p.arena_ids && p.k <= kLmfFusedSelectK && p.stride <= kLmfFusedSelectN));
+    // (fused selection: launch_ivf_lmf_tighten left at most kLmfFusedSelectN candidates or listed the query for the redo)
+    FA_THROW_IF_NOT(!p.fin_dis || (p.fin_ids && p.arena_ids && p.k <= kLmfFusedSelectK));
     const dim3 grid((unsigned)p.nq), block(256);
     if (p.kind == 0) {
         if (p.metric == METRIC_L2) hipLaunchKernelGGL(lmf_rerank_flat_kernel<METRIC_L2>, grid, block, 0, stream, p);

@@ -473,6 +473,12 @@ struct IvfLmParams {
     int filter;
     int gran_blocks;            // G: 32-row blocks per granule; a granule of a list = 32 G rows = two slots (lane halves)
     int min_stride;             // sweep 1 looks at every min_stride-th 32-row block of a row chunk (1 = all rows)
+    // sweep 1 looks only at the first sample_rows rows of every work item's row chunk (0 = the whole chunk; a multiple of
+    // 32 gran_blocks below rows_per_item): ANY subset of the rows bounds the k-th best estimate from above, and a
+    // contiguous prefix streams at the full rate (every 2nd 32-row block of the codes moved 2 KB of every 4: round 4's sampling).
+    // The looser bound admits ~ 1 / (sampled share) as many candidates; launch_ivf_lmf_tighten cuts them back to the rows
+    // inside the band of the k-th best COLLECTED estimate before anything exact is computed.
+    int sample_rows;
     uint32_t* prefixg;          // [nq][nprobe + 1] exclusive prefix of 2 * ceil(len / (32 G)): granule slots of the probes
     uint32_t* gmin;             // [nq][gstride] ordkey of the best estimate in every granule slot
     int64_t gstride;
@@ -505,6 +511,7 @@ struct IvfLmParams {
     float yn_max;               // max |y|^2 over the stored rows (kind 0) / upper bound of |r^|^2 from the codebook (kind 1)
     float cn_max;               // kind 1: max |centroid|^2
     float* band_out;            // optional [nq]: the error band E_q the bound kernel used (tests)
+    float* err_f;               // [nq] the error band E_q (written by the bound kernel, read by launch_ivf_lmf_tighten)
     // IDSelector of the search in flight (filter path only): one bit per arena row (launch_selector_mask), null = none.
     // Excluded rows take no part in the bound nor in the collection: the result is that of the selected subset.
     const uint32_t* sel_mask;
@@ -544,6 +551,20 @@ void launch_ivf_lmf_sweep(const IvfLmParams& p, int mode, int grid_blocks, hipSt
 // thr_f[q] from gmin (k-th best granule estimate + 2 x ivf_filter_err_bound); queries with qflags set get "nothing" and are
 // appended to ovf (zeroed here).  xn_bound: [nq] upper bound of |q'|^2 over the query's probes (kind 0: |q|^2).
 void launch_ivf_lmf_bound(const IvfLmParams& p, const float* xn_bound, hipStream_t stream);
+// Behind sweep 2, before the rerank: cnt[q] > stride -> listed in ovf (what launch_ivf_lm_clamp does); otherwise T2 = the k-th
+// best estimate among the query's collected candidates -- the k-th best estimate of ALL its rows, since everything at or
+// below thr_f >= T2 was collected -- and only candidates with estimate <= T2 + 2 E_q stay (compacted in place, cnt updated):
+// the smallest superset the error band allows, whatever sample the first sweep's bound came from.  fin_cap > 0: the rerank
+// workgroup will select in LDS; a query left with more than fin_cap candidates is listed in ovf instead.
+void launch_ivf_lmf_tighten(const IvfLmParams& p, int fin_cap, hipStream_t stream);
+// granule slots (per lane half) sweep 1 fills for a list of `len` rows: all its granules, or those of the sampled prefixes
+__host__ __device__ static inline uint32_t ivf_lmf_list_granules(uint32_t len, uint32_t rows_per_item, uint32_t grows,
+                                                                uint32_t sample_rows) {
+    if (sample_rows == 0 || sample_rows >= rows_per_item) return (len + grows - 1) / grows;
+    const uint32_t nfull = len / rows_per_item, rem = len - nfull * rows_per_item, gs = sample_rows / grows;
+    const uint32_t gr = (rem + grows - 1) / grows;
+    return nfull * gs + (gr < gs ? gr : gs);
+}
 // kind 1: xn_bound[q] = max over the probes of |q - c|^2; pair16 / pair_xh = the sweeps' B operands and query terms
 void launch_ivf_lmf_pq_prepare(const IvfLmParams& p, float* xn_bound, hipStream_t stream);
 // keys[q][0 .. cnt[q]) <- the exact distance of the query-major scan (ivf_fused.hip) for the same row, bit for bit

@@ -134,3 +134,34 @@ def test_index_shards_over_the_devices_of_this_box():
     faiss_amd.merge_knn_results_device(ress[0], METRIC_L2, nq, k, nshard, allD.data_ptr(), allI.data_ptr(), None,
                                        Dm.data_ptr(), Im.data_ptr())
     assert np.array_equal(Im.cpu().numpy(), Ir) and np.array_equal(Dm.cpu().numpy(), Dr), "device merge across two GPUs"
+
+
+@pytest.mark.parametrize("kind,metric,d,M,nlist,nb,nprobe,k", [
+    (0, METRIC_L2, 64, 0, 8, 90000, 3, 50),                # lists of ~11 000 rows: row chunks of 2816 rows, prefix 768
+    (0, METRIC_INNER_PRODUCT, 128, 0, 16, 60000, 6, 100),
+    (1, METRIC_L2, 64, 32, 8, 90000, 3, 50),
+    (1, METRIC_L2, 128, 64, 32, 120000, 8, 100),            # bench shape of the sweeps (PQ64, dsub 2)
+    (1, METRIC_INNER_PRODUCT, 32, 16, 8, 50000, 4, 10),
+    (0, METRIC_L2, 256, 0, 8, 40000, 4, 300),               # d > 128: two query blocks per item; k above the fused selection
+])
+def test_sampled_first_sweep_and_tightening_keep_the_bits(res, kind, metric, d, M, nlist, nb, nprobe, k):
+    """Sweep 1 of the filter path on a prefix of every work item (set_lmf_sampling 1 ... 4, and the rule) bounds the k-th best
+    estimate from a SAMPLE; sweep 2 then collects more rows and the tightening launch cuts them back.  Whatever the sample,
+    the results are the query-major scan's bit for bit, nobody is redone, and the rerank sees no more candidates than
+    without sampling (the tightened set does not depend on the sample at all)."""
+    xt, xb, xq = synthetic_dataset(d, 4000, nb, 700, seed=d + nlist)
+    idx = _make(res, kind, d, nlist, M, metric)
+    idx.train(xt)
+    idx.add(xb)
+    idx.nprobe = nprobe
+    idx.set_scan_mode(1)
+    Dr, Ir = idx.search(xq, k)
+    idx.set_scan_mode(2)
+    before = idx.scan_info()[2]
+    for shift in (-1, 0, 1, 2, 3, 4):
+        idx.set_lmf_sampling(shift)
+        D, I = idx.search(xq, k)
+        assert idx.scan_info()[1] == 2 and idx.last_scan_arith() == 0
+        assert np.array_equal(I, Ir) and np.array_equal(D, Dr), "sample shift %d" % shift
+    assert idx.scan_info()[2] == before, "queries were redone"
+    idx.set_lmf_sampling(0)
