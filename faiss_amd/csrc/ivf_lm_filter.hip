@@ -43,7 +43,7 @@ typedef unsigned long long u64;
 
 constexpr int LF_THREADS = 256;
 constexpr int LF_PARK = 1024;                     // parked candidates per wave (a (32-row, 32-query) block always fits)
-constexpr int LF_LDS = 4 * LF_PARK * (8 + 4);     // 48 KB: two workgroups per CU
+constexpr int LF_LDS = 4 * LF_PARK * (8 + 4) + 4 * (4 * (64 * 16 + 32) + 64 * 16); // 48 KB of parked candidates + 20.5 KB of staged records (LS_WAVE): two workgroups per CU
 constexpr int MODE_MIN = 1, MODE_COLLECT = 2, MODE_DUMP = 3;
 
 template <int METRIC>
@@ -61,6 +61,9 @@ __device__ __forceinline__ void lmf_store_u32(uint32_t* at, uint32_t v) {
 }
 __device__ __forceinline__ void lmf_store_u64(u64* at, u64 v) {
     asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(at), "v"(v));
+}
+__device__ __forceinline__ void lmf_store_u16(uint16_t* at, uint32_t v) {
+    asm volatile("global_store_short %0, %1, off" ::"v"(at), "v"(v));
 }
 
 bool ivf_lmf_supported(int kind, int d, int dpad, int M) {
@@ -255,6 +258,69 @@ __device__ __forceinline__ void lmf_scores(f32x16& a, const f32x4 (&rn)[4], bool
     }
 }
 
+// Candidate parking of sweep 2 (round 5).  Round 4 tested the 16 scores of every lane against the query's threshold in
+// registers (80 VALU instructions per (row block, query block) that holds a hit), ran a wave scan and then 16 predicated
+// store sequences -- and at nb <= 10M nearly EVERY pair holds a hit (250 candidates per query over 78 000 rows x 32 queries
+// per block: 3 per pair at nb = 10M, 33 at nb = 1M), so sweep 2 cost twice sweep 1 at nb = 1M and a looser bound (sampled
+// sweep 1) made it VALU-bound.  Now a lane whose maximum reaches its threshold dumps its 16 scores + its query's terms as
+// one RECORD into a wave-private LDS staging area (slot = its rank among the hit lanes: one ballot + mbcnt, four 16-byte
+// stores), and when the area is full a DENSE pass looks at the records with all 64 lanes -- 16 lanes per record, one
+// score each, four records per step -- and appends the rows that pass to the parked candidates.
+constexpr int LS_NST = 64;                       // records per wave (a pair may add 64)
+constexpr int LS_PLANE = LS_NST * 16 + 32;       // bytes of one score plane [record][4 floats] (+ 8 banks: conflict-free reads)
+constexpr int LS_WAVE = 4 * LS_PLANE + LS_NST * 16; // + tq, pos, qpr, xh per record
+struct LmfStage {
+    char* base;  // this wave's slice
+    int cnt;     // (wave-uniform) records waiting
+    __device__ __forceinline__ float* plane(int pl) const { return (float*)(base + pl * LS_PLANE); }
+    __device__ __forceinline__ float* tq() const { return (float*)(base + 4 * LS_PLANE); }
+    __device__ __forceinline__ uint32_t* pos() const { return (uint32_t*)(base + 4 * LS_PLANE + LS_NST * 4); }
+    __device__ __forceinline__ uint32_t* qpr() const { return (uint32_t*)(base + 4 * LS_PLANE + LS_NST * 8); }
+    __device__ __forceinline__ float* xh() const { return (float*)(base + 4 * LS_PLANE + LS_NST * 12); }
+};
+__device__ __forceinline__ int lmf_rank_in(unsigned long long bal) { // number of set bits below this lane
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+}
+// lanes with `hit` write their record (room for all of them was made by the caller)
+__device__ __forceinline__ void lmf_stage_push(LmfStage& st, bool hit, unsigned long long bal, const f32x16& a, float tq, uint32_t pos0,
+                                               uint32_t qpr, float xh) {
+    const int idx = st.cnt + lmf_rank_in(bal);
+    if (hit) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *(f32x4*)(st.plane(g) + 4 * idx) = f32x4{a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
+        st.tq()[idx] = tq;
+        st.pos()[idx] = pos0;
+        st.qpr()[idx] = qpr;
+        st.xh()[idx] = xh;
+    }
+    st.cnt += __popcll(bal);
+}
+// dense pass over the staged records: parked candidates go to pk_keys / pk_q (wcnt of them so far, room PARK; `flush` empties them)
+template <int METRIC, int PARK, typename Flush>
+__device__ __forceinline__ void lmf_stage_expand(LmfStage& st, int lane, u64* pk_keys, uint32_t* pk_q, int& wcnt, Flush&& flush) {
+    const int r = lane & 15, sub = lane >> 4;
+    for (int b0 = 0; b0 < st.cnt; b0 += 4) {
+        const int rec = b0 + sub;
+        const bool valid = rec < st.cnt;
+        const int rc = valid ? rec : 0;
+        const float sc = st.plane(r >> 2)[4 * rc + (r & 3)];
+        const bool pass = valid && sc >= st.tq()[rc];
+        const unsigned long long bal = __ballot(pass);
+        if (!bal) continue;
+        const int n = __popcll(bal);
+        if (wcnt + n > PARK) flush();
+        if (pass) {
+            const int at = wcnt + lmf_rank_in(bal);
+            // row of score r = 4 g + e of a lane: 8 g + e rows behind the lane's first
+            const uint32_t pos = st.pos()[rc] + (uint32_t)(8 * (r >> 2) + (r & 3));
+            pk_keys[at] = ((u64)ordkey<METRIC>(lmf_to_est<METRIC>(sc + st.xh()[rc])) << 32) | pos;
+            pk_q[at] = st.qpr()[rc];
+        }
+        wcnt += n;
+    }
+    st.cnt = 0;
+}
+
 // Work items of a sweep, drawn per XCD.  The plan emits the items in list order -- the query groups of one (list, row
 // chunk) next to each other -- and a list that meets more queries than an item holds is read once per group: the item range
 // is cut into eight contiguous parts, the wavefronts of XCD x (block b runs on XCD b % 8: observed, a matter of speed only)
@@ -312,20 +378,27 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
     __shared__ float rn_lds_all[4][64];
     float* rn_lds = rn_lds_all[wave];
     int wcnt = 0; // (wave-uniform) parked candidates
+    LmfStage st{smem + 4 * LF_PARK * 12 + wave * LS_WAVE, 0};
     auto flush = [&]() __attribute__((always_inline)) {
         for (int e = lane; e < wcnt; e += 64) {
             const u64 key = pk_keys[e];
             const uint32_t qp = pk_q[e];
             const uint32_t qq = qp >> 11;
-            const uint32_t slot = atomicAdd(p.cnt + qq, 1u);
+            // (returning atomic + wait inside the asm: the dense pass runs INSIDE the block loop, and with a memory operation
+            // of its own there hipcc stops counting the loads in flight and waits vmcnt(0) before every use)
+            uint32_t slot;
+            uint32_t* cp = p.cnt + qq;
+            const uint32_t one = 1u;
+            asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(slot) : "v"(cp), "v"(one) : "memory");
             if ((int64_t)slot < p.stride) {
-                p.keys[(int64_t)qq * p.stride + slot] = key;
-                p.cand_pr[(int64_t)qq * p.stride + slot] = (uint16_t)(qp & 2047u);
+                lmf_store_u64(p.keys + (int64_t)qq * p.stride + slot, key);
+                lmf_store_u16(p.cand_pr + (int64_t)qq * p.stride + slot, qp & 2047u);
             }
         }
         wcnt = 0;
-        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): no store in flight on any path into the block loop
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // no store in flight on any path back into the block loop
     };
+    auto expand = [&]() __attribute__((always_inline)) { lmf_stage_expand<METRIC, LF_PARK>(st, lane, pk_keys, pk_q, wcnt, flush); };
 
     const uint32_t it0 = p.item_bounds[1], it1 = p.item_bounds[2];
     LmfDraw draw(p.item_bounds, MODE == MODE_MIN ? 0 : 1, it0, it1);
@@ -373,12 +446,13 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
             L[b].gq = nullptr;
             L[b].kq = nullptr;
             if (MODE == MODE_MIN) L[b].gq = p.gmin + (int64_t)q * p.gstride + p.prefixg[(int64_t)q * (np + 1) + pr] + h;
-            if (MODE == MODE_COLLECT && L[b].qv) L[b].tq = (METRIC == METRIC_L2 ? -0.5f * p.thr_f[q] : p.thr_f[q]) - L[b].xh;
+            // (>= -FLT_MAX: rows that take no part carry a score of -inf and must not pass an "everything" threshold)
+            if (MODE == MODE_COLLECT && L[b].qv)
+                L[b].tq = fmaxf((METRIC == METRIC_L2 ? -0.5f * p.thr_f[q] : p.thr_f[q]) - L[b].xh, -FLT_MAX);
             if (MODE == MODE_DUMP) L[b].kq = p.keys + (int64_t)q * p.stride + L[b].base_pos;
         }
 
         int t = r0;
-        int skip_b = 0; // MODE_COLLECT: query blocks of block t whose candidates were parked before the slice filled up
         while (t < rend) {
             // ---- (re-)entry: the rows of block t.  Rows behind the end of the list belong to the next list or the
             // arena's padding: loaded, never looked at.
@@ -391,7 +465,6 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
                 else a[s] = half8{0, 0, 0, 0, 0, 0, 0, 0};
                 asm volatile("" ::: "memory");
             }
-            bool full = false;
             // sweep 1 may look at every min_stride-th block only (a SAMPLE of the rows still bounds the k-th best estimate
             // from above; fewer rows -> a looser bound -> more candidates in sweep 2)
             const int bstep = MODE == MODE_MIN ? 32 * p.min_stride : 32;
@@ -496,50 +569,22 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
                 } else {
 #pragma unroll
                     for (int b = 0; b < NQB; ++b) {
-                        // ---- does any of this lane's 16 scores of query block b reach its query's threshold?
-                        if (b < skip_b) continue;
+                        // ---- lanes whose best score of query block b reaches their query's threshold stage their 16 scores
                         lmf_scores<METRIC, SEL>(acc[b], rn, tail, row_b, r1, mw);
-                        if (!__ballot(lmf_lane_max(acc[b]) >= L[b].tq)) continue; // (wave-uniform)
-                        // (opaque copy: hipcc otherwise computes the 16 row tests of the first query block ABOVE the branch,
-                        // ~55 VALU instructions for every block of every item)
-                        float tqv = L[b].tq;
-                        asm volatile("" : "+v"(tqv));
-                        unsigned mask = 0;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            mask |= (acc[b][r] >= tqv && acc[b][r] > -INFINITY) ? 1u << r : 0u;
-                        if (!__ballot(mask != 0u)) continue;
-                        // park the candidates: this lane's go behind those of the lanes before it
-                        const int c = __popc(mask);
-                        const int inc = (int)wave_incl_scan((unsigned)c);
-                        const int total = __builtin_amdgcn_readlane(inc, 63);
-                        if (wcnt + total > LF_PARK) {
-                            full = true; // block t is redone after the flush, from query block b on
-                            skip_b = b;
-                            break;
-                        }
-                        int at = wcnt + inc - c;
-#pragma unroll
-                        for (int g = 0; g < 4; ++g)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                if (mask & (1u << (4 * g + e))) {
-                                    const uint32_t pos = L[b].base_pos + (uint32_t)(row_b + 8 * g + e);
-                                    pk_keys[at] = ((u64)ordkey<METRIC>(lmf_to_est<METRIC>(acc[b][4 * g + e] + L[b].xh)) << 32) | pos;
-                                    pk_q[at] = L[b].qpr;
-                                    ++at;
-                                }
-                            }
-                        wcnt += total;
+                        const bool hit = lmf_lane_max(acc[b]) >= L[b].tq;
+                        const unsigned long long bal = __ballot(hit);
+                        if (!bal) continue; // (wave-uniform)
+                        if (st.cnt + __popcll(bal) > LS_NST) expand();
+                        lmf_stage_push(st, hit, bal, acc[b], L[b].tq, L[b].base_pos + (uint32_t)row_b, L[b].qpr, L[b].xh);
                     }
-                    if (full) break;
-                    skip_b = 0;
                 }
             }
-            if (MODE == MODE_COLLECT && full) flush();
         }
     }
-    if (MODE == MODE_COLLECT && wcnt > 0) flush();
+    if (MODE == MODE_COLLECT) {
+        if (st.cnt > 0) expand();
+        if (wcnt > 0) flush();
+    }
 }
 
 // ------------------------------------------------------------------ IVFPQ sweep, fp16 codebook in LDS
@@ -554,13 +599,14 @@ constexpr int LP_BR = 32;    // rows per block
 constexpr int LP_PARK = 256; // parked candidates per wave
 constexpr int LP_AHEAD = 3;  // k-steps the codebook gathers run ahead of the MFMAs (ring of 4 operands)
 struct LpLayout {
-    int cb_bytes, off_park, total;
+    int cb_bytes, off_park, off_stage, total;
 };
 __host__ __device__ static inline LpLayout lp_layout(int d, int M) {
     LpLayout L;
     L.cb_bytes = d * 256 * 2;
     L.off_park = (L.cb_bytes + 15) & ~15;
-    L.total = L.off_park + 8 * LP_PARK * (8 + 4);
+    L.off_stage = L.off_park + 8 * LP_PARK * (8 + 4);
+    L.total = L.off_stage + 8 * (4 * (64 * 16 + 32) + 64 * 16); // (8 x LS_WAVE: the staged records of sweep 2)
     return L;
 }
 // code dwords a lane holds per 32-row block (IvfLmParams::cs_bpl / 4, at most): 8 k-steps x (8 / dsub) codes
@@ -597,6 +643,7 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
     __shared__ float rn_lds_all[8][64]; // |r^|^2 of the rows of the block in hand, per wave (see the flat kernel)
     float* rn_lds = rn_lds_all[wave];
     int wcnt = 0;
+    LmfStage st{smem + LY.off_stage + wave * LS_WAVE, 0};
     auto flush = [&]() __attribute__((always_inline)) {
         for (int e = lane; e < wcnt; e += 64) {
             const u64 key = pk_keys[e];
@@ -607,12 +654,14 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
             const uint32_t one = 1u;
             asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(slot) : "v"(cp), "v"(one) : "memory");
             if ((int64_t)slot < p.stride) {
-                p.keys[(int64_t)qq * p.stride + slot] = key;
-                p.cand_pr[(int64_t)qq * p.stride + slot] = (uint16_t)(qp & 2047u);
+                lmf_store_u64(p.keys + (int64_t)qq * p.stride + slot, key);
+                lmf_store_u16(p.cand_pr + (int64_t)qq * p.stride + slot, qp & 2047u);
             }
         }
         wcnt = 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
+    auto expand = [&]() __attribute__((always_inline)) { lmf_stage_expand<METRIC, LP_PARK>(st, lane, pk_keys, pk_q, wcnt, flush); };
     __syncthreads();
 
     // operand-major code shadow (IvfLmParams::arena_cs): a block = npiece pieces of 64 lanes x cs_piece bytes
@@ -710,7 +759,8 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
             L[b].gq = nullptr;
             L[b].kq = nullptr;
             if (MODE == MODE_MIN) L[b].gq = p.gmin + (int64_t)q * p.gstride + p.prefixg[(int64_t)q * (np + 1) + pr] + h;
-            if (MODE == MODE_COLLECT && L[b].qv) L[b].tq = (METRIC == METRIC_L2 ? -0.5f * p.thr_f[q] : p.thr_f[q]) - L[b].xh;
+            if (MODE == MODE_COLLECT && L[b].qv)
+                L[b].tq = fmaxf((METRIC == METRIC_L2 ? -0.5f * p.thr_f[q] : p.thr_f[q]) - L[b].xh, -FLT_MAX); // (see the flat kernel)
             if (MODE == MODE_DUMP) L[b].kq = p.keys + (int64_t)q * p.stride + L[b].base_pos;
         }
 
@@ -829,37 +879,13 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
             } else {
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
-                    // ---- does any of this lane's 16 scores of query block b reach its query's threshold?
+                    // ---- lanes whose best score of query block b reaches their query's threshold stage their 16 scores
                     lmf_scores<METRIC, SEL>(acc[b], rn, tail, row_b, r1, mw);
-                    if (!__ballot(lmf_lane_max(acc[b]) >= L[b].tq)) continue; // (wave-uniform)
-                    float tqv = L[b].tq; // (opaque copy: keeps the 16 row tests below the branch, see the flat kernel)
-                    asm volatile("" : "+v"(tqv));
-                    unsigned mask = 0;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) mask |= (acc[b][r] >= tqv && acc[b][r] > -INFINITY) ? 1u << r : 0u;
-                    if (!__ballot(mask != 0u)) continue;
-                    // park the candidates row group by row group (8 g + 4 h + e, g = 0 .. 3): a group holds at most
-                    // 4 x 64 = LP_PARK candidates, so it always fits an empty slice
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const unsigned mg = (mask >> (4 * g)) & 15u;
-                        if (!__ballot(mg != 0u)) continue;
-                        const int c = __popc(mg);
-                        const int inc = (int)wave_incl_scan((unsigned)c);
-                        const int total = __builtin_amdgcn_readlane(inc, 63);
-                        if (wcnt + total > LP_PARK) flush();
-                        int at = wcnt + inc - c;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            if (mg & (1u << e)) {
-                                const uint32_t pos = L[b].base_pos + (uint32_t)(row_b + 8 * g + e);
-                                pk_keys[at] = ((u64)ordkey<METRIC>(lmf_to_est<METRIC>(acc[b][4 * g + e] + L[b].xh)) << 32) | pos;
-                                pk_q[at] = L[b].qpr;
-                                ++at;
-                            }
-                        }
-                        wcnt += total;
-                    }
+                    const bool hit = lmf_lane_max(acc[b]) >= L[b].tq;
+                    const unsigned long long bal = __ballot(hit);
+                    if (!bal) continue; // (wave-uniform)
+                    if (st.cnt + __popcll(bal) > LS_NST) expand();
+                    lmf_stage_push(st, hit, bal, acc[b], L[b].tq, L[b].base_pos + (uint32_t)row_b, L[b].qpr, L[b].xh);
                 }
             }
 #pragma unroll
@@ -870,7 +896,10 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
         else if (npair > 32) run_item(std::integral_constant<int, 2>{});
         else run_item(std::integral_constant<int, 1>{});
     }
-    if (MODE == MODE_COLLECT && wcnt > 0) flush();
+    if (MODE == MODE_COLLECT) {
+        if (st.cnt > 0) expand();
+        if (wcnt > 0) flush();
+    }
 }
 
 // ------------------------------------------------------------------ launchers of the sweeps
