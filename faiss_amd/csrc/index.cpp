@@ -2768,6 +2768,8 @@ void GpuIndexIVF::search_listmajor_filter_chunk_(int ni, int q0, const float* xq
     {
         // clamp of overflowed segments + the smallest superset the band allows (launch_ivf_lmf_tighten)
         SpanGuard sg(&R, "ivf_lmf_tighten");
+        static const char* notight = experiment_env("FAISS_AMD_LMF_NOTIGHTEN"); // diagnostics: keep every collected candidate
+        if (notight) HIP_CHECK(hipMemsetAsync(P.err_f, 0x7f, (size_t)ni * 4, R.stream)); // (huge band: nothing is cut)
         launch_ivf_lmf_tighten(P, fused_select ? kLmfFusedSelectN : 0, R.stream);
     }
     if (fused_select) {

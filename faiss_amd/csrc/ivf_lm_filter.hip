@@ -215,9 +215,10 @@ template <int METRIC>
 __device__ __forceinline__ float lmf_to_est(float sc) {
     return METRIC == METRIC_L2 ? -2.f * sc : sc;
 }
+// (volatile: the consumers of accumulators must stay behind lmf_scores' wait, see there)
 __device__ __forceinline__ float lmf_max3(float a, float b, float c) {
     float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
 __device__ __forceinline__ float lmf_lane_max(const f32x16& a) { // 8 instructions
@@ -244,6 +245,15 @@ __device__ __forceinline__ void lmf_scores(f32x16& a, const f32x4 (&rn)[4], bool
                 a[4 * g + e] = a2[0];
                 a[4 * g + e + 1] = a2[1];
             }
+    }
+    else {
+        // Inner product: nothing is computed on the accumulators, so the first instruction that reads them is the v_max3
+        // of lmf_lane_max -- an asm statement the compiler's hazard recogniser does not look into, and the hardware does not
+        // interlock a VALU read of a register an MFMA is still writing (19 wait states behind a 16-pass XDL write).  Found in
+        // round 5: with ONE query block per item the v_max3 sat right behind the last MFMA and read stale maxima -- rows of
+        // the answer were not collected, a few queries per thousand, depending on the instruction schedule.  (L2: the
+        // compiler-visible v_pk_fma above reads the accumulators first and gets its wait states from the compiler.)
+        asm volatile("s_nop 15\n\ts_nop 3" ::"v"(a));
     }
     // L2: rows behind the end of the chunk arrive with |y'|^2 = +inf (rn_fetch of the sweeps), so they are -inf already --
     // the 16 row tests hipcc hoisted out of the `tail` branch cost every block 32 VALU instructions.

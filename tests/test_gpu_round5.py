@@ -61,7 +61,7 @@ def test_redo_set_goes_through_the_key_scan_in_sub_tiles(res):
     ref.set_scan_mode(1)
     Dr, Ir = ref.search(xq, k)
     res2 = faiss_amd.StandardGpuResources(0)
-    res2.setTempMemory(8 << 20)  # 8 MB: ~26 queries of 4 x ~10 000 rows x 8 bytes per sub-tile
+    res2.setTempMemory(64 << 20)  # the minimum, 64 MiB: ~200 queries of 4 x ~10 000 rows x 8 bytes per sub-tile (600 are redone)
     idx = faiss_amd.GpuIndexIVFFlat(res2, d, nlist, METRIC_L2)
     idx.copy_centroids(ref.get_centroids())
     idx.add(xb)
