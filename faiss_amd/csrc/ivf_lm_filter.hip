@@ -211,6 +211,15 @@ struct LmfLane { // per (lane, query block)
     uint32_t* gq;           // sweep 1: gmin + q * gstride + granule-slot base of this (query, probe) + h
     u64* kq;                // MODE_DUMP: keys + q * stride + base_pos
 };
+// threshold of sweep 2 on a row score (without the query's own term xh): scores >= it are collected.  thr = the query's
+// threshold on the estimate.  "Nothing" (the bound kernel's sentinel for queries it hands to the redo path) becomes NaN:
+// no score passes it, not even +inf.  "Everything" is clamped to -FLT_MAX: rows that take no part carry a score of -inf.
+template <int METRIC>
+__device__ __forceinline__ float lmf_collect_threshold(float thr, float xh) {
+    const bool nothing = METRIC == METRIC_L2 ? thr == -INFINITY : thr == INFINITY;
+    const float t = (METRIC == METRIC_L2 ? -0.5f * thr : thr) - xh;
+    return nothing ? __builtin_nanf("") : fmaxf(t, -FLT_MAX);
+}
 template <int METRIC>
 __device__ __forceinline__ float lmf_to_est(float sc) {
     return METRIC == METRIC_L2 ? -2.f * sc : sc;
@@ -451,14 +460,12 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
             L[b].xh = METRIC == METRIC_L2 ? -0.5f * p.xqn[q] : 0.f;
             L[b].base_pos = p.prefix[(int64_t)q * (np + 1) + pr];
             L[b].qpr = ((uint32_t)q << 11) | (uint32_t)pr;
-            L[b].tq = INFINITY;
+            L[b].tq = __builtin_nanf(""); // nothing passes a NaN threshold -- not even a score of +inf (a query beyond the fp16 range)
             L[b].gm = -INFINITY;
             L[b].gq = nullptr;
             L[b].kq = nullptr;
             if (MODE == MODE_MIN) L[b].gq = p.gmin + (int64_t)q * p.gstride + p.prefixg[(int64_t)q * (np + 1) + pr] + h;
-            // (>= -FLT_MAX: rows that take no part carry a score of -inf and must not pass an "everything" threshold)
-            if (MODE == MODE_COLLECT && L[b].qv)
-                L[b].tq = fmaxf((METRIC == METRIC_L2 ? -0.5f * p.thr_f[q] : p.thr_f[q]) - L[b].xh, -FLT_MAX);
+            if (MODE == MODE_COLLECT && L[b].qv) L[b].tq = lmf_collect_threshold<METRIC>(p.thr_f[q], L[b].xh);
             if (MODE == MODE_DUMP) L[b].kq = p.keys + (int64_t)q * p.stride + L[b].base_pos;
         }
 
@@ -764,13 +771,12 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
             L[b].xh = METRIC == METRIC_L2 ? p.pair_xh[pi] : p.coarse_dis[pi];
             L[b].base_pos = p.prefix[(int64_t)q * (np + 1) + pr];
             L[b].qpr = ((uint32_t)q << 11) | (uint32_t)pr;
-            L[b].tq = INFINITY;
+            L[b].tq = __builtin_nanf(""); // (see the flat kernel)
             L[b].gm = -INFINITY;
             L[b].gq = nullptr;
             L[b].kq = nullptr;
             if (MODE == MODE_MIN) L[b].gq = p.gmin + (int64_t)q * p.gstride + p.prefixg[(int64_t)q * (np + 1) + pr] + h;
-            if (MODE == MODE_COLLECT && L[b].qv)
-                L[b].tq = fmaxf((METRIC == METRIC_L2 ? -0.5f * p.thr_f[q] : p.thr_f[q]) - L[b].xh, -FLT_MAX); // (see the flat kernel)
+            if (MODE == MODE_COLLECT && L[b].qv) L[b].tq = lmf_collect_threshold<METRIC>(p.thr_f[q], L[b].xh);
             if (MODE == MODE_DUMP) L[b].kq = p.keys + (int64_t)q * p.stride + L[b].base_pos;
         }
 
@@ -1102,7 +1108,11 @@ __global__ void __launch_bounds__(256) lmf_tighten_kernel(IvfLmParams p, int fin
     const int q = blockIdx.x;
     const int tid = threadIdx.x;
     const uint32_t raw = p.cnt[q];
+    // (queries the bound kernel handed to the redo path -- threshold "nothing" -- are listed already)
+    const float thr0 = p.thr_f[q];
+    const bool listed = METRIC == METRIC_L2 ? thr0 == -INFINITY : thr0 == INFINITY;
     auto overflow = [&]() {
+        if (listed) return;
         const uint32_t s = atomicAdd(&p.ovf[0], 1u);
         p.ovf[1 + s] = (uint32_t)q;
     };
