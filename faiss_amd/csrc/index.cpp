@@ -1655,6 +1655,7 @@ void GpuIndexIVF::grow_lists_(const std::vector<uint32_t>& new_len, const std::v
         const int64_t ncap = (int64_t)round_up((size_t)std::ceil(want), (size_t)G);
         FA_THROW_IF_NOT_MSG(ncap < ((int64_t)1 << 32), "inverted list too long");
         if (list_len_[l] > 0) jobs.push_back({list_start_[l], arena_rows_ + extra, (int64_t)round_up(list_len_[l], (size_t)G)});
+        if (!moved_.empty()) moved_[l] = 1;
         hole_rows_ += list_cap_[l];
         list_start_[l] = arena_rows_ + extra;
         list_cap_[l] = (uint32_t)ncap;
@@ -1662,7 +1663,7 @@ void GpuIndexIVF::grow_lists_(const std::vector<uint32_t>& new_len, const std::v
     }
     if (extra == 0) return;
     const GpuResources& R = *res_;
-    shadow_dirty_ = true;
+    if (moved_.empty()) shadow_dirty_ = true; // (add_core_ patches a live copy of the lists: it passes moved_)
     ensure_arena_(arena_rows_ + extra); // (keeps rows [0, arena_rows_): the jobs' sources)
     arena_rows_ += extra;
     if (!jobs.empty()) {
@@ -1793,7 +1794,14 @@ void GpuIndexIVF::add_core_(idx_t n, const float* x, const idx_t* xids, const id
     res_->set_device();
     const GpuResources& R = *res_;
     const idx_t page = std::max<idx_t>(1, std::min<idx_t>(((idx_t)512 << 20) / ((idx_t)dpad_ * 4), 1 << 20));
-    shadow_dirty_ = true;
+    // the filter sweeps' copy of the lists: a live one is kept up to date page by page (lmf_patch_), otherwise it is (re)built
+    // as a whole by the first list-major search that wants it
+    const bool patch = use_filter_shadow && !shadow_dirty_ && lmf_shadow_bytes_() > 0 && lmf_capable_();
+    if (!patch) shadow_dirty_ = true;
+    struct MovedScope {
+        std::vector<uint8_t>& m;
+        ~MovedScope() { m.clear(); }
+    } moved_scope{moved_};
     const int chunk = 2048;
     const idx_t pn = std::min(page, n);
     a_xpad_.ensure((size_t)pn * dpad_ * 4);
@@ -1838,6 +1846,7 @@ void GpuIndexIVF::add_core_(idx_t n, const float* x, const idx_t* xids, const id
             est[l] = (double)len0[l] + ((double)new_len[l] - (double)len0[l]) * scale;
             added += (idx_t)new_len[l] - (idx_t)list_len_[l];
         }
+        if (patch) moved_.assign((size_t)nlist, 0);
         grow_lists_(new_len, &est);
         // ---- destination rows (insertion order kept inside every list), then encode / scatter
         launch_ivf_rank(a_lab_.as<int64_t>(), ni, nlist, chunk, a_hist_.as<uint32_t>(), d_list_start_.as<int64_t>(),
@@ -1845,6 +1854,20 @@ void GpuIndexIVF::add_core_(idx_t n, const float* x, const idx_t* xids, const id
         append_(ni, a_xpad_.as<float>(), a_lab_.as<int64_t>(), a_dest_.as<int64_t>());
         launch_scatter_i64(a_ids_.as<int64_t>(), a_dest_.as<int64_t>(), ni, arena_ids_.as<int64_t>(), R.stream);
         HIP_CHECK(hipMemcpyAsync(d_list_len_.p, a_newlen_.p, (size_t)nlist * 4, hipMemcpyDeviceToDevice, R.stream));
+        if (patch && !shadow_dirty_) {
+            h_first_row_.resize((size_t)nlist);
+            for (int l = 0; l < nlist; l++)
+                h_first_row_[l] = moved_[l] ? 0u : new_len[l] != list_len_[l] ? (list_len_[l] & ~31u) : 0xffffffffu;
+            a_first_row_.ensure((size_t)nlist * 4);
+            HIP_CHECK(hipMemcpyAsync(a_first_row_.p, h_first_row_.data(), (size_t)nlist * 4, hipMemcpyHostToDevice, R.stream));
+            try {
+                lmf_patch_(a_first_row_.as<uint32_t>());
+            } catch (const DeviceOutOfMemory&) {
+                // no room to grow the copy: drop it (the next list-major search rebuilds it, or falls back to query-major)
+                (void)lmf_release_();
+                shadow_dirty_ = true;
+            }
+        }
         list_len_ = new_len;
         nstored_ += added;
         ntotal += ni;
@@ -3160,16 +3183,38 @@ bool GpuIndexIVFFlat::lmf_capable_() const {
 // 6 bytes per coordinate) at the first list-major search after a list changed (add / copy_lists / compaction): a
 // database that is built once and searched many times pays it once, interleaved add / search workloads pay one arena
 // pass per add call.
+void GpuIndexIVFFlat::lmf_shadow_room_() const {
+    // whole 32-row blocks + padding (the sweeps prefetch the next block they look at: up to 8 blocks behind the last list)
+    const size_t need = ((size_t)arena_cap_rows_ / 32 + 10) * (size_t)(ivf_lmf_row_halfs(d) / 16) * 1024;
+    if (need > arena_h_.cap) arena_h_.ensure(need, shadow_dirty_ ? 0 : arena_h_.cap, res_->stream);
+}
+// add(): the blocks that hold new rows, and the relocated lists (GpuIndexIVF::add_core_).  max |y|^2 and the fp16-range flag
+// of the rows written merge into those of the copy.
+void GpuIndexIVFFlat::lmf_patch_(const uint32_t* d_first_row) {
+    const GpuResources& R = *res_;
+    const int dh = ivf_lmf_row_halfs(d);
+    lmf_shadow_room_();
+    lm_scalar_.ensure(64);
+    HIP_CHECK(hipMemsetAsync(lm_scalar_.p, 0, 4, R.stream));
+    launch_ivf_lmf_shadow(arena_.as<float>(), dpad_, arena_rn_.as<float>(), d, nlist, d_list_len_.as<uint32_t>(),
+                          d_list_start_.as<int64_t>(), arena_h_.p, dh, lm_scalar_.as<unsigned>(), d_first_row, R.stream);
+    unsigned bits = 0;
+    HIP_CHECK(hipMemcpyAsync(&bits, lm_scalar_.p, 4, hipMemcpyDeviceToHost, R.stream));
+    R.sync();
+    if (bits == 0x7f800000u) shadow_in_range_ = false;
+    float mx;
+    memcpy(&mx, &bits, 4);
+    if (shadow_in_range_) shadow_yn_max_ = std::max(shadow_yn_max_, mx);
+}
 bool GpuIndexIVFFlat::lmf_prepare_(IvfLmParams& p) const {
     const int dh = ivf_lmf_row_halfs(d);
+    lmf_shadow_room_();
     if (shadow_dirty_) {
         const GpuResources& R = *res_;
-        // whole 32-row blocks + padding (the sweeps prefetch the next block they look at: up to 8 blocks behind the last list)
-        arena_h_.ensure(((size_t)arena_cap_rows_ / 32 + 10) * (size_t)(dh / 16) * 1024);
         lm_scalar_.ensure(64);
         HIP_CHECK(hipMemsetAsync(lm_scalar_.p, 0, 4, R.stream));
         launch_ivf_lmf_shadow(arena_.as<float>(), dpad_, arena_rn_.as<float>(), d, nlist, d_list_len_.as<uint32_t>(),
-                              d_list_start_.as<int64_t>(), arena_h_.p, dh, lm_scalar_.as<unsigned>(), R.stream);
+                              d_list_start_.as<int64_t>(), arena_h_.p, dh, lm_scalar_.as<unsigned>(), nullptr, R.stream);
         unsigned bits = 0;
         HIP_CHECK(hipMemcpyAsync(&bits, lm_scalar_.p, 4, hipMemcpyDeviceToHost, R.stream));
         R.sync();
@@ -3454,6 +3499,18 @@ bool GpuIndexIVFPQ::lmf_capable_() const {
 }
 // fp16 codebook + the norm bounds of the filter's error band: upper bound of |r^|^2 (sum over the sub-quantizers of their
 // largest squared entry norm), max |centroid|^2.  Rebuilt when a quantizer changed.
+void GpuIndexIVFPQ::lmf_shadow_room_() const {
+    int bpl = 0, piece = 0;
+    ivf_lmf_code_shadow_shape(d, M, &bpl, &piece);
+    const size_t blk = (size_t)64 * ((bpl + piece - 1) / piece) * piece;
+    const size_t need = ((size_t)arena_cap_rows_ / 32 + 4) * blk;
+    if (need > arena_cs_.cap) arena_cs_.ensure(need, shadow_dirty_ ? 0 : arena_cs_.cap, res_->stream);
+}
+void GpuIndexIVFPQ::lmf_patch_(const uint32_t* d_first_row) {
+    lmf_shadow_room_();
+    launch_ivf_lmf_code_shadow(arena_.as<uint8_t>(), d, M, nlist, d_list_len_.as<uint32_t>(), d_list_start_.as<int64_t>(),
+                               arena_cs_.as<uint8_t>(), d_first_row, res_->stream);
+}
 bool GpuIndexIVFPQ::lmf_prepare_(IvfLmParams& p) const {
     if (lmf_quant_dirty_) {
         FA_THROW_IF_NOT_MSG(pq_.p && quantizer->ntotal == nlist, "index not trained");
@@ -3498,13 +3555,12 @@ bool GpuIndexIVFPQ::lmf_prepare_(IvfLmParams& p) const {
     if (!pq16_in_range_) return false;
     int bpl = 0, piece = 0;
     ivf_lmf_code_shadow_shape(d, M, &bpl, &piece);
+    lmf_shadow_room_();
     if (shadow_dirty_) {
-        // operand-major copy of the codes (kernels.h IvfLmParams::arena_cs): rebuilt as a whole at the first list-major
-        // search after a list changed, like the fp16 shadow of IVFFlat
-        const size_t blk = (size_t)64 * ((bpl + piece - 1) / piece) * piece;
-        arena_cs_.ensure(((size_t)arena_cap_rows_ / 32 + 4) * blk);
+        // operand-major copy of the codes (kernels.h IvfLmParams::arena_cs): built as a whole at the first list-major search
+        // that finds none (add() keeps a live one up to date, lmf_patch_)
         launch_ivf_lmf_code_shadow(arena_.as<uint8_t>(), d, M, nlist, d_list_len_.as<uint32_t>(), d_list_start_.as<int64_t>(),
-                                   arena_cs_.as<uint8_t>(), res_->stream);
+                                   arena_cs_.as<uint8_t>(), nullptr, res_->stream);
         res_->sync();
         shadow_dirty_ = false;
     }

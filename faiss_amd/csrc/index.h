@@ -449,6 +449,14 @@ class GpuIndexIVF : public Index {
     // bytes freed by dropping the sweeps' own copies of the lists (rebuilt at the next list-major search)
     virtual size_t lmf_release_() { return 0; }
     virtual size_t lmf_shadow_bytes_() const { return 0; }
+    // add() keeps a LIVE copy up to date instead of invalidating it (round 5; the reference appends into the layout it scans,
+    // faiss/gpu/impl/IVFBase.cu:595-905): after a page has been appended, the 32-row blocks of the copy that hold new rows --
+    // and every block of a list grow_lists_ relocated -- are rebuilt from the lists (launch_ivf_lmf_shadow /
+    // launch_ivf_lmf_code_shadow with a first row per list).  d_first_row: device [nlist], 0xffffffff = list unchanged.
+    virtual void lmf_patch_(const uint32_t* d_first_row) {}
+    std::vector<uint8_t> moved_;        // lists relocated by grow_lists_ during the add page in flight
+    std::vector<uint32_t> h_first_row_; // host image of the patch's first rows (alive until the page's synchronisation)
+    DevBuf a_first_row_;
     mutable bool cur_lmf_ = false;        // the list-major search in flight runs the filter sweeps
     mutable bool cur_preassigned_ = false; // ... with the caller's coarse assignment (search_preassigned)
     mutable int last_scan_arith_ = 0;     // oracle restatement of the last search: 0 query-major arithmetic, 1 f32 list-major
@@ -532,6 +540,8 @@ class GpuIndexIVFFlat : public GpuIndexIVF {
     bool lmf_prepare_(struct IvfLmParams& p) const override;
     mutable DevBuf arena_h_;          // fp16 shadow of the arena rows [arena_cap_rows_ + 128][dh_]
     size_t lmf_shadow_bytes_() const override { return arena_h_.cap; }
+    void lmf_patch_(const uint32_t* d_first_row) override;
+    void lmf_shadow_room_() const; // arena_h_ holds the blocks of arena_cap_rows_ rows (contents kept)
     size_t lmf_release_() override {
         const size_t b = arena_h_.cap;
         arena_h_.release();
@@ -579,6 +589,8 @@ class GpuIndexIVFPQ : public GpuIndexIVF {
     mutable DevBuf pq16_;             // fp16 codebook [M][256][dsub]
     mutable DevBuf arena_cs_;         // operand-major copy of the codes for the filter sweeps (kernels.h IvfLmParams::arena_cs)
     size_t lmf_shadow_bytes_() const override { return arena_cs_.cap + pq16_.cap; }
+    void lmf_patch_(const uint32_t* d_first_row) override;
+    void lmf_shadow_room_() const; // arena_cs_ holds the blocks of arena_cap_rows_ rows (contents kept)
     size_t lmf_release_() override {
         const size_t b = arena_cs_.cap;
         arena_cs_.release();

@@ -96,22 +96,28 @@ int ivf_lmf_queries_per_item(int kind, int d) {
 __global__ void __launch_bounds__(256) lmf_shadow_kernel(const float* __restrict__ arena, int64_t ldv,
                                                          const float* __restrict__ arena_rn, int d, const uint32_t* list_len,
                                                          const int64_t* list_start, _Float16* __restrict__ arena_h, int dh,
-                                                         unsigned* __restrict__ yn_max_bits) {
+                                                         unsigned* __restrict__ yn_max_bits,
+                                                         const uint32_t* __restrict__ first_row) {
     const int list = blockIdx.x;
     const uint32_t len = list_len[list];
     const int64_t start = list_start[list]; // (a multiple of 32)
     const int nks = dh >> 4;
     float mx = 0.f;
     bool bad = false;
+    // incremental maintenance (add()): only the 32-row blocks from row first_row[list] on are (re)written -- the blocks the
+    // call appended to, or the whole list when it moved; 0xffffffff = the list did not change
+    const uint32_t fr = first_row ? first_row[list] : 0u;
+    if (fr == 0xffffffffu) return; // (workgroup-uniform)
+    const int64_t b0 = fr >> 5;
     // piece i of the list's shadow: (block, k-step, lane) with the lane fastest -- consecutive threads write consecutive
     // 16-byte pieces; rows behind the end of the list are written as zeros
-    const int64_t nblk = (len + 31) / 32;
+    const int64_t nblk = (len + 31) / 32 - b0;
     const int64_t total = nblk * nks * 64;
     for (int64_t i = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.y * blockDim.x) {
         const int ln = (int)(i & 63);
         const int64_t bs = i >> 6;
         const int s = (int)(bs % nks);
-        const int64_t b = bs / nks;
+        const int64_t b = b0 + bs / nks;
         const int h = ln >> 5, j = ln & 31;
         const int64_t r = b * 32 + j;
         const int c = 16 * s + 8 * h;
@@ -138,10 +144,11 @@ __global__ void __launch_bounds__(256) lmf_shadow_kernel(const float* __restrict
     if ((threadIdx.x & 63) == 0) atomicMax(yn_max_bits, anybad ? 0x7f800000u : __float_as_uint(mx));
 }
 void launch_ivf_lmf_shadow(const float* arena, int64_t ldv, const float* arena_rn, int d, int nlist, const uint32_t* list_len,
-                           const int64_t* list_start, void* arena_h, int dh, unsigned* yn_max_bits, hipStream_t stream) {
+                           const int64_t* list_start, void* arena_h, int dh, unsigned* yn_max_bits, const uint32_t* first_row,
+                           hipStream_t stream) {
     if (nlist == 0) return;
-    hipLaunchKernelGGL(lmf_shadow_kernel, dim3((unsigned)nlist, 4), dim3(256), 0, stream, arena, ldv, arena_rn, d, list_len,
-                       list_start, (_Float16*)arena_h, dh, yn_max_bits);
+    hipLaunchKernelGGL(lmf_shadow_kernel, dim3((unsigned)nlist, first_row ? 1 : 4), dim3(256), 0, stream, arena, ldv, arena_rn, d,
+                       list_len, list_start, (_Float16*)arena_h, dh, yn_max_bits, first_row);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -154,20 +161,24 @@ void ivf_lmf_code_shadow_shape(int d, int M, int* bpl, int* piece) {
 }
 __global__ void __launch_bounds__(256) lmf_code_shadow_kernel(const uint8_t* __restrict__ arena_codes, int d, int M,
                                                               const uint32_t* list_len, const int64_t* list_start,
-                                                              uint8_t* __restrict__ arena_cs, int bpl, int piece) {
+                                                              uint8_t* __restrict__ arena_cs, int bpl, int piece,
+                                                              const uint32_t* __restrict__ first_row) {
     const int list = blockIdx.x;
     const uint32_t len = list_len[list];
     const int64_t start = list_start[list]; // (a multiple of 64)
     const int dsub = d / M;
     const int ncode = dsub >= 8 ? 1 : 8 / dsub;
     const int npiece = (bpl + piece - 1) / piece;
-    const int64_t nblk = (len + 31) / 32;
+    const uint32_t fr = first_row ? first_row[list] : 0u; // (incremental maintenance: see lmf_shadow_kernel)
+    if (fr == 0xffffffffu) return;
+    const int64_t b0 = fr >> 5;
+    const int64_t nblk = (len + 31) / 32 - b0;
     const int64_t total = nblk * npiece * 64; // pieces of the list's shadow, lane fastest
     for (int64_t i = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.y * blockDim.x) {
         const int ln = (int)(i & 63);
         const int64_t bp = i >> 6;
         const int pc = (int)(bp % npiece);
-        const int64_t b = bp / npiece;
+        const int64_t b = b0 + bp / npiece;
         const int h = ln >> 5, j = ln & 31;
         const int64_t r = b * 32 + j;
         uint8_t* dst = arena_cs + ((start >> 5) + b) * (int64_t)(64 * npiece * piece) + ((int64_t)pc * 64 + ln) * piece;
@@ -184,12 +195,12 @@ __global__ void __launch_bounds__(256) lmf_code_shadow_kernel(const uint8_t* __r
     }
 }
 void launch_ivf_lmf_code_shadow(const uint8_t* arena_codes, int d, int M, int nlist, const uint32_t* list_len,
-                                const int64_t* list_start, uint8_t* arena_cs, hipStream_t stream) {
+                                const int64_t* list_start, uint8_t* arena_cs, const uint32_t* first_row, hipStream_t stream) {
     if (nlist == 0) return;
     int bpl, piece;
     ivf_lmf_code_shadow_shape(d, M, &bpl, &piece);
-    hipLaunchKernelGGL(lmf_code_shadow_kernel, dim3((unsigned)nlist, 8), dim3(256), 0, stream, arena_codes, d, M, list_len,
-                       list_start, arena_cs, bpl, piece);
+    hipLaunchKernelGGL(lmf_code_shadow_kernel, dim3((unsigned)nlist, first_row ? 1 : 8), dim3(256), 0, stream, arena_codes, d, M,
+                       list_len, list_start, arena_cs, bpl, piece, first_row);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -571,12 +571,15 @@ void launch_ivf_lmf_pq_prepare(const IvfLmParams& p, float* xn_bound, hipStream_
 void launch_ivf_lmf_rerank(const IvfLmParams& p, hipStream_t stream);
 // fp16 shadow of the rows of every list (rows [0, len) of each; dh halfs per row, zero padded) + max |y|^2 over them
 // (float bits by atomicMax; 0x7f800000 when a stored value is NaN / inf / beyond the fp16 range)
+// first_row (device, [nlist], may be null = every list from row 0): only the 32-row blocks from that row of the list on are
+// (re)written, 0xffffffff = the list is skipped -- the incremental maintenance of add() (GpuIndexIVF::lmf_patch_)
 void launch_ivf_lmf_shadow(const float* arena, int64_t ldv, const float* arena_rn, int d, int nlist, const uint32_t* list_len,
-                           const int64_t* list_start, void* arena_h, int dh, unsigned* yn_max_bits, hipStream_t stream);
+                           const int64_t* list_start, void* arena_h, int dh, unsigned* yn_max_bits, const uint32_t* first_row,
+                           hipStream_t stream);
 // IVFPQ: operand-major copy of the codes of every list (see IvfLmParams::arena_cs); bytes per lane and block / piece size
 void ivf_lmf_code_shadow_shape(int d, int M, int* bpl, int* piece);
 void launch_ivf_lmf_code_shadow(const uint8_t* arena_codes, int d, int M, int nlist, const uint32_t* list_len,
-                                const int64_t* list_start, uint8_t* arena_cs, hipStream_t stream);
+                                const int64_t* list_start, uint8_t* arena_cs, const uint32_t* first_row, hipStream_t stream);
 // kind 0: M unused; kind 1: M = sub-quantizers; kind 2: M = SqCodeType
 bool ivf_lm_supported(int kind, int dpad, int M, int d);
 // prefix / p0 / cnt, the pairs grouped by (pass, list), the work items.  (4 launches + 1 memset)

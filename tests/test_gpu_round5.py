@@ -165,3 +165,95 @@ def test_sampled_first_sweep_and_tightening_keep_the_bits(res, kind, metric, d, 
         assert np.array_equal(I, Ir) and np.array_equal(D, Dr), "sample shift %d" % shift
     assert idx.scan_info()[2] == before, "queries were redone"
     idx.set_lmf_sampling(0)
+
+
+@pytest.mark.parametrize("kind,metric", [(0, METRIC_L2), (1, METRIC_L2), (0, METRIC_INNER_PRODUCT)])
+def test_add_keeps_the_sweeps_copy_of_the_lists_up_to_date(res, kind, metric):
+    """add() after a list-major search patches the sweeps' copy of the lists in place (the 32-row blocks that received rows,
+    every block of a relocated list) instead of invalidating it: many small and a few large adds interleaved with searches
+    -- lists outgrow their slack and move, the arena is reallocated, reclaimMemory / a forced compaction drop the copy in
+    between -- and every search returns the bits of the query-major scan on the same index, and of an index built in one
+    add.  resident_bytes shows the copy alive (never rebuilt from nothing) across the adds."""
+    d, nlist, M, nq, k = 64, 16, 16, 300, 40
+    rs = np.random.RandomState(9)
+    xt, xb, xq = synthetic_dataset(d, 3000, 90000, nq, seed=31)
+    idx = _make(res, kind, d, nlist, M, metric)
+    idx.train(xt)
+    idx.nprobe = 5
+    sizes = [3000, 17, 1, 2000, 64, 5, 33, 20000, 100, 1, 31, 32, 40000, 7, 999]
+    done = 0
+    for step, n in enumerate(sizes):
+        idx.add(xb[done:done + n])
+        done += n
+        if step == 0:
+            idx.set_scan_mode(2)
+            idx.search(xq, k)  # builds the copy
+            assert idx.resident_bytes()[1] > 0
+            continue
+        assert idx.resident_bytes()[1] > 0, "the copy was dropped by add()"
+        if step == 9:
+            idx.reclaimMemory()  # drops the copy and compacts the lists: the next search rebuilds it
+        idx.set_scan_mode(2)
+        D, I = idx.search(xq, k)
+        assert idx.scan_info()[1] == 2 and idx.last_scan_arith() == 0
+        idx.set_scan_mode(1)
+        Dr, Ir = idx.search(xq, k)
+        assert np.array_equal(I, Ir) and np.array_equal(D, Dr), "after add #%d (%d rows)" % (step, n)
+    fresh = _make(res, kind, d, nlist, M, metric)
+    fresh.copy_centroids(idx.get_centroids())
+    if kind == 1:
+        fresh.copy_pq_centroids(idx.get_pq_centroids())
+    fresh.add(xb[:done])
+    fresh.nprobe = 5
+    fresh.set_scan_mode(2)
+    Df, If = fresh.search(xq, k)
+    assert np.array_equal(I, If) and np.array_equal(D, Df)
+
+
+def test_add_then_search_loop_at_10m_stays_list_major_and_fast(res):
+    """alternate add(1000) / search(4096) 50 times on an IVFFlat index of 10M rows.  Before round 5 every add
+    invalidated the fp16 shadow and the next list-major search rebuilt ALL of it (an O(nb) pass, ~10 ms at this size); now the
+    add patches the blocks it touched.  Asserted: list-major every time, the last results equal those of the query-major
+    scan, and the searches behind an add cost what a search without an add costs (within 25 %, medians)."""
+    import time
+    import torch
+    from faiss_amd.datasets import synthetic_dataset as sd, synthetic_more_device
+    d, nlist, nq, k = 128, 4096, 4096, 100
+    xt, xb, xq, dmap = sd(d, 100000, 1000000, nq, seed=1338, return_map=True)
+    dev = torch.device("cuda", 0)
+    idx = faiss_amd.GpuIndexIVFFlat(res, d, nlist, METRIC_L2)
+    idx.train(xt)
+    idx.add(xb)
+    for c in range(1, 10):
+        x = synthetic_more_device(dmap, 1000000, 1338 + c, dev)
+        idx.add_ptr(1000000, x.data_ptr())
+        del x
+    idx.nprobe = 32
+    extra = synthetic_more_device(dmap, 50000, 4242, dev)
+    xq_dev = torch.from_numpy(xq).to(dev)
+    Dd = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    Id = torch.empty((nq, k), dtype=torch.int64, device=dev)
+
+    def search():
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        idx.search_ptr(nq, xq_dev.data_ptr(), k, Dd.data_ptr(), Id.data_ptr())
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    search()
+    steady = float(np.median([search() for _ in range(7)]))
+    assert idx.scan_info()[1] == 2
+    after_add = []
+    for i in range(50):
+        idx.add_ptr(1000, extra.data_ptr() + i * 1000 * d * 4)
+        after_add.append(search())
+        assert idx.scan_info()[1] == 2 and idx.last_scan_arith() == 0, "add #%d sent the search to another scan" % i
+    med = float(np.median(after_add))
+    print("search of 4096 queries at nb = 10M: %.3f ms steady, %.3f ms behind an add of 1000 rows" % (steady * 1e3, med * 1e3))
+    assert med <= 1.25 * steady, (med, steady)
+    D, I = Dd.cpu().numpy(), Id.cpu().numpy()
+    idx.set_scan_mode(1)
+    idx.search_ptr(nq, xq_dev.data_ptr(), k, Dd.data_ptr(), Id.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(I, Id.cpu().numpy()) and np.array_equal(D, Dd.cpu().numpy())
