@@ -952,6 +952,11 @@ int faiss_amd_GpuIndexIVF_set_lmf_sampling(FaissAmdIndex* index, int sample_shif
     as<GpuIndexIVF>(index, "GpuIndexIVF")->lmf_sample_shift = sample_shift;
     FA_CATCH
 }
+int faiss_amd_GpuIndexIVFPQ_set_lmf_two_copies(FaissAmdIndex* index, int on) {
+    FA_TRY
+    as<GpuIndexIVFPQ>(index, "GpuIndexIVFPQ")->set_lmf_two_copies(on != 0);
+    FA_CATCH
+}
 int faiss_amd_GpuIndexIVF_test_filter_dump(const FaissAmdIndex* index, int64_t n, const float* x, int nprobe, int64_t k, int64_t stride,
                                            uint64_t* keys_out, float* band_out) {
     FA_TRY

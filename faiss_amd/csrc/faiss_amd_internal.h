@@ -29,6 +29,9 @@ int faiss_amd_GpuIndexIVF_set_lmf_tuning(FaissAmdIndex* index, int rows_per_item
 /* Sweep 1 of the filter path on a sample of the rows: the first rows_per_item >> sample_shift rows of every work item
  * (1 ... 4), 0 = the built-in rule (a quarter for lists of >= 1024 rows on average), -1 = every row.  Results never change. */
 int faiss_amd_GpuIndexIVF_set_lmf_sampling(FaissAmdIndex* index, int sample_shift);
+/* A/B knob of the IVFPQ sweeps at PQ64 over d = 128: the fp16 codebook twice in LDS with different code -> bank maps and a copy
+ * choice stored with the sweeps' copy of the codes (on, the default) against round 4's one-copy sweeps.  Results never change. */
+int faiss_amd_GpuIndexIVFPQ_set_lmf_two_copies(FaissAmdIndex* index, int on);
 /* Test hook of the f16 filter (no reference counterpart): for n host queries, the ESTIMATED distance of every row they
  * probe as a key (ordkey(estimate) << 32 | scan position) at keys_out[q * stride + scan position] (slots nobody owns
  * hold ~0), and band_out[q] = the error band the filter grants query q (|estimate - exact| <= band is what makes the

@@ -2787,7 +2787,8 @@ void GpuIndexIVF::search_listmajor_filter_chunk_(int ni, int q0, const float* xq
     // (IVFFlat: rerank 0.135 -> 0.19 ms for 0.105 ms of selection launch at nb = 1M; IVFPQ keeps the separate launch: its rerank
     // workgroups -- two per CU, the 64 KB table -- serialise the tail: 0.25 -> 0.52 ms).  The tightening launch leaves a query
     // with more than kLmfFusedSelectN candidates (that many rows inside the band of its k-th best) to the redo path.
-    const bool fused_select = P.kind == 0 && k <= kLmfFusedSelectK;
+    static const char* pqfs = experiment_env("FAISS_AMD_LMF_PQ_FUSED_SELECT"); // timing experiment
+    const bool fused_select = (P.kind == 0 || (pqfs && atoi(pqfs) == 1)) && k <= kLmfFusedSelectK;
     {
         // clamp of overflowed segments + the smallest superset the band allows (launch_ivf_lmf_tighten)
         SpanGuard sg(&R, "ivf_lmf_tighten");
@@ -3499,17 +3500,27 @@ bool GpuIndexIVFPQ::lmf_capable_() const {
 }
 // fp16 codebook + the norm bounds of the filter's error band: upper bound of |r^|^2 (sum over the sub-quantizers of their
 // largest squared entry norm), max |centroid|^2.  Rebuilt when a quantizer changed.
+bool GpuIndexIVFPQ::lmf_two_copies_() const {
+    return lmf_two_copies && ivf_lmf_choice_shape(d, M);
+}
 void GpuIndexIVFPQ::lmf_shadow_room_() const {
     int bpl = 0, piece = 0;
     ivf_lmf_code_shadow_shape(d, M, &bpl, &piece);
-    const size_t blk = (size_t)64 * ((bpl + piece - 1) / piece) * piece;
+    const size_t blk = lmf_two_copies_() ? (size_t)64 * 40 : (size_t)64 * ((bpl + piece - 1) / piece) * piece;
     const size_t need = ((size_t)arena_cap_rows_ / 32 + 4) * blk;
     if (need > arena_cs_.cap) arena_cs_.ensure(need, shadow_dirty_ ? 0 : arena_cs_.cap, res_->stream);
 }
+void GpuIndexIVFPQ::lmf_write_copy_(const uint32_t* d_first_row) const {
+    if (lmf_two_copies_())
+        launch_ivf_lmf_code_choice(arena_.as<uint8_t>(), nlist, d_list_len_.as<uint32_t>(), d_list_start_.as<int64_t>(),
+                                   arena_cs_.as<uint8_t>(), d_first_row, res_->stream);
+    else
+        launch_ivf_lmf_code_shadow(arena_.as<uint8_t>(), d, M, nlist, d_list_len_.as<uint32_t>(), d_list_start_.as<int64_t>(),
+                                   arena_cs_.as<uint8_t>(), d_first_row, res_->stream);
+}
 void GpuIndexIVFPQ::lmf_patch_(const uint32_t* d_first_row) {
     lmf_shadow_room_();
-    launch_ivf_lmf_code_shadow(arena_.as<uint8_t>(), d, M, nlist, d_list_len_.as<uint32_t>(), d_list_start_.as<int64_t>(),
-                               arena_cs_.as<uint8_t>(), d_first_row, res_->stream);
+    lmf_write_copy_(d_first_row);
 }
 bool GpuIndexIVFPQ::lmf_prepare_(IvfLmParams& p) const {
     if (lmf_quant_dirty_) {
@@ -3559,14 +3570,14 @@ bool GpuIndexIVFPQ::lmf_prepare_(IvfLmParams& p) const {
     if (shadow_dirty_) {
         // operand-major copy of the codes (kernels.h IvfLmParams::arena_cs): built as a whole at the first list-major search
         // that finds none (add() keeps a live one up to date, lmf_patch_)
-        launch_ivf_lmf_code_shadow(arena_.as<uint8_t>(), d, M, nlist, d_list_len_.as<uint32_t>(), d_list_start_.as<int64_t>(),
-                                   arena_cs_.as<uint8_t>(), nullptr, res_->stream);
+        lmf_write_copy_(nullptr);
         res_->sync();
         shadow_dirty_ = false;
     }
     p.arena_cs = arena_cs_.as<uint8_t>();
     p.cs_bpl = bpl;
     p.cs_piece = piece;
+    p.cs_choice = lmf_two_copies_() ? 1 : 0;
     p.filter = 1;
     p.pq_t = pq_t_.as<float>();
     p.pq16 = pq16_.p;

@@ -591,6 +591,23 @@ class GpuIndexIVFPQ : public GpuIndexIVF {
     size_t lmf_shadow_bytes_() const override { return arena_cs_.cap + pq16_.cap; }
     void lmf_patch_(const uint32_t* d_first_row) override;
     void lmf_shadow_room_() const; // arena_cs_ holds the blocks of arena_cap_rows_ rows (contents kept)
+    void lmf_write_copy_(const uint32_t* d_first_row) const;
+    bool lmf_two_copies_() const;
+
+   public:
+    // PQ64 over d = 128: the sweeps' codebook twice in LDS with different code -> bank maps, copy chosen per (row, sub-quantizer)
+    // when the copy of the codes is written (ivf_lm_filter.hip lmf_code_choice_kernel).  false: round 4's one-copy sweeps.
+    // Changing it drops the copy of the codes (rebuilt by the next list-major search).
+    bool lmf_two_copies = false; // measured in round 5 and not adopted: fewer LDS conflicts, more VALU, slower
+    void set_lmf_two_copies(bool on) {
+        std::lock_guard<std::mutex> g(mu_);
+        if (on != lmf_two_copies) {
+            lmf_two_copies = on;
+            (void)lmf_release_();
+        }
+    }
+
+   protected:
     size_t lmf_release_() override {
         const size_t b = arena_cs_.cap;
         arena_cs_.release();

@@ -204,6 +204,104 @@ void launch_ivf_lmf_code_shadow(const uint8_t* arena_codes, int d, int M, int nl
     HIP_CHECK(hipGetLastError());
 }
 
+// ------------------------------------------------------------------ IVFPQ, PQ64 over d = 128: the codes with a COPY CHOICE
+// The sweeps of this shape are bound by the LDS: every lane gathers 32 codebook entries of 4 bytes per 32-row block, and the
+// 32 lanes of an access group ask one sub-quantizer's 1 KB table for 32 entries by 32 unrelated code bytes -- 32 balls into
+// 32 banks, the fullest bank holds 3.2 on average, so a gather costs three LDS cycles where a conflict-free one costs one
+// (PMC round 4: LDS instructions active 94 % of the busy cycles, 60 % of the LDS cycles conflict replays).  No layout of ONE
+// table changes that.  TWO copies of it with different code -> bank maps do: copy 0 keeps entry c at slot c (bank c mod 32),
+// copy 1 at slot rotr8(c, 3) (bank (c >> 3) mod 32), and for every (32-row block, sub-quantizer) the rows are dealt between
+// the copies so that the fullest bank holds as little as possible (greedy: every row takes the less loaded of its two banks;
+// 2.1 on average for unrelated codes) -- decided ONCE, when this copy of the codes is written, and stored with them: the sweeps
+// read a 9-bit field (copy << 8 | slot) per gather instead of a code byte.  Both copies of all 64 tables are 128 KB of the
+// 160 KB of LDS: [m][copy][256] entries of two halfs.
+// Layout of a 32-row block (2560 bytes): per lane (h, j) 40 bytes = 8 k-steps x 5 bytes, stored as three pieces
+// [64 lanes][16 B], [64 lanes][16 B], [64 lanes][8 B]; the 40 bits of k-step s (little endian) hold the fields of the gathers
+// u = 0 .. 3 (sub-quantizer 8 s + 4 h + u of row j) at bits 9 u .. 9 u + 8.
+constexpr int kLmfChoiceBlockBytes = 64 * 40;
+__host__ __device__ static inline unsigned lmf_rotr8(unsigned c, int n) {
+    return ((c >> n) | (c << (8 - n))) & 255u;
+}
+bool ivf_lmf_choice_shape(int d, int M) {
+    return d == 128 && M == 64;
+}
+// one 64-thread workgroup per 32-row block: thread m deals the block's rows between the two copies of table m (phase 1),
+// then thread (h, j) packs its lane's 32 fields (phase 2)
+__global__ void __launch_bounds__(64) lmf_code_choice_kernel(const uint8_t* __restrict__ arena_codes, const uint32_t* list_len,
+                                                             const int64_t* list_start, uint8_t* __restrict__ arena_cs,
+                                                             const uint32_t* __restrict__ first_row) {
+    constexpr int M = 64;
+    __shared__ uint32_t copy_of[M]; // bit j: row j of the block reads sub-quantizer m from copy 1
+    const int list = blockIdx.x;
+    const uint32_t len = list_len[list];
+    const int64_t start = list_start[list];
+    const uint32_t fr = first_row ? first_row[list] : 0u;
+    if (fr == 0xffffffffu) return;
+    const int nblk = (int)((len + 31) / 32);
+    const int tid = threadIdx.x;
+    for (int b = (int)(fr >> 5) + (int)blockIdx.y; b < nblk; b += (int)gridDim.y) {
+        const int64_t row0 = start + (int64_t)b * 32;
+        const int nrow = min(32, (int)len - b * 32);
+        {
+            // phase 1: bank loads as 32 nibbles; rows in order, each to the less loaded of its two banks (ties: copy 0)
+            const int m = tid;
+            unsigned long long lo = 0ull, hi = 0ull; // nibble b of (hi:lo) = entries bank b holds so far (<= 15 by the cap below)
+            uint32_t bits = 0u;
+            for (int j = 0; j < nrow; ++j) {
+                const unsigned c = arena_codes[pq_code_offset(M, row0 + j, m)];
+                const unsigned b0 = c & 31u, b1 = (c >> 3) & 31u;
+                const unsigned n0 = (unsigned)(((b0 < 16 ? lo : hi) >> (4 * (b0 & 15u))) & 15ull);
+                const unsigned n1 = (unsigned)(((b1 < 16 ? lo : hi) >> (4 * (b1 & 15u))) & 15ull);
+                const bool one = n1 < n0;
+                const unsigned bk = one ? b1 : b0;
+                if ((one ? n1 : n0) < 15u) {
+                    if (bk < 16) lo += 1ull << (4 * bk);
+                    else hi += 1ull << (4 * (bk & 15u));
+                }
+                bits |= one ? 1u << j : 0u;
+            }
+            copy_of[m] = bits;
+        }
+        __syncthreads();
+        {
+            const int h = tid >> 5, j = tid & 31;
+            uint32_t out[10];
+#pragma unroll
+            for (int i = 0; i < 10; ++i) out[i] = 0u;
+            if (j < nrow) {
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    unsigned long long v = 0ull;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int m = 8 * s + 4 * h + u;
+                        const unsigned c = arena_codes[pq_code_offset(M, row0 + j, m)];
+                        const unsigned one = (copy_of[m] >> j) & 1u;
+                        const unsigned field = (one << 8) | (one ? lmf_rotr8(c, 3) : c);
+                        v |= (unsigned long long)field << (9 * u);
+                    }
+                    // bytes 5 s .. 5 s + 4 of the lane's 40-byte string
+                    const int o = 5 * s, i = o >> 2, r = o & 3;
+                    out[i] |= (uint32_t)(v << (8 * r));
+                    out[i + 1] |= (uint32_t)((r ? v >> (32 - 8 * r) : v >> 32));
+                }
+            }
+            uint8_t* blk = arena_cs + ((start >> 5) + b) * (int64_t)kLmfChoiceBlockBytes;
+            *(uint4*)(blk + tid * 16) = uint4{out[0], out[1], out[2], out[3]};
+            *(uint4*)(blk + 1024 + tid * 16) = uint4{out[4], out[5], out[6], out[7]};
+            *(uint2*)(blk + 2048 + tid * 8) = uint2{out[8], out[9]};
+        }
+        __syncthreads();
+    }
+}
+void launch_ivf_lmf_code_choice(const uint8_t* arena_codes, int nlist, const uint32_t* list_len, const int64_t* list_start,
+                                uint8_t* arena_cs, const uint32_t* first_row, hipStream_t stream) {
+    if (nlist == 0) return;
+    hipLaunchKernelGGL(lmf_code_choice_kernel, dim3((unsigned)nlist, first_row ? 4 : 32), dim3(64), 0, stream, arena_codes, list_len,
+                       list_start, arena_cs, first_row);
+    HIP_CHECK(hipGetLastError());
+}
+
 // ------------------------------------------------------------------ scores, shared by the two sweep kernels
 // The epilogue of a 32-row x 32-query block works on SCORES, larger = better, whose order is the order of the estimates:
 //   L2   score = <q', y'> - |y'|^2 / 2 - |q'|^2 / 2,   estimate = -2 score          IP   score = <q', y'> [+ coarse term] = estimate
@@ -296,24 +394,26 @@ __device__ __forceinline__ void lmf_scores(f32x16& a, const f32x4 (&rn)[4], bool
 // one RECORD into a wave-private LDS staging area (slot = its rank among the hit lanes: one ballot + mbcnt, four 16-byte
 // stores), and when the area is full a DENSE pass looks at the records with all 64 lanes -- 16 lanes per record, one
 // score each, four records per step -- and appends the rows that pass to the parked candidates.
-constexpr int LS_NST = 64;                       // records per wave (a pair may add 64)
-constexpr int LS_PLANE = LS_NST * 16 + 32;       // bytes of one score plane [record][4 floats] (+ 8 banks: conflict-free reads)
-constexpr int LS_WAVE = 4 * LS_PLANE + LS_NST * 16; // + tq, pos, qpr, xh per record
+template <int NST> // records per wave: 64 (a pair may add 64 at once) or 32 (pairs are staged in two halves)
 struct LmfStage {
+    static constexpr int PLANE = NST * 16 + 32;        // bytes of one score plane [record][4 floats] (+ 8 banks: conflict-free reads)
+    static constexpr int BYTES = 4 * PLANE + NST * 16; // + tq, pos, qpr, xh per record
     char* base;  // this wave's slice
     int cnt;     // (wave-uniform) records waiting
-    __device__ __forceinline__ float* plane(int pl) const { return (float*)(base + pl * LS_PLANE); }
-    __device__ __forceinline__ float* tq() const { return (float*)(base + 4 * LS_PLANE); }
-    __device__ __forceinline__ uint32_t* pos() const { return (uint32_t*)(base + 4 * LS_PLANE + LS_NST * 4); }
-    __device__ __forceinline__ uint32_t* qpr() const { return (uint32_t*)(base + 4 * LS_PLANE + LS_NST * 8); }
-    __device__ __forceinline__ float* xh() const { return (float*)(base + 4 * LS_PLANE + LS_NST * 12); }
+    __device__ __forceinline__ float* plane(int pl) const { return (float*)(base + pl * PLANE); }
+    __device__ __forceinline__ float* tq() const { return (float*)(base + 4 * PLANE); }
+    __device__ __forceinline__ uint32_t* pos() const { return (uint32_t*)(base + 4 * PLANE + NST * 4); }
+    __device__ __forceinline__ uint32_t* qpr() const { return (uint32_t*)(base + 4 * PLANE + NST * 8); }
+    __device__ __forceinline__ float* xh() const { return (float*)(base + 4 * PLANE + NST * 12); }
 };
+constexpr int LS_WAVE = LmfStage<64>::BYTES;
 __device__ __forceinline__ int lmf_rank_in(unsigned long long bal) { // number of set bits below this lane
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
 }
 // lanes with `hit` write their record (room for all of them was made by the caller)
-__device__ __forceinline__ void lmf_stage_push(LmfStage& st, bool hit, unsigned long long bal, const f32x16& a, float tq, uint32_t pos0,
-                                               uint32_t qpr, float xh) {
+template <int NST>
+__device__ __forceinline__ void lmf_stage_push(LmfStage<NST>& st, bool hit, unsigned long long bal, const f32x16& a, float tq,
+                                               uint32_t pos0, uint32_t qpr, float xh) {
     const int idx = st.cnt + lmf_rank_in(bal);
     if (hit) {
 #pragma unroll
@@ -325,9 +425,11 @@ __device__ __forceinline__ void lmf_stage_push(LmfStage& st, bool hit, unsigned 
     }
     st.cnt += __popcll(bal);
 }
-// dense pass over the staged records: parked candidates go to pk_keys / pk_q (wcnt of them so far, room PARK; `flush` empties them)
-template <int METRIC, int PARK, typename Flush>
-__device__ __forceinline__ void lmf_stage_expand(LmfStage& st, int lane, u64* pk_keys, uint32_t* pk_q, int& wcnt, Flush&& flush) {
+// dense pass over the staged records: parked candidates go to pk_keys / pk_q (wcnt of them so far, room PARK >= 64; `flush`
+// empties them)
+template <int METRIC, int PARK, int NST, typename Flush>
+__device__ __forceinline__ void lmf_stage_expand(LmfStage<NST>& st, int lane, u64* pk_keys, uint32_t* pk_q, int& wcnt, Flush&& flush) {
+    static_assert(PARK >= 64, "a step of the dense pass parks up to 64 candidates");
     const int r = lane & 15, sub = lane >> 4;
     for (int b0 = 0; b0 < st.cnt; b0 += 4) {
         const int rec = b0 + sub;
@@ -349,6 +451,26 @@ __device__ __forceinline__ void lmf_stage_expand(LmfStage& st, int lane, u64* pk
         wcnt += n;
     }
     st.cnt = 0;
+}
+// the lanes of a (row block, query block) pair whose best score reaches their query's threshold stage their 16 scores
+template <int NST, typename Expand>
+__device__ __forceinline__ void lmf_collect_pair(LmfStage<NST>& st, int lane, bool hit, const f32x16& a, float tq, uint32_t pos0,
+                                                 uint32_t qpr, float xh, Expand&& expand) {
+    if (NST >= 64) {
+        const unsigned long long bal = __ballot(hit);
+        if (!bal) return; // (wave-uniform)
+        if (st.cnt + __popcll(bal) > NST) expand();
+        lmf_stage_push(st, hit, bal, a, tq, pos0, qpr, xh);
+    } else { // (a half of the lanes at a time: <= 32 records)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const bool hh = hit && (lane >> 5) == half;
+            const unsigned long long bal = __ballot(hh);
+            if (!bal) continue;
+            if (st.cnt + __popcll(bal) > NST) expand();
+            lmf_stage_push(st, hh, bal, a, tq, pos0, qpr, xh);
+        }
+    }
 }
 
 // Work items of a sweep, drawn per XCD.  The plan emits the items in list order -- the query groups of one (list, row
@@ -408,7 +530,7 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
     __shared__ float rn_lds_all[4][64];
     float* rn_lds = rn_lds_all[wave];
     int wcnt = 0; // (wave-uniform) parked candidates
-    LmfStage st{smem + 4 * LF_PARK * 12 + wave * LS_WAVE, 0};
+    LmfStage<64> st{smem + 4 * LF_PARK * 12 + wave * LS_WAVE, 0};
     auto flush = [&]() __attribute__((always_inline)) {
         for (int e = lane; e < wcnt; e += 64) {
             const u64 key = pk_keys[e];
@@ -428,7 +550,7 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
         wcnt = 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // no store in flight on any path back into the block loop
     };
-    auto expand = [&]() __attribute__((always_inline)) { lmf_stage_expand<METRIC, LF_PARK>(st, lane, pk_keys, pk_q, wcnt, flush); };
+    auto expand = [&]() __attribute__((always_inline)) { lmf_stage_expand<METRIC, LF_PARK, 64>(st, lane, pk_keys, pk_q, wcnt, flush); };
 
     const uint32_t it0 = p.item_bounds[1], it1 = p.item_bounds[2];
     LmfDraw draw(p.item_bounds, MODE == MODE_MIN ? 0 : 1, it0, it1);
@@ -599,11 +721,8 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
                     for (int b = 0; b < NQB; ++b) {
                         // ---- lanes whose best score of query block b reaches their query's threshold stage their 16 scores
                         lmf_scores<METRIC, SEL>(acc[b], rn, tail, row_b, r1, mw);
-                        const bool hit = lmf_lane_max(acc[b]) >= L[b].tq;
-                        const unsigned long long bal = __ballot(hit);
-                        if (!bal) continue; // (wave-uniform)
-                        if (st.cnt + __popcll(bal) > LS_NST) expand();
-                        lmf_stage_push(st, hit, bal, acc[b], L[b].tq, L[b].base_pos + (uint32_t)row_b, L[b].qpr, L[b].xh);
+                        lmf_collect_pair(st, lane, lmf_lane_max(acc[b]) >= L[b].tq, acc[b], L[b].tq, L[b].base_pos + (uint32_t)row_b,
+                                         L[b].qpr, L[b].xh, expand);
                     }
                 }
             }
@@ -626,29 +745,34 @@ constexpr int LP_THREADS = 512;
 constexpr int LP_BR = 32;    // rows per block
 constexpr int LP_PARK = 256; // parked candidates per wave
 constexpr int LP_AHEAD = 3;  // k-steps the codebook gathers run ahead of the MFMAs (ring of 4 operands)
+// TWOC (the two-copy codebook of PQ64 over d = 128, lmf_code_choice_kernel): 128 KB of tables leave 30 KB for the eight
+// wavefronts' parked candidates (64 each) and staged records (32 each: pairs are staged half by half)
+constexpr int LP_PARK2 = 64, LP_NST2 = 32;
 struct LpLayout {
     int cb_bytes, off_park, off_stage, total;
 };
-__host__ __device__ static inline LpLayout lp_layout(int d, int M) {
+__host__ __device__ static inline LpLayout lp_layout(int d, int M, bool twoc = false) {
     LpLayout L;
-    L.cb_bytes = d * 256 * 2;
+    L.cb_bytes = d * 256 * 2 * (twoc ? 2 : 1);
     L.off_park = (L.cb_bytes + 15) & ~15;
-    L.off_stage = L.off_park + 8 * LP_PARK * (8 + 4);
-    L.total = L.off_stage + 8 * (4 * (64 * 16 + 32) + 64 * 16); // (8 x LS_WAVE: the staged records of sweep 2)
+    L.off_stage = L.off_park + 8 * (twoc ? LP_PARK2 : LP_PARK) * (8 + 4);
+    L.total = L.off_stage + 8 * (twoc ? LmfStage<LP_NST2>::BYTES : LmfStage<64>::BYTES); // (the staged records of sweep 2)
     return L;
 }
-// code dwords a lane holds per 32-row block (IvfLmParams::cs_bpl / 4, at most): 8 k-steps x (8 / dsub) codes
-template <int DS>
+// code dwords a lane holds per 32-row block (IvfLmParams::cs_bpl / 4, at most): 8 k-steps x (8 / dsub) codes; TWOC: 8 x 5 bytes
+template <int DS, bool TWOC>
 struct LpCodes {
-    static constexpr int ND = DS == 1 ? 16 : DS == 2 ? 8 : DS == 4 ? 4 : 2;
+    static constexpr int ND = TWOC ? 10 : DS == 1 ? 16 : DS == 2 ? 8 : DS == 4 ? 4 : 2;
 };
 
 // FULLK: d == 128 (8 k-steps, no runtime bound in the operand pipeline) and, for DS == 2, M == 64 (two 16-byte code pieces
 // per lane and block): the block loop then holds no conditional code around its loads and LDS reads -- with runtime bounds
 // hipcc closed every k-step with lgkmcnt(0) / vmcnt(0) (the gathers of step s + 2 were waited for before the MFMAs of step
 // s, the code prefetch before the next instruction): 8400 cycles per 24-MFMA block, every unit idle (profiles/r04_g_pmc_*).
-template <int METRIC, int MODE, int NQB, int DS, bool SEL, bool FULLK>
+template <int METRIC, int MODE, int NQB, int DS, bool SEL, bool FULLK, bool TWOC>
 __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p) {
+    static_assert(!TWOC || (FULLK && DS == 2), "the two-copy codebook serves PQ64 over d = 128");
+    constexpr int PARK = TWOC ? LP_PARK2 : LP_PARK, NST = TWOC ? LP_NST2 : 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -659,19 +783,38 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
     const int M = p.M, dsub = p.dsub;
     const int nks = FULLK ? 8 : (p.d >> 4);
     const int gsh = __builtin_ctz((unsigned)p.gran_blocks); // blocks per granule: a power of two
-    const LpLayout LY = lp_layout(p.d, M);
+    const LpLayout LY = lp_layout(p.d, M, TWOC);
     const _Float16* cb = (const _Float16*)smem;
-    {
+    if (TWOC) {
+        // [m][copy][256] entries of two halfs: copy 0 holds entry c at slot c, copy 1 at slot rotr8(c, 3)
+        const uint32_t* src = (const uint32_t*)p.pq16;
+        uint32_t* dst = (uint32_t*)smem;
+        for (int e = tid; e < 64 * 256; e += LP_THREADS) {
+            const uint32_t v = src[e];
+            const int m = e >> 8;
+            const unsigned c = (unsigned)e & 255u;
+            dst[(m << 9) + (int)c] = v;
+            dst[(m << 9) + 256 + (int)lmf_rotr8(c, 3)] = v;
+        }
+    } else {
         const uint4* src = (const uint4*)p.pq16;
         uint4* dst = (uint4*)smem;
         for (int i = tid; i < p.d * 32; i += LP_THREADS) dst[i] = src[i];
     }
-    u64* pk_keys = (u64*)(smem + LY.off_park) + wave * LP_PARK;
-    uint32_t* pk_q = (uint32_t*)(smem + LY.off_park + 8 * LP_PARK * 8) + wave * LP_PARK;
+    // (the upper 32 tables through a base of their own: 64 KB above the first, beyond the reach of a 16-bit offset.  Typed
+    // LDS pointers: behind the opaque copy a generic pointer lost its address space and every gather became a flat load
+    // with 64-bit address arithmetic -- + 36 % VALU instructions, profiles/r5f_pmc_two_copies_*)
+    typedef const __attribute__((address_space(3))) _Float16* lds_half;
+    typedef const __attribute__((address_space(3))) half2v* lds_half2;
+    const lds_half cb3 = (lds_half)cb;
+    lds_half cb_hi = cb3 + 32 * 512 * 2;
+    asm volatile("" : "+v"(cb_hi));
+    u64* pk_keys = (u64*)(smem + LY.off_park) + wave * PARK;
+    uint32_t* pk_q = (uint32_t*)(smem + LY.off_park + 8 * PARK * 8) + wave * PARK;
     __shared__ float rn_lds_all[8][64]; // |r^|^2 of the rows of the block in hand, per wave (see the flat kernel)
     float* rn_lds = rn_lds_all[wave];
     int wcnt = 0;
-    LmfStage st{smem + LY.off_stage + wave * LS_WAVE, 0};
+    LmfStage<NST> st{smem + LY.off_stage + wave * LmfStage<NST>::BYTES, 0};
     auto flush = [&]() __attribute__((always_inline)) {
         for (int e = lane; e < wcnt; e += 64) {
             const u64 key = pk_keys[e];
@@ -689,14 +832,14 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
         wcnt = 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
-    auto expand = [&]() __attribute__((always_inline)) { lmf_stage_expand<METRIC, LP_PARK>(st, lane, pk_keys, pk_q, wcnt, flush); };
+    auto expand = [&]() __attribute__((always_inline)) { lmf_stage_expand<METRIC, PARK, NST>(st, lane, pk_keys, pk_q, wcnt, flush); };
     __syncthreads();
 
     // operand-major code shadow (IvfLmParams::arena_cs): a block = npiece pieces of 64 lanes x cs_piece bytes
-    constexpr int ND = LpCodes<DS>::ND;
+    constexpr int ND = LpCodes<DS, TWOC>::ND;
     const bool x4 = p.cs_piece == 16;
     const int npiece = (p.cs_bpl + p.cs_piece - 1) / p.cs_piece;
-    const int64_t blk_bytes = (int64_t)64 * npiece * p.cs_piece;
+    const int64_t blk_bytes = TWOC ? (int64_t)kLmfChoiceBlockBytes : (int64_t)64 * npiece * p.cs_piece;
     const uint32_t it0 = p.item_bounds[1], it1 = p.item_bounds[2];
     LmfDraw draw(p.item_bounds, MODE == MODE_MIN ? 0 : 1, it0, it1);
     for (;;) {
@@ -725,7 +868,13 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
         for (int i = 0; i < ND; ++i) cw[i] = cn[i] = cn2[i] = 0u;
         auto fetch = [&](int t, unsigned (&dst)[ND]) __attribute__((always_inline)) {
             const uint8_t* bp = p.arena_cs + ((start + t) >> 5) * blk_bytes;
-            if (FULLK && DS == 2) { // two 16-byte pieces, unconditionally
+            if (TWOC) { // 40 bytes per lane: two 16-byte pieces and one of 8
+                const uint4 v0 = *(const uint4*)(bp + (int64_t)lane * 16), v1 = *(const uint4*)(bp + 1024 + (int64_t)lane * 16);
+                const uint2 v2 = *(const uint2*)(bp + 2048 + (int64_t)lane * 8);
+                dst[0] = v0.x, dst[1] = v0.y, dst[2] = v0.z, dst[3] = v0.w;
+                dst[4] = v1.x, dst[5] = v1.y, dst[6] = v1.z, dst[7] = v1.w;
+                dst[8 % ND] = v2.x, dst[9 % ND] = v2.y;
+            } else if (FULLK && DS == 2) { // two 16-byte pieces, unconditionally
                 const uint4 v0 = *(const uint4*)(bp + (int64_t)lane * 16), v1 = *(const uint4*)(bp + ((int64_t)64 + lane) * 16);
                 dst[0] = v0.x, dst[1] = v0.y, dst[2] = v0.z, dst[3] = v0.w;
                 dst[4] = v1.x, dst[5] = v1.y, dst[6] = v1.z, dst[7] = v1.w;
@@ -807,6 +956,22 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
                 const half4v lo = *(const half4v*)(cb + ((m0 << 8) + (int)(c2 & 255u)) * 4);
                 const half4v hi = *(const half4v*)(cb + (((m0 + 1) << 8) + (int)(c2 >> 8)) * 4);
                 a = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            } else if (TWOC) {
+                // the 40 bits of k-step s_ (bytes 5 s_ .. 5 s_ + 4 of the lane's string): four 9-bit fields copy << 8 | slot
+                // (32-bit pieces by hand: a 64-bit shift of two array elements sent the array to scratch memory)
+                const int o = 5 * s_, i = o >> 2, r = o & 3, i4 = (o + 4) >> 2, r4 = (o + 4) & 3;
+                const unsigned lo32 = r ? __builtin_amdgcn_alignbyte(cw[(i + 1) % ND], cw[i % ND], (unsigned)r) : cw[i % ND];
+                const unsigned hi4 = (cw[i4 % ND] >> (8 * r4)) & 15u;
+                const unsigned fields[4] = {lo32 & 511u, (lo32 >> 9) & 511u, (lo32 >> 18) & 511u, (lo32 >> 27) | (hi4 << 5)};
+                const int m0 = kb >> 1; // sub-quantizers m0 .. m0 + 3: all below 32 or all from 32 on
+                const lds_half bm = m0 < 32 ? cb3 : cb_hi;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned field = fields[u];
+                    const half2v e2 = *(lds_half2)(bm + ((((m0 + u) & 31) << 9) + (int)field) * 2);
+                    a[2 * u] = e2[0];
+                    a[2 * u + 1] = e2[1];
+                }
             } else if (DS == 2) {
                 const unsigned c4 = cw[s_];
                 const int m0 = kb >> 1;
@@ -908,11 +1073,8 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
                 for (int b = 0; b < NB; ++b) {
                     // ---- lanes whose best score of query block b reaches their query's threshold stage their 16 scores
                     lmf_scores<METRIC, SEL>(acc[b], rn, tail, row_b, r1, mw);
-                    const bool hit = lmf_lane_max(acc[b]) >= L[b].tq;
-                    const unsigned long long bal = __ballot(hit);
-                    if (!bal) continue; // (wave-uniform)
-                    if (st.cnt + __popcll(bal) > LS_NST) expand();
-                    lmf_stage_push(st, hit, bal, acc[b], L[b].tq, L[b].base_pos + (uint32_t)row_b, L[b].qpr, L[b].xh);
+                    lmf_collect_pair(st, lane, lmf_lane_max(acc[b]) >= L[b].tq, acc[b], L[b].tq, L[b].base_pos + (uint32_t)row_b,
+                                     L[b].qpr, L[b].xh, expand);
                 }
             }
 #pragma unroll
@@ -954,20 +1116,24 @@ static void lmf_flat_launch(const IvfLmParams& p, int grid_blocks, hipStream_t s
 template <int METRIC, int MODE, bool SEL>
 static void lmf_pq_launch(const IvfLmParams& p, int grid_blocks, hipStream_t stream) {
     constexpr int NQB = kLmfQueryBlocks;
-    const int lds = lp_layout(p.d, p.M).total;
+    const bool twoc = p.cs_choice != 0;
+    const int lds = lp_layout(p.d, p.M, twoc).total;
     const int ds = p.dsub >= 8 ? 8 : p.dsub;
-#define FA_LP(DS_, FK_)                                                                                                        \
+#define FA_LP(DS_, FK_, TC_)                                                                                                   \
     do {                                                                                                                       \
-        HIP_CHECK(hipFuncSetAttribute((const void*)ivf_lmf_pq_kernel<METRIC, MODE, NQB, DS_, SEL, FK_>,                        \
+        HIP_CHECK(hipFuncSetAttribute((const void*)ivf_lmf_pq_kernel<METRIC, MODE, NQB, DS_, SEL, FK_, TC_>,                   \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));                                       \
-        hipLaunchKernelGGL((ivf_lmf_pq_kernel<METRIC, MODE, NQB, DS_, SEL, FK_>), dim3((unsigned)grid_blocks), dim3(LP_THREADS), \
-                           lds, stream, p);                                                                                    \
+        hipLaunchKernelGGL((ivf_lmf_pq_kernel<METRIC, MODE, NQB, DS_, SEL, FK_, TC_>), dim3((unsigned)grid_blocks),            \
+                           dim3(LP_THREADS), lds, stream, p);                                                                  \
     } while (0)
-    if (ds == 2 && p.d == 128 && p.M == 64 && p.cs_piece == 16) FA_LP(2, true); // the bench shape: PQ64 over d = 128
-    else if (ds == 1) FA_LP(1, false);
-    else if (ds == 2) FA_LP(2, false);
-    else if (ds == 4) FA_LP(4, false);
-    else FA_LP(8, false);
+    if (twoc) {
+        FA_THROW_IF_NOT(ds == 2 && ivf_lmf_choice_shape(p.d, p.M));
+        FA_LP(2, true, true); // PQ64 over d = 128 with the two-copy codebook
+    } else if (ds == 2 && p.d == 128 && p.M == 64 && p.cs_piece == 16) FA_LP(2, true, false); // the same shape, one copy
+    else if (ds == 1) FA_LP(1, false, false);
+    else if (ds == 2) FA_LP(2, false, false);
+    else if (ds == 4) FA_LP(4, false, false);
+    else FA_LP(8, false, false);
 #undef FA_LP
 }
 template <int METRIC, bool SEL>
@@ -1001,7 +1167,7 @@ void launch_ivf_lmf_sweep(const IvfLmParams& p, int mode, int grid_blocks, hipSt
     } else {
         FA_THROW_IF_NOT(p.pq16 && p.arena_cs && p.cs_bpl > 0 && (p.cs_piece == 4 || p.cs_piece == 16) && p.centroids &&
                         p.ldq % 4 == 0 && p.ldc % 4 == 0);
-        FA_THROW_IF_NOT(lp_layout(p.d, p.M).total <= 160 * 1024 && (p.metric != METRIC_L2 || p.arena_rn));
+        FA_THROW_IF_NOT(lp_layout(p.d, p.M, p.cs_choice != 0).total + 2048 <= 160 * 1024 && (p.metric != METRIC_L2 || p.arena_rn));
     }
     if (p.metric == METRIC_L2) lmf_launch_mode<METRIC_L2>(p, mode, grid_blocks, stream);
     else lmf_launch_mode<METRIC_INNER_PRODUCT>(p, mode, grid_blocks, stream);

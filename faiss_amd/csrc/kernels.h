@@ -497,6 +497,10 @@ struct IvfLmParams {
     // the sweeps load their codes straight into registers, no LDS staging, no un-rotation
     const uint8_t* arena_cs;
     int cs_bpl, cs_piece;
+    // PQ64 over d = 128 only: arena_cs holds 9-bit fields copy << 8 | slot for a codebook kept TWICE in LDS with different
+    // code -> bank maps, the copy of every (row, sub-quantizer) chosen when the copy of the codes was written so that the
+    // gathers of a 32-lane group spread over the banks (ivf_lm_filter.hip, lmf_code_choice_kernel): 40 bytes per lane and block
+    int cs_choice;
     const void* pq16;           // [M][256][dsub] fp16 codebook (kind 1)
     const float* pq_t;          // [256][M][dsub] fp32 codebook, transposed: the order the exact path builds its table in
     const uint32_t* qflags;     // [nq] nonzero: the query leaves the fp16 range / holds NaN -> not filtered (fallback)
@@ -578,6 +582,10 @@ void launch_ivf_lmf_shadow(const float* arena, int64_t ldv, const float* arena_r
                            hipStream_t stream);
 // IVFPQ: operand-major copy of the codes of every list (see IvfLmParams::arena_cs); bytes per lane and block / piece size
 void ivf_lmf_code_shadow_shape(int d, int M, int* bpl, int* piece);
+bool ivf_lmf_choice_shape(int d, int M); // the shape the two-copy codebook serves
+// the copy of the codes in the two-copy format (2560 bytes per 32-row block); first_row as for launch_ivf_lmf_code_shadow
+void launch_ivf_lmf_code_choice(const uint8_t* arena_codes, int nlist, const uint32_t* list_len, const int64_t* list_start,
+                                uint8_t* arena_cs, const uint32_t* first_row, hipStream_t stream);
 void launch_ivf_lmf_code_shadow(const uint8_t* arena_codes, int d, int M, int nlist, const uint32_t* list_len,
                                 const int64_t* list_start, uint8_t* arena_cs, const uint32_t* first_row, hipStream_t stream);
 // kind 0: M unused; kind 1: M = sub-quantizers; kind 2: M = SqCodeType

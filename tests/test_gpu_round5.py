@@ -257,3 +257,31 @@ def test_add_then_search_loop_at_10m_stays_list_major_and_fast(res):
     idx.search_ptr(nq, xq_dev.data_ptr(), k, Dd.data_ptr(), Id.data_ptr())
     torch.cuda.synchronize()
     assert np.array_equal(I, Id.cpu().numpy()) and np.array_equal(D, Dd.cpu().numpy())
+
+
+@pytest.mark.parametrize("metric", [METRIC_L2, METRIC_INNER_PRODUCT])
+def test_two_copy_codebook_of_the_pq_sweeps_keeps_the_bits(res, metric):
+    """The A/B knob of round 5's LDS experiment (PQ64 over d = 128: the sweeps' codebook twice in LDS with different code ->
+    bank maps, the copy of every (row, sub-quantizer) chosen when the operand-major copy of the codes is written): measured
+    slower and off by default, but a supported path -- same bits as the one-copy sweeps and the query-major scan, also
+    through add() (the blocks add() touches are re-dealt) and with a selector."""
+    d, nlist, M, k = 128, 16, 64, 60
+    xt, xb, xq = synthetic_dataset(d, 4000, 50000, 500, seed=77)
+    idx = _make(res, 1, d, nlist, M, metric)
+    idx.train(xt)
+    idx.add(xb[:30000])
+    idx.nprobe = 6
+    idx.set_scan_mode(1)
+    Dr, Ir = idx.search(xq, k)
+    idx.set_scan_mode(2)
+    for two in (True, False, True):
+        idx.set_lmf_two_copies(two)
+        D, I = idx.search(xq, k)
+        assert idx.scan_info()[1] == 2 and np.array_equal(I, Ir) and np.array_equal(D, Dr), "two copies %s" % two
+    idx.add(xb[30000:30007])
+    idx.add(xb[30007:])
+    D, I = idx.search(xq, k)
+    idx.set_scan_mode(1)
+    Dr, Ir = idx.search(xq, k)
+    assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+    idx.set_lmf_two_copies(False)

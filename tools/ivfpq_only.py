@@ -23,6 +23,8 @@ while done < nb:  # BASELINE.json configs[3]: nb = 100M, generated and added chu
     idx.add_ptr(n_c, xbc.data_ptr())
     done += n_c
     del xbc
+if os.environ.get("TWO_COPIES", "1") != "1":
+    idx.set_lmf_two_copies(False)  # A/B: round 4's one-copy sweeps
 print("train+add of %d vectors: %.1fs" % (nb, time.time() - t0), flush=True)
 dev = torch.device("cuda", 0)
 xq_dev = torch.from_numpy(xq).to(dev)

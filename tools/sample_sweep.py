@@ -13,6 +13,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ["FAISS_AMD_EXPERIMENTS"] = "1"
 import torch  # noqa: E402  (before the library: one HIP runtime)
 
 import faiss_amd  # noqa: E402
@@ -66,14 +67,18 @@ def main():
         idx.set_scan_mode(2)
         print("==== %s nb=%d" % (kind, nb), flush=True)
         base = None
-        for shift in shifts:
-            idx.set_lmf_sampling(shift)
-            ms, sp = timed(idx, res, xq_dev, Dd, Id, steps=5)
-            got = (Dd.cpu().numpy().copy(), Id.cpu().numpy().copy())
-            if base is None:
-                base = got
-            same = np.array_equal(base[0], got[0]) and np.array_equal(base[1], got[1])
-            print("sample shift %2d: %8.3f ms redo %5d same %s  %s" % (shift, ms, idx.scan_info()[2], same, sp), flush=True)
+        for two in ((1, 0) if kind == "ivfpq" else (1,)):
+            if kind == "ivfpq":
+                idx.set_lmf_two_copies(bool(two))
+            for shift in shifts:
+                idx.set_lmf_sampling(shift)
+                ms, sp = timed(idx, res, xq_dev, Dd, Id, steps=5)
+                got = (Dd.cpu().numpy().copy(), Id.cpu().numpy().copy())
+                if base is None:
+                    base = got
+                same = np.array_equal(base[0], got[0]) and np.array_equal(base[1], got[1])
+                print("two copies %d sample shift %2d: %8.3f ms redo %5d same %s  %s" % (two, shift, ms, idx.scan_info()[2], same, sp),
+                      flush=True)
         idx.set_lmf_sampling(0)
         del idx
 
