@@ -1701,7 +1701,7 @@ size_t GpuIndexIVF::reclaimMemory() {
     // plan tables, granule minima): all of it is re-grown on demand
     for (DevBuf* b : {&a_xpad_, &a_lab_, &a_dis_, &a_dest_, &a_ids_, &a_hist_, &a_newlen_, &a_jobs_, &lm_prefix_, &lm_p0_,
                       &lm_cnt_, &lm_bucket_, &lm_bstart_, &lm_pairs_, &lm_items_, &lm_bounds_, &lm_thr_, &lm_keys_, &lm_ovf_,
-                      &lm_qn_, &lm_prefixg_, &lm_gmin_, &lm_thrf_, &lm_candpr_, &lm_q16_, &lm_qflags_, &lm_xnb_, &lm_pqgrid_, &lm_pair16_, &lm_pairxh_, &lm_errf_,
+                      &lm_qn_, &lm_prefixg_, &lm_gmin_, &lm_thrf_, &lm_candpr_, &lm_q16_, &lm_qflags_, &lm_xnb_, &lm_pqgrid_, &lm_pair16_, &lm_pairxh_, &lm_errf_, &lm_an_,
                       &part_keys_, &part_cnt_, &keys_}) {
         before += b->cap;
         b->release();
@@ -2358,7 +2358,7 @@ bool GpuIndexIVF::list_major_rule(idx_t n, int nprobe_now, idx_t k, bool has_sel
     if (!(lm_capable_() || lmf_capable_()) || (has_selector && !lmf_capable_()) || k > kMaxSelectionK || nstored_ == 0) return false;
     const int64_t np = std::min<int64_t>(nprobe_now, nlist);
     const double avg_len = (double)nstored_ / (double)nlist;
-    if (fused_kind_() == 2 || (fused_kind_() == 1 && !lmf_capable_())) {
+    if (fused_kind_() != 0 && !lmf_capable_()) {
         // scalar quantizer / IVFPQ shapes the filter does not serve: round 3's f32 list-major scan and its rule (measured at
         // nlist 4096 / nprobe 32 only: IVFPQ break-even near (rows per list) x (queries per list) = 415 x 78): every list
         // has to meet >= 8 of the batch's queries on average, below that the 32-query MFMA blocks run mostly empty
@@ -2386,7 +2386,7 @@ bool GpuIndexIVF::list_major_rule(idx_t n, int nprobe_now, idx_t k, bool has_sel
     const double stream = pairs * avg_len * (double)ref_row_bytes_();
     const double kq = 0.5 + 0.5 * std::min<double>((double)k, 1000.0) / 100.0; // candidates per query grow with k
     double est_qm, est_lm; // ms
-    if (fused_kind_() == 0) {
+    if (fused_kind_() != 1) { // IVFFlat, and the scalar quantizer (the same sweeps over the fp16 copy of its codes)
         est_qm = 0.12 + stream / 4.9e9;
         est_lm = 0.27 + 0.10e-3 * kq * (double)n + 2.0 * touched * (double)nstored_ * (2.0 * ivf_lmf_row_halfs(d) + 4.0) / 4.0e9;
     } else {
@@ -2463,7 +2463,7 @@ void GpuIndexIVF::search_listmajor_(int ni, const float* xq_pad, const idx_t* c_
             gstride = std::max<int64_t>(gstride, 2);
         }
         const size_t per_q = (size_t)stride * 10 + (size_t)gstride * 4 + (size_t)(np + 1) * 12 + 256 +
-                             (fused_kind_() == 1 ? (size_t)np * ((size_t)d * 2 + 4) : 0); // (IVFPQ: fp16 residual query per probe)
+                             (fused_kind_() != 0 ? (size_t)np * ((size_t)ivf_lmf_row_halfs(d) * 2 + 4) : 0); // (IVFPQ / SQ: fp16 operands per probe)
         const int64_t fit = std::max<int64_t>(1, std::min<int64_t>((int64_t)(R.temp_budget_bytes / per_q), (1 << 20)));
         for (int c0 = 0; c0 < ni; c0 += (int)std::min<int64_t>(fit, ni)) {
             const int cn = (int)std::min<int64_t>(fit, ni - c0);
@@ -2748,8 +2748,9 @@ void GpuIndexIVF::search_listmajor_filter_chunk_(int ni, int q0, const float* xq
     // ---- queries: fp16 copy + range flags + |q|^2 (the sequential chain of the flat index)
     {
         SpanGuard sg(&R, "ivf_lmf_prepare");
-        const int dh = P.kind == 0 ? ivf_lmf_row_halfs(d) : (int)round_up(d, 16);
+        const int dh = P.kind != 1 ? ivf_lmf_row_halfs(d) : (int)round_up(d, 16);
         lm_q16_.ensure((size_t)ni * dh * 2);
+        // (the scalar quantizer's operands come from launch_ivf_lmf_sq_prepare below; |q|^2 is still wanted)
         launch_prep_queries(xq_pad, dpad_, ni, d, dpad_, lm_q16_.p, dh, lm_qflags_.as<uint32_t>(), lm_qn_.as<float>(),
                             lm_scalar_.as<unsigned>(), R.stream);
         P.xq16 = lm_q16_.p;
@@ -2762,6 +2763,16 @@ void GpuIndexIVF::search_listmajor_filter_chunk_(int ni, int q0, const float* xq
             P.pair16 = lm_pair16_.p;
             P.pair_xh = lm_pairxh_.as<float>();
             launch_ivf_lmf_pq_prepare(P, lm_xnb_.as<float>(), R.stream);
+        } else if (P.kind == 2) {
+            // scalar quantizer: B operands (a o s as fp16) and query terms per (query, probe) pair, flags, norm bounds
+            lm_pair16_.ensure((size_t)ni * np * dh * 2);
+            lm_pairxh_.ensure((size_t)ni * np * 4);
+            lm_an_.ensure((size_t)ni * 4);
+            P.pair16 = lm_pair16_.p;
+            P.pair_xh = lm_pairxh_.as<float>();
+            P.ldq16 = dh;
+            P.an_bound = lm_an_.as<float>();
+            launch_ivf_lmf_sq_prepare(P, lm_xnb_.as<float>(), lm_an_.as<float>(), R.stream);
         }
         // granule slots nobody writes must never look like good estimates
         HIP_CHECK(hipMemsetAsync(P.gmin, 0xff, (size_t)ni * gstride * 4, R.stream));
@@ -2777,7 +2788,7 @@ void GpuIndexIVF::search_listmajor_filter_chunk_(int ni, int q0, const float* xq
     }
     {
         SpanGuard sg(&R, "ivf_lmf_bound");
-        launch_ivf_lmf_bound(P, P.kind == 1 ? lm_xnb_.as<float>() : lm_qn_.as<float>(), R.stream);
+        launch_ivf_lmf_bound(P, P.kind != 0 ? lm_xnb_.as<float>() : lm_qn_.as<float>(), R.stream);
     }
     {
         SpanGuard sg(&R, "ivf_lmf_sweep_collect");
@@ -2803,7 +2814,8 @@ void GpuIndexIVF::search_listmajor_filter_chunk_(int ni, int q0, const float* xq
     }
     {
         SpanGuard sg(&R, "ivf_lmf_rerank");
-        launch_ivf_lmf_rerank(P, R.stream);
+        if (P.kind == 2) launch_ivf_lmf_rerank_sq(P, R.stream);
+        else launch_ivf_lmf_rerank(P, R.stream);
     }
     SelectParams sp{};
     sp.metric = metric_type;
@@ -2932,7 +2944,7 @@ void GpuIndexIVF::test_filter_dump(idx_t n, const float* x, int nprobe_now, idx_
     P.ovf = ovf.as<uint32_t>();
     P.qflags = qflags.as<uint32_t>();
     P.band_out = band.as<float>();
-    const int dh = P.kind == 0 ? ivf_lmf_row_halfs(d) : (int)round_up(d, 16);
+    const int dh = P.kind != 1 ? ivf_lmf_row_halfs(d) : (int)round_up(d, 16);
     q16.ensure((size_t)ni * dh * 2);
     launch_prep_queries(P.xq, dpad_, ni, d, dpad_, q16.p, dh, qflags.as<uint32_t>(), qn.as<float>(), scalar.as<unsigned>(), R.stream);
     P.xq16 = q16.p;
@@ -2947,10 +2959,20 @@ void GpuIndexIVF::test_filter_dump(idx_t n, const float* x, int nprobe_now, idx_
         P.pair_xh = pairxh.as<float>();
         launch_ivf_lmf_pq_prepare(P, xnb.as<float>(), R.stream);
     }
+    DevBuf anb;
+    if (P.kind == 2) {
+        pair16.ensure((size_t)ni * np * dh * 2);
+        pairxh.ensure((size_t)ni * np * 4);
+        anb.ensure((size_t)ni * 4);
+        P.pair16 = pair16.p;
+        P.pair_xh = pairxh.as<float>();
+        P.an_bound = anb.as<float>();
+        launch_ivf_lmf_sq_prepare(P, xnb.as<float>(), anb.as<float>(), R.stream);
+    }
     launch_ivf_lm_plan(P, R.stream);
     const int gb = ivf_lmf_grid_blocks(P, R.num_cus);
     launch_ivf_lmf_sweep(P, 1, gb, R.stream);
-    launch_ivf_lmf_bound(P, P.kind == 1 ? xnb.as<float>() : qn.as<float>(), R.stream);
+    launch_ivf_lmf_bound(P, P.kind != 0 ? xnb.as<float>() : qn.as<float>(), R.stream);
     launch_ivf_lmf_sweep(P, 3, gb, R.stream);
     HIP_CHECK(hipMemcpyAsync(keys_out, keys.p, (size_t)ni * stride * 8, hipMemcpyDeviceToHost, R.stream));
     HIP_CHECK(hipMemcpyAsync(band_out, band.p, (size_t)ni * 4, hipMemcpyDeviceToHost, R.stream));
@@ -2988,7 +3010,7 @@ GpuIndexIVFScalarQuantizer::GpuIndexIVFScalarQuantizer(std::shared_ptr<GpuResour
     code_bytes_ = (size_t)(dsq_ / 16) * sq_chunk_bytes(ct_); // arena row: whole 16-component chunks, zero padded
     granule_ = 64;                                           // 64-row chunk-major blocks (kernels.h sq_code_offset)
     // |s o code|^2 per stored row: the second L2 term of the list-major scan
-    use_rn_ = metric == METRIC_L2 && ivf_lm_supported(2, dpad_, ct_, dims);
+    use_rn_ = metric == METRIC_L2 && (ivf_lm_supported(2, dpad_, ct_, dims) || ivf_lmf_supported(2, dims, dpad_, ct_));
     res_->set_device();
     sq_zero_.ensure((size_t)dsq_ * 4);
     HIP_CHECK(hipMemset(sq_zero_.p, 0, (size_t)dsq_ * 4));
@@ -3030,9 +3052,13 @@ void GpuIndexIVFScalarQuantizer::upload_tables_() {
         for (int i = 0; i < d; i++) bm[i] = std::fmaf(mid, s[i], b[i]);
         sq_bm_.ensure((size_t)dsq_ * 4);
         HIP_CHECK(hipMemcpy(sq_bm_.p, bm.data(), (size_t)dsq_ * 4, hipMemcpyHostToDevice));
+        double bn = 0.0;
+        for (int i = 0; i < d; i++) bn += (double)bm[i] * (double)bm[i];
+        sq_bn_ = (float)(bn * 1.0001);
     }
     // the scale changed under rows that are already stored (set_trained after copy_lists): their norms follow
     if (use_rn_ && nstored_ > 0 && arena_.p) row_norms_all_();
+    shadow_dirty_ = true; // (the filter path's norm bounds are read from the norms when its copy of the lists is written)
 }
 void GpuIndexIVFScalarQuantizer::row_norms_all_() {
     if (!use_rn_ || arena_rows_ == 0) return;
@@ -3060,6 +3086,54 @@ void GpuIndexIVFScalarQuantizer::fill_lm_(IvfLmParams& p) const {
     p.sq_s = sq_s_.as<float>();
     p.sq_b = sq_bm_.as<float>();
     p.sq_zero = sq_zero_.as<float>();
+}
+bool GpuIndexIVFScalarQuantizer::lmf_capable_() const {
+    return ivf_lmf_supported(2, d, dpad_, ct_);
+}
+void GpuIndexIVFScalarQuantizer::lmf_shadow_room_() const {
+    const size_t need = ((size_t)arena_cap_rows_ / 32 + 10) * (size_t)(ivf_lmf_row_halfs(d) / 16) * 1024;
+    if (need > arena_h_.cap) arena_h_.ensure(need, shadow_dirty_ ? 0 : arena_h_.cap, res_->stream);
+}
+// the copy of the lists the sweeps read (whole, or the blocks add() touched) + the norm bounds of the error band
+void GpuIndexIVFScalarQuantizer::lmf_write_copy_(const uint32_t* d_first_row, bool merge) const {
+    const GpuResources& R = *res_;
+    lmf_shadow_room_();
+    lm_scalar_.ensure(64);
+    HIP_CHECK(hipMemsetAsync(lm_scalar_.p, 0, 8, R.stream));
+    launch_ivf_lmf_sq_shadow(arena_.as<uint8_t>(), ct_, (int)code_bytes_, use_rn_ ? arena_rn_.as<float>() : nullptr, d, nlist,
+                             d_list_len_.as<uint32_t>(), d_list_start_.as<int64_t>(), arena_h_.p, ivf_lmf_row_halfs(d),
+                             lm_scalar_.as<unsigned>(), d_first_row, R.stream);
+    unsigned bits[2] = {0, 0};
+    HIP_CHECK(hipMemcpyAsync(bits, lm_scalar_.p, 8, hipMemcpyDeviceToHost, R.stream));
+    R.sync();
+    float rn, cn;
+    memcpy(&rn, &bits[0], 4);
+    memcpy(&cn, &bits[1], 4);
+    const bool ok = bits[0] != 0x7f800000u && cn < 3.0e38f;
+    if (!merge) shadow_in_range_ = ok, sq_rn_max_ = 0.f, sq_cn_max_ = 0.f;
+    else if (!ok) shadow_in_range_ = false;
+    if (ok) sq_rn_max_ = std::max(sq_rn_max_, rn), sq_cn_max_ = std::max(sq_cn_max_, cn);
+}
+void GpuIndexIVFScalarQuantizer::lmf_patch_(const uint32_t* d_first_row) {
+    lmf_write_copy_(d_first_row, true);
+}
+bool GpuIndexIVFScalarQuantizer::lmf_prepare_(IvfLmParams& p) const {
+    lmf_shadow_room_();
+    if (shadow_dirty_) {
+        lmf_write_copy_(nullptr, false);
+        shadow_dirty_ = false;
+    }
+    if (!shadow_in_range_) return false;
+    const float mid = ct_ == SQ_U8 ? 127.5f : ct_ == SQ_U4 ? 7.5f : ct_ == SQ_U6 ? 31.5f : 0.f;
+    p.filter = 1;
+    p.arena_h = arena_h_.p;
+    p.ldh = ivf_lmf_row_halfs(d);
+    p.cmid2 = (float)d * mid * mid;
+    p.yn_max = ct_ == SQ_F16 ? sq_cn_max_ : p.cmid2; // |code'|^2 <= d mid^2 for the integer types
+    p.rn_max = sq_rn_max_;
+    p.bn = sq_bn_;
+    p.sq_b_plain = sq_b_.as<float>();
+    return true;
 }
 void GpuIndexIVFScalarQuantizer::set_trained(const float* t, size_t n) {
     FA_THROW_IF_NOT_MSG(needs_training_(), "this scalar quantizer type has no trained range");

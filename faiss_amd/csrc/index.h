@@ -462,7 +462,7 @@ class GpuIndexIVF : public Index {
     mutable int last_scan_arith_ = 0;     // oracle restatement of the last search: 0 query-major arithmetic, 1 f32 list-major
     mutable bool shadow_dirty_ = true;    // a list changed since the fp16 shadow was built
     mutable bool lmf_quant_dirty_ = true; // a quantizer changed since the fp16 codebook / norm bounds were built
-    mutable DevBuf lm_prefixg_, lm_gmin_, lm_thrf_, lm_candpr_, lm_q16_, lm_qflags_, lm_xnb_, lm_pqgrid_, lm_scalar_, lm_pair16_, lm_pairxh_, lm_errf_;
+    mutable DevBuf lm_prefixg_, lm_gmin_, lm_thrf_, lm_candpr_, lm_q16_, lm_qflags_, lm_xnb_, lm_pqgrid_, lm_scalar_, lm_pair16_, lm_pairxh_, lm_errf_, lm_an_;
     // queries whose candidate segment overflowed (or that leave the fp16 range) are appended to `redo`
     void search_listmajor_filter_chunk_(int ni, int q0, const float* xq_pad, const idx_t* c_ids, const float* c_dis, int np, int k,
                                         float* dD, idx_t* dI, int64_t stride, int rt_g, int64_t gstride, int min_stride,
@@ -659,8 +659,25 @@ class GpuIndexIVFScalarQuantizer : public GpuIndexIVF {
     void lists_changed_() override;
     bool lm_capable_() const override;
     void fill_lm_(struct IvfLmParams& p) const override;
+    // behind the f16 filter (round 5): the IVFFlat sweeps over an fp16 copy of the centred codes, d <= 512, every code type
+    bool lmf_capable_() const override;
+    bool lmf_prepare_(struct IvfLmParams& p) const override;
+    void lmf_patch_(const uint32_t* d_first_row) override;
+    size_t lmf_shadow_bytes_() const override { return arena_h_.cap; }
+    size_t lmf_release_() override {
+        const size_t b = arena_h_.cap;
+        arena_h_.release();
+        shadow_dirty_ = true;
+        return b;
+    }
 
    private:
+    mutable DevBuf arena_h_;                // fp16 copy of the centred codes, operand-major 32-row blocks (IvfLmParams::arena_h)
+    mutable float sq_rn_max_ = 0.f, sq_cn_max_ = 0.f; // max |s o code'|^2 (L2) / bound of max |code'|^2 over the stored rows
+    mutable bool shadow_in_range_ = true;
+    float sq_bn_ = 0.f;                     // |b'|^2
+    void lmf_shadow_room_() const;
+    void lmf_write_copy_(const uint32_t* d_first_row, bool merge) const;
     int dsq_;      // d rounded up to 16
     int ct_;       // SqCodeType of the scan kernel
     float levels_; // 255 / 15 / 63 (code range of the type), 0 for the types without a trained range

@@ -920,6 +920,96 @@ __global__ void __launch_bounds__(SQ_FB, 4) ivfsq_fused_kernel(IvfFusedParams p)
 }
 
 // ---------------------------------------------------------------------------------
+// Rerank of the list-major scan behind the f16 filter, scalar quantizer (ivf_lm_filter.hip, round 5): the exact distance of
+// every collected candidate with the arithmetic of ivfsq_fused_kernel above -- the same sq_comp / sq_fold, the same table
+// entries (a_i, s_i), the same two chains over the even and the odd dimensions -- so that a large batch returns, bit for
+// bit, what the query-major scan returns.  One workgroup per query, one LANE per candidate (the query-major kernel gives a
+// lane a row too); the table entries of a candidate's probe are recomputed per lane from the query, the centroid row and
+// the decoder tables (all cache resident).  Components beyond d: a = 0 and s = 0 there, tt * tt adds exactly nothing.
+// ---------------------------------------------------------------------------------
+template <int METRIC, int CT>
+__global__ void __launch_bounds__(256) lmf_rerank_sq_kernel(IvfLmParams p) {
+    constexpr int W = SqChunk<CT>::WORDS;
+    constexpr int CHB = W * 4;
+    __shared__ float s_qb;
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const int np = p.nprobe;
+    const int n = (int)min((int64_t)p.cnt[q], p.stride);
+    u64* kq = p.keys + (int64_t)q * p.stride;
+    const uint16_t* cpr = p.cand_pr + (int64_t)q * p.stride;
+    const float* xq = p.xq + (int64_t)q * p.ldq;
+    const int nch = (p.d + 15) >> 4;
+    const bool per_probe = METRIC == METRIC_L2 && p.sq_by_residual;
+    if (METRIC != METRIC_L2) {
+        if (tid == 0) { // <q, b>: one sequential chain (ivfsq_fused_kernel)
+            float acc = 0.f;
+            if (CT != SQ_F16)
+                for (int i = 0; i < p.d; ++i) acc = __fmaf_rn(xq[i], p.sq_b_plain[i], acc);
+            s_qb = acc;
+        }
+        __syncthreads();
+    }
+    const float qb = METRIC != METRIC_L2 ? s_qb : 0.f;
+    for (int i = tid; i < n; i += 256) {
+        const uint32_t pos = (uint32_t)kq[i];
+        const int pr = (int)cpr[i];
+        const int64_t l = p.coarse_ids[(int64_t)q * np + pr];
+        const int64_t row = p.list_start[l] + (pos - p.prefix[(int64_t)q * (np + 1) + pr]);
+        const uint8_t* rp = p.arena_codes + (row >> 6) * 64 * (int64_t)p.sq_ld + (row & 63) * CHB;
+        const float* cen = p.centroids + l * p.ldc;
+        f32x2 acc = {0.f, 0.f};
+        for (int c = 0; c < nch; ++c) {
+            unsigned w[W];
+            const unsigned* src = (const unsigned*)(rp + (int64_t)c * 64 * CHB);
+#pragma unroll
+            for (int u = 0; u < W; ++u) w[u] = src[u];
+            float sv[16], av[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int jx = 16 * c + e;
+                float a = 0.f, sj = 0.f;
+                if (jx < p.d) {
+                    if (CT != SQ_F16) sj = p.sq_s[jx];
+                    if (per_probe) {
+                        a = xq[jx] - cen[jx];
+                        if (CT != SQ_F16) a = a - p.sq_b_plain[jx];
+                    } else if (METRIC == METRIC_L2) {
+                        a = CT == SQ_F16 ? xq[jx] : xq[jx] - p.sq_b_plain[jx];
+                    } else {
+                        a = CT == SQ_F16 ? xq[jx] : xq[jx] * p.sq_s[jx];
+                    }
+                }
+                av[e] = a;
+                sv[e] = sj;
+            }
+            sq_fold<METRIC, CT, 0>(w, sv, av, acc);
+        }
+        float dis = acc[0] + acc[1];
+        if (METRIC != METRIC_L2) dis = (dis + qb) + (p.sq_by_residual ? p.coarse_dis[(int64_t)q * np + pr] : 0.f);
+        kq[i] = ((u64)ordkey<METRIC>(dis) << 32) | (u64)pos;
+    }
+}
+void launch_ivf_lmf_rerank_sq(const IvfLmParams& p, hipStream_t stream) {
+    if (p.nq == 0) return;
+    FA_THROW_IF_NOT(p.kind == 2 && p.arena_codes && p.sq_s && p.sq_b_plain && p.centroids && p.keys && p.cand_pr && p.cnt);
+    const dim3 grid((unsigned)p.nq), block(256);
+    const bool l2 = p.metric == METRIC_L2;
+#define FA_RRSQ(CT_)                                                                                        \
+    do {                                                                                                    \
+        if (l2) hipLaunchKernelGGL((lmf_rerank_sq_kernel<METRIC_L2, CT_>), grid, block, 0, stream, p);     \
+        else hipLaunchKernelGGL((lmf_rerank_sq_kernel<METRIC_INNER_PRODUCT, CT_>), grid, block, 0, stream, p); \
+    } while (0)
+    switch (p.sq_ct) {
+        case SQ_U8: FA_RRSQ(SQ_U8); break;
+        case SQ_U4: FA_RRSQ(SQ_U4); break;
+        case SQ_U6: FA_RRSQ(SQ_U6); break;
+        default: FA_RRSQ(SQ_F16); break;
+    }
+#undef FA_RRSQ
+    HIP_CHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------
 // Deferred finish (IvfFusedParams::defer_finish): the reservoir a scan workgroup left in part_keys[q][0..n) is cut to
 // the k best, translated to user ids and ordered by a small workgroup of its own -- 256 threads, ~11 KB of LDS, many
 // per CU -- instead of on the critical path of a 75 KB scan workgroup.  Same code as the in-kernel finish.

@@ -69,6 +69,9 @@ __device__ __forceinline__ void lmf_store_u16(uint16_t* at, uint32_t v) {
 bool ivf_lmf_supported(int kind, int d, int dpad, int M) {
     if ((dpad & 7) || d < 1) return false;
     if (kind == 0) return dpad <= 512; // (d > 128: one or two query blocks per item, see ivf_lmf_queries_per_item)
+    // scalar quantizer (round 5): the IVFFlat sweeps over an fp16 copy of the CENTRED codes (exact in fp16), the scale folded
+    // into per-(query, probe) B operands; M = the SqCodeType
+    if (kind == 2) return d <= 512 && M >= SQ_U8 && M <= SQ_F16;
     if (dpad > 128) return false;
     if (kind == 1) {
         if (M < 4 || (M & 3) || d % M) return false;
@@ -149,6 +152,85 @@ void launch_ivf_lmf_shadow(const float* arena, int64_t ldv, const float* arena_r
     if (nlist == 0) return;
     hipLaunchKernelGGL(lmf_shadow_kernel, dim3((unsigned)nlist, first_row ? 1 : 4), dim3(256), 0, stream, arena, ldv, arena_rn, d,
                        list_len, list_start, (_Float16*)arena_h, dh, yn_max_bits, first_row);
+    HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ scalar quantizer: fp16 copy of the centred codes
+// component j of arena row `row` as the CENTRED code (code - mid; fp16 codes: the half itself): exactly representable in fp16
+__device__ __forceinline__ float lmf_sq_centred(const uint8_t* arena, int64_t row, int j, int ct, int ld) {
+    const int chb = sq_chunk_bytes(ct);
+    const uint8_t* ch = arena + (row >> 6) * 64 * (int64_t)ld + (int64_t)(j >> 4) * 64 * chb + (row & 63) * chb;
+    const int e = j & 15;
+    if (ct == SQ_U8) return (float)ch[e] - 127.5f;
+    if (ct == SQ_U4) return (float)((ch[e >> 1] >> (4 * (e & 1))) & 15u) - 7.5f;
+    if (ct == SQ_U6) {
+        const int off = 6 * e, by = off >> 3, sh = off & 7;
+        const unsigned v = (unsigned)ch[by] | ((unsigned)ch[by + 1 < 12 ? by + 1 : by] << 8);
+        return (float)((v >> sh) & 63u) - 31.5f;
+    }
+    return (float)*(const _Float16*)(ch + 2 * e);
+}
+// the operand-major blocks of lmf_shadow_kernel, filled with the centred codes.  stat_bits[0]: max |s o code'|^2 over the
+// rows written (L2: from arena_rn; 0x7f800000 when a stored fp16 code is not finite), stat_bits[1]: max |code'|^2 (fp16 codes)
+__global__ void __launch_bounds__(256) lmf_sq_shadow_kernel(const uint8_t* __restrict__ arena, int ct, int ld,
+                                                            const float* __restrict__ arena_rn, int d, const uint32_t* list_len,
+                                                            const int64_t* list_start, _Float16* __restrict__ arena_h, int dh,
+                                                            unsigned* __restrict__ stat_bits, const uint32_t* __restrict__ first_row) {
+    const int list = blockIdx.x;
+    const uint32_t len = list_len[list];
+    const int64_t start = list_start[list]; // (a multiple of 64)
+    const int nks = dh >> 4;
+    const uint32_t fr = first_row ? first_row[list] : 0u;
+    if (fr == 0xffffffffu) return;
+    const int64_t b0 = fr >> 5;
+    const int64_t nblk = (len + 31) / 32 - b0;
+    const int64_t total = nblk * nks * 64;
+    float mx = 0.f, mc = 0.f;
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.y * blockDim.x) {
+        const int ln = (int)(i & 63);
+        const int64_t bs = i >> 6;
+        const int s = (int)(bs % nks);
+        const int64_t b = b0 + bs / nks;
+        const int h = ln >> 5, j = ln & 31;
+        const int64_t r = b * 32 + j;
+        const int c = 16 * s + 8 * h;
+        half8 o = half8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (r < (int64_t)len) {
+            float sq = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = c + e < d ? lmf_sq_centred(arena, start + r, c + e, ct, ld) : 0.f;
+                if (!(fabsf(v) <= 65000.f)) bad = true;
+                o[e] = (_Float16)v;
+                sq = __fmaf_rn(v, v, sq);
+            }
+            if (ct == SQ_F16) mc = fmaxf(mc, sq * (float)nks * 2.f); // (a piece's share times the pieces: an upper bound, refined below)
+            if (c == 0 && arena_rn) {
+                const float n = arena_rn[start + r];
+                if (!(n <= 3.0e38f)) bad = true;
+                mx = fmaxf(mx, n);
+            }
+        }
+        *(half8*)(arena_h + (((start >> 5) + b) * nks + s) * 512 + ln * 8) = o;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        mc = fmaxf(mc, __shfl_xor(mc, off, 64));
+    }
+    const bool anybad = __ballot(bad) != 0ull;
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(stat_bits, anybad ? 0x7f800000u : __float_as_uint(mx));
+        atomicMax(stat_bits + 1, __float_as_uint(mc));
+    }
+}
+void launch_ivf_lmf_sq_shadow(const uint8_t* arena, int ct, int ld, const float* arena_rn, int d, int nlist, const uint32_t* list_len,
+                              const int64_t* list_start, void* arena_h, int dh, unsigned* stat_bits, const uint32_t* first_row,
+                              hipStream_t stream) {
+    if (nlist == 0) return;
+    hipLaunchKernelGGL(lmf_sq_shadow_kernel, dim3((unsigned)nlist, first_row ? 1 : 4), dim3(256), 0, stream, arena, ct, ld, arena_rn,
+                       d, list_len, list_start, (_Float16*)arena_h, dh, stat_bits, first_row);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -509,7 +591,9 @@ struct LmfDraw {
 // The A operands wait in a ring of R pieces (a whole block at d <= 128, half a block beyond: the registers go to the B
 // operands): the shadow is operand-major, so the ring simply runs R KB ahead of the MFMAs through the k-steps of this block
 // and the next one looked at.
-template <int METRIC, int MODE, int NQB, int KS, bool FULL, bool SEL>
+// PAIRB (scalar quantizer): the B operands and the query terms are per (query, probe) PAIR -- pair16 / pair_xh, prepared once per
+// search by lmf_sq_prepare_kernel -- instead of per query; the A operands are the fp16 copy of the centred codes.
+template <int METRIC, int MODE, int NQB, int KS, bool FULL, bool SEL, bool PAIRB>
 __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams p) {
     static_assert(KS == 8 || (FULL && (KS == 16 || KS == 24 || KS == 32)), "k-steps");
     constexpr int R = KS == 8 ? 8 : KS / 2; // (KS % R == 0: slot s % R holds k-step s of the block at its start)
@@ -584,13 +668,13 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
             const uint32_t pi = p.pairs[pb + (uint32_t)(qt * (32 * NQB)) + (uint32_t)(L[b].qv ? my : 0)];
             const int q = (int)(pi / (uint32_t)np);
             const int pr = (int)(pi - (uint32_t)q * (uint32_t)np);
-            const _Float16* qrow = xq16 + (int64_t)q * p.ldq16 + 8 * h;
+            const _Float16* qrow = (PAIRB ? (const _Float16*)p.pair16 + (int64_t)pi * p.ldq16 : xq16 + (int64_t)q * p.ldq16) + 8 * h;
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 if (FULL || s < nks) bq[b][s] = *(const half8*)(qrow + 16 * s);
                 else bq[b][s] = half8{0, 0, 0, 0, 0, 0, 0, 0};
             }
-            L[b].xh = METRIC == METRIC_L2 ? -0.5f * p.xqn[q] : 0.f;
+            L[b].xh = PAIRB ? p.pair_xh[pi] : METRIC == METRIC_L2 ? -0.5f * p.xqn[q] : 0.f;
             L[b].base_pos = p.prefix[(int64_t)q * (np + 1) + pr];
             L[b].qpr = ((uint32_t)q << 11) | (uint32_t)pr;
             L[b].tq = __builtin_nanf(""); // nothing passes a NaN threshold -- not even a score of +inf (a query beyond the fp16 range)
@@ -1096,14 +1180,14 @@ int ivf_lmf_grid_blocks(const IvfLmParams& p, int num_cus) {
     if (p.kind == 1) return num_cus;       // one 8-wave workgroup per CU (codebook + slices in its LDS)
     return 2 * num_cus / 8 * 8;            // IVFFlat: two 4-wave workgroups per CU
 }
-template <int METRIC, int MODE, bool SEL>
+template <int METRIC, int MODE, bool SEL, bool PAIRB>
 static void lmf_flat_launch(const IvfLmParams& p, int grid_blocks, hipStream_t stream) {
     const int lds = MODE == MODE_COLLECT ? LF_LDS : 0;
 #define FA_LF(NQB_, KS_, FULL_)                                                                                                \
     do {                                                                                                                       \
-        HIP_CHECK(hipFuncSetAttribute((const void*)ivf_lmf_flat_kernel<METRIC, MODE, NQB_, KS_, FULL_, SEL>,                   \
+        HIP_CHECK(hipFuncSetAttribute((const void*)ivf_lmf_flat_kernel<METRIC, MODE, NQB_, KS_, FULL_, SEL, PAIRB>,            \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, LF_LDS));                                    \
-        hipLaunchKernelGGL((ivf_lmf_flat_kernel<METRIC, MODE, NQB_, KS_, FULL_, SEL>), dim3((unsigned)grid_blocks),            \
+        hipLaunchKernelGGL((ivf_lmf_flat_kernel<METRIC, MODE, NQB_, KS_, FULL_, SEL, PAIRB>), dim3((unsigned)grid_blocks),     \
                            dim3(LF_THREADS), lds, stream, p);                                                                  \
     } while (0)
     if (p.ldh == 128) FA_LF(kLmfQueryBlocks, 8, true);
@@ -1139,9 +1223,13 @@ static void lmf_pq_launch(const IvfLmParams& p, int grid_blocks, hipStream_t str
 template <int METRIC, bool SEL>
 static void lmf_launch_sel(const IvfLmParams& p, int mode, int grid_blocks, hipStream_t stream) {
     if (p.kind == 0) {
-        if (mode == MODE_MIN) lmf_flat_launch<METRIC, MODE_MIN, SEL>(p, grid_blocks, stream);
-        else if (mode == MODE_COLLECT) lmf_flat_launch<METRIC, MODE_COLLECT, SEL>(p, grid_blocks, stream);
-        else lmf_flat_launch<METRIC, MODE_DUMP, SEL>(p, grid_blocks, stream);
+        if (mode == MODE_MIN) lmf_flat_launch<METRIC, MODE_MIN, SEL, false>(p, grid_blocks, stream);
+        else if (mode == MODE_COLLECT) lmf_flat_launch<METRIC, MODE_COLLECT, SEL, false>(p, grid_blocks, stream);
+        else lmf_flat_launch<METRIC, MODE_DUMP, SEL, false>(p, grid_blocks, stream);
+    } else if (p.kind == 2) {
+        if (mode == MODE_MIN) lmf_flat_launch<METRIC, MODE_MIN, SEL, true>(p, grid_blocks, stream);
+        else if (mode == MODE_COLLECT) lmf_flat_launch<METRIC, MODE_COLLECT, SEL, true>(p, grid_blocks, stream);
+        else lmf_flat_launch<METRIC, MODE_DUMP, SEL, true>(p, grid_blocks, stream);
     } else {
         if (mode == MODE_MIN) lmf_pq_launch<METRIC, MODE_MIN, SEL>(p, grid_blocks, stream);
         else if (mode == MODE_COLLECT) lmf_pq_launch<METRIC, MODE_COLLECT, SEL>(p, grid_blocks, stream);
@@ -1156,7 +1244,8 @@ static void lmf_launch_mode(const IvfLmParams& p, int mode, int grid_blocks, hip
 }
 void launch_ivf_lmf_sweep(const IvfLmParams& p, int mode, int grid_blocks, hipStream_t stream) {
     if (p.nq == 0) return;
-    FA_THROW_IF_NOT(p.filter && ivf_lmf_supported(p.kind, p.d, p.dpad, p.M) && mode >= 1 && mode <= 3 && grid_blocks > 0);
+    FA_THROW_IF_NOT(p.filter && ivf_lmf_supported(p.kind, p.d, p.dpad, p.kind == 2 ? p.sq_ct : p.M) && mode >= 1 && mode <= 3 &&
+                    grid_blocks > 0);
     FA_THROW_IF_NOT(p.min_stride >= 1 && p.min_stride <= 8);
     FA_THROW_IF_NOT(p.qpi == ivf_lmf_queries_per_item(p.kind, p.d) && p.nq < (1 << 21) && p.nprobe <= 2048 &&
                     p.gran_blocks >= 1 && (p.gran_blocks & (p.gran_blocks - 1)) == 0);
@@ -1164,6 +1253,9 @@ void launch_ivf_lmf_sweep(const IvfLmParams& p, int mode, int grid_blocks, hipSt
         FA_THROW_IF_NOT(p.xq16 && p.arena_h && p.ldh == ivf_lmf_row_halfs(p.d) && p.ldh <= 512 && p.ldq16 >= p.ldh &&
                         p.ldq16 % 8 == 0);
         FA_THROW_IF_NOT(p.metric != METRIC_L2 || (p.arena_rn && p.xqn));
+    } else if (p.kind == 2) {
+        FA_THROW_IF_NOT(p.pair16 && p.pair_xh && p.arena_h && p.ldh == ivf_lmf_row_halfs(p.d) && p.ldh <= 512 && p.ldq16 == p.ldh);
+        FA_THROW_IF_NOT(p.metric != METRIC_L2 || p.arena_rn);
     } else {
         FA_THROW_IF_NOT(p.pq16 && p.arena_cs && p.cs_bpl > 0 && (p.cs_piece == 4 || p.cs_piece == 16) && p.centroids &&
                         p.ldq % 4 == 0 && p.ldc % 4 == 0);
@@ -1186,7 +1278,7 @@ __global__ void __launch_bounds__(256) lmf_bound_kernel(IvfLmParams p, const flo
     const uint32_t S = p.prefixg[(int64_t)q * (np + 1) + np];
     const uint32_t* g = p.gmin + (int64_t)q * p.gstride;
     // (IVFPQ: the B operands are fp16 (q - c): every coordinate is below sqrt(max |q - c|^2), which must stay in range)
-    if ((p.qflags && p.qflags[q]) || (p.kind == 1 && !(xn_bound[q] <= 9.0e8f))) {
+    if ((p.qflags && p.qflags[q]) || (p.kind != 0 && !(xn_bound[q] <= 9.0e8f))) {
         // outside the fp16 range / NaN: nothing is collected, the query is redone by the query-major scan
         if (tid == 0) {
             p.thr_f[q] = METRIC == METRIC_L2 ? -INFINITY : INFINITY;
@@ -1251,7 +1343,18 @@ __global__ void __launch_bounds__(256) lmf_bound_kernel(IvfLmParams p, const flo
                 // + the fp32 chains of those terms themselves (d products each: d 2^-24 |c| |r^| and the like), ADVICE r4
                 extra = (4.8e-7f * (float)p.M + 1.2e-7f * (float)(p.d + 8)) * sroot * sroot;
             }
-            const float E = ivf_filter_err_bound(METRIC, p.d, xn_bound[q], p.yn_max, extra);
+            if (p.kind == 2) {
+                // scalar quantizer: xn_bound / yn_max are the norms of the matrix pipe's operands (a o s and the centred codes);
+                // on top, the fp32 chains of |a|^2 and |s o code'|^2, the exact path's own chains over d dimensions and the
+                // one rounding of b' = b + mid s per dimension, all in terms of the magnitudes they act on
+                const float an = p.an_bound[q], sa = sqrtf(an), sr = sqrtf(p.rn_max), sb = sqrtf(p.bn);
+                if (METRIC == METRIC_L2) extra = 2.4e-7f * (float)(p.d + 8) * (an + p.rn_max) + 4.8e-7f * sb * (sa + sr);
+                else extra = 2.4e-7f * (float)(p.d + 8) * (sa * sb + 2.f * sqrtf(xn_bound[q]) * (sqrtf(p.yn_max) + sqrtf(p.cmid2)));
+            }
+            // (kind 2: the operands' norms are in code units -- d 127.5^2 for 8-bit codes -- and say nothing about the magnitudes
+            // the fp32 chains act on: the generic bound's norm terms are replaced by `extra` above)
+            const float E = p.kind == 2 ? 1.25f * ((METRIC == METRIC_L2 ? 2.f : 1.f) * ivf_filter_err_mfma(p.d, xn_bound[q], p.yn_max) + extra) + 1e-30f
+                                        : ivf_filter_err_bound(METRIC, p.d, xn_bound[q], p.yn_max, extra);
             if (p.band_out) p.band_out[q] = E;
             if (p.err_f) p.err_f[q] = E;
             thr = METRIC == METRIC_L2 ? T + 2.f * E : T - 2.f * E;
@@ -1435,6 +1538,80 @@ void launch_ivf_lmf_pq_prepare(const IvfLmParams& p, float* xn_bound, hipStream_
     HIP_CHECK(hipMemsetAsync(xn_bound, 0, (size_t)p.nq * 4, stream));
     hipLaunchKernelGGL(lmf_pq_prepare_kernel, dim3((unsigned)div_up((size_t)p.nq * p.nprobe * 16, 256)), dim3(256), 0, stream, p,
                        xn_bound);
+    HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ scalar quantizer: per-search preparation
+// B operands and query terms of every (query, probe) pair (kernels.h IvfLmParams, kind 2), with a_j = (q_j [- centroid_j]) - b'_j:
+//   L2: pair16 = fp16(a o s), pair_xh = -|a|^2 / 2;        IP: pair16 = fp16(q o s), pair_xh = <q, b'> [+ coarse term]
+// xn_bound[q] = max over the probes of |B|^2 (the operand's norm: the matrix pipe's share of the error band), an_bound[q] = max of
+// |a|^2 (L2) / |q|^2 (IP) (the fp32 chains' share); qflags[q] |= 1 when a B coordinate leaves the fp16 range.  P = dh / 8 lanes
+// (a power of two, 2 .. 64) per pair, one 8-coordinate operand piece each.
+__global__ void __launch_bounds__(256) lmf_sq_prepare_kernel(IvfLmParams p, float* __restrict__ xn_bound, float* __restrict__ an_bound,
+                                                             int P) {
+    const int np = p.nprobe;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t pair = t / P;
+    const int sub = (int)(t - pair * P);
+    if (pair >= (int64_t)p.nq * np) return; // (whole groups leave together: P divides 64)
+    const int q = (int)(pair / np);
+    const bool l2 = p.metric == METRIC_L2;
+    const int64_t l = p.coarse_ids[pair];
+    const bool res = p.sq_by_residual && l >= 0;
+    float an = 0.f, bn = 0.f, qb = 0.f;
+    bool bad = false;
+    if (8 * sub < (int)p.ldh) {
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int jx = 8 * sub + e;
+            float B = 0.f;
+            if (jx < p.d) {
+                const float x = p.xq[(int64_t)q * p.ldq + jx];
+                const float sj = p.sq_s[jx], bj = p.sq_b[jx];
+                if (l2) {
+                    float a = x;
+                    if (res) a = a - p.centroids[l * p.ldc + jx];
+                    a = a - bj;
+                    an = __fmaf_rn(a, a, an);
+                    B = a * sj;
+                } else {
+                    an = __fmaf_rn(x, x, an);
+                    qb = __fmaf_rn(x, bj, qb);
+                    B = x * sj;
+                }
+            }
+            if (!(fabsf(B) <= 65000.f)) bad = true;
+            bn = __fmaf_rn(B, B, bn);
+            o[e] = (_Float16)B;
+        }
+        *(half8*)((_Float16*)p.pair16 + pair * p.ldh + 8 * sub) = o;
+    }
+    for (int off = 1; off < P; off <<= 1) {
+        an += __shfl_xor(an, off, 64);
+        bn += __shfl_xor(bn, off, 64);
+        qb += __shfl_xor(qb, off, 64);
+        bad = bad || __shfl_xor((int)bad, off, 64);
+    }
+    if (sub == 0) {
+        p.pair_xh[pair] = l2 ? -0.5f * an : qb + (p.sq_by_residual ? p.coarse_dis[pair] : 0.f);
+        if (l >= 0) {
+            atomicMax((unsigned*)xn_bound + q, __float_as_uint(bn * 1.0001f));
+            atomicMax((unsigned*)an_bound + q, __float_as_uint(an * 1.0001f));
+        }
+        if (bad || !(an <= 3.0e38f)) atomicOr(const_cast<uint32_t*>(p.qflags) + q, 1u);
+    }
+}
+void launch_ivf_lmf_sq_prepare(const IvfLmParams& p, float* xn_bound, float* an_bound, hipStream_t stream) {
+    if (p.nq == 0) return;
+    FA_THROW_IF_NOT(p.kind == 2 && p.pair16 && p.pair_xh && p.qflags && p.sq_s && p.sq_b && p.centroids && p.ldh % 16 == 0 && p.ldh <= 512);
+    int P = 2;
+    while (P * 8 < p.ldh) P <<= 1;
+    HIP_CHECK(hipMemsetAsync(xn_bound, 0, (size_t)p.nq * 4, stream));
+    HIP_CHECK(hipMemsetAsync(an_bound, 0, (size_t)p.nq * 4, stream));
+    HIP_CHECK(hipMemsetAsync(const_cast<uint32_t*>(p.qflags), 0, (size_t)p.nq * 4, stream));
+    hipLaunchKernelGGL(lmf_sq_prepare_kernel, dim3((unsigned)div_up((size_t)p.nq * p.nprobe * P, 256)), dim3(256), 0, stream, p,
+                       xn_bound, an_bound, P);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -466,6 +466,7 @@ struct IvfLmParams {
     const float* sq_s;     // [>= dpad] scale per dimension (0 beyond d)
     const float* sq_b;     // [>= dpad] b': offset per dimension moved to the middle of the code range (fp16: s = 1, b' = 0)
     const float* sq_zero;  // [>= dpad] zeros: the "centroid" of a search without residual encoding
+    const float* sq_b_plain; // [>= dpad] b (not centred): the table of the query-major scan, for the filter path's exact rerank
     // ---- f16 filter scan (round 4, ivf_lm_filter.hip; kinds 0 and 1).  Every (query, probe) pair is a "pass 2" pair
     // (filter = 1: the plan puts p0 = 0); two sweeps over the same work items -- granule minima of the ESTIMATED
     // distances, then the collection of every row whose estimate is at or below the query's threshold -- and the
@@ -514,6 +515,10 @@ struct IvfLmParams {
     const float* xn_full;       // [nq] |q|^2 (kind 0: == xqn)
     float yn_max;               // max |y|^2 over the stored rows (kind 0) / upper bound of |r^|^2 from the codebook (kind 1)
     float cn_max;               // kind 1: max |centroid|^2
+    // kind 2 (scalar quantizer behind the filter): [nq] max over the probes of |a|^2 (L2) / |q|^2 (IP), |b'|^2 of the centred
+    // offsets, max |s o code'|^2 over the stored rows (L2), d mid^2 (the centring constant's share of the plain codes' norm)
+    const float* an_bound;
+    float bn, rn_max, cmid2;
     float* band_out;            // optional [nq]: the error band E_q the bound kernel used (tests)
     float* err_f;               // [nq] the error band E_q (written by the bound kernel, read by launch_ivf_lmf_tighten)
     // IDSelector of the search in flight (filter path only): one bit per arena row (launch_selector_mask), null = none.
@@ -535,6 +540,11 @@ constexpr int kLmfFusedSelectK = 256, kLmfFusedSelectN = 1024;
 // d fp32 accumulations (4 d 2^-24: margin for the pipe's internal order), fp16 denormals; the fp32 chains of the norms,
 // the final fmaf and the exact path's own rounding ((d + 8) 2^-23 of the magnitudes involved).  extra: kind 1's table
 // grid and per-row terms, see lmf_bound_kernel.  Verified on hardware by test_list_filter_error_bound_holds.
+// the matrix pipe's share alone: |<f16 B, f16 A> (fp32 accumulation) - <B, A>| for operands of squared norms xn, yn
+__host__ __device__ static inline float ivf_filter_err_mfma(int d, float xn, float yn) {
+    const float nq = sqrtf(xn), ny = sqrtf(yn);
+    return (9.775e-4f /*2^-10 * 1.001*/ + 2.4e-7f * (float)d) * nq * ny + 3.0e-8f * sqrtf((float)d) * (nq + ny);
+}
 __host__ __device__ static inline float ivf_filter_err_bound(int metric, int d, float xn, float yn_max, float extra = 0.f) {
     const float nq = sqrtf(xn), ny = sqrtf(yn_max);
     float e = (9.775e-4f /*2^-10 * 1.001*/ + 2.4e-7f * (float)d) * nq * ny + 3.0e-8f * sqrtf((float)d) * (nq + ny);
@@ -580,6 +590,16 @@ void launch_ivf_lmf_rerank(const IvfLmParams& p, hipStream_t stream);
 void launch_ivf_lmf_shadow(const float* arena, int64_t ldv, const float* arena_rn, int d, int nlist, const uint32_t* list_len,
                            const int64_t* list_start, void* arena_h, int dh, unsigned* yn_max_bits, const uint32_t* first_row,
                            hipStream_t stream);
+// scalar quantizer: the operand-major fp16 blocks of launch_ivf_lmf_shadow filled with the CENTRED codes (exact in fp16);
+// stat_bits[0] = max |s o code'|^2 of the rows written (from arena_rn; 0x7f800000: a stored fp16 code is not finite),
+// stat_bits[1] = an upper bound of max |code'|^2 (fp16 codes; the integer types use d mid^2)
+void launch_ivf_lmf_sq_shadow(const uint8_t* arena, int ct, int ld, const float* arena_rn, int d, int nlist, const uint32_t* list_len,
+                              const int64_t* list_start, void* arena_h, int dh, unsigned* stat_bits, const uint32_t* first_row,
+                              hipStream_t stream);
+// kind 2: pair16 / pair_xh / qflags, xn_bound[q] = max |B|^2, an_bound[q] = max |a|^2 (see lmf_sq_prepare_kernel)
+void launch_ivf_lmf_sq_prepare(const IvfLmParams& p, float* xn_bound, float* an_bound, hipStream_t stream);
+// kind 2: keys[q][0 .. cnt[q]) <- the exact distance of ivfsq_fused_kernel for the same row (ivf_fused.hip: same code)
+void launch_ivf_lmf_rerank_sq(const IvfLmParams& p, hipStream_t stream);
 // IVFPQ: operand-major copy of the codes of every list (see IvfLmParams::arena_cs); bytes per lane and block / piece size
 void ivf_lmf_code_shadow_shape(int d, int M, int* bpl, int* piece);
 bool ivf_lmf_choice_shape(int d, int M); // the shape the two-copy codebook serves

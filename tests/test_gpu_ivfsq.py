@@ -226,7 +226,11 @@ LM_QTYPES = QTYPES
 
 
 def _lm_check(idx, qtype, metric, by_residual, xq, nprobe, k, nsel=48):
-    """query-major vs list-major vs the oracle's restatement of the list-major arithmetic (orc_ivfsq_search_ex, arith 1)"""
+    """query-major vs the two list-major scans vs the oracle:
+      * SCAN_LIST_MAJOR (round 5: behind the f16 filter, ivf_lm_filter.hip over an fp16 copy of the centred codes): the very
+        bits of the query-major scan (arith 0), for every query;
+      * SCAN_LIST_MAJOR_F32 (round 3's f32 MFMA scan, d <= 128): bit-exact against its own restatement (arith 1), within the
+        north-star tolerance of the query-major scan."""
     d = xq.shape[1]
     idx.nprobe = nprobe
     idx.set_scan_mode(idx.SCAN_QUERY_MAJOR)
@@ -234,18 +238,25 @@ def _lm_check(idx, qtype, metric, by_residual, xq, nprobe, k, nsel=48):
     assert idx.scan_info()[1] == 1
     idx.set_scan_mode(idx.SCAN_LIST_MAJOR)
     D, I = idx.search(xq, k)
-    assert idx.scan_info()[1] == 2 and idx.last_scan_arith() == 1
-    # (two roundings of the same sums: where offset and code terms cancel -- inner products near zero at deep ranks --
-    # neighbours a few 1e-6 of the row's scale apart may swap; each scan is bit-exact against its own restatement below)
-    check_knn(D, I, D0, I0, rtol=1e-4, tie_rtol=2e-3, name="ivfsq list-major vs query-major")
-    cent = idx.get_centroids()
-    vmin, vdiff = Oracle.sq_unpack(qtype, d, idx.get_trained())
-    sizes, codes, ids = _gpu_lists(idx)
-    sel = np.r_[0:min(len(xq), nsel)]
-    Do, Io = Oracle.ivfsq_search(qtype, by_residual, metric, cent, sizes, codes, ids, vmin, vdiff, xq[sel], nprobe, k, arith=1)
-    check_knn(D[sel], I[sel], Do, Io, exact=True, name="ivfsq list-major vs oracle")
-    D2, I2 = idx.search(xq, k)  # run to run: the order in which wavefronts append candidates never shows
+    assert idx.scan_info()[1] == 2 and idx.last_scan_arith() == 0
+    assert np.array_equal(I, I0) and np.array_equal(D, D0), "filter path differs from the query-major scan"
+    D2, I2 = idx.search(xq, k)
     assert np.array_equal(D, D2) and np.array_equal(I, I2)
+    if d <= 128:
+        idx.set_scan_mode(idx.SCAN_LIST_MAJOR_F32)
+        D, I = idx.search(xq, k)
+        assert idx.scan_info()[1] == 2 and idx.last_scan_arith() == 1
+        # (two roundings of the same sums: where offset and code terms cancel -- inner products near zero at deep ranks --
+        # neighbours a few 1e-6 of the row's scale apart may swap; each scan is bit-exact against its own restatement below)
+        check_knn(D, I, D0, I0, rtol=1e-4, tie_rtol=2e-3, name="ivfsq list-major vs query-major")
+        cent = idx.get_centroids()
+        vmin, vdiff = Oracle.sq_unpack(qtype, d, idx.get_trained())
+        sizes, codes, ids = _gpu_lists(idx)
+        sel = np.r_[0:min(len(xq), nsel)]
+        Do, Io = Oracle.ivfsq_search(qtype, by_residual, metric, cent, sizes, codes, ids, vmin, vdiff, xq[sel], nprobe, k, arith=1)
+        check_knn(D[sel], I[sel], Do, Io, exact=True, name="ivfsq list-major vs oracle")
+        D2, I2 = idx.search(xq, k)  # run to run: the order in which wavefronts append candidates never shows
+        assert np.array_equal(D, D2) and np.array_equal(I, I2)
     idx.set_scan_mode(idx.SCAN_AUTO)
     return D, I
 
@@ -288,29 +299,42 @@ def test_ivfsq_list_major_shapes(res, qtype, metric, by_residual, d, nlist, nb, 
 
 def test_ivfsq_list_major_rule_and_refusals(res):
     d, nlist = 32, 16
-    xt, xb, xq = synthetic_dataset(d, 4000, 6000, 2500, seed=3)
+    xt, xb, xq = synthetic_dataset(d, 4000, 200000, 2500, seed=3)
     idx = faiss_amd.GpuIndexIVFScalarQuantizer(res, d, nlist, SQ.QT_8bit, METRIC_L2, True)
     idx.train(xt)
     idx.add(xb)
     idx.nprobe = 4
-    # large batches take the list-major scan on their own, small ones and IDSelector searches the query-major one
-    assert idx.list_major_rule(2500) and not idx.list_major_rule(500)
+    # large batches take the list-major scan on their own (the cost model of the filter path since round 5: the bytes a
+    # query-major scan streams against the sweeps' fixed cost), small ones the query-major one
+    assert idx.list_major_rule(2500) and not idx.list_major_rule(20)
     D, I = idx.search(xq, 10)
     assert idx.scan_info()[1] == 2
     D1, I1 = idx.search(xq[:100], 10)
     assert idx.scan_info()[1] == 1
-    check_knn(D[:100], I[:100], D1, I1, rtol=1e-4, tie_rtol=1e-4, name="auto: list-major vs query-major")
-    # d > 128 keeps the query-major scan
+    # (behind the f16 filter the two scans return the same bits)
+    assert idx.last_scan_arith() == 0 and np.array_equal(D[:100], D1) and np.array_equal(I[:100], I1)
+    # d > 128: the filter path serves up to d = 512 (same bits as the query-major scan), the f32 scan refuses
     xt2, xb2, xq2 = synthetic_dataset(136, 3000, 4000, 2100, seed=5)
     wide = faiss_amd.GpuIndexIVFScalarQuantizer(res, 136, nlist, SQ.QT_8bit, METRIC_L2, True)
     wide.train(xt2)
     wide.add(xb2)
-    assert not wide.list_major_rule(2500)
-    wide.search(xq2, 10)
-    assert wide.scan_info()[1] == 1
+    wide.nprobe = 4
+    wide.set_scan_mode(wide.SCAN_QUERY_MAJOR)
+    Dq, Iq = wide.search(xq2, 10)
     wide.set_scan_mode(wide.SCAN_LIST_MAJOR)
+    Dl, Il = wide.search(xq2, 10)
+    assert wide.scan_info()[1] == 2 and np.array_equal(Iq, Il) and np.array_equal(Dq, Dl)
+    wide.set_scan_mode(wide.SCAN_LIST_MAJOR_F32)
     with pytest.raises(RuntimeError):
         wide.search(xq2, 10)
+    huge = faiss_amd.GpuIndexIVFScalarQuantizer(res, 520, nlist, SQ.QT_8bit, METRIC_L2, True)
+    xt3, xb3, xq3 = synthetic_dataset(520, 2000, 3000, 2100, seed=6)
+    huge.train(xt3)
+    huge.add(xb3)
+    assert not huge.list_major_rule(2500)
+    huge.set_scan_mode(huge.SCAN_LIST_MAJOR)
+    with pytest.raises(RuntimeError):
+        huge.search(xq3, 10)
 
 
 def test_ivfsq_list_major_row_norms_follow_the_rows(res):
@@ -328,7 +352,7 @@ def test_ivfsq_list_major_row_norms_follow_the_rows(res):
         b.add(xb[i0:i0 + 777])
     for idx in (a, b):
         idx.nprobe = 5
-        idx.set_scan_mode(idx.SCAN_LIST_MAJOR)
+        idx.set_scan_mode(idx.SCAN_LIST_MAJOR_F32)
     Da, Ia = a.search(xq, k)
     Db, Ib = b.search(xq, k)
     assert np.array_equal(Da, Db) and np.array_equal(Ia, Ib)
@@ -338,6 +362,6 @@ def test_ivfsq_list_major_row_norms_follow_the_rows(res):
     c.copy_lists(*_gpu_lists(a))
     c.copy_trained(a.get_trained())  # the same ranges again, now under stored rows: the norms are recomputed
     c.nprobe = 5
-    c.set_scan_mode(c.SCAN_LIST_MAJOR)
+    c.set_scan_mode(c.SCAN_LIST_MAJOR_F32)
     Dc, Ic = c.search(xq, k)
     assert np.array_equal(Da, Dc) and np.array_equal(Ia, Ic)

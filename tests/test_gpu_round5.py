@@ -285,3 +285,93 @@ def test_two_copy_codebook_of_the_pq_sweeps_keeps_the_bits(res, metric):
     Dr, Ir = idx.search(xq, k)
     assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
     idx.set_lmf_two_copies(False)
+
+
+# ------------------------------------------------------------------ scalar quantizer behind the f16 filter
+from faiss_amd import ScalarQuantizer as SQ  # noqa: E402
+
+
+@pytest.mark.parametrize("qtype,metric,by_residual,d", [
+    (SQ.QT_8bit, METRIC_L2, True, 128), (SQ.QT_8bit, METRIC_INNER_PRODUCT, True, 128), (SQ.QT_8bit, METRIC_L2, False, 96),
+    (SQ.QT_4bit, METRIC_L2, True, 64), (SQ.QT_6bit, METRIC_INNER_PRODUCT, False, 72), (SQ.QT_fp16, METRIC_L2, True, 128),
+    (SQ.QT_fp16, METRIC_INNER_PRODUCT, True, 40), (SQ.QT_8bit_uniform, METRIC_L2, True, 256), (SQ.QT_8bit, METRIC_L2, True, 500),
+    (SQ.QT_8bit_direct, METRIC_L2, False, 32),
+])
+def test_scalar_quantizer_results_do_not_depend_on_the_batch_size(res, qtype, metric, by_residual, d):
+    """the scalar quantizer's list-major scan summed in its own order (f32 MFMA chains), so a query's bits
+    depended on the batch it arrived in.  Behind the f16 filter (the IVFFlat sweeps over an fp16 copy of the centred codes +
+    the exact rerank with ivfsq_fused_kernel's arithmetic) a large batch returns what the same queries return one batch at a
+    time, for every code type, both metrics, with and without residual encoding, d up to 512 -- also with an IDSelector and
+    after incremental adds."""
+    nlist, k = 32, 40
+    xt, xb, xq = synthetic_dataset(d, 4000, 50000, 1500, seed=d + qtype)
+    if qtype == SQ.QT_8bit_direct:
+        sc = 255.0 / max(xt.max(), xb.max(), xq.max())
+        xt, xb, xq = (np.floor(np.abs(v) * sc).astype(np.float32) for v in (xt, xb, xq))
+    idx = faiss_amd.GpuIndexIVFScalarQuantizer(res, d, nlist, qtype, metric, by_residual)
+    idx.train(xt)
+    idx.add(xb[:40000])
+    idx.nprobe = 8
+    idx.set_scan_mode(idx.SCAN_LIST_MAJOR)
+    D, I = idx.search(xq, k)
+    assert idx.scan_info()[1] == 2 and idx.last_scan_arith() == 0
+    idx.set_scan_mode(idx.SCAN_QUERY_MAJOR)
+    for lo, hi in ((0, 30), (30, 31), (700, 1500)):
+        D1, I1 = idx.search(xq[lo:hi], k)
+        assert np.array_equal(D1, D[lo:hi]) and np.array_equal(I1, I[lo:hi]), (lo, hi)
+    # incremental adds keep the sweeps' copy alive; a selector search through the sweeps == through the query-major scan
+    idx.add(xb[40000:40003])
+    idx.add(xb[40003:])
+    sel = faiss_amd.IDSelectorRange(1000, 30000)
+    idx.set_scan_mode(idx.SCAN_LIST_MAJOR)
+    Ds, Is = idx.search(xq, k, params=faiss_amd.SearchParametersIVF(sel=sel))
+    assert idx.scan_info()[1] == 2
+    idx.set_scan_mode(idx.SCAN_QUERY_MAJOR)
+    Dq, Iq = idx.search(xq, k, params=faiss_amd.SearchParametersIVF(sel=sel))
+    assert np.array_equal(Ds, Dq) and np.array_equal(Is, Iq)
+
+
+@pytest.mark.parametrize("qtype,metric,by_residual,d,scale", [
+    (SQ.QT_8bit, METRIC_L2, True, 128, 1.0), (SQ.QT_8bit, METRIC_INNER_PRODUCT, True, 128, 1.0),
+    (SQ.QT_8bit, METRIC_L2, False, 64, 1.0), (SQ.QT_8bit, METRIC_L2, False, 64, -1.0),   # scale < 0: every coordinate + 20
+    (SQ.QT_4bit, METRIC_L2, True, 64, 1.0), (SQ.QT_6bit, METRIC_INNER_PRODUCT, False, 72, 1.0),
+    (SQ.QT_fp16, METRIC_L2, True, 128, 1.0), (SQ.QT_fp16, METRIC_INNER_PRODUCT, False, 128, 1.0),
+    (SQ.QT_8bit, METRIC_L2, True, 128, 300.0), (SQ.QT_8bit, METRIC_L2, True, 256, 1.0),
+])
+def test_scalar_quantizer_filter_error_bound_holds(res, qtype, metric, by_residual, d, scale):
+    """|estimate - exact| <= E_q for every probed row (the superset argument): the estimates of the sweeps (test hook) against
+    the distances the query-major scan returns for the same rows (k = all rows a query probes), with the band the bound
+    kernel grants -- also for data far from the origin (the offsets b' are then large against the distances) and large
+    values."""
+    nlist, nb, nq, nprobe = 16, 4000, 64, 3
+    xt, xb, xq = synthetic_dataset(d, 3000, nb, nq, seed=d + qtype)
+    if scale < 0:
+        xt, xb, xq = xt + np.float32(20.0), xb + np.float32(20.0), xq + np.float32(20.0)
+        scale = 1.0
+    xt, xb, xq = xt * np.float32(scale), xb * np.float32(scale), xq * np.float32(scale)
+    idx = faiss_amd.GpuIndexIVFScalarQuantizer(res, d, nlist, qtype, metric, by_residual)
+    idx.train(xt)
+    idx.add(xb)
+    idx.nprobe = nprobe
+    Dq, Iq = idx.quantizer_search(xq, nprobe)
+    sizes = np.array([idx.get_list_size(l) for l in range(nlist)])
+    lids = [idx.get_list_ids(l) for l in range(nlist)]
+    rows = np.array([int(sum(sizes[l] for l in Iq[q] if l >= 0)) for q in range(nq)])
+    assert rows.max() <= 2048
+    stride = int(nprobe * sizes.max())
+    est, band = idx.filter_dump(xq, 10, stride)
+    assert np.isfinite(band).all() and (band > 0).all()
+    idx.set_scan_mode(idx.SCAN_QUERY_MAJOR)
+    De, Ie = idx.search(xq, int(rows.max()))
+    worst = 0.0
+    for q in range(nq):
+        pos_ids = np.concatenate([lids[l] for l in Iq[q] if l >= 0])
+        assert len(pos_ids) == rows[q]
+        order = {int(i): r for r, i in enumerate(Ie[q, :rows[q]])}
+        exact = np.array([De[q, order[int(i)]] for i in pos_ids], dtype=np.float64)
+        err = np.abs(est[q, :rows[q]].astype(np.float64) - exact)
+        assert (err <= band[q]).all(), (q, float(err.max()), float(band[q]))
+        worst = max(worst, float(err.max() / band[q]))
+    print("qtype %d metric %d d %d scale %g: worst |estimate - exact| / band = %.5f (band %.3g, distances ~ %.3g)" % (
+        qtype, metric, d, scale, worst, float(band.mean()), float(np.abs(De[:, 0]).mean())))
+    assert worst > 1e-6
