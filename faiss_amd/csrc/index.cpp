@@ -2750,9 +2750,10 @@ void GpuIndexIVF::search_listmajor_filter_chunk_(int ni, int q0, const float* xq
         SpanGuard sg(&R, "ivf_lmf_prepare");
         const int dh = P.kind != 1 ? ivf_lmf_row_halfs(d) : (int)round_up(d, 16);
         lm_q16_.ensure((size_t)ni * dh * 2);
-        // (the scalar quantizer's operands come from launch_ivf_lmf_sq_prepare below; |q|^2 is still wanted)
-        launch_prep_queries(xq_pad, dpad_, ni, d, dpad_, lm_q16_.p, dh, lm_qflags_.as<uint32_t>(), lm_qn_.as<float>(),
-                            lm_scalar_.as<unsigned>(), R.stream);
+        // (the scalar quantizer's operands, flags and norms all come from launch_ivf_lmf_sq_prepare below)
+        if (P.kind != 2)
+            launch_prep_queries(xq_pad, dpad_, ni, d, dpad_, lm_q16_.p, dh, lm_qflags_.as<uint32_t>(), lm_qn_.as<float>(),
+                                lm_scalar_.as<unsigned>(), R.stream);
         P.xq16 = lm_q16_.p;
         P.ldq16 = dh;
         P.xqn = lm_qn_.as<float>();
@@ -2799,7 +2800,7 @@ void GpuIndexIVF::search_listmajor_filter_chunk_(int ni, int q0, const float* xq
     // workgroups -- two per CU, the 64 KB table -- serialise the tail: 0.25 -> 0.52 ms).  The tightening launch leaves a query
     // with more than kLmfFusedSelectN candidates (that many rows inside the band of its k-th best) to the redo path.
     static const char* pqfs = experiment_env("FAISS_AMD_LMF_PQ_FUSED_SELECT"); // timing experiment
-    const bool fused_select = (P.kind == 0 || (pqfs && atoi(pqfs) == 1)) && k <= kLmfFusedSelectK;
+    const bool fused_select = (P.kind != 1 || (pqfs && atoi(pqfs) == 1)) && k <= kLmfFusedSelectK;
     {
         // clamp of overflowed segments + the smallest superset the band allows (launch_ivf_lmf_tighten)
         SpanGuard sg(&R, "ivf_lmf_tighten");

@@ -21,6 +21,7 @@
 //             among equal distances (faiss/IndexIVF.cpp:642-655 + strict heap admission); the k winners
 //             are then ordered by (distance, id) (faiss/impl/ResultHandler.h:439-453).
 #include "kernels.h"
+#include "lmf_select.h"
 #include "wg_select.h"
 
 namespace faiss_amd {
@@ -932,9 +933,14 @@ __global__ void __launch_bounds__(256) lmf_rerank_sq_kernel(IvfLmParams p) {
     constexpr int W = SqChunk<CT>::WORDS;
     constexpr int CHB = W * 4;
     __shared__ float s_qb;
+    __shared__ u64 sel_k[kLmfFusedSelectN];
+    __shared__ uint32_t sel_wk[kLmfFusedSelectK];
+    __shared__ int64_t sel_wl[kLmfFusedSelectK];
+    const bool fin = p.fin_dis != nullptr;
     const int q = blockIdx.x, tid = threadIdx.x;
     const int np = p.nprobe;
-    const int n = (int)min((int64_t)p.cnt[q], p.stride);
+    int n = (int)min((int64_t)p.cnt[q], p.stride);
+    if (fin) n = min(n, kLmfFusedSelectN); // (more: the tightening launch listed the query for the redo)
     u64* kq = p.keys + (int64_t)q * p.stride;
     const uint16_t* cpr = p.cand_pr + (int64_t)q * p.stride;
     const float* xq = p.xq + (int64_t)q * p.ldq;
@@ -963,35 +969,68 @@ __global__ void __launch_bounds__(256) lmf_rerank_sq_kernel(IvfLmParams p) {
             const unsigned* src = (const unsigned*)(rp + (int64_t)c * 64 * CHB);
 #pragma unroll
             for (int u = 0; u < W; ++u) w[u] = src[u];
+            // the table entries of this chunk for the candidate's probe: the expressions of ivfsq_fused_kernel's table build.
+            // Whole chunks through 16-byte loads (the rows of xq / centroids / sq_s / sq_b are padded to 8 floats and more)
             float sv[16], av[16];
+            if (16 * c + 16 <= p.d) { // (workgroup-uniform)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int jx = 16 * c + e;
-                float a = 0.f, sj = 0.f;
-                if (jx < p.d) {
-                    if (CT != SQ_F16) sj = p.sq_s[jx];
-                    if (per_probe) {
-                        a = xq[jx] - cen[jx];
-                        if (CT != SQ_F16) a = a - p.sq_b_plain[jx];
-                    } else if (METRIC == METRIC_L2) {
-                        a = CT == SQ_F16 ? xq[jx] : xq[jx] - p.sq_b_plain[jx];
-                    } else {
-                        a = CT == SQ_F16 ? xq[jx] : xq[jx] * p.sq_s[jx];
+                for (int v4 = 0; v4 < 4; ++v4) {
+                    const f32x4 x4 = *(const f32x4*)(xq + 16 * c + 4 * v4);
+                    f32x4 s4 = f32x4{0.f, 0.f, 0.f, 0.f}, b4 = s4, c4 = s4;
+                    if (CT != SQ_F16) {
+                        s4 = *(const f32x4*)(p.sq_s + 16 * c + 4 * v4);
+                        b4 = *(const f32x4*)(p.sq_b_plain + 16 * c + 4 * v4);
+                    }
+                    if (per_probe) c4 = *(const f32x4*)(cen + 16 * c + 4 * v4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float a;
+                        if (per_probe) {
+                            a = x4[e] - c4[e];
+                            if (CT != SQ_F16) a = a - b4[e];
+                        } else if (METRIC == METRIC_L2) {
+                            a = CT == SQ_F16 ? x4[e] : x4[e] - b4[e];
+                        } else {
+                            a = CT == SQ_F16 ? x4[e] : x4[e] * s4[e];
+                        }
+                        av[4 * v4 + e] = a;
+                        sv[4 * v4 + e] = s4[e];
                     }
                 }
-                av[e] = a;
-                sv[e] = sj;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int jx = 16 * c + e;
+                    float a = 0.f, sj = 0.f;
+                    if (jx < p.d) {
+                        if (CT != SQ_F16) sj = p.sq_s[jx];
+                        if (per_probe) {
+                            a = xq[jx] - cen[jx];
+                            if (CT != SQ_F16) a = a - p.sq_b_plain[jx];
+                        } else if (METRIC == METRIC_L2) {
+                            a = CT == SQ_F16 ? xq[jx] : xq[jx] - p.sq_b_plain[jx];
+                        } else {
+                            a = CT == SQ_F16 ? xq[jx] : xq[jx] * p.sq_s[jx];
+                        }
+                    }
+                    av[e] = a;
+                    sv[e] = sj;
+                }
             }
             sq_fold<METRIC, CT, 0>(w, sv, av, acc);
         }
         float dis = acc[0] + acc[1];
         if (METRIC != METRIC_L2) dis = (dis + qb) + (p.sq_by_residual ? p.coarse_dis[(int64_t)q * np + pr] : 0.f);
-        kq[i] = ((u64)ordkey<METRIC>(dis) << 32) | (u64)pos;
+        const u64 key = ((u64)ordkey<METRIC>(dis) << 32) | (u64)pos;
+        if (fin) sel_k[i] = key;
+        else kq[i] = key;
     }
+    if (fin) lmf_select_tail<256>(p, q, n, sel_k, cpr, sel_wk, sel_wl);
 }
 void launch_ivf_lmf_rerank_sq(const IvfLmParams& p, hipStream_t stream) {
     if (p.nq == 0) return;
     FA_THROW_IF_NOT(p.kind == 2 && p.arena_codes && p.sq_s && p.sq_b_plain && p.centroids && p.keys && p.cand_pr && p.cnt);
+    FA_THROW_IF_NOT(!p.fin_dis || (p.fin_ids && p.arena_ids && p.k <= kLmfFusedSelectK));
     const dim3 grid((unsigned)p.nq), block(256);
     const bool l2 = p.metric == METRIC_L2;
 #define FA_RRSQ(CT_)                                                                                        \

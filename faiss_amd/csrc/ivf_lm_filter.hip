@@ -29,6 +29,7 @@
 // Reference behaviour kept: faiss/gpu/impl/IVFInterleaved.cuh:33-224, PQScanMultiPassNoPrecomputed-inl.cuh:173-270
 // (exhaustive scan of the probed lists, k best under (distance, scan position)).
 #include "kernels.h"
+#include "lmf_select.h"
 #include <type_traits>
 
 namespace faiss_amd {
@@ -1547,12 +1548,12 @@ void launch_ivf_lmf_pq_prepare(const IvfLmParams& p, float* xn_bound, hipStream_
 // xn_bound[q] = max over the probes of |B|^2 (the operand's norm: the matrix pipe's share of the error band), an_bound[q] = max of
 // |a|^2 (L2) / |q|^2 (IP) (the fp32 chains' share); qflags[q] |= 1 when a B coordinate leaves the fp16 range.  P = dh / 8 lanes
 // (a power of two, 2 .. 64) per pair, one 8-coordinate operand piece each.
-__global__ void __launch_bounds__(256) lmf_sq_prepare_kernel(IvfLmParams p, float* __restrict__ xn_bound, float* __restrict__ an_bound,
-                                                             int P) {
+template <int P>
+__global__ void __launch_bounds__(256) lmf_sq_prepare_kernel(IvfLmParams p, float* __restrict__ xn_bound, float* __restrict__ an_bound) {
     const int np = p.nprobe;
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t pair = t / P;
-    const int sub = (int)(t - pair * P);
+    const int64_t pair = t / P; // (P a power of two: a shift)
+    const int sub = (int)(t & (P - 1));
     if (pair >= (int64_t)p.nq * np) return; // (whole groups leave together: P divides 64)
     const int q = (int)(pair / np);
     const bool l2 = p.metric == METRIC_L2;
@@ -1562,23 +1563,31 @@ __global__ void __launch_bounds__(256) lmf_sq_prepare_kernel(IvfLmParams p, floa
     bool bad = false;
     if (8 * sub < (int)p.ldh) {
         half8 o;
+        // (rows of xq / centroids / the decoder tables are padded to multiples of 8 floats with zeros: whole 16-byte loads)
+        float x[8], sj[8], bj[8], cj[8];
+        const bool in = 8 * sub < p.dpad;
+#pragma unroll
+        for (int v4 = 0; v4 < 2; ++v4) {
+            const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 x4 = in ? *(const f32x4*)(p.xq + (int64_t)q * p.ldq + 8 * sub + 4 * v4) : z;
+            const f32x4 s4 = in ? *(const f32x4*)(p.sq_s + 8 * sub + 4 * v4) : z;
+            const f32x4 b4 = in ? *(const f32x4*)(p.sq_b + 8 * sub + 4 * v4) : z;
+            const f32x4 c4 = in && res ? *(const f32x4*)(p.centroids + l * p.ldc + 8 * sub + 4 * v4) : z;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[4 * v4 + e] = x4[e], sj[4 * v4 + e] = s4[e], bj[4 * v4 + e] = b4[e], cj[4 * v4 + e] = c4[e];
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int jx = 8 * sub + e;
             float B = 0.f;
-            if (jx < p.d) {
-                const float x = p.xq[(int64_t)q * p.ldq + jx];
-                const float sj = p.sq_s[jx], bj = p.sq_b[jx];
+            if (8 * sub + e < p.d) {
                 if (l2) {
-                    float a = x;
-                    if (res) a = a - p.centroids[l * p.ldc + jx];
-                    a = a - bj;
+                    const float a = (x[e] - cj[e]) - bj[e];
                     an = __fmaf_rn(a, a, an);
-                    B = a * sj;
+                    B = a * sj[e];
                 } else {
-                    an = __fmaf_rn(x, x, an);
-                    qb = __fmaf_rn(x, bj, qb);
-                    B = x * sj;
+                    an = __fmaf_rn(x[e], x[e], an);
+                    qb = __fmaf_rn(x[e], bj[e], qb);
+                    B = x[e] * sj[e];
                 }
             }
             if (!(fabsf(B) <= 65000.f)) bad = true;
@@ -1587,6 +1596,7 @@ __global__ void __launch_bounds__(256) lmf_sq_prepare_kernel(IvfLmParams p, floa
         }
         *(half8*)((_Float16*)p.pair16 + pair * p.ldh + 8 * sub) = o;
     }
+#pragma unroll
     for (int off = 1; off < P; off <<= 1) {
         an += __shfl_xor(an, off, 64);
         bn += __shfl_xor(bn, off, 64);
@@ -1605,13 +1615,16 @@ __global__ void __launch_bounds__(256) lmf_sq_prepare_kernel(IvfLmParams p, floa
 void launch_ivf_lmf_sq_prepare(const IvfLmParams& p, float* xn_bound, float* an_bound, hipStream_t stream) {
     if (p.nq == 0) return;
     FA_THROW_IF_NOT(p.kind == 2 && p.pair16 && p.pair_xh && p.qflags && p.sq_s && p.sq_b && p.centroids && p.ldh % 16 == 0 && p.ldh <= 512);
-    int P = 2;
-    while (P * 8 < p.ldh) P <<= 1;
+    FA_THROW_IF_NOT(p.dpad % 8 == 0 && p.ldq % 4 == 0 && p.ldc % 4 == 0);
     HIP_CHECK(hipMemsetAsync(xn_bound, 0, (size_t)p.nq * 4, stream));
     HIP_CHECK(hipMemsetAsync(an_bound, 0, (size_t)p.nq * 4, stream));
     HIP_CHECK(hipMemsetAsync(const_cast<uint32_t*>(p.qflags), 0, (size_t)p.nq * 4, stream));
-    hipLaunchKernelGGL(lmf_sq_prepare_kernel, dim3((unsigned)div_up((size_t)p.nq * p.nprobe * P, 256)), dim3(256), 0, stream, p,
-                       xn_bound, an_bound, P);
+    const int pieces = (int)p.ldh / 8; // 2 .. 64
+    const int P = pieces <= 16 ? 16 : pieces <= 32 ? 32 : 64;
+    const dim3 grid((unsigned)div_up((size_t)p.nq * p.nprobe * P, 256)), block(256);
+    if (P == 16) hipLaunchKernelGGL(lmf_sq_prepare_kernel<16>, grid, block, 0, stream, p, xn_bound, an_bound);
+    else if (P == 32) hipLaunchKernelGGL(lmf_sq_prepare_kernel<32>, grid, block, 0, stream, p, xn_bound, an_bound);
+    else hipLaunchKernelGGL(lmf_sq_prepare_kernel<64>, grid, block, 0, stream, p, xn_bound, an_bound);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -1621,53 +1634,6 @@ void launch_ivf_lmf_sq_prepare(const IvfLmParams& p, float* xn_bound, float* an_
 // IVFFlat: the arithmetic of ivfflat_fused_kernel -- lane ln of the group owns the 16-byte chunks ln, ln + 8, ... of the row
 // and keeps one sequential fmaf chain of (q - y)^2 (inner product: q * y) over them; the eight partial sums meet in the
 // xor butterfly ((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7)).
-// The k best of a query's re-derived candidates, by the workgroup that holds them (IvfLmParams::fin_dis): keys kl[0 .. n) in
-// LDS (ordkey << 32 | scan position, all distinct), their probe numbers in cpr.  Winners = the k smallest keys (rank by
-// counting: every thread reads the same kl[j], an LDS broadcast); labels from the stored ids; output order by (distance,
-// label) among the winners, ties of both by their winner slot -- what select_k_kernel / wave_select_kernel produce.
-// wk / wl: LDS room for kLmfFusedSelectK winners.  Called by all threads of the workgroup.
-template <int THREADS>
-__device__ __forceinline__ void lmf_select_tail(const IvfLmParams& p, int q, int n, const u64* kl, const uint16_t* cpr, uint32_t* wk,
-                                                int64_t* wl) {
-    const int tid = threadIdx.x, np = p.nprobe, k = p.k;
-    __syncthreads();
-    for (int i = tid; i < n; i += THREADS) {
-        const u64 ki = kl[i];
-        int r = 0;
-        for (int j = 0; j < n; ++j) r += kl[j] < ki ? 1 : 0;
-        if (r < k) {
-            const uint32_t pos = (uint32_t)ki;
-            const int pr = (int)cpr[i];
-            const int64_t l = p.coarse_ids[(int64_t)q * np + pr];
-            wk[r] = (uint32_t)(ki >> 32);
-            wl[r] = p.arena_ids[p.list_start[l] + (pos - p.prefix[(int64_t)q * (np + 1) + pr])];
-        }
-    }
-    __syncthreads();
-    const int nwin = min(n, k);
-    const float pad = neutral_distance(p.metric);
-    float* od = p.fin_dis + (int64_t)q * k;
-    int64_t* oi = p.fin_ids + (int64_t)q * k;
-    for (int i = tid; i < k; i += THREADS) {
-        if (i >= nwin) { // fewer candidates than k: the tail is padding
-            od[i] = pad;
-            oi[i] = -1;
-            continue;
-        }
-        const uint32_t a = wk[i];
-        const int64_t ia = wl[i];
-        int r = 0;
-        for (int j = 0; j < nwin; ++j) {
-            const uint32_t b = wk[j];
-            const int64_t ib = wl[j];
-            r += (b < a || (b == a && (ib < ia || (ib == ia && j < i)))) ? 1 : 0;
-        }
-        const bool real = a < kInvalidOrdKey;
-        od[r] = real ? unordkey_rt(p.metric, a) : pad;
-        oi[r] = real ? ia : -1;
-    }
-}
-
 template <int METRIC>
 __global__ void __launch_bounds__(256) lmf_rerank_flat_kernel(IvfLmParams p) {
     __shared__ u64 sel_k[kLmfFusedSelectN];
