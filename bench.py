@@ -48,9 +48,9 @@ PEAK_F16_MFMA_TFLOPS = 2500.0  # same guide: dense f16/bf16 MFMA (v_mfma_f32_32x
 PEAK_HBM_GBS = 8000.0
 # committed rocprofv3 --pmc summaries (tools/profile_round.sh; one file per profiled search loop)
 PROFILE_DIR = os.path.join(ROOT, "profiles")
-PROFILE_JSON = {"flat": "r05_pmc_flat.json", "ivfpq": "r05_pmc_ivfpq_1m.json", "ivfsq": "r05_pmc_ivfsq_1m.json",
-                "ivfflat": "r05_pmc_ivfflat_1m.json", "ivfflat_10m": "r05_pmc_ivfflat_10m.json",
-                "ivfpq_10m": "r05_pmc_ivfpq_10m.json", "ivfpq_100m": "r05_pmc_ivfpq_100m.json"}
+PROFILE_JSON = {"flat": "r5_pmc_flat.json", "ivfpq": "r5_pmc_ivfpq_1m.json", "ivfsq": "r5_pmc_ivfsq_1m.json",
+                "ivfflat": "r5_pmc_ivfflat_1m.json", "ivfflat_10m": "r5_pmc_ivfflat_10m.json",
+                "ivfpq_10m": "r5_pmc_ivfpq_10m.json", "ivfpq_100m": "r5_pmc_ivfpq_100m.json"}
 
 
 def log(*a):
@@ -397,14 +397,15 @@ def lmf_roofline(spans, kind, nb, row_bytes, profile=None):
     figure of the query-major formulation for comparison."""
     (m1, n1), (m2, n2) = spans["ivf_lmf_sweep_min"], spans["ivf_lmf_sweep_collect"]
     sweep_ms = m2 / max(n2, 1)  # sweep 2 reads every probed row (sweep 1 may sample the 32-row blocks of long lists)
-    per_row = (2.0 * D + 4.0) if kind == "ivfflat" else (float(row_bytes) + 4.0)
+    # (the scalar quantizer's sweeps read an fp16 copy of its centred codes: the IVFFlat kernel, the IVFFlat bytes)
+    per_row = (2.0 * D + 4.0) if kind in ("ivfflat", "ivfsq") else (float(row_bytes) + 4.0)
     unique = nb * per_row
     ach = unique / (sweep_ms * 1e-3) / 1e9
     flops = 2.0 * NQ * NPROBE * (nb / float(NLIST)) * D
     alg_bytes = float(NPROBE) * nb / NLIST * row_bytes * NQ
     search_ms = sum(v[0] for k, v in spans.items() if k.startswith("ivf_lm") or k in ("select_k_kernel",)) / max(n2, 1)
-    return {"bound": "hbm", "kernel": ("ivf_lmf_flat_kernel" if kind == "ivfflat" else "ivf_lmf_pq_kernel") +
-                                       " in sweep 2 (collect: every probed row; sweep 1 = the same loop, granule minima, every 2nd block of long lists)",
+    return {"bound": "hbm", "kernel": ("ivf_lmf_flat_kernel" if kind in ("ivfflat", "ivfsq") else "ivf_lmf_pq_kernel") +
+                                       " in sweep 2 (collect: every probed row; sweep 1 = the same loop over a quarter of every work item's rows: granule minima)",
             "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4),
             "avg_kernel_ms": round(sweep_ms, 3), "launches": int(n2),
             "sweep1_avg_kernel_ms": round(m1 / max(n1, 1), 3),

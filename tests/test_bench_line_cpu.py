@@ -1,6 +1,6 @@
 """bench.py prints ONE line the driver can parse: the compact view (< 4 KB) of the full record, which goes to
 bench_detail.json.  Round 4's 25 KB line came back as `parsed: null`; this pins the assembler on that very record
-(profiles/r05_bench_line.json, the full line of the round-4 run) and on degenerate records."""
+(profiles/r04_final_bench_line.json, the full line of the round-4 run) and on degenerate records."""
 import json
 import os
 import sys
@@ -14,7 +14,7 @@ REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 
 
 def canned():
-    return json.loads(open(os.path.join(ROOT, "profiles", "r05_bench_line.json")).read())
+    return json.loads(open(os.path.join(ROOT, "profiles", "r04_final_bench_line.json")).read())
 
 
 def test_compact_line_is_small_and_round_trips():
