@@ -6,13 +6,16 @@
 #   3. one --pmc pass per counter group (never combined with runtime / sys tracing) on the same search loops:
 #      <TAG>_pmc_<leg>.{txt,json} (bench.py reads its roofline.traffic numbers from the JSON summaries).
 TAG=${1:-r5}
+MODE=${2:-all} # "stats": the per-leg kernel statistics only
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
+if [ "$MODE" != "stats" ]; then
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_kt -o kt -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 > $O/${TAG}_profiled_bench.log 2>&1
 grep '^{' $O/${TAG}_profiled_bench.log | tail -1 > $O/${TAG}_profiled_bench_line.json
 find $O/${TAG}_kt -name "*kernel_stats.csv" -exec cp {} $O/${TAG}_bench_kernel_stats.csv \;
 rm -rf $O/${TAG}_kt
+fi
 G_FETCH="FETCH_SIZE"
 G_SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE"
 leg() { # name script nb filter
@@ -21,17 +24,27 @@ leg() { # name script nb filter
   python - <<PY
 import csv, glob
 rows = []
-for f in glob.glob("$O/${TAG}_${name}_kt/**/*kernel_stats.csv", recursive=True):
-    rows += [r for r in csv.DictReader(open(f))]
-keep = [r for r in rows if any(s in r["Name"] for s in ("ivf", "flat_", "select", "lmf", "lm_", "prep_queries", "convert", "finish"))]
-keep.sort(key=lambda r: -float(r["TotalDurationNs"]))
+for f in glob.glob("$O/${TAG}_${name}_kt/**/*kernel_trace.csv", recursive=True):
+    rows += [(r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(f))]
+rows.sort(key=lambda r: r[1])
+# the SEARCH loop only: from 1 ms before the first plan launch of an IVF leg (its coarse quantizer runs ahead of the plan; the
+# build ended long before: host-side prints, query upload); the flat leg has no build kernels worth the name
+plan = [r[1] for r in rows if "lm_plan_kernel" in r[0]]
+t0 = plan[0] - 1000000 if plan else 0
+agg = {}
+for name, a, b in rows:
+    if a >= t0:
+        e = agg.setdefault(name, [0, 0, 1 << 62, 0])
+        e[0] += 1; e[1] += b - a; e[2] = min(e[2], b - a); e[3] = max(e[3], b - a)
+nsearch = max(1, len(plan)) if plan else 6
 with open("$O/${TAG}_${name}_kernel_stats.csv", "w") as fo:
-    fo.write("# rocprofv3 --kernel-trace --stats of tools/$script 5 $nb (6 searches of 10 000 queries after the build; build kernels left out)\n")
-    fo.write("kernel,calls,total_ns,average_ns,min_ns,max_ns\n")
-    for r in keep:
-        fo.write('"%s",%s,%s,%s,%s,%s\n' % (r["Name"][:140], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"]))
+    fo.write("# rocprofv3 --kernel-trace of tools/$script 5 $nb: the %d searches of 10 000 queries behind the build (dispatches from the first search on)\n" % nsearch)
+    fo.write("kernel,calls,calls_per_search,total_ns,average_ns,min_ns,max_ns\n")
+    for k, e in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        fo.write('"%s",%d,%.2f,%d,%.1f,%d,%d\n' % (k[:150], e[0], e[0] / nsearch, e[1], e[1] / e[0], e[2], e[3]))
 PY
   rm -rf $O/${TAG}_${name}_kt
+  if [ "$MODE" = "stats" ]; then return; fi
   local i=0 dirs=""
   for grp in "$G_FETCH" "$G_SQ"; do
     i=$((i + 1))
