@@ -2815,6 +2815,11 @@ void GpuIndexIVF::search_listmajor_filter_chunk_(int ni, int q0, const float* xq
     }
     {
         SpanGuard sg(&R, "ivf_lmf_rerank");
+        static const char* rr_old = experiment_env("FAISS_AMD_LMF_RERANK_WG"); // A/B: 1 = the workgroup-per-query kernel
+        if (P.kind == 1 && !(rr_old && atoi(rr_old) == 1)) {
+            P.rr_counter = lm_scalar_.as<uint32_t>() + 8;
+            P.rr_blocks = R.num_cus;
+        }
         if (P.kind == 2) launch_ivf_lmf_rerank_sq(P, R.stream);
         else launch_ivf_lmf_rerank(P, R.stream);
     }

@@ -1848,6 +1848,105 @@ __global__ void __launch_bounds__(RRQ_THREADS) lmf_rerank_pq_kernel(IvfLmParams 
     }
     if (fin) lmf_select_tail<RRQ_THREADS>(p, q, n, sel_k, cpr, sel_wk, sel_wl);
 }
+// PQ64 over d = 128 (round 5): one WAVEFRONT per query, the fp32 codebook in LDS for the life of a 16-wave workgroup per CU.
+// The kernel above gives every query a 512-thread workgroup that re-reads the 128 KB codebook from L2 and writes the query's
+// 64 KB table into LDS before it looks at ~150 candidates: 0.24 ms per 10 000 queries whatever the database size -- a
+// quarter of the IVF4096,PQ64 search at nb = 1M.  Here no table is stored: a query needs (a) the grid, i.e. B = sum_m max_c
+// |entry(m, c)| -- lane m walks the 256 entries of sub-quantizer m (codebook reads from LDS, the running maximum in a
+// register, no atomics, no barrier) -- and (b) the 64 entries its candidates' codes select, recomputed per candidate from the
+// LDS codebook: lane = candidate, the row's 64 stored bytes in four 16-byte loads, all of a pass's metadata loads in flight
+// together.  Same arithmetic as above and as ivfpq_fused_kernel: entries as fmaf chains from 0, B summed in sub-quantizer
+// order, entries rounded to the grid where they are looked up, the sum order-free.
+constexpr int RW_THREADS = 1024;
+template <int METRIC>
+__global__ void __launch_bounds__(RW_THREADS) lmf_rerank_pq64_kernel(IvfLmParams p, uint32_t* __restrict__ qcounter) {
+    constexpr int M = 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* cbt = (float2*)smem;                 // [256][64] entries (two coordinates each): 128 KB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float2* qx = (float2*)(smem + 256 * 64 * 8) + wave * 64; // this wave's query, coordinate pairs by sub-quantizer
+    {
+        const uint4* src = (const uint4*)p.pq_t;
+        uint4* dst = (uint4*)smem;
+        for (int i = tid; i < 256 * 64 * 8 / 16; i += RW_THREADS) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int np = p.nprobe;
+    for (;;) {
+        int q = 0;
+        if (lane == 0) q = (int)atomicAdd(qcounter, 1u);
+        q = __builtin_amdgcn_readfirstlane(q);
+        if (q >= p.nq) break;
+        const int n = (int)min((int64_t)p.cnt[q], p.stride);
+        if (n == 0) continue;
+        u64* kq = p.keys + (int64_t)q * p.stride;
+        const uint16_t* cpr = p.cand_pr + (int64_t)q * p.stride;
+        const float2 x2 = *(const float2*)(p.xq + (int64_t)q * p.ldq + 2 * lane);
+        __builtin_amdgcn_wave_barrier(); // (the reads of the previous query's pairs were issued: LDS keeps a wave's order)
+        qx[lane] = x2;
+        // ---- (a) max_c |entry(m = lane, c)|, as bit patterns (NaN beats every number, like the oracle)
+        uint32_t mx = 0u;
+#pragma unroll 8
+        for (int c = 0; c < 256; ++c) {
+            const float2 e = cbt[c * M + lane];
+            const float acc = __fmaf_rn(x2.y, e.y, __fmaf_rn(x2.x, e.x, 0.f));
+            mx = max(mx, __float_as_uint(fabsf(acc)));
+        }
+        float B = 0.f; // in sub-quantizer order, in every lane
+#pragma unroll
+        for (int m = 0; m < M; ++m) B = B + __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)mx, m));
+        float delta = 0.f, inv = 0.f;
+        const bool on = pq_lut_grid(B, &delta, &inv);
+        // ---- (b) candidates, 64 per pass
+        for (int base = 0; base < n; base += 64) {
+            const int i = base + lane;
+            const bool valid = i < n;
+            float s = 0.f, dis0 = 0.f, t2 = 0.f;
+            uint32_t pos = 0;
+            if (valid) {
+                pos = (uint32_t)kq[i];
+                const int pr = (int)cpr[i];
+                const int64_t l = p.coarse_ids[(int64_t)q * np + pr];
+                const int64_t row = p.list_start[l] + (pos - p.prefix[(int64_t)q * (np + 1) + pr]);
+                dis0 = p.coarse_dis[(int64_t)q * np + pr];
+                if (METRIC == METRIC_L2) t2 = p.arena_t2[row];
+                const int lrot = (int)(row & 63);
+                if (on) {
+                    // the row's 64 stored bytes: chunk ch holds the stored bytes 16 ch .. 16 ch + 15 (kernels.h pq_code_offset);
+                    // stored byte x is the code of sub-quantizer (x + row) mod 64
+                    const uint8_t* rp = p.arena_codes + (size_t)(row >> 6) * 64 * M + (size_t)lrot * 16;
+                    uint4 w[4];
+#pragma unroll
+                    for (int ch = 0; ch < 4; ++ch) w[ch] = *(const uint4*)(rp + ch * 1024);
+#pragma unroll
+                    for (int ch = 0; ch < 4; ++ch) {
+                        const unsigned ww[4] = {w[ch].x, w[ch].y, w[ch].z, w[ch].w};
+#pragma unroll
+                        for (int b = 0; b < 16; ++b) {
+                            const int m = (16 * ch + b + lrot) & (M - 1);
+                            const unsigned code = (ww[b >> 2] >> (8 * (b & 3))) & 255u;
+                            const float2 e = cbt[(int)code * M + m];
+                            const float2 xm = qx[m];
+                            const float ent = __fmaf_rn(xm.y, e.y, __fmaf_rn(xm.x, e.x, 0.f));
+                            s = s + __builtin_rintf(ent * inv) * delta;
+                        }
+                    }
+                } else {
+                    // no grid (NaN / inf / all-zero tables): the plain sum in sub-quantizer order, like the oracle
+                    for (int m = 0; m < M; ++m) {
+                        const unsigned code = p.arena_codes[pq_code_offset(M, row, m)];
+                        const float2 e = cbt[(int)code * M + m];
+                        const float2 xm = qx[m];
+                        s = s + __fmaf_rn(xm.y, e.y, __fmaf_rn(xm.x, e.x, 0.f));
+                    }
+                }
+                const float dis = METRIC == METRIC_L2 ? __fmaf_rn(-2.f, s, dis0 + t2) : dis0 + s;
+                kq[i] = ((u64)ordkey<METRIC>(dis) << 32) | (u64)pos;
+            }
+        }
+    }
+}
 void launch_ivf_lmf_rerank(const IvfLmParams& p, hipStream_t stream) {
     if (p.nq == 0) return;
     // (fused selection: launch_ivf_lmf_tighten left at most kLmfFusedSelectN candidates or listed the query for the redo)
@@ -1856,6 +1955,21 @@ void launch_ivf_lmf_rerank(const IvfLmParams& p, hipStream_t stream) {
     if (p.kind == 0) {
         if (p.metric == METRIC_L2) hipLaunchKernelGGL(lmf_rerank_flat_kernel<METRIC_L2>, grid, block, 0, stream, p);
         else hipLaunchKernelGGL(lmf_rerank_flat_kernel<METRIC_INNER_PRODUCT>, grid, block, 0, stream, p);
+    } else if (p.M == 64 && p.dsub == 2 && !p.fin_dis && p.rr_counter) {
+        // the bench shape: a wavefront per query, the codebook in LDS (lmf_rerank_pq64_kernel)
+        FA_THROW_IF_NOT((p.metric != METRIC_L2 || p.arena_t2) && p.pq_t && p.ldq % 2 == 0);
+        const int lds = 256 * 64 * 8 + (RW_THREADS / 64) * 64 * 8;
+        const int blocks = std::max(1, std::min(p.rr_blocks, (p.nq + RW_THREADS / 64 - 1) / (RW_THREADS / 64)));
+        HIP_CHECK(hipMemsetAsync(p.rr_counter, 0, 4, stream));
+        if (p.metric == METRIC_L2) {
+            HIP_CHECK(hipFuncSetAttribute((const void*)lmf_rerank_pq64_kernel<METRIC_L2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            hipLaunchKernelGGL(lmf_rerank_pq64_kernel<METRIC_L2>, dim3((unsigned)blocks), dim3(RW_THREADS), lds, stream, p, p.rr_counter);
+        } else {
+            HIP_CHECK(hipFuncSetAttribute((const void*)lmf_rerank_pq64_kernel<METRIC_INNER_PRODUCT>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            hipLaunchKernelGGL(lmf_rerank_pq64_kernel<METRIC_INNER_PRODUCT>, dim3((unsigned)blocks), dim3(RW_THREADS), lds, stream, p,
+                               p.rr_counter);
+        }
     } else {
         FA_THROW_IF_NOT((p.metric != METRIC_L2 || p.arena_t2) && p.pq_t);
         const int lds = ((p.M * 1024 + p.M * 4 + 16 + 15) & ~15) + (p.fin_dis ? kLmfFusedSelectN * 8 + kLmfFusedSelectK * 12 : 0);

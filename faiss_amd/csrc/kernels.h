@@ -529,6 +529,10 @@ struct IvfLmParams {
     // the rule of select_k_kernel / wave_select_kernel -- and writes the result rows; no selection launch follows
     float* fin_dis;
     int64_t* fin_ids;
+    // IVFPQ rerank, PQ64 over d = 128 (lmf_rerank_pq64_kernel): query counter the wavefronts draw from (null: the
+    // workgroup-per-query kernel serves the shape too), workgroups to launch (one per CU)
+    uint32_t* rr_counter;
+    int rr_blocks;
     const int64_t* arena_ids;
 };
 constexpr int kLmfFusedSelectK = 256, kLmfFusedSelectN = 1024;
