@@ -259,8 +259,9 @@ def test_ivf4096_1m_vs_oracle_and_live_reference(res, sift_shaped, kind):
 def test_ivfsq8_4096_1m_vs_oracle_and_live_reference(res, sift_shaped):
     """IVF4096,SQ8 (QT_8bit, residual encoding) at the metric's database size: the reference index with the GPU-trained
     quantizers is filled by its own add(), its lists are loaded into a second GPU index (copyFrom); nprobe 32, k 100.
-    The automatic choice for 10 000 queries is the list-major scan (ivf_listmajor.hip, kind 2); both scans are compared
-    with the reference on ALL queries and bit-exactly with their own restatement on 48 of them."""
+    The automatic choice for 10 000 queries is the list-major scan behind the f16 filter (round 5: the bits of the query-major
+    scan); the query-major scan, the filter path and round 3's f32 list-major scan are compared with the reference on ALL
+    queries and bit-exactly with their own restatement on 48 of them."""
     if not Ref.available():
         pytest.skip("oracle/_ref not shipped")
     from faiss_amd import ScalarQuantizer as SQ
@@ -282,11 +283,11 @@ def test_ivfsq8_4096_1m_vs_oracle_and_live_reference(res, sift_shaped):
     vmin, vdiff = Oracle.sq_unpack(SQ.QT_8bit, D_, trained)
     sel = np.random.RandomState(4).choice(NQ, 48, replace=False)
     D, I = g2.search(xq, K)
-    assert g2.last_scan_arith() == 1, "10 000 queries x 32 probes over 4096 lists: the list-major scan"
-    for mode in (g2.SCAN_QUERY_MAJOR, g2.SCAN_LIST_MAJOR):
+    assert g2.scan_info()[1] == 2 and g2.last_scan_arith() == 0, "10 000 queries x 32 probes over 4096 lists: the list-major scan behind the filter"
+    for mode in (g2.SCAN_QUERY_MAJOR, g2.SCAN_LIST_MAJOR, g2.SCAN_LIST_MAJOR_F32):
         g2.set_scan_mode(mode)
         Dm, Im = g2.search(xq, K)
-        assert g2.scan_info()[1] == mode
+        assert g2.scan_info()[1] == min(mode, 2)
         st = check_knn(Dm, Im, Dr, Ir, rtol=1e-4, max_tie_frac=2e-3, name="ivfsq8 1M scan mode %d vs live reference" % mode)
         _report("ivfsq8 1M x 10k (scan mode %d)" % mode, st)
         assert st["max_rel_err"] < 2e-5
