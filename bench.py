@@ -955,16 +955,15 @@ def compact_leg(name, leg):
     c = leg.get("cpu_baseline")
     if isinstance(c, dict) and "value" in c:
         out["cpu_qps"] = c["value"]
-        out["cpu_queries"] = c.get("queries", NQ)
+        if c.get("queries", NQ) != NQ:
+            out["cpu_queries"] = c["queries"]  # (the CPU baseline ran a bounded sample of the queries)
         pv = c.get("parity_vs_gpu") or {}
         if "real_mismatches" in pv:
             out["real_mismatches"] = pv["real_mismatches"] if isinstance(pv["real_mismatches"], int) else "FAILED"
-            out["max_rel_dist_err"] = pv.get("max_rel_dist_err")
     par = leg.get("parity")
     if isinstance(par, dict):
         out["oracle_sample_bit_exact"] = bool(par.get("sampled_queries_bit_exact_vs_oracle_on_probed_lists",
                                                       par.get("merged_bit_exact") and all(par.get("per_shard_bit_exact", [False]))))
-        out["oracle_sample_queries"] = par.get("sampled_queries")
     return {k: v for k, v in out.items() if v is not None}
 
 
@@ -1008,8 +1007,7 @@ def compact_line(detail, detail_path=DETAIL_NAME):
     if legs:
         top["legs"] = legs
     top["detail"] = detail_path
-    drop_order = ("oracle_sample_queries", "cpu_queries", "max_rel_dist_err", "steps", "kernel_ms", "recall_at_100", "scan",
-                  "workload")
+    drop_order = ("cpu_queries", "steps", "kernel_ms", "recall_at_100", "scan", "workload")
     s = json.dumps(top, separators=(",", ":"))
     for key in drop_order:
         if len(s) < MAX_LINE_BYTES:

@@ -21,7 +21,7 @@ def test_compact_line_is_small_and_round_trips():
     full = canned()
     assert len(json.dumps(full)) > 20000  # the record that broke the driver's parser
     s = bench.compact_line(full)
-    assert "\n" not in s and len(s) < bench.MAX_LINE_BYTES
+    assert "\n" not in s and len(s) < bench.MAX_LINE_BYTES - 512  # (head room for longer CPU model names / more digits)
     line = json.loads(s)
     for k in REQUIRED:
         assert k in line, k
