@@ -2386,7 +2386,15 @@ bool GpuIndexIVF::list_major_rule(idx_t n, int nprobe_now, idx_t k, bool has_sel
     const double stream = pairs * avg_len * (double)ref_row_bytes_();
     const double kq = 0.5 + 0.5 * std::min<double>((double)k, 1000.0) / 100.0; // candidates per query grow with k
     double est_qm, est_lm; // ms
-    if (fused_kind_() != 1) { // IVFFlat, and the scalar quantizer (the same sweeps over the fp16 copy of its codes)
+    if (fused_kind_() == 1 && lmf_sweep_kind_() == 2) {
+        // IVFPQ through its decoded residuals (round 5; tools/pq_dim_sweep.py, profiles/r5_pq_dim_sweep.txt).  Query-major: the
+        // fused scan is bound by its table lookups -- 2.6e12 per second with the 16-byte code chunks of M = 32 / 64, 0.77e12
+        // otherwise (M = 48: 4.95 ms, M = 128: 12.8 ms for 160 k pairs x 488 rows).  List-major: the IVFFlat sweeps over 2 dh + 4
+        // bytes per row + a rerank whose per-query table grows with M.
+        const double lookups = pairs * avg_len * (double)fused_M_();
+        est_qm = 0.13 + lookups / ((fused_M_() == 32 || fused_M_() == 64) ? 2.6e9 : 0.77e9);
+        est_lm = 0.30 + 0.17e-3 * kq * (double)n + 2.0 * touched * (double)nstored_ * (2.0 * ivf_lmf_row_halfs(d) + 4.0) / 4.0e9;
+    } else if (lmf_sweep_kind_() != 1) { // IVFFlat and the scalar quantizer: the same sweeps over an fp16 copy of the rows / codes
         est_qm = 0.12 + stream / 4.9e9;
         est_lm = 0.27 + 0.10e-3 * kq * (double)n + 2.0 * touched * (double)nstored_ * (2.0 * ivf_lmf_row_halfs(d) + 4.0) / 4.0e9;
     } else {
@@ -2464,6 +2472,7 @@ void GpuIndexIVF::search_listmajor_(int ni, const float* xq_pad, const idx_t* c_
         }
         const size_t per_q = (size_t)stride * 10 + (size_t)gstride * 4 + (size_t)(np + 1) * 12 + 256 +
                              (fused_kind_() != 0 ? (size_t)np * ((size_t)ivf_lmf_row_halfs(d) * 2 + 4) : 0); // (IVFPQ / SQ: fp16 operands per probe)
+        // (kind 1's sq-style prepare also writes lm_an_: sized in the chunk function)
         const int64_t fit = std::max<int64_t>(1, std::min<int64_t>((int64_t)(R.temp_budget_bytes / per_q), (1 << 20)));
         for (int c0 = 0; c0 < ni; c0 += (int)std::min<int64_t>(fit, ni)) {
             const int cn = (int)std::min<int64_t>(fit, ni - c0);
@@ -2677,7 +2686,7 @@ void GpuIndexIVF::search_listmajor_filter_chunk_(int ni, int q0, const float* xq
         max_len = std::max(max_len, l);
     }
     const int64_t npairs = (int64_t)ni * np;
-    const int qpi = ivf_lmf_queries_per_item(fused_kind_(), d);
+    const int qpi = ivf_lmf_queries_per_item(lmf_sweep_kind_(), d);
     const int64_t max_items = nrt_max * (int64_t)div_up((size_t)npairs, (size_t)qpi) + 2 * sum_nrt + 16;
     FA_THROW_IF_NOT_MSG(max_items < ((int64_t)1 << 30), "list-major scan: too many work items");
 
@@ -2748,7 +2757,7 @@ void GpuIndexIVF::search_listmajor_filter_chunk_(int ni, int q0, const float* xq
     // ---- queries: fp16 copy + range flags + |q|^2 (the sequential chain of the flat index)
     {
         SpanGuard sg(&R, "ivf_lmf_prepare");
-        const int dh = P.kind != 1 ? ivf_lmf_row_halfs(d) : (int)round_up(d, 16);
+        const int dh = (P.kind != 1 || P.lmf_pairb) ? ivf_lmf_row_halfs(d) : (int)round_up(d, 16);
         lm_q16_.ensure((size_t)ni * dh * 2);
         // (the scalar quantizer's operands, flags and norms all come from launch_ivf_lmf_sq_prepare below)
         if (P.kind != 2)
@@ -2758,13 +2767,13 @@ void GpuIndexIVF::search_listmajor_filter_chunk_(int ni, int q0, const float* xq
         P.ldq16 = dh;
         P.xqn = lm_qn_.as<float>();
         P.xn_full = lm_qn_.as<float>();
-        if (P.kind == 1) {
+        if (P.kind == 1 && !P.lmf_pairb) {
             lm_pair16_.ensure((size_t)ni * (metric_type == METRIC_L2 ? np : 1) * d * 2);
             lm_pairxh_.ensure((size_t)ni * np * 4);
             P.pair16 = lm_pair16_.p;
             P.pair_xh = lm_pairxh_.as<float>();
             launch_ivf_lmf_pq_prepare(P, lm_xnb_.as<float>(), R.stream);
-        } else if (P.kind == 2) {
+        } else if (P.kind == 2 || P.lmf_pairb) {
             // scalar quantizer: B operands (a o s as fp16) and query terms per (query, probe) pair, flags, norm bounds
             lm_pair16_.ensure((size_t)ni * np * dh * 2);
             lm_pairxh_.ensure((size_t)ni * np * 4);
@@ -2801,6 +2810,7 @@ void GpuIndexIVF::search_listmajor_filter_chunk_(int ni, int q0, const float* xq
     // with more than kLmfFusedSelectN candidates (that many rows inside the band of its k-th best) to the redo path.
     static const char* pqfs = experiment_env("FAISS_AMD_LMF_PQ_FUSED_SELECT"); // timing experiment
     const bool fused_select = (P.kind != 1 || (pqfs && atoi(pqfs) == 1)) && k <= kLmfFusedSelectK;
+    // (IVFPQ through the decoded-residual copy prepared its operands like the scalar quantizer; everything from here on is IVFPQ's)
     {
         // clamp of overflowed segments + the smallest superset the band allows (launch_ivf_lmf_tighten)
         SpanGuard sg(&R, "ivf_lmf_tighten");
@@ -2883,7 +2893,7 @@ void GpuIndexIVF::test_filter_dump(idx_t n, const float* x, int nprobe_now, idx_
         nrt_max = std::max(nrt_max, nrt);
     }
     const int64_t npairs = (int64_t)ni * np;
-    const int qpi = ivf_lmf_queries_per_item(fused_kind_(), d);
+    const int qpi = ivf_lmf_queries_per_item(lmf_sweep_kind_(), d);
     const int64_t max_items = nrt_max * (int64_t)div_up((size_t)npairs, (size_t)qpi) + 2 * sum_nrt + 16;
     const int64_t gstride = 2 * (int64_t)np * (int64_t)div_up((size_t)max_len, (size_t)(32 * G));
     IvfLmParams P{};
@@ -2950,7 +2960,7 @@ void GpuIndexIVF::test_filter_dump(idx_t n, const float* x, int nprobe_now, idx_
     P.ovf = ovf.as<uint32_t>();
     P.qflags = qflags.as<uint32_t>();
     P.band_out = band.as<float>();
-    const int dh = P.kind != 1 ? ivf_lmf_row_halfs(d) : (int)round_up(d, 16);
+    const int dh = (P.kind != 1 || P.lmf_pairb) ? ivf_lmf_row_halfs(d) : (int)round_up(d, 16);
     q16.ensure((size_t)ni * dh * 2);
     launch_prep_queries(P.xq, dpad_, ni, d, dpad_, q16.p, dh, qflags.as<uint32_t>(), qn.as<float>(), scalar.as<unsigned>(), R.stream);
     P.xq16 = q16.p;
@@ -2958,7 +2968,7 @@ void GpuIndexIVF::test_filter_dump(idx_t n, const float* x, int nprobe_now, idx_
     P.xqn = qn.as<float>();
     P.xn_full = qn.as<float>();
     DevBuf pair16, pairxh;
-    if (P.kind == 1) {
+    if (P.kind == 1 && !P.lmf_pairb) {
         pair16.ensure((size_t)ni * (metric_type == METRIC_L2 ? np : 1) * d * 2);
         pairxh.ensure((size_t)ni * np * 4);
         P.pair16 = pair16.p;
@@ -2966,7 +2976,7 @@ void GpuIndexIVF::test_filter_dump(idx_t n, const float* x, int nprobe_now, idx_
         launch_ivf_lmf_pq_prepare(P, xnb.as<float>(), R.stream);
     }
     DevBuf anb;
-    if (P.kind == 2) {
+    if (P.kind == 2 || P.lmf_pairb) {
         pair16.ensure((size_t)ni * np * dh * 2);
         pairxh.ensure((size_t)ni * np * 4);
         anb.ensure((size_t)ni * 4);
@@ -3575,8 +3585,17 @@ bool GpuIndexIVFPQ::ivf_lm_pq_lds_supported_() const {
 bool GpuIndexIVFPQ::lm_capable_() const {
     return ivf_lm_supported(1, dpad_, M, d);
 }
-bool GpuIndexIVFPQ::lmf_capable_() const {
+// the LDS-codebook sweeps (d <= 128, d a multiple of 16, dsub 1 / 2 / 4 / 8 k) ...
+bool GpuIndexIVFPQ::lmf_codebook_capable_() const {
     return ivf_lmf_supported(1, d, dpad_, M) && (size_t)d * 512 + 8 * 256 * 12 <= 160 * 1024;
+}
+// ... and every other shape up to d = 512 through an fp16 copy of the DECODED residuals (round 5: 2 d bytes per row instead of
+// M; the IVFFlat sweeps with per-pair operands, ivf_lm_filter.hip lmf_pq_decode_kernel)
+bool GpuIndexIVFPQ::lmf_decoded_() const {
+    return !lmf_codebook_capable_() && ivf_lmf_pq_decoded_supported(d, dpad_, M);
+}
+bool GpuIndexIVFPQ::lmf_capable_() const {
+    return lmf_codebook_capable_() || lmf_decoded_();
 }
 // fp16 codebook + the norm bounds of the filter's error band: upper bound of |r^|^2 (sum over the sub-quantizers of their
 // largest squared entry norm), max |centroid|^2.  Rebuilt when a quantizer changed.
@@ -3584,14 +3603,23 @@ bool GpuIndexIVFPQ::lmf_two_copies_() const {
     return lmf_two_copies && ivf_lmf_choice_shape(d, M);
 }
 void GpuIndexIVFPQ::lmf_shadow_room_() const {
-    int bpl = 0, piece = 0;
-    ivf_lmf_code_shadow_shape(d, M, &bpl, &piece);
-    const size_t blk = lmf_two_copies_() ? (size_t)64 * 40 : (size_t)64 * ((bpl + piece - 1) / piece) * piece;
-    const size_t need = ((size_t)arena_cap_rows_ / 32 + 4) * blk;
+    size_t blk, pad = 4;
+    if (lmf_decoded_()) {
+        blk = (size_t)(ivf_lmf_row_halfs(d) / 16) * 1024; // (the IVFFlat shadow's blocks; its sweeps prefetch up to 8 blocks ahead)
+        pad = 10;
+    } else {
+        int bpl = 0, piece = 0;
+        ivf_lmf_code_shadow_shape(d, M, &bpl, &piece);
+        blk = lmf_two_copies_() ? (size_t)64 * 40 : (size_t)64 * ((bpl + piece - 1) / piece) * piece;
+    }
+    const size_t need = ((size_t)arena_cap_rows_ / 32 + pad) * blk;
     if (need > arena_cs_.cap) arena_cs_.ensure(need, shadow_dirty_ ? 0 : arena_cs_.cap, res_->stream);
 }
 void GpuIndexIVFPQ::lmf_write_copy_(const uint32_t* d_first_row) const {
-    if (lmf_two_copies_())
+    if (lmf_decoded_())
+        launch_ivf_lmf_pq_decode(arena_.as<uint8_t>(), pq_.as<float>(), d, M, nlist, d_list_len_.as<uint32_t>(),
+                                 d_list_start_.as<int64_t>(), arena_cs_.p, ivf_lmf_row_halfs(d), d_first_row, res_->stream);
+    else if (lmf_two_copies_())
         launch_ivf_lmf_code_choice(arena_.as<uint8_t>(), nlist, d_list_len_.as<uint32_t>(), d_list_start_.as<int64_t>(),
                                    arena_cs_.as<uint8_t>(), d_first_row, res_->stream);
     else
@@ -3645,7 +3673,7 @@ bool GpuIndexIVFPQ::lmf_prepare_(IvfLmParams& p) const {
     }
     if (!pq16_in_range_) return false;
     int bpl = 0, piece = 0;
-    ivf_lmf_code_shadow_shape(d, M, &bpl, &piece);
+    if (!lmf_decoded_()) ivf_lmf_code_shadow_shape(d, M, &bpl, &piece);
     lmf_shadow_room_();
     if (shadow_dirty_) {
         // operand-major copy of the codes (kernels.h IvfLmParams::arena_cs): built as a whole at the first list-major search
@@ -3654,10 +3682,29 @@ bool GpuIndexIVFPQ::lmf_prepare_(IvfLmParams& p) const {
         res_->sync();
         shadow_dirty_ = false;
     }
-    p.arena_cs = arena_cs_.as<uint8_t>();
-    p.cs_bpl = bpl;
-    p.cs_piece = piece;
-    p.cs_choice = lmf_two_copies_() ? 1 : 0;
+    if (lmf_decoded_()) {
+        // the sweeps of the scalar quantizer (pair operands) over the decoded residuals: scale 1, offset 0
+        if (!sq_one_.p) {
+            const int dsq = (int)round_up(d, 16);
+            std::vector<float> one((size_t)dsq, 0.f);
+            for (int i = 0; i < d; i++) one[i] = 1.f;
+            sq_one_.ensure((size_t)dsq * 4);
+            sq_nil_.ensure((size_t)dsq * 4);
+            HIP_CHECK(hipMemcpy(sq_one_.p, one.data(), (size_t)dsq * 4, hipMemcpyHostToDevice));
+            HIP_CHECK(hipMemset(sq_nil_.p, 0, (size_t)dsq * 4));
+        }
+        p.lmf_pairb = 1;
+        p.arena_h = arena_cs_.p;
+        p.ldh = ivf_lmf_row_halfs(d);
+        p.sq_s = sq_one_.as<float>();
+        p.sq_b = sq_nil_.as<float>();
+        p.sq_by_residual = 1; // (L2: a = q - centroid; inner product: the coarse term joins the query term)
+    } else {
+        p.arena_cs = arena_cs_.as<uint8_t>();
+        p.cs_bpl = bpl;
+        p.cs_piece = piece;
+        p.cs_choice = lmf_two_copies_() ? 1 : 0;
+    }
     p.filter = 1;
     p.pq_t = pq_t_.as<float>();
     p.pq16 = pq16_.p;

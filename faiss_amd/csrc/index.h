@@ -446,6 +446,9 @@ class GpuIndexIVF : public Index {
     // fp16 range (the search takes the query-major scan).
     virtual bool lmf_capable_() const { return false; }
     virtual bool lmf_prepare_(struct IvfLmParams& p) const { return false; }
+    // flavour of the sweeps that serve this index (ivf_lmf_queries_per_item): 0 IVFFlat, 1 IVFPQ's codebook kernel, 2 the
+    // pair-operand IVFFlat kernel (scalar quantizer, IVFPQ through its decoded residuals)
+    virtual int lmf_sweep_kind_() const { return fused_kind_(); }
     // bytes freed by dropping the sweeps' own copies of the lists (rebuilt at the next list-major search)
     virtual size_t lmf_release_() { return 0; }
     virtual size_t lmf_shadow_bytes_() const { return 0; }
@@ -593,6 +596,10 @@ class GpuIndexIVFPQ : public GpuIndexIVF {
     void lmf_shadow_room_() const; // arena_cs_ holds the blocks of arena_cap_rows_ rows (contents kept)
     void lmf_write_copy_(const uint32_t* d_first_row) const;
     bool lmf_two_copies_() const;
+    bool lmf_codebook_capable_() const;
+    bool lmf_decoded_() const;
+    int lmf_sweep_kind_() const override { return lmf_decoded_() ? 2 : 1; }
+    mutable DevBuf sq_one_, sq_nil_; // decoded mode: scale 1 / offset 0 for the pair-operand preparation
 
    public:
     // PQ64 over d = 128: the sweeps' codebook twice in LDS with different code -> bank maps, copy chosen per (row, sub-quantizer)

@@ -83,6 +83,10 @@ bool ivf_lmf_supported(int kind, int d, int dpad, int M) {
     }
     return false;
 }
+// IVFPQ shapes served through the decoded-residual copy (lmf_pq_decode_kernel) when the codebook kernel does not take them
+bool ivf_lmf_pq_decoded_supported(int d, int dpad, int M) {
+    return (dpad & 7) == 0 && d >= 1 && dpad <= 512 && M >= 1 && d % M == 0;
+}
 // halfs per row of the fp16 shadow / the fp16 queries: d <= 128 whole 16-coordinate k-steps, beyond that whole groups of
 // 8 k-steps (zeros behind d): the sweeps' block loops then have compile-time bounds (8 / 16 / 24 / 32 k-steps)
 int ivf_lmf_row_halfs(int d) {
@@ -232,6 +236,56 @@ void launch_ivf_lmf_sq_shadow(const uint8_t* arena, int ct, int ld, const float*
     if (nlist == 0) return;
     hipLaunchKernelGGL(lmf_sq_shadow_kernel, dim3((unsigned)nlist, first_row ? 1 : 4), dim3(256), 0, stream, arena, ct, ld, arena_rn,
                        d, list_len, list_start, (_Float16*)arena_h, dh, stat_bits, first_row);
+    HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ IVFPQ beyond the codebook kernel: DECODED residuals
+// IVFPQ shapes the LDS-codebook sweeps do not serve (d > 128: the fp16 codebook of d = 256 is 128 KB; d not a multiple of 16; dsub
+// 3, 5, 6, ...) run the IVFFlat sweeps over an fp16 copy of the DECODED residuals r^ -- the operand-major blocks of
+// lmf_shadow_kernel, 2 d bytes per row instead of M -- with the B operands and query terms per (query, probe) pair
+// (lmf_sq_prepare_kernel with scale 1 and offset 0: fp16 (q - centroid), -|q - centroid|^2 / 2).  The estimates are the ones the
+// codebook kernel computes (its A operands are the same fp16 codebook entries); bound, tightening and the exact rerank are IVFPQ's.
+__global__ void __launch_bounds__(256) lmf_pq_decode_kernel(const uint8_t* __restrict__ arena_codes, const float* __restrict__ pq,
+                                                            int d, int M, int dsub, const uint32_t* list_len,
+                                                            const int64_t* list_start, _Float16* __restrict__ arena_h, int dh,
+                                                            const uint32_t* __restrict__ first_row) {
+    const int list = blockIdx.x;
+    const uint32_t len = list_len[list];
+    const int64_t start = list_start[list]; // (a multiple of 64)
+    const int nks = dh >> 4;
+    const uint32_t fr = first_row ? first_row[list] : 0u;
+    if (fr == 0xffffffffu) return;
+    const int64_t b0 = fr >> 5;
+    const int64_t nblk = (len + 31) / 32 - b0;
+    const int64_t total = nblk * nks * 64;
+    for (int64_t i = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.y * blockDim.x) {
+        const int ln = (int)(i & 63);
+        const int64_t bs = i >> 6;
+        const int s = (int)(bs % nks);
+        const int64_t b = b0 + bs / nks;
+        const int h = ln >> 5, j = ln & 31;
+        const int64_t r = b * 32 + j;
+        const int c = 16 * s + 8 * h;
+        half8 o = half8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (r < (int64_t)len) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int jx = c + e;
+                if (jx < d) {
+                    const int m = jx / dsub, off = jx - m * dsub;
+                    const unsigned code = arena_codes[pq_code_offset(M, start + r, m)];
+                    o[e] = (_Float16)pq[((size_t)m * 256 + code) * dsub + off];
+                }
+            }
+        }
+        *(half8*)(arena_h + (((start >> 5) + b) * nks + s) * 512 + ln * 8) = o;
+    }
+}
+void launch_ivf_lmf_pq_decode(const uint8_t* arena_codes, const float* pq, int d, int M, int nlist, const uint32_t* list_len,
+                              const int64_t* list_start, void* arena_h, int dh, const uint32_t* first_row, hipStream_t stream) {
+    if (nlist == 0) return;
+    hipLaunchKernelGGL(lmf_pq_decode_kernel, dim3((unsigned)nlist, first_row ? 1 : 4), dim3(256), 0, stream, arena_codes, pq, d, M,
+                       d / M, list_len, list_start, (_Float16*)arena_h, dh, first_row);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -1178,7 +1232,7 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
 
 // ------------------------------------------------------------------ launchers of the sweeps
 int ivf_lmf_grid_blocks(const IvfLmParams& p, int num_cus) {
-    if (p.kind == 1) return num_cus;       // one 8-wave workgroup per CU (codebook + slices in its LDS)
+    if (p.kind == 1 && !p.lmf_pairb) return num_cus; // one 8-wave workgroup per CU (codebook + slices in its LDS)
     return 2 * num_cus / 8 * 8;            // IVFFlat: two 4-wave workgroups per CU
 }
 template <int METRIC, int MODE, bool SEL, bool PAIRB>
@@ -1227,7 +1281,7 @@ static void lmf_launch_sel(const IvfLmParams& p, int mode, int grid_blocks, hipS
         if (mode == MODE_MIN) lmf_flat_launch<METRIC, MODE_MIN, SEL, false>(p, grid_blocks, stream);
         else if (mode == MODE_COLLECT) lmf_flat_launch<METRIC, MODE_COLLECT, SEL, false>(p, grid_blocks, stream);
         else lmf_flat_launch<METRIC, MODE_DUMP, SEL, false>(p, grid_blocks, stream);
-    } else if (p.kind == 2) {
+    } else if (p.kind == 2 || p.lmf_pairb) {
         if (mode == MODE_MIN) lmf_flat_launch<METRIC, MODE_MIN, SEL, true>(p, grid_blocks, stream);
         else if (mode == MODE_COLLECT) lmf_flat_launch<METRIC, MODE_COLLECT, SEL, true>(p, grid_blocks, stream);
         else lmf_flat_launch<METRIC, MODE_DUMP, SEL, true>(p, grid_blocks, stream);
@@ -1245,18 +1299,20 @@ static void lmf_launch_mode(const IvfLmParams& p, int mode, int grid_blocks, hip
 }
 void launch_ivf_lmf_sweep(const IvfLmParams& p, int mode, int grid_blocks, hipStream_t stream) {
     if (p.nq == 0) return;
-    FA_THROW_IF_NOT(p.filter && ivf_lmf_supported(p.kind, p.d, p.dpad, p.kind == 2 ? p.sq_ct : p.M) && mode >= 1 && mode <= 3 &&
-                    grid_blocks > 0);
+    const int skind = p.lmf_pairb ? 2 : p.kind; // the sweeps' flavour: decoded IVFPQ residuals run the pair-operand IVFFlat kernel
+    FA_THROW_IF_NOT(p.filter && mode >= 1 && mode <= 3 && grid_blocks > 0);
+    FA_THROW_IF_NOT(p.lmf_pairb && p.kind == 1 ? ivf_lmf_pq_decoded_supported(p.d, p.dpad, p.M)
+                                               : ivf_lmf_supported(p.kind, p.d, p.dpad, p.kind == 2 ? p.sq_ct : p.M));
     FA_THROW_IF_NOT(p.min_stride >= 1 && p.min_stride <= 8);
-    FA_THROW_IF_NOT(p.qpi == ivf_lmf_queries_per_item(p.kind, p.d) && p.nq < (1 << 21) && p.nprobe <= 2048 &&
+    FA_THROW_IF_NOT(p.qpi == ivf_lmf_queries_per_item(skind, p.d) && p.nq < (1 << 21) && p.nprobe <= 2048 &&
                     p.gran_blocks >= 1 && (p.gran_blocks & (p.gran_blocks - 1)) == 0);
-    if (p.kind == 0) {
+    if (skind == 2) {
+        FA_THROW_IF_NOT(p.pair16 && p.pair_xh && p.arena_h && p.ldh == ivf_lmf_row_halfs(p.d) && p.ldh <= 512 && p.ldq16 == p.ldh);
+        FA_THROW_IF_NOT(p.metric != METRIC_L2 || p.arena_rn);
+    } else if (p.kind == 0) {
         FA_THROW_IF_NOT(p.xq16 && p.arena_h && p.ldh == ivf_lmf_row_halfs(p.d) && p.ldh <= 512 && p.ldq16 >= p.ldh &&
                         p.ldq16 % 8 == 0);
         FA_THROW_IF_NOT(p.metric != METRIC_L2 || (p.arena_rn && p.xqn));
-    } else if (p.kind == 2) {
-        FA_THROW_IF_NOT(p.pair16 && p.pair_xh && p.arena_h && p.ldh == ivf_lmf_row_halfs(p.d) && p.ldh <= 512 && p.ldq16 == p.ldh);
-        FA_THROW_IF_NOT(p.metric != METRIC_L2 || p.arena_rn);
     } else {
         FA_THROW_IF_NOT(p.pq16 && p.arena_cs && p.cs_bpl > 0 && (p.cs_piece == 4 || p.cs_piece == 16) && p.centroids &&
                         p.ldq % 4 == 0 && p.ldc % 4 == 0);
@@ -1614,7 +1670,8 @@ __global__ void __launch_bounds__(256) lmf_sq_prepare_kernel(IvfLmParams p, floa
 }
 void launch_ivf_lmf_sq_prepare(const IvfLmParams& p, float* xn_bound, float* an_bound, hipStream_t stream) {
     if (p.nq == 0) return;
-    FA_THROW_IF_NOT(p.kind == 2 && p.pair16 && p.pair_xh && p.qflags && p.sq_s && p.sq_b && p.centroids && p.ldh % 16 == 0 && p.ldh <= 512);
+    FA_THROW_IF_NOT((p.kind == 2 || p.lmf_pairb) && p.pair16 && p.pair_xh && p.qflags && p.sq_s && p.sq_b && p.centroids &&
+                    p.ldh % 16 == 0 && p.ldh <= 512);
     FA_THROW_IF_NOT(p.dpad % 8 == 0 && p.ldq % 4 == 0 && p.ldc % 4 == 0);
     HIP_CHECK(hipMemsetAsync(xn_bound, 0, (size_t)p.nq * 4, stream));
     HIP_CHECK(hipMemsetAsync(an_bound, 0, (size_t)p.nq * 4, stream));

@@ -472,6 +472,9 @@ struct IvfLmParams {
     // distances, then the collection of every row whose estimate is at or below the query's threshold -- and the
     // exact arithmetic of the query-major scan on the few survivors (launch_ivf_lmf_rerank).
     int filter;
+    // kind 1 through the DECODED-residual copy (ivf_lm_filter.hip lmf_pq_decode_kernel): the sweeps are the pair-operand IVFFlat
+    // kernel over arena_h = fp16 r^, prepared like the scalar quantizer with sq_s = 1, sq_b = 0; bound / tighten / rerank are IVFPQ's
+    int lmf_pairb;
     int gran_blocks;            // G: 32-row blocks per granule; a granule of a list = 32 G rows = two slots (lane halves)
     int min_stride;             // sweep 1 looks at every min_stride-th 32-row block of a row chunk (1 = all rows)
     // sweep 1 looks only at the first sample_rows rows of every work item's row chunk (0 = the whole chunk; a multiple of
@@ -607,6 +610,10 @@ void launch_ivf_lmf_rerank_sq(const IvfLmParams& p, hipStream_t stream);
 // IVFPQ: operand-major copy of the codes of every list (see IvfLmParams::arena_cs); bytes per lane and block / piece size
 void ivf_lmf_code_shadow_shape(int d, int M, int* bpl, int* piece);
 bool ivf_lmf_choice_shape(int d, int M); // the shape the two-copy codebook serves
+bool ivf_lmf_pq_decoded_supported(int d, int dpad, int M);
+// fp16 copy of the decoded residuals of every list in the operand-major blocks of launch_ivf_lmf_shadow (pq: [M][256][dsub] fp32)
+void launch_ivf_lmf_pq_decode(const uint8_t* arena_codes, const float* pq, int d, int M, int nlist, const uint32_t* list_len,
+                              const int64_t* list_start, void* arena_h, int dh, const uint32_t* first_row, hipStream_t stream);
 // the copy of the codes in the two-copy format (2560 bytes per 32-row block); first_row as for launch_ivf_lmf_code_shadow
 void launch_ivf_lmf_code_choice(const uint8_t* arena_codes, int nlist, const uint32_t* list_len, const int64_t* list_start,
                                 uint8_t* arena_cs, const uint32_t* first_row, hipStream_t stream);

@@ -241,11 +241,18 @@ def test_scan_mode_rule_and_refusals(res):
             big.set_scan_mode(m)
             with pytest.raises(faiss_amd.FaissAmdError, match="not supported"):
                 big.search(np.zeros((3, dbig), "float32"), 2)
-    pq_big = faiss_amd.GpuIndexIVFPQ(res, 256, 8, 32, 8, METRIC_L2)  # IVFPQ: d <= 128
-    pq_big.set_scan_mode(pq_big.SCAN_LIST_MAJOR)
+    # IVFPQ: the codebook sweeps serve d <= 128; beyond that (round 5) the filter runs over the decoded residuals, up to d = 512;
+    # the f32 scan still refuses
+    pq_big = faiss_amd.GpuIndexIVFPQ(res, 256, 8, 32, 8, METRIC_L2)
     xs = np.random.RandomState(2).rand(3000, 256).astype("float32")
     pq_big.train(xs)
     pq_big.add(xs[:500])
+    pq_big.set_scan_mode(pq_big.SCAN_QUERY_MAJOR)
+    Dq, Iq = pq_big.search(xs[:3], 2)
+    pq_big.set_scan_mode(pq_big.SCAN_LIST_MAJOR)
+    Dl, Il = pq_big.search(xs[:3], 2)
+    assert np.array_equal(Dq, Dl) and np.array_equal(Iq, Il)
+    pq_big.set_scan_mode(pq_big.SCAN_LIST_MAJOR_F32)
     with pytest.raises(faiss_amd.FaissAmdError, match="not supported"):
         pq_big.search(xs[:3], 2)
 

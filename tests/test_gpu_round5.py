@@ -375,3 +375,64 @@ def test_scalar_quantizer_filter_error_bound_holds(res, qtype, metric, by_residu
     print("qtype %d metric %d d %d scale %g: worst |estimate - exact| / band = %.5f (band %.3g, distances ~ %.3g)" % (
         qtype, metric, d, scale, worst, float(band.mean()), float(np.abs(De[:, 0]).mean())))
     assert worst > 1e-6
+
+
+@pytest.mark.parametrize("metric,d,M", [
+    (METRIC_L2, 256, 128),            # PQ128 over d = 256 (dsub 2)
+    (METRIC_L2, 192, 48),             # dsub 4, d = 192: rows padded to 256 halfs
+    (METRIC_INNER_PRODUCT, 256, 32),  # dsub 8
+    (METRIC_L2, 96, 32),              # dsub 3: a shape the codebook sweeps refuse although d <= 128
+    (METRIC_L2, 120, 24),             # dsub 5, d not a multiple of 16
+    (METRIC_INNER_PRODUCT, 384, 64),  # dsub 6, three groups of eight k-steps
+])
+def test_ivfpq_beyond_the_codebook_kernel_through_decoded_residuals(res, metric, d, M):
+    """IVFPQ shapes the LDS-codebook sweeps do not serve (d > 128, d not a multiple of 16, dsub 3 / 5 / 6) take the filter path
+    over an fp16 copy of the DECODED residuals (the pair-operand IVFFlat sweeps): same bits as the query-major scan, whatever
+    the batch, through incremental adds and with a selector; the error band holds row by row."""
+    nlist, k = 16, 40
+    xt, xb, xq = synthetic_dataset(d, 6000, 40000, 900, seed=d + M)
+    idx = faiss_amd.GpuIndexIVFPQ(res, d, nlist, M, 8, metric)
+    idx.train(xt)
+    idx.add(xb[:30000])
+    idx.nprobe = 5
+    idx.set_scan_mode(idx.SCAN_QUERY_MAJOR)
+    Dr, Ir = idx.search(xq, k)
+    idx.set_scan_mode(idx.SCAN_LIST_MAJOR)
+    D, I = idx.search(xq, k)
+    assert idx.scan_info()[1] == 2 and idx.last_scan_arith() == 0
+    assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+    D1, I1 = idx.search(xq[40:77], k)
+    assert np.array_equal(D1, D[40:77]) and np.array_equal(I1, I[40:77])
+    lists, shadow = idx.resident_bytes()
+    assert shadow >= 30000 * 2 * d  # 2 d bytes per row (rows padded to whole groups of k-steps beyond d = 128)
+    idx.add(xb[30000:30011])
+    idx.add(xb[30011:])
+    sel = faiss_amd.IDSelectorRange(500, 25000)
+    Ds, Is = idx.search(xq, k, params=faiss_amd.SearchParametersIVF(sel=sel))
+    idx.set_scan_mode(idx.SCAN_QUERY_MAJOR)
+    Dq, Iq = idx.search(xq, k, params=faiss_amd.SearchParametersIVF(sel=sel))
+    assert np.array_equal(Ds, Dq) and np.array_equal(Is, Iq)
+    # the estimates of the sweeps against the exact distances, row by row (a small index: k = every probed row)
+    small = faiss_amd.GpuIndexIVFPQ(res, d, nlist, M, 8, metric)
+    small.copy_centroids(idx.get_centroids())
+    small.copy_pq_centroids(idx.get_pq_centroids())
+    small.add(xb[:4000])
+    small.nprobe = 3
+    nq = 48
+    Dc, Ic = small.quantizer_search(xq[:nq], 3)
+    sizes = np.array([small.get_list_size(l) for l in range(nlist)])
+    lids = [small.get_list_ids(l) for l in range(nlist)]
+    rows = np.array([int(sum(sizes[l] for l in Ic[q] if l >= 0)) for q in range(nq)])
+    assert rows.max() <= 2048
+    est, band = small.filter_dump(xq[:nq], 10, int(3 * sizes.max()))
+    small.set_scan_mode(small.SCAN_QUERY_MAJOR)
+    De, Ie = small.search(xq[:nq], int(rows.max()))
+    worst = 0.0
+    for q in range(nq):
+        pos_ids = np.concatenate([lids[l] for l in Ic[q] if l >= 0])
+        order = {int(i): r for r, i in enumerate(Ie[q, :rows[q]])}
+        exact = np.array([De[q, order[int(i)]] for i in pos_ids], dtype=np.float64)
+        err = np.abs(est[q, :rows[q]].astype(np.float64) - exact)
+        assert (err <= band[q]).all(), (q, float(err.max()), float(band[q]))
+        worst = max(worst, float(err.max() / band[q]))
+    print("IVFPQ decoded d %d M %d metric %d: worst |estimate - exact| / band = %.4f" % (d, M, metric, worst))
