@@ -1706,39 +1706,56 @@ __global__ void __launch_bounds__(256) lmf_rerank_flat_kernel(IvfLmParams p) {
     u64* kq = p.keys + (int64_t)q * p.stride;
     const uint16_t* cpr = p.cand_pr + (int64_t)q * p.stride;
     const float* qrow = p.xq + (int64_t)q * p.ldq;
-    for (int base = 0; base < n; base += 32) {
-        const int i = base + grp;
-        const bool valid = i < n;
-        float a = 0.f;
-        uint32_t pos = 0;
-        if (valid) {
-            pos = (uint32_t)kq[i];
-            const int pr = (int)cpr[i];
-            const int64_t l = p.coarse_ids[(int64_t)q * np + pr];
-            const int64_t row = p.list_start[l] + (pos - p.prefix[(int64_t)q * (np + 1) + pr]);
-            const float* rowp = p.arena_vecs + row * p.ldv;
-            for (int c4 = ln; c4 < nch; c4 += 8) {
-                const f32x4 y4 = *(const f32x4*)(rowp + 4 * c4);
-                const f32x4 q4 = *(const f32x4*)(qrow + 4 * c4);
+    // Two phases per 256 candidates (round 5): first every thread resolves ONE candidate's row (key -> probe -> list -> row: four
+    // dependent loads, all 256 chains in flight together), then the groups of eight lanes walk the rows.  (One phase -- every group
+    // resolving its own candidate before reading it -- paid the chain once per round of 32 candidates: 0.154 ms at nb = 1M.)
+    __shared__ int64_t s_row[256];
+    __shared__ uint32_t s_pos[256];
+    for (int cbase = 0; cbase < n; cbase += 256) {
+        {
+            const int i = cbase + (int)threadIdx.x;
+            if (i < n) {
+                const uint32_t pos = (uint32_t)kq[i];
+                const int pr = (int)cpr[i];
+                const int64_t l = p.coarse_ids[(int64_t)q * np + pr];
+                s_row[threadIdx.x] = p.list_start[l] + (pos - p.prefix[(int64_t)q * (np + 1) + pr]);
+                s_pos[threadIdx.x] = pos;
+            }
+        }
+        __syncthreads();
+        const int cn = min(256, n - cbase);
+        for (int base = 0; base < cn; base += 32) {
+            const int ci = base + grp;
+            const bool valid = ci < cn;
+            float a = 0.f;
+            uint32_t pos = 0;
+            if (valid) {
+                pos = s_pos[ci];
+                const float* rowp = p.arena_vecs + s_row[ci] * p.ldv;
+                for (int c4 = ln; c4 < nch; c4 += 8) {
+                    const f32x4 y4 = *(const f32x4*)(rowp + 4 * c4);
+                    const f32x4 q4 = *(const f32x4*)(qrow + 4 * c4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (METRIC == METRIC_L2) {
-                        const float tt = q4[e] - y4[e];
-                        a = __fmaf_rn(tt, tt, a);
-                    } else {
-                        a = __fmaf_rn(q4[e], y4[e], a);
+                    for (int e = 0; e < 4; ++e) {
+                        if (METRIC == METRIC_L2) {
+                            const float tt = q4[e] - y4[e];
+                            a = __fmaf_rn(tt, tt, a);
+                        } else {
+                            a = __fmaf_rn(q4[e], y4[e], a);
+                        }
                     }
                 }
             }
+            a = a + __shfl_xor(a, 1, 64);
+            a = a + __shfl_xor(a, 2, 64);
+            a = a + __shfl_xor(a, 4, 64);
+            if (valid && ln == 0) {
+                const u64 key = ((u64)ordkey<METRIC>(a) << 32) | (u64)pos;
+                if (fin) sel_k[cbase + ci] = key;
+                else kq[cbase + ci] = key;
+            }
         }
-        a = a + __shfl_xor(a, 1, 64);
-        a = a + __shfl_xor(a, 2, 64);
-        a = a + __shfl_xor(a, 4, 64);
-        if (valid && ln == 0) {
-            const u64 key = ((u64)ordkey<METRIC>(a) << 32) | (u64)pos;
-            if (fin) sel_k[i] = key;
-            else kq[i] = key;
-        }
+        __syncthreads(); // (s_row / s_pos are rewritten by the next 256 candidates; kq[i] of this chunk was read in phase one)
     }
     if (fin) lmf_select_tail<256>(p, q, n, sel_k, cpr, sel_wk, sel_wl);
 }
