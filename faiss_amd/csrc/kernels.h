@@ -239,6 +239,8 @@ struct SelectParams {
     // upper bound of seg_cnt known to the caller (0 = unknown).  nseg == 1, k <= 256 and max_cnt <= 4096 (bound) /
     // 8192 (selection) take the wavefront-per-query kernel (select_kernels.hip: keys in registers, bisection)
     int64_t max_cnt;
+    // set by launch_select_k: queries with <= 256 keys were served by small_select_kernel, the general wavefront kernel skips them
+    int small_done;
 };
 // Exact k-selection: MSB radix select on 64-bit keys + bitonic sort of the k winners by
 // (distance, label).  Replaces faiss/gpu/utils/BlockSelectKernel.cuh:15-132 and the

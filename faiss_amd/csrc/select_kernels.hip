@@ -261,6 +261,7 @@ __global__ void __launch_bounds__(256) wave_select_kernel(SelectParams p, int kp
     const int q = blockIdx.x * 4 + wave;
     if (q >= p.nq) return; // (no barrier below: wavefronts are independent)
     const unsigned n = p.seg_cnt[q];
+    if (p.small_done && n <= 256u) return; // (served by small_select_kernel)
     u64* seg = const_cast<u64*>(p.keys) + (p.q_off ? p.q_off[q] : (int64_t)q * p.q_stride);
     const unsigned k = (unsigned)p.k;
     const bool resident = n <= 64u * WS_KPL;
@@ -311,7 +312,51 @@ __global__ void __launch_bounds__(256) wave_select_kernel(SelectParams p, int kp
         return c;
     };
     unsigned T = 0xffffffffu, P = 0xffffffffu; // winners: hi < T, or hi == T and lo <= P
-    if (n > k) {
+    bool ranked = false;
+    if (n > k && n <= 256u) {
+        // small segments (round 5: the filter path hands ~ k + a few dozen re-derived candidates per query): the k-th smallest
+        // key by COUNTING -- the keys go through this wave's LDS slice, every lane ranks its (at most four) keys against all n
+        // with broadcast reads; the key of rank k - 1 is the bound.  The bisection below costs up to 64 rounds of ballots over the
+        // key space whatever n is: 20 us per query for 140 keys.  (Keys are distinct: the payload is a scan position / an id;
+        // should two ever coincide no key has rank k - 1 and the bisection decides.)
+        u64* sk = (u64*)(smem + (size_t)4 * kp * (BOUND ? 8 : 12)) + (size_t)wave * 256;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned idx = (unsigned)lane + 64u * i;
+            if (idx < n) sk[idx] = ((u64)hi[i] << 32) | lo[i];
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        u64 mykey[4];
+        unsigned r[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mykey[i] = ((u64)hi[i] << 32) | lo[i];
+        for (unsigned j = 0; j < n; ++j) {
+            const u64 kj = sk[j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r[i] += kj < mykey[i] ? 1u : 0u;
+        }
+        bool found = false;
+        unsigned fh = 0u, fl = 0u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if ((unsigned)lane + 64u * i < n && r[i] == k - 1u) {
+                found = true;
+                fh = hi[i];
+                fl = lo[i];
+            }
+        }
+        const unsigned long long fb = __ballot(found);
+        if (fb) {
+            const int src = __builtin_ctzll(fb);
+            T = (unsigned)__shfl((int)fh, src, 64);
+            P = (unsigned)__shfl((int)fl, src, 64);
+            ranked = true;
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier(); // (the slice is not reused before every lane has read it)
+    }
+    if (n > k && !ranked) {
         unsigned mn = 0xffffffffu, mx = 0u;
         for_keys([&](unsigned h, unsigned) {
             mn = min(mn, h);
@@ -472,6 +517,113 @@ __global__ void __launch_bounds__(256) wave_select_kernel(SelectParams p, int kp
         p.out_ids[(int64_t)q * p.k + i] = id;
     }
 }
+// ---------------------------------------------------------------------------------
+// Small segments (round 5): one wavefront per query for n <= 256 keys, k <= 256, label modes 0 / 1 with fewer than 64 probes --
+// what the filter path of IVFPQ hands over: ~ k + a few dozen re-derived candidates per query.  At most four keys per lane,
+// both rankings by COUNTING through the wave's LDS slice (broadcast reads): (distance, position) picks the k winners -- rank =
+// winner slot, no scan --, (distance, label) orders them, ties of both by the winner slot: the result of wave_select_kernel /
+// select_k_kernel.  Few registers: 8 wavefronts per SIMD, the whole batch of 10 000 queries resident at once (the general
+// kernel keeps 64 keys per lane in registers: 2 wavefronts per SIMD, 20 us per query whatever n is -- 0.10 ms per search).
+// Queries with more keys are left to the general kernel (SelectParams::small_done tells it which were served).
+// ---------------------------------------------------------------------------------
+constexpr int SS_N = 256;
+__global__ void __launch_bounds__(256) small_select_kernel(SelectParams p) {
+    __shared__ u64 s_keys[4][SS_N];
+    __shared__ unsigned s_wk[4][SS_N];
+    __shared__ int64_t s_wl[4][SS_N];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + wave;
+    if (q >= p.nq) return; // (wavefronts are independent: no workgroup barrier below)
+    const unsigned n = p.seg_cnt[q];
+    if (n > (unsigned)SS_N) return;
+    const u64* seg = p.keys + (p.q_off ? p.q_off[q] : (int64_t)q * p.q_stride);
+    const unsigned k = (unsigned)p.k;
+    u64* sk = s_keys[wave];
+    unsigned* wk = s_wk[wave];
+    int64_t* wl = s_wl[wave];
+    u64 key[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned idx = (unsigned)lane + 64u * i;
+        key[i] = idx < n ? seg[idx] : ~0ull;
+        if (idx < n) sk[idx] = key[i];
+    }
+    // probes of the query in the lanes' registers (mode 1): a winner's position -> probe by bisection over other lanes' values
+    uint32_t pre_l = 0xffffffffu;
+    int64_t base_l = 0;
+    if (p.mode == 1) {
+        const uint32_t* pre = p.ivf_prefix + (int64_t)q * (p.nprobe + 1);
+        if (lane <= p.nprobe) pre_l = pre[lane];
+        if (lane < p.nprobe) {
+            const int64_t list = p.coarse_ids[(int64_t)q * p.nprobe + lane];
+            base_l = list >= 0 ? p.list_start[list] : 0;
+        }
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    unsigned r[4] = {0u, 0u, 0u, 0u};
+    for (unsigned j = 0; j < n; ++j) {
+        const u64 kj = sk[j];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] += kj < key[i] ? 1u : 0u;
+    }
+    const unsigned nwin = min(n, k);
+    // winners -> slot = rank, with their labels
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { // (uniform trip count: the shuffles need every lane)
+        const bool win = (unsigned)lane + 64u * i < n && r[i] < k;
+        const uint32_t l = (uint32_t)key[i];
+        int64_t label;
+        if (p.mode == 0) {
+            label = (int64_t)l + p.id_base;
+        } else {
+            int a = 0, b = p.nprobe; // invariant pre[a] <= payload < pre[b]
+            for (int step = 0; step < 6; ++step) {
+                const int mid = (a + b) >> 1;
+                const uint32_t pm = (uint32_t)__shfl((int)pre_l, mid, 64);
+                if (b - a > 1) {
+                    if (pm <= l) a = mid;
+                    else b = mid;
+                }
+            }
+            const uint32_t pa = (uint32_t)__shfl((int)pre_l, a, 64);
+            const int64_t base = ((int64_t)__shfl((int)(base_l >> 32), a, 64) << 32) | (uint32_t)__shfl((int)base_l, a, 64);
+            label = win ? p.arena_ids[base + (l - pa)] : -1;
+        }
+        if (win) {
+            wk[r[i]] = (unsigned)(key[i] >> 32);
+            wl[r[i]] = label;
+        }
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const float pad = neutral_distance(p.metric);
+    float* od = p.out_dis + (int64_t)q * k;
+    int64_t* oi = p.out_ids + (int64_t)q * k;
+    for (unsigned t = lane; t < k; t += 64) {
+        if (t >= nwin) { // fewer keys than k: the tail is padding
+            od[t] = pad;
+            oi[t] = -1;
+            continue;
+        }
+        const unsigned a = wk[t];
+        const int64_t ia = wl[t];
+        unsigned r2 = 0;
+        for (unsigned j = 0; j < nwin; ++j) {
+            const unsigned b = wk[j];
+            const int64_t ib = wl[j];
+            r2 += (b < a || (b == a && (ib < ia || (ib == ia && j < t)))) ? 1u : 0u;
+        }
+        const bool real = a < kInvalidOrdKey;
+        od[r2] = real ? unordkey_rt(p.metric, a) : pad;
+        oi[r2] = real ? ia : -1;
+    }
+}
+static bool small_select_serves(const SelectParams& p) {
+    return !p.kth_out && p.nseg == 1 && p.k <= SS_N && (p.mode == 0 || (p.mode == 1 && p.nprobe < 64)) && p.max_cnt > 0;
+}
+
 static bool wave_select_serves(const SelectParams& p) {
     static const char* e = experiment_env("FAISS_AMD_WAVE_SELECT"); // timing experiments: 0 = the radix kernel everywhere
     if (e && atoi(e) == 0) return false;
@@ -632,8 +784,15 @@ void launch_select_k(const SelectParams& p, hipStream_t stream) {
     while (kp < p.k) kp <<= 1;
     if (wave_select_serves(p)) {
         const dim3 grid((unsigned)div_up(p.nq, 4));
-        if (p.kth_out) hipLaunchKernelGGL((wave_select_kernel<true>), grid, dim3(256), (size_t)4 * kp * 8, stream, p, kp);
-        else hipLaunchKernelGGL((wave_select_kernel<false>), grid, dim3(256), (size_t)4 * kp * 12, stream, p, kp);
+        SelectParams pw = p;
+        if (small_select_serves(p)) {
+            hipLaunchKernelGGL(small_select_kernel, grid, dim3(256), 0, stream, p);
+            pw.small_done = 1; // the general kernel below takes the queries with more than 256 keys
+        }
+        const SelectParams& p = pw;
+        // (+ 4 x 256 keys: the counting rank of small segments)
+        if (p.kth_out) hipLaunchKernelGGL((wave_select_kernel<true>), grid, dim3(256), (size_t)4 * kp * 8 + 4 * 256 * 8, stream, p, kp);
+        else hipLaunchKernelGGL((wave_select_kernel<false>), grid, dim3(256), (size_t)4 * kp * 12 + 4 * 256 * 8, stream, p, kp);
         HIP_CHECK(hipGetLastError());
         return;
     }
