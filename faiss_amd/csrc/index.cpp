@@ -1701,7 +1701,7 @@ size_t GpuIndexIVF::reclaimMemory() {
     // plan tables, granule minima): all of it is re-grown on demand
     for (DevBuf* b : {&a_xpad_, &a_lab_, &a_dis_, &a_dest_, &a_ids_, &a_hist_, &a_newlen_, &a_jobs_, &lm_prefix_, &lm_p0_,
                       &lm_cnt_, &lm_bucket_, &lm_bstart_, &lm_pairs_, &lm_items_, &lm_bounds_, &lm_thr_, &lm_keys_, &lm_ovf_,
-                      &lm_qn_, &lm_prefixg_, &lm_gmin_, &lm_thrf_, &lm_candpr_, &lm_q16_, &lm_qflags_, &lm_xnb_, &lm_pqgrid_, &lm_pair16_, &lm_pairxh_, &lm_errf_, &lm_an_,
+                      &lm_qn_, &lm_prefixg_, &lm_gmin_, &lm_thrf_, &lm_candpr_, &lm_q16_, &lm_qflags_, &lm_xnb_, &lm_pqgrid_, &lm_pair16_, &lm_pairxh_, &lm_errf_, &lm_an_, &lm_rowbase_,
                       &part_keys_, &part_cnt_, &keys_}) {
         before += b->cap;
         b->release();
@@ -2718,6 +2718,7 @@ void GpuIndexIVF::search_listmajor_filter_chunk_(int ni, int q0, const float* xq
     lm_thrf_.ensure((size_t)ni * 4);
     lm_keys_.ensure((size_t)ni * stride * 8);
     lm_candpr_.ensure((size_t)ni * stride * 2);
+    lm_rowbase_.ensure((size_t)ni * np * 8);
     lm_gmin_.ensure((size_t)ni * gstride * 4);
     lm_ovf_.ensure((size_t)(ni + 1) * 4);
     lm_qflags_.ensure((size_t)ni * 4);
@@ -2750,6 +2751,7 @@ void GpuIndexIVF::search_listmajor_filter_chunk_(int ni, int q0, const float* xq
     P.thr_f = lm_thrf_.as<float>();
     P.keys = lm_keys_.as<unsigned long long>();
     P.cand_pr = lm_candpr_.as<uint16_t>();
+    P.row_base = lm_rowbase_.as<int64_t>();
     P.stride = stride;
     P.ovf = lm_ovf_.as<uint32_t>();
     P.qflags = lm_qflags_.as<uint32_t>();

@@ -465,7 +465,7 @@ class GpuIndexIVF : public Index {
     mutable int last_scan_arith_ = 0;     // oracle restatement of the last search: 0 query-major arithmetic, 1 f32 list-major
     mutable bool shadow_dirty_ = true;    // a list changed since the fp16 shadow was built
     mutable bool lmf_quant_dirty_ = true; // a quantizer changed since the fp16 codebook / norm bounds were built
-    mutable DevBuf lm_prefixg_, lm_gmin_, lm_thrf_, lm_candpr_, lm_q16_, lm_qflags_, lm_xnb_, lm_pqgrid_, lm_scalar_, lm_pair16_, lm_pairxh_, lm_errf_, lm_an_;
+    mutable DevBuf lm_prefixg_, lm_gmin_, lm_thrf_, lm_candpr_, lm_q16_, lm_qflags_, lm_xnb_, lm_pqgrid_, lm_scalar_, lm_pair16_, lm_pairxh_, lm_errf_, lm_an_, lm_rowbase_;
     // queries whose candidate segment overflowed (or that leave the fp16 range) are appended to `redo`
     void search_listmajor_filter_chunk_(int ni, int q0, const float* xq_pad, const idx_t* c_ids, const float* c_dis, int np, int k,
                                         float* dD, idx_t* dI, int64_t stride, int rt_g, int64_t gstride, int min_stride,

@@ -960,7 +960,7 @@ __global__ void __launch_bounds__(256) lmf_rerank_sq_kernel(IvfLmParams p) {
         const uint32_t pos = (uint32_t)kq[i];
         const int pr = (int)cpr[i];
         const int64_t l = p.coarse_ids[(int64_t)q * np + pr];
-        const int64_t row = p.list_start[l] + (pos - p.prefix[(int64_t)q * (np + 1) + pr]);
+        const int64_t row = p.row_base[(int64_t)q * np + pr] + (int64_t)pos;
         const uint8_t* rp = p.arena_codes + (row >> 6) * 64 * (int64_t)p.sq_ld + (row & 63) * CHB;
         const float* cen = p.centroids + l * p.ldc;
         f32x2 acc = {0.f, 0.f};
@@ -1031,6 +1031,7 @@ void launch_ivf_lmf_rerank_sq(const IvfLmParams& p, hipStream_t stream) {
     if (p.nq == 0) return;
     FA_THROW_IF_NOT(p.kind == 2 && p.arena_codes && p.sq_s && p.sq_b_plain && p.centroids && p.keys && p.cand_pr && p.cnt);
     FA_THROW_IF_NOT(!p.fin_dis || (p.fin_ids && p.arena_ids && p.k <= kLmfFusedSelectK));
+    FA_THROW_IF_NOT(p.row_base != nullptr); // (written by launch_ivf_lm_plan)
     const dim3 grid((unsigned)p.nq), block(256);
     const bool l2 = p.metric == METRIC_L2;
 #define FA_RRSQ(CT_)                                                                                        \

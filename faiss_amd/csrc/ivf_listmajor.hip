@@ -294,6 +294,7 @@ __global__ void __launch_bounds__(256) lm_plan_kernel(IvfLmParams p) {
         if (pr < np) {
             pre[pr] = cum + inc - len;
             pre1[pr] = cum1 + inc1 - len1;
+            if (p.row_base) p.row_base[(int64_t)q * np + pr] = l >= 0 ? p.list_start[l] - (int64_t)(cum + inc - len) : 0;
         }
         if (p.filter) {
             const uint32_t lg = 2u * ivf_lmf_list_granules(len, (uint32_t)p.rows_per_item, grows, (uint32_t)p.sample_rows);

@@ -1706,7 +1706,7 @@ __global__ void __launch_bounds__(256) lmf_rerank_flat_kernel(IvfLmParams p) {
     u64* kq = p.keys + (int64_t)q * p.stride;
     const uint16_t* cpr = p.cand_pr + (int64_t)q * p.stride;
     const float* qrow = p.xq + (int64_t)q * p.ldq;
-    // Two phases per 256 candidates (round 5): first every thread resolves ONE candidate's row (key -> probe -> list -> row: four
+    // Two phases per 256 candidates (round 5): first every thread resolves ONE candidate's row (key -> probe -> row base: two
     // dependent loads, all 256 chains in flight together), then the groups of eight lanes walk the rows.  (One phase -- every group
     // resolving its own candidate before reading it -- paid the chain once per round of 32 candidates: 0.154 ms at nb = 1M.)
     __shared__ int64_t s_row[256];
@@ -1717,8 +1717,7 @@ __global__ void __launch_bounds__(256) lmf_rerank_flat_kernel(IvfLmParams p) {
             if (i < n) {
                 const uint32_t pos = (uint32_t)kq[i];
                 const int pr = (int)cpr[i];
-                const int64_t l = p.coarse_ids[(int64_t)q * np + pr];
-                s_row[threadIdx.x] = p.list_start[l] + (pos - p.prefix[(int64_t)q * (np + 1) + pr]);
+                s_row[threadIdx.x] = p.row_base[(int64_t)q * np + pr] + (int64_t)pos;
                 s_pos[threadIdx.x] = pos;
             }
         }
@@ -1869,8 +1868,7 @@ __global__ void __launch_bounds__(RRQ_THREADS) lmf_rerank_pq_kernel(IvfLmParams 
         if (valid) {
             pos = (uint32_t)kq[i];
             const int pr = (int)cpr[i];
-            const int64_t l = p.coarse_ids[(int64_t)q * np + pr];
-            const int64_t row = p.list_start[l] + (pos - p.prefix[(int64_t)q * (np + 1) + pr]);
+            const int64_t row = p.row_base[(int64_t)q * np + pr] + (int64_t)pos;
             dis0 = p.coarse_dis[(int64_t)q * np + pr];
             if (METRIC == METRIC_L2) t2 = p.arena_t2[row];
             if (on && fastc) {
@@ -1947,52 +1945,102 @@ __global__ void __launch_bounds__(RW_THREADS) lmf_rerank_pq64_kernel(IvfLmParams
     }
     __syncthreads();
     const int np = p.nprobe;
-    for (;;) {
-        int q = 0;
-        if (lane == 0) q = (int)atomicAdd(qcounter, 1u);
-        q = __builtin_amdgcn_readfirstlane(q);
-        if (q >= p.nq) break;
-        const int n = (int)min((int64_t)p.cnt[q], p.stride);
-        if (n == 0) continue;
+    // Latency, not arithmetic, bounds this kernel (skipping all of (b)'s arithmetic moved 0.21 ms to 0.17): a query's
+    // candidates hang off a chain of dependent loads (count -> key / probe number -> row base -> codes), and a wave that walks
+    // the chain once per 64 candidates and once per query spends its time waiting.  So: the NEXT query's number, count and
+    // coordinates are fetched while this one is worked on; the key / probe number / row base / norm loads of up to four
+    // passes are issued together BEFORE the walk over the codebook entries (a), which hides them; and the code bytes of pass
+    // j + 1 are in flight while pass j is summed.
+    constexpr int NPF = 4; // passes of 64 candidates whose metadata is fetched together
+    // the workgroup's share of the queries, handed out to its waves through a counter in LDS (ten thousand atomics on ONE
+    // device-wide counter serialise at the memory side: ~ 17 ns each, which WAS the kernel's duration)
+    uint32_t* wq = (uint32_t*)(smem + 256 * 64 * 8 + (RW_THREADS / 64) * 64 * 8);
+    const int q_end = (int)(((int64_t)p.nq * (blockIdx.x + 1)) / gridDim.x);
+    if (tid == 0) *wq = (uint32_t)(((int64_t)p.nq * blockIdx.x) / gridDim.x);
+    __syncthreads();
+    int q = 0;
+    if (lane == 0) q = (int)atomicAdd(wq, 1u);
+    q = __builtin_amdgcn_readfirstlane(q);
+    int n = 0;
+    float2 x2 = make_float2(0.f, 0.f);
+    if (q < q_end) {
+        n = (int)min((int64_t)p.cnt[q], p.stride);
+        x2 = *(const float2*)(p.xq + (int64_t)q * p.ldq + 2 * lane);
+    }
+    while (q < q_end) {
+        int qn_raw = 0;
+        if (lane == 0) qn_raw = (int)atomicAdd(wq, 1u); // (read after (a))
         u64* kq = p.keys + (int64_t)q * p.stride;
         const uint16_t* cpr = p.cand_pr + (int64_t)q * p.stride;
-        const float2 x2 = *(const float2*)(p.xq + (int64_t)q * p.ldq + 2 * lane);
-        __builtin_amdgcn_wave_barrier(); // (the reads of the previous query's pairs were issued: LDS keeps a wave's order)
-        qx[lane] = x2;
-        // ---- (a) max_c |entry(m = lane, c)|, as bit patterns (NaN beats every number, like the oracle)
-        uint32_t mx = 0u;
-#pragma unroll 8
-        for (int c = 0; c < 256; ++c) {
-            const float2 e = cbt[c * M + lane];
-            const float acc = __fmaf_rn(x2.y, e.y, __fmaf_rn(x2.x, e.x, 0.f));
-            mx = max(mx, __float_as_uint(fabsf(acc)));
-        }
-        float B = 0.f; // in sub-quantizer order, in every lane
-#pragma unroll
-        for (int m = 0; m < M; ++m) B = B + __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)mx, m));
+        const int64_t* rbq = p.row_base + (int64_t)q * np;
+        const float* cdq = p.coarse_dis + (int64_t)q * np;
         float delta = 0.f, inv = 0.f;
-        const bool on = pq_lut_grid(B, &delta, &inv);
-        // ---- (b) candidates, 64 per pass
-        for (int base = 0; base < n; base += 64) {
-            const int i = base + lane;
-            const bool valid = i < n;
-            float s = 0.f, dis0 = 0.f, t2 = 0.f;
-            uint32_t pos = 0;
-            if (valid) {
-                pos = (uint32_t)kq[i];
-                const int pr = (int)cpr[i];
-                const int64_t l = p.coarse_ids[(int64_t)q * np + pr];
-                const int64_t row = p.list_start[l] + (pos - p.prefix[(int64_t)q * (np + 1) + pr]);
-                dis0 = p.coarse_dis[(int64_t)q * np + pr];
-                if (METRIC == METRIC_L2) t2 = p.arena_t2[row];
-                const int lrot = (int)(row & 63);
-                if (on) {
-                    // the row's 64 stored bytes: chunk ch holds the stored bytes 16 ch .. 16 ch + 15 (kernels.h pq_code_offset);
-                    // stored byte x is the code of sub-quantizer (x + row) mod 64
-                    const uint8_t* rp = p.arena_codes + (size_t)(row >> 6) * 64 * M + (size_t)lrot * 16;
-                    uint4 w[4];
+        bool on = false;
+        int qn = 0, nn = 0;
+        float2 x2n = make_float2(0.f, 0.f);
+        auto fetch_next = [&]() __attribute__((always_inline)) {
+            qn = __builtin_amdgcn_readfirstlane(qn_raw);
+            if (qn < q_end) {
+                nn = (int)min((int64_t)p.cnt[qn], p.stride);
+                x2n = *(const float2*)(p.xq + (int64_t)qn * p.ldq + 2 * lane);
+            }
+        };
+        if (n == 0) fetch_next();
+        for (int base0 = 0; base0 < n; base0 += 64 * NPF) {
+            // ---- metadata of the group's passes (indices clamped: every lane loads, only valid lanes store)
+            uint32_t pos[NPF];
+            int pr[NPF];
+#pragma unroll
+            for (int j = 0; j < NPF; ++j) {
+                const int i = min(base0 + 64 * j + lane, n - 1);
+                pos[j] = (uint32_t)kq[i];
+                pr[j] = (int)cpr[i];
+            }
+            int64_t row[NPF];
+            float dis0[NPF], t2[NPF];
+#pragma unroll
+            for (int j = 0; j < NPF; ++j) {
+                row[j] = rbq[pr[j]] + (int64_t)pos[j];
+                dis0[j] = cdq[pr[j]];
+            }
+#pragma unroll
+            for (int j = 0; j < NPF; ++j) t2[j] = METRIC == METRIC_L2 ? p.arena_t2[row[j]] : 0.f;
+            if (base0 == 0) {
+                __builtin_amdgcn_wave_barrier(); // (the reads of the previous query's pairs were issued: LDS keeps a wave's order)
+                qx[lane] = x2;
+                // ---- (a) max_c |entry(m = lane, c)|, as bit patterns (NaN beats every number, like the oracle)
+                uint32_t mx = 0u;
+#pragma unroll 8
+                for (int c = 0; c < 256; ++c) {
+                    const float2 e = cbt[c * M + lane];
+                    const float acc = __fmaf_rn(x2.y, e.y, __fmaf_rn(x2.x, e.x, 0.f));
+                    mx = max(mx, __float_as_uint(fabsf(acc)));
+                }
+                float B = 0.f; // in sub-quantizer order, in every lane
+#pragma unroll
+                for (int m = 0; m < M; ++m) B = B + __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)mx, m));
+                on = pq_lut_grid(B, &delta, &inv);
+                // the next query: its number arrived during (a); its count and coordinates travel during the passes
+                fetch_next();
+            }
+            // ---- (b) candidates, 64 per pass
+            if (on) {
+                // a row's 64 stored bytes: chunk ch holds the stored bytes 16 ch .. 16 ch + 15 (kernels.h pq_code_offset);
+                // stored byte x is the code of sub-quantizer (x + row) mod 64
+                auto codes_of = [&](int64_t r, uint4 (&w)[4]) __attribute__((always_inline)) {
+                    const uint8_t* rp = p.arena_codes + (size_t)(r >> 6) * 64 * M + (size_t)(r & 63) * 16;
 #pragma unroll
                     for (int ch = 0; ch < 4; ++ch) w[ch] = *(const uint4*)(rp + ch * 1024);
+                };
+                uint4 w[4];
+                codes_of(row[0], w);
+#pragma unroll
+                for (int j = 0; j < NPF; ++j) {
+                    if (base0 + 64 * j >= n) break; // (wave-uniform)
+                    uint4 wn[4] = {};
+                    if (j + 1 < NPF && base0 + 64 * (j + 1) < n) codes_of(row[j + 1 < NPF ? j + 1 : j], wn);
+                    const int lrot = (int)(row[j] & 63);
+                    float s = 0.f;
 #pragma unroll
                     for (int ch = 0; ch < 4; ++ch) {
                         const unsigned ww[4] = {w[ch].x, w[ch].y, w[ch].z, w[ch].w};
@@ -2006,25 +2054,38 @@ __global__ void __launch_bounds__(RW_THREADS) lmf_rerank_pq64_kernel(IvfLmParams
                             s = s + __builtin_rintf(ent * inv) * delta;
                         }
                     }
-                } else {
-                    // no grid (NaN / inf / all-zero tables): the plain sum in sub-quantizer order, like the oracle
+                    const float dis = METRIC == METRIC_L2 ? __fmaf_rn(-2.f, s, dis0[j] + t2[j]) : dis0[j] + s;
+                    const int i = base0 + 64 * j + lane;
+                    if (i < n) kq[i] = ((u64)ordkey<METRIC>(dis) << 32) | (u64)pos[j];
+#pragma unroll
+                    for (int ch = 0; ch < 4; ++ch) w[ch] = wn[ch];
+                }
+            } else {
+                // no grid (NaN / inf / all-zero tables): the plain sum in sub-quantizer order, like the oracle
+#pragma unroll
+                for (int j = 0; j < NPF; ++j) {
+                    const int i = base0 + 64 * j + lane;
+                    if (i >= n) continue;
+                    float s = 0.f;
                     for (int m = 0; m < M; ++m) {
-                        const unsigned code = p.arena_codes[pq_code_offset(M, row, m)];
+                        const unsigned code = p.arena_codes[pq_code_offset(M, row[j], m)];
                         const float2 e = cbt[(int)code * M + m];
                         const float2 xm = qx[m];
                         s = s + __fmaf_rn(xm.y, e.y, __fmaf_rn(xm.x, e.x, 0.f));
                     }
+                    const float dis = METRIC == METRIC_L2 ? __fmaf_rn(-2.f, s, dis0[j] + t2[j]) : dis0[j] + s;
+                    kq[i] = ((u64)ordkey<METRIC>(dis) << 32) | (u64)pos[j];
                 }
-                const float dis = METRIC == METRIC_L2 ? __fmaf_rn(-2.f, s, dis0 + t2) : dis0 + s;
-                kq[i] = ((u64)ordkey<METRIC>(dis) << 32) | (u64)pos;
             }
         }
+        q = qn, n = nn, x2 = x2n;
     }
 }
 void launch_ivf_lmf_rerank(const IvfLmParams& p, hipStream_t stream) {
     if (p.nq == 0) return;
     // (fused selection: launch_ivf_lmf_tighten left at most kLmfFusedSelectN candidates or listed the query for the redo)
     FA_THROW_IF_NOT(!p.fin_dis || (p.fin_ids && p.arena_ids && p.k <= kLmfFusedSelectK));
+    FA_THROW_IF_NOT(p.row_base != nullptr); // (written by launch_ivf_lm_plan)
     const dim3 grid((unsigned)p.nq), block(256);
     if (p.kind == 0) {
         if (p.metric == METRIC_L2) hipLaunchKernelGGL(lmf_rerank_flat_kernel<METRIC_L2>, grid, block, 0, stream, p);
@@ -2032,7 +2093,7 @@ void launch_ivf_lmf_rerank(const IvfLmParams& p, hipStream_t stream) {
     } else if (p.M == 64 && p.dsub == 2 && !p.fin_dis && p.rr_counter) {
         // the bench shape: a wavefront per query, the codebook in LDS (lmf_rerank_pq64_kernel)
         FA_THROW_IF_NOT((p.metric != METRIC_L2 || p.arena_t2) && p.pq_t && p.ldq % 2 == 0);
-        const int lds = 256 * 64 * 8 + (RW_THREADS / 64) * 64 * 8;
+        const int lds = 256 * 64 * 8 + (RW_THREADS / 64) * 64 * 8 + 16;
         const int blocks = std::max(1, std::min(p.rr_blocks, (p.nq + RW_THREADS / 64 - 1) / (RW_THREADS / 64)));
         HIP_CHECK(hipMemsetAsync(p.rr_counter, 0, 4, stream));
         if (p.metric == METRIC_L2) {

@@ -516,6 +516,8 @@ struct IvfLmParams {
     void* pair16;
     float* pair_xh;
     uint16_t* cand_pr;          // [nq][stride] probe number of every collected candidate (beside keys)
+    int64_t* row_base;          // [nq][nprobe] list_start[list of the probe] - prefix[q][probe]: arena row = row_base + scan position
+                                // (written by the plan when not null; the rerank kernels read it instead of three dependent loads)
     const float* arena_t2;      // kind 1, L2: the per-row term of the query-major scan (rerank)
     const float* xn_full;       // [nq] |q|^2 (kind 0: == xqn)
     float yn_max;               // max |y|^2 over the stored rows (kind 0) / upper bound of |r^|^2 from the codebook (kind 1)

@@ -22,9 +22,8 @@ __device__ __forceinline__ void lmf_select_tail(const IvfLmParams& p, int q, int
         if (r < k) {
             const uint32_t pos = (uint32_t)ki;
             const int pr = (int)cpr[i];
-            const int64_t l = p.coarse_ids[(int64_t)q * np + pr];
             wk[r] = (uint32_t)(ki >> 32);
-            wl[r] = p.arena_ids[p.list_start[l] + (pos - p.prefix[(int64_t)q * (np + 1) + pr])];
+            wl[r] = p.arena_ids[p.row_base[(int64_t)q * np + pr] + (int64_t)pos];
         }
     }
     __syncthreads();
