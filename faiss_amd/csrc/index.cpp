@@ -2808,7 +2808,9 @@ void GpuIndexIVF::search_listmajor_filter_chunk_(int ni, int q0, const float* xq
     }
     // the workgroup that re-derives a query's candidates also selects its k best when both fit its LDS (no selection launch)
     // (IVFFlat: rerank 0.135 -> 0.19 ms for 0.105 ms of selection launch at nb = 1M; IVFPQ keeps the separate launch: its rerank
-    // workgroups -- two per CU, the 64 KB table -- serialise the tail: 0.25 -> 0.52 ms).  The tightening launch leaves a query
+    // workgroups -- two per CU, the 64 KB table -- serialise the tail: 0.25 -> 0.52 ms; and a selection inside the wave-per-query
+    // kernel -- ranks by v_readlane counting, k = 100 -- cost that kernel the 0.065 ms the selection launch takes: 0.092 + 0.063
+    // -> 0.158).  The tightening launch leaves a query
     // with more than kLmfFusedSelectN candidates (that many rows inside the band of its k-th best) to the redo path.
     static const char* pqfs = experiment_env("FAISS_AMD_LMF_PQ_FUSED_SELECT"); // timing experiment
     const bool fused_select = (P.kind != 1 || (pqfs && atoi(pqfs) == 1)) && k <= kLmfFusedSelectK;
@@ -2828,10 +2830,7 @@ void GpuIndexIVF::search_listmajor_filter_chunk_(int ni, int q0, const float* xq
     {
         SpanGuard sg(&R, "ivf_lmf_rerank");
         static const char* rr_old = experiment_env("FAISS_AMD_LMF_RERANK_WG"); // A/B: 1 = the workgroup-per-query kernel
-        if (P.kind == 1 && !(rr_old && atoi(rr_old) == 1)) {
-            P.rr_counter = lm_scalar_.as<uint32_t>() + 8;
-            P.rr_blocks = R.num_cus;
-        }
+        if (P.kind == 1 && !(rr_old && atoi(rr_old) == 1)) P.rr_blocks = R.num_cus;
         if (P.kind == 2) launch_ivf_lmf_rerank_sq(P, R.stream);
         else launch_ivf_lmf_rerank(P, R.stream);
     }

@@ -1931,7 +1931,7 @@ __global__ void __launch_bounds__(RRQ_THREADS) lmf_rerank_pq_kernel(IvfLmParams 
 // order, entries rounded to the grid where they are looked up, the sum order-free.
 constexpr int RW_THREADS = 1024;
 template <int METRIC>
-__global__ void __launch_bounds__(RW_THREADS) lmf_rerank_pq64_kernel(IvfLmParams p, uint32_t* __restrict__ qcounter) {
+__global__ void __launch_bounds__(RW_THREADS) lmf_rerank_pq64_kernel(IvfLmParams p) {
     constexpr int M = 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* cbt = (float2*)smem;                 // [256][64] entries (two coordinates each): 128 KB
@@ -2090,20 +2090,18 @@ void launch_ivf_lmf_rerank(const IvfLmParams& p, hipStream_t stream) {
     if (p.kind == 0) {
         if (p.metric == METRIC_L2) hipLaunchKernelGGL(lmf_rerank_flat_kernel<METRIC_L2>, grid, block, 0, stream, p);
         else hipLaunchKernelGGL(lmf_rerank_flat_kernel<METRIC_INNER_PRODUCT>, grid, block, 0, stream, p);
-    } else if (p.M == 64 && p.dsub == 2 && !p.fin_dis && p.rr_counter) {
+    } else if (p.M == 64 && p.dsub == 2 && !p.fin_dis && p.rr_blocks > 0) {
         // the bench shape: a wavefront per query, the codebook in LDS (lmf_rerank_pq64_kernel)
         FA_THROW_IF_NOT((p.metric != METRIC_L2 || p.arena_t2) && p.pq_t && p.ldq % 2 == 0);
         const int lds = 256 * 64 * 8 + (RW_THREADS / 64) * 64 * 8 + 16;
         const int blocks = std::max(1, std::min(p.rr_blocks, (p.nq + RW_THREADS / 64 - 1) / (RW_THREADS / 64)));
-        HIP_CHECK(hipMemsetAsync(p.rr_counter, 0, 4, stream));
         if (p.metric == METRIC_L2) {
             HIP_CHECK(hipFuncSetAttribute((const void*)lmf_rerank_pq64_kernel<METRIC_L2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            hipLaunchKernelGGL(lmf_rerank_pq64_kernel<METRIC_L2>, dim3((unsigned)blocks), dim3(RW_THREADS), lds, stream, p, p.rr_counter);
+            hipLaunchKernelGGL(lmf_rerank_pq64_kernel<METRIC_L2>, dim3((unsigned)blocks), dim3(RW_THREADS), lds, stream, p);
         } else {
             HIP_CHECK(hipFuncSetAttribute((const void*)lmf_rerank_pq64_kernel<METRIC_INNER_PRODUCT>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            hipLaunchKernelGGL(lmf_rerank_pq64_kernel<METRIC_INNER_PRODUCT>, dim3((unsigned)blocks), dim3(RW_THREADS), lds, stream, p,
-                               p.rr_counter);
+            hipLaunchKernelGGL(lmf_rerank_pq64_kernel<METRIC_INNER_PRODUCT>, dim3((unsigned)blocks), dim3(RW_THREADS), lds, stream, p);
         }
     } else {
         FA_THROW_IF_NOT((p.metric != METRIC_L2 || p.arena_t2) && p.pq_t);

@@ -536,9 +536,8 @@ struct IvfLmParams {
     // the rule of select_k_kernel / wave_select_kernel -- and writes the result rows; no selection launch follows
     float* fin_dis;
     int64_t* fin_ids;
-    // IVFPQ rerank, PQ64 over d = 128 (lmf_rerank_pq64_kernel): query counter the wavefronts draw from (null: the
-    // workgroup-per-query kernel serves the shape too), workgroups to launch (one per CU)
-    uint32_t* rr_counter;
+    // IVFPQ rerank, PQ64 over d = 128 (lmf_rerank_pq64_kernel, a wavefront per query): workgroups to launch (one per CU; 0: the
+    // workgroup-per-query kernel serves the shape too)
     int rr_blocks;
     const int64_t* arena_ids;
 };

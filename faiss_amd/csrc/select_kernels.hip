@@ -327,24 +327,21 @@ __global__ void __launch_bounds__(256) wave_select_kernel(SelectParams p, int kp
         }
         asm volatile("" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        u64 mykey[4];
-        unsigned r[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) mykey[i] = ((u64)hi[i] << 32) | lo[i];
-        for (unsigned j = 0; j < n; ++j) {
-            const u64 kj = sk[j];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) r[i] += kj < mykey[i] ? 1u : 0u;
-        }
+        // (two keys of the lane per walk over the slice: the 128 key registers leave room for little else at three waves per SIMD)
         bool found = false;
         unsigned fh = 0u, fl = 0u;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if ((unsigned)lane + 64u * i < n && r[i] == k - 1u) {
-                found = true;
-                fh = hi[i];
-                fl = lo[i];
+        for (int i0 = 0; i0 < 4; i0 += 2) {
+            if (64u * i0 >= n) break; // (wave-uniform)
+            unsigned r0 = 0u, r1 = 0u;
+            for (unsigned j = 0; j < n; ++j) {
+                const u64 kj = sk[j];
+                const unsigned jh = (unsigned)(kj >> 32), jl = (unsigned)kj;
+                r0 += (jh < hi[i0] || (jh == hi[i0] && jl < lo[i0])) ? 1u : 0u;
+                r1 += (jh < hi[i0 + 1] || (jh == hi[i0 + 1] && jl < lo[i0 + 1])) ? 1u : 0u;
             }
+            if ((unsigned)lane + 64u * i0 < n && r0 == k - 1u) found = true, fh = hi[i0], fl = lo[i0];
+            if ((unsigned)lane + 64u * (i0 + 1) < n && r1 == k - 1u) found = true, fh = hi[i0 + 1], fl = lo[i0 + 1];
         }
         const unsigned long long fb = __ballot(found);
         if (fb) {
