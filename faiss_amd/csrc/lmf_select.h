@@ -37,13 +37,17 @@ __device__ __forceinline__ void lmf_select_tail(const IvfLmParams& p, int q, int
             oi[i] = -1;
             continue;
         }
+        // (the slots are in (distance, position) order: the winners with a smaller distance are the slots before the run of equal
+        // distances around i, and only that run -- one slot unless distances tie -- is ranked by (label, slot))
         const uint32_t a = wk[i];
         const int64_t ia = wl[i];
-        int r = 0;
-        for (int j = 0; j < nwin; ++j) {
-            const uint32_t b = wk[j];
+        int lo = i, hi = i + 1;
+        while (lo > 0 && wk[lo - 1] == a) --lo;
+        while (hi < nwin && wk[hi] == a) ++hi;
+        int r = lo;
+        for (int j = lo; j < hi; ++j) {
             const int64_t ib = wl[j];
-            r += (b < a || (b == a && (ib < ia || (ib == ia && j < i)))) ? 1 : 0;
+            r += (ib < ia || (ib == ia && j < i)) ? 1 : 0;
         }
         const bool real = a < kInvalidOrdKey;
         od[r] = real ? unordkey_rt(p.metric, a) : pad;

@@ -11,6 +11,7 @@
 // exit when the k-th key is the maximum of its bucket), gather of the <= k winners into LDS,
 // payload -> label translation, bitonic sort of the winners, coalesced write-out.
 #include "kernels.h"
+#include <type_traits>
 #include "wave_select.h"
 #include "wg_select.h"
 
@@ -560,11 +561,20 @@ __global__ void __launch_bounds__(256) small_select_kernel(SelectParams p) {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     unsigned r[4] = {0u, 0u, 0u, 0u};
-    for (unsigned j = 0; j < n; ++j) {
-        const u64 kj = sk[j];
+    // (the kernel is VALU-bound -- 10 000 waves x a few thousand instructions --, so only the register slots that hold keys are
+    // ranked: n = 140 fills three of the four)
+    auto rank_slots = [&](auto ns_c) __attribute__((always_inline)) {
+        constexpr int NS = decltype(ns_c)::value;
+        for (unsigned j = 0; j < n; ++j) {
+            const u64 kj = sk[j];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) r[i] += kj < key[i] ? 1u : 0u;
-    }
+            for (int i = 0; i < NS; ++i) r[i] += kj < key[i] ? 1u : 0u;
+        }
+    };
+    if (n <= 64u) rank_slots(std::integral_constant<int, 1>{});
+    else if (n <= 128u) rank_slots(std::integral_constant<int, 2>{});
+    else if (n <= 192u) rank_slots(std::integral_constant<int, 3>{});
+    else rank_slots(std::integral_constant<int, 4>{});
     const unsigned nwin = min(n, k);
     // winners -> slot = rank, with their labels
 #pragma unroll
@@ -604,13 +614,17 @@ __global__ void __launch_bounds__(256) small_select_kernel(SelectParams p) {
             oi[t] = -1;
             continue;
         }
+        // The slots are in (distance, position) order, so the winners with a smaller distance are exactly the slots before the
+        // run of equal distances around t: only that run -- one slot unless distances tie -- is ranked by (label, slot).
         const unsigned a = wk[t];
         const int64_t ia = wl[t];
-        unsigned r2 = 0;
-        for (unsigned j = 0; j < nwin; ++j) {
-            const unsigned b = wk[j];
+        unsigned lo = t, hi = t + 1u;
+        while (lo > 0u && wk[lo - 1u] == a) --lo;
+        while (hi < nwin && wk[hi] == a) ++hi;
+        unsigned r2 = lo;
+        for (unsigned j = lo; j < hi; ++j) {
             const int64_t ib = wl[j];
-            r2 += (b < a || (b == a && (ib < ia || (ib == ia && j < t)))) ? 1u : 0u;
+            r2 += (ib < ia || (ib == ia && j < t)) ? 1u : 0u;
         }
         const bool real = a < kInvalidOrdKey;
         od[r2] = real ? unordkey_rt(p.metric, a) : pad;
