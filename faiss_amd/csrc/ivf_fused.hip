@@ -956,6 +956,73 @@ __global__ void __launch_bounds__(256) lmf_rerank_sq_kernel(IvfLmParams p) {
         __syncthreads();
     }
     const float qb = METRIC != METRIC_L2 ? s_qb : 0.f;
+    // The table entries (a_j, s_j) of the query -- per probe when the codes are residuals -- are computed ONCE per workgroup into
+    // LDS when they fit (nprobe x 16 nch <= 4096 floats: nprobe <= 32 at d = 128).  (Every lane recomputing them from the query,
+    // the decoder tables and its probe's centroid cost 16 sixteen-byte loads per lane and chunk, 136 per candidate: the
+    // texture path, not HBM, paced the kernel -- 0.18 ms at nb = 1M.)  Same expressions, evaluated once instead of per candidate.
+    // Rows of s_a are dp + 4 floats apart: lanes of different probes read the same chunk of different rows at once, and rows a
+    // multiple of 128 bytes apart would all start in the same bank.
+    __shared__ __attribute__((aligned(16))) float s_a[4096 + 4 * 64];
+    __shared__ __attribute__((aligned(16))) float s_s[512];
+    const int dp = 16 * nch, lda = dp + 4;
+    const int arows = per_probe ? np : 1;
+    const bool staged = arows * dp <= 4096 && arows <= 64 && dp <= 512; // (workgroup-uniform)
+    if (staged) {
+        // one (row, chunk) per thread and round: its loads leave together
+        for (int t = tid; t < arows * nch; t += 256) {
+            const int pr = t / nch, c = t - pr * nch;
+            const int64_t l = per_probe ? p.coarse_ids[(int64_t)q * np + pr] : -1;
+            const float* cen = p.centroids + (l >= 0 ? l : 0) * p.ldc;
+            float av[16];
+            if (16 * c + 16 <= p.d) {
+#pragma unroll
+                for (int v4 = 0; v4 < 4; ++v4) {
+                    const f32x4 x4 = *(const f32x4*)(xq + 16 * c + 4 * v4);
+                    f32x4 s4 = f32x4{0.f, 0.f, 0.f, 0.f}, b4 = s4, c4 = s4;
+                    if (CT != SQ_F16) {
+                        s4 = *(const f32x4*)(p.sq_s + 16 * c + 4 * v4);
+                        b4 = *(const f32x4*)(p.sq_b_plain + 16 * c + 4 * v4);
+                    }
+                    if (per_probe && l >= 0) c4 = *(const f32x4*)(cen + 16 * c + 4 * v4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float a;
+                        if (per_probe) {
+                            a = x4[e] - c4[e];
+                            if (CT != SQ_F16) a = a - b4[e];
+                        } else if (METRIC == METRIC_L2) {
+                            a = CT == SQ_F16 ? x4[e] : x4[e] - b4[e];
+                        } else {
+                            a = CT == SQ_F16 ? x4[e] : x4[e] * s4[e];
+                        }
+                        av[4 * v4 + e] = a;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int jx = 16 * c + e;
+                    float a = 0.f;
+                    if (jx < p.d) {
+                        if (per_probe) {
+                            a = xq[jx] - (l >= 0 ? cen[jx] : 0.f);
+                            if (CT != SQ_F16) a = a - p.sq_b_plain[jx];
+                        } else if (METRIC == METRIC_L2) {
+                            a = CT == SQ_F16 ? xq[jx] : xq[jx] - p.sq_b_plain[jx];
+                        } else {
+                            a = CT == SQ_F16 ? xq[jx] : xq[jx] * p.sq_s[jx];
+                        }
+                    }
+                    av[e] = a;
+                }
+            }
+#pragma unroll
+            for (int v4 = 0; v4 < 4; ++v4)
+                *(f32x4*)(s_a + pr * lda + 16 * c + 4 * v4) = f32x4{av[4 * v4], av[4 * v4 + 1], av[4 * v4 + 2], av[4 * v4 + 3]};
+        }
+        for (int t = tid; t < dp; t += 256) s_s[t] = (CT != SQ_F16 && t < p.d) ? p.sq_s[t] : 0.f;
+        __syncthreads();
+    }
     for (int i = tid; i < n; i += 256) {
         const uint32_t pos = (uint32_t)kq[i];
         const int pr = (int)cpr[i];
@@ -968,7 +1035,15 @@ __global__ void __launch_bounds__(256) lmf_rerank_sq_kernel(IvfLmParams p) {
             // the table entries of this chunk for the candidate's probe: the expressions of ivfsq_fused_kernel's table build.
             // Whole chunks through 16-byte loads (the rows of xq / centroids / sq_s / sq_b are padded to 8 floats and more)
             float sv[16], av[16];
-            if (16 * c + 16 <= p.d) { // (workgroup-uniform)
+            if (staged) {
+                const float* ar = s_a + (per_probe ? pr : 0) * lda + 16 * c;
+#pragma unroll
+                for (int v4 = 0; v4 < 4; ++v4) {
+                    const f32x4 a4 = *(const f32x4*)(ar + 4 * v4), s4 = *(const f32x4*)(s_s + 16 * c + 4 * v4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) av[4 * v4 + e] = a4[e], sv[4 * v4 + e] = s4[e];
+                }
+            } else if (16 * c + 16 <= p.d) { // (workgroup-uniform)
 #pragma unroll
                 for (int v4 = 0; v4 < 4; ++v4) {
                     const f32x4 x4 = *(const f32x4*)(xq + 16 * c + 4 * v4);

@@ -56,6 +56,7 @@ def main():
         kind, size = leg.split("_")
         nb = int(size[:-1]) * 1000000
         idx = (faiss_amd.GpuIndexIVFPQ(res, D, NLIST, 64, 8, faiss_amd.METRIC_L2) if kind == "ivfpq"
+               else faiss_amd.GpuIndexIVFScalarQuantizer(res, D, NLIST, faiss_amd.ScalarQuantizer.QT_8bit, faiss_amd.METRIC_L2, True) if kind == "ivfsq"
                else faiss_amd.GpuIndexIVFFlat(res, D, NLIST, faiss_amd.METRIC_L2))
         idx.train(xt)
         idx.add(xb)
