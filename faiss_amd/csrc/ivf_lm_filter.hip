@@ -1324,7 +1324,7 @@ void launch_ivf_lmf_sweep(const IvfLmParams& p, int mode, int grid_blocks, hipSt
 }
 
 // ------------------------------------------------------------------ bound: k-th best granule estimate + error band
-// One workgroup per query: radix select (4 x 8 bits) over the query's granule slots.
+// One workgroup per query: radix select (8 bits per pass) over the query's granule slots.
 template <int METRIC>
 __global__ void __launch_bounds__(256) lmf_bound_kernel(IvfLmParams p, const float* __restrict__ xn_bound) {
     __shared__ uint32_t hist[256];
@@ -1349,19 +1349,65 @@ __global__ void __launch_bounds__(256) lmf_bound_kernel(IvfLmParams p, const flo
         if (tid == 0) p.thr_f[q] = lmf_worst<METRIC>();
         return;
     }
+    // The estimates of one query share sign and exponent and most of them the leading mantissa bits: a digit of the raw key
+    // puts every slot into one or two bins (256 threads queueing on the same LDS word) and the top pass decides nothing.  So
+    // the digits are those of key - min over the bits in which the query's valid keys differ at all: ceil(bits / 8) passes
+    // (three for the usual 2^22 .. 2^24 spread) over evenly filled bins.  Empty slots (0xffffffff) take no part: with fewer
+    // than k valid slots the k-th best is an empty one.
+    __shared__ uint32_t red_min[4], red_max[4], red_cnt[4];
+    // Up to 2048 slots live in registers (eight per thread, loaded together): the passes below then cost no memory round trips
+    // (a loop of dependent L2 reads per pass -- six rounds at nb = 10M, four passes -- was most of the kernel's 0.09 ms).
+    constexpr int BR = 8;
+    const bool inreg = S <= 256u * BR; // (workgroup-uniform)
+    uint32_t vals[BR];
+#pragma unroll
+    for (int u = 0; u < BR; ++u) {
+        const uint32_t i = (uint32_t)tid + 256u * u;
+        vals[u] = inreg && i < S ? g[i] : 0xffffffffu;
+    }
+    auto for_slots = [&](auto fn) __attribute__((always_inline)) {
+        if (inreg) {
+#pragma unroll
+            for (int u = 0; u < BR; ++u) fn(vals[u]);
+        } else {
+            for (uint32_t i = tid; i < S; i += 256) fn(g[i]);
+        }
+    };
+    uint32_t vmin = 0xffffffffu, vmax = 0u, nval = 0u;
+    for_slots([&](uint32_t v) {
+        if (v < kInvalidOrdKey) {
+            vmin = min(vmin, v);
+            vmax = max(vmax, v);
+            ++nval;
+        }
+    });
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        vmin = min(vmin, (uint32_t)__shfl_xor((int)vmin, off, 64));
+        vmax = max(vmax, (uint32_t)__shfl_xor((int)vmax, off, 64));
+        nval += (uint32_t)__shfl_xor((int)nval, off, 64);
+    }
+    if ((tid & 63) == 0) red_min[tid >> 6] = vmin, red_max[tid >> 6] = vmax, red_cnt[tid >> 6] = nval;
     if (tid == 0) {
         sel_prefix = 0u;
         sel_need = (uint32_t)p.k;
     }
-    for (int pass = 3; pass >= 0; --pass) {
+    __syncthreads();
+    vmin = min(min(red_min[0], red_min[1]), min(red_min[2], red_min[3]));
+    vmax = max(max(red_max[0], red_max[1]), max(red_max[2], red_max[3]));
+    nval = red_cnt[0] + red_cnt[1] + red_cnt[2] + red_cnt[3];
+    const bool enough = nval >= (uint32_t)p.k; // (workgroup-uniform)
+    const uint32_t range = enough ? vmax - vmin : 0u;
+    const int npass = range == 0u ? 0 : (32 - __builtin_clz(range) + 7) >> 3;
+    for (int pass = npass - 1; pass >= 0; --pass) {
         hist[tid] = 0u;
         __syncthreads();
         const uint32_t pre = sel_prefix;
-        for (uint32_t i = tid; i < S; i += 256) {
-            const uint32_t v = g[i];
-            const bool in = pass == 3 || (v >> (8 * (pass + 1))) == pre;
-            if (in) atomicAdd(&hist[(v >> (8 * pass)) & 255u], 1u);
-        }
+        for_slots([&](uint32_t v) {
+            const uint32_t w = v - vmin;
+            const bool in = v < kInvalidOrdKey && (pass == 3 || (w >> (8 * (pass + 1))) == pre);
+            if (in) atomicAdd(&hist[(w >> (8 * pass)) & 255u], 1u);
+        });
         __syncthreads();
         if (tid < 64) {
             // bucket holding the sel_need-th smallest: exclusive prefix over 256 bins, 4 bins per lane
@@ -1386,7 +1432,7 @@ __global__ void __launch_bounds__(256) lmf_bound_kernel(IvfLmParams p, const flo
         __syncthreads();
     }
     if (tid == 0) {
-        const uint32_t tk = sel_prefix;
+        const uint32_t tk = enough ? vmin + sel_prefix : 0xffffffffu;
         float thr;
         if (tk >= kInvalidOrdKey) {
             thr = lmf_worst<METRIC>();
