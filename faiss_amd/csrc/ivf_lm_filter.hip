@@ -1511,19 +1511,56 @@ __global__ void __launch_bounds__(256) lmf_tighten_kernel(IvfLmParams p, int fin
     uint16_t* cpr = p.cand_pr + (int64_t)q * p.stride;
     const float E = p.err_f[q];
     if (n > (uint32_t)p.k && E < INFINITY) {
+        // (as in lmf_bound_kernel: up to 2048 candidates wait in registers -- one round of loads for the selection passes and the
+        // compaction --, and the digits are those of key - min over the bits in which the query's estimate keys differ)
+        constexpr int BR = 8;
+        const bool inreg = n <= 256u * BR; // (workgroup-uniform)
+        u64 kv[BR];
+        uint16_t pv[BR];
+#pragma unroll
+        for (int u = 0; u < BR; ++u) {
+            const uint32_t i = (uint32_t)tid + 256u * u;
+            const bool ok = inreg && i < n;
+            kv[u] = ok ? kq[i] : ~0ull;
+            pv[u] = ok ? cpr[i] : (uint16_t)0;
+        }
+        auto for_est = [&](auto fn) __attribute__((always_inline)) { // fn(estimate key, it is a candidate's)
+            if (inreg) {
+#pragma unroll
+                for (int u = 0; u < BR; ++u) fn((uint32_t)(kv[u] >> 32), (uint32_t)tid + 256u * u < n);
+            } else {
+                for (uint32_t i = tid; i < n; i += 256) fn((uint32_t)(kq[i] >> 32), true);
+            }
+        };
+        __shared__ uint32_t red_min[4], red_max[4];
+        uint32_t vmin = 0xffffffffu, vmax = 0u;
+        for_est([&](uint32_t v, bool ok) {
+            if (ok) vmin = min(vmin, v), vmax = max(vmax, v);
+        });
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            vmin = min(vmin, (uint32_t)__shfl_xor((int)vmin, off, 64));
+            vmax = max(vmax, (uint32_t)__shfl_xor((int)vmax, off, 64));
+        }
+        if ((tid & 63) == 0) red_min[tid >> 6] = vmin, red_max[tid >> 6] = vmax;
         if (tid == 0) {
             sel_prefix = 0u;
             sel_need = (uint32_t)p.k;
             nkeep = 0u;
         }
-        for (int pass = 3; pass >= 0; --pass) { // radix select of the k-th smallest estimate key (lmf_bound_kernel's loop)
+        __syncthreads();
+        vmin = min(min(red_min[0], red_min[1]), min(red_min[2], red_min[3]));
+        vmax = max(max(red_max[0], red_max[1]), max(red_max[2], red_max[3]));
+        const uint32_t range = vmax - vmin;
+        const int npass = range == 0u ? 0 : (32 - __builtin_clz(range) + 7) >> 3;
+        for (int pass = npass - 1; pass >= 0; --pass) { // radix select of the k-th smallest estimate key
             hist[tid] = 0u;
             __syncthreads();
             const uint32_t pre = sel_prefix;
-            for (uint32_t i = tid; i < n; i += 256) {
-                const uint32_t v = (uint32_t)(kq[i] >> 32);
-                if (pass == 3 || (v >> (8 * (pass + 1))) == pre) atomicAdd(&hist[(v >> (8 * pass)) & 255u], 1u);
-            }
+            for_est([&](uint32_t v, bool ok) {
+                const uint32_t w = v - vmin;
+                if (ok && (pass == 3 || (w >> (8 * (pass + 1))) == pre)) atomicAdd(&hist[(w >> (8 * pass)) & 255u], 1u);
+            });
             __syncthreads();
             if (tid < 64) {
                 uint32_t c[4], sum = 0;
@@ -1546,23 +1583,26 @@ __global__ void __launch_bounds__(256) lmf_tighten_kernel(IvfLmParams p, int fin
             }
             __syncthreads();
         }
-        const float T2 = unordkey<METRIC>(sel_prefix);
+        const float T2 = unordkey<METRIC>(vmin + sel_prefix);
         float thr = METRIC == METRIC_L2 ? T2 + 2.f * E : T2 - 2.f * E;
         if (thr != thr) thr = lmf_worst<METRIC>();
         const uint32_t tkey = ordkey<METRIC>(thr);
         // (an estimate key of a collected row is never the invalid key; tkey >= the k-th key, so at least k rows stay)
-        for (uint32_t i0 = 0; i0 < n; i0 += 256) {
-            const uint32_t i = i0 + tid;
-            if (i < n) {
-                const u64 key = kq[i];
-                if ((uint32_t)(key >> 32) <= tkey) {
-                    const uint32_t s = atomicAdd(&nkeep, 1u);
-                    if (s < (uint32_t)LT_CAP) {
-                        keep_k[s] = key;
-                        keep_p[s] = cpr[i];
-                    }
+        auto keep = [&](u64 key, uint16_t pr) __attribute__((always_inline)) {
+            if ((uint32_t)(key >> 32) <= tkey) {
+                const uint32_t s = atomicAdd(&nkeep, 1u);
+                if (s < (uint32_t)LT_CAP) {
+                    keep_k[s] = key;
+                    keep_p[s] = pr;
                 }
             }
+        };
+        if (inreg) {
+#pragma unroll
+            for (int u = 0; u < BR; ++u)
+                if ((uint32_t)tid + 256u * u < n) keep(kv[u], pv[u]);
+        } else {
+            for (uint32_t i = tid; i < n; i += 256) keep(kq[i], cpr[i]);
         }
         __syncthreads();
         const uint32_t kept = nkeep;
