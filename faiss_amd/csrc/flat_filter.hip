@@ -797,8 +797,11 @@ struct RrShared {
     unsigned total;
 };
 
-template <int METRIC>
-__global__ void __launch_bounds__(RR_THREADS) flat_rerank_kernel(FlatRerankParams p) {
+// THREADS: 256, or 64 for small k (the coarse quantizer of an IVF search: k = nprobe, ~ 60 candidates per query -- a 256-thread
+// workgroup keeps three of its four waves idle through every dependent load while it occupies a CU's wave slots: a wavefront per
+// query doubles the queries in flight)
+template <int METRIC, int THREADS>
+__global__ void __launch_bounds__(THREADS) flat_rerank_kernel(FlatRerankParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     RrShared* sh = (RrShared*)smem;
     u64* cand = (u64*)(smem + ((sizeof(RrShared) + 15) & ~(size_t)15)); // [gcap]
@@ -814,11 +817,11 @@ __global__ void __launch_bounds__(RR_THREADS) flat_rerank_kernel(FlatRerankParam
         return;
     }
     if (tid == 0) sh->total = 0;
-    for (int c = tid; c < p.dpad; c += RR_THREADS) qs[c] = p.xq[(int64_t)q * p.ldq + c];
+    for (int c = tid; c < p.dpad; c += THREADS) qs[c] = p.xq[(int64_t)q * p.ldq + c];
     __syncthreads();
     // ---- gather the (query, split) segments into LDS: one thread per segment, so the nsplit
     // dependent (count -> keys) global loads run side by side instead of one after the other
-    for (int s = tid; s < p.nsplit; s += RR_THREADS) {
+    for (int s = tid; s < p.nsplit; s += THREADS) {
         const unsigned cnt = p.res_cnt[(int64_t)q * p.nsplit + s];
         if (cnt) {
             const unsigned base = atomicAdd(&sh->total, cnt);
@@ -859,7 +862,7 @@ __global__ void __launch_bounds__(RR_THREADS) flat_rerank_kernel(FlatRerankParam
     // ---- k-th best approximate score over all splits -> error band -> rows to re-rank
     if (n > p.k) {
         u64 kth;
-        if (n <= RR_THREADS) { // (one key per thread; beyond that the radix select is the faster one)
+        if (n <= THREADS) { // (one key per thread; beyond that the radix select is the faster one)
             if (tid < n) {
                 const u64 x = cand[tid];
                 if (rank_of(x, n) == p.k - 1) sh->ctl.kth = x;
@@ -868,12 +871,12 @@ __global__ void __launch_bounds__(RR_THREADS) flat_rerank_kernel(FlatRerankParam
             kth = sh->ctl.kth;
             // (wg_compact below starts with a barrier before anything is rewritten)
         } else {
-            kth = wg_select_kth<RR_THREADS>(cand, n, p.k, sh->hist, &sh->ctl);
+            kth = wg_select_kth<THREADS>(cand, n, p.k, sh->hist, &sh->ctl);
         }
         const float e = flat_filter_err_bound(METRIC, p.d, p.xqn[q], p.yn_max, p.exact_inputs != 0);
         const float thr = band_threshold(key_score((uint32_t)(kth >> 32)), e);
         const u64 key_thr = ((u64)score_key(thr) << 32) | 0xffffffffull;
-        wg_compact<RR_THREADS>(cand, n, key_thr, &sh->ctl);
+        wg_compact<THREADS>(cand, n, key_thr, &sh->ctl);
         n = (int)sh->ctl.cnt;
     }
     if (n > RR_CAND) {
@@ -883,7 +886,7 @@ __global__ void __launch_bounds__(RR_THREADS) flat_rerank_kernel(FlatRerankParam
 
     // ---- exact fp32 distances, same chain as flat_scan_kernel / oracle orc_ip_chain
     const float xn = METRIC == METRIC_L2 ? p.xqn[q] : 0.f;
-    for (int c = tid; c < n; c += RR_THREADS) {
+    for (int c = tid; c < n; c += THREADS) {
         const unsigned row = (unsigned)cand[c];
         const float* yr = p.xb ? p.xb + (int64_t)row * p.ldb : nullptr;
         const _Float16* yh = p.xb16 + (int64_t)row * p.ldb16;
@@ -948,7 +951,7 @@ __global__ void __launch_bounds__(RR_THREADS) flat_rerank_kernel(FlatRerankParam
     if (n <= RR_RANK_MAX) {
         // the usual case (k plus the few rows inside the error band): every key straight to its rank
         const float pad = neutral_distance(METRIC);
-        for (int c = tid; c < n; c += RR_THREADS) {
+        for (int c = tid; c < n; c += THREADS) {
             const u64 key = cand[c];
             const int r = rank_of(key, n);
             if (r < p.k) {
@@ -958,18 +961,18 @@ __global__ void __launch_bounds__(RR_THREADS) flat_rerank_kernel(FlatRerankParam
                 p.out_ids[(int64_t)q * p.k + r] = ok ? (int64_t)(uint32_t)key + p.id_base : -1;
             }
         }
-        for (int i = n + tid; i < p.k; i += RR_THREADS) {
+        for (int i = n + tid; i < p.k; i += THREADS) {
             p.out_dis[(int64_t)q * p.k + i] = pad;
             p.out_ids[(int64_t)q * p.k + i] = -1;
         }
         return;
     }
     if (n > p.k) {
-        const u64 kth = wg_select_kth<RR_THREADS>(cand, n, p.k, sh->hist, &sh->ctl);
-        wg_compact<RR_THREADS>(cand, n, kth, &sh->ctl);
+        const u64 kth = wg_select_kth<THREADS>(cand, n, p.k, sh->hist, &sh->ctl);
+        wg_compact<THREADS>(cand, n, kth, &sh->ctl);
         n = (int)sh->ctl.cnt;
     }
-    for (int i = tid; i < p.kp; i += RR_THREADS) {
+    for (int i = tid; i < p.kp; i += THREADS) {
         unsigned wk = 0xffffffffu;
         int64_t wi = INT64_MAX;
         if (i < n) {
@@ -981,9 +984,9 @@ __global__ void __launch_bounds__(RR_THREADS) flat_rerank_kernel(FlatRerankParam
         w_id[i] = wi;
     }
     __syncthreads();
-    wg_bitonic_sort<RR_THREADS>(w_key, w_id, p.kp);
+    wg_bitonic_sort<THREADS>(w_key, w_id, p.kp);
     const float pad = neutral_distance(METRIC);
-    for (int i = tid; i < p.k; i += RR_THREADS) {
+    for (int i = tid; i < p.k; i += THREADS) {
         float dis = pad;
         int64_t id = -1;
         if (i < n && w_key[i] < kInvalidOrdKey) {
@@ -1002,16 +1005,22 @@ void launch_flat_rerank(const FlatRerankParams& p, hipStream_t stream) {
     const size_t lds = ((sizeof(RrShared) + 15) & ~(size_t)15) + (size_t)p.gcap * 8 +
                        (size_t)(p.dpad + (p.dpad & 1)) * 4 + (size_t)p.kp * 12;
     FA_THROW_IF_NOT_MSG(lds <= 160 * 1024, "re-rank workspace exceeds the LDS");
+    static const char* e64 = experiment_env("FAISS_AMD_FLAT_RERANK_WAVE"); // A/B: 0 = 256-thread workgroups for every k
+    const bool wave = p.k <= 64 && p.nsplit <= 64 && !(e64 && atoi(e64) == 0);
+#define FA_RR(METRIC_, T_)                                                                                                     \
+    do {                                                                                                                       \
+        HIP_CHECK(hipFuncSetAttribute((const void*)flat_rerank_kernel<METRIC_, T_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)lds));                                                                              \
+        hipLaunchKernelGGL((flat_rerank_kernel<METRIC_, T_>), dim3((unsigned)p.nq), dim3(T_), lds, stream, p);                 \
+    } while (0)
     if (p.metric == METRIC_L2) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)flat_rerank_kernel<METRIC_L2>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((flat_rerank_kernel<METRIC_L2>), dim3((unsigned)p.nq), dim3(RR_THREADS), lds, stream, p);
+        if (wave) FA_RR(METRIC_L2, 64);
+        else FA_RR(METRIC_L2, RR_THREADS);
     } else {
-        HIP_CHECK(hipFuncSetAttribute((const void*)flat_rerank_kernel<METRIC_INNER_PRODUCT>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((flat_rerank_kernel<METRIC_INNER_PRODUCT>), dim3((unsigned)p.nq), dim3(RR_THREADS), lds,
-                           stream, p);
+        if (wave) FA_RR(METRIC_INNER_PRODUCT, 64);
+        else FA_RR(METRIC_INNER_PRODUCT, RR_THREADS);
     }
+#undef FA_RR
     HIP_CHECK(hipGetLastError());
 }
 

@@ -31,7 +31,11 @@ __device__ u64 wg_select_kth(const u64* keys, int n, int k, unsigned* hist, WgSe
     u64 prefix = 0, mask = 0;
     int need = k;
     for (int shift = 56; shift >= 0; shift -= 8) {
-        if (tid < 256) hist[tid] = 0;
+        if (BLOCK >= 256) {
+            if (tid < 256) hist[tid] = 0;
+        } else {
+            for (int i = tid; i < 256; i += BLOCK) hist[i] = 0;
+        }
         __syncthreads();
         for (int i = tid; i < n; i += BLOCK) {
             const u64 key = keys[i];
