@@ -46,3 +46,43 @@ def test_tie_run_rule_equals_all_pairs_ranking():
         a, b = order_all_pairs(wk, wl), order_tie_run(wk, wl)
         assert a == b, (trial, wk, wl)
         assert all(x is not None for x in a) and a == sorted(a)  # a permutation, ordered by (key, label)
+
+
+def kth_min_relative_radix(vals, k, invalid=0xFFFFFFFF):
+    """lmf_bound_kernel / lmf_tighten_kernel (ivf_lm_filter.hip): the k-th smallest valid key through 8-bit digits of key - min over
+    the bits in which the valid keys differ; fewer than k valid keys: the invalid key."""
+    valid = [v for v in vals if v < invalid]
+    if len(valid) < k:
+        return invalid
+    vmin, vmax = min(valid), max(valid)
+    rng = vmax - vmin
+    npass = 0 if rng == 0 else (rng.bit_length() + 7) // 8
+    prefix, need = 0, k
+    for p in range(npass - 1, -1, -1):
+        hist = [0] * 256
+        for v in valid:
+            w = v - vmin
+            if p == 3 or (w >> (8 * (p + 1))) == prefix:
+                hist[(w >> (8 * p)) & 255] += 1
+        before = 0
+        for b in range(256):
+            if before < need <= before + hist[b]:
+                prefix, need = (prefix << 8) | b, need - before
+                break
+            before += hist[b]
+    return vmin + prefix
+
+
+def test_min_relative_radix_select_finds_the_kth_smallest():
+    rng = np.random.RandomState(5)
+    for trial in range(300):
+        n = int(rng.randint(1, 600))
+        spread = int(rng.choice([1, 2, 300, 70000, 1 << 24, 0xFFFFFFF0]))
+        base = int(rng.randint(0, 0xFFFFFFFF - spread))
+        vals = (base + rng.randint(0, spread, n).astype(np.int64)).tolist()
+        for i in rng.choice(n, size=n // 5, replace=False):
+            vals[i] = 0xFFFFFFFF  # empty granule slots
+        valid = sorted(v for v in vals if v < 0xFFFFFFFF)
+        for k in {1, max(1, len(valid) // 2), max(1, len(valid)), len(valid) + 1}:
+            want = valid[k - 1] if k <= len(valid) else 0xFFFFFFFF
+            assert kth_min_relative_radix(vals, k) == want, (trial, k)
