@@ -29,8 +29,14 @@ void DevBuf::ensure(size_t bytes, size_t keep_bytes, hipStream_t stream) {
     if (bytes <= cap) return;
     size_t ncap = std::max(bytes, cap + cap / 2);
     ncap = round_up(ncap, 256);
+    if (p && keep_bytes == 0) release(); // nothing to keep: the peak must not hold the old and the new buffer together
     void* np = nullptr;
-    const hipError_t me = hipMalloc(&np, ncap);
+    hipError_t me = hipMalloc(&np, ncap);
+    if (me == hipErrorOutOfMemory && ncap > round_up(bytes, 256)) {
+        (void)hipGetLastError();
+        ncap = round_up(bytes, 256); // the geometric head-room is a convenience, not a requirement
+        me = hipMalloc(&np, ncap);
+    }
     if (me == hipErrorOutOfMemory) {
         (void)hipGetLastError(); // (not sticky: the next call must not see it)
         throw DeviceOutOfMemory("out of device memory allocating " + std::to_string(ncap) + " bytes");
@@ -1846,7 +1852,16 @@ void GpuIndexIVF::add_core_(idx_t n, const float* x, const idx_t* xids, const id
             est[l] = (double)len0[l] + ((double)new_len[l] - (double)len0[l]) * scale;
             added += (idx_t)new_len[l] - (idx_t)list_len_[l];
         }
-        if (patch) moved_.assign((size_t)nlist, 0);
+        // a live copy of the lists is patched per page; from the moment the lists start to change until lmf_patch_ has
+        // returned the copy counts as dirty, so that ANY exception in between (HIP error, OOM, ...) leaves a copy that the
+        // next list-major search rebuilds instead of one that silently misses relocated / extended blocks
+        const bool live = patch && !shadow_dirty_;
+        if (live) {
+            moved_.assign((size_t)nlist, 0);
+            shadow_dirty_ = true;
+        } else {
+            moved_.clear();
+        }
         grow_lists_(new_len, &est);
         // ---- destination rows (insertion order kept inside every list), then encode / scatter
         launch_ivf_rank(a_lab_.as<int64_t>(), ni, nlist, chunk, a_hist_.as<uint32_t>(), d_list_start_.as<int64_t>(),
@@ -1854,18 +1869,22 @@ void GpuIndexIVF::add_core_(idx_t n, const float* x, const idx_t* xids, const id
         append_(ni, a_xpad_.as<float>(), a_lab_.as<int64_t>(), a_dest_.as<int64_t>());
         launch_scatter_i64(a_ids_.as<int64_t>(), a_dest_.as<int64_t>(), ni, arena_ids_.as<int64_t>(), R.stream);
         HIP_CHECK(hipMemcpyAsync(d_list_len_.p, a_newlen_.p, (size_t)nlist * 4, hipMemcpyDeviceToDevice, R.stream));
-        if (patch && !shadow_dirty_) {
+        if (live) {
             h_first_row_.resize((size_t)nlist);
             for (int l = 0; l < nlist; l++)
                 h_first_row_[l] = moved_[l] ? 0u : new_len[l] != list_len_[l] ? (list_len_[l] & ~31u) : 0xffffffffu;
             a_first_row_.ensure((size_t)nlist * 4);
             HIP_CHECK(hipMemcpyAsync(a_first_row_.p, h_first_row_.data(), (size_t)nlist * 4, hipMemcpyHostToDevice, R.stream));
             try {
+                shadow_dirty_ = false; // (lmf_shadow_room_ keeps the contents of a clean copy when it grows the buffer)
                 lmf_patch_(a_first_row_.as<uint32_t>());
             } catch (const DeviceOutOfMemory&) {
                 // no room to grow the copy: drop it (the next list-major search rebuilds it, or falls back to query-major)
                 (void)lmf_release_();
                 shadow_dirty_ = true;
+            } catch (...) {
+                shadow_dirty_ = true;
+                throw;
             }
         }
         list_len_ = new_len;
@@ -3421,6 +3440,9 @@ void GpuIndexIVFPQ::set_pq_centroids(const float* pq) {
     std::swap(pq_.p, npq.p);
     std::swap(pq_.cap, npq.cap);
     lmf_quant_dirty_ = true;
+    // the decoded-residual copy of the lists (lmf_decoded_()) holds fp16 values DECODED WITH pq_: a new codebook makes it stale
+    // (the codebook mode's copy holds raw code bytes and stays valid)
+    if (lmf_decoded_()) shadow_dirty_ = true;
     update_is_trained_();
     if (nstored_ > 0 && is_trained) lists_changed_();
 }

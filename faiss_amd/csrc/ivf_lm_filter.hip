@@ -1751,7 +1751,8 @@ __global__ void __launch_bounds__(256) lmf_sq_prepare_kernel(IvfLmParams p, floa
             atomicMax((unsigned*)xn_bound + q, __float_as_uint(bn * 1.0001f));
             atomicMax((unsigned*)an_bound + q, __float_as_uint(an * 1.0001f));
         }
-        if (bad || !(an <= 3.0e38f)) atomicOr(const_cast<uint32_t*>(p.qflags) + q, 1u);
+        // (a pair without a list -- a preassigned -1 column -- is never scanned: its operand must not send the query to the redo)
+        if (l >= 0 && (bad || !(an <= 3.0e38f))) atomicOr(const_cast<uint32_t*>(p.qflags) + q, 1u);
     }
 }
 void launch_ivf_lmf_sq_prepare(const IvfLmParams& p, float* xn_bound, float* an_bound, hipStream_t stream) {
@@ -1761,7 +1762,9 @@ void launch_ivf_lmf_sq_prepare(const IvfLmParams& p, float* xn_bound, float* an_
     FA_THROW_IF_NOT(p.dpad % 8 == 0 && p.ldq % 4 == 0 && p.ldc % 4 == 0);
     HIP_CHECK(hipMemsetAsync(xn_bound, 0, (size_t)p.nq * 4, stream));
     HIP_CHECK(hipMemsetAsync(an_bound, 0, (size_t)p.nq * 4, stream));
-    HIP_CHECK(hipMemsetAsync(const_cast<uint32_t*>(p.qflags), 0, (size_t)p.nq * 4, stream));
+    // the scalar quantizer's flags come from this launch alone; the decoded-residual IVFPQ sweeps (kind 1, pair operands) run
+    // launch_prep_queries first, whose NaN / fp16-range flags of the raw queries stay: this launch only ORs into them
+    if (p.kind == 2) HIP_CHECK(hipMemsetAsync(const_cast<uint32_t*>(p.qflags), 0, (size_t)p.nq * 4, stream));
     const int pieces = (int)p.ldh / 8; // 2 .. 64
     const int P = pieces <= 16 ? 16 : pieces <= 32 ? 32 : 64;
     const dim3 grid((unsigned)div_up((size_t)p.nq * p.nprobe * P, 256)), block(256);

@@ -796,6 +796,7 @@ void launch_select_k(const SelectParams& p, hipStream_t stream) {
     if (wave_select_serves(p)) {
         const dim3 grid((unsigned)div_up(p.nq, 4));
         SelectParams pw = p;
+        pw.small_done = 0; // (set here only: a caller's uninitialised field must not make the general kernel skip queries)
         if (small_select_serves(p)) {
             hipLaunchKernelGGL(small_select_kernel, grid, dim3(256), 0, stream, p);
             pw.small_done = 1; // the general kernel below takes the queries with more than 256 keys

@@ -31,11 +31,16 @@ __device__ u64 wg_select_kth(const u64* keys, int n, int k, unsigned* hist, WgSe
     u64 prefix = 0, mask = 0;
     int need = k;
     for (int shift = 56; shift >= 0; shift -= 8) {
+#ifdef FAISS_AMD_WGS_LOOP_REPRO
+        // (round 5's faulting variant, kept buildable for tools/wgs_fault_repro.sh: `make variant-wgsloop`)
+        for (int i = tid; i < 256; i += BLOCK) hist[i] = 0;
+#else
         if (BLOCK >= 256) {
             if (tid < 256) hist[tid] = 0;
         } else {
             for (int i = tid; i < 256; i += BLOCK) hist[i] = 0;
         }
+#endif
         __syncthreads();
         for (int i = tid; i < n; i += BLOCK) {
             const u64 key = keys[i];
