@@ -125,8 +125,8 @@ def cpu_baseline_flat(xb, xq, k, gpu_D, gpu_I, budget_s=25.0):
             Dr, Ir = idx.search(xq[:ns], k)
             dt = time.time() - t0
         kind, threads = "reference", Ref.max_threads()
-        sample = "faiss 1.15.0 IndexFlatL2.search, one batch of the first %d of the %d queries, nb=%d, k=%d, %d OpenMP threads" % (
-            ns, len(xq), len(xb), k, threads)
+        sample = "faiss 1.15.0 IndexFlatL2.search k=%d nb=%d, one batch of the first %d of the %d queries, %d OpenMP threads" % (
+            k, len(xb), ns, len(xq), threads)
     else:
         ns = 8
         t0 = time.time()
@@ -134,7 +134,8 @@ def cpu_baseline_flat(xb, xq, k, gpu_D, gpu_I, budget_s=25.0):
         dt = time.time() - t0
         kind, threads = "port", cores
         sample = "oracle/faiss_oracle.c restatement (OpenMP over queries), first %d queries" % ns
-    out = {"value": round(ns / dt, 1), "unit": "QPS", "cores": int(threads), "cpu_model": cpu_model(), "kind": kind, "sample": sample}
+    out = {"value": round(ns / dt, 1), "unit": "QPS", "cores": int(threads), "cpu_model": cpu_model(), "kind": kind, "sample": sample,
+           "k": int(k), "queries": int(ns)}
     if gpu_I is not None:
         out["parity_vs_gpu"] = classify_parity(gpu_D[:ns], gpu_I[:ns], Dr, Ir)
         out["parity_vs_gpu"]["recall_at_1"] = float((gpu_I[:ns, 0] == Ir[:, 0]).mean())
@@ -989,15 +990,15 @@ def compact_line(detail, detail_path=DETAIL_NAME):
     top["roofline"] = rc
     c = detail.get("cpu_baseline")
     if isinstance(c, dict):
-        top["cpu_baseline"] = {k: (str(c[k])[:100] if k in ("sample", "error", "cpu_model") else c[k])
-                               for k in ("value", "unit", "cores", "cpu_model", "kind", "sample", "error") if k in c}
+        top["cpu_baseline"] = {k: (str(c[k])[:160] if k in ("sample", "error", "cpu_model") else c[k])
+                               for k in ("value", "unit", "cores", "cpu_model", "kind", "sample", "k", "queries", "error") if k in c}
         pv = c.get("parity_vs_gpu") or {}
         if "real_mismatches" in pv:
             top["parity_vs_cpu_reference"] = {"queries": pv.get("queries"),
                                               "real_mismatches": pv["real_mismatches"] if isinstance(pv["real_mismatches"], int) else "FAILED",
                                               "near_tie_mismatches": pv.get("near_tie_mismatches"),
                                               "max_rel_dist_err": pv.get("max_rel_dist_err")}
-    for k in ("recall_at_1", "value_host_buffers", "filter_overflow_queries", "ranks_seen", "devices"):
+    for k in ("recall_at_1", "value_host_buffers", "filter_overflow_queries", "ranks_seen", "devices", "ranks_seen_via"):
         if detail.get(k) is not None:
             top[k] = detail[k]
     legs = {}
@@ -1075,12 +1076,16 @@ def main():
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # launched by torch.distributed.run (RANK set): the process group is RCCL even for ONE rank, so that a 1-GPU box runs the
+    # very init order / collectives / gather path an N-GPU node does (tests/test_gpu_rccl_world1.py); plain `python bench.py`
+    # (the driver's N = 1 command) involves no process group at all
+    use_dist = world > 1 or "RANK" in os.environ
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
     ranks_seen, devices = 1, [local_rank]
-    if world > 1:
+    if use_dist:
         # self-validation of an N-GPU record: the ranks the RCCL backend really connected (all-reduce of ones) and the HIP
         # device each of them runs on (all-gather of hipGetDevice), printed in the line
         ones = torch.ones(1, dtype=torch.int32, device=dev)
@@ -1133,7 +1138,7 @@ def main():
         return D_loc, I_loc
 
     if replicas:
-        rep = ReplicatedSearcher(local_search_block, NQ, dev)
+        rep = ReplicatedSearcher(local_search_block, NQ, dev, force_collectives=use_dist)
 
         class _S:  # same call shape as ShardedSearcher.search
             @staticmethod
@@ -1141,10 +1146,10 @@ def main():
                 return rep.search(k)
         searcher = _S
     else:
-        searcher = ShardedSearcher(local_search, merge, [b - a for a, b in bounds], dev)
+        searcher = ShardedSearcher(local_search, merge, [b - a for a, b in bounds], dev, force_collectives=use_dist)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -1159,7 +1164,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -1234,7 +1239,7 @@ def main():
                      "hbm_frac": round(hbm_bytes / (avg_scan_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 5)},
         "other_kernels_ms": others,
         "filter_overflow_queries": int(n_overflow),
-        "ranks_seen": ranks_seen, "devices": devices,
+        "ranks_seen": ranks_seen, "devices": devices, "ranks_seen_via": "rccl all_reduce" if use_dist else "no process group",
     }
     if world == 1:
         # the same search handed pageable host buffers (queries H2D, results D2H inside the timed region)
@@ -1294,8 +1299,9 @@ def main():
     if world > 1 and shards_multi is not None:
         line["ivfpq_shards"] = shards_multi
     print(compact_line(line, write_detail(line)), flush=True)
-    if world > 1:
-        dist.barrier()
+    if use_dist:
+        if world > 1:
+            dist.barrier()
         dist.destroy_process_group()
 
 

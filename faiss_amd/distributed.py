@@ -38,12 +38,15 @@ class ShardedSearcher:
     [world, nq, k] tensors (device merge kernel on GPU, host merge in the gloo tests).
     """
 
-    def __init__(self, local_search, merge, shard_sizes, device, group=None):
+    def __init__(self, local_search, merge, shard_sizes, device, group=None, force_collectives=False):
         self.local_search = local_search
         self.merge = merge
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # force_collectives: run the gather even in a group of ONE rank (tests/test_gpu_rccl_world1.py: the RCCL path --
+        # communicator set-up next to the library's own HIP streams, gather, fence, device merge -- on a one-GPU box)
+        self.collect = dist.is_initialized() and (self.world > 1 or force_collectives)
         assert len(shard_sizes) == self.world
         # successive_ids: shard s's labels are shifted by the number of rows before it
         # (faiss/IndexShards.cpp:214-219)
@@ -53,7 +56,7 @@ class ShardedSearcher:
 
     def search(self, xq, k):
         D, I = self.local_search(xq, k)
-        if self.world == 1:
+        if not self.collect:
             return self.merge(D.unsqueeze(0), I.unsqueeze(0), self.base)
         nq = D.shape[0]
         if self.rank == 0:
@@ -80,11 +83,12 @@ class ReplicatedSearcher:
     queries [lo, hi); `per` = replica_bounds(nq, world)[1] (equal block size, so one gather moves everything).
     """
 
-    def __init__(self, local_search, nq, device, group=None):
+    def __init__(self, local_search, nq, device, group=None, force_collectives=False):
         self.local_search = local_search
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.collect = dist.is_initialized() and (self.world > 1 or force_collectives)
         self.nq = nq
         self.bounds, self.per = replica_bounds(nq, self.world)
         self.device = device
@@ -93,7 +97,7 @@ class ReplicatedSearcher:
     def search(self, k):
         lo, hi = self.bounds[self.rank]
         D, I = self.local_search(lo, hi, k)
-        if self.world == 1:
+        if not self.collect:
             return D[: self.nq], I[: self.nq]
         assert D.shape == (self.per, k) and I.shape == (self.per, k)
         if self.rank == 0:
@@ -140,11 +144,11 @@ def shard_chunks(rows_per_rank, rank, chunk_rows=1000000):
     return out
 
 
-def broadcast_arrays(arrays, device, src=0, group=None):
+def broadcast_arrays(arrays, device, src=0, group=None, force=False):
     """float32 numpy arrays of rank `src` -> every rank (shapes known on every rank; the values of the other ranks are
     ignored): the trained coarse quantizer and product-quantizer codebook of a sharded IVF index -- the only collective of
     the layout, once per build (the reference clones one trained CPU index to every device, gpu/GpuCloner.cpp:368-391)."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
         return [np.ascontiguousarray(a, dtype=np.float32) for a in arrays]
     out = []
     for a in arrays:
