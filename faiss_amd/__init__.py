@@ -60,6 +60,12 @@ def load_library():
         "faiss_amd_StandardGpuResources_setPagedSearch": (i32, [vp, sz, i64]),
         "faiss_amd_StandardGpuResources_getPagedSearchCount": (i32, [vp, P(i64)]),
         "faiss_amd_StandardGpuResources_setDefaultStream": (i32, [vp, vp]),
+        "faiss_amd_StandardGpuResources_getMemoryInfo": (i32, [vp, P(sz), P(sz), P(sz), P(sz), P(sz), P(sz)]),
+        "faiss_amd_StandardGpuResources_setLogMemoryAllocations": (i32, [vp, i32]),
+        "faiss_amd_GpuIndexIVFFlat_new_with_quantizer": (i32, [P(vp), vp, vp, i32, i32, i32, vp]),
+        "faiss_amd_GpuIndexIVFPQ_new_with_quantizer": (i32, [P(vp), vp, vp, i32, i32, i32, i32, i32, vp]),
+        "faiss_amd_GpuIndexIVFScalarQuantizer_new_with_quantizer": (i32, [P(vp), vp, vp, i32, i32, i32, i32, i32, vp]),
+        "faiss_amd_GpuIndexIVF_quantizer_info": (i32, [vp, P(i32), P(i32), P(i32)]),
         "faiss_amd_GpuIndexFlat_new": (i32, [P(vp), vp, i32, i32]),
         "faiss_amd_GpuIndexIVFFlat_new": (i32, [P(vp), vp, i32, i32, i32]),
         "faiss_amd_GpuIndexIVFPQ_new": (i32, [P(vp), vp, i32, i32, i32, i32, i32]),
@@ -239,6 +245,16 @@ class StandardGpuResources:
 
     def setTempMemory(self, nbytes):
         _check(self._lib.faiss_amd_StandardGpuResources_setTempMemory(self._h, int(nbytes)))
+
+    def getMemoryInfo(self):
+        """StandardGpuResources.getMemoryInfo: the library's live device allocations on this device"""
+        v = [ctypes.c_size_t(0) for _ in range(6)]
+        _check(self._lib.faiss_amd_StandardGpuResources_getMemoryInfo(self._h, *[ctypes.byref(x) for x in v]))
+        keys = ("allocations", "bytes", "peak_bytes", "temp_memory", "device_free", "device_total")
+        return {k: x.value for k, x in zip(keys, v)}
+
+    def setLogMemoryAllocations(self, enable):
+        _check(self._lib.faiss_amd_StandardGpuResources_setLogMemoryAllocations(self._h, int(bool(enable))))
 
     def setDefaultStream(self, stream):
         """order all work of this resources object on `stream` (a hipStream_t value, e.g.
@@ -485,8 +501,27 @@ class GpuIndexFlatIP(GpuIndexFlat):
         super().__init__(res, d, METRIC_INNER_PRODUCT, config)
 
 
+INDICES_CPU, INDICES_IVF, INDICES_32_BIT, INDICES_64_BIT = range(4)  # faiss/gpu/GpuIndicesOptions.h
+
+
 class _GpuIndexIVF(Index):
     """faiss.GpuIndexIVF (faiss/gpu/GpuIndexIVF.h:37-153)."""
+
+    def _adopt(self, quantizer):
+        # GpuIndexIVF*(resources, coarseQuantizer, ...): the caller's flat index, not owned -- kept alive with this object
+        if quantizer is not None:
+            if not isinstance(quantizer, GpuIndexFlat):
+                raise TypeError("the coarse quantizer must be a GpuIndexFlat of this library (any other index: run its search on "
+                                "the host and call search_preassigned / add_core)")
+            self._keep.append(quantizer)
+            self.quantizer = quantizer
+        return quantizer._h if quantizer is not None else None
+
+    def quantizer_info(self):
+        """(own_fields, the quantizer stores fp16, IndicesOptions)"""
+        a, b, c = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        _check(self._lib.faiss_amd_GpuIndexIVF_quantizer_info(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return bool(a.value), bool(b.value), c.value
 
     def quantizer_search(self, x, k):
         """index.quantizer.search(x, k): the coarse centroids nearest to x (distances, list ids)"""
@@ -835,23 +870,24 @@ class _params_handle:
 class GpuIndexIVFFlat(_GpuIndexIVF):
     """faiss.GpuIndexIVFFlat (faiss/gpu/GpuIndexIVFFlat.h:33-126)."""
 
-    def __init__(self, res, d, nlist, metric=METRIC_L2, config=None):
+    def __init__(self, res, d, nlist, metric=METRIC_L2, config=None, quantizer=None):
         super().__init__()
         self._keep.append(res)
-        _check(self._lib.faiss_amd_GpuIndexIVFFlat_new_with_config(ctypes.byref(self._h), res._h, int(d), int(nlist),
-                                                                   int(metric), ctypes.byref(config) if config else None))
+        _check(self._lib.faiss_amd_GpuIndexIVFFlat_new_with_quantizer(ctypes.byref(self._h), res._h, self._adopt(quantizer), int(d),
+                                                                      int(nlist), int(metric),
+                                                                      ctypes.byref(config) if config else None))
 
 
 class GpuIndexIVFPQ(_GpuIndexIVF):
     """faiss.GpuIndexIVFPQ (faiss/gpu/GpuIndexIVFPQ.h:53-176)."""
 
-    def __init__(self, res, d, nlist, M, nbits=8, metric=METRIC_L2, config=None):
+    def __init__(self, res, d, nlist, M, nbits=8, metric=METRIC_L2, config=None, quantizer=None):
         super().__init__()
         self._keep.append(res)
         self.M = int(M)
-        _check(self._lib.faiss_amd_GpuIndexIVFPQ_new_with_config(ctypes.byref(self._h), res._h, int(d), int(nlist), int(M),
-                                                                 int(nbits), int(metric),
-                                                                 ctypes.byref(config) if config else None))
+        _check(self._lib.faiss_amd_GpuIndexIVFPQ_new_with_quantizer(ctypes.byref(self._h), res._h, self._adopt(quantizer), int(d),
+                                                                    int(nlist), int(M), int(nbits), int(metric),
+                                                                    ctypes.byref(config) if config else None))
 
     def _info(self):
         v = [ctypes.c_int(0) for _ in range(4)]
@@ -901,11 +937,12 @@ class ScalarQuantizer:
 class GpuIndexIVFScalarQuantizer(_GpuIndexIVF):
     """faiss.GpuIndexIVFScalarQuantizer (faiss/gpu/GpuIndexIVFScalarQuantizer.h:27-131)."""
 
-    def __init__(self, res, d, nlist, qtype, metric=METRIC_L2, encodeResidual=True):
+    def __init__(self, res, d, nlist, qtype, metric=METRIC_L2, encodeResidual=True, config=None, quantizer=None):
         super().__init__()
         self._keep.append(res)
-        _check(self._lib.faiss_amd_GpuIndexIVFScalarQuantizer_new(ctypes.byref(self._h), res._h, int(d), int(nlist),
-                                                                  int(qtype), int(metric), int(bool(encodeResidual))))
+        _check(self._lib.faiss_amd_GpuIndexIVFScalarQuantizer_new_with_quantizer(
+            ctypes.byref(self._h), res._h, self._adopt(quantizer), int(d), int(nlist), int(qtype), int(metric),
+            int(bool(encodeResidual)), ctypes.byref(config) if config else None))
 
     def _info(self):
         qt, br = ctypes.c_int(0), ctypes.c_int(0)

@@ -201,9 +201,13 @@ static void check_common_config(const std::shared_ptr<GpuResources>& r, int devi
 }
 static void check_ivf_config(const std::shared_ptr<GpuResources>& r, const FaissAmdGpuIndexIVFConfig& c) {
     check_common_config(r, c.device, c.memorySpace);
-    FA_THROW_IF_NOT_MSG(c.indicesOptions == 3 || c.indicesOptions == 2,
-                        "indicesOptions must be INDICES_64_BIT or INDICES_32_BIT (ids live on the device)");
-    FA_THROW_IF_NOT_MSG(!c.flat_useFloat16, "an fp16 coarse quantizer is not supported");
+    FA_THROW_IF_NOT_MSG(c.indicesOptions >= 0 && c.indicesOptions <= 3, "indicesOptions: not a faiss::gpu::IndicesOptions value");
+}
+// coarse quantizer handed in by the caller (null: the index makes its own): one of our flat indexes
+static GpuIndexFlat* coarse_of(FaissAmdIndex* q) {
+    if (!q) return nullptr;
+    return as<GpuIndexFlat>(q, "GpuIndexFlat (the coarse quantizer of a GpuIndexIVF must be a flat index of this library; any other "
+                               "faiss::Index is served on the reference side through search_preassigned, INTEGRATION.md)");
 }
 int faiss_amd_GpuIndexFlat_new_with_config(FaissAmdIndex** p_index, FaissAmdGpuResources* res, int d,
                                            FaissAmdMetricType metric, const FaissAmdGpuIndexFlatConfig* config) {
@@ -224,20 +228,91 @@ int faiss_amd_GpuIndexFlat_new_with_config(FaissAmdIndex** p_index, FaissAmdGpuR
     *p_index = h;
     FA_CATCH
 }
+int faiss_amd_GpuIndexIVFFlat_new_with_quantizer(FaissAmdIndex** p_index, FaissAmdGpuResources* res, FaissAmdIndex* coarse_quantizer,
+                                                 int d, int nlist, FaissAmdMetricType metric, const FaissAmdGpuIndexIVFConfig* config) {
+    FA_TRY
+    auto r = R(res);
+    if (config) check_ivf_config(r, *config);
+    auto* h = new FaissAmdIndex_H{nullptr, r};
+    try {
+        h->index = new GpuIndexIVFFlat(r, d, nlist, (int)metric, coarse_of(coarse_quantizer), config && config->flat_useFloat16,
+                                       config ? config->indicesOptions : 3);
+    } catch (...) {
+        delete h;
+        throw;
+    }
+    *p_index = h;
+    FA_CATCH
+}
+int faiss_amd_GpuIndexIVFPQ_new_with_quantizer(FaissAmdIndex** p_index, FaissAmdGpuResources* res, FaissAmdIndex* coarse_quantizer,
+                                               int d, int nlist, int M, int nbits, FaissAmdMetricType metric,
+                                               const FaissAmdGpuIndexIVFPQConfig* config) {
+    FA_TRY
+    auto r = R(res);
+    if (config) check_ivf_config(r, config->ivf);
+    auto* h = new FaissAmdIndex_H{nullptr, r};
+    try {
+        h->index = new GpuIndexIVFPQ(r, d, nlist, M, nbits, (int)metric, coarse_of(coarse_quantizer),
+                                     config && config->ivf.flat_useFloat16, config ? config->ivf.indicesOptions : 3);
+    } catch (...) {
+        delete h;
+        throw;
+    }
+    *p_index = h;
+    FA_CATCH
+}
+int faiss_amd_GpuIndexIVFScalarQuantizer_new_with_quantizer(FaissAmdIndex** p_index, FaissAmdGpuResources* res,
+                                                            FaissAmdIndex* coarse_quantizer, int d, int nlist, int qtype,
+                                                            FaissAmdMetricType metric, int encode_residual,
+                                                            const FaissAmdGpuIndexIVFConfig* config) {
+    FA_TRY
+    auto r = R(res);
+    if (config) check_ivf_config(r, *config);
+    auto* h = new FaissAmdIndex_H{nullptr, r};
+    try {
+        h->index = new GpuIndexIVFScalarQuantizer(r, d, nlist, qtype, (int)metric, encode_residual != 0, coarse_of(coarse_quantizer),
+                                                  config && config->flat_useFloat16, config ? config->indicesOptions : 3);
+    } catch (...) {
+        delete h;
+        throw;
+    }
+    *p_index = h;
+    FA_CATCH
+}
 int faiss_amd_GpuIndexIVFFlat_new_with_config(FaissAmdIndex** p_index, FaissAmdGpuResources* res, int d, int nlist,
                                               FaissAmdMetricType metric, const FaissAmdGpuIndexIVFConfig* config) {
-    FA_TRY
-    if (config) check_ivf_config(R(res), *config);
-    FA_CATCH_RC
-    return faiss_amd_GpuIndexIVFFlat_new(p_index, res, d, nlist, metric);
+    return faiss_amd_GpuIndexIVFFlat_new_with_quantizer(p_index, res, nullptr, d, nlist, metric, config);
 }
 int faiss_amd_GpuIndexIVFPQ_new_with_config(FaissAmdIndex** p_index, FaissAmdGpuResources* res, int d, int nlist, int M,
                                             int nbits, FaissAmdMetricType metric,
                                             const FaissAmdGpuIndexIVFPQConfig* config) {
+    return faiss_amd_GpuIndexIVFPQ_new_with_quantizer(p_index, res, nullptr, d, nlist, M, nbits, metric, config);
+}
+int faiss_amd_GpuIndexIVF_quantizer_info(const FaissAmdIndex* index, int* own_fields, int* use_float16, int* indices_options) {
     FA_TRY
-    if (config) check_ivf_config(R(res), config->ivf);
-    FA_CATCH_RC
-    return faiss_amd_GpuIndexIVFPQ_new(p_index, res, d, nlist, M, nbits, metric);
+    auto* ivf = as<GpuIndexIVF>(index, "GpuIndexIVF");
+    if (own_fields) *own_fields = ivf->own_fields ? 1 : 0;
+    if (use_float16) *use_float16 = ivf->quantizer->getUseFloat16() ? 1 : 0;
+    if (indices_options) *indices_options = ivf->indices_options;
+    FA_CATCH
+}
+int faiss_amd_StandardGpuResources_getMemoryInfo(FaissAmdGpuResources* res, size_t* allocations, size_t* bytes, size_t* peak_bytes,
+                                                 size_t* temp_memory, size_t* device_free, size_t* device_total) {
+    FA_TRY
+    auto r = R(res);
+    r->set_device();
+    device_memory_info(r->device, allocations, bytes, peak_bytes);
+    if (temp_memory) *temp_memory = r->temp_budget_bytes;
+    size_t fr = 0, tot = 0;
+    HIP_CHECK(hipMemGetInfo(&fr, &tot));
+    if (device_free) *device_free = fr;
+    if (device_total) *device_total = tot;
+    FA_CATCH
+}
+int faiss_amd_StandardGpuResources_setLogMemoryAllocations(FaissAmdGpuResources* res, int enable) {
+    FA_TRY
+    set_log_memory_allocations(R(res)->device, enable != 0);
+    FA_CATCH
 }
 int faiss_amd_GpuIndexIVFScalarQuantizer_new(FaissAmdIndex** p_index, FaissAmdGpuResources* res, int d, int nlist,
                                              int qtype, FaissAmdMetricType metric, int encode_residual) {

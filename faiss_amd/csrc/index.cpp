@@ -3,6 +3,7 @@
 // kernels.h; there is no CPU compute fallback anywhere in this file.
 #include "index.h"
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -15,12 +16,52 @@
 namespace faiss_amd {
 
 // ====================================================================== memory helpers
+// Accounting of every device allocation of the library (all of them are DevBuf's), per device: what
+// StandardGpuResources::getMemoryInfo reports and setLogMemoryAllocations prints (faiss/gpu/StandardGpuResources.cpp:327,676).
+namespace {
+constexpr int kMaxDevices = 64;
+std::atomic<size_t> g_dev_bytes[kMaxDevices], g_dev_allocs[kMaxDevices], g_dev_peak[kMaxDevices];
+std::atomic<int> g_log_allocs[kMaxDevices];
+int current_device_() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        dev = 0;
+    }
+    return dev >= 0 && dev < kMaxDevices ? dev : 0;
+}
+void account_(int dev, size_t bytes, bool alloc, const void* ptr) {
+    if (alloc) {
+        const size_t now = g_dev_bytes[dev].fetch_add(bytes) + bytes;
+        g_dev_allocs[dev].fetch_add(1);
+        size_t peak = g_dev_peak[dev].load();
+        while (now > peak && !g_dev_peak[dev].compare_exchange_weak(peak, now)) {}
+    } else {
+        g_dev_bytes[dev].fetch_sub(bytes);
+        g_dev_allocs[dev].fetch_sub(1);
+    }
+    if (g_log_allocs[dev].load(std::memory_order_relaxed))
+        fprintf(stderr, "faiss_amd: device %d %s %zu bytes at %p (%zu bytes in %zu allocations)\n", dev, alloc ? "alloc" : "free", bytes,
+                ptr, g_dev_bytes[dev].load(), g_dev_allocs[dev].load());
+}
+} // namespace
+void device_memory_info(int device, size_t* allocations, size_t* bytes, size_t* peak_bytes) {
+    FA_THROW_IF_NOT(device >= 0 && device < kMaxDevices);
+    if (allocations) *allocations = g_dev_allocs[device].load();
+    if (bytes) *bytes = g_dev_bytes[device].load();
+    if (peak_bytes) *peak_bytes = g_dev_peak[device].load();
+}
+void set_log_memory_allocations(int device, bool on) {
+    FA_THROW_IF_NOT(device >= 0 && device < kMaxDevices);
+    g_log_allocs[device].store(on ? 1 : 0);
+}
 DevBuf::~DevBuf() {
     release();
 }
 void DevBuf::release() {
     if (p) {
         (void)hipFree(p);
+        account_(dev, cap, false, p);
         p = nullptr;
         cap = 0;
     }
@@ -46,9 +87,11 @@ void DevBuf::ensure(size_t bytes, size_t keep_bytes, hipStream_t stream) {
         HIP_CHECK(hipMemcpyAsync(np, p, keep_bytes, hipMemcpyDeviceToDevice, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
     }
-    if (p) (void)hipFree(p);
+    if (p) release();
     p = np;
     cap = ncap;
+    dev = current_device_();
+    account_(dev, cap, true, p);
 }
 
 bool is_device_pointer(const void* p) {
@@ -343,6 +386,16 @@ const float* GpuIndexFlat::device_vectors() const {
 size_t GpuIndexFlat::resident_bytes() const {
     const size_t n = (size_t)ntotal;
     return (use_float16_ ? 0 : n * dpad_ * 4) + n * 4 + (n + kFilterTileRows) * ((size_t)dh_ * 2 + 4);
+}
+void GpuIndexFlat::rows_to_f32(float* dst) const {
+    if (ntotal == 0) return;
+    res_->set_device();
+    if (!use_float16_) {
+        HIP_CHECK(hipMemcpyAsync(dst, xb_.p, (size_t)ntotal * dpad_ * 4, hipMemcpyDeviceToDevice, res_->stream));
+    } else {
+        launch_f16_rows_to_f32(xbh_.as<_Float16>(), dh_, ntotal, dpad_, dst, res_->stream);
+    }
+    res_->sync();
 }
 const float* GpuIndexFlat::rows_f32_(DevBuf& tmp) const {
     if (!use_float16_) return xb_.as<float>();
@@ -1076,10 +1129,21 @@ static int flat_query_tile(const GpuResources& R, int k, bool simple, idx_t nb) 
 }
 
 void GpuIndexFlat::search_device(int n, const float* xq_pad, int k, float* dD, idx_t* dI) const {
+    // (a caller-owned coarse quantizer may serve several IVF indexes: the scratch of a search belongs to one call at a time)
+    std::lock_guard<std::mutex> g(mu_);
     const int tile = flat_query_tile(*res_, k, use_simple_kernel || is_general_metric(metric_type), ntotal);
     for (int i0 = 0; i0 < n; i0 += tile) {
         int ni = std::min(tile, n - i0);
-        search_tile_(ni, xq_pad + (size_t)i0 * dpad_, k, dD + (size_t)i0 * k, dI + (size_t)i0 * k);
+        const float* q = xq_pad + (size_t)i0 * dpad_;
+        if (use_float16_) {
+            // fp16 storage: the queries are converted too (FlatIndex::query, faiss/gpu/impl/FlatIndex.cu:112-135); the caller's
+            // copy stays fp32 (an IVF index takes its residuals from the unrounded query)
+            q_pad_.ensure((size_t)ni * dpad_ * 4);
+            HIP_CHECK(hipMemcpyAsync(q_pad_.p, q, (size_t)ni * dpad_ * 4, hipMemcpyDeviceToDevice, res_->stream));
+            launch_round_f16_inplace(q_pad_.as<float>(), (int64_t)ni * dpad_, res_->stream);
+            q = q_pad_.as<float>();
+        }
+        search_tile_(ni, q, k, dD + (size_t)i0 * k, dI + (size_t)i0 * k);
     }
 }
 
@@ -1512,16 +1576,30 @@ void Clustering::train_device_(idx_t nx, const float* x_in, int64_t ldx, GpuInde
 }
 
 // ====================================================================== GpuIndexIVF
-GpuIndexIVF::GpuIndexIVF(std::shared_ptr<GpuResources> res, int dims, int metric, int nlist_)
-        : Index(dims, metric), nlist(nlist_), res_(std::move(res)) {
+GpuIndexIVF::GpuIndexIVF(std::shared_ptr<GpuResources> res, int dims, int metric, int nlist_, GpuIndexFlat* coarse_quantizer,
+                         bool coarse_f16, int indices_options_)
+        : Index(dims, metric), nlist(nlist_), indices_options(indices_options_), res_(std::move(res)) {
     FA_THROW_IF_NOT_MSG(nlist > 0, "nlist must be positive");
     FA_THROW_IF_NOT_MSG(metric_supported(1, metric), "unsupported metric type (reference: faiss/gpu/GpuIndexIVF.cu:35-37)");
+    FA_THROW_IF_NOT_MSG(indices_options >= 0 && indices_options <= 3, "invalid indicesOptions");
     dpad_ = (int)round_up(dims, 8);
-    quantizer = new GpuIndexFlat(res_, dims, metric);
-    // the coarse quantizer holds only nlist rows: let it take the fp16 filter + exact re-rank path from
-    // 2048 centroids on (bit-identical results; the fp32 scan's per-split reservoirs bootstrap poorly
-    // on a few thousand rows)
-    quantizer->filter_min_rows = 2048;
+    if (coarse_quantizer) {
+        // the caller's quantizer (faiss/gpu/GpuIndexIVF.cu:41-70 verifyIVFSettings_): same dimension, same device, not owned
+        FA_THROW_IF_NOT_MSG(coarse_quantizer->d == dims, "the coarse quantizer's dimension differs from the index's");
+        FA_THROW_IF_NOT_MSG(coarse_quantizer->device() == res_->device, "the coarse quantizer lives on another device");
+        FA_THROW_IF_NOT_MSG(coarse_quantizer->metric_type == METRIC_L2 || coarse_quantizer->metric_type == METRIC_INNER_PRODUCT,
+                            "the coarse quantizer must be an L2 / inner-product flat index");
+        FA_THROW_IF_NOT_MSG(coarse_quantizer->ntotal == 0 || coarse_quantizer->ntotal == nlist,
+                            "the coarse quantizer must be empty or hold exactly nlist centroids");
+        quantizer = coarse_quantizer;
+        own_fields = false;
+    } else {
+        quantizer = new GpuIndexFlat(res_, dims, metric, coarse_f16);
+        // the coarse quantizer holds only nlist rows: let it take the fp16 filter + exact re-rank path from
+        // 2048 centroids on (bit-identical results; the fp32 scan's per-split reservoirs bootstrap poorly
+        // on a few thousand rows)
+        quantizer->filter_min_rows = 2048;
+    }
     is_trained = false;
     list_len_.assign(nlist, 0);
     list_cap_.assign(nlist, 0);
@@ -1530,11 +1608,31 @@ GpuIndexIVF::GpuIndexIVF(std::shared_ptr<GpuResources> res, int dims, int metric
 GpuIndexIVF::~GpuIndexIVF() {
     (void)hipSetDevice(res_->device);
     if (h_lm_) (void)hipHostFree(h_lm_);
-    delete quantizer;
+    if (own_fields) delete quantizer;
 }
 
 void GpuIndexIVF::update_is_trained_() {
     is_trained = quantizer->ntotal == nlist && extra_trained_();
+    cent_dirty_ = true;
+}
+// end of a derived constructor: a caller-owned quantizer that already holds its centroids makes the coarse level trained
+// (faiss/gpu/GpuIndexIVF.cu:60-70: is_trained = quantizer->is_trained && quantizer->ntotal == nlist)
+void GpuIndexIVF::adopt_quantizer_() {
+    if (quantizer->ntotal != nlist) return;
+    res_->set_device();
+    update_is_trained_();
+    ensure_arena_(64);
+    upload_list_tables_();
+}
+const float* GpuIndexIVF::centroids_dev_() const {
+    if (!quantizer->getUseFloat16()) return centroids_dev_();
+    if (cent_dirty_) {
+        FA_THROW_IF_NOT_MSG(quantizer->ntotal == nlist, "the coarse quantizer does not hold nlist centroids");
+        cent_f32_.ensure((size_t)nlist * dpad_ * 4);
+        quantizer->rows_to_f32(cent_f32_.as<float>());
+        cent_dirty_ = false;
+    }
+    return cent_f32_.as<float>();
 }
 
 void GpuIndexIVF::upload_list_tables_() {
@@ -1623,6 +1721,7 @@ void GpuIndexIVF::train(idx_t n, const float* x) {
     {
         // residual training (IVFPQ) works on padded device copies
         std::lock_guard<std::mutex> g(mu_);
+        cent_dirty_ = true;
         if (!extra_trained_()) {
             DevBuf xpad;
             xpad.ensure((size_t)n * dpad_ * 4);
@@ -1867,7 +1966,11 @@ void GpuIndexIVF::add_core_(idx_t n, const float* x, const idx_t* xids, const id
         launch_ivf_rank(a_lab_.as<int64_t>(), ni, nlist, chunk, a_hist_.as<uint32_t>(), d_list_start_.as<int64_t>(),
                         a_dest_.as<int64_t>(), R.stream);
         append_(ni, a_xpad_.as<float>(), a_lab_.as<int64_t>(), a_dest_.as<int64_t>());
-        launch_scatter_i64(a_ids_.as<int64_t>(), a_dest_.as<int64_t>(), ni, arena_ids_.as<int64_t>(), R.stream);
+        if (indices_options == 1) // INDICES_IVF: the label of an entry is (list << 32 | offset), user ids are not kept at all
+            launch_ivf_pair_ids(a_lab_.as<int64_t>(), a_dest_.as<int64_t>(), ni, d_list_start_.as<int64_t>(), arena_ids_.as<int64_t>(),
+                                R.stream);
+        else
+            launch_scatter_i64(a_ids_.as<int64_t>(), a_dest_.as<int64_t>(), ni, arena_ids_.as<int64_t>(), R.stream);
         HIP_CHECK(hipMemcpyAsync(d_list_len_.p, a_newlen_.p, (size_t)nlist * 4, hipMemcpyDeviceToDevice, R.stream));
         if (live) {
             h_first_row_.resize((size_t)nlist);
@@ -1914,7 +2017,7 @@ void GpuIndexIVF::set_lists(const uint32_t* list_sizes, const uint8_t* codes, co
         acc += list_sizes[l];
         rows += ncap[l];
     }
-    FA_THROW_IF_NOT_MSG(acc == 0 || (codes && ids), "null codes / ids");
+    FA_THROW_IF_NOT_MSG(acc == 0 || (codes && (ids || indices_options == 1)), "null codes / ids");
     shadow_dirty_ = true;
     // nothing of the index changes before every device copy has been issued successfully
     arena_rows_ = 0; // (old contents are dropped: nothing to keep when the buffers grow)
@@ -1925,7 +2028,15 @@ void GpuIndexIVF::set_lists(const uint32_t* list_sizes, const uint8_t* codes, co
         // ids: list by list into the lists' row ranges
         DevBuf tmp_ids, tmp_codes, dsrc;
         tmp_ids.ensure((size_t)acc * 8);
+        std::vector<idx_t> pair_ids;
+        if (indices_options == 1) { // INDICES_IVF: (list << 32 | offset) instead of the caller's ids
+            pair_ids.resize((size_t)acc);
+            for (int l = 0; l < nlist; l++)
+                for (uint32_t j = 0; j < list_sizes[l]; j++) pair_ids[(size_t)src_start[l] + j] = ((idx_t)l << 32) | (idx_t)j;
+            ids = pair_ids.data();
+        }
         HIP_CHECK(hipMemcpyAsync(tmp_ids.p, ids, (size_t)acc * 8, hipMemcpyDefault, R.stream));
+        if (!pair_ids.empty()) R.sync(); // (the host vector goes out of scope below)
         std::vector<IvfMoveJob> jobs;
         for (int l = 0; l < nlist; l++)
             if (list_sizes[l]) jobs.push_back({src_start[l], nstart[l], (int64_t)list_sizes[l]});
@@ -3017,8 +3128,10 @@ void GpuIndexIVF::test_filter_dump(idx_t n, const float* x, int nprobe_now, idx_
 
 // ---------------------------------------------------------------------- IVF scalar quantizer
 GpuIndexIVFScalarQuantizer::GpuIndexIVFScalarQuantizer(std::shared_ptr<GpuResources> res, int dims, int nlist, int qtype_,
-                                                       int metric, bool encode_residual)
-        : GpuIndexIVF(std::move(res), dims, metric, nlist), qtype(qtype_), by_residual(encode_residual) {
+                                                       int metric, bool encode_residual, GpuIndexFlat* coarse_quantizer,
+                                                       bool coarse_f16, int indices_options_)
+        : GpuIndexIVF(std::move(res), dims, metric, nlist, coarse_quantizer, coarse_f16, indices_options_), qtype(qtype_),
+          by_residual(encode_residual) {
     // the types GpuIndexIVFScalarQuantizer accepts (faiss/gpu/impl/GpuScalarQuantizer.cuh:20-33 isSQSupported)
     dsq_ = (int)round_up(dims, 16);
     switch (qtype) {
@@ -3051,6 +3164,7 @@ GpuIndexIVFScalarQuantizer::GpuIndexIVFScalarQuantizer(std::shared_ptr<GpuResour
     sq_zero_.ensure((size_t)dsq_ * 4);
     HIP_CHECK(hipMemset(sq_zero_.p, 0, (size_t)dsq_ * 4));
     upload_tables_();
+    adopt_quantizer_();
 }
 
 // decoder tables: x^_i = fmaf(code_i, s_i, b_i) with s = vdiff / levels, b = vmin + s / 2 -- the reconstruction
@@ -3114,7 +3228,7 @@ void GpuIndexIVFScalarQuantizer::fill_lm_(IvfLmParams& p) const {
     p.arena_codes = arena_.as<uint8_t>();
     p.arena_rn = arena_rn_.as<float>();
     p.M = ct_; // (ivf_lm_supported's third argument for this kind)
-    p.centroids = quantizer->device_vectors();
+    p.centroids = centroids_dev_();
     p.ldc = dpad_;
     p.sq_ct = ct_;
     p.sq_ld = (int)code_bytes_;
@@ -3212,7 +3326,7 @@ void GpuIndexIVFScalarQuantizer::train_residual_(idx_t n, const float* x_dev_pad
         ddis.ensure((size_t)nt * 4);
         dres.ensure((size_t)nt * d * 4);
         quantizer->search_device((int)nt, xs, 1, ddis.as<float>(), dlab.as<idx_t>());
-        launch_residual(xs, dpad_, nt, d, dlab.as<idx_t>(), quantizer->device_vectors(), dpad_, dres.as<float>(), d, R.stream);
+        launch_residual(xs, dpad_, nt, d, dlab.as<idx_t>(), centroids_dev_(), dpad_, dres.as<float>(), d, R.stream);
         xs = dres.as<float>();
         ldr = d;
     }
@@ -3253,7 +3367,7 @@ void GpuIndexIVFScalarQuantizer::train_residual_(idx_t n, const float* x_dev_pad
     upload_tables_();
 }
 void GpuIndexIVFScalarQuantizer::append_(int n, const float* x_pad, const int64_t* d_labels, const int64_t* d_dest) {
-    launch_ivfsq_encode_append(qtype, x_pad, dpad_, n, d, d_labels, d_dest, quantizer->device_vectors(), dpad_, by_residual,
+    launch_ivfsq_encode_append(qtype, x_pad, dpad_, n, d, d_labels, d_dest, centroids_dev_(), dpad_, by_residual,
                                vmin_.as<float>(), vdiff_.as<float>(), arena_.as<uint8_t>(), (int)code_bytes_, res_->stream);
     if (use_rn_)
         launch_ivfsq_row_norms(arena_.as<uint8_t>(), ct_, (int)code_bytes_, d, sq_s_.as<float>(), d_dest, 0, n,
@@ -3267,7 +3381,7 @@ void GpuIndexIVFScalarQuantizer::fill_fused_(IvfFusedParams& p) const {
     p.sq_by_residual = by_residual ? 1 : 0;
     p.sq_s = sq_s_.as<float>();
     p.sq_b = sq_b_.as<float>();
-    p.centroids = quantizer->device_vectors();
+    p.centroids = centroids_dev_();
     p.ldc = dpad_;
 }
 int GpuIndexIVFScalarQuantizer::sq_chunk_bytes_() const {
@@ -3278,14 +3392,16 @@ void GpuIndexIVFScalarQuantizer::scan_(int, const float*, int, const int64_t*) c
 }
 
 // ---------------------------------------------------------------------- IVFFlat
-GpuIndexIVFFlat::GpuIndexIVFFlat(std::shared_ptr<GpuResources> res, int dims, int nlist, int metric)
-        : GpuIndexIVF(std::move(res), dims, metric, nlist) {
+GpuIndexIVFFlat::GpuIndexIVFFlat(std::shared_ptr<GpuResources> res, int dims, int nlist, int metric, GpuIndexFlat* coarse_quantizer,
+                                 bool coarse_f16, int indices_options_)
+        : GpuIndexIVF(std::move(res), dims, metric, nlist, coarse_quantizer, coarse_f16, indices_options_) {
     code_bytes_ = (size_t)dpad_ * 4;
     // lists start on multiples of 32 rows: the fp16 shadow of the filter sweeps is kept in 32-row operand-major blocks
     granule_ = 32;
     // |y|^2 per stored row: second term of the list-major scans' L2 distances / estimates; the filter's error band needs
     // max |y|^2 for the inner product as well
     use_rn_ = true;
+    adopt_quantizer_();
 }
 bool GpuIndexIVFFlat::lmf_capable_() const {
     return ivf_lmf_supported(0, d, dpad_, 0);
@@ -3409,8 +3525,8 @@ void GpuIndexIVFFlat::scan_(int nq, const float* xq_pad, int, const int64_t*) co
 
 // ---------------------------------------------------------------------- IVFPQ
 GpuIndexIVFPQ::GpuIndexIVFPQ(std::shared_ptr<GpuResources> res, int dims, int nlist, int M_, int nbits_,
-                             int metric)
-        : GpuIndexIVF(std::move(res), dims, metric, nlist), M(M_), nbits(nbits_) {
+                             int metric, GpuIndexFlat* coarse_quantizer, bool coarse_f16, int indices_options_)
+        : GpuIndexIVF(std::move(res), dims, metric, nlist, coarse_quantizer, coarse_f16, indices_options_), M(M_), nbits(nbits_) {
     // same restrictions as the reference GPU index (faiss/gpu/GpuIndexIVFPQ.cu:574-617), minus its
     // shared-memory limit on M: 160 KB of LDS holds an fp32 table up to M = 128.
     FA_THROW_IF_NOT_MSG(nbits == 8, "only 8 bits per code are supported");
@@ -3425,6 +3541,7 @@ GpuIndexIVFPQ::GpuIndexIVFPQ(std::shared_ptr<GpuResources> res, int dims, int nl
     res_->set_device();
     zero_row_.ensure((size_t)dpad_ * 4);
     HIP_CHECK(hipMemset(zero_row_.p, 0, (size_t)dpad_ * 4));
+    adopt_quantizer_();
 }
 void GpuIndexIVFPQ::set_pq_centroids(const float* pq) {
     FA_THROW_IF_NOT_MSG(pq, "null codebook");
@@ -3483,7 +3600,7 @@ void GpuIndexIVFPQ::train_residual_(idx_t n, const float* x_dev_pad) {
     ddis.ensure((size_t)nt * 4);
     dres.ensure((size_t)nt * d * 4);
     quantizer->search_device((int)nt, xs, 1, ddis.as<float>(), dlab.as<idx_t>());
-    launch_residual(xs, dpad_, nt, d, dlab.as<idx_t>(), quantizer->device_vectors(), dpad_,
+    launch_residual(xs, dpad_, nt, d, dlab.as<idx_t>(), centroids_dev_(), dpad_,
                     dres.as<float>(), d, R.stream);
     R.sync();
     std::vector<float> pq((size_t)M * 256 * dsub);
@@ -3581,10 +3698,10 @@ void GpuIndexIVFPQ::train_pq_batched_(idx_t nt, const float* res, std::vector<fl
     HIP_CHECK(hipMemcpy(pq.data(), cen.p, (size_t)KT * dsub * 4, hipMemcpyDeviceToHost));
 }
 void GpuIndexIVFPQ::append_(int n, const float* x_pad, const int64_t* d_labels, const int64_t* d_dest) {
-    launch_ivfpq_encode_append(x_pad, dpad_, n, d, d_labels, d_dest, quantizer->device_vectors(), dpad_, M,
+    launch_ivfpq_encode_append(x_pad, dpad_, n, d, d_labels, d_dest, centroids_dev_(), dpad_, M,
                                dsub, pq_.as<float>(), arena_.as<uint8_t>(), res_->stream);
     if (use_t2_)
-        launch_ivfpq_t2_rows(arena_.as<uint8_t>(), d_labels, d_dest, n, quantizer->device_vectors(), dpad_, M, dsub,
+        launch_ivfpq_t2_rows(arena_.as<uint8_t>(), d_labels, d_dest, n, centroids_dev_(), dpad_, M, dsub,
                              pq_.as<float>(), arena_t2_.as<float>(), res_->stream);
     // |r^|^2 of the new rows = the same chain against a zero centroid (fmaf(2, 0, r) == r): the list-major scan's term
     if (use_rn_)
@@ -3596,7 +3713,7 @@ void GpuIndexIVFPQ::lists_changed_() {
     if (nstored_ == 0) return;
     if (use_t2_)
         launch_ivfpq_t2_lists(arena_.as<uint8_t>(), d_list_start_.as<int64_t>(), d_list_len_.as<uint32_t>(), nlist,
-                              quantizer->device_vectors(), dpad_, M, dsub, pq_.as<float>(), arena_t2_.as<float>(), res_->stream);
+                              centroids_dev_(), dpad_, M, dsub, pq_.as<float>(), arena_t2_.as<float>(), res_->stream);
     if (use_rn_)
         launch_ivfpq_t2_lists(arena_.as<uint8_t>(), d_list_start_.as<int64_t>(), d_list_len_.as<uint32_t>(), nlist,
                               zero_row_.as<float>(), 0, M, dsub, pq_.as<float>(), arena_rn_.as<float>(), res_->stream);
@@ -3676,7 +3793,7 @@ bool GpuIndexIVFPQ::lmf_prepare_(IvfLmParams& p) const {
             yn += mx;
         }
         std::vector<float> cen((size_t)nlist * dpad_);
-        HIP_CHECK(hipMemcpy(cen.data(), quantizer->device_vectors(), cen.size() * 4, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(cen.data(), centroids_dev_(), cen.size() * 4, hipMemcpyDeviceToHost));
         double cn = 0.0;
         for (int l = 0; l < nlist; l++) {
             double nn = 0.0;
@@ -3743,12 +3860,12 @@ void GpuIndexIVFPQ::fill_lm_(IvfLmParams& p) const {
     p.M = M;
     p.dsub = dsub;
     p.pq_centroids = pq_.as<float>();
-    p.centroids = quantizer->device_vectors();
+    p.centroids = centroids_dev_();
     p.ldc = dpad_;
 }
 void GpuIndexIVFPQ::fill_fused_(IvfFusedParams& p) const {
     p.arena_t2 = arena_t2_.as<float>();
-    p.centroids = quantizer->device_vectors();
+    p.centroids = centroids_dev_();
     p.ldc = dpad_;
     p.M = M;
     p.dsub = dsub;
@@ -3772,7 +3889,7 @@ void GpuIndexIVFPQ::scan_(int nq, const float* xq_pad, int, const int64_t*) cons
     p.prefix = prefix_.as<uint32_t>();
     p.q_off = q_off_.as<int64_t>();
     p.keys = keys_.as<unsigned long long>();
-    p.centroids = quantizer->device_vectors();
+    p.centroids = centroids_dev_();
     p.ldc = dpad_;
     p.M = M;
     p.dsub = dsub;

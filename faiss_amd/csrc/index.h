@@ -25,6 +25,7 @@ namespace faiss_amd {
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    int dev = 0; // device the allocation was made on (accounting)
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
@@ -39,6 +40,11 @@ struct DevBuf {
 };
 
 bool is_device_pointer(const void* p);
+// device memory held by the library on `device` (every allocation is a DevBuf): live allocations, their bytes, the peak
+// (StandardGpuResources::getMemoryInfo, faiss/gpu/StandardGpuResources.cpp:676); log = one stderr line per alloc / free
+// (setLogMemoryAllocations, :327)
+void device_memory_info(int device, size_t* allocations, size_t* bytes, size_t* peak_bytes);
+void set_log_memory_allocations(int device, bool on);
 
 // ------------------------------------------------------------------ resources
 // One per device (and per host thread driving it), like StandardGpuResources: owns the
@@ -266,6 +272,8 @@ class GpuIndexFlat : public Index {
 
     int dpad() const { return dpad_; }
     const float* device_vectors() const; // fp32 rows [ntotal][dpad] (not available with fp16 storage)
+    // the rows as fp32 [ntotal][dpad] written to dst (device): a copy (fp32 storage) or the widened fp16 values
+    void rows_to_f32(float* dst) const;
     size_t resident_bytes() const;       // device bytes held for the database (rows, shadow copy, norms)
     std::shared_ptr<GpuResources> resources() const { return res_; }
 
@@ -327,12 +335,20 @@ struct ClusteringParameters {
 // ------------------------------------------------------------------ GpuIndexIVF
 class GpuIndexIVF : public Index {
    public:
-    GpuIndexIVF(std::shared_ptr<GpuResources> res, int dims, int metric, int nlist);
+    // coarse_quantizer: null = the index creates and owns a GpuIndexFlat (fp16 storage when coarse_f16:
+    // GpuIndexIVFConfig::flatConfig.useFloat16, faiss/gpu/GpuIndexIVF.h:23-35); otherwise the CALLER's flat index on the same
+    // device, not owned (own_fields = false, faiss/gpu/GpuIndexIVF.cu:41-70,107-108) -- it may hold its nlist centroids already
+    // (the index is then trained as far as the coarse level goes) and may be shared between indexes.
+    // indices_options: faiss/gpu/GpuIndicesOptions.h (INDICES_IVF: labels are list << 32 | offset).
+    GpuIndexIVF(std::shared_ptr<GpuResources> res, int dims, int metric, int nlist, GpuIndexFlat* coarse_quantizer = nullptr,
+                bool coarse_f16 = false, int indices_options = 3);
     ~GpuIndexIVF() override;
 
     int nlist;
     int nprobe = 1;
-    GpuIndexFlat* quantizer; // owned
+    GpuIndexFlat* quantizer; // owned iff own_fields
+    bool own_fields = true;
+    int indices_options = 3; // INDICES_CPU 0 (ids are kept on the device all the same), INDICES_IVF 1, INDICES_32_BIT 2, INDICES_64_BIT 3
 
     void train(idx_t n, const float* x) override;
     void add(idx_t n, const float* x) override;
@@ -389,6 +405,12 @@ class GpuIndexIVF : public Index {
    protected:
     std::shared_ptr<GpuResources> res_;
     int dpad_;
+    // the coarse centroids as fp32 rows [nlist][dpad_] on the device: the quantizer's own rows, or -- fp16 quantizer -- a
+    // widened copy (residuals are taken against the fp16-rounded centroids, as the reference's reconstruct gives them);
+    // refreshed after train / set_centroids / updateQuantizer
+    const float* centroids_dev_() const;
+    mutable DevBuf cent_f32_;
+    mutable bool cent_dirty_ = true;
     size_t code_bytes_ = 0; // bytes per arena row (dpad*4 for IVFFlat, M for IVFPQ)
     int granule_ = 8;       // list capacities and starts are multiples of this many rows
     bool use_t2_ = false;   // IVFPQ L2: per-row term in arena_t2_
@@ -413,6 +435,7 @@ class GpuIndexIVF : public Index {
     // everything add()/search() needs besides the coarse centroids is in place (IVFPQ: the codebook)
     virtual bool extra_trained_() const { return true; }
     void update_is_trained_();
+    void adopt_quantizer_();
     // called (under mu_) when rows [lists] were bulk-loaded or the quantizers changed: derived per-row data
     virtual void lists_changed_() {}
     // encode/scatter n staged vectors (device, padded) with given labels into arena rows dest
@@ -524,7 +547,8 @@ class GpuIndexIVF : public Index {
 
 class GpuIndexIVFFlat : public GpuIndexIVF {
    public:
-    GpuIndexIVFFlat(std::shared_ptr<GpuResources> res, int dims, int nlist, int metric);
+    GpuIndexIVFFlat(std::shared_ptr<GpuResources> res, int dims, int nlist, int metric, GpuIndexFlat* coarse_quantizer = nullptr,
+                    bool coarse_f16 = false, int indices_options = 3);
     // stored vector of id `key` (ids as given to add_with_ids / generated by add); faiss/gpu/GpuIndexIVFFlat.cu:370-390
     // offers reconstruct_n for contiguous ids, this is the same by-id lookup
     void reconstruct_n(idx_t i0, idx_t ni, float* recons) const override;
@@ -557,7 +581,8 @@ class GpuIndexIVFFlat : public GpuIndexIVF {
 
 class GpuIndexIVFPQ : public GpuIndexIVF {
    public:
-    GpuIndexIVFPQ(std::shared_ptr<GpuResources> res, int dims, int nlist, int M, int nbits, int metric);
+    GpuIndexIVFPQ(std::shared_ptr<GpuResources> res, int dims, int nlist, int M, int nbits, int metric,
+                  GpuIndexFlat* coarse_quantizer = nullptr, bool coarse_f16 = false, int indices_options = 3);
     int M, nbits, dsub;
     int pq_niter = 25; // faiss::ClusteringParameters default used by ProductQuantizer::train
     // the M sub-quantizers are trained as one k-means (ivf_kernels.hip pq_train_*); false, or FAISS_AMD_PQ_TRAIN_LOOP=1 in
@@ -642,7 +667,8 @@ class GpuIndexIVFPQ : public GpuIndexIVF {
 class GpuIndexIVFScalarQuantizer : public GpuIndexIVF {
    public:
     GpuIndexIVFScalarQuantizer(std::shared_ptr<GpuResources> res, int dims, int nlist, int qtype, int metric,
-                               bool encode_residual = true);
+                               bool encode_residual = true, GpuIndexFlat* coarse_quantizer = nullptr, bool coarse_f16 = false,
+                               int indices_options = 3);
     int qtype;
     bool by_residual;
     size_t code_size; // bytes per vector as the reference counts them (sq.code_size)

@@ -975,6 +975,22 @@ void launch_scatter_i64(const int64_t* src, const int64_t* dest, int64_t n, int6
     HIP_CHECK(hipGetLastError());
 }
 
+// INDICES_IVF (faiss/gpu/GpuIndicesOptions.h:20-23, impl/IVFUtilsSelect2.cu:148): the label of an entry is
+// (inverted list << 32 | offset inside the list) instead of a user id
+__global__ void pair_ids_kernel(const int64_t* __restrict__ labels, const int64_t* __restrict__ dest, int64_t n,
+                                const int64_t* __restrict__ list_start, int64_t* __restrict__ dst) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t t = dest[i], l = labels[i];
+    if (t >= 0 && l >= 0) dst[t] = (l << 32) | (t - list_start[l]);
+}
+void launch_ivf_pair_ids(const int64_t* labels, const int64_t* dest, int64_t n, const int64_t* list_start, int64_t* dst,
+                         hipStream_t stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(pair_ids_kernel, dim3((unsigned)div_up(n, 256)), dim3(256), 0, stream, labels, dest, n, list_start, dst);
+    HIP_CHECK(hipGetLastError());
+}
+
 __global__ void residual_kernel(const float* __restrict__ x, int64_t ldx, int64_t n, int d,
                                 const int64_t* __restrict__ labels, const float* __restrict__ centroids,
                                 int64_t ldc, float* __restrict__ out, int64_t ldo) {

@@ -783,6 +783,9 @@ void launch_pq_transpose(const float* pq, int M, int dsub, float* pq_t, hipStrea
 // dst[dest[i]] = src[i]  (dest < 0 skipped)
 void launch_scatter_i64(const int64_t* src, const int64_t* dest, int64_t n, int64_t* dst,
                         hipStream_t stream);
+// dst[dest[i]] = labels[i] << 32 | (dest[i] - list_start[labels[i]])  (INDICES_IVF labels; dest / labels < 0 skipped)
+void launch_ivf_pair_ids(const int64_t* labels, const int64_t* dest, int64_t n, const int64_t* list_start, int64_t* dst,
+                         hipStream_t stream);
 // out[i] = x[i] - centroids[labels[i]]  (faiss/gpu/impl/VectorResidual.cu:26)
 void launch_residual(const float* x, int64_t ldx, int64_t n, int d, const int64_t* labels,
                      const float* centroids, int64_t ldc, float* out, int64_t ldo, hipStream_t stream);

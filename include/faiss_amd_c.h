@@ -115,10 +115,16 @@ int faiss_amd_IndexIVFSQ_set_rangestat(FaissAmdIndex* index, int rangestat, floa
  *   useFloat16        GpuIndexFlat: vectors stored as fp16 only, queries converted to fp16, distances = the fp32
  *                     distances of those fp16 values (impl/FlatIndex.cu:39-135).  Halves the resident bytes.
  *   storeTransposed   accepted, ignored (the device layout is private to the kernels)
- *   indicesOptions    INDICES_64_BIT (3) or INDICES_32_BIT (2; ids are held as 64-bit anyway); INDICES_CPU / INDICES_IVF
- *                     (ids not on the device) are refused
- *   flat_useFloat16   coarse quantizer in fp16: refused (the residual / table kernels read fp32 centroids)
- *   allowCpuCoarseQuantizer  accepted, ignored (the coarse quantizer is always a device flat index)
+ *   indicesOptions    faiss/gpu/GpuIndicesOptions.h: INDICES_64_BIT (3), INDICES_32_BIT (2; ids are held as 64-bit anyway),
+ *                     INDICES_CPU (0; the reference keeps the ids on the host and translates there -- here they stay on the
+ *                     device, the results are the same user ids), INDICES_IVF (1: no user ids at all, the label of a result
+ *                     is inverted list << 32 | offset in the list, impl/IVFUtilsSelect2.cu:148)
+ *   flat_useFloat16   the index's own coarse quantizer stores its centroids as fp16 (GpuIndexIVFConfig::flatConfig.useFloat16,
+ *                     faiss/gpu/GpuIndexIVF.h:23-35): queries are rounded to fp16 for the coarse search, residuals are taken
+ *                     against the rounded centroids (what the quantizer's reconstruct returns), like the reference
+ *   allowCpuCoarseQuantizer  accepted: a coarse quantizer that is not a flat index of this library runs on the reference side
+ *                     (integration/faiss_amd_bridge.h: quantizer->search on the host, then search_preassigned / add_core --
+ *                     faiss/gpu/impl/IVFBase.cu:526-546)
  *   useFloat16LookupTables   accepted, ignored: the tables are fp32 on a per-query power-of-two grid (>= fp16 accuracy)
  *   usePrecomputedTables     accepted, ignored: the list-dependent L2 term is always kept per stored vector (4 B each),
  *                            which is what precomputed tables buy, without the nlist x M x 256 table
@@ -139,6 +145,29 @@ int faiss_amd_GpuIndexIVFFlat_new_with_config(FaissAmdIndex** p_index, FaissAmdG
                                               FaissAmdMetricType metric, const FaissAmdGpuIndexIVFConfig* config);
 int faiss_amd_GpuIndexIVFPQ_new_with_config(FaissAmdIndex** p_index, FaissAmdGpuResources* res, int d, int nlist, int M,
                                             int nbits, FaissAmdMetricType metric, const FaissAmdGpuIndexIVFPQConfig* config);
+/* GpuIndexIVFFlat / IVFPQ / IVFScalarQuantizer(resources, coarseQuantizer, ...) (faiss/gpu/GpuIndexIVFFlat.h:49-56,
+ * GpuIndexIVFPQ.h:70-79, GpuIndexIVFScalarQuantizer.h:47-55; GpuIndexIVF.cu:41-70): the coarse quantizer is the CALLER's flat
+ * index of this library on the same device -- NOT owned by the new index (own_fields = false: it must outlive it), possibly
+ * shared between indexes, possibly holding its nlist centroids already (the index then needs no coarse training).  null =
+ * the index creates and owns one (then identical to *_new_with_config).  config may be null. */
+int faiss_amd_GpuIndexIVFFlat_new_with_quantizer(FaissAmdIndex** p_index, FaissAmdGpuResources* res, FaissAmdIndex* coarse_quantizer,
+                                                 int d, int nlist, FaissAmdMetricType metric, const FaissAmdGpuIndexIVFConfig* config);
+int faiss_amd_GpuIndexIVFPQ_new_with_quantizer(FaissAmdIndex** p_index, FaissAmdGpuResources* res, FaissAmdIndex* coarse_quantizer,
+                                               int d, int nlist, int M, int nbits, FaissAmdMetricType metric,
+                                               const FaissAmdGpuIndexIVFPQConfig* config);
+int faiss_amd_GpuIndexIVFScalarQuantizer_new_with_quantizer(FaissAmdIndex** p_index, FaissAmdGpuResources* res,
+                                                            FaissAmdIndex* coarse_quantizer, int d, int nlist, int qtype,
+                                                            FaissAmdMetricType metric, int encode_residual,
+                                                            const FaissAmdGpuIndexIVFConfig* config);
+/* own_fields (0: caller-owned quantizer), whether the quantizer stores fp16, the index's IndicesOptions; pointers nullable */
+int faiss_amd_GpuIndexIVF_quantizer_info(const FaissAmdIndex* index, int* own_fields, int* use_float16, int* indices_options);
+/* StandardGpuResources::getMemoryInfo (faiss/gpu/StandardGpuResources.cpp:676; the reference returns a map device ->
+ * allocation type -> (count, bytes)): live device allocations of the library on the resources' device, their bytes, the peak
+ * of those bytes, the temp-memory budget (setTempMemory), and the device's free / total memory; every pointer nullable.
+ * setLogMemoryAllocations (StandardGpuResources.cpp:327): one stderr line per device allocation / release. */
+int faiss_amd_StandardGpuResources_getMemoryInfo(FaissAmdGpuResources* res, size_t* allocations, size_t* bytes, size_t* peak_bytes,
+                                                 size_t* temp_memory, size_t* device_free, size_t* device_total);
+int faiss_amd_StandardGpuResources_setLogMemoryAllocations(FaissAmdGpuResources* res, int enable);
 /* device bytes held for the database of a flat index (rows, fp16 shadow / storage, norms) */
 int faiss_amd_GpuIndexFlat_resident_bytes(const FaissAmdIndex* index, size_t* p_bytes);
 int faiss_amd_IndexShards_new(FaissAmdIndex** p_index, int d, int threaded, int successive_ids);

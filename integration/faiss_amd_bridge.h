@@ -21,6 +21,7 @@
 // tests/test_gpu_bridge.py; the product library does not depend on it.
 #pragma once
 
+#include <faiss/Clustering.h>
 #include <faiss/Index.h>
 #include <faiss/IndexFlat.h>
 #include <faiss/IndexIVF.h>
@@ -302,21 +303,73 @@ struct AmdQuantizerView : faiss::Index {
 /// faiss::gpu::GpuIndexIVF counterpart
 struct AmdIndexIVF : AmdIndex, faiss::IndexIVFInterface {
     AmdQuantizerView quantizer_view;
+    /// GpuIndexIVF(provider, Index* coarseQuantizer, ...) (faiss/gpu/GpuIndexIVF.cu:41-70): the caller's coarse quantizer, NOT
+    /// owned (own_fields = false).  A flat index of this backend (AmdIndexFlat) is handed to the device side as it is
+    /// (faiss_amd_GpuIndexIVF*_new_with_quantizer); ANY OTHER faiss::Index -- IndexFlat, IndexHNSWFlat, ... on the host -- is a
+    /// "CPU coarse quantizer" (GpuIndexIVFConfig::allowCpuCoarseQuantizer, faiss/gpu/impl/IVFBase.cu:526-546): its search / assign
+    /// run on the host and feed search_preassigned / add_core; the device keeps a copy of its reconstructed centroids for the
+    /// residuals (IVFPQ, scalar quantizer), like the reference's ivfCentroids_ (IVFBase.cu:480-507 updateQuantizer).
+    faiss::Index* user_quantizer = nullptr;
+    bool cpu_coarse = false;
 
-    AmdIndexIVF(FaissAmdIndex* handle, size_t nlist_in)
+    /// backend handle of a caller's quantizer when it is a flat index of this backend, else null
+    static FaissAmdIndex* native_quantizer(faiss::Index* q) {
+        auto* f = dynamic_cast<AmdIndexFlat*>(q);
+        return f ? f->h : nullptr;
+    }
+
+    AmdIndexIVF(FaissAmdIndex* handle, size_t nlist_in, faiss::Index* coarse_quantizer = nullptr)
             : AmdIndex(handle),
               faiss::IndexIVFInterface(nullptr, nlist_in),
               quantizer_view(handle, d, metric_type, nlist_in) {
         quantizer = &quantizer_view;
         own_fields = false;
+        if (coarse_quantizer) {
+            FAISS_THROW_IF_NOT_MSG(coarse_quantizer->d == d, "the coarse quantizer's dimension differs from the index's");
+            user_quantizer = coarse_quantizer;
+            quantizer = coarse_quantizer;
+            cpu_coarse = native_quantizer(coarse_quantizer) == nullptr;
+            if (cpu_coarse && coarse_quantizer->is_trained && coarse_quantizer->ntotal == (idx_t)nlist) push_cpu_centroids_();
+            sync();
+        }
         refresh_quantizer_();
+    }
+    /// the device's copy of a CPU quantizer's centroids (what the residuals are taken against)
+    void push_cpu_centroids_() {
+        std::vector<float> c(nlist * (size_t)d);
+        quantizer->reconstruct_n(0, nlist, c.data());
+        amd_check(faiss_amd_IndexIVF_copy_centroids(h, c.data()));
     }
     void refresh_quantizer_() {
         // (is the coarse quantizer in place? get_centroids fails cleanly when it is not)
         std::vector<float> c(nlist * (size_t)d);
         quantizer_view.ntotal = faiss_amd_IndexIVF_get_centroids(h, c.data()) == 0 ? (idx_t)nlist : 0;
+        if (auto* f = dynamic_cast<AmdIndex*>(user_quantizer)) f->sync(); // (a native quantizer is filled on the device side)
+    }
+    void add(idx_t n, const float* x) override {
+        if (!cpu_coarse) return AmdIndex::add(n, x);
+        add_with_ids(n, x, nullptr);
+    }
+    void add_with_ids(idx_t n, const float* x, const idx_t* xids) override {
+        if (!cpu_coarse) return AmdIndex::add_with_ids(n, x, xids);
+        FAISS_THROW_IF_NOT_MSG(is_trained, "index must be trained before adding vectors");
+        std::vector<idx_t> a((size_t)n);
+        quantizer->assign(n, x, a.data()); // IndexIVF::add_with_ids: quantizer->assign, then add_core (faiss/IndexIVF.cpp:194-215)
+        add_core(n, x, xids, a.data());
     }
     void train(idx_t n, const float* x) override {
+        if (cpu_coarse) {
+            if (quantizer->ntotal != (idx_t)nlist) {
+                // Level1Quantizer::train_q1 (faiss/IndexIVF.cpp:59-127, quantizer_trains_alone = 0) = GpuIndexIVF::trainQuantizer_
+                // (faiss/gpu/GpuIndexIVF.cu:508-538): k-means with the quantizer itself as the assignment index
+                faiss::Clustering clus(d, nlist, cp);
+                quantizer->reset();
+                clus.train(n, x, *quantizer);
+                quantizer->is_trained = true;
+                FAISS_THROW_IF_NOT(quantizer->ntotal == (idx_t)nlist);
+            }
+            push_cpu_centroids_();
+        }
         // GpuIndexIVF::cp (Level1Quantizer::cp, faiss/IndexIVF.h:60): the clustering parameters of the coarse quantizer
         FaissAmdClusteringParameters p;
         faiss_amd_ClusteringParameters_init(&p);
@@ -344,6 +397,7 @@ struct AmdIndexIVF : AmdIndex, faiss::IndexIVFInterface {
         return bytes;
     }
     void updateQuantizer() {
+        if (cpu_coarse && quantizer->ntotal == (idx_t)nlist) push_cpu_centroids_();
         amd_check(faiss_amd_GpuIndexIVF_updateQuantizer(h));
         sync();
         refresh_quantizer_();
@@ -369,6 +423,17 @@ struct AmdIndexIVF : AmdIndex, faiss::IndexIVFInterface {
             sel = ivf_params->sel; // on the stored ids, as IndexIVF::search applies it (faiss/IndexIVF.cpp scan_codes)
         }
         AmdSearchParams sp(sel, -1, true, np);
+        if (cpu_coarse) {
+            // CPU coarse quantizer (faiss/gpu/impl/IVFBase.cu:549-590): its search on the host, the lists on the device
+            np = std::min(np, nlist);
+            std::vector<float> cd((size_t)n * np);
+            std::vector<idx_t> ci((size_t)n * np);
+            quantizer->search(n, x, (idx_t)np, cd.data(), ci.data());
+            AmdSearchParams sp2(sel, -1, true, np);
+            amd_check(faiss_amd_GpuIndexIVF_search_preassigned_with_params(h, n, x, k, ci.data(), cd.data(), sp2.h, distances,
+                                                                           labels));
+            return;
+        }
         amd_check(faiss_amd_Index_search_with_params(h, n, x, k, sp.h, distances, labels));
     }
     void search_preassigned(idx_t n, const float* x, idx_t k, const idx_t* assign, const float* centroid_dis,
@@ -417,8 +482,13 @@ struct AmdIndexIVF : AmdIndex, faiss::IndexIVFInterface {
         FAISS_THROW_IF_NOT_MSG(index->quantizer && index->quantizer->ntotal == (idx_t)nlist, "untrained coarse quantizer");
         std::vector<float> c(nlist * (size_t)d);
         index->quantizer->reconstruct_n(0, nlist, c.data());
+        if (cpu_coarse) { // the caller's host-side quantizer takes the centroids too (GpuIndexIVF::copyFrom, GpuIndexIVF.cu:139-230)
+            quantizer->reset();
+            quantizer->add(nlist, c.data());
+        }
         amd_check(faiss_amd_IndexIVF_copy_centroids(h, c.data()));
         quantizer_view.ntotal = nlist;
+        refresh_quantizer_();
     }
     /// copyTo(IndexIVF*): a flat CPU quantizer holding our centroids + ArrayInvertedLists with our lists
     /// (faiss/gpu/GpuIndexIVF.cu:232-268, impl/IVFBase.cu:346-390 copyInvertedListsTo)
@@ -469,6 +539,17 @@ struct AmdIndexIVFFlat : AmdIndexIVF {
     }
     AmdIndexIVFFlat(AmdGpuResources* res, int d, size_t nlist, MetricType metric = METRIC_L2)
             : AmdIndexIVF(make(res, d, nlist, metric), nlist) {}
+    /// GpuIndexIVFFlat(provider, Index* coarseQuantizer, dims, nlist, metric, config) (faiss/gpu/GpuIndexIVFFlat.h:49-56)
+    static FaissAmdIndex* make_q(AmdGpuResources* res, faiss::Index* q, int d, size_t nlist, MetricType metric,
+                                 const FaissAmdGpuIndexIVFConfig* config) {
+        FaissAmdIndex* handle = nullptr;
+        amd_check(faiss_amd_GpuIndexIVFFlat_new_with_quantizer(&handle, res->h, native_quantizer(q), d, (int)nlist,
+                                                               (FaissAmdMetricType)metric, config));
+        return handle;
+    }
+    AmdIndexIVFFlat(AmdGpuResources* res, faiss::Index* coarseQuantizer, int d, size_t nlist, MetricType metric = METRIC_L2,
+                    const FaissAmdGpuIndexIVFConfig* config = nullptr)
+            : AmdIndexIVF(make_q(res, coarseQuantizer, d, nlist, metric, config), nlist, coarseQuantizer) {}
     AmdIndexIVFFlat(AmdGpuResources* res, const faiss::IndexIVFFlat* index)
             : AmdIndexIVF(make(res, index->d, index->nlist, index->metric_type), index->nlist) {
         copyFrom(index);
@@ -495,6 +576,19 @@ struct AmdIndexIVFPQ : AmdIndexIVF {
     }
     AmdIndexIVFPQ(AmdGpuResources* res, int d, size_t nlist, int M_, int nbits_, MetricType metric = METRIC_L2)
             : AmdIndexIVF(make(res, d, nlist, M_, nbits_, metric), nlist), M(M_), nbits(nbits_) {}
+    /// GpuIndexIVFPQ(provider, Index* coarseQuantizer, dims, nlist, subQuantizers, bitsPerCode, metric, config) (GpuIndexIVFPQ.h:70-79)
+    static FaissAmdIndex* make_q(AmdGpuResources* res, faiss::Index* q, int d, size_t nlist, int M, int nbits, MetricType metric,
+                                 const FaissAmdGpuIndexIVFPQConfig* config) {
+        FaissAmdIndex* handle = nullptr;
+        amd_check(faiss_amd_GpuIndexIVFPQ_new_with_quantizer(&handle, res->h, native_quantizer(q), d, (int)nlist, M, nbits,
+                                                             (FaissAmdMetricType)metric, config));
+        return handle;
+    }
+    AmdIndexIVFPQ(AmdGpuResources* res, faiss::Index* coarseQuantizer, int d, size_t nlist, int M_, int nbits_,
+                  MetricType metric = METRIC_L2, const FaissAmdGpuIndexIVFPQConfig* config = nullptr)
+            : AmdIndexIVF(make_q(res, coarseQuantizer, d, nlist, M_, nbits_, metric, config), nlist, coarseQuantizer),
+              M(M_),
+              nbits(nbits_) {}
     /// GpuIndexIVFPQ(resources, const IndexIVFPQ*) (faiss/gpu/GpuIndexIVFPQ.cu:48-62, copyFrom :98-168)
     AmdIndexIVFPQ(AmdGpuResources* res, const faiss::IndexIVFPQ* index)
             : AmdIndexIVF(make(res, index->d, index->nlist, (int)index->pq.M, (int)index->pq.nbits, index->metric_type),
@@ -545,6 +639,21 @@ struct AmdIndexIVFScalarQuantizer : AmdIndexIVF {
     AmdIndexIVFScalarQuantizer(AmdGpuResources* res, int d, size_t nlist, faiss::ScalarQuantizer::QuantizerType qtype,
                                MetricType metric = METRIC_L2, bool encodeResidual = true)
             : AmdIndexIVF(make(res, d, nlist, (int)qtype, metric, encodeResidual), nlist),
+              sq(d, qtype),
+              by_residual(encodeResidual) {}
+    /// GpuIndexIVFScalarQuantizer(provider, Index* coarseQuantizer, dims, nlist, qtype, metric, encodeResidual, config)
+    /// (faiss/gpu/GpuIndexIVFScalarQuantizer.h:47-55)
+    static FaissAmdIndex* make_q(AmdGpuResources* res, faiss::Index* q, int d, size_t nlist, int qtype, MetricType metric,
+                                 bool by_residual, const FaissAmdGpuIndexIVFConfig* config) {
+        FaissAmdIndex* handle = nullptr;
+        amd_check(faiss_amd_GpuIndexIVFScalarQuantizer_new_with_quantizer(&handle, res->h, native_quantizer(q), d, (int)nlist, qtype,
+                                                                          (FaissAmdMetricType)metric, by_residual ? 1 : 0, config));
+        return handle;
+    }
+    AmdIndexIVFScalarQuantizer(AmdGpuResources* res, faiss::Index* coarseQuantizer, int d, size_t nlist,
+                               faiss::ScalarQuantizer::QuantizerType qtype, MetricType metric = METRIC_L2, bool encodeResidual = true,
+                               const FaissAmdGpuIndexIVFConfig* config = nullptr)
+            : AmdIndexIVF(make_q(res, coarseQuantizer, d, nlist, (int)qtype, metric, encodeResidual, config), nlist, coarseQuantizer),
               sq(d, qtype),
               by_residual(encodeResidual) {}
     /// GpuIndexIVFScalarQuantizer(resources, const IndexIVFScalarQuantizer*) (GpuIndexIVFScalarQuantizer.cu:27-43)

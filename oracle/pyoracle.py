@@ -554,6 +554,32 @@ class Ref:
         return cls._wrap_ptr(cls.lib().ref_amd_index_gpu_to_cpu(ctypes.c_void_p(gpu_index.h)), gpu_index.d, [gpu_index])
 
     @classmethod
+    def amd_flat(cls, res, d, metric=METRIC_L2):
+        """a flat index of the backend as a faiss::Index of the bridge (AmdIndexFlat)"""
+        cls.lib().ref_amd_flat_new.restype = ctypes.c_void_p
+        return cls._wrap_ptr(cls.lib().ref_amd_flat_new(ctypes.c_void_p(res), ctypes.c_int(d), ctypes.c_int(metric)), d)
+
+    @classmethod
+    def amd_ivf_with_quantizer(cls, res, quantizer, kind, d, nlist, arg=0, metric=METRIC_L2, coarse_f16=False, indices_options=3):
+        """the bridge's GpuIndexIVFFlat (kind 0) / IVFPQ (1, arg = M) / IVFScalarQuantizer (2, arg = qtype) over the CALLER's coarse
+        quantizer `quantizer` (any RefIndex: Ref.amd_flat(...) runs on the device, a CPU index on the host)"""
+        cls.lib().ref_amd_ivf_new_with_quantizer.restype = ctypes.c_void_p
+        h = cls.lib().ref_amd_ivf_new_with_quantizer(ctypes.c_void_p(res), ctypes.c_void_p(quantizer.h), ctypes.c_int(kind),
+                                                     ctypes.c_int(d), ctypes.c_int(nlist), ctypes.c_int(arg), ctypes.c_int(metric),
+                                                     ctypes.c_int(int(coarse_f16)), ctypes.c_int(indices_options))
+        return cls._wrap_ptr(h, d, [quantizer])
+
+    @classmethod
+    def write_index(cls, index, path):
+        if cls.lib().ref_write_index(ctypes.c_void_p(index.h), path.encode()) != 0:
+            raise RuntimeError("reference error: " + cls.lib().ref_last_error().decode())
+
+    @classmethod
+    def read_index(cls, path, d):
+        cls.lib().ref_read_index.restype = ctypes.c_void_p
+        return cls._wrap_ptr(cls.lib().ref_read_index(path.encode()), d)
+
+    @classmethod
     def ivfflat_with_quantizer(cls, quantizer, d, nlist, metric=METRIC_L2):
         """a reference faiss::IndexIVFFlat whose coarse quantizer is `quantizer` (any RefIndex, e.g. Ref.adapter(...))"""
         cls.lib().ref_ivfflat_with_quantizer.restype = ctypes.c_void_p

@@ -19,6 +19,7 @@
 #include <faiss/IndexScalarQuantizer.h>
 #include <faiss/IndexShards.h>
 #include <faiss/index_factory.h>
+#include <faiss/index_io.h>
 #include <faiss/impl/FaissException.h>
 #include <faiss/utils/distances.h>
 #include <omp.h>
@@ -104,8 +105,14 @@ static faiss::IndexIVF* ivf(void* p) {
     if (!r) FAISS_THROW_MSG("not an IndexIVF");
     return r;
 }
+// (IndexIVFInterface: the reference's IndexIVF and the bridge's AmdIndexIVF alike -- nprobe / cp are its members)
+static faiss::IndexIVFInterface* ivfi(void* p) {
+    auto* i = dynamic_cast<faiss::IndexIVFInterface*>((faiss::Index*)p);
+    FAISS_THROW_IF_NOT_MSG(i, "not an IVF index");
+    return i;
+}
 int ref_ivf_set_nprobe(void* p, int nprobe) {
-    SHIM_TRY ivf(p)->nprobe = nprobe;
+    SHIM_TRY ivfi(p)->nprobe = nprobe;
     SHIM_CATCH
 }
 int ref_ivf_nlist(void* p) {
@@ -262,10 +269,9 @@ int ref_ivf_set_centroids(void* p, const float* centroids) {
 // quantizer (ProductQuantizer::cp); <= 0 leaves a value unchanged.  Used to bound the training time of
 // the CPU baseline (search speed does not depend on it).
 int ref_ivf_set_train_niter(void* p, int niter_coarse, int niter_pq) {
-    SHIM_TRY auto* ivf = dynamic_cast<faiss::IndexIVF*>((faiss::Index*)p);
-    FAISS_THROW_IF_NOT_MSG(ivf, "not an IndexIVF");
+    SHIM_TRY auto* ivf = ivfi(p);
     if (niter_coarse > 0) ivf->cp.niter = niter_coarse;
-    auto* pq = dynamic_cast<faiss::IndexIVFPQ*>(ivf);
+    auto* pq = dynamic_cast<faiss::IndexIVFPQ*>((faiss::Index*)p);
     if (pq && niter_pq > 0) pq->pq.cp.niter = niter_pq;
     SHIM_CATCH
 }
@@ -341,6 +347,52 @@ void* ref_amd_index_cpu_to_gpu_multiple(void** res, int nres, void* cpu_index, i
 void* ref_amd_index_gpu_to_cpu(void* gpu_index) {
     try {
         return faiss::amd::index_gpu_to_cpu((const faiss::Index*)gpu_index);
+    } catch (std::exception& e) {
+        g_err = e.what();
+        return nullptr;
+    }
+}
+// a flat index of the backend as a faiss::Index (AmdIndexFlat): e.g. the caller-owned coarse quantizer of an IVF index
+void* ref_amd_flat_new(void* res, int d, int metric) {
+    try {
+        return (faiss::Index*)new faiss::amd::AmdIndexFlat((faiss::amd::AmdGpuResources*)res, d, (faiss::MetricType)metric);
+    } catch (std::exception& e) {
+        g_err = e.what();
+        return nullptr;
+    }
+}
+// GpuIndexIVFFlat / IVFPQ / IVFScalarQuantizer(provider, Index* coarseQuantizer, ...) of the bridge: `quantizer` is ANY
+// faiss::Index* -- a backend flat index (handed to the device side) or a host index (CPU coarse quantizer).  kind 0 IVFFlat,
+// 1 IVFPQ (arg = M), 2 scalar quantizer (arg = qtype, residual encoding)
+void* ref_amd_ivf_new_with_quantizer(void* res, void* quantizer, int kind, int d, int nlist, int arg, int metric, int coarse_f16,
+                                     int indices_options) {
+    try {
+        auto* r = (faiss::amd::AmdGpuResources*)res;
+        auto* q = (faiss::Index*)quantizer;
+        FaissAmdGpuIndexIVFPQConfig cfg;
+        memset(&cfg, 0, sizeof(cfg));
+        cfg.ivf.device = -1;
+        cfg.ivf.indicesOptions = indices_options;
+        cfg.ivf.flat_useFloat16 = coarse_f16;
+        const auto mt = (faiss::MetricType)metric;
+        if (kind == 0) return (faiss::Index*)new faiss::amd::AmdIndexIVFFlat(r, q, d, (size_t)nlist, mt, &cfg.ivf);
+        if (kind == 1) return (faiss::Index*)new faiss::amd::AmdIndexIVFPQ(r, q, d, (size_t)nlist, arg, 8, mt, &cfg);
+        return (faiss::Index*)new faiss::amd::AmdIndexIVFScalarQuantizer(r, q, d, (size_t)nlist, (faiss::ScalarQuantizer::QuantizerType)arg,
+                                                                        mt, true, &cfg.ivf);
+    } catch (std::exception& e) {
+        g_err = e.what();
+        return nullptr;
+    }
+}
+// faiss::write_index / read_index (faiss/index_io.h; impl/index_write.cpp, impl/index_read.cpp): the checkpoint path of a GPU
+// index is index_gpu_to_cpu -> write_index, and back read_index -> index_cpu_to_gpu (faiss/gpu/test/test_gpu_index_serialize.py)
+int ref_write_index(void* p, const char* path) {
+    SHIM_TRY faiss::write_index((const faiss::Index*)p, path);
+    SHIM_CATCH
+}
+void* ref_read_index(const char* path) {
+    try {
+        return faiss::read_index(path);
     } catch (std::exception& e) {
         g_err = e.what();
         return nullptr;

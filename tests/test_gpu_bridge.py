@@ -131,3 +131,101 @@ def test_index_cpu_to_gpu_multiple(bres, desc, mode):
         back.set_nprobe(8)
     Db, Ib = back.search(xq, k)
     check_knn(Db, Ib, Dr, Ir, rtol=1e-6, name="%s %s back on the CPU" % (desc, mode))
+
+
+@pytest.mark.parametrize("desc", ["Flat", "IVF64,Flat", "IVF64,PQ16", "IVF64,SQ8"])
+def test_serialization_round_trip_through_the_cpu_index(bres, desc, tmp_path):
+    """faiss/gpu/test/test_gpu_index_serialize.py: a GPU index is checkpointed as index_gpu_to_cpu -> write_index and restored as
+    read_index -> index_cpu_to_gpu (the reference has no GPU file format of its own).  The restored backend index returns the
+    bits of the original."""
+    d, k = 64, 20
+    xt, xb, xq = synthetic_dataset(d, 4000, 20000, 300, seed=43)
+    cpu = _cpu_index(desc, d, xt, xb)
+    gpu = Ref.index_cpu_to_gpu(bres[0], cpu)
+    D0, I0 = gpu.search(xq, k)
+    path = str(tmp_path / "ckpt.faissindex")
+    Ref.write_index(Ref.index_gpu_to_cpu(gpu), path)
+    del gpu
+    restored_cpu = Ref.read_index(path, d)
+    assert restored_cpu.ntotal == len(xb) and restored_cpu.is_trained
+    if "IVF" in desc:
+        restored_cpu.set_nprobe(8)  # (nprobe is not part of the file: faiss/impl/index_write.cpp write_ivf_header)
+    gpu2 = Ref.index_cpu_to_gpu(bres[1], restored_cpu)
+    assert "Amd" in gpu2.type_name() and gpu2.ntotal == len(xb)
+    D1, I1 = gpu2.search(xq, k)
+    assert np.array_equal(I1, I0) and np.array_equal(D1, D0)
+    # the file is the reference's: its own CPU search on the restored index equals its search before the round trip
+    Dr, Ir = cpu.search(xq, k)
+    Db, Ib = restored_cpu.search(xq, k)
+    assert np.array_equal(Ib, Ir) and np.array_equal(Db, Dr)
+
+
+@pytest.mark.parametrize("kind,arg", [(0, 0), (1, 16), (2, 0)])
+def test_caller_owned_backend_quantizer_through_the_bridge(bres, kind, arg):
+    """GpuIndexIVF*(provider, Index* coarseQuantizer, ...) (faiss/gpu/GpuIndexIVF.cu:41-70) with a flat index OF THE BACKEND as the
+    caller's quantizer: handed to the device side, not owned, trained in place when empty, shared by two indexes."""
+    d, nlist, k, nprobe = 64, 32, 15, 6
+    xt, xb, xq = synthetic_dataset(d, 4000, 20000, 300, seed=47)
+    q = Ref.amd_flat(bres[0], d)
+    a = Ref.amd_ivf_with_quantizer(bres[0], q, kind, d, nlist, arg)
+    assert not a.is_trained and q.ntotal == 0
+    a.set_train_niter(5, 6)
+    a.train(xt)
+    assert a.is_trained and q.ntotal == nlist  # the caller's quantizer holds the centroids now
+    b = Ref.amd_ivf_with_quantizer(bres[0], q, 0, d, nlist)  # a second index over the same (now trained) quantizer
+    assert b.is_trained
+    for idx in (a, b):
+        idx.add(xb)
+        idx.set_nprobe(nprobe)
+    D, I = a.search(xq, k)
+    assert (I[:, 0] >= 0).all() and a.ntotal == len(xb)
+    Dq, Iq = q.search(xq, nprobe)  # the quantizer stays an ordinary index of the caller's
+    assert Iq.min() >= 0 and Iq.max() < nlist
+    Db, Ib = b.search(xq, k)
+    # b (IVFFlat over q) == a reference IVFFlat built on the host from the same centroids, within the flat tolerance
+    cpu = Ref.index_factory(d, "IVF%d,Flat" % nlist, METRIC_L2)
+    cpu.set_centroids(q.reconstruct_n(0, nlist))
+    cpu.add(xb)
+    cpu.set_nprobe(nprobe)
+    Dr, Ir = cpu.search(xq, k)
+    check_knn(Db, Ib, Dr, Ir, rtol=1e-4, name="IVFFlat over a caller-owned backend quantizer")
+    del a, b
+    assert q.ntotal == nlist and q.search(xq[:3], 2)[1].shape == (3, 2)  # the quantizer outlives the indexes
+
+
+@pytest.mark.parametrize("kind,arg,qdesc", [(0, 0, "Flat"), (1, 16, "Flat"), (2, 0, "Flat"), (0, 0, "HNSW16")])
+def test_cpu_coarse_quantizer_through_the_bridge(bres, kind, arg, qdesc):
+    """GpuIndexIVFConfig::allowCpuCoarseQuantizer (faiss/gpu/GpuIndexIVF.h:23-35, impl/IVFBase.cu:526-546): the coarse quantizer is
+    ANY faiss::Index on the host (IndexFlatL2, IndexHNSWFlat): its search / assign run there and feed search_preassigned /
+    add_core; the lists live on the device.  Flat CPU quantizer: the lists are those the quantizer's own assignment gives, and
+    the search agrees with the reference's CPU search of the index cloned back (same lists, same quantizer) to 1e-4; HNSW (an
+    approximate quantizer) is checked for recall."""
+    d, nlist, k, nprobe = 64, 32, 15, 6
+    xt, xb, xq = synthetic_dataset(d, 4000, 20000, 300, seed=53)
+    cq = Ref.index_factory(d, qdesc, METRIC_L2)
+    g = Ref.amd_ivf_with_quantizer(bres[0], cq, kind, d, nlist, arg)
+    assert not g.is_trained
+    g.set_train_niter(5, 6)
+    g.train(xt)
+    assert g.is_trained and cq.ntotal == nlist
+    g.add(xb)
+    g.set_nprobe(nprobe)
+    assert g.ntotal == len(xb)
+    D, I = g.search(xq, k)
+    assert (I[:, 0] >= 0).all()
+    if qdesc == "Flat":
+        back = Ref.index_gpu_to_cpu(g)
+        sizes, _, ids = back.lists()
+        lab = cq.search(xb, 1)[1][:, 0]
+        assert np.array_equal(np.bincount(lab, minlength=nlist).astype(sizes.dtype), sizes)
+        order = np.argsort(lab, kind="stable")
+        assert np.array_equal(ids, order)  # insertion order inside every list
+        assert np.array_equal(back.centroids(), cq.reconstruct_n(0, nlist))
+        back.set_nprobe(nprobe)
+        Db, Ib = back.search(xq, k)
+        check_knn(D, I, Db, Ib, rtol=1e-4, name="CPU coarse quantizer: device lists vs the cloned-back CPU index")
+    else:
+        flat = Ref.index_factory(d, "Flat", METRIC_L2)
+        flat.add(xb)
+        _, gt = flat.search(xq, 1)
+        assert (I == gt[:, :1]).any(axis=1).mean() > 0.8

@@ -46,7 +46,7 @@ def test_bench_under_torchrun_counts_its_ranks_through_rccl():
     out = _torchrun(["bench.py", "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-ivf", "--scale-legs", "", "--no-cpu-baseline"],
                     {}, 900)
     assert out["n_gpus"] == 1 and out["ranks_seen"] == 1 and out.get("ranks_seen_via") == "rccl all_reduce", out
-    assert out["value"] > 1e5 and out["recall_at_1"] == 1.0
+    assert out["value"] > 1e5 and out["roofline"]["frac"] > 0.05
 
 
 def test_group_of_one_protocol_on_gloo():

@@ -36,3 +36,161 @@ def test_new_pq_codebook_invalidates_the_decoded_copy_of_the_lists(res, d, M):
     Dq, Iq = idx.search(xq, k)
     assert np.array_equal(I1, Iq) and np.array_equal(D1, Dq)
     assert not np.array_equal(I0, I1)  # (the codebook really changed the answer)
+
+
+# ------------------------------------------------------------------ caller-owned / fp16 coarse quantizer, indices options
+def _trained_pair(res, d, nlist, seed):
+    xt, xb, xq = synthetic_dataset(d, 6000, 30000, 500, seed=seed)
+    cent, _ = faiss_amd.kmeans(res, xt, nlist, niter=6, seed=3)
+    return xt, xb, xq, cent
+
+
+@pytest.mark.parametrize("metric", [METRIC_L2, METRIC_INNER_PRODUCT])
+def test_caller_owned_coarse_quantizer_shared_by_two_indexes(res, metric):
+    """GpuIndexIVFFlat / GpuIndexIVFPQ(resources, coarseQuantizer, ...) (faiss/gpu/GpuIndexIVF.cu:41-70): the quantizer is the
+    caller's GpuIndexFlat, not owned, may already hold its centroids (no coarse training then) and may serve several indexes."""
+    d, nlist, M, k = 64, 32, 16, 25
+    xt, xb, xq, cent = _trained_pair(res, d, nlist, 17)
+    q = faiss_amd.GpuIndexFlat(res, d, metric)
+    q.add(cent)
+    a = faiss_amd.GpuIndexIVFFlat(res, d, nlist, metric, quantizer=q)
+    assert a.is_trained and a.quantizer_info() == (False, False, faiss_amd.INDICES_64_BIT)
+    b = faiss_amd.GpuIndexIVFPQ(res, d, nlist, M, 8, metric, quantizer=q)
+    assert not b.is_trained  # the product quantizer is still missing
+    b.train(xt)
+    assert b.is_trained and q.ntotal == nlist and np.array_equal(q.reconstruct_n(0, nlist), cent)  # coarse level untouched
+    own_a = faiss_amd.GpuIndexIVFFlat(res, d, nlist, metric)
+    own_a.copy_centroids(cent)
+    own_b = faiss_amd.GpuIndexIVFPQ(res, d, nlist, M, 8, metric)
+    own_b.copy_centroids(cent)
+    own_b.copy_pq_centroids(b.get_pq_centroids())
+    for idx in (a, b, own_a, own_b):
+        idx.add(xb)
+        idx.nprobe = 7
+    for mine, ref in ((a, own_a), (b, own_b)):
+        for nq in (500, 9):  # list-major / query-major
+            D, I = mine.search(xq[:nq], k)
+            Dr, Ir = ref.search(xq[:nq], k)
+            assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+    # an EMPTY caller-owned quantizer is trained in place by the index (trainQuantizer_, GpuIndexIVF.cu:508-538)
+    q2 = faiss_amd.GpuIndexFlat(res, d, metric)
+    c = faiss_amd.GpuIndexIVFFlat(res, d, nlist, metric, quantizer=q2)
+    assert not c.is_trained
+    c.train(xt)
+    assert c.is_trained and q2.ntotal == nlist
+    # the indexes go first, the quantizer survives them
+    del a, b, c
+    Dq, Iq = q.search(xq[:5], 3)
+    assert Iq.shape == (5, 3)
+    # wrong shapes are refused like the reference's verifyIVFSettings_
+    with pytest.raises(faiss_amd.FaissAmdError):
+        faiss_amd.GpuIndexIVFFlat(res, d + 8, nlist, metric, quantizer=q)
+    with pytest.raises(faiss_amd.FaissAmdError):
+        faiss_amd.GpuIndexIVFFlat(res, d, nlist + 1, metric, quantizer=q)
+
+
+@pytest.mark.parametrize("kind", ["flat", "pq", "sq"])
+def test_fp16_coarse_quantizer(res, kind):
+    """GpuIndexIVFConfig::flatConfig.useFloat16 (faiss/gpu/GpuIndexIVF.h:23-35; TestGpuIndexIVFPQ.cpp Float16Coarse): the coarse
+    quantizer stores fp16 centroids.  Coarse search = the search of a GpuIndexFlat with useFloat16 over the centroids; residuals
+    are taken against the ROUNDED centroids.  Checked bit for bit against an fp32-quantizer index that is handed the rounded
+    centroids and that coarse search's output (add_core / search_preassigned)."""
+    d, nlist, M, k, nprobe = 64, 32, 16, 20, 6
+    xt, xb, xq, cent = _trained_pair(res, d, nlist, 23)
+    cfg = faiss_amd.GpuIndexIVFConfig(flat_useFloat16=True)
+    if kind == "flat":
+        mk = lambda c: faiss_amd.GpuIndexIVFFlat(res, d, nlist, METRIC_L2, config=c)  # noqa: E731
+    elif kind == "pq":
+        mk = lambda c: faiss_amd.GpuIndexIVFPQ(res, d, nlist, M, 8, METRIC_L2,  # noqa: E731
+                                               config=faiss_amd.GpuIndexIVFPQConfig(flat_useFloat16=True) if c else None)
+    else:
+        mk = lambda c: faiss_amd.GpuIndexIVFScalarQuantizer(res, d, nlist, faiss_amd.ScalarQuantizer.QT_8bit, METRIC_L2, True,  # noqa: E731
+                                                            config=c)
+    h = mk(cfg)
+    assert h.quantizer_info()[1] is True
+    h.copy_centroids(cent)
+    f16 = faiss_amd.GpuIndexFlat(res, d, METRIC_L2, config=faiss_amd.GpuIndexFlatConfig(useFloat16=True))
+    f16.add(cent)
+    rounded = f16.reconstruct_n(0, nlist)
+    assert np.array_equal(rounded, cent.astype(np.float16).astype(np.float32)) and not np.array_equal(rounded, cent)
+    assert np.array_equal(h.get_centroids(), rounded)
+    r = mk(None)
+    r.copy_centroids(rounded)
+    if kind == "pq":
+        h.train(xt)
+        r.copy_pq_centroids(h.get_pq_centroids())
+    elif kind == "sq":
+        h.train(xt)
+        r.copy_trained(h.get_trained())
+    h.add(xb)
+    _, a1 = f16.search(xb, 1)
+    r.add_core(xb, a1[:, 0])
+    for l in range(nlist):
+        assert np.array_equal(h.get_list_ids(l), r.get_list_ids(l)) and np.array_equal(h.get_list_codes(l), r.get_list_codes(l))
+    h.nprobe = r.nprobe = nprobe
+    Dc, Ic = f16.search(xq, nprobe)
+    for nq in (500, 11):
+        D, I = h.search(xq[:nq], k)
+        Dr, Ir = r.search_preassigned(xq[:nq], k, Ic[:nq], Dc[:nq])
+        assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_indices_options(res, kind):
+    """faiss/gpu/GpuIndicesOptions.h: INDICES_CPU returns the user ids (as INDICES_64_BIT does); INDICES_IVF keeps no ids at all and
+    labels a result (inverted list << 32 | offset in the list) -- impl/IVFUtilsSelect2.cu:148."""
+    d, nlist, M, k = 32, 16, 8, 15
+    xt, xb, xq, cent = _trained_pair(res, d, nlist, 29)
+    ids = np.arange(len(xb), dtype=np.int64) * 3 + 7
+
+    def mk(opt):
+        c = faiss_amd.GpuIndexIVFConfig(indicesOptions=opt)
+        idx = (faiss_amd.GpuIndexIVFFlat(res, d, nlist, METRIC_L2, config=c) if kind == 0 else
+               faiss_amd.GpuIndexIVFPQ(res, d, nlist, M, 8, METRIC_L2, config=faiss_amd.GpuIndexIVFPQConfig(indicesOptions=opt)))
+        idx.copy_centroids(cent)
+        if kind == 1:
+            idx.copy_pq_centroids(pq)
+        idx.add_with_ids(xb[:20000], ids[:20000])
+        idx.add_with_ids(xb[20000:], ids[20000:])  # (a second add: offsets continue, relocated lists keep theirs)
+        idx.nprobe = 5
+        return idx
+
+    pq = None
+    if kind == 1:
+        t = faiss_amd.GpuIndexIVFPQ(res, d, nlist, M, 8, METRIC_L2)
+        t.train(xt)
+        pq, cent = t.get_pq_centroids(), t.get_centroids()
+    base = mk(faiss_amd.INDICES_64_BIT)
+    D0, I0 = base.search(xq, k)
+    for opt in (faiss_amd.INDICES_CPU, faiss_amd.INDICES_32_BIT):
+        D, I = mk(opt).search(xq, k)
+        assert np.array_equal(D, D0) and np.array_equal(I, I0)
+    ivf = mk(faiss_amd.INDICES_IVF)
+    assert ivf.quantizer_info()[2] == faiss_amd.INDICES_IVF
+    D, I = ivf.search(xq, k)
+    assert np.array_equal(D, D0)
+    lists = [base.get_list_ids(l) for l in range(nlist)]
+    ok = I0 >= 0
+    assert np.array_equal(I >= 0, ok)
+    back = np.array([lists[int(v) >> 32][int(v) & 0xffffffff] for v in I[ok]])
+    # (equal distances: the order of tied results follows the label, which differs between the two id schemes: compare as sets per query)
+    assert np.array_equal(np.sort(back), np.sort(I0[ok])) and (back == I0[ok]).mean() > 0.99
+
+
+def test_memory_info_follows_the_indexes(res):
+    """StandardGpuResources::getMemoryInfo (faiss/gpu/StandardGpuResources.cpp:676): the library's own device allocations"""
+    import gc
+    gc.collect()
+    m0 = res.getMemoryInfo()
+    d, nb = 64, 200000
+    _, xb, _ = synthetic_dataset(d, 0, nb, 1, seed=3)
+    idx = faiss_amd.GpuIndexFlatL2(res, d)
+    idx.add(xb)
+    m1 = res.getMemoryInfo()
+    assert m1["bytes"] - m0["bytes"] >= nb * d * 4 and m1["allocations"] > m0["allocations"]
+    assert m1["peak_bytes"] >= m1["bytes"] and m1["device_total"] > 200e9 and m1["temp_memory"] >= (64 << 20)
+    assert m1["device_free"] < m1["device_total"]
+    del idx
+    gc.collect()
+    m2 = res.getMemoryInfo()
+    assert m2["bytes"] <= m0["bytes"] + (1 << 20)
