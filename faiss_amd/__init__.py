@@ -66,6 +66,7 @@ def load_library():
         "faiss_amd_GpuIndexIVFPQ_new_with_quantizer": (i32, [P(vp), vp, vp, i32, i32, i32, i32, i32, vp]),
         "faiss_amd_GpuIndexIVFScalarQuantizer_new_with_quantizer": (i32, [P(vp), vp, vp, i32, i32, i32, i32, i32, vp]),
         "faiss_amd_GpuIndexIVF_quantizer_info": (i32, [vp, P(i32), P(i32), P(i32)]),
+        "faiss_amd_sq_train_rangestat": (i32, [i32, i32, ctypes.c_float, i64, i32, vp, vp]),
         "faiss_amd_GpuIndexFlat_new": (i32, [P(vp), vp, i32, i32]),
         "faiss_amd_GpuIndexIVFFlat_new": (i32, [P(vp), vp, i32, i32, i32]),
         "faiss_amd_GpuIndexIVFPQ_new": (i32, [P(vp), vp, i32, i32, i32, i32, i32]),
@@ -999,6 +1000,16 @@ class IndexReplicas(Index):
 def add_preassigned(index_ivf, x, a, ids=None):
     """faiss.contrib.ivf_tools.add_preassigned (contrib/ivf_tools.py:12-24)"""
     index_ivf.add_core(x, a, ids)
+
+
+def sq_train_rangestat(qtype, rangestat, rangestat_arg, x):
+    """test hook: `trained` of faiss.ScalarQuantizer(d, qtype) trained on x with RS_meanstd / RS_quantiles / RS_optim (host code)"""
+    x = _f32(x)
+    uniform = qtype in (ScalarQuantizer.QT_8bit_uniform, ScalarQuantizer.QT_4bit_uniform)
+    out = np.empty(2 if uniform else 2 * x.shape[1], dtype=np.float32)
+    _check(load_library().faiss_amd_sq_train_rangestat(int(qtype), int(rangestat), float(rangestat_arg), x.shape[0], x.shape[1],
+                                                       _ptr(x), _ptr(out)))
+    return out
 
 
 def kmeans(res, x, k, niter=25, seed=1234):

@@ -356,6 +356,16 @@ int faiss_amd_IndexIVFSQ_set_rangestat(FaissAmdIndex* index, int rangestat, floa
     sq->rangestat_arg = rangestat_arg;
     FA_CATCH
 }
+int faiss_amd_sq_train_rangestat(int qtype, int rangestat, float rangestat_arg, int64_t n, int d, const float* rows, float* trained_out) {
+    FA_TRY
+    FA_THROW_IF_NOT_MSG(qtype == 0 || qtype == 1 || qtype == 2 || qtype == 3 || qtype == 6, "a quantizer type with a trained range");
+    const bool uniform = qtype == 2 || qtype == 3;
+    const int bits = (qtype == 1 || qtype == 3) ? 4 : qtype == 6 ? 6 : 8;
+    std::vector<float> t;
+    sq_train_rangestat_host(rangestat, rangestat_arg, n, d, 1 << bits, uniform, rows, t);
+    memcpy(trained_out, t.data(), t.size() * 4);
+    FA_CATCH
+}
 int faiss_amd_GpuIndexFlat_resident_bytes(const FaissAmdIndex* index, size_t* p_bytes) {
     FA_TRY
     *p_bytes = as<GpuIndexFlat>(index, "GpuIndexFlat")->resident_bytes();

@@ -40,6 +40,11 @@ int faiss_amd_GpuIndexIVFPQ_set_lmf_two_copies(FaissAmdIndex* index, int on);
 int faiss_amd_GpuIndexIVF_test_filter_dump(const FaissAmdIndex* index, int64_t n, const float* x, int nprobe, int64_t k, int64_t stride,
                                            uint64_t* keys_out, float* band_out);
 
+/* Test hook of the scalar quantizer's host-side range statistics (RS_meanstd 1 / RS_quantiles 2 / RS_optim 3,
+ * faiss/impl/scalar_quantizer/training.cpp:235-332): `trained` of faiss::ScalarQuantizer(d, qtype)::train(n, rows) -- 2 floats for
+ * the uniform types, 2 d otherwise.  Pure host code: callable without a GPU (tests/test_oracle_cpu.py pins it on the reference). */
+int faiss_amd_sq_train_rangestat(int qtype, int rangestat, float rangestat_arg, int64_t n, int d, const float* rows, float* trained_out);
+
 #ifdef __cplusplus
 }
 #endif

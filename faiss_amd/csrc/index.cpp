@@ -3295,12 +3295,117 @@ void GpuIndexIVFScalarQuantizer::set_trained(const float* t, size_t n) {
     upload_tables_();
     update_is_trained_();
 }
+// ---- ScalarQuantizer range statistics other than RS_minmax (faiss/impl/scalar_quantizer/training.cpp:209-332 train_Uniform,
+// :334-385 train_NonUniform).  The reference's GPU class trains its ScalarQuantizer on the HOST (gpu/GpuIndexIVFScalarQuantizer.cu:
+// 96-160: sq.train_residual), and these statistics are sequential float recurrences over <= 100 000 training rows (RS_optim: up to
+// 2000 passes of a least-squares fit, every pass a running float sum) -- so this is a host restatement too, column-parallel, of the
+// very operation order of the reference as GCC compiles it (-O3 -mfma contracts a * b + c into one fused multiply-add; this file
+// is built with -ffp-contract=off, so every fmaf below is one the reference build has): `trained` comes out byte-identical
+// (tests/test_oracle_cpu.py::test_sq_rangestat_training_is_byte_identical_to_the_reference, no GPU needed).
+// x: n values (stride 1).  k = 2^bits levels.  Returns {vmin, vdiff}.
+static void sq_train_uniform_host(int rs, float rs_arg, int64_t n, int k, const float* x, float* out) {
+    float vmin, vmax;
+    if (rs == 1) { // RS_meanstd
+        double sum = 0, sum2 = 0;
+        for (int64_t i = 0; i < n; i++) {
+            sum += x[i];
+            sum2 += x[i] * x[i];
+        }
+        const float mean = (float)(sum / n);
+        const float var = (float)(sum2 / n - (double)(mean * mean));
+        const float sd = var <= 0 ? 1.0f : std::sqrt(var);
+        const float w = sd * rs_arg; // (used twice: the reference build keeps the product, no fused multiply-add here)
+        vmin = mean - w;
+        vmax = mean + w;
+    } else if (rs == 2) { // RS_quantiles
+        std::vector<float> c(x, x + n);
+        int64_t o = (int64_t)(rs_arg * n);
+        if (o < 0) o = 0;
+        if (o > n - o) o = n / 2;
+        std::nth_element(c.begin(), c.begin() + o, c.end());
+        vmin = c[o];
+        std::nth_element(c.begin(), c.begin() + (n - 1 - o), c.end());
+        vmax = c[n - 1 - o];
+    } else { // RS_optim: alternating least squares of x ~ a * round((x - b) / a) + b
+        float a, b, sx = 0;
+        vmin = HUGE_VALF, vmax = -HUGE_VALF;
+        for (int64_t i = 0; i < n; i++) {
+            if (x[i] < vmin) vmin = x[i];
+            if (x[i] > vmax) vmax = x[i];
+            sx += x[i];
+        }
+        b = vmin;
+        a = (vmax - vmin) / (float)(k - 1);
+        float last_err = -1;
+        int iter_last_err = 0;
+        const float nf = (float)n, kf = (float)k;
+        for (int it = 0; it < 2000; it++) {
+            float sn = 0, sn2 = 0, sxn = 0, err1 = 0;
+            for (int64_t i = 0; i < n; i++) {
+                const float xi = x[i];
+                float ni = (float)std::floor((double)((xi - b) / a) + 0.5);
+                if (ni < 0) ni = 0;
+                if (ni >= kf) ni = (float)(k - 1);
+                const float u = xi - fmaf(ni, a, b);
+                err1 = fmaf(u, u, err1);
+                sn += ni;
+                sn2 = fmaf(ni, ni, sn2);
+                sxn = fmaf(ni, xi, sxn);
+            }
+            if (err1 == last_err) {
+                if (++iter_last_err == 16) break;
+            } else {
+                last_err = err1;
+                iter_last_err = 0;
+            }
+            const float det = fmaf(sn, sn, -(sn2 * nf));
+            const float nb = fmaf(sn, sxn, -(sn2 * sx)) / det;
+            const float na = fmaf(sn, sx, -(nf * sxn)) / det;
+            b = nb;
+            a = na;
+        }
+        vmin = b;
+        vmax = fmaf(a, (float)(k - 1), b);
+    }
+    out[0] = vmin;
+    out[1] = vmax - vmin;
+}
+// rows: [n][d] dense.  uniform: one range over all n * d values; else one per dimension -- over the column as the reference
+// builds it, i.e. with ROW 0 LEFT AT ZERO (training.cpp:366 transposes from i = 1; kept, because `trained` has to match).
+void sq_train_rangestat_host(int rangestat, float rangestat_arg, int64_t n, int d, int k, bool uniform, const float* rows,
+                             std::vector<float>& trained) {
+    FA_THROW_IF_NOT_MSG(rangestat >= 1 && rangestat <= 3, "invalid range statistic");
+    FA_THROW_IF_NOT(n > 0 && rows);
+    if (uniform) {
+        trained.assign(2, 0.f);
+        sq_train_uniform_host(rangestat, rangestat_arg, n * d, k, rows, trained.data());
+        return;
+    }
+    trained.assign((size_t)2 * d, 0.f);
+    const int nthr = (int)std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), (unsigned)d));
+    std::vector<std::thread> pool;
+    std::atomic<int> next{0};
+    for (int t = 0; t < nthr; t++)
+        pool.emplace_back([&]() {
+            std::vector<float> col((size_t)n);
+            float o[2];
+            for (int j = next.fetch_add(1); j < d; j = next.fetch_add(1)) {
+                col[0] = 0.f;
+                for (int64_t i = 1; i < n; i++) col[i] = rows[(size_t)i * d + j];
+                sq_train_uniform_host(rangestat, rangestat_arg, n, k, col.data(), o);
+                trained[j] = o[0];
+                trained[(size_t)d + j] = o[1];
+            }
+        });
+    for (auto& th : pool) th.join();
+}
+
 void GpuIndexIVFScalarQuantizer::train_residual_(idx_t n, const float* x_dev_pad) {
     // IndexIVF::train_encoder on at most 100000 vectors (IndexScalarQuantizer.cpp:152-161), residuals when
     // by_residual (IndexIVF.cpp train_encoder path), then ScalarQuantizer::train = per-dimension (or global) range
     // (impl/scalar_quantizer/training.cpp:209-232, 333-365)
     if (!needs_training_()) return;
-    FA_THROW_IF_NOT_MSG(rangestat == 0, "only RS_minmax ranges are trained on the device; train the CPU index and copy it");
+    FA_THROW_IF_NOT_MSG(rangestat >= 0 && rangestat <= 3, "invalid ScalarQuantizer::RangeStat");
     const GpuResources& R = *res_;
     idx_t nt = std::min<idx_t>(n, 100000);
     DevBuf dsel, dsub_rows, dlab, ddis, dres, dmm;
@@ -3330,6 +3435,18 @@ void GpuIndexIVFScalarQuantizer::train_residual_(idx_t n, const float* x_dev_pad
         xs = dres.as<float>();
         ldr = d;
     }
+    const bool uniform = qtype == QT_8bit_uniform || qtype == QT_4bit_uniform;
+    if (rangestat != 0) {
+        // RS_meanstd / RS_quantiles / RS_optim: the (residual) training rows come back to the host (sq_train_rangestat_host above)
+        std::vector<float> rows((size_t)nt * d);
+        HIP_CHECK(hipMemcpy2DAsync(rows.data(), (size_t)d * 4, xs, (size_t)ldr * 4, (size_t)d * 4, (size_t)nt, hipMemcpyDeviceToHost,
+                                   R.stream));
+        R.sync();
+        const int bits = (qtype == QT_4bit || qtype == QT_4bit_uniform) ? 4 : qtype == QT_6bit ? 6 : 8;
+        sq_train_rangestat_host(rangestat, rangestat_arg, nt, d, 1 << bits, uniform, rows.data(), trained);
+        upload_tables_();
+        return;
+    }
     const int nb = ivfsq_minmax_blocks(nt);
     dmm.ensure((size_t)nb * 2 * d * 4);
     launch_ivfsq_minmax(xs, ldr, nt, d, dmm.as<float>(), R.stream);
@@ -3342,7 +3459,6 @@ void GpuIndexIVFScalarQuantizer::train_residual_(idx_t n, const float* x_dev_pad
             lo[j] = std::min(lo[j], mm[((size_t)b * 2 + 0) * d + j]);
             hi[j] = std::max(hi[j], mm[((size_t)b * 2 + 1) * d + j]);
         }
-    const bool uniform = qtype == QT_8bit_uniform || qtype == QT_4bit_uniform;
     if (uniform) {
         float vmin = INFINITY, vmax = -INFINITY;
         for (int j = 0; j < d; j++) {

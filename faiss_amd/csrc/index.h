@@ -789,6 +789,9 @@ void merge_knn_results(int metric, idx_t nq, idx_t k, int nshard, const float* a
 // Brute-force k-nearest-neighbour on raw row-major fp32 arrays, host or device (the float32 / row-major subset
 // of faiss::gpu::bfKnn, faiss/gpu/GpuDistance.h:32-152 and GpuDistance.cu:bfKnn).  Same kernels, same tie rule and
 // the same bits as GpuIndexFlat::search on an index holding `vectors`.
+// ScalarQuantizer::train with RS_meanstd (1) / RS_quantiles (2) / RS_optim (3) on the host (index.cpp): rows [n][d] dense, k = 2^bits
+void sq_train_rangestat_host(int rangestat, float rangestat_arg, int64_t n, int d, int k, bool uniform, const float* rows,
+                             std::vector<float>& trained);
 void bfKnn(std::shared_ptr<GpuResources> res, int metric, const float* vectors, idx_t num_vectors, const float* queries,
            idx_t num_queries, int dims, idx_t k, float* out_distances, idx_t* out_indices);
 

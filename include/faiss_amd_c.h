@@ -104,8 +104,10 @@ int faiss_amd_IndexIVFSQ_info(const FaissAmdIndex* index, int* qtype, int* by_re
  * otherwise -- the array copyFrom / copyTo move (gpu/GpuIndexIVFScalarQuantizer.cu copyFrom: sq = index->sq) */
 int faiss_amd_IndexIVFSQ_get_trained(const FaissAmdIndex* index, float* out);
 int faiss_amd_IndexIVFSQ_copy_trained(FaissAmdIndex* index, const float* trained, size_t n);
-/* index->sq.rangestat / rangestat_arg (ScalarQuantizer.h:60-70) used by train(); only RS_minmax (0) trains on the
- * device -- other statistics: train the CPU index and copy `trained` */
+/* index->sq.rangestat / rangestat_arg (ScalarQuantizer.h:60-70) used by train(): RS_minmax (0) is a device reduction; RS_meanstd (1),
+ * RS_quantiles (2), RS_optim (3) run on the host over the <= 100 000 (residual) training rows -- the reference GPU class trains its
+ * ScalarQuantizer on the host for every statistic (gpu/GpuIndexIVFScalarQuantizer.cu:96-160) -- and give the reference's `trained`
+ * byte for byte (training.cpp:209-385 restated in its operation order) */
 int faiss_amd_IndexIVFSQ_set_rangestat(FaissAmdIndex* index, int rangestat, float rangestat_arg);
 /* ---- the same constructors with the reference's config structs (faiss/gpu/GpuIndex.h:30-47 GpuIndexConfig,
  *      GpuIndexFlat.h:24-40 GpuIndexFlatConfig, GpuIndexIVF.h:24-38 GpuIndexIVFConfig, GpuIndexIVFPQ.h:25-49

@@ -554,6 +554,18 @@ class Ref:
         return cls._wrap_ptr(cls.lib().ref_amd_index_gpu_to_cpu(ctypes.c_void_p(gpu_index.h)), gpu_index.d, [gpu_index])
 
     @classmethod
+    def sq_train(cls, qtype, rangestat, rangestat_arg, x):
+        """faiss::ScalarQuantizer(d, qtype).train(x) with the given RangeStat: the `trained` vector"""
+        x = _f32(x)
+        out = np.empty(2 * x.shape[1], dtype=np.float32)
+        n = ctypes.c_size_t(0)
+        rc = cls.lib().ref_sq_train(ctypes.c_int(x.shape[1]), ctypes.c_int(qtype), ctypes.c_int(rangestat), ctypes.c_float(rangestat_arg),
+                                    ctypes.c_int64(x.shape[0]), _p(x), _p(out), ctypes.byref(n))
+        if rc != 0:
+            raise RuntimeError("reference error: " + cls.lib().ref_last_error().decode())
+        return out[:n.value].copy()
+
+    @classmethod
     def amd_flat(cls, res, d, metric=METRIC_L2):
         """a flat index of the backend as a faiss::Index of the bridge (AmdIndexFlat)"""
         cls.lib().ref_amd_flat_new.restype = ctypes.c_void_p

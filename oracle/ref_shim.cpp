@@ -248,6 +248,16 @@ int ref_ivfsq_set_trained(void* p, const float* centroids, const float* trained,
     SHIM_CATCH
 }
 // ScalarQuantizer::decode of n codes (the stored values, without the list centroid)
+// faiss::ScalarQuantizer(d, qtype) with the given range statistic trained on x [n][d]: its `trained` vector
+int ref_sq_train(int d, int qtype, int rangestat, float rangestat_arg, idx_t n, const float* x, float* trained_out, size_t* n_out) {
+    SHIM_TRY faiss::ScalarQuantizer sq(d, (faiss::ScalarQuantizer::QuantizerType)qtype);
+    sq.rangestat = (faiss::ScalarQuantizer::RangeStat)rangestat;
+    sq.rangestat_arg = rangestat_arg;
+    sq.train(n, x);
+    memcpy(trained_out, sq.trained.data(), sizeof(float) * sq.trained.size());
+    *n_out = sq.trained.size();
+    SHIM_CATCH
+}
 int ref_ivfsq_decode(void* p, idx_t n, const uint8_t* codes, float* out) {
     SHIM_TRY auto* i = dynamic_cast<faiss::IndexIVFScalarQuantizer*>((faiss::Index*)p);
     FAISS_THROW_IF_NOT_MSG(i, "not an IndexIVFScalarQuantizer");

@@ -194,3 +194,41 @@ def test_memory_info_follows_the_indexes(res):
     gc.collect()
     m2 = res.getMemoryInfo()
     assert m2["bytes"] <= m0["bytes"] + (1 << 20)
+
+
+@pytest.mark.parametrize("rangestat,arg", [(1, 2.5), (2, 0.02), (3, 0.0)])
+@pytest.mark.parametrize("by_residual", [False, True])
+def test_ivfsq_trains_every_range_statistic(res, rangestat, arg, by_residual):
+    """GpuIndexIVFScalarQuantizer.train with RS_meanstd / RS_quantiles / RS_optim: `trained` is what
+    faiss::ScalarQuantizer::train gives on the (residual) training vectors -- the host restatement is pinned byte for byte on the
+    compiled reference by tests/test_oracle_cpu.py; here the index must feed it the right rows and encode / search with the result."""
+    from faiss_amd import ScalarQuantizer as SQ
+    d, nlist = 32, 16
+    xt, xb, xq = synthetic_dataset(d, 5000, 20000, 200, seed=61)
+    for qtype in (SQ.QT_8bit, SQ.QT_4bit_uniform, SQ.QT_6bit):
+        idx = faiss_amd.GpuIndexIVFScalarQuantizer(res, d, nlist, qtype, METRIC_L2, by_residual)
+        idx.set_rangestat(rangestat, arg)
+        idx.train(xt)
+        rows = xt
+        if by_residual:
+            cent = idx.get_centroids()
+            _, lab = idx.quantizer_search(xt, 1)
+            rows = (xt - cent[lab[:, 0]]).astype(np.float32)
+        want = faiss_amd.sq_train_rangestat(qtype, rangestat, arg, rows)
+        assert np.array_equal(idx.get_trained().view(np.uint32), want.view(np.uint32))
+        idx.add(xb)
+        idx.nprobe = 4
+        D, I = idx.search(xq, 10)
+        assert (I[:, 0] >= 0).all() and np.isfinite(D[:, 0]).all()
+        # the codes are ScalarQuantizer::compute_codes with that range (oracle restatement, pinned on the reference elsewhere)
+        from oracle.pyoracle import Oracle
+        vmin, vdiff = Oracle.sq_unpack(qtype, d, idx.get_trained())
+        cent = idx.get_centroids()
+        lab = Oracle.ivf_assign(METRIC_L2, cent, xb)
+        codes = Oracle.sq_encode(qtype, xb, vmin, vdiff, lab if by_residual else None, cent if by_residual else None)
+        got = np.empty_like(codes)
+        for l in range(nlist):
+            ids = idx.get_list_ids(l)
+            if len(ids):
+                got[ids] = idx.get_list_codes(l)
+        assert np.array_equal(got, codes)
