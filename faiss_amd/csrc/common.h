@@ -129,6 +129,15 @@ static inline size_t div_up(size_t x, size_t m) {
 // through the LDS crossbar (~100 cycles each, serialised by lgkmcnt(0)): the candidate parking of the list-major sweeps
 // runs one scan per (32-row block, 32-query block) that holds a candidate -- nearly all of them at nb <= 10M.
 // tools/dpp_scan_probe.hip checks it against the shuffle ladder on the device.
+// A `volatile` access through a plain (generic) pointer to LDS stays a FLAT instruction -- hipcc's address-space inference does not
+// rewrite volatile accesses -- i.e. it goes through the vector-memory path with an aperture check, is waited for with vmcnt(0)
+// (which also drains every LDS-DMA / global load in flight) and, for stores and atomics, is not covered by the lgkmcnt(0) in
+// front of an s_barrier (wg_select.h).  Volatile LDS accesses therefore go through a pointer typed to the LDS
+// address space: a ds_read / ds_write that the compiler still may not cache or drop.
+typedef volatile __attribute__((address_space(3))) unsigned lds_volatile_u32;
+__device__ __forceinline__ lds_volatile_u32* lds_volatile(const void* p) {
+    return (lds_volatile_u32*)(__attribute__((address_space(3))) void*)p;
+}
 __device__ __forceinline__ unsigned wave_incl_scan(unsigned v) {
     int x = (int)v;
     x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true); // row_shr:1

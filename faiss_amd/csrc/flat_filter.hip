@@ -637,7 +637,7 @@ __global__ void __launch_bounds__(FqGeom<QB>::THREADS, 2) flat_filter_kernel(Fla
         wcnt = 0;
     };
     constexpr int WFLUSH = WBLK / 2;
-    volatile unsigned* lgen = (volatile unsigned*)(smem + G::LDS_GEN);
+    lds_volatile_u32* lgen = lds_volatile(smem + G::LDS_GEN); // (typed to LDS: a generic volatile store is a FLAT store + vmcnt(0), common.h)
 
     int gslot = 0; // (u / TPB) % 3
     int u = 0;

@@ -49,7 +49,7 @@ __device__ inline u64 wave_select_kth(const u64* __restrict__ keys, int n, int k
         wave_mem_sync();
         uint4 c;
         {
-            volatile unsigned* hv = hist + 4 * lane;
+            lds_volatile_u32* hv = lds_volatile(hist + 4 * lane); // (typed to LDS: a generic volatile read is a FLAT load, common.h)
             c.x = hv[0]; c.y = hv[1]; c.z = hv[2]; c.w = hv[3];
         }
         unsigned s = c.x + c.y + c.z + c.w;

@@ -25,28 +25,44 @@ __device__ __forceinline__ int wgs_lane() {
 
 // k-th smallest (1-based) of n unique keys in LDS, n > k >= 1.  Every thread of the workgroup
 // calls it (uniform control flow, BLOCK threads); hist = 256 LDS words.
+// Round 5 / 6 finding (DESIGN.md 6b "the wg_select_kth fault"): as a plain `__device__` template this function was NOT inlined --
+// hipcc emitted one out-of-line copy per BLOCK and 112 `s_swappc_b64` call sites -- and an out-of-line function sees `keys`, `hist`
+// and `ctl` as GENERIC pointers: every access to the LDS histogram became a FLAT instruction (flat_store / flat_atomic_add /
+// flat_load through the aperture check) guarded before each s_barrier by `s_waitcnt lgkmcnt(0)` only.  On gfx950 that is not
+// enough for a no-return flat_atomic_add that lands in LDS: under the right timing the wavefront that scans the 256 bins reads
+// them before every increment has been performed, picks a later bucket, returns a key ABOVE the k-th smallest, and the
+// compaction keeps more than k keys -- a partial result of n > k keys then overruns its slot of part_keys and the merge launch
+// faults (tools/wgs_fault_repro.sh reproduces it: 100 % with the out-of-line build whose zeroing is written as a loop, 0 % with an
+// extra `s_waitcnt vmcnt(0)` in front of the barriers, 0 % inlined).  Inlined, the pointers keep their LDS address space and the
+// accesses are DS instructions, which lgkmcnt does cover.  tests/test_isa_lint_cpu.py asserts that no kernel file contains a
+// call or a FLAT access at all where LDS is meant.
+#ifdef FAISS_AMD_WGS_OUTOFLINE_REPRO
+#define FA_WGS_INLINE __attribute__((noinline))
+#else
+#define FA_WGS_INLINE __forceinline__
+#endif
+#ifdef FAISS_AMD_WGS_VMCNT_REPRO
+#define FA_WGS_SYNC()                                        \
+    do {                                                     \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     \
+        __syncthreads();                                     \
+    } while (0)
+#else
+#define FA_WGS_SYNC() __syncthreads()
+#endif
 template <int BLOCK>
-__device__ u64 wg_select_kth(const u64* keys, int n, int k, unsigned* hist, WgSelCtl* ctl) {
+__device__ FA_WGS_INLINE u64 wg_select_kth(const u64* keys, int n, int k, unsigned* hist, WgSelCtl* ctl) {
     const int tid = threadIdx.x;
     u64 prefix = 0, mask = 0;
     int need = k;
     for (int shift = 56; shift >= 0; shift -= 8) {
-#ifdef FAISS_AMD_WGS_LOOP_REPRO
-        // (round 5's faulting variant, kept buildable for tools/wgs_fault_repro.sh: `make variant-wgsloop`)
-        for (int i = tid; i < 256; i += BLOCK) hist[i] = 0;
-#else
-        if (BLOCK >= 256) {
-            if (tid < 256) hist[tid] = 0;
-        } else {
-            for (int i = tid; i < 256; i += BLOCK) hist[i] = 0;
-        }
-#endif
-        __syncthreads();
+        for (int i = tid; i < 256; i += BLOCK) hist[i] = 0; // (the form that faulted out of line in round 5: see above)
+        FA_WGS_SYNC();
         for (int i = tid; i < n; i += BLOCK) {
             const u64 key = keys[i];
             if ((key & mask) == prefix) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
         }
-        __syncthreads();
+        FA_WGS_SYNC();
         if (tid < 64) {
             // one wavefront scans the 256 bins: lane l owns bins 4l..4l+3
             const int lane = tid;
@@ -73,7 +89,7 @@ __device__ u64 wg_select_kth(const u64* keys, int n, int k, unsigned* hist, WgSe
                 ctl->kth = 0;
             }
         }
-        __syncthreads();
+        FA_WGS_SYNC();
         prefix |= (u64)ctl->digit << shift;
         mask |= (u64)255u << shift;
         need = (int)ctl->rem;
@@ -90,12 +106,12 @@ __device__ u64 wg_select_kth(const u64* keys, int n, int k, unsigned* hist, WgSe
                 best = o > best ? o : best;
             }
             if ((tid & 63) == 0 && best) atomicMax(&ctl->kth, best);
-            __syncthreads();
+            FA_WGS_SYNC();
             const u64 r = ctl->kth;
-            __syncthreads(); // ctl is rewritten by the next call
+            FA_WGS_SYNC(); // ctl is rewritten by the next call
             return r;
         }
-        __syncthreads(); // hist / ctl are rewritten by the next pass
+        FA_WGS_SYNC(); // hist / ctl are rewritten by the next pass
     }
     return prefix;
 }

@@ -945,7 +945,11 @@ def test_config_structs_on_the_constructors(res):
     with pytest.raises(faiss_amd.FaissAmdError):
         faiss_amd.GpuIndexFlat(res, d, METRIC_L2, faiss_amd.GpuIndexFlatConfig(memorySpace=1))
     faiss_amd.GpuIndexIVFFlat(res, d, 8, METRIC_L2, faiss_amd.GpuIndexIVFConfig(indicesOptions=2))  # INDICES_32_BIT
-    for bad in (dict(indicesOptions=0), dict(indicesOptions=1), dict(flat_useFloat16=True)):
+    # round 6: INDICES_CPU / INDICES_IVF and an fp16 coarse quantizer are served (tests/test_gpu_round6.py); what is left to refuse
+    # is a value outside the enum and Unified memory
+    for ok in (dict(indicesOptions=0), dict(indicesOptions=1), dict(flat_useFloat16=True)):
+        faiss_amd.GpuIndexIVFFlat(res, d, 8, METRIC_L2, faiss_amd.GpuIndexIVFConfig(**ok))
+    for bad in (dict(indicesOptions=4), dict(indicesOptions=-1), dict(memorySpace=1)):
         with pytest.raises(faiss_amd.FaissAmdError):
             faiss_amd.GpuIndexIVFFlat(res, d, 8, METRIC_L2, faiss_amd.GpuIndexIVFConfig(**bad))
     xt, xb, xq = synthetic_dataset(d, 2000, 3000, 20, seed=3)

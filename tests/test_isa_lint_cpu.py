@@ -57,3 +57,41 @@ def test_the_lint_catches_round_5s_hazard_when_the_guard_is_removed(kernel_build
     # accumulators through a compiler-visible v_pk_fma first
     assert all(re.search(r"kernelILi0E", k) for k in bad), [k[:60] for k in bad if not re.search(r"kernelILi0E", k)][:5]
     assert any(f[4] and "v_max3_f32" in f[5] for fs in bad.values() for f in fs)
+
+
+def _calls_and_lds_casts(asm_path):
+    calls = casts = 0
+    with open(asm_path) as f:
+        for line in f:
+            s = line.split(";")[0]
+            calls += "s_swappc_b64" in s
+            casts += "src_shared_base" in s
+    return calls, casts
+
+
+def test_lds_is_never_reached_through_flat_instructions(kernel_builds):
+    """Root cause of round 5's "equivalent code faults" (wg_select.h): hipcc kept wg_select_kth OUT OF LINE; an
+    out-of-line function sees its LDS arguments as generic pointers, so the histogram of the radix select was zeroed, incremented
+    and read with FLAT instructions, and a no-return flat_atomic_add that lands in LDS is not complete when the `s_waitcnt
+    lgkmcnt(0)` in front of the barrier lets the wave through -- the scan then misses increments, the k-th key comes out too large,
+    more than k keys survive and overrun the partial-result slot.  The same lowering happens to `volatile` accesses through a generic
+    pointer.  Both leave fingerprints in the ISA: a call (`s_swappc_b64`) and an LDS -> generic pointer cast (`src_shared_base`).
+    No kernel file may contain either."""
+    for name, (asm, _) in kernel_builds.items():
+        calls, casts = _calls_and_lds_casts(asm)
+        assert calls == 0, "%s: %d out-of-line device function calls (a helper lost its __forceinline__?)" % (name, calls)
+        assert casts == 0, "%s: %d LDS pointers cast to generic (volatile access without lds_volatile(), common.h?)" % (name, casts)
+
+
+def test_the_lint_sees_the_out_of_line_build_that_faulted(tmp_path):
+    """ivf_fused.hip built the way it was when it faulted (wg_select_kth out of line: -DFAISS_AMD_WGS_OUTOFLINE_REPRO, the build
+    tools/wgs_fault_repro.sh runs on the GPU) shows both fingerprints."""
+    import isa_lint
+    if not os.path.exists(isa_lint.HIPCC):
+        pytest.skip("hipcc not available")
+    out = str(tmp_path / "outofline.s")
+    isa_lint.compile_asm(os.path.join(isa_lint.CSRC, "ivf_fused.hip"), out, extra=["-DFAISS_AMD_WGS_OUTOFLINE_REPRO"])
+    calls, casts = _calls_and_lds_casts(out)
+    assert calls >= 50 and casts >= 10, (calls, casts)
+    text = open(out).read()
+    assert "flat_atomic_add" in text and "wg_select_kth" in text
