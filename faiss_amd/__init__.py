@@ -129,6 +129,7 @@ def load_library():
         "faiss_amd_GpuIndexIVF_set_lmf_tuning": (i32, [vp, i32, i32, i32, i32]),
         "faiss_amd_GpuIndexIVF_set_lmf_sampling": (i32, [vp, i32]),
         "faiss_amd_GpuIndexIVFPQ_set_lmf_two_copies": (i32, [vp, i32]),
+        "faiss_amd_GpuIndexIVFPQ_set_lmf_fast_gather": (i32, [vp, i32]),
         "faiss_amd_GpuIndexIVF_list_major_rule": (i32, [vp, i64, i32, i64, P(i32)]),
         "faiss_amd_GpuIndexFlat_set_use_filter_kernel": (i32, [vp, i32, i64]),
         "faiss_amd_GpuIndexFlat_filter_stats": (i32, [vp, P(i32), P(i32)]),
@@ -632,6 +633,9 @@ class _GpuIndexIVF(Index):
     def set_lmf_sampling(self, sample_shift=0):
         """sweep 1 of the filter path on the first rows_per_item >> shift rows of every item (0 rule, -1 all rows)"""
         _check(self._lib.faiss_amd_GpuIndexIVF_set_lmf_sampling(self._h, int(sample_shift)))
+
+    def set_lmf_fast_gather(self, on):
+        _check(self._lib.faiss_amd_GpuIndexIVFPQ_set_lmf_fast_gather(self._h, int(bool(on))))
 
     def set_lmf_two_copies(self, on):
         """IVFPQ, PQ64 over d = 128: two-copy codebook of the filter sweeps on / off (A/B; results never change)"""

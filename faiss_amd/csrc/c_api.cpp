@@ -1037,6 +1037,11 @@ int faiss_amd_GpuIndexIVF_set_lmf_sampling(FaissAmdIndex* index, int sample_shif
     as<GpuIndexIVF>(index, "GpuIndexIVF")->lmf_sample_shift = sample_shift;
     FA_CATCH
 }
+int faiss_amd_GpuIndexIVFPQ_set_lmf_fast_gather(FaissAmdIndex* index, int on) {
+    FA_TRY
+    as<GpuIndexIVFPQ>(index, "GpuIndexIVFPQ")->lmf_fast_gather = on != 0;
+    FA_CATCH
+}
 int faiss_amd_GpuIndexIVFPQ_set_lmf_two_copies(FaissAmdIndex* index, int on) {
     FA_TRY
     as<GpuIndexIVFPQ>(index, "GpuIndexIVFPQ")->set_lmf_two_copies(on != 0);

@@ -3960,6 +3960,7 @@ bool GpuIndexIVFPQ::lmf_prepare_(IvfLmParams& p) const {
         p.cs_bpl = bpl;
         p.cs_piece = piece;
         p.cs_choice = lmf_two_copies_() ? 1 : 0;
+        p.lmf_fast_gather = lmf_fast_gather ? 1 : 0;
     }
     p.filter = 1;
     p.pq_t = pq_t_.as<float>();

@@ -630,6 +630,9 @@ class GpuIndexIVFPQ : public GpuIndexIVF {
     // PQ64 over d = 128: the sweeps' codebook twice in LDS with different code -> bank maps, copy chosen per (row, sub-quantizer)
     // when the copy of the codes is written (ivf_lm_filter.hip lmf_code_choice_kernel).  false: round 4's one-copy sweeps.
     // Changing it drops the copy of the codes (rebuilt by the next list-major search).
+    // PQ64 over d = 128: codebook gathers of the filter sweeps as one VALU instruction + one ds_read_b32 (ivf_lm_filter.hip FG,
+    // round 6); off = the gathers as hipcc compiles them (A/B knob, results never change)
+    bool lmf_fast_gather = true;
     bool lmf_two_copies = false; // measured in round 5 and not adopted: fewer LDS conflicts, more VALU, slower
     void set_lmf_two_copies(bool on) {
         std::lock_guard<std::mutex> g(mu_);

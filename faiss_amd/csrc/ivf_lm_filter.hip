@@ -888,10 +888,23 @@ constexpr int LP_AHEAD = 3;  // k-steps the codebook gathers run ahead of the MF
 // wavefronts' parked candidates (64 each) and staged records (32 each: pairs are staged half by half)
 constexpr int LP_PARK2 = 64, LP_NST2 = 32;
 struct LpLayout {
-    int cb_bytes, off_park, off_stage, total;
+    int cb_bytes, off_park, off_stage, total, off_rn;
 };
-__host__ __device__ static inline LpLayout lp_layout(int d, int M, bool twoc = false) {
+// fastg (round 6, PQ64 over d = 128): the 64 tables of 1 KB in two halves -- sub-quantizers with (m & 4) == 0 at LDS bytes [0, 32 K),
+// the others at [64 K, 96 K) -- so that the table of k-step s, slot u is the IMMEDIATE offset (4 s + u) KB of a ds_read_b32 for both
+// halves of a wavefront (lanes 32 .. 63 carry bit 16 in their address register); parked candidates + row norms sit in the hole
+// [32 K, 64 K), the staged records behind the upper tables
+__host__ __device__ static inline LpLayout lp_layout(int d, int M, bool twoc = false, bool fastg = false) {
     LpLayout L;
+    if (fastg) {
+        L.cb_bytes = 98304;
+        L.off_park = 32768;
+        L.off_rn = 32768 + 8 * LP_PARK * (8 + 4);
+        L.off_stage = 98304;
+        L.total = L.off_stage + 8 * LmfStage<64>::BYTES;
+        return L;
+    }
+    L.off_rn = 0;
     L.cb_bytes = d * 256 * 2 * (twoc ? 2 : 1);
     L.off_park = (L.cb_bytes + 15) & ~15;
     L.off_stage = L.off_park + 8 * (twoc ? LP_PARK2 : LP_PARK) * (8 + 4);
@@ -908,9 +921,41 @@ struct LpCodes {
 // per lane and block): the block loop then holds no conditional code around its loads and LDS reads -- with runtime bounds
 // hipcc closed every k-step with lgkmcnt(0) / vmcnt(0) (the gathers of step s + 2 were waited for before the MFMAs of step
 // s, the code prefetch before the next instruction): 8400 cycles per 24-MFMA block, every unit idle (profiles/r04_g_pmc_*).
-template <int METRIC, int MODE, int NQB, int DS, bool SEL, bool FULLK, bool TWOC>
+// the four codebook gathers of one k-step of the FG sweeps (below): S_ = k-step inside the block, tables 8 S_ + 4 h + u at the
+// immediate offsets (4 S_ + u) KB; c4 = the four code bytes; va0 / va1 = address registers whose high half holds the lane's
+// table half (h << 16; the SDWA shifts rewrite the low half only)
+template <int S_>
+__device__ __forceinline__ void lp_gather(unsigned c4, unsigned (&dst)[4], unsigned& va0, unsigned& va1, unsigned two) {
+    asm volatile(
+            "v_lshlrev_b32_sdwa %4, %7, %6 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_0\n\t"
+            "v_lshlrev_b32_sdwa %5, %7, %6 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_1\n\t"
+            "ds_read_b32 %0, %4 offset:%8\n\t"
+            "ds_read_b32 %1, %5 offset:%9\n\t"
+            "v_lshlrev_b32_sdwa %4, %7, %6 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_2\n\t"
+            "v_lshlrev_b32_sdwa %5, %7, %6 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_3\n\t"
+            "ds_read_b32 %2, %4 offset:%10\n\t"
+            "ds_read_b32 %3, %5 offset:%11"
+            : "=&v"(dst[0]), "=&v"(dst[1]), "=&v"(dst[2]), "=&v"(dst[3]), "+v"(va0), "+v"(va1)
+            : "v"(c4), "v"(two), "n"((4 * S_) * 1024), "n"((4 * S_ + 1) * 1024), "n"((4 * S_ + 2) * 1024), "n"((4 * S_ + 3) * 1024)
+            : "memory");
+}
+// the gathers of a ring slot have landed (at most 12 younger LDS operations outstanding); ties the registers to the wait
+__device__ __forceinline__ half8 lp_landed(unsigned (&dst)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(dst[0]), "+v"(dst[1]), "+v"(dst[2]), "+v"(dst[3])::"memory");
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    return __builtin_bit_cast(half8, u32x4{dst[0], dst[1], dst[2], dst[3]});
+}
+// FG (round 6, "fast gathers"; FULLK, DS == 2, one copy): a codebook gather is ONE VALU instruction + one ds_read_b32 -- v_lshlrev_b32_sdwa
+// moves (code byte u) << 2 into the low half of an address register whose high half holds the lane's table half, the table itself is
+// the read's immediate offset (lp_layout) -- instead of the 2.3 instructions per gather hipcc makes of the C++ (v_bfe / v_and + shifts
+// + v_lshl_add: 75 of the 108 VALU instructions of a 24-MFMA block, profiles/r6_pq_sweep_isa.txt).  The reads are issued from asm
+// statements, so their waits are counted by hand: the operands of k-step s are complete when at most 12 LDS operations (the gathers of
+// the three k-steps issued behind them) are outstanding; LDS returns in order, so operations the compiler issues in between only
+// make that wait conservative, and its own waits (which do not count the asm reads) wait for more than they need, never for less.
+template <int METRIC, int MODE, int NQB, int DS, bool SEL, bool FULLK, bool TWOC, bool FG = false>
 __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p) {
     static_assert(!TWOC || (FULLK && DS == 2), "the two-copy codebook serves PQ64 over d = 128");
+    static_assert(!FG || (FULLK && DS == 2 && !TWOC), "fast gathers: PQ64 over d = 128, one copy");
     constexpr int PARK = TWOC ? LP_PARK2 : LP_PARK, NST = TWOC ? LP_NST2 : 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -922,9 +967,18 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
     const int M = p.M, dsub = p.dsub;
     const int nks = FULLK ? 8 : (p.d >> 4);
     const int gsh = __builtin_ctz((unsigned)p.gran_blocks); // blocks per granule: a power of two
-    const LpLayout LY = lp_layout(p.d, M, TWOC);
+    const LpLayout LY = lp_layout(p.d, M, TWOC, FG);
     const _Float16* cb = (const _Float16*)smem;
-    if (TWOC) {
+    if (FG) {
+        // (the immediate offsets are absolute LDS addresses: the dynamic segment must start at 0, i.e. no static __shared__ here)
+        if ((unsigned)(size_t)(const __attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();
+        const uint4* src = (const uint4*)p.pq16;
+        for (int i = tid; i < 64 * 64; i += LP_THREADS) { // 64 tables of 64 x 16 bytes
+            const int m = i >> 6;
+            const int tb = ((m & 4) ? 65536 : 0) + (((m >> 3) << 2) + (m & 3)) * 1024;
+            *(uint4*)(smem + tb + (i & 63) * 16) = src[i];
+        }
+    } else if (TWOC) {
         // [m][copy][256] entries of two halfs: copy 0 holds entry c at slot c, copy 1 at slot rotr8(c, 3)
         const uint32_t* src = (const uint32_t*)p.pq16;
         uint32_t* dst = (uint32_t*)smem;
@@ -950,8 +1004,13 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
     asm volatile("" : "+v"(cb_hi));
     u64* pk_keys = (u64*)(smem + LY.off_park) + wave * PARK;
     uint32_t* pk_q = (uint32_t*)(smem + LY.off_park + 8 * PARK * 8) + wave * PARK;
-    __shared__ float rn_lds_all[8][64]; // |r^|^2 of the rows of the block in hand, per wave (see the flat kernel)
-    float* rn_lds = rn_lds_all[wave];
+    float* rn_lds; // |r^|^2 of the rows of the block in hand, per wave (see the flat kernel)
+    if constexpr (FG) {
+        rn_lds = (float*)(smem + LY.off_rn) + wave * 64;
+    } else {
+        __shared__ float rn_lds_all[8][64];
+        rn_lds = rn_lds_all[wave];
+    }
     int wcnt = 0;
     LmfStage<NST> st{smem + LY.off_stage + wave * LmfStage<NST>::BYTES, 0};
     auto flush = [&]() __attribute__((always_inline)) {
@@ -1131,8 +1190,18 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
         };
         int bi = 0;
         half8 av[4]; // ring of decoded A operands (k-step s in slot s % 4)
+        // FG: the four dwords of a ring slot are written by asm ds_reads; va0 / va1 = address registers (high half: the lane's table half)
+        unsigned ar[4][4];
+        unsigned va0 = (unsigned)h << 16, va1 = (unsigned)h << 16;
+        const unsigned two = 2u;
+        if constexpr (FG) {
+            lp_gather<0>(cw[0], ar[0], va0, va1, two);
+            lp_gather<1>(cw[1], ar[1], va0, va1, two);
+            lp_gather<2>(cw[2], ar[2], va0, va1, two);
+        } else {
 #pragma unroll
-        for (int s = 0; s < LP_AHEAD; ++s) av[s] = operand_of(cw, s);
+            for (int s = 0; s < LP_AHEAD; ++s) av[s] = operand_of(cw, s);
+        }
         for (int t = r0; t < rend; t += bstep, ++bi) {
             if (METRIC == METRIC_L2) {
                 asm volatile("" ::: "memory");
@@ -1159,10 +1228,15 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
             // from).  The pipeline runs ACROSS blocks: the last k-steps of a block gather the first operands of the next
             // block looked at (its code bytes wait in cn), so that a block does not open with LP_AHEAD exposed LDS latencies
             // and the epilogue runs with gathers in flight.
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                if (s + LP_AHEAD < 8) av[(s + LP_AHEAD) % 4] = operand_of(cw, s + LP_AHEAD);
-                else av[(s + LP_AHEAD) % 4] = operand_of(cn, s + LP_AHEAD - 8);
+            auto step = [&](auto s_c) __attribute__((always_inline)) {
+                constexpr int s = decltype(s_c)::value;
+                if constexpr (FG) {
+                    constexpr int sn = (s + LP_AHEAD) & 7;
+                    lp_gather<sn>(s + LP_AHEAD < 8 ? cw[sn] : cn[sn], ar[(s + LP_AHEAD) % 4], va0, va1, two);
+                } else {
+                    if (s + LP_AHEAD < 8) av[(s + LP_AHEAD) % 4] = operand_of(cw, s + LP_AHEAD);
+                    else av[(s + LP_AHEAD) % 4] = operand_of(cn, s + LP_AHEAD - 8);
+                }
                 if (s == 1) fetch(min(t + 2 * bstep, tlast), cn2);
                 if (s == 5 && METRIC == METRIC_L2) { // |r^|^2 of the block's rows (lane: rows 8 g + 4 h + e) from the wave's slice
 #pragma unroll
@@ -1170,12 +1244,21 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (FULLK || s < nks) {
+                    const half8 a = FG ? lp_landed(ar[s % 4]) : av[s % 4];
 #pragma unroll
                     for (int b = 0; b < NB; ++b)
-                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s % 4], bq[b][s], acc[b], 0, 0, 0);
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq[b][s], acc[b], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-            }
+            };
+            step(std::integral_constant<int, 0>{});
+            step(std::integral_constant<int, 1>{});
+            step(std::integral_constant<int, 2>{});
+            step(std::integral_constant<int, 3>{});
+            step(std::integral_constant<int, 4>{});
+            step(std::integral_constant<int, 5>{});
+            step(std::integral_constant<int, 6>{});
+            step(std::integral_constant<int, 7>{});
             if constexpr (MODE == MODE_MIN) {
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
@@ -1256,19 +1339,22 @@ template <int METRIC, int MODE, bool SEL>
 static void lmf_pq_launch(const IvfLmParams& p, int grid_blocks, hipStream_t stream) {
     constexpr int NQB = kLmfQueryBlocks;
     const bool twoc = p.cs_choice != 0;
-    const int lds = lp_layout(p.d, p.M, twoc).total;
     const int ds = p.dsub >= 8 ? 8 : p.dsub;
-#define FA_LP(DS_, FK_, TC_)                                                                                                   \
+    const bool bench_shape = !twoc && ds == 2 && p.d == 128 && p.M == 64 && p.cs_piece == 16;
+    const bool fastg = bench_shape && p.lmf_fast_gather != 0;
+    const int lds = lp_layout(p.d, p.M, twoc, fastg).total;
+#define FA_LP(DS_, FK_, TC_, ...)                                                                                              \
     do {                                                                                                                       \
-        HIP_CHECK(hipFuncSetAttribute((const void*)ivf_lmf_pq_kernel<METRIC, MODE, NQB, DS_, SEL, FK_, TC_>,                   \
+        HIP_CHECK(hipFuncSetAttribute((const void*)ivf_lmf_pq_kernel<METRIC, MODE, NQB, DS_, SEL, FK_, TC_, ##__VA_ARGS__>,    \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));                                       \
-        hipLaunchKernelGGL((ivf_lmf_pq_kernel<METRIC, MODE, NQB, DS_, SEL, FK_, TC_>), dim3((unsigned)grid_blocks),            \
+        hipLaunchKernelGGL((ivf_lmf_pq_kernel<METRIC, MODE, NQB, DS_, SEL, FK_, TC_, ##__VA_ARGS__>), dim3((unsigned)grid_blocks), \
                            dim3(LP_THREADS), lds, stream, p);                                                                  \
     } while (0)
     if (twoc) {
         FA_THROW_IF_NOT(ds == 2 && ivf_lmf_choice_shape(p.d, p.M));
         FA_LP(2, true, true); // PQ64 over d = 128 with the two-copy codebook
-    } else if (ds == 2 && p.d == 128 && p.M == 64 && p.cs_piece == 16) FA_LP(2, true, false); // the same shape, one copy
+    } else if (fastg) FA_LP(2, true, false, true); // PQ64 over d = 128, one copy, one-instruction gathers (round 6)
+    else if (bench_shape) FA_LP(2, true, false); // the same shape, gathers as hipcc compiles them
     else if (ds == 1) FA_LP(1, false, false);
     else if (ds == 2) FA_LP(2, false, false);
     else if (ds == 4) FA_LP(4, false, false);

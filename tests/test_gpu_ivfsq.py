@@ -114,9 +114,14 @@ def test_ivfsq_trained_range_is_minmax_of_the_residuals(res):
             vexp = (vmax - vmin) * np.float32(arg)
             assert np.array_equal(t[:d], vmin - vexp) and np.array_equal(t[d:], (vmax + vexp) - (vmin - vexp))
     idx = faiss_amd.GpuIndexIVFScalarQuantizer(res, d, nlist, SQ.QT_8bit, METRIC_L2, True)
-    idx.set_rangestat(SQ.RS_meanstd, 2.0)
+    idx.set_rangestat(SQ.RS_meanstd, 2.0)  # (served since round 6: tests/test_gpu_round6.py::test_ivfsq_trains_every_range_statistic)
+    idx.train(xt)
+    assert idx.is_trained
+    idx.set_rangestat(7, 0.0)  # not a ScalarQuantizer::RangeStat
+    idx2 = faiss_amd.GpuIndexIVFScalarQuantizer(res, d, nlist, SQ.QT_8bit, METRIC_L2, True)
+    idx2.set_rangestat(7, 0.0)
     with pytest.raises(RuntimeError):
-        idx.train(xt)
+        idx2.train(xt)
     # the types without a range are trained as soon as the coarse quantizer is
     f = faiss_amd.GpuIndexIVFScalarQuantizer(res, d, nlist, SQ.QT_fp16, METRIC_L2, True)
     f.train(xt)
