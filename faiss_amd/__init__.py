@@ -1076,16 +1076,49 @@ class GpuParameterSpace:
     """faiss.GpuParameterSpace (faiss/gpu/GpuAutoTune.h / .cpp:40-114): the tunable parameters of a backend index"""
 
     def initialize(self, index):
-        """parameter ranges like ParameterSpace::initialize: nprobe in powers of two up to min(nlist, 2048)"""
+        """GpuParameterSpace::initialize (faiss/gpu/GpuAutoTune.cpp:33-77): nprobe = 1, 2, 4, ... below nlist and up to the k-selection
+        limit of 2048 (at most 12 values)"""
         self.parameter_ranges = {}
         nl = getattr(index, "nlist", None)
         if nl:
-            vals, v = [], 1
-            while v <= min(nl, 2048):
+            vals = []
+            for i in range(12):
+                v = 1 << i
+                if v >= nl or v > 2048:
+                    break
                 vals.append(v)
-                v *= 2
             self.parameter_ranges["nprobe"] = vals
         return self.parameter_ranges
+
+    def explore(self, index, xq, k, gt, criterion="1-recall@1"):
+        """ParameterSpace::explore (faiss/AutoTune.cpp:632-737) over the ranges of initialize(): every combination is applied and timed
+        on `index` (one warm-up search, then the best of three), perf = the share of queries whose true nearest neighbour gt[q] is the
+        first result.  Returns the OPTIMAL operating points [(perf, seconds, 'nprobe=..')], sorted by perf, like OperatingPoints."""
+        import time as _time
+        ranges = self.initialize(index)
+        names = sorted(ranges)
+        combos = [()]
+        for nm in names:
+            combos = [c + ((nm, v),) for c in combos for v in ranges[nm]]
+        gt = np.asarray(gt).reshape(-1)
+        pts = []
+        for combo in combos:
+            for nm, v in combo:
+                self.set_index_parameter(index, nm, v)
+            index.search(xq, k)
+            best = float("inf")
+            for _ in range(3):
+                t0 = _time.perf_counter()
+                _, I = index.search(xq, k)
+                best = min(best, _time.perf_counter() - t0)
+            pts.append((float((I[:, 0] == gt).mean()), best, ",".join("%s=%d" % (nm, v) for nm, v in combo)))
+        pts.sort(key=lambda p: (p[1], -p[0]))
+        optimal, top = [], -1.0
+        for p in pts:  # a point is optimal when nothing faster reaches its perf
+            if p[0] > top:
+                optimal.append(p)
+                top = p[0]
+        return sorted(optimal)
 
     def set_index_parameter(self, index, name, val):
         _check(load_library().faiss_amd_GpuParameterSpace_set_index_parameter(index._h, name.encode(), float(val)))

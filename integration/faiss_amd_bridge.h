@@ -21,12 +21,14 @@
 // tests/test_gpu_bridge.py; the product library does not depend on it.
 #pragma once
 
+#include <faiss/AutoTune.h>
 #include <faiss/Clustering.h>
 #include <faiss/Index.h>
 #include <faiss/IndexFlat.h>
 #include <faiss/IndexIVF.h>
 #include <faiss/IndexIVFFlat.h>
 #include <faiss/IndexIVFPQ.h>
+#include <faiss/IndexPreTransform.h>
 #include <faiss/IndexReplicas.h>
 #include <faiss/IndexScalarQuantizer.h>
 #include <faiss/IndexShards.h>
@@ -696,6 +698,65 @@ struct AmdIndexIVFScalarQuantizer : AmdIndexIVF {
         amd_check(faiss_amd_IndexIVFSQ_info(h, nullptr, nullptr, nullptr, &nt));
         sq.trained.resize(nt);
         if (nt) amd_check(faiss_amd_IndexIVFSQ_get_trained(h, sq.trained.data()));
+    }
+};
+
+// ------------------------------------------------------------------ GpuParameterSpace (faiss/gpu/GpuAutoTune.h, GpuAutoTune.cpp:33-114)
+/// The tunable parameters of backend indexes for the reference's own AutoTune machinery: `initialize` lists them (nprobe in powers
+/// of two below nlist and up to the k-selection limit, through IndexPreTransform / IndexReplicas / IndexShards like the
+/// reference), `set_index_parameter` applies one, and the inherited `ParameterSpace::explore` (faiss/AutoTune.cpp:632-737) then
+/// measures operating points on the backend unchanged.
+struct AmdParameterSpace : faiss::ParameterSpace {
+    void initialize(const faiss::Index* index) override {
+        if (auto* pt = dynamic_cast<const faiss::IndexPreTransform*>(index)) {
+            initialize(pt->index);
+            return;
+        }
+        if (dynamic_cast<const faiss::IndexShardsIVF*>(index)) {
+            faiss::ParameterSpace::initialize(index);
+            return;
+        }
+        if (auto* rep = dynamic_cast<const faiss::IndexReplicas*>(index)) {
+            if (rep->count() == 0) return;
+            index = rep->at(0);
+        }
+        if (auto* sh = dynamic_cast<const faiss::IndexShards*>(index)) {
+            if (sh->count() == 0) return;
+            index = sh->at(0);
+        }
+        if (auto* ivf = dynamic_cast<const AmdIndexIVF*>(index)) {
+            faiss::ParameterRange& pr = add_range("nprobe");
+            for (int i = 0; i < 12; i++) {
+                const size_t np = (size_t)1 << i;
+                if (np >= ivf->nlist || np > 2048) break; // (getMaxKSelection: 2048, faiss/gpu/impl/IndexUtils.cu:28-42)
+                pr.values.push_back((double)np);
+            }
+            // a host-side coarse quantizer (CPU coarse quantizer mode) brings its own parameters, prefixed like the reference's
+            if (ivf->cpu_coarse) {
+                faiss::ParameterSpace qs;
+                qs.initialize(ivf->quantizer);
+                for (const faiss::ParameterRange& q : qs.parameter_ranges) add_range("quantizer_" + q.name).values = q.values;
+            }
+        }
+    }
+    void set_index_parameter(faiss::Index* index, const std::string& name, double val) const override {
+        if (auto* rep = dynamic_cast<faiss::IndexReplicas*>(index)) {
+            for (int i = 0; i < rep->count(); i++) set_index_parameter(rep->at(i), name, val);
+            return;
+        }
+        if (auto* ivf = dynamic_cast<AmdIndexIVF*>(index)) {
+            if (name == "nprobe") {
+                ivf->nprobe = (size_t)val;
+                return;
+            }
+            if (name.rfind("quantizer_", 0) == 0 && ivf->cpu_coarse) {
+                faiss::ParameterSpace().set_index_parameter(ivf->quantizer, name.substr(strlen("quantizer_")), val);
+                return;
+            }
+            amd_check(faiss_amd_GpuParameterSpace_set_index_parameter(ivf->h, name.c_str(), val)); // (use_precomputed_table ...)
+            return;
+        }
+        faiss::ParameterSpace::set_index_parameter(index, name, val);
     }
 };
 

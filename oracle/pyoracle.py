@@ -582,6 +582,23 @@ class Ref:
         return cls._wrap_ptr(h, d, [quantizer])
 
     @classmethod
+    def amd_autotune(cls, index, xq, k, gt):
+        """the bridge's GpuParameterSpace::initialize + the reference's ParameterSpace::explore on `index` (1-recall@1 against gt [nq]):
+        (number of parameter ranges, [(perf, seconds, key)] of the optimal operating points)"""
+        xq = _f32(xq)
+        gt = np.ascontiguousarray(gt, dtype=np.int64).reshape(-1)
+        cap = 64
+        perf, t = np.zeros(cap), np.zeros(cap)
+        nr, npts = ctypes.c_int(0), ctypes.c_int(0)
+        buf = ctypes.create_string_buffer(4096)
+        rc = cls.lib().ref_amd_autotune(ctypes.c_void_p(index.h), ctypes.c_int64(xq.shape[0]), _p(xq), ctypes.c_int64(k), _p(gt),
+                                        ctypes.c_int(cap), ctypes.byref(nr), ctypes.byref(npts), _p(perf), _p(t), buf, ctypes.c_int(4096))
+        if rc != 0:
+            raise RuntimeError("reference error: " + cls.lib().ref_last_error().decode())
+        keys = [x for x in buf.value.decode().split(";")][:npts.value]
+        return nr.value, [(float(perf[i]), float(t[i]), keys[i]) for i in range(npts.value)]
+
+    @classmethod
     def write_index(cls, index, path):
         if cls.lib().ref_write_index(ctypes.c_void_p(index.h), path.encode()) != 0:
             raise RuntimeError("reference error: " + cls.lib().ref_last_error().decode())

@@ -10,6 +10,7 @@
 // path -- faiss::Clustering::train (faiss/Clustering.cpp:255-357), faiss::IndexShards (faiss/IndexShards.cpp:135-265),
 // faiss::IndexShardsIVF, faiss::IndexReplicas, faiss::IndexIVF with the backend as coarse quantizer
 // (faiss/IndexIVF.cpp:194,336-342) -- run unchanged on the MI355X backend.  (This library links libfaiss_amd.so.)
+#include <faiss/AutoTune.h>
 #include <faiss/Clustering.h>
 #include <faiss/Index.h>
 #include <faiss/IndexFlat.h>
@@ -393,6 +394,34 @@ void* ref_amd_ivf_new_with_quantizer(void* res, void* quantizer, int kind, int d
         g_err = e.what();
         return nullptr;
     }
+}
+// GpuParameterSpace of the bridge + the reference's ParameterSpace::explore on a backend index (faiss/AutoTune.cpp:632-737):
+// 1-recall@1 against `gt` [nq] as the criterion; returns the optimal operating points (perf, seconds, key strings joined by ';')
+int ref_amd_autotune(void* index, idx_t nq, const float* xq, idx_t k, const idx_t* gt, int cap, int* n_ranges, int* n_pts, double* perf,
+                     double* t, char* keys, int keys_cap) {
+    SHIM_TRY auto* ix = (faiss::Index*)index;
+    faiss::amd::AmdParameterSpace ps;
+    ps.initialize(ix);
+    *n_ranges = (int)ps.parameter_ranges.size();
+    ps.verbose = 0;
+    ps.n_experiments = 0; // try all combinations
+    faiss::OneRecallAtRCriterion crit(nq, 1);
+    crit.set_groundtruth(1, nullptr, gt);
+    crit.nnn = k;
+    faiss::OperatingPoints ops;
+    ps.explore(ix, nq, xq, crit, &ops);
+    std::string ks;
+    int n = 0;
+    for (const auto& op : ops.optimal_pts) {
+        if (n >= cap) break;
+        perf[n] = op.perf;
+        t[n] = op.t;
+        ks += op.key + ";";
+        n++;
+    }
+    *n_pts = n;
+    snprintf(keys, keys_cap, "%s", ks.c_str());
+    SHIM_CATCH
 }
 // faiss::write_index / read_index (faiss/index_io.h; impl/index_write.cpp, impl/index_read.cpp): the checkpoint path of a GPU
 // index is index_gpu_to_cpu -> write_index, and back read_index -> index_cpu_to_gpu (faiss/gpu/test/test_gpu_index_serialize.py)

