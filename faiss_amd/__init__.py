@@ -130,6 +130,7 @@ def load_library():
         "faiss_amd_GpuIndexIVF_set_lmf_sampling": (i32, [vp, i32]),
         "faiss_amd_GpuIndexIVFPQ_set_lmf_two_copies": (i32, [vp, i32]),
         "faiss_amd_GpuIndexIVFPQ_set_lmf_fast_gather": (i32, [vp, i32]),
+        "faiss_amd_Index_set_small_fused": (i32, [vp, i32]),
         "faiss_amd_GpuIndexIVF_list_major_rule": (i32, [vp, i64, i32, i64, P(i32)]),
         "faiss_amd_GpuIndexFlat_set_use_filter_kernel": (i32, [vp, i32, i64]),
         "faiss_amd_GpuIndexFlat_filter_stats": (i32, [vp, P(i32), P(i32)]),
@@ -341,6 +342,10 @@ class Index:
             with _params_handle(self._lib, params) as h:
                 _check(self._lib.faiss_amd_Index_search_with_params(self._h, n, _ptr(x), int(k), h, _ptr(D), _ptr(I)))
         return D, I
+
+    def set_small_fused(self, on):
+        """A/B knob: flat searches over <= 4096 rows (this index, or the coarse quantizer of an IVF index) in one launch"""
+        _check(self._lib.faiss_amd_Index_set_small_fused(self._h, int(bool(on))))
 
     def search_ptr(self, n, x_ptr, k, d_ptr, i_ptr, params=None):
         """Raw-pointer search (host or device addresses), e.g. torch tensors' ``data_ptr()``."""

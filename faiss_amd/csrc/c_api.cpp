@@ -1037,6 +1037,12 @@ int faiss_amd_GpuIndexIVF_set_lmf_sampling(FaissAmdIndex* index, int sample_shif
     as<GpuIndexIVF>(index, "GpuIndexIVF")->lmf_sample_shift = sample_shift;
     FA_CATCH
 }
+int faiss_amd_Index_set_small_fused(FaissAmdIndex* index, int on) {
+    FA_TRY
+    if (auto* ivf = dynamic_cast<GpuIndexIVF*>(I(index))) ivf->quantizer->use_small_fused = on != 0;
+    else as<GpuIndexFlat>(index, "GpuIndexFlat")->use_small_fused = on != 0;
+    FA_CATCH
+}
 int faiss_amd_GpuIndexIVFPQ_set_lmf_fast_gather(FaissAmdIndex* index, int on) {
     FA_TRY
     as<GpuIndexIVFPQ>(index, "GpuIndexIVFPQ")->lmf_fast_gather = on != 0;

@@ -692,6 +692,240 @@ __global__ void __launch_bounds__(FqGeom<QB>::THREADS, 2) flat_filter_kernel(Fla
     }
 }
 
+// ---------------------------------------------------------------------------------
+// Small databases in ONE launch (round 6): the coarse quantizer of an IVF search -- 10 000 queries against nlist <= 4096
+// centroids, k = nprobe -- through maxima pass, threshold, collect pass, exact re-rank and ordering inside one workgroup
+// per 32 queries, instead of the five launches (maxima / tighten / collect / re-rank + the overflow count's round trip) the
+// general path spends ~ 130 us on for 10 GFLOP (profiles/r5_ivfpq_1m_kernel_stats.csv).  Same scheme, same
+// guarantees as above: approximate scores on v_mfma_f32_32x32x16_f16 over the fp16 rows, the per-query error band of
+// flat_filter_err_bound, a SUPERSET of the answer re-ranked with the fmaf chain of flat_scan_kernel -- results bit-identical
+// to the general path.  (Round 2's one-launch kernel lost because a 4-wave workgroup walked two serial sweeps of all rows
+// with one block in flight; here the four waves split the rows and keep three 32-row blocks of loads ahead of the MFMAs, two
+// workgroups per CU.)
+//   * a wave owns the 32-row blocks w, w + 4, ...; B operands = the workgroup's 32 queries (8 k-steps in registers);
+//   * scores = MFMA chain from zero + (-|y|^2 / 2) (one more rounding than starting the chain there: inside the band,
+//     which budgets d roundings of that magnitude);
+//   * pass 1: maximum per (query, 16-row half block) -> LDS; threshold = band_threshold(k-th largest maximum, e_q) (the k
+//     rows that realise the k largest maxima are distinct, so the k-th best score is at least that);
+//   * pass 2: rows at or above the threshold -> candidate list of the query (u16 row numbers, FS_CAP per query);
+//   * re-rank: one thread per (query, candidate), the chain of flat_rerank_kernel; ordering by counting.
+// Queries flagged by prep_queries (fp16 range, NaN) or with more than FS_CAP candidates go to the exact scan (ovf_list).
+// ---------------------------------------------------------------------------------
+constexpr int FS_THREADS = 256, FS_WAVES = FS_THREADS / 64, FS_Q = 32, FS_CAP = 128, FS_MAXCH = 256;
+struct FsShared {
+    float cmax[FS_Q][FS_MAXCH]; // pass 1: chunk maxima; later: the candidates' exact keys (u64 [FS_Q][FS_CAP])
+    float qs[FS_Q][128];        // fp32 queries (re-rank)
+    uint16_t cand[FS_Q][FS_CAP];
+    float thr[FS_Q], xn[FS_Q];
+    unsigned cnt[FS_Q], pre[FS_Q + 1];
+    unsigned bad[FS_Q];
+};
+static_assert(sizeof(float) * FS_MAXCH == sizeof(u64) * FS_CAP, "the exact keys reuse the maxima");
+
+template <int METRIC>
+__global__ void __launch_bounds__(FS_THREADS, 2) flat_small_fused_kernel(FlatSmallParams p) {
+    __shared__ FsShared sh;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    const int q0 = blockIdx.x * FS_Q;
+    const int nblk = (p.nb + 31) >> 5, nch = 2 * nblk;
+    const int qj = min(q0 + j, p.nq - 1);
+    // ---- queries: B operands, fp32 copies, thresholds' ingredients
+    half8 bq[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) bq[s] = *(const half8*)(p.xqh + (int64_t)qj * p.ldqh + 16 * s + 8 * h);
+    for (int i = tid; i < FS_Q * 128; i += FS_THREADS) {
+        const int qq = i >> 7, c = i & 127;
+        sh.qs[qq][c] = (q0 + qq < p.nq && c < p.dpad) ? p.xq[(int64_t)(q0 + qq) * p.ldq + c] : 0.f;
+    }
+    if (tid < FS_Q) {
+        const int q = q0 + tid;
+        sh.cnt[tid] = 0;
+        sh.bad[tid] = (q >= p.nq) ? 2u : (p.flags[q] ? 1u : 0u);
+        sh.xn[tid] = q < p.nq ? p.xqn[q] : 0.f;
+    }
+    // one pass over this wave's blocks; MODE_MAX writes the chunk maxima, MODE_COLLECT the candidates
+    auto sweep = [&](auto mode_c) __attribute__((always_inline)) {
+        constexpr int MODE = decltype(mode_c)::value;
+        const float th = MODE == MODE_COLLECT ? sh.thr[j] : 0.f;
+        auto loadblk = [&](int b, half8 (&a)[8]) __attribute__((always_inline)) {
+            const _Float16* r = p.xbh + (int64_t)(32 * b + j) * p.ldbh + 8 * h; // (rows behind nb: the padding tile)
+#pragma unroll
+            for (int s = 0; s < 8; ++s) a[s] = *(const half8*)(r + 16 * s);
+        };
+        half8 a0[8], a1[8], a2[8];
+        int b = wave;
+        if (b < nblk) loadblk(b, a0);
+        if (b + FS_WAVES < nblk) loadblk(b + FS_WAVES, a1);
+        if (b + 2 * FS_WAVES < nblk) loadblk(b + 2 * FS_WAVES, a2);
+        for (; b < nblk; b += FS_WAVES) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            f32x4 bias[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bias[g] = *(const f32x4*)(p.xbhn + 32 * b + 8 * g + 4 * h);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[s], bq[s], acc, 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) a0[s] = a1[s], a1[s] = a2[s];
+            if (b + 3 * FS_WAVES < nblk) loadblk(b + 3 * FS_WAVES, a2);
+            float sc[16], m = -INFINITY;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = 32 * b + 8 * g + 4 * h + e;
+                    float v = acc[4 * g + e] + bias[g][e];
+                    v = row < p.nb ? v : -INFINITY;
+                    sc[4 * g + e] = v;
+                    m = fmaxf(m, v); // (drops a NaN score like the general path's v_max3)
+                }
+            if (MODE == MODE_MAX) {
+                sh.cmax[j][2 * b + h] = m;
+            } else if (m >= th) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (sc[i] >= th) {
+                        const unsigned slot = atomicAdd(&sh.cnt[j], 1u);
+                        if (slot < (unsigned)FS_CAP) sh.cand[j][slot] = (uint16_t)(32 * b + 8 * (i >> 2) + 4 * h + (i & 3));
+                    }
+            }
+        }
+    };
+    sweep(std::integral_constant<int, MODE_MAX>{});
+    __syncthreads();
+    // ---- thresholds: wave w serves queries 8 w .. 8 w + 7; k-th smallest score key of the nch maxima by bisection on the bits
+    for (int qi = 0; qi < FS_Q / FS_WAVES; ++qi) {
+        const int qq = (FS_Q / FS_WAVES) * wave + qi;
+        uint32_t key[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) key[u] = lane + 64 * u < nch ? score_key(sh.cmax[qq][lane + 64 * u]) : 0xffffffffu;
+        uint32_t pre = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t cand = pre | ((1u << bit) - 1u); // (keys <= cand: this bit clear under the prefix found so far)
+            int c = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) c += __popcll(__ballot(key[u] <= cand));
+            if (c < p.k) pre |= 1u << bit;
+        }
+        if (lane == 0) {
+            const float e = flat_filter_err_bound(METRIC, p.d, sh.xn[qq], p.yn_max, false);
+            const float tk = key_score(pre);
+            sh.thr[qq] = (sh.bad[qq] || !(e < FLT_MAX)) ? INFINITY : (tk > -INFINITY ? band_threshold(tk, e) : -INFINITY);
+            if (!(e < FLT_MAX) && sh.bad[qq] == 0) sh.bad[qq] = 1u;
+        }
+    }
+    __syncthreads();
+    sweep(std::integral_constant<int, MODE_COLLECT>{});
+    __syncthreads();
+    // ---- exact distances of the candidates: (query, candidate) pairs dealt to the threads
+    if (tid == 0) {
+        unsigned acc = 0;
+        for (int qq = 0; qq < FS_Q; ++qq) {
+            sh.pre[qq] = acc;
+            unsigned c = sh.cnt[qq];
+            if (sh.bad[qq] == 0 && c > (unsigned)FS_CAP) {
+                sh.bad[qq] = 1u; // more rows inside the band than the list holds: exact scan for this query
+            }
+            if (sh.bad[qq]) c = 0;
+            sh.cnt[qq] = c;
+            acc += c;
+        }
+        sh.pre[FS_Q] = acc;
+    }
+    __syncthreads();
+    if (tid < FS_Q && sh.bad[tid] == 1u) p.ovf_list[atomicAdd(p.ovf_cnt, 1u)] = (uint32_t)(q0 + tid);
+    const unsigned total = sh.pre[FS_Q];
+    u64* ekey = (u64*)&sh.cmax[0][0]; // [FS_Q][FS_CAP] (the maxima are dead)
+    u64 mine[(FS_Q * FS_CAP + FS_THREADS - 1) / FS_THREADS];
+    int nmine = 0;
+    for (unsigned g = tid; g < total; g += FS_THREADS, ++nmine) {
+        int qq = 0;
+        while (sh.pre[qq + 1] <= g) ++qq;
+        const unsigned row = sh.cand[qq][g - sh.pre[qq]];
+        const float* yr = p.xb + (int64_t)row * p.ldb;
+        const float* qs = sh.qs[qq];
+        float acc = 0.f;
+        // the chain of flat_scan_kernel / flat_rerank_kernel: 8-float steps, e and 4 + e interleaved
+        auto step = [&](const f32x4& y0, const f32x4& y1, int s) {
+            const f32x4 x0 = *(const f32x4*)(qs + s), x1 = *(const f32x4*)(qs + s + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc = __fmaf_rn(y0[e], x0[e], acc);
+                acc = __fmaf_rn(y1[e], x1[e], acc);
+            }
+        };
+        int s = 0;
+        for (; s + 32 <= p.dpad; s += 32) {
+            f32x4 y[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) y[u] = *(const f32x4*)(yr + s + 4 * u);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) step(y[2 * u], y[2 * u + 1], s + 8 * u);
+        }
+        for (; s < p.dpad; s += 8) step(*(const f32x4*)(yr + s), *(const f32x4*)(yr + s + 4), s);
+        float dis;
+        if (METRIC == METRIC_L2) {
+            dis = __fmaf_rn(-2.f, acc, sh.xn[qq] + p.xbn[row]);
+            dis = dis < 0.f ? 0.f : dis;
+        } else {
+            dis = acc;
+        }
+        mine[nmine] = ((u64)ordkey<METRIC>(dis) << 32) | row;
+    }
+    __syncthreads(); // (every candidate list has been read: the keys may overwrite the maxima)
+    nmine = 0;
+    for (unsigned g = tid; g < total; g += FS_THREADS, ++nmine) {
+        int qq = 0;
+        while (sh.pre[qq + 1] <= g) ++qq;
+        ekey[qq * FS_CAP + (g - sh.pre[qq])] = mine[nmine];
+    }
+    __syncthreads();
+    // ---- exact top-k under (distance, id): every key straight to its rank
+    const float pad = neutral_distance(METRIC);
+    nmine = 0;
+    for (unsigned g = tid; g < total; g += FS_THREADS, ++nmine) {
+        int qq = 0;
+        while (sh.pre[qq + 1] <= g) ++qq;
+        const int n = (int)sh.cnt[qq];
+        const u64 x = mine[nmine];
+        const u64* kk = ekey + qq * FS_CAP;
+        int r = 0;
+        for (int i = 0; i < n; ++i) r += kk[i] < x ? 1 : 0;
+        if (r < p.k) {
+            const uint32_t wk = (uint32_t)(x >> 32);
+            const bool ok = wk < kInvalidOrdKey;
+            p.out_dis[(int64_t)(q0 + qq) * p.k + r] = ok ? unordkey<METRIC>(wk) : pad;
+            p.out_ids[(int64_t)(q0 + qq) * p.k + r] = ok ? (int64_t)(uint32_t)x : -1;
+        }
+    }
+    // (fewer candidates than k: only when the database holds fewer rows)
+    for (int i = tid; i < FS_Q * p.k; i += FS_THREADS) {
+        const int qq = i / p.k, r = i - qq * p.k;
+        if (q0 + qq < p.nq && sh.bad[qq] == 0 && r >= (int)sh.cnt[qq]) {
+            p.out_dis[(int64_t)(q0 + qq) * p.k + r] = pad;
+            p.out_ids[(int64_t)(q0 + qq) * p.k + r] = -1;
+        }
+    }
+}
+
+bool flat_small_fused_supported(int metric, int nb, int d, int dh, int k) {
+    const int nch = 2 * ((nb + 31) / 32);
+    return (metric == METRIC_L2 || metric == METRIC_INNER_PRODUCT) && dh == 128 && d <= 128 && nb <= 32 * (FS_MAXCH / 2) &&
+           k <= 64 && nch >= 4 * k && nb >= k;
+}
+void launch_flat_small_fused(const FlatSmallParams& p, hipStream_t stream) {
+    if (p.nq == 0) return;
+    FA_THROW_IF_NOT(flat_small_fused_supported(p.metric, p.nb, p.d, (int)p.ldbh, p.k) && p.dpad <= 128 && p.dpad % 8 == 0 && p.xb);
+    const dim3 grid((unsigned)div_up(p.nq, FS_Q)), block(FS_THREADS);
+    if (p.metric == METRIC_L2) hipLaunchKernelGGL((flat_small_fused_kernel<METRIC_L2>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((flat_small_fused_kernel<METRIC_INNER_PRODUCT>), grid, block, 0, stream, p);
+    HIP_CHECK(hipGetLastError());
+}
+
 int flat_filter_queries_per_block(int geom) {
     return geom == 2 ? FqGeom<4>::QPB : FqGeom<2>::QPB;
 }

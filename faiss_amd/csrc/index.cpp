@@ -861,6 +861,62 @@ void GpuIndexFlat::search_tile_(int n, const float* xq_pad, int k, float* dD, id
     last_used_filter = true;
     const GpuResources& R = *res_;
     const int nb = (int)ntotal;
+    // ---- queries whose segments overflowed (or left the fp16 range) go through the exact fp32 scan
+    auto redo_overflow = [&]() {
+        if (!h_novf_) HIP_CHECK(hipHostMalloc((void**)&h_novf_, 64, hipHostMallocDefault));
+        HIP_CHECK(hipMemcpyAsync(h_novf_, scal_.as<unsigned>() + 2, 4, hipMemcpyDeviceToHost, R.stream));
+        R.sync();
+        const unsigned novf = *h_novf_;
+        last_filter_overflow = (int)novf;
+        if (novf > 0) {
+            ovf_q_.ensure((size_t)novf * dpad_ * 4);
+            ovf_d_.ensure((size_t)novf * k * 4);
+            ovf_i_.ensure((size_t)novf * k * 8);
+            launch_gather_rows(xq_pad, dpad_, dpad_, ovf_list_.as<uint32_t>(), (int)novf, ovf_q_.as<float>(), R.stream);
+            // the exact scan tiles its own scratch; reuse of res_keys_ is ordered on the stream
+            const int tile = 16384;
+            for (int i0 = 0; i0 < (int)novf; i0 += tile) {
+                const int ni = std::min(tile, (int)novf - i0);
+                search_tile_exact_(ni, ovf_q_.as<float>() + (size_t)i0 * dpad_, k, ovf_d_.as<float>() + (size_t)i0 * k,
+                                   ovf_i_.as<idx_t>() + (size_t)i0 * k);
+            }
+            launch_scatter_results(ovf_d_.as<float>(), ovf_i_.as<idx_t>(), k, ovf_list_.as<uint32_t>(), (int)novf, dD, dI,
+                                   R.stream);
+        }
+    };
+    // ---- small databases (the coarse quantizer of an IVF index: nlist <= 4096 centroids, k = nprobe <= 64): maxima pass, threshold,
+    // collect pass, exact re-rank and ordering in ONE launch (flat_filter.hip flat_small_fused_kernel, round 6) -- same bits
+    if (use_small_fused && !sel_active_ && !use_float16_ && flat_small_fused_supported(metric_type, nb, d, dh_, k)) {
+        qh_.ensure((size_t)n * dh_ * 2);
+        flags_.ensure((size_t)n * 4);
+        q_norm_.ensure((size_t)n * 4);
+        ovf_list_.ensure((size_t)n * 4);
+        {
+            SpanGuard sg(&R, "convert_f16_query");
+            launch_prep_queries(xq_pad, dpad_, n, d, dpad_, qh_.p, dh_, flags_.as<uint32_t>(), q_norm_.as<float>(),
+                                scal_.as<unsigned>() + 2, R.stream);
+        }
+        FlatSmallParams sp{};
+        sp.metric = metric_type, sp.nq = n, sp.nb = nb, sp.d = d, sp.dpad = dpad_, sp.k = k;
+        sp.xqh = qh_.as<_Float16>(), sp.ldqh = dh_;
+        sp.xq = xq_pad, sp.ldq = dpad_;
+        sp.xqn = q_norm_.as<float>();
+        sp.flags = flags_.as<uint32_t>();
+        sp.xbh = xbh_.as<_Float16>(), sp.ldbh = dh_;
+        sp.xbhn = xbhn_.as<float>();
+        sp.xb = xb_.as<float>(), sp.ldb = dpad_;
+        sp.xbn = xbn_.as<float>();
+        sp.yn_max = yn_max_;
+        sp.out_dis = dD, sp.out_ids = dI;
+        sp.ovf_list = ovf_list_.as<uint32_t>();
+        sp.ovf_cnt = scal_.as<unsigned>() + 2;
+        {
+            SpanGuard sg(&R, "flat_small_fused_kernel");
+            launch_flat_small_fused(sp, R.stream);
+        }
+        redo_overflow();
+        return;
+    }
     FlatFilterParams fp{};
     fp.metric = metric_type;
     int gcap = 4096;
@@ -947,27 +1003,7 @@ void GpuIndexFlat::search_tile_(int n, const float* xq_pad, int k, float* dD, id
         SpanGuard sg(&R, "flat_rerank_kernel");
         launch_flat_rerank(rp, R.stream);
     }
-    // ---- queries whose segments overflowed (or left the fp16 range) go through the exact fp32 scan
-    if (!h_novf_) HIP_CHECK(hipHostMalloc((void**)&h_novf_, 64, hipHostMallocDefault));
-    HIP_CHECK(hipMemcpyAsync(h_novf_, scal_.as<unsigned>() + 2, 4, hipMemcpyDeviceToHost, R.stream));
-    R.sync();
-    const unsigned novf = *h_novf_;
-    last_filter_overflow = (int)novf;
-    if (novf > 0) {
-        ovf_q_.ensure((size_t)novf * dpad_ * 4);
-        ovf_d_.ensure((size_t)novf * k * 4);
-        ovf_i_.ensure((size_t)novf * k * 8);
-        launch_gather_rows(xq_pad, dpad_, dpad_, ovf_list_.as<uint32_t>(), (int)novf, ovf_q_.as<float>(), R.stream);
-        // the exact scan tiles its own scratch; reuse of res_keys_ is ordered on the stream
-        const int tile = 16384;
-        for (int i0 = 0; i0 < (int)novf; i0 += tile) {
-            const int ni = std::min(tile, (int)novf - i0);
-            search_tile_exact_(ni, ovf_q_.as<float>() + (size_t)i0 * dpad_, k, ovf_d_.as<float>() + (size_t)i0 * k,
-                               ovf_i_.as<idx_t>() + (size_t)i0 * k);
-        }
-        launch_scatter_results(ovf_d_.as<float>(), ovf_i_.as<idx_t>(), k, ovf_list_.as<uint32_t>(), (int)novf, dD, dI,
-                               R.stream);
-    }
+    redo_overflow();
 }
 
 void GpuIndexFlat::filter_scores(idx_t n, const float* x, float* scores, float* err_bound) const {

@@ -264,6 +264,9 @@ class GpuIndexFlat : public Index {
     // fp16 range and any query whose error band overflows its reservoir
     bool use_filter_kernel = true;
     idx_t filter_min_rows = 16384;
+    // databases of <= 4096 rows, k <= 64 (an IVF coarse quantizer): the whole filter path in one launch (flat_small_fused_kernel,
+    // round 6); off = the general launches (A/B knob, results never change)
+    bool use_small_fused = true;
     // statistics of the last search() tile (tests / bench): queries re-run through the exact scan
     mutable int last_filter_overflow = 0;
     mutable bool last_used_filter = false;

@@ -142,6 +142,30 @@ void launch_flat_filter(const FlatFilterParams& p, int mode, hipStream_t stream)
 void launch_flat_tighten(const FlatFilterParams& p, hipStream_t stream);
 size_t flat_filter_lds_bytes();
 
+// one-launch search of a small database (flat_filter.hip flat_small_fused_kernel, round 6): the IVF coarse quantizer
+struct FlatSmallParams {
+    int metric, nq, nb, d, dpad, k;
+    const _Float16* xqh; // [nq][ldqh] fp16 queries (prep_queries)
+    int64_t ldqh;
+    const float* xq; // [nq][ldq] fp32 padded queries
+    int64_t ldq;
+    const float* xqn;      // [nq] |q|^2 (prep_queries)
+    const uint32_t* flags; // [nq] fp16 range / NaN flags of the queries (prep_queries)
+    const _Float16* xbh;   // [nb + tile][ldbh] fp16 rows
+    int64_t ldbh;
+    const float* xbhn; // [nb + 64] -|y|^2 / 2 (L2) / 0 (IP), then -inf
+    const float* xb;   // [nb][ldb] fp32 rows
+    int64_t ldb;
+    const float* xbn; // [nb]
+    float yn_max;
+    float* out_dis;
+    int64_t* out_ids;
+    uint32_t* ovf_list; // queries for the exact scan
+    unsigned* ovf_cnt;
+};
+bool flat_small_fused_supported(int metric, int nb, int d, int dh, int k);
+void launch_flat_small_fused(const FlatSmallParams& p, hipStream_t stream);
+
 struct FlatRerankParams {
     int metric;
     int nq, k, kp, d, dpad, nsplit, cap;

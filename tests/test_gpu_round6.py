@@ -250,3 +250,55 @@ def test_parameter_space_initialize_and_explore(res):
     pts = ps.explore(idx, xq, 10, gt[:, 0])
     perfs = [p[0] for p in pts]
     assert perfs == sorted(perfs) and perfs[-1] > 0.97 and len(pts) >= 3
+
+
+# ------------------------------------------------------------------ small databases in one launch (the IVF coarse quantizer)
+@pytest.mark.parametrize("metric", [METRIC_L2, METRIC_INNER_PRODUCT])
+@pytest.mark.parametrize("d,nb,k,nq", [(128, 4096, 32, 1500), (128, 4096, 64, 333), (64, 4000, 32, 700), (100, 2100, 16, 40),
+                                       (128, 3000, 1, 129), (32, 4096, 8, 2500)])
+def test_small_database_in_one_launch_equals_the_general_path(res, metric, d, nb, k, nq):
+    """flat_small_fused_kernel: a flat search over <= 4096 rows with k <= 64 -- what the coarse quantizer of
+    an IVF4096 index runs -- in one launch: maxima pass, threshold, collect pass, exact re-rank, ordering.  Bit-identical to the
+    general launches and to the oracle (ties by label included), also for rows / queries that are not multiples of 32."""
+    from oracle.pyoracle import Oracle, integer_dataset
+    _, xb, xq = synthetic_dataset(d, 0, nb, nq, seed=d + k)
+    idx = faiss_amd.GpuIndexFlat(res, d, metric)
+    idx.add(xb)
+    idx.set_use_filter_kernel(True, 2048)  # (what GpuIndexIVF sets on its quantizer)
+    idx.set_small_fused(True)
+    D1, I1 = idx.search(xq, k)
+    used, novf = idx.filter_stats()
+    assert used and novf == 0
+    idx.set_small_fused(False)
+    D0, I0 = idx.search(xq, k)
+    assert np.array_equal(I1, I0) and np.array_equal(D1, D0)
+    Do, Io = Oracle.flat_search(metric, xb, xq[:64], k)
+    assert np.array_equal(I1[:64], Io) and np.array_equal(D1[:64], Do)
+    # many exact ties (integer data): more rows inside the band than a candidate list holds -> those queries take the exact scan
+    xbi, xqi = integer_dataset(d, nb, 200, seed=3, hi=3)
+    ti = faiss_amd.GpuIndexFlat(res, d, metric)
+    ti.add(xbi)
+    ti.set_use_filter_kernel(True, 2048)
+    Dt, It = ti.search(xqi, k)
+    Dto, Ito = Oracle.flat_search(metric, xbi, xqi, k)
+    assert np.array_equal(It, Ito) and np.array_equal(Dt, Dto)
+
+
+def test_ivf_search_with_the_one_launch_coarse_quantizer(res):
+    """the IVF legs of the bench shape in small: coarse quantization through the one-launch kernel or the general launches --
+    the same lists probed, the same results"""
+    d, nlist, M, k = 128, 4096, 64, 20
+    xt, xb, xq = synthetic_dataset(d, 20000, 60000, 2500, seed=71)
+    cent, _ = faiss_amd.kmeans(res, xt, nlist, niter=2, seed=3)
+    idx = faiss_amd.GpuIndexIVFFlat(res, d, nlist, METRIC_L2)
+    idx.copy_centroids(cent)
+    idx.add(xb)
+    idx.nprobe = 32
+    idx.set_small_fused(True)
+    D1, I1 = idx.search(xq, k)
+    Dc1, Ic1 = idx.quantizer_search(xq, 32)
+    idx.set_small_fused(False)
+    D0, I0 = idx.search(xq, k)
+    Dc0, Ic0 = idx.quantizer_search(xq, 32)
+    assert np.array_equal(Ic1, Ic0) and np.array_equal(Dc1, Dc0)
+    assert np.array_equal(I1, I0) and np.array_equal(D1, D0)
