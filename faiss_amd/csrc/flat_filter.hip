@@ -707,16 +707,19 @@ __global__ void __launch_bounds__(FqGeom<QB>::THREADS, 2) flat_filter_kernel(Fla
 //     which budgets d roundings of that magnitude);
 //   * pass 1: maximum per (query, 16-row half block) -> LDS; threshold = band_threshold(k-th largest maximum, e_q) (the k
 //     rows that realise the k largest maxima are distinct, so the k-th best score is at least that);
-//   * pass 2: rows at or above the threshold -> candidate list of the query (u16 row numbers, FS_CAP per query);
+//   * pass 2: rows at or above the threshold -> a list per LANE (no atomics: 16 returning LDS atomics per block serialised pass 2
+//     in the first version), merged into the query's candidate list (u16 row numbers, FS_CAP per query) afterwards;
 //   * re-rank: one thread per (query, candidate), the chain of flat_rerank_kernel; ordering by counting.
 // Queries flagged by prep_queries (fp16 range, NaN) or with more than FS_CAP candidates go to the exact scan (ovf_list).
 // ---------------------------------------------------------------------------------
-constexpr int FS_THREADS = 256, FS_WAVES = FS_THREADS / 64, FS_Q = 32, FS_CAP = 128, FS_MAXCH = 256;
+constexpr int FS_THREADS = 256, FS_WAVES = FS_THREADS / 64, FS_Q = 32, FS_CAP = 128, FS_MAXCH = 256, FS_SUB = 32;
 struct FsShared {
     float cmax[FS_Q][FS_MAXCH]; // pass 1: chunk maxima; later: the candidates' exact keys (u64 [FS_Q][FS_CAP])
     float qs[FS_Q][128];        // fp32 queries (re-rank)
-    uint16_t cand[FS_Q][FS_CAP];
+    uint16_t sub[FS_Q][2 * FS_WAVES][FS_SUB]; // pass 2: the rows a LANE found (query j, half h of wave w: list 2 w + h) -- no atomics
+    uint16_t cand[FS_Q][FS_CAP];              // the query's candidates, compacted
     float thr[FS_Q], xn[FS_Q];
+    unsigned cnt8[FS_Q][2 * FS_WAVES];
     unsigned cnt[FS_Q], pre[FS_Q + 1];
     unsigned bad[FS_Q];
 };
@@ -736,20 +739,23 @@ __global__ void __launch_bounds__(FS_THREADS, 2) flat_small_fused_kernel(FlatSma
     half8 bq[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) bq[s] = *(const half8*)(p.xqh + (int64_t)qj * p.ldqh + 16 * s + 8 * h);
-    for (int i = tid; i < FS_Q * 128; i += FS_THREADS) {
-        const int qq = i >> 7, c = i & 127;
-        sh.qs[qq][c] = (q0 + qq < p.nq && c < p.dpad) ? p.xq[(int64_t)(q0 + qq) * p.ldq + c] : 0.f;
+    for (int i = tid; i < FS_Q * 32; i += FS_THREADS) { // (four floats per thread and step)
+        const int qq = i >> 5, c = (i & 31) * 4;
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (q0 + qq < p.nq && c < p.dpad) v = *(const f32x4*)(p.xq + (int64_t)(q0 + qq) * p.ldq + c);
+        *(f32x4*)&sh.qs[qq][c] = v;
     }
     if (tid < FS_Q) {
         const int q = q0 + tid;
-        sh.cnt[tid] = 0;
         sh.bad[tid] = (q >= p.nq) ? 2u : (p.flags[q] ? 1u : 0u);
         sh.xn[tid] = q < p.nq ? p.xqn[q] : 0.f;
     }
-    // one pass over this wave's blocks; MODE_MAX writes the chunk maxima, MODE_COLLECT the candidates
+    // one pass over this wave's blocks; MODE_MAX writes the chunk maxima, MODE_COLLECT the lane's candidate rows
     auto sweep = [&](auto mode_c) __attribute__((always_inline)) {
         constexpr int MODE = decltype(mode_c)::value;
         const float th = MODE == MODE_COLLECT ? sh.thr[j] : 0.f;
+        uint16_t* mysub = sh.sub[j][2 * wave + h];
+        unsigned nsub = 0;
         auto loadblk = [&](int b, half8 (&a)[8]) __attribute__((always_inline)) {
             const _Float16* r = p.xbh + (int64_t)(32 * b + j) * p.ldbh + 8 * h; // (rows behind nb: the padding tile)
 #pragma unroll
@@ -789,11 +795,12 @@ __global__ void __launch_bounds__(FS_THREADS, 2) flat_small_fused_kernel(FlatSma
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
                     if (sc[i] >= th) {
-                        const unsigned slot = atomicAdd(&sh.cnt[j], 1u);
-                        if (slot < (unsigned)FS_CAP) sh.cand[j][slot] = (uint16_t)(32 * b + 8 * (i >> 2) + 4 * h + (i & 3));
+                        if (nsub < (unsigned)FS_SUB) mysub[nsub] = (uint16_t)(32 * b + 8 * (i >> 2) + 4 * h + (i & 3));
+                        ++nsub;
                     }
             }
         }
+        if (MODE == MODE_COLLECT) sh.cnt8[j][2 * wave + h] = nsub;
     };
     sweep(std::integral_constant<int, MODE_MAX>{});
     __syncthreads();
@@ -821,35 +828,61 @@ __global__ void __launch_bounds__(FS_THREADS, 2) flat_small_fused_kernel(FlatSma
     __syncthreads();
     sweep(std::integral_constant<int, MODE_COLLECT>{});
     __syncthreads();
-    // ---- exact distances of the candidates: (query, candidate) pairs dealt to the threads
+    // ---- the eight lane lists of a query -> one list (thread = (query, list)); a list or a query that overflowed: exact scan
+    {
+        const int qq = tid >> 3, sl = tid & 7;
+        unsigned off = 0, tot = 0;
+        bool over = false;
+#pragma unroll
+        for (int u = 0; u < 2 * FS_WAVES; ++u) {
+            const unsigned c = sh.cnt8[qq][u];
+            over = over || c > (unsigned)FS_SUB;
+            if (u < sl) off += c;
+            tot += c;
+        }
+        over = over || tot > (unsigned)FS_CAP;
+        if (!over && sh.bad[qq] == 0) {
+            const unsigned c = sh.cnt8[qq][sl];
+            for (unsigned i = 0; i < c; ++i) sh.cand[qq][off + i] = sh.sub[qq][sl][i];
+        }
+        if (sl == 0) {
+            if (over && sh.bad[qq] == 0) sh.bad[qq] = 1u;
+            sh.cnt[qq] = sh.bad[qq] ? 0u : tot;
+        }
+    }
+    __syncthreads();
     if (tid == 0) {
         unsigned acc = 0;
         for (int qq = 0; qq < FS_Q; ++qq) {
             sh.pre[qq] = acc;
-            unsigned c = sh.cnt[qq];
-            if (sh.bad[qq] == 0 && c > (unsigned)FS_CAP) {
-                sh.bad[qq] = 1u; // more rows inside the band than the list holds: exact scan for this query
-            }
-            if (sh.bad[qq]) c = 0;
-            sh.cnt[qq] = c;
-            acc += c;
+            acc += sh.cnt[qq];
         }
         sh.pre[FS_Q] = acc;
     }
     __syncthreads();
     if (tid < FS_Q && sh.bad[tid] == 1u) p.ovf_list[atomicAdd(p.ovf_cnt, 1u)] = (uint32_t)(q0 + tid);
+    // ---- exact distances of the candidates: (query, candidate) pairs dealt to the threads
     const unsigned total = sh.pre[FS_Q];
     u64* ekey = (u64*)&sh.cmax[0][0]; // [FS_Q][FS_CAP] (the maxima are dead)
-    u64 mine[(FS_Q * FS_CAP + FS_THREADS - 1) / FS_THREADS];
+    constexpr int NM = (FS_Q * FS_CAP + FS_THREADS - 1) / FS_THREADS;
+    u64 mine[NM];
+    uint16_t where[NM]; // query << 8 | position in its list
     int nmine = 0;
-    for (unsigned g = tid; g < total; g += FS_THREADS, ++nmine) {
+    {
         int qq = 0;
-        while (sh.pre[qq + 1] <= g) ++qq;
-        const unsigned row = sh.cand[qq][g - sh.pre[qq]];
+        for (unsigned g = tid; g < total; g += FS_THREADS, ++nmine) {
+            while (sh.pre[qq + 1] <= g) ++qq;
+            where[nmine] = (uint16_t)((qq << 8) | (int)(g - sh.pre[qq]));
+        }
+    }
+    for (int m_ = 0; m_ < nmine; ++m_) {
+        const int qq = where[m_] >> 8;
+        const unsigned row = sh.cand[qq][where[m_] & 255];
         const float* yr = p.xb + (int64_t)row * p.ldb;
         const float* qs = sh.qs[qq];
         float acc = 0.f;
-        // the chain of flat_scan_kernel / flat_rerank_kernel: 8-float steps, e and 4 + e interleaved
+        // the chain of flat_scan_kernel / flat_rerank_kernel: 8-float steps, e and 4 + e interleaved.  The row is a random
+        // 512-byte read: all its loads are issued before the chain consumes the first (one round trip per candidate)
         auto step = [&](const f32x4& y0, const f32x4& y1, int s) {
             const f32x4 x0 = *(const f32x4*)(qs + s), x1 = *(const f32x4*)(qs + s + 4);
 #pragma unroll
@@ -858,15 +891,23 @@ __global__ void __launch_bounds__(FS_THREADS, 2) flat_small_fused_kernel(FlatSma
                 acc = __fmaf_rn(y1[e], x1[e], acc);
             }
         };
-        int s = 0;
-        for (; s + 32 <= p.dpad; s += 32) {
-            f32x4 y[8];
+        if (p.dpad == 128) {
+            f32x4 y[32];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) y[u] = *(const f32x4*)(yr + s + 4 * u);
+            for (int u = 0; u < 32; ++u) y[u] = *(const f32x4*)(yr + 4 * u);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) step(y[2 * u], y[2 * u + 1], s + 8 * u);
+            for (int u = 0; u < 16; ++u) step(y[2 * u], y[2 * u + 1], 8 * u);
+        } else {
+            int s = 0;
+            for (; s + 32 <= p.dpad; s += 32) {
+                f32x4 y[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) y[u] = *(const f32x4*)(yr + s + 4 * u);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) step(y[2 * u], y[2 * u + 1], s + 8 * u);
+            }
+            for (; s < p.dpad; s += 8) step(*(const f32x4*)(yr + s), *(const f32x4*)(yr + s + 4), s);
         }
-        for (; s < p.dpad; s += 8) step(*(const f32x4*)(yr + s), *(const f32x4*)(yr + s + 4), s);
         float dis;
         if (METRIC == METRIC_L2) {
             dis = __fmaf_rn(-2.f, acc, sh.xn[qq] + p.xbn[row]);
@@ -874,27 +915,23 @@ __global__ void __launch_bounds__(FS_THREADS, 2) flat_small_fused_kernel(FlatSma
         } else {
             dis = acc;
         }
-        mine[nmine] = ((u64)ordkey<METRIC>(dis) << 32) | row;
+        mine[m_] = ((u64)ordkey<METRIC>(dis) << 32) | row;
     }
-    __syncthreads(); // (every candidate list has been read: the keys may overwrite the maxima)
-    nmine = 0;
-    for (unsigned g = tid; g < total; g += FS_THREADS, ++nmine) {
-        int qq = 0;
-        while (sh.pre[qq + 1] <= g) ++qq;
-        ekey[qq * FS_CAP + (g - sh.pre[qq])] = mine[nmine];
-    }
+    __syncthreads(); // (every maximum has long been read: the keys may overwrite them)
+    for (int m_ = 0; m_ < nmine; ++m_) ekey[(where[m_] >> 8) * FS_CAP + (where[m_] & 255)] = mine[m_];
     __syncthreads();
     // ---- exact top-k under (distance, id): every key straight to its rank
     const float pad = neutral_distance(METRIC);
-    nmine = 0;
-    for (unsigned g = tid; g < total; g += FS_THREADS, ++nmine) {
-        int qq = 0;
-        while (sh.pre[qq + 1] <= g) ++qq;
+    for (int m_ = 0; m_ < nmine; ++m_) {
+        const int qq = where[m_] >> 8;
         const int n = (int)sh.cnt[qq];
-        const u64 x = mine[nmine];
-        const u64* kk = ekey + qq * FS_CAP;
+        const u64 x = mine[m_];
+        const ulonglong2* kk = (const ulonglong2*)(ekey + qq * FS_CAP);
         int r = 0;
-        for (int i = 0; i < n; ++i) r += kk[i] < x ? 1 : 0;
+        for (int i = 0; i < n; i += 2) {
+            const ulonglong2 k2 = kk[i >> 1];
+            r += (k2.x < x ? 1 : 0) + ((i + 1 < n && k2.y < x) ? 1 : 0);
+        }
         if (r < p.k) {
             const uint32_t wk = (uint32_t)(x >> 32);
             const bool ok = wk < kInvalidOrdKey;
