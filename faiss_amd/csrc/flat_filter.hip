@@ -756,10 +756,13 @@ __global__ void __launch_bounds__(FS_THREADS, 2) flat_small_fused_kernel(FlatSma
         const float th = MODE == MODE_COLLECT ? sh.thr[j] : 0.f;
         uint16_t* mysub = sh.sub[j][2 * wave + h];
         unsigned nsub = 0;
+        // (operand-major copy of the rows, flat_operand_major_kernel: k-step s of block b = one contiguous KB, lane l its 16 bytes.
+        // From the row-major copy every load instruction touched 32 cache lines -- the L1's request rate, not bytes, paced the
+        // first version: 0.21 ms for the launch)
         auto loadblk = [&](int b, half8 (&a)[8]) __attribute__((always_inline)) {
-            const _Float16* r = p.xbh + (int64_t)(32 * b + j) * p.ldbh + 8 * h; // (rows behind nb: the padding tile)
+            const half8* r = (const half8*)p.xbo + (int64_t)b * 512 + lane;
 #pragma unroll
-            for (int s = 0; s < 8; ++s) a[s] = *(const half8*)(r + 16 * s);
+            for (int s = 0; s < 8; ++s) a[s] = r[64 * s];
         };
         half8 a0[8], a1[8], a2[8];
         int b = wave;
@@ -949,6 +952,25 @@ __global__ void __launch_bounds__(FS_THREADS, 2) flat_small_fused_kernel(FlatSma
     }
 }
 
+// operand-major fp16 copy of a small database for flat_small_fused_kernel: out[(b * 8 + s) * 64 + l] (16 bytes) = coordinates
+// 16 s + 8 (l >> 5) .. + 7 of row 32 b + (l & 31) -- what lane l feeds the MFMA of k-step s (rows behind nb: zeros)
+__global__ void flat_operand_major_kernel(const _Float16* __restrict__ xbh, int64_t ldbh, int nb, half8* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x; // (b * 8 + s) * 64 + l
+    const int nblk = (nb + 31) >> 5;
+    if (i >= nblk * 512) return;
+    const int l = i & 63, s = (i >> 6) & 7, b = i >> 9;
+    const int row = 32 * b + (l & 31);
+    half8 v = half8{0, 0, 0, 0, 0, 0, 0, 0};
+    if (row < nb) v = *(const half8*)(xbh + (int64_t)row * ldbh + 16 * s + 8 * (l >> 5));
+    out[i] = v;
+}
+void launch_flat_operand_major(const void* xbh, int64_t ldbh, int nb, void* out, hipStream_t stream) {
+    if (nb == 0) return;
+    const int n = ((nb + 31) >> 5) * 512;
+    hipLaunchKernelGGL(flat_operand_major_kernel, dim3((unsigned)div_up(n, 256)), dim3(256), 0, stream, (const _Float16*)xbh, ldbh, nb,
+                       (half8*)out);
+    HIP_CHECK(hipGetLastError());
+}
 bool flat_small_fused_supported(int metric, int nb, int d, int dh, int k) {
     const int nch = 2 * ((nb + 31) / 32);
     return (metric == METRIC_L2 || metric == METRIC_INNER_PRODUCT) && dh == 128 && d <= 128 && nb <= 32 * (FS_MAXCH / 2) &&
@@ -956,7 +978,7 @@ bool flat_small_fused_supported(int metric, int nb, int d, int dh, int k) {
 }
 void launch_flat_small_fused(const FlatSmallParams& p, hipStream_t stream) {
     if (p.nq == 0) return;
-    FA_THROW_IF_NOT(flat_small_fused_supported(p.metric, p.nb, p.d, (int)p.ldbh, p.k) && p.dpad <= 128 && p.dpad % 8 == 0 && p.xb);
+    FA_THROW_IF_NOT(flat_small_fused_supported(p.metric, p.nb, p.d, (int)p.ldbh, p.k) && p.dpad <= 128 && p.dpad % 8 == 0 && p.xb && p.xbo);
     const dim3 grid((unsigned)div_up(p.nq, FS_Q)), block(FS_THREADS);
     if (p.metric == METRIC_L2) hipLaunchKernelGGL((flat_small_fused_kernel<METRIC_L2>), grid, block, 0, stream, p);
     else hipLaunchKernelGGL((flat_small_fused_kernel<METRIC_INNER_PRODUCT>), grid, block, 0, stream, p);

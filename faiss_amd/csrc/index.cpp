@@ -406,6 +406,7 @@ const float* GpuIndexFlat::rows_f32_(DevBuf& tmp) const {
 
 void GpuIndexFlat::reset() {
     std::lock_guard<std::mutex> g(mu_);
+    xbo_rows_ = -1;
     ntotal = 0;
     yn_max_ = 0.f;
     db_f16_ok_ = true;
@@ -419,6 +420,7 @@ void GpuIndexFlat::add(idx_t n, const float* x) {
     FA_THROW_IF_NOT_MSG(ntotal + n < ((idx_t)1 << 31), "at most 2^31-1 vectors per device index");
     std::lock_guard<std::mutex> g(mu_);
     res_->set_device();
+    xbo_rows_ = -1; // (the operand-major copy of a small database is rebuilt by the next search that wants it)
     const size_t row = (size_t)dpad_ * sizeof(float);
     if (!use_float16_) xb_.ensure((size_t)(ntotal + n) * row, (size_t)ntotal * row, res_->stream);
     xbn_.ensure((size_t)(ntotal + n) * sizeof(float), (size_t)ntotal * sizeof(float), res_->stream);
@@ -896,8 +898,14 @@ void GpuIndexFlat::search_tile_(int n, const float* xq_pad, int k, float* dD, id
             launch_prep_queries(xq_pad, dpad_, n, d, dpad_, qh_.p, dh_, flags_.as<uint32_t>(), q_norm_.as<float>(),
                                 scal_.as<unsigned>() + 2, R.stream);
         }
+        if (xbo_rows_ != ntotal) { // (operand-major copy of the fp16 rows: rebuilt behind add() / reset(), <= 1 MB)
+            xbo_.ensure((size_t)div_up(nb, 32) * 8192);
+            launch_flat_operand_major(xbh_.p, dh_, nb, xbo_.p, R.stream);
+            xbo_rows_ = ntotal;
+        }
         FlatSmallParams sp{};
         sp.metric = metric_type, sp.nq = n, sp.nb = nb, sp.d = d, sp.dpad = dpad_, sp.k = k;
+        sp.xbo = xbo_.p;
         sp.xqh = qh_.as<_Float16>(), sp.ldqh = dh_;
         sp.xq = xq_pad, sp.ldq = dpad_;
         sp.xqn = q_norm_.as<float>();

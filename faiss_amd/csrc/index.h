@@ -292,6 +292,9 @@ class GpuIndexFlat : public Index {
     // fp16 shadow copy for the filter kernel: rows padded to dh_ (multiple of 128) halfs, |y|^2/2
     int dh_;
     DevBuf xbh_, xbhn_;
+    // operand-major copy of xbh_ for the one-launch kernel of small databases (flat_small_fused_kernel); valid for xbo_rows_ rows
+    mutable DevBuf xbo_;
+    mutable idx_t xbo_rows_ = -1;
     DevBuf scal_;            // device scalars: [0] max |x| bits, [1] max |y|^2 bits, [2] overflow counter
     // pinned host word the overflow count of a filter search is copied to (a pageable destination would make the 4-byte
     // read-back a staged, blocking copy: tens of microseconds on every search)

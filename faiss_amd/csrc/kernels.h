@@ -153,6 +153,7 @@ struct FlatSmallParams {
     const uint32_t* flags; // [nq] fp16 range / NaN flags of the queries (prep_queries)
     const _Float16* xbh;   // [nb + tile][ldbh] fp16 rows
     int64_t ldbh;
+    const void* xbo; // the same rows operand-major (launch_flat_operand_major): [ceil(nb / 32)][8 k-steps][64 lanes][16 bytes]
     const float* xbhn; // [nb + 64] -|y|^2 / 2 (L2) / 0 (IP), then -inf
     const float* xb;   // [nb][ldb] fp32 rows
     int64_t ldb;
@@ -164,6 +165,7 @@ struct FlatSmallParams {
     unsigned* ovf_cnt;
 };
 bool flat_small_fused_supported(int metric, int nb, int d, int dh, int k);
+void launch_flat_operand_major(const void* xbh, int64_t ldbh, int nb, void* out, hipStream_t stream);
 void launch_flat_small_fused(const FlatSmallParams& p, hipStream_t stream);
 
 struct FlatRerankParams {
