@@ -759,17 +759,18 @@ __global__ void __launch_bounds__(FS_THREADS, 2) flat_small_fused_kernel(FlatSma
         // (operand-major copy of the rows, flat_operand_major_kernel: k-step s of block b = one contiguous KB, lane l its 16 bytes.
         // From the row-major copy every load instruction touched 32 cache lines -- the L1's request rate, not bytes, paced the
         // first version: 0.21 ms for the launch)
+        // (UNCONDITIONAL: behind the last block the loads re-read it -- a branch around a prefetch makes hipcc wait vmcnt(0) at the
+        // join, i.e. for the prefetch it has just issued: 1700 cycles per block in the first version)
         auto loadblk = [&](int b, half8 (&a)[8]) __attribute__((always_inline)) {
-            const half8* r = (const half8*)p.xbo + (int64_t)b * 512 + lane;
+            const half8* r = (const half8*)p.xbo + (int64_t)min(b, nblk - 1) * 512 + lane;
 #pragma unroll
             for (int s = 0; s < 8; ++s) a[s] = r[64 * s];
         };
+        // three blocks of loads ahead of the MFMAs in three named buffers: the loop is unrolled by three so that no buffer is ever
+        // COPIED (a rotating copy waits for the newest load before it moves it: one block of look-ahead instead of three --
+        // 1700 cycles per block in the first version, an L2 round trip each)
         half8 a0[8], a1[8], a2[8];
-        int b = wave;
-        if (b < nblk) loadblk(b, a0);
-        if (b + FS_WAVES < nblk) loadblk(b + FS_WAVES, a1);
-        if (b + 2 * FS_WAVES < nblk) loadblk(b + 2 * FS_WAVES, a2);
-        for (; b < nblk; b += FS_WAVES) {
+        auto block = [&](int b, half8 (&a)[8]) __attribute__((always_inline)) {
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -777,18 +778,15 @@ __global__ void __launch_bounds__(FS_THREADS, 2) flat_small_fused_kernel(FlatSma
 #pragma unroll
             for (int g = 0; g < 4; ++g) bias[g] = *(const f32x4*)(p.xbhn + 32 * b + 8 * g + 4 * h);
 #pragma unroll
-            for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[s], bq[s], acc, 0, 0, 0);
-#pragma unroll
-            for (int s = 0; s < 8; ++s) a0[s] = a1[s], a1[s] = a2[s];
-            if (b + 3 * FS_WAVES < nblk) loadblk(b + 3 * FS_WAVES, a2);
+            for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s], bq[s], acc, 0, 0, 0);
+            loadblk(b + 3 * FS_WAVES, a);
             float sc[16], m = -INFINITY;
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int row = 32 * b + 8 * g + 4 * h + e;
-                    float v = acc[4 * g + e] + bias[g][e];
-                    v = row < p.nb ? v : -INFINITY;
+                    // (rows behind nb: their bias is the -inf padding of xbhn, 64 rows of it -- no test)
+                    const float v = acc[4 * g + e] + bias[g][e];
                     sc[4 * g + e] = v;
                     m = fmaxf(m, v); // (drops a NaN score like the general path's v_max3)
                 }
@@ -802,26 +800,52 @@ __global__ void __launch_bounds__(FS_THREADS, 2) flat_small_fused_kernel(FlatSma
                         ++nsub;
                     }
             }
+        };
+        int b = wave;
+        loadblk(b, a0);
+        loadblk(b + FS_WAVES, a1);
+        loadblk(b + 2 * FS_WAVES, a2);
+        for (; b < nblk; b += 3 * FS_WAVES) {
+            block(b, a0);
+            if (b + FS_WAVES < nblk) block(b + FS_WAVES, a1);
+            if (b + 2 * FS_WAVES < nblk) block(b + 2 * FS_WAVES, a2);
         }
         if (MODE == MODE_COLLECT) sh.cnt8[j][2 * wave + h] = nsub;
     };
+#ifdef FS_TIMING
+    unsigned long long tm[8];
+    int tmi = 0;
+#define FS_MARK() tm[tmi++] = __builtin_readcyclecounter()
+#else
+#define FS_MARK()
+#endif
+    FS_MARK();
     sweep(std::integral_constant<int, MODE_MAX>{});
     __syncthreads();
-    // ---- thresholds: wave w serves queries 8 w .. 8 w + 7; k-th smallest score key of the nch maxima by bisection on the bits
-    for (int qi = 0; qi < FS_Q / FS_WAVES; ++qi) {
-        const int qq = (FS_Q / FS_WAVES) * wave + qi;
-        uint32_t key[4];
+    FS_MARK();
+    // ---- thresholds: wave w serves queries 8 w .. 8 w + 7, EIGHT LANES per query (32 maxima each); k-th smallest score key of the
+    // nch maxima by bisection on the bits, all eight queries of the wave at once (the first version bisected one query at a
+    // time through ballots: 256 dependent VALU -> SALU round trips per wave, 23 us)
+    {
+        const int qq = (FS_Q / FS_WAVES) * wave + (lane >> 3), sl = lane & 7;
+        uint32_t key[FS_MAXCH / 8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) key[u] = lane + 64 * u < nch ? score_key(sh.cmax[qq][lane + 64 * u]) : 0xffffffffu;
+        for (int u = 0; u < FS_MAXCH / 8; ++u) key[u] = 8 * u + sl < nch ? score_key(sh.cmax[qq][8 * u + sl]) : 0xffffffffu;
         uint32_t pre = 0;
         for (int bit = 31; bit >= 0; --bit) {
             const uint32_t cand = pre | ((1u << bit) - 1u); // (keys <= cand: this bit clear under the prefix found so far)
-            int c = 0;
+            // keys <= cand, counted through the borrow of cand - key (a v_cmp -> v_cndmask pair per key costs two wait states on the
+            // condition register each: 27 000 cycles for the 32 x 32 compares of a lane in the first version)
+            int c = FS_MAXCH / 8;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) c += __popcll(__ballot(key[u] <= cand));
+            for (int u = 0; u < FS_MAXCH / 8; ++u) c += (int)(((unsigned long long)cand - (unsigned long long)key[u]) >> 32);
+            // sum over the eight lanes of the query: quad swaps, then the mirrored lane of the other quad
+            c += __builtin_amdgcn_update_dpp(0, c, 0xB1, 0xf, 0xf, false);  // quad_perm [1, 0, 3, 2]
+            c += __builtin_amdgcn_update_dpp(0, c, 0x4E, 0xf, 0xf, false);  // quad_perm [2, 3, 0, 1]
+            c += __builtin_amdgcn_update_dpp(0, c, 0x141, 0xf, 0xf, false); // row_half_mirror
             if (c < p.k) pre |= 1u << bit;
         }
-        if (lane == 0) {
+        if (sl == 0) {
             const float e = flat_filter_err_bound(METRIC, p.d, sh.xn[qq], p.yn_max, false);
             const float tk = key_score(pre);
             sh.thr[qq] = (sh.bad[qq] || !(e < FLT_MAX)) ? INFINITY : (tk > -INFINITY ? band_threshold(tk, e) : -INFINITY);
@@ -829,8 +853,10 @@ __global__ void __launch_bounds__(FS_THREADS, 2) flat_small_fused_kernel(FlatSma
         }
     }
     __syncthreads();
+    FS_MARK();
     sweep(std::integral_constant<int, MODE_COLLECT>{});
     __syncthreads();
+    FS_MARK();
     // ---- the eight lane lists of a query -> one list (thread = (query, list)); a list or a query that overflowed: exact scan
     {
         const int qq = tid >> 3, sl = tid & 7;
@@ -864,6 +890,7 @@ __global__ void __launch_bounds__(FS_THREADS, 2) flat_small_fused_kernel(FlatSma
     }
     __syncthreads();
     if (tid < FS_Q && sh.bad[tid] == 1u) p.ovf_list[atomicAdd(p.ovf_cnt, 1u)] = (uint32_t)(q0 + tid);
+    FS_MARK();
     // ---- exact distances of the candidates: (query, candidate) pairs dealt to the threads
     const unsigned total = sh.pre[FS_Q];
     u64* ekey = (u64*)&sh.cmax[0][0]; // [FS_Q][FS_CAP] (the maxima are dead)
@@ -920,6 +947,7 @@ __global__ void __launch_bounds__(FS_THREADS, 2) flat_small_fused_kernel(FlatSma
         }
         mine[m_] = ((u64)ordkey<METRIC>(dis) << 32) | row;
     }
+    FS_MARK();
     __syncthreads(); // (every maximum has long been read: the keys may overwrite them)
     for (int m_ = 0; m_ < nmine; ++m_) ekey[(where[m_] >> 8) * FS_CAP + (where[m_] & 255)] = mine[m_];
     __syncthreads();
@@ -950,6 +978,12 @@ __global__ void __launch_bounds__(FS_THREADS, 2) flat_small_fused_kernel(FlatSma
             p.out_ids[(int64_t)(q0 + qq) * p.k + r] = -1;
         }
     }
+    FS_MARK();
+#ifdef FS_TIMING
+    if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 200))
+        printf("fs timing block %d: pass1 %llu select %llu pass2 %llu merge %llu rerank %llu rank+out %llu (cycles) total cand %u\n", (int)blockIdx.x,
+               tm[1] - tm[0], tm[2] - tm[1], tm[3] - tm[2], tm[4] - tm[3], tm[5] - tm[4], tm[6] - tm[5], total);
+#endif
 }
 
 // operand-major fp16 copy of a small database for flat_small_fused_kernel: out[(b * 8 + s) * 64 + l] (16 bytes) = coordinates
