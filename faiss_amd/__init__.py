@@ -131,6 +131,7 @@ def load_library():
         "faiss_amd_GpuIndexIVFPQ_set_lmf_two_copies": (i32, [vp, i32]),
         "faiss_amd_GpuIndexIVFPQ_set_lmf_fast_gather": (i32, [vp, i32]),
         "faiss_amd_Index_set_small_fused": (i32, [vp, i32]),
+        "faiss_amd_GpuIndexIVF_set_lmf_pair": (i32, [vp, i32]),
         "faiss_amd_GpuIndexIVF_list_major_rule": (i32, [vp, i64, i32, i64, P(i32)]),
         "faiss_amd_GpuIndexFlat_set_use_filter_kernel": (i32, [vp, i32, i64]),
         "faiss_amd_GpuIndexFlat_filter_stats": (i32, [vp, P(i32), P(i32)]),
@@ -523,6 +524,9 @@ class _GpuIndexIVF(Index):
             self._keep.append(quantizer)
             self.quantizer = quantizer
         return quantizer._h if quantizer is not None else None
+
+    def set_lmf_pair(self, on):
+        _check(self._lib.faiss_amd_GpuIndexIVF_set_lmf_pair(self._h, int(bool(on))))
 
     def quantizer_info(self):
         """(own_fields, the quantizer stores fp16, IndicesOptions)"""

@@ -1037,6 +1037,11 @@ int faiss_amd_GpuIndexIVF_set_lmf_sampling(FaissAmdIndex* index, int sample_shif
     as<GpuIndexIVF>(index, "GpuIndexIVF")->lmf_sample_shift = sample_shift;
     FA_CATCH
 }
+int faiss_amd_GpuIndexIVF_set_lmf_pair(FaissAmdIndex* index, int on) {
+    FA_TRY
+    as<GpuIndexIVF>(index, "GpuIndexIVF")->lmf_pair = on != 0;
+    FA_CATCH
+}
 int faiss_amd_Index_set_small_fused(FaissAmdIndex* index, int on) {
     FA_TRY
     if (auto* ivf = dynamic_cast<GpuIndexIVF*>(I(index))) ivf->quantizer->use_small_fused = on != 0;

@@ -403,6 +403,9 @@ class GpuIndexIVF : public Index {
     void arena_stats(int64_t* used, int64_t* holes, int64_t* allocated) const;
     // Clustering parameters used by train() (reference default niter=10 for the GPU IVF
     // quantizer, faiss/gpu/GpuIndexIVF.cu:80)
+    // filter sweeps of IVFFlat / the scalar quantizer (rows of <= 128 coordinates): two-wave workgroups that walk sibling items -- the
+    // query groups of one (list, row chunk) -- in lock-step (ivf_lm_filter.hip PAIR, round 6); off = a wavefront per item (A/B knob)
+    bool lmf_pair = true;
     int cp_niter = 10;
     int cp_seed = 1234;
     // the rest of GpuIndexIVF::cp (faiss/gpu/GpuIndexIVF.h, faiss/Clustering.h:27-60); niter / seed above win

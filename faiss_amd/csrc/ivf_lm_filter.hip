@@ -648,9 +648,17 @@ struct LmfDraw {
 // and the next one looked at.
 // PAIRB (scalar quantizer): the B operands and the query terms are per (query, probe) PAIR -- pair16 / pair_xh, prepared once per
 // search by lmf_sq_prepare_kernel -- instead of per query; the A operands are the fp16 copy of the centred codes.
-template <int METRIC, int MODE, int NQB, int KS, bool FULL, bool SEL, bool PAIRB>
-__global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams p) {
+// PAIR (round 6): two-wave workgroups that walk the two query groups of a (list, row chunk) IN LOCK-STEP.  A list
+// probed by more than 96 queries of the batch is an item per group of 96, and every group streams the chunk's rows again: 1.41 x
+// the unique bytes per sweep at nb = 10M although sibling items are drawn back to back on one XCD -- two free-running wavefronts
+// drift apart by more than the few microseconds a line survives in a 4 MB L2 that turns over at 0.6 TB/s.  Here the workgroup draws
+// ONE item; if the next item is its sibling (same list, same chunk, next group) wave 1 takes that one and the two waves meet at a
+// barrier before every 32-row block: the second read of a block hits the CU's L1 / the XCD's L2.  Without a sibling the two waves
+// split the item's rows.  (The drawer of a sibling item skips it: it belongs to the workgroup that drew the item in front.)
+template <int METRIC, int MODE, int NQB, int KS, bool FULL, bool SEL, bool PAIRB, bool PAIR = false>
+__global__ void __launch_bounds__(PAIR ? 128 : LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams p) {
     static_assert(KS == 8 || (FULL && (KS == 16 || KS == 24 || KS == 32)), "k-steps");
+    constexpr int NW = PAIR ? 2 : 4; // wavefronts per workgroup
     constexpr int R = KS == 8 ? 8 : KS / 2; // (KS % R == 0: slot s % R holds k-step s of the block at its start)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -664,12 +672,13 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
     const _Float16* xq16 = (const _Float16*)p.xq16;
     const _Float16* arena_h = (const _Float16*)p.arena_h;
     u64* pk_keys = (u64*)smem + wave * LF_PARK;
-    uint32_t* pk_q = (uint32_t*)(smem + 4 * LF_PARK * 8) + wave * LF_PARK;
+    uint32_t* pk_q = (uint32_t*)(smem + NW * LF_PARK * 8) + wave * LF_PARK;
     // |y|^2 of the rows of TWO consecutive blocks of this wave (see the block loop)
-    __shared__ float rn_lds_all[4][64];
+    __shared__ float rn_lds_all[NW][64];
+    __shared__ uint32_t pair_it; // PAIR: the item the workgroup drew
     float* rn_lds = rn_lds_all[wave];
     int wcnt = 0; // (wave-uniform) parked candidates
-    LmfStage<64> st{smem + 4 * LF_PARK * 12 + wave * LS_WAVE, 0};
+    LmfStage<64> st{smem + NW * LF_PARK * 12 + wave * LS_WAVE, 0};
     auto flush = [&]() __attribute__((always_inline)) {
         for (int e = lane; e < wcnt; e += 64) {
             const u64 key = pk_keys[e];
@@ -694,9 +703,35 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
     const uint32_t it0 = p.item_bounds[1], it1 = p.item_bounds[2];
     LmfDraw draw(p.item_bounds, MODE == MODE_MIN ? 0 : 1, it0, it1);
     for (;;) {
-        const uint32_t it = draw.next(lane);
+        uint32_t it;
+        if (PAIR) {
+            if (wave == 0) {
+                it = draw.next(lane);
+                if (lane == 0) pair_it = it;
+            }
+            __syncthreads();
+            it = pair_it;
+            __syncthreads(); // (wave 0 must not draw again before wave 1 has read the word)
+        } else {
+            it = draw.next(lane);
+        }
         if (it >= it1) break;
-        const IvfLmItem item = p.items[it];
+        IvfLmItem item = p.items[it];
+        bool paired = false;
+        if (PAIR) {
+            // (all of this is wave- and workgroup-uniform: both waves see the same items)
+            if ((item.qt & 1) && it > it0) {
+                const IvfLmItem pv = p.items[it - 1];
+                const bool follower = pv.bucket == item.bucket && pv.rt == item.rt && pv.both == item.both && pv.qt + 1 == item.qt;
+                if (__builtin_amdgcn_readfirstlane((int)follower)) continue;
+            }
+            if (!(item.qt & 1) && it + 1 < it1) {
+                const IvfLmItem nx = p.items[it + 1];
+                paired = nx.bucket == item.bucket && nx.rt == item.rt && nx.both == item.both && nx.qt == item.qt + 1;
+                paired = __builtin_amdgcn_readfirstlane((int)paired) != 0;
+                if (paired && wave == 1) item = nx;
+            }
+        }
         const int bk = __builtin_amdgcn_readfirstlane(item.bucket);
         const int qt = __builtin_amdgcn_readfirstlane(item.qt);
         const int rt = __builtin_amdgcn_readfirstlane(item.rt);
@@ -710,8 +745,16 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
         // sweep 1 may look at a prefix of the chunk only (IvfLmParams::sample_rows): rows [r0, rend); its granule slots are
         // then numbered over the sampled granules of the list (ivf_lmf_list_granules)
         const bool smp = MODE == MODE_MIN && p.sample_rows > 0 && p.sample_rows < p.rows_per_item;
-        const int rend = smp ? min(r1, r0 + p.sample_rows) : r1;
+        const int rend_item = smp ? min(r1, r0 + p.sample_rows) : r1;
         const int gbase = smp ? rt * (p.sample_rows >> (5 + gsh)) - ((r0 >> 5) >> gsh) : 0;
+        // PAIR without a sibling: the two waves split the rows at a granule boundary (a granule's minimum has ONE writer)
+        int ra = r0, rend = rend_item;
+        if (PAIR && !paired) {
+            const int gr = (32 << gsh) * (MODE == MODE_MIN ? p.min_stride : 1);
+            const int mid = min(rend_item, r0 + (((rend_item - r0 + 1) / 2 + gr - 1) / gr) * gr);
+            if (wave == 0) rend = mid;
+            else ra = mid;
+        }
 
         // ---- this lane's queries: one per 32-query block
         LmfLane L[NQB];
@@ -741,7 +784,7 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
             if (MODE == MODE_DUMP) L[b].kq = p.keys + (int64_t)q * p.stride + L[b].base_pos;
         }
 
-        int t = r0;
+        int t = PAIR ? ra : r0;
         while (t < rend) {
             // ---- (re-)entry: the rows of block t.  Rows behind the end of the list belong to the next list or the
             // arena's padding: loaded, never looked at.
@@ -774,6 +817,7 @@ __global__ void __launch_bounds__(LF_THREADS, 2) ivf_lmf_flat_kernel(IvfLmParams
             float pf0 = rn_fetch(0), pf1 = rn_fetch(1), pf2 = rn_fetch(2), pf3 = rn_fetch(3);
             int bi = 0; // blocks of this run so far
             for (; t < rend; t += bstep, ++bi) {
+                if (PAIR && paired) __syncthreads(); // lock-step with the sibling item's wave (same rows, same trip count)
                 const _Float16* acur = arow; // (KS > R: the ring refills from this block first)
                 arow += (bstep >> 5) * nks * 512;
                 if (METRIC == METRIC_L2) { // (no branch: unconditional loads keep the compiler counting them)
@@ -1321,6 +1365,14 @@ int ivf_lmf_grid_blocks(const IvfLmParams& p, int num_cus) {
 template <int METRIC, int MODE, bool SEL, bool PAIRB>
 static void lmf_flat_launch(const IvfLmParams& p, int grid_blocks, hipStream_t stream) {
     const int lds = MODE == MODE_COLLECT ? LF_LDS : 0;
+    if constexpr (MODE != MODE_DUMP && !SEL) {
+        if (p.lmf_pair && p.ldh == 128) { // two-wave workgroups in lock-step over sibling items (round 6): twice the workgroups
+            auto kern = ivf_lmf_flat_kernel<METRIC, MODE, kLmfQueryBlocks, 8, true, SEL, PAIRB, true>;
+            HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LF_LDS / 2));
+            hipLaunchKernelGGL(kern, dim3((unsigned)(2 * grid_blocks)), dim3(128), MODE == MODE_COLLECT ? LF_LDS / 2 : 0, stream, p);
+            return;
+        }
+    }
 #define FA_LF(NQB_, KS_, FULL_)                                                                                                \
     do {                                                                                                                       \
         HIP_CHECK(hipFuncSetAttribute((const void*)ivf_lmf_flat_kernel<METRIC, MODE, NQB_, KS_, FULL_, SEL, PAIRB>,            \

@@ -533,6 +533,7 @@ struct IvfLmParams {
     // code -> bank maps, the copy of every (row, sub-quantizer) chosen when the copy of the codes was written so that the
     // gathers of a 32-lane group spread over the banks (ivf_lm_filter.hip, lmf_code_choice_kernel): 40 bytes per lane and block
     int cs_choice;
+    int lmf_pair;        // IVFFlat / scalar-quantizer sweeps at <= 128 coordinates: two-wave workgroups in lock-step over sibling items (round 6)
     int lmf_fast_gather; // IVFPQ sweeps at PQ64 over d = 128, one copy: one-instruction codebook gathers (ivf_lm_filter.hip FG, round 6)
     const void* pq16;           // [M][256][dsub] fp16 codebook (kind 1)
     const float* pq_t;          // [256][M][dsub] fp32 codebook, transposed: the order the exact path builds its table in

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
                         "faiss_amd_GpuIndexIVF_set_lmf_tuning", "faiss_amd_GpuIndexIVF_test_filter_dump",
                         "faiss_amd_GpuIndexIVF_set_lmf_sampling", "faiss_amd_GpuIndexIVFPQ_set_lmf_two_copies",
                         "faiss_amd_GpuIndexIVFPQ_set_lmf_fast_gather", "faiss_amd_sq_train_rangestat",
-                        "faiss_amd_Index_set_small_fused"}
+                        "faiss_amd_Index_set_small_fused", "faiss_amd_GpuIndexIVF_set_lmf_pair"}
     assert not (public & internal)
     lib = ctypes.CDLL(faiss_amd.LIB_PATH)
     missing = [s for s in sorted(public | internal) if not hasattr(lib, s)]

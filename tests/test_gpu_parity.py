@@ -1075,7 +1075,7 @@ def test_gpu_parameter_space_and_interrupt(res):
     ivf.train(xt)
     ivf.add(xb)
     ps = faiss_amd.GpuParameterSpace()
-    assert ps.initialize(ivf)["nprobe"] == [1, 2, 4, 8, 16]
+    assert ps.initialize(ivf)["nprobe"] == [1, 2, 4, 8]  # (below nlist = 16, like the reference: GpuAutoTune.cpp:57-63)
     ps.set_index_parameters(ivf, "nprobe=8")
     assert ivf.nprobe == 8
     sh = faiss_amd.IndexShards(d, threaded=False, successive_ids=False)

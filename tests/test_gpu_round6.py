@@ -302,3 +302,30 @@ def test_ivf_search_with_the_one_launch_coarse_quantizer(res):
     Dc0, Ic0 = idx.quantizer_search(xq, 32)
     assert np.array_equal(Ic1, Ic0) and np.array_equal(Dc1, Dc0)
     assert np.array_equal(I1, I0) and np.array_equal(D1, D0)
+
+
+@pytest.mark.parametrize("kind,metric", [(0, METRIC_L2), (0, METRIC_INNER_PRODUCT), (2, METRIC_L2)])
+def test_lock_step_pair_sweeps_return_the_same_bits(res, kind, metric):
+    """ivf_lm_filter.hip PAIR: two-wave workgroups walk the query groups of a (list, row chunk) in lock-step, or
+    split an item's rows when it has no sibling.  Few lists + many queries: every list is probed by several groups of 96 queries;
+    uneven list lengths and a batch that is not a multiple of anything.  Same results as a free-running wavefront per item and as
+    the query-major scan; also with sampling of sweep 1 forced on (split rows at granule boundaries)."""
+    d, nlist, nb, nq, k = 128, 24, 90000, 3001, 40
+    xt, xb, xq = synthetic_dataset(d, 6000, nb, nq, seed=73)
+    if kind == 0:
+        idx = faiss_amd.GpuIndexIVFFlat(res, d, nlist, metric)
+    else:
+        idx = faiss_amd.GpuIndexIVFScalarQuantizer(res, d, nlist, faiss_amd.ScalarQuantizer.QT_8bit, metric, True)
+    idx.train(xt)
+    idx.add(xb)
+    idx.nprobe = 6
+    idx.set_scan_mode(idx.SCAN_QUERY_MAJOR)
+    Dq, Iq = idx.search(xq, k)
+    idx.set_scan_mode(idx.SCAN_LIST_MAJOR)
+    for sampling in (0, 2, -1):
+        idx.set_lmf_sampling(sampling)
+        for on in (True, False):
+            idx.set_lmf_pair(on)
+            D, I = idx.search(xq, k)
+            assert idx.scan_info()[1] == 2 and idx.last_scan_arith() == 0
+            assert np.array_equal(I, Iq) and np.array_equal(D, Dq), (sampling, on)
