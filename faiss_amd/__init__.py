@@ -526,7 +526,7 @@ class _GpuIndexIVF(Index):
         return quantizer._h if quantizer is not None else None
 
     def set_lmf_pair(self, on):
-        _check(self._lib.faiss_amd_GpuIndexIVF_set_lmf_pair(self._h, int(bool(on))))
+        _check(self._lib.faiss_amd_GpuIndexIVF_set_lmf_pair(self._h, int(on)))  # 0 off, 1 sweep 1 only (default), 2 both sweeps
 
     def quantizer_info(self):
         """(own_fields, the quantizer stores fp16, IndicesOptions)"""

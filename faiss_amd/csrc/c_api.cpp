@@ -1039,7 +1039,8 @@ int faiss_amd_GpuIndexIVF_set_lmf_sampling(FaissAmdIndex* index, int sample_shif
 }
 int faiss_amd_GpuIndexIVF_set_lmf_pair(FaissAmdIndex* index, int on) {
     FA_TRY
-    as<GpuIndexIVF>(index, "GpuIndexIVF")->lmf_pair = on != 0;
+    FA_THROW_IF_NOT_MSG(on >= 0 && on <= 2, "0 off, 1 sweep 1 only, 2 both sweeps");
+    as<GpuIndexIVF>(index, "GpuIndexIVF")->lmf_pair = on;
     FA_CATCH
 }
 int faiss_amd_Index_set_small_fused(FaissAmdIndex* index, int on) {

@@ -33,7 +33,7 @@ int faiss_amd_GpuIndexIVF_set_lmf_sampling(FaissAmdIndex* index, int sample_shif
  * choice stored with the sweeps' copy of the codes (on) against the one-copy sweeps (off, the DEFAULT: measured slower).  Results never change. */
 int faiss_amd_GpuIndexIVFPQ_set_lmf_two_copies(FaissAmdIndex* index, int on);
 /* A/B knob of the IVFFlat / scalar-quantizer filter sweeps (rows of <= 128 coordinates): two-wave workgroups in lock-step over the
- * query groups of a (list, row chunk) (on, the default since round 6) against a free-running wavefront per item (off). */
+ * query groups of a (list, row chunk): 0 = a free-running wavefront per item, 1 = sweep 1 only (the default), 2 = both sweeps. */
 int faiss_amd_GpuIndexIVF_set_lmf_pair(FaissAmdIndex* index, int on);
 /* A/B knob of flat searches over <= 4096 rows with k <= 64 (the coarse quantizer of an IVF index; `index` = a GpuIndexFlat or a
  * GpuIndexIVF, whose quantizer is meant): the one-launch kernel of round 6 (on, the default) against the general launches. */

@@ -2930,7 +2930,7 @@ void GpuIndexIVF::search_listmajor_filter_chunk_(int ni, int q0, const float* xq
     P.ovf = lm_ovf_.as<uint32_t>();
     P.qflags = lm_qflags_.as<uint32_t>();
     P.sel_mask = cur_sel_mask_;
-    P.lmf_pair = lmf_pair ? 1 : 0;
+    P.lmf_pair = lmf_pair;
     // ---- queries: fp16 copy + range flags + |q|^2 (the sequential chain of the flat index)
     {
         SpanGuard sg(&R, "ivf_lmf_prepare");

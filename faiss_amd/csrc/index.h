@@ -405,7 +405,7 @@ class GpuIndexIVF : public Index {
     // quantizer, faiss/gpu/GpuIndexIVF.cu:80)
     // filter sweeps of IVFFlat / the scalar quantizer (rows of <= 128 coordinates): two-wave workgroups that walk sibling items -- the
     // query groups of one (list, row chunk) -- in lock-step (ivf_lm_filter.hip PAIR, round 6); off = a wavefront per item (A/B knob)
-    bool lmf_pair = true;
+    int lmf_pair = 1; // 0 off, 1 sweep 1 only (measured: the only place it pays), 2 both sweeps
     int cp_niter = 10;
     int cp_seed = 1234;
     // the rest of GpuIndexIVF::cp (faiss/gpu/GpuIndexIVF.h, faiss/Clustering.h:27-60); niter / seed above win

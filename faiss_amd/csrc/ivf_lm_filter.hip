@@ -1366,7 +1366,9 @@ template <int METRIC, int MODE, bool SEL, bool PAIRB>
 static void lmf_flat_launch(const IvfLmParams& p, int grid_blocks, hipStream_t stream) {
     const int lds = MODE == MODE_COLLECT ? LF_LDS : 0;
     if constexpr (MODE != MODE_DUMP && !SEL) {
-        if (p.lmf_pair && p.ldh == 128) { // two-wave workgroups in lock-step over sibling items (round 6): twice the workgroups
+        // two-wave workgroups in lock-step over sibling items (round 6): twice the workgroups.  lmf_pair 1: sweep 1 only (the
+        // default: measured faster there, slower in sweep 2 -- DESIGN 3.12), 2: both sweeps
+        if ((p.lmf_pair == 2 || (p.lmf_pair == 1 && MODE == MODE_MIN)) && p.ldh == 128) {
             auto kern = ivf_lmf_flat_kernel<METRIC, MODE, kLmfQueryBlocks, 8, true, SEL, PAIRB, true>;
             HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LF_LDS / 2));
             hipLaunchKernelGGL(kern, dim3((unsigned)(2 * grid_blocks)), dim3(128), MODE == MODE_COLLECT ? LF_LDS / 2 : 0, stream, p);

@@ -324,7 +324,7 @@ def test_lock_step_pair_sweeps_return_the_same_bits(res, kind, metric):
     idx.set_scan_mode(idx.SCAN_LIST_MAJOR)
     for sampling in (0, 2, -1):
         idx.set_lmf_sampling(sampling)
-        for on in (True, False):
+        for on in (2, 1, 0):
             idx.set_lmf_pair(on)
             D, I = idx.search(xq, k)
             assert idx.scan_info()[1] == 2 and idx.last_scan_arith() == 0

@@ -26,7 +26,7 @@ def ab(idx, label):
     print(label, flush=True)
     for rep in range(3):
         for on in (0, 1):
-            idx.set_lmf_pair(on)
+            idx.set_lmf_pair(2 * on)  # both sweeps
             for _ in range(3):
                 idx.search_ptr(10000, xq_dev.data_ptr(), 100, D[on].data_ptr(), I[on].data_ptr())
             torch.cuda.synchronize()

@@ -26,6 +26,8 @@ while done < nb:  # further chunks of the same distribution (never 5 GB on the h
     del xbc
 print("train+add of %d vectors: %.1fs" % (nb, time.time() - t0), flush=True)
 idx.nprobe = 32
+if os.environ.get("LMF_PAIR") is not None:
+    idx.set_lmf_pair(int(os.environ["LMF_PAIR"]))  # A/B: lock-step pair sweeps (round 6) on / off
 dev = torch.device("cuda", 0)
 xq_dev = torch.from_numpy(xq).to(dev)
 Dd = torch.empty((10000, 100), dtype=torch.float32, device=dev)
