@@ -996,8 +996,17 @@ __device__ __forceinline__ half8 lp_landed(unsigned (&dst)[4]) {
 // statements, so their waits are counted by hand: the operands of k-step s are complete when at most 12 LDS operations (the gathers of
 // the three k-steps issued behind them) are outstanding; LDS returns in order, so operations the compiler issues in between only
 // make that wait conservative, and its own waits (which do not count the asm reads) wait for more than they need, never for less.
-template <int METRIC, int MODE, int NQB, int DS, bool SEL, bool FULLK, bool TWOC, bool FG = false>
+//
+// ABL (tools/pq_sweep_ablation.py; instantiated only in the variant library built with -DFAISS_AMD_LMF_ABLATE, results are WRONG): the
+// FG sweep with one of its units taken out, to see which of them the others wait for --
+//   1  no codebook gathers (the A operands are the code bytes themselves, masked to finite halfs: same VALU count, no LDS reads)
+//   2  the MFMAs of k-step 0 only (3 of 24 per block)
+//   3  no epilogue (no score / maximum / threshold / parking code behind the MFMAs)
+//   4  conflict-free gathers (the low five bits of every code byte replaced by the lane's row: same reads, no bank conflicts)
+//   5  no code loads from memory (the next block's code bytes are computed from this block's)
+template <int METRIC, int MODE, int NQB, int DS, bool SEL, bool FULLK, bool TWOC, bool FG = false, int ABL = 0>
 __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p) {
+    static_assert(ABL == 0 || (FG && MODE != MODE_DUMP), "ablations: the FG sweeps");
     static_assert(!TWOC || (FULLK && DS == 2), "the two-copy codebook serves PQ64 over d = 128");
     static_assert(!FG || (FULLK && DS == 2 && !TWOC), "fast gathers: PQ64 over d = 128, one copy");
     constexpr int PARK = TWOC ? LP_PARK2 : LP_PARK, NST = TWOC ? LP_NST2 : 64;
@@ -1109,6 +1118,11 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
 #pragma unroll
         for (int i = 0; i < ND; ++i) cw[i] = cn[i] = cn2[i] = 0u;
         auto fetch = [&](int t, unsigned (&dst)[ND]) __attribute__((always_inline)) {
+            if constexpr (ABL == 5) {
+#pragma unroll
+                for (int i = 0; i < ND; ++i) dst[i] = cw[i] * 0x9E3779B1u + (unsigned)(t + lane);
+                return;
+            }
             const uint8_t* bp = p.arena_cs + ((start + t) >> 5) * blk_bytes;
             if (TWOC) { // 40 bytes per lane: two 16-byte pieces and one of 8
                 const uint4 v0 = *(const uint4*)(bp + (int64_t)lane * 16), v1 = *(const uint4*)(bp + 1024 + (int64_t)lane * 16);
@@ -1238,11 +1252,15 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
         unsigned ar[4][4];
         unsigned va0 = (unsigned)h << 16, va1 = (unsigned)h << 16;
         const unsigned two = 2u;
-        if constexpr (FG) {
-            lp_gather<0>(cw[0], ar[0], va0, va1, two);
-            lp_gather<1>(cw[1], ar[1], va0, va1, two);
-            lp_gather<2>(cw[2], ar[2], va0, va1, two);
-        } else {
+        // (ABL 4: code bytes whose low five bits are the lane's row -> 32 distinct banks per half wavefront)
+        auto abl_code = [&](unsigned c4) __attribute__((always_inline)) -> unsigned {
+            return ABL == 4 ? (c4 & 0xE0E0E0E0u) | ((unsigned)j * 0x01010101u) : c4;
+        };
+        if constexpr (FG && ABL != 1) {
+            lp_gather<0>(abl_code(cw[0]), ar[0], va0, va1, two);
+            lp_gather<1>(abl_code(cw[1]), ar[1], va0, va1, two);
+            lp_gather<2>(abl_code(cw[2]), ar[2], va0, va1, two);
+        } else if constexpr (!FG) {
 #pragma unroll
             for (int s = 0; s < LP_AHEAD; ++s) av[s] = operand_of(cw, s);
         }
@@ -1274,10 +1292,10 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
             // and the epilogue runs with gathers in flight.
             auto step = [&](auto s_c) __attribute__((always_inline)) {
                 constexpr int s = decltype(s_c)::value;
-                if constexpr (FG) {
+                if constexpr (FG && ABL != 1) {
                     constexpr int sn = (s + LP_AHEAD) & 7;
-                    lp_gather<sn>(s + LP_AHEAD < 8 ? cw[sn] : cn[sn], ar[(s + LP_AHEAD) % 4], va0, va1, two);
-                } else {
+                    lp_gather<sn>(abl_code(s + LP_AHEAD < 8 ? cw[sn] : cn[sn]), ar[(s + LP_AHEAD) % 4], va0, va1, two);
+                } else if constexpr (!FG) {
                     if (s + LP_AHEAD < 8) av[(s + LP_AHEAD) % 4] = operand_of(cw, s + LP_AHEAD);
                     else av[(s + LP_AHEAD) % 4] = operand_of(cn, s + LP_AHEAD - 8);
                 }
@@ -1288,10 +1306,18 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (FULLK || s < nks) {
-                    const half8 a = FG ? lp_landed(ar[s % 4]) : av[s % 4];
+                    half8 a;
+                    if constexpr (ABL == 1) {
+                        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                        constexpr unsigned fin = 0x3bff3bffu; // (halfs below 1)
+                        a = __builtin_bit_cast(half8, u32x4{cw[s] & fin, cw[(s + 1) & 7] & fin, cw[(s + 2) & 7] & fin, cw[(s + 3) & 7] & fin});
+                    } else if constexpr (FG) a = lp_landed(ar[s % 4]);
+                    else a = av[s % 4];
+                    if (ABL != 2 || s == 0) {
 #pragma unroll
-                    for (int b = 0; b < NB; ++b)
-                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq[b][s], acc[b], 0, 0, 0);
+                        for (int b = 0; b < NB; ++b)
+                            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq[b][s], acc[b], 0, 0, 0);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             };
@@ -1303,7 +1329,13 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
             step(std::integral_constant<int, 5>{});
             step(std::integral_constant<int, 6>{});
             step(std::integral_constant<int, 7>{});
-            if constexpr (MODE == MODE_MIN) {
+            if constexpr (ABL == 3) { // (the accumulators stay alive through one instruction; the store below never happens)
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    L[b].gm = lmf_max3(L[b].gm, acc[b][0], acc[b][15]);
+                    if (t + bstep >= rend && L[b].gm == 1.2345f) p.cnt[0] = 1u;
+                }
+            } else if constexpr (MODE == MODE_MIN) {
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
                     lmf_scores<METRIC, SEL>(acc[b], rn, tail, row_b, r1, mw);
@@ -1407,7 +1439,22 @@ static void lmf_pq_launch(const IvfLmParams& p, int grid_blocks, hipStream_t str
     if (twoc) {
         FA_THROW_IF_NOT(ds == 2 && ivf_lmf_choice_shape(p.d, p.M));
         FA_LP(2, true, true); // PQ64 over d = 128 with the two-copy codebook
-    } else if (fastg) FA_LP(2, true, false, true); // PQ64 over d = 128, one copy, one-instruction gathers (round 6)
+    }
+#ifdef FAISS_AMD_LMF_ABLATE
+    else if (const char* abl = fastg && METRIC == METRIC_L2 && !SEL && MODE != MODE_DUMP ? experiment_env("FAISS_AMD_LMF_ABLATE") : nullptr;
+             abl && atoi(abl) >= 1 && atoi(abl) <= 5) {
+        if constexpr (METRIC == METRIC_L2 && !SEL && MODE != MODE_DUMP) {
+            switch (atoi(abl)) {
+            case 1: FA_LP(2, true, false, true, 1); break;
+            case 2: FA_LP(2, true, false, true, 2); break;
+            case 3: FA_LP(2, true, false, true, 3); break;
+            case 4: FA_LP(2, true, false, true, 4); break;
+            default: FA_LP(2, true, false, true, 5); break;
+            }
+        }
+    }
+#endif
+    else if (fastg) FA_LP(2, true, false, true); // PQ64 over d = 128, one copy, one-instruction gathers (round 6)
     else if (bench_shape) FA_LP(2, true, false); // the same shape, gathers as hipcc compiles them
     else if (ds == 1) FA_LP(1, false, false);
     else if (ds == 2) FA_LP(2, false, false);

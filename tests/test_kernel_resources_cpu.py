@@ -119,7 +119,7 @@ def test_filter_sweeps(usage):
         return [int(x) for x in re.findall(r"L[ib](n?\d+)E", name.split("kernelI")[1].split("EEvNS_")[0] + "E")]
 
     for name, u in flat.items():
-        metric, mode, nqb, ks, full, sel, pairb = targs(name)
+        metric, mode, nqb, ks, full, sel, pairb = targs(name)[:7]
         # IVFFlat / scalar quantizer, rows of <= 128 coordinates (KS = 8), the two sweeps, no selector: nothing in scratch
         if mode in (1, 2) and nqb == 3 and ks == 8 and not sel:
             assert u["scratch"] == 0, (name, u)
