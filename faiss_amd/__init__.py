@@ -41,6 +41,9 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    variant = os.environ.get("FAISS_AMD_LIB_VARIANT") if os.environ.get("FAISS_AMD_EXPERIMENTS") == "1" else None
+    if variant:  # tools/ only: an A/B build of the library under lib/variants/ (`make -C faiss_amd/csrc variants`)
+        globals()["LIB_PATH"] = os.path.join(_HERE, "lib", "variants", "libfaiss_amd_%s.so" % variant)
     if not os.path.exists(LIB_PATH):
         raise FaissAmdError(
             "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -2981,6 +2981,16 @@ void GpuIndexIVF::search_listmajor_filter_chunk_(int ni, int q0, const float* xq
         SpanGuard sg(&R, "ivf_lmf_sweep_collect");
         launch_ivf_lmf_sweep(P, 2, grid, R.stream);
     }
+    static const bool lmf_stats = experiment_env("FAISS_AMD_LMF_STATS") != nullptr; // diagnostics only: candidates sweep 2 collected
+    if (lmf_stats) {
+        std::vector<uint32_t> hc((size_t)ni);
+        HIP_CHECK(hipMemcpyAsync(hc.data(), P.cnt, (size_t)ni * 4, hipMemcpyDeviceToHost, R.stream));
+        R.sync();
+        double sum = 0;
+        uint32_t mx = 0;
+        for (uint32_t c : hc) sum += c, mx = std::max(mx, c);
+        fprintf(stderr, "ivf_lmf sweep 2: %.1f candidates per query (max %u, stride %lld)\n", sum / std::max<int64_t>(ni, 1), mx, (long long)stride);
+    }
     // the workgroup that re-derives a query's candidates also selects its k best when both fit its LDS (no selection launch)
     // (IVFFlat: rerank 0.135 -> 0.19 ms for 0.105 ms of selection launch at nb = 1M; IVFPQ keeps the separate launch: its rerank
     // workgroups -- two per CU, the 64 KB table -- serialise the tail: 0.25 -> 0.52 ms; and a selection inside the wave-per-query

@@ -487,8 +487,12 @@ __device__ __forceinline__ float lmf_lane_max(const f32x16& a) { // 8 instructio
 template <int METRIC, bool SEL>
 __device__ __forceinline__ void lmf_scores(f32x16& a, const f32x4 (&rn)[4], bool tail, int row_b, int r1, uint32_t mw) {
     if (METRIC == METRIC_L2) {
-        // two accumulators per v_pk_fma_f32 (asked for explicitly: left to itself hipcc emits 16 v_fma_f32 in some
-        // instantiations and 8 packed ones in others)
+        // ONE v_fma_f32 per accumulator.  Rounds 4 / 5 asked for v_pk_fma_f32 here (two accumulators per instruction); round 6's
+        // ablation (tools/pq_sweep_ablation.py, profiles/r6_pq_sweep_ablation.txt) put the always-on part of the epilogue at 0.6 of
+        // the 3.2 ms of sweep 2 at nb = 100M -- ~ 520 cycles per 32-row block for 24 packed fma + 24 v_max3 --, and the guide's
+        // timing table prices a packed f32 instruction beside MFMAs at + 22 cycles against two plain ones (the file is compiled
+        // with -fno-slp-vectorize for the same reason: hipcc packs adjacent scalar f32 operations by itself).
+#ifdef FAISS_AMD_LMF_PK_SCORES
         const f32x2 mh = f32x2{-0.5f, -0.5f};
 #pragma unroll
         for (int g = 0; g < 4; ++g)
@@ -500,6 +504,12 @@ __device__ __forceinline__ void lmf_scores(f32x16& a, const f32x4 (&rn)[4], bool
                 a[4 * g + e] = a2[0];
                 a[4 * g + e + 1] = a2[1];
             }
+#else
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[4 * g + e] = __builtin_fmaf(-0.5f, rn[g][e], a[4 * g + e]);
+#endif
     }
     else {
         // Inner product: nothing is computed on the accumulators, so the first instruction that reads them is the v_max3
@@ -562,30 +572,102 @@ __device__ __forceinline__ void lmf_stage_push(LmfStage<NST>& st, bool hit, unsi
     }
     st.cnt += __popcll(bal);
 }
-// dense pass over the staged records: parked candidates go to pk_keys / pk_q (wcnt of them so far, room PARK >= 64; `flush`
-// empties them)
+// parked candidates -> the queries' candidate lists in memory (slot = the query's counter).  Round 6: the returning atomics of up to
+// four candidates per lane are ISSUED TOGETHER and waited for once -- one memory round trip per 256 candidates instead of four, each
+// followed by a second one for the stores (the sweep's wavefronts do nothing else meanwhile: tools/pq_sweep_ablation.py, the epilogue
+// was 0.29 of 0.55 ms of sweep 2 at nb = 10M).  Nothing waits for the stores: they are invisible to the compiler's count of the
+// loads in flight, which only makes its waits conservative (an older load is complete whenever the counter allows it).
+__device__ __forceinline__ void lmf_flush_parked(const IvfLmParams& p, int lane, const u64* pk_keys, const uint32_t* pk_q, int& wcnt) {
+    for (int e0 = 0; e0 < wcnt; e0 += 256) {
+        // (ONE asm statement from the first atomic to the wait: the compiler may copy an output register of an asm statement right
+        // behind it -- it did, in front of a wait that stood in a statement of its own -- and would copy what the atomic has not
+        // returned yet.  The lanes without a candidate are masked off inside the statement; exec is restored before it ends.)
+        uint32_t slot[4];
+        uint32_t* cp[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cp[i] = p.cnt + (pk_q[e0 + 64 * i + lane] >> 11); // (slots behind wcnt: stale, masked off)
+        const int w0 = wcnt - e0, el = lane;
+        const uint32_t one = 1u;
+        unsigned long long sv;
+        asm volatile(
+                "s_mov_b64 %[sv], exec\n\t"
+                "v_cmp_gt_i32 vcc, %[w0], %[el]\n\t"
+                "s_and_b64 exec, %[sv], vcc\n\t"
+                "global_atomic_add %[s0], %[a0], %[one], off sc0\n\t"
+                "v_cmp_gt_i32 vcc, %[w1], %[el]\n\t"
+                "s_and_b64 exec, %[sv], vcc\n\t"
+                "global_atomic_add %[s1], %[a1], %[one], off sc0\n\t"
+                "v_cmp_gt_i32 vcc, %[w2], %[el]\n\t"
+                "s_and_b64 exec, %[sv], vcc\n\t"
+                "global_atomic_add %[s2], %[a2], %[one], off sc0\n\t"
+                "v_cmp_gt_i32 vcc, %[w3], %[el]\n\t"
+                "s_and_b64 exec, %[sv], vcc\n\t"
+                "global_atomic_add %[s3], %[a3], %[one], off sc0\n\t"
+                "s_mov_b64 exec, %[sv]\n\t"
+                "s_waitcnt vmcnt(0)"
+                : [s0] "=&v"(slot[0]), [s1] "=&v"(slot[1]), [s2] "=&v"(slot[2]), [s3] "=&v"(slot[3]), [sv] "=&s"(sv)
+                : [a0] "v"(cp[0]), [a1] "v"(cp[1]), [a2] "v"(cp[2]), [a3] "v"(cp[3]), [one] "v"(one), [el] "v"(el), [w0] "s"(w0),
+                  [w1] "s"(w0 - 64), [w2] "s"(w0 - 128), [w3] "s"(w0 - 192)
+                : "vcc", "memory");
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = e0 + 64 * i + lane;
+            if (e < wcnt && (int64_t)slot[i] < p.stride) {
+                const uint32_t qp = pk_q[e];
+                const int64_t at = (int64_t)(qp >> 11) * p.stride + slot[i];
+                lmf_store_u64(p.keys + at, pk_keys[e]);
+                lmf_store_u16(p.cand_pr + at, qp & 2047u);
+            }
+        }
+    }
+    wcnt = 0;
+}
+// dense pass over the staged records: parked candidates go to pk_keys / pk_q (wcnt of them so far; `flush`
+// empties them).  Round 6: LANE l looks at RECORD l -- its 16 scores arrive as four 16-byte reads, one (prefetched) per step, and a
+// step appends the rows that pass of four score positions.  The first version walked the records four at a time, 16 lanes each, and
+// paid two dependent LDS round trips per step through an LDS that eight wavefronts gather from: ~ 30 of them per 64 records.
 template <int METRIC, int PARK, int NST, typename Flush>
 __device__ __forceinline__ void lmf_stage_expand(LmfStage<NST>& st, int lane, u64* pk_keys, uint32_t* pk_q, int& wcnt, Flush&& flush) {
-    static_assert(PARK >= 64, "a step of the dense pass parks up to 64 candidates");
-    const int r = lane & 15, sub = lane >> 4;
-    for (int b0 = 0; b0 < st.cnt; b0 += 4) {
-        const int rec = b0 + sub;
-        const bool valid = rec < st.cnt;
-        const int rc = valid ? rec : 0;
-        const float sc = st.plane(r >> 2)[4 * rc + (r & 3)];
-        const bool pass = valid && sc >= st.tq()[rc];
-        const unsigned long long bal = __ballot(pass);
-        if (!bal) continue;
-        const int n = __popcll(bal);
-        if (wcnt + n > PARK) flush();
-        if (pass) {
-            const int at = wcnt + lmf_rank_in(bal);
-            // row of score r = 4 g + e of a lane: 8 g + e rows behind the lane's first
-            const uint32_t pos = st.pos()[rc] + (uint32_t)(8 * (r >> 2) + (r & 3));
-            pk_keys[at] = ((u64)ordkey<METRIC>(lmf_to_est<METRIC>(sc + st.xh()[rc])) << 32) | pos;
-            pk_q[at] = st.qpr()[rc];
+    // score positions per step: as many as always fit behind a flush (4 with the sweeps' 256 .. 1024 parked candidates per wave; the
+    // two-copy codebook leaves room for 64 candidates and 32 records: 2)
+    constexpr int EPS = PARK >= 4 * NST ? 4 : PARK >= 2 * NST ? 2 : 1;
+    static_assert(NST <= 64 && PARK >= NST, "a record per lane; a score position of every record fits");
+    const bool valid = lane < st.cnt;
+    const int rc = valid ? lane : 0;
+    const float tq = valid ? st.tq()[rc] : __builtin_nanf(""); // (nothing passes NaN)
+    const uint32_t pos0 = st.pos()[rc], qpr = st.qpr()[rc];
+    const float xh = st.xh()[rc];
+    f32x4 nx = *(const f32x4*)(st.plane(0) + 4 * rc);
+#pragma unroll 1
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 s4 = nx;
+        nx = *(const f32x4*)(st.plane(min(g + 1, 3)) + 4 * rc);
+#pragma unroll
+        for (int e0 = 0; e0 < 4; e0 += EPS) {
+            bool ps[EPS];
+            unsigned long long bl[EPS];
+            int first[EPS + 1];
+            first[0] = 0;
+#pragma unroll
+            for (int e = 0; e < EPS; ++e) {
+                ps[e] = s4[e0 + e] >= tq;
+                bl[e] = __ballot(ps[e]);
+                first[e + 1] = first[e] + __popcll(bl[e]);
+            }
+            const int n = first[EPS];
+            if (n == 0) continue;
+            if (wcnt + n > PARK) flush();
+#pragma unroll
+            for (int e = 0; e < EPS; ++e) {
+                if (ps[e]) {
+                    const int at = wcnt + first[e] + lmf_rank_in(bl[e]);
+                    // row of score 4 g + e of a lane: 8 g + e rows behind the lane's first
+                    pk_keys[at] = ((u64)ordkey<METRIC>(lmf_to_est<METRIC>(s4[e0 + e] + xh)) << 32) | (pos0 + (uint32_t)(8 * g + e0 + e));
+                    pk_q[at] = qpr;
+                }
+            }
+            wcnt += n;
         }
-        wcnt += n;
     }
     st.cnt = 0;
 }
@@ -679,25 +761,7 @@ __global__ void __launch_bounds__(PAIR ? 128 : LF_THREADS, 2) ivf_lmf_flat_kerne
     float* rn_lds = rn_lds_all[wave];
     int wcnt = 0; // (wave-uniform) parked candidates
     LmfStage<64> st{smem + NW * LF_PARK * 12 + wave * LS_WAVE, 0};
-    auto flush = [&]() __attribute__((always_inline)) {
-        for (int e = lane; e < wcnt; e += 64) {
-            const u64 key = pk_keys[e];
-            const uint32_t qp = pk_q[e];
-            const uint32_t qq = qp >> 11;
-            // (returning atomic + wait inside the asm: the dense pass runs INSIDE the block loop, and with a memory operation
-            // of its own there hipcc stops counting the loads in flight and waits vmcnt(0) before every use)
-            uint32_t slot;
-            uint32_t* cp = p.cnt + qq;
-            const uint32_t one = 1u;
-            asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(slot) : "v"(cp), "v"(one) : "memory");
-            if ((int64_t)slot < p.stride) {
-                lmf_store_u64(p.keys + (int64_t)qq * p.stride + slot, key);
-                lmf_store_u16(p.cand_pr + (int64_t)qq * p.stride + slot, qp & 2047u);
-            }
-        }
-        wcnt = 0;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // no store in flight on any path back into the block loop
-    };
+    auto flush = [&]() __attribute__((always_inline)) { lmf_flush_parked(p, lane, pk_keys, pk_q, wcnt); };
     auto expand = [&]() __attribute__((always_inline)) { lmf_stage_expand<METRIC, LF_PARK, 64>(st, lane, pk_keys, pk_q, wcnt, flush); };
 
     const uint32_t it0 = p.item_bounds[1], it1 = p.item_bounds[2];
@@ -900,13 +964,17 @@ __global__ void __launch_bounds__(PAIR ? 128 : LF_THREADS, 2) ivf_lmf_flat_kerne
                             }
                     }
                 } else {
+                    // ---- lanes whose best score of query block b reaches their query's threshold stage their 16 scores (the scores
+                    // of all query blocks first: the row norms are dead by the time a dense pass needs registers)
+                    bool hit[NQB];
 #pragma unroll
                     for (int b = 0; b < NQB; ++b) {
-                        // ---- lanes whose best score of query block b reaches their query's threshold stage their 16 scores
                         lmf_scores<METRIC, SEL>(acc[b], rn, tail, row_b, r1, mw);
-                        lmf_collect_pair(st, lane, lmf_lane_max(acc[b]) >= L[b].tq, acc[b], L[b].tq, L[b].base_pos + (uint32_t)row_b,
-                                         L[b].qpr, L[b].xh, expand);
+                        hit[b] = lmf_lane_max(acc[b]) >= L[b].tq;
                     }
+#pragma unroll
+                    for (int b = 0; b < NQB; ++b)
+                        lmf_collect_pair(st, lane, hit[b], acc[b], L[b].tq, L[b].base_pos + (uint32_t)row_b, L[b].qpr, L[b].xh, expand);
                 }
             }
         }
@@ -998,12 +1066,16 @@ __device__ __forceinline__ half8 lp_landed(unsigned (&dst)[4]) {
 // make that wait conservative, and its own waits (which do not count the asm reads) wait for more than they need, never for less.
 //
 // ABL (tools/pq_sweep_ablation.py; instantiated only in the variant library built with -DFAISS_AMD_LMF_ABLATE, results are WRONG): the
-// FG sweep with one of its units taken out, to see which of them the others wait for --
-//   1  no codebook gathers (the A operands are the code bytes themselves, masked to finite halfs: same VALU count, no LDS reads)
-//   2  the MFMAs of k-step 0 only (3 of 24 per block)
-//   3  no epilogue (no score / maximum / threshold / parking code behind the MFMAs)
-//   4  conflict-free gathers (the low five bits of every code byte replaced by the lane's row: same reads, no bank conflicts)
-//   5  no code loads from memory (the next block's code bytes are computed from this block's)
+// FG sweep with units taken out, to see which of them the others wait for -- a MASK of
+//     1  no codebook gathers (the A operands are the code bytes themselves, masked to finite halfs: same VALU count, no LDS reads)
+//     2  the MFMAs of k-step 0 only (3 of 24 per block)
+//     4  no epilogue (no score / maximum / threshold / parking code behind the MFMAs)
+//     8  conflict-free gathers (the low five bits of every code byte replaced by the lane's row: same reads, no bank conflicts)
+//    16  no code loads from memory (the next block's code bytes are computed from this block's)
+//    32  the whole epilogue, but no score ever reaches a threshold (NaN thresholds)
+//    64  no row-norm term (the scores are the accumulators)
+//   128  parked candidates are dropped instead of flushed to memory
+//   256  staged records are dropped instead of expanded
 template <int METRIC, int MODE, int NQB, int DS, bool SEL, bool FULLK, bool TWOC, bool FG = false, int ABL = 0>
 __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p) {
     static_assert(ABL == 0 || (FG && MODE != MODE_DUMP), "ablations: the FG sweeps");
@@ -1067,23 +1139,13 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
     int wcnt = 0;
     LmfStage<NST> st{smem + LY.off_stage + wave * LmfStage<NST>::BYTES, 0};
     auto flush = [&]() __attribute__((always_inline)) {
-        for (int e = lane; e < wcnt; e += 64) {
-            const u64 key = pk_keys[e];
-            const uint32_t qp = pk_q[e];
-            const uint32_t qq = qp >> 11;
-            uint32_t slot;
-            uint32_t* cp = p.cnt + qq;
-            const uint32_t one = 1u;
-            asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(slot) : "v"(cp), "v"(one) : "memory");
-            if ((int64_t)slot < p.stride) {
-                lmf_store_u64(p.keys + (int64_t)qq * p.stride + slot, key);
-                lmf_store_u16(p.cand_pr + (int64_t)qq * p.stride + slot, qp & 2047u);
-            }
-        }
-        wcnt = 0;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr ((ABL & 128) != 0) wcnt = 0;
+        else lmf_flush_parked(p, lane, pk_keys, pk_q, wcnt);
     };
-    auto expand = [&]() __attribute__((always_inline)) { lmf_stage_expand<METRIC, PARK, NST>(st, lane, pk_keys, pk_q, wcnt, flush); };
+    auto expand = [&]() __attribute__((always_inline)) {
+        if constexpr ((ABL & 256) != 0) st.cnt = 0;
+        else lmf_stage_expand<METRIC, PARK, NST>(st, lane, pk_keys, pk_q, wcnt, flush);
+    };
     __syncthreads();
 
     // operand-major code shadow (IvfLmParams::arena_cs): a block = npiece pieces of 64 lanes x cs_piece bytes
@@ -1118,7 +1180,7 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
 #pragma unroll
         for (int i = 0; i < ND; ++i) cw[i] = cn[i] = cn2[i] = 0u;
         auto fetch = [&](int t, unsigned (&dst)[ND]) __attribute__((always_inline)) {
-            if constexpr (ABL == 5) {
+            if constexpr ((ABL & 16) != 0) {
 #pragma unroll
                 for (int i = 0; i < ND; ++i) dst[i] = cw[i] * 0x9E3779B1u + (unsigned)(t + lane);
                 return;
@@ -1193,6 +1255,7 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
             L[b].kq = nullptr;
             if (MODE == MODE_MIN) L[b].gq = p.gmin + (int64_t)q * p.gstride + p.prefixg[(int64_t)q * (np + 1) + pr] + h;
             if (MODE == MODE_COLLECT && L[b].qv) L[b].tq = lmf_collect_threshold<METRIC>(p.thr_f[q], L[b].xh);
+            if ((ABL & 32) != 0) L[b].tq = __builtin_nanf("");
             if (MODE == MODE_DUMP) L[b].kq = p.keys + (int64_t)q * p.stride + L[b].base_pos;
         }
 
@@ -1252,11 +1315,11 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
         unsigned ar[4][4];
         unsigned va0 = (unsigned)h << 16, va1 = (unsigned)h << 16;
         const unsigned two = 2u;
-        // (ABL 4: code bytes whose low five bits are the lane's row -> 32 distinct banks per half wavefront)
+        // (ABL 8: code bytes whose low five bits are the lane's row -> 32 distinct banks per half wavefront)
         auto abl_code = [&](unsigned c4) __attribute__((always_inline)) -> unsigned {
-            return ABL == 4 ? (c4 & 0xE0E0E0E0u) | ((unsigned)j * 0x01010101u) : c4;
+            return (ABL & 8) ? (c4 & 0xE0E0E0E0u) | ((unsigned)j * 0x01010101u) : c4;
         };
-        if constexpr (FG && ABL != 1) {
+        if constexpr (FG && !(ABL & 1)) {
             lp_gather<0>(abl_code(cw[0]), ar[0], va0, va1, two);
             lp_gather<1>(abl_code(cw[1]), ar[1], va0, va1, two);
             lp_gather<2>(abl_code(cw[2]), ar[2], va0, va1, two);
@@ -1292,7 +1355,7 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
             // and the epilogue runs with gathers in flight.
             auto step = [&](auto s_c) __attribute__((always_inline)) {
                 constexpr int s = decltype(s_c)::value;
-                if constexpr (FG && ABL != 1) {
+                if constexpr (FG && !(ABL & 1)) {
                     constexpr int sn = (s + LP_AHEAD) & 7;
                     lp_gather<sn>(abl_code(s + LP_AHEAD < 8 ? cw[sn] : cn[sn]), ar[(s + LP_AHEAD) % 4], va0, va1, two);
                 } else if constexpr (!FG) {
@@ -1307,13 +1370,13 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
                 __builtin_amdgcn_sched_barrier(0);
                 if (FULLK || s < nks) {
                     half8 a;
-                    if constexpr (ABL == 1) {
+                    if constexpr ((ABL & 1) != 0) {
                         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                         constexpr unsigned fin = 0x3bff3bffu; // (halfs below 1)
                         a = __builtin_bit_cast(half8, u32x4{cw[s] & fin, cw[(s + 1) & 7] & fin, cw[(s + 2) & 7] & fin, cw[(s + 3) & 7] & fin});
                     } else if constexpr (FG) a = lp_landed(ar[s % 4]);
                     else a = av[s % 4];
-                    if (ABL != 2 || s == 0) {
+                    if (!(ABL & 2) || s == 0) {
 #pragma unroll
                         for (int b = 0; b < NB; ++b)
                             acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq[b][s], acc[b], 0, 0, 0);
@@ -1329,7 +1392,7 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
             step(std::integral_constant<int, 5>{});
             step(std::integral_constant<int, 6>{});
             step(std::integral_constant<int, 7>{});
-            if constexpr (ABL == 3) { // (the accumulators stay alive through one instruction; the store below never happens)
+            if constexpr ((ABL & 4) != 0) { // (the accumulators stay alive through one instruction; the store below never happens)
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
                     L[b].gm = lmf_max3(L[b].gm, acc[b][0], acc[b][15]);
@@ -1367,13 +1430,17 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
                         }
                 }
             } else {
+                // ---- lanes whose best score of query block b reaches their query's threshold stage their 16 scores (the scores of
+                // all query blocks first: the row norms are dead by the time a dense pass needs registers)
+                bool hit[NB];
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
-                    // ---- lanes whose best score of query block b reaches their query's threshold stage their 16 scores
-                    lmf_scores<METRIC, SEL>(acc[b], rn, tail, row_b, r1, mw);
-                    lmf_collect_pair(st, lane, lmf_lane_max(acc[b]) >= L[b].tq, acc[b], L[b].tq, L[b].base_pos + (uint32_t)row_b,
-                                     L[b].qpr, L[b].xh, expand);
+                    if constexpr (!(ABL & 64)) lmf_scores<METRIC, SEL>(acc[b], rn, tail, row_b, r1, mw);
+                    hit[b] = lmf_lane_max(acc[b]) >= L[b].tq;
                 }
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+                    lmf_collect_pair(st, lane, hit[b], acc[b], L[b].tq, L[b].base_pos + (uint32_t)row_b, L[b].qpr, L[b].xh, expand);
             }
 #pragma unroll
             for (int i = 0; i < ND; ++i) cw[i] = cn[i], cn[i] = cn2[i];
@@ -1442,14 +1509,30 @@ static void lmf_pq_launch(const IvfLmParams& p, int grid_blocks, hipStream_t str
     }
 #ifdef FAISS_AMD_LMF_ABLATE
     else if (const char* abl = fastg && METRIC == METRIC_L2 && !SEL && MODE != MODE_DUMP ? experiment_env("FAISS_AMD_LMF_ABLATE") : nullptr;
-             abl && atoi(abl) >= 1 && atoi(abl) <= 5) {
+             abl && atoi(abl) >= 1) {
         if constexpr (METRIC == METRIC_L2 && !SEL && MODE != MODE_DUMP) {
             switch (atoi(abl)) {
             case 1: FA_LP(2, true, false, true, 1); break;
             case 2: FA_LP(2, true, false, true, 2); break;
-            case 3: FA_LP(2, true, false, true, 3); break;
             case 4: FA_LP(2, true, false, true, 4); break;
-            default: FA_LP(2, true, false, true, 5); break;
+            case 8: FA_LP(2, true, false, true, 8); break;
+            case 16: FA_LP(2, true, false, true, 16); break;
+            case 32: FA_LP(2, true, false, true, 32); break;
+            case 64: FA_LP(2, true, false, true, 64); break;
+            case 128: FA_LP(2, true, false, true, 128); break;
+            case 256: FA_LP(2, true, false, true, 256); break;
+            case 5: FA_LP(2, true, false, true, 5); break;
+            case 6: FA_LP(2, true, false, true, 6); break;
+            case 20: FA_LP(2, true, false, true, 20); break;
+            case 7: FA_LP(2, true, false, true, 7); break;
+            case 21: FA_LP(2, true, false, true, 21); break;
+            case 22: FA_LP(2, true, false, true, 22); break;
+            case 23: FA_LP(2, true, false, true, 23); break;
+            case 33: FA_LP(2, true, false, true, 33); break;
+            case 34: FA_LP(2, true, false, true, 34); break;
+            case 48: FA_LP(2, true, false, true, 48); break;
+            case 96: FA_LP(2, true, false, true, 96); break;
+            default: FA_THROW_IF_NOT(!"FAISS_AMD_LMF_ABLATE: a mask that is not instantiated");
             }
         }
     }

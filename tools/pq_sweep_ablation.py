@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """tools/pq_sweep_ablation.py -- which unit of the IVFPQ filter sweeps do the others wait for?  ("or a committed A/B
 that shows which unit refused to overlap".)  Runs lib/variants/libfaiss_amd_lmf_ablate.so (`make -C faiss_amd/csrc variants`), whose
-`ivf_lmf_pq_kernel<..., FG, ABL>` instantiations take ONE unit out of the sweep (ivf_lm_filter.hip: 1 no codebook gathers, 2 three of
-the 24 MFMAs per block, 3 no epilogue, 4 conflict-free gathers, 5 no code loads), chosen per launch by FAISS_AMD_LMF_ABLATE.  Results of
+`ivf_lmf_pq_kernel<..., FG, ABL>` instantiations take units out of the sweep (ABL = a mask, see BITS below and ivf_lm_filter.hip),
+chosen per launch by FAISS_AMD_LMF_ABLATE.  Results of
 an ablated search are WRONG by construction; only the spans of the two sweeps are read.  IVF4096,PQ64, nprobe 32, 10 000 queries,
 k = 100; sizes in millions as arguments (default 10)."""
 import os
@@ -19,8 +19,10 @@ import faiss_amd  # noqa: E402
 faiss_amd.LIB_PATH = os.path.join(os.path.dirname(faiss_amd.LIB_PATH), "variants", "libfaiss_amd_lmf_ablate.so")
 from faiss_amd.datasets import synthetic_dataset, synthetic_more_device  # noqa: E402
 
-NAMES = {0: "the sweep as shipped", 1: "no codebook gathers", 2: "3 of 24 MFMAs", 3: "no epilogue", 4: "conflict-free gathers",
-         5: "no code loads"}
+BITS = {1: "no gathers", 2: "3 of 24 MFMAs", 4: "no epilogue", 8: "conflict-free gathers", 16: "no code loads", 32: "NaN thresholds (no hits)",
+        64: "no row-norm term", 128: "no flush", 256: "no dense pass"}
+MASKS = [0, 1, 2, 4, 8, 16, 32, 64, 128, 256, 4 + 1, 4 + 2, 4 + 16, 4 + 1 + 2, 4 + 1 + 16, 4 + 2 + 16, 4 + 1 + 2 + 16, 32 + 1, 32 + 2, 32 + 16, 32 + 64]
+NAMES = {m: " + ".join(BITS[b] for b in BITS if m & b) or "the sweep as shipped" for m in MASKS}
 sizes = [int(a) for a in sys.argv[1:]] or [10]
 res = faiss_amd.StandardGpuResources(0)
 dev = torch.device("cuda", 0)
@@ -44,7 +46,7 @@ for mb in sizes:
         del xbc
     print("nb = %dM" % mb, flush=True)
     for rep in range(2):
-        for abl in (0, 1, 2, 3, 4, 5):
+        for abl in MASKS:
             os.environ["FAISS_AMD_LMF_ABLATE"] = str(abl)
             s1, s2 = [], []
             for it in range(4):
@@ -56,6 +58,6 @@ for mb in sizes:
                 if it:
                     s1.append(a)
                     s2.append(b)
-            print("   run %d  %d %-24s sweep 1 %.3f ms   sweep 2 %.3f ms   scan %s" % (rep, abl, NAMES[abl], min(s1), min(s2), idx.scan_info()),
+            print("   run %d  %3d %-58s sweep 1 %.3f ms   sweep 2 %.3f ms   scan %s" % (rep, abl, NAMES[abl], min(s1), min(s2), idx.scan_info()),
                   flush=True)
 os.environ["FAISS_AMD_LMF_ABLATE"] = "0"
