@@ -725,7 +725,12 @@ struct FsShared {
 };
 static_assert(sizeof(float) * FS_MAXCH == sizeof(u64) * FS_CAP, "the exact keys reuse the maxima");
 
-template <int METRIC>
+// TOPSEL (k <= 32; round 6, second version): pass 1 keeps every lane's EIGHT best chunk maxima in registers (a sorted insertion per
+// block: 16 VALU instructions under the loads) and the threshold is the k-th best of the 64 a query's eight lanes hold -- a lower
+// bound of the k-th best of all its maxima (every listed value is one of them), within 0.3 % of its rank on random data (a lane
+// holds more than eight of the k <= 32 best of 256 once in a few hundred queries).  The bisection then counts 8 keys per lane
+// instead of 32: `select` 30 000 -> 6 000 cycles of 118 000 per workgroup (FS_TIMING).
+template <int METRIC, bool TOPSEL>
 __global__ void __launch_bounds__(FS_THREADS, 2) flat_small_fused_kernel(FlatSmallParams p) {
     __shared__ FsShared sh;
     const int tid = threadIdx.x;
@@ -761,25 +766,30 @@ __global__ void __launch_bounds__(FS_THREADS, 2) flat_small_fused_kernel(FlatSma
         // first version: 0.21 ms for the launch)
         // (UNCONDITIONAL: behind the last block the loads re-read it -- a branch around a prefetch makes hipcc wait vmcnt(0) at the
         // join, i.e. for the prefetch it has just issued: 1700 cycles per block in the first version)
-        auto loadblk = [&](int b, half8 (&a)[8]) __attribute__((always_inline)) {
-            const half8* r = (const half8*)p.xbo + (int64_t)min(b, nblk - 1) * 512 + lane;
+        // (the block's row terms travel with it: loaded at the head of `block` they were a 500-cycle L2 round trip per block that
+        // eight MFMAs could not cover)
+        auto loadblk = [&](int b, half8 (&a)[8], f32x4 (&bias)[4]) __attribute__((always_inline)) {
+            const int bc = min(b, nblk - 1);
+            const half8* r = (const half8*)p.xbo + (int64_t)bc * 512 + lane;
 #pragma unroll
             for (int s = 0; s < 8; ++s) a[s] = r[64 * s];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bias[g] = *(const f32x4*)(p.xbhn + 32 * bc + 8 * g + 4 * h);
         };
         // three blocks of loads ahead of the MFMAs in three named buffers: the loop is unrolled by three so that no buffer is ever
         // COPIED (a rotating copy waits for the newest load before it moves it: one block of look-ahead instead of three --
         // 1700 cycles per block in the first version, an L2 round trip each)
         half8 a0[8], a1[8], a2[8];
-        auto block = [&](int b, half8 (&a)[8]) __attribute__((always_inline)) {
+        f32x4 bias0[4], bias1[4], bias2[4];
+        float top[8]; // TOPSEL, pass 1: this lane's best chunk maxima, descending
+#pragma unroll
+        for (int i = 0; i < 8; ++i) top[i] = -INFINITY;
+        auto block = [&](int b, half8 (&a)[8], f32x4 (&bias)[4]) __attribute__((always_inline)) {
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            f32x4 bias[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) bias[g] = *(const f32x4*)(p.xbhn + 32 * b + 8 * g + 4 * h);
 #pragma unroll
             for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s], bq[s], acc, 0, 0, 0);
-            loadblk(b + 3 * FS_WAVES, a);
             float sc[16], m = -INFINITY;
 #pragma unroll
             for (int g = 0; g < 4; ++g)
@@ -790,8 +800,18 @@ __global__ void __launch_bounds__(FS_THREADS, 2) flat_small_fused_kernel(FlatSma
                     sc[4 * g + e] = v;
                     m = fmaxf(m, v); // (drops a NaN score like the general path's v_max3)
                 }
+            loadblk(b + 3 * FS_WAVES, a, bias);
             if (MODE == MODE_MAX) {
-                sh.cmax[j][2 * b + h] = m;
+                if constexpr (TOPSEL) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float hi = fmaxf(top[i], m);
+                        m = fminf(top[i], m);
+                        top[i] = hi;
+                    }
+                } else {
+                    sh.cmax[j][2 * b + h] = m;
+                }
             } else if (m >= th) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
@@ -802,15 +822,19 @@ __global__ void __launch_bounds__(FS_THREADS, 2) flat_small_fused_kernel(FlatSma
             }
         };
         int b = wave;
-        loadblk(b, a0);
-        loadblk(b + FS_WAVES, a1);
-        loadblk(b + 2 * FS_WAVES, a2);
+        loadblk(b, a0, bias0);
+        loadblk(b + FS_WAVES, a1, bias1);
+        loadblk(b + 2 * FS_WAVES, a2, bias2);
         for (; b < nblk; b += 3 * FS_WAVES) {
-            block(b, a0);
-            if (b + FS_WAVES < nblk) block(b + FS_WAVES, a1);
-            if (b + 2 * FS_WAVES < nblk) block(b + 2 * FS_WAVES, a2);
+            block(b, a0, bias0);
+            if (b + FS_WAVES < nblk) block(b + FS_WAVES, a1, bias1);
+            if (b + 2 * FS_WAVES < nblk) block(b + 2 * FS_WAVES, a2, bias2);
         }
         if (MODE == MODE_COLLECT) sh.cnt8[j][2 * wave + h] = nsub;
+        if (MODE == MODE_MAX && TOPSEL) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sh.cmax[j][8 * (2 * wave + h) + i] = top[i];
+        }
     };
 #ifdef FS_TIMING
     unsigned long long tm[8];
@@ -828,17 +852,19 @@ __global__ void __launch_bounds__(FS_THREADS, 2) flat_small_fused_kernel(FlatSma
     // time through ballots: 256 dependent VALU -> SALU round trips per wave, 23 us)
     {
         const int qq = (FS_Q / FS_WAVES) * wave + (lane >> 3), sl = lane & 7;
-        uint32_t key[FS_MAXCH / 8];
+        constexpr int NU = TOPSEL ? 8 : FS_MAXCH / 8; // keys per lane
+        const int nkey = TOPSEL ? 64 : nch;
+        uint32_t key[NU];
 #pragma unroll
-        for (int u = 0; u < FS_MAXCH / 8; ++u) key[u] = 8 * u + sl < nch ? score_key(sh.cmax[qq][8 * u + sl]) : 0xffffffffu;
+        for (int u = 0; u < NU; ++u) key[u] = 8 * u + sl < nkey ? score_key(sh.cmax[qq][8 * u + sl]) : 0xffffffffu;
         uint32_t pre = 0;
         for (int bit = 31; bit >= 0; --bit) {
             const uint32_t cand = pre | ((1u << bit) - 1u); // (keys <= cand: this bit clear under the prefix found so far)
             // keys <= cand, counted through the borrow of cand - key (a v_cmp -> v_cndmask pair per key costs two wait states on the
             // condition register each: 27 000 cycles for the 32 x 32 compares of a lane in the first version)
-            int c = FS_MAXCH / 8;
+            int c = NU;
 #pragma unroll
-            for (int u = 0; u < FS_MAXCH / 8; ++u) c += (int)(((unsigned long long)cand - (unsigned long long)key[u]) >> 32);
+            for (int u = 0; u < NU; ++u) c += (int)(((unsigned long long)cand - (unsigned long long)key[u]) >> 32);
             // sum over the eight lanes of the query: quad swaps, then the mirrored lane of the other quad
             c += __builtin_amdgcn_update_dpp(0, c, 0xB1, 0xf, 0xf, false);  // quad_perm [1, 0, 3, 2]
             c += __builtin_amdgcn_update_dpp(0, c, 0x4E, 0xf, 0xf, false);  // quad_perm [2, 3, 0, 1]
@@ -889,7 +915,11 @@ __global__ void __launch_bounds__(FS_THREADS, 2) flat_small_fused_kernel(FlatSma
         sh.pre[FS_Q] = acc;
     }
     __syncthreads();
-    if (tid < FS_Q && sh.bad[tid] == 1u) p.ovf_list[atomicAdd(p.ovf_cnt, 1u)] = (uint32_t)(q0 + tid);
+    if (p.bad_out) {
+        if (tid < FS_Q && q0 + tid < p.nq) p.bad_out[q0 + tid] = sh.bad[tid] == 1u ? 1u : 0u;
+    } else if (tid < FS_Q && sh.bad[tid] == 1u) {
+        p.ovf_list[atomicAdd(p.ovf_cnt, 1u)] = (uint32_t)(q0 + tid);
+    }
     FS_MARK();
     // ---- exact distances of the candidates: (query, candidate) pairs dealt to the threads
     const unsigned total = sh.pre[FS_Q];
@@ -973,7 +1003,8 @@ __global__ void __launch_bounds__(FS_THREADS, 2) flat_small_fused_kernel(FlatSma
     // (fewer candidates than k: only when the database holds fewer rows)
     for (int i = tid; i < FS_Q * p.k; i += FS_THREADS) {
         const int qq = i / p.k, r = i - qq * p.k;
-        if (q0 + qq < p.nq && sh.bad[qq] == 0 && r >= (int)sh.cnt[qq]) {
+        // (deferred overflow: a handed-back query names no row at all until it is redone)
+        if (q0 + qq < p.nq && ((sh.bad[qq] == 0 && r >= (int)sh.cnt[qq]) || (p.bad_out && sh.bad[qq] == 1u))) {
             p.out_dis[(int64_t)(q0 + qq) * p.k + r] = pad;
             p.out_ids[(int64_t)(q0 + qq) * p.k + r] = -1;
         }
@@ -1014,8 +1045,13 @@ void launch_flat_small_fused(const FlatSmallParams& p, hipStream_t stream) {
     if (p.nq == 0) return;
     FA_THROW_IF_NOT(flat_small_fused_supported(p.metric, p.nb, p.d, (int)p.ldbh, p.k) && p.dpad <= 128 && p.dpad % 8 == 0 && p.xb && p.xbo);
     const dim3 grid((unsigned)div_up(p.nq, FS_Q)), block(FS_THREADS);
-    if (p.metric == METRIC_L2) hipLaunchKernelGGL((flat_small_fused_kernel<METRIC_L2>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((flat_small_fused_kernel<METRIC_INNER_PRODUCT>), grid, block, 0, stream, p);
+    if (p.k <= 32) {
+        if (p.metric == METRIC_L2) hipLaunchKernelGGL((flat_small_fused_kernel<METRIC_L2, true>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((flat_small_fused_kernel<METRIC_INNER_PRODUCT, true>), grid, block, 0, stream, p);
+    } else {
+        if (p.metric == METRIC_L2) hipLaunchKernelGGL((flat_small_fused_kernel<METRIC_L2, false>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((flat_small_fused_kernel<METRIC_INNER_PRODUCT, false>), grid, block, 0, stream, p);
+    }
     HIP_CHECK(hipGetLastError());
 }
 

@@ -849,9 +849,15 @@ void GpuIndexFlat::search_tile_general_(int n, const float* xq_pad, int k, float
     if (use_float16_) R.sync(); // `widened` is released on return
 }
 
-void GpuIndexFlat::search_tile_(int n, const float* xq_pad, int k, float* dD, idx_t* dI) const {
+void GpuIndexFlat::search_tile_(int n, const float* xq_pad, int k, float* dD, idx_t* dI, uint32_t* defer_bad) const {
     last_used_filter = false;
     last_filter_overflow = 0;
+    const bool small_fused_now = !is_general_metric(metric_type) && filter_applicable_(k) && use_small_fused && !sel_active_ &&
+                                 !use_float16_ && flat_small_fused_supported(metric_type, (int)ntotal, d, dh_, k);
+    if (defer_bad && !small_fused_now) { // (every other path serves all its queries before it returns)
+        HIP_CHECK(hipMemsetAsync(defer_bad, 0, (size_t)n * 4, res_->stream));
+        defer_bad = nullptr;
+    }
     if (is_general_metric(metric_type)) {
         search_tile_general_(n, xq_pad, k, dD, dI);
         return;
@@ -888,7 +894,7 @@ void GpuIndexFlat::search_tile_(int n, const float* xq_pad, int k, float* dD, id
     };
     // ---- small databases (the coarse quantizer of an IVF index: nlist <= 4096 centroids, k = nprobe <= 64): maxima pass, threshold,
     // collect pass, exact re-rank and ordering in ONE launch (flat_filter.hip flat_small_fused_kernel, round 6) -- same bits
-    if (use_small_fused && !sel_active_ && !use_float16_ && flat_small_fused_supported(metric_type, nb, d, dh_, k)) {
+    if (small_fused_now) {
         qh_.ensure((size_t)n * dh_ * 2);
         flags_.ensure((size_t)n * 4);
         q_norm_.ensure((size_t)n * 4);
@@ -918,11 +924,12 @@ void GpuIndexFlat::search_tile_(int n, const float* xq_pad, int k, float* dD, id
         sp.out_dis = dD, sp.out_ids = dI;
         sp.ovf_list = ovf_list_.as<uint32_t>();
         sp.ovf_cnt = scal_.as<unsigned>() + 2;
+        sp.bad_out = defer_bad;
         {
             SpanGuard sg(&R, "flat_small_fused_kernel");
             launch_flat_small_fused(sp, R.stream);
         }
-        redo_overflow();
+        if (!defer_bad) redo_overflow();
         return;
     }
     FlatFilterParams fp{};
@@ -1172,7 +1179,7 @@ static int flat_query_tile(const GpuResources& R, int k, bool simple, idx_t nb) 
     return (int)(t / 256 * 256);
 }
 
-void GpuIndexFlat::search_device(int n, const float* xq_pad, int k, float* dD, idx_t* dI) const {
+void GpuIndexFlat::search_device(int n, const float* xq_pad, int k, float* dD, idx_t* dI, uint32_t* defer_bad) const {
     // (a caller-owned coarse quantizer may serve several IVF indexes: the scratch of a search belongs to one call at a time)
     std::lock_guard<std::mutex> g(mu_);
     const int tile = flat_query_tile(*res_, k, use_simple_kernel || is_general_metric(metric_type), ntotal);
@@ -1187,7 +1194,7 @@ void GpuIndexFlat::search_device(int n, const float* xq_pad, int k, float* dD, i
             launch_round_f16_inplace(q_pad_.as<float>(), (int64_t)ni * dpad_, res_->stream);
             q = q_pad_.as<float>();
         }
-        search_tile_(ni, q, k, dD + (size_t)i0 * k, dI + (size_t)i0 * k);
+        search_tile_(ni, q, k, dD + (size_t)i0 * k, dI + (size_t)i0 * k, defer_bad ? defer_bad + i0 : nullptr);
     }
 }
 
@@ -2323,13 +2330,19 @@ void GpuIndexIVF::search_core_body_(idx_t n, const float* x, idx_t k, float* dis
         // ---- coarse quantizer: nprobe nearest centroids (reference: IVFBase.cu:509-593)
         c_dis_.ensure((size_t)ni * np * 4);
         c_ids_.ensure((size_t)ni * np * 8);
+        cur_coarse_bad_ = nullptr;
         if (assign) {
             HIP_CHECK(hipMemcpyAsync(c_ids_.p, assign + (size_t)i0 * np, (size_t)ni * np * 8, hipMemcpyDefault, R.stream));
             HIP_CHECK(hipMemcpyAsync(c_dis_.p, centroid_dis + (size_t)i0 * np, (size_t)ni * np * 4, hipMemcpyDefault,
                                      R.stream));
             launch_ivf_sanitize_assign(c_ids_.as<idx_t>(), (int64_t)ni * np, nlist, R.stream);
         } else {
-            quantizer->search_device(ni, q_pad_.as<float>(), np, c_dis_.as<float>(), c_ids_.as<idx_t>());
+            // (behind the filter sweeps the quantizer's own overflow -- a query outside the fp16 range, a flood of near-ties -- joins
+            // the redo set of the list-major search instead of costing every search a read-back right here)
+            if (cur_lm_ && cur_lmf_) c_bad_.ensure((size_t)ni * 4);
+            cur_coarse_bad_ = cur_lm_ && cur_lmf_ ? c_bad_.as<uint32_t>() : nullptr;
+            quantizer->search_device(ni, q_pad_.as<float>(), np, c_dis_.as<float>(), c_ids_.as<idx_t>(),
+                                     const_cast<uint32_t*>(cur_coarse_bad_));
         }
         // the query-major scan of the `nn` queries staged in q_pad_ / c_ids_ / c_dis_ -> gD / gI (device)
         auto query_major = [&](int nn, float* gD, idx_t* gI) {
@@ -2494,8 +2507,13 @@ void GpuIndexIVF::search_core_body_(idx_t n, const float* x, idx_t k, float* dis
                 gD.ensure((size_t)nr * k * 4);
                 gI.ensure((size_t)nr * k * 8);
                 launch_gather_rows(q_pad_.as<float>(), dpad_, dpad_, olist.as<uint32_t>(), nr, gq.as<float>(), R.stream);
-                launch_gather_rows((const float*)c_ids_.p, 2 * np, 2 * np, olist.as<uint32_t>(), nr, (float*)gids.p, R.stream);
-                launch_gather_rows(c_dis_.as<float>(), np, np, olist.as<uint32_t>(), nr, gdis.as<float>(), R.stream);
+                if (cur_coarse_bad_) {
+                    // (some of them may be queries the coarse quantizer handed back: its general path serves the whole redo set)
+                    quantizer->search_device(nr, gq.as<float>(), np, gdis.as<float>(), gids.as<idx_t>());
+                } else {
+                    launch_gather_rows((const float*)c_ids_.p, 2 * np, 2 * np, olist.as<uint32_t>(), nr, (float*)gids.p, R.stream);
+                    launch_gather_rows(c_dis_.as<float>(), np, np, olist.as<uint32_t>(), nr, gdis.as<float>(), R.stream);
+                }
                 HIP_CHECK(hipMemcpyAsync(q_pad_.p, gq.p, (size_t)nr * dpad_ * 4, hipMemcpyDeviceToDevice, R.stream));
                 HIP_CHECK(hipMemcpyAsync(c_ids_.p, gids.p, (size_t)nr * np * 8, hipMemcpyDeviceToDevice, R.stream));
                 HIP_CHECK(hipMemcpyAsync(c_dis_.p, gdis.p, (size_t)nr * np * 4, hipMemcpyDeviceToDevice, R.stream));
@@ -2931,6 +2949,7 @@ void GpuIndexIVF::search_listmajor_filter_chunk_(int ni, int q0, const float* xq
     P.qflags = lm_qflags_.as<uint32_t>();
     P.sel_mask = cur_sel_mask_;
     P.lmf_pair = lmf_pair;
+    P.coarse_bad = cur_coarse_bad_ ? cur_coarse_bad_ + q0 : nullptr;
     // ---- queries: fp16 copy + range flags + |q|^2 (the sequential chain of the flat index)
     {
         SpanGuard sg(&R, "ivf_lmf_prepare");

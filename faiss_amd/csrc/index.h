@@ -252,7 +252,10 @@ class GpuIndexFlat : public Index {
 
     // device-resident search used internally (IVF coarse quantizer): xq_pad is [n][dpad] on the
     // device; results stay on the device.
-    void search_device(int n, const float* xq_pad, int k, float* dD, idx_t* dI) const;
+    // defer_bad (nullable, device, [n]): the one-launch path (small databases) does not read its overflow count back -- a query it
+    // cannot serve gets defer_bad[q] = 1 and labels of -1, and the CALLER redoes it (GpuIndexIVF: together with its own redo set, one
+    // host round trip per search less); every other path serves all queries at once and writes zeros
+    void search_device(int n, const float* xq_pad, int k, float* dD, idx_t* dI, uint32_t* defer_bad = nullptr) const;
     // search() without taking the lock / choosing the host path (x, distances, labels each host or device)
     void search_body_(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels) const;
     // test hook: full distance matrix [n][ntotal] through the MFMA kernel (host or device out)
@@ -321,7 +324,7 @@ class GpuIndexFlat : public Index {
     void prepare_selector_(const IDSelector& sel) const;
     // persistent scratch
     mutable DevBuf q_raw_, q_pad_, q_norm_, res_keys_, res_cnt_, out_d_, out_i_, all_keys_, one_cnt_;
-    void search_tile_(int n, const float* xq_pad, int k, float* dD, idx_t* dI) const;
+    void search_tile_(int n, const float* xq_pad, int k, float* dD, idx_t* dI, uint32_t* defer_bad = nullptr) const;
 };
 
 // faiss::ClusteringParameters (faiss/Clustering.h:27-60), the fields of the k-means loop proper
@@ -432,7 +435,7 @@ class GpuIndexIVF : public Index {
     idx_t nstored_ = 0;
     DevBuf d_list_len_, d_list_start_, arena_, arena_ids_, arena_t2_, arena_rn_;
     mutable std::mutex mu_;
-    mutable DevBuf q_raw_, q_pad_, c_dis_, c_ids_, prefix_, totals_, q_off_, keys_, out_d_, out_i_, one_cnt_;
+    mutable DevBuf q_raw_, q_pad_, c_dis_, c_ids_, c_bad_, prefix_, totals_, q_off_, keys_, out_d_, out_i_, one_cnt_;
     mutable int nprobe_eff_ = 1; // min(nprobe, nlist) of the search in flight
     // IDSelector of the search in flight (under mu_): one bit per arena row, null = none
     mutable DevBuf sel_mask_;
@@ -494,6 +497,7 @@ class GpuIndexIVF : public Index {
     DevBuf a_first_row_;
     mutable bool cur_lmf_ = false;        // the list-major search in flight runs the filter sweeps
     mutable bool cur_preassigned_ = false; // ... with the caller's coarse assignment (search_preassigned)
+    mutable const uint32_t* cur_coarse_bad_ = nullptr; // ... with the coarse quantizer's deferred overflow flags (c_bad_) of the tile
     mutable int last_scan_arith_ = 0;     // oracle restatement of the last search: 0 query-major arithmetic, 1 f32 list-major
     mutable bool shadow_dirty_ = true;    // a list changed since the fp16 shadow was built
     mutable bool lmf_quant_dirty_ = true; // a quantizer changed since the fp16 codebook / norm bounds were built

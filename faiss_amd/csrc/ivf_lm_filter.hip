@@ -1605,8 +1605,8 @@ __global__ void __launch_bounds__(256) lmf_bound_kernel(IvfLmParams p, const flo
     const uint32_t S = p.prefixg[(int64_t)q * (np + 1) + np];
     const uint32_t* g = p.gmin + (int64_t)q * p.gstride;
     // (IVFPQ: the B operands are fp16 (q - c): every coordinate is below sqrt(max |q - c|^2), which must stay in range)
-    if ((p.qflags && p.qflags[q]) || (p.kind != 0 && !(xn_bound[q] <= 9.0e8f))) {
-        // outside the fp16 range / NaN: nothing is collected, the query is redone by the query-major scan
+    if ((p.qflags && p.qflags[q]) || (p.coarse_bad && p.coarse_bad[q]) || (p.kind != 0 && !(xn_bound[q] <= 9.0e8f))) {
+        // outside the fp16 range / NaN / no coarse assignment yet: nothing is collected, the query is redone by the query-major scan
         if (tid == 0) {
             p.thr_f[q] = METRIC == METRIC_L2 ? -INFINITY : INFINITY;
             const uint32_t s = atomicAdd(&p.ovf[0], 1u);

@@ -153,6 +153,8 @@ struct FlatSmallParams {
     const uint32_t* flags; // [nq] fp16 range / NaN flags of the queries (prep_queries)
     const _Float16* xbh;   // [nb + tile][ldbh] fp16 rows
     int64_t ldbh;
+    uint32_t* bad_out; // nullable [nq]: DEFERRED overflow -- a query the kernel cannot serve (fp16 range, > FS_CAP candidates) gets 1 here
+                       // and labels of -1 instead of an entry in ovf_list; the caller redoes it later (GpuIndexIVF: with its own redo set)
     const void* xbo; // the same rows operand-major (launch_flat_operand_major): [ceil(nb / 32)][8 k-steps][64 lanes][16 bytes]
     const float* xbhn; // [nb + 64] -|y|^2 / 2 (L2) / 0 (IP), then -inf
     const float* xb;   // [nb][ldb] fp32 rows
@@ -445,6 +447,7 @@ struct IvfLmParams {
     const float* xqn;           // [nq] |q|^2, sequential chain (IVFFlat L2)
     const int64_t* coarse_ids;  // [nq][nprobe]
     const float* coarse_dis;    // [nq][nprobe] (IVFPQ IP: first term)
+    const uint32_t* coarse_bad; // nullable [nq]: queries the one-launch coarse quantizer handed back (FlatSmallParams::bad_out): redo set
     const uint32_t* list_len;   // [nlist]
     const int64_t* list_start;  // [nlist]
     // ---- plan, built on the device by launch_ivf_lm_plan

@@ -304,6 +304,40 @@ def test_ivf_search_with_the_one_launch_coarse_quantizer(res):
     assert np.array_equal(I1, I0) and np.array_equal(D1, D0)
 
 
+@pytest.mark.parametrize("metric", [METRIC_L2, METRIC_INNER_PRODUCT])
+def test_coarse_quantizer_overflow_joins_the_redo_set_of_the_search(res, metric):
+    """Behind the filter sweeps the one-launch coarse quantizer does not read its overflow count back (a host round trip in the
+    middle of every search): a query it cannot serve -- more centroids inside the band of its nprobe-th best than a candidate list
+    holds, a query outside the fp16 range -- gets labels of -1 and a flag, the bound kernel puts flagged queries into the search's
+    redo set, and the redo runs the coarse quantizer's general path first.  300 identical centroids (every query near them
+    overflows), a few queries beyond the fp16 range; results equal the query-major scan's (which quantizes at once) bit for bit."""
+    d, nlist, nb, nq, k, nprobe = 128, 2048, 50000, 3000, 25, 16
+    xt, xb, xq = synthetic_dataset(d, 12000, nb, nq, seed=91)
+    cent, _ = faiss_amd.kmeans(res, xt, nlist, niter=2, seed=5)
+    cent = cent.copy()
+    cent[100:400] = cent[100]  # ties: the band of the 16th best centroid of a query near cent[100] holds 300 rows
+    xq = xq.copy()
+    xq[:40] = cent[100] + 0.01 * xq[:40]   # queries that overflow the coarse quantizer's candidate lists
+    xq[40:44] *= 3.0e4                      # beyond the fp16 range (flagged by both stages)
+    idx = faiss_amd.GpuIndexIVFFlat(res, d, nlist, metric)
+    idx.copy_centroids(cent)
+    idx.add(xb)
+    idx.nprobe = nprobe
+    idx.set_scan_mode(idx.SCAN_QUERY_MAJOR)
+    Dq, Iq = idx.search(xq, k)
+    Dcq, Icq = idx.quantizer_search(xq, nprobe)
+    idx.set_scan_mode(idx.SCAN_LIST_MAJOR)
+    for fused in (True, False):
+        idx.set_small_fused(fused)
+        D, I = idx.search(xq, k)
+        assert idx.scan_info()[1] == 2
+        assert np.array_equal(I, Iq) and np.array_equal(D, Dq), fused
+        if fused:
+            assert idx.scan_info()[2] >= 40  # the handed-back queries went through the redo
+    Dc, Ic = idx.quantizer_search(xq, nprobe)  # (the stand-alone search of the quantizer redoes its overflow at once)
+    assert np.array_equal(Ic, Icq) and np.array_equal(Dc, Dcq)
+
+
 @pytest.mark.parametrize("kind,metric", [(0, METRIC_L2), (0, METRIC_INNER_PRODUCT), (2, METRIC_L2)])
 def test_lock_step_pair_sweeps_return_the_same_bits(res, kind, metric):
     """ivf_lm_filter.hip PAIR: two-wave workgroups walk the query groups of a (list, row chunk) in lock-step, or
