@@ -712,11 +712,14 @@ __global__ void __launch_bounds__(FqGeom<QB>::THREADS, 2) flat_filter_kernel(Fla
 //   * re-rank: one thread per (query, candidate), the chain of flat_rerank_kernel; ordering by counting.
 // Queries flagged by prep_queries (fp16 range, NaN) or with more than FS_CAP candidates go to the exact scan (ovf_list).
 // ---------------------------------------------------------------------------------
-constexpr int FS_THREADS = 256, FS_WAVES = FS_THREADS / 64, FS_Q = 32, FS_CAP = 128, FS_MAXCH = 256, FS_SUB = 32;
+constexpr int FS_THREADS = 256, FS_WAVES = FS_THREADS / 64, FS_Q = 32, FS_CAP = 128, FS_MAXCH = 256, FS_SUB = 16;
 struct FsShared {
     float cmax[FS_Q][FS_MAXCH]; // pass 1: chunk maxima; later: the candidates' exact keys (u64 [FS_Q][FS_CAP])
-    float qs[FS_Q][128];        // fp32 queries (re-rank)
-    uint16_t sub[FS_Q][2 * FS_WAVES][FS_SUB]; // pass 2: the rows a LANE found (query j, half h of wave w: list 2 w + h) -- no atomics
+    // pass 2: what a LANE found (query j, half h of wave w: list 2 w + h), no atomics -- a record per 16-row half block that holds a
+    // candidate: block << 16 | one bit per score position (round 6, second version: a compare + add-with-carry per position instead
+    // of a branch, a row number and a store per position: pass 2 61 000 -> 47 000 cycles per workgroup)
+    uint32_t sub[FS_Q][2 * FS_WAVES][FS_SUB]; // (dead behind the merge: the row staging of the re-rank, FS_STAGE bytes per wave)
+    float qs[FS_Q][128];                      // fp32 queries (re-rank)
     uint16_t cand[FS_Q][FS_CAP];              // the query's candidates, compacted
     float thr[FS_Q], xn[FS_Q];
     unsigned cnt8[FS_Q][2 * FS_WAVES];
@@ -724,6 +727,8 @@ struct FsShared {
     unsigned bad[FS_Q];
 };
 static_assert(sizeof(float) * FS_MAXCH == sizeof(u64) * FS_CAP, "the exact keys reuse the maxima");
+constexpr int FS_STAGE = 64 * 64; // a wave's staging area of the re-rank: 16 coordinates of 64 rows
+static_assert(FS_WAVES * FS_STAGE <= (int)(sizeof(uint32_t) * FS_Q * 2 * FS_WAVES * FS_SUB), "the staging areas overlay the records of pass 2");
 
 // TOPSEL (k <= 32; round 6, second version): pass 1 keeps every lane's EIGHT best chunk maxima in registers (a sorted insertion per
 // block: 16 VALU instructions under the loads) and the threshold is the k-th best of the 64 a query's eight lanes hold -- a lower
@@ -759,8 +764,8 @@ __global__ void __launch_bounds__(FS_THREADS, 2) flat_small_fused_kernel(FlatSma
     auto sweep = [&](auto mode_c) __attribute__((always_inline)) {
         constexpr int MODE = decltype(mode_c)::value;
         const float th = MODE == MODE_COLLECT ? sh.thr[j] : 0.f;
-        uint16_t* mysub = sh.sub[j][2 * wave + h];
-        unsigned nsub = 0;
+        uint32_t* mysub = sh.sub[j][2 * wave + h];
+        unsigned nsub = 0, ncand = 0; // records, candidates of this lane
         // (operand-major copy of the rows, flat_operand_major_kernel: k-step s of block b = one contiguous KB, lane l its 16 bytes.
         // From the row-major copy every load instruction touched 32 cache lines -- the L1's request rate, not bytes, paced the
         // first version: 0.21 ms for the launch)
@@ -813,12 +818,12 @@ __global__ void __launch_bounds__(FS_THREADS, 2) flat_small_fused_kernel(FlatSma
                     sh.cmax[j][2 * b + h] = m;
                 }
             } else if (m >= th) {
+                unsigned mask = 0;
 #pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    if (sc[i] >= th) {
-                        if (nsub < (unsigned)FS_SUB) mysub[nsub] = (uint16_t)(32 * b + 8 * (i >> 2) + 4 * h + (i & 3));
-                        ++nsub;
-                    }
+                for (int i = 15; i >= 0; --i) mask = mask + mask + (sc[i] >= th ? 1u : 0u); // (bit i = score position i)
+                if (nsub < (unsigned)FS_SUB) mysub[nsub] = ((unsigned)b << 16) | mask;
+                ++nsub;
+                ncand += (unsigned)__popc(mask);
             }
         };
         int b = wave;
@@ -830,7 +835,8 @@ __global__ void __launch_bounds__(FS_THREADS, 2) flat_small_fused_kernel(FlatSma
             if (b + FS_WAVES < nblk) block(b + FS_WAVES, a1, bias1);
             if (b + 2 * FS_WAVES < nblk) block(b + 2 * FS_WAVES, a2, bias2);
         }
-        if (MODE == MODE_COLLECT) sh.cnt8[j][2 * wave + h] = nsub;
+        // (a lane that ran out of records reports more candidates than a query may have: the query goes to the exact scan)
+        if (MODE == MODE_COLLECT) sh.cnt8[j][2 * wave + h] = nsub > (unsigned)FS_SUB ? (unsigned)FS_CAP + 1u : ncand;
         if (MODE == MODE_MAX && TOPSEL) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) sh.cmax[j][8 * (2 * wave + h) + i] = top[i];
@@ -891,14 +897,19 @@ __global__ void __launch_bounds__(FS_THREADS, 2) flat_small_fused_kernel(FlatSma
 #pragma unroll
         for (int u = 0; u < 2 * FS_WAVES; ++u) {
             const unsigned c = sh.cnt8[qq][u];
-            over = over || c > (unsigned)FS_SUB;
             if (u < sl) off += c;
             tot += c;
         }
         over = over || tot > (unsigned)FS_CAP;
         if (!over && sh.bad[qq] == 0) {
             const unsigned c = sh.cnt8[qq][sl];
-            for (unsigned i = 0; i < c; ++i) sh.cand[qq][off + i] = sh.sub[qq][sl][i];
+            for (unsigned i = 0, r = 0; i < c; ++r) {
+                const uint32_t rec = sh.sub[qq][sl][r];
+                for (uint32_t m = rec & 0xffffu; m; m &= m - 1u) {
+                    const int pos = __builtin_ctz(m);
+                    sh.cand[qq][off + i++] = (uint16_t)(32 * (rec >> 16) + 8 * (pos >> 2) + 4 * (sl & 1) + (pos & 3));
+                }
+            }
         }
         if (sl == 0) {
             if (over && sh.bad[qq] == 0) sh.bad[qq] = 1u;
@@ -921,53 +932,11 @@ __global__ void __launch_bounds__(FS_THREADS, 2) flat_small_fused_kernel(FlatSma
         p.ovf_list[atomicAdd(p.ovf_cnt, 1u)] = (uint32_t)(q0 + tid);
     }
     FS_MARK();
-    // ---- exact distances of the candidates: (query, candidate) pairs dealt to the threads
+    // ---- exact distances of the candidates: (query, candidate) pair g -> thread g % 256 in round g / 256
     const unsigned total = sh.pre[FS_Q];
-    u64* ekey = (u64*)&sh.cmax[0][0]; // [FS_Q][FS_CAP] (the maxima are dead)
-    constexpr int NM = (FS_Q * FS_CAP + FS_THREADS - 1) / FS_THREADS;
-    u64 mine[NM];
-    uint16_t where[NM]; // query << 8 | position in its list
-    int nmine = 0;
-    {
-        int qq = 0;
-        for (unsigned g = tid; g < total; g += FS_THREADS, ++nmine) {
-            while (sh.pre[qq + 1] <= g) ++qq;
-            where[nmine] = (uint16_t)((qq << 8) | (int)(g - sh.pre[qq]));
-        }
-    }
-    for (int m_ = 0; m_ < nmine; ++m_) {
-        const int qq = where[m_] >> 8;
-        const unsigned row = sh.cand[qq][where[m_] & 255];
-        const float* yr = p.xb + (int64_t)row * p.ldb;
-        const float* qs = sh.qs[qq];
-        float acc = 0.f;
-        // the chain of flat_scan_kernel / flat_rerank_kernel: 8-float steps, e and 4 + e interleaved.  The row is a random
-        // 512-byte read: all its loads are issued before the chain consumes the first (one round trip per candidate)
-        auto step = [&](const f32x4& y0, const f32x4& y1, int s) {
-            const f32x4 x0 = *(const f32x4*)(qs + s), x1 = *(const f32x4*)(qs + s + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc = __fmaf_rn(y0[e], x0[e], acc);
-                acc = __fmaf_rn(y1[e], x1[e], acc);
-            }
-        };
-        if (p.dpad == 128) {
-            f32x4 y[32];
-#pragma unroll
-            for (int u = 0; u < 32; ++u) y[u] = *(const f32x4*)(yr + 4 * u);
-#pragma unroll
-            for (int u = 0; u < 16; ++u) step(y[2 * u], y[2 * u + 1], 8 * u);
-        } else {
-            int s = 0;
-            for (; s + 32 <= p.dpad; s += 32) {
-                f32x4 y[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) y[u] = *(const f32x4*)(yr + s + 4 * u);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) step(y[2 * u], y[2 * u + 1], s + 8 * u);
-            }
-            for (; s < p.dpad; s += 8) step(*(const f32x4*)(yr + s), *(const f32x4*)(yr + s + 4), s);
-        }
+    u64* ekey = (u64*)&sh.cmax[0][0]; // [FS_Q][FS_CAP] (the maxima are dead since the thresholds were taken)
+    const int niter = (int)((total + FS_THREADS - 1) / FS_THREADS);
+    auto finish = [&](int qq, unsigned row, float acc) __attribute__((always_inline)) -> u64 {
         float dis;
         if (METRIC == METRIC_L2) {
             dis = __fmaf_rn(-2.f, acc, sh.xn[qq] + p.xbn[row]);
@@ -975,29 +944,113 @@ __global__ void __launch_bounds__(FS_THREADS, 2) flat_small_fused_kernel(FlatSma
         } else {
             dis = acc;
         }
-        mine[m_] = ((u64)ordkey<METRIC>(dis) << 32) | row;
+        return ((u64)ordkey<METRIC>(dis) << 32) | row;
+    };
+    // the chain of flat_scan_kernel / flat_rerank_kernel: 8-float steps, e and 4 + e interleaved
+    auto step = [&](float& acc, const float* qs, const f32x4& y0, const f32x4& y1, int s) __attribute__((always_inline)) {
+        const f32x4 x0 = *(const f32x4*)(qs + s), x1 = *(const f32x4*)(qs + s + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc = __fmaf_rn(y0[e], x0[e], acc);
+            acc = __fmaf_rn(y1[e], x1[e], acc);
+        }
+    };
+    {
+        int qq = 0; // (the pairs of a thread come in query order: the search for a pair's query resumes where the last one ended)
+        if (p.dpad == 128) {
+            // Rows through LDS (round 6, second version).  A thread owns a pair and needs the candidate's 512-byte row in chain order;
+            // read by the thread itself, every load instruction of a wave touched 64 cache lines (the L1's tag rate: 50 000 cycles
+            // per workgroup for 1200 rows).  Now FOUR LANES fetch 64 bytes of a row together -- 16 lines per instruction --, the pieces
+            // pass through the wave's 4 KB staging area (the records of pass 2, dead since the merge), and every lane reads the 16
+            // coordinates of its own row back: eight stages per pair.  Staged piece c of row r sits at chunk c ^ ((r >> 2) & 3) of the
+            // row's 64 bytes: sixteen lanes' 16-byte reads (rows l .. l + 15, one chunk index) fall into sixteen different bank groups.
+            char* stg = (char*)&sh.sub[0][0][0] + wave * FS_STAGE;
+            for (int m_ = 0; m_ < niter; ++m_) {
+                const unsigned g = (unsigned)m_ * FS_THREADS + (unsigned)tid;
+                const bool valid = g < total;
+                if (valid)
+                    while (sh.pre[qq + 1] <= g) ++qq;
+                const int pos = valid ? (int)(g - sh.pre[qq]) : 0;
+                const unsigned row = valid ? sh.cand[qq][pos] : 0u;
+                // the rows this lane helps to fetch: slot 16 i + (lane >> 2), i = 0 .. 3; its chunk of their 64 bytes: lane & 3
+                const float* src[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) src[i] = p.xb + (int64_t)__shfl((int)row, 16 * i + (lane >> 2)) * p.ldb + 4 * (lane & 3);
+                // (a ring of four stages: sixteen loads in flight, the slot of a stage refilled as soon as it has been staged)
+                f32x4 v[4][4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[t][i] = *(const f32x4*)(src[i] + 16 * t);
+                const float* qs = sh.qs[qq];
+                float acc = 0.f;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_wave_barrier(); // (the reads of the stage before were issued: LDS keeps a wave's order)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = 16 * i + (lane >> 2);
+                        *(f32x4*)(stg + r * 64 + 16 * ((lane & 3) ^ ((r >> 2) & 3))) = v[t & 3][i];
+                        if (t + 4 < 8) v[t & 3][i] = *(const f32x4*)(src[i] + 16 * (t + 4));
+                    }
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_wave_barrier();
+                    f32x4 y[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) y[u] = *(const f32x4*)(stg + lane * 64 + 16 * (u ^ ((lane >> 2) & 3)));
+                    step(acc, qs, y[0], y[1], 16 * t);
+                    step(acc, qs, y[2], y[3], 16 * t + 8);
+                }
+                if (valid) ekey[qq * FS_CAP + pos] = finish(qq, row, acc);
+            }
+        } else {
+            for (int m_ = 0; m_ < niter; ++m_) {
+                const unsigned g = (unsigned)m_ * FS_THREADS + (unsigned)tid;
+                if (g >= total) break;
+                while (sh.pre[qq + 1] <= g) ++qq;
+                const int pos = (int)(g - sh.pre[qq]);
+                const unsigned row = sh.cand[qq][pos];
+                const float* yr = p.xb + (int64_t)row * p.ldb;
+                const float* qs = sh.qs[qq];
+                float acc = 0.f;
+                int s = 0;
+                for (; s + 32 <= p.dpad; s += 32) {
+                    f32x4 y[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) y[u] = *(const f32x4*)(yr + s + 4 * u);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) step(acc, qs, y[2 * u], y[2 * u + 1], s + 8 * u);
+                }
+                for (; s < p.dpad; s += 8) step(acc, qs, *(const f32x4*)(yr + s), *(const f32x4*)(yr + s + 4), s);
+                ekey[qq * FS_CAP + pos] = finish(qq, row, acc);
+            }
+        }
     }
     FS_MARK();
-    __syncthreads(); // (every maximum has long been read: the keys may overwrite them)
-    for (int m_ = 0; m_ < nmine; ++m_) ekey[(where[m_] >> 8) * FS_CAP + (where[m_] & 255)] = mine[m_];
     __syncthreads();
     // ---- exact top-k under (distance, id): every key straight to its rank
     const float pad = neutral_distance(METRIC);
-    for (int m_ = 0; m_ < nmine; ++m_) {
-        const int qq = where[m_] >> 8;
-        const int n = (int)sh.cnt[qq];
-        const u64 x = mine[m_];
-        const ulonglong2* kk = (const ulonglong2*)(ekey + qq * FS_CAP);
-        int r = 0;
-        for (int i = 0; i < n; i += 2) {
-            const ulonglong2 k2 = kk[i >> 1];
-            r += (k2.x < x ? 1 : 0) + ((i + 1 < n && k2.y < x) ? 1 : 0);
-        }
-        if (r < p.k) {
-            const uint32_t wk = (uint32_t)(x >> 32);
-            const bool ok = wk < kInvalidOrdKey;
-            p.out_dis[(int64_t)(q0 + qq) * p.k + r] = ok ? unordkey<METRIC>(wk) : pad;
-            p.out_ids[(int64_t)(q0 + qq) * p.k + r] = ok ? (int64_t)(uint32_t)x : -1;
+    {
+        int qq = 0;
+        for (int m_ = 0; m_ < niter; ++m_) {
+            const unsigned g = (unsigned)m_ * FS_THREADS + (unsigned)tid;
+            if (g >= total) break;
+            while (sh.pre[qq + 1] <= g) ++qq;
+            const int n = (int)sh.cnt[qq];
+            const u64 x = ekey[qq * FS_CAP + (int)(g - sh.pre[qq])];
+            const ulonglong2* kk = (const ulonglong2*)(ekey + qq * FS_CAP);
+            int r = 0;
+            for (int i = 0; i < n; i += 2) {
+                const ulonglong2 k2 = kk[i >> 1];
+                r += (k2.x < x ? 1 : 0) + ((i + 1 < n && k2.y < x) ? 1 : 0);
+            }
+            if (r < p.k) {
+                const uint32_t wk = (uint32_t)(x >> 32);
+                const bool ok = wk < kInvalidOrdKey;
+                p.out_dis[(int64_t)(q0 + qq) * p.k + r] = ok ? unordkey<METRIC>(wk) : pad;
+                p.out_ids[(int64_t)(q0 + qq) * p.k + r] = ok ? (int64_t)(uint32_t)x : -1;
+            }
         }
     }
     // (fewer candidates than k: only when the database holds fewer rows)
