@@ -47,9 +47,11 @@ def test_no_kernel_spills_beyond_the_known_cold_paths(usage):
     # MFMA pipeline of a block -- test_list_major_scan checks the bench shape's instantiations more tightly)
     # (wave_select_kernel: scalar registers saved around the memory-streaming fallback loops; the 128 key registers stay)
     # (filter sweeps, ivf_lm_filter.hip: the instantiations beside the bench shapes -- rows of more than 128 coordinates, dsub = 1,
-    # collect with a selector -- keep a few per-item values in scratch; test_filter_sweeps pins the bench shapes at zero)
+    # collect with a selector -- keep a few per-item values in scratch; test_filter_sweeps pins the bench shapes at zero.  Round 6:
+    # the flush of the parked candidates holds four returning atomics per lane at once; beside 128 VGPRs of B operands (rows of
+    # 257 .. 512 coordinates) that costs the collect sweep up to 68 bytes of scratch around the flush, once per 256 candidates)
     allowed = {"ivfflat_fused_kernel": 64, "ivfsq_fused_kernel": 48, "ivf_lm_scan_kernel": 48, "ivf_lm_pq_kernel": 320,
-               "wave_select_kernel": 32, "ivf_lmf_flat_kernel": 40, "ivf_lmf_pq_kernel": 136}
+               "wave_select_kernel": 32, "ivf_lmf_flat_kernel": 72, "ivf_lmf_pq_kernel": 136}
     for name, u in usage.items():
         limit = max([v for k, v in allowed.items() if k in name] or [0])
         assert u["scratch"] <= limit, (name, u)
