@@ -2630,7 +2630,10 @@ void GpuIndexIVF::search_listmajor_(int ni, const float* xq_pad, const idx_t* c_
         // lmf_sample_shift: 0 = this rule, 1 .. 4 = prefix of RT >> shift rows, -1 = no sampling.
         int sample_rows = 0;
         {
-            int shift = lmf_sample_shift > 0 ? lmf_sample_shift : (lmf_sample_shift == 0 && avg_len >= 1024 ? 2 : 0);
+            // (round 6, behind the cheaper candidate path of sweep 2: an EIGHTH of the chunk where the lists are long -- nb = 100M,
+            // 24 000-row lists: sweep 1 0.82 -> 0.50 ms, sweep 2 3.22 -> 3.51, search 4.76 -> 4.64; a sixteenth loses again:
+            // profiles/r6_ab_sweep1_sampling.txt)
+            int shift = lmf_sample_shift > 0 ? lmf_sample_shift : (lmf_sample_shift == 0 ? (avg_len >= 16384 ? 3 : avg_len >= 1024 ? 2 : 0) : 0);
             while (shift > 0 && (double)np * (double)avg_len / (double)(1 << shift) < 64.0 * (double)k) --shift;
             if (shift > 0) sample_rows = (int)round_up((size_t)(RT >> shift), 256);
             if (sample_rows >= RT) sample_rows = 0;
