@@ -1,11 +1,11 @@
 #!/bin/bash
-# tools/profile_round5.sh TAG -- the rocprofv3 passes behind profiles/<TAG>_* (run on the GPU box through gpurun):
+# tools/profile_round6.sh TAG -- the rocprofv3 passes behind profiles/<TAG>_* (run on the GPU box through gpurun):
 #   1. kernel trace + stats of the DEFAULT bench command (the driver's --steps 20 --warmup 5, all legs);
 #   2. PER LEG: kernel trace + stats of the search loop of that leg alone -> <TAG>_<leg>_kernel_stats.csv,
 #      one row per kernel (calls, average ns): a `frac` of the bench line can be recomputed from ONE row;
 #   3. one --pmc pass per counter group (never combined with runtime / sys tracing) on the same search loops:
 #      <TAG>_pmc_<leg>.{txt,json} (bench.py reads its roofline.traffic numbers from the JSON summaries).
-TAG=${1:-r5}
+TAG=${1:-r6}
 MODE=${2:-all} # "stats": the per-leg kernel statistics only
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
