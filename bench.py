@@ -48,9 +48,9 @@ PEAK_F16_MFMA_TFLOPS = 2500.0  # same guide: dense f16/bf16 MFMA (v_mfma_f32_32x
 PEAK_HBM_GBS = 8000.0
 # committed rocprofv3 --pmc summaries (tools/profile_round.sh; one file per profiled search loop)
 PROFILE_DIR = os.path.join(ROOT, "profiles")
-PROFILE_JSON = {"flat": "r5_pmc_flat.json", "ivfpq": "r5_pmc_ivfpq_1m.json", "ivfsq": "r5_pmc_ivfsq_1m.json",
-                "ivfflat": "r5_pmc_ivfflat_1m.json", "ivfflat_10m": "r5_pmc_ivfflat_10m.json",
-                "ivfpq_10m": "r5_pmc_ivfpq_10m.json", "ivfpq_100m": "r5_pmc_ivfpq_100m.json"}
+PROFILE_JSON = {"flat": "r6_pmc_flat.json", "ivfpq": "r6_pmc_ivfpq_1m.json", "ivfsq": "r6_pmc_ivfsq_1m.json",
+                "ivfflat": "r6_pmc_ivfflat_1m.json", "ivfflat_10m": "r6_pmc_ivfflat_10m.json",
+                "ivfpq_10m": "r6_pmc_ivfpq_10m.json", "ivfpq_100m": "r6_pmc_ivfpq_100m.json"}
 
 
 def log(*a):

@@ -89,8 +89,10 @@ void launch_convert_f16(const float* src, int64_t ld_src, int64_t n, int d, void
 __global__ void __launch_bounds__(64) prep_queries_kernel(const float* __restrict__ xq_pad, int64_t ld, int64_t n, int d,
                                                           int dpad, _Float16* __restrict__ qh, int dh,
                                                           uint32_t* __restrict__ flags, float* __restrict__ qnorm,
-                                                          unsigned* __restrict__ counter) {
+                                                          unsigned* __restrict__ counter, ClearList clear) {
     const int64_t i = blockIdx.x;
+    for (int k = 0; k < clear.cnt; ++k)
+        for (uint32_t w = (uint32_t)i * 64u + threadIdx.x; w < clear.n[k]; w += gridDim.x * 64u) clear.p[k][w] = 0u;
     const float* r = xq_pad + i * ld;
     _Float16* o = qh + i * dh;
     bool bad = false;
@@ -121,10 +123,23 @@ __global__ void __launch_bounds__(64) prep_queries_kernel(const float* __restric
     }
 }
 void launch_prep_queries(const float* xq_pad, int64_t ld, int64_t n, int d, int dpad, void* qh, int dh, uint32_t* flags,
-                         float* qnorm, unsigned* counter, hipStream_t stream) {
+                         float* qnorm, unsigned* counter, hipStream_t stream, const ClearList* clear) {
     if (n == 0) return;
+    ClearList c{};
+    if (clear) c = *clear;
     hipLaunchKernelGGL(prep_queries_kernel, dim3((unsigned)n), dim3(64), 0, stream, xq_pad, ld, n, d, dpad,
-                       (_Float16*)qh, dh, flags, qnorm, counter);
+                       (_Float16*)qh, dh, flags, qnorm, counter, c);
+    HIP_CHECK(hipGetLastError());
+}
+__global__ void __launch_bounds__(256) clear_words_kernel(ClearList clear) {
+    for (int k = 0; k < clear.cnt; ++k)
+        for (uint32_t w = blockIdx.x * 256u + threadIdx.x; w < clear.n[k]; w += gridDim.x * 256u) clear.p[k][w] = 0u;
+}
+void launch_clear_words(const ClearList& c, hipStream_t stream) {
+    uint32_t mx = 0;
+    for (int k = 0; k < c.cnt; ++k) mx = std::max(mx, c.n[k]);
+    if (mx == 0) return;
+    hipLaunchKernelGGL(clear_words_kernel, dim3(std::min<unsigned>((unsigned)div_up(mx, 256), 1024u)), dim3(256), 0, stream, c);
     HIP_CHECK(hipGetLastError());
 }
 

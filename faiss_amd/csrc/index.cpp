@@ -2958,10 +2958,24 @@ void GpuIndexIVF::search_listmajor_filter_chunk_(int ni, int q0, const float* xq
         SpanGuard sg(&R, "ivf_lmf_prepare");
         const int dh = (P.kind != 1 || P.lmf_pairb) ? ivf_lmf_row_halfs(d) : (int)round_up(d, 16);
         lm_q16_.ensure((size_t)ni * dh * 2);
+        // the search's scratch counters, zeroed by ONE launch (the query preparation itself where there is one) instead of a
+        // fillBuffer packet each: the redo count, the plan's bucket counters, the norm bounds the prepare kernels raise atomically,
+        // the scalar quantizer's flags
+        const bool pair_ops = P.kind == 2 || P.lmf_pairb;
+        if (pair_ops) lm_an_.ensure((size_t)ni * 4);
+        ClearList cl{};
+        cl.add(P.ovf, 1);
+        cl.add(P.bucket_cnt, (size_t)4 * nlist);
+        if (P.kind != 0) cl.add(lm_xnb_.p, (size_t)ni);
+        if (pair_ops) cl.add(lm_an_.p, (size_t)ni);
+        if (P.kind == 2) cl.add(lm_qflags_.p, (size_t)ni);
+        P.pre_cleared = 1;
         // (the scalar quantizer's operands, flags and norms all come from launch_ivf_lmf_sq_prepare below)
         if (P.kind != 2)
             launch_prep_queries(xq_pad, dpad_, ni, d, dpad_, lm_q16_.p, dh, lm_qflags_.as<uint32_t>(), lm_qn_.as<float>(),
-                                lm_scalar_.as<unsigned>(), R.stream);
+                                lm_scalar_.as<unsigned>(), R.stream, &cl);
+        else
+            launch_clear_words(cl, R.stream);
         P.xq16 = lm_q16_.p;
         P.ldq16 = dh;
         P.xqn = lm_qn_.as<float>();

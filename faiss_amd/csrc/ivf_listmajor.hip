@@ -475,7 +475,7 @@ void launch_ivf_lm_plan(const IvfLmParams& p, hipStream_t stream) {
     FA_THROW_IF_NOT(!p.filter || (p.sample_rows >= 0 && p.sample_rows % (32 * p.gran_blocks) == 0));
     // bucket_cnt and bucket_fill are one allocation [2][2 nlist]
     FA_THROW_IF_NOT(p.bucket_fill == p.bucket_cnt + 2 * p.nlist);
-    HIP_CHECK(hipMemsetAsync(p.bucket_cnt, 0, (size_t)4 * p.nlist * 4, stream));
+    if (!p.pre_cleared) HIP_CHECK(hipMemsetAsync(p.bucket_cnt, 0, (size_t)4 * p.nlist * 4, stream));
     hipLaunchKernelGGL(lm_plan_kernel, dim3((unsigned)div_up(p.nq, 4)), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(lm_items_kernel, dim3(1), dim3(1024), 0, stream, p);
     hipLaunchKernelGGL(lm_fill_kernel, dim3((unsigned)div_up((size_t)p.nq * p.nprobe, 256)), dim3(256), 0, stream, p);

@@ -1738,7 +1738,7 @@ __global__ void __launch_bounds__(256) lmf_bound_kernel(IvfLmParams p, const flo
 }
 void launch_ivf_lmf_bound(const IvfLmParams& p, const float* xn_bound, hipStream_t stream) {
     if (p.nq == 0) return;
-    HIP_CHECK(hipMemsetAsync(p.ovf, 0, 4, stream));
+    if (!p.pre_cleared) HIP_CHECK(hipMemsetAsync(p.ovf, 0, 4, stream));
     if (p.metric == METRIC_L2) hipLaunchKernelGGL(lmf_bound_kernel<METRIC_L2>, dim3((unsigned)p.nq), dim3(256), 0, stream, p, xn_bound);
     else hipLaunchKernelGGL(lmf_bound_kernel<METRIC_INNER_PRODUCT>, dim3((unsigned)p.nq), dim3(256), 0, stream, p, xn_bound);
     HIP_CHECK(hipGetLastError());
@@ -1948,7 +1948,7 @@ __global__ void __launch_bounds__(256) lmf_pq_prepare_kernel(IvfLmParams p, floa
 void launch_ivf_lmf_pq_prepare(const IvfLmParams& p, float* xn_bound, hipStream_t stream) {
     if (p.nq == 0) return;
     FA_THROW_IF_NOT(p.kind == 1 && p.centroids && p.pair16 && p.pair_xh && p.d % 16 == 0 && p.d <= 128 && p.ldq % 4 == 0 && p.ldc % 4 == 0);
-    HIP_CHECK(hipMemsetAsync(xn_bound, 0, (size_t)p.nq * 4, stream));
+    if (!p.pre_cleared) HIP_CHECK(hipMemsetAsync(xn_bound, 0, (size_t)p.nq * 4, stream));
     hipLaunchKernelGGL(lmf_pq_prepare_kernel, dim3((unsigned)div_up((size_t)p.nq * p.nprobe * 16, 256)), dim3(256), 0, stream, p,
                        xn_bound);
     HIP_CHECK(hipGetLastError());
@@ -2030,11 +2030,13 @@ void launch_ivf_lmf_sq_prepare(const IvfLmParams& p, float* xn_bound, float* an_
     FA_THROW_IF_NOT((p.kind == 2 || p.lmf_pairb) && p.pair16 && p.pair_xh && p.qflags && p.sq_s && p.sq_b && p.centroids &&
                     p.ldh % 16 == 0 && p.ldh <= 512);
     FA_THROW_IF_NOT(p.dpad % 8 == 0 && p.ldq % 4 == 0 && p.ldc % 4 == 0);
-    HIP_CHECK(hipMemsetAsync(xn_bound, 0, (size_t)p.nq * 4, stream));
-    HIP_CHECK(hipMemsetAsync(an_bound, 0, (size_t)p.nq * 4, stream));
+    if (!p.pre_cleared) {
+        HIP_CHECK(hipMemsetAsync(xn_bound, 0, (size_t)p.nq * 4, stream));
+        HIP_CHECK(hipMemsetAsync(an_bound, 0, (size_t)p.nq * 4, stream));
+    }
     // the scalar quantizer's flags come from this launch alone; the decoded-residual IVFPQ sweeps (kind 1, pair operands) run
     // launch_prep_queries first, whose NaN / fp16-range flags of the raw queries stay: this launch only ORs into them
-    if (p.kind == 2) HIP_CHECK(hipMemsetAsync(const_cast<uint32_t*>(p.qflags), 0, (size_t)p.nq * 4, stream));
+    if (p.kind == 2 && !p.pre_cleared) HIP_CHECK(hipMemsetAsync(const_cast<uint32_t*>(p.qflags), 0, (size_t)p.nq * 4, stream));
     const int pieces = (int)p.ldh / 8; // 2 .. 64
     const int P = pieces <= 16 ? 16 : pieces <= 32 ? 32 : 64;
     const dim3 grid((unsigned)div_up((size_t)p.nq * p.nprobe * P, 256)), block(256);

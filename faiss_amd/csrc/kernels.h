@@ -136,8 +136,19 @@ __host__ __device__ static inline float flat_filter_err_bound(int metric, int d,
 }
 // mode: 0 = maxima pass, 1 = collect pass, 2 = dump every score (tests)
 // fp16 copy + range flags + |q|^2 (sequential fmaf chain) of n padded queries and *counter = 0, one launch
+// ClearList: up to six word ranges zeroed by the same launch (the scratch counters of the IVF filter path: four fillBuffer packets
+// of ~ 5 us each per search before round 6)
+struct ClearList {
+    uint32_t* p[6];
+    uint32_t n[6]; // words
+    int cnt;
+    void add(void* ptr, size_t words) {
+        if (ptr && words) p[cnt] = (uint32_t*)ptr, n[cnt] = (uint32_t)words, ++cnt;
+    }
+};
 void launch_prep_queries(const float* xq_pad, int64_t ld, int64_t n, int d, int dpad, void* qh, int dh, uint32_t* flags,
-                         float* qnorm, unsigned* counter, hipStream_t stream);
+                         float* qnorm, unsigned* counter, hipStream_t stream, const ClearList* clear = nullptr);
+void launch_clear_words(const ClearList& c, hipStream_t stream);
 void launch_flat_filter(const FlatFilterParams& p, int mode, hipStream_t stream);
 void launch_flat_tighten(const FlatFilterParams& p, hipStream_t stream);
 size_t flat_filter_lds_bytes();
@@ -447,6 +458,8 @@ struct IvfLmParams {
     const float* xqn;           // [nq] |q|^2, sequential chain (IVFFlat L2)
     const int64_t* coarse_ids;  // [nq][nprobe]
     const float* coarse_dis;    // [nq][nprobe] (IVFPQ IP: first term)
+    int pre_cleared;            // the caller zeroed ovf[0], bucket_cnt, the norm bounds and (kind 2) qflags itself, in one launch
+                                // (launch_clear_words) or inside launch_prep_queries: the launchers below skip their memsets
     const uint32_t* coarse_bad; // nullable [nq]: queries the one-launch coarse quantizer handed back (FlatSmallParams::bad_out): redo set
     const uint32_t* list_len;   // [nlist]
     const int64_t* list_start;  // [nlist]
