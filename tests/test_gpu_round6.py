@@ -363,3 +363,50 @@ def test_lock_step_pair_sweeps_return_the_same_bits(res, kind, metric):
             D, I = idx.search(xq, k)
             assert idx.scan_info()[1] == 2 and idx.last_scan_arith() == 0
             assert np.array_equal(I, Iq) and np.array_equal(D, Dq), (sampling, on)
+
+
+# ------------------------------------------------------------------ randomized differential test of the rebuilt candidate path
+def _fuzz_cases():
+    rng = np.random.default_rng(20260930)
+    cases = []
+    for i in range(14):
+        kind = int(rng.integers(0, 3))  # 0 IVFFlat, 1 IVFPQ, 2 IVFSQ8
+        metric = METRIC_L2 if rng.random() < 0.6 else METRIC_INNER_PRODUCT
+        d = int(rng.choice([32, 64, 96, 128])) if kind != 0 else int(rng.choice([24, 64, 100, 128, 200]))
+        nlist = int(rng.choice([8, 20, 64, 200]))
+        nb = int(rng.choice([20000, 60000, 130000]))
+        nq = int(rng.choice([2049, 2500, 4100]))
+        k = int(rng.choice([1, 10, 100, 200]))
+        nprobe = int(min(nlist, rng.choice([1, 4, 9, 32])))
+        cap = int(rng.choice([0, 0, 300, 1200]))  # a small candidate room forces flush overflow + the redo path
+        cases.append((i, kind, metric, d, nlist, nb, nq, k, nprobe, cap))
+    return cases
+
+
+@pytest.mark.parametrize("case", _fuzz_cases(), ids=lambda c: "case%d-kind%d" % (c[0], c[1]))
+def test_filter_path_equals_the_query_major_scan_on_random_shapes(res, case):
+    """The dense pass / flush of sweep 2 were rebuilt in round 6 (a record per lane, atomics issued in batches): random index
+    types, metrics, dimensions, list counts, batch sizes, k, nprobe and candidate rooms (small rooms: parked candidates beyond a
+    query's segment are dropped, the query is redone) -- the list-major search behind the f16 filter returns the bits of the
+    query-major scan every time, whatever the sampling of sweep 1."""
+    i, kind, metric, d, nlist, nb, nq, k, nprobe, cap = case
+    xt, xb, xq = synthetic_dataset(d, 8000, nb, nq, seed=200 + i)
+    if kind == 0:
+        idx = faiss_amd.GpuIndexIVFFlat(res, d, nlist, metric)
+    elif kind == 1:
+        idx = faiss_amd.GpuIndexIVFPQ(res, d, nlist, d // 2 if d % 2 == 0 and d <= 128 else d // 4, 8, metric)
+    else:
+        idx = faiss_amd.GpuIndexIVFScalarQuantizer(res, d, nlist, faiss_amd.ScalarQuantizer.QT_8bit, metric, True)
+    idx.train(xt)
+    idx.add(xb)
+    idx.nprobe = nprobe
+    idx.set_scan_mode(idx.SCAN_QUERY_MAJOR)
+    Dq, Iq = idx.search(xq, k)
+    idx.set_scan_mode(idx.SCAN_LIST_MAJOR)
+    if cap:
+        idx.set_lmf_tuning(0, 0, cap, 0)
+    for sampling in (0, -1):
+        idx.set_lmf_sampling(sampling)
+        D, I = idx.search(xq, k)
+        assert idx.scan_info()[1] == 2
+        assert np.array_equal(I, Iq) and np.array_equal(D, Dq), (case, sampling)
