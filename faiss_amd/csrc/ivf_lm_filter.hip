@@ -577,6 +577,8 @@ __device__ __forceinline__ void lmf_stage_push(LmfStage<NST>& st, bool hit, unsi
 // followed by a second one for the stores (the sweep's wavefronts do nothing else meanwhile: tools/pq_sweep_ablation.py, the epilogue
 // was 0.29 of 0.55 ms of sweep 2 at nb = 10M).  Nothing waits for the stores: they are invisible to the compiler's count of the
 // loads in flight, which only makes its waits conservative (an older load is complete whenever the counter allows it).
+// (NOCONTEND: ablation only -- every atomic goes to a word of its own inside the key area, the slots are garbage)
+template <bool NOCONTEND = false>
 __device__ __forceinline__ void lmf_flush_parked(const IvfLmParams& p, int lane, const u64* pk_keys, const uint32_t* pk_q, int& wcnt) {
     for (int e0 = 0; e0 < wcnt; e0 += 256) {
         // (ONE asm statement from the first atomic to the wait: the compiler may copy an output register of an asm statement right
@@ -585,7 +587,10 @@ __device__ __forceinline__ void lmf_flush_parked(const IvfLmParams& p, int lane,
         uint32_t slot[4];
         uint32_t* cp[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) cp[i] = p.cnt + (pk_q[e0 + 64 * i + lane] >> 11); // (slots behind wcnt: stale, masked off)
+        for (int i = 0; i < 4; ++i) {
+            cp[i] = p.cnt + (pk_q[e0 + 64 * i + lane] >> 11); // (slots behind wcnt: stale, masked off)
+            if (NOCONTEND) cp[i] = (uint32_t*)p.keys + ((size_t)(blockIdx.x * 8 + (threadIdx.x >> 6)) * 256 + 64 * i + lane) * 16;
+        }
         const int w0 = wcnt - e0, el = lane;
         const uint32_t one = 1u;
         unsigned long long sv;
@@ -612,6 +617,7 @@ __device__ __forceinline__ void lmf_flush_parked(const IvfLmParams& p, int lane,
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int e = e0 + 64 * i + lane;
+            if (NOCONTEND) slot[i] &= 255u;
             if (e < wcnt && (int64_t)slot[i] < p.stride) {
                 const uint32_t qp = pk_q[e];
                 const int64_t at = (int64_t)(qp >> 11) * p.stride + slot[i];
@@ -1076,6 +1082,7 @@ __device__ __forceinline__ half8 lp_landed(unsigned (&dst)[4]) {
 //    64  no row-norm term (the scores are the accumulators)
 //   128  parked candidates are dropped instead of flushed to memory
 //   256  staged records are dropped instead of expanded
+//   512  the flush's atomics go to words of their own (no two on one address: what the per-query counters' contention costs)
 template <int METRIC, int MODE, int NQB, int DS, bool SEL, bool FULLK, bool TWOC, bool FG = false, int ABL = 0>
 __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p) {
     static_assert(ABL == 0 || (FG && MODE != MODE_DUMP), "ablations: the FG sweeps");
@@ -1140,7 +1147,7 @@ __global__ void __launch_bounds__(LP_THREADS, 2) ivf_lmf_pq_kernel(IvfLmParams p
     LmfStage<NST> st{smem + LY.off_stage + wave * LmfStage<NST>::BYTES, 0};
     auto flush = [&]() __attribute__((always_inline)) {
         if constexpr ((ABL & 128) != 0) wcnt = 0;
-        else lmf_flush_parked(p, lane, pk_keys, pk_q, wcnt);
+        else lmf_flush_parked<(ABL & 512) != 0>(p, lane, pk_keys, pk_q, wcnt);
     };
     auto expand = [&]() __attribute__((always_inline)) {
         if constexpr ((ABL & 256) != 0) st.cnt = 0;
@@ -1532,6 +1539,7 @@ static void lmf_pq_launch(const IvfLmParams& p, int grid_blocks, hipStream_t str
             case 34: FA_LP(2, true, false, true, 34); break;
             case 48: FA_LP(2, true, false, true, 48); break;
             case 96: FA_LP(2, true, false, true, 96); break;
+            case 512: FA_LP(2, true, false, true, 512); break;
             default: FA_THROW_IF_NOT(!"FAISS_AMD_LMF_ABLATE: a mask that is not instantiated");
             }
         }

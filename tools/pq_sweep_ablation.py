@@ -20,8 +20,8 @@ faiss_amd.LIB_PATH = os.path.join(os.path.dirname(faiss_amd.LIB_PATH), "variants
 from faiss_amd.datasets import synthetic_dataset, synthetic_more_device  # noqa: E402
 
 BITS = {1: "no gathers", 2: "3 of 24 MFMAs", 4: "no epilogue", 8: "conflict-free gathers", 16: "no code loads", 32: "NaN thresholds (no hits)",
-        64: "no row-norm term", 128: "no flush", 256: "no dense pass"}
-MASKS = [0, 1, 2, 4, 8, 16, 32, 64, 128, 256, 4 + 1, 4 + 2, 4 + 16, 4 + 1 + 2, 4 + 1 + 16, 4 + 2 + 16, 4 + 1 + 2 + 16, 32 + 1, 32 + 2, 32 + 16, 32 + 64]
+        64: "no row-norm term", 128: "no flush", 256: "no dense pass", 512: "uncontended flush atomics"}
+MASKS = [0, 1, 2, 4, 8, 16, 32, 64, 128, 256, 4 + 1, 4 + 2, 4 + 16, 4 + 1 + 2, 4 + 1 + 16, 4 + 2 + 16, 4 + 1 + 2 + 16, 32 + 1, 32 + 2, 32 + 16, 32 + 64, 512]
 NAMES = {m: " + ".join(BITS[b] for b in BITS if m & b) or "the sweep as shipped" for m in MASKS}
 sizes = [int(a) for a in sys.argv[1:]] or [10]
 res = faiss_amd.StandardGpuResources(0)
